@@ -1,0 +1,257 @@
+/*
+ * piqp_amd.h -- C-ABI of the MI355X-native KKT backend for PIQP (libpiqp_amd.so).
+ *
+ * Drop-in boundary: these entry points are what a PIQP build would bind to replace the bodies of its
+ * KKT plugin interface and of the KKTSystem shell that drives it.  Every function cites the reference
+ * interface it replaces (paths relative to PIQP v0.6.2 include/piqp/).  INTEGRATION.md shows the
+ * reference-side adapter class (a KKTSolverBase<T,I,PIQP_DENSE> subclass calling pq_kkt_*).
+ *
+ * Conventions
+ *   - fp64 everywhere, column-major dense matrices, int32 index lists (common.hpp:38-39, typedefs.hpp:53-68).
+ *   - Opaque handles own all device memory; nothing is allocated after *_create (the reference's tests
+ *     enforce alloc-free factor/solve: fwd.hpp:44-52).
+ *   - Return: >= 0 success (factor calls: 1 = factorised, 0 = numerical failure exactly where the
+ *     reference returns false), < 0 = pq_status error.  Nothing throws across this boundary.
+ *   - Vector arguments live where the handle's pointer mode says: PQ_MEM_HOST (default; the library
+ *     stages them through its own pinned buffers -- this is the reference's calling convention) or
+ *     PQ_MEM_DEVICE (already resident in HBM; no copies, calls are asynchronous on the handle's stream
+ *     except where a scalar must come back to the host).
+ *   - A handle is not thread-safe; distinct handles may be used concurrently (one HIP stream each),
+ *     like independent solver copies in the reference (kkt_system.hpp:70-95).
+ *   - There is no CPU fallback: if no HIP device is usable, *_create fails with PQ_ERR_HIP.
+ */
+#ifndef PIQP_AMD_H
+#define PIQP_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    PQ_OK = 0,
+    PQ_ERR_INVALID = -1,     /* bad argument / size mismatch */
+    PQ_ERR_HIP = -2,         /* HIP runtime error (see pq_last_error_string) */
+    PQ_ERR_UNSUPPORTED = -3, /* kkt solver not supported (kkt_system.hpp:464-465,493-494) */
+    PQ_ERR_NOMEM = -4
+} pq_status;
+
+typedef enum { PQ_MEM_HOST = 0, PQ_MEM_DEVICE = 1 } pq_mem;
+
+/* settings.hpp:18-26 KKTSolver (+ the in-tree pivot-free LDLt of dense/ldlt_no_pivot.hpp as a second dense kernel) */
+typedef enum {
+    PQ_DENSE_CHOLESKY = 0,
+    PQ_SPARSE_LDLT = 1,
+    PQ_SPARSE_LDLT_EQ_COND = 2,
+    PQ_SPARSE_LDLT_INEQ_COND = 3,
+    PQ_SPARSE_LDLT_COND = 4,
+    PQ_SPARSE_MULTISTAGE = 5,
+    PQ_DENSE_LDLT_NO_PIVOT = 16
+} pq_kkt_solver;
+
+/* kkt_fwd.hpp:23-29 KKTUpdateOptions */
+enum { PQ_KKT_UPDATE_NONE = 0, PQ_KKT_UPDATE_P = 1, PQ_KKT_UPDATE_A = 2, PQ_KKT_UPDATE_G = 4 };
+
+/* results.hpp:18-27 Status */
+enum {
+    PQ_SOLVED = 1,
+    PQ_MAX_ITER_REACHED = -1,
+    PQ_PRIMAL_INFEASIBLE = -2,
+    PQ_DUAL_INFEASIBLE = -3,
+    PQ_NUMERICS = -8,
+    PQ_UNSOLVED = -9,
+    PQ_INVALID_SETTINGS = -10
+};
+
+/* dense/data.hpp:22-51 -- the (Ruiz-scaled) problem data a backend reads.  Matrices are the TRANSPOSED
+ * constraint matrices exactly as dense::Data stores them.  `mem` says where these arrays live. */
+typedef struct {
+    int n, p, m;
+    const double *P_utri; /* n x n, upper triangle read */
+    const double *AT;     /* n x p */
+    const double *GT;     /* n x m */
+    /* the remaining fields are only read by pq_kktsys_* (KKTSystem), never by pq_kkt_* (backend) */
+    int n_h_l, n_h_u, n_x_l, n_x_u;
+    const int *h_l_idx, *h_u_idx, *x_l_idx, *x_u_idx; /* finite-bound index lists, ascending */
+    const double *x_b_scaling;                         /* n, NULL = all ones */
+    int mem;                                           /* pq_mem */
+} pq_dense_data;
+
+/* sparse/data.hpp:26-54 -- CSC int32/fp64 (P_utri upper triangle; AT = A^T n x p; GT = G^T n x m) */
+typedef struct {
+    int n, p, m;
+    const int *P_colptr, *P_rowind; const double *P_val;
+    const int *AT_colptr, *AT_rowind; const double *AT_val;
+    const int *GT_colptr, *GT_rowind; const double *GT_val;
+    int n_h_l, n_h_u, n_x_l, n_x_u;
+    const int *h_l_idx, *h_u_idx, *x_l_idx, *x_u_idx;
+    const double *x_b_scaling;
+    int mem; /* host only in this release */
+} pq_sparse_data;
+
+/* variables.hpp:19-105 Variables<T>: ten vectors (box vectors length n, compressed to the first
+ * n_x_l / n_x_u entries exactly as the reference keeps them) */
+typedef struct {
+    double *x, *y, *z_l, *z_u, *z_bl, *z_bu, *s_l, *s_u, *s_bl, *s_bu;
+} pq_vars;
+
+/* settings.hpp:43-82 Settings<T> (same fields, same defaults via pq_settings_default) */
+typedef struct {
+    double rho_init, delta_init;
+    double eps_abs, eps_rel;
+    int check_duality_gap;
+    double eps_duality_gap_abs, eps_duality_gap_rel;
+    double infeasibility_threshold;
+    double reg_lower_limit, reg_finetune_lower_limit;
+    int reg_finetune_primal_update_threshold, reg_finetune_dual_update_threshold;
+    int max_iter, max_factor_retires;
+    int preconditioner_scale_cost, preconditioner_reuse_on_update, preconditioner_iter;
+    double tau;
+    int kkt_solver; /* pq_kkt_solver */
+    int iterative_refinement_always_enabled;
+    double iterative_refinement_eps_abs, iterative_refinement_eps_rel;
+    int iterative_refinement_max_iter;
+    double iterative_refinement_min_improvement_rate;
+    double iterative_refinement_static_regularization_eps;
+    double iterative_refinement_static_regularization_rel;
+    int verbose, compute_timings;
+} pq_settings;
+
+/* results.hpp:45-89 Info<T> */
+typedef struct {
+    int status;
+    int iter;
+    double rho, delta, mu, sigma, primal_step, dual_step;
+    double primal_res, primal_res_rel, dual_res, dual_res_rel;
+    double primal_res_reg, primal_res_reg_rel, dual_res_reg, dual_res_reg_rel;
+    double primal_prox_inf, dual_prox_inf;
+    double prev_primal_res, prev_dual_res;
+    double primal_obj, dual_obj, duality_gap, duality_gap_rel;
+    int factor_retires;
+    double reg_limit;
+    int no_primal_update, no_dual_update;
+    double setup_time, update_time, solve_time, kkt_factor_time, kkt_solve_time, run_time;
+    int n_factor, n_solve, n_backend_solve; /* call counters (not in the reference) */
+} pq_info;
+
+void pq_settings_default(pq_settings *s);       /* settings.hpp:45-82 */
+const char *pq_last_error_string(void);          /* thread-local text of the last < 0 return */
+int pq_device_count(void);                       /* number of visible HIP devices (0 = library unusable) */
+const char *pq_version(void);
+
+/* ===================== KKT backend: replaces KKTSolverBase<T,I,MatrixType> ===================== */
+typedef struct pq_kkt pq_kkt;
+
+/* dense::KKT ctor, dense/kkt.hpp:39-55 (uploads P_utri/AT/GT, builds AT_A = AT*AT^T).
+ * kkt_solver: PQ_DENSE_CHOLESKY (Eigen::LLT semantics, dense/kkt.hpp:82-83) or PQ_DENSE_LDLT_NO_PIVOT. */
+int pq_kkt_create_dense(pq_kkt **out, const pq_dense_data *data, int kkt_solver, int device);
+/* sparse::KKT ctor, sparse/kkt.hpp:51-70 (assemble KKT by mode, AMD, permute, symbolic, upload) */
+int pq_kkt_create_sparse(pq_kkt **out, const pq_sparse_data *data, int kkt_solver, int device);
+int pq_kkt_clone(const pq_kkt *k, pq_kkt **out); /* kkt_solver_base.hpp:28 clone() */
+void pq_kkt_destroy(pq_kkt *k);                  /* kkt_solver_base.hpp:26 */
+int pq_kkt_set_pointer_mode(pq_kkt *k, int mem); /* where vector arguments of the calls below live */
+/* kkt_solver_base.hpp:30 update_data(data, options): re-reads the flagged matrices from `data`
+ * (dense re-uploads all three on every call, see SURVEY.md section 7 last bullet) */
+int pq_kkt_update_data_dense(pq_kkt *k, const pq_dense_data *data, int options);
+int pq_kkt_update_data_sparse(pq_kkt *k, const pq_sparse_data *data, int options);
+/* kkt_solver_base.hpp:32: returns 1 ok / 0 failed.  dense: llt.info()==Success (dense/kkt.hpp:83);
+ * sparse: n == cols (sparse/kkt.hpp:104).  x_reg[n], z_reg[m] are consumed during the call. */
+int pq_kkt_update_scalings_and_factor(pq_kkt *k, double delta, const double *x_reg, const double *z_reg);
+/* kkt_solver_base.hpp:34 solve(): outputs caller-allocated (n, p, m) */
+int pq_kkt_solve(pq_kkt *k, const double *rhs_x, const double *rhs_y, const double *rhs_z, double *lhs_x,
+                 double *lhs_y, double *lhs_z);
+/* kkt_solver_base.hpp:37 z = alpha * P * x */
+int pq_kkt_eval_P_x(pq_kkt *k, double alpha, const double *x, double *z);
+/* kkt_solver_base.hpp:39 zn = alpha_n * A * xn, zt = alpha_t * A^T * xt */
+int pq_kkt_eval_A_xn_and_AT_xt(pq_kkt *k, double alpha_n, double alpha_t, const double *xn, const double *xt,
+                               double *zn, double *zt);
+/* kkt_solver_base.hpp:41 zn = alpha_n * G * xn, zt = alpha_t * G^T * xt */
+int pq_kkt_eval_G_xn_and_GT_xt(pq_kkt *k, double alpha_n, double alpha_t, const double *xn, const double *xt,
+                               double *zn, double *zt);
+int pq_kkt_print_info(pq_kkt *k);                                   /* kkt_solver_base.hpp:43 */
+int pq_kkt_synchronize(pq_kkt *k);                                  /* wait for the handle's stream */
+void *pq_kkt_stream(pq_kkt *k);                                     /* hipStream_t of the handle */
+/* test hooks: dense/kkt.hpp:134 internal_kkt_mat() and the factor; copy n*n doubles to HOST memory */
+int pq_kkt_internal_kkt_mat(pq_kkt *k, double *out_host);
+int pq_kkt_internal_factor(pq_kkt *k, double *out_host);
+int pq_kkt_dims(const pq_kkt *k, int *n, int *p, int *m);
+/* measurement hooks: when enabled, the backend brackets its stages with hipEvents on its own stream.
+ * stage 0 = KKT assembly kernel (dense: k_syrk_lower<ASSEMBLE>), 1 = factorisation (all panels),
+ * 2 = backend solve.  pq_kkt_get_profile returns the accumulated milliseconds / call count and resets them. */
+int pq_kkt_set_profiling(pq_kkt *k, int enable);
+int pq_kkt_get_profile(pq_kkt *k, int stage, double *total_ms, int *count);
+
+/* ===================== KKTSystem: replaces piqp::KKTSystem<T,I,MatrixType> ===================== */
+typedef struct pq_kktsys pq_kktsys;
+
+/* KKTSystem::init, kkt_system.hpp:97-132 (+ backend factory :455-497 keyed by settings->kkt_solver) */
+int pq_kktsys_create_dense(pq_kktsys **out, const pq_dense_data *data, const pq_settings *settings, int device);
+int pq_kktsys_create_sparse(pq_kktsys **out, const pq_sparse_data *data, const pq_settings *settings, int device);
+int pq_kktsys_clone(const pq_kktsys *k, pq_kktsys **out); /* kkt_system.hpp:70-95 */
+void pq_kktsys_destroy(pq_kktsys *k);
+int pq_kktsys_set_pointer_mode(pq_kktsys *k, int mem);
+pq_kkt *pq_kktsys_backend(pq_kktsys *k); /* borrowed */
+/* kkt_system.hpp:134-141 */
+int pq_kktsys_update_data_dense(pq_kktsys *k, const pq_dense_data *data, int options);
+int pq_kktsys_update_data_sparse(pq_kktsys *k, const pq_sparse_data *data, int options);
+/* kkt_system.hpp:143-211; returns 1 ok / 0 factor failed */
+int pq_kktsys_update_scalings_and_factor(pq_kktsys *k, int iterative_refinement, double rho, double delta,
+                                         const pq_vars *vars);
+/* kkt_system.hpp:213-369 incl. the iterative-refinement loop (:256-301) run against device-resident
+ * vectors; returns 1 ok / 0 (non-finite).  lhs buffers are written in place (never swapped). */
+int pq_kktsys_solve(pq_kktsys *k, const pq_vars *rhs, pq_vars *lhs);
+/* kkt_system.hpp:392-425 rhs = K_full * lhs */
+int pq_kktsys_mul(pq_kktsys *k, const pq_vars *lhs, pq_vars *rhs);
+/* diagnostics of the last solve: refinement steps taken, backend solves, final refine error, rhs norm */
+int pq_kktsys_last_solve_stats(const pq_kktsys *k, int *refine_steps, int *backend_solves, double *refine_error,
+                               double *rhs_norm);
+/* ||rhs_bar - K_cond * lhs||_inf and ||rhs_bar||_inf of the last solve, recomputed on device via
+ * mul_condensed_kkt (kkt_system.hpp:507-536); the harness's parity metric (SURVEY.md 8b last row) */
+int pq_kktsys_condensed_residual(pq_kktsys *k, double *res_inf, double *rhs_inf);
+int pq_kktsys_synchronize(pq_kktsys *k);
+
+/* ===================== Solver: piqp::DenseSolver / SparseSolver front-end (caller of the hot path) ===== */
+typedef struct pq_solver pq_solver;
+
+int pq_solver_create(pq_solver **out, int device);
+void pq_solver_destroy(pq_solver *s);
+int pq_solver_clone(const pq_solver *s, pq_solver **out);
+pq_settings *pq_solver_settings(pq_solver *s); /* solver.hpp:65 settings() */
+/* DenseSolver::setup, solver.hpp:1266-1277: P n x n, A p x n, G m x n column-major HOST arrays;
+ * NULL = nullopt.  Returns 1 when setup_done. */
+int pq_solver_setup_dense(pq_solver *s, int n, int p, int m, const double *P, const double *c, const double *A,
+                          const double *b, const double *G, const double *h_l, const double *h_u, const double *x_l,
+                          const double *x_u);
+/* SparseSolver::setup, solver.hpp:1297-1308: CSC HOST arrays (P full or upper) */
+int pq_solver_setup_sparse(pq_solver *s, int n, int p, int m, const int *Pp, const int *Pi, const double *Px,
+                           const double *c, const int *Ap, const int *Ai, const double *Ax, const double *b,
+                           const int *Gp, const int *Gi, const double *Gx, const double *h_l, const double *h_u,
+                           const double *x_l, const double *x_u);
+/* DenseSolver::update, solver.hpp:1279-1290 */
+int pq_solver_update_dense(pq_solver *s, const double *P, const double *c, const double *A, const double *b,
+                           const double *G, const double *h_l, const double *h_u, const double *x_l,
+                           const double *x_u);
+int pq_solver_update_sparse(pq_solver *s, const int *Pp, const int *Pi, const double *Px, const double *c,
+                            const int *Ap, const int *Ai, const double *Ax, const double *b, const int *Gp,
+                            const int *Gi, const double *Gx, const double *h_l, const double *h_u,
+                            const double *x_l, const double *x_u);
+int pq_solver_solve(pq_solver *s);               /* solver.hpp:69-148; returns Status */
+const pq_info *pq_solver_info(const pq_solver *s); /* result().info */
+/* result(): copies the ten solution vectors (sizes n,p,m,m,n,n,m,m,n,n) into host buffers (NULL skipped) */
+int pq_solver_get_result(const pq_solver *s, pq_vars *out_host);
+int pq_solver_dims(const pq_solver *s, int *n, int *p, int *m);
+/* optional per-iteration trace (rows of 11 doubles = the verbose table, solver.hpp:590-602) */
+int pq_solver_set_trace(pq_solver *s, double *buf_host, int max_rows);
+int pq_solver_trace_rows(const pq_solver *s);
+
+/* ===================== small utilities used by the measurement harness ===================== */
+/* fp64 MFMA / HBM micro-benchmarks on `device` (used once by bench.py to report measured peaks) */
+int pq_microbench_mfma_f64(int device, int iters, double *tflops_out);
+int pq_microbench_hbm_copy(int device, size_t bytes, int iters, double *gbps_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PIQP_AMD_H */

@@ -1,0 +1,529 @@
+// piqp_amd/csrc/capi.cpp -- the extern "C" boundary declared in include/piqp_amd.h.
+// Thin: argument checks, host<->device staging for PQ_MEM_HOST callers, exception fencing.
+#include <memory>
+#include <stdexcept>
+
+#include "dense_kernels.hpp"
+#include "kkt_solver_base.hpp"
+#include "kkt_system.hpp"
+#include "solver.hpp"
+
+using namespace pq;
+
+namespace {
+
+struct VarSizes {
+    int n, p, m;
+    int size(int k) const
+    {
+        switch (k) { case 0: return n; case 1: return p; case 2: case 3: return m; case 4: case 5: return n; case 6: case 7: return m; default: return n; }
+    }
+};
+inline double** var_field(pq_vars& v, int k)
+{
+    switch (k) { case 0: return &v.x; case 1: return &v.y; case 2: return &v.z_l; case 3: return &v.z_u; case 4: return &v.z_bl; case 5: return &v.z_bu;
+                 case 6: return &v.s_l; case 7: return &v.s_u; case 8: return &v.s_bl; default: return &v.s_bu; }
+}
+inline double* const* var_field(const pq_vars& v, int k) { return var_field(const_cast<pq_vars&>(v), k); }
+
+// device staging for one Variables set
+struct VarStage {
+    DBuf<double> buf[10];
+    pq_vars v{};
+    void alloc(VarSizes s)
+    {
+        for (int k = 0; k < 10; ++k) { buf[k].alloc(s.size(k) > 0 ? s.size(k) : 1); *var_field(v, k) = buf[k].p; }
+    }
+    void zero(hipStream_t st) { for (int k = 0; k < 10; ++k) buf[k].zero(st); }
+};
+
+}  // namespace
+
+struct pq_kkt {
+    KKTSolverBase* impl = nullptr;
+    bool owned = true;
+    int ptr_mode = PQ_MEM_HOST;
+    // staging (host pointer mode)
+    DBuf<double> sx, sy, sz, lx, ly, lz, xr, zr;
+    bool staged = false;
+    void ensure_staging()
+    {
+        if (staged) return;
+        const int n = impl->n(), p = impl->p(), m = impl->m();
+        sx.alloc(n); sy.alloc(p > 0 ? p : 1); sz.alloc(m > 0 ? m : 1);
+        lx.alloc(n); ly.alloc(p > 0 ? p : 1); lz.alloc(m > 0 ? m : 1);
+        xr.alloc(n); zr.alloc(m > 0 ? m : 1);
+        staged = true;
+    }
+    ~pq_kkt() { if (owned) delete impl; }
+};
+
+struct pq_kktsys {
+    KKTSystem* impl = nullptr;
+    pq_kkt backend_view;
+    int ptr_mode = PQ_MEM_HOST;
+    VarStage in, out;
+    bool staged = false;
+    const double* last_lhs_x = nullptr;
+    const double* last_lhs_y = nullptr;
+    void ensure_staging()
+    {
+        if (staged) return;
+        VarSizes s{impl->n(), impl->p(), impl->m()};
+        in.alloc(s); out.alloc(s);
+        in.zero(impl->stream()); out.zero(impl->stream());
+        staged = true;
+    }
+    ~pq_kktsys() { delete impl; }
+};
+
+static void h2d(double* dst, const double* src, int n, hipStream_t st)
+{
+    if (n > 0) PQ_HIP(hipMemcpyAsync(dst, src, sizeof(double) * n, hipMemcpyHostToDevice, st));
+}
+static void d2h(double* dst, const double* src, int n, hipStream_t st)
+{
+    if (n > 0) PQ_HIP(hipMemcpyAsync(dst, src, sizeof(double) * n, hipMemcpyDeviceToHost, st));
+}
+
+extern "C" {
+
+void pq_settings_default(pq_settings* s)
+{
+    // settings.hpp:45-82
+    s->rho_init = 1e-6; s->delta_init = 1e-4;
+    s->eps_abs = 1e-8; s->eps_rel = 1e-9;
+    s->check_duality_gap = 1; s->eps_duality_gap_abs = 1e-8; s->eps_duality_gap_rel = 1e-9;
+    s->infeasibility_threshold = 0.9;
+    s->reg_lower_limit = 1e-10; s->reg_finetune_lower_limit = 1e-13;
+    s->reg_finetune_primal_update_threshold = 7; s->reg_finetune_dual_update_threshold = 7;
+    s->max_iter = 250; s->max_factor_retires = 10;
+    s->preconditioner_scale_cost = 0; s->preconditioner_reuse_on_update = 0; s->preconditioner_iter = 10;
+    s->tau = 0.99;
+    s->kkt_solver = PQ_DENSE_CHOLESKY;
+    s->iterative_refinement_always_enabled = 0;
+    s->iterative_refinement_eps_abs = 1e-12; s->iterative_refinement_eps_rel = 1e-12;
+    s->iterative_refinement_max_iter = 10;
+    s->iterative_refinement_min_improvement_rate = 5.0;
+    s->iterative_refinement_static_regularization_eps = 1e-8;
+    s->iterative_refinement_static_regularization_rel = 2.220446049250313e-16 * 2.220446049250313e-16;
+    s->verbose = 0; s->compute_timings = 0;
+}
+
+const char* pq_last_error_string(void) { return last_error().c_str(); }
+const char* pq_version(void) { return "piqp_amd 0.1 (gfx950; KKT path of PIQP v0.6.2)"; }
+
+int pq_device_count(void)
+{
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess) return 0;
+    return c;
+}
+
+static int check_device(int device)
+{
+    int c = pq_device_count();
+    if (c <= 0) return fail(PQ_ERR_HIP, "no HIP device visible: this library has no CPU fallback");
+    if (device < 0 || device >= c) return fail(PQ_ERR_INVALID, "device %d out of range (%d visible)", device, c);
+    return PQ_OK;
+}
+
+// ------------------------------------------------------------------------------------ backend
+int pq_kkt_create_dense(pq_kkt** out, const pq_dense_data* data, int kkt_solver, int device)
+{
+    if (!out || !data) return fail(PQ_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (kkt_solver != PQ_DENSE_CHOLESKY && kkt_solver != PQ_DENSE_LDLT_NO_PIVOT) return fail(PQ_ERR_UNSUPPORTED, "kkt solver not supported");
+    int rc = check_device(device);
+    if (rc < 0) return rc;
+    return guarded([&] {
+        std::unique_ptr<pq_kkt> h(new pq_kkt);
+        h->impl = make_dense_kkt(data, kkt_solver, device);
+        *out = h.release();
+        return (int)PQ_OK;
+    });
+}
+
+int pq_kkt_create_sparse(pq_kkt** out, const pq_sparse_data* data, int kkt_solver, int device)
+{
+    if (!out || !data) return fail(PQ_ERR_INVALID, "null argument");
+    *out = nullptr;
+    int rc = check_device(device);
+    if (rc < 0) return rc;
+    return guarded([&] {
+        std::unique_ptr<pq_kkt> h(new pq_kkt);
+        h->impl = make_sparse_kkt(data, kkt_solver, device);
+        if (!h->impl) return fail(PQ_ERR_UNSUPPORTED, "kkt solver not supported");
+        *out = h.release();
+        return (int)PQ_OK;
+    });
+}
+
+int pq_kkt_clone(const pq_kkt* k, pq_kkt** out)
+{
+    if (!k || !out) return fail(PQ_ERR_INVALID, "null argument");
+    return guarded([&] {
+        std::unique_ptr<pq_kkt> h(new pq_kkt);
+        h->impl = k->impl->clone();
+        h->ptr_mode = k->ptr_mode;
+        *out = h.release();
+        return (int)PQ_OK;
+    });
+}
+
+void pq_kkt_destroy(pq_kkt* k)
+{
+    if (k && k->owned) delete k;
+}
+
+int pq_kkt_set_pointer_mode(pq_kkt* k, int mem)
+{
+    if (!k || (mem != PQ_MEM_HOST && mem != PQ_MEM_DEVICE)) return fail(PQ_ERR_INVALID, "bad pointer mode");
+    k->ptr_mode = mem;
+    return PQ_OK;
+}
+
+int pq_kkt_update_data_dense(pq_kkt* k, const pq_dense_data* data, int options)
+{
+    if (!k || !data) return fail(PQ_ERR_INVALID, "null argument");
+    return guarded([&] { k->impl->update_data_dense(data, options); return (int)PQ_OK; });
+}
+int pq_kkt_update_data_sparse(pq_kkt* k, const pq_sparse_data* data, int options)
+{
+    if (!k || !data) return fail(PQ_ERR_INVALID, "null argument");
+    return guarded([&] { k->impl->update_data_sparse(data, options); return (int)PQ_OK; });
+}
+
+int pq_kkt_update_scalings_and_factor(pq_kkt* k, double delta, const double* x_reg, const double* z_reg)
+{
+    if (!k || !x_reg || (k->impl->m() > 0 && !z_reg)) return fail(PQ_ERR_INVALID, "null argument");
+    return guarded([&] {
+        PQ_HIP(hipSetDevice(k->impl->device()));
+        hipStream_t st = k->impl->stream();
+        if (k->ptr_mode == PQ_MEM_HOST) {
+            k->ensure_staging();
+            h2d(k->xr.p, x_reg, k->impl->n(), st);
+            h2d(k->zr.p, z_reg, k->impl->m(), st);
+            return k->impl->update_scalings_and_factor(delta, k->xr.p, k->zr.p) ? 1 : 0;
+        }
+        return k->impl->update_scalings_and_factor(delta, x_reg, z_reg) ? 1 : 0;
+    });
+}
+
+int pq_kkt_solve(pq_kkt* k, const double* rhs_x, const double* rhs_y, const double* rhs_z, double* lhs_x, double* lhs_y, double* lhs_z)
+{
+    if (!k || !rhs_x || !lhs_x) return fail(PQ_ERR_INVALID, "null argument");
+    return guarded([&] {
+        PQ_HIP(hipSetDevice(k->impl->device()));
+        hipStream_t st = k->impl->stream();
+        const int n = k->impl->n(), p = k->impl->p(), m = k->impl->m();
+        if (k->ptr_mode == PQ_MEM_HOST) {
+            k->ensure_staging();
+            h2d(k->sx.p, rhs_x, n, st); h2d(k->sy.p, rhs_y, p, st); h2d(k->sz.p, rhs_z, m, st);
+            k->impl->solve(k->sx.p, k->sy.p, k->sz.p, k->lx.p, k->ly.p, k->lz.p);
+            d2h(lhs_x, k->lx.p, n, st); d2h(lhs_y, k->ly.p, p, st); d2h(lhs_z, k->lz.p, m, st);
+            PQ_HIP(hipStreamSynchronize(st));
+        } else {
+            k->impl->solve(rhs_x, rhs_y, rhs_z, lhs_x, lhs_y, lhs_z);
+        }
+        return (int)PQ_OK;
+    });
+}
+
+int pq_kkt_eval_P_x(pq_kkt* k, double alpha, const double* x, double* z)
+{
+    if (!k || !x || !z) return fail(PQ_ERR_INVALID, "null argument");
+    return guarded([&] {
+        PQ_HIP(hipSetDevice(k->impl->device()));
+        hipStream_t st = k->impl->stream();
+        const int n = k->impl->n();
+        if (k->ptr_mode == PQ_MEM_HOST) {
+            k->ensure_staging();
+            h2d(k->sx.p, x, n, st);
+            k->impl->eval_P_x(alpha, k->sx.p, k->lx.p);
+            d2h(z, k->lx.p, n, st);
+            PQ_HIP(hipStreamSynchronize(st));
+        } else {
+            k->impl->eval_P_x(alpha, x, z);
+        }
+        return (int)PQ_OK;
+    });
+}
+
+static int eval_pair(pq_kkt* k, bool isG, double an, double at, const double* xn, const double* xt, double* zn, double* zt)
+{
+    if (!k) return fail(PQ_ERR_INVALID, "null argument");
+    return guarded([&] {
+        PQ_HIP(hipSetDevice(k->impl->device()));
+        hipStream_t st = k->impl->stream();
+        const int n = k->impl->n(), q = isG ? k->impl->m() : k->impl->p();
+        if (k->ptr_mode == PQ_MEM_HOST) {
+            k->ensure_staging();
+            double* sq = isG ? k->sz.p : k->sy.p;
+            double* lq = isG ? k->lz.p : k->ly.p;
+            h2d(k->sx.p, xn, n, st); h2d(sq, xt, q, st);
+            if (isG) k->impl->eval_G_xn_and_GT_xt(an, at, k->sx.p, sq, lq, k->lx.p);
+            else k->impl->eval_A_xn_and_AT_xt(an, at, k->sx.p, sq, lq, k->lx.p);
+            d2h(zn, lq, q, st); d2h(zt, k->lx.p, n, st);
+            PQ_HIP(hipStreamSynchronize(st));
+        } else {
+            if (isG) k->impl->eval_G_xn_and_GT_xt(an, at, xn, xt, zn, zt);
+            else k->impl->eval_A_xn_and_AT_xt(an, at, xn, xt, zn, zt);
+        }
+        return (int)PQ_OK;
+    });
+}
+
+int pq_kkt_eval_A_xn_and_AT_xt(pq_kkt* k, double alpha_n, double alpha_t, const double* xn, const double* xt, double* zn, double* zt)
+{
+    return eval_pair(k, false, alpha_n, alpha_t, xn, xt, zn, zt);
+}
+int pq_kkt_eval_G_xn_and_GT_xt(pq_kkt* k, double alpha_n, double alpha_t, const double* xn, const double* xt, double* zn, double* zt)
+{
+    return eval_pair(k, true, alpha_n, alpha_t, xn, xt, zn, zt);
+}
+
+int pq_kkt_print_info(pq_kkt* k)
+{
+    if (!k) return fail(PQ_ERR_INVALID, "null argument");
+    return guarded([&] { k->impl->print_info(); return (int)PQ_OK; });
+}
+int pq_kkt_synchronize(pq_kkt* k)
+{
+    if (!k) return fail(PQ_ERR_INVALID, "null argument");
+    return guarded([&] { PQ_HIP(hipSetDevice(k->impl->device())); PQ_HIP(hipStreamSynchronize(k->impl->stream())); return (int)PQ_OK; });
+}
+void* pq_kkt_stream(pq_kkt* k) { return k ? (void*)k->impl->stream() : nullptr; }
+int pq_kkt_internal_kkt_mat(pq_kkt* k, double* out_host)
+{
+    if (!k || !out_host) return fail(PQ_ERR_INVALID, "null argument");
+    return guarded([&] { k->impl->internal_kkt_mat(out_host); return (int)PQ_OK; });
+}
+int pq_kkt_internal_factor(pq_kkt* k, double* out_host)
+{
+    if (!k || !out_host) return fail(PQ_ERR_INVALID, "null argument");
+    return guarded([&] { k->impl->internal_factor(out_host); return (int)PQ_OK; });
+}
+int pq_kkt_set_profiling(pq_kkt* k, int enable)
+{
+    if (!k) return fail(PQ_ERR_INVALID, "null argument");
+    return guarded([&] { k->impl->set_profiling(enable != 0); return (int)PQ_OK; });
+}
+int pq_kkt_get_profile(pq_kkt* k, int stage, double* total_ms, int* count)
+{
+    if (!k || !total_ms || !count) return fail(PQ_ERR_INVALID, "null argument");
+    return guarded([&] { k->impl->get_profile(stage, total_ms, count); return (int)PQ_OK; });
+}
+int pq_kkt_dims(const pq_kkt* k, int* n, int* p, int* m)
+{
+    if (!k) return fail(PQ_ERR_INVALID, "null argument");
+    if (n) *n = k->impl->n();
+    if (p) *p = k->impl->p();
+    if (m) *m = k->impl->m();
+    return PQ_OK;
+}
+
+// ------------------------------------------------------------------------------------ KKTSystem
+static pq_kktsys* wrap_kktsys(KKTSystem* sys)
+{
+    pq_kktsys* h = new pq_kktsys;
+    h->impl = sys;
+    h->backend_view.impl = sys->backend();
+    h->backend_view.owned = false;
+    return h;
+}
+
+int pq_kktsys_create_dense(pq_kktsys** out, const pq_dense_data* data, const pq_settings* settings, int device)
+{
+    if (!out || !data || !settings) return fail(PQ_ERR_INVALID, "null argument");
+    *out = nullptr;
+    // KKTSystem::init_kkt_solver<PIQP_DENSE>, kkt_system.hpp:455-468
+    if (settings->kkt_solver != PQ_DENSE_CHOLESKY && settings->kkt_solver != PQ_DENSE_LDLT_NO_PIVOT) return fail(PQ_ERR_UNSUPPORTED, "kkt solver not supported");
+    int rc = check_device(device);
+    if (rc < 0) return rc;
+    return guarded([&] {
+        std::unique_ptr<KKTSolverBase> b(make_dense_kkt(data, settings->kkt_solver, device));
+        std::unique_ptr<KKTSystem> sys(new KKTSystem(b.get(), *settings));
+        b.release();
+        sys->set_bounds(data->n_h_l, data->n_h_u, data->n_x_l, data->n_x_u, data->h_l_idx, data->h_u_idx, data->x_l_idx, data->x_u_idx, data->x_b_scaling, data->mem);
+        *out = wrap_kktsys(sys.release());
+        return (int)PQ_OK;
+    });
+}
+
+int pq_kktsys_create_sparse(pq_kktsys** out, const pq_sparse_data* data, const pq_settings* settings, int device)
+{
+    if (!out || !data || !settings) return fail(PQ_ERR_INVALID, "null argument");
+    *out = nullptr;
+    int rc = check_device(device);
+    if (rc < 0) return rc;
+    return guarded([&] {
+        std::unique_ptr<KKTSolverBase> b(make_sparse_kkt(data, settings->kkt_solver, device));
+        if (!b) return fail(PQ_ERR_UNSUPPORTED, "kkt solver not supported");
+        std::unique_ptr<KKTSystem> sys(new KKTSystem(b.get(), *settings));
+        b.release();
+        sys->set_bounds(data->n_h_l, data->n_h_u, data->n_x_l, data->n_x_u, data->h_l_idx, data->h_u_idx, data->x_l_idx, data->x_u_idx, data->x_b_scaling, data->mem);
+        *out = wrap_kktsys(sys.release());
+        return (int)PQ_OK;
+    });
+}
+
+int pq_kktsys_clone(const pq_kktsys* k, pq_kktsys** out)
+{
+    if (!k || !out) return fail(PQ_ERR_INVALID, "null argument");
+    return guarded([&] {
+        pq_kktsys* h = wrap_kktsys(k->impl->clone());
+        h->ptr_mode = k->ptr_mode;
+        *out = h;
+        return (int)PQ_OK;
+    });
+}
+
+void pq_kktsys_destroy(pq_kktsys* k) { delete k; }
+
+int pq_kktsys_set_pointer_mode(pq_kktsys* k, int mem)
+{
+    if (!k || (mem != PQ_MEM_HOST && mem != PQ_MEM_DEVICE)) return fail(PQ_ERR_INVALID, "bad pointer mode");
+    k->ptr_mode = mem;
+    k->backend_view.ptr_mode = mem;
+    return PQ_OK;
+}
+
+pq_kkt* pq_kktsys_backend(pq_kktsys* k) { return k ? &k->backend_view : nullptr; }
+
+int pq_kktsys_update_data_dense(pq_kktsys* k, const pq_dense_data* data, int options)
+{
+    if (!k || !data) return fail(PQ_ERR_INVALID, "null argument");
+    return guarded([&] {
+        // kkt_system.hpp:134-141 (P_diag is refreshed by the backend's upload)
+        k->impl->backend()->update_data_dense(data, options);
+        k->impl->set_bounds(data->n_h_l, data->n_h_u, data->n_x_l, data->n_x_u, data->h_l_idx, data->h_u_idx, data->x_l_idx, data->x_u_idx, data->x_b_scaling, data->mem);
+        return (int)PQ_OK;
+    });
+}
+int pq_kktsys_update_data_sparse(pq_kktsys* k, const pq_sparse_data* data, int options)
+{
+    if (!k || !data) return fail(PQ_ERR_INVALID, "null argument");
+    return guarded([&] {
+        k->impl->backend()->update_data_sparse(data, options);
+        k->impl->set_bounds(data->n_h_l, data->n_h_u, data->n_x_l, data->n_x_u, data->h_l_idx, data->h_u_idx, data->x_l_idx, data->x_u_idx, data->x_b_scaling, data->mem);
+        return (int)PQ_OK;
+    });
+}
+
+// copy the used part of a host Variables set into the staging set
+static void stage_in(pq_kktsys* k, const pq_vars* src, VarStage& dst)
+{
+    hipStream_t st = k->impl->stream();
+    VarSizes s{k->impl->n(), k->impl->p(), k->impl->m()};
+    for (int f = 0; f < 10; ++f) {
+        const double* hp = *var_field(*src, f);
+        if (hp) h2d(dst.buf[f].p, hp, s.size(f), st);
+    }
+}
+static void stage_out(pq_kktsys* k, VarStage& src, pq_vars* dst)
+{
+    hipStream_t st = k->impl->stream();
+    VarSizes s{k->impl->n(), k->impl->p(), k->impl->m()};
+    for (int f = 0; f < 10; ++f) {
+        double* hp = *var_field(*dst, f);
+        if (hp) d2h(hp, src.buf[f].p, s.size(f), st);
+    }
+    PQ_HIP(hipStreamSynchronize(st));
+}
+
+int pq_kktsys_update_scalings_and_factor(pq_kktsys* k, int iterative_refinement, double rho, double delta, const pq_vars* vars)
+{
+    if (!k || !vars) return fail(PQ_ERR_INVALID, "null argument");
+    return guarded([&] {
+        PQ_HIP(hipSetDevice(k->impl->device()));
+        if (k->ptr_mode == PQ_MEM_HOST) {
+            k->ensure_staging();
+            stage_in(k, vars, k->in);
+            return k->impl->update_scalings_and_factor(iterative_refinement != 0, rho, delta, k->in.v) ? 1 : 0;
+        }
+        return k->impl->update_scalings_and_factor(iterative_refinement != 0, rho, delta, *vars) ? 1 : 0;
+    });
+}
+
+int pq_kktsys_solve(pq_kktsys* k, const pq_vars* rhs, pq_vars* lhs)
+{
+    if (!k || !rhs || !lhs) return fail(PQ_ERR_INVALID, "null argument");
+    return guarded([&] {
+        PQ_HIP(hipSetDevice(k->impl->device()));
+        bool ok;
+        if (k->ptr_mode == PQ_MEM_HOST) {
+            k->ensure_staging();
+            stage_in(k, rhs, k->in);
+            k->impl->last_rhs_y = k->in.v.y;
+            ok = k->impl->solve(k->in.v, k->out.v);
+            k->last_lhs_x = k->out.v.x; k->last_lhs_y = k->out.v.y;
+            stage_out(k, k->out, lhs);
+        } else {
+            k->impl->last_rhs_y = rhs->y;
+            ok = k->impl->solve(*rhs, *lhs);
+            k->last_lhs_x = lhs->x; k->last_lhs_y = lhs->y;
+        }
+        return ok ? 1 : 0;
+    });
+}
+
+int pq_kktsys_mul(pq_kktsys* k, const pq_vars* lhs, pq_vars* rhs)
+{
+    if (!k || !rhs || !lhs) return fail(PQ_ERR_INVALID, "null argument");
+    return guarded([&] {
+        PQ_HIP(hipSetDevice(k->impl->device()));
+        if (k->ptr_mode == PQ_MEM_HOST) {
+            k->ensure_staging();
+            stage_in(k, lhs, k->in);
+            // keep the last solve's outputs intact: multiply into a scratch Variables set
+            VarStage tmp;
+            tmp.alloc(VarSizes{k->impl->n(), k->impl->p(), k->impl->m()});
+            tmp.zero(k->impl->stream());
+            k->impl->mul(k->in.v, tmp.v);
+            stage_out(k, tmp, rhs);
+        } else {
+            k->impl->mul(*lhs, *rhs);
+        }
+        return (int)PQ_OK;
+    });
+}
+
+int pq_kktsys_last_solve_stats(const pq_kktsys* k, int* refine_steps, int* backend_solves, double* refine_error, double* rhs_norm)
+{
+    if (!k) return fail(PQ_ERR_INVALID, "null argument");
+    if (refine_steps) *refine_steps = k->impl->last_refine_steps;
+    if (backend_solves) *backend_solves = k->impl->last_backend_solves;
+    if (refine_error) *refine_error = k->impl->last_refine_error;
+    if (rhs_norm) *rhs_norm = k->impl->last_rhs_norm;
+    return PQ_OK;
+}
+
+int pq_kktsys_condensed_residual(pq_kktsys* k, double* res_inf, double* rhs_inf)
+{
+    if (!k || !res_inf || !rhs_inf) return fail(PQ_ERR_INVALID, "null argument");
+    if (!k->last_lhs_x) return fail(PQ_ERR_INVALID, "no solve yet");
+    return guarded([&] { k->impl->condensed_residual(k->last_lhs_x, k->last_lhs_y, res_inf, rhs_inf); return (int)PQ_OK; });
+}
+
+int pq_kktsys_synchronize(pq_kktsys* k)
+{
+    if (!k) return fail(PQ_ERR_INVALID, "null argument");
+    return guarded([&] { PQ_HIP(hipSetDevice(k->impl->device())); PQ_HIP(hipStreamSynchronize(k->impl->stream())); return (int)PQ_OK; });
+}
+
+// ------------------------------------------------------------------------------------ micro-benchmarks
+int pq_microbench_mfma_f64(int device, int iters, double* tflops_out)
+{
+    int rc = check_device(device);
+    if (rc < 0) return rc;
+    return guarded([&] { PQ_HIP(hipSetDevice(device)); *tflops_out = dense::microbench_mfma_f64(iters, nullptr); return (int)PQ_OK; });
+}
+int pq_microbench_hbm_copy(int device, size_t bytes, int iters, double* gbps_out)
+{
+    int rc = check_device(device);
+    if (rc < 0) return rc;
+    return guarded([&] { PQ_HIP(hipSetDevice(device)); *gbps_out = dense::microbench_hbm_copy(bytes, iters, nullptr); return (int)PQ_OK; });
+}
+
+}  // extern "C"

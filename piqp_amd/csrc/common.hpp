@@ -1,0 +1,176 @@
+// piqp_amd/csrc/common.hpp -- shared host-side plumbing for the HIP KKT backend (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/piqp_amd.h"
+
+namespace pq {
+
+// thread-local error text behind pq_last_error_string()
+inline std::string& last_error()
+{
+    static thread_local std::string s;
+    return s;
+}
+inline int fail(int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    last_error() = buf;
+    return code;
+}
+
+struct HipError {
+    hipError_t err;
+    const char* what;
+    const char* file;
+    int line;
+};
+
+#define PQ_HIP(expr)                                                         \
+    do {                                                                     \
+        hipError_t e_ = (expr);                                              \
+        if (e_ != hipSuccess) throw ::pq::HipError{e_, #expr, __FILE__, __LINE__}; \
+    } while (0)
+
+// Every extern "C" entry wraps its body in this: no exception crosses the ABI.
+template <class F>
+inline int guarded(F&& f)
+{
+    try {
+        return f();
+    } catch (const HipError& e) {
+        return fail(PQ_ERR_HIP, "%s failed: %s (%s:%d)", e.what, hipGetErrorString(e.err), e.file, e.line);
+    } catch (const std::bad_alloc&) {
+        return fail(PQ_ERR_NOMEM, "out of memory");
+    } catch (const std::exception& e) {
+        return fail(PQ_ERR_INVALID, "%s", e.what());
+    } catch (...) {
+        return fail(PQ_ERR_INVALID, "unknown error");
+    }
+}
+
+// RAII device buffer (all allocation happens in constructors / create paths)
+template <class T>
+struct DBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    DBuf() = default;
+    explicit DBuf(size_t count) { alloc(count); }
+    DBuf(const DBuf&) = delete;
+    DBuf& operator=(const DBuf&) = delete;
+    DBuf(DBuf&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+    DBuf& operator=(DBuf&& o) noexcept
+    {
+        if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; }
+        return *this;
+    }
+    ~DBuf() { release(); }
+    void alloc(size_t count)
+    {
+        release();
+        n = count;
+        if (count) PQ_HIP(hipMalloc((void**)&p, count * sizeof(T)));
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    void zero(hipStream_t s) { if (n) PQ_HIP(hipMemsetAsync(p, 0, n * sizeof(T), s)); }
+    size_t bytes() const { return n * sizeof(T); }
+};
+
+// pinned host staging buffer
+template <class T>
+struct HBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    HBuf() = default;
+    explicit HBuf(size_t count) { alloc(count); }
+    HBuf(const HBuf&) = delete;
+    HBuf& operator=(const HBuf&) = delete;
+    ~HBuf() { release(); }
+    void alloc(size_t count)
+    {
+        release();
+        n = count;
+        if (count) PQ_HIP(hipHostMalloc((void**)&p, count * sizeof(T), hipHostMallocDefault));
+    }
+    void release()
+    {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        n = 0;
+    }
+};
+
+inline void copy_in(void* dst_dev, const void* src, size_t bytes, int src_mem, hipStream_t s)
+{
+    if (!bytes) return;
+    PQ_HIP(hipMemcpyAsync(dst_dev, src, bytes, src_mem == PQ_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+}
+
+inline int div_up(int a, int b) { return (a + b - 1) / b; }
+
+// hipEvent brackets around stages of a backend, accumulated lazily (events are read at query time,
+// after the stream has been synchronised; nothing here blocks the timed region)
+struct StageProfiler {
+    static constexpr int NSTAGE = 3;
+    bool enabled = false;
+    struct Pair { hipEvent_t a, b; };
+    std::vector<Pair> pending[NSTAGE], pool;
+    ~StageProfiler()
+    {
+        for (auto& v : pending) for (auto& pr : v) { (void)hipEventDestroy(pr.a); (void)hipEventDestroy(pr.b); }
+        for (auto& pr : pool) { (void)hipEventDestroy(pr.a); (void)hipEventDestroy(pr.b); }
+    }
+    Pair get()
+    {
+        if (!pool.empty()) { Pair p = pool.back(); pool.pop_back(); return p; }
+        Pair p;
+        PQ_HIP(hipEventCreate(&p.a));
+        PQ_HIP(hipEventCreate(&p.b));
+        return p;
+    }
+    int begin(int stage, hipStream_t s)
+    {
+        if (!enabled) return -1;
+        Pair p = get();
+        PQ_HIP(hipEventRecord(p.a, s));
+        pending[stage].push_back(p);
+        return (int)pending[stage].size() - 1;
+    }
+    void end(int stage, int tok, hipStream_t s)
+    {
+        if (tok >= 0) PQ_HIP(hipEventRecord(pending[stage][tok].b, s));
+    }
+    void collect(int stage, hipStream_t s, double* total_ms, int* count)
+    {
+        PQ_HIP(hipStreamSynchronize(s));
+        double tot = 0.0;
+        for (auto& pr : pending[stage]) {
+            float ms = 0.f;
+            PQ_HIP(hipEventElapsedTime(&ms, pr.a, pr.b));
+            tot += ms;
+            pool.push_back(pr);
+        }
+        *count = (int)pending[stage].size();
+        *total_ms = tot;
+        pending[stage].clear();
+    }
+};
+
+}  // namespace pq

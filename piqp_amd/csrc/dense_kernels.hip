@@ -1,0 +1,837 @@
+// piqp_amd/csrc/dense_kernels.hip -- hand-written gfx950 kernels of the dense KKT path.
+//
+// Reference operations replaced (PIQP v0.6.2 include/piqp/):
+//   dense/kkt.hpp:140-160  update_kkt       -> k_syrk_lower<EPI_ASSEMBLE>  (fp64 MFMA 16x16x4, LDS double-buffered)
+//   dense/kkt.hpp:53,68    AT_A = AT*AT^T   -> k_syrk_lower<EPI_STORE>
+//   Eigen::LLT::compute (dense/kkt.hpp:82) / LDLTNoPivot (dense/ldlt_no_pivot.hpp:313-354)
+//                                           -> k_potrf_diag + k_trsm_panel + k_syrk_lower<EPI_SUBTRACT>
+//   llt.solveInPlace (dense/kkt.hpp:170) / ldlt_no_pivot.hpp:432-450 -> k_trsv_fwd_step / k_trsv_bwd_step
+//   dense/kkt.hpp:94-104,112-131 GEMVs      -> k_gemv_n_partial + k_reduce_partials, k_gemv_t
+//
+// Layout: everything column-major fp64.  The product matrices GT (n x m) / AT (n x p) are stored as in
+// dense::Data (dense/data.hpp:29-31): column k of GT is row k of G, so both SYRK operands are read
+// along contiguous columns (1 KiB per wave-instruction).
+#include "dense_kernels.hpp"
+
+namespace pq {
+namespace dense {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ double readlane_d(double v, int srclane)
+{
+    long long bits = __double_as_longlong(v);
+    int lo = (int)(bits & 0xffffffffll), hi = (int)(bits >> 32);
+    lo = __builtin_amdgcn_readlane(lo, srclane);
+    hi = __builtin_amdgcn_readlane(hi, srclane);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// ------------------------------------------------------------------------------------------------
+// P_full = symmetric completion of P_utri (used by the assembly epilogue, coalesced along rows, and
+// by eval_P_x as a plain column-dot GEMV).  dense/kkt.hpp:112-113 reads both triangles of P_utri.
+__global__ __launch_bounds__(256) void k_symmetrize_upper(const double* __restrict__ Pu, int n, double* __restrict__ Pf, double* __restrict__ pdiag)
+{
+    __shared__ double tile[32][33];
+    const int r0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const bool lower_tile = r0 > c0;
+    const int sr0 = lower_tile ? c0 : r0, sc0 = lower_tile ? r0 : c0;  // source tile in the upper triangle
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;            // 32 x 8
+    for (int cc = ty; cc < 32; cc += 8) {
+        int r = sr0 + tx, c = sc0 + cc;
+        tile[cc][tx] = (r < n && c < n) ? Pu[r + (size_t)c * n] : 0.0;  // tile[col][row] of the source
+    }
+    __syncthreads();
+    for (int cc = ty; cc < 32; cc += 8) {
+        int i = r0 + tx, j = c0 + cc;  // output element (i, j)
+        if (i < n && j < n) {
+            double v;
+            if (lower_tile) v = tile[tx][cc];                       // Pu[j, i]: source row = j - sr0 = cc, col = i - sc0 = tx
+            else if (r0 == c0) v = (tx <= cc) ? tile[cc][tx] : tile[tx][cc];
+            else v = tile[cc][tx];
+            Pf[i + (size_t)j * n] = v;
+            if (i == j && pdiag) pdiag[i] = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Lower-triangular rank-k product on the fp64 matrix cores.
+//   acc(i,j) = sum_k A[i,k] * w[k] * B[j,k]      (A, B: n x kdim column-major; w optional)
+//   EPI_ASSEMBLE: C(i,j) = Pfull(i,j) + [i==j] x_reg(i) + dinv * ATA(i,j) + acc     (dense/kkt.hpp:144-158)
+//   EPI_SUBTRACT: C(i,j) -= acc                                                     (LLT rankUpdate / ldlt_no_pivot.hpp:350)
+//   EPI_STORE   : C(i,j) = acc                                                      (dense/kkt.hpp:53)
+// One 128x128 output tile per 256-thread workgroup (2x2 waves, each 64x64 = 4x4 MFMA 16x16 tiles,
+// 64 fp64 accumulators per lane).  K is consumed in steps of 16 through two LDS stages; global loads
+// of stage t+1 are issued before the MFMAs of stage t.  LDS rows are padded to 144 doubles so the
+// 16-lane groups of a ds_read_b64 fall on disjoint banks.  The MFMA is issued with the COLUMN
+// operand as A and the ROW operand as B so that each lane's four results are consecutive ROWS of C:
+// stores (and the Pfull / ATA epilogue loads) are 128 B contiguous per 16 lanes.
+constexpr int TS = 128;
+constexpr int BK = 16;
+constexpr int LDS_LD = TS + 16;
+constexpr int SYRK_LDS_BYTES = 2 * 2 * BK * LDS_LD * (int)sizeof(double);
+
+template <bool CHECK>
+__device__ __forceinline__ void load_tile(const double* __restrict__ M, int ld, int r0, int k0, int nrows, int kdim, int tid, d2 (&v)[4])
+{
+    const int r = r0 + 2 * (tid & 63);
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int k = k0 + it * 4 + (tid >> 6);
+        if (!CHECK) {
+            v[it] = *reinterpret_cast<const d2*>(M + r + (size_t)k * ld);
+        } else {
+            d2 t = {0.0, 0.0};
+            if (k < kdim) {
+                if (r < nrows) t.x = M[r + (size_t)k * ld];
+                if (r + 1 < nrows) t.y = M[r + 1 + (size_t)k * ld];
+            }
+            v[it] = t;
+        }
+    }
+}
+
+__device__ __forceinline__ void store_tile(double* __restrict__ S, int tid, const d2 (&v)[4])
+{
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int k = it * 4 + (tid >> 6);
+        *reinterpret_cast<d2*>(S + k * LDS_LD + 2 * (tid & 63)) = v[it];
+    }
+}
+
+template <bool CHECK>
+__device__ __forceinline__ void scale_tile(const double* __restrict__ w, int k0, int kdim, int tid, d2 (&v)[4])
+{
+    if (!w) return;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int k = k0 + it * 4 + (tid >> 6);
+        const double s = (!CHECK || k < kdim) ? w[k] : 0.0;
+        v[it].x *= s;
+        v[it].y *= s;
+    }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void k_syrk_lower(SyrkArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* As = smem;                    // [2][BK][LDS_LD]
+    double* Bs = smem + 2 * BK * LDS_LD;  // [2][BK][LDS_LD]
+
+    // linear block id -> lower-triangular tile (ti >= tj)
+    const int b = blockIdx.x;
+    int ti = (int)((sqrt(8.0 * (double)b + 1.0) - 1.0) * 0.5);
+    while ((ti + 1) * (ti + 2) / 2 <= b) ++ti;
+    while (ti * (ti + 1) / 2 > b) --ti;
+    const int tj = b - ti * (ti + 1) / 2;
+    const int row0 = ti * TS, col0 = tj * TS;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const bool edge = (row0 + TS > a.n) || (col0 + TS > a.n) || a.unaligned;
+    const bool skip_wave = (ti == tj) && (wr < wc);  // sub-tile strictly above the diagonal
+
+    d4 acc[4][4];
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y) acc[x][y] = (d4){0.0, 0.0, 0.0, 0.0};
+
+    const int nkt = (a.kdim + BK - 1) / BK;
+    d2 va[4], vb[4];
+    if (nkt > 0) {
+        const bool chk = edge || (BK > a.kdim);
+        if (chk) { load_tile<true>(a.A, a.lda, row0, 0, a.n, a.kdim, tid, va); load_tile<true>(a.B, a.ldb, col0, 0, a.n, a.kdim, tid, vb); scale_tile<true>(a.w, 0, a.kdim, tid, vb); }
+        else { load_tile<false>(a.A, a.lda, row0, 0, a.n, a.kdim, tid, va); load_tile<false>(a.B, a.ldb, col0, 0, a.n, a.kdim, tid, vb); scale_tile<false>(a.w, 0, a.kdim, tid, vb); }
+        store_tile(As, tid, va);
+        store_tile(Bs, tid, vb);
+    }
+    __syncthreads();
+
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        const bool more = (kt + 1 < nkt);
+        if (more) {
+            const int k0 = (kt + 1) * BK;
+            const bool chk = edge || (k0 + BK > a.kdim);
+            if (chk) { load_tile<true>(a.A, a.lda, row0, k0, a.n, a.kdim, tid, va); load_tile<true>(a.B, a.ldb, col0, k0, a.n, a.kdim, tid, vb); scale_tile<true>(a.w, k0, a.kdim, tid, vb); }
+            else { load_tile<false>(a.A, a.lda, row0, k0, a.n, a.kdim, tid, va); load_tile<false>(a.B, a.ldb, col0, k0, a.n, a.kdim, tid, vb); scale_tile<false>(a.w, k0, a.kdim, tid, vb); }
+        }
+        if (!skip_wave) {
+            const double* Asb = As + cur * BK * LDS_LD + wr * 64 + (lane & 15);
+            const double* Bsb = Bs + cur * BK * LDS_LD + wc * 64 + (lane & 15);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int kk = ks * 4 + (lane >> 4);
+                double af[4], bf[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { af[q] = Asb[kk * LDS_LD + q * 16]; bf[q] = Bsb[kk * LDS_LD + q * 16]; }
+#pragma unroll
+                for (int x = 0; x < 4; ++x)
+#pragma unroll
+                    for (int y = 0; y < 4; ++y)
+                        acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[x], af[y], acc[x][y], 0, 0, 0);
+            }
+        }
+        if (more) {
+            store_tile(As + (cur ^ 1) * BK * LDS_LD, tid, va);
+            store_tile(Bs + (cur ^ 1) * BK * LDS_LD, tid, vb);
+        }
+        __syncthreads();
+    }
+
+    if (skip_wave) return;
+    // epilogue: lane holds rows gi (consecutive over lane&15) and columns gj = base + (lane>>4) + 4*r
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+#pragma unroll
+        for (int y = 0; y < 4; ++y) {
+            const int gi = row0 + wr * 64 + y * 16 + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gj = col0 + wc * 64 + x * 16 + (lane >> 4) + 4 * r;
+                if (gi < a.n && gj < a.n && gi >= gj) {
+                    const size_t ci = (size_t)gi + (size_t)gj * a.ldc;
+                    const double v = acc[x][y][r];
+                    if (EPI == EPI_ASSEMBLE) {
+                        double base = a.Pfull[(size_t)gi + (size_t)gj * a.ldp];
+                        if (gi == gj) base += a.x_reg[gi];
+                        if (a.ATA) base += a.dinv * a.ATA[(size_t)gi + (size_t)gj * a.ldata];
+                        a.C[ci] = base + v;
+                    } else if (EPI == EPI_SUBTRACT) {
+                        a.C[ci] -= v;
+                    } else {
+                        a.C[ci] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+void launch_syrk(int epi, const SyrkArgs& args_in, hipStream_t s)
+{
+    SyrkArgs a = args_in;
+    if (a.n <= 0) return;
+    a.unaligned = ((a.lda & 1) || (a.ldb & 1) || (reinterpret_cast<uintptr_t>(a.A) & 15) || (reinterpret_cast<uintptr_t>(a.B) & 15)) ? 1 : 0;
+    const int T = div_up(a.n, TS);
+    const int nblocks = T * (T + 1) / 2;
+    static bool attr_set = false;
+    if (!attr_set) {
+        PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk_lower<EPI_ASSEMBLE>), hipFuncAttributeMaxDynamicSharedMemorySize, SYRK_LDS_BYTES));
+        PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk_lower<EPI_SUBTRACT>), hipFuncAttributeMaxDynamicSharedMemorySize, SYRK_LDS_BYTES));
+        PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk_lower<EPI_STORE>), hipFuncAttributeMaxDynamicSharedMemorySize, SYRK_LDS_BYTES));
+        attr_set = true;
+    }
+    switch (epi) {
+    case EPI_ASSEMBLE: hipLaunchKernelGGL(k_syrk_lower<EPI_ASSEMBLE>, dim3(nblocks), dim3(256), SYRK_LDS_BYTES, s, a); break;
+    case EPI_SUBTRACT: hipLaunchKernelGGL(k_syrk_lower<EPI_SUBTRACT>, dim3(nblocks), dim3(256), SYRK_LDS_BYTES, s, a); break;
+    default: hipLaunchKernelGGL(k_syrk_lower<EPI_STORE>, dim3(nblocks), dim3(256), SYRK_LDS_BYTES, s, a); break;
+    }
+    PQ_HIP(hipGetLastError());
+}
+
+// assembly without inequality rows (m == 0): C_lower = Pfull + diag(x_reg) + dinv*ATA
+__global__ __launch_bounds__(256) void k_assemble_no_g(int n, const double* __restrict__ Pf, const double* __restrict__ x_reg, const double* __restrict__ ATA, double dinv, double* __restrict__ C)
+{
+    const int j = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n && i >= j) {
+        double v = Pf[i + (size_t)j * n];
+        if (i == j) v += x_reg[i];
+        if (ATA) v += dinv * ATA[i + (size_t)j * n];
+        C[i + (size_t)j * n] = v;
+    }
+}
+void launch_assemble_no_g(int n, const double* Pf, const double* x_reg, const double* ATA, double dinv, double* C, hipStream_t s)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_assemble_no_g, dim3(div_up(n, 256), n), dim3(256), 0, s, n, Pf, x_reg, ATA, dinv, C);
+    PQ_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------
+// Diagonal-block factorisation (one workgroup, block resident in LDS).
+//   LDLT == false: Eigen LLT unblocked semantics per SURVEY.md A.4: pivot x <= 0 -> fail, l = sqrt(x), column / l
+//   LDLT == true : dense/ldlt_no_pivot.hpp:278-311: unit L, D on the diagonal, fail iff pivot == 0
+// Inner structure: 16-column steps; the 16x16 diagonal piece is factored by one wave in registers
+// (row per lane, v_readlane broadcasts), the panel below by one thread per row, and the in-block
+// trailing update by 16x16x4 fp64 MFMA tiles.
+constexpr int NB = 128;
+constexpr int PLD = NB + 16;  // LDS leading dimension (bank-conflict-free MFMA operand reads)
+constexpr int POTRF_LDS_BYTES = NB * PLD * (int)sizeof(double);
+
+template <bool LDLT>
+__global__ __launch_bounds__(256) void k_potrf_diag(double* __restrict__ A, int lda, int nb, int kglobal, int* __restrict__ info)
+{
+    extern __shared__ __attribute__((aligned(16))) double S[];  // S[c * PLD + r]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nbp = (nb + 15) & ~15;
+    const int nt = nbp >> 4;
+    for (int idx = tid; idx < nbp * nbp; idx += 256) {
+        const int r = idx % nbp, c = idx / nbp;
+        double v = 0.0;
+        if (r < nb && c < nb) { if (r >= c) v = A[r + (size_t)c * lda]; }
+        else if (r == c) v = 1.0;  // identity padding
+        S[c * PLD + r] = v;
+    }
+    __syncthreads();
+
+    for (int jb = 0; jb < nt; ++jb) {
+        const int j0 = jb * 16;
+        // (1) 16x16 diagonal piece, wave 0, row (lane & 15) per lane
+        if (wave == 0) {
+            const int i = lane & 15;
+            double a[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) a[c] = S[(j0 + c) * PLD + j0 + i];
+            int failed = -1;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                double dk = readlane_d(a[k], k);
+                double yk = a[k];
+                if (!LDLT) {
+                    if (!(dk > 0.0)) { if (failed < 0) failed = k; dk = 1.0; }
+                    const double l = sqrt(dk);
+                    a[k] = (i == k) ? l : a[k] / l;
+                } else {
+                    if (dk == 0.0) { if (failed < 0) failed = k; dk = 1.0; }
+                    a[k] = (i == k) ? dk : a[k] / dk;
+                }
+#pragma unroll
+                for (int j = k + 1; j < 16; ++j) {
+                    const double ljk = readlane_d(a[k], j);
+                    a[j] -= (LDLT ? yk : a[k]) * ljk;
+                }
+            }
+            if (lane < 16) {
+#pragma unroll
+                for (int c = 0; c < 16; ++c) if (c <= i) S[(j0 + c) * PLD + j0 + i] = a[c];
+            }
+            if (failed >= 0 && lane == 0 && j0 + failed < nb) { if (*info < 0) *info = kglobal + j0 + failed; }
+        }
+        __syncthreads();
+        // (2) panel below the diagonal piece: X = A * Ljj^-T (LLT) / Y = A * Ljj^-T(unit), X = Y D^-1 (LDLT)
+        {
+            const int i = j0 + 16 + tid;
+            if (i < nbp) {
+                double x[16];
+#pragma unroll
+                for (int c = 0; c < 16; ++c) x[c] = S[(j0 + c) * PLD + i];
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    double sacc = x[c];
+#pragma unroll
+                    for (int q = 0; q < c; ++q) sacc -= (LDLT ? x[q] * S[(j0 + q) * PLD + j0 + q] : x[q]) * S[(j0 + q) * PLD + j0 + c];
+                    x[c] = sacc / S[(j0 + c) * PLD + j0 + c];
+                }
+#pragma unroll
+                for (int c = 0; c < 16; ++c) S[(j0 + c) * PLD + i] = x[c];
+            }
+        }
+        __syncthreads();
+        // (3) trailing update inside the block with MFMA tiles: S(tr,tc) -= X_tr * (D) * X_tc^T
+        {
+            const int rem = nt - 1 - jb;
+            const int ntile = rem * (rem + 1) / 2;
+            for (int t = wave; t < ntile; t += 4) {
+                int tr = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+                while ((tr + 1) * (tr + 2) / 2 <= t) ++tr;
+                while (tr * (tr + 1) / 2 > t) --tr;
+                const int tc = t - tr * (tr + 1) / 2;
+                const int R0 = (jb + 1 + tr) * 16, C0 = (jb + 1 + tc) * 16;
+                d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int k = j0 + ks * 4 + (lane >> 4);
+                    const double av = S[k * PLD + R0 + (lane & 15)];
+                    double bv = S[k * PLD + C0 + (lane & 15)];
+                    if (LDLT) bv *= S[k * PLD + k];
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(bv, av, acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) S[(C0 + (lane >> 4) + 4 * r) * PLD + R0 + (lane & 15)] -= acc[r];
+            }
+        }
+        __syncthreads();
+    }
+    for (int idx = tid; idx < nb * nb; idx += 256) {
+        const int r = idx % nb, c = idx / nb;
+        if (r >= c) A[r + (size_t)c * lda] = S[c * PLD + r];
+    }
+}
+
+void launch_potrf_diag(bool ldlt, double* A, int lda, int nb, int kglobal, int* info, hipStream_t s)
+{
+    static bool attr_set = false;
+    if (!attr_set) {
+        PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_diag<false>), hipFuncAttributeMaxDynamicSharedMemorySize, POTRF_LDS_BYTES));
+        PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_diag<true>), hipFuncAttributeMaxDynamicSharedMemorySize, POTRF_LDS_BYTES));
+        attr_set = true;
+    }
+    if (ldlt) hipLaunchKernelGGL(k_potrf_diag<true>, dim3(1), dim3(256), POTRF_LDS_BYTES, s, A, lda, nb, kglobal, info);
+    else hipLaunchKernelGGL(k_potrf_diag<false>, dim3(1), dim3(256), POTRF_LDS_BYTES, s, A, lda, nb, kglobal, info);
+    PQ_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------
+// Panel solve below the diagonal block:  A21 <- A21 * L11^-T            (Eigen LLT: solveInPlace<OnTheRight>)
+//                                        A21 <- A21 * L11^-T(unit) D^-1 (dense/ldlt_no_pivot.hpp:345-346)
+// One workgroup per 64 rows; the row block lives in LDS, L11 is read from L2.
+constexpr int RB = 64;
+constexpr int XLD = RB + 16;
+constexpr int TRSM_LDS_BYTES = (NB * XLD + 16 * 17) * (int)sizeof(double);
+
+template <bool LDLT>
+__global__ __launch_bounds__(256) void k_trsm_panel(double* __restrict__ A, int lda, int k0, int nb, int n)
+{
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double* Xs = sm;              // Xs[c * XLD + r], c < nbp, r < RB
+    double* Lj = sm + NB * XLD;   // Lj[q * 17 + c] = L11[j0 + c, j0 + q]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nbp = (nb + 15) & ~15, nt = nbp >> 4;
+    const int r0 = k0 + nb + blockIdx.x * RB;
+    const double* L11 = A + k0 + (size_t)k0 * lda;
+    for (int idx = tid; idx < RB * nbp; idx += 256) {
+        const int r = idx % RB, c = idx / RB;
+        Xs[c * XLD + r] = (r0 + r < n && c < nb) ? A[(r0 + r) + (size_t)(k0 + c) * lda] : 0.0;
+    }
+    __syncthreads();
+    for (int jb = 0; jb < nt; ++jb) {
+        const int j0 = jb * 16;
+        {
+            const int c = tid & 15, q = tid >> 4;  // 256 entries
+            double v = 0.0;
+            if (j0 + c < nb && j0 + q < nb) { if (c >= q) v = L11[(j0 + c) + (size_t)(j0 + q) * lda]; }
+            else if (c == q) v = 1.0;
+            Lj[q * 17 + c] = v;
+        }
+        __syncthreads();
+        if (tid < RB) {
+            double x[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) x[c] = Xs[(j0 + c) * XLD + tid];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                double sacc = x[c];
+#pragma unroll
+                for (int q = 0; q < c; ++q) sacc -= x[q] * Lj[q * 17 + c];
+                x[c] = LDLT ? sacc : sacc / Lj[c * 17 + c];
+            }
+#pragma unroll
+            for (int c = 0; c < 16; ++c) Xs[(j0 + c) * XLD + tid] = x[c];
+        }
+        __syncthreads();
+        // update remaining column tiles: Xs[:, ct] -= X_jb * L11[ct, jb]^T
+        const int rem = nt - 1 - jb;
+        for (int t = wave; t < rem * 4; t += 4) {
+            const int ct = jb + 1 + t / 4, rt = t & 3;
+            d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int k = j0 + ks * 4 + (lane >> 4);
+                const double xv = Xs[k * XLD + rt * 16 + (lane & 15)];
+                const int lr = ct * 16 + (lane & 15);
+                const double lv = (lr < nb && k < nb) ? L11[lr + (size_t)k * lda] : 0.0;
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(lv, xv, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Xs[(ct * 16 + (lane >> 4) + 4 * r) * XLD + rt * 16 + (lane & 15)] -= acc[r];
+        }
+        __syncthreads();
+    }
+    for (int idx = tid; idx < RB * nb; idx += 256) {
+        const int r = idx % RB, c = idx / RB;
+        if (r0 + r < n) {
+            double v = Xs[c * XLD + r];
+            if (LDLT) v /= L11[c + (size_t)c * lda];
+            A[(r0 + r) + (size_t)(k0 + c) * lda] = v;
+        }
+    }
+}
+
+void launch_trsm_panel(bool ldlt, double* A, int lda, int k0, int nb, int n, hipStream_t s)
+{
+    const int rs = n - k0 - nb;
+    if (rs <= 0) return;
+    static bool attr_set = false;
+    if (!attr_set) {
+        PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_trsm_panel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, TRSM_LDS_BYTES));
+        PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_trsm_panel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, TRSM_LDS_BYTES));
+        attr_set = true;
+    }
+    if (ldlt) hipLaunchKernelGGL(k_trsm_panel<true>, dim3(div_up(rs, RB)), dim3(256), TRSM_LDS_BYTES, s, A, lda, k0, nb, n);
+    else hipLaunchKernelGGL(k_trsm_panel<false>, dim3(div_up(rs, RB)), dim3(256), TRSM_LDS_BYTES, s, A, lda, k0, nb, n);
+    PQ_HIP(hipGetLastError());
+}
+
+// D vector of the LDLt factor (diag of the factor buffer) for the trailing update's per-k scale
+__global__ void k_extract_diag(const double* __restrict__ A, int lda, int k0, int nb, double* __restrict__ d)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nb) d[i] = A[(k0 + i) + (size_t)(k0 + i) * lda];
+}
+void launch_extract_diag(const double* A, int lda, int k0, int nb, double* d, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_extract_diag, dim3(div_up(nb, 128)), dim3(128), 0, s, A, lda, k0, nb, d);
+    PQ_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------
+// Triangular solves with one right-hand side, blocked by 128 columns.  Step j of the forward sweep:
+// every row block r >= j first applies the contribution of block column j-1 (whose x is final), then
+// block r == j solves its diagonal block.  The diagonal solve is a single-wave substitution (two rows
+// per lane, v_readlane broadcast of the pivot).  unit_diag/div_d implement dense/ldlt_no_pivot.hpp:446-448.
+constexpr int TB = 128;
+constexpr int TRSV_LDS_BYTES = (TB * (TB + 1) + TB) * (int)sizeof(double);
+
+__global__ __launch_bounds__(256) void k_trsv_fwd_step(const double* __restrict__ L, int ld, int n, double* __restrict__ x, int j, int unit_diag)
+{
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double* Ls = sm;                    // Ls[c * (TB+1) + r]
+    double* xs = sm + TB * (TB + 1);    // x of block j-1 / rhs of block j
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = j + blockIdx.x;
+    const int row0 = r * TB, nrows = min(TB, n - row0);
+    if (j > 0) {
+        const int c0 = (j - 1) * TB;
+        if (tid < TB) xs[tid] = x[c0 + tid];
+        __syncthreads();
+        // two threads per row, 64 columns each; fixed summation order (deterministic)
+        const int row = tid & 127, half = tid >> 7;
+        double sacc = 0.0;
+        if (row < nrows) {
+            const double* Lp = L + (row0 + row) + (size_t)(c0 + half * 64) * ld;
+#pragma unroll 8
+            for (int c = 0; c < 64; ++c) sacc += Lp[(size_t)c * ld] * xs[half * 64 + c];
+        }
+        __syncthreads();
+        if (half == 1) xs[row] = sacc;
+        __syncthreads();
+        if (half == 0 && row < nrows) x[row0 + row] -= (sacc + xs[row]);
+        __syncthreads();
+    }
+    if (r != j) return;
+    // diagonal block solve: stage L_jj in LDS, then wave 0 substitutes
+    for (int idx = tid; idx < TB * TB; idx += 256) {
+        const int rr = idx & (TB - 1), cc = idx >> 7;
+        Ls[cc * (TB + 1) + rr] = (rr < nrows && cc < nrows && rr >= cc) ? L[(row0 + rr) + (size_t)(row0 + cc) * ld] : (rr == cc ? 1.0 : 0.0);
+    }
+    __syncthreads();
+    if (wave == 0) {
+        double b0 = (lane < nrows) ? x[row0 + lane] : 0.0;
+        double b1 = (lane + 64 < nrows) ? x[row0 + lane + 64] : 0.0;
+        for (int k = 0; k < 64; ++k) {
+            double piv = readlane_d(b0, k);
+            if (!unit_diag) piv /= Ls[k * (TB + 1) + k];
+            if (lane == k) b0 = piv;
+            if (lane > k) b0 -= Ls[k * (TB + 1) + lane] * piv;
+            b1 -= Ls[k * (TB + 1) + lane + 64] * piv;
+        }
+        for (int k = 64; k < 128; ++k) {
+            double piv = readlane_d(b1, k - 64);
+            if (!unit_diag) piv /= Ls[k * (TB + 1) + k];
+            if (lane + 64 == k) b1 = piv;
+            if (lane + 64 > k) b1 -= Ls[k * (TB + 1) + lane + 64] * piv;
+        }
+        if (lane < nrows) x[row0 + lane] = b0;
+        if (lane + 64 < nrows) x[row0 + lane + 64] = b1;
+    }
+}
+
+// backward sweep (L^T x = y).  Step j (descending): block rows r <= j apply the contribution of block
+// column j+1 (x_{j+1} final) to x_r -= L[j+1 block, r block]^T x_{j+1}; block r == j then solves L_jj^T.
+__global__ __launch_bounds__(256) void k_trsv_bwd_step(const double* __restrict__ L, int ld, int n, double* __restrict__ x, int j, int nblk, int unit_diag)
+{
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double* Ls = sm;
+    double* xs = sm + TB * (TB + 1);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = blockIdx.x;  // 0..j
+    const int row0 = r * TB, nrows = min(TB, n - row0);
+    if (j + 1 < nblk) {
+        const int c0 = (j + 1) * TB, nc = min(TB, n - c0);
+        if (tid < TB) xs[tid] = (tid < nc) ? x[c0 + tid] : 0.0;
+        __syncthreads();
+        // x_r[i] -= sum_c L[c0 + c, row0 + i] * x_{j+1}[c] : column (row0+i) of L, contiguous in c.
+        // one wave handles 32 of the 128 output rows, lanes stride over c (fixed-order shuffle reduce).
+        for (int ii = 0; ii < 32; ++ii) {
+            const int i = wave * 32 + ii;
+            if (i < nrows) {
+                const double* Lp = L + c0 + (size_t)(row0 + i) * ld;
+                double sacc = 0.0;
+                if (lane < nc) sacc += Lp[lane] * xs[lane];
+                if (lane + 64 < nc) sacc += Lp[lane + 64] * xs[lane + 64];
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) sacc += __shfl_down(sacc, off, 64);
+                if (lane == 0) x[row0 + i] -= sacc;
+            }
+        }
+        __syncthreads();
+    }
+    if (r != j) return;
+    for (int idx = tid; idx < TB * TB; idx += 256) {
+        const int rr = idx & (TB - 1), cc = idx >> 7;
+        Ls[cc * (TB + 1) + rr] = (rr < nrows && cc < nrows && rr >= cc) ? L[(row0 + rr) + (size_t)(row0 + cc) * ld] : (rr == cc ? 1.0 : 0.0);
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (wave == 0) {
+        // solve L_jj^T y = b : y_k = (b_k - sum_{i>k} L[i,k] y_i) / L[k,k], k descending.
+        // lanes hold b (two per lane); after y_k is known, b_i -= L[k... use row form: for each k descending,
+        // y_k final, then b_i -= L[k, i] * y_k for i < k  (L[k,i] = Ls[i*(TB+1)+k]).
+        double b0 = (lane < nrows) ? x[row0 + lane] : 0.0;
+        double b1 = (lane + 64 < nrows) ? x[row0 + lane + 64] : 0.0;
+        for (int k = 127; k >= 64; --k) {
+            double piv = readlane_d(b1, k - 64);
+            if (!unit_diag) piv /= Ls[k * (TB + 1) + k];
+            if (lane + 64 == k) b1 = piv;
+            if (lane + 64 < k) b1 -= Ls[(lane + 64) * (TB + 1) + k] * piv;
+            b0 -= Ls[lane * (TB + 1) + k] * piv;
+        }
+        for (int k = 63; k >= 0; --k) {
+            double piv = readlane_d(b0, k);
+            if (!unit_diag) piv /= Ls[k * (TB + 1) + k];
+            if (lane == k) b0 = piv;
+            if (lane < k) b0 -= Ls[lane * (TB + 1) + k] * piv;
+        }
+        if (lane < nrows) x[row0 + lane] = b0;
+        if (lane + 64 < nrows) x[row0 + lane + 64] = b1;
+    }
+}
+
+__global__ void k_div_diag(const double* __restrict__ L, int ld, int n, double* __restrict__ x)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] /= L[i + (size_t)i * ld];
+}
+
+void launch_trsv(const double* L, int ld, int n, double* x, bool ldlt, hipStream_t s)
+{
+    if (n <= 0) return;
+    static bool attr_set = false;
+    if (!attr_set) {
+        PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_trsv_fwd_step), hipFuncAttributeMaxDynamicSharedMemorySize, TRSV_LDS_BYTES));
+        PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_trsv_bwd_step), hipFuncAttributeMaxDynamicSharedMemorySize, TRSV_LDS_BYTES));
+        attr_set = true;
+    }
+    const int nblk = div_up(n, TB);
+    for (int j = 0; j < nblk; ++j)
+        hipLaunchKernelGGL(k_trsv_fwd_step, dim3(nblk - j), dim3(256), TRSV_LDS_BYTES, s, L, ld, n, x, j, ldlt ? 1 : 0);
+    if (ldlt) hipLaunchKernelGGL(k_div_diag, dim3(div_up(n, 256)), dim3(256), 0, s, L, ld, n, x);
+    for (int j = nblk - 1; j >= 0; --j)
+        hipLaunchKernelGGL(k_trsv_bwd_step, dim3(j + 1), dim3(256), TRSV_LDS_BYTES, s, L, ld, n, x, j, nblk, ldlt ? 1 : 0);
+    PQ_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------
+// GEMV, "N" form:  part[ks][i] = alpha * sum_{c in slice ks} M[i,c] * (scale ? scale[c] : 1) * v[c]
+// Thread per row pair, slices of the column range across blockIdx.y; partial sums are combined by
+// k_reduce_partials in a fixed order (bitwise reproducible -- the reference's clone test needs it).
+constexpr int GEMV_N_ROWS = 512;  // rows per block (256 threads x 2)
+__global__ __launch_bounds__(256) void k_gemv_n_partial(int rows, int cols, const double* __restrict__ M, int ld, const double* __restrict__ v,
+                                                        const double* __restrict__ scale, double alpha, int cols_per_slice, double* __restrict__ part)
+{
+    __shared__ double vs[256];
+    const int tid = threadIdx.x;
+    const int i = blockIdx.x * GEMV_N_ROWS + 2 * tid;
+    const int c_begin = blockIdx.y * cols_per_slice;
+    const int c_end = min(cols, c_begin + cols_per_slice);
+    double s0 = 0.0, s1 = 0.0;
+    const bool vec_ok = ((ld & 1) == 0) && ((reinterpret_cast<uintptr_t>(M) & 15) == 0);
+    for (int cb = c_begin; cb < c_end; cb += 256) {
+        const int cn = min(256, c_end - cb);
+        __syncthreads();
+        if (tid < cn) vs[tid] = alpha * v[cb + tid] * (scale ? scale[cb + tid] : 1.0);
+        __syncthreads();
+        if (i + 1 < rows && vec_ok) {
+            const double* Mp = M + i + (size_t)cb * ld;
+#pragma unroll 4
+            for (int c = 0; c < cn; ++c) {
+                const d2 mv = *reinterpret_cast<const d2*>(Mp + (size_t)c * ld);
+                s0 += mv.x * vs[c];
+                s1 += mv.y * vs[c];
+            }
+        } else if (i < rows) {
+            const double* Mp = M + i + (size_t)cb * ld;
+            for (int c = 0; c < cn; ++c) {
+                s0 += Mp[(size_t)c * ld] * vs[c];
+                if (i + 1 < rows) s1 += Mp[1 + (size_t)c * ld] * vs[c];
+            }
+        }
+    }
+    if (i < rows) part[(size_t)blockIdx.y * rows + i] = s0;
+    if (i + 1 < rows) part[(size_t)blockIdx.y * rows + i + 1] = s1;
+}
+
+// y[i] = (base ? base[i] : 0) + sum_s part[s][i]
+__global__ __launch_bounds__(256) void k_reduce_partials(int rows, int nslices, const double* __restrict__ part, const double* __restrict__ base, double* __restrict__ y)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows) return;
+    double s = base ? base[i] : 0.0;
+    for (int k = 0; k < nslices; ++k) s += part[(size_t)k * rows + i];
+    y[i] = s;
+}
+
+int gemv_n_slices(int rows, int cols)
+{
+    // enough blocks to cover the chip (256 CUs x ~4) without making slices thinner than 32 columns
+    const int row_blocks = div_up(rows, GEMV_N_ROWS);
+    int want = div_up(1024, row_blocks > 0 ? row_blocks : 1);
+    int maxs = div_up(cols, 32);
+    int sl = want < maxs ? want : maxs;
+    if (sl < 1) sl = 1;
+    return sl;
+}
+
+int launch_gemv_n_partial(int rows, int cols, const double* M, int ld, const double* v, const double* scale, double alpha, double* part, hipStream_t s)
+{
+    if (rows <= 0 || cols <= 0) return 0;
+    const int sl = gemv_n_slices(rows, cols);
+    const int cps = div_up(cols, sl);
+    const int sl_eff = div_up(cols, cps);
+    hipLaunchKernelGGL(k_gemv_n_partial, dim3(div_up(rows, GEMV_N_ROWS), sl_eff), dim3(256), 0, s, rows, cols, M, ld, v, scale, alpha, cps, part);
+    PQ_HIP(hipGetLastError());
+    return sl_eff;
+}
+
+void launch_reduce_partials(int rows, int nslices, const double* part, const double* base, double* y, hipStream_t s)
+{
+    if (rows <= 0) return;
+    hipLaunchKernelGGL(k_reduce_partials, dim3(div_up(rows, 256)), dim3(256), 0, s, rows, nslices, part, base, y);
+    PQ_HIP(hipGetLastError());
+}
+
+// GEMV, "T" form: one wave per column.  out[j] = (alpha * dot(M[:,j], v) + beta * c[j]) * (sc ? sc[j] : 1)
+__global__ __launch_bounds__(256) void k_gemv_t(int rows, int cols, const double* __restrict__ M, int ld, const double* __restrict__ v, double alpha,
+                                                double beta, const double* __restrict__ c, const double* __restrict__ sc, double* __restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= cols) return;
+    const double* Mp = M + (size_t)j * ld;
+    double s0 = 0.0, s1 = 0.0;
+    const bool vec_ok = ((ld & 1) == 0) && ((reinterpret_cast<uintptr_t>(M) & 15) == 0) && ((reinterpret_cast<uintptr_t>(v) & 15) == 0);
+    if (vec_ok) {
+        int i = 2 * lane;
+        for (; i + 1 < rows; i += 128) {
+            const d2 mv = *reinterpret_cast<const d2*>(Mp + i);
+            const d2 xv = *reinterpret_cast<const d2*>(v + i);
+            s0 += mv.x * xv.x;
+            s1 += mv.y * xv.y;
+        }
+        if (i < rows) s0 += Mp[i] * v[i];
+    } else {
+        for (int i = lane; i < rows; i += 64) s0 += Mp[i] * v[i];
+    }
+    double sacc = s0 + s1;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sacc += __shfl_down(sacc, off, 64);
+    if (lane == 0) {
+        double r = alpha * sacc;
+        if (c) r += beta * c[j];
+        if (sc) r *= sc[j];
+        out[j] = r;
+    }
+}
+
+void launch_gemv_t(int rows, int cols, const double* M, int ld, const double* v, double alpha, double beta, const double* c, const double* sc, double* out, hipStream_t s)
+{
+    if (cols <= 0) return;
+    hipLaunchKernelGGL(k_gemv_t, dim3(div_up(cols, 4)), dim3(256), 0, s, rows, cols, M, ld, v, alpha, beta, c, sc, out);
+    PQ_HIP(hipGetLastError());
+}
+
+void launch_symmetrize_upper(const double* Pu, int n, double* Pf, double* pdiag, hipStream_t s)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_symmetrize_upper, dim3(div_up(n, 32), div_up(n, 32)), dim3(256), 0, s, Pu, n, Pf, pdiag);
+    PQ_HIP(hipGetLastError());
+}
+
+// z_reg_inv = 1 / z_reg   (dense/kkt.hpp:78)
+__global__ void k_reciprocal(int n, const double* __restrict__ a, double* __restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = 1.0 / a[i];
+}
+void launch_reciprocal(int n, const double* a, double* out, hipStream_t s)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_reciprocal, dim3(div_up(n, 256)), dim3(256), 0, s, n, a, out);
+    PQ_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------
+// micro-benchmarks used by the measurement harness (peak fp64 MFMA issue rate, HBM copy rate)
+__global__ __launch_bounds__(256) void k_mfma_f64_peak(int iters, double* out)
+{
+    d4 acc[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc[q] = (d4){0.0, 0.0, 0.0, 0.0};
+    double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[q], 0, 0, 0);
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) s += acc[q][0] + acc[q][1] + acc[q][2] + acc[q][3];
+    if (s == 12345.678) out[0] = s;
+}
+__global__ __launch_bounds__(256) void k_copy_d2(size_t n2, const d2* __restrict__ in, d2* __restrict__ out)
+{
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (; i < n2; i += stride) out[i] = in[i];
+}
+
+double microbench_mfma_f64(int iters, hipStream_t s)
+{
+    DBuf<double> out(8);
+    hipEvent_t e0, e1;
+    PQ_HIP(hipEventCreate(&e0));
+    PQ_HIP(hipEventCreate(&e1));
+    const int blocks = 256 * 8;
+    hipLaunchKernelGGL(k_mfma_f64_peak, dim3(blocks), dim3(256), 0, s, 10, out.p);
+    PQ_HIP(hipStreamSynchronize(s));
+    PQ_HIP(hipEventRecord(e0, s));
+    hipLaunchKernelGGL(k_mfma_f64_peak, dim3(blocks), dim3(256), 0, s, iters, out.p);
+    PQ_HIP(hipEventRecord(e1, s));
+    PQ_HIP(hipEventSynchronize(e1));
+    float ms = 0;
+    PQ_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    const double flops = (double)blocks * 4.0 * (double)iters * 8.0 * 2.0 * 16 * 16 * 4;
+    return flops / (ms * 1e-3) * 1e-12;
+}
+
+double microbench_hbm_copy(size_t bytes, int iters, hipStream_t s)
+{
+    const size_t n2 = bytes / 16;
+    DBuf<d2> a(n2), b(n2);
+    PQ_HIP(hipMemsetAsync(a.p, 1, n2 * 16, s));
+    hipEvent_t e0, e1;
+    PQ_HIP(hipEventCreate(&e0));
+    PQ_HIP(hipEventCreate(&e1));
+    hipLaunchKernelGGL(k_copy_d2, dim3(256 * 8), dim3(256), 0, s, n2, a.p, b.p);
+    PQ_HIP(hipStreamSynchronize(s));
+    PQ_HIP(hipEventRecord(e0, s));
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(k_copy_d2, dim3(256 * 8), dim3(256), 0, s, n2, a.p, b.p);
+    PQ_HIP(hipEventRecord(e1, s));
+    PQ_HIP(hipEventSynchronize(e1));
+    float ms = 0;
+    PQ_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return 2.0 * (double)n2 * 16.0 * iters / (ms * 1e-3) * 1e-9;
+}
+
+}  // namespace dense
+}  // namespace pq

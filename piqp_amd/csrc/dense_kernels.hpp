@@ -1,0 +1,44 @@
+// piqp_amd/csrc/dense_kernels.hpp -- launchers of the dense-path gfx950 kernels (see dense_kernels.hip)
+#pragma once
+
+#include "common.hpp"
+
+namespace pq {
+namespace dense {
+
+enum { EPI_ASSEMBLE = 0, EPI_SUBTRACT = 1, EPI_STORE = 2 };
+
+struct SyrkArgs {
+    int n = 0;     // C is n x n, lower triangle written
+    int kdim = 0;  // inner dimension
+    const double* A = nullptr; int lda = 0;  // row operand   (n x kdim, column-major)
+    const double* B = nullptr; int ldb = 0;  // column operand (n x kdim, column-major)
+    const double* w = nullptr;               // optional per-k scale applied to B
+    double* C = nullptr; int ldc = 0;
+    // EPI_ASSEMBLE extras (dense/kkt.hpp:144-151)
+    const double* Pfull = nullptr; int ldp = 0;
+    const double* x_reg = nullptr;
+    const double* ATA = nullptr; int ldata = 0;
+    double dinv = 0.0;
+    int unaligned = 0;  // set by the launcher
+};
+
+void launch_syrk(int epi, const SyrkArgs& args, hipStream_t s);
+void launch_assemble_no_g(int n, const double* Pf, const double* x_reg, const double* ATA, double dinv, double* C, hipStream_t s);
+void launch_potrf_diag(bool ldlt, double* A, int lda, int nb, int kglobal, int* info, hipStream_t s);
+void launch_trsm_panel(bool ldlt, double* A, int lda, int k0, int nb, int n, hipStream_t s);
+void launch_extract_diag(const double* A, int lda, int k0, int nb, double* d, hipStream_t s);
+void launch_trsv(const double* L, int ld, int n, double* x, bool ldlt, hipStream_t s);
+int gemv_n_slices(int rows, int cols);
+int launch_gemv_n_partial(int rows, int cols, const double* M, int ld, const double* v, const double* scale, double alpha, double* part, hipStream_t s);
+void launch_reduce_partials(int rows, int nslices, const double* part, const double* base, double* y, hipStream_t s);
+void launch_gemv_t(int rows, int cols, const double* M, int ld, const double* v, double alpha, double beta, const double* c, const double* sc, double* out, hipStream_t s);
+void launch_symmetrize_upper(const double* Pu, int n, double* Pf, double* pdiag, hipStream_t s);
+void launch_reciprocal(int n, const double* a, double* out, hipStream_t s);
+double microbench_mfma_f64(int iters, hipStream_t s);
+double microbench_hbm_copy(size_t bytes, int iters, hipStream_t s);
+
+constexpr int FACTOR_NB = 128;  // panel width of the blocked factorisation
+
+}  // namespace dense
+}  // namespace pq

@@ -1,0 +1,265 @@
+// piqp_amd/csrc/dense_kkt.cpp -- device-resident replacement of piqp::dense::KKT<T>
+// (reference include/piqp/dense/kkt.hpp:24-180).  Same members, same call sequence; the bodies
+// launch the gfx950 kernels of dense_kernels.hip on the handle's stream.
+//
+//   reference member           here
+//   m_delta                    delta_
+//   m_z_reg_inv                z_reg_inv_ (device, m)
+//   kkt_mat + llt's copy       fac_ (device, n x n; assembly writes the lower triangle straight into the
+//                              buffer that is then factored in place -- Eigen::LLT::compute makes that copy
+//                              internally, dense/kkt.hpp:82)
+//   AT_A                       ATA_ (device, n x n lower, only if p > 0)
+//   W_delta_inv_G              not materialised: diag(z_reg_inv) is applied to the column operand while it is
+//                              staged into LDS (saves the 134 MB write + read at n = m = 4096)
+//   data.P_utri/AT/GT          Pfull_ (symmetric completion), AT_, GT_ (device copies, refreshed by update_data)
+#include <stdexcept>
+
+#include "dense_kernels.hpp"
+#include "kkt_solver_base.hpp"
+
+namespace pq {
+
+namespace {
+
+class DenseKKT final : public KKTSolverBase {
+public:
+    DenseKKT(const pq_dense_data* d, int kkt_solver, int device) : dev_(device), n_(d->n), p_(d->p), m_(d->m), ldlt_(kkt_solver == PQ_DENSE_LDLT_NO_PIVOT)
+    {
+        if (n_ <= 0 || p_ < 0 || m_ < 0) throw std::runtime_error("dense KKT: bad dimensions");
+        PQ_HIP(hipSetDevice(dev_));
+        PQ_HIP(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
+        alloc();
+        upload(d);
+    }
+
+    ~DenseKKT() override
+    {
+        (void)hipSetDevice(dev_);
+        if (st_) { (void)hipStreamSynchronize(st_); (void)hipStreamDestroy(st_); }
+    }
+
+    // dense/kkt.hpp:57-60
+    KKTSolverBase* clone() const override
+    {
+        PQ_HIP(hipSetDevice(dev_));
+        PQ_HIP(hipStreamSynchronize(st_));
+        DenseKKT* k = new DenseKKT(*this, 0);
+        return k;
+    }
+
+    // dense/kkt.hpp:62-71.  The reference backend re-reads data.P_utri/AT/GT at every factor and solve, and
+    // Solver::update rewrites them (unscale -> rescale) even when no matrix is passed, so every update_data
+    // call refreshes all three device copies; AT_A is rebuilt as in :66-69.
+    void update_data_dense(const pq_dense_data* d, int options) override
+    {
+        (void)options;
+        if (d->n != n_ || d->p != p_ || d->m != m_) throw std::runtime_error("update_data: dimension mismatch");
+        PQ_HIP(hipSetDevice(dev_));
+        upload(d);
+    }
+
+    // dense/kkt.hpp:73-84
+    bool update_scalings_and_factor(double delta, const double* x_reg, const double* z_reg) override
+    {
+        PQ_HIP(hipSetDevice(dev_));
+        delta_ = delta;
+        dense::launch_reciprocal(m_, z_reg, z_reg_inv_.p, st_);
+        PQ_HIP(hipMemcpyAsync(x_reg_last_.p, x_reg, sizeof(double) * n_, hipMemcpyDeviceToDevice, st_));
+        int t0 = prof_.begin(0, st_);
+        update_kkt(x_reg_last_.p, fac_.p);
+        prof_.end(0, t0, st_);
+        int t1 = prof_.begin(1, st_);
+        launch_factor_panels();
+        prof_.end(1, t1, st_);
+        return factor_status();
+    }
+
+    // dense/kkt.hpp:86-105
+    void solve(const double* rhs_x, const double* rhs_y, const double* rhs_z, double* lhs_x, double* lhs_y, double* lhs_z) override
+    {
+        PQ_HIP(hipSetDevice(dev_));
+        const int tk = prof_.begin(2, st_);
+        const double delta_inv = 1.0 / delta_;
+        // lhs_x = rhs_x + GT * (z_reg_inv o rhs_z) + delta_inv * AT * rhs_y
+        int nsl = 0;
+        if (m_ > 0) nsl += dense::launch_gemv_n_partial(n_, m_, GT_.p, n_, rhs_z, z_reg_inv_.p, 1.0, part_.p + (size_t)nsl * n_, st_);
+        if (p_ > 0) nsl += dense::launch_gemv_n_partial(n_, p_, AT_.p, n_, rhs_y, nullptr, delta_inv, part_.p + (size_t)nsl * n_, st_);
+        dense::launch_reduce_partials(n_, nsl, part_.p, rhs_x, lhs_x, st_);
+        // solve_ldlt_in_place: llt.solveInPlace(lhs_x)
+        dense::launch_trsv(fac_.p, n_, n_, lhs_x, ldlt_, st_);
+        // lhs_y = delta_inv * AT^T lhs_x - delta_inv * rhs_y
+        if (p_ > 0) dense::launch_gemv_t(n_, p_, AT_.p, n_, lhs_x, delta_inv, -delta_inv, rhs_y, nullptr, lhs_y, st_);
+        // lhs_z = (GT^T lhs_x - rhs_z) o z_reg_inv
+        if (m_ > 0) dense::launch_gemv_t(n_, m_, GT_.p, n_, lhs_x, 1.0, -1.0, rhs_z, z_reg_inv_.p, lhs_z, st_);
+        prof_.end(2, tk, st_);
+    }
+
+    // dense/kkt.hpp:108-114
+    void eval_P_x(double alpha, const double* x, double* z) override
+    {
+        PQ_HIP(hipSetDevice(dev_));
+        dense::launch_gemv_t(n_, n_, Pfull_.p, n_, x, alpha, 0.0, nullptr, nullptr, z, st_);
+    }
+
+    // dense/kkt.hpp:117-123
+    void eval_A_xn_and_AT_xt(double alpha_n, double alpha_t, const double* xn, const double* xt, double* zn, double* zt) override
+    {
+        PQ_HIP(hipSetDevice(dev_));
+        if (p_ > 0) dense::launch_gemv_t(n_, p_, AT_.p, n_, xn, alpha_n, 0.0, nullptr, nullptr, zn, st_);
+        int nsl = 0;
+        if (p_ > 0) nsl = dense::launch_gemv_n_partial(n_, p_, AT_.p, n_, xt, nullptr, alpha_t, part_.p, st_);
+        dense::launch_reduce_partials(n_, nsl, part_.p, nullptr, zt, st_);
+    }
+
+    // dense/kkt.hpp:126-132
+    void eval_G_xn_and_GT_xt(double alpha_n, double alpha_t, const double* xn, const double* xt, double* zn, double* zt) override
+    {
+        PQ_HIP(hipSetDevice(dev_));
+        if (m_ > 0) dense::launch_gemv_t(n_, m_, GT_.p, n_, xn, alpha_n, 0.0, nullptr, nullptr, zn, st_);
+        int nsl = 0;
+        if (m_ > 0) nsl = dense::launch_gemv_n_partial(n_, m_, GT_.p, n_, xt, nullptr, alpha_t, part_.p, st_);
+        dense::launch_reduce_partials(n_, nsl, part_.p, nullptr, zt, st_);
+    }
+
+    void print_info() override {}
+
+    const double* P_diag_device() const override { return Pdiag_.p; }
+    int n() const override { return n_; }
+    int p() const override { return p_; }
+    int m() const override { return m_; }
+    hipStream_t stream() const override { return st_; }
+    int device() const override { return dev_; }
+
+    // dense/kkt.hpp:134 internal_kkt_mat(): re-assembled on demand into a scratch buffer (test hook only)
+    void internal_kkt_mat(double* out_host) override
+    {
+        PQ_HIP(hipSetDevice(dev_));
+        DBuf<double> tmp((size_t)n_ * n_);
+        tmp.zero(st_);
+        update_kkt(x_reg_last_.p, tmp.p);
+        PQ_HIP(hipMemcpyAsync(out_host, tmp.p, sizeof(double) * (size_t)n_ * n_, hipMemcpyDeviceToHost, st_));
+        PQ_HIP(hipStreamSynchronize(st_));
+    }
+    void set_profiling(bool on) override { prof_.enabled = on; }
+    void get_profile(int stage, double* total_ms, int* count) override
+    {
+        if (stage < 0 || stage >= StageProfiler::NSTAGE) throw std::runtime_error("bad stage");
+        PQ_HIP(hipSetDevice(dev_));
+        prof_.collect(stage, st_, total_ms, count);
+    }
+    void internal_factor(double* out_host) override
+    {
+        PQ_HIP(hipSetDevice(dev_));
+        PQ_HIP(hipMemcpyAsync(out_host, fac_.p, sizeof(double) * (size_t)n_ * n_, hipMemcpyDeviceToHost, st_));
+        PQ_HIP(hipStreamSynchronize(st_));
+    }
+
+private:
+    // copy-construction for clone(): same device, fresh stream, deep copies of all state
+    DenseKKT(const DenseKKT& o, int) : dev_(o.dev_), n_(o.n_), p_(o.p_), m_(o.m_), ldlt_(o.ldlt_), delta_(o.delta_)
+    {
+        PQ_HIP(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
+        alloc();
+        auto cp = [&](DBuf<double>& dst, const DBuf<double>& src) { if (src.n) PQ_HIP(hipMemcpyAsync(dst.p, src.p, src.bytes(), hipMemcpyDeviceToDevice, st_)); };
+        cp(Pfull_, o.Pfull_); cp(Pdiag_, o.Pdiag_); cp(AT_, o.AT_); cp(GT_, o.GT_); cp(ATA_, o.ATA_); cp(fac_, o.fac_);
+        cp(z_reg_inv_, o.z_reg_inv_); cp(x_reg_last_, o.x_reg_last_);
+        PQ_HIP(hipStreamSynchronize(st_));
+    }
+
+    void alloc()
+    {
+        const size_t nn = (size_t)n_ * n_;
+        Pfull_.alloc(nn); Pdiag_.alloc(n_);
+        AT_.alloc((size_t)n_ * p_); GT_.alloc((size_t)n_ * m_);
+        if (p_ > 0) ATA_.alloc(nn);
+        fac_.alloc(nn);
+        z_reg_inv_.alloc(m_); x_reg_last_.alloc(n_); dvec_.alloc(dense::FACTOR_NB);
+        const int sl = dense::gemv_n_slices(n_, m_ > 0 ? m_ : 1) + dense::gemv_n_slices(n_, p_ > 0 ? p_ : 1) + dense::gemv_n_slices(n_, n_);
+        part_.alloc((size_t)sl * n_);
+        info_.alloc(1);
+        info_h_.alloc(1);
+        x_reg_last_.zero(st_);
+        fac_.zero(st_);
+    }
+
+    void upload(const pq_dense_data* d)
+    {
+        const size_t nn = (size_t)n_ * n_;
+        // P_utri staged through the factor buffer, completed to the symmetric Pfull_ + diag(P)
+        copy_in(fac_.p, d->P_utri, nn * sizeof(double), d->mem, st_);
+        dense::launch_symmetrize_upper(fac_.p, n_, Pfull_.p, Pdiag_.p, st_);
+        copy_in(AT_.p, d->AT, (size_t)n_ * p_ * sizeof(double), d->mem, st_);
+        copy_in(GT_.p, d->GT, (size_t)n_ * m_ * sizeof(double), d->mem, st_);
+        if (p_ > 0) {
+            // dense/kkt.hpp:53 AT_A.lower = AT * AT^T
+            dense::SyrkArgs a;
+            a.n = n_; a.kdim = p_; a.A = AT_.p; a.lda = n_; a.B = AT_.p; a.ldb = n_; a.C = ATA_.p; a.ldc = n_;
+            dense::launch_syrk(dense::EPI_STORE, a, st_);
+        }
+        PQ_HIP(hipStreamSynchronize(st_));  // host source buffers may be released by the caller after return
+    }
+
+    // dense/kkt.hpp:140-160 into the lower triangle of `out`
+    void update_kkt(const double* x_reg, double* out)
+    {
+        const double dinv = 1.0 / delta_;
+        if (m_ > 0) {
+            dense::SyrkArgs a;
+            a.n = n_; a.kdim = m_; a.A = GT_.p; a.lda = n_; a.B = GT_.p; a.ldb = n_; a.w = z_reg_inv_.p; a.C = out; a.ldc = n_;
+            a.Pfull = Pfull_.p; a.ldp = n_; a.x_reg = x_reg; a.ATA = p_ > 0 ? ATA_.p : nullptr; a.ldata = n_; a.dinv = dinv;
+            dense::launch_syrk(dense::EPI_ASSEMBLE, a, st_);
+        } else {
+            dense::launch_assemble_no_g(n_, Pfull_.p, x_reg, p_ > 0 ? ATA_.p : nullptr, dinv, out, st_);
+        }
+    }
+
+    // blocked right-looking factorisation of the lower triangle of fac_ (panel width 128):
+    // Eigen::LLT::compute (dense/kkt.hpp:82) or LDLTNoPivot::compute (dense/ldlt_no_pivot.hpp:313-354)
+    void launch_factor_panels()
+    {
+        PQ_HIP(hipMemsetAsync(info_.p, 0xFF, sizeof(int), st_));  // -1
+        const int NB = dense::FACTOR_NB;
+        for (int k = 0; k < n_; k += NB) {
+            const int nb = (n_ - k < NB) ? n_ - k : NB;
+            const int rs = n_ - k - nb;
+            double* A11 = fac_.p + k + (size_t)k * n_;
+            dense::launch_potrf_diag(ldlt_, A11, n_, nb, k, info_.p, st_);
+            if (rs > 0) {
+                dense::launch_trsm_panel(ldlt_, fac_.p, n_, k, nb, n_, st_);
+                dense::SyrkArgs a;
+                a.n = rs; a.kdim = nb;
+                a.A = fac_.p + (k + nb) + (size_t)k * n_; a.lda = n_;
+                a.B = a.A; a.ldb = n_;
+                if (ldlt_) { dense::launch_extract_diag(fac_.p, n_, k, nb, dvec_.p, st_); a.w = dvec_.p; }
+                a.C = fac_.p + (k + nb) + (size_t)(k + nb) * n_; a.ldc = n_;
+                dense::launch_syrk(dense::EPI_SUBTRACT, a, st_);
+            }
+        }
+    }
+    // llt.info() == Success (dense/kkt.hpp:83): one 4-byte read-back per factor call
+    bool factor_status()
+    {
+        PQ_HIP(hipMemcpyAsync(info_h_.p, info_.p, sizeof(int), hipMemcpyDeviceToHost, st_));
+        PQ_HIP(hipStreamSynchronize(st_));
+        return info_h_.p[0] == -1;
+    }
+
+    int dev_, n_, p_, m_;
+    bool ldlt_;
+    double delta_ = 1.0;
+    hipStream_t st_ = nullptr;
+    DBuf<double> Pfull_, Pdiag_, AT_, GT_, ATA_, fac_, z_reg_inv_, x_reg_last_, dvec_, part_;
+    DBuf<int> info_;
+    HBuf<int> info_h_;
+    StageProfiler prof_;
+};
+
+}  // namespace
+
+KKTSolverBase* make_dense_kkt(const pq_dense_data* data, int kkt_solver, int device)
+{
+    if (kkt_solver != PQ_DENSE_CHOLESKY && kkt_solver != PQ_DENSE_LDLT_NO_PIVOT) throw std::runtime_error("kkt solver not supported");
+    return new DenseKKT(data, kkt_solver, device);
+}
+
+}  // namespace pq

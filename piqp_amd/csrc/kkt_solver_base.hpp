@@ -1,0 +1,52 @@
+// piqp_amd/csrc/kkt_solver_base.hpp
+// Host-side mirror of piqp::KKTSolverBase<T,I,MatrixType> (reference include/piqp/kkt_solver_base.hpp:20-44)
+// for device-resident data: same seven operations, same argument meaning, same bool/void error
+// convention.  All vector arguments are DEVICE pointers on the backend's stream; the C-ABI layer
+// (capi.cpp) stages host vectors when the caller uses PQ_MEM_HOST.
+#pragma once
+
+#include <stdexcept>
+
+#include "common.hpp"
+
+namespace pq {
+
+class KKTSolverBase {
+public:
+    virtual ~KKTSolverBase() = default;
+
+    // kkt_solver_base.hpp:28
+    virtual KKTSolverBase* clone() const = 0;
+    // kkt_solver_base.hpp:30 -- `data` is the C-ABI descriptor (host or device arrays per data->mem)
+    virtual void update_data_dense(const pq_dense_data* data, int options) { (void)data; (void)options; throw std::runtime_error("update_data: wrong matrix type"); }
+    virtual void update_data_sparse(const pq_sparse_data* data, int options) { (void)data; (void)options; throw std::runtime_error("update_data: wrong matrix type"); }
+    // kkt_solver_base.hpp:32 -- x_reg[n], z_reg[m] device pointers, consumed during the call
+    virtual bool update_scalings_and_factor(double delta, const double* x_reg, const double* z_reg) = 0;
+    // kkt_solver_base.hpp:34
+    virtual void solve(const double* rhs_x, const double* rhs_y, const double* rhs_z, double* lhs_x, double* lhs_y, double* lhs_z) = 0;
+    // kkt_solver_base.hpp:37,39,41
+    virtual void eval_P_x(double alpha, const double* x, double* z) = 0;
+    virtual void eval_A_xn_and_AT_xt(double alpha_n, double alpha_t, const double* xn, const double* xt, double* zn, double* zt) = 0;
+    virtual void eval_G_xn_and_GT_xt(double alpha_n, double alpha_t, const double* xn, const double* xt, double* zn, double* zt) = 0;
+    // kkt_solver_base.hpp:43
+    virtual void print_info() {}
+
+    // device-side extras the KKTSystem needs (the reference reads these straight out of `data`)
+    virtual const double* P_diag_device() const = 0;  // diag(P) for the static regularisation (kkt_system.hpp:198)
+    virtual int n() const = 0;
+    virtual int p() const = 0;
+    virtual int m() const = 0;
+    virtual hipStream_t stream() const = 0;
+    virtual int device() const = 0;
+    // test hooks (dense/kkt.hpp:134): copy n*n doubles to host
+    virtual void internal_kkt_mat(double* out_host) { (void)out_host; throw std::runtime_error("internal_kkt_mat: dense only"); }
+    virtual void internal_factor(double* out_host) { (void)out_host; throw std::runtime_error("internal_factor: dense only"); }
+    // measurement hooks (hipEvent brackets on the backend's stream)
+    virtual void set_profiling(bool on) { (void)on; }
+    virtual void get_profile(int stage, double* total_ms, int* count) { (void)stage; *total_ms = 0.0; *count = 0; }
+};
+
+KKTSolverBase* make_dense_kkt(const pq_dense_data* data, int kkt_solver, int device);
+KKTSolverBase* make_sparse_kkt(const pq_sparse_data* data, int kkt_solver, int device);
+
+}  // namespace pq

@@ -1,0 +1,348 @@
+"""Host-side mirror of the reference's KKT plugin surface over the C-ABI.
+
+Class / method names and argument meaning follow PIQP v0.6.2:
+  Data            dense::Data<T>                      include/piqp/dense/data.hpp:22-208
+  DenseKKT        dense::KKT<T> : KKTSolverBase       include/piqp/dense/kkt.hpp, kkt_solver_base.hpp:20-44
+  KKTSystem       piqp::KKTSystem<T,I,PIQP_DENSE>     include/piqp/kkt_system.hpp
+  Variables       piqp::Variables<T>                  include/piqp/variables.hpp
+Vectors may be numpy arrays (PQ_MEM_HOST: staged by the library) or torch CUDA tensors
+(PQ_MEM_DEVICE: used in place in HBM, asynchronous on the handle's stream).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import VAR_NAMES, check
+
+PIQP_INF = 1e30  # fwd.hpp:54
+DENSE_CHOLESKY, SPARSE_LDLT, SPARSE_LDLT_EQ_COND, SPARSE_LDLT_INEQ_COND, SPARSE_LDLT_COND, SPARSE_MULTISTAGE = range(6)
+DENSE_LDLT_NO_PIVOT = 16
+KKT_UPDATE_NONE, KKT_UPDATE_P, KKT_UPDATE_A, KKT_UPDATE_G = 0, 1, 2, 4
+MEM_HOST, MEM_DEVICE = 0, 1
+
+
+def _is_torch(a):
+    return type(a).__module__.startswith("torch")
+
+
+def _ptr(a):
+    """raw address of a numpy array / torch tensor (None -> NULL)"""
+    if a is None:
+        return None
+    if _is_torch(a):
+        return a.data_ptr()
+    return a.ctypes.data
+
+
+def _f64(a, order="C"):
+    if a is None:
+        return None
+    if _is_torch(a):
+        return a
+    return np.require(a, dtype=np.float64, requirements=["F_CONTIGUOUS" if order == "F" else "C_CONTIGUOUS", "ALIGNED"])
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def var_sizes(n, p, m):
+    return dict(x=n, y=p, z_l=m, z_u=m, z_bl=n, z_bu=n, s_l=m, s_u=m, s_bl=n, s_bu=n)
+
+
+class Variables(dict):
+    """piqp::Variables<T> as a dict of ten numpy vectors (variables.hpp:19-105)."""
+
+    @classmethod
+    def zeros(cls, n, p, m, fill=0.0):
+        return cls({k: np.full(sz, fill, dtype=np.float64) for k, sz in var_sizes(n, p, m).items()})
+
+    def to_struct(self):
+        s = _lib.Vars()
+        for k in VAR_NAMES:
+            setattr(s, k, _ptr(self[k]))
+        return s
+
+
+class Data:
+    """dense::Data<T>: stores the upper triangle of P and the TRANSPOSED A and G, plus the finite-bound
+    index lists (dense/data.hpp:53-208).  All arithmetic here is setup-time host logic."""
+
+    def __init__(self, P, c, A=None, b=None, G=None, h_l=None, h_u=None, x_l=None, x_u=None):
+        P = np.asarray(P, dtype=np.float64)
+        n = P.shape[0]
+        self.n = n
+        self.p = 0 if A is None else np.asarray(A).shape[0]
+        self.m = 0 if G is None else np.asarray(G).shape[0]
+        self.P_utri = np.asfortranarray(np.triu(P))
+        self.AT = np.asfortranarray(np.asarray(A, dtype=np.float64).T) if self.p else np.zeros((n, 0), order="F")
+        self.GT = np.asfortranarray(np.asarray(G, dtype=np.float64).T) if self.m else np.zeros((n, 0), order="F")
+        self.c = np.array(c, dtype=np.float64)
+        self.b = np.array(b, dtype=np.float64) if self.p else np.zeros(0)
+        self.h_l = np.zeros(self.m); self.h_u = np.zeros(self.m)
+        self.x_l = np.zeros(n); self.x_u = np.zeros(n)
+        self.x_b_scaling = np.ones(n)
+        self.set_h_l(h_l); self.set_h_u(h_u); self.disable_inf_constraints()
+        self.set_x_l(x_l); self.set_x_u(x_u)
+
+    # dense/data.hpp:98-142
+    def set_h_l(self, h_l):
+        if h_l is None:
+            self.h_l[:] = -PIQP_INF
+            self.h_l_idx = np.zeros(0, np.int32)
+        else:
+            h = np.asarray(h_l, dtype=np.float64)
+            fin = h > -PIQP_INF
+            self.h_l = np.where(fin, h, -PIQP_INF)
+            self.h_l_idx = np.nonzero(fin)[0].astype(np.int32)
+        self.n_h_l = len(self.h_l_idx)
+
+    def set_h_u(self, h_u):
+        if h_u is None:
+            self.h_u[:] = PIQP_INF
+            self.h_u_idx = np.zeros(0, np.int32)
+        else:
+            h = np.asarray(h_u, dtype=np.float64)
+            fin = h < PIQP_INF
+            self.h_u = np.where(fin, h, PIQP_INF)
+            self.h_u_idx = np.nonzero(fin)[0].astype(np.int32)
+        self.n_h_u = len(self.h_u_idx)
+
+    # dense/data.hpp:144-169
+    def disable_inf_constraints(self):
+        both = (self.h_l <= -PIQP_INF) & (self.h_u >= PIQP_INF)
+        if both.any():
+            self.GT[:, both] = 0.0
+            self.h_l[both] = -1.0
+            self.h_u[both] = 1.0
+            self.set_h_l(self.h_l.copy()); self.set_h_u(self.h_u.copy())
+
+    # dense/data.hpp:171-207 (finite bounds compressed into the head of x_l / x_u)
+    def set_x_l(self, x_l):
+        self.x_l_idx = np.zeros(0, np.int32)
+        if x_l is not None:
+            x = np.asarray(x_l, dtype=np.float64)
+            fin = x > -PIQP_INF
+            self.x_l_idx = np.nonzero(fin)[0].astype(np.int32)
+            self.x_l[: fin.sum()] = x[fin]
+        self.n_x_l = len(self.x_l_idx)
+
+    def set_x_u(self, x_u):
+        self.x_u_idx = np.zeros(0, np.int32)
+        if x_u is not None:
+            x = np.asarray(x_u, dtype=np.float64)
+            fin = x < PIQP_INF
+            self.x_u_idx = np.nonzero(fin)[0].astype(np.int32)
+            self.x_u[: fin.sum()] = x[fin]
+        self.n_x_u = len(self.x_u_idx)
+
+    def descriptor(self):
+        """pq_dense_data view of this object (host memory); keeps the arrays alive on self"""
+        d = _lib.DenseData()
+        d.n, d.p, d.m = self.n, self.p, self.m
+        self._keep = [np.asfortranarray(self.P_utri, dtype=np.float64), np.asfortranarray(self.AT, dtype=np.float64),
+                      np.asfortranarray(self.GT, dtype=np.float64), _i32(self.h_l_idx), _i32(self.h_u_idx),
+                      _i32(self.x_l_idx), _i32(self.x_u_idx), np.ascontiguousarray(self.x_b_scaling, dtype=np.float64)]
+        d.P_utri, d.AT, d.GT = (a.ctypes.data for a in self._keep[:3])
+        d.n_h_l, d.n_h_u, d.n_x_l, d.n_x_u = self.n_h_l, self.n_h_u, self.n_x_l, self.n_x_u
+        d.h_l_idx, d.h_u_idx, d.x_l_idx, d.x_u_idx = (a.ctypes.data for a in self._keep[3:7])
+        d.x_b_scaling = self._keep[7].ctypes.data
+        d.mem = MEM_HOST
+        return d
+
+
+class _Handle:
+    _destroy = None
+
+    def __del__(self):
+        h = getattr(self, "h", None)
+        if h and getattr(self, "_owned", True):
+            getattr(self.L, self._destroy)(h)
+            self.h = None
+
+
+class DenseKKT(_Handle):
+    """dense::KKT<T> (dense/kkt.hpp) behind pq_kkt_*.  Same seven operations as KKTSolverBase."""
+    _destroy = "pq_kkt_destroy"
+
+    def __init__(self, data, kkt_solver=DENSE_CHOLESKY, device=0, _h=None, _owned=True):
+        self.L = _lib.load()
+        self._owned = _owned
+        if _h is not None:
+            self.h = _h
+        else:
+            h = C.c_void_p()
+            desc = data.descriptor()
+            check(self.L.pq_kkt_create_dense(C.byref(h), C.byref(desc), kkt_solver, device), "pq_kkt_create_dense")
+            self.h = h
+        n, p, m = C.c_int(), C.c_int(), C.c_int()
+        self.L.pq_kkt_dims(self.h, C.byref(n), C.byref(p), C.byref(m))
+        self.n, self.p, self.m = n.value, p.value, m.value
+        self._mode = MEM_HOST
+
+    def _set_mode(self, *arrays):
+        mode = MEM_DEVICE if any(_is_torch(a) for a in arrays if a is not None) else MEM_HOST
+        if mode != self._mode:
+            check(self.L.pq_kkt_set_pointer_mode(self.h, mode))
+            self._mode = mode
+        return mode
+
+    def _out(self, like, size):
+        if _is_torch(like):
+            import torch
+            return torch.empty(size, dtype=torch.float64, device=like.device)
+        return np.empty(size, dtype=np.float64)
+
+    def clone(self):
+        h = C.c_void_p()
+        check(self.L.pq_kkt_clone(self.h, C.byref(h)), "pq_kkt_clone")
+        return DenseKKT(None, _h=h)
+
+    def update_data(self, data, options):
+        desc = data.descriptor()
+        check(self.L.pq_kkt_update_data_dense(self.h, C.byref(desc), options), "update_data")
+
+    def update_scalings_and_factor(self, delta, x_reg, z_reg):
+        x_reg, z_reg = _f64(x_reg), _f64(z_reg)
+        self._set_mode(x_reg, z_reg)
+        return bool(check(self.L.pq_kkt_update_scalings_and_factor(self.h, float(delta), _ptr(x_reg), _ptr(z_reg)), "factor"))
+
+    def solve(self, rhs_x, rhs_y, rhs_z):
+        rhs_x, rhs_y, rhs_z = _f64(rhs_x), _f64(rhs_y), _f64(rhs_z)
+        self._set_mode(rhs_x, rhs_y, rhs_z)
+        lx, ly, lz = self._out(rhs_x, self.n), self._out(rhs_x, self.p), self._out(rhs_x, self.m)
+        check(self.L.pq_kkt_solve(self.h, _ptr(rhs_x), _ptr(rhs_y), _ptr(rhs_z), _ptr(lx), _ptr(ly), _ptr(lz)), "solve")
+        return lx, ly, lz
+
+    def eval_P_x(self, alpha, x):
+        x = _f64(x)
+        self._set_mode(x)
+        z = self._out(x, self.n)
+        check(self.L.pq_kkt_eval_P_x(self.h, float(alpha), _ptr(x), _ptr(z)), "eval_P_x")
+        return z
+
+    def eval_A_xn_and_AT_xt(self, alpha_n, alpha_t, xn, xt):
+        xn, xt = _f64(xn), _f64(xt)
+        self._set_mode(xn, xt)
+        zn, zt = self._out(xn, self.p), self._out(xn, self.n)
+        check(self.L.pq_kkt_eval_A_xn_and_AT_xt(self.h, float(alpha_n), float(alpha_t), _ptr(xn), _ptr(xt), _ptr(zn), _ptr(zt)))
+        return zn, zt
+
+    def eval_G_xn_and_GT_xt(self, alpha_n, alpha_t, xn, xt):
+        xn, xt = _f64(xn), _f64(xt)
+        self._set_mode(xn, xt)
+        zn, zt = self._out(xn, self.m), self._out(xn, self.n)
+        check(self.L.pq_kkt_eval_G_xn_and_GT_xt(self.h, float(alpha_n), float(alpha_t), _ptr(xn), _ptr(xt), _ptr(zn), _ptr(zt)))
+        return zn, zt
+
+    def synchronize(self):
+        check(self.L.pq_kkt_synchronize(self.h))
+
+    def stream(self):
+        return self.L.pq_kkt_stream(self.h)
+
+    def set_profiling(self, on=True):
+        check(self.L.pq_kkt_set_profiling(self.h, int(on)))
+
+    def get_profile(self, stage):
+        ms, cnt = C.c_double(), C.c_int()
+        check(self.L.pq_kkt_get_profile(self.h, stage, C.byref(ms), C.byref(cnt)))
+        return ms.value, cnt.value
+
+    def internal_kkt_mat(self):
+        out = np.zeros((self.n, self.n), order="F")
+        check(self.L.pq_kkt_internal_kkt_mat(self.h, out.ctypes.data))
+        return out
+
+    def internal_factor(self):
+        out = np.zeros((self.n, self.n), order="F")
+        check(self.L.pq_kkt_internal_factor(self.h, out.ctypes.data))
+        return out
+
+
+def default_settings(**kw):
+    s = _lib.Settings()
+    _lib.load().pq_settings_default(C.byref(s))
+    for k, v in kw.items():
+        setattr(s, k, v)
+    return s
+
+
+class KKTSystem(_Handle):
+    """piqp::KKTSystem (kkt_system.hpp) behind pq_kktsys_*; Variables are dicts of numpy arrays or torch CUDA tensors."""
+    _destroy = "pq_kktsys_destroy"
+
+    def __init__(self, data, settings=None, device=0, _h=None):
+        self.L = _lib.load()
+        self.settings = settings or default_settings()
+        if _h is not None:
+            self.h = _h
+        else:
+            h = C.c_void_p()
+            desc = data.descriptor()
+            check(self.L.pq_kktsys_create_dense(C.byref(h), C.byref(desc), C.byref(self.settings), device), "pq_kktsys_create_dense")
+            self.h = h
+        self.n, self.p, self.m = (data.n, data.p, data.m) if data is not None else (None, None, None)
+        self._mode = MEM_HOST
+
+    def clone(self):
+        h = C.c_void_p()
+        check(self.L.pq_kktsys_clone(self.h, C.byref(h)))
+        k = KKTSystem(None, self.settings, _h=h)
+        k.n, k.p, k.m = self.n, self.p, self.m
+        return k
+
+    def backend(self):
+        return DenseKKT(None, _h=self.L.pq_kktsys_backend(self.h), _owned=False)
+
+    def _set_mode(self, v):
+        mode = MEM_DEVICE if any(_is_torch(a) for a in v.values()) else MEM_HOST
+        if mode != self._mode:
+            check(self.L.pq_kktsys_set_pointer_mode(self.h, mode))
+            self._mode = mode
+
+    def update_data(self, data, options):
+        desc = data.descriptor()
+        check(self.L.pq_kktsys_update_data_dense(self.h, C.byref(desc), options))
+
+    def update_scalings_and_factor(self, iterative_refinement, rho, delta, vars_):
+        self._set_mode(vars_)
+        vs = Variables.to_struct(vars_)
+        return bool(check(self.L.pq_kktsys_update_scalings_and_factor(self.h, int(iterative_refinement), float(rho), float(delta), C.byref(vs))))
+
+    def solve(self, rhs, lhs=None):
+        self._set_mode(rhs)
+        if lhs is None:
+            if self._mode == MEM_DEVICE:
+                import torch
+                lhs = {k: torch.zeros(sz, dtype=torch.float64, device=rhs["x"].device) for k, sz in var_sizes(self.n, self.p, self.m).items()}
+            else:
+                lhs = Variables.zeros(self.n, self.p, self.m)
+        rs, ls = Variables.to_struct(rhs), Variables.to_struct(lhs)
+        ok = bool(check(self.L.pq_kktsys_solve(self.h, C.byref(rs), C.byref(ls))))
+        return ok, lhs
+
+    def mul(self, lhs):
+        self._set_mode(lhs)
+        if self._mode == MEM_DEVICE:
+            import torch
+            rhs = {k: torch.zeros(sz, dtype=torch.float64, device=lhs["x"].device) for k, sz in var_sizes(self.n, self.p, self.m).items()}
+        else:
+            rhs = Variables.zeros(self.n, self.p, self.m)
+        ls, rs = Variables.to_struct(lhs), Variables.to_struct(rhs)
+        check(self.L.pq_kktsys_mul(self.h, C.byref(ls), C.byref(rs)))
+        return rhs
+
+    def last_solve_stats(self):
+        a, b, c, d = C.c_int(), C.c_int(), C.c_double(), C.c_double()
+        self.L.pq_kktsys_last_solve_stats(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d))
+        return dict(refine_steps=a.value, backend_solves=b.value, refine_error=c.value, rhs_norm=d.value)
+
+    def condensed_residual(self):
+        r, q = C.c_double(), C.c_double()
+        check(self.L.pq_kktsys_condensed_residual(self.h, C.byref(r), C.byref(q)))
+        return r.value, q.value
+
+    def synchronize(self):
+        check(self.L.pq_kktsys_synchronize(self.h))

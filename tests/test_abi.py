@@ -1,0 +1,78 @@
+"""CPU-only checks of the drop-in boundary: the shared library loads and exports exactly the symbols
+include/piqp_amd.h declares; without a GPU every constructor fails loudly (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    txt = open(os.path.join(ROOT, "include", "piqp_amd.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(pq_[A-Za-z0-9_]+)\s*\(", txt)))
+
+
+def test_header_symbols_are_exported():
+    import piqp_amd
+    L = piqp_amd._lib.load()
+    syms = _header_symbols()
+    assert len(syms) >= 50
+    for s in syms:
+        assert hasattr(L, s), f"{s} declared in include/piqp_amd.h but not exported"
+    assert sorted(piqp_amd._lib.SYMBOLS) == syms
+
+
+def test_settings_defaults_match_reference():
+    """settings.hpp:45-82"""
+    import piqp_amd
+    s = piqp_amd.default_settings()
+    assert (s.rho_init, s.delta_init, s.eps_abs, s.eps_rel) == (1e-6, 1e-4, 1e-8, 1e-9)
+    assert (s.reg_lower_limit, s.reg_finetune_lower_limit, s.max_iter, s.max_factor_retires) == (1e-10, 1e-13, 250, 10)
+    assert (s.tau, s.preconditioner_iter, s.iterative_refinement_max_iter) == (0.99, 10, 10)
+    assert s.iterative_refinement_static_regularization_rel == np.finfo(float).eps ** 2
+    assert s.kkt_solver == piqp_amd.DENSE_CHOLESKY
+
+
+def test_no_cpu_fallback_without_device():
+    import torch
+    import piqp_amd
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    L = piqp_amd._lib.load()
+    assert L.pq_device_count() == 0
+    d = piqp_amd.Data(np.eye(3), np.zeros(3))
+    with pytest.raises(RuntimeError, match="no HIP device|failed"):
+        piqp_amd.DenseKKT(d)
+    with pytest.raises(RuntimeError):
+        piqp_amd.KKTSystem(d)
+
+
+def test_product_never_imports_oracle():
+    """the product package must not reference oracle/ in any way"""
+    pkg = os.path.join(ROOT, "piqp_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h")):
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "pyorc" not in txt and "orc.h" not in txt and "liborc" not in txt, f
+
+
+def test_data_mirror_matches_oracle_data(orc):
+    """piqp_amd.Data (host mirror of dense::Data) agrees with the oracle's restatement on index lists and transposes"""
+    import piqp_amd
+    from qp_gen import dense_strongly_convex_qp
+    q = dense_strongly_convex_qp(30, 7, 19, seed=5)
+    q["h_l"][3] = -np.inf; q["h_u"][3] = np.inf  # a row with no finite bound -> disabled (dense/data.hpp:144-169)
+    d = piqp_amd.Data(**q)
+    o = orc.Data.dense(**q)
+    assert (d.n_h_l, d.n_h_u, d.n_x_l, d.n_x_u) == o.counts()
+    for nm in ("h_l", "h_u", "x_l", "x_u"):
+        assert np.array_equal(getattr(d, nm + "_idx"), o.idx(nm))
+    assert np.array_equal(d.GT, o.mat("GT")) and np.array_equal(d.AT, o.mat("AT"))
+    assert np.array_equal(np.triu(d.P_utri), np.triu(o.mat("P_utri")))
+    assert np.array_equal(d.h_l, o.vec("h_l")) and np.array_equal(d.h_u, o.vec("h_u"))
+    assert np.array_equal(d.x_l[: d.n_x_l], o.vec("x_l")[: d.n_x_l])

@@ -1,0 +1,263 @@
+"""GPU parity tests of the dense KKT hot path: HIP kernels (through the C-ABI) vs the CPU oracle on the
+same seeded inputs.  Tolerances: fp64; north_star asks <= 1e-10 relative KKT residual; element-wise
+comparisons against the oracle use bounds scaled by the conditioning of the test matrices.
+
+Mirrors the reference's tests/src/dense/kkt_test.cpp (UpdateData, FactorizeSolve) and ldlt_test.cpp,
+run against both implementations.
+"""
+import numpy as np
+import pytest
+
+from qp_gen import dense_strongly_convex_qp, random_vars
+
+pytestmark = pytest.mark.gpu
+
+DIMS = [(20, 8, 9), (10, 8, 9), (64, 0, 30), (40, 12, 0), (33, 5, 0), (130, 20, 70), (200, 50, 100), (257, 3, 129), (384, 64, 256), (512, 0, 512)]
+
+
+def _mk(hip, orc, n, p, m, seed):
+    q = dense_strongly_convex_qp(n, p, m, seed=seed)
+    return q, hip.Data(**q), orc.Data.dense(**q)
+
+
+def _rel(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    if a.size == 0:
+        return 0.0
+    return float(np.abs(a - b).max() / (1e-300 + np.abs(b).max()))
+
+
+@pytest.mark.parametrize("dims", DIMS)
+def test_mfma_f64_assembly_matches_oracle(hip, orc, dims):
+    """dense/kkt.hpp:140-160 update_kkt: K_lower = P^T + diag(x_reg) + AT_A/delta + GT diag(1/z_reg) GT^T"""
+    n, p, m = dims
+    q, d, od = _mk(hip, orc, n, p, m, seed=n + m)
+    rng = np.random.default_rng(1)
+    x_reg = rng.uniform(0.5, 2.0, n); z_reg = rng.uniform(0.1, 3.0, m); delta = 1.2
+    k = hip.DenseKKT(d)
+    ko = orc.KKT(od)
+    assert k.update_scalings_and_factor(delta, x_reg, z_reg)
+    assert ko.update_scalings_and_factor(delta, x_reg, z_reg)
+    K, Ko = np.tril(k.internal_kkt_mat()), np.tril(ko.internal_kkt_mat())
+    assert _rel(K, Ko) < 1e-13
+    # asymmetric-operand check of the MFMA fragment mapping: every entry individually close
+    assert np.allclose(K, Ko, rtol=1e-12, atol=1e-12 * np.abs(Ko).max())
+
+
+@pytest.mark.parametrize("kkt_solver", [0, 16])
+@pytest.mark.parametrize("dims", DIMS)
+def test_factor_matches_oracle(hip, orc, kkt_solver, dims):
+    """Eigen::LLT (dense/kkt.hpp:82) / LDLTNoPivot (dense/ldlt_no_pivot.hpp:313-354): factor entries vs the oracle's"""
+    n, p, m = dims
+    q, d, od = _mk(hip, orc, n, p, m, seed=2 * n + p)
+    rng = np.random.default_rng(2)
+    x_reg = rng.uniform(0.5, 2.0, n); z_reg = rng.uniform(0.1, 3.0, m); delta = 0.7
+    k = hip.DenseKKT(d, kkt_solver=kkt_solver)
+    ko = orc.KKT(od, use_ldlt=(kkt_solver == 16))
+    assert k.update_scalings_and_factor(delta, x_reg, z_reg)
+    assert ko.update_scalings_and_factor(delta, x_reg, z_reg)
+    F, Fo = np.tril(k.internal_factor()), np.tril(ko.internal_factor())
+    assert _rel(F, Fo) < 1e-10
+    # reconstruct K from the device factor
+    K = np.tril(ko.internal_kkt_mat()); K = K + np.tril(K, -1).T
+    if kkt_solver == 0:
+        R = F @ F.T
+    else:
+        L = np.tril(F, -1) + np.eye(n)
+        R = L @ np.diag(np.diag(F)) @ L.T
+    assert _rel(R, K) < 1e-12
+
+
+@pytest.mark.parametrize("kkt_solver", [0, 16])
+@pytest.mark.parametrize("dims", DIMS)
+def test_backend_solve_and_evals_match_oracle(hip, orc, kkt_solver, dims):
+    """dense/kkt.hpp:86-132 solve + eval_P_x / eval_A.. / eval_G.. against the oracle"""
+    n, p, m = dims
+    q, d, od = _mk(hip, orc, n, p, m, seed=3 * n + m)
+    rng = np.random.default_rng(3)
+    x_reg = rng.uniform(0.5, 2.0, n); z_reg = rng.uniform(0.1, 3.0, m); delta = 1.2
+    k = hip.DenseKKT(d, kkt_solver=kkt_solver)
+    ko = orc.KKT(od, use_ldlt=(kkt_solver == 16))
+    assert k.update_scalings_and_factor(delta, x_reg, z_reg) and ko.update_scalings_and_factor(delta, x_reg, z_reg)
+    rx, ry, rz = rng.standard_normal(n), rng.standard_normal(p), rng.standard_normal(m)
+    lx, ly, lz = k.solve(rx, ry, rz)
+    ox, oy, oz = ko.solve(rx, ry, rz)
+    assert _rel(lx, ox) < 1e-9 and _rel(ly, oy) < 1e-9 and _rel(lz, oz) < 1e-9
+    # residual of the 3x3 condensed system (kkt_system.hpp:507-519), computed in numpy
+    P = np.triu(q["P"]); Pf = P + np.triu(P, 1).T
+    A = q["A"] if p else np.zeros((0, n)); G = q["G"] if m else np.zeros((0, n))
+    r1 = rx - (Pf @ lx + x_reg * lx + A.T @ ly + G.T @ lz)
+    r2 = ry - (A @ lx - delta * ly)
+    r3 = rz - (G @ lx - z_reg * lz)
+    nrm = max([np.abs(v).max() for v in (rx, ry, rz) if v.size])
+    assert max([np.abs(v).max() for v in (r1, r2, r3) if v.size]) <= 1e-10 * nrm
+    x = rng.standard_normal(n); y = rng.standard_normal(p); z = rng.standard_normal(m)
+    assert _rel(k.eval_P_x(-1.5, x), ko.eval_P_x(-1.5, x)) < 1e-13
+    for (a, b_) in zip(k.eval_A_xn_and_AT_xt(-1.0, 2.0, x, y), ko.eval_A_xn_and_AT_xt(-1.0, 2.0, x, y)):
+        assert _rel(a, b_) < 1e-13 or np.abs(np.asarray(a) - b_).max() < 1e-13
+    for (a, b_) in zip(k.eval_G_xn_and_GT_xt(0.5, -3.0, x, z), ko.eval_G_xn_and_GT_xt(0.5, -3.0, x, z)):
+        assert _rel(a, b_) < 1e-13 or np.abs(np.asarray(a) - b_).max() < 1e-13
+
+
+def test_update_data_equals_fresh_bitwise(hip, orc):
+    """dense/kkt_test.cpp:24-65: update_data + refactor == fresh backend, lower triangle bit-equal"""
+    q = dense_strongly_convex_qp(10, 8, 9, seed=1)
+    d = hip.Data(**q)
+    d.P_utri[1, 1] = 0.0
+    rho, delta = 0.9, 1.2
+    x_reg = np.full(10, rho); z_reg = np.full(9, 1 + delta)
+    k = hip.DenseKKT(d)
+    assert k.update_scalings_and_factor(delta, x_reg, z_reg)
+    q2 = dense_strongly_convex_qp(10, 8, 9, seed=2)
+    d2 = hip.Data(**q2)
+    k.update_data(d2, hip.KKT_UPDATE_P | hip.KKT_UPDATE_A | hip.KKT_UPDATE_G)
+    assert k.update_scalings_and_factor(delta, x_reg, z_reg)
+    k2 = hip.DenseKKT(d2)
+    assert k2.update_scalings_and_factor(delta, x_reg, z_reg)
+    assert np.array_equal(np.tril(k.internal_kkt_mat()), np.tril(k2.internal_kkt_mat()))
+    assert np.array_equal(np.tril(k.internal_factor()), np.tril(k2.internal_factor()))
+
+
+def test_factor_failure_semantics(hip, orc):
+    """LLT fails iff a pivot <= 0 (dense/kkt.hpp:83); LDLTNoPivot only on an exact zero pivot (ldlt_no_pivot.hpp:307)"""
+    n = 40
+    P = -np.eye(n)  # negative definite, no constraints
+    d = hip.Data(P, np.zeros(n))
+    od = orc.Data.dense(P, np.zeros(n))
+    x_reg = np.full(n, 0.5); z_reg = np.zeros(0)
+    assert hip.DenseKKT(d).update_scalings_and_factor(1.0, x_reg, z_reg) is False
+    assert orc.KKT(od).update_scalings_and_factor(1.0, x_reg, z_reg) is False
+    assert hip.DenseKKT(d, kkt_solver=16).update_scalings_and_factor(1.0, x_reg, z_reg) is True
+    assert orc.KKT(od, use_ldlt=True).update_scalings_and_factor(1.0, x_reg, z_reg) is True
+    x_reg0 = np.full(n, 1.0)  # P + I = 0 -> exact zero pivot
+    assert hip.DenseKKT(d, kkt_solver=16).update_scalings_and_factor(1.0, x_reg0, z_reg) is False
+    assert orc.KKT(od, use_ldlt=True).update_scalings_and_factor(1.0, x_reg0, z_reg) is False
+    # failure deep inside a large matrix (second panel)
+    n = 300
+    q = dense_strongly_convex_qp(n, 0, 0, seed=9)
+    Pn = q["P"].copy(); Pn[200, 200] = -1e6
+    d = hip.Data(Pn, q["c"]); od = orc.Data.dense(Pn, q["c"])
+    assert hip.DenseKKT(d).update_scalings_and_factor(1.0, np.full(n, 1e-3), z_reg) is False
+    assert orc.KKT(od).update_scalings_and_factor(1.0, np.full(n, 1e-3), z_reg) is False
+
+
+@pytest.mark.parametrize("kkt_solver", [0, 16])
+@pytest.mark.parametrize("dims", [(20, 8, 9), (64, 0, 30), (40, 12, 0), (130, 20, 70), (200, 50, 100)])
+def test_kkt_system_factorize_solve(hip, orc, kkt_solver, dims):
+    """dense/kkt_test.cpp:67-139 FactorizeSolve through pq_kktsys_*: mul(solve(rhs)) ~ rhs (1e-8) and == oracle"""
+    n, p, m = dims
+    q, d, od = _mk(hip, orc, n, p, m, seed=7 + n)
+    st = hip.default_settings(kkt_solver=kkt_solver)
+    k = hip.KKTSystem(d, st)
+    ko = orc.KKTSystem(od, orc.Settings(kkt_solver=kkt_solver))
+    scaling = hip.Variables.zeros(n, p, m, fill=1.0)
+    assert k.update_scalings_and_factor(False, 0.9, 1.2, scaling)
+    assert ko.update_scalings_and_factor(False, 0.9, 1.2, scaling)
+    rng = np.random.default_rng(0)
+    rhs = random_vars(n, p, m, rng)
+    ok, lhs = k.solve(rhs)
+    oko, ref = ko.solve(rhs)
+    assert ok and oko
+    back = k.mul(lhs)
+    oback = ko.mul(lhs)
+    nxl, nxu = d.n_x_l, d.n_x_u
+    for key in ("x", "y"):
+        assert np.allclose(rhs[key], back[key], rtol=1e-8, atol=1e-8)
+    for key, cnt in (("z_bl", nxl), ("z_bu", nxu), ("s_bl", nxl), ("s_bu", nxu)):
+        assert np.allclose(rhs[key][:cnt], back[key][:cnt], rtol=1e-8, atol=1e-8)
+        assert np.allclose(back[key][:cnt], oback[key][:cnt], rtol=1e-12, atol=1e-12)
+    for key, idx in (("z_l", d.h_l_idx), ("s_l", d.h_l_idx), ("z_u", d.h_u_idx), ("s_u", d.h_u_idx)):
+        assert np.allclose(rhs[key][idx], back[key][idx], rtol=0, atol=1e-8)
+    for key in lhs:
+        cnt = {"z_bl": nxl, "s_bl": nxl, "z_bu": nxu, "s_bu": nxu}.get(key, len(ref[key]))
+        assert _rel(lhs[key][:cnt], ref[key][:cnt]) < 1e-9, key
+    res, nrm = k.condensed_residual()
+    assert res <= 1e-10 * nrm
+
+
+@pytest.mark.parametrize("dims", [(60, 10, 40), (200, 50, 100), (300, 0, 200)])
+def test_kkt_system_iterative_refinement(hip, orc, dims):
+    """kkt_system.hpp:195-207,256-301: static regularisation + refinement loop on an interior IPM state;
+    same number of refinement steps as the oracle and the same solution."""
+    n, p, m = dims
+    q, d, od = _mk(hip, orc, n, p, m, seed=11 + n)
+    k = hip.KKTSystem(d)
+    ko = orc.KKTSystem(od)
+    rng = np.random.default_rng(5)
+    state = random_vars(n, p, m, rng, positive=True)
+    assert k.update_scalings_and_factor(True, 1e-6, 1e-4, state)
+    assert ko.update_scalings_and_factor(True, 1e-6, 1e-4, state)
+    rhs = random_vars(n, p, m, rng)
+    ok, lhs = k.solve(rhs)
+    oko, ref = ko.solve(rhs)
+    assert ok and oko
+    stats = k.last_solve_stats()
+    assert abs(stats["refine_steps"] - ko.last_refine_steps()) <= 1
+    res, nrm = k.condensed_residual()
+    assert res <= 1e-10 * nrm
+    nxl, nxu = d.n_x_l, d.n_x_u
+    for key in lhs:
+        cnt = {"z_bl": nxl, "s_bl": nxl, "z_bu": nxu, "s_bu": nxu}.get(key, len(ref[key]))
+        assert _rel(lhs[key][:cnt], ref[key][:cnt]) < 1e-8, key
+
+
+def test_clone_is_bitwise_deterministic(hip):
+    """kkt_system.hpp:70-95 clone + tests/src/dense/solver_test.cpp:379-401: a copy gives bit-identical results"""
+    n, p, m = 200, 50, 100
+    q = dense_strongly_convex_qp(n, p, m, seed=21)
+    d = hip.Data(**q)
+    k = hip.KKTSystem(d)
+    rng = np.random.default_rng(8)
+    state = random_vars(n, p, m, rng, positive=True)
+    rhs = random_vars(n, p, m, rng)
+    assert k.update_scalings_and_factor(False, 1e-6, 1e-4, state)
+    k2 = k.clone()
+    ok1, l1 = k.solve(rhs)
+    ok2, l2 = k2.solve(rhs)
+    assert ok1 and ok2
+    for key in l1:
+        assert np.array_equal(l1[key], l2[key]), key
+    # refactor in the clone from the same state: still bit-identical
+    assert k2.update_scalings_and_factor(False, 1e-6, 1e-4, state)
+    ok3, l3 = k2.solve(rhs)
+    for key in l1:
+        assert np.array_equal(l1[key], l3[key]), key
+
+
+def test_device_pointer_mode_matches_host_mode(hip):
+    """PQ_MEM_DEVICE: vectors resident in HBM (torch CUDA tensors) give the same bits as the staged host path"""
+    import torch
+    n, p, m = 130, 20, 70
+    q = dense_strongly_convex_qp(n, p, m, seed=31)
+    d = hip.Data(**q)
+    k = hip.KKTSystem(d)
+    rng = np.random.default_rng(9)
+    state = random_vars(n, p, m, rng, positive=True)
+    rhs = random_vars(n, p, m, rng)
+    assert k.update_scalings_and_factor(False, 1e-6, 1e-4, state)
+    ok, lhs = k.solve(rhs)
+    dstate = {kk: torch.from_numpy(v).cuda() for kk, v in state.items()}
+    drhs = {kk: torch.from_numpy(v).cuda() for kk, v in rhs.items()}
+    assert k.update_scalings_and_factor(False, 1e-6, 1e-4, dstate)
+    ok2, dl = k.solve(drhs)
+    k.synchronize()
+    assert ok and ok2
+    for key in lhs:
+        cnt = {"z_bl": d.n_x_l, "s_bl": d.n_x_l, "z_bu": d.n_x_u, "s_bu": d.n_x_u}.get(key, len(lhs[key]))
+        assert np.array_equal(lhs[key][:cnt], dl[key].cpu().numpy()[:cnt]), key
+
+
+@pytest.mark.parametrize("n,m", [(1024, 1024), (2048, 1536)])
+def test_large_factor_solve_residual(hip, n, m):
+    """size-independent property at larger sizes: ||rhs - K lhs|| / ||rhs|| <= 1e-10 (north_star tolerance)"""
+    q = dense_strongly_convex_qp(n, 0, m, seed=n, double_sided=True)
+    d = hip.Data(**q)
+    for solver in (0, 16):
+        k = hip.KKTSystem(d, hip.default_settings(kkt_solver=solver))
+        rng = np.random.default_rng(4)
+        state = random_vars(n, 0, m, rng, positive=True)
+        assert k.update_scalings_and_factor(False, 1e-6, 1e-4, state)
+        ok, lhs = k.solve(random_vars(n, 0, m, rng))
+        assert ok
+        res, nrm = k.condensed_residual()
+        assert res <= 1e-10 * nrm, (solver, res, nrm)

@@ -1,0 +1,272 @@
+"""Pins the CPU oracle (oracle/) to the reference: every property / known answer the reference's own
+tests hold for the dense path, plus the one recorded IPM trace (docs notebook).  CPU only.
+
+Reference tests mirrored (tests/src/...):
+  dense/ldlt_test.cpp:22-77      LDLTNoPivot: info()==Success, b ~ P_full x (1e-8)
+  dense/kkt_test.cpp:24-65       UpdateData: update == fresh, lower triangle bit-equal
+  dense/kkt_test.cpp:67-139      FactorizeSolve: K * lhs ~ rhs on every block (1e-8), rho=.9, delta=1.2
+  dense/solver_test.cpp          SimpleQPWithUpdate / Primal-/DualInfeasible / IllConditionedSmall /
+                                 InfinityBounds / CopyConstructor (bitwise) / random strongly convex QPs
+  docs/assets/robust_scenario_mpc.ipynb  recorded 12-iteration table (tests/golden/c0_trace.json)
+"""
+import numpy as np
+import pytest
+import scipy.linalg as sla
+
+from qp_gen import dense_strongly_convex_qp, random_vars
+from qp_io import dense_args, load_json, load_qp
+
+
+def _spd(n, seed):
+    rng = np.random.default_rng(seed)
+    U = np.triu(rng.standard_normal((n, n)), 1)
+    S = U + U.T
+    S += (1e-2 + abs(np.linalg.eigvalsh(S).min())) * np.eye(n)
+    return S
+
+
+@pytest.mark.parametrize("n", [5, 31, 32, 50, 200, 300])
+def test_llt_matches_scipy_cholesky(orc, n):
+    import ctypes as C
+    L = orc.lib()
+    S = _spd(n, n)
+    a = np.asfortranarray(S.copy())
+    ret = L.orc_llt_compute(a.ctypes.data_as(orc._dp), n, n)
+    assert ret == -1
+    ref = sla.cholesky(S, lower=True)
+    assert np.allclose(np.tril(a), ref, rtol=1e-11, atol=1e-12)
+    b = np.random.default_rng(1).standard_normal(n)
+    x = b.copy()
+    L.orc_llt_solve_inplace(a.ctypes.data_as(orc._dp), n, n, x.ctypes.data_as(orc._dp))
+    assert np.allclose(S @ x, b, rtol=1e-8, atol=1e-8)  # ldlt_test.cpp: b.isApprox(P*x, 1e-8)
+
+
+def test_llt_reports_first_nonpositive_pivot(orc):
+    L = orc.lib()
+    S = _spd(40, 3)
+    S[17, 17] = -1.0  # Eigen LLT: pivot x <= 0 -> return k
+    a = np.asfortranarray(S.copy())
+    ret = L.orc_llt_compute(a.ctypes.data_as(orc._dp), 40, 40)
+    assert 0 <= ret <= 17
+
+
+@pytest.mark.parametrize("n", [10, 50, 64, 200])
+def test_ldlt_no_pivot(orc, n):
+    L = orc.lib()
+    S = _spd(n, 100 + n)
+    a = np.asfortranarray(S.copy())
+    w = np.zeros(n)
+    ret = L.orc_ldlt_no_pivot_compute(a.ctypes.data_as(orc._dp), n, n, w.ctypes.data_as(orc._dp))
+    assert ret == -1  # info() == Success
+    Lm = np.tril(a, -1) + np.eye(n)
+    D = np.diag(np.diag(a))
+    assert np.allclose(Lm @ D @ Lm.T, S, rtol=1e-10, atol=1e-10)
+    b = np.random.default_rng(2).standard_normal(n)
+    x = b.copy()
+    L.orc_ldlt_no_pivot_solve_inplace(a.ctypes.data_as(orc._dp), n, n, x.ctypes.data_as(orc._dp))
+    assert np.allclose(S @ x, b, rtol=1e-8, atol=1e-8)
+
+
+def test_ldlt_quasi_definite_and_zero_pivot(orc):
+    L = orc.lib()
+    # indefinite but strongly factorisable: negative pivots are fine for LDLTNoPivot, exact zero fails (:307)
+    S = np.array([[2.0, 1.0], [1.0, -3.0]])
+    a = np.asfortranarray(S.copy()); w = np.zeros(2)
+    assert L.orc_ldlt_no_pivot_compute(a.ctypes.data_as(orc._dp), 2, 2, w.ctypes.data_as(orc._dp)) == -1
+    assert a[1, 1] < 0
+    Z = np.array([[0.0, 1.0], [1.0, 1.0]])
+    a = np.asfortranarray(Z.copy())
+    assert L.orc_ldlt_no_pivot_compute(a.ctypes.data_as(orc._dp), 2, 2, w.ctypes.data_as(orc._dp)) == 0
+
+
+def _kkt_dense_numpy(data, delta, x_reg, z_reg):
+    P = data.mat("P_utri"); AT = data.mat("AT"); GT = data.mat("GT")
+    Pf = np.triu(P) + np.triu(P, 1).T
+    K = Pf + np.diag(x_reg)
+    if data.p:
+        K = K + AT @ AT.T / delta
+    if data.m:
+        K = K + GT @ np.diag(1.0 / z_reg) @ GT.T
+    return K
+
+
+@pytest.mark.parametrize("use_ldlt", [False, True])
+def test_dense_kkt_update_data_equals_fresh(orc, use_ldlt):
+    """dense/kkt_test.cpp:24-65"""
+    q = dense_strongly_convex_qp(10, 8, 9, seed=1)
+    d = orc.Data.dense(**q)
+    d.mat("P_utri")[1, 1] = 0.0
+    rho, delta = 0.9, 1.2
+    x_reg = np.full(10, rho); z_reg = np.full(9, 1 + delta)
+    k = orc.KKT(d, use_ldlt=use_ldlt)
+    assert k.update_scalings_and_factor(delta, x_reg, z_reg)
+    q2 = dense_strongly_convex_qp(10, 8, 9, seed=2)
+    d2 = orc.Data.dense(**q2)
+    for nm in ("P_utri", "AT", "GT"):
+        d.mat(nm)[...] = d2.mat(nm)
+    k.update_data(orc.KKT_UPDATE_P | orc.KKT_UPDATE_A | orc.KKT_UPDATE_G)
+    assert k.update_scalings_and_factor(delta, x_reg, z_reg)
+    k2 = orc.KKT(d, use_ldlt=use_ldlt)
+    assert k2.update_scalings_and_factor(delta, x_reg, z_reg)
+    assert np.array_equal(np.tril(k.internal_kkt_mat()), np.tril(k2.internal_kkt_mat()))  # bit-equal
+    assert np.allclose(np.tril(k.internal_kkt_mat()), np.tril(_kkt_dense_numpy(d, delta, x_reg, z_reg)), rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("kkt_solver", [0, 16])
+@pytest.mark.parametrize("dims", [(20, 8, 9), (64, 0, 30), (40, 12, 0), (130, 20, 70)])
+def test_kkt_system_factorize_solve(orc, kkt_solver, dims):
+    """dense/kkt_test.cpp:67-139 FactorizeSolve: mul(solve(rhs)) ~ rhs"""
+    n, p, m = dims
+    q = dense_strongly_convex_qp(n, p, m, seed=7 + n)
+    d = orc.Data.dense(**q)
+    st = orc.Settings(kkt_solver=kkt_solver)
+    k = orc.KKTSystem(d, st)
+    scaling = orc.make_vars(n, p, m, fill=1.0)
+    assert k.update_scalings_and_factor(False, 0.9, 1.2, scaling)
+    rng = np.random.default_rng(0)
+    rhs = random_vars(n, p, m, rng)
+    ok, lhs = k.solve(rhs)
+    assert ok
+    back = k.mul(lhs)
+    nhl, nhu, nxl, nxu = d.counts()
+    assert np.allclose(rhs["x"], back["x"], rtol=1e-8, atol=1e-8)
+    assert np.allclose(rhs["y"], back["y"], rtol=1e-8, atol=1e-8)
+    for key, cnt in (("z_bl", nxl), ("z_bu", nxu), ("s_bl", nxl), ("s_bu", nxu)):
+        assert np.allclose(rhs[key][:cnt], back[key][:cnt], rtol=1e-8, atol=1e-8)
+    il, iu = d.idx("h_l"), d.idx("h_u")
+    for key, idx in (("z_l", il), ("s_l", il), ("z_u", iu), ("s_u", iu)):
+        assert np.allclose(rhs[key][idx], back[key][idx], rtol=0, atol=1e-8)
+
+
+def test_kkt_system_iterative_refinement_reaches_target(orc):
+    """kkt_system.hpp:256-301 with an interior (s, z) state; residual of the condensed system <= 1e-12(1+|rhs|)"""
+    n, p, m = 60, 10, 40
+    q = dense_strongly_convex_qp(n, p, m, seed=11)
+    d = orc.Data.dense(**q)
+    k = orc.KKTSystem(d)
+    rng = np.random.default_rng(5)
+    state = random_vars(n, p, m, rng, positive=True)
+    assert k.update_scalings_and_factor(True, 1e-6, 1e-4, state)
+    rhs = random_vars(n, p, m, rng)
+    ok, lhs = k.solve(rhs)
+    assert ok
+    # condensed residual recomputed in numpy
+    P = d.mat("P_utri"); Pf = np.triu(P) + np.triu(P, 1).T
+    AT, GT = d.mat("AT"), d.mat("GT")
+    x_reg, z_reg = k.x_reg(), k.z_reg()
+    rx, rz = k.rhs_x_bar(), k.rhs_z_bar()
+    # z = z_u - z_l in the condensed unknowns
+    z = lhs["z_u"] - lhs["z_l"]
+    res_x = rx - (Pf @ lhs["x"] + x_reg * lhs["x"] + AT @ lhs["y"] + GT @ z)
+    res_y = rhs["y"] - (AT.T @ lhs["x"] - 1e-4 * lhs["y"])
+    nrm = max(np.abs(rx).max(), np.abs(rhs["y"]).max(), np.abs(rz).max())
+    assert np.abs(res_x).max() <= 1e-9 * (1 + nrm)
+    assert np.abs(res_y).max() <= 1e-9 * (1 + nrm)
+
+
+# ------------------------------------------------------------------------------- solver KATs
+def test_simple_qp_with_update(orc):
+    """dense/solver_test.cpp:31-97"""
+    kat = load_json("kat_small.json")["dense_simple_qp"]
+    inf = np.inf
+    P = np.array([[6.0, 0], [0, 4]]); c = np.array([-1.0, -4]); A = np.array([[1.0, -2]]); b = np.array([0.0])
+    G = np.array([[1.0, 0], [1, 0], [1, 0]]); h_l = np.array([-1, -inf, -2]); h_u = np.array([inf, 1, 2.0])
+    x_l = np.array([-inf, -1]); x_u = np.array([inf, 1.0])
+    s = orc.Solver()
+    assert s.setup(P, c, A, b, G, h_l, h_u, x_l, x_u)
+    assert s.solve() == orc.SOLVED
+    r = s.result()
+    assert np.allclose(r["x"], kat["x"], atol=kat["tol"]) and np.allclose(r["y"], kat["y"], atol=kat["tol"])
+    for k in ("z_l", "z_u", "z_bl", "z_bu"):
+        assert np.allclose(r[k], 0, atol=1e-6)
+    P[0, 0] = 8; A[0, 1] = -3; h_u[0] = 2; x_u[1] = 2
+    assert s.update(P, c, A, b, None, None, h_u, None, x_u)
+    assert s.solve() == orc.SOLVED
+    r = s.result()
+    assert np.allclose(r["x"], kat["x_after_update"], atol=1e-6) and np.allclose(r["y"], kat["y_after_update"], atol=1e-6)
+
+
+def test_primal_infeasible(orc):
+    """dense/solver_test.cpp:103-125"""
+    P = np.array([[6.0, 0], [0, 4]]); c = np.array([-1.0, -4]); A = np.array([[1.0, -2]]); b = np.array([0.0])
+    G = np.array([[1.0, 0], [0, 1], [-1, 0], [0, -1]]); h = np.array([0.0, 2, 1, -1])
+    s = orc.Solver()
+    s.setup(P, c, A, b, G, None, h, None, None)
+    assert s.solve() == orc.PRIMAL_INFEASIBLE
+
+
+def test_dual_infeasible(orc):
+    """dense/solver_test.cpp:131-154"""
+    P = np.zeros((2, 2)); c = np.array([-1.0, -1]); G = np.array([[-1.0, 0], [0, -1]]); h = np.array([0.0, 0])
+    s = orc.Solver()
+    s.setup(P, c, None, None, G, None, h, None, None)
+    assert s.solve() == orc.DUAL_INFEASIBLE
+
+
+def test_ill_conditioned_small(orc):
+    """dense/solver_test.cpp:156-182"""
+    inf = np.inf
+    P = np.diag([61, 2e9, 61, 2e9, 1000, 100.0]); c = np.zeros(6)
+    A = np.array([[1.0, 0, 1, 0, 1, 0], [2.4, 0, -2.4, 0, 0, 1]]); b = np.zeros(2)
+    x_l = np.array([-2e4, -0.3491, -2e4, -0.3491, -inf, -inf]); x_u = np.array([2e4, 0.3491, 2e4, 0.3491, inf, inf])
+    s = orc.Solver()
+    s.setup(P, c, A, b, None, None, None, x_l, x_u)
+    assert s.solve() == orc.SOLVED
+
+
+def test_infinity_bounds(orc):
+    """dense/solver_test.cpp:347-377"""
+    P = np.eye(4); c = np.ones(4)
+    G = np.array([[1.0, 0, 0, 0], [1, 0, -1, 0], [-1, 0, -1, 0], [-1, 0, 0, 0], [-1, 0, 1, 0], [1, 0, 1, 0]])
+    h = np.array([1, 1, 1, 1, np.inf, np.inf])
+    s = orc.Solver()
+    s.setup(P, c, None, None, G, None, h)
+    assert s.solve() == orc.SOLVED
+    assert np.allclose(s.result()["x"], load_json("kat_small.json")["infinity_bounds"]["x"], atol=1e-6)
+
+
+@pytest.mark.parametrize("dims", [(20, 10, 12), (30, 0, 20), (25, 10, 0), (60, 20, 40)])
+def test_random_strongly_convex_solved_and_clone_bitwise(orc, dims):
+    """dense/solver_test.cpp random QPs -> PIQP_SOLVED; CopyConstructor: ASSERT_EQ(x1, x2) bitwise (:379-401)"""
+    n, p, m = dims
+    q = dense_strongly_convex_qp(n, p, m, seed=3 * n + p)
+    s1 = orc.Solver()
+    assert s1.setup(**q)
+    s2 = s1.clone()
+    assert s1.solve() == orc.SOLVED
+    assert s2.solve() == orc.SOLVED
+    assert np.array_equal(s1.result()["x"], s2.result()["x"])
+    # optimality cross-check against an independent KKT solve is implied by the residual tolerances:
+    assert s1.info.primal_res < 1e-7 and s1.info.dual_res < 1e-7
+
+
+def test_recorded_notebook_trace_c0(orc):
+    """The only IPM trace recorded in the reference tree: 12 iterations, objective 4.45173e+03,
+    per-iteration table to the printed precision for the columns that do not sit at rounding level."""
+    q = load_qp("qp_c0_scenario_mpc")
+    tr = load_json("c0_trace.json")
+    s = orc.Solver()
+    s.enable_trace()
+    assert s.setup(*dense_args(q))
+    assert s.solve() == orc.SOLVED
+    assert s.info.iter == tr["iterations"]
+    assert abs(s.info.primal_obj - tr["objective_scipy_trust_constr"]) < 1e-3
+    t = s.trace()
+    ref = np.array(tr["rows"])
+    assert t.shape == ref.shape
+    # prim_obj, dual_obj, gap, prim_res, rho, delta, mu, steps: printed with 4-6 significant digits
+    for col, rtol in ((1, 2e-6), (2, 2e-5), (3, 5e-3), (4, 2e-5), (6, 1e-3), (7, 1e-3), (8, 1e-3)):
+        assert np.allclose(t[:, col], ref[:, col], rtol=rtol, atol=1e-12), col
+    assert np.allclose(t[:, 9:], ref[:, 9:], atol=6e-5)
+    # dual_res agrees while it is above rounding level (the notebook's own two backends differ below 1e-5)
+    assert np.allclose(t[:9, 5], ref[:9, 5], rtol=1e-4)
+
+
+@pytest.mark.parametrize("name", ["qp_small_dense", "qp_scenario_mpc_small", "qp_chain_mass_sqp", "mm_HS21", "mm_HS35", "mm_HS76",
+                                  "mm_DUAL1", "mm_QAFIRO", "mm_HS118", "mm_CVXQP1_S", "mm_DUALC1"])
+def test_fixture_problems_solved(orc, name):
+    """reference fixtures solved through the dense path (maros_meszaros_tests.cpp: status == SOLVED)"""
+    q = load_qp(name)
+    s = orc.Solver()
+    assert s.setup(*dense_args(q))
+    assert s.solve() == orc.SOLVED
