@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""bench.py -- KKT factor+solve throughput of the dense hot path on MI355X (BASELINE.json configs[1]).
+
+A "step" is the KKT work of ONE interior-point iteration exactly as the reference's own timers count it
+(include/piqp/solver.hpp:683-714,728-737,761-769): one KKTSystem::update_scalings_and_factor
+(scalings + KKT assembly + factorisation) followed by the predictor and the corrector
+KKTSystem::solve.  Inputs (problem matrices, the interior (s,z) state, the right-hand sides) are resident
+in HBM before the timed region starts; calls go through the C-ABI in PQ_MEM_DEVICE pointer mode.
+
+  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+
+Multi-GPU: the dense single-QP path does not shard (SURVEY.md 8e "replicas only"); with N ranks every
+rank factors+solves its own independent QP instance of the same shape (weak scaling, no data-path
+collective; the barrier and the max-over-ranks reduction are the only communication).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+PEAK_FP64_MFMA_TFLOPS = 78.6  # MI355X fp64 matrix peak (vendor sheet; measured value reported alongside)
+PEAK_HBM_GBS = 8000.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=4096)
+    ap.add_argument("--m", type=int, default=4096)
+    ap.add_argument("--p", type=int, default=0)
+    ap.add_argument("--kkt-solver", type=int, default=0, help="0 = dense_cholesky (reference default), 16 = pivot-free LDLt")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=0, help="0 = auto (about 10-30 s of CPU work)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import piqp_amd
+    from qp_gen import dense_strongly_convex_qp, random_vars
+
+    n, p, m = args.n, args.p, args.m
+    # synthetic QP of the BASELINE shape; one independent instance per rank (seed 43 + rank)
+    q = dense_strongly_convex_qp(n, p, m, seed=43 + rank, double_sided=True)
+    data = piqp_amd.Data(**q)
+    st = piqp_amd.default_settings(kkt_solver=args.kkt_solver)
+    ksys = piqp_amd.KKTSystem(data, st, device=local_rank)
+    backend = ksys.backend()
+
+    rng = np.random.default_rng(1000 + rank)
+    # two interior IPM states and rhs sets, alternated so no step re-reads its predecessor's vectors
+    states = [{k: torch.from_numpy(v).to(dev) for k, v in random_vars(n, p, m, rng, positive=True).items()} for _ in range(2)]
+    rhss = [{k: torch.from_numpy(v).to(dev) for k, v in random_vars(n, p, m, rng).items()} for _ in range(4)]
+    lhs = {k: torch.zeros_like(v) for k, v in rhss[0].items()}
+    rho, delta = 1e-6, 1e-4
+
+    def step(i):
+        ok = ksys.update_scalings_and_factor(False, rho, delta, states[i & 1])
+        ok1, _ = ksys.solve(rhss[(2 * i) & 3], lhs)       # predictor
+        ok2, _ = ksys.solve(rhss[(2 * i + 1) & 3], lhs)   # corrector
+        return ok and ok1 and ok2
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        ksys.synchronize()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        assert step(i), "factorisation failed in warmup"
+    # parity gate: relative KKT residual of the last solve
+    res, nrm = ksys.condensed_residual()
+    rel_res = res / nrm
+    assert rel_res <= 1e-10, f"KKT residual {rel_res:.3e} above 1e-10"
+
+    backend.set_profiling(True)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ok = step(i)
+    barrier()
+    t1 = time.perf_counter()
+    assert ok
+    backend.set_profiling(False)
+    elapsed = t1 - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    asm_ms, asm_cnt = backend.get_profile(0)
+    fac_ms, fac_cnt = backend.get_profile(1)
+    sol_ms, sol_cnt = backend.get_profile(2)
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = world * args.steps / elapsed
+        # dominant kernel: k_syrk_lower<ASSEMBLE>; algorithmic flops per launch = n(n+1)m
+        flops_asm = float(n) * (n + 1) * m
+        asm_avg_s = asm_ms / max(asm_cnt, 1) * 1e-3
+        achieved = flops_asm / asm_avg_s / 1e12 if asm_avg_s > 0 else 0.0
+        flops_llt = n ** 3 / 3.0
+        fac_avg_s = fac_ms / max(fac_cnt, 1) * 1e-3
+        out = {
+            "metric": "KKT factor+solve/sec (per IPM iter)",
+            "value": value,
+            "unit": "IPM-iter KKT (1 factor + 2 solves)/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"dense QP n={n} p={p} m_ineq={m} (BASELINE configs[1]), kkt_solver={'dense_cholesky' if args.kkt_solver == 0 else 'dense_ldlt_no_pivot'}, "
+                                   "1 update_scalings_and_factor + 2 KKTSystem::solve per step, inputs resident in HBM",
+                       "n": n, "p": p, "m": m, "parallelism": f"independent QP replicas x{world}"},
+            "roofline": {"bound": "mfma", "kernel": "k_syrk_lower<EPI_ASSEMBLE> (dense/kkt.hpp:140-160)",
+                         "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": None,
+                         "alg_flops_per_launch": flops_asm, "avg_launch_ms": asm_avg_s * 1e3, "launches": asm_cnt},
+            "stages": {"assembly_ms": asm_avg_s * 1e3, "factorisation_ms": fac_avg_s * 1e3,
+                       "factorisation_tflops": flops_llt / fac_avg_s / 1e12 if fac_avg_s > 0 else 0.0,
+                       "backend_solve_ms": sol_ms / max(sol_cnt, 1)},
+            "parity": {"rel_kkt_residual": rel_res, "tolerance": 1e-10},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(q, n, p, m, args)
+            if out["cpu_baseline"].get("value"):
+                out["speedup_vs_cpu_baseline"] = value / world / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(q, n, p, m, args):
+    """The oracle (CPU restatement of the reference algorithms) timed on this box's host cores on a bounded
+    sample of the same workload: the same step (1 factor + 2 KKTSystem::solve).  kind = "port"."""
+    import numpy as np
+    from oracle import pyorc
+    from qp_gen import random_vars
+    try:
+        L = pyorc.lib(native=True)  # -march=native build made on this machine
+        build = "gcc -O3 -march=native -fopenmp"
+    except Exception:
+        L = pyorc.lib()
+        build = "gcc -O3 -march=x86-64-v3 -fopenmp"
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    L.orc_set_num_threads(cores)
+    od = pyorc.Data.dense(**q, L=L)
+    ks = pyorc.KKTSystem(od, pyorc.Settings(L, kkt_solver=args.kkt_solver))
+    rng = np.random.default_rng(1000)
+    state = random_vars(n, p, m, rng, positive=True)
+    rhs = [random_vars(n, p, m, rng) for _ in range(2)]
+
+    def step():
+        ok = ks.update_scalings_and_factor(False, 1e-6, 1e-4, state)
+        ks.solve(rhs[0])
+        ks.solve(rhs[1])
+        return ok
+
+    t0 = time.perf_counter()
+    assert step()
+    first = time.perf_counter() - t0
+    steps = args.cpu_steps or max(1, min(20, int(15.0 / max(first, 1e-3))))
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    el = time.perf_counter() - t0
+    flops = float(n) * (n + 1) * m + n ** 3 / 3.0
+    return {"value": steps / el, "unit": "IPM-iter KKT (1 factor + 2 solves)/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} steps of the same n={n} p={p} m={m} workload (after 1 untimed step), oracle built with {build}",
+            "seconds": el, "factor_gflops": flops * steps / el / 1e9}
+
+
+if __name__ == "__main__":
+    main()

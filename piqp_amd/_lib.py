@@ -90,6 +90,12 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    try:
+        # one HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64/libhsa-runtime; if it is going to be
+        # used at all (device tensors, torch.distributed) it must be loaded before this library resolves libamdhip64.
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(hipcc, gfx950). piqp_amd has no CPU fallback.")

@@ -455,12 +455,10 @@ int pq_kktsys_solve(pq_kktsys* k, const pq_vars* rhs, pq_vars* lhs)
         if (k->ptr_mode == PQ_MEM_HOST) {
             k->ensure_staging();
             stage_in(k, rhs, k->in);
-            k->impl->last_rhs_y = k->in.v.y;
             ok = k->impl->solve(k->in.v, k->out.v);
             k->last_lhs_x = k->out.v.x; k->last_lhs_y = k->out.v.y;
             stage_out(k, k->out, lhs);
         } else {
-            k->impl->last_rhs_y = rhs->y;
             ok = k->impl->solve(*rhs, *lhs);
             k->last_lhs_x = lhs->x; k->last_lhs_y = lhs->y;
         }
@@ -475,12 +473,14 @@ int pq_kktsys_mul(pq_kktsys* k, const pq_vars* lhs, pq_vars* rhs)
         PQ_HIP(hipSetDevice(k->impl->device()));
         if (k->ptr_mode == PQ_MEM_HOST) {
             k->ensure_staging();
-            stage_in(k, lhs, k->in);
-            // keep the last solve's outputs intact: multiply into a scratch Variables set
-            VarStage tmp;
+            // keep the last solve's staged vectors intact: multiply through scratch Variables sets
+            VarStage tin, tmp;
+            tin.alloc(VarSizes{k->impl->n(), k->impl->p(), k->impl->m()});
             tmp.alloc(VarSizes{k->impl->n(), k->impl->p(), k->impl->m()});
+            tin.zero(k->impl->stream());
             tmp.zero(k->impl->stream());
-            k->impl->mul(k->in.v, tmp.v);
+            stage_in(k, lhs, tin);
+            k->impl->mul(tin.v, tmp.v);
             stage_out(k, tmp, rhs);
         } else {
             k->impl->mul(*lhs, *rhs);

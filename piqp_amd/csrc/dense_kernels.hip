@@ -265,19 +265,37 @@ constexpr int NB = 128;
 constexpr int PLD = NB + 16;  // LDS leading dimension (bank-conflict-free MFMA operand reads)
 constexpr int POTRF_LDS_BYTES = NB * PLD * (int)sizeof(double);
 
+// 1/sqrt(d) to ~1 ulp without the IEEE sqrt + divide chains (two Newton steps on v_rsq_f64)
+__device__ __forceinline__ double rsqrt_newton(double d)
+{
+    double y = __builtin_amdgcn_rsq(d);
+    y = y * (1.5 - 0.5 * d * y * y);
+    y = y * (1.5 - 0.5 * d * y * y);
+    return y;
+}
+__device__ __forceinline__ double rcp_newton(double d)
+{
+    double y = __builtin_amdgcn_rcp(d);
+    y = y * (2.0 - d * y);
+    y = y * (2.0 - d * y);
+    return y;
+}
+
 template <bool LDLT>
-__global__ __launch_bounds__(256) void k_potrf_diag(double* __restrict__ A, int lda, int nb, int kglobal, int* __restrict__ info)
+__global__ __launch_bounds__(256) void k_potrf_diag(double* __restrict__ A, int lda, int nb, int kglobal, int* __restrict__ info, double* __restrict__ rdiag)
 {
     extern __shared__ __attribute__((aligned(16))) double S[];  // S[c * PLD + r]
+    __shared__ double rd16[16];                                  // reciprocals of the current 16 pivots
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nbp = (nb + 15) & ~15;
     const int nt = nbp >> 4;
-    for (int idx = tid; idx < nbp * nbp; idx += 256) {
-        const int r = idx % nbp, c = idx / nbp;
-        double v = 0.0;
-        if (r < nb && c < nb) { if (r >= c) v = A[r + (size_t)c * lda]; }
-        else if (r == c) v = 1.0;  // identity padding
-        S[c * PLD + r] = v;
+    for (int c = wave; c < nbp; c += 4) {
+        for (int r = lane; r < nbp; r += 64) {
+            double v = 0.0;
+            if (r < nb && c < nb) { if (r >= c) v = A[r + (size_t)c * lda]; }
+            else if (r == c) v = 1.0;  // identity padding
+            S[c * PLD + r] = v;
+        }
     }
     __syncthreads();
 
@@ -290,18 +308,22 @@ __global__ __launch_bounds__(256) void k_potrf_diag(double* __restrict__ A, int 
 #pragma unroll
             for (int c = 0; c < 16; ++c) a[c] = S[(j0 + c) * PLD + j0 + i];
             int failed = -1;
+            double rdk = 0.0;
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
                 double dk = readlane_d(a[k], k);
-                double yk = a[k];
+                const double yk = a[k];
+                double r;
                 if (!LDLT) {
                     if (!(dk > 0.0)) { if (failed < 0) failed = k; dk = 1.0; }
-                    const double l = sqrt(dk);
-                    a[k] = (i == k) ? l : a[k] / l;
+                    r = rsqrt_newton(dk);            // 1/l
+                    a[k] = (i == k) ? dk * r : a[k] * r;
                 } else {
                     if (dk == 0.0) { if (failed < 0) failed = k; dk = 1.0; }
-                    a[k] = (i == k) ? dk : a[k] / dk;
+                    r = rcp_newton(dk);              // 1/d
+                    a[k] = (i == k) ? dk : a[k] * r;
                 }
+                if (lane == k) rdk = r;
 #pragma unroll
                 for (int j = k + 1; j < 16; ++j) {
                     const double ljk = readlane_d(a[k], j);
@@ -311,6 +333,8 @@ __global__ __launch_bounds__(256) void k_potrf_diag(double* __restrict__ A, int 
             if (lane < 16) {
 #pragma unroll
                 for (int c = 0; c < 16; ++c) if (c <= i) S[(j0 + c) * PLD + j0 + i] = a[c];
+                rd16[lane] = rdk;
+                if (j0 + lane < nb) rdiag[kglobal + j0 + lane] = rdk;
             }
             if (failed >= 0 && lane == 0 && j0 + failed < nb) { if (*info < 0) *info = kglobal + j0 + failed; }
         }
@@ -327,7 +351,7 @@ __global__ __launch_bounds__(256) void k_potrf_diag(double* __restrict__ A, int 
                     double sacc = x[c];
 #pragma unroll
                     for (int q = 0; q < c; ++q) sacc -= (LDLT ? x[q] * S[(j0 + q) * PLD + j0 + q] : x[q]) * S[(j0 + q) * PLD + j0 + c];
-                    x[c] = sacc / S[(j0 + c) * PLD + j0 + c];
+                    x[c] = sacc * rd16[c];
                 }
 #pragma unroll
                 for (int c = 0; c < 16; ++c) S[(j0 + c) * PLD + i] = x[c];
@@ -359,13 +383,11 @@ __global__ __launch_bounds__(256) void k_potrf_diag(double* __restrict__ A, int 
         }
         __syncthreads();
     }
-    for (int idx = tid; idx < nb * nb; idx += 256) {
-        const int r = idx % nb, c = idx / nb;
-        if (r >= c) A[r + (size_t)c * lda] = S[c * PLD + r];
-    }
+    for (int c = wave; c < nb; c += 4)
+        for (int r = c + lane; r < nb; r += 64) A[r + (size_t)c * lda] = S[c * PLD + r];
 }
 
-void launch_potrf_diag(bool ldlt, double* A, int lda, int nb, int kglobal, int* info, hipStream_t s)
+void launch_potrf_diag(bool ldlt, double* A, int lda, int nb, int kglobal, int* info, double* rdiag, hipStream_t s)
 {
     static bool attr_set = false;
     if (!attr_set) {
@@ -373,8 +395,8 @@ void launch_potrf_diag(bool ldlt, double* A, int lda, int nb, int kglobal, int* 
         PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_diag<true>), hipFuncAttributeMaxDynamicSharedMemorySize, POTRF_LDS_BYTES));
         attr_set = true;
     }
-    if (ldlt) hipLaunchKernelGGL(k_potrf_diag<true>, dim3(1), dim3(256), POTRF_LDS_BYTES, s, A, lda, nb, kglobal, info);
-    else hipLaunchKernelGGL(k_potrf_diag<false>, dim3(1), dim3(256), POTRF_LDS_BYTES, s, A, lda, nb, kglobal, info);
+    if (ldlt) hipLaunchKernelGGL(k_potrf_diag<true>, dim3(1), dim3(256), POTRF_LDS_BYTES, s, A, lda, nb, kglobal, info, rdiag);
+    else hipLaunchKernelGGL(k_potrf_diag<false>, dim3(1), dim3(256), POTRF_LDS_BYTES, s, A, lda, nb, kglobal, info, rdiag);
     PQ_HIP(hipGetLastError());
 }
 
@@ -384,32 +406,37 @@ void launch_potrf_diag(bool ldlt, double* A, int lda, int nb, int kglobal, int* 
 // One workgroup per 64 rows; the row block lives in LDS, L11 is read from L2.
 constexpr int RB = 64;
 constexpr int XLD = RB + 16;
-constexpr int TRSM_LDS_BYTES = (NB * XLD + 16 * 17) * (int)sizeof(double);
+constexpr int LSLD = NB + 16;  // leading dimension of the staged L11 strip (rows of L11 contiguous)
+constexpr int TRSM_LDS_BYTES = (NB * XLD + 16 * LSLD + 16) * (int)sizeof(double);
 
 template <bool LDLT>
-__global__ __launch_bounds__(256) void k_trsm_panel(double* __restrict__ A, int lda, int k0, int nb, int n)
+__global__ __launch_bounds__(256) void k_trsm_panel(double* __restrict__ A, int lda, int k0, int nb, int n, const double* __restrict__ rdiag)
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    double* Xs = sm;              // Xs[c * XLD + r], c < nbp, r < RB
-    double* Lj = sm + NB * XLD;   // Lj[q * 17 + c] = L11[j0 + c, j0 + q]
+    double* Xs = sm;                  // Xs[c * XLD + r], c < nbp, r < RB
+    double* Ls = sm + NB * XLD;       // Ls[q * LSLD + rr] = L11[rr, j0 + q]  (rr >= j0), strip of 16 columns
+    double* rd = Ls + 16 * LSLD;      // reciprocal pivots of the strip
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nbp = (nb + 15) & ~15, nt = nbp >> 4;
     const int r0 = k0 + nb + blockIdx.x * RB;
     const double* L11 = A + k0 + (size_t)k0 * lda;
-    for (int idx = tid; idx < RB * nbp; idx += 256) {
-        const int r = idx % RB, c = idx / RB;
+    for (int c = wave; c < nbp; c += 4) {
+        const int r = lane;
         Xs[c * XLD + r] = (r0 + r < n && c < nb) ? A[(r0 + r) + (size_t)(k0 + c) * lda] : 0.0;
     }
-    __syncthreads();
     for (int jb = 0; jb < nt; ++jb) {
         const int j0 = jb * 16;
-        {
-            const int c = tid & 15, q = tid >> 4;  // 256 entries
-            double v = 0.0;
-            if (j0 + c < nb && j0 + q < nb) { if (c >= q) v = L11[(j0 + c) + (size_t)(j0 + q) * lda]; }
-            else if (c == q) v = 1.0;
-            Lj[q * 17 + c] = v;
+        __syncthreads();
+        // stage the 16-column strip of L11 (rows j0 .. nbp) and its reciprocal pivots
+        for (int q = wave; q < 16; q += 4) {
+            for (int rr = j0 + lane; rr < nbp; rr += 64) {
+                double v = 0.0;
+                if (rr < nb && j0 + q < nb) v = L11[rr + (size_t)(j0 + q) * lda];
+                else if (rr == j0 + q) v = 1.0;
+                Ls[q * LSLD + rr] = v;
+            }
         }
+        if (tid < 16) rd[tid] = (j0 + tid < nb) ? rdiag[k0 + j0 + tid] : 1.0;
         __syncthreads();
         if (tid < RB) {
             double x[16];
@@ -419,42 +446,41 @@ __global__ __launch_bounds__(256) void k_trsm_panel(double* __restrict__ A, int 
             for (int c = 0; c < 16; ++c) {
                 double sacc = x[c];
 #pragma unroll
-                for (int q = 0; q < c; ++q) sacc -= x[q] * Lj[q * 17 + c];
-                x[c] = LDLT ? sacc : sacc / Lj[c * 17 + c];
+                for (int q = 0; q < c; ++q) sacc -= x[q] * Ls[q * LSLD + j0 + c];
+                x[c] = LDLT ? sacc : sacc * rd[c];
             }
 #pragma unroll
             for (int c = 0; c < 16; ++c) Xs[(j0 + c) * XLD + tid] = x[c];
         }
         __syncthreads();
-        // update remaining column tiles: Xs[:, ct] -= X_jb * L11[ct, jb]^T
+        // update remaining column tiles: Xs[:, ct] -= X_jb * L11[ct, jb]^T   (MFMA, both operands from LDS)
         const int rem = nt - 1 - jb;
         for (int t = wave; t < rem * 4; t += 4) {
             const int ct = jb + 1 + t / 4, rt = t & 3;
             d4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const int k = j0 + ks * 4 + (lane >> 4);
-                const double xv = Xs[k * XLD + rt * 16 + (lane & 15)];
-                const int lr = ct * 16 + (lane & 15);
-                const double lv = (lr < nb && k < nb) ? L11[lr + (size_t)k * lda] : 0.0;
+                const int kq = ks * 4 + (lane >> 4);
+                const double xv = Xs[(j0 + kq) * XLD + rt * 16 + (lane & 15)];
+                const double lv = Ls[kq * LSLD + ct * 16 + (lane & 15)];
                 acc = __builtin_amdgcn_mfma_f64_16x16x4f64(lv, xv, acc, 0, 0, 0);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) Xs[(ct * 16 + (lane >> 4) + 4 * r) * XLD + rt * 16 + (lane & 15)] -= acc[r];
         }
-        __syncthreads();
     }
-    for (int idx = tid; idx < RB * nb; idx += 256) {
-        const int r = idx % RB, c = idx / RB;
+    __syncthreads();
+    for (int c = wave; c < nb; c += 4) {
+        const int r = lane;
         if (r0 + r < n) {
             double v = Xs[c * XLD + r];
-            if (LDLT) v /= L11[c + (size_t)c * lda];
+            if (LDLT) v *= rdiag[k0 + c];
             A[(r0 + r) + (size_t)(k0 + c) * lda] = v;
         }
     }
 }
 
-void launch_trsm_panel(bool ldlt, double* A, int lda, int k0, int nb, int n, hipStream_t s)
+void launch_trsm_panel(bool ldlt, double* A, int lda, int k0, int nb, int n, const double* rdiag, hipStream_t s)
 {
     const int rs = n - k0 - nb;
     if (rs <= 0) return;
@@ -464,8 +490,8 @@ void launch_trsm_panel(bool ldlt, double* A, int lda, int k0, int nb, int n, hip
         PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_trsm_panel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, TRSM_LDS_BYTES));
         attr_set = true;
     }
-    if (ldlt) hipLaunchKernelGGL(k_trsm_panel<true>, dim3(div_up(rs, RB)), dim3(256), TRSM_LDS_BYTES, s, A, lda, k0, nb, n);
-    else hipLaunchKernelGGL(k_trsm_panel<false>, dim3(div_up(rs, RB)), dim3(256), TRSM_LDS_BYTES, s, A, lda, k0, nb, n);
+    if (ldlt) hipLaunchKernelGGL(k_trsm_panel<true>, dim3(div_up(rs, RB)), dim3(256), TRSM_LDS_BYTES, s, A, lda, k0, nb, n, rdiag);
+    else hipLaunchKernelGGL(k_trsm_panel<false>, dim3(div_up(rs, RB)), dim3(256), TRSM_LDS_BYTES, s, A, lda, k0, nb, n, rdiag);
     PQ_HIP(hipGetLastError());
 }
 
@@ -486,131 +512,199 @@ void launch_extract_diag(const double* A, int lda, int k0, int nb, double* d, hi
 // every row block r >= j first applies the contribution of block column j-1 (whose x is final), then
 // block r == j solves its diagonal block.  The diagonal solve is a single-wave substitution (two rows
 // per lane, v_readlane broadcast of the pivot).  unit_diag/div_d implement dense/ldlt_no_pivot.hpp:446-448.
-constexpr int TB = 128;
-constexpr int TRSV_LDS_BYTES = (TB * (TB + 1) + TB) * (int)sizeof(double);
 
-__global__ __launch_bounds__(256) void k_trsv_fwd_step(const double* __restrict__ L, int ld, int n, double* __restrict__ x, int j, int unit_diag)
+// Single-wave substitution on a 128x128 triangular block held in LDS (Ls[c*(TB+1)+r] = L[r,c], zeros above the
+// diagonal, identity padding).  Lane l owns rows l and l+64.  The block is consumed 16 columns at a time: the 32
+// entries a lane needs are pulled into registers first, then 16 dependent steps run without touching LDS.
+__device__ __forceinline__ void diag_solve_fwd(const double* __restrict__ Ls, const double* __restrict__ rd, int lane, double& b0, double& b1)
+{
+    constexpr int LD = 128 + 1;
+#pragma unroll 1
+    for (int kb = 0; kb < 8; ++kb) {
+        double l0[16], l1[16], rr[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int k = kb * 16 + q;
+            l0[q] = Ls[k * LD + lane];
+            l1[q] = Ls[k * LD + lane + 64];
+            rr[q] = rd[k];
+        }
+        if (kb < 4) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int k = kb * 16 + q;
+                const double piv = readlane_d(b0, k) * rr[q];
+                b0 = (lane == k) ? piv : b0 - l0[q] * piv;
+                b1 -= l1[q] * piv;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int k = kb * 16 + q;
+                const double piv = readlane_d(b1, k - 64) * rr[q];
+                b1 = (lane + 64 == k) ? piv : b1 - l1[q] * piv;
+            }
+        }
+    }
+}
+// L^T y = b on the same staged block: k descending, b_i -= L[k,i] y_k for i < k, L[k,i] = Ls[i*(TB+1)+k]
+__device__ __forceinline__ void diag_solve_bwd(const double* __restrict__ Ls, const double* __restrict__ rd, int lane, double& b0, double& b1)
+{
+    constexpr int LD = 128 + 1;
+#pragma unroll 1
+    for (int kb = 7; kb >= 0; --kb) {
+        double l0[16], l1[16], rr[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int k = kb * 16 + q;
+            l0[q] = (lane < k) ? Ls[lane * LD + k] : 0.0;
+            l1[q] = (lane + 64 < k) ? Ls[(lane + 64) * LD + k] : 0.0;
+            rr[q] = rd[k];
+        }
+        if (kb >= 4) {
+#pragma unroll
+            for (int q = 15; q >= 0; --q) {
+                const int k = kb * 16 + q;
+                const double piv = readlane_d(b1, k - 64) * rr[q];
+                b1 = (lane + 64 == k) ? piv : b1 - l1[q] * piv;
+                b0 -= l0[q] * piv;
+            }
+        } else {
+#pragma unroll
+            for (int q = 15; q >= 0; --q) {
+                const int k = kb * 16 + q;
+                const double piv = readlane_d(b0, k) * rr[q];
+                b0 = (lane == k) ? piv : b0 - l0[q] * piv;
+            }
+        }
+    }
+}
+
+constexpr int TB = 128;
+constexpr int TRSV_LDS_BYTES = (TB * (TB + 1) + 3 * TB) * (int)sizeof(double);
+
+// forward step j: row blocks r >= j subtract L[r, j-1] * x_{j-1}; block r == j then solves L_jj y = b.
+// rdiag = reciprocal diagonal of L (nullptr: unit diagonal).  The diagonal workgroup issues the loads of
+// L_jj before it touches x, so they overlap with the update.
+__global__ __launch_bounds__(256) void k_trsv_fwd_step(const double* __restrict__ L, int ld, int n, double* __restrict__ x, const double* __restrict__ rdiag, int j)
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double* Ls = sm;                    // Ls[c * (TB+1) + r]
-    double* xs = sm + TB * (TB + 1);    // x of block j-1 / rhs of block j
+    double* xs = sm + TB * (TB + 1);    // x of block j-1
+    double* bs = xs + TB;               // partial sums / rhs of block j
+    double* rd = bs + TB;               // reciprocal pivots of block j
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = j + blockIdx.x;
     const int row0 = r * TB, nrows = min(TB, n - row0);
+    const bool diag = (r == j);
+    if (diag) {
+        for (int cc = wave; cc < TB; cc += 4) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int rr = lane + 64 * h;
+                Ls[cc * (TB + 1) + rr] = (rr < nrows && cc < nrows && rr >= cc) ? L[(row0 + rr) + (size_t)(row0 + cc) * ld] : (rr == cc ? 1.0 : 0.0);
+            }
+        }
+        if (tid < TB) rd[tid] = (rdiag && tid < nrows) ? rdiag[row0 + tid] : 1.0;
+    }
+    const int row = tid & 127, half = tid >> 7;
+    double mine = (half == 0 && row < nrows) ? x[row0 + row] : 0.0;
     if (j > 0) {
         const int c0 = (j - 1) * TB;
         if (tid < TB) xs[tid] = x[c0 + tid];
         __syncthreads();
-        // two threads per row, 64 columns each; fixed summation order (deterministic)
-        const int row = tid & 127, half = tid >> 7;
         double sacc = 0.0;
         if (row < nrows) {
             const double* Lp = L + (row0 + row) + (size_t)(c0 + half * 64) * ld;
-#pragma unroll 8
-            for (int c = 0; c < 64; ++c) sacc += Lp[(size_t)c * ld] * xs[half * 64 + c];
+            double lv[64];
+#pragma unroll
+            for (int c = 0; c < 64; ++c) lv[c] = Lp[(size_t)c * ld];  // all 64 loads in flight before the first FMA
+#pragma unroll
+            for (int c = 0; c < 64; ++c) sacc += lv[c] * xs[half * 64 + c];
         }
+        if (half == 1) bs[row] = sacc;
         __syncthreads();
-        if (half == 1) xs[row] = sacc;
-        __syncthreads();
-        if (half == 0 && row < nrows) x[row0 + row] -= (sacc + xs[row]);
+        if (half == 0) mine -= (sacc + bs[row]);
         __syncthreads();
     }
-    if (r != j) return;
-    // diagonal block solve: stage L_jj in LDS, then wave 0 substitutes
-    for (int idx = tid; idx < TB * TB; idx += 256) {
-        const int rr = idx & (TB - 1), cc = idx >> 7;
-        Ls[cc * (TB + 1) + rr] = (rr < nrows && cc < nrows && rr >= cc) ? L[(row0 + rr) + (size_t)(row0 + cc) * ld] : (rr == cc ? 1.0 : 0.0);
+    if (!diag) {
+        if (half == 0 && row < nrows && j > 0) x[row0 + row] = mine;
+        return;
     }
+    if (half == 0) bs[row] = mine;
     __syncthreads();
     if (wave == 0) {
-        double b0 = (lane < nrows) ? x[row0 + lane] : 0.0;
-        double b1 = (lane + 64 < nrows) ? x[row0 + lane + 64] : 0.0;
-        for (int k = 0; k < 64; ++k) {
-            double piv = readlane_d(b0, k);
-            if (!unit_diag) piv /= Ls[k * (TB + 1) + k];
-            if (lane == k) b0 = piv;
-            if (lane > k) b0 -= Ls[k * (TB + 1) + lane] * piv;
-            b1 -= Ls[k * (TB + 1) + lane + 64] * piv;
-        }
-        for (int k = 64; k < 128; ++k) {
-            double piv = readlane_d(b1, k - 64);
-            if (!unit_diag) piv /= Ls[k * (TB + 1) + k];
-            if (lane + 64 == k) b1 = piv;
-            if (lane + 64 > k) b1 -= Ls[k * (TB + 1) + lane + 64] * piv;
-        }
+        double b0 = bs[lane], b1 = bs[lane + 64];
+        diag_solve_fwd(Ls, rd, lane, b0, b1);
         if (lane < nrows) x[row0 + lane] = b0;
         if (lane + 64 < nrows) x[row0 + lane + 64] = b1;
     }
 }
 
-// backward sweep (L^T x = y).  Step j (descending): block rows r <= j apply the contribution of block
-// column j+1 (x_{j+1} final) to x_r -= L[j+1 block, r block]^T x_{j+1}; block r == j then solves L_jj^T.
-__global__ __launch_bounds__(256) void k_trsv_bwd_step(const double* __restrict__ L, int ld, int n, double* __restrict__ x, int j, int nblk, int unit_diag)
+// backward step j (descending): row blocks r <= j subtract L[j+1 block, r block]^T x_{j+1}; block r == j then
+// solves L_jj^T y = b.  The off-diagonal block is transposed through LDS (coalesced loads along the rows
+// of L, conflict-free reads along its columns).
+__global__ __launch_bounds__(256) void k_trsv_bwd_step(const double* __restrict__ L, int ld, int n, double* __restrict__ x, const double* __restrict__ rdiag, int j, int nblk)
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double* Ls = sm;
     double* xs = sm + TB * (TB + 1);
+    double* bs = xs + TB;
+    double* rd = bs + TB;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = blockIdx.x;  // 0..j
     const int row0 = r * TB, nrows = min(TB, n - row0);
+    const bool diag = (r == j);
+    double mine = (tid < nrows) ? x[row0 + tid] : 0.0;
     if (j + 1 < nblk) {
         const int c0 = (j + 1) * TB, nc = min(TB, n - c0);
         if (tid < TB) xs[tid] = (tid < nc) ? x[c0 + tid] : 0.0;
-        __syncthreads();
-        // x_r[i] -= sum_c L[c0 + c, row0 + i] * x_{j+1}[c] : column (row0+i) of L, contiguous in c.
-        // one wave handles 32 of the 128 output rows, lanes stride over c (fixed-order shuffle reduce).
-        for (int ii = 0; ii < 32; ++ii) {
-            const int i = wave * 32 + ii;
-            if (i < nrows) {
-                const double* Lp = L + c0 + (size_t)(row0 + i) * ld;
-                double sacc = 0.0;
-                if (lane < nc) sacc += Lp[lane] * xs[lane];
-                if (lane + 64 < nc) sacc += Lp[lane + 64] * xs[lane + 64];
+        // tile[i * (TB+1) + c] = L[c0 + c, row0 + i]
+        for (int i = wave; i < TB; i += 4) {
 #pragma unroll
-                for (int off = 32; off > 0; off >>= 1) sacc += __shfl_down(sacc, off, 64);
-                if (lane == 0) x[row0 + i] -= sacc;
+            for (int h = 0; h < 2; ++h) {
+                const int c = lane + 64 * h;
+                Ls[i * (TB + 1) + c] = (i < nrows && c < nc) ? L[(c0 + c) + (size_t)(row0 + i) * ld] : 0.0;
             }
         }
         __syncthreads();
+        if (tid < TB) {
+            double sacc = 0.0;
+#pragma unroll 16
+            for (int c = 0; c < TB; ++c) sacc += Ls[tid * (TB + 1) + c] * xs[c];
+            mine -= sacc;
+        }
+        __syncthreads();
     }
-    if (r != j) return;
-    for (int idx = tid; idx < TB * TB; idx += 256) {
-        const int rr = idx & (TB - 1), cc = idx >> 7;
-        Ls[cc * (TB + 1) + rr] = (rr < nrows && cc < nrows && rr >= cc) ? L[(row0 + rr) + (size_t)(row0 + cc) * ld] : (rr == cc ? 1.0 : 0.0);
+    if (!diag) {
+        if (tid < nrows && j + 1 < nblk) x[row0 + tid] = mine;
+        return;
     }
-    __threadfence_block();
+    if (tid < TB) { bs[tid] = mine; rd[tid] = (rdiag && tid < nrows) ? rdiag[row0 + tid] : 1.0; }
+    for (int cc = wave; cc < TB; cc += 4) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int rr = lane + 64 * h;
+            Ls[cc * (TB + 1) + rr] = (rr < nrows && cc < nrows && rr >= cc) ? L[(row0 + rr) + (size_t)(row0 + cc) * ld] : (rr == cc ? 1.0 : 0.0);
+        }
+    }
     __syncthreads();
     if (wave == 0) {
-        // solve L_jj^T y = b : y_k = (b_k - sum_{i>k} L[i,k] y_i) / L[k,k], k descending.
-        // lanes hold b (two per lane); after y_k is known, b_i -= L[k... use row form: for each k descending,
-        // y_k final, then b_i -= L[k, i] * y_k for i < k  (L[k,i] = Ls[i*(TB+1)+k]).
-        double b0 = (lane < nrows) ? x[row0 + lane] : 0.0;
-        double b1 = (lane + 64 < nrows) ? x[row0 + lane + 64] : 0.0;
-        for (int k = 127; k >= 64; --k) {
-            double piv = readlane_d(b1, k - 64);
-            if (!unit_diag) piv /= Ls[k * (TB + 1) + k];
-            if (lane + 64 == k) b1 = piv;
-            if (lane + 64 < k) b1 -= Ls[(lane + 64) * (TB + 1) + k] * piv;
-            b0 -= Ls[lane * (TB + 1) + k] * piv;
-        }
-        for (int k = 63; k >= 0; --k) {
-            double piv = readlane_d(b0, k);
-            if (!unit_diag) piv /= Ls[k * (TB + 1) + k];
-            if (lane == k) b0 = piv;
-            if (lane < k) b0 -= Ls[lane * (TB + 1) + k] * piv;
-        }
+        double b0 = bs[lane], b1 = bs[lane + 64];
+        diag_solve_bwd(Ls, rd, lane, b0, b1);
         if (lane < nrows) x[row0 + lane] = b0;
         if (lane + 64 < nrows) x[row0 + lane + 64] = b1;
     }
 }
 
-__global__ void k_div_diag(const double* __restrict__ L, int ld, int n, double* __restrict__ x)
+__global__ void k_mul_vec(int n, const double* __restrict__ d, double* __restrict__ x)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) x[i] /= L[i + (size_t)i * ld];
+    if (i < n) x[i] *= d[i];
 }
 
-void launch_trsv(const double* L, int ld, int n, double* x, bool ldlt, hipStream_t s)
+// LLT: L y = b, L^T x = y with rdiag = 1/diag(L).  LDLt: unit L, then x *= rdiag (= 1/D), then unit L^T.
+void launch_trsv(const double* L, int ld, int n, double* x, const double* rdiag, bool ldlt, hipStream_t s)
 {
     if (n <= 0) return;
     static bool attr_set = false;
@@ -620,11 +714,12 @@ void launch_trsv(const double* L, int ld, int n, double* x, bool ldlt, hipStream
         attr_set = true;
     }
     const int nblk = div_up(n, TB);
+    const double* rd = ldlt ? nullptr : rdiag;
     for (int j = 0; j < nblk; ++j)
-        hipLaunchKernelGGL(k_trsv_fwd_step, dim3(nblk - j), dim3(256), TRSV_LDS_BYTES, s, L, ld, n, x, j, ldlt ? 1 : 0);
-    if (ldlt) hipLaunchKernelGGL(k_div_diag, dim3(div_up(n, 256)), dim3(256), 0, s, L, ld, n, x);
+        hipLaunchKernelGGL(k_trsv_fwd_step, dim3(nblk - j), dim3(256), TRSV_LDS_BYTES, s, L, ld, n, x, rd, j);
+    if (ldlt) hipLaunchKernelGGL(k_mul_vec, dim3(div_up(n, 256)), dim3(256), 0, s, n, rdiag, x);
     for (int j = nblk - 1; j >= 0; --j)
-        hipLaunchKernelGGL(k_trsv_bwd_step, dim3(j + 1), dim3(256), TRSV_LDS_BYTES, s, L, ld, n, x, j, nblk, ldlt ? 1 : 0);
+        hipLaunchKernelGGL(k_trsv_bwd_step, dim3(j + 1), dim3(256), TRSV_LDS_BYTES, s, L, ld, n, x, rd, j, nblk);
     PQ_HIP(hipGetLastError());
 }
 

@@ -86,7 +86,7 @@ public:
         if (p_ > 0) nsl += dense::launch_gemv_n_partial(n_, p_, AT_.p, n_, rhs_y, nullptr, delta_inv, part_.p + (size_t)nsl * n_, st_);
         dense::launch_reduce_partials(n_, nsl, part_.p, rhs_x, lhs_x, st_);
         // solve_ldlt_in_place: llt.solveInPlace(lhs_x)
-        dense::launch_trsv(fac_.p, n_, n_, lhs_x, ldlt_, st_);
+        dense::launch_trsv(fac_.p, n_, n_, lhs_x, rdiag_.p, ldlt_, st_);
         // lhs_y = delta_inv * AT^T lhs_x - delta_inv * rhs_y
         if (p_ > 0) dense::launch_gemv_t(n_, p_, AT_.p, n_, lhs_x, delta_inv, -delta_inv, rhs_y, nullptr, lhs_y, st_);
         // lhs_z = (GT^T lhs_x - rhs_z) o z_reg_inv
@@ -162,7 +162,7 @@ private:
         alloc();
         auto cp = [&](DBuf<double>& dst, const DBuf<double>& src) { if (src.n) PQ_HIP(hipMemcpyAsync(dst.p, src.p, src.bytes(), hipMemcpyDeviceToDevice, st_)); };
         cp(Pfull_, o.Pfull_); cp(Pdiag_, o.Pdiag_); cp(AT_, o.AT_); cp(GT_, o.GT_); cp(ATA_, o.ATA_); cp(fac_, o.fac_);
-        cp(z_reg_inv_, o.z_reg_inv_); cp(x_reg_last_, o.x_reg_last_);
+        cp(z_reg_inv_, o.z_reg_inv_); cp(x_reg_last_, o.x_reg_last_); cp(rdiag_, o.rdiag_);
         PQ_HIP(hipStreamSynchronize(st_));
     }
 
@@ -173,7 +173,7 @@ private:
         AT_.alloc((size_t)n_ * p_); GT_.alloc((size_t)n_ * m_);
         if (p_ > 0) ATA_.alloc(nn);
         fac_.alloc(nn);
-        z_reg_inv_.alloc(m_); x_reg_last_.alloc(n_); dvec_.alloc(dense::FACTOR_NB);
+        z_reg_inv_.alloc(m_); x_reg_last_.alloc(n_); dvec_.alloc(dense::FACTOR_NB); rdiag_.alloc(n_);
         const int sl = dense::gemv_n_slices(n_, m_ > 0 ? m_ : 1) + dense::gemv_n_slices(n_, p_ > 0 ? p_ : 1) + dense::gemv_n_slices(n_, n_);
         part_.alloc((size_t)sl * n_);
         info_.alloc(1);
@@ -223,9 +223,9 @@ private:
             const int nb = (n_ - k < NB) ? n_ - k : NB;
             const int rs = n_ - k - nb;
             double* A11 = fac_.p + k + (size_t)k * n_;
-            dense::launch_potrf_diag(ldlt_, A11, n_, nb, k, info_.p, st_);
+            dense::launch_potrf_diag(ldlt_, A11, n_, nb, k, info_.p, rdiag_.p, st_);
             if (rs > 0) {
-                dense::launch_trsm_panel(ldlt_, fac_.p, n_, k, nb, n_, st_);
+                dense::launch_trsm_panel(ldlt_, fac_.p, n_, k, nb, n_, rdiag_.p, st_);
                 dense::SyrkArgs a;
                 a.n = rs; a.kdim = nb;
                 a.A = fac_.p + (k + nb) + (size_t)k * n_; a.lda = n_;
@@ -248,7 +248,7 @@ private:
     bool ldlt_;
     double delta_ = 1.0;
     hipStream_t st_ = nullptr;
-    DBuf<double> Pfull_, Pdiag_, AT_, GT_, ATA_, fac_, z_reg_inv_, x_reg_last_, dvec_, part_;
+    DBuf<double> Pfull_, Pdiag_, AT_, GT_, ATA_, fac_, z_reg_inv_, x_reg_last_, dvec_, part_, rdiag_;
     DBuf<int> info_;
     HBuf<int> info_h_;
     StageProfiler prof_;

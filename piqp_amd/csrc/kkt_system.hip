@@ -285,7 +285,7 @@ void KKTSystem::alloc()
     rhs_x_bar.alloc(n); rhs_z_bar.alloc(m);
     work_x.alloc(n); work_x2.alloc(n); work_x3.alloc(n); work_y.alloc(p); work_z.alloc(m); work_z2.alloc(m); lhs_z_buf.alloc(m);
     ref_err_x.alloc(n); ref_err_y.alloc(p); ref_err_z.alloc(m);
-    ref_lhs_x.alloc(n); ref_lhs_y.alloc(p); ref_lhs_z.alloc(m);
+    ref_lhs_x.alloc(n); ref_lhs_y.alloc(p); ref_lhs_z.alloc(m); rhs_y_keep.alloc(p);
     has_l.alloc(m); has_u.alloc(m); pos_l.alloc(n); pos_u.alloc(n);
     h_l_idx.alloc(m); h_u_idx.alloc(m); x_l_idx.alloc(n); x_u_idx.alloc(n);
     x_b_scaling.alloc(n);
@@ -417,6 +417,8 @@ bool KKTSystem::solve(const pq_vars& rhs, pq_vars& lhs)
 
     kkt_solver->solve(rhs_x_bar.p, rhs.y, rhs_z_bar.p, lhs.x, lhs.y, lhs_z);
     last_backend_solves++;
+    d2d(rhs_y_keep.p, rhs.y, p, st_);  // kept for condensed_residual(); the caller may reuse its buffer
+    last_rhs_y = rhs_y_keep.p;
 
     if (use_iterative_refinement) {
         // :259  rhs_norm

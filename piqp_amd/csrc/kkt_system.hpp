@@ -61,7 +61,7 @@ private:
     DBuf<double> m_s_l, m_s_u, m_s_bl, m_s_bu, m_z_l_inv, m_z_u_inv, m_z_bl_inv, m_z_bu_inv;
     DBuf<double> m_x_reg, m_z_reg, rhs_x_bar, rhs_z_bar;
     DBuf<double> work_x, work_x2, work_x3, work_y, work_z, work_z2, lhs_z_buf;
-    DBuf<double> ref_err_x, ref_err_y, ref_err_z, ref_lhs_x, ref_lhs_y, ref_lhs_z;
+    DBuf<double> ref_err_x, ref_err_y, ref_err_z, ref_lhs_x, ref_lhs_y, ref_lhs_z, rhs_y_keep;
     bool use_iterative_refinement = false;  // kkt_system.hpp:64
     bool finite_check_pending = false;
 

@@ -19,11 +19,12 @@ def _min_eig_sym_from_upper(U):
     return float(np.linalg.eigvalsh(S).min())
 
 
-def dense_strongly_convex_qp(dim, n_eq, n_ineq, seed=42, bounds_perc=0.5, strong_convexity_factor=1e-2, double_sided=False):
+def dense_strongly_convex_qp(dim, n_eq, n_ineq, seed=42, bounds_perc=0.5, strong_convexity_factor=1e-2, double_sided=False, exact_shift=True):
     """returns dict(P, c, A, b, G, h_l, h_u, x_l, x_u); P holds the upper triangle only (like the reference's Model)"""
     rng = np.random.default_rng(seed)
     P = np.triu(rng.standard_normal((dim, dim)), 1)
-    lam_min = _min_eig_sym_from_upper(P)
+    # |lambda_min| of a symmetric N(0,1) matrix -> 2 sqrt(n) (semicircle law); exact_shift=False avoids the O(n^3) eig
+    lam_min = _min_eig_sym_from_upper(P) if exact_shift else -2.2 * np.sqrt(dim)
     P[np.arange(dim), np.arange(dim)] += strong_convexity_factor + abs(lam_min)
     A = rng.standard_normal((n_eq, dim))
     G = rng.standard_normal((n_ineq, dim))
