@@ -3,6 +3,6 @@
 Only the hot path: KKT factor / solve / iterative refinement behind PIQP's KKTSolverBase + KKTSystem
 interface, as hand-written HIP kernels behind the C-ABI of include/piqp_amd.h.  No CPU fallback.
 """
-from . import _lib  # noqa: F401
+from . import _lib, kkt  # noqa: F401
 from .kkt import (DENSE_CHOLESKY, DENSE_LDLT_NO_PIVOT, KKT_UPDATE_A, KKT_UPDATE_G, KKT_UPDATE_NONE, KKT_UPDATE_P,  # noqa: F401
-                  Data, DenseKKT, KKTSystem, Variables, default_settings)
+                  Data, DenseKKT, DenseSolver, KKTSystem, SparseSolver, Variables, default_settings)

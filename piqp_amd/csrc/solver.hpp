@@ -1,4 +1,127 @@
-// piqp_amd/csrc/solver.hpp -- host-side DenseSolver/SparseSolver front-end (reference solver.hpp) over the
-// device-resident KKTSystem.  Declared here, defined in solver.cpp; exported through capi (pq_solver_*).
+// piqp_amd/csrc/solver.hpp -- host-side front end: piqp::DenseSolver / SparseSolver (reference solver.hpp)
+// over the device-resident KKTSystem.  The interior-point loop is the CALLER of the hot path: it is
+// restated here on the host so that iteration counts can be compared with the CPU path; every
+// KKT factor / solve / mat-vec it issues goes to the GPU through pq::KKTSystem.
 #pragma once
-#include "common.hpp"
+
+#include <memory>
+#include <vector>
+
+#include "kkt_system.hpp"
+
+namespace pq {
+
+using Vec = std::vector<double>;
+using IVec = std::vector<int>;
+
+// compressed sparse column, int32 / fp64 (typedefs.hpp:53-54)
+struct Csc {
+    int rows = 0, cols = 0;
+    IVec colptr, rowind;
+    Vec val;
+    int nnz() const { return colptr.empty() ? 0 : colptr[cols]; }
+};
+
+// dense::Data<T> (dense/data.hpp:22-208) and sparse::Data<T,I> (sparse/data.hpp:26-231) in one struct
+struct HostData {
+    bool sparse = false;
+    int n = 0, p = 0, m = 0;
+    Vec P_utri, AT, GT;  // dense, column-major (n x n, n x p, n x m)
+    Csc sP_utri, sAT, sGT;
+    Vec c, b, h_l, h_u, x_l, x_u, x_b_scaling;
+    int n_h_l = 0, n_h_u = 0, n_x_l = 0, n_x_u = 0;
+    IVec h_l_idx, h_u_idx, x_l_idx, x_u_idx;
+
+    void resize_vectors();
+    void set_h_l(const double* v);
+    void set_h_u(const double* v);
+    void disable_inf_constraints();
+    void set_x_l(const double* v);
+    void set_x_u(const double* v);
+    pq_dense_data dense_descriptor() const;
+    pq_sparse_data sparse_descriptor() const;
+};
+
+// dense::RuizEquilibration / sparse::RuizEquilibration (dense/preconditioner.hpp, sparse/preconditioner.hpp)
+struct Ruiz {
+    int n = 0, p = 0, m = 0;
+    double c = 1.0, c_inv = 1.0;
+    Vec delta, delta_b, delta_inv, delta_b_inv;
+    void init(const HostData& d);
+    void scale_data(HostData& d, bool reuse_prev_scaling, bool scale_cost, int max_iter, double epsilon = 1e-3);
+    void unscale_data(HostData& d);
+};
+
+struct HostVars {
+    Vec x, y, z_l, z_u, z_bl, z_bu, s_l, s_u, s_bl, s_bu;
+    void resize(int n, int p, int m);
+    Vec& field(int k);
+    const Vec& field(int k) const { return const_cast<HostVars*>(this)->field(k); }
+};
+
+class Solver {
+public:
+    explicit Solver(int device);
+    ~Solver();
+    Solver* clone() const;
+
+    pq_settings& settings() { return m_settings; }
+    bool setup(std::unique_ptr<HostData> data);  // solver.hpp:151-216
+    bool update_dense(const double* P, const double* c, const double* A, const double* b, const double* G, const double* h_l, const double* h_u, const double* x_l,
+                      const double* x_u);  // solver.hpp:218-308
+    bool update_sparse(const int* Pp, const int* Pi, const double* Px, const double* c, const int* Ap, const int* Ai, const double* Ax, const double* b, const int* Gp,
+                       const int* Gi, const double* Gx, const double* h_l, const double* h_u, const double* x_l, const double* x_u);
+    int solve();  // solver.hpp:69-148
+    const pq_info& info() const { return m_info; }
+    const HostVars& result() const { return m_result; }
+    const HostData* data() const { return m_data.get(); }
+    void set_trace(double* buf, int max_rows) { trace_ = buf; trace_max_ = max_rows; trace_rows_ = 0; }
+    int trace_rows() const { return trace_rows_; }
+    int device() const { return device_; }
+
+private:
+    int solve_impl();
+    bool kkt_factor();
+    void kkt_solve(const HostVars& rhs, HostVars& lhs);
+    void eval_P_x(double alpha, const Vec& x, Vec& z);
+    void eval_A(double an, double at, const Vec& xn, const Vec& xt, Vec& zn, Vec& zt);
+    void eval_G(double an, double at, const Vec& xn, const Vec& xt, Vec& zn, Vec& zt);
+    double calculate_mu() const;
+    void calculate_step(double& alpha_s, double& alpha_z) const;
+    void update_residuals_nr();
+    void update_residuals_r();
+    double primal_res_of(const HostVars& v) const;
+    double dual_res_of(const Vec& x) const;
+    double primal_prox_inf() const;
+    double dual_prox_inf() const;
+    void unscale_results();
+    void restore_dual();
+    void make_kkt();
+    void stage_alloc();
+    void to_device(const HostVars& h, pq_vars& d);
+    void from_device(const pq_vars& d, HostVars& h);
+
+    int device_;
+    pq_settings m_settings;
+    pq_info m_info{};
+    std::unique_ptr<HostData> m_data;
+    Ruiz m_preconditioner;
+    std::unique_ptr<KKTSystem> m_kkt_system;
+    bool m_first_run = true, m_setup_done = false, m_enable_iterative_refinement = false;
+    HostVars m_result, res_nr, res, step, prox_vars;
+
+    // device staging: two Variables sets + three work vectors per size class
+    std::vector<DBuf<double>> dev_in_, dev_out_;
+    pq_vars din_{}, dout_{};
+    DBuf<double> dxa_, dxb_, dxc_, dya_, dyb_, dza_, dzb_;
+    double* trace_ = nullptr;
+    int trace_max_ = 0, trace_rows_ = 0;
+};
+
+std::unique_ptr<HostData> make_dense_host_data(int n, int p, int m, const double* P, const double* c, const double* A, const double* b, const double* G, const double* h_l,
+                                               const double* h_u, const double* x_l, const double* x_u);
+std::unique_ptr<HostData> make_sparse_host_data(int n, int p, int m, const int* Pp, const int* Pi, const double* Px, const double* c, const int* Ap, const int* Ai,
+                                                const double* Ax, const double* b, const int* Gp, const int* Gi, const double* Gx, const double* h_l, const double* h_u,
+                                                const double* x_l, const double* x_u);
+
+}  // namespace pq

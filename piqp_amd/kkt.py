@@ -346,3 +346,101 @@ class KKTSystem(_Handle):
 
     def synchronize(self):
         check(self.L.pq_kktsys_synchronize(self.h))
+
+
+# results.hpp:18-27
+PIQP_SOLVED, PIQP_MAX_ITER_REACHED, PIQP_PRIMAL_INFEASIBLE, PIQP_DUAL_INFEASIBLE = 1, -1, -2, -3
+PIQP_NUMERICS, PIQP_UNSOLVED, PIQP_INVALID_SETTINGS = -8, -9, -10
+
+
+class DenseSolver(_Handle):
+    """piqp::DenseSolver<T> (solver.hpp:1262-1291): setup / update / solve / result over pq_solver_*.
+    The interior-point loop runs on the host; every KKT factor, solve and mat-vec runs on the GPU."""
+    _destroy = "pq_solver_destroy"
+    _sparse = False
+
+    def __init__(self, device=0, _h=None):
+        self.L = _lib.load()
+        if _h is not None:
+            self.h = _h
+        else:
+            h = C.c_void_p()
+            check(self.L.pq_solver_create(C.byref(h), device), "pq_solver_create")
+            self.h = h
+        self._trace = None
+
+    @property
+    def settings(self):
+        return self.L.pq_solver_settings(self.h).contents
+
+    def clone(self):
+        h = C.c_void_p()
+        check(self.L.pq_solver_clone(self.h, C.byref(h)))
+        return type(self)(_h=h)
+
+    @staticmethod
+    def _col(a):
+        return None if a is None else np.asfortranarray(a, dtype=np.float64)
+
+    @staticmethod
+    def _vec(a):
+        return None if a is None else np.ascontiguousarray(a, dtype=np.float64)
+
+    def setup(self, P, c, A=None, b=None, G=None, h_l=None, h_u=None, x_l=None, x_u=None):
+        P = self._col(P)
+        n = P.shape[0]
+        p = 0 if A is None else np.asarray(A).shape[0]
+        m = 0 if G is None else np.asarray(G).shape[0]
+        keep = [P, self._vec(c), self._col(A), self._vec(b), self._col(G), self._vec(h_l), self._vec(h_u), self._vec(x_l), self._vec(x_u)]
+        return bool(check(self.L.pq_solver_setup_dense(self.h, n, p, m, *[_ptr(a) for a in keep]), "setup"))
+
+    def update(self, P=None, c=None, A=None, b=None, G=None, h_l=None, h_u=None, x_l=None, x_u=None):
+        keep = [self._col(P), self._vec(c), self._col(A), self._vec(b), self._col(G), self._vec(h_l), self._vec(h_u), self._vec(x_l), self._vec(x_u)]
+        return bool(check(self.L.pq_solver_update_dense(self.h, *[_ptr(a) for a in keep]), "update"))
+
+    def enable_trace(self, max_rows=512):
+        self._trace = np.zeros((max_rows, 11))
+        check(self.L.pq_solver_set_trace(self.h, self._trace.ctypes.data, max_rows))
+
+    def trace(self):
+        return self._trace[: self.L.pq_solver_trace_rows(self.h)].copy()
+
+    def solve(self):
+        return self.L.pq_solver_solve(self.h)
+
+    @property
+    def info(self):
+        return self.L.pq_solver_info(self.h).contents
+
+    def result(self):
+        n, p, m = C.c_int(), C.c_int(), C.c_int()
+        check(self.L.pq_solver_dims(self.h, C.byref(n), C.byref(p), C.byref(m)))
+        out = Variables.zeros(n.value, p.value, m.value)
+        vs = Variables.to_struct(out)
+        check(self.L.pq_solver_get_result(self.h, C.byref(vs)))
+        return out
+
+
+class SparseSolver(DenseSolver):
+    """piqp::SparseSolver<T,I> (solver.hpp:1293-1322): CSC inputs."""
+    _sparse = True
+
+    @staticmethod
+    def _csc(M):
+        import scipy.sparse as sp
+        if M is None:
+            return [None, None, None]
+        M = sp.csc_matrix(M)
+        M.sort_indices()
+        return [np.ascontiguousarray(M.indptr, dtype=np.int32), np.ascontiguousarray(M.indices, dtype=np.int32), np.ascontiguousarray(M.data, dtype=np.float64)]
+
+    def setup(self, P, c, A=None, b=None, G=None, h_l=None, h_u=None, x_l=None, x_u=None):
+        n = P.shape[0]
+        p = 0 if A is None else A.shape[0]
+        m = 0 if G is None else G.shape[0]
+        keep = self._csc(P) + [self._vec(c)] + self._csc(A) + [self._vec(b)] + self._csc(G) + [self._vec(h_l), self._vec(h_u), self._vec(x_l), self._vec(x_u)]
+        return bool(check(self.L.pq_solver_setup_sparse(self.h, n, p, m, *[_ptr(a) for a in keep]), "setup"))
+
+    def update(self, P=None, c=None, A=None, b=None, G=None, h_l=None, h_u=None, x_l=None, x_u=None):
+        keep = self._csc(P) + [self._vec(c)] + self._csc(A) + [self._vec(b)] + self._csc(G) + [self._vec(h_l), self._vec(h_u), self._vec(x_l), self._vec(x_u)]
+        return bool(check(self.L.pq_solver_update_sparse(self.h, *[_ptr(a) for a in keep]), "update"))

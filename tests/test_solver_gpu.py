@@ -1,0 +1,118 @@
+"""GPU tests of the solver front end (host IPM loop over the device KKTSystem): the reference's known answers
+(tests/src/dense/solver_test.cpp), and iteration-count / trajectory parity with the CPU oracle on the same inputs
+(north_star: "identical iteration counts")."""
+import numpy as np
+import pytest
+
+from qp_gen import dense_strongly_convex_qp
+from qp_io import dense_args, load_json, load_qp
+
+pytestmark = pytest.mark.gpu
+inf = np.inf
+
+
+def _both(hip, orc, args, kkt_solver=0, **settings):
+    sh, so = hip.DenseSolver(), orc.Solver()
+    for s in (sh.settings, so.settings):
+        s.kkt_solver = kkt_solver
+        for k, v in settings.items():
+            setattr(s, k, v)
+    sh.enable_trace(); so.enable_trace()
+    assert sh.setup(*args) and so.setup(*args)
+    return sh, so, sh.solve(), so.solve()
+
+
+def test_simple_qp_with_update(hip, orc):
+    """dense/solver_test.cpp:31-97"""
+    kat = load_json("kat_small.json")["dense_simple_qp"]
+    P = np.array([[6.0, 0], [0, 4]]); c = np.array([-1.0, -4]); A = np.array([[1.0, -2]]); b = np.array([0.0])
+    G = np.array([[1.0, 0], [1, 0], [1, 0]]); h_l = np.array([-1, -inf, -2]); h_u = np.array([inf, 1, 2.0])
+    x_l = np.array([-inf, -1]); x_u = np.array([inf, 1.0])
+    s = hip.DenseSolver()
+    assert s.setup(P, c, A, b, G, h_l, h_u, x_l, x_u)
+    assert s.solve() == hip.kkt.PIQP_SOLVED
+    r = s.result()
+    assert np.allclose(r["x"], kat["x"], atol=1e-6) and np.allclose(r["y"], kat["y"], atol=1e-6)
+    for k in ("z_l", "z_u", "z_bl", "z_bu"):
+        assert np.allclose(r[k], 0, atol=1e-6)
+    P[0, 0] = 8; A[0, 1] = -3; h_u[0] = 2; x_u[1] = 2
+    assert s.update(P, c, A, b, None, None, h_u, None, x_u)
+    assert s.solve() == hip.kkt.PIQP_SOLVED
+    r = s.result()
+    assert np.allclose(r["x"], kat["x_after_update"], atol=1e-6) and np.allclose(r["y"], kat["y_after_update"], atol=1e-6)
+
+
+def test_infeasibility_statuses_and_infinity_bounds(hip):
+    """dense/solver_test.cpp:103-154, 347-377"""
+    P = np.array([[6.0, 0], [0, 4]]); c = np.array([-1.0, -4]); A = np.array([[1.0, -2]]); b = np.array([0.0])
+    G = np.array([[1.0, 0], [0, 1], [-1, 0], [0, -1]]); h = np.array([0.0, 2, 1, -1])
+    s = hip.DenseSolver(); s.setup(P, c, A, b, G, None, h)
+    assert s.solve() == hip.kkt.PIQP_PRIMAL_INFEASIBLE
+    s = hip.DenseSolver(); s.setup(np.zeros((2, 2)), np.array([-1.0, -1]), None, None, np.array([[-1.0, 0], [0, -1]]), None, np.zeros(2))
+    assert s.solve() == hip.kkt.PIQP_DUAL_INFEASIBLE
+    G = np.array([[1.0, 0, 0, 0], [1, 0, -1, 0], [-1, 0, -1, 0], [-1, 0, 0, 0], [-1, 0, 1, 0], [1, 0, 1, 0]])
+    s = hip.DenseSolver(); s.setup(np.eye(4), np.ones(4), None, None, G, None, np.array([1, 1, 1, 1, inf, inf]))
+    assert s.solve() == hip.kkt.PIQP_SOLVED
+    assert np.allclose(s.result()["x"], [-0.5, -1, -0.5, -1], atol=1e-6)
+
+
+def test_ill_conditioned_small(hip, orc):
+    """dense/solver_test.cpp:156-182 (exercises the factor-failure -> refinement -> regularisation retry path)"""
+    P = np.diag([61, 2e9, 61, 2e9, 1000, 100.0]); c = np.zeros(6)
+    A = np.array([[1.0, 0, 1, 0, 1, 0], [2.4, 0, -2.4, 0, 0, 1]]); b = np.zeros(2)
+    x_l = np.array([-2e4, -0.3491, -2e4, -0.3491, -inf, -inf]); x_u = np.array([2e4, 0.3491, 2e4, 0.3491, inf, inf])
+    sh, so, st_h, st_o = _both(hip, orc, (P, c, A, b, None, None, None, x_l, x_u))
+    assert st_h == st_o == 1
+    assert sh.info.iter == so.info.iter
+
+
+@pytest.mark.parametrize("kkt_solver", [0, 16])
+@pytest.mark.parametrize("dims", [(20, 10, 12), (30, 0, 20), (25, 10, 0), (60, 20, 40), (200, 50, 100)])
+def test_iteration_parity_random_qp(hip, orc, kkt_solver, dims):
+    """same iteration count, same status and the same trajectory as the CPU path on the same inputs"""
+    n, p, m = dims
+    q = dense_strongly_convex_qp(n, p, m, seed=5 * n + m)
+    args = (q["P"], q["c"], q["A"], q["b"], q["G"], q["h_l"], q["h_u"], q["x_l"], q["x_u"])
+    sh, so, st_h, st_o = _both(hip, orc, args, kkt_solver)
+    assert st_h == st_o == 1
+    assert sh.info.iter == so.info.iter
+    th, to = sh.trace(), so.trace()
+    assert th.shape == to.shape
+    assert np.allclose(th[:, 6:9], to[:, 6:9], rtol=1e-6)  # rho, delta, mu
+    rh, ro = sh.result(), so.result()
+    assert np.allclose(rh["x"], ro["x"], rtol=1e-6, atol=1e-8)
+    assert abs(sh.info.primal_obj - so.info.primal_obj) <= 1e-8 * (1 + abs(so.info.primal_obj))
+
+
+def test_c0_notebook_trace(hip, orc):
+    """the recorded reference trace through the GPU-backed solver: 12 iterations, objective 4451.73"""
+    q = load_qp("qp_c0_scenario_mpc")
+    tr = load_json("c0_trace.json")
+    sh, so, st_h, st_o = _both(hip, orc, dense_args(q))
+    assert st_h == st_o == 1
+    assert sh.info.iter == so.info.iter == tr["iterations"]
+    assert abs(sh.info.primal_obj - tr["objective_scipy_trust_constr"]) < 1e-3
+    ref = np.array(tr["rows"])
+    t = sh.trace()
+    for col, rtol in ((1, 2e-6), (2, 2e-5), (4, 2e-5), (6, 1e-3), (7, 1e-3), (8, 1e-3)):
+        assert np.allclose(t[:, col], ref[:, col], rtol=rtol, atol=1e-12), col
+
+
+@pytest.mark.parametrize("name", ["qp_small_dense", "qp_scenario_mpc_small", "qp_chain_mass_sqp", "qp_robot_arm_sqp", "mm_HS21", "mm_HS118", "mm_DUAL1",
+                                  "mm_CVXQP1_S", "mm_QAFIRO"])
+def test_fixture_iteration_parity(hip, orc, name):
+    """reference fixtures (tests/data, benchmarks/data, Maros-Meszaros) through the dense path: SOLVED, same iterations"""
+    q = load_qp(name)
+    sh, so, st_h, st_o = _both(hip, orc, dense_args(q))
+    assert st_h == st_o == 1
+    assert abs(sh.info.iter - so.info.iter) <= (0 if so.info.iter < 30 else 1)
+
+
+def test_clone_bitwise(hip):
+    """dense/solver_test.cpp:379-401 CopyConstructor: ASSERT_EQ(solver1.result().x, solver2.result().x)"""
+    q = dense_strongly_convex_qp(20, 10, 12, seed=77)
+    s1 = hip.DenseSolver()
+    assert s1.setup(q["P"], q["c"], q["A"], q["b"], q["G"], q["h_l"], q["h_u"], q["x_l"], q["x_u"])
+    s2 = s1.clone()
+    assert s1.solve() == 1 and s2.solve() == 1
+    assert np.array_equal(s1.result()["x"], s2.result()["x"])
