@@ -1,0 +1,728 @@
+/*
+ * oracle/orc_sparse.c -- CPU restatement of PIQP's sparse KKT backend (TEST INFRASTRUCTURE ONLY).
+ *
+ * Follows (paths under /root/reference/include/piqp/):
+ *   sparse/ldlt.hpp:42-99     LDLt::factorize_symbolic_upper_triangular (etree + column counts)
+ *   sparse/ldlt.hpp:101-169   LDLt::factorize_numeric_upper_triangular  (up-looking, no FMA: this file is
+ *                             compiled with -ffp-contract=off, cf. the comments at :151,:156)
+ *   sparse/ldlt.hpp:171-218   lsolve / dsolve / ltsolve
+ *   sparse/utils.hpp:32-128   permute_sparse_symmetric_matrix (returns the A-index -> C-index map)
+ *   sparse/ordering.hpp:67-124 AMDOrdering (P[new] = old, perm / permt)
+ *   sparse/kkt_full.hpp:39-251 KKTImpl<KKT_FULL>: create_kkt_matrix, update_kkt_*_scalings, update_data_impl
+ *   sparse/kkt.hpp:51-203     sparse::KKT ctor / update_scalings_and_factor / solve / eval_*
+ *
+ * Eigen::AMDOrdering is third-party and absent from the image; orc_amd_order restates the published
+ * approximate-minimum-degree algorithm (Amestoy, Davis, Duff, SIAM J. Matrix Anal. Appl. 17(4), 1996;
+ * the quotient-graph form of Davis' "Direct Methods for Sparse Linear Systems", ch. 7, which Eigen's Amd.h
+ * derives from): A+A' with diagonal, dense-row threshold max(16, 10 sqrt(n)), approximate external degrees,
+ * aggressive absorption, supervariable detection by hashing, mass elimination, final assembly-tree postorder.
+ * It is pinned on the reference's exact 4x4 case (tests/src/sparse/utils_test.cpp:55-92); on larger inputs the
+ * permutation is "parity unpinned" -- only its validity and fill quality are tested.
+ *
+ * Only KKT_FULL (sparse_ldlt) is restated in this round; the condensed modes are SURVEY.md 8(f) rank 2.
+ */
+#include "orc.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+static int *ialloc(size_t n) { int *p = (int *)calloc(n ? n : 1, sizeof(int)); if (!p) abort(); return p; }
+static double *dalloc(size_t n) { double *p = (double *)calloc(n ? n : 1, sizeof(double)); if (!p) abort(); return p; }
+static int *idup(const int *s, size_t n) { int *p = ialloc(n); if (n) memcpy(p, s, n * sizeof(int)); return p; }
+static double *ddup(const double *s, size_t n) { double *p = dalloc(n); if (n) memcpy(p, s, n * sizeof(double)); return p; }
+
+/* =============================================================================================== LDLt */
+struct orc_sparse_ldlt {
+    int n;
+    int *etree, *L_cols, *L_nnz, *L_ind;
+    double *L_vals, *D, *D_inv;
+    int *flag, *pattern;
+    double *y;
+};
+
+orc_sparse_ldlt *orc_sparse_ldlt_create(void) { return (orc_sparse_ldlt *)calloc(1, sizeof(orc_sparse_ldlt)); }
+static void ldlt_release(orc_sparse_ldlt *f)
+{
+    free(f->etree); free(f->L_cols); free(f->L_nnz); free(f->L_ind); free(f->L_vals); free(f->D); free(f->D_inv);
+    free(f->flag); free(f->pattern); free(f->y);
+    memset(f, 0, sizeof(*f));
+}
+void orc_sparse_ldlt_free(orc_sparse_ldlt *f) { if (f) { ldlt_release(f); free(f); } }
+int orc_sparse_ldlt_nnz(const orc_sparse_ldlt *f) { return f->L_cols ? f->L_cols[f->n] : 0; }
+
+static orc_sparse_ldlt *ldlt_clone(const orc_sparse_ldlt *s)
+{
+    orc_sparse_ldlt *f = orc_sparse_ldlt_create();
+    int n = s->n, nnz = s->L_cols ? s->L_cols[n] : 0;
+    f->n = n;
+    f->etree = idup(s->etree, n); f->L_cols = idup(s->L_cols, n + 1); f->L_nnz = idup(s->L_nnz, n); f->L_ind = idup(s->L_ind, nnz);
+    f->L_vals = ddup(s->L_vals, nnz); f->D = ddup(s->D, n); f->D_inv = ddup(s->D_inv, n);
+    f->flag = idup(s->flag, n); f->pattern = idup(s->pattern, n); f->y = ddup(s->y, n);
+    return f;
+}
+
+/* sparse/ldlt.hpp:42-99 */
+void orc_sparse_ldlt_symbolic(orc_sparse_ldlt *f, int n, const int *Ap, const int *Ai)
+{
+    ldlt_release(f);
+    f->n = n;
+    f->etree = ialloc(n); f->L_cols = ialloc(n + 1); f->L_nnz = ialloc(n);
+    f->D = dalloc(n); f->D_inv = dalloc(n);
+    f->flag = ialloc(n); f->pattern = ialloc(n); f->y = dalloc(n);
+    for (int k = 0; k < n; k++) {
+        f->etree[k] = -1;
+        f->flag[k] = k;
+        f->L_nnz[k] = 0;
+        for (int p = Ap[k]; p < Ap[k + 1]; p++) {
+            int i = Ai[p];
+            for (; f->flag[i] != k; i = f->etree[i]) {
+                if (f->etree[i] == -1) f->etree[i] = k;
+                f->L_nnz[i]++;
+                f->flag[i] = k;
+            }
+        }
+    }
+    f->L_cols[0] = 0;
+    for (int k = 0; k < n; k++) f->L_cols[k + 1] = f->L_cols[k] + f->L_nnz[k];
+    f->L_ind = ialloc(f->L_cols[n]);
+    f->L_vals = dalloc(f->L_cols[n]);
+}
+
+/* sparse/ldlt.hpp:101-169; returns n on success, k on D[k] == 0 */
+int orc_sparse_ldlt_numeric(orc_sparse_ldlt *f, int n, const int *Ap, const int *Ai, const double *Ax)
+{
+    int *flag = f->flag, *pattern = f->pattern, *etree = f->etree, *L_cols = f->L_cols, *L_nnz = f->L_nnz, *L_ind = f->L_ind;
+    double *y = f->y, *D = f->D, *L_vals = f->L_vals;
+    for (int k = 0; k < n; k++) {
+        y[k] = 0.0;
+        int top = n;
+        flag[k] = k;
+        L_nnz[k] = 0;
+        for (int p = Ap[k]; p < Ap[k + 1]; p++) {
+            int i = Ai[p];
+            y[i] = Ax[p];
+            int len;
+            for (len = 0; flag[i] != k; i = etree[i]) {
+                pattern[len++] = i;
+                flag[i] = k;
+            }
+            while (len > 0) pattern[--top] = pattern[--len];
+        }
+        D[k] = y[k];
+        y[k] = 0.0;
+        for (; top < n; top++) {
+            int i = pattern[top];
+            double yi = y[i];
+            y[i] = 0.0;
+            int p2 = L_cols[i] + L_nnz[i];
+            int p;
+            for (p = L_cols[i]; p < p2; p++) {
+                double tmp = L_vals[p] * yi; /* two roundings, as the reference forces */
+                y[L_ind[p]] -= tmp;
+            }
+            double l_ki = yi / D[i];
+            double tmp = l_ki * yi;
+            D[k] -= tmp;
+            L_ind[p] = k;
+            L_vals[p] = l_ki;
+            L_nnz[i]++;
+        }
+        if (D[k] == 0.0) return k;
+    }
+    for (int k = 0; k < n; k++) f->D_inv[k] = 1.0 / D[k];
+    return n;
+}
+
+/* sparse/ldlt.hpp:171-218 */
+void orc_sparse_ldlt_solve_inplace(const orc_sparse_ldlt *f, double *x)
+{
+    int n = f->n;
+    for (int j = 0; j < n; j++) {
+        double xj = x[j];
+        for (int p = f->L_cols[j]; p < f->L_cols[j + 1]; p++) x[f->L_ind[p]] -= f->L_vals[p] * xj;
+    }
+    for (int j = 0; j < n; j++) x[j] *= f->D_inv[j];
+    for (int j = n - 1; j >= 0; j--) {
+        double s = x[j];
+        for (int p = f->L_cols[j]; p < f->L_cols[j + 1]; p++) s -= f->L_vals[p] * x[f->L_ind[p]];
+        x[j] = s;
+    }
+}
+
+/* ==================================================================================== AMD ordering */
+#define FLIP(i) (-(i)-2)
+
+static int amd_wclear(int mark, int lemax, int *w, int n)
+{
+    if (mark < 2 || (mark + lemax < 0)) {
+        for (int k = 0; k < n; k++) if (w[k] != 0) w[k] = 1;
+        mark = 2;
+    }
+    return mark;
+}
+
+/* depth-first postorder of the tree rooted at j (next[] sibling links, head[] first child) */
+static int amd_tdfs(int j, int k, int *head, const int *next, int *post, int *stack)
+{
+    int top = 0;
+    stack[0] = j;
+    while (top >= 0) {
+        int p = stack[top];
+        int i = head[p];
+        if (i == -1) {
+            top--;
+            post[k++] = p;
+        } else {
+            head[p] = next[i];
+            stack[++top] = i;
+        }
+    }
+    return k;
+}
+
+/* Pattern of the upper-triangular CSC matrix (Ap, Ai) is symmetrised (diagonal included).  perm[k] = original
+ * index of the k-th pivot (P[new] = old, sparse/ordering.hpp:101-110). */
+void orc_amd_order(int n, const int *Ap, const int *Ai, int *perm)
+{
+    if (n <= 0) return;
+    /* C = pattern of A + A' including the diagonal, columns sorted & unique */
+    int *cnt = ialloc(n + 1);
+    for (int j = 0; j < n; j++) {
+        int has_diag = 0;
+        for (int p = Ap[j]; p < Ap[j + 1]; p++) {
+            int i = Ai[p];
+            if (i == j) { has_diag = 1; continue; }
+            cnt[i]++; cnt[j]++;
+        }
+        (void)has_diag;
+        cnt[j]++; /* diagonal always present in the symmetrised pattern */
+    }
+    int cnz = 0;
+    for (int j = 0; j < n; j++) cnz += cnt[j];
+    int t = cnz + cnz / 5 + 2 * n; /* elbow room */
+    int *Cp = ialloc(n + 1);
+    int *Ci = ialloc((size_t)t + 1);
+    for (int j = 0; j < n; j++) Cp[j + 1] = Cp[j] + cnt[j];
+    int *nxt = idup(Cp, n);
+    /* fill in row-sorted order: iterate columns j ascending, entries (i,j) with i<j put i into col j later... use
+     * two passes so every column ends up sorted: first all entries smaller than the column index, then diag, then larger */
+    for (int j = 0; j < n; j++) {
+        for (int p = Ap[j]; p < Ap[j + 1]; p++) { int i = Ai[p]; if (i < j) Ci[nxt[j]++] = i; }
+    }
+    /* at this point column j holds its upper entries (rows < j) -- but lower-row entries must come after: they are
+     * generated by scanning columns c > j that contain row j; scanning c ascending keeps them sorted */
+    for (int j = 0; j < n; j++) Ci[nxt[j]++] = j;
+    for (int c = 0; c < n; c++) {
+        for (int p = Ap[c]; p < Ap[c + 1]; p++) { int i = Ai[p]; if (i < c) Ci[nxt[i]++] = c; }
+    }
+    /* duplicates in the input are not expected (solver.hpp assumes none) */
+    free(nxt); free(cnt);
+
+    int dense = (int)(10.0 * sqrt((double)n));
+    if (dense < 16) dense = 16;
+    if (dense > n - 2) dense = n - 2;
+
+    int *W = ialloc(8 * (size_t)(n + 1));
+    int *len = W, *nv = W + (n + 1), *next = W + 2 * (n + 1), *head = W + 3 * (n + 1), *elen = W + 4 * (n + 1),
+        *degree = W + 5 * (n + 1), *w = W + 6 * (n + 1), *hhead = W + 7 * (n + 1);
+    int *last = perm; /* use perm as workspace for last during elimination */
+    int *P = ialloc(n + 1);
+
+    for (int k = 0; k < n; k++) len[k] = Cp[k + 1] - Cp[k];
+    len[n] = 0;
+    int nzmax = t;
+    for (int i = 0; i <= n; i++) {
+        head[i] = -1; last[i < n ? i : 0] = (i < n) ? -1 : last[0];
+        next[i] = -1; hhead[i] = -1; nv[i] = 1; w[i] = 1; elen[i] = 0; degree[i] = len[i];
+    }
+    for (int i = 0; i < n; i++) last[i] = -1;
+    int lemax = 0;
+    int mark = amd_wclear(0, 0, w, n);
+    int nel = 0;
+    /* initialise degree lists */
+    for (int i = 0; i < n; i++) {
+        int has_diag = 0;
+        for (int p = Cp[i]; p < Cp[i + 1]; ++p) if (Ci[p] == i) { has_diag = 1; break; }
+        int d = degree[i];
+        if (d == 1 && has_diag) { /* node i is empty */
+            elen[i] = -2; nel++; Cp[i] = -1; w[i] = 0;
+        } else if (d > dense || !has_diag) { /* dense node, or no structural diagonal */
+            nv[i] = 0; elen[i] = -1; nel++; Cp[i] = FLIP(n); nv[n]++;
+        } else {
+            if (head[d] != -1) last[head[d]] = i;
+            next[i] = head[d];
+            head[d] = i;
+        }
+    }
+    elen[n] = -2; Cp[n] = -1; w[n] = 0;
+
+    int mindeg = 0;
+    while (nel < n) {
+        int k;
+        for (k = -1; mindeg < n && (k = head[mindeg]) == -1; mindeg++) {}
+        if (next[k] != -1) last[next[k]] = -1;
+        head[mindeg] = next[k];
+        int elenk = elen[k];
+        int nvk = nv[k];
+        nel += nvk;
+
+        /* garbage collection */
+        if (elenk > 0 && cnz + mindeg >= nzmax) {
+            for (int j = 0; j < n; j++) {
+                int p;
+                if ((p = Cp[j]) >= 0) { Cp[j] = Ci[p]; Ci[p] = FLIP(j); }
+            }
+            int q = 0, p = 0;
+            for (; p < cnz;) {
+                int j;
+                if ((j = FLIP(Ci[p++])) >= 0) {
+                    Ci[q] = Cp[j];
+                    Cp[j] = q++;
+                    for (int k3 = 0; k3 < len[j] - 1; k3++) Ci[q++] = Ci[p++];
+                }
+            }
+            cnz = q;
+        }
+
+        /* construct new element */
+        int dk = 0;
+        nv[k] = -nvk;
+        int p = Cp[k];
+        int pk1 = (elenk == 0) ? p : cnz;
+        int pk2 = pk1;
+        for (int k1 = 1; k1 <= elenk + 1; k1++) {
+            int e, pj, ln;
+            if (k1 > elenk) { e = k; pj = p; ln = len[k] - elenk; }
+            else { e = Ci[p++]; pj = Cp[e]; ln = len[e]; }
+            for (int k2 = 1; k2 <= ln; k2++) {
+                int i = Ci[pj++];
+                int nvi;
+                if ((nvi = nv[i]) <= 0) continue;
+                dk += nvi;
+                nv[i] = -nvi;
+                Ci[pk2++] = i;
+                if (next[i] != -1) last[next[i]] = last[i];
+                if (last[i] != -1) next[last[i]] = next[i];
+                else head[degree[i]] = next[i];
+            }
+            if (e != k) { Cp[e] = FLIP(k); w[e] = 0; }
+        }
+        if (elenk != 0) cnz = pk2;
+        degree[k] = dk;
+        Cp[k] = pk1;
+        len[k] = pk2 - pk1;
+        elen[k] = -2;
+
+        /* find set differences */
+        mark = amd_wclear(mark, lemax, w, n);
+        for (int pk = pk1; pk < pk2; pk++) {
+            int i = Ci[pk];
+            int eln;
+            if ((eln = elen[i]) <= 0) continue;
+            int nvi = -nv[i];
+            int wnvi = mark - nvi;
+            for (p = Cp[i]; p <= Cp[i] + eln - 1; p++) {
+                int e = Ci[p];
+                if (w[e] >= mark) w[e] -= nvi;
+                else if (w[e] != 0) w[e] = degree[e] + wnvi;
+            }
+        }
+
+        /* degree update */
+        for (int pk = pk1; pk < pk2; pk++) {
+            int i = Ci[pk];
+            int p1 = Cp[i];
+            int p2 = p1 + elen[i] - 1;
+            int pn = p1;
+            int h = 0, d = 0;
+            for (p = p1; p <= p2; p++) {
+                int e = Ci[p];
+                if (w[e] != 0) {
+                    int dext = w[e] - mark;
+                    if (dext > 0) { d += dext; Ci[pn++] = e; h += e; }
+                    else { Cp[e] = FLIP(k); w[e] = 0; } /* aggressive absorption */
+                }
+            }
+            elen[i] = pn - p1 + 1;
+            int p3 = pn;
+            int p4 = p1 + len[i];
+            for (p = p2 + 1; p < p4; p++) {
+                int j = Ci[p];
+                int nvj;
+                if ((nvj = nv[j]) <= 0) continue;
+                d += nvj;
+                Ci[pn++] = j;
+                h += j;
+            }
+            if (d == 0) { /* mass elimination */
+                Cp[i] = FLIP(k);
+                int nvi = -nv[i];
+                dk -= nvi;
+                nvk += nvi;
+                nel += nvi;
+                nv[i] = 0;
+                elen[i] = -1;
+            } else {
+                degree[i] = degree[i] < d ? degree[i] : d;
+                Ci[pn] = Ci[p3];
+                Ci[p3] = Ci[p1];
+                Ci[p1] = k;
+                len[i] = pn - p1 + 1;
+                h = (h < 0) ? -h : h;
+                h %= n;
+                next[i] = hhead[h];
+                hhead[h] = i;
+                last[i] = h;
+            }
+        }
+        degree[k] = dk;
+        lemax = lemax > dk ? lemax : dk;
+        mark = amd_wclear(mark + lemax, lemax, w, n);
+
+        /* supernode detection */
+        for (int pk = pk1; pk < pk2; pk++) {
+            int i = Ci[pk];
+            if (nv[i] >= 0) continue;
+            int h = last[i];
+            i = hhead[h];
+            hhead[h] = -1;
+            for (; i != -1 && next[i] != -1; i = next[i], mark++) {
+                int ln = len[i];
+                int eln = elen[i];
+                for (p = Cp[i] + 1; p <= Cp[i] + ln - 1; p++) w[Ci[p]] = mark;
+                int jlast = i;
+                for (int j = next[i]; j != -1;) {
+                    int ok = (len[j] == ln) && (elen[j] == eln);
+                    for (p = Cp[j] + 1; ok && p <= Cp[j] + ln - 1; p++) if (w[Ci[p]] != mark) ok = 0;
+                    if (ok) {
+                        Cp[j] = FLIP(i);
+                        nv[i] += nv[j];
+                        nv[j] = 0;
+                        elen[j] = -1;
+                        j = next[j];
+                        next[jlast] = j;
+                    } else {
+                        jlast = j;
+                        j = next[j];
+                    }
+                }
+            }
+        }
+
+        /* finalise new element */
+        int pw = pk1;
+        for (int pk = pk1; pk < pk2; pk++) {
+            int i = Ci[pk];
+            int nvi;
+            if ((nvi = -nv[i]) <= 0) continue;
+            nv[i] = nvi;
+            int d = degree[i] + dk - nvi;
+            d = d < n - nel - nvi ? d : n - nel - nvi;
+            if (head[d] != -1) last[head[d]] = i;
+            next[i] = head[d];
+            last[i] = -1;
+            head[d] = i;
+            mindeg = mindeg < d ? mindeg : d;
+            degree[i] = d;
+            Ci[pw++] = i;
+        }
+        nv[k] = nvk;
+        if ((len[k] = pw - pk1) == 0) { Cp[k] = -1; w[k] = 0; }
+        if (elenk != 0) cnz = pw;
+    }
+
+    /* postordering */
+    for (int i = 0; i < n; i++) Cp[i] = FLIP(Cp[i]);
+    for (int j = 0; j <= n; j++) head[j] = -1;
+    for (int j = n; j >= 0; j--) { /* place unordered nodes in lists */
+        if (nv[j] > 0) continue;
+        next[j] = head[Cp[j]];
+        head[Cp[j]] = j;
+    }
+    for (int e = n; e >= 0; e--) { /* place elements in lists */
+        if (nv[e] <= 0) continue;
+        if (Cp[e] != -1) { next[e] = head[Cp[e]]; head[Cp[e]] = e; }
+    }
+    int k = 0;
+    for (int i = 0; i <= n; i++) if (Cp[i] == -1) k = amd_tdfs(i, k, head, next, P, w);
+    for (int i = 0; i < n; i++) perm[i] = P[i];
+    free(P); free(W); free(Ci); free(Cp);
+}
+
+/* ============================================================ permute_sparse_symmetric_matrix (utils.hpp:32-128) */
+void orc_permute_sym_upper(int n, const int *Ap, const int *Ai, const double *Ax, const int *perm_inv, int *Cp, int *Ci,
+                           double *Cx, int *Ai_to_Ci)
+{
+    int nnz = Ap[n];
+    int *w = ialloc(n);
+    for (int j = 0; j < n; j++) {
+        int j2 = perm_inv[j];
+        for (int p = Ap[j]; p < Ap[j + 1]; p++) {
+            int i = Ai[p];
+            if (i > j) continue;
+            int i2 = perm_inv[i];
+            w[i2 < j2 ? i2 : j2]++;
+        }
+    }
+    int *CTp = ialloc(n + 1), *CTi = ialloc(nnz), *CTi_to_Ai = ialloc(nnz);
+    double *CTx = dalloc(nnz);
+    int sum = 0;
+    for (int i = 0; i < n; i++) { CTp[i] = sum; sum += w[i]; w[i] = CTp[i]; }
+    CTp[n] = sum;
+    for (int j = 0; j < n; j++) {
+        int j2 = perm_inv[j];
+        for (int k = Ap[j]; k < Ap[j + 1]; k++) {
+            int i = Ai[k];
+            if (i > j) continue;
+            int i2 = perm_inv[i];
+            int q = w[i2 < j2 ? i2 : j2]++;
+            CTi[q] = i2 > j2 ? i2 : j2;
+            CTx[q] = Ax ? Ax[k] : 0.0;
+            CTi_to_Ai[q] = k;
+        }
+    }
+    for (int j = 0; j <= n; j++) Cp[j] = 0;
+    for (int j = 0; j < n; j++) for (int p = CTp[j]; p < CTp[j + 1]; p++) Cp[CTi[p]]++;
+    sum = 0;
+    for (int j = 0; j < n; j++) { int tmp = Cp[j]; Cp[j] = sum; w[j] = sum; sum += tmp; }
+    Cp[n] = sum;
+    for (int j = 0; j < n; j++) {
+        for (int k = CTp[j]; k < CTp[j + 1]; k++) {
+            int i = CTi[k];
+            int q = w[i]++;
+            Ci[q] = j;
+            if (Cx) Cx[q] = CTx[k];
+            Ai_to_Ci[CTi_to_Ai[k]] = q;
+        }
+    }
+    free(w); free(CTp); free(CTi); free(CTi_to_Ai); free(CTx);
+}
+
+/* =================================================================================== sparse::KKT<FULL> */
+typedef struct {
+    orc_kkt base;
+    int n, p, m, N;
+    double m_delta;
+    double *m_z_reg_inv;
+    int *P, *P_inv;                 /* ordering */
+    int *PKPt_p, *PKPt_i; double *PKPt_x; int nnzK;
+    int *PKi;                       /* K index -> PKPt index */
+    int *P_utri_to_Ki, *AT_to_Ki, *GT_to_Ki; int nzP, nzA, nzG;
+    double *P_diagonal;
+    orc_sparse_ldlt *ldlt;
+    double *rhs, *rhs_perm;
+} sparse_kkt;
+
+static void spmv_csc(const orc_csc *M, double alpha, const double *x, double *y /* += alpha M x */)
+{
+    for (int j = 0; j < M->cols; j++) {
+        double xj = alpha * x[j];
+        for (int q = M->colptr[j]; q < M->colptr[j + 1]; q++) y[M->rowind[q]] += M->val[q] * xj;
+    }
+}
+static void spmv_csc_t(const orc_csc *M, double alpha, const double *x, double *y /* = alpha M^T x */)
+{
+    for (int j = 0; j < M->cols; j++) {
+        double s = 0.0;
+        for (int q = M->colptr[j]; q < M->colptr[j + 1]; q++) s += M->val[q] * x[M->rowind[q]];
+        y[j] = alpha * s;
+    }
+}
+
+static void sparse_destroy(orc_kkt *self)
+{
+    sparse_kkt *k = (sparse_kkt *)self;
+    free(k->m_z_reg_inv); free(k->P); free(k->P_inv); free(k->PKPt_p); free(k->PKPt_i); free(k->PKPt_x); free(k->PKi);
+    free(k->P_utri_to_Ki); free(k->AT_to_Ki); free(k->GT_to_Ki); free(k->P_diagonal);
+    orc_sparse_ldlt_free(k->ldlt);
+    free(k->rhs); free(k->rhs_perm);
+    free(k);
+}
+
+/* sparse/kkt_full.hpp:212-251 */
+static void sparse_update_data(orc_kkt *self, const orc_data *d, int options)
+{
+    sparse_kkt *k = (sparse_kkt *)self;
+    if (options & ORC_KKT_UPDATE_P) {
+        for (int j = 0; j < d->n; j++)
+            for (int q = d->sP_utri.colptr[j]; q < d->sP_utri.colptr[j + 1]; q++) {
+                k->PKPt_x[k->PKi[k->P_utri_to_Ki[q]]] = d->sP_utri.val[q];
+                if (j == d->sP_utri.rowind[q]) k->P_diagonal[j] = d->sP_utri.val[q];
+            }
+    }
+    if (options & ORC_KKT_UPDATE_A) {
+        int nnz = d->sAT.colptr[d->p];
+        for (int q = 0; q < nnz; q++) k->PKPt_x[k->PKi[k->AT_to_Ki[q]]] = d->sAT.val[q];
+    }
+    if (options & ORC_KKT_UPDATE_G) {
+        int nnz = d->sGT.colptr[d->m];
+        for (int q = 0; q < nnz; q++) k->PKPt_x[k->PKi[k->GT_to_Ki[q]]] = d->sGT.val[q];
+    }
+}
+
+/* sparse/kkt.hpp:83-105 + kkt_full.hpp:172-210 */
+static int sparse_factor(orc_kkt *self, const orc_data *d, double delta, const double *x_reg, const double *z_reg)
+{
+    sparse_kkt *k = (sparse_kkt *)self;
+    k->m_delta = delta;
+    for (int i = 0; i < k->m; i++) k->m_z_reg_inv[i] = 1.0 / z_reg[i];
+    for (int col = 0; col < k->n; col++) k->PKPt_x[k->PKPt_p[k->P_inv[col] + 1] - 1] = k->P_diagonal[col] + x_reg[col];
+    for (int col = k->n; col < k->n + k->p; col++) k->PKPt_x[k->PKPt_p[k->P_inv[col] + 1] - 1] = -delta;
+    for (int col = k->n + k->p, q = 0; col < k->N; col++, q++) k->PKPt_x[k->PKPt_p[k->P_inv[col] + 1] - 1] = -z_reg[q];
+    int ret = orc_sparse_ldlt_numeric(k->ldlt, k->N, k->PKPt_p, k->PKPt_i, k->PKPt_x);
+    return ret == k->N;
+}
+
+/* sparse/kkt.hpp:107-176 (KKT_FULL branch) */
+static void sparse_solve(orc_kkt *self, const orc_data *d, const double *rhs_x, const double *rhs_y, const double *rhs_z,
+                         double *lhs_x, double *lhs_y, double *lhs_z)
+{
+    sparse_kkt *k = (sparse_kkt *)self;
+    int n = k->n, p = k->p, m = k->m, N = k->N;
+    memcpy(k->rhs, rhs_x, sizeof(double) * (size_t)n);
+    memcpy(k->rhs + n, rhs_y, sizeof(double) * (size_t)p);
+    memcpy(k->rhs + n + p, rhs_z, sizeof(double) * (size_t)m);
+    for (int j = 0; j < N; j++) k->rhs_perm[j] = k->rhs[k->P[j]];      /* ordering.perm */
+    orc_sparse_ldlt_solve_inplace(k->ldlt, k->rhs_perm);
+    for (int j = 0; j < N; j++) k->rhs[k->P[j]] = k->rhs_perm[j];      /* ordering.permt */
+    memcpy(lhs_x, k->rhs, sizeof(double) * (size_t)n);
+    memcpy(lhs_y, k->rhs + n, sizeof(double) * (size_t)p);
+    memcpy(lhs_z, k->rhs + n + p, sizeof(double) * (size_t)m);
+}
+
+/* sparse/kkt.hpp:179-203 */
+static void sparse_eval_P_x(orc_kkt *self, const orc_data *d, double alpha, const double *x, double *z)
+{
+    int n = d->n;
+    memset(z, 0, sizeof(double) * (size_t)n);
+    const orc_csc *U = &d->sP_utri;
+    for (int j = 0; j < n; j++) {
+        double xj = alpha * x[j];
+        for (int q = U->colptr[j]; q < U->colptr[j + 1]; q++) z[U->rowind[q]] += U->val[q] * xj;
+    }
+    for (int j = 0; j < n; j++) {
+        double s = 0.0;
+        for (int q = U->colptr[j]; q < U->colptr[j + 1]; q++) if (U->rowind[q] < j) s += U->val[q] * x[U->rowind[q]];
+        z[j] += alpha * s;
+    }
+}
+static void sparse_eval_A(orc_kkt *self, const orc_data *d, double an, double at, const double *xn, const double *xt, double *zn, double *zt)
+{
+    spmv_csc_t(&d->sAT, an, xn, zn);
+    memset(zt, 0, sizeof(double) * (size_t)d->n);
+    spmv_csc(&d->sAT, at, xt, zt);
+}
+static void sparse_eval_G(orc_kkt *self, const orc_data *d, double an, double at, const double *xn, const double *xt, double *zn, double *zt)
+{
+    spmv_csc_t(&d->sGT, an, xn, zn);
+    memset(zt, 0, sizeof(double) * (size_t)d->n);
+    spmv_csc(&d->sGT, at, xt, zt);
+}
+static void sparse_print_info(orc_kkt *self) { (void)self; }
+static orc_kkt *sparse_clone(const orc_kkt *self);
+
+static void sparse_fill_vtable(sparse_kkt *k)
+{
+    k->base.clone = sparse_clone;
+    k->base.update_data = sparse_update_data;
+    k->base.update_scalings_and_factor = sparse_factor;
+    k->base.solve = sparse_solve;
+    k->base.eval_P_x = sparse_eval_P_x;
+    k->base.eval_A_xn_and_AT_xt = sparse_eval_A;
+    k->base.eval_G_xn_and_GT_xt = sparse_eval_G;
+    k->base.print_info = sparse_print_info;
+    k->base.destroy = sparse_destroy;
+}
+
+/* sparse/kkt.hpp:51-70 with create_kkt_matrix of kkt_full.hpp:39-170 */
+orc_kkt *orc_sparse_kkt_create(const orc_data *d, int mode)
+{
+    if (mode != 0) { fprintf(stderr, "kkt solver not supported\n"); return NULL; }
+    sparse_kkt *k = (sparse_kkt *)calloc(1, sizeof(sparse_kkt));
+    sparse_fill_vtable(k);
+    int n = d->n, p = d->p, m = d->m, N = n + p + m;
+    k->n = n; k->p = p; k->m = m; k->N = N;
+    k->m_delta = 0.0; /* the reference reads an uninitialised m_delta here; values are overwritten before every factor */
+    k->m_z_reg_inv = dalloc(m);
+    k->rhs = dalloc(N); k->rhs_perm = dalloc(N);
+    const orc_csc *U = &d->sP_utri, *AT = &d->sAT, *GT = &d->sGT;
+    k->nzP = U->colptr[n]; k->nzA = AT->colptr[p]; k->nzG = GT->colptr[m];
+    k->P_utri_to_Ki = ialloc(k->nzP); k->AT_to_Ki = ialloc(k->nzA); k->GT_to_Ki = ialloc(k->nzG);
+    k->P_diagonal = dalloc(n);
+    /* count */
+    int *Kp = ialloc(N + 1);
+    int nz = 0, jk = 0;
+    for (int j = 0; j < n; j++) {
+        int col_nnz = U->colptr[j + 1] - U->colptr[j];
+        if (col_nnz > 0) { if (U->rowind[U->colptr[j + 1] - 1] != j) col_nnz += 1; }
+        else col_nnz += 1;
+        nz += col_nnz; Kp[++jk] = nz;
+    }
+    for (int j = 0; j < p; j++) { nz += AT->colptr[j + 1] - AT->colptr[j] + 1; Kp[++jk] = nz; }
+    for (int j = 0; j < m; j++) { nz += GT->colptr[j + 1] - GT->colptr[j] + 1; Kp[++jk] = nz; }
+    int *Ki = ialloc(nz); double *Kx = dalloc(nz);
+    jk = 0;
+    for (int j = 0; j < n; j++) {
+        int kk = Kp[jk], col_nnz = U->colptr[j + 1] - U->colptr[j];
+        memcpy(Ki + kk, U->rowind + U->colptr[j], sizeof(int) * (size_t)col_nnz);
+        memcpy(Kx + kk, U->val + U->colptr[j], sizeof(double) * (size_t)col_nnz);
+        int kcol = Kp[jk + 1] - Kp[jk];
+        if (kcol > col_nnz) { Ki[kk + kcol - 1] = jk; Kx[kk + kcol - 1] = 1.0; }
+        else { k->P_diagonal[j] = U->val[U->colptr[j + 1] - 1]; Kx[kk + kcol - 1] += 1.0; }
+        for (int q = U->colptr[j], i = 0; q < U->colptr[j + 1]; q++, i++) k->P_utri_to_Ki[q] = kk + i;
+        jk++;
+    }
+    for (int j = 0; j < p; j++) {
+        int kk = Kp[jk], col_nnz = AT->colptr[j + 1] - AT->colptr[j];
+        memcpy(Ki + kk, AT->rowind + AT->colptr[j], sizeof(int) * (size_t)col_nnz);
+        memcpy(Kx + kk, AT->val + AT->colptr[j], sizeof(double) * (size_t)col_nnz);
+        Ki[kk + col_nnz] = jk; Kx[kk + col_nnz] = -k->m_delta;
+        for (int q = AT->colptr[j], i = 0; q < AT->colptr[j + 1]; q++, i++) k->AT_to_Ki[q] = kk + i;
+        jk++;
+    }
+    for (int j = 0; j < m; j++) {
+        int kk = Kp[jk], col_nnz = GT->colptr[j + 1] - GT->colptr[j];
+        memcpy(Ki + kk, GT->rowind + GT->colptr[j], sizeof(int) * (size_t)col_nnz);
+        memcpy(Kx + kk, GT->val + GT->colptr[j], sizeof(double) * (size_t)col_nnz);
+        Ki[kk + col_nnz] = jk; Kx[kk + col_nnz] = -1.0 - k->m_delta;
+        for (int q = GT->colptr[j], i = 0; q < GT->colptr[j + 1]; q++, i++) k->GT_to_Ki[q] = kk + i;
+        jk++;
+    }
+    /* ordering.init(KKT); PKi = permute_sparse_symmetric_matrix(KKT, PKPt, ordering) */
+    k->P = ialloc(N); k->P_inv = ialloc(N);
+    orc_amd_order(N, Kp, Ki, k->P);
+    for (int i = 0; i < N; i++) k->P_inv[k->P[i]] = i;
+    k->nnzK = nz;
+    k->PKPt_p = ialloc(N + 1); k->PKPt_i = ialloc(nz); k->PKPt_x = dalloc(nz); k->PKi = ialloc(nz);
+    orc_permute_sym_upper(N, Kp, Ki, Kx, k->P_inv, k->PKPt_p, k->PKPt_i, k->PKPt_x, k->PKi);
+    k->ldlt = orc_sparse_ldlt_create();
+    orc_sparse_ldlt_symbolic(k->ldlt, N, k->PKPt_p, k->PKPt_i);
+    free(Kp); free(Ki); free(Kx);
+    return &k->base;
+}
+
+static orc_kkt *sparse_clone(const orc_kkt *self)
+{
+    const sparse_kkt *s = (const sparse_kkt *)self;
+    sparse_kkt *k = (sparse_kkt *)calloc(1, sizeof(sparse_kkt));
+    *k = *s;
+    int N = s->N, nz = s->nnzK;
+    k->m_z_reg_inv = ddup(s->m_z_reg_inv, s->m);
+    k->P = idup(s->P, N); k->P_inv = idup(s->P_inv, N);
+    k->PKPt_p = idup(s->PKPt_p, N + 1); k->PKPt_i = idup(s->PKPt_i, nz); k->PKPt_x = ddup(s->PKPt_x, nz); k->PKi = idup(s->PKi, nz);
+    k->P_utri_to_Ki = idup(s->P_utri_to_Ki, s->nzP); k->AT_to_Ki = idup(s->AT_to_Ki, s->nzA); k->GT_to_Ki = idup(s->GT_to_Ki, s->nzG);
+    k->P_diagonal = ddup(s->P_diagonal, s->n);
+    k->ldlt = ldlt_clone(s->ldlt);
+    k->rhs = dalloc(N); k->rhs_perm = dalloc(N);
+    return &k->base;
+}
+
+/* test hooks */
+int orc_sparse_kkt_dim(const orc_kkt *k) { return ((const sparse_kkt *)k)->N; }
+const int *orc_sparse_kkt_PKPt_colptr(const orc_kkt *k) { return ((const sparse_kkt *)k)->PKPt_p; }
+const int *orc_sparse_kkt_PKPt_rowind(const orc_kkt *k) { return ((const sparse_kkt *)k)->PKPt_i; }
+const double *orc_sparse_kkt_PKPt_val(const orc_kkt *k) { return ((const sparse_kkt *)k)->PKPt_x; }
+const int *orc_sparse_kkt_perm(const orc_kkt *k) { return ((const sparse_kkt *)k)->P; }
+int orc_sparse_kkt_L_nnz(const orc_kkt *k) { return orc_sparse_ldlt_nnz(((const sparse_kkt *)k)->ldlt); }
