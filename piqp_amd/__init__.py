@@ -5,4 +5,6 @@ interface, as hand-written HIP kernels behind the C-ABI of include/piqp_amd.h.  
 """
 from . import _lib, kkt  # noqa: F401
 from .kkt import (DENSE_CHOLESKY, DENSE_LDLT_NO_PIVOT, KKT_UPDATE_A, KKT_UPDATE_G, KKT_UPDATE_NONE, KKT_UPDATE_P,  # noqa: F401
-                  Data, DenseKKT, DenseSolver, KKTSystem, SparseSolver, Variables, default_settings)
+                  Data, DenseKKT, DenseSolver, KKTSystem, SparseData, SparseSolver, Variables, default_settings)
+SparseKKT = DenseKKT  # same handle type: pq_kkt_* dispatches on the backend (KKTSolverBase is one interface)
+SPARSE_LDLT = 1

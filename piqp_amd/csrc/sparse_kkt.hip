@@ -1,0 +1,578 @@
+// piqp_amd/csrc/sparse_kkt.hip -- device-resident replacement of piqp::sparse::KKT<T,I,KKT_FULL>
+// (reference include/piqp/sparse/kkt.hpp + kkt_full.hpp + ldlt.hpp).
+//
+//   reference                                        here
+//   PKPt values + diagonal refresh (kkt_full:172-210) k_set_diag on the device copy of the PKPt values
+//   LDLt::factorize_numeric (ldlt.hpp:101-169,         supernodal multifrontal LDLt: k_scatter_fronts (assembly),
+//     up-looking, serial over rows)                    per tree level k_front_factor (extend-add + partial dense LDLt,
+//                                                      one workgroup per front, LDS-resident when it fits); fronts
+//                                                      wider than BIG_FRONT go through the dense MFMA panel kernels
+//   lsolve/dsolve/ltsolve + perm/permt (ldlt:171-218)  k_perm_gather, per level k_front_fwd, k_scale, k_front_bwd, k_perm_scatter
+//   eval_P_x / eval_A.. / eval_G.. (kkt.hpp:179-203)   k_spmv_cols on CSC copies (P symmetrised, A and G kept in both
+//                                                      orientations so every product is a conflict-free column dot)
+//   update_data_impl (kkt_full:212-251)                k_remap_values through the composed index maps
+// No atomics anywhere: children are merged into their parent in a fixed order, so results are bitwise
+// reproducible (the reference's clone test needs that).
+#include <algorithm>
+#include <cstdio>
+#include <stdexcept>
+
+#include "dense_kernels.hpp"
+#include "kkt_solver_base.hpp"
+#include "sparse_symbolic.hpp"
+
+namespace pq {
+
+namespace {
+
+constexpr int BIG_FRONT = 192;      // fronts at least this large with >= BIG_PIVOTS pivots use the dense multi-workgroup kernels
+constexpr int BIG_PIVOTS = 32;
+constexpr int LDS_FRONT_DOUBLES = 12288;  // 96 KiB: fronts up to 110 x 110 are factored inside LDS
+
+struct FrontMeta {  // device-side views of the symbolic analysis
+    const int* sn_first;
+    const int* front_rows_ptr;
+    const int* front_rows;
+    const long long* front_off;
+    const int* child_ptr;
+    const int* child;
+    const int* rel_ptr;
+    const int* rel;
+};
+
+__global__ void k_set_diag(int n, int p, int m, const int* __restrict__ diag_pos, const double* __restrict__ Pdiag, const double* __restrict__ x_reg, double delta,
+                           const double* __restrict__ z_reg, double* __restrict__ vals)
+{
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    const int N = n + p + m;
+    if (col >= N) return;
+    double v;
+    if (col < n) v = Pdiag[col] + x_reg[col];        // kkt_full.hpp:181
+    else if (col < n + p) v = -delta;                // :194
+    else v = -z_reg[col - n - p];                    // :207
+    vals[diag_pos[col]] = v;
+}
+
+__global__ void k_scatter_fronts(int nnz, const long long* __restrict__ a_dst, const double* __restrict__ vals, double* __restrict__ fronts)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < nnz) fronts[a_dst[q]] = vals[q];
+}
+
+__global__ void k_remap_values(int nnz, const int* __restrict__ dst_idx, const double* __restrict__ src, double* __restrict__ dst)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < nnz) dst[dst_idx[q]] = src[q];
+}
+__global__ void k_gather_values(int nnz, const int* __restrict__ src_idx, const double* __restrict__ src, double* __restrict__ dst)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < nnz) dst[q] = src[src_idx[q]];
+}
+
+// y[j] = alpha * sum_q val[q] * x[row[q]] over column j  (CSC column dot; thread per column)
+__global__ void k_spmv_cols(int ncols, const int* __restrict__ colptr, const int* __restrict__ rowind, const double* __restrict__ val, const double* __restrict__ x,
+                            double alpha, double* __restrict__ y)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= ncols) return;
+    double s = 0.0;
+    for (int q = colptr[j]; q < colptr[j + 1]; ++q) s += val[q] * x[rowind[q]];
+    y[j] = alpha * s;
+}
+
+__global__ void k_perm_gather(int N, const int* __restrict__ P, const double* __restrict__ a, int na, const double* __restrict__ b, int nb, const double* __restrict__ c,
+                              double* __restrict__ out)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= N) return;
+    const int o = P[j];  // ordering.perm: x[j] = rhs[P[j]] with rhs = [a; b; c]
+    out[j] = o < na ? a[o] : (o < na + nb ? b[o - na] : c[o - na - nb]);
+}
+__global__ void k_perm_scatter(int N, const int* __restrict__ P, const double* __restrict__ in, double* __restrict__ a, int na, double* __restrict__ b, int nb,
+                               double* __restrict__ c)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= N) return;
+    const int o = P[j];  // ordering.permt: rhs[P[j]] = x[j]
+    const double v = in[j];
+    if (o < na) a[o] = v; else if (o < na + nb) b[o - na] = v; else c[o - na - nb] = v;
+}
+__global__ void k_scale(int N, const double* __restrict__ d, double* __restrict__ x)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < N) x[j] *= d[j];
+}
+
+// extend-add of every child's update matrix into front s (fixed child order)
+__device__ void extend_add(const FrontMeta& M, double* __restrict__ fronts, int s, double* __restrict__ F, int f)
+{
+    for (int ci = M.child_ptr[s]; ci < M.child_ptr[s + 1]; ++ci) {
+        const int c = M.child[ci];
+        const int wc = M.sn_first[c + 1] - M.sn_first[c];
+        const int fc = M.front_rows_ptr[c + 1] - M.front_rows_ptr[c];
+        const int uc = fc - wc;
+        const double* U = fronts + M.front_off[c] + wc + (long long)wc * fc;
+        const int* rel = M.rel + M.rel_ptr[c];
+        for (int idx = threadIdx.x; idx < uc * uc; idx += blockDim.x) {
+            const int i = idx % uc, j = idx / uc;
+            if (i >= j) F[rel[i] + (long long)rel[j] * f] += U[i + (long long)j * fc];
+        }
+        __syncthreads();
+    }
+}
+
+// One workgroup per front: extend-add, then right-looking LDLt of the first w columns (unit L below the
+// diagonal, D on it), Schur complement left in the trailing (f-w) x (f-w) block for the parent.
+// Fails (info = first failing global column) iff a pivot is exactly zero, like ldlt.hpp:163.
+__global__ __launch_bounds__(256) void k_front_factor(FrontMeta M, double* __restrict__ fronts, const int* __restrict__ list, int big_front, int big_pivots,
+                                                      double* __restrict__ rdiag, int* __restrict__ info)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int s = list[blockIdx.x];
+    const int first = M.sn_first[s];
+    const int w = M.sn_first[s + 1] - first;
+    const int f = M.front_rows_ptr[s + 1] - M.front_rows_ptr[s];
+    if (f >= big_front && w >= big_pivots) return;  // handled by the dense path
+    double* F = fronts + M.front_off[s];
+    extend_add(M, fronts, s, F, f);
+    const bool in_lds = (long long)f * f <= LDS_FRONT_DOUBLES;
+    double* W = F;
+    if (in_lds) {
+        for (int idx = threadIdx.x; idx < f * f; idx += blockDim.x) lds[idx] = F[idx];
+        __syncthreads();
+        W = lds;
+    }
+    __shared__ double piv_s;
+    for (int k = 0; k < w; ++k) {
+        if (threadIdx.x == 0) {
+            double d = W[k + (long long)k * f];
+            if (d == 0.0) { if (*info < 0) *info = first + k; d = 1.0; }
+            piv_s = d;
+            rdiag[first + k] = 1.0 / d;
+        }
+        __syncthreads();
+        const double d = piv_s;
+        const double dinv = 1.0 / d;
+        // trailing update with the UNSCALED column: F[i,j] -= (a_i / d) * a_j  for j > k, i >= j
+        const int r = f - k - 1;
+        const double* colk = W + (k + 1) + (long long)k * f;
+        for (int idx = threadIdx.x; idx < r * r; idx += blockDim.x) {
+            const int i = idx % r, j = idx / r;
+            if (i >= j) W[(k + 1 + i) + (long long)(k + 1 + j) * f] -= (colk[i] * dinv) * colk[j];
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < r; i += blockDim.x) W[(k + 1 + i) + (long long)k * f] *= dinv;
+        __syncthreads();
+    }
+    if (in_lds) {
+        for (int idx = threadIdx.x; idx < f * f; idx += blockDim.x) F[idx] = lds[idx];
+    }
+}
+
+// extend-add of ONE child into a front that is then factored by the dense kernels (one launch per child: stream
+// order = fixed merge order, entries of one child never collide)
+__global__ __launch_bounds__(256) void k_front_extend_add_child(FrontMeta M, double* __restrict__ fronts, int s, int c)
+{
+    const int f = M.front_rows_ptr[s + 1] - M.front_rows_ptr[s];
+    double* F = fronts + M.front_off[s];
+    const int wc = M.sn_first[c + 1] - M.sn_first[c];
+    const int fc = M.front_rows_ptr[c + 1] - M.front_rows_ptr[c];
+    const int uc = fc - wc;
+    const double* U = fronts + M.front_off[c] + wc + (long long)wc * fc;
+    const int* rel = M.rel + M.rel_ptr[c];
+    const long long tot = (long long)uc * uc;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < tot; idx += (long long)gridDim.x * blockDim.x) {
+        const int i = (int)(idx % uc), j = (int)(idx / uc);
+        if (i >= j) F[rel[i] + (long long)rel[j] * f] += U[i + (long long)j * fc];
+    }
+}
+
+// forward substitution on one front: v = [x(pivots) + children; children], y = L11^-1 v1, v2 -= L21 y
+__global__ __launch_bounds__(256) void k_front_fwd(FrontMeta M, const double* __restrict__ fronts, const int* __restrict__ list, double* __restrict__ x,
+                                                   double* __restrict__ fvec)
+{
+    const int s = list[blockIdx.x];
+    const int first = M.sn_first[s];
+    const int w = M.sn_first[s + 1] - first;
+    const int f = M.front_rows_ptr[s + 1] - M.front_rows_ptr[s];
+    const double* F = fronts + M.front_off[s];
+    double* v = fvec + M.front_rows_ptr[s];
+    for (int i = threadIdx.x; i < f; i += blockDim.x) v[i] = (i < w) ? x[first + i] : 0.0;
+    __syncthreads();
+    for (int ci = M.child_ptr[s]; ci < M.child_ptr[s + 1]; ++ci) {
+        const int c = M.child[ci];
+        const int wc = M.sn_first[c + 1] - M.sn_first[c];
+        const int fc = M.front_rows_ptr[c + 1] - M.front_rows_ptr[c];
+        const double* vc = fvec + M.front_rows_ptr[c] + wc;
+        const int* rel = M.rel + M.rel_ptr[c];
+        for (int i = threadIdx.x; i < fc - wc; i += blockDim.x) v[rel[i]] += vc[i];
+        __syncthreads();
+    }
+    for (int k = 0; k < w; ++k) {
+        const double yk = v[k];
+        const double* col = F + (long long)k * f;
+        for (int i = k + 1 + threadIdx.x; i < f; i += blockDim.x) v[i] -= col[i] * yk;
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < w; i += blockDim.x) x[first + i] = v[i];
+}
+
+// backward substitution on one front: x1 = L11^-T (y1 - L21^T x2), x2 gathered from the already-final ancestors
+__global__ __launch_bounds__(256) void k_front_bwd(FrontMeta M, const double* __restrict__ fronts, const int* __restrict__ list, double* __restrict__ x,
+                                                   double* __restrict__ fvec)
+{
+    const int s = list[blockIdx.x];
+    const int first = M.sn_first[s];
+    const int w = M.sn_first[s + 1] - first;
+    const int f = M.front_rows_ptr[s + 1] - M.front_rows_ptr[s];
+    const double* F = fronts + M.front_off[s];
+    const int* rows = M.front_rows + M.front_rows_ptr[s];
+    double* v = fvec + M.front_rows_ptr[s];
+    for (int i = threadIdx.x; i < f; i += blockDim.x) v[i] = x[rows[i]];
+    __syncthreads();
+    // y1[k] -= sum_{i >= w} L[i,k] * x2[i]   (thread per pivot column, contiguous reads down the column)
+    for (int k = threadIdx.x; k < w; k += blockDim.x) {
+        const double* col = F + (long long)k * f;
+        double sacc = 0.0;
+        for (int i = w; i < f; ++i) sacc += col[i] * v[i];
+        v[k] -= sacc;
+    }
+    __syncthreads();
+    for (int i = w - 1; i > 0; --i) {
+        const double xi = v[i];
+        for (int k = threadIdx.x; k < i; k += blockDim.x) v[k] -= F[i + (long long)k * f] * xi;
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < w; i += blockDim.x) x[first + i] = v[i];
+}
+
+inline dim3 g1(int n) { return dim3(n > 0 ? (n + 255) / 256 : 1); }
+
+template <class T>
+void upload(DBuf<T>& d, const std::vector<T>& h, hipStream_t st)
+{
+    d.alloc(h.size() ? h.size() : 1);
+    if (!h.empty()) PQ_HIP(hipMemcpyAsync(d.p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, st));
+}
+
+// host-side CSC transpose with a value map: T = M^T, tmap[q_in_T] = q_in_M
+void transpose_with_map(int rows, int cols, const int* Mp, const int* Mi, std::vector<int>& Tp, std::vector<int>& Ti, std::vector<int>& tmap)
+{
+    const int nnz = Mp[cols];
+    Tp.assign(rows + 1, 0); Ti.assign(nnz, 0); tmap.assign(nnz, 0);
+    for (int q = 0; q < nnz; ++q) Tp[Mi[q] + 1]++;
+    for (int i = 0; i < rows; ++i) Tp[i + 1] += Tp[i];
+    std::vector<int> nx(Tp.begin(), Tp.end() - 1);
+    for (int j = 0; j < cols; ++j) for (int q = Mp[j]; q < Mp[j + 1]; ++q) { const int t = nx[Mi[q]]++; Ti[t] = j; tmap[t] = q; }
+}
+
+class SparseKKT final : public KKTSolverBase {
+public:
+    SparseKKT(const pq_sparse_data* d, int device) : dev_(device)
+    {
+        if (d->mem != PQ_MEM_HOST) throw std::runtime_error("sparse data must be host-resident");
+        PQ_HIP(hipSetDevice(dev_));
+        PQ_HIP(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
+        sparse::analyse_kkt_full(d, S_);
+        n_ = S_.n; p_ = S_.p; m_ = S_.m; N_ = S_.N;
+        compute_level_lds();
+        build_device(d);
+    }
+    ~SparseKKT() override
+    {
+        (void)hipSetDevice(dev_);
+        if (st_) { (void)hipStreamSynchronize(st_); (void)hipStreamDestroy(st_); }
+    }
+
+    KKTSolverBase* clone() const override
+    {
+        PQ_HIP(hipSetDevice(dev_));
+        PQ_HIP(hipStreamSynchronize(st_));
+        return new SparseKKT(*this, 0);
+    }
+
+    // sparse/kkt_full.hpp:212-251
+    void update_data_sparse(const pq_sparse_data* d, int options) override
+    {
+        if (d->n != n_ || d->p != p_ || d->m != m_) throw std::runtime_error("update_data: dimension mismatch");
+        PQ_HIP(hipSetDevice(dev_));
+        // values only (identical sparsity is a precondition, solver.hpp:325,341,356); the flags say which matrices changed,
+        // but Solver::update rewrites all of them through unscale -> rescale, so refresh everything that is stored
+        (void)options;
+        upload_values(d);
+    }
+
+    // sparse/kkt.hpp:83-105
+    bool update_scalings_and_factor(double delta, const double* x_reg, const double* z_reg) override
+    {
+        PQ_HIP(hipSetDevice(dev_));
+        delta_ = delta;
+        const int t0 = prof_.begin(0, st_);
+        hipLaunchKernelGGL(k_set_diag, g1(N_), dim3(256), 0, st_, n_, p_, m_, diag_pos_.p, Pdiag_.p, x_reg, delta, z_reg, vals_.p);
+        PQ_HIP(hipMemsetAsync(fronts_.p, 0, sizeof(double) * (size_t)S_.front_doubles, st_));
+        hipLaunchKernelGGL(k_scatter_fronts, g1(nnzK_), dim3(256), 0, st_, nnzK_, a_dst_.p, vals_.p, fronts_.p);
+        prof_.end(0, t0, st_);
+        const int t1 = prof_.begin(1, st_);
+        PQ_HIP(hipMemsetAsync(info_.p, 0xFF, sizeof(int), st_));
+        FrontMeta M = meta();
+        for (int l = 0; l < S_.nlevels; ++l) {
+            const int cnt = S_.level_ptr[l + 1] - S_.level_ptr[l];
+            hipLaunchKernelGGL(k_front_factor, dim3(cnt), dim3(256), level_lds_[l], st_, M, fronts_.p, level_sn_.p + S_.level_ptr[l], BIG_FRONT, BIG_PIVOTS,
+                               rdiag_.p, info_.p);
+            for (int q = S_.level_ptr[l]; q < S_.level_ptr[l + 1]; ++q) {
+                const int s = S_.level_sn[q];
+                const int w = S_.sn_first[s + 1] - S_.sn_first[s];
+                const int f = S_.front_rows_ptr[s + 1] - S_.front_rows_ptr[s];
+                if (f >= BIG_FRONT && w >= BIG_PIVOTS) factor_big_front(M, s, w, f);
+            }
+        }
+        PQ_HIP(hipGetLastError());
+        prof_.end(1, t1, st_);
+        PQ_HIP(hipMemcpyAsync(info_h_.p, info_.p, sizeof(int), hipMemcpyDeviceToHost, st_));
+        PQ_HIP(hipStreamSynchronize(st_));
+        return info_h_.p[0] == -1;  // n == cols (sparse/kkt.hpp:104)
+    }
+
+    // sparse/kkt.hpp:107-176, KKT_FULL branch
+    void solve(const double* rhs_x, const double* rhs_y, const double* rhs_z, double* lhs_x, double* lhs_y, double* lhs_z) override
+    {
+        PQ_HIP(hipSetDevice(dev_));
+        const int tk = prof_.begin(2, st_);
+        FrontMeta M = meta();
+        hipLaunchKernelGGL(k_perm_gather, g1(N_), dim3(256), 0, st_, N_, P_.p, rhs_x, n_, rhs_y, p_, rhs_z, xp_.p);
+        for (int l = 0; l < S_.nlevels; ++l) {
+            const int cnt = S_.level_ptr[l + 1] - S_.level_ptr[l];
+            hipLaunchKernelGGL(k_front_fwd, dim3(cnt), dim3(256), 0, st_, M, fronts_.p, level_sn_.p + S_.level_ptr[l], xp_.p, fvec_.p);
+        }
+        hipLaunchKernelGGL(k_scale, g1(N_), dim3(256), 0, st_, N_, rdiag_.p, xp_.p);
+        for (int l = S_.nlevels - 1; l >= 0; --l) {
+            const int cnt = S_.level_ptr[l + 1] - S_.level_ptr[l];
+            hipLaunchKernelGGL(k_front_bwd, dim3(cnt), dim3(256), 0, st_, M, fronts_.p, level_sn_.p + S_.level_ptr[l], xp_.p, fvec_.p);
+        }
+        hipLaunchKernelGGL(k_perm_scatter, g1(N_), dim3(256), 0, st_, N_, P_.p, xp_.p, lhs_x, n_, lhs_y, p_, lhs_z);
+        PQ_HIP(hipGetLastError());
+        prof_.end(2, tk, st_);
+    }
+
+    // sparse/kkt.hpp:179-203
+    void eval_P_x(double alpha, const double* x, double* z) override
+    {
+        PQ_HIP(hipSetDevice(dev_));
+        hipLaunchKernelGGL(k_spmv_cols, g1(n_), dim3(256), 0, st_, n_, Pf_p_.p, Pf_i_.p, Pf_x_.p, x, alpha, z);
+    }
+    void eval_A_xn_and_AT_xt(double alpha_n, double alpha_t, const double* xn, const double* xt, double* zn, double* zt) override
+    {
+        PQ_HIP(hipSetDevice(dev_));
+        if (p_ > 0) hipLaunchKernelGGL(k_spmv_cols, g1(p_), dim3(256), 0, st_, p_, AT_p_.p, AT_i_.p, AT_x_.p, xn, alpha_n, zn);  // A x = (AT)^T x
+        hipLaunchKernelGGL(k_spmv_cols, g1(n_), dim3(256), 0, st_, n_, A_p_.p, A_i_.p, A_x_.p, xt, alpha_t, zt);                   // AT y = (A)^T y
+    }
+    void eval_G_xn_and_GT_xt(double alpha_n, double alpha_t, const double* xn, const double* xt, double* zn, double* zt) override
+    {
+        PQ_HIP(hipSetDevice(dev_));
+        if (m_ > 0) hipLaunchKernelGGL(k_spmv_cols, g1(m_), dim3(256), 0, st_, m_, GT_p_.p, GT_i_.p, GT_x_.p, xn, alpha_n, zn);
+        hipLaunchKernelGGL(k_spmv_cols, g1(n_), dim3(256), 0, st_, n_, G_p_.p, G_i_.p, G_x_.p, xt, alpha_t, zt);
+    }
+
+    void print_info() override
+    {
+        std::printf("sparse multifrontal LDLt: N = %d, nnz(K) = %d, nnz(L) = %lld, supernodes = %d, levels = %d, max front = %d, front storage = %.1f MB\n", N_, nnzK_, S_.nnzL,
+                    S_.nsuper, S_.nlevels, S_.max_front, S_.front_doubles * 8.0 / 1e6);
+    }
+
+    const double* P_diag_device() const override { return Pdiag_.p; }
+    int n() const override { return n_; }
+    int p() const override { return p_; }
+    int m() const override { return m_; }
+    hipStream_t stream() const override { return st_; }
+    int device() const override { return dev_; }
+    void set_profiling(bool on) override { prof_.enabled = on; }
+    void get_profile(int stage, double* total_ms, int* count) override
+    {
+        if (stage < 0 || stage >= StageProfiler::NSTAGE) throw std::runtime_error("bad stage");
+        PQ_HIP(hipSetDevice(dev_));
+        prof_.collect(stage, st_, total_ms, count);
+    }
+    const sparse::Symbolic& symbolic() const { return S_; }
+
+private:
+    SparseKKT(const SparseKKT& o, int) : dev_(o.dev_), n_(o.n_), p_(o.p_), m_(o.m_), N_(o.N_), nnzK_(o.nnzK_), delta_(o.delta_), S_(o.S_), Pf_map_(o.Pf_map_), A_map_(o.A_map_), G_map_(o.G_map_), level_lds_(o.level_lds_)
+    {
+        PQ_HIP(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
+        auto cpd = [&](DBuf<double>& d, const DBuf<double>& s) { d.alloc(s.n ? s.n : 1); if (s.n) PQ_HIP(hipMemcpyAsync(d.p, s.p, s.bytes(), hipMemcpyDeviceToDevice, st_)); };
+        auto cpi = [&](DBuf<int>& d, const DBuf<int>& s) { d.alloc(s.n ? s.n : 1); if (s.n) PQ_HIP(hipMemcpyAsync(d.p, s.p, s.bytes(), hipMemcpyDeviceToDevice, st_)); };
+        auto cpl = [&](DBuf<long long>& d, const DBuf<long long>& s) { d.alloc(s.n ? s.n : 1); if (s.n) PQ_HIP(hipMemcpyAsync(d.p, s.p, s.bytes(), hipMemcpyDeviceToDevice, st_)); };
+        cpd(vals_, o.vals_); cpd(fronts_, o.fronts_); cpd(rdiag_, o.rdiag_); cpd(Pdiag_, o.Pdiag_); cpd(Pf_x_, o.Pf_x_); cpd(AT_x_, o.AT_x_); cpd(A_x_, o.A_x_);
+        cpd(GT_x_, o.GT_x_); cpd(G_x_, o.G_x_);
+        xp_.alloc(o.xp_.n); fvec_.alloc(o.fvec_.n); stage_vals_.alloc(o.stage_vals_.n); dvec_.alloc(o.dvec_.n);
+        cpi(diag_pos_, o.diag_pos_); cpi(P_, o.P_); cpi(level_sn_, o.level_sn_); cpi(sn_first_, o.sn_first_); cpi(front_rows_ptr_, o.front_rows_ptr_); cpi(front_rows_, o.front_rows_);
+        cpi(child_ptr_, o.child_ptr_); cpi(child_, o.child_); cpi(rel_ptr_, o.rel_ptr_); cpi(rel_, o.rel_); cpi(Pf_p_, o.Pf_p_); cpi(Pf_i_, o.Pf_i_); cpi(AT_p_, o.AT_p_);
+        cpi(AT_i_, o.AT_i_); cpi(A_p_, o.A_p_); cpi(A_i_, o.A_i_); cpi(GT_p_, o.GT_p_); cpi(GT_i_, o.GT_i_); cpi(G_p_, o.G_p_); cpi(G_i_, o.G_i_);
+        cpi(mapP_, o.mapP_); cpi(mapA_, o.mapA_); cpi(mapG_, o.mapG_); cpi(Pf_src_, o.Pf_src_); cpi(A_src_, o.A_src_); cpi(G_src_, o.G_src_); cpi(Pdiag_src_, o.Pdiag_src_);
+        cpl(a_dst_, o.a_dst_); cpl(front_off_, o.front_off_);
+        info_.alloc(1); info_h_.alloc(1);
+        PQ_HIP(hipStreamSynchronize(st_));
+    }
+
+    // dynamic LDS of the level kernel = largest front of the level that is factored inside LDS
+    void compute_level_lds()
+    {
+        static bool attr_set = false;
+        if (!attr_set) {
+            PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_front_factor), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_FRONT_DOUBLES * (int)sizeof(double)));
+            attr_set = true;
+        }
+        level_lds_.assign(S_.nlevels, 0);
+        for (int l = 0; l < S_.nlevels; ++l) {
+            long long mx = 0;
+            for (int q = S_.level_ptr[l]; q < S_.level_ptr[l + 1]; ++q) {
+                const int s = S_.level_sn[q];
+                const long long f = S_.front_rows_ptr[s + 1] - S_.front_rows_ptr[s];
+                if (f * f <= LDS_FRONT_DOUBLES) mx = std::max(mx, f * f);
+            }
+            level_lds_[l] = (int)mx * (int)sizeof(double);
+        }
+    }
+
+    FrontMeta meta() const { return FrontMeta{sn_first_.p, front_rows_ptr_.p, front_rows_.p, front_off_.p, child_ptr_.p, child_.p, rel_ptr_.p, rel_.p}; }
+
+    void build_device(const pq_sparse_data* d)
+    {
+        nnzK_ = S_.Cp[N_];
+        upload(diag_pos_, S_.diag_pos, st_); upload(P_, S_.P, st_); upload(level_sn_, S_.level_sn, st_); upload(sn_first_, S_.sn_first, st_);
+        upload(front_rows_ptr_, S_.front_rows_ptr, st_); upload(front_rows_, S_.front_rows, st_); upload(child_ptr_, S_.child_ptr, st_); upload(child_, S_.child, st_);
+        upload(rel_ptr_, S_.rel_ptr, st_); upload(rel_, S_.rel, st_); upload(a_dst_, S_.a_dst, st_); upload(front_off_, S_.front_off, st_);
+        vals_.alloc(nnzK_ ? nnzK_ : 1); vals_.zero(st_);
+        fronts_.alloc(S_.front_doubles ? (size_t)S_.front_doubles : 1);
+        rdiag_.alloc(N_); xp_.alloc(N_); fvec_.alloc(S_.front_rows.size() ? S_.front_rows.size() : 1); Pdiag_.alloc(n_); Pdiag_.zero(st_);
+        dvec_.alloc(dense::FACTOR_NB);
+        info_.alloc(1); info_h_.alloc(1);
+        // value maps K-index -> PKPt-index composed with the per-matrix maps (kkt_full.hpp:219-249)
+        const int nzP = d->P_colptr[n_], nzA = p_ ? d->AT_colptr[p_] : 0, nzG = m_ ? d->GT_colptr[m_] : 0;
+        std::vector<int> mp(nzP), ma(nzA), mg(nzG);
+        for (int q = 0; q < nzP; ++q) mp[q] = S_.PKi[S_.P_utri_to_Ki[q]];
+        for (int q = 0; q < nzA; ++q) ma[q] = S_.PKi[S_.AT_to_Ki[q]];
+        for (int q = 0; q < nzG; ++q) mg[q] = S_.PKi[S_.GT_to_Ki[q]];
+        upload(mapP_, mp, st_); upload(mapA_, ma, st_); upload(mapG_, mg, st_);
+        // symmetric completion of P (pattern + source index of every entry) and P's diagonal positions
+        {
+            std::vector<int> cnt(n_ + 1, 0);
+            for (int j = 0; j < n_; ++j) for (int q = d->P_colptr[j]; q < d->P_colptr[j + 1]; ++q) { const int i = d->P_rowind[q]; cnt[j + 1]++; if (i != j) cnt[i + 1]++; }
+            std::vector<int> fp(n_ + 1, 0);
+            for (int j = 0; j < n_; ++j) fp[j + 1] = fp[j] + cnt[j + 1];
+            std::vector<int> fi(fp[n_]), src(fp[n_]), nx(fp.begin(), fp.end() - 1), dsrc(n_, -1);
+            // rows ascending in every column: first the upper entries of column j (rows <= j), later the mirrored ones (rows > j)
+            for (int j = 0; j < n_; ++j) for (int q = d->P_colptr[j]; q < d->P_colptr[j + 1]; ++q) { const int t = nx[j]++; fi[t] = d->P_rowind[q]; src[t] = q; if (d->P_rowind[q] == j) dsrc[j] = q; }
+            for (int j = 0; j < n_; ++j) for (int q = d->P_colptr[j]; q < d->P_colptr[j + 1]; ++q) { const int i = d->P_rowind[q]; if (i != j) { const int t = nx[i]++; fi[t] = j; src[t] = q; } }
+            upload(Pf_p_, fp, st_); upload(Pf_i_, fi, st_); upload(Pf_src_, src, st_);
+            Pf_x_.alloc(fp[n_] ? fp[n_] : 1);
+            Pf_map_ = fp[n_];
+            std::vector<int> ds(n_);
+            for (int j = 0; j < n_; ++j) ds[j] = dsrc[j];
+            upload(Pdiag_src_, ds, st_);
+        }
+        // AT (n x p) and its transpose A (p x n); GT (n x m) and G
+        {
+            std::vector<int> atp(d->AT_colptr, d->AT_colptr + p_ + 1), ati(d->AT_rowind, d->AT_rowind + nzA);
+            upload(AT_p_, atp, st_); upload(AT_i_, ati, st_); AT_x_.alloc(nzA ? nzA : 1);
+            std::vector<int> tp, ti, tm;
+            transpose_with_map(n_, p_, atp.data(), ati.data(), tp, ti, tm);
+            upload(A_p_, tp, st_); upload(A_i_, ti, st_); upload(A_src_, tm, st_); A_x_.alloc(nzA ? nzA : 1); A_map_ = nzA;
+            std::vector<int> gtp(d->GT_colptr, d->GT_colptr + m_ + 1), gti(d->GT_rowind, d->GT_rowind + nzG);
+            upload(GT_p_, gtp, st_); upload(GT_i_, gti, st_); GT_x_.alloc(nzG ? nzG : 1);
+            transpose_with_map(n_, m_, gtp.data(), gti.data(), tp, ti, tm);
+            upload(G_p_, tp, st_); upload(G_i_, ti, st_); upload(G_src_, tm, st_); G_x_.alloc(nzG ? nzG : 1); G_map_ = nzG;
+        }
+        stage_vals_.alloc(std::max(1, std::max(nzP, std::max(nzA, nzG))));
+        upload_values(d);
+    }
+
+    void upload_values(const pq_sparse_data* d)
+    {
+        const int nzP = d->P_colptr[n_], nzA = p_ ? d->AT_colptr[p_] : 0, nzG = m_ ? d->GT_colptr[m_] : 0;
+        // P
+        if (nzP) {
+            PQ_HIP(hipMemcpyAsync(stage_vals_.p, d->P_val, sizeof(double) * nzP, hipMemcpyHostToDevice, st_));
+            hipLaunchKernelGGL(k_remap_values, g1(nzP), dim3(256), 0, st_, nzP, mapP_.p, stage_vals_.p, vals_.p);
+            hipLaunchKernelGGL(k_gather_values, g1(Pf_map_), dim3(256), 0, st_, Pf_map_, Pf_src_.p, stage_vals_.p, Pf_x_.p);
+        }
+        {
+            // diag(P) (0 where P has no structural diagonal): extract_P_diag, kkt_system.hpp:437-453 / P_diagonal of kkt_full.hpp
+            std::vector<double> pd(n_, 0.0);
+            for (int j = 0; j < n_; ++j) for (int q = d->P_colptr[j]; q < d->P_colptr[j + 1]; ++q) if (d->P_rowind[q] == j) pd[j] = d->P_val[q];
+            PQ_HIP(hipMemcpyAsync(Pdiag_.p, pd.data(), sizeof(double) * n_, hipMemcpyHostToDevice, st_));
+            PQ_HIP(hipStreamSynchronize(st_));
+        }
+        if (nzA) {
+            PQ_HIP(hipMemcpyAsync(AT_x_.p, d->AT_val, sizeof(double) * nzA, hipMemcpyHostToDevice, st_));
+            hipLaunchKernelGGL(k_remap_values, g1(nzA), dim3(256), 0, st_, nzA, mapA_.p, AT_x_.p, vals_.p);
+            hipLaunchKernelGGL(k_gather_values, g1(nzA), dim3(256), 0, st_, nzA, A_src_.p, AT_x_.p, A_x_.p);
+        }
+        if (nzG) {
+            PQ_HIP(hipMemcpyAsync(GT_x_.p, d->GT_val, sizeof(double) * nzG, hipMemcpyHostToDevice, st_));
+            hipLaunchKernelGGL(k_remap_values, g1(nzG), dim3(256), 0, st_, nzG, mapG_.p, GT_x_.p, vals_.p);
+            hipLaunchKernelGGL(k_gather_values, g1(nzG), dim3(256), 0, st_, nzG, G_src_.p, GT_x_.p, G_x_.p);
+        }
+        PQ_HIP(hipGetLastError());
+        PQ_HIP(hipStreamSynchronize(st_));
+    }
+
+    // a large front: children merged one kernel per child (stream order = fixed order), then the dense blocked
+    // partial LDLt of the first w columns with the MFMA kernels of the dense path
+    void factor_big_front(const FrontMeta& M, int s, int w, int f)
+    {
+        double* F = fronts_.p + S_.front_off[s];
+        for (int ci = S_.child_ptr[s]; ci < S_.child_ptr[s + 1]; ++ci) {
+            const int c = S_.child[ci];
+            const int uc = (S_.front_rows_ptr[c + 1] - S_.front_rows_ptr[c]) - (S_.sn_first[c + 1] - S_.sn_first[c]);
+            if (uc <= 0) continue;
+            const long long tot = (long long)uc * uc;
+            const int blocks = (int)std::min<long long>(2048, (tot + 255) / 256);
+            hipLaunchKernelGGL(k_front_extend_add_child, dim3(blocks), dim3(256), 0, st_, M, fronts_.p, s, c);
+        }
+        const int NB = dense::FACTOR_NB;
+        double* rd = rdiag_.p + S_.sn_first[s];
+        for (int k = 0; k < w; k += NB) {
+            const int nb = std::min(NB, w - k);
+            dense::launch_potrf_diag(true, F + k + (size_t)k * f, f, nb, S_.sn_first[s] + k, info_.p, rdiag_.p, st_);
+            const int rs = f - k - nb;
+            if (rs > 0) {
+                dense::launch_trsm_panel(true, F, f, k, nb, f, rd, st_);
+                dense::launch_extract_diag(F, f, k, nb, dvec_.p, st_);
+                dense::SyrkArgs a;
+                a.n = rs; a.kdim = nb;
+                a.A = F + (k + nb) + (size_t)k * f; a.lda = f; a.B = a.A; a.ldb = f; a.w = dvec_.p;
+                a.C = F + (k + nb) + (size_t)(k + nb) * f; a.ldc = f;
+                dense::launch_syrk(dense::EPI_SUBTRACT, a, st_);
+            }
+        }
+    }
+
+    int dev_, n_ = 0, p_ = 0, m_ = 0, N_ = 0, nnzK_ = 0;
+    double delta_ = 1.0;
+    hipStream_t st_ = nullptr;
+    sparse::Symbolic S_;
+    int Pf_map_ = 0, A_map_ = 0, G_map_ = 0;
+    std::vector<int> level_lds_;
+    DBuf<double> vals_, fronts_, rdiag_, xp_, fvec_, Pdiag_, stage_vals_, dvec_;
+    DBuf<double> Pf_x_, AT_x_, A_x_, GT_x_, G_x_;
+    DBuf<int> diag_pos_, P_, level_sn_, sn_first_, front_rows_ptr_, front_rows_, child_ptr_, child_, rel_ptr_, rel_;
+    DBuf<int> Pf_p_, Pf_i_, AT_p_, AT_i_, A_p_, A_i_, GT_p_, GT_i_, G_p_, G_i_;
+    DBuf<int> mapP_, mapA_, mapG_, Pf_src_, A_src_, G_src_, Pdiag_src_;
+    DBuf<long long> a_dst_, front_off_;
+    DBuf<int> info_;
+    HBuf<int> info_h_;
+    StageProfiler prof_;
+};
+
+}  // namespace
+
+// KKTSystem::init_kkt_solver<PIQP_SPARSE> (kkt_system.hpp:470-497): only sparse_ldlt (KKT_FULL) exists in this release;
+// the condensed modes and sparse_multistage report "kkt solver not supported" exactly like a build without them.
+KKTSolverBase* make_sparse_kkt(const pq_sparse_data* data, int kkt_solver, int device)
+{
+    if (kkt_solver != PQ_SPARSE_LDLT) return nullptr;
+    return new SparseKKT(data, device);
+}
+
+}  // namespace pq

@@ -1,0 +1,63 @@
+// piqp_amd/csrc/sparse_symbolic.hpp -- host-side (setup-time) analysis for the sparse KKT backend.
+//
+// Replaces the integer work of sparse::KKT's constructor (reference sparse/kkt.hpp:51-70):
+//   create_kkt_matrix (sparse/kkt_full.hpp:39-170)            -> build_kkt_full
+//   AMDOrdering::init (sparse/ordering.hpp:67-84, Eigen AMD)  -> amd_order
+//   permute_sparse_symmetric_matrix (sparse/utils.hpp:32-128) -> permute_sym_upper
+//   LDLt::factorize_symbolic (sparse/ldlt.hpp:42-99)          -> etree / column structure, extended here to
+//                                                                supernodes + multifrontal assembly maps
+// The reference's numeric phase is an up-looking row-by-row LDLt (strictly serial).  The device numeric
+// phase is a supernodal multifrontal LDLt: the elimination tree is postordered, columns with identical
+// structure are merged into supernodes, every supernode owns a dense frontal matrix in HBM, and fronts of
+// the same tree level are factored concurrently.  This file computes everything that depends only on the
+// sparsity pattern.
+#pragma once
+
+#include <vector>
+
+#include "common.hpp"
+
+namespace pq {
+namespace sparse {
+
+using IVec = std::vector<int>;
+using DVec = std::vector<double>;
+
+struct Symbolic {
+    int n = 0, p = 0, m = 0, N = 0;  // N = n + p + m (KKT_FULL dimension)
+    // K (upper, diagonal last in every column) and the value maps of kkt_full.hpp
+    IVec Kp, Ki;
+    DVec Kx;
+    IVec P_utri_to_Ki, AT_to_Ki, GT_to_Ki;
+    // ordering: P[new] = old, P_inv[old] = new (AMD composed with the etree postorder)
+    IVec P, P_inv;
+    // permuted matrix PKPt (upper) and K-index -> PKPt-index map
+    IVec Cp, Ci, PKi;
+    IVec diag_pos;  // PKPt value index of the diagonal of ORIGINAL column `col` (kkt_full.hpp:181,194,207)
+    // elimination tree / supernodes / fronts
+    IVec etree;
+    int nsuper = 0;
+    IVec sn_first;          // nsuper+1: first column of each supernode
+    IVec sn_of_col;         // N
+    IVec sn_parent;         // assembly tree
+    IVec front_rows_ptr;    // nsuper+1 into front_rows
+    IVec front_rows;        // global (permuted) indices of every front, pivots first, sorted
+    std::vector<long long> front_off;  // nsuper+1 offsets (in doubles) into the front workspace
+    IVec level_ptr, level_sn;          // supernodes grouped by level (leaves first)
+    int nlevels = 0;
+    // assembly: PKPt value q goes to fronts[a_dst[q]]
+    std::vector<long long> a_dst;
+    // extend-add: for child c, rel[rel_ptr[c] + i] = position in the parent's front of c's i-th update row
+    IVec rel_ptr, rel;
+    IVec child_ptr, child;  // children lists (fixed order = increasing supernode id)
+    long long front_doubles = 0;
+    long long nnzL = 0;      // entries of L below the diagonal (for the roofline byte counts)
+    double flops = 0.0;      // sum_j (c_j^2 + 3 c_j)
+    int max_front = 0;
+};
+
+void amd_order(int n, const int* Ap, const int* Ai, int* perm);
+void analyse_kkt_full(const pq_sparse_data* d, Symbolic& S);
+
+}  // namespace sparse
+}  // namespace pq

@@ -152,6 +152,52 @@ class Data:
         return d
 
 
+class SparseData(Data):
+    """sparse::Data<T,I> (sparse/data.hpp:26-231): P_utri, AT, GT as CSC int32/fp64 + the same bound bookkeeping."""
+
+    def __init__(self, P, c, A=None, b=None, G=None, h_l=None, h_u=None, x_l=None, x_u=None):
+        import scipy.sparse as sp
+        P = sp.csc_matrix(P)
+        n = P.shape[0]
+        self.n = n
+        self.p = 0 if A is None else A.shape[0]
+        self.m = 0 if G is None else G.shape[0]
+        self.P_utri = sp.triu(P, format="csc"); self.P_utri.sort_indices()
+        self.AT = sp.csc_matrix(A).T.tocsc() if self.p else sp.csc_matrix((n, 0)); self.AT.sort_indices()
+        self.GT = sp.csc_matrix(G).T.tocsc() if self.m else sp.csc_matrix((n, 0)); self.GT.sort_indices()
+        self.c = np.array(c, dtype=np.float64)
+        self.b = np.array(b, dtype=np.float64) if self.p else np.zeros(0)
+        self.h_l = np.zeros(self.m); self.h_u = np.zeros(self.m)
+        self.x_l = np.zeros(n); self.x_u = np.zeros(n)
+        self.x_b_scaling = np.ones(n)
+        self.set_h_l(h_l); self.set_h_u(h_u); self.disable_inf_constraints()
+        self.set_x_l(x_l); self.set_x_u(x_u)
+
+    def disable_inf_constraints(self):
+        both = (self.h_l <= -PIQP_INF) & (self.h_u >= PIQP_INF)
+        if both.any():
+            for i in np.nonzero(both)[0]:
+                self.GT.data[self.GT.indptr[i]:self.GT.indptr[i + 1]] = 0.0
+            self.h_l[both] = -1.0
+            self.h_u[both] = 1.0
+            self.set_h_l(self.h_l.copy()); self.set_h_u(self.h_u.copy())
+
+    def descriptor(self):
+        d = _lib.SparseData()
+        d.n, d.p, d.m = self.n, self.p, self.m
+        k = []
+        for M in (self.P_utri, self.AT, self.GT):
+            k += [_i32(M.indptr), _i32(M.indices), np.ascontiguousarray(M.data, dtype=np.float64)]
+        k += [_i32(self.h_l_idx), _i32(self.h_u_idx), _i32(self.x_l_idx), _i32(self.x_u_idx), np.ascontiguousarray(self.x_b_scaling, dtype=np.float64)]
+        self._keep = k
+        (d.P_colptr, d.P_rowind, d.P_val, d.AT_colptr, d.AT_rowind, d.AT_val, d.GT_colptr, d.GT_rowind, d.GT_val) = (a.ctypes.data for a in k[:9])
+        d.n_h_l, d.n_h_u, d.n_x_l, d.n_x_u = self.n_h_l, self.n_h_u, self.n_x_l, self.n_x_u
+        d.h_l_idx, d.h_u_idx, d.x_l_idx, d.x_u_idx = (a.ctypes.data for a in k[9:13])
+        d.x_b_scaling = k[13].ctypes.data
+        d.mem = MEM_HOST
+        return d
+
+
 class _Handle:
     _destroy = None
 
@@ -160,6 +206,10 @@ class _Handle:
         if h and getattr(self, "_owned", True):
             getattr(self.L, self._destroy)(h)
             self.h = None
+
+
+class SparseKKTMixin:
+    pass
 
 
 class DenseKKT(_Handle):
@@ -174,7 +224,10 @@ class DenseKKT(_Handle):
         else:
             h = C.c_void_p()
             desc = data.descriptor()
-            check(self.L.pq_kkt_create_dense(C.byref(h), C.byref(desc), kkt_solver, device), "pq_kkt_create_dense")
+            if isinstance(data, SparseData):
+                check(self.L.pq_kkt_create_sparse(C.byref(h), C.byref(desc), kkt_solver, device), "pq_kkt_create_sparse")
+            else:
+                check(self.L.pq_kkt_create_dense(C.byref(h), C.byref(desc), kkt_solver, device), "pq_kkt_create_dense")
             self.h = h
         n, p, m = C.c_int(), C.c_int(), C.c_int()
         self.L.pq_kkt_dims(self.h, C.byref(n), C.byref(p), C.byref(m))
@@ -201,7 +254,13 @@ class DenseKKT(_Handle):
 
     def update_data(self, data, options):
         desc = data.descriptor()
-        check(self.L.pq_kkt_update_data_dense(self.h, C.byref(desc), options), "update_data")
+        if isinstance(data, SparseData):
+            check(self.L.pq_kkt_update_data_sparse(self.h, C.byref(desc), options), "update_data")
+        else:
+            check(self.L.pq_kkt_update_data_dense(self.h, C.byref(desc), options), "update_data")
+
+    def print_info(self):
+        check(self.L.pq_kkt_print_info(self.h))
 
     def update_scalings_and_factor(self, delta, x_reg, z_reg):
         x_reg, z_reg = _f64(x_reg), _f64(z_reg)
@@ -281,7 +340,10 @@ class KKTSystem(_Handle):
         else:
             h = C.c_void_p()
             desc = data.descriptor()
-            check(self.L.pq_kktsys_create_dense(C.byref(h), C.byref(desc), C.byref(self.settings), device), "pq_kktsys_create_dense")
+            if isinstance(data, SparseData):
+                check(self.L.pq_kktsys_create_sparse(C.byref(h), C.byref(desc), C.byref(self.settings), device), "pq_kktsys_create_sparse")
+            else:
+                check(self.L.pq_kktsys_create_dense(C.byref(h), C.byref(desc), C.byref(self.settings), device), "pq_kktsys_create_dense")
             self.h = h
         self.n, self.p, self.m = (data.n, data.p, data.m) if data is not None else (None, None, None)
         self._mode = MEM_HOST
@@ -304,7 +366,10 @@ class KKTSystem(_Handle):
 
     def update_data(self, data, options):
         desc = data.descriptor()
-        check(self.L.pq_kktsys_update_data_dense(self.h, C.byref(desc), options))
+        if isinstance(data, SparseData):
+            check(self.L.pq_kktsys_update_data_sparse(self.h, C.byref(desc), options))
+        else:
+            check(self.L.pq_kktsys_update_data_dense(self.h, C.byref(desc), options))
 
     def update_scalings_and_factor(self, iterative_refinement, rho, delta, vars_):
         self._set_mode(vars_)
