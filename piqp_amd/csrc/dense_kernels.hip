@@ -13,6 +13,8 @@
 // along contiguous columns (1 KiB per wave-instruction).
 #include "dense_kernels.hpp"
 
+#include <algorithm>
+
 namespace pq {
 namespace dense {
 
@@ -122,8 +124,9 @@ __global__ __launch_bounds__(256, 2) void k_syrk_lower(SyrkArgs a)
     double* As = smem;                    // [2][BK][LDS_LD]
     double* Bs = smem + 2 * BK * LDS_LD;  // [2][BK][LDS_LD]
 
-    // linear block id -> lower-triangular tile (ti >= tj)
-    const int b = blockIdx.x;
+    // linear block id -> lower-triangular tile (ti >= tj); split launches map several K-slices onto one tile
+    const int b = a.tile_begin + (int)blockIdx.x / a.k_split;
+    const int kslice = (int)blockIdx.x % a.k_split;
     int ti = (int)((sqrt(8.0 * (double)b + 1.0) - 1.0) * 0.5);
     while ((ti + 1) * (ti + 2) / 2 <= b) ++ti;
     while (ti * (ti + 1) / 2 > b) --ti;
@@ -141,12 +144,16 @@ __global__ __launch_bounds__(256, 2) void k_syrk_lower(SyrkArgs a)
 #pragma unroll
         for (int y = 0; y < 4; ++y) acc[x][y] = (d4){0.0, 0.0, 0.0, 0.0};
 
-    const int nkt = (a.kdim + BK - 1) / BK;
+    const int nkt_all = (a.kdim + BK - 1) / BK;
+    const int kt_per = (nkt_all + a.k_split - 1) / a.k_split;
+    const int kt_begin = kslice * kt_per;
+    const int nkt = max(0, min(nkt_all, kt_begin + kt_per) - kt_begin);
     d2 va[4], vb[4];
     if (nkt > 0) {
-        const bool chk = edge || (BK > a.kdim);
-        if (chk) { load_tile<true>(a.A, a.lda, row0, 0, a.n, a.kdim, tid, va); load_tile<true>(a.B, a.ldb, col0, 0, a.n, a.kdim, tid, vb); scale_tile<true>(a.w, 0, a.kdim, tid, vb); }
-        else { load_tile<false>(a.A, a.lda, row0, 0, a.n, a.kdim, tid, va); load_tile<false>(a.B, a.ldb, col0, 0, a.n, a.kdim, tid, vb); scale_tile<false>(a.w, 0, a.kdim, tid, vb); }
+        const int k0 = kt_begin * BK;
+        const bool chk = edge || (k0 + BK > a.kdim);
+        if (chk) { load_tile<true>(a.A, a.lda, row0, k0, a.n, a.kdim, tid, va); load_tile<true>(a.B, a.ldb, col0, k0, a.n, a.kdim, tid, vb); scale_tile<true>(a.w, k0, a.kdim, tid, vb); }
+        else { load_tile<false>(a.A, a.lda, row0, k0, a.n, a.kdim, tid, va); load_tile<false>(a.B, a.ldb, col0, k0, a.n, a.kdim, tid, vb); scale_tile<false>(a.w, k0, a.kdim, tid, vb); }
         store_tile(As, tid, va);
         store_tile(Bs, tid, vb);
     }
@@ -156,7 +163,7 @@ __global__ __launch_bounds__(256, 2) void k_syrk_lower(SyrkArgs a)
         const int cur = kt & 1;
         const bool more = (kt + 1 < nkt);
         if (more) {
-            const int k0 = (kt + 1) * BK;
+            const int k0 = (kt_begin + kt + 1) * BK;
             const bool chk = edge || (k0 + BK > a.kdim);
             if (chk) { load_tile<true>(a.A, a.lda, row0, k0, a.n, a.kdim, tid, va); load_tile<true>(a.B, a.ldb, col0, k0, a.n, a.kdim, tid, vb); scale_tile<true>(a.w, k0, a.kdim, tid, vb); }
             else { load_tile<false>(a.A, a.lda, row0, k0, a.n, a.kdim, tid, va); load_tile<false>(a.B, a.ldb, col0, k0, a.n, a.kdim, tid, vb); scale_tile<false>(a.w, k0, a.kdim, tid, vb); }
@@ -185,6 +192,18 @@ __global__ __launch_bounds__(256, 2) void k_syrk_lower(SyrkArgs a)
     }
 
     if (skip_wave) return;
+    if (a.part) {
+        // split launch: raw partial tile (column-major 128 x 128) for k_syrk_tail_reduce; fixed slot per (tile, slice)
+        double* P = a.part + (size_t)blockIdx.x * TS * TS;
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+#pragma unroll
+            for (int y = 0; y < 4; ++y)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    P[(wr * 64 + y * 16 + (lane & 15)) + (size_t)(wc * 64 + x * 16 + (lane >> 4) + 4 * r) * TS] = acc[x][y][r];
+        return;
+    }
     // epilogue: lane holds rows gi (consecutive over lane&15) and columns gj = base + (lane>>4) + 4*r
 #pragma unroll
     for (int x = 0; x < 4; ++x) {
@@ -213,13 +232,95 @@ __global__ __launch_bounds__(256, 2) void k_syrk_lower(SyrkArgs a)
     }
 }
 
-void launch_syrk(int epi, const SyrkArgs& args_in, hipStream_t s)
+// sums the K-slices of a split tile in slice order and applies the epilogue (one workgroup per tile)
+template <int EPI>
+__global__ __launch_bounds__(256) void k_syrk_tail_reduce(SyrkArgs a)
+{
+    const int b = a.tile_begin + (int)blockIdx.x;
+    int ti = (int)((sqrt(8.0 * (double)b + 1.0) - 1.0) * 0.5);
+    while ((ti + 1) * (ti + 2) / 2 <= b) ++ti;
+    while (ti * (ti + 1) / 2 > b) --ti;
+    const int tj = b - ti * (ti + 1) / 2;
+    const int row0 = ti * TS, col0 = tj * TS;
+    const double* P0 = a.part + (size_t)blockIdx.x * a.k_split * TS * TS;
+    {
+        const int idx = (int)blockIdx.y * 256 + (int)threadIdx.x;  // one element per thread
+        const int li = idx & (TS - 1), lj = idx >> 7;
+        const int gi = row0 + li, gj = col0 + lj;
+        if (gi >= a.n || gj >= a.n || gi < gj) return;
+        double v = 0.0;
+#pragma unroll 8
+        for (int sl = 0; sl < a.k_split; ++sl) v += P0[(size_t)sl * TS * TS + idx];
+        const size_t ci = (size_t)gi + (size_t)gj * a.ldc;
+        if (EPI == EPI_ASSEMBLE) {
+            double base = a.Pfull[(size_t)gi + (size_t)gj * a.ldp];
+            if (gi == gj) base += a.x_reg[gi];
+            if (a.ATA) base += a.dinv * a.ATA[(size_t)gi + (size_t)gj * a.ldata];
+            a.C[ci] = base + v;
+        } else if (EPI == EPI_SUBTRACT) {
+            a.C[ci] -= v;
+        } else {
+            a.C[ci] = v;
+        }
+    }
+}
+
+static int g_slots = 0;  // resident workgroup slots of the SYRK kernel (2 per CU)
+static int syrk_slots()
+{
+    if (g_slots == 0) {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        g_slots = 2 * (cus > 0 ? cus : 256);
+    }
+    return g_slots;
+}
+// tail plan: the last `rem` tiles of a launch that would occupy < 60 % of one more round are split along K
+static void syrk_tail_plan(int n, int kdim, int& rem, int& ksplit)
+{
+    const int T = div_up(n, TS);
+    const int ntiles = T * (T + 1) / 2;
+    const int slots = syrk_slots();
+    const int nkt = div_up(kdim, BK);
+    rem = ntiles % slots;
+    ksplit = 1;
+    if (ntiles > slots && rem > 0 && rem * 10 < slots * 6) {
+        int s = slots / rem;
+        s = std::min(s, nkt / 4);
+        if (s >= 2) ksplit = s;
+    }
+    if (ksplit == 1) rem = 0;
+}
+size_t syrk_split_workspace_doubles(int n, int kdim)
+{
+    int rem, ks;
+    syrk_tail_plan(n, kdim, rem, ks);
+    return (size_t)rem * ks * TS * TS;
+}
+
+template <int EPI>
+static void launch_syrk_t(SyrkArgs a, hipStream_t s, double* ws, size_t ws_doubles)
+{
+    const int T = div_up(a.n, TS);
+    const int ntiles = T * (T + 1) / 2;
+    int rem = 0, ks = 1;
+    if (ws) syrk_tail_plan(a.n, a.kdim, rem, ks);
+    if (rem > 0 && (size_t)rem * ks * TS * TS > ws_doubles) { rem = 0; ks = 1; }
+    const int main_tiles = ntiles - rem;
+    a.tile_begin = 0; a.k_split = 1; a.part = nullptr;
+    hipLaunchKernelGGL(k_syrk_lower<EPI>, dim3(main_tiles), dim3(256), SYRK_LDS_BYTES, s, a);
+    if (rem > 0) {
+        a.tile_begin = main_tiles; a.k_split = ks; a.part = ws;
+        hipLaunchKernelGGL(k_syrk_lower<EPI>, dim3(rem * ks), dim3(256), SYRK_LDS_BYTES, s, a);
+        hipLaunchKernelGGL(k_syrk_tail_reduce<EPI>, dim3(rem, TS * TS / 256), dim3(256), 0, s, a);
+    }
+}
+
+void launch_syrk(int epi, const SyrkArgs& args_in, hipStream_t s, double* split_ws, size_t split_ws_doubles)
 {
     SyrkArgs a = args_in;
     if (a.n <= 0) return;
     a.unaligned = ((a.lda & 1) || (a.ldb & 1) || (reinterpret_cast<uintptr_t>(a.A) & 15) || (reinterpret_cast<uintptr_t>(a.B) & 15)) ? 1 : 0;
-    const int T = div_up(a.n, TS);
-    const int nblocks = T * (T + 1) / 2;
     static bool attr_set = false;
     if (!attr_set) {
         PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk_lower<EPI_ASSEMBLE>), hipFuncAttributeMaxDynamicSharedMemorySize, SYRK_LDS_BYTES));
@@ -228,9 +329,9 @@ void launch_syrk(int epi, const SyrkArgs& args_in, hipStream_t s)
         attr_set = true;
     }
     switch (epi) {
-    case EPI_ASSEMBLE: hipLaunchKernelGGL(k_syrk_lower<EPI_ASSEMBLE>, dim3(nblocks), dim3(256), SYRK_LDS_BYTES, s, a); break;
-    case EPI_SUBTRACT: hipLaunchKernelGGL(k_syrk_lower<EPI_SUBTRACT>, dim3(nblocks), dim3(256), SYRK_LDS_BYTES, s, a); break;
-    default: hipLaunchKernelGGL(k_syrk_lower<EPI_STORE>, dim3(nblocks), dim3(256), SYRK_LDS_BYTES, s, a); break;
+    case EPI_ASSEMBLE: launch_syrk_t<EPI_ASSEMBLE>(a, s, split_ws, split_ws_doubles); break;
+    case EPI_SUBTRACT: launch_syrk_t<EPI_SUBTRACT>(a, s, split_ws, split_ws_doubles); break;
+    default: launch_syrk_t<EPI_STORE>(a, s, split_ws, split_ws_doubles); break;
     }
     PQ_HIP(hipGetLastError());
 }
@@ -252,6 +353,35 @@ void launch_assemble_no_g(int n, const double* Pf, const double* x_reg, const do
     if (n <= 0) return;
     hipLaunchKernelGGL(k_assemble_no_g, dim3(div_up(n, 256), n), dim3(256), 0, s, n, Pf, x_reg, ATA, dinv, C);
     PQ_HIP(hipGetLastError());
+}
+
+
+// Stage the lower triangle of an nr x nr block (nr <= NBLK) into LDS as Ls[c * LD + r], zeros above the diagonal,
+// identity padding beyond nr.  All loads are unconditional (clamped address + select) and issued 16 at a time per
+// thread, so a thread has 16 L2 round trips in flight instead of one per loop iteration.
+template <int NBLK, int LD>
+__device__ __forceinline__ void stage_lower_block(const double* __restrict__ A, int lda, int nr, double* __restrict__ Ls, int tid)
+{
+    constexpr int PER_THREAD = NBLK * NBLK / 256;
+    constexpr int BATCH = 16;
+#pragma unroll 1
+    for (int b0 = 0; b0 < PER_THREAD; b0 += BATCH) {
+        double v[BATCH];
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+            const int idx = (b0 + u) * 256 + tid;
+            const int r = idx % NBLK, c = idx / NBLK;
+            const bool ok = (r < nr) && (c < nr) && (r >= c);
+            const double* p = ok ? (A + r + (size_t)c * lda) : A;
+            const double t = *p;
+            v[u] = ok ? t : ((r == c) ? 1.0 : 0.0);
+        }
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+            const int idx = (b0 + u) * 256 + tid;
+            Ls[(idx / NBLK) * LD + (idx % NBLK)] = v[u];
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -289,14 +419,7 @@ __global__ __launch_bounds__(256) void k_potrf_diag(double* __restrict__ A, int 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nbp = (nb + 15) & ~15;
     const int nt = nbp >> 4;
-    for (int c = wave; c < nbp; c += 4) {
-        for (int r = lane; r < nbp; r += 64) {
-            double v = 0.0;
-            if (r < nb && c < nb) { if (r >= c) v = A[r + (size_t)c * lda]; }
-            else if (r == c) v = 1.0;  // identity padding
-            S[c * PLD + r] = v;
-        }
-    }
+    stage_lower_block<NB, PLD>(A, lda, nb, S, tid);
     __syncthreads();
 
     for (int jb = 0; jb < nt; ++jb) {
@@ -346,12 +469,13 @@ __global__ __launch_bounds__(256) void k_potrf_diag(double* __restrict__ A, int 
                 double x[16];
 #pragma unroll
                 for (int c = 0; c < 16; ++c) x[c] = S[(j0 + c) * PLD + i];
+                // right-looking (axpy) substitution: the updates of one column step are independent of each other
 #pragma unroll
                 for (int c = 0; c < 16; ++c) {
-                    double sacc = x[c];
+                    const double yc = x[c];              // LLT: y = x l_cc ; LDLT: y = x d_c
+                    x[c] = yc * rd16[c];
 #pragma unroll
-                    for (int q = 0; q < c; ++q) sacc -= (LDLT ? x[q] * S[(j0 + q) * PLD + j0 + q] : x[q]) * S[(j0 + q) * PLD + j0 + c];
-                    x[c] = sacc * rd16[c];
+                    for (int c2 = c + 1; c2 < 16; ++c2) x[c2] -= (LDLT ? yc : x[c]) * S[(j0 + c) * PLD + j0 + c2];
                 }
 #pragma unroll
                 for (int c = 0; c < 16; ++c) S[(j0 + c) * PLD + i] = x[c];
@@ -362,23 +486,37 @@ __global__ __launch_bounds__(256) void k_potrf_diag(double* __restrict__ A, int 
         {
             const int rem = nt - 1 - jb;
             const int ntile = rem * (rem + 1) / 2;
-            for (int t = wave; t < ntile; t += 4) {
-                int tr = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
-                while ((tr + 1) * (tr + 2) / 2 <= t) ++tr;
-                while (tr * (tr + 1) / 2 > t) --tr;
-                const int tc = t - tr * (tr + 1) / 2;
-                const int R0 = (jb + 1 + tr) * 16, C0 = (jb + 1 + tc) * 16;
-                d4 acc = {0.0, 0.0, 0.0, 0.0};
+            for (int t = wave; t < ntile; t += 8) {
+                int R0[2], C0[2];
+                bool on[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int tt = t + 4 * u;
+                    on[u] = tt < ntile;
+                    int tr = (int)((sqrtf(8.0f * (float)tt + 1.0f) - 1.0f) * 0.5f);
+                    while ((tr + 1) * (tr + 2) / 2 <= tt) ++tr;
+                    while (tr * (tr + 1) / 2 > tt) --tr;
+                    const int tc = tt - tr * (tr + 1) / 2;
+                    R0[u] = on[u] ? (jb + 1 + tr) * 16 : (jb + 1) * 16;
+                    C0[u] = on[u] ? (jb + 1 + tc) * 16 : (jb + 1) * 16;
+                }
+                d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
                     const int k = j0 + ks * 4 + (lane >> 4);
-                    const double av = S[k * PLD + R0 + (lane & 15)];
-                    double bv = S[k * PLD + C0 + (lane & 15)];
-                    if (LDLT) bv *= S[k * PLD + k];
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(bv, av, acc, 0, 0, 0);
+                    const double dk = LDLT ? S[k * PLD + k] : 1.0;
+                    const double av0 = S[k * PLD + R0[0] + (lane & 15)], av1 = S[k * PLD + R0[1] + (lane & 15)];
+                    double bv0 = S[k * PLD + C0[0] + (lane & 15)], bv1 = S[k * PLD + C0[1] + (lane & 15)];
+                    if (LDLT) { bv0 *= dk; bv1 *= dk; }
+                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(bv0, av0, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(bv1, av1, acc1, 0, 0, 0);
                 }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) S[(C0 + (lane >> 4) + 4 * r) * PLD + R0 + (lane & 15)] -= acc[r];
+                for (int r = 0; r < 4; ++r) S[(C0[0] + (lane >> 4) + 4 * r) * PLD + R0[0] + (lane & 15)] -= acc0[r];
+                if (on[1]) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) S[(C0[1] + (lane >> 4) + 4 * r) * PLD + R0[1] + (lane & 15)] -= acc1[r];
+                }
             }
         }
         __syncthreads();
@@ -420,20 +558,44 @@ __global__ __launch_bounds__(256) void k_trsm_panel(double* __restrict__ A, int 
     const int nbp = (nb + 15) & ~15, nt = nbp >> 4;
     const int r0 = k0 + nb + blockIdx.x * RB;
     const double* L11 = A + k0 + (size_t)k0 * lda;
-    for (int c = wave; c < nbp; c += 4) {
-        const int r = lane;
-        Xs[c * XLD + r] = (r0 + r < n && c < nb) ? A[(r0 + r) + (size_t)(k0 + c) * lda] : 0.0;
+    {
+        // 64 rows x 128 columns: 32 loads per thread, issued 16 at a time (unconditional, clamped)
+#pragma unroll 1
+        for (int b0 = 0; b0 < 32; b0 += 16) {
+            double v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int c = wave + 4 * (b0 + u);
+                const bool ok = (r0 + lane < n) && (c < nb);
+                const double* p = ok ? (A + (r0 + lane) + (size_t)(k0 + c) * lda) : A;
+                const double t = *p;
+                v[u] = ok ? t : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) Xs[(wave + 4 * (b0 + u)) * XLD + lane] = v[u];
+        }
     }
     for (int jb = 0; jb < nt; ++jb) {
         const int j0 = jb * 16;
         __syncthreads();
         // stage the 16-column strip of L11 (rows j0 .. nbp) and its reciprocal pivots
-        for (int q = wave; q < 16; q += 4) {
-            for (int rr = j0 + lane; rr < nbp; rr += 64) {
-                double v = 0.0;
-                if (rr < nb && j0 + q < nb) v = L11[rr + (size_t)(j0 + q) * lda];
-                else if (rr == j0 + q) v = 1.0;
-                Ls[q * LSLD + rr] = v;
+        {
+            // 16 columns x (nbp - j0) rows: 4 columns per wave, 2 row chunks -> 8 unconditional loads per thread
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int q = wave + 4 * (u >> 1);
+                const int rr = j0 + lane + 64 * (u & 1);
+                const bool ok = (rr < nb) && (j0 + q < nb);
+                const double* p = ok ? (L11 + rr + (size_t)(j0 + q) * lda) : L11;
+                const double t = *p;
+                v[u] = ok ? t : ((rr == j0 + q) ? 1.0 : 0.0);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int q = wave + 4 * (u >> 1);
+                const int rr = j0 + lane + 64 * (u & 1);
+                if (rr < nbp) Ls[q * LSLD + rr] = v[u];
             }
         }
         if (tid < 16) rd[tid] = (j0 + tid < nb) ? rdiag[k0 + j0 + tid] : 1.0;
@@ -444,10 +606,9 @@ __global__ __launch_bounds__(256) void k_trsm_panel(double* __restrict__ A, int 
             for (int c = 0; c < 16; ++c) x[c] = Xs[(j0 + c) * XLD + tid];
 #pragma unroll
             for (int c = 0; c < 16; ++c) {
-                double sacc = x[c];
+                if (!LDLT) x[c] *= rd[c];               // LDLT keeps Y = A L^-T (unit) here, D^-1 applied at the end
 #pragma unroll
-                for (int q = 0; q < c; ++q) sacc -= x[q] * Ls[q * LSLD + j0 + c];
-                x[c] = LDLT ? sacc : sacc * rd[c];
+                for (int c2 = c + 1; c2 < 16; ++c2) x[c2] -= x[c] * Ls[c * LSLD + j0 + c2];
             }
 #pragma unroll
             for (int c = 0; c < 16; ++c) Xs[(j0 + c) * XLD + tid] = x[c];
@@ -455,18 +616,26 @@ __global__ __launch_bounds__(256) void k_trsm_panel(double* __restrict__ A, int 
         __syncthreads();
         // update remaining column tiles: Xs[:, ct] -= X_jb * L11[ct, jb]^T   (MFMA, both operands from LDS)
         const int rem = nt - 1 - jb;
-        for (int t = wave; t < rem * 4; t += 4) {
-            const int ct = jb + 1 + t / 4, rt = t & 3;
-            d4 acc = {0.0, 0.0, 0.0, 0.0};
+        for (int t = wave; t < rem * 4; t += 8) {
+            const int t1 = t + 4;
+            const bool on1 = t1 < rem * 4;
+            const int ct0 = jb + 1 + t / 4, rt0 = t & 3;
+            const int ct1 = on1 ? jb + 1 + t1 / 4 : ct0, rt1 = on1 ? (t1 & 3) : rt0;
+            d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const int kq = ks * 4 + (lane >> 4);
-                const double xv = Xs[(j0 + kq) * XLD + rt * 16 + (lane & 15)];
-                const double lv = Ls[kq * LSLD + ct * 16 + (lane & 15)];
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(lv, xv, acc, 0, 0, 0);
+                const double xv0 = Xs[(j0 + kq) * XLD + rt0 * 16 + (lane & 15)], xv1 = Xs[(j0 + kq) * XLD + rt1 * 16 + (lane & 15)];
+                const double lv0 = Ls[kq * LSLD + ct0 * 16 + (lane & 15)], lv1 = Ls[kq * LSLD + ct1 * 16 + (lane & 15)];
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(lv0, xv0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(lv1, xv1, acc1, 0, 0, 0);
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) Xs[(ct * 16 + (lane >> 4) + 4 * r) * XLD + rt * 16 + (lane & 15)] -= acc[r];
+            for (int r = 0; r < 4; ++r) Xs[(ct0 * 16 + (lane >> 4) + 4 * r) * XLD + rt0 * 16 + (lane & 15)] -= acc0[r];
+            if (on1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Xs[(ct1 * 16 + (lane >> 4) + 4 * r) * XLD + rt1 * 16 + (lane & 15)] -= acc1[r];
+            }
         }
     }
     __syncthreads();
@@ -598,13 +767,7 @@ __global__ __launch_bounds__(256) void k_trsv_fwd_step(const double* __restrict_
     const int row0 = r * TB, nrows = min(TB, n - row0);
     const bool diag = (r == j);
     if (diag) {
-        for (int cc = wave; cc < TB; cc += 4) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int rr = lane + 64 * h;
-                Ls[cc * (TB + 1) + rr] = (rr < nrows && cc < nrows && rr >= cc) ? L[(row0 + rr) + (size_t)(row0 + cc) * ld] : (rr == cc ? 1.0 : 0.0);
-            }
-        }
+        stage_lower_block<TB, TB + 1>(L + row0 + (size_t)row0 * ld, ld, nrows, Ls, tid);
         if (tid < TB) rd[tid] = (rdiag && tid < nrows) ? rdiag[row0 + tid] : 1.0;
     }
     const int row = tid & 127, half = tid >> 7;
@@ -681,19 +844,99 @@ __global__ __launch_bounds__(256) void k_trsv_bwd_step(const double* __restrict_
         return;
     }
     if (tid < TB) { bs[tid] = mine; rd[tid] = (rdiag && tid < nrows) ? rdiag[row0 + tid] : 1.0; }
-    for (int cc = wave; cc < TB; cc += 4) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int rr = lane + 64 * h;
-            Ls[cc * (TB + 1) + rr] = (rr < nrows && cc < nrows && rr >= cc) ? L[(row0 + rr) + (size_t)(row0 + cc) * ld] : (rr == cc ? 1.0 : 0.0);
-        }
-    }
+    stage_lower_block<TB, TB + 1>(L + row0 + (size_t)row0 * ld, ld, nrows, Ls, tid);
     __syncthreads();
     if (wave == 0) {
         double b0 = bs[lane], b1 = bs[lane + 64];
         diag_solve_bwd(Ls, rd, lane, b0, b1);
         if (lane < nrows) x[row0 + lane] = b0;
         if (lane + 64 < nrows) x[row0 + lane + 64] = b1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Persistent triangular sweep: ONE launch per sweep, one workgroup per 128-row block, blocks chained through
+// per-block flags instead of kernel boundaries.  Block r waits only for the x_j it consumes next; the 128x128
+// block of L it will multiply by x_j is already in registers when x_j arrives (its loads are issued before the
+// wait), and its own diagonal block is staged in LDS at kernel start.  Hand-off follows the write-through recipe
+// (cdna_hip_programming.md, Guideline 16 R1): x_r is stored with agent-scope relaxed atomics (sc1, L2
+// write-through), every storing wave drains vmcnt, then one lane publishes flag[r]; consumers poll the flag
+// relaxed and read x_j with agent-scope loads (sc1), so no acquire fence is needed.  Waits only ever target
+// workgroups with a LOWER block index (dispatched earlier), and every spin is bounded (err flag on timeout).
+typedef unsigned long long u64;
+__device__ __forceinline__ void st_agent(double* p, double v)
+{
+    __hip_atomic_store(reinterpret_cast<u64*>(p), (u64)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double ld_agent(const double* p)
+{
+    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const u64*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
+template <bool FWD>
+__global__ __launch_bounds__(256) void k_trsv_persistent(const double* __restrict__ L, int ld, int n, double* __restrict__ x, const double* __restrict__ rdiag,
+                                                         int nblk, int* __restrict__ flags, int* __restrict__ err)
+{
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double* Ls = sm;                    // own diagonal block, Ls[c * (TB+1) + r]
+    double* xs = sm + TB * (TB + 1);    // x_j of the block being consumed
+    double* bs = xs + TB;
+    double* rd = bs + TB;
+    __shared__ int ok_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = FWD ? (int)blockIdx.x : nblk - 1 - (int)blockIdx.x;
+    const int row0 = r * TB, nrows = min(TB, n - row0);
+    // stage the diagonal block and reciprocal pivots
+    stage_lower_block<TB, TB + 1>(L + row0 + (size_t)row0 * ld, ld, nrows, Ls, tid);
+    if (tid < TB) rd[tid] = (rdiag && tid < nrows) ? rdiag[row0 + tid] : 1.0;
+    const int row = tid & 127, half = tid >> 7;
+    double mine = (half == 0 && row < nrows) ? x[row0 + row] : 0.0;
+    double acc = 0.0;
+    const int nsteps = FWD ? r : nblk - 1 - r;
+    for (int t = 0; t < nsteps; ++t) {
+        const int j = FWD ? t : nblk - 1 - t;  // producer block
+        const int c0 = j * TB;
+        const int nc = min(TB, n - c0);
+        // operand block into registers BEFORE waiting for x_j
+        double lv[64];
+        if (FWD) {  // rows of block r, columns of block j: L[row0+row, c0 + half*64 + c]
+            const double* Lp = L + (row0 + row) + (size_t)(c0 + half * 64) * ld;
+#pragma unroll
+            for (int c = 0; c < 64; ++c) lv[c] = (row < nrows) ? Lp[(size_t)c * ld] : 0.0;
+        } else {    // transposed: L[c0 + half*64 + c, row0+row] (column row0+row of L, contiguous in c)
+            const double* Lp = L + (c0 + half * 64) + (size_t)(row0 + row) * ld;
+#pragma unroll
+            for (int c = 0; c < 64; ++c) lv[c] = (row < nrows && half * 64 + c < nc) ? Lp[c] : 0.0;
+        }
+        if (tid == 0) {
+            int ok = 1;
+            unsigned spins = 0;
+            while (__hip_atomic_load(flags + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > 20000000u) { ok = 0; __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            }
+            ok_s = ok;
+        }
+        __syncthreads();
+        if (!ok_s) return;
+        if (tid < TB) xs[tid] = (tid < nc) ? ld_agent(x + c0 + tid) : 0.0;
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 64; ++c) acc += lv[c] * xs[half * 64 + c];
+        __syncthreads();
+    }
+    if (half == 1) bs[row] = acc;
+    __syncthreads();
+    if (half == 0) bs[row] = mine - (acc + bs[row]);
+    __syncthreads();
+    if (wave == 0) {
+        double b0 = bs[lane], b1 = bs[lane + 64];
+        if (FWD) diag_solve_fwd(Ls, rd, lane, b0, b1);
+        else diag_solve_bwd(Ls, rd, lane, b0, b1);
+        if (lane < nrows) st_agent(x + row0 + lane, b0);
+        if (lane + 64 < nrows) st_agent(x + row0 + lane + 64, b1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_store(flags + r, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -704,22 +947,33 @@ __global__ void k_mul_vec(int n, const double* __restrict__ d, double* __restric
 }
 
 // LLT: L y = b, L^T x = y with rdiag = 1/diag(L).  LDLt: unit L, then x *= rdiag (= 1/D), then unit L^T.
-void launch_trsv(const double* L, int ld, int n, double* x, const double* rdiag, bool ldlt, hipStream_t s)
+// `flags` = 2 * nblk + 1 ints of scratch (zeroed here on the stream).
+void launch_trsv(const double* L, int ld, int n, double* x, const double* rdiag, bool ldlt, int* flags, hipStream_t s)
 {
     if (n <= 0) return;
     static bool attr_set = false;
     if (!attr_set) {
         PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_trsv_fwd_step), hipFuncAttributeMaxDynamicSharedMemorySize, TRSV_LDS_BYTES));
         PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_trsv_bwd_step), hipFuncAttributeMaxDynamicSharedMemorySize, TRSV_LDS_BYTES));
+        PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_trsv_persistent<true>), hipFuncAttributeMaxDynamicSharedMemorySize, TRSV_LDS_BYTES));
+        PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_trsv_persistent<false>), hipFuncAttributeMaxDynamicSharedMemorySize, TRSV_LDS_BYTES));
         attr_set = true;
     }
     const int nblk = div_up(n, TB);
     const double* rd = ldlt ? nullptr : rdiag;
-    for (int j = 0; j < nblk; ++j)
-        hipLaunchKernelGGL(k_trsv_fwd_step, dim3(nblk - j), dim3(256), TRSV_LDS_BYTES, s, L, ld, n, x, rd, j);
-    if (ldlt) hipLaunchKernelGGL(k_mul_vec, dim3(div_up(n, 256)), dim3(256), 0, s, n, rdiag, x);
-    for (int j = nblk - 1; j >= 0; --j)
-        hipLaunchKernelGGL(k_trsv_bwd_step, dim3(j + 1), dim3(256), TRSV_LDS_BYTES, s, L, ld, n, x, rd, j, nblk);
+    const bool persistent = flags != nullptr && nblk <= 224;  // every block resident (one per CU) with room to spare
+    if (persistent) {
+        PQ_HIP(hipMemsetAsync(flags, 0, sizeof(int) * (2 * nblk + 1), s));
+        hipLaunchKernelGGL(k_trsv_persistent<true>, dim3(nblk), dim3(256), TRSV_LDS_BYTES, s, L, ld, n, x, rd, nblk, flags, flags + 2 * nblk);
+        if (ldlt) hipLaunchKernelGGL(k_mul_vec, dim3(div_up(n, 256)), dim3(256), 0, s, n, rdiag, x);
+        hipLaunchKernelGGL(k_trsv_persistent<false>, dim3(nblk), dim3(256), TRSV_LDS_BYTES, s, L, ld, n, x, rd, nblk, flags + nblk, flags + 2 * nblk);
+    } else {
+        for (int j = 0; j < nblk; ++j)
+            hipLaunchKernelGGL(k_trsv_fwd_step, dim3(nblk - j), dim3(256), TRSV_LDS_BYTES, s, L, ld, n, x, rd, j);
+        if (ldlt) hipLaunchKernelGGL(k_mul_vec, dim3(div_up(n, 256)), dim3(256), 0, s, n, rdiag, x);
+        for (int j = nblk - 1; j >= 0; --j)
+            hipLaunchKernelGGL(k_trsv_bwd_step, dim3(j + 1), dim3(256), TRSV_LDS_BYTES, s, L, ld, n, x, rd, j, nblk);
+    }
     PQ_HIP(hipGetLastError());
 }
 

@@ -21,14 +21,20 @@ struct SyrkArgs {
     const double* ATA = nullptr; int ldata = 0;
     double dinv = 0.0;
     int unaligned = 0;  // set by the launcher
+    // tail balancing (set by the launcher): blocks [0, ...) of a split launch handle tile `tile_begin + b / k_split`,
+    // K-slice `b % k_split`, and write raw 128x128 partial tiles to `part` instead of running the epilogue
+    int tile_begin = 0;
+    int k_split = 1;
+    double* part = nullptr;
 };
 
-void launch_syrk(int epi, const SyrkArgs& args, hipStream_t s);
+void launch_syrk(int epi, const SyrkArgs& args, hipStream_t s, double* split_ws = nullptr, size_t split_ws_doubles = 0);
+size_t syrk_split_workspace_doubles(int n, int kdim);
 void launch_assemble_no_g(int n, const double* Pf, const double* x_reg, const double* ATA, double dinv, double* C, hipStream_t s);
 void launch_potrf_diag(bool ldlt, double* A, int lda, int nb, int kglobal, int* info, double* rdiag, hipStream_t s);
 void launch_trsm_panel(bool ldlt, double* A, int lda, int k0, int nb, int n, const double* rdiag, hipStream_t s);
 void launch_extract_diag(const double* A, int lda, int k0, int nb, double* d, hipStream_t s);
-void launch_trsv(const double* L, int ld, int n, double* x, const double* rdiag, bool ldlt, hipStream_t s);
+void launch_trsv(const double* L, int ld, int n, double* x, const double* rdiag, bool ldlt, int* flags, hipStream_t s);
 int gemv_n_slices(int rows, int cols);
 int launch_gemv_n_partial(int rows, int cols, const double* M, int ld, const double* v, const double* scale, double alpha, double* part, hipStream_t s);
 void launch_reduce_partials(int rows, int nslices, const double* part, const double* base, double* y, hipStream_t s);

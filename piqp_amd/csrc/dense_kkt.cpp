@@ -12,7 +12,9 @@
 //   W_delta_inv_G              not materialised: diag(z_reg_inv) is applied to the column operand while it is
 //                              staged into LDS (saves the 134 MB write + read at n = m = 4096)
 //   data.P_utri/AT/GT          Pfull_ (symmetric completion), AT_, GT_ (device copies, refreshed by update_data)
+#include <cstdlib>
 #include <stdexcept>
+#include <string>
 
 #include "dense_kernels.hpp"
 #include "kkt_solver_base.hpp"
@@ -86,7 +88,7 @@ public:
         if (p_ > 0) nsl += dense::launch_gemv_n_partial(n_, p_, AT_.p, n_, rhs_y, nullptr, delta_inv, part_.p + (size_t)nsl * n_, st_);
         dense::launch_reduce_partials(n_, nsl, part_.p, rhs_x, lhs_x, st_);
         // solve_ldlt_in_place: llt.solveInPlace(lhs_x)
-        dense::launch_trsv(fac_.p, n_, n_, lhs_x, rdiag_.p, ldlt_, st_);
+        dense::launch_trsv(fac_.p, n_, n_, lhs_x, rdiag_.p, ldlt_, use_persistent_trsv_ ? flags_.p : nullptr, st_);
         // lhs_y = delta_inv * AT^T lhs_x - delta_inv * rhs_y
         if (p_ > 0) dense::launch_gemv_t(n_, p_, AT_.p, n_, lhs_x, delta_inv, -delta_inv, rhs_y, nullptr, lhs_y, st_);
         // lhs_z = (GT^T lhs_x - rhs_z) o z_reg_inv
@@ -176,8 +178,11 @@ private:
         z_reg_inv_.alloc(m_); x_reg_last_.alloc(n_); dvec_.alloc(dense::FACTOR_NB); rdiag_.alloc(n_);
         const int sl = dense::gemv_n_slices(n_, m_ > 0 ? m_ : 1) + dense::gemv_n_slices(n_, p_ > 0 ? p_ : 1) + dense::gemv_n_slices(n_, n_);
         part_.alloc((size_t)sl * n_);
+        split_ws_.alloc(dense::syrk_split_workspace_doubles(n_, m_ > 0 ? m_ : 1));
         info_.alloc(1);
         info_h_.alloc(1);
+        flags_.alloc(2 * (size_t)((n_ + 127) / 128) + 1);
+        if (const char* e = std::getenv("PIQP_AMD_TRSV")) use_persistent_trsv_ = std::string(e) != "steps";
         x_reg_last_.zero(st_);
         fac_.zero(st_);
     }
@@ -207,7 +212,7 @@ private:
             dense::SyrkArgs a;
             a.n = n_; a.kdim = m_; a.A = GT_.p; a.lda = n_; a.B = GT_.p; a.ldb = n_; a.w = z_reg_inv_.p; a.C = out; a.ldc = n_;
             a.Pfull = Pfull_.p; a.ldp = n_; a.x_reg = x_reg; a.ATA = p_ > 0 ? ATA_.p : nullptr; a.ldata = n_; a.dinv = dinv;
-            dense::launch_syrk(dense::EPI_ASSEMBLE, a, st_);
+            dense::launch_syrk(dense::EPI_ASSEMBLE, a, st_, split_ws_.p, split_ws_.n);
         } else {
             dense::launch_assemble_no_g(n_, Pfull_.p, x_reg, p_ > 0 ? ATA_.p : nullptr, dinv, out, st_);
         }
@@ -248,10 +253,11 @@ private:
     bool ldlt_;
     double delta_ = 1.0;
     hipStream_t st_ = nullptr;
-    DBuf<double> Pfull_, Pdiag_, AT_, GT_, ATA_, fac_, z_reg_inv_, x_reg_last_, dvec_, part_, rdiag_;
-    DBuf<int> info_;
+    DBuf<double> Pfull_, Pdiag_, AT_, GT_, ATA_, fac_, z_reg_inv_, x_reg_last_, dvec_, part_, rdiag_, split_ws_;
+    DBuf<int> info_, flags_;
     HBuf<int> info_h_;
     StageProfiler prof_;
+    bool use_persistent_trsv_ = true;
 };
 
 }  // namespace
