@@ -14,6 +14,7 @@
 #include "dense_kernels.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace pq {
 namespace dense {
@@ -130,7 +131,8 @@ __global__ __launch_bounds__(256, 2) void k_syrk_lower(SyrkArgs a)
     int ti = (int)((sqrt(8.0 * (double)b + 1.0) - 1.0) * 0.5);
     while ((ti + 1) * (ti + 2) / 2 <= b) ++ti;
     while (ti * (ti + 1) / 2 > b) --ti;
-    const int tj = b - ti * (ti + 1) / 2;
+    int tj = b - ti * (ti + 1) / 2;
+    if (a.first_col_only) { ti = b; tj = 0; }
     const int row0 = ti * TS, col0 = tj * TS;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -302,9 +304,9 @@ template <int EPI>
 static void launch_syrk_t(SyrkArgs a, hipStream_t s, double* ws, size_t ws_doubles)
 {
     const int T = div_up(a.n, TS);
-    const int ntiles = T * (T + 1) / 2;
+    const int ntiles = a.first_col_only ? T : T * (T + 1) / 2;
     int rem = 0, ks = 1;
-    if (ws) syrk_tail_plan(a.n, a.kdim, rem, ks);
+    if (ws && !a.first_col_only) syrk_tail_plan(a.n, a.kdim, rem, ks);
     if (rem > 0 && (size_t)rem * ks * TS * TS > ws_doubles) { rem = 0; ks = 1; }
     const int main_tiles = ntiles - rem;
     a.tile_begin = 0; a.k_split = 1; a.part = nullptr;
@@ -359,17 +361,17 @@ void launch_assemble_no_g(int n, const double* Pf, const double* x_reg, const do
 // Stage the lower triangle of an nr x nr block (nr <= NBLK) into LDS as Ls[c * LD + r], zeros above the diagonal,
 // identity padding beyond nr.  All loads are unconditional (clamped address + select) and issued 16 at a time per
 // thread, so a thread has 16 L2 round trips in flight instead of one per loop iteration.
-template <int NBLK, int LD>
+template <int NBLK, int LD, int NT = 256>
 __device__ __forceinline__ void stage_lower_block(const double* __restrict__ A, int lda, int nr, double* __restrict__ Ls, int tid)
 {
-    constexpr int PER_THREAD = NBLK * NBLK / 256;
+    constexpr int PER_THREAD = NBLK * NBLK / NT;
     constexpr int BATCH = 16;
 #pragma unroll 1
     for (int b0 = 0; b0 < PER_THREAD; b0 += BATCH) {
         double v[BATCH];
 #pragma unroll
         for (int u = 0; u < BATCH; ++u) {
-            const int idx = (b0 + u) * 256 + tid;
+            const int idx = (b0 + u) * NT + tid;
             const int r = idx % NBLK, c = idx / NBLK;
             const bool ok = (r < nr) && (c < nr) && (r >= c);
             const double* p = ok ? (A + r + (size_t)c * lda) : A;
@@ -378,7 +380,7 @@ __device__ __forceinline__ void stage_lower_block(const double* __restrict__ A, 
         }
 #pragma unroll
         for (int u = 0; u < BATCH; ++u) {
-            const int idx = (b0 + u) * 256 + tid;
+            const int idx = (b0 + u) * NT + tid;
             Ls[(idx / NBLK) * LD + (idx % NBLK)] = v[u];
         }
     }
@@ -411,21 +413,22 @@ __device__ __forceinline__ double rcp_newton(double d)
     return y;
 }
 
+constexpr int POTRF_THREADS = 512;
 template <bool LDLT>
-__global__ __launch_bounds__(256) void k_potrf_diag(double* __restrict__ A, int lda, int nb, int kglobal, int* __restrict__ info, double* __restrict__ rdiag)
+__global__ __launch_bounds__(POTRF_THREADS) void k_potrf_diag(double* __restrict__ A, int lda, int nb, int kglobal, int* __restrict__ info, double* __restrict__ rdiag, int dbg)
 {
     extern __shared__ __attribute__((aligned(16))) double S[];  // S[c * PLD + r]
     __shared__ double rd16[16];                                  // reciprocals of the current 16 pivots
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nbp = (nb + 15) & ~15;
     const int nt = nbp >> 4;
-    stage_lower_block<NB, PLD>(A, lda, nb, S, tid);
+    stage_lower_block<NB, PLD, POTRF_THREADS>(A, lda, nb, S, tid);
     __syncthreads();
 
     for (int jb = 0; jb < nt; ++jb) {
         const int j0 = jb * 16;
         // (1) 16x16 diagonal piece, wave 0, row (lane & 15) per lane
-        if (wave == 0) {
+        if (wave == 0 && !(dbg & 1)) {
             const int i = lane & 15;
             double a[16];
 #pragma unroll
@@ -465,7 +468,7 @@ __global__ __launch_bounds__(256) void k_potrf_diag(double* __restrict__ A, int 
         // (2) panel below the diagonal piece: X = A * Ljj^-T (LLT) / Y = A * Ljj^-T(unit), X = Y D^-1 (LDLT)
         {
             const int i = j0 + 16 + tid;
-            if (i < nbp) {
+            if (i < nbp && !(dbg & 2)) {
                 double x[16];
 #pragma unroll
                 for (int c = 0; c < 16; ++c) x[c] = S[(j0 + c) * PLD + i];
@@ -485,13 +488,13 @@ __global__ __launch_bounds__(256) void k_potrf_diag(double* __restrict__ A, int 
         // (3) trailing update inside the block with MFMA tiles: S(tr,tc) -= X_tr * (D) * X_tc^T
         {
             const int rem = nt - 1 - jb;
-            const int ntile = rem * (rem + 1) / 2;
-            for (int t = wave; t < ntile; t += 8) {
+            const int ntile = (dbg & 4) ? 0 : rem * (rem + 1) / 2;
+            for (int t = wave; t < ntile; t += 2 * (POTRF_THREADS / 64)) {
                 int R0[2], C0[2];
                 bool on[2];
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
-                    const int tt = t + 4 * u;
+                    const int tt = t + (POTRF_THREADS / 64) * u;
                     on[u] = tt < ntile;
                     int tr = (int)((sqrtf(8.0f * (float)tt + 1.0f) - 1.0f) * 0.5f);
                     while ((tr + 1) * (tr + 2) / 2 <= tt) ++tr;
@@ -521,7 +524,7 @@ __global__ __launch_bounds__(256) void k_potrf_diag(double* __restrict__ A, int 
         }
         __syncthreads();
     }
-    for (int c = wave; c < nb; c += 4)
+    for (int c = wave; c < nb; c += POTRF_THREADS / 64)
         for (int r = c + lane; r < nb; r += 64) A[r + (size_t)c * lda] = S[c * PLD + r];
 }
 
@@ -533,8 +536,10 @@ void launch_potrf_diag(bool ldlt, double* A, int lda, int nb, int kglobal, int* 
         PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_diag<true>), hipFuncAttributeMaxDynamicSharedMemorySize, POTRF_LDS_BYTES));
         attr_set = true;
     }
-    if (ldlt) hipLaunchKernelGGL(k_potrf_diag<true>, dim3(1), dim3(256), POTRF_LDS_BYTES, s, A, lda, nb, kglobal, info, rdiag);
-    else hipLaunchKernelGGL(k_potrf_diag<false>, dim3(1), dim3(256), POTRF_LDS_BYTES, s, A, lda, nb, kglobal, info, rdiag);
+    static int dbg = -1;
+    if (dbg < 0) { const char* e = std::getenv("PIQP_AMD_POTRF_DBG"); dbg = e ? std::atoi(e) : 0; }
+    if (ldlt) hipLaunchKernelGGL(k_potrf_diag<true>, dim3(1), dim3(POTRF_THREADS), POTRF_LDS_BYTES, s, A, lda, nb, kglobal, info, rdiag, dbg);
+    else hipLaunchKernelGGL(k_potrf_diag<false>, dim3(1), dim3(POTRF_THREADS), POTRF_LDS_BYTES, s, A, lda, nb, kglobal, info, rdiag, dbg);
     PQ_HIP(hipGetLastError());
 }
 

@@ -26,6 +26,7 @@ struct SyrkArgs {
     int tile_begin = 0;
     int k_split = 1;
     double* part = nullptr;
+    int first_col_only = 0;  // 1: only the tiles (ti, 0) of the first 128-column strip (panel look-ahead)
 };
 
 void launch_syrk(int epi, const SyrkArgs& args, hipStream_t s, double* split_ws = nullptr, size_t split_ws_doubles = 0);
