@@ -76,13 +76,14 @@ constexpr int BK = 16;
 constexpr int LDS_LD = TS + 16;
 constexpr int SYRK_LDS_BYTES = 2 * 2 * BK * LDS_LD * (int)sizeof(double);
 
-template <bool CHECK>
-__device__ __forceinline__ void load_tile(const double* __restrict__ M, int ld, int r0, int k0, int nrows, int kdim, int tid, d2 (&v)[4])
+// NT threads cooperate on a 128 x 16 operand stage (1024 double2): ITERS = 1024 / NT loads per thread
+template <bool CHECK, int NT>
+__device__ __forceinline__ void load_tile(const double* __restrict__ M, int ld, int r0, int k0, int nrows, int kdim, int tid, d2 (&v)[1024 / NT])
 {
     const int r = r0 + 2 * (tid & 63);
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int k = k0 + it * 4 + (tid >> 6);
+    for (int it = 0; it < 1024 / NT; ++it) {
+        const int k = k0 + it * (NT / 64) + (tid >> 6);
         if (!CHECK) {
             v[it] = *reinterpret_cast<const d2*>(M + r + (size_t)k * ld);
         } else {
@@ -96,31 +97,38 @@ __device__ __forceinline__ void load_tile(const double* __restrict__ M, int ld, 
     }
 }
 
-__device__ __forceinline__ void store_tile(double* __restrict__ S, int tid, const d2 (&v)[4])
+template <int NT>
+__device__ __forceinline__ void store_tile(double* __restrict__ S, int tid, const d2 (&v)[1024 / NT])
 {
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int k = it * 4 + (tid >> 6);
+    for (int it = 0; it < 1024 / NT; ++it) {
+        const int k = it * (NT / 64) + (tid >> 6);
         *reinterpret_cast<d2*>(S + k * LDS_LD + 2 * (tid & 63)) = v[it];
     }
 }
 
-template <bool CHECK>
-__device__ __forceinline__ void scale_tile(const double* __restrict__ w, int k0, int kdim, int tid, d2 (&v)[4])
+template <bool CHECK, int NT>
+__device__ __forceinline__ void scale_tile(const double* __restrict__ w, int k0, int kdim, int tid, d2 (&v)[1024 / NT])
 {
     if (!w) return;
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int k = k0 + it * 4 + (tid >> 6);
+    for (int it = 0; it < 1024 / NT; ++it) {
+        const int k = k0 + it * (NT / 64) + (tid >> 6);
         const double s = (!CHECK || k < kdim) ? w[k] : 0.0;
         v[it].x *= s;
         v[it].y *= s;
     }
 }
 
-template <int EPI>
-__global__ __launch_bounds__(256, 2) void k_syrk_lower(SyrkArgs a)
+// WD = waves per tile dimension: WD = 2 -> 256 threads, 64x64 per wave (throughput shape, 2 workgroups per CU);
+//                                WD = 4 -> 1024 threads, 32x32 per wave (low-latency shape for short K: a quarter of the
+//                                MFMA chain per wave, used for the trailing updates of the factorisation).
+template <int EPI, int WD>
+__global__ __launch_bounds__(64 * WD * WD, WD == 2 ? 2 : 4) void k_syrk_lower(SyrkArgs a)
 {
+    constexpr int NT = 64 * WD * WD;
+    constexpr int MT = 8 / WD;     // MFMA tiles per wave per dimension
+    constexpr int SUB = TS / WD;   // rows / columns of C per wave
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* As = smem;                    // [2][BK][LDS_LD]
     double* Bs = smem + 2 * BK * LDS_LD;  // [2][BK][LDS_LD]
@@ -136,28 +144,28 @@ __global__ __launch_bounds__(256, 2) void k_syrk_lower(SyrkArgs a)
     const int row0 = ti * TS, col0 = tj * TS;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = wave / WD, wc = wave % WD;
     const bool edge = (row0 + TS > a.n) || (col0 + TS > a.n) || a.unaligned;
     const bool skip_wave = (ti == tj) && (wr < wc);  // sub-tile strictly above the diagonal
 
-    d4 acc[4][4];
+    d4 acc[MT][MT];
 #pragma unroll
-    for (int x = 0; x < 4; ++x)
+    for (int x = 0; x < MT; ++x)
 #pragma unroll
-        for (int y = 0; y < 4; ++y) acc[x][y] = (d4){0.0, 0.0, 0.0, 0.0};
+        for (int y = 0; y < MT; ++y) acc[x][y] = (d4){0.0, 0.0, 0.0, 0.0};
 
     const int nkt_all = (a.kdim + BK - 1) / BK;
     const int kt_per = (nkt_all + a.k_split - 1) / a.k_split;
     const int kt_begin = kslice * kt_per;
     const int nkt = max(0, min(nkt_all, kt_begin + kt_per) - kt_begin);
-    d2 va[4], vb[4];
+    d2 va[1024 / NT], vb[1024 / NT];
     if (nkt > 0) {
         const int k0 = kt_begin * BK;
         const bool chk = edge || (k0 + BK > a.kdim);
-        if (chk) { load_tile<true>(a.A, a.lda, row0, k0, a.n, a.kdim, tid, va); load_tile<true>(a.B, a.ldb, col0, k0, a.n, a.kdim, tid, vb); scale_tile<true>(a.w, k0, a.kdim, tid, vb); }
-        else { load_tile<false>(a.A, a.lda, row0, k0, a.n, a.kdim, tid, va); load_tile<false>(a.B, a.ldb, col0, k0, a.n, a.kdim, tid, vb); scale_tile<false>(a.w, k0, a.kdim, tid, vb); }
-        store_tile(As, tid, va);
-        store_tile(Bs, tid, vb);
+        if (chk) { load_tile<true, NT>(a.A, a.lda, row0, k0, a.n, a.kdim, tid, va); load_tile<true, NT>(a.B, a.ldb, col0, k0, a.n, a.kdim, tid, vb); scale_tile<true, NT>(a.w, k0, a.kdim, tid, vb); }
+        else { load_tile<false, NT>(a.A, a.lda, row0, k0, a.n, a.kdim, tid, va); load_tile<false, NT>(a.B, a.ldb, col0, k0, a.n, a.kdim, tid, vb); scale_tile<false, NT>(a.w, k0, a.kdim, tid, vb); }
+        store_tile<NT>(As, tid, va);
+        store_tile<NT>(Bs, tid, vb);
     }
     __syncthreads();
 
@@ -167,28 +175,28 @@ __global__ __launch_bounds__(256, 2) void k_syrk_lower(SyrkArgs a)
         if (more) {
             const int k0 = (kt_begin + kt + 1) * BK;
             const bool chk = edge || (k0 + BK > a.kdim);
-            if (chk) { load_tile<true>(a.A, a.lda, row0, k0, a.n, a.kdim, tid, va); load_tile<true>(a.B, a.ldb, col0, k0, a.n, a.kdim, tid, vb); scale_tile<true>(a.w, k0, a.kdim, tid, vb); }
-            else { load_tile<false>(a.A, a.lda, row0, k0, a.n, a.kdim, tid, va); load_tile<false>(a.B, a.ldb, col0, k0, a.n, a.kdim, tid, vb); scale_tile<false>(a.w, k0, a.kdim, tid, vb); }
+            if (chk) { load_tile<true, NT>(a.A, a.lda, row0, k0, a.n, a.kdim, tid, va); load_tile<true, NT>(a.B, a.ldb, col0, k0, a.n, a.kdim, tid, vb); scale_tile<true, NT>(a.w, k0, a.kdim, tid, vb); }
+            else { load_tile<false, NT>(a.A, a.lda, row0, k0, a.n, a.kdim, tid, va); load_tile<false, NT>(a.B, a.ldb, col0, k0, a.n, a.kdim, tid, vb); scale_tile<false, NT>(a.w, k0, a.kdim, tid, vb); }
         }
         if (!skip_wave) {
-            const double* Asb = As + cur * BK * LDS_LD + wr * 64 + (lane & 15);
-            const double* Bsb = Bs + cur * BK * LDS_LD + wc * 64 + (lane & 15);
+            const double* Asb = As + cur * BK * LDS_LD + wr * SUB + (lane & 15);
+            const double* Bsb = Bs + cur * BK * LDS_LD + wc * SUB + (lane & 15);
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const int kk = ks * 4 + (lane >> 4);
-                double af[4], bf[4];
+                double af[MT], bf[MT];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) { af[q] = Asb[kk * LDS_LD + q * 16]; bf[q] = Bsb[kk * LDS_LD + q * 16]; }
+                for (int q = 0; q < MT; ++q) { af[q] = Asb[kk * LDS_LD + q * 16]; bf[q] = Bsb[kk * LDS_LD + q * 16]; }
 #pragma unroll
-                for (int x = 0; x < 4; ++x)
+                for (int x = 0; x < MT; ++x)
 #pragma unroll
-                    for (int y = 0; y < 4; ++y)
+                    for (int y = 0; y < MT; ++y)
                         acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[x], af[y], acc[x][y], 0, 0, 0);
             }
         }
         if (more) {
-            store_tile(As + (cur ^ 1) * BK * LDS_LD, tid, va);
-            store_tile(Bs + (cur ^ 1) * BK * LDS_LD, tid, vb);
+            store_tile<NT>(As + (cur ^ 1) * BK * LDS_LD, tid, va);
+            store_tile<NT>(Bs + (cur ^ 1) * BK * LDS_LD, tid, vb);
         }
         __syncthreads();
     }
@@ -198,23 +206,23 @@ __global__ __launch_bounds__(256, 2) void k_syrk_lower(SyrkArgs a)
         // split launch: raw partial tile (column-major 128 x 128) for k_syrk_tail_reduce; fixed slot per (tile, slice)
         double* P = a.part + (size_t)blockIdx.x * TS * TS;
 #pragma unroll
-        for (int x = 0; x < 4; ++x)
+        for (int x = 0; x < MT; ++x)
 #pragma unroll
-            for (int y = 0; y < 4; ++y)
+            for (int y = 0; y < MT; ++y)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    P[(wr * 64 + y * 16 + (lane & 15)) + (size_t)(wc * 64 + x * 16 + (lane >> 4) + 4 * r) * TS] = acc[x][y][r];
+                    P[(wr * SUB + y * 16 + (lane & 15)) + (size_t)(wc * SUB + x * 16 + (lane >> 4) + 4 * r) * TS] = acc[x][y][r];
         return;
     }
     // epilogue: lane holds rows gi (consecutive over lane&15) and columns gj = base + (lane>>4) + 4*r
 #pragma unroll
-    for (int x = 0; x < 4; ++x) {
+    for (int x = 0; x < MT; ++x) {
 #pragma unroll
-        for (int y = 0; y < 4; ++y) {
-            const int gi = row0 + wr * 64 + y * 16 + (lane & 15);
+        for (int y = 0; y < MT; ++y) {
+            const int gi = row0 + wr * SUB + y * 16 + (lane & 15);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int gj = col0 + wc * 64 + x * 16 + (lane >> 4) + 4 * r;
+                const int gj = col0 + wc * SUB + x * 16 + (lane >> 4) + 4 * r;
                 if (gi < a.n && gj < a.n && gi >= gj) {
                     const size_t ci = (size_t)gi + (size_t)gj * a.ldc;
                     const double v = acc[x][y][r];
@@ -310,10 +318,13 @@ static void launch_syrk_t(SyrkArgs a, hipStream_t s, double* ws, size_t ws_doubl
     if (rem > 0 && (size_t)rem * ks * TS * TS > ws_doubles) { rem = 0; ks = 1; }
     const int main_tiles = ntiles - rem;
     a.tile_begin = 0; a.k_split = 1; a.part = nullptr;
-    hipLaunchKernelGGL(k_syrk_lower<EPI>, dim3(main_tiles), dim3(256), SYRK_LDS_BYTES, s, a);
+    // short inner dimension (factorisation trailing updates, K = 128): latency-bound per tile -> 16-wave shape
+    const bool low_latency = a.kdim <= 256;
+    if (low_latency) hipLaunchKernelGGL((k_syrk_lower<EPI, 4>), dim3(main_tiles), dim3(1024), SYRK_LDS_BYTES, s, a);
+    else hipLaunchKernelGGL((k_syrk_lower<EPI, 2>), dim3(main_tiles), dim3(256), SYRK_LDS_BYTES, s, a);
     if (rem > 0) {
         a.tile_begin = main_tiles; a.k_split = ks; a.part = ws;
-        hipLaunchKernelGGL(k_syrk_lower<EPI>, dim3(rem * ks), dim3(256), SYRK_LDS_BYTES, s, a);
+        hipLaunchKernelGGL((k_syrk_lower<EPI, 2>), dim3(rem * ks), dim3(256), SYRK_LDS_BYTES, s, a);
         hipLaunchKernelGGL(k_syrk_tail_reduce<EPI>, dim3(rem, TS * TS / 256), dim3(256), 0, s, a);
     }
 }
@@ -325,9 +336,12 @@ void launch_syrk(int epi, const SyrkArgs& args_in, hipStream_t s, double* split_
     a.unaligned = ((a.lda & 1) || (a.ldb & 1) || (reinterpret_cast<uintptr_t>(a.A) & 15) || (reinterpret_cast<uintptr_t>(a.B) & 15)) ? 1 : 0;
     static bool attr_set = false;
     if (!attr_set) {
-        PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk_lower<EPI_ASSEMBLE>), hipFuncAttributeMaxDynamicSharedMemorySize, SYRK_LDS_BYTES));
-        PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk_lower<EPI_SUBTRACT>), hipFuncAttributeMaxDynamicSharedMemorySize, SYRK_LDS_BYTES));
-        PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk_lower<EPI_STORE>), hipFuncAttributeMaxDynamicSharedMemorySize, SYRK_LDS_BYTES));
+        PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk_lower<EPI_ASSEMBLE, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, SYRK_LDS_BYTES));
+        PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk_lower<EPI_SUBTRACT, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, SYRK_LDS_BYTES));
+        PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk_lower<EPI_STORE, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, SYRK_LDS_BYTES));
+        PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk_lower<EPI_ASSEMBLE, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, SYRK_LDS_BYTES));
+        PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk_lower<EPI_SUBTRACT, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, SYRK_LDS_BYTES));
+        PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk_lower<EPI_STORE, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, SYRK_LDS_BYTES));
         attr_set = true;
     }
     switch (epi) {
