@@ -42,19 +42,14 @@ def main():
 
     import numpy as np
     import torch
-    import torch.distributed as dist
-
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
 
     import piqp_amd
+    from piqp_amd import dist as pd
+
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    rank, world, local_rank = pd.init()  # RCCL ("nccl") process group when WORLD_SIZE > 1
+    dev = torch.device("cuda", local_rank)
     from qp_gen import dense_strongly_convex_qp, random_vars
 
     n, p, m = args.n, args.p, args.m
@@ -79,8 +74,7 @@ def main():
         return ok and ok1 and ok2
 
     def barrier():
-        if world > 1:
-            dist.barrier()
+        pd.barrier()
         ksys.synchronize()
         torch.cuda.synchronize()
 
@@ -100,11 +94,7 @@ def main():
     t1 = time.perf_counter()
     assert ok
     backend.set_profiling(False)
-    elapsed = t1 - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = pd.max_over_ranks(t1 - t0, device=dev if world > 1 else None)
     asm_ms, asm_cnt = backend.get_profile(0)
     fac_ms, fac_cnt = backend.get_profile(1)
     sol_ms, sol_cnt = backend.get_profile(2)
@@ -118,6 +108,13 @@ def main():
         achieved = flops_asm / asm_avg_s / 1e12 if asm_avg_s > 0 else 0.0
         flops_llt = n ** 3 / 3.0
         fac_avg_s = fac_ms / max(fac_cnt, 1) * 1e-3
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_dense_c2.json")))
+            if (pmc["n"], pmc["m"], pmc["p"]) == (n, m, p):
+                traffic = pmc["assembly_per_step"]["traffic_bytes"]  # rocprofv3 PMC passes of this same workload (see file)
+        except Exception:
+            pass
         out = {
             "metric": "KKT factor+solve/sec (per IPM iter)",
             "value": value,
@@ -134,7 +131,7 @@ def main():
                        "n": n, "p": p, "m": m, "parallelism": f"independent QP replicas x{world}"},
             "roofline": {"bound": "mfma", "kernel": "k_syrk_lower<EPI_ASSEMBLE> (dense/kkt.hpp:140-160)",
                          "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic,
                          "alg_flops_per_launch": flops_asm, "avg_launch_ms": asm_avg_s * 1e3, "launches": asm_cnt},
             "stages": {"assembly_ms": asm_avg_s * 1e3, "factorisation_ms": fac_avg_s * 1e3,
                        "factorisation_tflops": flops_llt / fac_avg_s / 1e12 if fac_avg_s > 0 else 0.0,
@@ -146,9 +143,12 @@ def main():
             if out["cpu_baseline"].get("value"):
                 out["speedup_vs_cpu_baseline"] = value / world / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    pd.finalize()
+
+
+def dense_strongly_convex_qp_small():
+    from qp_gen import dense_strongly_convex_qp
+    return dense_strongly_convex_qp(1024, 0, 1024, seed=7, double_sided=True, exact_shift=False)
 
 
 def cpu_baseline(q, n, p, m, args):
@@ -163,11 +163,26 @@ def cpu_baseline(q, n, p, m, args):
     except Exception:
         L = pyorc.lib()
         build = "gcc -O3 -march=x86-64-v3 -fopenmp"
-    cores = os.cpu_count() or 1
+    avail = os.cpu_count() or 1
     try:
-        cores = len(os.sched_getaffinity(0))
+        avail = len(os.sched_getaffinity(0))
     except Exception:
         pass
+    # pick the thread count that is actually fastest on this box (cgroup quotas / SMT make "all logical CPUs" a bad default):
+    # one factorisation of a small instance per candidate
+    cal_q = dense_strongly_convex_qp_small()
+    cal_d = pyorc.Data.dense(**cal_q, L=L)
+    cal_state = random_vars(cal_d.n, 0, cal_d.m, np.random.default_rng(1), positive=True)
+    best, cores = None, 1
+    for t in [c for c in (1, 2, 4, 8, 16, 32, 64, 128) if c <= avail]:
+        L.orc_set_num_threads(t)
+        kc = pyorc.KKTSystem(cal_d, pyorc.Settings(L))
+        kc.update_scalings_and_factor(False, 1e-6, 1e-4, cal_state)
+        t0 = time.perf_counter()
+        kc.update_scalings_and_factor(False, 1e-6, 1e-4, cal_state)
+        dt = time.perf_counter() - t0
+        if best is None or dt < best:
+            best, cores = dt, t
     L.orc_set_num_threads(cores)
     od = pyorc.Data.dense(**q, L=L)
     ks = pyorc.KKTSystem(od, pyorc.Settings(L, kkt_solver=args.kkt_solver))
@@ -191,7 +206,7 @@ def cpu_baseline(q, n, p, m, args):
     el = time.perf_counter() - t0
     flops = float(n) * (n + 1) * m + n ** 3 / 3.0
     return {"value": steps / el, "unit": "IPM-iter KKT (1 factor + 2 solves)/s", "cores": cores, "kind": "port",
-            "sample": f"{steps} steps of the same n={n} p={p} m={m} workload (after 1 untimed step), oracle built with {build}",
+            "sample": f"{steps} steps of the same n={n} p={p} m={m} workload (after 1 untimed step), oracle built with {build}, {cores} OpenMP threads (fastest of a 1..{avail} sweep)",
             "seconds": el, "factor_gflops": flops * steps / el / 1e9}
 
 
