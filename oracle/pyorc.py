@@ -107,6 +107,13 @@ def _bind(L):
     if hasattr(L, "orc_sparse_kkt_create"):
         L.orc_sparse_kkt_create.restype = vp
         L.orc_sparse_kkt_create.argtypes = [C.POINTER(DataS), C.c_int]
+    if hasattr(L, "orc_multistage_kkt_create"):
+        L.orc_multistage_kkt_create.restype = vp
+        L.orc_multistage_kkt_create.argtypes = [C.POINTER(DataS)]
+        L.orc_multistage_num_blocks.restype = C.c_int
+        L.orc_multistage_num_blocks.argtypes = [vp]
+        L.orc_multistage_block_info.argtypes = [vp, _ip]
+        L.orc_multistage_row_perm.argtypes = [vp, C.c_int, _ip, _ip]
     L.orc_dense_kkt_internal_kkt_mat.restype = _dp
     L.orc_dense_kkt_internal_kkt_mat.argtypes = [vp]
     L.orc_dense_kkt_internal_factor.restype = _dp
@@ -339,6 +346,8 @@ class KKT:
             self.ptr = _ptr
         elif kind == "dense":
             self.ptr = self.L.orc_dense_kkt_create(data.ptr, int(use_ldlt))
+        elif kind == "multistage":
+            self.ptr = self.L.orc_multistage_kkt_create(data.ptr)
         else:
             self.ptr = self.L.orc_sparse_kkt_create(data.ptr, mode)
         self.owned = _ptr is None
@@ -384,6 +393,21 @@ class KKT:
         a, ap = _f(xn); b, bp = _f(xt); zn, zt = np.zeros(d.m), np.zeros(d.n)
         self.L.orc_kkt_eval_G_xn_and_GT_xt(self.ptr, d.ptr, an, at, ap, bp, zn.ctypes.data_as(_dp), zt.ctypes.data_as(_dp))
         return zn, zt
+
+    def block_info(self):
+        """multistage only: rows of (start, diag_size, off_diag_size); the last row is the arrow corner block."""
+        N = self.L.orc_multistage_num_blocks(self.ptr)
+        out = np.zeros(3 * N, np.int32)
+        self.L.orc_multistage_block_info(self.ptr, out.ctypes.data_as(_ip))
+        return out.reshape(N, 3)
+
+    def row_perm(self, which):
+        """multistage only: (perm, block_row_sizes) of AT (which=0) / GT (which=1)."""
+        N = self.L.orc_multistage_num_blocks(self.ptr)
+        rows = self.data.p if which == 0 else self.data.m
+        perm = np.zeros(max(rows, 1), np.int32); sizes = np.zeros(max(N - 1, 1), np.int32)
+        self.L.orc_multistage_row_perm(self.ptr, which, perm.ctypes.data_as(_ip), sizes.ctypes.data_as(_ip))
+        return perm[:rows], sizes[:N - 1]
 
     def internal_kkt_mat(self):
         n = self.data.n
