@@ -147,7 +147,9 @@ typedef struct pq_kkt pq_kkt;
 /* dense::KKT ctor, dense/kkt.hpp:39-55 (uploads P_utri/AT/GT, builds AT_A = AT*AT^T).
  * kkt_solver: PQ_DENSE_CHOLESKY (Eigen::LLT semantics, dense/kkt.hpp:82-83) or PQ_DENSE_LDLT_NO_PIVOT. */
 int pq_kkt_create_dense(pq_kkt **out, const pq_dense_data *data, int kkt_solver, int device);
-/* sparse::KKT ctor, sparse/kkt.hpp:51-70 (assemble KKT by mode, AMD, permute, symbolic, upload) */
+/* sparse::KKT ctor, sparse/kkt.hpp:51-70 (assemble KKT by mode, AMD, permute, symbolic, upload) for
+ * kkt_solver = PQ_SPARSE_LDLT; MultistageKKT ctor, sparse/multistage_kkt.hpp:76-135 (arrow-structure
+ * detection, block containers, AtA) for kkt_solver = PQ_SPARSE_MULTISTAGE */
 int pq_kkt_create_sparse(pq_kkt **out, const pq_sparse_data *data, int kkt_solver, int device);
 int pq_kkt_clone(const pq_kkt *k, pq_kkt **out); /* kkt_solver_base.hpp:28 clone() */
 void pq_kkt_destroy(pq_kkt *k);                  /* kkt_solver_base.hpp:26 */
@@ -177,6 +179,10 @@ void *pq_kkt_stream(pq_kkt *k);                                     /* hipStream
 int pq_kkt_internal_kkt_mat(pq_kkt *k, double *out_host);
 int pq_kkt_internal_factor(pq_kkt *k, double *out_host);
 int pq_kkt_dims(const pq_kkt *k, int *n, int *p, int *m);
+/* sparse_multistage only: what MultistageKKT::print_info reports (multistage_kkt.hpp:385-393).  Writes up to
+ * `capacity` rows of (start, diag_size, off_diag_size) -- the last row is the arrow corner block -- and
+ * returns the number of blocks (call with out_host = NULL to size the buffer). */
+int pq_kkt_multistage_block_info(pq_kkt *k, int *out_host, int capacity);
 /* measurement hooks: when enabled, the backend brackets its stages with hipEvents on its own stream.
  * stage 0 = KKT assembly kernel (dense: k_syrk_lower<ASSEMBLE>), 1 = factorisation (all panels),
  * 2 = backend solve.  pq_kkt_get_profile returns the accumulated milliseconds / call count and resets them. */

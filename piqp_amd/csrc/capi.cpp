@@ -1,5 +1,6 @@
 // piqp_amd/csrc/capi.cpp -- the extern "C" boundary declared in include/piqp_amd.h.
 // Thin: argument checks, host<->device staging for PQ_MEM_HOST callers, exception fencing.
+#include <algorithm>
 #include <memory>
 #include <stdexcept>
 
@@ -313,6 +314,17 @@ int pq_kkt_get_profile(pq_kkt* k, int stage, double* total_ms, int* count)
 {
     if (!k || !total_ms || !count) return fail(PQ_ERR_INVALID, "null argument");
     return guarded([&] { k->impl->get_profile(stage, total_ms, count); return (int)PQ_OK; });
+}
+int pq_kkt_multistage_block_info(pq_kkt* k, int* out_host, int capacity)
+{
+    if (!k) return fail(PQ_ERR_INVALID, "null argument");
+    return guarded([&] {
+        std::vector<int> bi;
+        k->impl->multistage_block_info(bi);
+        const int N = (int)bi.size() / 3;
+        if (out_host) for (int i = 0; i < 3 * std::min(N, capacity); ++i) out_host[i] = bi[i];
+        return N;
+    });
 }
 int pq_kkt_dims(const pq_kkt* k, int* n, int* p, int* m)
 {

@@ -41,6 +41,8 @@ public:
     // test hooks (dense/kkt.hpp:134): copy n*n doubles to host
     virtual void internal_kkt_mat(double* out_host) { (void)out_host; throw std::runtime_error("internal_kkt_mat: dense only"); }
     virtual void internal_factor(double* out_host) { (void)out_host; throw std::runtime_error("internal_factor: dense only"); }
+    // test hook: rows of (start, diag_size, off_diag_size) of the multistage backend (print_info, multistage_kkt.hpp:385-393)
+    virtual void multistage_block_info(std::vector<int>& out) const { (void)out; throw std::runtime_error("block_info: sparse_multistage only"); }
     // measurement hooks (hipEvent brackets on the backend's stream)
     virtual void set_profiling(bool on) { (void)on; }
     virtual void get_profile(int stage, double* total_ms, int* count) { (void)stage; *total_ms = 0.0; *count = 0; }
@@ -48,5 +50,6 @@ public:
 
 KKTSolverBase* make_dense_kkt(const pq_dense_data* data, int kkt_solver, int device);
 KKTSolverBase* make_sparse_kkt(const pq_sparse_data* data, int kkt_solver, int device);
+KKTSolverBase* make_multistage_kkt(const pq_sparse_data* data, int device);
 
 }  // namespace pq

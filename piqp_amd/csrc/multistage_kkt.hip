@@ -1,0 +1,486 @@
+// piqp_amd/csrc/multistage_kkt.hip -- device-resident replacement of piqp::sparse::MultistageKKT<T,I>
+// (reference include/piqp/sparse/multistage_kkt.hpp, KKTSolver::sparse_multistage).
+//
+//   reference (blasfeo calls, OpenMP over stages)               here
+//   block_gemm_nd + block_syrk_ln_calc + populate_kkt_fac        k_ms_assemble: one launch, a workgroup (or several) per stage builds the
+//     (:186-216, :832-994, :1008-1219)                             stage's whole frontal matrix  P + diag(x_reg) + delta^-1 AtA + X_G W X_G^T
+//                                                                  (the sqrt scaling of GT is folded into the product as W = diag(1/z_reg))
+//   block_syrk_ln_calc(AT, AT, AtA) at setup / update (:113,161)  k_ms_gram on the grouped equality rows (once per update_data)
+//   factor_kkt (:1253-1352), serial recurrence over stages        k_ms_factor: ONE launch, one workgroup walks the chain; the front of the
+//                                                                  current stage sits in LDS (when it fits), the Schur complement of stage i
+//                                                                  (C_i C_i^T, F_i C_i^T, F_i F_i^T) is carried to stage i+1 / the arrow corner
+//                                                                  inside LDS as the multifrontal update matrix
+//   solve_llt_in_place (:1709-1816)                               k_ms_solve: ONE launch for the forward + backward sweep; the diagonal blocks
+//                                                                  are applied through their explicit inverses (computed during the factorisation)
+//                                                                  so every stage is two dense mat-vecs instead of a column-serial trsv
+//   fold / recover in solve (:221-288), eval_* (:291-383)         CSC column dots of CscOperators (same products, caller's row order, so the
+//                                                                  BlockVec permutations disappear)
+// Like the reference, update_scalings_and_factor always reports success (:218): a non-positive pivot
+// zeroes its column (blasfeo dpotrf semantics) and the caller's refinement loop notices.
+#include <algorithm>
+#include <cstdio>
+#include <stdexcept>
+
+#include "kkt_solver_base.hpp"
+#include "multistage_symbolic.hpp"
+#include "sparse_ops.hpp"
+
+namespace pq {
+
+namespace {
+
+constexpr int NT = 256;
+constexpr int LDS_LIMIT_BYTES = 159 * 1024;  // gfx950: 160 KiB of LDS per workgroup
+constexpr int ASM_CHUNK = 4096;              // front entries per assembly workgroup
+
+struct MsMeta {  // device views of multistage::Symbolic
+    int N, arrow, n;
+    const int* w;
+    const int* off;
+    const int* h;
+    const int* start;
+    const long long* front_off;
+    const long long* pan_off;
+};
+struct GroupMeta {
+    const int* row_ptr;  // N entries
+    const int* rows;     // grouped position -> caller's constraint index
+    const long long* x_off;
+};
+
+__global__ void k_ms_reciprocal(int m, const double* __restrict__ z, double* __restrict__ zinv)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) zinv[i] = 1.0 / z[i];
+}
+
+// lower triangle of X_b X_b^T for every stage (equality rows; the reference's AtA, :113 / :161)
+__global__ __launch_bounds__(NT) void k_ms_gram(MsMeta M, GroupMeta Gm, const double* __restrict__ X, double* __restrict__ out)
+{
+    const int b = blockIdx.x;
+    const int h = M.h[b];
+    const int rows = Gm.row_ptr[b + 1] - Gm.row_ptr[b];
+    const double* Xb = X + Gm.x_off[b];
+    double* O = out + M.front_off[b];
+    const int total = h * h;
+    const int lo = blockIdx.y * ASM_CHUNK, hi = min(total, lo + ASM_CHUNK);
+    for (int idx = lo + threadIdx.x; idx < hi; idx += NT) {
+        const int r = idx % h, c = idx / h;
+        if (r < c) continue;
+        double s = 0.0;
+        for (int k = 0; k < rows; ++k) s += Xb[r + (long long)k * h] * Xb[c + (long long)k * h];
+        O[idx] = s;
+    }
+}
+
+// frontal matrix of stage b (lower triangle): P + delta^-1 AtA + X_G diag(1/z_reg) X_G^T, x_reg on the pivot diagonal.
+// Block N-1 is the arrow corner (P + x_reg only; all products that land there are carried by the stage fronts).
+__global__ __launch_bounds__(NT) void k_ms_assemble(MsMeta M, GroupMeta Gm, const double* __restrict__ XG, const double* __restrict__ Pf, const double* __restrict__ AtAf,
+                                                    const double* __restrict__ zinv, const double* __restrict__ x_reg, double delta_inv, double* __restrict__ F)
+{
+    const int b = blockIdx.x;
+    const int h = M.h[b], w = M.w[b];
+    const int total = h * h;
+    const int lo = blockIdx.y * ASM_CHUNK, hi = min(total, lo + ASM_CHUNK);
+    if (lo >= hi) return;
+    const bool corner = b == M.N - 1;
+    const int rows = corner ? 0 : Gm.row_ptr[b + 1] - Gm.row_ptr[b];
+    const double* Xb = XG + (corner ? 0 : Gm.x_off[b]);
+    const int* rid = Gm.rows + (corner ? 0 : Gm.row_ptr[b]);
+    const long long fo = M.front_off[b];
+    const int start = M.start[b];
+    for (int idx = lo + threadIdx.x; idx < hi; idx += NT) {
+        const int r = idx % h, c = idx / h;
+        if (r < c) continue;
+        double s = 0.0;
+        for (int k = 0; k < rows; ++k) s += Xb[r + (long long)k * h] * zinv[rid[k]] * Xb[c + (long long)k * h];
+        double v = Pf[fo + idx] + delta_inv * AtAf[fo + idx] + s;
+        if (r == c && c < w) v += x_reg[start + c];
+        F[fo + idx] = v;
+    }
+}
+
+// position inside front b of the t-th row of the update matrix carried from stage b-1 ([off_{b-1} | arrow])
+__device__ __forceinline__ int carry_row(int t, int off_prev, int w, int offb, bool corner)
+{
+    if (t < off_prev) return t;
+    return corner ? t - off_prev : w + offb + (t - off_prev);
+}
+
+// One workgroup walks the block-tridiagonal-arrow chain (factor_kkt, :1253-1352).  Per stage b:
+//   front += carried update;  [L_b; C_b; F_b] = panel Cholesky of the first w_b columns;
+//   carried update = trailing block - [C_b; F_b][C_b; F_b]^T;  inverse of L_b for the solves.
+// LDS = true: front, carried update and inverse live in LDS; false: everything in place in HBM/L2.
+template <bool LDS>
+__global__ __launch_bounds__(NT) void k_ms_factor(MsMeta M, double* __restrict__ fronts, double* __restrict__ pan, int fcap, int lofs, int li_in_lds)
+{
+    extern __shared__ double sm[];
+    const int tid = threadIdx.x;
+    const int N = M.N;
+    int u_prev = 0, off_prev = 0, ldu = 0;
+    double* Usrc = nullptr;
+    for (int b = 0; b < N; ++b) {
+        const int h = M.h[b], w = M.w[b];
+        if (h == 0) break;  // no arrow corner
+        const bool corner = b == N - 1;
+        const int offb = M.off[b];
+        const int u = h - w;
+        double* Fg = fronts + M.front_off[b];
+        double* P = pan + M.pan_off[b];
+        double* Li = P + (long long)h * w;  // w x w inverse of L_b, written straight to its final place
+        double* F;
+        if constexpr (LDS) {
+            F = sm;
+            for (int idx = tid; idx < h * h; idx += NT) F[idx] = Fg[idx];
+            __syncthreads();
+        } else {
+            F = Fg;
+        }
+        const int ld = h;
+        if (u_prev > 0) {  // extend-add of the carried update matrix (distinct targets -> no conflicts)
+            for (int idx = tid; idx < u_prev * u_prev; idx += NT) {
+                const int i = idx % u_prev, j = idx / u_prev;
+                if (i < j) continue;
+                F[carry_row(i, off_prev, w, offb, corner) + carry_row(j, off_prev, w, offb, corner) * ld] += Usrc[i + j * ldu];
+            }
+            __syncthreads();
+        }
+        // right-looking Cholesky of the h x w column panel
+        for (int j = 0; j < w; ++j) {
+            const double d = F[j + j * ld];
+            const double inv = d > 0.0 ? 1.0 / sqrt(d) : 0.0;
+            for (int r = j + 1 + tid; r < h; r += NT) F[r + j * ld] *= inv;
+            __syncthreads();
+            if (tid == 0) F[j + j * ld] = d * inv;
+            const int nc = w - j - 1, nr = h - j - 1;
+            for (int idx = tid; idx < nc * nr; idx += NT) {
+                const int c = j + 1 + idx / nr, r = j + 1 + idx % nr;
+                if (r >= c) F[r + c * ld] -= F[r + j * ld] * F[c + j * ld];
+            }
+            __syncthreads();
+        }
+        // wave 0: explicit inverse of L_b (lane c solves L X = e_c by forward substitution, X staged in LDS when it fits);
+        // waves 1-3: Schur complement of the panel
+        double* Udst;
+        int ldud;
+        if constexpr (LDS) { Udst = sm + fcap; ldud = u; } else { Udst = F + w + w * ld; ldud = ld; }
+        double* Xb = li_in_lds ? sm + lofs : Li;
+        if (tid < 64) {
+            for (int c = tid; c < w; c += 64) {
+                double* X = Xb + c * w;
+                for (int r = 0; r < c; ++r) X[r] = 0.0;
+                const double dc = F[c + c * ld];
+                X[c] = dc != 0.0 ? 1.0 / dc : 0.0;
+                for (int r = c + 1; r < w; ++r) {
+                    double s = 0.0;
+                    for (int k = c; k < r; ++k) s += F[r + k * ld] * X[k];
+                    const double dr = F[r + r * ld];
+                    X[r] = dr != 0.0 ? -s / dr : 0.0;
+                }
+            }
+        } else {
+            for (int idx = tid - 64; idx < u * u; idx += NT - 64) {
+                const int i = idx % u, j = idx / u;
+                if (i < j) continue;
+                double s = F[(w + i) + (w + j) * ld];
+                for (int k = 0; k < w; ++k) s -= F[(w + i) + k * ld] * F[(w + j) + k * ld];
+                Udst[i + j * ldud] = s;
+            }
+            // factor panel to HBM for the solves
+            for (int idx = tid - 64; idx < h * w; idx += NT - 64) P[idx] = F[idx];
+        }
+        __syncthreads();
+        if (li_in_lds) {
+            for (int idx = tid; idx < w * w; idx += NT) Li[idx] = Xb[idx];
+            __syncthreads();
+        }
+        u_prev = u; off_prev = offb; Usrc = Udst; ldu = ldud;
+    }
+}
+
+// Forward and backward block substitution in one launch (solve_llt_in_place, :1709-1816); x is overwritten.
+template <bool LDS>
+__global__ __launch_bounds__(NT) void k_ms_solve(MsMeta M, const double* __restrict__ pan, double* __restrict__ x, int pcap, int hcap)
+{
+    extern __shared__ double sm[];
+    double* xs = sm;           // hcap
+    double* ys = sm + hcap;    // hcap
+    double* Pl = sm + 2 * hcap;  // pcap (LDS variant only)
+    const int tid = threadIdx.x;
+    const int N = M.N, n = M.n, arrow = M.arrow;
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int bb = 0; bb < N; ++bb) {
+            const int b = pass == 0 ? bb : N - 1 - bb;
+            const int h = M.h[b], w = M.w[b];
+            if (h == 0) continue;
+            const int u = h - w, offb = M.off[b], start = M.start[b];
+            const double* Pg = pan + M.pan_off[b];
+            const double* P;
+            if constexpr (LDS) {
+                const int cnt = h * w + w * w;
+                for (int idx = tid; idx < cnt; idx += NT) Pl[idx] = Pg[idx];
+                P = Pl;
+            } else {
+                P = Pg;
+            }
+            const double* Li = P + (long long)h * w;
+            if (pass == 0) {
+                for (int r = tid; r < w; r += NT) xs[r] = x[start + r];
+                __syncthreads();
+                // y_b = L_b^{-1} x_b
+                for (int r = tid; r < w; r += NT) {
+                    double s = 0.0;
+                    for (int k = 0; k <= r; ++k) s += Li[r + k * w] * xs[k];
+                    ys[r] = s;
+                }
+                __syncthreads();
+                for (int r = tid; r < w; r += NT) x[start + r] = ys[r];
+                // x_{b+1}[0:off] -= C_b y_b ;  x_N -= F_b y_b
+                for (int t = tid; t < u; t += NT) {
+                    double s = 0.0;
+                    for (int k = 0; k < w; ++k) s += P[(w + t) + k * h] * ys[k];
+                    const int tgt = t < offb ? start + w + t : n - arrow + (t - offb);
+                    x[tgt] -= s;
+                }
+                __syncthreads();
+            } else {
+                for (int r = tid; r < w; r += NT) xs[r] = x[start + r];
+                for (int t = tid; t < u; t += NT) xs[w + t] = x[t < offb ? start + w + t : n - arrow + (t - offb)];
+                __syncthreads();
+                // z = x_b - C_b^T x_{b+1}[0:off] - F_b^T x_N
+                for (int k = tid; k < w; k += NT) {
+                    double s = xs[k];
+                    for (int t = 0; t < u; ++t) s -= P[(w + t) + k * h] * xs[w + t];
+                    ys[k] = s;
+                }
+                __syncthreads();
+                // x_b = L_b^{-T} z
+                for (int r = tid; r < w; r += NT) {
+                    double s = 0.0;
+                    for (int k = r; k < w; ++k) s += Li[k + r * w] * ys[k];
+                    x[start + r] = s;
+                }
+                __syncthreads();
+            }
+        }
+    }
+    (void)pcap;
+}
+
+template <class T>
+void clone_buf(DBuf<T>& d, const DBuf<T>& s, hipStream_t st)
+{
+    d.alloc(s.n ? s.n : 1);
+    if (s.n) PQ_HIP(hipMemcpyAsync(d.p, s.p, s.bytes(), hipMemcpyDeviceToDevice, st));
+}
+
+class MultistageKKT final : public KKTSolverBase {
+public:
+    MultistageKKT(const pq_sparse_data* d, int device) : dev_(device)
+    {
+        if (d->mem != PQ_MEM_HOST) throw std::runtime_error("sparse data must be host-resident");
+        PQ_HIP(hipSetDevice(dev_));
+        PQ_HIP(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
+        multistage::analyse(d, S_);
+        n_ = S_.n; p_ = S_.p; m_ = S_.m;
+        plan_lds();
+        // device copies of the symbolic analysis
+        std::vector<int> start(S_.N);
+        for (int b = 0; b < S_.N; ++b) start[b] = S_.block_info[b].start;
+        upload_vec(w_, S_.w, st_); upload_vec(off_, S_.off, st_); upload_vec(h_, S_.h, st_); upload_vec(start_, start, st_);
+        upload_vec(front_off_, S_.front_off, st_); upload_vec(pan_off_, S_.pan_off, st_);
+        upload_vec(a_row_ptr_, S_.A.row_ptr, st_); upload_vec(a_rows_, S_.A.rows, st_); upload_vec(a_x_off_, S_.A.x_off, st_); upload_vec(a_dst_, S_.A.dst, st_);
+        upload_vec(g_row_ptr_, S_.G.row_ptr, st_); upload_vec(g_rows_, S_.G.rows, st_); upload_vec(g_x_off_, S_.G.x_off, st_); upload_vec(g_dst_, S_.G.dst, st_);
+        upload_vec(p_dst_, S_.P_dst, st_);
+        auto arena = [&](DBuf<double>& b, long long cnt) { b.alloc(cnt > 0 ? (size_t)cnt : 1); b.zero(st_); };
+        arena(Pf_, S_.front_doubles); arena(AtAf_, S_.front_doubles); arena(F_, S_.front_doubles); arena(pan_, S_.pan_doubles);
+        arena(XA_, S_.A.x_doubles); arena(XG_, S_.G.x_doubles);
+        zinv_.alloc(m_ ? m_ : 1);
+        ops_.init(d, st_);
+        scatter_values(KKT_ALL);
+    }
+    ~MultistageKKT() override
+    {
+        (void)hipSetDevice(dev_);
+        if (st_) { (void)hipStreamSynchronize(st_); (void)hipStreamDestroy(st_); }
+    }
+
+    KKTSolverBase* clone() const override
+    {
+        PQ_HIP(hipSetDevice(dev_));
+        PQ_HIP(hipStreamSynchronize(st_));
+        return new MultistageKKT(*this, 0);
+    }
+
+    // multistage_kkt.hpp:142-178
+    void update_data_sparse(const pq_sparse_data* d, int options) override
+    {
+        PQ_HIP(hipSetDevice(dev_));
+        (void)options;  // Solver::update rewrites all three matrices through unscale -> rescale; refresh everything stored
+        ops_.upload_values(d, st_);
+        scatter_values(KKT_ALL);
+    }
+
+    // multistage_kkt.hpp:180-219
+    bool update_scalings_and_factor(double delta, const double* x_reg, const double* z_reg) override
+    {
+        PQ_HIP(hipSetDevice(dev_));
+        delta_ = delta;
+        const int t0 = prof_.begin(0, st_);
+        if (m_ > 0) hipLaunchKernelGGL(k_ms_reciprocal, dim3((m_ + 255) / 256), dim3(256), 0, st_, m_, z_reg, zinv_.p);
+        hipLaunchKernelGGL(k_ms_assemble, dim3(S_.N, asm_chunks_), dim3(NT), 0, st_, meta(), gmeta(), XG_.p, Pf_.p, AtAf_.p, zinv_.p, x_reg, 1.0 / delta, F_.p);
+        prof_.end(0, t0, st_);
+        const int t1 = prof_.begin(1, st_);
+        if (factor_in_lds_) hipLaunchKernelGGL(k_ms_factor<true>, dim3(1), dim3(NT), factor_lds_bytes_, st_, meta(), F_.p, pan_.p, fcap_, fcap_ + ucap_, 1);
+        else hipLaunchKernelGGL(k_ms_factor<false>, dim3(1), dim3(NT), factor_lds_bytes_, st_, meta(), F_.p, pan_.p, 0, 0, li_in_lds_ ? 1 : 0);
+        prof_.end(1, t1, st_);
+        PQ_HIP(hipGetLastError());
+        return true;  // :218
+    }
+
+    // multistage_kkt.hpp:221-288
+    void solve(const double* rhs_x, const double* rhs_y, const double* rhs_z, double* lhs_x, double* lhs_y, double* lhs_z) override
+    {
+        PQ_HIP(hipSetDevice(dev_));
+        const int tk = prof_.begin(2, st_);
+        const double delta_inv = 1.0 / delta_;
+        ops_.fold_rhs(rhs_x, rhs_y, rhs_z, zinv_.p, delta_inv, lhs_x, st_);
+        if (solve_in_lds_) hipLaunchKernelGGL(k_ms_solve<true>, dim3(1), dim3(NT), solve_lds_bytes_, st_, meta(), pan_.p, lhs_x, pcap_, hcap_);
+        else hipLaunchKernelGGL(k_ms_solve<false>, dim3(1), dim3(NT), 2 * hcap_ * (int)sizeof(double), st_, meta(), pan_.p, lhs_x, pcap_, hcap_);
+        ops_.recover_duals(lhs_x, rhs_y, rhs_z, zinv_.p, delta_inv, lhs_y, lhs_z, st_);
+        PQ_HIP(hipGetLastError());
+        prof_.end(2, tk, st_);
+    }
+
+    void eval_P_x(double alpha, const double* x, double* z) override
+    {
+        PQ_HIP(hipSetDevice(dev_));
+        ops_.eval_P_x(alpha, x, z, st_);
+    }
+    void eval_A_xn_and_AT_xt(double alpha_n, double alpha_t, const double* xn, const double* xt, double* zn, double* zt) override
+    {
+        PQ_HIP(hipSetDevice(dev_));
+        ops_.eval_A_xn_and_AT_xt(alpha_n, alpha_t, xn, xt, zn, zt, st_);
+    }
+    void eval_G_xn_and_GT_xt(double alpha_n, double alpha_t, const double* xn, const double* xt, double* zn, double* zt) override
+    {
+        PQ_HIP(hipSetDevice(dev_));
+        ops_.eval_G_xn_and_GT_xt(alpha_n, alpha_t, xn, xt, zn, zt, st_);
+    }
+
+    // multistage_kkt.hpp:385-393 (same text), plus where the chain runs
+    void print_info() override
+    {
+        std::printf("block sizes:");
+        for (int b = 0; b + 1 < S_.N; ++b) std::printf(" %d,%d", S_.block_info[b].diag_size, S_.block_info[b].off_diag_size);
+        std::printf("\narrow width: %d\n", S_.arrow);
+        std::printf("multistage chain: %d stages, max front %d, factor %s, solve %s, front storage %.2f MB\n", S_.N - 1, S_.max_h, factor_in_lds_ ? "in LDS" : "in HBM",
+                    solve_in_lds_ ? "in LDS" : "in HBM", S_.front_doubles * 8.0 / 1e6);
+    }
+
+    const double* P_diag_device() const override { return ops_.P_diag(); }
+    int n() const override { return n_; }
+    int p() const override { return p_; }
+    int m() const override { return m_; }
+    hipStream_t stream() const override { return st_; }
+    int device() const override { return dev_; }
+    void set_profiling(bool on) override { prof_.enabled = on; }
+    void get_profile(int stage, double* total_ms, int* count) override
+    {
+        if (stage < 0 || stage >= StageProfiler::NSTAGE) throw std::runtime_error("bad stage");
+        PQ_HIP(hipSetDevice(dev_));
+        prof_.collect(stage, st_, total_ms, count);
+    }
+    void multistage_block_info(std::vector<int>& out) const override
+    {
+        out.clear();
+        for (const auto& b : S_.block_info) { out.push_back(b.start); out.push_back(b.diag_size); out.push_back(b.off_diag_size); }
+    }
+
+private:
+    enum { KKT_ALL = 7 };
+
+    MultistageKKT(const MultistageKKT& o, int)
+        : dev_(o.dev_), n_(o.n_), p_(o.p_), m_(o.m_), delta_(o.delta_), S_(o.S_), factor_in_lds_(o.factor_in_lds_), li_in_lds_(o.li_in_lds_), solve_in_lds_(o.solve_in_lds_),
+          factor_lds_bytes_(o.factor_lds_bytes_), solve_lds_bytes_(o.solve_lds_bytes_), fcap_(o.fcap_), ucap_(o.ucap_), pcap_(o.pcap_), hcap_(o.hcap_), asm_chunks_(o.asm_chunks_)
+    {
+        PQ_HIP(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
+        ops_.clone_from(o.ops_, st_);
+        clone_buf(w_, o.w_, st_); clone_buf(off_, o.off_, st_); clone_buf(h_, o.h_, st_); clone_buf(start_, o.start_, st_);
+        clone_buf(front_off_, o.front_off_, st_); clone_buf(pan_off_, o.pan_off_, st_);
+        clone_buf(a_row_ptr_, o.a_row_ptr_, st_); clone_buf(a_rows_, o.a_rows_, st_); clone_buf(a_x_off_, o.a_x_off_, st_); clone_buf(a_dst_, o.a_dst_, st_);
+        clone_buf(g_row_ptr_, o.g_row_ptr_, st_); clone_buf(g_rows_, o.g_rows_, st_); clone_buf(g_x_off_, o.g_x_off_, st_); clone_buf(g_dst_, o.g_dst_, st_);
+        clone_buf(p_dst_, o.p_dst_, st_);
+        clone_buf(Pf_, o.Pf_, st_); clone_buf(AtAf_, o.AtAf_, st_); clone_buf(F_, o.F_, st_); clone_buf(pan_, o.pan_, st_);
+        clone_buf(XA_, o.XA_, st_); clone_buf(XG_, o.XG_, st_); clone_buf(zinv_, o.zinv_, st_);
+        PQ_HIP(hipStreamSynchronize(st_));
+    }
+
+    MsMeta meta() const { return MsMeta{S_.N, S_.arrow, n_, w_.p, off_.p, h_.p, start_.p, front_off_.p, pan_off_.p}; }
+    GroupMeta gmeta() const { return GroupMeta{g_row_ptr_.p, g_rows_.p, g_x_off_.p}; }
+    GroupMeta ameta() const { return GroupMeta{a_row_ptr_.p, a_rows_.p, a_x_off_.p}; }
+
+    // where the chain kernels keep their working set
+    void plan_lds()
+    {
+        int max_u = 0;
+        long long max_pan = 0;
+        for (int b = 0; b < S_.N; ++b) {
+            max_u = std::max(max_u, S_.h[b] - S_.w[b]);
+            max_pan = std::max(max_pan, (long long)S_.h[b] * S_.w[b] + (long long)S_.w[b] * S_.w[b]);
+        }
+        fcap_ = S_.max_h * S_.max_h;
+        ucap_ = max_u * max_u;
+        const long long lbytes = (long long)S_.max_w * S_.max_w * (long long)sizeof(double);
+        const long long fbytes = ((long long)fcap_ + ucap_) * (long long)sizeof(double) + lbytes;
+        factor_in_lds_ = fbytes <= LDS_LIMIT_BYTES;
+        li_in_lds_ = factor_in_lds_ || lbytes <= LDS_LIMIT_BYTES;
+        factor_lds_bytes_ = factor_in_lds_ ? (int)fbytes : (li_in_lds_ ? (int)lbytes : 0);
+        hcap_ = std::max(1, S_.max_h);
+        pcap_ = (int)std::min<long long>(max_pan, 1 << 30);
+        const long long sbytes = (2LL * hcap_ + max_pan) * (long long)sizeof(double);
+        solve_in_lds_ = sbytes <= LDS_LIMIT_BYTES;
+        solve_lds_bytes_ = solve_in_lds_ ? (int)sbytes : 0;
+        if (2LL * hcap_ * (long long)sizeof(double) > LDS_LIMIT_BYTES) throw std::runtime_error("multistage: a stage is too wide for this backend");
+        asm_chunks_ = std::max(1, (fcap_ + ASM_CHUNK - 1) / ASM_CHUNK);
+        static bool attr_set = false;
+        if (!attr_set) {
+            PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ms_factor<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT_BYTES));
+            PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ms_factor<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT_BYTES));
+            PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ms_solve<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT_BYTES));
+            PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ms_solve<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT_BYTES));
+            attr_set = true;
+        }
+    }
+
+    // caller's CSC values -> front / grouped-row arenas (utri_to_kkt :599-670, transpose_to_block_mat :672-818), then AtA (:161)
+    void scatter_values(int options)
+    {
+        if (options & 1) launch_remap_values64(ops_.nzP(), p_dst_.p, ops_.P_x(), Pf_.p, st_);
+        if (options & 2) {
+            launch_remap_values64(ops_.nzA(), a_dst_.p, ops_.AT_x(), XA_.p, st_);
+            hipLaunchKernelGGL(k_ms_gram, dim3(S_.N - 1, asm_chunks_), dim3(NT), 0, st_, meta(), ameta(), XA_.p, AtAf_.p);
+        }
+        if (options & 4) launch_remap_values64(ops_.nzG(), g_dst_.p, ops_.GT_x(), XG_.p, st_);
+        PQ_HIP(hipGetLastError());
+        PQ_HIP(hipStreamSynchronize(st_));
+    }
+
+    int dev_, n_ = 0, p_ = 0, m_ = 0;
+    double delta_ = 1.0;
+    hipStream_t st_ = nullptr;
+    multistage::Symbolic S_;
+    bool factor_in_lds_ = true, li_in_lds_ = true, solve_in_lds_ = true;
+    int factor_lds_bytes_ = 0, solve_lds_bytes_ = 0, fcap_ = 0, ucap_ = 0, pcap_ = 0, hcap_ = 1, asm_chunks_ = 1;
+    CscOperators ops_;
+    DBuf<int> w_, off_, h_, start_, a_row_ptr_, a_rows_, g_row_ptr_, g_rows_;
+    DBuf<long long> front_off_, pan_off_, a_x_off_, g_x_off_, a_dst_, g_dst_, p_dst_;
+    DBuf<double> Pf_, AtAf_, F_, pan_, XA_, XG_, zinv_;
+    StageProfiler prof_;
+};
+
+}  // namespace
+
+KKTSolverBase* make_multistage_kkt(const pq_sparse_data* data, int device) { return new MultistageKKT(data, device); }
+
+}  // namespace pq

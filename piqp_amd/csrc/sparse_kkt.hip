@@ -19,6 +19,7 @@
 
 #include "dense_kernels.hpp"
 #include "kkt_solver_base.hpp"
+#include "sparse_ops.hpp"
 #include "sparse_symbolic.hpp"
 
 namespace pq {
@@ -57,28 +58,6 @@ __global__ void k_scatter_fronts(int nnz, const long long* __restrict__ a_dst, c
 {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q < nnz) fronts[a_dst[q]] = vals[q];
-}
-
-__global__ void k_remap_values(int nnz, const int* __restrict__ dst_idx, const double* __restrict__ src, double* __restrict__ dst)
-{
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q < nnz) dst[dst_idx[q]] = src[q];
-}
-__global__ void k_gather_values(int nnz, const int* __restrict__ src_idx, const double* __restrict__ src, double* __restrict__ dst)
-{
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q < nnz) dst[q] = src[src_idx[q]];
-}
-
-// y[j] = alpha * sum_q val[q] * x[row[q]] over column j  (CSC column dot; thread per column)
-__global__ void k_spmv_cols(int ncols, const int* __restrict__ colptr, const int* __restrict__ rowind, const double* __restrict__ val, const double* __restrict__ x,
-                            double alpha, double* __restrict__ y)
-{
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= ncols) return;
-    double s = 0.0;
-    for (int q = colptr[j]; q < colptr[j + 1]; ++q) s += val[q] * x[rowind[q]];
-    y[j] = alpha * s;
 }
 
 __global__ void k_perm_gather(int N, const int* __restrict__ P, const double* __restrict__ a, int na, const double* __restrict__ b, int nb, const double* __restrict__ c,
@@ -249,24 +228,6 @@ __global__ __launch_bounds__(256) void k_front_bwd(FrontMeta M, const double* __
 
 inline dim3 g1(int n) { return dim3(n > 0 ? (n + 255) / 256 : 1); }
 
-template <class T>
-void upload(DBuf<T>& d, const std::vector<T>& h, hipStream_t st)
-{
-    d.alloc(h.size() ? h.size() : 1);
-    if (!h.empty()) PQ_HIP(hipMemcpyAsync(d.p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, st));
-}
-
-// host-side CSC transpose with a value map: T = M^T, tmap[q_in_T] = q_in_M
-void transpose_with_map(int rows, int cols, const int* Mp, const int* Mi, std::vector<int>& Tp, std::vector<int>& Ti, std::vector<int>& tmap)
-{
-    const int nnz = Mp[cols];
-    Tp.assign(rows + 1, 0); Ti.assign(nnz, 0); tmap.assign(nnz, 0);
-    for (int q = 0; q < nnz; ++q) Tp[Mi[q] + 1]++;
-    for (int i = 0; i < rows; ++i) Tp[i + 1] += Tp[i];
-    std::vector<int> nx(Tp.begin(), Tp.end() - 1);
-    for (int j = 0; j < cols; ++j) for (int q = Mp[j]; q < Mp[j + 1]; ++q) { const int t = nx[Mi[q]]++; Ti[t] = j; tmap[t] = q; }
-}
-
 class SparseKKT final : public KKTSolverBase {
 public:
     SparseKKT(const pq_sparse_data* d, int device) : dev_(device)
@@ -309,7 +270,7 @@ public:
         PQ_HIP(hipSetDevice(dev_));
         delta_ = delta;
         const int t0 = prof_.begin(0, st_);
-        hipLaunchKernelGGL(k_set_diag, g1(N_), dim3(256), 0, st_, n_, p_, m_, diag_pos_.p, Pdiag_.p, x_reg, delta, z_reg, vals_.p);
+        hipLaunchKernelGGL(k_set_diag, g1(N_), dim3(256), 0, st_, n_, p_, m_, diag_pos_.p, ops_.P_diag(), x_reg, delta, z_reg, vals_.p);
         PQ_HIP(hipMemsetAsync(fronts_.p, 0, sizeof(double) * (size_t)S_.front_doubles, st_));
         hipLaunchKernelGGL(k_scatter_fronts, g1(nnzK_), dim3(256), 0, st_, nnzK_, a_dst_.p, vals_.p, fronts_.p);
         prof_.end(0, t0, st_);
@@ -359,19 +320,17 @@ public:
     void eval_P_x(double alpha, const double* x, double* z) override
     {
         PQ_HIP(hipSetDevice(dev_));
-        hipLaunchKernelGGL(k_spmv_cols, g1(n_), dim3(256), 0, st_, n_, Pf_p_.p, Pf_i_.p, Pf_x_.p, x, alpha, z);
+        ops_.eval_P_x(alpha, x, z, st_);
     }
     void eval_A_xn_and_AT_xt(double alpha_n, double alpha_t, const double* xn, const double* xt, double* zn, double* zt) override
     {
         PQ_HIP(hipSetDevice(dev_));
-        if (p_ > 0) hipLaunchKernelGGL(k_spmv_cols, g1(p_), dim3(256), 0, st_, p_, AT_p_.p, AT_i_.p, AT_x_.p, xn, alpha_n, zn);  // A x = (AT)^T x
-        hipLaunchKernelGGL(k_spmv_cols, g1(n_), dim3(256), 0, st_, n_, A_p_.p, A_i_.p, A_x_.p, xt, alpha_t, zt);                   // AT y = (A)^T y
+        ops_.eval_A_xn_and_AT_xt(alpha_n, alpha_t, xn, xt, zn, zt, st_);
     }
     void eval_G_xn_and_GT_xt(double alpha_n, double alpha_t, const double* xn, const double* xt, double* zn, double* zt) override
     {
         PQ_HIP(hipSetDevice(dev_));
-        if (m_ > 0) hipLaunchKernelGGL(k_spmv_cols, g1(m_), dim3(256), 0, st_, m_, GT_p_.p, GT_i_.p, GT_x_.p, xn, alpha_n, zn);
-        hipLaunchKernelGGL(k_spmv_cols, g1(n_), dim3(256), 0, st_, n_, G_p_.p, G_i_.p, G_x_.p, xt, alpha_t, zt);
+        ops_.eval_G_xn_and_GT_xt(alpha_n, alpha_t, xn, xt, zn, zt, st_);
     }
 
     void print_info() override
@@ -380,7 +339,7 @@ public:
                     S_.nsuper, S_.nlevels, S_.max_front, S_.front_doubles * 8.0 / 1e6);
     }
 
-    const double* P_diag_device() const override { return Pdiag_.p; }
+    const double* P_diag_device() const override { return ops_.P_diag(); }
     int n() const override { return n_; }
     int p() const override { return p_; }
     int m() const override { return m_; }
@@ -396,19 +355,18 @@ public:
     const sparse::Symbolic& symbolic() const { return S_; }
 
 private:
-    SparseKKT(const SparseKKT& o, int) : dev_(o.dev_), n_(o.n_), p_(o.p_), m_(o.m_), N_(o.N_), nnzK_(o.nnzK_), delta_(o.delta_), S_(o.S_), Pf_map_(o.Pf_map_), A_map_(o.A_map_), G_map_(o.G_map_), level_lds_(o.level_lds_)
+    SparseKKT(const SparseKKT& o, int) : dev_(o.dev_), n_(o.n_), p_(o.p_), m_(o.m_), N_(o.N_), nnzK_(o.nnzK_), delta_(o.delta_), S_(o.S_), level_lds_(o.level_lds_)
     {
         PQ_HIP(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
         auto cpd = [&](DBuf<double>& d, const DBuf<double>& s) { d.alloc(s.n ? s.n : 1); if (s.n) PQ_HIP(hipMemcpyAsync(d.p, s.p, s.bytes(), hipMemcpyDeviceToDevice, st_)); };
         auto cpi = [&](DBuf<int>& d, const DBuf<int>& s) { d.alloc(s.n ? s.n : 1); if (s.n) PQ_HIP(hipMemcpyAsync(d.p, s.p, s.bytes(), hipMemcpyDeviceToDevice, st_)); };
         auto cpl = [&](DBuf<long long>& d, const DBuf<long long>& s) { d.alloc(s.n ? s.n : 1); if (s.n) PQ_HIP(hipMemcpyAsync(d.p, s.p, s.bytes(), hipMemcpyDeviceToDevice, st_)); };
-        cpd(vals_, o.vals_); cpd(fronts_, o.fronts_); cpd(rdiag_, o.rdiag_); cpd(Pdiag_, o.Pdiag_); cpd(Pf_x_, o.Pf_x_); cpd(AT_x_, o.AT_x_); cpd(A_x_, o.A_x_);
-        cpd(GT_x_, o.GT_x_); cpd(G_x_, o.G_x_);
-        xp_.alloc(o.xp_.n); fvec_.alloc(o.fvec_.n); stage_vals_.alloc(o.stage_vals_.n); dvec_.alloc(o.dvec_.n);
+        ops_.clone_from(o.ops_, st_);
+        cpd(vals_, o.vals_); cpd(fronts_, o.fronts_); cpd(rdiag_, o.rdiag_);
+        xp_.alloc(o.xp_.n); fvec_.alloc(o.fvec_.n); dvec_.alloc(o.dvec_.n);
         cpi(diag_pos_, o.diag_pos_); cpi(P_, o.P_); cpi(level_sn_, o.level_sn_); cpi(sn_first_, o.sn_first_); cpi(front_rows_ptr_, o.front_rows_ptr_); cpi(front_rows_, o.front_rows_);
-        cpi(child_ptr_, o.child_ptr_); cpi(child_, o.child_); cpi(rel_ptr_, o.rel_ptr_); cpi(rel_, o.rel_); cpi(Pf_p_, o.Pf_p_); cpi(Pf_i_, o.Pf_i_); cpi(AT_p_, o.AT_p_);
-        cpi(AT_i_, o.AT_i_); cpi(A_p_, o.A_p_); cpi(A_i_, o.A_i_); cpi(GT_p_, o.GT_p_); cpi(GT_i_, o.GT_i_); cpi(G_p_, o.G_p_); cpi(G_i_, o.G_i_);
-        cpi(mapP_, o.mapP_); cpi(mapA_, o.mapA_); cpi(mapG_, o.mapG_); cpi(Pf_src_, o.Pf_src_); cpi(A_src_, o.A_src_); cpi(G_src_, o.G_src_); cpi(Pdiag_src_, o.Pdiag_src_);
+        cpi(child_ptr_, o.child_ptr_); cpi(child_, o.child_); cpi(rel_ptr_, o.rel_ptr_); cpi(rel_, o.rel_);
+        cpi(mapP_, o.mapP_); cpi(mapA_, o.mapA_); cpi(mapG_, o.mapG_);
         cpl(a_dst_, o.a_dst_); cpl(front_off_, o.front_off_);
         info_.alloc(1); info_h_.alloc(1);
         PQ_HIP(hipStreamSynchronize(st_));
@@ -439,12 +397,12 @@ private:
     void build_device(const pq_sparse_data* d)
     {
         nnzK_ = S_.Cp[N_];
-        upload(diag_pos_, S_.diag_pos, st_); upload(P_, S_.P, st_); upload(level_sn_, S_.level_sn, st_); upload(sn_first_, S_.sn_first, st_);
-        upload(front_rows_ptr_, S_.front_rows_ptr, st_); upload(front_rows_, S_.front_rows, st_); upload(child_ptr_, S_.child_ptr, st_); upload(child_, S_.child, st_);
-        upload(rel_ptr_, S_.rel_ptr, st_); upload(rel_, S_.rel, st_); upload(a_dst_, S_.a_dst, st_); upload(front_off_, S_.front_off, st_);
+        upload_vec(diag_pos_, S_.diag_pos, st_); upload_vec(P_, S_.P, st_); upload_vec(level_sn_, S_.level_sn, st_); upload_vec(sn_first_, S_.sn_first, st_);
+        upload_vec(front_rows_ptr_, S_.front_rows_ptr, st_); upload_vec(front_rows_, S_.front_rows, st_); upload_vec(child_ptr_, S_.child_ptr, st_); upload_vec(child_, S_.child, st_);
+        upload_vec(rel_ptr_, S_.rel_ptr, st_); upload_vec(rel_, S_.rel, st_); upload_vec(a_dst_, S_.a_dst, st_); upload_vec(front_off_, S_.front_off, st_);
         vals_.alloc(nnzK_ ? nnzK_ : 1); vals_.zero(st_);
         fronts_.alloc(S_.front_doubles ? (size_t)S_.front_doubles : 1);
-        rdiag_.alloc(N_); xp_.alloc(N_); fvec_.alloc(S_.front_rows.size() ? S_.front_rows.size() : 1); Pdiag_.alloc(n_); Pdiag_.zero(st_);
+        rdiag_.alloc(N_); xp_.alloc(N_); fvec_.alloc(S_.front_rows.size() ? S_.front_rows.size() : 1);
         dvec_.alloc(dense::FACTOR_NB);
         info_.alloc(1); info_h_.alloc(1);
         // value maps K-index -> PKPt-index composed with the per-matrix maps (kkt_full.hpp:219-249)
@@ -453,66 +411,23 @@ private:
         for (int q = 0; q < nzP; ++q) mp[q] = S_.PKi[S_.P_utri_to_Ki[q]];
         for (int q = 0; q < nzA; ++q) ma[q] = S_.PKi[S_.AT_to_Ki[q]];
         for (int q = 0; q < nzG; ++q) mg[q] = S_.PKi[S_.GT_to_Ki[q]];
-        upload(mapP_, mp, st_); upload(mapA_, ma, st_); upload(mapG_, mg, st_);
-        // symmetric completion of P (pattern + source index of every entry) and P's diagonal positions
-        {
-            std::vector<int> cnt(n_ + 1, 0);
-            for (int j = 0; j < n_; ++j) for (int q = d->P_colptr[j]; q < d->P_colptr[j + 1]; ++q) { const int i = d->P_rowind[q]; cnt[j + 1]++; if (i != j) cnt[i + 1]++; }
-            std::vector<int> fp(n_ + 1, 0);
-            for (int j = 0; j < n_; ++j) fp[j + 1] = fp[j] + cnt[j + 1];
-            std::vector<int> fi(fp[n_]), src(fp[n_]), nx(fp.begin(), fp.end() - 1), dsrc(n_, -1);
-            // rows ascending in every column: first the upper entries of column j (rows <= j), later the mirrored ones (rows > j)
-            for (int j = 0; j < n_; ++j) for (int q = d->P_colptr[j]; q < d->P_colptr[j + 1]; ++q) { const int t = nx[j]++; fi[t] = d->P_rowind[q]; src[t] = q; if (d->P_rowind[q] == j) dsrc[j] = q; }
-            for (int j = 0; j < n_; ++j) for (int q = d->P_colptr[j]; q < d->P_colptr[j + 1]; ++q) { const int i = d->P_rowind[q]; if (i != j) { const int t = nx[i]++; fi[t] = j; src[t] = q; } }
-            upload(Pf_p_, fp, st_); upload(Pf_i_, fi, st_); upload(Pf_src_, src, st_);
-            Pf_x_.alloc(fp[n_] ? fp[n_] : 1);
-            Pf_map_ = fp[n_];
-            std::vector<int> ds(n_);
-            for (int j = 0; j < n_; ++j) ds[j] = dsrc[j];
-            upload(Pdiag_src_, ds, st_);
-        }
-        // AT (n x p) and its transpose A (p x n); GT (n x m) and G
-        {
-            std::vector<int> atp(d->AT_colptr, d->AT_colptr + p_ + 1), ati(d->AT_rowind, d->AT_rowind + nzA);
-            upload(AT_p_, atp, st_); upload(AT_i_, ati, st_); AT_x_.alloc(nzA ? nzA : 1);
-            std::vector<int> tp, ti, tm;
-            transpose_with_map(n_, p_, atp.data(), ati.data(), tp, ti, tm);
-            upload(A_p_, tp, st_); upload(A_i_, ti, st_); upload(A_src_, tm, st_); A_x_.alloc(nzA ? nzA : 1); A_map_ = nzA;
-            std::vector<int> gtp(d->GT_colptr, d->GT_colptr + m_ + 1), gti(d->GT_rowind, d->GT_rowind + nzG);
-            upload(GT_p_, gtp, st_); upload(GT_i_, gti, st_); GT_x_.alloc(nzG ? nzG : 1);
-            transpose_with_map(n_, m_, gtp.data(), gti.data(), tp, ti, tm);
-            upload(G_p_, tp, st_); upload(G_i_, ti, st_); upload(G_src_, tm, st_); G_x_.alloc(nzG ? nzG : 1); G_map_ = nzG;
-        }
-        stage_vals_.alloc(std::max(1, std::max(nzP, std::max(nzA, nzG))));
-        upload_values(d);
+        upload_vec(mapP_, mp, st_); upload_vec(mapA_, ma, st_); upload_vec(mapG_, mg, st_);
+        ops_.init(d, st_);  // CSC copies for the mat-vecs (uploads the values once)
+        remap_values();
     }
 
     void upload_values(const pq_sparse_data* d)
     {
-        const int nzP = d->P_colptr[n_], nzA = p_ ? d->AT_colptr[p_] : 0, nzG = m_ ? d->GT_colptr[m_] : 0;
-        // P
-        if (nzP) {
-            PQ_HIP(hipMemcpyAsync(stage_vals_.p, d->P_val, sizeof(double) * nzP, hipMemcpyHostToDevice, st_));
-            hipLaunchKernelGGL(k_remap_values, g1(nzP), dim3(256), 0, st_, nzP, mapP_.p, stage_vals_.p, vals_.p);
-            hipLaunchKernelGGL(k_gather_values, g1(Pf_map_), dim3(256), 0, st_, Pf_map_, Pf_src_.p, stage_vals_.p, Pf_x_.p);
-        }
-        {
-            // diag(P) (0 where P has no structural diagonal): extract_P_diag, kkt_system.hpp:437-453 / P_diagonal of kkt_full.hpp
-            std::vector<double> pd(n_, 0.0);
-            for (int j = 0; j < n_; ++j) for (int q = d->P_colptr[j]; q < d->P_colptr[j + 1]; ++q) if (d->P_rowind[q] == j) pd[j] = d->P_val[q];
-            PQ_HIP(hipMemcpyAsync(Pdiag_.p, pd.data(), sizeof(double) * n_, hipMemcpyHostToDevice, st_));
-            PQ_HIP(hipStreamSynchronize(st_));
-        }
-        if (nzA) {
-            PQ_HIP(hipMemcpyAsync(AT_x_.p, d->AT_val, sizeof(double) * nzA, hipMemcpyHostToDevice, st_));
-            hipLaunchKernelGGL(k_remap_values, g1(nzA), dim3(256), 0, st_, nzA, mapA_.p, AT_x_.p, vals_.p);
-            hipLaunchKernelGGL(k_gather_values, g1(nzA), dim3(256), 0, st_, nzA, A_src_.p, AT_x_.p, A_x_.p);
-        }
-        if (nzG) {
-            PQ_HIP(hipMemcpyAsync(GT_x_.p, d->GT_val, sizeof(double) * nzG, hipMemcpyHostToDevice, st_));
-            hipLaunchKernelGGL(k_remap_values, g1(nzG), dim3(256), 0, st_, nzG, mapG_.p, GT_x_.p, vals_.p);
-            hipLaunchKernelGGL(k_gather_values, g1(nzG), dim3(256), 0, st_, nzG, G_src_.p, GT_x_.p, G_x_.p);
-        }
+        ops_.upload_values(d, st_);
+        remap_values();
+    }
+
+    // device copies of the caller's values -> PKPt value array
+    void remap_values()
+    {
+        launch_remap_values(ops_.nzP(), mapP_.p, ops_.P_x(), vals_.p, st_);
+        launch_remap_values(ops_.nzA(), mapA_.p, ops_.AT_x(), vals_.p, st_);
+        launch_remap_values(ops_.nzG(), mapG_.p, ops_.GT_x(), vals_.p, st_);
         PQ_HIP(hipGetLastError());
         PQ_HIP(hipStreamSynchronize(st_));
     }
@@ -552,13 +467,11 @@ private:
     double delta_ = 1.0;
     hipStream_t st_ = nullptr;
     sparse::Symbolic S_;
-    int Pf_map_ = 0, A_map_ = 0, G_map_ = 0;
     std::vector<int> level_lds_;
-    DBuf<double> vals_, fronts_, rdiag_, xp_, fvec_, Pdiag_, stage_vals_, dvec_;
-    DBuf<double> Pf_x_, AT_x_, A_x_, GT_x_, G_x_;
+    CscOperators ops_;
+    DBuf<double> vals_, fronts_, rdiag_, xp_, fvec_, dvec_;
     DBuf<int> diag_pos_, P_, level_sn_, sn_first_, front_rows_ptr_, front_rows_, child_ptr_, child_, rel_ptr_, rel_;
-    DBuf<int> Pf_p_, Pf_i_, AT_p_, AT_i_, A_p_, A_i_, GT_p_, GT_i_, G_p_, G_i_;
-    DBuf<int> mapP_, mapA_, mapG_, Pf_src_, A_src_, G_src_, Pdiag_src_;
+    DBuf<int> mapP_, mapA_, mapG_;
     DBuf<long long> a_dst_, front_off_;
     DBuf<int> info_;
     HBuf<int> info_h_;
@@ -567,10 +480,11 @@ private:
 
 }  // namespace
 
-// KKTSystem::init_kkt_solver<PIQP_SPARSE> (kkt_system.hpp:470-497): only sparse_ldlt (KKT_FULL) exists in this release;
-// the condensed modes and sparse_multistage report "kkt solver not supported" exactly like a build without them.
+// KKTSystem::init_kkt_solver<PIQP_SPARSE> (kkt_system.hpp:470-497): sparse_ldlt (KKT_FULL) and sparse_multistage exist in this
+// release; the condensed modes report "kkt solver not supported" exactly like a build without them.
 KKTSolverBase* make_sparse_kkt(const pq_sparse_data* data, int kkt_solver, int device)
 {
+    if (kkt_solver == PQ_SPARSE_MULTISTAGE) return make_multistage_kkt(data, device);
     if (kkt_solver != PQ_SPARSE_LDLT) return nullptr;
     return new SparseKKT(data, device);
 }

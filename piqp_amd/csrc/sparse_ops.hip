@@ -1,0 +1,197 @@
+// piqp_amd/csrc/sparse_ops.hip -- see sparse_ops.hpp.
+#include "sparse_ops.hpp"
+
+#include <stdexcept>
+
+namespace pq {
+
+namespace {
+
+inline dim3 g1(int n) { return dim3(n > 0 ? (n + 255) / 256 : 1); }
+
+__global__ void k_remap_values(int nnz, const int* __restrict__ dst_idx, const double* __restrict__ src, double* __restrict__ dst)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < nnz) dst[dst_idx[q]] = src[q];
+}
+__global__ void k_remap_values64(int nnz, const long long* __restrict__ dst_idx, const double* __restrict__ src, double* __restrict__ dst)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < nnz) dst[dst_idx[q]] = src[q];
+}
+__global__ void k_gather_values(int nnz, const int* __restrict__ src_idx, const double* __restrict__ src, double* __restrict__ dst)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < nnz) dst[q] = src[src_idx[q]];
+}
+
+// y[j] = (ACC ? y[j] : 0) + alpha * sum_q val[q] * x[row[q]] over column j  (CSC column dot; thread per column)
+template <bool ACC>
+__global__ void k_spmv_cols(int ncols, const int* __restrict__ colptr, const int* __restrict__ rowind, const double* __restrict__ val, const double* __restrict__ x,
+                            double alpha, double* __restrict__ y)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= ncols) return;
+    double s = 0.0;
+    for (int q = colptr[j]; q < colptr[j + 1]; ++q) s += val[q] * x[rowind[q]];
+    y[j] = ACC ? y[j] + alpha * s : alpha * s;
+}
+
+// out[j] = rhs_x[j] + sum_{G rows i of column j} G(i,j) zinv[i] rhs_z[i] + delta_inv * sum_{A rows i} A(i,j) rhs_y[i]
+__global__ void k_fold_rhs(int n, const int* __restrict__ Gp, const int* __restrict__ Gi, const double* __restrict__ Gx, const int* __restrict__ Ap, const int* __restrict__ Ai,
+                           const double* __restrict__ Ax, const double* __restrict__ rhs_x, const double* __restrict__ rhs_y, const double* __restrict__ rhs_z,
+                           const double* __restrict__ zinv, double delta_inv, double* __restrict__ out)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    double sg = 0.0, sa = 0.0;
+    for (int q = Gp[j]; q < Gp[j + 1]; ++q) { const int i = Gi[q]; sg += Gx[q] * (zinv[i] * rhs_z[i]); }
+    for (int q = Ap[j]; q < Ap[j + 1]; ++q) sa += Ax[q] * rhs_y[Ai[q]];
+    out[j] = (rhs_x[j] + sg) + delta_inv * sa;
+}
+// rows k < p: lhs_y ; rows p <= k < p + m: lhs_z
+__global__ void k_recover_duals(int p, int m, const int* __restrict__ ATp, const int* __restrict__ ATi, const double* __restrict__ ATx, const int* __restrict__ GTp,
+                                const int* __restrict__ GTi, const double* __restrict__ GTx, const double* __restrict__ x, const double* __restrict__ rhs_y,
+                                const double* __restrict__ rhs_z, const double* __restrict__ zinv, double delta_inv, double* __restrict__ lhs_y, double* __restrict__ lhs_z)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < p) {
+        double s = 0.0;
+        for (int q = ATp[k]; q < ATp[k + 1]; ++q) s += ATx[q] * x[ATi[q]];
+        lhs_y[k] = delta_inv * s - delta_inv * rhs_y[k];
+    } else if (k < p + m) {
+        const int i = k - p;
+        double s = 0.0;
+        for (int q = GTp[i]; q < GTp[i + 1]; ++q) s += GTx[q] * x[GTi[q]];
+        lhs_z[i] = (s - rhs_z[i]) * zinv[i];
+    }
+}
+
+// host-side CSC transpose with a value map: T = M^T, tmap[q_in_T] = q_in_M
+void transpose_with_map(int rows, int cols, const int* Mp, const int* Mi, std::vector<int>& Tp, std::vector<int>& Ti, std::vector<int>& tmap)
+{
+    const int nnz = Mp[cols];
+    Tp.assign(rows + 1, 0); Ti.assign(nnz, 0); tmap.assign(nnz, 0);
+    for (int q = 0; q < nnz; ++q) Tp[Mi[q] + 1]++;
+    for (int i = 0; i < rows; ++i) Tp[i + 1] += Tp[i];
+    std::vector<int> nx(Tp.begin(), Tp.end() - 1);
+    for (int j = 0; j < cols; ++j) for (int q = Mp[j]; q < Mp[j + 1]; ++q) { const int t = nx[Mi[q]]++; Ti[t] = j; tmap[t] = q; }
+}
+
+}  // namespace
+
+void launch_remap_values(int nnz, const int* dst_idx, const double* src, double* dst, hipStream_t st)
+{
+    if (nnz > 0) hipLaunchKernelGGL(k_remap_values, g1(nnz), dim3(256), 0, st, nnz, dst_idx, src, dst);
+}
+void launch_remap_values64(int nnz, const long long* dst_idx, const double* src, double* dst, hipStream_t st)
+{
+    if (nnz > 0) hipLaunchKernelGGL(k_remap_values64, g1(nnz), dim3(256), 0, st, nnz, dst_idx, src, dst);
+}
+void launch_gather_values(int nnz, const int* src_idx, const double* src, double* dst, hipStream_t st)
+{
+    if (nnz > 0) hipLaunchKernelGGL(k_gather_values, g1(nnz), dim3(256), 0, st, nnz, src_idx, src, dst);
+}
+
+void CscOperators::init(const pq_sparse_data* d, hipStream_t st)
+{
+    n_ = d->n; p_ = d->p; m_ = d->m;
+    nzP_ = d->P_colptr[n_]; nzA_ = p_ ? d->AT_colptr[p_] : 0; nzG_ = m_ ? d->GT_colptr[m_] : 0;
+    // symmetric completion of P: pattern + source index of every entry
+    {
+        std::vector<int> cnt(n_ + 1, 0);
+        for (int j = 0; j < n_; ++j) for (int q = d->P_colptr[j]; q < d->P_colptr[j + 1]; ++q) { const int i = d->P_rowind[q]; cnt[j + 1]++; if (i != j) cnt[i + 1]++; }
+        std::vector<int> fp(n_ + 1, 0);
+        for (int j = 0; j < n_; ++j) fp[j + 1] = fp[j] + cnt[j + 1];
+        std::vector<int> fi(fp[n_]), src(fp[n_]), nx(fp.begin(), fp.end() - 1);
+        // rows ascending in every column: first the upper entries of column j (rows <= j), later the mirrored ones (rows > j)
+        for (int j = 0; j < n_; ++j) for (int q = d->P_colptr[j]; q < d->P_colptr[j + 1]; ++q) { const int t = nx[j]++; fi[t] = d->P_rowind[q]; src[t] = q; }
+        for (int j = 0; j < n_; ++j) for (int q = d->P_colptr[j]; q < d->P_colptr[j + 1]; ++q) { const int i = d->P_rowind[q]; if (i != j) { const int t = nx[i]++; fi[t] = j; src[t] = q; } }
+        upload_vec(Pf_p_, fp, st); upload_vec(Pf_i_, fi, st); upload_vec(Pf_src_, src, st);
+        nzPf_ = fp[n_];
+        Pf_x_.alloc(nzPf_ ? nzPf_ : 1);
+    }
+    P_x_.alloc(nzP_ ? nzP_ : 1);
+    Pdiag_.alloc(n_ ? n_ : 1);
+    // AT (n x p) and its transpose A (p x n); GT (n x m) and G
+    {
+        std::vector<int> atp(d->AT_colptr, d->AT_colptr + p_ + 1), ati(d->AT_rowind, d->AT_rowind + nzA_);
+        if (!p_) atp.assign(1, 0);
+        upload_vec(AT_p_, atp, st); upload_vec(AT_i_, ati, st); AT_x_.alloc(nzA_ ? nzA_ : 1);
+        std::vector<int> tp, ti, tm;
+        transpose_with_map(n_, p_, atp.data(), ati.data(), tp, ti, tm);
+        upload_vec(A_p_, tp, st); upload_vec(A_i_, ti, st); upload_vec(A_src_, tm, st); A_x_.alloc(nzA_ ? nzA_ : 1);
+        std::vector<int> gtp(d->GT_colptr, d->GT_colptr + m_ + 1), gti(d->GT_rowind, d->GT_rowind + nzG_);
+        if (!m_) gtp.assign(1, 0);
+        upload_vec(GT_p_, gtp, st); upload_vec(GT_i_, gti, st); GT_x_.alloc(nzG_ ? nzG_ : 1);
+        transpose_with_map(n_, m_, gtp.data(), gti.data(), tp, ti, tm);
+        upload_vec(G_p_, tp, st); upload_vec(G_i_, ti, st); upload_vec(G_src_, tm, st); G_x_.alloc(nzG_ ? nzG_ : 1);
+    }
+    upload_values(d, st);
+}
+
+void CscOperators::upload_values(const pq_sparse_data* d, hipStream_t st)
+{
+    if (d->n != n_ || d->p != p_ || d->m != m_) throw std::runtime_error("update_data: dimension mismatch");
+    if (nzP_) {
+        PQ_HIP(hipMemcpyAsync(P_x_.p, d->P_val, sizeof(double) * nzP_, hipMemcpyHostToDevice, st));
+        launch_gather_values(nzPf_, Pf_src_.p, P_x_.p, Pf_x_.p, st);
+    }
+    std::vector<double> pd(n_, 0.0);
+    for (int j = 0; j < n_; ++j) for (int q = d->P_colptr[j]; q < d->P_colptr[j + 1]; ++q) if (d->P_rowind[q] == j) pd[j] = d->P_val[q];
+    if (n_) PQ_HIP(hipMemcpyAsync(Pdiag_.p, pd.data(), sizeof(double) * n_, hipMemcpyHostToDevice, st));
+    if (nzA_) {
+        PQ_HIP(hipMemcpyAsync(AT_x_.p, d->AT_val, sizeof(double) * nzA_, hipMemcpyHostToDevice, st));
+        launch_gather_values(nzA_, A_src_.p, AT_x_.p, A_x_.p, st);
+    }
+    if (nzG_) {
+        PQ_HIP(hipMemcpyAsync(GT_x_.p, d->GT_val, sizeof(double) * nzG_, hipMemcpyHostToDevice, st));
+        launch_gather_values(nzG_, G_src_.p, GT_x_.p, G_x_.p, st);
+    }
+    PQ_HIP(hipGetLastError());
+    PQ_HIP(hipStreamSynchronize(st));  // `pd` and the caller's arrays must outlive the copies
+}
+
+void CscOperators::clone_from(const CscOperators& o, hipStream_t st)
+{
+    n_ = o.n_; p_ = o.p_; m_ = o.m_; nzP_ = o.nzP_; nzA_ = o.nzA_; nzG_ = o.nzG_; nzPf_ = o.nzPf_;
+    auto cpd = [&](DBuf<double>& d, const DBuf<double>& s) { d.alloc(s.n ? s.n : 1); if (s.n) PQ_HIP(hipMemcpyAsync(d.p, s.p, s.bytes(), hipMemcpyDeviceToDevice, st)); };
+    auto cpi = [&](DBuf<int>& d, const DBuf<int>& s) { d.alloc(s.n ? s.n : 1); if (s.n) PQ_HIP(hipMemcpyAsync(d.p, s.p, s.bytes(), hipMemcpyDeviceToDevice, st)); };
+    cpd(P_x_, o.P_x_); cpd(Pf_x_, o.Pf_x_); cpd(AT_x_, o.AT_x_); cpd(A_x_, o.A_x_); cpd(GT_x_, o.GT_x_); cpd(G_x_, o.G_x_); cpd(Pdiag_, o.Pdiag_);
+    cpi(Pf_p_, o.Pf_p_); cpi(Pf_i_, o.Pf_i_); cpi(Pf_src_, o.Pf_src_); cpi(AT_p_, o.AT_p_); cpi(AT_i_, o.AT_i_); cpi(A_p_, o.A_p_); cpi(A_i_, o.A_i_);
+    cpi(A_src_, o.A_src_); cpi(GT_p_, o.GT_p_); cpi(GT_i_, o.GT_i_); cpi(G_p_, o.G_p_); cpi(G_i_, o.G_i_); cpi(G_src_, o.G_src_);
+}
+
+void CscOperators::eval_P_x(double alpha, const double* x, double* z, hipStream_t st) const
+{
+    hipLaunchKernelGGL(k_spmv_cols<false>, g1(n_), dim3(256), 0, st, n_, Pf_p_.p, Pf_i_.p, Pf_x_.p, x, alpha, z);
+}
+void CscOperators::eval_A_xn_and_AT_xt(double an, double at, const double* xn, const double* xt, double* zn, double* zt, hipStream_t st) const
+{
+    if (p_ > 0) hipLaunchKernelGGL(k_spmv_cols<false>, g1(p_), dim3(256), 0, st, p_, AT_p_.p, AT_i_.p, AT_x_.p, xn, an, zn);  // A x = (AT)^T x
+    hipLaunchKernelGGL(k_spmv_cols<false>, g1(n_), dim3(256), 0, st, n_, A_p_.p, A_i_.p, A_x_.p, xt, at, zt);                   // AT y = (A)^T y
+}
+void CscOperators::eval_G_xn_and_GT_xt(double an, double at, const double* xn, const double* xt, double* zn, double* zt, hipStream_t st) const
+{
+    if (m_ > 0) hipLaunchKernelGGL(k_spmv_cols<false>, g1(m_), dim3(256), 0, st, m_, GT_p_.p, GT_i_.p, GT_x_.p, xn, an, zn);
+    hipLaunchKernelGGL(k_spmv_cols<false>, g1(n_), dim3(256), 0, st, n_, G_p_.p, G_i_.p, G_x_.p, xt, at, zt);
+}
+void CscOperators::fold_rhs(const double* rhs_x, const double* rhs_y, const double* rhs_z, const double* zinv, double delta_inv, double* out, hipStream_t st) const
+{
+    hipLaunchKernelGGL(k_fold_rhs, g1(n_), dim3(256), 0, st, n_, G_p_.p, G_i_.p, G_x_.p, A_p_.p, A_i_.p, A_x_.p, rhs_x, rhs_y, rhs_z, zinv, delta_inv, out);
+}
+void CscOperators::recover_duals(const double* x, const double* rhs_y, const double* rhs_z, const double* zinv, double delta_inv, double* lhs_y, double* lhs_z, hipStream_t st) const
+{
+    if (p_ + m_ > 0)
+        hipLaunchKernelGGL(k_recover_duals, g1(p_ + m_), dim3(256), 0, st, p_, m_, AT_p_.p, AT_i_.p, AT_x_.p, GT_p_.p, GT_i_.p, GT_x_.p, x, rhs_y, rhs_z, zinv, delta_inv, lhs_y, lhs_z);
+}
+void CscOperators::add_AT_y(double alpha, const double* y, double* z, hipStream_t st) const
+{
+    if (p_ > 0) hipLaunchKernelGGL(k_spmv_cols<true>, g1(n_), dim3(256), 0, st, n_, A_p_.p, A_i_.p, A_x_.p, y, alpha, z);
+}
+void CscOperators::add_GT_y(double alpha, const double* y, double* z, hipStream_t st) const
+{
+    if (m_ > 0) hipLaunchKernelGGL(k_spmv_cols<true>, g1(n_), dim3(256), 0, st, n_, G_p_.p, G_i_.p, G_x_.p, y, alpha, z);
+}
+
+}  // namespace pq

@@ -1,0 +1,65 @@
+// piqp_amd/csrc/sparse_ops.hpp -- device-resident CSC copies of the problem matrices and the mat-vec
+// products every sparse backend needs (reference sparse/kkt.hpp:179-203; the multistage backend's
+// block_symv_l / block_t_gemv_* of sparse/multistage_kkt.hpp:291-383,1355-1706 compute the same products).
+//
+// P is kept symmetrised, A and G in both orientations, so each product is a conflict-free column dot
+// (one thread per output entry, no atomics -> bitwise reproducible).  The original-order device value
+// arrays are exposed so the owning backend can remap them into its own storage without another H2D copy.
+#pragma once
+
+#include <vector>
+
+#include "common.hpp"
+
+namespace pq {
+
+template <class T>
+inline void upload_vec(DBuf<T>& d, const std::vector<T>& h, hipStream_t st)
+{
+    d.alloc(h.size() ? h.size() : 1);
+    if (!h.empty()) PQ_HIP(hipMemcpyAsync(d.p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, st));
+}
+
+class CscOperators {
+public:
+    // patterns (host CSC of P_utri n x n, AT n x p, GT n x m) + values; synchronises `st`
+    void init(const pq_sparse_data* d, hipStream_t st);
+    // values only, identical sparsity (solver.hpp:325,341,356); synchronises `st`
+    void upload_values(const pq_sparse_data* d, hipStream_t st);
+    void clone_from(const CscOperators& o, hipStream_t st);
+
+    void eval_P_x(double alpha, const double* x, double* z, hipStream_t st) const;
+    void eval_A_xn_and_AT_xt(double an, double at, const double* xn, const double* xt, double* zn, double* zt, hipStream_t st) const;
+    void eval_G_xn_and_GT_xt(double an, double at, const double* xn, const double* xt, double* zn, double* zt, hipStream_t st) const;
+    // z += alpha * AT * y  /  z += alpha * GT * y  (n-vectors; used by the condensed right-hand sides)
+    void add_AT_y(double alpha, const double* y, double* z, hipStream_t st) const;
+    void add_GT_y(double alpha, const double* y, double* z, hipStream_t st) const;
+
+    // out = rhs_x + GT * (zinv .* rhs_z) + delta_inv * AT * rhs_y   (condensed right-hand side, multistage_kkt.hpp:234-252)
+    void fold_rhs(const double* rhs_x, const double* rhs_y, const double* rhs_z, const double* zinv, double delta_inv, double* out, hipStream_t st) const;
+    // lhs_y = delta_inv * A x - delta_inv * rhs_y ;  lhs_z = (G x - rhs_z) .* zinv   (multistage_kkt.hpp:266-287)
+    void recover_duals(const double* x, const double* rhs_y, const double* rhs_z, const double* zinv, double delta_inv, double* lhs_y, double* lhs_z, hipStream_t st) const;
+
+    int n() const { return n_; }
+    int p() const { return p_; }
+    int m() const { return m_; }
+    int nzP() const { return nzP_; }
+    int nzA() const { return nzA_; }
+    int nzG() const { return nzG_; }
+    const double* P_x() const { return P_x_.p; }    // P_utri values, caller's CSC order
+    const double* AT_x() const { return AT_x_.p; }  // AT values, caller's CSC order
+    const double* GT_x() const { return GT_x_.p; }
+    const double* P_diag() const { return Pdiag_.p; }  // 0 where P has no structural diagonal (kkt_system.hpp:437-453)
+
+private:
+    int n_ = 0, p_ = 0, m_ = 0, nzP_ = 0, nzA_ = 0, nzG_ = 0, nzPf_ = 0;
+    DBuf<double> P_x_, Pf_x_, AT_x_, A_x_, GT_x_, G_x_, Pdiag_;
+    DBuf<int> Pf_p_, Pf_i_, Pf_src_, AT_p_, AT_i_, A_p_, A_i_, A_src_, GT_p_, GT_i_, G_p_, G_i_, G_src_;
+};
+
+// generic value movers shared by the sparse backends
+void launch_remap_values(int nnz, const int* dst_idx, const double* src, double* dst, hipStream_t st);          // dst[dst_idx[q]] = src[q]
+void launch_remap_values64(int nnz, const long long* dst_idx, const double* src, double* dst, hipStream_t st);  // 64-bit destinations
+void launch_gather_values(int nnz, const int* src_idx, const double* src, double* dst, hipStream_t st);         // dst[q] = src[src_idx[q]]
+
+}  // namespace pq

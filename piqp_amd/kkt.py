@@ -309,6 +309,13 @@ class DenseKKT(_Handle):
         check(self.L.pq_kkt_get_profile(self.h, stage, C.byref(ms), C.byref(cnt)))
         return ms.value, cnt.value
 
+    def block_info(self):
+        """sparse_multistage only: rows of (start, diag_size, off_diag_size); last row = arrow corner block."""
+        N = check(self.L.pq_kkt_multistage_block_info(self.h, None, 0), "block_info")
+        out = np.zeros((N, 3), dtype=np.int32)
+        check(self.L.pq_kkt_multistage_block_info(self.h, out.ctypes.data, N), "block_info")
+        return out
+
     def internal_kkt_mat(self):
         out = np.zeros((self.n, self.n), order="F")
         check(self.L.pq_kkt_internal_kkt_mat(self.h, out.ctypes.data))
