@@ -252,6 +252,34 @@ int pq_solver_dims(const pq_solver *s, int *n, int *p, int *m);
 int pq_solver_set_trace(pq_solver *s, double *buf_host, int max_rows);
 int pq_solver_trace_rows(const pq_solver *s);
 
+/* ===================== Batched solver: many structurally identical sparse QPs in one launch ===================== */
+/* The reference has no batch API (one SolverBase per QP, solver.hpp:42); this is the device-side equivalent of
+ *     for (i < batch) { SparseSolver s; s.settings() = settings; s.setup(P_i, c_i, A_i, ...); s.solve(); }
+ * with kkt_solver = sparse_multistage: one workgroup runs the whole interior-point method (solver.hpp:379-1259) of one
+ * QP, the batch is the grid.  All instances share the sparsity patterns and the set of finite bounds. */
+typedef struct pq_batch pq_batch;
+
+int pq_batch_create(pq_batch **out, int device);
+void pq_batch_destroy(pq_batch *s);
+pq_settings *pq_batch_settings(pq_batch *s); /* solver.hpp:65 settings(), shared by all instances */
+/* SparseSolver::setup (solver.hpp:1297-1308) per instance.  Patterns (CSC, HOST): P n x n (upper triangle taken),
+ * A p x n, G m x n; NULL pattern = absent.  Values / vectors are [batch][nnz] resp. [batch][len] row-major HOST
+ * arrays; NULL h_l/h_u/x_l/x_u = nullopt.  Returns 1 when set up. */
+int pq_batch_setup_sparse(pq_batch *s, int batch, int n, int p, int m, const int *Pp, const int *Pi, const double *Px,
+                          const double *c, const int *Ap, const int *Ai, const double *Ax, const double *b,
+                          const int *Gp, const int *Gi, const double *Gx, const double *h_l, const double *h_u,
+                          const double *x_l, const double *x_u);
+/* solve() of every instance (solver.hpp:69-148); returns the number of instances that ended PQ_SOLVED (>= 0) */
+int pq_batch_solve(pq_batch *s);
+const pq_info *pq_batch_info(const pq_batch *s, int instance); /* result().info of one instance */
+/* result(): field k of Variables (0..9 = x, y, z_l, z_u, z_bl, z_bu, s_l, s_u, s_bl, s_bu) of ALL instances,
+ * copied to a HOST array [batch][len] (len = n, p or m) */
+int pq_batch_get_result(pq_batch *s, int field, double *out_host);
+int pq_batch_dims(const pq_batch *s, int *batch, int *n, int *p, int *m);
+int pq_batch_block_info(const pq_batch *s, int *out_host, int capacity); /* as pq_kkt_multistage_block_info */
+/* hipEvent time of the last solve's kernel and the workgroup size used per QP */
+int pq_batch_last_kernel_ms(const pq_batch *s, double *ms, int *threads_per_qp);
+
 /* ===================== small utilities used by the measurement harness ===================== */
 /* fp64 MFMA / HBM micro-benchmarks on `device` (used once by bench.py to report measured peaks) */
 int pq_microbench_mfma_f64(int device, int iters, double *tflops_out);

@@ -10,3 +10,4 @@ SparseKKT = DenseKKT  # same handle type: pq_kkt_* dispatches on the backend (KK
 SPARSE_LDLT = 1
 SPARSE_MULTISTAGE = 5
 MultistageKKT = DenseKKT
+from .batch import BatchSparseSolver  # noqa: E402,F401

@@ -1,0 +1,1319 @@
+// piqp_amd/csrc/batch_solver.hip -- batched interior-point solves of structurally identical sparse QPs with the
+// sparse_multistage KKT backend: ONE workgroup runs the WHOLE proximal interior-point method of ONE QP
+// (reference solver.hpp:379-1259 solve_impl + kkt_system.hpp + sparse/multistage_kkt.hpp) inside a single kernel
+// launch; the batch dimension is the grid.  Independent QPs share nothing, so there is no lock-step, no host
+// round trip per iteration and no collective: a QP that converges early simply retires its workgroup.
+//
+// The reference has no batch API (one SolverBase per QP, solver.hpp:42); `pq_batch_*` is the device-side
+// equivalent of looping `SparseSolver::setup(...); solve();` over the instances.  Per instance the arithmetic
+// follows the single-QP path operation by operation:
+//   setup (host): sparse::Data + RuizEquilibration::scale_data exactly as Solver::setup (solver.hpp:151-216)
+//   device:       solve_impl: initial factor/solve, shift to the interior, predictor-corrector loop with the
+//                 proximal updates of rho/delta, KKTSystem scalings / condensed right-hand sides / iterative refinement /
+//                 dual recovery, multistage chain Cholesky (msdev::factor_chain) and block substitution
+//                 (msdev::solve_chain), residuals and termination tests; unscale + restore_dual at the end.
+// All instances must share the sparsity patterns AND the set of finite bounds (checked at setup).
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <memory>
+#include <stdexcept>
+#include <thread>
+
+#include "multistage_device.hpp"
+#include "multistage_symbolic.hpp"
+#include "solver.hpp"
+#include "sparse_ops.hpp"
+
+namespace pq {
+
+namespace {
+
+using msdev::GroupMeta;
+using msdev::MsMeta;
+
+constexpr int LDS_LIMIT_BYTES = 159 * 1024;
+
+// fields of a Variables set (variables.hpp:19-105)
+enum { FX = 0, FY, FZL, FZU, FZBL, FZBU, FSL, FSU, FSBL, FSBU, NF };
+// per-instance arena slots
+enum {
+    D_PX = 0, D_ATX, D_GTX, D_C, D_B, D_HL, D_HU, D_XL, D_XU, D_XBS, D_DL, D_DLI, D_DB, D_DBI,
+    V_R, V_NR = V_R + NF, V_RS = V_NR + NF, V_ST = V_RS + NF, V_PX = V_ST + NF,
+    K_SL = V_PX + NF, K_SU, K_SBL, K_SBU, K_ZLI, K_ZUI, K_ZBLI, K_ZBUI, K_XREG, K_ZREG, K_ZREGR, K_RXB, K_RZB, K_WX, K_LZ, K_EX, K_EY, K_EZ, K_RLX, K_RLY, K_RLZ,
+    B_ZINV, B_PF, B_ATAF, B_F, B_PAN, B_XA, B_XG,
+    NSLOT
+};
+
+struct BatchShared {
+    int n, p, m, n_h_l, n_h_u, n_x_l, n_x_u;
+    const int *h_l_idx, *h_u_idx, *x_l_idx, *x_u_idx, *has_l, *has_u, *pos_l, *pos_u;
+    const int *Pf_p, *Pf_i, *Pf_src, *AT_p, *AT_i, *A_p, *A_i, *A_src, *GT_p, *GT_i, *G_p, *G_i, *G_src;
+    int nzP, nzA, nzG;
+    MsMeta M;
+    GroupMeta GA, GG;
+    const long long *P_dst, *A_dst, *G_dst;
+    int fcap, lofs, hcap, chain_lds_doubles;
+    long long off[NSLOT];
+    long long stride;
+    pq_settings set;
+};
+
+// ---- workgroup collectives ------------------------------------------------------------------------------------
+struct OpSum { __device__ double operator()(double a, double b) const { return a + b; } };
+struct OpMax { __device__ double operator()(double a, double b) const { return a < b ? b : a; } };            // std::max
+struct OpMin { __device__ double operator()(double a, double b) const { return b < a ? b : a; } };            // std::min
+struct OpAbsMaxNan { __device__ double operator()(double r, double a) const { return (a > r || a != a) ? a : r; } };  // Eigen lpNorm<Infinity>: NaN propagates
+
+template <int NT, class Op>
+__device__ __forceinline__ double wg_reduce(double v, Op op, double* red)
+{
+    for (int o = 32; o > 0; o >>= 1) v = op(v, __shfl_xor(v, o));
+    if constexpr (NT > 64) {
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+        __syncthreads();
+        v = red[0];
+        for (int i = 1; i < NT / 64; ++i) v = op(v, red[i]);
+    }
+    return v;
+}
+
+template <int NT, bool LDS>
+struct Ipm {
+    const BatchShared& S;
+    double* base;
+    double* sm;   // chain workspace (dynamic LDS)
+    double* red;  // reduction scratch
+    double rz_c, rz_c_inv;
+    pq_info info;
+    bool refine_enabled = false;
+    // KKTSystem state
+    double ks_rho = 0.0, ks_delta = 0.0, be_delta = 1.0;
+    bool ks_use_refine = false;
+
+    __device__ Ipm(const BatchShared& s, double* b, double* sm_, double* red_) : S(s), base(b), sm(sm_), red(red_) {}
+
+    __device__ __forceinline__ double* at(int slot) const { return base + S.off[slot]; }
+    __device__ __forceinline__ double* v(int set, int f) const { return base + S.off[set + f]; }
+    __device__ __forceinline__ int tid() const { return threadIdx.x; }
+
+    template <class Op>
+    __device__ __forceinline__ double reduce(double x, Op op) const { return wg_reduce<NT>(x, op, red); }
+
+    // ---- mat-vecs (sparse/kkt.hpp:179-203 / multistage_kkt.hpp:291-383), ending with a barrier --------------------
+    __device__ void eval_P_x(double alpha, const double* x, double* z) const
+    {
+        const double* Px = at(D_PX);
+        for (int j = tid(); j < S.n; j += NT) {
+            double s = 0.0;
+            for (int q = S.Pf_p[j]; q < S.Pf_p[j + 1]; ++q) s += Px[S.Pf_src[q]] * x[S.Pf_i[q]];
+            z[j] = alpha * s;
+        }
+        __syncthreads();
+    }
+    __device__ void eval_A(double an, double at_, const double* xn, const double* xt, double* zn, double* zt) const
+    {
+        const double* Ax = at(D_ATX);
+        for (int k = tid(); k < S.p; k += NT) {
+            double s = 0.0;
+            for (int q = S.AT_p[k]; q < S.AT_p[k + 1]; ++q) s += Ax[q] * xn[S.AT_i[q]];
+            zn[k] = an * s;
+        }
+        for (int j = tid(); j < S.n; j += NT) {
+            double s = 0.0;
+            for (int q = S.A_p[j]; q < S.A_p[j + 1]; ++q) s += Ax[S.A_src[q]] * xt[S.A_i[q]];
+            zt[j] = at_ * s;
+        }
+        __syncthreads();
+    }
+    __device__ void eval_G(double an, double at_, const double* xn, const double* xt, double* zn, double* zt) const
+    {
+        const double* Gx = at(D_GTX);
+        for (int k = tid(); k < S.m; k += NT) {
+            double s = 0.0;
+            for (int q = S.GT_p[k]; q < S.GT_p[k + 1]; ++q) s += Gx[q] * xn[S.GT_i[q]];
+            zn[k] = an * s;
+        }
+        for (int j = tid(); j < S.n; j += NT) {
+            double s = 0.0;
+            for (int q = S.G_p[j]; q < S.G_p[j + 1]; ++q) s += Gx[S.G_src[q]] * xt[S.G_i[q]];
+            zt[j] = at_ * s;
+        }
+        __syncthreads();
+    }
+
+    // ---- multistage backend (multistage_kkt.hpp:180-288) -----------------------------------------------------
+    __device__ void be_factor(double delta, const double* x_reg, const double* z_reg)
+    {
+        double* zinv = at(B_ZINV);
+        for (int i = tid(); i < S.m; i += NT) zinv[i] = 1.0 / z_reg[i];
+        __syncthreads();
+        be_delta = delta;
+        const double delta_inv = 1.0 / delta;
+        for (int b = 0; b < S.M.N; ++b) {
+            const int h = S.M.h[b];
+            msdev::assemble_stage<NT>(S.M, S.GG, at(B_XG), at(B_PF), at(B_ATAF), zinv, x_reg, delta_inv, at(B_F), b, 0, h * h);
+        }
+        __syncthreads();
+        msdev::factor_chain<NT, LDS>(S.M, at(B_F), at(B_PAN), sm, S.fcap, S.lofs, 1);
+        __syncthreads();
+        info.n_factor++;
+    }
+    __device__ void be_solve(const double* rhs_x, const double* rhs_y, const double* rhs_z, double* lhs_x, double* lhs_y, double* lhs_z)
+    {
+        const double* zinv = at(B_ZINV);
+        const double* Ax = at(D_ATX);
+        const double* Gx = at(D_GTX);
+        const double delta_inv = 1.0 / be_delta;
+        for (int j = tid(); j < S.n; j += NT) {
+            double sg = 0.0, sa = 0.0;
+            for (int q = S.G_p[j]; q < S.G_p[j + 1]; ++q) { const int i = S.G_i[q]; sg += Gx[S.G_src[q]] * (zinv[i] * rhs_z[i]); }
+            for (int q = S.A_p[j]; q < S.A_p[j + 1]; ++q) sa += Ax[S.A_src[q]] * rhs_y[S.A_i[q]];
+            lhs_x[j] = (rhs_x[j] + sg) + delta_inv * sa;
+        }
+        __syncthreads();
+        msdev::solve_chain<NT, LDS>(S.M, at(B_PAN), lhs_x, sm, S.hcap);
+        for (int k = tid(); k < S.p; k += NT) {
+            double s = 0.0;
+            for (int q = S.AT_p[k]; q < S.AT_p[k + 1]; ++q) s += Ax[q] * lhs_x[S.AT_i[q]];
+            lhs_y[k] = delta_inv * s - delta_inv * rhs_y[k];
+        }
+        for (int i = tid(); i < S.m; i += NT) {
+            double s = 0.0;
+            for (int q = S.GT_p[i]; q < S.GT_p[i + 1]; ++q) s += Gx[q] * lhs_x[S.GT_i[q]];
+            lhs_z[i] = (s - rhs_z[i]) * zinv[i];
+        }
+        __syncthreads();
+        info.n_backend_solve++;
+    }
+
+    // ---- KKTSystem (kkt_system.hpp) -----------------------------------------------------------------------------
+    // :143-211
+    __device__ bool ks_update_scalings_and_factor(bool iterative_refinement, double rho, double delta)
+    {
+        const int n = S.n, m = S.m;
+        ks_rho = rho; ks_delta = delta;
+        const double* xbs = at(D_XBS);
+        double *s_l = at(K_SL), *s_u = at(K_SU), *s_bl = at(K_SBL), *s_bu = at(K_SBU);
+        double *zli = at(K_ZLI), *zui = at(K_ZUI), *zbli = at(K_ZBLI), *zbui = at(K_ZBUI);
+        double *x_reg = at(K_XREG), *z_reg = at(K_ZREG), *z_reg_ref = at(K_ZREGR);
+        for (int i = tid(); i < m; i += NT) {
+            s_l[i] = v(V_R, FSL)[i]; s_u[i] = v(V_R, FSU)[i];
+            zli[i] = 1.0 / v(V_R, FZL)[i]; zui[i] = 1.0 / v(V_R, FZU)[i];
+        }
+        for (int i = tid(); i < S.n_x_l; i += NT) { s_bl[i] = v(V_R, FSBL)[i]; zbli[i] = 1.0 / v(V_R, FZBL)[i]; }
+        for (int i = tid(); i < S.n_x_u; i += NT) { s_bu[i] = v(V_R, FSBU)[i]; zbui[i] = 1.0 / v(V_R, FZBU)[i]; }
+        __syncthreads();
+        for (int j = tid(); j < n; j += NT) {
+            double xr = rho;
+            const int il = S.pos_l[j], iu = S.pos_u[j];
+            if (il >= 0) xr += xbs[j] * xbs[j] / (zbli[il] * s_bl[il] + delta);
+            if (iu >= 0) xr += xbs[j] * xbs[j] / (zbui[iu] * s_bu[iu] + delta);
+            x_reg[j] = xr;
+        }
+        for (int i = tid(); i < m; i += NT) {
+            double zr = 0.0;
+            if (S.has_l[i]) zr += 1.0 / (zli[i] * s_l[i] + delta);
+            if (S.has_u[i]) zr += 1.0 / (zui[i] * s_u[i] + delta);
+            zr = 1.0 / zr;
+            z_reg[i] = zr; z_reg_ref[i] = zr;
+        }
+        __syncthreads();
+        double delta_reg = delta;
+        if (iterative_refinement) {
+            const double* Pd = at(D_PX);  // diag(P) gathered below through the symmetrised pattern
+            double mx = 0.0;
+            for (int j = tid(); j < n; j += NT) {
+                double pd = 0.0;
+                for (int q = S.Pf_p[j]; q < S.Pf_p[j + 1]; ++q) if (S.Pf_i[q] == j) pd = Pd[S.Pf_src[q]];
+                const double a = fabs(pd + x_reg[j]);
+                if (a > mx) mx = a;
+            }
+            double zm = 0.0;
+            for (int i = tid(); i < m; i += NT) { const double a = fabs(z_reg_ref[i]); if (a > zm || a != a) zm = a; }
+            double max_diag = reduce(mx, OpMax());
+            const double zmax = reduce(zm, OpAbsMaxNan());
+            if (zmax > max_diag) max_diag = zmax;
+            const double reg = S.set.iterative_refinement_static_regularization_eps + S.set.iterative_refinement_static_regularization_rel * max_diag;
+            delta_reg += reg;
+            __syncthreads();
+            for (int j = tid(); j < n; j += NT) x_reg[j] += reg;
+            for (int i = tid(); i < m; i += NT) z_reg_ref[i] += reg;
+            __syncthreads();
+        }
+        ks_use_refine = iterative_refinement;
+        be_factor(delta_reg, x_reg, z_reg_ref);
+        return true;  // multistage_kkt.hpp:218
+    }
+
+    // :507-536 err = rhs - K_cond * lhs, returns |err|_inf (NaN-propagating)
+    __device__ double refine_error(const double* lx, const double* ly, const double* lz, const double* rx, const double* ry, const double* rz, double* ex, double* ey,
+                                   double* ez)
+    {
+        const int n = S.n, p = S.p, m = S.m;
+        const double* Px = at(D_PX);
+        const double* Ax = at(D_ATX);
+        const double* Gx = at(D_GTX);
+        const double* x_reg = at(K_XREG);
+        const double* z_reg = at(K_ZREG);
+        double mx = 0.0;
+        for (int j = tid(); j < n; j += NT) {
+            double sp = 0.0, sa = 0.0, sg = 0.0;
+            for (int q = S.Pf_p[j]; q < S.Pf_p[j + 1]; ++q) sp += Px[S.Pf_src[q]] * lx[S.Pf_i[q]];
+            for (int q = S.A_p[j]; q < S.A_p[j + 1]; ++q) sa += Ax[S.A_src[q]] * ly[S.A_i[q]];
+            for (int q = S.G_p[j]; q < S.G_p[j + 1]; ++q) sg += Gx[S.G_src[q]] * lz[S.G_i[q]];
+            const double e = rx[j] - (((sp + x_reg[j] * lx[j]) + sa) + sg);
+            ex[j] = e;
+            const double a = fabs(e);
+            if (a > mx || a != a) mx = a;
+        }
+        for (int k = tid(); k < p; k += NT) {
+            double s = 0.0;
+            for (int q = S.AT_p[k]; q < S.AT_p[k + 1]; ++q) s += Ax[q] * lx[S.AT_i[q]];
+            const double e = ry[k] - (s - ks_delta * ly[k]);
+            ey[k] = e;
+            const double a = fabs(e);
+            if (a > mx || a != a) mx = a;
+        }
+        for (int i = tid(); i < m; i += NT) {
+            double s = 0.0;
+            for (int q = S.GT_p[i]; q < S.GT_p[i + 1]; ++q) s += Gx[q] * lx[S.GT_i[q]];
+            const double e = rz[i] - (s - z_reg[i] * lz[i]);
+            ez[i] = e;
+            const double a = fabs(e);
+            if (a > mx || a != a) mx = a;
+        }
+        const double r = reduce(mx, OpAbsMaxNan());
+        __syncthreads();
+        return r;
+    }
+
+    __device__ double inf_norm3(const double* a, int na, const double* b, int nb, const double* c, int nc)
+    {
+        double mx = 0.0;
+        for (int i = tid(); i < na; i += NT) { const double t = fabs(a[i]); if (t > mx || t != t) mx = t; }
+        for (int i = tid(); i < nb; i += NT) { const double t = fabs(b[i]); if (t > mx || t != t) mx = t; }
+        for (int i = tid(); i < nc; i += NT) { const double t = fabs(c[i]); if (t > mx || t != t) mx = t; }
+        return reduce(mx, OpAbsMaxNan());
+    }
+
+    // :213-369  (rhs, lhs = Variables sets)
+    __device__ bool ks_solve(int rhs, int lhs)
+    {
+        const int n = S.n, p = S.p, m = S.m;
+        const double* xbs = at(D_XBS);
+        const double *s_l = at(K_SL), *s_u = at(K_SU), *s_bl = at(K_SBL), *s_bu = at(K_SBU);
+        const double *zli = at(K_ZLI), *zui = at(K_ZUI), *zbli = at(K_ZBLI), *zbui = at(K_ZBUI);
+        const double* z_reg = at(K_ZREG);
+        double *rxb = at(K_RXB), *rzb = at(K_RZB), *lz = at(K_LZ);
+        const double delta = ks_delta;
+        for (int i = tid(); i < m; i += NT) {
+            double r = 0.0;
+            if (S.has_l[i]) r -= 1.0 / (zli[i] * s_l[i] + delta) * (v(rhs, FZL)[i] - zli[i] * v(rhs, FSL)[i]);
+            if (S.has_u[i]) r += 1.0 / (zui[i] * s_u[i] + delta) * (v(rhs, FZU)[i] - zui[i] * v(rhs, FSU)[i]);
+            rzb[i] = r * z_reg[i];
+        }
+        for (int j = tid(); j < n; j += NT) {
+            double r = v(rhs, FX)[j];
+            const int il = S.pos_l[j], iu = S.pos_u[j];
+            if (il >= 0) r -= xbs[j] * (v(rhs, FZBL)[il] - zbli[il] * v(rhs, FSBL)[il]) / (s_bl[il] * zbli[il] + delta);
+            if (iu >= 0) r += xbs[j] * (v(rhs, FZBU)[iu] - zbui[iu] * v(rhs, FSBU)[iu]) / (s_bu[iu] * zbui[iu] + delta);
+            rxb[j] = r;
+        }
+        __syncthreads();
+        double *lx = v(lhs, FX), *ly = v(lhs, FY);
+        const double* ry = v(rhs, FY);
+        be_solve(rxb, ry, rzb, lx, ly, lz);
+
+        if (ks_use_refine) {
+            double *ex = at(K_EX), *ey = at(K_EY), *ez = at(K_EZ), *rlx = at(K_RLX), *rly = at(K_RLY), *rlz = at(K_RLZ);
+            const double rhs_norm = inf_norm3(rxb, n, ry, p, rzb, m);
+            double err = refine_error(lx, ly, lz, rxb, ry, rzb, ex, ey, ez);
+            if (!isfinite(err)) return false;
+            for (int it = 0; it < S.set.iterative_refinement_max_iter; ++it) {
+                if (err <= S.set.iterative_refinement_eps_abs + S.set.iterative_refinement_eps_rel * rhs_norm) break;
+                const double prev = err;
+                be_solve(ex, ey, ez, rlx, rly, rlz);
+                for (int j = tid(); j < n; j += NT) rlx[j] += lx[j];
+                for (int k = tid(); k < p; k += NT) rly[k] += ly[k];
+                for (int i = tid(); i < m; i += NT) rlz[i] += lz[i];
+                __syncthreads();
+                err = refine_error(rlx, rly, rlz, rxb, ry, rzb, ex, ey, ez);
+                if (!isfinite(err)) return false;
+                const double rate = prev / err;
+                const bool stop = rate < S.set.iterative_refinement_min_improvement_rate;
+                if (!stop || rate > 1.0) {  // the reference swaps the buffers (:292-300); the refined iterate becomes lhs
+                    for (int j = tid(); j < n; j += NT) lx[j] = rlx[j];
+                    for (int k = tid(); k < p; k += NT) ly[k] = rly[k];
+                    for (int i = tid(); i < m; i += NT) lz[i] = rlz[i];
+                    __syncthreads();
+                }
+                if (stop) break;
+            }
+        } else {
+            double bad = 0.0;
+            for (int j = tid(); j < n; j += NT) if (!isfinite(lx[j])) bad = 1.0;
+            for (int k = tid(); k < p; k += NT) if (!isfinite(ly[k])) bad = 1.0;
+            for (int i = tid(); i < m; i += NT) if (!isfinite(lz[i])) bad = 1.0;
+            if (reduce(bad, OpMax()) > 0.0) return false;
+        }
+
+        // :310-345 dual recovery
+        for (int i = tid(); i < m; i += NT) {
+            const bool hl = S.has_l[i] != 0, hu = S.has_u[i] != 0;
+            double zl = 0.0, zu = 0.0, sl = 0.0, su = 0.0;
+            if (hl && hu) {
+                const double rz_l_bar = v(rhs, FZL)[i] - zli[i] * v(rhs, FSL)[i];
+                const double W_l_inv = 1.0 / (zli[i] * s_l[i] + delta);
+                const double rz_u_bar = v(rhs, FZU)[i] - zui[i] * v(rhs, FSU)[i];
+                const double W_u_inv = 1.0 / (zui[i] * s_u[i] + delta);
+                const double r_sum = W_l_inv * W_u_inv * (rz_l_bar + rz_u_bar);
+                zl = -z_reg[i] * (r_sum + W_l_inv * lz[i]);
+                zu = -z_reg[i] * (r_sum - W_u_inv * lz[i]);
+                sl = zli[i] * (v(rhs, FSL)[i] - s_l[i] * zl);
+                su = zui[i] * (v(rhs, FSU)[i] - s_u[i] * zu);
+            } else if (hl) {
+                zl = -lz[i];
+                sl = zli[i] * (v(rhs, FSL)[i] - s_l[i] * zl);
+            } else if (hu) {
+                zu = lz[i];
+                su = zui[i] * (v(rhs, FSU)[i] - s_u[i] * zu);
+            }
+            v(lhs, FZL)[i] = zl; v(lhs, FZU)[i] = zu; v(lhs, FSL)[i] = sl; v(lhs, FSU)[i] = su;
+        }
+        // :347-366 box dual recovery
+        for (int i = tid(); i < S.n_x_l; i += NT) {
+            const int idx = S.x_l_idx[i];
+            const double z = (-xbs[idx] * lx[idx] - v(rhs, FZBL)[i] + zbli[i] * v(rhs, FSBL)[i]) / (s_bl[i] * zbli[i] + delta);
+            v(lhs, FZBL)[i] = z;
+            v(lhs, FSBL)[i] = zbli[i] * (v(rhs, FSBL)[i] - s_bl[i] * z);
+        }
+        for (int i = tid(); i < S.n_x_u; i += NT) {
+            const int idx = S.x_u_idx[i];
+            const double z = (xbs[idx] * lx[idx] - v(rhs, FZBU)[i] + zbui[i] * v(rhs, FSBU)[i]) / (s_bu[i] * zbui[i] + delta);
+            v(lhs, FZBU)[i] = z;
+            v(lhs, FSBU)[i] = zbui[i] * (v(rhs, FSBU)[i] - s_bu[i] * z);
+        }
+        __syncthreads();
+        info.n_solve++;
+        return true;
+    }
+
+    // ---- solver.hpp helpers --------------------------------------------------------------------------------------
+    __device__ double dot2(const double* a, const double* b, int cnt)
+    {
+        double s = 0.0;
+        for (int i = tid(); i < cnt; i += NT) s += a[i] * b[i];
+        return reduce(s, OpSum());
+    }
+    // :884-891
+    __device__ double calculate_mu()
+    {
+        const double s = dot2(v(V_R, FSL), v(V_R, FZL), S.m) + dot2(v(V_R, FSU), v(V_R, FZU), S.m) + dot2(v(V_R, FSBL), v(V_R, FZBL), S.n_x_l) +
+                         dot2(v(V_R, FSBU), v(V_R, FZBU), S.n_x_u);
+        return s / (double)(S.n_h_l + S.n_h_u + S.n_x_l + S.n_x_u);
+    }
+    // :893-958
+    __device__ void calculate_step(double& alpha_s, double& alpha_z)
+    {
+        double as = 1.0, az = 1.0;
+        auto upd = [](double& a, double r, double st) { if (st < 0) { const double c = -r / st; if (c < a) a = c; } };
+        for (int i = tid(); i < S.m; i += NT) {
+            upd(as, v(V_R, FSL)[i], v(V_ST, FSL)[i]); upd(as, v(V_R, FSU)[i], v(V_ST, FSU)[i]);
+            upd(az, v(V_R, FZL)[i], v(V_ST, FZL)[i]); upd(az, v(V_R, FZU)[i], v(V_ST, FZU)[i]);
+        }
+        for (int i = tid(); i < S.n_x_l; i += NT) { upd(as, v(V_R, FSBL)[i], v(V_ST, FSBL)[i]); upd(az, v(V_R, FZBL)[i], v(V_ST, FZBL)[i]); }
+        for (int i = tid(); i < S.n_x_u; i += NT) { upd(as, v(V_R, FSBU)[i], v(V_ST, FSBU)[i]); upd(az, v(V_R, FZBU)[i], v(V_ST, FZBU)[i]); }
+        alpha_s = reduce(as, OpMin());
+        alpha_z = reduce(az, OpMin());
+    }
+    __device__ double min_coeff(const double* a, int cnt)
+    {
+        double mn = DBL_MAX;
+        for (int i = tid(); i < cnt; i += NT) if (a[i] < mn) mn = a[i];
+        return reduce(mn, OpMin());
+    }
+    __device__ double inf_scaled(const double* a, const double* sc, double c, int cnt)
+    {
+        double mx = 0.0;
+        for (int i = tid(); i < cnt; i += NT) { const double t = fabs(a[i] * c * sc[i]); if (t > mx || t != t) mx = t; }
+        return reduce(mx, OpAbsMaxNan());
+    }
+    // :1130-1164
+    __device__ double primal_res_of(int set)
+    {
+        const int n = S.n, p = S.p, m = S.m;
+        const double* dinv = at(D_DLI);
+        const double* dbi = at(D_DBI);
+        double inf = inf_scaled(v(set, FY), dinv + n, 1.0, p);
+        inf = fmax_std(inf, inf_scaled(v(set, FZL), dinv + n + p, 1.0, m));
+        inf = fmax_std(inf, inf_scaled(v(set, FZU), dinv + n + p, 1.0, m));
+        double mx = inf;
+        for (int i = tid(); i < S.n_x_l; i += NT) { const double t = v(set, FZBL)[i] * dbi[S.x_l_idx[i]]; if (mx < t) mx = t; }
+        for (int i = tid(); i < S.n_x_u; i += NT) { const double t = v(set, FZBU)[i] * dbi[S.x_u_idx[i]]; if (mx < t) mx = t; }
+        return reduce(mx, OpMax());
+    }
+    static __device__ __forceinline__ double fmax_std(double a, double b) { return a < b ? b : a; }
+    // :1184-1196
+    __device__ double dual_res_of(const double* x) { return inf_scaled(x, at(D_DLI), rz_c_inv, S.n); }
+    // :1166-1182
+    __device__ double primal_prox_inf()
+    {
+        const int n = S.n, p = S.p, m = S.m;
+        const double* dl = at(D_DL);
+        const double* db = at(D_DB);
+        const double ci = rz_c_inv;
+        double mx = 0.0;
+        for (int i = tid(); i < p; i += NT) { const double t = fabs((v(V_PX, FY)[i] - v(V_R, FY)[i]) * ci * dl[n + i]); if (mx < t) mx = t; }
+        for (int i = tid(); i < m; i += NT) {
+            double t = fabs((v(V_PX, FZL)[i] - v(V_R, FZL)[i]) * ci * dl[n + p + i]); if (mx < t) mx = t;
+            t = fabs((v(V_PX, FZU)[i] - v(V_R, FZU)[i]) * ci * dl[n + p + i]); if (mx < t) mx = t;
+        }
+        for (int i = tid(); i < S.n_x_l; i += NT) { const double t = (v(V_PX, FZBL)[i] - v(V_R, FZBL)[i]) * ci * db[S.x_l_idx[i]]; if (mx < t) mx = t; }
+        for (int i = tid(); i < S.n_x_u; i += NT) { const double t = (v(V_PX, FZBU)[i] - v(V_R, FZBU)[i]) * ci * db[S.x_u_idx[i]]; if (mx < t) mx = t; }
+        return reduce(mx, OpMax());
+    }
+    // :1198-1203
+    __device__ double dual_prox_inf()
+    {
+        const double* dl = at(D_DL);
+        double mx = 0.0;
+        for (int i = tid(); i < S.n; i += NT) { const double t = fabs((v(V_R, FX)[i] - v(V_PX, FX)[i]) * dl[i]); if (mx < t) mx = t; }
+        return reduce(mx, OpMax());
+    }
+
+    // :960-1105
+    __device__ void update_residuals_nr()
+    {
+        const int n = S.n, p = S.p, m = S.m;
+        const double ci = rz_c_inv;
+        const double* dinv = at(D_DLI);
+        const double* dbi = at(D_DBI);
+        const double* xbs = at(D_XBS);
+        double* work_x = v(V_ST, FX);
+        double* work_z = v(V_ST, FZL);
+        double* nrx = v(V_NR, FX);
+        const double *rx = v(V_R, FX), *c = at(D_C), *bb = at(D_B), *hl = at(D_HL), *hu = at(D_HU), *xl = at(D_XL), *xu = at(D_XU);
+
+        eval_A(-1.0, 1.0, rx, v(V_R, FY), v(V_NR, FY), work_x);
+        for (int i = tid(); i < m; i += NT) work_z[i] = v(V_R, FZU)[i] - v(V_R, FZL)[i];
+        __syncthreads();
+        double* work_x_2 = nrx;
+        eval_G(1.0, 1.0, rx, work_z, v(V_NR, FZL), work_x_2);
+        for (int i = tid(); i < m; i += NT) v(V_NR, FZU)[i] = -v(V_NR, FZL)[i];
+        for (int j = tid(); j < n; j += NT) work_x[j] += work_x_2[j];
+        __syncthreads();
+
+        eval_P_x(-1.0, rx, nrx);
+        double dual_rel_norm = inf_scaled(nrx, dinv, ci, n);
+
+        double tmp = -dot2(rx, nrx, n);
+        info.primal_obj = 0.5 * tmp;
+        info.dual_obj = -0.5 * tmp;
+        double dg_rel = ci * fabs(tmp);
+        tmp = dot2(c, rx, n); info.primal_obj += tmp; dg_rel = fmax_std(dg_rel, ci * fabs(tmp));
+        tmp = dot2(bb, v(V_R, FY), p); info.dual_obj -= tmp; dg_rel = fmax_std(dg_rel, ci * fabs(tmp));
+        tmp = -dot2(hl, v(V_R, FZL), m); info.dual_obj -= tmp; dg_rel = fmax_std(dg_rel, ci * fabs(tmp));
+        tmp = dot2(hu, v(V_R, FZU), m); info.dual_obj -= tmp; dg_rel = fmax_std(dg_rel, ci * fabs(tmp));
+        tmp = -dot2(xl, v(V_R, FZBL), S.n_x_l); info.dual_obj -= tmp; dg_rel = fmax_std(dg_rel, ci * fabs(tmp));
+        tmp = dot2(xu, v(V_R, FZBU), S.n_x_u); info.dual_obj -= tmp; dg_rel = fmax_std(dg_rel, ci * fabs(tmp));
+
+        info.duality_gap = fabs(info.primal_obj - info.dual_obj);
+        info.primal_obj *= ci; info.dual_obj *= ci; info.duality_gap *= ci;
+        info.duality_gap_rel = info.duality_gap / fmax_std(1.0, dg_rel);
+
+        __syncthreads();
+        for (int j = tid(); j < n; j += NT) {
+            nrx[j] -= c[j];
+            double wx = work_x[j];
+            const int il = S.pos_l[j], iu = S.pos_u[j];
+            if (il >= 0) wx -= xbs[j] * v(V_R, FZBL)[il];
+            if (iu >= 0) wx += xbs[j] * v(V_R, FZBU)[iu];
+            work_x[j] = wx;
+        }
+        __syncthreads();
+        dual_rel_norm = fmax_std(dual_rel_norm, inf_scaled(c, dinv, ci, n));
+        dual_rel_norm = fmax_std(dual_rel_norm, inf_scaled(work_x, dinv, ci, n));
+        for (int j = tid(); j < n; j += NT) nrx[j] -= work_x[j];
+
+        double primal_rel_norm = inf_scaled(v(V_NR, FY), dinv + n, 1.0, p);
+        __syncthreads();
+        for (int i = tid(); i < p; i += NT) v(V_NR, FY)[i] += bb[i];
+        primal_rel_norm = fmax_std(primal_rel_norm, inf_scaled(bb, dinv + n, 1.0, p));
+
+        const double* dz = dinv + n + p;
+        double mx = primal_rel_norm;
+        for (int i = tid(); i < m; i += NT) {
+            if (S.has_l[i]) {
+                double* z = v(V_NR, FZL);
+                mx = fmax_std(mx, z[i] * dz[i]);  // signed, like the reference (:1047)
+                z[i] += -hl[i] - v(V_R, FSL)[i];
+                mx = fmax_std(mx, hl[i] * dz[i]);
+                mx = fmax_std(mx, v(V_R, FSL)[i] * dz[i]);
+            } else {
+                v(V_NR, FZL)[i] = 0.0;
+            }
+            if (S.has_u[i]) {
+                double* z = v(V_NR, FZU);
+                mx = fmax_std(mx, z[i] * dz[i]);
+                z[i] += hu[i] - v(V_R, FSU)[i];
+                mx = fmax_std(mx, hu[i] * dz[i]);
+                mx = fmax_std(mx, v(V_R, FSU)[i] * dz[i]);
+            } else {
+                v(V_NR, FZU)[i] = 0.0;
+            }
+        }
+        for (int i = tid(); i < S.n_x_l; i += NT) {
+            const int idx = S.x_l_idx[i];
+            const double t = xbs[idx] * rx[idx];
+            mx = fmax_std(mx, t * dbi[idx]);
+            mx = fmax_std(mx, xl[i] * dbi[idx]);
+            mx = fmax_std(mx, v(V_R, FSBL)[i] * dbi[idx]);
+            v(V_NR, FZBL)[i] = t + (-xl[i] - v(V_R, FSBL)[i]);
+        }
+        for (int i = tid(); i < S.n_x_u; i += NT) {
+            const int idx = S.x_u_idx[i];
+            const double t = -xbs[idx] * rx[idx];
+            mx = fmax_std(mx, t * dbi[idx]);
+            mx = fmax_std(mx, xu[i] * dbi[idx]);
+            mx = fmax_std(mx, v(V_R, FSBU)[i] * dbi[idx]);
+            v(V_NR, FZBU)[i] = t + (xu[i] - v(V_R, FSBU)[i]);
+        }
+        primal_rel_norm = reduce(mx, OpMax());
+        __syncthreads();
+
+        info.prev_primal_res = info.primal_res;
+        info.prev_dual_res = info.dual_res;
+        info.primal_res = primal_res_of(V_NR);
+        info.primal_res_rel = info.primal_res / fmax_std(1.0, primal_rel_norm);
+        info.dual_res = dual_res_of(nrx);
+        info.dual_res_rel = info.dual_res / fmax_std(1.0, dual_rel_norm);
+    }
+
+    // :1107-1128
+    __device__ void update_residuals_r()
+    {
+        const int n = S.n, p = S.p, m = S.m;
+        const double rho = info.rho, delta = info.delta;
+        for (int j = tid(); j < n; j += NT) v(V_RS, FX)[j] = v(V_NR, FX)[j] - rho * (v(V_R, FX)[j] - v(V_PX, FX)[j]);
+        for (int i = tid(); i < p; i += NT) v(V_RS, FY)[i] = v(V_NR, FY)[i] - delta * (v(V_PX, FY)[i] - v(V_R, FY)[i]);
+        for (int i = tid(); i < m; i += NT) {
+            v(V_RS, FZL)[i] = v(V_NR, FZL)[i] - delta * (v(V_PX, FZL)[i] - v(V_R, FZL)[i]);
+            v(V_RS, FZU)[i] = v(V_NR, FZU)[i] - delta * (v(V_PX, FZU)[i] - v(V_R, FZU)[i]);
+        }
+        for (int i = tid(); i < S.n_x_l; i += NT) v(V_RS, FZBL)[i] = v(V_NR, FZBL)[i] - delta * (v(V_PX, FZBL)[i] - v(V_R, FZBL)[i]);
+        for (int i = tid(); i < S.n_x_u; i += NT) v(V_RS, FZBU)[i] = v(V_NR, FZBU)[i] - delta * (v(V_PX, FZBU)[i] - v(V_R, FZBU)[i]);
+        __syncthreads();
+        const double primal_rel_scaling = info.primal_res_rel > 0 ? info.primal_res / info.primal_res_rel : 1.0;
+        const double dual_rel_scaling = info.dual_res_rel > 0 ? info.dual_res / info.dual_res_rel : 1.0;
+        info.primal_res_reg = primal_res_of(V_RS);
+        info.primal_res_reg_rel = info.primal_res_reg / primal_rel_scaling;
+        info.dual_res_reg = dual_res_of(v(V_RS, FX));
+        info.dual_res_reg_rel = info.dual_res_reg / dual_rel_scaling;
+        info.primal_prox_inf = primal_prox_inf() * info.delta;
+        info.dual_prox_inf = dual_prox_inf() * info.rho;
+    }
+
+    // the factor-with-retries loops of :446-465 / :688-708; returns false on PIQP_NUMERICS
+    __device__ bool factor_with_retries(bool in_loop, bool& regularization_changed)
+    {
+        while (!ks_update_scalings_and_factor(refine_enabled, info.rho, info.delta)) {
+            if (!refine_enabled) { refine_enabled = true; continue; }
+            if (info.factor_retires < S.set.max_factor_retires) {
+                info.delta *= 100; info.rho *= 100; info.factor_retires++;
+                info.reg_limit = fmin(10 * info.reg_limit, S.set.eps_abs);
+                if (in_loop) regularization_changed = true;
+                continue;
+            }
+            return false;
+        }
+        info.factor_retires = 0;
+        return true;
+    }
+
+    __device__ void copy_prox_duals()
+    {
+        for (int i = tid(); i < S.p; i += NT) v(V_PX, FY)[i] = v(V_R, FY)[i];
+        for (int i = tid(); i < S.m; i += NT) { v(V_PX, FZL)[i] = v(V_R, FZL)[i]; v(V_PX, FZU)[i] = v(V_R, FZU)[i]; }
+        for (int i = tid(); i < S.n_x_l; i += NT) v(V_PX, FZBL)[i] = v(V_R, FZBL)[i];
+        for (int i = tid(); i < S.n_x_u; i += NT) v(V_PX, FZBU)[i] = v(V_R, FZBU)[i];
+    }
+
+    // solver.hpp:379-882
+    __device__ int solve_impl()
+    {
+        const pq_settings& set = S.set;
+        const int n = S.n, p = S.p, m = S.m;
+        info.kkt_factor_time = 0; info.kkt_solve_time = 0;
+        info.n_factor = info.n_solve = info.n_backend_solve = 0;
+        info.status = PQ_UNSOLVED;
+        info.iter = 0;
+        info.reg_limit = set.reg_lower_limit;
+        info.factor_retires = 0; info.no_primal_update = 0; info.no_dual_update = 0;
+        info.mu = 0; info.primal_step = 0; info.dual_step = 0; info.sigma = 0;
+        info.rho = set.rho_init; info.delta = set.delta_init;
+        info.primal_res = info.dual_res = info.primal_res_rel = info.dual_res_rel = 0;
+
+        // :416-437
+        for (int i = tid(); i < m; i += NT) {
+            const double l = S.has_l[i] ? 1.0 : 0.0, u = S.has_u[i] ? 1.0 : 0.0;
+            v(V_R, FSL)[i] = l; v(V_R, FZL)[i] = l; v(V_R, FSU)[i] = u; v(V_R, FZU)[i] = u;
+        }
+        for (int i = tid(); i < n; i += NT) {
+            const double l = i < S.n_x_l ? 1.0 : 0.0, u = i < S.n_x_u ? 1.0 : 0.0;
+            v(V_R, FSBL)[i] = l; v(V_R, FZBL)[i] = l; v(V_R, FSBU)[i] = u; v(V_R, FZBU)[i] = u;
+        }
+        __syncthreads();
+        refine_enabled = set.iterative_refinement_always_enabled != 0;
+        bool dummy = false;
+        if (!factor_with_retries(false, dummy)) { info.status = PQ_NUMERICS; return info.status; }
+
+        for (int i = tid(); i < n; i += NT) { v(V_RS, FX)[i] = -at(D_C)[i]; v(V_RS, FSBL)[i] = 0.0; v(V_RS, FSBU)[i] = 0.0; }
+        for (int i = tid(); i < p; i += NT) v(V_RS, FY)[i] = at(D_B)[i];
+        for (int i = tid(); i < m; i += NT) { v(V_RS, FZL)[i] = -at(D_HL)[i]; v(V_RS, FZU)[i] = at(D_HU)[i]; v(V_RS, FSL)[i] = 0.0; v(V_RS, FSU)[i] = 0.0; }
+        // x_l / x_u are stored compressed to the first n_x_l / n_x_u entries (sparse/data.hpp)
+        for (int i = tid(); i < n; i += NT) { v(V_RS, FZBL)[i] = -at(D_XL)[i]; v(V_RS, FZBU)[i] = at(D_XU)[i]; }
+        __syncthreads();
+        ks_solve(V_RS, V_R);
+
+        if (m + S.n_x_l + S.n_x_u > 0) {
+            // :504-570
+            double delta_s = 0.0, delta_z = 0.0;
+            if (m > 0) { delta_s = fmax_std(delta_s, -min_coeff(v(V_R, FSL), m)); delta_s = fmax_std(delta_s, -min_coeff(v(V_R, FSU), m)); }
+            if (S.n_x_l > 0) delta_s = fmax_std(delta_s, -min_coeff(v(V_R, FSBL), S.n_x_l));
+            if (S.n_x_u > 0) delta_s = fmax_std(delta_s, -min_coeff(v(V_R, FSBU), S.n_x_u));
+            if (m > 0) { delta_z = fmax_std(delta_z, -min_coeff(v(V_R, FZL), m)); delta_z = fmax_std(delta_z, -min_coeff(v(V_R, FZU), m)); }
+            if (S.n_x_l > 0) delta_z = fmax_std(delta_z, -min_coeff(v(V_R, FZBL), S.n_x_l));
+            if (S.n_x_u > 0) delta_z = fmax_std(delta_z, -min_coeff(v(V_R, FZBU), S.n_x_u));
+            __syncthreads();
+            for (int i = tid(); i < m; i += NT) {
+                if (S.has_l[i]) { v(V_R, FSL)[i] += delta_s; v(V_R, FZL)[i] += delta_z; }
+                if (S.has_u[i]) { v(V_R, FSU)[i] += delta_s; v(V_R, FZU)[i] += delta_z; }
+            }
+            for (int i = tid(); i < S.n_x_l; i += NT) { v(V_R, FSBL)[i] += delta_s; v(V_R, FZBL)[i] += delta_z; }
+            for (int i = tid(); i < S.n_x_u; i += NT) { v(V_R, FSBU)[i] += delta_s; v(V_R, FZBU)[i] += delta_z; }
+            __syncthreads();
+            info.mu = fmax_std(calculate_mu(), 1e-10);
+            const double mu = info.mu;
+            auto centre = [&](double& z, double& s) { const double cc = z - delta_z; z = (cc + sqrt(cc * cc + 4 * mu)) / 2; s = z - cc; };
+            __syncthreads();
+            for (int i = tid(); i < m; i += NT) {
+                if (S.has_l[i]) centre(v(V_R, FZL)[i], v(V_R, FSL)[i]);
+                if (S.has_u[i]) centre(v(V_R, FZU)[i], v(V_R, FSU)[i]);
+            }
+            for (int i = tid(); i < S.n_x_l; i += NT) centre(v(V_R, FZBL)[i], v(V_R, FSBL)[i]);
+            for (int i = tid(); i < S.n_x_u; i += NT) centre(v(V_R, FZBU)[i], v(V_R, FSBU)[i]);
+            __syncthreads();
+            info.mu = calculate_mu();
+        }
+
+        for (int i = tid(); i < n; i += NT) v(V_PX, FX)[i] = v(V_R, FX)[i];
+        copy_prox_duals();
+        __syncthreads();
+
+        while (info.iter < set.max_iter) {
+            if (info.iter == 0) {
+                update_residuals_nr();
+                info.prev_primal_res = info.primal_res;
+                info.prev_dual_res = info.dual_res;
+            }
+            if ((info.primal_res < set.eps_abs || info.primal_res_rel < set.eps_rel) && (info.dual_res < set.eps_abs || info.dual_res_rel < set.eps_rel) &&
+                (!set.check_duality_gap || info.duality_gap < set.eps_duality_gap_abs || info.duality_gap_rel < set.eps_duality_gap_rel)) {
+                info.status = PQ_SOLVED;
+                return info.status;
+            }
+            update_residuals_r();
+            if (info.no_dual_update > min(5, set.reg_finetune_dual_update_threshold) && info.primal_prox_inf > set.infeasibility_threshold &&
+                (info.primal_res_reg < set.eps_abs || info.primal_res_reg_rel < set.eps_rel)) {
+                info.status = PQ_PRIMAL_INFEASIBLE;
+                return info.status;
+            }
+            if (info.no_primal_update > min(5, set.reg_finetune_primal_update_threshold) && info.dual_prox_inf > set.infeasibility_threshold &&
+                (info.dual_res_reg < set.eps_abs || info.dual_res_reg_rel < set.eps_rel)) {
+                info.status = PQ_DUAL_INFEASIBLE;
+                return info.status;
+            }
+            info.iter++;
+
+            // :634-666 keep z off the boundary
+            const double epsilon = DBL_EPSILON;
+            double shifted = 0.0;
+            for (int i = tid(); i < m; i += NT) {
+                if (S.has_l[i] && v(V_R, FZL)[i] < epsilon) { v(V_R, FZL)[i] += epsilon; shifted = 1.0; }
+                if (S.has_u[i] && v(V_R, FZU)[i] < epsilon) { v(V_R, FZU)[i] += epsilon; shifted = 1.0; }
+            }
+            bool boundary_shifted = reduce(shifted, OpMax()) > 0.0;
+            if (S.n_x_l > 0 && min_coeff(v(V_R, FZBL), S.n_x_l) < epsilon) {
+                __syncthreads();
+                for (int i = tid(); i < S.n_x_l; i += NT) v(V_R, FZBL)[i] += epsilon;
+                boundary_shifted = true;
+            }
+            if (S.n_x_u > 0 && min_coeff(v(V_R, FZBU), S.n_x_u) < epsilon) {
+                __syncthreads();
+                for (int i = tid(); i < S.n_x_u; i += NT) v(V_R, FZBU)[i] += epsilon;
+                boundary_shifted = true;
+            }
+            __syncthreads();
+            if (boundary_shifted) info.mu = calculate_mu();
+
+            // :668-681
+            if ((info.no_primal_update > set.reg_finetune_primal_update_threshold && info.rho == info.reg_limit && info.reg_limit != set.reg_finetune_lower_limit) ||
+                (info.no_dual_update > set.reg_finetune_dual_update_threshold && info.delta == info.reg_limit && info.reg_limit != set.reg_finetune_lower_limit)) {
+                if (info.dual_prox_inf < set.infeasibility_threshold && info.primal_prox_inf < set.infeasibility_threshold) {
+                    info.reg_limit = set.reg_finetune_lower_limit;
+                    info.no_primal_update = 0;
+                    info.no_dual_update = 0;
+                }
+            }
+
+            bool regularization_changed = false;
+            if (!factor_with_retries(true, regularization_changed)) { info.status = PQ_NUMERICS; return info.status; }
+            if (regularization_changed) update_residuals_r();
+
+            if (m + S.n_x_l + S.n_x_u > 0) {
+                // predictor
+                for (int i = tid(); i < m; i += NT) { v(V_RS, FSL)[i] = -v(V_R, FSL)[i] * v(V_R, FZL)[i]; v(V_RS, FSU)[i] = -v(V_R, FSU)[i] * v(V_R, FZU)[i]; }
+                for (int i = tid(); i < S.n_x_l; i += NT) v(V_RS, FSBL)[i] = -v(V_R, FSBL)[i] * v(V_R, FZBL)[i];
+                for (int i = tid(); i < S.n_x_u; i += NT) v(V_RS, FSBU)[i] = -v(V_R, FSBU)[i] * v(V_R, FZBU)[i];
+                __syncthreads();
+                ks_solve(V_RS, V_ST);
+
+                double alpha_s, alpha_z;
+                calculate_step(alpha_s, alpha_z);
+                alpha_s *= set.tau; alpha_z *= set.tau;
+
+                auto sdot = [&](int fs, int fz, int cnt) {
+                    double acc = 0.0;
+                    for (int i = tid(); i < cnt; i += NT) acc += (v(V_R, fs)[i] + alpha_s * v(V_ST, fs)[i]) * (v(V_R, fz)[i] + alpha_z * v(V_ST, fz)[i]);
+                    return reduce(acc, OpSum());
+                };
+                double sigma = sdot(FSL, FZL, m);
+                sigma += sdot(FSU, FZU, m);
+                sigma += sdot(FSBL, FZBL, S.n_x_l);
+                sigma += sdot(FSBU, FZBU, S.n_x_u);
+                sigma /= (info.mu * (double)(S.n_h_l + S.n_h_u + S.n_x_l + S.n_x_u));
+                sigma = fmax_std(0.0, sigma < 1.0 ? sigma : 1.0);
+                info.sigma = sigma * sigma * sigma;
+
+                // corrector
+                const double smu = info.sigma * info.mu;
+                __syncthreads();
+                for (int i = tid(); i < m; i += NT) {
+                    v(V_RS, FSL)[i] += -v(V_ST, FSL)[i] * v(V_ST, FZL)[i] + smu;
+                    v(V_RS, FSU)[i] += -v(V_ST, FSU)[i] * v(V_ST, FZU)[i] + smu;
+                }
+                for (int i = tid(); i < S.n_x_l; i += NT) v(V_RS, FSBL)[i] += -v(V_ST, FSBL)[i] * v(V_ST, FZBL)[i] + smu;
+                for (int i = tid(); i < S.n_x_u; i += NT) v(V_RS, FSBU)[i] += -v(V_ST, FSBU)[i] * v(V_ST, FZBU)[i] + smu;
+                __syncthreads();
+                ks_solve(V_RS, V_ST);
+
+                calculate_step(alpha_s, alpha_z);
+                info.primal_step = alpha_s * set.tau;
+                info.dual_step = alpha_z * set.tau;
+                const double ps = info.primal_step, ds = info.dual_step;
+                __syncthreads();
+                for (int i = tid(); i < n; i += NT) v(V_R, FX)[i] += ps * v(V_ST, FX)[i];
+                for (int i = tid(); i < p; i += NT) v(V_R, FY)[i] += ds * v(V_ST, FY)[i];
+                for (int i = tid(); i < m; i += NT) {
+                    v(V_R, FZL)[i] += ds * v(V_ST, FZL)[i]; v(V_R, FZU)[i] += ds * v(V_ST, FZU)[i];
+                    v(V_R, FSL)[i] += ps * v(V_ST, FSL)[i]; v(V_R, FSU)[i] += ps * v(V_ST, FSU)[i];
+                }
+                for (int i = tid(); i < S.n_x_l; i += NT) { v(V_R, FZBL)[i] += ds * v(V_ST, FZBL)[i]; v(V_R, FSBL)[i] += ps * v(V_ST, FSBL)[i]; }
+                for (int i = tid(); i < S.n_x_u; i += NT) { v(V_R, FZBU)[i] += ds * v(V_ST, FZBU)[i]; v(V_R, FSBU)[i] += ps * v(V_ST, FSBU)[i]; }
+                __syncthreads();
+
+                const double mu_prev = info.mu;
+                info.mu = calculate_mu();
+                const double mu_rate = fmax_std(0.0, (mu_prev - info.mu) / mu_prev);
+
+                update_residuals_nr();
+
+                if (info.dual_res < 0.95 * info.prev_dual_res || (info.dual_res < set.eps_abs || info.dual_res_rel < set.eps_rel) ||
+                    (info.rho == set.reg_finetune_lower_limit && info.dual_prox_inf < set.infeasibility_threshold)) {
+                    for (int i = tid(); i < n; i += NT) v(V_PX, FX)[i] = v(V_R, FX)[i];
+                    info.rho = fmax_std(info.reg_limit, (1.0 - mu_rate) * info.rho);
+                } else {
+                    info.no_primal_update++;
+                    if (info.iter < 5 || info.dual_prox_inf < set.infeasibility_threshold) info.rho = fmax_std(info.reg_limit, (1.0 - 0.666 * mu_rate) * info.rho);
+                }
+                if (info.primal_res < 0.95 * info.prev_primal_res || (info.primal_res < set.eps_abs || info.primal_res_rel < set.eps_rel) ||
+                    (info.delta == set.reg_finetune_lower_limit && info.primal_prox_inf < set.infeasibility_threshold)) {
+                    copy_prox_duals();
+                    info.delta = fmax_std(info.reg_limit, (1.0 - mu_rate) * info.delta);
+                } else {
+                    info.no_dual_update++;
+                    if (info.iter < 5 || info.primal_prox_inf < set.infeasibility_threshold) info.delta = fmax_std(info.reg_limit, (1.0 - 0.666 * mu_rate) * info.delta);
+                }
+                __syncthreads();
+            } else {
+                // :831-877 no inequalities: one solve, full step
+                ks_solve(V_RS, V_ST);
+                info.primal_step = 1.0; info.dual_step = 1.0;
+                for (int i = tid(); i < n; i += NT) v(V_R, FX)[i] += v(V_ST, FX)[i];
+                for (int i = tid(); i < p; i += NT) v(V_R, FY)[i] += v(V_ST, FY)[i];
+                __syncthreads();
+                update_residuals_nr();
+                if (info.dual_res < 0.95 * info.prev_dual_res || (info.dual_res < set.eps_abs || info.dual_res_rel < set.eps_rel)) {
+                    for (int i = tid(); i < n; i += NT) v(V_PX, FX)[i] = v(V_R, FX)[i];
+                    info.rho = fmax_std(info.reg_limit, 0.1 * info.rho);
+                } else {
+                    info.no_primal_update++;
+                    if (info.iter < 5 || info.dual_prox_inf < set.infeasibility_threshold) info.rho = fmax_std(info.reg_limit, 0.5 * info.rho);
+                }
+                if (info.primal_res < 0.95 * info.prev_primal_res || (info.primal_res < set.eps_abs || info.primal_res_rel < set.eps_rel)) {
+                    for (int i = tid(); i < p; i += NT) v(V_PX, FY)[i] = v(V_R, FY)[i];
+                    info.delta = fmax_std(info.reg_limit, 0.1 * info.delta);
+                } else {
+                    info.no_dual_update++;
+                    if (info.iter < 5 || info.primal_prox_inf < set.infeasibility_threshold) info.delta = fmax_std(info.reg_limit, 0.5 * info.delta);
+                }
+                __syncthreads();
+            }
+        }
+        info.status = PQ_MAX_ITER_REACHED;
+        return info.status;
+    }
+
+    // solver.hpp:1205-1259 unscale_results + restore_dual; the expanded box duals go to the RS set (scratch) and back
+    __device__ void finish()
+    {
+        const int n = S.n, p = S.p, m = S.m;
+        const double* dl = at(D_DL);
+        const double* dli = at(D_DLI);
+        const double* db = at(D_DB);
+        const double* dbi = at(D_DBI);
+        const double ci = rz_c_inv;
+        for (int i = tid(); i < n; i += NT) v(V_R, FX)[i] *= dl[i];
+        for (int i = tid(); i < p; i += NT) v(V_R, FY)[i] = v(V_R, FY)[i] * ci * dl[n + i];
+        for (int i = tid(); i < m; i += NT) {
+            double zl = v(V_R, FZL)[i] * ci * dl[n + p + i], zu = v(V_R, FZU)[i] * ci * dl[n + p + i];
+            double sl = v(V_R, FSL)[i] * dli[n + p + i], su = v(V_R, FSU)[i] * dli[n + p + i];
+            if (zl == 0) sl = 1e30;
+            if (zu == 0) su = 1e30;
+            v(V_R, FZL)[i] = zl; v(V_R, FZU)[i] = zu; v(V_R, FSL)[i] = sl; v(V_R, FSU)[i] = su;
+        }
+        for (int j = tid(); j < n; j += NT) {
+            const int il = S.pos_l[j], iu = S.pos_u[j];
+            v(V_RS, FZBL)[j] = il >= 0 ? v(V_R, FZBL)[il] * ci * db[j] : 0.0;
+            v(V_RS, FSBL)[j] = il >= 0 ? v(V_R, FSBL)[il] * dbi[j] : 1e30;
+            v(V_RS, FZBU)[j] = iu >= 0 ? v(V_R, FZBU)[iu] * ci * db[j] : 0.0;
+            v(V_RS, FSBU)[j] = iu >= 0 ? v(V_R, FSBU)[iu] * dbi[j] : 1e30;
+        }
+        __syncthreads();
+        for (int j = tid(); j < n; j += NT) {
+            v(V_R, FZBL)[j] = v(V_RS, FZBL)[j]; v(V_R, FSBL)[j] = v(V_RS, FSBL)[j];
+            v(V_R, FZBU)[j] = v(V_RS, FZBU)[j]; v(V_R, FSBU)[j] = v(V_RS, FSBU)[j];
+        }
+        __syncthreads();
+    }
+};
+
+// per instance: caller's (Ruiz-scaled) values -> front / grouped-row arenas and the AtA fronts (multistage ctor, :76-135)
+template <int NT>
+__global__ __launch_bounds__(NT) void k_batch_prepare(const BatchShared* __restrict__ Sp, double* __restrict__ arena)
+{
+    const BatchShared& S = *Sp;
+    double* base = arena + (long long)blockIdx.x * S.stride;
+    const int tid = threadIdx.x;
+    double *Pf = base + S.off[B_PF], *XA = base + S.off[B_XA], *XG = base + S.off[B_XG];
+    const double *Px = base + S.off[D_PX], *Ax = base + S.off[D_ATX], *Gx = base + S.off[D_GTX];
+    for (int q = tid; q < S.nzP; q += NT) Pf[S.P_dst[q]] = Px[q];
+    for (int q = tid; q < S.nzA; q += NT) XA[S.A_dst[q]] = Ax[q];
+    for (int q = tid; q < S.nzG; q += NT) XG[S.G_dst[q]] = Gx[q];
+    __syncthreads();
+    for (int b = 0; b + 1 < S.M.N; ++b) {
+        const int h = S.M.h[b];
+        msdev::gram_stage<NT>(S.M, S.GA, XA, base + S.off[B_ATAF], b, 0, h * h);
+    }
+}
+
+template <int NT, bool LDS>
+__global__ __launch_bounds__(NT) void k_batch_ipm(const BatchShared* __restrict__ Sp, double* __restrict__ arena, const double* __restrict__ ruiz_c, pq_info* __restrict__ infos)
+{
+    extern __shared__ double sm[];
+    __shared__ double red[NT / 64 > 0 ? NT / 64 : 1];
+    const BatchShared& S = *Sp;
+    const int q = blockIdx.x;
+    Ipm<NT, LDS> ipm(S, arena + (long long)q * S.stride, sm, red);
+    ipm.rz_c = ruiz_c[q];
+    ipm.rz_c_inv = 1.0 / ruiz_c[q];
+    ipm.info = pq_info{};
+    ipm.solve_impl();
+    __syncthreads();
+    ipm.finish();
+    if (threadIdx.x == 0) infos[q] = ipm.info;
+}
+
+struct Layout {
+    long long off[NSLOT];
+    long long stride = 0;
+};
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ host class
+class BatchSolver {
+public:
+    explicit BatchSolver(int device) : dev_(device)
+    {
+        pq_settings_default(&settings_);
+        settings_.kkt_solver = PQ_SPARSE_MULTISTAGE;
+        PQ_HIP(hipSetDevice(dev_));
+        PQ_HIP(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
+    }
+    ~BatchSolver()
+    {
+        (void)hipSetDevice(dev_);
+        if (st_) { (void)hipStreamSynchronize(st_); (void)hipStreamDestroy(st_); }
+    }
+    pq_settings& settings() { return settings_; }
+    int batch() const { return batch_; }
+    int n() const { return n_; }
+    int p() const { return p_; }
+    int m() const { return m_; }
+
+    // SparseSolver::setup (solver.hpp:1297-1308) for every instance; patterns shared, values [batch][nnz] / [batch][len]
+    bool setup(int batch, int n, int p, int m, const int* Pp, const int* Pi, const double* Px, const double* c, const int* Ap, const int* Ai, const double* Ax, const double* b,
+               const int* Gp, const int* Gi, const double* Gx, const double* h_l, const double* h_u, const double* x_l, const double* x_u)
+    {
+        if (batch <= 0 || n <= 0) throw std::runtime_error("batch setup: bad dimensions");
+        if (settings_.kkt_solver != PQ_SPARSE_MULTISTAGE) throw std::runtime_error("batch mode: only kkt_solver = sparse_multistage");
+        PQ_HIP(hipSetDevice(dev_));
+        batch_ = batch;
+        const int nzP = Pp[n], nzA = Ap ? Ap[n] : 0, nzG = Gp ? Gp[n] : 0;
+        // ---- per-instance Data + Ruiz on the host (the instances are independent: one host thread per slice) ----
+        std::vector<std::unique_ptr<HostData>> data(batch);
+        std::vector<Ruiz> ruiz(batch);
+        auto build = [&](int lo, int hi) {
+            for (int i = lo; i < hi; ++i) {
+                data[i] = make_sparse_host_data(n, p, m, Pp, Pi, Px + (size_t)i * nzP, c + (size_t)i * n, Ap, Ai, Ax ? Ax + (size_t)i * nzA : nullptr, b ? b + (size_t)i * p : nullptr,
+                                                Gp, Gi, Gx ? Gx + (size_t)i * nzG : nullptr, h_l ? h_l + (size_t)i * m : nullptr, h_u ? h_u + (size_t)i * m : nullptr,
+                                                x_l ? x_l + (size_t)i * n : nullptr, x_u ? x_u + (size_t)i * n : nullptr);
+                ruiz[i].init(*data[i]);
+                ruiz[i].scale_data(*data[i], false, settings_.preconditioner_scale_cost != 0, settings_.preconditioner_iter);
+            }
+        };
+        {
+            const int nthreads = std::max(1, std::min<int>(batch, (int)std::thread::hardware_concurrency()));
+            std::vector<std::thread> pool;
+            std::vector<std::exception_ptr> errs(nthreads);
+            for (int t = 0; t < nthreads; ++t) {
+                const int lo = (int)((long long)batch * t / nthreads), hi = (int)((long long)batch * (t + 1) / nthreads);
+                pool.emplace_back([&, t, lo, hi] { try { build(lo, hi); } catch (...) { errs[t] = std::current_exception(); } });
+            }
+            for (auto& th : pool) th.join();
+            for (auto& e : errs) if (e) std::rethrow_exception(e);
+        }
+        const HostData& d0 = *data[0];
+        n_ = d0.n; p_ = d0.p; m_ = d0.m;
+        for (int i = 1; i < batch; ++i) {
+            const HostData& d = *data[i];
+            const bool same = d.n_h_l == d0.n_h_l && d.n_h_u == d0.n_h_u && d.n_x_l == d0.n_x_l && d.n_x_u == d0.n_x_u &&
+                              std::equal(d.h_l_idx.begin(), d.h_l_idx.begin() + d.n_h_l, d0.h_l_idx.begin()) &&
+                              std::equal(d.h_u_idx.begin(), d.h_u_idx.begin() + d.n_h_u, d0.h_u_idx.begin()) &&
+                              std::equal(d.x_l_idx.begin(), d.x_l_idx.begin() + d.n_x_l, d0.x_l_idx.begin()) &&
+                              std::equal(d.x_u_idx.begin(), d.x_u_idx.begin() + d.n_x_u, d0.x_u_idx.begin());
+            if (!same) throw std::runtime_error("batch setup: instances differ in which bounds are finite");
+        }
+        // ---- shared structure ----
+        pq_sparse_data desc = d0.sparse_descriptor();
+        multistage::analyse(&desc, sym_);
+        build_shared(d0);
+        // ---- per-instance arena ----
+        arena_.alloc((size_t)layout_.stride * batch);
+        arena_.zero(st_);
+        ruiz_c_.alloc(batch);
+        infos_.alloc(batch);
+        infos_h_.resize(batch);
+        std::vector<double> stage((size_t)layout_.stride * std::min(batch, STAGE_INST));
+        std::vector<double> rc(batch);
+        for (int i0 = 0; i0 < batch; i0 += STAGE_INST) {
+            const int cnt = std::min(STAGE_INST, batch - i0);
+            std::fill(stage.begin(), stage.begin() + (size_t)layout_.stride * cnt, 0.0);
+            for (int k = 0; k < cnt; ++k) pack_instance(*data[i0 + k], ruiz[i0 + k], stage.data() + (size_t)layout_.stride * k);
+            PQ_HIP(hipMemcpyAsync(arena_.p + (size_t)layout_.stride * i0, stage.data(), sizeof(double) * (size_t)layout_.stride * cnt, hipMemcpyHostToDevice, st_));
+            PQ_HIP(hipStreamSynchronize(st_));
+        }
+        for (int i = 0; i < batch; ++i) rc[i] = ruiz[i].c;
+        PQ_HIP(hipMemcpyAsync(ruiz_c_.p, rc.data(), sizeof(double) * batch, hipMemcpyHostToDevice, st_));
+        launch_prepare();
+        PQ_HIP(hipStreamSynchronize(st_));
+        setup_done_ = true;
+        return true;
+    }
+
+    // solve() of every instance; returns the number of instances that ended PIQP_SOLVED
+    int solve()
+    {
+        if (!setup_done_) throw std::runtime_error("batch solver not set up");
+        if (!verify_settings(settings_)) {
+            for (auto& i : infos_h_) { i = pq_info{}; i.status = PQ_INVALID_SETTINGS; }
+            return 0;
+        }
+        PQ_HIP(hipSetDevice(dev_));
+        shared_h_.set = settings_;
+        PQ_HIP(hipMemcpyAsync(shared_.p, &shared_h_, sizeof(BatchShared), hipMemcpyHostToDevice, st_));
+        hipEvent_t e0, e1;
+        PQ_HIP(hipEventCreate(&e0)); PQ_HIP(hipEventCreate(&e1));
+        PQ_HIP(hipEventRecord(e0, st_));
+        launch_ipm();
+        PQ_HIP(hipEventRecord(e1, st_));
+        PQ_HIP(hipGetLastError());
+        PQ_HIP(hipMemcpyAsync(infos_h_.data(), infos_.p, sizeof(pq_info) * batch_, hipMemcpyDeviceToHost, st_));
+        PQ_HIP(hipStreamSynchronize(st_));
+        float ms = 0.f;
+        PQ_HIP(hipEventElapsedTime(&ms, e0, e1));
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        last_kernel_ms_ = ms;
+        int solved = 0;
+        for (const auto& i : infos_h_) solved += i.status == PQ_SOLVED;
+        return solved;
+    }
+    double last_kernel_ms() const { return last_kernel_ms_; }
+    const pq_info& info(int i) const { return infos_h_.at(i); }
+
+    // field k of Variables (x, y, z_l, z_u, z_bl, z_bu, s_l, s_u, s_bl, s_bu) of all instances -> host [batch][len]
+    void get_result(int field, double* out_host)
+    {
+        const int len = field_len(field);
+        if (len == 0) return;
+        PQ_HIP(hipSetDevice(dev_));
+        PQ_HIP(hipMemcpy2DAsync(out_host, sizeof(double) * len, arena_.p + layout_.off[V_R + field], sizeof(double) * layout_.stride, sizeof(double) * len, batch_,
+                                hipMemcpyDeviceToHost, st_));
+        PQ_HIP(hipStreamSynchronize(st_));
+    }
+    int field_len(int field) const
+    {
+        switch (field) { case FX: case FZBL: case FZBU: case FSBL: case FSBU: return n_; case FY: return p_; default: return m_; }
+    }
+    void block_info(std::vector<int>& out) const
+    {
+        out.clear();
+        for (const auto& b : sym_.block_info) { out.push_back(b.start); out.push_back(b.diag_size); out.push_back(b.off_diag_size); }
+    }
+    int threads_per_qp() const { return nt_; }
+
+private:
+    static constexpr int STAGE_INST = 256;
+
+    template <class T>
+    const T* up(std::vector<DBuf<T>>& pool, const std::vector<T>& h)
+    {
+        pool.emplace_back();
+        upload_vec(pool.back(), h, st_);
+        return pool.back().p;
+    }
+
+    void build_shared(const HostData& d)
+    {
+        const int n = n_, p = p_, m = m_;
+        BatchShared& S = shared_h_;
+        S = BatchShared{};
+        S.n = n; S.p = p; S.m = m; S.n_h_l = d.n_h_l; S.n_h_u = d.n_h_u; S.n_x_l = d.n_x_l; S.n_x_u = d.n_x_u;
+        ibufs_.clear(); lbufs_.clear();
+        ibufs_.reserve(64); lbufs_.reserve(16);
+        std::vector<int> has_l(std::max(m, 1), 0), has_u(std::max(m, 1), 0), pos_l(n, -1), pos_u(n, -1);
+        for (int i = 0; i < d.n_h_l; ++i) has_l[d.h_l_idx[i]] = 1;
+        for (int i = 0; i < d.n_h_u; ++i) has_u[d.h_u_idx[i]] = 1;
+        for (int i = 0; i < d.n_x_l; ++i) pos_l[d.x_l_idx[i]] = i;
+        for (int i = 0; i < d.n_x_u; ++i) pos_u[d.x_u_idx[i]] = i;
+        S.h_l_idx = up(ibufs_, d.h_l_idx); S.h_u_idx = up(ibufs_, d.h_u_idx); S.x_l_idx = up(ibufs_, d.x_l_idx); S.x_u_idx = up(ibufs_, d.x_u_idx);
+        S.has_l = up(ibufs_, has_l); S.has_u = up(ibufs_, has_u); S.pos_l = up(ibufs_, pos_l); S.pos_u = up(ibufs_, pos_u);
+        // symmetrised P and row-oriented A, G with value-source maps
+        const Csc& U = d.sP_utri;
+        S.nzP = U.nnz(); S.nzA = d.sAT.nnz(); S.nzG = d.sGT.nnz();
+        {
+            std::vector<int> fp(n + 1, 0);
+            for (int j = 0; j < n; ++j) for (int q = U.colptr[j]; q < U.colptr[j + 1]; ++q) { fp[j + 1]++; if (U.rowind[q] != j) fp[U.rowind[q] + 1]++; }
+            for (int j = 0; j < n; ++j) fp[j + 1] += fp[j];
+            std::vector<int> fi(fp[n]), src(fp[n]), nx(fp.begin(), fp.end() - 1);
+            for (int j = 0; j < n; ++j) for (int q = U.colptr[j]; q < U.colptr[j + 1]; ++q) { const int t = nx[j]++; fi[t] = U.rowind[q]; src[t] = q; }
+            for (int j = 0; j < n; ++j) for (int q = U.colptr[j]; q < U.colptr[j + 1]; ++q) { const int i = U.rowind[q]; if (i != j) { const int t = nx[i]++; fi[t] = j; src[t] = q; } }
+            S.Pf_p = up(ibufs_, fp); S.Pf_i = up(ibufs_, fi); S.Pf_src = up(ibufs_, src);
+        }
+        auto rows_of = [&](const Csc& T, const int*& Tp, const int*& Ti, const int*& Rp, const int*& Ri, const int*& Rs) {
+            std::vector<int> tp(T.colptr), ti(T.rowind);
+            if (tp.empty()) tp.assign(1, 0);
+            Tp = up(ibufs_, tp); Ti = up(ibufs_, ti);
+            const int cols = T.cols, nnz = T.nnz();
+            std::vector<int> rp(n + 1, 0), ri(nnz), rs(nnz);
+            for (int q = 0; q < nnz; ++q) rp[T.rowind[q] + 1]++;
+            for (int j = 0; j < n; ++j) rp[j + 1] += rp[j];
+            std::vector<int> nx(rp.begin(), rp.end() - 1);
+            for (int k = 0; k < cols; ++k) for (int q = T.colptr[k]; q < T.colptr[k + 1]; ++q) { const int t = nx[T.rowind[q]]++; ri[t] = k; rs[t] = q; }
+            Rp = up(ibufs_, rp); Ri = up(ibufs_, ri); Rs = up(ibufs_, rs);
+        };
+        rows_of(d.sAT, S.AT_p, S.AT_i, S.A_p, S.A_i, S.A_src);
+        rows_of(d.sGT, S.GT_p, S.GT_i, S.G_p, S.G_i, S.G_src);
+        // multistage structure
+        std::vector<int> start(sym_.N);
+        for (int b = 0; b < sym_.N; ++b) start[b] = sym_.block_info[b].start;
+        S.M = MsMeta{sym_.N, sym_.arrow, n, up(ibufs_, sym_.w), up(ibufs_, sym_.off), up(ibufs_, sym_.h), up(ibufs_, start), up(lbufs_, sym_.front_off), up(lbufs_, sym_.pan_off)};
+        S.GA = GroupMeta{up(ibufs_, sym_.A.row_ptr), up(ibufs_, sym_.A.rows), up(lbufs_, sym_.A.x_off)};
+        S.GG = GroupMeta{up(ibufs_, sym_.G.row_ptr), up(ibufs_, sym_.G.rows), up(lbufs_, sym_.G.x_off)};
+        S.P_dst = up(lbufs_, sym_.P_dst); S.A_dst = up(lbufs_, sym_.A.dst); S.G_dst = up(lbufs_, sym_.G.dst);
+        // chain workspace: front + carried update + inverse (factor) / 2 vectors + panel (solve)
+        int max_u = 0;
+        long long max_pan = 0;
+        for (int b = 0; b < sym_.N; ++b) {
+            max_u = std::max(max_u, sym_.h[b] - sym_.w[b]);
+            max_pan = std::max(max_pan, (long long)sym_.h[b] * sym_.w[b] + (long long)sym_.w[b] * sym_.w[b]);
+        }
+        S.fcap = sym_.max_h * sym_.max_h;
+        S.lofs = S.fcap + max_u * max_u;
+        S.hcap = std::max(1, sym_.max_h);
+        const long long fdoubles = (long long)S.lofs + (long long)sym_.max_w * sym_.max_w;
+        const long long sdoubles = 2LL * S.hcap + max_pan;
+        lds_ = std::max(fdoubles, sdoubles) * (long long)sizeof(double) <= LDS_LIMIT_BYTES;
+        if (!lds_) {  // in-HBM chain: only the inverse (factor) / the two stage vectors (solve) are staged
+            S.fcap = 0;
+            S.lofs = 0;
+            const long long need = std::max<long long>((long long)sym_.max_w * sym_.max_w, 2LL * S.hcap);
+            if (need * (long long)sizeof(double) > LDS_LIMIT_BYTES) throw std::runtime_error("batch setup: a stage is too wide for this backend");
+            S.chain_lds_doubles = (int)need;
+        } else {
+            S.chain_lds_doubles = (int)std::max(fdoubles, sdoubles);
+        }
+        nt_ = (n <= 512 && sym_.max_h <= 24) ? 64 : 256;
+        // arena layout
+        long long o = 0;
+        auto put = [&](int slot, long long cnt) { layout_.off[slot] = o; o += (cnt + 1) & ~1LL; };
+        put(D_PX, S.nzP); put(D_ATX, S.nzA); put(D_GTX, S.nzG); put(D_C, n); put(D_B, p); put(D_HL, m); put(D_HU, m); put(D_XL, n); put(D_XU, n); put(D_XBS, n);
+        put(D_DL, n + p + m); put(D_DLI, n + p + m); put(D_DB, n); put(D_DBI, n);
+        const long long flen[NF] = {n, p, m, m, n, n, m, m, n, n};
+        for (int set : {(int)V_R, (int)V_NR, (int)V_RS, (int)V_ST, (int)V_PX}) for (int f = 0; f < NF; ++f) put(set + f, flen[f]);
+        put(K_SL, m); put(K_SU, m); put(K_SBL, n); put(K_SBU, n); put(K_ZLI, m); put(K_ZUI, m); put(K_ZBLI, n); put(K_ZBUI, n); put(K_XREG, n); put(K_ZREG, m); put(K_ZREGR, m);
+        put(K_RXB, n); put(K_RZB, m); put(K_WX, n); put(K_LZ, m); put(K_EX, n); put(K_EY, p); put(K_EZ, m); put(K_RLX, n); put(K_RLY, p); put(K_RLZ, m);
+        put(B_ZINV, m); put(B_PF, sym_.front_doubles); put(B_ATAF, sym_.front_doubles); put(B_F, sym_.front_doubles); put(B_PAN, sym_.pan_doubles);
+        put(B_XA, sym_.A.x_doubles); put(B_XG, sym_.G.x_doubles);
+        layout_.stride = o;
+        for (int s = 0; s < NSLOT; ++s) S.off[s] = layout_.off[s];
+        S.stride = layout_.stride;
+        S.set = settings_;
+        shared_.alloc(1);
+        PQ_HIP(hipMemcpyAsync(shared_.p, &S, sizeof(BatchShared), hipMemcpyHostToDevice, st_));
+        PQ_HIP(hipStreamSynchronize(st_));
+    }
+
+    void pack_instance(const HostData& d, const Ruiz& r, double* dst) const
+    {
+        auto cp = [&](int slot, const Vec& v, size_t cnt) { if (cnt) std::copy(v.begin(), v.begin() + cnt, dst + layout_.off[slot]); };
+        cp(D_PX, d.sP_utri.val, d.sP_utri.val.size()); cp(D_ATX, d.sAT.val, d.sAT.val.size()); cp(D_GTX, d.sGT.val, d.sGT.val.size());
+        cp(D_C, d.c, n_); cp(D_B, d.b, p_); cp(D_HL, d.h_l, m_); cp(D_HU, d.h_u, m_); cp(D_XL, d.x_l, n_); cp(D_XU, d.x_u, n_); cp(D_XBS, d.x_b_scaling, n_);
+        cp(D_DL, r.delta, n_ + p_ + m_); cp(D_DLI, r.delta_inv, n_ + p_ + m_); cp(D_DB, r.delta_b, n_); cp(D_DBI, r.delta_b_inv, n_);
+    }
+
+    void launch_prepare()
+    {
+        if (nt_ == 64) hipLaunchKernelGGL(k_batch_prepare<64>, dim3(batch_), dim3(64), 0, st_, shared_.p, arena_.p);
+        else hipLaunchKernelGGL(k_batch_prepare<256>, dim3(batch_), dim3(256), 0, st_, shared_.p, arena_.p);
+        PQ_HIP(hipGetLastError());
+    }
+    template <int NTv, bool LDSv>
+    void launch_ipm_as()
+    {
+        const int bytes = shared_h_.chain_lds_doubles * (int)sizeof(double);
+        static bool attr = false;
+        if (!attr) {
+            PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_batch_ipm<NTv, LDSv>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT_BYTES));
+            attr = true;
+        }
+        hipLaunchKernelGGL((k_batch_ipm<NTv, LDSv>), dim3(batch_), dim3(NTv), bytes, st_, shared_.p, arena_.p, ruiz_c_.p, infos_.p);
+    }
+    void launch_ipm()
+    {
+        if (nt_ == 64) { if (lds_) launch_ipm_as<64, true>(); else launch_ipm_as<64, false>(); }
+        else { if (lds_) launch_ipm_as<256, true>(); else launch_ipm_as<256, false>(); }
+    }
+
+    int dev_, batch_ = 0, n_ = 0, p_ = 0, m_ = 0, nt_ = 64;
+    bool lds_ = true, setup_done_ = false;
+    double last_kernel_ms_ = 0.0;
+    hipStream_t st_ = nullptr;
+    pq_settings settings_;
+    multistage::Symbolic sym_;
+    Layout layout_;
+    BatchShared shared_h_{};
+    DBuf<BatchShared> shared_;
+    std::vector<DBuf<int>> ibufs_;
+    std::vector<DBuf<long long>> lbufs_;
+    DBuf<double> arena_, ruiz_c_;
+    DBuf<pq_info> infos_;
+    std::vector<pq_info> infos_h_;
+};
+
+}  // namespace pq
+
+// ------------------------------------------------------------------ C-ABI (include/piqp_amd.h, "Batched solver" section)
+using namespace pq;
+
+struct pq_batch {
+    std::unique_ptr<BatchSolver> impl;
+};
+
+extern "C" {
+
+int pq_batch_create(pq_batch** out, int device)
+{
+    if (!out) return fail(PQ_ERR_INVALID, "null argument");
+    *out = nullptr;
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0) return fail(PQ_ERR_HIP, "no HIP device visible: this library has no CPU fallback");
+    if (device < 0 || device >= cnt) return fail(PQ_ERR_INVALID, "device %d out of range", device);
+    return guarded([&] { auto* h = new pq_batch; h->impl.reset(new BatchSolver(device)); *out = h; return (int)PQ_OK; });
+}
+void pq_batch_destroy(pq_batch* s) { delete s; }
+pq_settings* pq_batch_settings(pq_batch* s) { return s ? &s->impl->settings() : nullptr; }
+int pq_batch_setup_sparse(pq_batch* s, int batch, int n, int p, int m, const int* Pp, const int* Pi, const double* Px, const double* c, const int* Ap, const int* Ai,
+                          const double* Ax, const double* b, const int* Gp, const int* Gi, const double* Gx, const double* h_l, const double* h_u, const double* x_l,
+                          const double* x_u)
+{
+    if (!s || !Pp || !Pi || !Px || !c) return fail(PQ_ERR_INVALID, "null argument");
+    return guarded([&] { return s->impl->setup(batch, n, p, m, Pp, Pi, Px, c, Ap, Ai, Ax, b, Gp, Gi, Gx, h_l, h_u, x_l, x_u) ? 1 : 0; });
+}
+int pq_batch_solve(pq_batch* s)
+{
+    if (!s) return fail(PQ_ERR_INVALID, "null argument");
+    return guarded([&] { return s->impl->solve(); });
+}
+const pq_info* pq_batch_info(const pq_batch* s, int instance)
+{
+    if (!s || instance < 0 || instance >= s->impl->batch()) return nullptr;
+    return &s->impl->info(instance);
+}
+int pq_batch_get_result(pq_batch* s, int field, double* out_host)
+{
+    if (!s || !out_host || field < 0 || field >= 10) return fail(PQ_ERR_INVALID, "bad argument");
+    return guarded([&] { s->impl->get_result(field, out_host); return (int)PQ_OK; });
+}
+int pq_batch_dims(const pq_batch* s, int* batch, int* n, int* p, int* m)
+{
+    if (!s) return fail(PQ_ERR_INVALID, "null argument");
+    if (batch) *batch = s->impl->batch();
+    if (n) *n = s->impl->n();
+    if (p) *p = s->impl->p();
+    if (m) *m = s->impl->m();
+    return PQ_OK;
+}
+int pq_batch_block_info(const pq_batch* s, int* out_host, int capacity)
+{
+    if (!s) return fail(PQ_ERR_INVALID, "null argument");
+    return guarded([&] {
+        std::vector<int> bi;
+        s->impl->block_info(bi);
+        const int N = (int)bi.size() / 3;
+        if (out_host) for (int i = 0; i < 3 * std::min(N, capacity); ++i) out_host[i] = bi[i];
+        return N;
+    });
+}
+int pq_batch_last_kernel_ms(const pq_batch* s, double* ms, int* threads_per_qp)
+{
+    if (!s) return fail(PQ_ERR_INVALID, "null argument");
+    if (ms) *ms = s->impl->last_kernel_ms();
+    if (threads_per_qp) *threads_per_qp = s->impl->threads_per_qp();
+    return PQ_OK;
+}
+
+}  // extern "C"

@@ -22,6 +22,7 @@
 #include <stdexcept>
 
 #include "kkt_solver_base.hpp"
+#include "multistage_device.hpp"
 #include "multistage_symbolic.hpp"
 #include "sparse_ops.hpp"
 
@@ -33,20 +34,8 @@ constexpr int NT = 256;
 constexpr int LDS_LIMIT_BYTES = 159 * 1024;  // gfx950: 160 KiB of LDS per workgroup
 constexpr int ASM_CHUNK = 4096;              // front entries per assembly workgroup
 
-struct MsMeta {  // device views of multistage::Symbolic
-    int N, arrow, n;
-    const int* w;
-    const int* off;
-    const int* h;
-    const int* start;
-    const long long* front_off;
-    const long long* pan_off;
-};
-struct GroupMeta {
-    const int* row_ptr;  // N entries
-    const int* rows;     // grouped position -> caller's constraint index
-    const long long* x_off;
-};
+using msdev::GroupMeta;
+using msdev::MsMeta;
 
 __global__ void k_ms_reciprocal(int m, const double* __restrict__ z, double* __restrict__ zinv)
 {
@@ -54,217 +43,38 @@ __global__ void k_ms_reciprocal(int m, const double* __restrict__ z, double* __r
     if (i < m) zinv[i] = 1.0 / z[i];
 }
 
-// lower triangle of X_b X_b^T for every stage (equality rows; the reference's AtA, :113 / :161)
+// grid (stage, chunk): lower triangle of X_b X_b^T for every stage (equality rows; the reference's AtA, :113 / :161)
 __global__ __launch_bounds__(NT) void k_ms_gram(MsMeta M, GroupMeta Gm, const double* __restrict__ X, double* __restrict__ out)
 {
     const int b = blockIdx.x;
-    const int h = M.h[b];
-    const int rows = Gm.row_ptr[b + 1] - Gm.row_ptr[b];
-    const double* Xb = X + Gm.x_off[b];
-    double* O = out + M.front_off[b];
-    const int total = h * h;
+    const int total = M.h[b] * M.h[b];
     const int lo = blockIdx.y * ASM_CHUNK, hi = min(total, lo + ASM_CHUNK);
-    for (int idx = lo + threadIdx.x; idx < hi; idx += NT) {
-        const int r = idx % h, c = idx / h;
-        if (r < c) continue;
-        double s = 0.0;
-        for (int k = 0; k < rows; ++k) s += Xb[r + (long long)k * h] * Xb[c + (long long)k * h];
-        O[idx] = s;
-    }
+    msdev::gram_stage<NT>(M, Gm, X, out, b, lo, hi);
 }
 
-// frontal matrix of stage b (lower triangle): P + delta^-1 AtA + X_G diag(1/z_reg) X_G^T, x_reg on the pivot diagonal.
-// Block N-1 is the arrow corner (P + x_reg only; all products that land there are carried by the stage fronts).
+// grid (block, chunk): frontal matrix of every stage + the arrow corner
 __global__ __launch_bounds__(NT) void k_ms_assemble(MsMeta M, GroupMeta Gm, const double* __restrict__ XG, const double* __restrict__ Pf, const double* __restrict__ AtAf,
                                                     const double* __restrict__ zinv, const double* __restrict__ x_reg, double delta_inv, double* __restrict__ F)
 {
     const int b = blockIdx.x;
-    const int h = M.h[b], w = M.w[b];
-    const int total = h * h;
+    const int total = M.h[b] * M.h[b];
     const int lo = blockIdx.y * ASM_CHUNK, hi = min(total, lo + ASM_CHUNK);
     if (lo >= hi) return;
-    const bool corner = b == M.N - 1;
-    const int rows = corner ? 0 : Gm.row_ptr[b + 1] - Gm.row_ptr[b];
-    const double* Xb = XG + (corner ? 0 : Gm.x_off[b]);
-    const int* rid = Gm.rows + (corner ? 0 : Gm.row_ptr[b]);
-    const long long fo = M.front_off[b];
-    const int start = M.start[b];
-    for (int idx = lo + threadIdx.x; idx < hi; idx += NT) {
-        const int r = idx % h, c = idx / h;
-        if (r < c) continue;
-        double s = 0.0;
-        for (int k = 0; k < rows; ++k) s += Xb[r + (long long)k * h] * zinv[rid[k]] * Xb[c + (long long)k * h];
-        double v = Pf[fo + idx] + delta_inv * AtAf[fo + idx] + s;
-        if (r == c && c < w) v += x_reg[start + c];
-        F[fo + idx] = v;
-    }
+    msdev::assemble_stage<NT>(M, Gm, XG, Pf, AtAf, zinv, x_reg, delta_inv, F, b, lo, hi);
 }
 
-// position inside front b of the t-th row of the update matrix carried from stage b-1 ([off_{b-1} | arrow])
-__device__ __forceinline__ int carry_row(int t, int off_prev, int w, int offb, bool corner)
-{
-    if (t < off_prev) return t;
-    return corner ? t - off_prev : w + offb + (t - off_prev);
-}
-
-// One workgroup walks the block-tridiagonal-arrow chain (factor_kkt, :1253-1352).  Per stage b:
-//   front += carried update;  [L_b; C_b; F_b] = panel Cholesky of the first w_b columns;
-//   carried update = trailing block - [C_b; F_b][C_b; F_b]^T;  inverse of L_b for the solves.
-// LDS = true: front, carried update and inverse live in LDS; false: everything in place in HBM/L2.
 template <bool LDS>
 __global__ __launch_bounds__(NT) void k_ms_factor(MsMeta M, double* __restrict__ fronts, double* __restrict__ pan, int fcap, int lofs, int li_in_lds)
 {
     extern __shared__ double sm[];
-    const int tid = threadIdx.x;
-    const int N = M.N;
-    int u_prev = 0, off_prev = 0, ldu = 0;
-    double* Usrc = nullptr;
-    for (int b = 0; b < N; ++b) {
-        const int h = M.h[b], w = M.w[b];
-        if (h == 0) break;  // no arrow corner
-        const bool corner = b == N - 1;
-        const int offb = M.off[b];
-        const int u = h - w;
-        double* Fg = fronts + M.front_off[b];
-        double* P = pan + M.pan_off[b];
-        double* Li = P + (long long)h * w;  // w x w inverse of L_b, written straight to its final place
-        double* F;
-        if constexpr (LDS) {
-            F = sm;
-            for (int idx = tid; idx < h * h; idx += NT) F[idx] = Fg[idx];
-            __syncthreads();
-        } else {
-            F = Fg;
-        }
-        const int ld = h;
-        if (u_prev > 0) {  // extend-add of the carried update matrix (distinct targets -> no conflicts)
-            for (int idx = tid; idx < u_prev * u_prev; idx += NT) {
-                const int i = idx % u_prev, j = idx / u_prev;
-                if (i < j) continue;
-                F[carry_row(i, off_prev, w, offb, corner) + carry_row(j, off_prev, w, offb, corner) * ld] += Usrc[i + j * ldu];
-            }
-            __syncthreads();
-        }
-        // right-looking Cholesky of the h x w column panel
-        for (int j = 0; j < w; ++j) {
-            const double d = F[j + j * ld];
-            const double inv = d > 0.0 ? 1.0 / sqrt(d) : 0.0;
-            for (int r = j + 1 + tid; r < h; r += NT) F[r + j * ld] *= inv;
-            __syncthreads();
-            if (tid == 0) F[j + j * ld] = d * inv;
-            const int nc = w - j - 1, nr = h - j - 1;
-            for (int idx = tid; idx < nc * nr; idx += NT) {
-                const int c = j + 1 + idx / nr, r = j + 1 + idx % nr;
-                if (r >= c) F[r + c * ld] -= F[r + j * ld] * F[c + j * ld];
-            }
-            __syncthreads();
-        }
-        // wave 0: explicit inverse of L_b (lane c solves L X = e_c by forward substitution, X staged in LDS when it fits);
-        // waves 1-3: Schur complement of the panel
-        double* Udst;
-        int ldud;
-        if constexpr (LDS) { Udst = sm + fcap; ldud = u; } else { Udst = F + w + w * ld; ldud = ld; }
-        double* Xb = li_in_lds ? sm + lofs : Li;
-        if (tid < 64) {
-            for (int c = tid; c < w; c += 64) {
-                double* X = Xb + c * w;
-                for (int r = 0; r < c; ++r) X[r] = 0.0;
-                const double dc = F[c + c * ld];
-                X[c] = dc != 0.0 ? 1.0 / dc : 0.0;
-                for (int r = c + 1; r < w; ++r) {
-                    double s = 0.0;
-                    for (int k = c; k < r; ++k) s += F[r + k * ld] * X[k];
-                    const double dr = F[r + r * ld];
-                    X[r] = dr != 0.0 ? -s / dr : 0.0;
-                }
-            }
-        } else {
-            for (int idx = tid - 64; idx < u * u; idx += NT - 64) {
-                const int i = idx % u, j = idx / u;
-                if (i < j) continue;
-                double s = F[(w + i) + (w + j) * ld];
-                for (int k = 0; k < w; ++k) s -= F[(w + i) + k * ld] * F[(w + j) + k * ld];
-                Udst[i + j * ldud] = s;
-            }
-            // factor panel to HBM for the solves
-            for (int idx = tid - 64; idx < h * w; idx += NT - 64) P[idx] = F[idx];
-        }
-        __syncthreads();
-        if (li_in_lds) {
-            for (int idx = tid; idx < w * w; idx += NT) Li[idx] = Xb[idx];
-            __syncthreads();
-        }
-        u_prev = u; off_prev = offb; Usrc = Udst; ldu = ldud;
-    }
+    msdev::factor_chain<NT, LDS>(M, fronts, pan, sm, fcap, lofs, li_in_lds);
 }
 
-// Forward and backward block substitution in one launch (solve_llt_in_place, :1709-1816); x is overwritten.
 template <bool LDS>
-__global__ __launch_bounds__(NT) void k_ms_solve(MsMeta M, const double* __restrict__ pan, double* __restrict__ x, int pcap, int hcap)
+__global__ __launch_bounds__(NT) void k_ms_solve(MsMeta M, const double* __restrict__ pan, double* __restrict__ x, int hcap)
 {
     extern __shared__ double sm[];
-    double* xs = sm;           // hcap
-    double* ys = sm + hcap;    // hcap
-    double* Pl = sm + 2 * hcap;  // pcap (LDS variant only)
-    const int tid = threadIdx.x;
-    const int N = M.N, n = M.n, arrow = M.arrow;
-    for (int pass = 0; pass < 2; ++pass) {
-        for (int bb = 0; bb < N; ++bb) {
-            const int b = pass == 0 ? bb : N - 1 - bb;
-            const int h = M.h[b], w = M.w[b];
-            if (h == 0) continue;
-            const int u = h - w, offb = M.off[b], start = M.start[b];
-            const double* Pg = pan + M.pan_off[b];
-            const double* P;
-            if constexpr (LDS) {
-                const int cnt = h * w + w * w;
-                for (int idx = tid; idx < cnt; idx += NT) Pl[idx] = Pg[idx];
-                P = Pl;
-            } else {
-                P = Pg;
-            }
-            const double* Li = P + (long long)h * w;
-            if (pass == 0) {
-                for (int r = tid; r < w; r += NT) xs[r] = x[start + r];
-                __syncthreads();
-                // y_b = L_b^{-1} x_b
-                for (int r = tid; r < w; r += NT) {
-                    double s = 0.0;
-                    for (int k = 0; k <= r; ++k) s += Li[r + k * w] * xs[k];
-                    ys[r] = s;
-                }
-                __syncthreads();
-                for (int r = tid; r < w; r += NT) x[start + r] = ys[r];
-                // x_{b+1}[0:off] -= C_b y_b ;  x_N -= F_b y_b
-                for (int t = tid; t < u; t += NT) {
-                    double s = 0.0;
-                    for (int k = 0; k < w; ++k) s += P[(w + t) + k * h] * ys[k];
-                    const int tgt = t < offb ? start + w + t : n - arrow + (t - offb);
-                    x[tgt] -= s;
-                }
-                __syncthreads();
-            } else {
-                for (int r = tid; r < w; r += NT) xs[r] = x[start + r];
-                for (int t = tid; t < u; t += NT) xs[w + t] = x[t < offb ? start + w + t : n - arrow + (t - offb)];
-                __syncthreads();
-                // z = x_b - C_b^T x_{b+1}[0:off] - F_b^T x_N
-                for (int k = tid; k < w; k += NT) {
-                    double s = xs[k];
-                    for (int t = 0; t < u; ++t) s -= P[(w + t) + k * h] * xs[w + t];
-                    ys[k] = s;
-                }
-                __syncthreads();
-                // x_b = L_b^{-T} z
-                for (int r = tid; r < w; r += NT) {
-                    double s = 0.0;
-                    for (int k = r; k < w; ++k) s += Li[k + r * w] * ys[k];
-                    x[start + r] = s;
-                }
-                __syncthreads();
-            }
-        }
-    }
-    (void)pcap;
+    msdev::solve_chain<NT, LDS>(M, pan, x, sm, hcap);
 }
 
 template <class T>
@@ -345,8 +155,8 @@ public:
         const int tk = prof_.begin(2, st_);
         const double delta_inv = 1.0 / delta_;
         ops_.fold_rhs(rhs_x, rhs_y, rhs_z, zinv_.p, delta_inv, lhs_x, st_);
-        if (solve_in_lds_) hipLaunchKernelGGL(k_ms_solve<true>, dim3(1), dim3(NT), solve_lds_bytes_, st_, meta(), pan_.p, lhs_x, pcap_, hcap_);
-        else hipLaunchKernelGGL(k_ms_solve<false>, dim3(1), dim3(NT), 2 * hcap_ * (int)sizeof(double), st_, meta(), pan_.p, lhs_x, pcap_, hcap_);
+        if (solve_in_lds_) hipLaunchKernelGGL(k_ms_solve<true>, dim3(1), dim3(NT), solve_lds_bytes_, st_, meta(), pan_.p, lhs_x, hcap_);
+        else hipLaunchKernelGGL(k_ms_solve<false>, dim3(1), dim3(NT), 2 * hcap_ * (int)sizeof(double), st_, meta(), pan_.p, lhs_x, hcap_);
         ops_.recover_duals(lhs_x, rhs_y, rhs_z, zinv_.p, delta_inv, lhs_y, lhs_z, st_);
         PQ_HIP(hipGetLastError());
         prof_.end(2, tk, st_);

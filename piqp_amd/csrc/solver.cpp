@@ -744,7 +744,7 @@ void Solver::update_residuals_r()
     m_info.dual_prox_inf = dual_prox_inf() * m_info.rho;
 }
 
-static bool verify_settings(const pq_settings& s)
+bool verify_settings(const pq_settings& s)
 {
     // settings.hpp:84-106
     return s.rho_init > 0 && s.delta_init > 0 && s.eps_abs > 0 && s.eps_rel >= 0 && s.eps_duality_gap_abs > 0 && s.eps_duality_gap_rel >= 0 &&

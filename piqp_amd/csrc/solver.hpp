@@ -118,6 +118,8 @@ private:
     int trace_max_ = 0, trace_rows_ = 0;
 };
 
+bool verify_settings(const pq_settings& s);  // settings.hpp:84-106
+
 std::unique_ptr<HostData> make_dense_host_data(int n, int p, int m, const double* P, const double* c, const double* A, const double* b, const double* G, const double* h_l,
                                                const double* h_u, const double* x_l, const double* x_u);
 std::unique_ptr<HostData> make_sparse_host_data(int n, int p, int m, const int* Pp, const int* Pi, const double* Px, const double* c, const int* Ap, const int* Ai,

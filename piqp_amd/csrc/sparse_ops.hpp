@@ -17,7 +17,10 @@ template <class T>
 inline void upload_vec(DBuf<T>& d, const std::vector<T>& h, hipStream_t st)
 {
     d.alloc(h.size() ? h.size() : 1);
-    if (!h.empty()) PQ_HIP(hipMemcpyAsync(d.p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, st));
+    if (!h.empty()) {
+        PQ_HIP(hipMemcpyAsync(d.p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, st));
+        PQ_HIP(hipStreamSynchronize(st));  // setup-time only; `h` is often a temporary
+    }
 }
 
 class CscOperators {

@@ -65,3 +65,67 @@ def random_vars(n, p, m, rng, positive=False):
         else:
             v[k] = rng.standard_normal(sz)
     return v
+
+
+def mpc_batch(batch, T=40, nx=2, nu=1, seed=1000, shuffle_rows=False):
+    """BASELINE configs[3] (C4): `batch` independent linear-MPC QPs of identical structure.
+    Variables [x_0,u_0,...,x_{T-1},u_{T-1}] (n = T(nx+nu)); p = T*nx equality rows (x_0 = x_init and
+    x_{k+1} = A_d x_k + B_d u_k); box bounds on every variable; Q, R diagonal positive definite; no general
+    inequalities.  Per instance: own (A_d, B_d) perturbation, Q, R, x_init (seed + instance).
+    Returns shared scipy patterns and stacked value arrays in the patterns' sorted-CSC order."""
+    import scipy.sparse as sp
+    nz = nx + nu
+    n, p = T * nz, T * nx
+    rows, cols = [], []
+    for i in range(nx):                       # x_0 = x_init
+        rows.append(i); cols.append(i)
+    for k in range(T - 1):
+        for i in range(nx):
+            r = nx + k * nx + i
+            for j in range(nz):
+                rows.append(r); cols.append(k * nz + j)
+            rows.append(r); cols.append((k + 1) * nz + i)
+    rows, cols = np.array(rows), np.array(cols)
+    perm = np.arange(p)
+    if shuffle_rows:
+        perm = np.random.default_rng(seed - 1).permutation(p)
+        rows = perm[rows]
+    order = np.lexsort((rows, cols))          # CSC order: by column, then row
+    A_pattern = sp.csc_matrix((np.ones(len(rows)), (rows, cols)), shape=(p, n))
+    A_pattern.sort_indices()
+    P_pattern = sp.identity(n, format="csc")
+    A_base = np.eye(nx) + 0.1 * np.random.default_rng(seed - 2).standard_normal((nx, nx))
+    A_base *= 0.95 / max(1.0, np.abs(np.linalg.eigvals(A_base)).max())   # (marginally) stable: every instance stays feasible
+    B_base = np.random.default_rng(seed - 3).standard_normal((nx, nu))
+    Pv = np.zeros((batch, n)); Av = np.zeros((batch, len(rows))); c = np.zeros((batch, n)); b = np.zeros((batch, p))
+    xl = np.zeros((batch, n)); xu = np.zeros((batch, n))
+    for inst in range(batch):
+        rng = np.random.default_rng(seed + inst)
+        Ad = A_base + 0.02 * rng.standard_normal((nx, nx)); Bd = B_base + 0.05 * rng.standard_normal((nx, nu))
+        q = rng.uniform(0.5, 2.0, nx); r = rng.uniform(0.05, 0.5, nu)
+        Pv[inst] = np.tile(np.concatenate([q, r]), T)
+        c[inst] = 0.1 * rng.standard_normal(n)
+        vals = [1.0] * nx
+        for k in range(T - 1):
+            for i in range(nx):
+                vals.extend(list(Ad[i]) + list(Bd[i]) + [-1.0])
+        Av[inst] = np.array(vals)[order]
+        bi = np.zeros(p); bi[:nx] = rng.uniform(-0.8, 0.8, nx)
+        b[inst] = bi if not shuffle_rows else _scatter(bi, perm)
+        lim = np.tile(np.concatenate([np.full(nx, 3.0), np.full(nu, 0.3)]), T)
+        xl[inst], xu[inst] = -lim, lim
+    return dict(P_pattern=P_pattern, P_values=Pv, c=c, A_pattern=A_pattern, A_values=Av, b=b, x_l=xl, x_u=xu, n=n, p=p)
+
+
+def _scatter(v, perm):
+    out = np.zeros_like(v)
+    out[perm] = v
+    return out
+
+
+def mpc_instance(mb, i):
+    """instance i of mpc_batch as scipy matrices / vectors (for the single-QP solvers)"""
+    import scipy.sparse as sp
+    P = mb["P_pattern"].copy(); P.data = mb["P_values"][i].copy()
+    A = mb["A_pattern"].copy(); A.data = mb["A_values"][i].copy()
+    return (sp.csc_matrix(P), mb["c"][i], sp.csc_matrix(A), mb["b"][i], None, None, None, mb["x_l"][i], mb["x_u"][i])

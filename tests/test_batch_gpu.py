@@ -1,0 +1,115 @@
+"""GPU parity tests of the batched solver (pq_batch_*): every instance of a batch must end with the status, the iteration
+count and the solution the CPU oracle (restatement of the reference's SparseSolver with kkt_solver = sparse_multistage)
+reaches on that instance alone.  BASELINE configs[3]: linear-MPC QPs n = 120 (40 stages of n_x = 2, n_u = 1)."""
+import numpy as np
+import pytest
+
+from qp_gen import mpc_batch, mpc_instance
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_solve(orc, args):
+    s = orc.Solver()
+    s.settings.kkt_solver = orc.SPARSE_MULTISTAGE
+    assert s.setup(*args, sparse=True)
+    st = s.solve()
+    return st, s.info.iter, s.info.primal_obj, s.result()
+
+
+def _run_batch(hip, mb):
+    bs = hip.BatchSparseSolver()
+    assert bs.setup(mb["P_pattern"], mb["P_values"], mb["c"], mb["A_pattern"], mb["A_values"], mb["b"], x_l=mb["x_l"], x_u=mb["x_u"])
+    solved = bs.solve()
+    return bs, solved
+
+
+@pytest.mark.parametrize("shuffle", [False, True])
+def test_mpc_batch_matches_oracle_per_instance(hip, orc, shuffle):
+    B = 24
+    mb = mpc_batch(B, seed=1000, shuffle_rows=shuffle)
+    bs, solved = _run_batch(hip, mb)
+    assert solved == B
+    x, y, zbl, zbu = bs.result("x"), bs.result("y"), bs.result("z_bl"), bs.result("z_bu")
+    k = orc.KKT(orc.Data.sparse(*mpc_instance(mb, 0)), kind="multistage")
+    assert np.array_equal(bs.block_info(), k.block_info())
+    for i in range(B):
+        st, it, obj, ref = _oracle_solve(orc, mpc_instance(mb, i))
+        info = bs.info(i)
+        assert info.status == st == 1
+        assert info.iter == it, (i, info.iter, it)
+        assert abs(info.primal_obj - obj) <= 1e-8 * (1 + abs(obj))
+        scale = 1 + np.abs(ref["x"]).max()
+        assert np.abs(x[i] - ref["x"]).max() <= 1e-7 * scale
+        assert np.abs(y[i] - ref["y"]).max() <= 1e-6 * (1 + np.abs(ref["y"]).max())
+        assert np.abs(zbl[i] - ref["z_bl"]).max() <= 1e-6 * (1 + np.abs(ref["z_bl"]).max())
+        assert np.abs(zbu[i] - ref["z_bu"]).max() <= 1e-6 * (1 + np.abs(ref["z_bu"]).max())
+
+
+def test_batch_equals_single_qp_device_solver(hip):
+    """the batched kernel and the host-driven single-QP solver run the same algorithm on the same backend"""
+    B = 6
+    mb = mpc_batch(B, T=12, nx=3, nu=2, seed=77)
+    bs, solved = _run_batch(hip, mb)
+    assert solved == B
+    x = bs.result("x")
+    for i in range(B):
+        s = hip.SparseSolver(); s.settings.kkt_solver = hip.SPARSE_MULTISTAGE
+        assert s.setup(*mpc_instance(mb, i))
+        assert s.solve() == 1
+        assert s.info.iter == bs.info(i).iter
+        assert np.abs(s.result()["x"] - x[i]).max() <= 1e-8 * (1 + np.abs(x[i]).max())
+
+
+def test_batch_properties_at_full_size(hip):
+    """BASELINE configs[3] at full size (8192 QPs): size-independent properties -- every instance solved, primal feasibility
+    and bound satisfaction of the returned points, and instance i of the big batch == instance i of a small batch (bitwise:
+    instances never interact)"""
+    B = 8192
+    mb = mpc_batch(B, seed=1000)
+    bs, solved = _run_batch(hip, mb)
+    assert solved == B
+    x = bs.result("x")
+    A = mb["A_pattern"].copy()
+    worst = 0.0
+    for i in range(0, B, 257):
+        A.data = mb["A_values"][i]
+        worst = max(worst, np.abs(A @ x[i] - mb["b"][i]).max())
+        assert np.all(x[i] >= mb["x_l"][i] - 1e-6) and np.all(x[i] <= mb["x_u"][i] + 1e-6)
+    assert worst <= 1e-6
+    small = {k: (v[:16] if isinstance(v, np.ndarray) and v.ndim == 2 else v) for k, v in mb.items()}
+    bs2, solved2 = _run_batch(hip, small)
+    assert solved2 == 16
+    assert np.array_equal(bs2.result("x"), x[:16])
+    assert np.array_equal(bs2.iterations(), bs.iterations()[:16])
+
+
+def test_batch_with_general_inequalities_and_one_sided_bounds(hip, orc):
+    """m > 0 with one-sided rows and partially bounded variables exercises every branch of the in-kernel KKTSystem"""
+    import scipy.sparse as sp
+    B = 8
+    mb = mpc_batch(B, T=10, nx=2, nu=2, seed=5)
+    n, p = mb["n"], mb["p"]
+    rng = np.random.default_rng(3)
+    m = 12
+    rows = np.repeat(np.arange(m), 2)
+    cols = np.concatenate([[4 * (r % 10) + 0, 4 * (r % 10) + 2] for r in range(m)])
+    G_pattern = sp.csc_matrix((np.ones(2 * m), (rows, cols)), shape=(m, n)); G_pattern.sort_indices()
+    Gv = rng.standard_normal((B, G_pattern.nnz))
+    h_l = np.tile(np.where(np.arange(m) % 3 == 0, -np.inf, -1.0), (B, 1)) * np.ones((B, m))
+    h_u = np.tile(np.where(np.arange(m) % 3 == 1, np.inf, 1.5), (B, 1)) * np.ones((B, m))
+    x_l = mb["x_l"].copy(); x_l[:, ::3] = -np.inf
+    x_u = mb["x_u"].copy(); x_u[:, 1::4] = np.inf
+    bs = hip.BatchSparseSolver()
+    assert bs.setup(mb["P_pattern"], mb["P_values"], mb["c"], mb["A_pattern"], mb["A_values"], mb["b"], G_pattern, Gv, h_l, h_u, x_l, x_u)
+    assert bs.solve() == B
+    x, zl, zu = bs.result("x"), bs.result("z_l"), bs.result("z_u")
+    for i in range(B):
+        P, c, A, b, _, _, _, _, _ = mpc_instance(mb, i)
+        G = G_pattern.copy(); G.data = Gv[i].copy()
+        st, it, obj, ref = _oracle_solve(orc, (P, c, A, b, sp.csc_matrix(G), h_l[i], h_u[i], x_l[i], x_u[i]))
+        assert st == 1 and bs.info(i).status == 1
+        assert bs.info(i).iter == it
+        assert np.abs(x[i] - ref["x"]).max() <= 1e-7 * (1 + np.abs(ref["x"]).max())
+        assert np.abs(zl[i] - ref["z_l"]).max() <= 1e-6 * (1 + np.abs(ref["z_l"]).max())
+        assert np.abs(zu[i] - ref["z_u"]).max() <= 1e-6 * (1 + np.abs(ref["z_u"]).max())

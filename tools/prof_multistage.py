@@ -1,0 +1,100 @@
+#!/usr/bin/env python3
+"""Stage timings of the sparse_multistage backend on fixtures / synthetic chains (device) next to the oracle (CPU).
+
+  python tools/prof_multistage.py [--reps 50]
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import scipy.sparse as sp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def mpc_chain(nx, nu, T, seed):
+    rng = np.random.default_rng(seed)
+    nz = nx + nu
+    n = T * nz + nx
+    Ad = np.eye(nx) + 0.1 * rng.standard_normal((nx, nx)); Bd = rng.standard_normal((nx, nu))
+    rows, cols, vals = [], [], []
+    for t in range(T):
+        for i in range(nx):
+            for j in range(nx):
+                rows.append(t * nx + i); cols.append(t * nz + j); vals.append(Ad[i, j])
+            for j in range(nu):
+                rows.append(t * nx + i); cols.append(t * nz + nx + j); vals.append(Bd[i, j])
+            rows.append(t * nx + i); cols.append((t + 1) * nz + i); vals.append(-1.0)
+    p = T * nx
+    A = sp.csc_matrix((vals, (rows, cols)), shape=(p, n))
+    P = sp.diags(rng.uniform(0.5, 2.0, n), format="csc")
+    return (P, rng.standard_normal(n), A, np.zeros(p), None, None, None, -np.ones(n), np.ones(n))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reps", type=int, default=50)
+    args = ap.parse_args()
+    import torch  # noqa: F401
+    import piqp_amd as hip
+    from oracle import pyorc as orc
+    from qp_gen import random_vars
+    from qp_io import load_qp
+
+    def fixture(name):
+        q = load_qp(name)
+        return (q["P"], q["c"], q["A"], q["b"], q["G"], q["h_l"], q["h_u"], q["x_l"], q["x_u"])
+
+    cases = [("c0_scenario_mpc", fixture("qp_c0_scenario_mpc")), ("scenario_mpc", fixture("qp_scenario_mpc")), ("chain_mass_sqp", fixture("qp_chain_mass_sqp")),
+             ("robot_arm_sqp", fixture("qp_robot_arm_sqp")), ("mpc nx=2 nu=1 T=40", mpc_chain(2, 1, 40, 1)), ("mpc nx=12 nu=8 T=1000", mpc_chain(12, 8, 1000, 2)),
+             ("mpc nx=12 nu=8 T=5000", mpc_chain(12, 8, 5000, 3))]
+    for name, a in cases:
+        d = hip.SparseData(*a); od = orc.Data.sparse(*a)
+        n, p, m = od.n, od.p, od.m
+        rng = np.random.default_rng(0)
+        for ks, kname in ((hip.SPARSE_MULTISTAGE, "multistage"), (hip.SPARSE_LDLT, "sparse_ldlt")):
+            k = hip.KKTSystem(d, hip.default_settings(kkt_solver=ks))
+            ko = orc.KKTSystem(od, orc.Settings(kkt_solver=ks))
+            state = random_vars(n, p, m, rng, positive=True)
+            rhs = random_vars(n, p, m, rng)
+            be = k.backend()
+            for _ in range(3):
+                k.update_scalings_and_factor(False, 1e-6, 1e-4, state); k.solve(rhs)
+            be.set_profiling(True)
+            k.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.reps):
+                k.update_scalings_and_factor(False, 1e-6, 1e-4, state)
+            k.synchronize()
+            t_fac = (time.perf_counter() - t0) / args.reps
+            t0 = time.perf_counter()
+            for _ in range(args.reps):
+                k.solve(rhs)
+            k.synchronize()
+            t_sol = (time.perf_counter() - t0) / args.reps
+            be.set_profiling(False)
+            prof = [be.get_profile(s) for s in range(3)]
+            res, nrm = k.condensed_residual()
+            t0 = time.perf_counter()
+            reps_o = max(3, args.reps // 5)
+            for _ in range(reps_o):
+                ko.update_scalings_and_factor(False, 1e-6, 1e-4, state)
+            o_fac = (time.perf_counter() - t0) / reps_o
+            t0 = time.perf_counter()
+            for _ in range(reps_o):
+                ko.solve(rhs)
+            o_sol = (time.perf_counter() - t0) / reps_o
+            bi = be.block_info() if ks == hip.SPARSE_MULTISTAGE else None
+            extra = f" stages={len(bi) - 1} maxw={bi[:-1, 1].max()} arrow={bi[-1, 1]}" if bi is not None else ""
+            print(f"{name:24s} {kname:11s} n={n} p={p} m={m}{extra}\n"
+                  f"    device: factor call {t_fac * 1e6:8.1f} us (assemble {prof[0][0] / max(prof[0][1], 1) * 1e3:7.1f} us, chain {prof[1][0] / max(prof[1][1], 1) * 1e3:7.1f} us)"
+                  f"  solve call {t_sol * 1e6:8.1f} us (backend {prof[2][0] / max(prof[2][1], 1) * 1e3:7.1f} us x{prof[2][1] / args.reps:.1f})  rel.res {res / nrm:.1e}\n"
+                  f"    oracle: factor {o_fac * 1e6:8.1f} us  solve {o_sol * 1e6:8.1f} us", flush=True)
+
+
+if __name__ == "__main__":
+    main()
