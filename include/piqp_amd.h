@@ -277,6 +277,9 @@ const pq_info *pq_batch_info(const pq_batch *s, int instance); /* result().info 
 int pq_batch_get_result(pq_batch *s, int field, double *out_host);
 int pq_batch_dims(const pq_batch *s, int *batch, int *n, int *p, int *m);
 int pq_batch_block_info(const pq_batch *s, int *out_host, int capacity); /* as pq_kkt_multistage_block_info */
+/* in-kernel device-clock seconds of one instance's last solve: out8 = {KKT assembly, chain factorisation, chain
+ * substitution, KKTSystem::solve total, residual updates, whole solve, 0, 0} */
+int pq_batch_get_profile(pq_batch *s, int instance, double *out8);
 /* hipEvent time of the last solve's kernel and the workgroup size used per QP */
 int pq_batch_last_kernel_ms(const pq_batch *s, double *ms, int *threads_per_qp);
 

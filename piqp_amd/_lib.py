@@ -80,7 +80,7 @@ SYMBOLS = [
     "pq_solver_setup_sparse", "pq_solver_update_dense", "pq_solver_update_sparse", "pq_solver_solve", "pq_solver_info",
     "pq_solver_get_result", "pq_solver_dims", "pq_solver_set_trace", "pq_solver_trace_rows",
     "pq_batch_create", "pq_batch_destroy", "pq_batch_settings", "pq_batch_setup_sparse", "pq_batch_solve", "pq_batch_info", "pq_batch_get_result",
-    "pq_batch_dims", "pq_batch_block_info", "pq_batch_last_kernel_ms",
+    "pq_batch_dims", "pq_batch_block_info", "pq_batch_get_profile", "pq_batch_last_kernel_ms",
     "pq_microbench_mfma_f64", "pq_microbench_hbm_copy",
 ]
 
@@ -138,6 +138,7 @@ def load():
     L.pq_batch_get_result.argtypes = [vp, C.c_int, vp]
     L.pq_batch_dims.argtypes = [vp, _ip, _ip, _ip, _ip]
     L.pq_batch_block_info.argtypes = [vp, vp, C.c_int]
+    L.pq_batch_get_profile.argtypes = [vp, C.c_int, vp]
     L.pq_batch_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_double), _ip]
     L.pq_kkt_set_profiling.argtypes = [vp, C.c_int]
     L.pq_kkt_get_profile.argtypes = [vp, C.c_int, _dp, _ip]

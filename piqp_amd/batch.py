@@ -92,6 +92,12 @@ class BatchSparseSolver(_Handle):
         check(self.L.pq_batch_block_info(self.h, out.ctypes.data, N))
         return out
 
+    def profile(self, i):
+        """device-clock seconds of instance i: dict(assemble, factor, chain_solve, kkt_solve, residuals, total)"""
+        out = np.zeros(8)
+        check(self.L.pq_batch_get_profile(self.h, i, out.ctypes.data))
+        return dict(zip(("assemble", "factor", "chain_solve", "kkt_solve", "residuals", "total"), out[:6]))
+
     def last_kernel_ms(self):
         ms, nt = C.c_double(), C.c_int()
         check(self.L.pq_batch_last_kernel_ms(self.h, C.byref(ms), C.byref(nt)))

@@ -32,8 +32,10 @@ namespace {
 
 using msdev::GroupMeta;
 using msdev::MsMeta;
+using msdev::PackedMeta;
 
-constexpr int LDS_LIMIT_BYTES = 159 * 1024;
+constexpr int LDS_LIMIT_BYTES = 152 * 1024;  // dynamic LDS budget (the kernel also keeps ~3 KB of static LDS)
+constexpr int RESIDENT_LIMIT_BYTES = 40 * 1024;  // keeps >= 4 workgroups per CU in resident mode
 
 // fields of a Variables set (variables.hpp:19-105)
 enum { FX = 0, FY, FZL, FZU, FZBL, FZBU, FSL, FSU, FSBL, FSBU, NF };
@@ -55,6 +57,8 @@ struct BatchShared {
     GroupMeta GA, GG;
     const long long *P_dst, *A_dst, *G_dst;
     int fcap, lofs, hcap, chain_lds_doubles;
+    int meta_ofs;  // LDS offset (doubles) of the per-stage structure tables copied in at kernel start
+    int res_f, res_pan, res_x, res_chain;  // MODE_RESIDENT: LDS offsets (doubles) of the fronts, the factor panels, the solve vector, chain scratch
     long long off[NSLOT];
     long long stride;
     pq_settings set;
@@ -80,20 +84,50 @@ __device__ __forceinline__ double wg_reduce(double v, Op op, double* red)
     return v;
 }
 
-template <int NT, bool LDS>
+// in-kernel stage clock (wall_clock64, 100 MHz): [0] assemble, [1] chain factor, [2] chain solve, [3] KKTSystem::solve total,
+// [4] residuals, [5] whole solve
+enum { T_ASM = 0, T_FAC, T_CHAIN, T_KS, T_RES, T_ALL, NPROF = 8 };
+
+struct IpmState {
+    long long prof[NPROF];
+    pq_info info;
+    double rz_c, rz_c_inv, ks_rho, ks_delta, be_delta;
+    int refine_enabled, ks_use_refine;
+};
+
+// MODE: where the multistage chain keeps its working set
+//   MODE_HBM       fronts and factor panels in HBM/L2, only the diagonal-block inverse staged in LDS (wide stages)
+//   MODE_STAGED    the current stage's front / panel is copied into LDS, the arenas stay in HBM
+//   MODE_RESIDENT  ALL fronts, ALL factor panels and the solve vector live in LDS for the whole solve (small QPs:
+//                  the chain never waits on HBM)
+enum { MODE_HBM = 0, MODE_STAGED = 1, MODE_RESIDENT = 2 };
+
+template <int NT, int MODE>
 struct Ipm {
+    static constexpr bool LDS = MODE == MODE_STAGED;
+    static constexpr bool RES = MODE == MODE_RESIDENT;
     const BatchShared& S;
     double* base;
     double* sm;   // chain workspace (dynamic LDS)
     double* red;  // reduction scratch
-    double rz_c, rz_c_inv;
-    pq_info info;
-    bool refine_enabled = false;
-    // KKTSystem state
-    double ks_rho = 0.0, ks_delta = 0.0, be_delta = 1.0;
-    bool ks_use_refine = false;
+    // Scalar solver state.  Every thread computes the same scalars; they are kept ONCE PER WAVE in LDS instead of in
+    // per-lane private memory (a 350-byte Info per lane would turn into scratch and throttle occupancy).  A wave only
+    // ever touches its own copy, so there are no cross-wave hazards.
+    IpmState& st;
+    pq_info& info;
+    double& rz_c;
+    double& rz_c_inv;
+    double& ks_rho;
+    double& ks_delta;
+    double& be_delta;
+    int& refine_enabled;
+    int& ks_use_refine;
 
-    __device__ Ipm(const BatchShared& s, double* b, double* sm_, double* red_) : S(s), base(b), sm(sm_), red(red_) {}
+    __device__ Ipm(const BatchShared& s, double* b, double* sm_, double* red_, IpmState& state)
+        : S(s), base(b), sm(sm_), red(red_), st(state), info(state.info), rz_c(state.rz_c), rz_c_inv(state.rz_c_inv), ks_rho(state.ks_rho), ks_delta(state.ks_delta),
+          be_delta(state.be_delta), refine_enabled(state.refine_enabled), ks_use_refine(state.ks_use_refine)
+    {
+    }
 
     __device__ __forceinline__ double* at(int slot) const { return base + S.off[slot]; }
     __device__ __forceinline__ double* v(int set, int f) const { return base + S.off[set + f]; }
@@ -145,44 +179,69 @@ struct Ipm {
     }
 
     // ---- multistage backend (multistage_kkt.hpp:180-288) -----------------------------------------------------
-    __device__ void be_factor(double delta, const double* x_reg, const double* z_reg)
+    // LDS-derived views: built from the `extern __shared__` symbol (not from the generic pointers stored in this object) so
+    // that address-space inference turns the chain's accesses into ds_read / ds_write
+    static __device__ __forceinline__ PackedMeta packed_meta(const BatchShared& s, double* dyn)
     {
+        const int* mi = reinterpret_cast<const int*>(dyn + s.meta_ofs);
+        return PackedMeta{s.M.N, s.M.arrow, s.M.n, mi, reinterpret_cast<const long long*>(mi + 4 * s.M.N)};
+    }
+
+    __device__ __noinline__ void be_factor(double delta, const double* x_reg, const double* z_reg)
+    {
+        extern __shared__ double dyn[];
+        const PackedMeta PM = packed_meta(S, dyn);
+        double* F = RES ? dyn + S.res_f : at(B_F);
+        double* PAN = RES ? dyn + S.res_pan : at(B_PAN);
+        double* CH = RES ? dyn + S.res_chain : dyn;
         double* zinv = at(B_ZINV);
         for (int i = tid(); i < S.m; i += NT) zinv[i] = 1.0 / z_reg[i];
         __syncthreads();
         be_delta = delta;
         const double delta_inv = 1.0 / delta;
-        for (int b = 0; b < S.M.N; ++b) {
-            const int h = S.M.h[b];
-            msdev::assemble_stage<NT>(S.M, S.GG, at(B_XG), at(B_PF), at(B_ATAF), zinv, x_reg, delta_inv, at(B_F), b, 0, h * h);
+        const long long t0 = wall_clock64();
+        for (int b = 0; b < PM.N; ++b) {
+            const int h = PM.H(b);
+            msdev::assemble_stage<NT>(PM, S.GG, at(B_XG), at(B_PF), at(B_ATAF), zinv, x_reg, delta_inv, F, b, 0, h * h);
         }
         __syncthreads();
-        msdev::factor_chain<NT, LDS>(S.M, at(B_F), at(B_PAN), sm, S.fcap, S.lofs, 1);
+        const long long t1 = wall_clock64();
+        msdev::factor_chain<NT, LDS>(PM, F, PAN, CH, S.fcap, S.lofs, 1);
         __syncthreads();
+        const long long t2 = wall_clock64();
+        st.prof[T_ASM] += t1 - t0; st.prof[T_FAC] += t2 - t1;
         info.n_factor++;
     }
-    __device__ void be_solve(const double* rhs_x, const double* rhs_y, const double* rhs_z, double* lhs_x, double* lhs_y, double* lhs_z)
+    __device__ __noinline__ void be_solve(const double* rhs_x, const double* rhs_y, const double* rhs_z, double* lhs_x, double* lhs_y, double* lhs_z)
     {
+        extern __shared__ double dyn[];
+        const PackedMeta PM = packed_meta(S, dyn);
+        const double* PAN = RES ? dyn + S.res_pan : at(B_PAN);
+        double* CH = RES ? dyn + S.res_chain : dyn;
         const double* zinv = at(B_ZINV);
         const double* Ax = at(D_ATX);
         const double* Gx = at(D_GTX);
         const double delta_inv = 1.0 / be_delta;
+        double* xw = RES ? dyn + S.res_x : lhs_x;  // the chain works on an LDS copy of x in resident mode
         for (int j = tid(); j < S.n; j += NT) {
             double sg = 0.0, sa = 0.0;
             for (int q = S.G_p[j]; q < S.G_p[j + 1]; ++q) { const int i = S.G_i[q]; sg += Gx[S.G_src[q]] * (zinv[i] * rhs_z[i]); }
             for (int q = S.A_p[j]; q < S.A_p[j + 1]; ++q) sa += Ax[S.A_src[q]] * rhs_y[S.A_i[q]];
-            lhs_x[j] = (rhs_x[j] + sg) + delta_inv * sa;
+            xw[j] = (rhs_x[j] + sg) + delta_inv * sa;
         }
         __syncthreads();
-        msdev::solve_chain<NT, LDS>(S.M, at(B_PAN), lhs_x, sm, S.hcap);
+        const long long t0 = wall_clock64();
+        msdev::solve_chain<NT, LDS>(PM, PAN, xw, CH, S.hcap);
+        st.prof[T_CHAIN] += wall_clock64() - t0;
+        if constexpr (RES) for (int j = tid(); j < S.n; j += NT) lhs_x[j] = xw[j];
         for (int k = tid(); k < S.p; k += NT) {
             double s = 0.0;
-            for (int q = S.AT_p[k]; q < S.AT_p[k + 1]; ++q) s += Ax[q] * lhs_x[S.AT_i[q]];
+            for (int q = S.AT_p[k]; q < S.AT_p[k + 1]; ++q) s += Ax[q] * xw[S.AT_i[q]];
             lhs_y[k] = delta_inv * s - delta_inv * rhs_y[k];
         }
         for (int i = tid(); i < S.m; i += NT) {
             double s = 0.0;
-            for (int q = S.GT_p[i]; q < S.GT_p[i + 1]; ++q) s += Gx[q] * lhs_x[S.GT_i[q]];
+            for (int q = S.GT_p[i]; q < S.GT_p[i + 1]; ++q) s += Gx[q] * xw[S.GT_i[q]];
             lhs_z[i] = (s - rhs_z[i]) * zinv[i];
         }
         __syncthreads();
@@ -191,7 +250,7 @@ struct Ipm {
 
     // ---- KKTSystem (kkt_system.hpp) -----------------------------------------------------------------------------
     // :143-211
-    __device__ bool ks_update_scalings_and_factor(bool iterative_refinement, double rho, double delta)
+    __device__ __noinline__ bool ks_update_scalings_and_factor(bool iterative_refinement, double rho, double delta)
     {
         const int n = S.n, m = S.m;
         ks_rho = rho; ks_delta = delta;
@@ -243,13 +302,13 @@ struct Ipm {
             for (int i = tid(); i < m; i += NT) z_reg_ref[i] += reg;
             __syncthreads();
         }
-        ks_use_refine = iterative_refinement;
+        ks_use_refine = iterative_refinement ? 1 : 0;
         be_factor(delta_reg, x_reg, z_reg_ref);
         return true;  // multistage_kkt.hpp:218
     }
 
     // :507-536 err = rhs - K_cond * lhs, returns |err|_inf (NaN-propagating)
-    __device__ double refine_error(const double* lx, const double* ly, const double* lz, const double* rx, const double* ry, const double* rz, double* ex, double* ey,
+    __device__ __noinline__ double refine_error(const double* lx, const double* ly, const double* lz, const double* rx, const double* ry, const double* rz, double* ex, double* ey,
                                    double* ez)
     {
         const int n = S.n, p = S.p, m = S.m;
@@ -300,7 +359,14 @@ struct Ipm {
     }
 
     // :213-369  (rhs, lhs = Variables sets)
-    __device__ bool ks_solve(int rhs, int lhs)
+    __device__ __noinline__ bool ks_solve(int rhs, int lhs)
+    {
+        const long long t_begin = wall_clock64();
+        const bool ok = ks_solve_impl(rhs, lhs);
+        st.prof[T_KS] += wall_clock64() - t_begin;
+        return ok;
+    }
+    __device__ __forceinline__ bool ks_solve_impl(int rhs, int lhs)
     {
         const int n = S.n, p = S.p, m = S.m;
         const double* xbs = at(D_XBS);
@@ -402,21 +468,21 @@ struct Ipm {
     }
 
     // ---- solver.hpp helpers --------------------------------------------------------------------------------------
-    __device__ double dot2(const double* a, const double* b, int cnt)
+    __device__ __noinline__ double dot2(const double* a, const double* b, int cnt)
     {
         double s = 0.0;
         for (int i = tid(); i < cnt; i += NT) s += a[i] * b[i];
         return reduce(s, OpSum());
     }
     // :884-891
-    __device__ double calculate_mu()
+    __device__ __noinline__ double calculate_mu()
     {
         const double s = dot2(v(V_R, FSL), v(V_R, FZL), S.m) + dot2(v(V_R, FSU), v(V_R, FZU), S.m) + dot2(v(V_R, FSBL), v(V_R, FZBL), S.n_x_l) +
                          dot2(v(V_R, FSBU), v(V_R, FZBU), S.n_x_u);
         return s / (double)(S.n_h_l + S.n_h_u + S.n_x_l + S.n_x_u);
     }
     // :893-958
-    __device__ void calculate_step(double& alpha_s, double& alpha_z)
+    __device__ __noinline__ void calculate_step(double& alpha_s, double& alpha_z)
     {
         double as = 1.0, az = 1.0;
         auto upd = [](double& a, double r, double st) { if (st < 0) { const double c = -r / st; if (c < a) a = c; } };
@@ -429,20 +495,20 @@ struct Ipm {
         alpha_s = reduce(as, OpMin());
         alpha_z = reduce(az, OpMin());
     }
-    __device__ double min_coeff(const double* a, int cnt)
+    __device__ __noinline__ double min_coeff(const double* a, int cnt)
     {
         double mn = DBL_MAX;
         for (int i = tid(); i < cnt; i += NT) if (a[i] < mn) mn = a[i];
         return reduce(mn, OpMin());
     }
-    __device__ double inf_scaled(const double* a, const double* sc, double c, int cnt)
+    __device__ __noinline__ double inf_scaled(const double* a, const double* sc, double c, int cnt)
     {
         double mx = 0.0;
         for (int i = tid(); i < cnt; i += NT) { const double t = fabs(a[i] * c * sc[i]); if (t > mx || t != t) mx = t; }
         return reduce(mx, OpAbsMaxNan());
     }
     // :1130-1164
-    __device__ double primal_res_of(int set)
+    __device__ __noinline__ double primal_res_of(int set)
     {
         const int n = S.n, p = S.p, m = S.m;
         const double* dinv = at(D_DLI);
@@ -485,7 +551,13 @@ struct Ipm {
     }
 
     // :960-1105
-    __device__ void update_residuals_nr()
+    __device__ __noinline__ void update_residuals_nr()
+    {
+        const long long t_begin = wall_clock64();
+        update_residuals_nr_impl();
+        st.prof[T_RES] += wall_clock64() - t_begin;
+    }
+    __device__ __forceinline__ void update_residuals_nr_impl()
     {
         const int n = S.n, p = S.p, m = S.m;
         const double ci = rz_c_inv;
@@ -593,7 +665,7 @@ struct Ipm {
     }
 
     // :1107-1128
-    __device__ void update_residuals_r()
+    __device__ __noinline__ void update_residuals_r()
     {
         const int n = S.n, p = S.p, m = S.m;
         const double rho = info.rho, delta = info.delta;
@@ -619,8 +691,8 @@ struct Ipm {
     // the factor-with-retries loops of :446-465 / :688-708; returns false on PIQP_NUMERICS
     __device__ bool factor_with_retries(bool in_loop, bool& regularization_changed)
     {
-        while (!ks_update_scalings_and_factor(refine_enabled, info.rho, info.delta)) {
-            if (!refine_enabled) { refine_enabled = true; continue; }
+        while (!ks_update_scalings_and_factor(refine_enabled != 0, info.rho, info.delta)) {
+            if (!refine_enabled) { refine_enabled = 1; continue; }
             if (info.factor_retires < S.set.max_factor_retires) {
                 info.delta *= 100; info.rho *= 100; info.factor_retires++;
                 info.reg_limit = fmin(10 * info.reg_limit, S.set.eps_abs);
@@ -666,7 +738,7 @@ struct Ipm {
             v(V_R, FSBL)[i] = l; v(V_R, FZBL)[i] = l; v(V_R, FSBU)[i] = u; v(V_R, FZBU)[i] = u;
         }
         __syncthreads();
-        refine_enabled = set.iterative_refinement_always_enabled != 0;
+        refine_enabled = set.iterative_refinement_always_enabled != 0 ? 1 : 0;
         bool dummy = false;
         if (!factor_with_retries(false, dummy)) { info.status = PQ_NUMERICS; return info.status; }
 
@@ -929,21 +1001,61 @@ __global__ __launch_bounds__(NT) void k_batch_prepare(const BatchShared* __restr
     }
 }
 
-template <int NT, bool LDS>
-__global__ __launch_bounds__(NT) void k_batch_ipm(const BatchShared* __restrict__ Sp, double* __restrict__ arena, const double* __restrict__ ruiz_c, pq_info* __restrict__ infos)
+// WPE = waves per SIMD the register allocator must leave room for (occupancy vs spills; measured)
+template <int NT, int MODE, int WPE>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_batch_ipm(const BatchShared* __restrict__ Sp, double* __restrict__ arena, const double* __restrict__ ruiz_c, pq_info* __restrict__ infos,
+                                                                                                   double* __restrict__ prof_out)
 {
     extern __shared__ double sm[];
     __shared__ double red[NT / 64 > 0 ? NT / 64 : 1];
-    const BatchShared& S = *Sp;
+    // The shared descriptor and the per-stage structure tables are read on every stage of every chain sweep: keep them in
+    // LDS (a dependent chain of global loads per stage was the largest single latency of the first version).
+    __shared__ BatchShared Ssh;
+    {
+        const int words = (int)(sizeof(BatchShared) / sizeof(int));
+        const int* src = reinterpret_cast<const int*>(Sp);
+        int* dst = reinterpret_cast<int*>(&Ssh);
+        for (int i = threadIdx.x; i < words; i += NT) dst[i] = src[i];
+        __syncthreads();
+        const int N = Ssh.M.N;
+        int* mi = reinterpret_cast<int*>(sm + Ssh.meta_ofs);
+        long long* ml = reinterpret_cast<long long*>(mi + 4 * N);
+        for (int i = threadIdx.x; i < N; i += NT) {
+            mi[i] = Ssh.M.w[i]; mi[N + i] = Ssh.M.off[i]; mi[2 * N + i] = Ssh.M.h[i]; mi[3 * N + i] = Ssh.M.start[i];
+            ml[i] = Ssh.M.front_off[i]; ml[N + i] = Ssh.M.pan_off[i];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            Ssh.M.w = mi; Ssh.M.off = mi + N; Ssh.M.h = mi + 2 * N; Ssh.M.start = mi + 3 * N;
+            Ssh.M.front_off = ml; Ssh.M.pan_off = ml + N;
+        }
+        __syncthreads();
+    }
+    const BatchShared& S = Ssh;
     const int q = blockIdx.x;
-    Ipm<NT, LDS> ipm(S, arena + (long long)q * S.stride, sm, red);
-    ipm.rz_c = ruiz_c[q];
-    ipm.rz_c_inv = 1.0 / ruiz_c[q];
-    ipm.info = pq_info{};
+    __shared__ IpmState state[NT / 64 > 0 ? NT / 64 : 1];
+    IpmState& my = state[threadIdx.x >> 6];
+    Ipm<NT, MODE> ipm(S, arena + (long long)q * S.stride, sm, red, my);
+    my.info = pq_info{};
+    for (int i = 0; i < NPROF; ++i) my.prof[i] = 0;
+    const long long t_start = wall_clock64();
+    my.rz_c = ruiz_c[q];
+    my.rz_c_inv = 1.0 / ruiz_c[q];
+    my.ks_rho = 0.0; my.ks_delta = 0.0; my.be_delta = 1.0;
+    my.refine_enabled = 0; my.ks_use_refine = 0;
     ipm.solve_impl();
     __syncthreads();
     ipm.finish();
-    if (threadIdx.x == 0) infos[q] = ipm.info;
+    if (threadIdx.x == 0) {
+        my.prof[T_ALL] = wall_clock64() - t_start;
+        my.prof[6] = t_start;  // absolute start tick (concurrency analysis)
+        // Info's timing fields (results.hpp:76-82) from the device clock: seconds spent in factorisations / KKT solves / the whole solve
+        my.info.kkt_factor_time = (double)(my.prof[T_ASM] + my.prof[T_FAC]) * 1e-8;
+        my.info.kkt_solve_time = (double)my.prof[T_KS] * 1e-8;
+        my.info.solve_time = (double)my.prof[T_ALL] * 1e-8;
+        infos[q] = my.info;
+        for (int i = 0; i < NPROF; ++i) prof_out[(long long)q * NPROF + i] = (double)my.prof[i] * 1e-8;
+    }
 }
 
 struct Layout {
@@ -1026,6 +1138,7 @@ public:
         arena_.zero(st_);
         ruiz_c_.alloc(batch);
         infos_.alloc(batch);
+        prof_.alloc((size_t)batch * NPROF);
         infos_h_.resize(batch);
         std::vector<double> stage((size_t)layout_.stride * std::min(batch, STAGE_INST));
         std::vector<double> rc(batch);
@@ -1093,7 +1206,14 @@ public:
         out.clear();
         for (const auto& b : sym_.block_info) { out.push_back(b.start); out.push_back(b.diag_size); out.push_back(b.off_diag_size); }
     }
+    // seconds per stage of one instance, measured by the device clock inside the kernel (see T_* above)
+    void get_profile(int instance, double* out8)
+    {
+        PQ_HIP(hipSetDevice(dev_));
+        PQ_HIP(hipMemcpy(out8, prof_.p + (size_t)instance * NPROF, sizeof(double) * NPROF, hipMemcpyDeviceToHost));
+    }
     int threads_per_qp() const { return nt_; }
+    int mode() const { return mode_; }
 
 private:
     static constexpr int STAGE_INST = 256;
@@ -1166,16 +1286,25 @@ private:
         S.hcap = std::max(1, sym_.max_h);
         const long long fdoubles = (long long)S.lofs + (long long)sym_.max_w * sym_.max_w;
         const long long sdoubles = 2LL * S.hcap + max_pan;
-        lds_ = std::max(fdoubles, sdoubles) * (long long)sizeof(double) <= LDS_LIMIT_BYTES;
-        if (!lds_) {  // in-HBM chain: only the inverse (factor) / the two stage vectors (solve) are staged
+        const long long small_chain = std::max<long long>((long long)sym_.max_w * sym_.max_w, 2LL * S.hcap);  // inverse (factor) / two stage vectors (solve)
+        const long long res_doubles = sym_.front_doubles + sym_.pan_doubles + n + small_chain;
+        if (res_doubles * (long long)sizeof(double) <= RESIDENT_LIMIT_BYTES) {
+            mode_ = MODE_RESIDENT;
+            S.res_f = 0; S.res_pan = (int)sym_.front_doubles; S.res_x = S.res_pan + (int)sym_.pan_doubles; S.res_chain = S.res_x + n;
+            S.fcap = 0; S.lofs = 0;
+            S.chain_lds_doubles = (int)res_doubles;
+        } else if (std::max(fdoubles, sdoubles) * (long long)sizeof(double) <= LDS_LIMIT_BYTES) {
+            mode_ = MODE_STAGED;
+            S.chain_lds_doubles = (int)std::max(fdoubles, sdoubles);
+        } else {
+            mode_ = MODE_HBM;
             S.fcap = 0;
             S.lofs = 0;
-            const long long need = std::max<long long>((long long)sym_.max_w * sym_.max_w, 2LL * S.hcap);
-            if (need * (long long)sizeof(double) > LDS_LIMIT_BYTES) throw std::runtime_error("batch setup: a stage is too wide for this backend");
-            S.chain_lds_doubles = (int)need;
-        } else {
-            S.chain_lds_doubles = (int)std::max(fdoubles, sdoubles);
+            if (small_chain * (long long)sizeof(double) > LDS_LIMIT_BYTES) throw std::runtime_error("batch setup: a stage is too wide for this backend");
+            S.chain_lds_doubles = (int)small_chain;
         }
+        S.meta_ofs = S.chain_lds_doubles;
+        S.chain_lds_doubles += 4 * sym_.N + 2;  // 4 int + 2 int64 tables of N entries
         nt_ = (n <= 512 && sym_.max_h <= 24) ? 64 : 256;
         // arena layout
         long long o = 0;
@@ -1211,25 +1340,45 @@ private:
         else hipLaunchKernelGGL(k_batch_prepare<256>, dim3(batch_), dim3(256), 0, st_, shared_.p, arena_.p);
         PQ_HIP(hipGetLastError());
     }
-    template <int NTv, bool LDSv>
-    void launch_ipm_as()
+    template <int NTv, int MODEv, int WPEv>
+    void launch_ipm_with()
     {
         const int bytes = shared_h_.chain_lds_doubles * (int)sizeof(double);
         static bool attr = false;
         if (!attr) {
-            PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_batch_ipm<NTv, LDSv>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT_BYTES));
+            PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_batch_ipm<NTv, MODEv, WPEv>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT_BYTES));
             attr = true;
         }
-        hipLaunchKernelGGL((k_batch_ipm<NTv, LDSv>), dim3(batch_), dim3(NTv), bytes, st_, shared_.p, arena_.p, ruiz_c_.p, infos_.p);
+        hipLaunchKernelGGL((k_batch_ipm<NTv, MODEv, WPEv>), dim3(batch_), dim3(NTv), bytes, st_, shared_.p, arena_.p, ruiz_c_.p, infos_.p, prof_.p);
+    }
+    template <int NTv, int MODEv>
+    void launch_ipm_as()
+    {
+        if constexpr (NTv == 64) {
+            if (wpe_ == 2) launch_ipm_with<NTv, MODEv, 2>();
+            else if (wpe_ == 3) launch_ipm_with<NTv, MODEv, 3>();
+            else launch_ipm_with<NTv, MODEv, 4>();
+        } else {
+            launch_ipm_with<NTv, MODEv, 2>();
+        }
     }
     void launch_ipm()
     {
-        if (nt_ == 64) { if (lds_) launch_ipm_as<64, true>(); else launch_ipm_as<64, false>(); }
-        else { if (lds_) launch_ipm_as<256, true>(); else launch_ipm_as<256, false>(); }
+        if (const char* e = std::getenv("PIQP_AMD_BATCH_WPE")) wpe_ = std::atoi(e);
+        if (nt_ == 64) {
+            if (mode_ == MODE_RESIDENT) launch_ipm_as<64, MODE_RESIDENT>();
+            else if (mode_ == MODE_STAGED) launch_ipm_as<64, MODE_STAGED>();
+            else launch_ipm_as<64, MODE_HBM>();
+        } else {
+            if (mode_ == MODE_RESIDENT) launch_ipm_as<256, MODE_RESIDENT>();
+            else if (mode_ == MODE_STAGED) launch_ipm_as<256, MODE_STAGED>();
+            else launch_ipm_as<256, MODE_HBM>();
+        }
     }
 
     int dev_, batch_ = 0, n_ = 0, p_ = 0, m_ = 0, nt_ = 64;
-    bool lds_ = true, setup_done_ = false;
+    int mode_ = MODE_STAGED, wpe_ = 4;
+    bool setup_done_ = false;
     double last_kernel_ms_ = 0.0;
     hipStream_t st_ = nullptr;
     pq_settings settings_;
@@ -1239,7 +1388,7 @@ private:
     DBuf<BatchShared> shared_;
     std::vector<DBuf<int>> ibufs_;
     std::vector<DBuf<long long>> lbufs_;
-    DBuf<double> arena_, ruiz_c_;
+    DBuf<double> arena_, ruiz_c_, prof_;
     DBuf<pq_info> infos_;
     std::vector<pq_info> infos_h_;
 };
@@ -1307,6 +1456,11 @@ int pq_batch_block_info(const pq_batch* s, int* out_host, int capacity)
         if (out_host) for (int i = 0; i < 3 * std::min(N, capacity); ++i) out_host[i] = bi[i];
         return N;
     });
+}
+int pq_batch_get_profile(pq_batch* s, int instance, double* out8)
+{
+    if (!s || !out8 || instance < 0 || instance >= s->impl->batch()) return fail(PQ_ERR_INVALID, "bad argument");
+    return guarded([&] { s->impl->get_profile(instance, out8); return (int)PQ_OK; });
 }
 int pq_batch_last_kernel_ms(const pq_batch* s, double* ms, int* threads_per_qp)
 {

@@ -23,6 +23,25 @@ struct MsMeta {  // device views of multistage::Symbolic
     const int* start;
     const long long* front_off;
     const long long* pan_off;
+    __device__ __forceinline__ int W(int b) const { return w[b]; }
+    __device__ __forceinline__ int Off(int b) const { return off[b]; }
+    __device__ __forceinline__ int H(int b) const { return h[b]; }
+    __device__ __forceinline__ int Start(int b) const { return start[b]; }
+    __device__ __forceinline__ long long FrontOff(int b) const { return front_off[b]; }
+    __device__ __forceinline__ long long PanOff(int b) const { return pan_off[b]; }
+};
+// the same tables as one packed copy (w | off | h | start as int, then front_off | pan_off as int64); the batched kernel
+// keeps it in LDS and builds this view from the `extern __shared__` symbol so the compiler emits ds_read, not flat loads
+struct PackedMeta {
+    int N, arrow, n;
+    const int* mi;
+    const long long* ml;
+    __device__ __forceinline__ int W(int b) const { return mi[b]; }
+    __device__ __forceinline__ int Off(int b) const { return mi[N + b]; }
+    __device__ __forceinline__ int H(int b) const { return mi[2 * N + b]; }
+    __device__ __forceinline__ int Start(int b) const { return mi[3 * N + b]; }
+    __device__ __forceinline__ long long FrontOff(int b) const { return ml[b]; }
+    __device__ __forceinline__ long long PanOff(int b) const { return ml[N + b]; }
 };
 struct GroupMeta {
     const int* row_ptr;  // N entries
@@ -31,13 +50,13 @@ struct GroupMeta {
 };
 
 // entries [lo, hi) of the lower triangle of X_b X_b^T
-template <int NT>
-__device__ __forceinline__ void gram_stage(const MsMeta& M, const GroupMeta& Gm, const double* __restrict__ X, double* __restrict__ out, int b, int lo, int hi)
+template <int NT, class Meta>
+__device__ __forceinline__ void gram_stage(const Meta& M, const GroupMeta& Gm, const double* __restrict__ X, double* __restrict__ out, int b, int lo, int hi)
 {
-    const int h = M.h[b];
+    const int h = M.H(b);
     const int rows = Gm.row_ptr[b + 1] - Gm.row_ptr[b];
     const double* Xb = X + Gm.x_off[b];
-    double* O = out + M.front_off[b];
+    double* O = out + M.FrontOff(b);
     for (int idx = lo + (int)threadIdx.x; idx < hi; idx += NT) {
         const int r = idx % h, c = idx / h;
         if (r < c) continue;
@@ -49,18 +68,18 @@ __device__ __forceinline__ void gram_stage(const MsMeta& M, const GroupMeta& Gm,
 
 // entries [lo, hi) of stage b's frontal matrix (lower triangle); block N-1 is the arrow corner (P + x_reg only: every
 // product that lands there is carried by the stage fronts)
-template <int NT>
-__device__ __forceinline__ void assemble_stage(const MsMeta& M, const GroupMeta& Gm, const double* __restrict__ XG, const double* __restrict__ Pf,
+template <int NT, class Meta>
+__device__ __forceinline__ void assemble_stage(const Meta& M, const GroupMeta& Gm, const double* __restrict__ XG, const double* __restrict__ Pf,
                                                const double* __restrict__ AtAf, const double* __restrict__ zinv, const double* __restrict__ x_reg, double delta_inv,
                                                double* __restrict__ F, int b, int lo, int hi)
 {
-    const int h = M.h[b], w = M.w[b];
+    const int h = M.H(b), w = M.W(b);
     const bool corner = b == M.N - 1;
     const int rows = corner ? 0 : Gm.row_ptr[b + 1] - Gm.row_ptr[b];
     const double* Xb = XG + (corner ? 0 : Gm.x_off[b]);
     const int* rid = Gm.rows + (corner ? 0 : Gm.row_ptr[b]);
-    const long long fo = M.front_off[b];
-    const int start = M.start[b];
+    const long long fo = M.FrontOff(b);
+    const int start = M.Start(b);
     for (int idx = lo + (int)threadIdx.x; idx < hi; idx += NT) {
         const int r = idx % h, c = idx / h;
         if (r < c) continue;
@@ -84,21 +103,21 @@ __device__ __forceinline__ int carry_row(int t, int off_prev, int w, int offb, b
 //   carried update = trailing block - [C_b; F_b][C_b; F_b]^T;  inverse of L_b for the solves.
 // LDS = true: front (sm[0..fcap)), carried update (sm[fcap..lofs)) and inverse (sm[lofs..)) live in LDS;
 // false: the front is factored in place in HBM/L2 and only the inverse is staged in LDS (when li_in_lds).
-template <int NT, bool LDS>
-__device__ void factor_chain(const MsMeta& M, double* __restrict__ fronts, double* __restrict__ pan, double* sm, int fcap, int lofs, int li_in_lds)
+template <int NT, bool LDS, class Meta>
+__device__ __forceinline__ void factor_chain(const Meta& M, double* __restrict__ fronts, double* __restrict__ pan, double* sm, int fcap, int lofs, int li_in_lds)
 {
     const int tid = threadIdx.x;
     const int N = M.N;
     int u_prev = 0, off_prev = 0, ldu = 0;
     double* Usrc = nullptr;
     for (int b = 0; b < N; ++b) {
-        const int h = M.h[b], w = M.w[b];
+        const int h = M.H(b), w = M.W(b);
         if (h == 0) break;  // no arrow corner
         const bool corner = b == N - 1;
-        const int offb = M.off[b];
+        const int offb = M.Off(b);
         const int u = h - w;
-        double* Fg = fronts + M.front_off[b];
-        double* P = pan + M.pan_off[b];
+        double* Fg = fronts + M.FrontOff(b);
+        double* P = pan + M.PanOff(b);
         double* Li = P + (long long)h * w;
         double* F;
         if constexpr (LDS) {
@@ -178,8 +197,8 @@ __device__ void factor_chain(const MsMeta& M, double* __restrict__ fronts, doubl
 }
 
 // Forward and backward block substitution; x (n entries) is overwritten.  sm: xs[hcap], ys[hcap], panel[...] (LDS variant).
-template <int NT, bool LDS>
-__device__ void solve_chain(const MsMeta& M, const double* __restrict__ pan, double* __restrict__ x, double* sm, int hcap)
+template <int NT, bool LDS, class Meta>
+__device__ __forceinline__ void solve_chain(const Meta& M, const double* __restrict__ pan, double* __restrict__ x, double* sm, int hcap)
 {
     double* xs = sm;
     double* ys = sm + hcap;
@@ -189,10 +208,10 @@ __device__ void solve_chain(const MsMeta& M, const double* __restrict__ pan, dou
     for (int pass = 0; pass < 2; ++pass) {
         for (int bb = 0; bb < N; ++bb) {
             const int b = pass == 0 ? bb : N - 1 - bb;
-            const int h = M.h[b], w = M.w[b];
+            const int h = M.H(b), w = M.W(b);
             if (h == 0) continue;
-            const int u = h - w, offb = M.off[b], start = M.start[b];
-            const double* Pg = pan + M.pan_off[b];
+            const int u = h - w, offb = M.Off(b), start = M.Start(b);
+            const double* Pg = pan + M.PanOff(b);
             const double* P;
             if constexpr (LDS) {
                 const int cnt = h * w + w * w;

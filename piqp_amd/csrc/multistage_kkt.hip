@@ -47,7 +47,7 @@ __global__ void k_ms_reciprocal(int m, const double* __restrict__ z, double* __r
 __global__ __launch_bounds__(NT) void k_ms_gram(MsMeta M, GroupMeta Gm, const double* __restrict__ X, double* __restrict__ out)
 {
     const int b = blockIdx.x;
-    const int total = M.h[b] * M.h[b];
+    const int total = M.H(b) * M.H(b);
     const int lo = blockIdx.y * ASM_CHUNK, hi = min(total, lo + ASM_CHUNK);
     msdev::gram_stage<NT>(M, Gm, X, out, b, lo, hi);
 }
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(NT) void k_ms_assemble(MsMeta M, GroupMeta Gm, cons
                                                     const double* __restrict__ zinv, const double* __restrict__ x_reg, double delta_inv, double* __restrict__ F)
 {
     const int b = blockIdx.x;
-    const int total = M.h[b] * M.h[b];
+    const int total = M.H(b) * M.H(b);
     const int lo = blockIdx.y * ASM_CHUNK, hi = min(total, lo + ASM_CHUNK);
     if (lo >= hi) return;
     msdev::assemble_stage<NT>(M, Gm, XG, Pf, AtAf, zinv, x_reg, delta_inv, F, b, lo, hi);
