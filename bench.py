@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--p", type=int, default=0)
     ap.add_argument("--kkt-solver", type=int, default=0, help="0 = dense_cholesky (reference default), 16 = pivot-free LDLt")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--batch-total", type=int, default=8192, help="BASELINE configs[3]: number of MPC QPs in the batched leg (0 = skip)")
     ap.add_argument("--cpu-steps", type=int, default=0, help="0 = auto (about 10-30 s of CPU work)")
     args = ap.parse_args()
 
@@ -142,8 +143,82 @@ def main():
             out["cpu_baseline"] = cpu_baseline(q, n, p, m, args)
             if out["cpu_baseline"].get("value"):
                 out["speedup_vs_cpu_baseline"] = value / world / out["cpu_baseline"]["value"]
+    else:
+        out = None
+    # second half of BASELINE.json's metric ("QP solves/sec at 1/2/4/8 GPUs"): the batched sparse_multistage leg
+    if args.batch_total > 0:
+        bq = batched_qp(args, rank, world, local_rank, dev, pd)
+        if rank == 0:
+            out["batched_qp"] = bq
+    if rank == 0:
         print(json.dumps(out), flush=True)
     pd.finalize()
+
+
+def batched_qp(args, rank, world, local_rank, dev, pd):
+    """BASELINE configs[3]: --batch-total independent MPC QPs (n = 120, 40 stages of n_x = 2, n_u = 1, p = 80, box bounds),
+    solved by the batched kernel (one workgroup = one whole interior-point solve).  Instances are independent, so the
+    batch is sharded contiguously over the ranks with no data-path collective ("strong": the fixed batch is split;
+    "weak": every rank solves a full batch of its own).  Timed region = solve() of all instances, inputs resident."""
+    import numpy as np
+    import torch
+    import piqp_amd
+    from qp_gen import mpc_batch, mpc_instance
+
+    def run(mb, reps=3):
+        bs = piqp_amd.BatchSparseSolver(device=local_rank)
+        assert bs.setup(mb["P_pattern"], mb["P_values"], mb["c"], mb["A_pattern"], mb["A_values"], mb["b"], x_l=mb["x_l"], x_u=mb["x_u"])
+        bs.solve()  # warm-up
+        pd.barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            solved = bs.solve()
+        torch.cuda.synchronize(); pd.barrier()
+        el = (time.perf_counter() - t0) / reps
+        return bs, solved, pd.max_over_ranks(el, device=dev if world > 1 else None)
+
+    total = args.batch_total
+    full = mpc_batch(total, seed=1000)
+    sub = lambda lo, hi: {k: (v[lo:hi] if isinstance(v, np.ndarray) and v.ndim == 2 else v) for k, v in full.items()}
+    res = {}
+    lo, hi = pd.shard_range(total, rank, world)
+    bs, solved, el = run(sub(lo, hi))
+    rows = pd.gather_stats([[float(solved), float(bs.iterations().sum()), float(hi - lo)]], device=dev if world > 1 else None)
+    if rank == 0:
+        tot_solved = sum(r[0] for r in rows); tot_it = sum(r[1] for r in rows)
+        res["strong"] = {"qps_total": total, "qp_per_s": total / el, "ms": el * 1e3, "solved": int(tot_solved), "iters_mean": tot_it / total,
+                         "kernel_ms_rank0": bs.last_kernel_ms()[0], "threads_per_qp": bs.last_kernel_ms()[1]}
+    if world > 1:
+        bsw, solved_w, el_w = run(full)
+        rows = pd.gather_stats([[float(solved_w)]], device=dev)
+        if rank == 0:
+            res["weak"] = {"qps_total": total * world, "qp_per_s": total * world / el_w, "ms": el_w * 1e3, "solved": int(sum(r[0] for r in rows))}
+    if rank != 0:
+        return None
+    res["workload"] = f"{total} linear-MPC QPs, n=120 (40 stages x (n_x=2,n_u=1)), p=80, box bounds on all variables, kkt_solver=sparse_multistage (BASELINE configs[3])"
+    res["unit"] = "QP solves/s (whole interior-point solve, inputs resident in HBM)"
+    res["sharding"] = f"contiguous shards of independent QPs over {world} rank(s), no data-path collective"
+    pr = bs.profile(0)
+    res["in_kernel_us_instance0"] = {k: v * 1e6 for k, v in pr.items()}
+    if not args.no_cpu_baseline:
+        # CPU baseline: the oracle (restatement of the reference's SparseSolver + sparse_multistage) on a bounded sample, 1 thread
+        from oracle import pyorc
+        sample = min(256, total)
+        solvers = []
+        for i in range(sample):
+            so = pyorc.Solver(); so.settings.kkt_solver = pyorc.SPARSE_MULTISTAGE
+            so.setup(*mpc_instance(full, i), sparse=True)
+            solvers.append(so)
+        t0 = time.perf_counter()
+        its = [(so.solve(), so.info.iter) for so in solvers]
+        el_cpu = time.perf_counter() - t0
+        dev_it = bs.iterations()[:sample] if lo == 0 else None
+        same = None if dev_it is None else float(np.mean([its[i][1] == dev_it[i] for i in range(min(sample, len(dev_it)))]))
+        res["cpu_baseline"] = {"value": sample / el_cpu, "unit": "QP solves/s", "cores": 1, "kind": "port",
+                               "sample": f"solve() of the first {sample} instances (setup excluded), oracle built with gcc -O3, 1 thread", "seconds": el_cpu}
+        res["iteration_count_parity_on_sample"] = same
+        res["speedup_vs_cpu_core"] = res["strong"]["qp_per_s"] / (sample / el_cpu)
+    return res
 
 
 def dense_strongly_convex_qp_small():
