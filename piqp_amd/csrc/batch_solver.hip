@@ -56,6 +56,8 @@ struct BatchShared {
     MsMeta M;
     GroupMeta GA, GG;
     const long long *P_dst, *A_dst, *G_dst;
+    const int *ent_b, *ent_rc;  // lower-triangular entries of all fronts (flat assembly)
+    int n_ent;
     int fcap, lofs, hcap, chain_lds_doubles;
     int meta_ofs;  // LDS offset (doubles) of the per-stage structure tables copied in at kernel start
     int res_f, res_pan, res_x, res_chain;  // MODE_RESIDENT: LDS offsets (doubles) of the fronts, the factor panels, the solve vector, chain scratch
@@ -98,14 +100,18 @@ struct IpmState {
 // MODE: where the multistage chain keeps its working set
 //   MODE_HBM       fronts and factor panels in HBM/L2, only the diagonal-block inverse staged in LDS (wide stages)
 //   MODE_STAGED    the current stage's front / panel is copied into LDS, the arenas stay in HBM
+//   MODE_WAVE      64-thread workgroups, every front has <= 64 entries: factor panels + solve vector resident in LDS, the
+//                  assembled fronts stay in HBM and are prefetched one stage ahead into a register; single-wave chain
+//                  routines without barriers (msdev::factor_chain_wave / solve_chain_wave)
 //   MODE_RESIDENT  ALL fronts, ALL factor panels and the solve vector live in LDS for the whole solve (small QPs:
 //                  the chain never waits on HBM)
-enum { MODE_HBM = 0, MODE_STAGED = 1, MODE_RESIDENT = 2 };
+enum { MODE_HBM = 0, MODE_STAGED = 1, MODE_RESIDENT = 2, MODE_WAVE = 3 };
 
 template <int NT, int MODE>
 struct Ipm {
     static constexpr bool LDS = MODE == MODE_STAGED;
     static constexpr bool RES = MODE == MODE_RESIDENT;
+    static constexpr bool WAVE = MODE == MODE_WAVE;
     const BatchShared& S;
     double* base;
     double* sm;   // chain workspace (dynamic LDS)
@@ -192,21 +198,19 @@ struct Ipm {
         extern __shared__ double dyn[];
         const PackedMeta PM = packed_meta(S, dyn);
         double* F = RES ? dyn + S.res_f : at(B_F);
-        double* PAN = RES ? dyn + S.res_pan : at(B_PAN);
-        double* CH = RES ? dyn + S.res_chain : dyn;
+        double* PAN = (RES || WAVE) ? dyn + S.res_pan : at(B_PAN);
+        double* CH = (RES || WAVE) ? dyn + S.res_chain : dyn;
         double* zinv = at(B_ZINV);
         for (int i = tid(); i < S.m; i += NT) zinv[i] = 1.0 / z_reg[i];
         __syncthreads();
         be_delta = delta;
         const double delta_inv = 1.0 / delta;
         const long long t0 = wall_clock64();
-        for (int b = 0; b < PM.N; ++b) {
-            const int h = PM.H(b);
-            msdev::assemble_stage<NT>(PM, S.GG, at(B_XG), at(B_PF), at(B_ATAF), zinv, x_reg, delta_inv, F, b, 0, h * h);
-        }
+        msdev::assemble_flat<NT>(PM, S.GG, at(B_XG), at(B_PF), at(B_ATAF), zinv, x_reg, delta_inv, F, S.ent_b, S.ent_rc, S.n_ent);
         __syncthreads();
         const long long t1 = wall_clock64();
-        msdev::factor_chain<NT, LDS>(PM, F, PAN, CH, S.fcap, S.lofs, 1);
+        if constexpr (WAVE) msdev::factor_chain_wave(PM, (msdev::global_cdouble*)F, PAN);
+        else msdev::factor_chain<NT, LDS>(PM, F, PAN, CH, S.fcap, S.lofs, 1);
         __syncthreads();
         const long long t2 = wall_clock64();
         st.prof[T_ASM] += t1 - t0; st.prof[T_FAC] += t2 - t1;
@@ -216,13 +220,13 @@ struct Ipm {
     {
         extern __shared__ double dyn[];
         const PackedMeta PM = packed_meta(S, dyn);
-        const double* PAN = RES ? dyn + S.res_pan : at(B_PAN);
-        double* CH = RES ? dyn + S.res_chain : dyn;
+        const double* PAN = (RES || WAVE) ? dyn + S.res_pan : at(B_PAN);
+        double* CH = (RES || WAVE) ? dyn + S.res_chain : dyn;
         const double* zinv = at(B_ZINV);
         const double* Ax = at(D_ATX);
         const double* Gx = at(D_GTX);
         const double delta_inv = 1.0 / be_delta;
-        double* xw = RES ? dyn + S.res_x : lhs_x;  // the chain works on an LDS copy of x in resident mode
+        double* xw = (RES || WAVE) ? dyn + S.res_x : lhs_x;  // the chain works on an LDS copy of x in resident mode
         for (int j = tid(); j < S.n; j += NT) {
             double sg = 0.0, sa = 0.0;
             for (int q = S.G_p[j]; q < S.G_p[j + 1]; ++q) { const int i = S.G_i[q]; sg += Gx[S.G_src[q]] * (zinv[i] * rhs_z[i]); }
@@ -231,9 +235,10 @@ struct Ipm {
         }
         __syncthreads();
         const long long t0 = wall_clock64();
-        msdev::solve_chain<NT, LDS>(PM, PAN, xw, CH, S.hcap);
+        if constexpr (WAVE) { msdev::solve_chain_wave(PM, PAN, xw); __syncthreads(); }
+        else msdev::solve_chain<NT, LDS>(PM, PAN, xw, CH, S.hcap);
         st.prof[T_CHAIN] += wall_clock64() - t0;
-        if constexpr (RES) for (int j = tid(); j < S.n; j += NT) lhs_x[j] = xw[j];
+        if constexpr (RES || WAVE) for (int j = tid(); j < S.n; j += NT) lhs_x[j] = xw[j];
         for (int k = tid(); k < S.p; k += NT) {
             double s = 0.0;
             for (int q = S.AT_p[k]; q < S.AT_p[k + 1]; ++q) s += Ax[q] * xw[S.AT_i[q]];
@@ -1274,6 +1279,16 @@ private:
         S.GA = GroupMeta{up(ibufs_, sym_.A.row_ptr), up(ibufs_, sym_.A.rows), up(lbufs_, sym_.A.x_off)};
         S.GG = GroupMeta{up(ibufs_, sym_.G.row_ptr), up(ibufs_, sym_.G.rows), up(lbufs_, sym_.G.x_off)};
         S.P_dst = up(lbufs_, sym_.P_dst); S.A_dst = up(lbufs_, sym_.A.dst); S.G_dst = up(lbufs_, sym_.G.dst);
+        {
+            std::vector<int> eb, erc;
+            for (int b = 0; b < sym_.N; ++b) {
+                const int h = sym_.h[b];
+                if (h >= 65536) throw std::runtime_error("batch setup: a stage is too wide for this backend");
+                for (int c = 0; c < h; ++c) for (int r = c; r < h; ++r) { eb.push_back(b); erc.push_back(r | (c << 16)); }
+            }
+            S.n_ent = (int)eb.size();
+            S.ent_b = up(ibufs_, eb); S.ent_rc = up(ibufs_, erc);
+        }
         // chain workspace: front + carried update + inverse (factor) / 2 vectors + panel (solve)
         int max_u = 0;
         long long max_pan = 0;
@@ -1288,7 +1303,17 @@ private:
         const long long sdoubles = 2LL * S.hcap + max_pan;
         const long long small_chain = std::max<long long>((long long)sym_.max_w * sym_.max_w, 2LL * S.hcap);  // inverse (factor) / two stage vectors (solve)
         const long long res_doubles = sym_.front_doubles + sym_.pan_doubles + n + small_chain;
-        if (res_doubles * (long long)sizeof(double) <= RESIDENT_LIMIT_BYTES) {
+        bool wave_pan = false;
+        const long long wave_doubles = sym_.qpan_doubles + n;
+        nt_ = (n <= 512 && sym_.max_h <= 24) ? 64 : 256;
+        if (const char* e = std::getenv("PIQP_AMD_BATCH_MODE")) forced_mode_ = std::atoi(e);
+        if (nt_ == 64 && sym_.max_h * sym_.max_h <= 64 && wave_doubles * (long long)sizeof(double) <= RESIDENT_LIMIT_BYTES && sym_.max_w <= msdev::WAVE_WMAX && (forced_mode_ < 0 || forced_mode_ == MODE_WAVE)) {
+            mode_ = MODE_WAVE;
+            S.res_f = 0; S.res_pan = 0; S.res_x = (int)sym_.qpan_doubles; S.res_chain = S.res_x + n;
+            S.fcap = 0; S.lofs = 0;
+            S.chain_lds_doubles = (int)wave_doubles;
+            wave_pan = true;
+        } else if (res_doubles * (long long)sizeof(double) <= RESIDENT_LIMIT_BYTES && (forced_mode_ < 0 || forced_mode_ == MODE_RESIDENT)) {
             mode_ = MODE_RESIDENT;
             S.res_f = 0; S.res_pan = (int)sym_.front_doubles; S.res_x = S.res_pan + (int)sym_.pan_doubles; S.res_chain = S.res_x + n;
             S.fcap = 0; S.lofs = 0;
@@ -1303,9 +1328,9 @@ private:
             if (small_chain * (long long)sizeof(double) > LDS_LIMIT_BYTES) throw std::runtime_error("batch setup: a stage is too wide for this backend");
             S.chain_lds_doubles = (int)small_chain;
         }
+        if (wave_pan) S.M.pan_off = up(lbufs_, sym_.qpan_off);  // compact Linv | Q panels
         S.meta_ofs = S.chain_lds_doubles;
         S.chain_lds_doubles += 4 * sym_.N + 2;  // 4 int + 2 int64 tables of N entries
-        nt_ = (n <= 512 && sym_.max_h <= 24) ? 64 : 256;
         // arena layout
         long long o = 0;
         auto put = [&](int slot, long long cnt) { layout_.off[slot] = o; o += (cnt + 1) & ~1LL; };
@@ -1343,7 +1368,8 @@ private:
     template <int NTv, int MODEv, int WPEv>
     void launch_ipm_with()
     {
-        const int bytes = shared_h_.chain_lds_doubles * (int)sizeof(double);
+        int bytes = shared_h_.chain_lds_doubles * (int)sizeof(double);
+        if (const char* e = std::getenv("PIQP_AMD_BATCH_LDS_PAD")) bytes += std::atoi(e);  // occupancy experiments
         static bool attr = false;
         if (!attr) {
             PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_batch_ipm<NTv, MODEv, WPEv>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT_BYTES));
@@ -1357,6 +1383,9 @@ private:
         if constexpr (NTv == 64) {
             if (wpe_ == 2) launch_ipm_with<NTv, MODEv, 2>();
             else if (wpe_ == 3) launch_ipm_with<NTv, MODEv, 3>();
+            else if (wpe_ == 5 && MODEv == MODE_WAVE) launch_ipm_with<NTv, MODE_WAVE, 5>();
+            else if (wpe_ == 6 && MODEv == MODE_WAVE) launch_ipm_with<NTv, MODE_WAVE, 6>();
+            else if (wpe_ == 8 && MODEv == MODE_WAVE) launch_ipm_with<NTv, MODE_WAVE, 8>();
             else launch_ipm_with<NTv, MODEv, 4>();
         } else {
             launch_ipm_with<NTv, MODEv, 2>();
@@ -1366,7 +1395,8 @@ private:
     {
         if (const char* e = std::getenv("PIQP_AMD_BATCH_WPE")) wpe_ = std::atoi(e);
         if (nt_ == 64) {
-            if (mode_ == MODE_RESIDENT) launch_ipm_as<64, MODE_RESIDENT>();
+            if (mode_ == MODE_WAVE) launch_ipm_as<64, MODE_WAVE>();
+            else if (mode_ == MODE_RESIDENT) launch_ipm_as<64, MODE_RESIDENT>();
             else if (mode_ == MODE_STAGED) launch_ipm_as<64, MODE_STAGED>();
             else launch_ipm_as<64, MODE_HBM>();
         } else {
@@ -1377,7 +1407,7 @@ private:
     }
 
     int dev_, batch_ = 0, n_ = 0, p_ = 0, m_ = 0, nt_ = 64;
-    int mode_ = MODE_STAGED, wpe_ = 4;
+    int mode_ = MODE_STAGED, wpe_ = 4, forced_mode_ = -1;
     bool setup_done_ = false;
     double last_kernel_ms_ = 0.0;
     hipStream_t st_ = nullptr;

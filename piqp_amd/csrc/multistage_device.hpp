@@ -91,6 +91,30 @@ __device__ __forceinline__ void assemble_stage(const Meta& M, const GroupMeta& G
     }
 }
 
+// all fronts of one QP in one flat loop over the lower-triangular entries (ent_b = stage, ent_rc = row | col << 16): full
+// lane utilisation and one round of overlapped HBM loads instead of one short, dependent loop per stage
+template <int NT, class Meta>
+__device__ __forceinline__ void assemble_flat(const Meta& M, const GroupMeta& Gm, const double* __restrict__ XG, const double* __restrict__ Pf,
+                                              const double* __restrict__ AtAf, const double* __restrict__ zinv, const double* __restrict__ x_reg, double delta_inv,
+                                              double* __restrict__ F, const int* __restrict__ ent_b, const int* __restrict__ ent_rc, int n_ent)
+{
+    for (int e = threadIdx.x; e < n_ent; e += NT) {
+        const int b = ent_b[e], rc = ent_rc[e];
+        const int r = rc & 0xffff, c = rc >> 16;
+        const int h = M.H(b);
+        const long long at = M.FrontOff(b) + r + (long long)c * h;
+        double s = 0.0;
+        if (b < M.N - 1) {
+            const int k0 = Gm.row_ptr[b], rows = Gm.row_ptr[b + 1] - k0;
+            const double* Xb = XG + Gm.x_off[b];
+            for (int k = 0; k < rows; ++k) s += Xb[r + (long long)k * h] * zinv[Gm.rows[k0 + k]] * Xb[c + (long long)k * h];
+        }
+        double v = Pf[at] + delta_inv * AtAf[at] + s;
+        if (r == c && c < M.W(b)) v += x_reg[M.Start(b) + c];
+        F[at] = v;
+    }
+}
+
 // position inside front b of the t-th row of the update matrix carried from stage b-1 ([off_{b-1} | arrow])
 __device__ __forceinline__ int carry_row(int t, int off_prev, int w, int offb, bool corner)
 {
@@ -256,6 +280,194 @@ __device__ __forceinline__ void solve_chain(const Meta& M, const double* __restr
                 __syncthreads();
             }
         }
+    }
+}
+
+// ---- single-wave variants for tiny stages (every front has at most 64 entries: one entry per lane) --------------------
+// Used by the batched kernel with 64-thread workgroups.  The front of the current stage lives in REGISTERS (lane = row +
+// col * h holds one entry); pivots and panel columns are broadcast with v_readlane, the carried update matrix moves
+// between stages with one cross-lane permute, and nothing waits on a barrier or on HBM (the next stage's assembled
+// front is prefetched into a register while this stage is factored).  What the solves need is not L itself but
+//   Linv_b = L_bb^{-1} (w x w)   and   Q_b = [C_b; F_b] * Linv_b (u x w),
+// so that a forward step is  y_b = Linv_b x_b,  x_next -= Q_b x_b  (both straight from x_b: one LDS round trip per stage)
+// and a backward step is  x_b = Linv_b^T x_b - Q_b^T x_next.  They are written to `pan` (LDS) per stage: Linv | Q.
+constexpr int WAVE_WMAX = 8;
+
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0); vmcnt / expcnt untouched
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// 1/sqrt(d) to ~1 ulp without the IEEE sqrt + divide chains (two Newton steps on v_rsq_f64)
+__device__ __forceinline__ double rsqrt_newton(double d)
+{
+    double y = __builtin_amdgcn_rsq(d);
+    y = y * (1.5 - 0.5 * d * y * y);
+    y = y * (1.5 - 0.5 * d * y * y);
+    return y;
+}
+
+// value of `v` in lane `src` (uniform) broadcast to every lane
+__device__ __forceinline__ double lane_bcast(double v, int src)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+
+// wave-uniform 64-bit value -> scalar registers
+__device__ __forceinline__ long long uni(long long v)
+{
+    const int lo = __builtin_amdgcn_readfirstlane((int)(v & 0xffffffffLL));
+    const int hi = __builtin_amdgcn_readfirstlane((int)(v >> 32));
+    return ((long long)hi << 32) | (unsigned int)lo;
+}
+
+typedef const double __attribute__((address_space(1))) global_cdouble;  // HBM pointer (global_load: does not touch lgkmcnt)
+
+// fronts_g: assembled fronts in HBM; pan: LDS, per stage Linv (w x w) then Q (u x w) at PanOff(b)
+template <class Meta>
+__device__ __forceinline__ void factor_chain_wave(const Meta& M, global_cdouble* fronts_g, double* __restrict__ pan)
+{
+    const int lane = threadIdx.x;
+    const int N = M.N;
+    int h = __builtin_amdgcn_readfirstlane(M.H(0));
+    double nxt = lane < h * h ? fronts_g[uni(M.FrontOff(0)) + lane] : 0.0;
+    int r = lane % h, c = lane / h;  // lane -> (row, col) of the current front; recomputed only when h changes
+    int h_prev = 0, w_prev = 0, off_prev = 0;
+    double f = 0.0;                  // after a stage: lanes (r >= w, c >= w, r >= c) hold the carried update matrix
+    for (int b = 0; b < N; ++b) {
+        if (h == 0) break;  // no arrow corner
+        const int w = __builtin_amdgcn_readfirstlane(M.W(b));
+        const bool corner = b == N - 1;
+        const int offb = __builtin_amdgcn_readfirstlane(M.Off(b));
+        const int u = h - w;
+        // ---- carried update: new entry (r, c) <- old trailing entry (i, j), a fixed cross-lane permutation ----
+        double carried = 0.0;
+        if (h_prev > 0) {
+            auto inv_carry = [&](int t) {  // inverse of carry_row: -1 = nothing lands on row t
+                if (t < off_prev) return t;
+                const int base = corner ? 0 : w + offb;
+                if (t >= base && !corner) return off_prev + (t - base);
+                if (corner) return off_prev + t;
+                return -1;
+            };
+            const int i = inv_carry(r), j = inv_carry(c);
+            const int u_prev = h_prev - w_prev;
+            const bool has = lane < h * h && i >= 0 && j >= 0 && i < u_prev && j < u_prev && i >= j;
+            const int src = has ? (w_prev + i) + (w_prev + j) * h_prev : lane;
+            const double got = __shfl(f, src);
+            carried = has ? got : 0.0;
+        }
+        f = nxt + carried;
+        const int hn = b + 1 < N ? __builtin_amdgcn_readfirstlane(M.H(b + 1)) : 0;
+        if (hn > 0) nxt = lane < hn * hn ? fronts_g[uni(M.FrontOff(b + 1)) + lane] : 0.0;  // prefetch, consumed next iteration
+        // ---- right-looking Cholesky of the h x w column panel, pivots / columns by v_readlane ----
+        double invs[WAVE_WMAX];
+#pragma unroll
+        for (int j = 0; j < WAVE_WMAX; ++j) {
+            invs[j] = 0.0;
+            if (j < w) {
+                const double d = lane_bcast(f, j + j * h);
+                const double inv = d > 0.0 ? rsqrt_newton(d) : 0.0;
+                invs[j] = inv;
+                if (c == j) f = r == j ? d * inv : (r > j ? f * inv : f);
+                double a = 0.0, bb = 0.0;
+                for (int k = j + 1; k < h; ++k) {
+                    const double v = lane_bcast(f, k + j * h);
+                    a = r == k ? v : a;
+                    bb = c == k ? v : bb;
+                }
+                if (c > j && c < w && r >= c) f -= a * bb;
+            }
+        }
+        // ---- Schur complement of the panel: lanes (r >= w, c >= w, r >= c) ----
+        for (int k = 0; k < w; ++k) {
+            double a = 0.0, bb = 0.0;
+            for (int t = w; t < h; ++t) {
+                const double v = lane_bcast(f, t + k * h);
+                a = r == t ? v : a;
+                bb = c == t ? v : bb;
+            }
+            if (r >= w && c >= w && r >= c) f -= a * bb;
+        }
+        // ---- Linv: lane j < w builds column j of L^{-1} in registers (1/L_kk = invs[k]: no divisions) ----
+        double X[WAVE_WMAX];
+#pragma unroll
+        for (int k = 0; k < WAVE_WMAX; ++k) X[k] = 0.0;
+#pragma unroll
+        for (int rr = 0; rr < WAVE_WMAX; ++rr) {
+            if (rr < w) {
+                double s = 0.0;
+#pragma unroll
+                for (int k = 0; k < WAVE_WMAX; ++k)
+                    if (k < rr) s += lane_bcast(f, rr + k * h) * X[k];  // X[k] is 0 for k < lane
+                X[rr] = lane == rr ? invs[rr] : (lane < rr ? -invs[rr] * s : 0.0);
+            }
+        }
+        // ---- Q = [C; F] * Linv and the stores for the solves ----
+        double* P = pan + uni(M.PanOff(b));
+#pragma unroll
+        for (int k = 0; k < WAVE_WMAX; ++k)
+            if (k < w && lane < w) P[k + lane * w] = X[k];
+        for (int t = 0; t < u; ++t) {
+            double q = 0.0;
+#pragma unroll
+            for (int k = 0; k < WAVE_WMAX; ++k)
+                if (k < w) q += lane_bcast(f, (w + t) + k * h) * X[k];
+            if (lane < w) P[w * w + t + lane * u] = q;
+        }
+        h_prev = h; w_prev = w; off_prev = offb;
+        if (hn != h && hn > 0) { r = lane % hn; c = lane / hn; }
+        h = hn;
+    }
+    wave_lds_sync();
+}
+
+// pan, x: LDS.  Forward and backward block substitution by one wave, one LDS round trip per stage.
+template <class Meta>
+__device__ __forceinline__ void solve_chain_wave(const Meta& M, const double* __restrict__ pan, double* __restrict__ x)
+{
+    const int lane = threadIdx.x;
+    const int N = M.N, n = M.n, arrow = M.arrow;
+    for (int b = 0; b < N; ++b) {
+        const int h = __builtin_amdgcn_readfirstlane(M.H(b)), w = __builtin_amdgcn_readfirstlane(M.W(b));
+        if (h == 0) continue;
+        const int u = h - w, offb = __builtin_amdgcn_readfirstlane(M.Off(b)), start = __builtin_amdgcn_readfirstlane(M.Start(b));
+        const double* Li = pan + uni(M.PanOff(b));
+        const double* Q = Li + w * w;
+        double acc = 0.0;
+        int tgt = -1;
+        if (lane < w) {  // y_b = Linv x_b
+            for (int k = 0; k <= lane; ++k) acc += Li[lane + k * w] * x[start + k];
+            tgt = start + lane;
+        } else if (lane < h) {  // x_next -= Q x_b
+            const int t = lane - w;
+            tgt = t < offb ? start + w + t : n - arrow + (t - offb);
+            acc = x[tgt];
+            for (int k = 0; k < w; ++k) acc -= Q[t + k * u] * x[start + k];
+        }
+        wave_lds_sync();  // every read of x_b above has returned before any lane overwrites it
+        if (tgt >= 0) x[tgt] = acc;
+        wave_lds_sync();
+    }
+    for (int b = N - 1; b >= 0; --b) {
+        const int h = __builtin_amdgcn_readfirstlane(M.H(b)), w = __builtin_amdgcn_readfirstlane(M.W(b));
+        if (h == 0) continue;
+        const int u = h - w, offb = __builtin_amdgcn_readfirstlane(M.Off(b)), start = __builtin_amdgcn_readfirstlane(M.Start(b));
+        const double* Li = pan + uni(M.PanOff(b));
+        const double* Q = Li + w * w;
+        double acc = 0.0;
+        if (lane < w) {  // x_b = Linv^T x_b - Q^T x_next
+            for (int k = lane; k < w; ++k) acc += Li[k + lane * w] * x[start + k];
+            for (int t = 0; t < u; ++t) acc -= Q[t + lane * u] * x[t < offb ? start + w + t : n - arrow + (t - offb)];
+        }
+        wave_lds_sync();
+        if (lane < w) x[start + lane] = acc;
+        wave_lds_sync();
     }
 }
 

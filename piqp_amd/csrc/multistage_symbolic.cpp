@@ -236,7 +236,7 @@ void analyse(const pq_sparse_data* d, Symbolic& S)
     }
     const int N = S.N;
     S.w.assign(N, 0); S.off.assign(N, 0); S.h.assign(N, 0);
-    S.front_off.assign(N + 1, 0); S.pan_off.assign(N + 1, 0);
+    S.front_off.assign(N + 1, 0); S.pan_off.assign(N + 1, 0); S.qpan_off.assign(N + 1, 0);
     for (int b = 0; b < N; ++b) {
         S.w[b] = S.block_info[b].diag_size;
         S.off[b] = b < N - 1 ? S.block_info[b].off_diag_size : 0;
@@ -244,6 +244,7 @@ void analyse(const pq_sparse_data* d, Symbolic& S)
         if (b + 1 < N - 1 && S.off[b] > S.block_info[b + 1].diag_size) throw std::runtime_error("multistage: off-diagonal block wider than the next stage");
         S.front_off[b + 1] = S.front_off[b] + (long long)S.h[b] * S.h[b];
         S.pan_off[b + 1] = S.pan_off[b] + (long long)S.h[b] * S.w[b] + (long long)S.w[b] * S.w[b];
+        S.qpan_off[b + 1] = S.qpan_off[b] + (long long)S.h[b] * S.w[b];  // w*w + (h-w)*w
         S.max_h = std::max(S.max_h, S.h[b]);
         S.max_w = std::max(S.max_w, S.w[b]);
         const double wv = S.w[b], u = S.h[b] - S.w[b];
@@ -251,6 +252,7 @@ void analyse(const pq_sparse_data* d, Symbolic& S)
     }
     S.front_doubles = S.front_off[N];
     S.pan_doubles = S.pan_off[N];
+    S.qpan_doubles = S.qpan_off[N];
     // P_utri entry (row j <= column i) is the lower entry (i, j): it lives in the front of the stage that owns column j
     const int nzP = d->P_colptr[S.n];
     S.P_dst.assign(nzP, 0);

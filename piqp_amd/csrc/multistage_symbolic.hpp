@@ -42,6 +42,9 @@ struct Symbolic {
     // followed by the w_i x w_i inverse of L_ii
     std::vector<long long> pan_off;  // N+1
     long long pan_doubles = 0;
+    // compact variant used by the single-wave chain: per stage only L_ii^{-1} (w x w) and Q_i = [C_i; F_i] L_ii^{-1} ((h-w) x w)
+    std::vector<long long> qpan_off;  // N+1
+    long long qpan_doubles = 0;
     // constraint matrices grouped by stage: X_i is h_i x rows_i, column-major, ld = h_i
     struct Grouped {
         std::vector<int> row_ptr;          // N: first grouped row of each stage (row_ptr[N-1] = number of grouped rows)
