@@ -28,16 +28,25 @@ namespace {
 
 constexpr int BIG_FRONT = 192;      // fronts at least this large with >= BIG_PIVOTS pivots use the dense multi-workgroup kernels
 constexpr int BIG_PIVOTS = 32;
+constexpr int SUB_THREADS = 256;    // small subtrees: fronts reach ~100 rows near the subtree root, so a full workgroup (64 threads measured 2x slower)
 constexpr int LDS_FRONT_DOUBLES = 12288;  // 96 KiB: fronts up to 110 x 110 are factored inside LDS
 
+struct SnRec {  // everything the numeric kernels need about one supernode, in one 32-byte record (one load instead of a
+                 // chain of dependent loads through six index arrays)
+    int first;      // first (permuted) column
+    int w;          // pivots
+    int f;          // front order
+    int rows_ptr;   // offset into front_rows / fvec
+    int child_lo, child_hi;  // range in `child`
+    int rel_ptr;    // offset into `rel` of this supernode's update rows inside its parent
+    int pad;
+    long long front_off;
+    long long pad2;
+};
 struct FrontMeta {  // device-side views of the symbolic analysis
-    const int* sn_first;
-    const int* front_rows_ptr;
+    const SnRec* sn;
     const int* front_rows;
-    const long long* front_off;
-    const int* child_ptr;
     const int* child;
-    const int* rel_ptr;
     const int* rel;
 };
 
@@ -86,13 +95,13 @@ __global__ void k_scale(int N, const double* __restrict__ d, double* __restrict_
 // extend-add of every child's update matrix into front s (fixed child order)
 __device__ void extend_add(const FrontMeta& M, double* __restrict__ fronts, int s, double* __restrict__ F, int f)
 {
-    for (int ci = M.child_ptr[s]; ci < M.child_ptr[s + 1]; ++ci) {
-        const int c = M.child[ci];
-        const int wc = M.sn_first[c + 1] - M.sn_first[c];
-        const int fc = M.front_rows_ptr[c + 1] - M.front_rows_ptr[c];
+    const SnRec me = M.sn[s];
+    for (int ci = me.child_lo; ci < me.child_hi; ++ci) {
+        const SnRec ch = M.sn[M.child[ci]];
+        const int wc = ch.w, fc = ch.f;
         const int uc = fc - wc;
-        const double* U = fronts + M.front_off[c] + wc + (long long)wc * fc;
-        const int* rel = M.rel + M.rel_ptr[c];
+        const double* U = fronts + ch.front_off + wc + (long long)wc * fc;
+        const int* rel = M.rel + ch.rel_ptr;
         for (int idx = threadIdx.x; idx < uc * uc; idx += blockDim.x) {
             const int i = idx % uc, j = idx / uc;
             if (i >= j) F[rel[i] + (long long)rel[j] * f] += U[i + (long long)j * fc];
@@ -104,16 +113,13 @@ __device__ void extend_add(const FrontMeta& M, double* __restrict__ fronts, int 
 // One workgroup per front: extend-add, then right-looking LDLt of the first w columns (unit L below the
 // diagonal, D on it), Schur complement left in the trailing (f-w) x (f-w) block for the parent.
 // Fails (info = first failing global column) iff a pivot is exactly zero, like ldlt.hpp:163.
-__global__ __launch_bounds__(256) void k_front_factor(FrontMeta M, double* __restrict__ fronts, const int* __restrict__ list, int big_front, int big_pivots,
-                                                      double* __restrict__ rdiag, int* __restrict__ info)
+__device__ void front_factor(const FrontMeta& M, double* __restrict__ fronts, int s, int big_front, int big_pivots, double* __restrict__ rdiag, int* __restrict__ info,
+                             double* __restrict__ lds)
 {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int s = list[blockIdx.x];
-    const int first = M.sn_first[s];
-    const int w = M.sn_first[s + 1] - first;
-    const int f = M.front_rows_ptr[s + 1] - M.front_rows_ptr[s];
+    const SnRec me = M.sn[s];
+    const int first = me.first, w = me.w, f = me.f;
     if (f >= big_front && w >= big_pivots) return;  // handled by the dense path
-    double* F = fronts + M.front_off[s];
+    double* F = fronts + me.front_off;
     extend_add(M, fronts, s, F, f);
     const bool in_lds = (long long)f * f <= LDS_FRONT_DOUBLES;
     double* W = F;
@@ -122,26 +128,39 @@ __global__ __launch_bounds__(256) void k_front_factor(FrontMeta M, double* __res
         __syncthreads();
         W = lds;
     }
-    __shared__ double piv_s;
+    // ---- panel: right-looking LDLt of the first w columns, updates confined to the panel (rows k+1..f-1, columns k+1..w-1)
+    const int tid = threadIdx.x, nt = blockDim.x;
     for (int k = 0; k < w; ++k) {
-        if (threadIdx.x == 0) {
-            double d = W[k + (long long)k * f];
-            if (d == 0.0) { if (*info < 0) *info = first + k; d = 1.0; }
-            piv_s = d;
-            rdiag[first + k] = 1.0 / d;
-        }
-        __syncthreads();
-        const double d = piv_s;
+        double d = W[k + (long long)k * f];  // every thread reads the same word (broadcast)
+        if (d == 0.0) { if (tid == 0 && *info < 0) *info = first + k; d = 1.0; }
         const double dinv = 1.0 / d;
-        // trailing update with the UNSCALED column: F[i,j] -= (a_i / d) * a_j  for j > k, i >= j
-        const int r = f - k - 1;
+        if (tid == 0) rdiag[first + k] = dinv;
+        const int r = f - k - 1, pc = w - k - 1;
         const double* colk = W + (k + 1) + (long long)k * f;
-        for (int idx = threadIdx.x; idx < r * r; idx += blockDim.x) {
+        // W[i,j] -= (a_i / d) * a_j for k < j < w, i >= j, with the UNSCALED column k
+        for (int idx = tid; idx < r * pc; idx += nt) {
             const int i = idx % r, j = idx / r;
             if (i >= j) W[(k + 1 + i) + (long long)(k + 1 + j) * f] -= (colk[i] * dinv) * colk[j];
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < r; i += blockDim.x) W[(k + 1 + i) + (long long)k * f] *= dinv;
+        for (int i = tid; i < r; i += nt) W[(k + 1 + i) + (long long)k * f] *= dinv;
+        __syncthreads();
+    }
+    // ---- Schur complement of the trailing block in one pass: T[i,j] -= sum_k L[i,k] d_k L[j,k]  (no barriers, long dot products)
+    const int u = f - w;
+    if (u > 0) {
+        const int tx = tid & 15, ty = tid >> 4, tys = nt >> 4;
+        for (int j = ty; j < u; j += tys) {
+            for (int i = j - (j & 15) + tx; i < u; i += 16) {
+                if (i < j) continue;
+                double acc = 0.0;
+                for (int k = 0; k < w; ++k) {
+                    const double dk = W[k + (long long)k * f];
+                    acc += (W[(w + i) + (long long)k * f] * dk) * W[(w + j) + (long long)k * f];
+                }
+                W[(w + i) + (long long)(w + j) * f] -= acc;
+            }
+        }
         __syncthreads();
     }
     if (in_lds) {
@@ -149,17 +168,38 @@ __global__ __launch_bounds__(256) void k_front_factor(FrontMeta M, double* __res
     }
 }
 
+// one workgroup per front of an assembly-tree level
+__global__ __launch_bounds__(256) void k_front_factor(FrontMeta M, double* __restrict__ fronts, const int* __restrict__ list, int big_front, int big_pivots,
+                                                      double* __restrict__ rdiag, int* __restrict__ info)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    front_factor(M, fronts, list[blockIdx.x], big_front, big_pivots, rdiag, info, lds);
+}
+
+// one workgroup per small subtree: its supernodes lo..hi (a postorder range, children before parents) are factored one
+// after the other by the same workgroup -- no launch and no inter-workgroup dependency inside the subtree
+__global__ __launch_bounds__(SUB_THREADS) void k_subtree_factor(FrontMeta M, double* __restrict__ fronts, const int* __restrict__ sub_lo, const int* __restrict__ sub_hi,
+                                                        double* __restrict__ rdiag, int* __restrict__ info)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int lo = sub_lo[blockIdx.x], hi = sub_hi[blockIdx.x];
+    for (int s = lo; s <= hi; ++s) {
+        front_factor(M, fronts, s, 1 << 30, 1 << 30, rdiag, info, lds);
+        __syncthreads();
+    }
+}
+
 // extend-add of ONE child into a front that is then factored by the dense kernels (one launch per child: stream
 // order = fixed merge order, entries of one child never collide)
 __global__ __launch_bounds__(256) void k_front_extend_add_child(FrontMeta M, double* __restrict__ fronts, int s, int c)
 {
-    const int f = M.front_rows_ptr[s + 1] - M.front_rows_ptr[s];
-    double* F = fronts + M.front_off[s];
-    const int wc = M.sn_first[c + 1] - M.sn_first[c];
-    const int fc = M.front_rows_ptr[c + 1] - M.front_rows_ptr[c];
+    const SnRec me = M.sn[s], ch = M.sn[c];
+    const int f = me.f;
+    double* F = fronts + me.front_off;
+    const int wc = ch.w, fc = ch.f;
     const int uc = fc - wc;
-    const double* U = fronts + M.front_off[c] + wc + (long long)wc * fc;
-    const int* rel = M.rel + M.rel_ptr[c];
+    const double* U = fronts + ch.front_off + wc + (long long)wc * fc;
+    const int* rel = M.rel + ch.rel_ptr;
     const long long tot = (long long)uc * uc;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < tot; idx += (long long)gridDim.x * blockDim.x) {
         const int i = (int)(idx % uc), j = (int)(idx / uc);
@@ -168,23 +208,19 @@ __global__ __launch_bounds__(256) void k_front_extend_add_child(FrontMeta M, dou
 }
 
 // forward substitution on one front: v = [x(pivots) + children; children], y = L11^-1 v1, v2 -= L21 y
-__global__ __launch_bounds__(256) void k_front_fwd(FrontMeta M, const double* __restrict__ fronts, const int* __restrict__ list, double* __restrict__ x,
-                                                   double* __restrict__ fvec)
+__device__ void front_fwd(const FrontMeta& M, const double* __restrict__ fronts, int s, double* __restrict__ x, double* __restrict__ fvec)
 {
-    const int s = list[blockIdx.x];
-    const int first = M.sn_first[s];
-    const int w = M.sn_first[s + 1] - first;
-    const int f = M.front_rows_ptr[s + 1] - M.front_rows_ptr[s];
-    const double* F = fronts + M.front_off[s];
-    double* v = fvec + M.front_rows_ptr[s];
+    const SnRec me = M.sn[s];
+    const int first = me.first, w = me.w, f = me.f;
+    const double* F = fronts + me.front_off;
+    double* v = fvec + me.rows_ptr;
     for (int i = threadIdx.x; i < f; i += blockDim.x) v[i] = (i < w) ? x[first + i] : 0.0;
     __syncthreads();
-    for (int ci = M.child_ptr[s]; ci < M.child_ptr[s + 1]; ++ci) {
-        const int c = M.child[ci];
-        const int wc = M.sn_first[c + 1] - M.sn_first[c];
-        const int fc = M.front_rows_ptr[c + 1] - M.front_rows_ptr[c];
-        const double* vc = fvec + M.front_rows_ptr[c] + wc;
-        const int* rel = M.rel + M.rel_ptr[c];
+    for (int ci = me.child_lo; ci < me.child_hi; ++ci) {
+        const SnRec ch = M.sn[M.child[ci]];
+        const int wc = ch.w, fc = ch.f;
+        const double* vc = fvec + ch.rows_ptr + wc;
+        const int* rel = M.rel + ch.rel_ptr;
         for (int i = threadIdx.x; i < fc - wc; i += blockDim.x) v[rel[i]] += vc[i];
         __syncthreads();
     }
@@ -196,18 +232,26 @@ __global__ __launch_bounds__(256) void k_front_fwd(FrontMeta M, const double* __
     }
     for (int i = threadIdx.x; i < w; i += blockDim.x) x[first + i] = v[i];
 }
-
-// backward substitution on one front: x1 = L11^-T (y1 - L21^T x2), x2 gathered from the already-final ancestors
-__global__ __launch_bounds__(256) void k_front_bwd(FrontMeta M, const double* __restrict__ fronts, const int* __restrict__ list, double* __restrict__ x,
+__global__ __launch_bounds__(256) void k_front_fwd(FrontMeta M, const double* __restrict__ fronts, const int* __restrict__ list, double* __restrict__ x,
                                                    double* __restrict__ fvec)
 {
-    const int s = list[blockIdx.x];
-    const int first = M.sn_first[s];
-    const int w = M.sn_first[s + 1] - first;
-    const int f = M.front_rows_ptr[s + 1] - M.front_rows_ptr[s];
-    const double* F = fronts + M.front_off[s];
-    const int* rows = M.front_rows + M.front_rows_ptr[s];
-    double* v = fvec + M.front_rows_ptr[s];
+    front_fwd(M, fronts, list[blockIdx.x], x, fvec);
+}
+__global__ __launch_bounds__(SUB_THREADS) void k_subtree_fwd(FrontMeta M, const double* __restrict__ fronts, const int* __restrict__ sub_lo, const int* __restrict__ sub_hi,
+                                                     double* __restrict__ x, double* __restrict__ fvec)
+{
+    const int lo = sub_lo[blockIdx.x], hi = sub_hi[blockIdx.x];
+    for (int s = lo; s <= hi; ++s) { front_fwd(M, fronts, s, x, fvec); __syncthreads(); }
+}
+
+// backward substitution on one front: x1 = L11^-T (y1 - L21^T x2), x2 gathered from the already-final ancestors
+__device__ void front_bwd(const FrontMeta& M, const double* __restrict__ fronts, int s, double* __restrict__ x, double* __restrict__ fvec)
+{
+    const SnRec me = M.sn[s];
+    const int first = me.first, w = me.w, f = me.f;
+    const double* F = fronts + me.front_off;
+    const int* rows = M.front_rows + me.rows_ptr;
+    double* v = fvec + me.rows_ptr;
     for (int i = threadIdx.x; i < f; i += blockDim.x) v[i] = x[rows[i]];
     __syncthreads();
     // y1[k] -= sum_{i >= w} L[i,k] * x2[i]   (thread per pivot column, contiguous reads down the column)
@@ -224,6 +268,17 @@ __global__ __launch_bounds__(256) void k_front_bwd(FrontMeta M, const double* __
         __syncthreads();
     }
     for (int i = threadIdx.x; i < w; i += blockDim.x) x[first + i] = v[i];
+}
+__global__ __launch_bounds__(256) void k_front_bwd(FrontMeta M, const double* __restrict__ fronts, const int* __restrict__ list, double* __restrict__ x,
+                                                   double* __restrict__ fvec)
+{
+    front_bwd(M, fronts, list[blockIdx.x], x, fvec);
+}
+__global__ __launch_bounds__(SUB_THREADS) void k_subtree_bwd(FrontMeta M, const double* __restrict__ fronts, const int* __restrict__ sub_lo, const int* __restrict__ sub_hi,
+                                                     double* __restrict__ x, double* __restrict__ fvec)
+{
+    const int lo = sub_lo[blockIdx.x], hi = sub_hi[blockIdx.x];
+    for (int s = hi; s >= lo; --s) { front_bwd(M, fronts, s, x, fvec); __syncthreads(); }
 }
 
 inline dim3 g1(int n) { return dim3(n > 0 ? (n + 255) / 256 : 1); }
@@ -277,12 +332,13 @@ public:
         const int t1 = prof_.begin(1, st_);
         PQ_HIP(hipMemsetAsync(info_.p, 0xFF, sizeof(int), st_));
         FrontMeta M = meta();
-        for (int l = 0; l < S_.nlevels; ++l) {
-            const int cnt = S_.level_ptr[l + 1] - S_.level_ptr[l];
-            hipLaunchKernelGGL(k_front_factor, dim3(cnt), dim3(256), level_lds_[l], st_, M, fronts_.p, level_sn_.p + S_.level_ptr[l], BIG_FRONT, BIG_PIVOTS,
+        if (S_.nsub > 0) hipLaunchKernelGGL(k_subtree_factor, dim3(S_.nsub), dim3(SUB_THREADS), sub_lds_, st_, M, fronts_.p, sub_lo_.p, sub_hi_.p, rdiag_.p, info_.p);
+        for (int l = 0; l < S_.top_nlevels; ++l) {
+            const int cnt = S_.top_level_ptr[l + 1] - S_.top_level_ptr[l];
+            hipLaunchKernelGGL(k_front_factor, dim3(cnt), dim3(256), level_lds_[l], st_, M, fronts_.p, level_sn_.p + S_.top_level_ptr[l], BIG_FRONT, BIG_PIVOTS,
                                rdiag_.p, info_.p);
-            for (int q = S_.level_ptr[l]; q < S_.level_ptr[l + 1]; ++q) {
-                const int s = S_.level_sn[q];
+            for (int q = S_.top_level_ptr[l]; q < S_.top_level_ptr[l + 1]; ++q) {
+                const int s = S_.top_level_sn[q];
                 const int w = S_.sn_first[s + 1] - S_.sn_first[s];
                 const int f = S_.front_rows_ptr[s + 1] - S_.front_rows_ptr[s];
                 if (f >= BIG_FRONT && w >= BIG_PIVOTS) factor_big_front(M, s, w, f);
@@ -302,15 +358,17 @@ public:
         const int tk = prof_.begin(2, st_);
         FrontMeta M = meta();
         hipLaunchKernelGGL(k_perm_gather, g1(N_), dim3(256), 0, st_, N_, P_.p, rhs_x, n_, rhs_y, p_, rhs_z, xp_.p);
-        for (int l = 0; l < S_.nlevels; ++l) {
-            const int cnt = S_.level_ptr[l + 1] - S_.level_ptr[l];
-            hipLaunchKernelGGL(k_front_fwd, dim3(cnt), dim3(256), 0, st_, M, fronts_.p, level_sn_.p + S_.level_ptr[l], xp_.p, fvec_.p);
+        if (S_.nsub > 0) hipLaunchKernelGGL(k_subtree_fwd, dim3(S_.nsub), dim3(SUB_THREADS), 0, st_, M, fronts_.p, sub_lo_.p, sub_hi_.p, xp_.p, fvec_.p);
+        for (int l = 0; l < S_.top_nlevels; ++l) {
+            const int cnt = S_.top_level_ptr[l + 1] - S_.top_level_ptr[l];
+            hipLaunchKernelGGL(k_front_fwd, dim3(cnt), dim3(256), 0, st_, M, fronts_.p, level_sn_.p + S_.top_level_ptr[l], xp_.p, fvec_.p);
         }
         hipLaunchKernelGGL(k_scale, g1(N_), dim3(256), 0, st_, N_, rdiag_.p, xp_.p);
-        for (int l = S_.nlevels - 1; l >= 0; --l) {
-            const int cnt = S_.level_ptr[l + 1] - S_.level_ptr[l];
-            hipLaunchKernelGGL(k_front_bwd, dim3(cnt), dim3(256), 0, st_, M, fronts_.p, level_sn_.p + S_.level_ptr[l], xp_.p, fvec_.p);
+        for (int l = S_.top_nlevels - 1; l >= 0; --l) {
+            const int cnt = S_.top_level_ptr[l + 1] - S_.top_level_ptr[l];
+            hipLaunchKernelGGL(k_front_bwd, dim3(cnt), dim3(256), 0, st_, M, fronts_.p, level_sn_.p + S_.top_level_ptr[l], xp_.p, fvec_.p);
         }
+        if (S_.nsub > 0) hipLaunchKernelGGL(k_subtree_bwd, dim3(S_.nsub), dim3(SUB_THREADS), 0, st_, M, fronts_.p, sub_lo_.p, sub_hi_.p, xp_.p, fvec_.p);
         hipLaunchKernelGGL(k_perm_scatter, g1(N_), dim3(256), 0, st_, N_, P_.p, xp_.p, lhs_x, n_, lhs_y, p_, lhs_z);
         PQ_HIP(hipGetLastError());
         prof_.end(2, tk, st_);
@@ -335,8 +393,8 @@ public:
 
     void print_info() override
     {
-        std::printf("sparse multifrontal LDLt: N = %d, nnz(K) = %d, nnz(L) = %lld, supernodes = %d, levels = %d, max front = %d, front storage = %.1f MB\n", N_, nnzK_, S_.nnzL,
-                    S_.nsuper, S_.nlevels, S_.max_front, S_.front_doubles * 8.0 / 1e6);
+        std::printf("sparse multifrontal LDLt (%s ordering): N = %d, nnz(K) = %d, nnz(L) = %lld, supernodes = %d, tree levels = %d (%d subtrees walked by one workgroup each + %d level launches), max front = %d, front storage = %.1f MB\n",
+                    S_.ordering, N_, nnzK_, S_.nnzL, S_.nsuper, S_.nlevels, S_.nsub, S_.top_nlevels, S_.max_front, S_.front_doubles * 8.0 / 1e6);
     }
 
     const double* P_diag_device() const override { return ops_.P_diag(); }
@@ -355,7 +413,7 @@ public:
     const sparse::Symbolic& symbolic() const { return S_; }
 
 private:
-    SparseKKT(const SparseKKT& o, int) : dev_(o.dev_), n_(o.n_), p_(o.p_), m_(o.m_), N_(o.N_), nnzK_(o.nnzK_), delta_(o.delta_), S_(o.S_), level_lds_(o.level_lds_)
+    SparseKKT(const SparseKKT& o, int) : dev_(o.dev_), n_(o.n_), p_(o.p_), m_(o.m_), N_(o.N_), nnzK_(o.nnzK_), delta_(o.delta_), S_(o.S_), level_lds_(o.level_lds_), sub_lds_(o.sub_lds_)
     {
         PQ_HIP(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
         auto cpd = [&](DBuf<double>& d, const DBuf<double>& s) { d.alloc(s.n ? s.n : 1); if (s.n) PQ_HIP(hipMemcpyAsync(d.p, s.p, s.bytes(), hipMemcpyDeviceToDevice, st_)); };
@@ -364,7 +422,8 @@ private:
         ops_.clone_from(o.ops_, st_);
         cpd(vals_, o.vals_); cpd(fronts_, o.fronts_); cpd(rdiag_, o.rdiag_);
         xp_.alloc(o.xp_.n); fvec_.alloc(o.fvec_.n); dvec_.alloc(o.dvec_.n);
-        cpi(diag_pos_, o.diag_pos_); cpi(P_, o.P_); cpi(level_sn_, o.level_sn_); cpi(sn_first_, o.sn_first_); cpi(front_rows_ptr_, o.front_rows_ptr_); cpi(front_rows_, o.front_rows_);
+        cpi(diag_pos_, o.diag_pos_); cpi(P_, o.P_); cpi(level_sn_, o.level_sn_); cpi(sub_lo_, o.sub_lo_); cpi(sub_hi_, o.sub_hi_);
+        snrec_.alloc(o.snrec_.n ? o.snrec_.n : 1); if (o.snrec_.n) PQ_HIP(hipMemcpyAsync(snrec_.p, o.snrec_.p, o.snrec_.bytes(), hipMemcpyDeviceToDevice, st_)); cpi(sn_first_, o.sn_first_); cpi(front_rows_ptr_, o.front_rows_ptr_); cpi(front_rows_, o.front_rows_);
         cpi(child_ptr_, o.child_ptr_); cpi(child_, o.child_); cpi(rel_ptr_, o.rel_ptr_); cpi(rel_, o.rel_);
         cpi(mapP_, o.mapP_); cpi(mapA_, o.mapA_); cpi(mapG_, o.mapG_);
         cpl(a_dst_, o.a_dst_); cpl(front_off_, o.front_off_);
@@ -378,28 +437,43 @@ private:
         static bool attr_set = false;
         if (!attr_set) {
             PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_front_factor), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_FRONT_DOUBLES * (int)sizeof(double)));
+            PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_subtree_factor), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_FRONT_DOUBLES * (int)sizeof(double)));
             attr_set = true;
         }
-        level_lds_.assign(S_.nlevels, 0);
-        for (int l = 0; l < S_.nlevels; ++l) {
+        level_lds_.assign(S_.top_nlevels, 0);
+        for (int l = 0; l < S_.top_nlevels; ++l) {
             long long mx = 0;
-            for (int q = S_.level_ptr[l]; q < S_.level_ptr[l + 1]; ++q) {
-                const int s = S_.level_sn[q];
+            for (int q = S_.top_level_ptr[l]; q < S_.top_level_ptr[l + 1]; ++q) {
+                const int s = S_.top_level_sn[q];
                 const long long f = S_.front_rows_ptr[s + 1] - S_.front_rows_ptr[s];
                 if (f * f <= LDS_FRONT_DOUBLES) mx = std::max(mx, f * f);
             }
             level_lds_[l] = (int)mx * (int)sizeof(double);
         }
+        {
+            const long long f = S_.sub_max_front;
+            sub_lds_ = (int)(std::min<long long>(f * f, LDS_FRONT_DOUBLES) * (long long)sizeof(double));
+        }
     }
 
-    FrontMeta meta() const { return FrontMeta{sn_first_.p, front_rows_ptr_.p, front_rows_.p, front_off_.p, child_ptr_.p, child_.p, rel_ptr_.p, rel_.p}; }
+    FrontMeta meta() const { return FrontMeta{snrec_.p, front_rows_.p, child_.p, rel_.p}; }
 
     void build_device(const pq_sparse_data* d)
     {
         nnzK_ = S_.Cp[N_];
-        upload_vec(diag_pos_, S_.diag_pos, st_); upload_vec(P_, S_.P, st_); upload_vec(level_sn_, S_.level_sn, st_); upload_vec(sn_first_, S_.sn_first, st_);
+        upload_vec(diag_pos_, S_.diag_pos, st_); upload_vec(P_, S_.P, st_); upload_vec(level_sn_, S_.top_level_sn, st_); upload_vec(sub_lo_, S_.sub_lo, st_); upload_vec(sub_hi_, S_.sub_hi, st_); upload_vec(sn_first_, S_.sn_first, st_);
         upload_vec(front_rows_ptr_, S_.front_rows_ptr, st_); upload_vec(front_rows_, S_.front_rows, st_); upload_vec(child_ptr_, S_.child_ptr, st_); upload_vec(child_, S_.child, st_);
         upload_vec(rel_ptr_, S_.rel_ptr, st_); upload_vec(rel_, S_.rel, st_); upload_vec(a_dst_, S_.a_dst, st_); upload_vec(front_off_, S_.front_off, st_);
+        {
+            std::vector<SnRec> rec(S_.nsuper ? S_.nsuper : 1);
+            for (int q = 0; q < S_.nsuper; ++q) {
+                SnRec& r = rec[q];
+                r.first = S_.sn_first[q]; r.w = S_.sn_first[q + 1] - S_.sn_first[q]; r.f = S_.front_rows_ptr[q + 1] - S_.front_rows_ptr[q];
+                r.rows_ptr = S_.front_rows_ptr[q]; r.child_lo = S_.child_ptr[q]; r.child_hi = S_.child_ptr[q + 1]; r.rel_ptr = S_.rel_ptr[q]; r.pad = 0;
+                r.front_off = S_.front_off[q]; r.pad2 = 0;
+            }
+            upload_vec(snrec_, rec, st_);
+        }
         vals_.alloc(nnzK_ ? nnzK_ : 1); vals_.zero(st_);
         fronts_.alloc(S_.front_doubles ? (size_t)S_.front_doubles : 1);
         rdiag_.alloc(N_); xp_.alloc(N_); fvec_.alloc(S_.front_rows.size() ? S_.front_rows.size() : 1);
@@ -468,8 +542,11 @@ private:
     hipStream_t st_ = nullptr;
     sparse::Symbolic S_;
     std::vector<int> level_lds_;
+    int sub_lds_ = 0;
     CscOperators ops_;
     DBuf<double> vals_, fronts_, rdiag_, xp_, fvec_, dvec_;
+    DBuf<int> sub_lo_, sub_hi_;
+    DBuf<SnRec> snrec_;
     DBuf<int> diag_pos_, P_, level_sn_, sn_first_, front_rows_ptr_, front_rows_, child_ptr_, child_, rel_ptr_, rel_;
     DBuf<int> mapP_, mapA_, mapG_;
     DBuf<long long> a_dst_, front_off_;

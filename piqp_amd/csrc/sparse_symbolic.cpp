@@ -3,7 +3,9 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <stdexcept>
+#include <string>
 
 namespace pq {
 namespace sparse {
@@ -243,6 +245,125 @@ void amd_order(int n, const int* Ap, const int* Ai, int* perm)
     for (int i = 0; i < n; ++i) perm[i] = P[i];
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Nested dissection by BFS level structures (George & Liu, "Computer Solution of Large Sparse Positive Definite
+// Systems", 1981, ch. 8: automatic nested dissection): a connected part is split by the middle level of the rooted
+// level structure of a pseudo-peripheral node; parts below `leaf` nodes are ordered by AMD on their induced subgraph,
+// separators are numbered after both halves.  Not in the reference: its up-looking LDLt is serial, so it only cares
+// about fill (AMD).  On the device the numeric phase runs one assembly-tree LEVEL at a time, so the depth of the
+// tree is the length of the critical path; for chain-like KKT graphs (banded / staged problems) AMD produces trees
+// thousands of levels deep while dissection gives O(log N) separator levels on top of shallow leaves.
+void nd_order(int n, const int* Ap, const int* Ai, int* perm, int leaf)
+{
+    if (n <= 0) return;
+    // symmetric adjacency without the diagonal
+    IVec xadj(n + 1, 0);
+    for (int j = 0; j < n; ++j) for (int p = Ap[j]; p < Ap[j + 1]; ++p) { const int i = Ai[p]; if (i != j) { xadj[i + 1]++; xadj[j + 1]++; } }
+    for (int j = 0; j < n; ++j) xadj[j + 1] += xadj[j];
+    IVec adj(xadj[n]), nx(xadj.begin(), xadj.end() - 1);
+    for (int j = 0; j < n; ++j) for (int p = Ap[j]; p < Ap[j + 1]; ++p) { const int i = Ai[p]; if (i != j) { adj[nx[i]++] = j; adj[nx[j]++] = i; } }
+
+    IVec part(n, 0);      // current part id of every node (-1 = already numbered)
+    IVec level(n, -1), queue(n), local(n, -1);
+    int next_part = 1, pos = 0;
+    struct Item { int part; std::vector<int> nodes; bool is_sep; };
+    std::vector<Item> stack;
+    {
+        Item all; all.part = 0; all.is_sep = false; all.nodes.resize(n);
+        for (int i = 0; i < n; ++i) all.nodes[i] = i;
+        stack.push_back(std::move(all));
+    }
+    // rooted level structure of `root` inside part `pid`; returns number of levels, nodes in BFS order in queue[0..cnt)
+    auto bfs = [&](int root, int pid, int& cnt) {
+        int head = 0;
+        cnt = 0;
+        queue[cnt++] = root; level[root] = 0;
+        int maxl = 0;
+        while (head < cnt) {
+            const int v = queue[head++];
+            for (int q = xadj[v]; q < xadj[v + 1]; ++q) {
+                const int wn = adj[q];
+                if (part[wn] == pid && level[wn] < 0) { level[wn] = level[v] + 1; maxl = level[wn]; queue[cnt++] = wn; }
+            }
+        }
+        return maxl + 1;
+    };
+    auto number_leaf = [&](const std::vector<int>& nodes) {
+        const int k = (int)nodes.size();
+        if (k <= 2) { for (int v : nodes) perm[pos++] = v; return; }
+        for (int i = 0; i < k; ++i) local[nodes[i]] = i;
+        IVec lp(k + 1, 0), li;
+        for (int i = 0; i < k; ++i) {  // upper pattern of the induced subgraph, diagonal included
+            const int v = nodes[i];
+            for (int q = xadj[v]; q < xadj[v + 1]; ++q) { const int l = local[adj[q]]; if (l >= 0 && l < i) li.push_back(l); }
+            li.push_back(i);
+            lp[i + 1] = (int)li.size();
+        }
+        IVec lperm(k);
+        amd_order(k, lp.data(), li.data(), lperm.data());
+        for (int i = 0; i < k; ++i) perm[pos++] = nodes[lperm[i]];
+        for (int i = 0; i < k; ++i) local[nodes[i]] = -1;
+    };
+    // the stack is processed so that, for every dissection, both halves are numbered before their separator
+    while (!stack.empty()) {
+        Item it = std::move(stack.back());
+        stack.pop_back();
+        if (it.is_sep) { for (int v : it.nodes) { perm[pos++] = v; part[v] = -1; } continue; }
+        if ((int)it.nodes.size() <= leaf) { number_leaf(it.nodes); for (int v : it.nodes) part[v] = -1; continue; }
+        const int pid = it.part;
+        // connected component of the first node
+        int cnt = 0;
+        bfs(it.nodes[0], pid, cnt);
+        if (cnt < (int)it.nodes.size()) {  // disconnected: split off this component, revisit the rest
+            Item comp, rest;
+            comp.part = next_part++; comp.is_sep = false; rest.part = pid; rest.is_sep = false;
+            for (int q = 0; q < cnt; ++q) { comp.nodes.push_back(queue[q]); part[queue[q]] = comp.part; }
+            for (int v : it.nodes) if (part[v] == pid) rest.nodes.push_back(v);
+            for (int q = 0; q < cnt; ++q) level[queue[q]] = -1;
+            stack.push_back(std::move(rest));
+            stack.push_back(std::move(comp));
+            continue;
+        }
+        // pseudo-peripheral root: restart from a node of the last level while the structure gets deeper
+        int nlev = 0, root = queue[cnt - 1];
+        for (int sweep = 0; sweep < 4; ++sweep) {
+            for (int q = 0; q < cnt; ++q) level[queue[q]] = -1;
+            const int nl = bfs(root, pid, cnt);
+            if (nl <= nlev) { nlev = nl; break; }
+            nlev = nl;
+            root = queue[cnt - 1];
+        }
+        if (nlev < 3) {  // no interior level to cut at
+            for (int q = 0; q < cnt; ++q) level[queue[q]] = -1;
+            number_leaf(it.nodes);
+            for (int v : it.nodes) part[v] = -1;
+            continue;
+        }
+        // cut level: the smallest level within the middle third (by node count)
+        IVec lsize(nlev, 0);
+        for (int q = 0; q < cnt; ++q) lsize[level[queue[q]]]++;
+        int cum = 0, lo = 1, hi = nlev - 2;
+        for (int l = 0; l < nlev; ++l) { cum += lsize[l]; if (3 * cum < cnt) lo = std::max(lo, l + 1); if (3 * cum <= 2 * cnt) hi = std::min(nlev - 2, std::max(l, 1)); }
+        if (hi < lo) hi = lo = std::min(std::max(1, (lo + hi) / 2), nlev - 2);
+        int cut = lo;
+        for (int l = lo; l <= hi; ++l) if (lsize[l] < lsize[cut]) cut = l;
+        Item A, B, Sp;
+        A.part = next_part++; B.part = next_part++; Sp.part = -1;
+        A.is_sep = B.is_sep = false; Sp.is_sep = true;
+        for (int q = 0; q < cnt; ++q) {
+            const int v = queue[q];
+            if (level[v] < cut) { A.nodes.push_back(v); part[v] = A.part; }
+            else if (level[v] > cut) { B.nodes.push_back(v); part[v] = B.part; }
+            else { Sp.nodes.push_back(v); part[v] = -2; }
+            level[v] = -1;
+        }
+        stack.push_back(std::move(Sp));  // popped last
+        stack.push_back(std::move(B));
+        stack.push_back(std::move(A));
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // C = upper(P A P') with sorted rows; Ai_to_Ci maps value positions (sparse/utils.hpp:32-128)
 static void permute_sym_upper(int n, const IVec& Ap, const IVec& Ai, const int* perm_inv, IVec& Cp, IVec& Ci, IVec& Ai_to_Ci)
@@ -315,6 +436,8 @@ static void postorder(int n, const IVec& parent, IVec& post)
     }
 }
 
+static void analyse_with_order(Symbolic& S, const IVec& perm0);
+
 void analyse_kkt_full(const pq_sparse_data* d, Symbolic& S)
 {
     const int n = d->n, p = d->p, m = d->m, N = n + p + m;
@@ -354,9 +477,31 @@ void analyse_kkt_full(const pq_sparse_data* d, Symbolic& S)
         S.Ki[kk + c] = jk; S.Kx[kk + c] = 0.0;
     }
 
-    // ---- fill-reducing ordering, then postorder of the elimination tree (keeps the fill, makes subtrees contiguous)
-    IVec perm0(N), pinv0(N);
-    amd_order(N, S.Kp.data(), S.Ki.data(), perm0.data());
+    // ---- ordering: AMD (what the reference uses, sparse/ordering.hpp:72-74) or nested dissection, whichever gives the
+    // cheaper device schedule (levels = dependent kernel launches; fill = HBM traffic and flops)
+    IVec perm_amd(N);
+    amd_order(N, S.Kp.data(), S.Ki.data(), perm_amd.data());
+    const char* want = std::getenv("PIQP_AMD_ORDERING");
+    const std::string mode = want ? want : "auto";
+    if (mode == "amd" || (mode == "auto" && N < 4000)) { analyse_with_order(S, perm_amd); S.ordering = "amd"; return; }
+    IVec perm_nd(N);
+    nd_order(N, S.Kp.data(), S.Ki.data(), perm_nd.data(), 96);
+    Symbolic T = S;
+    analyse_with_order(T, perm_nd);
+    T.ordering = "nested dissection";
+    if (mode == "nd") { S = std::move(T); return; }
+    analyse_with_order(S, perm_amd);
+    S.ordering = "amd";
+    // ~12 us per level (one launch per level) against ~1e11 flop/s and ~1e12 B/s on small fronts
+    auto cost = [](const Symbolic& X) { return 12e-6 * (X.top_nlevels + 1) + X.flops / 1e11 + 8.0 * (double)X.front_doubles / 1e12; };
+    if (cost(T) < 0.7 * cost(S)) S = std::move(T);
+}
+
+// everything that follows from a fill-reducing ordering perm0 (perm0[new] = old) of K
+static void analyse_with_order(Symbolic& S, const IVec& perm0)
+{
+    const int N = S.N;
+    IVec pinv0(N);
     for (int i = 0; i < N; ++i) pinv0[perm0[i]] = i;
     {
         IVec Cp0, Ci0, map0, parent0, cc0, post;
@@ -444,6 +589,46 @@ void analyse_kkt_full(const pq_sparse_data* d, Symbolic& S)
     {
         IVec nx(S.level_ptr.begin(), S.level_ptr.end() - 1);
         for (int s = 0; s < ns; ++s) S.level_sn[nx[level[s]]++] = s;
+    }
+
+    // ---- subtree-to-workgroup partition: a supernode roots a "small subtree" when its whole subtree has at most SUB_COLS
+    // columns and its parent's does not.  Supernodes are numbered in postorder, so a subtree is the contiguous range
+    // [s - desc[s], s].
+    {
+        const int SUB_COLS = 192;
+        IVec cols(ns, 0), desc(ns, 0);
+        for (int s = 0; s < ns; ++s) {
+            cols[s] += S.sn_first[s + 1] - S.sn_first[s];
+            const int ps = S.sn_parent[s];
+            if (ps >= 0) { cols[ps] += cols[s]; desc[ps] += desc[s] + 1; }
+        }
+        IVec in_sub(ns, 0);
+        S.sub_lo.clear(); S.sub_hi.clear(); S.sub_max_front = 0;
+        for (int s = 0; s < ns; ++s) {
+            const int ps = S.sn_parent[s];
+            if (cols[s] <= SUB_COLS && (ps < 0 || cols[ps] > SUB_COLS)) {
+                S.sub_lo.push_back(s - desc[s]); S.sub_hi.push_back(s);
+                for (int t = s - desc[s]; t <= s; ++t) { in_sub[t] = 1; S.sub_max_front = std::max(S.sub_max_front, S.front_rows_ptr[t + 1] - S.front_rows_ptr[t]); }
+            }
+        }
+        S.nsub = (int)S.sub_lo.size();
+        IVec tl(ns, -1);
+        int tmax = -1;
+        for (int s = 0; s < ns; ++s) {
+            if (in_sub[s]) continue;
+            if (tl[s] < 0) tl[s] = 0;
+            tmax = std::max(tmax, tl[s]);
+            const int ps = S.sn_parent[s];
+            if (ps >= 0) tl[ps] = std::max(tl[ps], tl[s] + 1);
+        }
+        // a parent of a subtree root starts at level 0 (its subtree children are complete before the level phase)
+        S.top_nlevels = tmax + 1;
+        S.top_level_ptr.assign(S.top_nlevels + 1, 0);
+        for (int s = 0; s < ns; ++s) if (!in_sub[s]) S.top_level_ptr[tl[s] + 1]++;
+        for (int l = 0; l < S.top_nlevels; ++l) S.top_level_ptr[l + 1] += S.top_level_ptr[l];
+        S.top_level_sn.assign(S.top_level_ptr[S.top_nlevels], 0);
+        IVec nx(S.top_level_ptr.begin(), S.top_level_ptr.end() - 1);
+        for (int s = 0; s < ns; ++s) if (!in_sub[s]) S.top_level_sn[nx[tl[s]]++] = s;
     }
 
     // ---- assembly map: upper entry (i, k), i <= k  ==  lower entry (k, i) of the front that owns column i

@@ -45,6 +45,12 @@ struct Symbolic {
     std::vector<long long> front_off;  // nsuper+1 offsets (in doubles) into the front workspace
     IVec level_ptr, level_sn;          // supernodes grouped by level (leaves first)
     int nlevels = 0;
+    // device schedule: small subtrees are walked by ONE workgroup each (supernodes sub_lo[k]..sub_hi[k], a postorder range)
+    // in a single launch; only the supernodes above them are processed level by level (top_level_*)
+    IVec sub_lo, sub_hi;
+    int nsub = 0, sub_max_front = 0;
+    IVec top_level_ptr, top_level_sn;
+    int top_nlevels = 0;
     // assembly: PKPt value q goes to fronts[a_dst[q]]
     std::vector<long long> a_dst;
     // extend-add: for child c, rel[rel_ptr[c] + i] = position in the parent's front of c's i-th update row
@@ -54,9 +60,12 @@ struct Symbolic {
     long long nnzL = 0;      // entries of L below the diagonal (for the roofline byte counts)
     double flops = 0.0;      // sum_j (c_j^2 + 3 c_j)
     int max_front = 0;
+    const char* ordering = "amd";
 };
 
 void amd_order(int n, const int* Ap, const int* Ai, int* perm);
+// nested dissection by BFS level structures, AMD inside parts of at most `leaf` nodes; perm[new] = old
+void nd_order(int n, const int* Ap, const int* Ai, int* perm, int leaf);
 void analyse_kkt_full(const pq_sparse_data* d, Symbolic& S);
 
 }  // namespace sparse

@@ -1,0 +1,98 @@
+#!/usr/bin/env python3
+"""BASELINE configs[2] (C3): sparse QP n=50k, nnz(KKT) ~ 1M, sparse_ldlt (supernodal multifrontal LDLt) on the device next to
+the CPU oracle (restatement of the reference's up-looking LDLt with the same AMD ordering).
+
+  python tools/prof_sparse.py [--n 50000] [--reps 10] [--no-oracle]
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import scipy.sparse as sp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def c3_problem(n=50000, p=20000, m=30000, seed=44, spread=40):
+    """P banded upper-tri (~3 nnz/col + diagonal), A and G rows with 5 nnz each"""
+    rng = np.random.default_rng(seed)
+    P = sp.diags([rng.uniform(1, 2, n), rng.uniform(-0.3, 0.3, n - 1), rng.uniform(-0.2, 0.2, n - 2), rng.uniform(-0.1, 0.1, n - 3)], [0, 1, 2, 3], format="csc")
+
+    def rows(k):
+        cols = (rng.integers(0, n - spread, k)[:, None] + rng.choice(spread, (k, 5), replace=True)).ravel()
+        M = sp.csc_matrix((rng.standard_normal(5 * k), (np.repeat(np.arange(k), 5), cols)), shape=(k, n))
+        M.sum_duplicates()
+        return M
+    A, G = rows(p), rows(m)
+    return (P, rng.standard_normal(n), A, np.zeros(p), G, -np.ones(m), np.ones(m), None, None), (n, p, m)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=50000)
+    ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--no-oracle", action="store_true")
+    args = ap.parse_args()
+    import torch  # noqa: F401
+    import piqp_amd as hip
+    from qp_gen import random_vars
+    scale = args.n / 50000.0
+    a, (n, p, m) = c3_problem(args.n, int(20000 * scale), int(30000 * scale))
+    nnzK = sp.triu(a[0]).nnz + a[2].nnz + p + a[4].nnz + m
+    t0 = time.perf_counter()
+    d = hip.SparseData(*a)
+    k = hip.KKTSystem(d, hip.default_settings(kkt_solver=hip.SPARSE_LDLT))
+    t_setup = time.perf_counter() - t0
+    be = k.backend()
+    be.print_info()
+    rng = np.random.default_rng(0)
+    state = random_vars(n, p, m, rng, positive=True)
+    rhs = random_vars(n, p, m, rng)
+    for _ in range(2):
+        assert k.update_scalings_and_factor(False, 1e-6, 1e-4, state)
+        k.solve(rhs)
+    be.set_profiling(True)
+    k.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.reps):
+        k.update_scalings_and_factor(False, 1e-6, 1e-4, state)
+    k.synchronize()
+    t_fac = (time.perf_counter() - t0) / args.reps
+    t0 = time.perf_counter()
+    for _ in range(args.reps):
+        ok, lhs = k.solve(rhs)
+    k.synchronize()
+    t_sol = (time.perf_counter() - t0) / args.reps
+    be.set_profiling(False)
+    prof = [be.get_profile(s) for s in range(3)]
+    res, nrm = k.condensed_residual()
+    print(f"C3 n={n} p={p} m={m} nnz(upper KKT)={nnzK}  setup {t_setup:.2f} s")
+    print(f"device: factor call {t_fac * 1e3:.3f} ms (assembly {prof[0][0] / max(prof[0][1], 1):.3f} ms, numeric {prof[1][0] / max(prof[1][1], 1):.3f} ms)  "
+          f"KKTSystem::solve {t_sol * 1e3:.3f} ms (backend solve {prof[2][0] / max(prof[2][1], 1):.3f} ms)  rel.res {res / nrm:.2e}")
+    print(f"device: {1.0 / (t_fac + 2 * t_sol):.1f} IPM-iter KKT (1 factor + 2 solves)/s")
+    if not args.no_oracle:
+        from oracle import pyorc as orc
+        od = orc.Data.sparse(*a)
+        t0 = time.perf_counter()
+        ko = orc.KKTSystem(od, orc.Settings(kkt_solver=orc.SPARSE_LDLT))
+        o_setup = time.perf_counter() - t0
+        ko.update_scalings_and_factor(False, 1e-6, 1e-4, state)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            ko.update_scalings_and_factor(False, 1e-6, 1e-4, state)
+        o_fac = (time.perf_counter() - t0) / 3
+        t0 = time.perf_counter()
+        for _ in range(3):
+            ko.solve(rhs)
+        o_sol = (time.perf_counter() - t0) / 3
+        L = orc.lib()
+        print(f"oracle (1 core): setup {o_setup:.2f} s  factor {o_fac * 1e3:.3f} ms  solve {o_sol * 1e3:.3f} ms  nnz(L) {L.orc_sparse_kkt_L_nnz(ko.backend().ptr)}  "
+              f"-> {1.0 / (o_fac + 2 * o_sol):.1f} IPM-iter KKT/s")
+
+
+if __name__ == "__main__":
+    main()
