@@ -483,7 +483,7 @@ void analyse_kkt_full(const pq_sparse_data* d, Symbolic& S)
     amd_order(N, S.Kp.data(), S.Ki.data(), perm_amd.data());
     const char* want = std::getenv("PIQP_AMD_ORDERING");
     const std::string mode = want ? want : "auto";
-    if (mode == "amd" || (mode == "auto" && N < 4000)) { analyse_with_order(S, perm_amd); S.ordering = "amd"; return; }
+    if (mode == "amd" || (mode == "auto" && N < 200)) { analyse_with_order(S, perm_amd); S.ordering = "amd"; return; }
     IVec perm_nd(N);
     nd_order(N, S.Kp.data(), S.Ki.data(), perm_nd.data(), 96);
     Symbolic T = S;

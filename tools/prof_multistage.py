@@ -38,6 +38,7 @@ def mpc_chain(nx, nu, T, seed):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=50)
+    ap.add_argument("--c5", action="store_true", help="only BASELINE configs[4]: one block-tridiagonal QP, n = 500k (25000 stages of n_x=12, n_u=8)")
     args = ap.parse_args()
     import torch  # noqa: F401
     import piqp_amd as hip
@@ -52,13 +53,19 @@ def main():
     cases = [("c0_scenario_mpc", fixture("qp_c0_scenario_mpc")), ("scenario_mpc", fixture("qp_scenario_mpc")), ("chain_mass_sqp", fixture("qp_chain_mass_sqp")),
              ("robot_arm_sqp", fixture("qp_robot_arm_sqp")), ("mpc nx=2 nu=1 T=40", mpc_chain(2, 1, 40, 1)), ("mpc nx=12 nu=8 T=1000", mpc_chain(12, 8, 1000, 2)),
              ("mpc nx=12 nu=8 T=5000", mpc_chain(12, 8, 5000, 3))]
+    if args.c5:
+        cases = [("C5 mpc nx=12 nu=8 T=25000", mpc_chain(12, 8, 25000, 5))]
     for name, a in cases:
         d = hip.SparseData(*a); od = orc.Data.sparse(*a)
         n, p, m = od.n, od.p, od.m
         rng = np.random.default_rng(0)
-        for ks, kname in ((hip.SPARSE_MULTISTAGE, "multistage"), (hip.SPARSE_LDLT, "sparse_ldlt")):
+        for ks, kname in (((hip.SPARSE_LDLT, "sparse_ldlt"),) if args.c5 else ((hip.SPARSE_MULTISTAGE, "multistage"), (hip.SPARSE_LDLT, "sparse_ldlt"))):
+            t_s = time.perf_counter()
             k = hip.KKTSystem(d, hip.default_settings(kkt_solver=ks))
-            ko = orc.KKTSystem(od, orc.Settings(kkt_solver=ks))
+            t_setup = time.perf_counter() - t_s
+            ko = orc.KKTSystem(od, orc.Settings(kkt_solver=ks if not args.c5 else orc.SPARSE_MULTISTAGE))
+            if args.c5:
+                k.backend().print_info(); print(f"    device setup {t_setup:.2f} s (oracle column = CPU multistage backend)")
             state = random_vars(n, p, m, rng, positive=True)
             rhs = random_vars(n, p, m, rng)
             be = k.backend()
