@@ -186,6 +186,9 @@ void orc_sparse_ldlt_symbolic(orc_sparse_ldlt *f, int n, const int *Ap, const in
 int orc_sparse_ldlt_numeric(orc_sparse_ldlt *f, int n, const int *Ap, const int *Ai, const double *Ax);
 void orc_sparse_ldlt_solve_inplace(const orc_sparse_ldlt *f, double *x);
 int orc_sparse_ldlt_nnz(const orc_sparse_ldlt *f);
+orc_sparse_ldlt *orc_sparse_ldlt_clone(const orc_sparse_ldlt *f);
+/* condensed modes: KKT_EQ_ELIMINATED = 1, KKT_INEQ_ELIMINATED = 2, KKT_ALL_ELIMINATED = 3 (kkt_fwd.hpp:15-21) */
+orc_kkt *orc_sparse_cond_kkt_create(const orc_data *d, int mode);
 /* AMD ordering (sparse/ordering.hpp:67-84 -> Eigen::AMDOrdering, third-party) on the pattern of an
  * upper-triangular CSC matrix; writes perm[n] (new -> old). */
 void orc_amd_order(int n, const int *Ap, const int *Ai, int *perm);

@@ -52,7 +52,7 @@ static void ldlt_release(orc_sparse_ldlt *f)
 void orc_sparse_ldlt_free(orc_sparse_ldlt *f) { if (f) { ldlt_release(f); free(f); } }
 int orc_sparse_ldlt_nnz(const orc_sparse_ldlt *f) { return f->L_cols ? f->L_cols[f->n] : 0; }
 
-static orc_sparse_ldlt *ldlt_clone(const orc_sparse_ldlt *s)
+orc_sparse_ldlt *orc_sparse_ldlt_clone(const orc_sparse_ldlt *s)
 {
     orc_sparse_ldlt *f = orc_sparse_ldlt_create();
     int n = s->n, nnz = s->L_cols ? s->L_cols[n] : 0;
@@ -500,6 +500,8 @@ void orc_permute_sym_upper(int n, const int *Ap, const int *Ai, const double *Ax
     free(w); free(CTp); free(CTi); free(CTi_to_Ai); free(CTx);
 }
 
+orc_kkt *orc_sparse_cond_kkt_create(const orc_data *d, int mode) __attribute__((weak));
+
 /* =================================================================================== sparse::KKT<FULL> */
 typedef struct {
     orc_kkt base;
@@ -639,7 +641,11 @@ static void sparse_fill_vtable(sparse_kkt *k)
 /* sparse/kkt.hpp:51-70 with create_kkt_matrix of kkt_full.hpp:39-170 */
 orc_kkt *orc_sparse_kkt_create(const orc_data *d, int mode)
 {
-    if (mode != 0) { fprintf(stderr, "kkt solver not supported\n"); return NULL; }
+    if (mode != 0) {  /* condensed modes live in orc_sparse_cond.c */
+        if (orc_sparse_cond_kkt_create) return orc_sparse_cond_kkt_create(d, mode);
+        fprintf(stderr, "kkt solver not supported\n");
+        return NULL;
+    }
     sparse_kkt *k = (sparse_kkt *)calloc(1, sizeof(sparse_kkt));
     sparse_fill_vtable(k);
     int n = d->n, p = d->p, m = d->m, N = n + p + m;
@@ -714,7 +720,7 @@ static orc_kkt *sparse_clone(const orc_kkt *self)
     k->PKPt_p = idup(s->PKPt_p, N + 1); k->PKPt_i = idup(s->PKPt_i, nz); k->PKPt_x = ddup(s->PKPt_x, nz); k->PKi = idup(s->PKi, nz);
     k->P_utri_to_Ki = idup(s->P_utri_to_Ki, s->nzP); k->AT_to_Ki = idup(s->AT_to_Ki, s->nzA); k->GT_to_Ki = idup(s->GT_to_Ki, s->nzG);
     k->P_diagonal = ddup(s->P_diagonal, s->n);
-    k->ldlt = ldlt_clone(s->ldlt);
+    k->ldlt = orc_sparse_ldlt_clone(s->ldlt);
     k->rhs = dalloc(N); k->rhs_perm = dalloc(N);
     return &k->base;
 }

@@ -63,6 +63,41 @@ __global__ void k_set_diag(int n, int p, int m, const int* __restrict__ diag_pos
     vals[diag_pos[col]] = v;
 }
 
+// condensed modes (kkt_{eq,ineq,all}_eliminated.hpp update_kkt_*): diagonal of the top-left block += x_reg, of a kept
+// constraint block = -delta / -z_reg; col indexes the columns of K in the caller's order (n, then kept p, then kept m)
+__global__ void k_cond_diag(int n, int np, int nm, const int* __restrict__ diag_pos, const double* __restrict__ x_reg, double delta, const double* __restrict__ z_reg,
+                            double* __restrict__ vals)
+{
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= n + np + nm) return;
+    if (col < n) vals[diag_pos[col]] += x_reg[col];
+    else if (col < n + np) vals[diag_pos[col]] = -delta;
+    else vals[diag_pos[col]] = -z_reg[col - n - np];
+}
+// value of every entry of upper(MT diag(1/w) MT^T) from its product-term list (constraints ascending, the reference's order);
+// w == nullptr: unit weights.  out[e] (ACC: += alpha * sum, through the index map dst) 
+template <bool MAPPED>
+__global__ void k_gram_values(int nent, const int* __restrict__ ptr, const int* __restrict__ q1, const int* __restrict__ q2, const int* __restrict__ kk,
+                              const double* __restrict__ x, const double* __restrict__ w, const int* __restrict__ dst, double* __restrict__ out)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nent) return;
+    double s = 0.0;
+    if (w) for (int t = ptr[e]; t < ptr[e + 1]; ++t) s += x[q2[t]] * x[q1[t]] / w[kk[t]];
+    else for (int t = ptr[e]; t < ptr[e + 1]; ++t) s += x[q2[t]] * x[q1[t]];
+    if (MAPPED) out[dst[e]] += s; else out[e] = s;
+}
+__global__ void k_axpy_mapped(int nent, const int* __restrict__ dst, double alpha, const double* __restrict__ src, double* __restrict__ out)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < nent) out[dst[e]] += alpha * src[e];
+}
+__global__ void k_reciprocal(int m, const double* __restrict__ z, double* __restrict__ zinv)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) zinv[i] = 1.0 / z[i];
+}
+
 __global__ void k_scatter_fronts(int nnz, const long long* __restrict__ a_dst, const double* __restrict__ vals, double* __restrict__ fronts)
 {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
@@ -285,12 +320,12 @@ inline dim3 g1(int n) { return dim3(n > 0 ? (n + 255) / 256 : 1); }
 
 class SparseKKT final : public KKTSolverBase {
 public:
-    SparseKKT(const pq_sparse_data* d, int device) : dev_(device)
+    SparseKKT(const pq_sparse_data* d, int mode, int device) : dev_(device), mode_(mode)
     {
         if (d->mem != PQ_MEM_HOST) throw std::runtime_error("sparse data must be host-resident");
         PQ_HIP(hipSetDevice(dev_));
         PQ_HIP(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
-        sparse::analyse_kkt_full(d, S_);
+        sparse::analyse_kkt(d, mode, S_);
         n_ = S_.n; p_ = S_.p; m_ = S_.m; N_ = S_.N;
         compute_level_lds();
         build_device(d);
@@ -325,7 +360,21 @@ public:
         PQ_HIP(hipSetDevice(dev_));
         delta_ = delta;
         const int t0 = prof_.begin(0, st_);
-        hipLaunchKernelGGL(k_set_diag, g1(N_), dim3(256), 0, st_, n_, p_, m_, diag_pos_.p, ops_.P_diag(), x_reg, delta, z_reg, vals_.p);
+        if (mode_ == 0) {
+            hipLaunchKernelGGL(k_set_diag, g1(N_), dim3(256), 0, st_, n_, p_, m_, diag_pos_.p, ops_.P_diag(), x_reg, delta, z_reg, vals_.p);
+        } else {
+            // update_kkt_cost_scalings / _equality_scalings / _inequality_scaling of the mode, in the reference's accumulation order
+            const bool eq = mode_ & 1, ineq = mode_ & 2;
+            if (m_ > 0) hipLaunchKernelGGL(k_reciprocal, g1(m_), dim3(256), 0, st_, m_, z_reg, zinv_.p);
+            PQ_HIP(hipMemsetAsync(vals_.p, 0, sizeof(double) * (size_t)nnzK_, st_));
+            launch_remap_values(ops_.nzP(), mapP_.p, ops_.P_x(), vals_.p, st_);
+            hipLaunchKernelGGL(k_cond_diag, g1(N_), dim3(256), 0, st_, n_, eq ? 0 : p_, ineq ? 0 : m_, diag_pos_.p, x_reg, delta, z_reg, vals_.p);
+            if (eq) { if (nzAA_) hipLaunchKernelGGL(k_axpy_mapped, g1(nzAA_), dim3(256), 0, st_, nzAA_, mapAA_.p, 1.0 / delta, ata_vals_.p, vals_.p); }
+            else launch_remap_values(ops_.nzA(), mapA_.p, ops_.AT_x(), vals_.p, st_);
+            if (ineq) {
+                if (nzGG_) hipLaunchKernelGGL(k_gram_values<true>, g1(nzGG_), dim3(256), 0, st_, nzGG_, gg_ptr_.p, gg_q1_.p, gg_q2_.p, gg_k_.p, ops_.GT_x(), z_reg, mapGG_.p, vals_.p);
+            } else launch_remap_values(ops_.nzG(), mapG_.p, ops_.GT_x(), vals_.p, st_);
+        }
         PQ_HIP(hipMemsetAsync(fronts_.p, 0, sizeof(double) * (size_t)S_.front_doubles, st_));
         hipLaunchKernelGGL(k_scatter_fronts, g1(nnzK_), dim3(256), 0, st_, nnzK_, a_dst_.p, vals_.p, fronts_.p);
         prof_.end(0, t0, st_);
@@ -357,7 +406,17 @@ public:
         PQ_HIP(hipSetDevice(dev_));
         const int tk = prof_.begin(2, st_);
         FrontMeta M = meta();
-        hipLaunchKernelGGL(k_perm_gather, g1(N_), dim3(256), 0, st_, N_, P_.p, rhs_x, n_, rhs_y, p_, rhs_z, xp_.p);
+        const bool eq = mode_ & 1, ineq = mode_ & 2;
+        const double delta_inv = 1.0 / delta_;
+        if (mode_ == 0) {
+            hipLaunchKernelGGL(k_perm_gather, g1(N_), dim3(256), 0, st_, N_, P_.p, rhs_x, n_, rhs_y, p_, rhs_z, xp_.p);
+        } else {
+            // sparse/kkt.hpp:113-136: fold the eliminated blocks into the x part of the right-hand side
+            ops_.fold_rhs(rhs_x, rhs_y, rhs_z, zinv_.p, delta_inv, rhs_top_.p, st_, eq, ineq);
+            const double* tail = mode_ == 1 ? rhs_z : rhs_y;
+            const int ntail = mode_ == 1 ? m_ : (mode_ == 2 ? p_ : 0);
+            hipLaunchKernelGGL(k_perm_gather, g1(N_), dim3(256), 0, st_, N_, P_.p, rhs_top_.p, n_, tail, ntail, (const double*)nullptr, xp_.p);
+        }
         if (S_.nsub > 0) hipLaunchKernelGGL(k_subtree_fwd, dim3(S_.nsub), dim3(SUB_THREADS), 0, st_, M, fronts_.p, sub_lo_.p, sub_hi_.p, xp_.p, fvec_.p);
         for (int l = 0; l < S_.top_nlevels; ++l) {
             const int cnt = S_.top_level_ptr[l + 1] - S_.top_level_ptr[l];
@@ -369,7 +428,14 @@ public:
             hipLaunchKernelGGL(k_front_bwd, dim3(cnt), dim3(256), 0, st_, M, fronts_.p, level_sn_.p + S_.top_level_ptr[l], xp_.p, fvec_.p);
         }
         if (S_.nsub > 0) hipLaunchKernelGGL(k_subtree_bwd, dim3(S_.nsub), dim3(SUB_THREADS), 0, st_, M, fronts_.p, sub_lo_.p, sub_hi_.p, xp_.p, fvec_.p);
-        hipLaunchKernelGGL(k_perm_scatter, g1(N_), dim3(256), 0, st_, N_, P_.p, xp_.p, lhs_x, n_, lhs_y, p_, lhs_z);
+        if (mode_ == 0) {
+            hipLaunchKernelGGL(k_perm_scatter, g1(N_), dim3(256), 0, st_, N_, P_.p, xp_.p, lhs_x, n_, lhs_y, p_, lhs_z);
+        } else {
+            double* tail = mode_ == 1 ? lhs_z : lhs_y;
+            const int ntail = mode_ == 1 ? m_ : (mode_ == 2 ? p_ : 0);
+            hipLaunchKernelGGL(k_perm_scatter, g1(N_), dim3(256), 0, st_, N_, P_.p, xp_.p, lhs_x, n_, tail, ntail, (double*)nullptr);
+            ops_.recover_duals(lhs_x, rhs_y, rhs_z, zinv_.p, delta_inv, lhs_y, lhs_z, st_, eq, ineq);  // sparse/kkt.hpp:147-175
+        }
         PQ_HIP(hipGetLastError());
         prof_.end(2, tk, st_);
     }
@@ -413,7 +479,7 @@ public:
     const sparse::Symbolic& symbolic() const { return S_; }
 
 private:
-    SparseKKT(const SparseKKT& o, int) : dev_(o.dev_), n_(o.n_), p_(o.p_), m_(o.m_), N_(o.N_), nnzK_(o.nnzK_), delta_(o.delta_), S_(o.S_), level_lds_(o.level_lds_), sub_lds_(o.sub_lds_)
+    SparseKKT(const SparseKKT& o, int) : dev_(o.dev_), mode_(o.mode_), nzAA_(o.nzAA_), nzGG_(o.nzGG_), n_(o.n_), p_(o.p_), m_(o.m_), N_(o.N_), nnzK_(o.nnzK_), delta_(o.delta_), S_(o.S_), level_lds_(o.level_lds_), sub_lds_(o.sub_lds_)
     {
         PQ_HIP(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
         auto cpd = [&](DBuf<double>& d, const DBuf<double>& s) { d.alloc(s.n ? s.n : 1); if (s.n) PQ_HIP(hipMemcpyAsync(d.p, s.p, s.bytes(), hipMemcpyDeviceToDevice, st_)); };
@@ -426,6 +492,9 @@ private:
         snrec_.alloc(o.snrec_.n ? o.snrec_.n : 1); if (o.snrec_.n) PQ_HIP(hipMemcpyAsync(snrec_.p, o.snrec_.p, o.snrec_.bytes(), hipMemcpyDeviceToDevice, st_)); cpi(sn_first_, o.sn_first_); cpi(front_rows_ptr_, o.front_rows_ptr_); cpi(front_rows_, o.front_rows_);
         cpi(child_ptr_, o.child_ptr_); cpi(child_, o.child_); cpi(rel_ptr_, o.rel_ptr_); cpi(rel_, o.rel_);
         cpi(mapP_, o.mapP_); cpi(mapA_, o.mapA_); cpi(mapG_, o.mapG_);
+        cpi(mapAA_, o.mapAA_); cpi(mapGG_, o.mapGG_); cpi(aa_ptr_, o.aa_ptr_); cpi(aa_q1_, o.aa_q1_); cpi(aa_q2_, o.aa_q2_); cpi(aa_k_, o.aa_k_);
+        cpi(gg_ptr_, o.gg_ptr_); cpi(gg_q1_, o.gg_q1_); cpi(gg_q2_, o.gg_q2_); cpi(gg_k_, o.gg_k_);
+        cpd(ata_vals_, o.ata_vals_); cpd(zinv_, o.zinv_); rhs_top_.alloc(o.rhs_top_.n ? o.rhs_top_.n : 1);
         cpl(a_dst_, o.a_dst_); cpl(front_off_, o.front_off_);
         info_.alloc(1); info_h_.alloc(1);
         PQ_HIP(hipStreamSynchronize(st_));
@@ -481,11 +550,21 @@ private:
         info_.alloc(1); info_h_.alloc(1);
         // value maps K-index -> PKPt-index composed with the per-matrix maps (kkt_full.hpp:219-249)
         const int nzP = d->P_colptr[n_], nzA = p_ ? d->AT_colptr[p_] : 0, nzG = m_ ? d->GT_colptr[m_] : 0;
-        std::vector<int> mp(nzP), ma(nzA), mg(nzG);
+        const bool eq = mode_ & 1, ineq = mode_ & 2;
+        std::vector<int> mp(nzP), ma(eq ? 0 : nzA), mg(ineq ? 0 : nzG);
         for (int q = 0; q < nzP; ++q) mp[q] = S_.PKi[S_.P_utri_to_Ki[q]];
-        for (int q = 0; q < nzA; ++q) ma[q] = S_.PKi[S_.AT_to_Ki[q]];
-        for (int q = 0; q < nzG; ++q) mg[q] = S_.PKi[S_.GT_to_Ki[q]];
+        for (size_t q = 0; q < ma.size(); ++q) ma[q] = S_.PKi[S_.AT_to_Ki[q]];
+        for (size_t q = 0; q < mg.size(); ++q) mg[q] = S_.PKi[S_.GT_to_Ki[q]];
         upload_vec(mapP_, mp, st_); upload_vec(mapA_, ma, st_); upload_vec(mapG_, mg, st_);
+        // eliminated blocks: entry -> PKPt index and product-term lists
+        nzAA_ = (int)S_.gramA.rowind.size(); nzGG_ = (int)S_.gramG.rowind.size();
+        std::vector<int> maa(nzAA_), mgg(nzGG_);
+        for (int e = 0; e < nzAA_; ++e) maa[e] = S_.PKi[S_.gramA_to_Ki[e]];
+        for (int e = 0; e < nzGG_; ++e) mgg[e] = S_.PKi[S_.gramG_to_Ki[e]];
+        upload_vec(mapAA_, maa, st_); upload_vec(mapGG_, mgg, st_);
+        upload_vec(aa_ptr_, S_.gramA.ptr, st_); upload_vec(aa_q1_, S_.gramA.q1, st_); upload_vec(aa_q2_, S_.gramA.q2, st_); upload_vec(aa_k_, S_.gramA.k, st_);
+        upload_vec(gg_ptr_, S_.gramG.ptr, st_); upload_vec(gg_q1_, S_.gramG.q1, st_); upload_vec(gg_q2_, S_.gramG.q2, st_); upload_vec(gg_k_, S_.gramG.k, st_);
+        ata_vals_.alloc(nzAA_ ? nzAA_ : 1); zinv_.alloc(m_ ? m_ : 1); rhs_top_.alloc(n_ ? n_ : 1);
         ops_.init(d, st_);  // CSC copies for the mat-vecs (uploads the values once)
         remap_values();
     }
@@ -499,9 +578,15 @@ private:
     // device copies of the caller's values -> PKPt value array
     void remap_values()
     {
-        launch_remap_values(ops_.nzP(), mapP_.p, ops_.P_x(), vals_.p, st_);
-        launch_remap_values(ops_.nzA(), mapA_.p, ops_.AT_x(), vals_.p, st_);
-        launch_remap_values(ops_.nzG(), mapG_.p, ops_.GT_x(), vals_.p, st_);
+        if (mode_ == 0) {
+            launch_remap_values(ops_.nzP(), mapP_.p, ops_.P_x(), vals_.p, st_);
+            launch_remap_values(ops_.nzA(), mapA_.p, ops_.AT_x(), vals_.p, st_);
+            launch_remap_values(ops_.nzG(), mapG_.p, ops_.GT_x(), vals_.p, st_);
+        } else if ((mode_ & 1) && nzAA_) {
+            // update_AT_A (kkt_all_eliminated.hpp:184-202): the values change only with the data; every factorisation rebuilds PKPt
+            hipLaunchKernelGGL(k_gram_values<false>, g1(nzAA_), dim3(256), 0, st_, nzAA_, aa_ptr_.p, aa_q1_.p, aa_q2_.p, aa_k_.p, ops_.AT_x(), (const double*)nullptr,
+                               (const int*)nullptr, ata_vals_.p);
+        }
         PQ_HIP(hipGetLastError());
         PQ_HIP(hipStreamSynchronize(st_));
     }
@@ -537,7 +622,7 @@ private:
         }
     }
 
-    int dev_, n_ = 0, p_ = 0, m_ = 0, N_ = 0, nnzK_ = 0;
+    int dev_, mode_ = 0, nzAA_ = 0, nzGG_ = 0, n_ = 0, p_ = 0, m_ = 0, N_ = 0, nnzK_ = 0;
     double delta_ = 1.0;
     hipStream_t st_ = nullptr;
     sparse::Symbolic S_;
@@ -548,7 +633,8 @@ private:
     DBuf<int> sub_lo_, sub_hi_;
     DBuf<SnRec> snrec_;
     DBuf<int> diag_pos_, P_, level_sn_, sn_first_, front_rows_ptr_, front_rows_, child_ptr_, child_, rel_ptr_, rel_;
-    DBuf<int> mapP_, mapA_, mapG_;
+    DBuf<int> mapP_, mapA_, mapG_, mapAA_, mapGG_, aa_ptr_, aa_q1_, aa_q2_, aa_k_, gg_ptr_, gg_q1_, gg_q2_, gg_k_;
+    DBuf<double> ata_vals_, zinv_, rhs_top_;
     DBuf<long long> a_dst_, front_off_;
     DBuf<int> info_;
     HBuf<int> info_h_;
@@ -557,13 +643,17 @@ private:
 
 }  // namespace
 
-// KKTSystem::init_kkt_solver<PIQP_SPARSE> (kkt_system.hpp:470-497): sparse_ldlt (KKT_FULL) and sparse_multistage exist in this
-// release; the condensed modes report "kkt solver not supported" exactly like a build without them.
+// KKTSystem::init_kkt_solver<PIQP_SPARSE> (kkt_system.hpp:470-497): all six sparse backends of the reference
 KKTSolverBase* make_sparse_kkt(const pq_sparse_data* data, int kkt_solver, int device)
 {
-    if (kkt_solver == PQ_SPARSE_MULTISTAGE) return make_multistage_kkt(data, device);
-    if (kkt_solver != PQ_SPARSE_LDLT) return nullptr;
-    return new SparseKKT(data, device);
+    switch (kkt_solver) {
+    case PQ_SPARSE_MULTISTAGE: return make_multistage_kkt(data, device);
+    case PQ_SPARSE_LDLT: return new SparseKKT(data, 0, device);
+    case PQ_SPARSE_LDLT_EQ_COND: return new SparseKKT(data, 1, device);    // KKTMode::KKT_EQ_ELIMINATED
+    case PQ_SPARSE_LDLT_INEQ_COND: return new SparseKKT(data, 2, device);  // KKTMode::KKT_INEQ_ELIMINATED
+    case PQ_SPARSE_LDLT_COND: return new SparseKKT(data, 3, device);       // KKTMode::KKT_ALL_ELIMINATED
+    default: return nullptr;
+    }
 }
 
 }  // namespace pq

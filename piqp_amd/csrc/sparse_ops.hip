@@ -40,26 +40,29 @@ __global__ void k_spmv_cols(int ncols, const int* __restrict__ colptr, const int
 // out[j] = rhs_x[j] + sum_{G rows i of column j} G(i,j) zinv[i] rhs_z[i] + delta_inv * sum_{A rows i} A(i,j) rhs_y[i]
 __global__ void k_fold_rhs(int n, const int* __restrict__ Gp, const int* __restrict__ Gi, const double* __restrict__ Gx, const int* __restrict__ Ap, const int* __restrict__ Ai,
                            const double* __restrict__ Ax, const double* __restrict__ rhs_x, const double* __restrict__ rhs_y, const double* __restrict__ rhs_z,
-                           const double* __restrict__ zinv, double delta_inv, double* __restrict__ out)
+                           const double* __restrict__ zinv, double delta_inv, double* __restrict__ out, int with_A, int with_G)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
     double sg = 0.0, sa = 0.0;
-    for (int q = Gp[j]; q < Gp[j + 1]; ++q) { const int i = Gi[q]; sg += Gx[q] * (zinv[i] * rhs_z[i]); }
-    for (int q = Ap[j]; q < Ap[j + 1]; ++q) sa += Ax[q] * rhs_y[Ai[q]];
+    if (with_G) for (int q = Gp[j]; q < Gp[j + 1]; ++q) { const int i = Gi[q]; sg += Gx[q] * (zinv[i] * rhs_z[i]); }
+    if (with_A) for (int q = Ap[j]; q < Ap[j + 1]; ++q) sa += Ax[q] * rhs_y[Ai[q]];
     out[j] = (rhs_x[j] + sg) + delta_inv * sa;
 }
 // rows k < p: lhs_y ; rows p <= k < p + m: lhs_z
 __global__ void k_recover_duals(int p, int m, const int* __restrict__ ATp, const int* __restrict__ ATi, const double* __restrict__ ATx, const int* __restrict__ GTp,
                                 const int* __restrict__ GTi, const double* __restrict__ GTx, const double* __restrict__ x, const double* __restrict__ rhs_y,
-                                const double* __restrict__ rhs_z, const double* __restrict__ zinv, double delta_inv, double* __restrict__ lhs_y, double* __restrict__ lhs_z)
+                                const double* __restrict__ rhs_z, const double* __restrict__ zinv, double delta_inv, double* __restrict__ lhs_y, double* __restrict__ lhs_z,
+                                int with_A, int with_G)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k < p) {
+        if (!with_A) return;
         double s = 0.0;
         for (int q = ATp[k]; q < ATp[k + 1]; ++q) s += ATx[q] * x[ATi[q]];
         lhs_y[k] = delta_inv * s - delta_inv * rhs_y[k];
     } else if (k < p + m) {
+        if (!with_G) return;
         const int i = k - p;
         double s = 0.0;
         for (int q = GTp[i]; q < GTp[i + 1]; ++q) s += GTx[q] * x[GTi[q]];
@@ -176,14 +179,18 @@ void CscOperators::eval_G_xn_and_GT_xt(double an, double at, const double* xn, c
     if (m_ > 0) hipLaunchKernelGGL(k_spmv_cols<false>, g1(m_), dim3(256), 0, st, m_, GT_p_.p, GT_i_.p, GT_x_.p, xn, an, zn);
     hipLaunchKernelGGL(k_spmv_cols<false>, g1(n_), dim3(256), 0, st, n_, G_p_.p, G_i_.p, G_x_.p, xt, at, zt);
 }
-void CscOperators::fold_rhs(const double* rhs_x, const double* rhs_y, const double* rhs_z, const double* zinv, double delta_inv, double* out, hipStream_t st) const
+void CscOperators::fold_rhs(const double* rhs_x, const double* rhs_y, const double* rhs_z, const double* zinv, double delta_inv, double* out, hipStream_t st, bool with_A,
+                            bool with_G) const
 {
-    hipLaunchKernelGGL(k_fold_rhs, g1(n_), dim3(256), 0, st, n_, G_p_.p, G_i_.p, G_x_.p, A_p_.p, A_i_.p, A_x_.p, rhs_x, rhs_y, rhs_z, zinv, delta_inv, out);
+    hipLaunchKernelGGL(k_fold_rhs, g1(n_), dim3(256), 0, st, n_, G_p_.p, G_i_.p, G_x_.p, A_p_.p, A_i_.p, A_x_.p, rhs_x, rhs_y, rhs_z, zinv, delta_inv, out, with_A ? 1 : 0,
+                       with_G ? 1 : 0);
 }
-void CscOperators::recover_duals(const double* x, const double* rhs_y, const double* rhs_z, const double* zinv, double delta_inv, double* lhs_y, double* lhs_z, hipStream_t st) const
+void CscOperators::recover_duals(const double* x, const double* rhs_y, const double* rhs_z, const double* zinv, double delta_inv, double* lhs_y, double* lhs_z, hipStream_t st,
+                                 bool with_A, bool with_G) const
 {
     if (p_ + m_ > 0)
-        hipLaunchKernelGGL(k_recover_duals, g1(p_ + m_), dim3(256), 0, st, p_, m_, AT_p_.p, AT_i_.p, AT_x_.p, GT_p_.p, GT_i_.p, GT_x_.p, x, rhs_y, rhs_z, zinv, delta_inv, lhs_y, lhs_z);
+        hipLaunchKernelGGL(k_recover_duals, g1(p_ + m_), dim3(256), 0, st, p_, m_, AT_p_.p, AT_i_.p, AT_x_.p, GT_p_.p, GT_i_.p, GT_x_.p, x, rhs_y, rhs_z, zinv, delta_inv, lhs_y, lhs_z,
+                           with_A ? 1 : 0, with_G ? 1 : 0);
 }
 void CscOperators::add_AT_y(double alpha, const double* y, double* z, hipStream_t st) const
 {

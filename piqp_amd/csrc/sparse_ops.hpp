@@ -39,9 +39,11 @@ public:
     void add_GT_y(double alpha, const double* y, double* z, hipStream_t st) const;
 
     // out = rhs_x + GT * (zinv .* rhs_z) + delta_inv * AT * rhs_y   (condensed right-hand side, multistage_kkt.hpp:234-252)
-    void fold_rhs(const double* rhs_x, const double* rhs_y, const double* rhs_z, const double* zinv, double delta_inv, double* out, hipStream_t st) const;
+    void fold_rhs(const double* rhs_x, const double* rhs_y, const double* rhs_z, const double* zinv, double delta_inv, double* out, hipStream_t st, bool with_A = true,
+                  bool with_G = true) const;
     // lhs_y = delta_inv * A x - delta_inv * rhs_y ;  lhs_z = (G x - rhs_z) .* zinv   (multistage_kkt.hpp:266-287)
-    void recover_duals(const double* x, const double* rhs_y, const double* rhs_z, const double* zinv, double delta_inv, double* lhs_y, double* lhs_z, hipStream_t st) const;
+    void recover_duals(const double* x, const double* rhs_y, const double* rhs_z, const double* zinv, double delta_inv, double* lhs_y, double* lhs_z, hipStream_t st,
+                       bool with_A = true, bool with_G = true) const;
 
     int n() const { return n_; }
     int p() const { return p_; }

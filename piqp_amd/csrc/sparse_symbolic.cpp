@@ -438,58 +438,123 @@ static void postorder(int n, const IVec& parent, IVec& post)
 
 static void analyse_with_order(Symbolic& S, const IVec& perm0);
 
-void analyse_kkt_full(const pq_sparse_data* d, Symbolic& S)
+// structural upper triangle of MT * MT^T (MT: n x k CSC) with, for every entry (i <= j), the list of value-index pairs
+// (q_i, q_j) of the constraints k that contain both variables, constraints ascending -- the summation order of the
+// reference's update_AT_A / update_GT_W_delta_inv_G (kkt_all_eliminated.hpp:184-223)
+static void gram_structure(int n, int k, const int* MTp, const int* MTi, Symbolic::Gram& Gm)
 {
-    const int n = d->n, p = d->p, m = d->m, N = n + p + m;
-    S.n = n; S.p = p; S.m = m; S.N = N;
-    const int* Pp = d->P_colptr; const int* Pi = d->P_rowind; const double* Px = d->P_val;
-    const int* Atp = d->AT_colptr; const int* Ati = d->AT_rowind; const double* Atx = d->AT_val;
-    const int* Gtp = d->GT_colptr; const int* Gti = d->GT_rowind; const double* Gtx = d->GT_val;
-    const int nzP = Pp[n], nzA = p ? Atp[p] : 0, nzG = m ? Gtp[m] : 0;
-
-    // ---- K = [P+rho, AT, GT; ., -delta, .; ., ., -(W+delta)] upper, diagonal last in every column (kkt_full.hpp:39-170)
-    S.Kp.assign(N + 1, 0);
-    S.P_utri_to_Ki.assign(nzP, 0); S.AT_to_Ki.assign(nzA, 0); S.GT_to_Ki.assign(nzG, 0);
-    int nz = 0, jk = 0;
+    // row-oriented view: for variable j the (constraint, value index) pairs, constraints ascending
+    IVec rp(n + 1, 0);
+    const int nnz = k ? MTp[k] : 0;
+    for (int q = 0; q < nnz; ++q) rp[MTi[q] + 1]++;
+    for (int j = 0; j < n; ++j) rp[j + 1] += rp[j];
+    IVec rk(nnz), rq(nnz), nx(rp.begin(), rp.end() - 1);
+    for (int c = 0; c < k; ++c) for (int q = MTp[c]; q < MTp[c + 1]; ++q) { const int t = nx[MTi[q]]++; rk[t] = c; rq[t] = q; }
+    Gm.colptr.assign(n + 1, 0);
+    Gm.rowind.clear(); Gm.ptr.assign(1, 0); Gm.q1.clear(); Gm.q2.clear(); Gm.k.clear();
+    IVec head(n, -1);  // head[i] = entry index of (i, j) in the current column
+    std::vector<std::vector<int>> tmp;  // per entry of the current column: (q1, q2, k) triples
     for (int j = 0; j < n; ++j) {
-        int c = Pp[j + 1] - Pp[j];
-        if (c == 0 || Pi[Pp[j + 1] - 1] != j) c += 1;
-        nz += c; S.Kp[++jk] = nz;
+        IVec rows;
+        for (int t = rp[j]; t < rp[j + 1]; ++t) {
+            const int c = rk[t], qj = rq[t];
+            for (int q = MTp[c]; q < MTp[c + 1]; ++q) {
+                const int i = MTi[q];
+                if (i > j) continue;
+                if (head[i] < 0) { head[i] = (int)rows.size(); rows.push_back(i); tmp.emplace_back(); if ((int)tmp.size() < (int)rows.size()) tmp.resize(rows.size()); }
+                auto& L = tmp[head[i]];
+                L.push_back(q); L.push_back(qj); L.push_back(c);
+            }
+        }
+        IVec order(rows.size());
+        for (size_t a = 0; a < rows.size(); ++a) order[a] = (int)a;
+        std::sort(order.begin(), order.end(), [&](int a, int b2) { return rows[a] < rows[b2]; });
+        for (int a : order) {
+            Gm.rowind.push_back(rows[a]);
+            const auto& L = tmp[a];
+            for (size_t t = 0; t < L.size(); t += 3) { Gm.q1.push_back(L[t]); Gm.q2.push_back(L[t + 1]); Gm.k.push_back(L[t + 2]); }
+            Gm.ptr.push_back((int)Gm.q1.size());
+        }
+        for (int i : rows) head[i] = -1;
+        for (size_t a = 0; a < rows.size(); ++a) tmp[a].clear();
+        Gm.colptr[j + 1] = (int)Gm.rowind.size();
     }
-    for (int j = 0; j < p; ++j) { nz += Atp[j + 1] - Atp[j] + 1; S.Kp[++jk] = nz; }
-    for (int j = 0; j < m; ++j) { nz += Gtp[j + 1] - Gtp[j] + 1; S.Kp[++jk] = nz; }
-    S.Ki.assign(nz, 0); S.Kx.assign(nz, 0.0);
-    jk = 0;
-    for (int j = 0; j < n; ++j, ++jk) {
-        const int kk = S.Kp[jk], c = Pp[j + 1] - Pp[j];
-        for (int q = 0; q < c; ++q) { S.Ki[kk + q] = Pi[Pp[j] + q]; S.Kx[kk + q] = Px[Pp[j] + q]; S.P_utri_to_Ki[Pp[j] + q] = kk + q; }
-        const int kc = S.Kp[jk + 1] - kk;
-        if (kc > c) { S.Ki[kk + kc - 1] = jk; S.Kx[kk + kc - 1] = 0.0; }
+}
+
+void analyse_kkt_full(const pq_sparse_data* d, Symbolic& S) { analyse_kkt(d, 0, S); }
+
+// mode: KKTMode bits (kkt_fwd.hpp:15-21): 1 = equalities eliminated, 2 = inequalities eliminated
+void analyse_kkt(const pq_sparse_data* d, int mode, Symbolic& S)
+{
+    const int n = d->n, p = d->p, m = d->m;
+    const bool eq = (mode & 1) != 0, ineq = (mode & 2) != 0;
+    const int N = n + (eq ? 0 : p) + (ineq ? 0 : m);
+    S.n = n; S.p = p; S.m = m; S.N = N; S.mode = mode;
+    static const int zero_ptr[1] = {0};
+    const int* Pp = d->P_colptr; const int* Pi = d->P_rowind; const double* Px = d->P_val;
+    const int* Atp = p ? d->AT_colptr : zero_ptr; const int* Ati = d->AT_rowind; const double* Atx = d->AT_val;
+    const int* Gtp = m ? d->GT_colptr : zero_ptr; const int* Gti = d->GT_rowind; const double* Gtx = d->GT_val;
+    const int nzP = Pp[n], nzA = p ? Atp[p] : 0, nzG = m ? Gtp[m] : 0;
+    if (eq) gram_structure(n, p, Atp, Ati, S.gramA); else S.gramA = Symbolic::Gram();
+    if (ineq) gram_structure(n, m, Gtp, Gti, S.gramG); else S.gramG = Symbolic::Gram();
+
+    // ---- K upper, diagonal last in every column.  Top-left block: P_utri + I (+ A'A) (+ G'G) as a sorted merge
+    // (kkt_{eq,ineq,all}_eliminated.hpp create_kkt_matrix; kkt_full.hpp:39-170 when nothing is eliminated); then one column
+    // per kept constraint: [AT col; -delta] and [GT col; -z_reg]
+    S.Kp.assign(N + 1, 0);
+    S.Ki.clear(); S.Kx.clear();
+    S.P_utri_to_Ki.assign(nzP, 0); S.AT_to_Ki.assign(eq ? 0 : nzA, 0); S.GT_to_Ki.assign(ineq ? 0 : nzG, 0);
+    S.gramA_to_Ki.assign(eq ? S.gramA.rowind.size() : 0, 0); S.gramG_to_Ki.assign(ineq ? S.gramG.rowind.size() : 0, 0);
+    for (int j = 0; j < n; ++j) {
+        int a = Pp[j], ae = Pp[j + 1];
+        int b = eq ? S.gramA.colptr[j] : 0, be = eq ? S.gramA.colptr[j + 1] : 0;
+        int c = ineq ? S.gramG.colptr[j] : 0, ce = ineq ? S.gramG.colptr[j + 1] : 0;
+        bool diag_done = false;
+        for (;;) {
+            int r = n + 1;
+            if (a < ae) r = std::min(r, Pi[a]);
+            if (b < be) r = std::min(r, S.gramA.rowind[b]);
+            if (c < ce) r = std::min(r, S.gramG.rowind[c]);
+            if (!diag_done) r = std::min(r, j);
+            if (r > n) break;
+            const int at = (int)S.Ki.size();
+            double v = 0.0;
+            if (a < ae && Pi[a] == r) { v = Px[a]; S.P_utri_to_Ki[a++] = at; }
+            if (b < be && S.gramA.rowind[b] == r) S.gramA_to_Ki[b++] = at;
+            if (c < ce && S.gramG.rowind[c] == r) S.gramG_to_Ki[c++] = at;
+            if (r == j) diag_done = true;
+            if (r > j) throw std::runtime_error("symbolic: P is not upper triangular");
+            S.Ki.push_back(r); S.Kx.push_back(v);
+        }
+        S.Kp[j + 1] = (int)S.Ki.size();
     }
-    for (int j = 0; j < p; ++j, ++jk) {
-        const int kk = S.Kp[jk], c = Atp[j + 1] - Atp[j];
-        for (int q = 0; q < c; ++q) { S.Ki[kk + q] = Ati[Atp[j] + q]; S.Kx[kk + q] = Atx[Atp[j] + q]; S.AT_to_Ki[Atp[j] + q] = kk + q; }
-        S.Ki[kk + c] = jk; S.Kx[kk + c] = 0.0;
-    }
-    for (int j = 0; j < m; ++j, ++jk) {
-        const int kk = S.Kp[jk], c = Gtp[j + 1] - Gtp[j];
-        for (int q = 0; q < c; ++q) { S.Ki[kk + q] = Gti[Gtp[j] + q]; S.Kx[kk + q] = Gtx[Gtp[j] + q]; S.GT_to_Ki[Gtp[j] + q] = kk + q; }
-        S.Ki[kk + c] = jk; S.Kx[kk + c] = 0.0;
-    }
+    int jk = n;
+    if (!eq)
+        for (int j = 0; j < p; ++j, ++jk) {
+            for (int q = Atp[j]; q < Atp[j + 1]; ++q) { S.AT_to_Ki[q] = (int)S.Ki.size(); S.Ki.push_back(Ati[q]); S.Kx.push_back(Atx[q]); }
+            S.Ki.push_back(jk); S.Kx.push_back(0.0);
+            S.Kp[jk + 1] = (int)S.Ki.size();
+        }
+    if (!ineq)
+        for (int j = 0; j < m; ++j, ++jk) {
+            for (int q = Gtp[j]; q < Gtp[j + 1]; ++q) { S.GT_to_Ki[q] = (int)S.Ki.size(); S.Ki.push_back(Gti[q]); S.Kx.push_back(Gtx[q]); }
+            S.Ki.push_back(jk); S.Kx.push_back(0.0);
+            S.Kp[jk + 1] = (int)S.Ki.size();
+        }
 
     // ---- ordering: AMD (what the reference uses, sparse/ordering.hpp:72-74) or nested dissection, whichever gives the
     // cheaper device schedule (levels = dependent kernel launches; fill = HBM traffic and flops)
     IVec perm_amd(N);
     amd_order(N, S.Kp.data(), S.Ki.data(), perm_amd.data());
     const char* want = std::getenv("PIQP_AMD_ORDERING");
-    const std::string mode = want ? want : "auto";
-    if (mode == "amd" || (mode == "auto" && N < 200)) { analyse_with_order(S, perm_amd); S.ordering = "amd"; return; }
+    const std::string ord = want ? want : "auto";
+    if (ord == "amd" || (ord == "auto" && N < 200)) { analyse_with_order(S, perm_amd); S.ordering = "amd"; return; }
     IVec perm_nd(N);
     nd_order(N, S.Kp.data(), S.Ki.data(), perm_nd.data(), 96);
     Symbolic T = S;
     analyse_with_order(T, perm_nd);
     T.ordering = "nested dissection";
-    if (mode == "nd") { S = std::move(T); return; }
+    if (ord == "nd") { S = std::move(T); return; }
     analyse_with_order(S, perm_amd);
     S.ordering = "amd";
     // ~12 us per level (one launch per level) against ~1e11 flop/s and ~1e12 B/s on small fronts

@@ -24,7 +24,15 @@ using IVec = std::vector<int>;
 using DVec = std::vector<double>;
 
 struct Symbolic {
-    int n = 0, p = 0, m = 0, N = 0;  // N = n + p + m (KKT_FULL dimension)
+    int n = 0, p = 0, m = 0, N = 0;  // N = KKT dimension of the mode (n + p + m for KKT_FULL)
+    int mode = 0;                    // KKTMode bits: 1 = equalities eliminated, 2 = inequalities eliminated
+    // eliminated blocks: pattern of upper(MT MT^T) and, per entry, the value-index pairs / constraint of every product term
+    struct Gram {
+        IVec colptr, rowind;  // n x n upper CSC pattern
+        IVec ptr;             // per entry: range in q1/q2/k
+        IVec q1, q2, k;       // value indices of (i, k) and (j, k) in MT, and the constraint k (weight index)
+    } gramA, gramG;
+    IVec gramA_to_Ki, gramG_to_Ki;
     // K (upper, diagonal last in every column) and the value maps of kkt_full.hpp
     IVec Kp, Ki;
     DVec Kx;
@@ -67,6 +75,8 @@ void amd_order(int n, const int* Ap, const int* Ai, int* perm);
 // nested dissection by BFS level structures, AMD inside parts of at most `leaf` nodes; perm[new] = old
 void nd_order(int n, const int* Ap, const int* Ai, int* perm, int leaf);
 void analyse_kkt_full(const pq_sparse_data* d, Symbolic& S);
+// any KKTMode (kkt_fwd.hpp:15-21): 0 full, 1 eq eliminated, 2 ineq eliminated, 3 all eliminated
+void analyse_kkt(const pq_sparse_data* d, int mode, Symbolic& S);
 
 }  // namespace sparse
 }  // namespace pq

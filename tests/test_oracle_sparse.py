@@ -191,3 +191,71 @@ def test_fixtures_sparse_backend(orc, name):
         assert st == orc.DUAL_INFEASIBLE  # tests/src/sparse/solver_test.cpp
     else:
         assert st == orc.SOLVED
+
+
+MODES = [(0, "SPARSE_LDLT"), (1, "SPARSE_LDLT_EQ_COND"), (2, "SPARSE_LDLT_INEQ_COND"), (3, "SPARSE_LDLT_COND")]
+
+
+@pytest.mark.parametrize("mode,ks", MODES)
+def test_sparse_kkt_modes_factorize_solve(orc, mode, ks):
+    """sparse/kkt_test.cpp:88-162 is typed over all four KKTModes: K lhs ~ rhs (1e-8) through KKTSystem, and every condensed
+    mode must agree with KKT_FULL on the same QP"""
+    n, p, m = 20, 8, 9
+    qs = _sparsify(dense_strongly_convex_qp(n, p, m, seed=3), 0.4, 1)
+    d = orc.Data.sparse(**qs)
+    ksys = orc.KKTSystem(d, orc.Settings(kkt_solver=getattr(orc, ks)))
+    kfull = orc.KKTSystem(d, orc.Settings(kkt_solver=orc.SPARSE_LDLT))
+    scaling = orc.make_vars(n, p, m, fill=1.0)
+    assert ksys.update_scalings_and_factor(False, 0.9, 1.2, scaling) and kfull.update_scalings_and_factor(False, 0.9, 1.2, scaling)
+    rhs = random_vars(n, p, m, np.random.default_rng(0))
+    ok, lhs = ksys.solve(rhs)
+    okf, lhf = kfull.solve(rhs)
+    assert ok and okf
+    back = ksys.mul(lhs)
+    nhl, nhu, nxl, nxu = d.counts()
+    assert np.allclose(rhs["x"], back["x"], atol=1e-8) and np.allclose(rhs["y"], back["y"], atol=1e-8)
+    for key, cnt in (("z_bl", nxl), ("z_bu", nxu), ("s_bl", nxl), ("s_bu", nxu)):
+        assert np.allclose(rhs[key][:cnt], back[key][:cnt], atol=1e-8)
+    for key in lhs:
+        cnt = {"z_bl": nxl, "s_bl": nxl, "z_bu": nxu, "s_bu": nxu}.get(key, len(lhs[key]))
+        assert np.allclose(lhs[key][:cnt], lhf[key][:cnt], rtol=1e-9, atol=1e-9), key
+
+
+@pytest.mark.parametrize("mode", [1, 2, 3])
+def test_sparse_kkt_modes_update_data_equals_fresh(orc, mode):
+    """sparse/kkt_test.cpp:40-86 for the condensed modes: new values on the same pattern, update + refactor == fresh"""
+    n, p, m = 10, 8, 9
+    q1 = _sparsify(dense_strongly_convex_qp(n, p, m, seed=1), 0.5, 2)
+    d = orc.Data.sparse(**q1)
+    k = orc.KKT(d, kind="sparse", mode=mode)
+    x_reg, z_reg = np.full(n, 0.9), np.full(m, 2.2)
+    assert k.update_scalings_and_factor(1.2, x_reg, z_reg)
+    rng = np.random.default_rng(5)
+    dC = d.ptr.contents
+    for cs in (dC.sP_utri, dC.sAT, dC.sGT):
+        for i in range(cs.colptr[cs.cols]):
+            cs.val[i] = cs.val[i] * (1.0 + 0.1 * rng.standard_normal())
+    k.update_data(orc.KKT_UPDATE_P | orc.KKT_UPDATE_A | orc.KKT_UPDATE_G)
+    assert k.update_scalings_and_factor(1.2, x_reg, z_reg)
+    k2 = orc.KKT(d, kind="sparse", mode=mode)
+    assert k2.update_scalings_and_factor(1.2, x_reg, z_reg)
+    r = [rng.standard_normal(s) for s in (n, p, m)]
+    for a, b in zip(k.solve(*r), k2.solve(*r)):
+        assert np.array_equal(a, b)
+    L = orc.lib()
+    N = L.orc_sparse_kkt_dim(k.ptr) if mode == 0 else None
+    assert N is None
+
+
+@pytest.mark.parametrize("name", ["qp_small_dense", "qp_scenario_mpc_small", "qp_scenario_mpc", "mm_HS21", "mm_DUAL1", "mm_QAFIRO", "mm_CVXQP1_S", "mm_LOTSCHD"])
+@pytest.mark.parametrize("ks", ["SPARSE_LDLT_EQ_COND", "SPARSE_LDLT_INEQ_COND", "SPARSE_LDLT_COND"])
+def test_fixtures_condensed_backends(orc, name, ks):
+    q = load_qp(name)
+    s = orc.Solver()
+    s.settings.kkt_solver = getattr(orc, ks)
+    assert s.setup(*_sparse_args(q), sparse=True)
+    assert s.solve() == orc.SOLVED
+    s0 = orc.Solver(); s0.settings.kkt_solver = orc.SPARSE_LDLT
+    assert s0.setup(*_sparse_args(q), sparse=True)
+    s0.solve()
+    assert abs(s.info.primal_obj - s0.info.primal_obj) <= 1e-5 * (1 + abs(s0.info.primal_obj))
