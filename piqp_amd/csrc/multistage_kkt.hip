@@ -18,8 +18,12 @@
 // Like the reference, update_scalings_and_factor always reports success (:218): a non-positive pivot
 // zeroes its column (blasfeo dpotrf semantics) and the caller's refinement loop notices.
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
+#include <cstdlib>
+#include <memory>
 #include <stdexcept>
+#include <string>
 
 #include "kkt_solver_base.hpp"
 #include "multistage_device.hpp"
@@ -119,16 +123,26 @@ public:
     {
         PQ_HIP(hipSetDevice(dev_));
         PQ_HIP(hipStreamSynchronize(st_));
-        return new MultistageKKT(*this, 0);
+        MultistageKKT* c = new MultistageKKT(*this, 0);
+        if (tree_) c->tree_.reset(tree_->clone());
+        return c;
     }
+
+    // Stage-parallel elimination.  The serial recurrence of factor_kkt is the reference's algorithm, not a property of the
+    // matrix: the condensed block-tridiagonal-arrow system can equally be eliminated along a nested-dissection tree
+    // (segments of stages in parallel, separators last), which is what the multifrontal engine does for
+    // KKTMode::KKT_ALL_ELIMINATED on exactly this matrix.  When a tree engine is attached, factor / solve go through it
+    // (one stream: the engine runs on its own stream, so calls are bracketed by synchronisation points).
+    void attach_tree_engine(KKTSolverBase* engine) { tree_.reset(engine); }
+    bool uses_tree_engine() const { return (bool)tree_; }
 
     // multistage_kkt.hpp:142-178
     void update_data_sparse(const pq_sparse_data* d, int options) override
     {
         PQ_HIP(hipSetDevice(dev_));
-        (void)options;  // Solver::update rewrites all three matrices through unscale -> rescale; refresh everything stored
         ops_.upload_values(d, st_);
-        scatter_values(KKT_ALL);
+        scatter_values(KKT_ALL);  // Solver::update rewrites all three matrices through unscale -> rescale; refresh everything stored
+        if (tree_) tree_->update_data_sparse(d, options);
     }
 
     // multistage_kkt.hpp:180-219
@@ -136,6 +150,14 @@ public:
     {
         PQ_HIP(hipSetDevice(dev_));
         delta_ = delta;
+        if (tree_) {
+            PQ_HIP(hipStreamSynchronize(st_));  // x_reg / z_reg were produced on this handle's stream
+            const int t = prof_.begin(1, st_);
+            tree_->update_scalings_and_factor(delta, x_reg, z_reg);
+            PQ_HIP(hipStreamSynchronize(tree_->stream()));
+            prof_.end(1, t, st_);
+            return true;  // :218
+        }
         const int t0 = prof_.begin(0, st_);
         if (m_ > 0) hipLaunchKernelGGL(k_ms_reciprocal, dim3((m_ + 255) / 256), dim3(256), 0, st_, m_, z_reg, zinv_.p);
         hipLaunchKernelGGL(k_ms_assemble, dim3(S_.N, asm_chunks_), dim3(NT), 0, st_, meta(), gmeta(), XG_.p, Pf_.p, AtAf_.p, zinv_.p, x_reg, 1.0 / delta, F_.p);
@@ -152,6 +174,14 @@ public:
     void solve(const double* rhs_x, const double* rhs_y, const double* rhs_z, double* lhs_x, double* lhs_y, double* lhs_z) override
     {
         PQ_HIP(hipSetDevice(dev_));
+        if (tree_) {
+            PQ_HIP(hipStreamSynchronize(st_));
+            const int t = prof_.begin(2, st_);
+            tree_->solve(rhs_x, rhs_y, rhs_z, lhs_x, lhs_y, lhs_z);
+            PQ_HIP(hipStreamSynchronize(tree_->stream()));
+            prof_.end(2, t, st_);
+            return;
+        }
         const int tk = prof_.begin(2, st_);
         const double delta_inv = 1.0 / delta_;
         ops_.fold_rhs(rhs_x, rhs_y, rhs_z, zinv_.p, delta_inv, lhs_x, st_);
@@ -186,6 +216,8 @@ public:
         std::printf("\narrow width: %d\n", S_.arrow);
         std::printf("multistage chain: %d stages, max front %d, factor %s, solve %s, front storage %.2f MB\n", S_.N - 1, S_.max_h, factor_in_lds_ ? "in LDS" : "in HBM",
                     solve_in_lds_ ? "in LDS" : "in HBM", S_.front_doubles * 8.0 / 1e6);
+        if (tree_) { std::printf("elimination: stage-parallel (nested-dissection tree of the condensed system), engine: "); tree_->print_info(); }
+        else std::printf("elimination: serial stage recurrence (factor_kkt order)\n");
     }
 
     const double* P_diag_device() const override { return ops_.P_diag(); }
@@ -287,10 +319,57 @@ private:
     DBuf<long long> front_off_, pan_off_, a_x_off_, g_x_off_, a_dst_, g_dst_, p_dst_;
     DBuf<double> Pf_, AtAf_, F_, pan_, XA_, XG_, zinv_;
     StageProfiler prof_;
+    std::unique_ptr<KKTSolverBase> tree_;
 };
+
+// wall time of one factorisation + one solve on `k` with unit scalings (setup-time probe)
+double probe_ms(KKTSolverBase* k, int n, int p, int m, const double* ones, double* out, int reps)
+{
+    auto run = [&]() {
+        k->update_scalings_and_factor(1.0, ones, ones);
+        k->solve(ones, ones, ones, out, out + n, out + n + p);
+        PQ_HIP(hipStreamSynchronize(k->stream()));
+    };
+    run();
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int r = 0; r < reps; ++r) run();
+    (void)m;
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / reps;
+}
+
+__global__ void k_fill_ones(int n, double* __restrict__ a)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[i] = 1.0;
+}
 
 }  // namespace
 
-KKTSolverBase* make_multistage_kkt(const pq_sparse_data* data, int device) { return new MultistageKKT(data, device); }
+// MultistageKKT ctor (multistage_kkt.hpp:76-135).  For chains of 16+ stages both elimination orders are built and the faster one
+// (measured once, here) is kept: PIQP_AMD_MULTISTAGE=chain|tree forces the choice.
+KKTSolverBase* make_multistage_kkt(const pq_sparse_data* data, int device)
+{
+    std::unique_ptr<MultistageKKT> ms(new MultistageKKT(data, device));
+    const char* env = std::getenv("PIQP_AMD_MULTISTAGE");
+    const std::string want = env ? env : "auto";
+    std::vector<int> bi;
+    ms->multistage_block_info(bi);
+    const int stages = (int)bi.size() / 3 - 1;
+    if (want == "chain" || (want == "auto" && stages < 16)) return ms.release();
+    std::unique_ptr<KKTSolverBase> tree(make_sparse_kkt(data, PQ_SPARSE_LDLT_COND, device));
+    if (!tree) return ms.release();
+    if (want != "tree") {
+        const int n = ms->n(), p = ms->p(), m = ms->m();
+        const int len = std::max(n, std::max(p, m)) + 1;
+        DBuf<double> ones(len), out((size_t)n + p + m + 1);
+        hipLaunchKernelGGL(k_fill_ones, dim3((len + 255) / 256), dim3(256), 0, ms->stream(), len, ones.p);
+        PQ_HIP(hipStreamSynchronize(ms->stream()));
+        const double t_chain = probe_ms(ms.get(), n, p, m, ones.p, out.p, 3);
+        const double t_tree = probe_ms(tree.get(), n, p, m, ones.p, out.p, 3);
+        if (t_tree > 0.9 * t_chain) return ms.release();
+    }
+    ms->attach_tree_engine(tree.release());
+    return ms.release();
+}
 
 }  // namespace pq

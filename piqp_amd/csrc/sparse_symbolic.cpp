@@ -269,10 +269,19 @@ void nd_order(int n, const int* Ap, const int* Ai, int* perm, int leaf)
     int next_part = 1, pos = 0;
     struct Item { int part; std::vector<int> nodes; bool is_sep; };
     std::vector<Item> stack;
+    // "dense" nodes (global variables / coupling constraints: degree far above the average) would put every other node within two
+    // hops of each other and flatten every level structure; they are taken out of the graph and numbered last, like the
+    // dense-row treatment of AMD and like the arrow block of the multistage backend
+    std::vector<int> dense_nodes;
     {
-        Item all; all.part = 0; all.is_sep = false; all.nodes.resize(n);
-        for (int i = 0; i < n; ++i) all.nodes[i] = i;
-        stack.push_back(std::move(all));
+        const double avg = n ? (double)xadj[n] / n : 0.0;
+        const int thresh = std::max(32, (int)(10.0 * avg));
+        Item all; all.part = 0; all.is_sep = false;
+        for (int i = 0; i < n; ++i) {
+            if (xadj[i + 1] - xadj[i] > thresh) { dense_nodes.push_back(i); part[i] = -3; }
+            else all.nodes.push_back(i);
+        }
+        if (!all.nodes.empty()) stack.push_back(std::move(all));
     }
     // rooted level structure of `root` inside part `pid`; returns number of levels, nodes in BFS order in queue[0..cnt)
     auto bfs = [&](int root, int pid, int& cnt) {
@@ -362,6 +371,7 @@ void nd_order(int n, const int* Ap, const int* Ai, int* perm, int leaf)
         stack.push_back(std::move(B));
         stack.push_back(std::move(A));
     }
+    for (int v : dense_nodes) perm[pos++] = v;
 }
 
 // ------------------------------------------------------------------------------------------------

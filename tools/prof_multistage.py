@@ -38,6 +38,7 @@ def mpc_chain(nx, nu, T, seed):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=50)
+    ap.add_argument("--cond", action="store_true", help="time sparse_ldlt_cond (4) instead of sparse_ldlt (1) next to multistage")
     ap.add_argument("--c5", action="store_true", help="only BASELINE configs[4]: one block-tridiagonal QP, n = 500k (25000 stages of n_x=12, n_u=8)")
     args = ap.parse_args()
     import torch  # noqa: F401
@@ -59,7 +60,7 @@ def main():
         d = hip.SparseData(*a); od = orc.Data.sparse(*a)
         n, p, m = od.n, od.p, od.m
         rng = np.random.default_rng(0)
-        for ks, kname in (((hip.SPARSE_LDLT, "sparse_ldlt"),) if args.c5 else ((hip.SPARSE_MULTISTAGE, "multistage"), (hip.SPARSE_LDLT, "sparse_ldlt"))):
+        for ks, kname in (((hip.SPARSE_LDLT, "sparse_ldlt"),) if args.c5 else ((hip.SPARSE_MULTISTAGE, "multistage"), ((4, "ldlt_cond") if args.cond else (hip.SPARSE_LDLT, "sparse_ldlt")))):
             t_s = time.perf_counter()
             k = hip.KKTSystem(d, hip.default_settings(kkt_solver=ks))
             t_setup = time.perf_counter() - t_s
