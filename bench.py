@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--kkt-solver", type=int, default=0, help="0 = dense_cholesky (reference default), 16 = pivot-free LDLt")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--batch-total", type=int, default=8192, help="BASELINE configs[3]: number of MPC QPs in the batched leg (0 = skip)")
+    ap.add_argument("--no-sparse-legs", action="store_true", help="skip the sparse C3 / C5-size KKT legs (BASELINE configs[2], configs[4])")
     ap.add_argument("--cpu-steps", type=int, default=0, help="0 = auto (about 10-30 s of CPU work)")
     args = ap.parse_args()
 
@@ -150,9 +151,71 @@ def main():
         bq = batched_qp(args, rank, world, local_rank, dev, pd)
         if rank == 0:
             out["batched_qp"] = bq
+    if not args.no_sparse_legs:
+        sl = sparse_legs(args, rank, world, local_rank, dev, pd)
+        if rank == 0:
+            out["sparse_kkt"] = sl
     if rank == 0:
         print(json.dumps(out), flush=True)
     pd.finalize()
+
+
+def sparse_legs(args, rank, world, local_rank, dev, pd):
+    """KKT factor + 2 solves per second on the sparse configurations (one independent instance per rank, like the dense leg):
+    configs[2] C3 (n=50k, N=100k, sparse_ldlt) and a configs[4]-size chain (n=500k block-tridiagonal, sparse_ldlt with the
+    nested-dissection tree = stage-partitioned elimination on ONE GPU).  CPU baseline: the oracle on one core."""
+    import numpy as np
+    import torch
+    import piqp_amd
+    from qp_gen import c3_problem, mpc_chain, random_vars
+    res = {}
+    cases = [("C3", "sparse QP n=50000 p=20000 m=30000, nnz(upper KKT)=4.9e5, kkt_solver=sparse_ldlt (BASELINE configs[2])", c3_problem(seed=44 + rank), piqp_amd.SPARSE_LDLT, 1),
+             ("C5_single_gpu", "one block-tridiagonal QP n=500012 p=300000 (25000 stages of n_x=12,n_u=8), kkt_solver=sparse_ldlt, ONE GPU (BASELINE configs[4] size)",
+              mpc_chain(12, 8, 25000, 5 + rank), piqp_amd.SPARSE_LDLT, 5)]
+    for key, desc, a, ks, oracle_ks in cases:
+        d = piqp_amd.SparseData(*a)
+        n, p, m = d.n, d.p, d.m
+        t0 = time.perf_counter()
+        k = piqp_amd.KKTSystem(d, piqp_amd.default_settings(kkt_solver=ks), device=local_rank)
+        t_setup = time.perf_counter() - t0
+        rng = np.random.default_rng(7 + rank)
+        state = random_vars(n, p, m, rng, positive=True)
+        rhs = [random_vars(n, p, m, rng) for _ in range(2)]
+        for _ in range(2):
+            assert k.update_scalings_and_factor(False, 1e-6, 1e-4, state)
+            k.solve(rhs[0])
+        res_inf, nrm = k.condensed_residual()
+        steps = 10
+        be = k.backend(); be.set_profiling(True)
+        pd.barrier(); k.synchronize(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            k.update_scalings_and_factor(False, 1e-6, 1e-4, state)
+            k.solve(rhs[0]); k.solve(rhs[1])
+        k.synchronize(); torch.cuda.synchronize(); pd.barrier()
+        el = pd.max_over_ranks(time.perf_counter() - t0, device=dev if world > 1 else None)
+        be.set_profiling(False)
+        prof = [be.get_profile(s) for s in range(3)]
+        if rank == 0:
+            r = {"workload": desc, "value": world * steps / el, "unit": "IPM-iter KKT (1 factor + 2 solves)/s", "ms_per_step": el / steps * 1e3,
+                 "factor_ms": (prof[0][0] + prof[1][0]) / max(prof[1][1], 1), "backend_solve_ms": prof[2][0] / max(prof[2][1], 1), "setup_s": t_setup,
+                 "rel_kkt_residual": res_inf / nrm}
+            if not args.no_cpu_baseline:
+                from oracle import pyorc
+                od = pyorc.Data.sparse(*a)
+                ko = pyorc.KKTSystem(od, pyorc.Settings(kkt_solver=oracle_ks))
+                ko.update_scalings_and_factor(False, 1e-6, 1e-4, state)
+                t0 = time.perf_counter()
+                cs = 3
+                for _ in range(cs):
+                    ko.update_scalings_and_factor(False, 1e-6, 1e-4, state); ko.solve(rhs[0]); ko.solve(rhs[1])
+                elc = time.perf_counter() - t0
+                r["cpu_baseline"] = {"value": cs / elc, "unit": r["unit"], "cores": 1, "kind": "port",
+                                     "sample": f"{cs} steps of the same workload, oracle kkt_solver={'sparse_ldlt' if oracle_ks == 1 else 'sparse_multistage'} (gcc -O3), 1 thread"}
+                r["speedup_vs_cpu_core"] = r["value"] / world / (cs / elc)
+            res[key] = r
+        del k
+    return res if rank == 0 else None
 
 
 def batched_qp(args, rank, world, local_rank, dev, pd):

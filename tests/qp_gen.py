@@ -129,3 +129,40 @@ def mpc_instance(mb, i):
     P = mb["P_pattern"].copy(); P.data = mb["P_values"][i].copy()
     A = mb["A_pattern"].copy(); A.data = mb["A_values"][i].copy()
     return (sp.csc_matrix(P), mb["c"][i], sp.csc_matrix(A), mb["b"][i], None, None, None, mb["x_l"][i], mb["x_u"][i])
+
+
+def mpc_chain(nx, nu, T, seed):
+    """one linear-MPC QP as a long block-tridiagonal chain (BASELINE configs[4] recipe): variables [x_0,u_0,...,x_{T-1},u_{T-1},x_T],
+    p = T*nx dynamics rows x_{k+1} = A_d x_k + B_d u_k, diagonal P, box bounds on every variable; returns the nine setup arguments"""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(seed)
+    nz = nx + nu
+    n = T * nz + nx
+    Ad = np.eye(nx) + 0.1 * rng.standard_normal((nx, nx)); Bd = rng.standard_normal((nx, nu))
+    t = np.arange(T)
+    i = np.arange(nx)
+    rows_blk = (t[:, None, None] * nx + i[None, :, None])                       # T x nx x 1
+    cols_dyn = t[:, None, None] * nz + np.arange(nz)[None, None, :]              # T x 1 x nz
+    rows = np.concatenate([np.broadcast_to(rows_blk, (T, nx, nz)).ravel(), (t[:, None] * nx + i[None, :]).ravel()])
+    cols = np.concatenate([np.broadcast_to(cols_dyn, (T, nx, nz)).ravel(), ((t[:, None] + 1) * nz + i[None, :]).ravel()])
+    vals = np.concatenate([np.broadcast_to(np.hstack([Ad, Bd])[None, :, :], (T, nx, nz)).ravel(), -np.ones(T * nx)])
+    p = T * nx
+    A = sp.csc_matrix((vals, (rows, cols)), shape=(p, n))
+    P = sp.diags(rng.uniform(0.5, 2.0, n), format="csc")
+    return (P, rng.standard_normal(n), A, np.zeros(p), None, None, None, -np.ones(n), np.ones(n))
+
+
+def c3_problem(n=50000, p=20000, m=30000, seed=44, spread=40):
+    """BASELINE configs[2]: sparse QP, P banded upper-tri (~3 nnz/col + diagonal), A and G rows with 5 nnz each
+    inside a window of `spread` variables; N = n + p + m = 100 000, nnz(full KKT) ~ 0.9e6"""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(seed)
+    P = sp.diags([rng.uniform(1, 2, n), rng.uniform(-0.3, 0.3, n - 1), rng.uniform(-0.2, 0.2, n - 2), rng.uniform(-0.1, 0.1, n - 3)], [0, 1, 2, 3], format="csc")
+
+    def rows(k):
+        cols = (rng.integers(0, n - spread, k)[:, None] + rng.choice(spread, (k, 5), replace=True)).ravel()
+        M = sp.csc_matrix((rng.standard_normal(5 * k), (np.repeat(np.arange(k), 5), cols)), shape=(k, n))
+        M.sum_duplicates()
+        return M
+    A, G = rows(p), rows(m)
+    return (P, rng.standard_normal(n), A, np.zeros(p), G, -np.ones(m), np.ones(m), None, None)

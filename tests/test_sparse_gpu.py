@@ -309,9 +309,7 @@ def test_fixture_iteration_parity_condensed(hip, orc, ks, ksid, mode, name):
 def test_condensed_mode_on_long_chain(hip):
     """sparse_ldlt_cond on a C5-style chain: the condensed matrix is the block-tridiagonal system the multistage backend factors
     serially; the multifrontal backend factors it with a nested-dissection tree.  Property: relative KKT residual <= 1e-10."""
-    import sys, os
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
-    from prof_multistage import mpc_chain
+    from qp_gen import mpc_chain
     a = mpc_chain(6, 3, 600, 7)
     d = hip.SparseData(*a)
     k = hip.KKTSystem(d, hip.default_settings(kkt_solver=4))

@@ -16,23 +16,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def mpc_chain(nx, nu, T, seed):
-    rng = np.random.default_rng(seed)
-    nz = nx + nu
-    n = T * nz + nx
-    Ad = np.eye(nx) + 0.1 * rng.standard_normal((nx, nx)); Bd = rng.standard_normal((nx, nu))
-    rows, cols, vals = [], [], []
-    for t in range(T):
-        for i in range(nx):
-            for j in range(nx):
-                rows.append(t * nx + i); cols.append(t * nz + j); vals.append(Ad[i, j])
-            for j in range(nu):
-                rows.append(t * nx + i); cols.append(t * nz + nx + j); vals.append(Bd[i, j])
-            rows.append(t * nx + i); cols.append((t + 1) * nz + i); vals.append(-1.0)
-    p = T * nx
-    A = sp.csc_matrix((vals, (rows, cols)), shape=(p, n))
-    P = sp.diags(rng.uniform(0.5, 2.0, n), format="csc")
-    return (P, rng.standard_normal(n), A, np.zeros(p), None, None, None, -np.ones(n), np.ones(n))
+from qp_gen import mpc_chain  # noqa: E402
 
 
 def main():

@@ -17,18 +17,11 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def c3_problem(n=50000, p=20000, m=30000, seed=44, spread=40):
-    """P banded upper-tri (~3 nnz/col + diagonal), A and G rows with 5 nnz each"""
-    rng = np.random.default_rng(seed)
-    P = sp.diags([rng.uniform(1, 2, n), rng.uniform(-0.3, 0.3, n - 1), rng.uniform(-0.2, 0.2, n - 2), rng.uniform(-0.1, 0.1, n - 3)], [0, 1, 2, 3], format="csc")
+from qp_gen import c3_problem as _c3  # noqa: E402
 
-    def rows(k):
-        cols = (rng.integers(0, n - spread, k)[:, None] + rng.choice(spread, (k, 5), replace=True)).ravel()
-        M = sp.csc_matrix((rng.standard_normal(5 * k), (np.repeat(np.arange(k), 5), cols)), shape=(k, n))
-        M.sum_duplicates()
-        return M
-    A, G = rows(p), rows(m)
-    return (P, rng.standard_normal(n), A, np.zeros(p), G, -np.ones(m), np.ones(m), None, None), (n, p, m)
+
+def c3_problem(n=50000, p=20000, m=30000, seed=44, spread=40):
+    return _c3(n, p, m, seed, spread), (n, p, m)
 
 
 def main():
