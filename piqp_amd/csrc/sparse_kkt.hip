@@ -15,6 +15,7 @@
 // reproducible (the reference's clone test needs that).
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <stdexcept>
 
 #include "dense_kernels.hpp"
@@ -28,6 +29,7 @@ namespace {
 
 constexpr int BIG_FRONT = 192;      // fronts at least this large with >= BIG_PIVOTS pivots use the dense multi-workgroup kernels
 constexpr int BIG_PIVOTS = 32;
+constexpr int SUBTREE_LDS_BYTES = 150 * 1024;  // two fronts of the LDS-native subtree walker
 constexpr int SUB_THREADS = 256;    // small subtrees: fronts reach ~100 rows near the subtree root, so a full workgroup (64 threads measured 2x slower)
 constexpr int LDS_FRONT_DOUBLES = 12288;  // 96 KiB: fronts up to 110 x 110 are factored inside LDS
 
@@ -39,7 +41,7 @@ struct SnRec {  // everything the numeric kernels need about one supernode, in o
     int rows_ptr;   // offset into front_rows / fvec
     int child_lo, child_hi;  // range in `child`
     int rel_ptr;    // offset into `rel` of this supernode's update rows inside its parent
-    int pad;
+    int parent;     // parent supernode (-1: root)
     long long front_off;
     long long pad2;
 };
@@ -209,6 +211,90 @@ __global__ __launch_bounds__(256) void k_front_factor(FrontMeta M, double* __res
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     front_factor(M, fronts, list[blockIdx.x], big_front, big_pivots, rdiag, info, lds);
+}
+
+// One workgroup per small subtree, fronts never leave LDS: the front of supernode s is zeroed and assembled in LDS from the
+// K entries it owns (fe lists), children are merged from LDS when the child is the previous supernode of the walk (the usual
+// case: a chain) and from HBM otherwise, the panel + Schur complement run in LDS, and only the factor panel (f x w) is written
+// to HBM; the update matrix goes to HBM only when the parent is not the next supernode of this walk.  Two LDS buffers
+// alternate between "front being factored" and "previous front, holding the update matrix".
+__global__ __launch_bounds__(SUB_THREADS) void k_subtree_factor_lds(FrontMeta M, double* __restrict__ fronts, const double* __restrict__ vals, const int* __restrict__ fe_ptr,
+                                                            const int* __restrict__ fe_q, const int* __restrict__ fe_off, const int* __restrict__ sub_lo,
+                                                            const int* __restrict__ sub_hi, int cap, double* __restrict__ rdiag, int* __restrict__ info)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int lo = sub_lo[blockIdx.x], hi = sub_hi[blockIdx.x];
+    double* cur = lds;
+    double* prev = lds + cap;
+    bool prev_valid = false;  // prev holds the factored front of supernode s-1 (its trailing block = update matrix)
+    int prev_f = 0, prev_w = 0;
+    for (int s = lo; s <= hi; ++s) {
+        const SnRec me = M.sn[s];
+        const int first = me.first, w = me.w, f = me.f;
+        double* W = cur;
+        for (int idx = tid; idx < f * f; idx += nt) W[idx] = 0.0;
+        __syncthreads();
+        for (int e = fe_ptr[s] + tid; e < fe_ptr[s + 1]; e += nt) W[fe_off[e]] = vals[fe_q[e]];
+        __syncthreads();
+        for (int ci = me.child_lo; ci < me.child_hi; ++ci) {
+            const int c = M.child[ci];
+            const SnRec ch = M.sn[c];
+            const int wc = ch.w, fc = ch.f, uc = fc - wc;
+            const bool from_lds = prev_valid && c == s - 1;
+            const double* U = from_lds ? prev + wc + wc * fc : fronts + ch.front_off + wc + (long long)wc * fc;
+            const int* rel = M.rel + ch.rel_ptr;
+            for (int idx = tid; idx < uc * uc; idx += nt) {
+                const int i = idx % uc, j = idx / uc;
+                if (i >= j) W[rel[i] + rel[j] * f] += U[i + (long long)j * fc];
+            }
+            __syncthreads();
+        }
+        (void)prev_f; (void)prev_w;
+        // ---- panel
+        for (int k = 0; k < w; ++k) {
+            double d = W[k + k * f];
+            if (d == 0.0) { if (tid == 0 && *info < 0) *info = first + k; d = 1.0; }
+            const double dinv = 1.0 / d;
+            if (tid == 0) rdiag[first + k] = dinv;
+            const int r = f - k - 1, pc = w - k - 1;
+            const double* colk = W + (k + 1) + k * f;
+            for (int idx = tid; idx < r * pc; idx += nt) {
+                const int i = idx % r, j = idx / r;
+                if (i >= j) W[(k + 1 + i) + (k + 1 + j) * f] -= (colk[i] * dinv) * colk[j];
+            }
+            __syncthreads();
+            for (int i = tid; i < r; i += nt) W[(k + 1 + i) + k * f] *= dinv;
+            __syncthreads();
+        }
+        // ---- Schur complement
+        const int u = f - w;
+        if (u > 0) {
+            const int tx = tid & 15, ty = tid >> 4, tys = nt >> 4;
+            for (int j = ty; j < u; j += tys) {
+                for (int i = j - (j & 15) + tx; i < u; i += 16) {
+                    if (i < j) continue;
+                    double acc = 0.0;
+                    for (int k = 0; k < w; ++k) acc += (W[(w + i) + k * f] * W[k + k * f]) * W[(w + j) + k * f];
+                    W[(w + i) + (w + j) * f] -= acc;
+                }
+            }
+            __syncthreads();
+        }
+        // ---- factor panel to HBM (the first w columns of the front are contiguous); update matrix only if nobody reads it from LDS
+        double* F = fronts + me.front_off;
+        for (int idx = tid; idx < f * w; idx += nt) F[idx] = W[idx];
+        const bool keep = me.parent == s + 1 && s + 1 <= hi;
+        if (!keep && u > 0) {
+            for (int idx = tid; idx < u * u; idx += nt) {
+                const int i = idx % u, j = idx / u;
+                if (i >= j) F[(w + i) + (long long)(w + j) * f] = W[(w + i) + (w + j) * f];
+            }
+        }
+        __syncthreads();
+        double* t = cur; cur = prev; prev = t;
+        prev_valid = keep; prev_f = f; prev_w = w;
+    }
 }
 
 // one workgroup per small subtree: its supernodes lo..hi (a postorder range, children before parents) are factored one
@@ -381,7 +467,14 @@ public:
         const int t1 = prof_.begin(1, st_);
         PQ_HIP(hipMemsetAsync(info_.p, 0xFF, sizeof(int), st_));
         FrontMeta M = meta();
-        if (S_.nsub > 0) hipLaunchKernelGGL(k_subtree_factor, dim3(S_.nsub), dim3(SUB_THREADS), sub_lds_, st_, M, fronts_.p, sub_lo_.p, sub_hi_.p, rdiag_.p, info_.p);
+        if (S_.nsub > 0) {
+            const int cap = S_.sub_max_front * S_.sub_max_front;
+            if (2LL * cap * (long long)sizeof(double) <= SUBTREE_LDS_BYTES && !std::getenv("PIQP_AMD_SUBTREE_HBM"))
+                hipLaunchKernelGGL(k_subtree_factor_lds, dim3(S_.nsub), dim3(SUB_THREADS), 2 * cap * (int)sizeof(double), st_, M, fronts_.p, vals_.p, fe_ptr_.p, fe_q_.p, fe_off_.p,
+                                   sub_lo_.p, sub_hi_.p, cap, rdiag_.p, info_.p);
+            else
+                hipLaunchKernelGGL(k_subtree_factor, dim3(S_.nsub), dim3(SUB_THREADS), sub_lds_, st_, M, fronts_.p, sub_lo_.p, sub_hi_.p, rdiag_.p, info_.p);
+        }
         for (int l = 0; l < S_.top_nlevels; ++l) {
             const int cnt = S_.top_level_ptr[l + 1] - S_.top_level_ptr[l];
             hipLaunchKernelGGL(k_front_factor, dim3(cnt), dim3(256), level_lds_[l], st_, M, fronts_.p, level_sn_.p + S_.top_level_ptr[l], BIG_FRONT, BIG_PIVOTS,
@@ -488,7 +581,7 @@ private:
         ops_.clone_from(o.ops_, st_);
         cpd(vals_, o.vals_); cpd(fronts_, o.fronts_); cpd(rdiag_, o.rdiag_);
         xp_.alloc(o.xp_.n); fvec_.alloc(o.fvec_.n); dvec_.alloc(o.dvec_.n);
-        cpi(diag_pos_, o.diag_pos_); cpi(P_, o.P_); cpi(level_sn_, o.level_sn_); cpi(sub_lo_, o.sub_lo_); cpi(sub_hi_, o.sub_hi_);
+        cpi(diag_pos_, o.diag_pos_); cpi(P_, o.P_); cpi(level_sn_, o.level_sn_); cpi(sub_lo_, o.sub_lo_); cpi(sub_hi_, o.sub_hi_); cpi(fe_ptr_, o.fe_ptr_); cpi(fe_q_, o.fe_q_); cpi(fe_off_, o.fe_off_);
         snrec_.alloc(o.snrec_.n ? o.snrec_.n : 1); if (o.snrec_.n) PQ_HIP(hipMemcpyAsync(snrec_.p, o.snrec_.p, o.snrec_.bytes(), hipMemcpyDeviceToDevice, st_)); cpi(sn_first_, o.sn_first_); cpi(front_rows_ptr_, o.front_rows_ptr_); cpi(front_rows_, o.front_rows_);
         cpi(child_ptr_, o.child_ptr_); cpi(child_, o.child_); cpi(rel_ptr_, o.rel_ptr_); cpi(rel_, o.rel_);
         cpi(mapP_, o.mapP_); cpi(mapA_, o.mapA_); cpi(mapG_, o.mapG_);
@@ -507,6 +600,7 @@ private:
         if (!attr_set) {
             PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_front_factor), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_FRONT_DOUBLES * (int)sizeof(double)));
             PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_subtree_factor), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_FRONT_DOUBLES * (int)sizeof(double)));
+            PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_subtree_factor_lds), hipFuncAttributeMaxDynamicSharedMemorySize, SUBTREE_LDS_BYTES));
             attr_set = true;
         }
         level_lds_.assign(S_.top_nlevels, 0);
@@ -530,7 +624,7 @@ private:
     void build_device(const pq_sparse_data* d)
     {
         nnzK_ = S_.Cp[N_];
-        upload_vec(diag_pos_, S_.diag_pos, st_); upload_vec(P_, S_.P, st_); upload_vec(level_sn_, S_.top_level_sn, st_); upload_vec(sub_lo_, S_.sub_lo, st_); upload_vec(sub_hi_, S_.sub_hi, st_); upload_vec(sn_first_, S_.sn_first, st_);
+        upload_vec(diag_pos_, S_.diag_pos, st_); upload_vec(P_, S_.P, st_); upload_vec(level_sn_, S_.top_level_sn, st_); upload_vec(sub_lo_, S_.sub_lo, st_); upload_vec(sub_hi_, S_.sub_hi, st_); upload_vec(fe_ptr_, S_.fe_ptr, st_); upload_vec(fe_q_, S_.fe_q, st_); upload_vec(fe_off_, S_.fe_off, st_); upload_vec(sn_first_, S_.sn_first, st_);
         upload_vec(front_rows_ptr_, S_.front_rows_ptr, st_); upload_vec(front_rows_, S_.front_rows, st_); upload_vec(child_ptr_, S_.child_ptr, st_); upload_vec(child_, S_.child, st_);
         upload_vec(rel_ptr_, S_.rel_ptr, st_); upload_vec(rel_, S_.rel, st_); upload_vec(a_dst_, S_.a_dst, st_); upload_vec(front_off_, S_.front_off, st_);
         {
@@ -538,7 +632,7 @@ private:
             for (int q = 0; q < S_.nsuper; ++q) {
                 SnRec& r = rec[q];
                 r.first = S_.sn_first[q]; r.w = S_.sn_first[q + 1] - S_.sn_first[q]; r.f = S_.front_rows_ptr[q + 1] - S_.front_rows_ptr[q];
-                r.rows_ptr = S_.front_rows_ptr[q]; r.child_lo = S_.child_ptr[q]; r.child_hi = S_.child_ptr[q + 1]; r.rel_ptr = S_.rel_ptr[q]; r.pad = 0;
+                r.rows_ptr = S_.front_rows_ptr[q]; r.child_lo = S_.child_ptr[q]; r.child_hi = S_.child_ptr[q + 1]; r.rel_ptr = S_.rel_ptr[q]; r.parent = S_.sn_parent[q];
                 r.front_off = S_.front_off[q]; r.pad2 = 0;
             }
             upload_vec(snrec_, rec, st_);
@@ -630,7 +724,7 @@ private:
     int sub_lds_ = 0;
     CscOperators ops_;
     DBuf<double> vals_, fronts_, rdiag_, xp_, fvec_, dvec_;
-    DBuf<int> sub_lo_, sub_hi_;
+    DBuf<int> sub_lo_, sub_hi_, fe_ptr_, fe_q_, fe_off_;
     DBuf<SnRec> snrec_;
     DBuf<int> diag_pos_, P_, level_sn_, sn_first_, front_rows_ptr_, front_rows_, child_ptr_, child_, rel_ptr_, rel_;
     DBuf<int> mapP_, mapA_, mapG_, mapAA_, mapGG_, aa_ptr_, aa_q1_, aa_q2_, aa_k_, gg_ptr_, gg_q1_, gg_q2_, gg_k_;

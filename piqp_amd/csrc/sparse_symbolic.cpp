@@ -670,13 +670,15 @@ static void analyse_with_order(Symbolic& S, const IVec& perm0)
     // columns and its parent's does not.  Supernodes are numbered in postorder, so a subtree is the contiguous range
     // [s - desc[s], s].
     {
-        const int SUB_COLS = 192;
-        IVec cols(ns, 0), desc(ns, 0);
+        const int SUB_COLS = 192, SUB_FMAX = 96;  // two 96 x 96 fronts fit the 160 KiB of LDS of one workgroup
+        IVec cols(ns, 0), desc(ns, 0), fmax(ns, 0);
         for (int s = 0; s < ns; ++s) {
             cols[s] += S.sn_first[s + 1] - S.sn_first[s];
+            fmax[s] = std::max(fmax[s], S.front_rows_ptr[s + 1] - S.front_rows_ptr[s]);
             const int ps = S.sn_parent[s];
-            if (ps >= 0) { cols[ps] += cols[s]; desc[ps] += desc[s] + 1; }
+            if (ps >= 0) { cols[ps] += cols[s]; desc[ps] += desc[s] + 1; fmax[ps] = std::max(fmax[ps], fmax[s]); }
         }
+        for (int s = 0; s < ns; ++s) if (fmax[s] > SUB_FMAX) cols[s] = SUB_COLS + 1;  // a subtree holding a wide front is not "small"
         IVec in_sub(ns, 0);
         S.sub_lo.clear(); S.sub_hi.clear(); S.sub_max_front = 0;
         for (int s = 0; s < ns; ++s) {
@@ -725,6 +727,19 @@ static void analyse_with_order(Symbolic& S, const IVec& perm0)
             }
             S.a_dst[q] = S.front_off[s] + lrow + (long long)(i - first) * f;
         }
+    }
+
+    // ---- per-supernode lists of the K entries of its front (value index, offset inside the front): lets a workgroup assemble
+    // a front straight into LDS
+    {
+        S.fe_ptr.assign(ns + 1, 0);
+        const int nzk = S.Cp[N];
+        IVec owner(nzk);
+        for (int k = 0; k < N; ++k) for (int q = S.Cp[k]; q < S.Cp[k + 1]; ++q) { owner[q] = S.sn_of_col[S.Ci[q]]; S.fe_ptr[owner[q] + 1]++; }
+        for (int s = 0; s < ns; ++s) S.fe_ptr[s + 1] += S.fe_ptr[s];
+        S.fe_q.assign(nzk, 0); S.fe_off.assign(nzk, 0);
+        IVec nx(S.fe_ptr.begin(), S.fe_ptr.end() - 1);
+        for (int q = 0; q < nzk; ++q) { const int t = nx[owner[q]]++; S.fe_q[t] = q; S.fe_off[t] = (int)(S.a_dst[q] - S.front_off[owner[q]]); }
     }
 
     // ---- extend-add maps

@@ -61,6 +61,7 @@ struct Symbolic {
     int top_nlevels = 0;
     // assembly: PKPt value q goes to fronts[a_dst[q]]
     std::vector<long long> a_dst;
+    IVec fe_ptr, fe_q, fe_off;  // the same map grouped by owning supernode: entries fe_ptr[s]..fe_ptr[s+1]: value index, offset inside the front
     // extend-add: for child c, rel[rel_ptr[c] + i] = position in the parent's front of c's i-th update row
     IVec rel_ptr, rel;
     IVec child_ptr, child;  // children lists (fixed order = increasing supernode id)
