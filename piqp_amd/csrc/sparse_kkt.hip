@@ -29,6 +29,7 @@ namespace {
 
 constexpr int BIG_FRONT = 192;      // fronts at least this large with >= BIG_PIVOTS pivots use the dense multi-workgroup kernels
 constexpr int BIG_PIVOTS = 32;
+constexpr int SUB_SOLVE_THREADS = 64;   // substitution inside a subtree is a chain of short vector operations: one wave per subtree
 constexpr int SUBTREE_LDS_BYTES = 150 * 1024;  // two fronts of the LDS-native subtree walker
 constexpr int SUB_THREADS = 256;    // small subtrees: fronts reach ~100 rows near the subtree root, so a full workgroup (64 threads measured 2x slower)
 constexpr int LDS_FRONT_DOUBLES = 12288;  // 96 KiB: fronts up to 110 x 110 are factored inside LDS
@@ -358,7 +359,7 @@ __global__ __launch_bounds__(256) void k_front_fwd(FrontMeta M, const double* __
 {
     front_fwd(M, fronts, list[blockIdx.x], x, fvec);
 }
-__global__ __launch_bounds__(SUB_THREADS) void k_subtree_fwd(FrontMeta M, const double* __restrict__ fronts, const int* __restrict__ sub_lo, const int* __restrict__ sub_hi,
+__global__ __launch_bounds__(SUB_SOLVE_THREADS) void k_subtree_fwd(FrontMeta M, const double* __restrict__ fronts, const int* __restrict__ sub_lo, const int* __restrict__ sub_hi,
                                                      double* __restrict__ x, double* __restrict__ fvec)
 {
     const int lo = sub_lo[blockIdx.x], hi = sub_hi[blockIdx.x];
@@ -395,7 +396,7 @@ __global__ __launch_bounds__(256) void k_front_bwd(FrontMeta M, const double* __
 {
     front_bwd(M, fronts, list[blockIdx.x], x, fvec);
 }
-__global__ __launch_bounds__(SUB_THREADS) void k_subtree_bwd(FrontMeta M, const double* __restrict__ fronts, const int* __restrict__ sub_lo, const int* __restrict__ sub_hi,
+__global__ __launch_bounds__(SUB_SOLVE_THREADS) void k_subtree_bwd(FrontMeta M, const double* __restrict__ fronts, const int* __restrict__ sub_lo, const int* __restrict__ sub_hi,
                                                      double* __restrict__ x, double* __restrict__ fvec)
 {
     const int lo = sub_lo[blockIdx.x], hi = sub_hi[blockIdx.x];
@@ -510,7 +511,7 @@ public:
             const int ntail = mode_ == 1 ? m_ : (mode_ == 2 ? p_ : 0);
             hipLaunchKernelGGL(k_perm_gather, g1(N_), dim3(256), 0, st_, N_, P_.p, rhs_top_.p, n_, tail, ntail, (const double*)nullptr, xp_.p);
         }
-        if (S_.nsub > 0) hipLaunchKernelGGL(k_subtree_fwd, dim3(S_.nsub), dim3(SUB_THREADS), 0, st_, M, fronts_.p, sub_lo_.p, sub_hi_.p, xp_.p, fvec_.p);
+        if (S_.nsub > 0) hipLaunchKernelGGL(k_subtree_fwd, dim3(S_.nsub), dim3(SUB_SOLVE_THREADS), 0, st_, M, fronts_.p, sub_lo_.p, sub_hi_.p, xp_.p, fvec_.p);
         for (int l = 0; l < S_.top_nlevels; ++l) {
             const int cnt = S_.top_level_ptr[l + 1] - S_.top_level_ptr[l];
             hipLaunchKernelGGL(k_front_fwd, dim3(cnt), dim3(256), 0, st_, M, fronts_.p, level_sn_.p + S_.top_level_ptr[l], xp_.p, fvec_.p);
@@ -520,7 +521,7 @@ public:
             const int cnt = S_.top_level_ptr[l + 1] - S_.top_level_ptr[l];
             hipLaunchKernelGGL(k_front_bwd, dim3(cnt), dim3(256), 0, st_, M, fronts_.p, level_sn_.p + S_.top_level_ptr[l], xp_.p, fvec_.p);
         }
-        if (S_.nsub > 0) hipLaunchKernelGGL(k_subtree_bwd, dim3(S_.nsub), dim3(SUB_THREADS), 0, st_, M, fronts_.p, sub_lo_.p, sub_hi_.p, xp_.p, fvec_.p);
+        if (S_.nsub > 0) hipLaunchKernelGGL(k_subtree_bwd, dim3(S_.nsub), dim3(SUB_SOLVE_THREADS), 0, st_, M, fronts_.p, sub_lo_.p, sub_hi_.p, xp_.p, fvec_.p);
         if (mode_ == 0) {
             hipLaunchKernelGGL(k_perm_scatter, g1(N_), dim3(256), 0, st_, N_, P_.p, xp_.p, lhs_x, n_, lhs_y, p_, lhs_z);
         } else {
