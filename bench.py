@@ -179,11 +179,15 @@ def sparse_legs(args, rank, world, local_rank, dev, pd):
         k = piqp_amd.KKTSystem(d, piqp_amd.default_settings(kkt_solver=ks), device=local_rank)
         t_setup = time.perf_counter() - t0
         rng = np.random.default_rng(7 + rank)
-        state = random_vars(n, p, m, rng, positive=True)
-        rhs = [random_vars(n, p, m, rng) for _ in range(2)]
+        state_h = random_vars(n, p, m, rng, positive=True)
+        rhs_h = [random_vars(n, p, m, rng) for _ in range(2)]
+        # resident in HBM: device tensors, PQ_MEM_DEVICE pointer mode (no PCIe inside the timed region)
+        state = {kk: torch.from_numpy(v).to(dev) for kk, v in state_h.items()}
+        rhs = [{kk: torch.from_numpy(v).to(dev) for kk, v in r.items()} for r in rhs_h]
+        lhs = {kk: torch.zeros_like(v) for kk, v in rhs[0].items()}
         for _ in range(2):
             assert k.update_scalings_and_factor(False, 1e-6, 1e-4, state)
-            k.solve(rhs[0])
+            k.solve(rhs[0], lhs)
         res_inf, nrm = k.condensed_residual()
         steps = 10
         be = k.backend(); be.set_profiling(True)
@@ -191,7 +195,7 @@ def sparse_legs(args, rank, world, local_rank, dev, pd):
         t0 = time.perf_counter()
         for _ in range(steps):
             k.update_scalings_and_factor(False, 1e-6, 1e-4, state)
-            k.solve(rhs[0]); k.solve(rhs[1])
+            k.solve(rhs[0], lhs); k.solve(rhs[1], lhs)
         k.synchronize(); torch.cuda.synchronize(); pd.barrier()
         el = pd.max_over_ranks(time.perf_counter() - t0, device=dev if world > 1 else None)
         be.set_profiling(False)
@@ -204,11 +208,11 @@ def sparse_legs(args, rank, world, local_rank, dev, pd):
                 from oracle import pyorc
                 od = pyorc.Data.sparse(*a)
                 ko = pyorc.KKTSystem(od, pyorc.Settings(kkt_solver=oracle_ks))
-                ko.update_scalings_and_factor(False, 1e-6, 1e-4, state)
+                ko.update_scalings_and_factor(False, 1e-6, 1e-4, state_h)
                 t0 = time.perf_counter()
                 cs = 3
                 for _ in range(cs):
-                    ko.update_scalings_and_factor(False, 1e-6, 1e-4, state); ko.solve(rhs[0]); ko.solve(rhs[1])
+                    ko.update_scalings_and_factor(False, 1e-6, 1e-4, state_h); ko.solve(rhs_h[0]); ko.solve(rhs_h[1])
                 elc = time.perf_counter() - t0
                 r["cpu_baseline"] = {"value": cs / elc, "unit": r["unit"], "cores": 1, "kind": "port",
                                      "sample": f"{cs} steps of the same workload, oracle kkt_solver={'sparse_ldlt' if oracle_ks == 1 else 'sparse_multistage'} (gcc -O3), 1 thread"}
