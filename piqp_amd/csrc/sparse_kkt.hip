@@ -403,6 +403,86 @@ __global__ __launch_bounds__(SUB_SOLVE_THREADS) void k_subtree_bwd(FrontMeta M, 
     for (int s = hi; s >= lo; --s) { front_bwd(M, fronts, s, x, fvec); __syncthreads(); }
 }
 
+// ---- the top of the assembly tree in ONE launch: workgroup b takes the top supernodes b, b + G, ... of the level-sorted (=
+// topological) list and waits on per-supernode completion flags instead of on kernel boundaries.  Every dependency has a
+// smaller list index and all G workgroups are resident (G <= number of CUs, one workgroup per CU), so the smallest unfinished
+// index is always being worked on: no deadlock.  Flags are released / acquired at agent scope (the data crosses XCD L2s).
+// every spin is bounded: if the workgroups are not all resident (another stream occupies the device) the wait gives up, raises
+// `err` and the launch drains instead of hanging; the host then reports a failed factorisation / a non-finite solve
+__device__ __forceinline__ void top_wait(const int* flag, int* err)
+{
+    if (threadIdx.x == 0) {
+        unsigned spins = 0;
+        while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > 4000000u || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+__device__ __forceinline__ void top_done(int* flag)
+{
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __hip_atomic_store(flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+__global__ __launch_bounds__(256) void k_top_factor(FrontMeta M, double* __restrict__ fronts, const int* __restrict__ list, int ntop, const int* __restrict__ top_pos,
+                                                    int* __restrict__ flags, int* __restrict__ err, double* __restrict__ rdiag, int* __restrict__ info)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    for (int b = blockIdx.x; b < ntop; b += gridDim.x) {
+        const int s = list[b];
+        const SnRec me = M.sn[s];
+        for (int ci = me.child_lo; ci < me.child_hi; ++ci) {
+            const int tp = top_pos[M.child[ci]];
+            if (tp >= 0) top_wait(flags + tp, err);
+        }
+        front_factor(M, fronts, s, 1 << 30, 1 << 30, rdiag, info, lds);
+        top_done(flags + b);
+    }
+}
+__global__ __launch_bounds__(256) void k_top_fwd(FrontMeta M, const double* __restrict__ fronts, const int* __restrict__ list, int ntop, const int* __restrict__ top_pos,
+                                                 int* __restrict__ flags, int* __restrict__ err, double* __restrict__ x, double* __restrict__ fvec)
+{
+    for (int b = blockIdx.x; b < ntop; b += gridDim.x) {
+        const int s = list[b];
+        const SnRec me = M.sn[s];
+        for (int ci = me.child_lo; ci < me.child_hi; ++ci) {
+            const int tp = top_pos[M.child[ci]];
+            if (tp >= 0) top_wait(flags + tp, err);
+        }
+        front_fwd(M, fronts, s, x, fvec);
+        top_done(flags + b);
+    }
+}
+// backward: parents before children -> walk the list from the end; a supernode waits for its parent
+__global__ __launch_bounds__(256) void k_top_bwd(FrontMeta M, const double* __restrict__ fronts, const int* __restrict__ list, int ntop, const int* __restrict__ top_pos,
+                                                 int* __restrict__ flags, int* __restrict__ err, double* __restrict__ x, double* __restrict__ fvec)
+{
+    for (int b = blockIdx.x; b < ntop; b += gridDim.x) {
+        const int pos = ntop - 1 - b;
+        const int s = list[pos];
+        const int par = M.sn[s].parent;
+        if (par >= 0) top_wait(flags + top_pos[par], err);
+        front_bwd(M, fronts, s, x, fvec);
+        top_done(flags + pos);
+    }
+}
+
+// a timed-out wait surfaces as a failed factorisation (info) or a NaN in the solution (caught by KKTSystem's finite check)
+__global__ void k_top_check(const int* __restrict__ err, int* __restrict__ info, double* __restrict__ x)
+{
+    if (*err == 0) return;
+    if (info && *info < 0) *info = 0;
+    if (x) x[0] = __builtin_nan("");
+}
+
 inline dim3 g1(int n) { return dim3(n > 0 ? (n + 255) / 256 : 1); }
 
 class SparseKKT final : public KKTSolverBase {
@@ -476,7 +556,13 @@ public:
             else
                 hipLaunchKernelGGL(k_subtree_factor, dim3(S_.nsub), dim3(SUB_THREADS), sub_lds_, st_, M, fronts_.p, sub_lo_.p, sub_hi_.p, rdiag_.p, info_.p);
         }
-        for (int l = 0; l < S_.top_nlevels; ++l) {
+        if (top_persistent_) {
+            PQ_HIP(hipMemsetAsync(top_flags_.p, 0, sizeof(int) * (2 * (size_t)ntop_ + 1), st_));
+            hipLaunchKernelGGL(k_top_factor, dim3(top_grid_), dim3(256), top_lds_, st_, M, fronts_.p, level_sn_.p, ntop_, top_pos_.p, top_flags_.p, top_flags_.p + 2 * ntop_, rdiag_.p,
+                               info_.p);
+            hipLaunchKernelGGL(k_top_check, dim3(1), dim3(1), 0, st_, top_flags_.p + 2 * ntop_, info_.p, (double*)nullptr);
+        }
+        for (int l = 0; l < (top_persistent_ ? 0 : S_.top_nlevels); ++l) {
             const int cnt = S_.top_level_ptr[l + 1] - S_.top_level_ptr[l];
             hipLaunchKernelGGL(k_front_factor, dim3(cnt), dim3(256), level_lds_[l], st_, M, fronts_.p, level_sn_.p + S_.top_level_ptr[l], BIG_FRONT, BIG_PIVOTS,
                                rdiag_.p, info_.p);
@@ -512,12 +598,22 @@ public:
             hipLaunchKernelGGL(k_perm_gather, g1(N_), dim3(256), 0, st_, N_, P_.p, rhs_top_.p, n_, tail, ntail, (const double*)nullptr, xp_.p);
         }
         if (S_.nsub > 0) hipLaunchKernelGGL(k_subtree_fwd, dim3(S_.nsub), dim3(SUB_SOLVE_THREADS), 0, st_, M, fronts_.p, sub_lo_.p, sub_hi_.p, xp_.p, fvec_.p);
-        for (int l = 0; l < S_.top_nlevels; ++l) {
+        const bool top_solve_persistent = top_persistent_ && std::getenv("PIQP_AMD_TOP_SOLVE_PERSISTENT");
+        if (top_solve_persistent) {
+            PQ_HIP(hipMemsetAsync(top_flags_.p, 0, sizeof(int) * (2 * (size_t)ntop_ + 1), st_));
+            hipLaunchKernelGGL(k_top_fwd, dim3(top_grid_), dim3(256), 0, st_, M, fronts_.p, level_sn_.p, ntop_, top_pos_.p, top_flags_.p, top_flags_.p + 2 * ntop_, xp_.p, fvec_.p);
+        }
+        for (int l = 0; l < (top_solve_persistent ? 0 : S_.top_nlevels); ++l) {
             const int cnt = S_.top_level_ptr[l + 1] - S_.top_level_ptr[l];
             hipLaunchKernelGGL(k_front_fwd, dim3(cnt), dim3(256), 0, st_, M, fronts_.p, level_sn_.p + S_.top_level_ptr[l], xp_.p, fvec_.p);
         }
         hipLaunchKernelGGL(k_scale, g1(N_), dim3(256), 0, st_, N_, rdiag_.p, xp_.p);
-        for (int l = S_.top_nlevels - 1; l >= 0; --l) {
+        if (top_solve_persistent)
+        {
+            hipLaunchKernelGGL(k_top_bwd, dim3(top_grid_), dim3(256), 0, st_, M, fronts_.p, level_sn_.p, ntop_, top_pos_.p, top_flags_.p + ntop_, top_flags_.p + 2 * ntop_, xp_.p, fvec_.p);
+            hipLaunchKernelGGL(k_top_check, dim3(1), dim3(1), 0, st_, top_flags_.p + 2 * ntop_, (int*)nullptr, xp_.p);
+        }
+        for (int l = top_solve_persistent ? -1 : S_.top_nlevels - 1; l >= 0; --l) {
             const int cnt = S_.top_level_ptr[l + 1] - S_.top_level_ptr[l];
             hipLaunchKernelGGL(k_front_bwd, dim3(cnt), dim3(256), 0, st_, M, fronts_.p, level_sn_.p + S_.top_level_ptr[l], xp_.p, fvec_.p);
         }
@@ -553,6 +649,7 @@ public:
 
     void print_info() override
     {
+        std::printf("top of the tree: %d supernodes, %s\n", ntop_, top_persistent_ ? "factored in one persistent launch" : "one launch per level");
         std::printf("sparse multifrontal LDLt (%s ordering): N = %d, nnz(K) = %d, nnz(L) = %lld, supernodes = %d, tree levels = %d (%d subtrees walked by one workgroup each + %d level launches), max front = %d, front storage = %.1f MB\n",
                     S_.ordering, N_, nnzK_, S_.nnzL, S_.nsuper, S_.nlevels, S_.nsub, S_.top_nlevels, S_.max_front, S_.front_doubles * 8.0 / 1e6);
     }
@@ -573,7 +670,7 @@ public:
     const sparse::Symbolic& symbolic() const { return S_; }
 
 private:
-    SparseKKT(const SparseKKT& o, int) : dev_(o.dev_), mode_(o.mode_), nzAA_(o.nzAA_), nzGG_(o.nzGG_), n_(o.n_), p_(o.p_), m_(o.m_), N_(o.N_), nnzK_(o.nnzK_), delta_(o.delta_), S_(o.S_), level_lds_(o.level_lds_), sub_lds_(o.sub_lds_)
+    SparseKKT(const SparseKKT& o, int) : dev_(o.dev_), mode_(o.mode_), nzAA_(o.nzAA_), nzGG_(o.nzGG_), n_(o.n_), p_(o.p_), m_(o.m_), N_(o.N_), nnzK_(o.nnzK_), delta_(o.delta_), S_(o.S_), level_lds_(o.level_lds_), sub_lds_(o.sub_lds_), ntop_(o.ntop_), top_grid_(o.top_grid_), top_lds_(o.top_lds_), top_persistent_(o.top_persistent_)
     {
         PQ_HIP(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
         auto cpd = [&](DBuf<double>& d, const DBuf<double>& s) { d.alloc(s.n ? s.n : 1); if (s.n) PQ_HIP(hipMemcpyAsync(d.p, s.p, s.bytes(), hipMemcpyDeviceToDevice, st_)); };
@@ -582,7 +679,7 @@ private:
         ops_.clone_from(o.ops_, st_);
         cpd(vals_, o.vals_); cpd(fronts_, o.fronts_); cpd(rdiag_, o.rdiag_);
         xp_.alloc(o.xp_.n); fvec_.alloc(o.fvec_.n); dvec_.alloc(o.dvec_.n);
-        cpi(diag_pos_, o.diag_pos_); cpi(P_, o.P_); cpi(level_sn_, o.level_sn_); cpi(sub_lo_, o.sub_lo_); cpi(sub_hi_, o.sub_hi_); cpi(fe_ptr_, o.fe_ptr_); cpi(fe_q_, o.fe_q_); cpi(fe_off_, o.fe_off_);
+        cpi(diag_pos_, o.diag_pos_); cpi(P_, o.P_); cpi(level_sn_, o.level_sn_); cpi(sub_lo_, o.sub_lo_); cpi(sub_hi_, o.sub_hi_); cpi(top_pos_, o.top_pos_); top_flags_.alloc(o.top_flags_.n ? o.top_flags_.n : 1); cpi(fe_ptr_, o.fe_ptr_); cpi(fe_q_, o.fe_q_); cpi(fe_off_, o.fe_off_);
         snrec_.alloc(o.snrec_.n ? o.snrec_.n : 1); if (o.snrec_.n) PQ_HIP(hipMemcpyAsync(snrec_.p, o.snrec_.p, o.snrec_.bytes(), hipMemcpyDeviceToDevice, st_)); cpi(sn_first_, o.sn_first_); cpi(front_rows_ptr_, o.front_rows_ptr_); cpi(front_rows_, o.front_rows_);
         cpi(child_ptr_, o.child_ptr_); cpi(child_, o.child_); cpi(rel_ptr_, o.rel_ptr_); cpi(rel_, o.rel_);
         cpi(mapP_, o.mapP_); cpi(mapA_, o.mapA_); cpi(mapG_, o.mapG_);
@@ -602,6 +699,7 @@ private:
             PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_front_factor), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_FRONT_DOUBLES * (int)sizeof(double)));
             PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_subtree_factor), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_FRONT_DOUBLES * (int)sizeof(double)));
             PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_subtree_factor_lds), hipFuncAttributeMaxDynamicSharedMemorySize, SUBTREE_LDS_BYTES));
+            PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_top_factor), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_FRONT_DOUBLES * (int)sizeof(double)));
             attr_set = true;
         }
         level_lds_.assign(S_.top_nlevels, 0);
@@ -618,6 +716,21 @@ private:
             const long long f = S_.sub_max_front;
             sub_lds_ = (int)(std::min<long long>(f * f, LDS_FRONT_DOUBLES) * (long long)sizeof(double));
         }
+        // single-launch top of the tree: possible when no top front needs the multi-launch dense path
+        ntop_ = (int)S_.top_level_sn.size();
+        bool any_big = false;
+        long long top_mx = 0;
+        for (int s : S_.top_level_sn) {
+            const int w = S_.sn_first[s + 1] - S_.sn_first[s];
+            const long long f = S_.front_rows_ptr[s + 1] - S_.front_rows_ptr[s];
+            if (f >= BIG_FRONT && w >= BIG_PIVOTS) any_big = true;
+            if (f * f <= LDS_FRONT_DOUBLES) top_mx = std::max(top_mx, f * f);
+        }
+        top_lds_ = (int)top_mx * (int)sizeof(double);
+        top_grid_ = std::min(ntop_, 224);
+        // measured: worth it for the factorisation when every top supernode gets its own workgroup; the substitution fronts are too
+        // cheap to pay for agent-scope release / acquire per supernode, they stay on level launches
+        top_persistent_ = ntop_ > 0 && ntop_ <= 1024 && !any_big && !std::getenv("PIQP_AMD_TOP_LEVELS");
     }
 
     FrontMeta meta() const { return FrontMeta{snrec_.p, front_rows_.p, child_.p, rel_.p}; }
@@ -625,7 +738,13 @@ private:
     void build_device(const pq_sparse_data* d)
     {
         nnzK_ = S_.Cp[N_];
-        upload_vec(diag_pos_, S_.diag_pos, st_); upload_vec(P_, S_.P, st_); upload_vec(level_sn_, S_.top_level_sn, st_); upload_vec(sub_lo_, S_.sub_lo, st_); upload_vec(sub_hi_, S_.sub_hi, st_); upload_vec(fe_ptr_, S_.fe_ptr, st_); upload_vec(fe_q_, S_.fe_q, st_); upload_vec(fe_off_, S_.fe_off, st_); upload_vec(sn_first_, S_.sn_first, st_);
+        upload_vec(diag_pos_, S_.diag_pos, st_); upload_vec(P_, S_.P, st_); upload_vec(level_sn_, S_.top_level_sn, st_); upload_vec(sub_lo_, S_.sub_lo, st_); upload_vec(sub_hi_, S_.sub_hi, st_); {
+            std::vector<int> tp(S_.nsuper ? S_.nsuper : 1, -1);
+            for (size_t q = 0; q < S_.top_level_sn.size(); ++q) tp[S_.top_level_sn[q]] = (int)q;
+            upload_vec(top_pos_, tp, st_);
+            top_flags_.alloc(2 * S_.top_level_sn.size() + 2);
+        }
+        upload_vec(fe_ptr_, S_.fe_ptr, st_); upload_vec(fe_q_, S_.fe_q, st_); upload_vec(fe_off_, S_.fe_off, st_); upload_vec(sn_first_, S_.sn_first, st_);
         upload_vec(front_rows_ptr_, S_.front_rows_ptr, st_); upload_vec(front_rows_, S_.front_rows, st_); upload_vec(child_ptr_, S_.child_ptr, st_); upload_vec(child_, S_.child, st_);
         upload_vec(rel_ptr_, S_.rel_ptr, st_); upload_vec(rel_, S_.rel, st_); upload_vec(a_dst_, S_.a_dst, st_); upload_vec(front_off_, S_.front_off, st_);
         {
@@ -722,10 +841,11 @@ private:
     hipStream_t st_ = nullptr;
     sparse::Symbolic S_;
     std::vector<int> level_lds_;
-    int sub_lds_ = 0;
+    int sub_lds_ = 0, ntop_ = 0, top_grid_ = 0, top_lds_ = 0;
+    bool top_persistent_ = false;
     CscOperators ops_;
     DBuf<double> vals_, fronts_, rdiag_, xp_, fvec_, dvec_;
-    DBuf<int> sub_lo_, sub_hi_, fe_ptr_, fe_q_, fe_off_;
+    DBuf<int> sub_lo_, sub_hi_, fe_ptr_, fe_q_, fe_off_, top_pos_, top_flags_;
     DBuf<SnRec> snrec_;
     DBuf<int> diag_pos_, P_, level_sn_, sn_first_, front_rows_ptr_, front_rows_, child_ptr_, child_, rel_ptr_, rel_;
     DBuf<int> mapP_, mapA_, mapG_, mapAA_, mapGG_, aa_ptr_, aa_q1_, aa_q2_, aa_k_, gg_ptr_, gg_q1_, gg_q2_, gg_k_;
