@@ -413,6 +413,9 @@ bool Solver::setup(std::unique_ptr<HostData> data)
     make_kkt();
     if (!m_kkt_system) { m_setup_done = false; return false; }
     stage_alloc();
+    dipm_.reset();
+    const char* host_ipm = std::getenv("PIQP_AMD_HOST_IPM");
+    if (!(host_ipm && host_ipm[0] == '1')) { dipm_ = std::make_unique<DeviceIpm>(); dipm_->init(*m_data, m_preconditioner, m_kkt_system->stream()); }
     m_first_run = true; m_setup_done = true;
     m_info.setup_time = now_s() - t0;
     return true;
@@ -427,7 +430,10 @@ Solver* Solver::clone() const
         s->m_data = std::make_unique<HostData>(*m_data);
         s->m_preconditioner = m_preconditioner;
         s->m_result = m_result; s->res_nr = res_nr; s->res = res; s->step = step; s->prox_vars = prox_vars;
-        if (m_kkt_system) { s->m_kkt_system.reset(m_kkt_system->clone()); s->stage_alloc(); }
+        if (m_kkt_system) {
+            s->m_kkt_system.reset(m_kkt_system->clone()); s->stage_alloc();
+            if (dipm_) { s->dipm_ = std::make_unique<DeviceIpm>(); s->dipm_->init(*s->m_data, s->m_preconditioner, s->m_kkt_system->stream()); }
+        }
     }
     return s.release();
 }
@@ -464,6 +470,7 @@ bool Solver::update_dense(const double* P, const double* c, const double* A, con
     if (opt == PQ_KKT_UPDATE_NONE) reuse = true;
     m_preconditioner.scale_data(d, reuse, m_settings.preconditioner_scale_cost != 0, m_settings.preconditioner_iter);
     refresh_kkt(*this, *m_kkt_system, d, opt);
+    if (dipm_) dipm_->refresh_data(d, m_preconditioner);
     m_info.update_time = now_s() - t0;
     return true;
 }
@@ -505,6 +512,7 @@ bool Solver::update_sparse(const int* Pp, const int* Pi, const double* Px, const
     if (opt == PQ_KKT_UPDATE_NONE) reuse = true;
     m_preconditioner.scale_data(d, reuse, m_settings.preconditioner_scale_cost != 0, m_settings.preconditioner_iter);
     refresh_kkt(*this, *m_kkt_system, d, opt);
+    if (dipm_) dipm_->refresh_data(d, m_preconditioner);
     m_info.update_time = now_s() - t0;
     return true;
 }
@@ -762,6 +770,7 @@ int Solver::solve_impl()
     if (!m_setup_done) { std::fprintf(stderr, "Solver not setup yet\n"); info.status = PQ_UNSOLVED; return info.status; }
     if (!verify_settings(set)) { info.status = PQ_INVALID_SETTINGS; return info.status; }
     m_kkt_system->set_settings(set);
+    if (dipm_) return dipm_->solve(*m_kkt_system, set, m_preconditioner, info, trace_, trace_max_, &trace_rows_);
     const HostData& d = *m_data;
     const int n = d.n, p = d.p, m = d.m;
     HostVars& r = m_result; HostVars& px = prox_vars;
@@ -1041,7 +1050,10 @@ int Solver::solve()
     const double t0 = now_s();
     if (m_setup_done) PQ_HIP(hipSetDevice(device_));
     const int status = solve_impl();
-    if (m_setup_done && status != PQ_INVALID_SETTINGS) { unscale_results(); restore_dual(); }
+    if (m_setup_done && status != PQ_INVALID_SETTINGS) {
+        if (dipm_) dipm_->download_result(m_result);
+        else { unscale_results(); restore_dual(); }
+    }
     m_info.solve_time = now_s() - t0;
     m_info.run_time = (m_first_run ? m_info.setup_time : m_info.update_time) + m_info.solve_time;
     if (m_settings.verbose) std::printf("\nstatus:               %d\nnumber of iterations: %d\nobjective:            %.5e\n", status, m_info.iter, m_info.primal_obj);

@@ -59,6 +59,21 @@ struct HostVars {
     const Vec& field(int k) const { return const_cast<HostVars*>(this)->field(k); }
 };
 
+// the interior-point loop with device-resident vectors (device_ipm.hip); the default path of Solver::solve
+class DeviceIpm {
+public:
+    DeviceIpm();
+    ~DeviceIpm();
+    void init(const HostData& d, const Ruiz& rz, hipStream_t st);
+    void refresh_data(const HostData& d, const Ruiz& rz);  // after setup / update: scaled vectors, Ruiz scalings, finite-bound masks
+    int solve(KKTSystem& kkt, const pq_settings& set, const Ruiz& rz, pq_info& info, double* trace, int trace_max, int* trace_rows);
+    void download_result(HostVars& out);  // unscaled, expanded (unscale_results + restore_dual already applied)
+
+private:
+    struct Impl;
+    std::unique_ptr<Impl> I;
+};
+
 class Solver {
 public:
     explicit Solver(int device);
@@ -114,6 +129,7 @@ private:
     std::vector<DBuf<double>> dev_in_, dev_out_;
     pq_vars din_{}, dout_{};
     DBuf<double> dxa_, dxb_, dxc_, dya_, dyb_, dza_, dzb_;
+    std::unique_ptr<DeviceIpm> dipm_;  // null when PIQP_AMD_HOST_IPM=1
     double* trace_ = nullptr;
     int trace_max_ = 0, trace_rows_ = 0;
 };
