@@ -183,6 +183,32 @@ int pq_kkt_dims(const pq_kkt *k, int *n, int *p, int *m);
  * `capacity` rows of (start, diag_size, off_diag_size) -- the last row is the arrow corner block -- and
  * returns the number of blocks (call with out_host = NULL to size the buffer). */
 int pq_kkt_multistage_block_info(pq_kkt *k, int *out_host, int capacity);
+/* ---- stage-partitioned execution of ONE KKT system over several processes, one GPU each (BASELINE configs[4]; the
+ * reference has no counterpart, its multistage backend is a serial recurrence, multistage_kkt.hpp:1289-1347,1726-1814).
+ * Every process creates the same backend on the same data and calls pq_kkt_partition with its rank.  Vectors stay
+ * replicated; the assembly-tree work of factor / solve is split: each rank eliminates the subtrees it owns (for a
+ * multistage chain: a contiguous range of stages), the update matrices of the subtree roots are summed across ranks,
+ * and the few supernodes above them are eliminated by every rank on identical data.  The library never talks to the
+ * network itself: when data has to cross ranks it synchronises its stream and calls `exchange(user, which)`, and the
+ * caller performs the collective on the buffer it registered (torch.distributed over RCCL in piqp_amd/dist.py):
+ *   which = 0  all-reduce(sum) of buf_factor [sizes[0] doubles]   once per factorisation
+ *   which = 1  all-reduce(sum) of buf_forward [sizes[1] doubles]  once per backend solve
+ *   which = 2  all-gather in place of buf_gather [world x sizes[2] doubles, this rank's chunk at rank * sizes[2]]
+ * The callback returns 0 on success; it must return only when the result is visible to the handle's stream.
+ * Supported by the sparse_ldlt* backends and by sparse_multistage when it runs on the tree engine. */
+typedef int (*pq_exchange_fn)(void *user, int which);
+int pq_kkt_partition(pq_kkt *k, int rank, int world, long long sizes_out[3]);
+int pq_kkt_set_exchange(pq_kkt *k, pq_exchange_fn exchange, void *user, double *buf_factor, double *buf_forward,
+                        double *buf_gather);
+/* what the partition looks like: out[0] = supernodes owned by this rank, out[1] = shared supernodes, out[2] = boundary
+ * subtree roots, out[3..4] = this rank's column span, out[5] = work share of this rank in permille, out[6] = shared
+ * (replicated) work in permille */
+int pq_kkt_partition_info(pq_kkt *k, int out[8]);
+/* host-only planning hook for tests (no GPU needed): analyses the KKT pattern of `mode` (0 full .. 3 all eliminated)
+ * and writes the owning rank of every permuted column (-1 = shared top) into owner_out[N]; returns N */
+int pq_sparse_partition_plan(const pq_sparse_data *data, int mode, int world, int *owner_out, int capacity,
+                             double *work_out /* world + 1: per rank, then shared */);
+
 /* measurement hooks: when enabled, the backend brackets its stages with hipEvents on its own stream.
  * stage 0 = KKT assembly kernel (dense: k_syrk_lower<ASSEMBLE>), 1 = factorisation (all panels),
  * 2 = backend solve.  pq_kkt_get_profile returns the accumulated milliseconds / call count and resets them. */
@@ -251,6 +277,11 @@ int pq_solver_dims(const pq_solver *s, int *n, int *p, int *m);
 /* optional per-iteration trace (rows of 11 doubles = the verbose table, solver.hpp:590-602) */
 int pq_solver_set_trace(pq_solver *s, double *buf_host, int max_rows);
 int pq_solver_trace_rows(const pq_solver *s);
+/* pq_kkt_partition / pq_kkt_set_exchange on the solver's KKT backend (after setup): the interior-point loop then runs
+ * replicated on every rank, bit for bit the same, with the factor / solve work split across the ranks */
+int pq_solver_partition(pq_solver *s, int rank, int world, long long sizes_out[3]);
+int pq_solver_set_exchange(pq_solver *s, pq_exchange_fn exchange, void *user, double *buf_factor, double *buf_forward,
+                           double *buf_gather);
 
 /* ===================== Batched solver: many structurally identical sparse QPs in one launch ===================== */
 /* The reference has no batch API (one SolverBase per QP, solver.hpp:42); this is the device-side equivalent of

@@ -72,17 +72,20 @@ SYMBOLS = [
     "pq_kkt_update_data_dense", "pq_kkt_update_data_sparse", "pq_kkt_update_scalings_and_factor", "pq_kkt_solve",
     "pq_kkt_eval_P_x", "pq_kkt_eval_A_xn_and_AT_xt", "pq_kkt_eval_G_xn_and_GT_xt", "pq_kkt_print_info",
     "pq_kkt_synchronize", "pq_kkt_stream", "pq_kkt_internal_kkt_mat", "pq_kkt_internal_factor", "pq_kkt_dims", "pq_kkt_multistage_block_info", "pq_kkt_set_profiling", "pq_kkt_get_profile",
+    "pq_kkt_partition", "pq_kkt_set_exchange", "pq_kkt_partition_info", "pq_sparse_partition_plan",
     "pq_kktsys_create_dense", "pq_kktsys_create_sparse", "pq_kktsys_clone", "pq_kktsys_destroy",
     "pq_kktsys_set_pointer_mode", "pq_kktsys_backend", "pq_kktsys_update_data_dense", "pq_kktsys_update_data_sparse",
     "pq_kktsys_update_scalings_and_factor", "pq_kktsys_solve", "pq_kktsys_mul", "pq_kktsys_last_solve_stats",
     "pq_kktsys_condensed_residual", "pq_kktsys_synchronize",
     "pq_solver_create", "pq_solver_destroy", "pq_solver_clone", "pq_solver_settings", "pq_solver_setup_dense",
     "pq_solver_setup_sparse", "pq_solver_update_dense", "pq_solver_update_sparse", "pq_solver_solve", "pq_solver_info",
-    "pq_solver_get_result", "pq_solver_dims", "pq_solver_set_trace", "pq_solver_trace_rows",
+    "pq_solver_get_result", "pq_solver_dims", "pq_solver_set_trace", "pq_solver_trace_rows", "pq_solver_partition", "pq_solver_set_exchange",
     "pq_batch_create", "pq_batch_destroy", "pq_batch_settings", "pq_batch_setup_sparse", "pq_batch_solve", "pq_batch_info", "pq_batch_get_result",
     "pq_batch_dims", "pq_batch_block_info", "pq_batch_get_profile", "pq_batch_last_kernel_ms",
     "pq_microbench_mfma_f64", "pq_microbench_hbm_copy",
 ]
+
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, vp, C.c_int)  # pq_exchange_fn
 
 _lib = None
 
@@ -175,6 +178,12 @@ def load():
     L.pq_solver_dims.argtypes = [vp, _ip, _ip, _ip]
     L.pq_solver_set_trace.argtypes = [vp, vp, C.c_int]
     L.pq_solver_trace_rows.argtypes = [vp]
+    L.pq_kkt_partition.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_longlong)]
+    L.pq_kkt_set_exchange.argtypes = [vp, EXCHANGE_FN, vp, vp, vp, vp]
+    L.pq_kkt_partition_info.argtypes = [vp, _ip]
+    L.pq_sparse_partition_plan.argtypes = [C.POINTER(SparseData), C.c_int, C.c_int, vp, C.c_int, vp]
+    L.pq_solver_partition.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_longlong)]
+    L.pq_solver_set_exchange.argtypes = [vp, EXCHANGE_FN, vp, vp, vp, vp]
     L.pq_microbench_mfma_f64.argtypes = [C.c_int, C.c_int, _dp]
     L.pq_microbench_hbm_copy.argtypes = [C.c_int, C.c_size_t, C.c_int, _dp]
     _lib = L

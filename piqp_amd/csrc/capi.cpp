@@ -7,6 +7,7 @@
 #include "dense_kernels.hpp"
 #include "kkt_solver_base.hpp"
 #include "kkt_system.hpp"
+#include "sparse_symbolic.hpp"
 #include "solver.hpp"
 
 using namespace pq;
@@ -324,6 +325,36 @@ int pq_kkt_multistage_block_info(pq_kkt* k, int* out_host, int capacity)
         const int N = (int)bi.size() / 3;
         if (out_host) for (int i = 0; i < 3 * std::min(N, capacity); ++i) out_host[i] = bi[i];
         return N;
+    });
+}
+int pq_kkt_partition(pq_kkt* k, int rank, int world, long long sizes_out[3])
+{
+    if (!k || !sizes_out) return fail(PQ_ERR_INVALID, "null argument");
+    return guarded([&] { k->impl->partition(rank, world, sizes_out); return (int)PQ_OK; });
+}
+int pq_kkt_set_exchange(pq_kkt* k, pq_exchange_fn exchange, void* user, double* buf_factor, double* buf_forward, double* buf_gather)
+{
+    if (!k) return fail(PQ_ERR_INVALID, "null argument");
+    return guarded([&] { k->impl->set_exchange(exchange, user, buf_factor, buf_forward, buf_gather); return (int)PQ_OK; });
+}
+int pq_kkt_partition_info(pq_kkt* k, int out[8])
+{
+    if (!k || !out) return fail(PQ_ERR_INVALID, "null argument");
+    return guarded([&] { k->impl->partition_info(out); return (int)PQ_OK; });
+}
+int pq_sparse_partition_plan(const pq_sparse_data* data, int mode, int world, int* owner_out, int capacity, double* work_out)
+{
+    if (!data || world < 1) return fail(PQ_ERR_INVALID, "bad argument");
+    return guarded([&] {
+        sparse::Symbolic S;
+        sparse::analyse_kkt(data, mode, S);
+        sparse::Partition P;
+        sparse::partition_tree(S, world, P);
+        if (owner_out)
+            for (int s = 0; s < S.nsuper; ++s)
+                for (int j = S.sn_first[s]; j < S.sn_first[s + 1] && j < capacity; ++j) owner_out[j] = P.owner[s];
+        if (work_out) { for (int r = 0; r < world; ++r) work_out[r] = P.work[r]; work_out[world] = P.shared_work; }
+        return S.N;
     });
 }
 int pq_kkt_dims(const pq_kkt* k, int* n, int* p, int* m)

@@ -43,6 +43,14 @@ public:
     virtual void internal_factor(double* out_host) { (void)out_host; throw std::runtime_error("internal_factor: dense only"); }
     // test hook: rows of (start, diag_size, off_diag_size) of the multistage backend (print_info, multistage_kkt.hpp:385-393)
     virtual void multistage_block_info(std::vector<int>& out) const { (void)out; throw std::runtime_error("block_info: sparse_multistage only"); }
+    // stage-partitioned execution over several processes (include/piqp_amd.h, pq_kkt_partition)
+    virtual void partition(int rank, int world, long long sizes[3]) { (void)rank; (void)world; (void)sizes; throw std::runtime_error("partition: not supported by this backend"); }
+    virtual void set_exchange(pq_exchange_fn fn, void* user, double* buf_factor, double* buf_forward, double* buf_gather)
+    {
+        (void)fn; (void)user; (void)buf_factor; (void)buf_forward; (void)buf_gather;
+        throw std::runtime_error("set_exchange: not supported by this backend");
+    }
+    virtual void partition_info(int out[8]) const { (void)out; throw std::runtime_error("partition_info: not supported by this backend"); }
     // measurement hooks (hipEvent brackets on the backend's stream)
     virtual void set_profiling(bool on) { (void)on; }
     virtual void get_profile(int stage, double* total_ms, int* count) { (void)stage; *total_ms = 0.0; *count = 0; }

@@ -208,6 +208,25 @@ public:
         ops_.eval_G_xn_and_GT_xt(alpha_n, alpha_t, xn, xt, zn, zt, st_);
     }
 
+    // stage partition over several processes: the stage-parallel (tree) engine carries it; the serial recurrence cannot be split.
+    // The engine choice of make_multistage_kkt is a timing probe, so partitioned runs force it (PIQP_AMD_MULTISTAGE=tree) to keep
+    // every rank on the same code path.
+    void partition(int rank, int world, long long sizes[3]) override
+    {
+        if (!tree_) throw std::runtime_error("partition: sparse_multistage must run on the tree engine (set PIQP_AMD_MULTISTAGE=tree before setup)");
+        tree_->partition(rank, world, sizes);
+    }
+    void set_exchange(pq_exchange_fn fn, void* user, double* buf_factor, double* buf_forward, double* buf_gather) override
+    {
+        if (!tree_) throw std::runtime_error("set_exchange: not partitioned");
+        tree_->set_exchange(fn, user, buf_factor, buf_forward, buf_gather);
+    }
+    void partition_info(int out[8]) const override
+    {
+        if (!tree_) throw std::runtime_error("partition_info: not partitioned");
+        tree_->partition_info(out);
+    }
+
     // multistage_kkt.hpp:385-393 (same text), plus where the chain runs
     void print_info() override
     {

@@ -1146,6 +1146,16 @@ int pq_solver_set_trace(pq_solver* s, double* buf_host, int max_rows)
     s->impl->set_trace(buf_host, max_rows);
     return PQ_OK;
 }
+int pq_solver_partition(pq_solver* s, int rank, int world, long long sizes_out[3])
+{
+    if (!s || !sizes_out || !s->impl->backend()) return fail(PQ_ERR_INVALID, "solver not set up");
+    return guarded([&] { s->impl->backend()->partition(rank, world, sizes_out); return (int)PQ_OK; });
+}
+int pq_solver_set_exchange(pq_solver* s, pq_exchange_fn exchange, void* user, double* buf_factor, double* buf_forward, double* buf_gather)
+{
+    if (!s || !s->impl->backend()) return fail(PQ_ERR_INVALID, "solver not set up");
+    return guarded([&] { s->impl->backend()->set_exchange(exchange, user, buf_factor, buf_forward, buf_gather); return (int)PQ_OK; });
+}
 int pq_solver_trace_rows(const pq_solver* s) { return s ? s->impl->trace_rows() : 0; }
 
 }  // extern "C"

@@ -93,6 +93,7 @@ public:
     void set_trace(double* buf, int max_rows) { trace_ = buf; trace_max_ = max_rows; trace_rows_ = 0; }
     int trace_rows() const { return trace_rows_; }
     int device() const { return device_; }
+    KKTSolverBase* backend() { return m_kkt_system ? m_kkt_system->backend() : nullptr; }
 
 private:
     int solve_impl();

@@ -483,6 +483,79 @@ __global__ void k_top_check(const int* __restrict__ err, int* __restrict__ info,
     if (x) x[0] = __builtin_nan("");
 }
 
+// ---- stage partition (pq_kkt_partition): data that crosses ranks -----------------------------------------------------------
+// one workgroup per boundary subtree root: its u x u update block (lower triangle) -> dense slot of the exchange buffer; slots of
+// other ranks' subtrees are zeroed so that an all-reduce(sum) delivers every block to every rank.  The last double carries
+// "a pivot of my subtrees was zero".
+__global__ __launch_bounds__(256) void k_pack_updates(FrontMeta M, const double* __restrict__ fronts, const int* __restrict__ bsn, const int* __restrict__ bowner, int rank,
+                                                      const long long* __restrict__ boff, long long flag_off, const int* __restrict__ info, double* __restrict__ buf)
+{
+    const int b = blockIdx.x;
+    const SnRec ch = M.sn[bsn[b]];
+    const int wc = ch.w, fc = ch.f, uc = fc - wc;
+    double* out = buf + boff[b];
+    if (bowner[b] == rank) {
+        const double* U = fronts + ch.front_off + wc + (long long)wc * fc;
+        for (int idx = threadIdx.x; idx < uc * uc; idx += blockDim.x) {
+            const int i = idx % uc, j = idx / uc;
+            out[idx] = i >= j ? U[i + (long long)j * fc] : 0.0;
+        }
+    } else {
+        for (int idx = threadIdx.x; idx < uc * uc; idx += blockDim.x) out[idx] = 0.0;
+    }
+    if (b == 0 && threadIdx.x == 0) buf[flag_off] = *info >= 0 ? 1.0 : 0.0;
+}
+__global__ __launch_bounds__(256) void k_unpack_updates(FrontMeta M, double* __restrict__ fronts, const int* __restrict__ bsn, const int* __restrict__ bowner, int rank,
+                                                        const long long* __restrict__ boff, long long flag_off, int* __restrict__ info, const double* __restrict__ buf)
+{
+    const int b = blockIdx.x;
+    if (bowner[b] != rank) {
+        const SnRec ch = M.sn[bsn[b]];
+        const int wc = ch.w, fc = ch.f, uc = fc - wc;
+        const double* in = buf + boff[b];
+        double* U = fronts + ch.front_off + wc + (long long)wc * fc;
+        for (int idx = threadIdx.x; idx < uc * uc; idx += blockDim.x) {
+            const int i = idx % uc, j = idx / uc;
+            if (i >= j) U[i + (long long)j * fc] = in[idx];
+        }
+    }
+    if (b == 0 && threadIdx.x == 0 && buf[flag_off] > 0.0 && *info < 0) *info = 0;
+}
+__global__ __launch_bounds__(64) void k_pack_fvec(FrontMeta M, const double* __restrict__ fvec, const int* __restrict__ bsn, const int* __restrict__ bowner, int rank,
+                                                  const int* __restrict__ boff, double* __restrict__ buf)
+{
+    const int b = blockIdx.x;
+    const SnRec ch = M.sn[bsn[b]];
+    const int uc = ch.f - ch.w;
+    const double* v = fvec + ch.rows_ptr + ch.w;
+    const bool mine = bowner[b] == rank;
+    for (int i = threadIdx.x; i < uc; i += blockDim.x) buf[boff[b] + i] = mine ? v[i] : 0.0;
+}
+__global__ __launch_bounds__(64) void k_unpack_fvec(FrontMeta M, double* __restrict__ fvec, const int* __restrict__ bsn, const int* __restrict__ bowner, int rank,
+                                                    const int* __restrict__ boff, const double* __restrict__ buf)
+{
+    const int b = blockIdx.x;
+    if (bowner[b] == rank) return;
+    const SnRec ch = M.sn[bsn[b]];
+    const int uc = ch.f - ch.w;
+    double* v = fvec + ch.rows_ptr + ch.w;
+    for (int i = threadIdx.x; i < uc; i += blockDim.x) v[i] = buf[boff[b] + i];
+}
+// solution columns: this rank's span -> its chunk of the gather buffer; after the all-gather every other rank's span -> x
+__global__ void k_pack_span(int lo, int hi, const double* __restrict__ x, double* __restrict__ chunk)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (lo + i < hi) chunk[i] = x[lo + i];
+}
+__global__ void k_unpack_spans(int world, int rank, int max_span, const int* __restrict__ span_lo, const int* __restrict__ span_hi, const double* __restrict__ buf,
+                               double* __restrict__ x)
+{
+    const int q = blockIdx.y;
+    if (q == rank) return;
+    const int lo = span_lo[q], hi = span_hi[q];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; lo + i < hi; i += gridDim.x * blockDim.x) x[lo + i] = buf[(long long)q * max_span + i];
+}
+
 inline dim3 g1(int n) { return dim3(n > 0 ? (n + 255) / 256 : 1); }
 
 class SparseKKT final : public KKTSolverBase {
@@ -548,29 +621,25 @@ public:
         const int t1 = prof_.begin(1, st_);
         PQ_HIP(hipMemsetAsync(info_.p, 0xFF, sizeof(int), st_));
         FrontMeta M = meta();
-        if (S_.nsub > 0) {
-            const int cap = S_.sub_max_front * S_.sub_max_front;
-            if (2LL * cap * (long long)sizeof(double) <= SUBTREE_LDS_BYTES && !std::getenv("PIQP_AMD_SUBTREE_HBM"))
-                hipLaunchKernelGGL(k_subtree_factor_lds, dim3(S_.nsub), dim3(SUB_THREADS), 2 * cap * (int)sizeof(double), st_, M, fronts_.p, vals_.p, fe_ptr_.p, fe_q_.p, fe_off_.p,
-                                   sub_lo_.p, sub_hi_.p, cap, rdiag_.p, info_.p);
-            else
-                hipLaunchKernelGGL(k_subtree_factor, dim3(S_.nsub), dim3(SUB_THREADS), sub_lds_, st_, M, fronts_.p, sub_lo_.p, sub_hi_.p, rdiag_.p, info_.p);
-        }
-        if (top_persistent_) {
-            PQ_HIP(hipMemsetAsync(top_flags_.p, 0, sizeof(int) * (2 * (size_t)ntop_ + 1), st_));
-            hipLaunchKernelGGL(k_top_factor, dim3(top_grid_), dim3(256), top_lds_, st_, M, fronts_.p, level_sn_.p, ntop_, top_pos_.p, top_flags_.p, top_flags_.p + 2 * ntop_, rdiag_.p,
-                               info_.p);
-            hipLaunchKernelGGL(k_top_check, dim3(1), dim3(1), 0, st_, top_flags_.p + 2 * ntop_, info_.p, (double*)nullptr);
-        }
-        for (int l = 0; l < (top_persistent_ ? 0 : S_.top_nlevels); ++l) {
-            const int cnt = S_.top_level_ptr[l + 1] - S_.top_level_ptr[l];
-            hipLaunchKernelGGL(k_front_factor, dim3(cnt), dim3(256), level_lds_[l], st_, M, fronts_.p, level_sn_.p + S_.top_level_ptr[l], BIG_FRONT, BIG_PIVOTS,
-                               rdiag_.p, info_.p);
-            for (int q = S_.top_level_ptr[l]; q < S_.top_level_ptr[l + 1]; ++q) {
-                const int s = S_.top_level_sn[q];
-                const int w = S_.sn_first[s + 1] - S_.sn_first[s];
-                const int f = S_.front_rows_ptr[s + 1] - S_.front_rows_ptr[s];
-                if (f >= BIG_FRONT && w >= BIG_PIVOTS) factor_big_front(M, s, w, f);
+        if (part_on_) {
+            factor_subtrees(M, part_nsub_, part_sub_lo_.p, part_sub_hi_.p);
+            factor_levels(M, own_ptr_, own_sn_, own_sn_d_.p, own_lds_);
+            const int nb = (int)PT_.boundary.size();
+            if (nb > 0) {
+                hipLaunchKernelGGL(k_pack_updates, dim3(nb), dim3(256), 0, st_, M, fronts_.p, b_sn_.p, b_owner_.p, rank_, b_mat_off_.p, PT_.bmat_off.back(), info_.p, xbuf_factor_);
+                exchange(0);
+                hipLaunchKernelGGL(k_unpack_updates, dim3(nb), dim3(256), 0, st_, M, fronts_.p, b_sn_.p, b_owner_.p, rank_, b_mat_off_.p, PT_.bmat_off.back(), info_.p, xbuf_factor_);
+            }
+            factor_levels(M, sh_ptr_, sh_sn_, sh_sn_d_.p, sh_lds_);
+        } else {
+            factor_subtrees(M, S_.nsub, sub_lo_.p, sub_hi_.p);
+            if (top_persistent_) {
+                PQ_HIP(hipMemsetAsync(top_flags_.p, 0, sizeof(int) * (2 * (size_t)ntop_ + 1), st_));
+                hipLaunchKernelGGL(k_top_factor, dim3(top_grid_), dim3(256), top_lds_, st_, M, fronts_.p, level_sn_.p, ntop_, top_pos_.p, top_flags_.p, top_flags_.p + 2 * ntop_, rdiag_.p,
+                                   info_.p);
+                hipLaunchKernelGGL(k_top_check, dim3(1), dim3(1), 0, st_, top_flags_.p + 2 * ntop_, info_.p, (double*)nullptr);
+            } else {
+                factor_levels(M, S_.top_level_ptr, S_.top_level_sn, level_sn_.p, level_lds_);
             }
         }
         PQ_HIP(hipGetLastError());
@@ -597,27 +666,42 @@ public:
             const int ntail = mode_ == 1 ? m_ : (mode_ == 2 ? p_ : 0);
             hipLaunchKernelGGL(k_perm_gather, g1(N_), dim3(256), 0, st_, N_, P_.p, rhs_top_.p, n_, tail, ntail, (const double*)nullptr, xp_.p);
         }
+        if (part_on_) {
+            if (part_nsub_ > 0) hipLaunchKernelGGL(k_subtree_fwd, dim3(part_nsub_), dim3(SUB_SOLVE_THREADS), 0, st_, M, fronts_.p, part_sub_lo_.p, part_sub_hi_.p, xp_.p, fvec_.p);
+            fwd_levels(M, own_ptr_, own_sn_d_.p);
+            const int nb = (int)PT_.boundary.size();
+            if (nb > 0) {
+                hipLaunchKernelGGL(k_pack_fvec, dim3(nb), dim3(64), 0, st_, M, fvec_.p, b_sn_.p, b_owner_.p, rank_, b_vec_off_.p, xbuf_forward_);
+                exchange(1);
+                hipLaunchKernelGGL(k_unpack_fvec, dim3(nb), dim3(64), 0, st_, M, fvec_.p, b_sn_.p, b_owner_.p, rank_, b_vec_off_.p, xbuf_forward_);
+            }
+            fwd_levels(M, sh_ptr_, sh_sn_d_.p);
+            hipLaunchKernelGGL(k_scale, g1(N_), dim3(256), 0, st_, N_, rdiag_.p, xp_.p);
+            bwd_levels(M, sh_ptr_, sh_sn_d_.p);
+            bwd_levels(M, own_ptr_, own_sn_d_.p);
+            if (part_nsub_ > 0) hipLaunchKernelGGL(k_subtree_bwd, dim3(part_nsub_), dim3(SUB_SOLVE_THREADS), 0, st_, M, fronts_.p, part_sub_lo_.p, part_sub_hi_.p, xp_.p, fvec_.p);
+            if (world_ > 1) {
+                const int lo = PT_.span_lo[rank_], hi = PT_.span_hi[rank_];
+                if (hi > lo) hipLaunchKernelGGL(k_pack_span, g1(hi - lo), dim3(256), 0, st_, lo, hi, xp_.p, xbuf_gather_ + (size_t)rank_ * PT_.max_span);
+                exchange(2);
+                hipLaunchKernelGGL(k_unpack_spans, dim3(std::max(1, std::min(256, (PT_.max_span + 255) / 256)), world_), dim3(256), 0, st_, world_, rank_, PT_.max_span, span_lo_d_.p,
+                                   span_hi_d_.p, xbuf_gather_, xp_.p);
+            }
+        } else {
         if (S_.nsub > 0) hipLaunchKernelGGL(k_subtree_fwd, dim3(S_.nsub), dim3(SUB_SOLVE_THREADS), 0, st_, M, fronts_.p, sub_lo_.p, sub_hi_.p, xp_.p, fvec_.p);
         const bool top_solve_persistent = top_persistent_ && std::getenv("PIQP_AMD_TOP_SOLVE_PERSISTENT");
         if (top_solve_persistent) {
             PQ_HIP(hipMemsetAsync(top_flags_.p, 0, sizeof(int) * (2 * (size_t)ntop_ + 1), st_));
             hipLaunchKernelGGL(k_top_fwd, dim3(top_grid_), dim3(256), 0, st_, M, fronts_.p, level_sn_.p, ntop_, top_pos_.p, top_flags_.p, top_flags_.p + 2 * ntop_, xp_.p, fvec_.p);
-        }
-        for (int l = 0; l < (top_solve_persistent ? 0 : S_.top_nlevels); ++l) {
-            const int cnt = S_.top_level_ptr[l + 1] - S_.top_level_ptr[l];
-            hipLaunchKernelGGL(k_front_fwd, dim3(cnt), dim3(256), 0, st_, M, fronts_.p, level_sn_.p + S_.top_level_ptr[l], xp_.p, fvec_.p);
-        }
+        } else fwd_levels(M, S_.top_level_ptr, level_sn_.p);
         hipLaunchKernelGGL(k_scale, g1(N_), dim3(256), 0, st_, N_, rdiag_.p, xp_.p);
         if (top_solve_persistent)
         {
             hipLaunchKernelGGL(k_top_bwd, dim3(top_grid_), dim3(256), 0, st_, M, fronts_.p, level_sn_.p, ntop_, top_pos_.p, top_flags_.p + ntop_, top_flags_.p + 2 * ntop_, xp_.p, fvec_.p);
             hipLaunchKernelGGL(k_top_check, dim3(1), dim3(1), 0, st_, top_flags_.p + 2 * ntop_, (int*)nullptr, xp_.p);
-        }
-        for (int l = top_solve_persistent ? -1 : S_.top_nlevels - 1; l >= 0; --l) {
-            const int cnt = S_.top_level_ptr[l + 1] - S_.top_level_ptr[l];
-            hipLaunchKernelGGL(k_front_bwd, dim3(cnt), dim3(256), 0, st_, M, fronts_.p, level_sn_.p + S_.top_level_ptr[l], xp_.p, fvec_.p);
-        }
+        } else bwd_levels(M, S_.top_level_ptr, level_sn_.p);
         if (S_.nsub > 0) hipLaunchKernelGGL(k_subtree_bwd, dim3(S_.nsub), dim3(SUB_SOLVE_THREADS), 0, st_, M, fronts_.p, sub_lo_.p, sub_hi_.p, xp_.p, fvec_.p);
+        }
         if (mode_ == 0) {
             hipLaunchKernelGGL(k_perm_scatter, g1(N_), dim3(256), 0, st_, N_, P_.p, xp_.p, lhs_x, n_, lhs_y, p_, lhs_z);
         } else {
@@ -645,6 +729,61 @@ public:
     {
         PQ_HIP(hipSetDevice(dev_));
         ops_.eval_G_xn_and_GT_xt(alpha_n, alpha_t, xn, xt, zn, zt, st_);
+    }
+
+    // ---- pq_kkt_partition / pq_kkt_set_exchange (include/piqp_amd.h)
+    void partition(int rank, int world, long long sizes[3]) override
+    {
+        if (world < 1 || rank < 0 || rank >= world) throw std::runtime_error("partition: bad rank / world");
+        PQ_HIP(hipSetDevice(dev_));
+        sparse::partition_tree(S_, world, PT_);
+        rank_ = rank; world_ = world;
+        // schedules of this rank: the workgroup subtrees and level lists it owns, and the shared level lists
+        std::vector<int> slo, shi;
+        for (int k = 0; k < S_.nsub; ++k) if (PT_.owner[S_.sub_hi[k]] == rank) { slo.push_back(S_.sub_lo[k]); shi.push_back(S_.sub_hi[k]); }
+        part_nsub_ = (int)slo.size();
+        upload_vec(part_sub_lo_, slo, st_); upload_vec(part_sub_hi_, shi, st_);
+        auto filter = [&](int want, std::vector<int>& ptr, std::vector<int>& sn, DBuf<int>& dev, std::vector<int>& lds) {
+            ptr.assign(1, 0); sn.clear(); lds.clear();
+            for (int l = 0; l < S_.top_nlevels; ++l) {
+                long long mx = 0;
+                const size_t before = sn.size();
+                for (int q = S_.top_level_ptr[l]; q < S_.top_level_ptr[l + 1]; ++q) {
+                    const int s = S_.top_level_sn[q];
+                    if (PT_.owner[s] != want) continue;
+                    sn.push_back(s);
+                    const long long f = S_.front_rows_ptr[s + 1] - S_.front_rows_ptr[s];
+                    if (f * f <= LDS_FRONT_DOUBLES) mx = std::max(mx, f * f);
+                }
+                if (sn.size() > before) { ptr.push_back((int)sn.size()); lds.push_back((int)mx * (int)sizeof(double)); }
+            }
+            upload_vec(dev, sn, st_);
+        };
+        filter(rank, own_ptr_, own_sn_, own_sn_d_, own_lds_);
+        filter(-1, sh_ptr_, sh_sn_, sh_sn_d_, sh_lds_);
+        std::vector<int> bo(PT_.boundary.size());
+        for (size_t b = 0; b < bo.size(); ++b) bo[b] = PT_.owner[PT_.boundary[b]];
+        upload_vec(b_sn_, PT_.boundary, st_); upload_vec(b_owner_, bo, st_); upload_vec(b_mat_off_, PT_.bmat_off, st_); upload_vec(b_vec_off_, PT_.bvec_off, st_);
+        upload_vec(span_lo_d_, PT_.span_lo, st_); upload_vec(span_hi_d_, PT_.span_hi, st_);
+        PQ_HIP(hipMemsetAsync(rdiag_.p, 0, sizeof(double) * (size_t)N_, st_));
+        PQ_HIP(hipStreamSynchronize(st_));
+        part_on_ = true;
+        xfn_ = nullptr; xbuf_factor_ = xbuf_forward_ = xbuf_gather_ = nullptr;
+        sizes[0] = PT_.bmat_off.back() + 1; sizes[1] = std::max(1, PT_.bvec_off.back()); sizes[2] = std::max(1, PT_.max_span);
+    }
+    void set_exchange(pq_exchange_fn fn, void* user, double* buf_factor, double* buf_forward, double* buf_gather) override
+    {
+        if (!part_on_) throw std::runtime_error("set_exchange: call pq_kkt_partition first");
+        if (world_ > 1 && (!fn || !buf_factor || !buf_forward || !buf_gather)) throw std::runtime_error("set_exchange: null argument");
+        xfn_ = fn; xuser_ = user; xbuf_factor_ = buf_factor; xbuf_forward_ = buf_forward; xbuf_gather_ = buf_gather;
+    }
+    void partition_info(int out[8]) const override
+    {
+        if (!part_on_) throw std::runtime_error("partition_info: not partitioned");
+        int own = 0, sh = 0;
+        for (int o : PT_.owner) { own += o == rank_; sh += o < 0; }
+        out[0] = own; out[1] = sh; out[2] = (int)PT_.boundary.size(); out[3] = PT_.span_lo[rank_]; out[4] = PT_.span_hi[rank_];
+        out[5] = (int)(1000.0 * PT_.work[rank_] / std::max(PT_.total_work, 1.0)); out[6] = (int)(1000.0 * PT_.shared_work / std::max(PT_.total_work, 1.0)); out[7] = world_;
     }
 
     void print_info() override
@@ -734,6 +873,50 @@ private:
     }
 
     FrontMeta meta() const { return FrontMeta{snrec_.p, front_rows_.p, child_.p, rel_.p}; }
+
+    // data crosses ranks: the stream is drained, the caller's collective runs (pq_exchange_fn), then the stream continues
+    void exchange(int which)
+    {
+        if (world_ == 1) return;
+        if (!xfn_) throw std::runtime_error("partitioned backend used before pq_kkt_set_exchange");
+        PQ_HIP(hipStreamSynchronize(st_));
+        if (xfn_(xuser_, which) != 0) throw std::runtime_error("exchange callback failed");
+    }
+    void factor_subtrees(const FrontMeta& M, int nsub, const int* lo, const int* hi)
+    {
+        if (nsub <= 0) return;
+        const int cap = S_.sub_max_front * S_.sub_max_front;
+        if (2LL * cap * (long long)sizeof(double) <= SUBTREE_LDS_BYTES && !std::getenv("PIQP_AMD_SUBTREE_HBM"))
+            hipLaunchKernelGGL(k_subtree_factor_lds, dim3(nsub), dim3(SUB_THREADS), 2 * cap * (int)sizeof(double), st_, M, fronts_.p, vals_.p, fe_ptr_.p, fe_q_.p, fe_off_.p, lo, hi, cap,
+                               rdiag_.p, info_.p);
+        else
+            hipLaunchKernelGGL(k_subtree_factor, dim3(nsub), dim3(SUB_THREADS), sub_lds_, st_, M, fronts_.p, lo, hi, rdiag_.p, info_.p);
+    }
+    // one launch per level of a (possibly filtered) level schedule; wide fronts go through the dense multi-workgroup path
+    void factor_levels(const FrontMeta& M, const std::vector<int>& ptr, const std::vector<int>& sn, const int* sn_dev, const std::vector<int>& lds)
+    {
+        for (int l = 0; l + 1 < (int)ptr.size(); ++l) {
+            const int cnt = ptr[l + 1] - ptr[l];
+            if (cnt <= 0) continue;
+            hipLaunchKernelGGL(k_front_factor, dim3(cnt), dim3(256), lds[l], st_, M, fronts_.p, sn_dev + ptr[l], BIG_FRONT, BIG_PIVOTS, rdiag_.p, info_.p);
+            for (int q = ptr[l]; q < ptr[l + 1]; ++q) {
+                const int s = sn[q];
+                const int w = S_.sn_first[s + 1] - S_.sn_first[s];
+                const int f = S_.front_rows_ptr[s + 1] - S_.front_rows_ptr[s];
+                if (f >= BIG_FRONT && w >= BIG_PIVOTS) factor_big_front(M, s, w, f);
+            }
+        }
+    }
+    void fwd_levels(const FrontMeta& M, const std::vector<int>& ptr, const int* sn_dev)
+    {
+        for (int l = 0; l + 1 < (int)ptr.size(); ++l)
+            if (ptr[l + 1] > ptr[l]) hipLaunchKernelGGL(k_front_fwd, dim3(ptr[l + 1] - ptr[l]), dim3(256), 0, st_, M, fronts_.p, sn_dev + ptr[l], xp_.p, fvec_.p);
+    }
+    void bwd_levels(const FrontMeta& M, const std::vector<int>& ptr, const int* sn_dev)
+    {
+        for (int l = (int)ptr.size() - 2; l >= 0; --l)
+            if (ptr[l + 1] > ptr[l]) hipLaunchKernelGGL(k_front_bwd, dim3(ptr[l + 1] - ptr[l]), dim3(256), 0, st_, M, fronts_.p, sn_dev + ptr[l], xp_.p, fvec_.p);
+    }
 
     void build_device(const pq_sparse_data* d)
     {
@@ -854,6 +1037,16 @@ private:
     DBuf<int> info_;
     HBuf<int> info_h_;
     StageProfiler prof_;
+    // stage partition (pq_kkt_partition)
+    bool part_on_ = false;
+    int rank_ = 0, world_ = 1, part_nsub_ = 0;
+    sparse::Partition PT_;
+    std::vector<int> own_ptr_, own_sn_, own_lds_, sh_ptr_, sh_sn_, sh_lds_;
+    DBuf<int> part_sub_lo_, part_sub_hi_, own_sn_d_, sh_sn_d_, b_sn_, b_owner_, b_vec_off_, span_lo_d_, span_hi_d_;
+    DBuf<long long> b_mat_off_;
+    pq_exchange_fn xfn_ = nullptr;
+    void* xuser_ = nullptr;
+    double *xbuf_factor_ = nullptr, *xbuf_forward_ = nullptr, *xbuf_gather_ = nullptr;
 };
 
 }  // namespace

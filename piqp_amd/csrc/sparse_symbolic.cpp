@@ -767,5 +767,88 @@ static void analyse_with_order(Symbolic& S, const IVec& perm0)
     }
 }
 
+// ---- partition_tree --------------------------------------------------------------------------------------------------------
+// Subtree-to-rank mapping: start from the roots of the assembly forest and keep replacing the heaviest candidate subtree by
+// its children (its root joins the shared top) until no expandable candidate carries more than 1 / (4 world) of the work.
+// Workgroup subtrees (sub_lo..sub_hi) are atomic.  Candidates are then dealt to the ranks in postorder, contiguous and
+// balanced by prefix sums of their work, so that every rank owns one contiguous range of the (postordered) elimination order
+// interrupted only by shared supernodes: for a multistage chain that is a contiguous range of stages.
+void partition_tree(const Symbolic& S, int world, Partition& P)
+{
+    const int ns = S.nsuper;
+    P = Partition();
+    P.world = world;
+    P.owner.assign(ns, -1);
+    P.work.assign(world, 0.0);
+    P.span_lo.assign(world, 0); P.span_hi.assign(world, 0);
+    if (ns == 0) { P.bmat_off.assign(1, 0); P.bvec_off.assign(1, 0); return; }
+    IVec desc(ns, 0), in_sub(ns, 0);
+    DVec sw(ns, 0.0);
+    for (int k = 0; k < S.nsub; ++k) for (int t = S.sub_lo[k]; t <= S.sub_hi[k]; ++t) in_sub[t] = 1;
+    for (int s = 0; s < ns; ++s) {
+        const double w = S.sn_first[s + 1] - S.sn_first[s], f = S.front_rows_ptr[s + 1] - S.front_rows_ptr[s], u = f - w;
+        sw[s] += w * w * w / 3.0 + w * w * u + w * u * u + 4.0 * f * w + 2000.0;  // factor + substitution + a per-front latency term
+        const int ps = S.sn_parent[s];
+        if (ps >= 0) {
+            if (ps <= s) throw std::runtime_error("partition_tree: supernodes are not in postorder");
+            sw[ps] += sw[s]; desc[ps] += desc[s] + 1;
+        }
+    }
+    for (int s = 0; s < ns; ++s) if (S.sn_parent[s] < 0) P.total_work += sw[s];
+    // candidates kept in a max-heap on subtree work; only top supernodes (not inside a workgroup subtree) can be expanded
+    auto cmp = [&](int a, int b) { return sw[a] < sw[b] || (sw[a] == sw[b] && a < b); };
+    std::vector<int> heap, fixed;
+    for (int s = 0; s < ns; ++s) if (S.sn_parent[s] < 0) heap.push_back(s);
+    std::make_heap(heap.begin(), heap.end(), cmp);
+    const double limit = P.total_work / (4.0 * world);
+    std::vector<char> shared(ns, 0);
+    while (!heap.empty() && world > 1) {
+        std::pop_heap(heap.begin(), heap.end(), cmp);
+        const int s = heap.back(); heap.pop_back();
+        const bool expandable = !in_sub[s] && S.child_ptr[s + 1] > S.child_ptr[s];
+        if (sw[s] <= limit || (int)(heap.size() + fixed.size()) >= 64 * world) { fixed.push_back(s); fixed.insert(fixed.end(), heap.begin(), heap.end()); heap.clear(); break; }
+        if (!expandable) { fixed.push_back(s); continue; }
+        shared[s] = 1;
+        for (int ci = S.child_ptr[s]; ci < S.child_ptr[s + 1]; ++ci) { heap.push_back(S.child[ci]); std::push_heap(heap.begin(), heap.end(), cmp); }
+    }
+    fixed.insert(fixed.end(), heap.begin(), heap.end());
+    std::sort(fixed.begin(), fixed.end());
+    double cand_work = 0.0;
+    for (int c : fixed) cand_work += sw[c];
+    for (int s = 0; s < ns; ++s) if (shared[s]) {
+        double own = sw[s];
+        for (int ci = S.child_ptr[s]; ci < S.child_ptr[s + 1]; ++ci) own -= sw[S.child[ci]];
+        P.shared_work += own;
+    }
+    // contiguous deal: candidate c goes to the rank in whose work interval the midpoint of c falls
+    {
+        double acc = 0.0;
+        std::vector<char> seen(world, 0);
+        for (int c : fixed) {
+            int r = world == 1 ? 0 : (int)((acc + 0.5 * sw[c]) / cand_work * world);
+            r = std::min(std::max(r, 0), world - 1);
+            acc += sw[c];
+            for (int t = c - desc[c]; t <= c; ++t) P.owner[t] = r;
+            P.work[r] += sw[c];
+            const int lo = S.sn_first[c - desc[c]], hi = S.sn_first[c + 1];
+            if (!seen[r]) { P.span_lo[r] = lo; seen[r] = 1; }
+            P.span_hi[r] = hi;
+        }
+        for (int r = 0; r < world; ++r) P.max_span = std::max(P.max_span, P.span_hi[r] - P.span_lo[r]);
+    }
+    P.bmat_off.assign(1, 0); P.bvec_off.assign(1, 0);
+    for (int s = 0; s < ns; ++s) {
+        const int ps = S.sn_parent[s];
+        if (P.owner[s] >= 0 && ps >= 0 && P.owner[ps] < 0) {
+            const long long u = (S.front_rows_ptr[s + 1] - S.front_rows_ptr[s]) - (S.sn_first[s + 1] - S.sn_first[s]);
+            P.boundary.push_back(s);
+            P.bmat_off.push_back(P.bmat_off.back() + u * u);
+            P.bvec_off.push_back(P.bvec_off.back() + (int)u);
+        }
+        if (P.owner[s] >= 0 && ps >= 0 && P.owner[ps] >= 0 && P.owner[ps] != P.owner[s]) throw std::runtime_error("partition_tree: a parent and its child are owned by different ranks");
+        if (P.owner[s] < 0 && ps >= 0 && P.owner[ps] >= 0) throw std::runtime_error("partition_tree: a shared supernode below an owned one");
+    }
+}
+
 }  // namespace sparse
 }  // namespace pq

@@ -72,6 +72,21 @@ struct Symbolic {
     const char* ordering = "amd";
 };
 
+// Stage partition of the assembly tree over `world` processes: disjoint subtrees are owned by one rank each,
+// the supernodes above them ("shared top") are processed by every rank on exchanged data.
+struct Partition {
+    int world = 1;
+    IVec owner;                       // per supernode: owning rank, -1 = shared top
+    IVec boundary;                    // owned supernodes whose parent is shared, ascending: their update matrix / vector crosses ranks
+    std::vector<long long> bmat_off;  // boundary.size()+1 offsets (doubles) of the u x u update blocks in the factor exchange buffer
+    IVec bvec_off;                    // boundary.size()+1 offsets of the u-vectors in the forward-substitution exchange buffer
+    IVec span_lo, span_hi;            // per rank: permuted-column range holding every column the rank owns (other columns inside are shared)
+    int max_span = 0;
+    DVec work;                        // per rank: factorisation flops of the owned subtrees
+    double shared_work = 0.0, total_work = 0.0;
+};
+void partition_tree(const Symbolic& S, int world, Partition& P);
+
 void amd_order(int n, const int* Ap, const int* Ai, int* perm);
 // nested dissection by BFS level structures, AMD inside parts of at most `leaf` nodes; perm[new] = old
 void nd_order(int n, const int* Ap, const int* Ai, int* perm, int leaf);

@@ -75,6 +75,93 @@ def gather_stats(local_rows, device=None):
     return rows
 
 
+class StagePartition:
+    """Stage-partitioned execution of ONE KKT system / solver over the ranks of a process group (BASELINE configs[4]).
+
+    Every rank builds the same object on the same data and wraps it here.  The C library splits the assembly-tree work of
+    factor / solve (pq_kkt_partition, include/piqp_amd.h) and calls back whenever data has to cross ranks; the collectives
+    themselves are torch.distributed calls on device tensors -- RCCL over xGMI with the "nccl" backend, host-staged with
+    "gloo" (the CPU-rendezvous tests, where several ranks share one GPU)."""
+
+    def __init__(self, obj, rank=None, world=None, group=None):
+        import ctypes as C
+
+        import torch
+        import torch.distributed as dist
+
+        from . import _lib
+        self.torch, self.dist, self.group = torch, dist, group
+        L = _lib.load()
+        on = dist.is_available() and dist.is_initialized()
+        self.rank = rank if rank is not None else (dist.get_rank(group) if on else 0)
+        self.world = world if world is not None else (dist.get_world_size(group) if on else 1)
+        self.backend = dist.get_backend(group) if on else None
+        is_solver = hasattr(obj, "solve") and hasattr(obj, "setup")
+        h = obj.h if is_solver else (obj.backend().h if hasattr(obj, "backend") else obj.h)
+        part = L.pq_solver_partition if is_solver else L.pq_kkt_partition
+        setx = L.pq_solver_set_exchange if is_solver else L.pq_kkt_set_exchange
+        sizes = (C.c_longlong * 3)()
+        _lib.check(part(h, self.rank, self.world, sizes), "partition")
+        self.sizes = [int(v) for v in sizes]
+        dev = torch.device("cuda", torch.cuda.current_device())
+        self.buf_factor = torch.zeros(self.sizes[0], dtype=torch.float64, device=dev)
+        self.buf_forward = torch.zeros(self.sizes[1], dtype=torch.float64, device=dev)
+        self.buf_gather = torch.zeros(self.world * self.sizes[2], dtype=torch.float64, device=dev)
+        self.calls = [0, 0, 0]
+        self.error = None
+        self._cb = _lib.EXCHANGE_FN(self._exchange)  # must outlive the handle's use of it
+        self._obj = obj
+        _lib.check(setx(h, self._cb, None, self.buf_factor.data_ptr(), self.buf_forward.data_ptr(), self.buf_gather.data_ptr()), "set_exchange")
+        torch.cuda.synchronize(dev)
+        self.dev = dev
+
+    def _exchange(self, user, which):
+        # called from inside pq_kkt_update_scalings_and_factor / pq_kkt_solve with the handle's stream drained
+        try:
+            torch, dist = self.torch, self.dist
+            self.calls[which] += 1
+            if self.world == 1:
+                return 0
+            staged = self.backend != "nccl"
+            if which in (0, 1):
+                t = self.buf_factor if which == 0 else self.buf_forward
+                if staged:
+                    c = t.cpu()
+                    dist.all_reduce(c, group=self.group)
+                    t.copy_(c)
+                else:
+                    dist.all_reduce(t, group=self.group)
+            else:
+                sz = self.sizes[2]
+                mine = self.buf_gather[self.rank * sz:(self.rank + 1) * sz]
+                if staged:
+                    c = mine.cpu()
+                    outs = [torch.empty_like(c) for _ in range(self.world)]
+                    dist.all_gather(outs, c, group=self.group)
+                    self.buf_gather.copy_(torch.cat(outs))
+                else:
+                    dist.all_gather_into_tensor(self.buf_gather, mine.clone(), group=self.group)
+            torch.cuda.current_stream(self.dev).synchronize()
+            return 0
+        except Exception as e:  # never let an exception cross the C frame
+            self.error = e
+            return 1
+
+    def info(self):
+        import ctypes as C
+
+        from . import _lib
+        L = _lib.load()
+        obj = self._obj
+        if hasattr(obj, "solve") and hasattr(obj, "setup"):
+            return None
+        h = obj.backend().h if hasattr(obj, "backend") else obj.h
+        out = (C.c_int * 8)()
+        _lib.check(L.pq_kkt_partition_info(h, out), "partition_info")
+        return dict(owned_supernodes=out[0], shared_supernodes=out[1], boundary_roots=out[2], span=(out[3], out[4]), work_permille=out[5],
+                    shared_work_permille=out[6], world=out[7], exchange_doubles=self.sizes)
+
+
 def finalize():
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():

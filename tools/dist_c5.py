@@ -1,0 +1,144 @@
+#!/usr/bin/env python3
+"""BASELINE configs[4]: ONE block-tridiagonal multistage QP, stage-partitioned over the ranks of a process group.
+
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P tools/dist_c5.py [--stages 25000]
+
+One rank per GPU over RCCL ("nccl"); when the node has fewer GPUs than ranks (the 1-GPU test boxes) the ranks share cuda:0 and
+the collectives are host-staged through "gloo" -- same library code path, same partition, only the transport differs.
+Checks on every rank that the partitioned factor + solve reproduces the single-GPU result of the same backend bit for bit,
+times 1 update_scalings_and_factor + 2 KKTSystem::solve per step, optionally runs the full interior-point solve, and rank 0
+prints one JSON line."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--stages", type=int, default=25000)
+    ap.add_argument("--nx", type=int, default=12)
+    ap.add_argument("--nu", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--backend", default="multistage", choices=["multistage", "ldlt_cond", "ldlt"])
+    ap.add_argument("--problem", default="chain", choices=["chain", "c3"], help="c3: BASELINE configs[2], a general sparse QP (wide fronts at the top of the tree)")
+    ap.add_argument("--full-solve", action="store_true")
+    ap.add_argument("--no-reference", action="store_true", help="skip the unpartitioned run on every rank (bench mode)")
+    args = ap.parse_args()
+
+    os.environ["PIQP_AMD_MULTISTAGE"] = "tree"  # the engine choice must not depend on a per-rank timing probe
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    ngpu = torch.cuda.device_count()
+    shared_gpu = world > ngpu
+    dev_index = local_rank % max(ngpu, 1)
+    torch.cuda.set_device(dev_index)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if shared_gpu:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
+    import piqp_amd as hip
+    from piqp_amd import dist as pd
+    from qp_gen import c3_problem, mpc_chain, random_vars
+
+    a = mpc_chain(args.nx, args.nu, args.stages, 5) if args.problem == "chain" else c3_problem()
+    d = hip.SparseData(*a)
+    n, p, m = d.n, d.p, d.m
+    ks = {"multistage": hip.SPARSE_MULTISTAGE, "ldlt_cond": 4, "ldlt": hip.SPARSE_LDLT}[args.backend]
+    rng = np.random.default_rng(0)
+    dev = torch.device("cuda", dev_index)
+    to_dev = lambda v: {k: torch.from_numpy(np.ascontiguousarray(x)).to(dev) for k, x in v.items()}  # noqa: E731
+    state = to_dev(random_vars(n, p, m, rng, positive=True))
+    rhs = [to_dev(random_vars(n, p, m, rng)) for _ in range(2)]
+    out = {"workload": (f"multistage chain n_x={args.nx} n_u={args.nu} stages={args.stages}" if args.problem == "chain" else "C3 sparse QP") + f": n={n} p={p} m={m}", "backend": args.backend, "world": world,
+           "transport": "gloo (host-staged, ranks share one GPU)" if shared_gpu else ("rccl" if world > 1 else "none")}
+
+    def run_steps(k, steps):
+        for i in range(steps):
+            assert k.update_scalings_and_factor(False, 1e-6, 1e-4, state)
+            k.solve(rhs[0]); k.solve(rhs[1])
+        k.synchronize()
+
+    ref = None
+    if not args.no_reference:
+        k0 = hip.KKTSystem(d, hip.default_settings(kkt_solver=ks), device=dev_index)
+        assert k0.update_scalings_and_factor(False, 1e-6, 1e-4, state)
+        _, ref = k0.solve(rhs[0])
+        ref = {k: v.clone() for k, v in ref.items()}
+        run_steps(k0, args.warmup)
+        t0 = time.perf_counter(); run_steps(k0, args.steps); t_single = (time.perf_counter() - t0) / args.steps
+        out["single_gpu_ms_per_step"] = t_single * 1e3
+        del k0
+
+    k1 = hip.KKTSystem(d, hip.default_settings(kkt_solver=ks), device=dev_index)
+    sp = pd.StagePartition(k1)
+    info = sp.info()
+    assert k1.update_scalings_and_factor(False, 1e-6, 1e-4, state)
+    _, got = k1.solve(rhs[0])
+    if sp.error is not None:
+        raise sp.error
+    if ref is not None:
+        same = all(torch.equal(got[k], ref[k]) for k in ("x", "y", "z_l", "z_u", "z_bl", "z_bu", "s_l", "s_u", "s_bl", "s_bu"))
+        err = max(float((got[k] - ref[k]).abs().max()) if got[k].numel() else 0.0 for k in ref)
+        out["bitwise_equal_to_single_gpu"] = bool(same); out["max_abs_diff"] = err
+    res, nrm = k1.condensed_residual()
+    out["rel_kkt_residual"] = res / nrm
+    run_steps(k1, args.warmup)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter(); run_steps(k1, args.steps); el = time.perf_counter() - t0
+    el = pd.max_over_ranks(el)
+    out["ms_per_step"] = el / args.steps * 1e3
+    out["steps_per_s"] = args.steps / el
+    out["exchange_calls"] = sp.calls
+    rows = pd.gather_stats([[float(info["owned_supernodes"]), float(info["shared_supernodes"]), float(info["boundary_roots"]), float(info["span"][0]), float(info["span"][1]),
+                             float(info["work_permille"]), float(info["shared_work_permille"])]])
+    out["partition"] = [dict(rank=r, owned_supernodes=int(x[0]), span=[int(x[3]), int(x[4])], work_permille=int(x[5])) for r, x in enumerate(rows)]
+    out["shared_supernodes"] = int(rows[0][1]); out["boundary_roots"] = int(rows[0][2]); out["shared_work_permille"] = int(rows[0][6])
+    out["exchange_doubles"] = info["exchange_doubles"]
+    if ref is not None:
+        flags = pd.gather_stats([[1.0 if out["bitwise_equal_to_single_gpu"] else 0.0, out["rel_kkt_residual"]]])
+        out["bitwise_equal_all_ranks"] = all(f[0] == 1.0 for f in flags)
+        out["rel_kkt_residual"] = max(f[1] for f in flags)
+
+    if args.full_solve:
+        s0 = hip.SparseSolver(device=dev_index)
+        s0.settings.kkt_solver = ks
+        assert s0.setup(*a)
+        sp2 = pd.StagePartition(s0)
+        t0 = time.perf_counter(); st = s0.solve(); tsol = time.perf_counter() - t0
+        if sp2.error is not None:
+            raise sp2.error
+        x = s0.result()["x"]
+        out["full_solve"] = {"status": int(st), "iter": int(s0.info.iter), "solve_ms": pd.max_over_ranks(tsol) * 1e3, "kkt_factor_ms": s0.info.kkt_factor_time * 1e3,
+                             "kkt_solve_ms": s0.info.kkt_solve_time * 1e3, "primal_obj": float(s0.info.primal_obj)}
+        xs = pd.gather_stats([[float(np.sum(x)), float(np.abs(x).max()), float(s0.info.iter)]])
+        out["full_solve"]["identical_on_all_ranks"] = all(r == xs[0] for r in xs)
+        if not args.no_reference:
+            s1 = hip.SparseSolver(device=dev_index); s1.settings.kkt_solver = ks
+            assert s1.setup(*a)
+            t0 = time.perf_counter(); st1 = s1.solve(); t1 = time.perf_counter() - t0
+            out["full_solve"]["single_gpu"] = {"status": int(st1), "iter": int(s1.info.iter), "solve_ms": t1 * 1e3}
+            out["full_solve"]["x_equal_to_single_gpu"] = bool(np.array_equal(x, s1.result()["x"]))
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
