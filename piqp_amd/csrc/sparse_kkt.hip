@@ -3,7 +3,7 @@
 //
 //   reference                                        here
 //   PKPt values + diagonal refresh (kkt_full:172-210) k_set_diag on the device copy of the PKPt values
-//   LDLt::factorize_numeric (ldlt.hpp:101-169,         supernodal multifrontal LDLt: k_scatter_fronts (assembly),
+//   LDLt::factorize_numeric (ldlt.hpp:101-169,         supernodal multifrontal LDLt: fronts assembled from the PKPt values
 //     up-looking, serial over rows)                    per tree level k_front_factor (extend-add + partial dense LDLt,
 //                                                      one workgroup per front, LDS-resident when it fits); fronts
 //                                                      wider than BIG_FRONT go through the dense MFMA panel kernels
@@ -51,6 +51,11 @@ struct FrontMeta {  // device-side views of the symbolic analysis
     const int* front_rows;
     const int* child;
     const int* rel;
+    // assembly: the PKPt entries owned by supernode s are fe_q[fe_ptr[s] .. fe_ptr[s+1]), each at offset fe_off inside the front
+    const int* fe_ptr;
+    const int* fe_q;
+    const int* fe_off;
+    const double* vals;
 };
 
 __global__ void k_set_diag(int n, int p, int m, const int* __restrict__ diag_pos, const double* __restrict__ Pdiag, const double* __restrict__ x_reg, double delta,
@@ -158,14 +163,14 @@ __device__ void front_factor(const FrontMeta& M, double* __restrict__ fronts, in
     const int first = me.first, w = me.w, f = me.f;
     if (f >= big_front && w >= big_pivots) return;  // handled by the dense path
     double* F = fronts + me.front_off;
-    extend_add(M, fronts, s, F, f);
     const bool in_lds = (long long)f * f <= LDS_FRONT_DOUBLES;
-    double* W = F;
-    if (in_lds) {
-        for (int idx = threadIdx.x; idx < f * f; idx += blockDim.x) lds[idx] = F[idx];
-        __syncthreads();
-        W = lds;
-    }
+    double* W = in_lds ? lds : F;
+    // assembly: zero, own K entries, then the children's update matrices (fixed order)
+    for (int idx = threadIdx.x; idx < f * f; idx += blockDim.x) W[idx] = 0.0;
+    __syncthreads();
+    for (int e = M.fe_ptr[s] + threadIdx.x; e < M.fe_ptr[s + 1]; e += blockDim.x) W[M.fe_off[e]] = M.vals[M.fe_q[e]];
+    __syncthreads();
+    extend_add(M, fronts, s, W, f);
     // ---- panel: right-looking LDLt of the first w columns, updates confined to the panel (rows k+1..f-1, columns k+1..w-1)
     const int tid = threadIdx.x, nt = blockDim.x;
     for (int k = 0; k < w; ++k) {
@@ -313,6 +318,12 @@ __global__ __launch_bounds__(SUB_THREADS) void k_subtree_factor(FrontMeta M, dou
 
 // extend-add of ONE child into a front that is then factored by the dense kernels (one launch per child: stream
 // order = fixed merge order, entries of one child never collide)
+// own K entries of ONE front that the dense multi-workgroup path factors (the front was zeroed by a memset on the stream)
+__global__ void k_front_assemble(FrontMeta M, double* __restrict__ fronts, int s)
+{
+    double* F = fronts + M.sn[s].front_off;
+    for (int e = M.fe_ptr[s] + blockIdx.x * blockDim.x + threadIdx.x; e < M.fe_ptr[s + 1]; e += gridDim.x * blockDim.x) F[M.fe_off[e]] = M.vals[M.fe_q[e]];
+}
 __global__ __launch_bounds__(256) void k_front_extend_add_child(FrontMeta M, double* __restrict__ fronts, int s, int c)
 {
     const SnRec me = M.sn[s], ch = M.sn[c];
@@ -401,6 +412,149 @@ __global__ __launch_bounds__(SUB_SOLVE_THREADS) void k_subtree_bwd(FrontMeta M, 
 {
     const int lo = sub_lo[blockIdx.x], hi = sub_hi[blockIdx.x];
     for (int s = hi; s >= lo; --s) { front_bwd(M, fronts, s, x, fvec); __syncthreads(); }
+}
+
+// ---- single-wave subtree substitution: the front vector lives in registers (rows lane and lane + 64, fronts of a workgroup subtree have at
+// most SUB_FMAX <= 128 rows), pivots are broadcast with v_readlane, the panel columns are read straight from HBM with the loads of four
+// steps in flight, and a parent that directly follows its child in the walk takes the child's update vector from LDS.  Same arithmetic,
+// same order as front_fwd / front_bwd (bitwise the same results): what changes is that a dependent step costs an FMA + a readlane
+// instead of a global-memory round trip + a barrier.
+__device__ __forceinline__ double bcast_row(double v0, double v1, int row)
+{
+    const int r = __builtin_amdgcn_readfirstlane(row);
+    const double v = r < 64 ? v0 : v1;
+    const int src = r & 63;
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+__global__ __launch_bounds__(64) void k_subtree_fwd_wave(FrontMeta M, const double* __restrict__ fronts, const int* __restrict__ sub_lo, const int* __restrict__ sub_hi,
+                                                         double* __restrict__ x, double* __restrict__ fvec)
+{
+    __shared__ double sv[2][128];
+    const int lane = threadIdx.x, r0 = lane, r1 = lane + 64;
+    const int lo = sub_lo[blockIdx.x], hi = sub_hi[blockIdx.x];
+    int cur = 0;
+    bool prev_valid = false;  // sv[cur ^ 1][0 .. u) = update vector of supernode s - 1
+    for (int s = lo; s <= hi; ++s) {
+        const SnRec me = M.sn[s];
+        const int first = me.first, w = me.w, f = me.f;
+        const double* F = fronts + me.front_off;
+        double* a = sv[cur];
+        if (r0 < f) a[r0] = r0 < w ? x[first + r0] : 0.0;
+        if (r1 < f) a[r1] = r1 < w ? x[first + r1] : 0.0;
+        __syncthreads();
+        for (int ci = me.child_lo; ci < me.child_hi; ++ci) {
+            const int c = M.child[ci];
+            const SnRec ch = M.sn[c];
+            const int uc = ch.f - ch.w;
+            const double* vc = (prev_valid && c == s - 1) ? sv[cur ^ 1] : fvec + ch.rows_ptr + ch.w;
+            const int* rel = M.rel + ch.rel_ptr;
+            for (int i = lane; i < uc; i += 64) a[rel[i]] += vc[i];
+            __syncthreads();
+        }
+        double v0 = r0 < f ? a[r0] : 0.0, v1 = r1 < f ? a[r1] : 0.0;
+        int k = 0;
+        for (; k + 4 <= w; k += 4) {
+            double c0[4], c1[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const double* col = F + (long long)(k + u) * f;
+                c0[u] = (r0 > k + u && r0 < f) ? col[r0] : 0.0;
+                c1[u] = (r1 < f) ? col[r1] : 0.0;  // r1 >= 64 > k + u whenever the row exists and k + u < 64; checked below otherwise
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const double yk = bcast_row(v0, v1, k + u);
+                v0 -= c0[u] * yk;
+                if (r1 > k + u) v1 -= c1[u] * yk;
+            }
+        }
+        for (; k < w; ++k) {
+            const double* col = F + (long long)k * f;
+            const double c0 = (r0 > k && r0 < f) ? col[r0] : 0.0, c1 = (r1 > k && r1 < f) ? col[r1] : 0.0;
+            const double yk = bcast_row(v0, v1, k);
+            v0 -= c0 * yk;
+            v1 -= c1 * yk;
+        }
+        if (r0 < w) x[first + r0] = v0;
+        if (r1 < w) x[first + r1] = v1;
+        __syncthreads();  // every lane has taken its entries of `a`
+        const bool keep = me.parent == s + 1 && s + 1 <= hi;
+        if (r0 >= w && r0 < f) { a[r0 - w] = v0; if (!keep) fvec[me.rows_ptr + r0] = v0; }
+        if (r1 >= w && r1 < f) { a[r1 - w] = v1; if (!keep) fvec[me.rows_ptr + r1] = v1; }
+        __syncthreads();
+        cur ^= 1;
+        prev_valid = keep;
+    }
+}
+__global__ __launch_bounds__(64) void k_subtree_bwd_wave(FrontMeta M, const double* __restrict__ fronts, const int* __restrict__ sub_lo, const int* __restrict__ sub_hi,
+                                                         double* __restrict__ x)
+{
+    __shared__ double sv[2][128];
+    const int lane = threadIdx.x, r0 = lane, r1 = lane + 64;
+    const int lo = sub_lo[blockIdx.x], hi = sub_hi[blockIdx.x];
+    int cur = 0;
+    bool prev_valid = false;  // sv[cur ^ 1][0 .. f_parent) = final vector of supernode s + 1
+    for (int s = hi; s >= lo; --s) {
+        const SnRec me = M.sn[s];
+        const int first = me.first, w = me.w, f = me.f;
+        const double* F = fronts + me.front_off;
+        const int* rows = M.front_rows + me.rows_ptr;
+        const bool from_lds = prev_valid && me.parent == s + 1;
+        const double* pv = sv[cur ^ 1];
+        const int* rel = M.rel + me.rel_ptr;
+        double v0 = 0.0, v1 = 0.0;
+        if (r0 < f) v0 = r0 < w ? x[first + r0] : (from_lds ? pv[rel[r0 - w]] : x[rows[r0]]);
+        if (r1 < f) v1 = r1 < w ? x[first + r1] : (from_lds ? pv[rel[r1 - w]] : x[rows[r1]]);
+        // y1[j] -= sum_{i >= w} L[i,j] x2[i], ascending i (lane j = pivot column j)
+        {
+            double s0 = 0.0, s1 = 0.0;
+            const double* cj0 = F + (long long)r0 * f;
+            const double* cj1 = F + (long long)r1 * f;
+            int i = w;
+            for (; i + 4 <= f; i += 4) {
+                double a0[4], a1[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { a0[u] = r0 < w ? cj0[i + u] : 0.0; a1[u] = r1 < w ? cj1[i + u] : 0.0; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const double xi = bcast_row(v0, v1, i + u); s0 += a0[u] * xi; s1 += a1[u] * xi; }
+            }
+            for (; i < f; ++i) {
+                const double a0 = r0 < w ? cj0[i] : 0.0, a1 = r1 < w ? cj1[i] : 0.0;
+                const double xi = bcast_row(v0, v1, i);
+                s0 += a0 * xi; s1 += a1 * xi;
+            }
+            if (r0 < w) v0 -= s0;
+            if (r1 < w) v1 -= s1;
+        }
+        // x1 = L11^-T y1: rows w-1 .. 1, lane j < i
+        {
+            const double* cj0 = F + (long long)r0 * f;
+            const double* cj1 = F + (long long)r1 * f;
+            int i = w - 1;
+            for (; i - 3 >= 1; i -= 4) {
+                double a0[4], a1[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { a0[u] = r0 < i - u ? cj0[i - u] : 0.0; a1[u] = r1 < i - u ? cj1[i - u] : 0.0; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const double xi = bcast_row(v0, v1, i - u); v0 -= a0[u] * xi; v1 -= a1[u] * xi; }
+            }
+            for (; i >= 1; --i) {
+                const double a0 = r0 < i ? cj0[i] : 0.0, a1 = r1 < i ? cj1[i] : 0.0;
+                const double xi = bcast_row(v0, v1, i);
+                v0 -= a0 * xi; v1 -= a1 * xi;
+            }
+        }
+        if (r0 < w) x[first + r0] = v0;
+        if (r1 < w) x[first + r1] = v1;
+        double* a = sv[cur];
+        if (r0 < f) a[r0] = v0;
+        if (r1 < f) a[r1] = v1;
+        __syncthreads();
+        cur ^= 1;
+        prev_valid = true;
+    }
 }
 
 // ---- the top of the assembly tree in ONE launch: workgroup b takes the top supernodes b, b + G, ... of the level-sorted (=
@@ -615,9 +769,7 @@ public:
                 if (nzGG_) hipLaunchKernelGGL(k_gram_values<true>, g1(nzGG_), dim3(256), 0, st_, nzGG_, gg_ptr_.p, gg_q1_.p, gg_q2_.p, gg_k_.p, ops_.GT_x(), z_reg, mapGG_.p, vals_.p);
             } else launch_remap_values(ops_.nzG(), mapG_.p, ops_.GT_x(), vals_.p, st_);
         }
-        PQ_HIP(hipMemsetAsync(fronts_.p, 0, sizeof(double) * (size_t)S_.front_doubles, st_));
-        hipLaunchKernelGGL(k_scatter_fronts, g1(nnzK_), dim3(256), 0, st_, nnzK_, a_dst_.p, vals_.p, fronts_.p);
-        prof_.end(0, t0, st_);
+        prof_.end(0, t0, st_);  // the fronts are assembled from `vals` inside the factor kernels (no HBM zero-fill / scatter pass)
         const int t1 = prof_.begin(1, st_);
         PQ_HIP(hipMemsetAsync(info_.p, 0xFF, sizeof(int), st_));
         FrontMeta M = meta();
@@ -667,7 +819,7 @@ public:
             hipLaunchKernelGGL(k_perm_gather, g1(N_), dim3(256), 0, st_, N_, P_.p, rhs_top_.p, n_, tail, ntail, (const double*)nullptr, xp_.p);
         }
         if (part_on_) {
-            if (part_nsub_ > 0) hipLaunchKernelGGL(k_subtree_fwd, dim3(part_nsub_), dim3(SUB_SOLVE_THREADS), 0, st_, M, fronts_.p, part_sub_lo_.p, part_sub_hi_.p, xp_.p, fvec_.p);
+            subtree_fwd(M, part_nsub_, part_sub_lo_.p, part_sub_hi_.p);
             fwd_levels(M, own_ptr_, own_sn_d_.p);
             const int nb = (int)PT_.boundary.size();
             if (nb > 0) {
@@ -679,7 +831,7 @@ public:
             hipLaunchKernelGGL(k_scale, g1(N_), dim3(256), 0, st_, N_, rdiag_.p, xp_.p);
             bwd_levels(M, sh_ptr_, sh_sn_d_.p);
             bwd_levels(M, own_ptr_, own_sn_d_.p);
-            if (part_nsub_ > 0) hipLaunchKernelGGL(k_subtree_bwd, dim3(part_nsub_), dim3(SUB_SOLVE_THREADS), 0, st_, M, fronts_.p, part_sub_lo_.p, part_sub_hi_.p, xp_.p, fvec_.p);
+            subtree_bwd(M, part_nsub_, part_sub_lo_.p, part_sub_hi_.p);
             if (world_ > 1) {
                 const int lo = PT_.span_lo[rank_], hi = PT_.span_hi[rank_];
                 if (hi > lo) hipLaunchKernelGGL(k_pack_span, g1(hi - lo), dim3(256), 0, st_, lo, hi, xp_.p, xbuf_gather_ + (size_t)rank_ * PT_.max_span);
@@ -688,7 +840,7 @@ public:
                                    span_hi_d_.p, xbuf_gather_, xp_.p);
             }
         } else {
-        if (S_.nsub > 0) hipLaunchKernelGGL(k_subtree_fwd, dim3(S_.nsub), dim3(SUB_SOLVE_THREADS), 0, st_, M, fronts_.p, sub_lo_.p, sub_hi_.p, xp_.p, fvec_.p);
+        subtree_fwd(M, S_.nsub, sub_lo_.p, sub_hi_.p);
         const bool top_solve_persistent = top_persistent_ && std::getenv("PIQP_AMD_TOP_SOLVE_PERSISTENT");
         if (top_solve_persistent) {
             PQ_HIP(hipMemsetAsync(top_flags_.p, 0, sizeof(int) * (2 * (size_t)ntop_ + 1), st_));
@@ -700,7 +852,7 @@ public:
             hipLaunchKernelGGL(k_top_bwd, dim3(top_grid_), dim3(256), 0, st_, M, fronts_.p, level_sn_.p, ntop_, top_pos_.p, top_flags_.p + ntop_, top_flags_.p + 2 * ntop_, xp_.p, fvec_.p);
             hipLaunchKernelGGL(k_top_check, dim3(1), dim3(1), 0, st_, top_flags_.p + 2 * ntop_, (int*)nullptr, xp_.p);
         } else bwd_levels(M, S_.top_level_ptr, level_sn_.p);
-        if (S_.nsub > 0) hipLaunchKernelGGL(k_subtree_bwd, dim3(S_.nsub), dim3(SUB_SOLVE_THREADS), 0, st_, M, fronts_.p, sub_lo_.p, sub_hi_.p, xp_.p, fvec_.p);
+        subtree_bwd(M, S_.nsub, sub_lo_.p, sub_hi_.p);
         }
         if (mode_ == 0) {
             hipLaunchKernelGGL(k_perm_scatter, g1(N_), dim3(256), 0, st_, N_, P_.p, xp_.p, lhs_x, n_, lhs_y, p_, lhs_z);
@@ -872,7 +1024,7 @@ private:
         top_persistent_ = ntop_ > 0 && ntop_ <= 1024 && !any_big && !std::getenv("PIQP_AMD_TOP_LEVELS");
     }
 
-    FrontMeta meta() const { return FrontMeta{snrec_.p, front_rows_.p, child_.p, rel_.p}; }
+    FrontMeta meta() const { return FrontMeta{snrec_.p, front_rows_.p, child_.p, rel_.p, fe_ptr_.p, fe_q_.p, fe_off_.p, vals_.p}; }
 
     // data crosses ranks: the stream is drained, the caller's collective runs (pq_exchange_fn), then the stream continues
     void exchange(int which)
@@ -881,6 +1033,18 @@ private:
         if (!xfn_) throw std::runtime_error("partitioned backend used before pq_kkt_set_exchange");
         PQ_HIP(hipStreamSynchronize(st_));
         if (xfn_(xuser_, which) != 0) throw std::runtime_error("exchange callback failed");
+    }
+    void subtree_fwd(const FrontMeta& M, int nsub, const int* lo, const int* hi)
+    {
+        if (nsub <= 0) return;
+        if (S_.sub_max_front <= 128 && !std::getenv("PIQP_AMD_SUBTREE_SOLVE_V1")) hipLaunchKernelGGL(k_subtree_fwd_wave, dim3(nsub), dim3(64), 0, st_, M, fronts_.p, lo, hi, xp_.p, fvec_.p);
+        else hipLaunchKernelGGL(k_subtree_fwd, dim3(nsub), dim3(SUB_SOLVE_THREADS), 0, st_, M, fronts_.p, lo, hi, xp_.p, fvec_.p);
+    }
+    void subtree_bwd(const FrontMeta& M, int nsub, const int* lo, const int* hi)
+    {
+        if (nsub <= 0) return;
+        if (S_.sub_max_front <= 128 && !std::getenv("PIQP_AMD_SUBTREE_SOLVE_V1")) hipLaunchKernelGGL(k_subtree_bwd_wave, dim3(nsub), dim3(64), 0, st_, M, fronts_.p, lo, hi, xp_.p);
+        else hipLaunchKernelGGL(k_subtree_bwd, dim3(nsub), dim3(SUB_SOLVE_THREADS), 0, st_, M, fronts_.p, lo, hi, xp_.p, fvec_.p);
     }
     void factor_subtrees(const FrontMeta& M, int nsub, const int* lo, const int* hi)
     {
@@ -993,6 +1157,11 @@ private:
     void factor_big_front(const FrontMeta& M, int s, int w, int f)
     {
         double* F = fronts_.p + S_.front_off[s];
+        PQ_HIP(hipMemsetAsync(F, 0, sizeof(double) * (size_t)f * f, st_));
+        {
+            const int ne = S_.fe_ptr[s + 1] - S_.fe_ptr[s];
+            if (ne > 0) hipLaunchKernelGGL(k_front_assemble, dim3(std::min(1024, (ne + 255) / 256)), dim3(256), 0, st_, M, fronts_.p, s);
+        }
         for (int ci = S_.child_ptr[s]; ci < S_.child_ptr[s + 1]; ++ci) {
             const int c = S_.child[ci];
             const int uc = (S_.front_rows_ptr[c + 1] - S_.front_rows_ptr[c]) - (S_.sn_first[c + 1] - S_.sn_first[c]);
