@@ -40,7 +40,18 @@ def main():
     ap.add_argument("--batch-total", type=int, default=8192, help="BASELINE configs[3]: number of MPC QPs in the batched leg (0 = skip)")
     ap.add_argument("--no-sparse-legs", action="store_true", help="skip the sparse C3 / C5-size KKT legs (BASELINE configs[2], configs[4])")
     ap.add_argument("--cpu-steps", type=int, default=0, help="0 = auto (about 10-30 s of CPU work)")
+    ap.add_argument("--no-dist-c5", action="store_true", help="N > 1 only: skip the stage-partitioned single-QP leg (BASELINE configs[4])")
     args = ap.parse_args()
+
+    # BASELINE configs[4] at N > 1: ONE n = 500k multistage QP, stage-partitioned over the ranks (tools/dist_c5.py).  It runs in child
+    # processes with their own process group so that nothing in there can cost this run its JSON line; the children are started here,
+    # before this process touches the GPU, and wait on stdin until the other legs are done.
+    c5_child = None
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and not args.no_dist_c5 and not args.no_sparse_legs:
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("_pq_dist_spawn", os.path.join(ROOT, "piqp_amd", "dist.py"))
+        spawn_mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(spawn_mod)
+        c5_child = spawn_mod.spawn_waiting([os.path.join(ROOT, "tools", "dist_c5.py"), "--wait-stdin", "--steps", "10", "--full-solve"])
 
     import numpy as np
     import torch
@@ -49,8 +60,9 @@ def main():
     from piqp_amd import dist as pd
 
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
-    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-    rank, world, local_rank = pd.init()  # RCCL ("nccl") process group when WORLD_SIZE > 1
+    rank, world, local_rank = pd.init()  # RCCL ("nccl") process group when WORLD_SIZE > 1; local_rank = device index of this rank
+    if world > 1:
+        args.no_cpu_baseline = True  # the CPU baseline is a rank-0, N = 1 figure (torch.distributed.run also pins OMP_NUM_THREADS=1)
     dev = torch.device("cuda", local_rank)
     from qp_gen import dense_strongly_convex_qp, random_vars
 
@@ -155,6 +167,20 @@ def main():
         sl = sparse_legs(args, rank, world, local_rank, dev, pd)
         if rank == 0:
             out["sparse_kkt"] = sl
+    if c5_child is not None:
+        pd.barrier()
+        rc, c5_out, c5_err = pd.release_and_collect(c5_child, timeout=300)
+        if rank == 0:
+            leg = {"config": "BASELINE configs[4]: one block-tridiagonal multistage QP, n = 500k, stage-partitioned over the ranks", "scaling": "strong"}
+            line = [ln for ln in (c5_out or "").splitlines() if ln.startswith("{")]
+            if rc == 0 and line:
+                leg.update(json.loads(line[-1]))
+                if leg.get("single_gpu_ms_per_step"):
+                    leg["speedup_vs_single_gpu"] = leg["single_gpu_ms_per_step"] / leg["ms_per_step"]  # same backend, same data, unpartitioned, timed by every rank first
+            else:
+                leg["error"] = f"child returncode {rc} (None = timed out after 300 s)"; leg["stderr_tail"] = c5_err
+            out["stage_partitioned_c5"] = leg
+        pd.barrier()
     if rank == 0:
         print(json.dumps(out), flush=True)
     pd.finalize()

@@ -769,7 +769,7 @@ static void analyse_with_order(Symbolic& S, const IVec& perm0)
 
 // ---- partition_tree --------------------------------------------------------------------------------------------------------
 // Subtree-to-rank mapping: start from the roots of the assembly forest and keep replacing the heaviest candidate subtree by
-// its children (its root joins the shared top) until no expandable candidate carries more than 1 / (4 world) of the work.
+// its children (its root joins the shared top) until no expandable candidate carries more than 1 / (8 world) of the work.
 // Workgroup subtrees (sub_lo..sub_hi) are atomic.  Candidates are then dealt to the ranks in postorder, contiguous and
 // balanced by prefix sums of their work, so that every rank owns one contiguous range of the (postordered) elimination order
 // interrupted only by shared supernodes: for a multistage chain that is a contiguous range of stages.
@@ -800,7 +800,7 @@ void partition_tree(const Symbolic& S, int world, Partition& P)
     std::vector<int> heap, fixed;
     for (int s = 0; s < ns; ++s) if (S.sn_parent[s] < 0) heap.push_back(s);
     std::make_heap(heap.begin(), heap.end(), cmp);
-    const double limit = P.total_work / (4.0 * world);
+    const double limit = P.total_work / (8.0 * world);
     std::vector<char> shared(ns, 0);
     while (!heap.empty() && world > 1) {
         std::pop_heap(heap.begin(), heap.end(), cmp);

@@ -7,22 +7,40 @@ import os
 
 
 def init(backend=None):
-    """returns (rank, world, local_rank); initialises torch.distributed when WORLD_SIZE > 1"""
+    """returns (rank, world, device_index); initialises torch.distributed when WORLD_SIZE > 1.
+
+    One rank per GPU over RCCL ("nccl").  When the node has fewer GPUs than ranks (the 1-GPU test boxes) the ranks share
+    the devices round-robin and the process group is "gloo": the same code path end to end, host-staged collectives."""
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dev_index = local_rank
+    import torch
+    if torch.cuda.is_available():
+        ngpu = torch.cuda.device_count()
+        dev_index = local_rank % max(ngpu, 1)
+        if backend is None and world > 1:
+            backend = "nccl" if ngpu >= int(os.environ.get("LOCAL_WORLD_SIZE", world)) else "gloo"
+        torch.cuda.set_device(dev_index)
     if world > 1:
-        import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if not dist.is_initialized():
             if backend is None:
-                backend = "nccl" if torch.cuda.is_available() else "gloo"
+                backend = "gloo"
             kw = {}
             if backend == "nccl":
-                kw["device_id"] = torch.device("cuda", local_rank)
+                kw["device_id"] = torch.device("cuda", dev_index)
             dist.init_process_group(backend=backend, **kw)
-    return rank, world, local_rank
+    return rank, world, dev_index
+
+
+def _coll_device(device):
+    """tensors of the bookkeeping collectives live on the GPU only when the backend is RCCL"""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_backend() != "nccl":
+        return "cpu"
+    return device if device is not None else "cpu"
 
 
 def shard_range(total, rank, world):
@@ -44,7 +62,7 @@ def max_over_ranks(value, device=None):
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()):
         return float(value)
-    t = torch.tensor([float(value)], dtype=torch.float64, device=device if device is not None else "cpu")
+    t = torch.tensor([float(value)], dtype=torch.float64, device=_coll_device(device))
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -64,7 +82,7 @@ def gather_stats(local_rows, device=None):
     dist.all_gather_object(widths, width)
     width = max(widths)
     mx = max(counts)
-    buf = torch.zeros((mx, max(width, 1)), dtype=torch.float64, device=device if device is not None else "cpu")
+    buf = torch.zeros((mx, max(width, 1)), dtype=torch.float64, device=_coll_device(device))
     if local_rows:
         buf[: len(local_rows), :width] = torch.tensor(local_rows, dtype=torch.float64)
     out = [torch.zeros_like(buf) for _ in range(world)]
@@ -160,6 +178,34 @@ class StagePartition:
         _lib.check(L.pq_kkt_partition_info(h, out), "partition_info")
         return dict(owned_supernodes=out[0], shared_supernodes=out[1], boundary_roots=out[2], span=(out[3], out[4]), work_permille=out[5],
                     shared_work_permille=out[6], world=out[7], exchange_doubles=self.sizes)
+
+
+def spawn_waiting(argv, extra_env=None):
+    """Starts `python argv...` as a child that blocks on its stdin until release_and_collect() -- to be called BEFORE this process
+    touches the GPU (a process that has initialised HIP must not fork + exec).  The child inherits RANK / WORLD_SIZE / LOCAL_RANK /
+    MASTER_ADDR and gets its own MASTER_PORT, so the children of all ranks form a second, independent process group: a hang or a
+    crash in there cannot take the parent's group (and its one JSON line) down."""
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    env["MASTER_PORT"] = str(int(env.get("MASTER_PORT", "29500")) + 37)
+    for k in ("TORCHELASTIC_RUN_ID", "TORCHELASTIC_USE_AGENT_STORE"):  # the children rendezvous on their own TCPStore (rank 0 hosts it), not on the launcher's
+        env.pop(k, None)
+    if extra_env:
+        env.update(extra_env)
+    return subprocess.Popen([sys.executable] + list(argv), stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, text=True)
+
+
+def release_and_collect(proc, timeout):
+    """lets the waiting child run, returns (returncode or None on timeout, stdout, stderr tail); kills exactly that child on timeout"""
+    import subprocess
+    try:
+        out, err = proc.communicate(input="go\n", timeout=timeout)
+        return proc.returncode, out, err[-2000:]
+    except subprocess.TimeoutExpired:
+        proc.kill()
+        out, err = proc.communicate()
+        return None, out, (err or "")[-2000:]
 
 
 def finalize():

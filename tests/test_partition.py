@@ -1,0 +1,88 @@
+"""Stage partition of one KKT system over several processes (include/piqp_amd.h, pq_kkt_partition).
+
+CPU part: the subtree-to-rank plan (host code only, no device).  GPU part: two ranks that share the test box's single GPU over
+gloo reproduce the single-GPU factor / solve / full interior-point solve bit for bit (tools/dist_c5.py)."""
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def _plan(args, mode, world):
+    import piqp_amd as hip
+    from piqp_amd import _lib
+    L = _lib.load()
+    d = hip.SparseData(*args)
+    desc = d.descriptor()
+    N = L.pq_sparse_partition_plan(C.byref(desc), mode, world, None, 0, None)
+    assert N > 0
+    owner = np.full(N, -7, dtype=np.int32)
+    work = np.zeros(world + 1)
+    assert L.pq_sparse_partition_plan(C.byref(desc), mode, world, owner.ctypes.data, N, work.ctypes.data) == N
+    return owner, work
+
+
+@pytest.mark.parametrize("world", [1, 2, 4, 8])
+def test_plan_chain(world):
+    """a multistage chain: every rank gets one contiguous range of the elimination order (= of the stages), balanced, and the
+    replicated top is a negligible share of the work"""
+    from qp_gen import mpc_chain
+    owner, work = _plan(mpc_chain(4, 2, 1500, 3), 3, world)
+    assert owner.min() >= -1 and owner.max() == world - 1
+    if world == 1:
+        assert (owner == 0).all() and work[1] == 0.0
+        return
+    per_rank, shared = work[:world], work[world]
+    assert per_rank.min() > 0
+    assert per_rank.max() <= 1.25 * per_rank.mean()
+    assert shared <= 0.06 * per_rank.sum()
+    # contiguity: dropping the shared columns, the owner sequence is non-decreasing
+    o = owner[owner >= 0]
+    assert (np.diff(o) >= 0).all()
+    assert (owner < 0).sum() < 0.04 * owner.size
+
+
+@pytest.mark.parametrize("mode", [0, 3])
+def test_plan_general_sparse(mode):
+    """a general sparse QP: same invariants except balance / shared share, which depend on the top fronts"""
+    from qp_gen import c3_problem
+    args = c3_problem(n=2000, p=700, m=1100, seed=5, spread=40)
+    for world in (2, 4):
+        owner, work = _plan(args, mode, world)
+        assert owner.min() >= -1 and owner.max() <= world - 1
+        o = owner[owner >= 0]
+        assert (np.diff(o) >= 0).all()
+        assert abs(work.sum() - _plan(args, mode, 1)[1].sum()) <= 1e-9 * work.sum()
+
+
+def _run_ranks(nranks, extra, port):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nranks}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "tools", "dist_c5.py")] + extra
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "TORCHELASTIC_RUN_ID", "TORCHELASTIC_USE_AGENT_STORE"):
+        env.pop(k, None)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and lines, r.stderr[-3000:]
+    return json.loads(lines[-1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("backend,problem,nranks", [("multistage", "chain", 2), ("ldlt", "chain", 3), ("ldlt_cond", "c3", 2)])
+def test_partitioned_equals_single_gpu(backend, problem, nranks):
+    out = _run_ranks(nranks, ["--stages", "800", "--steps", "2", "--warmup", "1", "--backend", backend, "--problem", problem, "--full-solve"], 29650 + nranks)
+    assert out["world"] == nranks
+    assert out["bitwise_equal_all_ranks"] and out["max_abs_diff"] == 0.0
+    assert out["rel_kkt_residual"] <= 1e-10
+    assert out["exchange_calls"][0] >= 1 and out["exchange_calls"][1] == out["exchange_calls"][2] >= 1
+    fs = out["full_solve"]
+    assert fs["status"] == 1 and fs["identical_on_all_ranks"] and fs["x_equal_to_single_gpu"] and fs["iter"] == fs["single_gpu"]["iter"]
+    assert sum(p["owned_supernodes"] for p in out["partition"]) > 0 and out["shared_supernodes"] >= 1

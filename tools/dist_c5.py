@@ -32,24 +32,18 @@ def main():
     ap.add_argument("--problem", default="chain", choices=["chain", "c3"], help="c3: BASELINE configs[2], a general sparse QP (wide fronts at the top of the tree)")
     ap.add_argument("--full-solve", action="store_true")
     ap.add_argument("--no-reference", action="store_true", help="skip the unpartitioned run on every rank (bench mode)")
+    ap.add_argument("--wait-stdin", action="store_true", help="block on stdin before touching the GPU (spawned by bench.py, piqp_amd.dist.spawn_waiting)")
     args = ap.parse_args()
+    if args.wait_stdin:
+        sys.stdin.readline()
 
     os.environ["PIQP_AMD_MULTISTAGE"] = "tree"  # the engine choice must not depend on a per-rank timing probe
     import torch
     import torch.distributed as dist
-    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    ngpu = torch.cuda.device_count()
-    shared_gpu = world > ngpu
-    dev_index = local_rank % max(ngpu, 1)
-    torch.cuda.set_device(dev_index)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if shared_gpu:
-            dist.init_process_group(backend="gloo")
-        else:
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
-    import piqp_amd as hip
     from piqp_amd import dist as pd
+    rank, world, dev_index = pd.init()
+    shared_gpu = world > 1 and dist.get_backend() != "nccl"
+    import piqp_amd as hip
     from qp_gen import c3_problem, mpc_chain, random_vars
 
     a = mpc_chain(args.nx, args.nu, args.stages, 5) if args.problem == "chain" else c3_problem()
