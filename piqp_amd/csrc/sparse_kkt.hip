@@ -180,15 +180,19 @@ __device__ void front_factor(const FrontMeta& M, double* __restrict__ fronts, in
         if (tid == 0) rdiag[first + k] = dinv;
         const int r = f - k - 1, pc = w - k - 1;
         const double* colk = W + (k + 1) + (long long)k * f;
-        // W[i,j] -= (a_i / d) * a_j for k < j < w, i >= j, with the UNSCALED column k
+        // W[i,j] -= (a_i / d) * a_j for k < j < w, i >= j, with the UNSCALED column k (column k is final after this step: its
+        // scaling by 1/d is deferred to one pass after the loop -> one barrier per pivot instead of two)
         for (int idx = tid; idx < r * pc; idx += nt) {
             const int i = idx % r, j = idx / r;
             if (i >= j) W[(k + 1 + i) + (long long)(k + 1 + j) * f] -= (colk[i] * dinv) * colk[j];
         }
         __syncthreads();
-        for (int i = tid; i < r; i += nt) W[(k + 1 + i) + (long long)k * f] *= dinv;
-        __syncthreads();
     }
+    for (int idx = tid; idx < f * w; idx += nt) {
+        const int i = idx % f, k = idx / f;
+        if (i > k) { double d = W[k + (long long)k * f]; if (d == 0.0) d = 1.0; W[i + (long long)k * f] *= 1.0 / d; }
+    }
+    __syncthreads();
     // ---- Schur complement of the trailing block in one pass: T[i,j] -= sum_k L[i,k] d_k L[j,k]  (no barriers, long dot products)
     const int u = f - w;
     if (u > 0) {
@@ -270,9 +274,12 @@ __global__ __launch_bounds__(SUB_THREADS) void k_subtree_factor_lds(FrontMeta M,
                 if (i >= j) W[(k + 1 + i) + (k + 1 + j) * f] -= (colk[i] * dinv) * colk[j];
             }
             __syncthreads();
-            for (int i = tid; i < r; i += nt) W[(k + 1 + i) + k * f] *= dinv;
-            __syncthreads();
         }
+        for (int idx = tid; idx < f * w; idx += nt) {  // deferred scaling of the finished columns (see front_factor)
+            const int i = idx % f, k = idx / f;
+            if (i > k) { double d = W[k + k * f]; if (d == 0.0) d = 1.0; W[i + k * f] *= 1.0 / d; }
+        }
+        __syncthreads();
         // ---- Schur complement
         const int u = f - w;
         if (u > 0) {
@@ -300,6 +307,113 @@ __global__ __launch_bounds__(SUB_THREADS) void k_subtree_factor_lds(FrontMeta M,
         __syncthreads();
         double* t = cur; cur = prev; prev = t;
         prev_valid = keep; prev_f = f; prev_w = w;
+    }
+}
+
+// The same walk with every piece of per-subtree metadata staged in LDS at kernel start: a subtree is a contiguous supernode range, so
+// its records, its assembly lists (fe_*) and its child maps (rel) are contiguous too and arrive in ONE round of coalesced loads (plus
+// one gather of the K values) instead of a chain of three or four dependent global loads per supernode -- which is what the walk
+// above spends most of its time on (about 5 us per supernode against about 1 us of arithmetic).
+struct SubStage {
+    int ent_cap, rel_cap, sn_cap;  // capacities (max over the subtrees of the class)
+};
+struct SubClass {  // subtrees launched together: same dynamic LDS size
+    int nsub = 0, cap = 0, fmax = 0, bytes = 0, threads = 256;
+    bool staged = false, lds_walk = true;
+    SubStage stage{0, 0, 0};
+    DBuf<int> lo, hi;
+};
+struct SubSchedule {
+    std::vector<SubClass> cls;
+};
+__global__ __launch_bounds__(SUB_THREADS) void k_subtree_factor_staged(FrontMeta M, double* __restrict__ fronts, const int* __restrict__ sub_lo, const int* __restrict__ sub_hi,
+                                                                       int cap, SubStage G, double* __restrict__ rdiag, int* __restrict__ info)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int lo = sub_lo[blockIdx.x], hi = sub_hi[blockIdx.x];
+    const int nsn = hi - lo + 1;
+    double* cur = lds;
+    double* prev = lds + cap;
+    double* vals_s = lds + 2 * cap;
+    SnRec* rec_s = reinterpret_cast<SnRec*>(vals_s + G.ent_cap);
+    int* off_s = reinterpret_cast<int*>(rec_s + G.sn_cap);
+    int* rel_s = off_s + G.ent_cap;
+    int* feptr_s = rel_s + G.rel_cap;
+    // ---- stage
+    const int e0 = M.fe_ptr[lo], e1 = M.fe_ptr[hi + 1];
+    const SnRec first_rec = M.sn[lo], last_rec = M.sn[hi];
+    const int r0 = first_rec.rel_ptr, r1 = last_rec.rel_ptr + (last_rec.f - last_rec.w);
+    for (int i = tid; i < nsn; i += nt) rec_s[i] = M.sn[lo + i];
+    for (int i = tid; i <= nsn; i += nt) feptr_s[i] = M.fe_ptr[lo + i] - e0;
+    for (int e = e0 + tid; e < e1; e += nt) { off_s[e - e0] = M.fe_off[e]; vals_s[e - e0] = M.vals[M.fe_q[e]]; }
+    for (int i = r0 + tid; i < r1; i += nt) rel_s[i - r0] = M.rel[i];
+    __syncthreads();
+    bool prev_valid = false;
+    for (int s = lo; s <= hi; ++s) {
+        const SnRec me = rec_s[s - lo];
+        const int first = me.first, w = me.w, f = me.f;
+        double* W = cur;
+        for (int idx = tid; idx < f * f; idx += nt) W[idx] = 0.0;
+        __syncthreads();
+        for (int e = feptr_s[s - lo] + tid; e < feptr_s[s - lo + 1]; e += nt) W[off_s[e]] = vals_s[e];
+        __syncthreads();
+        for (int ci = me.child_lo; ci < me.child_hi; ++ci) {
+            const int c = M.child[ci];  // children of a supernode inside a subtree are inside it too
+            const SnRec ch = rec_s[c - lo];
+            const int wc = ch.w, fc = ch.f, uc = fc - wc;
+            const bool from_lds = prev_valid && c == s - 1;
+            const double* U = from_lds ? prev + wc + wc * fc : fronts + ch.front_off + wc + (long long)wc * fc;
+            const int* rel = rel_s + (ch.rel_ptr - r0);
+            for (int idx = tid; idx < uc * uc; idx += nt) {
+                const int i = idx % uc, j = idx / uc;
+                if (i >= j) W[rel[i] + rel[j] * f] += U[i + (long long)j * fc];
+            }
+            __syncthreads();
+        }
+        for (int k = 0; k < w; ++k) {
+            double d = W[k + k * f];
+            if (d == 0.0) { if (tid == 0 && *info < 0) *info = first + k; d = 1.0; }
+            const double dinv = 1.0 / d;
+            if (tid == 0) rdiag[first + k] = dinv;
+            const int r = f - k - 1, pc = w - k - 1;
+            const double* colk = W + (k + 1) + k * f;
+            for (int idx = tid; idx < r * pc; idx += nt) {
+                const int i = idx % r, j = idx / r;
+                if (i >= j) W[(k + 1 + i) + (k + 1 + j) * f] -= (colk[i] * dinv) * colk[j];
+            }
+            __syncthreads();
+        }
+        for (int idx = tid; idx < f * w; idx += nt) {
+            const int i = idx % f, k = idx / f;
+            if (i > k) { double d = W[k + k * f]; if (d == 0.0) d = 1.0; W[i + k * f] *= 1.0 / d; }
+        }
+        __syncthreads();
+        const int u = f - w;
+        if (u > 0) {
+            const int tx = tid & 15, ty = tid >> 4, tys = nt >> 4;
+            for (int j = ty; j < u; j += tys) {
+                for (int i = j - (j & 15) + tx; i < u; i += 16) {
+                    if (i < j) continue;
+                    double acc = 0.0;
+                    for (int k = 0; k < w; ++k) acc += (W[(w + i) + k * f] * W[k + k * f]) * W[(w + j) + k * f];
+                    W[(w + i) + (w + j) * f] -= acc;
+                }
+            }
+            __syncthreads();
+        }
+        double* F = fronts + me.front_off;
+        for (int idx = tid; idx < f * w; idx += nt) F[idx] = W[idx];
+        const bool keep = me.parent == s + 1 && s + 1 <= hi;
+        if (!keep && u > 0) {
+            for (int idx = tid; idx < u * u; idx += nt) {
+                const int i = idx % u, j = idx / u;
+                if (i >= j) F[(w + i) + (long long)(w + j) * f] = W[(w + i) + (w + j) * f];
+            }
+        }
+        __syncthreads();
+        double* t = cur; cur = prev; prev = t;
+        prev_valid = keep;
     }
 }
 
@@ -774,7 +888,7 @@ public:
         PQ_HIP(hipMemsetAsync(info_.p, 0xFF, sizeof(int), st_));
         FrontMeta M = meta();
         if (part_on_) {
-            factor_subtrees(M, part_nsub_, part_sub_lo_.p, part_sub_hi_.p);
+            factor_subtrees(M, part_sched_);
             factor_levels(M, own_ptr_, own_sn_, own_sn_d_.p, own_lds_);
             const int nb = (int)PT_.boundary.size();
             if (nb > 0) {
@@ -784,7 +898,7 @@ public:
             }
             factor_levels(M, sh_ptr_, sh_sn_, sh_sn_d_.p, sh_lds_);
         } else {
-            factor_subtrees(M, S_.nsub, sub_lo_.p, sub_hi_.p);
+            factor_subtrees(M, sched_);
             if (top_persistent_) {
                 PQ_HIP(hipMemsetAsync(top_flags_.p, 0, sizeof(int) * (2 * (size_t)ntop_ + 1), st_));
                 hipLaunchKernelGGL(k_top_factor, dim3(top_grid_), dim3(256), top_lds_, st_, M, fronts_.p, level_sn_.p, ntop_, top_pos_.p, top_flags_.p, top_flags_.p + 2 * ntop_, rdiag_.p,
@@ -819,7 +933,7 @@ public:
             hipLaunchKernelGGL(k_perm_gather, g1(N_), dim3(256), 0, st_, N_, P_.p, rhs_top_.p, n_, tail, ntail, (const double*)nullptr, xp_.p);
         }
         if (part_on_) {
-            subtree_fwd(M, part_nsub_, part_sub_lo_.p, part_sub_hi_.p);
+            subtree_fwd(M, part_sched_);
             fwd_levels(M, own_ptr_, own_sn_d_.p);
             const int nb = (int)PT_.boundary.size();
             if (nb > 0) {
@@ -831,7 +945,7 @@ public:
             hipLaunchKernelGGL(k_scale, g1(N_), dim3(256), 0, st_, N_, rdiag_.p, xp_.p);
             bwd_levels(M, sh_ptr_, sh_sn_d_.p);
             bwd_levels(M, own_ptr_, own_sn_d_.p);
-            subtree_bwd(M, part_nsub_, part_sub_lo_.p, part_sub_hi_.p);
+            subtree_bwd(M, part_sched_);
             if (world_ > 1) {
                 const int lo = PT_.span_lo[rank_], hi = PT_.span_hi[rank_];
                 if (hi > lo) hipLaunchKernelGGL(k_pack_span, g1(hi - lo), dim3(256), 0, st_, lo, hi, xp_.p, xbuf_gather_ + (size_t)rank_ * PT_.max_span);
@@ -840,7 +954,7 @@ public:
                                    span_hi_d_.p, xbuf_gather_, xp_.p);
             }
         } else {
-        subtree_fwd(M, S_.nsub, sub_lo_.p, sub_hi_.p);
+        subtree_fwd(M, sched_);
         const bool top_solve_persistent = top_persistent_ && std::getenv("PIQP_AMD_TOP_SOLVE_PERSISTENT");
         if (top_solve_persistent) {
             PQ_HIP(hipMemsetAsync(top_flags_.p, 0, sizeof(int) * (2 * (size_t)ntop_ + 1), st_));
@@ -852,7 +966,7 @@ public:
             hipLaunchKernelGGL(k_top_bwd, dim3(top_grid_), dim3(256), 0, st_, M, fronts_.p, level_sn_.p, ntop_, top_pos_.p, top_flags_.p + ntop_, top_flags_.p + 2 * ntop_, xp_.p, fvec_.p);
             hipLaunchKernelGGL(k_top_check, dim3(1), dim3(1), 0, st_, top_flags_.p + 2 * ntop_, (int*)nullptr, xp_.p);
         } else bwd_levels(M, S_.top_level_ptr, level_sn_.p);
-        subtree_bwd(M, S_.nsub, sub_lo_.p, sub_hi_.p);
+        subtree_bwd(M, sched_);
         }
         if (mode_ == 0) {
             hipLaunchKernelGGL(k_perm_scatter, g1(N_), dim3(256), 0, st_, N_, P_.p, xp_.p, lhs_x, n_, lhs_y, p_, lhs_z);
@@ -891,10 +1005,9 @@ public:
         sparse::partition_tree(S_, world, PT_);
         rank_ = rank; world_ = world;
         // schedules of this rank: the workgroup subtrees and level lists it owns, and the shared level lists
-        std::vector<int> slo, shi;
-        for (int k = 0; k < S_.nsub; ++k) if (PT_.owner[S_.sub_hi[k]] == rank) { slo.push_back(S_.sub_lo[k]); shi.push_back(S_.sub_hi[k]); }
-        part_nsub_ = (int)slo.size();
-        upload_vec(part_sub_lo_, slo, st_); upload_vec(part_sub_hi_, shi, st_);
+        std::vector<int> mine;
+        for (int k = 0; k < S_.nsub; ++k) if (PT_.owner[S_.sub_hi[k]] == rank) mine.push_back(k);
+        build_sub_schedule(mine, part_sched_);
         auto filter = [&](int want, std::vector<int>& ptr, std::vector<int>& sn, DBuf<int>& dev, std::vector<int>& lds) {
             ptr.assign(1, 0); sn.clear(); lds.clear();
             for (int l = 0; l < S_.top_nlevels; ++l) {
@@ -941,6 +1054,9 @@ public:
     void print_info() override
     {
         std::printf("top of the tree: %d supernodes, %s\n", ntop_, top_persistent_ ? "factored in one persistent launch" : "one launch per level");
+        for (const SubClass& c : sched_.cls)
+            std::printf("subtree walk class: %d subtrees, front capacity %d doubles, %d threads, %d bytes of LDS per workgroup%s\n", c.nsub, c.cap, c.threads, c.bytes,
+                        c.staged ? " (metadata staged in LDS)" : "");
         std::printf("sparse multifrontal LDLt (%s ordering): N = %d, nnz(K) = %d, nnz(L) = %lld, supernodes = %d, tree levels = %d (%d subtrees walked by one workgroup each + %d level launches), max front = %d, front storage = %.1f MB\n",
                     S_.ordering, N_, nnzK_, S_.nnzL, S_.nsuper, S_.nlevels, S_.nsub, S_.top_nlevels, S_.max_front, S_.front_doubles * 8.0 / 1e6);
     }
@@ -970,7 +1086,7 @@ private:
         ops_.clone_from(o.ops_, st_);
         cpd(vals_, o.vals_); cpd(fronts_, o.fronts_); cpd(rdiag_, o.rdiag_);
         xp_.alloc(o.xp_.n); fvec_.alloc(o.fvec_.n); dvec_.alloc(o.dvec_.n);
-        cpi(diag_pos_, o.diag_pos_); cpi(P_, o.P_); cpi(level_sn_, o.level_sn_); cpi(sub_lo_, o.sub_lo_); cpi(sub_hi_, o.sub_hi_); cpi(top_pos_, o.top_pos_); top_flags_.alloc(o.top_flags_.n ? o.top_flags_.n : 1); cpi(fe_ptr_, o.fe_ptr_); cpi(fe_q_, o.fe_q_); cpi(fe_off_, o.fe_off_);
+        cpi(diag_pos_, o.diag_pos_); cpi(P_, o.P_); cpi(level_sn_, o.level_sn_); cpi(top_pos_, o.top_pos_); top_flags_.alloc(o.top_flags_.n ? o.top_flags_.n : 1); cpi(fe_ptr_, o.fe_ptr_); cpi(fe_q_, o.fe_q_); cpi(fe_off_, o.fe_off_);
         snrec_.alloc(o.snrec_.n ? o.snrec_.n : 1); if (o.snrec_.n) PQ_HIP(hipMemcpyAsync(snrec_.p, o.snrec_.p, o.snrec_.bytes(), hipMemcpyDeviceToDevice, st_)); cpi(sn_first_, o.sn_first_); cpi(front_rows_ptr_, o.front_rows_ptr_); cpi(front_rows_, o.front_rows_);
         cpi(child_ptr_, o.child_ptr_); cpi(child_, o.child_); cpi(rel_ptr_, o.rel_ptr_); cpi(rel_, o.rel_);
         cpi(mapP_, o.mapP_); cpi(mapA_, o.mapA_); cpi(mapG_, o.mapG_);
@@ -979,6 +1095,7 @@ private:
         cpd(ata_vals_, o.ata_vals_); cpd(zinv_, o.zinv_); rhs_top_.alloc(o.rhs_top_.n ? o.rhs_top_.n : 1);
         cpl(a_dst_, o.a_dst_); cpl(front_off_, o.front_off_);
         info_.alloc(1); info_h_.alloc(1);
+        build_full_schedule();
         PQ_HIP(hipStreamSynchronize(st_));
     }
 
@@ -990,6 +1107,7 @@ private:
             PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_front_factor), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_FRONT_DOUBLES * (int)sizeof(double)));
             PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_subtree_factor), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_FRONT_DOUBLES * (int)sizeof(double)));
             PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_subtree_factor_lds), hipFuncAttributeMaxDynamicSharedMemorySize, SUBTREE_LDS_BYTES));
+            PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_subtree_factor_staged), hipFuncAttributeMaxDynamicSharedMemorySize, SUBTREE_LDS_BYTES));
             PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_top_factor), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_FRONT_DOUBLES * (int)sizeof(double)));
             attr_set = true;
         }
@@ -1034,27 +1152,95 @@ private:
         PQ_HIP(hipStreamSynchronize(st_));
         if (xfn_(xuser_, which) != 0) throw std::runtime_error("exchange callback failed");
     }
-    void subtree_fwd(const FrontMeta& M, int nsub, const int* lo, const int* hi)
+    // ---- subtree schedule: subtrees are binned by the LDS their walk needs (two fronts of their largest front order + the staged
+    // metadata), one launch per class with exactly that much dynamic LDS -- a schedule sized for the largest subtree of the problem
+    // leaves one workgroup per CU when a single subtree has a 96 x 96 front
+    void build_sub_schedule(const std::vector<int>& subs, SubSchedule& out)
     {
-        if (nsub <= 0) return;
-        if (S_.sub_max_front <= 128 && !std::getenv("PIQP_AMD_SUBTREE_SOLVE_V1")) hipLaunchKernelGGL(k_subtree_fwd_wave, dim3(nsub), dim3(64), 0, st_, M, fronts_.p, lo, hi, xp_.p, fvec_.p);
-        else hipLaunchKernelGGL(k_subtree_fwd, dim3(nsub), dim3(SUB_SOLVE_THREADS), 0, st_, M, fronts_.p, lo, hi, xp_.p, fvec_.p);
+        out.cls.clear();
+        // measured (C3, C5): launches of different classes run back to back and their tails add up (C5 backend solve 1.4 -> 2.1 ms with four
+        // classes), and staging the metadata costs more occupancy than the latency it removes (C5 factor 2.1 -> 3.9 ms at 54 KB per
+        // workgroup) -- so by default there is ONE class sized for the largest subtree and no staging; both stay available for experiments
+        static const int all_limits[] = {8 << 10, 12 << 10, 16 << 10, 20 << 10, 26 << 10, 32 << 10, 40 << 10, 52 << 10, 78 << 10, SUBTREE_LDS_BYTES};
+        static const int one_limit[] = {SUBTREE_LDS_BYTES};
+        const bool classes = std::getenv("PIQP_AMD_SUBTREE_CLASSES") != nullptr;
+        const int* limits = classes ? all_limits : one_limit;
+        const int ncls = classes ? (int)(sizeof(all_limits) / sizeof(all_limits[0])) : 1;
+        const bool want_stage = std::getenv("PIQP_AMD_SUBTREE_STAGED") != nullptr;
+        std::vector<std::vector<int>> members(ncls);
+        struct Need { int fm, ent, rel, sn; };
+        std::vector<Need> need(subs.size());
+        auto bytes_of = [&](long long cap, const Need& q, bool staged) -> long long {
+            long long b = 2 * cap * 8;
+            if (staged) b += (long long)((q.ent + 1) & ~1) * 8 + (long long)q.sn * (long long)sizeof(SnRec) + (long long)((q.ent + 1) & ~1) * 4 + (long long)(q.rel + 1) * 4 + (long long)(q.sn + 1) * 4 + 16;
+            return b;
+        };
+        for (size_t i = 0; i < subs.size(); ++i) {
+            const int lo = S_.sub_lo[subs[i]], hi = S_.sub_hi[subs[i]];
+            Need q{0, S_.fe_ptr[hi + 1] - S_.fe_ptr[lo], S_.rel_ptr[hi + 1] - S_.rel_ptr[lo], hi - lo + 1};
+            for (int t = lo; t <= hi; ++t) q.fm = std::max(q.fm, S_.front_rows_ptr[t + 1] - S_.front_rows_ptr[t]);
+            need[i] = q;
+            long long b = bytes_of((long long)q.fm * q.fm, q, want_stage);
+            if (b > SUBTREE_LDS_BYTES) b = bytes_of((long long)q.fm * q.fm, q, false);
+            int c = 0;
+            while (c + 1 < ncls && b > limits[c]) ++c;
+            members[c].push_back((int)i);
+        }
+        for (int c = 0; c < ncls; ++c) {
+            if (members[c].empty()) continue;
+            SubClass k;
+            Need mx{0, 0, 0, 0};
+            std::vector<int> lo, hi;
+            for (int i : members[c]) {
+                mx.fm = std::max(mx.fm, need[i].fm); mx.ent = std::max(mx.ent, need[i].ent); mx.rel = std::max(mx.rel, need[i].rel); mx.sn = std::max(mx.sn, need[i].sn);
+                lo.push_back(S_.sub_lo[subs[i]]); hi.push_back(S_.sub_hi[subs[i]]);
+            }
+            k.nsub = (int)lo.size();
+            k.cap = mx.fm * mx.fm;
+            k.fmax = mx.fm;
+            k.stage.ent_cap = (mx.ent + 1) & ~1; k.stage.rel_cap = mx.rel + 1; k.stage.sn_cap = mx.sn;
+            long long b = bytes_of(k.cap, mx, want_stage);
+            k.staged = want_stage && b <= SUBTREE_LDS_BYTES;
+            if (!k.staged) b = bytes_of(k.cap, mx, false);
+            k.bytes = (int)b;
+            k.lds_walk = b <= SUBTREE_LDS_BYTES && !std::getenv("PIQP_AMD_SUBTREE_HBM");
+            static const int thr_env = std::getenv("PIQP_AMD_SUBTREE_THREADS") ? std::atoi(std::getenv("PIQP_AMD_SUBTREE_THREADS")) : 0;
+            k.threads = thr_env > 0 ? thr_env : SUB_THREADS;
+            upload_vec(k.lo, lo, st_); upload_vec(k.hi, hi, st_);
+            out.cls.push_back(std::move(k));
+        }
     }
-    void subtree_bwd(const FrontMeta& M, int nsub, const int* lo, const int* hi)
+    void build_full_schedule()
     {
-        if (nsub <= 0) return;
-        if (S_.sub_max_front <= 128 && !std::getenv("PIQP_AMD_SUBTREE_SOLVE_V1")) hipLaunchKernelGGL(k_subtree_bwd_wave, dim3(nsub), dim3(64), 0, st_, M, fronts_.p, lo, hi, xp_.p);
-        else hipLaunchKernelGGL(k_subtree_bwd, dim3(nsub), dim3(SUB_SOLVE_THREADS), 0, st_, M, fronts_.p, lo, hi, xp_.p, fvec_.p);
+        std::vector<int> all(S_.nsub);
+        for (int k = 0; k < S_.nsub; ++k) all[k] = k;
+        build_sub_schedule(all, sched_);
     }
-    void factor_subtrees(const FrontMeta& M, int nsub, const int* lo, const int* hi)
+    void subtree_fwd(const FrontMeta& M, const SubSchedule& sc)
     {
-        if (nsub <= 0) return;
-        const int cap = S_.sub_max_front * S_.sub_max_front;
-        if (2LL * cap * (long long)sizeof(double) <= SUBTREE_LDS_BYTES && !std::getenv("PIQP_AMD_SUBTREE_HBM"))
-            hipLaunchKernelGGL(k_subtree_factor_lds, dim3(nsub), dim3(SUB_THREADS), 2 * cap * (int)sizeof(double), st_, M, fronts_.p, vals_.p, fe_ptr_.p, fe_q_.p, fe_off_.p, lo, hi, cap,
-                               rdiag_.p, info_.p);
-        else
-            hipLaunchKernelGGL(k_subtree_factor, dim3(nsub), dim3(SUB_THREADS), sub_lds_, st_, M, fronts_.p, lo, hi, rdiag_.p, info_.p);
+        for (const SubClass& c : sc.cls) {
+            if (c.fmax <= 128 && !std::getenv("PIQP_AMD_SUBTREE_SOLVE_V1")) hipLaunchKernelGGL(k_subtree_fwd_wave, dim3(c.nsub), dim3(64), 0, st_, M, fronts_.p, c.lo.p, c.hi.p, xp_.p, fvec_.p);
+            else hipLaunchKernelGGL(k_subtree_fwd, dim3(c.nsub), dim3(SUB_SOLVE_THREADS), 0, st_, M, fronts_.p, c.lo.p, c.hi.p, xp_.p, fvec_.p);
+        }
+    }
+    void subtree_bwd(const FrontMeta& M, const SubSchedule& sc)
+    {
+        for (const SubClass& c : sc.cls) {
+            if (c.fmax <= 128 && !std::getenv("PIQP_AMD_SUBTREE_SOLVE_V1")) hipLaunchKernelGGL(k_subtree_bwd_wave, dim3(c.nsub), dim3(64), 0, st_, M, fronts_.p, c.lo.p, c.hi.p, xp_.p);
+            else hipLaunchKernelGGL(k_subtree_bwd, dim3(c.nsub), dim3(SUB_SOLVE_THREADS), 0, st_, M, fronts_.p, c.lo.p, c.hi.p, xp_.p, fvec_.p);
+        }
+    }
+    void factor_subtrees(const FrontMeta& M, const SubSchedule& sc)
+    {
+        for (const SubClass& c : sc.cls) {
+            if (c.lds_walk && c.staged)
+                hipLaunchKernelGGL(k_subtree_factor_staged, dim3(c.nsub), dim3(c.threads), c.bytes, st_, M, fronts_.p, c.lo.p, c.hi.p, c.cap, c.stage, rdiag_.p, info_.p);
+            else if (c.lds_walk)
+                hipLaunchKernelGGL(k_subtree_factor_lds, dim3(c.nsub), dim3(c.threads), c.bytes, st_, M, fronts_.p, vals_.p, fe_ptr_.p, fe_q_.p, fe_off_.p, c.lo.p, c.hi.p, c.cap, rdiag_.p,
+                                   info_.p);
+            else
+                hipLaunchKernelGGL(k_subtree_factor, dim3(c.nsub), dim3(SUB_THREADS), sub_lds_, st_, M, fronts_.p, c.lo.p, c.hi.p, rdiag_.p, info_.p);
+        }
     }
     // one launch per level of a (possibly filtered) level schedule; wide fronts go through the dense multi-workgroup path
     void factor_levels(const FrontMeta& M, const std::vector<int>& ptr, const std::vector<int>& sn, const int* sn_dev, const std::vector<int>& lds)
@@ -1085,7 +1271,7 @@ private:
     void build_device(const pq_sparse_data* d)
     {
         nnzK_ = S_.Cp[N_];
-        upload_vec(diag_pos_, S_.diag_pos, st_); upload_vec(P_, S_.P, st_); upload_vec(level_sn_, S_.top_level_sn, st_); upload_vec(sub_lo_, S_.sub_lo, st_); upload_vec(sub_hi_, S_.sub_hi, st_); {
+        upload_vec(diag_pos_, S_.diag_pos, st_); upload_vec(P_, S_.P, st_); upload_vec(level_sn_, S_.top_level_sn, st_); {
             std::vector<int> tp(S_.nsuper ? S_.nsuper : 1, -1);
             for (size_t q = 0; q < S_.top_level_sn.size(); ++q) tp[S_.top_level_sn[q]] = (int)q;
             upload_vec(top_pos_, tp, st_);
@@ -1126,6 +1312,7 @@ private:
         upload_vec(aa_ptr_, S_.gramA.ptr, st_); upload_vec(aa_q1_, S_.gramA.q1, st_); upload_vec(aa_q2_, S_.gramA.q2, st_); upload_vec(aa_k_, S_.gramA.k, st_);
         upload_vec(gg_ptr_, S_.gramG.ptr, st_); upload_vec(gg_q1_, S_.gramG.q1, st_); upload_vec(gg_q2_, S_.gramG.q2, st_); upload_vec(gg_k_, S_.gramG.k, st_);
         ata_vals_.alloc(nzAA_ ? nzAA_ : 1); zinv_.alloc(m_ ? m_ : 1); rhs_top_.alloc(n_ ? n_ : 1);
+        build_full_schedule();
         ops_.init(d, st_);  // CSC copies for the mat-vecs (uploads the values once)
         remap_values();
     }
@@ -1194,10 +1381,11 @@ private:
     sparse::Symbolic S_;
     std::vector<int> level_lds_;
     int sub_lds_ = 0, ntop_ = 0, top_grid_ = 0, top_lds_ = 0;
+    SubSchedule sched_, part_sched_;
     bool top_persistent_ = false;
     CscOperators ops_;
     DBuf<double> vals_, fronts_, rdiag_, xp_, fvec_, dvec_;
-    DBuf<int> sub_lo_, sub_hi_, fe_ptr_, fe_q_, fe_off_, top_pos_, top_flags_;
+    DBuf<int> fe_ptr_, fe_q_, fe_off_, top_pos_, top_flags_;
     DBuf<SnRec> snrec_;
     DBuf<int> diag_pos_, P_, level_sn_, sn_first_, front_rows_ptr_, front_rows_, child_ptr_, child_, rel_ptr_, rel_;
     DBuf<int> mapP_, mapA_, mapG_, mapAA_, mapGG_, aa_ptr_, aa_q1_, aa_q2_, aa_k_, gg_ptr_, gg_q1_, gg_q2_, gg_k_;
@@ -1208,10 +1396,10 @@ private:
     StageProfiler prof_;
     // stage partition (pq_kkt_partition)
     bool part_on_ = false;
-    int rank_ = 0, world_ = 1, part_nsub_ = 0;
+    int rank_ = 0, world_ = 1;
     sparse::Partition PT_;
     std::vector<int> own_ptr_, own_sn_, own_lds_, sh_ptr_, sh_sn_, sh_lds_;
-    DBuf<int> part_sub_lo_, part_sub_hi_, own_sn_d_, sh_sn_d_, b_sn_, b_owner_, b_vec_off_, span_lo_d_, span_hi_d_;
+    DBuf<int> own_sn_d_, sh_sn_d_, b_sn_, b_owner_, b_vec_off_, span_lo_d_, span_hi_d_;
     DBuf<long long> b_mat_off_;
     pq_exchange_fn xfn_ = nullptr;
     void* xuser_ = nullptr;
