@@ -49,7 +49,9 @@ int main(void) {
 
 
 def test_entry_points_exported():
-    lib = C.CDLL(os.path.join(LIBDIR, "libpiqp_amd.so")) if not os.environ.get("PIQP_AMD_SKIP_DLOPEN") else None
+    sys.path.insert(0, ROOT)
+    from piqp_amd import _lib  # loads torch's HIP runtime before the library (one HIP runtime per process)
+    lib = _lib.load()
     for name in ENTRY_POINTS:
         assert hasattr(lib, name), name
     text = open(os.path.join(INC, "piqp_c_compat.h")).read()
