@@ -230,6 +230,25 @@ def sparse_legs(args, rank, world, local_rank, dev, pd):
             r = {"workload": desc, "value": world * steps / el, "unit": "IPM-iter KKT (1 factor + 2 solves)/s", "ms_per_step": el / steps * 1e3,
                  "factor_ms": (prof[0][0] + prof[1][0]) / max(prof[1][1], 1), "backend_solve_ms": prof[2][0] / max(prof[2][1], 1), "setup_s": t_setup,
                  "rel_kkt_residual": res_inf / nrm}
+            # roofline of the two dominant phases against HBM with the ALGORITHMIC bytes of SURVEY.md 8d (C3 row): factor reads PKPt once and
+            # writes L once (12 B per entry: value + index) plus D / D_inv / diag (24 N); one solve reads L twice plus six vector passes.
+            try:
+                stt = be.sparse_stats()
+                N_, nK, nL = stt["N"], stt["nnz_K"], stt["nnz_L"]
+                bytes_factor = 12.0 * nK + 12.0 * nL + 24.0 * N_
+                bytes_solve = 24.0 * nL + 48.0 * N_
+                fac_s = r["factor_ms"] * 1e-3; sol_s = r["backend_solve_ms"] * 1e-3
+                r["symbolic"] = stt
+                r["roofline"] = {"bound": "hbm", "kernel": "multifrontal factorisation (k_subtree_factor_lds + k_front_factor levels), hipEvent-bracketed on the backend stream",
+                                 "achieved": bytes_factor / fac_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": bytes_factor / fac_s / 1e9 / PEAK_HBM_GBS, "traffic": None,
+                                 "alg_bytes_per_launch": bytes_factor, "avg_launch_ms": r["factor_ms"],
+                                 "note": "dependent-latency bound (tree of small fronts), not bandwidth bound: see DESIGN.md section 6"}
+                r["roofline_solve"] = {"bound": "hbm", "kernel": "backend solve (k_subtree_fwd/bwd_wave + k_front_fwd/bwd levels)", "achieved": bytes_solve / sol_s / 1e9,
+                                       "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": bytes_solve / sol_s / 1e9 / PEAK_HBM_GBS, "traffic": None,
+                                       "alg_bytes_per_launch": bytes_solve, "avg_launch_ms": r["backend_solve_ms"]}
+                r["factor_gflops"] = stt["flops_factor"] / fac_s / 1e9
+            except Exception as e:  # noqa: BLE001
+                r["roofline_error"] = str(e)
             if not args.no_cpu_baseline:
                 from oracle import pyorc
                 od = pyorc.Data.sparse(*a)
@@ -293,6 +312,25 @@ def batched_qp(args, rank, world, local_rank, dev, pd):
     res["sharding"] = f"contiguous shards of independent QPs over {world} rank(s), no data-path collective"
     pr = bs.profile(0)
     res["in_kernel_us_instance0"] = {k: v * 1e6 for k, v in pr.items()}
+    # roofline with the ALGORITHMIC bytes of SURVEY.md 8d (C4 row), per QP and IPM iteration:
+    #   8 (sum |D_i| + |B_i|) (1 write + 1 read in the factorisation + 2 reads per backend solve) + 8 nnz(AT, GT blocks) (1 + 2 n_solves)
+    #   + 8 (n + p + m) * 12 vector passes, with n_solves = 2 (predictor + corrector, no refinement step needed on this recipe)
+    try:
+        bi = bs.block_info().astype(np.int64)
+        blocks = int((bi[:, 1] * bi[:, 1] + bi[:, 2] * bi[:, 1]).sum())
+        nnz_c = int(full["A_pattern"].nnz)
+        nvec = int(full["n"]) + int(full["p"])
+        n_solves = 2
+        bytes_iter = 8.0 * blocks * (2 + 2 * n_solves) + 8.0 * nnz_c * (1 + 2 * n_solves) + 8.0 * nvec * 12
+        kernel_s = bs.last_kernel_ms()[0] * 1e-3
+        its = float(bs.iterations().sum())
+        res["roofline"] = {"bound": "hbm", "kernel": "k_batch_ipm (one workgroup = one whole interior-point solve), hipEvent-bracketed",
+                           "achieved": bytes_iter * its / kernel_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": bytes_iter * its / kernel_s / 1e9 / PEAK_HBM_GBS,
+                           "traffic": None, "alg_bytes_per_qp_iteration": bytes_iter, "qp_iterations_in_launch": its, "avg_launch_ms": kernel_s * 1e3,
+                           "note": "fronts, panels and vectors stay in LDS / registers for the whole solve; the kernel is VALU-issue bound (profiles/r01_pmc_batch_c4.txt), "
+                                   "these algorithmic bytes never reach HBM"}
+    except Exception as e:  # noqa: BLE001
+        res["roofline_error"] = str(e)
     if not args.no_cpu_baseline:
         # CPU baseline: the oracle (restatement of the reference's SparseSolver + sparse_multistage) on a bounded sample, 1 thread
         from oracle import pyorc

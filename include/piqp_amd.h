@@ -183,6 +183,9 @@ int pq_kkt_dims(const pq_kkt *k, int *n, int *p, int *m);
  * `capacity` rows of (start, diag_size, off_diag_size) -- the last row is the arrow corner block -- and
  * returns the number of blocks (call with out_host = NULL to size the buffer). */
 int pq_kkt_multistage_block_info(pq_kkt *k, int *out_host, int capacity);
+/* sparse backends: figures of the symbolic analysis for roofline arithmetic.  out = { N, nnz(PKPt), nnz(L) below
+ * the diagonal, supernodes, tree levels, workgroup subtrees, max front order, factorisation flops sum_j (c_j^2 + 3 c_j) } */
+int pq_kkt_sparse_stats(pq_kkt *k, double out[8]);
 /* ---- stage-partitioned execution of ONE KKT system over several processes, one GPU each (BASELINE configs[4]; the
  * reference has no counterpart, its multistage backend is a serial recurrence, multistage_kkt.hpp:1289-1347,1726-1814).
  * Every process creates the same backend on the same data and calls pq_kkt_partition with its rank.  Vectors stay

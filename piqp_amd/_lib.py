@@ -72,7 +72,7 @@ SYMBOLS = [
     "pq_kkt_update_data_dense", "pq_kkt_update_data_sparse", "pq_kkt_update_scalings_and_factor", "pq_kkt_solve",
     "pq_kkt_eval_P_x", "pq_kkt_eval_A_xn_and_AT_xt", "pq_kkt_eval_G_xn_and_GT_xt", "pq_kkt_print_info",
     "pq_kkt_synchronize", "pq_kkt_stream", "pq_kkt_internal_kkt_mat", "pq_kkt_internal_factor", "pq_kkt_dims", "pq_kkt_multistage_block_info", "pq_kkt_set_profiling", "pq_kkt_get_profile",
-    "pq_kkt_partition", "pq_kkt_set_exchange", "pq_kkt_partition_info", "pq_sparse_partition_plan",
+    "pq_kkt_sparse_stats", "pq_kkt_partition", "pq_kkt_set_exchange", "pq_kkt_partition_info", "pq_sparse_partition_plan",
     "pq_kktsys_create_dense", "pq_kktsys_create_sparse", "pq_kktsys_clone", "pq_kktsys_destroy",
     "pq_kktsys_set_pointer_mode", "pq_kktsys_backend", "pq_kktsys_update_data_dense", "pq_kktsys_update_data_sparse",
     "pq_kktsys_update_scalings_and_factor", "pq_kktsys_solve", "pq_kktsys_mul", "pq_kktsys_last_solve_stats",
@@ -178,6 +178,7 @@ def load():
     L.pq_solver_dims.argtypes = [vp, _ip, _ip, _ip]
     L.pq_solver_set_trace.argtypes = [vp, vp, C.c_int]
     L.pq_solver_trace_rows.argtypes = [vp]
+    L.pq_kkt_sparse_stats.argtypes = [vp, _dp]
     L.pq_kkt_partition.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_longlong)]
     L.pq_kkt_set_exchange.argtypes = [vp, EXCHANGE_FN, vp, vp, vp, vp]
     L.pq_kkt_partition_info.argtypes = [vp, _ip]

@@ -327,6 +327,11 @@ int pq_kkt_multistage_block_info(pq_kkt* k, int* out_host, int capacity)
         return N;
     });
 }
+int pq_kkt_sparse_stats(pq_kkt* k, double out[8])
+{
+    if (!k || !out) return fail(PQ_ERR_INVALID, "null argument");
+    return guarded([&] { k->impl->sparse_stats(out); return (int)PQ_OK; });
+}
 int pq_kkt_partition(pq_kkt* k, int rank, int world, long long sizes_out[3])
 {
     if (!k || !sizes_out) return fail(PQ_ERR_INVALID, "null argument");

@@ -43,6 +43,9 @@ public:
     virtual void internal_factor(double* out_host) { (void)out_host; throw std::runtime_error("internal_factor: dense only"); }
     // test hook: rows of (start, diag_size, off_diag_size) of the multistage backend (print_info, multistage_kkt.hpp:385-393)
     virtual void multistage_block_info(std::vector<int>& out) const { (void)out; throw std::runtime_error("block_info: sparse_multistage only"); }
+    // symbolic-analysis figures of the sparse backends for the roofline arithmetic: N, nnz(PKPt), nnz(L) below the
+    // diagonal, supernodes, tree levels, workgroup subtrees, max front order, factorisation flops
+    virtual void sparse_stats(double out[8]) const { (void)out; throw std::runtime_error("sparse_stats: sparse backends only"); }
     // stage-partitioned execution over several processes (include/piqp_amd.h, pq_kkt_partition)
     virtual void partition(int rank, int world, long long sizes[3]) { (void)rank; (void)world; (void)sizes; throw std::runtime_error("partition: not supported by this backend"); }
     virtual void set_exchange(pq_exchange_fn fn, void* user, double* buf_factor, double* buf_forward, double* buf_gather)

@@ -208,6 +208,11 @@ public:
         ops_.eval_G_xn_and_GT_xt(alpha_n, alpha_t, xn, xt, zn, zt, st_);
     }
 
+    void sparse_stats(double out[8]) const override
+    {
+        if (!tree_) throw std::runtime_error("sparse_stats: chain engine (see multistage_block_info)");
+        tree_->sparse_stats(out);
+    }
     // stage partition over several processes: the stage-parallel (tree) engine carries it; the serial recurrence cannot be split.
     // The engine choice of make_multistage_kkt is a timing probe, so partitioned runs force it (PIQP_AMD_MULTISTAGE=tree) to keep
     // every rank on the same code path.

@@ -700,7 +700,9 @@ __device__ __forceinline__ void top_done(int* flag)
         __hip_atomic_store(flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
-__global__ __launch_bounds__(256) void k_top_factor(FrontMeta M, double* __restrict__ fronts, const int* __restrict__ list, int ntop, const int* __restrict__ top_pos,
+// `list` / `ntop` may be a SUFFIX of the level-sorted top list (start = its first position): children in earlier levels or in
+// subtrees were finished by earlier launches on the stream
+__global__ __launch_bounds__(256) void k_top_factor(FrontMeta M, double* __restrict__ fronts, const int* __restrict__ list, int ntop, const int* __restrict__ top_pos, int start,
                                                     int* __restrict__ flags, int* __restrict__ err, double* __restrict__ rdiag, int* __restrict__ info)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -708,7 +710,7 @@ __global__ __launch_bounds__(256) void k_top_factor(FrontMeta M, double* __restr
         const int s = list[b];
         const SnRec me = M.sn[s];
         for (int ci = me.child_lo; ci < me.child_hi; ++ci) {
-            const int tp = top_pos[M.child[ci]];
+            const int tp = top_pos[M.child[ci]] - start;
             if (tp >= 0) top_wait(flags + tp, err);
         }
         front_factor(M, fronts, s, 1 << 30, 1 << 30, rdiag, info, lds);
@@ -899,13 +901,13 @@ public:
             factor_levels(M, sh_ptr_, sh_sn_, sh_sn_d_.p, sh_lds_);
         } else {
             factor_subtrees(M, sched_);
-            if (top_persistent_) {
+            // wide lower levels: one launch per level; the narrow levels near the root (<= 1024 supernodes in total): one persistent launch
+            factor_levels(M, S_.top_level_ptr, S_.top_level_sn, level_sn_.p, level_lds_, top_l0_);
+            if (top_nper_ > 0) {
                 PQ_HIP(hipMemsetAsync(top_flags_.p, 0, sizeof(int) * (2 * (size_t)ntop_ + 1), st_));
-                hipLaunchKernelGGL(k_top_factor, dim3(top_grid_), dim3(256), top_lds_, st_, M, fronts_.p, level_sn_.p, ntop_, top_pos_.p, top_flags_.p, top_flags_.p + 2 * ntop_, rdiag_.p,
-                                   info_.p);
+                hipLaunchKernelGGL(k_top_factor, dim3(std::min(top_nper_, 224)), dim3(256), top_lds_, st_, M, fronts_.p, level_sn_.p + top_start_, top_nper_, top_pos_.p, top_start_,
+                                   top_flags_.p, top_flags_.p + 2 * ntop_, rdiag_.p, info_.p);
                 hipLaunchKernelGGL(k_top_check, dim3(1), dim3(1), 0, st_, top_flags_.p + 2 * ntop_, info_.p, (double*)nullptr);
-            } else {
-                factor_levels(M, S_.top_level_ptr, S_.top_level_sn, level_sn_.p, level_lds_);
             }
         }
         PQ_HIP(hipGetLastError());
@@ -997,6 +999,10 @@ public:
         ops_.eval_G_xn_and_GT_xt(alpha_n, alpha_t, xn, xt, zn, zt, st_);
     }
 
+    void sparse_stats(double out[8]) const override
+    {
+        out[0] = N_; out[1] = nnzK_; out[2] = (double)S_.nnzL; out[3] = S_.nsuper; out[4] = S_.nlevels; out[5] = S_.nsub; out[6] = S_.max_front; out[7] = S_.flops;
+    }
     // ---- pq_kkt_partition / pq_kkt_set_exchange (include/piqp_amd.h)
     void partition(int rank, int world, long long sizes[3]) override
     {
@@ -1053,7 +1059,7 @@ public:
 
     void print_info() override
     {
-        std::printf("top of the tree: %d supernodes, %s\n", ntop_, top_persistent_ ? "factored in one persistent launch" : "one launch per level");
+        std::printf("top of the tree: %d supernodes in %d levels: %d level launches, then %d supernodes in one persistent launch\n", ntop_, S_.top_nlevels, top_l0_, top_nper_);
         for (const SubClass& c : sched_.cls)
             std::printf("subtree walk class: %d subtrees, front capacity %d doubles, %d threads, %d bytes of LDS per workgroup%s\n", c.nsub, c.cap, c.threads, c.bytes,
                         c.staged ? " (metadata staged in LDS)" : "");
@@ -1077,7 +1083,7 @@ public:
     const sparse::Symbolic& symbolic() const { return S_; }
 
 private:
-    SparseKKT(const SparseKKT& o, int) : dev_(o.dev_), mode_(o.mode_), nzAA_(o.nzAA_), nzGG_(o.nzGG_), n_(o.n_), p_(o.p_), m_(o.m_), N_(o.N_), nnzK_(o.nnzK_), delta_(o.delta_), S_(o.S_), level_lds_(o.level_lds_), sub_lds_(o.sub_lds_), ntop_(o.ntop_), top_grid_(o.top_grid_), top_lds_(o.top_lds_), top_persistent_(o.top_persistent_)
+    SparseKKT(const SparseKKT& o, int) : dev_(o.dev_), mode_(o.mode_), nzAA_(o.nzAA_), nzGG_(o.nzGG_), n_(o.n_), p_(o.p_), m_(o.m_), N_(o.N_), nnzK_(o.nnzK_), delta_(o.delta_), S_(o.S_), level_lds_(o.level_lds_), sub_lds_(o.sub_lds_), ntop_(o.ntop_), top_grid_(o.top_grid_), top_lds_(o.top_lds_), top_l0_(o.top_l0_), top_start_(o.top_start_), top_nper_(o.top_nper_), top_persistent_(o.top_persistent_)
     {
         PQ_HIP(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
         auto cpd = [&](DBuf<double>& d, const DBuf<double>& s) { d.alloc(s.n ? s.n : 1); if (s.n) PQ_HIP(hipMemcpyAsync(d.p, s.p, s.bytes(), hipMemcpyDeviceToDevice, st_)); };
@@ -1140,6 +1146,22 @@ private:
         // measured: worth it for the factorisation when every top supernode gets its own workgroup; the substitution fronts are too
         // cheap to pay for agent-scope release / acquire per supernode, they stay on level launches
         top_persistent_ = ntop_ > 0 && ntop_ <= 1024 && !any_big && !std::getenv("PIQP_AMD_TOP_LEVELS");
+        // the levels from top_l0_ on (at most 1024 supernodes, none on the dense multi-launch path) go into the persistent launch
+        top_l0_ = S_.top_nlevels;
+        if (!std::getenv("PIQP_AMD_TOP_LEVELS")) {
+            for (int l = S_.top_nlevels - 1; l >= 0; --l) {
+                bool big = false;
+                for (int q = S_.top_level_ptr[l]; q < S_.top_level_ptr[l + 1]; ++q) {
+                    const int s = S_.top_level_sn[q];
+                    if (S_.front_rows_ptr[s + 1] - S_.front_rows_ptr[s] >= BIG_FRONT && S_.sn_first[s + 1] - S_.sn_first[s] >= BIG_PIVOTS) big = true;
+                }
+                if (big || ntop_ - S_.top_level_ptr[l] > 1024) break;
+                top_l0_ = l;
+            }
+        }
+        top_start_ = top_l0_ < S_.top_nlevels ? S_.top_level_ptr[top_l0_] : ntop_;
+        top_nper_ = ntop_ - top_start_;
+        if (top_nper_ < 2) { top_l0_ = S_.top_nlevels; top_start_ = ntop_; top_nper_ = 0; }  // a single supernode gains nothing
     }
 
     FrontMeta meta() const { return FrontMeta{snrec_.p, front_rows_.p, child_.p, rel_.p, fe_ptr_.p, fe_q_.p, fe_off_.p, vals_.p}; }
@@ -1243,9 +1265,9 @@ private:
         }
     }
     // one launch per level of a (possibly filtered) level schedule; wide fronts go through the dense multi-workgroup path
-    void factor_levels(const FrontMeta& M, const std::vector<int>& ptr, const std::vector<int>& sn, const int* sn_dev, const std::vector<int>& lds)
+    void factor_levels(const FrontMeta& M, const std::vector<int>& ptr, const std::vector<int>& sn, const int* sn_dev, const std::vector<int>& lds, int lend = 1 << 30)
     {
-        for (int l = 0; l + 1 < (int)ptr.size(); ++l) {
+        for (int l = 0; l + 1 < (int)ptr.size() && l < lend; ++l) {
             const int cnt = ptr[l + 1] - ptr[l];
             if (cnt <= 0) continue;
             hipLaunchKernelGGL(k_front_factor, dim3(cnt), dim3(256), lds[l], st_, M, fronts_.p, sn_dev + ptr[l], BIG_FRONT, BIG_PIVOTS, rdiag_.p, info_.p);
@@ -1380,7 +1402,7 @@ private:
     hipStream_t st_ = nullptr;
     sparse::Symbolic S_;
     std::vector<int> level_lds_;
-    int sub_lds_ = 0, ntop_ = 0, top_grid_ = 0, top_lds_ = 0;
+    int sub_lds_ = 0, ntop_ = 0, top_grid_ = 0, top_lds_ = 0, top_l0_ = 0, top_start_ = 0, top_nper_ = 0;
     SubSchedule sched_, part_sched_;
     bool top_persistent_ = false;
     CscOperators ops_;

@@ -309,6 +309,13 @@ class DenseKKT(_Handle):
         check(self.L.pq_kkt_get_profile(self.h, stage, C.byref(ms), C.byref(cnt)))
         return ms.value, cnt.value
 
+    def sparse_stats(self):
+        """dict of the symbolic-analysis figures (pq_kkt_sparse_stats)"""
+        out = (C.c_double * 8)()
+        check(self.L.pq_kkt_sparse_stats(self.h, out), "sparse_stats")
+        keys = ("N", "nnz_K", "nnz_L", "supernodes", "tree_levels", "subtrees", "max_front", "flops_factor")
+        return {k: (float(v) if k == "flops_factor" else int(v)) for k, v in zip(keys, out)}
+
     def block_info(self):
         """sparse_multistage only: rows of (start, diag_size, off_diag_size); last row = arrow corner block."""
         N = check(self.L.pq_kkt_multistage_block_info(self.h, None, 0), "block_info")
