@@ -120,6 +120,17 @@ __device__ __forceinline__ void scale_tile(const double* __restrict__ w, int k0,
     }
 }
 
+// diagonal-block factorisation on an LDS-resident block (defined with k_potrf_diag below); PACKED: 16-column block columns stored
+// without the rows above their diagonal block (9216 doubles = exactly the SYRK staging buffers)
+template <bool LDLT, int NTHREADS, bool PACKED>
+__device__ void potrf_block(double* __restrict__ S, int nb, int kglobal, int* __restrict__ info, double* __restrict__ rdiag, int dbg);
+template <bool PACKED>
+__device__ __forceinline__ int sidx(int r, int c);
+// layout of the fused next-panel factorisation: packed fits the 72 KB of the SYRK staging buffers but its block columns start on
+// the same LDS banks (measured 60 us per block against 43 us standalone); the padded layout needs 144 KB for the one launch
+constexpr bool FUSED_PACKED = false;
+constexpr int FUSED_LDS_BYTES = FUSED_PACKED ? 2 * 2 * 16 * (128 + 16) * 8 : 128 * (128 + 16) * 8;
+
 // WD = waves per tile dimension: WD = 2 -> 256 threads, 64x64 per wave (throughput shape, 2 workgroups per CU);
 //                                WD = 4 -> 1024 threads, 32x32 per wave (low-latency shape for short K: a quarter of the
 //                                MFMA chain per wave, used for the trailing updates of the factorisation).
@@ -201,6 +212,39 @@ __global__ __launch_bounds__(64 * WD * WD, WD == 2 ? 2 : 4) void k_syrk_lower(Sy
         __syncthreads();
     }
 
+    constexpr bool FPK = FUSED_PACKED;
+    if (EPI == EPI_SUBTRACT_POTRF && ti == 0 && tj == 0 && a.fuse_nb > 0) {
+        // next diagonal block: C - acc goes to LDS (the staging buffers are free now) instead of HBM, is factored there, and only the
+        // factor is written.  Every wave of the workgroup stays for the barriers of potrf_block.
+        double* S = smem;
+        const int nbn = a.fuse_nb;
+        if (nbn < TS) {  // identity padding (last, partial panel)
+            for (int idx = tid; idx < TS * TS; idx += NT) {
+                const int r = idx & (TS - 1), c = idx >> 7;
+                if (r >= c && (r >= nbn || c >= nbn)) S[sidx<FPK>(r, c)] = (r == c) ? 1.0 : 0.0;
+            }
+        }
+        if (!skip_wave) {
+#pragma unroll
+            for (int x = 0; x < MT; ++x) {
+#pragma unroll
+                for (int y = 0; y < MT; ++y) {
+                    const int li = wr * SUB + y * 16 + (lane & 15);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int lj = wc * SUB + x * 16 + (lane >> 4) + 4 * r;
+                        if (li < nbn && lj < nbn && li >= lj) S[sidx<FPK>(li, lj)] = a.C[(size_t)li + (size_t)lj * a.ldc] - acc[x][y][r];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (a.fuse_ldlt) potrf_block<true, NT, FPK>(S, nbn, a.fuse_kglobal, a.fuse_info, a.fuse_rdiag, 0);
+        else potrf_block<false, NT, FPK>(S, nbn, a.fuse_kglobal, a.fuse_info, a.fuse_rdiag, 0);
+        for (int c = wave; c < nbn; c += NT / 64)
+            for (int r = c + lane; r < nbn; r += 64) a.C[(size_t)r + (size_t)c * a.ldc] = S[sidx<FPK>(r, c)];
+        return;
+    }
     if (skip_wave) return;
     if (a.part) {
         // split launch: raw partial tile (column-major 128 x 128) for k_syrk_tail_reduce; fixed slot per (tile, slice)
@@ -231,7 +275,7 @@ __global__ __launch_bounds__(64 * WD * WD, WD == 2 ? 2 : 4) void k_syrk_lower(Sy
                         if (gi == gj) base += a.x_reg[gi];
                         if (a.ATA) base += a.dinv * a.ATA[(size_t)gi + (size_t)gj * a.ldata];
                         a.C[ci] = base + v;
-                    } else if (EPI == EPI_SUBTRACT) {
+                    } else if (EPI == EPI_SUBTRACT || EPI == EPI_SUBTRACT_POTRF) {
                         a.C[ci] -= v;
                     } else {
                         a.C[ci] = v;
@@ -344,6 +388,18 @@ void launch_syrk(int epi, const SyrkArgs& args_in, hipStream_t s, double* split_
         PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk_lower<EPI_STORE, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, SYRK_LDS_BYTES));
         attr_set = true;
     }
+    if (epi == EPI_SUBTRACT_POTRF) {
+        static bool fused_attr = false;
+        if (!fused_attr) {
+            PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk_lower<EPI_SUBTRACT_POTRF, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS_BYTES));
+            fused_attr = true;
+        }
+        const int T = div_up(a.n, TS);
+        a.tile_begin = 0; a.k_split = 1; a.part = nullptr; a.first_col_only = 0;
+        hipLaunchKernelGGL((k_syrk_lower<EPI_SUBTRACT_POTRF, 4>), dim3(T * (T + 1) / 2), dim3(1024), FUSED_LDS_BYTES, s, a);
+        PQ_HIP(hipGetLastError());
+        return;
+    }
     switch (epi) {
     case EPI_ASSEMBLE: launch_syrk_t<EPI_ASSEMBLE>(a, s, split_ws, split_ws_doubles); break;
     case EPI_SUBTRACT: launch_syrk_t<EPI_SUBTRACT>(a, s, split_ws, split_ws_doubles); break;
@@ -428,17 +484,20 @@ __device__ __forceinline__ double rcp_newton(double d)
 }
 
 constexpr int POTRF_THREADS = 512;
-template <bool LDLT>
-__global__ __launch_bounds__(POTRF_THREADS) void k_potrf_diag(double* __restrict__ A, int lda, int nb, int kglobal, int* __restrict__ info, double* __restrict__ rdiag, int dbg)
+template <bool PACKED>
+__device__ __forceinline__ int sidx(int r, int c)
 {
-    extern __shared__ __attribute__((aligned(16))) double S[];  // S[c * PLD + r]
-    __shared__ double rd16[16];                                  // reciprocals of the current 16 pivots
+    if (!PACKED) return c * PLD + r;
+    const int jb = c >> 4;  // block column jb holds rows 16 jb .. 127: height 128 - 16 jb, offset 16 * sum_{q < jb} (128 - 16 q)
+    return (2048 * jb - 128 * jb * (jb - 1)) + (c & 15) * (128 - 16 * jb) + (r - 16 * jb);
+}
+template <bool LDLT, int NTHREADS, bool PACKED>
+__device__ void potrf_block(double* __restrict__ S, int nb, int kglobal, int* __restrict__ info, double* __restrict__ rdiag, int dbg)
+{
+    __shared__ double rd16[16];  // reciprocals of the current 16 pivots
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nbp = (nb + 15) & ~15;
     const int nt = nbp >> 4;
-    stage_lower_block<NB, PLD, POTRF_THREADS>(A, lda, nb, S, tid);
-    __syncthreads();
-
     for (int jb = 0; jb < nt; ++jb) {
         const int j0 = jb * 16;
         // (1) 16x16 diagonal piece, wave 0, row (lane & 15) per lane
@@ -446,7 +505,7 @@ __global__ __launch_bounds__(POTRF_THREADS) void k_potrf_diag(double* __restrict
             const int i = lane & 15;
             double a[16];
 #pragma unroll
-            for (int c = 0; c < 16; ++c) a[c] = S[(j0 + c) * PLD + j0 + i];
+            for (int c = 0; c < 16; ++c) a[c] = S[sidx<PACKED>(j0 + i, j0 + c)];
             int failed = -1;
             double rdk = 0.0;
 #pragma unroll
@@ -472,7 +531,7 @@ __global__ __launch_bounds__(POTRF_THREADS) void k_potrf_diag(double* __restrict
             }
             if (lane < 16) {
 #pragma unroll
-                for (int c = 0; c < 16; ++c) if (c <= i) S[(j0 + c) * PLD + j0 + i] = a[c];
+                for (int c = 0; c < 16; ++c) if (c <= i) S[sidx<PACKED>(j0 + i, j0 + c)] = a[c];
                 rd16[lane] = rdk;
                 if (j0 + lane < nb) rdiag[kglobal + j0 + lane] = rdk;
             }
@@ -485,17 +544,17 @@ __global__ __launch_bounds__(POTRF_THREADS) void k_potrf_diag(double* __restrict
             if (i < nbp && !(dbg & 2)) {
                 double x[16];
 #pragma unroll
-                for (int c = 0; c < 16; ++c) x[c] = S[(j0 + c) * PLD + i];
+                for (int c = 0; c < 16; ++c) x[c] = S[sidx<PACKED>(i, j0 + c)];
                 // right-looking (axpy) substitution: the updates of one column step are independent of each other
 #pragma unroll
                 for (int c = 0; c < 16; ++c) {
                     const double yc = x[c];              // LLT: y = x l_cc ; LDLT: y = x d_c
                     x[c] = yc * rd16[c];
 #pragma unroll
-                    for (int c2 = c + 1; c2 < 16; ++c2) x[c2] -= (LDLT ? yc : x[c]) * S[(j0 + c) * PLD + j0 + c2];
+                    for (int c2 = c + 1; c2 < 16; ++c2) x[c2] -= (LDLT ? yc : x[c]) * S[sidx<PACKED>(j0 + c2, j0 + c)];
                 }
 #pragma unroll
-                for (int c = 0; c < 16; ++c) S[(j0 + c) * PLD + i] = x[c];
+                for (int c = 0; c < 16; ++c) S[sidx<PACKED>(i, j0 + c)] = x[c];
             }
         }
         __syncthreads();
@@ -503,12 +562,12 @@ __global__ __launch_bounds__(POTRF_THREADS) void k_potrf_diag(double* __restrict
         {
             const int rem = nt - 1 - jb;
             const int ntile = (dbg & 4) ? 0 : rem * (rem + 1) / 2;
-            for (int t = wave; t < ntile; t += 2 * (POTRF_THREADS / 64)) {
+            for (int t = wave; t < ntile; t += 2 * (NTHREADS / 64)) {
                 int R0[2], C0[2];
                 bool on[2];
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
-                    const int tt = t + (POTRF_THREADS / 64) * u;
+                    const int tt = t + (NTHREADS / 64) * u;
                     on[u] = tt < ntile;
                     int tr = (int)((sqrtf(8.0f * (float)tt + 1.0f) - 1.0f) * 0.5f);
                     while ((tr + 1) * (tr + 2) / 2 <= tt) ++tr;
@@ -521,23 +580,32 @@ __global__ __launch_bounds__(POTRF_THREADS) void k_potrf_diag(double* __restrict
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
                     const int k = j0 + ks * 4 + (lane >> 4);
-                    const double dk = LDLT ? S[k * PLD + k] : 1.0;
-                    const double av0 = S[k * PLD + R0[0] + (lane & 15)], av1 = S[k * PLD + R0[1] + (lane & 15)];
-                    double bv0 = S[k * PLD + C0[0] + (lane & 15)], bv1 = S[k * PLD + C0[1] + (lane & 15)];
+                    const double dk = LDLT ? S[sidx<PACKED>(k, k)] : 1.0;
+                    const double av0 = S[sidx<PACKED>(R0[0] + (lane & 15), k)], av1 = S[sidx<PACKED>(R0[1] + (lane & 15), k)];
+                    double bv0 = S[sidx<PACKED>(C0[0] + (lane & 15), k)], bv1 = S[sidx<PACKED>(C0[1] + (lane & 15), k)];
                     if (LDLT) { bv0 *= dk; bv1 *= dk; }
                     acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(bv0, av0, acc0, 0, 0, 0);
                     acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(bv1, av1, acc1, 0, 0, 0);
                 }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) S[(C0[0] + (lane >> 4) + 4 * r) * PLD + R0[0] + (lane & 15)] -= acc0[r];
+                for (int r = 0; r < 4; ++r) S[sidx<PACKED>(R0[0] + (lane & 15), C0[0] + (lane >> 4) + 4 * r)] -= acc0[r];
                 if (on[1]) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) S[(C0[1] + (lane >> 4) + 4 * r) * PLD + R0[1] + (lane & 15)] -= acc1[r];
+                    for (int r = 0; r < 4; ++r) S[sidx<PACKED>(R0[1] + (lane & 15), C0[1] + (lane >> 4) + 4 * r)] -= acc1[r];
                 }
             }
         }
         __syncthreads();
     }
+}
+template <bool LDLT>
+__global__ __launch_bounds__(POTRF_THREADS) void k_potrf_diag(double* __restrict__ A, int lda, int nb, int kglobal, int* __restrict__ info, double* __restrict__ rdiag, int dbg)
+{
+    extern __shared__ __attribute__((aligned(16))) double S[];  // S[c * PLD + r]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    stage_lower_block<NB, PLD, POTRF_THREADS>(A, lda, nb, S, tid);
+    __syncthreads();
+    potrf_block<LDLT, POTRF_THREADS, false>(S, nb, kglobal, info, rdiag, dbg);
     for (int c = wave; c < nb; c += POTRF_THREADS / 64)
         for (int r = c + lane; r < nb; r += 64) A[r + (size_t)c * lda] = S[c * PLD + r];
 }
@@ -564,15 +632,14 @@ void launch_potrf_diag(bool ldlt, double* A, int lda, int nb, int kglobal, int* 
 constexpr int RB = 64;
 constexpr int XLD = RB + 16;
 constexpr int LSLD = NB + 16;  // leading dimension of the staged L11 strip (rows of L11 contiguous)
-constexpr int TRSM_LDS_BYTES = (NB * XLD + 16 * LSLD + 16) * (int)sizeof(double);
+constexpr int TRSM_LDS_BYTES = (NB * XLD + 2 * (16 * LSLD + 16)) * (int)sizeof(double);
 
 template <bool LDLT>
 __global__ __launch_bounds__(256) void k_trsm_panel(double* __restrict__ A, int lda, int k0, int nb, int n, const double* __restrict__ rdiag)
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double* Xs = sm;                  // Xs[c * XLD + r], c < nbp, r < RB
-    double* Ls = sm + NB * XLD;       // Ls[q * LSLD + rr] = L11[rr, j0 + q]  (rr >= j0), strip of 16 columns
-    double* rd = Ls + 16 * LSLD;      // reciprocal pivots of the strip
+    double* Ls0 = sm + NB * XLD;      // two buffers of { Ls[q * LSLD + rr] = L11[rr, j0 + q] (rr >= j0), strip of 16 columns; 16 reciprocal pivots }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nbp = (nb + 15) & ~15, nt = nbp >> 4;
     const int r0 = k0 + nb + blockIdx.x * RB;
@@ -594,31 +661,35 @@ __global__ __launch_bounds__(256) void k_trsm_panel(double* __restrict__ A, int 
             for (int u = 0; u < 16; ++u) Xs[(wave + 4 * (b0 + u)) * XLD + lane] = v[u];
         }
     }
+    // the 16-column strips of L11 are double-buffered: strip jb + 1 is in flight (registers) while strip jb is being used
+    auto load_strip = [&](int jb, double (&v)[8]) {
+        const int j0 = jb * 16;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int q = wave + 4 * (u >> 1);
+            const int rr = j0 + lane + 64 * (u & 1);
+            const bool ok = (rr < nb) && (j0 + q < nb);
+            const double* p = ok ? (L11 + rr + (size_t)(j0 + q) * lda) : L11;
+            const double t = *p;
+            v[u] = ok ? t : ((rr == j0 + q) ? 1.0 : 0.0);
+        }
+    };
+    double sv[8];
+    load_strip(0, sv);
     for (int jb = 0; jb < nt; ++jb) {
         const int j0 = jb * 16;
-        __syncthreads();
-        // stage the 16-column strip of L11 (rows j0 .. nbp) and its reciprocal pivots
-        {
-            // 16 columns x (nbp - j0) rows: 4 columns per wave, 2 row chunks -> 8 unconditional loads per thread
-            double v[8];
+        double* Ls = Ls0 + (jb & 1) * (16 * LSLD + 16);
+        double* rd = Ls + 16 * LSLD;
+        // strip jb -> LDS (the buffer was last read two steps ago), reciprocal pivots
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int q = wave + 4 * (u >> 1);
-                const int rr = j0 + lane + 64 * (u & 1);
-                const bool ok = (rr < nb) && (j0 + q < nb);
-                const double* p = ok ? (L11 + rr + (size_t)(j0 + q) * lda) : L11;
-                const double t = *p;
-                v[u] = ok ? t : ((rr == j0 + q) ? 1.0 : 0.0);
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int q = wave + 4 * (u >> 1);
-                const int rr = j0 + lane + 64 * (u & 1);
-                if (rr < nbp) Ls[q * LSLD + rr] = v[u];
-            }
+        for (int u = 0; u < 8; ++u) {
+            const int q = wave + 4 * (u >> 1);
+            const int rr = j0 + lane + 64 * (u & 1);
+            if (rr < nbp) Ls[q * LSLD + rr] = sv[u];
         }
         if (tid < 16) rd[tid] = (j0 + tid < nb) ? rdiag[k0 + j0 + tid] : 1.0;
         __syncthreads();
+        if (jb + 1 < nt) load_strip(jb + 1, sv);
         if (tid < RB) {
             double x[16];
 #pragma unroll
@@ -924,8 +995,18 @@ __global__ __launch_bounds__(256) void k_trsv_persistent(const double* __restric
             for (int c = 0; c < 64; ++c) lv[c] = (row < nrows) ? Lp[(size_t)c * ld] : 0.0;
         } else {    // transposed: L[c0 + half*64 + c, row0+row] (column row0+row of L, contiguous in c)
             const double* Lp = L + (c0 + half * 64) + (size_t)(row0 + row) * ld;
+            // every lane streams its own column, so one load instruction touches 64 cache lines: 16-byte loads halve the number of
+            // line requests (the texture path, not HBM, bounds this phase); possible when the column starts are 16-byte aligned
+            if (((ld & 1) == 0) && ((reinterpret_cast<uintptr_t>(L) & 15) == 0) && nc == TB && row < nrows) {
 #pragma unroll
-            for (int c = 0; c < 64; ++c) lv[c] = (row < nrows && half * 64 + c < nc) ? Lp[c] : 0.0;
+                for (int c = 0; c < 64; c += 2) {
+                    const d2 t = *reinterpret_cast<const d2*>(Lp + c);
+                    lv[c] = t.x; lv[c + 1] = t.y;
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 64; ++c) lv[c] = (row < nrows && half * 64 + c < nc) ? Lp[c] : 0.0;
+            }
         }
         if (tid == 0) {
             int ok = 1;

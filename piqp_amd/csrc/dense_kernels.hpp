@@ -6,7 +6,7 @@
 namespace pq {
 namespace dense {
 
-enum { EPI_ASSEMBLE = 0, EPI_SUBTRACT = 1, EPI_STORE = 2 };
+enum { EPI_ASSEMBLE = 0, EPI_SUBTRACT = 1, EPI_STORE = 2, EPI_SUBTRACT_POTRF = 3 };
 
 struct SyrkArgs {
     int n = 0;     // C is n x n, lower triangle written
@@ -27,6 +27,13 @@ struct SyrkArgs {
     int k_split = 1;
     double* part = nullptr;
     int first_col_only = 0;  // 1: only the tiles (ti, 0) of the first 128-column strip (panel look-ahead)
+    // EPI_SUBTRACT_POTRF: tile (0,0) of the trailing matrix is the NEXT diagonal block; the workgroup that updates it keeps it in
+    // LDS and factors it right away (the serial k_potrf_diag of the next panel disappears behind the rest of this launch)
+    int fuse_nb = 0;            // order of the next diagonal block (<= 128)
+    int fuse_kglobal = 0;       // global index of its first column
+    int fuse_ldlt = 0;
+    int* fuse_info = nullptr;
+    double* fuse_rdiag = nullptr;
 };
 
 void launch_syrk(int epi, const SyrkArgs& args, hipStream_t s, double* split_ws = nullptr, size_t split_ws_doubles = 0);

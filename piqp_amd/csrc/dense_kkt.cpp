@@ -189,6 +189,7 @@ private:
         flags_.alloc(2 * (size_t)((n_ + 127) / 128) + 1);
         if (const char* e = std::getenv("PIQP_AMD_TRSV")) use_persistent_trsv_ = std::string(e) != "steps";
         if (const char* e = std::getenv("PIQP_AMD_LOOKAHEAD")) lookahead_ = std::string(e) == "1";
+        if (const char* e = std::getenv("PIQP_AMD_FUSED_POTRF")) fused_potrf_ = std::string(e) != "0";
         make_aux_stream();
         x_reg_last_.zero(st_);
         fac_.zero(st_);
@@ -258,12 +259,14 @@ private:
         PQ_HIP(hipMemsetAsync(info_.p, 0xFF, sizeof(int), st_));  // -1
         const int NB = dense::FACTOR_NB;
         const bool la = lookahead_ && st2_ != nullptr && n_ > 3 * NB;
+        // fused: the trailing update of panel p also factors the diagonal block of panel p + 1 (dense_kernels.hpp EPI_SUBTRACT_POTRF)
+        const bool fused = fused_potrf_ && !la;
         int p = 0, last_rest = -1;
         for (int k = 0; k < n_; k += NB, ++p) {
             const int nb = (n_ - k < NB) ? n_ - k : NB;
             const int rs = n_ - k - nb;
             double* A11 = fac_.p + k + (size_t)k * n_;
-            dense::launch_potrf_diag(ldlt_, A11, n_, nb, k, info_.p, rdiag_.p, st_);
+            if (!fused || k == 0) dense::launch_potrf_diag(ldlt_, A11, n_, nb, k, info_.p, rdiag_.p, st_);
             if (rs <= 0) break;
             dense::launch_trsm_panel(ldlt_, fac_.p, n_, k, nb, n_, rdiag_.p, st_);
             dense::SyrkArgs a;
@@ -272,6 +275,11 @@ private:
             a.B = a.A; a.ldb = n_;
             if (ldlt_) { dense::launch_extract_diag(fac_.p, n_, k, nb, dvec_.p + k, st_); a.w = dvec_.p + k; }
             a.C = fac_.p + (k + nb) + (size_t)(k + nb) * n_; a.ldc = n_;
+            if (fused) {
+                a.fuse_nb = rs < NB ? rs : NB; a.fuse_kglobal = k + nb; a.fuse_ldlt = ldlt_ ? 1 : 0; a.fuse_info = info_.p; a.fuse_rdiag = rdiag_.p;
+                dense::launch_syrk(dense::EPI_SUBTRACT_POTRF, a, st_);
+                continue;
+            }
             if (!la) {
                 dense::launch_syrk(dense::EPI_SUBTRACT, a, st_);
                 continue;
@@ -313,6 +321,7 @@ private:
     HBuf<int> info_h_;
     StageProfiler prof_;
     bool use_persistent_trsv_ = true;
+    bool fused_potrf_ = true;  // PIQP_AMD_FUSED_POTRF=0: separate k_potrf_diag launches
     bool lookahead_ = false;  // cross-stream event latency on this stack exceeds the overlap gained (measured: 4.1 -> 4.6 ms at n = 4096)
     hipStream_t st2_ = nullptr;
     std::vector<hipEvent_t> ev_trsm_, ev_rest_;
