@@ -44,7 +44,7 @@ struct SnRec {  // everything the numeric kernels need about one supernode, in o
     int rel_ptr;    // offset into `rel` of this supernode's update rows inside its parent
     int parent;     // parent supernode (-1: root)
     long long front_off;
-    long long pad2;
+    int fe_lo, fe_hi;  // assembly entries of this supernode: values vals[fe_lo .. fe_hi) (the value array is stored in this order), front offsets fe_off[..]
 };
 struct FrontMeta {  // device-side views of the symbolic analysis
     const SnRec* sn;
@@ -145,9 +145,12 @@ __device__ void extend_add(const FrontMeta& M, double* __restrict__ fronts, int 
         const int uc = fc - wc;
         const double* U = fronts + ch.front_off + wc + (long long)wc * fc;
         const int* rel = M.rel + ch.rel_ptr;
-        for (int idx = threadIdx.x; idx < uc * uc; idx += blockDim.x) {
-            const int i = idx % uc, j = idx / uc;
-            if (i >= j) F[rel[i] + (long long)rel[j] * f] += U[i + (long long)j * fc];
+        {   // 16 x (threads / 16) thread grid over the lower triangle: no integer division in the index arithmetic
+            const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4, tys = blockDim.x >> 4;
+            for (int j = ty; j < uc; j += tys) {
+                const long long cj = (long long)rel[j] * f;
+                for (int i = j + tx; i < uc; i += 16) F[rel[i] + cj] += U[i + (long long)j * fc];
+            }
         }
         __syncthreads();
     }
@@ -168,7 +171,7 @@ __device__ void front_factor(const FrontMeta& M, double* __restrict__ fronts, in
     // assembly: zero, own K entries, then the children's update matrices (fixed order)
     for (int idx = threadIdx.x; idx < f * f; idx += blockDim.x) W[idx] = 0.0;
     __syncthreads();
-    for (int e = M.fe_ptr[s] + threadIdx.x; e < M.fe_ptr[s + 1]; e += blockDim.x) W[M.fe_off[e]] = M.vals[M.fe_q[e]];
+    for (int e = me.fe_lo + threadIdx.x; e < me.fe_hi; e += blockDim.x) W[M.fe_off[e]] = M.vals[e];
     __syncthreads();
     extend_add(M, fronts, s, W, f);
     // ---- panel: right-looking LDLt of the first w columns, updates confined to the panel (rows k+1..f-1, columns k+1..w-1)
@@ -182,15 +185,24 @@ __device__ void front_factor(const FrontMeta& M, double* __restrict__ fronts, in
         const double* colk = W + (k + 1) + (long long)k * f;
         // W[i,j] -= (a_i / d) * a_j for k < j < w, i >= j, with the UNSCALED column k (column k is final after this step: its
         // scaling by 1/d is deferred to one pass after the loop -> one barrier per pivot instead of two)
-        for (int idx = tid; idx < r * pc; idx += nt) {
-            const int i = idx % r, j = idx / r;
-            if (i >= j) W[(k + 1 + i) + (long long)(k + 1 + j) * f] -= (colk[i] * dinv) * colk[j];
+        {
+            const int tx = tid & 15, ty = tid >> 4, tys = nt >> 4;
+            for (int j = ty; j < pc; j += tys) {
+                const double cj = colk[j];
+                double* Wj = W + (k + 1) + (long long)(k + 1 + j) * f;
+                for (int i = j + tx; i < r; i += 16) Wj[i] -= (colk[i] * dinv) * cj;
+            }
         }
         __syncthreads();
     }
-    for (int idx = tid; idx < f * w; idx += nt) {
-        const int i = idx % f, k = idx / f;
-        if (i > k) { double d = W[k + (long long)k * f]; if (d == 0.0) d = 1.0; W[i + (long long)k * f] *= 1.0 / d; }
+    {
+        const int tx = tid & 15, ty = tid >> 4, tys = nt >> 4;
+        for (int k = ty; k < w; k += tys) {
+            double d = W[k + (long long)k * f];
+            if (d == 0.0) d = 1.0;
+            const double dinv = 1.0 / d;
+            for (int i = k + 1 + tx; i < f; i += 16) W[i + (long long)k * f] *= dinv;
+        }
     }
     __syncthreads();
     // ---- Schur complement of the trailing block in one pass: T[i,j] -= sum_k L[i,k] d_k L[j,k]  (no barriers, long dot products)
@@ -245,7 +257,7 @@ __global__ __launch_bounds__(SUB_THREADS) void k_subtree_factor_lds(FrontMeta M,
         double* W = cur;
         for (int idx = tid; idx < f * f; idx += nt) W[idx] = 0.0;
         __syncthreads();
-        for (int e = fe_ptr[s] + tid; e < fe_ptr[s + 1]; e += nt) W[fe_off[e]] = vals[fe_q[e]];
+        for (int e = me.fe_lo + tid; e < me.fe_hi; e += nt) W[fe_off[e]] = vals[e];
         __syncthreads();
         for (int ci = me.child_lo; ci < me.child_hi; ++ci) {
             const int c = M.child[ci];
@@ -254,9 +266,12 @@ __global__ __launch_bounds__(SUB_THREADS) void k_subtree_factor_lds(FrontMeta M,
             const bool from_lds = prev_valid && c == s - 1;
             const double* U = from_lds ? prev + wc + wc * fc : fronts + ch.front_off + wc + (long long)wc * fc;
             const int* rel = M.rel + ch.rel_ptr;
-            for (int idx = tid; idx < uc * uc; idx += nt) {
-                const int i = idx % uc, j = idx / uc;
-                if (i >= j) W[rel[i] + rel[j] * f] += U[i + (long long)j * fc];
+            {
+                const int tx = tid & 15, ty = tid >> 4, tys = nt >> 4;
+                for (int j = ty; j < uc; j += tys) {
+                    const int cj = rel[j] * f;
+                    for (int i = j + tx; i < uc; i += 16) W[rel[i] + cj] += U[i + (long long)j * fc];
+                }
             }
             __syncthreads();
         }
@@ -269,15 +284,24 @@ __global__ __launch_bounds__(SUB_THREADS) void k_subtree_factor_lds(FrontMeta M,
             if (tid == 0) rdiag[first + k] = dinv;
             const int r = f - k - 1, pc = w - k - 1;
             const double* colk = W + (k + 1) + k * f;
-            for (int idx = tid; idx < r * pc; idx += nt) {
-                const int i = idx % r, j = idx / r;
-                if (i >= j) W[(k + 1 + i) + (k + 1 + j) * f] -= (colk[i] * dinv) * colk[j];
+            {
+                const int tx = tid & 15, ty = tid >> 4, tys = nt >> 4;
+                for (int j = ty; j < pc; j += tys) {
+                    const double cj = colk[j];
+                    double* Wj = W + (k + 1) + (k + 1 + j) * f;
+                    for (int i = j + tx; i < r; i += 16) Wj[i] -= (colk[i] * dinv) * cj;
+                }
             }
             __syncthreads();
         }
-        for (int idx = tid; idx < f * w; idx += nt) {  // deferred scaling of the finished columns (see front_factor)
-            const int i = idx % f, k = idx / f;
-            if (i > k) { double d = W[k + k * f]; if (d == 0.0) d = 1.0; W[i + k * f] *= 1.0 / d; }
+        {   // deferred scaling of the finished columns (see front_factor)
+            const int tx = tid & 15, ty = tid >> 4, tys = nt >> 4;
+            for (int k = ty; k < w; k += tys) {
+                double d = W[k + k * f];
+                if (d == 0.0) d = 1.0;
+                const double dinv = 1.0 / d;
+                for (int i = k + 1 + tx; i < f; i += 16) W[i + k * f] *= dinv;
+            }
         }
         __syncthreads();
         // ---- Schur complement
@@ -299,10 +323,9 @@ __global__ __launch_bounds__(SUB_THREADS) void k_subtree_factor_lds(FrontMeta M,
         for (int idx = tid; idx < f * w; idx += nt) F[idx] = W[idx];
         const bool keep = me.parent == s + 1 && s + 1 <= hi;
         if (!keep && u > 0) {
-            for (int idx = tid; idx < u * u; idx += nt) {
-                const int i = idx % u, j = idx / u;
-                if (i >= j) F[(w + i) + (long long)(w + j) * f] = W[(w + i) + (w + j) * f];
-            }
+            const int tx = tid & 15, ty = tid >> 4, tys = nt >> 4;
+            for (int j = ty; j < u; j += tys)
+                for (int i = j + tx; i < u; i += 16) F[(w + i) + (long long)(w + j) * f] = W[(w + i) + (w + j) * f];
         }
         __syncthreads();
         double* t = cur; cur = prev; prev = t;
@@ -346,7 +369,7 @@ __global__ __launch_bounds__(SUB_THREADS) void k_subtree_factor_staged(FrontMeta
     const int r0 = first_rec.rel_ptr, r1 = last_rec.rel_ptr + (last_rec.f - last_rec.w);
     for (int i = tid; i < nsn; i += nt) rec_s[i] = M.sn[lo + i];
     for (int i = tid; i <= nsn; i += nt) feptr_s[i] = M.fe_ptr[lo + i] - e0;
-    for (int e = e0 + tid; e < e1; e += nt) { off_s[e - e0] = M.fe_off[e]; vals_s[e - e0] = M.vals[M.fe_q[e]]; }
+    for (int e = e0 + tid; e < e1; e += nt) { off_s[e - e0] = M.fe_off[e]; vals_s[e - e0] = M.vals[e]; }
     for (int i = r0 + tid; i < r1; i += nt) rel_s[i - r0] = M.rel[i];
     __syncthreads();
     bool prev_valid = false;
@@ -365,9 +388,12 @@ __global__ __launch_bounds__(SUB_THREADS) void k_subtree_factor_staged(FrontMeta
             const bool from_lds = prev_valid && c == s - 1;
             const double* U = from_lds ? prev + wc + wc * fc : fronts + ch.front_off + wc + (long long)wc * fc;
             const int* rel = rel_s + (ch.rel_ptr - r0);
-            for (int idx = tid; idx < uc * uc; idx += nt) {
-                const int i = idx % uc, j = idx / uc;
-                if (i >= j) W[rel[i] + rel[j] * f] += U[i + (long long)j * fc];
+            {
+                const int tx = tid & 15, ty = tid >> 4, tys = nt >> 4;
+                for (int j = ty; j < uc; j += tys) {
+                    const int cj = rel[j] * f;
+                    for (int i = j + tx; i < uc; i += 16) W[rel[i] + cj] += U[i + (long long)j * fc];
+                }
             }
             __syncthreads();
         }
@@ -378,15 +404,24 @@ __global__ __launch_bounds__(SUB_THREADS) void k_subtree_factor_staged(FrontMeta
             if (tid == 0) rdiag[first + k] = dinv;
             const int r = f - k - 1, pc = w - k - 1;
             const double* colk = W + (k + 1) + k * f;
-            for (int idx = tid; idx < r * pc; idx += nt) {
-                const int i = idx % r, j = idx / r;
-                if (i >= j) W[(k + 1 + i) + (k + 1 + j) * f] -= (colk[i] * dinv) * colk[j];
+            {
+                const int tx = tid & 15, ty = tid >> 4, tys = nt >> 4;
+                for (int j = ty; j < pc; j += tys) {
+                    const double cj = colk[j];
+                    double* Wj = W + (k + 1) + (k + 1 + j) * f;
+                    for (int i = j + tx; i < r; i += 16) Wj[i] -= (colk[i] * dinv) * cj;
+                }
             }
             __syncthreads();
         }
-        for (int idx = tid; idx < f * w; idx += nt) {
-            const int i = idx % f, k = idx / f;
-            if (i > k) { double d = W[k + k * f]; if (d == 0.0) d = 1.0; W[i + k * f] *= 1.0 / d; }
+        {   // deferred scaling of the finished columns (see front_factor)
+            const int tx = tid & 15, ty = tid >> 4, tys = nt >> 4;
+            for (int k = ty; k < w; k += tys) {
+                double d = W[k + k * f];
+                if (d == 0.0) d = 1.0;
+                const double dinv = 1.0 / d;
+                for (int i = k + 1 + tx; i < f; i += 16) W[i + k * f] *= dinv;
+            }
         }
         __syncthreads();
         const int u = f - w;
@@ -406,10 +441,9 @@ __global__ __launch_bounds__(SUB_THREADS) void k_subtree_factor_staged(FrontMeta
         for (int idx = tid; idx < f * w; idx += nt) F[idx] = W[idx];
         const bool keep = me.parent == s + 1 && s + 1 <= hi;
         if (!keep && u > 0) {
-            for (int idx = tid; idx < u * u; idx += nt) {
-                const int i = idx % u, j = idx / u;
-                if (i >= j) F[(w + i) + (long long)(w + j) * f] = W[(w + i) + (w + j) * f];
-            }
+            const int tx = tid & 15, ty = tid >> 4, tys = nt >> 4;
+            for (int j = ty; j < u; j += tys)
+                for (int i = j + tx; i < u; i += 16) F[(w + i) + (long long)(w + j) * f] = W[(w + i) + (w + j) * f];
         }
         __syncthreads();
         double* t = cur; cur = prev; prev = t;
@@ -435,8 +469,9 @@ __global__ __launch_bounds__(SUB_THREADS) void k_subtree_factor(FrontMeta M, dou
 // own K entries of ONE front that the dense multi-workgroup path factors (the front was zeroed by a memset on the stream)
 __global__ void k_front_assemble(FrontMeta M, double* __restrict__ fronts, int s)
 {
-    double* F = fronts + M.sn[s].front_off;
-    for (int e = M.fe_ptr[s] + blockIdx.x * blockDim.x + threadIdx.x; e < M.fe_ptr[s + 1]; e += gridDim.x * blockDim.x) F[M.fe_off[e]] = M.vals[M.fe_q[e]];
+    const SnRec me = M.sn[s];
+    double* F = fronts + me.front_off;
+    for (int e = me.fe_lo + blockIdx.x * blockDim.x + threadIdx.x; e < me.fe_hi; e += gridDim.x * blockDim.x) F[M.fe_off[e]] = M.vals[e];
 }
 __global__ __launch_bounds__(256) void k_front_extend_add_child(FrontMeta M, double* __restrict__ fronts, int s, int c)
 {
@@ -1099,7 +1134,7 @@ private:
         cpi(mapAA_, o.mapAA_); cpi(mapGG_, o.mapGG_); cpi(aa_ptr_, o.aa_ptr_); cpi(aa_q1_, o.aa_q1_); cpi(aa_q2_, o.aa_q2_); cpi(aa_k_, o.aa_k_);
         cpi(gg_ptr_, o.gg_ptr_); cpi(gg_q1_, o.gg_q1_); cpi(gg_q2_, o.gg_q2_); cpi(gg_k_, o.gg_k_);
         cpd(ata_vals_, o.ata_vals_); cpd(zinv_, o.zinv_); rhs_top_.alloc(o.rhs_top_.n ? o.rhs_top_.n : 1);
-        cpl(a_dst_, o.a_dst_); cpl(front_off_, o.front_off_);
+        cpl(front_off_, o.front_off_);
         info_.alloc(1); info_h_.alloc(1);
         build_full_schedule();
         PQ_HIP(hipStreamSynchronize(st_));
@@ -1293,7 +1328,7 @@ private:
     void build_device(const pq_sparse_data* d)
     {
         nnzK_ = S_.Cp[N_];
-        upload_vec(diag_pos_, S_.diag_pos, st_); upload_vec(P_, S_.P, st_); upload_vec(level_sn_, S_.top_level_sn, st_); {
+        upload_vec(P_, S_.P, st_); upload_vec(level_sn_, S_.top_level_sn, st_); {
             std::vector<int> tp(S_.nsuper ? S_.nsuper : 1, -1);
             for (size_t q = 0; q < S_.top_level_sn.size(); ++q) tp[S_.top_level_sn[q]] = (int)q;
             upload_vec(top_pos_, tp, st_);
@@ -1301,14 +1336,14 @@ private:
         }
         upload_vec(fe_ptr_, S_.fe_ptr, st_); upload_vec(fe_q_, S_.fe_q, st_); upload_vec(fe_off_, S_.fe_off, st_); upload_vec(sn_first_, S_.sn_first, st_);
         upload_vec(front_rows_ptr_, S_.front_rows_ptr, st_); upload_vec(front_rows_, S_.front_rows, st_); upload_vec(child_ptr_, S_.child_ptr, st_); upload_vec(child_, S_.child, st_);
-        upload_vec(rel_ptr_, S_.rel_ptr, st_); upload_vec(rel_, S_.rel, st_); upload_vec(a_dst_, S_.a_dst, st_); upload_vec(front_off_, S_.front_off, st_);
+        upload_vec(rel_ptr_, S_.rel_ptr, st_); upload_vec(rel_, S_.rel, st_); upload_vec(front_off_, S_.front_off, st_);
         {
             std::vector<SnRec> rec(S_.nsuper ? S_.nsuper : 1);
             for (int q = 0; q < S_.nsuper; ++q) {
                 SnRec& r = rec[q];
                 r.first = S_.sn_first[q]; r.w = S_.sn_first[q + 1] - S_.sn_first[q]; r.f = S_.front_rows_ptr[q + 1] - S_.front_rows_ptr[q];
                 r.rows_ptr = S_.front_rows_ptr[q]; r.child_lo = S_.child_ptr[q]; r.child_hi = S_.child_ptr[q + 1]; r.rel_ptr = S_.rel_ptr[q]; r.parent = S_.sn_parent[q];
-                r.front_off = S_.front_off[q]; r.pad2 = 0;
+                r.front_off = S_.front_off[q]; r.fe_lo = S_.fe_ptr[q]; r.fe_hi = S_.fe_ptr[q + 1];
             }
             upload_vec(snrec_, rec, st_);
         }
@@ -1321,15 +1356,24 @@ private:
         const int nzP = d->P_colptr[n_], nzA = p_ ? d->AT_colptr[p_] : 0, nzG = m_ ? d->GT_colptr[m_] : 0;
         const bool eq = mode_ & 1, ineq = mode_ & 2;
         std::vector<int> mp(nzP), ma(eq ? 0 : nzA), mg(ineq ? 0 : nzG);
-        for (int q = 0; q < nzP; ++q) mp[q] = S_.PKi[S_.P_utri_to_Ki[q]];
-        for (size_t q = 0; q < ma.size(); ++q) ma[q] = S_.PKi[S_.AT_to_Ki[q]];
-        for (size_t q = 0; q < mg.size(); ++q) mg[q] = S_.PKi[S_.GT_to_Ki[q]];
+        // the device value array is stored in FRONT order (position e of the assembly lists holds PKPt entry fe_q[e]): a front reads
+        // its own entries as one contiguous run instead of gathering them through an index list
+        std::vector<int> pos(nnzK_ ? nnzK_ : 1, 0);
+        for (int e = 0; e < nnzK_; ++e) pos[S_.fe_q[e]] = e;
+        {
+            std::vector<int> dp(S_.diag_pos.size());
+            for (size_t c = 0; c < dp.size(); ++c) dp[c] = pos[S_.diag_pos[c]];
+            upload_vec(diag_pos_, dp, st_);
+        }
+        for (int q = 0; q < nzP; ++q) mp[q] = pos[S_.PKi[S_.P_utri_to_Ki[q]]];
+        for (size_t q = 0; q < ma.size(); ++q) ma[q] = pos[S_.PKi[S_.AT_to_Ki[q]]];
+        for (size_t q = 0; q < mg.size(); ++q) mg[q] = pos[S_.PKi[S_.GT_to_Ki[q]]];
         upload_vec(mapP_, mp, st_); upload_vec(mapA_, ma, st_); upload_vec(mapG_, mg, st_);
         // eliminated blocks: entry -> PKPt index and product-term lists
         nzAA_ = (int)S_.gramA.rowind.size(); nzGG_ = (int)S_.gramG.rowind.size();
         std::vector<int> maa(nzAA_), mgg(nzGG_);
-        for (int e = 0; e < nzAA_; ++e) maa[e] = S_.PKi[S_.gramA_to_Ki[e]];
-        for (int e = 0; e < nzGG_; ++e) mgg[e] = S_.PKi[S_.gramG_to_Ki[e]];
+        for (int e = 0; e < nzAA_; ++e) maa[e] = pos[S_.PKi[S_.gramA_to_Ki[e]]];
+        for (int e = 0; e < nzGG_; ++e) mgg[e] = pos[S_.PKi[S_.gramG_to_Ki[e]]];
         upload_vec(mapAA_, maa, st_); upload_vec(mapGG_, mgg, st_);
         upload_vec(aa_ptr_, S_.gramA.ptr, st_); upload_vec(aa_q1_, S_.gramA.q1, st_); upload_vec(aa_q2_, S_.gramA.q2, st_); upload_vec(aa_k_, S_.gramA.k, st_);
         upload_vec(gg_ptr_, S_.gramG.ptr, st_); upload_vec(gg_q1_, S_.gramG.q1, st_); upload_vec(gg_q2_, S_.gramG.q2, st_); upload_vec(gg_k_, S_.gramG.k, st_);
@@ -1412,7 +1456,7 @@ private:
     DBuf<int> diag_pos_, P_, level_sn_, sn_first_, front_rows_ptr_, front_rows_, child_ptr_, child_, rel_ptr_, rel_;
     DBuf<int> mapP_, mapA_, mapG_, mapAA_, mapGG_, aa_ptr_, aa_q1_, aa_q2_, aa_k_, gg_ptr_, gg_q1_, gg_q2_, gg_k_;
     DBuf<double> ata_vals_, zinv_, rhs_top_;
-    DBuf<long long> a_dst_, front_off_;
+    DBuf<long long> front_off_;
     DBuf<int> info_;
     HBuf<int> info_h_;
     StageProfiler prof_;
