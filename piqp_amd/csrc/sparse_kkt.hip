@@ -971,17 +971,17 @@ public:
         }
         if (part_on_) {
             subtree_fwd(M, part_sched_);
-            fwd_levels(M, own_ptr_, own_sn_d_.p);
+            fwd_levels(M, own_ptr_, own_sn_, own_sn_d_.p);
             const int nb = (int)PT_.boundary.size();
             if (nb > 0) {
                 hipLaunchKernelGGL(k_pack_fvec, dim3(nb), dim3(64), 0, st_, M, fvec_.p, b_sn_.p, b_owner_.p, rank_, b_vec_off_.p, xbuf_forward_);
                 exchange(1);
                 hipLaunchKernelGGL(k_unpack_fvec, dim3(nb), dim3(64), 0, st_, M, fvec_.p, b_sn_.p, b_owner_.p, rank_, b_vec_off_.p, xbuf_forward_);
             }
-            fwd_levels(M, sh_ptr_, sh_sn_d_.p);
+            fwd_levels(M, sh_ptr_, sh_sn_, sh_sn_d_.p);
             hipLaunchKernelGGL(k_scale, g1(N_), dim3(256), 0, st_, N_, rdiag_.p, xp_.p);
-            bwd_levels(M, sh_ptr_, sh_sn_d_.p);
-            bwd_levels(M, own_ptr_, own_sn_d_.p);
+            bwd_levels(M, sh_ptr_, sh_sn_, sh_sn_d_.p);
+            bwd_levels(M, own_ptr_, own_sn_, own_sn_d_.p);
             subtree_bwd(M, part_sched_);
             if (world_ > 1) {
                 const int lo = PT_.span_lo[rank_], hi = PT_.span_hi[rank_];
@@ -996,13 +996,13 @@ public:
         if (top_solve_persistent) {
             PQ_HIP(hipMemsetAsync(top_flags_.p, 0, sizeof(int) * (2 * (size_t)ntop_ + 1), st_));
             hipLaunchKernelGGL(k_top_fwd, dim3(top_grid_), dim3(256), 0, st_, M, fronts_.p, level_sn_.p, ntop_, top_pos_.p, top_flags_.p, top_flags_.p + 2 * ntop_, xp_.p, fvec_.p);
-        } else fwd_levels(M, S_.top_level_ptr, level_sn_.p);
+        } else fwd_levels(M, S_.top_level_ptr, S_.top_level_sn, level_sn_.p);
         hipLaunchKernelGGL(k_scale, g1(N_), dim3(256), 0, st_, N_, rdiag_.p, xp_.p);
         if (top_solve_persistent)
         {
             hipLaunchKernelGGL(k_top_bwd, dim3(top_grid_), dim3(256), 0, st_, M, fronts_.p, level_sn_.p, ntop_, top_pos_.p, top_flags_.p + ntop_, top_flags_.p + 2 * ntop_, xp_.p, fvec_.p);
             hipLaunchKernelGGL(k_top_check, dim3(1), dim3(1), 0, st_, top_flags_.p + 2 * ntop_, (int*)nullptr, xp_.p);
-        } else bwd_levels(M, S_.top_level_ptr, level_sn_.p);
+        } else bwd_levels(M, S_.top_level_ptr, S_.top_level_sn, level_sn_.p);
         subtree_bwd(M, sched_);
         }
         if (mode_ == 0) {
@@ -1314,15 +1314,31 @@ private:
             }
         }
     }
-    void fwd_levels(const FrontMeta& M, const std::vector<int>& ptr, const int* sn_dev)
+    // a level whose fronts all have at most 128 rows runs the single-wave substitution (one wave per front, vector in registers: the same
+    // kernels as the subtree walk with lo = hi = the supernode); wider fronts keep the 256-thread kernels
+    bool level_is_narrow(const std::vector<int>& ptr, const std::vector<int>& sn, int l) const
     {
-        for (int l = 0; l + 1 < (int)ptr.size(); ++l)
-            if (ptr[l + 1] > ptr[l]) hipLaunchKernelGGL(k_front_fwd, dim3(ptr[l + 1] - ptr[l]), dim3(256), 0, st_, M, fronts_.p, sn_dev + ptr[l], xp_.p, fvec_.p);
+        if (std::getenv("PIQP_AMD_SUBTREE_SOLVE_V1")) return false;
+        for (int q = ptr[l]; q < ptr[l + 1]; ++q) if (S_.front_rows_ptr[sn[q] + 1] - S_.front_rows_ptr[sn[q]] > 128) return false;
+        return true;
     }
-    void bwd_levels(const FrontMeta& M, const std::vector<int>& ptr, const int* sn_dev)
+    void fwd_levels(const FrontMeta& M, const std::vector<int>& ptr, const std::vector<int>& sn, const int* sn_dev)
     {
-        for (int l = (int)ptr.size() - 2; l >= 0; --l)
-            if (ptr[l + 1] > ptr[l]) hipLaunchKernelGGL(k_front_bwd, dim3(ptr[l + 1] - ptr[l]), dim3(256), 0, st_, M, fronts_.p, sn_dev + ptr[l], xp_.p, fvec_.p);
+        for (int l = 0; l + 1 < (int)ptr.size(); ++l) {
+            const int cnt = ptr[l + 1] - ptr[l];
+            if (cnt <= 0) continue;
+            if (level_is_narrow(ptr, sn, l)) hipLaunchKernelGGL(k_subtree_fwd_wave, dim3(cnt), dim3(64), 0, st_, M, fronts_.p, sn_dev + ptr[l], sn_dev + ptr[l], xp_.p, fvec_.p);
+            else hipLaunchKernelGGL(k_front_fwd, dim3(cnt), dim3(256), 0, st_, M, fronts_.p, sn_dev + ptr[l], xp_.p, fvec_.p);
+        }
+    }
+    void bwd_levels(const FrontMeta& M, const std::vector<int>& ptr, const std::vector<int>& sn, const int* sn_dev)
+    {
+        for (int l = (int)ptr.size() - 2; l >= 0; --l) {
+            const int cnt = ptr[l + 1] - ptr[l];
+            if (cnt <= 0) continue;
+            if (level_is_narrow(ptr, sn, l)) hipLaunchKernelGGL(k_subtree_bwd_wave, dim3(cnt), dim3(64), 0, st_, M, fronts_.p, sn_dev + ptr[l], sn_dev + ptr[l], xp_.p);
+            else hipLaunchKernelGGL(k_front_bwd, dim3(cnt), dim3(256), 0, st_, M, fronts_.p, sn_dev + ptr[l], xp_.p, fvec_.p);
+        }
     }
 
     void build_device(const pq_sparse_data* d)
