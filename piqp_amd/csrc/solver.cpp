@@ -7,11 +7,31 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <thread>
 
 namespace pq {
 
 namespace {
 constexpr double PIQP_INF = 1e30;  // fwd.hpp:54
+// host-side data preparation (transposes, Ruiz passes over n x (n + p + m) dense data) runs on a few threads: chunks of columns are
+// independent and every reduction below is a max (exact, order-free), so the results do not depend on the thread count
+template <class F>
+void parallel_for(int count, long long work_per_item, F&& f)
+{
+    int T = (int)std::min<long long>(16, std::max(1u, std::thread::hardware_concurrency()));
+    if ((long long)count * work_per_item < (1LL << 18) || count < 2 * T) T = 1;
+    if (T <= 1) { f(0, count, 0); return; }
+    std::vector<std::thread> th;
+    const int chunk = (count + T - 1) / T;
+    for (int t = 0; t < T; ++t) {
+        const int lo = t * chunk, hi = std::min(count, lo + chunk);
+        if (lo >= hi) break;
+        th.emplace_back([&f, lo, hi, t] { f(lo, hi, t); });
+    }
+    for (auto& x : th) x.join();
+}
+constexpr int PF_MAX_THREADS = 16;
+
 inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 inline double dot(const Vec& a, const Vec& b, int n) { double s = 0.0; for (int i = 0; i < n; ++i) s += a[i] * b[i]; return s; }
 inline double min_coeff(const Vec& a, int n) { double r = a[0]; for (int i = 1; i < n; ++i) r = std::min(r, a[i]); return r; }
@@ -43,7 +63,7 @@ void HostData::set_h_u(const double* v)
     }
 }
 // dense/data.hpp:144-169 (rows with no finite side: zero the row of G, pretend h = (-1, 1))
-void HostData::disable_inf_constraints()
+bool HostData::disable_inf_constraints()
 {
     bool any = false;
     for (int i = 0; i < m; ++i) {
@@ -55,6 +75,7 @@ void HostData::disable_inf_constraints()
         }
     }
     if (any) { Vec hl = h_l, hu = h_u; set_h_l(hl.data()); set_h_u(hu.data()); }
+    return any;
 }
 // dense/data.hpp:171-207
 void HostData::set_x_l(const double* v)
@@ -100,6 +121,18 @@ static void finish_data(HostData& d, const double* c, const double* b, const dou
     d.set_h_l(h_l); d.set_h_u(h_u); d.disable_inf_constraints(); d.set_x_l(x_l); d.set_x_u(x_u);
 }
 
+// MT(i, k) = M(k, i) for a rows x n column-major M: 32 x 32 tiles keep both sides of the transpose in cache
+static void transpose_into(int n, const double* M, int rows, Vec& MT)
+{
+    MT.resize((size_t)n * rows);
+    parallel_for((rows + 31) / 32, 32LL * n, [&](int lo, int hi, int) {
+        for (int kb = lo * 32; kb < std::min(rows, hi * 32); kb += 32)
+            for (int ib = 0; ib < n; ib += 32)
+                for (int k = kb; k < std::min(rows, kb + 32); ++k)
+                    for (int i = ib; i < std::min(n, ib + 32); ++i) MT[i + (size_t)k * n] = M[k + (size_t)i * rows];
+    });
+}
+
 // solver.hpp:169-192 (DenseSolver): P_utri = upper(P), AT = A^T, GT = G^T
 std::unique_ptr<HostData> make_dense_host_data(int n, int p, int m, const double* P, const double* c, const double* A, const double* b, const double* G, const double* h_l,
                                                const double* h_u, const double* x_l, const double* x_u)
@@ -108,11 +141,9 @@ std::unique_ptr<HostData> make_dense_host_data(int n, int p, int m, const double
     d->sparse = false; d->n = n; d->p = A ? p : 0; d->m = G ? m : 0;
     p = d->p; m = d->m;
     d->P_utri.assign((size_t)n * n, 0.0);
-    for (int j = 0; j < n; ++j) for (int i = 0; i <= j; ++i) d->P_utri[i + (size_t)j * n] = P[i + (size_t)j * n];
-    d->AT.assign((size_t)n * p, 0.0);
-    for (int k = 0; k < p; ++k) for (int i = 0; i < n; ++i) d->AT[i + (size_t)k * n] = A[k + (size_t)i * p];
-    d->GT.assign((size_t)n * m, 0.0);
-    for (int k = 0; k < m; ++k) for (int i = 0; i < n; ++i) d->GT[i + (size_t)k * n] = G[k + (size_t)i * m];
+    parallel_for(n, n, [&](int lo, int hi, int) { for (int j = lo; j < hi; ++j) for (int i = 0; i <= j; ++i) d->P_utri[i + (size_t)j * n] = P[i + (size_t)j * n]; });
+    if (p > 0) transpose_into(n, A, p, d->AT); else d->AT.clear();
+    if (m > 0) transpose_into(n, G, m, d->GT); else d->GT.clear();
     d->resize_vectors();
     finish_data(*d, c, b, h_l, h_u, x_l, x_u);
     return d;
@@ -169,8 +200,10 @@ void scale_P(HostData& d, const double* s)
 {
     const int n = d.n;
     if (!d.sparse) {
-        for (int k = 0; k < n; ++k) { double* col = d.P_utri.data() + (size_t)k * n; for (int i = 0; i <= k; ++i) col[i] *= s[k]; }
-        for (int k = 0; k < n; ++k) for (int j = k; j < n; ++j) d.P_utri[k + (size_t)j * n] *= s[k];
+        // column scaling first, then row scaling, per element (the order of the two products of the reference), one pass over the data
+        parallel_for(n, n, [&](int lo, int hi, int) {
+            for (int j = lo; j < hi; ++j) { double* col = d.P_utri.data() + (size_t)j * n; const double sj = s[j]; for (int i = 0; i <= j; ++i) col[i] = (col[i] * sj) * s[i]; }
+        });
     } else {
         Csc& U = d.sP_utri;
         for (int j = 0; j < n; ++j) for (int q = U.colptr[j]; q < U.colptr[j + 1]; ++q) U.val[q] *= s[U.rowind[q]];
@@ -179,7 +212,7 @@ void scale_P(HostData& d, const double* s)
 }
 void scale_P_scalar(HostData& d, double g)
 {
-    if (!d.sparse) for (double& v : d.P_utri) v *= g;
+    if (!d.sparse) { const int n = d.n; parallel_for(n, n, [&](int lo, int hi, int) { for (size_t q = (size_t)lo * n; q < (size_t)hi * n; ++q) d.P_utri[q] *= g; }); }
     else for (double& v : d.sP_utri.val) v *= g;
 }
 void scale_T(HostData& d, bool isG, const double* srow, const double* scol)
@@ -187,12 +220,31 @@ void scale_T(HostData& d, bool isG, const double* srow, const double* scol)
     const int n = d.n, cols = isG ? d.m : d.p;
     if (!d.sparse) {
         Vec& M = isG ? d.GT : d.AT;
-        for (int j = 0; j < cols; ++j) { double* col = M.data() + (size_t)j * n; for (int i = 0; i < n; ++i) col[i] = (srow[i] * col[i]) * scol[j]; }
+        parallel_for(cols, n, [&](int lo, int hi, int) {
+            for (int j = lo; j < hi; ++j) { double* col = M.data() + (size_t)j * n; const double sc = scol[j]; for (int i = 0; i < n; ++i) col[i] = (srow[i] * col[i]) * sc; }
+        });
     } else {
         Csc& M = isG ? d.sGT : d.sAT;
         for (int j = 0; j < cols; ++j) for (int q = M.colptr[j]; q < M.colptr[j + 1]; ++q) M.val[q] *= srow[M.rowind[q]];
         for (int j = 0; j < cols; ++j) for (int q = M.colptr[j]; q < M.colptr[j + 1]; ++q) M.val[q] *= scol[j];
     }
+}
+// out[k] = inf-norm of column k of the symmetric matrix stored as the upper triangle of d.P_utri (dense)
+void sym_col_inf_norms(const HostData& d, double* out)
+{
+    const int n = d.n;
+    Vec part((size_t)PF_MAX_THREADS * n, 0.0);
+    parallel_for(n, n, [&](int lo, int hi, int t) {
+        double* loc = part.data() + (size_t)t * n;
+        for (int j = lo; j < hi; ++j) {
+            const double* col = d.P_utri.data() + (size_t)j * n;
+            double cm = 0.0;
+            for (int i = 0; i < j; ++i) { const double a = std::fabs(col[i]); cm = std::max(cm, a); loc[i] = std::max(loc[i], a); }
+            loc[j] = std::max(loc[j], std::max(cm, std::fabs(col[j])));
+        }
+    });
+    for (int k = 0; k < n; ++k) out[k] = 0.0;
+    for (int t = 0; t < PF_MAX_THREADS; ++t) { const double* loc = part.data() + (size_t)t * n; for (int k = 0; k < n; ++k) out[k] = std::max(out[k], loc[k]); }
 }
 }  // namespace
 
@@ -214,16 +266,26 @@ void Ruiz::scale_data(HostData& d, bool reuse_prev_scaling, bool scale_cost, int
             for (int i = 0; i < n; ++i) dev = std::max(dev, std::fabs(1.0 - dib[i]));
             if (!(dev > epsilon)) break;
             if (!d.sparse) {
-                for (int k = 0; k < n; ++k) {
-                    double v = 0.0;
-                    for (int i = 0; i < k; ++i) v = std::max(v, std::fabs(d.P_utri[i + (size_t)k * n]));
-                    for (int j = k; j < n; ++j) v = std::max(v, std::fabs(d.P_utri[k + (size_t)j * n]));
-                    for (int j = 0; j < p; ++j) v = std::max(v, std::fabs(d.AT[k + (size_t)j * n]));
-                    for (int j = 0; j < m; ++j) v = std::max(v, std::fabs(d.GT[k + (size_t)j * n]));
-                    di[k] = std::max(v, d.x_b_scaling[k]);
-                }
-                for (int k = 0; k < p; ++k) { double v = 0.0; for (int i = 0; i < n; ++i) v = std::max(v, std::fabs(d.AT[i + (size_t)k * n])); di[n + k] = v; }
-                for (int k = 0; k < m; ++k) { double v = 0.0; for (int i = 0; i < n; ++i) v = std::max(v, std::fabs(d.GT[i + (size_t)k * n])); di[n + p + k] = v; }
+                // inf-norms of the columns of [P; A; G] (P symmetric from its upper triangle) and of the rows of A, G: every matrix is walked
+                // once in storage order, per-thread partial maxima are combined afterwards (max is exact, so this equals the column-by-column
+                // evaluation of dense/preconditioner.hpp:88-111)
+                sym_col_inf_norms(d, di.data());
+                Vec part((size_t)PF_MAX_THREADS * n, 0.0);
+                auto rows_and_cols = [&](const Vec& MT, int cols, double* colnorm) {
+                    parallel_for(cols, n, [&](int lo, int hi, int t) {
+                        double* loc = part.data() + (size_t)t * n;
+                        for (int j = lo; j < hi; ++j) {
+                            const double* col = MT.data() + (size_t)j * n;
+                            double cm = 0.0;
+                            for (int i = 0; i < n; ++i) { const double a = std::fabs(col[i]); cm = std::max(cm, a); loc[i] = std::max(loc[i], a); }
+                            colnorm[j] = cm;
+                        }
+                    });
+                };
+                if (p > 0) rows_and_cols(d.AT, p, di.data() + n);
+                if (m > 0) rows_and_cols(d.GT, m, di.data() + n + p);
+                for (int t = 0; t < PF_MAX_THREADS; ++t) { const double* loc = part.data() + (size_t)t * n; for (int k = 0; k < n; ++k) di[k] = std::max(di[k], loc[k]); }
+                for (int k = 0; k < n; ++k) di[k] = std::max(di[k], d.x_b_scaling[k]);
             } else {
                 std::fill(di.begin(), di.end(), 0.0);
                 const Csc& U = d.sP_utri;
@@ -257,12 +319,9 @@ void Ruiz::scale_data(HostData& d, bool reuse_prev_scaling, bool scale_cost, int
             if (scale_cost) {
                 double gamma = 0.0;
                 if (!d.sparse) {
-                    for (int k = 0; k < n; ++k) {
-                        double a = 0.0, b2 = 0.0;
-                        for (int i = 0; i < k; ++i) a = std::max(a, std::fabs(d.P_utri[i + (size_t)k * n]));
-                        for (int j = k; j < n; ++j) b2 = std::max(b2, std::fabs(d.P_utri[k + (size_t)j * n]));
-                        gamma += std::max(a, b2);
-                    }
+                    Vec tmp(n, 0.0);
+                    sym_col_inf_norms(d, tmp.data());
+                    for (int k = 0; k < n; ++k) gamma += tmp[k];
                 } else {
                     Vec tmp(n, 0.0);
                     const Csc& U = d.sP_utri;
@@ -312,6 +371,23 @@ void Ruiz::unscale_data(HostData& d)
     for (int i = 0; i < m; ++i) { d.h_l[i] *= delta_inv[n + p + i]; d.h_u[i] *= delta_inv[n + p + i]; }
     for (int i = 0; i < d.n_x_l; ++i) d.x_l[i] *= delta_b_inv[d.x_l_idx[i]];
     for (int i = 0; i < d.n_x_u; ++i) d.x_u[i] *= delta_b_inv[d.x_u_idx[i]];
+}
+
+void Ruiz::unscale_vectors(HostData& d) const
+{
+    for (int i = 0; i < n; ++i) d.c[i] *= c_inv * delta_inv[i];
+    for (int i = 0; i < p; ++i) d.b[i] *= delta_inv[n + i];
+    for (int i = 0; i < m; ++i) { d.h_l[i] *= delta_inv[n + p + i]; d.h_u[i] *= delta_inv[n + p + i]; }
+    for (int i = 0; i < d.n_x_l; ++i) d.x_l[i] *= delta_b_inv[d.x_l_idx[i]];
+    for (int i = 0; i < d.n_x_u; ++i) d.x_u[i] *= delta_b_inv[d.x_u_idx[i]];
+}
+void Ruiz::scale_vectors(HostData& d) const
+{
+    for (int i = 0; i < n; ++i) d.c[i] *= c * delta[i];
+    for (int i = 0; i < p; ++i) d.b[i] *= delta[n + i];
+    for (int i = 0; i < m; ++i) { d.h_l[i] *= delta[n + p + i]; d.h_u[i] *= delta[n + p + i]; }
+    for (int i = 0; i < d.n_x_l; ++i) d.x_l[i] *= delta_b[d.x_l_idx[i]];
+    for (int i = 0; i < d.n_x_u; ++i) d.x_u[i] *= delta_b[d.x_u_idx[i]];
 }
 
 // ------------------------------------------------------------------ HostVars
@@ -446,6 +522,28 @@ static void refresh_kkt(Solver&, KKTSystem& k, const HostData& d, int options)
     k.set_bounds(d.n_h_l, d.n_h_u, d.n_x_l, d.n_x_u, d.h_l_idx.data(), d.h_u_idx.data(), d.x_l_idx.data(), d.x_u_idx.data(), d.x_b_scaling.data(), PQ_MEM_HOST);
 }
 
+// update() without a matrix argument (solver.hpp:218-308 with every optional matrix empty): the reference still unscales and rescales
+// P, A, G with the unchanged scaling (reuse_prev_scaling is forced, :283-285) -- the identity up to rounding, O(n (n + p + m)) host work
+// and a full re-upload here.  Only the vectors go through unscale -> assign -> scale; the matrices stay as they are on host and device.
+bool Solver::update_vectors_only(const double* c, const double* b, const double* h_l, const double* h_u, const double* x_l, const double* x_u, double t0)
+{
+    HostData& d = *m_data;
+    m_preconditioner.unscale_vectors(d);
+    if (c) std::copy(c, c + d.n, d.c.begin());
+    if (b) std::copy(b, b + d.p, d.b.begin());
+    if (h_l) d.set_h_l(h_l);
+    if (h_u) d.set_h_u(h_u);
+    const bool row_zeroed = (h_l || h_u) && d.disable_inf_constraints();  // a row of G without any finite bound is zeroed: that IS a matrix change
+    if (x_l) d.set_x_l(x_l);
+    if (x_u) d.set_x_u(x_u);
+    m_preconditioner.scale_vectors(d);
+    if (row_zeroed) { refresh_kkt(*this, *m_kkt_system, d, PQ_KKT_UPDATE_G); }
+    else m_kkt_system->set_bounds(d.n_h_l, d.n_h_u, d.n_x_l, d.n_x_u, d.h_l_idx.data(), d.h_u_idx.data(), d.x_l_idx.data(), d.x_u_idx.data(), d.x_b_scaling.data(), PQ_MEM_HOST);
+    if (dipm_) dipm_->refresh_data(d, m_preconditioner);
+    m_info.update_time = now_s() - t0;
+    return true;
+}
+
 // solver.hpp:218-308 with the dense update_P/A/G of :311-351
 bool Solver::update_dense(const double* P, const double* c, const double* A, const double* b, const double* G, const double* h_l, const double* h_u, const double* x_l,
                           const double* x_u)
@@ -454,11 +552,21 @@ bool Solver::update_dense(const double* P, const double* c, const double* A, con
     const double t0 = now_s();
     HostData& d = *m_data;
     const int n = d.n, p = d.p, m = d.m;
+    if (!P && !A && !G) return update_vectors_only(c, b, h_l, h_u, x_l, x_u, t0);
     m_preconditioner.unscale_data(d);
     int opt = PQ_KKT_UPDATE_NONE;
-    if (P) { std::fill(d.P_utri.begin(), d.P_utri.end(), 0.0); for (int j = 0; j < n; ++j) for (int i = 0; i <= j; ++i) d.P_utri[i + (size_t)j * n] = P[i + (size_t)j * n]; opt |= PQ_KKT_UPDATE_P; }
-    if (A) { for (int k = 0; k < p; ++k) for (int i = 0; i < n; ++i) d.AT[i + (size_t)k * n] = A[k + (size_t)i * p]; opt |= PQ_KKT_UPDATE_A; }
-    if (G) { for (int k = 0; k < m; ++k) for (int i = 0; i < n; ++i) d.GT[i + (size_t)k * n] = G[k + (size_t)i * m]; opt |= PQ_KKT_UPDATE_G; }
+    if (P) {
+        parallel_for(n, n, [&](int lo, int hi, int) {
+            for (int j = lo; j < hi; ++j) {
+                double* col = d.P_utri.data() + (size_t)j * n;
+                for (int i = 0; i <= j; ++i) col[i] = P[i + (size_t)j * n];
+                for (int i = j + 1; i < n; ++i) col[i] = 0.0;
+            }
+        });
+        opt |= PQ_KKT_UPDATE_P;
+    }
+    if (A) { transpose_into(n, A, p, d.AT); opt |= PQ_KKT_UPDATE_A; }
+    if (G) { transpose_into(n, G, m, d.GT); opt |= PQ_KKT_UPDATE_G; }
     if (c) std::copy(c, c + n, d.c.begin());
     if (b) std::copy(b, b + p, d.b.begin());
     if (h_l) d.set_h_l(h_l);
@@ -483,6 +591,7 @@ bool Solver::update_sparse(const int* Pp, const int* Pi, const double* Px, const
     const double t0 = now_s();
     HostData& d = *m_data;
     const int n = d.n, p = d.p, m = d.m;
+    if (!Px && !Ax && !Gx) return update_vectors_only(c, b, h_l, h_u, x_l, x_u, t0);
     m_preconditioner.unscale_data(d);
     int opt = PQ_KKT_UPDATE_NONE;
     (void)Pi;

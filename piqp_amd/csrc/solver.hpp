@@ -35,7 +35,7 @@ struct HostData {
     void resize_vectors();
     void set_h_l(const double* v);
     void set_h_u(const double* v);
-    void disable_inf_constraints();
+    bool disable_inf_constraints();  // true if a row was disabled (its G row zeroed)
     void set_x_l(const double* v);
     void set_x_u(const double* v);
     pq_dense_data dense_descriptor() const;
@@ -50,6 +50,9 @@ struct Ruiz {
     void init(const HostData& d);
     void scale_data(HostData& d, bool reuse_prev_scaling, bool scale_cost, int max_iter, double epsilon = 1e-3);
     void unscale_data(HostData& d);
+    // the vector part of unscale_data / scale_data(reuse): updates that touch no matrix leave the scaled matrices alone
+    void unscale_vectors(HostData& d) const;
+    void scale_vectors(HostData& d) const;
 };
 
 struct HostVars {
@@ -97,6 +100,7 @@ public:
 
 private:
     int solve_impl();
+    bool update_vectors_only(const double* c, const double* b, const double* h_l, const double* h_u, const double* x_l, const double* x_u, double t0);
     bool kkt_factor();
     void kkt_solve(const HostVars& rhs, HostVars& lhs);
     void eval_P_x(double alpha, const Vec& x, Vec& z);
