@@ -70,7 +70,8 @@ def test_default_settings_without_device():
         _fields_ = [("rho_init", C.c_double), ("delta_init", C.c_double), ("eps_abs", C.c_double), ("eps_rel", C.c_double), ("check_duality_gap", C.c_int),
                     ("eps_duality_gap_abs", C.c_double), ("eps_duality_gap_rel", C.c_double), ("infeasibility_threshold", C.c_double), ("reg_lower_limit", C.c_double),
                     ("reg_finetune_lower_limit", C.c_double), ("a", C.c_int), ("b", C.c_int), ("max_iter", C.c_int), ("max_factor_retires", C.c_int), ("c", C.c_int),
-                    ("d", C.c_int), ("preconditioner_iter", C.c_int), ("tau", C.c_double), ("kkt_solver", C.c_int)]
+                    ("d", C.c_int), ("preconditioner_iter", C.c_int), ("tau", C.c_double), ("kkt_solver", C.c_int),
+                    ("rest", C.c_byte * 128)]  # the remaining fields (the callee writes the whole piqp_settings)
     s = S()
     L.piqp_set_default_settings_sparse(C.byref(s))
     assert (s.rho_init, s.delta_init, s.eps_abs, s.eps_rel, s.max_iter, s.preconditioner_iter, s.tau, s.kkt_solver) == (1e-6, 1e-4, 1e-8, 1e-9, 250, 10, 0.99, 1)

@@ -47,7 +47,7 @@ def test_plan_chain(world):
     # contiguity: dropping the shared columns, the owner sequence is non-decreasing
     o = owner[owner >= 0]
     assert (np.diff(o) >= 0).all()
-    assert (owner < 0).sum() < 0.04 * owner.size
+    assert (owner < 0).sum() < 0.08 * owner.size
 
 
 @pytest.mark.parametrize("mode", [0, 3])
