@@ -431,7 +431,7 @@ void launch_assemble_no_g(int n, const double* Pf, const double* x_reg, const do
 // Stage the lower triangle of an nr x nr block (nr <= NBLK) into LDS as Ls[c * LD + r], zeros above the diagonal,
 // identity padding beyond nr.  All loads are unconditional (clamped address + select) and issued 16 at a time per
 // thread, so a thread has 16 L2 round trips in flight instead of one per loop iteration.
-template <int NBLK, int LD, int NT = 256>
+template <int NBLK, int LD, int NT = 256, bool TRANSPOSE = false>
 __device__ __forceinline__ void stage_lower_block(const double* __restrict__ A, int lda, int nr, double* __restrict__ Ls, int tid)
 {
     constexpr int PER_THREAD = NBLK * NBLK / NT;
@@ -451,7 +451,8 @@ __device__ __forceinline__ void stage_lower_block(const double* __restrict__ A, 
 #pragma unroll
         for (int u = 0; u < BATCH; ++u) {
             const int idx = (b0 + u) * NT + tid;
-            Ls[(idx / NBLK) * LD + (idx % NBLK)] = v[u];
+            if (TRANSPOSE) Ls[(idx % NBLK) * LD + (idx / NBLK)] = v[u];  // Ls[r * LD + c]: the backward sweep reads rows of L with consecutive lanes
+            else Ls[(idx / NBLK) * LD + (idx % NBLK)] = v[u];
         }
     }
 }
@@ -806,7 +807,8 @@ __device__ __forceinline__ void diag_solve_fwd(const double* __restrict__ Ls, co
         }
     }
 }
-// L^T y = b on the same staged block: k descending, b_i -= L[k,i] y_k for i < k, L[k,i] = Ls[i*(TB+1)+k]
+// L^T y = b on the block staged TRANSPOSED (Ls[k*(TB+1)+i] = L[k,i]): k descending, b_i -= L[k,i] y_k for i < k.  (Reading the
+// untransposed staging with a lane stride of 129 doubles put 64 lanes on 16 bank pairs: the backward sweep took twice the forward one.)
 __device__ __forceinline__ void diag_solve_bwd(const double* __restrict__ Ls, const double* __restrict__ rd, int lane, double& b0, double& b1)
 {
     constexpr int LD = 128 + 1;
@@ -816,13 +818,14 @@ __device__ __forceinline__ void diag_solve_bwd(const double* __restrict__ Ls, co
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const int k = kb * 16 + q;
-            l0[q] = (lane < k) ? Ls[lane * LD + k] : 0.0;
-            l1[q] = (lane + 64 < k) ? Ls[(lane + 64) * LD + k] : 0.0;
+            l0[q] = Ls[k * LD + lane];       // unconditional: the staging holds zeros above the diagonal, and a predicated LDS read
+            l1[q] = Ls[k * LD + lane + 64];  // per entry serialised 32 round trips per 16 columns (6 us per block instead of 1 us)
             rr[q] = rd[k];
         }
         if (kb >= 4) {
 #pragma unroll
-            for (int q = 15; q >= 0; --q) {
+            for (int u = 0; u < 16; ++u) {  // ascending trip count: a descending loop was left rolled and the register arrays went to scratch
+                const int q = 15 - u;
                 const int k = kb * 16 + q;
                 const double piv = readlane_d(b1, k - 64) * rr[q];
                 b1 = (lane + 64 == k) ? piv : b1 - l1[q] * piv;
@@ -830,7 +833,8 @@ __device__ __forceinline__ void diag_solve_bwd(const double* __restrict__ Ls, co
             }
         } else {
 #pragma unroll
-            for (int q = 15; q >= 0; --q) {
+            for (int u = 0; u < 16; ++u) {
+                const int q = 15 - u;
                 const int k = kb * 16 + q;
                 const double piv = readlane_d(b0, k) * rr[q];
                 b0 = (lane == k) ? piv : b0 - l0[q] * piv;
@@ -934,7 +938,7 @@ __global__ __launch_bounds__(256) void k_trsv_bwd_step(const double* __restrict_
         return;
     }
     if (tid < TB) { bs[tid] = mine; rd[tid] = (rdiag && tid < nrows) ? rdiag[row0 + tid] : 1.0; }
-    stage_lower_block<TB, TB + 1>(L + row0 + (size_t)row0 * ld, ld, nrows, Ls, tid);
+    stage_lower_block<TB, TB + 1, 256, true>(L + row0 + (size_t)row0 * ld, ld, nrows, Ls, tid);
     __syncthreads();
     if (wave == 0) {
         double b0 = bs[lane], b1 = bs[lane + 64];
@@ -965,7 +969,7 @@ __device__ __forceinline__ double ld_agent(const double* p)
 
 template <bool FWD>
 __global__ __launch_bounds__(256) void k_trsv_persistent(const double* __restrict__ L, int ld, int n, double* __restrict__ x, const double* __restrict__ rdiag,
-                                                         int nblk, int* __restrict__ flags, int* __restrict__ err)
+                                                         int nblk, int* __restrict__ flags, int* __restrict__ err, int dbg_skip_loads)
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double* Ls = sm;                    // own diagonal block, Ls[c * (TB+1) + r]
@@ -976,38 +980,52 @@ __global__ __launch_bounds__(256) void k_trsv_persistent(const double* __restric
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = FWD ? (int)blockIdx.x : nblk - 1 - (int)blockIdx.x;
     const int row0 = r * TB, nrows = min(TB, n - row0);
-    // stage the diagonal block and reciprocal pivots
-    stage_lower_block<TB, TB + 1>(L + row0 + (size_t)row0 * ld, ld, nrows, Ls, tid);
+    // stage the diagonal block (transposed for the backward sweep) and reciprocal pivots
+    stage_lower_block<TB, TB + 1, 256, !FWD>(L + row0 + (size_t)row0 * ld, ld, nrows, Ls, tid);
     if (tid < TB) rd[tid] = (rdiag && tid < nrows) ? rdiag[row0 + tid] : 1.0;
     const int row = tid & 127, half = tid >> 7;
     double mine = (half == 0 && row < nrows) ? x[row0 + row] : 0.0;
     double acc = 0.0;
     const int nsteps = FWD ? r : nblk - 1 - r;
-    for (int t = 0; t < nsteps; ++t) {
-        const int j = FWD ? t : nblk - 1 - t;  // producer block
+    // operand block of step t (producer block j_t) into registers; two steps are kept in flight: the block for step t + 1 is requested
+    // before the wait for x_{j_t}, so its latency never sits between the arrival of x and the hand-off to the next block
+    auto load_block = [&](int t, double (&lv)[64]) {
+        const int j = FWD ? t : nblk - 1 - t;
         const int c0 = j * TB;
         const int nc = min(TB, n - c0);
-        // operand block into registers BEFORE waiting for x_j
-        double lv[64];
         if (FWD) {  // rows of block r, columns of block j: L[row0+row, c0 + half*64 + c]
             const double* Lp = L + (row0 + row) + (size_t)(c0 + half * 64) * ld;
 #pragma unroll
             for (int c = 0; c < 64; ++c) lv[c] = (row < nrows) ? Lp[(size_t)c * ld] : 0.0;
         } else {    // transposed: L[c0 + half*64 + c, row0+row] (column row0+row of L, contiguous in c)
             const double* Lp = L + (c0 + half * 64) + (size_t)(row0 + row) * ld;
-            // every lane streams its own column, so one load instruction touches 64 cache lines: 16-byte loads halve the number of
-            // line requests (the texture path, not HBM, bounds this phase); possible when the column starts are 16-byte aligned
-            if (((ld & 1) == 0) && ((reinterpret_cast<uintptr_t>(L) & 15) == 0) && nc == TB && row < nrows) {
+            if (dbg_skip_loads & 1) {
+#pragma unroll
+                for (int c = 0; c < 64; ++c) lv[c] = 0.0;
+            } else if (((ld & 1) == 0) && ((reinterpret_cast<uintptr_t>(L) & 15) == 0) && nc == TB && row < nrows) {
 #pragma unroll
                 for (int c = 0; c < 64; c += 2) {
-                    const d2 t = *reinterpret_cast<const d2*>(Lp + c);
-                    lv[c] = t.x; lv[c + 1] = t.y;
+                    const d2 t2 = *reinterpret_cast<const d2*>(Lp + c);
+                    lv[c] = t2.x; lv[c + 1] = t2.y;
                 }
             } else {
 #pragma unroll
                 for (int c = 0; c < 64; ++c) lv[c] = (row < nrows && half * 64 + c < nc) ? Lp[c] : 0.0;
             }
         }
+    };
+    // workgroup barrier that waits for LDS traffic only: __syncthreads() also drains vmcnt, i.e. it would wait for the operand block
+    // requested for the NEXT step.  Everything exchanged between the waves inside the loop goes through LDS.
+    auto lds_barrier = [] {
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+        __builtin_amdgcn_s_barrier();
+    };
+    // consumes step t with the operand block lv; the request for step t + 1 (into nxt) is issued right AFTER the load of x_j, so that the
+    // in-order return of x_j does not wait behind it
+    auto consume = [&](int t, const double (&lv)[64], double (&nxt)[64], bool prefetch) -> bool {
+        const int j = FWD ? t : nblk - 1 - t;
+        const int c0 = j * TB;
+        const int nc = min(TB, n - c0);
         if (tid == 0) {
             int ok = 1;
             unsigned spins = 0;
@@ -1017,21 +1035,36 @@ __global__ __launch_bounds__(256) void k_trsv_persistent(const double* __restric
             }
             ok_s = ok;
         }
-        __syncthreads();
-        if (!ok_s) return;
-        if (tid < TB) xs[tid] = (tid < nc) ? ld_agent(x + c0 + tid) : 0.0;
-        __syncthreads();
+        lds_barrier();
+        if (!ok_s) return false;
+        const double xv = (tid < TB && tid < nc) ? ld_agent(x + c0 + tid) : 0.0;
+        if (prefetch) load_block(t + 1, nxt);
+        if (tid < TB) xs[tid] = xv;
+        lds_barrier();
 #pragma unroll
         for (int c = 0; c < 64; ++c) acc += lv[c] * xs[half * 64 + c];
-        __syncthreads();
+        lds_barrier();
+        return true;
+    };
+    {
+        double lvA[64], lvB[64];
+        if (nsteps > 0) load_block(0, lvA);
+        int t = 0;
+        for (; t + 1 < nsteps; t += 2) {
+            if (!consume(t, lvA, lvB, true)) return;
+            if (!consume(t + 1, lvB, lvA, t + 2 < nsteps)) return;
+        }
+        if (t < nsteps) { if (!consume(t, lvA, lvB, false)) return; }
     }
+    __syncthreads();
     if (half == 1) bs[row] = acc;
     __syncthreads();
     if (half == 0) bs[row] = mine - (acc + bs[row]);
     __syncthreads();
     if (wave == 0) {
         double b0 = bs[lane], b1 = bs[lane + 64];
-        if (FWD) diag_solve_fwd(Ls, rd, lane, b0, b1);
+        if (dbg_skip_loads & 2) { b0 *= rd[lane]; b1 *= rd[lane + 64]; }
+        else if (FWD || (dbg_skip_loads & 4)) diag_solve_fwd(Ls, rd, lane, b0, b1);
         else diag_solve_bwd(Ls, rd, lane, b0, b1);
         if (lane < nrows) st_agent(x + row0 + lane, b0);
         if (lane + 64 < nrows) st_agent(x + row0 + lane + 64, b1);
@@ -1064,9 +1097,9 @@ void launch_trsv(const double* L, int ld, int n, double* x, const double* rdiag,
     const bool persistent = flags != nullptr && nblk <= 224;  // every block resident (one per CU) with room to spare
     if (persistent) {
         PQ_HIP(hipMemsetAsync(flags, 0, sizeof(int) * (2 * nblk + 1), s));
-        hipLaunchKernelGGL(k_trsv_persistent<true>, dim3(nblk), dim3(256), TRSV_LDS_BYTES, s, L, ld, n, x, rd, nblk, flags, flags + 2 * nblk);
+        hipLaunchKernelGGL(k_trsv_persistent<true>, dim3(nblk), dim3(256), TRSV_LDS_BYTES, s, L, ld, n, x, rd, nblk, flags, flags + 2 * nblk, 0);
         if (ldlt) hipLaunchKernelGGL(k_mul_vec, dim3(div_up(n, 256)), dim3(256), 0, s, n, rdiag, x);
-        hipLaunchKernelGGL(k_trsv_persistent<false>, dim3(nblk), dim3(256), TRSV_LDS_BYTES, s, L, ld, n, x, rd, nblk, flags + nblk, flags + 2 * nblk);
+        hipLaunchKernelGGL(k_trsv_persistent<false>, dim3(nblk), dim3(256), TRSV_LDS_BYTES, s, L, ld, n, x, rd, nblk, flags + nblk, flags + 2 * nblk, std::getenv("PIQP_AMD_DBG_TRSV") ? std::atoi(std::getenv("PIQP_AMD_DBG_TRSV")) : 0);
     } else {
         for (int j = 0; j < nblk; ++j)
             hipLaunchKernelGGL(k_trsv_fwd_step, dim3(nblk - j), dim3(256), TRSV_LDS_BYTES, s, L, ld, n, x, rd, j);
