@@ -495,54 +495,97 @@ __device__ __forceinline__ int sidx(int r, int c)
 template <bool LDLT, int NTHREADS, bool PACKED>
 __device__ void potrf_block(double* __restrict__ S, int nb, int kglobal, int* __restrict__ info, double* __restrict__ rdiag, int dbg)
 {
+    (void)dbg;
     __shared__ double rd16[16];  // reciprocals of the current 16 pivots
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int NW = NTHREADS / 64;
     const int nbp = (nb + 15) & ~15;
     const int nt = nbp >> 4;
+
+    // (1) 16x16 diagonal piece jb, one wave, row (lane & 15) per lane, everything in registers
+    auto diag_piece = [&](int jb) {
+        const int j0 = jb * 16;
+        const int i = lane & 15;
+        double a[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) a[c] = S[sidx<PACKED>(j0 + i, j0 + c)];
+        int failed = -1;
+        double rdk = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            double dk = readlane_d(a[k], k);
+            const double yk = a[k];
+            double r;
+            if (!LDLT) {
+                if (!(dk > 0.0)) { if (failed < 0) failed = k; dk = 1.0; }
+                r = rsqrt_newton(dk);            // 1/l
+                a[k] = (i == k) ? dk * r : a[k] * r;
+            } else {
+                if (dk == 0.0) { if (failed < 0) failed = k; dk = 1.0; }
+                r = rcp_newton(dk);              // 1/d
+                a[k] = (i == k) ? dk : a[k] * r;
+            }
+            if (lane == k) rdk = r;
+#pragma unroll
+            for (int j = k + 1; j < 16; ++j) {
+                const double ljk = readlane_d(a[k], j);
+                a[j] -= (LDLT ? yk : a[k]) * ljk;
+            }
+        }
+        if (lane < 16) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) if (c <= i) S[sidx<PACKED>(j0 + i, j0 + c)] = a[c];
+            rd16[lane] = rdk;
+            if (j0 + lane < nb) rdiag[kglobal + j0 + lane] = rdk;
+        }
+        if (failed >= 0 && lane == 0 && j0 + failed < nb) { if (*info < 0) *info = kglobal + j0 + failed; }
+    };
+    // (3) one or two 16x16 tiles of the in-block trailing update of step jb: S(tr,tc) -= X_tr * (D) * X_tc^T on the matrix cores
+    auto update_tiles = [&](int jb, int t0, int t1, int ntile) {
+        const int j0 = jb * 16;
+        int R0[2], C0[2];
+        bool on[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int tt = u == 0 ? t0 : t1;
+            on[u] = tt >= 0 && tt < ntile;
+            int tr = (int)((sqrtf(8.0f * (float)(on[u] ? tt : 0) + 1.0f) - 1.0f) * 0.5f);
+            const int tq = on[u] ? tt : 0;
+            while ((tr + 1) * (tr + 2) / 2 <= tq) ++tr;
+            while (tr * (tr + 1) / 2 > tq) --tr;
+            const int tc = tq - tr * (tr + 1) / 2;
+            R0[u] = on[u] ? (jb + 1 + tr) * 16 : (jb + 1) * 16;
+            C0[u] = on[u] ? (jb + 1 + tc) * 16 : (jb + 1) * 16;
+        }
+        d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int k = j0 + ks * 4 + (lane >> 4);
+            const double dk = LDLT ? S[sidx<PACKED>(k, k)] : 1.0;
+            const double av0 = S[sidx<PACKED>(R0[0] + (lane & 15), k)], av1 = S[sidx<PACKED>(R0[1] + (lane & 15), k)];
+            double bv0 = S[sidx<PACKED>(C0[0] + (lane & 15), k)], bv1 = S[sidx<PACKED>(C0[1] + (lane & 15), k)];
+            if (LDLT) { bv0 *= dk; bv1 *= dk; }
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(bv0, av0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(bv1, av1, acc1, 0, 0, 0);
+        }
+        if (on[0]) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) S[sidx<PACKED>(R0[0] + (lane & 15), C0[0] + (lane >> 4) + 4 * r)] -= acc0[r];
+        }
+        if (on[1]) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) S[sidx<PACKED>(R0[1] + (lane & 15), C0[1] + (lane >> 4) + 4 * r)] -= acc1[r];
+        }
+    };
+
+    if (wave == 0) diag_piece(0);
+    __syncthreads();
     for (int jb = 0; jb < nt; ++jb) {
         const int j0 = jb * 16;
-        // (1) 16x16 diagonal piece, wave 0, row (lane & 15) per lane
-        if (wave == 0 && !(dbg & 1)) {
-            const int i = lane & 15;
-            double a[16];
-#pragma unroll
-            for (int c = 0; c < 16; ++c) a[c] = S[sidx<PACKED>(j0 + i, j0 + c)];
-            int failed = -1;
-            double rdk = 0.0;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                double dk = readlane_d(a[k], k);
-                const double yk = a[k];
-                double r;
-                if (!LDLT) {
-                    if (!(dk > 0.0)) { if (failed < 0) failed = k; dk = 1.0; }
-                    r = rsqrt_newton(dk);            // 1/l
-                    a[k] = (i == k) ? dk * r : a[k] * r;
-                } else {
-                    if (dk == 0.0) { if (failed < 0) failed = k; dk = 1.0; }
-                    r = rcp_newton(dk);              // 1/d
-                    a[k] = (i == k) ? dk : a[k] * r;
-                }
-                if (lane == k) rdk = r;
-#pragma unroll
-                for (int j = k + 1; j < 16; ++j) {
-                    const double ljk = readlane_d(a[k], j);
-                    a[j] -= (LDLT ? yk : a[k]) * ljk;
-                }
-            }
-            if (lane < 16) {
-#pragma unroll
-                for (int c = 0; c < 16; ++c) if (c <= i) S[sidx<PACKED>(j0 + i, j0 + c)] = a[c];
-                rd16[lane] = rdk;
-                if (j0 + lane < nb) rdiag[kglobal + j0 + lane] = rdk;
-            }
-            if (failed >= 0 && lane == 0 && j0 + failed < nb) { if (*info < 0) *info = kglobal + j0 + failed; }
-        }
-        __syncthreads();
         // (2) panel below the diagonal piece: X = A * Ljj^-T (LLT) / Y = A * Ljj^-T(unit), X = Y D^-1 (LDLT)
         {
             const int i = j0 + 16 + tid;
-            if (i < nbp && !(dbg & 2)) {
+            if (i < nbp) {
                 double x[16];
 #pragma unroll
                 for (int c = 0; c < 16; ++c) x[c] = S[sidx<PACKED>(i, j0 + c)];
@@ -559,41 +602,16 @@ __device__ void potrf_block(double* __restrict__ S, int nb, int kglobal, int* __
             }
         }
         __syncthreads();
-        // (3) trailing update inside the block with MFMA tiles: S(tr,tc) -= X_tr * (D) * X_tc^T
+        // (3) trailing update inside the block.  Wave 0 takes only tile 0 -- the next diagonal piece -- and factors it right away
+        // (step (1) of jb + 1), while the other waves work through the remaining tiles: the serial 16x16 factorisation is off
+        // the critical path and one barrier per step disappears.
         {
             const int rem = nt - 1 - jb;
-            const int ntile = (dbg & 4) ? 0 : rem * (rem + 1) / 2;
-            for (int t = wave; t < ntile; t += 2 * (NTHREADS / 64)) {
-                int R0[2], C0[2];
-                bool on[2];
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int tt = t + (NTHREADS / 64) * u;
-                    on[u] = tt < ntile;
-                    int tr = (int)((sqrtf(8.0f * (float)tt + 1.0f) - 1.0f) * 0.5f);
-                    while ((tr + 1) * (tr + 2) / 2 <= tt) ++tr;
-                    while (tr * (tr + 1) / 2 > tt) --tr;
-                    const int tc = tt - tr * (tr + 1) / 2;
-                    R0[u] = on[u] ? (jb + 1 + tr) * 16 : (jb + 1) * 16;
-                    C0[u] = on[u] ? (jb + 1 + tc) * 16 : (jb + 1) * 16;
-                }
-                d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    const int k = j0 + ks * 4 + (lane >> 4);
-                    const double dk = LDLT ? S[sidx<PACKED>(k, k)] : 1.0;
-                    const double av0 = S[sidx<PACKED>(R0[0] + (lane & 15), k)], av1 = S[sidx<PACKED>(R0[1] + (lane & 15), k)];
-                    double bv0 = S[sidx<PACKED>(C0[0] + (lane & 15), k)], bv1 = S[sidx<PACKED>(C0[1] + (lane & 15), k)];
-                    if (LDLT) { bv0 *= dk; bv1 *= dk; }
-                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(bv0, av0, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(bv1, av1, acc1, 0, 0, 0);
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) S[sidx<PACKED>(R0[0] + (lane & 15), C0[0] + (lane >> 4) + 4 * r)] -= acc0[r];
-                if (on[1]) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) S[sidx<PACKED>(R0[1] + (lane & 15), C0[1] + (lane >> 4) + 4 * r)] -= acc1[r];
-                }
+            const int ntile = rem * (rem + 1) / 2;
+            if (wave == 0) {
+                if (ntile > 0) { update_tiles(jb, 0, -1, ntile); diag_piece(jb + 1); }
+            } else {
+                for (int t = 1 + (wave - 1); t < ntile; t += 2 * (NW - 1)) update_tiles(jb, t, t + (NW - 1), ntile);
             }
         }
         __syncthreads();

@@ -878,7 +878,10 @@ public:
     ~SparseKKT() override
     {
         (void)hipSetDevice(dev_);
-        if (st_) { (void)hipStreamSynchronize(st_); (void)hipStreamDestroy(st_); }
+        if (st_) { (void)hipStreamSynchronize(st_); }
+        if (factor_graph_) (void)hipGraphExecDestroy(factor_graph_);
+        if (solve_graph_) (void)hipGraphExecDestroy(solve_graph_);
+        if (st_) (void)hipStreamDestroy(st_);
     }
 
     KKTSolverBase* clone() const override
@@ -934,16 +937,13 @@ public:
                 hipLaunchKernelGGL(k_unpack_updates, dim3(nb), dim3(256), 0, st_, M, fronts_.p, b_sn_.p, b_owner_.p, rank_, b_mat_off_.p, PT_.bmat_off.back(), info_.p, xbuf_factor_);
             }
             factor_levels(M, sh_ptr_, sh_sn_, sh_sn_d_.p, sh_lds_);
+        } else if (use_graphs_) {
+            // the numeric phase touches only handle-owned buffers: recorded once, replayed as one graph launch
+            if (!factor_graph_) factor_graph_ = capture([&] { factor_numeric(M); });
+            if (factor_graph_) PQ_HIP(hipGraphLaunch(factor_graph_, st_));
+            else factor_numeric(M);
         } else {
-            factor_subtrees(M, sched_);
-            // wide lower levels: one launch per level; the narrow levels near the root (<= 1024 supernodes in total): one persistent launch
-            factor_levels(M, S_.top_level_ptr, S_.top_level_sn, level_sn_.p, level_lds_, top_l0_);
-            if (top_nper_ > 0) {
-                PQ_HIP(hipMemsetAsync(top_flags_.p, 0, sizeof(int) * (2 * (size_t)ntop_ + 1), st_));
-                hipLaunchKernelGGL(k_top_factor, dim3(std::min(top_nper_, 224)), dim3(256), top_lds_, st_, M, fronts_.p, level_sn_.p + top_start_, top_nper_, top_pos_.p, top_start_,
-                                   top_flags_.p, top_flags_.p + 2 * ntop_, rdiag_.p, info_.p);
-                hipLaunchKernelGGL(k_top_check, dim3(1), dim3(1), 0, st_, top_flags_.p + 2 * ntop_, info_.p, (double*)nullptr);
-            }
+            factor_numeric(M);
         }
         PQ_HIP(hipGetLastError());
         prof_.end(1, t1, st_);
@@ -990,20 +990,12 @@ public:
                 hipLaunchKernelGGL(k_unpack_spans, dim3(std::max(1, std::min(256, (PT_.max_span + 255) / 256)), world_), dim3(256), 0, st_, world_, rank_, PT_.max_span, span_lo_d_.p,
                                    span_hi_d_.p, xbuf_gather_, xp_.p);
             }
+        } else if (use_graphs_) {
+            if (!solve_graph_) solve_graph_ = capture([&] { solve_numeric(M); });
+            if (solve_graph_) PQ_HIP(hipGraphLaunch(solve_graph_, st_));
+            else solve_numeric(M);
         } else {
-        subtree_fwd(M, sched_);
-        const bool top_solve_persistent = top_persistent_ && std::getenv("PIQP_AMD_TOP_SOLVE_PERSISTENT");
-        if (top_solve_persistent) {
-            PQ_HIP(hipMemsetAsync(top_flags_.p, 0, sizeof(int) * (2 * (size_t)ntop_ + 1), st_));
-            hipLaunchKernelGGL(k_top_fwd, dim3(top_grid_), dim3(256), 0, st_, M, fronts_.p, level_sn_.p, ntop_, top_pos_.p, top_flags_.p, top_flags_.p + 2 * ntop_, xp_.p, fvec_.p);
-        } else fwd_levels(M, S_.top_level_ptr, S_.top_level_sn, level_sn_.p);
-        hipLaunchKernelGGL(k_scale, g1(N_), dim3(256), 0, st_, N_, rdiag_.p, xp_.p);
-        if (top_solve_persistent)
-        {
-            hipLaunchKernelGGL(k_top_bwd, dim3(top_grid_), dim3(256), 0, st_, M, fronts_.p, level_sn_.p, ntop_, top_pos_.p, top_flags_.p + ntop_, top_flags_.p + 2 * ntop_, xp_.p, fvec_.p);
-            hipLaunchKernelGGL(k_top_check, dim3(1), dim3(1), 0, st_, top_flags_.p + 2 * ntop_, (int*)nullptr, xp_.p);
-        } else bwd_levels(M, S_.top_level_ptr, S_.top_level_sn, level_sn_.p);
-        subtree_bwd(M, sched_);
+            solve_numeric(M);
         }
         if (mode_ == 0) {
             hipLaunchKernelGGL(k_perm_scatter, g1(N_), dim3(256), 0, st_, N_, P_.p, xp_.p, lhs_x, n_, lhs_y, p_, lhs_z);
@@ -1201,6 +1193,49 @@ private:
 
     FrontMeta meta() const { return FrontMeta{snrec_.p, front_rows_.p, child_.p, rel_.p, fe_ptr_.p, fe_q_.p, fe_off_.p, vals_.p}; }
 
+    // numeric phase of the factorisation / substitution on handle-owned buffers only (so that they can be recorded as graphs)
+    void factor_numeric(const FrontMeta& M)
+    {
+        factor_subtrees(M, sched_);
+        // wide lower levels: one launch per level; the narrow levels near the root (<= 1024 supernodes in total): one persistent launch
+        factor_levels(M, S_.top_level_ptr, S_.top_level_sn, level_sn_.p, level_lds_, top_l0_);
+        if (top_nper_ > 0) {
+            PQ_HIP(hipMemsetAsync(top_flags_.p, 0, sizeof(int) * (2 * (size_t)ntop_ + 1), st_));
+            hipLaunchKernelGGL(k_top_factor, dim3(std::min(top_nper_, 224)), dim3(256), top_lds_, st_, M, fronts_.p, level_sn_.p + top_start_, top_nper_, top_pos_.p, top_start_,
+                               top_flags_.p, top_flags_.p + 2 * ntop_, rdiag_.p, info_.p);
+            hipLaunchKernelGGL(k_top_check, dim3(1), dim3(1), 0, st_, top_flags_.p + 2 * ntop_, info_.p, (double*)nullptr);
+        }
+    }
+    void solve_numeric(const FrontMeta& M)
+    {
+        subtree_fwd(M, sched_);
+        const bool top_solve_persistent = top_persistent_ && std::getenv("PIQP_AMD_TOP_SOLVE_PERSISTENT");
+        if (top_solve_persistent) {
+            PQ_HIP(hipMemsetAsync(top_flags_.p, 0, sizeof(int) * (2 * (size_t)ntop_ + 1), st_));
+            hipLaunchKernelGGL(k_top_fwd, dim3(top_grid_), dim3(256), 0, st_, M, fronts_.p, level_sn_.p, ntop_, top_pos_.p, top_flags_.p, top_flags_.p + 2 * ntop_, xp_.p, fvec_.p);
+        } else fwd_levels(M, S_.top_level_ptr, S_.top_level_sn, level_sn_.p);
+        hipLaunchKernelGGL(k_scale, g1(N_), dim3(256), 0, st_, N_, rdiag_.p, xp_.p);
+        if (top_solve_persistent) {
+            hipLaunchKernelGGL(k_top_bwd, dim3(top_grid_), dim3(256), 0, st_, M, fronts_.p, level_sn_.p, ntop_, top_pos_.p, top_flags_.p + ntop_, top_flags_.p + 2 * ntop_, xp_.p, fvec_.p);
+            hipLaunchKernelGGL(k_top_check, dim3(1), dim3(1), 0, st_, top_flags_.p + 2 * ntop_, (int*)nullptr, xp_.p);
+        } else bwd_levels(M, S_.top_level_ptr, S_.top_level_sn, level_sn_.p);
+        subtree_bwd(M, sched_);
+    }
+    // records what `body` launches on the handle's stream into an executable graph (nullptr if the runtime refuses: the caller then
+    // launches directly)
+    template <class F>
+    hipGraphExec_t capture(F&& body)
+    {
+        hipGraph_t g = nullptr;
+        hipGraphExec_t exec = nullptr;
+        if (hipStreamBeginCapture(st_, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); use_graphs_ = false; return nullptr; }
+        body();
+        if (hipStreamEndCapture(st_, &g) != hipSuccess || !g) { (void)hipGetLastError(); use_graphs_ = false; return nullptr; }
+        if (hipGraphInstantiate(&exec, g, nullptr, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); exec = nullptr; use_graphs_ = false; }
+        (void)hipGraphDestroy(g);
+        return exec;
+    }
+
     // data crosses ranks: the stream is drained, the caller's collective runs (pq_exchange_fn), then the stream continues
     void exchange(int which)
     {
@@ -1269,6 +1304,7 @@ private:
     }
     void build_full_schedule()
     {
+        { const char* e = std::getenv("PIQP_AMD_GRAPHS"); use_graphs_ = e && e[0] == '1'; }
         std::vector<int> all(S_.nsub);
         for (int k = 0; k < S_.nsub; ++k) all[k] = k;
         build_sub_schedule(all, sched_);
@@ -1476,6 +1512,8 @@ private:
     DBuf<int> info_;
     HBuf<int> info_h_;
     StageProfiler prof_;
+    bool use_graphs_ = false;
+    hipGraphExec_t factor_graph_ = nullptr, solve_graph_ = nullptr;
     // stage partition (pq_kkt_partition)
     bool part_on_ = false;
     int rank_ = 0, world_ = 1;
