@@ -42,6 +42,52 @@ def test_simple_qp_with_update(hip, orc):
     assert np.allclose(r["x"], kat["x_after_update"], atol=1e-6) and np.allclose(r["y"], kat["y_after_update"], atol=1e-6)
 
 
+@pytest.mark.parametrize("sparse", [False, True])
+def test_vector_only_updates_match_oracle(hip, orc, sparse):
+    """update() without a matrix takes the fast path (vectors rescaled, matrices untouched on host and device); a sequence of such updates
+    -- including bounds that change which rows / variables are bounded, and one that leaves a row of G without any finite bound (its row
+    is zeroed: data.hpp disable_inf_constraints) -- must track the oracle, which unscales and rescales everything every time"""
+    import scipy.sparse as sp
+    q = dense_strongly_convex_qp(30, 8, 14, seed=11)
+    P, c, A, b, G, h_l, h_u, x_l, x_u = (q[k] for k in ("P", "c", "A", "b", "G", "h_l", "h_u", "x_l", "x_u"))
+    if sparse:
+        args = (sp.csc_matrix(np.triu(P)), c, sp.csc_matrix(A), b, sp.csc_matrix(G), h_l, h_u, x_l, x_u)
+        sh, so = hip.SparseSolver(), orc.Solver()
+        sh.settings.kkt_solver = so.settings.kkt_solver = 1  # sparse_ldlt
+        assert sh.setup(*args) and so.setup(*args, sparse=True)
+    else:
+        sh, so = hip.DenseSolver(), orc.Solver()
+        assert sh.setup(P, c, A, b, G, h_l, h_u, x_l, x_u) and so.setup(P, c, A, b, G, h_l, h_u, x_l, x_u)
+    rng = np.random.default_rng(3)
+
+    def both_solve(stale_g_in_reference=False):
+        st_h, st_o = sh.solve(), so.solve()
+        assert st_h == st_o == 1
+        # After a bounds update has zeroed a row of G, the reference's sparse backends keep factoring the OLD row: update() passes
+        # KKT_UPDATE_NONE (solver.hpp:244-301 sets the G flag only when G is given) although disable_inf_constraints changed G.  The
+        # oracle restates that (62 instead of 8 iterations on this problem, same optimum); the device refreshes its copy of G.
+        if stale_g_in_reference: assert sh.info.iter <= so.info.iter + 1
+        else: assert abs(sh.info.iter - so.info.iter) <= 1
+        assert np.allclose(sh.result()["x"], so.result()["x"], atol=1e-6)
+        assert abs(sh.info.primal_obj - so.info.primal_obj) <= 1e-7 * max(1.0, abs(so.info.primal_obj))
+
+    both_solve()
+    c2 = c + 0.1 * rng.standard_normal(c.size)
+    assert sh.update(c=c2) and so.update(c=c2)
+    both_solve()
+    h_u2 = h_u.copy(); h_l2 = h_l.copy()
+    h_u2[np.isfinite(h_u2) & (h_u2 < 1e29)] += 0.05
+    x_u2 = x_u.copy(); x_u2[0] = 5.0 if x_u2[0] > 1e29 else inf   # flips which variables carry an upper bound
+    x_l2 = x_l.copy(); x_l2[1] = -5.0
+    assert sh.update(b=b * 1.0, h_l=h_l2, h_u=h_u2, x_l=x_l2, x_u=x_u2) and so.update(b=b * 1.0, h_l=h_l2, h_u=h_u2, x_l=x_l2, x_u=x_u2)
+    both_solve()
+    h_l3 = h_l2.copy(); h_u3 = h_u2.copy(); h_l3[2] = -inf; h_u3[2] = inf   # row 2 of G loses both bounds
+    assert sh.update(h_l=h_l3, h_u=h_u3) and so.update(h_l=h_l3, h_u=h_u3)
+    both_solve(stale_g_in_reference=sparse)
+    assert sh.update(c=c) and so.update(c=c)  # and a matrix-free update after the row was zeroed
+    both_solve(stale_g_in_reference=sparse)
+
+
 def test_infeasibility_statuses_and_infinity_bounds(hip):
     """dense/solver_test.cpp:103-154, 347-377"""
     P = np.array([[6.0, 0], [0, 4]]); c = np.array([-1.0, -4]); A = np.array([[1.0, -2]]); b = np.array([0.0])
