@@ -135,6 +135,46 @@ __global__ void k_scale(int N, const double* __restrict__ d, double* __restrict_
     if (j < N) x[j] *= d[j];
 }
 
+// 1 / d for a pivot: v_rcp_f64 + two Newton steps + one residual correction (an IEEE division is ~250 dependent cycles on the critical
+// path of every pivot; this is ~80 and agrees with it to the last bit except in rare half-ulp cases)
+__device__ __forceinline__ double pivot_rcp(double d)
+{
+    double y = __builtin_amdgcn_rcp(d);
+    y = __builtin_fma(__builtin_fma(-d, y, 1.0), y, y);
+    y = __builtin_fma(__builtin_fma(-d, y, 1.0), y, y);
+    return __builtin_fma(__builtin_fma(-d, y, 1.0), y, y);
+}
+
+// Schur complement of the trailing u x u block in one pass, T[i,j] -= sum_k (L[i,k] d_k) L[j,k] (k ascending, lower triangle), 2 x 2 entries
+// per thread: five LDS reads feed four FMAs instead of twelve
+__device__ __forceinline__ void schur_2x2(double* __restrict__ W, int f, int w, int u, int tid, int nt)
+{
+    const int tx = tid & 15, ty = tid >> 4, tys = nt >> 4;
+    const int nb = (u + 1) >> 1;
+    for (int bj = ty; bj < nb; bj += tys) {
+        for (int bi = bj + tx; bi < nb; bi += 16) {
+            const int i0 = 2 * bi, j0 = 2 * bj;
+            const bool i1ok = i0 + 1 < u, j1ok = j0 + 1 < u;
+            const double* Li0 = W + (w + i0);
+            const double* Li1 = W + (w + (i1ok ? i0 + 1 : i0));
+            const double* Lj0 = W + (w + j0);
+            const double* Lj1 = W + (w + (j1ok ? j0 + 1 : j0));
+            double a00 = 0.0, a01 = 0.0, a10 = 0.0, a11 = 0.0;
+            for (int k = 0; k < w; ++k) {
+                const long long ck = (long long)k * f;
+                const double dk = W[k + ck];
+                const double x0 = Li0[ck] * dk, x1 = Li1[ck] * dk, y0 = Lj0[ck], y1 = Lj1[ck];
+                a00 += x0 * y0; a01 += x0 * y1; a10 += x1 * y0; a11 += x1 * y1;
+            }
+            double* T = W + (w + i0) + (long long)(w + j0) * f;
+            T[0] -= a00;                                   // i0 >= j0 always
+            if (i1ok) T[1] -= a10;                         // (i0 + 1, j0)
+            if (j1ok && i0 >= j0 + 1) T[f] -= a01;         // (i0, j0 + 1): below / on the diagonal only
+            if (i1ok && j1ok) T[f + 1] -= a11;             // (i0 + 1, j0 + 1)
+        }
+    }
+}
+
 // extend-add of every child's update matrix into front s (fixed child order)
 __device__ void extend_add(const FrontMeta& M, double* __restrict__ fronts, int s, double* __restrict__ F, int f)
 {
@@ -179,7 +219,7 @@ __device__ void front_factor(const FrontMeta& M, double* __restrict__ fronts, in
     for (int k = 0; k < w; ++k) {
         double d = W[k + (long long)k * f];  // every thread reads the same word (broadcast)
         if (d == 0.0) { if (tid == 0 && *info < 0) *info = first + k; d = 1.0; }
-        const double dinv = 1.0 / d;
+        const double dinv = pivot_rcp(d);
         if (tid == 0) rdiag[first + k] = dinv;
         const int r = f - k - 1, pc = w - k - 1;
         const double* colk = W + (k + 1) + (long long)k * f;
@@ -200,7 +240,7 @@ __device__ void front_factor(const FrontMeta& M, double* __restrict__ fronts, in
         for (int k = ty; k < w; k += tys) {
             double d = W[k + (long long)k * f];
             if (d == 0.0) d = 1.0;
-            const double dinv = 1.0 / d;
+            const double dinv = pivot_rcp(d);
             for (int i = k + 1 + tx; i < f; i += 16) W[i + (long long)k * f] *= dinv;
         }
     }
@@ -208,18 +248,7 @@ __device__ void front_factor(const FrontMeta& M, double* __restrict__ fronts, in
     // ---- Schur complement of the trailing block in one pass: T[i,j] -= sum_k L[i,k] d_k L[j,k]  (no barriers, long dot products)
     const int u = f - w;
     if (u > 0) {
-        const int tx = tid & 15, ty = tid >> 4, tys = nt >> 4;
-        for (int j = ty; j < u; j += tys) {
-            for (int i = j - (j & 15) + tx; i < u; i += 16) {
-                if (i < j) continue;
-                double acc = 0.0;
-                for (int k = 0; k < w; ++k) {
-                    const double dk = W[k + (long long)k * f];
-                    acc += (W[(w + i) + (long long)k * f] * dk) * W[(w + j) + (long long)k * f];
-                }
-                W[(w + i) + (long long)(w + j) * f] -= acc;
-            }
-        }
+        schur_2x2(W, f, w, u, tid, nt);
         __syncthreads();
     }
     if (in_lds) {
@@ -280,7 +309,7 @@ __global__ __launch_bounds__(SUB_THREADS) void k_subtree_factor_lds(FrontMeta M,
         for (int k = 0; k < w; ++k) {
             double d = W[k + k * f];
             if (d == 0.0) { if (tid == 0 && *info < 0) *info = first + k; d = 1.0; }
-            const double dinv = 1.0 / d;
+            const double dinv = pivot_rcp(d);
             if (tid == 0) rdiag[first + k] = dinv;
             const int r = f - k - 1, pc = w - k - 1;
             const double* colk = W + (k + 1) + k * f;
@@ -299,7 +328,7 @@ __global__ __launch_bounds__(SUB_THREADS) void k_subtree_factor_lds(FrontMeta M,
             for (int k = ty; k < w; k += tys) {
                 double d = W[k + k * f];
                 if (d == 0.0) d = 1.0;
-                const double dinv = 1.0 / d;
+                const double dinv = pivot_rcp(d);
                 for (int i = k + 1 + tx; i < f; i += 16) W[i + k * f] *= dinv;
             }
         }
@@ -307,15 +336,7 @@ __global__ __launch_bounds__(SUB_THREADS) void k_subtree_factor_lds(FrontMeta M,
         // ---- Schur complement
         const int u = f - w;
         if (u > 0) {
-            const int tx = tid & 15, ty = tid >> 4, tys = nt >> 4;
-            for (int j = ty; j < u; j += tys) {
-                for (int i = j - (j & 15) + tx; i < u; i += 16) {
-                    if (i < j) continue;
-                    double acc = 0.0;
-                    for (int k = 0; k < w; ++k) acc += (W[(w + i) + k * f] * W[k + k * f]) * W[(w + j) + k * f];
-                    W[(w + i) + (w + j) * f] -= acc;
-                }
-            }
+            schur_2x2(W, f, w, u, tid, nt);
             __syncthreads();
         }
         // ---- factor panel to HBM (the first w columns of the front are contiguous); update matrix only if nobody reads it from LDS
@@ -400,7 +421,7 @@ __global__ __launch_bounds__(SUB_THREADS) void k_subtree_factor_staged(FrontMeta
         for (int k = 0; k < w; ++k) {
             double d = W[k + k * f];
             if (d == 0.0) { if (tid == 0 && *info < 0) *info = first + k; d = 1.0; }
-            const double dinv = 1.0 / d;
+            const double dinv = pivot_rcp(d);
             if (tid == 0) rdiag[first + k] = dinv;
             const int r = f - k - 1, pc = w - k - 1;
             const double* colk = W + (k + 1) + k * f;
@@ -419,22 +440,14 @@ __global__ __launch_bounds__(SUB_THREADS) void k_subtree_factor_staged(FrontMeta
             for (int k = ty; k < w; k += tys) {
                 double d = W[k + k * f];
                 if (d == 0.0) d = 1.0;
-                const double dinv = 1.0 / d;
+                const double dinv = pivot_rcp(d);
                 for (int i = k + 1 + tx; i < f; i += 16) W[i + k * f] *= dinv;
             }
         }
         __syncthreads();
         const int u = f - w;
         if (u > 0) {
-            const int tx = tid & 15, ty = tid >> 4, tys = nt >> 4;
-            for (int j = ty; j < u; j += tys) {
-                for (int i = j - (j & 15) + tx; i < u; i += 16) {
-                    if (i < j) continue;
-                    double acc = 0.0;
-                    for (int k = 0; k < w; ++k) acc += (W[(w + i) + k * f] * W[k + k * f]) * W[(w + j) + k * f];
-                    W[(w + i) + (w + j) * f] -= acc;
-                }
-            }
+            schur_2x2(W, f, w, u, tid, nt);
             __syncthreads();
         }
         double* F = fronts + me.front_off;
