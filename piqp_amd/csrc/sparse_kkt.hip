@@ -1296,6 +1296,18 @@ private:
             SubClass k;
             Need mx{0, 0, 0, 0};
             std::vector<int> lo, hi;
+            // longest subtrees first: the launch is a handful of rounds of workgroups, so the last round should hold the short walks
+            {
+                std::vector<double> work(subs.size(), 0.0);
+                for (int i : members[c]) {
+                    for (int t = S_.sub_lo[subs[i]]; t <= S_.sub_hi[subs[i]]; ++t) {
+                        const double w = S_.sn_first[t + 1] - S_.sn_first[t], f = S_.front_rows_ptr[t + 1] - S_.front_rows_ptr[t], u = f - w;
+                        work[i] += w * w * w / 3.0 + w * w * u + w * u * u + 2.0 * f * f + 3000.0;
+                    }
+                }
+                if (!std::getenv("PIQP_AMD_SUBTREE_POSTORDER"))
+                    std::stable_sort(members[c].begin(), members[c].end(), [&](int a, int b) { return work[a] > work[b]; });
+            }
             for (int i : members[c]) {
                 mx.fm = std::max(mx.fm, need[i].fm); mx.ent = std::max(mx.ent, need[i].ent); mx.rel = std::max(mx.rel, need[i].rel); mx.sn = std::max(mx.sn, need[i].sn);
                 lo.push_back(S_.sub_lo[subs[i]]); hi.push_back(S_.sub_hi[subs[i]]);
