@@ -700,7 +700,9 @@ static void analyse_with_order(Symbolic& S, const IVec& perm0)
     // columns and its parent's does not.  Supernodes are numbered in postorder, so a subtree is the contiguous range
     // [s - desc[s], s].
     {
-        const int SUB_COLS = 192, SUB_FMAX = 96;  // two 96 x 96 fronts fit the 160 KiB of LDS of one workgroup
+        int SUB_COLS = 192, SUB_FMAX = 96;  // two 96 x 96 fronts fit the 160 KiB of LDS of one workgroup
+        if (const char* e = std::getenv("PIQP_AMD_SUB_COLS")) SUB_COLS = std::max(8, std::atoi(e));
+        if (const char* e = std::getenv("PIQP_AMD_SUB_FMAX")) SUB_FMAX = std::min(96, std::max(8, std::atoi(e)));
         IVec cols(ns, 0), desc(ns, 0), fmax(ns, 0);
         for (int s = 0; s < ns; ++s) {
             cols[s] += S.sn_first[s + 1] - S.sn_first[s];
