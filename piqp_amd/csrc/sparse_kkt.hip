@@ -1100,6 +1100,17 @@ public:
     void print_info() override
     {
         std::printf("top of the tree: %d supernodes in %d levels: %d level launches, then %d supernodes in one persistent launch\n", ntop_, S_.top_nlevels, top_l0_, top_nper_);
+        if (std::getenv("PIQP_AMD_PRINT_LEVELS")) {
+            for (int l = 0; l < S_.top_nlevels; ++l) {
+                int mf = 0, mw = 0; double fl = 0.0;
+                for (int q = S_.top_level_ptr[l]; q < S_.top_level_ptr[l + 1]; ++q) {
+                    const int s2 = S_.top_level_sn[q];
+                    const int w = S_.sn_first[s2 + 1] - S_.sn_first[s2], f = S_.front_rows_ptr[s2 + 1] - S_.front_rows_ptr[s2];
+                    mf = std::max(mf, f); mw = std::max(mw, w); fl += (double)w * f * f;
+                }
+                std::printf("  top level %2d: %5d fronts, max front %4d, max pivots %3d, sum w f^2 = %.2e\n", l, S_.top_level_ptr[l + 1] - S_.top_level_ptr[l], mf, mw, fl);
+            }
+        }
         for (const SubClass& c : sched_.cls)
             std::printf("subtree walk class: %d subtrees, front capacity %d doubles, %d threads, %d bytes of LDS per workgroup%s\n", c.nsub, c.cap, c.threads, c.bytes,
                         c.staged ? " (metadata staged in LDS)" : "");
