@@ -129,6 +129,13 @@ def main():
                 traffic = pmc["assembly_per_step"]["traffic_bytes"]  # rocprofv3 PMC passes of this same workload (see file)
         except Exception:
             pass
+        mfma_busy = None
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_dense_mfma.json")))
+            if (n, m, p) == (4096, 4096, 0):
+                mfma_busy = [v for k, v in pm.items() if k.startswith("k_syrk_lower<EPI_ASSEMBLE")][0]["mfma_pipe_busy_fraction"]
+        except Exception:  # noqa: BLE001
+            pass
         out = {
             "metric": "KKT factor+solve/sec (per IPM iter)",
             "value": value,
@@ -146,7 +153,8 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "k_syrk_lower<EPI_ASSEMBLE> (dense/kkt.hpp:140-160)",
                          "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic,
-                         "alg_flops_per_launch": flops_asm, "avg_launch_ms": asm_avg_s * 1e3, "launches": asm_cnt},
+                         "alg_flops_per_launch": flops_asm, "avg_launch_ms": asm_avg_s * 1e3, "launches": asm_cnt,
+                         "mfma_pipe_busy_frac_pmc": mfma_busy},
             "stages": {"assembly_ms": asm_avg_s * 1e3, "factorisation_ms": fac_avg_s * 1e3,
                        "factorisation_tflops": flops_llt / fac_avg_s / 1e12 if fac_avg_s > 0 else 0.0,
                        "backend_solve_ms": sol_ms / max(sol_cnt, 1)},
