@@ -32,6 +32,7 @@ struct SyrkArgs {
     int fuse_nb = 0;            // order of the next diagonal block (<= 128)
     int fuse_kglobal = 0;       // global index of its first column
     int fuse_ldlt = 0;
+    int fuse_dbg_skip = 0;      // timing experiments only: skip the factorisation of the block
     int* fuse_info = nullptr;
     double* fuse_rdiag = nullptr;
 };

@@ -276,7 +276,7 @@ private:
             if (ldlt_) { dense::launch_extract_diag(fac_.p, n_, k, nb, dvec_.p + k, st_); a.w = dvec_.p + k; }
             a.C = fac_.p + (k + nb) + (size_t)(k + nb) * n_; a.ldc = n_;
             if (fused) {
-                a.fuse_nb = rs < NB ? rs : NB; a.fuse_kglobal = k + nb; a.fuse_ldlt = ldlt_ ? 1 : 0; a.fuse_info = info_.p; a.fuse_rdiag = rdiag_.p;
+                a.fuse_nb = rs < NB ? rs : NB; a.fuse_kglobal = k + nb; a.fuse_ldlt = ldlt_ ? 1 : 0; a.fuse_info = info_.p; a.fuse_rdiag = rdiag_.p; a.fuse_dbg_skip = std::getenv("PIQP_AMD_DBG_FUSE_SKIP") ? 1 : 0;
                 dense::launch_syrk(dense::EPI_SUBTRACT_POTRF, a, st_);
                 continue;
             }
