@@ -986,9 +986,15 @@ __device__ __forceinline__ double ld_agent(const double* p)
     return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const u64*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
 
+// S > 1: every 128-row block is served by S workgroups on S different CUs.  One CU streaming its whole block row (up to 4 MB at n = 4096)
+// was what bounded a sweep once the hand-off chain was short.  Workgroup (r, 0) owns the block: it keeps the diagonal block in LDS, consumes
+// only the LAST producer of its row -- the one on the critical path -- adds the partial sums of its helpers and solves; helpers (r, s >= 1)
+// share the earlier producers round-robin, whose x arrived at least one hand-off earlier, and publish 128 partial sums each.  The partials
+// are added in helper order: fixed summation order, bitwise reproducible.
 template <bool FWD>
 __global__ __launch_bounds__(256) void k_trsv_persistent(const double* __restrict__ L, int ld, int n, double* __restrict__ x, const double* __restrict__ rdiag,
-                                                         int nblk, int* __restrict__ flags, int* __restrict__ err, int dbg_skip_loads)
+                                                         int nblk, int* __restrict__ flags, int* __restrict__ err, int dbg_skip_loads, int S, int* __restrict__ pflags,
+                                                         double* __restrict__ part)
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double* Ls = sm;                    // own diagonal block, Ls[c * (TB+1) + r]
@@ -997,16 +1003,25 @@ __global__ __launch_bounds__(256) void k_trsv_persistent(const double* __restric
     double* rd = bs + TB;
     __shared__ int ok_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = FWD ? (int)blockIdx.x : nblk - 1 - (int)blockIdx.x;
+    const int ridx = (int)blockIdx.x / S, hs = (int)blockIdx.x % S;  // position of the block in sweep order, role (0 = owner)
+    const int r = FWD ? ridx : nblk - 1 - ridx;
     const int row0 = r * TB, nrows = min(TB, n - row0);
+    const bool owner = hs == 0;
     // stage the diagonal block (transposed for the backward sweep) and reciprocal pivots
-    stage_lower_block<TB, TB + 1, 256, !FWD>(L + row0 + (size_t)row0 * ld, ld, nrows, Ls, tid);
-    if (tid < TB) rd[tid] = (rdiag && tid < nrows) ? rdiag[row0 + tid] : 1.0;
+    if (owner) {
+        stage_lower_block<TB, TB + 1, 256, !FWD>(L + row0 + (size_t)row0 * ld, ld, nrows, Ls, tid);
+        if (tid < TB) rd[tid] = (rdiag && tid < nrows) ? rdiag[row0 + tid] : 1.0;
+    }
     const int row = tid & 127, half = tid >> 7;
-    double mine = (half == 0 && row < nrows) ? x[row0 + row] : 0.0;
+    double mine = (owner && half == 0 && row < nrows) ? x[row0 + row] : 0.0;
     double acc = 0.0;
-    const int nsteps = FWD ? r : nblk - 1 - r;
-    // operand block of step t (producer block j_t) into registers; two steps are kept in flight: the block for step t + 1 is requested
+    const int nsteps = ridx;  // producers of this block row, in sweep order t = 0 .. nsteps - 1
+    // the steps this workgroup consumes: t = t_first + q * t_stride, q < nmine
+    int t_first, t_stride, nmine;
+    if (S == 1) { t_first = 0; t_stride = 1; nmine = nsteps; }
+    else if (owner) { t_first = nsteps - 1; t_stride = 1; nmine = nsteps > 0 ? 1 : 0; }
+    else { t_first = hs - 1; t_stride = S - 1; nmine = (nsteps - 1 > hs - 1) ? (nsteps - 1 - (hs - 1) - 1) / (S - 1) + 1 : 0; }
+    // operand block of step t (producer block j_t) into registers; two steps are kept in flight: the block for the next step is requested
     // before the wait for x_{j_t}, so its latency never sits between the arrival of x and the hand-off to the next block
     auto load_block = [&](int t, double (&lv)[64]) {
         const int j = FWD ? t : nblk - 1 - t;
@@ -1039,25 +1054,28 @@ __global__ __launch_bounds__(256) void k_trsv_persistent(const double* __restric
         __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
         __builtin_amdgcn_s_barrier();
     };
-    // consumes step t with the operand block lv; the request for step t + 1 (into nxt) is issued right AFTER the load of x_j, so that the
-    // in-order return of x_j does not wait behind it
-    auto consume = [&](int t, const double (&lv)[64], double (&nxt)[64], bool prefetch) -> bool {
-        const int j = FWD ? t : nblk - 1 - t;
-        const int c0 = j * TB;
-        const int nc = min(TB, n - c0);
+    auto wait_flag = [&](const int* f) -> bool {
         if (tid == 0) {
             int ok = 1;
             unsigned spins = 0;
-            while (__hip_atomic_load(flags + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+            while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
                 __builtin_amdgcn_s_sleep(1);
                 if (++spins > 20000000u) { ok = 0; __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
             }
             ok_s = ok;
         }
         lds_barrier();
-        if (!ok_s) return false;
+        return ok_s != 0;
+    };
+    // consumes step t with the operand block lv; the request for the next step (into nxt) is issued right AFTER the load of x_j, so that the
+    // in-order return of x_j does not wait behind it
+    auto consume = [&](int t, const double (&lv)[64], double (&nxt)[64], int t_next) -> bool {
+        const int j = FWD ? t : nblk - 1 - t;
+        const int c0 = j * TB;
+        const int nc = min(TB, n - c0);
+        if (!wait_flag(flags + j)) return false;
         const double xv = (tid < TB && tid < nc) ? ld_agent(x + c0 + tid) : 0.0;
-        if (prefetch) load_block(t + 1, nxt);
+        if (t_next >= 0) load_block(t_next, nxt);
         if (tid < TB) xs[tid] = xv;
         lds_barrier();
 #pragma unroll
@@ -1067,18 +1085,39 @@ __global__ __launch_bounds__(256) void k_trsv_persistent(const double* __restric
     };
     {
         double lvA[64], lvB[64];
-        if (nsteps > 0) load_block(0, lvA);
-        int t = 0;
-        for (; t + 1 < nsteps; t += 2) {
-            if (!consume(t, lvA, lvB, true)) return;
-            if (!consume(t + 1, lvB, lvA, t + 2 < nsteps)) return;
+        if (nmine > 0) load_block(t_first, lvA);
+        int q = 0;
+        for (; q + 1 < nmine; q += 2) {
+            const int t0 = t_first + q * t_stride;
+            if (!consume(t0, lvA, lvB, t0 + t_stride)) return;
+            if (!consume(t0 + t_stride, lvB, lvA, q + 2 < nmine ? t0 + 2 * t_stride : -1)) return;
         }
-        if (t < nsteps) { if (!consume(t, lvA, lvB, false)) return; }
+        if (q < nmine) { if (!consume(t_first + q * t_stride, lvA, lvB, -1)) return; }
     }
     __syncthreads();
     if (half == 1) bs[row] = acc;
     __syncthreads();
-    if (half == 0) bs[row] = mine - (acc + bs[row]);
+    if (!owner) {
+        // helper: publish the 128 partial sums of this workgroup (nothing to publish if it had no step: the owner knows the counts)
+        if (nmine > 0) {
+            if (half == 0 && row < nrows) st_agent(part + ((size_t)r * S + hs) * TB + row, acc + bs[row]);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(pflags + r * S + hs, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return;
+    }
+    double total = (half == 0) ? acc + bs[row] : 0.0;
+    if (S > 1) {
+        for (int h = 1; h < S; ++h) {
+            const int cnt = (nsteps - 1 > h - 1) ? (nsteps - 1 - (h - 1) - 1) / (S - 1) + 1 : 0;
+            if (cnt == 0) continue;
+            if (!wait_flag(pflags + r * S + h)) return;
+            if (half == 0 && row < nrows) total += ld_agent(part + ((size_t)r * S + h) * TB + row);
+        }
+    }
+    __syncthreads();
+    if (half == 0) bs[row] = mine - total;
     __syncthreads();
     if (wave == 0) {
         double b0 = bs[lane], b1 = bs[lane + 64];
@@ -1098,9 +1137,21 @@ __global__ void k_mul_vec(int n, const double* __restrict__ d, double* __restric
     if (i < n) x[i] *= d[i];
 }
 
+int trsv_split(int n)
+{
+    static int env = -1;
+    if (env < 0) { const char* e = std::getenv("PIQP_AMD_TRSV_SPLIT"); env = e ? std::max(1, std::atoi(e)) : 0; }
+    const int nblk = div_up(n, TB);
+    int S = env > 0 ? env : 1;  // measured at n = 4096: 203 / 222 us (S = 1), 222 / 234 (2), 257 / 267 (4): the extra hand-off costs more than the shared streaming saves
+    while (S > 1 && nblk * S > 224) --S;  // every workgroup of the launch must be resident (one per CU)
+    return S;
+}
+size_t trsv_flag_ints(int n) { const int nblk = div_up(n, TB); return 2 * ((size_t)nblk + (size_t)nblk * 8) + 1; }
+size_t trsv_part_doubles(int n) { const int nblk = div_up(n, TB); return (size_t)nblk * 8 * TB; }
+
 // LLT: L y = b, L^T x = y with rdiag = 1/diag(L).  LDLt: unit L, then x *= rdiag (= 1/D), then unit L^T.
-// `flags` = 2 * nblk + 1 ints of scratch (zeroed here on the stream).
-void launch_trsv(const double* L, int ld, int n, double* x, const double* rdiag, bool ldlt, int* flags, hipStream_t s)
+// `flags` = trsv_flag_ints(n) ints and `part` = trsv_part_doubles(n) doubles of scratch (flags zeroed here on the stream).
+void launch_trsv(const double* L, int ld, int n, double* x, const double* rdiag, bool ldlt, int* flags, double* part, hipStream_t s)
 {
     if (n <= 0) return;
     static bool attr_set = false;
@@ -1115,10 +1166,16 @@ void launch_trsv(const double* L, int ld, int n, double* x, const double* rdiag,
     const double* rd = ldlt ? nullptr : rdiag;
     const bool persistent = flags != nullptr && nblk <= 224;  // every block resident (one per CU) with room to spare
     if (persistent) {
-        PQ_HIP(hipMemsetAsync(flags, 0, sizeof(int) * (2 * nblk + 1), s));
-        hipLaunchKernelGGL(k_trsv_persistent<true>, dim3(nblk), dim3(256), TRSV_LDS_BYTES, s, L, ld, n, x, rd, nblk, flags, flags + 2 * nblk, 0);
+        const int S = part ? trsv_split(n) : 1;
+        static int dbg = -1;
+        if (dbg < 0) { const char* e = std::getenv("PIQP_AMD_DBG_TRSV"); dbg = e ? std::atoi(e) : 0; }
+        // layout: [fwd x flags nblk][fwd partial flags nblk*S][bwd x flags nblk][bwd partial flags nblk*S][err]
+        const size_t per = (size_t)nblk + (size_t)nblk * S;
+        PQ_HIP(hipMemsetAsync(flags, 0, sizeof(int) * (2 * per + 1), s));
+        int* err = flags + 2 * per;
+        hipLaunchKernelGGL(k_trsv_persistent<true>, dim3(nblk * S), dim3(256), TRSV_LDS_BYTES, s, L, ld, n, x, rd, nblk, flags, err, 0, S, flags + nblk, part);
         if (ldlt) hipLaunchKernelGGL(k_mul_vec, dim3(div_up(n, 256)), dim3(256), 0, s, n, rdiag, x);
-        hipLaunchKernelGGL(k_trsv_persistent<false>, dim3(nblk), dim3(256), TRSV_LDS_BYTES, s, L, ld, n, x, rd, nblk, flags + nblk, flags + 2 * nblk, std::getenv("PIQP_AMD_DBG_TRSV") ? std::atoi(std::getenv("PIQP_AMD_DBG_TRSV")) : 0);
+        hipLaunchKernelGGL(k_trsv_persistent<false>, dim3(nblk * S), dim3(256), TRSV_LDS_BYTES, s, L, ld, n, x, rd, nblk, flags + per, err, dbg, S, flags + per + nblk, part);
     } else {
         for (int j = 0; j < nblk; ++j)
             hipLaunchKernelGGL(k_trsv_fwd_step, dim3(nblk - j), dim3(256), TRSV_LDS_BYTES, s, L, ld, n, x, rd, j);

@@ -43,7 +43,9 @@ void launch_assemble_no_g(int n, const double* Pf, const double* x_reg, const do
 void launch_potrf_diag(bool ldlt, double* A, int lda, int nb, int kglobal, int* info, double* rdiag, hipStream_t s);
 void launch_trsm_panel(bool ldlt, double* A, int lda, int k0, int nb, int n, const double* rdiag, hipStream_t s);
 void launch_extract_diag(const double* A, int lda, int k0, int nb, double* d, hipStream_t s);
-void launch_trsv(const double* L, int ld, int n, double* x, const double* rdiag, bool ldlt, int* flags, hipStream_t s);
+size_t trsv_flag_ints(int n);
+size_t trsv_part_doubles(int n);
+void launch_trsv(const double* L, int ld, int n, double* x, const double* rdiag, bool ldlt, int* flags, double* part, hipStream_t s);
 int gemv_n_slices(int rows, int cols);
 int launch_gemv_n_partial(int rows, int cols, const double* M, int ld, const double* v, const double* scale, double alpha, double* part, hipStream_t s);
 void launch_reduce_partials(int rows, int nslices, const double* part, const double* base, double* y, hipStream_t s);

@@ -93,7 +93,7 @@ public:
         if (p_ > 0) nsl += dense::launch_gemv_n_partial(n_, p_, AT_.p, n_, rhs_y, nullptr, delta_inv, part_.p + (size_t)nsl * n_, st_);
         dense::launch_reduce_partials(n_, nsl, part_.p, rhs_x, lhs_x, st_);
         // solve_ldlt_in_place: llt.solveInPlace(lhs_x)
-        dense::launch_trsv(fac_.p, n_, n_, lhs_x, rdiag_.p, ldlt_, use_persistent_trsv_ ? flags_.p : nullptr, st_);
+        dense::launch_trsv(fac_.p, n_, n_, lhs_x, rdiag_.p, ldlt_, use_persistent_trsv_ ? flags_.p : nullptr, trsv_part_.p, st_);
         // lhs_y = delta_inv * AT^T lhs_x - delta_inv * rhs_y
         if (p_ > 0) dense::launch_gemv_t(n_, p_, AT_.p, n_, lhs_x, delta_inv, -delta_inv, rhs_y, nullptr, lhs_y, st_);
         // lhs_z = (GT^T lhs_x - rhs_z) o z_reg_inv
@@ -186,7 +186,8 @@ private:
         split_ws_.alloc(dense::syrk_split_workspace_doubles(n_, m_ > 0 ? m_ : 1));
         info_.alloc(1);
         info_h_.alloc(1);
-        flags_.alloc(2 * (size_t)((n_ + 127) / 128) + 1);
+        flags_.alloc(dense::trsv_flag_ints(n_));
+        trsv_part_.alloc(dense::trsv_part_doubles(n_));
         if (const char* e = std::getenv("PIQP_AMD_TRSV")) use_persistent_trsv_ = std::string(e) != "steps";
         if (const char* e = std::getenv("PIQP_AMD_LOOKAHEAD")) lookahead_ = std::string(e) == "1";
         if (const char* e = std::getenv("PIQP_AMD_FUSED_POTRF")) fused_potrf_ = std::string(e) != "0";
@@ -318,6 +319,7 @@ private:
     hipStream_t st_ = nullptr;
     DBuf<double> Pfull_, Pdiag_, AT_, GT_, ATA_, fac_, z_reg_inv_, x_reg_last_, dvec_, part_, rdiag_, split_ws_;
     DBuf<int> info_, flags_;
+    DBuf<double> trsv_part_;
     HBuf<int> info_h_;
     StageProfiler prof_;
     bool use_persistent_trsv_ = true;
