@@ -303,6 +303,11 @@ int pq_batch_setup_sparse(pq_batch *s, int batch, int n, int p, int m, const int
                           const double *c, const int *Ap, const int *Ai, const double *Ax, const double *b,
                           const int *Gp, const int *Gi, const double *Gx, const double *h_l, const double *h_u,
                           const double *x_l, const double *x_u);
+/* update() of every instance with new VECTORS only (solver.hpp:218-308 with every optional matrix empty; the Ruiz scaling of the
+ * setup is reused, :283-285).  [batch][len] HOST arrays, NULL = unchanged.  The set of finite bounds is part of the shared
+ * structure and must not change (error otherwise); a doubly-infinite row of G stays as it was at setup. */
+int pq_batch_update(pq_batch *s, const double *c, const double *b, const double *h_l, const double *h_u,
+                    const double *x_l, const double *x_u);
 /* solve() of every instance (solver.hpp:69-148); returns the number of instances that ended PQ_SOLVED (>= 0) */
 int pq_batch_solve(pq_batch *s);
 const pq_info *pq_batch_info(const pq_batch *s, int instance); /* result().info of one instance */

@@ -62,6 +62,12 @@ class BatchSparseSolver(_Handle):
         self.batch, self.n, self.p, self.m = batch, n, p, m
         return ok
 
+    def update(self, c=None, b=None, h_l=None, h_u=None, x_l=None, x_u=None):
+        """new vectors for every instance ([batch, len] arrays, None = unchanged); matrices and the set of finite bounds stay"""
+        keep = [self._stack(c, self.batch, self.n), self._stack(b, self.batch, self.p), self._stack(h_l, self.batch, self.m), self._stack(h_u, self.batch, self.m),
+                self._stack(x_l, self.batch, self.n), self._stack(x_u, self.batch, self.n)]
+        return bool(check(self.L.pq_batch_update(self.h, *[_ptr(a) for a in keep]), "pq_batch_update"))
+
     def solve(self):
         """returns the number of instances that ended SOLVED"""
         return check(self.L.pq_batch_solve(self.h), "pq_batch_solve")

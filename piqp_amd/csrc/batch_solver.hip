@@ -987,6 +987,27 @@ struct Ipm {
     }
 };
 
+// update() of every instance with new vectors only (solver.hpp:218-308 with every optional matrix empty): the new values are scaled on
+// the device with the Ruiz factors the instance got at setup (reuse_prev_scaling is forced for such updates, :283-285) and written over
+// the scaled copies in the arena.  NULL = unchanged.  Non-finite bounds are stored as -/+1e30 times the scaling, like set_h_l / set_h_u.
+__global__ void k_batch_update_vectors(const BatchShared* __restrict__ Sp, double* __restrict__ arena, const double* __restrict__ ruiz_c, const double* __restrict__ c,
+                                       const double* __restrict__ b, const double* __restrict__ h_l, const double* __restrict__ h_u, const double* __restrict__ x_l,
+                                       const double* __restrict__ x_u)
+{
+    const BatchShared& S = *Sp;
+    const int q = blockIdx.x, n = S.n, p = S.p, m = S.m;
+    double* base = arena + (long long)q * S.stride;
+    const double* dl = base + S.off[D_DL];
+    const double* db = base + S.off[D_DB];
+    const double rc = ruiz_c[q];
+    if (c) for (int i = threadIdx.x; i < n; i += blockDim.x) base[S.off[D_C] + i] = c[(size_t)q * n + i] * (rc * dl[i]);
+    if (b) for (int i = threadIdx.x; i < p; i += blockDim.x) base[S.off[D_B] + i] = b[(size_t)q * p + i] * dl[n + i];
+    if (h_l) for (int i = threadIdx.x; i < m; i += blockDim.x) { const double v = h_l[(size_t)q * m + i]; base[S.off[D_HL] + i] = (v > -1e30 ? v : -1e30) * dl[n + p + i]; }
+    if (h_u) for (int i = threadIdx.x; i < m; i += blockDim.x) { const double v = h_u[(size_t)q * m + i]; base[S.off[D_HU] + i] = (v < 1e30 ? v : 1e30) * dl[n + p + i]; }
+    if (x_l) for (int k = threadIdx.x; k < S.n_x_l; k += blockDim.x) { const int idx = S.x_l_idx[k]; base[S.off[D_XL] + k] = x_l[(size_t)q * n + idx] * db[idx]; }
+    if (x_u) for (int k = threadIdx.x; k < S.n_x_u; k += blockDim.x) { const int idx = S.x_u_idx[k]; base[S.off[D_XU] + k] = x_u[(size_t)q * n + idx] * db[idx]; }
+}
+
 // per instance: caller's (Ruiz-scaled) values -> front / grouped-row arenas and the AtA fronts (multistage ctor, :76-135)
 template <int NT>
 __global__ __launch_bounds__(NT) void k_batch_prepare(const BatchShared* __restrict__ Sp, double* __restrict__ arena)
@@ -1134,6 +1155,11 @@ public:
                               std::equal(d.x_u_idx.begin(), d.x_u_idx.begin() + d.n_x_u, d0.x_u_idx.begin());
             if (!same) throw std::runtime_error("batch setup: instances differ in which bounds are finite");
         }
+        fin_hl_.assign(m_, 0); fin_hu_.assign(m_, 0); fin_xl_.assign(n_, 0); fin_xu_.assign(n_, 0);
+        for (int k = 0; k < d0.n_h_l; ++k) fin_hl_[d0.h_l_idx[k]] = 1;
+        for (int k = 0; k < d0.n_h_u; ++k) fin_hu_[d0.h_u_idx[k]] = 1;
+        for (int k = 0; k < d0.n_x_l; ++k) fin_xl_[d0.x_l_idx[k]] = 1;
+        for (int k = 0; k < d0.n_x_u; ++k) fin_xu_[d0.x_u_idx[k]] = 1;
         // ---- shared structure ----
         pq_sparse_data desc = d0.sparse_descriptor();
         multistage::analyse(&desc, sym_);
@@ -1188,6 +1214,35 @@ public:
         int solved = 0;
         for (const auto& i : infos_h_) solved += i.status == PQ_SOLVED;
         return solved;
+    }
+    // update() of every instance, vectors only; the set of finite bounds must be the one given at setup (it is part of the shared structure)
+    bool update_vectors(const double* c, const double* b, const double* h_l, const double* h_u, const double* x_l, const double* x_u)
+    {
+        if (!setup_done_) throw std::runtime_error("batch solver not set up");
+        PQ_HIP(hipSetDevice(dev_));
+        auto pattern_ok = [&](const double* v, int len, const std::vector<char>& finite, bool lower) {
+            if (!v) return true;
+            for (int q = 0; q < batch_; ++q)
+                for (int i = 0; i < len; ++i) {
+                    const double x = v[(size_t)q * len + i];
+                    if ((lower ? x > -1e30 : x < 1e30) != (finite[i] != 0)) return false;
+                }
+            return true;
+        };
+        if (!pattern_ok(h_l, m_, fin_hl_, true) || !pattern_ok(h_u, m_, fin_hu_, false) || !pattern_ok(x_l, n_, fin_xl_, true) || !pattern_ok(x_u, n_, fin_xu_, false))
+            throw std::runtime_error("batch update: the set of finite bounds differs from the one given at setup");
+        DBuf<double> dc, dbv, dhl, dhu, dxl, dxu;
+        auto up = [&](DBuf<double>& d, const double* v, int len) -> const double* {
+            if (!v || len == 0) return nullptr;
+            d.alloc((size_t)batch_ * len);
+            PQ_HIP(hipMemcpyAsync(d.p, v, sizeof(double) * (size_t)batch_ * len, hipMemcpyHostToDevice, st_));
+            return d.p;
+        };
+        const double *pc = up(dc, c, n_), *pb = up(dbv, b, p_), *phl = up(dhl, h_l, m_), *phu = up(dhu, h_u, m_), *pxl = up(dxl, x_l, n_), *pxu = up(dxu, x_u, n_);
+        hipLaunchKernelGGL(k_batch_update_vectors, dim3(batch_), dim3(128), 0, st_, shared_.p, arena_.p, ruiz_c_.p, pc, pb, phl, phu, pxl, pxu);
+        PQ_HIP(hipGetLastError());
+        PQ_HIP(hipStreamSynchronize(st_));
+        return true;
     }
     double last_kernel_ms() const { return last_kernel_ms_; }
     const pq_info& info(int i) const { return infos_h_.at(i); }
@@ -1409,6 +1464,7 @@ private:
     int dev_, batch_ = 0, n_ = 0, p_ = 0, m_ = 0, nt_ = 64;
     int mode_ = MODE_STAGED, wpe_ = 4, forced_mode_ = -1;
     bool setup_done_ = false;
+    std::vector<char> fin_hl_, fin_hu_, fin_xl_, fin_xu_;  // which bounds are finite (shared by all instances)
     double last_kernel_ms_ = 0.0;
     hipStream_t st_ = nullptr;
     pq_settings settings_;
@@ -1451,6 +1507,11 @@ int pq_batch_setup_sparse(pq_batch* s, int batch, int n, int p, int m, const int
 {
     if (!s || !Pp || !Pi || !Px || !c) return fail(PQ_ERR_INVALID, "null argument");
     return guarded([&] { return s->impl->setup(batch, n, p, m, Pp, Pi, Px, c, Ap, Ai, Ax, b, Gp, Gi, Gx, h_l, h_u, x_l, x_u) ? 1 : 0; });
+}
+int pq_batch_update(pq_batch* s, const double* c, const double* b, const double* h_l, const double* h_u, const double* x_l, const double* x_u)
+{
+    if (!s) return fail(PQ_ERR_INVALID, "null argument");
+    return guarded([&] { return s->impl->update_vectors(c, b, h_l, h_u, x_l, x_u) ? 1 : 0; });
 }
 int pq_batch_solve(pq_batch* s)
 {

@@ -113,3 +113,33 @@ def test_batch_with_general_inequalities_and_one_sided_bounds(hip, orc):
         assert np.abs(x[i] - ref["x"]).max() <= 1e-7 * (1 + np.abs(ref["x"]).max())
         assert np.abs(zl[i] - ref["z_l"]).max() <= 1e-6 * (1 + np.abs(ref["z_l"]).max())
         assert np.abs(zu[i] - ref["z_u"]).max() <= 1e-6 * (1 + np.abs(ref["z_u"]).max())
+
+
+def test_batch_update_vectors_matches_oracle_update(hip, orc):
+    """pq_batch_update: new c / b / box bounds for every instance, Ruiz scaling of the setup reused -- the reference's update() without
+    a matrix argument (solver.hpp:218-308), per instance"""
+    B = 12
+    mb = mpc_batch(B, seed=2000)
+    bs, solved = _run_batch(hip, mb)
+    assert solved == B
+    rng = np.random.default_rng(5)
+    c2 = mb["c"] + 0.05 * rng.standard_normal(mb["c"].shape)
+    b2 = mb["b"].copy(); b2[:, :2] += 0.1 * rng.standard_normal((B, 2))   # the rows that carry x0 (and whatever the shuffle put there)
+    xl2 = mb["x_l"] * 1.1; xu2 = mb["x_u"] * 1.1                            # same finite pattern, wider box
+    assert bs.update(c=c2, b=b2, x_l=xl2, x_u=xu2)
+    assert bs.solve() == B
+    x = bs.result("x")
+    for i in range(B):
+        so = orc.Solver(); so.settings.kkt_solver = orc.SPARSE_MULTISTAGE
+        assert so.setup(*mpc_instance(mb, i), sparse=True)
+        so.solve()
+        assert so.update(c=c2[i], b=b2[i], x_l=xl2[i], x_u=xu2[i])
+        assert so.solve() == 1
+        info = bs.info(i)
+        assert info.status == 1 and abs(info.iter - so.info.iter) <= 1, (i, info.iter, so.info.iter)
+        assert abs(info.primal_obj - so.info.primal_obj) <= 1e-7 * (1 + abs(so.info.primal_obj))
+        assert np.abs(x[i] - so.result()["x"]).max() <= 1e-6 * (1 + np.abs(so.result()["x"]).max())
+    # a changed set of finite bounds is refused
+    bad = xu2.copy(); bad[0, 0] = np.inf
+    with pytest.raises(RuntimeError):
+        bs.update(x_u=bad)
