@@ -651,7 +651,7 @@ __global__ __launch_bounds__(64) void k_subtree_fwd_wave(FrontMeta M, const doub
     }
 }
 __global__ __launch_bounds__(64) void k_subtree_bwd_wave(FrontMeta M, const double* __restrict__ fronts, const int* __restrict__ sub_lo, const int* __restrict__ sub_hi,
-                                                         double* __restrict__ x)
+                                                         double* __restrict__ x, int red_thr)
 {
     __shared__ double sv[2][128];
     const int lane = threadIdx.x, r0 = lane, r1 = lane + 64;
@@ -669,8 +669,32 @@ __global__ __launch_bounds__(64) void k_subtree_bwd_wave(FrontMeta M, const doub
         double v0 = 0.0, v1 = 0.0;
         if (r0 < f) v0 = r0 < w ? x[first + r0] : (from_lds ? pv[rel[r0 - w]] : x[rows[r0]]);
         if (r1 < f) v1 = r1 < w ? x[first + r1] : (from_lds ? pv[rel[r1 - w]] : x[rows[r1]]);
-        // y1[j] -= sum_{i >= w} L[i,j] x2[i], ascending i (lane j = pivot column j)
-        {
+        // y1[j] -= sum_{i >= w} L[i,j] x2[i].  Few pivots under many update rows (the usual shape inside a subtree): lanes over the rows i,
+        // one coalesced column load and one wave reduction per pivot.  Otherwise lane j = pivot column j, ascending i, like front_bwd.
+        if (f - w > red_thr * w) {
+            int k = 0;
+            for (; k + 2 <= w; k += 2) {
+                const double* ca = F + (long long)k * f;
+                const double* cb = ca + f;
+                double pa = 0.0, pb = 0.0;
+                if (r0 >= w && r0 < f) { pa = ca[r0] * v0; pb = cb[r0] * v0; }
+                if (r1 >= w && r1 < f) { pa += ca[r1] * v1; pb += cb[r1] * v1; }
+                for (int o = 32; o > 0; o >>= 1) { pa += __shfl_xor(pa, o); pb += __shfl_xor(pb, o); }
+                if (r0 == k) v0 -= pa;
+                if (r0 == k + 1) v0 -= pb;
+                if (r1 == k) v1 -= pa;
+                if (r1 == k + 1) v1 -= pb;
+            }
+            for (; k < w; ++k) {
+                const double* ca = F + (long long)k * f;
+                double pa = 0.0;
+                if (r0 >= w && r0 < f) pa = ca[r0] * v0;
+                if (r1 >= w && r1 < f) pa += ca[r1] * v1;
+                for (int o = 32; o > 0; o >>= 1) pa += __shfl_xor(pa, o);
+                if (r0 == k) v0 -= pa;
+                if (r1 == k) v1 -= pa;
+            }
+        } else {
             double s0 = 0.0, s1 = 0.0;
             const double* cj0 = F + (long long)r0 * f;
             const double* cj1 = F + (long long)r1 * f;
@@ -1338,6 +1362,12 @@ private:
             out.cls.push_back(std::move(k));
         }
     }
+    static int bwd_red_thr()
+    {
+        static int v = -1;
+        if (v < 0) { const char* e = std::getenv("PIQP_AMD_BWD_RED"); v = e ? std::atoi(e) : 3; }
+        return v;
+    }
     void build_full_schedule()
     {
         { const char* e = std::getenv("PIQP_AMD_GRAPHS"); use_graphs_ = e && e[0] == '1'; }
@@ -1355,7 +1385,7 @@ private:
     void subtree_bwd(const FrontMeta& M, const SubSchedule& sc)
     {
         for (const SubClass& c : sc.cls) {
-            if (c.fmax <= 128 && !std::getenv("PIQP_AMD_SUBTREE_SOLVE_V1")) hipLaunchKernelGGL(k_subtree_bwd_wave, dim3(c.nsub), dim3(64), 0, st_, M, fronts_.p, c.lo.p, c.hi.p, xp_.p);
+            if (c.fmax <= 128 && !std::getenv("PIQP_AMD_SUBTREE_SOLVE_V1")) hipLaunchKernelGGL(k_subtree_bwd_wave, dim3(c.nsub), dim3(64), 0, st_, M, fronts_.p, c.lo.p, c.hi.p, xp_.p, bwd_red_thr());
             else hipLaunchKernelGGL(k_subtree_bwd, dim3(c.nsub), dim3(SUB_SOLVE_THREADS), 0, st_, M, fronts_.p, c.lo.p, c.hi.p, xp_.p, fvec_.p);
         }
     }
@@ -1408,7 +1438,7 @@ private:
         for (int l = (int)ptr.size() - 2; l >= 0; --l) {
             const int cnt = ptr[l + 1] - ptr[l];
             if (cnt <= 0) continue;
-            if (level_is_narrow(ptr, sn, l)) hipLaunchKernelGGL(k_subtree_bwd_wave, dim3(cnt), dim3(64), 0, st_, M, fronts_.p, sn_dev + ptr[l], sn_dev + ptr[l], xp_.p);
+            if (level_is_narrow(ptr, sn, l)) hipLaunchKernelGGL(k_subtree_bwd_wave, dim3(cnt), dim3(64), 0, st_, M, fronts_.p, sn_dev + ptr[l], sn_dev + ptr[l], xp_.p, bwd_red_thr());
             else hipLaunchKernelGGL(k_front_bwd, dim3(cnt), dim3(256), 0, st_, M, fronts_.p, sn_dev + ptr[l], xp_.p, fvec_.p);
         }
     }
