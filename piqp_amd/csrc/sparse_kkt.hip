@@ -581,6 +581,40 @@ __global__ __launch_bounds__(SUB_SOLVE_THREADS) void k_subtree_bwd(FrontMeta M, 
 // steps in flight, and a parent that directly follows its child in the walk takes the child's update vector from LDS.  Same arithmetic,
 // same order as front_fwd / front_bwd (bitwise the same results): what changes is that a dependent step costs an FMA + a readlane
 // instead of a global-memory round trip + a barrier.
+// agent-scope (L1-bypassing, write-through) accesses for values handed from one workgroup to another inside ONE launch
+template <bool AGENT>
+__device__ __forceinline__ double ldx(const double* p)
+{
+    if (!AGENT) return *p;
+    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+template <bool AGENT>
+__device__ __forceinline__ void stx(double* p, double v)
+{
+    if (!AGENT) { *p = v; return; }
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// single-wave workgroup: wait until *flag != 0 (bounded; a timeout raises err and lets the launch drain)
+__device__ __forceinline__ void wave_wait_flag(const int* flag, int* err)
+{
+    if (threadIdx.x == 0) {
+        unsigned spins = 0;
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > 8000000u || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ void wave_publish_flag(int* flag)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __device__ __forceinline__ double bcast_row(double v0, double v1, int row)
 {
     const int r = __builtin_amdgcn_readfirstlane(row);
@@ -590,12 +624,25 @@ __device__ __forceinline__ double bcast_row(double v0, double v1, int row)
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
     return __hiloint2double(hi, lo);
 }
+// TOP = true: the level-sorted top of the tree in ONE launch, one single-wave workgroup per supernode (sub_lo = the list, in dependency
+// order): a workgroup waits for the flags of its children, takes their update vectors with agent-scope loads (they were stored write-through
+// by another CU a microsecond earlier: no fence needed on either side) and publishes its own flag.  Dependencies always have a smaller
+// block index, so they were dispatched earlier: no deadlock whatever the residency.
+template <bool TOP>
 __global__ __launch_bounds__(64) void k_subtree_fwd_wave(FrontMeta M, const double* __restrict__ fronts, const int* __restrict__ sub_lo, const int* __restrict__ sub_hi,
-                                                         double* __restrict__ x, double* __restrict__ fvec)
+                                                         double* __restrict__ x, double* __restrict__ fvec, const int* __restrict__ top_pos, int* __restrict__ flags,
+                                                         int* __restrict__ err)
 {
     __shared__ double sv[2][128];
     const int lane = threadIdx.x, r0 = lane, r1 = lane + 64;
-    const int lo = sub_lo[blockIdx.x], hi = sub_hi[blockIdx.x];
+    const int lo = sub_lo[blockIdx.x], hi = TOP ? lo : sub_hi[blockIdx.x];
+    if (TOP) {
+        const SnRec me = M.sn[lo];
+        for (int ci = me.child_lo; ci < me.child_hi; ++ci) {
+            const int tp = top_pos[M.child[ci]];
+            if (tp >= 0) wave_wait_flag(flags + tp, err);
+        }
+    }
     int cur = 0;
     bool prev_valid = false;  // sv[cur ^ 1][0 .. u) = update vector of supernode s - 1
     for (int s = lo; s <= hi; ++s) {
@@ -612,7 +659,7 @@ __global__ __launch_bounds__(64) void k_subtree_fwd_wave(FrontMeta M, const doub
             const int uc = ch.f - ch.w;
             const double* vc = (prev_valid && c == s - 1) ? sv[cur ^ 1] : fvec + ch.rows_ptr + ch.w;
             const int* rel = M.rel + ch.rel_ptr;
-            for (int i = lane; i < uc; i += 64) a[rel[i]] += vc[i];
+            for (int i = lane; i < uc; i += 64) a[rel[i]] += (TOP ? ldx<true>(vc + i) : vc[i]);
             __syncthreads();
         }
         double v0 = r0 < f ? a[r0] : 0.0, v1 = r1 < f ? a[r1] : 0.0;
@@ -643,19 +690,28 @@ __global__ __launch_bounds__(64) void k_subtree_fwd_wave(FrontMeta M, const doub
         if (r1 < w) x[first + r1] = v1;
         __syncthreads();  // every lane has taken its entries of `a`
         const bool keep = me.parent == s + 1 && s + 1 <= hi;
-        if (r0 >= w && r0 < f) { a[r0 - w] = v0; if (!keep) fvec[me.rows_ptr + r0] = v0; }
-        if (r1 >= w && r1 < f) { a[r1 - w] = v1; if (!keep) fvec[me.rows_ptr + r1] = v1; }
+        if (r0 >= w && r0 < f) { a[r0 - w] = v0; if (!keep) stx<TOP>(fvec + me.rows_ptr + r0, v0); }
+        if (r1 >= w && r1 < f) { a[r1 - w] = v1; if (!keep) stx<TOP>(fvec + me.rows_ptr + r1, v1); }
         __syncthreads();
         cur ^= 1;
         prev_valid = keep;
     }
+    if (TOP) wave_publish_flag(flags + blockIdx.x);
 }
+// TOP = true: as above for the backward sweep; sub_lo = the level-sorted list, block b takes entry ntop - 1 - b (parents first) and waits
+// for its parent's flag; the ancestors' solution entries are read with agent-scope loads, its own are stored write-through
+template <bool TOP>
 __global__ __launch_bounds__(64) void k_subtree_bwd_wave(FrontMeta M, const double* __restrict__ fronts, const int* __restrict__ sub_lo, const int* __restrict__ sub_hi,
-                                                         double* __restrict__ x, int red_thr)
+                                                         double* __restrict__ x, int red_thr, int ntop, const int* __restrict__ top_pos, int* __restrict__ flags,
+                                                         int* __restrict__ err)
 {
     __shared__ double sv[2][128];
     const int lane = threadIdx.x, r0 = lane, r1 = lane + 64;
-    const int lo = sub_lo[blockIdx.x], hi = sub_hi[blockIdx.x];
+    const int lo = TOP ? sub_lo[ntop - 1 - (int)blockIdx.x] : sub_lo[blockIdx.x], hi = TOP ? lo : sub_hi[blockIdx.x];
+    if (TOP) {
+        const int par = M.sn[lo].parent;
+        if (par >= 0) wave_wait_flag(flags + top_pos[par], err);
+    }
     int cur = 0;
     bool prev_valid = false;  // sv[cur ^ 1][0 .. f_parent) = final vector of supernode s + 1
     for (int s = hi; s >= lo; --s) {
@@ -667,8 +723,8 @@ __global__ __launch_bounds__(64) void k_subtree_bwd_wave(FrontMeta M, const doub
         const double* pv = sv[cur ^ 1];
         const int* rel = M.rel + me.rel_ptr;
         double v0 = 0.0, v1 = 0.0;
-        if (r0 < f) v0 = r0 < w ? x[first + r0] : (from_lds ? pv[rel[r0 - w]] : x[rows[r0]]);
-        if (r1 < f) v1 = r1 < w ? x[first + r1] : (from_lds ? pv[rel[r1 - w]] : x[rows[r1]]);
+        if (r0 < f) v0 = r0 < w ? x[first + r0] : (from_lds ? pv[rel[r0 - w]] : ldx<TOP>(x + rows[r0]));
+        if (r1 < f) v1 = r1 < w ? x[first + r1] : (from_lds ? pv[rel[r1 - w]] : ldx<TOP>(x + rows[r1]));
         // y1[j] -= sum_{i >= w} L[i,j] x2[i].  Few pivots under many update rows (the usual shape inside a subtree): lanes over the rows i,
         // one coalesced column load and one wave reduction per pivot.  Otherwise lane j = pivot column j, ascending i, like front_bwd.
         if (f - w > red_thr * w) {
@@ -732,8 +788,8 @@ __global__ __launch_bounds__(64) void k_subtree_bwd_wave(FrontMeta M, const doub
                 v0 -= a0 * xi; v1 -= a1 * xi;
             }
         }
-        if (r0 < w) x[first + r0] = v0;
-        if (r1 < w) x[first + r1] = v1;
+        if (r0 < w) stx<TOP>(x + first + r0, v0);
+        if (r1 < w) stx<TOP>(x + first + r1, v1);
         double* a = sv[cur];
         if (r0 < f) a[r0] = v0;
         if (r1 < f) a[r1] = v1;
@@ -741,6 +797,7 @@ __global__ __launch_bounds__(64) void k_subtree_bwd_wave(FrontMeta M, const doub
         cur ^= 1;
         prev_valid = true;
     }
+    if (TOP) wave_publish_flag(flags + top_pos[lo]);
 }
 
 // ---- the top of the assembly tree in ONE launch: workgroup b takes the top supernodes b, b + G, ... of the level-sorted (=
@@ -1257,14 +1314,18 @@ private:
     void solve_numeric(const FrontMeta& M)
     {
         subtree_fwd(M, sched_);
-        const bool top_solve_persistent = top_persistent_ && std::getenv("PIQP_AMD_TOP_SOLVE_PERSISTENT");
-        if (top_solve_persistent) {
+        // the top of the tree: one launch per sweep when every top front fits the single-wave kernels, else one launch per level
+        bool wave_top = ntop_ > 1 && !std::getenv("PIQP_AMD_TOP_LEVELS_SOLVE") && !std::getenv("PIQP_AMD_SUBTREE_SOLVE_V1");
+        if (wave_top) for (int s2 : S_.top_level_sn) if (S_.front_rows_ptr[s2 + 1] - S_.front_rows_ptr[s2] > 128) { wave_top = false; break; }
+        if (wave_top) {
             PQ_HIP(hipMemsetAsync(top_flags_.p, 0, sizeof(int) * (2 * (size_t)ntop_ + 1), st_));
-            hipLaunchKernelGGL(k_top_fwd, dim3(top_grid_), dim3(256), 0, st_, M, fronts_.p, level_sn_.p, ntop_, top_pos_.p, top_flags_.p, top_flags_.p + 2 * ntop_, xp_.p, fvec_.p);
+            hipLaunchKernelGGL(k_subtree_fwd_wave<true>, dim3(ntop_), dim3(64), 0, st_, M, fronts_.p, level_sn_.p, level_sn_.p, xp_.p, fvec_.p, top_pos_.p, top_flags_.p,
+                               top_flags_.p + 2 * ntop_);
         } else fwd_levels(M, S_.top_level_ptr, S_.top_level_sn, level_sn_.p);
         hipLaunchKernelGGL(k_scale, g1(N_), dim3(256), 0, st_, N_, rdiag_.p, xp_.p);
-        if (top_solve_persistent) {
-            hipLaunchKernelGGL(k_top_bwd, dim3(top_grid_), dim3(256), 0, st_, M, fronts_.p, level_sn_.p, ntop_, top_pos_.p, top_flags_.p + ntop_, top_flags_.p + 2 * ntop_, xp_.p, fvec_.p);
+        if (wave_top) {
+            hipLaunchKernelGGL(k_subtree_bwd_wave<true>, dim3(ntop_), dim3(64), 0, st_, M, fronts_.p, level_sn_.p, level_sn_.p, xp_.p, bwd_red_thr(), ntop_, top_pos_.p,
+                               top_flags_.p + ntop_, top_flags_.p + 2 * ntop_);
             hipLaunchKernelGGL(k_top_check, dim3(1), dim3(1), 0, st_, top_flags_.p + 2 * ntop_, (int*)nullptr, xp_.p);
         } else bwd_levels(M, S_.top_level_ptr, S_.top_level_sn, level_sn_.p);
         subtree_bwd(M, sched_);
@@ -1378,14 +1439,14 @@ private:
     void subtree_fwd(const FrontMeta& M, const SubSchedule& sc)
     {
         for (const SubClass& c : sc.cls) {
-            if (c.fmax <= 128 && !std::getenv("PIQP_AMD_SUBTREE_SOLVE_V1")) hipLaunchKernelGGL(k_subtree_fwd_wave, dim3(c.nsub), dim3(64), 0, st_, M, fronts_.p, c.lo.p, c.hi.p, xp_.p, fvec_.p);
+            if (c.fmax <= 128 && !std::getenv("PIQP_AMD_SUBTREE_SOLVE_V1")) hipLaunchKernelGGL(k_subtree_fwd_wave<false>, dim3(c.nsub), dim3(64), 0, st_, M, fronts_.p, c.lo.p, c.hi.p, xp_.p, fvec_.p, (const int*)nullptr, (int*)nullptr, (int*)nullptr);
             else hipLaunchKernelGGL(k_subtree_fwd, dim3(c.nsub), dim3(SUB_SOLVE_THREADS), 0, st_, M, fronts_.p, c.lo.p, c.hi.p, xp_.p, fvec_.p);
         }
     }
     void subtree_bwd(const FrontMeta& M, const SubSchedule& sc)
     {
         for (const SubClass& c : sc.cls) {
-            if (c.fmax <= 128 && !std::getenv("PIQP_AMD_SUBTREE_SOLVE_V1")) hipLaunchKernelGGL(k_subtree_bwd_wave, dim3(c.nsub), dim3(64), 0, st_, M, fronts_.p, c.lo.p, c.hi.p, xp_.p, bwd_red_thr());
+            if (c.fmax <= 128 && !std::getenv("PIQP_AMD_SUBTREE_SOLVE_V1")) hipLaunchKernelGGL(k_subtree_bwd_wave<false>, dim3(c.nsub), dim3(64), 0, st_, M, fronts_.p, c.lo.p, c.hi.p, xp_.p, bwd_red_thr(), 0, (const int*)nullptr, (int*)nullptr, (int*)nullptr);
             else hipLaunchKernelGGL(k_subtree_bwd, dim3(c.nsub), dim3(SUB_SOLVE_THREADS), 0, st_, M, fronts_.p, c.lo.p, c.hi.p, xp_.p, fvec_.p);
         }
     }
@@ -1429,7 +1490,7 @@ private:
         for (int l = 0; l + 1 < (int)ptr.size(); ++l) {
             const int cnt = ptr[l + 1] - ptr[l];
             if (cnt <= 0) continue;
-            if (level_is_narrow(ptr, sn, l)) hipLaunchKernelGGL(k_subtree_fwd_wave, dim3(cnt), dim3(64), 0, st_, M, fronts_.p, sn_dev + ptr[l], sn_dev + ptr[l], xp_.p, fvec_.p);
+            if (level_is_narrow(ptr, sn, l)) hipLaunchKernelGGL(k_subtree_fwd_wave<false>, dim3(cnt), dim3(64), 0, st_, M, fronts_.p, sn_dev + ptr[l], sn_dev + ptr[l], xp_.p, fvec_.p, (const int*)nullptr, (int*)nullptr, (int*)nullptr);
             else hipLaunchKernelGGL(k_front_fwd, dim3(cnt), dim3(256), 0, st_, M, fronts_.p, sn_dev + ptr[l], xp_.p, fvec_.p);
         }
     }
@@ -1438,7 +1499,7 @@ private:
         for (int l = (int)ptr.size() - 2; l >= 0; --l) {
             const int cnt = ptr[l + 1] - ptr[l];
             if (cnt <= 0) continue;
-            if (level_is_narrow(ptr, sn, l)) hipLaunchKernelGGL(k_subtree_bwd_wave, dim3(cnt), dim3(64), 0, st_, M, fronts_.p, sn_dev + ptr[l], sn_dev + ptr[l], xp_.p, bwd_red_thr());
+            if (level_is_narrow(ptr, sn, l)) hipLaunchKernelGGL(k_subtree_bwd_wave<false>, dim3(cnt), dim3(64), 0, st_, M, fronts_.p, sn_dev + ptr[l], sn_dev + ptr[l], xp_.p, bwd_red_thr(), 0, (const int*)nullptr, (int*)nullptr, (int*)nullptr);
             else hipLaunchKernelGGL(k_front_bwd, dim3(cnt), dim3(256), 0, st_, M, fronts_.p, sn_dev + ptr[l], xp_.p, fvec_.p);
         }
     }
