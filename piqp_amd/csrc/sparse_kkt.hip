@@ -838,10 +838,26 @@ __global__ __launch_bounds__(256) void k_top_factor(FrontMeta M, double* __restr
     for (int b = blockIdx.x; b < ntop; b += gridDim.x) {
         const int s = list[b];
         const SnRec me = M.sn[s];
-        for (int ci = me.child_lo; ci < me.child_hi; ++ci) {
-            const int tp = top_pos[M.child[ci]] - start;
-            if (tp >= 0) top_wait(flags + tp, err);
+        // one lane polls every child's flag (relaxed), then ONE agent-scope acquire by that lane invalidates this CU's L1 for the whole
+        // workgroup (a fence per child executed by all 256 threads cost several microseconds per front)
+        if (threadIdx.x == 0) {
+            bool any = false;
+            for (int ci = me.child_lo; ci < me.child_hi; ++ci) {
+                const int tp = top_pos[M.child[ci]] - start;
+                if (tp < 0) continue;
+                any = true;
+                unsigned spins = 0;
+                while (__hip_atomic_load(flags + tp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > 8000000u || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                        __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                }
+            }
+            if (any) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
+        __syncthreads();
         front_factor(M, fronts, s, 1 << 30, 1 << 30, rdiag, info, lds);
         top_done(flags + b);
     }
