@@ -806,21 +806,6 @@ __global__ __launch_bounds__(64) void k_subtree_bwd_wave(FrontMeta M, const doub
 // index is always being worked on: no deadlock.  Flags are released / acquired at agent scope (the data crosses XCD L2s).
 // every spin is bounded: if the workgroups are not all resident (another stream occupies the device) the wait gives up, raises
 // `err` and the launch drains instead of hanging; the host then reports a failed factorisation / a non-finite solve
-__device__ __forceinline__ void top_wait(const int* flag, int* err)
-{
-    if (threadIdx.x == 0) {
-        unsigned spins = 0;
-        while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0) {
-            __builtin_amdgcn_s_sleep(2);
-            if (++spins > 4000000u || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-                __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;
-            }
-        }
-    }
-    __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-}
 __device__ __forceinline__ void top_done(int* flag)
 {
     __syncthreads();
@@ -862,34 +847,6 @@ __global__ __launch_bounds__(256) void k_top_factor(FrontMeta M, double* __restr
         top_done(flags + b);
     }
 }
-__global__ __launch_bounds__(256) void k_top_fwd(FrontMeta M, const double* __restrict__ fronts, const int* __restrict__ list, int ntop, const int* __restrict__ top_pos,
-                                                 int* __restrict__ flags, int* __restrict__ err, double* __restrict__ x, double* __restrict__ fvec)
-{
-    for (int b = blockIdx.x; b < ntop; b += gridDim.x) {
-        const int s = list[b];
-        const SnRec me = M.sn[s];
-        for (int ci = me.child_lo; ci < me.child_hi; ++ci) {
-            const int tp = top_pos[M.child[ci]];
-            if (tp >= 0) top_wait(flags + tp, err);
-        }
-        front_fwd(M, fronts, s, x, fvec);
-        top_done(flags + b);
-    }
-}
-// backward: parents before children -> walk the list from the end; a supernode waits for its parent
-__global__ __launch_bounds__(256) void k_top_bwd(FrontMeta M, const double* __restrict__ fronts, const int* __restrict__ list, int ntop, const int* __restrict__ top_pos,
-                                                 int* __restrict__ flags, int* __restrict__ err, double* __restrict__ x, double* __restrict__ fvec)
-{
-    for (int b = blockIdx.x; b < ntop; b += gridDim.x) {
-        const int pos = ntop - 1 - b;
-        const int s = list[pos];
-        const int par = M.sn[s].parent;
-        if (par >= 0) top_wait(flags + top_pos[par], err);
-        front_bwd(M, fronts, s, x, fvec);
-        top_done(flags + pos);
-    }
-}
-
 // a timed-out wait surfaces as a failed factorisation (info) or a NaN in the solution (caught by KKTSystem's finite check)
 __global__ void k_top_check(const int* __restrict__ err, int* __restrict__ info, double* __restrict__ x)
 {
