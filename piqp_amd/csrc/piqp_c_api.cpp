@@ -6,7 +6,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "../../include/piqp_amd.h"
@@ -81,12 +83,23 @@ int device_from_env()
     return e ? std::atoi(e) : 0;
 }
 
-// rows x cols row-major -> column-major
+// rows x cols row-major -> column-major, 32 x 32 tiles (both sides of the transpose stay in cache), a few threads for large matrices
 std::vector<double> to_col_major(const double* a, int rows, int cols)
 {
     std::vector<double> o((size_t)rows * cols);
-    for (int i = 0; i < rows; ++i)
-        for (int j = 0; j < cols; ++j) o[i + (size_t)j * rows] = a[(size_t)i * cols + j];
+    auto work = [&](int jb_lo, int jb_hi) {
+        for (int jb = jb_lo; jb < jb_hi; jb += 32)
+            for (int ib = 0; ib < rows; ib += 32)
+                for (int j = jb; j < std::min(cols, jb + 32); ++j)
+                    for (int i = ib; i < std::min(rows, ib + 32); ++i) o[i + (size_t)j * rows] = a[(size_t)i * cols + j];
+    };
+    const long long total = (long long)rows * cols;
+    int T = total < (1LL << 20) ? 1 : (int)std::min<unsigned>(8, std::max(1u, std::thread::hardware_concurrency()));
+    if (T <= 1) { work(0, cols); return o; }
+    std::vector<std::thread> th;
+    const int chunk = ((cols + T - 1) / T + 31) / 32 * 32;
+    for (int lo = 0; lo < cols; lo += chunk) th.emplace_back(work, lo, std::min(cols, lo + chunk));
+    for (auto& t : th) t.join();
     return o;
 }
 
