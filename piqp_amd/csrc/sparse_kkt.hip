@@ -269,7 +269,7 @@ __global__ __launch_bounds__(256) void k_front_factor(FrontMeta M, double* __res
 // case: a chain) and from HBM otherwise, the panel + Schur complement run in LDS, and only the factor panel (f x w) is written
 // to HBM; the update matrix goes to HBM only when the parent is not the next supernode of this walk.  Two LDS buffers
 // alternate between "front being factored" and "previous front, holding the update matrix".
-__global__ __launch_bounds__(SUB_THREADS) void k_subtree_factor_lds(FrontMeta M, double* __restrict__ fronts, const double* __restrict__ vals, const int* __restrict__ fe_ptr,
+__global__ __launch_bounds__(1024) void k_subtree_factor_lds(FrontMeta M, double* __restrict__ fronts, const double* __restrict__ vals, const int* __restrict__ fe_ptr,
                                                             const int* __restrict__ fe_q, const int* __restrict__ fe_off, const int* __restrict__ sub_lo,
                                                             const int* __restrict__ sub_hi, int cap, double* __restrict__ rdiag, int* __restrict__ info)
 {
@@ -1391,7 +1391,9 @@ private:
             k.bytes = (int)b;
             k.lds_walk = b <= SUBTREE_LDS_BYTES && !std::getenv("PIQP_AMD_SUBTREE_HBM");
             static const int thr_env = std::getenv("PIQP_AMD_SUBTREE_THREADS") ? std::atoi(std::getenv("PIQP_AMD_SUBTREE_THREADS")) : 0;
-            k.threads = thr_env > 0 ? thr_env : SUB_THREADS;
+            // a workgroup that has the CU to itself (LDS) gets eight waves instead of four: measured 1.08 -> 1.04 ms on C3; with several
+            // workgroups per CU more threads only add barrier cost (C5: 1.45 -> 2.0 ms)
+            k.threads = thr_env > 0 ? thr_env : (b > 80 * 1024 ? 512 : SUB_THREADS);
             upload_vec(k.lo, lo, st_); upload_vec(k.hi, hi, st_);
             out.cls.push_back(std::move(k));
         }
