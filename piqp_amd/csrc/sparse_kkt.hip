@@ -816,7 +816,7 @@ __device__ __forceinline__ void top_done(int* flag)
 }
 // `list` / `ntop` may be a SUFFIX of the level-sorted top list (start = its first position): children in earlier levels or in
 // subtrees were finished by earlier launches on the stream
-__global__ __launch_bounds__(256) void k_top_factor(FrontMeta M, double* __restrict__ fronts, const int* __restrict__ list, int ntop, const int* __restrict__ top_pos, int start,
+__global__ __launch_bounds__(512) void k_top_factor(FrontMeta M, double* __restrict__ fronts, const int* __restrict__ list, int ntop, const int* __restrict__ top_pos, int start,
                                                     int* __restrict__ flags, int* __restrict__ err, double* __restrict__ rdiag, int* __restrict__ info)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -1279,7 +1279,7 @@ private:
         factor_levels(M, S_.top_level_ptr, S_.top_level_sn, level_sn_.p, level_lds_, top_l0_);
         if (top_nper_ > 0) {
             PQ_HIP(hipMemsetAsync(top_flags_.p, 0, sizeof(int) * (2 * (size_t)ntop_ + 1), st_));
-            hipLaunchKernelGGL(k_top_factor, dim3(std::min(top_nper_, 224)), dim3(256), top_lds_, st_, M, fronts_.p, level_sn_.p + top_start_, top_nper_, top_pos_.p, top_start_,
+            hipLaunchKernelGGL(k_top_factor, dim3(std::min(top_nper_, 224)), dim3(top_threads()), top_lds_, st_, M, fronts_.p, level_sn_.p + top_start_, top_nper_, top_pos_.p, top_start_,
                                top_flags_.p, top_flags_.p + 2 * ntop_, rdiag_.p, info_.p);
             hipLaunchKernelGGL(k_top_check, dim3(1), dim3(1), 0, st_, top_flags_.p + 2 * ntop_, info_.p, (double*)nullptr);
         }
@@ -1397,6 +1397,12 @@ private:
             upload_vec(k.lo, lo, st_); upload_vec(k.hi, hi, st_);
             out.cls.push_back(std::move(k));
         }
+    }
+    static int top_threads()
+    {
+        static int v = -1;
+        if (v < 0) { const char* e = std::getenv("PIQP_AMD_TOP_THREADS"); v = e ? std::min(512, std::max(64, std::atoi(e))) : 512; }  // measured: 512 beats 256 (C3 1.04 -> 0.98 ms)
+        return v;
     }
     static int bwd_red_thr()
     {
