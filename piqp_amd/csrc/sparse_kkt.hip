@@ -1050,7 +1050,7 @@ public:
             bwd_levels(M, sh_ptr_, sh_sn_, sh_sn_d_.p);
             bwd_levels(M, own_ptr_, own_sn_, own_sn_d_.p);
             subtree_bwd(M, part_sched_);
-            if (world_ > 1) {
+            if (world_ > 1 || (std::getenv("PIQP_AMD_EXCHANGE_WORLD1") && xfn_)) {
                 const int lo = PT_.span_lo[rank_], hi = PT_.span_hi[rank_];
                 if (hi > lo) hipLaunchKernelGGL(k_pack_span, g1(hi - lo), dim3(256), 0, st_, lo, hi, xp_.p, xbuf_gather_ + (size_t)rank_ * PT_.max_span);
                 exchange(2);
@@ -1321,7 +1321,10 @@ private:
     // data crosses ranks: the stream is drained, the caller's collective runs (pq_exchange_fn), then the stream continues
     void exchange(int which)
     {
-        if (world_ == 1) return;
+        // a one-rank group has nothing to exchange; PIQP_AMD_EXCHANGE_WORLD1=1 still goes through the callback (a 1-GPU box can then
+        // exercise the caller's RCCL transport end to end)
+        static const bool force1 = std::getenv("PIQP_AMD_EXCHANGE_WORLD1") != nullptr;
+        if (world_ == 1 && !(force1 && xfn_)) return;
         if (!xfn_) throw std::runtime_error("partitioned backend used before pq_kkt_set_exchange");
         PQ_HIP(hipStreamSynchronize(st_));
         if (xfn_(xuser_, which) != 0) throw std::runtime_error("exchange callback failed");

@@ -19,12 +19,14 @@ def init(backend=None):
     if torch.cuda.is_available():
         ngpu = torch.cuda.device_count()
         dev_index = local_rank % max(ngpu, 1)
-        if backend is None and world > 1:
+        if backend is None and (world > 1 or os.environ.get("PIQP_AMD_FORCE_PG")):
             backend = "nccl" if ngpu >= int(os.environ.get("LOCAL_WORLD_SIZE", world)) else "gloo"
         torch.cuda.set_device(dev_index)
-    if world > 1:
+    if world > 1 or os.environ.get("PIQP_AMD_FORCE_PG"):  # PIQP_AMD_FORCE_PG=1: a one-rank group (exercises the RCCL path on a 1-GPU box)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29598")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         if not dist.is_initialized():
             if backend is None:
                 backend = "gloo"
@@ -36,9 +38,12 @@ def init(backend=None):
 
 
 def _coll_device(device):
-    """tensors of the bookkeeping collectives live on the GPU only when the backend is RCCL"""
+    """tensors of the bookkeeping collectives: on this rank's GPU with RCCL ("nccl" has no CPU path), on the host otherwise"""
+    import torch
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_backend() != "nccl":
+    if dist.is_available() and dist.is_initialized():
+        if dist.get_backend() == "nccl":
+            return device if device is not None else torch.device("cuda", torch.cuda.current_device())
         return "cpu"
     return device if device is not None else "cpu"
 
@@ -138,7 +143,7 @@ class StagePartition:
         try:
             torch, dist = self.torch, self.dist
             self.calls[which] += 1
-            if self.world == 1:
+            if self.world == 1 and not (dist.is_available() and dist.is_initialized()):
                 return 0
             staged = self.backend != "nccl"
             if which in (0, 1):

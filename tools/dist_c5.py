@@ -56,7 +56,7 @@ def main():
     state = to_dev(random_vars(n, p, m, rng, positive=True))
     rhs = [to_dev(random_vars(n, p, m, rng)) for _ in range(2)]
     out = {"workload": (f"multistage chain n_x={args.nx} n_u={args.nu} stages={args.stages}" if args.problem == "chain" else "C3 sparse QP") + f": n={n} p={p} m={m}", "backend": args.backend, "world": world,
-           "transport": "gloo (host-staged, ranks share one GPU)" if shared_gpu else ("rccl" if world > 1 else "none")}
+           "transport": "gloo (host-staged, ranks share one GPU)" if shared_gpu else ("rccl" if (dist.is_available() and dist.is_initialized()) else "none")}
 
     def run_steps(k, steps):
         for i in range(steps):
@@ -130,7 +130,7 @@ def main():
         dist.barrier()
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.destroy_process_group()
 
 
