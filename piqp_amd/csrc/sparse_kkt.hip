@@ -269,6 +269,129 @@ __global__ __launch_bounds__(256) void k_front_factor(FrontMeta M, double* __res
 // case: a chain) and from HBM otherwise, the panel + Schur complement run in LDS, and only the factor panel (f x w) is written
 // to HBM; the update matrix goes to HBM only when the parent is not the next supernode of this walk.  Two LDS buffers
 // alternate between "front being factored" and "previous front, holding the update matrix".
+// Packed variant of the LDS subtree walk: both front buffers hold only the lower triangle (column j starts at j (2f - j + 1) / 2),
+// which halves the LDS of a walk -- a subtree with a 96 x 96 front drops from 147 KB to 74.5 KB and two workgroups share a CU.
+// pk_base(j, f) + i is the slot of entry (i, j), i >= j.
+__device__ __forceinline__ int pk_base(int j, int f) { return (j * (2 * f - j - 1)) >> 1; }
+__device__ __forceinline__ void schur_2x2_pk(double* __restrict__ W, int f, int w, int u, int tid, int nt)
+{
+    const int tx = tid & 15, ty = tid >> 4, tys = nt >> 4;
+    const int nb = (u + 1) >> 1;
+    for (int bj = ty; bj < nb; bj += tys) {
+        for (int bi = bj + tx; bi < nb; bi += 16) {
+            const int i0 = 2 * bi, j0 = 2 * bj;
+            const bool i1ok = i0 + 1 < u, j1ok = j0 + 1 < u;
+            const int ri0 = w + i0, ri1 = w + (i1ok ? i0 + 1 : i0), rj0 = w + j0, rj1 = w + (j1ok ? j0 + 1 : j0);
+            double a00 = 0.0, a01 = 0.0, a10 = 0.0, a11 = 0.0;
+            int ck = 0;  // pk_base(k, f)
+            for (int k = 0; k < w; ++k) {
+                const double* Ck = W + ck;
+                const double dk = Ck[k];
+                const double x0 = Ck[ri0] * dk, x1 = Ck[ri1] * dk, y0 = Ck[rj0], y1 = Ck[rj1];
+                a00 += x0 * y0; a01 += x0 * y1; a10 += x1 * y0; a11 += x1 * y1;
+                ck += f - k - 1;
+            }
+            double* T0 = W + pk_base(w + j0, f) + (w + i0);
+            T0[0] -= a00;
+            if (i1ok) T0[1] -= a10;
+            if (j1ok) {
+                double* T1 = W + pk_base(w + j0 + 1, f) + (w + i0);
+                if (i0 >= j0 + 1) T1[0] -= a01;
+                if (i1ok) T1[1] -= a11;
+            }
+        }
+    }
+}
+__global__ __launch_bounds__(1024) void k_subtree_factor_pk(FrontMeta M, double* __restrict__ fronts, const double* __restrict__ vals, const int* __restrict__ fe_offp,
+                                                           const int* __restrict__ sub_lo, const int* __restrict__ sub_hi, int cap, double* __restrict__ rdiag,
+                                                           int* __restrict__ info)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int tx = tid & 15, ty = tid >> 4, tys = nt >> 4;
+    const int lo = sub_lo[blockIdx.x], hi = sub_hi[blockIdx.x];
+    double* cur = lds;
+    double* prev = lds + cap;
+    bool prev_valid = false;
+    for (int s = lo; s <= hi; ++s) {
+        const SnRec me = M.sn[s];
+        const int first = me.first, w = me.w, f = me.f;
+        double* W = cur;
+        const int npk = (f * (f + 1)) >> 1;
+        for (int idx = tid; idx < npk; idx += nt) W[idx] = 0.0;
+        __syncthreads();
+        for (int e = me.fe_lo + tid; e < me.fe_hi; e += nt) W[fe_offp[e]] = vals[e];
+        __syncthreads();
+        for (int ci = me.child_lo; ci < me.child_hi; ++ci) {
+            const int c = M.child[ci];
+            const SnRec ch = M.sn[c];
+            const int wc = ch.w, fc = ch.f, uc = fc - wc;
+            const bool from_lds = prev_valid && c == s - 1;
+            const int* rel = M.rel + ch.rel_ptr;
+            if (from_lds) {
+                for (int j = ty; j < uc; j += tys) {
+                    const int cj = pk_base(rel[j], f);
+                    const double* Uj = prev + pk_base(wc + j, fc) + wc;
+                    for (int i = j + tx; i < uc; i += 16) W[cj + rel[i]] += Uj[i];
+                }
+            } else {
+                const double* U = fronts + ch.front_off + wc + (long long)wc * fc;
+                for (int j = ty; j < uc; j += tys) {
+                    const int cj = pk_base(rel[j], f);
+                    for (int i = j + tx; i < uc; i += 16) W[cj + rel[i]] += U[i + (long long)j * fc];
+                }
+            }
+            __syncthreads();
+        }
+        // ---- panel
+        for (int k = 0; k < w; ++k) {
+            const int ck = pk_base(k, f);
+            double d = W[ck + k];
+            if (d == 0.0) { if (tid == 0 && *info < 0) *info = first + k; d = 1.0; }
+            const double dinv = pivot_rcp(d);
+            if (tid == 0) rdiag[first + k] = dinv;
+            const int r = f - k - 1, pc = w - k - 1;
+            const double* colk = W + ck + (k + 1);
+            for (int j = ty; j < pc; j += tys) {
+                const double cj = colk[j];
+                double* Wj = W + pk_base(k + 1 + j, f) + (k + 1);
+                for (int i = j + tx; i < r; i += 16) Wj[i] -= (colk[i] * dinv) * cj;
+            }
+            __syncthreads();
+        }
+        for (int k = ty; k < w; k += tys) {   // deferred scaling of the finished columns (see front_factor)
+            double* Ck = W + pk_base(k, f);
+            double d = Ck[k];
+            if (d == 0.0) d = 1.0;
+            const double dinv = pivot_rcp(d);
+            for (int i = k + 1 + tx; i < f; i += 16) Ck[i] *= dinv;
+        }
+        __syncthreads();
+        const int u = f - w;
+        if (u > 0) {
+            schur_2x2_pk(W, f, w, u, tid, nt);
+            __syncthreads();
+        }
+        // ---- factor panel to HBM (full column-major layout there: the solves and the parents outside the subtree read it)
+        double* F = fronts + me.front_off;
+        for (int j = ty; j < w; j += tys) {
+            const double* Cj = W + pk_base(j, f);
+            double* Fj = F + (long long)j * f;
+            for (int i = j + tx; i < f; i += 16) Fj[i] = Cj[i];
+        }
+        const bool keep = me.parent == s + 1 && s + 1 <= hi;
+        if (!keep && u > 0) {
+            for (int j = ty; j < u; j += tys) {
+                const double* Cj = W + pk_base(w + j, f) + w;
+                for (int i = j + tx; i < u; i += 16) F[(w + i) + (long long)(w + j) * f] = Cj[i];
+            }
+        }
+        __syncthreads();
+        double* t = cur; cur = prev; prev = t;
+        prev_valid = keep;
+    }
+}
+
 __global__ __launch_bounds__(1024) void k_subtree_factor_lds(FrontMeta M, double* __restrict__ fronts, const double* __restrict__ vals, const int* __restrict__ fe_ptr,
                                                             const int* __restrict__ fe_q, const int* __restrict__ fe_off, const int* __restrict__ sub_lo,
                                                             const int* __restrict__ sub_hi, int cap, double* __restrict__ rdiag, int* __restrict__ info)
@@ -363,7 +486,7 @@ struct SubStage {
 };
 struct SubClass {  // subtrees launched together: same dynamic LDS size
     int nsub = 0, cap = 0, fmax = 0, bytes = 0, threads = 256;
-    bool staged = false, lds_walk = true;
+    bool staged = false, lds_walk = true, packed = false;
     SubStage stage{0, 0, 0};
     DBuf<int> lo, hi;
 };
@@ -1197,7 +1320,7 @@ private:
         ops_.clone_from(o.ops_, st_);
         cpd(vals_, o.vals_); cpd(fronts_, o.fronts_); cpd(rdiag_, o.rdiag_);
         xp_.alloc(o.xp_.n); fvec_.alloc(o.fvec_.n); dvec_.alloc(o.dvec_.n);
-        cpi(diag_pos_, o.diag_pos_); cpi(P_, o.P_); cpi(level_sn_, o.level_sn_); cpi(top_pos_, o.top_pos_); top_flags_.alloc(o.top_flags_.n ? o.top_flags_.n : 1); cpi(fe_ptr_, o.fe_ptr_); cpi(fe_q_, o.fe_q_); cpi(fe_off_, o.fe_off_);
+        cpi(diag_pos_, o.diag_pos_); cpi(P_, o.P_); cpi(level_sn_, o.level_sn_); cpi(top_pos_, o.top_pos_); top_flags_.alloc(o.top_flags_.n ? o.top_flags_.n : 1); cpi(fe_ptr_, o.fe_ptr_); cpi(fe_q_, o.fe_q_); cpi(fe_off_, o.fe_off_); cpi(fe_offp_, o.fe_offp_);
         snrec_.alloc(o.snrec_.n ? o.snrec_.n : 1); if (o.snrec_.n) PQ_HIP(hipMemcpyAsync(snrec_.p, o.snrec_.p, o.snrec_.bytes(), hipMemcpyDeviceToDevice, st_)); cpi(sn_first_, o.sn_first_); cpi(front_rows_ptr_, o.front_rows_ptr_); cpi(front_rows_, o.front_rows_);
         cpi(child_ptr_, o.child_ptr_); cpi(child_, o.child_); cpi(rel_ptr_, o.rel_ptr_); cpi(rel_, o.rel_);
         cpi(mapP_, o.mapP_); cpi(mapA_, o.mapA_); cpi(mapG_, o.mapG_);
@@ -1218,6 +1341,7 @@ private:
             PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_front_factor), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_FRONT_DOUBLES * (int)sizeof(double)));
             PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_subtree_factor), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_FRONT_DOUBLES * (int)sizeof(double)));
             PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_subtree_factor_lds), hipFuncAttributeMaxDynamicSharedMemorySize, SUBTREE_LDS_BYTES));
+            PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_subtree_factor_pk), hipFuncAttributeMaxDynamicSharedMemorySize, SUBTREE_LDS_BYTES));
             PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_subtree_factor_staged), hipFuncAttributeMaxDynamicSharedMemorySize, SUBTREE_LDS_BYTES));
             PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_top_factor), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_FRONT_DOUBLES * (int)sizeof(double)));
             attr_set = true;
@@ -1393,10 +1517,17 @@ private:
             if (!k.staged) b = bytes_of(k.cap, mx, false);
             k.bytes = (int)b;
             k.lds_walk = b <= SUBTREE_LDS_BYTES && !std::getenv("PIQP_AMD_SUBTREE_HBM");
+            // a walk that would own the CU's LDS with full fronts keeps only their lower triangles instead: half the LDS, two workgroups per CU
+            // (PIQP_AMD_SUBTREE_PACKED=0 / 1 forces it off / on for every class)
+            {
+                static const char* pe = std::getenv("PIQP_AMD_SUBTREE_PACKED");
+                k.packed = k.lds_walk && !k.staged && (pe ? pe[0] == '1' : b > 80 * 1024);
+                if (k.packed) { k.cap = (mx.fm * (mx.fm + 1)) / 2; b = 2LL * k.cap * 8; k.bytes = (int)b; }
+            }
             static const int thr_env = std::getenv("PIQP_AMD_SUBTREE_THREADS") ? std::atoi(std::getenv("PIQP_AMD_SUBTREE_THREADS")) : 0;
             // a workgroup that has the CU to itself (LDS) gets eight waves instead of four: measured 1.08 -> 1.04 ms on C3; with several
             // workgroups per CU more threads only add barrier cost (C5: 1.45 -> 2.0 ms)
-            k.threads = thr_env > 0 ? thr_env : (b > 80 * 1024 ? 512 : SUB_THREADS);
+            k.threads = thr_env > 0 ? thr_env : (b > 80 * 1024 ? 512 : (k.packed && b > 52 * 1024 ? 384 : SUB_THREADS));  // two packed walks per CU: 384 (C3 0.82 -> 0.79 ms)
             upload_vec(k.lo, lo, st_); upload_vec(k.hi, hi, st_);
             out.cls.push_back(std::move(k));
         }
@@ -1439,6 +1570,8 @@ private:
         for (const SubClass& c : sc.cls) {
             if (c.lds_walk && c.staged)
                 hipLaunchKernelGGL(k_subtree_factor_staged, dim3(c.nsub), dim3(c.threads), c.bytes, st_, M, fronts_.p, c.lo.p, c.hi.p, c.cap, c.stage, rdiag_.p, info_.p);
+            else if (c.lds_walk && c.packed)
+                hipLaunchKernelGGL(k_subtree_factor_pk, dim3(c.nsub), dim3(c.threads), c.bytes, st_, M, fronts_.p, vals_.p, fe_offp_.p, c.lo.p, c.hi.p, c.cap, rdiag_.p, info_.p);
             else if (c.lds_walk)
                 hipLaunchKernelGGL(k_subtree_factor_lds, dim3(c.nsub), dim3(c.threads), c.bytes, st_, M, fronts_.p, vals_.p, fe_ptr_.p, fe_q_.p, fe_off_.p, c.lo.p, c.hi.p, c.cap, rdiag_.p,
                                    info_.p);
@@ -1497,7 +1630,19 @@ private:
             upload_vec(top_pos_, tp, st_);
             top_flags_.alloc(2 * S_.top_level_sn.size() + 2);
         }
-        upload_vec(fe_ptr_, S_.fe_ptr, st_); upload_vec(fe_q_, S_.fe_q, st_); upload_vec(fe_off_, S_.fe_off, st_); upload_vec(sn_first_, S_.sn_first, st_);
+        upload_vec(fe_ptr_, S_.fe_ptr, st_); upload_vec(fe_q_, S_.fe_q, st_); upload_vec(fe_off_, S_.fe_off, st_);
+        {   // the same offsets for a front stored as its packed lower triangle (k_subtree_factor_pk)
+            std::vector<int> offp(S_.fe_off.size());
+            for (int t = 0; t < S_.nsuper; ++t) {
+                const int f = S_.front_rows_ptr[t + 1] - S_.front_rows_ptr[t];
+                for (int e = S_.fe_ptr[t]; e < S_.fe_ptr[t + 1]; ++e) {
+                    const int i = S_.fe_off[e] % f, j = S_.fe_off[e] / f;
+                    if (i < j) throw std::runtime_error("front entry above the diagonal");
+                    offp[e] = (j * (2 * f - j - 1)) / 2 + i;
+                }
+            }
+            upload_vec(fe_offp_, offp, st_);
+        } upload_vec(sn_first_, S_.sn_first, st_);
         upload_vec(front_rows_ptr_, S_.front_rows_ptr, st_); upload_vec(front_rows_, S_.front_rows, st_); upload_vec(child_ptr_, S_.child_ptr, st_); upload_vec(child_, S_.child, st_);
         upload_vec(rel_ptr_, S_.rel_ptr, st_); upload_vec(rel_, S_.rel, st_); upload_vec(front_off_, S_.front_off, st_);
         {
@@ -1614,7 +1759,7 @@ private:
     bool top_persistent_ = false;
     CscOperators ops_;
     DBuf<double> vals_, fronts_, rdiag_, xp_, fvec_, dvec_;
-    DBuf<int> fe_ptr_, fe_q_, fe_off_, top_pos_, top_flags_;
+    DBuf<int> fe_ptr_, fe_q_, fe_off_, fe_offp_, top_pos_, top_flags_;
     DBuf<SnRec> snrec_;
     DBuf<int> diag_pos_, P_, level_sn_, sn_first_, front_rows_ptr_, front_rows_, child_ptr_, child_, rel_ptr_, rel_;
     DBuf<int> mapP_, mapA_, mapG_, mapAA_, mapGG_, aa_ptr_, aa_q1_, aa_q2_, aa_k_, gg_ptr_, gg_q1_, gg_q2_, gg_k_;
