@@ -1276,6 +1276,7 @@ public:
 
     void print_info() override
     {
+        std::printf("substitution schedule: %d single-wave walks, %d supernodes in %d flag-ordered levels above them\n", (int)S_.solve_sub_lo.size(), ntop_solve_, S_.solve_top_nlevels);
         std::printf("top of the tree: %d supernodes in %d levels: %d level launches, then %d supernodes in one persistent launch\n", ntop_, S_.top_nlevels, top_l0_, top_nper_);
         if (std::getenv("PIQP_AMD_PRINT_LEVELS")) {
             for (int l = 0; l < S_.top_nlevels; ++l) {
@@ -1320,7 +1321,7 @@ private:
         ops_.clone_from(o.ops_, st_);
         cpd(vals_, o.vals_); cpd(fronts_, o.fronts_); cpd(rdiag_, o.rdiag_);
         xp_.alloc(o.xp_.n); fvec_.alloc(o.fvec_.n); dvec_.alloc(o.dvec_.n);
-        cpi(diag_pos_, o.diag_pos_); cpi(P_, o.P_); cpi(level_sn_, o.level_sn_); cpi(top_pos_, o.top_pos_); top_flags_.alloc(o.top_flags_.n ? o.top_flags_.n : 1); cpi(fe_ptr_, o.fe_ptr_); cpi(fe_q_, o.fe_q_); cpi(fe_off_, o.fe_off_); cpi(fe_offp_, o.fe_offp_);
+        cpi(diag_pos_, o.diag_pos_); cpi(P_, o.P_); cpi(level_sn_, o.level_sn_); cpi(top_pos_, o.top_pos_); top_flags_.alloc(o.top_flags_.n ? o.top_flags_.n : 1); cpi(solve_level_sn_, o.solve_level_sn_); cpi(solve_top_pos_, o.solve_top_pos_); solve_flags_.alloc(o.solve_flags_.n ? o.solve_flags_.n : 1); ntop_solve_ = o.ntop_solve_; cpi(fe_ptr_, o.fe_ptr_); cpi(fe_q_, o.fe_q_); cpi(fe_off_, o.fe_off_); cpi(fe_offp_, o.fe_offp_);
         snrec_.alloc(o.snrec_.n ? o.snrec_.n : 1); if (o.snrec_.n) PQ_HIP(hipMemcpyAsync(snrec_.p, o.snrec_.p, o.snrec_.bytes(), hipMemcpyDeviceToDevice, st_)); cpi(sn_first_, o.sn_first_); cpi(front_rows_ptr_, o.front_rows_ptr_); cpi(front_rows_, o.front_rows_);
         cpi(child_ptr_, o.child_ptr_); cpi(child_, o.child_); cpi(rel_ptr_, o.rel_ptr_); cpi(rel_, o.rel_);
         cpi(mapP_, o.mapP_); cpi(mapA_, o.mapA_); cpi(mapG_, o.mapG_);
@@ -1330,6 +1331,7 @@ private:
         cpl(front_off_, o.front_off_);
         info_.alloc(1); info_h_.alloc(1);
         build_full_schedule();
+        build_solve_schedule();
         PQ_HIP(hipStreamSynchronize(st_));
     }
 
@@ -1410,22 +1412,24 @@ private:
     }
     void solve_numeric(const FrontMeta& M)
     {
-        subtree_fwd(M, sched_);
+        // the sweeps run on their own (finer) partition of the tree: S_.solve_*
+        const int nt = ntop_solve_;
+        subtree_fwd(M, solve_sched_);
         // the top of the tree: one launch per sweep when every top front fits the single-wave kernels, else one launch per level
-        bool wave_top = ntop_ > 1 && !std::getenv("PIQP_AMD_TOP_LEVELS_SOLVE") && !std::getenv("PIQP_AMD_SUBTREE_SOLVE_V1");
-        if (wave_top) for (int s2 : S_.top_level_sn) if (S_.front_rows_ptr[s2 + 1] - S_.front_rows_ptr[s2] > 128) { wave_top = false; break; }
+        bool wave_top = nt > 1 && !std::getenv("PIQP_AMD_TOP_LEVELS_SOLVE") && !std::getenv("PIQP_AMD_SUBTREE_SOLVE_V1");
+        if (wave_top) for (int s2 : S_.solve_top_level_sn) if (S_.front_rows_ptr[s2 + 1] - S_.front_rows_ptr[s2] > 128) { wave_top = false; break; }
         if (wave_top) {
-            PQ_HIP(hipMemsetAsync(top_flags_.p, 0, sizeof(int) * (2 * (size_t)ntop_ + 1), st_));
-            hipLaunchKernelGGL(k_subtree_fwd_wave<true>, dim3(ntop_), dim3(64), 0, st_, M, fronts_.p, level_sn_.p, level_sn_.p, xp_.p, fvec_.p, top_pos_.p, top_flags_.p,
-                               top_flags_.p + 2 * ntop_);
-        } else fwd_levels(M, S_.top_level_ptr, S_.top_level_sn, level_sn_.p);
+            PQ_HIP(hipMemsetAsync(solve_flags_.p, 0, sizeof(int) * (2 * (size_t)nt + 1), st_));
+            hipLaunchKernelGGL(k_subtree_fwd_wave<true>, dim3(nt), dim3(64), 0, st_, M, fronts_.p, solve_level_sn_.p, solve_level_sn_.p, xp_.p, fvec_.p, solve_top_pos_.p, solve_flags_.p,
+                               solve_flags_.p + 2 * nt);
+        } else fwd_levels(M, S_.solve_top_level_ptr, S_.solve_top_level_sn, solve_level_sn_.p);
         hipLaunchKernelGGL(k_scale, g1(N_), dim3(256), 0, st_, N_, rdiag_.p, xp_.p);
         if (wave_top) {
-            hipLaunchKernelGGL(k_subtree_bwd_wave<true>, dim3(ntop_), dim3(64), 0, st_, M, fronts_.p, level_sn_.p, level_sn_.p, xp_.p, bwd_red_thr(), ntop_, top_pos_.p,
-                               top_flags_.p + ntop_, top_flags_.p + 2 * ntop_);
-            hipLaunchKernelGGL(k_top_check, dim3(1), dim3(1), 0, st_, top_flags_.p + 2 * ntop_, (int*)nullptr, xp_.p);
-        } else bwd_levels(M, S_.top_level_ptr, S_.top_level_sn, level_sn_.p);
-        subtree_bwd(M, sched_);
+            hipLaunchKernelGGL(k_subtree_bwd_wave<true>, dim3(nt), dim3(64), 0, st_, M, fronts_.p, solve_level_sn_.p, solve_level_sn_.p, xp_.p, bwd_red_thr(), nt, solve_top_pos_.p,
+                               solve_flags_.p + nt, solve_flags_.p + 2 * nt);
+            hipLaunchKernelGGL(k_top_check, dim3(1), dim3(1), 0, st_, solve_flags_.p + 2 * nt, (int*)nullptr, xp_.p);
+        } else bwd_levels(M, S_.solve_top_level_ptr, S_.solve_top_level_sn, solve_level_sn_.p);
+        subtree_bwd(M, solve_sched_);
     }
     // records what `body` launches on the handle's stream into an executable graph (nullptr if the runtime refuses: the caller then
     // launches directly)
@@ -1551,6 +1555,16 @@ private:
         for (int k = 0; k < S_.nsub; ++k) all[k] = k;
         build_sub_schedule(all, sched_);
     }
+    void build_solve_schedule()
+    {
+        solve_sched_.cls.clear();
+        if (S_.solve_sub_lo.empty()) return;
+        SubClass k;
+        k.nsub = (int)S_.solve_sub_lo.size();
+        k.fmax = S_.solve_sub_max_front;
+        upload_vec(k.lo, S_.solve_sub_lo, st_); upload_vec(k.hi, S_.solve_sub_hi, st_);
+        solve_sched_.cls.push_back(std::move(k));
+    }
     void subtree_fwd(const FrontMeta& M, const SubSchedule& sc)
     {
         for (const SubClass& c : sc.cls) {
@@ -1629,6 +1643,15 @@ private:
             for (size_t q = 0; q < S_.top_level_sn.size(); ++q) tp[S_.top_level_sn[q]] = (int)q;
             upload_vec(top_pos_, tp, st_);
             top_flags_.alloc(2 * S_.top_level_sn.size() + 2);
+        }
+        {   // the substitution's own schedule
+            upload_vec(solve_level_sn_, S_.solve_top_level_sn, st_);
+            ntop_solve_ = (int)S_.solve_top_level_sn.size();
+            std::vector<int> tp(S_.nsuper ? S_.nsuper : 1, -1);
+            for (size_t q = 0; q < S_.solve_top_level_sn.size(); ++q) tp[S_.solve_top_level_sn[q]] = (int)q;
+            upload_vec(solve_top_pos_, tp, st_);
+            solve_flags_.alloc(2 * S_.solve_top_level_sn.size() + 2);
+            build_solve_schedule();
         }
         upload_vec(fe_ptr_, S_.fe_ptr, st_); upload_vec(fe_q_, S_.fe_q, st_); upload_vec(fe_off_, S_.fe_off, st_);
         {   // the same offsets for a front stored as its packed lower triangle (k_subtree_factor_pk)
@@ -1759,7 +1782,9 @@ private:
     bool top_persistent_ = false;
     CscOperators ops_;
     DBuf<double> vals_, fronts_, rdiag_, xp_, fvec_, dvec_;
-    DBuf<int> fe_ptr_, fe_q_, fe_off_, fe_offp_, top_pos_, top_flags_;
+    DBuf<int> fe_ptr_, fe_q_, fe_off_, fe_offp_, top_pos_, top_flags_, solve_level_sn_, solve_top_pos_, solve_flags_;
+    SubSchedule solve_sched_;
+    int ntop_solve_ = 0;
     DBuf<SnRec> snrec_;
     DBuf<int> diag_pos_, P_, level_sn_, sn_first_, front_rows_ptr_, front_rows_, child_ptr_, child_, rel_ptr_, rel_;
     DBuf<int> mapP_, mapA_, mapG_, mapAA_, mapGG_, aa_ptr_, aa_q1_, aa_q2_, aa_k_, gg_ptr_, gg_q1_, gg_q2_, gg_k_;

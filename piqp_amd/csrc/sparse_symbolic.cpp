@@ -699,10 +699,7 @@ static void analyse_with_order(Symbolic& S, const IVec& perm0)
     // ---- subtree-to-workgroup partition: a supernode roots a "small subtree" when its whole subtree has at most SUB_COLS
     // columns and its parent's does not.  Supernodes are numbered in postorder, so a subtree is the contiguous range
     // [s - desc[s], s].
-    {
-        int SUB_COLS = 192, SUB_FMAX = 96;  // two 96 x 96 fronts fit the 160 KiB of LDS of one workgroup
-        if (const char* e = std::getenv("PIQP_AMD_SUB_COLS")) SUB_COLS = std::max(8, std::atoi(e));
-        if (const char* e = std::getenv("PIQP_AMD_SUB_FMAX")) SUB_FMAX = std::min(96, std::max(8, std::atoi(e)));
+    auto subtree_schedule = [&](int SUB_COLS, int SUB_FMAX, IVec& sub_lo, IVec& sub_hi, int& sub_max_front, IVec& top_level_ptr, IVec& top_level_sn, int& top_nlevels) {
         IVec cols(ns, 0), desc(ns, 0), fmax(ns, 0);
         for (int s = 0; s < ns; ++s) {
             cols[s] += S.sn_first[s + 1] - S.sn_first[s];
@@ -712,15 +709,14 @@ static void analyse_with_order(Symbolic& S, const IVec& perm0)
         }
         for (int s = 0; s < ns; ++s) if (fmax[s] > SUB_FMAX) cols[s] = SUB_COLS + 1;  // a subtree holding a wide front is not "small"
         IVec in_sub(ns, 0);
-        S.sub_lo.clear(); S.sub_hi.clear(); S.sub_max_front = 0;
+        sub_lo.clear(); sub_hi.clear(); sub_max_front = 0;
         for (int s = 0; s < ns; ++s) {
             const int ps = S.sn_parent[s];
             if (cols[s] <= SUB_COLS && (ps < 0 || cols[ps] > SUB_COLS)) {
-                S.sub_lo.push_back(s - desc[s]); S.sub_hi.push_back(s);
-                for (int t = s - desc[s]; t <= s; ++t) { in_sub[t] = 1; S.sub_max_front = std::max(S.sub_max_front, S.front_rows_ptr[t + 1] - S.front_rows_ptr[t]); }
+                sub_lo.push_back(s - desc[s]); sub_hi.push_back(s);
+                for (int t = s - desc[s]; t <= s; ++t) { in_sub[t] = 1; sub_max_front = std::max(sub_max_front, S.front_rows_ptr[t + 1] - S.front_rows_ptr[t]); }
             }
         }
-        S.nsub = (int)S.sub_lo.size();
         IVec tl(ns, -1);
         int tmax = -1;
         for (int s = 0; s < ns; ++s) {
@@ -731,13 +727,31 @@ static void analyse_with_order(Symbolic& S, const IVec& perm0)
             if (ps >= 0) tl[ps] = std::max(tl[ps], tl[s] + 1);
         }
         // a parent of a subtree root starts at level 0 (its subtree children are complete before the level phase)
-        S.top_nlevels = tmax + 1;
-        S.top_level_ptr.assign(S.top_nlevels + 1, 0);
-        for (int s = 0; s < ns; ++s) if (!in_sub[s]) S.top_level_ptr[tl[s] + 1]++;
-        for (int l = 0; l < S.top_nlevels; ++l) S.top_level_ptr[l + 1] += S.top_level_ptr[l];
-        S.top_level_sn.assign(S.top_level_ptr[S.top_nlevels], 0);
-        IVec nx(S.top_level_ptr.begin(), S.top_level_ptr.end() - 1);
-        for (int s = 0; s < ns; ++s) if (!in_sub[s]) S.top_level_sn[nx[tl[s]]++] = s;
+        top_nlevels = tmax + 1;
+        top_level_ptr.assign(top_nlevels + 1, 0);
+        for (int s = 0; s < ns; ++s) if (!in_sub[s]) top_level_ptr[tl[s] + 1]++;
+        for (int l = 0; l < top_nlevels; ++l) top_level_ptr[l + 1] += top_level_ptr[l];
+        top_level_sn.assign(top_level_ptr[top_nlevels], 0);
+        IVec nx(top_level_ptr.begin(), top_level_ptr.end() - 1);
+        for (int s = 0; s < ns; ++s) if (!in_sub[s]) top_level_sn[nx[tl[s]]++] = s;
+    };
+    {
+        int SUB_COLS = 192, SUB_FMAX = 96;  // two 96 x 96 fronts fit the 160 KiB of LDS of one workgroup
+        if (const char* e = std::getenv("PIQP_AMD_SUB_COLS")) SUB_COLS = std::max(8, std::atoi(e));
+        if (const char* e = std::getenv("PIQP_AMD_SUB_FMAX")) SUB_FMAX = std::min(96, std::max(8, std::atoi(e)));
+        subtree_schedule(SUB_COLS, SUB_FMAX, S.sub_lo, S.sub_hi, S.sub_max_front, S.top_level_ptr, S.top_level_sn, S.top_nlevels);
+        S.nsub = (int)S.sub_lo.size();
+        // substitution: one wave walks a subtree front by front, so the sweep lasts as long as the longest walk -- shorter walks and a
+        // larger flag-ordered top are faster there (C3 backend solve 0.52 -> 0.42 ms, C5-size chain 0.89 -> 0.84 ms at 32 columns), the factorisation prefers the
+        // long LDS-resident walks above
+        int SOLVE_COLS = 32;
+        if (const char* e = std::getenv("PIQP_AMD_SOLVE_SUB_COLS")) SOLVE_COLS = std::atoi(e);
+        if (SOLVE_COLS <= 0 || SOLVE_COLS >= SUB_COLS) {
+            S.solve_sub_lo = S.sub_lo; S.solve_sub_hi = S.sub_hi; S.solve_top_level_ptr = S.top_level_ptr; S.solve_top_level_sn = S.top_level_sn;
+            S.solve_top_nlevels = S.top_nlevels; S.solve_sub_max_front = S.sub_max_front;
+        } else {
+            subtree_schedule(std::max(8, SOLVE_COLS), SUB_FMAX, S.solve_sub_lo, S.solve_sub_hi, S.solve_sub_max_front, S.solve_top_level_ptr, S.solve_top_level_sn, S.solve_top_nlevels);
+        }
     }
 
     // ---- assembly map: upper entry (i, k), i <= k  ==  lower entry (k, i) of the front that owns column i

@@ -59,6 +59,11 @@ struct Symbolic {
     int nsub = 0, sub_max_front = 0;
     IVec top_level_ptr, top_level_sn;
     int top_nlevels = 0;
+    // the substitution sweeps use their own, finer partition of the same tree (shorter single-wave walks, more supernodes in the
+    // flag-ordered top): same meaning as the five members above
+    IVec solve_sub_lo, solve_sub_hi;
+    IVec solve_top_level_ptr, solve_top_level_sn;
+    int solve_top_nlevels = 0, solve_sub_max_front = 0;
     // assembly: PKPt value q goes to fronts[a_dst[q]]
     std::vector<long long> a_dst;
     IVec fe_ptr, fe_q, fe_off;  // the same map grouped by owning supernode: entries fe_ptr[s]..fe_ptr[s+1]: value index, offset inside the front
