@@ -199,8 +199,18 @@ __device__ void extend_add(const FrontMeta& M, double* __restrict__ fronts, int 
 // One workgroup per front: extend-add, then right-looking LDLt of the first w columns (unit L below the
 // diagonal, D on it), Schur complement left in the trailing (f-w) x (f-w) block for the parent.
 // Fails (info = first failing global column) iff a pivot is exactly zero, like ldlt.hpp:163.
+// zero + the K entries the front owns: needs nothing from the children, so the persistent top kernel runs it while they are still busy
+__device__ __forceinline__ void front_assemble_own(const FrontMeta& M, double* __restrict__ fronts, const SnRec& me, double* __restrict__ lds)
+{
+    const int f = me.f;
+    double* W = (long long)f * f <= LDS_FRONT_DOUBLES ? lds : fronts + me.front_off;
+    for (int idx = threadIdx.x; idx < f * f; idx += blockDim.x) W[idx] = 0.0;
+    __syncthreads();
+    for (int e = me.fe_lo + threadIdx.x; e < me.fe_hi; e += blockDim.x) W[M.fe_off[e]] = M.vals[e];
+    __syncthreads();
+}
 __device__ void front_factor(const FrontMeta& M, double* __restrict__ fronts, int s, int big_front, int big_pivots, double* __restrict__ rdiag, int* __restrict__ info,
-                             double* __restrict__ lds)
+                             double* __restrict__ lds, bool own_assembled = false)
 {
     const SnRec me = M.sn[s];
     const int first = me.first, w = me.w, f = me.f;
@@ -209,10 +219,7 @@ __device__ void front_factor(const FrontMeta& M, double* __restrict__ fronts, in
     const bool in_lds = (long long)f * f <= LDS_FRONT_DOUBLES;
     double* W = in_lds ? lds : F;
     // assembly: zero, own K entries, then the children's update matrices (fixed order)
-    for (int idx = threadIdx.x; idx < f * f; idx += blockDim.x) W[idx] = 0.0;
-    __syncthreads();
-    for (int e = me.fe_lo + threadIdx.x; e < me.fe_hi; e += blockDim.x) W[M.fe_off[e]] = M.vals[e];
-    __syncthreads();
+    if (!own_assembled) front_assemble_own(M, fronts, me, lds);
     extend_add(M, fronts, s, W, f);
     // ---- panel: right-looking LDLt of the first w columns, updates confined to the panel (rows k+1..f-1, columns k+1..w-1)
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -252,7 +259,11 @@ __device__ void front_factor(const FrontMeta& M, double* __restrict__ fronts, in
         __syncthreads();
     }
     if (in_lds) {
-        for (int idx = threadIdx.x; idx < f * f; idx += blockDim.x) F[idx] = lds[idx];
+        // the factor panel (contiguous) and the lower triangle of the update matrix: nobody reads the rest
+        for (int idx = threadIdx.x; idx < f * w; idx += blockDim.x) F[idx] = lds[idx];
+        const int tx = tid & 15, ty = tid >> 4, tys = nt >> 4;
+        for (int j = w + ty; j < f; j += tys)
+            for (int i = j + tx; i < f; i += 16) F[i + (long long)j * f] = lds[i + j * f];
     }
 }
 
@@ -751,6 +762,24 @@ __device__ __forceinline__ double bcast_row(double v0, double v1, int row)
 // order): a workgroup waits for the flags of its children, takes their update vectors with agent-scope loads (they were stored write-through
 // by another CU a microsecond earlier: no fence needed on either side) and publishes its own flag.  Dependencies always have a smaller
 // block index, so they were dispatched earlier: no deadlock whatever the residency.
+// Pulls the factor panel of a front towards this CU while the wave still waits for its neighbours in the tree: one load per 128-byte
+// line (up to four per lane = 32 KB), summed and consumed by an empty asm only after the wait.
+struct PanelTouch { double t[4]; };
+__device__ __forceinline__ PanelTouch touch_panel(const double* __restrict__ F, int n, int lane)
+{
+    PanelTouch p;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int i = (lane + 64 * u) * 16;
+        p.t[u] = i < n ? F[i] : 0.0;
+    }
+    return p;
+}
+__device__ __forceinline__ void touch_done(const PanelTouch& p)
+{
+    const double acc = (p.t[0] + p.t[1]) + (p.t[2] + p.t[3]);
+    asm volatile("" ::"v"(acc));
+}
 template <bool TOP>
 __global__ __launch_bounds__(64) void k_subtree_fwd_wave(FrontMeta M, const double* __restrict__ fronts, const int* __restrict__ sub_lo, const int* __restrict__ sub_hi,
                                                          double* __restrict__ x, double* __restrict__ fvec, const int* __restrict__ top_pos, int* __restrict__ flags,
@@ -758,20 +787,24 @@ __global__ __launch_bounds__(64) void k_subtree_fwd_wave(FrontMeta M, const doub
 {
     __shared__ double sv[2][128];
     const int lane = threadIdx.x, r0 = lane, r1 = lane + 64;
-    const int lo = sub_lo[blockIdx.x], hi = TOP ? lo : sub_hi[blockIdx.x];
-    if (TOP) {
-        const SnRec me = M.sn[lo];
-        for (int ci = me.child_lo; ci < me.child_hi; ++ci) {
-            const int tp = top_pos[M.child[ci]];
-            if (tp >= 0) wave_wait_flag(flags + tp, err);
-        }
-    }
+    // TOP: the walk is a chain of top supernodes (parent[t] == t + 1); children outside the walk are waited for by flag
+    const int lo = sub_lo[blockIdx.x], hi = sub_hi[blockIdx.x];
     int cur = 0;
     bool prev_valid = false;  // sv[cur ^ 1][0 .. u) = update vector of supernode s - 1
     for (int s = lo; s <= hi; ++s) {
         const SnRec me = M.sn[s];
         const int first = me.first, w = me.w, f = me.f;
         const double* F = fronts + me.front_off;
+        if (TOP) {
+            const PanelTouch pt = touch_panel(F, f * w, lane);
+            for (int ci = me.child_lo; ci < me.child_hi; ++ci) {
+                const int c = M.child[ci];
+                if (prev_valid && c == s - 1) continue;
+                const int tp = top_pos[c];
+                if (tp >= 0) wave_wait_flag(flags + tp, err);
+            }
+            touch_done(pt);
+        }
         double* a = sv[cur];
         if (r0 < f) a[r0] = r0 < w ? x[first + r0] : 0.0;
         if (r1 < f) a[r1] = r1 < w ? x[first + r1] : 0.0;
@@ -819,7 +852,7 @@ __global__ __launch_bounds__(64) void k_subtree_fwd_wave(FrontMeta M, const doub
         cur ^= 1;
         prev_valid = keep;
     }
-    if (TOP) wave_publish_flag(flags + blockIdx.x);
+    if (TOP) wave_publish_flag(flags + top_pos[hi]);
 }
 // TOP = true: as above for the backward sweep; sub_lo = the level-sorted list, block b takes entry ntop - 1 - b (parents first) and waits
 // for its parent's flag; the ancestors' solution entries are read with agent-scope loads, its own are stored write-through
@@ -830,10 +863,16 @@ __global__ __launch_bounds__(64) void k_subtree_bwd_wave(FrontMeta M, const doub
 {
     __shared__ double sv[2][128];
     const int lane = threadIdx.x, r0 = lane, r1 = lane + 64;
-    const int lo = TOP ? sub_lo[ntop - 1 - (int)blockIdx.x] : sub_lo[blockIdx.x], hi = TOP ? lo : sub_hi[blockIdx.x];
+    // TOP: walks in reverse order (ntop = number of walks); the parent of the walk's last supernode is waited for by flag, every
+    // supernode of the walk publishes its own flag (children outside the walk hang off any of them)
+    const int wi = TOP ? ntop - 1 - (int)blockIdx.x : (int)blockIdx.x;
+    const int lo = sub_lo[wi], hi = sub_hi[wi];
     if (TOP) {
-        const int par = M.sn[lo].parent;
+        const SnRec me = M.sn[hi];
+        const PanelTouch pt = touch_panel(fronts + me.front_off, me.f * me.w, lane);
+        const int par = me.parent;
         if (par >= 0) wave_wait_flag(flags + top_pos[par], err);
+        touch_done(pt);
     }
     int cur = 0;
     bool prev_valid = false;  // sv[cur ^ 1][0 .. f_parent) = final vector of supernode s + 1
@@ -919,8 +958,8 @@ __global__ __launch_bounds__(64) void k_subtree_bwd_wave(FrontMeta M, const doub
         __syncthreads();
         cur ^= 1;
         prev_valid = true;
+        if (TOP) wave_publish_flag(flags + top_pos[s]);
     }
-    if (TOP) wave_publish_flag(flags + top_pos[lo]);
 }
 
 // ---- the top of the assembly tree in ONE launch: workgroup b takes the top supernodes b, b + G, ... of the level-sorted (=
@@ -946,6 +985,7 @@ __global__ __launch_bounds__(512) void k_top_factor(FrontMeta M, double* __restr
     for (int b = blockIdx.x; b < ntop; b += gridDim.x) {
         const int s = list[b];
         const SnRec me = M.sn[s];
+        front_assemble_own(M, fronts, me, lds);
         // one lane polls every child's flag (relaxed), then ONE agent-scope acquire by that lane invalidates this CU's L1 for the whole
         // workgroup (a fence per child executed by all 256 threads cost several microseconds per front)
         if (threadIdx.x == 0) {
@@ -966,7 +1006,7 @@ __global__ __launch_bounds__(512) void k_top_factor(FrontMeta M, double* __restr
             if (any) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
         __syncthreads();
-        front_factor(M, fronts, s, 1 << 30, 1 << 30, rdiag, info, lds);
+        front_factor(M, fronts, s, 1 << 30, 1 << 30, rdiag, info, lds, true);
         top_done(flags + b);
     }
 }
@@ -1277,6 +1317,7 @@ public:
     void print_info() override
     {
         std::printf("substitution schedule: %d single-wave walks, %d supernodes in %d flag-ordered levels above them\n", (int)S_.solve_sub_lo.size(), ntop_solve_, S_.solve_top_nlevels);
+        std::printf("substitution top: %d chain walks\n", nwalk_solve_);
         std::printf("top of the tree: %d supernodes in %d levels: %d level launches, then %d supernodes in one persistent launch\n", ntop_, S_.top_nlevels, top_l0_, top_nper_);
         if (std::getenv("PIQP_AMD_PRINT_LEVELS")) {
             for (int l = 0; l < S_.top_nlevels; ++l) {
@@ -1321,7 +1362,7 @@ private:
         ops_.clone_from(o.ops_, st_);
         cpd(vals_, o.vals_); cpd(fronts_, o.fronts_); cpd(rdiag_, o.rdiag_);
         xp_.alloc(o.xp_.n); fvec_.alloc(o.fvec_.n); dvec_.alloc(o.dvec_.n);
-        cpi(diag_pos_, o.diag_pos_); cpi(P_, o.P_); cpi(level_sn_, o.level_sn_); cpi(top_pos_, o.top_pos_); top_flags_.alloc(o.top_flags_.n ? o.top_flags_.n : 1); cpi(solve_level_sn_, o.solve_level_sn_); cpi(solve_top_pos_, o.solve_top_pos_); solve_flags_.alloc(o.solve_flags_.n ? o.solve_flags_.n : 1); ntop_solve_ = o.ntop_solve_; cpi(fe_ptr_, o.fe_ptr_); cpi(fe_q_, o.fe_q_); cpi(fe_off_, o.fe_off_); cpi(fe_offp_, o.fe_offp_);
+        cpi(diag_pos_, o.diag_pos_); cpi(P_, o.P_); cpi(level_sn_, o.level_sn_); cpi(top_pos_, o.top_pos_); top_flags_.alloc(o.top_flags_.n ? o.top_flags_.n : 1); cpi(solve_level_sn_, o.solve_level_sn_); cpi(solve_top_pos_, o.solve_top_pos_); solve_flags_.alloc(o.solve_flags_.n ? o.solve_flags_.n : 1); ntop_solve_ = o.ntop_solve_; cpi(solve_walk_lo_, o.solve_walk_lo_); cpi(solve_walk_hi_, o.solve_walk_hi_); nwalk_solve_ = o.nwalk_solve_; cpi(fe_ptr_, o.fe_ptr_); cpi(fe_q_, o.fe_q_); cpi(fe_off_, o.fe_off_); cpi(fe_offp_, o.fe_offp_);
         snrec_.alloc(o.snrec_.n ? o.snrec_.n : 1); if (o.snrec_.n) PQ_HIP(hipMemcpyAsync(snrec_.p, o.snrec_.p, o.snrec_.bytes(), hipMemcpyDeviceToDevice, st_)); cpi(sn_first_, o.sn_first_); cpi(front_rows_ptr_, o.front_rows_ptr_); cpi(front_rows_, o.front_rows_);
         cpi(child_ptr_, o.child_ptr_); cpi(child_, o.child_); cpi(rel_ptr_, o.rel_ptr_); cpi(rel_, o.rel_);
         cpi(mapP_, o.mapP_); cpi(mapA_, o.mapA_); cpi(mapG_, o.mapG_);
@@ -1420,12 +1461,12 @@ private:
         if (wave_top) for (int s2 : S_.solve_top_level_sn) if (S_.front_rows_ptr[s2 + 1] - S_.front_rows_ptr[s2] > 128) { wave_top = false; break; }
         if (wave_top) {
             PQ_HIP(hipMemsetAsync(solve_flags_.p, 0, sizeof(int) * (2 * (size_t)nt + 1), st_));
-            hipLaunchKernelGGL(k_subtree_fwd_wave<true>, dim3(nt), dim3(64), 0, st_, M, fronts_.p, solve_level_sn_.p, solve_level_sn_.p, xp_.p, fvec_.p, solve_top_pos_.p, solve_flags_.p,
+            hipLaunchKernelGGL(k_subtree_fwd_wave<true>, dim3(nwalk_solve_), dim3(64), 0, st_, M, fronts_.p, solve_walk_lo_.p, solve_walk_hi_.p, xp_.p, fvec_.p, solve_top_pos_.p, solve_flags_.p,
                                solve_flags_.p + 2 * nt);
         } else fwd_levels(M, S_.solve_top_level_ptr, S_.solve_top_level_sn, solve_level_sn_.p);
         hipLaunchKernelGGL(k_scale, g1(N_), dim3(256), 0, st_, N_, rdiag_.p, xp_.p);
         if (wave_top) {
-            hipLaunchKernelGGL(k_subtree_bwd_wave<true>, dim3(nt), dim3(64), 0, st_, M, fronts_.p, solve_level_sn_.p, solve_level_sn_.p, xp_.p, bwd_red_thr(), nt, solve_top_pos_.p,
+            hipLaunchKernelGGL(k_subtree_bwd_wave<true>, dim3(nwalk_solve_), dim3(64), 0, st_, M, fronts_.p, solve_walk_lo_.p, solve_walk_hi_.p, xp_.p, bwd_red_thr(), nwalk_solve_, solve_top_pos_.p,
                                solve_flags_.p + nt, solve_flags_.p + 2 * nt);
             hipLaunchKernelGGL(k_top_check, dim3(1), dim3(1), 0, st_, solve_flags_.p + 2 * nt, (int*)nullptr, xp_.p);
         } else bwd_levels(M, S_.solve_top_level_ptr, S_.solve_top_level_sn, solve_level_sn_.p);
@@ -1651,6 +1692,8 @@ private:
             for (size_t q = 0; q < S_.solve_top_level_sn.size(); ++q) tp[S_.solve_top_level_sn[q]] = (int)q;
             upload_vec(solve_top_pos_, tp, st_);
             solve_flags_.alloc(2 * S_.solve_top_level_sn.size() + 2);
+            upload_vec(solve_walk_lo_, S_.solve_walk_lo, st_); upload_vec(solve_walk_hi_, S_.solve_walk_hi, st_);
+            nwalk_solve_ = (int)S_.solve_walk_lo.size();
             build_solve_schedule();
         }
         upload_vec(fe_ptr_, S_.fe_ptr, st_); upload_vec(fe_q_, S_.fe_q, st_); upload_vec(fe_off_, S_.fe_off, st_);
@@ -1782,9 +1825,9 @@ private:
     bool top_persistent_ = false;
     CscOperators ops_;
     DBuf<double> vals_, fronts_, rdiag_, xp_, fvec_, dvec_;
-    DBuf<int> fe_ptr_, fe_q_, fe_off_, fe_offp_, top_pos_, top_flags_, solve_level_sn_, solve_top_pos_, solve_flags_;
+    DBuf<int> fe_ptr_, fe_q_, fe_off_, fe_offp_, top_pos_, top_flags_, solve_level_sn_, solve_top_pos_, solve_flags_, solve_walk_lo_, solve_walk_hi_;
     SubSchedule solve_sched_;
-    int ntop_solve_ = 0;
+    int ntop_solve_ = 0, nwalk_solve_ = 0;
     DBuf<SnRec> snrec_;
     DBuf<int> diag_pos_, P_, level_sn_, sn_first_, front_rows_ptr_, front_rows_, child_ptr_, child_, rel_ptr_, rel_;
     DBuf<int> mapP_, mapA_, mapG_, mapAA_, mapGG_, aa_ptr_, aa_q1_, aa_q2_, aa_k_, gg_ptr_, gg_q1_, gg_q2_, gg_k_;

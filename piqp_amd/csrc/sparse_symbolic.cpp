@@ -742,15 +742,33 @@ static void analyse_with_order(Symbolic& S, const IVec& perm0)
         subtree_schedule(SUB_COLS, SUB_FMAX, S.sub_lo, S.sub_hi, S.sub_max_front, S.top_level_ptr, S.top_level_sn, S.top_nlevels);
         S.nsub = (int)S.sub_lo.size();
         // substitution: one wave walks a subtree front by front, so the sweep lasts as long as the longest walk -- shorter walks and a
-        // larger flag-ordered top are faster there (C3 backend solve 0.52 -> 0.42 ms, C5-size chain 0.89 -> 0.84 ms at 32 columns), the factorisation prefers the
+        // larger flag-ordered top are faster there (C3 backend solve 0.52 -> 0.34 ms, C5-size chain 0.89 -> 0.79 ms at 24 columns, chains of the top merged into walks), the factorisation prefers the
         // long LDS-resident walks above
-        int SOLVE_COLS = 32;
+        int SOLVE_COLS = 24;
         if (const char* e = std::getenv("PIQP_AMD_SOLVE_SUB_COLS")) SOLVE_COLS = std::atoi(e);
         if (SOLVE_COLS <= 0 || SOLVE_COLS >= SUB_COLS) {
             S.solve_sub_lo = S.sub_lo; S.solve_sub_hi = S.sub_hi; S.solve_top_level_ptr = S.top_level_ptr; S.solve_top_level_sn = S.top_level_sn;
             S.solve_top_nlevels = S.top_nlevels; S.solve_sub_max_front = S.sub_max_front;
         } else {
             subtree_schedule(std::max(8, SOLVE_COLS), SUB_FMAX, S.solve_sub_lo, S.solve_sub_hi, S.solve_sub_max_front, S.solve_top_level_ptr, S.solve_top_level_sn, S.solve_top_nlevels);
+        }
+        {   // chains of the substitution's top
+            const int nt = (int)S.solve_top_level_sn.size();
+            IVec pos(ns, -1);
+            for (int q = 0; q < nt; ++q) pos[S.solve_top_level_sn[q]] = q;
+            const bool merge = !std::getenv("PIQP_AMD_SOLVE_NO_CHAINS");
+            std::vector<std::pair<int, std::pair<int, int>>> walks;  // (position of the last supernode, (lo, hi))
+            int s = 0;
+            while (s < ns) {
+                if (pos[s] < 0) { ++s; continue; }
+                int hi = s;
+                while (merge && hi + 1 < ns && pos[hi + 1] >= 0 && S.sn_parent[hi] == hi + 1) ++hi;
+                walks.push_back({pos[hi], {s, hi}});
+                s = hi + 1;
+            }
+            std::sort(walks.begin(), walks.end());
+            S.solve_walk_lo.clear(); S.solve_walk_hi.clear();
+            for (const auto& wk : walks) { S.solve_walk_lo.push_back(wk.second.first); S.solve_walk_hi.push_back(wk.second.second); }
         }
     }
 

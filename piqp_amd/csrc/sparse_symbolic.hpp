@@ -64,6 +64,9 @@ struct Symbolic {
     IVec solve_sub_lo, solve_sub_hi;
     IVec solve_top_level_ptr, solve_top_level_sn;
     int solve_top_nlevels = 0, solve_sub_max_front = 0;
+    // the top supernodes of the substitution grouped into walks: maximal runs lo..hi of consecutive supernodes with parent[t] == t + 1
+    // (a chain needs no flag between its links), ordered by the level of their last supernode
+    IVec solve_walk_lo, solve_walk_hi;
     // assembly: PKPt value q goes to fronts[a_dst[q]]
     std::vector<long long> a_dst;
     IVec fe_ptr, fe_q, fe_off;  // the same map grouped by owning supernode: entries fe_ptr[s]..fe_ptr[s+1]: value index, offset inside the front
