@@ -1010,6 +1010,120 @@ __global__ __launch_bounds__(512) void k_top_factor(FrontMeta M, double* __restr
         top_done(flags + b);
     }
 }
+
+// The persistent top launch over WALKS: a walk is a chain lo..hi of top supernodes with parent[t] == t + 1.  One workgroup factors the
+// chain with two packed lower-triangle fronts in LDS (like k_subtree_factor_pk): the update matrix of a link stays in LDS for the
+// next one, flags + HBM round trips only where the tree branches.  flags are per supernode (position in the list - start); walks are
+// sorted by the position of their last supernode, so every dependency has a smaller walk index.
+__global__ __launch_bounds__(512) void k_top_factor_walk(FrontMeta M, double* __restrict__ fronts, const double* __restrict__ vals, const int* __restrict__ fe_offp,
+                                                         const int* __restrict__ walk_lo, const int* __restrict__ walk_hi, int nwalk, const int* __restrict__ top_pos, int start,
+                                                         int cap, int* __restrict__ flags, int* __restrict__ err, double* __restrict__ rdiag, int* __restrict__ info)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int tx = tid & 15, ty = tid >> 4, tys = nt >> 4;
+    for (int b = blockIdx.x; b < nwalk; b += gridDim.x) {
+        const int lo = walk_lo[b], hi = walk_hi[b];
+        double* cur = lds;
+        double* prev = lds + cap;
+        bool prev_valid = false;
+        for (int s = lo; s <= hi; ++s) {
+            const SnRec me = M.sn[s];
+            const int first = me.first, w = me.w, f = me.f;
+            double* W = cur;
+            const int npk = (f * (f + 1)) >> 1;
+            // what needs nothing from the children comes first: they may still be busy
+            for (int idx = tid; idx < npk; idx += nt) W[idx] = 0.0;
+            __syncthreads();
+            for (int e = me.fe_lo + tid; e < me.fe_hi; e += nt) W[fe_offp[e]] = vals[e];
+            if (tid == 0) {
+                bool any = false;
+                for (int ci = me.child_lo; ci < me.child_hi; ++ci) {
+                    const int c = M.child[ci];
+                    if (prev_valid && c == s - 1) continue;
+                    const int tp = top_pos[c] - start;
+                    if (tp < 0) continue;
+                    any = true;
+                    unsigned spins = 0;
+                    while (__hip_atomic_load(flags + tp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+                        __builtin_amdgcn_s_sleep(1);
+                        if (++spins > 8000000u || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                            __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            break;
+                        }
+                    }
+                }
+                if (any) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+            __syncthreads();
+            for (int ci = me.child_lo; ci < me.child_hi; ++ci) {
+                const int c = M.child[ci];
+                const SnRec ch = M.sn[c];
+                const int wc = ch.w, fc = ch.f, uc = fc - wc;
+                const int* rel = M.rel + ch.rel_ptr;
+                if (prev_valid && c == s - 1) {
+                    for (int j = ty; j < uc; j += tys) {
+                        const int cj = pk_base(rel[j], f);
+                        const double* Uj = prev + pk_base(wc + j, fc) + wc;
+                        for (int i = j + tx; i < uc; i += 16) W[cj + rel[i]] += Uj[i];
+                    }
+                } else {
+                    const double* U = fronts + ch.front_off + wc + (long long)wc * fc;
+                    for (int j = ty; j < uc; j += tys) {
+                        const int cj = pk_base(rel[j], f);
+                        for (int i = j + tx; i < uc; i += 16) W[cj + rel[i]] += U[i + (long long)j * fc];
+                    }
+                }
+                __syncthreads();
+            }
+            for (int k = 0; k < w; ++k) {
+                const int ck = pk_base(k, f);
+                double d = W[ck + k];
+                if (d == 0.0) { if (tid == 0 && *info < 0) *info = first + k; d = 1.0; }
+                const double dinv = pivot_rcp(d);
+                if (tid == 0) rdiag[first + k] = dinv;
+                const int r = f - k - 1, pc = w - k - 1;
+                const double* colk = W + ck + (k + 1);
+                for (int j = ty; j < pc; j += tys) {
+                    const double cj = colk[j];
+                    double* Wj = W + pk_base(k + 1 + j, f) + (k + 1);
+                    for (int i = j + tx; i < r; i += 16) Wj[i] -= (colk[i] * dinv) * cj;
+                }
+                __syncthreads();
+            }
+            for (int k = ty; k < w; k += tys) {
+                double* Ck = W + pk_base(k, f);
+                double d = Ck[k];
+                if (d == 0.0) d = 1.0;
+                const double dinv = pivot_rcp(d);
+                for (int i = k + 1 + tx; i < f; i += 16) Ck[i] *= dinv;
+            }
+            __syncthreads();
+            const int u = f - w;
+            if (u > 0) {
+                schur_2x2_pk(W, f, w, u, tid, nt);
+                __syncthreads();
+            }
+            double* F = fronts + me.front_off;
+            for (int j = ty; j < w; j += tys) {
+                const double* Cj = W + pk_base(j, f);
+                double* Fj = F + (long long)j * f;
+                for (int i = j + tx; i < f; i += 16) Fj[i] = Cj[i];
+            }
+            const bool keep = me.parent == s + 1 && s + 1 <= hi;
+            if (!keep && u > 0) {
+                for (int j = ty; j < u; j += tys) {
+                    const double* Cj = W + pk_base(w + j, f) + w;
+                    for (int i = j + tx; i < u; i += 16) F[(w + i) + (long long)(w + j) * f] = Cj[i];
+                }
+            }
+            if (!keep) top_done(flags + (top_pos[s] - start));  // barrier + release + flag
+            else __syncthreads();
+            double* t = cur; cur = prev; prev = t;
+            prev_valid = keep;
+        }
+    }
+}
 // a timed-out wait surfaces as a failed factorisation (info) or a NaN in the solution (caught by KKTSystem's finite check)
 __global__ void k_top_check(const int* __restrict__ err, int* __restrict__ info, double* __restrict__ x)
 {
@@ -1317,7 +1431,7 @@ public:
     void print_info() override
     {
         std::printf("substitution schedule: %d single-wave walks, %d supernodes in %d flag-ordered levels above them\n", (int)S_.solve_sub_lo.size(), ntop_solve_, S_.solve_top_nlevels);
-        std::printf("substitution top: %d chain walks\n", nwalk_solve_);
+        std::printf("substitution top: %d chain walks; factor top: %d chain walks over %d supernodes\n", nwalk_solve_, ntopwalk_, top_nper_);
         std::printf("top of the tree: %d supernodes in %d levels: %d level launches, then %d supernodes in one persistent launch\n", ntop_, S_.top_nlevels, top_l0_, top_nper_);
         if (std::getenv("PIQP_AMD_PRINT_LEVELS")) {
             for (int l = 0; l < S_.top_nlevels; ++l) {
@@ -1362,7 +1476,7 @@ private:
         ops_.clone_from(o.ops_, st_);
         cpd(vals_, o.vals_); cpd(fronts_, o.fronts_); cpd(rdiag_, o.rdiag_);
         xp_.alloc(o.xp_.n); fvec_.alloc(o.fvec_.n); dvec_.alloc(o.dvec_.n);
-        cpi(diag_pos_, o.diag_pos_); cpi(P_, o.P_); cpi(level_sn_, o.level_sn_); cpi(top_pos_, o.top_pos_); top_flags_.alloc(o.top_flags_.n ? o.top_flags_.n : 1); cpi(solve_level_sn_, o.solve_level_sn_); cpi(solve_top_pos_, o.solve_top_pos_); solve_flags_.alloc(o.solve_flags_.n ? o.solve_flags_.n : 1); ntop_solve_ = o.ntop_solve_; cpi(solve_walk_lo_, o.solve_walk_lo_); cpi(solve_walk_hi_, o.solve_walk_hi_); nwalk_solve_ = o.nwalk_solve_; cpi(fe_ptr_, o.fe_ptr_); cpi(fe_q_, o.fe_q_); cpi(fe_off_, o.fe_off_); cpi(fe_offp_, o.fe_offp_);
+        cpi(diag_pos_, o.diag_pos_); cpi(P_, o.P_); cpi(level_sn_, o.level_sn_); cpi(top_pos_, o.top_pos_); top_flags_.alloc(o.top_flags_.n ? o.top_flags_.n : 1); cpi(solve_level_sn_, o.solve_level_sn_); cpi(solve_top_pos_, o.solve_top_pos_); solve_flags_.alloc(o.solve_flags_.n ? o.solve_flags_.n : 1); ntop_solve_ = o.ntop_solve_; cpi(solve_walk_lo_, o.solve_walk_lo_); cpi(solve_walk_hi_, o.solve_walk_hi_); nwalk_solve_ = o.nwalk_solve_; cpi(top_walk_lo_, o.top_walk_lo_); cpi(top_walk_hi_, o.top_walk_hi_); ntopwalk_ = o.ntopwalk_; top_walk_cap_ = o.top_walk_cap_; cpi(fe_ptr_, o.fe_ptr_); cpi(fe_q_, o.fe_q_); cpi(fe_off_, o.fe_off_); cpi(fe_offp_, o.fe_offp_);
         snrec_.alloc(o.snrec_.n ? o.snrec_.n : 1); if (o.snrec_.n) PQ_HIP(hipMemcpyAsync(snrec_.p, o.snrec_.p, o.snrec_.bytes(), hipMemcpyDeviceToDevice, st_)); cpi(sn_first_, o.sn_first_); cpi(front_rows_ptr_, o.front_rows_ptr_); cpi(front_rows_, o.front_rows_);
         cpi(child_ptr_, o.child_ptr_); cpi(child_, o.child_); cpi(rel_ptr_, o.rel_ptr_); cpi(rel_, o.rel_);
         cpi(mapP_, o.mapP_); cpi(mapA_, o.mapA_); cpi(mapG_, o.mapG_);
@@ -1434,6 +1548,32 @@ private:
         top_start_ = top_l0_ < S_.top_nlevels ? S_.top_level_ptr[top_l0_] : ntop_;
         top_nper_ = ntop_ - top_start_;
         if (top_nper_ < 2) { top_l0_ = S_.top_nlevels; top_start_ = ntop_; top_nper_ = 0; }  // a single supernode gains nothing
+        // chains of the persistent part -> walks (k_top_factor_walk) when two packed fronts of the largest one fit the LDS
+        ntopwalk_ = 0; top_walk_cap_ = 0;
+        if (top_nper_ > 0 && !std::getenv("PIQP_AMD_TOP_NO_WALKS")) {
+            std::vector<int> pos(S_.nsuper, -1);
+            for (int q = top_start_; q < ntop_; ++q) pos[S_.top_level_sn[q]] = q;
+            std::vector<std::pair<int, std::pair<int, int>>> walks;
+            long long fm = 0;
+            for (int s = 0; s < S_.nsuper;) {
+                if (pos[s] < 0) { ++s; continue; }
+                int hi = s;
+                while (hi + 1 < S_.nsuper && pos[hi + 1] >= 0 && S_.sn_parent[hi] == hi + 1) ++hi;
+                for (int t = s; t <= hi; ++t) fm = std::max<long long>(fm, S_.front_rows_ptr[t + 1] - S_.front_rows_ptr[t]);
+                walks.push_back({pos[hi], {s, hi}});
+                s = hi + 1;
+            }
+            const long long capP = fm * (fm + 1) / 2;
+            if (2 * capP * 8 <= SUBTREE_LDS_BYTES && (int)walks.size() < top_nper_) {
+                std::sort(walks.begin(), walks.end());
+                std::vector<int> lo, hi;
+                for (const auto& wk : walks) { lo.push_back(wk.second.first); hi.push_back(wk.second.second); }
+                upload_vec(top_walk_lo_, lo, st_); upload_vec(top_walk_hi_, hi, st_);
+                ntopwalk_ = (int)walks.size(); top_walk_cap_ = (int)capP;
+                static bool attr_set = false;
+                if (!attr_set) { PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_top_factor_walk), hipFuncAttributeMaxDynamicSharedMemorySize, SUBTREE_LDS_BYTES)); attr_set = true; }
+            }
+        }
     }
 
     FrontMeta meta() const { return FrontMeta{snrec_.p, front_rows_.p, child_.p, rel_.p, fe_ptr_.p, fe_q_.p, fe_off_.p, vals_.p}; }
@@ -1446,8 +1586,12 @@ private:
         factor_levels(M, S_.top_level_ptr, S_.top_level_sn, level_sn_.p, level_lds_, top_l0_);
         if (top_nper_ > 0) {
             PQ_HIP(hipMemsetAsync(top_flags_.p, 0, sizeof(int) * (2 * (size_t)ntop_ + 1), st_));
-            hipLaunchKernelGGL(k_top_factor, dim3(std::min(top_nper_, 224)), dim3(top_threads()), top_lds_, st_, M, fronts_.p, level_sn_.p + top_start_, top_nper_, top_pos_.p, top_start_,
-                               top_flags_.p, top_flags_.p + 2 * ntop_, rdiag_.p, info_.p);
+            if (ntopwalk_ > 0)
+                hipLaunchKernelGGL(k_top_factor_walk, dim3(std::min(ntopwalk_, 224)), dim3(top_threads()), 2 * (size_t)top_walk_cap_ * sizeof(double), st_, M, fronts_.p, vals_.p, fe_offp_.p,
+                                   top_walk_lo_.p, top_walk_hi_.p, ntopwalk_, top_pos_.p, top_start_, top_walk_cap_, top_flags_.p, top_flags_.p + 2 * ntop_, rdiag_.p, info_.p);
+            else
+                hipLaunchKernelGGL(k_top_factor, dim3(std::min(top_nper_, 224)), dim3(top_threads()), top_lds_, st_, M, fronts_.p, level_sn_.p + top_start_, top_nper_, top_pos_.p, top_start_,
+                                   top_flags_.p, top_flags_.p + 2 * ntop_, rdiag_.p, info_.p);
             hipLaunchKernelGGL(k_top_check, dim3(1), dim3(1), 0, st_, top_flags_.p + 2 * ntop_, info_.p, (double*)nullptr);
         }
     }
@@ -1828,6 +1972,8 @@ private:
     DBuf<int> fe_ptr_, fe_q_, fe_off_, fe_offp_, top_pos_, top_flags_, solve_level_sn_, solve_top_pos_, solve_flags_, solve_walk_lo_, solve_walk_hi_;
     SubSchedule solve_sched_;
     int ntop_solve_ = 0, nwalk_solve_ = 0;
+    DBuf<int> top_walk_lo_, top_walk_hi_;
+    int ntopwalk_ = 0, top_walk_cap_ = 0;
     DBuf<SnRec> snrec_;
     DBuf<int> diag_pos_, P_, level_sn_, sn_first_, front_rows_ptr_, front_rows_, child_ptr_, child_, rel_ptr_, rel_;
     DBuf<int> mapP_, mapA_, mapG_, mapAA_, mapGG_, aa_ptr_, aa_q1_, aa_q2_, aa_k_, gg_ptr_, gg_q1_, gg_q2_, gg_k_;
