@@ -46,6 +46,12 @@ struct SnRec {  // everything the numeric kernels need about one supernode, in o
     long long front_off;
     int fe_lo, fe_hi;  // assembly entries of this supernode: values vals[fe_lo .. fe_hi) (the value array is stored in this order), front offsets fe_off[..]
 };
+struct ChildRec {  // what a parent needs to know about one child, stored parallel to the child lists (one load instead of child -> record)
+    int c;        // the child supernode
+    int vc_off;   // offset of its update vector in fvec (rows_ptr + w)
+    int uc;       // update rows (f - w)
+    int rel_ptr;  // offset into `rel`
+};
 struct FrontMeta {  // device-side views of the symbolic analysis
     const SnRec* sn;
     const int* front_rows;
@@ -56,6 +62,7 @@ struct FrontMeta {  // device-side views of the symbolic analysis
     const int* fe_q;
     const int* fe_off;
     const double* vals;
+    const ChildRec* crec;
 };
 
 __global__ void k_set_diag(int n, int p, int m, const int* __restrict__ diag_pos, const double* __restrict__ Pdiag, const double* __restrict__ x_reg, double delta,
@@ -729,13 +736,20 @@ __device__ __forceinline__ void stx(double* p, double v)
     __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // single-wave workgroup: wait until *flag != 0 (bounded; a timeout raises err and lets the launch drain)
+// poll back-off of the flag waits: naps of 1, 2, 4 ... g_wait_nap_max x 64 cycles between two polls (set once per process from
+// PIQP_AMD_WAIT_NAP_MAX)
+__constant__ int g_wait_nap_max = 1;
+// debug: per-workgroup start / end / wait-done timestamps of the flag-ordered sweeps (PIQP_AMD_DBG_TS=file prefix)
+__device__ long long* g_dbg_ts = nullptr;
 __device__ __forceinline__ void wave_wait_flag(const int* flag, int* err)
 {
     if (threadIdx.x == 0) {
         unsigned spins = 0;
+        int nap = 1;
         while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
-            __builtin_amdgcn_s_sleep(1);
-            if (++spins > 8000000u || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+            for (int i = 0; i < nap; ++i) __builtin_amdgcn_s_sleep(1);
+            if (nap < g_wait_nap_max) nap <<= 1;
+            if (++spins > 8000000u || ((spins & 15) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
                 __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 break;
             }
@@ -783,65 +797,115 @@ __device__ __forceinline__ void touch_done(const PanelTouch& p)
 template <bool TOP>
 __global__ __launch_bounds__(64) void k_subtree_fwd_wave(FrontMeta M, const double* __restrict__ fronts, const int* __restrict__ sub_lo, const int* __restrict__ sub_hi,
                                                          double* __restrict__ x, double* __restrict__ fvec, const int* __restrict__ top_pos, int* __restrict__ flags,
-                                                         int* __restrict__ err)
+                                                         int* __restrict__ err, const int* __restrict__ child_tp)
 {
     __shared__ double sv[2][128];
     const int lane = threadIdx.x, r0 = lane, r1 = lane + 64;
     // TOP: the walk is a chain of top supernodes (parent[t] == t + 1); children outside the walk are waited for by flag
     const int lo = sub_lo[blockIdx.x], hi = sub_hi[blockIdx.x];
+    long long* const dbg = TOP ? g_dbg_ts : nullptr;
+    if (dbg && lane == 0) dbg[3 * blockIdx.x] = wall_clock64();
     int cur = 0;
     bool prev_valid = false;  // sv[cur ^ 1][0 .. u) = update vector of supernode s - 1
+    SnRec me = M.sn[lo];
     for (int s = lo; s <= hi; ++s) {
-        const SnRec me = M.sn[s];
+        const SnRec nxt = M.sn[s < hi ? s + 1 : s];  // the next link's record travels while this one is processed
         const int first = me.first, w = me.w, f = me.f;
         const double* F = fronts + me.front_off;
+        double* a = sv[cur];
+        int ci0 = me.child_lo;  // children from here on go through the generic gather below
         if (TOP) {
+            // everything that does not depend on the children is loaded BEFORE the wave waits for their flags: the panel (touched), the
+            // right-hand side, and for the first four children the record, the scatter indices and the flag position -- after the wait
+            // only the update vectors themselves are one round trip away, all children in flight together
+            constexpr int MAXC = 4;
             const PanelTouch pt = touch_panel(F, f * w, lane);
-            for (int ci = me.child_lo; ci < me.child_hi; ++ci) {
-                const int c = M.child[ci];
-                if (prev_valid && c == s - 1) continue;
-                const int tp = top_pos[c];
+            const double xa0 = r0 < w ? x[first + r0] : 0.0, xa1 = r1 < w ? x[first + r1] : 0.0;
+            const int nch = me.child_hi - me.child_lo;
+            const double* cvc[MAXC];
+            int cr0[MAXC], cr1[MAXC], ctp[MAXC];
+#pragma unroll
+            for (int q = 0; q < MAXC; ++q) {
+                cr0[q] = -1; cr1[q] = -1; ctp[q] = -1; cvc[q] = fvec;
+                if (q < nch) {
+                    const ChildRec cr = M.crec[me.child_lo + q];
+                    const int tpq = child_tp[me.child_lo + q];
+                    const bool inwalk = prev_valid && cr.c == s - 1;
+                    const int* rel = M.rel + cr.rel_ptr;
+                    cvc[q] = fvec + cr.vc_off;
+                    if (r0 < cr.uc) cr0[q] = rel[r0];
+                    if (r1 < cr.uc) cr1[q] = rel[r1];
+                    ctp[q] = inwalk ? -2 : tpq;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < MAXC; ++q) if (ctp[q] >= 0) wave_wait_flag(flags + ctp[q], err);
+            for (int ci = me.child_lo + MAXC; ci < me.child_hi; ++ci) {
+                if (prev_valid && M.child[ci] == s - 1) continue;  // the previous link of this walk: no flag, its vector is in LDS
+                const int tp = child_tp[ci];
                 if (tp >= 0) wave_wait_flag(flags + tp, err);
             }
             touch_done(pt);
+            if (dbg && lane == 0 && s == lo) dbg[3 * blockIdx.x + 1] = wall_clock64();
+            if (r0 < f) a[r0] = xa0;
+            if (r1 < f) a[r1] = xa1;
+            __syncthreads();
+            double g0[MAXC], g1[MAXC];
+#pragma unroll
+            for (int q = 0; q < MAXC; ++q) {
+                g0[q] = 0.0; g1[q] = 0.0;
+                if (cr0[q] >= 0) g0[q] = ctp[q] == -2 ? sv[cur ^ 1][r0] : ldx<true>(cvc[q] + r0);
+                if (cr1[q] >= 0) g1[q] = ctp[q] == -2 ? sv[cur ^ 1][r1] : ldx<true>(cvc[q] + r1);
+            }
+#pragma unroll
+            for (int q = 0; q < MAXC; ++q) {
+                if (q < nch) {  // uniform
+                    if (cr0[q] >= 0) a[cr0[q]] += g0[q];
+                    if (cr1[q] >= 0) a[cr1[q]] += g1[q];
+                    __syncthreads();
+                }
+            }
+            ci0 = me.child_lo + MAXC;
+        } else {
+            if (r0 < f) a[r0] = r0 < w ? x[first + r0] : 0.0;
+            if (r1 < f) a[r1] = r1 < w ? x[first + r1] : 0.0;
+            __syncthreads();
         }
-        double* a = sv[cur];
-        if (r0 < f) a[r0] = r0 < w ? x[first + r0] : 0.0;
-        if (r1 < f) a[r1] = r1 < w ? x[first + r1] : 0.0;
-        __syncthreads();
-        for (int ci = me.child_lo; ci < me.child_hi; ++ci) {
-            const int c = M.child[ci];
-            const SnRec ch = M.sn[c];
-            const int uc = ch.f - ch.w;
-            const double* vc = (prev_valid && c == s - 1) ? sv[cur ^ 1] : fvec + ch.rows_ptr + ch.w;
-            const int* rel = M.rel + ch.rel_ptr;
+        for (int ci = ci0; ci < me.child_hi; ++ci) {
+            const ChildRec cr = M.crec[ci];
+            const int uc = cr.uc;
+            const double* vc = (prev_valid && cr.c == s - 1) ? sv[cur ^ 1] : fvec + cr.vc_off;
+            const int* rel = M.rel + cr.rel_ptr;
             for (int i = lane; i < uc; i += 64) a[rel[i]] += (TOP ? ldx<true>(vc + i) : vc[i]);
             __syncthreads();
         }
         double v0 = r0 < f ? a[r0] : 0.0, v1 = r1 < f ? a[r1] : 0.0;
-        int k = 0;
-        for (; k + 4 <= w; k += 4) {
-            double c0[4], c1[4];
+        auto panel_sweep = [&](const double* __restrict__ Fp) {
+            int k = 0;
+            for (; k + 4 <= w; k += 4) {
+                double c0[4], c1[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const double* col = F + (long long)(k + u) * f;
-                c0[u] = (r0 > k + u && r0 < f) ? col[r0] : 0.0;
-                c1[u] = (r1 < f) ? col[r1] : 0.0;  // r1 >= 64 > k + u whenever the row exists and k + u < 64; checked below otherwise
-            }
+                for (int u = 0; u < 4; ++u) {
+                    const double* col = Fp + (k + u) * f;
+                    c0[u] = (r0 > k + u && r0 < f) ? col[r0] : 0.0;
+                    c1[u] = (r1 < f) ? col[r1] : 0.0;  // r1 >= 64 > k + u whenever the row exists and k + u < 64; checked below otherwise
+                }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const double yk = bcast_row(v0, v1, k + u);
-                v0 -= c0[u] * yk;
-                if (r1 > k + u) v1 -= c1[u] * yk;
+                for (int u = 0; u < 4; ++u) {
+                    const double yk = bcast_row(v0, v1, k + u);
+                    v0 -= c0[u] * yk;
+                    if (r1 > k + u) v1 -= c1[u] * yk;
+                }
             }
-        }
-        for (; k < w; ++k) {
-            const double* col = F + (long long)k * f;
-            const double c0 = (r0 > k && r0 < f) ? col[r0] : 0.0, c1 = (r1 > k && r1 < f) ? col[r1] : 0.0;
-            const double yk = bcast_row(v0, v1, k);
-            v0 -= c0 * yk;
-            v1 -= c1 * yk;
-        }
+            for (; k < w; ++k) {
+                const double* col = Fp + k * f;
+                const double c0 = (r0 > k && r0 < f) ? col[r0] : 0.0, c1 = (r1 > k && r1 < f) ? col[r1] : 0.0;
+                const double yk = bcast_row(v0, v1, k);
+                v0 -= c0 * yk;
+                v1 -= c1 * yk;
+            }
+        };
+        panel_sweep(F);
         if (r0 < w) x[first + r0] = v0;
         if (r1 < w) x[first + r1] = v1;
         __syncthreads();  // every lane has taken its entries of `a`
@@ -851,8 +915,10 @@ __global__ __launch_bounds__(64) void k_subtree_fwd_wave(FrontMeta M, const doub
         __syncthreads();
         cur ^= 1;
         prev_valid = keep;
+        me = nxt;
     }
     if (TOP) wave_publish_flag(flags + top_pos[hi]);
+    if (dbg && lane == 0) dbg[3 * blockIdx.x + 2] = wall_clock64();
 }
 // TOP = true: as above for the backward sweep; sub_lo = the level-sorted list, block b takes entry ntop - 1 - b (parents first) and waits
 // for its parent's flag; the ancestors' solution entries are read with agent-scope loads, its own are stored write-through
@@ -876,8 +942,9 @@ __global__ __launch_bounds__(64) void k_subtree_bwd_wave(FrontMeta M, const doub
     }
     int cur = 0;
     bool prev_valid = false;  // sv[cur ^ 1][0 .. f_parent) = final vector of supernode s + 1
+    SnRec me = M.sn[hi];
     for (int s = hi; s >= lo; --s) {
-        const SnRec me = M.sn[s];
+        const SnRec nxt = M.sn[s > lo ? s - 1 : s];  // the next link's record travels while this one is processed
         const int first = me.first, w = me.w, f = me.f;
         const double* F = fronts + me.front_off;
         const int* rows = M.front_rows + me.rows_ptr;
@@ -959,6 +1026,7 @@ __global__ __launch_bounds__(64) void k_subtree_bwd_wave(FrontMeta M, const doub
         cur ^= 1;
         prev_valid = true;
         if (TOP) wave_publish_flag(flags + top_pos[s]);
+        me = nxt;
     }
 }
 
@@ -1214,6 +1282,15 @@ public:
         if (d->mem != PQ_MEM_HOST) throw std::runtime_error("sparse data must be host-resident");
         PQ_HIP(hipSetDevice(dev_));
         PQ_HIP(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
+        {
+            static bool nap_set = false;
+            if (!nap_set) {
+                const char* e = std::getenv("PIQP_AMD_WAIT_NAP_MAX");
+                const int v = e ? std::max(1, std::atoi(e)) : 1;
+                PQ_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_wait_nap_max), &v, sizeof(int)));
+                nap_set = true;
+            }
+        }
         sparse::analyse_kkt(d, mode, S_);
         n_ = S_.n; p_ = S_.p; m_ = S_.m; N_ = S_.N;
         compute_level_lds();
@@ -1476,7 +1553,7 @@ private:
         ops_.clone_from(o.ops_, st_);
         cpd(vals_, o.vals_); cpd(fronts_, o.fronts_); cpd(rdiag_, o.rdiag_);
         xp_.alloc(o.xp_.n); fvec_.alloc(o.fvec_.n); dvec_.alloc(o.dvec_.n);
-        cpi(diag_pos_, o.diag_pos_); cpi(P_, o.P_); cpi(level_sn_, o.level_sn_); cpi(top_pos_, o.top_pos_); top_flags_.alloc(o.top_flags_.n ? o.top_flags_.n : 1); cpi(solve_level_sn_, o.solve_level_sn_); cpi(solve_top_pos_, o.solve_top_pos_); solve_flags_.alloc(o.solve_flags_.n ? o.solve_flags_.n : 1); ntop_solve_ = o.ntop_solve_; cpi(solve_walk_lo_, o.solve_walk_lo_); cpi(solve_walk_hi_, o.solve_walk_hi_); nwalk_solve_ = o.nwalk_solve_; cpi(top_walk_lo_, o.top_walk_lo_); cpi(top_walk_hi_, o.top_walk_hi_); ntopwalk_ = o.ntopwalk_; top_walk_cap_ = o.top_walk_cap_; cpi(fe_ptr_, o.fe_ptr_); cpi(fe_q_, o.fe_q_); cpi(fe_off_, o.fe_off_); cpi(fe_offp_, o.fe_offp_);
+        cpi(diag_pos_, o.diag_pos_); cpi(P_, o.P_); cpi(level_sn_, o.level_sn_); cpi(top_pos_, o.top_pos_); top_flags_.alloc(o.top_flags_.n ? o.top_flags_.n : 1); cpi(solve_level_sn_, o.solve_level_sn_); cpi(solve_top_pos_, o.solve_top_pos_); solve_flags_.alloc(o.solve_flags_.n ? o.solve_flags_.n : 1); ntop_solve_ = o.ntop_solve_; cpi(solve_walk_lo_, o.solve_walk_lo_); cpi(solve_walk_hi_, o.solve_walk_hi_); nwalk_solve_ = o.nwalk_solve_; cpi(solve_child_tp_, o.solve_child_tp_); crec_.alloc(o.crec_.n ? o.crec_.n : 1); if (o.crec_.n) PQ_HIP(hipMemcpyAsync(crec_.p, o.crec_.p, o.crec_.bytes(), hipMemcpyDeviceToDevice, st_)); cpi(top_walk_lo_, o.top_walk_lo_); cpi(top_walk_hi_, o.top_walk_hi_); ntopwalk_ = o.ntopwalk_; top_walk_cap_ = o.top_walk_cap_; cpi(fe_ptr_, o.fe_ptr_); cpi(fe_q_, o.fe_q_); cpi(fe_off_, o.fe_off_); cpi(fe_offp_, o.fe_offp_);
         snrec_.alloc(o.snrec_.n ? o.snrec_.n : 1); if (o.snrec_.n) PQ_HIP(hipMemcpyAsync(snrec_.p, o.snrec_.p, o.snrec_.bytes(), hipMemcpyDeviceToDevice, st_)); cpi(sn_first_, o.sn_first_); cpi(front_rows_ptr_, o.front_rows_ptr_); cpi(front_rows_, o.front_rows_);
         cpi(child_ptr_, o.child_ptr_); cpi(child_, o.child_); cpi(rel_ptr_, o.rel_ptr_); cpi(rel_, o.rel_);
         cpi(mapP_, o.mapP_); cpi(mapA_, o.mapA_); cpi(mapG_, o.mapG_);
@@ -1576,7 +1653,7 @@ private:
         }
     }
 
-    FrontMeta meta() const { return FrontMeta{snrec_.p, front_rows_.p, child_.p, rel_.p, fe_ptr_.p, fe_q_.p, fe_off_.p, vals_.p}; }
+    FrontMeta meta() const { return FrontMeta{snrec_.p, front_rows_.p, child_.p, rel_.p, fe_ptr_.p, fe_q_.p, fe_off_.p, vals_.p, crec_.p}; }
 
     // numeric phase of the factorisation / substitution on handle-owned buffers only (so that they can be recorded as graphs)
     void factor_numeric(const FrontMeta& M)
@@ -1605,8 +1682,24 @@ private:
         if (wave_top) for (int s2 : S_.solve_top_level_sn) if (S_.front_rows_ptr[s2 + 1] - S_.front_rows_ptr[s2] > 128) { wave_top = false; break; }
         if (wave_top) {
             PQ_HIP(hipMemsetAsync(solve_flags_.p, 0, sizeof(int) * (2 * (size_t)nt + 1), st_));
+            static const char* dbg_ts = std::getenv("PIQP_AMD_DBG_TS");
+            DBuf<long long> ts;
+            if (dbg_ts) { ts.alloc(3 * (size_t)nwalk_solve_); long long* pp = ts.p; PQ_HIP(hipMemsetAsync(ts.p, 0, ts.bytes(), st_)); PQ_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_ts), &pp, sizeof(pp))); }
             hipLaunchKernelGGL(k_subtree_fwd_wave<true>, dim3(nwalk_solve_), dim3(64), 0, st_, M, fronts_.p, solve_walk_lo_.p, solve_walk_hi_.p, xp_.p, fvec_.p, solve_top_pos_.p, solve_flags_.p,
-                               solve_flags_.p + 2 * nt);
+                               solve_flags_.p + 2 * nt, solve_child_tp_.p);
+            if (dbg_ts) {
+                PQ_HIP(hipStreamSynchronize(st_));
+                std::vector<long long> h(3 * (size_t)nwalk_solve_);
+                PQ_HIP(hipMemcpy(h.data(), ts.p, ts.bytes(), hipMemcpyDeviceToHost));
+                long long* pp = nullptr; PQ_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_ts), &pp, sizeof(pp)));
+                if (FILE* fo = std::fopen(dbg_ts, "wb")) {
+                    const int nw = nwalk_solve_;
+                    std::fwrite(&nw, sizeof(int), 1, fo);
+                    std::fwrite(h.data(), sizeof(long long), h.size(), fo);
+                    std::fwrite(S_.solve_walk_lo.data(), sizeof(int), nw, fo); std::fwrite(S_.solve_walk_hi.data(), sizeof(int), nw, fo);
+                    std::fclose(fo);
+                }
+            }
         } else fwd_levels(M, S_.solve_top_level_ptr, S_.solve_top_level_sn, solve_level_sn_.p);
         hipLaunchKernelGGL(k_scale, g1(N_), dim3(256), 0, st_, N_, rdiag_.p, xp_.p);
         if (wave_top) {
@@ -1753,7 +1846,7 @@ private:
     void subtree_fwd(const FrontMeta& M, const SubSchedule& sc)
     {
         for (const SubClass& c : sc.cls) {
-            if (c.fmax <= 128 && !std::getenv("PIQP_AMD_SUBTREE_SOLVE_V1")) hipLaunchKernelGGL(k_subtree_fwd_wave<false>, dim3(c.nsub), dim3(64), 0, st_, M, fronts_.p, c.lo.p, c.hi.p, xp_.p, fvec_.p, (const int*)nullptr, (int*)nullptr, (int*)nullptr);
+            if (c.fmax <= 128 && !std::getenv("PIQP_AMD_SUBTREE_SOLVE_V1")) hipLaunchKernelGGL(k_subtree_fwd_wave<false>, dim3(c.nsub), dim3(64), 0, st_, M, fronts_.p, c.lo.p, c.hi.p, xp_.p, fvec_.p, (const int*)nullptr, (int*)nullptr, (int*)nullptr, (const int*)nullptr);
             else hipLaunchKernelGGL(k_subtree_fwd, dim3(c.nsub), dim3(SUB_SOLVE_THREADS), 0, st_, M, fronts_.p, c.lo.p, c.hi.p, xp_.p, fvec_.p);
         }
     }
@@ -1806,7 +1899,7 @@ private:
         for (int l = 0; l + 1 < (int)ptr.size(); ++l) {
             const int cnt = ptr[l + 1] - ptr[l];
             if (cnt <= 0) continue;
-            if (level_is_narrow(ptr, sn, l)) hipLaunchKernelGGL(k_subtree_fwd_wave<false>, dim3(cnt), dim3(64), 0, st_, M, fronts_.p, sn_dev + ptr[l], sn_dev + ptr[l], xp_.p, fvec_.p, (const int*)nullptr, (int*)nullptr, (int*)nullptr);
+            if (level_is_narrow(ptr, sn, l)) hipLaunchKernelGGL(k_subtree_fwd_wave<false>, dim3(cnt), dim3(64), 0, st_, M, fronts_.p, sn_dev + ptr[l], sn_dev + ptr[l], xp_.p, fvec_.p, (const int*)nullptr, (int*)nullptr, (int*)nullptr, (const int*)nullptr);
             else hipLaunchKernelGGL(k_front_fwd, dim3(cnt), dim3(256), 0, st_, M, fronts_.p, sn_dev + ptr[l], xp_.p, fvec_.p);
         }
     }
@@ -1854,6 +1947,19 @@ private:
             upload_vec(fe_offp_, offp, st_);
         } upload_vec(sn_first_, S_.sn_first, st_);
         upload_vec(front_rows_ptr_, S_.front_rows_ptr, st_); upload_vec(front_rows_, S_.front_rows, st_); upload_vec(child_ptr_, S_.child_ptr, st_); upload_vec(child_, S_.child, st_);
+        {
+            std::vector<ChildRec> cr(S_.child.size() ? S_.child.size() : 1);
+            std::vector<int> ctp(S_.child.size() ? S_.child.size() : 1, -1);
+            std::vector<int> pos(S_.nsuper ? S_.nsuper : 1, -1);
+            for (size_t q = 0; q < S_.solve_top_level_sn.size(); ++q) pos[S_.solve_top_level_sn[q]] = (int)q;
+            for (size_t ci = 0; ci < S_.child.size(); ++ci) {
+                const int c = S_.child[ci];
+                const int wc = S_.sn_first[c + 1] - S_.sn_first[c], fc = S_.front_rows_ptr[c + 1] - S_.front_rows_ptr[c];
+                cr[ci] = ChildRec{c, S_.front_rows_ptr[c] + wc, fc - wc, S_.rel_ptr[c]};
+                ctp[ci] = pos[c];
+            }
+            upload_vec(crec_, cr, st_); upload_vec(solve_child_tp_, ctp, st_);
+        }
         upload_vec(rel_ptr_, S_.rel_ptr, st_); upload_vec(rel_, S_.rel, st_); upload_vec(front_off_, S_.front_off, st_);
         {
             std::vector<SnRec> rec(S_.nsuper ? S_.nsuper : 1);
@@ -1975,6 +2081,8 @@ private:
     DBuf<int> top_walk_lo_, top_walk_hi_;
     int ntopwalk_ = 0, top_walk_cap_ = 0;
     DBuf<SnRec> snrec_;
+    DBuf<ChildRec> crec_;
+    DBuf<int> solve_child_tp_;
     DBuf<int> diag_pos_, P_, level_sn_, sn_first_, front_rows_ptr_, front_rows_, child_ptr_, child_, rel_ptr_, rel_;
     DBuf<int> mapP_, mapA_, mapG_, mapAA_, mapGG_, aa_ptr_, aa_q1_, aa_q2_, aa_k_, gg_ptr_, gg_q1_, gg_q2_, gg_k_;
     DBuf<double> ata_vals_, zinv_, rhs_top_;
