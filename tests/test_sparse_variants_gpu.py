@@ -1,0 +1,53 @@
+"""The sparse multifrontal backend picks its device schedule from the shape of the assembly tree (full or packed fronts in the LDS subtree
+walk, chain walks or one supernode per workgroup in the persistent top, a finer subtree partition and chain walks for the substitution).
+None of that may change a single bit of the result: the order of the floating-point operations of every front is fixed by the tree.  Each
+variant runs in its own process (the toggles are read once per process) on the same seeded systems and the solutions are compared
+bitwise."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORKER = os.path.join(ROOT, "tests", "workers", "sparse_variant.py")
+
+VARIANTS = {
+    "default": {},
+    "packed_fronts_forced": {"PIQP_AMD_SUBTREE_PACKED": "1"},
+    "full_fronts_forced": {"PIQP_AMD_SUBTREE_PACKED": "0"},
+    "top_one_supernode_per_workgroup": {"PIQP_AMD_TOP_NO_WALKS": "1"},
+    "top_level_launches": {"PIQP_AMD_TOP_LEVELS": "1"},
+    "solve_on_factor_partition": {"PIQP_AMD_SOLVE_SUB_COLS": "0"},
+    "solve_without_chain_walks": {"PIQP_AMD_SOLVE_NO_CHAINS": "1"},
+    "solve_level_launches": {"PIQP_AMD_TOP_LEVELS_SOLVE": "1"},
+    "small_subtrees": {"PIQP_AMD_SUB_COLS": "48", "PIQP_AMD_SOLVE_SUB_COLS": "8"},
+}
+
+
+def _run(tmp_path, name, env_extra):
+    out = str(tmp_path / (name + ".npz"))
+    env = dict(os.environ)
+    for k in list(env):
+        if k.startswith("PIQP_AMD_"):
+            env.pop(k)
+    env.update(env_extra)
+    r = subprocess.run([sys.executable, WORKER, out], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, name + ": " + r.stderr[-2000:]
+    return dict(np.load(out))
+
+
+def test_schedule_variants_are_bitwise_identical(tmp_path):
+    ref = _run(tmp_path, "default", VARIANTS["default"])
+    assert all(np.isfinite(v).all() for v in ref.values())
+    assert any(np.abs(v).max() > 0 for v in ref.values())
+    for name, env in VARIANTS.items():
+        if name == "default":
+            continue
+        got = _run(tmp_path, name, env)
+        assert sorted(got) == sorted(ref)
+        for key in ref:
+            assert np.array_equal(got[key], ref[key]), f"{name}: {key} differs from the default schedule (max |d| = {np.abs(got[key] - ref[key]).max():.3e})"

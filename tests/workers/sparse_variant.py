@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Worker of tests/test_sparse_variants_gpu.py: factor + solve of one seeded sparse KKT system (and a multistage chain) with whatever
+PIQP_AMD_* schedule toggles the parent put into the environment; the solutions go to an .npz for a bitwise comparison.
+
+  python tests/workers/sparse_variant.py out.npz
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    import torch  # noqa: F401
+    import piqp_amd as hip
+    from qp_gen import c3_problem, mpc_chain, random_vars
+    out = {}
+    # (a) C3 recipe at n = 6000: fronts wide enough for every schedule variant to have work
+    n, p, m = 6000, 2400, 3600
+    a = c3_problem(n, p, m, 44, 40)
+    k = hip.KKTSystem(hip.SparseData(*a), hip.default_settings(kkt_solver=hip.SPARSE_LDLT))
+    rng = np.random.default_rng(0)
+    state = random_vars(n, p, m, rng, positive=True)
+    rhs = random_vars(n, p, m, rng)
+    assert k.update_scalings_and_factor(False, 1e-6, 1e-4, state)
+    ok, lhs = k.solve(rhs)
+    assert ok
+    for key, v in lhs.items():
+        out["c3_" + key] = np.asarray(v)
+    # (b) a block-tridiagonal chain (the shape of BASELINE configs[4]) through the same multifrontal backend
+    q = mpc_chain(6, 3, 400, 5)
+    k2 = hip.KKTSystem(hip.SparseData(*q), hip.default_settings(kkt_solver=hip.SPARSE_LDLT))
+    n2, p2, m2 = q[0].shape[0], q[2].shape[0], (q[4].shape[0] if q[4] is not None else 0)
+    state2 = random_vars(n2, p2, m2, rng, positive=True)
+    rhs2 = random_vars(n2, p2, m2, rng)
+    assert k2.update_scalings_and_factor(False, 1e-6, 1e-4, state2)
+    ok, lhs2 = k2.solve(rhs2)
+    assert ok
+    for key, v in lhs2.items():
+        out["chain_" + key] = np.asarray(v)
+    np.savez(sys.argv[1], **out)
+    print("ok", sorted(out))
+
+
+if __name__ == "__main__":
+    main()
