@@ -14,6 +14,10 @@
 #include "dense_kernels.hpp"
 
 #include <algorithm>
+#include <map>
+#include <mutex>
+#include <utility>
+#include <vector>
 #include <cstdlib>
 
 namespace pq {
@@ -147,10 +151,16 @@ __global__ __launch_bounds__(64 * WD * WD, WD == 2 ? 2 : 4) void k_syrk_lower(Sy
     // linear block id -> lower-triangular tile (ti >= tj); split launches map several K-slices onto one tile
     const int b = a.tile_begin + (int)blockIdx.x / a.k_split;
     const int kslice = (int)blockIdx.x % a.k_split;
-    int ti = (int)((sqrt(8.0 * (double)b + 1.0) - 1.0) * 0.5);
-    while ((ti + 1) * (ti + 2) / 2 <= b) ++ti;
-    while (ti * (ti + 1) / 2 > b) --ti;
-    int tj = b - ti * (ti + 1) / 2;
+    int ti, tj;
+    if (a.tile_order) {
+        const int pk = a.tile_order[b];
+        ti = pk >> 16; tj = pk & 0xffff;
+    } else {
+        ti = (int)((sqrt(8.0 * (double)b + 1.0) - 1.0) * 0.5);
+        while ((ti + 1) * (ti + 2) / 2 <= b) ++ti;
+        while (ti * (ti + 1) / 2 > b) --ti;
+        tj = b - ti * (ti + 1) / 2;
+    }
     if (a.first_col_only) { ti = b; tj = 0; }
     const int row0 = ti * TS, col0 = tj * TS;
 
@@ -292,10 +302,16 @@ template <int EPI>
 __global__ __launch_bounds__(256) void k_syrk_tail_reduce(SyrkArgs a)
 {
     const int b = a.tile_begin + (int)blockIdx.x;
-    int ti = (int)((sqrt(8.0 * (double)b + 1.0) - 1.0) * 0.5);
-    while ((ti + 1) * (ti + 2) / 2 <= b) ++ti;
-    while (ti * (ti + 1) / 2 > b) --ti;
-    const int tj = b - ti * (ti + 1) / 2;
+    int ti, tj;
+    if (a.tile_order) {
+        const int pk = a.tile_order[b];
+        ti = pk >> 16; tj = pk & 0xffff;
+    } else {
+        ti = (int)((sqrt(8.0 * (double)b + 1.0) - 1.0) * 0.5);
+        while ((ti + 1) * (ti + 2) / 2 <= b) ++ti;
+        while (ti * (ti + 1) / 2 > b) --ti;
+        tj = b - ti * (ti + 1) / 2;
+    }
     const int row0 = ti * TS, col0 = tj * TS;
     const double* P0 = a.part + (size_t)blockIdx.x * a.k_split * TS * TS;
     {
@@ -353,6 +369,36 @@ size_t syrk_split_workspace_doubles(int n, int kdim)
     return (size_t)rem * ks * TS * TS;
 }
 
+// device copy of the XCD-aware tile order for a T x T lower-triangular tile grid (built once per device and T, never freed: a few KB)
+static const int* syrk_tile_order(int T)
+{
+    static std::mutex mu;
+    static std::map<std::pair<int, int>, int*> cache;
+    static const bool off = std::getenv("PIQP_AMD_SYRK_LINEAR_TILES") != nullptr;
+    if (off || T < 16) return nullptr;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = cache.find({dev, T});
+    if (it != cache.end()) return it->second;
+    constexpr int S = 8, NX = 8;  // patch of S x S tiles (64 = the workgroups one XCD runs at a time), NX XCDs
+    std::vector<int> blocked;
+    for (int SI = 0; SI * S < T; ++SI)
+        for (int SJ = 0; SJ <= SI; ++SJ)
+            for (int ti = SI * S; ti < std::min(T, SI * S + S); ++ti)
+                for (int tj = SJ * S; tj < SJ * S + S && tj <= ti; ++tj) blocked.push_back(ti << 16 | tj);
+    const int nt = (int)blocked.size();
+    std::vector<int> start(NX + 1, 0);
+    for (int x = 0; x < NX; ++x) start[x + 1] = start[x] + nt / NX + (x < nt % NX ? 1 : 0);
+    std::vector<int> order(nt);
+    for (int b = 0; b < nt; ++b) order[b] = blocked[start[b % NX] + b / NX];
+    int* d = nullptr;
+    if (hipMalloc(&d, sizeof(int) * nt) != hipSuccess) { (void)hipGetLastError(); cache[{dev, T}] = nullptr; return nullptr; }
+    if (hipMemcpy(d, order.data(), sizeof(int) * nt, hipMemcpyHostToDevice) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(d); d = nullptr; }
+    cache[{dev, T}] = d;
+    return d;
+}
+
 template <int EPI>
 static void launch_syrk_t(SyrkArgs a, hipStream_t s, double* ws, size_t ws_doubles)
 {
@@ -365,6 +411,7 @@ static void launch_syrk_t(SyrkArgs a, hipStream_t s, double* ws, size_t ws_doubl
     a.tile_begin = 0; a.k_split = 1; a.part = nullptr;
     // short inner dimension (factorisation trailing updates, K = 128): latency-bound per tile -> 16-wave shape
     const bool low_latency = a.kdim <= 256;
+    a.tile_order = (!low_latency && !a.first_col_only) ? syrk_tile_order(T) : nullptr;
     if (low_latency) hipLaunchKernelGGL((k_syrk_lower<EPI, 4>), dim3(main_tiles), dim3(1024), SYRK_LDS_BYTES, s, a);
     else hipLaunchKernelGGL((k_syrk_lower<EPI, 2>), dim3(main_tiles), dim3(256), SYRK_LDS_BYTES, s, a);
     if (rem > 0) {

@@ -27,6 +27,10 @@ struct SyrkArgs {
     int k_split = 1;
     double* part = nullptr;
     int first_col_only = 0;  // 1: only the tiles (ti, 0) of the first 128-column strip (panel look-ahead)
+    // XCD-aware tile order (set by the launcher for long inner dimensions): tile of linear block b = tile_order[b] = ti << 16 | tj.
+    // Workgroups go to the eight XCDs round-robin, so the order hands every XCD a compact 8 x 8 patch of tiles: the 64 tiles it works on at
+    // the same time share 16 operand panels in its own L2 instead of nearly all of them
+    const int* tile_order = nullptr;
     // EPI_SUBTRACT_POTRF: tile (0,0) of the trailing matrix is the NEXT diagonal block; the workgroup that updates it keeps it in
     // LDS and factors it right away (the serial k_potrf_diag of the next panel disappears behind the rest of this launch)
     int fuse_nb = 0;            // order of the next diagonal block (<= 128)
