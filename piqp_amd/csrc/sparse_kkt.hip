@@ -1799,11 +1799,14 @@ private:
             if (!k.staged) b = bytes_of(k.cap, mx, false);
             k.bytes = (int)b;
             k.lds_walk = b <= SUBTREE_LDS_BYTES && !std::getenv("PIQP_AMD_SUBTREE_HBM");
-            // a walk that would own the CU's LDS with full fronts keeps only their lower triangles instead: half the LDS, two workgroups per CU
+            // a walk keeps only the lower triangles of its two fronts when that raises the occupancy: half the LDS (C3: two workgroups per CU instead of one)
             // (PIQP_AMD_SUBTREE_PACKED=0 / 1 forces it off / on for every class)
             {
                 static const char* pe = std::getenv("PIQP_AMD_SUBTREE_PACKED");
-                k.packed = k.lds_walk && !k.staged && (pe ? pe[0] == '1' : b > 80 * 1024);
+                // default: packed whenever that lets more walks share a CU (at most eight 256-thread workgroups fit by waves)
+                const long long bp = 2LL * ((long long)mx.fm * (mx.fm + 1) / 2) * 8;
+                const auto per_cu = [](long long bytes) { return std::min<long long>(8, (160 * 1024) / std::max<long long>(bytes, 1)); };
+                k.packed = k.lds_walk && !k.staged && (pe ? pe[0] == '1' : per_cu(bp) > per_cu(b));
                 if (k.packed) { k.cap = (mx.fm * (mx.fm + 1)) / 2; b = 2LL * k.cap * 8; k.bytes = (int)b; }
             }
             static const int thr_env = std::getenv("PIQP_AMD_SUBTREE_THREADS") ? std::atoi(std::getenv("PIQP_AMD_SUBTREE_THREADS")) : 0;

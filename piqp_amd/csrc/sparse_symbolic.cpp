@@ -629,6 +629,7 @@ static void analyse_with_order(Symbolic& S, const IVec& perm0)
                 if (j + 1 == N || !(S.etree[j] == j + 1 && cc[j] == cc[j + 1] + 1)) fcap = std::max(fcap, (j - a + 1) + cc[j]);
             }
             fcap = std::min(fcap, 64);
+            if (const char* e = std::getenv("PIQP_AMD_FCAP")) fcap = std::max(fcap, std::min(96, std::atoi(e)));  // experiments: allow larger merged fronts
         }
         int a = 0;            // first column of the current supernode
         long long sumcc = 0;  // sum of cc over its columns
