@@ -2,6 +2,7 @@
 #include "sparse_symbolic.hpp"
 
 #include <algorithm>
+#include <cstdio>
 #include <cmath>
 #include <cstdlib>
 #include <stdexcept>
@@ -446,7 +447,7 @@ static void postorder(int n, const IVec& parent, IVec& post)
     }
 }
 
-static void analyse_with_order(Symbolic& S, const IVec& perm0);
+static void analyse_with_order(Symbolic& S, const IVec& perm0, const IVec* forced_first = nullptr);
 
 // structural upper triangle of MT * MT^T (MT: n x k CSC) with, for every entry (i <= j), the list of value-index pairs
 // (q_i, q_j) of the constraints k that contain both variables, constraints ascending -- the summation order of the
@@ -573,12 +574,16 @@ void analyse_kkt(const pq_sparse_data* d, int mode, Symbolic& S)
 }
 
 // everything that follows from a fill-reducing ordering perm0 (perm0[new] = old) of K
-static void analyse_with_order(Symbolic& S, const IVec& perm0)
+// forced_first != nullptr: perm0 is already a postorder of its elimination tree and the supernode partition is given (second pass of
+// the leaf amalgamation below)
+static void analyse_with_order(Symbolic& S, const IVec& perm0, const IVec* forced_first)
 {
     const int N = S.N;
     IVec pinv0(N);
     for (int i = 0; i < N; ++i) pinv0[perm0[i]] = i;
-    {
+    if (forced_first) {
+        S.P = perm0; S.P_inv = pinv0;
+    } else {
         IVec Cp0, Ci0, map0, parent0, cc0, post;
         permute_sym_upper(N, S.Kp, S.Ki, pinv0.data(), Cp0, Ci0, map0);
         elimination_tree(N, Cp0, Ci0, parent0, cc0);
@@ -615,7 +620,13 @@ static void analyse_with_order(Symbolic& S, const IVec& perm0)
     // ones are merged generously (thresholds in the spirit of CHOLMOD's nrelax / zrelax); fronts are kept <= 64 rows unless exact.
     S.sn_of_col.assign(N, 0);
     S.sn_first.clear();
-    {
+    if (forced_first) {
+        S.sn_first = *forced_first;
+        for (size_t q = 0; q < S.sn_first.size(); ++q) {
+            const int hi = q + 1 < S.sn_first.size() ? S.sn_first[q + 1] : N;
+            for (int j = S.sn_first[q]; j < hi; ++j) S.sn_of_col[j] = (int)q;
+        }
+    } else {
         const char* rx = std::getenv("PIQP_AMD_RELAX");
         const bool relax = !(rx && rx[0] == '0');
         // merged fronts never exceed the largest front of the exact partition (capped at 64): the subtree walkers size their LDS for
@@ -679,6 +690,101 @@ static void analyse_with_order(Symbolic& S, const IVec& perm0)
     {
         IVec nx(S.child_ptr.begin(), S.child_ptr.end() - 1);
         for (int s = 0; s < ns; ++s) if (S.sn_parent[s] >= 0) S.child[nx[S.sn_parent[s]]++] = s;
+    }
+    // ---- leaf amalgamation.  The KKT matrix of a QP with (block-)diagonal P is full of single-column leaves: a primal variable whose
+    // only neighbours are its constraint rows (n = 500k chain: 361 281 of 396 598 supernodes are such leaves, 10-19 of them under every
+    // constraint block).  A supernode costs a few microseconds on the device whatever its size, so small childless supernodes are merged
+    // into their parent: the merged pivot block is [leaf columns, parent columns] (siblings are structurally independent, their mutual
+    // block is padded with zeros), and since struct(L_leaf) is contained in {parent columns} + struct(L_parent) the front is still
+    // {pivots} + struct(L_last).  That needs the leaves next to their parent in the elimination order: the children of every supernode
+    // are reordered (any postorder of the tree has the same fill) -- other children first, largest subtree last among them so that the
+    // chain walks follow the spine, then the merged leaves, then the parent -- and the analysis is redone for that order.
+    if (!forced_first && !(std::getenv("PIQP_AMD_LEAF_MERGE") && std::getenv("PIQP_AMD_LEAF_MERGE")[0] == '0')) {
+        int WMAX = 32, FMAX = 64;
+        if (const char* e = std::getenv("PIQP_AMD_LEAF_MERGE_W")) WMAX = std::max(2, std::atoi(e));
+        if (const char* e = std::getenv("PIQP_AMD_LEAF_MERGE_F")) FMAX = std::max(8, std::atoi(e));
+        IVec weff(ns), live_children(ns, 0), merged_into(ns, -1), sub_cols(ns, 0);
+        for (int s2 = 0; s2 < ns; ++s2) { weff[s2] = S.sn_first[s2 + 1] - S.sn_first[s2]; live_children[s2] = S.child_ptr[s2 + 1] - S.child_ptr[s2]; }
+        long long nmerged = 0;
+        std::vector<std::pair<int, int>> cand;
+        for (int p2 = 0; p2 < ns; ++p2) {  // postorder: the children of p2 are final when p2 is visited
+            sub_cols[p2] += S.sn_first[p2 + 1] - S.sn_first[p2];
+            if (S.sn_parent[p2] >= 0) sub_cols[S.sn_parent[p2]] += sub_cols[p2];
+            cand.clear();
+            for (int q = S.child_ptr[p2]; q < S.child_ptr[p2 + 1]; ++q) {
+                const int c = S.child[q];
+                if (live_children[c] == 0 && weff[c] <= 4) cand.push_back({weff[c], c});
+            }
+            if (cand.empty()) continue;
+            std::sort(cand.begin(), cand.end());
+            const int last = S.sn_first[p2 + 1] - 1;
+            const int fp = (S.sn_first[p2 + 1] - S.sn_first[p2]) + cc[last];  // front of p2 before any merge
+            for (const auto& cw : cand) {
+                const int wd = weff[p2] + cw.first;
+                const int fr = wd + cc[last];
+                if (wd > WMAX) break;
+                if (fr > FMAX && fr > fp + 4) break;
+                merged_into[cw.second] = p2;
+                weff[p2] = wd;
+                live_children[p2]--;
+                ++nmerged;
+            }
+        }
+        if (nmerged > 0) {
+            // new elimination order: iterative DFS over the supernode tree
+            std::vector<IVec> kids(ns), leaves(ns);
+            for (int s2 = 0; s2 < ns; ++s2) {
+                const int ps = S.sn_parent[s2];
+                if (ps < 0) continue;
+                if (merged_into[s2] == ps) leaves[ps].push_back(s2); else kids[ps].push_back(s2);
+            }
+            for (int s2 = 0; s2 < ns; ++s2) {
+                if (kids[s2].size() > 1) {  // largest subtree last (ties: keep the original order)
+                    size_t best = 0;
+                    for (size_t q = 1; q < kids[s2].size(); ++q) if (sub_cols[kids[s2][q]] >= sub_cols[kids[s2][best]]) best = q;
+                    const int b = kids[s2][best];
+                    kids[s2].erase(kids[s2].begin() + (long)best);
+                    kids[s2].push_back(b);
+                }
+            }
+            IVec perm1; perm1.reserve(N);
+            IVec first1;
+            // emits the pivot block of group g: merged leaves (each possibly a merged group itself), then g's own columns
+            std::vector<std::pair<int, int>> st;  // (supernode, phase): phase 0 = descend into live children, 1 = emit the group
+            auto emit_cols = [&](int g, auto&& self) -> void {
+                for (int l : leaves[g]) self(l, self);
+                for (int j = S.sn_first[g]; j < S.sn_first[g + 1]; ++j) perm1.push_back(S.P[j]);
+            };
+            for (int r = 0; r < ns; ++r) {
+                if (S.sn_parent[r] >= 0) continue;
+                st.push_back({r, 0});
+                while (!st.empty()) {
+                    auto [g, ph] = st.back();
+                    st.pop_back();
+                    if (ph == 0) {
+                        st.push_back({g, 1});
+                        for (size_t q = kids[g].size(); q-- > 0;) st.push_back({kids[g][q], 0});  // popped in order: first child first
+                    } else {
+                        first1.push_back((int)perm1.size());
+                        emit_cols(g, emit_cols);  // a merged leaf has no live children: the recursion depth is the depth of nested leaf merges (<= WMAX)
+                    }
+                }
+            }
+            if ((int)perm1.size() == N) { analyse_with_order(S, perm1, &first1); return; }
+        }
+    }
+    if (std::getenv("PIQP_AMD_SN_STATS")) {
+        long long leaves = 0, leaf_small = 0, one_child = 0, hist[9] = {0};
+        long long nchild_hist[6] = {0};
+        for (int s = 0; s < ns; ++s) {
+            const int nc = S.child_ptr[s + 1] - S.child_ptr[s], w = S.sn_first[s + 1] - S.sn_first[s];
+            hist[std::min(w, 8)]++;
+            nchild_hist[std::min(nc, 5)]++;
+            if (nc == 0) { leaves++; if (w <= 4) leaf_small++; }
+            if (nc == 1) one_child++;
+        }
+        std::fprintf(stderr, "supernodes %d: leaves %lld (w<=4: %lld), one child %lld; children histogram 0..5+: %lld %lld %lld %lld %lld %lld; width histogram 1..8+: %lld %lld %lld %lld %lld %lld %lld %lld\n",
+                     ns, leaves, leaf_small, one_child, nchild_hist[0], nchild_hist[1], nchild_hist[2], nchild_hist[3], nchild_hist[4], nchild_hist[5], hist[1], hist[2], hist[3], hist[4], hist[5], hist[6], hist[7], hist[8]);
     }
     IVec level(ns, 0);
     int maxlev = 0;
