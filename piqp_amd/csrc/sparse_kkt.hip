@@ -925,7 +925,7 @@ __global__ __launch_bounds__(64) void k_subtree_fwd_wave(FrontMeta M, const doub
 template <bool TOP>
 __global__ __launch_bounds__(64) void k_subtree_bwd_wave(FrontMeta M, const double* __restrict__ fronts, const int* __restrict__ sub_lo, const int* __restrict__ sub_hi,
                                                          double* __restrict__ x, int red_thr, int ntop, const int* __restrict__ top_pos, int* __restrict__ flags,
-                                                         int* __restrict__ err)
+                                                         int* __restrict__ err, const int* __restrict__ pub)
 {
     __shared__ double sv[2][128];
     const int lane = threadIdx.x, r0 = lane, r1 = lane + 64;
@@ -1025,7 +1025,7 @@ __global__ __launch_bounds__(64) void k_subtree_bwd_wave(FrontMeta M, const doub
         __syncthreads();
         cur ^= 1;
         prev_valid = true;
-        if (TOP) wave_publish_flag(flags + top_pos[s]);
+        if (TOP) { const int tp = top_pos[s]; if (pub[tp]) wave_publish_flag(flags + tp); }  // only where a child in another walk waits for it
         me = nxt;
     }
 }
@@ -1553,7 +1553,7 @@ private:
         ops_.clone_from(o.ops_, st_);
         cpd(vals_, o.vals_); cpd(fronts_, o.fronts_); cpd(rdiag_, o.rdiag_);
         xp_.alloc(o.xp_.n); fvec_.alloc(o.fvec_.n); dvec_.alloc(o.dvec_.n);
-        cpi(diag_pos_, o.diag_pos_); cpi(P_, o.P_); cpi(level_sn_, o.level_sn_); cpi(top_pos_, o.top_pos_); top_flags_.alloc(o.top_flags_.n ? o.top_flags_.n : 1); cpi(solve_level_sn_, o.solve_level_sn_); cpi(solve_top_pos_, o.solve_top_pos_); solve_flags_.alloc(o.solve_flags_.n ? o.solve_flags_.n : 1); ntop_solve_ = o.ntop_solve_; cpi(solve_walk_lo_, o.solve_walk_lo_); cpi(solve_walk_hi_, o.solve_walk_hi_); nwalk_solve_ = o.nwalk_solve_; cpi(solve_child_tp_, o.solve_child_tp_); crec_.alloc(o.crec_.n ? o.crec_.n : 1); if (o.crec_.n) PQ_HIP(hipMemcpyAsync(crec_.p, o.crec_.p, o.crec_.bytes(), hipMemcpyDeviceToDevice, st_)); cpi(top_walk_lo_, o.top_walk_lo_); cpi(top_walk_hi_, o.top_walk_hi_); ntopwalk_ = o.ntopwalk_; top_walk_cap_ = o.top_walk_cap_; cpi(fe_ptr_, o.fe_ptr_); cpi(fe_q_, o.fe_q_); cpi(fe_off_, o.fe_off_); cpi(fe_offp_, o.fe_offp_);
+        cpi(diag_pos_, o.diag_pos_); cpi(P_, o.P_); cpi(level_sn_, o.level_sn_); cpi(top_pos_, o.top_pos_); top_flags_.alloc(o.top_flags_.n ? o.top_flags_.n : 1); cpi(solve_level_sn_, o.solve_level_sn_); cpi(solve_top_pos_, o.solve_top_pos_); solve_flags_.alloc(o.solve_flags_.n ? o.solve_flags_.n : 1); ntop_solve_ = o.ntop_solve_; cpi(solve_pub_, o.solve_pub_); cpi(solve_walk_lo_, o.solve_walk_lo_); cpi(solve_walk_hi_, o.solve_walk_hi_); nwalk_solve_ = o.nwalk_solve_; cpi(solve_child_tp_, o.solve_child_tp_); crec_.alloc(o.crec_.n ? o.crec_.n : 1); if (o.crec_.n) PQ_HIP(hipMemcpyAsync(crec_.p, o.crec_.p, o.crec_.bytes(), hipMemcpyDeviceToDevice, st_)); cpi(top_walk_lo_, o.top_walk_lo_); cpi(top_walk_hi_, o.top_walk_hi_); ntopwalk_ = o.ntopwalk_; top_walk_cap_ = o.top_walk_cap_; cpi(fe_ptr_, o.fe_ptr_); cpi(fe_q_, o.fe_q_); cpi(fe_off_, o.fe_off_); cpi(fe_offp_, o.fe_offp_);
         snrec_.alloc(o.snrec_.n ? o.snrec_.n : 1); if (o.snrec_.n) PQ_HIP(hipMemcpyAsync(snrec_.p, o.snrec_.p, o.snrec_.bytes(), hipMemcpyDeviceToDevice, st_)); cpi(sn_first_, o.sn_first_); cpi(front_rows_ptr_, o.front_rows_ptr_); cpi(front_rows_, o.front_rows_);
         cpi(child_ptr_, o.child_ptr_); cpi(child_, o.child_); cpi(rel_ptr_, o.rel_ptr_); cpi(rel_, o.rel_);
         cpi(mapP_, o.mapP_); cpi(mapA_, o.mapA_); cpi(mapG_, o.mapG_);
@@ -1704,7 +1704,7 @@ private:
         hipLaunchKernelGGL(k_scale, g1(N_), dim3(256), 0, st_, N_, rdiag_.p, xp_.p);
         if (wave_top) {
             hipLaunchKernelGGL(k_subtree_bwd_wave<true>, dim3(nwalk_solve_), dim3(64), 0, st_, M, fronts_.p, solve_walk_lo_.p, solve_walk_hi_.p, xp_.p, bwd_red_thr(), nwalk_solve_, solve_top_pos_.p,
-                               solve_flags_.p + nt, solve_flags_.p + 2 * nt);
+                               solve_flags_.p + nt, solve_flags_.p + 2 * nt, solve_pub_.p);
             hipLaunchKernelGGL(k_top_check, dim3(1), dim3(1), 0, st_, solve_flags_.p + 2 * nt, (int*)nullptr, xp_.p);
         } else bwd_levels(M, S_.solve_top_level_ptr, S_.solve_top_level_sn, solve_level_sn_.p);
         subtree_bwd(M, solve_sched_);
@@ -1856,7 +1856,7 @@ private:
     void subtree_bwd(const FrontMeta& M, const SubSchedule& sc)
     {
         for (const SubClass& c : sc.cls) {
-            if (c.fmax <= 128 && !std::getenv("PIQP_AMD_SUBTREE_SOLVE_V1")) hipLaunchKernelGGL(k_subtree_bwd_wave<false>, dim3(c.nsub), dim3(64), 0, st_, M, fronts_.p, c.lo.p, c.hi.p, xp_.p, bwd_red_thr(), 0, (const int*)nullptr, (int*)nullptr, (int*)nullptr);
+            if (c.fmax <= 128 && !std::getenv("PIQP_AMD_SUBTREE_SOLVE_V1")) hipLaunchKernelGGL(k_subtree_bwd_wave<false>, dim3(c.nsub), dim3(64), 0, st_, M, fronts_.p, c.lo.p, c.hi.p, xp_.p, bwd_red_thr(), 0, (const int*)nullptr, (int*)nullptr, (int*)nullptr, (const int*)nullptr);
             else hipLaunchKernelGGL(k_subtree_bwd, dim3(c.nsub), dim3(SUB_SOLVE_THREADS), 0, st_, M, fronts_.p, c.lo.p, c.hi.p, xp_.p, fvec_.p);
         }
     }
@@ -1911,7 +1911,7 @@ private:
         for (int l = (int)ptr.size() - 2; l >= 0; --l) {
             const int cnt = ptr[l + 1] - ptr[l];
             if (cnt <= 0) continue;
-            if (level_is_narrow(ptr, sn, l)) hipLaunchKernelGGL(k_subtree_bwd_wave<false>, dim3(cnt), dim3(64), 0, st_, M, fronts_.p, sn_dev + ptr[l], sn_dev + ptr[l], xp_.p, bwd_red_thr(), 0, (const int*)nullptr, (int*)nullptr, (int*)nullptr);
+            if (level_is_narrow(ptr, sn, l)) hipLaunchKernelGGL(k_subtree_bwd_wave<false>, dim3(cnt), dim3(64), 0, st_, M, fronts_.p, sn_dev + ptr[l], sn_dev + ptr[l], xp_.p, bwd_red_thr(), 0, (const int*)nullptr, (int*)nullptr, (int*)nullptr, (const int*)nullptr);
             else hipLaunchKernelGGL(k_front_bwd, dim3(cnt), dim3(256), 0, st_, M, fronts_.p, sn_dev + ptr[l], xp_.p, fvec_.p);
         }
     }
@@ -1934,6 +1934,15 @@ private:
             solve_flags_.alloc(2 * S_.solve_top_level_sn.size() + 2);
             upload_vec(solve_walk_lo_, S_.solve_walk_lo, st_); upload_vec(solve_walk_hi_, S_.solve_walk_hi, st_);
             nwalk_solve_ = (int)S_.solve_walk_lo.size();
+            {   // backward sweep: a supernode publishes its flag only if a top child in ANOTHER walk waits for it
+                std::vector<int> walk_of(S_.nsuper ? S_.nsuper : 1, -1), pub(tp.size() ? S_.solve_top_level_sn.size() + 1 : 1, 0);
+                for (int wk = 0; wk < nwalk_solve_; ++wk) for (int t = S_.solve_walk_lo[wk]; t <= S_.solve_walk_hi[wk]; ++t) walk_of[t] = wk;
+                for (size_t q = 0; q < S_.solve_top_level_sn.size(); ++q) {
+                    const int c = S_.solve_top_level_sn[q], ps = S_.sn_parent[c];
+                    if (ps >= 0 && tp[ps] >= 0 && walk_of[ps] != walk_of[c]) pub[tp[ps]] = 1;
+                }
+                upload_vec(solve_pub_, pub, st_);
+            }
             build_solve_schedule();
         }
         upload_vec(fe_ptr_, S_.fe_ptr, st_); upload_vec(fe_q_, S_.fe_q, st_); upload_vec(fe_off_, S_.fe_off, st_);
@@ -2078,7 +2087,7 @@ private:
     bool top_persistent_ = false;
     CscOperators ops_;
     DBuf<double> vals_, fronts_, rdiag_, xp_, fvec_, dvec_;
-    DBuf<int> fe_ptr_, fe_q_, fe_off_, fe_offp_, top_pos_, top_flags_, solve_level_sn_, solve_top_pos_, solve_flags_, solve_walk_lo_, solve_walk_hi_;
+    DBuf<int> fe_ptr_, fe_q_, fe_off_, fe_offp_, top_pos_, top_flags_, solve_level_sn_, solve_top_pos_, solve_flags_, solve_walk_lo_, solve_walk_hi_, solve_pub_;
     SubSchedule solve_sched_;
     int ntop_solve_ = 0, nwalk_solve_ = 0;
     DBuf<int> top_walk_lo_, top_walk_hi_;
