@@ -561,7 +561,9 @@ void analyse_kkt(const pq_sparse_data* d, int mode, Symbolic& S)
     const std::string ord = want ? want : "auto";
     if (ord == "amd" || (ord == "auto" && N < 200)) { analyse_with_order(S, perm_amd); S.ordering = "amd"; return; }
     IVec perm_nd(N);
-    nd_order(N, S.Kp.data(), S.Ki.data(), perm_nd.data(), 96);
+    int nd_leaf = 256;  // measured with the leaf amalgamation: 96 -> 256 is +8 % on C3 and +5 % on the n = 500k chain, 384 falls off a cliff
+    if (const char* e = std::getenv("PIQP_AMD_ND_LEAF")) nd_leaf = std::max(8, std::atoi(e));
+    nd_order(N, S.Kp.data(), S.Ki.data(), perm_nd.data(), nd_leaf);
     Symbolic T = S;
     analyse_with_order(T, perm_nd);
     T.ordering = "nested dissection";
