@@ -979,6 +979,30 @@ __global__ __launch_bounds__(64) void k_subtree_bwd_wave(FrontMeta M, const doub
                 if (r0 == k) v0 -= pa;
                 if (r1 == k) v1 -= pa;
             }
+        } else if (w <= 32 && f - w >= 16) {
+            // at most 32 pivot columns: the wave splits into G = 64 / P groups (P = 8, 16 or 32 lanes, one per column) and every group takes
+            // 1 / G of the update rows, so the sweep is (f - w) / (4 G) dependent round trips to L2 instead of (f - w) / 4; the groups'
+            // partial sums are combined by shuffles.  x2 is read from LDS (the lanes of a batch need different rows).
+            double* xs = sv[cur];
+            if (r0 < f) xs[r0] = v0;
+            if (r1 < f) xs[r1] = v1;
+            __syncthreads();
+            const int P = w <= 8 ? 8 : (w <= 16 ? 16 : 32), G = 64 / P;
+            const int j = lane & (P - 1), h = lane / P;
+            const int u = f - w, chunk = (u + G - 1) / G;
+            const int ibeg = w + h * chunk, iend = min(f, ibeg + chunk);
+            const double* cj = F + (long long)j * f;
+            double sp = 0.0;
+            for (int i = ibeg; i < iend; i += 4) {
+                double a[4], xv[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { const bool ok = j < w && i + q < iend; a[q] = ok ? cj[i + q] : 0.0; xv[q] = ok ? xs[i + q] : 0.0; }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) sp += a[q] * xv[q];
+            }
+            for (int o = P; o < 64; o <<= 1) sp += __shfl_xor(sp, o);
+            if (lane < w) v0 -= sp;  // lane = column = pivot row (w <= 32)
+            __syncthreads();         // xs is reused for the final vector below
         } else {
             double s0 = 0.0, s1 = 0.0;
             const double* cj0 = F + (long long)r0 * f;
@@ -1826,7 +1850,7 @@ private:
     static int bwd_red_thr()
     {
         static int v = -1;
-        if (v < 0) { const char* e = std::getenv("PIQP_AMD_BWD_RED"); v = e ? std::atoi(e) : 3; }
+        if (v < 0) { const char* e = std::getenv("PIQP_AMD_BWD_RED"); v = e ? std::atoi(e) : 6; }  // 3 before the split-wave product existed; 6: C3 solve 0.31 -> 0.29 ms
         return v;
     }
     void build_full_schedule()
