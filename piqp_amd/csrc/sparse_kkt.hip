@@ -44,6 +44,7 @@ struct SnRec {  // everything the numeric kernels need about one supernode, in o
     int rel_ptr;    // offset into `rel` of this supernode's update rows inside its parent
     int parent;     // parent supernode (-1: root)
     long long front_off;
+    int nind;       // leading pivots that are mutually independent (merged sibling leaves): eliminated in one pass
     int fe_lo, fe_hi;  // assembly entries of this supernode: values vals[fe_lo .. fe_hi) (the value array is stored in this order), front offsets fe_off[..]
 };
 struct ChildRec {  // what a parent needs to know about one child, stored parallel to the child lists (one load instead of child -> record)
@@ -320,6 +321,41 @@ __device__ __forceinline__ void schur_2x2_pk(double* __restrict__ W, int f, int 
         }
     }
 }
+
+// The first `nind` pivots of a front are mutually independent (merged sibling leaves: their mutual block is structurally zero), so they
+// need no pivot-by-pivot loop: their reciprocals go to `scratch` (LDS) and every entry of the remaining panel columns receives its nind
+// updates in one pass, in the same pivot order and with the same operands as the per-pivot loop (bitwise the same result).  Returns the
+// first pivot the per-pivot loop still has to do.
+__device__ __forceinline__ int independent_pivots_pk(double* __restrict__ W, int f, int w, int nind, int first, double* __restrict__ scratch, double* __restrict__ rdiag,
+                                                     int* __restrict__ info, int tid, int nt)
+{
+    if (nind < 2) return 0;
+    const int tx = tid & 15, ty = tid >> 4, tys = nt >> 4;
+    for (int k = tid; k < nind; k += nt) {
+        double d = W[pk_base(k, f) + k];
+        if (d == 0.0) { if (*info < 0) *info = first + k; d = 1.0; }
+        const double dinv = pivot_rcp(d);
+        scratch[k] = dinv;
+        rdiag[first + k] = dinv;
+    }
+    __syncthreads();
+    for (int j = nind + ty; j < w; j += tys) {
+        double* Wj = W + pk_base(j, f);
+        for (int i = j + tx; i < f; i += 16) {
+            double a = Wj[i];
+            int ck = 0;  // pk_base(k, f)
+            for (int k = 0; k < nind; ++k) {
+                const double* Ck = W + ck;
+                const double cj = Ck[j];
+                if (cj != 0.0) a -= (Ck[i] * scratch[k]) * cj;
+                ck += f - k - 1;
+            }
+            Wj[i] = a;
+        }
+    }
+    __syncthreads();
+    return nind;
+}
 __global__ __launch_bounds__(1024) void k_subtree_factor_pk(FrontMeta M, double* __restrict__ fronts, const double* __restrict__ vals, const int* __restrict__ fe_offp,
                                                            const int* __restrict__ sub_lo, const int* __restrict__ sub_hi, int cap, double* __restrict__ rdiag,
                                                            int* __restrict__ info)
@@ -362,7 +398,7 @@ __global__ __launch_bounds__(1024) void k_subtree_factor_pk(FrontMeta M, double*
             __syncthreads();
         }
         // ---- panel
-        for (int k = 0; k < w; ++k) {
+        for (int k = independent_pivots_pk(W, f, w, me.nind, first, prev, rdiag, info, tid, nt); k < w; ++k) {
             const int ck = pk_base(k, f);
             double d = W[ck + k];
             if (d == 0.0) { if (tid == 0 && *info < 0) *info = first + k; d = 1.0; }
@@ -1168,7 +1204,7 @@ __global__ __launch_bounds__(512) void k_top_factor_walk(FrontMeta M, double* __
                 }
                 __syncthreads();
             }
-            for (int k = 0; k < w; ++k) {
+            for (int k = independent_pivots_pk(W, f, w, me.nind, first, prev, rdiag, info, tid, nt); k < w; ++k) {
                 const int ck = pk_base(k, f);
                 double d = W[ck + k];
                 if (d == 0.0) { if (tid == 0 && *info < 0) *info = first + k; d = 1.0; }
@@ -2003,7 +2039,7 @@ private:
                 SnRec& r = rec[q];
                 r.first = S_.sn_first[q]; r.w = S_.sn_first[q + 1] - S_.sn_first[q]; r.f = S_.front_rows_ptr[q + 1] - S_.front_rows_ptr[q];
                 r.rows_ptr = S_.front_rows_ptr[q]; r.child_lo = S_.child_ptr[q]; r.child_hi = S_.child_ptr[q + 1]; r.rel_ptr = S_.rel_ptr[q]; r.parent = S_.sn_parent[q];
-                r.front_off = S_.front_off[q]; r.fe_lo = S_.fe_ptr[q]; r.fe_hi = S_.fe_ptr[q + 1];
+                r.front_off = S_.front_off[q]; r.fe_lo = S_.fe_ptr[q]; r.fe_hi = S_.fe_ptr[q + 1]; r.nind = S_.sn_nind[q];
             }
             upload_vec(snrec_, rec, st_);
         }

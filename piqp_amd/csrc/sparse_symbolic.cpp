@@ -664,6 +664,7 @@ static void analyse_with_order(Symbolic& S, const IVec& perm0, const IVec* force
     S.sn_first.push_back(N);
     const int ns = S.nsuper;
     S.sn_parent.assign(ns, -1);
+    S.sn_nind.assign(ns, 1);
     S.front_rows_ptr.assign(ns + 1, 0);
     S.front_off.assign(ns + 1, 0);
     S.max_front = 0;
@@ -674,6 +675,17 @@ static void analyse_with_order(Symbolic& S, const IVec& perm0, const IVec* force
         S.front_off[s + 1] = S.front_off[s] + (long long)f * f;
         S.max_front = std::max(S.max_front, f);
         if (S.etree[last] >= 0) S.sn_parent[s] = S.sn_of_col[S.etree[last]];
+        {   // columns first .. first + m - 1 are mutually independent iff the parent (= first row of L) of each of them is >= first + m
+            const int a0 = S.sn_first[s];
+            int m = 1, runmin = S.etree[a0] < 0 ? N : S.etree[a0];
+            while (a0 + m <= last) {
+                const int e = S.etree[a0 + m] < 0 ? N : S.etree[a0 + m];
+                const int rm = std::min(runmin, e);
+                if (rm < a0 + m + 1) break;
+                runmin = rm; ++m;
+            }
+            S.sn_nind[s] = m;
+        }
     }
     S.front_doubles = S.front_off[ns];
     S.front_rows.assign(S.front_rows_ptr[ns], 0);

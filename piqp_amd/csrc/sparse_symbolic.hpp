@@ -48,6 +48,7 @@ struct Symbolic {
     IVec sn_first;          // nsuper+1: first column of each supernode
     IVec sn_of_col;         // N
     IVec sn_parent;         // assembly tree
+    IVec sn_nind;           // leading pivot columns of the supernode that are mutually independent (merged sibling leaves): no updates among them
     IVec front_rows_ptr;    // nsuper+1 into front_rows
     IVec front_rows;        // global (permuted) indices of every front, pivots first, sorted
     std::vector<long long> front_off;  // nsuper+1 offsets (in doubles) into the front workspace
