@@ -32,6 +32,7 @@ constexpr int BIG_PIVOTS = 32;
 constexpr int SUB_SOLVE_THREADS = 64;   // substitution inside a subtree is a chain of short vector operations: one wave per subtree
 constexpr int SUBTREE_LDS_BYTES = 150 * 1024;  // two fronts of the LDS-native subtree walker
 constexpr int SUB_THREADS = 256;    // small subtrees: fronts reach ~100 rows near the subtree root, so a full workgroup (64 threads measured 2x slower)
+constexpr int IND_SCRATCH = 128;     // doubles of LDS behind a front for the reciprocals of its independent leading pivots
 constexpr int LDS_FRONT_DOUBLES = 12288;  // 96 KiB: fronts up to 110 x 110 are factored inside LDS
 
 struct SnRec {  // everything the numeric kernels need about one supernode, in one 32-byte record (one load instead of a
@@ -231,7 +232,36 @@ __device__ void front_factor(const FrontMeta& M, double* __restrict__ fronts, in
     extend_add(M, fronts, s, W, f);
     // ---- panel: right-looking LDLt of the first w columns, updates confined to the panel (rows k+1..f-1, columns k+1..w-1)
     const int tid = threadIdx.x, nt = blockDim.x;
-    for (int k = 0; k < w; ++k) {
+    int k0 = 0;
+    if (me.nind >= 2) {
+        // independent leading pivots (merged sibling leaves): one pass instead of nind barriers, see independent_pivots_pk
+        const int ni = min(me.nind, IND_SCRATCH);
+        double* scratch = in_lds ? lds + f * f : lds;
+        const int tx = tid & 15, ty = tid >> 4, tys = nt >> 4;
+        for (int k = tid; k < ni; k += nt) {
+            double d = W[k + (long long)k * f];
+            if (d == 0.0) { if (*info < 0) *info = first + k; d = 1.0; }
+            const double dinv = pivot_rcp(d);
+            scratch[k] = dinv;
+            rdiag[first + k] = dinv;
+        }
+        __syncthreads();
+        for (int j = ni + ty; j < w; j += tys) {
+            double* Wj = W + (long long)j * f;
+            for (int i = j + tx; i < f; i += 16) {
+                double a = Wj[i];
+                for (int k = 0; k < ni; ++k) {
+                    const double* Ck = W + (long long)k * f;
+                    const double cj = Ck[j];
+                    if (cj != 0.0) a -= (Ck[i] * scratch[k]) * cj;
+                }
+                Wj[i] = a;
+            }
+        }
+        __syncthreads();
+        k0 = ni;
+    }
+    for (int k = k0; k < w; ++k) {
         double d = W[k + (long long)k * f];  // every thread reads the same word (broadcast)
         if (d == 0.0) { if (tid == 0 && *info < 0) *info = first + k; d = 1.0; }
         const double dinv = pivot_rcp(d);
@@ -1534,7 +1564,7 @@ public:
                     const long long f = S_.front_rows_ptr[s + 1] - S_.front_rows_ptr[s];
                     if (f * f <= LDS_FRONT_DOUBLES) mx = std::max(mx, f * f);
                 }
-                if (sn.size() > before) { ptr.push_back((int)sn.size()); lds.push_back((int)mx * (int)sizeof(double)); }
+                if (sn.size() > before) { ptr.push_back((int)sn.size()); lds.push_back(((int)mx + IND_SCRATCH) * (int)sizeof(double)); }
             }
             upload_vec(dev, sn, st_);
         };
@@ -1632,12 +1662,12 @@ private:
     {
         static bool attr_set = false;
         if (!attr_set) {
-            PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_front_factor), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_FRONT_DOUBLES * (int)sizeof(double)));
-            PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_subtree_factor), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_FRONT_DOUBLES * (int)sizeof(double)));
+            PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_front_factor), hipFuncAttributeMaxDynamicSharedMemorySize, (LDS_FRONT_DOUBLES + IND_SCRATCH) * (int)sizeof(double)));
+            PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_subtree_factor), hipFuncAttributeMaxDynamicSharedMemorySize, (LDS_FRONT_DOUBLES + IND_SCRATCH) * (int)sizeof(double)));
             PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_subtree_factor_lds), hipFuncAttributeMaxDynamicSharedMemorySize, SUBTREE_LDS_BYTES));
             PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_subtree_factor_pk), hipFuncAttributeMaxDynamicSharedMemorySize, SUBTREE_LDS_BYTES));
             PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_subtree_factor_staged), hipFuncAttributeMaxDynamicSharedMemorySize, SUBTREE_LDS_BYTES));
-            PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_top_factor), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_FRONT_DOUBLES * (int)sizeof(double)));
+            PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_top_factor), hipFuncAttributeMaxDynamicSharedMemorySize, (LDS_FRONT_DOUBLES + IND_SCRATCH) * (int)sizeof(double)));
             attr_set = true;
         }
         level_lds_.assign(S_.top_nlevels, 0);
@@ -1648,11 +1678,11 @@ private:
                 const long long f = S_.front_rows_ptr[s + 1] - S_.front_rows_ptr[s];
                 if (f * f <= LDS_FRONT_DOUBLES) mx = std::max(mx, f * f);
             }
-            level_lds_[l] = (int)mx * (int)sizeof(double);
+            level_lds_[l] = ((int)mx + IND_SCRATCH) * (int)sizeof(double);
         }
         {
             const long long f = S_.sub_max_front;
-            sub_lds_ = (int)(std::min<long long>(f * f, LDS_FRONT_DOUBLES) * (long long)sizeof(double));
+            sub_lds_ = (int)((std::min<long long>(f * f, LDS_FRONT_DOUBLES) + IND_SCRATCH) * (long long)sizeof(double));
         }
         // single-launch top of the tree: possible when no top front needs the multi-launch dense path
         ntop_ = (int)S_.top_level_sn.size();
@@ -1664,7 +1694,7 @@ private:
             if (f >= BIG_FRONT && w >= BIG_PIVOTS) any_big = true;
             if (f * f <= LDS_FRONT_DOUBLES) top_mx = std::max(top_mx, f * f);
         }
-        top_lds_ = (int)top_mx * (int)sizeof(double);
+        top_lds_ = ((int)top_mx + IND_SCRATCH) * (int)sizeof(double);
         top_grid_ = std::min(ntop_, 224);
         // measured: worth it for the factorisation when every top supernode gets its own workgroup; the substitution fronts are too
         // cheap to pay for agent-scope release / acquire per supernode, they stay on level launches
