@@ -127,6 +127,65 @@ __global__ void k_rhs_x_bar(int n, double delta, const int* __restrict__ pos_l, 
     out[idx] = v;
 }
 
+
+// ---- fused launches of the per-iteration elementwise work (one launch instead of six / two / six; every formula is the one of the
+// single-purpose kernel above it replaces, same operand order, so the values are bitwise the same) -------------------------------
+// kkt_system.hpp:150-193: copies + reciprocals + x_reg + z_reg.  x_reg needs the box slacks of OTHER indices, so it recomputes their
+// reciprocals from the caller's z instead of reading what a neighbouring thread is writing.
+__global__ void k_scalings_fused(int n, int m, int nxl, int nxu, double rho, double delta, const double* __restrict__ v_s_l, const double* __restrict__ v_z_l,
+                                 const double* __restrict__ v_s_u, const double* __restrict__ v_z_u, const double* __restrict__ v_s_bl, const double* __restrict__ v_z_bl,
+                                 const double* __restrict__ v_s_bu, const double* __restrict__ v_z_bu, const int* __restrict__ has_l, const int* __restrict__ has_u,
+                                 const int* __restrict__ pos_l, const int* __restrict__ pos_u, const double* __restrict__ xbs, double* __restrict__ s_l, double* __restrict__ zinv_l,
+                                 double* __restrict__ s_u, double* __restrict__ zinv_u, double* __restrict__ s_bl, double* __restrict__ zinv_bl, double* __restrict__ s_bu,
+                                 double* __restrict__ zinv_bu, double* __restrict__ x_reg, double* __restrict__ z_reg, double* __restrict__ z_reg_iter_ref)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) {
+        const double sl = v_s_l[i], zil = 1.0 / v_z_l[i], su = v_s_u[i], ziu = 1.0 / v_z_u[i];
+        s_l[i] = sl; zinv_l[i] = zil; s_u[i] = su; zinv_u[i] = ziu;
+        double v = 0.0;
+        if (has_l[i] >= 0) v += 1.0 / (zil * sl + delta);
+        if (has_u[i] >= 0) v += 1.0 / (ziu * su + delta);
+        v = 1.0 / v;
+        z_reg[i] = v;
+        z_reg_iter_ref[i] = v;
+    }
+    if (i < nxl) { s_bl[i] = v_s_bl[i]; zinv_bl[i] = 1.0 / v_z_bl[i]; }
+    if (i < nxu) { s_bu[i] = v_s_bu[i]; zinv_bu[i] = 1.0 / v_z_bu[i]; }
+    if (i < n) {
+        double v = rho;
+        const double sc = xbs[i];
+        const int il = pos_l[i], iu = pos_u[i];
+        if (il >= 0) v += sc * sc / ((1.0 / v_z_bl[il]) * v_s_bl[il] + delta);
+        if (iu >= 0) v += sc * sc / ((1.0 / v_z_bu[iu]) * v_s_bu[iu] + delta);
+        x_reg[i] = v;
+    }
+}
+// kkt_system.hpp:219-252: rhs_z_bar + rhs_x_bar; thread 0 also zeroes the scalar slots of the finite check that follows the backend solve
+__global__ void k_rhs_bars_fused(int n, int m, double delta, const int* __restrict__ has_l, const int* __restrict__ has_u, const double* __restrict__ s_l,
+                                 const double* __restrict__ zinv_l, const double* __restrict__ s_u, const double* __restrict__ zinv_u, const double* __restrict__ z_reg,
+                                 const double* __restrict__ r_z_l, const double* __restrict__ r_s_l, const double* __restrict__ r_z_u, const double* __restrict__ r_s_u,
+                                 const int* __restrict__ pos_l, const int* __restrict__ pos_u, const double* __restrict__ xbs, const double* __restrict__ s_bl,
+                                 const double* __restrict__ zinv_bl, const double* __restrict__ s_bu, const double* __restrict__ zinv_bu, const double* __restrict__ r_x,
+                                 const double* __restrict__ r_z_bl, const double* __restrict__ r_s_bl, const double* __restrict__ r_z_bu, const double* __restrict__ r_s_bu,
+                                 double* __restrict__ out_z, double* __restrict__ out_x, unsigned long long* __restrict__ scal)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) { scal[0] = 0ull; scal[1] = 0ull; scal[2] = 0ull; scal[3] = 0ull; }
+    if (i < m) {
+        double v = 0.0;
+        if (has_l[i] >= 0) v -= 1.0 / (zinv_l[i] * s_l[i] + delta) * (r_z_l[i] - zinv_l[i] * r_s_l[i]);
+        if (has_u[i] >= 0) v += 1.0 / (zinv_u[i] * s_u[i] + delta) * (r_z_u[i] - zinv_u[i] * r_s_u[i]);
+        out_z[i] = v * z_reg[i];
+    }
+    if (i < n) {
+        double v = r_x[i];
+        const int il = pos_l[i], iu = pos_u[i];
+        if (il >= 0) v -= xbs[i] * (r_z_bl[il] - zinv_bl[il] * r_s_bl[il]) / (s_bl[il] * zinv_bl[il] + delta);
+        if (iu >= 0) v += xbs[i] * (r_z_bu[iu] - zinv_bu[iu] * r_s_bu[iu]) / (s_bu[iu] * zinv_bu[iu] + delta);
+        out_x[i] = v;
+    }
+}
 // ---- kkt_system.hpp:507-536 condensed residual pieces -----------------------------------------------
 // err_x = rhs_x - (((Px + x_reg o lhs_x) + ATy) + GTz)
 __global__ void k_err_x(int n, const double* __restrict__ rhs_x, const double* __restrict__ Px, const double* __restrict__ x_reg, const double* __restrict__ lhs_x,
@@ -253,6 +312,71 @@ __global__ void k_fill(int n, double v, double* __restrict__ a)
 }
 
 inline dim3 g1(int n) { return dim3(n > 0 ? (n + 255) / 256 : 1); }
+// kkt_system.hpp:305-369 without refinement: the dual / box recoveries and the allFinite check of (lhs.x, lhs.y, lhs_z) in one launch.
+// The check is the NaN-propagating |.|_inf of k_absmax, max-combined into scal[0] (zeroed by k_rhs_bars_fused).
+__global__ __launch_bounds__(256) void k_recover_fused(int n, int p, int m, int nxl, int nxu, double delta, const int* __restrict__ has_l, const int* __restrict__ has_u,
+                                                       const double* __restrict__ s_l, const double* __restrict__ zinv_l, const double* __restrict__ s_u,
+                                                       const double* __restrict__ zinv_u, const double* __restrict__ z_reg, const double* __restrict__ lhs_z,
+                                                       const double* __restrict__ r_z_l, const double* __restrict__ r_s_l, const double* __restrict__ r_z_u,
+                                                       const double* __restrict__ r_s_u, double* __restrict__ o_z_l, double* __restrict__ o_z_u, double* __restrict__ o_s_l,
+                                                       double* __restrict__ o_s_u, const int* __restrict__ xl_idx, const int* __restrict__ xu_idx, const double* __restrict__ xbs,
+                                                       const double* __restrict__ lhs_x, const double* __restrict__ lhs_y, const double* __restrict__ s_bl,
+                                                       const double* __restrict__ zinv_bl, const double* __restrict__ r_z_bl, const double* __restrict__ r_s_bl,
+                                                       double* __restrict__ o_z_bl, double* __restrict__ o_s_bl, const double* __restrict__ s_bu, const double* __restrict__ zinv_bu,
+                                                       const double* __restrict__ r_z_bu, const double* __restrict__ r_s_bu, double* __restrict__ o_z_bu,
+                                                       double* __restrict__ o_s_bu, unsigned long long* __restrict__ scal)
+{
+    __shared__ double red[4];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < m) {
+        const bool l = has_l[i] >= 0, u = has_u[i] >= 0;
+        double zl = 0.0, zu = 0.0, sl = 0.0, su = 0.0;
+        if (l && u) {
+            const double rz_l_bar = r_z_l[i] - zinv_l[i] * r_s_l[i];
+            const double W_l_inv = 1.0 / (zinv_l[i] * s_l[i] + delta);
+            const double rz_u_bar = r_z_u[i] - zinv_u[i] * r_s_u[i];
+            const double W_u_inv = 1.0 / (zinv_u[i] * s_u[i] + delta);
+            const double r_sum = W_l_inv * W_u_inv * (rz_l_bar + rz_u_bar);
+            zl = -z_reg[i] * (r_sum + W_l_inv * lhs_z[i]);
+            zu = -z_reg[i] * (r_sum - W_u_inv * lhs_z[i]);
+            sl = zinv_l[i] * (r_s_l[i] - s_l[i] * zl);
+            su = zinv_u[i] * (r_s_u[i] - s_u[i] * zu);
+        } else if (l) {
+            zl = -lhs_z[i];
+            sl = zinv_l[i] * (r_s_l[i] - s_l[i] * zl);
+        } else if (u) {
+            zu = lhs_z[i];
+            su = zinv_u[i] * (r_s_u[i] - s_u[i] * zu);
+        }
+        o_z_l[i] = zl; o_z_u[i] = zu; o_s_l[i] = sl; o_s_u[i] = su;
+    }
+    if (i < nxl) {
+        const int idx = xl_idx[i];
+        const double zb = (-1.0 * xbs[idx] * lhs_x[idx] - r_z_bl[i] + zinv_bl[i] * r_s_bl[i]) / (s_bl[i] * zinv_bl[i] + delta);
+        o_z_bl[i] = zb;
+        o_s_bl[i] = zinv_bl[i] * (r_s_bl[i] - s_bl[i] * zb);
+    }
+    if (i < nxu) {
+        const int idx = xu_idx[i];
+        const double zb = (1.0 * xbs[idx] * lhs_x[idx] - r_z_bu[i] + zinv_bu[i] * r_s_bu[i]) / (s_bu[i] * zinv_bu[i] + delta);
+        o_z_bu[i] = zb;
+        o_s_bu[i] = zinv_bu[i] * (r_s_bu[i] - s_bu[i] * zb);
+    }
+    double v = 0.0;
+    if (i < n) { const double t = fabs(lhs_x[i]); v = (t != t || v != v) ? __builtin_nan("") : (t > v ? t : v); }
+    if (i < p) { const double t = fabs(lhs_y[i]); v = (t != t || v != v) ? __builtin_nan("") : (t > v ? t : v); }
+    if (i < m) { const double t = fabs(lhs_z[i]); v = (t != t || v != v) ? __builtin_nan("") : (t > v ? t : v); }
+    v = wave_max_nan(v);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double r = red[0];
+        for (int k = 1; k < 4; ++k) r = (r != r || red[k] != red[k]) ? __builtin_nan("") : (red[k] > r ? red[k] : r);
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(r != r ? __builtin_nan("") : r) & 0x7fffffffffffffffull;
+        if (bits != 0ull) atomicMax(scal, bits);
+    }
+}
+
 #define LAUNCH1(kern, n, st, ...)                                         \
     do {                                                                   \
         if ((n) > 0) {                                                     \
@@ -356,12 +480,11 @@ bool KKTSystem::update_scalings_and_factor(bool iterative_refinement, double rho
     double* m_z_reg_iter_ref = work_z.p;
     m_rho = rho;
     m_delta = delta;
-    LAUNCH1(k_copy_and_invert, m, st_, m, vars.s_l, vars.z_l, m_s_l.p, m_z_l_inv.p);
-    LAUNCH1(k_copy_and_invert, m, st_, m, vars.s_u, vars.z_u, m_s_u.p, m_z_u_inv.p);
-    LAUNCH1(k_copy_and_invert, n_x_l, st_, n_x_l, vars.s_bl, vars.z_bl, m_s_bl.p, m_z_bl_inv.p);
-    LAUNCH1(k_copy_and_invert, n_x_u, st_, n_x_u, vars.s_bu, vars.z_bu, m_s_bu.p, m_z_bu_inv.p);
-    LAUNCH1(k_x_reg, n, st_, n, rho, delta, pos_l.p, pos_u.p, x_b_scaling.p, m_s_bl.p, m_z_bl_inv.p, m_s_bu.p, m_z_bu_inv.p, m_x_reg.p);
-    LAUNCH1(k_z_reg, m, st_, m, delta, has_l.p, has_u.p, m_s_l.p, m_z_l_inv.p, m_s_u.p, m_z_u_inv.p, m_z_reg.p, m_z_reg_iter_ref);
+    {
+        const int cnt = std::max(std::max(n, m), std::max(n_x_l, n_x_u));
+        LAUNCH1(k_scalings_fused, cnt, st_, n, m, n_x_l, n_x_u, rho, delta, vars.s_l, vars.z_l, vars.s_u, vars.z_u, vars.s_bl, vars.z_bl, vars.s_bu, vars.z_bu, has_l.p, has_u.p, pos_l.p,
+                pos_u.p, x_b_scaling.p, m_s_l.p, m_z_l_inv.p, m_s_u.p, m_z_u_inv.p, m_s_bl.p, m_z_bl_inv.p, m_s_bu.p, m_z_bu_inv.p, m_x_reg.p, m_z_reg.p, m_z_reg_iter_ref);
+    }
 
     double delta_reg = delta;
     if (iterative_refinement) {
@@ -411,9 +534,9 @@ bool KKTSystem::solve(const pq_vars& rhs, pq_vars& lhs)
     double* lhs_z = lhs_z_buf.p;  // the reference aliases work_z; a dedicated buffer avoids the z_reg_iter_ref alias hazard
     last_refine_steps = 0; last_backend_solves = 0; last_refine_error = 0.0; last_rhs_norm = 0.0;
 
-    LAUNCH1(k_rhs_z_bar, m, st_, m, m_delta, has_l.p, has_u.p, m_s_l.p, m_z_l_inv.p, m_s_u.p, m_z_u_inv.p, m_z_reg.p, rhs.z_l, rhs.s_l, rhs.z_u, rhs.s_u, rhs_z_bar.p);
-    LAUNCH1(k_rhs_x_bar, n, st_, n, m_delta, pos_l.p, pos_u.p, x_b_scaling.p, m_s_bl.p, m_z_bl_inv.p, m_s_bu.p, m_z_bu_inv.p, rhs.x, rhs.z_bl, rhs.s_bl, rhs.z_bu, rhs.s_bu,
-            rhs_x_bar.p);
+    LAUNCH1(k_rhs_bars_fused, std::max(std::max(n, m), 1), st_, n, m, m_delta, has_l.p, has_u.p, m_s_l.p, m_z_l_inv.p, m_s_u.p, m_z_u_inv.p, m_z_reg.p, rhs.z_l, rhs.s_l, rhs.z_u,
+            rhs.s_u, pos_l.p, pos_u.p, x_b_scaling.p, m_s_bl.p, m_z_bl_inv.p, m_s_bu.p, m_z_bu_inv.p, rhs.x, rhs.z_bl, rhs.s_bl, rhs.z_bu, rhs.s_bu, rhs_z_bar.p, rhs_x_bar.p,
+            scal_d.p);
 
     kkt_solver->solve(rhs_x_bar.p, rhs.y, rhs_z_bar.p, lhs.x, lhs.y, lhs_z);
     last_backend_solves++;
@@ -460,19 +583,19 @@ bool KKTSystem::solve(const pq_vars& rhs, pq_vars& lhs)
             d2d(lhs.x, ref_lhs_x.p, n, st_); d2d(lhs.y, ref_lhs_y.p, p, st_); d2d(lhs_z, ref_lhs_z.p, m, st_);
             last_refine_error = refine_error;
         }
+        LAUNCH1(k_dual_recovery, m, st_, m, m_delta, has_l.p, has_u.p, m_s_l.p, m_z_l_inv.p, m_s_u.p, m_z_u_inv.p, m_z_reg.p, lhs_z, rhs.z_l, rhs.s_l, rhs.z_u, rhs.s_u, lhs.z_l,
+                lhs.z_u, lhs.s_l, lhs.s_u);
+        LAUNCH1(k_box_recovery, n_x_l, st_, n_x_l, -1.0, m_delta, x_l_idx.p, x_b_scaling.p, lhs.x, m_s_bl.p, m_z_bl_inv.p, rhs.z_bl, rhs.s_bl, lhs.z_bl, lhs.s_bl);
+        LAUNCH1(k_box_recovery, n_x_u, st_, n_x_u, 1.0, m_delta, x_u_idx.p, x_b_scaling.p, lhs.x, m_s_bu.p, m_z_bu_inv.p, rhs.z_bu, rhs.s_bu, lhs.z_bu, lhs.s_bu);
     } else {
-        // :305 allFinite check: NaN-propagating |.|_inf is finite iff every entry is
-        PQ_HIP(hipMemsetAsync(scal_d.p, 0, sizeof(unsigned long long) * 4, st_));
-        LAUNCH1(k_absmax, n, st_, n, lhs.x, (const double*)nullptr, scal_d.p);
-        LAUNCH1(k_absmax, p, st_, p, lhs.y, (const double*)nullptr, scal_d.p);
-        LAUNCH1(k_absmax, m, st_, m, lhs_z, (const double*)nullptr, scal_d.p);
+        // :305 allFinite check (NaN-propagating |.|_inf is finite iff every entry is) + the recoveries, one launch; scal_d was zeroed by
+        // k_rhs_bars_fused
+        const int cnt = std::max(std::max(std::max(n, p), m), std::max(n_x_l, n_x_u));
+        LAUNCH1(k_recover_fused, cnt, st_, n, p, m, n_x_l, n_x_u, m_delta, has_l.p, has_u.p, m_s_l.p, m_z_l_inv.p, m_s_u.p, m_z_u_inv.p, m_z_reg.p, lhs_z, rhs.z_l, rhs.s_l, rhs.z_u,
+                rhs.s_u, lhs.z_l, lhs.z_u, lhs.s_l, lhs.s_u, x_l_idx.p, x_u_idx.p, x_b_scaling.p, lhs.x, lhs.y, m_s_bl.p, m_z_bl_inv.p, rhs.z_bl, rhs.s_bl, lhs.z_bl, lhs.s_bl, m_s_bu.p,
+                m_z_bu_inv.p, rhs.z_bu, rhs.s_bu, lhs.z_bu, lhs.s_bu, scal_d.p);
         finite_check_pending = true;
     }
-
-    LAUNCH1(k_dual_recovery, m, st_, m, m_delta, has_l.p, has_u.p, m_s_l.p, m_z_l_inv.p, m_s_u.p, m_z_u_inv.p, m_z_reg.p, lhs_z, rhs.z_l, rhs.s_l, rhs.z_u, rhs.s_u, lhs.z_l,
-            lhs.z_u, lhs.s_l, lhs.s_u);
-    LAUNCH1(k_box_recovery, n_x_l, st_, n_x_l, -1.0, m_delta, x_l_idx.p, x_b_scaling.p, lhs.x, m_s_bl.p, m_z_bl_inv.p, rhs.z_bl, rhs.s_bl, lhs.z_bl, lhs.s_bl);
-    LAUNCH1(k_box_recovery, n_x_u, st_, n_x_u, 1.0, m_delta, x_u_idx.p, x_b_scaling.p, lhs.x, m_s_bu.p, m_z_bu_inv.p, rhs.z_bu, rhs.s_bu, lhs.z_bu, lhs.s_bu);
 
     if (finite_check_pending) {
         finite_check_pending = false;
