@@ -168,10 +168,12 @@ __global__ void k_rhs_bars_fused(int n, int m, double delta, const int* __restri
                                  const int* __restrict__ pos_l, const int* __restrict__ pos_u, const double* __restrict__ xbs, const double* __restrict__ s_bl,
                                  const double* __restrict__ zinv_bl, const double* __restrict__ s_bu, const double* __restrict__ zinv_bu, const double* __restrict__ r_x,
                                  const double* __restrict__ r_z_bl, const double* __restrict__ r_s_bl, const double* __restrict__ r_z_bu, const double* __restrict__ r_s_bu,
-                                 double* __restrict__ out_z, double* __restrict__ out_x, unsigned long long* __restrict__ scal)
+                                 double* __restrict__ out_z, double* __restrict__ out_x, unsigned long long* __restrict__ scal, int p, const double* __restrict__ r_y,
+                                 double* __restrict__ r_y_keep)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) { scal[0] = 0ull; scal[1] = 0ull; scal[2] = 0ull; scal[3] = 0ull; }
+    if (i < p && r_y_keep != r_y) r_y_keep[i] = r_y[i];  // kept for condensed_residual(): the caller may reuse its buffer
     if (i < m) {
         double v = 0.0;
         if (has_l[i] >= 0) v -= 1.0 / (zinv_l[i] * s_l[i] + delta) * (r_z_l[i] - zinv_l[i] * r_s_l[i]);
@@ -534,13 +536,12 @@ bool KKTSystem::solve(const pq_vars& rhs, pq_vars& lhs)
     double* lhs_z = lhs_z_buf.p;  // the reference aliases work_z; a dedicated buffer avoids the z_reg_iter_ref alias hazard
     last_refine_steps = 0; last_backend_solves = 0; last_refine_error = 0.0; last_rhs_norm = 0.0;
 
-    LAUNCH1(k_rhs_bars_fused, std::max(std::max(n, m), 1), st_, n, m, m_delta, has_l.p, has_u.p, m_s_l.p, m_z_l_inv.p, m_s_u.p, m_z_u_inv.p, m_z_reg.p, rhs.z_l, rhs.s_l, rhs.z_u,
+    LAUNCH1(k_rhs_bars_fused, std::max(std::max(n, m), std::max(p, 1)), st_, n, m, m_delta, has_l.p, has_u.p, m_s_l.p, m_z_l_inv.p, m_s_u.p, m_z_u_inv.p, m_z_reg.p, rhs.z_l, rhs.s_l, rhs.z_u,
             rhs.s_u, pos_l.p, pos_u.p, x_b_scaling.p, m_s_bl.p, m_z_bl_inv.p, m_s_bu.p, m_z_bu_inv.p, rhs.x, rhs.z_bl, rhs.s_bl, rhs.z_bu, rhs.s_bu, rhs_z_bar.p, rhs_x_bar.p,
-            scal_d.p);
+            scal_d.p, p, rhs.y, rhs_y_keep.p);
 
     kkt_solver->solve(rhs_x_bar.p, rhs.y, rhs_z_bar.p, lhs.x, lhs.y, lhs_z);
     last_backend_solves++;
-    d2d(rhs_y_keep.p, rhs.y, p, st_);  // kept for condensed_residual(); the caller may reuse its buffer
     last_rhs_y = rhs_y_keep.p;
 
     if (use_iterative_refinement) {

@@ -130,12 +130,13 @@ __global__ void k_perm_gather(int N, const int* __restrict__ P, const double* __
     out[j] = o < na ? a[o] : (o < na + nb ? b[o - na] : c[o - na - nb]);
 }
 __global__ void k_perm_scatter(int N, const int* __restrict__ P, const double* __restrict__ in, double* __restrict__ a, int na, double* __restrict__ b, int nb,
-                               double* __restrict__ c)
+                               double* __restrict__ c, const int* __restrict__ err, int epoch)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= N) return;
     const int o = P[j];  // ordering.permt: rhs[P[j]] = x[j]
-    const double v = in[j];
+    double v = in[j];
+    if (j == 0 && err && *err == epoch) v = __builtin_nan("");  // a flag wait of the sweeps gave up: the solution is poisoned, the caller's finite check reports it
     if (o < na) a[o] = v; else if (o < na + nb) b[o - na] = v; else c[o - na - nb] = v;
 }
 __global__ void k_scale(int N, const double* __restrict__ d, double* __restrict__ x)
@@ -807,27 +808,27 @@ __device__ __forceinline__ void stx(double* p, double v)
 __constant__ int g_wait_nap_max = 1;
 // debug: per-workgroup start / end / wait-done timestamps of the flag-ordered sweeps (PIQP_AMD_DBG_TS=file prefix)
 __device__ long long* g_dbg_ts = nullptr;
-__device__ __forceinline__ void wave_wait_flag(const int* flag, int* err)
+__device__ __forceinline__ void wave_wait_flag(const int* flag, int* err, int epoch)
 {
     if (threadIdx.x == 0) {
         unsigned spins = 0;
         int nap = 1;
-        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
             for (int i = 0; i < nap; ++i) __builtin_amdgcn_s_sleep(1);
             if (nap < g_wait_nap_max) nap <<= 1;
-            if (++spins > 8000000u || ((spins & 15) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-                __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (++spins > 8000000u || ((spins & 15) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch)) {
+                __hip_atomic_store(err, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 break;
             }
         }
     }
     __syncthreads();
 }
-__device__ __forceinline__ void wave_publish_flag(int* flag)
+__device__ __forceinline__ void wave_publish_flag(int* flag, int epoch)
 {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) __hip_atomic_store(flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ double bcast_row(double v0, double v1, int row)
 {
@@ -863,7 +864,7 @@ __device__ __forceinline__ void touch_done(const PanelTouch& p)
 template <bool TOP>
 __global__ __launch_bounds__(64) void k_subtree_fwd_wave(FrontMeta M, const double* __restrict__ fronts, const int* __restrict__ sub_lo, const int* __restrict__ sub_hi,
                                                          double* __restrict__ x, double* __restrict__ fvec, const int* __restrict__ top_pos, int* __restrict__ flags,
-                                                         int* __restrict__ err, const int* __restrict__ child_tp)
+                                                         int* __restrict__ err, const int* __restrict__ child_tp, int epoch)
 {
     __shared__ double sv[2][128];
     const int lane = threadIdx.x, r0 = lane, r1 = lane + 64;
@@ -905,11 +906,11 @@ __global__ __launch_bounds__(64) void k_subtree_fwd_wave(FrontMeta M, const doub
                 }
             }
 #pragma unroll
-            for (int q = 0; q < MAXC; ++q) if (ctp[q] >= 0) wave_wait_flag(flags + ctp[q], err);
+            for (int q = 0; q < MAXC; ++q) if (ctp[q] >= 0) wave_wait_flag(flags + ctp[q], err, epoch);
             for (int ci = me.child_lo + MAXC; ci < me.child_hi; ++ci) {
                 if (prev_valid && M.child[ci] == s - 1) continue;  // the previous link of this walk: no flag, its vector is in LDS
                 const int tp = child_tp[ci];
-                if (tp >= 0) wave_wait_flag(flags + tp, err);
+                if (tp >= 0) wave_wait_flag(flags + tp, err, epoch);
             }
             touch_done(pt);
             if (dbg && lane == 0 && s == lo) dbg[3 * blockIdx.x + 1] = wall_clock64();
@@ -983,7 +984,7 @@ __global__ __launch_bounds__(64) void k_subtree_fwd_wave(FrontMeta M, const doub
         prev_valid = keep;
         me = nxt;
     }
-    if (TOP) wave_publish_flag(flags + top_pos[hi]);
+    if (TOP) wave_publish_flag(flags + top_pos[hi], epoch);
     if (dbg && lane == 0) dbg[3 * blockIdx.x + 2] = wall_clock64();
 }
 // TOP = true: as above for the backward sweep; sub_lo = the level-sorted list, block b takes entry ntop - 1 - b (parents first) and waits
@@ -991,7 +992,7 @@ __global__ __launch_bounds__(64) void k_subtree_fwd_wave(FrontMeta M, const doub
 template <bool TOP>
 __global__ __launch_bounds__(64) void k_subtree_bwd_wave(FrontMeta M, const double* __restrict__ fronts, const int* __restrict__ sub_lo, const int* __restrict__ sub_hi,
                                                          double* __restrict__ x, int red_thr, int ntop, const int* __restrict__ top_pos, int* __restrict__ flags,
-                                                         int* __restrict__ err, const int* __restrict__ pub)
+                                                         int* __restrict__ err, const int* __restrict__ pub, int epoch)
 {
     __shared__ double sv[2][128];
     const int lane = threadIdx.x, r0 = lane, r1 = lane + 64;
@@ -1003,7 +1004,7 @@ __global__ __launch_bounds__(64) void k_subtree_bwd_wave(FrontMeta M, const doub
         const SnRec me = M.sn[hi];
         const PanelTouch pt = touch_panel(fronts + me.front_off, me.f * me.w, lane);
         const int par = me.parent;
-        if (par >= 0) wave_wait_flag(flags + top_pos[par], err);
+        if (par >= 0) wave_wait_flag(flags + top_pos[par], err, epoch);
         touch_done(pt);
     }
     int cur = 0;
@@ -1115,7 +1116,7 @@ __global__ __launch_bounds__(64) void k_subtree_bwd_wave(FrontMeta M, const doub
         __syncthreads();
         cur ^= 1;
         prev_valid = true;
-        if (TOP) { const int tp = top_pos[s]; if (pub[tp]) wave_publish_flag(flags + tp); }  // only where a child in another walk waits for it
+        if (TOP) { const int tp = top_pos[s]; if (pub[tp]) wave_publish_flag(flags + tp, epoch); }  // only where a child in another walk waits for it
         me = nxt;
     }
 }
@@ -1509,11 +1510,11 @@ public:
             solve_numeric(M);
         }
         if (mode_ == 0) {
-            hipLaunchKernelGGL(k_perm_scatter, g1(N_), dim3(256), 0, st_, N_, P_.p, xp_.p, lhs_x, n_, lhs_y, p_, lhs_z);
+            hipLaunchKernelGGL(k_perm_scatter, g1(N_), dim3(256), 0, st_, N_, P_.p, xp_.p, lhs_x, n_, lhs_y, p_, lhs_z, solve_err_ptr_, solve_epoch_used_);
         } else {
             double* tail = mode_ == 1 ? lhs_z : lhs_y;
             const int ntail = mode_ == 1 ? m_ : (mode_ == 2 ? p_ : 0);
-            hipLaunchKernelGGL(k_perm_scatter, g1(N_), dim3(256), 0, st_, N_, P_.p, xp_.p, lhs_x, n_, tail, ntail, (double*)nullptr);
+            hipLaunchKernelGGL(k_perm_scatter, g1(N_), dim3(256), 0, st_, N_, P_.p, xp_.p, lhs_x, n_, tail, ntail, (double*)nullptr, solve_err_ptr_, solve_epoch_used_);
             ops_.recover_duals(lhs_x, rhs_y, rhs_z, zinv_.p, delta_inv, lhs_y, lhs_z, st_, eq, ineq);  // sparse/kkt.hpp:147-175
         }
         PQ_HIP(hipGetLastError());
@@ -1643,7 +1644,7 @@ private:
         ops_.clone_from(o.ops_, st_);
         cpd(vals_, o.vals_); cpd(fronts_, o.fronts_); cpd(rdiag_, o.rdiag_);
         xp_.alloc(o.xp_.n); fvec_.alloc(o.fvec_.n); dvec_.alloc(o.dvec_.n);
-        cpi(diag_pos_, o.diag_pos_); cpi(P_, o.P_); cpi(level_sn_, o.level_sn_); cpi(top_pos_, o.top_pos_); top_flags_.alloc(o.top_flags_.n ? o.top_flags_.n : 1); cpi(solve_level_sn_, o.solve_level_sn_); cpi(solve_top_pos_, o.solve_top_pos_); solve_flags_.alloc(o.solve_flags_.n ? o.solve_flags_.n : 1); ntop_solve_ = o.ntop_solve_; cpi(solve_pub_, o.solve_pub_); cpi(solve_walk_lo_, o.solve_walk_lo_); cpi(solve_walk_hi_, o.solve_walk_hi_); nwalk_solve_ = o.nwalk_solve_; cpi(solve_child_tp_, o.solve_child_tp_); crec_.alloc(o.crec_.n ? o.crec_.n : 1); if (o.crec_.n) PQ_HIP(hipMemcpyAsync(crec_.p, o.crec_.p, o.crec_.bytes(), hipMemcpyDeviceToDevice, st_)); cpi(top_walk_lo_, o.top_walk_lo_); cpi(top_walk_hi_, o.top_walk_hi_); ntopwalk_ = o.ntopwalk_; top_walk_cap_ = o.top_walk_cap_; cpi(fe_ptr_, o.fe_ptr_); cpi(fe_q_, o.fe_q_); cpi(fe_off_, o.fe_off_); cpi(fe_offp_, o.fe_offp_);
+        cpi(diag_pos_, o.diag_pos_); cpi(P_, o.P_); cpi(level_sn_, o.level_sn_); cpi(top_pos_, o.top_pos_); top_flags_.alloc(o.top_flags_.n ? o.top_flags_.n : 1); cpi(solve_level_sn_, o.solve_level_sn_); cpi(solve_top_pos_, o.solve_top_pos_); solve_flags_.alloc(o.solve_flags_.n ? o.solve_flags_.n : 1); solve_flags_.zero(st_); ntop_solve_ = o.ntop_solve_; cpi(solve_pub_, o.solve_pub_); cpi(solve_walk_lo_, o.solve_walk_lo_); cpi(solve_walk_hi_, o.solve_walk_hi_); nwalk_solve_ = o.nwalk_solve_; cpi(solve_child_tp_, o.solve_child_tp_); crec_.alloc(o.crec_.n ? o.crec_.n : 1); if (o.crec_.n) PQ_HIP(hipMemcpyAsync(crec_.p, o.crec_.p, o.crec_.bytes(), hipMemcpyDeviceToDevice, st_)); cpi(top_walk_lo_, o.top_walk_lo_); cpi(top_walk_hi_, o.top_walk_hi_); ntopwalk_ = o.ntopwalk_; top_walk_cap_ = o.top_walk_cap_; cpi(fe_ptr_, o.fe_ptr_); cpi(fe_q_, o.fe_q_); cpi(fe_off_, o.fe_off_); cpi(fe_offp_, o.fe_offp_);
         snrec_.alloc(o.snrec_.n ? o.snrec_.n : 1); if (o.snrec_.n) PQ_HIP(hipMemcpyAsync(snrec_.p, o.snrec_.p, o.snrec_.bytes(), hipMemcpyDeviceToDevice, st_)); cpi(sn_first_, o.sn_first_); cpi(front_rows_ptr_, o.front_rows_ptr_); cpi(front_rows_, o.front_rows_);
         cpi(child_ptr_, o.child_ptr_); cpi(child_, o.child_); cpi(rel_ptr_, o.rel_ptr_); cpi(rel_, o.rel_);
         cpi(mapP_, o.mapP_); cpi(mapA_, o.mapA_); cpi(mapG_, o.mapG_);
@@ -1770,13 +1771,19 @@ private:
         // the top of the tree: one launch per sweep when every top front fits the single-wave kernels, else one launch per level
         bool wave_top = nt > 1 && !std::getenv("PIQP_AMD_TOP_LEVELS_SOLVE") && !std::getenv("PIQP_AMD_SUBTREE_SOLVE_V1");
         if (wave_top) for (int s2 : S_.solve_top_level_sn) if (S_.front_rows_ptr[s2 + 1] - S_.front_rows_ptr[s2] > 128) { wave_top = false; break; }
+        // flags carry the number of the solve that set them: no memset between solves (a recorded graph replays fixed arguments, so there
+        // the flags are zeroed and the epoch stays 1)
+        int epoch = 1;
+        solve_err_ptr_ = nullptr; solve_epoch_used_ = 0;
         if (wave_top) {
-            PQ_HIP(hipMemsetAsync(solve_flags_.p, 0, sizeof(int) * (2 * (size_t)nt + 1), st_));
+            if (use_graphs_ || solve_epoch_ >= 2000000000) { PQ_HIP(hipMemsetAsync(solve_flags_.p, 0, sizeof(int) * (2 * (size_t)nt + 1), st_)); solve_epoch_ = 0; }
+            if (!use_graphs_) epoch = ++solve_epoch_;
+            solve_err_ptr_ = solve_flags_.p + 2 * nt; solve_epoch_used_ = epoch;
             static const char* dbg_ts = std::getenv("PIQP_AMD_DBG_TS");
             DBuf<long long> ts;
             if (dbg_ts) { ts.alloc(3 * (size_t)nwalk_solve_); long long* pp = ts.p; PQ_HIP(hipMemsetAsync(ts.p, 0, ts.bytes(), st_)); PQ_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_ts), &pp, sizeof(pp))); }
             hipLaunchKernelGGL(k_subtree_fwd_wave<true>, dim3(nwalk_solve_), dim3(64), 0, st_, M, fronts_.p, solve_walk_lo_.p, solve_walk_hi_.p, xp_.p, fvec_.p, solve_top_pos_.p, solve_flags_.p,
-                               solve_flags_.p + 2 * nt, solve_child_tp_.p);
+                               solve_flags_.p + 2 * nt, solve_child_tp_.p, epoch);
             if (dbg_ts) {
                 PQ_HIP(hipStreamSynchronize(st_));
                 std::vector<long long> h(3 * (size_t)nwalk_solve_);
@@ -1794,8 +1801,8 @@ private:
         hipLaunchKernelGGL(k_scale, g1(N_), dim3(256), 0, st_, N_, rdiag_.p, xp_.p);
         if (wave_top) {
             hipLaunchKernelGGL(k_subtree_bwd_wave<true>, dim3(nwalk_solve_), dim3(64), 0, st_, M, fronts_.p, solve_walk_lo_.p, solve_walk_hi_.p, xp_.p, bwd_red_thr(), nwalk_solve_, solve_top_pos_.p,
-                               solve_flags_.p + nt, solve_flags_.p + 2 * nt, solve_pub_.p);
-            hipLaunchKernelGGL(k_top_check, dim3(1), dim3(1), 0, st_, solve_flags_.p + 2 * nt, (int*)nullptr, xp_.p);
+                               solve_flags_.p + nt, solve_flags_.p + 2 * nt, solve_pub_.p, epoch);
+            // a wait that gave up left the epoch in the error slot: k_perm_scatter poisons the solution (solve_err_ptr_)
         } else bwd_levels(M, S_.solve_top_level_ptr, S_.solve_top_level_sn, solve_level_sn_.p);
         subtree_bwd(M, solve_sched_);
     }
@@ -1939,14 +1946,14 @@ private:
     void subtree_fwd(const FrontMeta& M, const SubSchedule& sc)
     {
         for (const SubClass& c : sc.cls) {
-            if (c.fmax <= 128 && !std::getenv("PIQP_AMD_SUBTREE_SOLVE_V1")) hipLaunchKernelGGL(k_subtree_fwd_wave<false>, dim3(c.nsub), dim3(64), 0, st_, M, fronts_.p, c.lo.p, c.hi.p, xp_.p, fvec_.p, (const int*)nullptr, (int*)nullptr, (int*)nullptr, (const int*)nullptr);
+            if (c.fmax <= 128 && !std::getenv("PIQP_AMD_SUBTREE_SOLVE_V1")) hipLaunchKernelGGL(k_subtree_fwd_wave<false>, dim3(c.nsub), dim3(64), 0, st_, M, fronts_.p, c.lo.p, c.hi.p, xp_.p, fvec_.p, (const int*)nullptr, (int*)nullptr, (int*)nullptr, (const int*)nullptr, 0);
             else hipLaunchKernelGGL(k_subtree_fwd, dim3(c.nsub), dim3(SUB_SOLVE_THREADS), 0, st_, M, fronts_.p, c.lo.p, c.hi.p, xp_.p, fvec_.p);
         }
     }
     void subtree_bwd(const FrontMeta& M, const SubSchedule& sc)
     {
         for (const SubClass& c : sc.cls) {
-            if (c.fmax <= 128 && !std::getenv("PIQP_AMD_SUBTREE_SOLVE_V1")) hipLaunchKernelGGL(k_subtree_bwd_wave<false>, dim3(c.nsub), dim3(64), 0, st_, M, fronts_.p, c.lo.p, c.hi.p, xp_.p, bwd_red_thr(), 0, (const int*)nullptr, (int*)nullptr, (int*)nullptr, (const int*)nullptr);
+            if (c.fmax <= 128 && !std::getenv("PIQP_AMD_SUBTREE_SOLVE_V1")) hipLaunchKernelGGL(k_subtree_bwd_wave<false>, dim3(c.nsub), dim3(64), 0, st_, M, fronts_.p, c.lo.p, c.hi.p, xp_.p, bwd_red_thr(), 0, (const int*)nullptr, (int*)nullptr, (int*)nullptr, (const int*)nullptr, 0);
             else hipLaunchKernelGGL(k_subtree_bwd, dim3(c.nsub), dim3(SUB_SOLVE_THREADS), 0, st_, M, fronts_.p, c.lo.p, c.hi.p, xp_.p, fvec_.p);
         }
     }
@@ -1992,7 +1999,7 @@ private:
         for (int l = 0; l + 1 < (int)ptr.size(); ++l) {
             const int cnt = ptr[l + 1] - ptr[l];
             if (cnt <= 0) continue;
-            if (level_is_narrow(ptr, sn, l)) hipLaunchKernelGGL(k_subtree_fwd_wave<false>, dim3(cnt), dim3(64), 0, st_, M, fronts_.p, sn_dev + ptr[l], sn_dev + ptr[l], xp_.p, fvec_.p, (const int*)nullptr, (int*)nullptr, (int*)nullptr, (const int*)nullptr);
+            if (level_is_narrow(ptr, sn, l)) hipLaunchKernelGGL(k_subtree_fwd_wave<false>, dim3(cnt), dim3(64), 0, st_, M, fronts_.p, sn_dev + ptr[l], sn_dev + ptr[l], xp_.p, fvec_.p, (const int*)nullptr, (int*)nullptr, (int*)nullptr, (const int*)nullptr, 0);
             else hipLaunchKernelGGL(k_front_fwd, dim3(cnt), dim3(256), 0, st_, M, fronts_.p, sn_dev + ptr[l], xp_.p, fvec_.p);
         }
     }
@@ -2001,7 +2008,7 @@ private:
         for (int l = (int)ptr.size() - 2; l >= 0; --l) {
             const int cnt = ptr[l + 1] - ptr[l];
             if (cnt <= 0) continue;
-            if (level_is_narrow(ptr, sn, l)) hipLaunchKernelGGL(k_subtree_bwd_wave<false>, dim3(cnt), dim3(64), 0, st_, M, fronts_.p, sn_dev + ptr[l], sn_dev + ptr[l], xp_.p, bwd_red_thr(), 0, (const int*)nullptr, (int*)nullptr, (int*)nullptr, (const int*)nullptr);
+            if (level_is_narrow(ptr, sn, l)) hipLaunchKernelGGL(k_subtree_bwd_wave<false>, dim3(cnt), dim3(64), 0, st_, M, fronts_.p, sn_dev + ptr[l], sn_dev + ptr[l], xp_.p, bwd_red_thr(), 0, (const int*)nullptr, (int*)nullptr, (int*)nullptr, (const int*)nullptr, 0);
             else hipLaunchKernelGGL(k_front_bwd, dim3(cnt), dim3(256), 0, st_, M, fronts_.p, sn_dev + ptr[l], xp_.p, fvec_.p);
         }
     }
@@ -2021,7 +2028,7 @@ private:
             std::vector<int> tp(S_.nsuper ? S_.nsuper : 1, -1);
             for (size_t q = 0; q < S_.solve_top_level_sn.size(); ++q) tp[S_.solve_top_level_sn[q]] = (int)q;
             upload_vec(solve_top_pos_, tp, st_);
-            solve_flags_.alloc(2 * S_.solve_top_level_sn.size() + 2);
+            solve_flags_.alloc(2 * S_.solve_top_level_sn.size() + 2); solve_flags_.zero(st_);  // flags hold the epoch of the solve that set them: they must start at zero
             upload_vec(solve_walk_lo_, S_.solve_walk_lo, st_); upload_vec(solve_walk_hi_, S_.solve_walk_hi, st_);
             nwalk_solve_ = (int)S_.solve_walk_lo.size();
             {   // backward sweep: a supernode publishes its flag only if a top child in ANOTHER walk waits for it
@@ -2179,7 +2186,8 @@ private:
     DBuf<double> vals_, fronts_, rdiag_, xp_, fvec_, dvec_;
     DBuf<int> fe_ptr_, fe_q_, fe_off_, fe_offp_, top_pos_, top_flags_, solve_level_sn_, solve_top_pos_, solve_flags_, solve_walk_lo_, solve_walk_hi_, solve_pub_;
     SubSchedule solve_sched_;
-    int ntop_solve_ = 0, nwalk_solve_ = 0;
+    int ntop_solve_ = 0, nwalk_solve_ = 0, solve_epoch_ = 0, solve_epoch_used_ = 0;
+    const int* solve_err_ptr_ = nullptr;
     DBuf<int> top_walk_lo_, top_walk_hi_;
     int ntopwalk_ = 0, top_walk_cap_ = 0;
     DBuf<SnRec> snrec_;
