@@ -1127,18 +1127,18 @@ __global__ __launch_bounds__(64) void k_subtree_bwd_wave(FrontMeta M, const doub
 // index is always being worked on: no deadlock.  Flags are released / acquired at agent scope (the data crosses XCD L2s).
 // every spin is bounded: if the workgroups are not all resident (another stream occupies the device) the wait gives up, raises
 // `err` and the launch drains instead of hanging; the host then reports a failed factorisation / a non-finite solve
-__device__ __forceinline__ void top_done(int* flag)
+__device__ __forceinline__ void top_done(int* flag, int epoch)
 {
     __syncthreads();
     if (threadIdx.x == 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        __hip_atomic_store(flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(flag, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 // `list` / `ntop` may be a SUFFIX of the level-sorted top list (start = its first position): children in earlier levels or in
 // subtrees were finished by earlier launches on the stream
 __global__ __launch_bounds__(512) void k_top_factor(FrontMeta M, double* __restrict__ fronts, const int* __restrict__ list, int ntop, const int* __restrict__ top_pos, int start,
-                                                    int* __restrict__ flags, int* __restrict__ err, double* __restrict__ rdiag, int* __restrict__ info)
+                                                    int* __restrict__ flags, int* __restrict__ err, double* __restrict__ rdiag, int* __restrict__ info, int epoch)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     for (int b = blockIdx.x; b < ntop; b += gridDim.x) {
@@ -1154,10 +1154,11 @@ __global__ __launch_bounds__(512) void k_top_factor(FrontMeta M, double* __restr
                 if (tp < 0) continue;
                 any = true;
                 unsigned spins = 0;
-                while (__hip_atomic_load(flags + tp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+                while (__hip_atomic_load(flags + tp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
                     __builtin_amdgcn_s_sleep(1);
-                    if (++spins > 8000000u || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-                        __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (++spins > 8000000u || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch) {
+                        __hip_atomic_store(err, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (*info < 0) *info = 0;  // the factorisation is reported as failed (what k_top_check did after the launch)
                         break;
                     }
                 }
@@ -1166,7 +1167,7 @@ __global__ __launch_bounds__(512) void k_top_factor(FrontMeta M, double* __restr
         }
         __syncthreads();
         front_factor(M, fronts, s, 1 << 30, 1 << 30, rdiag, info, lds, true);
-        top_done(flags + b);
+        top_done(flags + b, epoch);
     }
 }
 
@@ -1176,7 +1177,7 @@ __global__ __launch_bounds__(512) void k_top_factor(FrontMeta M, double* __restr
 // sorted by the position of their last supernode, so every dependency has a smaller walk index.
 __global__ __launch_bounds__(512) void k_top_factor_walk(FrontMeta M, double* __restrict__ fronts, const double* __restrict__ vals, const int* __restrict__ fe_offp,
                                                          const int* __restrict__ walk_lo, const int* __restrict__ walk_hi, int nwalk, const int* __restrict__ top_pos, int start,
-                                                         int cap, int* __restrict__ flags, int* __restrict__ err, double* __restrict__ rdiag, int* __restrict__ info)
+                                                         int cap, int* __restrict__ flags, int* __restrict__ err, double* __restrict__ rdiag, int* __restrict__ info, int epoch)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -1204,10 +1205,11 @@ __global__ __launch_bounds__(512) void k_top_factor_walk(FrontMeta M, double* __
                     if (tp < 0) continue;
                     any = true;
                     unsigned spins = 0;
-                    while (__hip_atomic_load(flags + tp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+                    while (__hip_atomic_load(flags + tp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
                         __builtin_amdgcn_s_sleep(1);
-                        if (++spins > 8000000u || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-                            __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (++spins > 8000000u || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch) {
+                            __hip_atomic_store(err, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (*info < 0) *info = 0;  // the factorisation is reported as failed
                             break;
                         }
                     }
@@ -1276,7 +1278,7 @@ __global__ __launch_bounds__(512) void k_top_factor_walk(FrontMeta M, double* __
                     for (int i = j + tx; i < u; i += 16) F[(w + i) + (long long)(w + j) * f] = Cj[i];
                 }
             }
-            if (!keep) top_done(flags + (top_pos[s] - start));  // barrier + release + flag
+            if (!keep) top_done(flags + (top_pos[s] - start), epoch);  // barrier + release + flag
             else __syncthreads();
             double* t = cur; cur = prev; prev = t;
             prev_valid = keep;
@@ -1644,7 +1646,7 @@ private:
         ops_.clone_from(o.ops_, st_);
         cpd(vals_, o.vals_); cpd(fronts_, o.fronts_); cpd(rdiag_, o.rdiag_);
         xp_.alloc(o.xp_.n); fvec_.alloc(o.fvec_.n); dvec_.alloc(o.dvec_.n);
-        cpi(diag_pos_, o.diag_pos_); cpi(P_, o.P_); cpi(level_sn_, o.level_sn_); cpi(top_pos_, o.top_pos_); top_flags_.alloc(o.top_flags_.n ? o.top_flags_.n : 1); cpi(solve_level_sn_, o.solve_level_sn_); cpi(solve_top_pos_, o.solve_top_pos_); solve_flags_.alloc(o.solve_flags_.n ? o.solve_flags_.n : 1); solve_flags_.zero(st_); ntop_solve_ = o.ntop_solve_; cpi(solve_pub_, o.solve_pub_); cpi(solve_walk_lo_, o.solve_walk_lo_); cpi(solve_walk_hi_, o.solve_walk_hi_); nwalk_solve_ = o.nwalk_solve_; cpi(solve_child_tp_, o.solve_child_tp_); crec_.alloc(o.crec_.n ? o.crec_.n : 1); if (o.crec_.n) PQ_HIP(hipMemcpyAsync(crec_.p, o.crec_.p, o.crec_.bytes(), hipMemcpyDeviceToDevice, st_)); cpi(top_walk_lo_, o.top_walk_lo_); cpi(top_walk_hi_, o.top_walk_hi_); ntopwalk_ = o.ntopwalk_; top_walk_cap_ = o.top_walk_cap_; cpi(fe_ptr_, o.fe_ptr_); cpi(fe_q_, o.fe_q_); cpi(fe_off_, o.fe_off_); cpi(fe_offp_, o.fe_offp_);
+        cpi(diag_pos_, o.diag_pos_); cpi(P_, o.P_); cpi(level_sn_, o.level_sn_); cpi(top_pos_, o.top_pos_); top_flags_.alloc(o.top_flags_.n ? o.top_flags_.n : 1); top_flags_.zero(st_); cpi(solve_level_sn_, o.solve_level_sn_); cpi(solve_top_pos_, o.solve_top_pos_); solve_flags_.alloc(o.solve_flags_.n ? o.solve_flags_.n : 1); solve_flags_.zero(st_); ntop_solve_ = o.ntop_solve_; cpi(solve_pub_, o.solve_pub_); cpi(solve_walk_lo_, o.solve_walk_lo_); cpi(solve_walk_hi_, o.solve_walk_hi_); nwalk_solve_ = o.nwalk_solve_; cpi(solve_child_tp_, o.solve_child_tp_); crec_.alloc(o.crec_.n ? o.crec_.n : 1); if (o.crec_.n) PQ_HIP(hipMemcpyAsync(crec_.p, o.crec_.p, o.crec_.bytes(), hipMemcpyDeviceToDevice, st_)); cpi(top_walk_lo_, o.top_walk_lo_); cpi(top_walk_hi_, o.top_walk_hi_); ntopwalk_ = o.ntopwalk_; top_walk_cap_ = o.top_walk_cap_; cpi(fe_ptr_, o.fe_ptr_); cpi(fe_q_, o.fe_q_); cpi(fe_off_, o.fe_off_); cpi(fe_offp_, o.fe_offp_);
         snrec_.alloc(o.snrec_.n ? o.snrec_.n : 1); if (o.snrec_.n) PQ_HIP(hipMemcpyAsync(snrec_.p, o.snrec_.p, o.snrec_.bytes(), hipMemcpyDeviceToDevice, st_)); cpi(sn_first_, o.sn_first_); cpi(front_rows_ptr_, o.front_rows_ptr_); cpi(front_rows_, o.front_rows_);
         cpi(child_ptr_, o.child_ptr_); cpi(child_, o.child_); cpi(rel_ptr_, o.rel_ptr_); cpi(rel_, o.rel_);
         cpi(mapP_, o.mapP_); cpi(mapA_, o.mapA_); cpi(mapG_, o.mapG_);
@@ -1753,14 +1755,17 @@ private:
         // wide lower levels: one launch per level; the narrow levels near the root (<= 1024 supernodes in total): one persistent launch
         factor_levels(M, S_.top_level_ptr, S_.top_level_sn, level_sn_.p, level_lds_, top_l0_);
         if (top_nper_ > 0) {
-            PQ_HIP(hipMemsetAsync(top_flags_.p, 0, sizeof(int) * (2 * (size_t)ntop_ + 1), st_));
+            // flags carry the number of the factorisation that set them (no memset in between; a recorded graph replays fixed arguments,
+            // so there they are zeroed and the epoch stays 1)
+            int epoch = 1;
+            if (use_graphs_ || factor_epoch_ >= 2000000000) { PQ_HIP(hipMemsetAsync(top_flags_.p, 0, sizeof(int) * (2 * (size_t)ntop_ + 1), st_)); factor_epoch_ = 0; }
+            if (!use_graphs_) epoch = ++factor_epoch_;
             if (ntopwalk_ > 0)
                 hipLaunchKernelGGL(k_top_factor_walk, dim3(std::min(ntopwalk_, 224)), dim3(top_threads()), 2 * (size_t)top_walk_cap_ * sizeof(double), st_, M, fronts_.p, vals_.p, fe_offp_.p,
-                                   top_walk_lo_.p, top_walk_hi_.p, ntopwalk_, top_pos_.p, top_start_, top_walk_cap_, top_flags_.p, top_flags_.p + 2 * ntop_, rdiag_.p, info_.p);
+                                   top_walk_lo_.p, top_walk_hi_.p, ntopwalk_, top_pos_.p, top_start_, top_walk_cap_, top_flags_.p, top_flags_.p + 2 * ntop_, rdiag_.p, info_.p, epoch);
             else
                 hipLaunchKernelGGL(k_top_factor, dim3(std::min(top_nper_, 224)), dim3(top_threads()), top_lds_, st_, M, fronts_.p, level_sn_.p + top_start_, top_nper_, top_pos_.p, top_start_,
-                                   top_flags_.p, top_flags_.p + 2 * ntop_, rdiag_.p, info_.p);
-            hipLaunchKernelGGL(k_top_check, dim3(1), dim3(1), 0, st_, top_flags_.p + 2 * ntop_, info_.p, (double*)nullptr);
+                                   top_flags_.p, top_flags_.p + 2 * ntop_, rdiag_.p, info_.p, epoch);
         }
     }
     void solve_numeric(const FrontMeta& M)
@@ -2020,7 +2025,7 @@ private:
             std::vector<int> tp(S_.nsuper ? S_.nsuper : 1, -1);
             for (size_t q = 0; q < S_.top_level_sn.size(); ++q) tp[S_.top_level_sn[q]] = (int)q;
             upload_vec(top_pos_, tp, st_);
-            top_flags_.alloc(2 * S_.top_level_sn.size() + 2);
+            top_flags_.alloc(2 * S_.top_level_sn.size() + 2); top_flags_.zero(st_);
         }
         {   // the substitution's own schedule
             upload_vec(solve_level_sn_, S_.solve_top_level_sn, st_);
@@ -2186,7 +2191,7 @@ private:
     DBuf<double> vals_, fronts_, rdiag_, xp_, fvec_, dvec_;
     DBuf<int> fe_ptr_, fe_q_, fe_off_, fe_offp_, top_pos_, top_flags_, solve_level_sn_, solve_top_pos_, solve_flags_, solve_walk_lo_, solve_walk_hi_, solve_pub_;
     SubSchedule solve_sched_;
-    int ntop_solve_ = 0, nwalk_solve_ = 0, solve_epoch_ = 0, solve_epoch_used_ = 0;
+    int ntop_solve_ = 0, nwalk_solve_ = 0, solve_epoch_ = 0, solve_epoch_used_ = 0, factor_epoch_ = 0;
     const int* solve_err_ptr_ = nullptr;
     DBuf<int> top_walk_lo_, top_walk_hi_;
     int ntopwalk_ = 0, top_walk_cap_ = 0;
