@@ -992,7 +992,7 @@ __global__ __launch_bounds__(64) void k_subtree_fwd_wave(FrontMeta M, const doub
 template <bool TOP>
 __global__ __launch_bounds__(64) void k_subtree_bwd_wave(FrontMeta M, const double* __restrict__ fronts, const int* __restrict__ sub_lo, const int* __restrict__ sub_hi,
                                                          double* __restrict__ x, int red_thr, int ntop, const int* __restrict__ top_pos, int* __restrict__ flags,
-                                                         int* __restrict__ err, const int* __restrict__ pub, int epoch)
+                                                         int* __restrict__ err, const int* __restrict__ pub, int epoch, const double* __restrict__ rdiag)
 {
     __shared__ double sv[2][128];
     const int lane = threadIdx.x, r0 = lane, r1 = lane + 64;
@@ -1019,8 +1019,9 @@ __global__ __launch_bounds__(64) void k_subtree_bwd_wave(FrontMeta M, const doub
         const double* pv = sv[cur ^ 1];
         const int* rel = M.rel + me.rel_ptr;
         double v0 = 0.0, v1 = 0.0;
-        if (r0 < f) v0 = r0 < w ? x[first + r0] : (from_lds ? pv[rel[r0 - w]] : ldx<TOP>(x + rows[r0]));
-        if (r1 < f) v1 = r1 < w ? x[first + r1] : (from_lds ? pv[rel[r1 - w]] : ldx<TOP>(x + rows[r1]));
+        // rdiag != nullptr: the diagonal solve x <- D^-1 x rides along (every pivot is loaded exactly once in the backward sweep)
+        if (r0 < f) v0 = r0 < w ? (rdiag ? x[first + r0] * rdiag[first + r0] : x[first + r0]) : (from_lds ? pv[rel[r0 - w]] : ldx<TOP>(x + rows[r0]));
+        if (r1 < f) v1 = r1 < w ? (rdiag ? x[first + r1] * rdiag[first + r1] : x[first + r1]) : (from_lds ? pv[rel[r1 - w]] : ldx<TOP>(x + rows[r1]));
         // y1[j] -= sum_{i >= w} L[i,j] x2[i].  Few pivots under many update rows (the usual shape inside a subtree): lanes over the rows i,
         // one coalesced column load and one wave reduction per pivot.  Otherwise lane j = pivot column j, ascending i, like front_bwd.
         if (f - w > red_thr * w) {
@@ -1803,13 +1804,16 @@ private:
                 }
             }
         } else fwd_levels(M, S_.solve_top_level_ptr, S_.solve_top_level_sn, solve_level_sn_.p);
-        hipLaunchKernelGGL(k_scale, g1(N_), dim3(256), 0, st_, N_, rdiag_.p, xp_.p);
+        bool fuse_scale = wave_top && !std::getenv("PIQP_AMD_SUBTREE_SOLVE_V1");
+        for (const SubClass& c : solve_sched_.cls) if (c.fmax > 128) fuse_scale = false;
+        const double* rd = fuse_scale ? rdiag_.p : nullptr;  // the diagonal solve rides in the backward kernels when they are all single-wave
+        if (!fuse_scale) hipLaunchKernelGGL(k_scale, g1(N_), dim3(256), 0, st_, N_, rdiag_.p, xp_.p);
         if (wave_top) {
             hipLaunchKernelGGL(k_subtree_bwd_wave<true>, dim3(nwalk_solve_), dim3(64), 0, st_, M, fronts_.p, solve_walk_lo_.p, solve_walk_hi_.p, xp_.p, bwd_red_thr(), nwalk_solve_, solve_top_pos_.p,
-                               solve_flags_.p + nt, solve_flags_.p + 2 * nt, solve_pub_.p, epoch);
+                               solve_flags_.p + nt, solve_flags_.p + 2 * nt, solve_pub_.p, epoch, rd);
             // a wait that gave up left the epoch in the error slot: k_perm_scatter poisons the solution (solve_err_ptr_)
         } else bwd_levels(M, S_.solve_top_level_ptr, S_.solve_top_level_sn, solve_level_sn_.p);
-        subtree_bwd(M, solve_sched_);
+        subtree_bwd(M, solve_sched_, rd);
     }
     // records what `body` launches on the handle's stream into an executable graph (nullptr if the runtime refuses: the caller then
     // launches directly)
@@ -1955,10 +1959,10 @@ private:
             else hipLaunchKernelGGL(k_subtree_fwd, dim3(c.nsub), dim3(SUB_SOLVE_THREADS), 0, st_, M, fronts_.p, c.lo.p, c.hi.p, xp_.p, fvec_.p);
         }
     }
-    void subtree_bwd(const FrontMeta& M, const SubSchedule& sc)
+    void subtree_bwd(const FrontMeta& M, const SubSchedule& sc, const double* rd = nullptr)
     {
         for (const SubClass& c : sc.cls) {
-            if (c.fmax <= 128 && !std::getenv("PIQP_AMD_SUBTREE_SOLVE_V1")) hipLaunchKernelGGL(k_subtree_bwd_wave<false>, dim3(c.nsub), dim3(64), 0, st_, M, fronts_.p, c.lo.p, c.hi.p, xp_.p, bwd_red_thr(), 0, (const int*)nullptr, (int*)nullptr, (int*)nullptr, (const int*)nullptr, 0);
+            if (c.fmax <= 128 && !std::getenv("PIQP_AMD_SUBTREE_SOLVE_V1")) hipLaunchKernelGGL(k_subtree_bwd_wave<false>, dim3(c.nsub), dim3(64), 0, st_, M, fronts_.p, c.lo.p, c.hi.p, xp_.p, bwd_red_thr(), 0, (const int*)nullptr, (int*)nullptr, (int*)nullptr, (const int*)nullptr, 0, rd);
             else hipLaunchKernelGGL(k_subtree_bwd, dim3(c.nsub), dim3(SUB_SOLVE_THREADS), 0, st_, M, fronts_.p, c.lo.p, c.hi.p, xp_.p, fvec_.p);
         }
     }
@@ -2013,7 +2017,7 @@ private:
         for (int l = (int)ptr.size() - 2; l >= 0; --l) {
             const int cnt = ptr[l + 1] - ptr[l];
             if (cnt <= 0) continue;
-            if (level_is_narrow(ptr, sn, l)) hipLaunchKernelGGL(k_subtree_bwd_wave<false>, dim3(cnt), dim3(64), 0, st_, M, fronts_.p, sn_dev + ptr[l], sn_dev + ptr[l], xp_.p, bwd_red_thr(), 0, (const int*)nullptr, (int*)nullptr, (int*)nullptr, (const int*)nullptr, 0);
+            if (level_is_narrow(ptr, sn, l)) hipLaunchKernelGGL(k_subtree_bwd_wave<false>, dim3(cnt), dim3(64), 0, st_, M, fronts_.p, sn_dev + ptr[l], sn_dev + ptr[l], xp_.p, bwd_red_thr(), 0, (const int*)nullptr, (int*)nullptr, (int*)nullptr, (const int*)nullptr, 0, (const double*)nullptr);
             else hipLaunchKernelGGL(k_front_bwd, dim3(cnt), dim3(256), 0, st_, M, fronts_.p, sn_dev + ptr[l], xp_.p, fvec_.p);
         }
     }
