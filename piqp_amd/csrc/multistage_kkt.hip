@@ -18,7 +18,6 @@
 // Like the reference, update_scalings_and_factor always reports success (:218): a non-positive pivot
 // zeroes its column (blasfeo dpotrf semantics) and the caller's refinement loop notices.
 #include <algorithm>
-#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <memory>
@@ -346,31 +345,35 @@ private:
     std::unique_ptr<KKTSolverBase> tree_;
 };
 
-// wall time of one factorisation + one solve on `k` with unit scalings (setup-time probe)
-double probe_ms(KKTSolverBase* k, int n, int p, int m, const double* ones, double* out, int reps)
+// MultistageKKT ctor (multistage_kkt.hpp:76-135).  Chains of 16+ stages get both elimination orders analysed and a SYMBOLIC cost
+// model picks one (PIQP_AMD_MULTISTAGE=chain|tree forces it).  The choice depends on the sparsity structure only, so two processes
+// (and two boxes) always run the same arithmetic on the same input.  The model is microseconds per IPM iteration's backend work
+// (1 factorisation + 2 substitutions), fitted once on an MI355X to tools/calib_multistage.py (27 structures, fixtures and synthetic
+// chains, profiles/r02_calib_multistage.jsonl); it ranks the engines correctly on 26 of them (the 27th costs 14 %):
+//   chain (one workgroup walks the recurrence):  20 + sum_i (0.9 w_i + 2.6e-4 h_i^2 w_i)  +  2 sum_i (2.2 + 0.005 h_i w_i)
+//   tree  (critical path = levels of the assembly tree, c = nnz(L) / N the mean column count):
+//         70 + levels (1 + 0.35 c + 0.005 c^2) + flops / 2.5e5          +  2 levels (3.5 + 0.3 c)
+// The tree engine is taken when it is at least 10 % cheaper.
+double chain_cost_us(const std::vector<int>& bi)
 {
-    auto run = [&]() {
-        k->update_scalings_and_factor(1.0, ones, ones);
-        k->solve(ones, ones, ones, out, out + n, out + n + p);
-        PQ_HIP(hipStreamSynchronize(k->stream()));
-    };
-    run();
-    const auto t0 = std::chrono::steady_clock::now();
-    for (int r = 0; r < reps; ++r) run();
-    (void)m;
-    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / reps;
+    const int stages = (int)bi.size() / 3 - 1;
+    const double arrow = (double)bi[3 * stages + 1];
+    double fac = 20.0, sol = 0.0;
+    for (int i = 0; i < stages; ++i) {
+        const double w = bi[3 * i + 1], h = w + bi[3 * i + 2] + arrow;
+        fac += 0.9 * w + 2.6e-4 * h * h * w;
+        sol += 2.2 + 0.005 * h * w;
+    }
+    return fac + 2.0 * sol;
 }
-
-__global__ void k_fill_ones(int n, double* __restrict__ a)
+double tree_cost_us(const double st[8])
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) a[i] = 1.0;
+    const double N = st[0] > 0 ? st[0] : 1.0, c = st[2] / N, levels = st[4], flops = st[7];
+    return 70.0 + levels * (1.0 + 0.35 * c + 0.005 * c * c) + flops / 2.5e5 + 2.0 * levels * (3.5 + 0.3 * c);
 }
 
 }  // namespace
 
-// MultistageKKT ctor (multistage_kkt.hpp:76-135).  For chains of 16+ stages both elimination orders are built and the faster one
-// (measured once, here) is kept: PIQP_AMD_MULTISTAGE=chain|tree forces the choice.
 KKTSolverBase* make_multistage_kkt(const pq_sparse_data* data, int device)
 {
     std::unique_ptr<MultistageKKT> ms(new MultistageKKT(data, device));
@@ -383,14 +386,9 @@ KKTSolverBase* make_multistage_kkt(const pq_sparse_data* data, int device)
     std::unique_ptr<KKTSolverBase> tree(make_sparse_kkt(data, PQ_SPARSE_LDLT_COND, device));
     if (!tree) return ms.release();
     if (want != "tree") {
-        const int n = ms->n(), p = ms->p(), m = ms->m();
-        const int len = std::max(n, std::max(p, m)) + 1;
-        DBuf<double> ones(len), out((size_t)n + p + m + 1);
-        hipLaunchKernelGGL(k_fill_ones, dim3((len + 255) / 256), dim3(256), 0, ms->stream(), len, ones.p);
-        PQ_HIP(hipStreamSynchronize(ms->stream()));
-        const double t_chain = probe_ms(ms.get(), n, p, m, ones.p, out.p, 3);
-        const double t_tree = probe_ms(tree.get(), n, p, m, ones.p, out.p, 3);
-        if (t_tree > 0.9 * t_chain) return ms.release();
+        double st[8];
+        tree->sparse_stats(st);
+        if (tree_cost_us(st) > 0.9 * chain_cost_us(bi)) return ms.release();
     }
     ms->attach_tree_engine(tree.release());
     return ms.release();

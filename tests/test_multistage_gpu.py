@@ -241,3 +241,24 @@ def test_long_chain_mpc_residual(hip, orc):
     res, nrm = k.condensed_residual()
     assert res <= 1e-10 * nrm
     assert _rel(lhs["x"], ref["x"]) < 1e-7 and _rel(lhs["y"], ref["y"]) < 1e-7
+
+
+def test_two_processes_bitwise_equal(tmp_path):
+    """the chain/tree engine of `sparse_multistage` is chosen from the sparsity structure (symbolic cost model, multistage_kkt.hip), never
+    from a timing: two fresh processes must return bitwise the same solutions, and both engines must actually occur in the sample"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for i in range(2):
+        f = str(tmp_path / f"run{i}.npz")
+        env = {k: v for k, v in os.environ.items() if k != "PIQP_AMD_MULTISTAGE"}
+        r = subprocess.run([sys.executable, os.path.join(root, "tests", "workers", "multistage_repro.py"), f], capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs.append(dict(np.load(f)))
+    assert outs[0].keys() == outs[1].keys()
+    for key in outs[0]:
+        assert np.array_equal(outs[0][key], outs[1][key]), key
+    engines = {int(v[0]) for k, v in outs[0].items() if k.endswith("_engine")}
+    assert engines == {0, 1}, engines
