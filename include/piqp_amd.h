@@ -326,6 +326,9 @@ int pq_batch_last_kernel_ms(const pq_batch *s, double *ms, int *threads_per_qp);
 /* fp64 MFMA / HBM micro-benchmarks on `device` (used once by bench.py to report measured peaks) */
 int pq_microbench_mfma_f64(int device, int iters, double *tflops_out);
 int pq_microbench_hbm_copy(int device, size_t bytes, int iters, double *gbps_out);
+/* debugging aid: average microseconds of the 128 x 128 diagonal-block factorisation kernel and 64 in-kernel shader-clock stamps
+ * (step k at stamps64[8 k + q], see potrf_block in csrc/dense_kernels.hip); stamps64 may be NULL */
+int pq_microbench_potrf_block(int device, int ldlt, int reps, double *us_out, long long *stamps64);
 
 #ifdef __cplusplus
 }

@@ -567,6 +567,11 @@ int pq_microbench_mfma_f64(int device, int iters, double* tflops_out)
     if (rc < 0) return rc;
     return guarded([&] { PQ_HIP(hipSetDevice(device)); *tflops_out = dense::microbench_mfma_f64(iters, nullptr); return (int)PQ_OK; });
 }
+int pq_microbench_potrf_block(int device, int ldlt, int reps, double* us_out, long long* stamps64)
+{
+    if (!us_out) return fail(PQ_ERR_INVALID, "null output");
+    return guarded([&] { PQ_HIP(hipSetDevice(device)); *us_out = dense::microbench_potrf_block(ldlt != 0, reps, stamps64, nullptr); return (int)PQ_OK; });
+}
 int pq_microbench_hbm_copy(int device, size_t bytes, int iters, double* gbps_out)
 {
     int rc = check_device(device);

@@ -4,7 +4,7 @@
 //   dense/kkt.hpp:140-160  update_kkt       -> k_syrk_lower<EPI_ASSEMBLE>  (fp64 MFMA 16x16x4, LDS double-buffered)
 //   dense/kkt.hpp:53,68    AT_A = AT*AT^T   -> k_syrk_lower<EPI_STORE>
 //   Eigen::LLT::compute (dense/kkt.hpp:82) / LDLTNoPivot (dense/ldlt_no_pivot.hpp:313-354)
-//                                           -> k_potrf_diag + k_trsm_panel + k_syrk_lower<EPI_SUBTRACT>
+//                                           -> potrf_block (k_potrf_diag / fused into k_syrk_lower<EPI_SUBTRACT_POTRF>) + k_trsm_panel
 //   llt.solveInPlace (dense/kkt.hpp:170) / ldlt_no_pivot.hpp:432-450 -> k_trsv_fwd_step / k_trsv_bwd_step
 //   dense/kkt.hpp:94-104,112-131 GEMVs      -> k_gemv_n_partial + k_reduce_partials, k_gemv_t
 //
@@ -111,39 +111,44 @@ __device__ __forceinline__ void store_tile(double* __restrict__ S, int tid, cons
     }
 }
 
-template <bool CHECK, int NT>
+// NEG: the operand is staged negated, so that an accumulator initialised with C ends as C - A diag(w) B^T
+template <bool CHECK, int NT, bool NEG = false>
 __device__ __forceinline__ void scale_tile(const double* __restrict__ w, int k0, int kdim, int tid, d2 (&v)[1024 / NT])
 {
-    if (!w) return;
+    if (!w && !NEG) return;
 #pragma unroll
     for (int it = 0; it < 1024 / NT; ++it) {
         const int k = k0 + it * (NT / 64) + (tid >> 6);
-        const double s = (!CHECK || k < kdim) ? w[k] : 0.0;
+        double s = w ? ((!CHECK || k < kdim) ? w[k] : 0.0) : 1.0;
+        if (NEG) s = -s;
         v[it].x *= s;
         v[it].y *= s;
     }
 }
 
-// diagonal-block factorisation on an LDS-resident block (defined with k_potrf_diag below); PACKED: 16-column block columns stored
-// without the rows above their diagonal block (9216 doubles = exactly the SYRK staging buffers)
-template <bool LDLT, int NTHREADS, bool PACKED>
-__device__ void potrf_block(double* __restrict__ S, int nb, int kglobal, int* __restrict__ info, double* __restrict__ rdiag, int dbg);
-template <bool PACKED>
-__device__ __forceinline__ int sidx(int r, int c);
-// layout of the fused next-panel factorisation: packed fits the 72 KB of the SYRK staging buffers but its block columns start on
-// the same LDS banks (measured 60 us per block against 43 us standalone); the padded layout needs 144 KB for the one launch
-constexpr bool FUSED_PACKED = false;
-constexpr int FUSED_LDS_BYTES = FUSED_PACKED ? 2 * 2 * 16 * (128 + 16) * 8 : 128 * (128 + 16) * 8;
+// diagonal-block factorisation on an LDS-resident block (defined with k_potrf_diag below)
+template <bool LDLT, int NWAVES>
+__device__ __forceinline__ void potrf_block(double* __restrict__ Tb, double* __restrict__ rds, int nb, int kglobal, int* __restrict__ info, double* __restrict__ rdiag,
+                                            double* __restrict__ dvec, double* __restrict__ Aout, int lda, double* __restrict__ pack, long long* __restrict__ ts = nullptr);
+__device__ __forceinline__ int tb_index(int bi, int bj);
+__device__ __forceinline__ void tile_store(double* __restrict__ blk, int lane, d4 t);
+template <int NT>
+__device__ __forceinline__ void fused_next_diag(const SyrkArgs& a, double* __restrict__ smem);
+// the fused next-panel factorisation reuses the SYRK staging buffers (36 tile blocks = exactly their 72 KB) + 64 doubles of pivots
+constexpr int FUSED_LDS_BYTES = 2 * 2 * 16 * (128 + 16) * 8 + 64 * 8;
 
-// WD = waves per tile dimension: WD = 2 -> 256 threads, 64x64 per wave (throughput shape, 2 workgroups per CU);
-//                                WD = 4 -> 1024 threads, 32x32 per wave (low-latency shape for short K: a quarter of the
-//                                MFMA chain per wave, used for the trailing updates of the factorisation).
-template <int EPI, int WD>
-__global__ __launch_bounds__(64 * WD * WD, WD == 2 ? 2 : 4) void k_syrk_lower(SyrkArgs a)
+// WR x WC = waves per tile (rows x columns):
+//   2 x 2 -> 256 threads, 64 x 64 per wave (throughput shape, 2 workgroups per CU);
+//   4 x 4 -> 1024 threads, 32 x 32 per wave (low-latency shape for short K: a quarter of the MFMA chain per wave, used for the unfused
+//            trailing updates);
+//   4 x 2 -> 512 threads, 32 x 64 per wave: the fused trailing update + next diagonal block, whose in-register block factorisation needs
+//            more than the 128 VGPRs a 1024-thread workgroup can have.
+template <int EPI, int WR, int WC>
+__global__ __launch_bounds__(64 * WR * WC, (WR * WC == 4) ? 2 : (WR * WC == 8 ? 2 : 4)) void k_syrk_lower(SyrkArgs a)
 {
-    constexpr int NT = 64 * WD * WD;
-    constexpr int MT = 8 / WD;     // MFMA tiles per wave per dimension
-    constexpr int SUB = TS / WD;   // rows / columns of C per wave
+    constexpr int NT = 64 * WR * WC;
+    constexpr int MTR = 8 / WR, MTC = 8 / WC;     // MFMA tiles per wave: rows, columns
+    constexpr int SUBR = TS / WR, SUBC = TS / WC;  // rows / columns of C per wave
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* As = smem;                    // [2][BK][LDS_LD]
     double* Bs = smem + 2 * BK * LDS_LD;  // [2][BK][LDS_LD]
@@ -165,15 +170,36 @@ __global__ __launch_bounds__(64 * WD * WD, WD == 2 ? 2 : 4) void k_syrk_lower(Sy
     const int row0 = ti * TS, col0 = tj * TS;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave / WD, wc = wave % WD;
+    const int wr = wave / WC, wc = wave % WC;
+    if (EPI == EPI_SUBTRACT_POTRF && ti == 0 && tj == 0 && a.fuse_nb > 0) {
+        fused_next_diag<NT>(a, smem);  // tile (0, 0) of the trailing matrix = the next diagonal block: updated AND factored by this workgroup
+        return;
+    }
+    constexpr bool NEGB = (EPI == EPI_SUBTRACT_POTRF);  // accumulators start from C, the column operand is staged negated: pure-store epilogue
     const bool edge = (row0 + TS > a.n) || (col0 + TS > a.n) || a.unaligned;
-    const bool skip_wave = (ti == tj) && (wr < wc);  // sub-tile strictly above the diagonal
+    const bool skip_wave = (ti == tj) && ((wr + 1) * SUBR <= wc * SUBC);  // sub-tile strictly above the diagonal
 
-    d4 acc[MT][MT];
+    d4 acc[MTC][MTR];
 #pragma unroll
-    for (int x = 0; x < MT; ++x)
+    for (int x = 0; x < MTC; ++x)
 #pragma unroll
-        for (int y = 0; y < MT; ++y) acc[x][y] = (d4){0.0, 0.0, 0.0, 0.0};
+        for (int y = 0; y < MTR; ++y) acc[x][y] = (d4){0.0, 0.0, 0.0, 0.0};
+    if (NEGB && !skip_wave) {
+        // C is fetched BEFORE the K loop (its latency hides behind the first operand stages) instead of read-modify-written after it
+#pragma unroll
+        for (int x = 0; x < MTC; ++x)
+#pragma unroll
+            for (int y = 0; y < MTR; ++y) {
+                const int gi = row0 + wr * SUBR + y * 16 + (lane & 15);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int gj = col0 + wc * SUBC + x * 16 + (lane >> 4) + 4 * r;
+                    const bool ok = gi < a.n && gj < a.n && gi >= gj;
+                    const double cv = a.C[ok ? (size_t)gi + (size_t)gj * a.ldc : 0];
+                    acc[x][y][r] = ok ? cv : 0.0;
+                }
+            }
+    }
 
     const int nkt_all = (a.kdim + BK - 1) / BK;
     const int kt_per = (nkt_all + a.k_split - 1) / a.k_split;
@@ -183,8 +209,8 @@ __global__ __launch_bounds__(64 * WD * WD, WD == 2 ? 2 : 4) void k_syrk_lower(Sy
     if (nkt > 0) {
         const int k0 = kt_begin * BK;
         const bool chk = edge || (k0 + BK > a.kdim);
-        if (chk) { load_tile<true, NT>(a.A, a.lda, row0, k0, a.n, a.kdim, tid, va); load_tile<true, NT>(a.B, a.ldb, col0, k0, a.n, a.kdim, tid, vb); scale_tile<true, NT>(a.w, k0, a.kdim, tid, vb); }
-        else { load_tile<false, NT>(a.A, a.lda, row0, k0, a.n, a.kdim, tid, va); load_tile<false, NT>(a.B, a.ldb, col0, k0, a.n, a.kdim, tid, vb); scale_tile<false, NT>(a.w, k0, a.kdim, tid, vb); }
+        if (chk) { load_tile<true, NT>(a.A, a.lda, row0, k0, a.n, a.kdim, tid, va); load_tile<true, NT>(a.B, a.ldb, col0, k0, a.n, a.kdim, tid, vb); scale_tile<true, NT, NEGB>(a.w, k0, a.kdim, tid, vb); }
+        else { load_tile<false, NT>(a.A, a.lda, row0, k0, a.n, a.kdim, tid, va); load_tile<false, NT>(a.B, a.ldb, col0, k0, a.n, a.kdim, tid, vb); scale_tile<false, NT, NEGB>(a.w, k0, a.kdim, tid, vb); }
         store_tile<NT>(As, tid, va);
         store_tile<NT>(Bs, tid, vb);
     }
@@ -196,22 +222,24 @@ __global__ __launch_bounds__(64 * WD * WD, WD == 2 ? 2 : 4) void k_syrk_lower(Sy
         if (more) {
             const int k0 = (kt_begin + kt + 1) * BK;
             const bool chk = edge || (k0 + BK > a.kdim);
-            if (chk) { load_tile<true, NT>(a.A, a.lda, row0, k0, a.n, a.kdim, tid, va); load_tile<true, NT>(a.B, a.ldb, col0, k0, a.n, a.kdim, tid, vb); scale_tile<true, NT>(a.w, k0, a.kdim, tid, vb); }
-            else { load_tile<false, NT>(a.A, a.lda, row0, k0, a.n, a.kdim, tid, va); load_tile<false, NT>(a.B, a.ldb, col0, k0, a.n, a.kdim, tid, vb); scale_tile<false, NT>(a.w, k0, a.kdim, tid, vb); }
+            if (chk) { load_tile<true, NT>(a.A, a.lda, row0, k0, a.n, a.kdim, tid, va); load_tile<true, NT>(a.B, a.ldb, col0, k0, a.n, a.kdim, tid, vb); scale_tile<true, NT, NEGB>(a.w, k0, a.kdim, tid, vb); }
+            else { load_tile<false, NT>(a.A, a.lda, row0, k0, a.n, a.kdim, tid, va); load_tile<false, NT>(a.B, a.ldb, col0, k0, a.n, a.kdim, tid, vb); scale_tile<false, NT, NEGB>(a.w, k0, a.kdim, tid, vb); }
         }
         if (!skip_wave) {
-            const double* Asb = As + cur * BK * LDS_LD + wr * SUB + (lane & 15);
-            const double* Bsb = Bs + cur * BK * LDS_LD + wc * SUB + (lane & 15);
+            const double* Asb = As + cur * BK * LDS_LD + wr * SUBR + (lane & 15);
+            const double* Bsb = Bs + cur * BK * LDS_LD + wc * SUBC + (lane & 15);
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const int kk = ks * 4 + (lane >> 4);
-                double af[MT], bf[MT];
+                double af[MTR], bf[MTC];
 #pragma unroll
-                for (int q = 0; q < MT; ++q) { af[q] = Asb[kk * LDS_LD + q * 16]; bf[q] = Bsb[kk * LDS_LD + q * 16]; }
+                for (int q = 0; q < MTR; ++q) af[q] = Asb[kk * LDS_LD + q * 16];
 #pragma unroll
-                for (int x = 0; x < MT; ++x)
+                for (int q = 0; q < MTC; ++q) bf[q] = Bsb[kk * LDS_LD + q * 16];
 #pragma unroll
-                    for (int y = 0; y < MT; ++y)
+                for (int x = 0; x < MTC; ++x)
+#pragma unroll
+                    for (int y = 0; y < MTR; ++y)
                         acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[x], af[y], acc[x][y], 0, 0, 0);
             }
         }
@@ -222,62 +250,28 @@ __global__ __launch_bounds__(64 * WD * WD, WD == 2 ? 2 : 4) void k_syrk_lower(Sy
         __syncthreads();
     }
 
-    constexpr bool FPK = FUSED_PACKED;
-    if (EPI == EPI_SUBTRACT_POTRF && ti == 0 && tj == 0 && a.fuse_nb > 0) {
-        // next diagonal block: C - acc goes to LDS (the staging buffers are free now) instead of HBM, is factored there, and only the
-        // factor is written.  Every wave of the workgroup stays for the barriers of potrf_block.
-        double* S = smem;
-        const int nbn = a.fuse_nb;
-        if (nbn < TS) {  // identity padding (last, partial panel)
-            for (int idx = tid; idx < TS * TS; idx += NT) {
-                const int r = idx & (TS - 1), c = idx >> 7;
-                if (r >= c && (r >= nbn || c >= nbn)) S[sidx<FPK>(r, c)] = (r == c) ? 1.0 : 0.0;
-            }
-        }
-        if (!skip_wave) {
-#pragma unroll
-            for (int x = 0; x < MT; ++x) {
-#pragma unroll
-                for (int y = 0; y < MT; ++y) {
-                    const int li = wr * SUB + y * 16 + (lane & 15);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int lj = wc * SUB + x * 16 + (lane >> 4) + 4 * r;
-                        if (li < nbn && lj < nbn && li >= lj) S[sidx<FPK>(li, lj)] = a.C[(size_t)li + (size_t)lj * a.ldc] - acc[x][y][r];
-                    }
-                }
-            }
-        }
-        __syncthreads();
-        if (a.fuse_dbg_skip) { }
-        else if (a.fuse_ldlt) potrf_block<true, NT, FPK>(S, nbn, a.fuse_kglobal, a.fuse_info, a.fuse_rdiag, 0);
-        else potrf_block<false, NT, FPK>(S, nbn, a.fuse_kglobal, a.fuse_info, a.fuse_rdiag, 0);
-        for (int c = wave; c < nbn; c += NT / 64)
-            for (int r = c + lane; r < nbn; r += 64) a.C[(size_t)r + (size_t)c * a.ldc] = S[sidx<FPK>(r, c)];
-        return;
-    }
     if (skip_wave) return;
     if (a.part) {
         // split launch: raw partial tile (column-major 128 x 128) for k_syrk_tail_reduce; fixed slot per (tile, slice)
         double* P = a.part + (size_t)blockIdx.x * TS * TS;
 #pragma unroll
-        for (int x = 0; x < MT; ++x)
+        for (int x = 0; x < MTC; ++x)
 #pragma unroll
-            for (int y = 0; y < MT; ++y)
+            for (int y = 0; y < MTR; ++y)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    P[(wr * SUB + y * 16 + (lane & 15)) + (size_t)(wc * SUB + x * 16 + (lane >> 4) + 4 * r) * TS] = acc[x][y][r];
+                    P[(wr * SUBR + y * 16 + (lane & 15)) + (size_t)(wc * SUBC + x * 16 + (lane >> 4) + 4 * r) * TS] = acc[x][y][r];
         return;
     }
     // epilogue: lane holds rows gi (consecutive over lane&15) and columns gj = base + (lane>>4) + 4*r
 #pragma unroll
-    for (int x = 0; x < MT; ++x) {
+    for (int x = 0; x < MTC; ++x) {
 #pragma unroll
-        for (int y = 0; y < MT; ++y) {
-            const int gi = row0 + wr * SUB + y * 16 + (lane & 15);
+        for (int y = 0; y < MTR; ++y) {
+            const int gi = row0 + wr * SUBR + y * 16 + (lane & 15);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int gj = col0 + wc * SUB + x * 16 + (lane >> 4) + 4 * r;
+                const int gj = col0 + wc * SUBC + x * 16 + (lane >> 4) + 4 * r;
                 if (gi < a.n && gj < a.n && gi >= gj) {
                     const size_t ci = (size_t)gi + (size_t)gj * a.ldc;
                     const double v = acc[x][y][r];
@@ -286,7 +280,9 @@ __global__ __launch_bounds__(64 * WD * WD, WD == 2 ? 2 : 4) void k_syrk_lower(Sy
                         if (gi == gj) base += a.x_reg[gi];
                         if (a.ATA) base += a.dinv * a.ATA[(size_t)gi + (size_t)gj * a.ldata];
                         a.C[ci] = base + v;
-                    } else if (EPI == EPI_SUBTRACT || EPI == EPI_SUBTRACT_POTRF) {
+                    } else if (EPI == EPI_SUBTRACT_POTRF) {
+                        a.C[ci] = v;  // accumulator started from C
+                    } else if (EPI == EPI_SUBTRACT) {
                         a.C[ci] -= v;
                     } else {
                         a.C[ci] = v;
@@ -412,11 +408,11 @@ static void launch_syrk_t(SyrkArgs a, hipStream_t s, double* ws, size_t ws_doubl
     // short inner dimension (factorisation trailing updates, K = 128): latency-bound per tile -> 16-wave shape
     const bool low_latency = a.kdim <= 256;
     a.tile_order = (!low_latency && !a.first_col_only) ? syrk_tile_order(T) : nullptr;
-    if (low_latency) hipLaunchKernelGGL((k_syrk_lower<EPI, 4>), dim3(main_tiles), dim3(1024), SYRK_LDS_BYTES, s, a);
-    else hipLaunchKernelGGL((k_syrk_lower<EPI, 2>), dim3(main_tiles), dim3(256), SYRK_LDS_BYTES, s, a);
+    if (low_latency) hipLaunchKernelGGL((k_syrk_lower<EPI, 4, 4>), dim3(main_tiles), dim3(1024), SYRK_LDS_BYTES, s, a);
+    else hipLaunchKernelGGL((k_syrk_lower<EPI, 2, 2>), dim3(main_tiles), dim3(256), SYRK_LDS_BYTES, s, a);
     if (rem > 0) {
         a.tile_begin = main_tiles; a.k_split = ks; a.part = ws;
-        hipLaunchKernelGGL((k_syrk_lower<EPI, 2>), dim3(rem * ks), dim3(256), SYRK_LDS_BYTES, s, a);
+        hipLaunchKernelGGL((k_syrk_lower<EPI, 2, 2>), dim3(rem * ks), dim3(256), SYRK_LDS_BYTES, s, a);
         hipLaunchKernelGGL(k_syrk_tail_reduce<EPI>, dim3(rem, TS * TS / 256), dim3(256), 0, s, a);
     }
 }
@@ -428,23 +424,23 @@ void launch_syrk(int epi, const SyrkArgs& args_in, hipStream_t s, double* split_
     a.unaligned = ((a.lda & 1) || (a.ldb & 1) || (reinterpret_cast<uintptr_t>(a.A) & 15) || (reinterpret_cast<uintptr_t>(a.B) & 15)) ? 1 : 0;
     static bool attr_set = false;
     if (!attr_set) {
-        PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk_lower<EPI_ASSEMBLE, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, SYRK_LDS_BYTES));
-        PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk_lower<EPI_SUBTRACT, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, SYRK_LDS_BYTES));
-        PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk_lower<EPI_STORE, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, SYRK_LDS_BYTES));
-        PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk_lower<EPI_ASSEMBLE, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, SYRK_LDS_BYTES));
-        PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk_lower<EPI_SUBTRACT, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, SYRK_LDS_BYTES));
-        PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk_lower<EPI_STORE, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, SYRK_LDS_BYTES));
+        PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk_lower<EPI_ASSEMBLE, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, SYRK_LDS_BYTES));
+        PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk_lower<EPI_SUBTRACT, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, SYRK_LDS_BYTES));
+        PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk_lower<EPI_STORE, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, SYRK_LDS_BYTES));
+        PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk_lower<EPI_ASSEMBLE, 4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, SYRK_LDS_BYTES));
+        PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk_lower<EPI_SUBTRACT, 4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, SYRK_LDS_BYTES));
+        PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk_lower<EPI_STORE, 4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, SYRK_LDS_BYTES));
         attr_set = true;
     }
     if (epi == EPI_SUBTRACT_POTRF) {
         static bool fused_attr = false;
         if (!fused_attr) {
-            PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk_lower<EPI_SUBTRACT_POTRF, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS_BYTES));
+            PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk_lower<EPI_SUBTRACT_POTRF, 4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS_BYTES));
             fused_attr = true;
         }
         const int T = div_up(a.n, TS);
         a.tile_begin = 0; a.k_split = 1; a.part = nullptr; a.first_col_only = 0;
-        hipLaunchKernelGGL((k_syrk_lower<EPI_SUBTRACT_POTRF, 4>), dim3(T * (T + 1) / 2), dim3(1024), FUSED_LDS_BYTES, s, a);
+        hipLaunchKernelGGL((k_syrk_lower<EPI_SUBTRACT_POTRF, 4, 2>), dim3(T * (T + 1) / 2), dim3(512), FUSED_LDS_BYTES, s, a);
         PQ_HIP(hipGetLastError());
         return;
     }
@@ -506,15 +502,32 @@ __device__ __forceinline__ void stage_lower_block(const double* __restrict__ A, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// Diagonal-block factorisation (one workgroup, block resident in LDS).
-//   LDLT == false: Eigen LLT unblocked semantics per SURVEY.md A.4: pivot x <= 0 -> fail, l = sqrt(x), column / l
-//   LDLT == true : dense/ldlt_no_pivot.hpp:278-311: unit L, D on the diagonal, fail iff pivot == 0
-// Inner structure: 16-column steps; the 16x16 diagonal piece is factored by one wave in registers
-// (row per lane, v_readlane broadcasts), the panel below by one thread per row, and the in-block
-// trailing update by 16x16x4 fp64 MFMA tiles.
-constexpr int NB = 128;
-constexpr int PLD = NB + 16;  // LDS leading dimension (bank-conflict-free MFMA operand reads)
-constexpr int POTRF_LDS_BYTES = NB * PLD * (int)sizeof(double);
+// Serial part of the blocked factorisation: diagonal block (<= 128 x 128) and the panel below it.
+//
+// 16 x 16 tile toolkit.  A diagonal block lives in LDS as 36 column-major 16 x 16 blocks (its lower block triangle; block (bi, bj) at
+// tb_index(bi, bj) * 256, element (r, c) of a block at c * 16 + r).  A wave touches a block in one of two register forms:
+//   tile form: lane (i = lane & 15, g = lane >> 4), register r  <->  element [i][g + 4 r].  This is the C/D layout of v_mfma_f64_16x16x4
+//              AND the layout of its A / B operands: register ks of a tile is the operand of k-step ks.  For X, Y, T in tile form
+//                  T += X Y^T   is   T = mfma(Y[ks], X[ks], T), ks = 0..3
+//              so a product's result feeds the next product without any data movement, and the LDS reads (lanes of a group on 16
+//              consecutive doubles, groups 32 doubles apart) are conflict-free;
+//   row form:  every lane holds row (lane & 15) of the block in 16 registers (the four lane groups are replicas); the scalar recurrences
+//              (16 x 16 factorisation, substitution, inversion) run in this form with v_readlane broadcasts and no LDS traffic.
+__device__ __forceinline__ int tb_index(int bi, int bj) { return bi * (bi + 1) / 2 + bj; }
+constexpr int TB_BLOCKS = 36;
+constexpr int TB_DOUBLES = TB_BLOCKS * 256;
+constexpr int POTRF_LDS_BYTES = (TB_DOUBLES + 64) * (int)sizeof(double);
+
+__device__ __forceinline__ d4 tile_load(const double* __restrict__ blk, int lane)
+{
+    const double* p = blk + (lane >> 4) * 16 + (lane & 15);
+    return (d4){p[0], p[64], p[128], p[192]};
+}
+__device__ __forceinline__ void tile_store(double* __restrict__ blk, int lane, d4 t)
+{
+    double* p = blk + (lane >> 4) * 16 + (lane & 15);
+    p[0] = t[0]; p[64] = t[1]; p[128] = t[2]; p[192] = t[3];
+}
 
 // 1/sqrt(d) to ~1 ulp without the IEEE sqrt + divide chains (two Newton steps on v_rsq_f64)
 __device__ __forceinline__ double rsqrt_newton(double d)
@@ -532,152 +545,201 @@ __device__ __forceinline__ double rcp_newton(double d)
     return y;
 }
 
-constexpr int POTRF_THREADS = 512;
-template <bool PACKED>
-__device__ __forceinline__ int sidx(int r, int c)
+// 16 x 16 diagonal piece in tile form, one rank-1 update on the matrix cores per pivot: column c lives in lane group c & 3, register c >> 2;
+// its part below the diagonal, zero everywhere else, IS both operands of  T -= l l^T  (k-slot = the lane group), so a pivot step is a
+// handful of VALU instructions and one v_mfma_f64_16x16x4 instead of (15 - c) broadcast + FMA pairs.  Measured on MI355X (tools/dbg_potrf.py):
+// a single wave issues ~7 cycles per instruction and a DEPENDENT fp64 MFMA costs ~180 cycles, so a pivot is ~300 cycles either way
+// (row-form VALU version 5500 cycles per piece, this one 4500-5000; a variant that computes the next reciprocal pivot one step ahead by a
+// scalar recurrence was slower, 5600-6500: its broadcasts still wait for the MFMA in flight and the extra instructions are not free).
+//   LDLT == false: Eigen LLT unblocked semantics per SURVEY.md A.4: pivot x <= 0 -> fail, l = sqrt(x), column / l
+//   LDLT == true : dense/ldlt_no_pivot.hpp:278-311: unit L below the diagonal, D on it, fail iff pivot == 0
+// On return t holds the factor (zeros above the diagonal); lane c < 16 holds the reciprocal pivot of column c in rd (LLT: 1 / l_cc,
+// LDLT: 1 / d_c) and d_c in dd.  Returns the first failing column or -1.
+template <bool LDLT>
+__device__ __forceinline__ int factor16_tile(d4& t, int lane, double& rd, double& dd)
 {
-    if (!PACKED) return c * PLD + r;
-    const int jb = c >> 4;  // block column jb holds rows 16 jb .. 127: height 128 - 16 jb, offset 16 * sum_{q < jb} (128 - 16 q)
-    return (2048 * jb - 128 * jb * (jb - 1)) + (c & 15) * (128 - 16 * jb) + (r - 16 * jb);
+    const int i = lane & 15, g = lane >> 4;
+    int failed = -1;
+    rd = 0.0; dd = 0.0;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        const int g0 = c & 3, r0 = c >> 2;
+        double dk = readlane_d(t[r0], 16 * g0 + c);
+        const bool incol = (g == g0), below = incol && (i > c);
+        double r;
+        if (!LDLT) {
+            if (!(dk > 0.0)) { if (failed < 0) failed = c; dk = 1.0; }
+            r = rsqrt_newton(dk);  // 1 / l
+            const double lcol = below ? t[r0] * r : 0.0;
+            t[r0] = incol ? ((i == c) ? dk * r : lcol) : t[r0];
+            if (c < 15) t = __builtin_amdgcn_mfma_f64_16x16x4f64(lcol, -lcol, t, 0, 0, 0);
+        } else {
+            if (dk == 0.0) { if (failed < 0) failed = c; dk = 1.0; }
+            r = rcp_newton(dk);    // 1 / d
+            const double ycol = below ? t[r0] : 0.0;
+            const double lcol = ycol * r;
+            t[r0] = incol ? ((i == c) ? dk : lcol) : t[r0];
+            if (c < 15) t = __builtin_amdgcn_mfma_f64_16x16x4f64(lcol, -ycol, t, 0, 0, 0);
+        }
+        if (lane == c) { rd = r; dd = dk; }
+    }
+    return failed;
 }
-template <bool LDLT, int NTHREADS, bool PACKED>
-__device__ void potrf_block(double* __restrict__ S, int nb, int kglobal, int* __restrict__ info, double* __restrict__ rdiag, int dbg)
+
+// X <- X L^-T for a 16 x 16 lower-triangular L, both in tile form (LDLT: unit diagonal, then X <- X D^-1 when SCALE): column c of X is
+// final after c rank-1 updates  X[:, j] -= X[:, c] L[j][c]  (j > c), each ONE MFMA.  Its column-side operand -- column c of -L below the
+// diagonal, pre-scaled by 1 / l_cc -- does not depend on X, and its row-side operand is register c >> 2 of the accumulator as it is (the
+// other lane groups meet zeros), so the dependent chain is MFMA -> MFMA; the columns are scaled by their reciprocal pivots at the end.
+// rdc[r] = reciprocal pivot of column g + 4 r (this lane's columns).
+template <bool LDLT, bool SCALE>
+__device__ __forceinline__ void tile_trsm_rt(d4& x, const d4& L, const d4& rdc, int lane)
 {
-    (void)dbg;
-    __shared__ double rd16[16];  // reciprocals of the current 16 pivots
+    const int i = lane & 15, g = lane >> 4;
+    d4 nls;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) nls[r] = LDLT ? -L[r] : -L[r] * rdc[r];
+#pragma unroll
+    for (int c = 0; c < 15; ++c) {
+        const int g0 = c & 3, r0 = c >> 2;
+        const double aop = (g == g0 && i > c) ? nls[r0] : 0.0;
+        x = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, x[r0], x, 0, 0, 0);
+    }
+    if (!LDLT || SCALE) x *= rdc;
+}
+
+// Factorisation of a diagonal block of order nb <= 128 held in LDS (tile blocks Tb, identity-padded beyond nb).  Waves 0..7 own one
+// 16-row block row each; every other wave of the workgroup only takes part in the barriers.  Step k (16 columns):
+//   wave k      factors its diagonal piece in registers (factor16_tile) and leaves L_kk + reciprocal pivots in LDS          | barrier
+//   waves w > k solve their 16 x 16 piece of the panel against L_kk (tile_trsm_rt)                                          | barrier
+//   waves w > k update the tiles (w, k+1..w) of their block row: T -= X_w (D) X_c^T, nearest column first, so wave k + 1 walks
+//               straight from its last update into the factorisation of step k + 1;
+//   wave k      meanwhile inverts L_kk -- off the critical path, its block row is finished -- for the panel kernel below.
+// Outputs: the factor (lower triangle) to Aout, reciprocal pivots to rdiag[kglobal..], D to dvec (LDLT, nullable), and `pack`
+// (nullable): the operand pack of k_trsm_panel -- 28 strictly-lower blocks of -L at j (j - 1) / 2 + k, then the 8 inverted
+// diagonal pieces W_jj, all as column-major 16 x 16 blocks.
+constexpr int PACK_BLOCKS = 36;
+template <bool LDLT, int NWAVES>
+__device__ __forceinline__ void potrf_block(double* __restrict__ Tb, double* __restrict__ rds, int nb, int kglobal, int* __restrict__ info, double* __restrict__ rdiag,
+                            double* __restrict__ dvec, double* __restrict__ Aout, int lda, double* __restrict__ pack, long long* __restrict__ ts)
+{
+    // ts (debugging aid, nullptr in production): shader-clock stamps of step k at ts[8 k + q] -- q = 0 / 1 wave k before / after its 16 x 16
+    // factorisation, 2 / 3 wave k + 1 before / after its substitution, 4 / 5 wave k + 1 before / after its tile updates, 6 wave k after the inversion
+    auto stamp = [&](int k, int q) { if (ts && (threadIdx.x & 63) == 0) ts[8 * k + q] = clock64(); };
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    constexpr int NW = NTHREADS / 64;
-    const int nbp = (nb + 15) & ~15;
-    const int nt = nbp >> 4;
-
-    // (1) 16x16 diagonal piece jb, one wave, row (lane & 15) per lane, everything in registers
-    auto diag_piece = [&](int jb) {
-        const int j0 = jb * 16;
-        const int i = lane & 15;
-        double a[16];
-#pragma unroll
-        for (int c = 0; c < 16; ++c) a[c] = S[sidx<PACKED>(j0 + i, j0 + c)];
-        int failed = -1;
-        double rdk = 0.0;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            double dk = readlane_d(a[k], k);
-            const double yk = a[k];
-            double r;
-            if (!LDLT) {
-                if (!(dk > 0.0)) { if (failed < 0) failed = k; dk = 1.0; }
-                r = rsqrt_newton(dk);            // 1/l
-                a[k] = (i == k) ? dk * r : a[k] * r;
-            } else {
-                if (dk == 0.0) { if (failed < 0) failed = k; dk = 1.0; }
-                r = rcp_newton(dk);              // 1/d
-                a[k] = (i == k) ? dk : a[k] * r;
+    const int i = lane & 15, g = lane >> 4;
+#pragma unroll 1
+    for (int k = 0; k < 8; ++k) {
+        double* Dkk = Tb + tb_index(k, k) * 256;
+        double* rbuf = rds + (k & 1) * 32;  // reciprocal pivots [0, 16) and D [16, 32) of this step; double-buffered: wave k still reads them
+        double* dvs = rbuf + 16;            // (inversion) while wave k + 1 writes the next step's
+        d4 lkk = {0.0, 0.0, 0.0, 0.0};
+        double rd = 0.0, dmine = 0.0;
+        if (wave == k) {
+            stamp(k, 0);
+            lkk = tile_load(Dkk, lane);
+            const int failed = factor16_tile<LDLT>(lkk, lane, rd, dmine);
+            tile_store(Dkk, lane, lkk);
+            if (lane < 16) {
+                rbuf[lane] = rd;
+                if (LDLT) dvs[lane] = dmine;
             }
-            if (lane == k) rdk = r;
+            if (failed >= 0 && lane == 0 && 16 * k + failed < nb) { if (*info < 0) *info = kglobal + 16 * k + failed; }
+            stamp(k, 1);
+        }
+        __syncthreads();
+        if (wave > k && wave < 8) {
+            if (wave == k + 1) stamp(k, 2);
+            double* Xwk = Tb + tb_index(wave, k) * 256;
+            d4 x = tile_load(Xwk, lane);
+            const d4 L = tile_load(Dkk, lane);
+            const d4 rdc = {rbuf[g], rbuf[g + 4], rbuf[g + 8], rbuf[g + 12]};
+            tile_trsm_rt<LDLT, true>(x, L, rdc, lane);
+            tile_store(Xwk, lane, x);
+            if (wave == k + 1) stamp(k, 3);
+        }
+        __syncthreads();
+        if (wave > k && wave < 8) {
+            if (wave == k + 1) stamp(k, 4);
+            const d4 xw = tile_load(Tb + tb_index(wave, k) * 256, lane);
+            const d4 nxw = {-xw[0], -xw[1], -xw[2], -xw[3]};
+            d4 dsc = {1.0, 1.0, 1.0, 1.0};  // LDLT: D of the operand columns this lane feeds to the update products
+            if (LDLT) dsc = (d4){dvs[g], dvs[g + 4], dvs[g + 8], dvs[g + 12]};
+            for (int c = k + 1; c <= wave; ++c) {
+                d4 xc = tile_load(Tb + tb_index(c, k) * 256, lane);
+                if (LDLT) xc *= dsc;
+                double* Tw = Tb + tb_index(wave, c) * 256;
+                d4 t = tile_load(Tw, lane);
 #pragma unroll
-            for (int j = k + 1; j < 16; ++j) {
-                const double ljk = readlane_d(a[k], j);
-                a[j] -= (LDLT ? yk : a[k]) * ljk;
+                for (int ks = 0; ks < 4; ++ks) t = __builtin_amdgcn_mfma_f64_16x16x4f64(xc[ks], nxw[ks], t, 0, 0, 0);
+                tile_store(Tw, lane, t);
             }
-        }
-        if (lane < 16) {
+            if (wave == k + 1) stamp(k, 5);
+        } else if (wave == k) {
+            // the block row of wave k is finished: pivots out, and the inverse of L_kk for the panel kernel -- behind the second barrier, so
+            // that nobody waits for it (the next barrier is reached by wave k + 1 only after its own 16 x 16 factorisation).
+            // W^T = I L^-T by the same rank-1 substitution, then one product with the identity transposes it: W = I (W^T)^T.
+            if (lane < 16 && 16 * k + lane < nb) {
+                rdiag[kglobal + 16 * k + lane] = rd;
+                if (LDLT && dvec) dvec[16 * k + lane] = dmine;
+            }
+            if (pack) {
+                d4 eye;
 #pragma unroll
-            for (int c = 0; c < 16; ++c) if (c <= i) S[sidx<PACKED>(j0 + i, j0 + c)] = a[c];
-            rd16[lane] = rdk;
-            if (j0 + lane < nb) rdiag[kglobal + j0 + lane] = rdk;
-        }
-        if (failed >= 0 && lane == 0 && j0 + failed < nb) { if (*info < 0) *info = kglobal + j0 + failed; }
-    };
-    // (3) one or two 16x16 tiles of the in-block trailing update of step jb: S(tr,tc) -= X_tr * (D) * X_tc^T on the matrix cores
-    auto update_tiles = [&](int jb, int t0, int t1, int ntile) {
-        const int j0 = jb * 16;
-        int R0[2], C0[2];
-        bool on[2];
+                for (int r = 0; r < 4; ++r) eye[r] = (i == g + 4 * r) ? 1.0 : 0.0;
+                d4 z = eye;
+                const d4 rdc = {rbuf[g], rbuf[g + 4], rbuf[g + 8], rbuf[g + 12]};
+                tile_trsm_rt<LDLT, false>(z, lkk, rdc, lane);
+                d4 w = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int tt = u == 0 ? t0 : t1;
-            on[u] = tt >= 0 && tt < ntile;
-            int tr = (int)((sqrtf(8.0f * (float)(on[u] ? tt : 0) + 1.0f) - 1.0f) * 0.5f);
-            const int tq = on[u] ? tt : 0;
-            while ((tr + 1) * (tr + 2) / 2 <= tq) ++tr;
-            while (tr * (tr + 1) / 2 > tq) --tr;
-            const int tc = tq - tr * (tr + 1) / 2;
-            R0[u] = on[u] ? (jb + 1 + tr) * 16 : (jb + 1) * 16;
-            C0[u] = on[u] ? (jb + 1 + tc) * 16 : (jb + 1) * 16;
-        }
-        d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+                for (int ks = 0; ks < 4; ++ks) w = __builtin_amdgcn_mfma_f64_16x16x4f64(z[ks], eye[ks], w, 0, 0, 0);
+                tile_store(pack + (28 + k) * 256, lane, w);
+            }
+            // ... and block row k of the factor goes to HBM now (its blocks (k, 0..k) are final and only READ from here on), so that no
+            // store tail is left at the end: 128-byte segments; the negated strictly-lower blocks are the rest of the panel kernel's pack
+            for (int bj = 0; bj <= k; ++bj) {
+                const double* blk = Tb + tb_index(k, bj) * 256;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const int k = j0 + ks * 4 + (lane >> 4);
-            const double dk = LDLT ? S[sidx<PACKED>(k, k)] : 1.0;
-            const double av0 = S[sidx<PACKED>(R0[0] + (lane & 15), k)], av1 = S[sidx<PACKED>(R0[1] + (lane & 15), k)];
-            double bv0 = S[sidx<PACKED>(C0[0] + (lane & 15), k)], bv1 = S[sidx<PACKED>(C0[1] + (lane & 15), k)];
-            if (LDLT) { bv0 *= dk; bv1 *= dk; }
-            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(bv0, av0, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(bv1, av1, acc1, 0, 0, 0);
-        }
-        if (on[0]) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) S[sidx<PACKED>(R0[0] + (lane & 15), C0[0] + (lane >> 4) + 4 * r)] -= acc0[r];
-        }
-        if (on[1]) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) S[sidx<PACKED>(R0[1] + (lane & 15), C0[1] + (lane >> 4) + 4 * r)] -= acc1[r];
-        }
-    };
-
-    if (wave == 0) diag_piece(0);
-    __syncthreads();
-    for (int jb = 0; jb < nt; ++jb) {
-        const int j0 = jb * 16;
-        // (2) panel below the diagonal piece: X = A * Ljj^-T (LLT) / Y = A * Ljj^-T(unit), X = Y D^-1 (LDLT)
-        {
-            const int i = j0 + 16 + tid;
-            if (i < nbp) {
-                double x[16];
-#pragma unroll
-                for (int c = 0; c < 16; ++c) x[c] = S[sidx<PACKED>(i, j0 + c)];
-                // right-looking (axpy) substitution: the updates of one column step are independent of each other
-#pragma unroll
-                for (int c = 0; c < 16; ++c) {
-                    const double yc = x[c];              // LLT: y = x l_cc ; LDLT: y = x d_c
-                    x[c] = yc * rd16[c];
-#pragma unroll
-                    for (int c2 = c + 1; c2 < 16; ++c2) x[c2] -= (LDLT ? yc : x[c]) * S[sidx<PACKED>(j0 + c2, j0 + c)];
+                for (int q = 0; q < 4; ++q) {
+                    const int e = lane + 64 * q, r = 16 * k + (e & 15), c = 16 * bj + (e >> 4);
+                    const double v = blk[e];
+                    if (r < nb && c < nb && r >= c) Aout[(size_t)r + (size_t)c * lda] = v;
+                    if (pack && k > bj) pack[(k * (k - 1) / 2 + bj) * 256 + e] = -v;
                 }
-#pragma unroll
-                for (int c = 0; c < 16; ++c) S[sidx<PACKED>(i, j0 + c)] = x[c];
             }
+            stamp(k, 6);
         }
-        __syncthreads();
-        // (3) trailing update inside the block.  Wave 0 takes only tile 0 -- the next diagonal piece -- and factors it right away
-        // (step (1) of jb + 1), while the other waves work through the remaining tiles: the serial 16x16 factorisation is off
-        // the critical path and one barrier per step disappears.
-        {
-            const int rem = nt - 1 - jb;
-            const int ntile = rem * (rem + 1) / 2;
-            if (wave == 0) {
-                if (ntile > 0) { update_tiles(jb, 0, -1, ntile); diag_piece(jb + 1); }
-            } else {
-                for (int t = 1 + (wave - 1); t < ntile; t += 2 * (NW - 1)) update_tiles(jb, t, t + (NW - 1), ntile);
-            }
-        }
-        __syncthreads();
     }
 }
+
+constexpr int POTRF_THREADS = 512;
 template <bool LDLT>
-__global__ __launch_bounds__(POTRF_THREADS) void k_potrf_diag(double* __restrict__ A, int lda, int nb, int kglobal, int* __restrict__ info, double* __restrict__ rdiag, int dbg)
+__global__ __launch_bounds__(POTRF_THREADS) void k_potrf_diag(double* __restrict__ A, int lda, int nb, int kglobal, int* __restrict__ info, double* __restrict__ rdiag,
+                                                              double* __restrict__ dvec, double* __restrict__ pack, long long* __restrict__ ts)
 {
-    extern __shared__ __attribute__((aligned(16))) double S[];  // S[c * PLD + r]
+    extern __shared__ __attribute__((aligned(16))) double Tb[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    stage_lower_block<NB, PLD, POTRF_THREADS>(A, lda, nb, S, tid);
+    for (int b = wave; b < TB_BLOCKS; b += POTRF_THREADS / 64) {
+        int bi = 0;
+        while ((bi + 1) * (bi + 2) / 2 <= b) ++bi;
+        const int bj = b - bi * (bi + 1) / 2;
+        double v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = lane + 64 * q, r = 16 * bi + (e & 15), c = 16 * bj + (e >> 4);
+            const bool in = r < nb && c < nb;
+            const bool ok = in && r >= c;
+            const double* p = ok ? (A + r + (size_t)c * lda) : A;
+            const double t = *p;
+            v[q] = ok ? t : ((!in && r == c) ? 1.0 : 0.0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Tb[b * 256 + lane + 64 * q] = v[q];
+    }
     __syncthreads();
-    potrf_block<LDLT, POTRF_THREADS, false>(S, nb, kglobal, info, rdiag, dbg);
-    for (int c = wave; c < nb; c += POTRF_THREADS / 64)
-        for (int r = c + lane; r < nb; r += 64) A[r + (size_t)c * lda] = S[c * PLD + r];
+    potrf_block<LDLT, POTRF_THREADS / 64>(Tb, Tb + TB_DOUBLES, nb, kglobal, info, rdiag, dvec, A, lda, pack, ts);
 }
 
-void launch_potrf_diag(bool ldlt, double* A, int lda, int nb, int kglobal, int* info, double* rdiag, hipStream_t s)
+void launch_potrf_diag(bool ldlt, double* A, int lda, int nb, int kglobal, int* info, double* rdiag, double* dvec, double* pack, hipStream_t s, long long* ts)
 {
     static bool attr_set = false;
     if (!attr_set) {
@@ -685,128 +747,161 @@ void launch_potrf_diag(bool ldlt, double* A, int lda, int nb, int kglobal, int* 
         PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_diag<true>), hipFuncAttributeMaxDynamicSharedMemorySize, POTRF_LDS_BYTES));
         attr_set = true;
     }
-    static int dbg = -1;
-    if (dbg < 0) { const char* e = std::getenv("PIQP_AMD_POTRF_DBG"); dbg = e ? std::atoi(e) : 0; }
-    if (ldlt) hipLaunchKernelGGL(k_potrf_diag<true>, dim3(1), dim3(POTRF_THREADS), POTRF_LDS_BYTES, s, A, lda, nb, kglobal, info, rdiag, dbg);
-    else hipLaunchKernelGGL(k_potrf_diag<false>, dim3(1), dim3(POTRF_THREADS), POTRF_LDS_BYTES, s, A, lda, nb, kglobal, info, rdiag, dbg);
+    if (ldlt) hipLaunchKernelGGL(k_potrf_diag<true>, dim3(1), dim3(POTRF_THREADS), POTRF_LDS_BYTES, s, A, lda, nb, kglobal, info, rdiag, dvec, pack, ts);
+    else hipLaunchKernelGGL(k_potrf_diag<false>, dim3(1), dim3(POTRF_THREADS), POTRF_LDS_BYTES, s, A, lda, nb, kglobal, info, rdiag, dvec, pack, ts);
     PQ_HIP(hipGetLastError());
+}
+
+// Tile (0, 0) of a fused trailing update = the next diagonal block: this workgroup computes only its lower block triangle -- the 36 tile
+// blocks are dealt round-robin to the waves (4 or 5 each instead of the rectangular wave grid's 8 with the upper half wasted: the K loop of
+// this workgroup bounds the whole launch) --, starts the accumulators from C, stages ONE operand panel (rows 0..127 of the panel serve as
+// row and, negated and D-scaled, as column operand), leaves the result in LDS as tile blocks and factors it there (potrf_block).
+template <int NT>
+__device__ __forceinline__ void fused_next_diag(const SyrkArgs& a, double* __restrict__ smem)
+{
+    constexpr int NW = NT / 64, MAXT = (TB_BLOCKS + NW - 1) / NW;
+    double* As = smem;                    // [2][BK][LDS_LD]
+    double* Bs = smem + 2 * BK * LDS_LD;  // [2][BK][LDS_LD]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    const bool dbg_ts = a.fuse_ts && tid == 0;
+    if (dbg_ts) a.fuse_ts[0] = clock64();
+    const int nbn = a.fuse_nb;
+    const bool edge = (TS > a.n) || a.unaligned;
+    int bi[MAXT], bj[MAXT];
+    bool on[MAXT];
+    d4 acc[MAXT];
+#pragma unroll
+    for (int q = 0; q < MAXT; ++q) {
+        const int t = wave + NW * q;
+        on[q] = t < TB_BLOCKS;
+        const int tt = on[q] ? t : 0;
+        int b = 0;
+        while ((b + 1) * (b + 2) / 2 <= tt) ++b;
+        bi[q] = b; bj[q] = tt - b * (b + 1) / 2;
+        const int li = bi[q] * 16 + i;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int lj = bj[q] * 16 + g + 4 * r;
+            const bool in = li < nbn && lj < nbn;
+            const bool ok = on[q] && in && li >= lj;
+            const double cv = a.C[ok ? (size_t)li + (size_t)lj * a.ldc : 0];
+            acc[q][r] = ok ? cv : ((!in && li == lj) ? 1.0 : 0.0);  // identity padding (last, partial panel)
+        }
+    }
+    const int nkt = (a.kdim + BK - 1) / BK;
+    d2 va[1024 / NT], vb[1024 / NT];
+    auto fetch = [&](int kt) {
+        const int k0 = kt * BK;
+        if (edge || k0 + BK > a.kdim) load_tile<true, NT>(a.A, a.lda, 0, k0, a.n, a.kdim, tid, va);
+        else load_tile<false, NT>(a.A, a.lda, 0, k0, a.n, a.kdim, tid, va);
+#pragma unroll
+        for (int it = 0; it < 1024 / NT; ++it) vb[it] = va[it];
+        scale_tile<true, NT, true>(a.w, k0, a.kdim, tid, vb);
+    };
+    if (nkt > 0) { fetch(0); store_tile<NT>(As, tid, va); store_tile<NT>(Bs, tid, vb); }
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        const bool more = kt + 1 < nkt;
+        if (more) fetch(kt + 1);
+        const double* Asb = As + cur * BK * LDS_LD + i;
+        const double* Bsb = Bs + cur * BK * LDS_LD + i;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int kk = ks * 4 + g;
+#pragma unroll
+            for (int q = 0; q < MAXT; ++q) {
+                if (q < MAXT - 1 || on[q]) {
+                    const double af = Asb[kk * LDS_LD + bi[q] * 16], bf = Bsb[kk * LDS_LD + bj[q] * 16];
+                    acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf, af, acc[q], 0, 0, 0);
+                }
+            }
+        }
+        if (more) { store_tile<NT>(As + (cur ^ 1) * BK * LDS_LD, tid, va); store_tile<NT>(Bs + (cur ^ 1) * BK * LDS_LD, tid, vb); }
+        __syncthreads();
+    }
+    if (dbg_ts) a.fuse_ts[1] = clock64();
+    double* Tb = smem;  // the staging buffers are free now
+#pragma unroll
+    for (int q = 0; q < MAXT; ++q)
+        if (on[q]) tile_store(Tb + (wave + NW * q) * 256, lane, acc[q]);
+    __syncthreads();
+    if (dbg_ts) a.fuse_ts[2] = clock64();
+    long long* pts = a.fuse_ts ? a.fuse_ts + 8 : nullptr;
+    if (a.fuse_ldlt) potrf_block<true, NW>(Tb, Tb + TB_DOUBLES, nbn, a.fuse_kglobal, a.fuse_info, a.fuse_rdiag, a.fuse_dvec, a.C, a.ldc, a.fuse_pack, pts);
+    else potrf_block<false, NW>(Tb, Tb + TB_DOUBLES, nbn, a.fuse_kglobal, a.fuse_info, a.fuse_rdiag, a.fuse_dvec, a.C, a.ldc, a.fuse_pack, pts);
+    if (dbg_ts) a.fuse_ts[3] = clock64();
 }
 
 // ------------------------------------------------------------------------------------------------
 // Panel solve below the diagonal block:  A21 <- A21 * L11^-T            (Eigen LLT: solveInPlace<OnTheRight>)
 //                                        A21 <- A21 * L11^-T(unit) D^-1 (dense/ldlt_no_pivot.hpp:345-346)
-// One workgroup per 64 rows; the row block lives in LDS, L11 is read from L2.
-constexpr int RB = 64;
-constexpr int XLD = RB + 16;
-constexpr int LSLD = NB + 16;  // leading dimension of the staged L11 strip (rows of L11 contiguous)
-constexpr int TRSM_LDS_BYTES = (NB * XLD + 2 * (16 * LSLD + 16)) * (int)sizeof(double);
-
+// One wave per 16 rows, no barriers after the operand pack is staged: the 16 x 128 row block stays in registers as eight tiles and the
+// block substitution  X_k = T_k W_kk^T,  T_j -= X_k L_jk^T (j > k)  runs entirely on the matrix cores -- X_k comes out of the first
+// product in exactly the layout the second one consumes (tile form above).  W_kk are the inverted 16 x 16 diagonal pieces, -L_jk the
+// negated off-diagonal blocks, both prepared by potrf_block.
+constexpr int TRSM_ROWS = 64;  // rows per workgroup (4 waves)
+constexpr int TRSM_LDS_BYTES = PACK_BLOCKS * 256 * (int)sizeof(double);
 template <bool LDLT>
-__global__ __launch_bounds__(256) void k_trsm_panel(double* __restrict__ A, int lda, int k0, int nb, int n, const double* __restrict__ rdiag)
+__global__ __launch_bounds__(256) void k_trsm_panel(double* __restrict__ A, int lda, int k0, int nb, int n, const double* __restrict__ pack, const double* __restrict__ rdiag)
 {
-    extern __shared__ __attribute__((aligned(16))) double sm[];
-    double* Xs = sm;                  // Xs[c * XLD + r], c < nbp, r < RB
-    double* Ls0 = sm + NB * XLD;      // two buffers of { Ls[q * LSLD + rr] = L11[rr, j0 + q] (rr >= j0), strip of 16 columns; 16 reciprocal pivots }
+    extern __shared__ __attribute__((aligned(16))) double Ps[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nbp = (nb + 15) & ~15, nt = nbp >> 4;
-    const int r0 = k0 + nb + blockIdx.x * RB;
-    const double* L11 = A + k0 + (size_t)k0 * lda;
+    const int i = lane & 15, g = lane >> 4;
     {
-        // 64 rows x 128 columns: 32 loads per thread, issued 16 at a time (unconditional, clamped)
-#pragma unroll 1
-        for (int b0 = 0; b0 < 32; b0 += 16) {
-            double v[16];
+        const d2* src = reinterpret_cast<const d2*>(pack);
+        d2* dst = reinterpret_cast<d2*>(Ps);
+        d2 v[PACK_BLOCKS * 128 / 256];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int c = wave + 4 * (b0 + u);
-                const bool ok = (r0 + lane < n) && (c < nb);
-                const double* p = ok ? (A + (r0 + lane) + (size_t)(k0 + c) * lda) : A;
-                const double t = *p;
-                v[u] = ok ? t : 0.0;
-            }
+        for (int u = 0; u < PACK_BLOCKS * 128 / 256; ++u) v[u] = src[u * 256 + tid];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) Xs[(wave + 4 * (b0 + u)) * XLD + lane] = v[u];
-        }
+        for (int u = 0; u < PACK_BLOCKS * 128 / 256; ++u) dst[u * 256 + tid] = v[u];
     }
-    // the 16-column strips of L11 are double-buffered: strip jb + 1 is in flight (registers) while strip jb is being used
-    auto load_strip = [&](int jb, double (&v)[8]) {
-        const int j0 = jb * 16;
+    const int row = k0 + nb + (int)blockIdx.x * TRSM_ROWS + wave * 16 + i;
+    const bool row_ok = row < n;
+    double* Ar = A + (row_ok ? row : 0) + (size_t)k0 * lda;
+    d4 T[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int q = wave + 4 * (u >> 1);
-            const int rr = j0 + lane + 64 * (u & 1);
-            const bool ok = (rr < nb) && (j0 + q < nb);
-            const double* p = ok ? (L11 + rr + (size_t)(j0 + q) * lda) : L11;
-            const double t = *p;
-            v[u] = ok ? t : ((rr == j0 + q) ? 1.0 : 0.0);
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c = 16 * j + g + 4 * r;
+            const bool ok = row_ok && c < nb;
+            const double t = Ar[ok ? (size_t)c * lda : 0];
+            T[j][r] = ok ? t : 0.0;
         }
-    };
-    double sv[8];
-    load_strip(0, sv);
-    for (int jb = 0; jb < nt; ++jb) {
-        const int j0 = jb * 16;
-        double* Ls = Ls0 + (jb & 1) * (16 * LSLD + 16);
-        double* rd = Ls + 16 * LSLD;
-        // strip jb -> LDS (the buffer was last read two steps ago), reciprocal pivots
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int q = wave + 4 * (u >> 1);
-            const int rr = j0 + lane + 64 * (u & 1);
-            if (rr < nbp) Ls[q * LSLD + rr] = sv[u];
-        }
-        if (tid < 16) rd[tid] = (j0 + tid < nb) ? rdiag[k0 + j0 + tid] : 1.0;
-        __syncthreads();
-        if (jb + 1 < nt) load_strip(jb + 1, sv);
-        if (tid < RB) {
-            double x[16];
-#pragma unroll
-            for (int c = 0; c < 16; ++c) x[c] = Xs[(j0 + c) * XLD + tid];
-#pragma unroll
-            for (int c = 0; c < 16; ++c) {
-                if (!LDLT) x[c] *= rd[c];               // LDLT keeps Y = A L^-T (unit) here, D^-1 applied at the end
-#pragma unroll
-                for (int c2 = c + 1; c2 < 16; ++c2) x[c2] -= x[c] * Ls[c * LSLD + j0 + c2];
-            }
-#pragma unroll
-            for (int c = 0; c < 16; ++c) Xs[(j0 + c) * XLD + tid] = x[c];
-        }
-        __syncthreads();
-        // update remaining column tiles: Xs[:, ct] -= X_jb * L11[ct, jb]^T   (MFMA, both operands from LDS)
-        const int rem = nt - 1 - jb;
-        for (int t = wave; t < rem * 4; t += 8) {
-            const int t1 = t + 4;
-            const bool on1 = t1 < rem * 4;
-            const int ct0 = jb + 1 + t / 4, rt0 = t & 3;
-            const int ct1 = on1 ? jb + 1 + t1 / 4 : ct0, rt1 = on1 ? (t1 & 3) : rt0;
-            d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const int kq = ks * 4 + (lane >> 4);
-                const double xv0 = Xs[(j0 + kq) * XLD + rt0 * 16 + (lane & 15)], xv1 = Xs[(j0 + kq) * XLD + rt1 * 16 + (lane & 15)];
-                const double lv0 = Ls[kq * LSLD + ct0 * 16 + (lane & 15)], lv1 = Ls[kq * LSLD + ct1 * 16 + (lane & 15)];
-                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(lv0, xv0, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(lv1, xv1, acc1, 0, 0, 0);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) Xs[(ct0 * 16 + (lane >> 4) + 4 * r) * XLD + rt0 * 16 + (lane & 15)] -= acc0[r];
-            if (on1) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) Xs[(ct1 * 16 + (lane >> 4) + 4 * r) * XLD + rt1 * 16 + (lane & 15)] -= acc1[r];
-            }
-        }
-    }
     __syncthreads();
-    for (int c = wave; c < nb; c += 4) {
-        const int r = lane;
-        if (r0 + r < n) {
-            double v = Xs[c * XLD + r];
-            if (LDLT) v *= rdiag[k0 + c];
-            A[(r0 + r) + (size_t)(k0 + c) * lda] = v;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const d4 w = tile_load(Ps + (28 + k) * 256, lane);
+        d4 x = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) x = __builtin_amdgcn_mfma_f64_16x16x4f64(w[ks], T[k][ks], x, 0, 0, 0);
+        T[k] = x;
+#pragma unroll
+        for (int j = k + 1; j < 8; ++j) {
+            const d4 nl = tile_load(Ps + (j * (j - 1) / 2 + k) * 256, lane);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) T[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(nl[ks], x[ks], T[j], 0, 0, 0);
         }
+    }
+    if (row_ok) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = 16 * j + g + 4 * r;
+                if (c < nb) {
+                    double v = T[j][r];
+                    if (LDLT) v *= rdiag[k0 + c];
+                    Ar[(size_t)c * lda] = v;
+                }
+            }
     }
 }
 
-void launch_trsm_panel(bool ldlt, double* A, int lda, int k0, int nb, int n, const double* rdiag, hipStream_t s)
+void launch_trsm_panel(bool ldlt, double* A, int lda, int k0, int nb, int n, const double* pack, const double* rdiag, hipStream_t s)
 {
     const int rs = n - k0 - nb;
     if (rs <= 0) return;
@@ -816,20 +911,8 @@ void launch_trsm_panel(bool ldlt, double* A, int lda, int k0, int nb, int n, con
         PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_trsm_panel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, TRSM_LDS_BYTES));
         attr_set = true;
     }
-    if (ldlt) hipLaunchKernelGGL(k_trsm_panel<true>, dim3(div_up(rs, RB)), dim3(256), TRSM_LDS_BYTES, s, A, lda, k0, nb, n, rdiag);
-    else hipLaunchKernelGGL(k_trsm_panel<false>, dim3(div_up(rs, RB)), dim3(256), TRSM_LDS_BYTES, s, A, lda, k0, nb, n, rdiag);
-    PQ_HIP(hipGetLastError());
-}
-
-// D vector of the LDLt factor (diag of the factor buffer) for the trailing update's per-k scale
-__global__ void k_extract_diag(const double* __restrict__ A, int lda, int k0, int nb, double* __restrict__ d)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < nb) d[i] = A[(k0 + i) + (size_t)(k0 + i) * lda];
-}
-void launch_extract_diag(const double* A, int lda, int k0, int nb, double* d, hipStream_t s)
-{
-    hipLaunchKernelGGL(k_extract_diag, dim3(div_up(nb, 128)), dim3(128), 0, s, A, lda, k0, nb, d);
+    if (ldlt) hipLaunchKernelGGL(k_trsm_panel<true>, dim3(div_up(rs, TRSM_ROWS)), dim3(256), TRSM_LDS_BYTES, s, A, lda, k0, nb, n, pack, rdiag);
+    else hipLaunchKernelGGL(k_trsm_panel<false>, dim3(div_up(rs, TRSM_ROWS)), dim3(256), TRSM_LDS_BYTES, s, A, lda, k0, nb, n, pack, rdiag);
     PQ_HIP(hipGetLastError());
 }
 
@@ -1415,6 +1498,40 @@ double microbench_mfma_f64(int iters, hipStream_t s)
     (void)hipEventDestroy(e1);
     const double flops = (double)blocks * 4.0 * (double)iters * 8.0 * 2.0 * 16 * 16 * 4;
     return flops / (ms * 1e-3) * 1e-12;
+}
+
+__global__ void k_fill_spd_block(double* A, int n)
+{
+    const int r = threadIdx.x, c = blockIdx.x;
+    if (r < n && c < n) A[r + (size_t)c * n] = (r == c) ? (double)n + 1.0 : 1.0 / (1.0 + (double)((r * 7 + c * 13) % 17));
+}
+double microbench_potrf_block(bool ldlt, int reps, long long* stamps64, hipStream_t s)
+{
+    const int n = 128;
+    DBuf<double> A0((size_t)n * n), A((size_t)n * n), rdiag(n), dvec(n), pack(FACTOR_PACK_DOUBLES);
+    DBuf<int> info(1);
+    DBuf<long long> ts(64);
+    hipLaunchKernelGGL(k_fill_spd_block, dim3(n), dim3(n), 0, s, A0.p, n);
+    PQ_HIP(hipMemsetAsync(ts.p, 0, 64 * sizeof(long long), s));
+    PQ_HIP(hipMemsetAsync(info.p, 0xFF, sizeof(int), s));
+    hipEvent_t e0, e1;
+    PQ_HIP(hipEventCreate(&e0));
+    PQ_HIP(hipEventCreate(&e1));
+    float total = 0.f;
+    for (int r = 0; r < reps + 1; ++r) {
+        PQ_HIP(hipMemcpyAsync(A.p, A0.p, A.bytes(), hipMemcpyDeviceToDevice, s));
+        PQ_HIP(hipEventRecord(e0, s));
+        launch_potrf_diag(ldlt, A.p, n, n, 0, info.p, rdiag.p, dvec.p, pack.p, s, r == reps ? ts.p : nullptr);
+        PQ_HIP(hipEventRecord(e1, s));
+        PQ_HIP(hipEventSynchronize(e1));
+        float ms = 0.f;
+        PQ_HIP(hipEventElapsedTime(&ms, e0, e1));
+        if (r > 0 && r < reps) total += ms;
+    }
+    if (stamps64) PQ_HIP(hipMemcpy(stamps64, ts.p, 64 * sizeof(long long), hipMemcpyDeviceToHost));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return reps > 1 ? total / (reps - 1) * 1e3 : 0.0;
 }
 
 double microbench_hbm_copy(size_t bytes, int iters, hipStream_t s)

@@ -36,17 +36,23 @@ struct SyrkArgs {
     int fuse_nb = 0;            // order of the next diagonal block (<= 128)
     int fuse_kglobal = 0;       // global index of its first column
     int fuse_ldlt = 0;
-    int fuse_dbg_skip = 0;      // timing experiments only: skip the factorisation of the block
     int* fuse_info = nullptr;
     double* fuse_rdiag = nullptr;
+    double* fuse_dvec = nullptr;  // LDLT: D of the next panel (the per-k scale of the next trailing update), nullable
+    double* fuse_pack = nullptr;
+    long long* fuse_ts = nullptr; // debugging aid (PIQP_AMD_DBG_FUSED_TS): 72 shader-clock stamps of the workgroup that owns the next diagonal block  // operand pack of the next k_trsm_panel (FACTOR_PACK_DOUBLES), nullable
 };
 
 void launch_syrk(int epi, const SyrkArgs& args, hipStream_t s, double* split_ws = nullptr, size_t split_ws_doubles = 0);
 size_t syrk_split_workspace_doubles(int n, int kdim);
 void launch_assemble_no_g(int n, const double* Pf, const double* x_reg, const double* ATA, double dinv, double* C, hipStream_t s);
-void launch_potrf_diag(bool ldlt, double* A, int lda, int nb, int kglobal, int* info, double* rdiag, hipStream_t s);
-void launch_trsm_panel(bool ldlt, double* A, int lda, int k0, int nb, int n, const double* rdiag, hipStream_t s);
-void launch_extract_diag(const double* A, int lda, int k0, int nb, double* d, hipStream_t s);
+// diagonal block of order nb <= 128 at A: factor in place, reciprocal pivots to rdiag[kglobal..], D to dvec[0..nb) (LDLT, nullable), and the
+// operand pack of the panel solve (FACTOR_PACK_DOUBLES doubles, nullable: inverted 16 x 16 diagonal pieces + negated off-diagonal blocks)
+void launch_potrf_diag(bool ldlt, double* A, int lda, int nb, int kglobal, int* info, double* rdiag, double* dvec, double* pack, hipStream_t s, long long* ts = nullptr);
+// debugging aid: `reps` factorisations of a synthetic 128 x 128 block; average microseconds and the 64 shader-clock stamps of potrf_block
+double microbench_potrf_block(bool ldlt, int reps, long long* stamps64, hipStream_t s);
+// rows k0 + nb .. n of the panel at column k0:  A21 <- A21 L11^-T (D^-1), with the pack written by the factorisation of L11
+void launch_trsm_panel(bool ldlt, double* A, int lda, int k0, int nb, int n, const double* pack, const double* rdiag, hipStream_t s);
 size_t trsv_flag_ints(int n);
 size_t trsv_part_doubles(int n);
 void launch_trsv(const double* L, int ld, int n, double* x, const double* rdiag, bool ldlt, int* flags, double* part, hipStream_t s);
@@ -60,6 +66,7 @@ double microbench_mfma_f64(int iters, hipStream_t s);
 double microbench_hbm_copy(size_t bytes, int iters, hipStream_t s);
 
 constexpr int FACTOR_NB = 128;  // panel width of the blocked factorisation
+constexpr int FACTOR_PACK_DOUBLES = 36 * 256;
 
 }  // namespace dense
 }  // namespace pq

@@ -13,6 +13,7 @@
 //                              staged into LDS (saves the 134 MB write + read at n = m = 4096)
 //   data.P_utri/AT/GT          Pfull_ (symmetric completion), AT_, GT_ (device copies, refreshed by update_data)
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <stdexcept>
 #include <string>
@@ -184,6 +185,7 @@ private:
         const int sl = dense::gemv_n_slices(n_, m_ > 0 ? m_ : 1) + dense::gemv_n_slices(n_, p_ > 0 ? p_ : 1) + dense::gemv_n_slices(n_, n_);
         part_.alloc((size_t)sl * n_);
         split_ws_.alloc(dense::syrk_split_workspace_doubles(n_, m_ > 0 ? m_ : 1));
+        pack_.alloc(dense::FACTOR_PACK_DOUBLES);
         info_.alloc(1);
         info_h_.alloc(1);
         flags_.alloc(dense::trsv_flag_ints(n_));
@@ -191,6 +193,7 @@ private:
         if (const char* e = std::getenv("PIQP_AMD_TRSV")) use_persistent_trsv_ = std::string(e) != "steps";
         if (const char* e = std::getenv("PIQP_AMD_LOOKAHEAD")) lookahead_ = std::string(e) == "1";
         if (const char* e = std::getenv("PIQP_AMD_FUSED_POTRF")) fused_potrf_ = std::string(e) != "0";
+        if (const char* e = std::getenv("PIQP_AMD_DBG_FUSED_TS")) { dbg_panel_ = std::atoi(e); dbg_ts_.alloc(72); dbg_ts_.zero(st_); }
         make_aux_stream();
         x_reg_last_.zero(st_);
         fac_.zero(st_);
@@ -267,18 +270,21 @@ private:
             const int nb = (n_ - k < NB) ? n_ - k : NB;
             const int rs = n_ - k - nb;
             double* A11 = fac_.p + k + (size_t)k * n_;
-            if (!fused || k == 0) dense::launch_potrf_diag(ldlt_, A11, n_, nb, k, info_.p, rdiag_.p, st_);
+            if (!fused || k == 0) dense::launch_potrf_diag(ldlt_, A11, n_, nb, k, info_.p, rdiag_.p, dvec_.p + k, rs > 0 ? pack_.p : nullptr, st_);
             if (rs <= 0) break;
-            dense::launch_trsm_panel(ldlt_, fac_.p, n_, k, nb, n_, rdiag_.p, st_);
+            dense::launch_trsm_panel(ldlt_, fac_.p, n_, k, nb, n_, pack_.p, rdiag_.p, st_);
             dense::SyrkArgs a;
             a.n = rs; a.kdim = nb;
             a.A = fac_.p + (k + nb) + (size_t)k * n_; a.lda = n_;
             a.B = a.A; a.ldb = n_;
-            if (ldlt_) { dense::launch_extract_diag(fac_.p, n_, k, nb, dvec_.p + k, st_); a.w = dvec_.p + k; }
+            if (ldlt_) a.w = dvec_.p + k;  // D of this panel, written by its diagonal-block factorisation
             a.C = fac_.p + (k + nb) + (size_t)(k + nb) * n_; a.ldc = n_;
             if (fused) {
-                a.fuse_nb = rs < NB ? rs : NB; a.fuse_kglobal = k + nb; a.fuse_ldlt = ldlt_ ? 1 : 0; a.fuse_info = info_.p; a.fuse_rdiag = rdiag_.p; a.fuse_dbg_skip = std::getenv("PIQP_AMD_DBG_FUSE_SKIP") ? 1 : 0;
+                a.fuse_nb = rs < NB ? rs : NB; a.fuse_kglobal = k + nb; a.fuse_ldlt = ldlt_ ? 1 : 0; a.fuse_info = info_.p; a.fuse_rdiag = rdiag_.p; a.fuse_dvec = dvec_.p + k + nb;
+                a.fuse_pack = (rs - a.fuse_nb > 0) ? pack_.p : nullptr;
+                a.fuse_ts = (dbg_panel_ == p) ? dbg_ts_.p : nullptr;
                 dense::launch_syrk(dense::EPI_SUBTRACT_POTRF, a, st_);
+                if (a.fuse_ts) dump_fused_ts(p);
                 continue;
             }
             if (!la) {
@@ -305,6 +311,16 @@ private:
         }
         if (la && last_rest >= 0) PQ_HIP(hipStreamWaitEvent(st_, ev_rest_[last_rest], 0));
     }
+    // PIQP_AMD_DBG_FUSED_TS=<panel>: in-kernel timeline of the workgroup that updates and factors the next diagonal block, to stderr
+    void dump_fused_ts(int panel)
+    {
+        long long h[72];
+        PQ_HIP(hipMemcpyAsync(h, dbg_ts_.p, sizeof(h), hipMemcpyDeviceToHost, st_));
+        PQ_HIP(hipStreamSynchronize(st_));
+        std::fprintf(stderr, "[piqp_amd] fused panel %d (cycles): K loop %lld, tiles->LDS %lld, potrf_block %lld; potrf steps (factor/subst/update):", panel, h[1] - h[0], h[2] - h[1], h[3] - h[2]);
+        for (int k = 0; k < 8; ++k) std::fprintf(stderr, " %lld/%lld/%lld", h[8 + 8 * k + 1] - h[8 + 8 * k], h[8 + 8 * k + 3] - h[8 + 8 * k + 2], h[8 + 8 * k + 5] - h[8 + 8 * k + 4]);
+        std::fprintf(stderr, "\n");
+    }
     // llt.info() == Success (dense/kkt.hpp:83): one 4-byte read-back per factor call
     bool factor_status()
     {
@@ -317,11 +333,13 @@ private:
     bool ldlt_;
     double delta_ = 1.0;
     hipStream_t st_ = nullptr;
-    DBuf<double> Pfull_, Pdiag_, AT_, GT_, ATA_, fac_, z_reg_inv_, x_reg_last_, dvec_, part_, rdiag_, split_ws_;
+    DBuf<double> Pfull_, Pdiag_, AT_, GT_, ATA_, fac_, z_reg_inv_, x_reg_last_, dvec_, part_, rdiag_, split_ws_, pack_;
     DBuf<int> info_, flags_;
     DBuf<double> trsv_part_;
     HBuf<int> info_h_;
     StageProfiler prof_;
+    int dbg_panel_ = -1;
+    DBuf<long long> dbg_ts_;
     bool use_persistent_trsv_ = true;
     bool fused_potrf_ = true;  // PIQP_AMD_FUSED_POTRF=0: separate k_potrf_diag launches
     bool lookahead_ = false;  // cross-stream event latency on this stack exceeds the overlap gained (measured: 4.1 -> 4.6 ms at n = 4096)

@@ -1646,7 +1646,7 @@ private:
         auto cpl = [&](DBuf<long long>& d, const DBuf<long long>& s) { d.alloc(s.n ? s.n : 1); if (s.n) PQ_HIP(hipMemcpyAsync(d.p, s.p, s.bytes(), hipMemcpyDeviceToDevice, st_)); };
         ops_.clone_from(o.ops_, st_);
         cpd(vals_, o.vals_); cpd(fronts_, o.fronts_); cpd(rdiag_, o.rdiag_);
-        xp_.alloc(o.xp_.n); fvec_.alloc(o.fvec_.n); dvec_.alloc(o.dvec_.n);
+        xp_.alloc(o.xp_.n); fvec_.alloc(o.fvec_.n); dvec_.alloc(o.dvec_.n); dpack_.alloc(o.dpack_.n);
         cpi(diag_pos_, o.diag_pos_); cpi(P_, o.P_); cpi(level_sn_, o.level_sn_); cpi(top_pos_, o.top_pos_); top_flags_.alloc(o.top_flags_.n ? o.top_flags_.n : 1); top_flags_.zero(st_); cpi(solve_level_sn_, o.solve_level_sn_); cpi(solve_top_pos_, o.solve_top_pos_); solve_flags_.alloc(o.solve_flags_.n ? o.solve_flags_.n : 1); solve_flags_.zero(st_); ntop_solve_ = o.ntop_solve_; cpi(solve_pub_, o.solve_pub_); cpi(solve_walk_lo_, o.solve_walk_lo_); cpi(solve_walk_hi_, o.solve_walk_hi_); nwalk_solve_ = o.nwalk_solve_; cpi(solve_child_tp_, o.solve_child_tp_); crec_.alloc(o.crec_.n ? o.crec_.n : 1); if (o.crec_.n) PQ_HIP(hipMemcpyAsync(crec_.p, o.crec_.p, o.crec_.bytes(), hipMemcpyDeviceToDevice, st_)); cpi(top_walk_lo_, o.top_walk_lo_); cpi(top_walk_hi_, o.top_walk_hi_); ntopwalk_ = o.ntopwalk_; top_walk_cap_ = o.top_walk_cap_; cpi(fe_ptr_, o.fe_ptr_); cpi(fe_q_, o.fe_q_); cpi(fe_off_, o.fe_off_); cpi(fe_offp_, o.fe_offp_);
         snrec_.alloc(o.snrec_.n ? o.snrec_.n : 1); if (o.snrec_.n) PQ_HIP(hipMemcpyAsync(snrec_.p, o.snrec_.p, o.snrec_.bytes(), hipMemcpyDeviceToDevice, st_)); cpi(sn_first_, o.sn_first_); cpi(front_rows_ptr_, o.front_rows_ptr_); cpi(front_rows_, o.front_rows_);
         cpi(child_ptr_, o.child_ptr_); cpi(child_, o.child_); cpi(rel_ptr_, o.rel_ptr_); cpi(rel_, o.rel_);
@@ -2093,6 +2093,7 @@ private:
         fronts_.alloc(S_.front_doubles ? (size_t)S_.front_doubles : 1);
         rdiag_.alloc(N_); xp_.alloc(N_); fvec_.alloc(S_.front_rows.size() ? S_.front_rows.size() : 1);
         dvec_.alloc(dense::FACTOR_NB);
+        dpack_.alloc(dense::FACTOR_PACK_DOUBLES);
         info_.alloc(1); info_h_.alloc(1);
         // value maps K-index -> PKPt-index composed with the per-matrix maps (kkt_full.hpp:219-249)
         const int nzP = d->P_colptr[n_], nzA = p_ ? d->AT_colptr[p_] : 0, nzG = m_ ? d->GT_colptr[m_] : 0;
@@ -2169,11 +2170,10 @@ private:
         double* rd = rdiag_.p + S_.sn_first[s];
         for (int k = 0; k < w; k += NB) {
             const int nb = std::min(NB, w - k);
-            dense::launch_potrf_diag(true, F + k + (size_t)k * f, f, nb, S_.sn_first[s] + k, info_.p, rdiag_.p, st_);
             const int rs = f - k - nb;
+            dense::launch_potrf_diag(true, F + k + (size_t)k * f, f, nb, S_.sn_first[s] + k, info_.p, rdiag_.p, dvec_.p, rs > 0 ? dpack_.p : nullptr, st_);
             if (rs > 0) {
-                dense::launch_trsm_panel(true, F, f, k, nb, f, rd, st_);
-                dense::launch_extract_diag(F, f, k, nb, dvec_.p, st_);
+                dense::launch_trsm_panel(true, F, f, k, nb, f, dpack_.p, rd, st_);
                 dense::SyrkArgs a;
                 a.n = rs; a.kdim = nb;
                 a.A = F + (k + nb) + (size_t)k * f; a.lda = f; a.B = a.A; a.ldb = f; a.w = dvec_.p;
@@ -2192,7 +2192,7 @@ private:
     SubSchedule sched_, part_sched_;
     bool top_persistent_ = false;
     CscOperators ops_;
-    DBuf<double> vals_, fronts_, rdiag_, xp_, fvec_, dvec_;
+    DBuf<double> vals_, fronts_, rdiag_, xp_, fvec_, dvec_, dpack_;
     DBuf<int> fe_ptr_, fe_q_, fe_off_, fe_offp_, top_pos_, top_flags_, solve_level_sn_, solve_top_pos_, solve_flags_, solve_walk_lo_, solve_walk_hi_, solve_pub_;
     SubSchedule solve_sched_;
     int ntop_solve_ = 0, nwalk_solve_ = 0, solve_epoch_ = 0, solve_epoch_used_ = 0, factor_epoch_ = 0;

@@ -278,3 +278,22 @@ def test_assembly_split_k_tail_matches_numpy(hip):
     Pf = np.triu(P) + np.triu(P, 1).T
     ref = np.tril(Pf + np.diag(x_reg) + (G.T * (1.0 / z_reg)) @ G)
     assert np.abs(K - ref).max() <= 1e-12 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("kkt_solver", [0, 16])
+def test_accuracy_on_recorded_ipm_states_of_the_hardest_fixture(hip, orc, kkt_solver):
+    """qp_robot_arm_sqp ends at rho = delta = 1e-10 (the regularisation floor): the condensed matrix loses ~8 digits in ANY factorisation
+    (the oracle's relative residual is ~1e-8 there, far above the 1e-10 bar, which no implementation can meet on these states).  The device
+    panel solve multiplies by explicitly inverted 16 x 16 diagonal pieces (k_trsm_panel) instead of substituting, so the parity statement
+    that matters is checked on every recorded state of the oracle's solve: wherever both factorisations succeed, the device residual
+    (extended precision) is within one decimal digit of the oracle's on every state (the ratios scatter between 0.1 and 6 once both sit at
+    1e-7: rounding noise), within a factor 2 in the median, and meets the bar wherever the oracle does."""
+    from dense_replay import replay
+    rows = replay("qp_robot_arm_sqp", kkt_solver)
+    both = [(it, rh, ro) for it, rho, delta, okh, oko, rh, ro in rows if okh and oko]
+    assert len(both) >= 10
+    for it, rh, ro in both:
+        assert rh <= max(10.0 * ro, 1e-12), (it, rh, ro)
+        if ro <= 2.5e-11:
+            assert rh <= 1e-10, (it, rh, ro)
+    assert np.median([rh / ro for _, rh, ro in both]) <= 2.0

