@@ -7,7 +7,7 @@ A "step" is the KKT work of ONE interior-point iteration exactly as the referenc
 KKTSystem::solve.  Inputs (problem matrices, the interior (s,z) state, the right-hand sides) are resident
 in HBM before the timed region starts; calls go through the C-ABI in PQ_MEM_DEVICE pointer mode.
 
-  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W        (N>1: under torch.distributed.run, or alone -- it then starts the N ranks itself)
 
 Multi-GPU: the dense single-QP path does not shard (SURVEY.md 8e "replicas only"); with N ranks every
 rank factors+solves its own independent QP instance of the same shape (weak scaling, no data-path
@@ -27,6 +27,105 @@ PEAK_FP64_MFMA_TFLOPS = 78.6  # MI355X fp64 matrix peak (vendor sheet; measured 
 PEAK_HBM_GBS = 8000.0
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks ourselves (one per GPU, RCCL) as a child process
+    BEFORE anything here touches the GPU -- a process that has initialised HIP must never exec -- and leave with its exit code."""
+    if args.gpus <= 1 or "RANK" in os.environ or int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        return
+    import subprocess
+    port = 29500 + os.getpid() % 2000
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sys.exit(subprocess.run(cmd, env=env).returncode)
+
+
+def panel_update_flops(n, nb=128):
+    """algorithmic flops of the fused trailing-update launches of one factorisation (sum_k rs_k (rs_k + 1) nb, the
+    "panel update" of the north star) plus the diagonal blocks they factor (nb^3 / 3 each)"""
+    tot, launches = 0.0, 0
+    k = 0
+    while k + nb < n:
+        rs = n - k - nb
+        tot += float(rs) * (rs + 1) * nb + min(nb, rs) ** 3 / 3.0
+        launches += 1
+        k += nb
+    return tot, launches
+
+
+def pmc_traffic(kernel_key, n, m, p):
+    """HBM traffic of one launch of `kernel_key` from the committed rocprofv3 PMC passes of this workload (FETCH_SIZE / WRITE_SIZE in
+    separate passes, gfx950 correction applied, see the file); None when the file does not cover this shape.  Not measured in this run:
+    the source file and its commit are reported next to the number."""
+    path = os.path.join(ROOT, "profiles", "r02_pmc_dense_c2.json")
+    try:
+        pmc = json.load(open(path))
+        if (pmc["n"], pmc["m"], pmc["p"]) != (n, m, p):
+            return None, None
+        return pmc["per_launch"][kernel_key]["traffic_bytes"], f"profiles/r02_pmc_dense_c2.json ({pmc.get('collected', 'rocprofv3 --pmc passes of tools/prof_dense.py')})"
+    except Exception:  # noqa: BLE001
+        return None, None
+
+
+def dense_leg(piqp_amd, pd, torch, np, q, n, p, m, kkt_solver, refine, steps, warmup, rank, world, local_rank, dev, kernel_pass=0):
+    """times `steps` KKT steps (1 update_scalings_and_factor + 2 KKTSystem::solve) with every input resident in HBM; returns the raw figures"""
+    from qp_gen import random_vars
+    ksys = piqp_amd.KKTSystem(piqp_amd.Data(**q), piqp_amd.default_settings(kkt_solver=kkt_solver), device=local_rank)
+    backend = ksys.backend()
+    rng = np.random.default_rng(1000 + rank)
+    # two interior IPM states and rhs sets, alternated so no step re-reads its predecessor's vectors
+    states = [{k: torch.from_numpy(v).to(dev) for k, v in random_vars(n, p, m, rng, positive=True).items()} for _ in range(2)]
+    rhss = [{k: torch.from_numpy(v).to(dev) for k, v in random_vars(n, p, m, rng).items()} for _ in range(4)]
+    lhs = {k: torch.zeros_like(v) for k, v in rhss[0].items()}
+    rho, delta = 1e-6, 1e-4
+
+    def step(i):
+        ok = ksys.update_scalings_and_factor(refine, rho, delta, states[i & 1])
+        ok1, _ = ksys.solve(rhss[(2 * i) & 3], lhs)       # predictor
+        ok2, _ = ksys.solve(rhss[(2 * i + 1) & 3], lhs)   # corrector
+        return ok and ok1 and ok2
+
+    def barrier():
+        pd.barrier()
+        ksys.synchronize()
+        torch.cuda.synchronize()
+
+    for i in range(warmup):
+        assert step(i), "factorisation failed in warmup"
+    res, nrm = ksys.condensed_residual()  # parity gate (BASELINE.md section 3): relative KKT residual of the last solve
+    rel_res = res / nrm
+    assert rel_res <= 1e-10, f"KKT residual {rel_res:.3e} above 1e-10"
+    backend.set_profiling(1)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        ok = step(i)
+    barrier()
+    t1 = time.perf_counter()
+    assert ok
+    backend.set_profiling(0)
+    elapsed = pd.max_over_ranks(t1 - t0, device=dev if world > 1 else None)
+    prof = [backend.get_profile(s) for s in range(3)]
+    out = {"elapsed": elapsed, "rel_res": rel_res, "asm_ms": prof[0][0] / max(prof[0][1], 1), "fac_ms": prof[1][0] / max(prof[1][1], 1),
+           "sol_ms": prof[2][0] / max(prof[2][1], 1), "backend_solves_per_step": prof[2][1] / steps, "refine": ksys.last_solve_stats()}
+    if kernel_pass > 0:
+        # kernel-level brackets (hipEvents around every fused-update / panel-solve / sweep launch on the backend's stream) in a SEPARATE
+        # pass of the same steps right after the timed region: 62 extra event markers between dependent launches would cost the timed
+        # region ~0.1 ms per step
+        backend.set_profiling(2)
+        for i in range(kernel_pass):
+            step(i)
+        ksys.synchronize()
+        backend.set_profiling(0)
+        kp = [backend.get_profile(s) for s in range(6)]
+        out["kernels"] = {"fused_ms_per_step": kp[3][0] / kernel_pass, "fused_launches_per_step": kp[3][1] / kernel_pass,
+                          "trsm_ms_per_step": kp[4][0] / kernel_pass, "trsm_launches_per_step": kp[4][1] / kernel_pass,
+                          "sweeps_ms_per_solve": kp[5][0] / max(kp[5][1], 1), "assembly_ms_per_step": kp[0][0] / max(kp[0][1], 1)}
+    del ksys
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -39,9 +138,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--batch-total", type=int, default=8192, help="BASELINE configs[3]: number of MPC QPs in the batched leg (0 = skip)")
     ap.add_argument("--no-sparse-legs", action="store_true", help="skip the sparse C3 / C5-size KKT legs (BASELINE configs[2], configs[4])")
+    ap.add_argument("--no-extra-dense-legs", action="store_true", help="skip the dense_ldlt_no_pivot and refinement-on legs of configs[1]")
     ap.add_argument("--cpu-steps", type=int, default=0, help="0 = auto (about 10-30 s of CPU work)")
     ap.add_argument("--no-dist-c5", action="store_true", help="N > 1 only: skip the stage-partitioned single-QP leg (BASELINE configs[4])")
     args = ap.parse_args()
+    self_launch(args)
 
     # BASELINE configs[4] at N > 1: ONE n = 500k multistage QP, stage-partitioned over the ranks (tools/dist_c5.py).  It runs in child
     # processes with their own process group so that nothing in there can cost this run its JSON line; the children are started here,
@@ -64,78 +165,48 @@ def main():
     if world > 1:
         args.no_cpu_baseline = True  # the CPU baseline is a rank-0, N = 1 figure (torch.distributed.run also pins OMP_NUM_THREADS=1)
     dev = torch.device("cuda", local_rank)
-    from qp_gen import dense_strongly_convex_qp, random_vars
+    from qp_gen import dense_strongly_convex_qp
 
     n, p, m = args.n, args.p, args.m
     # synthetic QP of the BASELINE shape; one independent instance per rank (seed 43 + rank)
-    q = dense_strongly_convex_qp(n, p, m, seed=43 + rank, double_sided=True)
-    data = piqp_amd.Data(**q)
-    st = piqp_amd.default_settings(kkt_solver=args.kkt_solver)
-    ksys = piqp_amd.KKTSystem(data, st, device=local_rank)
-    backend = ksys.backend()
-
-    rng = np.random.default_rng(1000 + rank)
-    # two interior IPM states and rhs sets, alternated so no step re-reads its predecessor's vectors
-    states = [{k: torch.from_numpy(v).to(dev) for k, v in random_vars(n, p, m, rng, positive=True).items()} for _ in range(2)]
-    rhss = [{k: torch.from_numpy(v).to(dev) for k, v in random_vars(n, p, m, rng).items()} for _ in range(4)]
-    lhs = {k: torch.zeros_like(v) for k, v in rhss[0].items()}
-    rho, delta = 1e-6, 1e-4
-
-    def step(i):
-        ok = ksys.update_scalings_and_factor(False, rho, delta, states[i & 1])
-        ok1, _ = ksys.solve(rhss[(2 * i) & 3], lhs)       # predictor
-        ok2, _ = ksys.solve(rhss[(2 * i + 1) & 3], lhs)   # corrector
-        return ok and ok1 and ok2
-
-    def barrier():
-        pd.barrier()
-        ksys.synchronize()
-        torch.cuda.synchronize()
-
-    for i in range(args.warmup):
-        assert step(i), "factorisation failed in warmup"
-    # parity gate: relative KKT residual of the last solve
-    res, nrm = ksys.condensed_residual()
-    rel_res = res / nrm
-    assert rel_res <= 1e-10, f"KKT residual {rel_res:.3e} above 1e-10"
-
-    backend.set_profiling(True)
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        ok = step(i)
-    barrier()
-    t1 = time.perf_counter()
-    assert ok
-    backend.set_profiling(False)
-    elapsed = pd.max_over_ranks(t1 - t0, device=dev if world > 1 else None)
-    asm_ms, asm_cnt = backend.get_profile(0)
-    fac_ms, fac_cnt = backend.get_profile(1)
-    sol_ms, sol_cnt = backend.get_profile(2)
+    # (exact_shift=False: the diagonal shift that makes P positive definite comes from the semicircle law instead of an eigensolver run --
+    # round 1 ran torch.linalg.eigvalsh here and its rocSOLVER kernels polluted the rocprofv3 summaries of this command)
+    q = dense_strongly_convex_qp(n, p, m, seed=43 + rank, double_sided=True, exact_shift=False)
+    solver_name = {0: "dense_cholesky", 16: "dense_ldlt_no_pivot"}
+    main_leg = dense_leg(piqp_amd, pd, torch, np, q, n, p, m, args.kkt_solver, False, args.steps, args.warmup, rank, world, local_rank, dev, kernel_pass=5)
+    extra = {}
+    if not args.no_extra_dense_legs:
+        other = 16 if args.kkt_solver == 0 else 0
+        for key, ks, refine in ((solver_name[other], other, False), (solver_name[args.kkt_solver] + "+iterative_refinement", args.kkt_solver, True)):
+            extra[key] = dense_leg(piqp_amd, pd, torch, np, q, n, p, m, ks, refine, max(5, args.steps // 2), 2, rank, world, local_rank, dev, kernel_pass=3)
 
     if rank == 0:
+        L = piqp_amd._lib.load()
+        import ctypes as C
+        tf, gb = C.c_double(), C.c_double()
+        L.pq_microbench_mfma_f64(local_rank, 4000, C.byref(tf))
+        L.pq_microbench_hbm_copy(local_rank, 1 << 30, 10, C.byref(gb))
+        elapsed = main_leg["elapsed"]
         ms_per_step = elapsed / args.steps * 1e3
         value = world * args.steps / elapsed
-        # dominant kernel: k_syrk_lower<ASSEMBLE>; algorithmic flops per launch = n(n+1)m
-        flops_asm = float(n) * (n + 1) * m
-        asm_avg_s = asm_ms / max(asm_cnt, 1) * 1e-3
-        achieved = flops_asm / asm_avg_s / 1e12 if asm_avg_s > 0 else 0.0
+        kk = main_leg["kernels"]
+        flops_asm = float(n) * (n + 1) * m                    # k_syrk_lower<EPI_ASSEMBLE>, SURVEY.md 8d (C2)
+        flops_upd, upd_launches = panel_update_flops(n)       # all fused trailing-update launches of one factorisation
         flops_llt = n ** 3 / 3.0
-        fac_avg_s = fac_ms / max(fac_cnt, 1) * 1e-3
-        traffic = None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_dense_c2.json")))
-            if (pmc["n"], pmc["m"], pmc["p"]) == (n, m, p):
-                traffic = pmc["assembly_per_step"]["traffic_bytes"]  # rocprofv3 PMC passes of this same workload (see file)
-        except Exception:
-            pass
-        mfma_busy = None
-        try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_dense_mfma.json")))
-            if (n, m, p) == (4096, 4096, 0):
-                mfma_busy = [v for k, v in pm.items() if k.startswith("k_syrk_lower<EPI_ASSEMBLE")][0]["mfma_pipe_busy_fraction"]
-        except Exception:  # noqa: BLE001
-            pass
+        asm_s = main_leg["asm_ms"] * 1e-3
+        upd_s = kk["fused_ms_per_step"] * 1e-3
+
+        def roof(kernel, flops_per_step, secs_per_step, launches_per_step, key):
+            traffic, src = pmc_traffic(key, n, m, p)
+            ach = flops_per_step / secs_per_step / 1e12 if secs_per_step > 0 else 0.0
+            return {"bound": "mfma", "kernel": kernel, "achieved": ach, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP64_MFMA_TFLOPS,
+                    "traffic": traffic, "traffic_source": src, "alg_flops_per_launch": flops_per_step / max(launches_per_step, 1),
+                    "avg_launch_ms": secs_per_step * 1e3 / max(launches_per_step, 1), "launches_per_step": launches_per_step, "ms_per_step": secs_per_step * 1e3,
+                    "frac_of_measured_mfma_peak": ach / tf.value if tf.value > 0 else None}
+        r_asm = roof("k_syrk_lower<EPI_ASSEMBLE> (dense/kkt.hpp:140-160 update_kkt); hipEvent-bracketed in the timed region", flops_asm, asm_s, 1, "assembly")
+        r_upd = roof("k_syrk_lower<EPI_SUBTRACT_POTRF> = trailing (panel) update of the factorisation + next diagonal block (dense/ldlt_no_pivot.hpp:313-354, "
+                     "Eigen::LLT at dense/kkt.hpp:82); hipEvent-bracketed per launch in a separate pass of the same steps", flops_upd, upd_s, upd_launches, "panel_update")
+        dominant, secondary = (r_upd, r_asm) if upd_s >= asm_s else (r_asm, r_upd)
         out = {
             "metric": "KKT factor+solve/sec (per IPM iter)",
             "value": value,
@@ -147,19 +218,28 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"dense QP n={n} p={p} m_ineq={m} (BASELINE configs[1]), kkt_solver={'dense_cholesky' if args.kkt_solver == 0 else 'dense_ldlt_no_pivot'}, "
+            "config": {"workload": f"dense QP n={n} p={p} m_ineq={m} (BASELINE configs[1]), kkt_solver={solver_name[args.kkt_solver]}, "
                                    "1 update_scalings_and_factor + 2 KKTSystem::solve per step, inputs resident in HBM",
                        "n": n, "p": p, "m": m, "parallelism": f"independent QP replicas x{world}"},
-            "roofline": {"bound": "mfma", "kernel": "k_syrk_lower<EPI_ASSEMBLE> (dense/kkt.hpp:140-160)",
-                         "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic,
-                         "alg_flops_per_launch": flops_asm, "avg_launch_ms": asm_avg_s * 1e3, "launches": asm_cnt,
-                         "mfma_pipe_busy_frac_pmc": mfma_busy},
-            "stages": {"assembly_ms": asm_avg_s * 1e3, "factorisation_ms": fac_avg_s * 1e3,
-                       "factorisation_tflops": flops_llt / fac_avg_s / 1e12 if fac_avg_s > 0 else 0.0,
-                       "backend_solve_ms": sol_ms / max(sol_cnt, 1)},
-            "parity": {"rel_kkt_residual": rel_res, "tolerance": 1e-10},
+            "roofline": dominant,            # the kernel that takes the most time per step
+            "roofline_secondary": secondary,
+            "measured_peaks": {"fp64_mfma_tflops": tf.value, "hbm_copy_gbs": gb.value,
+                               "note": "pq_microbench_mfma_f64 (register-resident v_mfma_f64_16x16x4 stream on every SIMD) and pq_microbench_hbm_copy (1 GiB, read + write) "
+                                       "on this box; roofline.peak stays the vendor sheet figure"},
+            "stages": {"assembly_ms": main_leg["asm_ms"], "factorisation_ms": main_leg["fac_ms"],
+                       "factorisation_tflops": flops_llt / (main_leg["fac_ms"] * 1e-3) / 1e12 if main_leg["fac_ms"] > 0 else 0.0,
+                       "backend_solve_ms": main_leg["sol_ms"], "panel_update_ms": kk["fused_ms_per_step"], "panel_solve_ms": kk["trsm_ms_per_step"],
+                       "triangular_sweeps_ms_per_solve": kk["sweeps_ms_per_solve"],
+                       "step_tflops": (flops_asm + flops_llt) / (ms_per_step * 1e-3) / 1e12},
+            "parity": {"rel_kkt_residual": main_leg["rel_res"], "tolerance": 1e-10},
         }
+        for key, leg in extra.items():
+            st = max(5, args.steps // 2)
+            out.setdefault("dense_legs", {})[key] = {
+                "value": world * st / leg["elapsed"], "unit": out["unit"], "ms_per_step": leg["elapsed"] / st * 1e3, "assembly_ms": leg["asm_ms"],
+                "factorisation_ms": leg["fac_ms"], "backend_solve_ms": leg["sol_ms"], "backend_solves_per_step": leg["backend_solves_per_step"],
+                "rel_kkt_residual": leg["rel_res"], "last_solve": leg["refine"], "panel_update_ms": leg["kernels"]["fused_ms_per_step"],
+                "panel_solve_ms": leg["kernels"]["trsm_ms_per_step"]}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(q, n, p, m, args)
             if out["cpu_baseline"].get("value"):
@@ -370,7 +450,40 @@ def batched_qp(args, rank, world, local_rank, dev, pd):
                                "sample": f"solve() of the first {sample} instances (setup excluded), oracle built with gcc -O3, 1 thread", "seconds": el_cpu}
         res["iteration_count_parity_on_sample"] = same
         res["speedup_vs_cpu_core"] = res["strong"]["qp_per_s"] / (sample / el_cpu)
+        # ... and on ALL host cores: one process per core, each with its own solver objects (how a PIQP user parallelises independent QPs:
+        # the reference has no batch API).  Processes, not threads: spawned interpreters that never touch the GPU.
+        try:
+            import multiprocessing as mp
+            cores = len(os.sched_getaffinity(0))
+            per = 64
+            with mp.get_context("spawn").Pool(cores) as pool:
+                rows = pool.map(_cpu_batch_worker, [(1000 + 7919 * w, per) for w in range(cores)])
+            el_all = max(r[0] for r in rows)
+            nsolved = sum(r[1] for r in rows)
+            res["cpu_baseline_all_cores"] = {"value": cores * per / el_all, "unit": "QP solves/s", "cores": cores, "kind": "port",
+                                             "sample": f"{cores} processes x {per} QPs of the same recipe (own seeds), solve() only, slowest process's time; {nsolved} solved",
+                                             "seconds": el_all}
+            res["speedup_vs_cpu_all_cores"] = res["strong"]["qp_per_s"] / (cores * per / el_all)
+        except Exception as e:  # noqa: BLE001
+            res["cpu_baseline_all_cores"] = {"error": str(e)}
     return res
+
+
+def _cpu_batch_worker(job):
+    """one host process of the all-cores CPU baseline of the batched leg: `count` MPC QPs of the C4 recipe through the oracle (no GPU, no torch)"""
+    seed, count = job
+    from oracle import pyorc
+    from qp_gen import mpc_batch, mpc_instance
+    mb = mpc_batch(count, seed=seed)
+    solvers = []
+    for i in range(count):
+        so = pyorc.Solver(); so.settings.kkt_solver = pyorc.SPARSE_MULTISTAGE
+        so.setup(*mpc_instance(mb, i), sparse=True)
+        solvers.append(so)
+    [so.solve() for so in solvers]  # warm
+    t0 = time.perf_counter()
+    st = [so.solve() for so in solvers]
+    return time.perf_counter() - t0, sum(1 for v in st if v == 1)
 
 
 def dense_strongly_convex_qp_small():

@@ -214,7 +214,9 @@ int pq_sparse_partition_plan(const pq_sparse_data *data, int mode, int world, in
 
 /* measurement hooks: when enabled, the backend brackets its stages with hipEvents on its own stream.
  * stage 0 = KKT assembly kernel (dense: k_syrk_lower<ASSEMBLE>), 1 = factorisation (all panels),
- * 2 = backend solve.  pq_kkt_get_profile returns the accumulated milliseconds / call count and resets them. */
+ * 2 = backend solve.  enable = 2 (dense backend, measurement passes only) also brackets individual launches: 3 = fused trailing update +
+ * next diagonal block, 4 = panel solve, 5 = both triangular sweeps.  pq_kkt_get_profile returns the accumulated milliseconds / call count
+ * and resets them. */
 int pq_kkt_set_profiling(pq_kkt *k, int enable);
 int pq_kkt_get_profile(pq_kkt *k, int stage, double *total_ms, int *count);
 

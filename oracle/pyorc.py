@@ -543,3 +543,4 @@ class Solver:
         r = self.L.orc_solver_result(self.ptr).contents
         sizes = dict(x=d.n, y=d.p, z_l=d.m, z_u=d.m, z_bl=d.n, z_bu=d.n, s_l=d.m, s_u=d.m, s_bl=d.n, s_bu=d.n)
         return {k: _view(getattr(r, k), sizes[k]).copy() for k in VAR_NAMES}
+

@@ -309,7 +309,7 @@ int pq_kkt_internal_factor(pq_kkt* k, double* out_host)
 int pq_kkt_set_profiling(pq_kkt* k, int enable)
 {
     if (!k) return fail(PQ_ERR_INVALID, "null argument");
-    return guarded([&] { k->impl->set_profiling(enable != 0); return (int)PQ_OK; });
+    return guarded([&] { k->impl->set_profiling(enable); return (int)PQ_OK; });
 }
 int pq_kkt_get_profile(pq_kkt* k, int stage, double* total_ms, int* count)
 {

@@ -128,8 +128,9 @@ inline int div_up(int a, int b) { return (a + b - 1) / b; }
 // hipEvent brackets around stages of a backend, accumulated lazily (events are read at query time,
 // after the stream has been synchronised; nothing here blocks the timed region)
 struct StageProfiler {
-    static constexpr int NSTAGE = 3;
+    static constexpr int NSTAGE = 6;  // 0..2 stages of a backend; 3..5 kernel-level brackets of the dense backend (level 2)
     bool enabled = false;
+    int level = 0;  // 2: also bracket individual launches (adds event markers between dependent kernels: measurement passes only)
     struct Pair { hipEvent_t a, b; };
     std::vector<Pair> pending[NSTAGE], pool;
     ~StageProfiler()
@@ -147,7 +148,7 @@ struct StageProfiler {
     }
     int begin(int stage, hipStream_t s)
     {
-        if (!enabled) return -1;
+        if (!enabled || (stage >= 3 && level < 2)) return -1;
         Pair p = get();
         PQ_HIP(hipEventRecord(p.a, s));
         pending[stage].push_back(p);

@@ -94,7 +94,7 @@ public:
         if (p_ > 0) nsl += dense::launch_gemv_n_partial(n_, p_, AT_.p, n_, rhs_y, nullptr, delta_inv, part_.p + (size_t)nsl * n_, st_);
         dense::launch_reduce_partials(n_, nsl, part_.p, rhs_x, lhs_x, st_);
         // solve_ldlt_in_place: llt.solveInPlace(lhs_x)
-        dense::launch_trsv(fac_.p, n_, n_, lhs_x, rdiag_.p, ldlt_, use_persistent_trsv_ ? flags_.p : nullptr, trsv_part_.p, st_);
+        { const int tt = prof_.begin(5, st_); dense::launch_trsv(fac_.p, n_, n_, lhs_x, rdiag_.p, ldlt_, use_persistent_trsv_ ? flags_.p : nullptr, trsv_part_.p, st_); prof_.end(5, tt, st_); }
         // lhs_y = delta_inv * AT^T lhs_x - delta_inv * rhs_y
         if (p_ > 0) dense::launch_gemv_t(n_, p_, AT_.p, n_, lhs_x, delta_inv, -delta_inv, rhs_y, nullptr, lhs_y, st_);
         // lhs_z = (GT^T lhs_x - rhs_z) o z_reg_inv
@@ -148,7 +148,7 @@ public:
         PQ_HIP(hipMemcpyAsync(out_host, tmp.p, sizeof(double) * (size_t)n_ * n_, hipMemcpyDeviceToHost, st_));
         PQ_HIP(hipStreamSynchronize(st_));
     }
-    void set_profiling(bool on) override { prof_.enabled = on; }
+    void set_profiling(int level) override { prof_.enabled = level != 0; prof_.level = level; }
     void get_profile(int stage, double* total_ms, int* count) override
     {
         if (stage < 0 || stage >= StageProfiler::NSTAGE) throw std::runtime_error("bad stage");
@@ -272,7 +272,7 @@ private:
             double* A11 = fac_.p + k + (size_t)k * n_;
             if (!fused || k == 0) dense::launch_potrf_diag(ldlt_, A11, n_, nb, k, info_.p, rdiag_.p, dvec_.p + k, rs > 0 ? pack_.p : nullptr, st_);
             if (rs <= 0) break;
-            dense::launch_trsm_panel(ldlt_, fac_.p, n_, k, nb, n_, pack_.p, rdiag_.p, st_);
+            { const int tt = prof_.begin(4, st_); dense::launch_trsm_panel(ldlt_, fac_.p, n_, k, nb, n_, pack_.p, rdiag_.p, st_); prof_.end(4, tt, st_); }
             dense::SyrkArgs a;
             a.n = rs; a.kdim = nb;
             a.A = fac_.p + (k + nb) + (size_t)k * n_; a.lda = n_;
@@ -283,7 +283,7 @@ private:
                 a.fuse_nb = rs < NB ? rs : NB; a.fuse_kglobal = k + nb; a.fuse_ldlt = ldlt_ ? 1 : 0; a.fuse_info = info_.p; a.fuse_rdiag = rdiag_.p; a.fuse_dvec = dvec_.p + k + nb;
                 a.fuse_pack = (rs - a.fuse_nb > 0) ? pack_.p : nullptr;
                 a.fuse_ts = (dbg_panel_ == p) ? dbg_ts_.p : nullptr;
-                dense::launch_syrk(dense::EPI_SUBTRACT_POTRF, a, st_);
+                { const int tt = prof_.begin(3, st_); dense::launch_syrk(dense::EPI_SUBTRACT_POTRF, a, st_); prof_.end(3, tt, st_); }
                 if (a.fuse_ts) dump_fused_ts(p);
                 continue;
             }

@@ -55,7 +55,7 @@ public:
     }
     virtual void partition_info(int out[8]) const { (void)out; throw std::runtime_error("partition_info: not supported by this backend"); }
     // measurement hooks (hipEvent brackets on the backend's stream)
-    virtual void set_profiling(bool on) { (void)on; }
+    virtual void set_profiling(int level) { (void)level; }
     virtual void get_profile(int stage, double* total_ms, int* count) { (void)stage; *total_ms = 0.0; *count = 0; }
 };
 

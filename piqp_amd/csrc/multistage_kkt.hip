@@ -249,7 +249,7 @@ public:
     int m() const override { return m_; }
     hipStream_t stream() const override { return st_; }
     int device() const override { return dev_; }
-    void set_profiling(bool on) override { prof_.enabled = on; }
+    void set_profiling(int level) override { prof_.enabled = level != 0; }
     void get_profile(int stage, double* total_ms, int* count) override
     {
         if (stage < 0 || stage >= StageProfiler::NSTAGE) throw std::runtime_error("bad stage");
