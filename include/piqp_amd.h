@@ -203,6 +203,16 @@ typedef int (*pq_exchange_fn)(void *user, int which);
 int pq_kkt_partition(pq_kkt *k, int rank, int world, long long sizes_out[3]);
 int pq_kkt_set_exchange(pq_kkt *k, pq_exchange_fn exchange, void *user, double *buf_factor, double *buf_forward,
                         double *buf_gather);
+/* Native transport (the north star's "RCCL over xGMI"): instead of a callback the library creates its own communicator and enqueues the three
+ * collectives -- ncclAllReduce(sum, fp64) for which = 0, 1 and ncclAllGather for which = 2 -- on the handle's stream, right behind the kernels that
+ * pack its own exchange buffers: no stream drain, no host round trip.  Rank 0 obtains the 128-byte id (pq_rccl_unique_id = ncclGetUniqueId) and
+ * ships it to the other ranks by any means (MPI_Bcast, a file, torch.distributed.broadcast_object_list in piqp_amd/dist.py); then EVERY rank calls
+ * pq_kkt_set_comm_rccl after pq_kkt_partition with the rank / world it partitioned with (collective: ncclCommInitRank).  One process per GPU.
+ * librccl is loaded with dlopen at the first of these calls; single-GPU use never needs it. */
+int pq_rccl_unique_id(unsigned char id_out[128]);
+int pq_kkt_set_comm_rccl(pq_kkt *k, const unsigned char id[128], int rank, int world);
+/* collectives the native transport has enqueued so far: out[which] for which = 0, 1, 2 (test / bench bookkeeping) */
+int pq_kkt_native_exchange_calls(pq_kkt *k, int out[3]);
 /* what the partition looks like: out[0] = supernodes owned by this rank, out[1] = shared supernodes, out[2] = boundary
  * subtree roots, out[3..4] = this rank's column span, out[5] = work share of this rank in permille, out[6] = shared
  * (replicated) work in permille */
@@ -287,6 +297,8 @@ int pq_solver_trace_rows(const pq_solver *s);
 int pq_solver_partition(pq_solver *s, int rank, int world, long long sizes_out[3]);
 int pq_solver_set_exchange(pq_solver *s, pq_exchange_fn exchange, void *user, double *buf_factor, double *buf_forward,
                            double *buf_gather);
+int pq_solver_set_comm_rccl(pq_solver *s, const unsigned char id[128], int rank, int world);
+int pq_solver_native_exchange_calls(pq_solver *s, int out[3]);
 
 /* ===================== Batched solver: many structurally identical sparse QPs in one launch ===================== */
 /* The reference has no batch API (one SolverBase per QP, solver.hpp:42); this is the device-side equivalent of

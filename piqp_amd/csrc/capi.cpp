@@ -6,6 +6,7 @@
 
 #include "dense_kernels.hpp"
 #include "kkt_solver_base.hpp"
+#include "rccl_transport.hpp"
 #include "kkt_system.hpp"
 #include "sparse_symbolic.hpp"
 #include "solver.hpp"
@@ -341,6 +342,21 @@ int pq_kkt_set_exchange(pq_kkt* k, pq_exchange_fn exchange, void* user, double* 
 {
     if (!k) return fail(PQ_ERR_INVALID, "null argument");
     return guarded([&] { k->impl->set_exchange(exchange, user, buf_factor, buf_forward, buf_gather); return (int)PQ_OK; });
+}
+int pq_rccl_unique_id(unsigned char out[128])
+{
+    if (!out) return fail(PQ_ERR_INVALID, "null output");
+    return guarded([&] { rccl::unique_id(out); return (int)PQ_OK; });
+}
+int pq_kkt_set_comm_rccl(pq_kkt* k, const unsigned char id[128], int rank, int world)
+{
+    if (!k || !id) return fail(PQ_ERR_INVALID, "null argument");
+    return guarded([&] { k->impl->set_comm_rccl(id, rank, world); return (int)PQ_OK; });
+}
+int pq_kkt_native_exchange_calls(pq_kkt* k, int out[3])
+{
+    if (!k || !out) return fail(PQ_ERR_INVALID, "null argument");
+    return guarded([&] { k->impl->native_exchange_calls(out); return (int)PQ_OK; });
 }
 int pq_kkt_partition_info(pq_kkt* k, int out[8])
 {

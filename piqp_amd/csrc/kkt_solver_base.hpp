@@ -53,6 +53,9 @@ public:
         (void)fn; (void)user; (void)buf_factor; (void)buf_forward; (void)buf_gather;
         throw std::runtime_error("set_exchange: not supported by this backend");
     }
+    // native transport: the library issues the RCCL collectives itself on its stream (pq_kkt_set_comm_rccl)
+    virtual void set_comm_rccl(const unsigned char* id128, int rank, int world) { (void)id128; (void)rank; (void)world; throw std::runtime_error("set_comm_rccl: not supported by this backend"); }
+    virtual void native_exchange_calls(int out[3]) const { out[0] = out[1] = out[2] = 0; }
     virtual void partition_info(int out[8]) const { (void)out; throw std::runtime_error("partition_info: not supported by this backend"); }
     // measurement hooks (hipEvent brackets on the backend's stream)
     virtual void set_profiling(int level) { (void)level; }

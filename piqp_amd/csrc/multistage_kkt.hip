@@ -213,7 +213,7 @@ public:
         tree_->sparse_stats(out);
     }
     // stage partition over several processes: the stage-parallel (tree) engine carries it; the serial recurrence cannot be split.
-    // The engine choice of make_multistage_kkt is a timing probe, so partitioned runs force it (PIQP_AMD_MULTISTAGE=tree) to keep
+    // The engine is chosen by a symbolic cost model (make_multistage_kkt); partitioned runs may force it (PIQP_AMD_MULTISTAGE=tree) to keep
     // every rank on the same code path.
     void partition(int rank, int world, long long sizes[3]) override
     {
@@ -225,6 +225,12 @@ public:
         if (!tree_) throw std::runtime_error("set_exchange: not partitioned");
         tree_->set_exchange(fn, user, buf_factor, buf_forward, buf_gather);
     }
+    void set_comm_rccl(const unsigned char* id128, int rank, int world) override
+    {
+        if (!tree_) throw std::runtime_error("set_comm_rccl: not partitioned");
+        tree_->set_comm_rccl(id128, rank, world);
+    }
+    void native_exchange_calls(int out[3]) const override { if (tree_) tree_->native_exchange_calls(out); else out[0] = out[1] = out[2] = 0; }
     void partition_info(int out[8]) const override
     {
         if (!tree_) throw std::runtime_error("partition_info: not partitioned");

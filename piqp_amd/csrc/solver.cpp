@@ -1260,6 +1260,16 @@ int pq_solver_partition(pq_solver* s, int rank, int world, long long sizes_out[3
     if (!s || !sizes_out || !s->impl->backend()) return fail(PQ_ERR_INVALID, "solver not set up");
     return guarded([&] { s->impl->backend()->partition(rank, world, sizes_out); return (int)PQ_OK; });
 }
+int pq_solver_native_exchange_calls(pq_solver* s, int out[3])
+{
+    if (!s || !out) return fail(PQ_ERR_INVALID, "null argument");
+    return guarded([&] { s->impl->backend()->native_exchange_calls(out); return (int)PQ_OK; });
+}
+int pq_solver_set_comm_rccl(pq_solver* s, const unsigned char id[128], int rank, int world)
+{
+    if (!s || !id) return fail(PQ_ERR_INVALID, "null argument");
+    return guarded([&] { s->impl->backend()->set_comm_rccl(id, rank, world); return (int)PQ_OK; });
+}
 int pq_solver_set_exchange(pq_solver* s, pq_exchange_fn exchange, void* user, double* buf_factor, double* buf_forward, double* buf_gather)
 {
     if (!s || !s->impl->backend()) return fail(PQ_ERR_INVALID, "solver not set up");

@@ -21,6 +21,7 @@
 #include "dense_kernels.hpp"
 #include "kkt_solver_base.hpp"
 #include "sparse_ops.hpp"
+#include "rccl_transport.hpp"
 #include "sparse_symbolic.hpp"
 
 namespace pq {
@@ -1394,6 +1395,7 @@ public:
     {
         (void)hipSetDevice(dev_);
         if (st_) { (void)hipStreamSynchronize(st_); }
+        if (comm_) rccl::comm_destroy(comm_);
         if (factor_graph_) (void)hipGraphExecDestroy(factor_graph_);
         if (solve_graph_) (void)hipGraphExecDestroy(solve_graph_);
         if (st_) (void)hipStreamDestroy(st_);
@@ -1498,7 +1500,7 @@ public:
             bwd_levels(M, sh_ptr_, sh_sn_, sh_sn_d_.p);
             bwd_levels(M, own_ptr_, own_sn_, own_sn_d_.p);
             subtree_bwd(M, part_sched_);
-            if (world_ > 1 || (std::getenv("PIQP_AMD_EXCHANGE_WORLD1") && xfn_)) {
+            if (world_ > 1 || (std::getenv("PIQP_AMD_EXCHANGE_WORLD1") && (xfn_ || comm_))) {
                 const int lo = PT_.span_lo[rank_], hi = PT_.span_hi[rank_];
                 if (hi > lo) hipLaunchKernelGGL(k_pack_span, g1(hi - lo), dim3(256), 0, st_, lo, hi, xp_.p, xbuf_gather_ + (size_t)rank_ * PT_.max_span);
                 exchange(2);
@@ -1590,6 +1592,20 @@ public:
         if (world_ > 1 && (!fn || !buf_factor || !buf_forward || !buf_gather)) throw std::runtime_error("set_exchange: null argument");
         xfn_ = fn; xuser_ = user; xbuf_factor_ = buf_factor; xbuf_forward_ = buf_forward; xbuf_gather_ = buf_gather;
     }
+    // pq_kkt_set_comm_rccl: from here on the three exchanges are ncclAllReduce / ncclAllGather calls enqueued on st_ behind the kernels that
+    // fill the library's own exchange buffers -- no stream drain, no host callback
+    void set_comm_rccl(const unsigned char* id128, int rank, int world) override
+    {
+        if (!part_on_) throw std::runtime_error("set_comm_rccl: call pq_kkt_partition first");
+        if (rank != rank_ || world != world_) throw std::runtime_error("set_comm_rccl: rank / world differ from pq_kkt_partition");
+        if (comm_) { rccl::comm_destroy(comm_); comm_ = nullptr; }
+        comm_ = rccl::comm_create(id128, rank, world, dev_);
+        own_factor_.alloc((size_t)PT_.bmat_off.back() + 1); own_forward_.alloc((size_t)std::max(1, PT_.bvec_off.back())); own_gather_.alloc((size_t)world_ * std::max(1, PT_.max_span));
+        own_factor_.zero(st_); own_forward_.zero(st_); own_gather_.zero(st_);
+        PQ_HIP(hipStreamSynchronize(st_));
+        xfn_ = nullptr; xbuf_factor_ = own_factor_.p; xbuf_forward_ = own_forward_.p; xbuf_gather_ = own_gather_.p;
+    }
+    void native_exchange_calls(int out[3]) const override { for (int q = 0; q < 3; ++q) out[q] = native_calls_[q]; }
     void partition_info(int out[8]) const override
     {
         if (!part_on_) throw std::runtime_error("partition_info: not partitioned");
@@ -1836,8 +1852,16 @@ private:
         // a one-rank group has nothing to exchange; PIQP_AMD_EXCHANGE_WORLD1=1 still goes through the callback (a 1-GPU box can then
         // exercise the caller's RCCL transport end to end)
         static const bool force1 = std::getenv("PIQP_AMD_EXCHANGE_WORLD1") != nullptr;
-        if (world_ == 1 && !(force1 && xfn_)) return;
-        if (!xfn_) throw std::runtime_error("partitioned backend used before pq_kkt_set_exchange");
+        if (world_ == 1 && !(force1 && (xfn_ || comm_))) return;
+        if (comm_) {
+            // native transport: stream-ordered behind the pack kernel, the unpack kernel follows on the same stream
+            if (which == 0) rccl::all_reduce_sum(comm_, xbuf_factor_, (size_t)PT_.bmat_off.back() + 1, st_);
+            else if (which == 1) rccl::all_reduce_sum(comm_, xbuf_forward_, (size_t)std::max(1, PT_.bvec_off.back()), st_);
+            else rccl::all_gather(comm_, xbuf_gather_, (size_t)std::max(1, PT_.max_span), rank_, st_);
+            ++native_calls_[which];
+            return;
+        }
+        if (!xfn_) throw std::runtime_error("partitioned backend used before pq_kkt_set_exchange / pq_kkt_set_comm_rccl");
         PQ_HIP(hipStreamSynchronize(st_));
         if (xfn_(xuser_, which) != 0) throw std::runtime_error("exchange callback failed");
     }
@@ -2219,6 +2243,9 @@ private:
     DBuf<int> own_sn_d_, sh_sn_d_, b_sn_, b_owner_, b_vec_off_, span_lo_d_, span_hi_d_;
     DBuf<long long> b_mat_off_;
     pq_exchange_fn xfn_ = nullptr;
+    rccl::Comm* comm_ = nullptr;  // native RCCL transport (pq_kkt_set_comm_rccl); the exchange buffers below are then the library's own
+    DBuf<double> own_factor_, own_forward_, own_gather_;
+    int native_calls_[3] = {0, 0, 0};
     void* xuser_ = nullptr;
     double *xbuf_factor_ = nullptr, *xbuf_forward_ = nullptr, *xbuf_gather_ = nullptr;
 };

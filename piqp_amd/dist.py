@@ -106,7 +106,7 @@ class StagePartition:
     themselves are torch.distributed calls on device tensors -- RCCL over xGMI with the "nccl" backend, host-staged with
     "gloo" (the CPU-rendezvous tests, where several ranks share one GPU)."""
 
-    def __init__(self, obj, rank=None, world=None, group=None):
+    def __init__(self, obj, rank=None, world=None, group=None, native=None):
         import ctypes as C
 
         import torch
@@ -131,10 +131,25 @@ class StagePartition:
         self.buf_forward = torch.zeros(self.sizes[1], dtype=torch.float64, device=dev)
         self.buf_gather = torch.zeros(self.world * self.sizes[2], dtype=torch.float64, device=dev)
         self.calls = [0, 0, 0]
+        # native = True: the library's own RCCL transport (pq_kkt_set_comm_rccl: collectives enqueued on the handle's stream, no callback).
+        # Default: native whenever the process group runs on RCCL ("nccl"), i.e. one GPU per rank; the callback path below remains for gloo
+        # (several ranks sharing one GPU in the CPU-rendezvous tests) and as the reference implementation of the protocol.
+        self.native = (self.backend == "nccl" and os.environ.get("PIQP_AMD_CALLBACK_EXCHANGE") is None) if native is None else bool(native)
         self.error = None
         self._cb = _lib.EXCHANGE_FN(self._exchange)  # must outlive the handle's use of it
         self._obj = obj
-        _lib.check(setx(h, self._cb, None, self.buf_factor.data_ptr(), self.buf_forward.data_ptr(), self.buf_gather.data_ptr()), "set_exchange")
+        if self.native:
+            idb = (C.c_ubyte * 128)()
+            if self.rank == 0:
+                _lib.check(L.pq_rccl_unique_id(idb), "rccl_unique_id")
+            box = [bytes(idb)]
+            if on and self.world > 1:
+                dist.broadcast_object_list(box, src=0, group=group, device=dev if self.backend == "nccl" else None)
+            idb = (C.c_ubyte * 128).from_buffer_copy(box[0])
+            setc = L.pq_solver_set_comm_rccl if is_solver else L.pq_kkt_set_comm_rccl
+            _lib.check(setc(h, idb, self.rank, self.world), "set_comm_rccl")
+        else:
+            _lib.check(setx(h, self._cb, None, self.buf_factor.data_ptr(), self.buf_forward.data_ptr(), self.buf_gather.data_ptr()), "set_exchange")
         torch.cuda.synchronize(dev)
         self.dev = dev
 
@@ -169,6 +184,21 @@ class StagePartition:
         except Exception as e:  # never let an exception cross the C frame
             self.error = e
             return 1
+
+    def exchange_calls(self):
+        """collectives performed so far, [which = 0, 1, 2]: counted by the callback, or read from the library for the native transport"""
+        if not self.native:
+            return list(self.calls)
+        import ctypes as C
+
+        from . import _lib
+        L = _lib.load()
+        obj = self._obj
+        is_solver = hasattr(obj, "solve") and hasattr(obj, "setup")
+        h = obj.h if is_solver else (obj.backend().h if hasattr(obj, "backend") else obj.h)
+        out = (C.c_int * 3)()
+        _lib.check((L.pq_solver_native_exchange_calls if is_solver else L.pq_kkt_native_exchange_calls)(h, out), "native_exchange_calls")
+        return [int(v) for v in out]
 
     def info(self):
         import ctypes as C

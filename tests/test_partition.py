@@ -89,22 +89,29 @@ def test_partitioned_equals_single_gpu(backend, problem, nranks):
 
 
 @pytest.mark.gpu
-def test_rccl_transport_with_a_one_rank_group():
-    """all a 1-GPU box can say about the RCCL transport: a one-rank "nccl" process group, the exchange callback forced on
-    (PIQP_AMD_EXCHANGE_WORLD1), so that every solve goes C library -> callback -> torch.distributed -> RCCL -> back on the registered
-    device buffers; plus the bookkeeping collectives on device tensors (tools/nccl_world1_check.py)"""
+@pytest.mark.parametrize("native", [True, False])
+def test_rccl_transport_with_a_one_rank_group(native):
+    """all a 1-GPU box can say about the RCCL transport: a one-rank "nccl" process group with the exchanges forced on
+    (PIQP_AMD_EXCHANGE_WORLD1).  native=True: the library's own communicator (pq_kkt_set_comm_rccl: ncclCommInitRank from the broadcast
+    unique id, ncclAllReduce / ncclAllGather enqueued on the handle's stream, no callback); native=False: the callback transport
+    (C library -> callback -> torch.distributed -> RCCL on the registered device buffers).  Plus the bookkeeping collectives on device
+    tensors (tools/nccl_world1_check.py)."""
     env = dict(os.environ)
-    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "TORCHELASTIC_RUN_ID", "TORCHELASTIC_USE_AGENT_STORE"):
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "TORCHELASTIC_RUN_ID", "TORCHELASTIC_USE_AGENT_STORE", "PIQP_AMD_CALLBACK_EXCHANGE"):
         env.pop(k, None)
-    env.update(PIQP_AMD_FORCE_PG="1", PIQP_AMD_EXCHANGE_WORLD1="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29671")
+    env.update(PIQP_AMD_FORCE_PG="1", PIQP_AMD_EXCHANGE_WORLD1="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29671" if native else "29673")
+    if not native:
+        env["PIQP_AMD_CALLBACK_EXCHANGE"] = "1"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dist_c5.py"), "--stages", "600", "--steps", "2", "--warmup", "1", "--full-solve"], capture_output=True, text=True,
                        timeout=600, env=env)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert r.returncode == 0 and lines, r.stderr[-3000:]
     out = json.loads(lines[-1])
-    assert out["transport"] == "rccl" and out["world"] == 1
-    assert out["bitwise_equal_all_ranks"] and out["exchange_calls"][2] >= 3
+    assert out["transport"] == "rccl" and out["world"] == 1 and out["native_rccl"] == native
+    assert out["bitwise_equal_all_ranks"] and out["exchange_calls"][2] >= 3  # (one rank owns every subtree: no boundary, so only the gather runs)
     assert out["full_solve"]["status"] == 1 and out["full_solve"]["x_equal_to_single_gpu"]
+    if native:
+        return
     env["MASTER_PORT"] = "29672"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "nccl_world1_check.py")], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0 and "OK" in r.stdout, r.stderr[-2000:]

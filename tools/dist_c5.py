@@ -96,7 +96,8 @@ def main():
     el = pd.max_over_ranks(el)
     out["ms_per_step"] = el / args.steps * 1e3
     out["steps_per_s"] = args.steps / el
-    out["exchange_calls"] = sp.calls
+    out["exchange_calls"] = sp.exchange_calls()
+    out["native_rccl"] = bool(sp.native)
     rows = pd.gather_stats([[float(info["owned_supernodes"]), float(info["shared_supernodes"]), float(info["boundary_roots"]), float(info["span"][0]), float(info["span"][1]),
                              float(info["work_permille"]), float(info["shared_work_permille"])]])
     out["partition"] = [dict(rank=r, owned_supernodes=int(x[0]), span=[int(x[3]), int(x[4])], work_permille=int(x[5])) for r, x in enumerate(rows)]
