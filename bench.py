@@ -286,6 +286,12 @@ def sparse_legs(args, rank, world, local_rank, dev, pd):
     cases = [("C3", "sparse QP n=50000 p=20000 m=30000, nnz(upper KKT)=4.9e5, kkt_solver=sparse_ldlt (BASELINE configs[2])", c3_problem(seed=44 + rank), piqp_amd.SPARSE_LDLT, 1),
              ("C5_single_gpu", "one block-tridiagonal QP n=500012 p=300000 (25000 stages of n_x=12,n_u=8), kkt_solver=sparse_ldlt, ONE GPU (BASELINE configs[4] size)",
               mpc_chain(12, 8, 25000, 5 + rank), piqp_amd.SPARSE_LDLT, 5)]
+    # the real Maros-Meszaros cross-checks SURVEY.md 8d names next to the synthetic C3 (frozen fixtures, tests/golden/make_fixtures.py)
+    from qp_io import load_qp
+    for nm, what in (("CONT-201", "PDE-constrained grid, n=40397 p=40198"), ("BOYD1", "n=93261 with 18 dense equality rows")):
+        q = load_qp("mm_" + nm)
+        cases.append(("MM_" + nm, f"Maros-Meszaros {nm} ({what}), kkt_solver=sparse_ldlt", (q["P"], q["c"], q["A"], q["b"], q["G"], q["h_l"], q["h_u"], q["x_l"], q["x_u"]),
+                      piqp_amd.SPARSE_LDLT, 1))
     for key, desc, a, ks, oracle_ks in cases:
         d = piqp_amd.SparseData(*a)
         n, p, m = d.n, d.p, d.m

@@ -147,6 +147,11 @@ def main():
         path = os.path.join(td, "maros_meszaros", f + ".mat")
         if os.path.exists(path):
             convert_mat(path, "mm_" + f)
+    # the larger Maros-Meszaros problems SURVEY.md 8d names as the real cross-checks of the sparse configuration (C3): CONT-201 (n = 40 397,
+    # p = 40 198: a PDE-constrained grid), BOYD1 (n = 93 261 with 18 dense equality rows), AUG3DCQP (3-D augmented system), LISWET1 (m = 10 000
+    # banded inequalities)
+    for f in ("CONT-201", "BOYD1", "AUG3DCQP", "LISWET1"):
+        convert_mat(os.path.join(td, "maros_meszaros", f + ".mat"), "mm_" + f)
 
     P, c, A, b, x_l, x_u = scenario_mpc()
     n, p = P.shape[0], A.shape[0]
