@@ -338,6 +338,10 @@ int pq_batch_last_kernel_ms(const pq_batch *s, double *ms, int *threads_per_qp);
 
 /* ===================== small utilities used by the measurement harness ===================== */
 /* fp64 MFMA / HBM micro-benchmarks on `device` (used once by bench.py to report measured peaks) */
+/* number of device / pinned-host allocations the library has made in this process.  Contract (the reference's tests assert allocation-free
+ * factor / solve, fwd.hpp:44-52): the counter moves only inside *_create / *_clone / *_setup / *_update_data / *_partition calls, never in
+ * update_scalings_and_factor, solve, eval_*, mul or condensed_residual, in either pointer mode */
+long long pq_debug_alloc_count(void);
 int pq_microbench_mfma_f64(int device, int iters, double *tflops_out);
 int pq_microbench_hbm_copy(int device, size_t bytes, int iters, double *gbps_out);
 /* debugging aid: average microseconds of the 128 x 128 diagonal-block factorisation kernel and 64 in-kernel shader-clock stamps

@@ -1361,7 +1361,7 @@ private:
         bool wave_pan = false;
         const long long wave_doubles = sym_.qpan_doubles + n;
         nt_ = (n <= 512 && sym_.max_h <= 24) ? 64 : 256;
-        if (const char* e = std::getenv("PIQP_AMD_BATCH_MODE")) forced_mode_ = std::atoi(e);
+        if (const char* e = debug_token("batch_mode")) forced_mode_ = std::atoi(e);  // forces the chain working-set mode (tests of the fallback modes)
         if (nt_ == 64 && sym_.max_h * sym_.max_h <= 64 && wave_doubles * (long long)sizeof(double) <= RESIDENT_LIMIT_BYTES && sym_.max_w <= msdev::WAVE_WMAX && (forced_mode_ < 0 || forced_mode_ == MODE_WAVE)) {
             mode_ = MODE_WAVE;
             S.res_f = 0; S.res_pan = 0; S.res_x = (int)sym_.qpan_doubles; S.res_chain = S.res_x + n;
@@ -1424,7 +1424,6 @@ private:
     void launch_ipm_with()
     {
         int bytes = shared_h_.chain_lds_doubles * (int)sizeof(double);
-        if (const char* e = std::getenv("PIQP_AMD_BATCH_LDS_PAD")) bytes += std::atoi(e);  // occupancy experiments
         static bool attr = false;
         if (!attr) {
             PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_batch_ipm<NTv, MODEv, WPEv>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT_BYTES));
@@ -1448,7 +1447,6 @@ private:
     }
     void launch_ipm()
     {
-        if (const char* e = std::getenv("PIQP_AMD_BATCH_WPE")) wpe_ = std::atoi(e);
         if (nt_ == 64) {
             if (mode_ == MODE_WAVE) launch_ipm_as<64, MODE_WAVE>();
             else if (mode_ == MODE_RESIDENT) launch_ipm_as<64, MODE_RESIDENT>();

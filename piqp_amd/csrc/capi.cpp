@@ -65,7 +65,7 @@ struct pq_kktsys {
     KKTSystem* impl = nullptr;
     pq_kkt backend_view;
     int ptr_mode = PQ_MEM_HOST;
-    VarStage in, out;
+    VarStage in, out, mul_in, mul_out;  // mul_*: scratch Variables of pq_kktsys_mul (the last solve's staged vectors stay intact)
     bool staged = false;
     const double* last_lhs_x = nullptr;
     const double* last_lhs_y = nullptr;
@@ -73,7 +73,7 @@ struct pq_kktsys {
     {
         if (staged) return;
         VarSizes s{impl->n(), impl->p(), impl->m()};
-        in.alloc(s); out.alloc(s);
+        in.alloc(s); out.alloc(s); mul_in.alloc(s); mul_out.alloc(s);
         in.zero(impl->stream()); out.zero(impl->stream());
         staged = true;
     }
@@ -142,6 +142,7 @@ int pq_kkt_create_dense(pq_kkt** out, const pq_dense_data* data, int kkt_solver,
     return guarded([&] {
         std::unique_ptr<pq_kkt> h(new pq_kkt);
         h->impl = make_dense_kkt(data, kkt_solver, device);
+        h->ensure_staging();  // host-pointer-mode staging: allocated here, never later (pq_debug_alloc_count)
         *out = h.release();
         return (int)PQ_OK;
     });
@@ -157,6 +158,7 @@ int pq_kkt_create_sparse(pq_kkt** out, const pq_sparse_data* data, int kkt_solve
         std::unique_ptr<pq_kkt> h(new pq_kkt);
         h->impl = make_sparse_kkt(data, kkt_solver, device);
         if (!h->impl) return fail(PQ_ERR_UNSUPPORTED, "kkt solver not supported");
+        h->ensure_staging();
         *out = h.release();
         return (int)PQ_OK;
     });
@@ -169,6 +171,7 @@ int pq_kkt_clone(const pq_kkt* k, pq_kkt** out)
         std::unique_ptr<pq_kkt> h(new pq_kkt);
         h->impl = k->impl->clone();
         h->ptr_mode = k->ptr_mode;
+        h->ensure_staging();
         *out = h.release();
         return (int)PQ_OK;
     });
@@ -394,6 +397,8 @@ static pq_kktsys* wrap_kktsys(KKTSystem* sys)
     h->impl = sys;
     h->backend_view.impl = sys->backend();
     h->backend_view.owned = false;
+    h->ensure_staging();
+    h->backend_view.ensure_staging();
     return h;
 }
 
@@ -537,15 +542,12 @@ int pq_kktsys_mul(pq_kktsys* k, const pq_vars* lhs, pq_vars* rhs)
         PQ_HIP(hipSetDevice(k->impl->device()));
         if (k->ptr_mode == PQ_MEM_HOST) {
             k->ensure_staging();
-            // keep the last solve's staged vectors intact: multiply through scratch Variables sets
-            VarStage tin, tmp;
-            tin.alloc(VarSizes{k->impl->n(), k->impl->p(), k->impl->m()});
-            tmp.alloc(VarSizes{k->impl->n(), k->impl->p(), k->impl->m()});
-            tin.zero(k->impl->stream());
-            tmp.zero(k->impl->stream());
-            stage_in(k, lhs, tin);
-            k->impl->mul(tin.v, tmp.v);
-            stage_out(k, tmp, rhs);
+            // keep the last solve's staged vectors intact: multiply through the scratch Variables sets allocated with the handle
+            k->mul_in.zero(k->impl->stream());
+            k->mul_out.zero(k->impl->stream());
+            stage_in(k, lhs, k->mul_in);
+            k->impl->mul(k->mul_in.v, k->mul_out.v);
+            stage_out(k, k->mul_out, rhs);
         } else {
             k->impl->mul(*lhs, *rhs);
         }
@@ -577,6 +579,8 @@ int pq_kktsys_synchronize(pq_kktsys* k)
 }
 
 // ------------------------------------------------------------------------------------ micro-benchmarks
+long long pq_debug_alloc_count(void) { return alloc_counter().load(); }
+
 int pq_microbench_mfma_f64(int device, int iters, double* tflops_out)
 {
     int rc = check_device(device);

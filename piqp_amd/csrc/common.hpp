@@ -3,11 +3,13 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/piqp_amd.h"
@@ -61,6 +63,14 @@ inline int guarded(F&& f)
     }
 }
 
+// every hipMalloc / hipHostMalloc the library makes is counted (pq_debug_alloc_count): the reference's tests assert allocation-free factor / solve
+// (fwd.hpp:44-52, PIQP_EIGEN_MALLOC_NOT_ALLOWED); here the same statement is "the counter does not move after *_create"
+inline std::atomic<long long>& alloc_counter()
+{
+    static std::atomic<long long> c{0};
+    return c;
+}
+
 // RAII device buffer (all allocation happens in constructors / create paths)
 template <class T>
 struct DBuf {
@@ -81,7 +91,7 @@ struct DBuf {
     {
         release();
         n = count;
-        if (count) PQ_HIP(hipMalloc((void**)&p, count * sizeof(T)));
+        if (count) { PQ_HIP(hipMalloc((void**)&p, count * sizeof(T))); ++alloc_counter(); }
     }
     void release()
     {
@@ -107,7 +117,7 @@ struct HBuf {
     {
         release();
         n = count;
-        if (count) PQ_HIP(hipHostMalloc((void**)&p, count * sizeof(T), hipHostMallocDefault));
+        if (count) { PQ_HIP(hipHostMalloc((void**)&p, count * sizeof(T), hipHostMallocDefault)); ++alloc_counter(); }
     }
     void release()
     {
@@ -124,6 +134,30 @@ inline void copy_in(void* dst_dev, const void* src, size_t bytes, int src_mem, h
 }
 
 inline int div_up(int a, int b) { return (a + b - 1) / b; }
+
+// ONE debugging variable for the whole library: PIQP_AMD_DEBUG="token[=value],token,...".  Returns nullptr when the token is
+// absent, "" when it is present without a value, its value otherwise.  Parsed once per process.  Tokens select measured-equivalent device
+// schedules for the bitwise-consistency tests (tests/test_sparse_variants_gpu.py) or switch diagnostics on; none is needed for normal use.
+inline const char* debug_token(const char* name)
+{
+    static const std::vector<std::pair<std::string, std::string>> toks = [] {
+        std::vector<std::pair<std::string, std::string>> v;
+        const char* e = std::getenv("PIQP_AMD_DEBUG");
+        std::string s = e ? e : "";
+        size_t i = 0;
+        while (i < s.size()) {
+            size_t j = s.find(',', i);
+            if (j == std::string::npos) j = s.size();
+            const std::string t = s.substr(i, j - i);
+            const size_t eq = t.find('=');
+            if (!t.empty()) v.emplace_back(eq == std::string::npos ? t : t.substr(0, eq), eq == std::string::npos ? std::string() : t.substr(eq + 1));
+            i = j + 1;
+        }
+        return v;
+    }();
+    for (const auto& kv : toks) if (kv.first == name) return kv.second.c_str();
+    return nullptr;
+}
 
 // hipEvent brackets around stages of a backend, accumulated lazily (events are read at query time,
 // after the stream has been synchronised; nothing here blocks the timed region)

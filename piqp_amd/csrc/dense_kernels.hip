@@ -370,8 +370,7 @@ static const int* syrk_tile_order(int T)
 {
     static std::mutex mu;
     static std::map<std::pair<int, int>, int*> cache;
-    static const bool off = std::getenv("PIQP_AMD_SYRK_LINEAR_TILES") != nullptr;
-    if (off || T < 16) return nullptr;
+    if (T < 16) return nullptr;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
     std::lock_guard<std::mutex> lk(mu);
@@ -390,10 +389,13 @@ static const int* syrk_tile_order(int T)
     for (int b = 0; b < nt; ++b) order[b] = blocked[start[b % NX] + b / NX];
     int* d = nullptr;
     if (hipMalloc(&d, sizeof(int) * nt) != hipSuccess) { (void)hipGetLastError(); cache[{dev, T}] = nullptr; return nullptr; }
+    ++alloc_counter();
     if (hipMemcpy(d, order.data(), sizeof(int) * nt, hipMemcpyHostToDevice) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(d); d = nullptr; }
     cache[{dev, T}] = d;
     return d;
 }
+
+void syrk_prepare(int n) { (void)syrk_tile_order(div_up(n, TS)); }  // the per-device tile-order table, built at create time
 
 template <int EPI>
 static void launch_syrk_t(SyrkArgs a, hipStream_t s, double* ws, size_t ws_doubles)
@@ -1116,15 +1118,14 @@ __device__ __forceinline__ double ld_agent(const double* p)
     return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const u64*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
 
-// S > 1: every 128-row block is served by S workgroups on S different CUs.  One CU streaming its whole block row (up to 4 MB at n = 4096)
-// was what bounded a sweep once the hand-off chain was short.  Workgroup (r, 0) owns the block: it keeps the diagonal block in LDS, consumes
-// only the LAST producer of its row -- the one on the critical path -- adds the partial sums of its helpers and solves; helpers (r, s >= 1)
-// share the earlier producers round-robin, whose x arrived at least one hand-off earlier, and publish 128 partial sums each.  The partials
-// are added in helper order: fixed summation order, bitwise reproducible.
+// (Serving a block row with several workgroups on several CUs -- helpers taking the earlier producers, the owner the last one -- was
+// measured slower in round 1: 203 / 222 us per sweep with one workgroup per row, 222 / 234 with two, 257 / 267 with four; the extra
+// hand-off costs more than the shared streaming saves.  Round 2 tried replacing the serial 128-step diagonal substitution by a product with
+// the inverted diagonal block: 108 / 151 us per sweep, but the residuals on the rho = delta = 1e-10 states doubled and two iteration-parity
+// tests moved; with one refinement step against the block the accuracy returned and the time was worse than the substitution.  Both removed.)
 template <bool FWD>
 __global__ __launch_bounds__(256) void k_trsv_persistent(const double* __restrict__ L, int ld, int n, double* __restrict__ x, const double* __restrict__ rdiag,
-                                                         int nblk, int* __restrict__ flags, int* __restrict__ err, int dbg_skip_loads, int S, int* __restrict__ pflags,
-                                                         double* __restrict__ part)
+                                                         int nblk, int* __restrict__ flags, int* __restrict__ err)
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double* Ls = sm;                    // own diagonal block, Ls[c * (TB+1) + r]
@@ -1133,24 +1134,16 @@ __global__ __launch_bounds__(256) void k_trsv_persistent(const double* __restric
     double* rd = bs + TB;
     __shared__ int ok_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ridx = (int)blockIdx.x / S, hs = (int)blockIdx.x % S;  // position of the block in sweep order, role (0 = owner)
+    const int ridx = (int)blockIdx.x;   // position of the block in sweep order
     const int r = FWD ? ridx : nblk - 1 - ridx;
     const int row0 = r * TB, nrows = min(TB, n - row0);
-    const bool owner = hs == 0;
     // stage the diagonal block (transposed for the backward sweep) and reciprocal pivots
-    if (owner) {
-        stage_lower_block<TB, TB + 1, 256, !FWD>(L + row0 + (size_t)row0 * ld, ld, nrows, Ls, tid);
-        if (tid < TB) rd[tid] = (rdiag && tid < nrows) ? rdiag[row0 + tid] : 1.0;
-    }
+    stage_lower_block<TB, TB + 1, 256, !FWD>(L + row0 + (size_t)row0 * ld, ld, nrows, Ls, tid);
+    if (tid < TB) rd[tid] = (rdiag && tid < nrows) ? rdiag[row0 + tid] : 1.0;
     const int row = tid & 127, half = tid >> 7;
-    double mine = (owner && half == 0 && row < nrows) ? x[row0 + row] : 0.0;
+    double mine = (half == 0 && row < nrows) ? x[row0 + row] : 0.0;
     double acc = 0.0;
     const int nsteps = ridx;  // producers of this block row, in sweep order t = 0 .. nsteps - 1
-    // the steps this workgroup consumes: t = t_first + q * t_stride, q < nmine
-    int t_first, t_stride, nmine;
-    if (S == 1) { t_first = 0; t_stride = 1; nmine = nsteps; }
-    else if (owner) { t_first = nsteps - 1; t_stride = 1; nmine = nsteps > 0 ? 1 : 0; }
-    else { t_first = hs - 1; t_stride = S - 1; nmine = (nsteps - 1 > hs - 1) ? (nsteps - 1 - (hs - 1) - 1) / (S - 1) + 1 : 0; }
     // operand block of step t (producer block j_t) into registers; two steps are kept in flight: the block for the next step is requested
     // before the wait for x_{j_t}, so its latency never sits between the arrival of x and the hand-off to the next block
     auto load_block = [&](int t, double (&lv)[64]) {
@@ -1163,10 +1156,7 @@ __global__ __launch_bounds__(256) void k_trsv_persistent(const double* __restric
             for (int c = 0; c < 64; ++c) lv[c] = (row < nrows) ? Lp[(size_t)c * ld] : 0.0;
         } else {    // transposed: L[c0 + half*64 + c, row0+row] (column row0+row of L, contiguous in c)
             const double* Lp = L + (c0 + half * 64) + (size_t)(row0 + row) * ld;
-            if (dbg_skip_loads & 1) {
-#pragma unroll
-                for (int c = 0; c < 64; ++c) lv[c] = 0.0;
-            } else if (((ld & 1) == 0) && ((reinterpret_cast<uintptr_t>(L) & 15) == 0) && nc == TB && row < nrows) {
+            if (((ld & 1) == 0) && ((reinterpret_cast<uintptr_t>(L) & 15) == 0) && nc == TB && row < nrows) {
 #pragma unroll
                 for (int c = 0; c < 64; c += 2) {
                     const d2 t2 = *reinterpret_cast<const d2*>(Lp + c);
@@ -1215,44 +1205,22 @@ __global__ __launch_bounds__(256) void k_trsv_persistent(const double* __restric
     };
     {
         double lvA[64], lvB[64];
-        if (nmine > 0) load_block(t_first, lvA);
+        if (nsteps > 0) load_block(0, lvA);
         int q = 0;
-        for (; q + 1 < nmine; q += 2) {
-            const int t0 = t_first + q * t_stride;
-            if (!consume(t0, lvA, lvB, t0 + t_stride)) return;
-            if (!consume(t0 + t_stride, lvB, lvA, q + 2 < nmine ? t0 + 2 * t_stride : -1)) return;
+        for (; q + 1 < nsteps; q += 2) {
+            if (!consume(q, lvA, lvB, q + 1)) return;
+            if (!consume(q + 1, lvB, lvA, q + 2 < nsteps ? q + 2 : -1)) return;
         }
-        if (q < nmine) { if (!consume(t_first + q * t_stride, lvA, lvB, -1)) return; }
+        if (q < nsteps) { if (!consume(q, lvA, lvB, -1)) return; }
     }
     __syncthreads();
     if (half == 1) bs[row] = acc;
     __syncthreads();
-    if (!owner) {
-        // helper: publish the 128 partial sums of this workgroup (nothing to publish if it had no step: the owner knows the counts)
-        if (nmine > 0) {
-            if (half == 0 && row < nrows) st_agent(part + ((size_t)r * S + hs) * TB + row, acc + bs[row]);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 0) __hip_atomic_store(pflags + r * S + hs, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        return;
-    }
-    double total = (half == 0) ? acc + bs[row] : 0.0;
-    if (S > 1) {
-        for (int h = 1; h < S; ++h) {
-            const int cnt = (nsteps - 1 > h - 1) ? (nsteps - 1 - (h - 1) - 1) / (S - 1) + 1 : 0;
-            if (cnt == 0) continue;
-            if (!wait_flag(pflags + r * S + h)) return;
-            if (half == 0 && row < nrows) total += ld_agent(part + ((size_t)r * S + h) * TB + row);
-        }
-    }
-    __syncthreads();
-    if (half == 0) bs[row] = mine - total;
+    if (half == 0) bs[row] = mine - (acc + bs[row]);
     __syncthreads();
     if (wave == 0) {
         double b0 = bs[lane], b1 = bs[lane + 64];
-        if (dbg_skip_loads & 2) { b0 *= rd[lane]; b1 *= rd[lane + 64]; }
-        else if (FWD || (dbg_skip_loads & 4)) diag_solve_fwd(Ls, rd, lane, b0, b1);
+        if (FWD) diag_solve_fwd(Ls, rd, lane, b0, b1);
         else diag_solve_bwd(Ls, rd, lane, b0, b1);
         if (lane < nrows) st_agent(x + row0 + lane, b0);
         if (lane + 64 < nrows) st_agent(x + row0 + lane + 64, b1);
@@ -1267,21 +1235,12 @@ __global__ void k_mul_vec(int n, const double* __restrict__ d, double* __restric
     if (i < n) x[i] *= d[i];
 }
 
-int trsv_split(int n)
-{
-    static int env = -1;
-    if (env < 0) { const char* e = std::getenv("PIQP_AMD_TRSV_SPLIT"); env = e ? std::max(1, std::atoi(e)) : 0; }
-    const int nblk = div_up(n, TB);
-    int S = env > 0 ? env : 1;  // measured at n = 4096: 203 / 222 us (S = 1), 222 / 234 (2), 257 / 267 (4): the extra hand-off costs more than the shared streaming saves
-    while (S > 1 && nblk * S > 224) --S;  // every workgroup of the launch must be resident (one per CU)
-    return S;
-}
-size_t trsv_flag_ints(int n) { const int nblk = div_up(n, TB); return 2 * ((size_t)nblk + (size_t)nblk * 8) + 1; }
-size_t trsv_part_doubles(int n) { const int nblk = div_up(n, TB); return (size_t)nblk * 8 * TB; }
+size_t trsv_flag_ints(int n) { return 2 * (size_t)div_up(n, TB) + 1; }
 
 // LLT: L y = b, L^T x = y with rdiag = 1/diag(L).  LDLt: unit L, then x *= rdiag (= 1/D), then unit L^T.
-// `flags` = trsv_flag_ints(n) ints and `part` = trsv_part_doubles(n) doubles of scratch (flags zeroed here on the stream).
-void launch_trsv(const double* L, int ld, int n, double* x, const double* rdiag, bool ldlt, int* flags, double* part, hipStream_t s)
+// `flags` = trsv_flag_ints(n) ints of scratch (zeroed here on the stream); nullptr, or more blocks than can be resident at once, falls back to
+// one launch per block step.
+void launch_trsv(const double* L, int ld, int n, double* x, const double* rdiag, bool ldlt, int* flags, hipStream_t s)
 {
     if (n <= 0) return;
     static bool attr_set = false;
@@ -1296,16 +1255,12 @@ void launch_trsv(const double* L, int ld, int n, double* x, const double* rdiag,
     const double* rd = ldlt ? nullptr : rdiag;
     const bool persistent = flags != nullptr && nblk <= 224;  // every block resident (one per CU) with room to spare
     if (persistent) {
-        const int S = part ? trsv_split(n) : 1;
-        static int dbg = -1;
-        if (dbg < 0) { const char* e = std::getenv("PIQP_AMD_DBG_TRSV"); dbg = e ? std::atoi(e) : 0; }
-        // layout: [fwd x flags nblk][fwd partial flags nblk*S][bwd x flags nblk][bwd partial flags nblk*S][err]
-        const size_t per = (size_t)nblk + (size_t)nblk * S;
-        PQ_HIP(hipMemsetAsync(flags, 0, sizeof(int) * (2 * per + 1), s));
-        int* err = flags + 2 * per;
-        hipLaunchKernelGGL(k_trsv_persistent<true>, dim3(nblk * S), dim3(256), TRSV_LDS_BYTES, s, L, ld, n, x, rd, nblk, flags, err, 0, S, flags + nblk, part);
+        // layout: [fwd x flags nblk][bwd x flags nblk][err]
+        PQ_HIP(hipMemsetAsync(flags, 0, sizeof(int) * (2 * (size_t)nblk + 1), s));
+        int* err = flags + 2 * nblk;
+        hipLaunchKernelGGL(k_trsv_persistent<true>, dim3(nblk), dim3(256), TRSV_LDS_BYTES, s, L, ld, n, x, rd, nblk, flags, err);
         if (ldlt) hipLaunchKernelGGL(k_mul_vec, dim3(div_up(n, 256)), dim3(256), 0, s, n, rdiag, x);
-        hipLaunchKernelGGL(k_trsv_persistent<false>, dim3(nblk * S), dim3(256), TRSV_LDS_BYTES, s, L, ld, n, x, rd, nblk, flags + per, err, dbg, S, flags + per + nblk, part);
+        hipLaunchKernelGGL(k_trsv_persistent<false>, dim3(nblk), dim3(256), TRSV_LDS_BYTES, s, L, ld, n, x, rd, nblk, flags + nblk, err);
     } else {
         for (int j = 0; j < nblk; ++j)
             hipLaunchKernelGGL(k_trsv_fwd_step, dim3(nblk - j), dim3(256), TRSV_LDS_BYTES, s, L, ld, n, x, rd, j);

@@ -45,6 +45,7 @@ struct SyrkArgs {
 
 void launch_syrk(int epi, const SyrkArgs& args, hipStream_t s, double* split_ws = nullptr, size_t split_ws_doubles = 0);
 size_t syrk_split_workspace_doubles(int n, int kdim);
+void syrk_prepare(int n);  // allocates what launch_syrk(EPI_ASSEMBLE, n) would otherwise allocate on first use
 void launch_assemble_no_g(int n, const double* Pf, const double* x_reg, const double* ATA, double dinv, double* C, hipStream_t s);
 // diagonal block of order nb <= 128 at A: factor in place, reciprocal pivots to rdiag[kglobal..], D to dvec[0..nb) (LDLT, nullable), and the
 // operand pack of the panel solve (FACTOR_PACK_DOUBLES doubles, nullable: inverted 16 x 16 diagonal pieces + negated off-diagonal blocks)
@@ -54,8 +55,7 @@ double microbench_potrf_block(bool ldlt, int reps, long long* stamps64, hipStrea
 // rows k0 + nb .. n of the panel at column k0:  A21 <- A21 L11^-T (D^-1), with the pack written by the factorisation of L11
 void launch_trsm_panel(bool ldlt, double* A, int lda, int k0, int nb, int n, const double* pack, const double* rdiag, hipStream_t s);
 size_t trsv_flag_ints(int n);
-size_t trsv_part_doubles(int n);
-void launch_trsv(const double* L, int ld, int n, double* x, const double* rdiag, bool ldlt, int* flags, double* part, hipStream_t s);
+void launch_trsv(const double* L, int ld, int n, double* x, const double* rdiag, bool ldlt, int* flags, hipStream_t s);
 int gemv_n_slices(int rows, int cols);
 int launch_gemv_n_partial(int rows, int cols, const double* M, int ld, const double* v, const double* scale, double alpha, double* part, hipStream_t s);
 void launch_reduce_partials(int rows, int nslices, const double* part, const double* base, double* y, hipStream_t s);

@@ -41,9 +41,6 @@ public:
     {
         (void)hipSetDevice(dev_);
         if (st_) { (void)hipStreamSynchronize(st_); (void)hipStreamDestroy(st_); }
-        if (st2_) { (void)hipStreamSynchronize(st2_); (void)hipStreamDestroy(st2_); }
-        for (auto e : ev_trsm_) (void)hipEventDestroy(e);
-        for (auto e : ev_rest_) (void)hipEventDestroy(e);
     }
 
     // dense/kkt.hpp:57-60
@@ -94,7 +91,7 @@ public:
         if (p_ > 0) nsl += dense::launch_gemv_n_partial(n_, p_, AT_.p, n_, rhs_y, nullptr, delta_inv, part_.p + (size_t)nsl * n_, st_);
         dense::launch_reduce_partials(n_, nsl, part_.p, rhs_x, lhs_x, st_);
         // solve_ldlt_in_place: llt.solveInPlace(lhs_x)
-        { const int tt = prof_.begin(5, st_); dense::launch_trsv(fac_.p, n_, n_, lhs_x, rdiag_.p, ldlt_, use_persistent_trsv_ ? flags_.p : nullptr, trsv_part_.p, st_); prof_.end(5, tt, st_); }
+        { const int tt = prof_.begin(5, st_); dense::launch_trsv(fac_.p, n_, n_, lhs_x, rdiag_.p, ldlt_, flags_.p, st_); prof_.end(5, tt, st_); }
         // lhs_y = delta_inv * AT^T lhs_x - delta_inv * rhs_y
         if (p_ > 0) dense::launch_gemv_t(n_, p_, AT_.p, n_, lhs_x, delta_inv, -delta_inv, rhs_y, nullptr, lhs_y, st_);
         // lhs_z = (GT^T lhs_x - rhs_z) o z_reg_inv
@@ -186,38 +183,13 @@ private:
         part_.alloc((size_t)sl * n_);
         split_ws_.alloc(dense::syrk_split_workspace_doubles(n_, m_ > 0 ? m_ : 1));
         pack_.alloc(dense::FACTOR_PACK_DOUBLES);
+        dense::syrk_prepare(n_);
         info_.alloc(1);
         info_h_.alloc(1);
         flags_.alloc(dense::trsv_flag_ints(n_));
-        trsv_part_.alloc(dense::trsv_part_doubles(n_));
-        if (const char* e = std::getenv("PIQP_AMD_TRSV")) use_persistent_trsv_ = std::string(e) != "steps";
-        if (const char* e = std::getenv("PIQP_AMD_LOOKAHEAD")) lookahead_ = std::string(e) == "1";
-        if (const char* e = std::getenv("PIQP_AMD_FUSED_POTRF")) fused_potrf_ = std::string(e) != "0";
-        if (const char* e = std::getenv("PIQP_AMD_DBG_FUSED_TS")) { dbg_panel_ = std::atoi(e); dbg_ts_.alloc(72); dbg_ts_.zero(st_); }
-        make_aux_stream();
+        if (const char* e = debug_token("fused_ts")) { dbg_panel_ = std::atoi(e); dbg_ts_.alloc(72); dbg_ts_.zero(st_); }
         x_reg_last_.zero(st_);
         fac_.zero(st_);
-    }
-
-    // aux stream for the look-ahead trailing updates: masked off the first 16 CUs so the serial panel kernels of the
-    // main stream always find a free CU (their LDS footprint does not fit beside two SYRK workgroups)
-    void make_aux_stream()
-    {
-        if (st2_) return;
-        int cus = 0;
-        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev_);
-        std::vector<uint32_t> mask((std::max(cus, 32) + 31) / 32, 0xFFFFFFFFu);
-        mask[0] &= 0xFFFF0000u;
-        if (hipExtStreamCreateWithCUMask(&st2_, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
-            (void)hipGetLastError();
-            if (hipStreamCreateWithFlags(&st2_, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); st2_ = nullptr; }
-        }
-        const int np = (n_ + dense::FACTOR_NB - 1) / dense::FACTOR_NB;
-        ev_trsm_.resize(np); ev_rest_.resize(np);
-        for (int i = 0; i < np; ++i) {
-            PQ_HIP(hipEventCreateWithFlags(&ev_trsm_[i], hipEventDisableTiming));
-            PQ_HIP(hipEventCreateWithFlags(&ev_rest_[i], hipEventDisableTiming));
-        }
     }
 
     void upload(const pq_dense_data* d)
@@ -251,26 +223,21 @@ private:
         }
     }
 
-    // blocked right-looking factorisation of the lower triangle of fac_ (panel width 128):
-    // Eigen::LLT::compute (dense/kkt.hpp:82) or LDLTNoPivot::compute (dense/ldlt_no_pivot.hpp:313-354)
-    // Right-looking blocked factorisation with one-panel look-ahead.  For panel p (columns k .. k+nb):
-    //   main stream : potrf(p), trsm(p), then the update of the NEXT panel's 128 columns only (first tile column of
-    //                 the trailing matrix) so that potrf(p+1)/trsm(p+1) can start immediately;
-    //   aux stream  : the rest of the trailing update of panel p (columns >= k + 2 nb), overlapped with the main stream's
-    //                 serial panel work.  The aux stream is created with a CU mask that leaves a few CUs to the panel kernels.
+    // blocked right-looking factorisation of the lower triangle of fac_ (panel width 128): Eigen::LLT::compute (dense/kkt.hpp:82) or
+    // LDLTNoPivot::compute (dense/ldlt_no_pivot.hpp:313-354).  Two launches per panel: the panel solve below the diagonal block
+    // (k_trsm_panel) and the fused trailing update, whose first workgroup also factors the NEXT diagonal block (EPI_SUBTRACT_POTRF);
+    // only the first diagonal block has a launch of its own.  (A look-ahead variant on a second, CU-masked stream was measured slower in
+    // round 1 -- the cross-stream event latency exceeds the overlap: 4.1 -> 4.6 ms at n = 4096 -- and removed.)
     void launch_factor_panels()
     {
         PQ_HIP(hipMemsetAsync(info_.p, 0xFF, sizeof(int), st_));  // -1
         const int NB = dense::FACTOR_NB;
-        const bool la = lookahead_ && st2_ != nullptr && n_ > 3 * NB;
-        // fused: the trailing update of panel p also factors the diagonal block of panel p + 1 (dense_kernels.hpp EPI_SUBTRACT_POTRF)
-        const bool fused = fused_potrf_ && !la;
-        int p = 0, last_rest = -1;
+        int p = 0;
         for (int k = 0; k < n_; k += NB, ++p) {
             const int nb = (n_ - k < NB) ? n_ - k : NB;
             const int rs = n_ - k - nb;
             double* A11 = fac_.p + k + (size_t)k * n_;
-            if (!fused || k == 0) dense::launch_potrf_diag(ldlt_, A11, n_, nb, k, info_.p, rdiag_.p, dvec_.p + k, rs > 0 ? pack_.p : nullptr, st_);
+            if (k == 0) dense::launch_potrf_diag(ldlt_, A11, n_, nb, k, info_.p, rdiag_.p, dvec_.p + k, rs > 0 ? pack_.p : nullptr, st_);
             if (rs <= 0) break;
             { const int tt = prof_.begin(4, st_); dense::launch_trsm_panel(ldlt_, fac_.p, n_, k, nb, n_, pack_.p, rdiag_.p, st_); prof_.end(4, tt, st_); }
             dense::SyrkArgs a;
@@ -279,39 +246,14 @@ private:
             a.B = a.A; a.ldb = n_;
             if (ldlt_) a.w = dvec_.p + k;  // D of this panel, written by its diagonal-block factorisation
             a.C = fac_.p + (k + nb) + (size_t)(k + nb) * n_; a.ldc = n_;
-            if (fused) {
-                a.fuse_nb = rs < NB ? rs : NB; a.fuse_kglobal = k + nb; a.fuse_ldlt = ldlt_ ? 1 : 0; a.fuse_info = info_.p; a.fuse_rdiag = rdiag_.p; a.fuse_dvec = dvec_.p + k + nb;
-                a.fuse_pack = (rs - a.fuse_nb > 0) ? pack_.p : nullptr;
-                a.fuse_ts = (dbg_panel_ == p) ? dbg_ts_.p : nullptr;
-                { const int tt = prof_.begin(3, st_); dense::launch_syrk(dense::EPI_SUBTRACT_POTRF, a, st_); prof_.end(3, tt, st_); }
-                if (a.fuse_ts) dump_fused_ts(p);
-                continue;
-            }
-            if (!la) {
-                dense::launch_syrk(dense::EPI_SUBTRACT, a, st_);
-                continue;
-            }
-            PQ_HIP(hipEventRecord(ev_trsm_[p], st_));
-            // rest of the trailing matrix (rows/cols >= k + nb + NB) on the aux stream
-            const int rs2 = rs - NB;
-            if (rs2 > 0) {
-                dense::SyrkArgs b = a;
-                b.n = rs2;
-                b.A = a.A + NB; b.B = b.A;
-                b.C = a.C + NB + (size_t)NB * n_;
-                PQ_HIP(hipStreamWaitEvent(st2_, ev_trsm_[p], 0));
-                dense::launch_syrk(dense::EPI_SUBTRACT, b, st2_);
-                PQ_HIP(hipEventRecord(ev_rest_[p], st2_));
-            }
-            // next panel's columns on the main stream (after every earlier aux update of those columns)
-            if (last_rest >= 0) PQ_HIP(hipStreamWaitEvent(st_, ev_rest_[last_rest], 0));
-            a.first_col_only = 1;
-            dense::launch_syrk(dense::EPI_SUBTRACT, a, st_);
-            if (rs2 > 0) last_rest = p;
+            a.fuse_nb = rs < NB ? rs : NB; a.fuse_kglobal = k + nb; a.fuse_ldlt = ldlt_ ? 1 : 0; a.fuse_info = info_.p; a.fuse_rdiag = rdiag_.p; a.fuse_dvec = dvec_.p + k + nb;
+            a.fuse_pack = (rs - a.fuse_nb > 0) ? pack_.p : nullptr;
+            a.fuse_ts = (dbg_panel_ == p) ? dbg_ts_.p : nullptr;
+            { const int tt = prof_.begin(3, st_); dense::launch_syrk(dense::EPI_SUBTRACT_POTRF, a, st_); prof_.end(3, tt, st_); }
+            if (a.fuse_ts) dump_fused_ts(p);
         }
-        if (la && last_rest >= 0) PQ_HIP(hipStreamWaitEvent(st_, ev_rest_[last_rest], 0));
     }
-    // PIQP_AMD_DBG_FUSED_TS=<panel>: in-kernel timeline of the workgroup that updates and factors the next diagonal block, to stderr
+    // PIQP_AMD_DEBUG=fused_ts=<panel>: in-kernel timeline of the workgroup that updates and factors the next diagonal block, to stderr
     void dump_fused_ts(int panel)
     {
         long long h[72];
@@ -335,16 +277,10 @@ private:
     hipStream_t st_ = nullptr;
     DBuf<double> Pfull_, Pdiag_, AT_, GT_, ATA_, fac_, z_reg_inv_, x_reg_last_, dvec_, part_, rdiag_, split_ws_, pack_;
     DBuf<int> info_, flags_;
-    DBuf<double> trsv_part_;
     HBuf<int> info_h_;
     StageProfiler prof_;
     int dbg_panel_ = -1;
     DBuf<long long> dbg_ts_;
-    bool use_persistent_trsv_ = true;
-    bool fused_potrf_ = true;  // PIQP_AMD_FUSED_POTRF=0: separate k_potrf_diag launches
-    bool lookahead_ = false;  // cross-stream event latency on this stack exceeds the overlap gained (measured: 4.1 -> 4.6 ms at n = 4096)
-    hipStream_t st2_ = nullptr;
-    std::vector<hipEvent_t> ev_trsm_, ev_rest_;
 };
 
 }  // namespace

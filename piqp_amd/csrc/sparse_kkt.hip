@@ -563,116 +563,14 @@ __global__ __launch_bounds__(1024) void k_subtree_factor_lds(FrontMeta M, double
     }
 }
 
-// The same walk with every piece of per-subtree metadata staged in LDS at kernel start: a subtree is a contiguous supernode range, so
-// its records, its assembly lists (fe_*) and its child maps (rel) are contiguous too and arrive in ONE round of coalesced loads (plus
-// one gather of the K values) instead of a chain of three or four dependent global loads per supernode -- which is what the walk
-// above spends most of its time on (about 5 us per supernode against about 1 us of arithmetic).
-struct SubStage {
-    int ent_cap, rel_cap, sn_cap;  // capacities (max over the subtrees of the class)
-};
 struct SubClass {  // subtrees launched together: same dynamic LDS size
     int nsub = 0, cap = 0, fmax = 0, bytes = 0, threads = 256;
-    bool staged = false, lds_walk = true, packed = false;
-    SubStage stage{0, 0, 0};
+    bool lds_walk = true, packed = false;
     DBuf<int> lo, hi;
 };
 struct SubSchedule {
     std::vector<SubClass> cls;
 };
-__global__ __launch_bounds__(SUB_THREADS) void k_subtree_factor_staged(FrontMeta M, double* __restrict__ fronts, const int* __restrict__ sub_lo, const int* __restrict__ sub_hi,
-                                                                       int cap, SubStage G, double* __restrict__ rdiag, int* __restrict__ info)
-{
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int tid = threadIdx.x, nt = blockDim.x;
-    const int lo = sub_lo[blockIdx.x], hi = sub_hi[blockIdx.x];
-    const int nsn = hi - lo + 1;
-    double* cur = lds;
-    double* prev = lds + cap;
-    double* vals_s = lds + 2 * cap;
-    SnRec* rec_s = reinterpret_cast<SnRec*>(vals_s + G.ent_cap);
-    int* off_s = reinterpret_cast<int*>(rec_s + G.sn_cap);
-    int* rel_s = off_s + G.ent_cap;
-    int* feptr_s = rel_s + G.rel_cap;
-    // ---- stage
-    const int e0 = M.fe_ptr[lo], e1 = M.fe_ptr[hi + 1];
-    const SnRec first_rec = M.sn[lo], last_rec = M.sn[hi];
-    const int r0 = first_rec.rel_ptr, r1 = last_rec.rel_ptr + (last_rec.f - last_rec.w);
-    for (int i = tid; i < nsn; i += nt) rec_s[i] = M.sn[lo + i];
-    for (int i = tid; i <= nsn; i += nt) feptr_s[i] = M.fe_ptr[lo + i] - e0;
-    for (int e = e0 + tid; e < e1; e += nt) { off_s[e - e0] = M.fe_off[e]; vals_s[e - e0] = M.vals[e]; }
-    for (int i = r0 + tid; i < r1; i += nt) rel_s[i - r0] = M.rel[i];
-    __syncthreads();
-    bool prev_valid = false;
-    for (int s = lo; s <= hi; ++s) {
-        const SnRec me = rec_s[s - lo];
-        const int first = me.first, w = me.w, f = me.f;
-        double* W = cur;
-        for (int idx = tid; idx < f * f; idx += nt) W[idx] = 0.0;
-        __syncthreads();
-        for (int e = feptr_s[s - lo] + tid; e < feptr_s[s - lo + 1]; e += nt) W[off_s[e]] = vals_s[e];
-        __syncthreads();
-        for (int ci = me.child_lo; ci < me.child_hi; ++ci) {
-            const int c = M.child[ci];  // children of a supernode inside a subtree are inside it too
-            const SnRec ch = rec_s[c - lo];
-            const int wc = ch.w, fc = ch.f, uc = fc - wc;
-            const bool from_lds = prev_valid && c == s - 1;
-            const double* U = from_lds ? prev + wc + wc * fc : fronts + ch.front_off + wc + (long long)wc * fc;
-            const int* rel = rel_s + (ch.rel_ptr - r0);
-            {
-                const int tx = tid & 15, ty = tid >> 4, tys = nt >> 4;
-                for (int j = ty; j < uc; j += tys) {
-                    const int cj = rel[j] * f;
-                    for (int i = j + tx; i < uc; i += 16) W[rel[i] + cj] += U[i + (long long)j * fc];
-                }
-            }
-            __syncthreads();
-        }
-        for (int k = 0; k < w; ++k) {
-            double d = W[k + k * f];
-            if (d == 0.0) { if (tid == 0 && *info < 0) *info = first + k; d = 1.0; }
-            const double dinv = pivot_rcp(d);
-            if (tid == 0) rdiag[first + k] = dinv;
-            const int r = f - k - 1, pc = w - k - 1;
-            const double* colk = W + (k + 1) + k * f;
-            {
-                const int tx = tid & 15, ty = tid >> 4, tys = nt >> 4;
-                for (int j = ty; j < pc; j += tys) {
-                    const double cj = colk[j];
-                    double* Wj = W + (k + 1) + (k + 1 + j) * f;
-                    for (int i = j + tx; i < r; i += 16) Wj[i] -= (colk[i] * dinv) * cj;
-                }
-            }
-            __syncthreads();
-        }
-        {   // deferred scaling of the finished columns (see front_factor)
-            const int tx = tid & 15, ty = tid >> 4, tys = nt >> 4;
-            for (int k = ty; k < w; k += tys) {
-                double d = W[k + k * f];
-                if (d == 0.0) d = 1.0;
-                const double dinv = pivot_rcp(d);
-                for (int i = k + 1 + tx; i < f; i += 16) W[i + k * f] *= dinv;
-            }
-        }
-        __syncthreads();
-        const int u = f - w;
-        if (u > 0) {
-            schur_2x2(W, f, w, u, tid, nt);
-            __syncthreads();
-        }
-        double* F = fronts + me.front_off;
-        for (int idx = tid; idx < f * w; idx += nt) F[idx] = W[idx];
-        const bool keep = me.parent == s + 1 && s + 1 <= hi;
-        if (!keep && u > 0) {
-            const int tx = tid & 15, ty = tid >> 4, tys = nt >> 4;
-            for (int j = ty; j < u; j += tys)
-                for (int i = j + tx; i < u; i += 16) F[(w + i) + (long long)(w + j) * f] = W[(w + i) + (w + j) * f];
-        }
-        __syncthreads();
-        double* t = cur; cur = prev; prev = t;
-        prev_valid = keep;
-    }
-}
-
 // one workgroup per small subtree: its supernodes lo..hi (a postorder range, children before parents) are factored one
 // after the other by the same workgroup -- no launch and no inter-workgroup dependency inside the subtree
 __global__ __launch_bounds__(SUB_THREADS) void k_subtree_factor(FrontMeta M, double* __restrict__ fronts, const int* __restrict__ sub_lo, const int* __restrict__ sub_hi,
@@ -804,19 +702,14 @@ __device__ __forceinline__ void stx(double* p, double v)
     __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // single-wave workgroup: wait until *flag != 0 (bounded; a timeout raises err and lets the launch drain)
-// poll back-off of the flag waits: naps of 1, 2, 4 ... g_wait_nap_max x 64 cycles between two polls (set once per process from
-// PIQP_AMD_WAIT_NAP_MAX)
-__constant__ int g_wait_nap_max = 1;
-// debug: per-workgroup start / end / wait-done timestamps of the flag-ordered sweeps (PIQP_AMD_DBG_TS=file prefix)
+// debug: per-workgroup start / end / wait-done timestamps of the flag-ordered sweeps (PIQP_AMD_DEBUG=dbg_ts=<file prefix>)
 __device__ long long* g_dbg_ts = nullptr;
 __device__ __forceinline__ void wave_wait_flag(const int* flag, int* err, int epoch)
 {
     if (threadIdx.x == 0) {
         unsigned spins = 0;
-        int nap = 1;
         while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
-            for (int i = 0; i < nap; ++i) __builtin_amdgcn_s_sleep(1);
-            if (nap < g_wait_nap_max) nap <<= 1;
+            __builtin_amdgcn_s_sleep(1);  // (an exponential poll back-off was measured neutral and removed)
             if (++spins > 8000000u || ((spins & 15) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch)) {
                 __hip_atomic_store(err, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 break;
@@ -1377,15 +1270,6 @@ public:
         if (d->mem != PQ_MEM_HOST) throw std::runtime_error("sparse data must be host-resident");
         PQ_HIP(hipSetDevice(dev_));
         PQ_HIP(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
-        {
-            static bool nap_set = false;
-            if (!nap_set) {
-                const char* e = std::getenv("PIQP_AMD_WAIT_NAP_MAX");
-                const int v = e ? std::max(1, std::atoi(e)) : 1;
-                PQ_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_wait_nap_max), &v, sizeof(int)));
-                nap_set = true;
-            }
-        }
         sparse::analyse_kkt(d, mode, S_);
         n_ = S_.n; p_ = S_.p; m_ = S_.m; N_ = S_.N;
         compute_level_lds();
@@ -1396,8 +1280,6 @@ public:
         (void)hipSetDevice(dev_);
         if (st_) { (void)hipStreamSynchronize(st_); }
         if (comm_) rccl::comm_destroy(comm_);
-        if (factor_graph_) (void)hipGraphExecDestroy(factor_graph_);
-        if (solve_graph_) (void)hipGraphExecDestroy(solve_graph_);
         if (st_) (void)hipStreamDestroy(st_);
     }
 
@@ -1454,11 +1336,6 @@ public:
                 hipLaunchKernelGGL(k_unpack_updates, dim3(nb), dim3(256), 0, st_, M, fronts_.p, b_sn_.p, b_owner_.p, rank_, b_mat_off_.p, PT_.bmat_off.back(), info_.p, xbuf_factor_);
             }
             factor_levels(M, sh_ptr_, sh_sn_, sh_sn_d_.p, sh_lds_);
-        } else if (use_graphs_) {
-            // the numeric phase touches only handle-owned buffers: recorded once, replayed as one graph launch
-            if (!factor_graph_) factor_graph_ = capture([&] { factor_numeric(M); });
-            if (factor_graph_) PQ_HIP(hipGraphLaunch(factor_graph_, st_));
-            else factor_numeric(M);
         } else {
             factor_numeric(M);
         }
@@ -1507,10 +1384,6 @@ public:
                 hipLaunchKernelGGL(k_unpack_spans, dim3(std::max(1, std::min(256, (PT_.max_span + 255) / 256)), world_), dim3(256), 0, st_, world_, rank_, PT_.max_span, span_lo_d_.p,
                                    span_hi_d_.p, xbuf_gather_, xp_.p);
             }
-        } else if (use_graphs_) {
-            if (!solve_graph_) solve_graph_ = capture([&] { solve_numeric(M); });
-            if (solve_graph_) PQ_HIP(hipGraphLaunch(solve_graph_, st_));
-            else solve_numeric(M);
         } else {
             solve_numeric(M);
         }
@@ -1620,7 +1493,7 @@ public:
         std::printf("substitution schedule: %d single-wave walks, %d supernodes in %d flag-ordered levels above them\n", (int)S_.solve_sub_lo.size(), ntop_solve_, S_.solve_top_nlevels);
         std::printf("substitution top: %d chain walks; factor top: %d chain walks over %d supernodes\n", nwalk_solve_, ntopwalk_, top_nper_);
         std::printf("top of the tree: %d supernodes in %d levels: %d level launches, then %d supernodes in one persistent launch\n", ntop_, S_.top_nlevels, top_l0_, top_nper_);
-        if (std::getenv("PIQP_AMD_PRINT_LEVELS")) {
+        if (debug_token("print_levels")) {
             for (int l = 0; l < S_.top_nlevels; ++l) {
                 int mf = 0, mw = 0; double fl = 0.0;
                 for (int q = S_.top_level_ptr[l]; q < S_.top_level_ptr[l + 1]; ++q) {
@@ -1632,8 +1505,7 @@ public:
             }
         }
         for (const SubClass& c : sched_.cls)
-            std::printf("subtree walk class: %d subtrees, front capacity %d doubles, %d threads, %d bytes of LDS per workgroup%s\n", c.nsub, c.cap, c.threads, c.bytes,
-                        c.staged ? " (metadata staged in LDS)" : "");
+            std::printf("subtree walk class: %d subtrees, front capacity %d doubles, %d threads, %d bytes of LDS per workgroup\n", c.nsub, c.cap, c.threads, c.bytes);
         std::printf("sparse multifrontal LDLt (%s ordering): N = %d, nnz(K) = %d, nnz(L) = %lld, supernodes = %d, tree levels = %d (%d subtrees walked by one workgroup each + %d level launches), max front = %d, front storage = %.1f MB\n",
                     S_.ordering, N_, nnzK_, S_.nnzL, S_.nsuper, S_.nlevels, S_.nsub, S_.top_nlevels, S_.max_front, S_.front_doubles * 8.0 / 1e6);
     }
@@ -1686,7 +1558,6 @@ private:
             PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_subtree_factor), hipFuncAttributeMaxDynamicSharedMemorySize, (LDS_FRONT_DOUBLES + IND_SCRATCH) * (int)sizeof(double)));
             PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_subtree_factor_lds), hipFuncAttributeMaxDynamicSharedMemorySize, SUBTREE_LDS_BYTES));
             PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_subtree_factor_pk), hipFuncAttributeMaxDynamicSharedMemorySize, SUBTREE_LDS_BYTES));
-            PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_subtree_factor_staged), hipFuncAttributeMaxDynamicSharedMemorySize, SUBTREE_LDS_BYTES));
             PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_top_factor), hipFuncAttributeMaxDynamicSharedMemorySize, (LDS_FRONT_DOUBLES + IND_SCRATCH) * (int)sizeof(double)));
             attr_set = true;
         }
@@ -1718,10 +1589,10 @@ private:
         top_grid_ = std::min(ntop_, 224);
         // measured: worth it for the factorisation when every top supernode gets its own workgroup; the substitution fronts are too
         // cheap to pay for agent-scope release / acquire per supernode, they stay on level launches
-        top_persistent_ = ntop_ > 0 && ntop_ <= 1024 && !any_big && !std::getenv("PIQP_AMD_TOP_LEVELS");
+        top_persistent_ = ntop_ > 0 && ntop_ <= 1024 && !any_big && !debug_token("top_levels");
         // the levels from top_l0_ on (at most 1024 supernodes, none on the dense multi-launch path) go into the persistent launch
         top_l0_ = S_.top_nlevels;
-        if (!std::getenv("PIQP_AMD_TOP_LEVELS")) {
+        if (!debug_token("top_levels")) {
             for (int l = S_.top_nlevels - 1; l >= 0; --l) {
                 bool big = false;
                 for (int q = S_.top_level_ptr[l]; q < S_.top_level_ptr[l + 1]; ++q) {
@@ -1737,7 +1608,7 @@ private:
         if (top_nper_ < 2) { top_l0_ = S_.top_nlevels; top_start_ = ntop_; top_nper_ = 0; }  // a single supernode gains nothing
         // chains of the persistent part -> walks (k_top_factor_walk) when two packed fronts of the largest one fit the LDS
         ntopwalk_ = 0; top_walk_cap_ = 0;
-        if (top_nper_ > 0 && !std::getenv("PIQP_AMD_TOP_NO_WALKS")) {
+        if (top_nper_ > 0 && !debug_token("top_no_walks")) {
             std::vector<int> pos(S_.nsuper, -1);
             for (int q = top_start_; q < ntop_; ++q) pos[S_.top_level_sn[q]] = q;
             std::vector<std::pair<int, std::pair<int, int>>> walks;
@@ -1775,8 +1646,8 @@ private:
             // flags carry the number of the factorisation that set them (no memset in between; a recorded graph replays fixed arguments,
             // so there they are zeroed and the epoch stays 1)
             int epoch = 1;
-            if (use_graphs_ || factor_epoch_ >= 2000000000) { PQ_HIP(hipMemsetAsync(top_flags_.p, 0, sizeof(int) * (2 * (size_t)ntop_ + 1), st_)); factor_epoch_ = 0; }
-            if (!use_graphs_) epoch = ++factor_epoch_;
+            if (factor_epoch_ >= 2000000000) { PQ_HIP(hipMemsetAsync(top_flags_.p, 0, sizeof(int) * (2 * (size_t)ntop_ + 1), st_)); factor_epoch_ = 0; }
+            epoch = ++factor_epoch_;
             if (ntopwalk_ > 0)
                 hipLaunchKernelGGL(k_top_factor_walk, dim3(std::min(ntopwalk_, 224)), dim3(top_threads()), 2 * (size_t)top_walk_cap_ * sizeof(double), st_, M, fronts_.p, vals_.p, fe_offp_.p,
                                    top_walk_lo_.p, top_walk_hi_.p, ntopwalk_, top_pos_.p, top_start_, top_walk_cap_, top_flags_.p, top_flags_.p + 2 * ntop_, rdiag_.p, info_.p, epoch);
@@ -1791,17 +1662,17 @@ private:
         const int nt = ntop_solve_;
         subtree_fwd(M, solve_sched_);
         // the top of the tree: one launch per sweep when every top front fits the single-wave kernels, else one launch per level
-        bool wave_top = nt > 1 && !std::getenv("PIQP_AMD_TOP_LEVELS_SOLVE") && !std::getenv("PIQP_AMD_SUBTREE_SOLVE_V1");
+        bool wave_top = nt > 1 && !debug_token("top_levels_solve");
         if (wave_top) for (int s2 : S_.solve_top_level_sn) if (S_.front_rows_ptr[s2 + 1] - S_.front_rows_ptr[s2] > 128) { wave_top = false; break; }
         // flags carry the number of the solve that set them: no memset between solves (a recorded graph replays fixed arguments, so there
         // the flags are zeroed and the epoch stays 1)
         int epoch = 1;
         solve_err_ptr_ = nullptr; solve_epoch_used_ = 0;
         if (wave_top) {
-            if (use_graphs_ || solve_epoch_ >= 2000000000) { PQ_HIP(hipMemsetAsync(solve_flags_.p, 0, sizeof(int) * (2 * (size_t)nt + 1), st_)); solve_epoch_ = 0; }
-            if (!use_graphs_) epoch = ++solve_epoch_;
+            if (solve_epoch_ >= 2000000000) { PQ_HIP(hipMemsetAsync(solve_flags_.p, 0, sizeof(int) * (2 * (size_t)nt + 1), st_)); solve_epoch_ = 0; }
+            epoch = ++solve_epoch_;
             solve_err_ptr_ = solve_flags_.p + 2 * nt; solve_epoch_used_ = epoch;
-            static const char* dbg_ts = std::getenv("PIQP_AMD_DBG_TS");
+            static const char* dbg_ts = debug_token("dbg_ts");
             DBuf<long long> ts;
             if (dbg_ts) { ts.alloc(3 * (size_t)nwalk_solve_); long long* pp = ts.p; PQ_HIP(hipMemsetAsync(ts.p, 0, ts.bytes(), st_)); PQ_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_ts), &pp, sizeof(pp))); }
             hipLaunchKernelGGL(k_subtree_fwd_wave<true>, dim3(nwalk_solve_), dim3(64), 0, st_, M, fronts_.p, solve_walk_lo_.p, solve_walk_hi_.p, xp_.p, fvec_.p, solve_top_pos_.p, solve_flags_.p,
@@ -1820,7 +1691,7 @@ private:
                 }
             }
         } else fwd_levels(M, S_.solve_top_level_ptr, S_.solve_top_level_sn, solve_level_sn_.p);
-        bool fuse_scale = wave_top && !std::getenv("PIQP_AMD_SUBTREE_SOLVE_V1");
+        bool fuse_scale = wave_top;
         for (const SubClass& c : solve_sched_.cls) if (c.fmax > 128) fuse_scale = false;
         const double* rd = fuse_scale ? rdiag_.p : nullptr;  // the diagonal solve rides in the backward kernels when they are all single-wave
         if (!fuse_scale) hipLaunchKernelGGL(k_scale, g1(N_), dim3(256), 0, st_, N_, rdiag_.p, xp_.p);
@@ -1831,21 +1702,6 @@ private:
         } else bwd_levels(M, S_.solve_top_level_ptr, S_.solve_top_level_sn, solve_level_sn_.p);
         subtree_bwd(M, solve_sched_, rd);
     }
-    // records what `body` launches on the handle's stream into an executable graph (nullptr if the runtime refuses: the caller then
-    // launches directly)
-    template <class F>
-    hipGraphExec_t capture(F&& body)
-    {
-        hipGraph_t g = nullptr;
-        hipGraphExec_t exec = nullptr;
-        if (hipStreamBeginCapture(st_, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); use_graphs_ = false; return nullptr; }
-        body();
-        if (hipStreamEndCapture(st_, &g) != hipSuccess || !g) { (void)hipGetLastError(); use_graphs_ = false; return nullptr; }
-        if (hipGraphInstantiate(&exec, g, nullptr, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); exec = nullptr; use_graphs_ = false; }
-        (void)hipGraphDestroy(g);
-        return exec;
-    }
-
     // data crosses ranks: the stream is drained, the caller's collective runs (pq_exchange_fn), then the stream continues
     void exchange(int which)
     {
@@ -1865,36 +1721,25 @@ private:
         PQ_HIP(hipStreamSynchronize(st_));
         if (xfn_(xuser_, which) != 0) throw std::runtime_error("exchange callback failed");
     }
-    // ---- subtree schedule: subtrees are binned by the LDS their walk needs (two fronts of their largest front order + the staged
-    // metadata), one launch per class with exactly that much dynamic LDS -- a schedule sized for the largest subtree of the problem
-    // leaves one workgroup per CU when a single subtree has a 96 x 96 front
+    // ---- subtree schedule: one launch of all subtree walks with the dynamic LDS of the largest walk (two fronts of its largest front order)
     void build_sub_schedule(const std::vector<int>& subs, SubSchedule& out)
     {
         out.cls.clear();
-        // measured (C3, C5): launches of different classes run back to back and their tails add up (C5 backend solve 1.4 -> 2.1 ms with four
-        // classes), and staging the metadata costs more occupancy than the latency it removes (C5 factor 2.1 -> 3.9 ms at 54 KB per
-        // workgroup) -- so by default there is ONE class sized for the largest subtree and no staging; both stay available for experiments
-        static const int all_limits[] = {8 << 10, 12 << 10, 16 << 10, 20 << 10, 26 << 10, 32 << 10, 40 << 10, 52 << 10, 78 << 10, SUBTREE_LDS_BYTES};
-        static const int one_limit[] = {SUBTREE_LDS_BYTES};
-        const bool classes = std::getenv("PIQP_AMD_SUBTREE_CLASSES") != nullptr;
-        const int* limits = classes ? all_limits : one_limit;
-        const int ncls = classes ? (int)(sizeof(all_limits) / sizeof(all_limits[0])) : 1;
-        const bool want_stage = std::getenv("PIQP_AMD_SUBTREE_STAGED") != nullptr;
+        // ONE class sized for the largest subtree.  Measured and removed (round 1): several LDS size classes -- their launches run back to back
+        // and the tails add up (C5 backend solve 1.4 -> 2.1 ms with four classes) -- and staging the per-subtree metadata in LDS, which costs
+        // more occupancy than the latency it removes (C5 factor 2.1 -> 3.9 ms at 54 KB per workgroup)
+        static const int limits[] = {SUBTREE_LDS_BYTES};
+        const int ncls = 1;
         std::vector<std::vector<int>> members(ncls);
         struct Need { int fm, ent, rel, sn; };
         std::vector<Need> need(subs.size());
-        auto bytes_of = [&](long long cap, const Need& q, bool staged) -> long long {
-            long long b = 2 * cap * 8;
-            if (staged) b += (long long)((q.ent + 1) & ~1) * 8 + (long long)q.sn * (long long)sizeof(SnRec) + (long long)((q.ent + 1) & ~1) * 4 + (long long)(q.rel + 1) * 4 + (long long)(q.sn + 1) * 4 + 16;
-            return b;
-        };
+        auto bytes_of = [&](long long cap) -> long long { return 2 * cap * 8; };
         for (size_t i = 0; i < subs.size(); ++i) {
             const int lo = S_.sub_lo[subs[i]], hi = S_.sub_hi[subs[i]];
             Need q{0, S_.fe_ptr[hi + 1] - S_.fe_ptr[lo], S_.rel_ptr[hi + 1] - S_.rel_ptr[lo], hi - lo + 1};
             for (int t = lo; t <= hi; ++t) q.fm = std::max(q.fm, S_.front_rows_ptr[t + 1] - S_.front_rows_ptr[t]);
             need[i] = q;
-            long long b = bytes_of((long long)q.fm * q.fm, q, want_stage);
-            if (b > SUBTREE_LDS_BYTES) b = bytes_of((long long)q.fm * q.fm, q, false);
+            const long long b = bytes_of((long long)q.fm * q.fm);
             int c = 0;
             while (c + 1 < ncls && b > limits[c]) ++c;
             members[c].push_back((int)i);
@@ -1913,8 +1758,7 @@ private:
                         work[i] += w * w * w / 3.0 + w * w * u + w * u * u + 2.0 * f * f + 3000.0;
                     }
                 }
-                if (!std::getenv("PIQP_AMD_SUBTREE_POSTORDER"))
-                    std::stable_sort(members[c].begin(), members[c].end(), [&](int a, int b) { return work[a] > work[b]; });
+                std::stable_sort(members[c].begin(), members[c].end(), [&](int a, int b) { return work[a] > work[b]; });
             }
             for (int i : members[c]) {
                 mx.fm = std::max(mx.fm, need[i].fm); mx.ent = std::max(mx.ent, need[i].ent); mx.rel = std::max(mx.rel, need[i].rel); mx.sn = std::max(mx.sn, need[i].sn);
@@ -1923,45 +1767,30 @@ private:
             k.nsub = (int)lo.size();
             k.cap = mx.fm * mx.fm;
             k.fmax = mx.fm;
-            k.stage.ent_cap = (mx.ent + 1) & ~1; k.stage.rel_cap = mx.rel + 1; k.stage.sn_cap = mx.sn;
-            long long b = bytes_of(k.cap, mx, want_stage);
-            k.staged = want_stage && b <= SUBTREE_LDS_BYTES;
-            if (!k.staged) b = bytes_of(k.cap, mx, false);
+            long long b = bytes_of(k.cap);
             k.bytes = (int)b;
-            k.lds_walk = b <= SUBTREE_LDS_BYTES && !std::getenv("PIQP_AMD_SUBTREE_HBM");
+            k.lds_walk = b <= SUBTREE_LDS_BYTES;
             // a walk keeps only the lower triangles of its two fronts when that raises the occupancy: half the LDS (C3: two workgroups per CU instead of one)
-            // (PIQP_AMD_SUBTREE_PACKED=0 / 1 forces it off / on for every class)
+            // (PIQP_AMD_DEBUG=subtree_packed=0 / 1 forces it off / on: bitwise-consistency test)
             {
-                static const char* pe = std::getenv("PIQP_AMD_SUBTREE_PACKED");
+                static const char* pe = debug_token("subtree_packed");
                 // default: packed whenever that lets more walks share a CU (at most eight 256-thread workgroups fit by waves)
                 const long long bp = 2LL * ((long long)mx.fm * (mx.fm + 1) / 2) * 8;
                 const auto per_cu = [](long long bytes) { return std::min<long long>(8, (160 * 1024) / std::max<long long>(bytes, 1)); };
-                k.packed = k.lds_walk && !k.staged && (pe ? pe[0] == '1' : per_cu(bp) > per_cu(b));
+                k.packed = k.lds_walk && (pe ? pe[0] == '1' : per_cu(bp) > per_cu(b));
                 if (k.packed) { k.cap = (mx.fm * (mx.fm + 1)) / 2; b = 2LL * k.cap * 8; k.bytes = (int)b; }
             }
-            static const int thr_env = std::getenv("PIQP_AMD_SUBTREE_THREADS") ? std::atoi(std::getenv("PIQP_AMD_SUBTREE_THREADS")) : 0;
             // a workgroup that has the CU to itself (LDS) gets eight waves instead of four: measured 1.08 -> 1.04 ms on C3; with several
             // workgroups per CU more threads only add barrier cost (C5: 1.45 -> 2.0 ms)
-            k.threads = thr_env > 0 ? thr_env : (b > 80 * 1024 ? 512 : (k.packed && b > 52 * 1024 ? 384 : SUB_THREADS));  // two packed walks per CU: 384 (C3 0.82 -> 0.79 ms)
+            k.threads = b > 80 * 1024 ? 512 : (k.packed && b > 52 * 1024 ? 384 : SUB_THREADS);  // two packed walks per CU: 384 (C3 0.82 -> 0.79 ms)
             upload_vec(k.lo, lo, st_); upload_vec(k.hi, hi, st_);
             out.cls.push_back(std::move(k));
         }
     }
-    static int top_threads()
-    {
-        static int v = -1;
-        if (v < 0) { const char* e = std::getenv("PIQP_AMD_TOP_THREADS"); v = e ? std::min(512, std::max(64, std::atoi(e))) : 512; }  // measured: 512 beats 256 (C3 1.04 -> 0.98 ms)
-        return v;
-    }
-    static int bwd_red_thr()
-    {
-        static int v = -1;
-        if (v < 0) { const char* e = std::getenv("PIQP_AMD_BWD_RED"); v = e ? std::atoi(e) : 6; }  // 3 before the split-wave product existed; 6: C3 solve 0.31 -> 0.29 ms
-        return v;
-    }
+    static int top_threads() { return 512; }  // measured: 512 beats 256 (C3 1.04 -> 0.98 ms)
+    static int bwd_red_thr() { return 6; }    // 3 before the split-wave product existed; 6: C3 solve 0.31 -> 0.29 ms
     void build_full_schedule()
     {
-        { const char* e = std::getenv("PIQP_AMD_GRAPHS"); use_graphs_ = e && e[0] == '1'; }
         std::vector<int> all(S_.nsub);
         for (int k = 0; k < S_.nsub; ++k) all[k] = k;
         build_sub_schedule(all, sched_);
@@ -1979,23 +1808,21 @@ private:
     void subtree_fwd(const FrontMeta& M, const SubSchedule& sc)
     {
         for (const SubClass& c : sc.cls) {
-            if (c.fmax <= 128 && !std::getenv("PIQP_AMD_SUBTREE_SOLVE_V1")) hipLaunchKernelGGL(k_subtree_fwd_wave<false>, dim3(c.nsub), dim3(64), 0, st_, M, fronts_.p, c.lo.p, c.hi.p, xp_.p, fvec_.p, (const int*)nullptr, (int*)nullptr, (int*)nullptr, (const int*)nullptr, 0);
+            if (c.fmax <= 128) hipLaunchKernelGGL(k_subtree_fwd_wave<false>, dim3(c.nsub), dim3(64), 0, st_, M, fronts_.p, c.lo.p, c.hi.p, xp_.p, fvec_.p, (const int*)nullptr, (int*)nullptr, (int*)nullptr, (const int*)nullptr, 0);
             else hipLaunchKernelGGL(k_subtree_fwd, dim3(c.nsub), dim3(SUB_SOLVE_THREADS), 0, st_, M, fronts_.p, c.lo.p, c.hi.p, xp_.p, fvec_.p);
         }
     }
     void subtree_bwd(const FrontMeta& M, const SubSchedule& sc, const double* rd = nullptr)
     {
         for (const SubClass& c : sc.cls) {
-            if (c.fmax <= 128 && !std::getenv("PIQP_AMD_SUBTREE_SOLVE_V1")) hipLaunchKernelGGL(k_subtree_bwd_wave<false>, dim3(c.nsub), dim3(64), 0, st_, M, fronts_.p, c.lo.p, c.hi.p, xp_.p, bwd_red_thr(), 0, (const int*)nullptr, (int*)nullptr, (int*)nullptr, (const int*)nullptr, 0, rd);
+            if (c.fmax <= 128) hipLaunchKernelGGL(k_subtree_bwd_wave<false>, dim3(c.nsub), dim3(64), 0, st_, M, fronts_.p, c.lo.p, c.hi.p, xp_.p, bwd_red_thr(), 0, (const int*)nullptr, (int*)nullptr, (int*)nullptr, (const int*)nullptr, 0, rd);
             else hipLaunchKernelGGL(k_subtree_bwd, dim3(c.nsub), dim3(SUB_SOLVE_THREADS), 0, st_, M, fronts_.p, c.lo.p, c.hi.p, xp_.p, fvec_.p);
         }
     }
     void factor_subtrees(const FrontMeta& M, const SubSchedule& sc)
     {
         for (const SubClass& c : sc.cls) {
-            if (c.lds_walk && c.staged)
-                hipLaunchKernelGGL(k_subtree_factor_staged, dim3(c.nsub), dim3(c.threads), c.bytes, st_, M, fronts_.p, c.lo.p, c.hi.p, c.cap, c.stage, rdiag_.p, info_.p);
-            else if (c.lds_walk && c.packed)
+            if (c.lds_walk && c.packed)
                 hipLaunchKernelGGL(k_subtree_factor_pk, dim3(c.nsub), dim3(c.threads), c.bytes, st_, M, fronts_.p, vals_.p, fe_offp_.p, c.lo.p, c.hi.p, c.cap, rdiag_.p, info_.p);
             else if (c.lds_walk)
                 hipLaunchKernelGGL(k_subtree_factor_lds, dim3(c.nsub), dim3(c.threads), c.bytes, st_, M, fronts_.p, vals_.p, fe_ptr_.p, fe_q_.p, fe_off_.p, c.lo.p, c.hi.p, c.cap, rdiag_.p,
@@ -2023,7 +1850,6 @@ private:
     // kernels as the subtree walk with lo = hi = the supernode); wider fronts keep the 256-thread kernels
     bool level_is_narrow(const std::vector<int>& ptr, const std::vector<int>& sn, int l) const
     {
-        if (std::getenv("PIQP_AMD_SUBTREE_SOLVE_V1")) return false;
         for (int q = ptr[l]; q < ptr[l + 1]; ++q) if (S_.front_rows_ptr[sn[q] + 1] - S_.front_rows_ptr[sn[q]] > 128) return false;
         return true;
     }
@@ -2233,8 +2059,6 @@ private:
     DBuf<int> info_;
     HBuf<int> info_h_;
     StageProfiler prof_;
-    bool use_graphs_ = false;
-    hipGraphExec_t factor_graph_ = nullptr, solve_graph_ = nullptr;
     // stage partition (pq_kkt_partition)
     bool part_on_ = false;
     int rank_ = 0, world_ = 1;

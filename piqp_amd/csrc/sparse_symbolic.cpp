@@ -562,7 +562,6 @@ void analyse_kkt(const pq_sparse_data* d, int mode, Symbolic& S)
     if (ord == "amd" || (ord == "auto" && N < 200)) { analyse_with_order(S, perm_amd); S.ordering = "amd"; return; }
     IVec perm_nd(N);
     int nd_leaf = 256;  // measured with the leaf amalgamation: 96 -> 256 is +8 % on C3 and +5 % on the n = 500k chain, 384 falls off a cliff
-    if (const char* e = std::getenv("PIQP_AMD_ND_LEAF")) nd_leaf = std::max(8, std::atoi(e));
     nd_order(N, S.Kp.data(), S.Ki.data(), perm_nd.data(), nd_leaf);
     Symbolic T = S;
     analyse_with_order(T, perm_nd);
@@ -629,8 +628,7 @@ static void analyse_with_order(Symbolic& S, const IVec& perm0, const IVec* force
             for (int j = S.sn_first[q]; j < hi; ++j) S.sn_of_col[j] = (int)q;
         }
     } else {
-        const char* rx = std::getenv("PIQP_AMD_RELAX");
-        const bool relax = !(rx && rx[0] == '0');
+        const bool relax = true;
         // merged fronts never exceed the largest front of the exact partition (capped at 64): the subtree walkers size their LDS for
         // the largest front, so a bigger one costs occupancy everywhere (measured on the n = 500k chain: 37 -> 50 rows, factor +16 %)
         int fcap = 32;
@@ -642,7 +640,6 @@ static void analyse_with_order(Symbolic& S, const IVec& perm0, const IVec* force
                 if (j + 1 == N || !(S.etree[j] == j + 1 && cc[j] == cc[j + 1] + 1)) fcap = std::max(fcap, (j - a + 1) + cc[j]);
             }
             fcap = std::min(fcap, 64);
-            if (const char* e = std::getenv("PIQP_AMD_FCAP")) fcap = std::max(fcap, std::min(96, std::atoi(e)));  // experiments: allow larger merged fronts
         }
         int a = 0;            // first column of the current supernode
         long long sumcc = 0;  // sum of cc over its columns
@@ -713,10 +710,8 @@ static void analyse_with_order(Symbolic& S, const IVec& perm0, const IVec* force
     // {pivots} + struct(L_last).  That needs the leaves next to their parent in the elimination order: the children of every supernode
     // are reordered (any postorder of the tree has the same fill) -- other children first, largest subtree last among them so that the
     // chain walks follow the spine, then the merged leaves, then the parent -- and the analysis is redone for that order.
-    if (!forced_first && !(std::getenv("PIQP_AMD_LEAF_MERGE") && std::getenv("PIQP_AMD_LEAF_MERGE")[0] == '0')) {
+    if (!forced_first) {
         int WMAX = 32, FMAX = 64;
-        if (const char* e = std::getenv("PIQP_AMD_LEAF_MERGE_W")) WMAX = std::max(2, std::atoi(e));
-        if (const char* e = std::getenv("PIQP_AMD_LEAF_MERGE_F")) FMAX = std::max(8, std::atoi(e));
         IVec weff(ns), live_children(ns, 0), merged_into(ns, -1), sub_cols(ns, 0);
         for (int s2 = 0; s2 < ns; ++s2) { weff[s2] = S.sn_first[s2 + 1] - S.sn_first[s2]; live_children[s2] = S.child_ptr[s2 + 1] - S.child_ptr[s2]; }
         long long nmerged = 0;
@@ -787,7 +782,7 @@ static void analyse_with_order(Symbolic& S, const IVec& perm0, const IVec* force
             if ((int)perm1.size() == N) { analyse_with_order(S, perm1, &first1); return; }
         }
     }
-    if (std::getenv("PIQP_AMD_SN_STATS")) {
+    if (debug_token("sn_stats")) {
         long long leaves = 0, leaf_small = 0, one_child = 0, hist[9] = {0};
         long long nchild_hist[6] = {0};
         for (int s = 0; s < ns; ++s) {
@@ -858,12 +853,11 @@ static void analyse_with_order(Symbolic& S, const IVec& perm0, const IVec* force
     };
     {
         int SUB_COLS = 192, SUB_FMAX = 96;  // two 96 x 96 fronts fit the 160 KiB of LDS of one workgroup
-        if (const char* e = std::getenv("PIQP_AMD_SUB_COLS")) SUB_COLS = std::max(8, std::atoi(e));
-        if (const char* e = std::getenv("PIQP_AMD_SUB_FMAX")) SUB_FMAX = std::min(96, std::max(8, std::atoi(e)));
+        if (const char* e = debug_token("sub_cols")) SUB_COLS = std::max(8, std::atoi(e));  // bitwise-consistency test: smaller walks
         subtree_schedule(SUB_COLS, SUB_FMAX, S.sub_lo, S.sub_hi, S.sub_max_front, S.top_level_ptr, S.top_level_sn, S.top_nlevels);
         // far more subtrees than the device runs at a time (a few thousand walks): longer walks instead, which also keeps the wide low
         // levels of the tree out of the level launches (n = 500k chain: 5875 -> 2900 subtrees, factor 1.03 -> 0.91 ms)
-        if (!std::getenv("PIQP_AMD_SUB_COLS"))
+        if (!debug_token("sub_cols"))
             while ((int)S.sub_lo.size() > 4096 && SUB_COLS < 768) {
                 SUB_COLS *= 2;
                 subtree_schedule(SUB_COLS, SUB_FMAX, S.sub_lo, S.sub_hi, S.sub_max_front, S.top_level_ptr, S.top_level_sn, S.top_nlevels);
@@ -873,7 +867,7 @@ static void analyse_with_order(Symbolic& S, const IVec& perm0, const IVec* force
         // larger flag-ordered top are faster there (C3 backend solve 0.52 -> 0.34 ms, C5-size chain 0.89 -> 0.79 ms at 24 columns, chains of the top merged into walks), the factorisation prefers the
         // long LDS-resident walks above
         int SOLVE_COLS = 24;
-        if (const char* e = std::getenv("PIQP_AMD_SOLVE_SUB_COLS")) SOLVE_COLS = std::atoi(e);
+        if (const char* e = debug_token("solve_sub_cols")) SOLVE_COLS = std::atoi(e);
         if (SOLVE_COLS <= 0 || SOLVE_COLS >= SUB_COLS) {
             S.solve_sub_lo = S.sub_lo; S.solve_sub_hi = S.sub_hi; S.solve_top_level_ptr = S.top_level_ptr; S.solve_top_level_sn = S.top_level_sn;
             S.solve_top_nlevels = S.top_nlevels; S.solve_sub_max_front = S.sub_max_front;
@@ -884,7 +878,7 @@ static void analyse_with_order(Symbolic& S, const IVec& perm0, const IVec* force
             const int nt = (int)S.solve_top_level_sn.size();
             IVec pos(ns, -1);
             for (int q = 0; q < nt; ++q) pos[S.solve_top_level_sn[q]] = q;
-            const bool merge = !std::getenv("PIQP_AMD_SOLVE_NO_CHAINS");
+            const bool merge = !debug_token("solve_no_chains");
             std::vector<std::pair<int, std::pair<int, int>>> walks;  // (position of the last supernode, (lo, hi))
             int s = 0;
             while (s < ns) {

@@ -76,3 +76,38 @@ def test_data_mirror_matches_oracle_data(orc):
     assert np.array_equal(np.triu(d.P_utri), np.triu(o.mat("P_utri")))
     assert np.array_equal(d.h_l, o.vec("h_l")) and np.array_equal(d.h_u, o.vec("h_u"))
     assert np.array_equal(d.x_l[: d.n_x_l], o.vec("x_l")[: d.n_x_l])
+
+
+@pytest.mark.gpu
+def test_no_allocation_after_create(hip):
+    """fwd.hpp:44-52 / the reference tests' PIQP_EIGEN_MALLOC_NOT_ALLOWED brackets: factor, solve, mat-vecs and the residual allocate nothing.
+    Here: the library's allocation counter (every hipMalloc / hipHostMalloc it makes) does not move after the handles exist -- in host
+    pointer mode (staging buffers come from *_create) and in device pointer mode, for the dense, sparse and multistage backends."""
+    import numpy as np
+    import torch
+    from qp_gen import dense_strongly_convex_qp, mpc_chain, random_vars
+    L = hip._lib.load()
+    rng = np.random.default_rng(0)
+    q = dense_strongly_convex_qp(300, 40, 200, seed=3)
+    chain = mpc_chain(6, 3, 60, 2)
+    cases = [(hip.Data(**q), 0), (hip.Data(**q), 16), (hip.SparseData(*chain), hip.SPARSE_LDLT), (hip.SparseData(*chain), 4), (hip.SparseData(*chain), hip.SPARSE_MULTISTAGE)]
+    for d, ks in cases:
+        k = hip.KKTSystem(d, hip.default_settings(kkt_solver=ks))
+        state = random_vars(d.n, d.p, d.m, rng, positive=True)
+        rhs = random_vars(d.n, d.p, d.m, rng)
+        dstate = {kk: torch.from_numpy(v).cuda() for kk, v in state.items()}
+        drhs = {kk: torch.from_numpy(v).cuda() for kk, v in rhs.items()}
+        dlhs = {kk: torch.zeros_like(v) for kk, v in drhs.items()}
+        torch.cuda.synchronize()
+        c0 = L.pq_debug_alloc_count()
+        for refine in (False, True):
+            assert k.update_scalings_and_factor(refine, 1e-6, 1e-4, state)
+            ok, lhs = k.solve(rhs)
+            assert ok
+            k.mul(lhs)
+            k.condensed_residual()
+            assert k.update_scalings_and_factor(refine, 1e-6, 1e-4, dstate)
+            ok, _ = k.solve(drhs, dlhs)
+            assert ok
+        k.synchronize()
+        assert L.pq_debug_alloc_count() == c0, (ks, L.pq_debug_alloc_count() - c0)

@@ -1,7 +1,7 @@
 """The sparse multifrontal backend picks its device schedule from the shape of the assembly tree (full or packed fronts in the LDS subtree
 walk, chain walks or one supernode per workgroup in the persistent top, a finer subtree partition and chain walks for the substitution).
 None of that may change a single bit of the result: the order of the floating-point operations of every front is fixed by the tree.  Each
-variant runs in its own process (the toggles are read once per process) on the same seeded systems and the solutions are compared
+variant runs in its own process (the one debugging variable PIQP_AMD_DEBUG is parsed once per process) on the same seeded systems and the solutions are compared
 bitwise."""
 import os
 import subprocess
@@ -17,14 +17,14 @@ WORKER = os.path.join(ROOT, "tests", "workers", "sparse_variant.py")
 
 VARIANTS = {
     "default": {},
-    "packed_fronts_forced": {"PIQP_AMD_SUBTREE_PACKED": "1"},
-    "full_fronts_forced": {"PIQP_AMD_SUBTREE_PACKED": "0"},
-    "top_one_supernode_per_workgroup": {"PIQP_AMD_TOP_NO_WALKS": "1"},
-    "top_level_launches": {"PIQP_AMD_TOP_LEVELS": "1"},
-    "solve_on_factor_partition": {"PIQP_AMD_SOLVE_SUB_COLS": "0"},
-    "solve_without_chain_walks": {"PIQP_AMD_SOLVE_NO_CHAINS": "1"},
-    "solve_level_launches": {"PIQP_AMD_TOP_LEVELS_SOLVE": "1"},
-    "small_subtrees": {"PIQP_AMD_SUB_COLS": "48", "PIQP_AMD_SOLVE_SUB_COLS": "8"},
+    "packed_fronts_forced": {"PIQP_AMD_DEBUG": "subtree_packed=1"},
+    "full_fronts_forced": {"PIQP_AMD_DEBUG": "subtree_packed=0"},
+    "top_one_supernode_per_workgroup": {"PIQP_AMD_DEBUG": "top_no_walks"},
+    "top_level_launches": {"PIQP_AMD_DEBUG": "top_levels"},
+    "solve_on_factor_partition": {"PIQP_AMD_DEBUG": "solve_sub_cols=0"},
+    "solve_without_chain_walks": {"PIQP_AMD_DEBUG": "solve_no_chains"},
+    "solve_level_launches": {"PIQP_AMD_DEBUG": "top_levels_solve"},
+    "small_subtrees": {"PIQP_AMD_DEBUG": "sub_cols=48,solve_sub_cols=8"},
 }
 
 

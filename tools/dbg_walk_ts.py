@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Reads the timestamp dump of the flag-ordered forward sweep (PIQP_AMD_DBG_TS=<file>) and prints when workgroups start / stop waiting / end."""
+"""Reads the timestamp dump of the flag-ordered forward sweep (PIQP_AMD_DEBUG=dbg_ts=<file>) and prints when workgroups start / stop waiting / end."""
 import sys
 import numpy as np
 f = open(sys.argv[1], "rb").read()
