@@ -129,7 +129,8 @@ __device__ __forceinline__ void scale_tile(const double* __restrict__ w, int k0,
 // diagonal-block factorisation on an LDS-resident block (defined with k_potrf_diag below)
 template <bool LDLT, int NWAVES>
 __device__ __forceinline__ void potrf_block(double* __restrict__ Tb, double* __restrict__ rds, int nb, int kglobal, int* __restrict__ info, double* __restrict__ rdiag,
-                                            double* __restrict__ dvec, double* __restrict__ Aout, int lda, double* __restrict__ pack, long long* __restrict__ ts = nullptr);
+                                            double* __restrict__ dvec, double* __restrict__ Aout, int lda, double* __restrict__ pack, double* __restrict__ w16,
+                                            long long* __restrict__ ts = nullptr);
 __device__ __forceinline__ int tb_index(int bi, int bj);
 __device__ __forceinline__ void tile_store(double* __restrict__ blk, int lane, d4 t);
 template <int NT>
@@ -618,11 +619,13 @@ __device__ __forceinline__ void tile_trsm_rt(d4& x, const d4& L, const d4& rdc, 
 //   wave k      meanwhile inverts L_kk -- off the critical path, its block row is finished -- for the panel kernel below.
 // Outputs: the factor (lower triangle) to Aout, reciprocal pivots to rdiag[kglobal..], D to dvec (LDLT, nullable), and `pack`
 // (nullable): the operand pack of k_trsm_panel -- 28 strictly-lower blocks of -L at j (j - 1) / 2 + k, then the 8 inverted
-// diagonal pieces W_jj, all as column-major 16 x 16 blocks.
+// diagonal pieces W_jj, all as column-major 16 x 16 blocks; `w16` (nullable): the same eight W_jj once more, into the array that holds them
+// for ALL diagonal pieces of the factor (the sweeps of launch_trsv multiply by them).
 constexpr int PACK_BLOCKS = 36;
 template <bool LDLT, int NWAVES>
 __device__ __forceinline__ void potrf_block(double* __restrict__ Tb, double* __restrict__ rds, int nb, int kglobal, int* __restrict__ info, double* __restrict__ rdiag,
-                            double* __restrict__ dvec, double* __restrict__ Aout, int lda, double* __restrict__ pack, long long* __restrict__ ts)
+                            double* __restrict__ dvec, double* __restrict__ Aout, int lda, double* __restrict__ pack, double* __restrict__ w16,
+                            long long* __restrict__ ts)
 {
     // ts (debugging aid, nullptr in production): shader-clock stamps of step k at ts[8 k + q] -- q = 0 / 1 wave k before / after its 16 x 16
     // factorisation, 2 / 3 wave k + 1 before / after its substitution, 4 / 5 wave k + 1 before / after its tile updates, 6 wave k after the inversion
@@ -684,7 +687,7 @@ __device__ __forceinline__ void potrf_block(double* __restrict__ Tb, double* __r
                 rdiag[kglobal + 16 * k + lane] = rd;
                 if (LDLT && dvec) dvec[16 * k + lane] = dmine;
             }
-            if (pack) {
+            if (pack || w16) {
                 d4 eye;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) eye[r] = (i == g + 4 * r) ? 1.0 : 0.0;
@@ -694,7 +697,8 @@ __device__ __forceinline__ void potrf_block(double* __restrict__ Tb, double* __r
                 d4 w = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) w = __builtin_amdgcn_mfma_f64_16x16x4f64(z[ks], eye[ks], w, 0, 0, 0);
-                tile_store(pack + (28 + k) * 256, lane, w);
+                if (pack) tile_store(pack + (28 + k) * 256, lane, w);
+                if (w16) tile_store(w16 + k * 256, lane, w);  // kept for the triangular sweeps (launch_trsv)
             }
             // ... and block row k of the factor goes to HBM now (its blocks (k, 0..k) are final and only READ from here on), so that no
             // store tail is left at the end: 128-byte segments; the negated strictly-lower blocks are the rest of the panel kernel's pack
@@ -716,7 +720,7 @@ __device__ __forceinline__ void potrf_block(double* __restrict__ Tb, double* __r
 constexpr int POTRF_THREADS = 512;
 template <bool LDLT>
 __global__ __launch_bounds__(POTRF_THREADS) void k_potrf_diag(double* __restrict__ A, int lda, int nb, int kglobal, int* __restrict__ info, double* __restrict__ rdiag,
-                                                              double* __restrict__ dvec, double* __restrict__ pack, long long* __restrict__ ts)
+                                                              double* __restrict__ dvec, double* __restrict__ pack, double* __restrict__ w16, long long* __restrict__ ts)
 {
     extern __shared__ __attribute__((aligned(16))) double Tb[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -738,10 +742,10 @@ __global__ __launch_bounds__(POTRF_THREADS) void k_potrf_diag(double* __restrict
         for (int q = 0; q < 4; ++q) Tb[b * 256 + lane + 64 * q] = v[q];
     }
     __syncthreads();
-    potrf_block<LDLT, POTRF_THREADS / 64>(Tb, Tb + TB_DOUBLES, nb, kglobal, info, rdiag, dvec, A, lda, pack, ts);
+    potrf_block<LDLT, POTRF_THREADS / 64>(Tb, Tb + TB_DOUBLES, nb, kglobal, info, rdiag, dvec, A, lda, pack, w16, ts);
 }
 
-void launch_potrf_diag(bool ldlt, double* A, int lda, int nb, int kglobal, int* info, double* rdiag, double* dvec, double* pack, hipStream_t s, long long* ts)
+void launch_potrf_diag(bool ldlt, double* A, int lda, int nb, int kglobal, int* info, double* rdiag, double* dvec, double* pack, double* w16, hipStream_t s, long long* ts)
 {
     static bool attr_set = false;
     if (!attr_set) {
@@ -749,8 +753,8 @@ void launch_potrf_diag(bool ldlt, double* A, int lda, int nb, int kglobal, int* 
         PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_diag<true>), hipFuncAttributeMaxDynamicSharedMemorySize, POTRF_LDS_BYTES));
         attr_set = true;
     }
-    if (ldlt) hipLaunchKernelGGL(k_potrf_diag<true>, dim3(1), dim3(POTRF_THREADS), POTRF_LDS_BYTES, s, A, lda, nb, kglobal, info, rdiag, dvec, pack, ts);
-    else hipLaunchKernelGGL(k_potrf_diag<false>, dim3(1), dim3(POTRF_THREADS), POTRF_LDS_BYTES, s, A, lda, nb, kglobal, info, rdiag, dvec, pack, ts);
+    if (ldlt) hipLaunchKernelGGL(k_potrf_diag<true>, dim3(1), dim3(POTRF_THREADS), POTRF_LDS_BYTES, s, A, lda, nb, kglobal, info, rdiag, dvec, pack, w16, ts);
+    else hipLaunchKernelGGL(k_potrf_diag<false>, dim3(1), dim3(POTRF_THREADS), POTRF_LDS_BYTES, s, A, lda, nb, kglobal, info, rdiag, dvec, pack, w16, ts);
     PQ_HIP(hipGetLastError());
 }
 
@@ -831,8 +835,8 @@ __device__ __forceinline__ void fused_next_diag(const SyrkArgs& a, double* __res
     __syncthreads();
     if (dbg_ts) a.fuse_ts[2] = clock64();
     long long* pts = a.fuse_ts ? a.fuse_ts + 8 : nullptr;
-    if (a.fuse_ldlt) potrf_block<true, NW>(Tb, Tb + TB_DOUBLES, nbn, a.fuse_kglobal, a.fuse_info, a.fuse_rdiag, a.fuse_dvec, a.C, a.ldc, a.fuse_pack, pts);
-    else potrf_block<false, NW>(Tb, Tb + TB_DOUBLES, nbn, a.fuse_kglobal, a.fuse_info, a.fuse_rdiag, a.fuse_dvec, a.C, a.ldc, a.fuse_pack, pts);
+    if (a.fuse_ldlt) potrf_block<true, NW>(Tb, Tb + TB_DOUBLES, nbn, a.fuse_kglobal, a.fuse_info, a.fuse_rdiag, a.fuse_dvec, a.C, a.ldc, a.fuse_pack, a.fuse_w16, pts);
+    else potrf_block<false, NW>(Tb, Tb + TB_DOUBLES, nbn, a.fuse_kglobal, a.fuse_info, a.fuse_rdiag, a.fuse_dvec, a.C, a.ldc, a.fuse_pack, a.fuse_w16, pts);
     if (dbg_ts) a.fuse_ts[3] = clock64();
 }
 
@@ -996,6 +1000,7 @@ __device__ __forceinline__ void diag_solve_bwd(const double* __restrict__ Ls, co
 
 constexpr int TB = 128;
 constexpr int TRSV_LDS_BYTES = (TB * (TB + 1) + 3 * TB) * (int)sizeof(double);
+constexpr int TRSV_P_LDS_BYTES = (TB * (TB + 1) + 3 * TB + 8 * 256 + 64) * (int)sizeof(double);  // + the eight inverted diagonal pieces, group scratch
 
 // forward step j: row blocks r >= j subtract L[r, j-1] * x_{j-1}; block r == j then solves L_jj y = b.
 // rdiag = reciprocal diagonal of L (nullptr: unit diagonal).  The diagonal workgroup issues the loads of
@@ -1123,15 +1128,21 @@ __device__ __forceinline__ double ld_agent(const double* p)
 // hand-off costs more than the shared streaming saves.  Round 2 tried replacing the serial 128-step diagonal substitution by a product with
 // the inverted diagonal block: 108 / 151 us per sweep, but the residuals on the rho = delta = 1e-10 states doubled and two iteration-parity
 // tests moved; with one refinement step against the block the accuracy returned and the time was worse than the substitution.  Both removed.)
+// The diagonal step runs in eight groups of 16 columns: x_g = W_g b_g with the explicitly inverted 16 x 16 diagonal piece W_g of the factorisation
+// (the conditioning level of the panel solve, which holds the accuracy gates of tests/dense_replay.py -- unlike a 128 x 128 inverse), one wave;
+// then every thread takes its 8 columns of the group off the rows still to be solved.  Two LDS barriers per group instead of a 128-step
+// dependent chain on one wave (4.2 us per block in round 1).  W16 == nullptr keeps that substitution (reciprocal pivots in rdiag).
 template <bool FWD>
 __global__ __launch_bounds__(256) void k_trsv_persistent(const double* __restrict__ L, int ld, int n, double* __restrict__ x, const double* __restrict__ rdiag,
-                                                         int nblk, int* __restrict__ flags, int* __restrict__ err)
+                                                         int nblk, int* __restrict__ flags, int* __restrict__ err, const double* __restrict__ W16)
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double* Ls = sm;                    // own diagonal block, Ls[c * (TB+1) + r]
     double* xs = sm + TB * (TB + 1);    // x_j of the block being consumed
     double* bs = xs + TB;
     double* rd = bs + TB;
+    double* Wg = rd + TB;               // eight inverted 16 x 16 diagonal pieces, column-major
+    double* up = Wg + 8 * 256;          // [2][16] partial updates of the current group, then [16] its solution
     __shared__ int ok_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ridx = (int)blockIdx.x;   // position of the block in sweep order
@@ -1140,6 +1151,10 @@ __global__ __launch_bounds__(256) void k_trsv_persistent(const double* __restric
     // stage the diagonal block (transposed for the backward sweep) and reciprocal pivots
     stage_lower_block<TB, TB + 1, 256, !FWD>(L + row0 + (size_t)row0 * ld, ld, nrows, Ls, tid);
     if (tid < TB) rd[tid] = (rdiag && tid < nrows) ? rdiag[row0 + tid] : 1.0;
+    if (W16) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) Wg[u * 256 + tid] = W16[(size_t)r * 8 * 256 + u * 256 + tid];
+    }
     const int row = tid & 127, half = tid >> 7;
     double mine = (half == 0 && row < nrows) ? x[row0 + row] : 0.0;
     double acc = 0.0;
@@ -1217,6 +1232,48 @@ __global__ __launch_bounds__(256) void k_trsv_persistent(const double* __restric
     if (half == 1) bs[row] = acc;
     __syncthreads();
     if (half == 0) bs[row] = mine - (acc + bs[row]);
+    if (W16) {
+        double upd = 0.0;  // what the groups solved so far take off row `row`: this thread's 8 columns of each
+#pragma unroll 1
+        for (int gi = 0; gi < 8; ++gi) {
+            const int g = FWD ? gi : 7 - gi;
+            const int rg = row - 16 * g;
+            if (rg >= 0 && rg < 16) up[half * 16 + rg] = upd;
+            __syncthreads();
+            if (wave == 0) {
+                // lane (i, q = lane >> 4) sums the columns c = q, q + 4, q + 8, q + 12 of row i of W_g (backward: of W_g^T); the four partial sums
+                // are added in q order
+                const int i = lane & 15, q = lane >> 4;
+                const double* Wp = Wg + g * 256;
+                double part = 0.0;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int c = q + 4 * t;
+                    const double bc = bs[16 * g + c] - (up[c] + up[16 + c]);
+                    part += (FWD ? Wp[c * 16 + i] : Wp[i * 16 + c]) * bc;
+                }
+                const double x1 = __shfl(part, i + 16, 64), x2 = __shfl(part, i + 32, 64), x3 = __shfl(part, i + 48, 64);
+                if (lane < 16) { const double xi = ((part + x1) + x2) + x3; up[32 + i] = xi; bs[16 * g + i] = xi; }
+            }
+            __syncthreads();
+            const bool todo = FWD ? (row > 16 * g + 15) : (row < 16 * g);
+            if (todo) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const int cc = half * 8 + c;
+                    upd += Ls[(16 * g + cc) * (TB + 1) + row] * up[32 + cc];
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < TB) {
+            if (tid < nrows) st_agent(x + row0 + tid, bs[tid]);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(flags + r, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
     __syncthreads();
     if (wave == 0) {
         double b0 = bs[lane], b1 = bs[lane + 64];
@@ -1240,15 +1297,15 @@ size_t trsv_flag_ints(int n) { return 2 * (size_t)div_up(n, TB) + 1; }
 // LLT: L y = b, L^T x = y with rdiag = 1/diag(L).  LDLt: unit L, then x *= rdiag (= 1/D), then unit L^T.
 // `flags` = trsv_flag_ints(n) ints of scratch (zeroed here on the stream); nullptr, or more blocks than can be resident at once, falls back to
 // one launch per block step.
-void launch_trsv(const double* L, int ld, int n, double* x, const double* rdiag, bool ldlt, int* flags, hipStream_t s)
+void launch_trsv(const double* L, int ld, int n, double* x, const double* rdiag, bool ldlt, int* flags, const double* w16, hipStream_t s)
 {
     if (n <= 0) return;
     static bool attr_set = false;
     if (!attr_set) {
         PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_trsv_fwd_step), hipFuncAttributeMaxDynamicSharedMemorySize, TRSV_LDS_BYTES));
         PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_trsv_bwd_step), hipFuncAttributeMaxDynamicSharedMemorySize, TRSV_LDS_BYTES));
-        PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_trsv_persistent<true>), hipFuncAttributeMaxDynamicSharedMemorySize, TRSV_LDS_BYTES));
-        PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_trsv_persistent<false>), hipFuncAttributeMaxDynamicSharedMemorySize, TRSV_LDS_BYTES));
+        PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_trsv_persistent<true>), hipFuncAttributeMaxDynamicSharedMemorySize, TRSV_P_LDS_BYTES));
+        PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_trsv_persistent<false>), hipFuncAttributeMaxDynamicSharedMemorySize, TRSV_P_LDS_BYTES));
         attr_set = true;
     }
     const int nblk = div_up(n, TB);
@@ -1258,9 +1315,9 @@ void launch_trsv(const double* L, int ld, int n, double* x, const double* rdiag,
         // layout: [fwd x flags nblk][bwd x flags nblk][err]
         PQ_HIP(hipMemsetAsync(flags, 0, sizeof(int) * (2 * (size_t)nblk + 1), s));
         int* err = flags + 2 * nblk;
-        hipLaunchKernelGGL(k_trsv_persistent<true>, dim3(nblk), dim3(256), TRSV_LDS_BYTES, s, L, ld, n, x, rd, nblk, flags, err);
+        hipLaunchKernelGGL(k_trsv_persistent<true>, dim3(nblk), dim3(256), TRSV_P_LDS_BYTES, s, L, ld, n, x, rd, nblk, flags, err, w16);
         if (ldlt) hipLaunchKernelGGL(k_mul_vec, dim3(div_up(n, 256)), dim3(256), 0, s, n, rdiag, x);
-        hipLaunchKernelGGL(k_trsv_persistent<false>, dim3(nblk), dim3(256), TRSV_LDS_BYTES, s, L, ld, n, x, rd, nblk, flags + nblk, err);
+        hipLaunchKernelGGL(k_trsv_persistent<false>, dim3(nblk), dim3(256), TRSV_P_LDS_BYTES, s, L, ld, n, x, rd, nblk, flags + nblk, err, w16);
     } else {
         for (int j = 0; j < nblk; ++j)
             hipLaunchKernelGGL(k_trsv_fwd_step, dim3(nblk - j), dim3(256), TRSV_LDS_BYTES, s, L, ld, n, x, rd, j);
@@ -1311,14 +1368,25 @@ __global__ __launch_bounds__(256) void k_gemv_n_partial(int rows, int cols, cons
     if (i + 1 < rows) part[(size_t)blockIdx.y * rows + i + 1] = s1;
 }
 
-// y[i] = (base ? base[i] : 0) + sum_s part[s][i]
+// y[i] = (base ? base[i] : 0) + sum_s part[s][i].  32 rows x 8 slice groups per workgroup: group g adds the slices g, g + 8, ... in order, the
+// eight group sums are added in group order -- a fixed summation tree (bitwise reproducible), 128 workgroups at n = 4096 instead of the 16 that
+// made this trivial 4 MB reduction take 30 us (one thread walking up to 128 slices with dependent adds).
 __global__ __launch_bounds__(256) void k_reduce_partials(int rows, int nslices, const double* __restrict__ part, const double* __restrict__ base, double* __restrict__ y)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= rows) return;
-    double s = base ? base[i] : 0.0;
-    for (int k = 0; k < nslices; ++k) s += part[(size_t)k * rows + i];
-    y[i] = s;
+    __shared__ double sh[8][33];
+    const int ri = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + ri;
+    double s = 0.0;
+    if (i < rows)
+        for (int k = g; k < nslices; k += 8) s += part[(size_t)k * rows + i];
+    sh[g][ri] = s;
+    __syncthreads();
+    if (g == 0 && i < rows) {
+        double t = base ? base[i] : 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t += sh[q][ri];
+        y[i] = t;
+    }
 }
 
 int gemv_n_slices(int rows, int cols)
@@ -1346,7 +1414,7 @@ int launch_gemv_n_partial(int rows, int cols, const double* M, int ld, const dou
 void launch_reduce_partials(int rows, int nslices, const double* part, const double* base, double* y, hipStream_t s)
 {
     if (rows <= 0) return;
-    hipLaunchKernelGGL(k_reduce_partials, dim3(div_up(rows, 256)), dim3(256), 0, s, rows, nslices, part, base, y);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(div_up(rows, 32)), dim3(256), 0, s, rows, nslices, part, base, y);
     PQ_HIP(hipGetLastError());
 }
 
@@ -1476,7 +1544,7 @@ double microbench_potrf_block(bool ldlt, int reps, long long* stamps64, hipStrea
     for (int r = 0; r < reps + 1; ++r) {
         PQ_HIP(hipMemcpyAsync(A.p, A0.p, A.bytes(), hipMemcpyDeviceToDevice, s));
         PQ_HIP(hipEventRecord(e0, s));
-        launch_potrf_diag(ldlt, A.p, n, n, 0, info.p, rdiag.p, dvec.p, pack.p, s, r == reps ? ts.p : nullptr);
+        launch_potrf_diag(ldlt, A.p, n, n, 0, info.p, rdiag.p, dvec.p, pack.p, nullptr, s, r == reps ? ts.p : nullptr);
         PQ_HIP(hipEventRecord(e1, s));
         PQ_HIP(hipEventSynchronize(e1));
         float ms = 0.f;

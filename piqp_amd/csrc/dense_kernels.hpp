@@ -40,6 +40,7 @@ struct SyrkArgs {
     double* fuse_rdiag = nullptr;
     double* fuse_dvec = nullptr;  // LDLT: D of the next panel (the per-k scale of the next trailing update), nullable
     double* fuse_pack = nullptr;
+    double* fuse_w16 = nullptr;   // inverted 16 x 16 diagonal pieces of the next diagonal block (8 x 256 doubles), kept for the sweeps; nullable
     long long* fuse_ts = nullptr; // debugging aid (PIQP_AMD_DBG_FUSED_TS): 72 shader-clock stamps of the workgroup that owns the next diagonal block  // operand pack of the next k_trsm_panel (FACTOR_PACK_DOUBLES), nullable
 };
 
@@ -49,13 +50,15 @@ void syrk_prepare(int n);  // allocates what launch_syrk(EPI_ASSEMBLE, n) would 
 void launch_assemble_no_g(int n, const double* Pf, const double* x_reg, const double* ATA, double dinv, double* C, hipStream_t s);
 // diagonal block of order nb <= 128 at A: factor in place, reciprocal pivots to rdiag[kglobal..], D to dvec[0..nb) (LDLT, nullable), and the
 // operand pack of the panel solve (FACTOR_PACK_DOUBLES doubles, nullable: inverted 16 x 16 diagonal pieces + negated off-diagonal blocks)
-void launch_potrf_diag(bool ldlt, double* A, int lda, int nb, int kglobal, int* info, double* rdiag, double* dvec, double* pack, hipStream_t s, long long* ts = nullptr);
+void launch_potrf_diag(bool ldlt, double* A, int lda, int nb, int kglobal, int* info, double* rdiag, double* dvec, double* pack, double* w16, hipStream_t s,
+                       long long* ts = nullptr);  // w16 (nullable): the eight inverted 16 x 16 diagonal pieces of this block, 8 x 256 doubles (for launch_trsv)
 // debugging aid: `reps` factorisations of a synthetic 128 x 128 block; average microseconds and the 64 shader-clock stamps of potrf_block
 double microbench_potrf_block(bool ldlt, int reps, long long* stamps64, hipStream_t s);
 // rows k0 + nb .. n of the panel at column k0:  A21 <- A21 L11^-T (D^-1), with the pack written by the factorisation of L11
 void launch_trsm_panel(bool ldlt, double* A, int lda, int k0, int nb, int n, const double* pack, const double* rdiag, hipStream_t s);
 size_t trsv_flag_ints(int n);
-void launch_trsv(const double* L, int ld, int n, double* x, const double* rdiag, bool ldlt, int* flags, hipStream_t s);
+// w16: the inverted 16 x 16 diagonal pieces written by the factorisation (8 x 256 doubles per 128-column panel), nullptr: substitution only
+void launch_trsv(const double* L, int ld, int n, double* x, const double* rdiag, bool ldlt, int* flags, const double* w16, hipStream_t s);
 int gemv_n_slices(int rows, int cols);
 int launch_gemv_n_partial(int rows, int cols, const double* M, int ld, const double* v, const double* scale, double alpha, double* part, hipStream_t s);
 void launch_reduce_partials(int rows, int nslices, const double* part, const double* base, double* y, hipStream_t s);

@@ -91,7 +91,7 @@ public:
         if (p_ > 0) nsl += dense::launch_gemv_n_partial(n_, p_, AT_.p, n_, rhs_y, nullptr, delta_inv, part_.p + (size_t)nsl * n_, st_);
         dense::launch_reduce_partials(n_, nsl, part_.p, rhs_x, lhs_x, st_);
         // solve_ldlt_in_place: llt.solveInPlace(lhs_x)
-        { const int tt = prof_.begin(5, st_); dense::launch_trsv(fac_.p, n_, n_, lhs_x, rdiag_.p, ldlt_, flags_.p, st_); prof_.end(5, tt, st_); }
+        { const int tt = prof_.begin(5, st_); dense::launch_trsv(fac_.p, n_, n_, lhs_x, rdiag_.p, ldlt_, flags_.p, w16_.p, st_); prof_.end(5, tt, st_); }
         // lhs_y = delta_inv * AT^T lhs_x - delta_inv * rhs_y
         if (p_ > 0) dense::launch_gemv_t(n_, p_, AT_.p, n_, lhs_x, delta_inv, -delta_inv, rhs_y, nullptr, lhs_y, st_);
         // lhs_z = (GT^T lhs_x - rhs_z) o z_reg_inv
@@ -167,7 +167,7 @@ private:
         alloc();
         auto cp = [&](DBuf<double>& dst, const DBuf<double>& src) { if (src.n) PQ_HIP(hipMemcpyAsync(dst.p, src.p, src.bytes(), hipMemcpyDeviceToDevice, st_)); };
         cp(Pfull_, o.Pfull_); cp(Pdiag_, o.Pdiag_); cp(AT_, o.AT_); cp(GT_, o.GT_); cp(ATA_, o.ATA_); cp(fac_, o.fac_);
-        cp(z_reg_inv_, o.z_reg_inv_); cp(x_reg_last_, o.x_reg_last_); cp(rdiag_, o.rdiag_);
+        cp(z_reg_inv_, o.z_reg_inv_); cp(x_reg_last_, o.x_reg_last_); cp(rdiag_, o.rdiag_); cp(w16_, o.w16_);
         PQ_HIP(hipStreamSynchronize(st_));
     }
 
@@ -183,6 +183,7 @@ private:
         part_.alloc((size_t)sl * n_);
         split_ws_.alloc(dense::syrk_split_workspace_doubles(n_, m_ > 0 ? m_ : 1));
         pack_.alloc(dense::FACTOR_PACK_DOUBLES);
+        w16_.alloc((size_t)((n_ + 127) / 128) * 8 * 256);  // inverted 16 x 16 diagonal pieces of the whole factor (potrf_block -> launch_trsv)
         dense::syrk_prepare(n_);
         info_.alloc(1);
         info_h_.alloc(1);
@@ -237,7 +238,7 @@ private:
             const int nb = (n_ - k < NB) ? n_ - k : NB;
             const int rs = n_ - k - nb;
             double* A11 = fac_.p + k + (size_t)k * n_;
-            if (k == 0) dense::launch_potrf_diag(ldlt_, A11, n_, nb, k, info_.p, rdiag_.p, dvec_.p + k, rs > 0 ? pack_.p : nullptr, st_);
+            if (k == 0) dense::launch_potrf_diag(ldlt_, A11, n_, nb, k, info_.p, rdiag_.p, dvec_.p + k, rs > 0 ? pack_.p : nullptr, w16_.p, st_);
             if (rs <= 0) break;
             { const int tt = prof_.begin(4, st_); dense::launch_trsm_panel(ldlt_, fac_.p, n_, k, nb, n_, pack_.p, rdiag_.p, st_); prof_.end(4, tt, st_); }
             dense::SyrkArgs a;
@@ -248,6 +249,7 @@ private:
             a.C = fac_.p + (k + nb) + (size_t)(k + nb) * n_; a.ldc = n_;
             a.fuse_nb = rs < NB ? rs : NB; a.fuse_kglobal = k + nb; a.fuse_ldlt = ldlt_ ? 1 : 0; a.fuse_info = info_.p; a.fuse_rdiag = rdiag_.p; a.fuse_dvec = dvec_.p + k + nb;
             a.fuse_pack = (rs - a.fuse_nb > 0) ? pack_.p : nullptr;
+            a.fuse_w16 = w16_.p + (size_t)((k + nb) / 16) * 256;
             a.fuse_ts = (dbg_panel_ == p) ? dbg_ts_.p : nullptr;
             { const int tt = prof_.begin(3, st_); dense::launch_syrk(dense::EPI_SUBTRACT_POTRF, a, st_); prof_.end(3, tt, st_); }
             if (a.fuse_ts) dump_fused_ts(p);
@@ -275,7 +277,7 @@ private:
     bool ldlt_;
     double delta_ = 1.0;
     hipStream_t st_ = nullptr;
-    DBuf<double> Pfull_, Pdiag_, AT_, GT_, ATA_, fac_, z_reg_inv_, x_reg_last_, dvec_, part_, rdiag_, split_ws_, pack_;
+    DBuf<double> Pfull_, Pdiag_, AT_, GT_, ATA_, fac_, z_reg_inv_, x_reg_last_, dvec_, part_, rdiag_, split_ws_, pack_, w16_;
     DBuf<int> info_, flags_;
     HBuf<int> info_h_;
     StageProfiler prof_;

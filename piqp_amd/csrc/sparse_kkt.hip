@@ -2021,7 +2021,7 @@ private:
         for (int k = 0; k < w; k += NB) {
             const int nb = std::min(NB, w - k);
             const int rs = f - k - nb;
-            dense::launch_potrf_diag(true, F + k + (size_t)k * f, f, nb, S_.sn_first[s] + k, info_.p, rdiag_.p, dvec_.p, rs > 0 ? dpack_.p : nullptr, st_);
+            dense::launch_potrf_diag(true, F + k + (size_t)k * f, f, nb, S_.sn_first[s] + k, info_.p, rdiag_.p, dvec_.p, rs > 0 ? dpack_.p : nullptr, nullptr, st_);
             if (rs > 0) {
                 dense::launch_trsm_panel(true, F, f, k, nb, f, dpack_.p, rd, st_);
                 dense::SyrkArgs a;
