@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <map>
 #include <mutex>
+#include <stdexcept>
 #include <utility>
 #include <vector>
 #include <cstdlib>
@@ -132,11 +133,15 @@ __device__ __forceinline__ void potrf_block(double* __restrict__ Tb, double* __r
                                             double* __restrict__ dvec, double* __restrict__ Aout, int lda, double* __restrict__ pack, double* __restrict__ w16,
                                             long long* __restrict__ ts = nullptr);
 __device__ __forceinline__ int tb_index(int bi, int bj);
+__device__ __forceinline__ void st_agent(double* p, double v);
+__device__ __forceinline__ double ld_agent(const double* p);
 __device__ __forceinline__ void tile_store(double* __restrict__ blk, int lane, d4 t);
+constexpr int FUSE_ROLES = 9, FUSE_OWN = 4;  // workgroups that share the next diagonal block of a fused trailing update (owner + 8 helpers), blocks per workgroup
 template <int NT>
-__device__ __forceinline__ void fused_next_diag(const SyrkArgs& a, double* __restrict__ smem);
-// the fused next-panel factorisation reuses the SYRK staging buffers (36 tile blocks = exactly their 72 KB) + 64 doubles of pivots
-constexpr int FUSED_LDS_BYTES = 2 * 2 * 16 * (128 + 16) * 8 + 64 * 8;
+__device__ __forceinline__ void fused_next_diag(const SyrkArgs& a, double* __restrict__ smem, int role);
+// the fused next-panel factorisation: its workgroups stage a whole 128 x 128 operand panel (147 KB: one workgroup per CU, which the kernel's
+// 147 VGPRs impose anyway); the 36 tile blocks + 64 doubles of pivots reuse that LDS afterwards
+constexpr int FUSED_LDS_BYTES = (128 * (128 + 16) + 128) * 8;  // whole operand panel of the next diagonal block + D; the tile blocks reuse it
 
 // WR x WC = waves per tile (rows x columns):
 //   2 x 2 -> 256 threads, 64 x 64 per wave (throughput shape, 2 workgroups per CU);
@@ -155,8 +160,15 @@ __global__ __launch_bounds__(64 * WR * WC, (WR * WC == 4) ? 2 : (WR * WC == 8 ? 
     double* Bs = smem + 2 * BK * LDS_LD;  // [2][BK][LDS_LD]
 
     // linear block id -> lower-triangular tile (ti >= tj); split launches map several K-slices onto one tile
-    const int b = a.tile_begin + (int)blockIdx.x / a.k_split;
-    const int kslice = (int)blockIdx.x % a.k_split;
+    int bid = (int)blockIdx.x;
+    if constexpr (EPI == EPI_SUBTRACT_POTRF) {
+        // tile (0, 0) of the trailing matrix = the next diagonal block: updated AND factored by the first FUSE_ROLES workgroups together (owner +
+        // helpers); the other tiles follow
+        if (bid < FUSE_ROLES) { fused_next_diag<NT>(a, smem, bid); return; }
+        bid -= FUSE_ROLES - 1;
+    }
+    const int b = a.tile_begin + bid / a.k_split;
+    const int kslice = bid % a.k_split;
     int ti, tj;
     if (a.tile_order) {
         const int pk = a.tile_order[b];
@@ -172,10 +184,6 @@ __global__ __launch_bounds__(64 * WR * WC, (WR * WC == 4) ? 2 : (WR * WC == 8 ? 
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave / WC, wc = wave % WC;
-    if (EPI == EPI_SUBTRACT_POTRF && ti == 0 && tj == 0 && a.fuse_nb > 0) {
-        fused_next_diag<NT>(a, smem);  // tile (0, 0) of the trailing matrix = the next diagonal block: updated AND factored by this workgroup
-        return;
-    }
     constexpr bool NEGB = (EPI == EPI_SUBTRACT_POTRF);  // accumulators start from C, the column operand is staged negated: pure-store epilogue
     const bool edge = (row0 + TS > a.n) || (col0 + TS > a.n) || a.unaligned;
     const bool skip_wave = (ti == tj) && ((wr + 1) * SUBR <= wc * SUBC);  // sub-tile strictly above the diagonal
@@ -443,7 +451,8 @@ void launch_syrk(int epi, const SyrkArgs& args_in, hipStream_t s, double* split_
         }
         const int T = div_up(a.n, TS);
         a.tile_begin = 0; a.k_split = 1; a.part = nullptr; a.first_col_only = 0;
-        hipLaunchKernelGGL((k_syrk_lower<EPI_SUBTRACT_POTRF, 4, 2>), dim3(T * (T + 1) / 2), dim3(512), FUSED_LDS_BYTES, s, a);
+        if (!a.fuse_scratch || !a.fuse_flags || a.fuse_nb <= 0 || a.kdim > TS) throw std::runtime_error("fused trailing update: scratch / flags / panel width");
+        hipLaunchKernelGGL((k_syrk_lower<EPI_SUBTRACT_POTRF, 4, 2>), dim3(T * (T + 1) / 2 + FUSE_ROLES - 1), dim3(512), FUSED_LDS_BYTES, s, a);
         PQ_HIP(hipGetLastError());
         return;
     }
@@ -558,8 +567,12 @@ __device__ __forceinline__ double rcp_newton(double d)
 //   LDLT == true : dense/ldlt_no_pivot.hpp:278-311: unit L below the diagonal, D on it, fail iff pivot == 0
 // On return t holds the factor (zeros above the diagonal); lane c < 16 holds the reciprocal pivot of column c in rd (LLT: 1 / l_cc,
 // LDLT: 1 / d_c) and d_c in dd.  Returns the first failing column or -1.
+// Dpub / rpub / prog (LDS): every FOURTH pivot the four columns just finished -- exactly one tile register -- are published: one unmasked store per
+// lane into the block's own LDS tile, their reciprocal pivots into rpub, then *prog = base + c + 1, so that the waves solving the panel below
+// (tile_trsm_rt_follow) run four columns behind this factorisation instead of starting after it.  (Publishing every column -- masked stores and a
+// fence per pivot, seven waves polling -- doubled the time of this routine: 4800 -> 10 500 cycles.)
 template <bool LDLT>
-__device__ __forceinline__ int factor16_tile(d4& t, int lane, double& rd, double& dd)
+__device__ __forceinline__ int factor16_tile(d4& t, int lane, double& rd, double& dd, volatile double* Dpub, volatile double* rpub, volatile int* prog, int base)
 {
     const int i = lane & 15, g = lane >> 4;
     int failed = -1;
@@ -585,6 +598,13 @@ __device__ __forceinline__ int factor16_tile(d4& t, int lane, double& rd, double
             if (c < 15) t = __builtin_amdgcn_mfma_f64_16x16x4f64(lcol, -ycol, t, 0, 0, 0);
         }
         if (lane == c) { rd = r; dd = dk; }
+        if ((c & 3) == 3) {
+            // columns 4 r0 .. 4 r0 + 3 are final and register r0 is not touched by the remaining updates (their operands are zero at p <= c)
+            Dpub[(g + 4 * r0) * 16 + i] = t[r0];
+            if (lane < 16 && (lane >> 2) == r0) rpub[lane] = rd;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // (a wave's LDS instructions execute in order anyway)
+            if (lane == 0) *prog = base + c + 1;
+        }
     }
     return failed;
 }
@@ -610,10 +630,36 @@ __device__ __forceinline__ void tile_trsm_rt(d4& x, const d4& L, const d4& rdc, 
     if (!LDLT || SCALE) x *= rdc;
 }
 
+// The same substitution run four columns BEHIND the factorisation of L by another wave of the workgroup (factor16_tile publishes one tile register
+// = four columns of L and their reciprocal pivots in LDS, then *prog): the rank-1 updates of those columns are issued as soon as they exist, so the
+// panel is solved about one register's worth of work after the diagonal piece is factored instead of ~3000 cycles.
+template <bool LDLT>
+__device__ __forceinline__ void tile_trsm_rt_follow(d4& x, const volatile double* Lpub, const volatile double* rpub, const volatile int* prog, int base, int lane)
+{
+    const int i = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int r0 = 0; r0 < 4; ++r0) {
+        while (*prog < base + 4 * r0 + 4) __builtin_amdgcn_s_sleep(2);  // ~128 cycles between polls: the factoring wave shares a SIMD with one of us
+        const double l = Lpub[(g + 4 * r0) * 16 + i];   // register r0 of L in tile form: column 4 r0 + g
+        const double rc = LDLT ? 1.0 : rpub[g + 4 * r0];
+        const double nls = -(l * rc);
+#pragma unroll
+        for (int g0 = 0; g0 < 4; ++g0) {
+            const int c = 4 * r0 + g0;
+            if (c < 15) {
+                const double aop = (g == g0 && i > c) ? nls : 0.0;
+                x = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, x[r0], x, 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) x[r] *= rpub[g + 4 * r];
+}
+
 // Factorisation of a diagonal block of order nb <= 128 held in LDS (tile blocks Tb, identity-padded beyond nb).  Waves 0..7 own one
 // 16-row block row each; every other wave of the workgroup only takes part in the barriers.  Step k (16 columns):
-//   wave k      factors its diagonal piece in registers (factor16_tile) and leaves L_kk + reciprocal pivots in LDS          | barrier
-//   waves w > k solve their 16 x 16 piece of the panel against L_kk (tile_trsm_rt)                                          | barrier
+//   wave k      factors its diagonal piece in registers (factor16_tile), publishing every finished column in LDS;
+//   waves w > k solve their 16 x 16 piece of the panel against L_kk one column behind it (tile_trsm_rt_follow)              | barrier
 //   waves w > k update the tiles (w, k+1..w) of their block row: T -= X_w (D) X_c^T, nearest column first, so wave k + 1 walks
 //               straight from its last update into the factorisation of step k + 1;
 //   wave k      meanwhile inverts L_kk -- off the critical path, its block row is finished -- for the panel kernel below.
@@ -632,6 +678,9 @@ __device__ __forceinline__ void potrf_block(double* __restrict__ Tb, double* __r
     auto stamp = [&](int k, int q) { if (ts && (threadIdx.x & 63) == 0) ts[8 * k + q] = clock64(); };
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, g = lane >> 4;
+    __shared__ int prog;  // columns of the block factored so far (monotonic over the eight steps): the panel waves follow it
+    if (tid == 0) prog = 0;
+    __syncthreads();
 #pragma unroll 1
     for (int k = 0; k < 8; ++k) {
         double* Dkk = Tb + tb_index(k, k) * 256;
@@ -642,7 +691,9 @@ __device__ __forceinline__ void potrf_block(double* __restrict__ Tb, double* __r
         if (wave == k) {
             stamp(k, 0);
             lkk = tile_load(Dkk, lane);
-            const int failed = factor16_tile<LDLT>(lkk, lane, rd, dmine);
+            __builtin_amdgcn_s_setprio(3);  // the critical wave: issue priority over the follower that shares its SIMD
+            const int failed = factor16_tile<LDLT>(lkk, lane, rd, dmine, Dkk, rbuf, &prog, 16 * k);
+            __builtin_amdgcn_s_setprio(0);
             tile_store(Dkk, lane, lkk);
             if (lane < 16) {
                 rbuf[lane] = rd;
@@ -650,15 +701,12 @@ __device__ __forceinline__ void potrf_block(double* __restrict__ Tb, double* __r
             }
             if (failed >= 0 && lane == 0 && 16 * k + failed < nb) { if (*info < 0) *info = kglobal + 16 * k + failed; }
             stamp(k, 1);
-        }
-        __syncthreads();
-        if (wave > k && wave < 8) {
+        } else if (wave > k && wave < 8) {
+            // no barrier between the factorisation and the panel: these waves follow wave k column by column
             if (wave == k + 1) stamp(k, 2);
             double* Xwk = Tb + tb_index(wave, k) * 256;
             d4 x = tile_load(Xwk, lane);
-            const d4 L = tile_load(Dkk, lane);
-            const d4 rdc = {rbuf[g], rbuf[g + 4], rbuf[g + 8], rbuf[g + 12]};
-            tile_trsm_rt<LDLT, true>(x, L, rdc, lane);
+            tile_trsm_rt_follow<LDLT>(x, Dkk, rbuf, &prog, 16 * k, lane);
             tile_store(Xwk, lane, x);
             if (wave == k + 1) stamp(k, 3);
         }
@@ -674,6 +722,8 @@ __device__ __forceinline__ void potrf_block(double* __restrict__ Tb, double* __r
                 if (LDLT) xc *= dsc;
                 double* Tw = Tb + tb_index(wave, c) * 256;
                 d4 t = tile_load(Tw, lane);
+                // one accumulator, k ascending: the summation order every parity test was pinned with (four independent products summed afterwards
+                // save ~200 cycles per step and moved two threshold-sitting iteration counts by one: mm_QAFIRO 13 -> 12, mm_CONT-201 12 -> 13)
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) t = __builtin_amdgcn_mfma_f64_16x16x4f64(xc[ks], nxw[ks], t, 0, 0, 0);
                 tile_store(Tw, lane, t);
@@ -758,80 +808,130 @@ void launch_potrf_diag(bool ldlt, double* A, int lda, int nb, int kglobal, int* 
     PQ_HIP(hipGetLastError());
 }
 
-// Tile (0, 0) of a fused trailing update = the next diagonal block: this workgroup computes only its lower block triangle -- the 36 tile
-// blocks are dealt round-robin to the waves (4 or 5 each instead of the rectangular wave grid's 8 with the upper half wasted: the K loop of
-// this workgroup bounds the whole launch) --, starts the accumulators from C, stages ONE operand panel (rows 0..127 of the panel serve as
-// row and, negated and D-scaled, as column operand), leaves the result in LDS as tile blocks and factors it there (potrf_block).
+// Tile (0, 0) of a fused trailing update = the next diagonal block.  Only its lower block triangle is computed -- 36 tile blocks, one wave
+// and one MFMA accumulator each --, the accumulators start from C, ONE operand panel is staged (rows 0..127 of the panel serve as row and,
+// times -D, as column operand), and the result is factored in LDS (potrf_block).  This tile bounds the whole launch, and on one CU its update
+// is pure matrix-core throughput (measured: 37 000 cycles for the 36 blocks), so it is spread over FUSE_ROLES = 9 workgroups on nine CUs, four
+// blocks each (one product wave per SIMD); a helper writes its blocks through to a.fuse_scratch (sc1 stores), drains, and publishes
+// a.fuse_flags[role] = a.fuse_token (unique per launch: no reset between launches); the owner polls the eight flags (bounded) and pulls the
+// blocks into its LDS with L1-bypassing loads -- the write-through recipe of MI355X_MICROARCH.md (no release / acquire fences).
+// K <= 128 (one panel): the WHOLE operand panel goes to LDS in one round of loads -- the double-buffered 16-column stages of the generic
+// kernel cost a load -> LDS -> barrier round trip each (measured 2700 cycles per stage) -- and the 32 MFMA k-slices run back to back on four
+// interleaved accumulator chains (a single chain is a dependent MFMA every ~180 cycles plus the LDS read in front of it: 18 000 cycles measured).
 template <int NT>
-__device__ __forceinline__ void fused_next_diag(const SyrkArgs& a, double* __restrict__ smem)
+__device__ __forceinline__ void fused_next_diag(const SyrkArgs& a, double* __restrict__ smem, int role)
 {
-    constexpr int NW = NT / 64, MAXT = (TB_BLOCKS + NW - 1) / NW;
-    double* As = smem;                    // [2][BK][LDS_LD]
-    double* Bs = smem + 2 * BK * LDS_LD;  // [2][BK][LDS_LD]
+    constexpr int NW = NT / 64;
+    static_assert(FUSE_OWN * FUSE_ROLES >= TB_BLOCKS && FUSE_OWN <= NW, "every tile block needs a wave");
+    double* As = smem;                    // [kdim <= 128][LDS_LD]: the whole operand panel
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, g = lane >> 4;
-    const bool dbg_ts = a.fuse_ts && tid == 0;
+    const bool dbg_ts = a.fuse_ts && tid == 0 && role == 0;
     if (dbg_ts) a.fuse_ts[0] = clock64();
     const int nbn = a.fuse_nb;
     const bool edge = (TS > a.n) || a.unaligned;
-    int bi[MAXT], bj[MAXT];
-    bool on[MAXT];
-    d4 acc[MAXT];
-#pragma unroll
-    for (int q = 0; q < MAXT; ++q) {
-        const int t = wave + NW * q;
-        on[q] = t < TB_BLOCKS;
-        const int tt = on[q] ? t : 0;
-        int b = 0;
-        while ((b + 1) * (b + 2) / 2 <= tt) ++b;
-        bi[q] = b; bj[q] = tt - b * (b + 1) / 2;
-        const int li = bi[q] * 16 + i;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int lj = bj[q] * 16 + g + 4 * r;
-            const bool in = li < nbn && lj < nbn;
-            const bool ok = on[q] && in && li >= lj;
-            const double cv = a.C[ok ? (size_t)li + (size_t)lj * a.ldc : 0];
-            acc[q][r] = ok ? cv : ((!in && li == lj) ? 1.0 : 0.0);  // identity padding (last, partial panel)
-        }
+    // the tile block of this wave
+    const int t = role * FUSE_OWN + wave;  // four blocks per workgroup: one wave per SIMD does the products, the other waves only help staging
+    const bool on = wave < FUSE_OWN && t < TB_BLOCKS;
+    int bi = 0;
+    {
+        const int tt = on ? t : 0;
+        while ((bi + 1) * (bi + 2) / 2 <= tt) ++bi;
     }
-    const int nkt = (a.kdim + BK - 1) / BK;
-    d2 va[1024 / NT], vb[1024 / NT];
-    auto fetch = [&](int kt) {
-        const int k0 = kt * BK;
-        if (edge || k0 + BK > a.kdim) load_tile<true, NT>(a.A, a.lda, 0, k0, a.n, a.kdim, tid, va);
-        else load_tile<false, NT>(a.A, a.lda, 0, k0, a.n, a.kdim, tid, va);
+    const int bj = (on ? t : 0) - bi * (bi + 1) / 2;
+    const int nkt = (a.kdim + BK - 1) / BK;  // <= 8
+    double* ws = smem + TS * LDS_LD;         // -D of the panel (LLT: -1), after the operand panel
+    d4 acc;
+    {
+        d2 va[8][1024 / NT];
 #pragma unroll
-        for (int it = 0; it < 1024 / NT; ++it) vb[it] = va[it];
-        scale_tile<true, NT, true>(a.w, k0, a.kdim, tid, vb);
-    };
-    if (nkt > 0) { fetch(0); store_tile<NT>(As, tid, va); store_tile<NT>(Bs, tid, vb); }
-    __syncthreads();
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int cur = kt & 1;
-        const bool more = kt + 1 < nkt;
-        if (more) fetch(kt + 1);
-        const double* Asb = As + cur * BK * LDS_LD + i;
-        const double* Bsb = Bs + cur * BK * LDS_LD + i;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const int kk = ks * 4 + g;
-#pragma unroll
-            for (int q = 0; q < MAXT; ++q) {
-                if (q < MAXT - 1 || on[q]) {
-                    const double af = Asb[kk * LDS_LD + bi[q] * 16], bf = Bsb[kk * LDS_LD + bj[q] * 16];
-                    acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf, af, acc[q], 0, 0, 0);
-                }
+        for (int kt = 0; kt < 8; ++kt) {
+            if (kt < nkt) {
+                const int k0 = kt * BK;
+                if (edge || k0 + BK > a.kdim) load_tile<true, NT>(a.A, a.lda, 0, k0, a.n, a.kdim, tid, va[kt]);
+                else load_tile<false, NT>(a.A, a.lda, 0, k0, a.n, a.kdim, tid, va[kt]);
             }
         }
-        if (more) { store_tile<NT>(As + (cur ^ 1) * BK * LDS_LD, tid, va); store_tile<NT>(Bs + (cur ^ 1) * BK * LDS_LD, tid, vb); }
+        const double wv = (tid < TS) ? -((a.w && tid < a.kdim) ? a.w[tid] : 1.0) : 0.0;  // the sign of C - A D A^T rides on D
+        // C of this wave's block (identity padding beyond the order of a last, partial panel)
+        const int li = bi * 16 + i;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int lj = bj * 16 + g + 4 * r;
+            const bool in = li < nbn && lj < nbn;
+            const bool ok = on && in && li >= lj;
+            const double cv = a.C[ok ? (size_t)li + (size_t)lj * a.ldc : 0];
+            acc[r] = ok ? cv : ((!in && li == lj) ? 1.0 : 0.0);
+        }
+        if (tid < TS) ws[tid] = wv;
+#pragma unroll
+        for (int kt = 0; kt < 8; ++kt)
+            if (kt < nkt) store_tile<NT>(As + kt * BK * LDS_LD, tid, va[kt]);
+    }
+    __syncthreads();
+    if (dbg_ts) a.fuse_ts[4] = clock64();
+    if (on) {
+        d4 p1 = {0.0, 0.0, 0.0, 0.0}, p2 = p1, p3 = p1;
+        const double* Ar = As + bi * 16 + i;
+        const double* Ac = As + bj * 16 + i;
+#pragma unroll 2
+        for (int ks = 0; ks < 4 * nkt; ks += 4) {
+            double af[4], bf[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int kk = (ks + u) * 4 + g;
+                af[u] = Ar[kk * LDS_LD];
+                bf[u] = Ac[kk * LDS_LD] * ws[kk];
+            }
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[0], af[0], acc, 0, 0, 0);
+            p1 = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[1], af[1], p1, 0, 0, 0);
+            p2 = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[2], af[2], p2, 0, 0, 0);
+            p3 = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[3], af[3], p3, 0, 0, 0);
+        }
+        acc = ((acc + p1) + p2) + p3;  // fixed order
+    }
+    __syncthreads();  // every wave is done with the operand panel (the owner reuses its LDS for the tile blocks)
+    if (role > 0) {
+        // helper: block -> scratch, written through; drained; then the token
+        if (on) {
+            double* blk = a.fuse_scratch + (size_t)t * 256 + g * 16 + i;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) st_agent(blk + 64 * r, acc[r]);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        if (tid == 0) __hip_atomic_store(a.fuse_flags + role, a.fuse_token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
     }
     if (dbg_ts) a.fuse_ts[1] = clock64();
-    double* Tb = smem;  // the staging buffers are free now
+    double* Tb = smem;  // the operand panel is dead now
+    if (on) tile_store(Tb + t * 256, lane, acc);
+    {
+        __shared__ int ok_s;
+        if (tid == 0) {
+            int ok = 1;
+            for (int h = 1; h < FUSE_ROLES && ok; ++h) {
+                unsigned spins = 0;
+                while (__hip_atomic_load(a.fuse_flags + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.fuse_token) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > 20000000u) { ok = 0; break; }
+                }
+            }
+            ok_s = ok;
+        }
+        __syncthreads();
+        if (!ok_s) {  // a helper never arrived (cannot happen with a healthy device): report the block as not factorisable instead of hanging
+            if (tid == 0 && *a.fuse_info < 0) *a.fuse_info = a.fuse_kglobal;
+            return;
+        }
+        // the helpers' blocks: (36 - 4) * 256 doubles, L1-bypassing loads, 16 per thread in flight
+        constexpr int PER = (TB_BLOCKS - FUSE_OWN) * 256 / NT;
+        double v[PER];
 #pragma unroll
-    for (int q = 0; q < MAXT; ++q)
-        if (on[q]) tile_store(Tb + (wave + NW * q) * 256, lane, acc[q]);
+        for (int u = 0; u < PER; ++u) v[u] = ld_agent(a.fuse_scratch + FUSE_OWN * 256 + u * NT + tid);
+#pragma unroll
+        for (int u = 0; u < PER; ++u) Tb[FUSE_OWN * 256 + u * NT + tid] = v[u];
+    }
     __syncthreads();
     if (dbg_ts) a.fuse_ts[2] = clock64();
     long long* pts = a.fuse_ts ? a.fuse_ts + 8 : nullptr;

@@ -40,6 +40,10 @@ struct SyrkArgs {
     double* fuse_rdiag = nullptr;
     double* fuse_dvec = nullptr;  // LDLT: D of the next panel (the per-k scale of the next trailing update), nullable
     double* fuse_pack = nullptr;
+    // the next diagonal block's update is shared by nine workgroups: owner + helpers on other CUs (dense_kernels.hip fused_next_diag)
+    int fuse_token = 0;             // launch-unique value the helpers publish in fuse_flags[role]
+    int* fuse_flags = nullptr;      // >= 9 ints (one per helper role)
+    double* fuse_scratch = nullptr; // 36 x 256 doubles: the helpers' tile blocks on their way to the owner's LDS
     double* fuse_w16 = nullptr;   // inverted 16 x 16 diagonal pieces of the next diagonal block (8 x 256 doubles), kept for the sweeps; nullable
     long long* fuse_ts = nullptr; // debugging aid (PIQP_AMD_DBG_FUSED_TS): 72 shader-clock stamps of the workgroup that owns the next diagonal block  // operand pack of the next k_trsm_panel (FACTOR_PACK_DOUBLES), nullable
 };

@@ -183,6 +183,7 @@ private:
         part_.alloc((size_t)sl * n_);
         split_ws_.alloc(dense::syrk_split_workspace_doubles(n_, m_ > 0 ? m_ : 1));
         pack_.alloc(dense::FACTOR_PACK_DOUBLES);
+        fuse_scratch_.alloc(dense::FACTOR_PACK_DOUBLES); fuse_flags_.alloc(16); fuse_flags_.zero(st_);
         w16_.alloc((size_t)((n_ + 127) / 128) * 8 * 256);  // inverted 16 x 16 diagonal pieces of the whole factor (potrf_block -> launch_trsv)
         dense::syrk_prepare(n_);
         info_.alloc(1);
@@ -250,6 +251,7 @@ private:
             a.fuse_nb = rs < NB ? rs : NB; a.fuse_kglobal = k + nb; a.fuse_ldlt = ldlt_ ? 1 : 0; a.fuse_info = info_.p; a.fuse_rdiag = rdiag_.p; a.fuse_dvec = dvec_.p + k + nb;
             a.fuse_pack = (rs - a.fuse_nb > 0) ? pack_.p : nullptr;
             a.fuse_w16 = w16_.p + (size_t)((k + nb) / 16) * 256;
+            a.fuse_token = ++fuse_token_; a.fuse_flags = fuse_flags_.p; a.fuse_scratch = fuse_scratch_.p;
             a.fuse_ts = (dbg_panel_ == p) ? dbg_ts_.p : nullptr;
             { const int tt = prof_.begin(3, st_); dense::launch_syrk(dense::EPI_SUBTRACT_POTRF, a, st_); prof_.end(3, tt, st_); }
             if (a.fuse_ts) dump_fused_ts(p);
@@ -261,7 +263,7 @@ private:
         long long h[72];
         PQ_HIP(hipMemcpyAsync(h, dbg_ts_.p, sizeof(h), hipMemcpyDeviceToHost, st_));
         PQ_HIP(hipStreamSynchronize(st_));
-        std::fprintf(stderr, "[piqp_amd] fused panel %d (cycles): K loop %lld, tiles->LDS %lld, potrf_block %lld; potrf steps (factor/subst/update):", panel, h[1] - h[0], h[2] - h[1], h[3] - h[2]);
+        std::fprintf(stderr, "[piqp_amd] fused panel %d (cycles): C + panel staged %lld, MFMA loop %lld, tiles->LDS %lld, potrf_block %lld; potrf steps (factor/subst/update):", panel, h[4] - h[0], h[1] - h[4], h[2] - h[1], h[3] - h[2]);
         for (int k = 0; k < 8; ++k) std::fprintf(stderr, " %lld/%lld/%lld", h[8 + 8 * k + 1] - h[8 + 8 * k], h[8 + 8 * k + 3] - h[8 + 8 * k + 2], h[8 + 8 * k + 5] - h[8 + 8 * k + 4]);
         std::fprintf(stderr, "\n");
     }
@@ -277,8 +279,9 @@ private:
     bool ldlt_;
     double delta_ = 1.0;
     hipStream_t st_ = nullptr;
-    DBuf<double> Pfull_, Pdiag_, AT_, GT_, ATA_, fac_, z_reg_inv_, x_reg_last_, dvec_, part_, rdiag_, split_ws_, pack_, w16_;
-    DBuf<int> info_, flags_;
+    DBuf<double> Pfull_, Pdiag_, AT_, GT_, ATA_, fac_, z_reg_inv_, x_reg_last_, dvec_, part_, rdiag_, split_ws_, pack_, w16_, fuse_scratch_;
+    DBuf<int> info_, flags_, fuse_flags_;
+    int fuse_token_ = 0;
     HBuf<int> info_h_;
     StageProfiler prof_;
     int dbg_panel_ = -1;
