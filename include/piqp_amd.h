@@ -211,6 +211,8 @@ int pq_kkt_set_exchange(pq_kkt *k, pq_exchange_fn exchange, void *user, double *
  * librccl is loaded with dlopen at the first of these calls; single-GPU use never needs it. */
 int pq_rccl_unique_id(unsigned char id_out[128]);
 int pq_kkt_set_comm_rccl(pq_kkt *k, const unsigned char id[128], int rank, int world);
+/* test hook (sparse backends): smallest |pivot| of the last factorisation */
+int pq_kkt_min_abs_pivot(pq_kkt *k, double *out);
 /* collectives the native transport has enqueued so far: out[which] for which = 0, 1, 2 (test / bench bookkeeping) */
 int pq_kkt_native_exchange_calls(pq_kkt *k, int out[3]);
 /* what the partition looks like: out[0] = supernodes owned by this rank, out[1] = shared supernodes, out[2] = boundary

@@ -356,6 +356,11 @@ int pq_kkt_set_comm_rccl(pq_kkt* k, const unsigned char id[128], int rank, int w
     if (!k || !id) return fail(PQ_ERR_INVALID, "null argument");
     return guarded([&] { k->impl->set_comm_rccl(id, rank, world); return (int)PQ_OK; });
 }
+int pq_kkt_min_abs_pivot(pq_kkt* k, double* out)
+{
+    if (!k || !out) return fail(PQ_ERR_INVALID, "null argument");
+    return guarded([&] { *out = k->impl->min_abs_pivot(); return (int)PQ_OK; });
+}
 int pq_kkt_native_exchange_calls(pq_kkt* k, int out[3])
 {
     if (!k || !out) return fail(PQ_ERR_INVALID, "null argument");

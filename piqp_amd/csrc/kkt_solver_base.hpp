@@ -55,6 +55,8 @@ public:
     }
     // native transport: the library issues the RCCL collectives itself on its stream (pq_kkt_set_comm_rccl)
     virtual void set_comm_rccl(const unsigned char* id128, int rank, int world) { (void)id128; (void)rank; (void)world; throw std::runtime_error("set_comm_rccl: not supported by this backend"); }
+    // test hook: smallest |pivot| of the last factorisation (sparse backends), read back through the host
+    virtual double min_abs_pivot() { throw std::runtime_error("min_abs_pivot: sparse backends only"); }
     virtual void native_exchange_calls(int out[3]) const { out[0] = out[1] = out[2] = 0; }
     virtual void partition_info(int out[8]) const { (void)out; throw std::runtime_error("partition_info: not supported by this backend"); }
     // measurement hooks (hipEvent brackets on the backend's stream)

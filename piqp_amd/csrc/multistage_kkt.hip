@@ -230,6 +230,7 @@ public:
         if (!tree_) throw std::runtime_error("set_comm_rccl: not partitioned");
         tree_->set_comm_rccl(id128, rank, world);
     }
+    double min_abs_pivot() override { if (!tree_) throw std::runtime_error("min_abs_pivot: chain engine"); return tree_->min_abs_pivot(); }
     void native_exchange_calls(int out[3]) const override { if (tree_) tree_->native_exchange_calls(out); else out[0] = out[1] = out[2] = 0; }
     void partition_info(int out[8]) const override
     {

@@ -1478,6 +1478,16 @@ public:
         PQ_HIP(hipStreamSynchronize(st_));
         xfn_ = nullptr; xbuf_factor_ = own_factor_.p; xbuf_forward_ = own_forward_.p; xbuf_gather_ = own_gather_.p;
     }
+    double min_abs_pivot() override
+    {
+        PQ_HIP(hipSetDevice(dev_));
+        std::vector<double> h((size_t)N_);
+        PQ_HIP(hipMemcpyAsync(h.data(), rdiag_.p, sizeof(double) * (size_t)N_, hipMemcpyDeviceToHost, st_));
+        PQ_HIP(hipStreamSynchronize(st_));
+        double mx = 0.0;
+        for (double r : h) mx = std::max(mx, std::fabs(r));
+        return mx > 0.0 ? 1.0 / mx : 0.0;
+    }
     void native_exchange_calls(int out[3]) const override { for (int q = 0; q < 3; ++q) out[q] = native_calls_[q]; }
     void partition_info(int out[8]) const override
     {

@@ -152,6 +152,17 @@ def main():
     # banded inequalities)
     for f in ("CONT-201", "BOYD1", "AUG3DCQP", "LISWET1"):
         convert_mat(os.path.join(td, "maros_meszaros", f + ".mat"), "mm_" + f)
+    # the problem sets of the reference's own sweeps (tests/src/sparse/maros_meszaros_tests.cpp: status == SOLVED on every file;
+    # netlib_lp_tests.cpp: SOLVED on data/, PRIMAL or DUAL INFEASIBLE on infeas/), every file up to a size limit that keeps the fixtures small:
+    # Maros-Meszaros <= 100 KB (107 of 137), netlib <= 50 KB (78 of 94 feasible, 25 of 29 infeasible)
+    import glob
+    for path in sorted(glob.glob(os.path.join(td, "maros_meszaros", "*.mat"))):
+        if os.path.getsize(path) <= 100e3:
+            convert_mat(path, "mm_" + os.path.basename(path)[:-4])
+    for sub, pre in (("data", "nl_"), ("infeas", "nli_")):
+        for path in sorted(glob.glob(os.path.join(td, "netlib", sub, "*.mat"))):
+            if os.path.getsize(path) <= 50e3:
+                convert_mat(path, pre + os.path.basename(path)[:-4])
 
     P, c, A, b, x_l, x_u = scenario_mpc()
     n, p = P.shape[0], A.shape[0]
