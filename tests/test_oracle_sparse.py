@@ -259,3 +259,39 @@ def test_fixtures_condensed_backends(orc, name, ks):
     assert s0.setup(*_sparse_args(q), sparse=True)
     s0.solve()
     assert abs(s.info.primal_obj - s0.info.primal_obj) <= 1e-5 * (1 + abs(s0.info.primal_obj))
+
+
+def _sweep_names(prefix, skip=()):
+    import glob
+    import os
+    from qp_io import GOLDEN
+    return sorted(n for n in (os.path.basename(f)[:-4] for f in glob.glob(os.path.join(GOLDEN, prefix + "*.npz"))) if n not in skip)
+
+
+# the reference's own sweeps as a pin of the ORACLE: tests/src/sparse/maros_meszaros_tests.cpp expects PIQP_SOLVED on every
+# Maros-Meszaros file, netlib_lp_tests.cpp (infeasibility_threshold = 0.01) SOLVED on data/ and PRIMAL / DUAL INFEASIBLE on infeas/.
+# mm_CONT-201 / mm_BOYD1 (10 s and 1 s of CPU) run in the GPU suite next to the device.
+ORACLE_MISSES_REFERENCE = {"nl_bnl2", "nl_pilot-we", "nli_ceria3d", "nli_cplex2", "nli_qual"}  # MAX_ITER in the oracle: degenerate LPs, see test_mm_real_gpu.py
+
+
+@pytest.mark.parametrize("name", _sweep_names("mm_", skip=("mm_CONT-201", "mm_BOYD1")))
+def test_oracle_meets_the_maros_meszaros_contract(orc, name):
+    from qp_io import load_qp
+    q = load_qp(name)
+    so = orc.Solver(); so.settings.kkt_solver = orc.SPARSE_LDLT
+    assert so.setup(q["P"], q["c"], q["A"], q["b"], q["G"], q["h_l"], q["h_u"], q["x_l"], q["x_u"], sparse=True)
+    assert so.solve() == orc.SOLVED
+
+
+@pytest.mark.parametrize("name", _sweep_names("nl_") + _sweep_names("nli_"))
+def test_oracle_meets_the_netlib_contract(orc, name):
+    from qp_io import load_qp
+    q = load_qp(name)
+    so = orc.Solver(); so.settings.kkt_solver = orc.SPARSE_LDLT; so.settings.infeasibility_threshold = 0.01
+    assert so.setup(q["P"], q["c"], q["A"], q["b"], q["G"], q["h_l"], q["h_u"], q["x_l"], q["x_u"], sparse=True)
+    st = so.solve()
+    expected = (orc.SOLVED,) if name.startswith("nl_") else (orc.PRIMAL_INFEASIBLE, orc.DUAL_INFEASIBLE)
+    if name in ORACLE_MISSES_REFERENCE:
+        assert st == orc.MAX_ITER_REACHED  # recorded deviation of the restatement from the reference's expectation (5 of 103)
+    else:
+        assert st in expected, (name, st)
