@@ -324,6 +324,13 @@ int pq_batch_setup_sparse(pq_batch *s, int batch, int n, int p, int m, const int
  * structure and must not change (error otherwise); a doubly-infinite row of G stays as it was at setup. */
 int pq_batch_update(pq_batch *s, const double *c, const double *b, const double *h_l, const double *h_u,
                     const double *x_l, const double *x_u);
+/* update() of every instance with new MATRIX VALUES and / or vectors (solver.hpp:218-308 with update_P / update_A / update_G of
+ * :317-358).  Px / Ax / Gx: [batch][nnz] HOST arrays in the CSC order of the patterns given at setup (identical sparsity is the
+ * reference's precondition too), NULL = unchanged.  Per instance, on the device: unscale_data, assign, scale_data with a fresh Ruiz
+ * equilibration (sparse/preconditioner.hpp:65-222) unless settings.preconditioner_reuse_on_update, then the front arenas are rebuilt.
+ * With all three matrices NULL this is pq_batch_update.  Returns 1. */
+int pq_batch_update_data(pq_batch *s, const double *Px, const double *Ax, const double *Gx, const double *c, const double *b,
+                         const double *h_l, const double *h_u, const double *x_l, const double *x_u);
 /* solve() of every instance (solver.hpp:69-148); returns the number of instances that ended PQ_SOLVED (>= 0) */
 int pq_batch_solve(pq_batch *s);
 const pq_info *pq_batch_info(const pq_batch *s, int instance); /* result().info of one instance */

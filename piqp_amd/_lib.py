@@ -80,7 +80,7 @@ SYMBOLS = [
     "pq_solver_create", "pq_solver_destroy", "pq_solver_clone", "pq_solver_settings", "pq_solver_setup_dense",
     "pq_solver_setup_sparse", "pq_solver_update_dense", "pq_solver_update_sparse", "pq_solver_solve", "pq_solver_info",
     "pq_solver_get_result", "pq_solver_dims", "pq_solver_set_trace", "pq_solver_trace_rows", "pq_solver_partition", "pq_solver_set_exchange",
-    "pq_batch_create", "pq_batch_destroy", "pq_batch_settings", "pq_batch_setup_sparse", "pq_batch_update", "pq_batch_solve", "pq_batch_info", "pq_batch_get_result",
+    "pq_batch_create", "pq_batch_destroy", "pq_batch_settings", "pq_batch_setup_sparse", "pq_batch_update", "pq_batch_update_data", "pq_batch_solve", "pq_batch_info", "pq_batch_get_result",
     "pq_batch_dims", "pq_batch_block_info", "pq_batch_get_profile", "pq_batch_last_kernel_ms",
     "pq_debug_alloc_count", "pq_microbench_mfma_f64", "pq_microbench_hbm_copy", "pq_microbench_potrf_block", "pq_rccl_unique_id", "pq_kkt_set_comm_rccl", "pq_solver_set_comm_rccl", "pq_kkt_native_exchange_calls", "pq_kkt_min_abs_pivot", "pq_solver_native_exchange_calls",
 ]
@@ -136,6 +136,7 @@ def load():
     L.pq_batch_settings.restype = C.POINTER(Settings)
     L.pq_batch_setup_sparse.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int] + [vp] * 15
     L.pq_batch_update.argtypes = [vp] + [vp] * 6
+    L.pq_batch_update_data.argtypes = [vp] + [vp] * 9
     L.pq_batch_solve.argtypes = [vp]
     L.pq_batch_info.argtypes = [vp, C.c_int]
     L.pq_batch_info.restype = C.POINTER(Info)

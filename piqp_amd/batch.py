@@ -68,6 +68,16 @@ class BatchSparseSolver(_Handle):
                 self._stack(x_l, self.batch, self.n), self._stack(x_u, self.batch, self.n)]
         return bool(check(self.L.pq_batch_update(self.h, *[_ptr(a) for a in keep]), "pq_batch_update"))
 
+    def update_data(self, P_values=None, A_values=None, G_values=None, c=None, b=None, h_l=None, h_u=None, x_l=None, x_u=None):
+        """new matrix values ([batch, nnz] in the CSC order of the setup patterns) and / or vectors for every instance, None = unchanged:
+        unscale -> assign -> (fresh) Ruiz equilibration on the device, solver.hpp:218-308"""
+        st = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.float64)
+        for a in (P_values, A_values, G_values):
+            assert a is None or np.asarray(a).shape[0] == self.batch
+        keep = [st(P_values), st(A_values), st(G_values), self._stack(c, self.batch, self.n), self._stack(b, self.batch, self.p), self._stack(h_l, self.batch, self.m),
+                self._stack(h_u, self.batch, self.m), self._stack(x_l, self.batch, self.n), self._stack(x_u, self.batch, self.n)]
+        return bool(check(self.L.pq_batch_update_data(self.h, *[_ptr(a) for a in keep]), "pq_batch_update_data"))
+
     def solve(self):
         """returns the number of instances that ended SOLVED"""
         return check(self.L.pq_batch_solve(self.h), "pq_batch_solve")

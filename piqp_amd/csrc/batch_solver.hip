@@ -990,9 +990,9 @@ struct Ipm {
 // update() of every instance with new vectors only (solver.hpp:218-308 with every optional matrix empty): the new values are scaled on
 // the device with the Ruiz factors the instance got at setup (reuse_prev_scaling is forced for such updates, :283-285) and written over
 // the scaled copies in the arena.  NULL = unchanged.  Non-finite bounds are stored as -/+1e30 times the scaling, like set_h_l / set_h_u.
-__global__ void k_batch_update_vectors(const BatchShared* __restrict__ Sp, double* __restrict__ arena, const double* __restrict__ ruiz_c, const double* __restrict__ c,
-                                       const double* __restrict__ b, const double* __restrict__ h_l, const double* __restrict__ h_u, const double* __restrict__ x_l,
-                                       const double* __restrict__ x_u)
+__global__ void k_batch_update_vectors(const BatchShared* __restrict__ Sp, double* __restrict__ arena, const double* __restrict__ ruiz_c, const int* __restrict__ disabled,
+                                       const double* __restrict__ c, const double* __restrict__ b, const double* __restrict__ h_l, const double* __restrict__ h_u,
+                                       const double* __restrict__ x_l, const double* __restrict__ x_u)
 {
     const BatchShared& S = *Sp;
     const int q = blockIdx.x, n = S.n, p = S.p, m = S.m;
@@ -1002,10 +1002,36 @@ __global__ void k_batch_update_vectors(const BatchShared* __restrict__ Sp, doubl
     const double rc = ruiz_c[q];
     if (c) for (int i = threadIdx.x; i < n; i += blockDim.x) base[S.off[D_C] + i] = c[(size_t)q * n + i] * (rc * dl[i]);
     if (b) for (int i = threadIdx.x; i < p; i += blockDim.x) base[S.off[D_B] + i] = b[(size_t)q * p + i] * dl[n + i];
-    if (h_l) for (int i = threadIdx.x; i < m; i += blockDim.x) { const double v = h_l[(size_t)q * m + i]; base[S.off[D_HL] + i] = (v > -1e30 ? v : -1e30) * dl[n + p + i]; }
-    if (h_u) for (int i = threadIdx.x; i < m; i += blockDim.x) { const double v = h_u[(size_t)q * m + i]; base[S.off[D_HU] + i] = (v < 1e30 ? v : 1e30) * dl[n + p + i]; }
+    // (rows of G without any finite bound stay disabled: zero row, h = (-1, 1), data.hpp:144-169)
+    if (h_l) for (int i = threadIdx.x; i < m; i += blockDim.x) { const double v = h_l[(size_t)q * m + i]; base[S.off[D_HL] + i] = (disabled[i] ? -1.0 : (v > -1e30 ? v : -1e30)) * dl[n + p + i]; }
+    if (h_u) for (int i = threadIdx.x; i < m; i += blockDim.x) { const double v = h_u[(size_t)q * m + i]; base[S.off[D_HU] + i] = (disabled[i] ? 1.0 : (v < 1e30 ? v : 1e30)) * dl[n + p + i]; }
     if (x_l) for (int k = threadIdx.x; k < S.n_x_l; k += blockDim.x) { const int idx = S.x_l_idx[k]; base[S.off[D_XL] + k] = x_l[(size_t)q * n + idx] * db[idx]; }
     if (x_u) for (int k = threadIdx.x; k < S.n_x_u; k += blockDim.x) { const int idx = S.x_u_idx[k]; base[S.off[D_XU] + k] = x_u[(size_t)q * n + idx] * db[idx]; }
+}
+
+// update() with matrices (solver.hpp:218-308, update_P / update_A / update_G of :317-358): the caller's new values, in the CSC order they had at
+// setup, overwrite the UNSCALED copies in the arena (k_ruiz_sparse ran in RUIZ_UNSCALE mode before this and scales everything again afterwards).
+// map*[k] = position of the k-th input value in the stored upper-triangular P / transposed A, G, or -1 (strictly-lower entries of P; entries of a
+// disabled row of G, which stay zero).  NULL = unchanged.
+struct BatchAssignArgs {
+    int nzP_in, nzA_in, nzG_in;
+    const int *mapP, *mapA, *mapG, *disabled;
+    const double *Px, *Ax, *Gx, *c, *b, *h_l, *h_u, *x_l, *x_u;
+};
+__global__ void k_batch_assign(const BatchShared* __restrict__ Sp, double* __restrict__ arena, BatchAssignArgs a)
+{
+    const BatchShared& S = *Sp;
+    const int q = blockIdx.x, n = S.n, p = S.p, m = S.m, t = threadIdx.x, NT = blockDim.x;
+    double* base = arena + (long long)q * S.stride;
+    if (a.Px) for (int k = t; k < a.nzP_in; k += NT) { const int d = a.mapP[k]; if (d >= 0) base[S.off[D_PX] + d] = a.Px[(size_t)q * a.nzP_in + k]; }
+    if (a.Ax) for (int k = t; k < a.nzA_in; k += NT) { const int d = a.mapA[k]; if (d >= 0) base[S.off[D_ATX] + d] = a.Ax[(size_t)q * a.nzA_in + k]; }
+    if (a.Gx) for (int k = t; k < a.nzG_in; k += NT) { const int d = a.mapG[k]; if (d >= 0) base[S.off[D_GTX] + d] = a.Gx[(size_t)q * a.nzG_in + k]; }
+    if (a.c) for (int i = t; i < n; i += NT) base[S.off[D_C] + i] = a.c[(size_t)q * n + i];
+    if (a.b) for (int i = t; i < p; i += NT) base[S.off[D_B] + i] = a.b[(size_t)q * p + i];
+    if (a.h_l) for (int i = t; i < m; i += NT) { const double v = a.h_l[(size_t)q * m + i]; base[S.off[D_HL] + i] = a.disabled[i] ? -1.0 : (v > -1e30 ? v : -1e30); }
+    if (a.h_u) for (int i = t; i < m; i += NT) { const double v = a.h_u[(size_t)q * m + i]; base[S.off[D_HU] + i] = a.disabled[i] ? 1.0 : (v < 1e30 ? v : 1e30); }
+    if (a.x_l) for (int k = t; k < S.n_x_l; k += NT) base[S.off[D_XL] + k] = a.x_l[(size_t)q * n + S.x_l_idx[k]];
+    if (a.x_u) for (int k = t; k < S.n_x_u; k += NT) base[S.off[D_XU] + k] = a.x_u[(size_t)q * n + S.x_u_idx[k]];
 }
 
 // per instance: caller's (Ruiz-scaled) values -> front / grouped-row arenas and the AtA fronts (multistage ctor, :76-135)
@@ -1121,16 +1147,24 @@ public:
         PQ_HIP(hipSetDevice(dev_));
         batch_ = batch;
         const int nzP = Pp[n], nzA = Ap ? Ap[n] : 0, nzG = Gp ? Gp[n] : 0;
-        // ---- per-instance Data + Ruiz on the host (the instances are independent: one host thread per slice) ----
+        // ---- which bounds are finite is part of the shared structure: the caller's pattern must be the same in every instance ----
+        auto finite_pattern = [&](const double* v, int len, bool lower, std::vector<char>& out) {
+            out.assign(len, 0);
+            if (!v) return;
+            for (int i = 0; i < len; ++i) out[i] = lower ? v[i] > -1e30 : v[i] < 1e30;
+            for (int q = 1; q < batch; ++q)
+                for (int i = 0; i < len; ++i)
+                    if ((lower ? v[(size_t)q * len + i] > -1e30 : v[(size_t)q * len + i] < 1e30) != (out[i] != 0)) throw std::runtime_error("batch setup: instances differ in which bounds are finite");
+        };
+        finite_pattern(Gp ? h_l : nullptr, Gp ? m : 0, true, fin_hl_); finite_pattern(Gp ? h_u : nullptr, Gp ? m : 0, false, fin_hu_);
+        finite_pattern(x_l, n, true, fin_xl_); finite_pattern(x_u, n, false, fin_xu_);
+        // ---- per-instance Data on the host (transposes, bound lists; the instances are independent: one host thread per slice) ----
         std::vector<std::unique_ptr<HostData>> data(batch);
-        std::vector<Ruiz> ruiz(batch);
         auto build = [&](int lo, int hi) {
             for (int i = lo; i < hi; ++i) {
                 data[i] = make_sparse_host_data(n, p, m, Pp, Pi, Px + (size_t)i * nzP, c + (size_t)i * n, Ap, Ai, Ax ? Ax + (size_t)i * nzA : nullptr, b ? b + (size_t)i * p : nullptr,
                                                 Gp, Gi, Gx ? Gx + (size_t)i * nzG : nullptr, h_l ? h_l + (size_t)i * m : nullptr, h_u ? h_u + (size_t)i * m : nullptr,
                                                 x_l ? x_l + (size_t)i * n : nullptr, x_u ? x_u + (size_t)i * n : nullptr);
-                ruiz[i].init(*data[i]);
-                ruiz[i].scale_data(*data[i], false, settings_.preconditioner_scale_cost != 0, settings_.preconditioner_iter);
             }
         };
         {
@@ -1155,15 +1189,12 @@ public:
                               std::equal(d.x_u_idx.begin(), d.x_u_idx.begin() + d.n_x_u, d0.x_u_idx.begin());
             if (!same) throw std::runtime_error("batch setup: instances differ in which bounds are finite");
         }
-        fin_hl_.assign(m_, 0); fin_hu_.assign(m_, 0); fin_xl_.assign(n_, 0); fin_xu_.assign(n_, 0);
-        for (int k = 0; k < d0.n_h_l; ++k) fin_hl_[d0.h_l_idx[k]] = 1;
-        for (int k = 0; k < d0.n_h_u; ++k) fin_hu_[d0.h_u_idx[k]] = 1;
-        for (int k = 0; k < d0.n_x_l; ++k) fin_xl_[d0.x_l_idx[k]] = 1;
-        for (int k = 0; k < d0.n_x_u; ++k) fin_xu_[d0.x_u_idx[k]] = 1;
+        fin_hl_.resize(m_, 0); fin_hu_.resize(m_, 0);
         // ---- shared structure ----
         pq_sparse_data desc = d0.sparse_descriptor();
         multistage::analyse(&desc, sym_);
         build_shared(d0);
+        build_update_maps(n, p, m, Pp, Pi, c, Ap, Ai, b, Gp, Gi, h_l, h_u, x_l, x_u, d0);
         // ---- per-instance arena ----
         arena_.alloc((size_t)layout_.stride * batch);
         arena_.zero(st_);
@@ -1172,16 +1203,15 @@ public:
         prof_.alloc((size_t)batch * NPROF);
         infos_h_.resize(batch);
         std::vector<double> stage((size_t)layout_.stride * std::min(batch, STAGE_INST));
-        std::vector<double> rc(batch);
         for (int i0 = 0; i0 < batch; i0 += STAGE_INST) {
             const int cnt = std::min(STAGE_INST, batch - i0);
             std::fill(stage.begin(), stage.begin() + (size_t)layout_.stride * cnt, 0.0);
-            for (int k = 0; k < cnt; ++k) pack_instance(*data[i0 + k], ruiz[i0 + k], stage.data() + (size_t)layout_.stride * k);
+            for (int k = 0; k < cnt; ++k) pack_instance(*data[i0 + k], stage.data() + (size_t)layout_.stride * k);
             PQ_HIP(hipMemcpyAsync(arena_.p + (size_t)layout_.stride * i0, stage.data(), sizeof(double) * (size_t)layout_.stride * cnt, hipMemcpyHostToDevice, st_));
             PQ_HIP(hipStreamSynchronize(st_));
         }
-        for (int i = 0; i < batch; ++i) rc[i] = ruiz[i].c;
-        PQ_HIP(hipMemcpyAsync(ruiz_c_.p, rc.data(), sizeof(double) * batch, hipMemcpyHostToDevice, st_));
+        // RuizEquilibration::scale_data of every instance (sparse/preconditioner.hpp:65-222) in one launch, then the front arenas
+        launch_ruiz(RUIZ_COMPUTE);
         launch_prepare();
         PQ_HIP(hipStreamSynchronize(st_));
         setup_done_ = true;
@@ -1220,17 +1250,7 @@ public:
     {
         if (!setup_done_) throw std::runtime_error("batch solver not set up");
         PQ_HIP(hipSetDevice(dev_));
-        auto pattern_ok = [&](const double* v, int len, const std::vector<char>& finite, bool lower) {
-            if (!v) return true;
-            for (int q = 0; q < batch_; ++q)
-                for (int i = 0; i < len; ++i) {
-                    const double x = v[(size_t)q * len + i];
-                    if ((lower ? x > -1e30 : x < 1e30) != (finite[i] != 0)) return false;
-                }
-            return true;
-        };
-        if (!pattern_ok(h_l, m_, fin_hl_, true) || !pattern_ok(h_u, m_, fin_hu_, false) || !pattern_ok(x_l, n_, fin_xl_, true) || !pattern_ok(x_u, n_, fin_xu_, false))
-            throw std::runtime_error("batch update: the set of finite bounds differs from the one given at setup");
+        check_patterns(h_l, h_u, x_l, x_u);
         DBuf<double> dc, dbv, dhl, dhu, dxl, dxu;
         auto up = [&](DBuf<double>& d, const double* v, int len) -> const double* {
             if (!v || len == 0) return nullptr;
@@ -1239,8 +1259,37 @@ public:
             return d.p;
         };
         const double *pc = up(dc, c, n_), *pb = up(dbv, b, p_), *phl = up(dhl, h_l, m_), *phu = up(dhu, h_u, m_), *pxl = up(dxl, x_l, n_), *pxu = up(dxu, x_u, n_);
-        hipLaunchKernelGGL(k_batch_update_vectors, dim3(batch_), dim3(128), 0, st_, shared_.p, arena_.p, ruiz_c_.p, pc, pb, phl, phu, pxl, pxu);
+        hipLaunchKernelGGL(k_batch_update_vectors, dim3(batch_), dim3(128), 0, st_, shared_.p, arena_.p, ruiz_c_.p, disabled_d_, pc, pb, phl, phu, pxl, pxu);
         PQ_HIP(hipGetLastError());
+        PQ_HIP(hipStreamSynchronize(st_));
+        return true;
+    }
+    // update() of every instance with new matrix values (patterns and the set of finite bounds as given at setup) and / or vectors: per instance
+    // unscale_data -> assign -> scale_data (fresh equilibration unless settings.preconditioner_reuse_on_update), all on the device
+    bool update_data(const double* Px, const double* Ax, const double* Gx, const double* c, const double* b, const double* h_l, const double* h_u, const double* x_l,
+                     const double* x_u)
+    {
+        if (!Px && !Ax && !Gx) return update_vectors(c, b, h_l, h_u, x_l, x_u);
+        if (!setup_done_) throw std::runtime_error("batch solver not set up");
+        PQ_HIP(hipSetDevice(dev_));
+        check_patterns(h_l, h_u, x_l, x_u);
+        DBuf<double> dP, dA, dG, dc, dbv, dhl, dhu, dxl, dxu;
+        auto up = [&](DBuf<double>& d, const double* v, int len) -> const double* {
+            if (!v || len == 0) return nullptr;
+            d.alloc((size_t)batch_ * len);
+            PQ_HIP(hipMemcpyAsync(d.p, v, sizeof(double) * (size_t)batch_ * len, hipMemcpyHostToDevice, st_));
+            return d.p;
+        };
+        BatchAssignArgs a{};
+        a.nzP_in = nzP_in_; a.nzA_in = nzA_in_; a.nzG_in = nzG_in_;
+        a.mapP = mapP_; a.mapA = mapA_; a.mapG = mapG_; a.disabled = disabled_d_;
+        a.Px = up(dP, Px, nzP_in_); a.Ax = up(dA, Ax, nzA_in_); a.Gx = up(dG, Gx, nzG_in_);
+        a.c = up(dc, c, n_); a.b = up(dbv, b, p_); a.h_l = up(dhl, h_l, m_); a.h_u = up(dhu, h_u, m_); a.x_l = up(dxl, x_l, n_); a.x_u = up(dxu, x_u, n_);
+        launch_ruiz(RUIZ_UNSCALE);
+        hipLaunchKernelGGL(k_batch_assign, dim3(batch_), dim3(128), 0, st_, shared_.p, arena_.p, a);
+        PQ_HIP(hipGetLastError());
+        launch_ruiz(settings_.preconditioner_reuse_on_update ? RUIZ_REUSE : RUIZ_COMPUTE);
+        launch_prepare();
         PQ_HIP(hipStreamSynchronize(st_));
         return true;
     }
@@ -1277,6 +1326,66 @@ public:
 
 private:
     static constexpr int STAGE_INST = 256;
+
+    void check_patterns(const double* h_l, const double* h_u, const double* x_l, const double* x_u) const
+    {
+        auto pattern_ok = [&](const double* v, int len, const std::vector<char>& finite, bool lower) {
+            if (!v) return true;
+            for (int q = 0; q < batch_; ++q)
+                for (int i = 0; i < len; ++i) {
+                    const double x = v[(size_t)q * len + i];
+                    if ((lower ? x > -1e30 : x < 1e30) != (finite[i] != 0)) return false;
+                }
+            return true;
+        };
+        if (!pattern_ok(h_l, m_, fin_hl_, true) || !pattern_ok(h_u, m_, fin_hu_, false) || !pattern_ok(x_l, n_, fin_xl_, true) || !pattern_ok(x_u, n_, fin_xu_, false))
+            throw std::runtime_error("batch update: the set of finite bounds differs from the one given at setup");
+    }
+
+    // Where the caller's k-th value of P / A / G lives in the arena: found by pushing the values 1, 2, 3, ... through the same host path the real
+    // values took at setup (make_sparse_host_data: upper-triangle extraction, transposes, disabled rows of G zeroed).
+    void build_update_maps(int n, int p, int m, const int* Pp, const int* Pi, const double* c, const int* Ap, const int* Ai, const double* b, const int* Gp, const int* Gi,
+                           const double* h_l, const double* h_u, const double* x_l, const double* x_u, const HostData& d0)
+    {
+        nzP_in_ = Pp[n]; nzA_in_ = Ap ? Ap[n] : 0; nzG_in_ = Gp ? Gp[n] : 0;
+        Vec iP(std::max(nzP_in_, 1)), iA(std::max(nzA_in_, 1)), iG(std::max(nzG_in_, 1));
+        for (int k = 0; k < nzP_in_; ++k) iP[k] = k + 1;
+        for (int k = 0; k < nzA_in_; ++k) iA[k] = k + 1;
+        for (int k = 0; k < nzG_in_; ++k) iG[k] = k + 1;
+        auto probe = make_sparse_host_data(n, p, m, Pp, Pi, iP.data(), c, Ap, Ai, Ap ? iA.data() : nullptr, b, Gp, Gi, Gp ? iG.data() : nullptr, h_l, h_u, x_l, x_u);
+        auto invert = [&](const Vec& stored, int nz_in) {
+            std::vector<int> map(std::max(nz_in, 1), -1);
+            for (size_t t = 0; t < stored.size(); ++t) if (stored[t] > 0.0) map[(int)stored[t] - 1] = (int)t;
+            return map;
+        };
+        mapP_ = up(ibufs_, invert(probe->sP_utri.val, nzP_in_));
+        mapA_ = up(ibufs_, invert(probe->sAT.val, nzA_in_));
+        mapG_ = up(ibufs_, invert(probe->sGT.val, nzG_in_));
+        std::vector<int> dis(std::max(m_, 1), 0);
+        for (int i = 0; i < m_; ++i) dis[i] = !fin_hl_[i] && !fin_hu_[i];
+        disabled_d_ = up(ibufs_, dis);
+        rzPp_ = up(ibufs_, d0.sP_utri.colptr);
+        rzPi_ = up(ibufs_, d0.sP_utri.rowind.empty() ? std::vector<int>(1, 0) : d0.sP_utri.rowind);
+        PQ_HIP(hipStreamSynchronize(st_));
+    }
+
+    // sparse/preconditioner.hpp on the arena: one workgroup per instance (ruiz_kernels.hip)
+    void launch_ruiz(int mode)
+    {
+        const BatchShared& S = shared_h_;
+        RuizSparseArgs a;
+        a.n = n_; a.p = p_; a.m = m_;
+        a.Pp = rzPp_; a.Pi = rzPi_; a.ATp = S.AT_p; a.ATi = S.AT_i; a.GTp = S.GT_p; a.GTi = S.GT_i;
+        a.stride = layout_.stride;
+        auto at = [&](int slot) { return arena_.p + layout_.off[slot]; };
+        a.Px = at(D_PX); a.ATx = at(D_ATX); a.GTx = at(D_GTX); a.c = at(D_C); a.xbs = at(D_XBS);
+        a.delta = at(D_DL); a.delta_inv = at(D_DLI); a.delta_b = at(D_DB); a.delta_b_inv = at(D_DBI); a.tmp = at(K_WX);
+        a.b = at(D_B); a.h_l = at(D_HL); a.h_u = at(D_HU); a.x_l = at(D_XL); a.x_u = at(D_XU);
+        a.x_l_idx = S.x_l_idx; a.x_u_idx = S.x_u_idx; a.n_x_l = S.n_x_l; a.n_x_u = S.n_x_u;
+        a.c_scale = ruiz_c_.p;
+        a.mode = mode; a.scale_cost = settings_.preconditioner_scale_cost != 0; a.max_iter = settings_.preconditioner_iter;
+        launch_ruiz_sparse(a, batch_, n_ + p_ + m_ <= 512 ? 64 : 256, st_);
+    }
 
     template <class T>
     const T* up(std::vector<DBuf<T>>& pool, const std::vector<T>& h)
@@ -1406,12 +1515,11 @@ private:
         PQ_HIP(hipStreamSynchronize(st_));
     }
 
-    void pack_instance(const HostData& d, const Ruiz& r, double* dst) const
+    void pack_instance(const HostData& d, double* dst) const
     {
         auto cp = [&](int slot, const Vec& v, size_t cnt) { if (cnt) std::copy(v.begin(), v.begin() + cnt, dst + layout_.off[slot]); };
         cp(D_PX, d.sP_utri.val, d.sP_utri.val.size()); cp(D_ATX, d.sAT.val, d.sAT.val.size()); cp(D_GTX, d.sGT.val, d.sGT.val.size());
         cp(D_C, d.c, n_); cp(D_B, d.b, p_); cp(D_HL, d.h_l, m_); cp(D_HU, d.h_u, m_); cp(D_XL, d.x_l, n_); cp(D_XU, d.x_u, n_); cp(D_XBS, d.x_b_scaling, n_);
-        cp(D_DL, r.delta, n_ + p_ + m_); cp(D_DLI, r.delta_inv, n_ + p_ + m_); cp(D_DB, r.delta_b, n_); cp(D_DBI, r.delta_b_inv, n_);
     }
 
     void launch_prepare()
@@ -1462,7 +1570,9 @@ private:
     int dev_, batch_ = 0, n_ = 0, p_ = 0, m_ = 0, nt_ = 64;
     int mode_ = MODE_STAGED, wpe_ = 4, forced_mode_ = -1;
     bool setup_done_ = false;
-    std::vector<char> fin_hl_, fin_hu_, fin_xl_, fin_xu_;  // which bounds are finite (shared by all instances)
+    std::vector<char> fin_hl_, fin_hu_, fin_xl_, fin_xu_;  // which of the caller's bounds are finite (shared by all instances)
+    int nzP_in_ = 0, nzA_in_ = 0, nzG_in_ = 0;             // the caller's nonzero counts (P may carry its lower triangle)
+    const int *mapP_ = nullptr, *mapA_ = nullptr, *mapG_ = nullptr, *disabled_d_ = nullptr, *rzPp_ = nullptr, *rzPi_ = nullptr;  // device, owned by ibufs_
     double last_kernel_ms_ = 0.0;
     hipStream_t st_ = nullptr;
     pq_settings settings_;
@@ -1510,6 +1620,12 @@ int pq_batch_update(pq_batch* s, const double* c, const double* b, const double*
 {
     if (!s) return fail(PQ_ERR_INVALID, "null argument");
     return guarded([&] { return s->impl->update_vectors(c, b, h_l, h_u, x_l, x_u) ? 1 : 0; });
+}
+int pq_batch_update_data(pq_batch* s, const double* Px, const double* Ax, const double* Gx, const double* c, const double* b, const double* h_l, const double* h_u,
+                         const double* x_l, const double* x_u)
+{
+    if (!s) return fail(PQ_ERR_INVALID, "null argument");
+    return guarded([&] { return s->impl->update_data(Px, Ax, Gx, c, b, h_l, h_u, x_l, x_u) ? 1 : 0; });
 }
 int pq_batch_solve(pq_batch* s)
 {

@@ -63,13 +63,14 @@ void HostData::set_h_u(const double* v)
     }
 }
 // dense/data.hpp:144-169 (rows with no finite side: zero the row of G, pretend h = (-1, 1))
-bool HostData::disable_inf_constraints()
+bool HostData::disable_inf_constraints(IVec* rows)
 {
     bool any = false;
     for (int i = 0; i < m; ++i) {
         if (h_l[i] <= -PIQP_INF && h_u[i] >= PIQP_INF) {
             if (sparse) { for (int k = sGT.colptr[i]; k < sGT.colptr[i + 1]; ++k) sGT.val[k] = 0.0; }
-            else std::fill(GT.begin() + (size_t)i * n, GT.begin() + (size_t)(i + 1) * n, 0.0);
+            else if (!GT.empty()) std::fill(GT.begin() + (size_t)i * n, GT.begin() + (size_t)(i + 1) * n, 0.0);  // (empty: the matrix lives on the device, see `rows`)
+            if (rows) rows->push_back(i);
             h_l[i] = -1.0; h_u[i] = 1.0;
             any = true;
         }
@@ -352,10 +353,23 @@ void Ruiz::scale_data(HostData& d, bool reuse_prev_scaling, bool scale_cost, int
         scale_T(d, true, delta.data(), delta.data() + n + p);
         for (int i = 0; i < n; ++i) d.x_b_scaling[i] *= delta_b[i] * delta[i];
     }
+    scale_bounds(d);
+}
+
+// dense/preconditioner.hpp:208-221 / :247-257: b, h_l, h_u, x_l, x_u
+void Ruiz::scale_bounds(HostData& d) const
+{
     for (int i = 0; i < p; ++i) d.b[i] *= delta[n + i];
     for (int i = 0; i < m; ++i) { d.h_l[i] *= delta[n + p + i]; d.h_u[i] *= delta[n + p + i]; }
     for (int i = 0; i < d.n_x_l; ++i) d.x_l[i] *= delta_b[d.x_l_idx[i]];
     for (int i = 0; i < d.n_x_u; ++i) d.x_u[i] *= delta_b[d.x_u_idx[i]];
+}
+void Ruiz::unscale_bounds(HostData& d) const
+{
+    for (int i = 0; i < p; ++i) d.b[i] *= delta_inv[n + i];
+    for (int i = 0; i < m; ++i) { d.h_l[i] *= delta_inv[n + p + i]; d.h_u[i] *= delta_inv[n + p + i]; }
+    for (int i = 0; i < d.n_x_l; ++i) d.x_l[i] *= delta_b_inv[d.x_l_idx[i]];
+    for (int i = 0; i < d.n_x_u; ++i) d.x_u[i] *= delta_b_inv[d.x_u_idx[i]];
 }
 
 // dense/preconditioner.hpp:224-258
@@ -367,27 +381,18 @@ void Ruiz::unscale_data(HostData& d)
     scale_T(d, false, delta_inv.data(), delta_inv.data() + n);
     scale_T(d, true, delta_inv.data(), delta_inv.data() + n + p);
     for (int i = 0; i < n; ++i) d.x_b_scaling[i] *= delta_b_inv[i] * delta_inv[i];
-    for (int i = 0; i < p; ++i) d.b[i] *= delta_inv[n + i];
-    for (int i = 0; i < m; ++i) { d.h_l[i] *= delta_inv[n + p + i]; d.h_u[i] *= delta_inv[n + p + i]; }
-    for (int i = 0; i < d.n_x_l; ++i) d.x_l[i] *= delta_b_inv[d.x_l_idx[i]];
-    for (int i = 0; i < d.n_x_u; ++i) d.x_u[i] *= delta_b_inv[d.x_u_idx[i]];
+    unscale_bounds(d);
 }
 
 void Ruiz::unscale_vectors(HostData& d) const
 {
     for (int i = 0; i < n; ++i) d.c[i] *= c_inv * delta_inv[i];
-    for (int i = 0; i < p; ++i) d.b[i] *= delta_inv[n + i];
-    for (int i = 0; i < m; ++i) { d.h_l[i] *= delta_inv[n + p + i]; d.h_u[i] *= delta_inv[n + p + i]; }
-    for (int i = 0; i < d.n_x_l; ++i) d.x_l[i] *= delta_b_inv[d.x_l_idx[i]];
-    for (int i = 0; i < d.n_x_u; ++i) d.x_u[i] *= delta_b_inv[d.x_u_idx[i]];
+    unscale_bounds(d);
 }
 void Ruiz::scale_vectors(HostData& d) const
 {
     for (int i = 0; i < n; ++i) d.c[i] *= c * delta[i];
-    for (int i = 0; i < p; ++i) d.b[i] *= delta[n + i];
-    for (int i = 0; i < m; ++i) { d.h_l[i] *= delta[n + p + i]; d.h_u[i] *= delta[n + p + i]; }
-    for (int i = 0; i < d.n_x_l; ++i) d.x_l[i] *= delta_b[d.x_l_idx[i]];
-    for (int i = 0; i < d.n_x_u; ++i) d.x_u[i] *= delta_b[d.x_u_idx[i]];
+    scale_bounds(d);
 }
 
 // ------------------------------------------------------------------ HostVars
@@ -462,7 +467,7 @@ void Solver::make_kkt()
     KKTSolverBase* backend = nullptr;
     if (!m_data->sparse) {
         if (m_settings.kkt_solver != PQ_DENSE_CHOLESKY && m_settings.kkt_solver != PQ_DENSE_LDLT_NO_PIVOT) { std::fprintf(stderr, "kkt solver not supported\n"); return; }
-        pq_dense_data desc = m_data->dense_descriptor();
+        pq_dense_data desc = druiz_ ? druiz_->dense_descriptor(*m_data) : m_data->dense_descriptor();
         backend = make_dense_kkt(&desc, m_settings.kkt_solver, device_);
     } else {
         pq_sparse_data desc = m_data->sparse_descriptor();
@@ -485,7 +490,13 @@ bool Solver::setup(std::unique_ptr<HostData> data)
     m_info = pq_info{};
     m_info.rho = m_settings.rho_init; m_info.delta = m_settings.delta_init;
     m_preconditioner.init(*m_data);
-    m_preconditioner.scale_data(*m_data, false, m_settings.preconditioner_scale_cost != 0, m_settings.preconditioner_iter);
+    // dense/preconditioner.hpp:62-222 on the device (ruiz_kernels.hip); the host routine stays reachable for the bitwise comparison test
+    druiz_.reset();
+    if (!debug_token("host_ruiz")) {
+        druiz_ = std::make_unique<DeviceRuiz>(device_, *m_data);
+        if (!m_data->sparse) { druiz_->upload_dense(*m_data, PQ_KKT_UPDATE_P | PQ_KKT_UPDATE_A | PQ_KKT_UPDATE_G); release_dense_staging(); }
+    }
+    scale_problem(false);
     make_kkt();
     if (!m_kkt_system) { m_setup_done = false; return false; }
     stage_alloc();
@@ -497,6 +508,28 @@ bool Solver::setup(std::unique_ptr<HostData> data)
     return true;
 }
 
+// the unscaled dense matrices are staging only once they are in HBM (the scaled truth is DeviceRuiz's)
+void Solver::release_dense_staging()
+{
+    Vec().swap(m_data->P_utri); Vec().swap(m_data->AT); Vec().swap(m_data->GT);
+}
+// preconditioner.scale_data / unscale_data of solver.hpp:163,260,287
+void Solver::scale_problem(bool reuse)
+{
+    HostData& d = *m_data;
+    const bool cost = m_settings.preconditioner_scale_cost != 0;
+    if (!druiz_) { m_preconditioner.scale_data(d, reuse, cost, m_settings.preconditioner_iter); return; }
+    druiz_->scale(d, m_preconditioner, reuse, cost, m_settings.preconditioner_iter);
+    m_preconditioner.scale_bounds(d);
+}
+void Solver::unscale_problem()
+{
+    HostData& d = *m_data;
+    if (!druiz_) { m_preconditioner.unscale_data(d); return; }
+    druiz_->unscale(d, m_preconditioner);
+    m_preconditioner.unscale_bounds(d);
+}
+
 Solver* Solver::clone() const
 {
     std::unique_ptr<Solver> s(new Solver(device_));
@@ -505,6 +538,7 @@ Solver* Solver::clone() const
     if (m_data) {
         s->m_data = std::make_unique<HostData>(*m_data);
         s->m_preconditioner = m_preconditioner;
+        if (druiz_) s->druiz_ = m_data->sparse ? std::make_unique<DeviceRuiz>(device_, *m_data) : druiz_->clone();
         s->m_result = m_result; s->res_nr = res_nr; s->res = res; s->step = step; s->prox_vars = prox_vars;
         if (m_kkt_system) {
             s->m_kkt_system.reset(m_kkt_system->clone()); s->stage_alloc();
@@ -514,10 +548,10 @@ Solver* Solver::clone() const
     return s.release();
 }
 
-static void refresh_kkt(Solver&, KKTSystem& k, const HostData& d, int options)
+static void refresh_kkt(const DeviceRuiz* dr, KKTSystem& k, const HostData& d, int options)
 {
     // KKTSystem::update_data, kkt_system.hpp:134-141 (+ bound lists / x_b_scaling, which live in `data` in the reference)
-    if (!d.sparse) { pq_dense_data desc = d.dense_descriptor(); k.backend()->update_data_dense(&desc, options); }
+    if (!d.sparse) { pq_dense_data desc = dr ? dr->dense_descriptor(d) : d.dense_descriptor(); k.backend()->update_data_dense(&desc, options); }
     else { pq_sparse_data desc = d.sparse_descriptor(); k.backend()->update_data_sparse(&desc, options); }
     k.set_bounds(d.n_h_l, d.n_h_u, d.n_x_l, d.n_x_u, d.h_l_idx.data(), d.h_u_idx.data(), d.x_l_idx.data(), d.x_u_idx.data(), d.x_b_scaling.data(), PQ_MEM_HOST);
 }
@@ -533,11 +567,13 @@ bool Solver::update_vectors_only(const double* c, const double* b, const double*
     if (b) std::copy(b, b + d.p, d.b.begin());
     if (h_l) d.set_h_l(h_l);
     if (h_u) d.set_h_u(h_u);
-    const bool row_zeroed = (h_l || h_u) && d.disable_inf_constraints();  // a row of G without any finite bound is zeroed: that IS a matrix change
+    IVec zeroed;
+    const bool row_zeroed = (h_l || h_u) && d.disable_inf_constraints(&zeroed);  // a row of G without any finite bound is zeroed: that IS a matrix change
+    if (row_zeroed && druiz_) druiz_->zero_G_rows(zeroed);
     if (x_l) d.set_x_l(x_l);
     if (x_u) d.set_x_u(x_u);
     m_preconditioner.scale_vectors(d);
-    if (row_zeroed) { refresh_kkt(*this, *m_kkt_system, d, PQ_KKT_UPDATE_G); }
+    if (row_zeroed) { refresh_kkt(druiz_.get(), *m_kkt_system, d, PQ_KKT_UPDATE_G); }
     else m_kkt_system->set_bounds(d.n_h_l, d.n_h_u, d.n_x_l, d.n_x_u, d.h_l_idx.data(), d.h_u_idx.data(), d.x_l_idx.data(), d.x_u_idx.data(), d.x_b_scaling.data(), PQ_MEM_HOST);
     if (dipm_) dipm_->refresh_data(d, m_preconditioner);
     m_info.update_time = now_s() - t0;
@@ -553,9 +589,10 @@ bool Solver::update_dense(const double* P, const double* c, const double* A, con
     HostData& d = *m_data;
     const int n = d.n, p = d.p, m = d.m;
     if (!P && !A && !G) return update_vectors_only(c, b, h_l, h_u, x_l, x_u, t0);
-    m_preconditioner.unscale_data(d);
+    unscale_problem();
     int opt = PQ_KKT_UPDATE_NONE;
     if (P) {
+        d.P_utri.resize((size_t)n * n);
         parallel_for(n, n, [&](int lo, int hi, int) {
             for (int j = lo; j < hi; ++j) {
                 double* col = d.P_utri.data() + (size_t)j * n;
@@ -571,13 +608,15 @@ bool Solver::update_dense(const double* P, const double* c, const double* A, con
     if (b) std::copy(b, b + p, d.b.begin());
     if (h_l) d.set_h_l(h_l);
     if (h_u) d.set_h_u(h_u);
-    if (h_l || h_u) d.disable_inf_constraints();
+    IVec zeroed;
+    if (h_l || h_u) d.disable_inf_constraints(&zeroed);
     if (x_l) d.set_x_l(x_l);
     if (x_u) d.set_x_u(x_u);
+    if (druiz_) { druiz_->upload_dense(d, opt); druiz_->zero_G_rows(zeroed); release_dense_staging(); }
     bool reuse = m_settings.preconditioner_reuse_on_update != 0;
     if (opt == PQ_KKT_UPDATE_NONE) reuse = true;
-    m_preconditioner.scale_data(d, reuse, m_settings.preconditioner_scale_cost != 0, m_settings.preconditioner_iter);
-    refresh_kkt(*this, *m_kkt_system, d, opt);
+    scale_problem(reuse);
+    refresh_kkt(druiz_.get(), *m_kkt_system, d, opt);
     if (dipm_) dipm_->refresh_data(d, m_preconditioner);
     m_info.update_time = now_s() - t0;
     return true;
@@ -592,7 +631,7 @@ bool Solver::update_sparse(const int* Pp, const int* Pi, const double* Px, const
     HostData& d = *m_data;
     const int n = d.n, p = d.p, m = d.m;
     if (!Px && !Ax && !Gx) return update_vectors_only(c, b, h_l, h_u, x_l, x_u, t0);
-    m_preconditioner.unscale_data(d);
+    unscale_problem();
     int opt = PQ_KKT_UPDATE_NONE;
     (void)Pi;
     if (Px) {
@@ -619,8 +658,8 @@ bool Solver::update_sparse(const int* Pp, const int* Pi, const double* Px, const
     if (x_u) d.set_x_u(x_u);
     bool reuse = m_settings.preconditioner_reuse_on_update != 0;
     if (opt == PQ_KKT_UPDATE_NONE) reuse = true;
-    m_preconditioner.scale_data(d, reuse, m_settings.preconditioner_scale_cost != 0, m_settings.preconditioner_iter);
-    refresh_kkt(*this, *m_kkt_system, d, opt);
+    scale_problem(reuse);
+    refresh_kkt(druiz_.get(), *m_kkt_system, d, opt);
     if (dipm_) dipm_->refresh_data(d, m_preconditioner);
     m_info.update_time = now_s() - t0;
     return true;

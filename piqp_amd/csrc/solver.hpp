@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "kkt_system.hpp"
+#include "ruiz_device.hpp"
 
 namespace pq {
 
@@ -35,7 +36,7 @@ struct HostData {
     void resize_vectors();
     void set_h_l(const double* v);
     void set_h_u(const double* v);
-    bool disable_inf_constraints();  // true if a row was disabled (its G row zeroed)
+    bool disable_inf_constraints(std::vector<int>* rows = nullptr);  // true if a row was disabled (its G row zeroed; the rows are appended to *rows)
     void set_x_l(const double* v);
     void set_x_u(const double* v);
     pq_dense_data dense_descriptor() const;
@@ -53,6 +54,9 @@ struct Ruiz {
     // the vector part of unscale_data / scale_data(reuse): updates that touch no matrix leave the scaled matrices alone
     void unscale_vectors(HostData& d) const;
     void scale_vectors(HostData& d) const;
+    // b, h_l, h_u, x_l, x_u alone (the matrices, c and x_b_scaling are DeviceRuiz's)
+    void scale_bounds(HostData& d) const;
+    void unscale_bounds(HostData& d) const;
 };
 
 struct HostVars {
@@ -117,6 +121,9 @@ private:
     void unscale_results();
     void restore_dual();
     void make_kkt();
+    void scale_problem(bool reuse);
+    void unscale_problem();
+    void release_dense_staging();
     void stage_alloc();
     void to_device(const HostVars& h, pq_vars& d);
     void from_device(const pq_vars& d, HostVars& h);
@@ -126,6 +133,7 @@ private:
     pq_info m_info{};
     std::unique_ptr<HostData> m_data;
     Ruiz m_preconditioner;
+    std::unique_ptr<DeviceRuiz> druiz_;  // device side of m_preconditioner; null only under PIQP_AMD_DEBUG=host_ruiz
     std::unique_ptr<KKTSystem> m_kkt_system;
     bool m_first_run = true, m_setup_done = false, m_enable_iterative_refinement = false;
     HostVars m_result, res_nr, res, step, prox_vars;

@@ -143,3 +143,44 @@ def test_batch_update_vectors_matches_oracle_update(hip, orc):
     bad = xu2.copy(); bad[0, 0] = np.inf
     with pytest.raises(RuntimeError):
         bs.update(x_u=bad)
+
+
+@pytest.mark.parametrize("reuse", [0, 1])
+def test_batch_update_matrices_equals_single_qp_update(hip, reuse):
+    """pq_batch_update_data: new P / A values (same patterns) and vectors for every instance -- unscale, assign and a fresh (or reused) Ruiz
+    equilibration per instance on the device (solver.hpp:218-308, sparse/preconditioner.hpp:65-258).  The single-QP SparseSolver::update runs
+    the same kernels on one instance, so iteration counts must agree exactly and the solutions to rounding."""
+    B = 6
+    mb = mpc_batch(B, T=12, nx=3, nu=2, seed=91)
+    bs = hip.BatchSparseSolver()
+    bs.settings.preconditioner_reuse_on_update = reuse
+    assert bs.setup(mb["P_pattern"], mb["P_values"], mb["c"], mb["A_pattern"], mb["A_values"], mb["b"], x_l=mb["x_l"], x_u=mb["x_u"])
+    assert bs.solve() == B
+    rng = np.random.default_rng(17)
+    P2 = mb["P_values"] * (1.0 + 0.5 * rng.random(mb["P_values"].shape))      # diagonal-dominant cost stays convex
+    A2 = mb["A_values"] * (1.0 + 0.02 * rng.standard_normal(mb["A_values"].shape))
+    c2 = mb["c"] + 0.1 * rng.standard_normal(mb["c"].shape)
+    xu2 = mb["x_u"] * 1.2
+    assert bs.update_data(P_values=P2, A_values=A2, c=c2, x_u=xu2)
+    assert bs.solve() == B
+    x, y = bs.result("x"), bs.result("y")
+    Pp, Ap = mb["P_pattern"].tocsc(), mb["A_pattern"].tocsc()
+    Pp.sort_indices(); Ap.sort_indices()
+    import scipy.sparse as sp
+    for i in range(B):
+        s = hip.SparseSolver(); s.settings.kkt_solver = hip.SPARSE_MULTISTAGE
+        s.settings.preconditioner_reuse_on_update = reuse
+        assert s.setup(*mpc_instance(mb, i))
+        assert s.solve() == 1
+        Pi = sp.csc_matrix((P2[i], Pp.indices, Pp.indptr), shape=Pp.shape)
+        Ai = sp.csc_matrix((A2[i], Ap.indices, Ap.indptr), shape=Ap.shape)
+        assert s.update(P=Pi, A=Ai, c=c2[i], x_u=xu2[i])
+        assert s.solve() == 1
+        assert s.info.iter == bs.info(i).iter, (i, s.info.iter, bs.info(i).iter)
+        assert np.abs(s.result()["x"] - x[i]).max() <= 1e-8 * (1 + np.abs(x[i]).max())
+        assert np.abs(s.result()["y"] - y[i]).max() <= 1e-7 * (1 + np.abs(y[i]).max())
+    # and the matrices really changed the problem
+    bs0 = hip.BatchSparseSolver()
+    assert bs0.setup(mb["P_pattern"], mb["P_values"], mb["c"], mb["A_pattern"], mb["A_values"], mb["b"], x_l=mb["x_l"], x_u=mb["x_u"])
+    assert bs0.solve() == B
+    assert np.abs(bs0.result("x") - x).max() > 1e-3
