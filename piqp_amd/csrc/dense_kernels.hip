@@ -528,7 +528,7 @@ __device__ __forceinline__ void stage_lower_block(const double* __restrict__ A, 
 __device__ __forceinline__ int tb_index(int bi, int bj) { return bi * (bi + 1) / 2 + bj; }
 constexpr int TB_BLOCKS = 36;
 constexpr int TB_DOUBLES = TB_BLOCKS * 256;
-constexpr int POTRF_LDS_BYTES = (TB_DOUBLES + 64) * (int)sizeof(double);
+constexpr int POTRF_LDS_BYTES = (TB_DOUBLES + 8 * 32) * (int)sizeof(double);  // tile blocks + the pivots of the eight steps
 
 __device__ __forceinline__ d4 tile_load(const double* __restrict__ blk, int lane)
 {
@@ -539,6 +539,14 @@ __device__ __forceinline__ void tile_store(double* __restrict__ blk, int lane, d
 {
     double* p = blk + (lane >> 4) * 16 + (lane & 15);
     p[0] = t[0]; p[64] = t[1]; p[128] = t[2]; p[192] = t[3];
+}
+
+// LDS hand-over between the lanes of ONE wave (its LDS instructions execute in order; this keeps the compiler from reordering them)
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 // 1/sqrt(d) to ~1 ulp without the IEEE sqrt + divide chains (two Newton steps on v_rsq_f64)
@@ -571,41 +579,104 @@ __device__ __forceinline__ double rcp_newton(double d)
 // lane into the block's own LDS tile, their reciprocal pivots into rpub, then *prog = base + c + 1, so that the waves solving the panel below
 // (tile_trsm_rt_follow) run four columns behind this factorisation instead of starting after it.  (Publishing every column -- masked stores and a
 // fence per pivot, seven waves polling -- doubled the time of this routine: 4800 -> 10 500 cycles.)
-template <bool LDLT>
-__device__ __forceinline__ int factor16_tile(d4& t, int lane, double& rd, double& dd, volatile double* Dpub, volatile double* rpub, volatile int* prog, int base)
+// The progress word and the published columns live in LDS.  Through generic `volatile` pointers the compiler emitted FLAT stores / loads with
+// sc0 sc1 and a vmcnt(0) drain per publication (~250 cycles per pivot, measured); explicit LDS pointers make them ds_write / ds_read.
+typedef __attribute__((address_space(3))) volatile double lds_vdouble;
+typedef __attribute__((address_space(3))) volatile int lds_vint;
+// Index permutation of the in-register factorisation: the 4 x 4 transpose of a 4-bit index (an involution).  The matrix core fixes which four
+// column indices a lane holds (g, g + 4, g + 8, g + 12); relabelling rows AND columns by pi makes those the CONSECUTIVE logical columns
+// 4 g .. 4 g + 3, so that the next pivot column usually lives in the same lanes as the current one.
+__device__ __forceinline__ constexpr int pi16(int x) { return (x >> 2) + 4 * (x & 3); }
+// 16 x 16 block image in LDS (column-major) <-> the permuted tile: lane (ip, g) register r holds logical element [pi(ip)][4 g + r]
+__device__ __forceinline__ d4 tile_load_perm(const double* __restrict__ blk, int lane)
 {
-    const int i = lane & 15, g = lane >> 4;
+    const double* p = blk + (lane >> 4) * 64 + pi16(lane & 15);
+    return (d4){p[0], p[16], p[32], p[48]};
+}
+__device__ __forceinline__ void tile_store_perm(double* __restrict__ blk, int lane, d4 t)
+{
+    double* p = blk + (lane >> 4) * 64 + pi16(lane & 15);
+    p[0] = t[0]; p[16] = t[1]; p[32] = t[2]; p[48] = t[3];
+}
+
+// In-register factorisation of one 16 x 16 diagonal piece by one wave: t in the PERMUTED tile form above, replaced by the factor (LDLT: D on
+// the diagonal).  Published to LDS for the waves that follow (tile_trsm_rt_follow): after every fourth column the four finished columns (natural
+// block image at Dpub), their reciprocal pivots rpub[0, 16) (and the pivots D at rpub[16, 32), LDLT), then the progress word.
+// One wave, in-order issue: every instruction of the pivot loop is on the clock (tools/ub/factor16.hip: 289 cycles per pivot for the first
+// tile-form version, ~100 of them waiting for the matrix core).  What keeps the loop short:
+//  * the NEGATED tile s = -T is carried and columns are scaled by +1 / l, so the rank-1 update is s += (-l)(-l)^T without operand negation;
+//  * the factor is collected in a second tile (Lo -= column, zero elsewhere) instead of being selected into the working tile: with the diagonal
+//    row inside the update operand the matrix core overwrites only entries nobody reads again;
+//  * the NEXT pivot column is updated on the vector ALU (one FMA with a lane-read scalar) from the matrix core's result of the PREVIOUS update,
+//    so the dependent chain column -> reciprocal square root -> scaled column -> next column never waits for the update in flight; only at the
+//    three crossings into another lane group (columns 4, 8, 12) is the column taken from the matrix core.  The FMA reproduces the matrix core's
+//    value bit for bit (one fused product per k-slice, the other three slices exact zeros: checked by tools/ub/factor16.hip);
+//  * pivots / reciprocals stay in uniform registers and go to LDS once per four columns.
+// A non-positive (LDLT: zero) pivot is recorded off the chain and NOT replaced: the rest of a failed block is NaN / Inf, which nobody reads
+// (dense/kkt.hpp:83 reports the failure, the caller regularises and factors again).
+template <bool LDLT>
+__device__ __forceinline__ int factor16_tile(d4& t, int lane, volatile double* Dpub_g, volatile double* rpub_g, volatile int* prog_g, int base)
+{
+    lds_vdouble* Dpub = (lds_vdouble*)Dpub_g;
+    lds_vdouble* rpub = (lds_vdouble*)rpub_g;
+    lds_vint* prog = (lds_vint*)prog_g;
+    const int ip = lane & 15, g = lane >> 4, il = pi16(ip);  // physical lane row, lane group, logical row
     int failed = -1;
-    rd = 0.0; dd = 0.0;
+    d4 s = {-t[0], -t[1], -t[2], -t[3]};
+    d4 Lo = {0.0, 0.0, 0.0, 0.0};
+    double col = s[0];                      // (negated) current pivot column in the lanes of its group, all updates applied
+    double dk = -readlane_d(col, 0);
+    double rq[4], dq[4];
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
-        const int g0 = c & 3, r0 = c >> 2;
-        double dk = readlane_d(t[r0], 16 * g0 + c);
-        const bool incol = (g == g0), below = incol && (i > c);
-        double r;
+        const int gc = c >> 2, rc = c & 3;
+        const bool incol = (g == gc);
+        const int c1 = (c + 1) & 15, gn = c1 >> 2, rn = c1 & 3;
+        const int src1 = 16 * gc + pi16(c1);  // lane of this column's entry in row c + 1
+        double r, lneg, yneg = 0.0;
         if (!LDLT) {
-            if (!(dk > 0.0)) { if (failed < 0) failed = c; dk = 1.0; }
+            if (!(dk > 0.0) && failed < 0) failed = c;
             r = rsqrt_newton(dk);  // 1 / l
-            const double lcol = below ? t[r0] * r : 0.0;
-            t[r0] = incol ? ((i == c) ? dk * r : lcol) : t[r0];
-            if (c < 15) t = __builtin_amdgcn_mfma_f64_16x16x4f64(lcol, -lcol, t, 0, 0, 0);
+            lneg = (incol && il >= c) ? col * r : 0.0;  // -(column c of L), diagonal included: s_cc r = -d r = -l_cc
+            Lo[rc] -= lneg;
         } else {
-            if (dk == 0.0) { if (failed < 0) failed = c; dk = 1.0; }
+            if (dk == 0.0 && failed < 0) failed = c;
             r = rcp_newton(dk);    // 1 / d
-            const double ycol = below ? t[r0] : 0.0;
-            const double lcol = ycol * r;
-            t[r0] = incol ? ((i == c) ? dk : lcol) : t[r0];
-            if (c < 15) t = __builtin_amdgcn_mfma_f64_16x16x4f64(lcol, -ycol, t, 0, 0, 0);
+            yneg = (incol && il > c) ? col : 0.0;       // -(column c of L D)
+            lneg = yneg * r;                            // -(column c of L)
+            Lo[rc] = (incol && il == c) ? dk : Lo[rc] - lneg;
         }
-        if (lane == c) { rd = r; dd = dk; }
-        if ((c & 3) == 3) {
-            // columns 4 r0 .. 4 r0 + 3 are final and register r0 is not touched by the remaining updates (their operands are zero at p <= c)
-            Dpub[(g + 4 * r0) * 16 + i] = t[r0];
-            if (lane < 16 && (lane >> 2) == r0) rpub[lane] = rd;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // (a wave's LDS instructions execute in order anyway)
+        rq[rc] = r; dq[rc] = dk;
+        if (c < 15) {
+            const double l1 = readlane_d(lneg, src1);
+            if (rn != 0) {
+                // column c + 1 sits in the same lanes: s[rn] carries the updates < c (matrix core, issued a whole pivot ago), update c by FMA
+                col = LDLT ? __builtin_fma(yneg, l1, s[rn]) : __builtin_fma(lneg, l1, s[rn]);
+                s = LDLT ? __builtin_amdgcn_mfma_f64_16x16x4f64(lneg, yneg, s, 0, 0, 0) : __builtin_amdgcn_mfma_f64_16x16x4f64(lneg, lneg, s, 0, 0, 0);
+            } else {
+                s = LDLT ? __builtin_amdgcn_mfma_f64_16x16x4f64(lneg, yneg, s, 0, 0, 0) : __builtin_amdgcn_mfma_f64_16x16x4f64(lneg, lneg, s, 0, 0, 0);
+                col = s[0];  // next lane group: the one place the chain waits for the matrix core
+            }
+            dk = -readlane_d(col, 16 * gn + pi16(c1));
+        }
+        if (rc == 3) {
+            // logical columns 4 gc .. 4 gc + 3 are final: the lanes of group gc hold them in their four registers.  No s_waitcnt between the
+            // data and the progress word: the LDS executes one wave's instructions in order (a release fence here costs ~350 cycles per
+            // publication, measured); the asm statements only pin the compiler's order.
+            if (incol) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) Dpub[(4 * gc + q) * 16 + il] = Lo[q];
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { rpub[4 * gc + q] = rq[q]; if (LDLT) rpub[16 + 4 * gc + q] = dq[q]; }
+            }
+            asm volatile("" ::: "memory");
             if (lane == 0) *prog = base + c + 1;
+            asm volatile("" ::: "memory");
         }
     }
+    t = Lo;
     return failed;
 }
 
@@ -634,8 +705,11 @@ __device__ __forceinline__ void tile_trsm_rt(d4& x, const d4& L, const d4& rdc, 
 // = four columns of L and their reciprocal pivots in LDS, then *prog): the rank-1 updates of those columns are issued as soon as they exist, so the
 // panel is solved about one register's worth of work after the diagonal piece is factored instead of ~3000 cycles.
 template <bool LDLT>
-__device__ __forceinline__ void tile_trsm_rt_follow(d4& x, const volatile double* Lpub, const volatile double* rpub, const volatile int* prog, int base, int lane)
+__device__ __forceinline__ void tile_trsm_rt_follow(d4& x, const volatile double* Lpub_g, const volatile double* rpub_g, const volatile int* prog_g, int base, int lane)
 {
+    const lds_vdouble* Lpub = (const lds_vdouble*)Lpub_g;
+    const lds_vdouble* rpub = (const lds_vdouble*)rpub_g;
+    const lds_vint* prog = (const lds_vint*)prog_g;
     const int i = lane & 15, g = lane >> 4;
 #pragma unroll
     for (int r0 = 0; r0 < 4; ++r0) {
@@ -656,18 +730,36 @@ __device__ __forceinline__ void tile_trsm_rt_follow(d4& x, const volatile double
     for (int r = 0; r < 4; ++r) x[r] *= rpub[g + 4 * r];
 }
 
-// Factorisation of a diagonal block of order nb <= 128 held in LDS (tile blocks Tb, identity-padded beyond nb).  Waves 0..7 own one
-// 16-row block row each; every other wave of the workgroup only takes part in the barriers.  Step k (16 columns):
-//   wave k      factors its diagonal piece in registers (factor16_tile), publishing every finished column in LDS;
-//   waves w > k solve their 16 x 16 piece of the panel against L_kk one column behind it (tile_trsm_rt_follow)              | barrier
-//   waves w > k update the tiles (w, k+1..w) of their block row: T -= X_w (D) X_c^T, nearest column first, so wave k + 1 walks
-//               straight from its last update into the factorisation of step k + 1;
-//   wave k      meanwhile inverts L_kk -- off the critical path, its block row is finished -- for the panel kernel below.
+// Factorisation of a diagonal block of order nb <= 128 held in LDS (tile blocks Tb, identity-padded beyond nb).  Waves 0..7 own one 16-row
+// block row each and run it as a dataflow program -- there is NO workgroup barrier between the steps; the waves meet through two kinds of
+// monotonic LDS words (one wave's LDS instructions execute in order, so a word written after the data is seen after the data):
+//   prog      columns of the block factored so far (factor16_tile, every fourth column);
+//   xdone[w]  steps whose panel piece X_w = tile (w, k) wave w has solved and stored.
+// Wave w, for k = 0 .. w - 1:
+//   solves its piece of panel k against L_kk four columns behind wave k's factorisation (tile_trsm_rt_follow), stores it, bumps xdone[w];
+//   updates the tiles (w, c), k < c < w, of its block row as X_c arrives: T -= X_w (D) X_c^T;
+//   updates its own diagonal tile (w, w), which lives in REGISTERS in the permuted form factor16_tile wants (operands re-read from the
+//   stored X_w with permuted rows), from its first update to its factorisation: the critical wave k + 1 goes from the last column of L_kk
+//   through one 16 x 16 substitution tail and four matrix-core products straight into the factorisation of step k + 1;
+// then, as step w: factors its diagonal piece, publishing as it goes; writes pivots, the inverse of L_ww (for the panel kernel and the
+// triangular sweeps) and block row w of the factor while the later waves carry on.
+// The wave that shares a SIMD with the factoring wave (w = k + 4, waves are dealt round-robin to the four SIMDs) does not follow column by
+// column: every matrix-core instruction of a SIMD partner sits between the pivots of the critical wave (measured: 5 700 instead of 4 400
+// cycles per 16 columns); it solves its piece when the whole of L_kk is there.  (Pausing the partner for the whole step, updates included,
+// makes the factorisation steps uniform -- 4 550 cycles -- but the paused waves then arrive late at their own steps: 63 500 cycles per
+// block instead of 57 000.)
 // Outputs: the factor (lower triangle) to Aout, reciprocal pivots to rdiag[kglobal..], D to dvec (LDLT, nullable), and `pack`
 // (nullable): the operand pack of k_trsm_panel -- 28 strictly-lower blocks of -L at j (j - 1) / 2 + k, then the 8 inverted
 // diagonal pieces W_jj, all as column-major 16 x 16 blocks; `w16` (nullable): the same eight W_jj once more, into the array that holds them
-// for ALL diagonal pieces of the factor (the sweeps of launch_trsv multiply by them).
+// for ALL diagonal pieces of the factor (the sweeps of launch_trsv multiply by them).  rds: 8 x 32 doubles of LDS (pivots of every step).
 constexpr int PACK_BLOCKS = 36;
+constexpr int POTRF_RDS_DOUBLES = 8 * 32;
+// block image (column-major 16 x 16) -> tile registers with the ROWS permuted: lane (ip, g) register r holds [pi(ip)][g + 4 r]
+__device__ __forceinline__ d4 tile_load_rowperm(const double* __restrict__ blk, int lane)
+{
+    const double* p = blk + (lane >> 4) * 16 + pi16(lane & 15);
+    return (d4){p[0], p[64], p[128], p[192]};
+}
 template <bool LDLT, int NWAVES>
 __device__ __forceinline__ void potrf_block(double* __restrict__ Tb, double* __restrict__ rds, int nb, int kglobal, int* __restrict__ info, double* __restrict__ rdiag,
                             double* __restrict__ dvec, double* __restrict__ Aout, int lda, double* __restrict__ pack, double* __restrict__ w16,
@@ -678,77 +770,89 @@ __device__ __forceinline__ void potrf_block(double* __restrict__ Tb, double* __r
     auto stamp = [&](int k, int q) { if (ts && (threadIdx.x & 63) == 0) ts[8 * k + q] = clock64(); };
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, g = lane >> 4;
-    __shared__ int prog;  // columns of the block factored so far (monotonic over the eight steps): the panel waves follow it
+    __shared__ int prog;      // columns of the block factored so far
+    __shared__ int xdone[8];  // per wave: panel pieces solved and stored so far
     if (tid == 0) prog = 0;
+    if (tid < 8) xdone[tid] = 0;
     __syncthreads();
+    lds_vint* progp = (lds_vint*)&prog;
+    lds_vint* xd = (lds_vint*)xdone;
+    if (wave < 8) {
+        const int w = wave;
+        double* Dww = Tb + tb_index(w, w) * 256;
+        d4 dperm = tile_load_perm(Dww, lane);  // own diagonal tile: in registers until it is factored
 #pragma unroll 1
-    for (int k = 0; k < 8; ++k) {
-        double* Dkk = Tb + tb_index(k, k) * 256;
-        double* rbuf = rds + (k & 1) * 32;  // reciprocal pivots [0, 16) and D [16, 32) of this step; double-buffered: wave k still reads them
-        double* dvs = rbuf + 16;            // (inversion) while wave k + 1 writes the next step's
-        d4 lkk = {0.0, 0.0, 0.0, 0.0};
-        double rd = 0.0, dmine = 0.0;
-        if (wave == k) {
-            stamp(k, 0);
-            lkk = tile_load(Dkk, lane);
-            __builtin_amdgcn_s_setprio(3);  // the critical wave: issue priority over the follower that shares its SIMD
-            const int failed = factor16_tile<LDLT>(lkk, lane, rd, dmine, Dkk, rbuf, &prog, 16 * k);
-            __builtin_amdgcn_s_setprio(0);
-            tile_store(Dkk, lane, lkk);
-            if (lane < 16) {
-                rbuf[lane] = rd;
-                if (LDLT) dvs[lane] = dmine;
-            }
-            if (failed >= 0 && lane == 0 && 16 * k + failed < nb) { if (*info < 0) *info = kglobal + 16 * k + failed; }
-            stamp(k, 1);
-        } else if (wave > k && wave < 8) {
-            // no barrier between the factorisation and the panel: these waves follow wave k column by column
-            if (wave == k + 1) stamp(k, 2);
-            double* Xwk = Tb + tb_index(wave, k) * 256;
+        for (int k = 0; k < w; ++k) {
+            double* Dkk = Tb + tb_index(k, k) * 256;
+            double* rbuf = rds + k * 32;  // reciprocal pivots [0, 16) and D [16, 32) of step k
+            const double* dvs = rbuf + 16;
+            double* Xwk = Tb + tb_index(w, k) * 256;
+            if (w == k + 1) stamp(k, 2);
             d4 x = tile_load(Xwk, lane);
+            if (w == k + 4) { while (*progp < 16 * k + 16) __builtin_amdgcn_s_sleep(8); }
             tile_trsm_rt_follow<LDLT>(x, Dkk, rbuf, &prog, 16 * k, lane);
             tile_store(Xwk, lane, x);
-            if (wave == k + 1) stamp(k, 3);
-        }
-        __syncthreads();
-        if (wave > k && wave < 8) {
-            if (wave == k + 1) stamp(k, 4);
-            const d4 xw = tile_load(Tb + tb_index(wave, k) * 256, lane);
-            const d4 nxw = {-xw[0], -xw[1], -xw[2], -xw[3]};
+            asm volatile("" ::: "memory");
+            if (lane == 0) xd[w] = k + 1;
+            asm volatile("" ::: "memory");
+            if (w == k + 1) { stamp(k, 3); stamp(k, 4); }
+            const d4 nxw = {-x[0], -x[1], -x[2], -x[3]};
             d4 dsc = {1.0, 1.0, 1.0, 1.0};  // LDLT: D of the operand columns this lane feeds to the update products
             if (LDLT) dsc = (d4){dvs[g], dvs[g + 4], dvs[g + 8], dvs[g + 12]};
-            for (int c = k + 1; c <= wave; ++c) {
-                d4 xc = tile_load(Tb + tb_index(c, k) * 256, lane);
-                if (LDLT) xc *= dsc;
-                double* Tw = Tb + tb_index(wave, c) * 256;
-                d4 t = tile_load(Tw, lane);
+            // own diagonal tile first (for wave k + 1 it is the only one): operands = the stored X_w with permuted rows
+            {
+                const d4 xp = tile_load_rowperm(Xwk, lane);
+                const d4 nxp = {-xp[0], -xp[1], -xp[2], -xp[3]};
+                d4 xcp = xp;
+                if (LDLT) xcp *= dsc;
                 // one accumulator, k ascending: the summation order every parity test was pinned with (four independent products summed afterwards
                 // save ~200 cycles per step and moved two threshold-sitting iteration counts by one: mm_QAFIRO 13 -> 12, mm_CONT-201 12 -> 13)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) dperm = __builtin_amdgcn_mfma_f64_16x16x4f64(xcp[ks], nxp[ks], dperm, 0, 0, 0);
+            }
+            for (int c = k + 1; c < w; ++c) {
+                while (xd[c] < k + 1) __builtin_amdgcn_s_sleep(2);
+                d4 xc = tile_load(Tb + tb_index(c, k) * 256, lane);
+                if (LDLT) xc *= dsc;
+                double* Tw = Tb + tb_index(w, c) * 256;
+                d4 t = tile_load(Tw, lane);
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) t = __builtin_amdgcn_mfma_f64_16x16x4f64(xc[ks], nxw[ks], t, 0, 0, 0);
                 tile_store(Tw, lane, t);
             }
-            if (wave == k + 1) stamp(k, 5);
-        } else if (wave == k) {
-            // the block row of wave k is finished: pivots out, and the inverse of L_kk for the panel kernel -- behind the second barrier, so
-            // that nobody waits for it (the next barrier is reached by wave k + 1 only after its own 16 x 16 factorisation).
+            if (w == k + 1) stamp(k, 5);
+        }
+        // ---- step w: the own diagonal piece ----
+        {
+            const int k = w;
+            double* rbuf = rds + k * 32;
+            const double* dvs = rbuf + 16;
+            stamp(k, 0);
+            __builtin_amdgcn_s_setprio(3);  // the critical wave
+            const int failed = factor16_tile<LDLT>(dperm, lane, Dww, rbuf, &prog, 16 * k);  // (fills Dww, rbuf and, LDLT, dvs)
+            __builtin_amdgcn_s_setprio(0);
+            if (failed >= 0 && lane == 0 && 16 * k + failed < nb) { if (*info < 0) *info = kglobal + 16 * k + failed; }
+            stamp(k, 1);
+            asm volatile("" ::: "memory");
+            // block row k is finished: pivots out, and the inverse of L_kk for the panel kernel / the sweeps -- nobody waits for it.
             // W^T = I L^-T by the same rank-1 substitution, then one product with the identity transposes it: W = I (W^T)^T.
             if (lane < 16 && 16 * k + lane < nb) {
-                rdiag[kglobal + 16 * k + lane] = rd;
-                if (LDLT && dvec) dvec[16 * k + lane] = dmine;
+                rdiag[kglobal + 16 * k + lane] = rbuf[lane];
+                if (LDLT && dvec) dvec[16 * k + lane] = dvs[lane];
             }
             if (pack || w16) {
+                const d4 lkk = tile_load(Dww, lane);  // the factored piece in the natural tile form
                 d4 eye;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) eye[r] = (i == g + 4 * r) ? 1.0 : 0.0;
                 d4 z = eye;
                 const d4 rdc = {rbuf[g], rbuf[g + 4], rbuf[g + 8], rbuf[g + 12]};
                 tile_trsm_rt<LDLT, false>(z, lkk, rdc, lane);
-                d4 w = {0.0, 0.0, 0.0, 0.0};
+                d4 wv = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) w = __builtin_amdgcn_mfma_f64_16x16x4f64(z[ks], eye[ks], w, 0, 0, 0);
-                if (pack) tile_store(pack + (28 + k) * 256, lane, w);
-                if (w16) tile_store(w16 + k * 256, lane, w);  // kept for the triangular sweeps (launch_trsv)
+                for (int ks = 0; ks < 4; ++ks) wv = __builtin_amdgcn_mfma_f64_16x16x4f64(z[ks], eye[ks], wv, 0, 0, 0);
+                if (pack) tile_store(pack + (28 + k) * 256, lane, wv);
+                if (w16) tile_store(w16 + k * 256, lane, wv);  // kept for the triangular sweeps (launch_trsv)
             }
             // ... and block row k of the factor goes to HBM now (its blocks (k, 0..k) are final and only READ from here on), so that no
             // store tail is left at the end: 128-byte segments; the negated strictly-lower blocks are the rest of the panel kernel's pack
@@ -765,6 +869,7 @@ __device__ __forceinline__ void potrf_block(double* __restrict__ Tb, double* __r
             stamp(k, 6);
         }
     }
+    __syncthreads();
 }
 
 constexpr int POTRF_THREADS = 512;
