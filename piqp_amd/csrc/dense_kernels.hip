@@ -131,7 +131,7 @@ __device__ __forceinline__ void scale_tile(const double* __restrict__ w, int k0,
 template <bool LDLT, int NWAVES>
 __device__ __forceinline__ void potrf_block(double* __restrict__ Tb, double* __restrict__ rds, int nb, int kglobal, int* __restrict__ info, double* __restrict__ rdiag,
                                             double* __restrict__ dvec, double* __restrict__ Aout, int lda, double* __restrict__ pack, double* __restrict__ w16,
-                                            long long* __restrict__ ts = nullptr);
+                                            long long* __restrict__ ts = nullptr, int* __restrict__ cnt = nullptr);
 __device__ __forceinline__ int tb_index(int bi, int bj);
 __device__ __forceinline__ void st_agent(double* p, double v);
 __device__ __forceinline__ double ld_agent(const double* p);
@@ -139,6 +139,8 @@ __device__ __forceinline__ void tile_store(double* __restrict__ blk, int lane, d
 constexpr int FUSE_ROLES = 9, FUSE_OWN = 4;  // workgroups that share the next diagonal block of a fused trailing update (owner + 8 helpers), blocks per workgroup
 template <int NT>
 __device__ __forceinline__ void fused_next_diag(const SyrkArgs& a, double* __restrict__ smem, int role);
+template <int NT, int MTC, int MTR>
+__device__ __forceinline__ void panel_follow(const SyrkArgs& a, double* __restrict__ smem, const d4 (&acc)[MTC][MTR], int row0, int wr, int wc);
 // the fused next-panel factorisation: its workgroups stage a whole 128 x 128 operand panel (147 KB: one workgroup per CU, which the kernel's
 // 147 VGPRs impose anyway); the 36 tile blocks + 64 doubles of pivots reuse that LDS afterwards
 constexpr int FUSED_LDS_BYTES = (128 * (128 + 16) + 128) * 8;  // whole operand panel of the next diagonal block + D; the tile blocks reuse it
@@ -170,7 +172,18 @@ __global__ __launch_bounds__(64 * WR * WC, (WR * WC == 4) ? 2 : (WR * WC == 8 ? 
     const int b = a.tile_begin + bid / a.k_split;
     const int kslice = bid % a.k_split;
     int ti, tj;
-    if (a.tile_order) {
+    if (EPI == EPI_SUBTRACT_POTRF) {
+        // the first tile column (= the next panel below its diagonal block) goes first: its workgroups also solve that panel (panel_follow)
+        const int T = (a.n + TS - 1) / TS;
+        if (b <= T - 1) { ti = b; tj = 0; }
+        else {
+            const int bb = b - T;  // lower triangle of the (T - 1) x (T - 1) rest
+            int t2 = (int)((sqrt(8.0 * (double)bb + 1.0) - 1.0) * 0.5);
+            while ((t2 + 1) * (t2 + 2) / 2 <= bb) ++t2;
+            while (t2 * (t2 + 1) / 2 > bb) --t2;
+            ti = t2 + 1; tj = bb - t2 * (t2 + 1) / 2 + 1;
+        }
+    } else if (a.tile_order) {
         const int pk = a.tile_order[b];
         ti = pk >> 16; tj = pk & 0xffff;
     } else {
@@ -259,6 +272,9 @@ __global__ __launch_bounds__(64 * WR * WC, (WR * WC == 4) ? 2 : (WR * WC == 8 ? 
         __syncthreads();
     }
 
+    if constexpr (EPI == EPI_SUBTRACT_POTRF) {
+        if (a.fuse_cnt && tj == 0 && a.fuse_pack) { panel_follow<NT, MTC, MTR>(a, smem, acc, row0, wr, wc); return; }
+    }
     if (skip_wave) return;
     if (a.part) {
         // split launch: raw partial tile (column-major 128 x 128) for k_syrk_tail_reduce; fixed slot per (tile, slice)
@@ -713,7 +729,7 @@ __device__ __forceinline__ void tile_trsm_rt_follow(d4& x, const volatile double
     const int i = lane & 15, g = lane >> 4;
 #pragma unroll
     for (int r0 = 0; r0 < 4; ++r0) {
-        while (*prog < base + 4 * r0 + 4) __builtin_amdgcn_s_sleep(2);  // ~128 cycles between polls: the factoring wave shares a SIMD with one of us
+        while (*prog < base + 4 * r0 + 4) __builtin_amdgcn_s_sleep(2);  // ~128 cycles between polls
         const double l = Lpub[(g + 4 * r0) * 16 + i];   // register r0 of L in tile form: column 4 r0 + g
         const double rc = LDLT ? 1.0 : rpub[g + 4 * r0];
         const double nls = -(l * rc);
@@ -752,6 +768,10 @@ __device__ __forceinline__ void tile_trsm_rt_follow(d4& x, const volatile double
 // (nullable): the operand pack of k_trsm_panel -- 28 strictly-lower blocks of -L at j (j - 1) / 2 + k, then the 8 inverted
 // diagonal pieces W_jj, all as column-major 16 x 16 blocks; `w16` (nullable): the same eight W_jj once more, into the array that holds them
 // for ALL diagonal pieces of the factor (the sweeps of launch_trsv multiply by them).  rds: 8 x 32 doubles of LDS (pivots of every step).
+// The pack goes to HBM AS THE STEPS COMPLETE (write-through stores): -L(w, k) by wave w right after its substitution of step k, W_kk and the
+// pivots by wave k after its inversion.  cnt (nullable): eight agent-scope counters, cnt[k] += 1 per wave once its part of step k is
+// in L2 (8 - k increments per call) -- the panel workgroups of the same launch (panel_follow) run step k of THEIR substitution when it
+// reaches call-count x (8 - k).  The increments trail the stores by a step so that no wave waits for its own write-through.
 constexpr int PACK_BLOCKS = 36;
 constexpr int POTRF_RDS_DOUBLES = 8 * 32;
 // block image (column-major 16 x 16) -> tile registers with the ROWS permuted: lane (ip, g) register r holds [pi(ip)][g + 4 r]
@@ -763,7 +783,7 @@ __device__ __forceinline__ d4 tile_load_rowperm(const double* __restrict__ blk, 
 template <bool LDLT, int NWAVES>
 __device__ __forceinline__ void potrf_block(double* __restrict__ Tb, double* __restrict__ rds, int nb, int kglobal, int* __restrict__ info, double* __restrict__ rdiag,
                             double* __restrict__ dvec, double* __restrict__ Aout, int lda, double* __restrict__ pack, double* __restrict__ w16,
-                            long long* __restrict__ ts)
+                            long long* __restrict__ ts, int* __restrict__ cnt)
 {
     // ts (debugging aid, nullptr in production): shader-clock stamps of step k at ts[8 k + q] -- q = 0 / 1 wave k before / after its 16 x 16
     // factorisation, 2 / 3 wave k + 1 before / after its substitution, 4 / 5 wave k + 1 before / after its tile updates, 6 wave k after the inversion
@@ -781,8 +801,17 @@ __device__ __forceinline__ void potrf_block(double* __restrict__ Tb, double* __r
         const int w = wave;
         double* Dww = Tb + tb_index(w, w) * 256;
         d4 dperm = tile_load_perm(Dww, lane);  // own diagonal tile: in registers until it is factored
+        int pending = -1;  // step whose pack stores this wave has not signalled yet
+        auto signal_pending = [&]() {
+            if (cnt && pending >= 0) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) __hip_atomic_fetch_add(cnt + pending, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            pending = -1;
+        };
 #pragma unroll 1
         for (int k = 0; k < w; ++k) {
+            signal_pending();  // (step k - 1: stored a whole step ago)
             double* Dkk = Tb + tb_index(k, k) * 256;
             double* rbuf = rds + k * 32;  // reciprocal pivots [0, 16) and D [16, 32) of step k
             const double* dvs = rbuf + 16;
@@ -797,6 +826,12 @@ __device__ __forceinline__ void potrf_block(double* __restrict__ Tb, double* __r
             asm volatile("" ::: "memory");
             if (w == k + 1) { stamp(k, 3); stamp(k, 4); }
             const d4 nxw = {-x[0], -x[1], -x[2], -x[3]};
+            if (pack) {
+                double* pb = pack + (size_t)(w * (w - 1) / 2 + k) * 256 + g * 16 + i;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) st_agent(pb + 64 * r, nxw[r]);
+            }
+            pending = k;
             d4 dsc = {1.0, 1.0, 1.0, 1.0};  // LDLT: D of the operand columns this lane feeds to the update products
             if (LDLT) dsc = (d4){dvs[g], dvs[g + 4], dvs[g + 8], dvs[g + 12]};
             // own diagonal tile first (for wave k + 1 it is the only one): operands = the stored X_w with permuted rows
@@ -822,6 +857,8 @@ __device__ __forceinline__ void potrf_block(double* __restrict__ Tb, double* __r
             }
             if (w == k + 1) stamp(k, 5);
         }
+        // the last wave lets the panel workgroups have its part of step 6 before it factors step 7 (nothing is left to hide the wait behind)
+        if (w == 7) signal_pending();
         // ---- step w: the own diagonal piece ----
         {
             const int k = w;
@@ -837,7 +874,7 @@ __device__ __forceinline__ void potrf_block(double* __restrict__ Tb, double* __r
             // block row k is finished: pivots out, and the inverse of L_kk for the panel kernel / the sweeps -- nobody waits for it.
             // W^T = I L^-T by the same rank-1 substitution, then one product with the identity transposes it: W = I (W^T)^T.
             if (lane < 16 && 16 * k + lane < nb) {
-                rdiag[kglobal + 16 * k + lane] = rbuf[lane];
+                st_agent(rdiag + kglobal + 16 * k + lane, rbuf[lane]);
                 if (LDLT && dvec) dvec[16 * k + lane] = dvs[lane];
             }
             if (pack || w16) {
@@ -851,11 +888,23 @@ __device__ __forceinline__ void potrf_block(double* __restrict__ Tb, double* __r
                 d4 wv = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) wv = __builtin_amdgcn_mfma_f64_16x16x4f64(z[ks], eye[ks], wv, 0, 0, 0);
-                if (pack) tile_store(pack + (28 + k) * 256, lane, wv);
+                if (pack) {
+                    double* pb = pack + (size_t)(28 + k) * 256 + g * 16 + i;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) st_agent(pb + 64 * r, wv[r]);
+                }
                 if (w16) tile_store(w16 + k * 256, lane, wv);  // kept for the triangular sweeps (launch_trsv)
             }
+            if (cnt) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) {
+                    __hip_atomic_fetch_add(cnt + k, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (pending >= 0) __hip_atomic_fetch_add(cnt + pending, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                pending = -1;
+            }
             // ... and block row k of the factor goes to HBM now (its blocks (k, 0..k) are final and only READ from here on), so that no
-            // store tail is left at the end: 128-byte segments; the negated strictly-lower blocks are the rest of the panel kernel's pack
+            // store tail is left at the end: 128-byte segments
             for (int bj = 0; bj <= k; ++bj) {
                 const double* blk = Tb + tb_index(k, bj) * 256;
 #pragma unroll
@@ -863,7 +912,6 @@ __device__ __forceinline__ void potrf_block(double* __restrict__ Tb, double* __r
                     const int e = lane + 64 * q, r = 16 * k + (e & 15), c = 16 * bj + (e >> 4);
                     const double v = blk[e];
                     if (r < nb && c < nb && r >= c) Aout[(size_t)r + (size_t)c * lda] = v;
-                    if (pack && k > bj) pack[(k * (k - 1) / 2 + bj) * 256 + e] = -v;
                 }
             }
             stamp(k, 6);
@@ -1040,9 +1088,88 @@ __device__ __forceinline__ void fused_next_diag(const SyrkArgs& a, double* __res
     __syncthreads();
     if (dbg_ts) a.fuse_ts[2] = clock64();
     long long* pts = a.fuse_ts ? a.fuse_ts + 8 : nullptr;
-    if (a.fuse_ldlt) potrf_block<true, NW>(Tb, Tb + TB_DOUBLES, nbn, a.fuse_kglobal, a.fuse_info, a.fuse_rdiag, a.fuse_dvec, a.C, a.ldc, a.fuse_pack, a.fuse_w16, pts);
-    else potrf_block<false, NW>(Tb, Tb + TB_DOUBLES, nbn, a.fuse_kglobal, a.fuse_info, a.fuse_rdiag, a.fuse_dvec, a.C, a.ldc, a.fuse_pack, a.fuse_w16, pts);
+    if (a.fuse_ldlt) potrf_block<true, NW>(Tb, Tb + TB_DOUBLES, nbn, a.fuse_kglobal, a.fuse_info, a.fuse_rdiag, a.fuse_dvec, a.C, a.ldc, a.fuse_pack, a.fuse_w16, pts, a.fuse_cnt);
+    else potrf_block<false, NW>(Tb, Tb + TB_DOUBLES, nbn, a.fuse_kglobal, a.fuse_info, a.fuse_rdiag, a.fuse_dvec, a.C, a.ldc, a.fuse_pack, a.fuse_w16, pts, a.fuse_cnt);
     if (dbg_ts) a.fuse_ts[3] = clock64();
+}
+
+// The panel solve of the NEXT panel inside the fused trailing update: the workgroup of tile (ti, 0) has just updated the 128 rows of that panel
+// it owns.  Instead of writing them out for a k_trsm_panel launch it keeps them -- tiles through LDS into the row-strip form of k_trsm_panel, one
+// wave per 16 rows, eight 16 x 16 tiles in registers -- and runs the block substitution  X_k = T_k W_kk^T,  T_j -= X_k L_jk^T (j > k)  step by
+// step BEHIND the factorisation of the diagonal block, which workgroup 0 of this launch publishes step by step (potrf_block: pack + cnt).  The
+// panel is finished about one step after the diagonal block instead of one launch later (k_trsm_panel: 9.6 us + two launch boundaries).  Same
+// products in the same order as k_trsm_panel: bitwise the same panel.  Waits only target workgroups with lower block indices; bounded spins.
+template <int NT, int MTC, int MTR>
+__device__ __forceinline__ void panel_follow(const SyrkArgs& a, double* __restrict__ smem, const d4 (&acc)[MTC][MTR], int row0, int wr, int wc)
+{
+    static_assert(NT == 512 && MTR * 4 == 8 && MTC * 2 == 8, "eight waves, one 16-row strip each");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    double* Ts = smem;             // the tile as 8 x 8 block images (row block, column block)
+    double* Ps = smem + 64 * 256;  // operand blocks of the current step: W_kk, then -L(j, k) for j = k + 1 .. 7
+    __shared__ int ok_s;
+#pragma unroll
+    for (int x = 0; x < MTC; ++x)
+#pragma unroll
+        for (int y = 0; y < MTR; ++y) tile_store(Ts + ((wr * MTR + y) * 8 + (wc * MTC + x)) * 256, lane, acc[x][y]);
+    __syncthreads();
+    d4 T[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) T[j] = tile_load(Ts + (wave * 8 + j) * 256, lane);
+    const bool dbg = a.fuse_ts && tid == 0 && row0 == TS;  // debugging aid: stamps of the first panel workgroup at fuse_ts[72..]
+    if (dbg) a.fuse_ts[80] = clock64();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        if (tid == 0) {
+            const int want = a.fuse_token * (8 - k);
+            int ok = 1;
+            unsigned spins = 0;
+            while (__hip_atomic_load(a.fuse_cnt + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want < 0) {
+                __builtin_amdgcn_s_sleep(4);
+                if (++spins > 20000000u) { ok = 0; break; }
+            }
+            ok_s = ok;
+            if (dbg) a.fuse_ts[72 + k] = clock64();
+        }
+        __syncthreads();
+        if (!ok_s) {  // the diagonal block never arrived (cannot happen with a healthy device): report instead of hanging
+            if (tid == 0 && *a.fuse_info < 0) *a.fuse_info = a.fuse_kglobal;
+            return;
+        }
+        for (int e = tid; e < (8 - k) * 256; e += NT) {
+            const int bq = e >> 8, j = k + bq;
+            const double* src = a.fuse_pack + (size_t)(bq == 0 ? 28 + k : j * (j - 1) / 2 + k) * 256;
+            Ps[e] = ld_agent(src + (e & 255));
+        }
+        __syncthreads();
+        const d4 w = tile_load(Ps, lane);
+        d4 x = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) x = __builtin_amdgcn_mfma_f64_16x16x4f64(w[ks], T[k][ks], x, 0, 0, 0);
+        T[k] = x;
+#pragma unroll
+        for (int j = k + 1; j < 8; ++j) {
+            const d4 nl = tile_load(Ps + (j - k) * 256, lane);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) T[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(nl[ks], x[ks], T[j], 0, 0, 0);
+        }
+    }
+    const int row = row0 + wave * 16 + i;
+    if (row < a.n) {
+        double* Cr = a.C + row;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = 16 * j + g + 4 * r;
+                if (c < a.fuse_nb) {
+                    double v = T[j][r];
+                    if (a.fuse_ldlt) v *= ld_agent(a.fuse_rdiag + a.fuse_kglobal + c);
+                    Cr[(size_t)c * a.ldc] = v;
+                }
+            }
+    }
+    if (dbg) a.fuse_ts[81] = clock64();
 }
 
 // ------------------------------------------------------------------------------------------------

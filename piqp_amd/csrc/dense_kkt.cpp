@@ -183,13 +183,13 @@ private:
         part_.alloc((size_t)sl * n_);
         split_ws_.alloc(dense::syrk_split_workspace_doubles(n_, m_ > 0 ? m_ : 1));
         pack_.alloc(dense::FACTOR_PACK_DOUBLES);
-        fuse_scratch_.alloc(dense::FACTOR_PACK_DOUBLES); fuse_flags_.alloc(16); fuse_flags_.zero(st_);
+        fuse_scratch_.alloc(dense::FACTOR_PACK_DOUBLES); fuse_flags_.alloc(16); fuse_flags_.zero(st_); fuse_cnt_.alloc(8); fuse_cnt_.zero(st_);
         w16_.alloc((size_t)((n_ + 127) / 128) * 8 * 256);  // inverted 16 x 16 diagonal pieces of the whole factor (potrf_block -> launch_trsv)
         dense::syrk_prepare(n_);
         info_.alloc(1);
         info_h_.alloc(1);
         flags_.alloc(dense::trsv_flag_ints(n_));
-        if (const char* e = debug_token("fused_ts")) { dbg_panel_ = std::atoi(e); dbg_ts_.alloc(72); dbg_ts_.zero(st_); }
+        if (const char* e = debug_token("fused_ts")) { dbg_panel_ = std::atoi(e); dbg_ts_.alloc(96); dbg_ts_.zero(st_); }
         x_reg_last_.zero(st_);
         fac_.zero(st_);
     }
@@ -241,7 +241,8 @@ private:
             double* A11 = fac_.p + k + (size_t)k * n_;
             if (k == 0) dense::launch_potrf_diag(ldlt_, A11, n_, nb, k, info_.p, rdiag_.p, dvec_.p + k, rs > 0 ? pack_.p : nullptr, w16_.p, st_);
             if (rs <= 0) break;
-            { const int tt = prof_.begin(4, st_); dense::launch_trsm_panel(ldlt_, fac_.p, n_, k, nb, n_, pack_.p, rdiag_.p, st_); prof_.end(4, tt, st_); }
+            // (the panels after the first are solved inside the previous fused launch, behind the factorisation of their diagonal block)
+            if (k == 0) { const int tt = prof_.begin(4, st_); dense::launch_trsm_panel(ldlt_, fac_.p, n_, k, nb, n_, pack_.p, rdiag_.p, st_); prof_.end(4, tt, st_); }
             dense::SyrkArgs a;
             a.n = rs; a.kdim = nb;
             a.A = fac_.p + (k + nb) + (size_t)k * n_; a.lda = n_;
@@ -251,7 +252,7 @@ private:
             a.fuse_nb = rs < NB ? rs : NB; a.fuse_kglobal = k + nb; a.fuse_ldlt = ldlt_ ? 1 : 0; a.fuse_info = info_.p; a.fuse_rdiag = rdiag_.p; a.fuse_dvec = dvec_.p + k + nb;
             a.fuse_pack = (rs - a.fuse_nb > 0) ? pack_.p : nullptr;
             a.fuse_w16 = w16_.p + (size_t)((k + nb) / 16) * 256;
-            a.fuse_token = ++fuse_token_; a.fuse_flags = fuse_flags_.p; a.fuse_scratch = fuse_scratch_.p;
+            a.fuse_token = ++fuse_token_; a.fuse_flags = fuse_flags_.p; a.fuse_scratch = fuse_scratch_.p; a.fuse_cnt = fuse_cnt_.p;
             a.fuse_ts = (dbg_panel_ == p) ? dbg_ts_.p : nullptr;
             { const int tt = prof_.begin(3, st_); dense::launch_syrk(dense::EPI_SUBTRACT_POTRF, a, st_); prof_.end(3, tt, st_); }
             if (a.fuse_ts) dump_fused_ts(p);
@@ -260,12 +261,16 @@ private:
     // PIQP_AMD_DEBUG=fused_ts=<panel>: in-kernel timeline of the workgroup that updates and factors the next diagonal block, to stderr
     void dump_fused_ts(int panel)
     {
-        long long h[72];
+        long long h[96];
         PQ_HIP(hipMemcpyAsync(h, dbg_ts_.p, sizeof(h), hipMemcpyDeviceToHost, st_));
         PQ_HIP(hipStreamSynchronize(st_));
         std::fprintf(stderr, "[piqp_amd] fused panel %d (cycles): C + panel staged %lld, MFMA loop %lld, tiles->LDS %lld, potrf_block %lld; potrf steps (factor/subst/update):", panel, h[4] - h[0], h[1] - h[4], h[2] - h[1], h[3] - h[2]);
         for (int k = 0; k < 8; ++k) std::fprintf(stderr, " %lld/%lld/%lld", h[8 + 8 * k + 1] - h[8 + 8 * k], h[8 + 8 * k + 3] - h[8 + 8 * k + 2], h[8 + 8 * k + 5] - h[8 + 8 * k + 4]);
-        std::fprintf(stderr, "\n");
+        std::fprintf(stderr, "\n[piqp_amd]   potrf step start / factored (since launch):");
+        for (int k = 0; k < 8; ++k) std::fprintf(stderr, " %lld/%lld", h[8 + 8 * k] - h[0], h[8 + 8 * k + 1] - h[0]);
+        std::fprintf(stderr, "; potrf_block end %lld\n[piqp_amd]   first panel workgroup: tile in registers %lld, step k operands seen:", h[3] - h[0], h[80] - h[0]);
+        for (int k = 0; k < 8; ++k) std::fprintf(stderr, " %lld", h[72 + k] - h[0]);
+        std::fprintf(stderr, ", panel stored %lld\n", h[81] - h[0]);
     }
     // llt.info() == Success (dense/kkt.hpp:83): one 4-byte read-back per factor call
     bool factor_status()
@@ -280,7 +285,7 @@ private:
     double delta_ = 1.0;
     hipStream_t st_ = nullptr;
     DBuf<double> Pfull_, Pdiag_, AT_, GT_, ATA_, fac_, z_reg_inv_, x_reg_last_, dvec_, part_, rdiag_, split_ws_, pack_, w16_, fuse_scratch_;
-    DBuf<int> info_, flags_, fuse_flags_;
+    DBuf<int> info_, flags_, fuse_flags_, fuse_cnt_;
     int fuse_token_ = 0;
     HBuf<int> info_h_;
     StageProfiler prof_;
