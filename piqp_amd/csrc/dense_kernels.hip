@@ -1466,7 +1466,7 @@ __device__ __forceinline__ double ld_agent(const double* p)
 // dependent chain on one wave (4.2 us per block in round 1).  W16 == nullptr keeps that substitution (reciprocal pivots in rdiag).
 template <bool FWD>
 __global__ __launch_bounds__(256) void k_trsv_persistent(const double* __restrict__ L, int ld, int n, double* __restrict__ x, const double* __restrict__ rdiag,
-                                                         int nblk, int* __restrict__ flags, int* __restrict__ err, const double* __restrict__ W16)
+                                                         int nblk, int* __restrict__ flags, int* __restrict__ err, const double* __restrict__ W16, int token, long long* __restrict__ ts)
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double* Ls = sm;                    // own diagonal block, Ls[c * (TB+1) + r]
@@ -1474,8 +1474,10 @@ __global__ __launch_bounds__(256) void k_trsv_persistent(const double* __restric
     double* bs = xs + TB;
     double* rd = bs + TB;
     double* Wg = rd + TB;               // eight inverted 16 x 16 diagonal pieces, column-major
-    double* up = Wg + 8 * 256;          // [2][16] partial updates of the current group, then [16] its solution
+    double* up = Wg + 8 * 256;          // scratch of the diagonal step
     __shared__ int ok_s;
+    __shared__ int sync_w[4];           // diagonal step: [0] groups solved by the chain wave, [1], [2] groups applied by the helper waves
+    if (threadIdx.x < 4) sync_w[threadIdx.x] = 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ridx = (int)blockIdx.x;   // position of the block in sweep order
     const int r = FWD ? ridx : nblk - 1 - ridx;
@@ -1525,7 +1527,7 @@ __global__ __launch_bounds__(256) void k_trsv_persistent(const double* __restric
         if (tid == 0) {
             int ok = 1;
             unsigned spins = 0;
-            while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+            while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != token) {
                 __builtin_amdgcn_s_sleep(1);
                 if (++spins > 20000000u) { ok = 0; __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
             }
@@ -1541,6 +1543,7 @@ __global__ __launch_bounds__(256) void k_trsv_persistent(const double* __restric
         const int c0 = j * TB;
         const int nc = min(TB, n - c0);
         if (!wait_flag(flags + j)) return false;
+        if (ts && tid == 0 && t + 1 == nsteps) ts[4 * r + 0] = clock64();  // debugging aid: the last producer's flag seen
         const double xv = (tid < TB && tid < nc) ? ld_agent(x + c0 + tid) : 0.0;
         if (t_next >= 0) load_block(t_next, nxt);
         if (tid < TB) xs[tid] = xv;
@@ -1561,49 +1564,121 @@ __global__ __launch_bounds__(256) void k_trsv_persistent(const double* __restric
         if (q < nsteps) { if (!consume(q, lvA, lvB, -1)) return; }
     }
     __syncthreads();
+    if (ts && tid == 0) ts[4 * r + 1] = clock64();  // products done
     if (half == 1) bs[row] = acc;
     __syncthreads();
     if (half == 0) bs[row] = mine - (acc + bs[row]);
     if (W16) {
-        double upd = 0.0;  // what the groups solved so far take off row `row`: this thread's 8 columns of each
-#pragma unroll 1
-        for (int gi = 0; gi < 8; ++gi) {
-            const int g = FWD ? gi : 7 - gi;
-            const int rg = row - 16 * g;
-            if (rg >= 0 && rg < 16) up[half * 16 + rg] = upd;
-            __syncthreads();
-            if (wave == 0) {
-                // lane (i, q = lane >> 4) sums the columns c = q, q + 4, q + 8, q + 12 of row i of W_g (backward: of W_g^T); the four partial sums
-                // are added in q order
-                const int i = lane & 15, q = lane >> 4;
+        // The diagonal step as a dataflow inside the workgroup, no barriers (round 2; two barriers per group of 16 cost 8 500 cycles per block,
+        // more than the hand-off between the blocks).  Groups of 16 columns, g-th group in sweep order = gi:
+        //   wave 0 (the chain)  x_g = W_g (b_g - far_g - L_{g,g-2} x_{g-2} - L_{g,g-1} x_{g-1}): the two nearest solved groups itself -- 16 x 16
+        //                       products, lane = (row i, quarter q), the four partial sums of a row added in q order over the quad by DPP;
+        //   waves 1, 2          one row each: far_row += L[row, group] x_group for every group solved at least three groups before the
+        //                       row's own, as the chain publishes them; running value in LDS after every group.
+        // Monotonic LDS words: cprog = groups solved by the chain, hp[w] = groups applied by helper wave w (one wave's LDS instructions
+        // execute in order, so a word written after the data is seen after the data).  The helpers have two chain steps of slack.  (Measured per 128-row block: 8 500 cycles with barriers, 7 150 in this form; the chain wave is
+        // issue-bound at ~100 instructions per group -- with the three nearest groups on the chain and more slack for the helpers: 7 500.)
+        lds_vint* cprog = (lds_vint*)&sync_w[0];
+        lds_vint* hp = (lds_vint*)&sync_w[1];
+        double* far = rd;  // reciprocal pivots are not used on this path
+        double* rt = up;   // the chain's 16-vector on its way from "one value per quad" to "four values per lane"
+        if (wave == 0) {
+            const int i = lane >> 2, q = lane & 3;
+            auto quad_sum = [&](double part) {  // ((p0 + p1) + p2) + p3 in every lane of the quad (quad_perm broadcasts)
+                const int plo = __double2loint(part), phi = __double2hiint(part);
+#define PQ_QUAD_BC(K) __hiloint2double(__builtin_amdgcn_update_dpp(0, phi, (K) * 0x55, 0xf, 0xf, false), __builtin_amdgcn_update_dpp(0, plo, (K) * 0x55, 0xf, 0xf, false))
+                const double r = ((PQ_QUAD_BC(0) + PQ_QUAD_BC(1)) + PQ_QUAD_BC(2)) + PQ_QUAD_BC(3);
+#undef PQ_QUAD_BC
+                return r;
+            };
+            // software-pipelined: everything of group gi + 1 that does not need x_gi (W row, b - far - L_{.,gi-1} x_{gi-1}, the L entries of the last
+            // product) is fetched and formed while group gi is in flight: per group the chain is  x write -> x read, 4 FMAs, quad sum, r write ->
+            // r read, 4 FMAs, quad sum
+            double wv[4], l1[4] = {0.0, 0.0, 0.0, 0.0};
+            double tv;
+            {
+                const int g = FWD ? 0 : 7;
                 const double* Wp = Wg + g * 256;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) { const int c = q + 4 * t; wv[t] = FWD ? Wp[c * 16 + i] : Wp[i * 16 + c]; }
+                tv = bs[16 * g + i];
+            }
+#pragma unroll
+            for (int gi = 0; gi < 8; ++gi) {
+                const int g = FWD ? gi : 7 - gi;
+                if (gi >= 1) {
+                    const int g1 = FWD ? g - 1 : g + 1;
+                    double part = 0.0;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) part += l1[t] * xs[16 * g1 + q + 4 * t];
+                    tv -= quad_sum(part);
+                }
+                if (q == 0) rt[i] = tv;
+                wave_lds_sync();
+                // ---- group gi + 1, the part that does not depend on x_gi ----
+                double wn[4] = {0.0, 0.0, 0.0, 0.0}, ln[4] = {0.0, 0.0, 0.0, 0.0}, tn = 0.0, pn = 0.0;
+                if (gi < 7) {
+                    const int gn = FWD ? g + 1 : g - 1;
+                    const double* Wn = Wg + gn * 256;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) { const int c = q + 4 * t; wn[t] = FWD ? Wn[c * 16 + i] : Wn[i * 16 + c]; }
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) ln[t] = Ls[(16 * g + q + 4 * t) * (TB + 1) + 16 * gn + i];
+                    tn = bs[16 * gn + i];
+                    if (gi + 1 >= 3) {
+                        const int hw = (16 * gn) >> 6;  // helper wave that owns these rows
+                        while (hp[hw] < gi - 1) __builtin_amdgcn_s_sleep(1);
+                        tn -= far[16 * gn + i];
+                    }
+                    if (gi >= 1) {
+                        const int g2 = FWD ? g - 1 : g + 1;  // two groups before gn
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) { const int c = 16 * g2 + q + 4 * t; pn += Ls[c * (TB + 1) + 16 * gn + i] * xs[c]; }
+                    }
+                }
+                // ---- x_gi = W r ----
                 double part = 0.0;
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const int c = q + 4 * t;
-                    const double bc = bs[16 * g + c] - (up[c] + up[16 + c]);
-                    part += (FWD ? Wp[c * 16 + i] : Wp[i * 16 + c]) * bc;
-                }
-                const double x1 = __shfl(part, i + 16, 64), x2 = __shfl(part, i + 32, 64), x3 = __shfl(part, i + 48, 64);
-                if (lane < 16) { const double xi = ((part + x1) + x2) + x3; up[32 + i] = xi; bs[16 * g + i] = xi; }
-            }
-            __syncthreads();
-            const bool todo = FWD ? (row > 16 * g + 15) : (row < 16 * g);
-            if (todo) {
+                for (int t = 0; t < 4; ++t) part += wv[t] * rt[q + 4 * t];
+                const double xi = quad_sum(part);
+                if (q == 0) { xs[16 * g + i] = xi; bs[16 * g + i] = xi; }
+                wave_lds_sync();
+                if (lane == 0) *cprog = gi + 1;
+                asm volatile("" ::: "memory");
+                if (gi < 7) {
+                    if (gi >= 1) tn -= quad_sum(pn);
+                    tv = tn;
 #pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    const int cc = half * 8 + c;
-                    upd += Ls[(16 * g + cc) * (TB + 1) + row] * up[32 + cc];
+                    for (int t = 0; t < 4; ++t) { wv[t] = wn[t]; l1[t] = ln[t]; }
                 }
+            }
+        } else if (wave <= 2) {
+            const int hrow = tid - 64;
+            const int G = FWD ? (hrow >> 4) : 7 - (hrow >> 4);  // the row's own group, in sweep order
+            double f = 0.0;
+#pragma unroll 1
+            for (int gi = 0; gi < 5; ++gi) {
+                const int g = FWD ? gi : 7 - gi;
+                while (*cprog < gi + 1) __builtin_amdgcn_s_sleep(1);
+                if (gi <= G - 3) {
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) f += Ls[(16 * g + c) * (TB + 1) + hrow] * xs[16 * g + c];
+                    far[hrow] = f;
+                }
+                wave_lds_sync();
+                if (lane == 0) hp[wave - 1] = gi + 1;
+                asm volatile("" ::: "memory");
             }
         }
         __syncthreads();
+        if (ts && tid == 0) ts[4 * r + 2] = clock64();  // diagonal block solved
         if (tid < TB) {
             if (tid < nrows) st_agent(x + row0 + tid, bs[tid]);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __syncthreads();
-        if (tid == 0) __hip_atomic_store(flags + r, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) __hip_atomic_store(flags + r, token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (ts && tid == 0) ts[4 * r + 3] = clock64();  // published
         return;
     }
     __syncthreads();
@@ -1614,7 +1689,7 @@ __global__ __launch_bounds__(256) void k_trsv_persistent(const double* __restric
         if (lane < nrows) st_agent(x + row0 + lane, b0);
         if (lane + 64 < nrows) st_agent(x + row0 + lane + 64, b1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_store(flags + r, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) __hip_atomic_store(flags + r, token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -1627,9 +1702,9 @@ __global__ void k_mul_vec(int n, const double* __restrict__ d, double* __restric
 size_t trsv_flag_ints(int n) { return 2 * (size_t)div_up(n, TB) + 1; }
 
 // LLT: L y = b, L^T x = y with rdiag = 1/diag(L).  LDLt: unit L, then x *= rdiag (= 1/D), then unit L^T.
-// `flags` = trsv_flag_ints(n) ints of scratch (zeroed here on the stream); nullptr, or more blocks than can be resident at once, falls back to
+// `flags` = trsv_flag_ints(n) ints of scratch (zeroed by the owner at allocation), `token` != 0 unique per call; nullptr, or more blocks than can be resident at once, falls back to
 // one launch per block step.
-void launch_trsv(const double* L, int ld, int n, double* x, const double* rdiag, bool ldlt, int* flags, const double* w16, hipStream_t s)
+void launch_trsv(const double* L, int ld, int n, double* x, const double* rdiag, bool ldlt, int* flags, int token, const double* w16, hipStream_t s, long long* ts)
 {
     if (n <= 0) return;
     static bool attr_set = false;
@@ -1644,12 +1719,12 @@ void launch_trsv(const double* L, int ld, int n, double* x, const double* rdiag,
     const double* rd = ldlt ? nullptr : rdiag;
     const bool persistent = flags != nullptr && nblk <= 224;  // every block resident (one per CU) with room to spare
     if (persistent) {
-        // layout: [fwd x flags nblk][bwd x flags nblk][err]
-        PQ_HIP(hipMemsetAsync(flags, 0, sizeof(int) * (2 * (size_t)nblk + 1), s));
+        // layout: [fwd x flags nblk][bwd x flags nblk][err]; a block is published when its flag holds `token` (unique per call on this flag
+        // array, never 0: the array is zeroed once, at allocation -- no memset per solve)
         int* err = flags + 2 * nblk;
-        hipLaunchKernelGGL(k_trsv_persistent<true>, dim3(nblk), dim3(256), TRSV_P_LDS_BYTES, s, L, ld, n, x, rd, nblk, flags, err, w16);
+        hipLaunchKernelGGL(k_trsv_persistent<true>, dim3(nblk), dim3(256), TRSV_P_LDS_BYTES, s, L, ld, n, x, rd, nblk, flags, err, w16, token, ts);
         if (ldlt) hipLaunchKernelGGL(k_mul_vec, dim3(div_up(n, 256)), dim3(256), 0, s, n, rdiag, x);
-        hipLaunchKernelGGL(k_trsv_persistent<false>, dim3(nblk), dim3(256), TRSV_P_LDS_BYTES, s, L, ld, n, x, rd, nblk, flags + nblk, err, w16);
+        hipLaunchKernelGGL(k_trsv_persistent<false>, dim3(nblk), dim3(256), TRSV_P_LDS_BYTES, s, L, ld, n, x, rd, nblk, flags + nblk, err, w16, token, (long long*)nullptr);
     } else {
         for (int j = 0; j < nblk; ++j)
             hipLaunchKernelGGL(k_trsv_fwd_step, dim3(nblk - j), dim3(256), TRSV_LDS_BYTES, s, L, ld, n, x, rd, j);

@@ -91,7 +91,8 @@ public:
         if (p_ > 0) nsl += dense::launch_gemv_n_partial(n_, p_, AT_.p, n_, rhs_y, nullptr, delta_inv, part_.p + (size_t)nsl * n_, st_);
         dense::launch_reduce_partials(n_, nsl, part_.p, rhs_x, lhs_x, st_);
         // solve_ldlt_in_place: llt.solveInPlace(lhs_x)
-        { const int tt = prof_.begin(5, st_); dense::launch_trsv(fac_.p, n_, n_, lhs_x, rdiag_.p, ldlt_, flags_.p, w16_.p, st_); prof_.end(5, tt, st_); }
+        { const int tt = prof_.begin(5, st_); dense::launch_trsv(fac_.p, n_, n_, lhs_x, rdiag_.p, ldlt_, flags_.p, next_trsv_token(), w16_.p, st_, trsv_ts_.p);
+          if (trsv_ts_.p) dump_trsv_ts(); prof_.end(5, tt, st_); }
         // lhs_y = delta_inv * AT^T lhs_x - delta_inv * rhs_y
         if (p_ > 0) dense::launch_gemv_t(n_, p_, AT_.p, n_, lhs_x, delta_inv, -delta_inv, rhs_y, nullptr, lhs_y, st_);
         // lhs_z = (GT^T lhs_x - rhs_z) o z_reg_inv
@@ -188,7 +189,8 @@ private:
         dense::syrk_prepare(n_);
         info_.alloc(1);
         info_h_.alloc(1);
-        flags_.alloc(dense::trsv_flag_ints(n_));
+        flags_.alloc(dense::trsv_flag_ints(n_)); flags_.zero(st_);
+        if (debug_token("trsv_ts")) { trsv_ts_.alloc(4 * ((n_ + 127) / 128)); trsv_ts_.zero(st_); }
         if (const char* e = debug_token("fused_ts")) { dbg_panel_ = std::atoi(e); dbg_ts_.alloc(96); dbg_ts_.zero(st_); }
         x_reg_last_.zero(st_);
         fac_.zero(st_);
@@ -286,11 +288,27 @@ private:
     hipStream_t st_ = nullptr;
     DBuf<double> Pfull_, Pdiag_, AT_, GT_, ATA_, fac_, z_reg_inv_, x_reg_last_, dvec_, part_, rdiag_, split_ws_, pack_, w16_, fuse_scratch_;
     DBuf<int> info_, flags_, fuse_flags_, fuse_cnt_;
-    int fuse_token_ = 0;
+    int fuse_token_ = 0, trsv_token_ = 0;
+    int next_trsv_token()
+    {
+        if (trsv_token_ == 0x7fffffff) { flags_.zero(st_); trsv_token_ = 0; }
+        return ++trsv_token_;
+    }
     HBuf<int> info_h_;
     StageProfiler prof_;
     int dbg_panel_ = -1;
-    DBuf<long long> dbg_ts_;
+    DBuf<long long> dbg_ts_, trsv_ts_;
+    // PIQP_AMD_DEBUG=trsv_ts: per block of the forward sweep, cycles from seeing the last producer's flag to products done / diagonal block
+    // solved / published (one workgroup's own clock: differences only)
+    void dump_trsv_ts()
+    {
+        std::vector<long long> h(trsv_ts_.n);
+        PQ_HIP(hipMemcpyAsync(h.data(), trsv_ts_.p, trsv_ts_.bytes(), hipMemcpyDeviceToHost, st_));
+        PQ_HIP(hipStreamSynchronize(st_));
+        std::fprintf(stderr, "[piqp_amd] forward sweep, per block (flag seen -> products / -> solved / -> published):");
+        for (size_t r = 1; r < h.size() / 4; ++r) std::fprintf(stderr, " %lld/%lld/%lld", h[4 * r + 1] - h[4 * r], h[4 * r + 2] - h[4 * r], h[4 * r + 3] - h[4 * r]);
+        std::fprintf(stderr, "\n");
+    }
 };
 
 }  // namespace
