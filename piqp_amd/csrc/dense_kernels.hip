@@ -1332,7 +1332,7 @@ __device__ __forceinline__ void diag_solve_bwd(const double* __restrict__ Ls, co
 
 constexpr int TB = 128;
 constexpr int TRSV_LDS_BYTES = (TB * (TB + 1) + 3 * TB) * (int)sizeof(double);
-constexpr int TRSV_P_LDS_BYTES = (TB * (TB + 1) + 3 * TB + 8 * 256 + 64) * (int)sizeof(double);  // + the eight inverted diagonal pieces, group scratch
+constexpr int TRSV_P_LDS_BYTES = (TB * (TB + 1) + 3 * TB + 8 * 256 + 64 + TB) * (int)sizeof(double);  // + the eight inverted diagonal pieces, scratch of the diagonal step
 
 // forward step j: row blocks r >= j subtract L[r, j-1] * x_{j-1}; block r == j then solves L_jj y = b.
 // rdiag = reciprocal diagonal of L (nullptr: unit diagonal).  The diagonal workgroup issues the loads of
@@ -1570,30 +1570,30 @@ __global__ __launch_bounds__(256) void k_trsv_persistent(const double* __restric
     if (half == 0) bs[row] = mine - (acc + bs[row]);
     if (W16) {
         // The diagonal step as a dataflow inside the workgroup, no barriers (round 2; two barriers per group of 16 cost 8 500 cycles per block,
-        // more than the hand-off between the blocks).  Groups of 16 columns, g-th group in sweep order = gi:
-        //   wave 0 (the chain)  x_g = W_g (b_g - far_g - L_{g,g-2} x_{g-2} - L_{g,g-1} x_{g-1}): the two nearest solved groups itself -- 16 x 16
-        //                       products, lane = (row i, quarter q), the four partial sums of a row added in q order over the quad by DPP;
-        //   waves 1, 2          one row each: far_row += L[row, group] x_group for every group solved at least three groups before the
-        //                       row's own, as the chain publishes them; running value in LDS after every group.
-        // Monotonic LDS words: cprog = groups solved by the chain, hp[w] = groups applied by helper wave w (one wave's LDS instructions
-        // execute in order, so a word written after the data is seen after the data).  The helpers have two chain steps of slack.  (Measured per 128-row block: 8 500 cycles with barriers, 7 150 in this form; the chain wave is
-        // issue-bound at ~100 instructions per group -- with the three nearest groups on the chain and more slack for the helpers: 7 500.)
+        // more than the hand-off between the blocks).  Groups of 16 columns, gi = position in sweep order; every wave has one job:
+        //   wave 0 (the chain)  x_g = W_g (b_g - L_{g,g-1} x_{g-1} - far_g - near_g): only the product with the group solved LAST and the
+        //                       product with the inverted diagonal piece -- 16 x 16, lane = (row i, quarter q), the four partial sums of a row
+        //                       added in q order over the quad by DPP.  One wave issues in order, so every instruction here is on the clock;
+        //   wave 3 (near)       near_g = L_{g,g-3} x_{g-3} + L_{g,g-2} x_{g-2} for the group the chain reaches next (one chain step of slack);
+        //   waves 1, 2 (far)    one row each: far_row += L[row, group] x_group for every group solved at least four groups before the row's own
+        //                       (three chain steps of slack); running value in LDS after every group.
+        // Monotonic LDS words: cprog = groups solved by the chain, hp[w] = groups applied by far wave w, np = groups whose near term is there
+        // (one wave's LDS instructions execute in order, so a word written after the data is seen after the data).
         lds_vint* cprog = (lds_vint*)&sync_w[0];
         lds_vint* hp = (lds_vint*)&sync_w[1];
-        double* far = rd;  // reciprocal pivots are not used on this path
-        double* rt = up;   // the chain's 16-vector on its way from "one value per quad" to "four values per lane"
+        lds_vint* np = (lds_vint*)&sync_w[3];
+        double* far = rd;        // reciprocal pivots are not used on this path
+        double* rt = up;         // the chain's 16-vector on its way from "one value per quad" to "four values per lane"
+        double* nearv = up + 64; // [TB]
+        auto quad_sum = [&](double part) {  // ((p0 + p1) + p2) + p3 in every lane of the quad (quad_perm broadcasts)
+            const int plo = __double2loint(part), phi = __double2hiint(part);
+#define PQ_QUAD_BC(K) __hiloint2double(__builtin_amdgcn_update_dpp(0, phi, (K) * 0x55, 0xf, 0xf, false), __builtin_amdgcn_update_dpp(0, plo, (K) * 0x55, 0xf, 0xf, false))
+            const double rs = ((PQ_QUAD_BC(0) + PQ_QUAD_BC(1)) + PQ_QUAD_BC(2)) + PQ_QUAD_BC(3);
+#undef PQ_QUAD_BC
+            return rs;
+        };
         if (wave == 0) {
             const int i = lane >> 2, q = lane & 3;
-            auto quad_sum = [&](double part) {  // ((p0 + p1) + p2) + p3 in every lane of the quad (quad_perm broadcasts)
-                const int plo = __double2loint(part), phi = __double2hiint(part);
-#define PQ_QUAD_BC(K) __hiloint2double(__builtin_amdgcn_update_dpp(0, phi, (K) * 0x55, 0xf, 0xf, false), __builtin_amdgcn_update_dpp(0, plo, (K) * 0x55, 0xf, 0xf, false))
-                const double r = ((PQ_QUAD_BC(0) + PQ_QUAD_BC(1)) + PQ_QUAD_BC(2)) + PQ_QUAD_BC(3);
-#undef PQ_QUAD_BC
-                return r;
-            };
-            // software-pipelined: everything of group gi + 1 that does not need x_gi (W row, b - far - L_{.,gi-1} x_{gi-1}, the L entries of the last
-            // product) is fetched and formed while group gi is in flight: per group the chain is  x write -> x read, 4 FMAs, quad sum, r write ->
-            // r read, 4 FMAs, quad sum
             double wv[4], l1[4] = {0.0, 0.0, 0.0, 0.0};
             double tv;
             {
@@ -1613,10 +1613,25 @@ __global__ __launch_bounds__(256) void k_trsv_persistent(const double* __restric
                     for (int t = 0; t < 4; ++t) part += l1[t] * xs[16 * g1 + q + 4 * t];
                     tv -= quad_sum(part);
                 }
+                if (gi >= 2) {
+                    // what the other waves took off these rows: asked for as late as possible (they have had a whole chain step).  The words and
+                    // the values come back from ONE round of LDS reads; reads execute in order, so values read after a word that says "done" are
+                    // the finished ones.
+                    const int hw = (16 * g) >> 6;  // far wave that owns these rows
+                    double fv, nv;
+                    while (true) {
+                        const int n_done = *np, h_done = hp[hw];
+                        fv = far[16 * g + i]; nv = nearv[16 * g + i];
+                        if (n_done >= gi && (gi < 4 || h_done >= gi - 3)) break;
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                    if (gi >= 4) tv -= fv;
+                    tv -= nv;
+                }
                 if (q == 0) rt[i] = tv;
                 wave_lds_sync();
-                // ---- group gi + 1, the part that does not depend on x_gi ----
-                double wn[4] = {0.0, 0.0, 0.0, 0.0}, ln[4] = {0.0, 0.0, 0.0, 0.0}, tn = 0.0, pn = 0.0;
+                // ---- group gi + 1: W row, b, the L entries of its last product -- fetched while x_gi is in flight ----
+                double wn[4] = {0.0, 0.0, 0.0, 0.0}, ln[4] = {0.0, 0.0, 0.0, 0.0}, tn = 0.0;
                 if (gi < 7) {
                     const int gn = FWD ? g + 1 : g - 1;
                     const double* Wn = Wg + gn * 256;
@@ -1625,16 +1640,6 @@ __global__ __launch_bounds__(256) void k_trsv_persistent(const double* __restric
 #pragma unroll
                     for (int t = 0; t < 4; ++t) ln[t] = Ls[(16 * g + q + 4 * t) * (TB + 1) + 16 * gn + i];
                     tn = bs[16 * gn + i];
-                    if (gi + 1 >= 3) {
-                        const int hw = (16 * gn) >> 6;  // helper wave that owns these rows
-                        while (hp[hw] < gi - 1) __builtin_amdgcn_s_sleep(1);
-                        tn -= far[16 * gn + i];
-                    }
-                    if (gi >= 1) {
-                        const int g2 = FWD ? g - 1 : g + 1;  // two groups before gn
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) { const int c = 16 * g2 + q + 4 * t; pn += Ls[c * (TB + 1) + 16 * gn + i] * xs[c]; }
-                    }
                 }
                 // ---- x_gi = W r ----
                 double part = 0.0;
@@ -1645,22 +1650,48 @@ __global__ __launch_bounds__(256) void k_trsv_persistent(const double* __restric
                 wave_lds_sync();
                 if (lane == 0) *cprog = gi + 1;
                 asm volatile("" ::: "memory");
-                if (gi < 7) {
-                    if (gi >= 1) tn -= quad_sum(pn);
-                    tv = tn;
+                if (ts && lane == 0 && r == 1) ts[4 * nblk + gi] = clock64();  // debugging aid: the groups of block 1
+                tv = tn;
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) { wv[t] = wn[t]; l1[t] = ln[t]; }
-                }
+                for (int t = 0; t < 4; ++t) { wv[t] = wn[t]; l1[t] = ln[t]; }
             }
-        } else if (wave <= 2) {
+        } else if (wave == 3) {
+            const int i = lane >> 2, q = lane & 3;
+#pragma unroll 1
+            for (int G = 2; G < 8; ++G) {
+                const int g = FWD ? G : 7 - G;
+                double n3 = 0.0;
+                if (G >= 3) {
+                    const int g3 = FWD ? g - 3 : g + 3;
+                    while (*cprog < G - 2) __builtin_amdgcn_s_sleep(1);
+                    double p = 0.0;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) { const int c = 16 * g3 + q + 4 * t; p += Ls[c * (TB + 1) + 16 * g + i] * xs[c]; }
+                    n3 = quad_sum(p);
+                }
+                const int g2 = FWD ? g - 2 : g + 2;
+                double l2[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) l2[t] = Ls[(16 * g2 + q + 4 * t) * (TB + 1) + 16 * g + i];
+                while (*cprog < G - 1) __builtin_amdgcn_s_sleep(1);
+                double p = 0.0;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) p += l2[t] * xs[16 * g2 + q + 4 * t];
+                const double nv = n3 + quad_sum(p);
+                if (q == 0) nearv[16 * g + i] = nv;
+                wave_lds_sync();
+                if (lane == 0) *np = G;
+                asm volatile("" ::: "memory");
+            }
+        } else {
             const int hrow = tid - 64;
             const int G = FWD ? (hrow >> 4) : 7 - (hrow >> 4);  // the row's own group, in sweep order
             double f = 0.0;
 #pragma unroll 1
-            for (int gi = 0; gi < 5; ++gi) {
+            for (int gi = 0; gi < 4; ++gi) {
                 const int g = FWD ? gi : 7 - gi;
                 while (*cprog < gi + 1) __builtin_amdgcn_s_sleep(1);
-                if (gi <= G - 3) {
+                if (gi <= G - 4) {
 #pragma unroll
                     for (int c = 0; c < 16; ++c) f += Ls[(16 * g + c) * (TB + 1) + hrow] * xs[16 * g + c];
                     far[hrow] = f;

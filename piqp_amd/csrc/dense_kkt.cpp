@@ -190,7 +190,7 @@ private:
         info_.alloc(1);
         info_h_.alloc(1);
         flags_.alloc(dense::trsv_flag_ints(n_)); flags_.zero(st_);
-        if (debug_token("trsv_ts")) { trsv_ts_.alloc(4 * ((n_ + 127) / 128)); trsv_ts_.zero(st_); }
+        if (debug_token("trsv_ts")) { trsv_ts_.alloc(4 * ((n_ + 127) / 128) + 8); trsv_ts_.zero(st_); }
         if (const char* e = debug_token("fused_ts")) { dbg_panel_ = std::atoi(e); dbg_ts_.alloc(96); dbg_ts_.zero(st_); }
         x_reg_last_.zero(st_);
         fac_.zero(st_);
@@ -306,7 +306,10 @@ private:
         PQ_HIP(hipMemcpyAsync(h.data(), trsv_ts_.p, trsv_ts_.bytes(), hipMemcpyDeviceToHost, st_));
         PQ_HIP(hipStreamSynchronize(st_));
         std::fprintf(stderr, "[piqp_amd] forward sweep, per block (flag seen -> products / -> solved / -> published):");
-        for (size_t r = 1; r < h.size() / 4; ++r) std::fprintf(stderr, " %lld/%lld/%lld", h[4 * r + 1] - h[4 * r], h[4 * r + 2] - h[4 * r], h[4 * r + 3] - h[4 * r]);
+        const size_t nb = (h.size() - 8) / 4;
+        for (size_t r = 1; r < nb; ++r) std::fprintf(stderr, " %lld/%lld/%lld", h[4 * r + 1] - h[4 * r], h[4 * r + 2] - h[4 * r], h[4 * r + 3] - h[4 * r]);
+        std::fprintf(stderr, "\n[piqp_amd]   block 1, groups of the diagonal step done at (since products):");
+        for (int g = 0; g < 8; ++g) std::fprintf(stderr, " %lld", h[4 * nb + g] - h[4 * 1 + 1]);
         std::fprintf(stderr, "\n");
     }
 };
