@@ -1606,17 +1606,10 @@ __global__ __launch_bounds__(256) void k_trsv_persistent(const double* __restric
 #pragma unroll
             for (int gi = 0; gi < 8; ++gi) {
                 const int g = FWD ? gi : 7 - gi;
-                if (gi >= 1) {
-                    const int g1 = FWD ? g - 1 : g + 1;
-                    double part = 0.0;
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) part += l1[t] * xs[16 * g1 + q + 4 * t];
-                    tv -= quad_sum(part);
-                }
                 if (gi >= 2) {
-                    // what the other waves took off these rows: asked for as late as possible (they have had a whole chain step).  The words and
-                    // the values come back from ONE round of LDS reads; reads execute in order, so values read after a word that says "done" are
-                    // the finished ones.
+                    // what the other waves took off these rows (they have had a whole chain step).  The words and the values come back from ONE
+                    // round of LDS reads; reads execute in order, so values read after a word that says "done" are the finished ones.  The terms
+                    // leave b in ascending column order (far, near, last group), like a plain substitution.
                     const int hw = (16 * g) >> 6;  // far wave that owns these rows
                     double fv, nv;
                     while (true) {
@@ -1627,6 +1620,13 @@ __global__ __launch_bounds__(256) void k_trsv_persistent(const double* __restric
                     }
                     if (gi >= 4) tv -= fv;
                     tv -= nv;
+                }
+                if (gi >= 1) {
+                    const int g1 = FWD ? g - 1 : g + 1;
+                    double part = 0.0;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) part += l1[t] * xs[16 * g1 + q + 4 * t];
+                    tv -= quad_sum(part);
                 }
                 if (q == 0) rt[i] = tv;
                 wave_lds_sync();
