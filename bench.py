@@ -43,12 +43,14 @@ def self_launch(args):
 
 def panel_update_flops(n, nb=128):
     """algorithmic flops of the fused trailing-update launches of one factorisation (sum_k rs_k (rs_k + 1) nb, the
-    "panel update" of the north star) plus the diagonal blocks they factor (nb^3 / 3 each)"""
+    "panel update" of the north star) plus what the same launches do besides: the next diagonal block (nb^3 / 3) and the substitution of the
+    next panel below it (rows x nb^2)"""
     tot, launches = 0.0, 0
     k = 0
     while k + nb < n:
         rs = n - k - nb
-        tot += float(rs) * (rs + 1) * nb + min(nb, rs) ** 3 / 3.0
+        nbn = min(nb, rs)
+        tot += float(rs) * (rs + 1) * nb + nbn ** 3 / 3.0 + float(max(0, rs - nbn)) * nbn * nbn
         launches += 1
         k += nb
     return tot, launches
@@ -204,8 +206,9 @@ def main():
                     "avg_launch_ms": secs_per_step * 1e3 / max(launches_per_step, 1), "launches_per_step": launches_per_step, "ms_per_step": secs_per_step * 1e3,
                     "frac_of_measured_mfma_peak": ach / tf.value if tf.value > 0 else None}
         r_asm = roof("k_syrk_lower<EPI_ASSEMBLE> (dense/kkt.hpp:140-160 update_kkt); hipEvent-bracketed in the timed region", flops_asm, asm_s, 1, "assembly")
-        r_upd = roof("k_syrk_lower<EPI_SUBTRACT_POTRF> = trailing (panel) update of the factorisation + next diagonal block (dense/ldlt_no_pivot.hpp:313-354, "
-                     "Eigen::LLT at dense/kkt.hpp:82); hipEvent-bracketed per launch in a separate pass of the same steps", flops_upd, upd_s, upd_launches, "panel_update")
+        r_upd = roof("k_syrk_lower<EPI_SUBTRACT_POTRF> = one launch per panel: trailing (panel) update of the factorisation + factorisation of the next diagonal "
+                     "block + substitution of the next panel behind it (dense/ldlt_no_pivot.hpp:313-354, Eigen::LLT at dense/kkt.hpp:82); hipEvent-bracketed per "
+                     "launch in a separate pass of the same steps", flops_upd, upd_s, upd_launches, "panel_update")
         dominant, secondary = (r_upd, r_asm) if upd_s >= asm_s else (r_asm, r_upd)
         out = {
             "metric": "KKT factor+solve/sec (per IPM iter)",
