@@ -577,6 +577,86 @@ void analyse_kkt(const pq_sparse_data* d, int mode, Symbolic& S)
 // everything that follows from a fill-reducing ordering perm0 (perm0[new] = old) of K
 // forced_first != nullptr: perm0 is already a postorder of its elimination tree and the supernode partition is given (second pass of
 // the leaf amalgamation below)
+// Bounded fan-in of the assembly tree.  A supernode with very many children (the arrow of a QP with a few dense rows: MM BOYD1 has
+// 93 247 single-column leaves under one 18-column root) makes its parent's extend-add -- and the gather of the forward substitution --
+// a serial loop over all of them: 67 ms per factorisation where the arithmetic is 5 MFLOP.  Consecutive children are therefore grouped,
+// `fanin` at a time, under ACCUMULATOR supernodes without pivot columns (w = 0): their front is the union of the members' update rows (a subset
+// of the parent's front), their "factorisation" is the extend-add alone and their update matrix is the whole front.  The kernels need
+// nothing new -- every loop over pivots is empty -- and a group of small leaves becomes one workgroup's subtree walk.  Accumulators sit right
+// behind their last member, so the numbering stays a postorder with contiguous subtrees; repeated until no fan-in exceeds the bound.
+// The partial sums change the order in which a parent receives its children's contributions (fixed, so still reproducible).
+static void insert_accumulators(Symbolic& S, int N, int fanin)
+{
+    for (int pass = 0; pass < 8; ++pass) {
+        const int ns = S.nsuper;
+        IVec cptr(ns + 1, 0);
+        for (int s = 0; s < ns; ++s) if (S.sn_parent[s] >= 0) cptr[S.sn_parent[s] + 1]++;
+        for (int s = 0; s < ns; ++s) cptr[s + 1] += cptr[s];
+        IVec ch(cptr[ns], 0);
+        {
+            IVec nx(cptr.begin(), cptr.end() - 1);
+            for (int s = 0; s < ns; ++s) if (S.sn_parent[s] >= 0) ch[nx[S.sn_parent[s]]++] = s;
+        }
+        struct Acc { int parent; int lo, hi; };  // members ch[lo .. hi)
+        std::vector<Acc> acc;
+        IVec after(ns, -1), under(ns, -1);
+        for (int p2 = 0; p2 < ns; ++p2) {
+            const int nc = cptr[p2 + 1] - cptr[p2];
+            if (nc <= fanin) continue;
+            for (int g0 = 0; g0 < nc; g0 += fanin) {
+                const int cnt = std::min(fanin, nc - g0);
+                if (cnt < 2) continue;
+                const int lo = cptr[p2] + g0;
+                after[ch[lo + cnt - 1]] = (int)acc.size();
+                for (int q = lo; q < lo + cnt; ++q) under[ch[q]] = (int)acc.size();
+                acc.push_back({p2, lo, lo + cnt});
+            }
+        }
+        if (acc.empty()) return;
+        const int nn = ns + (int)acc.size();
+        IVec newid(ns), accid(acc.size());
+        {
+            int t = 0;
+            for (int s = 0; s < ns; ++s) { newid[s] = t++; if (after[s] >= 0) accid[after[s]] = t++; }
+        }
+        IVec first(nn + 1, N), parent(nn, -1), nind(nn, 1), rptr(nn + 1, 0);
+        std::vector<IVec> rows(nn);
+        for (int s = 0; s < ns; ++s) {
+            const int t = newid[s];
+            first[t] = S.sn_first[s];
+            rows[t].assign(S.front_rows.begin() + S.front_rows_ptr[s], S.front_rows.begin() + S.front_rows_ptr[s + 1]);
+            nind[t] = S.sn_nind[s];
+            parent[t] = under[s] >= 0 ? accid[under[s]] : (S.sn_parent[s] >= 0 ? newid[S.sn_parent[s]] : -1);
+        }
+        for (size_t a = 0; a < acc.size(); ++a) {
+            const int t = accid[a];
+            const int last_member = ch[acc[a].hi - 1];
+            first[t] = S.sn_first[last_member + 1];  // no columns of its own: [first, first)
+            parent[t] = newid[acc[a].parent];
+            IVec& r = rows[t];
+            for (int q = acc[a].lo; q < acc[a].hi; ++q) {
+                const int c = ch[q];
+                const int w = S.sn_first[c + 1] - S.sn_first[c];
+                r.insert(r.end(), S.front_rows.begin() + S.front_rows_ptr[c] + w, S.front_rows.begin() + S.front_rows_ptr[c + 1]);
+            }
+            std::sort(r.begin(), r.end());
+            r.erase(std::unique(r.begin(), r.end()), r.end());
+        }
+        first[nn] = N;
+        S.front_off.assign(nn + 1, 0);
+        for (int t = 0; t < nn; ++t) {
+            rptr[t + 1] = rptr[t] + (int)rows[t].size();
+            S.front_off[t + 1] = S.front_off[t] + (long long)rows[t].size() * (long long)rows[t].size();
+        }
+        S.front_rows.assign(rptr[nn], 0);
+        for (int t = 0; t < nn; ++t) std::copy(rows[t].begin(), rows[t].end(), S.front_rows.begin() + rptr[t]);
+        for (int j = 0; j < N; ++j) S.sn_of_col[j] = newid[S.sn_of_col[j]];
+        S.sn_first = first; S.sn_parent = parent; S.sn_nind = nind; S.front_rows_ptr = rptr;
+        S.nsuper = nn;
+        S.front_doubles = S.front_off[nn];
+    }
+}
+
 static void analyse_with_order(Symbolic& S, const IVec& perm0, const IVec* forced_first)
 {
     const int N = S.N;
@@ -659,7 +739,7 @@ static void analyse_with_order(Symbolic& S, const IVec& perm0, const IVec* force
     }
     S.nsuper = (int)S.sn_first.size();
     S.sn_first.push_back(N);
-    const int ns = S.nsuper;
+    int ns = S.nsuper;  // (grows when accumulator supernodes are inserted below)
     S.sn_parent.assign(ns, -1);
     S.sn_nind.assign(ns, 1);
     S.front_rows_ptr.assign(ns + 1, 0);
@@ -780,6 +860,20 @@ static void analyse_with_order(Symbolic& S, const IVec& perm0, const IVec* force
                 }
             }
             if ((int)perm1.size() == N) { analyse_with_order(S, perm1, &first1); return; }
+        }
+    }
+    if (!debug_token("no_accumulators")) {
+        const int before = S.nsuper;
+        insert_accumulators(S, N, 64);
+        if (S.nsuper != before) {  // children lists of the extended tree
+            const int nn = S.nsuper;
+            S.child_ptr.assign(nn + 1, 0);
+            for (int s2 = 0; s2 < nn; ++s2) if (S.sn_parent[s2] >= 0) S.child_ptr[S.sn_parent[s2] + 1]++;
+            for (int s2 = 0; s2 < nn; ++s2) S.child_ptr[s2 + 1] += S.child_ptr[s2];
+            S.child.assign(S.child_ptr[nn], 0);
+            IVec nx(S.child_ptr.begin(), S.child_ptr.end() - 1);
+            for (int s2 = 0; s2 < nn; ++s2) if (S.sn_parent[s2] >= 0) S.child[nx[S.sn_parent[s2]]++] = s2;
+            ns = nn;
         }
     }
     if (debug_token("sn_stats")) {

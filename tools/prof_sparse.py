@@ -29,13 +29,20 @@ def main():
     ap.add_argument("--n", type=int, default=50000)
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--no-oracle", action="store_true")
+    ap.add_argument("--fixture", default=None, help="a frozen problem of tests/golden instead of the C3 generator, e.g. mm_BOYD1")
     args = ap.parse_args()
     import torch  # noqa: F401
     import piqp_amd as hip
     from qp_gen import random_vars
     scale = args.n / 50000.0
-    a, (n, p, m) = c3_problem(args.n, int(20000 * scale), int(30000 * scale))
-    nnzK = sp.triu(a[0]).nnz + a[2].nnz + p + a[4].nnz + m
+    if args.fixture:
+        from qp_io import load_qp
+        q = load_qp(args.fixture)
+        a = (q["P"], q["c"], q["A"], q["b"], q["G"], q["h_l"], q["h_u"], q["x_l"], q["x_u"])
+        n, p, m = q["P"].shape[0], (0 if q["A"] is None else q["A"].shape[0]), (0 if q["G"] is None else q["G"].shape[0])
+    else:
+        a, (n, p, m) = c3_problem(args.n, int(20000 * scale), int(30000 * scale))
+    nnzK = sp.triu(a[0]).nnz + (a[2].nnz if a[2] is not None else 0) + p + (a[4].nnz if a[4] is not None else 0) + m
     t0 = time.perf_counter()
     d = hip.SparseData(*a)
     k = hip.KKTSystem(d, hip.default_settings(kkt_solver=hip.SPARSE_LDLT))
