@@ -26,15 +26,38 @@ __global__ void k_gather_values(int nnz, const int* __restrict__ src_idx, const 
 }
 
 // y[j] = (ACC ? y[j] : 0) + alpha * sum_q val[q] * x[row[q]] over column j  (CSC column dot; thread per column)
+constexpr int SPMV_LONG_COL = 2048;  // columns with more entries than this are summed by a whole workgroup (k_spmv_long_cols)
 template <bool ACC>
 __global__ void k_spmv_cols(int ncols, const int* __restrict__ colptr, const int* __restrict__ rowind, const double* __restrict__ val, const double* __restrict__ x,
                             double alpha, double* __restrict__ y)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= ncols) return;
+    const int lo = colptr[j], hi = colptr[j + 1];
+    if (hi - lo > SPMV_LONG_COL) return;
     double s = 0.0;
-    for (int q = colptr[j]; q < colptr[j + 1]; ++q) s += val[q] * x[rowind[q]];
+    for (int q = lo; q < hi; ++q) s += val[q] * x[rowind[q]];
     y[j] = ACC ? y[j] + alpha * s : alpha * s;
+}
+// A column with very many entries (a dense row of A seen from its transpose copy: MM BOYD1 has 18 of 93 261 entries each) costs a thread-per-
+// column kernel a serial loop -- 1.15 ms per mat-vec there.  One workgroup per such column: thread t sums the entries t, t + 256, ... in
+// order, the 256 partial sums are added pairwise in a fixed tree.  Reproducible; not the left-to-right sum of the short columns.
+template <bool ACC>
+__global__ __launch_bounds__(256) void k_spmv_long_cols(const int* __restrict__ cols, const int* __restrict__ colptr, const int* __restrict__ rowind,
+                                                        const double* __restrict__ val, const double* __restrict__ x, double alpha, double* __restrict__ y)
+{
+    __shared__ double part[256];
+    const int j = cols[blockIdx.x], t = threadIdx.x;
+    const int lo = colptr[j], hi = colptr[j + 1];
+    double s = 0.0;
+    for (int q = lo + t; q < hi; q += 256) s += val[q] * x[rowind[q]];
+    part[t] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (t < w) part[t] += part[t + w];
+        __syncthreads();
+    }
+    if (t == 0) y[j] = ACC ? y[j] + alpha * part[0] : alpha * part[0];
 }
 
 // out[j] = rhs_x[j] + sum_{G rows i of column j} G(i,j) zinv[i] rhs_z[i] + delta_inv * sum_{A rows i} A(i,j) rhs_y[i]
@@ -130,6 +153,20 @@ void CscOperators::init(const pq_sparse_data* d, hipStream_t st)
         transpose_with_map(n_, m_, gtp.data(), gti.data(), tp, ti, tm);
         upload_vec(G_p_, tp, st); upload_vec(G_i_, ti, st); upload_vec(G_src_, tm, st); G_x_.alloc(nzG_ ? nzG_ : 1);
     }
+    // columns a single thread should not sum alone (k_spmv_long_cols)
+    {
+        auto longs = [&](const DBuf<int>& cp, int ncols, DBuf<int>& out, int& cnt) {
+            std::vector<int> h(ncols + 1, 0), l;
+            if (ncols > 0) PQ_HIP(hipMemcpy(h.data(), cp.p, sizeof(int) * (ncols + 1), hipMemcpyDeviceToHost));
+            for (int j = 0; j < ncols; ++j) if (h[j + 1] - h[j] > SPMV_LONG_COL) l.push_back(j);
+            cnt = (int)l.size();
+            if (l.empty()) l.push_back(0);
+            upload_vec(out, l, st);
+        };
+        PQ_HIP(hipStreamSynchronize(st));
+        longs(Pf_p_, n_, long_Pf_, nlong_[0]); longs(AT_p_, p_, long_AT_, nlong_[1]); longs(A_p_, n_, long_A_, nlong_[2]);
+        longs(GT_p_, m_, long_GT_, nlong_[3]); longs(G_p_, n_, long_G_, nlong_[4]);
+    }
     upload_values(d, st);
 }
 
@@ -163,21 +200,32 @@ void CscOperators::clone_from(const CscOperators& o, hipStream_t st)
     cpd(P_x_, o.P_x_); cpd(Pf_x_, o.Pf_x_); cpd(AT_x_, o.AT_x_); cpd(A_x_, o.A_x_); cpd(GT_x_, o.GT_x_); cpd(G_x_, o.G_x_); cpd(Pdiag_, o.Pdiag_);
     cpi(Pf_p_, o.Pf_p_); cpi(Pf_i_, o.Pf_i_); cpi(Pf_src_, o.Pf_src_); cpi(AT_p_, o.AT_p_); cpi(AT_i_, o.AT_i_); cpi(A_p_, o.A_p_); cpi(A_i_, o.A_i_);
     cpi(A_src_, o.A_src_); cpi(GT_p_, o.GT_p_); cpi(GT_i_, o.GT_i_); cpi(G_p_, o.G_p_); cpi(G_i_, o.G_i_); cpi(G_src_, o.G_src_);
+    cpi(long_Pf_, o.long_Pf_); cpi(long_AT_, o.long_AT_); cpi(long_A_, o.long_A_); cpi(long_GT_, o.long_GT_); cpi(long_G_, o.long_G_);
+    for (int q = 0; q < 5; ++q) nlong_[q] = o.nlong_[q];
+}
+
+template <bool ACC>
+static void spmv(int ncols, const DBuf<int>& cp, const DBuf<int>& ri, const DBuf<double>& v, const DBuf<int>& long_cols, int nlong, const double* x, double alpha, double* y,
+                 hipStream_t st)
+{
+    if (ncols <= 0) return;
+    hipLaunchKernelGGL(k_spmv_cols<ACC>, g1(ncols), dim3(256), 0, st, ncols, cp.p, ri.p, v.p, x, alpha, y);
+    if (nlong > 0) hipLaunchKernelGGL(k_spmv_long_cols<ACC>, dim3(nlong), dim3(256), 0, st, long_cols.p, cp.p, ri.p, v.p, x, alpha, y);
 }
 
 void CscOperators::eval_P_x(double alpha, const double* x, double* z, hipStream_t st) const
 {
-    hipLaunchKernelGGL(k_spmv_cols<false>, g1(n_), dim3(256), 0, st, n_, Pf_p_.p, Pf_i_.p, Pf_x_.p, x, alpha, z);
+    spmv<false>(n_, Pf_p_, Pf_i_, Pf_x_, long_Pf_, nlong_[0], x, alpha, z, st);
 }
 void CscOperators::eval_A_xn_and_AT_xt(double an, double at, const double* xn, const double* xt, double* zn, double* zt, hipStream_t st) const
 {
-    if (p_ > 0) hipLaunchKernelGGL(k_spmv_cols<false>, g1(p_), dim3(256), 0, st, p_, AT_p_.p, AT_i_.p, AT_x_.p, xn, an, zn);  // A x = (AT)^T x
-    hipLaunchKernelGGL(k_spmv_cols<false>, g1(n_), dim3(256), 0, st, n_, A_p_.p, A_i_.p, A_x_.p, xt, at, zt);                   // AT y = (A)^T y
+    spmv<false>(p_, AT_p_, AT_i_, AT_x_, long_AT_, nlong_[1], xn, an, zn, st);  // A x = (AT)^T x
+    spmv<false>(n_, A_p_, A_i_, A_x_, long_A_, nlong_[2], xt, at, zt, st);       // AT y = (A)^T y
 }
 void CscOperators::eval_G_xn_and_GT_xt(double an, double at, const double* xn, const double* xt, double* zn, double* zt, hipStream_t st) const
 {
-    if (m_ > 0) hipLaunchKernelGGL(k_spmv_cols<false>, g1(m_), dim3(256), 0, st, m_, GT_p_.p, GT_i_.p, GT_x_.p, xn, an, zn);
-    hipLaunchKernelGGL(k_spmv_cols<false>, g1(n_), dim3(256), 0, st, n_, G_p_.p, G_i_.p, G_x_.p, xt, at, zt);
+    spmv<false>(m_, GT_p_, GT_i_, GT_x_, long_GT_, nlong_[3], xn, an, zn, st);
+    spmv<false>(n_, G_p_, G_i_, G_x_, long_G_, nlong_[4], xt, at, zt, st);
 }
 void CscOperators::fold_rhs(const double* rhs_x, const double* rhs_y, const double* rhs_z, const double* zinv, double delta_inv, double* out, hipStream_t st, bool with_A,
                             bool with_G) const
@@ -194,11 +242,11 @@ void CscOperators::recover_duals(const double* x, const double* rhs_y, const dou
 }
 void CscOperators::add_AT_y(double alpha, const double* y, double* z, hipStream_t st) const
 {
-    if (p_ > 0) hipLaunchKernelGGL(k_spmv_cols<true>, g1(n_), dim3(256), 0, st, n_, A_p_.p, A_i_.p, A_x_.p, y, alpha, z);
+    if (p_ > 0) spmv<true>(n_, A_p_, A_i_, A_x_, long_A_, nlong_[2], y, alpha, z, st);
 }
 void CscOperators::add_GT_y(double alpha, const double* y, double* z, hipStream_t st) const
 {
-    if (m_ > 0) hipLaunchKernelGGL(k_spmv_cols<true>, g1(n_), dim3(256), 0, st, n_, G_p_.p, G_i_.p, G_x_.p, y, alpha, z);
+    if (m_ > 0) spmv<true>(n_, G_p_, G_i_, G_x_, long_G_, nlong_[4], y, alpha, z, st);
 }
 
 }  // namespace pq

@@ -60,6 +60,8 @@ private:
     int n_ = 0, p_ = 0, m_ = 0, nzP_ = 0, nzA_ = 0, nzG_ = 0, nzPf_ = 0;
     DBuf<double> P_x_, Pf_x_, AT_x_, A_x_, GT_x_, G_x_, Pdiag_;
     DBuf<int> Pf_p_, Pf_i_, Pf_src_, AT_p_, AT_i_, A_p_, A_i_, A_src_, GT_p_, GT_i_, G_p_, G_i_, G_src_;
+    DBuf<int> long_Pf_, long_AT_, long_A_, long_GT_, long_G_;  // columns with more than SPMV_LONG_COL entries, per copy
+    int nlong_[5] = {0, 0, 0, 0, 0};
 };
 
 // generic value movers shared by the sparse backends
