@@ -375,23 +375,15 @@ __device__ __forceinline__ void factor_chain_wave(const Meta& M, global_cdouble*
                 const double inv = d > 0.0 ? rsqrt_newton(d) : 0.0;
                 invs[j] = inv;
                 if (c == j) f = r == j ? d * inv : (r > j ? f * inv : f);
-                double a = 0.0, bb = 0.0;
-                for (int k = j + 1; k < h; ++k) {
-                    const double v = lane_bcast(f, k + j * h);
-                    a = r == k ? v : a;
-                    bb = c == k ? v : bb;
-                }
+                // L[r][j] and L[c][j] for the entry (r, c) this lane holds: two cross-lane permutes (a v_readlane loop over the rows of column j
+                // cost 15 instructions per row, and the kernel is bound by instruction issue at four waves per SIMD)
+                const double a = __shfl(f, r + j * h), bb = __shfl(f, c + j * h);
                 if (c > j && c < w && r >= c) f -= a * bb;
             }
         }
         // ---- Schur complement of the panel: lanes (r >= w, c >= w, r >= c) ----
         for (int k = 0; k < w; ++k) {
-            double a = 0.0, bb = 0.0;
-            for (int t = w; t < h; ++t) {
-                const double v = lane_bcast(f, t + k * h);
-                a = r == t ? v : a;
-                bb = c == t ? v : bb;
-            }
+            const double a = __shfl(f, r + k * h), bb = __shfl(f, c + k * h);
             if (r >= w && c >= w && r >= c) f -= a * bb;
         }
         // ---- Linv: lane j < w builds column j of L^{-1} in registers (1/L_kk = invs[k]: no divisions) ----
@@ -439,16 +431,21 @@ __device__ __forceinline__ void solve_chain_wave(const Meta& M, const double* __
         const int u = h - w, offb = __builtin_amdgcn_readfirstlane(M.Off(b)), start = __builtin_amdgcn_readfirstlane(M.Start(b));
         const double* Li = pan + uni(M.PanOff(b));
         const double* Q = Li + w * w;
+        // lanes < w: y_b = Linv x_b; lanes w .. h - 1: x_next -= Q x_b -- ONE loop for both (the stored Linv has exact zeros above its diagonal, so the
+        // row sum may run over all w columns; two divergent loops were issued one after the other)
         double acc = 0.0;
         int tgt = -1;
-        if (lane < w) {  // y_b = Linv x_b
-            for (int k = 0; k <= lane; ++k) acc += Li[lane + k * w] * x[start + k];
-            tgt = start + lane;
-        } else if (lane < h) {  // x_next -= Q x_b
-            const int t = lane - w;
-            tgt = t < offb ? start + w + t : n - arrow + (t - offb);
-            acc = x[tgt];
-            for (int k = 0; k < w; ++k) acc -= Q[t + k * u] * x[start + k];
+        const bool top = lane < w;
+        const int t = lane - w;
+        const double* cf = top ? Li + lane : Q + (lane < h ? t : 0);
+        const int cs = top ? w : u;
+        if (top) tgt = start + lane;
+        else if (lane < h) { tgt = t < offb ? start + w + t : n - arrow + (t - offb); acc = x[tgt]; }
+        if (lane < h) {
+            for (int k = 0; k < w; ++k) {
+                const double cv = cf[k * cs];
+                acc += (top ? cv : -cv) * x[start + k];
+            }
         }
         wave_lds_sync();  // every read of x_b above has returned before any lane overwrites it
         if (tgt >= 0) x[tgt] = acc;
