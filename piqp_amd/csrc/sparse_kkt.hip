@@ -187,7 +187,7 @@ __device__ __forceinline__ void schur_2x2(double* __restrict__ W, int f, int w, 
 }
 
 // extend-add of every child's update matrix into front s (fixed child order)
-__device__ void extend_add(const FrontMeta& M, double* __restrict__ fronts, int s, double* __restrict__ F, int f)
+__device__ __forceinline__ void extend_add(const FrontMeta& M, double* __restrict__ fronts, int s, double* __restrict__ F, int f)
 {
     const SnRec me = M.sn[s];
     for (int ci = me.child_lo; ci < me.child_hi; ++ci) {
@@ -213,24 +213,29 @@ __device__ void extend_add(const FrontMeta& M, double* __restrict__ fronts, int 
 // zero + the K entries the front owns: needs nothing from the children, so the persistent top kernel runs it while they are still busy
 __device__ __forceinline__ void front_assemble_own(const FrontMeta& M, double* __restrict__ fronts, const SnRec& me, double* __restrict__ lds)
 {
+    // (two copies of the loops instead of one pointer chosen at run time: a pointer that may be LDS or HBM compiles to FLAT accesses)
     const int f = me.f;
-    double* W = (long long)f * f <= LDS_FRONT_DOUBLES ? lds : fronts + me.front_off;
-    for (int idx = threadIdx.x; idx < f * f; idx += blockDim.x) W[idx] = 0.0;
-    __syncthreads();
-    for (int e = me.fe_lo + threadIdx.x; e < me.fe_hi; e += blockDim.x) W[M.fe_off[e]] = M.vals[e];
+    if ((long long)f * f <= LDS_FRONT_DOUBLES) {
+        for (int idx = threadIdx.x; idx < f * f; idx += blockDim.x) lds[idx] = 0.0;
+        __syncthreads();
+        for (int e = me.fe_lo + threadIdx.x; e < me.fe_hi; e += blockDim.x) lds[M.fe_off[e]] = M.vals[e];
+    } else {
+        double* W = fronts + me.front_off;
+        for (int idx = threadIdx.x; idx < f * f; idx += blockDim.x) W[idx] = 0.0;
+        __syncthreads();
+        for (int e = me.fe_lo + threadIdx.x; e < me.fe_hi; e += blockDim.x) W[M.fe_off[e]] = M.vals[e];
+    }
     __syncthreads();
 }
-__device__ void front_factor(const FrontMeta& M, double* __restrict__ fronts, int s, int big_front, int big_pivots, double* __restrict__ rdiag, int* __restrict__ info,
-                             double* __restrict__ lds, bool own_assembled = false)
+// IN_LDS: the front is worked on in LDS (W == lds) and copied out at the end; otherwise in place in HBM (W == F).  Two instantiations instead of
+// one pointer chosen at run time -- such a pointer compiles to FLAT loads / stores (k_front_factor had 20 + 10 of them in its pivot loops).
+template <bool IN_LDS>
+__device__ __forceinline__ void front_factor_body(const FrontMeta& M, double* __restrict__ fronts, int s, const SnRec& me, double* __restrict__ rdiag,
+                                                  int* __restrict__ info, double* __restrict__ lds, double* __restrict__ W)
 {
-    const SnRec me = M.sn[s];
     const int first = me.first, w = me.w, f = me.f;
-    if (f >= big_front && w >= big_pivots) return;  // handled by the dense path
     double* F = fronts + me.front_off;
-    const bool in_lds = (long long)f * f <= LDS_FRONT_DOUBLES;
-    double* W = in_lds ? lds : F;
-    // assembly: zero, own K entries, then the children's update matrices (fixed order)
-    if (!own_assembled) front_assemble_own(M, fronts, me, lds);
+    constexpr bool in_lds = IN_LDS;
     extend_add(M, fronts, s, W, f);
     // ---- panel: right-looking LDLt of the first w columns, updates confined to the panel (rows k+1..f-1, columns k+1..w-1)
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -305,6 +310,18 @@ __device__ void front_factor(const FrontMeta& M, double* __restrict__ fronts, in
         for (int j = w + ty; j < f; j += tys)
             for (int i = j + tx; i < f; i += 16) F[i + (long long)j * f] = lds[i + j * f];
     }
+}
+
+__device__ __forceinline__ void front_factor(const FrontMeta& M, double* __restrict__ fronts, int s, int big_front, int big_pivots, double* __restrict__ rdiag,
+                                             int* __restrict__ info, double* __restrict__ lds, bool own_assembled = false)
+{
+    const SnRec me = M.sn[s];
+    const int w = me.w, f = me.f;
+    if (f >= big_front && w >= big_pivots) return;  // handled by the dense path
+    // assembly: zero, own K entries, then the children's update matrices (fixed order)
+    if (!own_assembled) front_assemble_own(M, fronts, me, lds);
+    if ((long long)f * f <= LDS_FRONT_DOUBLES) front_factor_body<true>(M, fronts, s, me, rdiag, info, lds, lds);
+    else front_factor_body<false>(M, fronts, s, me, rdiag, info, lds, fronts + me.front_off);
 }
 
 // one workgroup per front of an assembly-tree level
