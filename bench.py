@@ -250,12 +250,19 @@ def main():
     else:
         out = None
     # second half of BASELINE.json's metric ("QP solves/sec at 1/2/4/8 GPUs"): the batched sparse_multistage leg
+    # (the secondary legs must never cost the run its JSON line: a failure is reported in place of the leg)
     if args.batch_total > 0:
-        bq = batched_qp(args, rank, world, local_rank, dev, pd)
+        try:
+            bq = batched_qp(args, rank, world, local_rank, dev, pd)
+        except Exception as e:  # noqa: BLE001
+            bq = {"error": f"{type(e).__name__}: {e}"}
         if rank == 0:
             out["batched_qp"] = bq
     if not args.no_sparse_legs:
-        sl = sparse_legs(args, rank, world, local_rank, dev, pd)
+        try:
+            sl = sparse_legs(args, rank, world, local_rank, dev, pd)
+        except Exception as e:  # noqa: BLE001
+            sl = {"error": f"{type(e).__name__}: {e}"}
         if rank == 0:
             out["sparse_kkt"] = sl
     if c5_child is not None:
