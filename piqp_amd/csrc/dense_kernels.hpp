@@ -44,7 +44,6 @@ struct SyrkArgs {
     int fuse_token = 0;             // launch-unique value the helpers publish in fuse_flags[role]
     int* fuse_flags = nullptr;      // >= 9 ints (one per helper role)
     double* fuse_scratch = nullptr; // 36 x 256 doubles: the helpers' tile blocks on their way to the owner's LDS
-    int pair_tiles = 0;             // set by the launcher: the bulk tiles of the fused launch go two per workgroup (fused_tile_pair)
     int* fuse_cnt = nullptr;        // 8 monotonic counters: what potrf_block has published of its step k (see there); non-null = the workgroups of the first
                                     // tile column solve the next panel in this launch, following the factorisation of the diagonal block
     double* fuse_w16 = nullptr;   // inverted 16 x 16 diagonal pieces of the next diagonal block (8 x 256 doubles), kept for the sweeps; nullable
