@@ -223,12 +223,67 @@ __global__ __launch_bounds__(64 * WR * WC, (WR * WC == 4) ? 2 : (WR * WC == 8 ? 
             }
     }
 
+    const bool dbg_tile = (EPI == EPI_SUBTRACT_POTRF) && a.fuse_ts && threadIdx.x == 0 && ti == 2 && tj == 1;  // debugging aid: an ordinary tile's timeline
+    if (dbg_tile) a.fuse_ts[84] = clock64();
     const int nkt_all = (a.kdim + BK - 1) / BK;
     const int kt_per = (nkt_all + a.k_split - 1) / a.k_split;
     const int kt_begin = kslice * kt_per;
     const int nkt = max(0, min(nkt_all, kt_begin + kt_per) - kt_begin);
+    if constexpr (EPI == EPI_SUBTRACT_POTRF) {
+        // K <= 128 here: eight operand stages at most.  ALL of them are requested at once, into registers (2 x 8 x 2 double2 per thread), before
+        // anything else waits: with one 147 KB-LDS workgroup per CU nothing else hides a stage's load latency, and the generic loop below --
+        // stage t + 1 requested while stage t is multiplied -- spent 2.9 us per 16-column stage, 23 us per tile, for 4 us of matrix-core work
+        // (in-kernel stamps of an ordinary tile).  The stages then arrive back to back; only the first one's latency is exposed.
+        constexpr int PER = 1024 / NT;
+        d2 pa[8][PER], pb[8][PER];
+#pragma unroll
+        for (int kt = 0; kt < 8; ++kt) {
+            if (kt < nkt) {
+                const int k0 = kt * BK;
+                if (edge || (k0 + BK > a.kdim)) { load_tile<true, NT>(a.A, a.lda, row0, k0, a.n, a.kdim, tid, pa[kt]); load_tile<true, NT>(a.B, a.ldb, col0, k0, a.n, a.kdim, tid, pb[kt]); }
+                else { load_tile<false, NT>(a.A, a.lda, row0, k0, a.n, a.kdim, tid, pa[kt]); load_tile<false, NT>(a.B, a.ldb, col0, k0, a.n, a.kdim, tid, pb[kt]); }
+            }
+        }
+        if (nkt > 0) {
+            scale_tile<true, NT, true>(a.w, 0, a.kdim, tid, pb[0]);
+            store_tile<NT>(As, tid, pa[0]);
+            store_tile<NT>(Bs, tid, pb[0]);
+        }
+        __syncthreads();
+        if (dbg_tile) a.fuse_ts[85] = clock64();  // first operand stage in LDS
+#pragma unroll
+        for (int kt = 0; kt < 8; ++kt) {
+            if (kt < nkt) {
+                const int cur = kt & 1;
+                if (kt + 1 < 8 && kt + 1 < nkt) {  // the other LDS buffer was last read before the previous barrier
+                    scale_tile<true, NT, true>(a.w, (kt + 1) * BK, a.kdim, tid, pb[(kt + 1) & 7]);
+                    store_tile<NT>(As + (cur ^ 1) * BK * LDS_LD, tid, pa[(kt + 1) & 7]);
+                    store_tile<NT>(Bs + (cur ^ 1) * BK * LDS_LD, tid, pb[(kt + 1) & 7]);
+                }
+                if (!skip_wave) {
+                    const double* Asb = As + cur * BK * LDS_LD + wr * SUBR + (lane & 15);
+                    const double* Bsb = Bs + cur * BK * LDS_LD + wc * SUBC + (lane & 15);
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        const int kk = ks * 4 + (lane >> 4);
+                        double af[MTR], bf[MTC];
+#pragma unroll
+                        for (int q = 0; q < MTR; ++q) af[q] = Asb[kk * LDS_LD + q * 16];
+#pragma unroll
+                        for (int q = 0; q < MTC; ++q) bf[q] = Bsb[kk * LDS_LD + q * 16];
+#pragma unroll
+                        for (int x = 0; x < MTC; ++x)
+#pragma unroll
+                            for (int y = 0; y < MTR; ++y)
+                                acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[x], af[y], acc[x][y], 0, 0, 0);
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    }
     d2 va[1024 / NT], vb[1024 / NT];
-    if (nkt > 0) {
+    if (EPI != EPI_SUBTRACT_POTRF && nkt > 0) {
         const int k0 = kt_begin * BK;
         const bool chk = edge || (k0 + BK > a.kdim);
         if (chk) { load_tile<true, NT>(a.A, a.lda, row0, k0, a.n, a.kdim, tid, va); load_tile<true, NT>(a.B, a.ldb, col0, k0, a.n, a.kdim, tid, vb); scale_tile<true, NT, NEGB>(a.w, k0, a.kdim, tid, vb); }
@@ -236,9 +291,9 @@ __global__ __launch_bounds__(64 * WR * WC, (WR * WC == 4) ? 2 : (WR * WC == 8 ? 
         store_tile<NT>(As, tid, va);
         store_tile<NT>(Bs, tid, vb);
     }
-    __syncthreads();
+    if (EPI != EPI_SUBTRACT_POTRF) __syncthreads();
 
-    for (int kt = 0; kt < nkt; ++kt) {
+    for (int kt = 0; kt < (EPI == EPI_SUBTRACT_POTRF ? 0 : nkt); ++kt) {
         const int cur = kt & 1;
         const bool more = (kt + 1 < nkt);
         if (more) {
@@ -272,6 +327,7 @@ __global__ __launch_bounds__(64 * WR * WC, (WR * WC == 4) ? 2 : (WR * WC == 8 ? 
         __syncthreads();
     }
 
+    if (dbg_tile) a.fuse_ts[86] = clock64();  // K loop done (the accumulators' first use waited for C)
     if constexpr (EPI == EPI_SUBTRACT_POTRF) {
         if (a.fuse_cnt && tj == 0 && a.fuse_pack) { panel_follow<NT, MTC, MTR>(a, smem, acc, row0, wr, wc); return; }
     }
@@ -316,6 +372,7 @@ __global__ __launch_bounds__(64 * WR * WC, (WR * WC == 4) ? 2 : (WR * WC == 8 ? 
             }
         }
     }
+    if (dbg_tile) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); a.fuse_ts[87] = clock64(); }  // stores drained
 }
 
 // sums the K-slices of a split tile in slice order and applies the epilogue (one workgroup per tile)

@@ -273,6 +273,8 @@ private:
         std::fprintf(stderr, "; potrf_block end %lld\n[piqp_amd]   first panel workgroup: tile in registers %lld, step k operands seen:", h[3] - h[0], h[80] - h[0]);
         for (int k = 0; k < 8; ++k) std::fprintf(stderr, " %lld", h[72 + k] - h[0]);
         std::fprintf(stderr, ", panel stored %lld\n", h[81] - h[0]);
+        std::fprintf(stderr, "[piqp_amd]   an ordinary tile (2, 1): first operand stage in LDS %lld, K loop (incl. the wait for C) %lld, stores drained %lld cycles\n", h[85] - h[84], h[86] - h[85],
+                     h[87] - h[86]);
     }
     // llt.info() == Success (dense/kkt.hpp:83): one 4-byte read-back per factor call
     bool factor_status()
