@@ -325,14 +325,25 @@ void nd_order(int n, const int* Ap, const int* Ai, int* perm, int leaf)
         // connected component of the first node
         int cnt = 0;
         bfs(it.nodes[0], pid, cnt);
-        if (cnt < (int)it.nodes.size()) {  // disconnected: split off this component, revisit the rest
-            Item comp, rest;
-            comp.part = next_part++; comp.is_sep = false; rest.part = pid; rest.is_sep = false;
-            for (int q = 0; q < cnt; ++q) { comp.nodes.push_back(queue[q]); part[queue[q]] = comp.part; }
-            for (int v : it.nodes) if (part[v] == pid) rest.nodes.push_back(v);
-            for (int q = 0; q < cnt; ++q) level[queue[q]] = -1;
-            stack.push_back(std::move(rest));
-            stack.push_back(std::move(comp));
+        if (cnt < (int)it.nodes.size()) {
+            // disconnected: ALL components of the part in one sweep, numbered in the order of their first node (splitting off one component and
+            // revisiting "the rest" is quadratic in the number of components: the 93 261 isolated variables that remain of MM BOYD1 once its 18
+            // dense rows are set aside took 10 s)
+            std::vector<Item> comps;
+            auto take = [&](int count) {
+                Item comp; comp.part = next_part++; comp.is_sep = false;
+                comp.nodes.assign(queue.begin(), queue.begin() + count);
+                for (int q = 0; q < count; ++q) { part[queue[q]] = comp.part; level[queue[q]] = -1; }
+                comps.push_back(std::move(comp));
+            };
+            take(cnt);
+            for (int v : it.nodes) {
+                if (part[v] != pid) continue;
+                int c2 = 0;
+                bfs(v, pid, c2);
+                take(c2);
+            }
+            for (size_t q = comps.size(); q-- > 0;) stack.push_back(std::move(comps[q]));  // popped in the order found
             continue;
         }
         // pseudo-peripheral root: restart from a node of the last level while the structure gets deeper
