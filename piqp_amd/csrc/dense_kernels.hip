@@ -4,8 +4,10 @@
 //   dense/kkt.hpp:140-160  update_kkt       -> k_syrk_lower<EPI_ASSEMBLE>  (fp64 MFMA 16x16x4, LDS double-buffered)
 //   dense/kkt.hpp:53,68    AT_A = AT*AT^T   -> k_syrk_lower<EPI_STORE>
 //   Eigen::LLT::compute (dense/kkt.hpp:82) / LDLTNoPivot (dense/ldlt_no_pivot.hpp:313-354)
-//                                           -> potrf_block (k_potrf_diag / fused into k_syrk_lower<EPI_SUBTRACT_POTRF>) + k_trsm_panel
-//   llt.solveInPlace (dense/kkt.hpp:170) / ldlt_no_pivot.hpp:432-450 -> k_trsv_fwd_step / k_trsv_bwd_step
+//                                           -> ONE launch per panel, k_syrk_lower<EPI_SUBTRACT_POTRF>: trailing update + potrf_block of the next
+//                                              diagonal block (fused_next_diag) + panel_follow of the next panel; k_potrf_diag + k_trsm_panel
+//                                              only for the first panel
+//   llt.solveInPlace (dense/kkt.hpp:170) / ldlt_no_pivot.hpp:432-450 -> k_trsv_persistent (k_trsv_fwd_step / k_trsv_bwd_step: fallback)
 //   dense/kkt.hpp:94-104,112-131 GEMVs      -> k_gemv_n_partial + k_reduce_partials, k_gemv_t
 //
 // Layout: everything column-major fp64.  The product matrices GT (n x m) / AT (n x p) are stored as in

@@ -47,7 +47,8 @@ struct SyrkArgs {
     int* fuse_cnt = nullptr;        // 8 monotonic counters: what potrf_block has published of its step k (see there); non-null = the workgroups of the first
                                     // tile column solve the next panel in this launch, following the factorisation of the diagonal block
     double* fuse_w16 = nullptr;   // inverted 16 x 16 diagonal pieces of the next diagonal block (8 x 256 doubles), kept for the sweeps; nullable
-    long long* fuse_ts = nullptr; // debugging aid (PIQP_AMD_DBG_FUSED_TS): 72 shader-clock stamps of the workgroup that owns the next diagonal block  // operand pack of the next k_trsm_panel (FACTOR_PACK_DOUBLES), nullable
+    long long* fuse_ts = nullptr; // debugging aid (PIQP_AMD_DEBUG=fused_ts=<panel>): 96 clock stamps -- the workgroup that owns the next diagonal block, the first panel
+                                  // workgroup, an ordinary tile
 };
 
 void launch_syrk(int epi, const SyrkArgs& args, hipStream_t s, double* split_ws = nullptr, size_t split_ws_doubles = 0);

@@ -228,10 +228,10 @@ private:
     }
 
     // blocked right-looking factorisation of the lower triangle of fac_ (panel width 128): Eigen::LLT::compute (dense/kkt.hpp:82) or
-    // LDLTNoPivot::compute (dense/ldlt_no_pivot.hpp:313-354).  Two launches per panel: the panel solve below the diagonal block
-    // (k_trsm_panel) and the fused trailing update, whose first workgroup also factors the NEXT diagonal block (EPI_SUBTRACT_POTRF);
-    // only the first diagonal block has a launch of its own.  (A look-ahead variant on a second, CU-masked stream was measured slower in
-    // round 1 -- the cross-stream event latency exceeds the overlap: 4.1 -> 4.6 ms at n = 4096 -- and removed.)
+    // LDLTNoPivot::compute (dense/ldlt_no_pivot.hpp:313-354).  One launch per panel: the fused trailing update of panel k also factors the NEXT
+    // diagonal block (workgroups 0-8) and solves the NEXT panel behind it (the workgroups of the first tile column), EPI_SUBTRACT_POTRF; only the
+    // first diagonal block and the first panel have launches of their own.  (A look-ahead variant on a second, CU-masked stream was measured
+    // slower in round 1 -- the cross-stream event latency exceeds the overlap: 4.1 -> 4.6 ms at n = 4096 -- and removed.)
     void launch_factor_panels()
     {
         PQ_HIP(hipMemsetAsync(info_.p, 0xFF, sizeof(int), st_));  // -1
