@@ -344,8 +344,8 @@ def sparse_legs(args, rank, world, local_rank, dev, pd):
                 fac_s = r["factor_ms"] * 1e-3; sol_s = r["backend_solve_ms"] * 1e-3
                 r["symbolic"] = stt
                 traffic_f = traffic_s = None
-                try:  # rocprofv3 PMC passes of the C3 workload (profiles/r01_pmc_sparse_batch.json); other workloads: not measured
-                    pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_sparse_batch.json")))["sparse_c3"]
+                try:  # rocprofv3 PMC passes of the C3 workload (profiles/r02_pmc_sparse_batch.json); other workloads: not measured
+                    pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_sparse_batch.json")))["sparse_c3"]
                     if key == "C3" and abs(pmc["factor_per_launch"]["algorithmic_bytes"] - bytes_factor) < 0.05 * bytes_factor:
                         traffic_f = pmc["factor_per_launch"]["traffic_bytes"]; traffic_s = pmc["solve_per_launch"]["traffic_bytes"]
                 except Exception:  # noqa: BLE001
@@ -438,14 +438,14 @@ def batched_qp(args, rank, world, local_rank, dev, pd):
         traffic_b = None
         try:
             if total == 8192 and world == 1:
-                traffic_b = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_sparse_batch.json")))["batch_c4"]["per_launch"]["traffic_bytes"]
+                traffic_b = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_sparse_batch.json")))["batch_c4"]["per_launch"]["traffic_bytes"]
         except Exception:  # noqa: BLE001
             pass
         res["roofline"] = {"bound": "hbm", "kernel": "k_batch_ipm (one workgroup = one whole interior-point solve), hipEvent-bracketed",
                            "achieved": bytes_iter * its / kernel_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": bytes_iter * its / kernel_s / 1e9 / PEAK_HBM_GBS,
                            "traffic": traffic_b, "alg_bytes_per_qp_iteration": bytes_iter, "qp_iterations_in_launch": its, "avg_launch_ms": kernel_s * 1e3,
                            "note": "chain fronts and panels stay in LDS / registers; the measured traffic (PMC) is the per-instance vector arena streaming through L2 / "
-                                   "Infinity Cache in every vector phase -- a miss-latency bound, see profiles/r01_pmc_sparse_batch.json"}
+                                   "Infinity Cache in every vector phase -- a miss-latency bound, see profiles/r02_pmc_sparse_batch.json"}
     except Exception as e:  # noqa: BLE001
         res["roofline_error"] = str(e)
     if not args.no_cpu_baseline:
