@@ -7,7 +7,7 @@
 //     up-looking, serial over rows)                    per tree level k_front_factor (extend-add + partial dense LDLt,
 //                                                      one workgroup per front, LDS-resident when it fits); fronts
 //                                                      wider than BIG_FRONT go through the dense MFMA panel kernels
-//   lsolve/dsolve/ltsolve + perm/permt (ldlt:171-218)  k_perm_gather, per level k_front_fwd, k_scale, k_front_bwd, k_perm_scatter
+//   lsolve/dsolve/ltsolve + perm/permt (ldlt:171-218)  k_perm_gather, per level k_subtree_fwd_wave / k_front_fwd_wide, k_scale, k_front_bwd_wide / k_subtree_bwd_wave, k_perm_scatter
 //   eval_P_x / eval_A.. / eval_G.. (kkt.hpp:179-203)   k_spmv_cols on CSC copies (P symmetrised, A and G kept in both
 //                                                      orientations so every product is a conflict-free column dot)
 //   update_data_impl (kkt_full:212-251)                k_remap_values through the composed index maps
@@ -651,11 +651,6 @@ __device__ void front_fwd(const FrontMeta& M, const double* __restrict__ fronts,
     }
     for (int i = threadIdx.x; i < w; i += blockDim.x) x[first + i] = v[i];
 }
-__global__ __launch_bounds__(256) void k_front_fwd(FrontMeta M, const double* __restrict__ fronts, const int* __restrict__ list, double* __restrict__ x,
-                                                   double* __restrict__ fvec)
-{
-    front_fwd(M, fronts, list[blockIdx.x], x, fvec);
-}
 __global__ __launch_bounds__(SUB_SOLVE_THREADS) void k_subtree_fwd(FrontMeta M, const double* __restrict__ fronts, const int* __restrict__ sub_lo, const int* __restrict__ sub_hi,
                                                      double* __restrict__ x, double* __restrict__ fvec)
 {
@@ -688,16 +683,157 @@ __device__ void front_bwd(const FrontMeta& M, const double* __restrict__ fronts,
     }
     for (int i = threadIdx.x; i < w; i += blockDim.x) x[first + i] = v[i];
 }
-__global__ __launch_bounds__(256) void k_front_bwd(FrontMeta M, const double* __restrict__ fronts, const int* __restrict__ list, double* __restrict__ x,
-                                                   double* __restrict__ fvec)
-{
-    front_bwd(M, fronts, list[blockIdx.x], x, fvec);
-}
 __global__ __launch_bounds__(SUB_SOLVE_THREADS) void k_subtree_bwd(FrontMeta M, const double* __restrict__ fronts, const int* __restrict__ sub_lo, const int* __restrict__ sub_hi,
                                                      double* __restrict__ x, double* __restrict__ fvec)
 {
     const int lo = sub_lo[blockIdx.x], hi = sub_hi[blockIdx.x];
     for (int s = hi; s >= lo; --s) { front_bwd(M, fronts, s, x, fvec); __syncthreads(); }
+}
+
+// ---- wide fronts (more than 128 rows) of the level-scheduled top: blocked substitution, the front vector in LDS.
+// front_fwd / front_bwd above pay one global-memory round trip and one barrier PER PIVOT (CONT-201's 714-row root: 382 us forward, 279 us
+// backward at 5 GB/s).  Here 32 pivots go at a time: their 32 x 32 triangle is solved by one wave in registers (v_readlane broadcasts, the
+// triangle prefetched), the rest of the block is a rank-32 update (forward: one row per thread, coalesced column reads) or 32 column dot
+// products (backward: left-looking, four columns per wave, lanes along the contiguous column, fixed-order wave reduction), two barriers per
+// block.  Which routine a front takes depends on the front alone (f > 128), never on the schedule, so every schedule variant still produces
+// the same bits; the forward sweep also keeps the per-entry operation order of front_fwd.
+constexpr int WIDE_NT = 512, WIDE_B = 32;
+constexpr int WIDE_FCAP = 7000;  // rows of a front this path keeps in LDS (56 KB); wider ones take front_fwd / front_bwd
+
+__device__ __forceinline__ double wide_bcast(double v, int src)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+
+__global__ __launch_bounds__(WIDE_NT) void k_front_fwd_wide(FrontMeta M, const double* __restrict__ fronts, const int* __restrict__ list, double* __restrict__ x,
+                                                            double* __restrict__ fvec)
+{
+    extern __shared__ __attribute__((aligned(16))) double vs[];
+    const int s = list[blockIdx.x];
+    const SnRec me = M.sn[s];
+    const int first = me.first, w = me.w, f = me.f;
+    if (f > WIDE_FCAP) { front_fwd(M, fronts, s, x, fvec); return; }
+    const double* __restrict__ F = fronts + me.front_off;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < f; i += WIDE_NT) vs[i] = (i < w) ? x[first + i] : 0.0;
+    __syncthreads();
+    for (int ci = me.child_lo; ci < me.child_hi; ++ci) {
+        const SnRec ch = M.sn[M.child[ci]];
+        const int wc = ch.w, fc = ch.f;
+        const double* vc = fvec + ch.rows_ptr + wc;
+        const int* rel = M.rel + ch.rel_ptr;
+        for (int i = tid; i < fc - wc; i += WIDE_NT) vs[rel[i]] += vc[i];
+        __syncthreads();
+    }
+    double Lt[WIDE_B], Lr[WIDE_B];
+    // operands of block kb: the strict lower triangle (wave 0, lane = row) and the first chunk of rows below it (thread = row)
+    auto prefetch = [&](int kb) {
+        const int nbk = min(WIDE_B, w - kb);
+        if (wave == 0) {
+#pragma unroll
+            for (int k = 0; k < WIDE_B; ++k) Lt[k] = (k < lane && lane < nbk) ? F[(kb + lane) + (long long)(kb + k) * f] : 0.0;
+        }
+        const int i = kb + nbk + tid;
+#pragma unroll
+        for (int k = 0; k < WIDE_B; ++k) Lr[k] = (i < f && k < nbk) ? F[i + (long long)(kb + k) * f] : 0.0;
+    };
+    if (w > 0) prefetch(0);
+    for (int kb = 0; kb < w; kb += WIDE_B) {
+        const int nbk = min(WIDE_B, w - kb);
+        if (wave == 0) {
+            double vv = lane < nbk ? vs[kb + lane] : 0.0;
+#pragma unroll
+            for (int k = 0; k < WIDE_B; ++k) {
+                const double yk = wide_bcast(vv, k);
+                vv = __builtin_fma(-Lt[k], yk, vv);  // Lt[k] = 0 for k >= lane and outside the block
+            }
+            if (lane < nbk) vs[kb + lane] = vv;
+        }
+        __syncthreads();
+        {
+            const int i = kb + nbk + tid;
+            if (i < f) {
+                double vi = vs[i];
+#pragma unroll
+                for (int k = 0; k < WIDE_B; ++k) vi = __builtin_fma(-Lr[k], vs[kb + (k < nbk ? k : 0)], vi);  // Lr[k] = 0 for k >= nbk
+                vs[i] = vi;
+            }
+            for (int i2 = i + WIDE_NT; i2 < f; i2 += WIDE_NT) {
+                double vi = vs[i2];
+                for (int k = 0; k < nbk; ++k) vi = __builtin_fma(-F[i2 + (long long)(kb + k) * f], vs[kb + k], vi);
+                vs[i2] = vi;
+            }
+        }
+        if (kb + WIDE_B < w) prefetch(kb + WIDE_B);
+        __syncthreads();
+    }
+    double* v = fvec + me.rows_ptr;
+    for (int i = tid; i < f; i += WIDE_NT) {
+        const double t = vs[i];
+        if (i < w) x[first + i] = t;
+        v[i] = t;
+    }
+}
+
+__global__ __launch_bounds__(WIDE_NT) void k_front_bwd_wide(FrontMeta M, const double* __restrict__ fronts, const int* __restrict__ list, double* __restrict__ x,
+                                                            double* __restrict__ fvec)
+{
+    extern __shared__ __attribute__((aligned(16))) double vs[];
+    const int s = list[blockIdx.x];
+    const SnRec me = M.sn[s];
+    const int first = me.first, w = me.w, f = me.f;
+    if (f > WIDE_FCAP) { front_bwd(M, fronts, s, x, fvec); return; }
+    const double* __restrict__ F = fronts + me.front_off;
+    const int* __restrict__ rows = M.front_rows + me.rows_ptr;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double* ss = vs + ((f + 1) & ~1);  // 32 column sums of the current block
+    for (int i = tid; i < f; i += WIDE_NT) vs[i] = x[rows[i]];
+    __syncthreads();
+    constexpr int CPW = WIDE_B / (WIDE_NT / 64);  // columns per wave
+    for (int kb = ((w - 1) / WIDE_B) * WIDE_B; kb >= 0; kb -= WIDE_B) {
+        const int nbk = min(WIDE_B, w - kb);
+        const int r0 = kb + nbk;
+        // the block's own triangle (wave 0, lane = column, row i' of the block in Lt[i']): in flight during the dot products
+        double Lt[WIDE_B];
+        if (wave == 0) {
+            const double* col = F + kb + (long long)(kb + (lane < nbk ? lane : 0)) * f;
+#pragma unroll
+            for (int i = 0; i < WIDE_B; ++i) Lt[i] = (lane < i && i < nbk) ? col[i] : 0.0;
+        }
+        // s_k = sum_{i >= r0} L[i, k] x[i]
+        double acc[CPW];
+#pragma unroll
+        for (int c = 0; c < CPW; ++c) acc[c] = 0.0;
+        for (int i = r0 + lane; i < f; i += 64) {
+            const double xi = vs[i];
+#pragma unroll
+            for (int c = 0; c < CPW; ++c) {
+                const int k = wave * CPW + c;
+                if (k < nbk) acc[c] = __builtin_fma(F[i + (long long)(kb + k) * f], xi, acc[c]);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CPW; ++c) {
+            double t = acc[c];
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) t += __shfl_xor(t, o);
+            if (lane == 0) ss[wave * CPW + c] = t;
+        }
+        __syncthreads();
+        if (wave == 0) {
+            double vk = lane < nbk ? vs[kb + lane] - ss[lane] : 0.0;
+#pragma unroll
+            for (int i = WIDE_B - 1; i >= 1; --i) {
+                const double xi = wide_bcast(vk, i);
+                vk = __builtin_fma(-Lt[i], xi, vk);  // Lt[i] = 0 for lanes >= i and rows outside the block
+            }
+            if (lane < nbk) vs[kb + lane] = vk;
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < w; i += WIDE_NT) x[first + i] = vs[i];
 }
 
 // ---- single-wave subtree substitution: the front vector lives in registers (rows lane and lane + 64, fronts of a workgroup subtree have at
@@ -1382,17 +1518,17 @@ public:
         }
         if (part_on_) {
             subtree_fwd(M, part_sched_);
-            fwd_levels(M, own_ptr_, own_sn_, own_sn_d_.p);
+            fwd_levels(M, own_ll_);
             const int nb = (int)PT_.boundary.size();
             if (nb > 0) {
                 hipLaunchKernelGGL(k_pack_fvec, dim3(nb), dim3(64), 0, st_, M, fvec_.p, b_sn_.p, b_owner_.p, rank_, b_vec_off_.p, xbuf_forward_);
                 exchange(1);
                 hipLaunchKernelGGL(k_unpack_fvec, dim3(nb), dim3(64), 0, st_, M, fvec_.p, b_sn_.p, b_owner_.p, rank_, b_vec_off_.p, xbuf_forward_);
             }
-            fwd_levels(M, sh_ptr_, sh_sn_, sh_sn_d_.p);
+            fwd_levels(M, sh_ll_);
             hipLaunchKernelGGL(k_scale, g1(N_), dim3(256), 0, st_, N_, rdiag_.p, xp_.p);
-            bwd_levels(M, sh_ptr_, sh_sn_, sh_sn_d_.p);
-            bwd_levels(M, own_ptr_, own_sn_, own_sn_d_.p);
+            bwd_levels(M, sh_ll_);
+            bwd_levels(M, own_ll_);
             subtree_bwd(M, part_sched_);
             if (world_ > 1 || (std::getenv("PIQP_AMD_EXCHANGE_WORLD1") && (xfn_ || comm_))) {
                 const int lo = PT_.span_lo[rank_], hi = PT_.span_hi[rank_];
@@ -1466,6 +1602,7 @@ public:
         };
         filter(rank, own_ptr_, own_sn_, own_sn_d_, own_lds_);
         filter(-1, sh_ptr_, sh_sn_, sh_sn_d_, sh_lds_);
+        build_level_lists(own_ptr_, own_sn_, own_ll_); build_level_lists(sh_ptr_, sh_sn_, sh_ll_);
         std::vector<int> bo(PT_.boundary.size());
         for (size_t b = 0; b < bo.size(); ++b) bo[b] = PT_.owner[PT_.boundary[b]];
         upload_vec(b_sn_, PT_.boundary, st_); upload_vec(b_owner_, bo, st_); upload_vec(b_mat_off_, PT_.bmat_off, st_); upload_vec(b_vec_off_, PT_.bvec_off, st_);
@@ -1560,6 +1697,7 @@ private:
         auto cpi = [&](DBuf<int>& d, const DBuf<int>& s) { d.alloc(s.n ? s.n : 1); if (s.n) PQ_HIP(hipMemcpyAsync(d.p, s.p, s.bytes(), hipMemcpyDeviceToDevice, st_)); };
         auto cpl = [&](DBuf<long long>& d, const DBuf<long long>& s) { d.alloc(s.n ? s.n : 1); if (s.n) PQ_HIP(hipMemcpyAsync(d.p, s.p, s.bytes(), hipMemcpyDeviceToDevice, st_)); };
         ops_.clone_from(o.ops_, st_);
+        build_level_lists(S_.solve_top_level_ptr, S_.solve_top_level_sn, solve_ll_);
         cpd(vals_, o.vals_); cpd(fronts_, o.fronts_); cpd(rdiag_, o.rdiag_);
         xp_.alloc(o.xp_.n); fvec_.alloc(o.fvec_.n); dvec_.alloc(o.dvec_.n); dpack_.alloc(o.dpack_.n);
         cpi(diag_pos_, o.diag_pos_); cpi(P_, o.P_); cpi(level_sn_, o.level_sn_); cpi(top_pos_, o.top_pos_); top_flags_.alloc(o.top_flags_.n ? o.top_flags_.n : 1); top_flags_.zero(st_); cpi(solve_level_sn_, o.solve_level_sn_); cpi(solve_top_pos_, o.solve_top_pos_); solve_flags_.alloc(o.solve_flags_.n ? o.solve_flags_.n : 1); solve_flags_.zero(st_); ntop_solve_ = o.ntop_solve_; cpi(solve_pub_, o.solve_pub_); cpi(solve_walk_lo_, o.solve_walk_lo_); cpi(solve_walk_hi_, o.solve_walk_hi_); nwalk_solve_ = o.nwalk_solve_; cpi(solve_child_tp_, o.solve_child_tp_); crec_.alloc(o.crec_.n ? o.crec_.n : 1); if (o.crec_.n) PQ_HIP(hipMemcpyAsync(crec_.p, o.crec_.p, o.crec_.bytes(), hipMemcpyDeviceToDevice, st_)); cpi(top_walk_lo_, o.top_walk_lo_); cpi(top_walk_hi_, o.top_walk_hi_); ntopwalk_ = o.ntopwalk_; top_walk_cap_ = o.top_walk_cap_; cpi(fe_ptr_, o.fe_ptr_); cpi(fe_q_, o.fe_q_); cpi(fe_off_, o.fe_off_); cpi(fe_offp_, o.fe_offp_);
@@ -1717,7 +1855,7 @@ private:
                     std::fclose(fo);
                 }
             }
-        } else fwd_levels(M, S_.solve_top_level_ptr, S_.solve_top_level_sn, solve_level_sn_.p);
+        } else fwd_levels(M, solve_ll_);
         bool fuse_scale = wave_top;
         for (const SubClass& c : solve_sched_.cls) if (c.fmax > 128) fuse_scale = false;
         const double* rd = fuse_scale ? rdiag_.p : nullptr;  // the diagonal solve rides in the backward kernels when they are all single-wave
@@ -1726,7 +1864,7 @@ private:
             hipLaunchKernelGGL(k_subtree_bwd_wave<true>, dim3(nwalk_solve_), dim3(64), 0, st_, M, fronts_.p, solve_walk_lo_.p, solve_walk_hi_.p, xp_.p, bwd_red_thr(), nwalk_solve_, solve_top_pos_.p,
                                solve_flags_.p + nt, solve_flags_.p + 2 * nt, solve_pub_.p, epoch, rd);
             // a wait that gave up left the epoch in the error slot: k_perm_scatter poisons the solution (solve_err_ptr_)
-        } else bwd_levels(M, S_.solve_top_level_ptr, S_.solve_top_level_sn, solve_level_sn_.p);
+        } else bwd_levels(M, solve_ll_);
         subtree_bwd(M, solve_sched_, rd);
     }
     // data crosses ranks: the stream is drained, the caller's collective runs (pq_exchange_fn), then the stream continues
@@ -1873,29 +2011,45 @@ private:
             }
         }
     }
-    // a level whose fronts all have at most 128 rows runs the single-wave substitution (one wave per front, vector in registers: the same
-    // kernels as the subtree walk with lo = hi = the supernode); wider fronts keep the 256-thread kernels
-    bool level_is_narrow(const std::vector<int>& ptr, const std::vector<int>& sn, int l) const
+    // Substitution by levels: the fronts of a level with at most 128 rows go through the single-wave kernels (one wave per front, vector in
+    // registers: the same kernels as the subtree walk with lo = hi = the supernode), the wider ones through the blocked LDS kernels -- two
+    // launches for a mixed level, from a per-level list sorted narrow first.
+    struct LevelLists {
+        std::vector<int> ptr, narrow, lds;  // level l = list[ptr[l] .. ptr[l+1]): `narrow[l]` single-wave fronts first; LDS bytes of its widest front
+        DBuf<int> dev;
+    };
+    void build_level_lists(const std::vector<int>& ptr, const std::vector<int>& sn, LevelLists& L)
     {
-        for (int q = ptr[l]; q < ptr[l + 1]; ++q) if (S_.front_rows_ptr[sn[q] + 1] - S_.front_rows_ptr[sn[q]] > 128) return false;
-        return true;
-    }
-    void fwd_levels(const FrontMeta& M, const std::vector<int>& ptr, const std::vector<int>& sn, const int* sn_dev)
-    {
+        L.ptr = ptr; L.narrow.clear(); L.lds.clear();
+        std::vector<int> order;
         for (int l = 0; l + 1 < (int)ptr.size(); ++l) {
-            const int cnt = ptr[l + 1] - ptr[l];
-            if (cnt <= 0) continue;
-            if (level_is_narrow(ptr, sn, l)) hipLaunchKernelGGL(k_subtree_fwd_wave<false>, dim3(cnt), dim3(64), 0, st_, M, fronts_.p, sn_dev + ptr[l], sn_dev + ptr[l], xp_.p, fvec_.p, (const int*)nullptr, (int*)nullptr, (int*)nullptr, (const int*)nullptr, 0);
-            else hipLaunchKernelGGL(k_front_fwd, dim3(cnt), dim3(256), 0, st_, M, fronts_.p, sn_dev + ptr[l], xp_.p, fvec_.p);
+            int fmax = 0;
+            for (int q = ptr[l]; q < ptr[l + 1]; ++q) if (S_.front_rows_ptr[sn[q] + 1] - S_.front_rows_ptr[sn[q]] <= 128) order.push_back(sn[q]);
+            L.narrow.push_back((int)order.size() - ptr[l]);
+            for (int q = ptr[l]; q < ptr[l + 1]; ++q) {
+                const int f = S_.front_rows_ptr[sn[q] + 1] - S_.front_rows_ptr[sn[q]];
+                if (f > 128) { order.push_back(sn[q]); if (f <= WIDE_FCAP) fmax = std::max(fmax, f); }
+            }
+            L.lds.push_back((((fmax + 1) & ~1) + WIDE_B) * (int)sizeof(double));
+        }
+        upload_vec(L.dev, order, st_);
+    }
+    void fwd_levels(const FrontMeta& M, const LevelLists& L)
+    {
+        for (int l = 0; l + 1 < (int)L.ptr.size(); ++l) {
+            const int cnt = L.ptr[l + 1] - L.ptr[l], nn = cnt > 0 ? L.narrow[l] : 0;
+            const int* list = L.dev.p + L.ptr[l];
+            if (nn > 0) hipLaunchKernelGGL(k_subtree_fwd_wave<false>, dim3(nn), dim3(64), 0, st_, M, fronts_.p, list, list, xp_.p, fvec_.p, (const int*)nullptr, (int*)nullptr, (int*)nullptr, (const int*)nullptr, 0);
+            if (cnt > nn) hipLaunchKernelGGL(k_front_fwd_wide, dim3(cnt - nn), dim3(WIDE_NT), L.lds[l], st_, M, fronts_.p, list + nn, xp_.p, fvec_.p);
         }
     }
-    void bwd_levels(const FrontMeta& M, const std::vector<int>& ptr, const std::vector<int>& sn, const int* sn_dev)
+    void bwd_levels(const FrontMeta& M, const LevelLists& L)
     {
-        for (int l = (int)ptr.size() - 2; l >= 0; --l) {
-            const int cnt = ptr[l + 1] - ptr[l];
-            if (cnt <= 0) continue;
-            if (level_is_narrow(ptr, sn, l)) hipLaunchKernelGGL(k_subtree_bwd_wave<false>, dim3(cnt), dim3(64), 0, st_, M, fronts_.p, sn_dev + ptr[l], sn_dev + ptr[l], xp_.p, bwd_red_thr(), 0, (const int*)nullptr, (int*)nullptr, (int*)nullptr, (const int*)nullptr, 0, (const double*)nullptr);
-            else hipLaunchKernelGGL(k_front_bwd, dim3(cnt), dim3(256), 0, st_, M, fronts_.p, sn_dev + ptr[l], xp_.p, fvec_.p);
+        for (int l = (int)L.ptr.size() - 2; l >= 0; --l) {
+            const int cnt = L.ptr[l + 1] - L.ptr[l], nn = cnt > 0 ? L.narrow[l] : 0;
+            const int* list = L.dev.p + L.ptr[l];
+            if (cnt > nn) hipLaunchKernelGGL(k_front_bwd_wide, dim3(cnt - nn), dim3(WIDE_NT), L.lds[l], st_, M, fronts_.p, list + nn, xp_.p, fvec_.p);
+            if (nn > 0) hipLaunchKernelGGL(k_subtree_bwd_wave<false>, dim3(nn), dim3(64), 0, st_, M, fronts_.p, list, list, xp_.p, bwd_red_thr(), 0, (const int*)nullptr, (int*)nullptr, (int*)nullptr, (const int*)nullptr, 0, (const double*)nullptr);
         }
     }
 
@@ -1910,6 +2064,7 @@ private:
         }
         {   // the substitution's own schedule
             upload_vec(solve_level_sn_, S_.solve_top_level_sn, st_);
+            build_level_lists(S_.solve_top_level_ptr, S_.solve_top_level_sn, solve_ll_);
             ntop_solve_ = (int)S_.solve_top_level_sn.size();
             std::vector<int> tp(S_.nsuper ? S_.nsuper : 1, -1);
             for (size_t q = 0; q < S_.solve_top_level_sn.size(); ++q) tp[S_.solve_top_level_sn[q]] = (int)q;
@@ -2072,6 +2227,7 @@ private:
     DBuf<double> vals_, fronts_, rdiag_, xp_, fvec_, dvec_, dpack_;
     DBuf<int> fe_ptr_, fe_q_, fe_off_, fe_offp_, top_pos_, top_flags_, solve_level_sn_, solve_top_pos_, solve_flags_, solve_walk_lo_, solve_walk_hi_, solve_pub_;
     SubSchedule solve_sched_;
+    LevelLists solve_ll_, own_ll_, sh_ll_;
     int ntop_solve_ = 0, nwalk_solve_ = 0, solve_epoch_ = 0, solve_epoch_used_ = 0, factor_epoch_ = 0;
     const int* solve_err_ptr_ = nullptr;
     DBuf<int> top_walk_lo_, top_walk_hi_;
