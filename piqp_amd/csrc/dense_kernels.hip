@@ -154,7 +154,7 @@ constexpr int FUSED_LDS_BYTES = (128 * (128 + 16) + 128) * 8;  // whole operand 
 //   4 x 2 -> 512 threads, 32 x 64 per wave: the fused trailing update + next diagonal block, whose in-register block factorisation needs
 //            more than the 128 VGPRs a 1024-thread workgroup can have.
 template <int EPI, int WR, int WC>
-__global__ __launch_bounds__(64 * WR * WC, (WR * WC == 4) ? 2 : (WR * WC == 8 ? 2 : 4)) void k_syrk_lower(SyrkArgs a)
+__device__ __forceinline__ void syrk_lower_body(const SyrkArgs& a, const int block_x)
 {
     constexpr int NT = 64 * WR * WC;
     constexpr int MTR = 8 / WR, MTC = 8 / WC;     // MFMA tiles per wave: rows, columns
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(64 * WR * WC, (WR * WC == 4) ? 2 : (WR * WC == 8 ? 
     double* Bs = smem + 2 * BK * LDS_LD;  // [2][BK][LDS_LD]
 
     // linear block id -> lower-triangular tile (ti >= tj); split launches map several K-slices onto one tile
-    int bid = (int)blockIdx.x;
+    int bid = block_x;
     if constexpr (EPI == EPI_SUBTRACT_POTRF) {
         // tile (0, 0) of the trailing matrix = the next diagonal block: updated AND factored by the first FUSE_ROLES workgroups together (owner +
         // helpers); the other tiles follow
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(64 * WR * WC, (WR * WC == 4) ? 2 : (WR * WC == 8 ? 
     if (skip_wave) return;
     if (a.part) {
         // split launch: raw partial tile (column-major 128 x 128) for k_syrk_tail_reduce; fixed slot per (tile, slice)
-        double* P = a.part + (size_t)blockIdx.x * TS * TS;
+        double* P = a.part + (size_t)block_x * TS * TS;
 #pragma unroll
         for (int x = 0; x < MTC; ++x)
 #pragma unroll
@@ -375,6 +375,38 @@ __global__ __launch_bounds__(64 * WR * WC, (WR * WC == 4) ? 2 : (WR * WC == 8 ? 
         }
     }
     if (dbg_tile) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); a.fuse_ts[87] = clock64(); }  // stores drained
+}
+
+template <int EPI, int WR, int WC>
+__global__ __launch_bounds__(64 * WR * WC, (WR * WC == 4) ? 2 : (WR * WC == 8 ? 2 : 4)) void k_syrk_lower(SyrkArgs a)
+{
+    syrk_lower_body<EPI, WR, WC>(a, (int)blockIdx.x);
+}
+
+// The trailing update of panel `panel` of MANY independent fronts (the big fronts of one level of a sparse assembly tree) in one launch:
+// blockIdx.y = front, blockIdx.x = tile of its trailing matrix (fronts with fewer tiles or fewer panels leave).
+__device__ __forceinline__ bool front_panel(const FrontJob& j, int panel, int& k, int& nb, int& rs)
+{
+    k = panel * FACTOR_NB;
+    if (k >= j.w) return false;
+    nb = min(FACTOR_NB, j.w - k);
+    rs = j.f - k - nb;
+    return true;
+}
+template <int WR, int WC>
+__global__ __launch_bounds__(64 * WR * WC, (WR * WC == 4) ? 2 : (WR * WC == 8 ? 2 : 4)) void k_syrk_lower_fronts(const FrontJob* __restrict__ jobs, int panel)
+{
+    const FrontJob j = jobs[blockIdx.y];
+    int k, nb, rs;
+    if (!front_panel(j, panel, k, nb, rs) || rs <= 0) return;
+    const int T = (rs + TS - 1) / TS;
+    if ((int)blockIdx.x >= T * (T + 1) / 2) return;
+    SyrkArgs a;
+    a.n = rs; a.kdim = nb;
+    a.A = j.F + (k + nb) + (size_t)k * j.f; a.lda = j.f; a.B = a.A; a.ldb = j.f; a.w = j.dvec;
+    a.C = j.F + (k + nb) + (size_t)(k + nb) * j.f; a.ldc = j.f;
+    a.unaligned = ((j.f & 1) || (reinterpret_cast<uintptr_t>(a.A) & 15)) ? 1 : 0;
+    syrk_lower_body<EPI_SUBTRACT, WR, WC>(a, (int)blockIdx.x);
 }
 
 // sums the K-slices of a split tile in slice order and applies the epilogue (one workgroup per tile)
@@ -981,8 +1013,8 @@ __device__ __forceinline__ void potrf_block(double* __restrict__ Tb, double* __r
 
 constexpr int POTRF_THREADS = 512;
 template <bool LDLT>
-__global__ __launch_bounds__(POTRF_THREADS) void k_potrf_diag(double* __restrict__ A, int lda, int nb, int kglobal, int* __restrict__ info, double* __restrict__ rdiag,
-                                                              double* __restrict__ dvec, double* __restrict__ pack, double* __restrict__ w16, long long* __restrict__ ts)
+__device__ __forceinline__ void potrf_diag_body(double* __restrict__ A, int lda, int nb, int kglobal, int* __restrict__ info, double* __restrict__ rdiag,
+                                                double* __restrict__ dvec, double* __restrict__ pack, double* __restrict__ w16, long long* __restrict__ ts)
 {
     extern __shared__ __attribute__((aligned(16))) double Tb[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1005,6 +1037,20 @@ __global__ __launch_bounds__(POTRF_THREADS) void k_potrf_diag(double* __restrict
     }
     __syncthreads();
     potrf_block<LDLT, POTRF_THREADS / 64>(Tb, Tb + TB_DOUBLES, nb, kglobal, info, rdiag, dvec, A, lda, pack, w16, ts);
+}
+template <bool LDLT>
+__global__ __launch_bounds__(POTRF_THREADS) void k_potrf_diag(double* __restrict__ A, int lda, int nb, int kglobal, int* __restrict__ info, double* __restrict__ rdiag,
+                                                              double* __restrict__ dvec, double* __restrict__ pack, double* __restrict__ w16, long long* __restrict__ ts)
+{
+    potrf_diag_body<LDLT>(A, lda, nb, kglobal, info, rdiag, dvec, pack, w16, ts);
+}
+// diagonal block of panel `panel` of every front of the list (LDLt; blockIdx.x = front)
+__global__ __launch_bounds__(POTRF_THREADS) void k_potrf_diag_fronts(const FrontJob* __restrict__ jobs, int panel, int* __restrict__ info, double* __restrict__ rdiag)
+{
+    const FrontJob j = jobs[blockIdx.x];
+    int k, nb, rs;
+    if (!front_panel(j, panel, k, nb, rs)) return;
+    potrf_diag_body<true>(j.F + k + (size_t)k * j.f, j.f, nb, j.first + k, info, rdiag, j.dvec, rs > 0 ? j.pack : nullptr, nullptr, nullptr);
 }
 
 void launch_potrf_diag(bool ldlt, double* A, int lda, int nb, int kglobal, int* info, double* rdiag, double* dvec, double* pack, double* w16, hipStream_t s, long long* ts)
@@ -1241,7 +1287,7 @@ __device__ __forceinline__ void panel_follow(const SyrkArgs& a, double* __restri
 constexpr int TRSM_ROWS = 64;  // rows per workgroup (4 waves)
 constexpr int TRSM_LDS_BYTES = PACK_BLOCKS * 256 * (int)sizeof(double);
 template <bool LDLT>
-__global__ __launch_bounds__(256) void k_trsm_panel(double* __restrict__ A, int lda, int k0, int nb, int n, const double* __restrict__ pack, const double* __restrict__ rdiag)
+__device__ __forceinline__ void trsm_panel_body(double* __restrict__ A, int lda, int k0, int nb, int n, const double* __restrict__ pack, const double* __restrict__ rdiag, const int block_x)
 {
     extern __shared__ __attribute__((aligned(16))) double Ps[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1255,7 +1301,7 @@ __global__ __launch_bounds__(256) void k_trsm_panel(double* __restrict__ A, int 
 #pragma unroll
         for (int u = 0; u < PACK_BLOCKS * 128 / 256; ++u) dst[u * 256 + tid] = v[u];
     }
-    const int row = k0 + nb + (int)blockIdx.x * TRSM_ROWS + wave * 16 + i;
+    const int row = k0 + nb + block_x * TRSM_ROWS + wave * 16 + i;
     const bool row_ok = row < n;
     double* Ar = A + (row_ok ? row : 0) + (size_t)k0 * lda;
     d4 T[8];
@@ -1296,6 +1342,40 @@ __global__ __launch_bounds__(256) void k_trsm_panel(double* __restrict__ A, int 
                 }
             }
     }
+}
+
+template <bool LDLT>
+__global__ __launch_bounds__(256) void k_trsm_panel(double* __restrict__ A, int lda, int k0, int nb, int n, const double* __restrict__ pack, const double* __restrict__ rdiag)
+{
+    trsm_panel_body<LDLT>(A, lda, k0, nb, n, pack, rdiag, (int)blockIdx.x);
+}
+// rows below the diagonal block of panel `panel` of every front of the list (blockIdx.y = front, blockIdx.x = strip of TRSM_ROWS rows)
+__global__ __launch_bounds__(256) void k_trsm_panel_fronts(const FrontJob* __restrict__ jobs, int panel, const double* __restrict__ rdiag)
+{
+    const FrontJob j = jobs[blockIdx.y];
+    int k, nb, rs;
+    if (!front_panel(j, panel, k, nb, rs) || (int)blockIdx.x * TRSM_ROWS >= rs) return;
+    trsm_panel_body<true>(j.F, j.f, k, nb, j.f, j.pack, rdiag + j.first, (int)blockIdx.x);
+}
+
+// one panel step of the partial LDLt of many fronts: diagonal blocks, panels, trailing updates -- three launches whatever the number of fronts
+void launch_front_panels(const FrontJob* jobs, int njobs, int panel, int max_rows_below, int* info, double* rdiag, hipStream_t s)
+{
+    if (njobs <= 0) return;
+    static bool attr_set = false;
+    if (!attr_set) {
+        PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_diag_fronts), hipFuncAttributeMaxDynamicSharedMemorySize, POTRF_LDS_BYTES));
+        PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_trsm_panel_fronts), hipFuncAttributeMaxDynamicSharedMemorySize, TRSM_LDS_BYTES));
+        PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk_lower_fronts<4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, SYRK_LDS_BYTES));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_potrf_diag_fronts, dim3(njobs), dim3(POTRF_THREADS), POTRF_LDS_BYTES, s, jobs, panel, info, rdiag);
+    if (max_rows_below > 0) {
+        hipLaunchKernelGGL(k_trsm_panel_fronts, dim3(div_up(max_rows_below, TRSM_ROWS), njobs), dim3(256), TRSM_LDS_BYTES, s, jobs, panel, rdiag);
+        const int T = div_up(max_rows_below, TS);
+        hipLaunchKernelGGL((k_syrk_lower_fronts<4, 4>), dim3(T * (T + 1) / 2, njobs), dim3(1024), SYRK_LDS_BYTES, s, jobs, panel);
+    }
+    PQ_HIP(hipGetLastError());
 }
 
 void launch_trsm_panel(bool ldlt, double* A, int lda, int k0, int nb, int n, const double* pack, const double* rdiag, hipStream_t s)

@@ -78,5 +78,15 @@ double microbench_hbm_copy(size_t bytes, int iters, hipStream_t s);
 constexpr int FACTOR_NB = 128;  // panel width of the blocked factorisation
 constexpr int FACTOR_PACK_DOUBLES = 36 * 256;
 
+// One front of a sparse assembly tree on the dense panel kernels: partial LDLt of the first w columns of the f x f column-major F, the
+// Schur complement left in the trailing block.  The big fronts of one tree level go through launch_front_panels together, panel by panel.
+struct FrontJob {
+    double* F = nullptr;
+    int f = 0, w = 0, first = 0;  // order, pivot columns, global index of the first pivot (rdiag / info)
+    double* pack = nullptr;       // FACTOR_PACK_DOUBLES of scratch owned by this front for the duration of the level
+    double* dvec = nullptr;       // FACTOR_NB doubles, likewise
+};
+void launch_front_panels(const FrontJob* jobs_device, int njobs, int panel, int max_rows_below, int* info, double* rdiag, hipStream_t s);
+
 }  // namespace dense
 }  // namespace pq

@@ -604,25 +604,38 @@ __global__ __launch_bounds__(SUB_THREADS) void k_subtree_factor(FrontMeta M, dou
 // extend-add of ONE child into a front that is then factored by the dense kernels (one launch per child: stream
 // order = fixed merge order, entries of one child never collide)
 // own K entries of ONE front that the dense multi-workgroup path factors (the front was zeroed by a memset on the stream)
-__global__ void k_front_assemble(FrontMeta M, double* __restrict__ fronts, int s)
+// ---- big fronts (>= BIG_FRONT rows, >= BIG_PIVOTS pivots): the dense MFMA panel kernels factor them, ALL big fronts of a tree level per launch
+// (blockIdx.y = front of the level's list).  Zero-fill and the front's own K entries need nothing from the children: one launch each for every
+// big front of the tree at the start of the factorisation.  The children are merged in rounds -- round r adds child r of every front --, so
+// an entry receives its contributions in child order whatever the grid (fixed summation order).
+__global__ __launch_bounds__(256) void k_big_zero(FrontMeta M, double* __restrict__ fronts, const int* __restrict__ list)
 {
-    const SnRec me = M.sn[s];
+    const SnRec me = M.sn[list[blockIdx.y]];
     double* F = fronts + me.front_off;
-    for (int e = me.fe_lo + blockIdx.x * blockDim.x + threadIdx.x; e < me.fe_hi; e += gridDim.x * blockDim.x) F[M.fe_off[e]] = M.vals[e];
+    const long long tot = (long long)me.f * me.f;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < tot; idx += (long long)gridDim.x * 256) F[idx] = 0.0;
 }
-__global__ __launch_bounds__(256) void k_front_extend_add_child(FrontMeta M, double* __restrict__ fronts, int s, int c)
+__global__ __launch_bounds__(256) void k_big_assemble(FrontMeta M, double* __restrict__ fronts, const int* __restrict__ list)
 {
-    const SnRec me = M.sn[s], ch = M.sn[c];
-    const int f = me.f;
+    const SnRec me = M.sn[list[blockIdx.y]];
     double* F = fronts + me.front_off;
-    const int wc = ch.w, fc = ch.f;
-    const int uc = fc - wc;
+    for (int e = me.fe_lo + blockIdx.x * 256 + threadIdx.x; e < me.fe_hi; e += gridDim.x * 256) F[M.fe_off[e]] = M.vals[e];
+}
+__global__ __launch_bounds__(256) void k_big_extend_add(FrontMeta M, double* __restrict__ fronts, const int* __restrict__ list, int round)
+{
+    const SnRec me = M.sn[list[blockIdx.y]];
+    const int ci = me.child_lo + round;
+    if (ci >= me.child_hi) return;
+    const SnRec ch = M.sn[M.child[ci]];
+    const int f = me.f, wc = ch.w, fc = ch.f, uc = fc - wc;
+    double* F = fronts + me.front_off;
     const double* U = fronts + ch.front_off + wc + (long long)wc * fc;
     const int* rel = M.rel + ch.rel_ptr;
-    const long long tot = (long long)uc * uc;
-    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < tot; idx += (long long)gridDim.x * blockDim.x) {
-        const int i = (int)(idx % uc), j = (int)(idx / uc);
-        if (i >= j) F[rel[i] + (long long)rel[j] * f] += U[i + (long long)j * fc];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;  // 16 rows x 16 columns of the child's update matrix per step
+    for (int j = blockIdx.x * 16 + ty; j < uc; j += gridDim.x * 16) {
+        const long long cj = (long long)rel[j] * f;
+        const double* Uj = U + (long long)j * fc;
+        for (int i = j + tx; i < uc; i += 16) F[rel[i] + cj] += Uj[i];
     }
 }
 
@@ -708,13 +721,13 @@ __device__ __forceinline__ double wide_bcast(double v, int src)
 }
 
 __global__ __launch_bounds__(WIDE_NT) void k_front_fwd_wide(FrontMeta M, const double* __restrict__ fronts, const int* __restrict__ list, double* __restrict__ x,
-                                                            double* __restrict__ fvec)
+                                                            double* __restrict__ fvec, int fcap)
 {
     extern __shared__ __attribute__((aligned(16))) double vs[];
     const int s = list[blockIdx.x];
     const SnRec me = M.sn[s];
     const int first = me.first, w = me.w, f = me.f;
-    if (f > WIDE_FCAP) { front_fwd(M, fronts, s, x, fvec); return; }
+    if (f > fcap) { front_fwd(M, fronts, s, x, fvec); return; }
     const double* __restrict__ F = fronts + me.front_off;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < f; i += WIDE_NT) vs[i] = (i < w) ? x[first + i] : 0.0;
@@ -778,13 +791,13 @@ __global__ __launch_bounds__(WIDE_NT) void k_front_fwd_wide(FrontMeta M, const d
 }
 
 __global__ __launch_bounds__(WIDE_NT) void k_front_bwd_wide(FrontMeta M, const double* __restrict__ fronts, const int* __restrict__ list, double* __restrict__ x,
-                                                            double* __restrict__ fvec)
+                                                            double* __restrict__ fvec, int fcap)
 {
     extern __shared__ __attribute__((aligned(16))) double vs[];
     const int s = list[blockIdx.x];
     const SnRec me = M.sn[s];
     const int first = me.first, w = me.w, f = me.f;
-    if (f > WIDE_FCAP) { front_bwd(M, fronts, s, x, fvec); return; }
+    if (f > fcap) { front_bwd(M, fronts, s, x, fvec); return; }
     const double* __restrict__ F = fronts + me.front_off;
     const int* __restrict__ rows = M.front_rows + me.rows_ptr;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1481,14 +1494,14 @@ public:
         FrontMeta M = meta();
         if (part_on_) {
             factor_subtrees(M, part_sched_);
-            factor_levels(M, own_ptr_, own_sn_, own_sn_d_.p, own_lds_);
+            factor_levels(M, own_ptr_, own_sn_d_.p, own_lds_, own_big_);
             const int nb = (int)PT_.boundary.size();
             if (nb > 0) {
                 hipLaunchKernelGGL(k_pack_updates, dim3(nb), dim3(256), 0, st_, M, fronts_.p, b_sn_.p, b_owner_.p, rank_, b_mat_off_.p, PT_.bmat_off.back(), info_.p, xbuf_factor_);
                 exchange(0);
                 hipLaunchKernelGGL(k_unpack_updates, dim3(nb), dim3(256), 0, st_, M, fronts_.p, b_sn_.p, b_owner_.p, rank_, b_mat_off_.p, PT_.bmat_off.back(), info_.p, xbuf_factor_);
             }
-            factor_levels(M, sh_ptr_, sh_sn_, sh_sn_d_.p, sh_lds_);
+            factor_levels(M, sh_ptr_, sh_sn_d_.p, sh_lds_, sh_big_);
         } else {
             factor_numeric(M);
         }
@@ -1603,6 +1616,7 @@ public:
         filter(rank, own_ptr_, own_sn_, own_sn_d_, own_lds_);
         filter(-1, sh_ptr_, sh_sn_, sh_sn_d_, sh_lds_);
         build_level_lists(own_ptr_, own_sn_, own_ll_); build_level_lists(sh_ptr_, sh_sn_, sh_ll_);
+        build_big_levels(own_ptr_, own_sn_, own_big_); build_big_levels(sh_ptr_, sh_sn_, sh_big_);
         std::vector<int> bo(PT_.boundary.size());
         for (size_t b = 0; b < bo.size(); ++b) bo[b] = PT_.owner[PT_.boundary[b]];
         upload_vec(b_sn_, PT_.boundary, st_); upload_vec(b_owner_, bo, st_); upload_vec(b_mat_off_, PT_.bmat_off, st_); upload_vec(b_vec_off_, PT_.bvec_off, st_);
@@ -1699,7 +1713,8 @@ private:
         ops_.clone_from(o.ops_, st_);
         build_level_lists(S_.solve_top_level_ptr, S_.solve_top_level_sn, solve_ll_);
         cpd(vals_, o.vals_); cpd(fronts_, o.fronts_); cpd(rdiag_, o.rdiag_);
-        xp_.alloc(o.xp_.n); fvec_.alloc(o.fvec_.n); dvec_.alloc(o.dvec_.n); dpack_.alloc(o.dpack_.n);
+        xp_.alloc(o.xp_.n); fvec_.alloc(o.fvec_.n);
+        build_big_levels(S_.top_level_ptr, S_.top_level_sn, top_big_);
         cpi(diag_pos_, o.diag_pos_); cpi(P_, o.P_); cpi(level_sn_, o.level_sn_); cpi(top_pos_, o.top_pos_); top_flags_.alloc(o.top_flags_.n ? o.top_flags_.n : 1); top_flags_.zero(st_); cpi(solve_level_sn_, o.solve_level_sn_); cpi(solve_top_pos_, o.solve_top_pos_); solve_flags_.alloc(o.solve_flags_.n ? o.solve_flags_.n : 1); solve_flags_.zero(st_); ntop_solve_ = o.ntop_solve_; cpi(solve_pub_, o.solve_pub_); cpi(solve_walk_lo_, o.solve_walk_lo_); cpi(solve_walk_hi_, o.solve_walk_hi_); nwalk_solve_ = o.nwalk_solve_; cpi(solve_child_tp_, o.solve_child_tp_); crec_.alloc(o.crec_.n ? o.crec_.n : 1); if (o.crec_.n) PQ_HIP(hipMemcpyAsync(crec_.p, o.crec_.p, o.crec_.bytes(), hipMemcpyDeviceToDevice, st_)); cpi(top_walk_lo_, o.top_walk_lo_); cpi(top_walk_hi_, o.top_walk_hi_); ntopwalk_ = o.ntopwalk_; top_walk_cap_ = o.top_walk_cap_; cpi(fe_ptr_, o.fe_ptr_); cpi(fe_q_, o.fe_q_); cpi(fe_off_, o.fe_off_); cpi(fe_offp_, o.fe_offp_);
         snrec_.alloc(o.snrec_.n ? o.snrec_.n : 1); if (o.snrec_.n) PQ_HIP(hipMemcpyAsync(snrec_.p, o.snrec_.p, o.snrec_.bytes(), hipMemcpyDeviceToDevice, st_)); cpi(sn_first_, o.sn_first_); cpi(front_rows_ptr_, o.front_rows_ptr_); cpi(front_rows_, o.front_rows_);
         cpi(child_ptr_, o.child_ptr_); cpi(child_, o.child_); cpi(rel_ptr_, o.rel_ptr_); cpi(rel_, o.rel_);
@@ -1806,7 +1821,7 @@ private:
     {
         factor_subtrees(M, sched_);
         // wide lower levels: one launch per level; the narrow levels near the root (<= 1024 supernodes in total): one persistent launch
-        factor_levels(M, S_.top_level_ptr, S_.top_level_sn, level_sn_.p, level_lds_, top_l0_);
+        factor_levels(M, S_.top_level_ptr, level_sn_.p, level_lds_, top_big_, top_l0_);
         if (top_nper_ > 0) {
             // flags carry the number of the factorisation that set them (no memset in between; a recorded graph replays fixed arguments,
             // so there they are zeroed and the epoch stays 1)
@@ -1996,19 +2011,77 @@ private:
                 hipLaunchKernelGGL(k_subtree_factor, dim3(c.nsub), dim3(SUB_THREADS), sub_lds_, st_, M, fronts_.p, c.lo.p, c.hi.p, rdiag_.p, info_.p);
         }
     }
-    // one launch per level of a (possibly filtered) level schedule; wide fronts go through the dense multi-workgroup path
-    void factor_levels(const FrontMeta& M, const std::vector<int>& ptr, const std::vector<int>& sn, const int* sn_dev, const std::vector<int>& lds, int lend = 1 << 30)
+    // ---- big fronts of a level schedule, grouped by level for the batched dense path
+    bool is_big(int s) const
     {
+        return S_.front_rows_ptr[s + 1] - S_.front_rows_ptr[s] >= BIG_FRONT && S_.sn_first[s + 1] - S_.sn_first[s] >= BIG_PIVOTS;
+    }
+    struct BigLevels {
+        std::vector<int> ptr, rounds;            // level l of the schedule -> jobs [ptr[l], ptr[l + 1]); children of its widest fan-in
+        std::vector<std::vector<int>> rows_below;  // per level, per panel: most rows below the diagonal block over the level's fronts (0 = none)
+        int total = 0, max_f = 0, max_own = 0;
+        DBuf<int> list;
+        DBuf<dense::FrontJob> jobs;
+        DBuf<double> scratch;  // pack + D of every front of the widest level
+    };
+    void build_big_levels(const std::vector<int>& ptr, const std::vector<int>& sn, BigLevels& B)
+    {
+        B.ptr.assign(1, 0); B.rounds.clear(); B.rows_below.clear(); B.total = 0; B.max_f = 0; B.max_own = 0;
+        std::vector<int> list;
+        int widest = 0;
+        for (int l = 0; l + 1 < (int)ptr.size(); ++l) {
+            int rounds = 0;
+            std::vector<int> rb;
+            for (int q = ptr[l]; q < ptr[l + 1]; ++q) {
+                const int s = sn[q];
+                if (!is_big(s)) continue;
+                list.push_back(s);
+                const int w = S_.sn_first[s + 1] - S_.sn_first[s], f = S_.front_rows_ptr[s + 1] - S_.front_rows_ptr[s];
+                rounds = std::max(rounds, S_.child_ptr[s + 1] - S_.child_ptr[s]);
+                B.max_f = std::max(B.max_f, f); B.max_own = std::max(B.max_own, S_.fe_ptr[s + 1] - S_.fe_ptr[s]);
+                for (int k = 0, pn = 0; k < w; k += dense::FACTOR_NB, ++pn) {
+                    if ((int)rb.size() <= pn) rb.push_back(0);
+                    rb[pn] = std::max(rb[pn], f - k - std::min(dense::FACTOR_NB, w - k));
+                }
+            }
+            B.ptr.push_back((int)list.size()); B.rounds.push_back(rounds); B.rows_below.push_back(rb);
+            widest = std::max(widest, B.ptr[l + 1] - B.ptr[l]);
+        }
+        B.total = (int)list.size();
+        if (B.total == 0) return;
+        constexpr size_t SLOT = dense::FACTOR_PACK_DOUBLES + dense::FACTOR_NB;
+        B.scratch.alloc((size_t)widest * SLOT);
+        std::vector<dense::FrontJob> jobs(B.total);
+        for (int l = 0; l + 1 < (int)B.ptr.size(); ++l)
+            for (int q = B.ptr[l]; q < B.ptr[l + 1]; ++q) {
+                const int s = list[q];
+                dense::FrontJob& j = jobs[q];
+                j.F = fronts_.p + S_.front_off[s];
+                j.f = S_.front_rows_ptr[s + 1] - S_.front_rows_ptr[s]; j.w = S_.sn_first[s + 1] - S_.sn_first[s]; j.first = S_.sn_first[s];
+                j.pack = B.scratch.p + (size_t)(q - B.ptr[l]) * SLOT; j.dvec = j.pack + dense::FACTOR_PACK_DOUBLES;
+            }
+        upload_vec(B.list, list, st_);
+        B.jobs.alloc(jobs.size());
+        PQ_HIP(hipMemcpyAsync(B.jobs.p, jobs.data(), jobs.size() * sizeof(dense::FrontJob), hipMemcpyHostToDevice, st_));
+        PQ_HIP(hipStreamSynchronize(st_));
+    }
+    // one launch per level of a (possibly filtered) level schedule for the fronts one workgroup factors; the level's big fronts then go through
+    // the dense multi-workgroup kernels together: children merged in rounds (fixed order), then the blocked partial LDLt panel by panel
+    void factor_levels(const FrontMeta& M, const std::vector<int>& ptr, const int* sn_dev, const std::vector<int>& lds, const BigLevels& B, int lend = 1 << 30)
+    {
+        if (B.total > 0) {
+            hipLaunchKernelGGL(k_big_zero, dim3((unsigned)std::min<long long>(256, ((long long)B.max_f * B.max_f + 255) / 256), B.total), dim3(256), 0, st_, M, fronts_.p, B.list.p);
+            if (B.max_own > 0) hipLaunchKernelGGL(k_big_assemble, dim3(std::min(64, (B.max_own + 255) / 256), B.total), dim3(256), 0, st_, M, fronts_.p, B.list.p);
+        }
         for (int l = 0; l + 1 < (int)ptr.size() && l < lend; ++l) {
             const int cnt = ptr[l + 1] - ptr[l];
             if (cnt <= 0) continue;
-            hipLaunchKernelGGL(k_front_factor, dim3(cnt), dim3(256), lds[l], st_, M, fronts_.p, sn_dev + ptr[l], BIG_FRONT, BIG_PIVOTS, rdiag_.p, info_.p);
-            for (int q = ptr[l]; q < ptr[l + 1]; ++q) {
-                const int s = sn[q];
-                const int w = S_.sn_first[s + 1] - S_.sn_first[s];
-                const int f = S_.front_rows_ptr[s + 1] - S_.front_rows_ptr[s];
-                if (f >= BIG_FRONT && w >= BIG_PIVOTS) factor_big_front(M, s, w, f);
-            }
+            const int nbig = B.total > 0 ? B.ptr[l + 1] - B.ptr[l] : 0;
+            if (cnt > nbig) hipLaunchKernelGGL(k_front_factor, dim3(cnt), dim3(256), lds[l], st_, M, fronts_.p, sn_dev + ptr[l], BIG_FRONT, BIG_PIVOTS, rdiag_.p, info_.p);
+            if (nbig <= 0) continue;
+            for (int r = 0; r < B.rounds[l]; ++r) hipLaunchKernelGGL(k_big_extend_add, dim3(64, nbig), dim3(256), 0, st_, M, fronts_.p, B.list.p + B.ptr[l], r);
+            for (int pn = 0; pn < (int)B.rows_below[l].size(); ++pn)
+                dense::launch_front_panels(B.jobs.p + B.ptr[l], nbig, pn, B.rows_below[l][pn], info_.p, rdiag_.p, st_);
         }
     }
     // Substitution by levels: the fronts of a level with at most 128 rows go through the single-wave kernels (one wave per front, vector in
@@ -2028,7 +2101,7 @@ private:
             L.narrow.push_back((int)order.size() - ptr[l]);
             for (int q = ptr[l]; q < ptr[l + 1]; ++q) {
                 const int f = S_.front_rows_ptr[sn[q] + 1] - S_.front_rows_ptr[sn[q]];
-                if (f > 128) { order.push_back(sn[q]); if (f <= WIDE_FCAP) fmax = std::max(fmax, f); }
+                if (f > 128) { order.push_back(sn[q]); if (f <= wide_fcap_) fmax = std::max(fmax, f); }
             }
             L.lds.push_back((((fmax + 1) & ~1) + WIDE_B) * (int)sizeof(double));
         }
@@ -2040,7 +2113,7 @@ private:
             const int cnt = L.ptr[l + 1] - L.ptr[l], nn = cnt > 0 ? L.narrow[l] : 0;
             const int* list = L.dev.p + L.ptr[l];
             if (nn > 0) hipLaunchKernelGGL(k_subtree_fwd_wave<false>, dim3(nn), dim3(64), 0, st_, M, fronts_.p, list, list, xp_.p, fvec_.p, (const int*)nullptr, (int*)nullptr, (int*)nullptr, (const int*)nullptr, 0);
-            if (cnt > nn) hipLaunchKernelGGL(k_front_fwd_wide, dim3(cnt - nn), dim3(WIDE_NT), L.lds[l], st_, M, fronts_.p, list + nn, xp_.p, fvec_.p);
+            if (cnt > nn) hipLaunchKernelGGL(k_front_fwd_wide, dim3(cnt - nn), dim3(WIDE_NT), L.lds[l], st_, M, fronts_.p, list + nn, xp_.p, fvec_.p, wide_fcap_);
         }
     }
     void bwd_levels(const FrontMeta& M, const LevelLists& L)
@@ -2048,7 +2121,7 @@ private:
         for (int l = (int)L.ptr.size() - 2; l >= 0; --l) {
             const int cnt = L.ptr[l + 1] - L.ptr[l], nn = cnt > 0 ? L.narrow[l] : 0;
             const int* list = L.dev.p + L.ptr[l];
-            if (cnt > nn) hipLaunchKernelGGL(k_front_bwd_wide, dim3(cnt - nn), dim3(WIDE_NT), L.lds[l], st_, M, fronts_.p, list + nn, xp_.p, fvec_.p);
+            if (cnt > nn) hipLaunchKernelGGL(k_front_bwd_wide, dim3(cnt - nn), dim3(WIDE_NT), L.lds[l], st_, M, fronts_.p, list + nn, xp_.p, fvec_.p, wide_fcap_);
             if (nn > 0) hipLaunchKernelGGL(k_subtree_bwd_wave<false>, dim3(nn), dim3(64), 0, st_, M, fronts_.p, list, list, xp_.p, bwd_red_thr(), 0, (const int*)nullptr, (int*)nullptr, (int*)nullptr, (const int*)nullptr, 0, (const double*)nullptr);
         }
     }
@@ -2124,8 +2197,7 @@ private:
         vals_.alloc(nnzK_ ? nnzK_ : 1); vals_.zero(st_);
         fronts_.alloc(S_.front_doubles ? (size_t)S_.front_doubles : 1);
         rdiag_.alloc(N_); xp_.alloc(N_); fvec_.alloc(S_.front_rows.size() ? S_.front_rows.size() : 1);
-        dvec_.alloc(dense::FACTOR_NB);
-        dpack_.alloc(dense::FACTOR_PACK_DOUBLES);
+        build_big_levels(S_.top_level_ptr, S_.top_level_sn, top_big_);
         info_.alloc(1); info_h_.alloc(1);
         // value maps K-index -> PKPt-index composed with the per-matrix maps (kkt_full.hpp:219-249)
         const int nzP = d->P_colptr[n_], nzA = p_ ? d->AT_colptr[p_] : 0, nzG = m_ ? d->GT_colptr[m_] : 0;
@@ -2180,41 +2252,6 @@ private:
         PQ_HIP(hipStreamSynchronize(st_));
     }
 
-    // a large front: children merged one kernel per child (stream order = fixed order), then the dense blocked
-    // partial LDLt of the first w columns with the MFMA kernels of the dense path
-    void factor_big_front(const FrontMeta& M, int s, int w, int f)
-    {
-        double* F = fronts_.p + S_.front_off[s];
-        PQ_HIP(hipMemsetAsync(F, 0, sizeof(double) * (size_t)f * f, st_));
-        {
-            const int ne = S_.fe_ptr[s + 1] - S_.fe_ptr[s];
-            if (ne > 0) hipLaunchKernelGGL(k_front_assemble, dim3(std::min(1024, (ne + 255) / 256)), dim3(256), 0, st_, M, fronts_.p, s);
-        }
-        for (int ci = S_.child_ptr[s]; ci < S_.child_ptr[s + 1]; ++ci) {
-            const int c = S_.child[ci];
-            const int uc = (S_.front_rows_ptr[c + 1] - S_.front_rows_ptr[c]) - (S_.sn_first[c + 1] - S_.sn_first[c]);
-            if (uc <= 0) continue;
-            const long long tot = (long long)uc * uc;
-            const int blocks = (int)std::min<long long>(2048, (tot + 255) / 256);
-            hipLaunchKernelGGL(k_front_extend_add_child, dim3(blocks), dim3(256), 0, st_, M, fronts_.p, s, c);
-        }
-        const int NB = dense::FACTOR_NB;
-        double* rd = rdiag_.p + S_.sn_first[s];
-        for (int k = 0; k < w; k += NB) {
-            const int nb = std::min(NB, w - k);
-            const int rs = f - k - nb;
-            dense::launch_potrf_diag(true, F + k + (size_t)k * f, f, nb, S_.sn_first[s] + k, info_.p, rdiag_.p, dvec_.p, rs > 0 ? dpack_.p : nullptr, nullptr, st_);
-            if (rs > 0) {
-                dense::launch_trsm_panel(true, F, f, k, nb, f, dpack_.p, rd, st_);
-                dense::SyrkArgs a;
-                a.n = rs; a.kdim = nb;
-                a.A = F + (k + nb) + (size_t)k * f; a.lda = f; a.B = a.A; a.ldb = f; a.w = dvec_.p;
-                a.C = F + (k + nb) + (size_t)(k + nb) * f; a.ldc = f;
-                dense::launch_syrk(dense::EPI_SUBTRACT, a, st_);
-            }
-        }
-    }
-
     int dev_, mode_ = 0, nzAA_ = 0, nzGG_ = 0, n_ = 0, p_ = 0, m_ = 0, N_ = 0, nnzK_ = 0;
     double delta_ = 1.0;
     hipStream_t st_ = nullptr;
@@ -2224,10 +2261,12 @@ private:
     SubSchedule sched_, part_sched_;
     bool top_persistent_ = false;
     CscOperators ops_;
-    DBuf<double> vals_, fronts_, rdiag_, xp_, fvec_, dvec_, dpack_;
+    DBuf<double> vals_, fronts_, rdiag_, xp_, fvec_;
     DBuf<int> fe_ptr_, fe_q_, fe_off_, fe_offp_, top_pos_, top_flags_, solve_level_sn_, solve_top_pos_, solve_flags_, solve_walk_lo_, solve_walk_hi_, solve_pub_;
     SubSchedule solve_sched_;
     LevelLists solve_ll_, own_ll_, sh_ll_;
+    int wide_fcap_ = debug_token("no_wide_solve") ? 0 : WIDE_FCAP;  // debugging aid: wide fronts through the per-pivot routines
+    BigLevels top_big_, own_big_, sh_big_;
     int ntop_solve_ = 0, nwalk_solve_ = 0, solve_epoch_ = 0, solve_epoch_used_ = 0, factor_epoch_ = 0;
     const int* solve_err_ptr_ = nullptr;
     DBuf<int> top_walk_lo_, top_walk_hi_;
