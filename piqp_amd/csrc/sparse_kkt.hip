@@ -6,7 +6,7 @@
 //   LDLt::factorize_numeric (ldlt.hpp:101-169,         supernodal multifrontal LDLt: fronts assembled from the PKPt values
 //     up-looking, serial over rows)                    per tree level k_front_factor (extend-add + partial dense LDLt,
 //                                                      one workgroup per front, LDS-resident when it fits); fronts
-//                                                      wider than BIG_FRONT go through the dense MFMA panel kernels
+//                                                      that big_front() selects go through the dense MFMA panel kernels, a tree level at a time
 //   lsolve/dsolve/ltsolve + perm/permt (ldlt:171-218)  k_perm_gather, per level k_subtree_fwd_wave / k_front_fwd_wide, k_scale, k_front_bwd_wide / k_subtree_bwd_wave, k_perm_scatter
 //   eval_P_x / eval_A.. / eval_G.. (kkt.hpp:179-203)   k_spmv_cols on CSC copies (P symmetrised, A and G kept in both
 //                                                      orientations so every product is a conflict-free column dot)
@@ -28,13 +28,24 @@ namespace pq {
 
 namespace {
 
-constexpr int BIG_FRONT = 192;      // fronts at least this large with >= BIG_PIVOTS pivots use the dense multi-workgroup kernels
-constexpr int BIG_PIVOTS = 32;
+// Fronts that go through the dense multi-workgroup MFMA kernels (all such fronts of a tree level together: ~80 us per level and panel whatever
+// their number) instead of one workgroup's pivot loop (1.5 - 2.5 us per pivot).  Fronts under 96 rows never do: C3 / C5-type trees (fronts <= 92
+// rows) keep their persistent top launch.
+__host__ __device__ inline bool big_front(int f, int w) { return f >= 192 && w >= 32; }
 constexpr int SUB_SOLVE_THREADS = 64;   // substitution inside a subtree is a chain of short vector operations: one wave per subtree
 constexpr int SUBTREE_LDS_BYTES = 150 * 1024;  // two fronts of the LDS-native subtree walker
 constexpr int SUB_THREADS = 256;    // small subtrees: fronts reach ~100 rows near the subtree root, so a full workgroup (64 threads measured 2x slower)
 constexpr int IND_SCRATCH = 128;     // doubles of LDS behind a front for the reciprocals of its independent leading pivots
 constexpr int LDS_FRONT_DOUBLES = 12288;  // 96 KiB: fronts up to 110 x 110 are factored inside LDS
+// doubles of LDS a one-workgroup front works in: the whole front when it fits, else its f x w pivot panel when that fits (the pivot loop then runs
+// at LDS latency, 0.2 - 0.3 us per pivot, and only the one-pass Schur complement touches the trailing block in HBM), else nothing (all in HBM:
+// a global-memory round trip per pivot, 5 - 10 us)
+__host__ __device__ inline long long front_lds_doubles(long long f, long long w)
+{
+    if (f * f <= LDS_FRONT_DOUBLES) return f * f;
+    if (w > 0 && f * w <= LDS_FRONT_DOUBLES) return f * w;
+    return 0;
+}
 
 struct SnRec {  // everything the numeric kernels need about one supernode, in one 32-byte record (one load instead of a
                  // chain of dependent loads through six index arrays)
@@ -158,8 +169,10 @@ __device__ __forceinline__ double pivot_rcp(double d)
 
 // Schur complement of the trailing u x u block in one pass, T[i,j] -= sum_k (L[i,k] d_k) L[j,k] (k ascending, lower triangle), 2 x 2 entries
 // per thread: five LDS reads feed four FMAs instead of twelve
-__device__ __forceinline__ void schur_2x2(double* __restrict__ W, int f, int w, int u, int tid, int nt)
+template <bool SPLIT>  // SPLIT: the panel L (LDS) and the trailing block T (HBM) are different arrays with the same f x f indexing
+__device__ __forceinline__ void schur_2x2(const double* __restrict__ Lp, double* __restrict__ Tp, int f, int w, int u, int tid, int nt)
 {
+    const double* W = Lp;
     const int tx = tid & 15, ty = tid >> 4, tys = nt >> 4;
     const int nb = (u + 1) >> 1;
     for (int bj = ty; bj < nb; bj += tys) {
@@ -177,7 +190,7 @@ __device__ __forceinline__ void schur_2x2(double* __restrict__ W, int f, int w, 
                 const double x0 = Li0[ck] * dk, x1 = Li1[ck] * dk, y0 = Lj0[ck], y1 = Lj1[ck];
                 a00 += x0 * y0; a01 += x0 * y1; a10 += x1 * y0; a11 += x1 * y1;
             }
-            double* T = W + (w + i0) + (long long)(w + j0) * f;
+            double* T = Tp + (w + i0) + (long long)(w + j0) * f;
             T[0] -= a00;                                   // i0 >= j0 always
             if (i1ok) T[1] -= a10;                         // (i0 + 1, j0)
             if (j1ok && i0 >= j0 + 1) T[f] -= a01;         // (i0, j0 + 1): below / on the diagonal only
@@ -227,23 +240,32 @@ __device__ __forceinline__ void front_assemble_own(const FrontMeta& M, double* _
     }
     __syncthreads();
 }
-// IN_LDS: the front is worked on in LDS (W == lds) and copied out at the end; otherwise in place in HBM (W == F).  Two instantiations instead of
-// one pointer chosen at run time -- such a pointer compiles to FLAT loads / stores (k_front_factor had 20 + 10 of them in its pivot loops).
-template <bool IN_LDS>
+// Where the front is worked on -- FRONT_LDS: all of it in LDS (W == lds), copied out at the end; FRONT_HBM: in place (W == F); FRONT_PANEL: assembled in
+// place, then its f x w pivot panel is staged in LDS for the pivot loop (W == lds, same column stride f) and only the Schur complement goes back to the
+// trailing block in HBM.  Same operations in the same order in all three.  Instantiations instead of one pointer chosen at run time -- such a
+// pointer compiles to FLAT loads / stores (k_front_factor had 20 + 10 of them in its pivot loops).
+enum { FRONT_HBM = 0, FRONT_LDS = 1, FRONT_PANEL = 2 };
+template <int WHERE>
 __device__ __forceinline__ void front_factor_body(const FrontMeta& M, double* __restrict__ fronts, int s, const SnRec& me, double* __restrict__ rdiag,
                                                   int* __restrict__ info, double* __restrict__ lds, double* __restrict__ W)
 {
     const int first = me.first, w = me.w, f = me.f;
     double* F = fronts + me.front_off;
-    constexpr bool in_lds = IN_LDS;
-    extend_add(M, fronts, s, W, f);
+    constexpr bool in_lds = WHERE == FRONT_LDS;
+    if constexpr (WHERE == FRONT_PANEL) {
+        extend_add(M, fronts, s, F, f);
+        for (int idx = threadIdx.x; idx < f * w; idx += blockDim.x) lds[idx] = F[idx];
+        __syncthreads();
+    } else {
+        extend_add(M, fronts, s, W, f);
+    }
     // ---- panel: right-looking LDLt of the first w columns, updates confined to the panel (rows k+1..f-1, columns k+1..w-1)
     const int tid = threadIdx.x, nt = blockDim.x;
     int k0 = 0;
     if (me.nind >= 2) {
         // independent leading pivots (merged sibling leaves): one pass instead of nind barriers, see independent_pivots_pk
         const int ni = min(me.nind, IND_SCRATCH);
-        double* scratch = in_lds ? lds + f * f : lds;
+        double* scratch = in_lds ? lds + f * f : (WHERE == FRONT_PANEL ? lds + f * w : lds);
         const int tx = tid & 15, ty = tid >> 4, tys = nt >> 4;
         for (int k = tid; k < ni; k += nt) {
             double d = W[k + (long long)k * f];
@@ -300,8 +322,12 @@ __device__ __forceinline__ void front_factor_body(const FrontMeta& M, double* __
     // ---- Schur complement of the trailing block in one pass: T[i,j] -= sum_k L[i,k] d_k L[j,k]  (no barriers, long dot products)
     const int u = f - w;
     if (u > 0) {
-        schur_2x2(W, f, w, u, tid, nt);
+        if constexpr (WHERE == FRONT_PANEL) schur_2x2<true>(lds, F, f, w, u, tid, nt);
+        else schur_2x2<false>(W, W, f, w, u, tid, nt);
         __syncthreads();
+    }
+    if constexpr (WHERE == FRONT_PANEL) {
+        for (int idx = threadIdx.x; idx < f * w; idx += blockDim.x) F[idx] = lds[idx];
     }
     if (in_lds) {
         // the factor panel (contiguous) and the lower triangle of the update matrix: nobody reads the rest
@@ -312,24 +338,25 @@ __device__ __forceinline__ void front_factor_body(const FrontMeta& M, double* __
     }
 }
 
-__device__ __forceinline__ void front_factor(const FrontMeta& M, double* __restrict__ fronts, int s, int big_front, int big_pivots, double* __restrict__ rdiag,
+__device__ __forceinline__ void front_factor(const FrontMeta& M, double* __restrict__ fronts, int s, bool skip_big, double* __restrict__ rdiag,
                                              int* __restrict__ info, double* __restrict__ lds, bool own_assembled = false)
 {
     const SnRec me = M.sn[s];
     const int w = me.w, f = me.f;
-    if (f >= big_front && w >= big_pivots) return;  // handled by the dense path
+    if (skip_big && big_front(f, w)) return;  // handled by the dense path
     // assembly: zero, own K entries, then the children's update matrices (fixed order)
     if (!own_assembled) front_assemble_own(M, fronts, me, lds);
-    if ((long long)f * f <= LDS_FRONT_DOUBLES) front_factor_body<true>(M, fronts, s, me, rdiag, info, lds, lds);
-    else front_factor_body<false>(M, fronts, s, me, rdiag, info, lds, fronts + me.front_off);
+    if ((long long)f * f <= LDS_FRONT_DOUBLES) front_factor_body<FRONT_LDS>(M, fronts, s, me, rdiag, info, lds, lds);
+    else if (front_lds_doubles(f, w) > 0) front_factor_body<FRONT_PANEL>(M, fronts, s, me, rdiag, info, lds, lds);
+    else front_factor_body<FRONT_HBM>(M, fronts, s, me, rdiag, info, lds, fronts + me.front_off);
 }
 
 // one workgroup per front of an assembly-tree level
-__global__ __launch_bounds__(256) void k_front_factor(FrontMeta M, double* __restrict__ fronts, const int* __restrict__ list, int big_front, int big_pivots,
+__global__ __launch_bounds__(256) void k_front_factor(FrontMeta M, double* __restrict__ fronts, const int* __restrict__ list,
                                                       double* __restrict__ rdiag, int* __restrict__ info)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    front_factor(M, fronts, list[blockIdx.x], big_front, big_pivots, rdiag, info, lds);
+    front_factor(M, fronts, list[blockIdx.x], true, rdiag, info, lds);
 }
 
 // One workgroup per small subtree, fronts never leave LDS: the front of supernode s is zeroed and assembled in LDS from the
@@ -562,7 +589,7 @@ __global__ __launch_bounds__(1024) void k_subtree_factor_lds(FrontMeta M, double
         // ---- Schur complement
         const int u = f - w;
         if (u > 0) {
-            schur_2x2(W, f, w, u, tid, nt);
+            schur_2x2<false>(W, W, f, w, u, tid, nt);
             __syncthreads();
         }
         // ---- factor panel to HBM (the first w columns of the front are contiguous); update matrix only if nobody reads it from LDS
@@ -596,7 +623,7 @@ __global__ __launch_bounds__(SUB_THREADS) void k_subtree_factor(FrontMeta M, dou
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int lo = sub_lo[blockIdx.x], hi = sub_hi[blockIdx.x];
     for (int s = lo; s <= hi; ++s) {
-        front_factor(M, fronts, s, 1 << 30, 1 << 30, rdiag, info, lds);
+        front_factor(M, fronts, s, false, rdiag, info, lds);
         __syncthreads();
     }
 }
@@ -604,7 +631,7 @@ __global__ __launch_bounds__(SUB_THREADS) void k_subtree_factor(FrontMeta M, dou
 // extend-add of ONE child into a front that is then factored by the dense kernels (one launch per child: stream
 // order = fixed merge order, entries of one child never collide)
 // own K entries of ONE front that the dense multi-workgroup path factors (the front was zeroed by a memset on the stream)
-// ---- big fronts (>= BIG_FRONT rows, >= BIG_PIVOTS pivots): the dense MFMA panel kernels factor them, ALL big fronts of a tree level per launch
+// ---- big fronts (big_front() above): the dense MFMA panel kernels factor them, ALL big fronts of a tree level per launch
 // (blockIdx.y = front of the level's list).  Zero-fill and the front's own K entries need nothing from the children: one launch each for every
 // big front of the tree at the start of the factorisation.  The children are merged in rounds -- round r adds child r of every front --, so
 // an entry receives its contributions in child order whatever the grid (fixed summation order).
@@ -1227,7 +1254,7 @@ __global__ __launch_bounds__(512) void k_top_factor(FrontMeta M, double* __restr
             if (any) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
         __syncthreads();
-        front_factor(M, fronts, s, 1 << 30, 1 << 30, rdiag, info, lds, true);
+        front_factor(M, fronts, s, false, rdiag, info, lds, true);
         top_done(flags + b, epoch);
     }
 }
@@ -1607,7 +1634,7 @@ public:
                     if (PT_.owner[s] != want) continue;
                     sn.push_back(s);
                     const long long f = S_.front_rows_ptr[s + 1] - S_.front_rows_ptr[s];
-                    if (f * f <= LDS_FRONT_DOUBLES) mx = std::max(mx, f * f);
+                    mx = std::max(mx, front_lds_doubles(f, S_.sn_first[s + 1] - S_.sn_first[s]));
                 }
                 if (sn.size() > before) { ptr.push_back((int)sn.size()); lds.push_back(((int)mx + IND_SCRATCH) * (int)sizeof(double)); }
             }
@@ -1679,7 +1706,12 @@ public:
                     const int w = S_.sn_first[s2 + 1] - S_.sn_first[s2], f = S_.front_rows_ptr[s2 + 1] - S_.front_rows_ptr[s2];
                     mf = std::max(mf, f); mw = std::max(mw, w); fl += (double)w * f * f;
                 }
-                std::printf("  top level %2d: %5d fronts, max front %4d, max pivots %3d, sum w f^2 = %.2e\n", l, S_.top_level_ptr[l + 1] - S_.top_level_ptr[l], mf, mw, fl);
+                std::printf("  top level %2d: %5d fronts, max front %4d, max pivots %3d, sum w f^2 = %.2e;  one-workgroup fronts (f x w) by pivots:", l, S_.top_level_ptr[l + 1] - S_.top_level_ptr[l], mf, mw, fl);
+                std::vector<std::pair<int, int>> small;
+                for (int q = S_.top_level_ptr[l]; q < S_.top_level_ptr[l + 1]; ++q) if (!is_big(S_.top_level_sn[q])) { const int s2 = S_.top_level_sn[q]; small.push_back({S_.sn_first[s2 + 1] - S_.sn_first[s2], S_.front_rows_ptr[s2 + 1] - S_.front_rows_ptr[s2]}); }
+                std::sort(small.rbegin(), small.rend());
+                for (size_t q = 0; q < small.size() && q < 4; ++q) std::printf(" %dx%d", small[q].second, small[q].first);
+                std::printf("\n");
             }
         }
         for (const SubClass& c : sched_.cls)
@@ -1747,13 +1779,13 @@ private:
             for (int q = S_.top_level_ptr[l]; q < S_.top_level_ptr[l + 1]; ++q) {
                 const int s = S_.top_level_sn[q];
                 const long long f = S_.front_rows_ptr[s + 1] - S_.front_rows_ptr[s];
-                if (f * f <= LDS_FRONT_DOUBLES) mx = std::max(mx, f * f);
+                mx = std::max(mx, front_lds_doubles(f, S_.sn_first[s + 1] - S_.sn_first[s]));
             }
             level_lds_[l] = ((int)mx + IND_SCRATCH) * (int)sizeof(double);
         }
         {
             const long long f = S_.sub_max_front;
-            sub_lds_ = (int)((std::min<long long>(f * f, LDS_FRONT_DOUBLES) + IND_SCRATCH) * (long long)sizeof(double));
+            sub_lds_ = (int)((std::min<long long>(f * f, LDS_FRONT_DOUBLES) + IND_SCRATCH) * (long long)sizeof(double));  // (a front that does not fit may still stage its panel: the cap covers it)
         }
         // single-launch top of the tree: possible when no top front needs the multi-launch dense path
         ntop_ = (int)S_.top_level_sn.size();
@@ -1762,8 +1794,8 @@ private:
         for (int s : S_.top_level_sn) {
             const int w = S_.sn_first[s + 1] - S_.sn_first[s];
             const long long f = S_.front_rows_ptr[s + 1] - S_.front_rows_ptr[s];
-            if (f >= BIG_FRONT && w >= BIG_PIVOTS) any_big = true;
-            if (f * f <= LDS_FRONT_DOUBLES) top_mx = std::max(top_mx, f * f);
+            if (big_front((int)f, w)) any_big = true;
+            top_mx = std::max(top_mx, front_lds_doubles(f, w));
         }
         top_lds_ = ((int)top_mx + IND_SCRATCH) * (int)sizeof(double);
         top_grid_ = std::min(ntop_, 224);
@@ -1777,7 +1809,7 @@ private:
                 bool big = false;
                 for (int q = S_.top_level_ptr[l]; q < S_.top_level_ptr[l + 1]; ++q) {
                     const int s = S_.top_level_sn[q];
-                    if (S_.front_rows_ptr[s + 1] - S_.front_rows_ptr[s] >= BIG_FRONT && S_.sn_first[s + 1] - S_.sn_first[s] >= BIG_PIVOTS) big = true;
+                    if (is_big(s)) big = true;
                 }
                 if (big || ntop_ - S_.top_level_ptr[l] > 1024) break;
                 top_l0_ = l;
@@ -2014,7 +2046,7 @@ private:
     // ---- big fronts of a level schedule, grouped by level for the batched dense path
     bool is_big(int s) const
     {
-        return S_.front_rows_ptr[s + 1] - S_.front_rows_ptr[s] >= BIG_FRONT && S_.sn_first[s + 1] - S_.sn_first[s] >= BIG_PIVOTS;
+        return big_front(S_.front_rows_ptr[s + 1] - S_.front_rows_ptr[s], S_.sn_first[s + 1] - S_.sn_first[s]);
     }
     struct BigLevels {
         std::vector<int> ptr, rounds;            // level l of the schedule -> jobs [ptr[l], ptr[l + 1]); children of its widest fan-in
@@ -2077,7 +2109,7 @@ private:
             const int cnt = ptr[l + 1] - ptr[l];
             if (cnt <= 0) continue;
             const int nbig = B.total > 0 ? B.ptr[l + 1] - B.ptr[l] : 0;
-            if (cnt > nbig) hipLaunchKernelGGL(k_front_factor, dim3(cnt), dim3(256), lds[l], st_, M, fronts_.p, sn_dev + ptr[l], BIG_FRONT, BIG_PIVOTS, rdiag_.p, info_.p);
+            if (cnt > nbig) hipLaunchKernelGGL(k_front_factor, dim3(cnt), dim3(256), lds[l], st_, M, fronts_.p, sn_dev + ptr[l], rdiag_.p, info_.p);
             if (nbig <= 0) continue;
             for (int r = 0; r < B.rounds[l]; ++r) hipLaunchKernelGGL(k_big_extend_add, dim3(64, nbig), dim3(256), 0, st_, M, fronts_.p, B.list.p + B.ptr[l], r);
             for (int pn = 0; pn < (int)B.rows_below[l].size(); ++pn)
