@@ -1049,7 +1049,7 @@ __global__ __launch_bounds__(POTRF_THREADS) void k_potrf_diag_fronts(const Front
 {
     const FrontJob j = jobs[blockIdx.x];
     int k, nb, rs;
-    if (!front_panel(j, panel, k, nb, rs)) return;
+    if (j.kind != 0 || !front_panel(j, panel, k, nb, rs)) return;
     potrf_diag_body<true>(j.F + k + (size_t)k * j.f, j.f, nb, j.first + k, info, rdiag, j.dvec, rs > 0 ? j.pack : nullptr, nullptr, nullptr);
 }
 
@@ -1354,27 +1354,34 @@ __global__ __launch_bounds__(256) void k_trsm_panel_fronts(const FrontJob* __res
 {
     const FrontJob j = jobs[blockIdx.y];
     int k, nb, rs;
-    if (!front_panel(j, panel, k, nb, rs) || (int)blockIdx.x * TRSM_ROWS >= rs) return;
+    if (j.kind != 0 || !front_panel(j, panel, k, nb, rs) || (int)blockIdx.x * TRSM_ROWS >= rs) return;
     trsm_panel_body<true>(j.F, j.f, k, nb, j.f, j.pack, rdiag + j.first, (int)blockIdx.x);
 }
 
-// one panel step of the partial LDLt of many fronts: diagonal blocks, panels, trailing updates -- three launches whatever the number of fronts
-void launch_front_panels(const FrontJob* jobs, int njobs, int panel, int max_rows_below, int* info, double* rdiag, hipStream_t s)
+// one panel step of the partial LDLt of many fronts: diagonal blocks and panels (two launches whatever the number of fronts), then the trailing updates
+static void front_attrs()
+{
+    static bool attr_set = false;
+    if (attr_set) return;
+    PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_diag_fronts), hipFuncAttributeMaxDynamicSharedMemorySize, POTRF_LDS_BYTES));
+    PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_trsm_panel_fronts), hipFuncAttributeMaxDynamicSharedMemorySize, TRSM_LDS_BYTES));
+    PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk_lower_fronts<4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, SYRK_LDS_BYTES));
+    attr_set = true;
+}
+void launch_front_diag_panels(const FrontJob* jobs, int njobs, int panel, int max_rows_below, int* info, double* rdiag, hipStream_t s)
 {
     if (njobs <= 0) return;
-    static bool attr_set = false;
-    if (!attr_set) {
-        PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_diag_fronts), hipFuncAttributeMaxDynamicSharedMemorySize, POTRF_LDS_BYTES));
-        PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_trsm_panel_fronts), hipFuncAttributeMaxDynamicSharedMemorySize, TRSM_LDS_BYTES));
-        PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk_lower_fronts<4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, SYRK_LDS_BYTES));
-        attr_set = true;
-    }
+    front_attrs();
     hipLaunchKernelGGL(k_potrf_diag_fronts, dim3(njobs), dim3(POTRF_THREADS), POTRF_LDS_BYTES, s, jobs, panel, info, rdiag);
-    if (max_rows_below > 0) {
-        hipLaunchKernelGGL(k_trsm_panel_fronts, dim3(div_up(max_rows_below, TRSM_ROWS), njobs), dim3(256), TRSM_LDS_BYTES, s, jobs, panel, rdiag);
-        const int T = div_up(max_rows_below, TS);
-        hipLaunchKernelGGL((k_syrk_lower_fronts<4, 4>), dim3(T * (T + 1) / 2, njobs), dim3(1024), SYRK_LDS_BYTES, s, jobs, panel);
-    }
+    if (max_rows_below > 0) hipLaunchKernelGGL(k_trsm_panel_fronts, dim3(div_up(max_rows_below, TRSM_ROWS), njobs), dim3(256), TRSM_LDS_BYTES, s, jobs, panel, rdiag);
+    PQ_HIP(hipGetLastError());
+}
+void launch_front_updates(const FrontJob* jobs, int njobs, int panel, int max_rows_below, hipStream_t s)
+{
+    if (njobs <= 0 || max_rows_below <= 0) return;
+    front_attrs();
+    const int T = div_up(max_rows_below, TS);
+    hipLaunchKernelGGL((k_syrk_lower_fronts<4, 4>), dim3(T * (T + 1) / 2, njobs), dim3(1024), SYRK_LDS_BYTES, s, jobs, panel);
     PQ_HIP(hipGetLastError());
 }
 

@@ -84,9 +84,12 @@ struct FrontJob {
     double* F = nullptr;
     int f = 0, w = 0, first = 0;  // order, pivot columns, global index of the first pivot (rdiag / info)
     double* pack = nullptr;       // FACTOR_PACK_DOUBLES of scratch owned by this front for the duration of the level
-    double* dvec = nullptr;       // FACTOR_NB doubles, likewise
+    double* dvec = nullptr;       // FACTOR_NB doubles, likewise: D of the current panel
+    int kind = 0;                 // 0: diagonal block + panel by launch_front_diag_panels; 1: the caller factors the (single, w <= FACTOR_NB) panel
+                                  //    itself and leaves D in dvec -- only the trailing update runs here
 };
-void launch_front_panels(const FrontJob* jobs_device, int njobs, int panel, int max_rows_below, int* info, double* rdiag, hipStream_t s);
+void launch_front_diag_panels(const FrontJob* jobs_device, int njobs, int panel, int max_rows_below, int* info, double* rdiag, hipStream_t s);
+void launch_front_updates(const FrontJob* jobs_device, int njobs, int panel, int max_rows_below, hipStream_t s);  // T -= L D L^T of panel `panel`, all fronts
 
 }  // namespace dense
 }  // namespace pq

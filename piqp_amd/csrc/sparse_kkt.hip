@@ -46,6 +46,11 @@ __host__ __device__ inline long long front_lds_doubles(long long f, long long w)
     if (w > 0 && f * w <= LDS_FRONT_DOUBLES) return f * w;
     return 0;
 }
+// A level-scheduled front that stages its panel: zero-fill, own entries and the children's update matrices are handled by the multi-workgroup kernels
+// of the big fronts (a single workgroup pays a memory round trip per handful of entries there), one workgroup factors the panel in LDS
+// (k_front_panel: the same rank-1 pivot loop as everywhere, no inverted blocks), and the Schur complement T -= L D L^T runs on the matrix cores
+// with the trailing updates of the level's big fronts (k_syrk_lower_fronts)
+__host__ __device__ inline bool panel_front(long long f, long long w) { return !big_front((int)f, (int)w) && f * f > LDS_FRONT_DOUBLES && w > 0 && f * w <= LDS_FRONT_DOUBLES; }
 
 struct SnRec {  // everything the numeric kernels need about one supernode, in one 32-byte record (one load instead of a
                  // chain of dependent loads through six index arrays)
@@ -213,7 +218,24 @@ __device__ __forceinline__ void extend_add(const FrontMeta& M, double* __restric
             const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4, tys = blockDim.x >> 4;
             for (int j = ty; j < uc; j += tys) {
                 const long long cj = (long long)rel[j] * f;
-                for (int i = j + tx; i < uc; i += 16) F[rel[i] + cj] += U[i + (long long)j * fc];
+                const double* __restrict__ Uj = U + (long long)j * fc;
+                // four entries per step, all loads before the first store: the child's update matrix and this front never overlap, but both hang off
+                // `fronts`, and a load the compiler must keep behind the previous store costs a memory round trip per entry (front in HBM)
+                for (int i = j + tx; i < uc; i += 64) {
+                    double uv[4], fv[4];
+                    long long at[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int iq = i + 16 * q;
+                        const bool ok = iq < uc;
+                        at[q] = ok ? rel[iq] + cj : -1;
+                        uv[q] = ok ? Uj[iq] : 0.0;
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) fv[q] = at[q] >= 0 ? F[at[q]] : 0.0;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) if (at[q] >= 0) F[at[q]] = fv[q] + uv[q];
+                }
             }
         }
         __syncthreads();
@@ -244,17 +266,27 @@ __device__ __forceinline__ void front_assemble_own(const FrontMeta& M, double* _
 // place, then its f x w pivot panel is staged in LDS for the pivot loop (W == lds, same column stride f) and only the Schur complement goes back to the
 // trailing block in HBM.  Same operations in the same order in all three.  Instantiations instead of one pointer chosen at run time -- such a
 // pointer compiles to FLAT loads / stores (k_front_factor had 20 + 10 of them in its pivot loops).
-enum { FRONT_HBM = 0, FRONT_LDS = 1, FRONT_PANEL = 2 };
+enum { FRONT_HBM = 0, FRONT_LDS = 1, FRONT_PANEL = 2, FRONT_PANEL_ONLY = 3 };  // PANEL_ONLY: assembled by other kernels, Schur complement by another kernel (D left in `dvec`)
 template <int WHERE>
 __device__ __forceinline__ void front_factor_body(const FrontMeta& M, double* __restrict__ fronts, int s, const SnRec& me, double* __restrict__ rdiag,
-                                                  int* __restrict__ info, double* __restrict__ lds, double* __restrict__ W)
+                                                  int* __restrict__ info, double* __restrict__ lds, double* __restrict__ W, double* __restrict__ dvec = nullptr)
 {
     const int first = me.first, w = me.w, f = me.f;
     double* F = fronts + me.front_off;
     constexpr bool in_lds = WHERE == FRONT_LDS;
-    if constexpr (WHERE == FRONT_PANEL) {
-        extend_add(M, fronts, s, F, f);
-        for (int idx = threadIdx.x; idx < f * w; idx += blockDim.x) lds[idx] = F[idx];
+    constexpr bool panel = WHERE == FRONT_PANEL || WHERE == FRONT_PANEL_ONLY;
+    if constexpr (panel) {
+        if constexpr (WHERE == FRONT_PANEL) extend_add(M, fronts, s, F, f);
+        {   // stage the panel, eight loads in flight per thread
+            const int n = f * w, nt8 = 8 * blockDim.x;
+            for (int base = 0; base < n; base += nt8) {
+                double v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { const int idx = base + q * blockDim.x + threadIdx.x; v[q] = idx < n ? F[idx] : 0.0; }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { const int idx = base + q * blockDim.x + threadIdx.x; if (idx < n) lds[idx] = v[q]; }
+            }
+        }
         __syncthreads();
     } else {
         extend_add(M, fronts, s, W, f);
@@ -265,7 +297,7 @@ __device__ __forceinline__ void front_factor_body(const FrontMeta& M, double* __
     if (me.nind >= 2) {
         // independent leading pivots (merged sibling leaves): one pass instead of nind barriers, see independent_pivots_pk
         const int ni = min(me.nind, IND_SCRATCH);
-        double* scratch = in_lds ? lds + f * f : (WHERE == FRONT_PANEL ? lds + f * w : lds);
+        double* scratch = in_lds ? lds + f * f : (panel ? lds + f * w : lds);
         const int tx = tid & 15, ty = tid >> 4, tys = nt >> 4;
         for (int k = tid; k < ni; k += nt) {
             double d = W[k + (long long)k * f];
@@ -319,6 +351,11 @@ __device__ __forceinline__ void front_factor_body(const FrontMeta& M, double* __
         }
     }
     __syncthreads();
+    if constexpr (WHERE == FRONT_PANEL_ONLY) {
+        for (int k = tid; k < w; k += nt) { const double d = lds[k + k * f]; dvec[k] = d == 0.0 ? 1.0 : d; }
+        for (int idx = tid; idx < f * w; idx += nt) F[idx] = lds[idx];
+        return;
+    }
     // ---- Schur complement of the trailing block in one pass: T[i,j] -= sum_k L[i,k] d_k L[j,k]  (no barriers, long dot products)
     const int u = f - w;
     if (u > 0) {
@@ -343,7 +380,7 @@ __device__ __forceinline__ void front_factor(const FrontMeta& M, double* __restr
 {
     const SnRec me = M.sn[s];
     const int w = me.w, f = me.f;
-    if (skip_big && big_front(f, w)) return;  // handled by the dense path
+    if (skip_big && (big_front(f, w) || panel_front(f, w))) return;  // handled by the multi-workgroup path of its level
     // assembly: zero, own K entries, then the children's update matrices (fixed order)
     if (!own_assembled) front_assemble_own(M, fronts, me, lds);
     if ((long long)f * f <= LDS_FRONT_DOUBLES) front_factor_body<FRONT_LDS>(M, fronts, s, me, rdiag, info, lds, lds);
@@ -357,6 +394,18 @@ __global__ __launch_bounds__(256) void k_front_factor(FrontMeta M, double* __res
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     front_factor(M, fronts, list[blockIdx.x], true, rdiag, info, lds);
+}
+
+// panel of every panel_front() of a level's job list (blockIdx.x = job; the other jobs are the dense path's)
+__global__ __launch_bounds__(256) void k_front_panel(FrontMeta M, double* __restrict__ fronts, const int* __restrict__ list, const dense::FrontJob* __restrict__ jobs,
+                                                     double* __restrict__ rdiag, int* __restrict__ info)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const dense::FrontJob j = jobs[blockIdx.x];
+    if (j.kind != 1) return;
+    const int s = list[blockIdx.x];
+    const SnRec me = M.sn[s];
+    front_factor_body<FRONT_PANEL_ONLY>(M, fronts, s, me, rdiag, info, lds, lds, j.dvec);
 }
 
 // One workgroup per small subtree, fronts never leave LDS: the front of supernode s is zeroed and assembled in LDS from the
@@ -661,8 +710,22 @@ __global__ __launch_bounds__(256) void k_big_extend_add(FrontMeta M, double* __r
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;  // 16 rows x 16 columns of the child's update matrix per step
     for (int j = blockIdx.x * 16 + ty; j < uc; j += gridDim.x * 16) {
         const long long cj = (long long)rel[j] * f;
-        const double* Uj = U + (long long)j * fc;
-        for (int i = j + tx; i < uc; i += 16) F[rel[i] + cj] += Uj[i];
+        const double* __restrict__ Uj = U + (long long)j * fc;
+        for (int i = j + tx; i < uc; i += 64) {  // four entries per step, loads before stores (see extend_add)
+            double uv[4], fv[4];
+            long long at[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int iq = i + 16 * q;
+                const bool ok = iq < uc;
+                at[q] = ok ? rel[iq] + cj : -1;
+                uv[q] = ok ? Uj[iq] : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) fv[q] = at[q] >= 0 ? F[at[q]] : 0.0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) if (at[q] >= 0) F[at[q]] = fv[q] + uv[q];
+        }
     }
 }
 
@@ -1767,6 +1830,7 @@ private:
         static bool attr_set = false;
         if (!attr_set) {
             PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_front_factor), hipFuncAttributeMaxDynamicSharedMemorySize, (LDS_FRONT_DOUBLES + IND_SCRATCH) * (int)sizeof(double)));
+            PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_front_panel), hipFuncAttributeMaxDynamicSharedMemorySize, (LDS_FRONT_DOUBLES + IND_SCRATCH) * (int)sizeof(double)));
             PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_subtree_factor), hipFuncAttributeMaxDynamicSharedMemorySize, (LDS_FRONT_DOUBLES + IND_SCRATCH) * (int)sizeof(double)));
             PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_subtree_factor_lds), hipFuncAttributeMaxDynamicSharedMemorySize, SUBTREE_LDS_BYTES));
             PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_subtree_factor_pk), hipFuncAttributeMaxDynamicSharedMemorySize, SUBTREE_LDS_BYTES));
@@ -1794,7 +1858,7 @@ private:
         for (int s : S_.top_level_sn) {
             const int w = S_.sn_first[s + 1] - S_.sn_first[s];
             const long long f = S_.front_rows_ptr[s + 1] - S_.front_rows_ptr[s];
-            if (big_front((int)f, w)) any_big = true;
+            if (big_front((int)f, w) || panel_front(f, w)) any_big = true;
             top_mx = std::max(top_mx, front_lds_doubles(f, w));
         }
         top_lds_ = ((int)top_mx + IND_SCRATCH) * (int)sizeof(double);
@@ -2046,10 +2110,11 @@ private:
     // ---- big fronts of a level schedule, grouped by level for the batched dense path
     bool is_big(int s) const
     {
-        return big_front(S_.front_rows_ptr[s + 1] - S_.front_rows_ptr[s], S_.sn_first[s + 1] - S_.sn_first[s]);
+        const int f = S_.front_rows_ptr[s + 1] - S_.front_rows_ptr[s], w = S_.sn_first[s + 1] - S_.sn_first[s];
+        return big_front(f, w) || panel_front(f, w);
     }
     struct BigLevels {
-        std::vector<int> ptr, rounds;            // level l of the schedule -> jobs [ptr[l], ptr[l + 1]); children of its widest fan-in
+        std::vector<int> ptr, rounds, ndense, npanel, panel_lds;  // level l of the schedule -> jobs [ptr[l], ptr[l + 1]); children of its widest fan-in; jobs by kind; LDS of k_front_panel
         std::vector<std::vector<int>> rows_below;  // per level, per panel: most rows below the diagonal block over the level's fronts (0 = none)
         int total = 0, max_f = 0, max_own = 0;
         DBuf<int> list;
@@ -2058,17 +2123,19 @@ private:
     };
     void build_big_levels(const std::vector<int>& ptr, const std::vector<int>& sn, BigLevels& B)
     {
-        B.ptr.assign(1, 0); B.rounds.clear(); B.rows_below.clear(); B.total = 0; B.max_f = 0; B.max_own = 0;
+        B.ptr.assign(1, 0); B.rounds.clear(); B.rows_below.clear(); B.ndense.clear(); B.npanel.clear(); B.panel_lds.clear(); B.total = 0; B.max_f = 0; B.max_own = 0;
         std::vector<int> list;
         int widest = 0;
         for (int l = 0; l + 1 < (int)ptr.size(); ++l) {
-            int rounds = 0;
+            int rounds = 0, nd = 0, np = 0;
+            long long plds = 0;
             std::vector<int> rb;
             for (int q = ptr[l]; q < ptr[l + 1]; ++q) {
                 const int s = sn[q];
                 if (!is_big(s)) continue;
                 list.push_back(s);
                 const int w = S_.sn_first[s + 1] - S_.sn_first[s], f = S_.front_rows_ptr[s + 1] - S_.front_rows_ptr[s];
+                if (panel_front(f, w)) { ++np; plds = std::max(plds, (long long)f * w); } else ++nd;
                 rounds = std::max(rounds, S_.child_ptr[s + 1] - S_.child_ptr[s]);
                 B.max_f = std::max(B.max_f, f); B.max_own = std::max(B.max_own, S_.fe_ptr[s + 1] - S_.fe_ptr[s]);
                 for (int k = 0, pn = 0; k < w; k += dense::FACTOR_NB, ++pn) {
@@ -2077,6 +2144,7 @@ private:
                 }
             }
             B.ptr.push_back((int)list.size()); B.rounds.push_back(rounds); B.rows_below.push_back(rb);
+            B.ndense.push_back(nd); B.npanel.push_back(np); B.panel_lds.push_back((int)((plds + IND_SCRATCH) * (long long)sizeof(double)));
             widest = std::max(widest, B.ptr[l + 1] - B.ptr[l]);
         }
         B.total = (int)list.size();
@@ -2091,6 +2159,7 @@ private:
                 j.F = fronts_.p + S_.front_off[s];
                 j.f = S_.front_rows_ptr[s + 1] - S_.front_rows_ptr[s]; j.w = S_.sn_first[s + 1] - S_.sn_first[s]; j.first = S_.sn_first[s];
                 j.pack = B.scratch.p + (size_t)(q - B.ptr[l]) * SLOT; j.dvec = j.pack + dense::FACTOR_PACK_DOUBLES;
+                j.kind = panel_front(j.f, j.w) ? 1 : 0;
             }
         upload_vec(B.list, list, st_);
         B.jobs.alloc(jobs.size());
@@ -2112,8 +2181,11 @@ private:
             if (cnt > nbig) hipLaunchKernelGGL(k_front_factor, dim3(cnt), dim3(256), lds[l], st_, M, fronts_.p, sn_dev + ptr[l], rdiag_.p, info_.p);
             if (nbig <= 0) continue;
             for (int r = 0; r < B.rounds[l]; ++r) hipLaunchKernelGGL(k_big_extend_add, dim3(64, nbig), dim3(256), 0, st_, M, fronts_.p, B.list.p + B.ptr[l], r);
-            for (int pn = 0; pn < (int)B.rows_below[l].size(); ++pn)
-                dense::launch_front_panels(B.jobs.p + B.ptr[l], nbig, pn, B.rows_below[l][pn], info_.p, rdiag_.p, st_);
+            if (B.npanel[l] > 0) hipLaunchKernelGGL(k_front_panel, dim3(nbig), dim3(256), B.panel_lds[l], st_, M, fronts_.p, B.list.p + B.ptr[l], B.jobs.p + B.ptr[l], rdiag_.p, info_.p);
+            for (int pn = 0; pn < (int)B.rows_below[l].size(); ++pn) {
+                if (B.ndense[l] > 0) dense::launch_front_diag_panels(B.jobs.p + B.ptr[l], nbig, pn, B.rows_below[l][pn], info_.p, rdiag_.p, st_);
+                dense::launch_front_updates(B.jobs.p + B.ptr[l], nbig, pn, B.rows_below[l][pn], st_);
+            }
         }
     }
     // Substitution by levels: the fronts of a level with at most 128 rows go through the single-wave kernels (one wave per front, vector in

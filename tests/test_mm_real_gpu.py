@@ -84,11 +84,13 @@ TRAJECTORY_SENSITIVE = {
 }
 
 
-# One iteration of slack where the count is decided by the last digits of the KKT solves: on CONT-201 both the oracle's and the device's solves of
-# the states 9 .. 12 (rho = delta = 1e-10) leave relative KKT residuals of 1e-6 .. 1e-9 (tools/dbg_sparse_accuracy.py mm_CONT-201: device 0.3x .. 6x
-# the oracle's, unchanged by the substitution kernels), and the duality gap crosses eps_abs = 1e-8 at iteration 12 (3.6e-9, per-pivot substitution of
-# the wide fronts: the count the oracle gets) or 13 (1.0e-7 at 12, blocked substitution) -- same optimum to 12 digits either way.
-ITER_SLACK = {"mm_CONT-201": 1}
+# One iteration of slack where the count is decided by the last digits of the KKT solves: the CONT-xxx family (PDE-constrained grids).  With
+# rho = delta = 1e-10 the solves of the last four or five states leave relative KKT residuals of 1e-6 .. 1e-9 in the oracle AND on the device
+# (tools/dbg_sparse_accuracy.py mm_CONT-201: device 0.3x .. 6x the oracle's; mm_CONT-101: device 0.3x .. 0.8x, i.e. more accurate on every state), and the
+# duality gap crosses eps_abs = 1e-8 one iteration earlier or later with every change of the summation order inside the fronts (measured on CONT-201: 12
+# with per-pivot substitution of the wide fronts = the oracle's count, 13 with the blocked substitution; CONT-101: 11 with the one-workgroup Schur
+# complements, 12 with the matrix-core ones) -- the same optimum to 12 digits either way (asserted below).
+ITER_SLACK = {"mm_CONT-101": 1, "mm_CONT-201": 1}
 
 
 @pytest.mark.parametrize("name", ALL_MM)
