@@ -794,14 +794,17 @@ __global__ __launch_bounds__(SUB_SOLVE_THREADS) void k_subtree_bwd(FrontMeta M, 
 }
 
 // ---- wide fronts (more than 128 rows) of the level-scheduled top: blocked substitution, the front vector in LDS.
-// front_fwd / front_bwd above pay one global-memory round trip and one barrier PER PIVOT (CONT-201's 714-row root: 382 us forward, 279 us
-// backward at 5 GB/s).  Here 32 pivots go at a time: their 32 x 32 triangle is solved by one wave in registers (v_readlane broadcasts, the
-// triangle prefetched), the rest of the block is a rank-32 update (forward: one row per thread, coalesced column reads) or 32 column dot
-// products (backward: left-looking, four columns per wave, lanes along the contiguous column, fixed-order wave reduction), two barriers per
-// block.  Which routine a front takes depends on the front alone (f > 128), never on the schedule, so every schedule variant still produces
-// the same bits; the forward sweep also keeps the per-entry operation order of front_fwd.
-constexpr int WIDE_NT = 512, WIDE_B = 32;
+// front_fwd / front_bwd above pay one global-memory round trip and one barrier PER PIVOT (CONT-201's 663-row root: 382 us forward, 279 us
+// backward at 5 GB/s).  Here 16 pivots go at a time: their 16 x 16 triangle is solved by one wave in registers (v_readlane broadcasts), the
+// rest of the block is a rank-16 update (forward: rows over the threads, coalesced column reads) or 16 column dot products (backward:
+// left-looking, two columns per wave, lanes along the contiguous column, fixed-order wave reduction); two barriers per block, and the operands
+// of block b + 1 are loaded into a second register buffer BEFORE block b is worked on, so that no step waits for memory (a 32-pivot, single-
+// buffered version of the same kernels waited one memory latency per block: 5 us per block on the 663-row root).  Which routine a front
+// takes depends on the front alone (f > 128), never on the schedule, so every schedule variant still produces the same bits; the forward
+// sweep also keeps the per-entry operation order of front_fwd.
+constexpr int WIDE_NT = 512, WIDE_B = 16;
 constexpr int WIDE_FCAP = 7000;  // rows of a front this path keeps in LDS (56 KB); wider ones take front_fwd / front_bwd
+constexpr int WIDE_BCH = 12;     // backward: 64-row chunks of a column held in registers (768 rows below the block; further rows are loaded in line)
 
 __device__ __forceinline__ double wide_bcast(double v, int src)
 {
@@ -809,6 +812,8 @@ __device__ __forceinline__ double wide_bcast(double v, int src)
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
     return __hiloint2double(hi, lo);
 }
+
+struct WideFwdOps { double Lt[WIDE_B], Lr0[WIDE_B], Lr1[WIDE_B]; };  // triangle row (wave 0, lane = row), two rows below the block per thread
 
 __global__ __launch_bounds__(WIDE_NT) void k_front_fwd_wide(FrontMeta M, const double* __restrict__ fronts, const int* __restrict__ list, double* __restrict__ x,
                                                             double* __restrict__ fvec, int fcap)
@@ -830,47 +835,61 @@ __global__ __launch_bounds__(WIDE_NT) void k_front_fwd_wide(FrontMeta M, const d
         for (int i = tid; i < fc - wc; i += WIDE_NT) vs[rel[i]] += vc[i];
         __syncthreads();
     }
-    double Lt[WIDE_B], Lr[WIDE_B];
-    // operands of block kb: the strict lower triangle (wave 0, lane = row) and the first chunk of rows below it (thread = row)
-    auto prefetch = [&](int kb) {
+    auto prefetch = [&](WideFwdOps& o, int kb) {
         const int nbk = min(WIDE_B, w - kb);
         if (wave == 0) {
 #pragma unroll
-            for (int k = 0; k < WIDE_B; ++k) Lt[k] = (k < lane && lane < nbk) ? F[(kb + lane) + (long long)(kb + k) * f] : 0.0;
+            for (int k = 0; k < WIDE_B; ++k) o.Lt[k] = (k < lane && lane < nbk) ? F[(kb + lane) + (long long)(kb + k) * f] : 0.0;
         }
-        const int i = kb + nbk + tid;
+        const int i0 = kb + nbk + tid, i1 = i0 + WIDE_NT;
 #pragma unroll
-        for (int k = 0; k < WIDE_B; ++k) Lr[k] = (i < f && k < nbk) ? F[i + (long long)(kb + k) * f] : 0.0;
+        for (int k = 0; k < WIDE_B; ++k) o.Lr0[k] = (i0 < f && k < nbk) ? F[i0 + (long long)(kb + k) * f] : 0.0;
+#pragma unroll
+        for (int k = 0; k < WIDE_B; ++k) o.Lr1[k] = (i1 < f && k < nbk) ? F[i1 + (long long)(kb + k) * f] : 0.0;
     };
-    if (w > 0) prefetch(0);
-    for (int kb = 0; kb < w; kb += WIDE_B) {
+    auto step = [&](const WideFwdOps& o, int kb) {
         const int nbk = min(WIDE_B, w - kb);
         if (wave == 0) {
             double vv = lane < nbk ? vs[kb + lane] : 0.0;
 #pragma unroll
             for (int k = 0; k < WIDE_B; ++k) {
                 const double yk = wide_bcast(vv, k);
-                vv = __builtin_fma(-Lt[k], yk, vv);  // Lt[k] = 0 for k >= lane and outside the block
+                vv = __builtin_fma(-o.Lt[k], yk, vv);  // Lt[k] = 0 for k >= lane and outside the block
             }
             if (lane < nbk) vs[kb + lane] = vv;
         }
         __syncthreads();
-        {
-            const int i = kb + nbk + tid;
-            if (i < f) {
-                double vi = vs[i];
+        double y[WIDE_B];
 #pragma unroll
-                for (int k = 0; k < WIDE_B; ++k) vi = __builtin_fma(-Lr[k], vs[kb + (k < nbk ? k : 0)], vi);  // Lr[k] = 0 for k >= nbk
-                vs[i] = vi;
-            }
-            for (int i2 = i + WIDE_NT; i2 < f; i2 += WIDE_NT) {
-                double vi = vs[i2];
-                for (int k = 0; k < nbk; ++k) vi = __builtin_fma(-F[i2 + (long long)(kb + k) * f], vs[kb + k], vi);
-                vs[i2] = vi;
-            }
+        for (int k = 0; k < WIDE_B; ++k) y[k] = vs[kb + (k < nbk ? k : 0)];  // Lr[k] = 0 for k >= nbk
+        const int i0 = kb + nbk + tid, i1 = i0 + WIDE_NT;
+        if (i0 < f) {
+            double vi = vs[i0];
+#pragma unroll
+            for (int k = 0; k < WIDE_B; ++k) vi = __builtin_fma(-o.Lr0[k], y[k], vi);
+            vs[i0] = vi;
         }
-        if (kb + WIDE_B < w) prefetch(kb + WIDE_B);
+        if (i1 < f) {
+            double vi = vs[i1];
+#pragma unroll
+            for (int k = 0; k < WIDE_B; ++k) vi = __builtin_fma(-o.Lr1[k], y[k], vi);
+            vs[i1] = vi;
+        }
+        for (int i2 = i1 + WIDE_NT; i2 < f; i2 += WIDE_NT) {
+            double vi = vs[i2];
+            for (int k = 0; k < nbk; ++k) vi = __builtin_fma(-F[i2 + (long long)(kb + k) * f], y[k], vi);
+            vs[i2] = vi;
+        }
         __syncthreads();
+    };
+    WideFwdOps A, B;
+    if (w > 0) prefetch(A, 0);
+    for (int kb = 0; kb < w; kb += 2 * WIDE_B) {
+        if (kb + WIDE_B < w) prefetch(B, kb + WIDE_B);
+        step(A, kb);
+        if (kb + WIDE_B >= w) break;
+        if (kb + 2 * WIDE_B < w) prefetch(A, kb + 2 * WIDE_B);
+        step(B, kb + WIDE_B);
     }
     double* v = fvec + me.rows_ptr;
     for (int i = tid; i < f; i += WIDE_NT) {
@@ -879,6 +898,9 @@ __global__ __launch_bounds__(WIDE_NT) void k_front_fwd_wide(FrontMeta M, const d
         v[i] = t;
     }
 }
+
+constexpr int WIDE_CPW = WIDE_B / (WIDE_NT / 64);  // backward: columns per wave
+struct WideBwdOps { double Lt[WIDE_B], col[WIDE_CPW][WIDE_BCH]; };  // triangle column (wave 0, lane = column), this wave's columns below the block
 
 __global__ __launch_bounds__(WIDE_NT) void k_front_bwd_wide(FrontMeta M, const double* __restrict__ fronts, const int* __restrict__ list, double* __restrict__ x,
                                                             double* __restrict__ fvec, int fcap)
@@ -891,38 +913,54 @@ __global__ __launch_bounds__(WIDE_NT) void k_front_bwd_wide(FrontMeta M, const d
     const double* __restrict__ F = fronts + me.front_off;
     const int* __restrict__ rows = M.front_rows + me.rows_ptr;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    double* ss = vs + ((f + 1) & ~1);  // 32 column sums of the current block
+    double* ss = vs + ((f + 1) & ~1);  // column sums of the current block
     for (int i = tid; i < f; i += WIDE_NT) vs[i] = x[rows[i]];
     __syncthreads();
-    constexpr int CPW = WIDE_B / (WIDE_NT / 64);  // columns per wave
-    for (int kb = ((w - 1) / WIDE_B) * WIDE_B; kb >= 0; kb -= WIDE_B) {
-        const int nbk = min(WIDE_B, w - kb);
-        const int r0 = kb + nbk;
-        // the block's own triangle (wave 0, lane = column, row i' of the block in Lt[i']): in flight during the dot products
-        double Lt[WIDE_B];
+    auto prefetch = [&](WideBwdOps& o, int kb) {
+        const int nbk = min(WIDE_B, w - kb), r0 = kb + nbk;
         if (wave == 0) {
             const double* col = F + kb + (long long)(kb + (lane < nbk ? lane : 0)) * f;
 #pragma unroll
-            for (int i = 0; i < WIDE_B; ++i) Lt[i] = (lane < i && i < nbk) ? col[i] : 0.0;
+            for (int i = 0; i < WIDE_B; ++i) o.Lt[i] = (lane < i && i < nbk) ? col[i] : 0.0;
         }
-        // s_k = sum_{i >= r0} L[i, k] x[i]
-        double acc[CPW];
 #pragma unroll
-        for (int c = 0; c < CPW; ++c) acc[c] = 0.0;
-        for (int i = r0 + lane; i < f; i += 64) {
+        for (int c = 0; c < WIDE_CPW; ++c) {
+            const int k = wave * WIDE_CPW + c;
+            const double* col = F + (long long)(kb + (k < nbk ? k : 0)) * f;
+#pragma unroll
+            for (int ch = 0; ch < WIDE_BCH; ++ch) {
+                const int i = r0 + lane + 64 * ch;
+                o.col[c][ch] = (k < nbk && i < f) ? col[i] : 0.0;
+            }
+        }
+    };
+    auto step = [&](const WideBwdOps& o, int kb) {
+        const int nbk = min(WIDE_B, w - kb), r0 = kb + nbk;
+        // s_k = sum_{i >= r0} L[i, k] x[i]
+        double acc[WIDE_CPW];
+#pragma unroll
+        for (int c = 0; c < WIDE_CPW; ++c) acc[c] = 0.0;
+#pragma unroll
+        for (int ch = 0; ch < WIDE_BCH; ++ch) {
+            const int i = r0 + lane + 64 * ch;
+            const double xi = i < f ? vs[i] : 0.0;
+#pragma unroll
+            for (int c = 0; c < WIDE_CPW; ++c) acc[c] = __builtin_fma(o.col[c][ch], xi, acc[c]);
+        }
+        for (int i = r0 + lane + 64 * WIDE_BCH; i < f; i += 64) {
             const double xi = vs[i];
 #pragma unroll
-            for (int c = 0; c < CPW; ++c) {
-                const int k = wave * CPW + c;
+            for (int c = 0; c < WIDE_CPW; ++c) {
+                const int k = wave * WIDE_CPW + c;
                 if (k < nbk) acc[c] = __builtin_fma(F[i + (long long)(kb + k) * f], xi, acc[c]);
             }
         }
 #pragma unroll
-        for (int c = 0; c < CPW; ++c) {
+        for (int c = 0; c < WIDE_CPW; ++c) {
             double t = acc[c];
 #pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) t += __shfl_xor(t, o);
-            if (lane == 0) ss[wave * CPW + c] = t;
+            for (int o2 = 32; o2 >= 1; o2 >>= 1) t += __shfl_xor(t, o2);
+            if (lane == 0) ss[wave * WIDE_CPW + c] = t;
         }
         __syncthreads();
         if (wave == 0) {
@@ -930,11 +968,21 @@ __global__ __launch_bounds__(WIDE_NT) void k_front_bwd_wide(FrontMeta M, const d
 #pragma unroll
             for (int i = WIDE_B - 1; i >= 1; --i) {
                 const double xi = wide_bcast(vk, i);
-                vk = __builtin_fma(-Lt[i], xi, vk);  // Lt[i] = 0 for lanes >= i and rows outside the block
+                vk = __builtin_fma(-o.Lt[i], xi, vk);  // Lt[i] = 0 for lanes >= i and rows outside the block
             }
             if (lane < nbk) vs[kb + lane] = vk;
         }
         __syncthreads();
+    };
+    WideBwdOps A, B;
+    const int klast = w > 0 ? ((w - 1) / WIDE_B) * WIDE_B : -1;
+    if (klast >= 0) prefetch(A, klast);
+    for (int kb = klast; kb >= 0; kb -= 2 * WIDE_B) {
+        if (kb - WIDE_B >= 0) prefetch(B, kb - WIDE_B);
+        step(A, kb);
+        if (kb - WIDE_B < 0) break;
+        if (kb - 2 * WIDE_B >= 0) prefetch(A, kb - 2 * WIDE_B);
+        step(B, kb - WIDE_B);
     }
     for (int i = tid; i < w; i += WIDE_NT) x[first + i] = vs[i];
 }
