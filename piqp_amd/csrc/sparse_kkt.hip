@@ -388,22 +388,18 @@ __device__ __forceinline__ void front_factor(const FrontMeta& M, double* __restr
     else front_factor_body<FRONT_HBM>(M, fronts, s, me, rdiag, info, lds, fronts + me.front_off);
 }
 
-// one workgroup per front of an assembly-tree level
-__global__ __launch_bounds__(256) void k_front_factor(FrontMeta M, double* __restrict__ fronts, const int* __restrict__ list,
-                                                      double* __restrict__ rdiag, int* __restrict__ info)
+// One workgroup per front of an assembly-tree level.  Fronts on the multi-workgroup path (job_of[s] >= 0) were assembled by its kernels: a big
+// front is left to the dense kernels, a panel_front() has its panel factored here (D left in the job's dvec for the trailing update) -- in the
+// same launch as the level's one-workgroup fronts, which are independent of it.
+__global__ __launch_bounds__(256) void k_front_factor(FrontMeta M, double* __restrict__ fronts, const int* __restrict__ list, const int* __restrict__ job_of,
+                                                      const dense::FrontJob* __restrict__ jobs, double* __restrict__ rdiag, int* __restrict__ info)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    front_factor(M, fronts, list[blockIdx.x], true, rdiag, info, lds);
-}
-
-// panel of every panel_front() of a level's job list (blockIdx.x = job; the other jobs are the dense path's)
-__global__ __launch_bounds__(256) void k_front_panel(FrontMeta M, double* __restrict__ fronts, const int* __restrict__ list, const dense::FrontJob* __restrict__ jobs,
-                                                     double* __restrict__ rdiag, int* __restrict__ info)
-{
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    const dense::FrontJob j = jobs[blockIdx.x];
-    if (j.kind != 1) return;
     const int s = list[blockIdx.x];
+    const int jid = job_of ? job_of[s] : -1;
+    if (jid < 0) { front_factor(M, fronts, s, false, rdiag, info, lds); return; }
+    const dense::FrontJob j = jobs[jid];
+    if (j.kind != 1) return;
     const SnRec me = M.sn[s];
     front_factor_body<FRONT_PANEL_ONLY>(M, fronts, s, me, rdiag, info, lds, lds, j.dvec);
 }
@@ -1878,7 +1874,6 @@ private:
         static bool attr_set = false;
         if (!attr_set) {
             PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_front_factor), hipFuncAttributeMaxDynamicSharedMemorySize, (LDS_FRONT_DOUBLES + IND_SCRATCH) * (int)sizeof(double)));
-            PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_front_panel), hipFuncAttributeMaxDynamicSharedMemorySize, (LDS_FRONT_DOUBLES + IND_SCRATCH) * (int)sizeof(double)));
             PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_subtree_factor), hipFuncAttributeMaxDynamicSharedMemorySize, (LDS_FRONT_DOUBLES + IND_SCRATCH) * (int)sizeof(double)));
             PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_subtree_factor_lds), hipFuncAttributeMaxDynamicSharedMemorySize, SUBTREE_LDS_BYTES));
             PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_subtree_factor_pk), hipFuncAttributeMaxDynamicSharedMemorySize, SUBTREE_LDS_BYTES));
@@ -2165,7 +2160,7 @@ private:
         std::vector<int> ptr, rounds, ndense, npanel, panel_lds;  // level l of the schedule -> jobs [ptr[l], ptr[l + 1]); children of its widest fan-in; jobs by kind; LDS of k_front_panel
         std::vector<std::vector<int>> rows_below;  // per level, per panel: most rows below the diagonal block over the level's fronts (0 = none)
         int total = 0, max_f = 0, max_own = 0;
-        DBuf<int> list;
+        DBuf<int> list, job_of;  // job_of[s] = index into jobs, -1 for the fronts one workgroup handles alone
         DBuf<dense::FrontJob> jobs;
         DBuf<double> scratch;  // pack + D of every front of the widest level
     };
@@ -2210,6 +2205,11 @@ private:
                 j.kind = panel_front(j.f, j.w) ? 1 : 0;
             }
         upload_vec(B.list, list, st_);
+        {
+            std::vector<int> jo(S_.nsuper ? S_.nsuper : 1, -1);
+            for (int q = 0; q < B.total; ++q) jo[list[q]] = q;
+            upload_vec(B.job_of, jo, st_);
+        }
         B.jobs.alloc(jobs.size());
         PQ_HIP(hipMemcpyAsync(B.jobs.p, jobs.data(), jobs.size() * sizeof(dense::FrontJob), hipMemcpyHostToDevice, st_));
         PQ_HIP(hipStreamSynchronize(st_));
@@ -2226,10 +2226,11 @@ private:
             const int cnt = ptr[l + 1] - ptr[l];
             if (cnt <= 0) continue;
             const int nbig = B.total > 0 ? B.ptr[l + 1] - B.ptr[l] : 0;
-            if (cnt > nbig) hipLaunchKernelGGL(k_front_factor, dim3(cnt), dim3(256), lds[l], st_, M, fronts_.p, sn_dev + ptr[l], rdiag_.p, info_.p);
+            if (nbig > 0) for (int r = 0; r < B.rounds[l]; ++r) hipLaunchKernelGGL(k_big_extend_add, dim3(64, nbig), dim3(256), 0, st_, M, fronts_.p, B.list.p + B.ptr[l], r);
+            if (cnt > nbig || (nbig > 0 && B.npanel[l] > 0))
+                hipLaunchKernelGGL(k_front_factor, dim3(cnt), dim3(256), std::max(lds[l], nbig > 0 ? B.panel_lds[l] : 0), st_, M, fronts_.p, sn_dev + ptr[l], B.total > 0 ? B.job_of.p : (const int*)nullptr,
+                                   B.jobs.p, rdiag_.p, info_.p);
             if (nbig <= 0) continue;
-            for (int r = 0; r < B.rounds[l]; ++r) hipLaunchKernelGGL(k_big_extend_add, dim3(64, nbig), dim3(256), 0, st_, M, fronts_.p, B.list.p + B.ptr[l], r);
-            if (B.npanel[l] > 0) hipLaunchKernelGGL(k_front_panel, dim3(nbig), dim3(256), B.panel_lds[l], st_, M, fronts_.p, B.list.p + B.ptr[l], B.jobs.p + B.ptr[l], rdiag_.p, info_.p);
             for (int pn = 0; pn < (int)B.rows_below[l].size(); ++pn) {
                 if (B.ndense[l] > 0) dense::launch_front_diag_panels(B.jobs.p + B.ptr[l], nbig, pn, B.rows_below[l][pn], info_.p, rdiag_.p, st_);
                 dense::launch_front_updates(B.jobs.p + B.ptr[l], nbig, pn, B.rows_below[l][pn], st_);
