@@ -375,12 +375,11 @@ __device__ __forceinline__ void front_factor_body(const FrontMeta& M, double* __
     }
 }
 
-__device__ __forceinline__ void front_factor(const FrontMeta& M, double* __restrict__ fronts, int s, bool skip_big, double* __restrict__ rdiag,
+__device__ __forceinline__ void front_factor(const FrontMeta& M, double* __restrict__ fronts, int s, double* __restrict__ rdiag,
                                              int* __restrict__ info, double* __restrict__ lds, bool own_assembled = false)
 {
     const SnRec me = M.sn[s];
     const int w = me.w, f = me.f;
-    if (skip_big && (big_front(f, w) || panel_front(f, w))) return;  // handled by the multi-workgroup path of its level
     // assembly: zero, own K entries, then the children's update matrices (fixed order)
     if (!own_assembled) front_assemble_own(M, fronts, me, lds);
     if ((long long)f * f <= LDS_FRONT_DOUBLES) front_factor_body<FRONT_LDS>(M, fronts, s, me, rdiag, info, lds, lds);
@@ -397,7 +396,7 @@ __global__ __launch_bounds__(256) void k_front_factor(FrontMeta M, double* __res
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int s = list[blockIdx.x];
     const int jid = job_of ? job_of[s] : -1;
-    if (jid < 0) { front_factor(M, fronts, s, false, rdiag, info, lds); return; }
+    if (jid < 0) { front_factor(M, fronts, s, rdiag, info, lds); return; }
     const dense::FrontJob j = jobs[jid];
     if (j.kind != 1) return;
     const SnRec me = M.sn[s];
@@ -668,7 +667,7 @@ __global__ __launch_bounds__(SUB_THREADS) void k_subtree_factor(FrontMeta M, dou
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int lo = sub_lo[blockIdx.x], hi = sub_hi[blockIdx.x];
     for (int s = lo; s <= hi; ++s) {
-        front_factor(M, fronts, s, false, rdiag, info, lds);
+        front_factor(M, fronts, s, rdiag, info, lds);
         __syncthreads();
     }
 }
@@ -1361,7 +1360,7 @@ __global__ __launch_bounds__(512) void k_top_factor(FrontMeta M, double* __restr
             if (any) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
         __syncthreads();
-        front_factor(M, fronts, s, false, rdiag, info, lds, true);
+        front_factor(M, fronts, s, rdiag, info, lds, true);
         top_done(flags + b, epoch);
     }
 }
