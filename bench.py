@@ -350,11 +350,11 @@ def sparse_legs(args, rank, world, local_rank, dev, pd):
                         traffic_f = pmc["factor_per_launch"]["traffic_bytes"]; traffic_s = pmc["solve_per_launch"]["traffic_bytes"]
                 except Exception:  # noqa: BLE001
                     pass
-                r["roofline"] = {"bound": "hbm", "kernel": "multifrontal factorisation (k_subtree_factor_lds / _pk + k_top_factor / k_front_factor levels), hipEvent-bracketed on the backend stream",
+                r["roofline"] = {"bound": "hbm", "kernel": "multifrontal factorisation (k_subtree_factor_lds / _pk + k_top_factor / k_front_factor levels; big fronts: k_potrf_diag_fronts / k_trsm_panel_fronts / k_syrk_lower_fronts per level), hipEvent-bracketed on the backend stream",
                                  "achieved": bytes_factor / fac_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": bytes_factor / fac_s / 1e9 / PEAK_HBM_GBS, "traffic": traffic_f,
                                  "alg_bytes_per_launch": bytes_factor, "avg_launch_ms": r["factor_ms"],
                                  "note": "dependent-latency bound (tree of small fronts), not bandwidth bound: see DESIGN.md section 6"}
-                r["roofline_solve"] = {"bound": "hbm", "kernel": "backend solve (k_subtree_fwd/bwd_wave + k_front_fwd/bwd levels)", "achieved": bytes_solve / sol_s / 1e9,
+                r["roofline_solve"] = {"bound": "hbm", "kernel": "backend solve (k_subtree_fwd/bwd_wave + k_front_fwd/bwd_wide levels)", "achieved": bytes_solve / sol_s / 1e9,
                                        "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": bytes_solve / sol_s / 1e9 / PEAK_HBM_GBS, "traffic": traffic_s,
                                        "alg_bytes_per_launch": bytes_solve, "avg_launch_ms": r["backend_solve_ms"]}
                 r["factor_gflops"] = stt["flops_factor"] / fac_s / 1e9
