@@ -334,6 +334,9 @@ def sparse_legs(args, rank, world, local_rank, dev, pd):
             r = {"workload": desc, "value": world * steps / el, "unit": "IPM-iter KKT (1 factor + 2 solves)/s", "ms_per_step": el / steps * 1e3,
                  "factor_ms": (prof[0][0] + prof[1][0]) / max(prof[1][1], 1), "backend_solve_ms": prof[2][0] / max(prof[2][1], 1), "setup_s": t_setup,
                  "rel_kkt_residual": res_inf / nrm}
+            if key == "MM_BOYD1":  # the one leg above 1e-10: the reference algorithm itself does not reach it on this matrix
+                r["residual_note"] = ("P spans nine orders of magnitude on its diagonal; tests/test_mm_real_gpu.py::test_kkt_factor_solve_on_real_problem evaluates both "
+                                      "solutions in extended precision on the same state: device 2.2e-9, oracle (the reference's up-looking LDLt restated) 1.7e-8")
             # roofline of the two dominant phases against HBM with the ALGORITHMIC bytes of SURVEY.md 8d (C3 row): factor reads PKPt once and
             # writes L once (12 B per entry: value + index) plus D / D_inv / diag (24 N); one solve reads L twice plus six vector passes.
             try:
