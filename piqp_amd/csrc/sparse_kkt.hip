@@ -677,8 +677,9 @@ __global__ __launch_bounds__(SUB_THREADS) void k_subtree_factor(FrontMeta M, dou
 // own K entries of ONE front that the dense multi-workgroup path factors (the front was zeroed by a memset on the stream)
 // ---- big fronts (big_front() above): the dense MFMA panel kernels factor them, ALL big fronts of a tree level per launch
 // (blockIdx.y = front of the level's list).  Zero-fill and the front's own K entries need nothing from the children: one launch each for every
-// big front of the tree at the start of the factorisation.  The children are merged in rounds -- round r adds child r of every front --, so
-// an entry receives its contributions in child order whatever the grid (fixed summation order).
+// big front of the tree at the start of the factorisation.  The children are merged by one launch per level: column c of a front belongs to
+// workgroup c mod G of that front, which walks the children in order -- an entry receives its contributions in child order whatever the
+// grid (fixed summation order), and no two workgroups touch the same entry.
 __global__ __launch_bounds__(256) void k_big_zero(FrontMeta M, double* __restrict__ fronts, const int* __restrict__ list)
 {
     const SnRec me = M.sn[list[blockIdx.y]];
@@ -692,34 +693,50 @@ __global__ __launch_bounds__(256) void k_big_assemble(FrontMeta M, double* __res
     double* F = fronts + me.front_off;
     for (int e = me.fe_lo + blockIdx.x * 256 + threadIdx.x; e < me.fe_hi; e += gridDim.x * 256) F[M.fe_off[e]] = M.vals[e];
 }
-__global__ __launch_bounds__(256) void k_big_extend_add(FrontMeta M, double* __restrict__ fronts, const int* __restrict__ list, int round)
+__global__ __launch_bounds__(256) void k_big_extend_add(FrontMeta M, double* __restrict__ fronts, const int* __restrict__ list)
 {
+    constexpr int OWN_CAP = 2048;
+    __shared__ int own[OWN_CAP];
+    __shared__ int nown;
     const SnRec me = M.sn[list[blockIdx.y]];
-    const int ci = me.child_lo + round;
-    if (ci >= me.child_hi) return;
-    const SnRec ch = M.sn[M.child[ci]];
-    const int f = me.f, wc = ch.w, fc = ch.f, uc = fc - wc;
+    const int f = me.f;
     double* F = fronts + me.front_off;
-    const double* U = fronts + ch.front_off + wc + (long long)wc * fc;
-    const int* rel = M.rel + ch.rel_ptr;
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;  // 16 rows x 16 columns of the child's update matrix per step
-    for (int j = blockIdx.x * 16 + ty; j < uc; j += gridDim.x * 16) {
-        const long long cj = (long long)rel[j] * f;
-        const double* __restrict__ Uj = U + (long long)j * fc;
-        for (int i = j + tx; i < uc; i += 64) {  // four entries per step, loads before stores (see extend_add)
-            double uv[4], fv[4];
-            long long at[4];
+    const int G = gridDim.x, mine = blockIdx.x;
+    for (int ci = me.child_lo; ci < me.child_hi; ++ci) {
+        const SnRec ch = M.sn[M.child[ci]];
+        const int wc = ch.w, fc = ch.f, uc = fc - wc;
+        const double* U = fronts + ch.front_off + wc + (long long)wc * fc;
+        const int* rel = M.rel + ch.rel_ptr;
+        for (int j0 = 0; j0 < uc; j0 += OWN_CAP) {
+            // the child's columns that land in this workgroup's columns of the front (column c of the front belongs to workgroup c mod G)
+            if (threadIdx.x == 0) nown = 0;
+            __syncthreads();
+            for (int j = j0 + threadIdx.x; j < min(uc, j0 + OWN_CAP); j += 256)
+                if (rel[j] % G == mine) own[atomicAdd(&nown, 1)] = j;
+            __syncthreads();
+            const int cnt = nown;
+            for (int q = ty; q < cnt; q += 16) {
+                const int j = own[q];
+                const long long cj = (long long)rel[j] * f;
+                const double* __restrict__ Uj = U + (long long)j * fc;
+                for (int i = j + tx; i < uc; i += 64) {  // four entries per step, loads before stores (see extend_add)
+                    double uv[4], fv[4];
+                    long long at[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int iq = i + 16 * q;
-                const bool ok = iq < uc;
-                at[q] = ok ? rel[iq] + cj : -1;
-                uv[q] = ok ? Uj[iq] : 0.0;
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        const int iq = i + 16 * q4;
+                        const bool ok = iq < uc;
+                        at[q4] = ok ? rel[iq] + cj : -1;
+                        uv[q4] = ok ? Uj[iq] : 0.0;
+                    }
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) fv[q4] = at[q4] >= 0 ? F[at[q4]] : 0.0;
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) if (at[q4] >= 0) F[at[q4]] = fv[q4] + uv[q4];
+                }
             }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) fv[q] = at[q] >= 0 ? F[at[q]] : 0.0;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) if (at[q] >= 0) F[at[q]] = fv[q] + uv[q];
+            __syncthreads();  // the next child (or chunk) may add to the same entries: this workgroup's stores first
         }
     }
 }
@@ -2214,7 +2231,7 @@ private:
         PQ_HIP(hipStreamSynchronize(st_));
     }
     // one launch per level of a (possibly filtered) level schedule for the fronts one workgroup factors; the level's big fronts then go through
-    // the dense multi-workgroup kernels together: children merged in rounds (fixed order), then the blocked partial LDLt panel by panel
+    // the dense multi-workgroup kernels together: children merged (fixed order), then the blocked partial LDLt panel by panel
     void factor_levels(const FrontMeta& M, const std::vector<int>& ptr, const int* sn_dev, const std::vector<int>& lds, const BigLevels& B, int lend = 1 << 30)
     {
         if (B.total > 0) {
@@ -2225,7 +2242,7 @@ private:
             const int cnt = ptr[l + 1] - ptr[l];
             if (cnt <= 0) continue;
             const int nbig = B.total > 0 ? B.ptr[l + 1] - B.ptr[l] : 0;
-            if (nbig > 0) for (int r = 0; r < B.rounds[l]; ++r) hipLaunchKernelGGL(k_big_extend_add, dim3(64, nbig), dim3(256), 0, st_, M, fronts_.p, B.list.p + B.ptr[l], r);
+            if (nbig > 0 && B.rounds[l] > 0) hipLaunchKernelGGL(k_big_extend_add, dim3(64, nbig), dim3(256), 0, st_, M, fronts_.p, B.list.p + B.ptr[l]);
             if (cnt > nbig || (nbig > 0 && B.npanel[l] > 0))
                 hipLaunchKernelGGL(k_front_factor, dim3(cnt), dim3(256), std::max(lds[l], nbig > 0 ? B.panel_lds[l] : 0), st_, M, fronts_.p, sn_dev + ptr[l], B.total > 0 ? B.job_of.p : (const int*)nullptr,
                                    B.jobs.p, rdiag_.p, info_.p);
