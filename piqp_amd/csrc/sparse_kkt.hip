@@ -1586,6 +1586,8 @@ public:
         if (d->mem != PQ_MEM_HOST) throw std::runtime_error("sparse data must be host-resident");
         PQ_HIP(hipSetDevice(dev_));
         PQ_HIP(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
+        PQ_HIP(hipStreamCreateWithFlags(&st2_, hipStreamNonBlocking));
+        PQ_HIP(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming)); PQ_HIP(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
         sparse::analyse_kkt(d, mode, S_);
         n_ = S_.n; p_ = S_.p; m_ = S_.m; N_ = S_.N;
         compute_level_lds();
@@ -1596,6 +1598,9 @@ public:
         (void)hipSetDevice(dev_);
         if (st_) { (void)hipStreamSynchronize(st_); }
         if (comm_) rccl::comm_destroy(comm_);
+        if (ev_fork_) (void)hipEventDestroy(ev_fork_);
+        if (ev_join_) (void)hipEventDestroy(ev_join_);
+        if (st2_) (void)hipStreamDestroy(st2_);
         if (st_) (void)hipStreamDestroy(st_);
     }
 
@@ -1862,6 +1867,8 @@ private:
     SparseKKT(const SparseKKT& o, int) : dev_(o.dev_), mode_(o.mode_), nzAA_(o.nzAA_), nzGG_(o.nzGG_), n_(o.n_), p_(o.p_), m_(o.m_), N_(o.N_), nnzK_(o.nnzK_), delta_(o.delta_), S_(o.S_), level_lds_(o.level_lds_), sub_lds_(o.sub_lds_), ntop_(o.ntop_), top_grid_(o.top_grid_), top_lds_(o.top_lds_), top_l0_(o.top_l0_), top_start_(o.top_start_), top_nper_(o.top_nper_), top_persistent_(o.top_persistent_)
     {
         PQ_HIP(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
+        PQ_HIP(hipStreamCreateWithFlags(&st2_, hipStreamNonBlocking));
+        PQ_HIP(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming)); PQ_HIP(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
         auto cpd = [&](DBuf<double>& d, const DBuf<double>& s) { d.alloc(s.n ? s.n : 1); if (s.n) PQ_HIP(hipMemcpyAsync(d.p, s.p, s.bytes(), hipMemcpyDeviceToDevice, st_)); };
         auto cpi = [&](DBuf<int>& d, const DBuf<int>& s) { d.alloc(s.n ? s.n : 1); if (s.n) PQ_HIP(hipMemcpyAsync(d.p, s.p, s.bytes(), hipMemcpyDeviceToDevice, st_)); };
         auto cpl = [&](DBuf<long long>& d, const DBuf<long long>& s) { d.alloc(s.n ? s.n : 1); if (s.n) PQ_HIP(hipMemcpyAsync(d.p, s.p, s.bytes(), hipMemcpyDeviceToDevice, st_)); };
@@ -2243,12 +2250,20 @@ private:
             if (cnt <= 0) continue;
             const int nbig = B.total > 0 ? B.ptr[l + 1] - B.ptr[l] : 0;
             if (nbig > 0 && B.rounds[l] > 0) hipLaunchKernelGGL(k_big_extend_add, dim3(64, nbig), dim3(256), 0, st_, M, fronts_.p, B.list.p + B.ptr[l]);
-            if (cnt > nbig || (nbig > 0 && B.npanel[l] > 0))
-                hipLaunchKernelGGL(k_front_factor, dim3(cnt), dim3(256), std::max(lds[l], nbig > 0 ? B.panel_lds[l] : 0), st_, M, fronts_.p, sn_dev + ptr[l], B.total > 0 ? B.job_of.p : (const int*)nullptr,
+            const bool small = cnt > nbig || (nbig > 0 && B.npanel[l] > 0);
+            // the fronts one workgroup handles and the big fronts' first diagonal blocks + panels are independent: side by side on two streams,
+            // joined before the trailing updates (which also carry the panel fronts' Schur complements)
+            const bool fork = small && nbig > 0 && B.ndense[l] > 0 && !no_fork_;
+            hipStream_t ss = st_;
+            if (fork) { PQ_HIP(hipEventRecord(ev_fork_, st_)); PQ_HIP(hipStreamWaitEvent(st2_, ev_fork_, 0)); ss = st2_; }
+            if (small)
+                hipLaunchKernelGGL(k_front_factor, dim3(cnt), dim3(256), std::max(lds[l], nbig > 0 ? B.panel_lds[l] : 0), ss, M, fronts_.p, sn_dev + ptr[l], B.total > 0 ? B.job_of.p : (const int*)nullptr,
                                    B.jobs.p, rdiag_.p, info_.p);
+            if (fork) PQ_HIP(hipEventRecord(ev_join_, st2_));
             if (nbig <= 0) continue;
             for (int pn = 0; pn < (int)B.rows_below[l].size(); ++pn) {
                 if (B.ndense[l] > 0) dense::launch_front_diag_panels(B.jobs.p + B.ptr[l], nbig, pn, B.rows_below[l][pn], info_.p, rdiag_.p, st_);
+                if (fork && pn == 0) PQ_HIP(hipStreamWaitEvent(st_, ev_join_, 0));
                 dense::launch_front_updates(B.jobs.p + B.ptr[l], nbig, pn, B.rows_below[l][pn], st_);
             }
         }
@@ -2423,7 +2438,8 @@ private:
 
     int dev_, mode_ = 0, nzAA_ = 0, nzGG_ = 0, n_ = 0, p_ = 0, m_ = 0, N_ = 0, nnzK_ = 0;
     double delta_ = 1.0;
-    hipStream_t st_ = nullptr;
+    hipStream_t st_ = nullptr, st2_ = nullptr;  // st2_: the one-workgroup fronts of a level next to its big fronts' diagonal blocks (factor_levels)
+    hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
     sparse::Symbolic S_;
     std::vector<int> level_lds_;
     int sub_lds_ = 0, ntop_ = 0, top_grid_ = 0, top_lds_ = 0, top_l0_ = 0, top_start_ = 0, top_nper_ = 0;
@@ -2434,6 +2450,7 @@ private:
     DBuf<int> fe_ptr_, fe_q_, fe_off_, fe_offp_, top_pos_, top_flags_, solve_level_sn_, solve_top_pos_, solve_flags_, solve_walk_lo_, solve_walk_hi_, solve_pub_;
     SubSchedule solve_sched_;
     LevelLists solve_ll_, own_ll_, sh_ll_;
+    bool no_fork_ = debug_token("no_fork") != nullptr;  // debugging aid: everything on one stream
     int wide_fcap_ = debug_token("no_wide_solve") ? 0 : WIDE_FCAP;  // debugging aid: wide fronts through the per-pivot routines
     BigLevels top_big_, own_big_, sh_big_;
     int ntop_solve_ = 0, nwalk_solve_ = 0, solve_epoch_ = 0, solve_epoch_used_ = 0, factor_epoch_ = 0;
