@@ -76,7 +76,7 @@ def _run_ranks(nranks, extra, port):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("backend,problem,nranks", [("multistage", "chain", 2), ("ldlt", "chain", 3), ("ldlt_cond", "c3", 2)])
+@pytest.mark.parametrize("backend,problem,nranks", [("multistage", "chain", 2), ("ldlt", "chain", 3), ("ldlt_cond", "c3", 2), ("ldlt", "cont", 2)])
 def test_partitioned_equals_single_gpu(backend, problem, nranks):
     out = _run_ranks(nranks, ["--stages", "800", "--steps", "2", "--warmup", "1", "--backend", backend, "--problem", problem, "--full-solve"], 29650 + nranks)
     assert out["world"] == nranks

@@ -29,7 +29,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--backend", default="multistage", choices=["multistage", "ldlt_cond", "ldlt"])
-    ap.add_argument("--problem", default="chain", choices=["chain", "c3"], help="c3: BASELINE configs[2], a general sparse QP (wide fronts at the top of the tree)")
+    ap.add_argument("--problem", default="chain", choices=["chain", "c3", "cont"],
+                    help="c3: BASELINE configs[2], a general sparse QP; cont: the frozen Maros-Meszaros CONT-101 (a PDE grid: big fronts on the batched dense kernels, "
+                         "panel fronts, wide-front substitution -- in the owned and in the shared part of the tree)")
     ap.add_argument("--full-solve", action="store_true")
     ap.add_argument("--no-reference", action="store_true", help="skip the unpartitioned run on every rank (bench mode)")
     ap.add_argument("--wait-stdin", action="store_true", help="block on stdin before touching the GPU (spawned by bench.py, piqp_amd.dist.spawn_waiting)")
@@ -46,7 +48,12 @@ def main():
     import piqp_amd as hip
     from qp_gen import c3_problem, mpc_chain, random_vars
 
-    a = mpc_chain(args.nx, args.nu, args.stages, 5) if args.problem == "chain" else c3_problem()
+    if args.problem == "cont":
+        from qp_io import load_qp
+        q = load_qp("mm_CONT-101")
+        a = (q["P"], q["c"], q["A"], q["b"], q["G"], q["h_l"], q["h_u"], q["x_l"], q["x_u"])
+    else:
+        a = mpc_chain(args.nx, args.nu, args.stages, 5) if args.problem == "chain" else c3_problem()
     d = hip.SparseData(*a)
     n, p, m = d.n, d.p, d.m
     ks = {"multistage": hip.SPARSE_MULTISTAGE, "ldlt_cond": 4, "ldlt": hip.SPARSE_LDLT}[args.backend]
@@ -55,7 +62,7 @@ def main():
     to_dev = lambda v: {k: torch.from_numpy(np.ascontiguousarray(x)).to(dev) for k, x in v.items()}  # noqa: E731
     state = to_dev(random_vars(n, p, m, rng, positive=True))
     rhs = [to_dev(random_vars(n, p, m, rng)) for _ in range(2)]
-    out = {"workload": (f"multistage chain n_x={args.nx} n_u={args.nu} stages={args.stages}" if args.problem == "chain" else "C3 sparse QP") + f": n={n} p={p} m={m}", "backend": args.backend, "world": world,
+    out = {"workload": (f"multistage chain n_x={args.nx} n_u={args.nu} stages={args.stages}" if args.problem == "chain" else ("C3 sparse QP" if args.problem == "c3" else "Maros-Meszaros CONT-101")) + f": n={n} p={p} m={m}", "backend": args.backend, "world": world,
            "transport": "gloo (host-staged, ranks share one GPU)" if shared_gpu else ("rccl" if (dist.is_available() and dist.is_initialized()) else "none")}
 
     def run_steps(k, steps):
