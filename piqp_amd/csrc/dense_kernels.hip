@@ -1286,7 +1286,12 @@ __device__ __forceinline__ void panel_follow(const SyrkArgs& a, double* __restri
 // negated off-diagonal blocks, both prepared by potrf_block.
 constexpr int TRSM_ROWS = 64;  // rows per workgroup (4 waves)
 constexpr int TRSM_LDS_BYTES = PACK_BLOCKS * 256 * (int)sizeof(double);
-template <bool LDLT>
+// SUBST: the 16-column steps solve against the diagonal piece L_kk itself (tile_trsm_rt: 15 dependent rank-1 updates on the matrix cores, the
+// arithmetic of a plain substitution) instead of multiplying by its explicit inverse W_kk (4 products).  The inverse is what the dense backend
+// uses -- its H is positive definite and the rho = delta = 1e-10 gates of tests/dense_replay.py hold --; the fronts of the sparse backend are
+// quasi-definite (pivots of +rho and -delta next to O(1) entries: unit-lower-triangular pieces with entries of 1e10), where the product with the
+// inverse cost an order of magnitude of KKT residual on the last interior-point states of CONT-201 (tools/dbg_sparse_accuracy.py).
+template <bool LDLT, bool SUBST = false>
 __device__ __forceinline__ void trsm_panel_body(double* __restrict__ A, int lda, int k0, int nb, int n, const double* __restrict__ pack, const double* __restrict__ rdiag, const int block_x)
 {
     extern __shared__ __attribute__((aligned(16))) double Ps[];
@@ -1317,10 +1322,24 @@ __device__ __forceinline__ void trsm_panel_body(double* __restrict__ A, int lda,
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        const d4 w = tile_load(Ps + (28 + k) * 256, lane);
         d4 x = {0.0, 0.0, 0.0, 0.0};
+        if constexpr (SUBST) {
+            d4 lkk;  // the factored diagonal piece from the front itself (strictly lower part used; beyond nb: nothing to solve)
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) x = __builtin_amdgcn_mfma_f64_16x16x4f64(w[ks], T[k][ks], x, 0, 0, 0);
+            for (int r = 0; r < 4; ++r) {
+                const int rr = 16 * k + i, cc = 16 * k + g + 4 * r;
+                const bool ok = rr < nb && cc < nb && rr > cc;
+                const double t = A[ok ? (size_t)(k0 + rr) + (size_t)(k0 + cc) * lda : 0];
+                lkk[r] = ok ? t : 0.0;
+            }
+            x = T[k];
+            const d4 one = {1.0, 1.0, 1.0, 1.0};
+            tile_trsm_rt<LDLT, false>(x, lkk, one, lane);
+        } else {
+            const d4 w = tile_load(Ps + (28 + k) * 256, lane);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) x = __builtin_amdgcn_mfma_f64_16x16x4f64(w[ks], T[k][ks], x, 0, 0, 0);
+        }
         T[k] = x;
 #pragma unroll
         for (int j = k + 1; j < 8; ++j) {
@@ -1355,7 +1374,7 @@ __global__ __launch_bounds__(256) void k_trsm_panel_fronts(const FrontJob* __res
     const FrontJob j = jobs[blockIdx.y];
     int k, nb, rs;
     if (j.kind != 0 || !front_panel(j, panel, k, nb, rs) || (int)blockIdx.x * TRSM_ROWS >= rs) return;
-    trsm_panel_body<true>(j.F, j.f, k, nb, j.f, j.pack, rdiag + j.first, (int)blockIdx.x);
+    trsm_panel_body<true, true>(j.F, j.f, k, nb, j.f, j.pack, rdiag + j.first, (int)blockIdx.x);
 }
 
 // one panel step of the partial LDLt of many fronts: diagonal blocks and panels (two launches whatever the number of fronts), then the trailing updates

@@ -1924,7 +1924,7 @@ private:
         for (int s : S_.top_level_sn) {
             const int w = S_.sn_first[s + 1] - S_.sn_first[s];
             const long long f = S_.front_rows_ptr[s + 1] - S_.front_rows_ptr[s];
-            if (big_front((int)f, w) || panel_front(f, w)) any_big = true;
+            if (is_big(s)) any_big = true;
             top_mx = std::max(top_mx, front_lds_doubles(f, w));
         }
         top_lds_ = ((int)top_mx + IND_SCRATCH) * (int)sizeof(double);
@@ -2177,6 +2177,7 @@ private:
     bool is_big(int s) const
     {
         const int f = S_.front_rows_ptr[s + 1] - S_.front_rows_ptr[s], w = S_.sn_first[s + 1] - S_.sn_first[s];
+        if (no_big_) return false;
         return big_front(f, w) || panel_front(f, w);
     }
     struct BigLevels {
@@ -2215,18 +2216,27 @@ private:
         }
         B.total = (int)list.size();
         if (B.total == 0) return;
-        constexpr size_t SLOT = dense::FACTOR_PACK_DOUBLES + dense::FACTOR_NB;
-        B.scratch.alloc((size_t)widest * SLOT);
+        // scratch of a level: D (FACTOR_NB doubles) for every front, the operand pack of the panel solve for the dense-path fronts only
+        size_t need = 0;
+        for (size_t l = 0; l < B.ndense.size(); ++l)
+            need = std::max(need, (size_t)(B.ndense[l] + B.npanel[l]) * dense::FACTOR_NB + (size_t)B.ndense[l] * dense::FACTOR_PACK_DOUBLES);
+        B.scratch.alloc(need);
+        (void)widest;
         std::vector<dense::FrontJob> jobs(B.total);
-        for (int l = 0; l + 1 < (int)B.ptr.size(); ++l)
+        for (int l = 0; l + 1 < (int)B.ptr.size(); ++l) {
+            const int nl = B.ptr[l + 1] - B.ptr[l];
+            double* packs = B.scratch.p + (size_t)nl * dense::FACTOR_NB;
+            int nd = 0;
             for (int q = B.ptr[l]; q < B.ptr[l + 1]; ++q) {
                 const int s = list[q];
                 dense::FrontJob& j = jobs[q];
                 j.F = fronts_.p + S_.front_off[s];
                 j.f = S_.front_rows_ptr[s + 1] - S_.front_rows_ptr[s]; j.w = S_.sn_first[s + 1] - S_.sn_first[s]; j.first = S_.sn_first[s];
-                j.pack = B.scratch.p + (size_t)(q - B.ptr[l]) * SLOT; j.dvec = j.pack + dense::FACTOR_PACK_DOUBLES;
                 j.kind = panel_front(j.f, j.w) ? 1 : 0;
+                j.dvec = B.scratch.p + (size_t)(q - B.ptr[l]) * dense::FACTOR_NB;
+                j.pack = j.kind == 0 ? packs + (size_t)(nd++) * dense::FACTOR_PACK_DOUBLES : nullptr;
             }
+        }
         upload_vec(B.list, list, st_);
         {
             std::vector<int> jo(S_.nsuper ? S_.nsuper : 1, -1);
@@ -2451,6 +2461,7 @@ private:
     SubSchedule solve_sched_;
     LevelLists solve_ll_, own_ll_, sh_ll_;
     bool no_fork_ = debug_token("no_fork") != nullptr;  // debugging aid: everything on one stream
+    bool no_big_ = debug_token("no_big") != nullptr;    // debugging aid: every front through one workgroup's pivot loop (accuracy comparisons)
     int wide_fcap_ = debug_token("no_wide_solve") ? 0 : WIDE_FCAP;  // debugging aid: wide fronts through the per-pivot routines
     BigLevels top_big_, own_big_, sh_big_;
     int ntop_solve_ = 0, nwalk_solve_ = 0, solve_epoch_ = 0, solve_epoch_used_ = 0, factor_epoch_ = 0;
