@@ -1515,9 +1515,13 @@ private:
         bool wave_pan = false;
         const long long wave_doubles = sym_.qpan_doubles + n;
         nt_ = (n <= 512 && sym_.max_h <= 24) ? 64 : 256;
+        if (const char* e = debug_token("batch_wpe")) wpe_ = std::atoi(e);  // waves per SIMD the kernel is compiled for (2 .. 6, 8)
         if (const char* e = debug_token("batch_mode")) forced_mode_ = std::atoi(e);  // forces the chain working-set mode (tests of the fallback modes)
         if (nt_ == 64 && sym_.max_h * sym_.max_h <= 64 && wave_doubles * (long long)sizeof(double) <= RESIDENT_LIMIT_BYTES && sym_.max_w <= msdev::WAVE_WMAX && (forced_mode_ < 0 || forced_mode_ == MODE_WAVE)) {
             mode_ = MODE_WAVE;
+            // the kernel needs 97 VGPRs: compiled for four waves per SIMD it gets a 128-register budget it does not use and 16 single-wave workgroups per
+            // CU; compiled for five (102 registers, no spills) the LDS bound of 18 workgroups per CU applies (8192 QPs: 8.78 -> 8.49 ms; six: 8.63, eight: 8.96)
+            if (!debug_token("batch_wpe")) wpe_ = 5;
             S.res_f = 0; S.res_pan = 0; S.res_x = (int)sym_.qpan_doubles; S.res_chain = S.res_x + n;
             S.fcap = 0; S.lofs = 0;
             S.chain_lds_doubles = (int)wave_doubles;
