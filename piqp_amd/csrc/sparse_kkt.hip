@@ -2069,7 +2069,8 @@ private:
         out.cls.clear();
         // ONE class sized for the largest subtree.  Measured and removed (round 1): several LDS size classes -- their launches run back to back
         // and the tails add up (C5 backend solve 1.4 -> 2.1 ms with four classes) -- and staging the per-subtree metadata in LDS, which costs
-        // more occupancy than the latency it removes (C5 factor 2.1 -> 3.9 ms at 54 KB per workgroup)
+        // more occupancy than the latency it removes (C5 factor 2.1 -> 3.9 ms at 54 KB per workgroup).  Round 2 re-measured two classes (packed fronts <= 40 KB:
+        // four walks per CU; the rest) launched side by side on the factorisation's two streams: C3 0.51 -> 0.56 ms, CONT-201 unchanged -- still one class
         static const int limits[] = {SUBTREE_LDS_BYTES};
         const int ncls = 1;
         std::vector<std::vector<int>> members(ncls);
