@@ -133,7 +133,7 @@ __device__ __forceinline__ void scale_tile(const double* __restrict__ w, int k0,
 template <bool LDLT, int NWAVES>
 __device__ __forceinline__ void potrf_block(double* __restrict__ Tb, double* __restrict__ rds, int nb, int kglobal, int* __restrict__ info, double* __restrict__ rdiag,
                                             double* __restrict__ dvec, double* __restrict__ Aout, int lda, double* __restrict__ pack, double* __restrict__ w16,
-                                            long long* __restrict__ ts = nullptr, int* __restrict__ cnt = nullptr);
+                                            long long* __restrict__ ts = nullptr, int* __restrict__ cnt = nullptr, int nactive = 8);
 __device__ __forceinline__ int tb_index(int bi, int bj);
 __device__ __forceinline__ void st_agent(double* p, double v);
 __device__ __forceinline__ double ld_agent(const double* p);
@@ -874,8 +874,11 @@ __device__ __forceinline__ d4 tile_load_rowperm(const double* __restrict__ blk, 
 template <bool LDLT, int NWAVES>
 __device__ __forceinline__ void potrf_block(double* __restrict__ Tb, double* __restrict__ rds, int nb, int kglobal, int* __restrict__ info, double* __restrict__ rdiag,
                             double* __restrict__ dvec, double* __restrict__ Aout, int lda, double* __restrict__ pack, double* __restrict__ w16,
-                            long long* __restrict__ ts, int* __restrict__ cnt)
+                            long long* __restrict__ ts, int* __restrict__ cnt, int nactive)
 {
+    // nactive < 8 (short blocks of the sparse fronts: nb <= 16 nactive): block rows nactive .. 7 are identity padding and their waves sit out -- nothing
+    // of theirs is stored (the pack blocks and inverted pieces of those rows stay unwritten: only a consumer that solves by substitution and masks the
+    // padded columns, trsm_panel_body<SUBST>, may follow; the dense backend always passes 8)
     // ts (debugging aid, nullptr in production): shader-clock stamps of step k at ts[8 k + q] -- q = 0 / 1 wave k before / after its 16 x 16
     // factorisation, 2 / 3 wave k + 1 before / after its substitution, 4 / 5 wave k + 1 before / after its tile updates, 6 wave k after the inversion
     auto stamp = [&](int k, int q) { if (ts && (threadIdx.x & 63) == 0) ts[8 * k + q] = clock64(); };
@@ -888,7 +891,7 @@ __device__ __forceinline__ void potrf_block(double* __restrict__ Tb, double* __r
     __syncthreads();
     lds_vint* progp = (lds_vint*)&prog;
     lds_vint* xd = (lds_vint*)xdone;
-    if (wave < 8) {
+    if (wave < nactive) {
         const int w = wave;
         double* Dww = Tb + tb_index(w, w) * 256;
         d4 dperm = tile_load_perm(Dww, lane);  // own diagonal tile: in registers until it is factored
@@ -1014,7 +1017,7 @@ __device__ __forceinline__ void potrf_block(double* __restrict__ Tb, double* __r
 constexpr int POTRF_THREADS = 512;
 template <bool LDLT>
 __device__ __forceinline__ void potrf_diag_body(double* __restrict__ A, int lda, int nb, int kglobal, int* __restrict__ info, double* __restrict__ rdiag,
-                                                double* __restrict__ dvec, double* __restrict__ pack, double* __restrict__ w16, long long* __restrict__ ts)
+                                                double* __restrict__ dvec, double* __restrict__ pack, double* __restrict__ w16, long long* __restrict__ ts, int nactive = 8)
 {
     extern __shared__ __attribute__((aligned(16))) double Tb[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1036,7 +1039,7 @@ __device__ __forceinline__ void potrf_diag_body(double* __restrict__ A, int lda,
         for (int q = 0; q < 4; ++q) Tb[b * 256 + lane + 64 * q] = v[q];
     }
     __syncthreads();
-    potrf_block<LDLT, POTRF_THREADS / 64>(Tb, Tb + TB_DOUBLES, nb, kglobal, info, rdiag, dvec, A, lda, pack, w16, ts);
+    potrf_block<LDLT, POTRF_THREADS / 64>(Tb, Tb + TB_DOUBLES, nb, kglobal, info, rdiag, dvec, A, lda, pack, w16, ts, nullptr, nactive);
 }
 template <bool LDLT>
 __global__ __launch_bounds__(POTRF_THREADS) void k_potrf_diag(double* __restrict__ A, int lda, int nb, int kglobal, int* __restrict__ info, double* __restrict__ rdiag,
@@ -1050,7 +1053,7 @@ __global__ __launch_bounds__(POTRF_THREADS) void k_potrf_diag_fronts(const Front
     const FrontJob j = jobs[blockIdx.x];
     int k, nb, rs;
     if (j.kind != 0 || !front_panel(j, panel, k, nb, rs)) return;
-    potrf_diag_body<true>(j.F + k + (size_t)k * j.f, j.f, nb, j.first + k, info, rdiag, j.dvec, rs > 0 ? j.pack : nullptr, nullptr, nullptr);
+    potrf_diag_body<true>(j.F + k + (size_t)k * j.f, j.f, nb, j.first + k, info, rdiag, j.dvec, rs > 0 ? j.pack : nullptr, nullptr, nullptr, min(8, (nb + 15) >> 4));
 }
 
 void launch_potrf_diag(bool ldlt, double* A, int lda, int nb, int kglobal, int* info, double* rdiag, double* dvec, double* pack, double* w16, hipStream_t s, long long* ts)
