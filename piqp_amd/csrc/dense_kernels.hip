@@ -1325,6 +1325,7 @@ __device__ __forceinline__ void trsm_panel_body(double* __restrict__ A, int lda,
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
+        if (SUBST && 16 * k >= nb) break;  // (padding beyond a short panel: nothing to solve, nothing stored)
         d4 x = {0.0, 0.0, 0.0, 0.0};
         if constexpr (SUBST) {
             d4 lkk;  // the factored diagonal piece from the front itself (strictly lower part used; beyond nb: nothing to solve)
