@@ -2214,6 +2214,7 @@ private:
             B.ptr.push_back((int)list.size()); B.rounds.push_back(rounds); B.rows_below.push_back(rb);
             B.ndense.push_back(nd); B.npanel.push_back(np); B.panel_lds.push_back((int)((plds + IND_SCRATCH) * (long long)sizeof(double)));
             widest = std::max(widest, B.ptr[l + 1] - B.ptr[l]);
+            if (B.ptr[l + 1] - B.ptr[l] > 65535) throw std::runtime_error("sparse backend: more than 65535 multi-workgroup fronts on one level of the assembly tree");
         }
         B.total = (int)list.size();
         if (B.total == 0) return;
@@ -2253,8 +2254,11 @@ private:
     void factor_levels(const FrontMeta& M, const std::vector<int>& ptr, const int* sn_dev, const std::vector<int>& lds, const BigLevels& B, int lend = 1 << 30)
     {
         if (B.total > 0) {
-            hipLaunchKernelGGL(k_big_zero, dim3((unsigned)std::min<long long>(256, ((long long)B.max_f * B.max_f + 255) / 256), B.total), dim3(256), 0, st_, M, fronts_.p, B.list.p);
-            if (B.max_own > 0) hipLaunchKernelGGL(k_big_assemble, dim3(std::min(64, (B.max_own + 255) / 256), B.total), dim3(256), 0, st_, M, fronts_.p, B.list.p);
+            for (int q0 = 0; q0 < B.total; q0 += 65535) {  // (grid.y limit)
+                const int nq = std::min(65535, B.total - q0);
+                hipLaunchKernelGGL(k_big_zero, dim3((unsigned)std::min<long long>(256, ((long long)B.max_f * B.max_f + 255) / 256), nq), dim3(256), 0, st_, M, fronts_.p, B.list.p + q0);
+                if (B.max_own > 0) hipLaunchKernelGGL(k_big_assemble, dim3(std::min(64, (B.max_own + 255) / 256), nq), dim3(256), 0, st_, M, fronts_.p, B.list.p + q0);
+            }
         }
         for (int l = 0; l + 1 < (int)ptr.size() && l < lend; ++l) {
             const int cnt = ptr[l + 1] - ptr[l];
