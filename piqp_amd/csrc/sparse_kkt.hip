@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <stdexcept>
+#include <type_traits>
 
 #include "dense_kernels.hpp"
 #include "kkt_solver_base.hpp"
@@ -825,6 +826,46 @@ __device__ __forceinline__ double wide_bcast(double v, int src)
     return __hiloint2double(hi, lo);
 }
 
+// workgroup barrier that waits for LDS traffic only: __syncthreads() also drains vmcnt, i.e. it would wait for the operands just requested for the NEXT
+// block -- the whole memory latency, every block.  Everything the waves exchange inside the block loops goes through LDS.
+__device__ __forceinline__ void wide_lds_barrier()
+{
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0); vmcnt / expcnt untouched
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// DPP exchange of a double (both halves)
+template <int CTRL>
+__device__ __forceinline__ double wide_dpp(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+// The xor butterfly t += t[lane ^ o], o = 32, 16, 8, 4, 2, 1 -- the summation tree every parity test was pinned with (another tree moves the
+// threshold-sitting iteration counts of CONT-201 and nl_perold) --, its four inner steps as DPP exchanges with the SAME partners instead of trips through
+// the LDS crossbar: lane ^ 8 = row_ror:8, lane ^ 4 = row_shl:4 on the even banks + row_shr:4 on the odd ones, lane ^ 2 / ^ 1 = quad permutes.
+__device__ __forceinline__ double wide_xor4(double v)
+{
+    int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x104, 0xf, 0x5, false);
+    int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x104, 0xf, 0x5, false);
+    lo = __builtin_amdgcn_update_dpp(lo, __double2loint(v), 0x114, 0xf, 0xa, false);
+    hi = __builtin_amdgcn_update_dpp(hi, __double2hiint(v), 0x114, 0xf, 0xa, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wide_wave_sum(double v)
+{
+    v += __shfl_xor(v, 32);
+    v += __shfl_xor(v, 16);
+    v += wide_dpp<0x128>(v);  // row_ror:8
+    v += wide_xor4(v);
+    v += wide_dpp<0x4E>(v);   // quad_perm [2, 3, 0, 1]
+    v += wide_dpp<0xB1>(v);   // quad_perm [1, 0, 3, 2]
+    return v;
+}
+
 struct WideFwdOps { double Lt[WIDE_B], Lr0[WIDE_B], Lr1[WIDE_B]; };  // triangle row (wave 0, lane = row), two rows below the block per thread
 
 __global__ __launch_bounds__(WIDE_NT) void k_front_fwd_wide(FrontMeta M, const double* __restrict__ fronts, const int* __restrict__ list, double* __restrict__ x,
@@ -847,33 +888,57 @@ __global__ __launch_bounds__(WIDE_NT) void k_front_fwd_wide(FrontMeta M, const d
         for (int i = tid; i < fc - wc; i += WIDE_NT) vs[rel[i]] += vc[i];
         __syncthreads();
     }
-    auto prefetch = [&](WideFwdOps& o, int kb) {
-        const int nbk = min(WIDE_B, w - kb);
+    // FULL: a whole block of WIDE_B pivots (every block but possibly the last): nbk is a compile-time constant there, which removes the clamps, the
+    // selects and most of the scalar address arithmetic (the generic instantiation spent ~400 scalar instructions per block on them)
+    auto prefetch_t = [&](auto full_tag, WideFwdOps& o, int kb) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        const int nbk = FULL ? WIDE_B : min(WIDE_B, w - kb);
         if (wave == 0) {
+            // (a load under a per-lane condition compiles to a branch of its own -- 48 of them per block --, and a select on the loaded value waits for
+            //  it, which turns the prefetch into a synchronous load: here every load is unconditional from an address clamped INTO the block, i.e. into cache
+            //  lines the neighbours fetch anyway, and the masks are applied where the values are USED)
+            const int lc = min(lane, nbk - 1);
 #pragma unroll
-            for (int k = 0; k < WIDE_B; ++k) o.Lt[k] = (k < lane && lane < nbk) ? F[(kb + lane) + (long long)(kb + k) * f] : 0.0;
+            for (int k = 0; k < WIDE_B; ++k) o.Lt[k] = F[(kb + lc) + (long long)(kb + min(k, nbk - 1)) * f];  // masked where it is used (step)
         }
         const int i0 = kb + nbk + tid, i1 = i0 + WIDE_NT;
+        const int wbase0 = i0 - lane, wbase1 = i1 - lane;  // first row of this wave's 64 rows: a wave entirely below the front loads nothing (uniform branch)
+        if (wbase0 < f) {
+            const bool ok0 = i0 < f;
+            const double* p0 = F + (ok0 ? i0 : f - 1) + (long long)kb * f;
 #pragma unroll
-        for (int k = 0; k < WIDE_B; ++k) o.Lr0[k] = (i0 < f && k < nbk) ? F[i0 + (long long)(kb + k) * f] : 0.0;
+            for (int k = 0; k < WIDE_B; ++k) o.Lr0[k] = p0[(long long)min(k, nbk - 1) * f];  // rows below the front are never stored, columns beyond nbk meet y = 0
+        } else {
 #pragma unroll
-        for (int k = 0; k < WIDE_B; ++k) o.Lr1[k] = (i1 < f && k < nbk) ? F[i1 + (long long)(kb + k) * f] : 0.0;
+            for (int k = 0; k < WIDE_B; ++k) o.Lr0[k] = 0.0;
+        }
+        if (wbase1 < f) {
+            const bool ok1 = i1 < f;
+            const double* p1 = F + (ok1 ? i1 : f - 1) + (long long)kb * f;
+#pragma unroll
+            for (int k = 0; k < WIDE_B; ++k) o.Lr1[k] = p1[(long long)min(k, nbk - 1) * f];
+        } else {
+#pragma unroll
+            for (int k = 0; k < WIDE_B; ++k) o.Lr1[k] = 0.0;
+        }
     };
-    auto step = [&](const WideFwdOps& o, int kb) {
-        const int nbk = min(WIDE_B, w - kb);
+    auto step_t = [&](auto full_tag, const WideFwdOps& o, int kb) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        const int nbk = FULL ? WIDE_B : min(WIDE_B, w - kb);
         if (wave == 0) {
             double vv = lane < nbk ? vs[kb + lane] : 0.0;
 #pragma unroll
             for (int k = 0; k < WIDE_B; ++k) {
                 const double yk = wide_bcast(vv, k);
-                vv = __builtin_fma(-o.Lt[k], yk, vv);  // Lt[k] = 0 for k >= lane and outside the block
+                const double l = (k < lane && lane < nbk) ? o.Lt[k] : 0.0;
+                vv = __builtin_fma(-l, yk, vv);
             }
             if (lane < nbk) vs[kb + lane] = vv;
         }
-        __syncthreads();
+        wide_lds_barrier();
         double y[WIDE_B];
 #pragma unroll
-        for (int k = 0; k < WIDE_B; ++k) y[k] = vs[kb + (k < nbk ? k : 0)];  // Lr[k] = 0 for k >= nbk
+        for (int k = 0; k < WIDE_B; ++k) { const double t = vs[kb + min(k, nbk - 1)]; y[k] = k < nbk ? t : 0.0; }
         const int i0 = kb + nbk + tid, i1 = i0 + WIDE_NT;
         if (i0 < f) {
             double vi = vs[i0];
@@ -892,16 +957,20 @@ __global__ __launch_bounds__(WIDE_NT) void k_front_fwd_wide(FrontMeta M, const d
             for (int k = 0; k < nbk; ++k) vi = __builtin_fma(-F[i2 + (long long)(kb + k) * f], y[k], vi);
             vs[i2] = vi;
         }
-        __syncthreads();
+        wide_lds_barrier();
     };
-    WideFwdOps A, B;
-    if (w > 0) prefetch(A, 0);
-    for (int kb = 0; kb < w; kb += 2 * WIDE_B) {
-        if (kb + WIDE_B < w) prefetch(B, kb + WIDE_B);
-        step(A, kb);
-        if (kb + WIDE_B >= w) break;
-        if (kb + 2 * WIDE_B < w) prefetch(A, kb + 2 * WIDE_B);
-        step(B, kb + WIDE_B);
+    {   // all blocks through the generic instantiation, double-buffered (forward: a compile-time-full instantiation for the whole blocks, as in the backward
+        // kernel, measured slower -- 1.24 -> 1.53 ms over CONT-201's wide fronts, a few spills)
+        const std::false_type gen{};
+        WideFwdOps A, B;
+        if (w > 0) prefetch_t(gen, A, 0);
+        for (int kb = 0; kb < w; kb += 2 * WIDE_B) {
+            if (kb + WIDE_B < w) prefetch_t(gen, B, kb + WIDE_B);
+            step_t(gen, A, kb);
+            if (kb + WIDE_B >= w) break;
+            if (kb + 2 * WIDE_B < w) prefetch_t(gen, A, kb + 2 * WIDE_B);
+            step_t(gen, B, kb + WIDE_B);
+        }
     }
     double* v = fvec + me.rows_ptr;
     for (int i = tid; i < f; i += WIDE_NT) {
@@ -928,26 +997,29 @@ __global__ __launch_bounds__(WIDE_NT) void k_front_bwd_wide(FrontMeta M, const d
     double* ss = vs + ((f + 1) & ~1);  // column sums of the current block
     for (int i = tid; i < f; i += WIDE_NT) vs[i] = x[rows[i]];
     __syncthreads();
-    auto prefetch = [&](WideBwdOps& o, int kb) {
-        const int nbk = min(WIDE_B, w - kb), r0 = kb + nbk;
+    auto prefetch_t = [&](auto full_tag, WideBwdOps& o, int kb) {
+        constexpr bool FULL = decltype(full_tag)::value;  // (see k_front_fwd_wide)
+        const int nbk = FULL ? WIDE_B : min(WIDE_B, w - kb), r0 = kb + nbk;
         if (wave == 0) {
-            const double* col = F + kb + (long long)(kb + (lane < nbk ? lane : 0)) * f;
+            const double* col = F + kb + (long long)(kb + min(lane, nbk - 1)) * f;
 #pragma unroll
-            for (int i = 0; i < WIDE_B; ++i) o.Lt[i] = (lane < i && i < nbk) ? col[i] : 0.0;
+            for (int i = 0; i < WIDE_B; ++i) o.Lt[i] = col[min(i, nbk - 1)];  // (clamped into the block; masked where it is used)
         }
 #pragma unroll
         for (int c = 0; c < WIDE_CPW; ++c) {
-            const int k = wave * WIDE_CPW + c;
-            const double* col = F + (long long)(kb + (k < nbk ? k : 0)) * f;
+            const int k = wave * WIDE_CPW + c;  // wave-uniform
+            const double* col = F + (long long)(kb + min(k, nbk - 1)) * f;
 #pragma unroll
             for (int ch = 0; ch < WIDE_BCH; ++ch) {
                 const int i = r0 + lane + 64 * ch;
-                o.col[c][ch] = (k < nbk && i < f) ? col[i] : 0.0;
+                if (k < nbk && r0 + 64 * ch < f) o.col[c][ch] = col[min(i, f - 1)];  // uniform condition; rows below the front meet x = 0 in the dot product
+                else o.col[c][ch] = 0.0;
             }
         }
     };
-    auto step = [&](const WideBwdOps& o, int kb) {
-        const int nbk = min(WIDE_B, w - kb), r0 = kb + nbk;
+    auto step_t = [&](auto full_tag, const WideBwdOps& o, int kb) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        const int nbk = FULL ? WIDE_B : min(WIDE_B, w - kb), r0 = kb + nbk;
         // s_k = sum_{i >= r0} L[i, k] x[i]
         double acc[WIDE_CPW];
 #pragma unroll
@@ -969,32 +1041,40 @@ __global__ __launch_bounds__(WIDE_NT) void k_front_bwd_wide(FrontMeta M, const d
         }
 #pragma unroll
         for (int c = 0; c < WIDE_CPW; ++c) {
-            double t = acc[c];
-#pragma unroll
-            for (int o2 = 32; o2 >= 1; o2 >>= 1) t += __shfl_xor(t, o2);
+            const double t = wide_wave_sum(acc[c]);
             if (lane == 0) ss[wave * WIDE_CPW + c] = t;
         }
-        __syncthreads();
+        wide_lds_barrier();
         if (wave == 0) {
             double vk = lane < nbk ? vs[kb + lane] - ss[lane] : 0.0;
 #pragma unroll
             for (int i = WIDE_B - 1; i >= 1; --i) {
                 const double xi = wide_bcast(vk, i);
-                vk = __builtin_fma(-o.Lt[i], xi, vk);  // Lt[i] = 0 for lanes >= i and rows outside the block
+                const double l = (lane < i && i < nbk) ? o.Lt[i] : 0.0;
+                vk = __builtin_fma(-l, xi, vk);
             }
             if (lane < nbk) vs[kb + lane] = vk;
         }
-        __syncthreads();
+        wide_lds_barrier();
     };
-    WideBwdOps A, B;
-    const int klast = w > 0 ? ((w - 1) / WIDE_B) * WIDE_B : -1;
-    if (klast >= 0) prefetch(A, klast);
-    for (int kb = klast; kb >= 0; kb -= 2 * WIDE_B) {
-        if (kb - WIDE_B >= 0) prefetch(B, kb - WIDE_B);
-        step(A, kb);
-        if (kb - WIDE_B < 0) break;
-        if (kb - 2 * WIDE_B >= 0) prefetch(A, kb - 2 * WIDE_B);
-        step(B, kb - WIDE_B);
+    {   // the ragged last block first, on its own; then the full blocks, double-buffered
+        const int wfull = w - w % WIDE_B;
+        if (wfull < w) {
+            WideBwdOps T;
+            prefetch_t(std::false_type{}, T, wfull);
+            step_t(std::false_type{}, T, wfull);
+        }
+        const std::true_type full{};
+        WideBwdOps A, B;
+        const int klast = wfull - WIDE_B;
+        if (klast >= 0) prefetch_t(full, A, klast);
+        for (int kb = klast; kb >= 0; kb -= 2 * WIDE_B) {
+            if (kb - WIDE_B >= 0) prefetch_t(full, B, kb - WIDE_B);
+            step_t(full, A, kb);
+            if (kb - WIDE_B < 0) break;
+            if (kb - 2 * WIDE_B >= 0) prefetch_t(full, A, kb - 2 * WIDE_B);
+            step_t(full, B, kb - WIDE_B);
+        }
     }
     for (int i = tid; i < w; i += WIDE_NT) x[first + i] = vs[i];
 }
