@@ -890,7 +890,7 @@ __global__ __launch_bounds__(WIDE_NT) void k_front_fwd_wide(FrontMeta M, const d
     }
     // FULL: a whole block of WIDE_B pivots (every block but possibly the last): nbk is a compile-time constant there, which removes the clamps, the
     // selects and most of the scalar address arithmetic (the generic instantiation spent ~400 scalar instructions per block on them)
-    auto prefetch_t = [&](auto full_tag, WideFwdOps& o, int kb) {
+    auto prefetch_tri = [&](auto full_tag, WideFwdOps& o, int kb) {
         constexpr bool FULL = decltype(full_tag)::value;
         const int nbk = FULL ? WIDE_B : min(WIDE_B, w - kb);
         if (wave == 0) {
@@ -898,16 +898,21 @@ __global__ __launch_bounds__(WIDE_NT) void k_front_fwd_wide(FrontMeta M, const d
             //  it, which turns the prefetch into a synchronous load: here every load is unconditional from an address clamped INTO the block, i.e. into cache
             //  lines the neighbours fetch anyway, and the masks are applied where the values are USED)
             const int lc = min(lane, nbk - 1);
+            const double* pt = F + (kb + lc) + (long long)kb * f;  // column pointers advance by f and stop at the block's last column: two scalar adds per load
 #pragma unroll
-            for (int k = 0; k < WIDE_B; ++k) o.Lt[k] = F[(kb + lc) + (long long)(kb + min(k, nbk - 1)) * f];  // masked where it is used (step)
+            for (int k = 0; k < WIDE_B; ++k) { o.Lt[k] = *pt; pt += (FULL || k + 1 < nbk) ? f : 0; }  // masked where it is used (step)
         }
+    };
+    auto prefetch_rows = [&](auto full_tag, WideFwdOps& o, int kb) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        const int nbk = FULL ? WIDE_B : min(WIDE_B, w - kb);
         const int i0 = kb + nbk + tid, i1 = i0 + WIDE_NT;
         const int wbase0 = i0 - lane, wbase1 = i1 - lane;  // first row of this wave's 64 rows: a wave entirely below the front loads nothing (uniform branch)
         if (wbase0 < f) {
             const bool ok0 = i0 < f;
             const double* p0 = F + (ok0 ? i0 : f - 1) + (long long)kb * f;
 #pragma unroll
-            for (int k = 0; k < WIDE_B; ++k) o.Lr0[k] = p0[(long long)min(k, nbk - 1) * f];  // rows below the front are never stored, columns beyond nbk meet y = 0
+            for (int k = 0; k < WIDE_B; ++k) { o.Lr0[k] = *p0; p0 += (FULL || k + 1 < nbk) ? f : 0; }  // rows below the front are never stored, columns beyond nbk meet y = 0
         } else {
 #pragma unroll
             for (int k = 0; k < WIDE_B; ++k) o.Lr0[k] = 0.0;
@@ -916,13 +921,15 @@ __global__ __launch_bounds__(WIDE_NT) void k_front_fwd_wide(FrontMeta M, const d
             const bool ok1 = i1 < f;
             const double* p1 = F + (ok1 ? i1 : f - 1) + (long long)kb * f;
 #pragma unroll
-            for (int k = 0; k < WIDE_B; ++k) o.Lr1[k] = p1[(long long)min(k, nbk - 1) * f];
+            for (int k = 0; k < WIDE_B; ++k) { o.Lr1[k] = *p1; p1 += (FULL || k + 1 < nbk) ? f : 0; }
         } else {
 #pragma unroll
             for (int k = 0; k < WIDE_B; ++k) o.Lr1[k] = 0.0;
         }
     };
-    auto step_t = [&](auto full_tag, const WideFwdOps& o, int kb) {
+    // Two register buffers, each refilled RIGHT AFTER its use with the operands of the block two ahead (kb2): a request then has a whole block of the
+    // other buffer to arrive in -- requested one block ahead at the top of the block, it had ~0.6 us of work to hide ~2 us of memory latency behind
+    auto step_t = [&](auto full_tag, WideFwdOps& o, int kb, int kb2) {
         constexpr bool FULL = decltype(full_tag)::value;
         const int nbk = FULL ? WIDE_B : min(WIDE_B, w - kb);
         if (wave == 0) {
@@ -935,6 +942,7 @@ __global__ __launch_bounds__(WIDE_NT) void k_front_fwd_wide(FrontMeta M, const d
             }
             if (lane < nbk) vs[kb + lane] = vv;
         }
+        if (kb2 < w) prefetch_tri(full_tag, o, kb2);
         wide_lds_barrier();
         double y[WIDE_B];
 #pragma unroll
@@ -957,19 +965,19 @@ __global__ __launch_bounds__(WIDE_NT) void k_front_fwd_wide(FrontMeta M, const d
             for (int k = 0; k < nbk; ++k) vi = __builtin_fma(-F[i2 + (long long)(kb + k) * f], y[k], vi);
             vs[i2] = vi;
         }
+        if (kb2 < w) prefetch_rows(full_tag, o, kb2);
         wide_lds_barrier();
     };
     {   // all blocks through the generic instantiation, double-buffered (forward: a compile-time-full instantiation for the whole blocks, as in the backward
         // kernel, measured slower -- 1.24 -> 1.53 ms over CONT-201's wide fronts, a few spills)
         const std::false_type gen{};
         WideFwdOps A, B;
-        if (w > 0) prefetch_t(gen, A, 0);
+        if (w > 0) { prefetch_tri(gen, A, 0); prefetch_rows(gen, A, 0); }
+        if (w > WIDE_B) { prefetch_tri(gen, B, WIDE_B); prefetch_rows(gen, B, WIDE_B); }
         for (int kb = 0; kb < w; kb += 2 * WIDE_B) {
-            if (kb + WIDE_B < w) prefetch_t(gen, B, kb + WIDE_B);
-            step_t(gen, A, kb);
+            step_t(gen, A, kb, kb + 2 * WIDE_B);
             if (kb + WIDE_B >= w) break;
-            if (kb + 2 * WIDE_B < w) prefetch_t(gen, A, kb + 2 * WIDE_B);
-            step_t(gen, B, kb + WIDE_B);
+            step_t(gen, B, kb + WIDE_B, kb + 3 * WIDE_B);
         }
     }
     double* v = fvec + me.rows_ptr;
@@ -997,14 +1005,18 @@ __global__ __launch_bounds__(WIDE_NT) void k_front_bwd_wide(FrontMeta M, const d
     double* ss = vs + ((f + 1) & ~1);  // column sums of the current block
     for (int i = tid; i < f; i += WIDE_NT) vs[i] = x[rows[i]];
     __syncthreads();
-    auto prefetch_t = [&](auto full_tag, WideBwdOps& o, int kb) {
+    auto prefetch_tri = [&](auto full_tag, WideBwdOps& o, int kb) {
         constexpr bool FULL = decltype(full_tag)::value;  // (see k_front_fwd_wide)
-        const int nbk = FULL ? WIDE_B : min(WIDE_B, w - kb), r0 = kb + nbk;
+        const int nbk = FULL ? WIDE_B : min(WIDE_B, w - kb);
         if (wave == 0) {
             const double* col = F + kb + (long long)(kb + min(lane, nbk - 1)) * f;
 #pragma unroll
             for (int i = 0; i < WIDE_B; ++i) o.Lt[i] = col[min(i, nbk - 1)];  // (clamped into the block; masked where it is used)
         }
+    };
+    auto prefetch_cols = [&](auto full_tag, WideBwdOps& o, int kb) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        const int nbk = FULL ? WIDE_B : min(WIDE_B, w - kb), r0 = kb + nbk;
 #pragma unroll
         for (int c = 0; c < WIDE_CPW; ++c) {
             const int k = wave * WIDE_CPW + c;  // wave-uniform
@@ -1017,7 +1029,8 @@ __global__ __launch_bounds__(WIDE_NT) void k_front_bwd_wide(FrontMeta M, const d
             }
         }
     };
-    auto step_t = [&](auto full_tag, const WideBwdOps& o, int kb) {
+    // (as in the forward kernel: a buffer is refilled right after its use with the operands of the block two further on, kb2 < 0: none)
+    auto step_t = [&](auto full_tag, WideBwdOps& o, int kb, int kb2) {
         constexpr bool FULL = decltype(full_tag)::value;
         const int nbk = FULL ? WIDE_B : min(WIDE_B, w - kb), r0 = kb + nbk;
         // s_k = sum_{i >= r0} L[i, k] x[i]
@@ -1039,6 +1052,7 @@ __global__ __launch_bounds__(WIDE_NT) void k_front_bwd_wide(FrontMeta M, const d
                 if (k < nbk) acc[c] = __builtin_fma(F[i + (long long)(kb + k) * f], xi, acc[c]);
             }
         }
+        if (kb2 >= 0) prefetch_cols(std::true_type{}, o, kb2);  // (every block after the first one processed is a full one)
 #pragma unroll
         for (int c = 0; c < WIDE_CPW; ++c) {
             const double t = wide_wave_sum(acc[c]);
@@ -1055,25 +1069,25 @@ __global__ __launch_bounds__(WIDE_NT) void k_front_bwd_wide(FrontMeta M, const d
             }
             if (lane < nbk) vs[kb + lane] = vk;
         }
+        if (kb2 >= 0) prefetch_tri(std::true_type{}, o, kb2);
         wide_lds_barrier();
     };
-    {   // the ragged last block first, on its own; then the full blocks, double-buffered
+    {   // the ragged last block first, on its own; then the full blocks on two buffers
         const int wfull = w - w % WIDE_B;
         if (wfull < w) {
             WideBwdOps T;
-            prefetch_t(std::false_type{}, T, wfull);
-            step_t(std::false_type{}, T, wfull);
+            prefetch_tri(std::false_type{}, T, wfull); prefetch_cols(std::false_type{}, T, wfull);
+            step_t(std::false_type{}, T, wfull, -1);
         }
         const std::true_type full{};
         WideBwdOps A, B;
         const int klast = wfull - WIDE_B;
-        if (klast >= 0) prefetch_t(full, A, klast);
+        if (klast >= 0) { prefetch_tri(full, A, klast); prefetch_cols(full, A, klast); }
+        if (klast - WIDE_B >= 0) { prefetch_tri(full, B, klast - WIDE_B); prefetch_cols(full, B, klast - WIDE_B); }
         for (int kb = klast; kb >= 0; kb -= 2 * WIDE_B) {
-            if (kb - WIDE_B >= 0) prefetch_t(full, B, kb - WIDE_B);
-            step_t(full, A, kb);
+            step_t(full, A, kb, kb - 2 * WIDE_B);
             if (kb - WIDE_B < 0) break;
-            if (kb - 2 * WIDE_B >= 0) prefetch_t(full, A, kb - 2 * WIDE_B);
-            step_t(full, B, kb - WIDE_B);
+            step_t(full, B, kb - WIDE_B, kb - 3 * WIDE_B);
         }
     }
     for (int i = tid; i < w; i += WIDE_NT) x[first + i] = vs[i];
