@@ -1253,19 +1253,20 @@ __global__ __launch_bounds__(64) void k_subtree_fwd_wave(FrontMeta M, const doub
         double v0 = r0 < f ? a[r0] : 0.0, v1 = r1 < f ? a[r1] : 0.0;
         auto panel_sweep = [&](const double* __restrict__ Fp) {
             int k = 0;
+            const int rc0 = min(r0, f - 1), rc1 = min(r1, f - 1);
             for (; k + 4 <= w; k += 4) {
                 double c0[4], c1[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const double* col = Fp + (k + u) * f;
-                    c0[u] = (r0 > k + u && r0 < f) ? col[r0] : 0.0;
-                    c1[u] = (r1 < f) ? col[r1] : 0.0;  // r1 >= 64 > k + u whenever the row exists and k + u < 64; checked below otherwise
+                for (int u = 0; u < 4; ++u) {  // unconditional loads from rows clamped into the front (a load under a lane condition is a branch of its own);
+                    const double* col = Fp + (k + u) * f;  // the masks are applied where the values are used (C3 / C5 backend solve -4 %; the same change in
+                    c0[u] = col[rc0];                      // the backward kernel measured neutral and was not kept)
+                    c1[u] = col[rc1];
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const double yk = bcast_row(v0, v1, k + u);
-                    v0 -= c0[u] * yk;
-                    if (r1 > k + u) v1 -= c1[u] * yk;
+                    v0 -= ((r0 > k + u && r0 < f) ? c0[u] : 0.0) * yk;
+                    if (r1 > k + u) v1 -= (r1 < f ? c1[u] : 0.0) * yk;
                 }
             }
             for (; k < w; ++k) {
