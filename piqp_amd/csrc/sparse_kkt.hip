@@ -2274,7 +2274,14 @@ private:
     {
         const int f = S_.front_rows_ptr[s + 1] - S_.front_rows_ptr[s], w = S_.sn_first[s + 1] - S_.sn_first[s];
         if (no_big_) return false;
-        return big_front(f, w) || panel_front(f, w);
+        if (big_front(f, w)) return true;
+        // a panel front alone does not pull a small top out of its single persistent launch (k_top_factor stages the panel itself): measured on AUG3DCQP
+        // (41 top supernodes, two panel fronts, none big): factorisation 0.45 ms persistent, 0.61 ms with eight level launches around the two fronts
+        if (tree_has_big_ < 0) {
+            tree_has_big_ = (int)S_.top_level_sn.size() > 1024 ? 1 : 0;
+            for (int t : S_.top_level_sn) if (big_front(S_.front_rows_ptr[t + 1] - S_.front_rows_ptr[t], S_.sn_first[t + 1] - S_.sn_first[t])) { tree_has_big_ = 1; break; }
+        }
+        return tree_has_big_ == 1 && panel_front(f, w);
     }
     struct BigLevels {
         std::vector<int> ptr, rounds, ndense, npanel, panel_lds;  // level l of the schedule -> jobs [ptr[l], ptr[l + 1]); children of its widest fan-in; jobs by kind; LDS of k_front_panel
@@ -2561,6 +2568,7 @@ private:
     SubSchedule solve_sched_;
     LevelLists solve_ll_, own_ll_, sh_ll_;
     bool no_fork_ = debug_token("no_fork") != nullptr;  // debugging aid: everything on one stream
+    mutable int tree_has_big_ = -1;  // lazily: does the top of the tree hold a front for the dense kernels (or is it too large for one persistent launch)
     bool no_big_ = debug_token("no_big") != nullptr;    // debugging aid: every front through one workgroup's pivot loop (accuracy comparisons)
     int wide_fcap_ = debug_token("no_wide_solve") ? 0 : WIDE_FCAP;  // debugging aid: wide fronts through the per-pivot routines
     BigLevels top_big_, own_big_, sh_big_;
