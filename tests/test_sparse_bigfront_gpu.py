@@ -31,7 +31,7 @@ def _rel(a, b):
     return float(np.abs(a - b).max() / max(1.0, np.abs(b).max()))
 
 
-@pytest.mark.parametrize("kind", ["grid", "dense_rows"])
+@pytest.mark.parametrize("kind", ["grid", "dense_rows", "dense_rows_big"])
 def test_big_fronts_agree_with_one_workgroup_fronts_and_oracle(tmp_path, kind):
     big = _run(tmp_path, kind, "big", {})
     one = _run(tmp_path, kind, "one", {"PIQP_AMD_DEBUG": "no_big"})

@@ -3,7 +3,7 @@
 with whatever PIQP_AMD_DEBUG the parent set (`no_big` = every front through one workgroup's pivot loop; default = big fronts on the batched dense
 kernels, panel fronts staged in LDS, wide fronts through the blocked substitution).  Solution, residual and symbolic figures go to an .npz.
 
-  python tests/workers/bigfront_variant.py {grid|dense_rows} out.npz
+  python tests/workers/bigfront_variant.py {grid|dense_rows|dense_rows_big} out.npz
 """
 import os
 import sys
@@ -31,8 +31,9 @@ def problem(kind):
         c = rng.standard_normal(n); b = rng.standard_normal(N)
         x_l = np.concatenate([np.full(N, -1e30), np.full(N, -1.0)]); x_u = np.concatenate([np.full(N, 1e30), np.full(N, 1.0)])
         return (P, c, A, b, None, None, None, x_l, x_u), n, N, 0
-    # a few hundred dense equality rows: the root front has that many pivots (several 128-column panels, the last one ragged) over a wide child level
-    n, p = 3000, 333
+    # a few hundred dense equality rows: the root front has that many pivots (several 128-column panels, the last one ragged) over a wide child level;
+    # dense_rows_big: 1150 of them -- a front beyond the 1040 / 768 rows the wide substitution kernels keep in registers per block (their in-line tails)
+    n, p = (4000, 1150) if kind == "dense_rows_big" else (3000, 333)
     P = sp.diags(0.5 + rng.random(n)).tocsc()
     A = sp.csc_matrix(rng.standard_normal((p, n)) * (rng.random((p, n)) < 0.6))
     G = sp.random(200, n, density=0.01, random_state=5, format="csc")
