@@ -42,6 +42,19 @@ def main():
     assert ok
     for key, v in lhs2.items():
         out["chain_" + key] = np.asarray(v)
+    # (c) a tree with real separators (frozen Maros-Meszaros CONT-101): big fronts on the batched dense kernels, panel fronts, wide-front substitution
+    from qp_io import load_qp
+    q3 = load_qp("mm_CONT-101")
+    a3 = (q3["P"], q3["c"], q3["A"], q3["b"], q3["G"], q3["h_l"], q3["h_u"], q3["x_l"], q3["x_u"])
+    d3 = hip.SparseData(*a3)
+    k3 = hip.KKTSystem(d3, hip.default_settings(kkt_solver=hip.SPARSE_LDLT))
+    state3 = random_vars(d3.n, d3.p, d3.m, rng, positive=True)
+    rhs3 = random_vars(d3.n, d3.p, d3.m, rng)
+    assert k3.update_scalings_and_factor(False, 1e-6, 1e-4, state3)
+    ok, lhs3 = k3.solve(rhs3)
+    assert ok
+    for key, v in lhs3.items():
+        out["cont_" + key] = np.asarray(v)
     np.savez(sys.argv[1], **out)
     print("ok", sorted(out))
 
