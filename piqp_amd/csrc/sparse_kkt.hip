@@ -2391,12 +2391,19 @@ private:
     struct LevelLists {
         std::vector<int> ptr, narrow, lds;  // level l = list[ptr[l] .. ptr[l+1]): `narrow[l]` single-wave fronts first; LDS bytes of its widest front
         DBuf<int> dev;
+        // runs of consecutive levels that hold single-wave fronts only and continue each other as chains (front t's one child inside the run is t - 1):
+        // ONE launch of chain walks per run instead of one launch per level (CONT-201: ten levels of four fronts each -> one launch of four walks)
+        struct Run { int a, b, off, nwalk; };
+        std::vector<Run> runs;
+        std::vector<int> run_of;  // level -> run (or -1)
+        DBuf<int> walk_lo, walk_hi;
     };
     void build_level_lists(const std::vector<int>& ptr, const std::vector<int>& sn, LevelLists& L)
     {
-        L.ptr = ptr; L.narrow.clear(); L.lds.clear();
+        L.ptr = ptr; L.narrow.clear(); L.lds.clear(); L.runs.clear();
+        const int nl = (int)ptr.size() - 1;
         std::vector<int> order;
-        for (int l = 0; l + 1 < (int)ptr.size(); ++l) {
+        for (int l = 0; l < nl; ++l) {
             int fmax = 0;
             for (int q = ptr[l]; q < ptr[l + 1]; ++q) if (S_.front_rows_ptr[sn[q] + 1] - S_.front_rows_ptr[sn[q]] <= 128) order.push_back(sn[q]);
             L.narrow.push_back((int)order.size() - ptr[l]);
@@ -2407,12 +2414,53 @@ private:
             L.lds.push_back((((fmax + 1) & ~1) + WIDE_B) * (int)sizeof(double));
         }
         upload_vec(L.dev, order, st_);
+        L.run_of.assign(std::max(nl, 1), -1);
+        if (no_runs_) return;
+        std::vector<int> lvl(S_.nsuper ? S_.nsuper : 1, -1), walk_end(S_.nsuper ? S_.nsuper : 1, -1), wlo, whi;
+        for (int l = 0; l < nl; ++l) for (int q = ptr[l]; q < ptr[l + 1]; ++q) lvl[sn[q]] = l;
+        auto narrow_only = [&](int l) { return ptr[l + 1] > ptr[l] && L.narrow[l] == ptr[l + 1] - ptr[l]; };
+        for (int l = 0; l < nl;) {
+            if (!narrow_only(l)) { ++l; continue; }
+            const int a = l, off = (int)wlo.size();
+            for (int q = ptr[a]; q < ptr[a + 1]; ++q) { walk_end[sn[q]] = (int)wlo.size(); wlo.push_back(sn[q]); whi.push_back(sn[q]); }
+            int b2 = a;
+            while (b2 + 1 < nl && narrow_only(b2 + 1)) {
+                bool ok = true;
+                for (int q = ptr[b2 + 1]; q < ptr[b2 + 2] && ok; ++q) {
+                    const int t = sn[q];
+                    int nin = 0, cin = -1;
+                    for (int ci = S_.child_ptr[t]; ci < S_.child_ptr[t + 1]; ++ci) { const int c = S_.child[ci]; if (lvl[c] >= a && lvl[c] <= b2) { ++nin; cin = c; } }
+                    if (nin == 0) continue;
+                    if (!(nin == 1 && cin == t - 1 && lvl[cin] == b2 && walk_end[cin] >= 0 && S_.sn_parent[cin] == t)) ok = false;
+                }
+                if (!ok) break;
+                for (int q = ptr[b2 + 1]; q < ptr[b2 + 2]; ++q) {
+                    const int t = sn[q];
+                    bool ext = false;
+                    for (int ci = S_.child_ptr[t]; ci < S_.child_ptr[t + 1]; ++ci) { const int c = S_.child[ci]; if (lvl[c] >= a && lvl[c] <= b2) ext = true; }
+                    if (ext) { const int wk = walk_end[t - 1]; whi[wk] = t; walk_end[t - 1] = -1; walk_end[t] = wk; }
+                    else { walk_end[t] = (int)wlo.size(); wlo.push_back(t); whi.push_back(t); }
+                }
+                ++b2;
+            }
+            if (b2 > a) {
+                for (int r = a; r <= b2; ++r) L.run_of[r] = (int)L.runs.size();
+                L.runs.push_back({a, b2, off, (int)wlo.size() - off});
+            } else { wlo.resize(off); whi.resize(off); }
+            l = b2 + 1;
+        }
+        if (!wlo.empty()) { upload_vec(L.walk_lo, wlo, st_); upload_vec(L.walk_hi, whi, st_); }
     }
     void fwd_levels(const FrontMeta& M, const LevelLists& L)
     {
         for (int l = 0; l + 1 < (int)L.ptr.size(); ++l) {
             const int cnt = L.ptr[l + 1] - L.ptr[l], nn = cnt > 0 ? L.narrow[l] : 0;
             const int* list = L.dev.p + L.ptr[l];
+            if (L.run_of[l] >= 0) {
+                const LevelLists::Run& r = L.runs[L.run_of[l]];
+                if (l == r.a) hipLaunchKernelGGL(k_subtree_fwd_wave<false>, dim3(r.nwalk), dim3(64), 0, st_, M, fronts_.p, L.walk_lo.p + r.off, L.walk_hi.p + r.off, xp_.p, fvec_.p, (const int*)nullptr, (int*)nullptr, (int*)nullptr, (const int*)nullptr, 0);
+                continue;
+            }
             if (nn > 0) hipLaunchKernelGGL(k_subtree_fwd_wave<false>, dim3(nn), dim3(64), 0, st_, M, fronts_.p, list, list, xp_.p, fvec_.p, (const int*)nullptr, (int*)nullptr, (int*)nullptr, (const int*)nullptr, 0);
             if (cnt > nn) hipLaunchKernelGGL(k_front_fwd_wide, dim3(cnt - nn), dim3(WIDE_NT), L.lds[l], st_, M, fronts_.p, list + nn, xp_.p, fvec_.p, wide_fcap_);
         }
@@ -2422,6 +2470,11 @@ private:
         for (int l = (int)L.ptr.size() - 2; l >= 0; --l) {
             const int cnt = L.ptr[l + 1] - L.ptr[l], nn = cnt > 0 ? L.narrow[l] : 0;
             const int* list = L.dev.p + L.ptr[l];
+            if (L.run_of[l] >= 0) {
+                const LevelLists::Run& r = L.runs[L.run_of[l]];
+                if (l == r.b) hipLaunchKernelGGL(k_subtree_bwd_wave<false>, dim3(r.nwalk), dim3(64), 0, st_, M, fronts_.p, L.walk_lo.p + r.off, L.walk_hi.p + r.off, xp_.p, bwd_red_thr(), 0, (const int*)nullptr, (int*)nullptr, (int*)nullptr, (const int*)nullptr, 0, (const double*)nullptr);
+                continue;
+            }
             if (cnt > nn) hipLaunchKernelGGL(k_front_bwd_wide, dim3(cnt - nn), dim3(WIDE_NT), L.lds[l], st_, M, fronts_.p, list + nn, xp_.p, fvec_.p, wide_fcap_);
             if (nn > 0) hipLaunchKernelGGL(k_subtree_bwd_wave<false>, dim3(nn), dim3(64), 0, st_, M, fronts_.p, list, list, xp_.p, bwd_red_thr(), 0, (const int*)nullptr, (int*)nullptr, (int*)nullptr, (const int*)nullptr, 0, (const double*)nullptr);
         }
@@ -2567,6 +2620,7 @@ private:
     DBuf<int> fe_ptr_, fe_q_, fe_off_, fe_offp_, top_pos_, top_flags_, solve_level_sn_, solve_top_pos_, solve_flags_, solve_walk_lo_, solve_walk_hi_, solve_pub_;
     SubSchedule solve_sched_;
     LevelLists solve_ll_, own_ll_, sh_ll_;
+    bool no_runs_ = debug_token("no_level_runs") != nullptr;  // debugging aid: one substitution launch per level, no merged runs of chain levels
     bool no_fork_ = debug_token("no_fork") != nullptr;  // debugging aid: everything on one stream
     mutable int tree_has_big_ = -1;  // lazily: does the top of the tree hold a front for the dense kernels (or is it too large for one persistent launch)
     bool no_big_ = debug_token("no_big") != nullptr;    // debugging aid: every front through one workgroup's pivot loop (accuracy comparisons)
