@@ -347,10 +347,13 @@ def sparse_legs(args, rank, world, local_rank, dev, pd):
                 fac_s = r["factor_ms"] * 1e-3; sol_s = r["backend_solve_ms"] * 1e-3
                 r["symbolic"] = stt
                 traffic_f = traffic_s = None
-                try:  # rocprofv3 PMC passes of the C3 workload (profiles/r02_pmc_sparse_batch.json); other workloads: not measured
+                try:  # rocprofv3 PMC passes of the C3 and CONT-201 workloads (profiles/r02_pmc_sparse_batch.json); other workloads: not measured
                     pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_sparse_batch.json")))["sparse_c3"]
                     if key == "C3" and abs(pmc["factor_per_launch"]["algorithmic_bytes"] - bytes_factor) < 0.05 * bytes_factor:
                         traffic_f = pmc["factor_per_launch"]["traffic_bytes"]; traffic_s = pmc["solve_per_launch"]["traffic_bytes"]
+                    pmc2 = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_sparse_batch.json"))).get("sparse_cont201")
+                    if key == "MM_CONT-201" and pmc2 and abs(pmc2["factor_per_launch"]["algorithmic_bytes"] - bytes_factor) < 0.05 * bytes_factor:
+                        traffic_f = pmc2["factor_per_launch"]["traffic_bytes"]; traffic_s = pmc2["solve_per_launch"]["traffic_bytes"]
                 except Exception:  # noqa: BLE001
                     pass
                 r["roofline"] = {"bound": "hbm", "kernel": "multifrontal factorisation (k_subtree_factor_lds / _pk + k_top_factor / k_front_factor levels; big fronts: k_potrf_diag_fronts / k_trsm_panel_fronts / k_syrk_lower_fronts per level), hipEvent-bracketed on the backend stream",

@@ -685,8 +685,13 @@ __global__ __launch_bounds__(256) void k_big_zero(FrontMeta M, double* __restric
 {
     const SnRec me = M.sn[list[blockIdx.y]];
     double* F = fronts + me.front_off;
-    const long long tot = (long long)me.f * me.f;
-    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < tot; idx += (long long)gridDim.x * 256) F[idx] = 0.0;
+    const int f = me.f;
+    // the lower triangle only: nothing reads the strict upper triangle of a multi-workgroup front as a number (half the zero-fill traffic, which
+    // was the largest single item of the factorisation's HBM traffic on CONT-201: profiles/r02_pmc_sparse_batch.json)
+    for (int j = blockIdx.x; j < f; j += gridDim.x) {
+        double* Fj = F + (long long)j * f;
+        for (int i = j + threadIdx.x; i < f; i += 256) Fj[i] = 0.0;
+    }
 }
 __global__ __launch_bounds__(256) void k_big_assemble(FrontMeta M, double* __restrict__ fronts, const int* __restrict__ list)
 {
