@@ -224,6 +224,24 @@ int pq_kkt_partition_info(pq_kkt *k, int out[8]);
 int pq_sparse_partition_plan(const pq_sparse_data *data, int mode, int world, int *owner_out, int capacity,
                              double *work_out /* world + 1: per rank, then shared */);
 
+/* ---- the integer work of sparse::KKT's constructor, host-only (no GPU needed), exported so that the index work of the product can be pinned bit for
+ * bit (tests/test_symbolic_parity.py: the reference's exact 4 x 4 case, tests/src/sparse/utils_test.cpp:55-92, and the oracle on the frozen fixtures).
+ * pq_sparse_amd_order: Eigen-style approximate minimum degree on the pattern of the upper-triangular CSC matrix (sparse/ordering.hpp:67-84: the
+ *   `P_eigen.indices()` of AMDOrdering::init, perm[new] = old).
+ * pq_sparse_permute_sym_upper: permute_sparse_symmetric_matrix (sparse/utils.hpp:32-128): C = upper(P A P') for perm_inv[old] = new, with the map
+ *   Ai_to_Ci of value positions (its return value); Cp[n + 1], Ci[nnz], Ai_to_Ci[nnz].
+ * pq_sparse_kkt_symbolic: create_kkt_matrix of `mode` (kkt_full.hpp:39-170 and the three eliminated variants; 0 full, 1 eq, 2 ineq, 3 all) followed by
+ *   the two steps above exactly as sparse/kkt.hpp:51-70 runs them.  Call with all outputs NULL to get sizes: returns N and writes nnz(K) to *nnz_out.
+ *   Kp[N + 1], Ki[nnz], perm[N] (the AMD ordering), PKp[N + 1], PKi_rows[nnz] (pattern of PKPt), PKi[nnz] (K value index -> PKPt value index).
+ * pq_kkt_sparse_ordering (sparse backends, after create): what the handle actually eliminates in.  fill_perm[N] = the fill-reducing ordering chosen
+ *   (AMD as above, or nested dissection; perm[new] = old), elim_perm[N] = the same composed with the assembly-tree postorder / leaf amalgamation the
+ *   device schedule uses (any postorder of the elimination tree has the same fill), returns 0 = amd, 1 = nested dissection, < 0 on error. */
+int pq_sparse_amd_order(int n, const int *Ap, const int *Ai, int *perm);
+int pq_sparse_permute_sym_upper(int n, const int *Ap, const int *Ai, const int *perm_inv, int *Cp, int *Ci, int *Ai_to_Ci);
+int pq_sparse_kkt_symbolic(const pq_sparse_data *data, int mode, int *nnz_out, int *Kp, int *Ki, int *perm, int *PKp, int *PKi_rows,
+                           int *PKi);
+int pq_kkt_sparse_ordering(pq_kkt *k, int *fill_perm, int *elim_perm);
+
 /* measurement hooks: when enabled, the backend brackets its stages with hipEvents on its own stream.
  * stage 0 = KKT assembly kernel (dense: k_syrk_lower<ASSEMBLE>), 1 = factorisation (all panels),
  * 2 = backend solve.  enable = 2 (dense backend, measurement passes only) also brackets individual launches: 3 = fused trailing update +

@@ -202,6 +202,14 @@ const int *orc_sparse_kkt_PKPt_rowind(const orc_kkt *k);
 const double *orc_sparse_kkt_PKPt_val(const orc_kkt *k);
 const int *orc_sparse_kkt_perm(const orc_kkt *k);
 int orc_sparse_kkt_L_nnz(const orc_kkt *k);
+const int *orc_sparse_kkt_PKi(const orc_kkt *k);
+int orc_sparse_kkt_nnz(const orc_kkt *k);
+int orc_sparse_cond_kkt_dim(const orc_kkt *k);
+int orc_sparse_cond_kkt_nnz(const orc_kkt *k);
+const int *orc_sparse_cond_kkt_perm(const orc_kkt *k);
+const int *orc_sparse_cond_kkt_PKPt_colptr(const orc_kkt *k);
+const int *orc_sparse_cond_kkt_PKPt_rowind(const orc_kkt *k);
+const int *orc_sparse_cond_kkt_PKi(const orc_kkt *k);
 
 /* ---- KKTSystem (kkt_system.hpp) ---------------------------------------- */
 typedef struct orc_kkt_system orc_kkt_system;

@@ -574,6 +574,26 @@ static int sparse_factor(orc_kkt *self, const orc_data *d, double delta, const d
     for (int col = k->n; col < k->n + k->p; col++) k->PKPt_x[k->PKPt_p[k->P_inv[col] + 1] - 1] = -delta;
     for (int col = k->n + k->p, q = 0; col < k->N; col++, q++) k->PKPt_x[k->PKPt_p[k->P_inv[col] + 1] - 1] = -z_reg[q];
     int ret = orc_sparse_ldlt_numeric(k->ldlt, k->N, k->PKPt_p, k->PKPt_i, k->PKPt_x);
+    if (ret == k->N && getenv("ORC_DEBUG_INERTIA")) {
+        /* diagnostic (tools/exp_zero_pivot.py): pivots of the quasi-definite K whose sign is not the block's (x: +, y / z: -) in a factorisation the
+         * reference's criterion (D[k] == 0 only) accepts */
+        int bad = 0, first = -1;
+        for (int j = 0; j < k->N; j++) { int col = k->P[j]; double dj = k->ldlt->D[j]; if (col < k->n ? dj < 0.0 : dj > 0.0) { if (!bad) first = j; bad++; } }
+        if (bad) fprintf(stderr, "orc inertia: %d wrong-sign pivots (first k=%d orig %d D=%.3e) delta=%.3e\n", bad, first, k->P[first], k->ldlt->D[first], delta);
+    }
+    if (ret != k->N && getenv("ORC_DEBUG_ZERO_PIVOT")) {
+        /* diagnostic (tools/exp_zero_pivot.py): which original row hits D[k] == 0 and what its row of L looks like */
+        int col = k->P[ret];
+        const orc_sparse_ldlt *f = k->ldlt;
+        fprintf(stderr, "orc zero pivot: k=%d of N=%d, original index %d (%s %d), delta=%.3e, K diagonal there %.17g; L(k,:) entries:", ret, k->N, col,
+                col < k->n ? "x" : col < k->n + k->p ? "y" : "z", col < k->n ? col : col < k->n + k->p ? col - k->n : col - k->n - k->p, delta,
+                k->PKPt_x[k->PKPt_p[ret + 1] - 1]);
+        int shown = 0;
+        for (int i = 0; i < ret && shown < 12; i++)
+            for (int q = f->L_cols[i]; q < f->L_cols[i] + f->L_nnz[i]; q++)
+                if (f->L_ind[q] == ret) { fprintf(stderr, " [col %d (orig %d) l=%.17g D=%.17g]", i, k->P[i], f->L_vals[q], f->D[i]); shown++; }
+        fprintf(stderr, "\n");
+    }
     return ret == k->N;
 }
 
@@ -731,4 +751,6 @@ const int *orc_sparse_kkt_PKPt_colptr(const orc_kkt *k) { return ((const sparse_
 const int *orc_sparse_kkt_PKPt_rowind(const orc_kkt *k) { return ((const sparse_kkt *)k)->PKPt_i; }
 const double *orc_sparse_kkt_PKPt_val(const orc_kkt *k) { return ((const sparse_kkt *)k)->PKPt_x; }
 const int *orc_sparse_kkt_perm(const orc_kkt *k) { return ((const sparse_kkt *)k)->P; }
+const int *orc_sparse_kkt_PKi(const orc_kkt *k) { return ((const sparse_kkt *)k)->PKi; }
+int orc_sparse_kkt_nnz(const orc_kkt *k) { return ((const sparse_kkt *)k)->nnzK; }
 int orc_sparse_kkt_L_nnz(const orc_kkt *k) { return orc_sparse_ldlt_nnz(((const sparse_kkt *)k)->ldlt); }

@@ -357,3 +357,11 @@ static orc_kkt *cond_clone(const orc_kkt *self)
     k->rhs = (double *)xc((size_t)N, sizeof(double)); k->rhs_perm = (double *)xc((size_t)N, sizeof(double));
     return &k->base;
 }
+
+/* test hooks (the integer work of the constructor, for tests/test_symbolic_parity.py) */
+int orc_sparse_cond_kkt_dim(const orc_kkt *k) { return ((const cond_kkt *)k)->N; }
+int orc_sparse_cond_kkt_nnz(const orc_kkt *k) { return ((const cond_kkt *)k)->nnzK; }
+const int *orc_sparse_cond_kkt_perm(const orc_kkt *k) { return ((const cond_kkt *)k)->P; }
+const int *orc_sparse_cond_kkt_PKPt_colptr(const orc_kkt *k) { return ((const cond_kkt *)k)->PKPt_p; }
+const int *orc_sparse_cond_kkt_PKPt_rowind(const orc_kkt *k) { return ((const cond_kkt *)k)->PKPt_i; }
+const int *orc_sparse_cond_kkt_PKi(const orc_kkt *k) { return ((const cond_kkt *)k)->PKi; }

@@ -193,8 +193,13 @@ def _bind(L):
         L.orc_sparse_ldlt_nnz.argtypes = [vp]
         L.orc_amd_order.argtypes = [C.c_int, _ip, _ip, _ip]
         L.orc_permute_sym_upper.argtypes = [C.c_int, _ip, _ip, _dp, _ip, _ip, _ip, _dp, _ip]
-        for nm, rt in (("dim", C.c_int), ("PKPt_colptr", _ip), ("PKPt_rowind", _ip), ("PKPt_val", _dp), ("perm", _ip), ("L_nnz", C.c_int)):
+        for nm, rt in (("dim", C.c_int), ("PKPt_colptr", _ip), ("PKPt_rowind", _ip), ("PKPt_val", _dp), ("perm", _ip), ("L_nnz", C.c_int), ("PKi", _ip),
+                       ("nnz", C.c_int)):
             f = getattr(L, "orc_sparse_kkt_" + nm)
+            f.restype = rt
+            f.argtypes = [vp]
+        for nm, rt in (("dim", C.c_int), ("nnz", C.c_int), ("perm", _ip), ("PKPt_colptr", _ip), ("PKPt_rowind", _ip), ("PKi", _ip)):
+            f = getattr(L, "orc_sparse_cond_kkt_" + nm)
             f.restype = rt
             f.argtypes = [vp]
     return L

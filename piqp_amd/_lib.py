@@ -130,6 +130,10 @@ def load():
     L.pq_kkt_internal_factor.argtypes = [vp, vp]
     L.pq_kkt_dims.argtypes = [vp, _ip, _ip, _ip]
     L.pq_kkt_multistage_block_info.argtypes = [vp, vp, C.c_int]
+    L.pq_sparse_amd_order.argtypes = [C.c_int, _ip, _ip, _ip]
+    L.pq_sparse_permute_sym_upper.argtypes = [C.c_int, _ip, _ip, _ip, _ip, _ip, _ip]
+    L.pq_sparse_kkt_symbolic.argtypes = [C.POINTER(SparseData), C.c_int, _ip, _ip, _ip, _ip, _ip, _ip, _ip]
+    L.pq_kkt_sparse_ordering.argtypes = [vp, _ip, _ip]
     L.pq_batch_create.argtypes = [C.POINTER(vp), C.c_int]
     L.pq_batch_destroy.argtypes = [vp]
     L.pq_batch_settings.argtypes = [vp]

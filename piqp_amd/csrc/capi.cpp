@@ -386,6 +386,54 @@ int pq_sparse_partition_plan(const pq_sparse_data* data, int mode, int world, in
         return S.N;
     });
 }
+int pq_sparse_amd_order(int n, const int* Ap, const int* Ai, int* perm)
+{
+    if (n < 0 || !Ap || (n && !perm)) return fail(PQ_ERR_INVALID, "bad argument");
+    return guarded([&] { sparse::amd_order(n, Ap, Ai, perm); return (int)PQ_OK; });
+}
+int pq_sparse_permute_sym_upper(int n, const int* Ap, const int* Ai, const int* perm_inv, int* Cp, int* Ci, int* Ai_to_Ci)
+{
+    if (n < 0 || !Ap || !perm_inv || !Cp) return fail(PQ_ERR_INVALID, "bad argument");
+    return guarded([&] {
+        sparse::IVec ap(Ap, Ap + n + 1), ai(Ai, Ai + Ap[n]), cp, ci, map;
+        sparse::permute_sym_upper(n, ap, ai, perm_inv, cp, ci, map);
+        std::copy(cp.begin(), cp.end(), Cp);
+        if (Ci) std::copy(ci.begin(), ci.end(), Ci);
+        if (Ai_to_Ci) std::copy(map.begin(), map.end(), Ai_to_Ci);
+        return (int)PQ_OK;
+    });
+}
+int pq_sparse_kkt_symbolic(const pq_sparse_data* data, int mode, int* nnz_out, int* Kp, int* Ki, int* perm, int* PKp, int* PKi_rows, int* PKi)
+{
+    if (!data || mode < 0 || mode > 3) return fail(PQ_ERR_INVALID, "bad argument");
+    return guarded([&] {
+        // analyse_kkt builds K exactly like create_kkt_matrix of the mode; the ordering / permutation steps are repeated here in the reference's own
+        // sequence (sparse/kkt.hpp:57-63: ordering.init(KKT); PKi = permute_sparse_symmetric_matrix(KKT, PKPt, ordering)) without the device schedule's
+        // postorder, which is what pq_kkt_sparse_ordering reports
+        sparse::Symbolic S;
+        sparse::analyse_kkt_pattern(data, mode, S);
+        const int N = S.N, nnz = S.Kp[N];
+        if (nnz_out) *nnz_out = nnz;
+        if (Kp) std::copy(S.Kp.begin(), S.Kp.end(), Kp);
+        if (Ki) std::copy(S.Ki.begin(), S.Ki.end(), Ki);
+        if (perm || PKp || PKi_rows || PKi) {
+            sparse::IVec pm(N), pinv(N), cp, ci, map;
+            sparse::amd_order(N, S.Kp.data(), S.Ki.data(), pm.data());
+            for (int i = 0; i < N; ++i) pinv[pm[i]] = i;
+            sparse::permute_sym_upper(N, S.Kp, S.Ki, pinv.data(), cp, ci, map);
+            if (perm) std::copy(pm.begin(), pm.end(), perm);
+            if (PKp) std::copy(cp.begin(), cp.end(), PKp);
+            if (PKi_rows) std::copy(ci.begin(), ci.end(), PKi_rows);
+            if (PKi) std::copy(map.begin(), map.end(), PKi);
+        }
+        return N;
+    });
+}
+int pq_kkt_sparse_ordering(pq_kkt* k, int* fill_perm, int* elim_perm)
+{
+    if (!k) return fail(PQ_ERR_INVALID, "null argument");
+    return guarded([&] { return k->impl->sparse_ordering(fill_perm, elim_perm); });
+}
 int pq_kkt_dims(const pq_kkt* k, int* n, int* p, int* m)
 {
     if (!k) return fail(PQ_ERR_INVALID, "null argument");

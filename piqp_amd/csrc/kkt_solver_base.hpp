@@ -46,6 +46,8 @@ public:
     // symbolic-analysis figures of the sparse backends for the roofline arithmetic: N, nnz(PKPt), nnz(L) below the
     // diagonal, supernodes, tree levels, workgroup subtrees, max front order, factorisation flops
     virtual void sparse_stats(double out[8]) const { (void)out; throw std::runtime_error("sparse_stats: sparse backends only"); }
+    // pq_kkt_sparse_ordering: the fill-reducing ordering and the elimination order built on it (perm[new] = old); returns 0 = amd, 1 = nested dissection
+    virtual int sparse_ordering(int* fill_perm, int* elim_perm) const { (void)fill_perm; (void)elim_perm; throw std::runtime_error("sparse_ordering: sparse backends only"); }
     // stage-partitioned execution over several processes (include/piqp_amd.h, pq_kkt_partition)
     virtual void partition(int rank, int world, long long sizes[3]) { (void)rank; (void)world; (void)sizes; throw std::runtime_error("partition: not supported by this backend"); }
     virtual void set_exchange(pq_exchange_fn fn, void* user, double* buf_factor, double* buf_forward, double* buf_gather)

@@ -207,6 +207,11 @@ public:
         ops_.eval_G_xn_and_GT_xt(alpha_n, alpha_t, xn, xt, zn, zt, st_);
     }
 
+    int sparse_ordering(int* fill_perm, int* elim_perm) const override
+    {
+        if (!tree_) throw std::runtime_error("sparse_ordering: chain engine (see multistage_block_info)");
+        return tree_->sparse_ordering(fill_perm, elim_perm);
+    }
     void sparse_stats(double out[8]) const override
     {
         if (!tree_) throw std::runtime_error("sparse_stats: chain engine (see multistage_block_info)");

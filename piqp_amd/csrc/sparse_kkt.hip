@@ -1841,6 +1841,12 @@ public:
     {
         out[0] = N_; out[1] = nnzK_; out[2] = (double)S_.nnzL; out[3] = S_.nsuper; out[4] = S_.nlevels; out[5] = S_.nsub; out[6] = S_.max_front; out[7] = S_.flops;
     }
+    int sparse_ordering(int* fill_perm, int* elim_perm) const override
+    {
+        if (fill_perm) std::copy(S_.fill_perm.begin(), S_.fill_perm.end(), fill_perm);
+        if (elim_perm) std::copy(S_.P.begin(), S_.P.end(), elim_perm);
+        return std::string(S_.ordering) == "amd" ? 0 : 1;
+    }
     // ---- pq_kkt_partition / pq_kkt_set_exchange (include/piqp_amd.h)
     void partition(int rank, int world, long long sizes[3]) override
     {

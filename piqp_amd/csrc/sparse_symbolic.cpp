@@ -388,7 +388,7 @@ void nd_order(int n, const int* Ap, const int* Ai, int* perm, int leaf)
 
 // ------------------------------------------------------------------------------------------------
 // C = upper(P A P') with sorted rows; Ai_to_Ci maps value positions (sparse/utils.hpp:32-128)
-static void permute_sym_upper(int n, const IVec& Ap, const IVec& Ai, const int* perm_inv, IVec& Cp, IVec& Ci, IVec& Ai_to_Ci)
+void permute_sym_upper(int n, const IVec& Ap, const IVec& Ai, const int* perm_inv, IVec& Cp, IVec& Ci, IVec& Ai_to_Ci)
 {
     const int nnz = Ap[n];
     IVec w(n, 0);
@@ -504,9 +504,17 @@ static void gram_structure(int n, int k, const int* MTp, const int* MTi, Symboli
 }
 
 void analyse_kkt_full(const pq_sparse_data* d, Symbolic& S) { analyse_kkt(d, 0, S); }
+static void order_and_analyse(Symbolic& S);
 
 // mode: KKTMode bits (kkt_fwd.hpp:15-21): 1 = equalities eliminated, 2 = inequalities eliminated
 void analyse_kkt(const pq_sparse_data* d, int mode, Symbolic& S)
+{
+    analyse_kkt_pattern(d, mode, S);
+    order_and_analyse(S);
+}
+
+// K of the mode and the value maps into it (create_kkt_matrix)
+void analyse_kkt_pattern(const pq_sparse_data* d, int mode, Symbolic& S)
 {
     const int n = d->n, p = d->p, m = d->m;
     const bool eq = (mode & 1) != 0, ineq = (mode & 2) != 0;
@@ -564,22 +572,29 @@ void analyse_kkt(const pq_sparse_data* d, int mode, Symbolic& S)
             S.Kp[jk + 1] = (int)S.Ki.size();
         }
 
+}
+
+static void order_and_analyse(Symbolic& S)
+{
+    const int N = S.N;
     // ---- ordering: AMD (what the reference uses, sparse/ordering.hpp:72-74) or nested dissection, whichever gives the
     // cheaper device schedule (levels = dependent kernel launches; fill = HBM traffic and flops)
     IVec perm_amd(N);
     amd_order(N, S.Kp.data(), S.Ki.data(), perm_amd.data());
     const char* want = std::getenv("PIQP_AMD_ORDERING");
     const std::string ord = want ? want : "auto";
-    if (ord == "amd" || (ord == "auto" && N < 200)) { analyse_with_order(S, perm_amd); S.ordering = "amd"; return; }
+    if (ord == "amd" || (ord == "auto" && N < 200)) { analyse_with_order(S, perm_amd); S.ordering = "amd"; S.fill_perm = perm_amd; return; }
     IVec perm_nd(N);
     int nd_leaf = 256;  // measured with the leaf amalgamation: 96 -> 256 is +8 % on C3 and +5 % on the n = 500k chain, 384 falls off a cliff
     nd_order(N, S.Kp.data(), S.Ki.data(), perm_nd.data(), nd_leaf);
     Symbolic T = S;
     analyse_with_order(T, perm_nd);
     T.ordering = "nested dissection";
+    T.fill_perm = perm_nd;
     if (ord == "nd") { S = std::move(T); return; }
     analyse_with_order(S, perm_amd);
     S.ordering = "amd";
+    S.fill_perm = perm_amd;
     // ~12 us per level (one launch per level) against ~1e11 flop/s and ~1e12 B/s on small fronts
     auto cost = [](const Symbolic& X) { return 12e-6 * (X.top_nlevels + 1) + X.flops / 1e11 + 8.0 * (double)X.front_doubles / 1e12; };
     if (cost(T) < 0.7 * cost(S)) S = std::move(T);

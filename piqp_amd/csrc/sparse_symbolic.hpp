@@ -39,6 +39,7 @@ struct Symbolic {
     IVec P_utri_to_Ki, AT_to_Ki, GT_to_Ki;
     // ordering: P[new] = old, P_inv[old] = new (AMD composed with the etree postorder)
     IVec P, P_inv;
+    IVec fill_perm;  // the fill-reducing ordering itself (AMD: what Eigen::AMDOrdering returns, sparse/ordering.hpp:72-76; or nested dissection), before the postorder
     // permuted matrix PKPt (upper) and K-index -> PKPt-index map
     IVec Cp, Ci, PKi;
     IVec diag_pos;  // PKPt value index of the diagonal of ORIGINAL column `col` (kkt_full.hpp:181,194,207)
@@ -97,11 +98,15 @@ struct Partition {
 void partition_tree(const Symbolic& S, int world, Partition& P);
 
 void amd_order(int n, const int* Ap, const int* Ai, int* perm);
+// permute_sparse_symmetric_matrix (sparse/utils.hpp:32-128): C = upper(P A P') with sorted columns, Ai_to_Ci = map of value positions
+void permute_sym_upper(int n, const IVec& Ap, const IVec& Ai, const int* perm_inv, IVec& Cp, IVec& Ci, IVec& Ai_to_Ci);
 // nested dissection by BFS level structures, AMD inside parts of at most `leaf` nodes; perm[new] = old
 void nd_order(int n, const int* Ap, const int* Ai, int* perm, int leaf);
 void analyse_kkt_full(const pq_sparse_data* d, Symbolic& S);
 // any KKTMode (kkt_fwd.hpp:15-21): 0 full, 1 eq eliminated, 2 ineq eliminated, 3 all eliminated
 void analyse_kkt(const pq_sparse_data* d, int mode, Symbolic& S);
+// its first half only: K of the mode (create_kkt_matrix) and the value maps into it, no ordering
+void analyse_kkt_pattern(const pq_sparse_data* d, int mode, Symbolic& S);
 
 }  // namespace sparse
 }  // namespace pq
