@@ -149,12 +149,15 @@ def main():
     # BASELINE configs[4] at N > 1: ONE n = 500k multistage QP, stage-partitioned over the ranks (tools/dist_c5.py).  It runs in child
     # processes with their own process group so that nothing in there can cost this run its JSON line; the children are started here,
     # before this process touches the GPU, and wait on stdin until the other legs are done.
-    c5_child = None
+    c5_child = c5_native_child = None
     if int(os.environ.get("WORLD_SIZE", "1")) > 1 and not args.no_dist_c5 and not args.no_sparse_legs:
         import importlib.util
         spec = importlib.util.spec_from_file_location("_pq_dist_spawn", os.path.join(ROOT, "piqp_amd", "dist.py"))
         spawn_mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(spawn_mod)
-        c5_child = spawn_mod.spawn_waiting([os.path.join(ROOT, "tools", "dist_c5.py"), "--wait-stdin", "--steps", "10", "--full-solve"])
+        c5_child = spawn_mod.spawn_waiting([os.path.join(ROOT, "tools", "dist_c5.py"), "--wait-stdin", "--steps", "10", "--full-solve", "--transport", "callback"])
+        # the same leg once more with the library's own RCCL communicator (pq_kkt_set_comm_rccl): never run on more than one rank so far, hence a
+        # second, separate group of children that can hang or fail without touching the first result
+        c5_native_child = spawn_mod.spawn_waiting([os.path.join(ROOT, "tools", "dist_c5.py"), "--wait-stdin", "--steps", "10", "--transport", "native"], port_offset=61)
 
     import numpy as np
     import torch
@@ -182,6 +185,9 @@ def main():
         for key, ks, refine in ((solver_name[other], other, False), (solver_name[args.kkt_solver] + "+iterative_refinement", args.kkt_solver, True)):
             extra[key] = dense_leg(piqp_amd, pd, torch, np, q, n, p, m, ks, refine, max(5, args.steps // 2), 2, rank, world, local_rank, dev, kernel_pass=3)
 
+    # who is in this run, as the process group itself reports it (every rank contributes its device): lets the reader of an N > 1 line check that
+    # N ranks on N distinct GPUs took part
+    ranks_rows = pd.gather_stats([[float(rank), float(local_rank), float(torch.cuda.device_count())]], device=dev if world > 1 else None)
     if rank == 0:
         L = piqp_amd._lib.load()
         import ctypes as C
@@ -235,6 +241,11 @@ def main():
                        "triangular_sweeps_ms_per_solve": kk["sweeps_ms_per_solve"],
                        "step_tflops": (flops_asm + flops_llt) / (ms_per_step * 1e-3) / 1e12},
             "parity": {"rel_kkt_residual": main_leg["rel_res"], "tolerance": 1e-10},
+            "process_group": {"collective_backend": (torch.distributed.get_backend() if (world > 1 and torch.distributed.is_initialized()) else "none (single process)"),
+                              "ranks_seen": (torch.distributed.get_world_size() if (world > 1 and torch.distributed.is_initialized()) else 1),
+                              "per_rank": [dict(rank=int(r[0]), device=int(r[1]), visible_devices=int(r[2])) for r in ranks_rows],
+                              "data_path_collectives": "none in this leg (independent replicas / shards); barrier + MAX of the elapsed time + final gather only",
+                              "note": "no multi-GPU figure was measured by the build itself (1-GPU boxes only): every N > 1 number is the driver's"},
         }
         for key, leg in extra.items():
             st = max(5, args.steps // 2)
@@ -278,6 +289,17 @@ def main():
             else:
                 leg["error"] = f"child returncode {rc} (None = timed out after 300 s)"; leg["stderr_tail"] = c5_err
             out["stage_partitioned_c5"] = leg
+        pd.barrier()
+        rc, n_out, n_err = pd.release_and_collect(c5_native_child, timeout=180)
+        if rank == 0:
+            line = [ln for ln in (n_out or "").splitlines() if ln.startswith("{")]
+            if rc == 0 and line:
+                nat = json.loads(line[-1])
+                keep = ("ms_per_step", "steps_per_s", "bitwise_equal_all_ranks", "rel_kkt_residual", "collective_backend", "ranks_seen", "ranks_seen_source", "per_rank", "exchange_calls",
+                        "exchange_bytes", "single_gpu_ms_per_step")
+                out["stage_partitioned_c5"]["native_rccl_transport"] = {k: nat[k] for k in keep if k in nat}
+            else:
+                out["stage_partitioned_c5"]["native_rccl_transport"] = {"error": f"child returncode {rc} (None = timed out after 180 s)", "stderr_tail": n_err}
         pd.barrier()
     if rank == 0:
         print(json.dumps(out), flush=True)

@@ -215,6 +215,10 @@ int pq_kkt_set_comm_rccl(pq_kkt *k, const unsigned char id[128], int rank, int w
 int pq_kkt_min_abs_pivot(pq_kkt *k, double *out);
 /* collectives the native transport has enqueued so far: out[which] for which = 0, 1, 2 (test / bench bookkeeping) */
 int pq_kkt_native_exchange_calls(pq_kkt *k, int out[3]);
+/* which transport a partitioned handle uses and what its communicator says about itself: out[0] = 0 none / 1 callback / 2 native RCCL; for the native
+ * transport out[1..3] = ncclCommCount, ncclCommUserRank, ncclCommCuDevice of the library's communicator (-1 otherwise) -- the figures a multi-GPU
+ * bench line carries so that "RCCL saw N ranks" can be checked from the outside */
+int pq_kkt_comm_info(pq_kkt *k, int out[4]);
 /* what the partition looks like: out[0] = supernodes owned by this rank, out[1] = shared supernodes, out[2] = boundary
  * subtree roots, out[3..4] = this rank's column span, out[5] = work share of this rank in permille, out[6] = shared
  * (replicated) work in permille */
@@ -319,6 +323,7 @@ int pq_solver_set_exchange(pq_solver *s, pq_exchange_fn exchange, void *user, do
                            double *buf_gather);
 int pq_solver_set_comm_rccl(pq_solver *s, const unsigned char id[128], int rank, int world);
 int pq_solver_native_exchange_calls(pq_solver *s, int out[3]);
+int pq_solver_comm_info(pq_solver *s, int out[4]); /* as pq_kkt_comm_info */
 
 /* ===================== Batched solver: many structurally identical sparse QPs in one launch ===================== */
 /* The reference has no batch API (one SolverBase per QP, solver.hpp:42); this is the device-side equivalent of

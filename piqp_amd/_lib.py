@@ -83,6 +83,7 @@ SYMBOLS = [
     "pq_batch_create", "pq_batch_destroy", "pq_batch_settings", "pq_batch_setup_sparse", "pq_batch_update", "pq_batch_update_data", "pq_batch_solve", "pq_batch_info", "pq_batch_get_result",
     "pq_batch_dims", "pq_batch_block_info", "pq_batch_get_profile", "pq_batch_last_kernel_ms",
     "pq_debug_alloc_count", "pq_microbench_mfma_f64", "pq_microbench_hbm_copy", "pq_microbench_potrf_block", "pq_rccl_unique_id", "pq_kkt_set_comm_rccl", "pq_solver_set_comm_rccl", "pq_kkt_native_exchange_calls", "pq_kkt_min_abs_pivot", "pq_solver_native_exchange_calls",
+    "pq_sparse_amd_order", "pq_sparse_permute_sym_upper", "pq_sparse_kkt_symbolic", "pq_kkt_sparse_ordering", "pq_kkt_comm_info", "pq_solver_comm_info",
 ]
 
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, vp, C.c_int)  # pq_exchange_fn
@@ -194,6 +195,8 @@ def load():
     L.pq_kkt_native_exchange_calls.argtypes = [vp, _ip]
     L.pq_kkt_min_abs_pivot.argtypes = [vp, _dp]
     L.pq_solver_native_exchange_calls.argtypes = [vp, _ip]
+    L.pq_kkt_comm_info.argtypes = [vp, _ip]
+    L.pq_solver_comm_info.argtypes = [vp, _ip]
     L.pq_sparse_partition_plan.argtypes = [C.POINTER(SparseData), C.c_int, C.c_int, vp, C.c_int, vp]
     L.pq_solver_partition.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_longlong)]
     L.pq_solver_set_exchange.argtypes = [vp, EXCHANGE_FN, vp, vp, vp, vp]

@@ -361,6 +361,11 @@ int pq_kkt_min_abs_pivot(pq_kkt* k, double* out)
     if (!k || !out) return fail(PQ_ERR_INVALID, "null argument");
     return guarded([&] { *out = k->impl->min_abs_pivot(); return (int)PQ_OK; });
 }
+int pq_kkt_comm_info(pq_kkt* k, int out[4])
+{
+    if (!k || !out) return fail(PQ_ERR_INVALID, "null argument");
+    return guarded([&] { k->impl->comm_info(out); return (int)PQ_OK; });
+}
 int pq_kkt_native_exchange_calls(pq_kkt* k, int out[3])
 {
     if (!k || !out) return fail(PQ_ERR_INVALID, "null argument");
@@ -643,6 +648,8 @@ int pq_microbench_mfma_f64(int device, int iters, double* tflops_out)
 int pq_microbench_potrf_block(int device, int ldlt, int reps, double* us_out, long long* stamps64)
 {
     if (!us_out) return fail(PQ_ERR_INVALID, "null output");
+    int rc = check_device(device);
+    if (rc < 0) return rc;
     return guarded([&] { PQ_HIP(hipSetDevice(device)); *us_out = dense::microbench_potrf_block(ldlt != 0, reps, stamps64, nullptr); return (int)PQ_OK; });
 }
 int pq_microbench_hbm_copy(int device, size_t bytes, int iters, double* gbps_out)

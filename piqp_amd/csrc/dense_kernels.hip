@@ -2087,26 +2087,72 @@ void launch_reciprocal(int n, const double* a, double* out, hipStream_t s)
 
 // ------------------------------------------------------------------------------------------------
 // micro-benchmarks used by the measurement harness (peak fp64 MFMA issue rate, HBM copy rate)
+// The peak is the best of several launch shapes (waves per SIMD x independent accumulator chains per wave): a register-resident MFMA stream is
+// sensitive to both, and a "peak" that a product kernel beats is not one (the fixed 8 x 8 shape sustained 46 TFLOP/s where the
+// assembly kernel reaches 53).  Operands differ per lane and per chain so that no two products are the same instruction on the same data.
+template <int ACC>
 __global__ __launch_bounds__(256) void k_mfma_f64_peak(int iters, double* out)
 {
-    d4 acc[8];
+    d4 acc[ACC];
+    double a[ACC], b[ACC];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) acc[q] = (d4){0.0, 0.0, 0.0, 0.0};
-    double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
+    for (int q = 0; q < ACC; ++q) {
+        acc[q] = (d4){0.0, 0.0, 0.0, 0.0};
+        a[q] = 1.0 + (threadIdx.x + 64 * q) * 1e-9;
+        b[q] = 1.0 - (threadIdx.x * 3 + q) * 1e-9;
+    }
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[q], 0, 0, 0);
+        for (int q = 0; q < ACC; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], b[q], acc[q], 0, 0, 0);
     }
     double s = 0.0;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) s += acc[q][0] + acc[q][1] + acc[q][2] + acc[q][3];
+    for (int q = 0; q < ACC; ++q) s += acc[q][0] + acc[q][1] + acc[q][2] + acc[q][3];
     if (s == 12345.678) out[0] = s;
 }
+// U independent 16-byte loads in flight per thread before the stores (grid-stride over blocks of U * gridDim * 256 elements)
+template <int U, bool NT>
 __global__ __launch_bounds__(256) void k_copy_d2(size_t n2, const d2* __restrict__ in, d2* __restrict__ out)
 {
-    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + (U - 1) * stride < n2; i += U * stride) {
+        d2 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (NT) v[u] = __builtin_nontemporal_load(&in[i + u * stride]);
+            else v[u] = in[i + u * stride];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (NT) __builtin_nontemporal_store(v[u], &out[i + u * stride]);
+            else out[i + u * stride] = v[u];
+        }
+    }
     for (; i < n2; i += stride) out[i] = in[i];
+}
+
+static int microbench_cus()
+{
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+    return prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+}
+
+template <int ACC>
+static double mfma_variant(int blocks, int iters, double* out, hipStream_t s, hipEvent_t e0, hipEvent_t e1)
+{
+    hipLaunchKernelGGL(k_mfma_f64_peak<ACC>, dim3(blocks), dim3(256), 0, s, 10, out);
+    PQ_HIP(hipStreamSynchronize(s));
+    PQ_HIP(hipEventRecord(e0, s));
+    hipLaunchKernelGGL(k_mfma_f64_peak<ACC>, dim3(blocks), dim3(256), 0, s, iters, out);
+    PQ_HIP(hipEventRecord(e1, s));
+    PQ_HIP(hipEventSynchronize(e1));
+    float ms = 0;
+    PQ_HIP(hipEventElapsedTime(&ms, e0, e1));
+    const double flops = (double)blocks * 4.0 * (double)iters * ACC * 2.0 * 16 * 16 * 4;
+    return flops / (ms * 1e-3) * 1e-12;
 }
 
 double microbench_mfma_f64(int iters, hipStream_t s)
@@ -2115,19 +2161,22 @@ double microbench_mfma_f64(int iters, hipStream_t s)
     hipEvent_t e0, e1;
     PQ_HIP(hipEventCreate(&e0));
     PQ_HIP(hipEventCreate(&e1));
-    const int blocks = 256 * 8;
-    hipLaunchKernelGGL(k_mfma_f64_peak, dim3(blocks), dim3(256), 0, s, 10, out.p);
-    PQ_HIP(hipStreamSynchronize(s));
-    PQ_HIP(hipEventRecord(e0, s));
-    hipLaunchKernelGGL(k_mfma_f64_peak, dim3(blocks), dim3(256), 0, s, iters, out.p);
-    PQ_HIP(hipEventRecord(e1, s));
-    PQ_HIP(hipEventSynchronize(e1));
-    float ms = 0;
-    PQ_HIP(hipEventElapsedTime(&ms, e0, e1));
+    const int cus = microbench_cus();
+    const bool verbose = debug_token("microbench") != nullptr;
+    double best = 0.0;
+    for (int per_cu : {1, 2, 4, 8}) {
+        const int blocks = cus * per_cu;
+        const int it = std::max(50, iters * 8 / per_cu / 4);
+        const double v[4] = {mfma_variant<2>(blocks, it * 4, out.p, s, e0, e1), mfma_variant<4>(blocks, it * 2, out.p, s, e0, e1),
+                             mfma_variant<8>(blocks, it, out.p, s, e0, e1), mfma_variant<16>(blocks, it / 2, out.p, s, e0, e1)};
+        for (int q = 0; q < 4; ++q) {
+            if (verbose) fprintf(stderr, "[piqp_amd] mfma_f64 microbench: %d waves/SIMD x %2d chains: %.1f TFLOP/s\n", per_cu, 2 << q, v[q]);
+            best = std::max(best, v[q]);
+        }
+    }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
-    const double flops = (double)blocks * 4.0 * (double)iters * 8.0 * 2.0 * 16 * 16 * 4;
-    return flops / (ms * 1e-3) * 1e-12;
+    return best;
 }
 
 __global__ void k_fill_spd_block(double* A, int n)
@@ -2164,6 +2213,21 @@ double microbench_potrf_block(bool ldlt, int reps, long long* stamps64, hipStrea
     return reps > 1 ? total / (reps - 1) * 1e3 : 0.0;
 }
 
+template <int U, bool NT>
+static double copy_variant(int blocks, size_t n2, const d2* a, d2* b, int iters, hipStream_t s, hipEvent_t e0, hipEvent_t e1)
+{
+    hipLaunchKernelGGL((k_copy_d2<U, NT>), dim3(blocks), dim3(256), 0, s, n2, a, b);
+    PQ_HIP(hipStreamSynchronize(s));
+    PQ_HIP(hipEventRecord(e0, s));
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((k_copy_d2<U, NT>), dim3(blocks), dim3(256), 0, s, n2, a, b);
+    PQ_HIP(hipEventRecord(e1, s));
+    PQ_HIP(hipEventSynchronize(e1));
+    float ms = 0;
+    PQ_HIP(hipEventElapsedTime(&ms, e0, e1));
+    return 2.0 * (double)n2 * 16.0 * iters / (ms * 1e-3) * 1e-9;
+}
+
+// best of several shapes (workgroups per CU x loads in flight per thread x plain / non-temporal): read + write bytes per second
 double microbench_hbm_copy(size_t bytes, int iters, hipStream_t s)
 {
     const size_t n2 = bytes / 16;
@@ -2172,17 +2236,23 @@ double microbench_hbm_copy(size_t bytes, int iters, hipStream_t s)
     hipEvent_t e0, e1;
     PQ_HIP(hipEventCreate(&e0));
     PQ_HIP(hipEventCreate(&e1));
-    hipLaunchKernelGGL(k_copy_d2, dim3(256 * 8), dim3(256), 0, s, n2, a.p, b.p);
-    PQ_HIP(hipStreamSynchronize(s));
-    PQ_HIP(hipEventRecord(e0, s));
-    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(k_copy_d2, dim3(256 * 8), dim3(256), 0, s, n2, a.p, b.p);
-    PQ_HIP(hipEventRecord(e1, s));
-    PQ_HIP(hipEventSynchronize(e1));
-    float ms = 0;
-    PQ_HIP(hipEventElapsedTime(&ms, e0, e1));
+    const int cus = microbench_cus();
+    const bool verbose = debug_token("microbench") != nullptr;
+    double best = 0.0;
+    for (int per_cu : {4, 8, 16, 32}) {
+        const int blocks = cus * per_cu;
+        const double v[6] = {copy_variant<1, false>(blocks, n2, a.p, b.p, iters, s, e0, e1), copy_variant<4, false>(blocks, n2, a.p, b.p, iters, s, e0, e1),
+                             copy_variant<8, false>(blocks, n2, a.p, b.p, iters, s, e0, e1), copy_variant<1, true>(blocks, n2, a.p, b.p, iters, s, e0, e1),
+                             copy_variant<4, true>(blocks, n2, a.p, b.p, iters, s, e0, e1), copy_variant<8, true>(blocks, n2, a.p, b.p, iters, s, e0, e1)};
+        static const char* nm[6] = {"1 load", "4 loads", "8 loads", "1 nt load", "4 nt loads", "8 nt loads"};
+        for (int q = 0; q < 6; ++q) {
+            if (verbose) fprintf(stderr, "[piqp_amd] hbm copy microbench: %2d workgroups/CU, %-10s in flight: %.0f GB/s\n", per_cu, nm[q], v[q]);
+            best = std::max(best, v[q]);
+        }
+    }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
-    return 2.0 * (double)n2 * 16.0 * iters / (ms * 1e-3) * 1e-9;
+    return best;
 }
 
 }  // namespace dense

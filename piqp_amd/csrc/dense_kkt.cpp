@@ -19,6 +19,7 @@
 #include <string>
 #include <vector>
 
+#include "trace.hpp"
 #include "dense_kernels.hpp"
 #include "kkt_solver_base.hpp"
 
@@ -66,6 +67,7 @@ public:
     // dense/kkt.hpp:73-84
     bool update_scalings_and_factor(double delta, const double* x_reg, const double* z_reg) override
     {
+        PQ_ZONE("piqp_amd::DenseKKT::update_scalings_and_factor");
         PQ_HIP(hipSetDevice(dev_));
         delta_ = delta;
         dense::launch_reciprocal(m_, z_reg, z_reg_inv_.p, st_);
@@ -82,6 +84,7 @@ public:
     // dense/kkt.hpp:86-105
     void solve(const double* rhs_x, const double* rhs_y, const double* rhs_z, double* lhs_x, double* lhs_y, double* lhs_z) override
     {
+        PQ_ZONE("piqp_amd::DenseKKT::solve");
         PQ_HIP(hipSetDevice(dev_));
         const int tk = prof_.begin(2, st_);
         const double delta_inv = 1.0 / delta_;
@@ -103,6 +106,7 @@ public:
     // dense/kkt.hpp:108-114
     void eval_P_x(double alpha, const double* x, double* z) override
     {
+        PQ_ZONE("piqp_amd::DenseKKT::eval_P_x");
         PQ_HIP(hipSetDevice(dev_));
         dense::launch_gemv_t(n_, n_, Pfull_.p, n_, x, alpha, 0.0, nullptr, nullptr, z, st_);
     }

@@ -14,6 +14,7 @@
 #include <cmath>
 #include <cstdio>
 
+#include "trace.hpp"
 #include "solver.hpp"
 
 namespace pq {
@@ -461,6 +462,7 @@ void DeviceIpm::download_result(HostVars& out)
 // solve_impl (solver.hpp:379-882) with device-resident vectors
 int DeviceIpm::solve(KKTSystem& kkt, const pq_settings& set, const Ruiz& rz, pq_info& info, double* trace, int trace_max, int* trace_rows)
 {
+    PQ_ZONE("piqp_amd::DeviceIpm::solve");  // solver.hpp:379 piqp::Solver::solve_impl
     Impl& s = *I;
     const Dims d = s.dims();
     const Masks M = s.masks();

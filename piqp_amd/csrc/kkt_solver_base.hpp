@@ -60,6 +60,8 @@ public:
     // test hook: smallest |pivot| of the last factorisation (sparse backends), read back through the host
     virtual double min_abs_pivot() { throw std::runtime_error("min_abs_pivot: sparse backends only"); }
     virtual void native_exchange_calls(int out[3]) const { out[0] = out[1] = out[2] = 0; }
+    // pq_kkt_comm_info: transport (0 none, 1 callback, 2 native RCCL), and for the native one what ncclCommCount / ncclCommUserRank / ncclCommCuDevice report
+    virtual void comm_info(int out[4]) const { out[0] = 0; out[1] = out[2] = out[3] = -1; }
     virtual void partition_info(int out[8]) const { (void)out; throw std::runtime_error("partition_info: not supported by this backend"); }
     // measurement hooks (hipEvent brackets on the backend's stream)
     virtual void set_profiling(int level) { (void)level; }

@@ -8,6 +8,7 @@
 // expanded once into a per-row mask / position table so each formula becomes one elementwise kernel
 // with the same operand order as the reference loop bodies.
 #include "kkt_system.hpp"
+#include "trace.hpp"
 
 namespace pq {
 
@@ -477,6 +478,7 @@ double KKTSystem::read_scalar_max(int slot)
 // kkt_system.hpp:143-211
 bool KKTSystem::update_scalings_and_factor(bool iterative_refinement, double rho, double delta, const pq_vars& vars)
 {
+    PQ_ZONE("piqp_amd::KKTSystem::update_scalings_and_factor");
     PQ_HIP(hipSetDevice(dev_));
     const int n = n_, m = m_;
     double* m_z_reg_iter_ref = work_z.p;
@@ -508,6 +510,7 @@ bool KKTSystem::update_scalings_and_factor(bool iterative_refinement, double rho
 double KKTSystem::get_refine_error(const double* lhs_x, const double* lhs_y, const double* lhs_z, const double* rhs_x, const double* rhs_y, const double* rhs_z,
                                    double* err_x, double* err_y, double* err_z)
 {
+    PQ_ZONE("piqp_amd::KKTSystem::get_refine_error");
     const int n = n_, p = p_, m = m_;
     // mul_condensed_kkt: Px -> work_x ; A x -> work_y, AT y -> work_x2 ; G x -> work_z2, GT z -> work_x3
     kkt_solver->eval_P_x(1.0, lhs_x, work_x.p);
@@ -531,6 +534,7 @@ static inline void d2d(double* dst, const double* src, int n, hipStream_t s)
 // kkt_system.hpp:213-369
 bool KKTSystem::solve(const pq_vars& rhs, pq_vars& lhs)
 {
+    PQ_ZONE("piqp_amd::KKTSystem::solve");
     PQ_HIP(hipSetDevice(dev_));
     const int n = n_, p = p_, m = m_;
     double* lhs_z = lhs_z_buf.p;  // the reference aliases work_z; a dedicated buffer avoids the z_reg_iter_ref alias hazard
@@ -557,6 +561,7 @@ bool KKTSystem::solve(const pq_vars& rhs, pq_vars& lhs)
         last_refine_error = refine_error;
         if (!std::isfinite(refine_error)) return false;
 
+        PQ_ZONE("piqp_amd::KKTSystem::solve::iterative_refinement");
         for (int i = 0; i < settings_.iterative_refinement_max_iter; i++) {
             if (refine_error <= settings_.iterative_refinement_eps_abs + settings_.iterative_refinement_eps_rel * rhs_norm) break;
             const double prev_refine_error = refine_error;

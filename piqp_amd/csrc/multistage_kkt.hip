@@ -24,6 +24,7 @@
 #include <stdexcept>
 #include <string>
 
+#include "trace.hpp"
 #include "kkt_solver_base.hpp"
 #include "multistage_device.hpp"
 #include "multistage_symbolic.hpp"
@@ -147,6 +148,7 @@ public:
     // multistage_kkt.hpp:180-219
     bool update_scalings_and_factor(double delta, const double* x_reg, const double* z_reg) override
     {
+        PQ_ZONE("piqp_amd::MultistageKKT::update_scalings_and_factor");
         PQ_HIP(hipSetDevice(dev_));
         delta_ = delta;
         if (tree_) {
@@ -172,6 +174,7 @@ public:
     // multistage_kkt.hpp:221-288
     void solve(const double* rhs_x, const double* rhs_y, const double* rhs_z, double* lhs_x, double* lhs_y, double* lhs_z) override
     {
+        PQ_ZONE("piqp_amd::MultistageKKT::solve");
         PQ_HIP(hipSetDevice(dev_));
         if (tree_) {
             PQ_HIP(hipStreamSynchronize(st_));
@@ -193,6 +196,7 @@ public:
 
     void eval_P_x(double alpha, const double* x, double* z) override
     {
+        PQ_ZONE("piqp_amd::MultistageKKT::eval_P_x");
         PQ_HIP(hipSetDevice(dev_));
         ops_.eval_P_x(alpha, x, z, st_);
     }
@@ -237,6 +241,7 @@ public:
     }
     double min_abs_pivot() override { if (!tree_) throw std::runtime_error("min_abs_pivot: chain engine"); return tree_->min_abs_pivot(); }
     void native_exchange_calls(int out[3]) const override { if (tree_) tree_->native_exchange_calls(out); else out[0] = out[1] = out[2] = 0; }
+    void comm_info(int out[4]) const override { if (tree_) tree_->comm_info(out); else KKTSolverBase::comm_info(out); }
     void partition_info(int out[8]) const override
     {
         if (!tree_) throw std::runtime_error("partition_info: not partitioned");

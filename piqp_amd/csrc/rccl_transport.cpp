@@ -21,6 +21,9 @@ struct Api {
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*CommCuDevice)(const ncclComm_t, int*) = nullptr;
 };
 
 const Api& api()
@@ -41,6 +44,9 @@ const Api& api()
         a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(sym("ncclAllReduce"));
         a.AllGather = reinterpret_cast<decltype(a.AllGather)>(sym("ncclAllGather"));
         a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(sym("ncclGetErrorString"));
+        a.CommCount = reinterpret_cast<decltype(a.CommCount)>(sym("ncclCommCount"));
+        a.CommUserRank = reinterpret_cast<decltype(a.CommUserRank)>(sym("ncclCommUserRank"));
+        a.CommCuDevice = reinterpret_cast<decltype(a.CommCuDevice)>(sym("ncclCommCuDevice"));
     });
     if (!err.empty()) throw std::runtime_error(err);
     return a;
@@ -83,6 +89,13 @@ void comm_destroy(Comm* c)
     if (!c) return;
     if (c->c) { (void)hipSetDevice(c->device); (void)api().CommDestroy(c->c); }
     delete c;
+}
+
+void comm_info(Comm* c, int out[3])
+{
+    check(api().CommCount(c->c, &out[0]), "ncclCommCount");
+    check(api().CommUserRank(c->c, &out[1]), "ncclCommUserRank");
+    check(api().CommCuDevice(c->c, &out[2]), "ncclCommCuDevice");
 }
 
 void all_reduce_sum(Comm* c, double* buf, size_t count, hipStream_t s)

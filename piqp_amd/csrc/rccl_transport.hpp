@@ -19,6 +19,7 @@ struct Comm;  // owns one ncclComm_t
 void unique_id(unsigned char out[UNIQUE_ID_BYTES]);                                     // ncclGetUniqueId (rank 0; ship the bytes to the other ranks)
 Comm* comm_create(const unsigned char id[UNIQUE_ID_BYTES], int rank, int world, int device);  // ncclCommInitRank on `device`
 void comm_destroy(Comm* c);
+void comm_info(Comm* c, int out[3]);  // what the communicator itself reports: ncclCommCount, ncclCommUserRank, ncclCommCuDevice
 void all_reduce_sum(Comm* c, double* buf, size_t count, hipStream_t s);                 // in place, fp64 sum
 void all_gather(Comm* c, double* buf, size_t count_per_rank, int rank, hipStream_t s);  // in place: this rank's chunk at rank * count_per_rank
 

@@ -1,5 +1,6 @@
 // piqp_amd/csrc/solver.cpp -- host front end (reference include/piqp/solver.hpp, dense|sparse/data.hpp,
 // dense|sparse/preconditioner.hpp) driving the device KKTSystem.  See solver.hpp.
+#include "trace.hpp"
 #include "solver.hpp"
 
 #include <algorithm>
@@ -913,6 +914,7 @@ bool verify_settings(const pq_settings& s)
 // solver.hpp:379-882
 int Solver::solve_impl()
 {
+    PQ_ZONE("piqp_amd::Solver::solve_impl");
     pq_info& info = m_info;
     const pq_settings& set = m_settings;
     if (!m_setup_done) { std::fprintf(stderr, "Solver not setup yet\n"); info.status = PQ_UNSOLVED; return info.status; }
@@ -1195,6 +1197,7 @@ void Solver::restore_dual()
 // solver.hpp:69-148
 int Solver::solve()
 {
+    PQ_ZONE("piqp_amd::Solver::solve");
     const double t0 = now_s();
     if (m_setup_done) PQ_HIP(hipSetDevice(device_));
     const int status = solve_impl();
@@ -1302,12 +1305,20 @@ int pq_solver_partition(pq_solver* s, int rank, int world, long long sizes_out[3
 int pq_solver_native_exchange_calls(pq_solver* s, int out[3])
 {
     if (!s || !out) return fail(PQ_ERR_INVALID, "null argument");
+    if (!s->impl->backend()) return fail(PQ_ERR_INVALID, "solver not set up");
     return guarded([&] { s->impl->backend()->native_exchange_calls(out); return (int)PQ_OK; });
 }
 int pq_solver_set_comm_rccl(pq_solver* s, const unsigned char id[128], int rank, int world)
 {
     if (!s || !id) return fail(PQ_ERR_INVALID, "null argument");
+    if (!s->impl->backend()) return fail(PQ_ERR_INVALID, "solver not set up");
     return guarded([&] { s->impl->backend()->set_comm_rccl(id, rank, world); return (int)PQ_OK; });
+}
+int pq_solver_comm_info(pq_solver* s, int out[4])
+{
+    if (!s || !out) return fail(PQ_ERR_INVALID, "null argument");
+    if (!s->impl->backend()) return fail(PQ_ERR_INVALID, "solver not set up");
+    return guarded([&] { s->impl->backend()->comm_info(out); return (int)PQ_OK; });
 }
 int pq_solver_set_exchange(pq_solver* s, pq_exchange_fn exchange, void* user, double* buf_factor, double* buf_forward, double* buf_gather)
 {

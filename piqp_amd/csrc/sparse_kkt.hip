@@ -19,6 +19,7 @@
 #include <stdexcept>
 #include <type_traits>
 
+#include "trace.hpp"
 #include "dense_kernels.hpp"
 #include "kkt_solver_base.hpp"
 #include "sparse_ops.hpp"
@@ -1725,6 +1726,7 @@ public:
     // sparse/kkt.hpp:83-105
     bool update_scalings_and_factor(double delta, const double* x_reg, const double* z_reg) override
     {
+        PQ_ZONE("piqp_amd::SparseKKT::update_scalings_and_factor");
         PQ_HIP(hipSetDevice(dev_));
         delta_ = delta;
         const int t0 = prof_.begin(0, st_);
@@ -1748,6 +1750,7 @@ public:
         PQ_HIP(hipMemsetAsync(info_.p, 0xFF, sizeof(int), st_));
         FrontMeta M = meta();
         if (part_on_) {
+            if (world_ > 1 && transport_ == Transport::None) throw std::runtime_error("partitioned backend used before pq_kkt_set_exchange / pq_kkt_set_comm_rccl");
             factor_subtrees(M, part_sched_);
             factor_levels(M, own_ptr_, own_sn_d_.p, own_lds_, own_big_);
             const int nb = (int)PT_.boundary.size();
@@ -1770,6 +1773,7 @@ public:
     // sparse/kkt.hpp:107-176, KKT_FULL branch
     void solve(const double* rhs_x, const double* rhs_y, const double* rhs_z, double* lhs_x, double* lhs_y, double* lhs_z) override
     {
+        PQ_ZONE("piqp_amd::SparseKKT::solve");
         PQ_HIP(hipSetDevice(dev_));
         const int tk = prof_.begin(2, st_);
         FrontMeta M = meta();
@@ -1785,6 +1789,7 @@ public:
             hipLaunchKernelGGL(k_perm_gather, g1(N_), dim3(256), 0, st_, N_, P_.p, rhs_top_.p, n_, tail, ntail, (const double*)nullptr, xp_.p);
         }
         if (part_on_) {
+            if (world_ > 1 && transport_ == Transport::None) throw std::runtime_error("partitioned backend used before pq_kkt_set_exchange / pq_kkt_set_comm_rccl");
             subtree_fwd(M, part_sched_);
             fwd_levels(M, own_ll_);
             const int nb = (int)PT_.boundary.size();
@@ -1798,7 +1803,7 @@ public:
             bwd_levels(M, sh_ll_);
             bwd_levels(M, own_ll_);
             subtree_bwd(M, part_sched_);
-            if (world_ > 1 || (std::getenv("PIQP_AMD_EXCHANGE_WORLD1") && (xfn_ || comm_))) {
+            if (world_ > 1 || (std::getenv("PIQP_AMD_EXCHANGE_WORLD1") && transport_ != Transport::None)) {
                 const int lo = PT_.span_lo[rank_], hi = PT_.span_hi[rank_];
                 if (hi > lo) hipLaunchKernelGGL(k_pack_span, g1(hi - lo), dim3(256), 0, st_, lo, hi, xp_.p, xbuf_gather_ + (size_t)rank_ * PT_.max_span);
                 exchange(2);
@@ -1823,6 +1828,7 @@ public:
     // sparse/kkt.hpp:179-203
     void eval_P_x(double alpha, const double* x, double* z) override
     {
+        PQ_ZONE("piqp_amd::SparseKKT::eval_P_x");
         PQ_HIP(hipSetDevice(dev_));
         ops_.eval_P_x(alpha, x, z, st_);
     }
@@ -1885,14 +1891,23 @@ public:
         PQ_HIP(hipMemsetAsync(rdiag_.p, 0, sizeof(double) * (size_t)N_, st_));
         PQ_HIP(hipStreamSynchronize(st_));
         part_on_ = true;
-        xfn_ = nullptr; xbuf_factor_ = xbuf_forward_ = xbuf_gather_ = nullptr;
+        drop_transport();  // a new partition invalidates both transports: their buffer sizes and the communicator's world belong to the old one
         sizes[0] = PT_.bmat_off.back() + 1; sizes[1] = std::max(1, PT_.bvec_off.back()); sizes[2] = std::max(1, PT_.max_span);
     }
     void set_exchange(pq_exchange_fn fn, void* user, double* buf_factor, double* buf_forward, double* buf_gather) override
     {
         if (!part_on_) throw std::runtime_error("set_exchange: call pq_kkt_partition first");
         if (world_ > 1 && (!fn || !buf_factor || !buf_forward || !buf_gather)) throw std::runtime_error("set_exchange: null argument");
+        drop_transport();  // the callback transport replaces a native one (its communicator and the library's own buffers go)
         xfn_ = fn; xuser_ = user; xbuf_factor_ = buf_factor; xbuf_forward_ = buf_forward; xbuf_gather_ = buf_gather;
+        transport_ = fn ? Transport::Callback : Transport::None;
+    }
+    void drop_transport()
+    {
+        if (comm_) { PQ_HIP(hipStreamSynchronize(st_)); rccl::comm_destroy(comm_); comm_ = nullptr; }
+        own_factor_.release(); own_forward_.release(); own_gather_.release();
+        xfn_ = nullptr; xuser_ = nullptr; xbuf_factor_ = xbuf_forward_ = xbuf_gather_ = nullptr;
+        transport_ = Transport::None;
     }
     // pq_kkt_set_comm_rccl: from here on the three exchanges are ncclAllReduce / ncclAllGather calls enqueued on st_ behind the kernels that
     // fill the library's own exchange buffers -- no stream drain, no host callback
@@ -1900,12 +1915,13 @@ public:
     {
         if (!part_on_) throw std::runtime_error("set_comm_rccl: call pq_kkt_partition first");
         if (rank != rank_ || world != world_) throw std::runtime_error("set_comm_rccl: rank / world differ from pq_kkt_partition");
-        if (comm_) { rccl::comm_destroy(comm_); comm_ = nullptr; }
+        drop_transport();
         comm_ = rccl::comm_create(id128, rank, world, dev_);
         own_factor_.alloc((size_t)PT_.bmat_off.back() + 1); own_forward_.alloc((size_t)std::max(1, PT_.bvec_off.back())); own_gather_.alloc((size_t)world_ * std::max(1, PT_.max_span));
         own_factor_.zero(st_); own_forward_.zero(st_); own_gather_.zero(st_);
         PQ_HIP(hipStreamSynchronize(st_));
         xfn_ = nullptr; xbuf_factor_ = own_factor_.p; xbuf_forward_ = own_forward_.p; xbuf_gather_ = own_gather_.p;
+        transport_ = Transport::Native;
     }
     double min_abs_pivot() override
     {
@@ -1918,6 +1934,12 @@ public:
         return mx > 0.0 ? 1.0 / mx : 0.0;
     }
     void native_exchange_calls(int out[3]) const override { for (int q = 0; q < 3; ++q) out[q] = native_calls_[q]; }
+    void comm_info(int out[4]) const override
+    {
+        out[0] = transport_ == Transport::Native ? 2 : (transport_ == Transport::Callback ? 1 : 0);
+        out[1] = out[2] = out[3] = -1;
+        if (transport_ == Transport::Native && comm_) rccl::comm_info(comm_, out + 1);
+    }
     void partition_info(int out[8]) const override
     {
         if (!part_on_) throw std::runtime_error("partition_info: not partitioned");
@@ -2087,6 +2109,7 @@ private:
     // numeric phase of the factorisation / substitution on handle-owned buffers only (so that they can be recorded as graphs)
     void factor_numeric(const FrontMeta& M)
     {
+        PQ_ZONE("piqp_amd::SparseKKT::factor_numeric");  // sparse/ldlt.hpp:109 piqp::LDLt::factorize_numeric
         factor_subtrees(M, sched_);
         // wide lower levels: one launch per level; the narrow levels near the root (<= 1024 supernodes in total): one persistent launch
         factor_levels(M, S_.top_level_ptr, level_sn_.p, level_lds_, top_big_, top_l0_);
@@ -2156,8 +2179,8 @@ private:
         // a one-rank group has nothing to exchange; PIQP_AMD_EXCHANGE_WORLD1=1 still goes through the callback (a 1-GPU box can then
         // exercise the caller's RCCL transport end to end)
         static const bool force1 = std::getenv("PIQP_AMD_EXCHANGE_WORLD1") != nullptr;
-        if (world_ == 1 && !(force1 && (xfn_ || comm_))) return;
-        if (comm_) {
+        if (world_ == 1 && !(force1 && transport_ != Transport::None)) return;
+        if (transport_ == Transport::Native) {
             // native transport: stream-ordered behind the pack kernel, the unpack kernel follows on the same stream
             if (which == 0) rccl::all_reduce_sum(comm_, xbuf_factor_, (size_t)PT_.bmat_off.back() + 1, st_);
             else if (which == 1) rccl::all_reduce_sum(comm_, xbuf_forward_, (size_t)std::max(1, PT_.bvec_off.back()), st_);
@@ -2165,7 +2188,7 @@ private:
             ++native_calls_[which];
             return;
         }
-        if (!xfn_) throw std::runtime_error("partitioned backend used before pq_kkt_set_exchange / pq_kkt_set_comm_rccl");
+        if (transport_ != Transport::Callback || !xfn_) throw std::runtime_error("partitioned backend used before pq_kkt_set_exchange / pq_kkt_set_comm_rccl");
         PQ_HIP(hipStreamSynchronize(st_));
         if (xfn_(xuser_, which) != 0) throw std::runtime_error("exchange callback failed");
     }
@@ -2658,6 +2681,8 @@ private:
     std::vector<int> own_ptr_, own_sn_, own_lds_, sh_ptr_, sh_sn_, sh_lds_;
     DBuf<int> own_sn_d_, sh_sn_d_, b_sn_, b_owner_, b_vec_off_, span_lo_d_, span_hi_d_;
     DBuf<long long> b_mat_off_;
+    enum class Transport { None, Callback, Native };  // who performs the three exchanges: nobody yet / the caller's callback / the library's own RCCL calls
+    Transport transport_ = Transport::None;
     pq_exchange_fn xfn_ = nullptr;
     rccl::Comm* comm_ = nullptr;  // native RCCL transport (pq_kkt_set_comm_rccl); the exchange buffers below are then the library's own
     DBuf<double> own_factor_, own_forward_, own_gather_;

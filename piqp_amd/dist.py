@@ -134,7 +134,13 @@ class StagePartition:
         # native = True: the library's own RCCL transport (pq_kkt_set_comm_rccl: collectives enqueued on the handle's stream, no callback).
         # Default: native whenever the process group runs on RCCL ("nccl"), i.e. one GPU per rank; the callback path below remains for gloo
         # (several ranks sharing one GPU in the CPU-rendezvous tests) and as the reference implementation of the protocol.
-        self.native = (self.backend == "nccl" and os.environ.get("PIQP_AMD_CALLBACK_EXCHANGE") is None) if native is None else bool(native)
+        # Round 3: no multi-rank run of the native transport exists yet (no multi-GPU node was available to the build), so it is OPT-IN
+        # (native=True or PIQP_AMD_NATIVE_RCCL=1) and the callback transport -- torch.distributed's own RCCL collectives on the registered device
+        # buffers -- is the default; bench.py --gpus N runs both and compares them bit for bit.
+        self.native = (self.backend == "nccl" and os.environ.get("PIQP_AMD_NATIVE_RCCL") == "1"
+                       and os.environ.get("PIQP_AMD_CALLBACK_EXCHANGE") is None) if native is None else bool(native)
+        if self.native and self.world > 1 and not on:
+            raise RuntimeError("StagePartition(native=True) with world > 1 needs an initialised torch.distributed process group to ship the RCCL unique id")
         self.error = None
         self._cb = _lib.EXCHANGE_FN(self._exchange)  # must outlive the handle's use of it
         self._obj = obj
@@ -144,7 +150,9 @@ class StagePartition:
                 _lib.check(L.pq_rccl_unique_id(idb), "rccl_unique_id")
             box = [bytes(idb)]
             if on and self.world > 1:
-                dist.broadcast_object_list(box, src=0, group=group, device=dev if self.backend == "nccl" else None)
+                # `src` is a GLOBAL rank; the id comes from the group's rank 0
+                src = dist.get_global_rank(group, 0) if group is not None else 0
+                dist.broadcast_object_list(box, src=src, group=group, device=dev if self.backend == "nccl" else None)
             idb = (C.c_ubyte * 128).from_buffer_copy(box[0])
             setc = L.pq_solver_set_comm_rccl if is_solver else L.pq_kkt_set_comm_rccl
             _lib.check(setc(h, idb, self.rank, self.world), "set_comm_rccl")
@@ -200,6 +208,23 @@ class StagePartition:
         _lib.check((L.pq_solver_native_exchange_calls if is_solver else L.pq_kkt_native_exchange_calls)(h, out), "native_exchange_calls")
         return [int(v) for v in out]
 
+    def comm_info(self):
+        """what ran the collectives, as seen from the inside (the figures a multi-GPU bench line carries so that "RCCL saw N ranks" can be checked):
+        transport, the process group's backend and size, and for the native transport the library communicator's own ncclCommCount / rank / device"""
+        import ctypes as C
+
+        from . import _lib
+        L = _lib.load()
+        obj = self._obj
+        is_solver = hasattr(obj, "solve") and hasattr(obj, "setup")
+        h = obj.h if is_solver else (obj.backend().h if hasattr(obj, "backend") else obj.h)
+        out = (C.c_int * 4)()
+        _lib.check((L.pq_solver_comm_info if is_solver else L.pq_kkt_comm_info)(h, out), "comm_info")
+        on = self.dist.is_available() and self.dist.is_initialized()
+        return dict(transport=("none", "callback", "native")[out[0]], process_group_backend=self.backend, process_group_size=(self.dist.get_world_size(self.group) if on else 1),
+                    library_comm_count=int(out[1]), library_comm_rank=int(out[2]), library_comm_device=int(out[3]), device=int(self.dev.index),
+                    exchange_bytes=[8 * int(self.sizes[0]), 8 * int(self.sizes[1]), 8 * int(self.sizes[2]) * int(self.world)])
+
     def info(self):
         import ctypes as C
 
@@ -215,7 +240,7 @@ class StagePartition:
                     shared_work_permille=out[6], world=out[7], exchange_doubles=self.sizes)
 
 
-def spawn_waiting(argv, extra_env=None):
+def spawn_waiting(argv, extra_env=None, port_offset=37):
     """Starts `python argv...` as a child that blocks on its stdin until release_and_collect() -- to be called BEFORE this process
     touches the GPU (a process that has initialised HIP must not fork + exec).  The child inherits RANK / WORLD_SIZE / LOCAL_RANK /
     MASTER_ADDR and gets its own MASTER_PORT, so the children of all ranks form a second, independent process group: a hang or a
@@ -223,7 +248,7 @@ def spawn_waiting(argv, extra_env=None):
     import subprocess
     import sys
     env = dict(os.environ)
-    env["MASTER_PORT"] = str(int(env.get("MASTER_PORT", "29500")) + 37)
+    env["MASTER_PORT"] = str(int(env.get("MASTER_PORT", "29500")) + port_offset)
     for k in ("TORCHELASTIC_RUN_ID", "TORCHELASTIC_USE_AGENT_STORE"):  # the children rendezvous on their own TCPStore (rank 0 hosts it), not on the launcher's
         env.pop(k, None)
     if extra_env:

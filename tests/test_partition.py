@@ -100,7 +100,10 @@ def test_rccl_transport_with_a_one_rank_group(native):
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "TORCHELASTIC_RUN_ID", "TORCHELASTIC_USE_AGENT_STORE", "PIQP_AMD_CALLBACK_EXCHANGE"):
         env.pop(k, None)
     env.update(PIQP_AMD_FORCE_PG="1", PIQP_AMD_EXCHANGE_WORLD1="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29671" if native else "29673")
-    if not native:
+    env.pop("PIQP_AMD_NATIVE_RCCL", None)
+    if native:
+        env["PIQP_AMD_NATIVE_RCCL"] = "1"  # opt-in since round 3 (piqp_amd/dist.py): no multi-rank run of the native transport exists yet
+    else:
         env["PIQP_AMD_CALLBACK_EXCHANGE"] = "1"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dist_c5.py"), "--stages", "600", "--steps", "2", "--warmup", "1", "--full-solve"], capture_output=True, text=True,
                        timeout=600, env=env)

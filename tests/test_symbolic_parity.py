@@ -133,7 +133,7 @@ out = {}
 for name in sys.argv[2:]:
     q = load_qp(name)
     d = piqp_amd.SparseData(q["P"], q["c"], q["A"], q["b"], q["G"], q["h_l"], q["h_u"], q["x_l"], q["x_u"])
-    k = piqp_amd.KKT(d, kkt_solver=piqp_amd.SPARSE_LDLT)
+    k = piqp_amd.SparseKKT(d, kkt_solver=piqp_amd.SPARSE_LDLT)
     N = d.n + d.p + d.m
     fp, ep = np.zeros(N, np.int32), np.zeros(N, np.int32)
     kind = k.L.pq_kkt_sparse_ordering(k.h, fp.ctypes.data_as(C.POINTER(C.c_int)), ep.ctypes.data_as(C.POINTER(C.c_int)))

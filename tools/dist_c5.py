@@ -32,6 +32,8 @@ def main():
     ap.add_argument("--problem", default="chain", choices=["chain", "c3", "cont"],
                     help="c3: BASELINE configs[2], a general sparse QP; cont: the frozen Maros-Meszaros CONT-101 (a PDE grid: big fronts on the batched dense kernels, "
                          "panel fronts, wide-front substitution -- in the owned and in the shared part of the tree)")
+    ap.add_argument("--transport", default="auto", choices=["auto", "callback", "native"],
+                    help="callback: torch.distributed's RCCL collectives on the registered device buffers (default); native: the library's own communicator")
     ap.add_argument("--full-solve", action="store_true")
     ap.add_argument("--no-reference", action="store_true", help="skip the unpartitioned run on every rank (bench mode)")
     ap.add_argument("--wait-stdin", action="store_true", help="block on stdin before touching the GPU (spawned by bench.py, piqp_amd.dist.spawn_waiting)")
@@ -83,7 +85,7 @@ def main():
         del k0
 
     k1 = hip.KKTSystem(d, hip.default_settings(kkt_solver=ks), device=dev_index)
-    sp = pd.StagePartition(k1)
+    sp = pd.StagePartition(k1, native=(args.transport == "native") if args.transport != "auto" else None)
     info = sp.info()
     assert k1.update_scalings_and_factor(False, 1e-6, 1e-4, state)
     _, got = k1.solve(rhs[0])
@@ -105,6 +107,16 @@ def main():
     out["steps_per_s"] = args.steps / el
     out["exchange_calls"] = sp.exchange_calls()
     out["native_rccl"] = bool(sp.native)
+    # self-proving multi-GPU record: who ran the collectives and what they saw, per rank
+    ci = sp.comm_info()
+    out["collective_backend"] = ("rccl (library's own communicator, ncclAllReduce / ncclAllGather on the handle's stream)" if ci["transport"] == "native"
+                                 else f"torch.distributed '{ci['process_group_backend']}' through the exchange callback" if ci["transport"] == "callback" else "none")
+    crow = pd.gather_stats([[float(ci["process_group_size"]), float(ci["library_comm_count"]), float(ci["library_comm_rank"]), float(ci["library_comm_device"]), float(ci["device"]),
+                             float(torch.cuda.device_count())]])
+    out["ranks_seen"] = int(crow[0][1]) if ci["transport"] == "native" else int(crow[0][0])
+    out["ranks_seen_source"] = "ncclCommCount of the library's communicator" if ci["transport"] == "native" else "torch.distributed.get_world_size"
+    out["per_rank"] = [dict(rank=r, device=int(x[4]), visible_devices=int(x[5]), library_comm_rank=int(x[2]), library_comm_device=int(x[3])) for r, x in enumerate(crow)]
+    out["exchange_bytes"] = dict(factor_all_reduce=ci["exchange_bytes"][0], forward_all_reduce=ci["exchange_bytes"][1], solution_all_gather=ci["exchange_bytes"][2])
     rows = pd.gather_stats([[float(info["owned_supernodes"]), float(info["shared_supernodes"]), float(info["boundary_roots"]), float(info["span"][0]), float(info["span"][1]),
                              float(info["work_permille"]), float(info["shared_work_permille"])]])
     out["partition"] = [dict(rank=r, owned_supernodes=int(x[0]), span=[int(x[3]), int(x[4])], work_permille=int(x[5])) for r, x in enumerate(rows)]
@@ -119,7 +131,7 @@ def main():
         s0 = hip.SparseSolver(device=dev_index)
         s0.settings.kkt_solver = ks
         assert s0.setup(*a)
-        sp2 = pd.StagePartition(s0)
+        sp2 = pd.StagePartition(s0, native=(args.transport == "native") if args.transport != "auto" else None)
         t0 = time.perf_counter(); st = s0.solve(); tsol = time.perf_counter() - t0
         if sp2.error is not None:
             raise sp2.error
