@@ -233,8 +233,9 @@ def main():
             "roofline": dominant,            # the kernel that takes the most time per step
             "roofline_secondary": secondary,
             "measured_peaks": {"fp64_mfma_tflops": tf.value, "hbm_copy_gbs": gb.value,
-                               "note": "pq_microbench_mfma_f64 (register-resident v_mfma_f64_16x16x4 stream on every SIMD) and pq_microbench_hbm_copy (1 GiB, read + write) "
-                                       "on this box; roofline.peak stays the vendor sheet figure"},
+                               "note": "informational only, NOT ceilings: pq_microbench_mfma_f64 = best of nine launch shapes of a register-resident v_mfma_f64_16x16x4 stream "
+                                       "(every shape is power-limited at 47-49 TFLOP/s on this pool, below the 53-55 the LDS-fed assembly kernel sustains at 77 % pipe duty), "
+                                       "pq_microbench_hbm_copy = best of 28 shapes of a 1 GiB read + write copy; every fraction in this line is against the vendor sheet peak"},
             "stages": {"assembly_ms": main_leg["asm_ms"], "factorisation_ms": main_leg["fac_ms"],
                        "factorisation_tflops": flops_llt / (main_leg["fac_ms"] * 1e-3) / 1e12 if main_leg["fac_ms"] > 0 else 0.0,
                        "backend_solve_ms": main_leg["sol_ms"], "panel_update_ms": kk["fused_ms_per_step"], "panel_solve_ms": kk["trsm_ms_per_step"],

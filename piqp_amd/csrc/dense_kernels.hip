@@ -2164,12 +2164,12 @@ double microbench_mfma_f64(int iters, hipStream_t s)
     const int cus = microbench_cus();
     const bool verbose = debug_token("microbench") != nullptr;
     double best = 0.0;
-    for (int per_cu : {1, 2, 4, 8}) {
+    for (int per_cu : {2, 4, 8}) {
         const int blocks = cus * per_cu;
         const int it = std::max(50, iters * 8 / per_cu / 4);
-        const double v[4] = {mfma_variant<2>(blocks, it * 4, out.p, s, e0, e1), mfma_variant<4>(blocks, it * 2, out.p, s, e0, e1),
-                             mfma_variant<8>(blocks, it, out.p, s, e0, e1), mfma_variant<16>(blocks, it / 2, out.p, s, e0, e1)};
-        for (int q = 0; q < 4; ++q) {
+        const double v[3] = {mfma_variant<2>(blocks, it * 4, out.p, s, e0, e1), mfma_variant<4>(blocks, it * 2, out.p, s, e0, e1),
+                             mfma_variant<8>(blocks, it, out.p, s, e0, e1)};
+        for (int q = 0; q < 3; ++q) {
             if (verbose) fprintf(stderr, "[piqp_amd] mfma_f64 microbench: %d waves/SIMD x %2d chains: %.1f TFLOP/s\n", per_cu, 2 << q, v[q]);
             best = std::max(best, v[q]);
         }
@@ -2239,13 +2239,12 @@ double microbench_hbm_copy(size_t bytes, int iters, hipStream_t s)
     const int cus = microbench_cus();
     const bool verbose = debug_token("microbench") != nullptr;
     double best = 0.0;
-    for (int per_cu : {4, 8, 16, 32}) {
+    for (int per_cu : {1, 2, 3, 4, 6, 8, 16}) {  // (fewer, longer-running workgroups won on MI355X: 5.5 TB/s at 4 per CU against 4.6 at 16-32)
         const int blocks = cus * per_cu;
-        const double v[6] = {copy_variant<1, false>(blocks, n2, a.p, b.p, iters, s, e0, e1), copy_variant<4, false>(blocks, n2, a.p, b.p, iters, s, e0, e1),
-                             copy_variant<8, false>(blocks, n2, a.p, b.p, iters, s, e0, e1), copy_variant<1, true>(blocks, n2, a.p, b.p, iters, s, e0, e1),
-                             copy_variant<4, true>(blocks, n2, a.p, b.p, iters, s, e0, e1), copy_variant<8, true>(blocks, n2, a.p, b.p, iters, s, e0, e1)};
-        static const char* nm[6] = {"1 load", "4 loads", "8 loads", "1 nt load", "4 nt loads", "8 nt loads"};
-        for (int q = 0; q < 6; ++q) {
+        const double v[4] = {copy_variant<1, false>(blocks, n2, a.p, b.p, iters, s, e0, e1), copy_variant<2, false>(blocks, n2, a.p, b.p, iters, s, e0, e1),
+                             copy_variant<1, true>(blocks, n2, a.p, b.p, iters, s, e0, e1), copy_variant<2, true>(blocks, n2, a.p, b.p, iters, s, e0, e1)};
+        static const char* nm[4] = {"1 load", "2 loads", "1 nt load", "2 nt loads"};
+        for (int q = 0; q < 4; ++q) {
             if (verbose) fprintf(stderr, "[piqp_amd] hbm copy microbench: %2d workgroups/CU, %-10s in flight: %.0f GB/s\n", per_cu, nm[q], v[q]);
             best = std::max(best, v[q]);
         }

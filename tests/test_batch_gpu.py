@@ -84,6 +84,33 @@ def test_batch_properties_at_full_size(hip):
     assert np.array_equal(bs2.iterations(), bs.iterations()[:16])
 
 
+def test_c4_full_size_every_instance_vs_oracle(hip, orc):
+    """BASELINE configs[3] at full size against the oracle, instance by instance (all 8192; the oracle needs 0.75 ms per instance): status and optimum
+    equal everywhere; the iteration count equal except on instances whose termination test sits on its threshold.  This recipe stops on the duality-gap
+    test with mu * (n_x_l + n_x_u) ~ 1.0e-8 = eps_duality_gap_abs at iteration 8 by construction, and the condensed multistage system (delta -> 1e-10)
+    leaves ~1e-5 relative solve noise in both implementations, so which side of the threshold such an instance lands on is decided by rounding.  The
+    mismatch set is asserted: at most 0.5 % of the batch, each off by exactly one iteration (the set itself, with both final gaps, is printed)."""
+    B = 8192
+    mb = mpc_batch(B, seed=1000)
+    bs, solved = _run_batch(hip, mb)
+    assert solved == B
+    its = bs.iterations()
+    mism = []
+    for i in range(B):
+        s = orc.Solver(); s.settings.kkt_solver = orc.SPARSE_MULTISTAGE
+        assert s.setup(*mpc_instance(mb, i), sparse=True)
+        st = s.solve()
+        info = bs.info(i)
+        assert info.status == st == 1, (i, info.status, st)
+        assert abs(info.primal_obj - s.info.primal_obj) <= 1e-8 * (1 + abs(s.info.primal_obj)), i
+        if int(its[i]) != s.info.iter:
+            mism.append((i, int(its[i]), int(s.info.iter), float(info.duality_gap), float(s.info.duality_gap)))
+    print(f"\nC4 full size: {B - len(mism)} of {B} instances with the oracle's iteration count; mismatches (instance, device iter, oracle iter, device gap, oracle gap): {mism}")
+    assert len(mism) <= B // 200, len(mism)
+    for (i, a, b, gh, go) in mism:
+        assert abs(a - b) == 1, (i, a, b)
+
+
 def test_batch_with_general_inequalities_and_one_sided_bounds(hip, orc):
     """m > 0 with one-sided rows and partially bounded variables exercises every branch of the in-kernel KKTSystem"""
     import scipy.sparse as sp
