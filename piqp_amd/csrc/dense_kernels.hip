@@ -1501,7 +1501,7 @@ __device__ __forceinline__ void diag_solve_bwd(const double* __restrict__ Ls, co
 
 constexpr int TB = 128;
 constexpr int TRSV_LDS_BYTES = (TB * (TB + 1) + 3 * TB) * (int)sizeof(double);
-constexpr int TRSV_P_LDS_BYTES = (TB * (TB + 1) + 3 * TB + 8 * 256 + 64 + TB) * (int)sizeof(double);  // + the eight inverted diagonal pieces, scratch of the diagonal step
+constexpr int TRSV_P_LDS_BYTES = (TB * (TB + 1) + 3 * TB + 8 * 256 + 64 + TB + TB) * (int)sizeof(double);  // + the eight inverted diagonal pieces, scratch of the diagonal step, W b
 
 // forward step j: row blocks r >= j subtract L[r, j-1] * x_{j-1}; block r == j then solves L_jj y = b.
 // rdiag = reciprocal diagonal of L (nullptr: unit diagonal).  The diagonal workgroup issues the loads of
@@ -1633,9 +1633,50 @@ __device__ __forceinline__ double ld_agent(const double* p)
 // (the conditioning level of the panel solve, which holds the accuracy gates of tests/dense_replay.py -- unlike a 128 x 128 inverse), one wave;
 // then every thread takes its 8 columns of the group off the rows still to be solved.  Two LDS barriers per group instead of a 128-step
 // dependent chain on one wave (4.2 us per block in round 1).  W16 == nullptr keeps that substitution (reciprocal pivots in rdiag).
+// Round 3: the diagonal step works on the PRE-SCALED diagonal block.  With W_g = M_gg^-1 (the inverted 16 x 16 diagonal pieces the factorisation leaves in
+// W16; M = L_rr, or its transpose in the backward sweep) the substitution  x_g = W_g (b_g - sum_{j<g} M_gj x_j)  is  x_g = (W_g b_g) - sum_{j<g} S_gj x_j
+// with S_gj = W_g M_gj, which k_trsv_scale_blocks forms once per factorisation (28 products of 16 x 16 blocks per 128-row block and direction).  The
+// product with W_g -- a second dependent 16 x 16 mat-vec and two of the three LDS round trips per group of the round-2 step -- leaves the chain: W b
+// is formed for all eight groups at once before the chain starts, and a group costs the chain wave one LDS round trip (x_g out, its four entries per
+// lane back), two independent 4-term products (groups g-1 and g-2) and their quad sums.  Same conditioning as before: only 16 x 16 inverses are formed
+// (the accuracy gate of tests/dense_replay.py rejected the 128 x 128 inverse), and the terms still leave the right-hand side in
+// ascending column order.  S == nullptr keeps the round-2 step.
+template <bool FWD>
+__global__ __launch_bounds__(256) void k_trsv_scale_blocks(const double* __restrict__ L, int ld, int n, const double* __restrict__ W16, double* __restrict__ S)
+{
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double* Ls = sm;                  // M[row][c] at Ls[c * (TB + 1) + row]
+    double* Wd = sm + TB * (TB + 1);  // Wd_g[i][k] at Wd[g * 256 + k * 16 + i]
+    const int tid = threadIdx.x;
+    const int r = (int)blockIdx.x;
+    const int row0 = r * TB, nrows = min(TB, n - row0);
+    stage_lower_block<TB, TB + 1, 256, !FWD>(L + row0 + (size_t)row0 * ld, ld, nrows, Ls, tid);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const double w = W16[(size_t)r * 8 * 256 + u * 256 + tid];  // W_u[i = tid & 15][c = tid >> 4]
+        if (FWD) Wd[u * 256 + tid] = w;                              // Wd[i][k] = W[i][k]
+        else Wd[u * 256 + (tid & 15) * 16 + (tid >> 4)] = w;         // Wd[i][k] = W[k][i]
+    }
+    __syncthreads();
+    double* Sr = S + (size_t)r * TB * TB;  // column-major 128 x 128
+    const int i = tid & 15, c = tid >> 4;
+    for (int g = 0; g < 8; ++g) {
+        for (int gj = 0; gj < 8; ++gj) {
+            double acc = 0.0;
+            const bool before = FWD ? (gj < g) : (gj > g);  // groups solved before g in sweep order
+            if (before) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) acc += Wd[g * 256 + k * 16 + i] * Ls[(16 * gj + c) * (TB + 1) + 16 * g + k];
+            }
+            Sr[(size_t)(16 * gj + c) * TB + 16 * g + i] = acc;  // zero on and beyond the block diagonal: never read, kept clean
+        }
+    }
+}
+
 template <bool FWD>
 __global__ __launch_bounds__(256) void k_trsv_persistent(const double* __restrict__ L, int ld, int n, double* __restrict__ x, const double* __restrict__ rdiag,
-                                                         int nblk, int* __restrict__ flags, int* __restrict__ err, const double* __restrict__ W16, int token, long long* __restrict__ ts)
+                                                         int nblk, int* __restrict__ flags, int* __restrict__ err, const double* __restrict__ W16, int token, long long* __restrict__ ts,
+                                                         const double* __restrict__ S)
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double* Ls = sm;                    // own diagonal block, Ls[c * (TB+1) + r]
@@ -1651,12 +1692,30 @@ __global__ __launch_bounds__(256) void k_trsv_persistent(const double* __restric
     const int ridx = (int)blockIdx.x;   // position of the block in sweep order
     const int r = FWD ? ridx : nblk - 1 - ridx;
     const int row0 = r * TB, nrows = min(TB, n - row0);
+    double* tws = up + 64 + TB;         // W b of the eight groups (pre-scaled step)
     // stage the diagonal block (transposed for the backward sweep) and reciprocal pivots
-    stage_lower_block<TB, TB + 1, 256, !FWD>(L + row0 + (size_t)row0 * ld, ld, nrows, Ls, tid);
+    if (S) {
+        // the pre-scaled block, already in sweep orientation: S[row][c] at Sr[c * TB + row] -> Ls[c * (TB + 1) + row]; 16 loads in flight per thread
+        const double* Sr = S + (size_t)r * TB * TB;
+#pragma unroll 1
+        for (int b0 = 0; b0 < TB * TB / 256; b0 += 16) {
+            double v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = Sr[(size_t)(b0 + u) * 256 + tid];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { const int idx = (b0 + u) * 256 + tid; Ls[(idx >> 7) * (TB + 1) + (idx & 127)] = v[u]; }
+        }
+    } else {
+        stage_lower_block<TB, TB + 1, 256, !FWD>(L + row0 + (size_t)row0 * ld, ld, nrows, Ls, tid);
+    }
     if (tid < TB) rd[tid] = (rdiag && tid < nrows) ? rdiag[row0 + tid] : 1.0;
     if (W16) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) Wg[u * 256 + tid] = W16[(size_t)r * 8 * 256 + u * 256 + tid];
+        for (int u = 0; u < 8; ++u) {
+            const double w = W16[(size_t)r * 8 * 256 + u * 256 + tid];
+            if (S && !FWD) Wg[u * 256 + (tid & 15) * 16 + (tid >> 4)] = w;  // pre-scaled step: Wg[g][k * 16 + i] = Wd_g[i][k] in both directions
+            else Wg[u * 256 + tid] = w;
+        }
     }
     const int row = tid & 127, half = tid >> 7;
     double mine = (half == 0 && row < nrows) ? x[row0 + row] : 0.0;
@@ -1737,6 +1796,142 @@ __global__ __launch_bounds__(256) void k_trsv_persistent(const double* __restric
     if (half == 1) bs[row] = acc;
     __syncthreads();
     if (half == 0) bs[row] = mine - (acc + bs[row]);
+    if (W16 && S) {
+        // ---- pre-scaled diagonal step (see k_trsv_scale_blocks) ----
+        __syncthreads();
+        if (tid < TB) {  // W b, all eight groups at once: row = 16 g + i
+            const int g = tid >> 4, i = tid & 15;
+            double t = 0.0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) t += Wg[g * 256 + k * 16 + i] * bs[16 * g + k];
+            tws[tid] = t;
+        }
+        __syncthreads();
+        lds_vint* cprog = (lds_vint*)&sync_w[0];
+        lds_vint* hp = (lds_vint*)&sync_w[1];
+        lds_vint* np = (lds_vint*)&sync_w[3];
+        double* far = rd;         // reciprocal pivots are not used on this path
+        double* nearv = up + 64;  // [TB]
+        auto quad_sum = [&](double part) {  // ((p0 + p1) + p2) + p3 in every lane of the quad (quad_perm broadcasts)
+            const int plo = __double2loint(part), phi = __double2hiint(part);
+#define PQ_QUAD_BC(K) __hiloint2double(__builtin_amdgcn_update_dpp(0, phi, (K) * 0x55, 0xf, 0xf, false), __builtin_amdgcn_update_dpp(0, plo, (K) * 0x55, 0xf, 0xf, false))
+            const double rs = ((PQ_QUAD_BC(0) + PQ_QUAD_BC(1)) + PQ_QUAD_BC(2)) + PQ_QUAD_BC(3);
+#undef PQ_QUAD_BC
+            return rs;
+        };
+        // position in the block of the group that is gi-th in sweep order
+        auto grp = [](int gi) { return FWD ? gi : 7 - gi; };
+        if (wave == 0) {
+            // the chain: x_g = (W b)_g - far_g - near_g - S_{g,g-2} x_{g-2} - S_{g,g-1} x_{g-1}; lane = (row i, quarter q), a 16-term product is four
+            // terms per lane and a quad sum
+            const int i = lane >> 2, q = lane & 3;
+            double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0}, xq1[4] = {0.0, 0.0, 0.0, 0.0}, xq2[4] = {0.0, 0.0, 0.0, 0.0};
+            double tv = tws[16 * grp(0) + i];
+#pragma unroll
+            for (int gi = 0; gi < 8; ++gi) {
+                const int g = grp(gi);
+                if (gi >= 3) {
+                    // what the other waves took off these rows: near = groups gi-4, gi-3 (two chain steps of slack), far = everything older.  Words and
+                    // values come back from one round of LDS reads; reads execute in order, so values read after a word that says "done" are final.
+                    double fv, nv;
+                    while (true) {
+                        const int n_done = *np, h_done = hp[(16 * g) >> 6];
+                        fv = far[16 * g + i]; nv = nearv[16 * g + i];
+                        if (n_done >= gi && (gi < 5 || h_done >= gi - 4)) break;
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                    if (gi >= 5) tv -= fv;
+                    tv -= nv;
+                }
+                if (gi >= 2) {
+                    double part = 0.0;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) part += s2[t] * xq2[t];
+                    tv -= quad_sum(part);
+                }
+                if (gi >= 1) {
+                    double part = 0.0;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) part += s1[t] * xq1[t];
+                    tv -= quad_sum(part);
+                }
+                if (q == 0) { xs[16 * g + i] = tv; bs[16 * g + i] = tv; }
+                wave_lds_sync();
+                if (lane == 0) *cprog = gi + 1;
+                asm volatile("" ::: "memory");
+                if (ts && lane == 0 && r == 1) ts[4 * nblk + gi] = clock64();  // debugging aid: the groups of block 1
+                if (gi < 7) {
+                    const int gn = grp(gi + 1), gp = gi >= 1 ? grp(gi - 1) : 0;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        xq2[t] = xq1[t];
+                        xq1[t] = xs[16 * g + q + 4 * t];
+                        s1[t] = Ls[(16 * g + q + 4 * t) * (TB + 1) + 16 * gn + i];
+                        s2[t] = gi >= 1 ? Ls[(16 * gp + q + 4 * t) * (TB + 1) + 16 * gn + i] : 0.0;
+                    }
+                    tv = tws[16 * gn + i];
+                }
+            }
+        } else if (wave == 3) {
+            // near: for the group the chain reaches at step G, the products with the groups solved at steps G-4 and G-3
+            const int i = lane >> 2, q = lane & 3;
+#pragma unroll 1
+            for (int G = 3; G < 8; ++G) {
+                const int g = grp(G);
+                double nv = 0.0;
+                if (G >= 4) {
+                    const int g4 = grp(G - 4);
+                    while (*cprog < G - 3) __builtin_amdgcn_s_sleep(1);
+                    double p = 0.0;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) { const int c = 16 * g4 + q + 4 * t; p += Ls[c * (TB + 1) + 16 * g + i] * xs[c]; }
+                    nv = quad_sum(p);
+                }
+                const int g3 = grp(G - 3);
+                double l3[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) l3[t] = Ls[(16 * g3 + q + 4 * t) * (TB + 1) + 16 * g + i];
+                while (*cprog < G - 2) __builtin_amdgcn_s_sleep(1);
+                double p = 0.0;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) p += l3[t] * xs[16 * g3 + q + 4 * t];
+                nv += quad_sum(p);
+                if (q == 0) nearv[16 * g + i] = nv;
+                wave_lds_sync();
+                if (lane == 0) *np = G;
+                asm volatile("" ::: "memory");
+            }
+            if (lane == 0) *np = 8;
+        } else {
+            // far: one row each, every group solved at least five steps before the row's own
+            const int hrow = tid - 64;
+            const int G = FWD ? (hrow >> 4) : 7 - (hrow >> 4);  // the row's own group, in sweep order
+            double f = 0.0;
+#pragma unroll 1
+            for (int gi = 0; gi < 3; ++gi) {
+                const int g = grp(gi);
+                while (*cprog < gi + 1) __builtin_amdgcn_s_sleep(1);
+                if (gi <= G - 5) {
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) f += Ls[(16 * g + c) * (TB + 1) + hrow] * xs[16 * g + c];
+                    far[hrow] = f;
+                }
+                wave_lds_sync();
+                if (lane == 0) hp[wave - 1] = gi + 1;
+                asm volatile("" ::: "memory");
+            }
+        }
+        __syncthreads();
+        if (ts && tid == 0) ts[4 * r + 2] = clock64();  // diagonal block solved
+        if (tid < TB) {
+            if (tid < nrows) st_agent(x + row0 + tid, bs[tid]);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(flags + r, token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (ts && tid == 0) ts[4 * r + 3] = clock64();  // published
+        return;
+    }
     if (W16) {
         // The diagonal step as a dataflow inside the workgroup, no barriers (round 2; two barriers per group of 16 cost 8 500 cycles per block,
         // more than the hand-off between the blocks).  Groups of 16 columns, gi = position in sweep order; every wave has one job:
@@ -1904,7 +2099,25 @@ size_t trsv_flag_ints(int n) { return 2 * (size_t)div_up(n, TB) + 1; }
 // LLT: L y = b, L^T x = y with rdiag = 1/diag(L).  LDLt: unit L, then x *= rdiag (= 1/D), then unit L^T.
 // `flags` = trsv_flag_ints(n) ints of scratch (zeroed by the owner at allocation), `token` != 0 unique per call; nullptr, or more blocks than can be resident at once, falls back to
 // one launch per block step.
-void launch_trsv(const double* L, int ld, int n, double* x, const double* rdiag, bool ldlt, int* flags, int token, const double* w16, hipStream_t s, long long* ts)
+constexpr int TRSV_SCALE_LDS_BYTES = (TB * (TB + 1) + 8 * 256) * (int)sizeof(double);
+size_t trsv_scaled_doubles(int n) { return 2 * (size_t)div_up(n, TB) * TB * TB; }
+// once per factorisation: the pre-scaled diagonal blocks of both sweeps, sblocks = [forward nblk x 128 x 128][backward nblk x 128 x 128]
+void launch_trsv_scale_blocks(const double* L, int ld, int n, const double* w16, double* sblocks, hipStream_t s)
+{
+    if (n <= 0) return;
+    static bool attr_set = false;
+    if (!attr_set) {
+        PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_trsv_scale_blocks<true>), hipFuncAttributeMaxDynamicSharedMemorySize, TRSV_SCALE_LDS_BYTES));
+        PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_trsv_scale_blocks<false>), hipFuncAttributeMaxDynamicSharedMemorySize, TRSV_SCALE_LDS_BYTES));
+        attr_set = true;
+    }
+    const int nblk = div_up(n, TB);
+    hipLaunchKernelGGL(k_trsv_scale_blocks<true>, dim3(nblk), dim3(256), TRSV_SCALE_LDS_BYTES, s, L, ld, n, w16, sblocks);
+    hipLaunchKernelGGL(k_trsv_scale_blocks<false>, dim3(nblk), dim3(256), TRSV_SCALE_LDS_BYTES, s, L, ld, n, w16, sblocks + (size_t)nblk * TB * TB);
+    PQ_HIP(hipGetLastError());
+}
+
+void launch_trsv(const double* L, int ld, int n, double* x, const double* rdiag, bool ldlt, int* flags, int token, const double* w16, hipStream_t s, long long* ts, const double* sblocks)
 {
     if (n <= 0) return;
     static bool attr_set = false;
@@ -1922,9 +2135,11 @@ void launch_trsv(const double* L, int ld, int n, double* x, const double* rdiag,
         // layout: [fwd x flags nblk][bwd x flags nblk][err]; a block is published when its flag holds `token` (unique per call on this flag
         // array, never 0: the array is zeroed once, at allocation -- no memset per solve)
         int* err = flags + 2 * nblk;
-        hipLaunchKernelGGL(k_trsv_persistent<true>, dim3(nblk), dim3(256), TRSV_P_LDS_BYTES, s, L, ld, n, x, rd, nblk, flags, err, w16, token, ts);
+        const double* sf = (w16 && sblocks) ? sblocks : nullptr;
+        const double* sb = sf ? sblocks + (size_t)nblk * TB * TB : nullptr;
+        hipLaunchKernelGGL(k_trsv_persistent<true>, dim3(nblk), dim3(256), TRSV_P_LDS_BYTES, s, L, ld, n, x, rd, nblk, flags, err, w16, token, ts, sf);
         if (ldlt) hipLaunchKernelGGL(k_mul_vec, dim3(div_up(n, 256)), dim3(256), 0, s, n, rdiag, x);
-        hipLaunchKernelGGL(k_trsv_persistent<false>, dim3(nblk), dim3(256), TRSV_P_LDS_BYTES, s, L, ld, n, x, rd, nblk, flags + nblk, err, w16, token, (long long*)nullptr);
+        hipLaunchKernelGGL(k_trsv_persistent<false>, dim3(nblk), dim3(256), TRSV_P_LDS_BYTES, s, L, ld, n, x, rd, nblk, flags + nblk, err, w16, token, (long long*)nullptr, sb);
     } else {
         for (int j = 0; j < nblk; ++j)
             hipLaunchKernelGGL(k_trsv_fwd_step, dim3(nblk - j), dim3(256), TRSV_LDS_BYTES, s, L, ld, n, x, rd, j);

@@ -65,7 +65,11 @@ double microbench_potrf_block(bool ldlt, int reps, long long* stamps64, hipStrea
 void launch_trsm_panel(bool ldlt, double* A, int lda, int k0, int nb, int n, const double* pack, const double* rdiag, hipStream_t s);
 size_t trsv_flag_ints(int n);
 // w16: the inverted 16 x 16 diagonal pieces written by the factorisation (8 x 256 doubles per 128-column panel), nullptr: substitution only
-void launch_trsv(const double* L, int ld, int n, double* x, const double* rdiag, bool ldlt, int* flags, int token, const double* w16, hipStream_t s, long long* ts = nullptr);  // ts: debugging aid, 4 stamps per block of the forward sweep
+// sblocks (nullable): the pre-scaled diagonal blocks of launch_trsv_scale_blocks (trsv_scaled_doubles(n) doubles), refreshed after every factorisation
+void launch_trsv(const double* L, int ld, int n, double* x, const double* rdiag, bool ldlt, int* flags, int token, const double* w16, hipStream_t s, long long* ts = nullptr,
+                 const double* sblocks = nullptr);  // ts: debugging aid, 4 stamps per block of the forward sweep
+size_t trsv_scaled_doubles(int n);
+void launch_trsv_scale_blocks(const double* L, int ld, int n, const double* w16, double* sblocks, hipStream_t s);
 int gemv_n_slices(int rows, int cols);
 int launch_gemv_n_partial(int rows, int cols, const double* M, int ld, const double* v, const double* scale, double alpha, double* part, hipStream_t s);
 void launch_reduce_partials(int rows, int nslices, const double* part, const double* base, double* y, hipStream_t s);

@@ -77,6 +77,7 @@ public:
         prof_.end(0, t0, st_);
         int t1 = prof_.begin(1, st_);
         launch_factor_panels();
+        if (sblocks_.p) dense::launch_trsv_scale_blocks(fac_.p, n_, n_, w16_.p, sblocks_.p, st_);  // part of the factorisation: what the sweeps multiply by
         prof_.end(1, t1, st_);
         return factor_status();
     }
@@ -94,7 +95,7 @@ public:
         if (p_ > 0) nsl += dense::launch_gemv_n_partial(n_, p_, AT_.p, n_, rhs_y, nullptr, delta_inv, part_.p + (size_t)nsl * n_, st_);
         dense::launch_reduce_partials(n_, nsl, part_.p, rhs_x, lhs_x, st_);
         // solve_ldlt_in_place: llt.solveInPlace(lhs_x)
-        { const int tt = prof_.begin(5, st_); dense::launch_trsv(fac_.p, n_, n_, lhs_x, rdiag_.p, ldlt_, flags_.p, next_trsv_token(), w16_.p, st_, trsv_ts_.p);
+        { const int tt = prof_.begin(5, st_); dense::launch_trsv(fac_.p, n_, n_, lhs_x, rdiag_.p, ldlt_, flags_.p, next_trsv_token(), w16_.p, st_, trsv_ts_.p, sblocks_.p);
           if (trsv_ts_.p) dump_trsv_ts(); prof_.end(5, tt, st_); }
         // lhs_y = delta_inv * AT^T lhs_x - delta_inv * rhs_y
         if (p_ > 0) dense::launch_gemv_t(n_, p_, AT_.p, n_, lhs_x, delta_inv, -delta_inv, rhs_y, nullptr, lhs_y, st_);
@@ -172,7 +173,7 @@ private:
         alloc();
         auto cp = [&](DBuf<double>& dst, const DBuf<double>& src) { if (src.n) PQ_HIP(hipMemcpyAsync(dst.p, src.p, src.bytes(), hipMemcpyDeviceToDevice, st_)); };
         cp(Pfull_, o.Pfull_); cp(Pdiag_, o.Pdiag_); cp(AT_, o.AT_); cp(GT_, o.GT_); cp(ATA_, o.ATA_); cp(fac_, o.fac_);
-        cp(z_reg_inv_, o.z_reg_inv_); cp(x_reg_last_, o.x_reg_last_); cp(rdiag_, o.rdiag_); cp(w16_, o.w16_);
+        cp(z_reg_inv_, o.z_reg_inv_); cp(x_reg_last_, o.x_reg_last_); cp(rdiag_, o.rdiag_); cp(w16_, o.w16_); cp(sblocks_, o.sblocks_);
         PQ_HIP(hipStreamSynchronize(st_));
     }
 
@@ -190,6 +191,7 @@ private:
         pack_.alloc(dense::FACTOR_PACK_DOUBLES);
         fuse_scratch_.alloc(dense::FACTOR_PACK_DOUBLES); fuse_flags_.alloc(16); fuse_flags_.zero(st_); fuse_cnt_.alloc(8); fuse_cnt_.zero(st_);
         w16_.alloc((size_t)((n_ + 127) / 128) * 8 * 256);  // inverted 16 x 16 diagonal pieces of the whole factor (potrf_block -> launch_trsv)
+        if (!debug_token("trsv_unscaled")) { sblocks_.alloc(dense::trsv_scaled_doubles(n_)); sblocks_.zero(st_); }  // pre-scaled diagonal blocks of the sweeps (PIQP_AMD_DEBUG=trsv_unscaled: the round-2 diagonal step)
         dense::syrk_prepare(n_);
         info_.alloc(1);
         info_h_.alloc(1);
@@ -292,7 +294,7 @@ private:
     bool ldlt_;
     double delta_ = 1.0;
     hipStream_t st_ = nullptr;
-    DBuf<double> Pfull_, Pdiag_, AT_, GT_, ATA_, fac_, z_reg_inv_, x_reg_last_, dvec_, part_, rdiag_, split_ws_, pack_, w16_, fuse_scratch_;
+    DBuf<double> Pfull_, Pdiag_, AT_, GT_, ATA_, fac_, z_reg_inv_, x_reg_last_, dvec_, part_, rdiag_, split_ws_, pack_, w16_, fuse_scratch_, sblocks_;
     DBuf<int> info_, flags_, fuse_flags_, fuse_cnt_;
     int fuse_token_ = 0, trsv_token_ = 0;
     int next_trsv_token()
