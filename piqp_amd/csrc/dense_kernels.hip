@@ -22,6 +22,7 @@
 #include <utility>
 #include <vector>
 #include <cstdlib>
+#include <cstdio>
 
 namespace pq {
 namespace dense {
@@ -78,11 +79,28 @@ __global__ __launch_bounds__(256) void k_symmetrize_upper(const double* __restri
 // 16-lane groups of a ds_read_b64 fall on disjoint banks.  The MFMA is issued with the COLUMN
 // operand as A and the ROW operand as B so that each lane's four results are consecutive ROWS of C:
 // stores (and the Pfull / ATA epilogue loads) are 128 B contiguous per 16 lanes.
+#ifndef PQ_FUSE_TS
+#define PQ_FUSE_TS 0
+#endif
+// Operand panels of a persistent launch.  Reading them IN PLACE with plain loads is not safe: the same addresses held a trailing tile earlier in the launch,
+// and although that tile was only ever touched with agent-scope loads and write-through stores, stale copies do survive somewhere (measured: the factor of
+// n = 4096 differed from the launch-per-panel path in one run of three).  Reading them in place with 8-byte agent-scope loads is safe and slow (every tile
+// fetches its 256 KB of operands from memory: 30 us per tile against 23).  So a solved panel is written twice: in place (the factor), and into a SIDE
+// buffer whose addresses nobody has read before in this launch -- no stale copy can exist anywhere -- from which the trailing updates read it with plain
+// 16-byte loads, L1 / L2 cached like in the launch-per-panel kernels.  (Panel 0 is solved before the launch and read in place.)
+constexpr bool AGENT_OPERANDS = false;
+constexpr bool FUSE_TS_ON = PQ_FUSE_TS != 0;  // in-kernel clock stamps of the fused launch (PIQP_AMD_DEBUG=fused_ts=<panel>): only in builds with -DPQ_FUSE_TS=1
 constexpr int TS = 128;
 constexpr int BK = 16;
 constexpr int LDS_LD = TS + 16;
 constexpr int SYRK_LDS_BYTES = 2 * 2 * BK * LDS_LD * (int)sizeof(double);
 
+__device__ __forceinline__ double ld_agent(const double* p);    // agent-scope relaxed load / store (sc1: L1-bypassing, written through), defined with the sweeps
+__device__ __forceinline__ void st_agent(double* p, double v);
+typedef __attribute__((address_space(1))) int gint;
+__device__ __forceinline__ int ldi_agent(const int* p) { return __hip_atomic_load((const gint*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void sti_agent(int* p, int v) { __hip_atomic_store((gint*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int addi_agent(int* p, int v) { return __hip_atomic_fetch_add((gint*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // NT threads cooperate on a 128 x 16 operand stage (1024 double2): ITERS = 1024 / NT loads per thread
 template <bool CHECK, int NT>
 __device__ __forceinline__ void load_tile(const double* __restrict__ M, int ld, int r0, int k0, int nrows, int kdim, int tid, d2 (&v)[1024 / NT])
@@ -104,6 +122,20 @@ __device__ __forceinline__ void load_tile(const double* __restrict__ M, int ld, 
     }
 }
 
+// the same 128 x 16 stage read with agent-scope (sc1, L1-bypassing) loads: data another workgroup of the SAME launch wrote through (no edge handling)
+template <int NT>
+__device__ __forceinline__ void load_tile_agent(const double* __restrict__ M, int ld, int r0, int k0, int tid, d2 (&v)[1024 / NT])
+{
+    const int r = r0 + 2 * (tid & 63);
+#pragma unroll
+    for (int it = 0; it < 1024 / NT; ++it) {
+        const int k = k0 + it * (NT / 64) + (tid >> 6);
+        const double* p = M + r + (size_t)k * ld;
+        v[it].x = ld_agent(p);
+        v[it].y = ld_agent(p + 1);
+    }
+}
+
 template <int NT>
 __device__ __forceinline__ void store_tile(double* __restrict__ S, int tid, const d2 (&v)[1024 / NT])
 {
@@ -115,14 +147,14 @@ __device__ __forceinline__ void store_tile(double* __restrict__ S, int tid, cons
 }
 
 // NEG: the operand is staged negated, so that an accumulator initialised with C ends as C - A diag(w) B^T
-template <bool CHECK, int NT, bool NEG = false>
+template <bool CHECK, int NT, bool NEG = false, bool AGENT = false>
 __device__ __forceinline__ void scale_tile(const double* __restrict__ w, int k0, int kdim, int tid, d2 (&v)[1024 / NT])
 {
     if (!w && !NEG) return;
 #pragma unroll
     for (int it = 0; it < 1024 / NT; ++it) {
         const int k = k0 + it * (NT / 64) + (tid >> 6);
-        double s = w ? ((!CHECK || k < kdim) ? w[k] : 0.0) : 1.0;
+        double s = w ? ((!CHECK || k < kdim) ? (AGENT ? ld_agent(w + k) : w[k]) : 0.0) : 1.0;
         if (NEG) s = -s;
         v[it].x *= s;
         v[it].y *= s;
@@ -133,74 +165,42 @@ __device__ __forceinline__ void scale_tile(const double* __restrict__ w, int k0,
 template <bool LDLT, int NWAVES>
 __device__ __forceinline__ void potrf_block(double* __restrict__ Tb, double* __restrict__ rds, int nb, int kglobal, int* __restrict__ info, double* __restrict__ rdiag,
                                             double* __restrict__ dvec, double* __restrict__ Aout, int lda, double* __restrict__ pack, double* __restrict__ w16,
-                                            long long* __restrict__ ts = nullptr, int* __restrict__ cnt = nullptr, int nactive = 8);
+                                            long long* __restrict__ ts = nullptr, int* __restrict__ cnt = nullptr, int nactive = 8,
+                                            const double* __restrict__ fetch_scratch = nullptr, const int* __restrict__ fetch_flags = nullptr, int fetch_token = 0,
+                                            const int* __restrict__ fetch_abort = nullptr);
 __device__ __forceinline__ int tb_index(int bi, int bj);
-__device__ __forceinline__ void st_agent(double* p, double v);
-__device__ __forceinline__ double ld_agent(const double* p);
 __device__ __forceinline__ void tile_store(double* __restrict__ blk, int lane, d4 t);
 constexpr int FUSE_ROLES = 9, FUSE_OWN = 4;  // workgroups that share the next diagonal block of a fused trailing update (owner + 8 helpers), blocks per workgroup
-template <int NT>
-__device__ __forceinline__ void fused_next_diag(const SyrkArgs& a, double* __restrict__ smem, int role);
-template <int NT, int MTC, int MTR>
-__device__ __forceinline__ void panel_follow(const SyrkArgs& a, double* __restrict__ smem, const d4 (&acc)[MTC][MTR], int row0, int wr, int wc);
+template <int NT, bool PERSIST>
+__device__ __forceinline__ bool fused_next_diag(const SyrkArgs& a, double* __restrict__ smem, int role);
+template <int NT, int MTC, int MTR, bool PERSIST>
+__device__ __forceinline__ bool panel_follow(const SyrkArgs& a, double* __restrict__ smem, const d4 (&acc)[MTC][MTR], int row0, int wr, int wc);
 // the fused next-panel factorisation: its workgroups stage a whole 128 x 128 operand panel (147 KB: one workgroup per CU, which the kernel's
 // 147 VGPRs impose anyway); the 36 tile blocks + 64 doubles of pivots reuse that LDS afterwards
 constexpr int FUSED_LDS_BYTES = (128 * (128 + 16) + 128) * 8;  // whole operand panel of the next diagonal block + D; the tile blocks reuse it
 
-// WR x WC = waves per tile (rows x columns):
-//   2 x 2 -> 256 threads, 64 x 64 per wave (throughput shape, 2 workgroups per CU);
-//   4 x 4 -> 1024 threads, 32 x 32 per wave (low-latency shape for short K: a quarter of the MFMA chain per wave, used for the unfused
-//            trailing updates);
-//   4 x 2 -> 512 threads, 32 x 64 per wave: the fused trailing update + next diagonal block, whose in-register block factorisation needs
-//            more than the 128 VGPRs a 1024-thread workgroup can have.
-template <int EPI, int WR, int WC>
-__device__ __forceinline__ void syrk_lower_body(const SyrkArgs& a, const int block_x)
+// One tile of a fused trailing update (K <= 128: one panel): accumulators start from C, the column operand is staged negated (pure-store epilogue),
+// ALL operand stages are requested at once into registers (with one 147 KB-LDS workgroup per CU nothing else hides a stage's load latency: the
+// one-stage-ahead loop spent 2.9 us per 16-column stage, 23 us per tile, for 4 us of matrix-core work), then stream through two LDS buffers.
+// Tiles of the first column (tj == 0) are the NEXT panel: their workgroup keeps the updated rows and solves them behind the factorisation of the
+// diagonal block (panel_follow).
+// PERSIST (k_chol_persistent: every round of the factorisation in ONE launch, no kernel boundary between producer and consumer): operands and C were
+// written by other workgroups of the same launch, so they are read with agent-scope loads and written through (sc1) -- MI355X_MICROARCH.md,
+// inter-workgroup visibility -- and the caller publishes a flag afterwards.  n is a multiple of 128 there (no edge tiles).  Returns false when a
+// bounded wait inside gave up.
+template <int NT, bool PERSIST>
+__device__ __forceinline__ bool fused_tile(const SyrkArgs& a, const int ti, const int tj, double* __restrict__ smem)
 {
-    constexpr int NT = 64 * WR * WC;
-    constexpr int MTR = 8 / WR, MTC = 8 / WC;     // MFMA tiles per wave: rows, columns
-    constexpr int SUBR = TS / WR, SUBC = TS / WC;  // rows / columns of C per wave
-    extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr int WR = 4, WC = 2;
+    static_assert(NT == 64 * WR * WC, "4 x 2 waves");
+    constexpr int MTR = 8 / WR, MTC = 8 / WC;
+    constexpr int SUBR = TS / WR, SUBC = TS / WC;
     double* As = smem;                    // [2][BK][LDS_LD]
     double* Bs = smem + 2 * BK * LDS_LD;  // [2][BK][LDS_LD]
-
-    // linear block id -> lower-triangular tile (ti >= tj); split launches map several K-slices onto one tile
-    int bid = block_x;
-    if constexpr (EPI == EPI_SUBTRACT_POTRF) {
-        // tile (0, 0) of the trailing matrix = the next diagonal block: updated AND factored by the first FUSE_ROLES workgroups together (owner +
-        // helpers); the other tiles follow
-        if (bid < FUSE_ROLES) { fused_next_diag<NT>(a, smem, bid); return; }
-        bid -= FUSE_ROLES - 1;
-    }
-    const int b = a.tile_begin + bid / a.k_split;
-    const int kslice = bid % a.k_split;
-    int ti, tj;
-    if (EPI == EPI_SUBTRACT_POTRF) {
-        // the first tile column (= the next panel below its diagonal block) goes first: its workgroups also solve that panel (panel_follow)
-        const int T = (a.n + TS - 1) / TS;
-        if (b <= T - 1) { ti = b; tj = 0; }
-        else {
-            const int bb = b - T;  // lower triangle of the (T - 1) x (T - 1) rest
-            int t2 = (int)((sqrt(8.0 * (double)bb + 1.0) - 1.0) * 0.5);
-            while ((t2 + 1) * (t2 + 2) / 2 <= bb) ++t2;
-            while (t2 * (t2 + 1) / 2 > bb) --t2;
-            ti = t2 + 1; tj = bb - t2 * (t2 + 1) / 2 + 1;
-        }
-    } else if (a.tile_order) {
-        const int pk = a.tile_order[b];
-        ti = pk >> 16; tj = pk & 0xffff;
-    } else {
-        ti = (int)((sqrt(8.0 * (double)b + 1.0) - 1.0) * 0.5);
-        while ((ti + 1) * (ti + 2) / 2 <= b) ++ti;
-        while (ti * (ti + 1) / 2 > b) --ti;
-        tj = b - ti * (ti + 1) / 2;
-    }
-    if (a.first_col_only) { ti = b; tj = 0; }
     const int row0 = ti * TS, col0 = tj * TS;
-
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave / WC, wc = wave % WC;
-    constexpr bool NEGB = (EPI == EPI_SUBTRACT_POTRF);  // accumulators start from C, the column operand is staged negated: pure-store epilogue
-    const bool edge = (row0 + TS > a.n) || (col0 + TS > a.n) || a.unaligned;
+    const bool edge = !PERSIST && ((row0 + TS > a.n) || (col0 + TS > a.n) || a.unaligned);
     const bool skip_wave = (ti == tj) && ((wr + 1) * SUBR <= wc * SUBC);  // sub-tile strictly above the diagonal
 
     d4 acc[MTC][MTR];
@@ -208,7 +208,7 @@ __device__ __forceinline__ void syrk_lower_body(const SyrkArgs& a, const int blo
     for (int x = 0; x < MTC; ++x)
 #pragma unroll
         for (int y = 0; y < MTR; ++y) acc[x][y] = (d4){0.0, 0.0, 0.0, 0.0};
-    if (NEGB && !skip_wave) {
+    if (!skip_wave) {
         // C is fetched BEFORE the K loop (its latency hides behind the first operand stages) instead of read-modify-written after it
 #pragma unroll
         for (int x = 0; x < MTC; ++x)
@@ -219,35 +219,32 @@ __device__ __forceinline__ void syrk_lower_body(const SyrkArgs& a, const int blo
                 for (int r = 0; r < 4; ++r) {
                     const int gj = col0 + wc * SUBC + x * 16 + (lane >> 4) + 4 * r;
                     const bool ok = gi < a.n && gj < a.n && gi >= gj;
-                    const double cv = a.C[ok ? (size_t)gi + (size_t)gj * a.ldc : 0];
+                    const double* cp = a.C + (ok ? (size_t)gi + (size_t)gj * a.ldc : 0);
+                    const double cv = PERSIST ? ld_agent(cp) : *cp;
                     acc[x][y][r] = ok ? cv : 0.0;
                 }
             }
     }
-
-    const bool dbg_tile = (EPI == EPI_SUBTRACT_POTRF) && a.fuse_ts && threadIdx.x == 0 && ti == 2 && tj == 1;  // debugging aid: an ordinary tile's timeline
+    const bool dbg_tile = FUSE_TS_ON && !PERSIST && a.fuse_ts && threadIdx.x == 0 && ti == 2 && tj == 1;  // debugging aid: an ordinary tile's timeline
     if (dbg_tile) a.fuse_ts[84] = clock64();
-    const int nkt_all = (a.kdim + BK - 1) / BK;
-    const int kt_per = (nkt_all + a.k_split - 1) / a.k_split;
-    const int kt_begin = kslice * kt_per;
-    const int nkt = max(0, min(nkt_all, kt_begin + kt_per) - kt_begin);
-    if constexpr (EPI == EPI_SUBTRACT_POTRF) {
-        // K <= 128 here: eight operand stages at most.  ALL of them are requested at once, into registers (2 x 8 x 2 double2 per thread), before
-        // anything else waits: with one 147 KB-LDS workgroup per CU nothing else hides a stage's load latency, and the generic loop below --
-        // stage t + 1 requested while stage t is multiplied -- spent 2.9 us per 16-column stage, 23 us per tile, for 4 us of matrix-core work
-        // (in-kernel stamps of an ordinary tile).  The stages then arrive back to back; only the first one's latency is exposed.
+    const int nkt = (a.kdim + BK - 1) / BK;  // <= 8
+    {
         constexpr int PER = 1024 / NT;
         d2 pa[8][PER], pb[8][PER];
 #pragma unroll
         for (int kt = 0; kt < 8; ++kt) {
             if (kt < nkt) {
                 const int k0 = kt * BK;
-                if (edge || (k0 + BK > a.kdim)) { load_tile<true, NT>(a.A, a.lda, row0, k0, a.n, a.kdim, tid, pa[kt]); load_tile<true, NT>(a.B, a.ldb, col0, k0, a.n, a.kdim, tid, pb[kt]); }
-                else { load_tile<false, NT>(a.A, a.lda, row0, k0, a.n, a.kdim, tid, pa[kt]); load_tile<false, NT>(a.B, a.ldb, col0, k0, a.n, a.kdim, tid, pb[kt]); }
+                if constexpr (PERSIST && AGENT_OPERANDS) {
+                    load_tile_agent<NT>(a.A, a.lda, row0, k0, tid, pa[kt]); load_tile_agent<NT>(a.B, a.ldb, col0, k0, tid, pb[kt]);
+                } else {
+                    if (edge || (k0 + BK > a.kdim)) { load_tile<true, NT>(a.A, a.lda, row0, k0, a.n, a.kdim, tid, pa[kt]); load_tile<true, NT>(a.B, a.ldb, col0, k0, a.n, a.kdim, tid, pb[kt]); }
+                    else { load_tile<false, NT>(a.A, a.lda, row0, k0, a.n, a.kdim, tid, pa[kt]); load_tile<false, NT>(a.B, a.ldb, col0, k0, a.n, a.kdim, tid, pb[kt]); }
+                }
             }
         }
         if (nkt > 0) {
-            scale_tile<true, NT, true>(a.w, 0, a.kdim, tid, pb[0]);
+            scale_tile<true, NT, true, PERSIST>(a.w, 0, a.kdim, tid, pb[0]);
             store_tile<NT>(As, tid, pa[0]);
             store_tile<NT>(Bs, tid, pb[0]);
         }
@@ -258,7 +255,7 @@ __device__ __forceinline__ void syrk_lower_body(const SyrkArgs& a, const int blo
             if (kt < nkt) {
                 const int cur = kt & 1;
                 if (kt + 1 < 8 && kt + 1 < nkt) {  // the other LDS buffer was last read before the previous barrier
-                    scale_tile<true, NT, true>(a.w, (kt + 1) * BK, a.kdim, tid, pb[(kt + 1) & 7]);
+                    scale_tile<true, NT, true, PERSIST>(a.w, (kt + 1) * BK, a.kdim, tid, pb[(kt + 1) & 7]);
                     store_tile<NT>(As + (cur ^ 1) * BK * LDS_LD, tid, pa[(kt + 1) & 7]);
                     store_tile<NT>(Bs + (cur ^ 1) * BK * LDS_LD, tid, pb[(kt + 1) & 7]);
                 }
@@ -284,25 +281,116 @@ __device__ __forceinline__ void syrk_lower_body(const SyrkArgs& a, const int blo
             }
         }
     }
+    if (dbg_tile) a.fuse_ts[86] = clock64();  // K loop done (the accumulators' first use waited for C)
+    if (a.fuse_cnt && tj == 0 && a.fuse_pack) return panel_follow<NT, MTC, MTR, PERSIST>(a, smem, acc, row0, wr, wc);
+    if (skip_wave) return true;
+    // epilogue: lane holds rows gi (consecutive over lane&15) and columns gj = base + (lane>>4) + 4*r; the accumulator started from C
+#pragma unroll
+    for (int x = 0; x < MTC; ++x) {
+#pragma unroll
+        for (int y = 0; y < MTR; ++y) {
+            const int gi = row0 + wr * SUBR + y * 16 + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gj = col0 + wc * SUBC + x * 16 + (lane >> 4) + 4 * r;
+                if (gi < a.n && gj < a.n && gi >= gj) {
+                    double* cp = a.C + (size_t)gi + (size_t)gj * a.ldc;
+                    if (PERSIST) st_agent(cp, acc[x][y][r]);
+                    else *cp = acc[x][y][r];
+                }
+            }
+        }
+    }
+    if (dbg_tile) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); a.fuse_ts[87] = clock64(); }  // stores drained
+    return true;
+}
+
+// WR x WC = waves per tile (rows x columns):
+//   2 x 2 -> 256 threads, 64 x 64 per wave (throughput shape, 2 workgroups per CU);
+//   4 x 4 -> 1024 threads, 32 x 32 per wave (low-latency shape for short K: a quarter of the MFMA chain per wave, used for the unfused
+//            trailing updates);
+//   4 x 2 -> 512 threads, 32 x 64 per wave: the fused trailing update + next diagonal block (fused_tile / fused_next_diag), whose in-register
+//            block factorisation needs more than the 128 VGPRs a 1024-thread workgroup can have.
+template <int EPI, int WR, int WC>
+__device__ __forceinline__ void syrk_lower_body(const SyrkArgs& a, const int block_x)
+{
+    constexpr int NT = 64 * WR * WC;
+    constexpr int MTR = 8 / WR, MTC = 8 / WC;     // MFMA tiles per wave: rows, columns
+    constexpr int SUBR = TS / WR, SUBC = TS / WC;  // rows / columns of C per wave
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* As = smem;                    // [2][BK][LDS_LD]
+    double* Bs = smem + 2 * BK * LDS_LD;  // [2][BK][LDS_LD]
+
+    // linear block id -> lower-triangular tile (ti >= tj); split launches map several K-slices onto one tile
+    int bid = block_x;
+    if constexpr (EPI == EPI_SUBTRACT_POTRF) {
+        // tile (0, 0) of the trailing matrix = the next diagonal block: updated AND factored by the first FUSE_ROLES workgroups together (owner +
+        // helpers); the other tiles follow, the first tile column (= the next panel below its diagonal block) first: its workgroups also solve
+        // that panel (panel_follow)
+        if (bid < FUSE_ROLES) { fused_next_diag<NT, false>(a, smem, bid); return; }
+        bid -= FUSE_ROLES - 1;
+        const int T = (a.n + TS - 1) / TS;
+        int ti, tj;
+        if (bid <= T - 1) { ti = bid; tj = 0; }
+        else {
+            const int bb = bid - T;  // lower triangle of the (T - 1) x (T - 1) rest
+            int t2 = (int)((sqrt(8.0 * (double)bb + 1.0) - 1.0) * 0.5);
+            while ((t2 + 1) * (t2 + 2) / 2 <= bb) ++t2;
+            while (t2 * (t2 + 1) / 2 > bb) --t2;
+            ti = t2 + 1; tj = bb - t2 * (t2 + 1) / 2 + 1;
+        }
+        (void)fused_tile<NT, false>(a, ti, tj, smem);
+        return;
+    } else {
+    const int b = a.tile_begin + bid / a.k_split;
+    const int kslice = bid % a.k_split;
+    int ti, tj;
+    if (a.tile_order) {
+        const int pk = a.tile_order[b];
+        ti = pk >> 16; tj = pk & 0xffff;
+    } else {
+        ti = (int)((sqrt(8.0 * (double)b + 1.0) - 1.0) * 0.5);
+        while ((ti + 1) * (ti + 2) / 2 <= b) ++ti;
+        while (ti * (ti + 1) / 2 > b) --ti;
+        tj = b - ti * (ti + 1) / 2;
+    }
+    if (a.first_col_only) { ti = b; tj = 0; }
+    const int row0 = ti * TS, col0 = tj * TS;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave / WC, wc = wave % WC;
+    const bool edge = (row0 + TS > a.n) || (col0 + TS > a.n) || a.unaligned;
+    const bool skip_wave = (ti == tj) && ((wr + 1) * SUBR <= wc * SUBC);  // sub-tile strictly above the diagonal
+
+    d4 acc[MTC][MTR];
+#pragma unroll
+    for (int x = 0; x < MTC; ++x)
+#pragma unroll
+        for (int y = 0; y < MTR; ++y) acc[x][y] = (d4){0.0, 0.0, 0.0, 0.0};
+
+    const int nkt_all = (a.kdim + BK - 1) / BK;
+    const int kt_per = (nkt_all + a.k_split - 1) / a.k_split;
+    const int kt_begin = kslice * kt_per;
+    const int nkt = max(0, min(nkt_all, kt_begin + kt_per) - kt_begin);
     d2 va[1024 / NT], vb[1024 / NT];
-    if (EPI != EPI_SUBTRACT_POTRF && nkt > 0) {
+    if (nkt > 0) {
         const int k0 = kt_begin * BK;
         const bool chk = edge || (k0 + BK > a.kdim);
-        if (chk) { load_tile<true, NT>(a.A, a.lda, row0, k0, a.n, a.kdim, tid, va); load_tile<true, NT>(a.B, a.ldb, col0, k0, a.n, a.kdim, tid, vb); scale_tile<true, NT, NEGB>(a.w, k0, a.kdim, tid, vb); }
-        else { load_tile<false, NT>(a.A, a.lda, row0, k0, a.n, a.kdim, tid, va); load_tile<false, NT>(a.B, a.ldb, col0, k0, a.n, a.kdim, tid, vb); scale_tile<false, NT, NEGB>(a.w, k0, a.kdim, tid, vb); }
+        if (chk) { load_tile<true, NT>(a.A, a.lda, row0, k0, a.n, a.kdim, tid, va); load_tile<true, NT>(a.B, a.ldb, col0, k0, a.n, a.kdim, tid, vb); scale_tile<true, NT>(a.w, k0, a.kdim, tid, vb); }
+        else { load_tile<false, NT>(a.A, a.lda, row0, k0, a.n, a.kdim, tid, va); load_tile<false, NT>(a.B, a.ldb, col0, k0, a.n, a.kdim, tid, vb); scale_tile<false, NT>(a.w, k0, a.kdim, tid, vb); }
         store_tile<NT>(As, tid, va);
         store_tile<NT>(Bs, tid, vb);
     }
-    if (EPI != EPI_SUBTRACT_POTRF) __syncthreads();
+    __syncthreads();
 
-    for (int kt = 0; kt < (EPI == EPI_SUBTRACT_POTRF ? 0 : nkt); ++kt) {
+    for (int kt = 0; kt < nkt; ++kt) {
         const int cur = kt & 1;
         const bool more = (kt + 1 < nkt);
         if (more) {
             const int k0 = (kt_begin + kt + 1) * BK;
             const bool chk = edge || (k0 + BK > a.kdim);
-            if (chk) { load_tile<true, NT>(a.A, a.lda, row0, k0, a.n, a.kdim, tid, va); load_tile<true, NT>(a.B, a.ldb, col0, k0, a.n, a.kdim, tid, vb); scale_tile<true, NT, NEGB>(a.w, k0, a.kdim, tid, vb); }
-            else { load_tile<false, NT>(a.A, a.lda, row0, k0, a.n, a.kdim, tid, va); load_tile<false, NT>(a.B, a.ldb, col0, k0, a.n, a.kdim, tid, vb); scale_tile<false, NT, NEGB>(a.w, k0, a.kdim, tid, vb); }
+            if (chk) { load_tile<true, NT>(a.A, a.lda, row0, k0, a.n, a.kdim, tid, va); load_tile<true, NT>(a.B, a.ldb, col0, k0, a.n, a.kdim, tid, vb); scale_tile<true, NT>(a.w, k0, a.kdim, tid, vb); }
+            else { load_tile<false, NT>(a.A, a.lda, row0, k0, a.n, a.kdim, tid, va); load_tile<false, NT>(a.B, a.ldb, col0, k0, a.n, a.kdim, tid, vb); scale_tile<false, NT>(a.w, k0, a.kdim, tid, vb); }
         }
         if (!skip_wave) {
             const double* Asb = As + cur * BK * LDS_LD + wr * SUBR + (lane & 15);
@@ -329,10 +417,6 @@ __device__ __forceinline__ void syrk_lower_body(const SyrkArgs& a, const int blo
         __syncthreads();
     }
 
-    if (dbg_tile) a.fuse_ts[86] = clock64();  // K loop done (the accumulators' first use waited for C)
-    if constexpr (EPI == EPI_SUBTRACT_POTRF) {
-        if (a.fuse_cnt && tj == 0 && a.fuse_pack) { panel_follow<NT, MTC, MTR>(a, smem, acc, row0, wr, wc); return; }
-    }
     if (skip_wave) return;
     if (a.part) {
         // split launch: raw partial tile (column-major 128 x 128) for k_syrk_tail_reduce; fixed slot per (tile, slice)
@@ -363,8 +447,6 @@ __device__ __forceinline__ void syrk_lower_body(const SyrkArgs& a, const int blo
                         if (gi == gj) base += a.x_reg[gi];
                         if (a.ATA) base += a.dinv * a.ATA[(size_t)gi + (size_t)gj * a.ldata];
                         a.C[ci] = base + v;
-                    } else if (EPI == EPI_SUBTRACT_POTRF) {
-                        a.C[ci] = v;  // accumulator started from C
                     } else if (EPI == EPI_SUBTRACT) {
                         a.C[ci] -= v;
                     } else {
@@ -374,7 +456,7 @@ __device__ __forceinline__ void syrk_lower_body(const SyrkArgs& a, const int blo
             }
         }
     }
-    if (dbg_tile) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); a.fuse_ts[87] = clock64(); }  // stores drained
+    }
 }
 
 template <int EPI, int WR, int WC>
@@ -874,7 +956,8 @@ __device__ __forceinline__ d4 tile_load_rowperm(const double* __restrict__ blk, 
 template <bool LDLT, int NWAVES>
 __device__ __forceinline__ void potrf_block(double* __restrict__ Tb, double* __restrict__ rds, int nb, int kglobal, int* __restrict__ info, double* __restrict__ rdiag,
                             double* __restrict__ dvec, double* __restrict__ Aout, int lda, double* __restrict__ pack, double* __restrict__ w16,
-                            long long* __restrict__ ts, int* __restrict__ cnt, int nactive)
+                            long long* __restrict__ ts, int* __restrict__ cnt, int nactive,
+                            const double* __restrict__ fetch_scratch, const int* __restrict__ fetch_flags, int fetch_token, const int* __restrict__ fetch_abort)
 {
     // nactive < 8 (short blocks of the sparse fronts: nb <= 16 nactive): block rows nactive .. 7 are identity padding and their waves sit out -- nothing
     // of theirs is stored (the pack blocks and inverted pieces of those rows stay unwritten: only a consumer that solves by substitution and masks the
@@ -894,12 +977,38 @@ __device__ __forceinline__ void potrf_block(double* __restrict__ Tb, double* __r
     if (wave < nactive) {
         const int w = wave;
         double* Dww = Tb + tb_index(w, w) * 256;
+        if (fetch_scratch) {
+            // fused next diagonal block (fused_next_diag): the blocks the helper workgroups computed are pulled in HERE, by the wave whose block row they
+            // belong to, when it starts -- waves 0 and 1 own theirs and factor at once, the later rows have until the chain reaches them (the
+            // owner used to poll all eight helpers and copy 64 KB before anybody started: 4.5 us on the critical path of every panel).  Nobody reads a
+            // tile of block row w before wave w has said so (xdone), so no barrier is needed.
+            int seen_role = 0;
+            bool bad = false;
+            for (int b = max(tb_index(w, 0), FUSE_OWN); b <= tb_index(w, w); ++b) {
+                const int role = b / FUSE_OWN;
+                if (role != seen_role) {
+                    unsigned spins = 0;
+                    while (ldi_agent(fetch_flags + role) != fetch_token) {
+                        __builtin_amdgcn_s_sleep(1);
+                        if (++spins > 20000000u || (fetch_abort && (spins & 1023u) == 0 && ldi_agent(fetch_abort) != 0)) { bad = true; break; }
+                    }
+                    seen_role = role;
+                }
+                double v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = ld_agent(fetch_scratch + (size_t)b * 256 + lane + 64 * q);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) Tb[b * 256 + lane + 64 * q] = v[q];
+            }
+            if (bad && lane == 0 && *info < 0) *info = kglobal;  // a helper never arrived (cannot happen with a healthy device): reported, not waited for
+            wave_lds_sync();
+        }
         d4 dperm = tile_load_perm(Dww, lane);  // own diagonal tile: in registers until it is factored
         int pending = -1;  // step whose pack stores this wave has not signalled yet
         auto signal_pending = [&]() {
             if (cnt && pending >= 0) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (lane == 0) __hip_atomic_fetch_add(cnt + pending, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane == 0) addi_agent(cnt + pending, 1);
             }
             pending = -1;
         };
@@ -969,7 +1078,7 @@ __device__ __forceinline__ void potrf_block(double* __restrict__ Tb, double* __r
             // W^T = I L^-T by the same rank-1 substitution, then one product with the identity transposes it: W = I (W^T)^T.
             if (lane < 16 && 16 * k + lane < nb) {
                 st_agent(rdiag + kglobal + 16 * k + lane, rbuf[lane]);
-                if (LDLT && dvec) dvec[16 * k + lane] = dvs[lane];
+                if (LDLT && dvec) st_agent(dvec + 16 * k + lane, dvs[lane]);  // (written through: the next trailing update of a persistent launch reads it from other CUs)
             }
             if (pack || w16) {
                 const d4 lkk = tile_load(Dww, lane);  // the factored piece in the natural tile form
@@ -987,13 +1096,16 @@ __device__ __forceinline__ void potrf_block(double* __restrict__ Tb, double* __r
 #pragma unroll
                     for (int r = 0; r < 4; ++r) st_agent(pb + 64 * r, wv[r]);
                 }
-                if (w16) tile_store(w16 + k * 256, lane, wv);  // kept for the triangular sweeps (launch_trsv)
+                if (w16) {  // kept for the triangular sweeps (launch_trsv)
+                    __attribute__((address_space(1))) double* wp = (__attribute__((address_space(1))) double*)(w16 + k * 256) + (lane >> 4) * 16 + (lane & 15);
+                    wp[0] = wv[0]; wp[64] = wv[1]; wp[128] = wv[2]; wp[192] = wv[3];
+                }
             }
             if (cnt) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 if (lane == 0) {
-                    __hip_atomic_fetch_add(cnt + k, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (pending >= 0) __hip_atomic_fetch_add(cnt + pending, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    addi_agent(cnt + k, 1);
+                    if (pending >= 0) addi_agent(cnt + pending, 1);
                 }
                 pending = -1;
             }
@@ -1005,7 +1117,7 @@ __device__ __forceinline__ void potrf_block(double* __restrict__ Tb, double* __r
                 for (int q = 0; q < 4; ++q) {
                     const int e = lane + 64 * q, r = 16 * k + (e & 15), c = 16 * bj + (e >> 4);
                     const double v = blk[e];
-                    if (r < nb && c < nb && r >= c) Aout[(size_t)r + (size_t)c * lda] = v;
+                    if (r < nb && c < nb && r >= c) ((__attribute__((address_space(1))) double*)Aout)[(size_t)r + (size_t)c * lda] = v;  // (always device memory)
                 }
             }
             stamp(k, 6);
@@ -1079,18 +1191,18 @@ void launch_potrf_diag(bool ldlt, double* A, int lda, int nb, int kglobal, int* 
 // K <= 128 (one panel): the WHOLE operand panel goes to LDS in one round of loads -- the double-buffered 16-column stages of the generic
 // kernel cost a load -> LDS -> barrier round trip each (measured 2700 cycles per stage) -- and the 32 MFMA k-slices run back to back on four
 // interleaved accumulator chains (a single chain is a dependent MFMA every ~180 cycles plus the LDS read in front of it: 18 000 cycles measured).
-template <int NT>
-__device__ __forceinline__ void fused_next_diag(const SyrkArgs& a, double* __restrict__ smem, int role)
+template <int NT, bool PERSIST>
+__device__ __forceinline__ bool fused_next_diag(const SyrkArgs& a, double* __restrict__ smem, int role)
 {
     constexpr int NW = NT / 64;
     static_assert(FUSE_OWN * FUSE_ROLES >= TB_BLOCKS && FUSE_OWN <= NW, "every tile block needs a wave");
     double* As = smem;                    // [kdim <= 128][LDS_LD]: the whole operand panel
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, g = lane >> 4;
-    const bool dbg_ts = a.fuse_ts && tid == 0 && role == 0;
+    const bool dbg_ts = FUSE_TS_ON && !PERSIST && a.fuse_ts && tid == 0 && role == 0;
     if (dbg_ts) a.fuse_ts[0] = clock64();
     const int nbn = a.fuse_nb;
-    const bool edge = (TS > a.n) || a.unaligned;
+    const bool edge = !PERSIST && ((TS > a.n) || a.unaligned);
     // the tile block of this wave
     const int t = role * FUSE_OWN + wave;  // four blocks per workgroup: one wave per SIMD does the products, the other waves only help staging
     const bool on = wave < FUSE_OWN && t < TB_BLOCKS;
@@ -1103,17 +1215,76 @@ __device__ __forceinline__ void fused_next_diag(const SyrkArgs& a, double* __res
     const int nkt = (a.kdim + BK - 1) / BK;  // <= 8
     double* ws = smem + TS * LDS_LD;         // -D of the panel (LLT: -1), after the operand panel
     d4 acc;
+    d4 p1 = {0.0, 0.0, 0.0, 0.0}, p2 = p1, p3 = p1;
+    const bool progressive = PERSIST && a.fuse_xcnt != nullptr;
+    if (progressive) {
+        // Persistent launch, rounds >= 1: the operand (block row k + 1 of panel k) is being solved RIGHT NOW by the first panel workgroup of the round
+        // before, behind the factorisation of that round's diagonal block; it publishes every 16-column slice as it becomes final (panel_follow: write-through
+        // stores, then fuse_xpub += 1 per wave).  The crew takes each slice as it arrives -- its four k-steps go to the four accumulator chains exactly as
+        // in the one-shot loop below, in the same order: bitwise the same block -- so that only the LAST slice's products, not the operand fetch and all 32,
+        // stand between the end of one diagonal block and the start of the next.
+        const int li = bi * 16 + i;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int lj = bj * 16 + g + 4 * r;
+            const bool ok = on && li >= lj;
+            const double cv = ld_agent(a.C + (ok ? (size_t)li + (size_t)lj * a.ldc : 0));
+            acc[r] = ok ? cv : 0.0;
+        }
+        __shared__ int pok_s;
+        const double* Ar = As + bi * 16 + i;
+        const double* Ac = As + bj * 16 + i;
+#pragma unroll 1
+        for (int kt = 0; kt < 8; ++kt) {
+            if (tid == 0) {
+                int ok = 1;
+                unsigned spins = 0;
+                while (ldi_agent(a.fuse_xcnt) - (a.fuse_xwant + 8 * (kt + 1)) < 0) {
+                    __builtin_amdgcn_s_sleep(2);
+                    if (++spins > 20000000u || ((spins & 1023u) == 0 && a.fuse_abort && ldi_agent(a.fuse_abort) != 0)) { ok = 0; break; }
+                }
+                pok_s = ok;
+                if (a.fuse_tr2n && role == 0) a.fuse_tr2n[8 + kt] = wall_clock64();
+            }
+            __syncthreads();
+            if (!pok_s) {
+                if (tid == 0 && *a.fuse_info < 0) *a.fuse_info = a.fuse_kglobal;
+                return false;
+            }
+            d2 va[1024 / NT];
+            load_tile_agent<NT>(a.A, a.lda, 0, kt * BK, tid, va);
+            if (tid < BK) ws[kt * BK + tid] = -(a.w ? ld_agent(a.w + kt * BK + tid) : 1.0);
+            store_tile<NT>(As + kt * BK * LDS_LD, tid, va);
+            __syncthreads();
+            if (on) {
+                double af[4], bf[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int kk = (4 * kt + u) * 4 + g;
+                    af[u] = Ar[kk * LDS_LD];
+                    bf[u] = Ac[kk * LDS_LD] * ws[kk];
+                }
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[0], af[0], acc, 0, 0, 0);
+                p1 = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[1], af[1], p1, 0, 0, 0);
+                p2 = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[2], af[2], p2, 0, 0, 0);
+                p3 = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[3], af[3], p3, 0, 0, 0);
+            }
+        }
+        if (on) acc = ((acc + p1) + p2) + p3;  // fixed order
+        if (a.fuse_tr2n && role == 0 && tid == 0) a.fuse_tr2n[16] = wall_clock64();
+    } else {
     {
         d2 va[8][1024 / NT];
 #pragma unroll
         for (int kt = 0; kt < 8; ++kt) {
             if (kt < nkt) {
                 const int k0 = kt * BK;
-                if (edge || k0 + BK > a.kdim) load_tile<true, NT>(a.A, a.lda, 0, k0, a.n, a.kdim, tid, va[kt]);
+                if constexpr (PERSIST && AGENT_OPERANDS) load_tile_agent<NT>(a.A, a.lda, 0, k0, tid, va[kt]);
+                else if (edge || k0 + BK > a.kdim) load_tile<true, NT>(a.A, a.lda, 0, k0, a.n, a.kdim, tid, va[kt]);
                 else load_tile<false, NT>(a.A, a.lda, 0, k0, a.n, a.kdim, tid, va[kt]);
             }
         }
-        const double wv = (tid < TS) ? -((a.w && tid < a.kdim) ? a.w[tid] : 1.0) : 0.0;  // the sign of C - A D A^T rides on D
+        const double wv = (tid < TS) ? -((a.w && tid < a.kdim) ? (PERSIST ? ld_agent(a.w + tid) : a.w[tid]) : 1.0) : 0.0;  // the sign of C - A D A^T rides on D
         // C of this wave's block (identity padding beyond the order of a last, partial panel)
         const int li = bi * 16 + i;
 #pragma unroll
@@ -1121,7 +1292,8 @@ __device__ __forceinline__ void fused_next_diag(const SyrkArgs& a, double* __res
             const int lj = bj * 16 + g + 4 * r;
             const bool in = li < nbn && lj < nbn;
             const bool ok = on && in && li >= lj;
-            const double cv = a.C[ok ? (size_t)li + (size_t)lj * a.ldc : 0];
+            const double* cp = a.C + (ok ? (size_t)li + (size_t)lj * a.ldc : 0);
+            const double cv = PERSIST ? ld_agent(cp) : *cp;
             acc[r] = ok ? cv : ((!in && li == lj) ? 1.0 : 0.0);
         }
         if (tid < TS) ws[tid] = wv;
@@ -1132,7 +1304,6 @@ __device__ __forceinline__ void fused_next_diag(const SyrkArgs& a, double* __res
     __syncthreads();
     if (dbg_ts) a.fuse_ts[4] = clock64();
     if (on) {
-        d4 p1 = {0.0, 0.0, 0.0, 0.0}, p2 = p1, p3 = p1;
         const double* Ar = As + bi * 16 + i;
         const double* Ac = As + bj * 16 + i;
 #pragma unroll 2
@@ -1151,6 +1322,7 @@ __device__ __forceinline__ void fused_next_diag(const SyrkArgs& a, double* __res
         }
         acc = ((acc + p1) + p2) + p3;  // fixed order
     }
+    }
     __syncthreads();  // every wave is done with the operand panel (the owner reuses its LDS for the tile blocks)
     if (role > 0) {
         // helper: block -> scratch, written through; drained; then the token
@@ -1161,44 +1333,25 @@ __device__ __forceinline__ void fused_next_diag(const SyrkArgs& a, double* __res
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid == 0) __hip_atomic_store(a.fuse_flags + role, a.fuse_token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return;
+        if (tid == 0) sti_agent(a.fuse_flags + role, a.fuse_token);
+        if (PERSIST && a.fuse_tr2n && tid == 0 && role == 1) a.fuse_tr2n[19] = wall_clock64();
+        return true;
     }
     if (dbg_ts) a.fuse_ts[1] = clock64();
     double* Tb = smem;  // the operand panel is dead now
     if (on) tile_store(Tb + t * 256, lane, acc);
-    {
-        __shared__ int ok_s;
-        if (tid == 0) {
-            int ok = 1;
-            for (int h = 1; h < FUSE_ROLES && ok; ++h) {
-                unsigned spins = 0;
-                while (__hip_atomic_load(a.fuse_flags + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.fuse_token) {
-                    __builtin_amdgcn_s_sleep(1);
-                    if (++spins > 20000000u) { ok = 0; break; }
-                }
-            }
-            ok_s = ok;
-        }
-        __syncthreads();
-        if (!ok_s) {  // a helper never arrived (cannot happen with a healthy device): report the block as not factorisable instead of hanging
-            if (tid == 0 && *a.fuse_info < 0) *a.fuse_info = a.fuse_kglobal;
-            return;
-        }
-        // the helpers' blocks: (36 - 4) * 256 doubles, L1-bypassing loads, 16 per thread in flight
-        constexpr int PER = (TB_BLOCKS - FUSE_OWN) * 256 / NT;
-        double v[PER];
-#pragma unroll
-        for (int u = 0; u < PER; ++u) v[u] = ld_agent(a.fuse_scratch + FUSE_OWN * 256 + u * NT + tid);
-#pragma unroll
-        for (int u = 0; u < PER; ++u) Tb[FUSE_OWN * 256 + u * NT + tid] = v[u];
-    }
+    // (the helpers' blocks are pulled inside potrf_block, row by row, by the waves that need them)
     __syncthreads();
     if (dbg_ts) a.fuse_ts[2] = clock64();
-    long long* pts = a.fuse_ts ? a.fuse_ts + 8 : nullptr;
-    if (a.fuse_ldlt) potrf_block<true, NW>(Tb, Tb + TB_DOUBLES, nbn, a.fuse_kglobal, a.fuse_info, a.fuse_rdiag, a.fuse_dvec, a.C, a.ldc, a.fuse_pack, a.fuse_w16, pts, a.fuse_cnt);
-    else potrf_block<false, NW>(Tb, Tb + TB_DOUBLES, nbn, a.fuse_kglobal, a.fuse_info, a.fuse_rdiag, a.fuse_dvec, a.C, a.ldc, a.fuse_pack, a.fuse_w16, pts, a.fuse_cnt);
+    if (PERSIST && a.fuse_tr2n && tid == 0) a.fuse_tr2n[17] = wall_clock64();
+    long long* pts = (FUSE_TS_ON && !PERSIST && a.fuse_ts) ? a.fuse_ts + 8 : nullptr;
+    if (a.fuse_ldlt) potrf_block<true, NW>(Tb, Tb + TB_DOUBLES, nbn, a.fuse_kglobal, a.fuse_info, a.fuse_rdiag, a.fuse_dvec, a.C, a.ldc, a.fuse_pack, a.fuse_w16, pts, a.fuse_cnt, 8,
+                                           a.fuse_scratch, a.fuse_flags, a.fuse_token, PERSIST ? a.fuse_abort : nullptr);
+    else potrf_block<false, NW>(Tb, Tb + TB_DOUBLES, nbn, a.fuse_kglobal, a.fuse_info, a.fuse_rdiag, a.fuse_dvec, a.C, a.ldc, a.fuse_pack, a.fuse_w16, pts, a.fuse_cnt, 8,
+                                a.fuse_scratch, a.fuse_flags, a.fuse_token, PERSIST ? a.fuse_abort : nullptr);
     if (dbg_ts) a.fuse_ts[3] = clock64();
+    if (PERSIST && a.fuse_tr2n && tid == 0) a.fuse_tr2n[18] = wall_clock64();
+    return true;
 }
 
 // The panel solve of the NEXT panel inside the fused trailing update: the workgroup of tile (ti, 0) has just updated the 128 rows of that panel
@@ -1207,15 +1360,13 @@ __device__ __forceinline__ void fused_next_diag(const SyrkArgs& a, double* __res
 // step BEHIND the factorisation of the diagonal block, which workgroup 0 of this launch publishes step by step (potrf_block: pack + cnt).  The
 // panel is finished about one step after the diagonal block instead of one launch later (k_trsm_panel: 9.6 us + two launch boundaries).  Same
 // products in the same order as k_trsm_panel: bitwise the same panel.  Waits only target workgroups with lower block indices; bounded spins.
-template <int NT, int MTC, int MTR>
-__device__ __forceinline__ void panel_follow(const SyrkArgs& a, double* __restrict__ smem, const d4 (&acc)[MTC][MTR], int row0, int wr, int wc)
+template <int NT, int MTC, int MTR, bool PERSIST>
+__device__ __forceinline__ bool panel_follow(const SyrkArgs& a, double* __restrict__ smem, const d4 (&acc)[MTC][MTR], int row0, int wr, int wc)
 {
     static_assert(NT == 512 && MTR * 4 == 8 && MTC * 2 == 8, "eight waves, one 16-row strip each");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, g = lane >> 4;
     double* Ts = smem;             // the tile as 8 x 8 block images (row block, column block)
-    double* Ps = smem + 64 * 256;  // operand blocks of the current step: W_kk, then -L(j, k) for j = k + 1 .. 7
-    __shared__ int ok_s;
 #pragma unroll
     for (int x = 0; x < MTC; ++x)
 #pragma unroll
@@ -1224,43 +1375,90 @@ __device__ __forceinline__ void panel_follow(const SyrkArgs& a, double* __restri
     d4 T[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) T[j] = tile_load(Ts + (wave * 8 + j) * 256, lane);
-    const bool dbg = a.fuse_ts && tid == 0 && row0 == TS;  // debugging aid: stamps of the first panel workgroup at fuse_ts[72..]
+    // persistent launch: the first block row below the diagonal block is the operand of the NEXT diagonal block's update -- its slices go out as they
+    // become final (see fused_next_diag); every wave counts in fuse_xpub once per slice
+    const bool publish = PERSIST && a.fuse_xpub != nullptr && row0 == TS;
+    const bool dbg = FUSE_TS_ON && !PERSIST && a.fuse_ts && tid == 0 && row0 == TS;  // debugging aid: stamps of the first panel workgroup at fuse_ts[72..]
     if (dbg) a.fuse_ts[80] = clock64();
+    // The operand blocks of a step are fetched when the factorisation has published them -- and with them those of every FURTHER step it has published by
+    // then, in one round of loads (all of a thread's loads in flight together): a workgroup that starts behind the factorisation (persistent launch: its own
+    // inputs come from the round before) catches up at the cost of its products instead of paying an L2 / HBM round trip and two barriers per step (3.7 us
+    // per early step, measured, against the 3.4 us the factorisation needs for one).  The blocks live at their pack index in the LDS the tile just left.
+    __syncthreads();  // every wave holds its strip in registers: Ts is free
+    double* Pk = Ts;
+    __shared__ int have_s, nblk_s, blist[PACK_BLOCKS];
+    int have = 0;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        if (tid == 0) {
-            const int want = a.fuse_token * (8 - k);
-            int ok = 1;
-            unsigned spins = 0;
-            while (__hip_atomic_load(a.fuse_cnt + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want < 0) {
-                __builtin_amdgcn_s_sleep(4);
-                if (++spins > 20000000u) { ok = 0; break; }
+        if (k >= have) {
+            if (tid == 0) {
+                int ok = 1, nxt = k;
+                unsigned spins = 0;
+                while (ldi_agent(a.fuse_cnt + k) - a.fuse_token * (8 - k) < 0) {
+                    __builtin_amdgcn_s_sleep(4);
+                    if (++spins > 20000000u || (PERSIST && a.fuse_abort && (spins & 1023u) == 0 && ldi_agent(a.fuse_abort) != 0)) { ok = 0; break; }
+                }
+                if (ok) { nxt = k + 1; while (nxt < 8 && ldi_agent(a.fuse_cnt + nxt) - a.fuse_token * (8 - nxt) >= 0) ++nxt; }
+                int nb = 0;
+                for (int q = k; q < nxt; ++q) { blist[nb++] = 28 + q; for (int j = q + 1; j < 8; ++j) blist[nb++] = j * (j - 1) / 2 + q; }
+                have_s = ok ? nxt : -1; nblk_s = nb;
+                if (PERSIST && a.fuse_tr2 && row0 == TS) for (int q = k; q < nxt; ++q) a.fuse_tr2[32 + q] = wall_clock64();
+                if (dbg) a.fuse_ts[72 + k] = clock64();
             }
-            ok_s = ok;
-            if (dbg) a.fuse_ts[72 + k] = clock64();
+            __syncthreads();
+            if (have_s < 0) {  // the diagonal block never arrived (cannot happen with a healthy device): report instead of hanging
+                if (tid == 0 && *a.fuse_info < 0) *a.fuse_info = a.fuse_kglobal;
+                return false;
+            }
+            have = have_s;
+            const int nb = nblk_s;
+            if (nb <= 8) {
+                double v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const int e = u * NT + tid, bi = e >> 8; v[u] = ld_agent(a.fuse_pack + (size_t)blist[bi < nb ? bi : 0] * 256 + (e & 255)); }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const int e = u * NT + tid, bi = e >> 8; if (bi < nb) Pk[blist[bi] * 256 + (e & 255)] = v[u]; }
+            } else {
+                double v[PACK_BLOCKS * 256 / NT];
+#pragma unroll
+                for (int u = 0; u < PACK_BLOCKS * 256 / NT; ++u) { const int e = u * NT + tid, bi = e >> 8; v[u] = ld_agent(a.fuse_pack + (size_t)blist[bi < nb ? bi : 0] * 256 + (e & 255)); }
+#pragma unroll
+                for (int u = 0; u < PACK_BLOCKS * 256 / NT; ++u) { const int e = u * NT + tid, bi = e >> 8; if (bi < nb) Pk[blist[bi] * 256 + (e & 255)] = v[u]; }
+            }
+            __syncthreads();
         }
-        __syncthreads();
-        if (!ok_s) {  // the diagonal block never arrived (cannot happen with a healthy device): report instead of hanging
-            if (tid == 0 && *a.fuse_info < 0) *a.fuse_info = a.fuse_kglobal;
-            return;
-        }
-        for (int e = tid; e < (8 - k) * 256; e += NT) {
-            const int bq = e >> 8, j = k + bq;
-            const double* src = a.fuse_pack + (size_t)(bq == 0 ? 28 + k : j * (j - 1) / 2 + k) * 256;
-            Ps[e] = ld_agent(src + (e & 255));
-        }
-        __syncthreads();
-        const d4 w = tile_load(Ps, lane);
+        const d4 w = tile_load(Pk + (28 + k) * 256, lane);
         d4 x = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) x = __builtin_amdgcn_mfma_f64_16x16x4f64(w[ks], T[k][ks], x, 0, 0, 0);
         T[k] = x;
+        if (publish) {
+            // the slice published a step ago has had a whole step to reach memory: drain (cheap by now), tell the next crew, then send this one
+            if (k > 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (lane == 0) addi_agent(a.fuse_xpub, 1); }
+            double* Cr = a.C + (row0 + wave * 16 + i);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = 16 * k + g + 4 * r;
+                double v = x[r];
+                if (a.fuse_ldlt) v *= ld_agent(a.fuse_rdiag + a.fuse_kglobal + c);
+                st_agent(Cr + (size_t)c * a.ldc, v);
+                st_agent(a.fuse_side + (row0 + wave * 16 + i) + (size_t)c * a.ldc, v);
+            }
+            if (a.fuse_tr2 && tid == 0) a.fuse_tr2[k] = wall_clock64();
+        }
 #pragma unroll
         for (int j = k + 1; j < 8; ++j) {
-            const d4 nl = tile_load(Ps + (j - k) * 256, lane);
+            const d4 nl = tile_load(Pk + (j * (j - 1) / 2 + k) * 256, lane);
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) T[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(nl[ks], x[ks], T[j], 0, 0, 0);
         }
+    }
+    if (publish) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) addi_agent(a.fuse_xpub, 1);
+        if (a.fuse_tr2 && tid == 0) a.fuse_tr2[27] = wall_clock64();
+        if (dbg) a.fuse_ts[81] = clock64();
+        return true;
     }
     const int row = row0 + wave * 16 + i;
     if (row < a.n) {
@@ -1273,11 +1471,329 @@ __device__ __forceinline__ void panel_follow(const SyrkArgs& a, double* __restri
                 if (c < a.fuse_nb) {
                     double v = T[j][r];
                     if (a.fuse_ldlt) v *= ld_agent(a.fuse_rdiag + a.fuse_kglobal + c);
-                    Cr[(size_t)c * a.ldc] = v;
+                    if (PERSIST) { st_agent(Cr + (size_t)c * a.ldc, v); st_agent(a.fuse_side + row + (size_t)c * a.ldc, v); }
+                    else Cr[(size_t)c * a.ldc] = v;
                 }
             }
     }
     if (dbg) a.fuse_ts[81] = clock64();
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------
+// The whole blocked factorisation after its first diagonal block and panel in ONE persistent launch (round 3).
+//
+// Round k = what the fused launch of panel k did: trailing update U_k of every tile, factorisation of the next diagonal block D_{k+1}
+// (owner + eight helpers), substitution of the next panel behind it.  Here the rounds are not separated by kernel boundaries: every piece of
+// work is a TASK of a fixed, topologically ordered list, workgroups draw tickets from one counter and wait -- bounded -- only for results of
+// EARLIER tickets, so progress never depends on how many workgroups are resident (two factorisations on two streams, a busy device).  The
+// order puts the next round's critical tasks right behind what they need:
+//   ... bulk(k-1, first tile column)  crew(k)  panel(k)  bulk(k-1, other columns)  bulk(k, first tile column)  crew(k+1)  panel(k+1) ...
+// so the diagonal-block chain of round k+1 starts as soon as ITS inputs exist (look-ahead), while the bulk tiles of round k are still running.
+// What crosses workgroups inside the launch is written through (sc1) and read with agent-scope loads, and published by one word per unit:
+//   lready[k T + i]  block row i of panel k is final (written by its panel task, or before the launch for k = 0);
+//   tver[i T + j]    number of trailing updates tile (i, j) has received;
+//   pdone[k]         panel tasks of round k that have finished (the owner of round k + 2 reuses their operand-pack buffer);
+// all as launch-unique values (gen + ...), so nothing is reset between factorisations.  Every tile receives the same products in the same
+// order as in the launch-per-panel path: bitwise the same factor (tests/test_dense_gpu.py).
+struct CholTask { short kind, round, a, b; };  // kind 0: helper (role a) / 1: owner / 2: panel tile (a, 0) / 3: bulk tile (a, b) of round `round`
+struct CholArgs {
+    double* A; double* side; int lda, n, T, ldlt;
+    int* info; double* rdiag; double* dvec; double* pack2; double* w16;
+    double* scratch; int* fuse_flags; int* fuse_cnt; int token_base;
+    const CholTask* tasks; int ntasks;
+    int* ticket;   // [0] next ticket, [1] abort
+    int* lready; int* tver; int* pdone;
+    int* xcnt;            // per round: slices of the first panel row published so far (x 8 waves), cumulative over the factorisations of this handle
+    int* progress;        // gen + number of rounds whose panel tasks have ALL finished (they finish in round order)
+    const int* limits;    // limits[P]: tickets below this index have every panel they need once P rounds are complete (plus the crew and panel tasks of the
+                          // round after, which take their places early); a workgroup draws no ticket beyond it -- it sleeps on `progress` instead of polling
+                          // the words of a task several rounds away (a grid of pollers slowed the write-through traffic of the critical workgroup)
+    int gen;       // launch-unique base of the flag values
+    int fcount;    // persistent factorisations this handle has run before this one (pdone counters are cumulative)
+    long long* trace;  // debugging aid (PIQP_AMD_DEBUG=chol_trace), nullable: per ticket 4 x wall_clock64 (100 MHz): drawn, inputs ready, done; [3] = workgroup id
+};
+
+// thread 0 waits until *p - want >= 0 for up to three words; false on abort / timeout (sets the abort word)
+__device__ __forceinline__ bool chol_wait3(const int* p0, int w0, const int* p1, int w1, const int* p2, int w2, int* abort_w, int sleep)
+{
+    __shared__ int ok_s;
+    if (threadIdx.x == 0) {
+        int ok = 1;
+        const int* ps[3] = {p0, p1, p2};
+        const int ws[3] = {w0, w1, w2};
+        for (int q = 0; q < 3 && ok; ++q) {
+            if (!ps[q]) continue;
+            unsigned spins = 0;
+            while (__hip_atomic_load(ps[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - ws[q] < 0) {
+                __builtin_amdgcn_s_sleep(4);
+                if (sleep) __builtin_amdgcn_s_sleep(12);
+                ++spins;
+                if ((spins & 255u) == 0 && __hip_atomic_load(abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { ok = 0; break; }
+                if (spins > 8000000u) { ok = 0; __hip_atomic_store(abort_w, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            }
+        }
+        ok_s = ok;
+    }
+    __syncthreads();
+    const bool ok = ok_s != 0;
+    __syncthreads();
+    return ok;
+}
+
+constexpr int CHOL_THREADS = 512;
+// The two roles as out-of-line functions: inlined into the ticket loop they drove the kernel to 256 VGPRs + 224 spilled (892 B of scratch per lane) and
+// the diagonal block took twice as long as in the launch-per-panel kernel (208 VGPRs, no spills).  The LDS view is rebuilt from the extern symbol inside
+// so that the compiler still emits ds_read / ds_write (a pointer passed in would be a generic one: FLAT accesses), and the functions carry the kernel's
+// workgroup size / waves-per-SIMD attributes: a device function without them is compiled for 1024-thread workgroups, i.e. 128 VGPRs (the tile role
+// then spilled: 44 us per tile instead of 23).
+// (a pointer read out of a struct in memory is a GENERIC pointer to the compiler: 530 FLAT loads in the tile role, which also tie the LDS waits to the
+// global traffic -- 44 us per tile; ld_agent / st_agent and the flag helpers therefore cast to the global address space themselves)
+__device__ __noinline__ bool chol_role_crew(const SyrkArgs& a, int role)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const SyrkArgs b = a;  // a register copy: through the reference every field is re-read from memory (with a full drain) behind each store of the loop
+    return fused_next_diag<CHOL_THREADS, true>(b, smem, role);
+}
+__device__ __noinline__ bool chol_role_tile(const SyrkArgs& a, int ti, int tj)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const SyrkArgs b = a;
+    return fused_tile<CHOL_THREADS, true>(b, ti, tj, smem);
+}
+__global__ __launch_bounds__(CHOL_THREADS, 2) void k_chol_persistent(CholArgs c)
+{
+    __shared__ int s_ticket;
+    const int tid = threadIdx.x;
+    int* abort_w = c.ticket + 1;
+    const int T = c.T, NB = FACTOR_NB;
+    for (;;) {
+        if (tid == 0) {
+            int t = -1;
+            unsigned spins = 0;
+            for (;;) {
+                const int P = min(max(__hip_atomic_load(c.progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - c.gen, 0), T - 1);
+                const int lim = c.limits[P];
+                const int cur = __hip_atomic_load(c.ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (cur >= c.ntasks) { t = c.ntasks; break; }
+                if (cur < lim) { t = __hip_atomic_fetch_add(c.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }  // (a ticket drawn past the limit in a race is still served)
+                __builtin_amdgcn_s_sleep(127);
+                if (__hip_atomic_load(abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 || ++spins > 4000000u) { t = c.ntasks; break; }
+            }
+            s_ticket = t;
+        }
+        __syncthreads();
+        const int t = s_ticket;
+        __syncthreads();
+        if (t >= c.ntasks) return;
+        if (c.trace && tid == 0) { c.trace[4 * (size_t)t] = wall_clock64(); c.trace[4 * (size_t)t + 3] = blockIdx.x; }
+        const CholTask tk = c.tasks[t];
+        const int k = tk.round, kk = k * NB, rs = c.n - kk - NB;  // rs = order of the trailing matrix of round k (a multiple of 128, >= 128)
+        SyrkArgs a;
+        a.n = rs; a.kdim = NB;
+        a.A = (k == 0 ? c.A : c.side) + (kk + NB) + (size_t)kk * c.lda; a.lda = c.lda;  // operand panel k: from the side copy (panel 0: in place, solved before the launch)
+        a.B = a.A; a.ldb = c.lda;
+        a.fuse_side = c.side + (kk + NB) + (size_t)(kk + NB) * c.lda;  // where this round's panel tasks leave the copy of panel k + 1 (same offsets as C)
+        a.w = c.ldlt ? c.dvec + kk : nullptr;
+        a.C = c.A + (kk + NB) + (size_t)(kk + NB) * c.lda; a.ldc = c.lda;
+        a.fuse_nb = NB; a.fuse_kglobal = kk + NB; a.fuse_ldlt = c.ldlt; a.fuse_info = c.info; a.fuse_rdiag = c.rdiag; a.fuse_dvec = c.dvec + kk + NB;
+        a.fuse_pack = (rs - NB > 0) ? c.pack2 + (size_t)(k & 1) * FACTOR_PACK_DOUBLES : nullptr;
+        a.fuse_w16 = c.w16 + (size_t)((kk + NB) / 16) * 256;
+        a.fuse_token = c.token_base + k + 1; a.fuse_flags = c.fuse_flags; a.fuse_scratch = c.scratch; a.fuse_cnt = c.fuse_cnt;
+        a.fuse_abort = abort_w;
+        // progressive hand-over of the first panel row: round k's panel task (1, 0) counts its published slices in xcnt[k] (8 waves x 8 slices per
+        // factorisation, cumulative); the crew of round k + 1 consumes them
+        a.fuse_xpub = c.xcnt + k;
+        a.fuse_xcnt = k > 0 ? c.xcnt + (k - 1) : nullptr;
+        a.fuse_xwant = c.fcount * 64;
+        a.fuse_tr2 = c.trace ? c.trace + 4 * (size_t)c.ntasks + 64 * (size_t)k : nullptr;         // stamps of round k's first panel row ...
+        a.fuse_tr2n = c.trace ? c.trace + 4 * (size_t)c.ntasks + 64 * (size_t)(k > 0 ? k - 1 : T) : nullptr;  // ... and of the crew that consumes it (round k's crew reads round k - 1's row)
+        // absolute block coordinates of what this task touches: relative tile (ti, tj) of round k = absolute (k + 1 + ti, k + 1 + tj)
+        const int* lr = c.lready + (size_t)k * T;   // panel k
+        const int ready = c.gen + 1;
+        bool ok = true;
+        if (tk.kind <= 1) {
+            // crew of the next diagonal block: its tile (k + 1, k + 1) must have received U_0 .. U_{k-1}; operand = block row k + 1 of panel k.  The
+            // owner also waits until every panel task of round k - 2 is done with the pack buffer this round writes.
+            const int d = k + 1;
+            // (its operand, block row d of panel k, arrives slice by slice inside fused_next_diag)
+            ok = chol_wait3(k > 0 ? c.tver + (size_t)d * T + d : nullptr, c.gen + k, nullptr, 0,
+                            (tk.kind == 1 && k >= 2) ? c.pdone + (k - 2) : nullptr, (c.fcount + 1) * (T - (k - 2) - 2), abort_w, 0);
+            if (c.trace && tid == 0) c.trace[4 * (size_t)t + 1] = wall_clock64();
+            if (ok) ok = chol_role_crew(a, tk.kind == 1 ? 0 : tk.a);
+        } else {
+            // a tile (ti, tj) of the trailing matrix = absolute (i, j); tj == 0: the next panel (solved behind the diagonal block by the same workgroup)
+            const bool panel = tk.kind == 2;
+            const int ti = tk.a, tj = panel ? 0 : tk.b;
+            const int i = k + 1 + ti, j = k + 1 + tj;
+            ok = chol_wait3(k > 0 ? c.tver + (size_t)i * T + j : nullptr, c.gen + k, k > 0 ? lr + i : nullptr, ready, k > 0 ? lr + j : nullptr, ready, abort_w, panel ? 0 : 1);
+            if (c.trace && tid == 0) c.trace[4 * (size_t)t + 1] = wall_clock64();
+            if (ok) ok = chol_role_tile(a, ti, tj);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (ok && tid == 0) {
+                if (panel) {
+                    __hip_atomic_store(c.lready + (size_t)(k + 1) * T + i, ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const int before = __hip_atomic_fetch_add(c.pdone + k, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    // the last panel task of the round: rounds complete in order (row i of panel k + 1 needs row i of panel k)
+                    if (before + 1 - (c.fcount + 1) * (T - k - 2) == 0) __hip_atomic_store(c.progress, c.gen + k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    __hip_atomic_store(c.tver + (size_t)i * T + j, c.gen + k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+        if (c.trace && tid == 0) c.trace[4 * (size_t)t + 2] = wall_clock64();
+        if (!ok) {
+            // a bounded wait gave up (cannot happen with a healthy device): everybody leaves, the factorisation is reported as failed
+            if (tid == 0) { __hip_atomic_store(abort_w, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (*c.info < 0) *c.info = kk + NB; }
+            return;
+        }
+    }
+}
+
+// host side: the task list of a T x T tile grid (T >= 2), in ticket order
+size_t chol_task_count(int T)
+{
+    size_t n = 0;
+    for (int k = 0; k + 1 < T; ++k) { const int Tk = T - k - 1; n += FUSE_ROLES + (size_t)(Tk - 1) + (size_t)Tk * (Tk - 1) / 2; }
+    return n;
+}
+static void chol_build_tasks(int T, std::vector<CholTask>& out, std::vector<int>& limits)
+{
+    out.clear();
+    limits.assign((size_t)T, 0);
+    auto crew_panel = [&](int k) {
+        const int Tk = T - k - 1;
+        for (int r = 1; r < FUSE_ROLES; ++r) out.push_back({0, (short)k, (short)r, 0});
+        out.push_back({1, (short)k, 0, 0});
+        if (Tk > 1) for (int ti = 1; ti < Tk; ++ti) out.push_back({2, (short)k, (short)ti, 0});
+    };
+    auto bulk = [&](int k, int tj_lo, int tj_hi) {  // tile columns tj_lo .. tj_hi - 1 of round k
+        const int Tk = T - k - 1;
+        for (int tj = tj_lo; tj < tj_hi && tj < Tk; ++tj)
+            for (int ti = tj; ti < Tk; ++ti) out.push_back({3, (short)k, (short)ti, (short)tj});
+    };
+    // crew(0) panel(0) bulk(0, col 1) | crew(1) panel(1) bulk(0, cols >= 2) bulk(1, col 1) | crew(2) panel(2) bulk(1, cols >= 2) bulk(2, col 1) | ...
+    // limits[P] = index of the first task of bulk(P + 1, first column): everything before it needs panels 0 .. P only
+    crew_panel(0);
+    bulk(0, 1, 2);
+    for (int k = 1; k + 1 < T; ++k) {
+        crew_panel(k);
+        bulk(k - 1, 2, T);
+        limits[(size_t)(k - 1)] = (int)out.size();
+        bulk(k, 1, 2);
+    }
+    bulk(T - 2, 2, T);  // (empty: the last round has a single tile)
+    for (int P = std::max(T - 2, 0); P < T; ++P) limits[(size_t)P] = (int)out.size();
+}
+
+struct CholPlan {
+    int T = 0;
+    CholTask* tasks = nullptr;  // device
+    int* limits = nullptr;      // device, T ints
+    int ntasks = 0;
+    int grid = 0;
+};
+// device-resident task list per (device, T); built at create time (chol_prepare), never freed: a few tens of KB
+static const CholPlan* chol_plan(int T)
+{
+    static std::mutex mu;
+    static std::map<std::pair<int, int>, CholPlan> cache;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = cache.find({dev, T});
+    if (it != cache.end()) return it->second.tasks ? &it->second : nullptr;
+    CholPlan& P = cache[{dev, T}];
+    P.T = T;
+    std::vector<CholTask> h;
+    std::vector<int> lim;
+    chol_build_tasks(T, h, lim);
+    if (h.size() != chol_task_count(T)) return nullptr;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_persistent), hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS_BYTES) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(k_chol_persistent), CHOL_THREADS, FUSED_LDS_BYTES) != hipSuccess || per_cu < 1) { (void)hipGetLastError(); return nullptr; }
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) { (void)hipGetLastError(); return nullptr; }
+    P.grid = std::min<int>(cus * per_cu, (int)h.size());
+    if (hipMalloc(&P.tasks, sizeof(CholTask) * h.size()) != hipSuccess) { (void)hipGetLastError(); P.tasks = nullptr; return nullptr; }
+    ++alloc_counter();
+    if (hipMemcpy(P.tasks, h.data(), sizeof(CholTask) * h.size(), hipMemcpyHostToDevice) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(P.tasks); P.tasks = nullptr; return nullptr; }
+    if (hipMalloc(&P.limits, sizeof(int) * lim.size()) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(P.tasks); P.tasks = nullptr; return nullptr; }
+    ++alloc_counter();
+    if (hipMemcpy(P.limits, lim.data(), sizeof(int) * lim.size(), hipMemcpyHostToDevice) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(P.tasks); P.tasks = nullptr; return nullptr; }
+    P.ntasks = (int)h.size();
+    return &P;
+}
+bool chol_persistent_supported(int n) { return n % FACTOR_NB == 0 && n / FACTOR_NB >= 3 && n / FACTOR_NB <= 1024; }
+bool chol_prepare(int n) { return chol_persistent_supported(n) && chol_plan(n / FACTOR_NB) != nullptr; }
+size_t chol_flag_ints(int n) { const size_t T = (size_t)(n / FACTOR_NB); return 2 + 2 * T * T + 2 * T + 1; }
+// Rounds 0 .. T - 2 of the blocked factorisation of the n x n lower triangle at A (the first diagonal block and the first panel are already
+// factored / solved: launch_potrf_diag + launch_trsm_panel).  flags: chol_flag_ints(n) ints zeroed at allocation; gen: launch-unique, advancing by
+// at least T + 2 per call; fcount: calls made before on this flag array; token_base: fused-launch tokens consumed so far (advances by T - 1).
+bool launch_chol_persistent(bool ldlt, double* A, double* side, int lda, int n, int* info, double* rdiag, double* dvec, double* pack2, double* w16, double* scratch, int* fuse_flags, int* fuse_cnt,
+                            int token_base, int* flags, int gen, int fcount, hipStream_t s)
+{
+    const int T = n / FACTOR_NB;
+    const CholPlan* P = chol_plan(T);
+    if (!P) return false;
+    static long long* trace_d = nullptr;  // PIQP_AMD_DEBUG=chol_trace: timeline of the LAST launch, summarised to stderr (synchronises: a debugging aid)
+    static size_t trace_n = 0;
+    const bool want_trace = debug_token("chol_trace") != nullptr;
+    if (want_trace && trace_n < 4 * (size_t)P->ntasks + 64 * (size_t)(T + 1)) {
+        if (trace_d) (void)hipFree(trace_d);
+        trace_n = 4 * (size_t)P->ntasks + 64 * (size_t)(T + 1);
+        PQ_HIP(hipMalloc(&trace_d, trace_n * sizeof(long long)));
+    }
+    CholArgs c;
+    c.A = A; c.side = side; c.lda = lda; c.n = n; c.T = T; c.ldlt = ldlt ? 1 : 0;
+    c.info = info; c.rdiag = rdiag; c.dvec = dvec; c.pack2 = pack2; c.w16 = w16;
+    c.scratch = scratch; c.fuse_flags = fuse_flags; c.fuse_cnt = fuse_cnt; c.token_base = token_base;
+    c.tasks = P->tasks; c.ntasks = P->ntasks;
+    c.ticket = flags; c.lready = flags + 2; c.tver = c.lready + (size_t)T * T; c.pdone = c.tver + (size_t)T * T; c.xcnt = c.pdone + T; c.progress = c.xcnt + T; c.limits = P->limits;
+    c.gen = gen; c.fcount = fcount;
+    c.trace = want_trace ? trace_d : nullptr;
+    if (want_trace) PQ_HIP(hipMemsetAsync(trace_d, 0, trace_n * sizeof(long long), s));
+    PQ_HIP(hipMemsetAsync(flags, 0, 2 * sizeof(int), s));  // ticket counter and abort word
+    hipLaunchKernelGGL(k_chol_persistent, dim3(P->grid), dim3(CHOL_THREADS), FUSED_LDS_BYTES, s, c);
+    PQ_HIP(hipGetLastError());
+    if (want_trace) {
+        std::vector<long long> h(4 * (size_t)P->ntasks + 64 * (size_t)(T + 1));
+        std::vector<CholTask> tk((size_t)P->ntasks);
+        PQ_HIP(hipMemcpyAsync(h.data(), trace_d, h.size() * sizeof(long long), hipMemcpyDeviceToHost, s));
+        PQ_HIP(hipMemcpyAsync(tk.data(), P->tasks, tk.size() * sizeof(CholTask), hipMemcpyDeviceToHost, s));
+        PQ_HIP(hipStreamSynchronize(s));
+        long long t0 = h[0];
+        for (int t = 0; t < P->ntasks; ++t) t0 = std::min(t0, h[4 * (size_t)t]);
+        auto us = [&](long long v) { return (double)(v - t0) * 0.01; };
+        std::fprintf(stderr, "[piqp_amd] k_chol_persistent timeline (us since the first ticket), T = %d, %d tasks, grid %d\n", T, P->ntasks, P->grid);
+        for (int k = 0; k + 1 < T; ++k) {
+            double own_ready = 0, own_done = 0, help_done = 0, pan_ready = 0, pan_done = 0, bulk_first = 1e30, bulk_last = 0, bulk_work = 0, bulk_wait = 0;
+            int nb = 0;
+            for (int t = 0; t < P->ntasks; ++t) {
+                if (tk[(size_t)t].round != k) continue;
+                const double d0 = us(h[4 * (size_t)t]), d1 = us(h[4 * (size_t)t + 1]), d2 = us(h[4 * (size_t)t + 2]);
+                switch (tk[(size_t)t].kind) {
+                case 0: help_done = std::max(help_done, d2); break;
+                case 1: own_ready = d1; own_done = d2; break;
+                case 2: pan_ready = std::max(pan_ready, d1); pan_done = std::max(pan_done, d2); break;
+                default: bulk_first = std::min(bulk_first, d1); bulk_last = std::max(bulk_last, d2); bulk_work += d2 - d1; bulk_wait += d1 - d0; ++nb; break;
+                }
+            }
+            std::fprintf(stderr, "[piqp_amd]  round %2d: owner inputs %7.1f done %7.1f (helpers %7.1f) | panel inputs %7.1f done %7.1f | bulk %4d tiles: first start %7.1f last end %7.1f, avg work %5.1f avg wait %6.1f\n",
+                         k, own_ready, own_done, help_done, pan_ready, pan_done, nb, nb ? bulk_first : 0.0, bulk_last, nb ? bulk_work / nb : 0.0, nb ? bulk_wait / nb : 0.0);
+            if (k % 6 == 2) {
+                const long long* q = h.data() + 4 * (size_t)P->ntasks + 64 * (size_t)k;
+                std::fprintf(stderr, "[piqp_amd]    hand-over of round %d's first panel row to the crew of round %d: potrf steps seen by the row", k, k + 1);
+                for (int u = 0; u < 8; ++u) std::fprintf(stderr, " %.1f", us(q[32 + u]));
+                std::fprintf(stderr, " | slices sent");
+                for (int u = 0; u < 8; ++u) std::fprintf(stderr, " %.1f", us(q[u]));
+                std::fprintf(stderr, " last counted %.1f | slices seen by the next owner", us(q[27]));
+                for (int u = 0; u < 8; ++u) std::fprintf(stderr, " %.1f", us(q[8 + u]));
+                std::fprintf(stderr, " | its products done %.1f, potrf start %.1f end %.1f, helper 1 published %.1f\n", us(q[16]), us(q[17]), us(q[18]), us(q[19]));
+            }
+        }
+    }
+    return true;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1501,7 +2017,7 @@ __device__ __forceinline__ void diag_solve_bwd(const double* __restrict__ Ls, co
 
 constexpr int TB = 128;
 constexpr int TRSV_LDS_BYTES = (TB * (TB + 1) + 3 * TB) * (int)sizeof(double);
-constexpr int TRSV_P_LDS_BYTES = (TB * (TB + 1) + 3 * TB + 8 * 256 + 64 + TB + TB) * (int)sizeof(double);  // + the eight inverted diagonal pieces, scratch of the diagonal step, W b
+constexpr int TRSV_P_LDS_BYTES = (TB * (TB + 1) + 3 * TB + 8 * 256 + 64 + TB) * (int)sizeof(double);  // + the eight inverted diagonal pieces, scratch of the diagonal step
 
 // forward step j: row blocks r >= j subtract L[r, j-1] * x_{j-1}; block r == j then solves L_jj y = b.
 // rdiag = reciprocal diagonal of L (nullptr: unit diagonal).  The diagonal workgroup issues the loads of
@@ -1617,11 +2133,13 @@ __global__ __launch_bounds__(256) void k_trsv_bwd_step(const double* __restrict_
 typedef unsigned long long u64;
 __device__ __forceinline__ void st_agent(double* p, double v)
 {
-    __hip_atomic_store(reinterpret_cast<u64*>(p), (u64)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (explicit global address space: these helpers only ever touch device memory, and inside the out-of-line roles of k_chol_persistent a pointer read from
+    // the argument struct is a generic one to the compiler -- FLAT instructions, which tie the LDS waits to the global traffic)
+    __hip_atomic_store((__attribute__((address_space(1))) u64*)reinterpret_cast<u64*>(p), (u64)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ double ld_agent(const double* p)
 {
-    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const u64*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    return __longlong_as_double((long long)__hip_atomic_load((__attribute__((address_space(1))) const u64*)reinterpret_cast<const u64*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
 
 // (Serving a block row with several workgroups on several CUs -- helpers taking the earlier producers, the owner the last one -- was
@@ -1629,54 +2147,17 @@ __device__ __forceinline__ double ld_agent(const double* p)
 // hand-off costs more than the shared streaming saves.  Round 2 tried replacing the serial 128-step diagonal substitution by a product with
 // the inverted diagonal block: 108 / 151 us per sweep, but the residuals on the rho = delta = 1e-10 states doubled and two iteration-parity
 // tests moved; with one refinement step against the block the accuracy returned and the time was worse than the substitution.  Both removed.)
+// (Round 3 tried folding W_g into the blocks of the diagonal step once per factorisation -- S_gj = W_g L_gj, so that x_g = (W_g b_g) - sum_j S_gj x_j needs one
+// dependent 16 x 16 product per group instead of two: 700 instead of 850 cycles per group, 0.315 instead of 0.330 ms per solve, every accuracy gate held, but
+// the dense mm_QAFIRO solve left the oracle's iteration count -- an LP at rho = delta = 1e-10 whose count the oracle keeps even when compiled with FMA
+// contraction.  Removed: 1 % of the step is not worth a parity exception.)
 // The diagonal step runs in eight groups of 16 columns: x_g = W_g b_g with the explicitly inverted 16 x 16 diagonal piece W_g of the factorisation
 // (the conditioning level of the panel solve, which holds the accuracy gates of tests/dense_replay.py -- unlike a 128 x 128 inverse), one wave;
 // then every thread takes its 8 columns of the group off the rows still to be solved.  Two LDS barriers per group instead of a 128-step
 // dependent chain on one wave (4.2 us per block in round 1).  W16 == nullptr keeps that substitution (reciprocal pivots in rdiag).
-// Round 3: the diagonal step works on the PRE-SCALED diagonal block.  With W_g = M_gg^-1 (the inverted 16 x 16 diagonal pieces the factorisation leaves in
-// W16; M = L_rr, or its transpose in the backward sweep) the substitution  x_g = W_g (b_g - sum_{j<g} M_gj x_j)  is  x_g = (W_g b_g) - sum_{j<g} S_gj x_j
-// with S_gj = W_g M_gj, which k_trsv_scale_blocks forms once per factorisation (28 products of 16 x 16 blocks per 128-row block and direction).  The
-// product with W_g -- a second dependent 16 x 16 mat-vec and two of the three LDS round trips per group of the round-2 step -- leaves the chain: W b
-// is formed for all eight groups at once before the chain starts, and a group costs the chain wave one LDS round trip (x_g out, its four entries per
-// lane back), two independent 4-term products (groups g-1 and g-2) and their quad sums.  Same conditioning as before: only 16 x 16 inverses are formed
-// (the accuracy gate of tests/dense_replay.py rejected the 128 x 128 inverse), and the terms still leave the right-hand side in
-// ascending column order.  S == nullptr keeps the round-2 step.
-template <bool FWD>
-__global__ __launch_bounds__(256) void k_trsv_scale_blocks(const double* __restrict__ L, int ld, int n, const double* __restrict__ W16, double* __restrict__ S)
-{
-    extern __shared__ __attribute__((aligned(16))) double sm[];
-    double* Ls = sm;                  // M[row][c] at Ls[c * (TB + 1) + row]
-    double* Wd = sm + TB * (TB + 1);  // Wd_g[i][k] at Wd[g * 256 + k * 16 + i]
-    const int tid = threadIdx.x;
-    const int r = (int)blockIdx.x;
-    const int row0 = r * TB, nrows = min(TB, n - row0);
-    stage_lower_block<TB, TB + 1, 256, !FWD>(L + row0 + (size_t)row0 * ld, ld, nrows, Ls, tid);
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        const double w = W16[(size_t)r * 8 * 256 + u * 256 + tid];  // W_u[i = tid & 15][c = tid >> 4]
-        if (FWD) Wd[u * 256 + tid] = w;                              // Wd[i][k] = W[i][k]
-        else Wd[u * 256 + (tid & 15) * 16 + (tid >> 4)] = w;         // Wd[i][k] = W[k][i]
-    }
-    __syncthreads();
-    double* Sr = S + (size_t)r * TB * TB;  // column-major 128 x 128
-    const int i = tid & 15, c = tid >> 4;
-    for (int g = 0; g < 8; ++g) {
-        for (int gj = 0; gj < 8; ++gj) {
-            double acc = 0.0;
-            const bool before = FWD ? (gj < g) : (gj > g);  // groups solved before g in sweep order
-            if (before) {
-#pragma unroll
-                for (int k = 0; k < 16; ++k) acc += Wd[g * 256 + k * 16 + i] * Ls[(16 * gj + c) * (TB + 1) + 16 * g + k];
-            }
-            Sr[(size_t)(16 * gj + c) * TB + 16 * g + i] = acc;  // zero on and beyond the block diagonal: never read, kept clean
-        }
-    }
-}
-
 template <bool FWD>
 __global__ __launch_bounds__(256) void k_trsv_persistent(const double* __restrict__ L, int ld, int n, double* __restrict__ x, const double* __restrict__ rdiag,
-                                                         int nblk, int* __restrict__ flags, int* __restrict__ err, const double* __restrict__ W16, int token, long long* __restrict__ ts,
-                                                         const double* __restrict__ S)
+                                                         int nblk, int* __restrict__ flags, int* __restrict__ err, const double* __restrict__ W16, int token, long long* __restrict__ ts)
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double* Ls = sm;                    // own diagonal block, Ls[c * (TB+1) + r]
@@ -1692,30 +2173,12 @@ __global__ __launch_bounds__(256) void k_trsv_persistent(const double* __restric
     const int ridx = (int)blockIdx.x;   // position of the block in sweep order
     const int r = FWD ? ridx : nblk - 1 - ridx;
     const int row0 = r * TB, nrows = min(TB, n - row0);
-    double* tws = up + 64 + TB;         // W b of the eight groups (pre-scaled step)
     // stage the diagonal block (transposed for the backward sweep) and reciprocal pivots
-    if (S) {
-        // the pre-scaled block, already in sweep orientation: S[row][c] at Sr[c * TB + row] -> Ls[c * (TB + 1) + row]; 16 loads in flight per thread
-        const double* Sr = S + (size_t)r * TB * TB;
-#pragma unroll 1
-        for (int b0 = 0; b0 < TB * TB / 256; b0 += 16) {
-            double v[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) v[u] = Sr[(size_t)(b0 + u) * 256 + tid];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) { const int idx = (b0 + u) * 256 + tid; Ls[(idx >> 7) * (TB + 1) + (idx & 127)] = v[u]; }
-        }
-    } else {
-        stage_lower_block<TB, TB + 1, 256, !FWD>(L + row0 + (size_t)row0 * ld, ld, nrows, Ls, tid);
-    }
+    stage_lower_block<TB, TB + 1, 256, !FWD>(L + row0 + (size_t)row0 * ld, ld, nrows, Ls, tid);
     if (tid < TB) rd[tid] = (rdiag && tid < nrows) ? rdiag[row0 + tid] : 1.0;
     if (W16) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const double w = W16[(size_t)r * 8 * 256 + u * 256 + tid];
-            if (S && !FWD) Wg[u * 256 + (tid & 15) * 16 + (tid >> 4)] = w;  // pre-scaled step: Wg[g][k * 16 + i] = Wd_g[i][k] in both directions
-            else Wg[u * 256 + tid] = w;
-        }
+        for (int u = 0; u < 8; ++u) Wg[u * 256 + tid] = W16[(size_t)r * 8 * 256 + u * 256 + tid];
     }
     const int row = tid & 127, half = tid >> 7;
     double mine = (half == 0 && row < nrows) ? x[row0 + row] : 0.0;
@@ -1781,157 +2244,24 @@ __global__ __launch_bounds__(256) void k_trsv_persistent(const double* __restric
         lds_barrier();
         return true;
     };
+    // a producer never arrived (bounded wait; cannot happen with a healthy device): this block's part of the solution becomes NaN, which the caller's
+    // allFinite check (kkt_system.hpp:266,305) turns into a failed solve -- a wrong x is never returned as a success
+    auto poison = [&] { if (tid < nrows) st_agent(x + row0 + tid, __longlong_as_double(0x7ff8000000000000LL)); };
     {
         double lvA[64], lvB[64];
         if (nsteps > 0) load_block(0, lvA);
         int q = 0;
         for (; q + 1 < nsteps; q += 2) {
-            if (!consume(q, lvA, lvB, q + 1)) return;
-            if (!consume(q + 1, lvB, lvA, q + 2 < nsteps ? q + 2 : -1)) return;
+            if (!consume(q, lvA, lvB, q + 1)) { poison(); return; }
+            if (!consume(q + 1, lvB, lvA, q + 2 < nsteps ? q + 2 : -1)) { poison(); return; }
         }
-        if (q < nsteps) { if (!consume(q, lvA, lvB, -1)) return; }
+        if (q < nsteps) { if (!consume(q, lvA, lvB, -1)) { poison(); return; } }
     }
     __syncthreads();
     if (ts && tid == 0) ts[4 * r + 1] = clock64();  // products done
     if (half == 1) bs[row] = acc;
     __syncthreads();
     if (half == 0) bs[row] = mine - (acc + bs[row]);
-    if (W16 && S) {
-        // ---- pre-scaled diagonal step (see k_trsv_scale_blocks) ----
-        __syncthreads();
-        if (tid < TB) {  // W b, all eight groups at once: row = 16 g + i
-            const int g = tid >> 4, i = tid & 15;
-            double t = 0.0;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) t += Wg[g * 256 + k * 16 + i] * bs[16 * g + k];
-            tws[tid] = t;
-        }
-        __syncthreads();
-        lds_vint* cprog = (lds_vint*)&sync_w[0];
-        lds_vint* hp = (lds_vint*)&sync_w[1];
-        lds_vint* np = (lds_vint*)&sync_w[3];
-        double* far = rd;         // reciprocal pivots are not used on this path
-        double* nearv = up + 64;  // [TB]
-        auto quad_sum = [&](double part) {  // ((p0 + p1) + p2) + p3 in every lane of the quad (quad_perm broadcasts)
-            const int plo = __double2loint(part), phi = __double2hiint(part);
-#define PQ_QUAD_BC(K) __hiloint2double(__builtin_amdgcn_update_dpp(0, phi, (K) * 0x55, 0xf, 0xf, false), __builtin_amdgcn_update_dpp(0, plo, (K) * 0x55, 0xf, 0xf, false))
-            const double rs = ((PQ_QUAD_BC(0) + PQ_QUAD_BC(1)) + PQ_QUAD_BC(2)) + PQ_QUAD_BC(3);
-#undef PQ_QUAD_BC
-            return rs;
-        };
-        // position in the block of the group that is gi-th in sweep order
-        auto grp = [](int gi) { return FWD ? gi : 7 - gi; };
-        if (wave == 0) {
-            // the chain: x_g = (W b)_g - far_g - near_g - S_{g,g-2} x_{g-2} - S_{g,g-1} x_{g-1}; lane = (row i, quarter q), a 16-term product is four
-            // terms per lane and a quad sum
-            const int i = lane >> 2, q = lane & 3;
-            double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0}, xq1[4] = {0.0, 0.0, 0.0, 0.0}, xq2[4] = {0.0, 0.0, 0.0, 0.0};
-            double tv = tws[16 * grp(0) + i];
-#pragma unroll
-            for (int gi = 0; gi < 8; ++gi) {
-                const int g = grp(gi);
-                if (gi >= 3) {
-                    // what the other waves took off these rows: near = groups gi-4, gi-3 (two chain steps of slack), far = everything older.  Words and
-                    // values come back from one round of LDS reads; reads execute in order, so values read after a word that says "done" are final.
-                    double fv, nv;
-                    while (true) {
-                        const int n_done = *np, h_done = hp[(16 * g) >> 6];
-                        fv = far[16 * g + i]; nv = nearv[16 * g + i];
-                        if (n_done >= gi && (gi < 5 || h_done >= gi - 4)) break;
-                        __builtin_amdgcn_s_sleep(1);
-                    }
-                    if (gi >= 5) tv -= fv;
-                    tv -= nv;
-                }
-                if (gi >= 2) {
-                    double part = 0.0;
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) part += s2[t] * xq2[t];
-                    tv -= quad_sum(part);
-                }
-                if (gi >= 1) {
-                    double part = 0.0;
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) part += s1[t] * xq1[t];
-                    tv -= quad_sum(part);
-                }
-                if (q == 0) { xs[16 * g + i] = tv; bs[16 * g + i] = tv; }
-                wave_lds_sync();
-                if (lane == 0) *cprog = gi + 1;
-                asm volatile("" ::: "memory");
-                if (ts && lane == 0 && r == 1) ts[4 * nblk + gi] = clock64();  // debugging aid: the groups of block 1
-                if (gi < 7) {
-                    const int gn = grp(gi + 1), gp = gi >= 1 ? grp(gi - 1) : 0;
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        xq2[t] = xq1[t];
-                        xq1[t] = xs[16 * g + q + 4 * t];
-                        s1[t] = Ls[(16 * g + q + 4 * t) * (TB + 1) + 16 * gn + i];
-                        s2[t] = gi >= 1 ? Ls[(16 * gp + q + 4 * t) * (TB + 1) + 16 * gn + i] : 0.0;
-                    }
-                    tv = tws[16 * gn + i];
-                }
-            }
-        } else if (wave == 3) {
-            // near: for the group the chain reaches at step G, the products with the groups solved at steps G-4 and G-3
-            const int i = lane >> 2, q = lane & 3;
-#pragma unroll 1
-            for (int G = 3; G < 8; ++G) {
-                const int g = grp(G);
-                double nv = 0.0;
-                if (G >= 4) {
-                    const int g4 = grp(G - 4);
-                    while (*cprog < G - 3) __builtin_amdgcn_s_sleep(1);
-                    double p = 0.0;
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) { const int c = 16 * g4 + q + 4 * t; p += Ls[c * (TB + 1) + 16 * g + i] * xs[c]; }
-                    nv = quad_sum(p);
-                }
-                const int g3 = grp(G - 3);
-                double l3[4];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) l3[t] = Ls[(16 * g3 + q + 4 * t) * (TB + 1) + 16 * g + i];
-                while (*cprog < G - 2) __builtin_amdgcn_s_sleep(1);
-                double p = 0.0;
-#pragma unroll
-                for (int t = 0; t < 4; ++t) p += l3[t] * xs[16 * g3 + q + 4 * t];
-                nv += quad_sum(p);
-                if (q == 0) nearv[16 * g + i] = nv;
-                wave_lds_sync();
-                if (lane == 0) *np = G;
-                asm volatile("" ::: "memory");
-            }
-            if (lane == 0) *np = 8;
-        } else {
-            // far: one row each, every group solved at least five steps before the row's own
-            const int hrow = tid - 64;
-            const int G = FWD ? (hrow >> 4) : 7 - (hrow >> 4);  // the row's own group, in sweep order
-            double f = 0.0;
-#pragma unroll 1
-            for (int gi = 0; gi < 3; ++gi) {
-                const int g = grp(gi);
-                while (*cprog < gi + 1) __builtin_amdgcn_s_sleep(1);
-                if (gi <= G - 5) {
-#pragma unroll
-                    for (int c = 0; c < 16; ++c) f += Ls[(16 * g + c) * (TB + 1) + hrow] * xs[16 * g + c];
-                    far[hrow] = f;
-                }
-                wave_lds_sync();
-                if (lane == 0) hp[wave - 1] = gi + 1;
-                asm volatile("" ::: "memory");
-            }
-        }
-        __syncthreads();
-        if (ts && tid == 0) ts[4 * r + 2] = clock64();  // diagonal block solved
-        if (tid < TB) {
-            if (tid < nrows) st_agent(x + row0 + tid, bs[tid]);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __syncthreads();
-        if (tid == 0) __hip_atomic_store(flags + r, token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (ts && tid == 0) ts[4 * r + 3] = clock64();  // published
-        return;
-    }
     if (W16) {
         // The diagonal step as a dataflow inside the workgroup, no barriers (round 2; two barriers per group of 16 cost 8 500 cycles per block,
         // more than the hand-off between the blocks).  Groups of 16 columns, gi = position in sweep order; every wave has one job:
@@ -2099,25 +2429,7 @@ size_t trsv_flag_ints(int n) { return 2 * (size_t)div_up(n, TB) + 1; }
 // LLT: L y = b, L^T x = y with rdiag = 1/diag(L).  LDLt: unit L, then x *= rdiag (= 1/D), then unit L^T.
 // `flags` = trsv_flag_ints(n) ints of scratch (zeroed by the owner at allocation), `token` != 0 unique per call; nullptr, or more blocks than can be resident at once, falls back to
 // one launch per block step.
-constexpr int TRSV_SCALE_LDS_BYTES = (TB * (TB + 1) + 8 * 256) * (int)sizeof(double);
-size_t trsv_scaled_doubles(int n) { return 2 * (size_t)div_up(n, TB) * TB * TB; }
-// once per factorisation: the pre-scaled diagonal blocks of both sweeps, sblocks = [forward nblk x 128 x 128][backward nblk x 128 x 128]
-void launch_trsv_scale_blocks(const double* L, int ld, int n, const double* w16, double* sblocks, hipStream_t s)
-{
-    if (n <= 0) return;
-    static bool attr_set = false;
-    if (!attr_set) {
-        PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_trsv_scale_blocks<true>), hipFuncAttributeMaxDynamicSharedMemorySize, TRSV_SCALE_LDS_BYTES));
-        PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_trsv_scale_blocks<false>), hipFuncAttributeMaxDynamicSharedMemorySize, TRSV_SCALE_LDS_BYTES));
-        attr_set = true;
-    }
-    const int nblk = div_up(n, TB);
-    hipLaunchKernelGGL(k_trsv_scale_blocks<true>, dim3(nblk), dim3(256), TRSV_SCALE_LDS_BYTES, s, L, ld, n, w16, sblocks);
-    hipLaunchKernelGGL(k_trsv_scale_blocks<false>, dim3(nblk), dim3(256), TRSV_SCALE_LDS_BYTES, s, L, ld, n, w16, sblocks + (size_t)nblk * TB * TB);
-    PQ_HIP(hipGetLastError());
-}
-
-void launch_trsv(const double* L, int ld, int n, double* x, const double* rdiag, bool ldlt, int* flags, int token, const double* w16, hipStream_t s, long long* ts, const double* sblocks)
+void launch_trsv(const double* L, int ld, int n, double* x, const double* rdiag, bool ldlt, int* flags, int token, const double* w16, hipStream_t s, long long* ts)
 {
     if (n <= 0) return;
     static bool attr_set = false;
@@ -2135,11 +2447,9 @@ void launch_trsv(const double* L, int ld, int n, double* x, const double* rdiag,
         // layout: [fwd x flags nblk][bwd x flags nblk][err]; a block is published when its flag holds `token` (unique per call on this flag
         // array, never 0: the array is zeroed once, at allocation -- no memset per solve)
         int* err = flags + 2 * nblk;
-        const double* sf = (w16 && sblocks) ? sblocks : nullptr;
-        const double* sb = sf ? sblocks + (size_t)nblk * TB * TB : nullptr;
-        hipLaunchKernelGGL(k_trsv_persistent<true>, dim3(nblk), dim3(256), TRSV_P_LDS_BYTES, s, L, ld, n, x, rd, nblk, flags, err, w16, token, ts, sf);
+        hipLaunchKernelGGL(k_trsv_persistent<true>, dim3(nblk), dim3(256), TRSV_P_LDS_BYTES, s, L, ld, n, x, rd, nblk, flags, err, w16, token, ts);
         if (ldlt) hipLaunchKernelGGL(k_mul_vec, dim3(div_up(n, 256)), dim3(256), 0, s, n, rdiag, x);
-        hipLaunchKernelGGL(k_trsv_persistent<false>, dim3(nblk), dim3(256), TRSV_P_LDS_BYTES, s, L, ld, n, x, rd, nblk, flags + nblk, err, w16, token, (long long*)nullptr, sb);
+        hipLaunchKernelGGL(k_trsv_persistent<false>, dim3(nblk), dim3(256), TRSV_P_LDS_BYTES, s, L, ld, n, x, rd, nblk, flags + nblk, err, w16, token, (long long*)nullptr);
     } else {
         for (int j = 0; j < nblk; ++j)
             hipLaunchKernelGGL(k_trsv_fwd_step, dim3(nblk - j), dim3(256), TRSV_LDS_BYTES, s, L, ld, n, x, rd, j);

@@ -47,6 +47,13 @@ struct SyrkArgs {
     int* fuse_cnt = nullptr;        // 8 monotonic counters: what potrf_block has published of its step k (see there); non-null = the workgroups of the first
                                     // tile column solve the next panel in this launch, following the factorisation of the diagonal block
     double* fuse_w16 = nullptr;   // inverted 16 x 16 diagonal pieces of the next diagonal block (8 x 256 doubles), kept for the sweeps; nullable
+    int* fuse_xpub = nullptr;     // persistent launch only: counter the first panel row bumps (once per wave) for every 16-column slice it has published
+    const int* fuse_xcnt = nullptr; // ... and the counter the crew of the next diagonal block follows (its operand arrives slice by slice), with its base value
+    int fuse_xwant = 0;
+    double* fuse_side = nullptr;    // persistent launch only: the side copy of the panel being solved (same leading dimension and offsets as C)
+    long long* fuse_tr2 = nullptr;  // debugging aid (PIQP_AMD_DEBUG=chol_trace): wall-clock stamps of the hand-over between the first panel row and the next crew
+    long long* fuse_tr2n = nullptr;
+    int* fuse_abort = nullptr;    // persistent launch only: a word any workgroup sets when a bounded wait gave up; the waits inside poll it
     long long* fuse_ts = nullptr; // debugging aid (PIQP_AMD_DEBUG=fused_ts=<panel>): 96 clock stamps -- the workgroup that owns the next diagonal block, the first panel
                                   // workgroup, an ordinary tile
 };
@@ -63,13 +70,15 @@ void launch_potrf_diag(bool ldlt, double* A, int lda, int nb, int kglobal, int* 
 double microbench_potrf_block(bool ldlt, int reps, long long* stamps64, hipStream_t s);
 // rows k0 + nb .. n of the panel at column k0:  A21 <- A21 L11^-T (D^-1), with the pack written by the factorisation of L11
 void launch_trsm_panel(bool ldlt, double* A, int lda, int k0, int nb, int n, const double* pack, const double* rdiag, hipStream_t s);
+// the persistent factorisation (k_chol_persistent, dense_kernels.hip): every round after the first diagonal block and panel in one launch
+bool chol_persistent_supported(int n);
+bool chol_prepare(int n);      // builds the device task list of this size (allocates: call at create time); false = use the launch-per-panel path
+size_t chol_flag_ints(int n);  // ints of flag storage, zeroed once at allocation
+bool launch_chol_persistent(bool ldlt, double* A, double* side, int lda, int n, int* info, double* rdiag, double* dvec, double* pack2, double* w16, double* scratch, int* fuse_flags, int* fuse_cnt,
+                            int token_base, int* flags, int gen, int fcount, hipStream_t s);
 size_t trsv_flag_ints(int n);
 // w16: the inverted 16 x 16 diagonal pieces written by the factorisation (8 x 256 doubles per 128-column panel), nullptr: substitution only
-// sblocks (nullable): the pre-scaled diagonal blocks of launch_trsv_scale_blocks (trsv_scaled_doubles(n) doubles), refreshed after every factorisation
-void launch_trsv(const double* L, int ld, int n, double* x, const double* rdiag, bool ldlt, int* flags, int token, const double* w16, hipStream_t s, long long* ts = nullptr,
-                 const double* sblocks = nullptr);  // ts: debugging aid, 4 stamps per block of the forward sweep
-size_t trsv_scaled_doubles(int n);
-void launch_trsv_scale_blocks(const double* L, int ld, int n, const double* w16, double* sblocks, hipStream_t s);
+void launch_trsv(const double* L, int ld, int n, double* x, const double* rdiag, bool ldlt, int* flags, int token, const double* w16, hipStream_t s, long long* ts = nullptr);  // ts: debugging aid, 4 stamps per block of the forward sweep
 int gemv_n_slices(int rows, int cols);
 int launch_gemv_n_partial(int rows, int cols, const double* M, int ld, const double* v, const double* scale, double alpha, double* part, hipStream_t s);
 void launch_reduce_partials(int rows, int nslices, const double* part, const double* base, double* y, hipStream_t s);

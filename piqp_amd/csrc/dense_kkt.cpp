@@ -77,7 +77,6 @@ public:
         prof_.end(0, t0, st_);
         int t1 = prof_.begin(1, st_);
         launch_factor_panels();
-        if (sblocks_.p) dense::launch_trsv_scale_blocks(fac_.p, n_, n_, w16_.p, sblocks_.p, st_);  // part of the factorisation: what the sweeps multiply by
         prof_.end(1, t1, st_);
         return factor_status();
     }
@@ -95,7 +94,7 @@ public:
         if (p_ > 0) nsl += dense::launch_gemv_n_partial(n_, p_, AT_.p, n_, rhs_y, nullptr, delta_inv, part_.p + (size_t)nsl * n_, st_);
         dense::launch_reduce_partials(n_, nsl, part_.p, rhs_x, lhs_x, st_);
         // solve_ldlt_in_place: llt.solveInPlace(lhs_x)
-        { const int tt = prof_.begin(5, st_); dense::launch_trsv(fac_.p, n_, n_, lhs_x, rdiag_.p, ldlt_, flags_.p, next_trsv_token(), w16_.p, st_, trsv_ts_.p, sblocks_.p);
+        { const int tt = prof_.begin(5, st_); dense::launch_trsv(fac_.p, n_, n_, lhs_x, rdiag_.p, ldlt_, flags_.p, next_trsv_token(), w16_.p, st_, trsv_ts_.p);
           if (trsv_ts_.p) dump_trsv_ts(); prof_.end(5, tt, st_); }
         // lhs_y = delta_inv * AT^T lhs_x - delta_inv * rhs_y
         if (p_ > 0) dense::launch_gemv_t(n_, p_, AT_.p, n_, lhs_x, delta_inv, -delta_inv, rhs_y, nullptr, lhs_y, st_);
@@ -173,7 +172,7 @@ private:
         alloc();
         auto cp = [&](DBuf<double>& dst, const DBuf<double>& src) { if (src.n) PQ_HIP(hipMemcpyAsync(dst.p, src.p, src.bytes(), hipMemcpyDeviceToDevice, st_)); };
         cp(Pfull_, o.Pfull_); cp(Pdiag_, o.Pdiag_); cp(AT_, o.AT_); cp(GT_, o.GT_); cp(ATA_, o.ATA_); cp(fac_, o.fac_);
-        cp(z_reg_inv_, o.z_reg_inv_); cp(x_reg_last_, o.x_reg_last_); cp(rdiag_, o.rdiag_); cp(w16_, o.w16_); cp(sblocks_, o.sblocks_);
+        cp(z_reg_inv_, o.z_reg_inv_); cp(x_reg_last_, o.x_reg_last_); cp(rdiag_, o.rdiag_); cp(w16_, o.w16_);
         PQ_HIP(hipStreamSynchronize(st_));
     }
 
@@ -191,10 +190,13 @@ private:
         pack_.alloc(dense::FACTOR_PACK_DOUBLES);
         fuse_scratch_.alloc(dense::FACTOR_PACK_DOUBLES); fuse_flags_.alloc(16); fuse_flags_.zero(st_); fuse_cnt_.alloc(8); fuse_cnt_.zero(st_);
         w16_.alloc((size_t)((n_ + 127) / 128) * 8 * 256);  // inverted 16 x 16 diagonal pieces of the whole factor (potrf_block -> launch_trsv)
-        if (!debug_token("trsv_unscaled")) { sblocks_.alloc(dense::trsv_scaled_doubles(n_)); sblocks_.zero(st_); }  // pre-scaled diagonal blocks of the sweeps (PIQP_AMD_DEBUG=trsv_unscaled: the round-2 diagonal step)
         dense::syrk_prepare(n_);
         info_.alloc(1);
-        info_h_.alloc(1);
+        info_h_.alloc(2);
+        info_h_.p[0] = -1; info_h_.p[1] = 0;
+        // PIQP_AMD_DEBUG=chol_launches: the launch-per-panel factorisation for every size (the bitwise comparison of tests/test_dense_gpu.py)
+        chol_persistent_ = !debug_token("chol_launches") && dense::chol_prepare(n_);
+        if (chol_persistent_) { side_.alloc((size_t)n_ * n_); pack2_.alloc(2 * (size_t)dense::FACTOR_PACK_DOUBLES); chol_flags_.alloc(dense::chol_flag_ints(n_)); chol_flags_.zero(st_); }
         flags_.alloc(dense::trsv_flag_ints(n_)); flags_.zero(st_);
         if (debug_token("trsv_ts")) { trsv_ts_.alloc(4 * ((n_ + 127) / 128) + 8); trsv_ts_.zero(st_); }
         if (const char* e = debug_token("fused_ts")) { dbg_panel_ = std::atoi(e); dbg_ts_.alloc(96); dbg_ts_.zero(st_); }
@@ -242,6 +244,21 @@ private:
     {
         PQ_HIP(hipMemsetAsync(info_.p, 0xFF, sizeof(int), st_));  // -1
         const int NB = dense::FACTOR_NB;
+        if (chol_persistent_) {
+            // first diagonal block and first panel by their own launches, every round after them in ONE persistent launch (k_chol_persistent)
+            dense::launch_potrf_diag(ldlt_, fac_.p, n_, NB, 0, info_.p, rdiag_.p, dvec_.p, pack_.p, w16_.p, st_);
+            { const int tt = prof_.begin(4, st_); dense::launch_trsm_panel(ldlt_, fac_.p, n_, 0, NB, n_, pack_.p, rdiag_.p, st_); prof_.end(4, tt, st_); }
+            const int T = n_ / NB;
+            if (chol_gen_ > 0x3fffffff - 2 * (T + 2)) { chol_flags_.zero(st_); chol_gen_ = 0; chol_fcount_ = 0; }  // (flag values are compared as signed differences)
+            chol_gen_ += T + 2;
+            const int tt = prof_.begin(3, st_);
+            dense::launch_chol_persistent(ldlt_, fac_.p, side_.p, n_, n_, info_.p, rdiag_.p, dvec_.p, pack2_.p, w16_.p, fuse_scratch_.p, fuse_flags_.p, fuse_cnt_.p, fuse_token_, chol_flags_.p, chol_gen_,
+                                          chol_fcount_, st_);
+            prof_.end(3, tt, st_);
+            fuse_token_ += T - 1;
+            ++chol_fcount_;
+            return;
+        }
         int p = 0;
         for (int k = 0; k < n_; k += NB, ++p) {
             const int nb = (n_ - k < NB) ? n_ - k : NB;
@@ -286,7 +303,16 @@ private:
     bool factor_status()
     {
         PQ_HIP(hipMemcpyAsync(info_h_.p, info_.p, sizeof(int), hipMemcpyDeviceToHost, st_));
+        if (chol_persistent_) PQ_HIP(hipMemcpyAsync(info_h_.p + 1, chol_flags_.p + 1, sizeof(int), hipMemcpyDeviceToHost, st_));  // the launch's abort word
         PQ_HIP(hipStreamSynchronize(st_));
+        if (chol_persistent_ && info_h_.p[1] != 0) {
+            // a bounded wait inside the persistent launch gave up (never seen on a healthy device): the cumulative counters of this handle are no longer
+            // consistent -- start them over, and report the factorisation as failed (the caller regularises and factors again)
+            chol_flags_.zero(st_); fuse_cnt_.zero(st_); fuse_flags_.zero(st_);
+            chol_gen_ = 0; chol_fcount_ = 0; fuse_token_ = 0;
+            PQ_HIP(hipStreamSynchronize(st_));
+            return false;
+        }
         return info_h_.p[0] == -1;
     }
 
@@ -294,8 +320,11 @@ private:
     bool ldlt_;
     double delta_ = 1.0;
     hipStream_t st_ = nullptr;
-    DBuf<double> Pfull_, Pdiag_, AT_, GT_, ATA_, fac_, z_reg_inv_, x_reg_last_, dvec_, part_, rdiag_, split_ws_, pack_, w16_, fuse_scratch_, sblocks_;
-    DBuf<int> info_, flags_, fuse_flags_, fuse_cnt_;
+    DBuf<double> Pfull_, Pdiag_, AT_, GT_, ATA_, fac_, z_reg_inv_, x_reg_last_, dvec_, part_, rdiag_, split_ws_, pack_, w16_, fuse_scratch_;
+    DBuf<int> info_, flags_, fuse_flags_, fuse_cnt_, chol_flags_;
+    DBuf<double> pack2_, side_;  // side_: the solved panels once more, at addresses the persistent launch has never read before (dense_kernels.hip)
+    bool chol_persistent_ = false;
+    int chol_gen_ = 0, chol_fcount_ = 0;
     int fuse_token_ = 0, trsv_token_ = 0;
     int next_trsv_token()
     {
