@@ -209,12 +209,18 @@ def main():
             ach = flops_per_step / secs_per_step / 1e12 if secs_per_step > 0 else 0.0
             return {"bound": "mfma", "kernel": kernel, "achieved": ach, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP64_MFMA_TFLOPS,
                     "traffic": traffic, "traffic_source": src, "alg_flops_per_launch": flops_per_step / max(launches_per_step, 1),
-                    "avg_launch_ms": secs_per_step * 1e3 / max(launches_per_step, 1), "launches_per_step": launches_per_step, "ms_per_step": secs_per_step * 1e3,
-                    "frac_of_measured_mfma_peak": ach / tf.value if tf.value > 0 else None}
+                    "avg_launch_ms": secs_per_step * 1e3 / max(launches_per_step, 1), "launches_per_step": launches_per_step, "ms_per_step": secs_per_step * 1e3}
         r_asm = roof("k_syrk_lower<EPI_ASSEMBLE> (dense/kkt.hpp:140-160 update_kkt); hipEvent-bracketed in the timed region", flops_asm, asm_s, 1, "assembly")
-        r_upd = roof("k_syrk_lower<EPI_SUBTRACT_POTRF> = one launch per panel: trailing (panel) update of the factorisation + factorisation of the next diagonal "
-                     "block + substitution of the next panel behind it (dense/ldlt_no_pivot.hpp:313-354, Eigen::LLT at dense/kkt.hpp:82); hipEvent-bracketed per "
-                     "launch in a separate pass of the same steps", flops_upd, upd_s, upd_launches, "panel_update")
+        persistent = kk["fused_launches_per_step"] < 1.5  # round 3: every round of the factorisation after the first diagonal block / panel in ONE launch
+        if persistent:
+            r_upd = roof("k_chol_persistent = the whole blocked factorisation after its first diagonal block and panel in ONE persistent launch: for every panel the "
+                         "trailing (panel) update, the factorisation of the next diagonal block and the substitution of the next panel behind it, as a ticket-ordered "
+                         "task list with look-ahead (dense/ldlt_no_pivot.hpp:313-354, Eigen::LLT at dense/kkt.hpp:82); hipEvent-bracketed in a separate pass of "
+                         "the same steps", flops_upd, upd_s, 1, "panel_update")
+        else:
+            r_upd = roof("k_syrk_lower<EPI_SUBTRACT_POTRF> = one launch per panel: trailing (panel) update of the factorisation + factorisation of the next diagonal "
+                         "block + substitution of the next panel behind it (dense/ldlt_no_pivot.hpp:313-354, Eigen::LLT at dense/kkt.hpp:82); hipEvent-bracketed per "
+                         "launch in a separate pass of the same steps", flops_upd, upd_s, upd_launches, "panel_update")
         dominant, secondary = (r_upd, r_asm) if upd_s >= asm_s else (r_asm, r_upd)
         out = {
             "metric": "KKT factor+solve/sec (per IPM iter)",

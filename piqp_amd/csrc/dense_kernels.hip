@@ -173,8 +173,8 @@ __device__ __forceinline__ void tile_store(double* __restrict__ blk, int lane, d
 constexpr int FUSE_ROLES = 9, FUSE_OWN = 4;  // workgroups that share the next diagonal block of a fused trailing update (owner + 8 helpers), blocks per workgroup
 template <int NT, bool PERSIST>
 __device__ __forceinline__ bool fused_next_diag(const SyrkArgs& a, double* __restrict__ smem, int role);
-template <int NT, int MTC, int MTR, bool PERSIST>
-__device__ __forceinline__ bool panel_follow(const SyrkArgs& a, double* __restrict__ smem, const d4 (&acc)[MTC][MTR], int row0, int wr, int wc);
+template <int NT, int MTC, int MTR, bool PERSIST, int NSTRIP>
+__device__ __forceinline__ bool panel_follow(const SyrkArgs& a, double* __restrict__ smem, const d4 (&acc)[MTC][MTR], int row0, int wr, int wc, bool first_row);
 // the fused next-panel factorisation: its workgroups stage a whole 128 x 128 operand panel (147 KB: one workgroup per CU, which the kernel's
 // 147 VGPRs impose anyway); the 36 tile blocks + 64 doubles of pivots reuse that LDS afterwards
 constexpr int FUSED_LDS_BYTES = (128 * (128 + 16) + 128) * 8;  // whole operand panel of the next diagonal block + D; the tile blocks reuse it
@@ -188,16 +188,21 @@ constexpr int FUSED_LDS_BYTES = (128 * (128 + 16) + 128) * 8;  // whole operand 
 // written by other workgroups of the same launch, so they are read with agent-scope loads and written through (sc1) -- MI355X_MICROARCH.md,
 // inter-workgroup visibility -- and the caller publishes a flag afterwards.  n is a multiple of 128 there (no edge tiles).  Returns false when a
 // bounded wait inside gave up.
-template <int NT, bool PERSIST>
-__device__ __forceinline__ bool fused_tile(const SyrkArgs& a, const int ti, const int tj, double* __restrict__ smem)
+// HALF (persistent launch, panel tiles only): the workgroup takes rows [64 h, 64 h + 64) of the tile -- the eight waves as 2 x 4 (32 x 32 each) for the
+// update, four strip waves for the substitution.  A panel row's task of round k needs that row's output of round k - 1, so update + substitution of ONE
+// workgroup (28 + 13 us for a whole tile) bound the round from below whatever the diagonal block does; two workgroups per row halve both.  Every element
+// receives the same products in the same order as in the whole-tile form.
+template <int NT, bool PERSIST, bool HALF = false>
+__device__ __forceinline__ bool fused_tile(const SyrkArgs& a, const int ti, const int tj, double* __restrict__ smem, const int h = 0)
 {
-    constexpr int WR = 4, WC = 2;
-    static_assert(NT == 64 * WR * WC, "4 x 2 waves");
-    constexpr int MTR = 8 / WR, MTC = 8 / WC;
-    constexpr int SUBR = TS / WR, SUBC = TS / WC;
+    constexpr int WR = HALF ? 2 : 4, WC = HALF ? 4 : 2;
+    static_assert(NT == 64 * WR * WC, "eight waves");
+    constexpr int MTR = 2, MTC = HALF ? 2 : 4;
+    constexpr int SUBR = 32, SUBC = HALF ? 32 : 64;
+    constexpr int ROWS = HALF ? 64 : TS;  // rows of the tile this workgroup works on
     double* As = smem;                    // [2][BK][LDS_LD]
     double* Bs = smem + 2 * BK * LDS_LD;  // [2][BK][LDS_LD]
-    const int row0 = ti * TS, col0 = tj * TS;
+    const int row0 = ti * TS + (HALF ? 64 * h : 0), col0 = tj * TS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave / WC, wc = wave % WC;
     const bool edge = !PERSIST && ((row0 + TS > a.n) || (col0 + TS > a.n) || a.unaligned);
@@ -227,6 +232,8 @@ __device__ __forceinline__ bool fused_tile(const SyrkArgs& a, const int ti, cons
     }
     const bool dbg_tile = FUSE_TS_ON && !PERSIST && a.fuse_ts && threadIdx.x == 0 && ti == 2 && tj == 1;  // debugging aid: an ordinary tile's timeline
     if (dbg_tile) a.fuse_ts[84] = clock64();
+    const bool tr_tile = PERSIST && !HALF && a.fuse_tr2 && threadIdx.x == 0 && ti == 5 && tj == 3;  // PIQP_AMD_DEBUG=chol_trace: one bulk tile per round
+    if (tr_tile) a.fuse_tr2[40] = wall_clock64();
     const int nkt = (a.kdim + BK - 1) / BK;  // <= 8
     {
         constexpr int PER = 1024 / NT;
@@ -235,7 +242,12 @@ __device__ __forceinline__ bool fused_tile(const SyrkArgs& a, const int ti, cons
         for (int kt = 0; kt < 8; ++kt) {
             if (kt < nkt) {
                 const int k0 = kt * BK;
-                if constexpr (PERSIST && AGENT_OPERANDS) {
+                if constexpr (HALF) {
+                    // 64 rows of the row operand (the upper half of the stage stays unused), the whole column operand
+                    if ((tid & 63) < 32) load_tile<false, NT>(a.A, a.lda, row0, k0, a.n, a.kdim, tid, pa[kt]);
+                    else { for (int it = 0; it < PER; ++it) pa[kt][it] = (d2){0.0, 0.0}; }
+                    load_tile<false, NT>(a.B, a.ldb, col0, k0, a.n, a.kdim, tid, pb[kt]);
+                } else if constexpr (PERSIST && AGENT_OPERANDS) {
                     load_tile_agent<NT>(a.A, a.lda, row0, k0, tid, pa[kt]); load_tile_agent<NT>(a.B, a.ldb, col0, k0, tid, pb[kt]);
                 } else {
                     if (edge || (k0 + BK > a.kdim)) { load_tile<true, NT>(a.A, a.lda, row0, k0, a.n, a.kdim, tid, pa[kt]); load_tile<true, NT>(a.B, a.ldb, col0, k0, a.n, a.kdim, tid, pb[kt]); }
@@ -250,6 +262,7 @@ __device__ __forceinline__ bool fused_tile(const SyrkArgs& a, const int ti, cons
         }
         __syncthreads();
         if (dbg_tile) a.fuse_ts[85] = clock64();  // first operand stage in LDS
+        if (tr_tile) a.fuse_tr2[41] = wall_clock64();
 #pragma unroll
         for (int kt = 0; kt < 8; ++kt) {
             if (kt < nkt) {
@@ -282,7 +295,8 @@ __device__ __forceinline__ bool fused_tile(const SyrkArgs& a, const int ti, cons
         }
     }
     if (dbg_tile) a.fuse_ts[86] = clock64();  // K loop done (the accumulators' first use waited for C)
-    if (a.fuse_cnt && tj == 0 && a.fuse_pack) return panel_follow<NT, MTC, MTR, PERSIST>(a, smem, acc, row0, wr, wc);
+    if (tr_tile) a.fuse_tr2[42] = wall_clock64();
+    if (a.fuse_cnt && tj == 0 && a.fuse_pack) return panel_follow<NT, MTC, MTR, PERSIST, ROWS / 16>(a, smem, acc, row0, wr, wc, ti == 1);
     if (skip_wave) return true;
     // epilogue: lane holds rows gi (consecutive over lane&15) and columns gj = base + (lane>>4) + 4*r; the accumulator started from C
 #pragma unroll
@@ -302,6 +316,7 @@ __device__ __forceinline__ bool fused_tile(const SyrkArgs& a, const int ti, cons
         }
     }
     if (dbg_tile) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); a.fuse_ts[87] = clock64(); }  // stores drained
+    if (tr_tile) { a.fuse_tr2[43] = wall_clock64(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); a.fuse_tr2[44] = wall_clock64(); }
     return true;
 }
 
@@ -1216,7 +1231,15 @@ __device__ __forceinline__ bool fused_next_diag(const SyrkArgs& a, double* __res
     double* ws = smem + TS * LDS_LD;         // -D of the panel (LLT: -1), after the operand panel
     d4 acc;
     d4 p1 = {0.0, 0.0, 0.0, 0.0}, p2 = p1, p3 = p1;
-    const bool progressive = PERSIST && a.fuse_xcnt != nullptr;
+    bool progressive = PERSIST && a.fuse_xcnt != nullptr;
+    if (progressive) {
+        // (a crew that arrives when the whole row is already published -- its own tile came late -- takes the one-shot path below: one round of loads
+        // instead of eight; same products, same order)
+        __shared__ int all_s;
+        if (tid == 0) all_s = (ldi_agent(a.fuse_xcnt + 7) - a.fuse_xwant >= 0) ? 1 : 0;
+        __syncthreads();
+        if (all_s) progressive = false;
+    }
     if (progressive) {
         // Persistent launch, rounds >= 1: the operand (block row k + 1 of panel k) is being solved RIGHT NOW by the first panel workgroup of the round
         // before, behind the factorisation of that round's diagonal block; it publishes every 16-column slice as it becomes final (panel_follow: write-through
@@ -1239,7 +1262,7 @@ __device__ __forceinline__ bool fused_next_diag(const SyrkArgs& a, double* __res
             if (tid == 0) {
                 int ok = 1;
                 unsigned spins = 0;
-                while (ldi_agent(a.fuse_xcnt) - (a.fuse_xwant + 8 * (kt + 1)) < 0) {
+                while (ldi_agent(a.fuse_xcnt + kt) - a.fuse_xwant < 0) {  // (one counter per slice: the strip waves of the row run independently of each other)
                     __builtin_amdgcn_s_sleep(2);
                     if (++spins > 20000000u || ((spins & 1023u) == 0 && a.fuse_abort && ldi_agent(a.fuse_abort) != 0)) { ok = 0; break; }
                 }
@@ -1360,10 +1383,11 @@ __device__ __forceinline__ bool fused_next_diag(const SyrkArgs& a, double* __res
 // step BEHIND the factorisation of the diagonal block, which workgroup 0 of this launch publishes step by step (potrf_block: pack + cnt).  The
 // panel is finished about one step after the diagonal block instead of one launch later (k_trsm_panel: 9.6 us + two launch boundaries).  Same
 // products in the same order as k_trsm_panel: bitwise the same panel.  Waits only target workgroups with lower block indices; bounded spins.
-template <int NT, int MTC, int MTR, bool PERSIST>
-__device__ __forceinline__ bool panel_follow(const SyrkArgs& a, double* __restrict__ smem, const d4 (&acc)[MTC][MTR], int row0, int wr, int wc)
+template <int NT, int MTC, int MTR, bool PERSIST, int NSTRIP>
+__device__ __forceinline__ bool panel_follow(const SyrkArgs& a, double* __restrict__ smem, const d4 (&acc)[MTC][MTR], int row0, int wr, int wc, bool first_row)
 {
-    static_assert(NT == 512 && MTR * 4 == 8 && MTC * 2 == 8, "eight waves, one 16-row strip each");
+    static_assert(NT == 512 && (NSTRIP == 8 || NSTRIP == 4), "eight waves; one 16-row strip per wave (NSTRIP = 4: a half tile, waves 4 .. 7 only help fetching)");
+    const bool strip = (threadIdx.x >> 6) < NSTRIP;  // this wave holds a strip
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, g = lane >> 4;
     double* Ts = smem;             // the tile as 8 x 8 block images (row block, column block)
@@ -1374,10 +1398,10 @@ __device__ __forceinline__ bool panel_follow(const SyrkArgs& a, double* __restri
     __syncthreads();
     d4 T[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) T[j] = tile_load(Ts + (wave * 8 + j) * 256, lane);
+    for (int j = 0; j < 8; ++j) T[j] = strip ? tile_load(Ts + (wave * 8 + j) * 256, lane) : (d4){0.0, 0.0, 0.0, 0.0};
     // persistent launch: the first block row below the diagonal block is the operand of the NEXT diagonal block's update -- its slices go out as they
     // become final (see fused_next_diag); every wave counts in fuse_xpub once per slice
-    const bool publish = PERSIST && a.fuse_xpub != nullptr && row0 == TS;
+    const bool publish = PERSIST && a.fuse_xpub != nullptr && first_row;
     const bool dbg = FUSE_TS_ON && !PERSIST && a.fuse_ts && tid == 0 && row0 == TS;  // debugging aid: stamps of the first panel workgroup at fuse_ts[72..]
     if (dbg) a.fuse_ts[80] = clock64();
     // The operand blocks of a step are fetched when the factorisation has published them -- and with them those of every FURTHER step it has published by
@@ -1402,7 +1426,7 @@ __device__ __forceinline__ bool panel_follow(const SyrkArgs& a, double* __restri
                 int nb = 0;
                 for (int q = k; q < nxt; ++q) { blist[nb++] = 28 + q; for (int j = q + 1; j < 8; ++j) blist[nb++] = j * (j - 1) / 2 + q; }
                 have_s = ok ? nxt : -1; nblk_s = nb;
-                if (PERSIST && a.fuse_tr2 && row0 == TS) for (int q = k; q < nxt; ++q) a.fuse_tr2[32 + q] = wall_clock64();
+                if (PERSIST && a.fuse_tr2 && first_row && row0 == TS) for (int q = k; q < nxt; ++q) a.fuse_tr2[32 + q] = wall_clock64();
                 if (dbg) a.fuse_ts[72 + k] = clock64();
             }
             __syncthreads();
@@ -1427,6 +1451,7 @@ __device__ __forceinline__ bool panel_follow(const SyrkArgs& a, double* __restri
             }
             __syncthreads();
         }
+        if (!strip) continue;
         const d4 w = tile_load(Pk + (28 + k) * 256, lane);
         d4 x = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -1434,7 +1459,7 @@ __device__ __forceinline__ bool panel_follow(const SyrkArgs& a, double* __restri
         T[k] = x;
         if (publish) {
             // the slice published a step ago has had a whole step to reach memory: drain (cheap by now), tell the next crew, then send this one
-            if (k > 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (lane == 0) addi_agent(a.fuse_xpub, 1); }
+            if (k > 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (lane == 0) addi_agent(a.fuse_xpub + (k - 1), 1); }
             double* Cr = a.C + (row0 + wave * 16 + i);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -1444,7 +1469,7 @@ __device__ __forceinline__ bool panel_follow(const SyrkArgs& a, double* __restri
                 st_agent(Cr + (size_t)c * a.ldc, v);
                 st_agent(a.fuse_side + (row0 + wave * 16 + i) + (size_t)c * a.ldc, v);
             }
-            if (a.fuse_tr2 && tid == 0) a.fuse_tr2[k] = wall_clock64();
+            if (a.fuse_tr2 && tid == 0 && row0 == TS) a.fuse_tr2[k] = wall_clock64();
         }
 #pragma unroll
         for (int j = k + 1; j < 8; ++j) {
@@ -1454,14 +1479,15 @@ __device__ __forceinline__ bool panel_follow(const SyrkArgs& a, double* __restri
         }
     }
     if (publish) {
+        if (!strip) return true;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) addi_agent(a.fuse_xpub, 1);
-        if (a.fuse_tr2 && tid == 0) a.fuse_tr2[27] = wall_clock64();
+        if (lane == 0) addi_agent(a.fuse_xpub + 7, 1);
+        if (a.fuse_tr2 && tid == 0 && row0 == TS) a.fuse_tr2[27] = wall_clock64();
         if (dbg) a.fuse_ts[81] = clock64();
         return true;
     }
     const int row = row0 + wave * 16 + i;
-    if (row < a.n) {
+    if (strip && row < a.n) {
         double* Cr = a.C + row;
 #pragma unroll
         for (int j = 0; j < 8; ++j)
@@ -1488,15 +1514,25 @@ __device__ __forceinline__ bool panel_follow(const SyrkArgs& a, double* __restri
 // work is a TASK of a fixed, topologically ordered list, workgroups draw tickets from one counter and wait -- bounded -- only for results of
 // EARLIER tickets, so progress never depends on how many workgroups are resident (two factorisations on two streams, a busy device).  The
 // order puts the next round's critical tasks right behind what they need:
-//   ... bulk(k-1, first tile column)  crew(k)  panel(k)  bulk(k-1, other columns)  bulk(k, first tile column)  crew(k+1)  panel(k+1) ...
-// so the diagonal-block chain of round k+1 starts as soon as ITS inputs exist (look-ahead), while the bulk tiles of round k are still running.
+//   crew(0) panel(0) bulk(0, col 1) | crew(1) panel(1) bulk(0, cols >= 2) bulk(1, col 1) | crew(2) panel(2) bulk(1, cols >= 2) bulk(2, col 1) | ...
+// so the diagonal-block chain of round k + 1 starts as soon as ITS inputs exist (look-ahead) while the bulk tiles of round k are still running.  A
+// ticket is drawn only when its `gate` is open -- that many rounds have all their panel tasks finished, one word every idle workgroup polls with a
+// long sleep --: crew and panel tasks are let in a round early (the crew follows the slices of its operand as they are published, a panel task
+// waits for its own two rows), everything else when the panel it reads is complete.
 // What crosses workgroups inside the launch is written through (sc1) and read with agent-scope loads, and published by one word per unit:
-//   lready[k T + i]  block row i of panel k is final (written by its panel task, or before the launch for k = 0);
+//   lready[k T + i]  panel tasks of block row i of panel k that have finished (split(k - 1) per row; panel 0 is solved before the launch);
 //   tver[i T + j]    number of trailing updates tile (i, j) has received;
 //   pdone[k]         panel tasks of round k that have finished (the owner of round k + 2 reuses their operand-pack buffer);
-// all as launch-unique values (gen + ...), so nothing is reset between factorisations.  Every tile receives the same products in the same
-// order as in the launch-per-panel path: bitwise the same factor (tests/test_dense_gpu.py).
-struct CholTask { short kind, round, a, b; };  // kind 0: helper (role a) / 1: owner / 2: panel tile (a, 0) / 3: bulk tile (a, b) of round `round`
+// as launch-unique or cumulative values, so nothing is reset between factorisations.  Every tile receives the same products in the same
+// order as in the launch-per-panel path: bitwise the same factor (tools/chk_chol_persistent.py, tests/test_dense_gpu.py).
+struct CholTask {
+    short kind, round, a, b;  // kind 0: helper (role a) / 1: owner / 2: panel tile (a, 0), half b (-1: the whole tile) / 3: bulk tile (a, b) of round `round`
+    int gate;                 // panel rounds that must be complete before the ticket is drawn
+};
+// workgroups per panel tile: a row's task of round k needs that row's output of round k - 1, so one workgroup's update + substitution (28 + 13 us for a
+// whole tile) bound a round from below; halves (fused_tile<HALF>) keep that under the diagonal block's 30 us.  Early rounds are bound by the bulk
+// tiles anyway and keep whole tiles (half as many workgroups parked on the chain).
+__host__ __device__ inline int chol_split(int T, int k) { (void)T; (void)k; return 2; }
 struct CholArgs {
     double* A; double* side; int lda, n, T, ldlt;
     int* info; double* rdiag; double* dvec; double* pack2; double* w16;
@@ -1504,11 +1540,8 @@ struct CholArgs {
     const CholTask* tasks; int ntasks;
     int* ticket;   // [0] next ticket, [1] abort
     int* lready; int* tver; int* pdone;
-    int* xcnt;            // per round: slices of the first panel row published so far (x 8 waves), cumulative over the factorisations of this handle
+    int* xcnt;            // per round and slice: strip waves of the first panel row that have published the slice, cumulative over the factorisations of this handle
     int* progress;        // gen + number of rounds whose panel tasks have ALL finished (they finish in round order)
-    const int* limits;    // limits[P]: tickets below this index have every panel they need once P rounds are complete (plus the crew and panel tasks of the
-                          // round after, which take their places early); a workgroup draws no ticket beyond it -- it sleeps on `progress` instead of polling
-                          // the words of a task several rounds away (a grid of pollers slowed the write-through traffic of the critical workgroup)
     int gen;       // launch-unique base of the flag values
     int fcount;    // persistent factorisations this handle has run before this one (pdone counters are cumulative)
     long long* trace;  // debugging aid (PIQP_AMD_DEBUG=chol_trace), nullable: per ticket 4 x wall_clock64 (100 MHz): drawn, inputs ready, done; [3] = workgroup id
@@ -1561,31 +1594,39 @@ __device__ __noinline__ bool chol_role_tile(const SyrkArgs& a, int ti, int tj)
     const SyrkArgs b = a;
     return fused_tile<CHOL_THREADS, true>(b, ti, tj, smem);
 }
+__device__ __noinline__ bool chol_role_half(const SyrkArgs& a, int ti, int h)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const SyrkArgs b = a;
+    return fused_tile<CHOL_THREADS, true, true>(b, ti, 0, smem, h);
+}
 __global__ __launch_bounds__(CHOL_THREADS, 2) void k_chol_persistent(CholArgs c)
 {
     __shared__ int s_ticket;
     const int tid = threadIdx.x;
     int* abort_w = c.ticket + 1;
-    const int T = c.T, NB = FACTOR_NB;
+    const int T = c.T, NB = FACTOR_NB, ntasks = c.ntasks;
     for (;;) {
         if (tid == 0) {
+            // Thread 0 draws the next ticket -- by fetch_add (a compare-and-swap on the head serialises a grid of drawers: 18 ms per factorisation,
+            // measured) and only while the head's gate is open: an idle workgroup sleeps on `progress` instead of parking on a task a round away and
+            // polling its words.  A ticket drawn past the gate in a race is still served: inside a task a workgroup only ever waits for EARLIER tickets.
             int t = -1;
             unsigned spins = 0;
             for (;;) {
-                const int P = min(max(__hip_atomic_load(c.progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - c.gen, 0), T - 1);
-                const int lim = c.limits[P];
-                const int cur = __hip_atomic_load(c.ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (cur >= c.ntasks) { t = c.ntasks; break; }
-                if (cur < lim) { t = __hip_atomic_fetch_add(c.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }  // (a ticket drawn past the limit in a race is still served)
-                __builtin_amdgcn_s_sleep(127);
-                if (__hip_atomic_load(abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 || ++spins > 4000000u) { t = c.ntasks; break; }
+                const int P = max(ldi_agent(c.progress) - c.gen, 0);
+                const int cur = ldi_agent(c.ticket);
+                if (cur >= ntasks) { t = ntasks; break; }
+                if (c.tasks[cur].gate <= P) { t = addi_agent(c.ticket, 1); break; }
+                __builtin_amdgcn_s_sleep(127);  // (an idle workgroup polls rarely: a grid of pollers slows the write-through traffic of the chain)
+                if (((++spins & 15u) == 0 && ldi_agent(abort_w) != 0) || spins > 8000000u) { t = ntasks; break; }
             }
             s_ticket = t;
         }
         __syncthreads();
         const int t = s_ticket;
         __syncthreads();
-        if (t >= c.ntasks) return;
+        if (t >= ntasks) return;
         if (c.trace && tid == 0) { c.trace[4 * (size_t)t] = wall_clock64(); c.trace[4 * (size_t)t + 3] = blockIdx.x; }
         const CholTask tk = c.tasks[t];
         const int k = tk.round, kk = k * NB, rs = c.n - kk - NB;  // rs = order of the trailing matrix of round k (a multiple of 128, >= 128)
@@ -1601,16 +1642,16 @@ __global__ __launch_bounds__(CHOL_THREADS, 2) void k_chol_persistent(CholArgs c)
         a.fuse_w16 = c.w16 + (size_t)((kk + NB) / 16) * 256;
         a.fuse_token = c.token_base + k + 1; a.fuse_flags = c.fuse_flags; a.fuse_scratch = c.scratch; a.fuse_cnt = c.fuse_cnt;
         a.fuse_abort = abort_w;
-        // progressive hand-over of the first panel row: round k's panel task (1, 0) counts its published slices in xcnt[k] (8 waves x 8 slices per
-        // factorisation, cumulative); the crew of round k + 1 consumes them
-        a.fuse_xpub = c.xcnt + k;
-        a.fuse_xcnt = k > 0 ? c.xcnt + (k - 1) : nullptr;
-        a.fuse_xwant = c.fcount * 64;
-        a.fuse_tr2 = c.trace ? c.trace + 4 * (size_t)c.ntasks + 64 * (size_t)k : nullptr;         // stamps of round k's first panel row ...
-        a.fuse_tr2n = c.trace ? c.trace + 4 * (size_t)c.ntasks + 64 * (size_t)(k > 0 ? k - 1 : T) : nullptr;  // ... and of the crew that consumes it (round k's crew reads round k - 1's row)
+        // progressive hand-over of the first panel row: the strip waves of round k's panel tasks (1, 0) count every published slice s in xcnt[8 k + s]
+        // (8 waves per slice and factorisation, cumulative); the crew of round k + 1 consumes them
+        a.fuse_xpub = c.xcnt + 8 * (size_t)k;
+        a.fuse_xcnt = k > 0 ? c.xcnt + 8 * (size_t)(k - 1) : nullptr;
+        a.fuse_xwant = (c.fcount + 1) * 8;
+        a.fuse_tr2 = c.trace ? c.trace + 4 * (size_t)ntasks + 64 * (size_t)k : nullptr;         // stamps of round k's first panel row ...
+        a.fuse_tr2n = c.trace ? c.trace + 4 * (size_t)ntasks + 64 * (size_t)(k > 0 ? k - 1 : T) : nullptr;  // ... and of the crew that consumes it (round k's crew reads round k - 1's row)
         // absolute block coordinates of what this task touches: relative tile (ti, tj) of round k = absolute (k + 1 + ti, k + 1 + tj)
         const int* lr = c.lready + (size_t)k * T;   // panel k
-        const int ready = c.gen + 1;
+        const int ready = (c.fcount + 1) * (k > 0 ? chol_split(T, k - 1) : 1);  // (cumulative counters: panel k was solved by the split(k - 1) tasks per block row of round k - 1)
         bool ok = true;
         if (tk.kind <= 1) {
             // crew of the next diagonal block: its tile (k + 1, k + 1) must have received U_0 .. U_{k-1}; operand = block row k + 1 of panel k.  The
@@ -1618,7 +1659,7 @@ __global__ __launch_bounds__(CHOL_THREADS, 2) void k_chol_persistent(CholArgs c)
             const int d = k + 1;
             // (its operand, block row d of panel k, arrives slice by slice inside fused_next_diag)
             ok = chol_wait3(k > 0 ? c.tver + (size_t)d * T + d : nullptr, c.gen + k, nullptr, 0,
-                            (tk.kind == 1 && k >= 2) ? c.pdone + (k - 2) : nullptr, (c.fcount + 1) * (T - (k - 2) - 2), abort_w, 0);
+                            (tk.kind == 1 && k >= 2) ? c.pdone + (k - 2) : nullptr, (c.fcount + 1) * chol_split(T, k - 2) * (T - (k - 2) - 2), abort_w, 0);
             if (c.trace && tid == 0) c.trace[4 * (size_t)t + 1] = wall_clock64();
             if (ok) ok = chol_role_crew(a, tk.kind == 1 ? 0 : tk.a);
         } else {
@@ -1628,15 +1669,15 @@ __global__ __launch_bounds__(CHOL_THREADS, 2) void k_chol_persistent(CholArgs c)
             const int i = k + 1 + ti, j = k + 1 + tj;
             ok = chol_wait3(k > 0 ? c.tver + (size_t)i * T + j : nullptr, c.gen + k, k > 0 ? lr + i : nullptr, ready, k > 0 ? lr + j : nullptr, ready, abort_w, panel ? 0 : 1);
             if (c.trace && tid == 0) c.trace[4 * (size_t)t + 1] = wall_clock64();
-            if (ok) ok = chol_role_tile(a, ti, tj);
+            if (ok) ok = (panel && tk.b >= 0) ? chol_role_half(a, ti, tk.b) : chol_role_tile(a, ti, tj);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (ok && tid == 0) {
                 if (panel) {
-                    __hip_atomic_store(c.lready + (size_t)(k + 1) * T + i, ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const int before = __hip_atomic_fetch_add(c.pdone + k, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    addi_agent(c.lready + (size_t)(k + 1) * T + i, 1);
+                    const int before = addi_agent(c.pdone + k, 1);
                     // the last panel task of the round: rounds complete in order (row i of panel k + 1 needs row i of panel k)
-                    if (before + 1 - (c.fcount + 1) * (T - k - 2) == 0) __hip_atomic_store(c.progress, c.gen + k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (before + 1 - (c.fcount + 1) * chol_split(T, k) * (T - k - 2) == 0) sti_agent(c.progress, c.gen + k + 1);
                 } else {
                     __hip_atomic_store(c.tver + (size_t)i * T + j, c.gen + k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
@@ -1651,46 +1692,46 @@ __global__ __launch_bounds__(CHOL_THREADS, 2) void k_chol_persistent(CholArgs c)
     }
 }
 
-// host side: the task list of a T x T tile grid (T >= 2), in ticket order
+// host side: the task list of a T x T tile grid (T >= 3), in ticket order.
+// (Tried and measured at n = 4096, factorisation ms in bench.py: this list 1.35-1.45; two queues -- crew, panel and first-column tiles in one served
+// first, the other tiles in a second, panel tasks drawn only when the round before is complete, a drawn task whose conditions do not hold yet held back --
+// 1.50: the rows start their update later than with the early draw, and that costs more than the parked workgroups it saves; drawing with a
+// compare-and-swap on the head, so that nobody overshoots a gate: 18 ms.)
+static void chol_build_tasks(int T, std::vector<CholTask>& H)
+{
+    H.clear();
+    auto crew_panel = [&](int k, int gate) {
+        const int Tk = T - k - 1, sp = chol_split(T, k);
+        for (int r = 1; r < FUSE_ROLES; ++r) H.push_back({0, (short)k, (short)r, 0, gate});
+        H.push_back({1, (short)k, 0, 0, gate});
+        for (int ti = 1; ti < Tk; ++ti) {
+            if (sp == 1) H.push_back({2, (short)k, (short)ti, -1, gate});
+            else for (int h = 0; h < sp; ++h) H.push_back({2, (short)k, (short)ti, (short)h, gate});
+        }
+    };
+    auto bulk = [&](int k, int tj_lo, int tj_hi, int gate) {  // tile columns tj_lo .. tj_hi - 1 of round k
+        const int Tk = T - k - 1;
+        for (int tj = tj_lo; tj < tj_hi && tj < Tk; ++tj)
+            for (int ti = tj; ti < Tk; ++ti) H.push_back({3, (short)k, (short)ti, (short)tj, gate});
+    };
+    crew_panel(0, 0);
+    bulk(0, 1, 2, 0);
+    for (int k = 1; k + 1 < T; ++k) {
+        crew_panel(k, k - 1);      // one round early: the crew follows the slices of its operand, a panel task waits for its own two rows
+        bulk(k - 1, 2, T, k - 1);  // needs panel k - 1: complete once k - 1 rounds are
+        bulk(k, 1, 2, k);          // needs panel k
+    }
+}
 size_t chol_task_count(int T)
 {
     size_t n = 0;
-    for (int k = 0; k + 1 < T; ++k) { const int Tk = T - k - 1; n += FUSE_ROLES + (size_t)(Tk - 1) + (size_t)Tk * (Tk - 1) / 2; }
+    for (int k = 0; k + 1 < T; ++k) { const int Tk = T - k - 1; n += FUSE_ROLES + (size_t)chol_split(T, k) * (Tk - 1) + (size_t)Tk * (Tk - 1) / 2; }
     return n;
-}
-static void chol_build_tasks(int T, std::vector<CholTask>& out, std::vector<int>& limits)
-{
-    out.clear();
-    limits.assign((size_t)T, 0);
-    auto crew_panel = [&](int k) {
-        const int Tk = T - k - 1;
-        for (int r = 1; r < FUSE_ROLES; ++r) out.push_back({0, (short)k, (short)r, 0});
-        out.push_back({1, (short)k, 0, 0});
-        if (Tk > 1) for (int ti = 1; ti < Tk; ++ti) out.push_back({2, (short)k, (short)ti, 0});
-    };
-    auto bulk = [&](int k, int tj_lo, int tj_hi) {  // tile columns tj_lo .. tj_hi - 1 of round k
-        const int Tk = T - k - 1;
-        for (int tj = tj_lo; tj < tj_hi && tj < Tk; ++tj)
-            for (int ti = tj; ti < Tk; ++ti) out.push_back({3, (short)k, (short)ti, (short)tj});
-    };
-    // crew(0) panel(0) bulk(0, col 1) | crew(1) panel(1) bulk(0, cols >= 2) bulk(1, col 1) | crew(2) panel(2) bulk(1, cols >= 2) bulk(2, col 1) | ...
-    // limits[P] = index of the first task of bulk(P + 1, first column): everything before it needs panels 0 .. P only
-    crew_panel(0);
-    bulk(0, 1, 2);
-    for (int k = 1; k + 1 < T; ++k) {
-        crew_panel(k);
-        bulk(k - 1, 2, T);
-        limits[(size_t)(k - 1)] = (int)out.size();
-        bulk(k, 1, 2);
-    }
-    bulk(T - 2, 2, T);  // (empty: the last round has a single tile)
-    for (int P = std::max(T - 2, 0); P < T; ++P) limits[(size_t)P] = (int)out.size();
 }
 
 struct CholPlan {
     int T = 0;
     CholTask* tasks = nullptr;  // device
-    int* limits = nullptr;      // device, T ints
     int ntasks = 0;
     int grid = 0;
 };
@@ -1707,8 +1748,7 @@ static const CholPlan* chol_plan(int T)
     CholPlan& P = cache[{dev, T}];
     P.T = T;
     std::vector<CholTask> h;
-    std::vector<int> lim;
-    chol_build_tasks(T, h, lim);
+    chol_build_tasks(T, h);
     if (h.size() != chol_task_count(T)) return nullptr;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_persistent), hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS_BYTES) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     int per_cu = 0, cus = 0;
@@ -1718,15 +1758,12 @@ static const CholPlan* chol_plan(int T)
     if (hipMalloc(&P.tasks, sizeof(CholTask) * h.size()) != hipSuccess) { (void)hipGetLastError(); P.tasks = nullptr; return nullptr; }
     ++alloc_counter();
     if (hipMemcpy(P.tasks, h.data(), sizeof(CholTask) * h.size(), hipMemcpyHostToDevice) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(P.tasks); P.tasks = nullptr; return nullptr; }
-    if (hipMalloc(&P.limits, sizeof(int) * lim.size()) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(P.tasks); P.tasks = nullptr; return nullptr; }
-    ++alloc_counter();
-    if (hipMemcpy(P.limits, lim.data(), sizeof(int) * lim.size(), hipMemcpyHostToDevice) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(P.tasks); P.tasks = nullptr; return nullptr; }
     P.ntasks = (int)h.size();
     return &P;
 }
 bool chol_persistent_supported(int n) { return n % FACTOR_NB == 0 && n / FACTOR_NB >= 3 && n / FACTOR_NB <= 1024; }
 bool chol_prepare(int n) { return chol_persistent_supported(n) && chol_plan(n / FACTOR_NB) != nullptr; }
-size_t chol_flag_ints(int n) { const size_t T = (size_t)(n / FACTOR_NB); return 2 + 2 * T * T + 2 * T + 1; }
+size_t chol_flag_ints(int n) { const size_t T = (size_t)(n / FACTOR_NB); return 4 + 2 * T * T + 9 * T + 1; }
 // Rounds 0 .. T - 2 of the blocked factorisation of the n x n lower triangle at A (the first diagonal block and the first panel are already
 // factored / solved: launch_potrf_diag + launch_trsm_panel).  flags: chol_flag_ints(n) ints zeroed at allocation; gen: launch-unique, advancing by
 // at least T + 2 per call; fcount: calls made before on this flag array; token_base: fused-launch tokens consumed so far (advances by T - 1).
@@ -1749,11 +1786,11 @@ bool launch_chol_persistent(bool ldlt, double* A, double* side, int lda, int n, 
     c.info = info; c.rdiag = rdiag; c.dvec = dvec; c.pack2 = pack2; c.w16 = w16;
     c.scratch = scratch; c.fuse_flags = fuse_flags; c.fuse_cnt = fuse_cnt; c.token_base = token_base;
     c.tasks = P->tasks; c.ntasks = P->ntasks;
-    c.ticket = flags; c.lready = flags + 2; c.tver = c.lready + (size_t)T * T; c.pdone = c.tver + (size_t)T * T; c.xcnt = c.pdone + T; c.progress = c.xcnt + T; c.limits = P->limits;
+    c.ticket = flags; c.lready = flags + 4; c.tver = c.lready + (size_t)T * T; c.pdone = c.tver + (size_t)T * T; c.xcnt = c.pdone + T; c.progress = c.xcnt + 8 * (size_t)T;
     c.gen = gen; c.fcount = fcount;
     c.trace = want_trace ? trace_d : nullptr;
     if (want_trace) PQ_HIP(hipMemsetAsync(trace_d, 0, trace_n * sizeof(long long), s));
-    PQ_HIP(hipMemsetAsync(flags, 0, 2 * sizeof(int), s));  // ticket counter and abort word
+    PQ_HIP(hipMemsetAsync(flags, 0, 4 * sizeof(int), s));  // the ticket counter and the abort word
     hipLaunchKernelGGL(k_chol_persistent, dim3(P->grid), dim3(CHOL_THREADS), FUSED_LDS_BYTES, s, c);
     PQ_HIP(hipGetLastError());
     if (want_trace) {
@@ -1790,6 +1827,8 @@ bool launch_chol_persistent(bool ldlt, double* A, double* side, int lda, int n, 
                 std::fprintf(stderr, " last counted %.1f | slices seen by the next owner", us(q[27]));
                 for (int u = 0; u < 8; ++u) std::fprintf(stderr, " %.1f", us(q[8 + u]));
                 std::fprintf(stderr, " | its products done %.1f, potrf start %.1f end %.1f, helper 1 published %.1f\n", us(q[16]), us(q[17]), us(q[18]), us(q[19]));
+                if (q[40]) std::fprintf(stderr, "[piqp_amd]    bulk tile (5, 3) of round %d: first stage in LDS +%.1f, K loop +%.1f, stores issued +%.1f, drained +%.1f us\n", k, (q[41] - q[40]) * 0.01,
+                                        (q[42] - q[41]) * 0.01, (q[43] - q[42]) * 0.01, (q[44] - q[43]) * 0.01);
             }
         }
     }

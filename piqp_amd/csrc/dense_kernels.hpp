@@ -47,7 +47,7 @@ struct SyrkArgs {
     int* fuse_cnt = nullptr;        // 8 monotonic counters: what potrf_block has published of its step k (see there); non-null = the workgroups of the first
                                     // tile column solve the next panel in this launch, following the factorisation of the diagonal block
     double* fuse_w16 = nullptr;   // inverted 16 x 16 diagonal pieces of the next diagonal block (8 x 256 doubles), kept for the sweeps; nullable
-    int* fuse_xpub = nullptr;     // persistent launch only: counter the first panel row bumps (once per wave) for every 16-column slice it has published
+    int* fuse_xpub = nullptr;     // persistent launch only: eight counters, one per 16-column slice, that every strip wave of the first panel row bumps once
     const int* fuse_xcnt = nullptr; // ... and the counter the crew of the next diagonal block follows (its operand arrives slice by slice), with its base value
     int fuse_xwant = 0;
     double* fuse_side = nullptr;    // persistent launch only: the side copy of the panel being solved (same leading dimension and offsets as C)
