@@ -291,9 +291,68 @@ def test_accuracy_on_recorded_ipm_states_of_the_hardest_fixture(hip, orc, kkt_so
     from dense_replay import replay
     rows = replay("qp_robot_arm_sqp", kkt_solver)
     both = [(it, rh, ro) for it, rho, delta, okh, oko, rh, ro in rows if okh and oko]
+    dev_only_fail = [it for it, rho, delta, okh, oko, rh, ro in rows if oko and not okh]
+    orc_only_fail = [it for it, rho, delta, okh, oko, rh, ro in rows if okh and not oko]
+    print(f"\nreplay kkt_solver={kkt_solver}: {len(rows)} states, both factorise on {len(both)}, device-only failures {dev_only_fail}, oracle-only failures {orc_only_fail}")
+    # a state the oracle factorises and the device does not would silently drop out of the comparison below, so such states are counted, not skipped:
+    # at most one, and only at the regularisation floor (rho = delta <= 1e-9), where the smallest pivot of the condensed matrix is of the size of the
+    # assembly's rounding error and its sign -- the failure criterion of Eigen::LLT, dense/kkt.hpp:83 -- is decided by the summation order of G' W G
+    # (measured in round 3: state 12 of 20 for LL^T, none for LDL^T)
+    floor = {it for it, rho, delta, okh, oko, rh, ro in rows if rho <= 1e-9 and delta <= 1e-9}
+    assert len(dev_only_fail) <= 1 and set(dev_only_fail) <= floor, dev_only_fail
     assert len(both) >= 10
     for it, rh, ro in both:
         assert rh <= max(10.0 * ro, 1e-12), (it, rh, ro)
         if ro <= 2.5e-11:
             assert rh <= 1e-10, (it, rh, ro)
     assert np.median([rh / ro for _, rh, ro in both]) <= 2.0
+
+
+def test_persistent_factorisation_is_bitwise_the_launch_per_panel_one(hip):
+    """round 3: k_chol_persistent (every round of the blocked factorisation in ONE launch: ticket-ordered task list, look-ahead, the first panel row handed
+    over slice by slice, two workgroups per panel tile) against the launch-per-panel path (PIQP_AMD_DEBUG=chol_launches): every tile receives the same
+    products in the same order, so factor, reciprocal pivots (through a solve) and success flag agree bit for bit, for LL^T and LDL^T, run after run"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "chk_chol_persistent.py"), "384", "640", "1024", "2048"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "ALL EQUAL" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_two_persistent_factorisations_on_two_streams(hip):
+    """two handles (one a clone of the other) factor and solve from two host threads at the same time: the persistent launches of both compete for the
+    CUs, neither is ever fully resident -- the ticket order guarantees progress with any number of resident workgroups -- and every result equals the
+    single-threaded one bit for bit"""
+    import threading
+    import torch
+    n = m = 2048
+    q = dense_strongly_convex_qp(n, 0, m, seed=5, double_sided=True, exact_shift=False)
+    k1 = hip.KKTSystem(hip.Data(**q), hip.default_settings(kkt_solver=0))
+    k2 = k1.clone()
+    rng = np.random.default_rng(0)
+    sv = random_vars(n, 0, m, rng, positive=True); rv = random_vars(n, 0, m, rng)
+    out, err = {}, []
+
+    def work(tag, k, reps):
+        try:
+            state = {kk: torch.from_numpy(v).cuda() for kk, v in sv.items()}
+            rhs = {kk: torch.from_numpy(v).cuda() for kk, v in rv.items()}
+            lhs = {kk: torch.zeros_like(v) for kk, v in rhs.items()}
+            ref = None
+            for it in range(reps):
+                assert k.update_scalings_and_factor(False, 1e-6, 1e-4, state)
+                k.solve(rhs, lhs)
+                x = lhs["x"].cpu().numpy().copy()
+                if ref is None:
+                    ref = x
+                assert np.array_equal(x, ref), (tag, it)
+            out[tag] = ref
+        except Exception as e:  # noqa: BLE001
+            err.append((tag, repr(e)))
+
+    work("single", k1, 3)
+    t1 = threading.Thread(target=work, args=("a", k1, 40)); t2 = threading.Thread(target=work, args=("b", k2, 40))
+    t1.start(); t2.start(); t1.join(300); t2.join(300)
+    assert not err, err
+    assert np.array_equal(out["a"], out["single"]) and np.array_equal(out["b"], out["single"])
