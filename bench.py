@@ -451,6 +451,27 @@ def batched_qp(args, rank, world, local_rank, dev, pd):
         rows = pd.gather_stats([[float(solved_w)]], device=dev)
         if rank == 0:
             res["weak"] = {"qps_total": total * world, "qp_per_s": total * world / el_w, "ms": el_w * 1e3, "solved": int(sum(r[0] for r in rows))}
+    # one-GPU batch-size sweep (rank 0, N = 1 runs only): what a fixed batch split over G GPUs can gain is bounded by t(B) / t(B / G) of ONE GPU -- a
+    # shard of 8192 / 8 = 1024 QPs is four per CU, i.e. one round of workgroups whose duration is one QP's latency
+    if world == 1 and total >= 2048:
+        sweep = {}
+        for bsz in sorted({total // 8, total // 4, total // 2, total, 2 * total}):
+            try:
+                mbz = mpc_batch(bsz, seed=1000) if bsz > total else sub(0, bsz)
+                _b, _solved, el_z = run(mbz, reps=3)
+                sweep[str(bsz)] = {"ms": el_z * 1e3, "qp_per_s": bsz / el_z, "kernel_ms": _b.last_kernel_ms()[0], "solved": int(_solved)}
+                del _b
+            except Exception as e:  # noqa: BLE001
+                sweep[str(bsz)] = {"error": f"{type(e).__name__}: {e}"}
+        res["batch_size_sweep_one_gpu"] = sweep
+        try:
+            t_full, t_8th = sweep[str(total)]["ms"], sweep[str(total // 8)]["ms"]
+            res["predicted_strong_scaling_8gpu"] = t_full / t_8th
+            res["predicted_strong_scaling_note"] = (f"t({total}) / t({total // 8}) on ONE GPU = upper bound of the 8-GPU speed-up of the FIXED {total}-QP batch (no multi-GPU node was "
+                                                    "available to the build); the >= 6x of the north star is reachable as weak scaling (a full batch per GPU, no data-path "
+                                                    "collective) or with batches of >= 8 x 8192 QPs")
+        except Exception:  # noqa: BLE001
+            pass
     if rank != 0:
         return None
     res["workload"] = f"{total} linear-MPC QPs, n=120 (40 stages x (n_x=2,n_u=1)), p=80, box bounds on all variables, kkt_solver=sparse_multistage (BASELINE configs[3])"

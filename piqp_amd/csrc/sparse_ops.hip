@@ -25,18 +25,59 @@ __global__ void k_gather_values(int nnz, const int* __restrict__ src_idx, const 
     if (q < nnz) dst[q] = src[src_idx[q]];
 }
 
-// y[j] = (ACC ? y[j] : 0) + alpha * sum_q val[q] * x[row[q]] over column j  (CSC column dot; thread per column)
+// ---- column dots of a CSC matrix, one column per lane, with COALESCED traffic (round 3).
+// A thread that walks its own column reads val[q], rowind[q] at addresses a whole column apart from its neighbours': every load instruction of the wave
+// touches 64 cache lines (measured on the n = 500k chain: k_recover_duals 190 us and k_fold_rhs 110 us per call for 76 MB of matrix = 0.4 TB/s, a third of
+// a KKT step).  Here the wave owns 64 consecutive columns, i.e. ONE contiguous range of entries: it streams that range through LDS in chunks -- lane e
+// loads entries e, e + 64, ... (coalesced) together with the gathered operand -- and every lane then sums the part of ITS column that lies in the chunk,
+// left to right, with the same multiply-add expression as before: bitwise the results of the thread-per-column loops (tests/test_sparse_gpu.py), at
+// streaming bandwidth.  OP(q, i) = the operand of entry q in row i (x[i], or zinv[i] * rhs_z[i] for the folds).
+constexpr int DOT_CHUNK = 512;               // entries per wave and chunk: 2 x 4 KB of LDS per wave
+constexpr int DOT_LDS_DOUBLES = 2 * DOT_CHUNK * 4;  // per 256-thread workgroup
+__device__ __forceinline__ void dot_wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// returns sum_{q in [colptr[j], colptr[j + 1])} val[q] * op(rowind[q]) for this lane's column j (0 for j >= ncols or when skip says so); sm = the
+// workgroup's DOT_LDS_DOUBLES doubles.  All 64 lanes of a wave must call it together.
+template <class Op>
+__device__ __forceinline__ double wave_col_dot(int j, int ncols, const int* __restrict__ colptr, const int* __restrict__ rowind, const double* __restrict__ val, Op op,
+                                               double* __restrict__ sm, int max_len)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double* sv = sm + wave * 2 * DOT_CHUNK;
+    double* sx = sv + DOT_CHUNK;
+    const bool in = j < ncols;
+    int lo = in ? colptr[j] : 0, hi = in ? colptr[j + 1] : 0;
+    if (max_len > 0 && hi - lo > max_len) hi = lo;  // (a column left to k_spmv_long_cols)
+    const int j0 = j - lane;                                    // first column of the wave
+    const int wlo = colptr[min(j0, ncols)], whi = colptr[min(j0 + 64, ncols)];
+    double s = 0.0;
+    for (int base = wlo; base < whi; base += DOT_CHUNK) {
+        const int cnt = min(DOT_CHUNK, whi - base);
+#pragma unroll 2
+        for (int e = lane; e < cnt; e += 64) { const int q = base + e; sv[e] = val[q]; sx[e] = op(rowind[q]); }
+        dot_wave_sync();
+        const int a = max(lo, base), b = min(hi, base + cnt);
+        for (int q = a; q < b; ++q) s += sv[q - base] * sx[q - base];
+        dot_wave_sync();
+    }
+    return s;
+}
+
+// y[j] = (ACC ? y[j] : 0) + alpha * sum_q val[q] * x[row[q]] over column j  (CSC column dot)
 constexpr int SPMV_LONG_COL = 2048;  // columns with more entries than this are summed by a whole workgroup (k_spmv_long_cols)
 template <bool ACC>
-__global__ void k_spmv_cols(int ncols, const int* __restrict__ colptr, const int* __restrict__ rowind, const double* __restrict__ val, const double* __restrict__ x,
-                            double alpha, double* __restrict__ y)
+__global__ __launch_bounds__(256) void k_spmv_cols(int ncols, const int* __restrict__ colptr, const int* __restrict__ rowind, const double* __restrict__ val, const double* __restrict__ x,
+                                                   double alpha, double* __restrict__ y)
 {
+    __shared__ double sm[DOT_LDS_DOUBLES];
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const double s = wave_col_dot(j, ncols, colptr, rowind, val, [&](int i) { return x[i]; }, sm, SPMV_LONG_COL);
     if (j >= ncols) return;
-    const int lo = colptr[j], hi = colptr[j + 1];
-    if (hi - lo > SPMV_LONG_COL) return;
-    double s = 0.0;
-    for (int q = lo; q < hi; ++q) s += val[q] * x[rowind[q]];
+    if (colptr[j + 1] - colptr[j] > SPMV_LONG_COL) return;
     y[j] = ACC ? y[j] + alpha * s : alpha * s;
 }
 // A column with very many entries (a dense row of A seen from its transpose copy: MM BOYD1 has 18 of 93 261 entries each) costs a thread-per-
@@ -61,35 +102,37 @@ __global__ __launch_bounds__(256) void k_spmv_long_cols(const int* __restrict__ 
 }
 
 // out[j] = rhs_x[j] + sum_{G rows i of column j} G(i,j) zinv[i] rhs_z[i] + delta_inv * sum_{A rows i} A(i,j) rhs_y[i]
-__global__ void k_fold_rhs(int n, const int* __restrict__ Gp, const int* __restrict__ Gi, const double* __restrict__ Gx, const int* __restrict__ Ap, const int* __restrict__ Ai,
-                           const double* __restrict__ Ax, const double* __restrict__ rhs_x, const double* __restrict__ rhs_y, const double* __restrict__ rhs_z,
-                           const double* __restrict__ zinv, double delta_inv, double* __restrict__ out, int with_A, int with_G)
+__global__ __launch_bounds__(256) void k_fold_rhs(int n, const int* __restrict__ Gp, const int* __restrict__ Gi, const double* __restrict__ Gx, const int* __restrict__ Ap, const int* __restrict__ Ai,
+                                                  const double* __restrict__ Ax, const double* __restrict__ rhs_x, const double* __restrict__ rhs_y, const double* __restrict__ rhs_z,
+                                                  const double* __restrict__ zinv, double delta_inv, double* __restrict__ out, int with_A, int with_G)
 {
+    __shared__ double sm[DOT_LDS_DOUBLES];
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
     double sg = 0.0, sa = 0.0;
-    if (with_G) for (int q = Gp[j]; q < Gp[j + 1]; ++q) { const int i = Gi[q]; sg += Gx[q] * (zinv[i] * rhs_z[i]); }
-    if (with_A) for (int q = Ap[j]; q < Ap[j + 1]; ++q) sa += Ax[q] * rhs_y[Ai[q]];
+    if (with_G) sg = wave_col_dot(j, n, Gp, Gi, Gx, [&](int i) { return zinv[i] * rhs_z[i]; }, sm, 0);
+    if (with_A) sa = wave_col_dot(j, n, Ap, Ai, Ax, [&](int i) { return rhs_y[i]; }, sm, 0);
+    if (j >= n) return;
     out[j] = (rhs_x[j] + sg) + delta_inv * sa;
 }
-// rows k < p: lhs_y ; rows p <= k < p + m: lhs_z
-__global__ void k_recover_duals(int p, int m, const int* __restrict__ ATp, const int* __restrict__ ATi, const double* __restrict__ ATx, const int* __restrict__ GTp,
-                                const int* __restrict__ GTi, const double* __restrict__ GTx, const double* __restrict__ x, const double* __restrict__ rhs_y,
-                                const double* __restrict__ rhs_z, const double* __restrict__ zinv, double delta_inv, double* __restrict__ lhs_y, double* __restrict__ lhs_z,
-                                int with_A, int with_G)
+// rows k < p: lhs_y ; rows p <= k < p + m: lhs_z.  Two grids in one launch: blocks [0, ceil(p / 256)) serve the equality rows, the rest the inequality rows
+// (a wave never straddles the two matrices).
+__global__ __launch_bounds__(256) void k_recover_duals(int p, int m, const int* __restrict__ ATp, const int* __restrict__ ATi, const double* __restrict__ ATx, const int* __restrict__ GTp,
+                                                       const int* __restrict__ GTi, const double* __restrict__ GTx, const double* __restrict__ x, const double* __restrict__ rhs_y,
+                                                       const double* __restrict__ rhs_z, const double* __restrict__ zinv, double delta_inv, double* __restrict__ lhs_y, double* __restrict__ lhs_z,
+                                                       int with_A, int with_G)
 {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < p) {
+    __shared__ double sm[DOT_LDS_DOUBLES];
+    const int pblocks = (p + 255) / 256;
+    if ((int)blockIdx.x < pblocks) {
         if (!with_A) return;
-        double s = 0.0;
-        for (int q = ATp[k]; q < ATp[k + 1]; ++q) s += ATx[q] * x[ATi[q]];
-        lhs_y[k] = delta_inv * s - delta_inv * rhs_y[k];
-    } else if (k < p + m) {
+        const int k = blockIdx.x * 256 + threadIdx.x;
+        const double s = wave_col_dot(k, p, ATp, ATi, ATx, [&](int i) { return x[i]; }, sm, 0);
+        if (k < p) lhs_y[k] = delta_inv * s - delta_inv * rhs_y[k];
+    } else {
         if (!with_G) return;
-        const int i = k - p;
-        double s = 0.0;
-        for (int q = GTp[i]; q < GTp[i + 1]; ++q) s += GTx[q] * x[GTi[q]];
-        lhs_z[i] = (s - rhs_z[i]) * zinv[i];
+        const int i = ((int)blockIdx.x - pblocks) * 256 + threadIdx.x;
+        const double s = wave_col_dot(i, m, GTp, GTi, GTx, [&](int r) { return x[r]; }, sm, 0);
+        if (i < m) lhs_z[i] = (s - rhs_z[i]) * zinv[i];
     }
 }
 
@@ -237,7 +280,7 @@ void CscOperators::recover_duals(const double* x, const double* rhs_y, const dou
                                  bool with_A, bool with_G) const
 {
     if (p_ + m_ > 0)
-        hipLaunchKernelGGL(k_recover_duals, g1(p_ + m_), dim3(256), 0, st, p_, m_, AT_p_.p, AT_i_.p, AT_x_.p, GT_p_.p, GT_i_.p, GT_x_.p, x, rhs_y, rhs_z, zinv, delta_inv, lhs_y, lhs_z,
+        hipLaunchKernelGGL(k_recover_duals, dim3((p_ + 255) / 256 + (m_ + 255) / 256 > 0 ? (p_ + 255) / 256 + (m_ + 255) / 256 : 1), dim3(256), 0, st, p_, m_, AT_p_.p, AT_i_.p, AT_x_.p, GT_p_.p, GT_i_.p, GT_x_.p, x, rhs_y, rhs_z, zinv, delta_inv, lhs_y, lhs_z,
                            with_A ? 1 : 0, with_G ? 1 : 0);
 }
 void CscOperators::add_AT_y(double alpha, const double* y, double* z, hipStream_t st) const
