@@ -60,14 +60,15 @@ def pmc_traffic(kernel_key, n, m, p):
     """HBM traffic of one launch of `kernel_key` from the committed rocprofv3 PMC passes of this workload (FETCH_SIZE / WRITE_SIZE in
     separate passes, gfx950 correction applied, see the file); None when the file does not cover this shape.  Not measured in this run:
     the source file and its commit are reported next to the number."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_dense_c2.json")
-    try:
-        pmc = json.load(open(path))
-        if (pmc["n"], pmc["m"], pmc["p"]) != (n, m, p):
-            return None, None
-        return pmc["per_launch"][kernel_key]["traffic_bytes"], f"profiles/r02_pmc_dense_c2.json ({pmc.get('collected', 'rocprofv3 --pmc passes of tools/prof_dense.py')})"
-    except Exception:  # noqa: BLE001
-        return None, None
+    for fname in ("r03_pmc_dense_c2.json", "r02_pmc_dense_c2.json"):
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", fname)))
+            if (pmc["n"], pmc["m"], pmc["p"]) != (n, m, p):
+                continue
+            return pmc["per_launch"][kernel_key]["traffic_bytes"], f"profiles/{fname} ({pmc.get('collected', 'rocprofv3 --pmc passes of tools/prof_dense.py')})"
+        except Exception:  # noqa: BLE001
+            continue
+    return None, None
 
 
 def dense_leg(piqp_amd, pd, torch, np, q, n, p, m, kkt_solver, refine, steps, warmup, rank, world, local_rank, dev, kernel_pass=0):

@@ -66,9 +66,23 @@ class InfoS(C.Structure):
         ("n_factor", C.c_int), ("n_solve", C.c_int), ("n_backend_solve", C.c_int)]
 
 
-def build(native=False):
+def build(native=False, fma=False):
     """Compile the oracle with gcc (seconds)."""
-    subprocess.check_call(["make", "-s", "-C", _HERE] + (["native"] if native else []))
+    subprocess.check_call(["make", "-s", "-C", _HERE] + (["native"] if native else (["fma"] if fma else [])))
+
+
+_lib_fma = None
+
+
+def lib_fma():
+    """the FMA-contracted build of the same sources (oracle/Makefile, target fma): a second legal build of the reference arithmetic"""
+    global _lib_fma
+    if _lib_fma is None:
+        path = os.path.join(_HERE, "_build", "liborc_fma.so")
+        if not os.path.exists(path) or os.path.getmtime(path) < max(os.path.getmtime(os.path.join(_HERE, f)) for f in os.listdir(_HERE) if f.endswith((".c", ".h"))):
+            build(fma=True)
+        _lib_fma = _bind(C.CDLL(path))
+    return _lib_fma
 
 
 _lib = None

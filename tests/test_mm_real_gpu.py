@@ -70,18 +70,49 @@ def test_kkt_factor_solve_on_real_problem(hip, orc, name):
         assert _rel(lhs[key], lo[key]) < 1e-6, (name, key)
 
 
-# Degenerate netlib-derived problems whose trajectories leave the oracle's once rho = delta = 1e-10: measured device / oracle iterations in the
-# comments.  The KKT solves are NOT less accurate there -- tools/dbg_sparse_accuracy.py replays the oracle's recorded states through both backends:
-# device residual 0.3x .. 2x the oracle's on every state -- but the trajectory is decided by rounding: on QBEACONF (integer data) the oracle's
-# AMD-ordered up-looking LDLt cancels to an EXACT zero pivot on four consecutive states, which sends the reference's loop into its recovery path
-# (regularisation x 100, refinement on: solver.hpp:691-704) and rescues the solve; the device, eliminating in another order, has smallest pivot
-# = delta there (a healthy factorisation), gets no such signal, and stalls.  Same mechanism on fffff800.  Held to: a valid status, and the
-# oracle's optimum whenever the device solves.
+# Degenerate netlib-derived problems whose trajectories are decided by rounding once rho = delta = 1e-10.  Round 3 evidence (profiles/r03_ordering_parity.txt,
+# tools/exp_ordering_parity.py, tools/exp_zero_pivot notes in DESIGN.md section 5):
+#  * the ORACLE ITSELF changes its count on them when the same sources are compiled with FMA contraction (oracle/Makefile target `fma` = gcc's default at
+#    -O3 -march=native, the flags the reference documents): QBEACONF 17 -> 18, QCAPRI 50 -> 35, QPILOTNO 35 -> 62, QSHIP08S 21 -> 19, fffff800 43 -> 39,
+#    pilot-we MAX_ITER -> 66 -- while it keeps it on all the others;
+#  * forcing the reference's elimination order on the device (PIQP_AMD_ORDERING=amd; these problems already run in it, N is small) changes nothing, nested
+#    dissection happens to give the oracle's 17 on QBEACONF and solves fffff800 in 47;
+#  * the mechanism on QBEACONF: two variables tied by one equality row, Schur complement 1e10 - 1e10 with a true value of 8e-7, below half an ulp of 1e10 --
+#    the oracle's non-fused arithmetic lands on exactly 0.0 (one third of the lattice points), which sends the reference's loop into its recovery path
+#    (regularisation x 100, refinement on, solver.hpp:691-704); any fused or re-ordered arithmetic gets +-1e-6 garbage instead and no such signal.
+# Held to: status SOLVED and the oracle's optimum, iteration count within one of the RANGE spanned by the two oracle builds -- except the two problems where
+# the device ends MAX_ITER (the stall after the unsignalled garbage pivot; the host-side loop on the same backend solves QBEACONF in 20).
 TRAJECTORY_SENSITIVE = {
-    "mm_QBEACONF": "device MAX_ITER (250), host-side loop 20, oracle 17",
-    "mm_QCAPRI": "34 vs 50", "mm_QETAMACR": "30 vs 29", "mm_QGROW7": "25 vs 24", "mm_QPILOTNO": "46 vs 35", "mm_QSHIP08L": "15 vs 16", "mm_QSHIP08S": "15 vs 21",
-    "nl_fffff800": "device MAX_ITER (250), oracle 43",
+    "mm_QBEACONF": "oracle 17 / 18 (fma); device MAX_ITER (250), host-side loop 20, nested dissection 17",
+    "mm_QCAPRI": "oracle 50 / 35 (fma); device 34", "mm_QETAMACR": "oracle 29 / 29; device 29-30", "mm_QGROW7": "oracle 24 / 24; device 25",
+    "mm_QPILOTNO": "oracle 35 / 62 (fma); device 50", "mm_QSHIP08L": "oracle 16 / 16; device 15", "mm_QSHIP08S": "oracle 21 / 19 (fma); device 20",
+    "nl_fffff800": "oracle 43 / 39 (fma); device MAX_ITER (250), nested dissection 47",
 }
+STATUS_EXCEPTIONS = {"mm_QBEACONF", "nl_fffff800"}  # device MAX_ITER where both oracle builds solve: recorded, see above
+
+
+def _oracle_both_builds(orc, q, netlib=False):
+    """(status, iterations) of the oracle as built (no FMA contraction in the sparse LDLt, like the reference forces) and of its FMA-contracted build"""
+    out = []
+    for L in (None, orc.lib_fma()):
+        so = orc.Solver(_L=L); so.settings.kkt_solver = orc.SPARSE_LDLT
+        if netlib:
+            so.settings.infeasibility_threshold = 0.01
+        assert so.setup(*_args(q), sparse=True)
+        out.append((so.solve(), so.info.iter, so.info.primal_obj))
+    return out
+
+
+def _check_sensitive(name, sh, st_h, builds):
+    (st_a, it_a, obj_a), (st_b, it_b, _) = builds
+    assert st_a == 1 and st_b == 1, (name, st_a, st_b)
+    if name in STATUS_EXCEPTIONS:
+        assert st_h in (1, -1), (name, st_h)
+    else:
+        assert st_h == 1, (name, st_h)
+    if st_h == 1:
+        assert min(it_a, it_b) - 1 <= sh.info.iter <= max(it_a, it_b) + 1, (name, sh.info.iter, it_a, it_b)
+        assert abs(sh.info.primal_obj - obj_a) <= 1e-6 * max(1.0, abs(obj_a)) + 10 * sh.settings.eps_abs
 
 
 # (The CONT-xxx family -- PDE-constrained grids, the fixtures with fronts of several hundred rows -- sat one iteration off the oracle for a while in
@@ -103,7 +134,8 @@ def test_status_and_iterations_match_oracle(hip, orc, name):
     st_h, st_o = sh.solve(), so.solve()
     assert st_o == 1, (name, st_o)  # the reference's sweep expects SOLVED on every file; the oracle meets it on all 110 frozen ones
     if name in TRAJECTORY_SENSITIVE:
-        assert st_h in (1, -1), (name, st_h)
+        _check_sensitive(name, sh, st_h, _oracle_both_builds(orc, q))
+        return
     else:
         assert st_h == st_o, (name, st_h, st_o)
         assert abs(sh.info.iter - so.info.iter) <= ITER_SLACK.get(name, 0 if so.info.iter < 30 else 1), (name, sh.info.iter, so.info.iter)
@@ -134,7 +166,7 @@ def test_netlib_lp_status_matches_oracle(hip, orc, name):
     else:
         assert st_o in expected, (name, st_o)
         if name in TRAJECTORY_SENSITIVE:
-            assert st_h in expected + (-1,), (name, st_h)
+            _check_sensitive(name, sh, st_h, _oracle_both_builds(orc, q, netlib=True))
         else:
             assert st_h in expected, (name, st_h, st_o)
     if st_o == 1 and st_h == 1:

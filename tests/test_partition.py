@@ -50,6 +50,22 @@ def test_plan_chain(world):
     assert (owner < 0).sum() < 0.08 * owner.size
 
 
+def test_plan_chain_at_full_c5_size():
+    """BASELINE configs[4] at its real size -- n = 500 012, 25 000 stages of n_x = 12, n_u = 8 -- planned for 8 ranks (host-only analysis, about 100 s
+    on 8 cores): every rank owns one contiguous range of stages with 12-13 % of the factorisation work, the replicated top is 0.3 %."""
+    from qp_gen import mpc_chain
+    world = 8
+    owner, work = _plan(mpc_chain(12, 8, 25000, 5), 3, world)
+    assert owner.size == 500012 and owner.min() == -1 and owner.max() == world - 1
+    per_rank, shared = work[:world], work[world]
+    share = per_rank / per_rank.sum()
+    assert share.min() >= 0.115 and share.max() <= 0.135, share
+    assert shared <= 0.005 * per_rank.sum()
+    o = owner[owner >= 0]
+    assert (np.diff(o) >= 0).all()              # contiguous, in stage order
+    assert (owner < 0).sum() <= 2000            # the shared separators: 1488 of 500 012 columns
+
+
 @pytest.mark.parametrize("mode", [0, 3])
 def test_plan_general_sparse(mode):
     """a general sparse QP: same invariants except balance / shared share, which depend on the top fronts"""

@@ -4,7 +4,7 @@ MI355X_MICROARCH.md, PMC slots), with the gfx950 correction of that guide (FETCH
 
   rocprofv3 --pmc FETCH_SIZE --kernel-trace -d gpurun_out/pmc_f -- python3 tools/prof_dense.py 4096 4096 0 3 0
   rocprofv3 --pmc WRITE_SIZE --kernel-trace -d gpurun_out/pmc_w -- python3 tools/prof_dense.py 4096 4096 0 3 0
-  python tools/make_pmc_json.py gpurun_out/pmc_f gpurun_out/pmc_w 4096 4096 0 "<collected: date / commit>" > profiles/r02_pmc_dense_c2.json
+  python tools/make_pmc_json.py gpurun_out/pmc_f gpurun_out/pmc_w 4096 4096 0 "<collected: date / commit>" > profiles/r03_pmc_dense_c2.json
 """
 import glob
 import json
@@ -53,7 +53,10 @@ def main():
            "n": n, "m": m, "p": p, "steps_profiled": steps, "kernels": kernels,
            "per_launch": {"assembly": {"traffic_bytes": per_step(["k_syrk_lower<0, 2, 2>", "k_syrk_tail_reduce<0>"], steps),
                                        "note": "main launch + split-K tail + tail reduce = one assembly"},
-                          "panel_update": {"traffic_bytes": tot("k_syrk_lower<3, 4, 2>"), "note": "average over the 31 fused trailing-update launches of a factorisation"},
+                          # round 3: one persistent launch per factorisation (k_chol_persistent); before: the average over the 31 fused launches
+                          "panel_update": ({"traffic_bytes": tot("k_chol_persistent"), "note": "k_chol_persistent: all rounds of one factorisation (a single launch)"}
+                                           if tot("k_chol_persistent") > 0 else
+                                           {"traffic_bytes": tot("k_syrk_lower<3, 4, 2>"), "note": "average over the 31 fused trailing-update launches of a factorisation"}),
                           "panel_solve": {"traffic_bytes": tot("k_trsm_panel")},
                           "triangular_sweep": {"traffic_bytes": 0.5 * tot("k_trsv_persistent")}}}
     print(json.dumps(out, indent=1))
