@@ -1532,7 +1532,10 @@ struct CholTask {
 // workgroups per panel tile: a row's task of round k needs that row's output of round k - 1, so one workgroup's update + substitution (28 + 13 us for a
 // whole tile) bound a round from below; halves (fused_tile<HALF>) keep that under the diagonal block's 30 us.  Early rounds are bound by the bulk
 // tiles anyway and keep whole tiles (half as many workgroups parked on the chain).
-__host__ __device__ inline int chol_split(int T, int k) { (void)T; (void)k; return 2; }
+// A round with >= 26 trailing tile rows (> 300 bulk tiles) is bound by the bulk tiles, not by the chain: there whole tiles park half as many workgroups on
+// the chain and leave them to the bulk.
+__host__ __device__ inline bool chol_bulk_bound(int T, int k) { return T - k - 1 >= 26; }
+__host__ __device__ inline int chol_split(int T, int k) { return chol_bulk_bound(T, k) ? 1 : 2; }
 struct CholArgs {
     double* A; double* side; int lda, n, T, ldlt;
     int* info; double* rdiag; double* dvec; double* pack2; double* w16;
@@ -1697,30 +1700,35 @@ __global__ __launch_bounds__(CHOL_THREADS, 2) void k_chol_persistent(CholArgs c)
 // first, the other tiles in a second, panel tasks drawn only when the round before is complete, a drawn task whose conditions do not hold yet held back --
 // 1.50: the rows start their update later than with the early draw, and that costs more than the parked workgroups it saves; drawing with a
 // compare-and-swap on the head, so that nobody overshoots a gate: 18 ms.)
+constexpr double CHOL_DEFER = 0.05;
 static void chol_build_tasks(int T, std::vector<CholTask>& H)
 {
-    H.clear();
-    auto crew_panel = [&](int k, int gate) {
-        const int Tk = T - k - 1, sp = chol_split(T, k);
-        for (int r = 1; r < FUSE_ROLES; ++r) H.push_back({0, (short)k, (short)r, 0, gate});
-        H.push_back({1, (short)k, 0, 0, gate});
+    // One queue, sorted by a key in units of chain rounds.  The crew and panel tasks of round k have key k - 1 (drawn a round early: the crew follows the
+    // slices of its operand, a panel task waits for its own rows); the first tile column of round k, which feeds them, k - 0.5; tile column tj >= 2 of
+    // round k,  k + CHOL_DEFER (tj - 1):  with CHOL_DEFER = 0 that is the plain order  crew(k+1) panel(k+1) bulk(k) ...;  a small slope pushes the far
+    // columns of the early rounds (465 tiles against a 36 us chain round: more than the chip does) a round or two back, behind the next chain tasks.
+    // Measured at T = 32 (factorisation ms): slope 0: 1.333, 0.02: 1.326, 0.04: 1.312, 0.07: 1.310, 0.1: 1.329, and 1.42 for the full deadline order
+    // (0.2 (j - 1) + 0.8 k: every workgroup busy with deferred tiles when a chain task comes up).  A tile's updates keep their order (the key grows with k),
+    // every task only waits for tasks with a smaller key, and a gate is never later than the tasks around it need (gate = round of the panel read).
+    struct Keyed { double key; int cls; CholTask t; };
+    std::vector<Keyed> all;
+    for (int k = 0; k + 1 < T; ++k) {
+        const int Tk = T - k - 1, sp = chol_split(T, k), gate = std::max(k - 1, 0);
+        const double kc = (double)k - 1.0;
+        for (int r = 1; r < FUSE_ROLES; ++r) all.push_back({kc, 0, {0, (short)k, (short)r, 0, gate}});
+        all.push_back({kc, 1, {1, (short)k, 0, 0, gate}});
         for (int ti = 1; ti < Tk; ++ti) {
-            if (sp == 1) H.push_back({2, (short)k, (short)ti, -1, gate});
-            else for (int h = 0; h < sp; ++h) H.push_back({2, (short)k, (short)ti, (short)h, gate});
+            if (sp == 1) all.push_back({kc, 2, {2, (short)k, (short)ti, -1, gate}});
+            else for (int h = 0; h < sp; ++h) all.push_back({kc, 2, {2, (short)k, (short)ti, (short)h, gate}});
         }
-    };
-    auto bulk = [&](int k, int tj_lo, int tj_hi, int gate) {  // tile columns tj_lo .. tj_hi - 1 of round k
-        const int Tk = T - k - 1;
-        for (int tj = tj_lo; tj < tj_hi && tj < Tk; ++tj)
-            for (int ti = tj; ti < Tk; ++ti) H.push_back({3, (short)k, (short)ti, (short)tj, gate});
-    };
-    crew_panel(0, 0);
-    bulk(0, 1, 2, 0);
-    for (int k = 1; k + 1 < T; ++k) {
-        crew_panel(k, k - 1);      // one round early: the crew follows the slices of its operand, a panel task waits for its own two rows
-        bulk(k - 1, 2, T, k - 1);  // needs panel k - 1: complete once k - 1 rounds are
-        bulk(k, 1, 2, k);          // needs panel k
+        for (int tj = 1; tj < Tk; ++tj) {
+            const double key = tj == 1 ? (double)k - 0.5 : (double)k + CHOL_DEFER * (tj - 1);
+            for (int ti = tj; ti < Tk; ++ti) all.push_back({key, 3, {3, (short)k, (short)ti, (short)tj, k}});
+        }
     }
+    std::stable_sort(all.begin(), all.end(), [](const Keyed& a, const Keyed& b) { return a.key != b.key ? a.key < b.key : a.cls < b.cls; });
+    H.clear();
+    for (const Keyed& q : all) H.push_back(q.t);
 }
 size_t chol_task_count(int T)
 {
