@@ -107,7 +107,10 @@ struct IpmState {
 //                  the chain never waits on HBM)
 enum { MODE_HBM = 0, MODE_STAGED = 1, MODE_RESIDENT = 2, MODE_WAVE = 3 };
 
-template <int NT, int MODE>
+// WPE (the kernel's waves-per-SIMD setting) is part of the type although nothing in the class reads it: the out-of-line members are then compiled once per
+// kernel variant, with that variant's register budget.  Shared between the variants they got the budget of the MOST restrictive one (eight waves per SIMD:
+// 64 VGPRs and 184 bytes of spills in be_factor, whatever the launched kernel allowed).
+template <int NT, int MODE, int WPE>
 struct Ipm {
     static constexpr bool LDS = MODE == MODE_STAGED;
     static constexpr bool RES = MODE == MODE_RESIDENT;
@@ -1132,7 +1135,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     const int q = blockIdx.x;
     __shared__ IpmState state[NT / 64 > 0 ? NT / 64 : 1];
     IpmState& my = state[threadIdx.x >> 6];
-    Ipm<NT, MODE> ipm(S, arena + (long long)q * S.stride, sm, red, my);
+    Ipm<NT, MODE, WPE> ipm(S, arena + (long long)q * S.stride, sm, red, my);
     my.info = pq_info{};
     for (int i = 0; i < NPROF; ++i) my.prof[i] = 0;
     const long long t_start = wall_clock64();
@@ -1515,7 +1518,7 @@ private:
         bool wave_pan = false;
         const long long wave_doubles = sym_.qpan_doubles + n;
         nt_ = (n <= 512 && sym_.max_h <= 24) ? 64 : 256;
-        if (const char* e = debug_token("batch_wpe")) wpe_ = std::atoi(e);  // waves per SIMD the kernel is compiled for (2 .. 6, 8)
+        if (const char* e = debug_token("batch_wpe")) wpe_ = std::atoi(e);  // waves per SIMD the kernel is compiled for (2 .. 6)
         if (const char* e = debug_token("batch_mode")) forced_mode_ = std::atoi(e);  // forces the chain working-set mode (tests of the fallback modes)
         if (nt_ == 64 && sym_.max_h * sym_.max_h <= 64 && wave_doubles * (long long)sizeof(double) <= RESIDENT_LIMIT_BYTES && sym_.max_w <= msdev::WAVE_WMAX && (forced_mode_ < 0 || forced_mode_ == MODE_WAVE)) {
             mode_ = MODE_WAVE;
@@ -1596,7 +1599,6 @@ private:
             else if (wpe_ == 3) launch_ipm_with<NTv, MODEv, 3>();
             else if (wpe_ == 5 && MODEv == MODE_WAVE) launch_ipm_with<NTv, MODE_WAVE, 5>();
             else if (wpe_ == 6 && MODEv == MODE_WAVE) launch_ipm_with<NTv, MODE_WAVE, 6>();
-            else if (wpe_ == 8 && MODEv == MODE_WAVE) launch_ipm_with<NTv, MODE_WAVE, 8>();
             else launch_ipm_with<NTv, MODEv, 4>();
         } else {
             launch_ipm_with<NTv, MODEv, 2>();

@@ -328,6 +328,68 @@ __device__ __forceinline__ long long uni(long long v)
 
 typedef const double __attribute__((address_space(1))) global_cdouble;  // HBM pointer (global_load: does not touch lgkmcnt)
 
+// cross-lane read of a double by byte address (lane << 2): the index arithmetic of __shfl leaves the stage loops
+__device__ __forceinline__ double bperm_d(int addr, double v)
+{
+    const int lo = __builtin_amdgcn_ds_bpermute(addr, __double2loint(v));
+    const int hi = __builtin_amdgcn_ds_bpermute(addr, __double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
+// One stage of factor_chain_wave with the panel width W known at compile time: every loop over the panel columns unrolls, the reciprocal pivots and the
+// column of Linv live in registers (with a run-time width they were indexed arrays in scratch), and cross-lane reads that do not depend on each other are
+// requested together -- one LDS round trip for the Schur complement instead of one per panel column (the wave's own LDS latencies, not instruction
+// issue, are most of a stage: rocprofv3 SQ_ACTIVE_INST_VALU 42 % of the SIMD cycles at 4.5 waves per SIMD, profiles/r03_pmc_batch_c4.txt).
+// The arithmetic is the run-time-width loop's, operation by operation (same expressions, same order): the factor is bitwise the same.
+//   f: this lane's entry (r, c) of the assembled front (+ carried update); on return lanes (r >= W, c >= W, r >= c) hold the update matrix to carry
+template <int W>
+__device__ __forceinline__ void factor_stage_wave(double& f, const int h, const int u, const int lane, const int r, const int c, double* __restrict__ P)
+{
+    int ar[W], ac[W];
+#pragma unroll
+    for (int j = 0; j < W; ++j) { ar[j] = (r + j * h) << 2; ac[j] = (c + j * h) << 2; }
+    // ---- right-looking Cholesky of the h x W column panel, pivots by v_readlane, columns by two cross-lane reads ----
+    double invs[W];
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+        const double d = lane_bcast(f, j + j * h);
+        const double inv = d > 0.0 ? rsqrt_newton(d) : 0.0;
+        invs[j] = inv;
+        if (c == j) f = r == j ? d * inv : (r > j ? f * inv : f);
+        const double a = bperm_d(ar[j], f), bb = bperm_d(ac[j], f);
+        if (c > j && c < W && r >= c) f -= a * bb;
+    }
+    // ---- Schur complement of the panel: lanes (r >= W, c >= W, r >= c); the panel columns they read are final, so all reads go out first ----
+    {
+        double a[W], bb[W];
+#pragma unroll
+        for (int k = 0; k < W; ++k) { a[k] = bperm_d(ar[k], f); bb[k] = bperm_d(ac[k], f); }
+        const bool mine = r >= W && c >= W && r >= c;
+#pragma unroll
+        for (int k = 0; k < W; ++k)
+            if (mine) f -= a[k] * bb[k];
+    }
+    // ---- Linv: lane j < W builds column j of L^{-1} in registers (1/L_kk = invs[k]: no divisions) ----
+    double X[W];
+#pragma unroll
+    for (int rr = 0; rr < W; ++rr) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < rr; ++k) s += lane_bcast(f, rr + k * h) * X[k];  // X[k] is 0 for k < lane
+        X[rr] = lane == rr ? invs[rr] : (lane < rr ? -invs[rr] * s : 0.0);
+    }
+    // ---- Q = [C; F] * Linv and the stores for the solves ----
+#pragma unroll
+    for (int k = 0; k < W; ++k)
+        if (lane < W) P[k + lane * W] = X[k];
+    for (int t = 0; t < u; ++t) {
+        double q = 0.0;
+#pragma unroll
+        for (int k = 0; k < W; ++k) q += lane_bcast(f, (W + t) + k * h) * X[k];
+        if (lane < W) P[W * W + t + lane * u] = q;
+    }
+}
+
 // fronts_g: assembled fronts in HBM; pan: LDS, per stage Linv (w x w) then Q (u x w) at PanOff(b)
 template <class Meta>
 __device__ __forceinline__ void factor_chain_wave(const Meta& M, global_cdouble* fronts_g, double* __restrict__ pan)
@@ -339,78 +401,55 @@ __device__ __forceinline__ void factor_chain_wave(const Meta& M, global_cdouble*
     int r = lane % h, c = lane / h;  // lane -> (row, col) of the current front; recomputed only when h changes
     int h_prev = 0, w_prev = 0, off_prev = 0;
     double f = 0.0;                  // after a stage: lanes (r >= w, c >= w, r >= c) hold the carried update matrix
+    // the carried update is a fixed cross-lane permutation per stage SHAPE: source lane and mask are recomputed only when the shape changes
+    int c_sig[7] = {-1, -1, -1, -1, -1, -1, -1};
+    int c_addr = 0;
+    bool c_has = false;
     for (int b = 0; b < N; ++b) {
         if (h == 0) break;  // no arrow corner
         const int w = __builtin_amdgcn_readfirstlane(M.W(b));
         const bool corner = b == N - 1;
         const int offb = __builtin_amdgcn_readfirstlane(M.Off(b));
         const int u = h - w;
-        // ---- carried update: new entry (r, c) <- old trailing entry (i, j), a fixed cross-lane permutation ----
+        // ---- carried update: new entry (r, c) <- old trailing entry (i, j) ----
         double carried = 0.0;
         if (h_prev > 0) {
-            auto inv_carry = [&](int t) {  // inverse of carry_row: -1 = nothing lands on row t
-                if (t < off_prev) return t;
-                const int base = corner ? 0 : w + offb;
-                if (t >= base && !corner) return off_prev + (t - base);
-                if (corner) return off_prev + t;
-                return -1;
-            };
-            const int i = inv_carry(r), j = inv_carry(c);
-            const int u_prev = h_prev - w_prev;
-            const bool has = lane < h * h && i >= 0 && j >= 0 && i < u_prev && j < u_prev && i >= j;
-            const int src = has ? (w_prev + i) + (w_prev + j) * h_prev : lane;
-            const double got = __shfl(f, src);
-            carried = has ? got : 0.0;
+            const int sig[7] = {h, w, offb, h_prev, w_prev, off_prev, (int)corner};
+            bool same = true;
+#pragma unroll
+            for (int q = 0; q < 7; ++q) same = same && sig[q] == c_sig[q];
+            if (!same) {
+#pragma unroll
+                for (int q = 0; q < 7; ++q) c_sig[q] = sig[q];
+                auto inv_carry = [&](int t) {  // inverse of carry_row: -1 = nothing lands on row t
+                    if (t < off_prev) return t;
+                    const int base = corner ? 0 : w + offb;
+                    if (t >= base && !corner) return off_prev + (t - base);
+                    if (corner) return off_prev + t;
+                    return -1;
+                };
+                const int i = inv_carry(r), j = inv_carry(c);
+                const int u_prev = h_prev - w_prev;
+                c_has = lane < h * h && i >= 0 && j >= 0 && i < u_prev && j < u_prev && i >= j;
+                c_addr = (c_has ? (w_prev + i) + (w_prev + j) * h_prev : lane) << 2;
+            }
+            const double got = bperm_d(c_addr, f);
+            carried = c_has ? got : 0.0;
         }
         f = nxt + carried;
         const int hn = b + 1 < N ? __builtin_amdgcn_readfirstlane(M.H(b + 1)) : 0;
         if (hn > 0) nxt = lane < hn * hn ? fronts_g[uni(M.FrontOff(b + 1)) + lane] : 0.0;  // prefetch, consumed next iteration
-        // ---- right-looking Cholesky of the h x w column panel, pivots / columns by v_readlane ----
-        double invs[WAVE_WMAX];
-#pragma unroll
-        for (int j = 0; j < WAVE_WMAX; ++j) {
-            invs[j] = 0.0;
-            if (j < w) {
-                const double d = lane_bcast(f, j + j * h);
-                const double inv = d > 0.0 ? rsqrt_newton(d) : 0.0;
-                invs[j] = inv;
-                if (c == j) f = r == j ? d * inv : (r > j ? f * inv : f);
-                // L[r][j] and L[c][j] for the entry (r, c) this lane holds: two cross-lane permutes (a v_readlane loop over the rows of column j
-                // cost 15 instructions per row, and the kernel is bound by instruction issue at four waves per SIMD)
-                const double a = __shfl(f, r + j * h), bb = __shfl(f, c + j * h);
-                if (c > j && c < w && r >= c) f -= a * bb;
-            }
-        }
-        // ---- Schur complement of the panel: lanes (r >= w, c >= w, r >= c) ----
-        for (int k = 0; k < w; ++k) {
-            const double a = __shfl(f, r + k * h), bb = __shfl(f, c + k * h);
-            if (r >= w && c >= w && r >= c) f -= a * bb;
-        }
-        // ---- Linv: lane j < w builds column j of L^{-1} in registers (1/L_kk = invs[k]: no divisions) ----
-        double X[WAVE_WMAX];
-#pragma unroll
-        for (int k = 0; k < WAVE_WMAX; ++k) X[k] = 0.0;
-#pragma unroll
-        for (int rr = 0; rr < WAVE_WMAX; ++rr) {
-            if (rr < w) {
-                double s = 0.0;
-#pragma unroll
-                for (int k = 0; k < WAVE_WMAX; ++k)
-                    if (k < rr) s += lane_bcast(f, rr + k * h) * X[k];  // X[k] is 0 for k < lane
-                X[rr] = lane == rr ? invs[rr] : (lane < rr ? -invs[rr] * s : 0.0);
-            }
-        }
-        // ---- Q = [C; F] * Linv and the stores for the solves ----
         double* P = pan + uni(M.PanOff(b));
-#pragma unroll
-        for (int k = 0; k < WAVE_WMAX; ++k)
-            if (k < w && lane < w) P[k + lane * w] = X[k];
-        for (int t = 0; t < u; ++t) {
-            double q = 0.0;
-#pragma unroll
-            for (int k = 0; k < WAVE_WMAX; ++k)
-                if (k < w) q += lane_bcast(f, (w + t) + k * h) * X[k];
-            if (lane < w) P[w * w + t + lane * u] = q;
+        switch (w) {
+        case 1: factor_stage_wave<1>(f, h, u, lane, r, c, P); break;
+        case 2: factor_stage_wave<2>(f, h, u, lane, r, c, P); break;
+        case 3: factor_stage_wave<3>(f, h, u, lane, r, c, P); break;
+        case 4: factor_stage_wave<4>(f, h, u, lane, r, c, P); break;
+        case 5: factor_stage_wave<5>(f, h, u, lane, r, c, P); break;
+        case 6: factor_stage_wave<6>(f, h, u, lane, r, c, P); break;
+        case 7: factor_stage_wave<7>(f, h, u, lane, r, c, P); break;
+        case 8: factor_stage_wave<8>(f, h, u, lane, r, c, P); break;
+        default: break;  // w == 0: nothing to eliminate (widths above WAVE_WMAX never reach this mode)
         }
         h_prev = h; w_prev = w; off_prev = offb;
         if (hn != h && hn > 0) { r = lane % hn; c = lane / hn; }
@@ -419,52 +458,90 @@ __device__ __forceinline__ void factor_chain_wave(const Meta& M, global_cdouble*
     wave_lds_sync();
 }
 
+// one stage of the forward / backward substitution, panel width W at compile time (all LDS reads of a stage in one round trip)
+template <int W>
+__device__ __forceinline__ void solve_stage_fwd_wave(const double* __restrict__ Li, double* __restrict__ x, const int h, const int u, const int offb, const int start, const int tail, const int lane)
+{
+    const double* Q = Li + W * W;
+    // lanes < W: y_b = Linv x_b; lanes W .. h - 1: x_next -= Q x_b -- ONE loop for both (the stored Linv has exact zeros above its diagonal, so the
+    // row sum may run over all W columns)
+    double acc = 0.0;
+    int tgt = -1;
+    const bool top = lane < W;
+    const int t = lane - W;
+    const double* cf = top ? Li + lane : Q + (lane < h ? t : 0);
+    const int cs = top ? W : u;
+    if (top) tgt = start + lane;
+    else if (lane < h) { tgt = t < offb ? start + W + t : tail + (t - offb); acc = x[tgt]; }
+    if (lane < h) {
+        double cv[W], xv[W];
+#pragma unroll
+        for (int k = 0; k < W; ++k) { cv[k] = cf[k * cs]; xv[k] = x[start + k]; }
+#pragma unroll
+        for (int k = 0; k < W; ++k) acc += (top ? cv[k] : -cv[k]) * xv[k];
+    }
+    wave_lds_sync();  // every read of x_b above has returned before any lane overwrites it
+    if (tgt >= 0) x[tgt] = acc;
+    wave_lds_sync();
+}
+template <int W>
+__device__ __forceinline__ void solve_stage_bwd_wave(const double* __restrict__ Li, double* __restrict__ x, const int u, const int offb, const int start, const int tail, const int lane)
+{
+    const double* Q = Li + W * W;
+    double acc = 0.0;
+    if (lane < W) {  // x_b = Linv^T x_b - Q^T x_next
+        double lv[W], xv[W];
+#pragma unroll
+        for (int k = 0; k < W; ++k) { lv[k] = Li[k + lane * W]; xv[k] = x[start + k]; }
+#pragma unroll
+        for (int k = 0; k < W; ++k)
+            if (k >= lane) acc += lv[k] * xv[k];
+        for (int t = 0; t < u; ++t) acc -= Q[t + lane * u] * x[t < offb ? start + W + t : tail + (t - offb)];
+    }
+    wave_lds_sync();
+    if (lane < W) x[start + lane] = acc;
+    wave_lds_sync();
+}
+
 // pan, x: LDS.  Forward and backward block substitution by one wave, one LDS round trip per stage.
 template <class Meta>
 __device__ __forceinline__ void solve_chain_wave(const Meta& M, const double* __restrict__ pan, double* __restrict__ x)
 {
     const int lane = threadIdx.x;
-    const int N = M.N, n = M.n, arrow = M.arrow;
+    const int N = M.N, tail = M.n - M.arrow;
     for (int b = 0; b < N; ++b) {
         const int h = __builtin_amdgcn_readfirstlane(M.H(b)), w = __builtin_amdgcn_readfirstlane(M.W(b));
         if (h == 0) continue;
         const int u = h - w, offb = __builtin_amdgcn_readfirstlane(M.Off(b)), start = __builtin_amdgcn_readfirstlane(M.Start(b));
         const double* Li = pan + uni(M.PanOff(b));
-        const double* Q = Li + w * w;
-        // lanes < w: y_b = Linv x_b; lanes w .. h - 1: x_next -= Q x_b -- ONE loop for both (the stored Linv has exact zeros above its diagonal, so the
-        // row sum may run over all w columns; two divergent loops were issued one after the other)
-        double acc = 0.0;
-        int tgt = -1;
-        const bool top = lane < w;
-        const int t = lane - w;
-        const double* cf = top ? Li + lane : Q + (lane < h ? t : 0);
-        const int cs = top ? w : u;
-        if (top) tgt = start + lane;
-        else if (lane < h) { tgt = t < offb ? start + w + t : n - arrow + (t - offb); acc = x[tgt]; }
-        if (lane < h) {
-            for (int k = 0; k < w; ++k) {
-                const double cv = cf[k * cs];
-                acc += (top ? cv : -cv) * x[start + k];
-            }
+        switch (w) {
+        case 1: solve_stage_fwd_wave<1>(Li, x, h, u, offb, start, tail, lane); break;
+        case 2: solve_stage_fwd_wave<2>(Li, x, h, u, offb, start, tail, lane); break;
+        case 3: solve_stage_fwd_wave<3>(Li, x, h, u, offb, start, tail, lane); break;
+        case 4: solve_stage_fwd_wave<4>(Li, x, h, u, offb, start, tail, lane); break;
+        case 5: solve_stage_fwd_wave<5>(Li, x, h, u, offb, start, tail, lane); break;
+        case 6: solve_stage_fwd_wave<6>(Li, x, h, u, offb, start, tail, lane); break;
+        case 7: solve_stage_fwd_wave<7>(Li, x, h, u, offb, start, tail, lane); break;
+        case 8: solve_stage_fwd_wave<8>(Li, x, h, u, offb, start, tail, lane); break;
+        default: break;
         }
-        wave_lds_sync();  // every read of x_b above has returned before any lane overwrites it
-        if (tgt >= 0) x[tgt] = acc;
-        wave_lds_sync();
     }
     for (int b = N - 1; b >= 0; --b) {
         const int h = __builtin_amdgcn_readfirstlane(M.H(b)), w = __builtin_amdgcn_readfirstlane(M.W(b));
         if (h == 0) continue;
         const int u = h - w, offb = __builtin_amdgcn_readfirstlane(M.Off(b)), start = __builtin_amdgcn_readfirstlane(M.Start(b));
         const double* Li = pan + uni(M.PanOff(b));
-        const double* Q = Li + w * w;
-        double acc = 0.0;
-        if (lane < w) {  // x_b = Linv^T x_b - Q^T x_next
-            for (int k = lane; k < w; ++k) acc += Li[k + lane * w] * x[start + k];
-            for (int t = 0; t < u; ++t) acc -= Q[t + lane * u] * x[t < offb ? start + w + t : n - arrow + (t - offb)];
+        switch (w) {
+        case 1: solve_stage_bwd_wave<1>(Li, x, u, offb, start, tail, lane); break;
+        case 2: solve_stage_bwd_wave<2>(Li, x, u, offb, start, tail, lane); break;
+        case 3: solve_stage_bwd_wave<3>(Li, x, u, offb, start, tail, lane); break;
+        case 4: solve_stage_bwd_wave<4>(Li, x, u, offb, start, tail, lane); break;
+        case 5: solve_stage_bwd_wave<5>(Li, x, u, offb, start, tail, lane); break;
+        case 6: solve_stage_bwd_wave<6>(Li, x, u, offb, start, tail, lane); break;
+        case 7: solve_stage_bwd_wave<7>(Li, x, u, offb, start, tail, lane); break;
+        case 8: solve_stage_bwd_wave<8>(Li, x, u, offb, start, tail, lane); break;
+        default: break;
         }
-        wave_lds_sync();
-        if (lane < w) x[start + lane] = acc;
-        wave_lds_sync();
     }
 }
 
