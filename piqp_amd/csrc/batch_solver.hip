@@ -66,6 +66,15 @@ struct BatchShared {
     pq_settings set;
 };
 
+// Everything in the per-instance arena and every shared index array is device memory, and the interior-point code says so in its pointer types: through
+// generic pointers (what a pointer read from a struct or passed to an out-of-line member is to the compiler) every access was a FLAT instruction, which
+// counts on the LDS counter as well -- each read of the descriptor or the solver state (LDS) then also waited for all vector loads in flight.
+typedef __attribute__((address_space(1))) double gdbl;
+template <class T>
+__device__ __forceinline__ const __attribute__((address_space(1))) T* g(const T* p) { return (const __attribute__((address_space(1))) T*)p; }
+__device__ __forceinline__ double* gen(gdbl* p) { return (double*)p; }              // for the routines shared with the LDS-resident modes
+__device__ __forceinline__ const double* gen(const gdbl* p) { return (const double*)p; }
+
 // ---- workgroup collectives ------------------------------------------------------------------------------------
 struct OpSum { __device__ double operator()(double a, double b) const { return a + b; } };
 struct OpMax { __device__ double operator()(double a, double b) const { return a < b ? b : a; } };            // std::max
@@ -116,7 +125,7 @@ struct Ipm {
     static constexpr bool RES = MODE == MODE_RESIDENT;
     static constexpr bool WAVE = MODE == MODE_WAVE;
     const BatchShared& S;
-    double* base;
+    gdbl* base;
     double* sm;   // chain workspace (dynamic LDS)
     double* red;  // reduction scratch
     // Scalar solver state.  Every thread computes the same scalars; they are kept ONCE PER WAVE in LDS instead of in
@@ -132,7 +141,7 @@ struct Ipm {
     int& refine_enabled;
     int& ks_use_refine;
 
-    __device__ Ipm(const BatchShared& s, double* b, double* sm_, double* red_, IpmState& state)
+    __device__ Ipm(const BatchShared& s, gdbl* b, double* sm_, double* red_, IpmState& state)
         : S(s), base(b), sm(sm_), red(red_), st(state), info(state.info), rz_c(state.rz_c), rz_c_inv(state.rz_c_inv), ks_rho(state.ks_rho), ks_delta(state.ks_delta),
           be_delta(state.be_delta), refine_enabled(state.refine_enabled), ks_use_refine(state.ks_use_refine)
     {
@@ -141,7 +150,7 @@ struct Ipm {
     // The out-of-line member functions see everything through generic pointers (FLAT loads / stores, which also tie the LDS and the memory wait
     // counters together).  What lives in LDS -- the shared descriptor, the solver state -- is stated as an assumption; address-space inference
     // then turns those accesses into ds_read / ds_write (8192 QPs: 9.2 -> 8.8 ms for the descriptor alone).
-    __device__ __forceinline__ double* arena_ptr(long long off) const
+    __device__ __forceinline__ gdbl* arena_ptr(long long off) const
     {
         return base + off;  // (stating "neither LDS nor private" as an assumption does not make these global_load with this compiler; they stay FLAT)
     }
@@ -170,50 +179,50 @@ struct Ipm {
         __builtin_assume(__builtin_amdgcn_is_shared((const void*)&ks_use_refine));
 #endif
     }
-    __device__ __forceinline__ double* at(int slot) const { return arena_ptr(shared().off[slot]); }
-    __device__ __forceinline__ double* v(int set, int f) const { return arena_ptr(shared().off[set + f]); }
+    __device__ __forceinline__ gdbl* at(int slot) const { return arena_ptr(shared().off[slot]); }
+    __device__ __forceinline__ gdbl* v(int set, int f) const { return arena_ptr(shared().off[set + f]); }
     __device__ __forceinline__ int tid() const { return threadIdx.x; }
 
     template <class Op>
     __device__ __forceinline__ double reduce(double x, Op op) const { return wg_reduce<NT>(x, op, red); }
 
     // ---- mat-vecs (sparse/kkt.hpp:179-203 / multistage_kkt.hpp:291-383), ending with a barrier --------------------
-    __device__ void eval_P_x(double alpha, const double* x, double* z) const
+    __device__ void eval_P_x(double alpha, const gdbl* x, gdbl* z) const
     {
-        const double* Px = at(D_PX);
+        const gdbl* Px = at(D_PX);
         for (int j = tid(); j < S.n; j += NT) {
             double s = 0.0;
-            for (int q = S.Pf_p[j]; q < S.Pf_p[j + 1]; ++q) s += Px[S.Pf_src[q]] * x[S.Pf_i[q]];
+            for (int q = g(S.Pf_p)[j]; q < g(S.Pf_p)[j + 1]; ++q) s += Px[g(S.Pf_src)[q]] * x[g(S.Pf_i)[q]];
             z[j] = alpha * s;
         }
         __syncthreads();
     }
-    __device__ void eval_A(double an, double at_, const double* xn, const double* xt, double* zn, double* zt) const
+    __device__ void eval_A(double an, double at_, const gdbl* xn, const gdbl* xt, gdbl* zn, gdbl* zt) const
     {
-        const double* Ax = at(D_ATX);
+        const gdbl* Ax = at(D_ATX);
         for (int k = tid(); k < S.p; k += NT) {
             double s = 0.0;
-            for (int q = S.AT_p[k]; q < S.AT_p[k + 1]; ++q) s += Ax[q] * xn[S.AT_i[q]];
+            for (int q = g(S.AT_p)[k]; q < g(S.AT_p)[k + 1]; ++q) s += Ax[q] * xn[g(S.AT_i)[q]];
             zn[k] = an * s;
         }
         for (int j = tid(); j < S.n; j += NT) {
             double s = 0.0;
-            for (int q = S.A_p[j]; q < S.A_p[j + 1]; ++q) s += Ax[S.A_src[q]] * xt[S.A_i[q]];
+            for (int q = g(S.A_p)[j]; q < g(S.A_p)[j + 1]; ++q) s += Ax[g(S.A_src)[q]] * xt[g(S.A_i)[q]];
             zt[j] = at_ * s;
         }
         __syncthreads();
     }
-    __device__ void eval_G(double an, double at_, const double* xn, const double* xt, double* zn, double* zt) const
+    __device__ void eval_G(double an, double at_, const gdbl* xn, const gdbl* xt, gdbl* zn, gdbl* zt) const
     {
-        const double* Gx = at(D_GTX);
+        const gdbl* Gx = at(D_GTX);
         for (int k = tid(); k < S.m; k += NT) {
             double s = 0.0;
-            for (int q = S.GT_p[k]; q < S.GT_p[k + 1]; ++q) s += Gx[q] * xn[S.GT_i[q]];
+            for (int q = g(S.GT_p)[k]; q < g(S.GT_p)[k + 1]; ++q) s += Gx[q] * xn[g(S.GT_i)[q]];
             zn[k] = an * s;
         }
         for (int j = tid(); j < S.n; j += NT) {
             double s = 0.0;
-            for (int q = S.G_p[j]; q < S.G_p[j + 1]; ++q) s += Gx[S.G_src[q]] * xt[S.G_i[q]];
+            for (int q = g(S.G_p)[j]; q < g(S.G_p)[j + 1]; ++q) s += Gx[g(S.G_src)[q]] * xt[g(S.G_i)[q]];
             zt[j] = at_ * s;
         }
         __syncthreads();
@@ -228,66 +237,80 @@ struct Ipm {
         return PackedMeta{s.M.N, s.M.arrow, s.M.n, mi, reinterpret_cast<const long long*>(mi + 4 * s.M.N)};
     }
 
-    __device__ __noinline__ void be_factor(double delta, const double* x_reg, const double* z_reg)
+    __device__ __noinline__ void be_factor(double delta, const gdbl* x_reg, const gdbl* z_reg)
     {
         assume_lds();
         extern __shared__ double dyn[];
         const PackedMeta PM = packed_meta(S, dyn);
-        double* F = RES ? dyn + S.res_f : at(B_F);
-        double* PAN = (RES || WAVE) ? dyn + S.res_pan : at(B_PAN);
-        double* CH = (RES || WAVE) ? dyn + S.res_chain : dyn;
-        double* zinv = at(B_ZINV);
+        gdbl* zinv = at(B_ZINV);
         for (int i = tid(); i < S.m; i += NT) zinv[i] = 1.0 / z_reg[i];
         __syncthreads();
         be_delta = delta;
         const double delta_inv = 1.0 / delta;
         const long long t0 = wall_clock64();
-        msdev::assemble_flat<NT>(PM, S.GG, at(B_XG), at(B_PF), at(B_ATAF), zinv, x_reg, delta_inv, F, S.ent_b, S.ent_rc, S.n_ent);
-        __syncthreads();
-        const long long t1 = wall_clock64();
-        if constexpr (WAVE) msdev::factor_chain_wave(PM, (msdev::global_cdouble*)F, PAN);
-        else msdev::factor_chain<NT, LDS>(PM, F, PAN, CH, S.fcap, S.lofs, 1);
+        long long t1;
+        if constexpr (WAVE) {  // fronts in the arena (device memory), factor panels in LDS
+            gdbl* F = at(B_F);
+            msdev::assemble_flat<NT>(PM, S.GG, at(B_XG), at(B_PF), at(B_ATAF), zinv, x_reg, delta_inv, F, g(S.ent_b), g(S.ent_rc), S.n_ent);
+            __syncthreads();
+            t1 = wall_clock64();
+            msdev::factor_chain_wave(PM, (msdev::global_cdouble*)F, dyn + S.res_pan);
+        } else {
+            double* F = RES ? dyn + S.res_f : gen(at(B_F));
+            double* PAN = RES ? dyn + S.res_pan : gen(at(B_PAN));
+            double* CH = RES ? dyn + S.res_chain : dyn;
+            msdev::assemble_flat<NT>(PM, S.GG, at(B_XG), at(B_PF), at(B_ATAF), zinv, x_reg, delta_inv, F, g(S.ent_b), g(S.ent_rc), S.n_ent);
+            __syncthreads();
+            t1 = wall_clock64();
+            msdev::factor_chain<NT, LDS>(PM, F, PAN, CH, S.fcap, S.lofs, 1);
+        }
         __syncthreads();
         const long long t2 = wall_clock64();
         st.prof[T_ASM] += t1 - t0; st.prof[T_FAC] += t2 - t1;
         info.n_factor++;
     }
-    __device__ __noinline__ void be_solve(const double* rhs_x, const double* rhs_y, const double* rhs_z, double* lhs_x, double* lhs_y, double* lhs_z)
+    // XW: the vector the chain works on -- an LDS copy of x in the resident / single-wave modes, lhs_x itself (arena) otherwise
+    template <class XW>
+    __device__ __forceinline__ void be_solve_with(XW xw, const gdbl* rhs_x, const gdbl* rhs_y, const gdbl* rhs_z, gdbl* lhs_x, gdbl* lhs_y, gdbl* lhs_z)
     {
-        assume_lds();
         extern __shared__ double dyn[];
         const PackedMeta PM = packed_meta(S, dyn);
-        const double* PAN = (RES || WAVE) ? dyn + S.res_pan : at(B_PAN);
-        double* CH = (RES || WAVE) ? dyn + S.res_chain : dyn;
-        const double* zinv = at(B_ZINV);
-        const double* Ax = at(D_ATX);
-        const double* Gx = at(D_GTX);
+        const gdbl* zinv = at(B_ZINV);
+        const gdbl* Ax = at(D_ATX);
+        const gdbl* Gx = at(D_GTX);
         const double delta_inv = 1.0 / be_delta;
-        double* xw = (RES || WAVE) ? dyn + S.res_x : lhs_x;  // the chain works on an LDS copy of x in resident mode
         for (int j = tid(); j < S.n; j += NT) {
             double sg = 0.0, sa = 0.0;
-            for (int q = S.G_p[j]; q < S.G_p[j + 1]; ++q) { const int i = S.G_i[q]; sg += Gx[S.G_src[q]] * (zinv[i] * rhs_z[i]); }
-            for (int q = S.A_p[j]; q < S.A_p[j + 1]; ++q) sa += Ax[S.A_src[q]] * rhs_y[S.A_i[q]];
+            for (int q = g(S.G_p)[j]; q < g(S.G_p)[j + 1]; ++q) { const int i = g(S.G_i)[q]; sg += Gx[g(S.G_src)[q]] * (zinv[i] * rhs_z[i]); }
+            for (int q = g(S.A_p)[j]; q < g(S.A_p)[j + 1]; ++q) sa += Ax[g(S.A_src)[q]] * rhs_y[g(S.A_i)[q]];
             xw[j] = (rhs_x[j] + sg) + delta_inv * sa;
         }
         __syncthreads();
         const long long t0 = wall_clock64();
-        if constexpr (WAVE) { msdev::solve_chain_wave(PM, PAN, xw); __syncthreads(); }
-        else msdev::solve_chain<NT, LDS>(PM, PAN, xw, CH, S.hcap);
+        if constexpr (WAVE) { msdev::solve_chain_wave(PM, dyn + S.res_pan, xw); __syncthreads(); }
+        else if constexpr (RES) msdev::solve_chain<NT, LDS>(PM, dyn + S.res_pan, xw, dyn + S.res_chain, S.hcap);
+        else msdev::solve_chain<NT, LDS>(PM, gen(at(B_PAN)), gen(xw), dyn, S.hcap);
         st.prof[T_CHAIN] += wall_clock64() - t0;
         if constexpr (RES || WAVE) for (int j = tid(); j < S.n; j += NT) lhs_x[j] = xw[j];
         for (int k = tid(); k < S.p; k += NT) {
             double s = 0.0;
-            for (int q = S.AT_p[k]; q < S.AT_p[k + 1]; ++q) s += Ax[q] * xw[S.AT_i[q]];
+            for (int q = g(S.AT_p)[k]; q < g(S.AT_p)[k + 1]; ++q) s += Ax[q] * xw[g(S.AT_i)[q]];
             lhs_y[k] = delta_inv * s - delta_inv * rhs_y[k];
         }
         for (int i = tid(); i < S.m; i += NT) {
             double s = 0.0;
-            for (int q = S.GT_p[i]; q < S.GT_p[i + 1]; ++q) s += Gx[q] * xw[S.GT_i[q]];
+            for (int q = g(S.GT_p)[i]; q < g(S.GT_p)[i + 1]; ++q) s += Gx[q] * xw[g(S.GT_i)[q]];
             lhs_z[i] = (s - rhs_z[i]) * zinv[i];
         }
         __syncthreads();
         info.n_backend_solve++;
+    }
+    __device__ __noinline__ void be_solve(const gdbl* rhs_x, const gdbl* rhs_y, const gdbl* rhs_z, gdbl* lhs_x, gdbl* lhs_y, gdbl* lhs_z)
+    {
+        assume_lds();
+        extern __shared__ double dyn[];
+        if constexpr (RES || WAVE) be_solve_with<double*>(dyn + S.res_x, rhs_x, rhs_y, rhs_z, lhs_x, lhs_y, lhs_z);
+        else be_solve_with<gdbl*>(lhs_x, rhs_x, rhs_y, rhs_z, lhs_x, lhs_y, lhs_z);
     }
 
     // ---- KKTSystem (kkt_system.hpp) -----------------------------------------------------------------------------
@@ -297,10 +320,10 @@ struct Ipm {
         assume_lds();
         const int n = S.n, m = S.m;
         ks_rho = rho; ks_delta = delta;
-        const double* xbs = at(D_XBS);
-        double *s_l = at(K_SL), *s_u = at(K_SU), *s_bl = at(K_SBL), *s_bu = at(K_SBU);
-        double *zli = at(K_ZLI), *zui = at(K_ZUI), *zbli = at(K_ZBLI), *zbui = at(K_ZBUI);
-        double *x_reg = at(K_XREG), *z_reg = at(K_ZREG), *z_reg_ref = at(K_ZREGR);
+        const gdbl* xbs = at(D_XBS);
+        gdbl*s_l = at(K_SL), *s_u = at(K_SU), *s_bl = at(K_SBL), *s_bu = at(K_SBU);
+        gdbl*zli = at(K_ZLI), *zui = at(K_ZUI), *zbli = at(K_ZBLI), *zbui = at(K_ZBUI);
+        gdbl*x_reg = at(K_XREG), *z_reg = at(K_ZREG), *z_reg_ref = at(K_ZREGR);
         for (int i = tid(); i < m; i += NT) {
             s_l[i] = v(V_R, FSL)[i]; s_u[i] = v(V_R, FSU)[i];
             zli[i] = 1.0 / v(V_R, FZL)[i]; zui[i] = 1.0 / v(V_R, FZU)[i];
@@ -310,26 +333,26 @@ struct Ipm {
         __syncthreads();
         for (int j = tid(); j < n; j += NT) {
             double xr = rho;
-            const int il = S.pos_l[j], iu = S.pos_u[j];
+            const int il = g(S.pos_l)[j], iu = g(S.pos_u)[j];
             if (il >= 0) xr += xbs[j] * xbs[j] / (zbli[il] * s_bl[il] + delta);
             if (iu >= 0) xr += xbs[j] * xbs[j] / (zbui[iu] * s_bu[iu] + delta);
             x_reg[j] = xr;
         }
         for (int i = tid(); i < m; i += NT) {
             double zr = 0.0;
-            if (S.has_l[i]) zr += 1.0 / (zli[i] * s_l[i] + delta);
-            if (S.has_u[i]) zr += 1.0 / (zui[i] * s_u[i] + delta);
+            if (g(S.has_l)[i]) zr += 1.0 / (zli[i] * s_l[i] + delta);
+            if (g(S.has_u)[i]) zr += 1.0 / (zui[i] * s_u[i] + delta);
             zr = 1.0 / zr;
             z_reg[i] = zr; z_reg_ref[i] = zr;
         }
         __syncthreads();
         double delta_reg = delta;
         if (iterative_refinement) {
-            const double* Pd = at(D_PX);  // diag(P) gathered below through the symmetrised pattern
+            const gdbl* Pd = at(D_PX);  // diag(P) gathered below through the symmetrised pattern
             double mx = 0.0;
             for (int j = tid(); j < n; j += NT) {
                 double pd = 0.0;
-                for (int q = S.Pf_p[j]; q < S.Pf_p[j + 1]; ++q) if (S.Pf_i[q] == j) pd = Pd[S.Pf_src[q]];
+                for (int q = g(S.Pf_p)[j]; q < g(S.Pf_p)[j + 1]; ++q) if (g(S.Pf_i)[q] == j) pd = Pd[g(S.Pf_src)[q]];
                 const double a = fabs(pd + x_reg[j]);
                 if (a > mx) mx = a;
             }
@@ -351,22 +374,22 @@ struct Ipm {
     }
 
     // :507-536 err = rhs - K_cond * lhs, returns |err|_inf (NaN-propagating)
-    __device__ __noinline__ double refine_error(const double* lx, const double* ly, const double* lz, const double* rx, const double* ry, const double* rz, double* ex, double* ey,
-                                   double* ez)
+    __device__ __noinline__ double refine_error(const gdbl* lx, const gdbl* ly, const gdbl* lz, const gdbl* rx, const gdbl* ry, const gdbl* rz, gdbl* ex, gdbl* ey,
+                                   gdbl* ez)
     {
         assume_lds();
         const int n = S.n, p = S.p, m = S.m;
-        const double* Px = at(D_PX);
-        const double* Ax = at(D_ATX);
-        const double* Gx = at(D_GTX);
-        const double* x_reg = at(K_XREG);
-        const double* z_reg = at(K_ZREG);
+        const gdbl* Px = at(D_PX);
+        const gdbl* Ax = at(D_ATX);
+        const gdbl* Gx = at(D_GTX);
+        const gdbl* x_reg = at(K_XREG);
+        const gdbl* z_reg = at(K_ZREG);
         double mx = 0.0;
         for (int j = tid(); j < n; j += NT) {
             double sp = 0.0, sa = 0.0, sg = 0.0;
-            for (int q = S.Pf_p[j]; q < S.Pf_p[j + 1]; ++q) sp += Px[S.Pf_src[q]] * lx[S.Pf_i[q]];
-            for (int q = S.A_p[j]; q < S.A_p[j + 1]; ++q) sa += Ax[S.A_src[q]] * ly[S.A_i[q]];
-            for (int q = S.G_p[j]; q < S.G_p[j + 1]; ++q) sg += Gx[S.G_src[q]] * lz[S.G_i[q]];
+            for (int q = g(S.Pf_p)[j]; q < g(S.Pf_p)[j + 1]; ++q) sp += Px[g(S.Pf_src)[q]] * lx[g(S.Pf_i)[q]];
+            for (int q = g(S.A_p)[j]; q < g(S.A_p)[j + 1]; ++q) sa += Ax[g(S.A_src)[q]] * ly[g(S.A_i)[q]];
+            for (int q = g(S.G_p)[j]; q < g(S.G_p)[j + 1]; ++q) sg += Gx[g(S.G_src)[q]] * lz[g(S.G_i)[q]];
             const double e = rx[j] - (((sp + x_reg[j] * lx[j]) + sa) + sg);
             ex[j] = e;
             const double a = fabs(e);
@@ -374,7 +397,7 @@ struct Ipm {
         }
         for (int k = tid(); k < p; k += NT) {
             double s = 0.0;
-            for (int q = S.AT_p[k]; q < S.AT_p[k + 1]; ++q) s += Ax[q] * lx[S.AT_i[q]];
+            for (int q = g(S.AT_p)[k]; q < g(S.AT_p)[k + 1]; ++q) s += Ax[q] * lx[g(S.AT_i)[q]];
             const double e = ry[k] - (s - ks_delta * ly[k]);
             ey[k] = e;
             const double a = fabs(e);
@@ -382,7 +405,7 @@ struct Ipm {
         }
         for (int i = tid(); i < m; i += NT) {
             double s = 0.0;
-            for (int q = S.GT_p[i]; q < S.GT_p[i + 1]; ++q) s += Gx[q] * lx[S.GT_i[q]];
+            for (int q = g(S.GT_p)[i]; q < g(S.GT_p)[i + 1]; ++q) s += Gx[q] * lx[g(S.GT_i)[q]];
             const double e = rz[i] - (s - z_reg[i] * lz[i]);
             ez[i] = e;
             const double a = fabs(e);
@@ -393,7 +416,7 @@ struct Ipm {
         return r;
     }
 
-    __device__ double inf_norm3(const double* a, int na, const double* b, int nb, const double* c, int nc)
+    __device__ double inf_norm3(const gdbl* a, int na, const gdbl* b, int nb, const gdbl* c, int nc)
     {
         double mx = 0.0;
         for (int i = tid(); i < na; i += NT) { const double t = fabs(a[i]); if (t > mx || t != t) mx = t; }
@@ -414,32 +437,32 @@ struct Ipm {
     __device__ __forceinline__ bool ks_solve_impl(int rhs, int lhs)
     {
         const int n = S.n, p = S.p, m = S.m;
-        const double* xbs = at(D_XBS);
-        const double *s_l = at(K_SL), *s_u = at(K_SU), *s_bl = at(K_SBL), *s_bu = at(K_SBU);
-        const double *zli = at(K_ZLI), *zui = at(K_ZUI), *zbli = at(K_ZBLI), *zbui = at(K_ZBUI);
-        const double* z_reg = at(K_ZREG);
-        double *rxb = at(K_RXB), *rzb = at(K_RZB), *lz = at(K_LZ);
+        const gdbl* xbs = at(D_XBS);
+        const gdbl*s_l = at(K_SL), *s_u = at(K_SU), *s_bl = at(K_SBL), *s_bu = at(K_SBU);
+        const gdbl*zli = at(K_ZLI), *zui = at(K_ZUI), *zbli = at(K_ZBLI), *zbui = at(K_ZBUI);
+        const gdbl* z_reg = at(K_ZREG);
+        gdbl*rxb = at(K_RXB), *rzb = at(K_RZB), *lz = at(K_LZ);
         const double delta = ks_delta;
         for (int i = tid(); i < m; i += NT) {
             double r = 0.0;
-            if (S.has_l[i]) r -= 1.0 / (zli[i] * s_l[i] + delta) * (v(rhs, FZL)[i] - zli[i] * v(rhs, FSL)[i]);
-            if (S.has_u[i]) r += 1.0 / (zui[i] * s_u[i] + delta) * (v(rhs, FZU)[i] - zui[i] * v(rhs, FSU)[i]);
+            if (g(S.has_l)[i]) r -= 1.0 / (zli[i] * s_l[i] + delta) * (v(rhs, FZL)[i] - zli[i] * v(rhs, FSL)[i]);
+            if (g(S.has_u)[i]) r += 1.0 / (zui[i] * s_u[i] + delta) * (v(rhs, FZU)[i] - zui[i] * v(rhs, FSU)[i]);
             rzb[i] = r * z_reg[i];
         }
         for (int j = tid(); j < n; j += NT) {
             double r = v(rhs, FX)[j];
-            const int il = S.pos_l[j], iu = S.pos_u[j];
+            const int il = g(S.pos_l)[j], iu = g(S.pos_u)[j];
             if (il >= 0) r -= xbs[j] * (v(rhs, FZBL)[il] - zbli[il] * v(rhs, FSBL)[il]) / (s_bl[il] * zbli[il] + delta);
             if (iu >= 0) r += xbs[j] * (v(rhs, FZBU)[iu] - zbui[iu] * v(rhs, FSBU)[iu]) / (s_bu[iu] * zbui[iu] + delta);
             rxb[j] = r;
         }
         __syncthreads();
-        double *lx = v(lhs, FX), *ly = v(lhs, FY);
-        const double* ry = v(rhs, FY);
+        gdbl*lx = v(lhs, FX), *ly = v(lhs, FY);
+        const gdbl* ry = v(rhs, FY);
         be_solve(rxb, ry, rzb, lx, ly, lz);
 
         if (ks_use_refine) {
-            double *ex = at(K_EX), *ey = at(K_EY), *ez = at(K_EZ), *rlx = at(K_RLX), *rly = at(K_RLY), *rlz = at(K_RLZ);
+            gdbl*ex = at(K_EX), *ey = at(K_EY), *ez = at(K_EZ), *rlx = at(K_RLX), *rly = at(K_RLY), *rlz = at(K_RLZ);
             const double rhs_norm = inf_norm3(rxb, n, ry, p, rzb, m);
             double err = refine_error(lx, ly, lz, rxb, ry, rzb, ex, ey, ez);
             if (!isfinite(err)) return false;
@@ -473,7 +496,7 @@ struct Ipm {
 
         // :310-345 dual recovery
         for (int i = tid(); i < m; i += NT) {
-            const bool hl = S.has_l[i] != 0, hu = S.has_u[i] != 0;
+            const bool hl = g(S.has_l)[i] != 0, hu = g(S.has_u)[i] != 0;
             double zl = 0.0, zu = 0.0, sl = 0.0, su = 0.0;
             if (hl && hu) {
                 const double rz_l_bar = v(rhs, FZL)[i] - zli[i] * v(rhs, FSL)[i];
@@ -496,13 +519,13 @@ struct Ipm {
         }
         // :347-366 box dual recovery
         for (int i = tid(); i < S.n_x_l; i += NT) {
-            const int idx = S.x_l_idx[i];
+            const int idx = g(S.x_l_idx)[i];
             const double z = (-xbs[idx] * lx[idx] - v(rhs, FZBL)[i] + zbli[i] * v(rhs, FSBL)[i]) / (s_bl[i] * zbli[i] + delta);
             v(lhs, FZBL)[i] = z;
             v(lhs, FSBL)[i] = zbli[i] * (v(rhs, FSBL)[i] - s_bl[i] * z);
         }
         for (int i = tid(); i < S.n_x_u; i += NT) {
-            const int idx = S.x_u_idx[i];
+            const int idx = g(S.x_u_idx)[i];
             const double z = (xbs[idx] * lx[idx] - v(rhs, FZBU)[i] + zbui[i] * v(rhs, FSBU)[i]) / (s_bu[i] * zbui[i] + delta);
             v(lhs, FZBU)[i] = z;
             v(lhs, FSBU)[i] = zbui[i] * (v(rhs, FSBU)[i] - s_bu[i] * z);
@@ -513,7 +536,7 @@ struct Ipm {
     }
 
     // ---- solver.hpp helpers --------------------------------------------------------------------------------------
-    __device__ __noinline__ double dot2(const double* a, const double* b, int cnt)
+    __device__ __noinline__ double dot2(const gdbl* a, const gdbl* b, int cnt)
     {
         assume_lds();
         double s = 0.0;
@@ -543,14 +566,14 @@ struct Ipm {
         alpha_s = reduce(as, OpMin());
         alpha_z = reduce(az, OpMin());
     }
-    __device__ __noinline__ double min_coeff(const double* a, int cnt)
+    __device__ __noinline__ double min_coeff(const gdbl* a, int cnt)
     {
         assume_lds();
         double mn = DBL_MAX;
         for (int i = tid(); i < cnt; i += NT) if (a[i] < mn) mn = a[i];
         return reduce(mn, OpMin());
     }
-    __device__ __noinline__ double inf_scaled(const double* a, const double* sc, double c, int cnt)
+    __device__ __noinline__ double inf_scaled(const gdbl* a, const gdbl* sc, double c, int cnt)
     {
         assume_lds();
         double mx = 0.0;
@@ -562,25 +585,25 @@ struct Ipm {
     {
         assume_lds();
         const int n = S.n, p = S.p, m = S.m;
-        const double* dinv = at(D_DLI);
-        const double* dbi = at(D_DBI);
+        const gdbl* dinv = at(D_DLI);
+        const gdbl* dbi = at(D_DBI);
         double inf = inf_scaled(v(set, FY), dinv + n, 1.0, p);
         inf = fmax_std(inf, inf_scaled(v(set, FZL), dinv + n + p, 1.0, m));
         inf = fmax_std(inf, inf_scaled(v(set, FZU), dinv + n + p, 1.0, m));
         double mx = inf;
-        for (int i = tid(); i < S.n_x_l; i += NT) { const double t = v(set, FZBL)[i] * dbi[S.x_l_idx[i]]; if (mx < t) mx = t; }
-        for (int i = tid(); i < S.n_x_u; i += NT) { const double t = v(set, FZBU)[i] * dbi[S.x_u_idx[i]]; if (mx < t) mx = t; }
+        for (int i = tid(); i < S.n_x_l; i += NT) { const double t = v(set, FZBL)[i] * dbi[g(S.x_l_idx)[i]]; if (mx < t) mx = t; }
+        for (int i = tid(); i < S.n_x_u; i += NT) { const double t = v(set, FZBU)[i] * dbi[g(S.x_u_idx)[i]]; if (mx < t) mx = t; }
         return reduce(mx, OpMax());
     }
     static __device__ __forceinline__ double fmax_std(double a, double b) { return a < b ? b : a; }
     // :1184-1196
-    __device__ double dual_res_of(const double* x) { return inf_scaled(x, at(D_DLI), rz_c_inv, S.n); }
+    __device__ double dual_res_of(const gdbl* x) { return inf_scaled(x, at(D_DLI), rz_c_inv, S.n); }
     // :1166-1182
     __device__ double primal_prox_inf()
     {
         const int n = S.n, p = S.p, m = S.m;
-        const double* dl = at(D_DL);
-        const double* db = at(D_DB);
+        const gdbl* dl = at(D_DL);
+        const gdbl* db = at(D_DB);
         const double ci = rz_c_inv;
         double mx = 0.0;
         for (int i = tid(); i < p; i += NT) { const double t = fabs((v(V_PX, FY)[i] - v(V_R, FY)[i]) * ci * dl[n + i]); if (mx < t) mx = t; }
@@ -588,14 +611,14 @@ struct Ipm {
             double t = fabs((v(V_PX, FZL)[i] - v(V_R, FZL)[i]) * ci * dl[n + p + i]); if (mx < t) mx = t;
             t = fabs((v(V_PX, FZU)[i] - v(V_R, FZU)[i]) * ci * dl[n + p + i]); if (mx < t) mx = t;
         }
-        for (int i = tid(); i < S.n_x_l; i += NT) { const double t = (v(V_PX, FZBL)[i] - v(V_R, FZBL)[i]) * ci * db[S.x_l_idx[i]]; if (mx < t) mx = t; }
-        for (int i = tid(); i < S.n_x_u; i += NT) { const double t = (v(V_PX, FZBU)[i] - v(V_R, FZBU)[i]) * ci * db[S.x_u_idx[i]]; if (mx < t) mx = t; }
+        for (int i = tid(); i < S.n_x_l; i += NT) { const double t = (v(V_PX, FZBL)[i] - v(V_R, FZBL)[i]) * ci * db[g(S.x_l_idx)[i]]; if (mx < t) mx = t; }
+        for (int i = tid(); i < S.n_x_u; i += NT) { const double t = (v(V_PX, FZBU)[i] - v(V_R, FZBU)[i]) * ci * db[g(S.x_u_idx)[i]]; if (mx < t) mx = t; }
         return reduce(mx, OpMax());
     }
     // :1198-1203
     __device__ double dual_prox_inf()
     {
-        const double* dl = at(D_DL);
+        const gdbl* dl = at(D_DL);
         double mx = 0.0;
         for (int i = tid(); i < S.n; i += NT) { const double t = fabs((v(V_R, FX)[i] - v(V_PX, FX)[i]) * dl[i]); if (mx < t) mx = t; }
         return reduce(mx, OpMax());
@@ -613,18 +636,18 @@ struct Ipm {
     {
         const int n = S.n, p = S.p, m = S.m;
         const double ci = rz_c_inv;
-        const double* dinv = at(D_DLI);
-        const double* dbi = at(D_DBI);
-        const double* xbs = at(D_XBS);
-        double* work_x = v(V_ST, FX);
-        double* work_z = v(V_ST, FZL);
-        double* nrx = v(V_NR, FX);
-        const double *rx = v(V_R, FX), *c = at(D_C), *bb = at(D_B), *hl = at(D_HL), *hu = at(D_HU), *xl = at(D_XL), *xu = at(D_XU);
+        const gdbl* dinv = at(D_DLI);
+        const gdbl* dbi = at(D_DBI);
+        const gdbl* xbs = at(D_XBS);
+        gdbl* work_x = v(V_ST, FX);
+        gdbl* work_z = v(V_ST, FZL);
+        gdbl* nrx = v(V_NR, FX);
+        const gdbl*rx = v(V_R, FX), *c = at(D_C), *bb = at(D_B), *hl = at(D_HL), *hu = at(D_HU), *xl = at(D_XL), *xu = at(D_XU);
 
         eval_A(-1.0, 1.0, rx, v(V_R, FY), v(V_NR, FY), work_x);
         for (int i = tid(); i < m; i += NT) work_z[i] = v(V_R, FZU)[i] - v(V_R, FZL)[i];
         __syncthreads();
-        double* work_x_2 = nrx;
+        gdbl* work_x_2 = nrx;
         eval_G(1.0, 1.0, rx, work_z, v(V_NR, FZL), work_x_2);
         for (int i = tid(); i < m; i += NT) v(V_NR, FZU)[i] = -v(V_NR, FZL)[i];
         for (int j = tid(); j < n; j += NT) work_x[j] += work_x_2[j];
@@ -652,7 +675,7 @@ struct Ipm {
         for (int j = tid(); j < n; j += NT) {
             nrx[j] -= c[j];
             double wx = work_x[j];
-            const int il = S.pos_l[j], iu = S.pos_u[j];
+            const int il = g(S.pos_l)[j], iu = g(S.pos_u)[j];
             if (il >= 0) wx -= xbs[j] * v(V_R, FZBL)[il];
             if (iu >= 0) wx += xbs[j] * v(V_R, FZBU)[iu];
             work_x[j] = wx;
@@ -667,11 +690,11 @@ struct Ipm {
         for (int i = tid(); i < p; i += NT) v(V_NR, FY)[i] += bb[i];
         primal_rel_norm = fmax_std(primal_rel_norm, inf_scaled(bb, dinv + n, 1.0, p));
 
-        const double* dz = dinv + n + p;
+        const gdbl* dz = dinv + n + p;
         double mx = primal_rel_norm;
         for (int i = tid(); i < m; i += NT) {
-            if (S.has_l[i]) {
-                double* z = v(V_NR, FZL);
+            if (g(S.has_l)[i]) {
+                gdbl* z = v(V_NR, FZL);
                 mx = fmax_std(mx, z[i] * dz[i]);  // signed, like the reference (:1047)
                 z[i] += -hl[i] - v(V_R, FSL)[i];
                 mx = fmax_std(mx, hl[i] * dz[i]);
@@ -679,8 +702,8 @@ struct Ipm {
             } else {
                 v(V_NR, FZL)[i] = 0.0;
             }
-            if (S.has_u[i]) {
-                double* z = v(V_NR, FZU);
+            if (g(S.has_u)[i]) {
+                gdbl* z = v(V_NR, FZU);
                 mx = fmax_std(mx, z[i] * dz[i]);
                 z[i] += hu[i] - v(V_R, FSU)[i];
                 mx = fmax_std(mx, hu[i] * dz[i]);
@@ -690,7 +713,7 @@ struct Ipm {
             }
         }
         for (int i = tid(); i < S.n_x_l; i += NT) {
-            const int idx = S.x_l_idx[i];
+            const int idx = g(S.x_l_idx)[i];
             const double t = xbs[idx] * rx[idx];
             mx = fmax_std(mx, t * dbi[idx]);
             mx = fmax_std(mx, xl[i] * dbi[idx]);
@@ -698,7 +721,7 @@ struct Ipm {
             v(V_NR, FZBL)[i] = t + (-xl[i] - v(V_R, FSBL)[i]);
         }
         for (int i = tid(); i < S.n_x_u; i += NT) {
-            const int idx = S.x_u_idx[i];
+            const int idx = g(S.x_u_idx)[i];
             const double t = -xbs[idx] * rx[idx];
             mx = fmax_std(mx, t * dbi[idx]);
             mx = fmax_std(mx, xu[i] * dbi[idx]);
@@ -783,7 +806,7 @@ struct Ipm {
 
         // :416-437
         for (int i = tid(); i < m; i += NT) {
-            const double l = S.has_l[i] ? 1.0 : 0.0, u = S.has_u[i] ? 1.0 : 0.0;
+            const double l = g(S.has_l)[i] ? 1.0 : 0.0, u = g(S.has_u)[i] ? 1.0 : 0.0;
             v(V_R, FSL)[i] = l; v(V_R, FZL)[i] = l; v(V_R, FSU)[i] = u; v(V_R, FZU)[i] = u;
         }
         for (int i = tid(); i < n; i += NT) {
@@ -814,19 +837,19 @@ struct Ipm {
             if (S.n_x_u > 0) delta_z = fmax_std(delta_z, -min_coeff(v(V_R, FZBU), S.n_x_u));
             __syncthreads();
             for (int i = tid(); i < m; i += NT) {
-                if (S.has_l[i]) { v(V_R, FSL)[i] += delta_s; v(V_R, FZL)[i] += delta_z; }
-                if (S.has_u[i]) { v(V_R, FSU)[i] += delta_s; v(V_R, FZU)[i] += delta_z; }
+                if (g(S.has_l)[i]) { v(V_R, FSL)[i] += delta_s; v(V_R, FZL)[i] += delta_z; }
+                if (g(S.has_u)[i]) { v(V_R, FSU)[i] += delta_s; v(V_R, FZU)[i] += delta_z; }
             }
             for (int i = tid(); i < S.n_x_l; i += NT) { v(V_R, FSBL)[i] += delta_s; v(V_R, FZBL)[i] += delta_z; }
             for (int i = tid(); i < S.n_x_u; i += NT) { v(V_R, FSBU)[i] += delta_s; v(V_R, FZBU)[i] += delta_z; }
             __syncthreads();
             info.mu = fmax_std(calculate_mu(), 1e-10);
             const double mu = info.mu;
-            auto centre = [&](double& z, double& s) { const double cc = z - delta_z; z = (cc + sqrt(cc * cc + 4 * mu)) / 2; s = z - cc; };
+            auto centre = [&](gdbl& z, gdbl& s) { const double cc = z - delta_z; z = (cc + sqrt(cc * cc + 4 * mu)) / 2; s = z - cc; };
             __syncthreads();
             for (int i = tid(); i < m; i += NT) {
-                if (S.has_l[i]) centre(v(V_R, FZL)[i], v(V_R, FSL)[i]);
-                if (S.has_u[i]) centre(v(V_R, FZU)[i], v(V_R, FSU)[i]);
+                if (g(S.has_l)[i]) centre(v(V_R, FZL)[i], v(V_R, FSL)[i]);
+                if (g(S.has_u)[i]) centre(v(V_R, FZU)[i], v(V_R, FSU)[i]);
             }
             for (int i = tid(); i < S.n_x_l; i += NT) centre(v(V_R, FZBL)[i], v(V_R, FSBL)[i]);
             for (int i = tid(); i < S.n_x_u; i += NT) centre(v(V_R, FZBU)[i], v(V_R, FSBU)[i]);
@@ -866,8 +889,8 @@ struct Ipm {
             const double epsilon = DBL_EPSILON;
             double shifted = 0.0;
             for (int i = tid(); i < m; i += NT) {
-                if (S.has_l[i] && v(V_R, FZL)[i] < epsilon) { v(V_R, FZL)[i] += epsilon; shifted = 1.0; }
-                if (S.has_u[i] && v(V_R, FZU)[i] < epsilon) { v(V_R, FZU)[i] += epsilon; shifted = 1.0; }
+                if (g(S.has_l)[i] && v(V_R, FZL)[i] < epsilon) { v(V_R, FZL)[i] += epsilon; shifted = 1.0; }
+                if (g(S.has_u)[i] && v(V_R, FZU)[i] < epsilon) { v(V_R, FZU)[i] += epsilon; shifted = 1.0; }
             }
             bool boundary_shifted = reduce(shifted, OpMax()) > 0.0;
             if (S.n_x_l > 0 && min_coeff(v(V_R, FZBL), S.n_x_l) < epsilon) {
@@ -1005,10 +1028,10 @@ struct Ipm {
     __device__ void finish()
     {
         const int n = S.n, p = S.p, m = S.m;
-        const double* dl = at(D_DL);
-        const double* dli = at(D_DLI);
-        const double* db = at(D_DB);
-        const double* dbi = at(D_DBI);
+        const gdbl* dl = at(D_DL);
+        const gdbl* dli = at(D_DLI);
+        const gdbl* db = at(D_DB);
+        const gdbl* dbi = at(D_DBI);
         const double ci = rz_c_inv;
         for (int i = tid(); i < n; i += NT) v(V_R, FX)[i] *= dl[i];
         for (int i = tid(); i < p; i += NT) v(V_R, FY)[i] = v(V_R, FY)[i] * ci * dl[n + i];
@@ -1020,7 +1043,7 @@ struct Ipm {
             v(V_R, FZL)[i] = zl; v(V_R, FZU)[i] = zu; v(V_R, FSL)[i] = sl; v(V_R, FSU)[i] = su;
         }
         for (int j = tid(); j < n; j += NT) {
-            const int il = S.pos_l[j], iu = S.pos_u[j];
+            const int il = g(S.pos_l)[j], iu = g(S.pos_u)[j];
             v(V_RS, FZBL)[j] = il >= 0 ? v(V_R, FZBL)[il] * ci * db[j] : 0.0;
             v(V_RS, FSBL)[j] = il >= 0 ? v(V_R, FSBL)[il] * dbi[j] : 1e30;
             v(V_RS, FZBU)[j] = iu >= 0 ? v(V_R, FZBU)[iu] * ci * db[j] : 0.0;
@@ -1135,7 +1158,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     const int q = blockIdx.x;
     __shared__ IpmState state[NT / 64 > 0 ? NT / 64 : 1];
     IpmState& my = state[threadIdx.x >> 6];
-    Ipm<NT, MODE, WPE> ipm(S, arena + (long long)q * S.stride, sm, red, my);
+    Ipm<NT, MODE, WPE> ipm(S, (gdbl*)(arena + (long long)q * S.stride), sm, red, my);
     my.info = pq_info{};
     for (int i = 0; i < NPROF; ++i) my.prof[i] = 0;
     const long long t_start = wall_clock64();

@@ -93,11 +93,16 @@ __device__ __forceinline__ void assemble_stage(const Meta& M, const GroupMeta& G
 
 // all fronts of one QP in one flat loop over the lower-triangular entries (ent_b = stage, ent_rc = row | col << 16): full
 // lane utilisation and one round of overlapped HBM loads instead of one short, dependent loop per stage
-template <int NT, class Meta>
-__device__ __forceinline__ void assemble_flat(const Meta& M, const GroupMeta& Gm, const double* __restrict__ XG, const double* __restrict__ Pf,
-                                              const double* __restrict__ AtAf, const double* __restrict__ zinv, const double* __restrict__ x_reg, double delta_inv,
-                                              double* __restrict__ F, const int* __restrict__ ent_b, const int* __restrict__ ent_rc, int n_ent)
+template <int NT, class Meta, class P1, class P2, class P3, class P4, class P5, class FP, class IP>
+__device__ __forceinline__ void assemble_flat(const Meta& M, const GroupMeta& Gm, P1 XG, P2 Pf, P3 AtAf, P4 zinv, P5 x_reg, double delta_inv, FP F, IP ent_b, IP ent_rc, int n_ent)
 {
+    // (P1 .. P5 / FP / IP: pointers to double / double / const int in whatever address space the caller holds them -- the batched kernel passes device-memory
+    // pointers so that the loads are global_load, not FLAT)
+    typedef __attribute__((address_space(1))) const int gcint;
+    typedef __attribute__((address_space(1))) const long long gcll;
+    gcint* row_ptr = (gcint*)Gm.row_ptr;
+    gcint* rows_i = (gcint*)Gm.rows;
+    gcll* x_off = (gcll*)Gm.x_off;
     for (int e = threadIdx.x; e < n_ent; e += NT) {
         const int b = ent_b[e], rc = ent_rc[e];
         const int r = rc & 0xffff, c = rc >> 16;
@@ -105,9 +110,9 @@ __device__ __forceinline__ void assemble_flat(const Meta& M, const GroupMeta& Gm
         const long long at = M.FrontOff(b) + r + (long long)c * h;
         double s = 0.0;
         if (b < M.N - 1) {
-            const int k0 = Gm.row_ptr[b], rows = Gm.row_ptr[b + 1] - k0;
-            const double* Xb = XG + Gm.x_off[b];
-            for (int k = 0; k < rows; ++k) s += Xb[r + (long long)k * h] * zinv[Gm.rows[k0 + k]] * Xb[c + (long long)k * h];
+            const int k0 = row_ptr[b], rows = row_ptr[b + 1] - k0;
+            const P1 Xb = XG + x_off[b];
+            for (int k = 0; k < rows; ++k) s += Xb[r + (long long)k * h] * zinv[rows_i[k0 + k]] * Xb[c + (long long)k * h];
         }
         double v = Pf[at] + delta_inv * AtAf[at] + s;
         if (r == c && c < M.W(b)) v += x_reg[M.Start(b) + c];
