@@ -192,6 +192,7 @@ constexpr int FUSED_LDS_BYTES = (128 * (128 + 16) + 128) * 8;  // whole operand 
 // update, four strip waves for the substitution.  A panel row's task of round k needs that row's output of round k - 1, so update + substitution of ONE
 // workgroup (28 + 13 us for a whole tile) bound the round from below whatever the diagonal block does; two workgroups per row halve both.  Every element
 // receives the same products in the same order as in the whole-tile form.
+__device__ __forceinline__ bool chol_wait3(const int* p0, int w0, const int* p1, int w1, const int* p2, int w2, int* abort_w, int sleep);
 template <int NT, bool PERSIST, bool HALF = false>
 __device__ __forceinline__ bool fused_tile(const SyrkArgs& a, const int ti, const int tj, double* __restrict__ smem, const int h = 0)
 {
@@ -200,13 +201,11 @@ __device__ __forceinline__ bool fused_tile(const SyrkArgs& a, const int ti, cons
     constexpr int MTR = 2, MTC = HALF ? 2 : 4;
     constexpr int SUBR = 32, SUBC = HALF ? 32 : 64;
     constexpr int ROWS = HALF ? 64 : TS;  // rows of the tile this workgroup works on
-    double* As = smem;                    // [2][BK][LDS_LD]
-    double* Bs = smem + 2 * BK * LDS_LD;  // [2][BK][LDS_LD]
     const int row0 = ti * TS + (HALF ? 64 * h : 0), col0 = tj * TS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave / WC, wc = wave % WC;
     const bool edge = !PERSIST && ((row0 + TS > a.n) || (col0 + TS > a.n) || a.unaligned);
-    const bool skip_wave = (ti == tj) && ((wr + 1) * SUBR <= wc * SUBC);  // sub-tile strictly above the diagonal
+    const bool skip_wave = (ti == tj) && ((HALF ? 64 * h : 0) + (wr + 1) * SUBR <= wc * SUBC);  // sub-tile strictly above the diagonal
 
     d4 acc[MTC][MTR];
 #pragma unroll
@@ -230,6 +229,13 @@ __device__ __forceinline__ bool fused_tile(const SyrkArgs& a, const int ti, cons
                 }
             }
     }
+    const bool tr_row = PERSIST && HALF && a.fuse_tr2 && threadIdx.x == 0 && ti == 1 && tj == 0 && h == 0;  // PIQP_AMD_DEBUG=chol_trace: the first panel row's own timeline
+    if (tr_row) a.fuse_tr2[48] = wall_clock64();
+    if constexpr (PERSIST) {
+        // (panel tiles: the operand rows come from the panel tasks of the round before, later than the tile itself -- wait for them with the tile's loads in flight)
+        if (a.late_p[0] && !chol_wait3(nullptr, 0, a.late_p[0], a.late_w[0], a.late_p[1], a.late_w[1], a.fuse_abort, 0)) return false;
+    }
+    if (tr_row) a.fuse_tr2[49] = wall_clock64();
     const bool dbg_tile = FUSE_TS_ON && !PERSIST && a.fuse_ts && threadIdx.x == 0 && ti == 2 && tj == 1;  // debugging aid: an ordinary tile's timeline
     if (dbg_tile) a.fuse_ts[84] = clock64();
     const bool tr_tile = PERSIST && !HALF && a.fuse_tr2 && threadIdx.x == 0 && ti == 5 && tj == 3;  // PIQP_AMD_DEBUG=chol_trace: one bulk tile per round
@@ -255,47 +261,64 @@ __device__ __forceinline__ bool fused_tile(const SyrkArgs& a, const int ti, cons
                 }
             }
         }
-        if (nkt > 0) {
-            scale_tile<true, NT, true, PERSIST>(a.w, 0, a.kdim, tid, pb[0]);
-            store_tile<NT>(As, tid, pa[0]);
-            store_tile<NT>(Bs, tid, pb[0]);
-        }
-        __syncthreads();
-        if (dbg_tile) a.fuse_ts[85] = clock64();  // first operand stage in LDS
-        if (tr_tile) a.fuse_tr2[41] = wall_clock64();
+        // The stages go through LDS four at a time (8 x 18 KB: the workgroup has the 145 KB of the diagonal-block role anyway): two groups, three barriers,
+        // and sixteen k-slices back to back whose LDS reads overlap -- with one stage per barrier the K loop of a HALF tile took 12 us for 3.4 us of matrix-core
+        // work per wave, and that loop sits in every panel row's round (update, substitution, publication: the cycle that bounds the late rounds).
+        // Same k order as before: bitwise the same tile.
+        constexpr int GRP = 4;
+        double* A4 = smem;                       // [GRP][BK][LDS_LD]
+        double* B4 = smem + GRP * BK * LDS_LD;   // [GRP][BK][LDS_LD]
+        static_assert(2 * GRP * BK * LDS_LD * (int)sizeof(double) <= FUSED_LDS_BYTES, "four stages per operand must fit");
 #pragma unroll
-        for (int kt = 0; kt < 8; ++kt) {
-            if (kt < nkt) {
-                const int cur = kt & 1;
-                if (kt + 1 < 8 && kt + 1 < nkt) {  // the other LDS buffer was last read before the previous barrier
-                    scale_tile<true, NT, true, PERSIST>(a.w, (kt + 1) * BK, a.kdim, tid, pb[(kt + 1) & 7]);
-                    store_tile<NT>(As + (cur ^ 1) * BK * LDS_LD, tid, pa[(kt + 1) & 7]);
-                    store_tile<NT>(Bs + (cur ^ 1) * BK * LDS_LD, tid, pb[(kt + 1) & 7]);
-                }
-                if (!skip_wave) {
-                    const double* Asb = As + cur * BK * LDS_LD + wr * SUBR + (lane & 15);
-                    const double* Bsb = Bs + cur * BK * LDS_LD + wc * SUBC + (lane & 15);
+        for (int g0 = 0; g0 < 8; g0 += GRP) {
+            if (g0 < nkt) {
+                if (g0 > 0) __syncthreads();  // every wave has read the previous group
 #pragma unroll
-                    for (int ks = 0; ks < 4; ++ks) {
-                        const int kk = ks * 4 + (lane >> 4);
-                        double af[MTR], bf[MTC];
-#pragma unroll
-                        for (int q = 0; q < MTR; ++q) af[q] = Asb[kk * LDS_LD + q * 16];
-#pragma unroll
-                        for (int q = 0; q < MTC; ++q) bf[q] = Bsb[kk * LDS_LD + q * 16];
-#pragma unroll
-                        for (int x = 0; x < MTC; ++x)
-#pragma unroll
-                            for (int y = 0; y < MTR; ++y)
-                                acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[x], af[y], acc[x][y], 0, 0, 0);
+                for (int q = 0; q < GRP; ++q) {
+                    const int kt = g0 + q;
+                    if (kt < nkt) {
+                        scale_tile<true, NT, true, PERSIST>(a.w, kt * BK, a.kdim, tid, pb[kt]);
+                        store_tile<NT>(A4 + q * BK * LDS_LD, tid, pa[kt]);
+                        store_tile<NT>(B4 + q * BK * LDS_LD, tid, pb[kt]);
                     }
                 }
                 __syncthreads();
+                if (g0 == 0) {
+                    if (dbg_tile) a.fuse_ts[85] = clock64();  // first operand stages in LDS
+                    if (tr_tile) a.fuse_tr2[41] = wall_clock64();
+                    if (tr_row) a.fuse_tr2[50] = wall_clock64();
+                }
+                if (!skip_wave) {
+#pragma unroll
+                    for (int q = 0; q < GRP; ++q) {
+                        const int kt = g0 + q;
+                        if (kt < nkt) {
+                            const double* Asb = A4 + q * BK * LDS_LD + wr * SUBR + (lane & 15);
+                            const double* Bsb = B4 + q * BK * LDS_LD + wc * SUBC + (lane & 15);
+#pragma unroll
+                            for (int ks = 0; ks < 4; ++ks) {
+                                const int kk = ks * 4 + (lane >> 4);
+                                double af[MTR], bf[MTC];
+#pragma unroll
+                                for (int u = 0; u < MTR; ++u) af[u] = Asb[kk * LDS_LD + u * 16];
+#pragma unroll
+                                for (int u = 0; u < MTC; ++u) bf[u] = Bsb[kk * LDS_LD + u * 16];
+#pragma unroll
+                                for (int x = 0; x < MTC; ++x)
+#pragma unroll
+                                    for (int y = 0; y < MTR; ++y)
+                                        acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[x], af[y], acc[x][y], 0, 0, 0);
+                            }
+                        }
+                    }
+                }
             }
         }
+        __syncthreads();  // the K loop is done with the LDS (the epilogue / panel_follow reuse it)
     }
     if (dbg_tile) a.fuse_ts[86] = clock64();  // K loop done (the accumulators' first use waited for C)
     if (tr_tile) a.fuse_tr2[42] = wall_clock64();
+    if (tr_row) a.fuse_tr2[51] = wall_clock64();
     if (a.fuse_cnt && tj == 0 && a.fuse_pack) return panel_follow<NT, MTC, MTR, PERSIST, ROWS / 16>(a, smem, acc, row0, wr, wc, ti == 1);
     if (skip_wave) return true;
     // epilogue: lane holds rows gi (consecutive over lane&15) and columns gj = base + (lane>>4) + 4*r; the accumulator started from C
@@ -1410,6 +1433,7 @@ __device__ __forceinline__ bool panel_follow(const SyrkArgs& a, double* __restri
     // per early step, measured, against the 3.4 us the factorisation needs for one).  The blocks live at their pack index in the LDS the tile just left.
     __syncthreads();  // every wave holds its strip in registers: Ts is free
     double* Pk = Ts;
+    double* rds = Ts + PACK_BLOCKS * 256;  // [128] reciprocal pivots of the published steps (LDLt, published rows only)
     __shared__ int have_s, nblk_s, blist[PACK_BLOCKS];
     int have = 0;
 #pragma unroll
@@ -1434,6 +1458,9 @@ __device__ __forceinline__ bool panel_follow(const SyrkArgs& a, double* __restri
                 if (tid == 0 && *a.fuse_info < 0) *a.fuse_info = a.fuse_kglobal;
                 return false;
             }
+            // (LDLt, published rows: the reciprocal pivots of the newly published steps go to LDS with the blocks -- a load inside the step loop would have the
+            // loop wait for its own write-through stores, which share the counter)
+            if (PERSIST && a.fuse_ldlt && tid < 128 && tid >= 16 * k && tid < 16 * have_s) rds[tid] = ld_agent(a.fuse_rdiag + a.fuse_kglobal + tid);
             have = have_s;
             const int nb = nblk_s;
             if (nb <= 8) {
@@ -1457,18 +1484,24 @@ __device__ __forceinline__ bool panel_follow(const SyrkArgs& a, double* __restri
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) x = __builtin_amdgcn_mfma_f64_16x16x4f64(w[ks], T[k][ks], x, 0, 0, 0);
         T[k] = x;
-        if (publish) {
-            // the slice published a step ago has had a whole step to reach memory: drain (cheap by now), tell the next crew, then send this one
-            if (k > 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (lane == 0) addi_agent(a.fuse_xpub + (k - 1), 1); }
+        if (PERSIST) {
+            // (every row of the persistent launch sends its slices as they become final -- a row that stored its whole strip at the end spent 3-5 us draining
+            // 64 write-through stores per lane before it could report, and the next round's first row waits for exactly that report; only the FIRST row
+            // announces its slices, to the next crew)
+            // This slice goes out now; the slice of TWO steps ago is announced.  A write-through store is acknowledged ~2 us after its issue and a step is
+            // ~0.5 us of products: draining before every announcement made the acknowledgement the length of a step (8 x 2.7 us behind a finished
+            // diagonal block -- the longest stretch of a late round, longer than the diagonal block itself).  Vector-memory operations leave the counter in
+            // issue order, so "at most 16 outstanding" = everything older than the two youngest slices (8 stores each) has arrived.
             double* Cr = a.C + (row0 + wave * 16 + i);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int c = 16 * k + g + 4 * r;
                 double v = x[r];
-                if (a.fuse_ldlt) v *= ld_agent(a.fuse_rdiag + a.fuse_kglobal + c);
+                if (a.fuse_ldlt) v *= rds[c];
                 st_agent(Cr + (size_t)c * a.ldc, v);
                 st_agent(a.fuse_side + (row0 + wave * 16 + i) + (size_t)c * a.ldc, v);
             }
+            if (publish && k >= 2) { asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); if (lane == 0) addi_agent(a.fuse_xpub + (k - 2), 1); }
             if (a.fuse_tr2 && tid == 0 && row0 == TS) a.fuse_tr2[k] = wall_clock64();
         }
 #pragma unroll
@@ -1478,8 +1511,11 @@ __device__ __forceinline__ bool panel_follow(const SyrkArgs& a, double* __restri
             for (int ks = 0; ks < 4; ++ks) T[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(nl[ks], x[ks], T[j], 0, 0, 0);
         }
     }
+    if (PERSIST && !publish) return true;  // (the caller drains the last slices before it reports the row)
     if (publish) {
         if (!strip) return true;
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        if (lane == 0) addi_agent(a.fuse_xpub + 6, 1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) addi_agent(a.fuse_xpub + 7, 1);
         if (a.fuse_tr2 && tid == 0 && row0 == TS) a.fuse_tr2[27] = wall_clock64();
@@ -1545,6 +1581,7 @@ struct CholArgs {
     int* lready; int* tver; int* pdone;
     int* xcnt;            // per round and slice: strip waves of the first panel row that have published the slice, cumulative over the factorisations of this handle
     int* progress;        // gen + number of rounds whose panel tasks have ALL finished (they finish in round order)
+    int* dhalf;           // per round: halves of the split diagonal tile of the first bulk column that have finished (cumulative over the factorisations)
     int gen;       // launch-unique base of the flag values
     int fcount;    // persistent factorisations this handle has run before this one (pdone counters are cumulative)
     long long* trace;  // debugging aid (PIQP_AMD_DEBUG=chol_trace), nullable: per ticket 4 x wall_clock64 (100 MHz): drawn, inputs ready, done; [3] = workgroup id
@@ -1597,11 +1634,11 @@ __device__ __noinline__ bool chol_role_tile(const SyrkArgs& a, int ti, int tj)
     const SyrkArgs b = a;
     return fused_tile<CHOL_THREADS, true>(b, ti, tj, smem);
 }
-__device__ __noinline__ bool chol_role_half(const SyrkArgs& a, int ti, int h)
+__device__ __noinline__ bool chol_role_half(const SyrkArgs& a, int ti, int tj, int h)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const SyrkArgs b = a;
-    return fused_tile<CHOL_THREADS, true, true>(b, ti, 0, smem, h);
+    return fused_tile<CHOL_THREADS, true, true>(b, ti, tj, smem, h);
 }
 __global__ __launch_bounds__(CHOL_THREADS, 2) void k_chol_persistent(CholArgs c)
 {
@@ -1668,11 +1705,17 @@ __global__ __launch_bounds__(CHOL_THREADS, 2) void k_chol_persistent(CholArgs c)
         } else {
             // a tile (ti, tj) of the trailing matrix = absolute (i, j); tj == 0: the next panel (solved behind the diagonal block by the same workgroup)
             const bool panel = tk.kind == 2;
+            const int dh = tk.kind >= 4 ? tk.kind - 4 : -1;  // half of a split bulk tile (the diagonal tile of the first bulk column: it feeds the next crew)
             const int ti = tk.a, tj = panel ? 0 : tk.b;
             const int i = k + 1 + ti, j = k + 1 + tj;
-            ok = chol_wait3(k > 0 ? c.tver + (size_t)i * T + j : nullptr, c.gen + k, k > 0 ? lr + i : nullptr, ready, k > 0 ? lr + j : nullptr, ready, abort_w, panel ? 0 : 1);
+            if (panel && k > 0) {
+                ok = chol_wait3(c.tver + (size_t)i * T + j, c.gen + k, nullptr, 0, nullptr, 0, abort_w, 0);
+                a.late_p[0] = lr + i; a.late_w[0] = ready; a.late_p[1] = lr + j; a.late_w[1] = ready;
+            } else {
+                ok = chol_wait3(k > 0 ? c.tver + (size_t)i * T + j : nullptr, c.gen + k, k > 0 ? lr + i : nullptr, ready, k > 0 ? lr + j : nullptr, ready, abort_w, panel ? 0 : 1);
+            }
             if (c.trace && tid == 0) c.trace[4 * (size_t)t + 1] = wall_clock64();
-            if (ok) ok = (panel && tk.b >= 0) ? chol_role_half(a, ti, tk.b) : chol_role_tile(a, ti, tj);
+            if (ok) ok = (panel && tk.b >= 0) ? chol_role_half(a, ti, 0, tk.b) : (dh >= 0 ? chol_role_half(a, ti, tj, dh) : chol_role_tile(a, ti, tj));
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (ok && tid == 0) {
@@ -1681,7 +1724,7 @@ __global__ __launch_bounds__(CHOL_THREADS, 2) void k_chol_persistent(CholArgs c)
                     const int before = addi_agent(c.pdone + k, 1);
                     // the last panel task of the round: rounds complete in order (row i of panel k + 1 needs row i of panel k)
                     if (before + 1 - (c.fcount + 1) * chol_split(T, k) * (T - k - 2) == 0) sti_agent(c.progress, c.gen + k + 1);
-                } else {
+                } else if (dh < 0 || addi_agent(c.dhalf + k, 1) + 1 == 2 * (c.fcount + 1)) {  // (a split tile: the second half to finish announces it)
                     __hip_atomic_store(c.tver + (size_t)i * T + j, c.gen + k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
@@ -1701,6 +1744,7 @@ __global__ __launch_bounds__(CHOL_THREADS, 2) void k_chol_persistent(CholArgs c)
 // 1.50: the rows start their update later than with the early draw, and that costs more than the parked workgroups it saves; drawing with a
 // compare-and-swap on the head, so that nobody overshoots a gate: 18 ms.)
 constexpr double CHOL_DEFER = 0.05;
+constexpr bool CHOL_SPLIT_DIAG = true;
 static void chol_build_tasks(int T, std::vector<CholTask>& H)
 {
     // One queue, sorted by a key in units of chain rounds.  The crew and panel tasks of round k have key k - 1 (drawn a round early: the crew follows the
@@ -1723,7 +1767,11 @@ static void chol_build_tasks(int T, std::vector<CholTask>& H)
         }
         for (int tj = 1; tj < Tk; ++tj) {
             const double key = tj == 1 ? (double)k - 0.5 : (double)k + CHOL_DEFER * (tj - 1);
-            for (int ti = tj; ti < Tk; ++ti) all.push_back({key, 3, {3, (short)k, (short)ti, (short)tj, k}});
+            for (int ti = tj; ti < Tk; ++ti) {
+                // tile (1, 1) is the next round's diagonal block: its update stands between this round's second panel row and the next crew -- two workgroups
+                if (ti == 1 && tj == 1 && CHOL_SPLIT_DIAG) { all.push_back({key, 3, {4, (short)k, 1, 1, k}}); all.push_back({key, 3, {5, (short)k, 1, 1, k}}); }
+                else all.push_back({key, 3, {3, (short)k, (short)ti, (short)tj, k}});
+            }
         }
     }
     std::stable_sort(all.begin(), all.end(), [](const Keyed& a, const Keyed& b) { return a.key != b.key ? a.key < b.key : a.cls < b.cls; });
@@ -1733,7 +1781,7 @@ static void chol_build_tasks(int T, std::vector<CholTask>& H)
 size_t chol_task_count(int T)
 {
     size_t n = 0;
-    for (int k = 0; k + 1 < T; ++k) { const int Tk = T - k - 1; n += FUSE_ROLES + (size_t)chol_split(T, k) * (Tk - 1) + (size_t)Tk * (Tk - 1) / 2; }
+    for (int k = 0; k + 1 < T; ++k) { const int Tk = T - k - 1; n += FUSE_ROLES + (size_t)chol_split(T, k) * (Tk - 1) + (size_t)Tk * (Tk - 1) / 2 + ((CHOL_SPLIT_DIAG && Tk >= 2) ? 1 : 0); }
     return n;
 }
 
@@ -1771,7 +1819,7 @@ static const CholPlan* chol_plan(int T)
 }
 bool chol_persistent_supported(int n) { return n % FACTOR_NB == 0 && n / FACTOR_NB >= 3 && n / FACTOR_NB <= 1024; }
 bool chol_prepare(int n) { return chol_persistent_supported(n) && chol_plan(n / FACTOR_NB) != nullptr; }
-size_t chol_flag_ints(int n) { const size_t T = (size_t)(n / FACTOR_NB); return 4 + 2 * T * T + 9 * T + 1; }
+size_t chol_flag_ints(int n) { const size_t T = (size_t)(n / FACTOR_NB); return 4 + 2 * T * T + 10 * T + 1; }
 // Rounds 0 .. T - 2 of the blocked factorisation of the n x n lower triangle at A (the first diagonal block and the first panel are already
 // factored / solved: launch_potrf_diag + launch_trsm_panel).  flags: chol_flag_ints(n) ints zeroed at allocation; gen: launch-unique, advancing by
 // at least T + 2 per call; fcount: calls made before on this flag array; token_base: fused-launch tokens consumed so far (advances by T - 1).
@@ -1794,7 +1842,7 @@ bool launch_chol_persistent(bool ldlt, double* A, double* side, int lda, int n, 
     c.info = info; c.rdiag = rdiag; c.dvec = dvec; c.pack2 = pack2; c.w16 = w16;
     c.scratch = scratch; c.fuse_flags = fuse_flags; c.fuse_cnt = fuse_cnt; c.token_base = token_base;
     c.tasks = P->tasks; c.ntasks = P->ntasks;
-    c.ticket = flags; c.lready = flags + 4; c.tver = c.lready + (size_t)T * T; c.pdone = c.tver + (size_t)T * T; c.xcnt = c.pdone + T; c.progress = c.xcnt + 8 * (size_t)T;
+    c.ticket = flags; c.lready = flags + 4; c.tver = c.lready + (size_t)T * T; c.pdone = c.tver + (size_t)T * T; c.xcnt = c.pdone + T; c.progress = c.xcnt + 8 * (size_t)T; c.dhalf = c.progress + 1;
     c.gen = gen; c.fcount = fcount;
     c.trace = want_trace ? trace_d : nullptr;
     if (want_trace) PQ_HIP(hipMemsetAsync(trace_d, 0, trace_n * sizeof(long long), s));
@@ -1813,6 +1861,7 @@ bool launch_chol_persistent(bool ldlt, double* A, double* side, int lda, int n, 
         std::fprintf(stderr, "[piqp_amd] k_chol_persistent timeline (us since the first ticket), T = %d, %d tasks, grid %d\n", T, P->ntasks, P->grid);
         for (int k = 0; k + 1 < T; ++k) {
             double own_ready = 0, own_done = 0, help_done = 0, pan_ready = 0, pan_done = 0, bulk_first = 1e30, bulk_last = 0, bulk_work = 0, bulk_wait = 0;
+            double r1[3] = {0, 0, 0}, r2[3] = {0, 0, 0}, dg[3] = {0, 0, 0};  // first / second panel row, diagonal tile of the first bulk column: drawn, inputs, done (latest half)
             int nb = 0;
             for (int t = 0; t < P->ntasks; ++t) {
                 if (tk[(size_t)t].round != k) continue;
@@ -1820,12 +1869,20 @@ bool launch_chol_persistent(bool ldlt, double* A, double* side, int lda, int n, 
                 switch (tk[(size_t)t].kind) {
                 case 0: help_done = std::max(help_done, d2); break;
                 case 1: own_ready = d1; own_done = d2; break;
-                case 2: pan_ready = std::max(pan_ready, d1); pan_done = std::max(pan_done, d2); break;
-                default: bulk_first = std::min(bulk_first, d1); bulk_last = std::max(bulk_last, d2); bulk_work += d2 - d1; bulk_wait += d1 - d0; ++nb; break;
+                case 2:
+                    pan_ready = std::max(pan_ready, d1); pan_done = std::max(pan_done, d2);
+                    if (tk[(size_t)t].a == 1) { r1[0] = std::max(r1[0], d0); r1[1] = std::max(r1[1], d1); r1[2] = std::max(r1[2], d2); }
+                    if (tk[(size_t)t].a == 2) { r2[0] = std::max(r2[0], d0); r2[1] = std::max(r2[1], d1); r2[2] = std::max(r2[2], d2); }
+                    break;
+                default:
+                    if (tk[(size_t)t].a == 1 && tk[(size_t)t].b == 1) { dg[0] = std::max(dg[0], d0); dg[1] = std::max(dg[1], d1); dg[2] = std::max(dg[2], d2); }
+                    bulk_first = std::min(bulk_first, d1); bulk_last = std::max(bulk_last, d2); bulk_work += d2 - d1; bulk_wait += d1 - d0; ++nb; break;
                 }
             }
             std::fprintf(stderr, "[piqp_amd]  round %2d: owner inputs %7.1f done %7.1f (helpers %7.1f) | panel inputs %7.1f done %7.1f | bulk %4d tiles: first start %7.1f last end %7.1f, avg work %5.1f avg wait %6.1f\n",
                          k, own_ready, own_done, help_done, pan_ready, pan_done, nb, nb ? bulk_first : 0.0, bulk_last, nb ? bulk_work / nb : 0.0, nb ? bulk_wait / nb : 0.0);
+            std::fprintf(stderr, "[piqp_amd]    first panel row drawn %7.1f inputs %7.1f done %7.1f | second row %7.1f %7.1f %7.1f | diagonal tile of the first bulk column %7.1f %7.1f %7.1f\n", r1[0], r1[1],
+                         r1[2], r2[0], r2[1], r2[2], dg[0], dg[1], dg[2]);
             if (k % 6 == 2) {
                 const long long* q = h.data() + 4 * (size_t)P->ntasks + 64 * (size_t)k;
                 std::fprintf(stderr, "[piqp_amd]    hand-over of round %d's first panel row to the crew of round %d: potrf steps seen by the row", k, k + 1);
@@ -1835,6 +1892,8 @@ bool launch_chol_persistent(bool ldlt, double* A, double* side, int lda, int n, 
                 std::fprintf(stderr, " last counted %.1f | slices seen by the next owner", us(q[27]));
                 for (int u = 0; u < 8; ++u) std::fprintf(stderr, " %.1f", us(q[8 + u]));
                 std::fprintf(stderr, " | its products done %.1f, potrf start %.1f end %.1f, helper 1 published %.1f\n", us(q[16]), us(q[17]), us(q[18]), us(q[19]));
+                if (q[48]) std::fprintf(stderr, "[piqp_amd]    first panel row (half 0) of round %d: tile requested %.1f, operand rows there +%.1f, first stage in LDS +%.1f, K loop +%.1f, first look at the diagonal block +%.1f us\n", k,
+                                        us(q[48]), (q[49] - q[48]) * 0.01, (q[50] - q[49]) * 0.01, (q[51] - q[50]) * 0.01, (q[32] - q[51]) * 0.01);
                 if (q[40]) std::fprintf(stderr, "[piqp_amd]    bulk tile (5, 3) of round %d: first stage in LDS +%.1f, K loop +%.1f, stores issued +%.1f, drained +%.1f us\n", k, (q[41] - q[40]) * 0.01,
                                         (q[42] - q[41]) * 0.01, (q[43] - q[42]) * 0.01, (q[44] - q[43]) * 0.01);
             }

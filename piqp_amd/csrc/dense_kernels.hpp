@@ -54,6 +54,10 @@ struct SyrkArgs {
     long long* fuse_tr2 = nullptr;  // debugging aid (PIQP_AMD_DEBUG=chol_trace): wall-clock stamps of the hand-over between the first panel row and the next crew
     long long* fuse_tr2n = nullptr;
     int* fuse_abort = nullptr;    // persistent launch only: a word any workgroup sets when a bounded wait gave up; the waits inside poll it
+    // persistent launch, panel tiles: the tile itself (C) is ready before the two operand rows are -- it is requested first, and the workgroup waits for the
+    // rows (counters late_p[q] reaching late_w[q]) while those loads are in flight
+    const int* late_p[2] = {nullptr, nullptr};
+    int late_w[2] = {0, 0};
     long long* fuse_ts = nullptr; // debugging aid (PIQP_AMD_DEBUG=fused_ts=<panel>): 96 clock stamps -- the workgroup that owns the next diagonal block, the first panel
                                   // workgroup, an ordinary tile
 };
