@@ -1761,6 +1761,8 @@ static void chol_build_tasks(int T, std::vector<CholTask>& H)
         const double kc = (double)k - 1.0;
         for (int r = 1; r < FUSE_ROLES; ++r) all.push_back({kc, 0, {0, (short)k, (short)r, 0, gate}});
         all.push_back({kc, 1, {1, (short)k, 0, 0, gate}});
+        // (Tried: drawing the panel tasks of the rows >= 3 of the bulk-bound rounds only when their inputs exist -- gate k, key k - 0.3 ... k - 0.7 -- so that they do
+        // not park a workgroup for a round: 1.24-1.27 ms against 1.26, inside the run-to-run spread.  Not kept.)
         for (int ti = 1; ti < Tk; ++ti) {
             if (sp == 1) all.push_back({kc, 2, {2, (short)k, (short)ti, -1, gate}});
             else for (int h = 0; h < sp; ++h) all.push_back({kc, 2, {2, (short)k, (short)ti, (short)h, gate}});
