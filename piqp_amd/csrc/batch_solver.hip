@@ -539,8 +539,19 @@ struct Ipm {
     __device__ __noinline__ double dot2(const gdbl* a, const gdbl* b, int cnt)
     {
         assume_lds();
+        if (cnt <= 0) return 0.0;  // (an empty block: the sum of the lanes' zeros)
         double s = 0.0;
-        for (int i = tid(); i < cnt; i += NT) s += a[i] * b[i];
+        // two trips of the lane-strided loop at once: the second element comes from a clamped (valid) address and is left out by its mask, so that all four
+        // loads are in flight together -- a wave is waiting for memory three quarters of its life (profiles/r03_pmc_batch_c4.txt), and with a run-time trip
+        // count that differs between the lanes the compiler's own unrolling runs a remainder trip first: two waits again.  Same sum, same order.
+        for (int i0 = tid(); i0 < cnt; i0 += 2 * NT) {
+            const int i1 = i0 + NT;
+            const bool ok1 = i1 < cnt;
+            const int j1 = ok1 ? i1 : i0;
+            const double a0 = a[i0], b0 = b[i0], a1 = a[j1], b1 = b[j1];
+            s += a0 * b0;
+            if (ok1) s += a1 * b1;
+        }
         return reduce(s, OpSum());
     }
     // :884-891
@@ -569,15 +580,29 @@ struct Ipm {
     __device__ __noinline__ double min_coeff(const gdbl* a, int cnt)
     {
         assume_lds();
+        if (cnt <= 0) return DBL_MAX;
         double mn = DBL_MAX;
-        for (int i = tid(); i < cnt; i += NT) if (a[i] < mn) mn = a[i];
+        for (int i0 = tid(); i0 < cnt; i0 += 2 * NT) {
+            const int i1 = i0 + NT;
+            const double a0 = a[i0], a1 = a[i1 < cnt ? i1 : i0];  // (the clamped duplicate cannot change a minimum)
+            if (a0 < mn) mn = a0;
+            if (a1 < mn) mn = a1;
+        }
         return reduce(mn, OpMin());
     }
     __device__ __noinline__ double inf_scaled(const gdbl* a, const gdbl* sc, double c, int cnt)
     {
         assume_lds();
+        if (cnt <= 0) return 0.0;
         double mx = 0.0;
-        for (int i = tid(); i < cnt; i += NT) { const double t = fabs(a[i] * c * sc[i]); if (t > mx || t != t) mx = t; }
+        for (int i0 = tid(); i0 < cnt; i0 += 2 * NT) {
+            const int i1 = i0 + NT;
+            const int j1 = i1 < cnt ? i1 : i0;  // (a clamped duplicate cannot change a maximum)
+            const double a0 = a[i0], s0 = sc[i0], a1 = a[j1], s1 = sc[j1];
+            const double t0 = fabs(a0 * c * s0), t1 = fabs(a1 * c * s1);
+            if (t0 > mx || t0 != t0) mx = t0;
+            if (t1 > mx || t1 != t1) mx = t1;
+        }
         return reduce(mx, OpAbsMaxNan());
     }
     // :1130-1164
