@@ -1568,9 +1568,10 @@ struct CholTask {
 // workgroups per panel tile: a row's task of round k needs that row's output of round k - 1, so one workgroup's update + substitution (28 + 13 us for a
 // whole tile) bound a round from below; halves (fused_tile<HALF>) keep that under the diagonal block's 30 us.  Early rounds are bound by the bulk
 // tiles anyway and keep whole tiles (half as many workgroups parked on the chain).
-// A round with >= 26 trailing tile rows (> 300 bulk tiles) is bound by the bulk tiles, not by the chain: there whole tiles park half as many workgroups on
+// A round with >= 22 trailing tile rows (> 230 bulk tiles) is bound by the bulk tiles, not by the chain: there whole tiles park half as many workgroups on
 // the chain and leave them to the bulk.
-__host__ __device__ inline bool chol_bulk_bound(int T, int k) { return T - k - 1 >= 26; }
+// (threshold swept at T = 32, factorisation ms: never 1.28-1.32, 30: 1.28, 26: 1.26, 22: 1.245, 18: 1.27, 14: 1.29, 10: 1.32)
+__host__ __device__ inline bool chol_bulk_bound(int T, int k) { return T - k - 1 >= 22; }
 __host__ __device__ inline int chol_split(int T, int k) { return chol_bulk_bound(T, k) ? 1 : 2; }
 struct CholArgs {
     double* A; double* side; int lda, n, T, ldlt;
