@@ -1304,12 +1304,12 @@ public:
             std::fill(stage.begin(), stage.begin() + (size_t)layout_.stride * cnt, 0.0);
             for (int k = 0; k < cnt; ++k) pack_instance(*data[i0 + k], stage.data() + (size_t)layout_.stride * k);
             PQ_HIP(hipMemcpyAsync(arena_.p + (size_t)layout_.stride * i0, stage.data(), sizeof(double) * (size_t)layout_.stride * cnt, hipMemcpyHostToDevice, st_));
-            PQ_HIP(hipStreamSynchronize(st_));
+            stream_wait(st_);
         }
         // RuizEquilibration::scale_data of every instance (sparse/preconditioner.hpp:65-222) in one launch, then the front arenas
         launch_ruiz(RUIZ_COMPUTE);
         launch_prepare();
-        PQ_HIP(hipStreamSynchronize(st_));
+        stream_wait(st_);
         setup_done_ = true;
         return true;
     }
@@ -1332,7 +1332,7 @@ public:
         PQ_HIP(hipEventRecord(e1, st_));
         PQ_HIP(hipGetLastError());
         PQ_HIP(hipMemcpyAsync(infos_h_.data(), infos_.p, sizeof(pq_info) * batch_, hipMemcpyDeviceToHost, st_));
-        PQ_HIP(hipStreamSynchronize(st_));
+        stream_wait(st_);
         float ms = 0.f;
         PQ_HIP(hipEventElapsedTime(&ms, e0, e1));
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
@@ -1357,7 +1357,7 @@ public:
         const double *pc = up(dc, c, n_), *pb = up(dbv, b, p_), *phl = up(dhl, h_l, m_), *phu = up(dhu, h_u, m_), *pxl = up(dxl, x_l, n_), *pxu = up(dxu, x_u, n_);
         hipLaunchKernelGGL(k_batch_update_vectors, dim3(batch_), dim3(128), 0, st_, shared_.p, arena_.p, ruiz_c_.p, disabled_d_, pc, pb, phl, phu, pxl, pxu);
         PQ_HIP(hipGetLastError());
-        PQ_HIP(hipStreamSynchronize(st_));
+        stream_wait(st_);
         return true;
     }
     // update() of every instance with new matrix values (patterns and the set of finite bounds as given at setup) and / or vectors: per instance
@@ -1386,7 +1386,7 @@ public:
         PQ_HIP(hipGetLastError());
         launch_ruiz(settings_.preconditioner_reuse_on_update ? RUIZ_REUSE : RUIZ_COMPUTE);
         launch_prepare();
-        PQ_HIP(hipStreamSynchronize(st_));
+        stream_wait(st_);
         return true;
     }
     double last_kernel_ms() const { return last_kernel_ms_; }
@@ -1400,7 +1400,7 @@ public:
         PQ_HIP(hipSetDevice(dev_));
         PQ_HIP(hipMemcpy2DAsync(out_host, sizeof(double) * len, arena_.p + layout_.off[V_R + field], sizeof(double) * layout_.stride, sizeof(double) * len, batch_,
                                 hipMemcpyDeviceToHost, st_));
-        PQ_HIP(hipStreamSynchronize(st_));
+        stream_wait(st_);
     }
     int field_len(int field) const
     {
@@ -1462,7 +1462,7 @@ private:
         disabled_d_ = up(ibufs_, dis);
         rzPp_ = up(ibufs_, d0.sP_utri.colptr);
         rzPi_ = up(ibufs_, d0.sP_utri.rowind.empty() ? std::vector<int>(1, 0) : d0.sP_utri.rowind);
-        PQ_HIP(hipStreamSynchronize(st_));
+        stream_wait(st_);
     }
 
     // sparse/preconditioner.hpp on the arena: one workgroup per instance (ruiz_kernels.hip)
@@ -1612,7 +1612,7 @@ private:
         S.set = settings_;
         shared_.alloc(1);
         PQ_HIP(hipMemcpyAsync(shared_.p, &S, sizeof(BatchShared), hipMemcpyHostToDevice, st_));
-        PQ_HIP(hipStreamSynchronize(st_));
+        stream_wait(st_);
     }
 
     void pack_instance(const HostData& d, double* dst) const

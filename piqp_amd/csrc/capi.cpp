@@ -228,7 +228,7 @@ int pq_kkt_solve(pq_kkt* k, const double* rhs_x, const double* rhs_y, const doub
             h2d(k->sx.p, rhs_x, n, st); h2d(k->sy.p, rhs_y, p, st); h2d(k->sz.p, rhs_z, m, st);
             k->impl->solve(k->sx.p, k->sy.p, k->sz.p, k->lx.p, k->ly.p, k->lz.p);
             d2h(lhs_x, k->lx.p, n, st); d2h(lhs_y, k->ly.p, p, st); d2h(lhs_z, k->lz.p, m, st);
-            PQ_HIP(hipStreamSynchronize(st));
+            stream_wait(st);
         } else {
             k->impl->solve(rhs_x, rhs_y, rhs_z, lhs_x, lhs_y, lhs_z);
         }
@@ -248,7 +248,7 @@ int pq_kkt_eval_P_x(pq_kkt* k, double alpha, const double* x, double* z)
             h2d(k->sx.p, x, n, st);
             k->impl->eval_P_x(alpha, k->sx.p, k->lx.p);
             d2h(z, k->lx.p, n, st);
-            PQ_HIP(hipStreamSynchronize(st));
+            stream_wait(st);
         } else {
             k->impl->eval_P_x(alpha, x, z);
         }
@@ -271,7 +271,7 @@ static int eval_pair(pq_kkt* k, bool isG, double an, double at, const double* xn
             if (isG) k->impl->eval_G_xn_and_GT_xt(an, at, k->sx.p, sq, lq, k->lx.p);
             else k->impl->eval_A_xn_and_AT_xt(an, at, k->sx.p, sq, lq, k->lx.p);
             d2h(zn, lq, q, st); d2h(zt, k->lx.p, n, st);
-            PQ_HIP(hipStreamSynchronize(st));
+            stream_wait(st);
         } else {
             if (isG) k->impl->eval_G_xn_and_GT_xt(an, at, xn, xt, zn, zt);
             else k->impl->eval_A_xn_and_AT_xt(an, at, xn, xt, zn, zt);
@@ -297,7 +297,7 @@ int pq_kkt_print_info(pq_kkt* k)
 int pq_kkt_synchronize(pq_kkt* k)
 {
     if (!k) return fail(PQ_ERR_INVALID, "null argument");
-    return guarded([&] { PQ_HIP(hipSetDevice(k->impl->device())); PQ_HIP(hipStreamSynchronize(k->impl->stream())); return (int)PQ_OK; });
+    return guarded([&] { PQ_HIP(hipSetDevice(k->impl->device())); stream_wait(k->impl->stream()); return (int)PQ_OK; });
 }
 void* pq_kkt_stream(pq_kkt* k) { return k ? (void*)k->impl->stream() : nullptr; }
 int pq_kkt_internal_kkt_mat(pq_kkt* k, double* out_host)
@@ -556,7 +556,7 @@ static void stage_out(pq_kktsys* k, VarStage& src, pq_vars* dst)
         double* hp = *var_field(*dst, f);
         if (hp) d2h(hp, src.buf[f].p, s.size(f), st);
     }
-    PQ_HIP(hipStreamSynchronize(st));
+    stream_wait(st);
 }
 
 int pq_kktsys_update_scalings_and_factor(pq_kktsys* k, int iterative_refinement, double rho, double delta, const pq_vars* vars)
@@ -633,7 +633,7 @@ int pq_kktsys_condensed_residual(pq_kktsys* k, double* res_inf, double* rhs_inf)
 int pq_kktsys_synchronize(pq_kktsys* k)
 {
     if (!k) return fail(PQ_ERR_INVALID, "null argument");
-    return guarded([&] { PQ_HIP(hipSetDevice(k->impl->device())); PQ_HIP(hipStreamSynchronize(k->impl->stream())); return (int)PQ_OK; });
+    return guarded([&] { PQ_HIP(hipSetDevice(k->impl->device())); stream_wait(k->impl->stream()); return (int)PQ_OK; });
 }
 
 // ------------------------------------------------------------------------------------ micro-benchmarks

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <string>
 #include <utility>
 #include <vector>
@@ -45,6 +46,31 @@ struct HipError {
         hipError_t e_ = (expr);                                              \
         if (e_ != hipSuccess) throw ::pq::HipError{e_, #expr, __FILE__, __LINE__}; \
     } while (0)
+
+// Waits for a stream: polls it for up to two milliseconds, then blocks.  One interior-point iteration reads three or four scalars back (factorisation status,
+// finiteness of a solve: kkt_system.hpp:266,305), each a full drain of the stream; hipStreamSynchronize sleeps on an interrupt, and the wake-up was 30-150 us per
+// read on the boxes of this pool (0.4 ms of a 3.4 ms step on a freshly booted one), the poll is a few microseconds.  PIQP_AMD_DEBUG=sync_block keeps the
+// blocking wait (a host thread that must not spin).
+const char* debug_token(const char* name);
+inline void stream_wait(hipStream_t s)
+{
+    static const bool spin = debug_token("sync_block") == nullptr;
+    if (spin) {
+        timespec t0;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        for (unsigned it = 0;; ++it) {
+            const hipError_t e = hipStreamQuery(s);
+            if (e == hipSuccess) return;
+            if (e != hipErrorNotReady) throw ::pq::HipError{e, "hipStreamQuery", __FILE__, __LINE__};
+            if ((it & 15u) == 15u) {
+                timespec t1;
+                clock_gettime(CLOCK_MONOTONIC, &t1);
+                if ((t1.tv_sec - t0.tv_sec) * 1000000000LL + (t1.tv_nsec - t0.tv_nsec) > 2000000LL) break;
+            }
+        }
+    }
+    PQ_HIP(hipStreamSynchronize(s));
+}
 
 // Every extern "C" entry wraps its body in this: no exception crosses the ABI.
 template <class F>
@@ -194,7 +220,7 @@ struct StageProfiler {
     }
     void collect(int stage, hipStream_t s, double* total_ms, int* count)
     {
-        PQ_HIP(hipStreamSynchronize(s));
+        stream_wait(s);
         double tot = 0.0;
         for (auto& pr : pending[stage]) {
             float ms = 0.f;

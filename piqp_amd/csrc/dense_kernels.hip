@@ -1857,7 +1857,7 @@ bool launch_chol_persistent(bool ldlt, double* A, double* side, int lda, int n, 
         std::vector<CholTask> tk((size_t)P->ntasks);
         PQ_HIP(hipMemcpyAsync(h.data(), trace_d, h.size() * sizeof(long long), hipMemcpyDeviceToHost, s));
         PQ_HIP(hipMemcpyAsync(tk.data(), P->tasks, tk.size() * sizeof(CholTask), hipMemcpyDeviceToHost, s));
-        PQ_HIP(hipStreamSynchronize(s));
+        stream_wait(s);
         long long t0 = h[0];
         for (int t = 0; t < P->ntasks; ++t) t0 = std::min(t0, h[4 * (size_t)t]);
         auto us = [&](long long v) { return (double)(v - t0) * 0.01; };
@@ -2778,7 +2778,7 @@ template <int ACC>
 static double mfma_variant(int blocks, int iters, double* out, hipStream_t s, hipEvent_t e0, hipEvent_t e1)
 {
     hipLaunchKernelGGL(k_mfma_f64_peak<ACC>, dim3(blocks), dim3(256), 0, s, 10, out);
-    PQ_HIP(hipStreamSynchronize(s));
+    stream_wait(s);
     PQ_HIP(hipEventRecord(e0, s));
     hipLaunchKernelGGL(k_mfma_f64_peak<ACC>, dim3(blocks), dim3(256), 0, s, iters, out);
     PQ_HIP(hipEventRecord(e1, s));
@@ -2851,7 +2851,7 @@ template <int U, bool NT>
 static double copy_variant(int blocks, size_t n2, const d2* a, d2* b, int iters, hipStream_t s, hipEvent_t e0, hipEvent_t e1)
 {
     hipLaunchKernelGGL((k_copy_d2<U, NT>), dim3(blocks), dim3(256), 0, s, n2, a, b);
-    PQ_HIP(hipStreamSynchronize(s));
+    stream_wait(s);
     PQ_HIP(hipEventRecord(e0, s));
     for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((k_copy_d2<U, NT>), dim3(blocks), dim3(256), 0, s, n2, a, b);
     PQ_HIP(hipEventRecord(e1, s));

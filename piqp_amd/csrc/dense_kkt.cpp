@@ -48,7 +48,7 @@ public:
     KKTSolverBase* clone() const override
     {
         PQ_HIP(hipSetDevice(dev_));
-        PQ_HIP(hipStreamSynchronize(st_));
+        stream_wait(st_);
         DenseKKT* k = new DenseKKT(*this, 0);
         return k;
     }
@@ -148,7 +148,7 @@ public:
         tmp.zero(st_);
         update_kkt(x_reg_last_.p, tmp.p);
         PQ_HIP(hipMemcpyAsync(out_host, tmp.p, sizeof(double) * (size_t)n_ * n_, hipMemcpyDeviceToHost, st_));
-        PQ_HIP(hipStreamSynchronize(st_));
+        stream_wait(st_);
     }
     void set_profiling(int level) override { prof_.enabled = level != 0; prof_.level = level; }
     void get_profile(int stage, double* total_ms, int* count) override
@@ -161,7 +161,7 @@ public:
     {
         PQ_HIP(hipSetDevice(dev_));
         PQ_HIP(hipMemcpyAsync(out_host, fac_.p, sizeof(double) * (size_t)n_ * n_, hipMemcpyDeviceToHost, st_));
-        PQ_HIP(hipStreamSynchronize(st_));
+        stream_wait(st_);
     }
 
 private:
@@ -173,7 +173,7 @@ private:
         auto cp = [&](DBuf<double>& dst, const DBuf<double>& src) { if (src.n) PQ_HIP(hipMemcpyAsync(dst.p, src.p, src.bytes(), hipMemcpyDeviceToDevice, st_)); };
         cp(Pfull_, o.Pfull_); cp(Pdiag_, o.Pdiag_); cp(AT_, o.AT_); cp(GT_, o.GT_); cp(ATA_, o.ATA_); cp(fac_, o.fac_);
         cp(z_reg_inv_, o.z_reg_inv_); cp(x_reg_last_, o.x_reg_last_); cp(rdiag_, o.rdiag_); cp(w16_, o.w16_);
-        PQ_HIP(hipStreamSynchronize(st_));
+        stream_wait(st_);
     }
 
     void alloc()
@@ -218,7 +218,7 @@ private:
             a.n = n_; a.kdim = p_; a.A = AT_.p; a.lda = n_; a.B = AT_.p; a.ldb = n_; a.C = ATA_.p; a.ldc = n_;
             dense::launch_syrk(dense::EPI_STORE, a, st_);
         }
-        PQ_HIP(hipStreamSynchronize(st_));  // host source buffers may be released by the caller after return
+        stream_wait(st_);  // host source buffers may be released by the caller after return
     }
 
     // dense/kkt.hpp:140-160 into the lower triangle of `out`
@@ -288,7 +288,7 @@ private:
     {
         long long h[96];
         PQ_HIP(hipMemcpyAsync(h, dbg_ts_.p, sizeof(h), hipMemcpyDeviceToHost, st_));
-        PQ_HIP(hipStreamSynchronize(st_));
+        stream_wait(st_);
         std::fprintf(stderr, "[piqp_amd] fused panel %d (cycles): C + panel staged %lld, MFMA loop %lld, tiles->LDS %lld, potrf_block %lld; potrf steps (factor/subst/update):", panel, h[4] - h[0], h[1] - h[4], h[2] - h[1], h[3] - h[2]);
         for (int k = 0; k < 8; ++k) std::fprintf(stderr, " %lld/%lld/%lld", h[8 + 8 * k + 1] - h[8 + 8 * k], h[8 + 8 * k + 3] - h[8 + 8 * k + 2], h[8 + 8 * k + 5] - h[8 + 8 * k + 4]);
         std::fprintf(stderr, "\n[piqp_amd]   potrf step start / factored (since launch):");
@@ -304,13 +304,13 @@ private:
     {
         PQ_HIP(hipMemcpyAsync(info_h_.p, info_.p, sizeof(int), hipMemcpyDeviceToHost, st_));
         if (chol_persistent_) PQ_HIP(hipMemcpyAsync(info_h_.p + 1, chol_flags_.p + 1, sizeof(int), hipMemcpyDeviceToHost, st_));  // the launch's abort word
-        PQ_HIP(hipStreamSynchronize(st_));
+        stream_wait(st_);
         if (chol_persistent_ && info_h_.p[1] != 0) {
             // a bounded wait inside the persistent launch gave up (never seen on a healthy device): the cumulative counters of this handle are no longer
             // consistent -- start them over, and report the factorisation as failed (the caller regularises and factors again)
             chol_flags_.zero(st_); fuse_cnt_.zero(st_); fuse_flags_.zero(st_);
             chol_gen_ = 0; chol_fcount_ = 0; fuse_token_ = 0;
-            PQ_HIP(hipStreamSynchronize(st_));
+            stream_wait(st_);
             return false;
         }
         return info_h_.p[0] == -1;
@@ -341,7 +341,7 @@ private:
     {
         std::vector<long long> h(trsv_ts_.n);
         PQ_HIP(hipMemcpyAsync(h.data(), trsv_ts_.p, trsv_ts_.bytes(), hipMemcpyDeviceToHost, st_));
-        PQ_HIP(hipStreamSynchronize(st_));
+        stream_wait(st_);
         std::fprintf(stderr, "[piqp_amd] forward sweep, per block (flag seen -> products / -> solved / -> published):");
         const size_t nb = (h.size() - 8) / 4;
         for (size_t r = 1; r < nb; ++r) std::fprintf(stderr, " %lld/%lld/%lld", h[4 * r + 1] - h[4 * r], h[4 * r + 2] - h[4 * r], h[4 * r + 3] - h[4 * r]);

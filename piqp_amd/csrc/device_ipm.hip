@@ -404,7 +404,7 @@ struct DeviceIpm::Impl {
     const double* fetch(int count)
     {
         (void)count;  // k_final_reduce wrote the scalars into the pinned buffer itself (one device-to-host copy less per synchronisation, ~9 per iteration)
-        PQ_HIP(hipStreamSynchronize(st));
+        stream_wait(st);
         return scal_h.p;
     }
 };
@@ -456,7 +456,7 @@ void DeviceIpm::download_result(HostVars& out)
     const pq_vars& o = s.OUT;
     const double* src[10] = {o.x, o.y, o.z_l, o.z_u, o.z_bl, o.z_bu, o.s_l, o.s_u, o.s_bl, o.s_bu};
     for (int k = 0; k < 10; ++k) { Vec& v = out.field(k); if (!v.empty()) PQ_HIP(hipMemcpyAsync(v.data(), src[k], v.size() * sizeof(double), hipMemcpyDeviceToHost, s.st)); }
-    PQ_HIP(hipStreamSynchronize(s.st));
+    stream_wait(s.st);
 }
 
 // solve_impl (solver.hpp:379-882) with device-resident vectors
@@ -493,7 +493,7 @@ int DeviceIpm::solve(KKTSystem& kkt, const pq_settings& set, const Ruiz& rz, pq_
         info.n_solve++;
         kkt.solve(rhs, lhs);
         info.n_backend_solve += kkt.last_backend_solves;
-        PQ_HIP(hipStreamSynchronize(st));
+        stream_wait(st);
         info.kkt_solve_time += now() - t0;
     };
 

@@ -442,14 +442,14 @@ void KKTSystem::set_bounds(int n_h_l_, int n_h_u_, int n_x_l_, int n_x_u_, const
     LAUNCH1(k_scatter_pos, n_h_u, st_, n_h_u, h_u_idx.p, has_u.p);
     LAUNCH1(k_scatter_pos, n_x_l, st_, n_x_l, x_l_idx.p, pos_l.p);
     LAUNCH1(k_scatter_pos, n_x_u, st_, n_x_u, x_u_idx.p, pos_u.p);
-    PQ_HIP(hipStreamSynchronize(st_));
+    stream_wait(st_);
 }
 
 // kkt_system.hpp:70-95 (copy ctor): state vectors copied, work/refinement buffers fresh
 KKTSystem* KKTSystem::clone() const
 {
     PQ_HIP(hipSetDevice(dev_));
-    PQ_HIP(hipStreamSynchronize(st_));
+    stream_wait(st_);
     KKTSolverBase* b = kkt_solver->clone();
     KKTSystem* k = new KKTSystem(b, settings_);
     k->m_rho = m_rho; k->m_delta = m_delta; k->use_iterative_refinement = use_iterative_refinement;
@@ -462,14 +462,14 @@ KKTSystem* KKTSystem::clone() const
     cpd(k->x_b_scaling, x_b_scaling);
     cpi(k->has_l, has_l); cpi(k->has_u, has_u); cpi(k->pos_l, pos_l); cpi(k->pos_u, pos_u);
     cpi(k->h_l_idx, h_l_idx); cpi(k->h_u_idx, h_u_idx); cpi(k->x_l_idx, x_l_idx); cpi(k->x_u_idx, x_u_idx);
-    PQ_HIP(hipStreamSynchronize(k->st_));
+    stream_wait(k->st_);
     return k;
 }
 
 double KKTSystem::read_scalar_max(int slot)
 {
     PQ_HIP(hipMemcpyAsync(scal_h.p, scal_d.p, sizeof(unsigned long long) * 4, hipMemcpyDeviceToHost, st_));
-    PQ_HIP(hipStreamSynchronize(st_));
+    stream_wait(st_);
     double v;
     std::memcpy(&v, &scal_h.p[slot], sizeof(double));
     return v;

@@ -122,7 +122,7 @@ public:
     KKTSolverBase* clone() const override
     {
         PQ_HIP(hipSetDevice(dev_));
-        PQ_HIP(hipStreamSynchronize(st_));
+        stream_wait(st_);
         MultistageKKT* c = new MultistageKKT(*this, 0);
         if (tree_) c->tree_.reset(tree_->clone());
         return c;
@@ -152,10 +152,10 @@ public:
         PQ_HIP(hipSetDevice(dev_));
         delta_ = delta;
         if (tree_) {
-            PQ_HIP(hipStreamSynchronize(st_));  // x_reg / z_reg were produced on this handle's stream
+            stream_wait(st_);  // x_reg / z_reg were produced on this handle's stream
             const int t = prof_.begin(1, st_);
             tree_->update_scalings_and_factor(delta, x_reg, z_reg);
-            PQ_HIP(hipStreamSynchronize(tree_->stream()));
+            stream_wait(tree_->stream());
             prof_.end(1, t, st_);
             return true;  // :218
         }
@@ -177,10 +177,10 @@ public:
         PQ_ZONE("piqp_amd::MultistageKKT::solve");
         PQ_HIP(hipSetDevice(dev_));
         if (tree_) {
-            PQ_HIP(hipStreamSynchronize(st_));
+            stream_wait(st_);
             const int t = prof_.begin(2, st_);
             tree_->solve(rhs_x, rhs_y, rhs_z, lhs_x, lhs_y, lhs_z);
-            PQ_HIP(hipStreamSynchronize(tree_->stream()));
+            stream_wait(tree_->stream());
             prof_.end(2, t, st_);
             return;
         }
@@ -295,7 +295,7 @@ private:
         clone_buf(p_dst_, o.p_dst_, st_);
         clone_buf(Pf_, o.Pf_, st_); clone_buf(AtAf_, o.AtAf_, st_); clone_buf(F_, o.F_, st_); clone_buf(pan_, o.pan_, st_);
         clone_buf(XA_, o.XA_, st_); clone_buf(XG_, o.XG_, st_); clone_buf(zinv_, o.zinv_, st_);
-        PQ_HIP(hipStreamSynchronize(st_));
+        stream_wait(st_);
     }
 
     MsMeta meta() const { return MsMeta{S_.N, S_.arrow, n_, w_.p, off_.p, h_.p, start_.p, front_off_.p, pan_off_.p}; }
@@ -345,7 +345,7 @@ private:
         }
         if (options & 4) launch_remap_values64(ops_.nzG(), g_dst_.p, ops_.GT_x(), XG_.p, st_);
         PQ_HIP(hipGetLastError());
-        PQ_HIP(hipStreamSynchronize(st_));
+        stream_wait(st_);
     }
 
     int dev_, n_ = 0, p_ = 0, m_ = 0;

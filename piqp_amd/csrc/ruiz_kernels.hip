@@ -354,7 +354,7 @@ DeviceRuiz::DeviceRuiz(int device, const HostData& d) : I(new Impl)
         s.P.alloc(std::max<size_t>(d.sP_utri.val.size(), 1));
         s.AT.alloc(std::max<size_t>(d.sAT.val.size(), 1));
         s.GT.alloc(std::max<size_t>(d.sGT.val.size(), 1));
-        PQ_HIP(hipStreamSynchronize(s.st));
+        stream_wait(s.st);
     }
 }
 DeviceRuiz::~DeviceRuiz() = default;
@@ -368,11 +368,11 @@ std::unique_ptr<DeviceRuiz> DeviceRuiz::clone() const
     std::unique_ptr<DeviceRuiz> r(new DeviceRuiz(s.device, shape));
     Impl& t = *r->I;
     PQ_HIP(hipSetDevice(s.device));
-    PQ_HIP(hipStreamSynchronize(s.st));
+    stream_wait(s.st);
     auto cp = [&](DBuf<double>& dst, const DBuf<double>& src) { if (src.n) PQ_HIP(hipMemcpyAsync(dst.p, src.p, src.bytes(), hipMemcpyDeviceToDevice, t.st)); };
     cp(t.P, s.P); cp(t.AT, s.AT); cp(t.GT, s.GT); cp(t.vec, s.vec);
     PQ_HIP(hipMemcpyAsync(t.state.p, s.state.p, sizeof(DenseState), hipMemcpyDeviceToDevice, t.st));
-    PQ_HIP(hipStreamSynchronize(t.st));
+    stream_wait(t.st);
     return r;
 }
 
@@ -385,7 +385,7 @@ void DeviceRuiz::upload_dense(const HostData& d, int options)
     if ((options & PQ_KKT_UPDATE_P) && s.P.n) PQ_HIP(hipMemcpyAsync(s.P.p, d.P_utri.data(), s.P.bytes(), hipMemcpyHostToDevice, s.st));
     if ((options & PQ_KKT_UPDATE_A) && s.AT.n) PQ_HIP(hipMemcpyAsync(s.AT.p, d.AT.data(), n * s.p * sizeof(double), hipMemcpyHostToDevice, s.st));
     if ((options & PQ_KKT_UPDATE_G) && s.GT.n) PQ_HIP(hipMemcpyAsync(s.GT.p, d.GT.data(), n * s.m * sizeof(double), hipMemcpyHostToDevice, s.st));
-    PQ_HIP(hipStreamSynchronize(s.st));
+    stream_wait(s.st);
 }
 
 void DeviceRuiz::zero_G_rows(const std::vector<int>& rows)
@@ -394,7 +394,7 @@ void DeviceRuiz::zero_G_rows(const std::vector<int>& rows)
     if (s.sparse || rows.empty()) return;
     PQ_HIP(hipSetDevice(s.device));
     for (int r : rows) PQ_HIP(hipMemsetAsync(s.GT.p + (size_t)r * s.n, 0, sizeof(double) * s.n, s.st));
-    PQ_HIP(hipStreamSynchronize(s.st));
+    stream_wait(s.st);
 }
 
 pq_dense_data DeviceRuiz::dense_descriptor(const HostData& d) const
@@ -467,7 +467,7 @@ void DeviceRuiz::run(HostData& d, Ruiz& rz, int mode, bool scale_cost, int max_i
         } else {
             DenseState hs{rz.c, rz.c_inv, 1.0, 0};
             PQ_HIP(hipMemcpyAsync(ds, &hs, sizeof(DenseState), hipMemcpyHostToDevice, st));
-            PQ_HIP(hipStreamSynchronize(st));  // hs is a stack object
+            stream_wait(st);  // hs is a stack object
             const double *sv = mode == RUIZ_REUSE ? s.delta : s.delta_inv, *sb = mode == RUIZ_REUSE ? s.delta_b : s.delta_b_inv;
             const double* cs = mode == RUIZ_REUSE ? &ds->c : &ds->c_inv;
             hipLaunchKernelGGL((k_rzd_pass<true, true, false, true>), gP, dim3(TR), 0, st, n, n, s.P.p, sv, sv, cs, nullptr, nullptr, ds, 1);
@@ -481,7 +481,7 @@ void DeviceRuiz::run(HostData& d, Ruiz& rz, int mode, bool scale_cost, int max_i
     PQ_HIP(hipMemcpyAsync(h, s.vec.p, (odbi + n) * sizeof(double), hipMemcpyDeviceToHost, st));
     DenseState hs{};
     if (!s.sparse && mode == RUIZ_COMPUTE) PQ_HIP(hipMemcpyAsync(&hs, s.state.p, sizeof(DenseState), hipMemcpyDeviceToHost, st));
-    PQ_HIP(hipStreamSynchronize(st));
+    stream_wait(st);
     std::copy(h + oc, h + oc + n, d.c.begin());
     std::copy(h + ox, h + ox + n, d.x_b_scaling.begin());
     if (mode == RUIZ_COMPUTE) {

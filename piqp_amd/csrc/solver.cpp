@@ -458,7 +458,7 @@ void Solver::from_device(const pq_vars& d, HostVars& h)
         if (k == 5 || k == 9) cnt = nxu;
         if (cnt) PQ_HIP(hipMemcpyAsync(v.data(), *vars_field(const_cast<pq_vars&>(d), k), cnt * sizeof(double), hipMemcpyDeviceToHost, st));
     }
-    PQ_HIP(hipStreamSynchronize(st));
+    stream_wait(st);
 }
 
 // KKTSystem::init + init_kkt_solver (kkt_system.hpp:97-132,455-497)
@@ -688,7 +688,7 @@ void Solver::eval_P_x(double alpha, const Vec& x, Vec& z)
     PQ_HIP(hipMemcpyAsync(dxa_.p, x.data(), n * sizeof(double), hipMemcpyHostToDevice, st));
     m_kkt_system->backend()->eval_P_x(alpha, dxa_.p, dxb_.p);
     PQ_HIP(hipMemcpyAsync(z.data(), dxb_.p, n * sizeof(double), hipMemcpyDeviceToHost, st));
-    PQ_HIP(hipStreamSynchronize(st));
+    stream_wait(st);
 }
 void Solver::eval_A(double an, double at, const Vec& xn, const Vec& xt, Vec& zn, Vec& zt)
 {
@@ -699,7 +699,7 @@ void Solver::eval_A(double an, double at, const Vec& xn, const Vec& xt, Vec& zn,
     m_kkt_system->backend()->eval_A_xn_and_AT_xt(an, at, dxa_.p, dya_.p, dyb_.p, dxb_.p);
     if (p) PQ_HIP(hipMemcpyAsync(zn.data(), dyb_.p, p * sizeof(double), hipMemcpyDeviceToHost, st));
     PQ_HIP(hipMemcpyAsync(zt.data(), dxb_.p, n * sizeof(double), hipMemcpyDeviceToHost, st));
-    PQ_HIP(hipStreamSynchronize(st));
+    stream_wait(st);
 }
 void Solver::eval_G(double an, double at, const Vec& xn, const Vec& xt, Vec& zn, Vec& zt)
 {
@@ -710,7 +710,7 @@ void Solver::eval_G(double an, double at, const Vec& xn, const Vec& xt, Vec& zn,
     m_kkt_system->backend()->eval_G_xn_and_GT_xt(an, at, dxa_.p, dza_.p, dzb_.p, dxb_.p);
     if (m) PQ_HIP(hipMemcpyAsync(zn.data(), dzb_.p, m * sizeof(double), hipMemcpyDeviceToHost, st));
     PQ_HIP(hipMemcpyAsync(zt.data(), dxb_.p, n * sizeof(double), hipMemcpyDeviceToHost, st));
-    PQ_HIP(hipStreamSynchronize(st));
+    stream_wait(st);
 }
 
 // solver.hpp:884-891

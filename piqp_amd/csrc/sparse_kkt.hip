@@ -1708,7 +1708,7 @@ public:
     KKTSolverBase* clone() const override
     {
         PQ_HIP(hipSetDevice(dev_));
-        PQ_HIP(hipStreamSynchronize(st_));
+        stream_wait(st_);
         return new SparseKKT(*this, 0);
     }
 
@@ -1766,7 +1766,7 @@ public:
         PQ_HIP(hipGetLastError());
         prof_.end(1, t1, st_);
         PQ_HIP(hipMemcpyAsync(info_h_.p, info_.p, sizeof(int), hipMemcpyDeviceToHost, st_));
-        PQ_HIP(hipStreamSynchronize(st_));
+        stream_wait(st_);
         return info_h_.p[0] == -1;  // n == cols (sparse/kkt.hpp:104)
     }
 
@@ -1889,7 +1889,7 @@ public:
         upload_vec(b_sn_, PT_.boundary, st_); upload_vec(b_owner_, bo, st_); upload_vec(b_mat_off_, PT_.bmat_off, st_); upload_vec(b_vec_off_, PT_.bvec_off, st_);
         upload_vec(span_lo_d_, PT_.span_lo, st_); upload_vec(span_hi_d_, PT_.span_hi, st_);
         PQ_HIP(hipMemsetAsync(rdiag_.p, 0, sizeof(double) * (size_t)N_, st_));
-        PQ_HIP(hipStreamSynchronize(st_));
+        stream_wait(st_);
         part_on_ = true;
         drop_transport();  // a new partition invalidates both transports: their buffer sizes and the communicator's world belong to the old one
         sizes[0] = PT_.bmat_off.back() + 1; sizes[1] = std::max(1, PT_.bvec_off.back()); sizes[2] = std::max(1, PT_.max_span);
@@ -1904,7 +1904,7 @@ public:
     }
     void drop_transport()
     {
-        if (comm_) { PQ_HIP(hipStreamSynchronize(st_)); rccl::comm_destroy(comm_); comm_ = nullptr; }
+        if (comm_) { stream_wait(st_); rccl::comm_destroy(comm_); comm_ = nullptr; }
         own_factor_.release(); own_forward_.release(); own_gather_.release();
         xfn_ = nullptr; xuser_ = nullptr; xbuf_factor_ = xbuf_forward_ = xbuf_gather_ = nullptr;
         transport_ = Transport::None;
@@ -1919,7 +1919,7 @@ public:
         comm_ = rccl::comm_create(id128, rank, world, dev_);
         own_factor_.alloc((size_t)PT_.bmat_off.back() + 1); own_forward_.alloc((size_t)std::max(1, PT_.bvec_off.back())); own_gather_.alloc((size_t)world_ * std::max(1, PT_.max_span));
         own_factor_.zero(st_); own_forward_.zero(st_); own_gather_.zero(st_);
-        PQ_HIP(hipStreamSynchronize(st_));
+        stream_wait(st_);
         xfn_ = nullptr; xbuf_factor_ = own_factor_.p; xbuf_forward_ = own_forward_.p; xbuf_gather_ = own_gather_.p;
         transport_ = Transport::Native;
     }
@@ -1928,7 +1928,7 @@ public:
         PQ_HIP(hipSetDevice(dev_));
         std::vector<double> h((size_t)N_);
         PQ_HIP(hipMemcpyAsync(h.data(), rdiag_.p, sizeof(double) * (size_t)N_, hipMemcpyDeviceToHost, st_));
-        PQ_HIP(hipStreamSynchronize(st_));
+        stream_wait(st_);
         double mx = 0.0;
         for (double r : h) mx = std::max(mx, std::fabs(r));
         return mx > 0.0 ? 1.0 / mx : 0.0;
@@ -2016,7 +2016,7 @@ private:
         info_.alloc(1); info_h_.alloc(1);
         build_full_schedule();
         build_solve_schedule();
-        PQ_HIP(hipStreamSynchronize(st_));
+        stream_wait(st_);
     }
 
     // dynamic LDS of the level kernel = largest front of the level that is factored inside LDS
@@ -2149,7 +2149,7 @@ private:
             hipLaunchKernelGGL(k_subtree_fwd_wave<true>, dim3(nwalk_solve_), dim3(64), 0, st_, M, fronts_.p, solve_walk_lo_.p, solve_walk_hi_.p, xp_.p, fvec_.p, solve_top_pos_.p, solve_flags_.p,
                                solve_flags_.p + 2 * nt, solve_child_tp_.p, epoch);
             if (dbg_ts) {
-                PQ_HIP(hipStreamSynchronize(st_));
+                stream_wait(st_);
                 std::vector<long long> h(3 * (size_t)nwalk_solve_);
                 PQ_HIP(hipMemcpy(h.data(), ts.p, ts.bytes(), hipMemcpyDeviceToHost));
                 long long* pp = nullptr; PQ_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_ts), &pp, sizeof(pp)));
@@ -2189,7 +2189,7 @@ private:
             return;
         }
         if (transport_ != Transport::Callback || !xfn_) throw std::runtime_error("partitioned backend used before pq_kkt_set_exchange / pq_kkt_set_comm_rccl");
-        PQ_HIP(hipStreamSynchronize(st_));
+        stream_wait(st_);
         if (xfn_(xuser_, which) != 0) throw std::runtime_error("exchange callback failed");
     }
     // ---- subtree schedule: one launch of all subtree walks with the dynamic LDS of the largest walk (two fronts of its largest front order)
@@ -2383,7 +2383,7 @@ private:
         }
         B.jobs.alloc(jobs.size());
         PQ_HIP(hipMemcpyAsync(B.jobs.p, jobs.data(), jobs.size() * sizeof(dense::FrontJob), hipMemcpyHostToDevice, st_));
-        PQ_HIP(hipStreamSynchronize(st_));
+        stream_wait(st_);
     }
     // one launch per level of a (possibly filtered) level schedule for the fronts one workgroup factors; the level's big fronts then go through
     // the dense multi-workgroup kernels together: children merged (fixed order), then the blocked partial LDLt panel by panel
@@ -2637,7 +2637,7 @@ private:
                                (const int*)nullptr, ata_vals_.p);
         }
         PQ_HIP(hipGetLastError());
-        PQ_HIP(hipStreamSynchronize(st_));
+        stream_wait(st_);
     }
 
     int dev_, mode_ = 0, nzAA_ = 0, nzGG_ = 0, n_ = 0, p_ = 0, m_ = 0, N_ = 0, nnzK_ = 0;

@@ -206,7 +206,7 @@ void CscOperators::init(const pq_sparse_data* d, hipStream_t st)
             if (l.empty()) l.push_back(0);
             upload_vec(out, l, st);
         };
-        PQ_HIP(hipStreamSynchronize(st));
+        stream_wait(st);
         longs(Pf_p_, n_, long_Pf_, nlong_[0]); longs(AT_p_, p_, long_AT_, nlong_[1]); longs(A_p_, n_, long_A_, nlong_[2]);
         longs(GT_p_, m_, long_GT_, nlong_[3]); longs(G_p_, n_, long_G_, nlong_[4]);
     }
@@ -232,7 +232,7 @@ void CscOperators::upload_values(const pq_sparse_data* d, hipStream_t st)
         launch_gather_values(nzG_, G_src_.p, GT_x_.p, G_x_.p, st);
     }
     PQ_HIP(hipGetLastError());
-    PQ_HIP(hipStreamSynchronize(st));  // `pd` and the caller's arrays must outlive the copies
+    stream_wait(st);  // `pd` and the caller's arrays must outlive the copies
 }
 
 void CscOperators::clone_from(const CscOperators& o, hipStream_t st)

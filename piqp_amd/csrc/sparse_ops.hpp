@@ -19,7 +19,7 @@ inline void upload_vec(DBuf<T>& d, const std::vector<T>& h, hipStream_t st)
     d.alloc(h.size() ? h.size() : 1);
     if (!h.empty()) {
         PQ_HIP(hipMemcpyAsync(d.p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, st));
-        PQ_HIP(hipStreamSynchronize(st));  // setup-time only; `h` is often a temporary
+        stream_wait(st);  // setup-time only; `h` is often a temporary
     }
 }
 
