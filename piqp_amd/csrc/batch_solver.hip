@@ -186,6 +186,27 @@ struct Ipm {
     template <class Op>
     __device__ __forceinline__ double reduce(double x, Op op) const { return wg_reduce<NT>(x, op, red); }
 
+    // ---- element-wise passes ---------------------------------------------------------------------------------------------------
+    // f(i, x) for every i < cnt with x[q] = in[q][i]: the lane's two next trips (i, i + NT) are loaded together -- the second from a clamped address when it
+    // does not exist -- before f stores anything.  A plain lane-strided loop waits for memory once per trip (the compiler cannot move the second trip's loads
+    // over the first trip's stores: any arena vector may alias any other), and a wave of this kernel spends three quarters of its life in such waits
+    // (profiles/r03_pmc_batch_c4.txt).  The arithmetic per element is whatever f does: unchanged.  f must not read, through other pointers, what an earlier
+    // call of f in the same pass has written (element-wise passes do not).
+    template <int NIN, class F>
+    __device__ __forceinline__ void map2(int cnt, const gdbl* const (&in)[NIN], F f) const
+    {
+        for (int i0 = tid(); i0 < cnt; i0 += 2 * NT) {
+            const int i1 = i0 + NT;
+            const bool ok1 = i1 < cnt;
+            const int j1 = ok1 ? i1 : i0;
+            double x0[NIN], x1[NIN];
+#pragma unroll
+            for (int q = 0; q < NIN; ++q) { x0[q] = in[q][i0]; x1[q] = in[q][j1]; }
+            f(i0, x0);
+            if (ok1) f(i1, x1);
+        }
+    }
+
     // ---- mat-vecs (sparse/kkt.hpp:179-203 / multistage_kkt.hpp:291-383), ending with a barrier --------------------
     __device__ void eval_P_x(double alpha, const gdbl* x, gdbl* z) const
     {
@@ -237,7 +258,11 @@ struct Ipm {
         return PackedMeta{s.M.N, s.M.arrow, s.M.n, mi, reinterpret_cast<const long long*>(mi + 4 * s.M.N)};
     }
 
-    __device__ __noinline__ void be_factor(double delta, const gdbl* x_reg, const gdbl* z_reg)
+    // (be_factor / be_solve / refine_error are inlined into their callers: an out-of-line member that uses the kernel's 96 VGPRs saves and restores ~30
+    // callee-saved registers per call through scratch -- 64 KB of scratch per wave times 4 600 waves in flight is far beyond the L2, so that was HBM traffic:
+    // 18.7 -> 16.6 GB per launch and 7.8 -> 7.2 ms with these three inlined.  Inlining EVERYTHING into one function was measured too: 9.1 ms, the chain
+    // substitution spills inside a 240 KB function.)
+    __device__ __forceinline__ void be_factor(double delta, const gdbl* x_reg, const gdbl* z_reg)
     {
         assume_lds();
         extern __shared__ double dyn[];
@@ -305,7 +330,7 @@ struct Ipm {
         __syncthreads();
         info.n_backend_solve++;
     }
-    __device__ __noinline__ void be_solve(const gdbl* rhs_x, const gdbl* rhs_y, const gdbl* rhs_z, gdbl* lhs_x, gdbl* lhs_y, gdbl* lhs_z)
+    __device__ __forceinline__ void be_solve(const gdbl* rhs_x, const gdbl* rhs_y, const gdbl* rhs_z, gdbl* lhs_x, gdbl* lhs_y, gdbl* lhs_z)
     {
         assume_lds();
         extern __shared__ double dyn[];
@@ -328,15 +353,31 @@ struct Ipm {
             s_l[i] = v(V_R, FSL)[i]; s_u[i] = v(V_R, FSU)[i];
             zli[i] = 1.0 / v(V_R, FZL)[i]; zui[i] = 1.0 / v(V_R, FZU)[i];
         }
-        for (int i = tid(); i < S.n_x_l; i += NT) { s_bl[i] = v(V_R, FSBL)[i]; zbli[i] = 1.0 / v(V_R, FZBL)[i]; }
-        for (int i = tid(); i < S.n_x_u; i += NT) { s_bu[i] = v(V_R, FSBU)[i]; zbui[i] = 1.0 / v(V_R, FZBU)[i]; }
+        map2<2>(S.n_x_l, {v(V_R, FSBL), v(V_R, FZBL)}, [&](int i, const double (&x)[2]) { s_bl[i] = x[0]; zbli[i] = 1.0 / x[1]; });
+        map2<2>(S.n_x_u, {v(V_R, FSBU), v(V_R, FZBU)}, [&](int i, const double (&x)[2]) { s_bu[i] = x[0]; zbui[i] = 1.0 / x[1]; });
         __syncthreads();
-        for (int j = tid(); j < n; j += NT) {
-            double xr = rho;
-            const int il = g(S.pos_l)[j], iu = g(S.pos_u)[j];
-            if (il >= 0) xr += xbs[j] * xbs[j] / (zbli[il] * s_bl[il] + delta);
-            if (iu >= 0) xr += xbs[j] * xbs[j] / (zbui[iu] * s_bu[iu] + delta);
-            x_reg[j] = xr;
+        {
+            // (two trips at once, the gathered operands through clamped indices: see map2)
+            const auto pos_l = g(S.pos_l), pos_u = g(S.pos_u);
+            for (int j0 = tid(); j0 < n; j0 += 2 * NT) {
+                const int j1 = j0 + NT;
+                const bool ok1 = j1 < n;
+                const int jj[2] = {j0, ok1 ? j1 : j0};
+                int il[2], iu[2];
+                double xb[2], zl[2], sl[2], zu[2], su[2];
+#pragma unroll
+                for (int r = 0; r < 2; ++r) { il[r] = pos_l[jj[r]]; iu[r] = pos_u[jj[r]]; xb[r] = xbs[jj[r]]; }
+#pragma unroll
+                for (int r = 0; r < 2; ++r) { const int a = il[r] > 0 ? il[r] : 0, b = iu[r] > 0 ? iu[r] : 0; zl[r] = zbli[a]; sl[r] = s_bl[a]; zu[r] = zbui[b]; su[r] = s_bu[b]; }
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    if (r == 1 && !ok1) break;
+                    double xr = rho;
+                    if (il[r] >= 0) xr += xb[r] * xb[r] / (zl[r] * sl[r] + delta);
+                    if (iu[r] >= 0) xr += xb[r] * xb[r] / (zu[r] * su[r] + delta);
+                    x_reg[jj[r]] = xr;
+                }
+            }
         }
         for (int i = tid(); i < m; i += NT) {
             double zr = 0.0;
@@ -374,7 +415,7 @@ struct Ipm {
     }
 
     // :507-536 err = rhs - K_cond * lhs, returns |err|_inf (NaN-propagating)
-    __device__ __noinline__ double refine_error(const gdbl* lx, const gdbl* ly, const gdbl* lz, const gdbl* rx, const gdbl* ry, const gdbl* rz, gdbl* ex, gdbl* ey,
+    __device__ __forceinline__ double refine_error(const gdbl* lx, const gdbl* ly, const gdbl* lz, const gdbl* rx, const gdbl* ry, const gdbl* rz, gdbl* ex, gdbl* ey,
                                    gdbl* ez)
     {
         assume_lds();
@@ -449,12 +490,32 @@ struct Ipm {
             if (g(S.has_u)[i]) r += 1.0 / (zui[i] * s_u[i] + delta) * (v(rhs, FZU)[i] - zui[i] * v(rhs, FSU)[i]);
             rzb[i] = r * z_reg[i];
         }
-        for (int j = tid(); j < n; j += NT) {
-            double r = v(rhs, FX)[j];
-            const int il = g(S.pos_l)[j], iu = g(S.pos_u)[j];
-            if (il >= 0) r -= xbs[j] * (v(rhs, FZBL)[il] - zbli[il] * v(rhs, FSBL)[il]) / (s_bl[il] * zbli[il] + delta);
-            if (iu >= 0) r += xbs[j] * (v(rhs, FZBU)[iu] - zbui[iu] * v(rhs, FSBU)[iu]) / (s_bu[iu] * zbui[iu] + delta);
-            rxb[j] = r;
+        {
+            const auto pos_l = g(S.pos_l), pos_u = g(S.pos_u);
+            const gdbl*rx_ = v(rhs, FX), *rzbl = v(rhs, FZBL), *rsbl = v(rhs, FSBL), *rzbu = v(rhs, FZBU), *rsbu = v(rhs, FSBU);
+            for (int j0 = tid(); j0 < n; j0 += 2 * NT) {
+                const int j1 = j0 + NT;
+                const bool ok1 = j1 < n;
+                const int jj[2] = {j0, ok1 ? j1 : j0};
+                int il[2], iu[2];
+                double r0[2], xb[2], a_zl[2], a_sl[2], a_zi[2], a_s[2], b_zu[2], b_su[2], b_zi[2], b_s[2];
+#pragma unroll
+                for (int r = 0; r < 2; ++r) { il[r] = pos_l[jj[r]]; iu[r] = pos_u[jj[r]]; r0[r] = rx_[jj[r]]; xb[r] = xbs[jj[r]]; }
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const int a = il[r] > 0 ? il[r] : 0, b = iu[r] > 0 ? iu[r] : 0;
+                    a_zl[r] = rzbl[a]; a_sl[r] = rsbl[a]; a_zi[r] = zbli[a]; a_s[r] = s_bl[a];
+                    b_zu[r] = rzbu[b]; b_su[r] = rsbu[b]; b_zi[r] = zbui[b]; b_s[r] = s_bu[b];
+                }
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    if (r == 1 && !ok1) break;
+                    double rr = r0[r];
+                    if (il[r] >= 0) rr -= xb[r] * (a_zl[r] - a_zi[r] * a_sl[r]) / (a_s[r] * a_zi[r] + delta);
+                    if (iu[r] >= 0) rr += xb[r] * (b_zu[r] - b_zi[r] * b_su[r]) / (b_s[r] * b_zi[r] + delta);
+                    rxb[jj[r]] = rr;
+                }
+            }
         }
         __syncthreads();
         gdbl*lx = v(lhs, FX), *ly = v(lhs, FY);
@@ -470,27 +531,27 @@ struct Ipm {
                 if (err <= S.set.iterative_refinement_eps_abs + S.set.iterative_refinement_eps_rel * rhs_norm) break;
                 const double prev = err;
                 be_solve(ex, ey, ez, rlx, rly, rlz);
-                for (int j = tid(); j < n; j += NT) rlx[j] += lx[j];
-                for (int k = tid(); k < p; k += NT) rly[k] += ly[k];
-                for (int i = tid(); i < m; i += NT) rlz[i] += lz[i];
+                map2<2>(n, {rlx, lx}, [&](int j, const double (&x)[2]) { rlx[j] = x[0] + x[1]; });
+                map2<2>(p, {rly, ly}, [&](int k, const double (&x)[2]) { rly[k] = x[0] + x[1]; });
+                map2<2>(m, {rlz, lz}, [&](int i, const double (&x)[2]) { rlz[i] = x[0] + x[1]; });
                 __syncthreads();
                 err = refine_error(rlx, rly, rlz, rxb, ry, rzb, ex, ey, ez);
                 if (!isfinite(err)) return false;
                 const double rate = prev / err;
                 const bool stop = rate < S.set.iterative_refinement_min_improvement_rate;
                 if (!stop || rate > 1.0) {  // the reference swaps the buffers (:292-300); the refined iterate becomes lhs
-                    for (int j = tid(); j < n; j += NT) lx[j] = rlx[j];
-                    for (int k = tid(); k < p; k += NT) ly[k] = rly[k];
-                    for (int i = tid(); i < m; i += NT) lz[i] = rlz[i];
+                    map2<1>(n, {rlx}, [&](int j, const double (&x)[1]) { lx[j] = x[0]; });
+                    map2<1>(p, {rly}, [&](int k, const double (&x)[1]) { ly[k] = x[0]; });
+                    map2<1>(m, {rlz}, [&](int i, const double (&x)[1]) { lz[i] = x[0]; });
                     __syncthreads();
                 }
                 if (stop) break;
             }
         } else {
             double bad = 0.0;
-            for (int j = tid(); j < n; j += NT) if (!isfinite(lx[j])) bad = 1.0;
-            for (int k = tid(); k < p; k += NT) if (!isfinite(ly[k])) bad = 1.0;
-            for (int i = tid(); i < m; i += NT) if (!isfinite(lz[i])) bad = 1.0;
+            map2<1>(n, {lx}, [&](int, const double (&x)[1]) { if (!isfinite(x[0])) bad = 1.0; });
+            map2<1>(p, {ly}, [&](int, const double (&x)[1]) { if (!isfinite(x[0])) bad = 1.0; });
+            map2<1>(m, {lz}, [&](int, const double (&x)[1]) { if (!isfinite(x[0])) bad = 1.0; });
             if (reduce(bad, OpMax()) > 0.0) return false;
         }
 
@@ -518,17 +579,31 @@ struct Ipm {
             v(lhs, FZL)[i] = zl; v(lhs, FZU)[i] = zu; v(lhs, FSL)[i] = sl; v(lhs, FSU)[i] = su;
         }
         // :347-366 box dual recovery
-        for (int i = tid(); i < S.n_x_l; i += NT) {
-            const int idx = g(S.x_l_idx)[i];
-            const double z = (-xbs[idx] * lx[idx] - v(rhs, FZBL)[i] + zbli[i] * v(rhs, FSBL)[i]) / (s_bl[i] * zbli[i] + delta);
-            v(lhs, FZBL)[i] = z;
-            v(lhs, FSBL)[i] = zbli[i] * (v(rhs, FSBL)[i] - s_bl[i] * z);
-        }
-        for (int i = tid(); i < S.n_x_u; i += NT) {
-            const int idx = g(S.x_u_idx)[i];
-            const double z = (xbs[idx] * lx[idx] - v(rhs, FZBU)[i] + zbui[i] * v(rhs, FSBU)[i]) / (s_bu[i] * zbui[i] + delta);
-            v(lhs, FZBU)[i] = z;
-            v(lhs, FSBU)[i] = zbui[i] * (v(rhs, FSBU)[i] - s_bu[i] * z);
+        {
+            // box dual recovery, two trips at once: the index and the element-wise operands first, then the two gathered ones, then the stores
+            auto box = [&](int cnt, const __attribute__((address_space(1))) int* idxs, const gdbl* rz, const gdbl* rs, const gdbl* zi, const gdbl* sb, gdbl* oz, gdbl* os, const bool upper) {
+                for (int i0 = tid(); i0 < cnt; i0 += 2 * NT) {
+                    const int i1 = i0 + NT;
+                    const bool ok1 = i1 < cnt;
+                    const int ii[2] = {i0, ok1 ? i1 : i0};
+                    int idx[2];
+                    double a_rz[2], a_rs[2], a_zi[2], a_sb[2], xb[2], lxv[2];
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) { idx[r] = idxs[ii[r]]; a_rz[r] = rz[ii[r]]; a_rs[r] = rs[ii[r]]; a_zi[r] = zi[ii[r]]; a_sb[r] = sb[ii[r]]; }
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) { xb[r] = xbs[idx[r]]; lxv[r] = lx[idx[r]]; }
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) {
+                        if (r == 1 && !ok1) break;
+                        const double z = upper ? (xb[r] * lxv[r] - a_rz[r] + a_zi[r] * a_rs[r]) / (a_sb[r] * a_zi[r] + delta)
+                                               : (-xb[r] * lxv[r] - a_rz[r] + a_zi[r] * a_rs[r]) / (a_sb[r] * a_zi[r] + delta);
+                        oz[ii[r]] = z;
+                        os[ii[r]] = a_zi[r] * (a_rs[r] - a_sb[r] * z);
+                    }
+                }
+            };
+            box(S.n_x_l, g(S.x_l_idx), v(rhs, FZBL), v(rhs, FSBL), zbli, s_bl, v(lhs, FZBL), v(lhs, FSBL), false);
+            box(S.n_x_u, g(S.x_u_idx), v(rhs, FZBU), v(rhs, FSBU), zbui, s_bu, v(lhs, FZBU), v(lhs, FSBU), true);
         }
         __syncthreads();
         info.n_solve++;
@@ -616,8 +691,19 @@ struct Ipm {
         inf = fmax_std(inf, inf_scaled(v(set, FZL), dinv + n + p, 1.0, m));
         inf = fmax_std(inf, inf_scaled(v(set, FZU), dinv + n + p, 1.0, m));
         double mx = inf;
-        for (int i = tid(); i < S.n_x_l; i += NT) { const double t = v(set, FZBL)[i] * dbi[g(S.x_l_idx)[i]]; if (mx < t) mx = t; }
-        for (int i = tid(); i < S.n_x_u; i += NT) { const double t = v(set, FZBU)[i] * dbi[g(S.x_u_idx)[i]]; if (mx < t) mx = t; }
+        auto boxmax = [&](int cnt, const __attribute__((address_space(1))) int* idxs, const gdbl* z) {
+            for (int i0 = tid(); i0 < cnt; i0 += 2 * NT) {
+                const int i1 = i0 + NT;
+                const int j1 = i1 < cnt ? i1 : i0;  // (a clamped duplicate cannot change a maximum)
+                const int x0 = idxs[i0], x1 = idxs[j1];
+                const double z0 = z[i0], z1 = z[j1];
+                const double t0 = z0 * dbi[x0], t1 = z1 * dbi[x1];
+                if (mx < t0) mx = t0;
+                if (mx < t1) mx = t1;
+            }
+        };
+        boxmax(S.n_x_l, g(S.x_l_idx), v(set, FZBL));
+        boxmax(S.n_x_u, g(S.x_u_idx), v(set, FZBU));
         return reduce(mx, OpMax());
     }
     static __device__ __forceinline__ double fmax_std(double a, double b) { return a < b ? b : a; }
@@ -631,13 +717,24 @@ struct Ipm {
         const gdbl* db = at(D_DB);
         const double ci = rz_c_inv;
         double mx = 0.0;
-        for (int i = tid(); i < p; i += NT) { const double t = fabs((v(V_PX, FY)[i] - v(V_R, FY)[i]) * ci * dl[n + i]); if (mx < t) mx = t; }
+        map2<3>(p, {v(V_PX, FY), v(V_R, FY), dl + n}, [&](int, const double (&x)[3]) { const double t = fabs((x[0] - x[1]) * ci * x[2]); if (mx < t) mx = t; });
         for (int i = tid(); i < m; i += NT) {
             double t = fabs((v(V_PX, FZL)[i] - v(V_R, FZL)[i]) * ci * dl[n + p + i]); if (mx < t) mx = t;
             t = fabs((v(V_PX, FZU)[i] - v(V_R, FZU)[i]) * ci * dl[n + p + i]); if (mx < t) mx = t;
         }
-        for (int i = tid(); i < S.n_x_l; i += NT) { const double t = (v(V_PX, FZBL)[i] - v(V_R, FZBL)[i]) * ci * db[g(S.x_l_idx)[i]]; if (mx < t) mx = t; }
-        for (int i = tid(); i < S.n_x_u; i += NT) { const double t = (v(V_PX, FZBU)[i] - v(V_R, FZBU)[i]) * ci * db[g(S.x_u_idx)[i]]; if (mx < t) mx = t; }
+        auto boxprox = [&](int cnt, const __attribute__((address_space(1))) int* idxs, const gdbl* a, const gdbl* b) {
+            for (int i0 = tid(); i0 < cnt; i0 += 2 * NT) {
+                const int i1 = i0 + NT;
+                const int j1 = i1 < cnt ? i1 : i0;  // (a clamped duplicate cannot change a maximum)
+                const int x0 = idxs[i0], x1 = idxs[j1];
+                const double a0 = a[i0], b0 = b[i0], a1 = a[j1], b1 = b[j1];
+                const double t0 = (a0 - b0) * ci * db[x0], t1 = (a1 - b1) * ci * db[x1];
+                if (mx < t0) mx = t0;
+                if (mx < t1) mx = t1;
+            }
+        };
+        boxprox(S.n_x_l, g(S.x_l_idx), v(V_PX, FZBL), v(V_R, FZBL));
+        boxprox(S.n_x_u, g(S.x_u_idx), v(V_PX, FZBU), v(V_R, FZBU));
         return reduce(mx, OpMax());
     }
     // :1198-1203
@@ -645,7 +742,7 @@ struct Ipm {
     {
         const gdbl* dl = at(D_DL);
         double mx = 0.0;
-        for (int i = tid(); i < S.n; i += NT) { const double t = fabs((v(V_R, FX)[i] - v(V_PX, FX)[i]) * dl[i]); if (mx < t) mx = t; }
+        map2<3>(S.n, {v(V_R, FX), v(V_PX, FX), dl}, [&](int, const double (&x)[3]) { const double t = fabs((x[0] - x[1]) * x[2]); if (mx < t) mx = t; });
         return reduce(mx, OpMax());
     }
 
@@ -675,7 +772,7 @@ struct Ipm {
         gdbl* work_x_2 = nrx;
         eval_G(1.0, 1.0, rx, work_z, v(V_NR, FZL), work_x_2);
         for (int i = tid(); i < m; i += NT) v(V_NR, FZU)[i] = -v(V_NR, FZL)[i];
-        for (int j = tid(); j < n; j += NT) work_x[j] += work_x_2[j];
+        map2<2>(n, {work_x, work_x_2}, [&](int j, const double (&x)[2]) { work_x[j] = x[0] + x[1]; });
         __syncthreads();
 
         eval_P_x(-1.0, rx, nrx);
@@ -697,22 +794,38 @@ struct Ipm {
         info.duality_gap_rel = info.duality_gap / fmax_std(1.0, dg_rel);
 
         __syncthreads();
-        for (int j = tid(); j < n; j += NT) {
-            nrx[j] -= c[j];
-            double wx = work_x[j];
-            const int il = g(S.pos_l)[j], iu = g(S.pos_u)[j];
-            if (il >= 0) wx -= xbs[j] * v(V_R, FZBL)[il];
-            if (iu >= 0) wx += xbs[j] * v(V_R, FZBU)[iu];
-            work_x[j] = wx;
+        {
+            const auto pos_l = g(S.pos_l), pos_u = g(S.pos_u);
+            const gdbl*zbl = v(V_R, FZBL), *zbu = v(V_R, FZBU);
+            for (int j0 = tid(); j0 < n; j0 += 2 * NT) {
+                const int j1 = j0 + NT;
+                const bool ok1 = j1 < n;
+                const int jj[2] = {j0, ok1 ? j1 : j0};
+                int il[2], iu[2];
+                double a_n[2], a_c[2], a_w[2], xb[2], gl[2], gu[2];
+#pragma unroll
+                for (int r = 0; r < 2; ++r) { il[r] = pos_l[jj[r]]; iu[r] = pos_u[jj[r]]; a_n[r] = nrx[jj[r]]; a_c[r] = c[jj[r]]; a_w[r] = work_x[jj[r]]; xb[r] = xbs[jj[r]]; }
+#pragma unroll
+                for (int r = 0; r < 2; ++r) { gl[r] = zbl[il[r] > 0 ? il[r] : 0]; gu[r] = zbu[iu[r] > 0 ? iu[r] : 0]; }
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    if (r == 1 && !ok1) break;
+                    nrx[jj[r]] = a_n[r] - a_c[r];
+                    double wx = a_w[r];
+                    if (il[r] >= 0) wx -= xb[r] * gl[r];
+                    if (iu[r] >= 0) wx += xb[r] * gu[r];
+                    work_x[jj[r]] = wx;
+                }
+            }
         }
         __syncthreads();
         dual_rel_norm = fmax_std(dual_rel_norm, inf_scaled(c, dinv, ci, n));
         dual_rel_norm = fmax_std(dual_rel_norm, inf_scaled(work_x, dinv, ci, n));
-        for (int j = tid(); j < n; j += NT) nrx[j] -= work_x[j];
+        map2<2>(n, {nrx, work_x}, [&](int j, const double (&x)[2]) { nrx[j] = x[0] - x[1]; });
 
         double primal_rel_norm = inf_scaled(v(V_NR, FY), dinv + n, 1.0, p);
         __syncthreads();
-        for (int i = tid(); i < p; i += NT) v(V_NR, FY)[i] += bb[i];
+        { gdbl* o = v(V_NR, FY); map2<2>(p, {v(V_NR, FY), bb}, [&](int i, const double (&x)[2]) { o[i] = x[0] + x[1]; }); }
         primal_rel_norm = fmax_std(primal_rel_norm, inf_scaled(bb, dinv + n, 1.0, p));
 
         const gdbl* dz = dinv + n + p;
@@ -737,21 +850,31 @@ struct Ipm {
                 v(V_NR, FZU)[i] = 0.0;
             }
         }
-        for (int i = tid(); i < S.n_x_l; i += NT) {
-            const int idx = g(S.x_l_idx)[i];
-            const double t = xbs[idx] * rx[idx];
-            mx = fmax_std(mx, t * dbi[idx]);
-            mx = fmax_std(mx, xl[i] * dbi[idx]);
-            mx = fmax_std(mx, v(V_R, FSBL)[i] * dbi[idx]);
-            v(V_NR, FZBL)[i] = t + (-xl[i] - v(V_R, FSBL)[i]);
-        }
-        for (int i = tid(); i < S.n_x_u; i += NT) {
-            const int idx = g(S.x_u_idx)[i];
-            const double t = -xbs[idx] * rx[idx];
-            mx = fmax_std(mx, t * dbi[idx]);
-            mx = fmax_std(mx, xu[i] * dbi[idx]);
-            mx = fmax_std(mx, v(V_R, FSBU)[i] * dbi[idx]);
-            v(V_NR, FZBU)[i] = t + (xu[i] - v(V_R, FSBU)[i]);
+        {
+            auto boxres = [&](int cnt, const __attribute__((address_space(1))) int* idxs, const gdbl* xb_, const gdbl* sb, gdbl* o, const bool upper) {
+                for (int i0 = tid(); i0 < cnt; i0 += 2 * NT) {
+                    const int i1 = i0 + NT;
+                    const bool ok1 = i1 < cnt;
+                    const int ii[2] = {i0, ok1 ? i1 : i0};
+                    int idx[2];
+                    double a_b[2], a_s[2], gx[2], gr[2], gd[2];
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) { idx[r] = idxs[ii[r]]; a_b[r] = xb_[ii[r]]; a_s[r] = sb[ii[r]]; }
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) { gx[r] = xbs[idx[r]]; gr[r] = rx[idx[r]]; gd[r] = dbi[idx[r]]; }
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) {
+                        if (r == 1 && !ok1) break;
+                        const double t = upper ? -gx[r] * gr[r] : gx[r] * gr[r];
+                        mx = fmax_std(mx, t * gd[r]);
+                        mx = fmax_std(mx, a_b[r] * gd[r]);
+                        mx = fmax_std(mx, a_s[r] * gd[r]);
+                        o[ii[r]] = upper ? t + (a_b[r] - a_s[r]) : t + (-a_b[r] - a_s[r]);
+                    }
+                }
+            };
+            boxres(S.n_x_l, g(S.x_l_idx), xl, v(V_R, FSBL), v(V_NR, FZBL), false);
+            boxres(S.n_x_u, g(S.x_u_idx), xu, v(V_R, FSBU), v(V_NR, FZBU), true);
         }
         primal_rel_norm = reduce(mx, OpMax());
         __syncthreads();
@@ -770,14 +893,13 @@ struct Ipm {
         assume_lds();
         const int n = S.n, p = S.p, m = S.m;
         const double rho = info.rho, delta = info.delta;
-        for (int j = tid(); j < n; j += NT) v(V_RS, FX)[j] = v(V_NR, FX)[j] - rho * (v(V_R, FX)[j] - v(V_PX, FX)[j]);
-        for (int i = tid(); i < p; i += NT) v(V_RS, FY)[i] = v(V_NR, FY)[i] - delta * (v(V_PX, FY)[i] - v(V_R, FY)[i]);
-        for (int i = tid(); i < m; i += NT) {
-            v(V_RS, FZL)[i] = v(V_NR, FZL)[i] - delta * (v(V_PX, FZL)[i] - v(V_R, FZL)[i]);
-            v(V_RS, FZU)[i] = v(V_NR, FZU)[i] - delta * (v(V_PX, FZU)[i] - v(V_R, FZU)[i]);
-        }
-        for (int i = tid(); i < S.n_x_l; i += NT) v(V_RS, FZBL)[i] = v(V_NR, FZBL)[i] - delta * (v(V_PX, FZBL)[i] - v(V_R, FZBL)[i]);
-        for (int i = tid(); i < S.n_x_u; i += NT) v(V_RS, FZBU)[i] = v(V_NR, FZBU)[i] - delta * (v(V_PX, FZBU)[i] - v(V_R, FZBU)[i]);
+        { gdbl* o = v(V_RS, FX); map2<3>(n, {v(V_NR, FX), v(V_R, FX), v(V_PX, FX)}, [&](int j, const double (&x)[3]) { o[j] = x[0] - rho * (x[1] - x[2]); }); }
+        auto prox_dual = [&](int f, int cnt) { gdbl* o = v(V_RS, f); map2<3>(cnt, {v(V_NR, f), v(V_PX, f), v(V_R, f)}, [&](int i, const double (&x)[3]) { o[i] = x[0] - delta * (x[1] - x[2]); }); };
+        prox_dual(FY, p);
+        prox_dual(FZL, m);
+        prox_dual(FZU, m);
+        prox_dual(FZBL, S.n_x_l);
+        prox_dual(FZBU, S.n_x_u);
         __syncthreads();
         const double primal_rel_scaling = info.primal_res_rel > 0 ? info.primal_res / info.primal_res_rel : 1.0;
         const double dual_rel_scaling = info.dual_res_rel > 0 ? info.dual_res / info.dual_res_rel : 1.0;
@@ -808,10 +930,8 @@ struct Ipm {
 
     __device__ void copy_prox_duals()
     {
-        for (int i = tid(); i < S.p; i += NT) v(V_PX, FY)[i] = v(V_R, FY)[i];
-        for (int i = tid(); i < S.m; i += NT) { v(V_PX, FZL)[i] = v(V_R, FZL)[i]; v(V_PX, FZU)[i] = v(V_R, FZU)[i]; }
-        for (int i = tid(); i < S.n_x_l; i += NT) v(V_PX, FZBL)[i] = v(V_R, FZBL)[i];
-        for (int i = tid(); i < S.n_x_u; i += NT) v(V_PX, FZBU)[i] = v(V_R, FZBU)[i];
+        auto cp = [&](int f, int cnt) { gdbl* o = v(V_PX, f); map2<1>(cnt, {v(V_R, f)}, [&](int i, const double (&x)[1]) { o[i] = x[0]; }); };
+        cp(FY, S.p); cp(FZL, S.m); cp(FZU, S.m); cp(FZBL, S.n_x_l); cp(FZBU, S.n_x_u);
     }
 
     // solver.hpp:379-882
@@ -882,7 +1002,7 @@ struct Ipm {
             info.mu = calculate_mu();
         }
 
-        for (int i = tid(); i < n; i += NT) v(V_PX, FX)[i] = v(V_R, FX)[i];
+        { gdbl* o = v(V_PX, FX); map2<1>(n, {v(V_R, FX)}, [&](int i, const double (&x)[1]) { o[i] = x[0]; }); }
         copy_prox_duals();
         __syncthreads();
 
@@ -947,9 +1067,8 @@ struct Ipm {
 
             if (m + S.n_x_l + S.n_x_u > 0) {
                 // predictor
-                for (int i = tid(); i < m; i += NT) { v(V_RS, FSL)[i] = -v(V_R, FSL)[i] * v(V_R, FZL)[i]; v(V_RS, FSU)[i] = -v(V_R, FSU)[i] * v(V_R, FZU)[i]; }
-                for (int i = tid(); i < S.n_x_l; i += NT) v(V_RS, FSBL)[i] = -v(V_R, FSBL)[i] * v(V_R, FZBL)[i];
-                for (int i = tid(); i < S.n_x_u; i += NT) v(V_RS, FSBU)[i] = -v(V_R, FSBU)[i] * v(V_R, FZBU)[i];
+                auto pred = [&](int fs, int fz, int cnt) { gdbl* o = v(V_RS, fs); map2<2>(cnt, {v(V_R, fs), v(V_R, fz)}, [&](int i, const double (&x)[2]) { o[i] = -x[0] * x[1]; }); };
+                pred(FSL, FZL, m); pred(FSU, FZU, m); pred(FSBL, FZBL, S.n_x_l); pred(FSBU, FZBU, S.n_x_u);
                 __syncthreads();
                 ks_solve(V_RS, V_ST);
 
@@ -958,8 +1077,9 @@ struct Ipm {
                 alpha_s *= set.tau; alpha_z *= set.tau;
 
                 auto sdot = [&](int fs, int fz, int cnt) {
+                    if (cnt <= 0) return 0.0;
                     double acc = 0.0;
-                    for (int i = tid(); i < cnt; i += NT) acc += (v(V_R, fs)[i] + alpha_s * v(V_ST, fs)[i]) * (v(V_R, fz)[i] + alpha_z * v(V_ST, fz)[i]);
+                    map2<4>(cnt, {v(V_R, fs), v(V_ST, fs), v(V_R, fz), v(V_ST, fz)}, [&](int, const double (&x)[4]) { acc += (x[0] + alpha_s * x[1]) * (x[2] + alpha_z * x[3]); });
                     return reduce(acc, OpSum());
                 };
                 double sigma = sdot(FSL, FZL, m);
@@ -973,12 +1093,8 @@ struct Ipm {
                 // corrector
                 const double smu = info.sigma * info.mu;
                 __syncthreads();
-                for (int i = tid(); i < m; i += NT) {
-                    v(V_RS, FSL)[i] += -v(V_ST, FSL)[i] * v(V_ST, FZL)[i] + smu;
-                    v(V_RS, FSU)[i] += -v(V_ST, FSU)[i] * v(V_ST, FZU)[i] + smu;
-                }
-                for (int i = tid(); i < S.n_x_l; i += NT) v(V_RS, FSBL)[i] += -v(V_ST, FSBL)[i] * v(V_ST, FZBL)[i] + smu;
-                for (int i = tid(); i < S.n_x_u; i += NT) v(V_RS, FSBU)[i] += -v(V_ST, FSBU)[i] * v(V_ST, FZBU)[i] + smu;
+                auto corr = [&](int fs, int fz, int cnt) { gdbl* o = v(V_RS, fs); map2<3>(cnt, {v(V_RS, fs), v(V_ST, fs), v(V_ST, fz)}, [&](int i, const double (&x)[3]) { o[i] = x[0] + (-x[1] * x[2] + smu); }); };
+                corr(FSL, FZL, m); corr(FSU, FZU, m); corr(FSBL, FZBL, S.n_x_l); corr(FSBU, FZBU, S.n_x_u);
                 __syncthreads();
                 ks_solve(V_RS, V_ST);
 
@@ -987,14 +1103,10 @@ struct Ipm {
                 info.dual_step = alpha_z * set.tau;
                 const double ps = info.primal_step, ds = info.dual_step;
                 __syncthreads();
-                for (int i = tid(); i < n; i += NT) v(V_R, FX)[i] += ps * v(V_ST, FX)[i];
-                for (int i = tid(); i < p; i += NT) v(V_R, FY)[i] += ds * v(V_ST, FY)[i];
-                for (int i = tid(); i < m; i += NT) {
-                    v(V_R, FZL)[i] += ds * v(V_ST, FZL)[i]; v(V_R, FZU)[i] += ds * v(V_ST, FZU)[i];
-                    v(V_R, FSL)[i] += ps * v(V_ST, FSL)[i]; v(V_R, FSU)[i] += ps * v(V_ST, FSU)[i];
-                }
-                for (int i = tid(); i < S.n_x_l; i += NT) { v(V_R, FZBL)[i] += ds * v(V_ST, FZBL)[i]; v(V_R, FSBL)[i] += ps * v(V_ST, FSBL)[i]; }
-                for (int i = tid(); i < S.n_x_u; i += NT) { v(V_R, FZBU)[i] += ds * v(V_ST, FZBU)[i]; v(V_R, FSBU)[i] += ps * v(V_ST, FSBU)[i]; }
+                auto step = [&](int f, double a, int cnt) { gdbl* o = v(V_R, f); map2<2>(cnt, {v(V_R, f), v(V_ST, f)}, [&](int i, const double (&x)[2]) { o[i] = x[0] + a * x[1]; }); };
+                step(FX, ps, n); step(FY, ds, p);
+                step(FZL, ds, m); step(FZU, ds, m); step(FSL, ps, m); step(FSU, ps, m);
+                step(FZBL, ds, S.n_x_l); step(FSBL, ps, S.n_x_l); step(FZBU, ds, S.n_x_u); step(FSBU, ps, S.n_x_u);
                 __syncthreads();
 
                 const double mu_prev = info.mu;
@@ -1005,7 +1117,7 @@ struct Ipm {
 
                 if (info.dual_res < 0.95 * info.prev_dual_res || (info.dual_res < set.eps_abs || info.dual_res_rel < set.eps_rel) ||
                     (info.rho == set.reg_finetune_lower_limit && info.dual_prox_inf < set.infeasibility_threshold)) {
-                    for (int i = tid(); i < n; i += NT) v(V_PX, FX)[i] = v(V_R, FX)[i];
+                    { gdbl* o = v(V_PX, FX); map2<1>(n, {v(V_R, FX)}, [&](int i, const double (&x)[1]) { o[i] = x[0]; }); }
                     info.rho = fmax_std(info.reg_limit, (1.0 - mu_rate) * info.rho);
                 } else {
                     info.no_primal_update++;
@@ -1029,7 +1141,7 @@ struct Ipm {
                 __syncthreads();
                 update_residuals_nr();
                 if (info.dual_res < 0.95 * info.prev_dual_res || (info.dual_res < set.eps_abs || info.dual_res_rel < set.eps_rel)) {
-                    for (int i = tid(); i < n; i += NT) v(V_PX, FX)[i] = v(V_R, FX)[i];
+                    { gdbl* o = v(V_PX, FX); map2<1>(n, {v(V_R, FX)}, [&](int i, const double (&x)[1]) { o[i] = x[0]; }); }
                     info.rho = fmax_std(info.reg_limit, 0.1 * info.rho);
                 } else {
                     info.no_primal_update++;
