@@ -1682,9 +1682,17 @@ private:
         if (const char* e = debug_token("batch_mode")) forced_mode_ = std::atoi(e);  // forces the chain working-set mode (tests of the fallback modes)
         if (nt_ == 64 && sym_.max_h * sym_.max_h <= 64 && wave_doubles * (long long)sizeof(double) <= RESIDENT_LIMIT_BYTES && sym_.max_w <= msdev::WAVE_WMAX && (forced_mode_ < 0 || forced_mode_ == MODE_WAVE)) {
             mode_ = MODE_WAVE;
-            // the kernel needs 97 VGPRs: compiled for four waves per SIMD it gets a 128-register budget it does not use and 16 single-wave workgroups per
-            // CU; compiled for five (102 registers, no spills) the LDS bound of 18 workgroups per CU applies (8192 QPs: 8.78 -> 8.49 ms; six: 8.63, eight: 8.96)
-            if (!debug_token("batch_wpe")) wpe_ = 5;
+            // Register budget against waves in flight (round 3, after the out-of-line members got the launched variant's budget): the interior-point code
+            // spills at 102 registers, and under load the kernel is bound by what its waves move through memory -- scratch included --, not by how many
+            // of them wait: 8192 QPs 6.77 ms compiled for four waves per SIMD (128 registers, 16 workgroups per CU), 7.25 for five (18 per CU, the LDS
+            // bound), 7.54 for three, 8.97 for six.  A batch that fits in one round of workgroups anyway takes the largest budget that still holds it:
+            // 1024 QPs 2.41 ms for two waves per SIMD, 2.43 three, 2.52 four, 2.67 five.
+            if (!debug_token("batch_wpe")) {
+                int dev = 0, cus = 256;
+                if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+                const long long per_cu = ((long long)batch_ + cus - 1) / std::max(cus, 1);
+                wpe_ = per_cu <= 8 ? 2 : (per_cu <= 12 ? 3 : 4);
+            }
             S.res_f = 0; S.res_pan = 0; S.res_x = (int)sym_.qpan_doubles; S.res_chain = S.res_x + n;
             S.fcap = 0; S.lofs = 0;
             S.chain_lds_doubles = (int)wave_doubles;
