@@ -258,7 +258,8 @@ struct Ipm {
         return PackedMeta{s.M.N, s.M.arrow, s.M.n, mi, reinterpret_cast<const long long*>(mi + 4 * s.M.N)};
     }
 
-    // (be_factor / be_solve / refine_error are inlined into their callers: an out-of-line member that uses the kernel's 96 VGPRs saves and restores ~30
+    // (be_factor / be_solve / refine_error, the scalings and the two residual updates are inlined into their callers -- ks_solve, with three call sites, is not:
+    // inlined too, the chain substitution spills, 7.8 ms --: an out-of-line member that uses the kernel's 96 VGPRs saves and restores ~30
     // callee-saved registers per call through scratch -- 64 KB of scratch per wave times 4 600 waves in flight is far beyond the L2, so that was HBM traffic:
     // 18.7 -> 16.6 GB per launch and 7.8 -> 7.2 ms with these three inlined.  Inlining EVERYTHING into one function was measured too: 9.1 ms, the chain
     // substitution spills inside a 240 KB function.)
@@ -340,7 +341,7 @@ struct Ipm {
 
     // ---- KKTSystem (kkt_system.hpp) -----------------------------------------------------------------------------
     // :143-211
-    __device__ __noinline__ bool ks_update_scalings_and_factor(bool iterative_refinement, double rho, double delta)
+    __device__ __forceinline__ bool ks_update_scalings_and_factor(bool iterative_refinement, double rho, double delta)
     {
         assume_lds();
         const int n = S.n, m = S.m;
@@ -747,7 +748,7 @@ struct Ipm {
     }
 
     // :960-1105
-    __device__ __noinline__ void update_residuals_nr()
+    __device__ __forceinline__ void update_residuals_nr()
     {
         assume_lds();
         const long long t_begin = wall_clock64();
@@ -888,7 +889,7 @@ struct Ipm {
     }
 
     // :1107-1128
-    __device__ __noinline__ void update_residuals_r()
+    __device__ __forceinline__ void update_residuals_r()
     {
         assume_lds();
         const int n = S.n, p = S.p, m = S.m;
