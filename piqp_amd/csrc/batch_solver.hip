@@ -59,6 +59,7 @@ struct BatchShared {
     const int *ent_b, *ent_rc;  // lower-triangular entries of all fronts (flat assembly)
     int n_ent;
     int fcap, lofs, hcap, chain_lds_doubles;
+    int chain_reg_w, chain_reg_k, chain_reg_nst;  // chain_reg_w > 0: stages 0 .. chain_reg_k - 1 of the chain_reg_nst stages form a uniform gap-free chain without arrow -- register-carried substitution (msdev::solve_chain_wave_reg)
     int meta_ofs;  // LDS offset (doubles) of the per-stage structure tables copied in at kernel start
     int res_f, res_pan, res_x, res_chain;  // MODE_RESIDENT: LDS offsets (doubles) of the fronts, the factor panels, the solve vector, chain scratch
     long long off[NSLOT];
@@ -313,7 +314,7 @@ struct Ipm {
         }
         __syncthreads();
         const long long t0 = wall_clock64();
-        if constexpr (WAVE) { msdev::solve_chain_wave(PM, dyn + S.res_pan, xw); __syncthreads(); }
+        if constexpr (WAVE) { msdev::solve_chain_wave(PM, dyn + S.res_pan, xw, S.chain_reg_w, S.chain_reg_k, S.chain_reg_nst); __syncthreads(); }
         else if constexpr (RES) msdev::solve_chain<NT, LDS>(PM, dyn + S.res_pan, xw, dyn + S.res_chain, S.hcap);
         else msdev::solve_chain<NT, LDS>(PM, gen(at(B_PAN)), gen(xw), dyn, S.hcap);
         st.prof[T_CHAIN] += wall_clock64() - t0;
@@ -1698,6 +1699,26 @@ private:
             S.fcap = 0; S.lofs = 0;
             S.chain_lds_doubles = (int)wave_doubles;
             wave_pan = true;
+            {   // the register-carried chain substitution: no arrow, no gaps, and a leading run of stages that all eliminate W columns (W <= 6: the row shift
+                // and h = W + u <= 16 stay inside one row of lanes); what follows the run -- usually one terminal stage -- takes the LDS steps
+                int nst = sym_.N;
+                while (nst > 0 && sym_.h[nst - 1] == 0) --nst;
+                const int W0 = nst > 0 ? sym_.w[0] : 0;
+                bool chain = sym_.arrow == 0 && nst >= 1 && nst <= 64 && W0 >= 1 && W0 <= 6 && !debug_token("batch_no_chain_reg");
+                for (int b = 0; chain && b < nst; ++b) {
+                    chain = sym_.h[b] == sym_.w[b] + sym_.off[b] && sym_.h[b] <= 16;
+                    if (chain && b + 1 < nst) chain = sym_.block_info[b + 1].start == sym_.block_info[b].start + sym_.w[b] && sym_.off[b] <= sym_.w[b + 1];
+                    if (chain && b + 1 == nst) chain = sym_.off[b] == 0;
+                }
+                int K = 0;
+                while (chain && K < nst && sym_.w[K] == W0 && sym_.off[K] <= W0) ++K;
+                const bool ok = chain && K >= 4;
+                if (debug_token("batch_chain_info"))
+                    std::fprintf(stderr, "[piqp_amd] batch chain: %d stages, arrow %d, register-carried substitution for the first %d (w = %d)\n", nst, sym_.arrow, ok ? K : 0, W0);
+                S.chain_reg_w = ok ? W0 : 0;
+                S.chain_reg_k = ok ? K : 0;
+                S.chain_reg_nst = ok ? nst : 0;
+            }
         } else if (res_doubles * (long long)sizeof(double) <= RESIDENT_LIMIT_BYTES && (forced_mode_ < 0 || forced_mode_ == MODE_RESIDENT)) {
             mode_ = MODE_RESIDENT;
             S.res_f = 0; S.res_pan = (int)sym_.front_doubles; S.res_x = S.res_pan + (int)sym_.pan_doubles; S.res_chain = S.res_x + n;
