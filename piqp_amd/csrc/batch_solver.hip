@@ -57,6 +57,8 @@ struct BatchShared {
     GroupMeta GA, GG;
     const long long *P_dst, *A_dst, *G_dst;
     const int *ent_b, *ent_rc;  // lower-triangular entries of all fronts (flat assembly)
+    const int *ent_at, *ent_xr;  // ... as offsets into the front arena / index of the x_reg entry added there (-1: none)
+    int ent_flat;
     int n_ent;
     int fcap, lofs, hcap, chain_lds_doubles;
     int chain_reg_w, chain_reg_k, chain_reg_nst;  // chain_reg_w > 0: stages 0 .. chain_reg_k - 1 of the chain_reg_nst stages form a uniform gap-free chain without arrow -- register-carried substitution (msdev::solve_chain_wave_reg)
@@ -278,6 +280,29 @@ struct Ipm {
         long long t1;
         if constexpr (WAVE) {  // fronts in the arena (device memory), factor panels in LDS
             gdbl* F = at(B_F);
+            if (S.m == 0 && S.ent_flat) {
+                // no inequality rows: an entry is P + delta^-1 A'A (+ x_reg on the pivots) -- offsets and x_reg indices come precomputed, two trips at once
+                const gdbl*Pf = at(B_PF), *AtAf = at(B_ATAF);
+                const auto eat = g(S.ent_at), exr = g(S.ent_xr);
+                for (int e0 = tid(); e0 < S.n_ent; e0 += 2 * NT) {
+                    const int e1 = e0 + NT;
+                    const bool ok1 = e1 < S.n_ent;
+                    const int ee[2] = {e0, ok1 ? e1 : e0};
+                    int a[2], xr[2];
+                    double pv[2], av[2], rv[2];
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) { a[r] = eat[ee[r]]; xr[r] = exr[ee[r]]; }
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) { pv[r] = Pf[a[r]]; av[r] = AtAf[a[r]]; rv[r] = x_reg[xr[r] > 0 ? xr[r] : 0]; }
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) {
+                        if (r == 1 && !ok1) break;
+                        double v = pv[r] + delta_inv * av[r] + 0.0;  // (+ s with an empty row sum s = 0.0, as assemble_flat adds it)
+                        if (xr[r] >= 0) v += rv[r];
+                        F[a[r]] = v;
+                    }
+                }
+            } else
             msdev::assemble_flat<NT>(PM, S.GG, at(B_XG), at(B_PF), at(B_ATAF), zinv, x_reg, delta_inv, F, g(S.ent_b), g(S.ent_rc), S.n_ent);
             __syncthreads();
             t1 = wall_clock64();
@@ -1662,6 +1687,17 @@ private:
             }
             S.n_ent = (int)eb.size();
             S.ent_b = up(ibufs_, eb); S.ent_rc = up(ibufs_, erc);
+            // the same entries as absolute front-arena offsets + the x_reg entry that lands on them (-1: none): what a QP without inequality rows needs of
+            // the assembly (no per-stage row loop), two loads instead of a chain through the stage tables
+            std::vector<int> eat(eb.size()), exr(eb.size());
+            bool fits = sym_.front_doubles < (1LL << 31);
+            for (size_t e = 0; e < eb.size(); ++e) {
+                const int b = eb[e], r = erc[e] & 0xffff, c = erc[e] >> 16;
+                eat[e] = (int)(sym_.front_off[b] + r + (long long)c * sym_.h[b]);
+                exr[e] = (r == c && c < sym_.w[b]) ? sym_.block_info[b].start + c : -1;
+            }
+            S.ent_at = up(ibufs_, eat); S.ent_xr = up(ibufs_, exr);
+            S.ent_flat = fits ? 1 : 0;
         }
         // chain workspace: front + carried update + inverse (factor) / 2 vectors + panel (solve)
         int max_u = 0;
