@@ -1747,7 +1747,8 @@ private:
                     if (chain && b + 1 == nst) chain = sym_.off[b] == 0;
                 }
                 int K = 0;
-                while (chain && K < nst && sym_.w[K] == W0 && sym_.off[K] <= W0) ++K;
+                while (chain && K < nst && sym_.w[K] == W0 && sym_.off[K] == sym_.off[0] && sym_.off[K] <= W0 && sym_.off[K] >= 1 &&
+                       sym_.qpan_off[K + 1] - sym_.qpan_off[K] == (long long)W0 * W0 + (long long)sym_.off[0] * W0) ++K;
                 const bool ok = chain && K >= 4;
                 if (debug_token("batch_chain_info"))
                     std::fprintf(stderr, "[piqp_amd] batch chain: %d stages, arrow %d, register-carried substitution for the first %d (w = %d)\n", nst, sym_.arrow, ok ? K : 0, W0);

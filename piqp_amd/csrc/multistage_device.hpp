@@ -527,32 +527,29 @@ __device__ __forceinline__ double dpp_row_shl(double v)
 template <int W, bool FWD, class Meta>
 __device__ __forceinline__ void solve_chain_wave_reg(const Meta& M, const double* __restrict__ pan, double* __restrict__ x, const int K, const int nst)
 {
+    // the K stages have ONE shape (W columns, u rows below them, checked at setup): stage b starts at s0 + b W and keeps its panel at p0 + b (W W + u W) --
+    // no table look-ups in the loops, the per-lane operand pointers just advance
     const int lane = threadIdx.x;
-    int mH = 0, mU = 0, mS = 0, mP = 0;  // lane b: order, rows below the pivots, first column and panel offset of stage b
-    if (lane < nst) { mH = M.H(lane); mU = M.Off(lane); mS = M.Start(lane); mP = (int)M.PanOff(lane); }
+    const int u = __builtin_amdgcn_readfirstlane(M.Off(0)), s0 = __builtin_amdgcn_readfirstlane(M.Start(0)), p0 = __builtin_amdgcn_readfirstlane((int)M.PanOff(0));
+    const int h = W + u, PS = W * W + u * W;
     const bool top = lane < W;
     if constexpr (FWD) {
-    // ---- forward: y_b = Linv_b x_b,  x_{b+1}[0 : u_b] -= Q_b x_b ----
-    auto coef_fwd = [&](int hb, int ub, int pb, double (&cf)[W]) {
-        const double* base = pan + pb + (top ? lane : W * W + (lane < hb ? lane - W : 0));
-        const int cs = top ? W : ub;
-#pragma unroll
-        for (int k = 0; k < W; ++k) cf[k] = base[k * cs];
-    };
-    {
-        int hb = __builtin_amdgcn_readlane(mH, 0), ub = __builtin_amdgcn_readlane(mU, 0), sb = __builtin_amdgcn_readlane(mS, 0), pb = __builtin_amdgcn_readlane(mP, 0);
+        // ---- forward: y_b = Linv_b x_b,  x_{b+1}[0 : u] -= Q_b x_b ----
+        const double* cfp = pan + p0 + (top ? lane : W * W + (lane < h ? lane - W : 0));
+        const int cs = top ? W : u;
+        double* xp = x + s0 + lane;
         double cf[W];
-        coef_fwd(hb, ub, pb, cf);
-        double cur = lane < hb ? x[sb + lane] : 0.0;
+#pragma unroll
+        for (int k = 0; k < W; ++k) cf[k] = cfp[k * cs];
+        double cur = lane < h ? xp[0] : 0.0;
         for (int b = 0; b < K; ++b) {
-            const bool more = b + 1 < nst;
-            const int bn = more ? b + 1 : b;
-            const int hn = __builtin_amdgcn_readlane(mH, bn), un = __builtin_amdgcn_readlane(mU, bn), sn = __builtin_amdgcn_readlane(mS, bn), pn = __builtin_amdgcn_readlane(mP, bn);
+            cfp += PS;
             double cfn[W];
             double fresh = 0.0;
-            if (more) {
-                coef_fwd(hn, un, pn, cfn);
-                if (lane >= ub && lane < hn) fresh = x[sn + lane];  // (entries no earlier stage has written: still the right-hand side)
+            if (b + 1 < K) {
+#pragma unroll
+                for (int k = 0; k < W; ++k) cfn[k] = cfp[k * cs];
+                if (lane >= u && lane < h) fresh = xp[W];  // (entries no earlier stage has written: still the right-hand side)
             }
             double xk[W];
 #pragma unroll
@@ -560,51 +557,46 @@ __device__ __forceinline__ void solve_chain_wave_reg(const Meta& M, const double
             double acc = top ? 0.0 : cur;
 #pragma unroll
             for (int k = 0; k < W; ++k) acc += (top ? cf[k] : -cf[k]) * xk[k];
-            if (top) x[sb + lane] = acc;  // y_b (read again by the backward sweep only)
+            if (top) xp[0] = acc;  // y_b (read again by the backward sweep only)
             const double down = dpp_row_shl<W>(acc);
-            cur = lane < ub ? down : fresh;
+            cur = lane < u ? down : fresh;
 #pragma unroll
             for (int k = 0; k < W; ++k) cf[k] = cfn[k];
-            if (b + 1 == K && more && lane < ub) x[sn + lane] = cur;  // hand-over: what stage K finds in x
-            hb = hn; ub = un; sb = sn; pb = pn;
+            xp += W;
         }
-    }
+        if (K < nst && lane < u) xp[0] = cur;  // hand-over: what stage K finds in x
     } else {
-    // ---- backward: x_b = Linv_b^T y_b - Q_b^T x_{b+1}[0 : u_b] ----
-    auto coef_bwd = [&](int sb, int pb, double (&lv)[W], double (&yv)[W]) {
-#pragma unroll
-        for (int k = 0; k < W; ++k) { lv[k] = pan[pb + k + (top ? lane : 0) * W]; yv[k] = x[sb + k]; }
-    };
-    {
-        int b = K - 1;
-        int ub = __builtin_amdgcn_readlane(mU, b), sb = __builtin_amdgcn_readlane(mS, b), pb = __builtin_amdgcn_readlane(mP, b);
+        // ---- backward: x_b = Linv_b^T y_b - Q_b^T x_{b+1}[0 : u] ----
+        const double* lp = pan + p0 + (K - 1) * PS + (top ? lane : 0) * W;  // Linv_b[k + lane W]
+        const double* qp = pan + p0 + (K - 1) * PS + W * W + (top ? lane : 0) * u;  // Q_b[t + lane u]
+        double* xb = x + s0 + (K - 1) * W;
         double lv[W], yv[W];
-        coef_bwd(sb, pb, lv, yv);
-        double sol = 0.0;  // lanes < u_b: the solution of the stage above, as far as this stage needs it
-        if (K < nst && lane < ub) sol = x[__builtin_amdgcn_readlane(mS, K) + lane];
-        for (; b >= 0; --b) {
-            const bool more = b > 0;
-            const int bn = more ? b - 1 : b;
-            const int un = __builtin_amdgcn_readlane(mU, bn), sn = __builtin_amdgcn_readlane(mS, bn), pn = __builtin_amdgcn_readlane(mP, bn);
+#pragma unroll
+        for (int k = 0; k < W; ++k) { lv[k] = lp[k]; yv[k] = xb[k]; }
+        double sol = 0.0;  // lanes < u: the solution of the stage above, as far as this stage needs it
+        if (K < nst && lane < u) sol = xb[W + lane];
+        for (int b = K - 1; b >= 0; --b) {
             double qv[WAVE_WMAX];
 #pragma unroll
-            for (int t = 0; t < WAVE_WMAX; ++t) qv[t] = t < ub ? pan[pb + W * W + t + (top ? lane : 0) * ub] : 0.0;
+            for (int t = 0; t < WAVE_WMAX; ++t) qv[t] = t < u ? qp[t] : 0.0;
             double lvn[W], yvn[W];
-            if (more) coef_bwd(sn, pn, lvn, yvn);
+            if (b > 0) {
+#pragma unroll
+                for (int k = 0; k < W; ++k) { lvn[k] = lp[k - PS]; yvn[k] = xb[k - W]; }
+            }
             double acc = 0.0;
 #pragma unroll
             for (int k = 0; k < W; ++k)
                 if (k >= lane) acc += lv[k] * yv[k];
 #pragma unroll
             for (int t = 0; t < WAVE_WMAX; ++t)
-                if (t < ub) acc -= qv[t] * lane_bcast(sol, t);
-            if (top) x[sb + lane] = acc;
+                if (t < u) acc -= qv[t] * lane_bcast(sol, t);
+            if (top) xb[lane] = acc;
             sol = acc;
 #pragma unroll
             for (int k = 0; k < W; ++k) { lv[k] = lvn[k]; yv[k] = yvn[k]; }
-            ub = un; sb = sn; pb = pn;
+            lp -= PS; qp -= PS; xb -= W;
         }
-    }
     }
 }
 
