@@ -306,7 +306,7 @@ struct Ipm {
             msdev::assemble_flat<NT>(PM, S.GG, at(B_XG), at(B_PF), at(B_ATAF), zinv, x_reg, delta_inv, F, g(S.ent_b), g(S.ent_rc), S.n_ent);
             __syncthreads();
             t1 = wall_clock64();
-            msdev::factor_chain_wave(PM, (msdev::global_cdouble*)F, dyn + S.res_pan);
+            msdev::factor_chain_wave(PM, (msdev::global_cdouble*)F, dyn + S.res_pan, S.chain_reg_w > 0 ? S.chain_reg_k : 0);
         } else {
             double* F = RES ? dyn + S.res_f : gen(at(B_F));
             double* PAN = RES ? dyn + S.res_pan : gen(at(B_PAN));
@@ -1748,7 +1748,8 @@ private:
                 }
                 int K = 0;
                 while (chain && K < nst && sym_.w[K] == W0 && sym_.off[K] == sym_.off[0] && sym_.off[K] <= W0 && sym_.off[K] >= 1 &&
-                       sym_.qpan_off[K + 1] - sym_.qpan_off[K] == (long long)W0 * W0 + (long long)sym_.off[0] * W0) ++K;
+                       sym_.qpan_off[K + 1] - sym_.qpan_off[K] == (long long)W0 * W0 + (long long)sym_.off[0] * W0 &&
+                       sym_.front_off[K + 1] - sym_.front_off[K] == (long long)sym_.h[0] * sym_.h[0] && sym_.h[K] == sym_.h[0]) ++K;
                 const bool ok = chain && K >= 4;
                 if (debug_token("batch_chain_info"))
                     std::fprintf(stderr, "[piqp_amd] batch chain: %d stages, arrow %d, register-carried substitution for the first %d (w = %d)\n", nst, sym_.arrow, ok ? K : 0, W0);

@@ -397,10 +397,15 @@ __device__ __forceinline__ void factor_stage_wave(double& f, const int h, const 
 
 // fronts_g: assembled fronts in HBM; pan: LDS, per stage Linv (w x w) then Q (u x w) at PanOff(b)
 template <class Meta>
-__device__ __forceinline__ void factor_chain_wave(const Meta& M, global_cdouble* fronts_g, double* __restrict__ pan)
+__device__ __forceinline__ void factor_chain_wave(const Meta& M, global_cdouble* fronts_g, double* __restrict__ pan, const int reg_k = 0)
 {
+    // reg_k > 0: the stages 0 .. reg_k - 1 have ONE shape and follow each other without gaps (the run the register-carried substitution uses, checked at
+    // setup): their widths and offsets are affine in the stage number and are not looked up in the table (five LDS reads + waits per stage)
     const int lane = threadIdx.x;
     const int N = M.N;
+    const int rw = reg_k > 0 ? __builtin_amdgcn_readfirstlane(M.W(0)) : 0, ro = reg_k > 0 ? __builtin_amdgcn_readfirstlane(M.Off(0)) : 0;
+    const int rh = rw + ro;
+    const long long rf0 = reg_k > 0 ? uni(M.FrontOff(0)) : 0, rp0 = reg_k > 0 ? uni(M.PanOff(0)) : 0;
     int h = __builtin_amdgcn_readfirstlane(M.H(0));
     double nxt = lane < h * h ? fronts_g[uni(M.FrontOff(0)) + lane] : 0.0;
     int r = lane % h, c = lane / h;  // lane -> (row, col) of the current front; recomputed only when h changes
@@ -412,9 +417,10 @@ __device__ __forceinline__ void factor_chain_wave(const Meta& M, global_cdouble*
     bool c_has = false;
     for (int b = 0; b < N; ++b) {
         if (h == 0) break;  // no arrow corner
-        const int w = __builtin_amdgcn_readfirstlane(M.W(b));
+        const bool affine = b < reg_k;
+        const int w = affine ? rw : __builtin_amdgcn_readfirstlane(M.W(b));
         const bool corner = b == N - 1;
-        const int offb = __builtin_amdgcn_readfirstlane(M.Off(b));
+        const int offb = affine ? ro : __builtin_amdgcn_readfirstlane(M.Off(b));
         const int u = h - w;
         // ---- carried update: new entry (r, c) <- old trailing entry (i, j) ----
         double carried = 0.0;
@@ -442,9 +448,10 @@ __device__ __forceinline__ void factor_chain_wave(const Meta& M, global_cdouble*
             carried = c_has ? got : 0.0;
         }
         f = nxt + carried;
-        const int hn = b + 1 < N ? __builtin_amdgcn_readfirstlane(M.H(b + 1)) : 0;
-        if (hn > 0) nxt = lane < hn * hn ? fronts_g[uni(M.FrontOff(b + 1)) + lane] : 0.0;  // prefetch, consumed next iteration
-        double* P = pan + uni(M.PanOff(b));
+        const bool affine_n = b + 1 < reg_k;
+        const int hn = affine_n ? rh : (b + 1 < N ? __builtin_amdgcn_readfirstlane(M.H(b + 1)) : 0);
+        if (hn > 0) nxt = lane < hn * hn ? fronts_g[(affine_n ? rf0 + (long long)(b + 1) * (rh * rh) : uni(M.FrontOff(b + 1))) + lane] : 0.0;  // prefetch, consumed next iteration
+        double* P = pan + (affine ? rp0 + (long long)b * (rw * rw + ro * rw) : uni(M.PanOff(b)));
         switch (w) {
         case 1: factor_stage_wave<1>(f, h, u, lane, r, c, P); break;
         case 2: factor_stage_wave<2>(f, h, u, lane, r, c, P); break;
