@@ -20,6 +20,7 @@
 #include <memory>
 #include <stdexcept>
 #include <thread>
+#include <type_traits>
 
 #include "multistage_device.hpp"
 #include "multistage_symbolic.hpp"
@@ -84,10 +85,29 @@ struct OpMax { __device__ double operator()(double a, double b) const { return a
 struct OpMin { __device__ double operator()(double a, double b) const { return b < a ? b : a; } };            // std::min
 struct OpAbsMaxNan { __device__ double operator()(double r, double a) const { return (a > r || a != a) ? a : r; } };  // Eigen lpNorm<Infinity>: NaN propagates
 
+// value of `v` in the lane the DPP control selects (quad_perm / row_half_mirror / row_mirror: all lanes have a source)
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
 template <int NT, class Op>
 __device__ __forceinline__ double wg_reduce(double v, Op op, double* red)
 {
-    for (int o = 32; o > 0; o >>= 1) v = op(v, __shfl_xor(v, o));
+    if constexpr (std::is_same<Op, OpSum>::value) {
+        // a sum depends on its order: the xor butterfly the parity tests were pinned with (six cross-lane permutes through the LDS crossbar)
+        for (int o = 32; o > 0; o >>= 1) v = op(v, __shfl_xor(v, o));
+    } else {
+        // maxima and minima do not: four DPP steps inside each row of 16 lanes, then the four rows through v_readlane -- ~150 cycles instead of ~800
+        v = op(v, dpp_move<0xb1>(v));   // quad_perm [1, 0, 3, 2]
+        v = op(v, dpp_move<0x4e>(v));   // quad_perm [2, 3, 0, 1]
+        v = op(v, dpp_move<0x141>(v));  // row_half_mirror
+        v = op(v, dpp_move<0x140>(v));  // row_mirror
+        auto row = [&](int l) { return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l)); };
+        v = op(op(op(row(0), row(16)), row(32)), row(48));
+    }
     if constexpr (NT > 64) {
         __syncthreads();
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
