@@ -109,13 +109,17 @@ __device__ __forceinline__ void load_tile(const double* __restrict__ M, int ld, 
 #pragma unroll
     for (int it = 0; it < 1024 / NT; ++it) {
         const int k = k0 + it * (NT / 64) + (tid >> 6);
+        // (explicit global address space: inside the out-of-line roles of k_chol_persistent the operand pointer comes out of a struct in memory and is a
+        // GENERIC pointer to the compiler -- FLAT loads, which also count on the LDS counter, so the first LDS reads of the K loop waited for every operand
+        // stage still in flight)
+        const __attribute__((address_space(1))) double* Mg = (const __attribute__((address_space(1))) double*)M;
         if (!CHECK) {
-            v[it] = *reinterpret_cast<const d2*>(M + r + (size_t)k * ld);
+            v[it] = *reinterpret_cast<const __attribute__((address_space(1))) d2*>(Mg + r + (size_t)k * ld);
         } else {
             d2 t = {0.0, 0.0};
             if (k < kdim) {
-                if (r < nrows) t.x = M[r + (size_t)k * ld];
-                if (r + 1 < nrows) t.y = M[r + 1 + (size_t)k * ld];
+                if (r < nrows) t.x = Mg[r + (size_t)k * ld];
+                if (r + 1 < nrows) t.y = Mg[r + 1 + (size_t)k * ld];
             }
             v[it] = t;
         }
@@ -154,7 +158,7 @@ __device__ __forceinline__ void scale_tile(const double* __restrict__ w, int k0,
 #pragma unroll
     for (int it = 0; it < 1024 / NT; ++it) {
         const int k = k0 + it * (NT / 64) + (tid >> 6);
-        double s = w ? ((!CHECK || k < kdim) ? (AGENT ? ld_agent(w + k) : w[k]) : 0.0) : 1.0;
+        double s = w ? ((!CHECK || k < kdim) ? (AGENT ? ld_agent(w + k) : ((const __attribute__((address_space(1))) double*)w)[k]) : 0.0) : 1.0;
         if (NEG) s = -s;
         v[it].x *= s;
         v[it].y *= s;
@@ -484,11 +488,11 @@ __device__ __forceinline__ void syrk_lower_body(const SyrkArgs& a, const int blo
                         double base = a.Pfull[(size_t)gi + (size_t)gj * a.ldp];
                         if (gi == gj) base += a.x_reg[gi];
                         if (a.ATA) base += a.dinv * a.ATA[(size_t)gi + (size_t)gj * a.ldata];
-                        a.C[ci] = base + v;
+                        ((__attribute__((address_space(1))) double*)a.C)[ci] = base + v;
                     } else if (EPI == EPI_SUBTRACT) {
-                        a.C[ci] -= v;
+                        ((__attribute__((address_space(1))) double*)a.C)[ci] -= v;  // (explicit global address space: the front kernels build their arguments from a job record in memory)
                     } else {
-                        a.C[ci] = v;
+                        ((__attribute__((address_space(1))) double*)a.C)[ci] = v;
                     }
                 }
             }
@@ -1599,12 +1603,12 @@ __device__ __forceinline__ bool chol_wait3(const int* p0, int w0, const int* p1,
         for (int q = 0; q < 3 && ok; ++q) {
             if (!ps[q]) continue;
             unsigned spins = 0;
-            while (__hip_atomic_load(ps[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - ws[q] < 0) {
+            while (ldi_agent(ps[q]) - ws[q] < 0) {
                 __builtin_amdgcn_s_sleep(4);
                 if (sleep) __builtin_amdgcn_s_sleep(12);
                 ++spins;
-                if ((spins & 255u) == 0 && __hip_atomic_load(abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { ok = 0; break; }
-                if (spins > 8000000u) { ok = 0; __hip_atomic_store(abort_w, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                if ((spins & 255u) == 0 && ldi_agent(abort_w) != 0) { ok = 0; break; }
+                if (spins > 8000000u) { ok = 0; sti_agent(abort_w, 1); break; }
             }
         }
         ok_s = ok;
@@ -1920,13 +1924,18 @@ constexpr int TRSM_LDS_BYTES = PACK_BLOCKS * 256 * (int)sizeof(double);
 // quasi-definite (pivots of +rho and -delta next to O(1) entries: unit-lower-triangular pieces with entries of 1e10), where the product with the
 // inverse cost an order of magnitude of KKT residual on the last interior-point states of CONT-201 (tools/dbg_sparse_accuracy.py).
 template <bool LDLT, bool SUBST = false>
-__device__ __forceinline__ void trsm_panel_body(double* __restrict__ A, int lda, int k0, int nb, int n, const double* __restrict__ pack, const double* __restrict__ rdiag, const int block_x)
+__device__ __forceinline__ void trsm_panel_body(double* __restrict__ A_, int lda, int k0, int nb, int n, const double* __restrict__ pack_, const double* __restrict__ rdiag_, const int block_x)
 {
+    // (explicit global address space: the front kernels pass pointers read from a job record in memory -- generic pointers, FLAT accesses otherwise)
+    typedef __attribute__((address_space(1))) double gd;
+    gd* A = (gd*)A_;
+    const gd* pack = (const gd*)pack_;
+    const gd* rdiag = (const gd*)rdiag_;
     extern __shared__ __attribute__((aligned(16))) double Ps[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, g = lane >> 4;
     {
-        const d2* src = reinterpret_cast<const d2*>(pack);
+        const __attribute__((address_space(1))) d2* src = reinterpret_cast<const __attribute__((address_space(1))) d2*>(pack);
         d2* dst = reinterpret_cast<d2*>(Ps);
         d2 v[PACK_BLOCKS * 128 / 256];
 #pragma unroll
@@ -1936,7 +1945,7 @@ __device__ __forceinline__ void trsm_panel_body(double* __restrict__ A, int lda,
     }
     const int row = k0 + nb + block_x * TRSM_ROWS + wave * 16 + i;
     const bool row_ok = row < n;
-    double* Ar = A + (row_ok ? row : 0) + (size_t)k0 * lda;
+    gd* Ar = A + (row_ok ? row : 0) + (size_t)k0 * lda;
     d4 T[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j)
