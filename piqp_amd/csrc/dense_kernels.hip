@@ -1956,20 +1956,27 @@ __device__ __forceinline__ void trsm_panel_body(double* __restrict__ A_, int lda
             const double t = Ar[ok ? (size_t)c * lda : 0];
             T[j][r] = ok ? t : 0.0;
         }
+    // SUBST: the eight factored diagonal pieces come from the front itself (strictly lower parts; beyond nb: nothing to solve) -- all requested here,
+    // before the steps: loaded inside the step loop (behind its early exit) each piece was a memory round trip in front of its 15 dependent products
+    d4 lkk_all[SUBST ? 8 : 1];
+    if constexpr (SUBST) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rr = 16 * k + i, cc = 16 * k + g + 4 * r;
+                const bool ok = rr < nb && cc < nb && rr > cc;
+                const double t = A[ok ? (size_t)(k0 + rr) + (size_t)(k0 + cc) * lda : 0];
+                lkk_all[k][r] = ok ? t : 0.0;
+            }
+    }
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         if (SUBST && 16 * k >= nb) break;  // (padding beyond a short panel: nothing to solve, nothing stored)
         d4 x = {0.0, 0.0, 0.0, 0.0};
         if constexpr (SUBST) {
-            d4 lkk;  // the factored diagonal piece from the front itself (strictly lower part used; beyond nb: nothing to solve)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int rr = 16 * k + i, cc = 16 * k + g + 4 * r;
-                const bool ok = rr < nb && cc < nb && rr > cc;
-                const double t = A[ok ? (size_t)(k0 + rr) + (size_t)(k0 + cc) * lda : 0];
-                lkk[r] = ok ? t : 0.0;
-            }
+            const d4 lkk = lkk_all[k];
             x = T[k];
             const d4 one = {1.0, 1.0, 1.0, 1.0};
             tile_trsm_rt<LDLT, false>(x, lkk, one, lane);
