@@ -448,7 +448,26 @@ def batched_qp(args, rank, world, local_rank, dev, pd):
     if rank == 0:
         tot_solved = sum(r[0] for r in rows); tot_it = sum(r[1] for r in rows)
         res["strong"] = {"qps_total": total, "qp_per_s": total / el, "ms": el * 1e3, "solved": int(tot_solved), "iters_mean": tot_it / total,
-                         "kernel_ms_rank0": bs.last_kernel_ms()[0], "threads_per_qp": bs.last_kernel_ms()[1]}
+                         "kernel_ms_rank0": bs.last_kernel_ms()[0], "threads_per_qp": bs.last_kernel_ms()[1],
+                         "start_order": "longest first by the PREVIOUS solve's iteration counts (the library's default; the timed solves follow a warm-up solve of the same "
+                                        "batch, as a receding-horizon controller re-solves its batch): see ms_index_order for the same batch started in index order"}
+    # the same batch with the start order switched off (what the first solve of a fresh batch gets)
+    try:
+        bs.set_start_order(False)
+        bs.solve()
+        pd.barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            bs.solve()
+        torch.cuda.synchronize(); pd.barrier()
+        el_idx = pd.max_over_ranks((time.perf_counter() - t0) / 3, device=dev if world > 1 else None)
+        bs.set_start_order(True)
+        if rank == 0:
+            res["strong"]["ms_index_order"] = el_idx * 1e3
+            res["strong"]["qp_per_s_index_order"] = total / el_idx
+    except Exception as e:  # noqa: BLE001
+        if rank == 0:
+            res["strong"]["index_order_error"] = f"{type(e).__name__}: {e}"
     if world > 1:
         bsw, solved_w, el_w = run(full)
         rows = pd.gather_stats([[float(solved_w)]], device=dev)

@@ -367,6 +367,10 @@ int pq_batch_block_info(const pq_batch *s, int *out_host, int capacity); /* as p
 int pq_batch_get_profile(pq_batch *s, int instance, double *out8);
 /* hipEvent time of the last solve's kernel and the workgroup size used per QP */
 int pq_batch_last_kernel_ms(const pq_batch *s, double *ms, int *threads_per_qp);
+/* start order of the instances inside the launch: 1 (default) = the instances that needed most iterations in the PREVIOUS solve of this handle start first
+ * (receding-horizon batches repeat their counts; a batch larger than the device holds at once then ends earlier), 0 = always in index order.  Results do not
+ * depend on it. */
+int pq_batch_set_start_order(pq_batch *s, int longest_first);
 
 /* ===================== small utilities used by the measurement harness ===================== */
 /* fp64 MFMA / HBM micro-benchmarks on `device` (used once by bench.py to report measured peaks) */

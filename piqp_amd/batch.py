@@ -114,6 +114,10 @@ class BatchSparseSolver(_Handle):
         check(self.L.pq_batch_get_profile(self.h, i, out.ctypes.data))
         return dict(zip(("assemble", "factor", "chain_solve", "kkt_solve", "residuals", "total"), out[:6]))
 
+    def set_start_order(self, longest_first=True):
+        """True (default): the instances that needed most iterations in the previous solve start first in the next launch; False: index order"""
+        check(self.L.pq_batch_set_start_order(self.h, 1 if longest_first else 0), "pq_batch_set_start_order")
+
     def last_kernel_ms(self):
         ms, nt = C.c_double(), C.c_int()
         check(self.L.pq_batch_last_kernel_ms(self.h, C.byref(ms), C.byref(nt)))

@@ -211,3 +211,17 @@ def test_batch_update_matrices_equals_single_qp_update(hip, reuse):
     assert bs0.setup(mb["P_pattern"], mb["P_values"], mb["c"], mb["A_pattern"], mb["A_values"], mb["b"], x_l=mb["x_l"], x_u=mb["x_u"])
     assert bs0.solve() == B
     assert np.abs(bs0.result("x") - x).max() > 1e-3
+
+
+def test_start_order_does_not_change_results(hip):
+    """pq_batch_set_start_order: the second solve of a handle starts the instances that took longest first; every instance's result is what it is in index order"""
+    B = 300
+    mb = mpc_batch(B, seed=555)
+    bs, solved = _run_batch(hip, mb)
+    assert solved == B
+    x1, it1 = bs.result("x").copy(), np.asarray(bs.iterations()).copy()
+    assert bs.solve() == B  # started longest first
+    assert np.array_equal(bs.result("x"), x1) and np.array_equal(np.asarray(bs.iterations()), it1)
+    bs.set_start_order(False)
+    assert bs.solve() == B  # index order again
+    assert np.array_equal(bs.result("x"), x1) and np.array_equal(np.asarray(bs.iterations()), it1)
