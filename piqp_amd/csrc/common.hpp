@@ -60,12 +60,15 @@ inline void stream_wait(hipStream_t s)
         clock_gettime(CLOCK_MONOTONIC, &t0);
         for (unsigned it = 0;; ++it) {
             const hipError_t e = hipStreamQuery(s);
-            if (e == hipSuccess) return;
+            if (e == hipSuccess) {
+                if (it > 0) (void)hipGetLastError();  // (the "not ready" answers of the polls before must not look like the error of a later launch check)
+                return;
+            }
             if (e != hipErrorNotReady) throw ::pq::HipError{e, "hipStreamQuery", __FILE__, __LINE__};
             if ((it & 15u) == 15u) {
                 timespec t1;
                 clock_gettime(CLOCK_MONOTONIC, &t1);
-                if ((t1.tv_sec - t0.tv_sec) * 1000000000LL + (t1.tv_nsec - t0.tv_nsec) > 2000000LL) break;
+                if ((t1.tv_sec - t0.tv_sec) * 1000000000LL + (t1.tv_nsec - t0.tv_nsec) > 2000000LL) { (void)hipGetLastError(); break; }
             }
         }
     }
