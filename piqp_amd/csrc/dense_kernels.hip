@@ -197,7 +197,10 @@ constexpr int FUSED_LDS_BYTES = (128 * (128 + 16) + 128) * 8;  // whole operand 
 // workgroup (28 + 13 us for a whole tile) bound the round from below whatever the diagonal block does; two workgroups per row halve both.  Every element
 // receives the same products in the same order as in the whole-tile form.
 __device__ __forceinline__ bool chol_wait3(const int* p0, int w0, const int* p1, int w1, const int* p2, int w2, int* abort_w, int sleep);
-template <int NT, bool PERSIST, bool HALF = false>
+// SUMSUB (the trailing updates of the sparse fronts, launch_front_updates): the products are summed from zero and subtracted from C at the end, the arithmetic of
+// k_syrk_lower<EPI_SUBTRACT> -- the quasi-definite fronts lose accuracy when the accumulators start from C -- with this function's
+// operand staging (every stage requested at once) and, with HALF, two workgroups per tile.
+template <int NT, bool PERSIST, bool HALF = false, bool SUMSUB = false>
 __device__ __forceinline__ bool fused_tile(const SyrkArgs& a, const int ti, const int tj, double* __restrict__ smem, const int h = 0)
 {
     constexpr int WR = HALF ? 2 : 4, WC = HALF ? 4 : 2;
@@ -216,6 +219,7 @@ __device__ __forceinline__ bool fused_tile(const SyrkArgs& a, const int ti, cons
     for (int x = 0; x < MTC; ++x)
 #pragma unroll
         for (int y = 0; y < MTR; ++y) acc[x][y] = (d4){0.0, 0.0, 0.0, 0.0};
+    d4 cfetch[SUMSUB ? MTC : 1][SUMSUB ? MTR : 1];  // SUMSUB: C waits here for the sum
     if (!skip_wave) {
         // C is fetched BEFORE the K loop (its latency hides behind the first operand stages) instead of read-modify-written after it
 #pragma unroll
@@ -229,7 +233,8 @@ __device__ __forceinline__ bool fused_tile(const SyrkArgs& a, const int ti, cons
                     const bool ok = gi < a.n && gj < a.n && gi >= gj;
                     const double* cp = a.C + (ok ? (size_t)gi + (size_t)gj * a.ldc : 0);
                     const double cv = PERSIST ? ld_agent(cp) : *cp;
-                    acc[x][y][r] = ok ? cv : 0.0;
+                    if constexpr (SUMSUB) cfetch[x][y][r] = ok ? cv : 0.0;
+                    else acc[x][y][r] = ok ? cv : 0.0;
                 }
             }
     }
@@ -254,9 +259,10 @@ __device__ __forceinline__ bool fused_tile(const SyrkArgs& a, const int ti, cons
                 const int k0 = kt * BK;
                 if constexpr (HALF) {
                     // 64 rows of the row operand (the upper half of the stage stays unused), the whole column operand
-                    if ((tid & 63) < 32) load_tile<false, NT>(a.A, a.lda, row0, k0, a.n, a.kdim, tid, pa[kt]);
+                    const bool chk = !PERSIST && (edge || (k0 + BK > a.kdim));
+                    if ((tid & 63) < 32) { if (chk) load_tile<true, NT>(a.A, a.lda, row0, k0, a.n, a.kdim, tid, pa[kt]); else load_tile<false, NT>(a.A, a.lda, row0, k0, a.n, a.kdim, tid, pa[kt]); }
                     else { for (int it = 0; it < PER; ++it) pa[kt][it] = (d2){0.0, 0.0}; }
-                    load_tile<false, NT>(a.B, a.ldb, col0, k0, a.n, a.kdim, tid, pb[kt]);
+                    if (chk) load_tile<true, NT>(a.B, a.ldb, col0, k0, a.n, a.kdim, tid, pb[kt]); else load_tile<false, NT>(a.B, a.ldb, col0, k0, a.n, a.kdim, tid, pb[kt]);
                 } else if constexpr (PERSIST && AGENT_OPERANDS) {
                     load_tile_agent<NT>(a.A, a.lda, row0, k0, tid, pa[kt]); load_tile_agent<NT>(a.B, a.ldb, col0, k0, tid, pb[kt]);
                 } else {
@@ -281,7 +287,7 @@ __device__ __forceinline__ bool fused_tile(const SyrkArgs& a, const int ti, cons
                 for (int q = 0; q < GRP; ++q) {
                     const int kt = g0 + q;
                     if (kt < nkt) {
-                        scale_tile<true, NT, true, PERSIST>(a.w, kt * BK, a.kdim, tid, pb[kt]);
+                        scale_tile<true, NT, !SUMSUB, PERSIST>(a.w, kt * BK, a.kdim, tid, pb[kt]);
                         store_tile<NT>(A4 + q * BK * LDS_LD, tid, pa[kt]);
                         store_tile<NT>(B4 + q * BK * LDS_LD, tid, pb[kt]);
                     }
@@ -337,6 +343,7 @@ __device__ __forceinline__ bool fused_tile(const SyrkArgs& a, const int ti, cons
                 if (gi < a.n && gj < a.n && gi >= gj) {
                     double* cp = a.C + (size_t)gi + (size_t)gj * a.ldc;
                     if (PERSIST) st_agent(cp, acc[x][y][r]);
+                    else if constexpr (SUMSUB) *(__attribute__((address_space(1))) double*)cp = cfetch[x][y][r] - acc[x][y][r];
                     else *cp = acc[x][y][r];
                 }
             }
@@ -531,6 +538,32 @@ __global__ __launch_bounds__(64 * WR * WC, (WR * WC == 4) ? 2 : (WR * WC == 8 ? 
     a.C = j.F + (k + nb) + (size_t)(k + nb) * j.f; a.ldc = j.f;
     a.unaligned = ((j.f & 1) || (reinterpret_cast<uintptr_t>(a.A) & 15)) ? 1 : 0;
     syrk_lower_body<EPI_SUBTRACT, WR, WC>(a, (int)blockIdx.x);
+}
+
+// The same update for the levels near the root of an assembly tree, where a handful of tiles is all there is and 250 CUs idle: two workgroups per tile (rows
+// [64 h, 64 h + 64)), every operand stage requested at once (fused_tile<HALF, SUMSUB>): a 128 x 128 x 128 tile is 13.6 us of matrix-core work on ONE CU whatever
+// the wave shape, and the generic kernel adds a load -> LDS -> barrier round trip per 16-column stage (30 us per launch measured at the top of CONT-201).
+// Same products in the same order, summed from zero and subtracted from C: bitwise the tile of k_syrk_lower_fronts.
+__global__ __launch_bounds__(512) void k_syrk_half_fronts(const FrontJob* __restrict__ jobs, int panel)
+{
+    const FrontJob j = jobs[blockIdx.y];
+    int k, nb, rs;
+    if (!front_panel(j, panel, k, nb, rs) || rs <= 0) return;
+    const int T = (rs + TS - 1) / TS;
+    const int b = (int)blockIdx.x >> 1, h = (int)blockIdx.x & 1;
+    if (b >= T * (T + 1) / 2) return;
+    int ti = (int)((sqrt(8.0 * (double)b + 1.0) - 1.0) * 0.5);
+    while ((ti + 1) * (ti + 2) / 2 <= b) ++ti;
+    while (ti * (ti + 1) / 2 > b) --ti;
+    const int tj = b - ti * (ti + 1) / 2;
+    if (ti * TS + 64 * h >= rs) return;  // (nothing in this half)
+    SyrkArgs a;
+    a.n = rs; a.kdim = nb;
+    a.A = j.F + (k + nb) + (size_t)k * j.f; a.lda = j.f; a.B = a.A; a.ldb = j.f; a.w = j.dvec;
+    a.C = j.F + (k + nb) + (size_t)(k + nb) * j.f; a.ldc = j.f;
+    a.unaligned = ((j.f & 1) || (reinterpret_cast<uintptr_t>(a.A) & 15)) ? 1 : 0;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    (void)fused_tile<512, false, true, true>(a, ti, tj, smem, h);
 }
 
 // sums the K-slices of a split tile in slice order and applies the epilogue (one workgroup per tile)
@@ -2030,6 +2063,7 @@ static void front_attrs()
     PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_diag_fronts), hipFuncAttributeMaxDynamicSharedMemorySize, POTRF_LDS_BYTES));
     PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_trsm_panel_fronts), hipFuncAttributeMaxDynamicSharedMemorySize, TRSM_LDS_BYTES));
     PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk_lower_fronts<4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, SYRK_LDS_BYTES));
+    PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk_half_fronts), hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS_BYTES));
     attr_set = true;
 }
 void launch_front_diag_panels(const FrontJob* jobs, int njobs, int panel, int max_rows_below, int* info, double* rdiag, hipStream_t s)
@@ -2045,6 +2079,12 @@ void launch_front_updates(const FrontJob* jobs, int njobs, int panel, int max_ro
     if (njobs <= 0 || max_rows_below <= 0) return;
     front_attrs();
     const int T = div_up(max_rows_below, TS);
+    static const bool no_half = debug_token("front_updates_whole_tiles") != nullptr;
+    if (!no_half && (long long)njobs * T * (T + 1) <= 256) {  // few tiles (the top of the tree): two workgroups per tile, every workgroup on its own CU
+        hipLaunchKernelGGL(k_syrk_half_fronts, dim3(T * (T + 1), njobs), dim3(512), FUSED_LDS_BYTES, s, jobs, panel);
+        PQ_HIP(hipGetLastError());
+        return;
+    }
     hipLaunchKernelGGL((k_syrk_lower_fronts<4, 4>), dim3(T * (T + 1) / 2, njobs), dim3(1024), SYRK_LDS_BYTES, s, jobs, panel);
     PQ_HIP(hipGetLastError());
 }
