@@ -200,19 +200,22 @@ __device__ __forceinline__ bool chol_wait3(const int* p0, int w0, const int* p1,
 // SUMSUB (the trailing updates of the sparse fronts, launch_front_updates): the products are summed from zero and subtracted from C at the end, the arithmetic of
 // k_syrk_lower<EPI_SUBTRACT> -- the quasi-definite fronts lose accuracy when the accumulators start from C -- with this function's
 // operand staging (every stage requested at once) and, with HALF, two workgroups per tile.
-template <int NT, bool PERSIST, bool HALF = false, bool SUMSUB = false>
+// QUARTER (with HALF, front updates only): rows [32 h, 32 h + 32), the waves as 1 x 8 (32 x 16 each) -- four workgroups per tile where even halves leave the chip empty.
+template <int NT, bool PERSIST, bool HALF = false, bool SUMSUB = false, bool QUARTER = false>
 __device__ __forceinline__ bool fused_tile(const SyrkArgs& a, const int ti, const int tj, double* __restrict__ smem, const int h = 0)
 {
-    constexpr int WR = HALF ? 2 : 4, WC = HALF ? 4 : 2;
+    static_assert(!QUARTER || HALF, "QUARTER refines HALF");
+    constexpr int SPLIT = QUARTER ? 4 : (HALF ? 2 : 1);
+    constexpr int WR = 4 / SPLIT, WC = 8 / WR;
     static_assert(NT == 64 * WR * WC, "eight waves");
-    constexpr int MTR = 2, MTC = HALF ? 2 : 4;
-    constexpr int SUBR = 32, SUBC = HALF ? 32 : 64;
-    constexpr int ROWS = HALF ? 64 : TS;  // rows of the tile this workgroup works on
-    const int row0 = ti * TS + (HALF ? 64 * h : 0), col0 = tj * TS;
+    constexpr int SUBR = 32, SUBC = TS / WC;
+    constexpr int MTR = 2, MTC = SUBC / 16;
+    constexpr int ROWS = TS / SPLIT;  // rows of the tile this workgroup works on
+    const int row0 = ti * TS + (HALF ? ROWS * h : 0), col0 = tj * TS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave / WC, wc = wave % WC;
     const bool edge = !PERSIST && ((row0 + TS > a.n) || (col0 + TS > a.n) || a.unaligned);
-    const bool skip_wave = (ti == tj) && ((HALF ? 64 * h : 0) + (wr + 1) * SUBR <= wc * SUBC);  // sub-tile strictly above the diagonal
+    const bool skip_wave = (ti == tj) && ((HALF ? ROWS * h : 0) + (wr + 1) * SUBR <= wc * SUBC);  // sub-tile strictly above the diagonal
 
     d4 acc[MTC][MTR];
 #pragma unroll
@@ -258,9 +261,9 @@ __device__ __forceinline__ bool fused_tile(const SyrkArgs& a, const int ti, cons
             if (kt < nkt) {
                 const int k0 = kt * BK;
                 if constexpr (HALF) {
-                    // 64 rows of the row operand (the upper half of the stage stays unused), the whole column operand
+                    // ROWS rows of the row operand (the rest of the stage stays unused), the whole column operand
                     const bool chk = !PERSIST && (edge || (k0 + BK > a.kdim));
-                    if ((tid & 63) < 32) { if (chk) load_tile<true, NT>(a.A, a.lda, row0, k0, a.n, a.kdim, tid, pa[kt]); else load_tile<false, NT>(a.A, a.lda, row0, k0, a.n, a.kdim, tid, pa[kt]); }
+                    if ((tid & 63) < ROWS / 2) { if (chk) load_tile<true, NT>(a.A, a.lda, row0, k0, a.n, a.kdim, tid, pa[kt]); else load_tile<false, NT>(a.A, a.lda, row0, k0, a.n, a.kdim, tid, pa[kt]); }
                     else { for (int it = 0; it < PER; ++it) pa[kt][it] = (d2){0.0, 0.0}; }
                     if (chk) load_tile<true, NT>(a.B, a.ldb, col0, k0, a.n, a.kdim, tid, pb[kt]); else load_tile<false, NT>(a.B, a.ldb, col0, k0, a.n, a.kdim, tid, pb[kt]);
                 } else if constexpr (PERSIST && AGENT_OPERANDS) {
@@ -329,7 +332,9 @@ __device__ __forceinline__ bool fused_tile(const SyrkArgs& a, const int ti, cons
     if (dbg_tile) a.fuse_ts[86] = clock64();  // K loop done (the accumulators' first use waited for C)
     if (tr_tile) a.fuse_tr2[42] = wall_clock64();
     if (tr_row) a.fuse_tr2[51] = wall_clock64();
-    if (a.fuse_cnt && tj == 0 && a.fuse_pack) return panel_follow<NT, MTC, MTR, PERSIST, ROWS / 16>(a, smem, acc, row0, wr, wc, ti == 1);
+    if constexpr (!QUARTER) {
+        if (a.fuse_cnt && tj == 0 && a.fuse_pack) return panel_follow<NT, MTC, MTR, PERSIST, ROWS / 16>(a, smem, acc, row0, wr, wc, ti == 1);
+    }
     if (skip_wave) return true;
     // epilogue: lane holds rows gi (consecutive over lane&15) and columns gj = base + (lane>>4) + 4*r; the accumulator started from C
 #pragma unroll
@@ -544,26 +549,27 @@ __global__ __launch_bounds__(64 * WR * WC, (WR * WC == 4) ? 2 : (WR * WC == 8 ? 
 // [64 h, 64 h + 64)), every operand stage requested at once (fused_tile<HALF, SUMSUB>): a 128 x 128 x 128 tile is 13.6 us of matrix-core work on ONE CU whatever
 // the wave shape, and the generic kernel adds a load -> LDS -> barrier round trip per 16-column stage (30 us per launch measured at the top of CONT-201).
 // Same products in the same order, summed from zero and subtracted from C: bitwise the tile of k_syrk_lower_fronts.
+template <int SPLIT>
 __global__ __launch_bounds__(512) void k_syrk_half_fronts(const FrontJob* __restrict__ jobs, int panel)
 {
     const FrontJob j = jobs[blockIdx.y];
     int k, nb, rs;
     if (!front_panel(j, panel, k, nb, rs) || rs <= 0) return;
     const int T = (rs + TS - 1) / TS;
-    const int b = (int)blockIdx.x >> 1, h = (int)blockIdx.x & 1;
+    const int b = (int)blockIdx.x / SPLIT, h = (int)blockIdx.x % SPLIT;
     if (b >= T * (T + 1) / 2) return;
     int ti = (int)((sqrt(8.0 * (double)b + 1.0) - 1.0) * 0.5);
     while ((ti + 1) * (ti + 2) / 2 <= b) ++ti;
     while (ti * (ti + 1) / 2 > b) --ti;
     const int tj = b - ti * (ti + 1) / 2;
-    if (ti * TS + 64 * h >= rs) return;  // (nothing in this half)
+    if (ti * TS + (TS / SPLIT) * h >= rs) return;  // (nothing in this part)
     SyrkArgs a;
     a.n = rs; a.kdim = nb;
     a.A = j.F + (k + nb) + (size_t)k * j.f; a.lda = j.f; a.B = a.A; a.ldb = j.f; a.w = j.dvec;
     a.C = j.F + (k + nb) + (size_t)(k + nb) * j.f; a.ldc = j.f;
     a.unaligned = ((j.f & 1) || (reinterpret_cast<uintptr_t>(a.A) & 15)) ? 1 : 0;
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    (void)fused_tile<512, false, true, true>(a, ti, tj, smem, h);
+    (void)fused_tile<512, false, true, true, SPLIT == 4>(a, ti, tj, smem, h);
 }
 
 // sums the K-slices of a split tile in slice order and applies the epilogue (one workgroup per tile)
@@ -2063,7 +2069,8 @@ static void front_attrs()
     PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_diag_fronts), hipFuncAttributeMaxDynamicSharedMemorySize, POTRF_LDS_BYTES));
     PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_trsm_panel_fronts), hipFuncAttributeMaxDynamicSharedMemorySize, TRSM_LDS_BYTES));
     PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk_lower_fronts<4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, SYRK_LDS_BYTES));
-    PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk_half_fronts), hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS_BYTES));
+    PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk_half_fronts<2>), hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS_BYTES));
+    PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk_half_fronts<4>), hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS_BYTES));
     attr_set = true;
 }
 void launch_front_diag_panels(const FrontJob* jobs, int njobs, int panel, int max_rows_below, int* info, double* rdiag, hipStream_t s)
@@ -2080,8 +2087,9 @@ void launch_front_updates(const FrontJob* jobs, int njobs, int panel, int max_ro
     front_attrs();
     const int T = div_up(max_rows_below, TS);
     static const bool no_half = debug_token("front_updates_whole_tiles") != nullptr;
-    if (!no_half && (long long)njobs * T * (T + 1) <= 256) {  // few tiles (the top of the tree): two workgroups per tile, every workgroup on its own CU
-        hipLaunchKernelGGL(k_syrk_half_fronts, dim3(T * (T + 1), njobs), dim3(512), FUSED_LDS_BYTES, s, jobs, panel);
+    if (!no_half && (long long)njobs * T * (T + 1) <= 256) {  // few tiles (the top of the tree): two or four workgroups per tile, every workgroup on its own CU
+        if ((long long)njobs * T * (T + 1) * 2 <= 256) hipLaunchKernelGGL(k_syrk_half_fronts<4>, dim3(2 * T * (T + 1), njobs), dim3(512), FUSED_LDS_BYTES, s, jobs, panel);
+        else hipLaunchKernelGGL(k_syrk_half_fronts<2>, dim3(T * (T + 1), njobs), dim3(512), FUSED_LDS_BYTES, s, jobs, panel);
         PQ_HIP(hipGetLastError());
         return;
     }
