@@ -1616,6 +1616,16 @@ struct CholTask {
 // (threshold swept at T = 32, factorisation ms: never 1.28-1.32, 30: 1.28, 26: 1.26, 22: 1.245, 18: 1.27, 14: 1.29, 10: 1.32)
 __host__ __device__ inline bool chol_bulk_bound(int T, int k) { return T - k - 1 >= 22; }
 __host__ __device__ inline int chol_split(int T, int k) { return chol_bulk_bound(T, k) ? 1 : 2; }
+// ... except the first CHOL_FAST_ROWS block rows below the diagonal block, which are always halves: the first row's slices feed the next crew and the second
+// row's completion starts the next round's first row, and a whole tile's update (31 us) arrives at the diagonal block when that is finished (the rounds with
+// whole first rows ran at 48 us, the others at 36)
+constexpr int CHOL_FAST_ROWS = 2;
+__host__ __device__ inline int chol_split_row(int T, int k, int ti) { return ti <= CHOL_FAST_ROWS ? 2 : chol_split(T, k); }
+__host__ __device__ inline int chol_panel_tasks(int T, int k)  // panel tasks of round k (rows ti = 1 .. T - k - 2)
+{
+    const int rows = T - k - 2, fast = rows < CHOL_FAST_ROWS ? rows : CHOL_FAST_ROWS;
+    return rows <= 0 ? 0 : 2 * fast + chol_split(T, k) * (rows - fast);
+}
 struct CholArgs {
     double* A; double* side; int lda, n, T, ldlt;
     int* info; double* rdiag; double* dvec; double* pack2; double* w16;
@@ -1735,7 +1745,8 @@ __global__ __launch_bounds__(CHOL_THREADS, 2) void k_chol_persistent(CholArgs c)
         a.fuse_tr2n = c.trace ? c.trace + 4 * (size_t)ntasks + 64 * (size_t)(k > 0 ? k - 1 : T) : nullptr;  // ... and of the crew that consumes it (round k's crew reads round k - 1's row)
         // absolute block coordinates of what this task touches: relative tile (ti, tj) of round k = absolute (k + 1 + ti, k + 1 + tj)
         const int* lr = c.lready + (size_t)k * T;   // panel k
-        const int ready = (c.fcount + 1) * (k > 0 ? chol_split(T, k - 1) : 1);  // (cumulative counters: panel k was solved by the split(k - 1) tasks per block row of round k - 1)
+        // (cumulative counters: block row i of panel k was solved by the split_row(k - 1, i - k) tasks of round k - 1; the first row of panel k, i = k + 1, by two)
+        auto ready_of = [&](int i) { return (c.fcount + 1) * (k > 0 ? chol_split_row(T, k - 1, i - k) : 1); };
         bool ok = true;
         if (tk.kind <= 1) {
             // crew of the next diagonal block: its tile (k + 1, k + 1) must have received U_0 .. U_{k-1}; operand = block row k + 1 of panel k.  The
@@ -1743,7 +1754,7 @@ __global__ __launch_bounds__(CHOL_THREADS, 2) void k_chol_persistent(CholArgs c)
             const int d = k + 1;
             // (its operand, block row d of panel k, arrives slice by slice inside fused_next_diag)
             ok = chol_wait3(k > 0 ? c.tver + (size_t)d * T + d : nullptr, c.gen + k, nullptr, 0,
-                            (tk.kind == 1 && k >= 2) ? c.pdone + (k - 2) : nullptr, (c.fcount + 1) * chol_split(T, k - 2) * (T - (k - 2) - 2), abort_w, 0);
+                            (tk.kind == 1 && k >= 2) ? c.pdone + (k - 2) : nullptr, (c.fcount + 1) * chol_panel_tasks(T, k - 2), abort_w, 0);
             if (c.trace && tid == 0) c.trace[4 * (size_t)t + 1] = wall_clock64();
             if (ok) ok = chol_role_crew(a, tk.kind == 1 ? 0 : tk.a);
         } else {
@@ -1754,9 +1765,9 @@ __global__ __launch_bounds__(CHOL_THREADS, 2) void k_chol_persistent(CholArgs c)
             const int i = k + 1 + ti, j = k + 1 + tj;
             if (panel && k > 0) {
                 ok = chol_wait3(c.tver + (size_t)i * T + j, c.gen + k, nullptr, 0, nullptr, 0, abort_w, 0);
-                a.late_p[0] = lr + i; a.late_w[0] = ready; a.late_p[1] = lr + j; a.late_w[1] = ready;
+                a.late_p[0] = lr + i; a.late_w[0] = ready_of(i); a.late_p[1] = lr + j; a.late_w[1] = ready_of(j);
             } else {
-                ok = chol_wait3(k > 0 ? c.tver + (size_t)i * T + j : nullptr, c.gen + k, k > 0 ? lr + i : nullptr, ready, k > 0 ? lr + j : nullptr, ready, abort_w, panel ? 0 : 1);
+                ok = chol_wait3(k > 0 ? c.tver + (size_t)i * T + j : nullptr, c.gen + k, k > 0 ? lr + i : nullptr, ready_of(i), k > 0 ? lr + j : nullptr, ready_of(j), abort_w, panel ? 0 : 1);
             }
             if (c.trace && tid == 0) c.trace[4 * (size_t)t + 1] = wall_clock64();
             if (ok) ok = (panel && tk.b >= 0) ? chol_role_half(a, ti, 0, tk.b) : (dh >= 0 ? chol_role_half(a, ti, tj, dh) : chol_role_tile(a, ti, tj));
@@ -1767,7 +1778,7 @@ __global__ __launch_bounds__(CHOL_THREADS, 2) void k_chol_persistent(CholArgs c)
                     addi_agent(c.lready + (size_t)(k + 1) * T + i, 1);
                     const int before = addi_agent(c.pdone + k, 1);
                     // the last panel task of the round: rounds complete in order (row i of panel k + 1 needs row i of panel k)
-                    if (before + 1 - (c.fcount + 1) * chol_split(T, k) * (T - k - 2) == 0) sti_agent(c.progress, c.gen + k + 1);
+                    if (before + 1 - (c.fcount + 1) * chol_panel_tasks(T, k) == 0) sti_agent(c.progress, c.gen + k + 1);
                 } else if (dh < 0 || addi_agent(c.dhalf + k, 1) + 1 == 2 * (c.fcount + 1)) {  // (a split tile: the second half to finish announces it)
                     __hip_atomic_store(c.tver + (size_t)i * T + j, c.gen + k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
@@ -1801,18 +1812,21 @@ static void chol_build_tasks(int T, std::vector<CholTask>& H)
     struct Keyed { double key; int cls; CholTask t; };
     std::vector<Keyed> all;
     for (int k = 0; k + 1 < T; ++k) {
-        const int Tk = T - k - 1, sp = chol_split(T, k), gate = std::max(k - 1, 0);
+        const int Tk = T - k - 1, gate = std::max(k - 1, 0);
         const double kc = (double)k - 1.0;
         for (int r = 1; r < FUSE_ROLES; ++r) all.push_back({kc, 0, {0, (short)k, (short)r, 0, gate}});
         all.push_back({kc, 1, {1, (short)k, 0, 0, gate}});
         // (Tried: drawing the panel tasks of the rows >= 3 of the bulk-bound rounds only when their inputs exist -- gate k, key k - 0.3 ... k - 0.7 -- so that they do
         // not park a workgroup for a round: 1.24-1.27 ms against 1.26, inside the run-to-run spread.  Not kept.)
         for (int ti = 1; ti < Tk; ++ti) {
-            if (sp == 1) all.push_back({kc, 2, {2, (short)k, (short)ti, -1, gate}});
-            else for (int h = 0; h < sp; ++h) all.push_back({kc, 2, {2, (short)k, (short)ti, (short)h, gate}});
+            const int spr = chol_split_row(T, k, ti);
+            if (spr == 1) all.push_back({kc, 2, {2, (short)k, (short)ti, -1, gate}});
+            else for (int h = 0; h < spr; ++h) all.push_back({kc, 2, {2, (short)k, (short)ti, (short)h, gate}});
         }
         for (int tj = 1; tj < Tk; ++tj) {
-            const double key = tj == 1 ? (double)k - 0.5 : (double)k + CHOL_DEFER * (tj - 1);
+            // (the second tile column as well: its diagonal tile is the diagonal block two rounds on, its other tiles the panel after next -- behind the deferred far
+            // columns of earlier rounds their updates arrived late, and the crew of round k + 2 waited for them)
+            const double key = tj == 1 ? (double)k - 0.5 : (tj == 2 ? (double)k - 0.25 : (double)k + CHOL_DEFER * (tj - 1));
             for (int ti = tj; ti < Tk; ++ti) {
                 // tile (1, 1) is the next round's diagonal block: its update stands between this round's second panel row and the next crew -- two workgroups
                 if (ti == 1 && tj == 1 && CHOL_SPLIT_DIAG) { all.push_back({key, 3, {4, (short)k, 1, 1, k}}); all.push_back({key, 3, {5, (short)k, 1, 1, k}}); }
@@ -1827,7 +1841,7 @@ static void chol_build_tasks(int T, std::vector<CholTask>& H)
 size_t chol_task_count(int T)
 {
     size_t n = 0;
-    for (int k = 0; k + 1 < T; ++k) { const int Tk = T - k - 1; n += FUSE_ROLES + (size_t)chol_split(T, k) * (Tk - 1) + (size_t)Tk * (Tk - 1) / 2 + ((CHOL_SPLIT_DIAG && Tk >= 2) ? 1 : 0); }
+    for (int k = 0; k + 1 < T; ++k) { const int Tk = T - k - 1; n += FUSE_ROLES + (size_t)chol_panel_tasks(T, k) + (size_t)Tk * (Tk - 1) / 2 + ((CHOL_SPLIT_DIAG && Tk >= 2) ? 1 : 0); }
     return n;
 }
 
