@@ -1797,7 +1797,13 @@ __global__ __launch_bounds__(CHOL_THREADS, 2) void k_chol_persistent(CholArgs c)
 // (Tried and measured at n = 4096, factorisation ms in bench.py: this list 1.35-1.45; two queues -- crew, panel and first-column tiles in one served
 // first, the other tiles in a second, panel tasks drawn only when the round before is complete, a drawn task whose conditions do not hold yet held back --
 // 1.50: the rows start their update later than with the early draw, and that costs more than the parked workgroups it saves; drawing with a
-// compare-and-swap on the head, so that nobody overshoots a gate: 18 ms.)
+// compare-and-swap on the head, so that nobody overshoots a gate: 18 ms.
+// Round 3 repeated the two queues WITH the early draw kept (crew, panel rows and the first two tile columns in a chain queue served first, the other tiles in a
+// bulk queue, every task carrying the number of tickets of the other queue that must be drawn before it may start, a workgroup holding such a task serving the
+// other queue meanwhile -- deadlock-free under any residency, bitwise equal results): 1.35-1.41 ms against 1.27 for this list on the same box, whatever the
+// queue membership (0 / 1 / 2 / 4 tile columns) and with or without a late draw of the panel rows >= 3.  The timeline shows why: in the bulk-bound rounds the
+// chain queue's ~130 tasks per round are drawn the moment their gate opens and wait inside, which takes a third of the chip away from the trailing tiles --
+// the chain reaches round 9 at 600 us instead of 512.  The single list meters the chain tasks out between the tiles; that is worth more than the bypass.)
 constexpr double CHOL_DEFER = 0.05;
 constexpr bool CHOL_SPLIT_DIAG = true;
 static void chol_build_tasks(int T, std::vector<CholTask>& H)
