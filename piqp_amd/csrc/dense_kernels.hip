@@ -1018,6 +1018,19 @@ __device__ __forceinline__ void tile_trsm_rt_follow(d4& x, const volatile double
 // cycles per 16 columns); it solves its piece when the whole of L_kk is there.  (Pausing the partner for the whole step, updates included,
 // makes the factorisation steps uniform -- 4 550 cycles -- but the paused waves then arrive late at their own steps: 63 500 cycles per
 // block instead of 57 000.)
+// (Round 3, measured with tools/dbg_potrf.py on the 56 100-cycle block and all bitwise neutral -- none kept:
+//  * the pivot recurrence of factor16_tile kept uniform in vector registers (entry of row c + 1 and diagonal entry of column c + 1 read off the chain, no
+//    lane read between two reciprocal square roots; tools/ub/factor16.hip "UNI"): 255 instead of 241 ticks per pivot -- the loop is bound by the number of
+//    instructions a single wave issues, not by the latency of the chain;
+//  * the update of the wave's own diagonal tile pipelined into the substitution (slice ks behind the published register ks, so that the wave the next
+//    factorisation waits for is left with three rank-1 updates and ONE product behind the last publication): 55 800 cycles, the launch unchanged (1.240-1.249 ms);
+//    with a branch between the last product of a matrix-core chain and the vector instruction that reads its result the compiler's wait-state count came out
+//    short on the taken path and the results changed from run to run -- keep such code straight-line;
+//  * the tiles of a block row updated two at a time with interleaved product chains: unchanged -- a tile update is 660 cycles of which the four products
+//    are the smaller part (three tile loads, the wait for the operand piece, the store);
+//  * all tile updates but the first deferred into the waits of the NEXT substitution (the bottom block rows run a whole step behind the factorisation --
+//    wave 7 enters step k when factor16 of step k has finished -- and the last step starts 3 300 cycles after the seventh has ended): 64 200 cycles, the
+//    deferred products then sit between the pivots of whichever wave shares the SIMD.)
 // Outputs: the factor (lower triangle) to Aout, reciprocal pivots to rdiag[kglobal..], D to dvec (LDLT, nullable), and `pack`
 // (nullable): the operand pack of k_trsm_panel -- 28 strictly-lower blocks of -L at j (j - 1) / 2 + k, then the 8 inverted
 // diagonal pieces W_jj, all as column-major 16 x 16 blocks; `w16` (nullable): the same eight W_jj once more, into the array that holds them

@@ -2,6 +2,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -ffp-contract=on tools/ub/factor16.hip -o /tmp/ub_f16 && /tmp/ub_f16
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstring>
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) volatile double lds_vdouble;
 typedef __attribute__((address_space(3))) volatile int lds_vint;
@@ -193,6 +194,97 @@ __global__ void k_f16(double* out, long long* ts)
     out[lane] = t[0] + t[1] + t[2] + t[3] + rd + dd + D[lane] + R[lane & 15] + prog;
     if (lane == 0) ts[0] = t1 - t0;
 }
+
+// ---- round 3: the product's loop (CUR) against the same arithmetic with the pivot recurrence kept UNIFORM in vector registers (UNI): the entry of row c + 1 and
+// the diagonal entry of column c + 1 are read off the chain (before 1 / l is known), l_{c+1,c} = entry * (1 / l) and d_{c+1} = -fma(l, l, diag) are computed in
+// every lane, so no lane read sits between two reciprocal square roots.  Bitwise the same values (checked below).
+template <bool UNI>
+__device__ __forceinline__ void factor16_r3(d4& t, int lane, lds_vdouble* Dpub, lds_vdouble* rpub, lds_vint* prog, int base)
+{
+    const int ip = lane & 15, g = lane >> 4, il = pi16(ip);
+    d4 s = {-t[0], -t[1], -t[2], -t[3]};
+    d4 Lo = {0.0, 0.0, 0.0, 0.0};
+    double col = s[0];
+    double dk = -readlane_d(col, 0);
+    double rq[4];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        const int gc = c >> 2, rc = c & 3;
+        const bool incol = (g == gc);
+        const int c1 = (c + 1) & 15, gn = c1 >> 2, rn = c1 & 3;
+        const int src1 = 16 * gc + pi16(c1);
+        if (!UNI) {
+            const double r = rsqrt_newton(dk);
+            const double lneg = (incol && il >= c) ? col * r : 0.0;
+            Lo[rc] -= lneg;
+            rq[rc] = r;
+            if (c < 15) {
+                const double l1 = readlane_d(lneg, src1);
+                if (rn != 0) {
+                    col = __builtin_fma(lneg, l1, s[rn]);
+                    s = __builtin_amdgcn_mfma_f64_16x16x4f64(lneg, lneg, s, 0, 0, 0);
+                } else {
+                    s = __builtin_amdgcn_mfma_f64_16x16x4f64(lneg, lneg, s, 0, 0, 0);
+                    col = s[0];
+                }
+                dk = -readlane_d(col, 16 * gn + pi16(c1));
+            }
+        } else {
+            const double colm = (incol && il >= c) ? col : 0.0;
+            double sc1 = 0.0, sd = 0.0;
+            if (c < 15) { sc1 = readlane_d(colm, src1); if (rn != 0) sd = readlane_d(s[rn], src1); }
+            const double r = rsqrt_newton(dk);
+            const double lneg = colm * r;
+            Lo[rc] -= lneg;
+            rq[rc] = r;
+            if (c < 15) {
+                const double l1 = sc1 * r;
+                if (rn != 0) {
+                    dk = -__builtin_fma(l1, l1, sd);
+                    col = __builtin_fma(lneg, l1, s[rn]);
+                    s = __builtin_amdgcn_mfma_f64_16x16x4f64(lneg, lneg, s, 0, 0, 0);
+                } else {
+                    s = __builtin_amdgcn_mfma_f64_16x16x4f64(lneg, lneg, s, 0, 0, 0);
+                    col = s[0];
+                    dk = -readlane_d(col, 16 * gn + pi16(c1));
+                }
+            }
+        }
+        if (rc == 3) {
+            if (incol) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) Dpub[(4 * gc + q) * 16 + il] = Lo[q];
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) rpub[4 * gc + q] = rq[q];
+            }
+            asm volatile("" ::: "memory");
+            if (lane == 0) *prog = base + c + 1;
+            asm volatile("" ::: "memory");
+        }
+    }
+    t = Lo;
+}
+template <bool UNI>
+__global__ void k_f16_r3(double* out, long long* ts)
+{
+    __shared__ double D[256], R[32];
+    __shared__ int prog;
+    const int lane = threadIdx.x & 63;
+    for (int e = lane; e < 256; e += 64) D[e] = 0.0;
+    __syncthreads();
+    d4 t;
+    for (int r = 0; r < 4; ++r) { const int i = pi16(lane & 15), j = 4 * (lane >> 4) + r; t[r] = i == j ? 2.0 + 0.37 * i : 0.9 / (1.3 + i + j) + 1e-3 * ((i * 7 + j * 3) % 11); }
+    long long t0 = tick4(t);
+    factor16_r3<UNI>(t, lane, (lds_vdouble*)D, (lds_vdouble*)R, (lds_vint*)&prog, 0);
+    long long t1 = tick4(t);
+    __syncthreads();
+    for (int r = 0; r < 4; ++r) out[lane * 4 + r] = t[r];
+    for (int e = lane; e < 256; e += 64) out[256 + e] = D[e];
+    if (lane < 16) out[512 + lane] = R[lane];
+    if (lane == 0) ts[0] = t1 - t0;
+}
 // does the scalar-operand FMA reproduce the matrix core's value of the next pivot element bit for bit?
 __global__ void k_check(double* out, int* mism)
 {
@@ -241,6 +333,18 @@ int main()
         hipLaunchKernelGGL(k_f16_new, dim3(1), dim3(64), 0, 0, out, t, 0); rep("NEW form, alone");
         hipLaunchKernelGGL(k_f16_new, dim3(1), dim3(256), 0, 0, out, t, 3); rep("NEW form, 3 followers on the other SIMDs");
         hipLaunchKernelGGL(k_f16_new, dim3(1), dim3(512), 0, 0, out, t, 7); rep("NEW form, 7 followers (one shares the SIMD)");
+    }
+    {
+        static double a[528], b[528];
+        hipLaunchKernelGGL(k_f16_r3<false>, dim3(1), dim3(64), 0, 0, out, t); rep("round 3: product loop (CUR)");
+        (void)hipMemcpy(a, out, sizeof(a), hipMemcpyDeviceToHost);
+        hipLaunchKernelGGL(k_f16_r3<true>, dim3(1), dim3(64), 0, 0, out, t); rep("round 3: uniform pivot recurrence (UNI)");
+        (void)hipMemcpy(b, out, sizeof(b), hipMemcpyDeviceToHost);
+        int diff = 0;
+        for (int e = 0; e < 528; ++e) diff += memcmp(&a[e], &b[e], 8) != 0;
+        printf("CUR vs UNI: %d of 528 output doubles differ (0 = bitwise equal); L[5][3] = %.17g\n", diff, a[256 + 3 * 16 + 5]);
+        hipLaunchKernelGGL(k_f16_r3<false>, dim3(1), dim3(64), 0, 0, out, t); rep("round 3: product loop (CUR)");
+        hipLaunchKernelGGL(k_f16_r3<true>, dim3(1), dim3(64), 0, 0, out, t); rep("round 3: uniform pivot recurrence (UNI)");
     }
     return 0;
 }
