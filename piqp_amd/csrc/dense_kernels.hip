@@ -1654,18 +1654,18 @@ struct CholArgs {
     long long* trace;  // debugging aid (PIQP_AMD_DEBUG=chol_trace), nullable: per ticket 4 x wall_clock64 (100 MHz): drawn, inputs ready, done; [3] = workgroup id
 };
 
-// thread 0 waits until *p - want >= 0 for up to three words; false on abort / timeout (sets the abort word)
+// waits until *p - want >= 0 for up to three words; false on abort / timeout (sets the abort word).  Threads 0 .. 2 take one word each: the words come from L2
+// (agent-scope loads, 0.7-1 us apiece under load) and one thread asking for them in turn put three of those round trips in front of every task.
 __device__ __forceinline__ bool chol_wait3(const int* p0, int w0, const int* p1, int w1, const int* p2, int w2, int* abort_w, int sleep)
 {
-    __shared__ int ok_s;
-    if (threadIdx.x == 0) {
+    __shared__ int ok_s[3];
+    if (threadIdx.x < 3) {
+        const int* p = threadIdx.x == 0 ? p0 : (threadIdx.x == 1 ? p1 : p2);
+        const int w = threadIdx.x == 0 ? w0 : (threadIdx.x == 1 ? w1 : w2);
         int ok = 1;
-        const int* ps[3] = {p0, p1, p2};
-        const int ws[3] = {w0, w1, w2};
-        for (int q = 0; q < 3 && ok; ++q) {
-            if (!ps[q]) continue;
+        if (p) {
             unsigned spins = 0;
-            while (ldi_agent(ps[q]) - ws[q] < 0) {
+            while (ldi_agent(p) - w < 0) {
                 __builtin_amdgcn_s_sleep(4);
                 if (sleep) __builtin_amdgcn_s_sleep(12);
                 ++spins;
@@ -1673,10 +1673,10 @@ __device__ __forceinline__ bool chol_wait3(const int* p0, int w0, const int* p1,
                 if (spins > 8000000u) { ok = 0; sti_agent(abort_w, 1); break; }
             }
         }
-        ok_s = ok;
+        ok_s[threadIdx.x] = ok;
     }
     __syncthreads();
-    const bool ok = ok_s != 0;
+    const bool ok = (ok_s[0] & ok_s[1] & ok_s[2]) != 0;
     __syncthreads();
     return ok;
 }
@@ -1710,6 +1710,7 @@ __device__ __noinline__ bool chol_role_half(const SyrkArgs& a, int ti, int tj, i
 __global__ __launch_bounds__(CHOL_THREADS, 2) void k_chol_persistent(CholArgs c)
 {
     __shared__ int s_ticket;
+    __shared__ CholTask s_task;
     const int tid = threadIdx.x;
     int* abort_w = c.ticket + 1;
     const int T = c.T, NB = FACTOR_NB, ntasks = c.ntasks;
@@ -1720,22 +1721,33 @@ __global__ __launch_bounds__(CHOL_THREADS, 2) void k_chol_persistent(CholArgs c)
             // polling its words.  A ticket drawn past the gate in a race is still served: inside a task a workgroup only ever waits for EARLIER tickets.
             int t = -1;
             unsigned spins = 0;
+            // (Every step of this is a round trip to L2, 0.7-1 us under load, and a bulk-bound round is thousands of tasks: the two words are requested
+            // together, the head's task record is kept -- it is the drawn task unless another workgroup drew in between -- and handed to the workgroup
+            // through LDS instead of being read again by everybody.)
+            CholTask tk = {0, 0, 0, 0, 0};
             for (;;) {
-                const int P = max(ldi_agent(c.progress) - c.gen, 0);
+                const int praw = ldi_agent(c.progress);
                 const int cur = ldi_agent(c.ticket);
+                const int P = max(praw - c.gen, 0);
                 if (cur >= ntasks) { t = ntasks; break; }
-                if (c.tasks[cur].gate <= P) { t = addi_agent(c.ticket, 1); break; }
+                tk = c.tasks[cur];
+                if (tk.gate <= P) {
+                    t = addi_agent(c.ticket, 1);
+                    if (t != cur && t < ntasks) tk = c.tasks[t];
+                    break;
+                }
                 __builtin_amdgcn_s_sleep(127);  // (an idle workgroup polls rarely: a grid of pollers slows the write-through traffic of the chain)
                 if (((++spins & 15u) == 0 && ldi_agent(abort_w) != 0) || spins > 8000000u) { t = ntasks; break; }
             }
+            s_task = tk;
             s_ticket = t;
         }
         __syncthreads();
         const int t = s_ticket;
+        const CholTask tk = s_task;
         __syncthreads();
         if (t >= ntasks) return;
         if (c.trace && tid == 0) { c.trace[4 * (size_t)t] = wall_clock64(); c.trace[4 * (size_t)t + 3] = blockIdx.x; }
-        const CholTask tk = c.tasks[t];
         const int k = tk.round, kk = k * NB, rs = c.n - kk - NB;  // rs = order of the trailing matrix of round k (a multiple of 128, >= 128)
         SyrkArgs a;
         a.n = rs; a.kdim = NB;
