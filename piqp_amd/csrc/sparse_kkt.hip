@@ -708,7 +708,6 @@ __global__ __launch_bounds__(256) void k_big_extend_add(FrontMeta M, double* __r
     const SnRec me = M.sn[list[blockIdx.y]];
     const int f = me.f;
     double* F = fronts + me.front_off;
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;  // 16 rows x 16 columns of the child's update matrix per step
     const int G = gridDim.x, mine = blockIdx.x;
     for (int ci = me.child_lo; ci < me.child_hi; ++ci) {
         const SnRec ch = M.sn[M.child[ci]];
@@ -723,16 +722,20 @@ __global__ __launch_bounds__(256) void k_big_extend_add(FrontMeta M, double* __r
                 if (rel[j] % G == mine) own[atomicAdd(&nown, 1)] = j;
             __syncthreads();
             const int cnt = nown;
-            for (int q = ty; q < cnt; q += 16) {
+            // 16 rows x 16 columns of the child's update matrix per step, or 64 rows x 4 columns where this workgroup owns only a few columns (the top of the
+            // tree: one to four fronts per level on a wider grid -- a column of 500 rows was eight dependent rounds of index, load, store on 16 lanes)
+            const int TX = cnt <= 4 ? 64 : 16, TY = 256 / TX;
+            const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+            for (int q = ty; q < cnt; q += TY) {
                 const int j = own[q];
                 const long long cj = (long long)rel[j] * f;
                 const double* __restrict__ Uj = U + (long long)j * fc;
-                for (int i = j + tx; i < uc; i += 64) {  // four entries per step, loads before stores (see extend_add)
+                for (int i = j + tx; i < uc; i += 4 * TX) {  // four entries per step, loads before stores (see extend_add)
                     double uv[4], fv[4];
                     long long at[4];
 #pragma unroll
                     for (int q4 = 0; q4 < 4; ++q4) {
-                        const int iq = i + 16 * q4;
+                        const int iq = i + TX * q4;
                         const bool ok = iq < uc;
                         at[q4] = ok ? rel[iq] + cj : -1;
                         uv[q4] = ok ? Uj[iq] : 0.0;
@@ -2400,7 +2403,10 @@ private:
             const int cnt = ptr[l + 1] - ptr[l];
             if (cnt <= 0) continue;
             const int nbig = B.total > 0 ? B.ptr[l + 1] - B.ptr[l] : 0;
-            if (nbig > 0 && B.rounds[l] > 0) hipLaunchKernelGGL(k_big_extend_add, dim3(64, nbig), dim3(256), 0, st_, M, fronts_.p, B.list.p + B.ptr[l]);
+            // (column c of a front belongs to workgroup c mod G, an entry receives its contributions in child order whatever G is: the levels with a handful
+            // of fronts take a wider grid)
+            const int ea_grid = debug_token("extend_add_grid64") ? 64 : (nbig <= 4 ? 256 : (nbig <= 16 ? 128 : 64));
+            if (nbig > 0 && B.rounds[l] > 0) hipLaunchKernelGGL(k_big_extend_add, dim3(ea_grid, nbig), dim3(256), 0, st_, M, fronts_.p, B.list.p + B.ptr[l]);
             const bool small = cnt > nbig || (nbig > 0 && B.npanel[l] > 0);
             // the fronts one workgroup handles and the big fronts' first diagonal blocks + panels are independent: side by side on two streams,
             // joined before the trailing updates (which also carry the panel fronts' Schur complements)
