@@ -171,7 +171,7 @@ __device__ __forceinline__ void potrf_block(double* __restrict__ Tb, double* __r
                                             double* __restrict__ dvec, double* __restrict__ Aout, int lda, double* __restrict__ pack, double* __restrict__ w16,
                                             long long* __restrict__ ts = nullptr, int* __restrict__ cnt = nullptr, int nactive = 8,
                                             const double* __restrict__ fetch_scratch = nullptr, const int* __restrict__ fetch_flags = nullptr, int fetch_token = 0,
-                                            const int* __restrict__ fetch_abort = nullptr);
+                                            const int* __restrict__ fetch_abort = nullptr, bool pack_lkk = false);
 __device__ __forceinline__ int tb_index(int bi, int bj);
 __device__ __forceinline__ void tile_store(double* __restrict__ blk, int lane, d4 t);
 constexpr int FUSE_ROLES = 9, FUSE_OWN = 4;  // workgroups that share the next diagonal block of a fused trailing update (owner + 8 helpers), blocks per workgroup
@@ -1051,8 +1051,10 @@ template <bool LDLT, int NWAVES>
 __device__ __forceinline__ void potrf_block(double* __restrict__ Tb, double* __restrict__ rds, int nb, int kglobal, int* __restrict__ info, double* __restrict__ rdiag,
                             double* __restrict__ dvec, double* __restrict__ Aout, int lda, double* __restrict__ pack, double* __restrict__ w16,
                             long long* __restrict__ ts, int* __restrict__ cnt, int nactive,
-                            const double* __restrict__ fetch_scratch, const int* __restrict__ fetch_flags, int fetch_token, const int* __restrict__ fetch_abort)
+                            const double* __restrict__ fetch_scratch, const int* __restrict__ fetch_flags, int fetch_token, const int* __restrict__ fetch_abort, bool pack_lkk)
 {
+    // pack_lkk: slot 28 + k of the pack takes the factored piece L_kk itself instead of its inverse (the consumers that solve by substitution:
+    // front_trsm_follow)
     // nactive < 8 (short blocks of the sparse fronts: nb <= 16 nactive): block rows nactive .. 7 are identity padding and their waves sit out -- nothing
     // of theirs is stored (the pack blocks and inverted pieces of those rows stay unwritten: only a consumer that solves by substitution and masks the
     // padded columns, trsm_panel_body<SUBST>, may follow; the dense backend always passes 8)
@@ -1174,7 +1176,12 @@ __device__ __forceinline__ void potrf_block(double* __restrict__ Tb, double* __r
                 st_agent(rdiag + kglobal + 16 * k + lane, rbuf[lane]);
                 if (LDLT && dvec) st_agent(dvec + 16 * k + lane, dvs[lane]);  // (written through: the next trailing update of a persistent launch reads it from other CUs)
             }
-            if (pack || w16) {
+            if (pack && pack_lkk) {
+                const d4 lkk = tile_load(Dww, lane);
+                double* pb = pack + (size_t)(28 + k) * 256 + g * 16 + i;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) st_agent(pb + 64 * r, lkk[r]);
+            } else if (pack || w16) {
                 const d4 lkk = tile_load(Dww, lane);  // the factored piece in the natural tile form
                 d4 eye;
 #pragma unroll
@@ -1223,7 +1230,8 @@ __device__ __forceinline__ void potrf_block(double* __restrict__ Tb, double* __r
 constexpr int POTRF_THREADS = 512;
 template <bool LDLT>
 __device__ __forceinline__ void potrf_diag_body(double* __restrict__ A, int lda, int nb, int kglobal, int* __restrict__ info, double* __restrict__ rdiag,
-                                                double* __restrict__ dvec, double* __restrict__ pack, double* __restrict__ w16, long long* __restrict__ ts, int nactive = 8)
+                                                double* __restrict__ dvec, double* __restrict__ pack, double* __restrict__ w16, long long* __restrict__ ts, int nactive = 8,
+                                                int* __restrict__ cnt = nullptr, bool pack_lkk = false)
 {
     extern __shared__ __attribute__((aligned(16))) double Tb[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1245,7 +1253,7 @@ __device__ __forceinline__ void potrf_diag_body(double* __restrict__ A, int lda,
         for (int q = 0; q < 4; ++q) Tb[b * 256 + lane + 64 * q] = v[q];
     }
     __syncthreads();
-    potrf_block<LDLT, POTRF_THREADS / 64>(Tb, Tb + TB_DOUBLES, nb, kglobal, info, rdiag, dvec, A, lda, pack, w16, ts, nullptr, nactive);
+    potrf_block<LDLT, POTRF_THREADS / 64>(Tb, Tb + TB_DOUBLES, nb, kglobal, info, rdiag, dvec, A, lda, pack, w16, ts, cnt, nactive, nullptr, nullptr, 0, nullptr, pack_lkk);
 }
 template <bool LDLT>
 __global__ __launch_bounds__(POTRF_THREADS) void k_potrf_diag(double* __restrict__ A, int lda, int nb, int kglobal, int* __restrict__ info, double* __restrict__ rdiag,
@@ -2106,6 +2114,104 @@ __global__ __launch_bounds__(256) void k_trsm_panel_fronts(const FrontJob* __res
     trsm_panel_body<true, true>(j.F, j.f, k, nb, j.f, j.pack, rdiag + j.first, (int)blockIdx.x);
 }
 
+// The same rows solved step by step BEHIND the factorisation of the diagonal block, which workgroup 0 of the SAME launch runs (k_potrf_trsm_fronts): potrf_block
+// writes -L(j, k) and the factored piece L_kk through to L2 as its 16-column steps complete and counts them in cnt[k] (fresh counters per front and panel:
+// nact - k increments say step k is there); every wave here keeps its 16 rows in registers and runs step k when it is -- the arithmetic of
+// trsm_panel_body<LDLT, true>, product for product.  After the block's last step a wave is left with one 16 x 16 substitution instead of the whole panel
+// (the substitution launch took 23 us behind the 32 us of the diagonal block, at every 128-column panel of the top of the tree).
+template <bool LDLT>
+__device__ __forceinline__ void front_trsm_follow(double* __restrict__ A_, int lda, int k0, int nb, int n, const double* __restrict__ pack, const double* __restrict__ rdiag,
+                                                  const int* __restrict__ cnt, int strip, int* __restrict__ info, int kglobal)
+{
+    typedef __attribute__((address_space(1))) double gd;
+    gd* A = (gd*)A_;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    const int row = k0 + nb + strip * (POTRF_THREADS / 64) * 16 + wave * 16 + i;
+    const bool row_ok = row < n;
+    gd* Ar = A + (row_ok ? row : 0) + (size_t)k0 * lda;
+    d4 T[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c = 16 * j + g + 4 * r;
+            const bool ok = row_ok && c < nb;
+            const double t = Ar[ok ? (size_t)c * lda : 0];
+            T[j][r] = ok ? t : 0.0;
+        }
+    const int nact = min(8, (nb + 15) >> 4);
+    bool alive = true;
+    d4 rd[8];  // reciprocal pivots of this lane's columns, requested with the pieces of their step (asked for at the end they were a round trip behind the last step)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) rd[k] = (d4){1.0, 1.0, 1.0, 1.0};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        if (16 * k >= nb) break;  // (padding beyond a short panel: nothing to solve, nothing stored)
+        if (alive) {
+            unsigned spins = 0;
+            while (__builtin_amdgcn_readfirstlane(ldi_agent(cnt + k)) < nact - k) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > 20000000u) { alive = false; break; }  // (cannot happen with a healthy device; reported below)
+            }
+        }
+        d4 lkk;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int rr = 16 * k + i, cc = 16 * k + g + 4 * r;
+            const double t = ld_agent(pack + (size_t)(28 + k) * 256 + (g + 4 * r) * 16 + i);
+            lkk[r] = (rr < nb && cc < nb && rr > cc) ? t : 0.0;
+        }
+        d4 nl[8];
+#pragma unroll
+        for (int j = k + 1; j < 8; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) nl[j][r] = ld_agent(pack + (size_t)(j * (j - 1) / 2 + k) * 256 + (g + 4 * r) * 16 + i);
+        if (LDLT) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const int c = 16 * k + g + 4 * r; rd[k][r] = ld_agent(rdiag + k0 + (c < nb ? c : 0)); }
+        }
+        d4 x = T[k];
+        const d4 one = {1.0, 1.0, 1.0, 1.0};
+        tile_trsm_rt<LDLT, false>(x, lkk, one, lane);
+        T[k] = x;
+#pragma unroll
+        for (int j = k + 1; j < 8; ++j) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) T[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(nl[j][ks], x[ks], T[j], 0, 0, 0);
+        }
+    }
+    if (!alive && lane == 0 && *info < 0) *info = kglobal;
+    if (row_ok) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = 16 * j + g + 4 * r;
+                if (c < nb) {
+                    double v = T[j][r];
+                    if (LDLT) v *= rd[j][r];
+                    Ar[(size_t)c * lda] = v;
+                }
+            }
+    }
+}
+// diagonal block (workgroup 0) and the rows below it (workgroups 1 ..: 128 rows each) of panel `panel` of every front of the list, one launch
+__global__ __launch_bounds__(POTRF_THREADS) void k_potrf_trsm_fronts(const FrontJob* __restrict__ jobs, int panel, int* __restrict__ info, double* __restrict__ rdiag)
+{
+    const FrontJob j = jobs[blockIdx.y];
+    int k, nb, rs;
+    if (j.kind != 0 || !front_panel(j, panel, k, nb, rs)) return;
+    int* cnt = j.cnt + 8 * panel;
+    if (blockIdx.x == 0) {
+        potrf_diag_body<true>(j.F + k + (size_t)k * j.f, j.f, nb, j.first + k, info, rdiag, j.dvec, rs > 0 ? j.pack : nullptr, nullptr, nullptr, min(8, (nb + 15) >> 4), rs > 0 ? cnt : nullptr, true);
+        return;
+    }
+    const int strip = (int)blockIdx.x - 1;
+    if (strip * (POTRF_THREADS / 64) * 16 >= rs) return;
+    front_trsm_follow<true>(j.F, j.f, k, nb, j.f, j.pack, rdiag + j.first, cnt, strip, info, j.first + k);
+}
+
 // one panel step of the partial LDLt of many fronts: diagonal blocks and panels (two launches whatever the number of fronts), then the trailing updates
 static void front_attrs()
 {
@@ -2113,15 +2219,23 @@ static void front_attrs()
     if (attr_set) return;
     PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_diag_fronts), hipFuncAttributeMaxDynamicSharedMemorySize, POTRF_LDS_BYTES));
     PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_trsm_panel_fronts), hipFuncAttributeMaxDynamicSharedMemorySize, TRSM_LDS_BYTES));
+    PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_trsm_fronts), hipFuncAttributeMaxDynamicSharedMemorySize, POTRF_LDS_BYTES));
     PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk_lower_fronts<4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, SYRK_LDS_BYTES));
     PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk_half_fronts<2>), hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS_BYTES));
     PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk_half_fronts<4>), hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS_BYTES));
     attr_set = true;
 }
-void launch_front_diag_panels(const FrontJob* jobs, int njobs, int panel, int max_rows_below, int* info, double* rdiag, hipStream_t s)
+void launch_front_diag_panels(const FrontJob* jobs, int njobs, int panel, int max_rows_below, int* info, double* rdiag, hipStream_t s, bool follow)
 {
     if (njobs <= 0) return;
     front_attrs();
+    static const bool no_follow = debug_token("front_no_follow") != nullptr;
+    if (follow && !no_follow && panel < FRONT_CNT_PANELS) {
+        // (workgroup 0 of a front is dispatched before its followers, which wait for nobody else: no deadlock whatever part of the grid is resident)
+        hipLaunchKernelGGL(k_potrf_trsm_fronts, dim3(1 + div_up(std::max(max_rows_below, 0), (POTRF_THREADS / 64) * 16), njobs), dim3(POTRF_THREADS), POTRF_LDS_BYTES, s, jobs, panel, info, rdiag);
+        PQ_HIP(hipGetLastError());
+        return;
+    }
     hipLaunchKernelGGL(k_potrf_diag_fronts, dim3(njobs), dim3(POTRF_THREADS), POTRF_LDS_BYTES, s, jobs, panel, info, rdiag);
     if (max_rows_below > 0) hipLaunchKernelGGL(k_trsm_panel_fronts, dim3(div_up(max_rows_below, TRSM_ROWS), njobs), dim3(256), TRSM_LDS_BYTES, s, jobs, panel, rdiag);
     PQ_HIP(hipGetLastError());

@@ -104,8 +104,12 @@ struct FrontJob {
     double* dvec = nullptr;       // FACTOR_NB doubles, likewise: D of the current panel
     int kind = 0;                 // 0: diagonal block + panel by launch_front_diag_panels; 1: the caller factors the (single, w <= FACTOR_NB) panel
                                   //    itself and leaves D in dvec -- only the trailing update runs here
+    int* cnt = nullptr;           // 8 x FRONT_CNT_PANELS step counters of this front's panels (zeroed by the caller before every factorisation): the panel rows
+                                  //    follow the diagonal block inside one launch (k_potrf_trsm_fronts); nullptr: two launches
 };
-void launch_front_diag_panels(const FrontJob* jobs_device, int njobs, int panel, int max_rows_below, int* info, double* rdiag, hipStream_t s);
+constexpr int FRONT_CNT_PANELS = 16;
+// follow: the jobs carry zeroed step counters (FrontJob::cnt)
+void launch_front_diag_panels(const FrontJob* jobs_device, int njobs, int panel, int max_rows_below, int* info, double* rdiag, hipStream_t s, bool follow = false);
 void launch_front_updates(const FrontJob* jobs_device, int njobs, int panel, int max_rows_below, hipStream_t s);  // T -= L D L^T of panel `panel`, all fronts
 
 }  // namespace dense

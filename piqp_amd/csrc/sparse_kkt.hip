@@ -2327,6 +2327,7 @@ private:
         DBuf<int> list, job_of;  // job_of[s] = index into jobs, -1 for the fronts one workgroup handles alone
         DBuf<dense::FrontJob> jobs;
         DBuf<double> scratch;  // pack + D of every front of the widest level
+        DBuf<int> cnt;         // per job 8 x FRONT_CNT_PANELS step counters (dense::FrontJob::cnt), zeroed at the start of every factorisation
     };
     void build_big_levels(const std::vector<int>& ptr, const std::vector<int>& sn, BigLevels& B)
     {
@@ -2364,6 +2365,7 @@ private:
         B.scratch.alloc(need);
         (void)widest;
         std::vector<dense::FrontJob> jobs(B.total);
+        B.cnt.alloc((size_t)B.total * 8 * dense::FRONT_CNT_PANELS);
         for (int l = 0; l + 1 < (int)B.ptr.size(); ++l) {
             const int nl = B.ptr[l + 1] - B.ptr[l];
             double* packs = B.scratch.p + (size_t)nl * dense::FACTOR_NB;
@@ -2376,6 +2378,7 @@ private:
                 j.kind = panel_front(j.f, j.w) ? 1 : 0;
                 j.dvec = B.scratch.p + (size_t)(q - B.ptr[l]) * dense::FACTOR_NB;
                 j.pack = j.kind == 0 ? packs + (size_t)(nd++) * dense::FACTOR_PACK_DOUBLES : nullptr;
+                j.cnt = B.cnt.p + (size_t)q * 8 * dense::FRONT_CNT_PANELS;
             }
         }
         upload_vec(B.list, list, st_);
@@ -2393,6 +2396,7 @@ private:
     void factor_levels(const FrontMeta& M, const std::vector<int>& ptr, const int* sn_dev, const std::vector<int>& lds, const BigLevels& B, int lend = 1 << 30)
     {
         if (B.total > 0) {
+            PQ_HIP(hipMemsetAsync(B.cnt.p, 0, (size_t)B.total * 8 * dense::FRONT_CNT_PANELS * sizeof(int), st_));
             for (int q0 = 0; q0 < B.total; q0 += 65535) {  // (grid.y limit)
                 const int nq = std::min(65535, B.total - q0);
                 hipLaunchKernelGGL(k_big_zero, dim3((unsigned)std::min<long long>(256, ((long long)B.max_f * B.max_f + 255) / 256), nq), dim3(256), 0, st_, M, fronts_.p, B.list.p + q0);
@@ -2419,7 +2423,7 @@ private:
             if (fork) PQ_HIP(hipEventRecord(ev_join_, st2_));
             if (nbig <= 0) continue;
             for (int pn = 0; pn < (int)B.rows_below[l].size(); ++pn) {
-                if (B.ndense[l] > 0) dense::launch_front_diag_panels(B.jobs.p + B.ptr[l], nbig, pn, B.rows_below[l][pn], info_.p, rdiag_.p, st_);
+                if (B.ndense[l] > 0) dense::launch_front_diag_panels(B.jobs.p + B.ptr[l], nbig, pn, B.rows_below[l][pn], info_.p, rdiag_.p, st_, true);
                 if (fork && pn == 0) PQ_HIP(hipStreamWaitEvent(st_, ev_join_, 0));
                 dense::launch_front_updates(B.jobs.p + B.ptr[l], nbig, pn, B.rows_below[l][pn], st_);
             }
