@@ -2151,7 +2151,7 @@ __device__ __forceinline__ void front_trsm_follow(double* __restrict__ A_, int l
         if (alive) {
             unsigned spins = 0;
             while (__builtin_amdgcn_readfirstlane(ldi_agent(cnt + k)) < nact - k) {
-                __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_s_sleep(4);  // (a grid of tight pollers slows the write-through traffic of the block they wait for)
                 if (++spins > 20000000u) { alive = false; break; }  // (cannot happen with a healthy device; reported below)
             }
         }
