@@ -222,9 +222,11 @@ def main():
             r_upd = roof("k_syrk_lower<EPI_SUBTRACT_POTRF> = one launch per panel: trailing (panel) update of the factorisation + factorisation of the next diagonal "
                          "block + substitution of the next panel behind it (dense/ldlt_no_pivot.hpp:313-354, Eigen::LLT at dense/kkt.hpp:82); hipEvent-bracketed per "
                          "launch in a separate pass of the same steps", flops_upd, upd_s, upd_launches, "panel_update")
-        # the dominant kernel = the main kernel of the longer STAGE (factorisation = first diagonal block + panel + the persistent launch; assembly = the SYRK): the
-        # two kernels are within 2 % of each other now, and comparing the bare kernel times would flip the object from run to run
-        dominant, secondary = (r_upd, r_asm) if max(upd_s, main_leg["fac_ms"] * 1e-3) >= asm_s else (r_asm, r_upd)
+        # the dominant kernel: the factorisation's persistent launch and the assembly STAGE are within 2 % of each other now (1.20 ms in ONE launch -- the longest
+        # launch of the step -- against 1.22-1.25 ms in two SYRK launches and a reduction), so a plain comparison flips the object from run to run.  The primary
+        # object stays the factorisation kernel (the one the round-2 review named, and the lower fraction of the two) unless the assembly stage exceeds its
+        # stage by more than 10 %; the other kernel is always reported beside it (roofline_secondary).
+        dominant, secondary = (r_upd, r_asm) if max(upd_s, main_leg["fac_ms"] * 1e-3) * 1.1 >= asm_s else (r_asm, r_upd)
         out = {
             "metric": "KKT factor+solve/sec (per IPM iter)",
             "value": value,
