@@ -140,6 +140,24 @@ __device__ __forceinline__ void load_tile_agent(const double* __restrict__ M, in
     }
 }
 
+// ... with the edge handling of load_tile<true> (the fronts of the sparse backend: k_front_panel_step)
+template <int NT>
+__device__ __forceinline__ void load_tile_agent_chk(const double* __restrict__ M, int ld, int r0, int k0, int nrows, int kdim, int tid, d2 (&v)[1024 / NT])
+{
+    const int r = r0 + 2 * (tid & 63);
+#pragma unroll
+    for (int it = 0; it < 1024 / NT; ++it) {
+        const int k = k0 + it * (NT / 64) + (tid >> 6);
+        d2 t = {0.0, 0.0};
+        if (k < kdim) {
+            const double* p = M + r + (size_t)k * ld;
+            if (r < nrows) t.x = ld_agent(p);
+            if (r + 1 < nrows) t.y = ld_agent(p + 1);
+        }
+        v[it] = t;
+    }
+}
+
 template <int NT>
 __device__ __forceinline__ void store_tile(double* __restrict__ S, int tid, const d2 (&v)[1024 / NT])
 {
@@ -243,10 +261,9 @@ __device__ __forceinline__ bool fused_tile(const SyrkArgs& a, const int ti, cons
     }
     const bool tr_row = PERSIST && HALF && a.fuse_tr2 && threadIdx.x == 0 && ti == 1 && tj == 0 && h == 0;  // PIQP_AMD_DEBUG=chol_trace: the first panel row's own timeline
     if (tr_row) a.fuse_tr2[48] = wall_clock64();
-    if constexpr (PERSIST) {
-        // (panel tiles: the operand rows come from the panel tasks of the round before, later than the tile itself -- wait for them with the tile's loads in flight)
-        if (a.late_p[0] && !chol_wait3(nullptr, 0, a.late_p[0], a.late_w[0], a.late_p[1], a.late_w[1], a.fuse_abort, 0)) return false;
-    }
+    // (persistent launch, panel tiles: the operand rows come from the panel tasks of the round before, later than the tile itself -- wait for them with the
+    // tile's loads in flight; front panel steps in one launch, k_front_panel_step: the operand rows are solved by other workgroups of the same launch)
+    if (a.late_p[0] && !chol_wait3(nullptr, 0, a.late_p[0], a.late_w[0], a.late_p[1], a.late_w[1], a.fuse_abort, 0)) return false;
     if (tr_row) a.fuse_tr2[49] = wall_clock64();
     const bool dbg_tile = FUSE_TS_ON && !PERSIST && a.fuse_ts && threadIdx.x == 0 && ti == 2 && tj == 1;  // debugging aid: an ordinary tile's timeline
     if (dbg_tile) a.fuse_ts[84] = clock64();
@@ -263,9 +280,17 @@ __device__ __forceinline__ bool fused_tile(const SyrkArgs& a, const int ti, cons
                 if constexpr (HALF) {
                     // ROWS rows of the row operand (the rest of the stage stays unused), the whole column operand
                     const bool chk = !PERSIST && (edge || (k0 + BK > a.kdim));
-                    if ((tid & 63) < ROWS / 2) { if (chk) load_tile<true, NT>(a.A, a.lda, row0, k0, a.n, a.kdim, tid, pa[kt]); else load_tile<false, NT>(a.A, a.lda, row0, k0, a.n, a.kdim, tid, pa[kt]); }
-                    else { for (int it = 0; it < PER; ++it) pa[kt][it] = (d2){0.0, 0.0}; }
-                    if (chk) load_tile<true, NT>(a.B, a.ldb, col0, k0, a.n, a.kdim, tid, pb[kt]); else load_tile<false, NT>(a.B, a.ldb, col0, k0, a.n, a.kdim, tid, pb[kt]);
+                    // (operand rows other workgroups of THIS launch solved and wrote through: a 128-byte line at a strip boundary may sit in this XCD's L2 with
+                    // the old values of the neighbouring strip -- agent-scope loads)
+                    const bool agent = !PERSIST && a.late_p[0] != nullptr;
+                    if ((tid & 63) < ROWS / 2) {
+                        if (agent) load_tile_agent_chk<NT>(a.A, a.lda, row0, k0, a.n, a.kdim, tid, pa[kt]);
+                        else if (chk) load_tile<true, NT>(a.A, a.lda, row0, k0, a.n, a.kdim, tid, pa[kt]);
+                        else load_tile<false, NT>(a.A, a.lda, row0, k0, a.n, a.kdim, tid, pa[kt]);
+                    } else { for (int it = 0; it < PER; ++it) pa[kt][it] = (d2){0.0, 0.0}; }
+                    if (agent) load_tile_agent_chk<NT>(a.B, a.ldb, col0, k0, a.n, a.kdim, tid, pb[kt]);
+                    else if (chk) load_tile<true, NT>(a.B, a.ldb, col0, k0, a.n, a.kdim, tid, pb[kt]);
+                    else load_tile<false, NT>(a.B, a.ldb, col0, k0, a.n, a.kdim, tid, pb[kt]);
                 } else if constexpr (PERSIST && AGENT_OPERANDS) {
                     load_tile_agent<NT>(a.A, a.lda, row0, k0, tid, pa[kt]); load_tile_agent<NT>(a.B, a.ldb, col0, k0, tid, pb[kt]);
                 } else {
@@ -530,9 +555,10 @@ __device__ __forceinline__ bool front_panel(const FrontJob& j, int panel, int& k
     return true;
 }
 template <int WR, int WC>
-__global__ __launch_bounds__(64 * WR * WC, (WR * WC == 4) ? 2 : (WR * WC == 8 ? 2 : 4)) void k_syrk_lower_fronts(const FrontJob* __restrict__ jobs, int panel)
+__global__ __launch_bounds__(64 * WR * WC, (WR * WC == 4) ? 2 : (WR * WC == 8 ? 2 : 4)) void k_syrk_lower_fronts(const FrontJob* __restrict__ jobs, int panel, int kind)
 {
     const FrontJob j = jobs[blockIdx.y];
+    if (kind >= 0 && j.kind != kind) return;  // (kind: only the fronts of that kind, -1: all)
     int k, nb, rs;
     if (!front_panel(j, panel, k, nb, rs) || rs <= 0) return;
     const int T = (rs + TS - 1) / TS;
@@ -550,9 +576,10 @@ __global__ __launch_bounds__(64 * WR * WC, (WR * WC == 4) ? 2 : (WR * WC == 8 ? 
 // the wave shape, and the generic kernel adds a load -> LDS -> barrier round trip per 16-column stage (30 us per launch measured at the top of CONT-201).
 // Same products in the same order, summed from zero and subtracted from C: bitwise the tile of k_syrk_lower_fronts.
 template <int SPLIT>
-__global__ __launch_bounds__(512) void k_syrk_half_fronts(const FrontJob* __restrict__ jobs, int panel)
+__global__ __launch_bounds__(512) void k_syrk_half_fronts(const FrontJob* __restrict__ jobs, int panel, int kind)
 {
     const FrontJob j = jobs[blockIdx.y];
+    if (kind >= 0 && j.kind != kind) return;
     int k, nb, rs;
     if (!front_panel(j, panel, k, nb, rs) || rs <= 0) return;
     const int T = (rs + TS - 1) / TS;
@@ -2119,9 +2146,11 @@ __global__ __launch_bounds__(256) void k_trsm_panel_fronts(const FrontJob* __res
 // nact - k increments say step k is there); every wave here keeps its 16 rows in registers and runs step k when it is -- the arithmetic of
 // trsm_panel_body<LDLT, true>, product for product.  After the block's last step a wave is left with one 16 x 16 substitution instead of the whole panel
 // (the substitution launch took 23 us behind the 32 us of the diagonal block, at every 128-column panel of the top of the tree).
-template <bool LDLT>
+// SIGNAL (k_front_panel_step: the trailing update runs in the same launch): the solved rows are written through and every wave counts itself in done[strip]
+// when its rows have landed -- eight waves say the 128-row strip is there.
+template <bool LDLT, bool SIGNAL = false>
 __device__ __forceinline__ void front_trsm_follow(double* __restrict__ A_, int lda, int k0, int nb, int n, const double* __restrict__ pack, const double* __restrict__ rdiag,
-                                                  const int* __restrict__ cnt, int strip, int* __restrict__ info, int kglobal)
+                                                  const int* __restrict__ cnt, int strip, int* __restrict__ info, int kglobal, int* __restrict__ done = nullptr)
 {
     typedef __attribute__((address_space(1))) double gd;
     gd* A = (gd*)A_;
@@ -2191,9 +2220,14 @@ __device__ __forceinline__ void front_trsm_follow(double* __restrict__ A_, int l
                 if (c < nb) {
                     double v = T[j][r];
                     if (LDLT) v *= rd[j][r];
-                    Ar[(size_t)c * lda] = v;
+                    if constexpr (SIGNAL) st_agent((double*)(Ar + (size_t)c * lda), v);
+                    else Ar[(size_t)c * lda] = v;
                 }
             }
+    }
+    if constexpr (SIGNAL) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) addi_agent(done + strip, 1);
     }
 }
 // diagonal block (workgroup 0) and the rows below it (workgroups 1 ..: 128 rows each) of panel `panel` of every front of the list, one launch
@@ -2202,7 +2236,7 @@ __global__ __launch_bounds__(POTRF_THREADS) void k_potrf_trsm_fronts(const Front
     const FrontJob j = jobs[blockIdx.y];
     int k, nb, rs;
     if (j.kind != 0 || !front_panel(j, panel, k, nb, rs)) return;
-    int* cnt = j.cnt + 8 * panel;
+    int* cnt = j.cnt + FRONT_CNT_INTS * panel;
     if (blockIdx.x == 0) {
         potrf_diag_body<true>(j.F + k + (size_t)k * j.f, j.f, nb, j.first + k, info, rdiag, j.dvec, rs > 0 ? j.pack : nullptr, nullptr, nullptr, min(8, (nb + 15) >> 4), rs > 0 ? cnt : nullptr, true);
         return;
@@ -2210,6 +2244,50 @@ __global__ __launch_bounds__(POTRF_THREADS) void k_potrf_trsm_fronts(const Front
     const int strip = (int)blockIdx.x - 1;
     if (strip * (POTRF_THREADS / 64) * 16 >= rs) return;
     front_trsm_follow<true>(j.F, j.f, k, nb, j.f, j.pack, rdiag + j.first, cnt, strip, info, j.first + k);
+}
+
+// A whole panel step of the fronts of a level in ONE launch (the top of an assembly tree: a handful of fronts, no one-workgroup panel fronts among them):
+// workgroup 0 of a front factors the diagonal block, workgroups 1 .. nstrips solve the rows below it behind that factorisation (front_trsm_follow<SIGNAL>),
+// the others are the half / quarter tiles of the trailing update (the body of k_syrk_half_fronts): a tile requests C, waits until the two 128-row strips it
+// multiplies are there (done[ti], done[tj] at eight waves each) and then runs as before -- its launch, its C fetch and the update's prologue no longer sit
+// behind the panel solve.  Producers always have the lower block index within their front: dispatched first, no deadlock whatever part of the grid is resident.
+template <int SPLIT>
+__global__ __launch_bounds__(POTRF_THREADS) void k_front_panel_step(const FrontJob* __restrict__ jobs, int panel, int nstrips, int* __restrict__ info, double* __restrict__ rdiag)
+{
+    const FrontJob j = jobs[blockIdx.y];
+    int k, nb, rs;
+    if (j.kind != 0 || !front_panel(j, panel, k, nb, rs)) return;
+    int* cnt = j.cnt + FRONT_CNT_INTS * panel;
+    int* done = cnt + 16;
+    const int bx = (int)blockIdx.x;
+    if (bx == 0) {
+        potrf_diag_body<true>(j.F + k + (size_t)k * j.f, j.f, nb, j.first + k, info, rdiag, j.dvec, rs > 0 ? j.pack : nullptr, nullptr, nullptr, min(8, (nb + 15) >> 4), rs > 0 ? cnt : nullptr, true);
+        return;
+    }
+    if (bx <= nstrips) {
+        const int strip = bx - 1;
+        if (strip * TS >= rs) return;
+        front_trsm_follow<true, true>(j.F, j.f, k, nb, j.f, j.pack, rdiag + j.first, cnt, strip, info, j.first + k, done);
+        return;
+    }
+    if (rs <= 0) return;
+    const int T = (rs + TS - 1) / TS;
+    const int b = (bx - 1 - nstrips) / SPLIT, h = (bx - 1 - nstrips) % SPLIT;
+    if (b >= T * (T + 1) / 2) return;
+    int ti = (int)((sqrt(8.0 * (double)b + 1.0) - 1.0) * 0.5);
+    while ((ti + 1) * (ti + 2) / 2 <= b) ++ti;
+    while (ti * (ti + 1) / 2 > b) --ti;
+    const int tj = b - ti * (ti + 1) / 2;
+    if (ti * TS + (TS / SPLIT) * h >= rs) return;  // (nothing in this part)
+    SyrkArgs a;
+    a.n = rs; a.kdim = nb;
+    a.A = j.F + (k + nb) + (size_t)k * j.f; a.lda = j.f; a.B = a.A; a.ldb = j.f; a.w = j.dvec;
+    a.C = j.F + (k + nb) + (size_t)(k + nb) * j.f; a.ldc = j.f;
+    a.unaligned = ((j.f & 1) || (reinterpret_cast<uintptr_t>(a.A) & 15)) ? 1 : 0;
+    a.late_p[0] = done + ti; a.late_w[0] = POTRF_THREADS / 64; a.late_p[1] = done + tj; a.late_w[1] = POTRF_THREADS / 64;
+    a.fuse_abort = cnt + 8;  // (a word nobody sets: the bounded waits look at it)
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    (void)fused_tile<512, false, true, true, SPLIT == 4>(a, ti, tj, smem, h);
 }
 
 // one panel step of the partial LDLt of many fronts: diagonal blocks and panels (two launches whatever the number of fronts), then the trailing updates
@@ -2220,6 +2298,8 @@ static void front_attrs()
     PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_diag_fronts), hipFuncAttributeMaxDynamicSharedMemorySize, POTRF_LDS_BYTES));
     PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_trsm_panel_fronts), hipFuncAttributeMaxDynamicSharedMemorySize, TRSM_LDS_BYTES));
     PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_trsm_fronts), hipFuncAttributeMaxDynamicSharedMemorySize, POTRF_LDS_BYTES));
+    PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_front_panel_step<2>), hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS_BYTES));
+    PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_front_panel_step<4>), hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS_BYTES));
     PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk_lower_fronts<4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, SYRK_LDS_BYTES));
     PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk_half_fronts<2>), hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS_BYTES));
     PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk_half_fronts<4>), hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS_BYTES));
@@ -2240,19 +2320,32 @@ void launch_front_diag_panels(const FrontJob* jobs, int njobs, int panel, int ma
     if (max_rows_below > 0) hipLaunchKernelGGL(k_trsm_panel_fronts, dim3(div_up(max_rows_below, TRSM_ROWS), njobs), dim3(256), TRSM_LDS_BYTES, s, jobs, panel, rdiag);
     PQ_HIP(hipGetLastError());
 }
-void launch_front_updates(const FrontJob* jobs, int njobs, int panel, int max_rows_below, hipStream_t s)
+bool launch_front_panel_step(const FrontJob* jobs, int njobs, int panel, int max_rows_below, int* info, double* rdiag, hipStream_t s)
+{
+    static const bool off = debug_token("front_no_follow") != nullptr || debug_token("front_no_step") != nullptr || debug_token("front_updates_whole_tiles") != nullptr;
+    if (off || njobs <= 0 || max_rows_below <= 0 || panel >= FRONT_CNT_PANELS) return false;
+    const int T = div_up(max_rows_below, TS);
+    if (T > 16 || (long long)njobs * T * (T + 1) > 256) return false;  // (the levels whose updates take half or quarter tiles anyway: launch_front_updates)
+    front_attrs();
+    const int nstrips = T;
+    if ((long long)njobs * T * (T + 1) * 2 <= 256) hipLaunchKernelGGL(k_front_panel_step<4>, dim3(1 + nstrips + 2 * T * (T + 1), njobs), dim3(POTRF_THREADS), FUSED_LDS_BYTES, s, jobs, panel, nstrips, info, rdiag);
+    else hipLaunchKernelGGL(k_front_panel_step<2>, dim3(1 + nstrips + T * (T + 1), njobs), dim3(POTRF_THREADS), FUSED_LDS_BYTES, s, jobs, panel, nstrips, info, rdiag);
+    PQ_HIP(hipGetLastError());
+    return true;
+}
+void launch_front_updates(const FrontJob* jobs, int njobs, int panel, int max_rows_below, hipStream_t s, int kind)
 {
     if (njobs <= 0 || max_rows_below <= 0) return;
     front_attrs();
     const int T = div_up(max_rows_below, TS);
     static const bool no_half = debug_token("front_updates_whole_tiles") != nullptr;
     if (!no_half && (long long)njobs * T * (T + 1) <= 256) {  // few tiles (the top of the tree): two or four workgroups per tile, every workgroup on its own CU
-        if ((long long)njobs * T * (T + 1) * 2 <= 256) hipLaunchKernelGGL(k_syrk_half_fronts<4>, dim3(2 * T * (T + 1), njobs), dim3(512), FUSED_LDS_BYTES, s, jobs, panel);
-        else hipLaunchKernelGGL(k_syrk_half_fronts<2>, dim3(T * (T + 1), njobs), dim3(512), FUSED_LDS_BYTES, s, jobs, panel);
+        if ((long long)njobs * T * (T + 1) * 2 <= 256) hipLaunchKernelGGL(k_syrk_half_fronts<4>, dim3(2 * T * (T + 1), njobs), dim3(512), FUSED_LDS_BYTES, s, jobs, panel, kind);
+        else hipLaunchKernelGGL(k_syrk_half_fronts<2>, dim3(T * (T + 1), njobs), dim3(512), FUSED_LDS_BYTES, s, jobs, panel, kind);
         PQ_HIP(hipGetLastError());
         return;
     }
-    hipLaunchKernelGGL((k_syrk_lower_fronts<4, 4>), dim3(T * (T + 1) / 2, njobs), dim3(1024), SYRK_LDS_BYTES, s, jobs, panel);
+    hipLaunchKernelGGL((k_syrk_lower_fronts<4, 4>), dim3(T * (T + 1) / 2, njobs), dim3(1024), SYRK_LDS_BYTES, s, jobs, panel, kind);
     PQ_HIP(hipGetLastError());
 }
 

@@ -2365,7 +2365,7 @@ private:
         B.scratch.alloc(need);
         (void)widest;
         std::vector<dense::FrontJob> jobs(B.total);
-        B.cnt.alloc((size_t)B.total * 8 * dense::FRONT_CNT_PANELS);
+        B.cnt.alloc((size_t)B.total * dense::FRONT_CNT_INTS * dense::FRONT_CNT_PANELS);
         for (int l = 0; l + 1 < (int)B.ptr.size(); ++l) {
             const int nl = B.ptr[l + 1] - B.ptr[l];
             double* packs = B.scratch.p + (size_t)nl * dense::FACTOR_NB;
@@ -2378,7 +2378,7 @@ private:
                 j.kind = panel_front(j.f, j.w) ? 1 : 0;
                 j.dvec = B.scratch.p + (size_t)(q - B.ptr[l]) * dense::FACTOR_NB;
                 j.pack = j.kind == 0 ? packs + (size_t)(nd++) * dense::FACTOR_PACK_DOUBLES : nullptr;
-                j.cnt = B.cnt.p + (size_t)q * 8 * dense::FRONT_CNT_PANELS;
+                j.cnt = B.cnt.p + (size_t)q * dense::FRONT_CNT_INTS * dense::FRONT_CNT_PANELS;
             }
         }
         upload_vec(B.list, list, st_);
@@ -2396,7 +2396,7 @@ private:
     void factor_levels(const FrontMeta& M, const std::vector<int>& ptr, const int* sn_dev, const std::vector<int>& lds, const BigLevels& B, int lend = 1 << 30)
     {
         if (B.total > 0) {
-            PQ_HIP(hipMemsetAsync(B.cnt.p, 0, (size_t)B.total * 8 * dense::FRONT_CNT_PANELS * sizeof(int), st_));
+            PQ_HIP(hipMemsetAsync(B.cnt.p, 0, (size_t)B.total * dense::FRONT_CNT_INTS * dense::FRONT_CNT_PANELS * sizeof(int), st_));
             for (int q0 = 0; q0 < B.total; q0 += 65535) {  // (grid.y limit)
                 const int nq = std::min(65535, B.total - q0);
                 hipLaunchKernelGGL(k_big_zero, dim3((unsigned)std::min<long long>(256, ((long long)B.max_f * B.max_f + 255) / 256), nq), dim3(256), 0, st_, M, fronts_.p, B.list.p + q0);
@@ -2422,10 +2422,23 @@ private:
                                    B.jobs.p, rdiag_.p, info_.p);
             if (fork) PQ_HIP(hipEventRecord(ev_join_, st2_));
             if (nbig <= 0) continue;
+            static const bool joint_updates = debug_token("front_joint_updates") != nullptr;
             for (int pn = 0; pn < (int)B.rows_below[l].size(); ++pn) {
-                if (B.ndense[l] > 0) dense::launch_front_diag_panels(B.jobs.p + B.ptr[l], nbig, pn, B.rows_below[l][pn], info_.p, rdiag_.p, st_, true);
+                // The big fronts' own panel step needs nothing from the second stream: diagonal block, panel rows and trailing update -- in one launch where the
+                // level is few enough fronts for half / quarter tiles -- run before the join; only the Schur complements of the panel fronts (factored by the
+                // one-workgroup launch next door, single panel) wait for it.  (One update launch for both kinds behind the join left the big fronts' update
+                // waiting for the 45-65 us pivot loops of the panel fronts at ten levels of CONT-201.)
+                const bool split = fork && pn == 0 && B.npanel[l] > 0 && B.ndense[l] > 0 && !joint_updates;
+                bool done_big = false;
+                if (B.ndense[l] > 0 && (B.npanel[l] == 0 || split || pn > 0))  // (a panel front has one panel: nothing of its kind beyond pn = 0)
+                    done_big = dense::launch_front_panel_step(B.jobs.p + B.ptr[l], nbig, pn, B.rows_below[l][pn], info_.p, rdiag_.p, st_);
+                if (!done_big) {
+                    if (B.ndense[l] > 0) dense::launch_front_diag_panels(B.jobs.p + B.ptr[l], nbig, pn, B.rows_below[l][pn], info_.p, rdiag_.p, st_, true);
+                    if (split) dense::launch_front_updates(B.jobs.p + B.ptr[l], nbig, pn, B.rows_below[l][pn], st_, 0);
+                }
                 if (fork && pn == 0) PQ_HIP(hipStreamWaitEvent(st_, ev_join_, 0));
-                dense::launch_front_updates(B.jobs.p + B.ptr[l], nbig, pn, B.rows_below[l][pn], st_);
+                if (split) dense::launch_front_updates(B.jobs.p + B.ptr[l], nbig, pn, B.rows_below[l][pn], st_, 1);
+                else if (!done_big) dense::launch_front_updates(B.jobs.p + B.ptr[l], nbig, pn, B.rows_below[l][pn], st_);
             }
         }
     }
