@@ -2285,9 +2285,10 @@ __global__ __launch_bounds__(POTRF_THREADS) void k_front_panel_step(const FrontJ
     a.C = j.F + (k + nb) + (size_t)(k + nb) * j.f; a.ldc = j.f;
     a.unaligned = ((j.f & 1) || (reinterpret_cast<uintptr_t>(a.A) & 15)) ? 1 : 0;
     a.late_p[0] = done + ti; a.late_w[0] = POTRF_THREADS / 64; a.late_p[1] = done + tj; a.late_w[1] = POTRF_THREADS / 64;
-    a.fuse_abort = cnt + 8;  // (a word nobody sets: the bounded waits look at it)
+    a.fuse_abort = cnt + 8;  // (only a wait that gave up sets it; zeroed with the counters before every factorisation)
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    (void)fused_tile<512, false, true, true, SPLIT == 4>(a, ti, tj, smem, h);
+    // a strip never arrived (bounded wait; cannot happen with a healthy device): the tile is left as it was and the factorisation is reported as failed
+    if (!fused_tile<512, false, true, true, SPLIT == 4>(a, ti, tj, smem, h) && threadIdx.x == 0 && *info < 0) *info = j.first + k;
 }
 
 // one panel step of the partial LDLt of many fronts: diagonal blocks and panels (two launches whatever the number of fronts), then the trailing updates
