@@ -219,10 +219,14 @@ __device__ __forceinline__ bool chol_wait3(const int* p0, int w0, const int* p1,
 // k_syrk_lower<EPI_SUBTRACT> -- the quasi-definite fronts lose accuracy when the accumulators start from C -- with this function's
 // operand staging (every stage requested at once) and, with HALF, two workgroups per tile.
 // QUARTER (with HALF, front updates only): rows [32 h, 32 h + 32), the waves as 1 x 8 (32 x 16 each) -- four workgroups per tile where even halves leave the chip empty.
-template <int NT, bool PERSIST, bool HALF = false, bool SUMSUB = false, bool QUARTER = false>
+// FOLLOW (k_front_panel_step, with HALF and SUMSUB): the operand rows are being solved by other workgroups of the same launch, 16 columns at a time -- K stage kt
+// is requested when both row strips have counted step kt (late_p[q][kt] reaching late_w[q]), so the tile's K loop runs one stage behind the panel solve instead
+// of starting after it.  Same products in the same order.
+template <int NT, bool PERSIST, bool HALF = false, bool SUMSUB = false, bool QUARTER = false, bool FOLLOW = false>
 __device__ __forceinline__ bool fused_tile(const SyrkArgs& a, const int ti, const int tj, double* __restrict__ smem, const int h = 0)
 {
     static_assert(!QUARTER || HALF, "QUARTER refines HALF");
+    static_assert(!FOLLOW || (HALF && SUMSUB && !PERSIST), "FOLLOW: the front tiles");
     constexpr int SPLIT = QUARTER ? 4 : (HALF ? 2 : 1);
     constexpr int WR = 4 / SPLIT, WC = 8 / WR;
     static_assert(NT == 64 * WR * WC, "eight waves");
@@ -263,14 +267,54 @@ __device__ __forceinline__ bool fused_tile(const SyrkArgs& a, const int ti, cons
     if (tr_row) a.fuse_tr2[48] = wall_clock64();
     // (persistent launch, panel tiles: the operand rows come from the panel tasks of the round before, later than the tile itself -- wait for them with the
     // tile's loads in flight; front panel steps in one launch, k_front_panel_step: the operand rows are solved by other workgroups of the same launch)
-    if (a.late_p[0] && !chol_wait3(nullptr, 0, a.late_p[0], a.late_w[0], a.late_p[1], a.late_w[1], a.fuse_abort, 0)) return false;
+    if constexpr (!FOLLOW) {
+        if (a.late_p[0] && !chol_wait3(nullptr, 0, a.late_p[0], a.late_w[0], a.late_p[1], a.late_w[1], a.fuse_abort, 0)) return false;
+    }
     if (tr_row) a.fuse_tr2[49] = wall_clock64();
     const bool dbg_tile = FUSE_TS_ON && !PERSIST && a.fuse_ts && threadIdx.x == 0 && ti == 2 && tj == 1;  // debugging aid: an ordinary tile's timeline
     if (dbg_tile) a.fuse_ts[84] = clock64();
     const bool tr_tile = PERSIST && !HALF && a.fuse_tr2 && threadIdx.x == 0 && ti == 5 && tj == 3;  // PIQP_AMD_DEBUG=chol_trace: one bulk tile per round
     if (tr_tile) a.fuse_tr2[40] = wall_clock64();
     const int nkt = (a.kdim + BK - 1) / BK;  // <= 8
-    {
+    if constexpr (FOLLOW) {
+        constexpr int PER = 1024 / NT;
+        double* A2 = smem;                     // [2][BK][LDS_LD]: stage kt in slot kt & 1
+        double* B2 = smem + 2 * BK * LDS_LD;
+#pragma unroll 1
+        for (int kt = 0; kt < nkt; ++kt) {
+            if (!chol_wait3(nullptr, 0, a.late_p[0] + kt, a.late_w[0], a.late_p[1] + kt, a.late_w[1], a.fuse_abort, 1)) return false;  // (polls 0.4 us apart: a grid of tight pollers slows what it waits for)
+            const int k0 = kt * BK;
+            d2 pa0[PER], pb0[PER];
+            // (agent-scope loads: a 128-byte line at a strip boundary may sit in this XCD's L2 with the old values of the neighbouring strip)
+            if ((tid & 63) < ROWS / 2) load_tile_agent_chk<NT>(a.A, a.lda, row0, k0, a.n, a.kdim, tid, pa0);
+            else { for (int it = 0; it < PER; ++it) pa0[it] = (d2){0.0, 0.0}; }
+            load_tile_agent_chk<NT>(a.B, a.ldb, col0, k0, a.n, a.kdim, tid, pb0);
+            scale_tile<true, NT, !SUMSUB, true>(a.w, k0, a.kdim, tid, pb0);
+            const int q = kt & 1;
+            store_tile<NT>(A2 + q * BK * LDS_LD, tid, pa0);
+            store_tile<NT>(B2 + q * BK * LDS_LD, tid, pb0);
+            __syncthreads();  // (also: every wave is done with the other slot's previous stage before anybody writes it again)
+            if (!skip_wave) {
+                const double* Asb = A2 + q * BK * LDS_LD + wr * SUBR + (lane & 15);
+                const double* Bsb = B2 + q * BK * LDS_LD + wc * SUBC + (lane & 15);
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int kk = ks * 4 + (lane >> 4);
+                    double af[MTR], bf[MTC];
+#pragma unroll
+                    for (int u = 0; u < MTR; ++u) af[u] = Asb[kk * LDS_LD + u * 16];
+#pragma unroll
+                    for (int u = 0; u < MTC; ++u) bf[u] = Bsb[kk * LDS_LD + u * 16];
+#pragma unroll
+                    for (int x = 0; x < MTC; ++x)
+#pragma unroll
+                        for (int y = 0; y < MTR; ++y)
+                            acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[x], af[y], acc[x][y], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    } else {
         constexpr int PER = 1024 / NT;
         d2 pa[8][PER], pb[8][PER];
 #pragma unroll
@@ -2171,12 +2215,20 @@ __device__ __forceinline__ void front_trsm_follow(double* __restrict__ A_, int l
         }
     const int nact = min(8, (nb + 15) >> 4);
     bool alive = true;
+    int last = -1;  // SIGNAL: the step whose rows this wave has stored but not counted yet
     d4 rd[8];  // reciprocal pivots of this lane's columns, requested with the pieces of their step (asked for at the end they were a round trip behind the last step)
 #pragma unroll
     for (int k = 0; k < 8; ++k) rd[k] = (d4){1.0, 1.0, 1.0, 1.0};
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         if (16 * k >= nb) break;  // (padding beyond a short panel: nothing to solve, nothing stored)
+        if constexpr (SIGNAL) {
+            // the 16 solved columns of the step before have landed by now or shortly: count them (the trailing tiles of this launch run one K stage behind)
+            if (last >= 0) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) addi_agent(done + 8 * strip + last, 1);
+            }
+        }
         if (alive) {
             unsigned spins = 0;
             while (__builtin_amdgcn_readfirstlane(ldi_agent(cnt + k)) < nact - k) {
@@ -2204,6 +2256,16 @@ __device__ __forceinline__ void front_trsm_follow(double* __restrict__ A_, int l
         const d4 one = {1.0, 1.0, 1.0, 1.0};
         tile_trsm_rt<LDLT, false>(x, lkk, one, lane);
         T[k] = x;
+        if constexpr (SIGNAL) {
+            if (row_ok) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int c = 16 * k + g + 4 * r;
+                    if (c < nb) st_agent((double*)(Ar + (size_t)c * lda), LDLT ? x[r] * rd[k][r] : x[r]);
+                }
+            }
+            last = k;
+        }
 #pragma unroll
         for (int j = k + 1; j < 8; ++j) {
 #pragma unroll
@@ -2211,6 +2273,13 @@ __device__ __forceinline__ void front_trsm_follow(double* __restrict__ A_, int l
         }
     }
     if (!alive && lane == 0 && *info < 0) *info = kglobal;
+    if constexpr (SIGNAL) {
+        if (last >= 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) addi_agent(done + 8 * strip + last, 1);
+        }
+        return;
+    }
     if (row_ok) {
 #pragma unroll
         for (int j = 0; j < 8; ++j)
@@ -2220,14 +2289,9 @@ __device__ __forceinline__ void front_trsm_follow(double* __restrict__ A_, int l
                 if (c < nb) {
                     double v = T[j][r];
                     if (LDLT) v *= rd[j][r];
-                    if constexpr (SIGNAL) st_agent((double*)(Ar + (size_t)c * lda), v);
-                    else Ar[(size_t)c * lda] = v;
+                    Ar[(size_t)c * lda] = v;
                 }
             }
-    }
-    if constexpr (SIGNAL) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) addi_agent(done + strip, 1);
     }
 }
 // diagonal block (workgroup 0) and the rows below it (workgroups 1 ..: 128 rows each) of panel `panel` of every front of the list, one launch
@@ -2258,7 +2322,7 @@ __global__ __launch_bounds__(POTRF_THREADS) void k_front_panel_step(const FrontJ
     int k, nb, rs;
     if (j.kind != 0 || !front_panel(j, panel, k, nb, rs)) return;
     int* cnt = j.cnt + FRONT_CNT_INTS * panel;
-    int* done = cnt + 16;
+    int* done = cnt + 32;  // [strip][step]: waves of the strip whose 16 columns of that step have landed
     const int bx = (int)blockIdx.x;
     if (bx == 0) {
         potrf_diag_body<true>(j.F + k + (size_t)k * j.f, j.f, nb, j.first + k, info, rdiag, j.dvec, rs > 0 ? j.pack : nullptr, nullptr, nullptr, min(8, (nb + 15) >> 4), rs > 0 ? cnt : nullptr, true);
@@ -2284,11 +2348,11 @@ __global__ __launch_bounds__(POTRF_THREADS) void k_front_panel_step(const FrontJ
     a.A = j.F + (k + nb) + (size_t)k * j.f; a.lda = j.f; a.B = a.A; a.ldb = j.f; a.w = j.dvec;
     a.C = j.F + (k + nb) + (size_t)(k + nb) * j.f; a.ldc = j.f;
     a.unaligned = ((j.f & 1) || (reinterpret_cast<uintptr_t>(a.A) & 15)) ? 1 : 0;
-    a.late_p[0] = done + ti; a.late_w[0] = POTRF_THREADS / 64; a.late_p[1] = done + tj; a.late_w[1] = POTRF_THREADS / 64;
+    a.late_p[0] = done + 8 * ti; a.late_w[0] = POTRF_THREADS / 64; a.late_p[1] = done + 8 * tj; a.late_w[1] = POTRF_THREADS / 64;
     a.fuse_abort = cnt + 8;  // (only a wait that gave up sets it; zeroed with the counters before every factorisation)
     extern __shared__ __attribute__((aligned(16))) double smem[];
     // a strip never arrived (bounded wait; cannot happen with a healthy device): the tile is left as it was and the factorisation is reported as failed
-    if (!fused_tile<512, false, true, true, SPLIT == 4>(a, ti, tj, smem, h) && threadIdx.x == 0 && *info < 0) *info = j.first + k;
+    if (!fused_tile<512, false, true, true, SPLIT == 4, true>(a, ti, tj, smem, h) && threadIdx.x == 0 && *info < 0) *info = j.first + k;
 }
 
 // one panel step of the partial LDLt of many fronts: diagonal blocks and panels (two launches whatever the number of fronts), then the trailing updates

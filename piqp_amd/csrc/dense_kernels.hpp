@@ -105,10 +105,11 @@ struct FrontJob {
     int kind = 0;                 // 0: diagonal block + panel by launch_front_diag_panels; 1: the caller factors the (single, w <= FACTOR_NB) panel
                                   //    itself and leaves D in dvec -- only the trailing update runs here
     int* cnt = nullptr;           // FRONT_CNT_INTS x FRONT_CNT_PANELS counters of this front's panels (zeroed by the caller before every factorisation): per panel
-                                  //    [0, 8) steps of the diagonal block, [8] a word nobody sets, [16, 32) solved 128-row strips below it -- the panel rows follow
-                                  //    the diagonal block inside one launch (k_potrf_trsm_fronts), the trailing tiles the rows (k_front_panel_step)
+                                  //    [0, 8) steps of the diagonal block, [8] a word only a wait that gave up sets, [32, 160) per 128-row strip below it (<= 16) and
+                                  //    step: waves whose 16 solved columns have landed -- the panel rows follow the diagonal block inside one launch
+                                  //    (k_potrf_trsm_fronts), the trailing tiles the rows, one K stage behind (k_front_panel_step)
 };
-constexpr int FRONT_CNT_PANELS = 16, FRONT_CNT_INTS = 32;
+constexpr int FRONT_CNT_PANELS = 16, FRONT_CNT_INTS = 160;
 // follow: the jobs carry zeroed step counters (FrontJob::cnt)
 void launch_front_diag_panels(const FrontJob* jobs_device, int njobs, int panel, int max_rows_below, int* info, double* rdiag, hipStream_t s, bool follow = false);
 void launch_front_updates(const FrontJob* jobs_device, int njobs, int panel, int max_rows_below, hipStream_t s, int kind = -1);  // kind: only the fronts of that kind
