@@ -333,6 +333,8 @@ __device__ __forceinline__ void front_factor_body(const FrontMeta& M, double* __
         const double* colk = W + (k + 1) + (long long)k * f;
         // W[i,j] -= (a_i / d) * a_j for k < j < w, i >= j, with the UNSCALED column k (column k is final after this step: its
         // scaling by 1/d is deferred to one pass after the loop -> one barrier per pivot instead of two)
+        // (Round 3 tried two columns of a thread's stride per pass, the scaled entry a_i / d read once for both -- five LDS accesses per two multiply-adds
+        // instead of six, bitwise the same: CONT-201 factorisation 2.29 instead of 2.21 ms, C3 unchanged.  Not kept.)
         {
             const int tx = tid & 15, ty = tid >> 4, tys = nt >> 4;
             for (int j = ty; j < pc; j += tys) {
