@@ -394,7 +394,7 @@ __device__ __forceinline__ void front_factor(const FrontMeta& M, double* __restr
 // One workgroup per front of an assembly-tree level.  Fronts on the multi-workgroup path (job_of[s] >= 0) were assembled by its kernels: a big
 // front is left to the dense kernels, a panel_front() has its panel factored here (D left in the job's dvec for the trailing update) -- in the
 // same launch as the level's one-workgroup fronts, which are independent of it.
-__global__ __launch_bounds__(256) void k_front_factor(FrontMeta M, double* __restrict__ fronts, const int* __restrict__ list, const int* __restrict__ job_of,
+__global__ __launch_bounds__(1024) void k_front_factor(FrontMeta M, double* __restrict__ fronts, const int* __restrict__ list, const int* __restrict__ job_of,
                                                       const dense::FrontJob* __restrict__ jobs, double* __restrict__ rdiag, int* __restrict__ info)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -2419,8 +2419,13 @@ private:
             const bool fork = small && nbig > 0 && B.ndense[l] > 0 && !no_fork_;
             hipStream_t ss = st_;
             if (fork) { PQ_HIP(hipEventRecord(ev_fork_, st_)); PQ_HIP(hipStreamWaitEvent(st2_, ev_fork_, 0)); ss = st2_; }
+            // (a level that holds panel fronts -- 130-220 rows, up to 128 pivots at 0.3 us each in one workgroup's LDS pivot loop, the longest item of ten levels
+            // of CONT-201 -- runs its one-workgroup launch with eight waves: two per SIMD hide each other's LDS round trips; the work of an entry does not
+            // depend on the thread that does it)
+            static const bool ff256 = debug_token("front_factor_256") != nullptr;
+            const int ff_threads = (!ff256 && nbig > 0 && B.npanel[l] > 0) ? 1024 : 256;
             if (small)
-                hipLaunchKernelGGL(k_front_factor, dim3(cnt), dim3(256), std::max(lds[l], nbig > 0 ? B.panel_lds[l] : 0), ss, M, fronts_.p, sn_dev + ptr[l], B.total > 0 ? B.job_of.p : (const int*)nullptr,
+                hipLaunchKernelGGL(k_front_factor, dim3(cnt), dim3(ff_threads), std::max(lds[l], nbig > 0 ? B.panel_lds[l] : 0), ss, M, fronts_.p, sn_dev + ptr[l], B.total > 0 ? B.job_of.p : (const int*)nullptr,
                                    B.jobs.p, rdiag_.p, info_.p);
             if (fork) PQ_HIP(hipEventRecord(ev_join_, st2_));
             if (nbig <= 0) continue;
