@@ -879,11 +879,11 @@ __device__ __forceinline__ double wide_wave_sum(double v)
 
 struct WideFwdOps { double Lt[WIDE_B], Lr0[WIDE_B], Lr1[WIDE_B]; };  // triangle row (wave 0, lane = row), two rows below the block per thread
 
-__global__ __launch_bounds__(WIDE_NT) void k_front_fwd_wide(FrontMeta M, const double* __restrict__ fronts, const int* __restrict__ list, double* __restrict__ x,
-                                                            double* __restrict__ fvec, int fcap)
+__device__ __forceinline__ void front_fwd_wide_body(const FrontMeta& M, const double* __restrict__ fronts, const int* __restrict__ list, double* __restrict__ x,
+                                                    double* __restrict__ fvec, int fcap, const int bid)
 {
     extern __shared__ __attribute__((aligned(16))) double vs[];
-    const int s = list[blockIdx.x];
+    const int s = list[bid];
     const SnRec me = M.sn[s];
     const int first = me.first, w = me.w, f = me.f;
     if (f > fcap) { front_fwd(M, fronts, s, x, fvec); return; }
@@ -998,15 +998,20 @@ __global__ __launch_bounds__(WIDE_NT) void k_front_fwd_wide(FrontMeta M, const d
         v[i] = t;
     }
 }
+__global__ __launch_bounds__(WIDE_NT) void k_front_fwd_wide(FrontMeta M, const double* __restrict__ fronts, const int* __restrict__ list, double* __restrict__ x,
+                                                            double* __restrict__ fvec, int fcap)
+{
+    front_fwd_wide_body(M, fronts, list, x, fvec, fcap, (int)blockIdx.x);
+}
 
 constexpr int WIDE_CPW = WIDE_B / (WIDE_NT / 64);  // backward: columns per wave
 struct WideBwdOps { double Lt[WIDE_B], col[WIDE_CPW][WIDE_BCH]; };  // triangle column (wave 0, lane = column), this wave's columns below the block
 
-__global__ __launch_bounds__(WIDE_NT) void k_front_bwd_wide(FrontMeta M, const double* __restrict__ fronts, const int* __restrict__ list, double* __restrict__ x,
-                                                            double* __restrict__ fvec, int fcap)
+__device__ __forceinline__ void front_bwd_wide_body(const FrontMeta& M, const double* __restrict__ fronts, const int* __restrict__ list, double* __restrict__ x,
+                                                    double* __restrict__ fvec, int fcap, const int bid)
 {
     extern __shared__ __attribute__((aligned(16))) double vs[];
-    const int s = list[blockIdx.x];
+    const int s = list[bid];
     const SnRec me = M.sn[s];
     const int first = me.first, w = me.w, f = me.f;
     if (f > fcap) { front_bwd(M, fronts, s, x, fvec); return; }
@@ -1103,6 +1108,11 @@ __global__ __launch_bounds__(WIDE_NT) void k_front_bwd_wide(FrontMeta M, const d
     }
     for (int i = tid; i < w; i += WIDE_NT) x[first + i] = vs[i];
 }
+__global__ __launch_bounds__(WIDE_NT) void k_front_bwd_wide(FrontMeta M, const double* __restrict__ fronts, const int* __restrict__ list, double* __restrict__ x,
+                                                            double* __restrict__ fvec, int fcap)
+{
+    front_bwd_wide_body(M, fronts, list, x, fvec, fcap, (int)blockIdx.x);
+}
 
 // ---- single-wave subtree substitution: the front vector lives in registers (rows lane and lane + 64, fronts of a workgroup subtree have at
 // most SUB_FMAX <= 128 rows), pivots are broadcast with v_readlane, the panel columns are read straight from HBM with the loads of four
@@ -1177,16 +1187,16 @@ __device__ __forceinline__ void touch_done(const PanelTouch& p)
     asm volatile("" ::"v"(acc));
 }
 template <bool TOP>
-__global__ __launch_bounds__(64) void k_subtree_fwd_wave(FrontMeta M, const double* __restrict__ fronts, const int* __restrict__ sub_lo, const int* __restrict__ sub_hi,
-                                                         double* __restrict__ x, double* __restrict__ fvec, const int* __restrict__ top_pos, int* __restrict__ flags,
-                                                         int* __restrict__ err, const int* __restrict__ child_tp, int epoch)
+__device__ __forceinline__ void subtree_fwd_wave_body(const FrontMeta& M, const double* __restrict__ fronts, const int* __restrict__ sub_lo, const int* __restrict__ sub_hi,
+                                                      double* __restrict__ x, double* __restrict__ fvec, const int* __restrict__ top_pos, int* __restrict__ flags,
+                                                      int* __restrict__ err, const int* __restrict__ child_tp, int epoch, const int bid)
 {
     __shared__ double sv[2][128];
     const int lane = threadIdx.x, r0 = lane, r1 = lane + 64;
     // TOP: the walk is a chain of top supernodes (parent[t] == t + 1); children outside the walk are waited for by flag
-    const int lo = sub_lo[blockIdx.x], hi = sub_hi[blockIdx.x];
+    const int lo = sub_lo[bid], hi = sub_hi[bid];
     long long* const dbg = TOP ? g_dbg_ts : nullptr;
-    if (dbg && lane == 0) dbg[3 * blockIdx.x] = wall_clock64();
+    if (dbg && lane == 0) dbg[3 * bid] = wall_clock64();
     int cur = 0;
     bool prev_valid = false;  // sv[cur ^ 1][0 .. u) = update vector of supernode s - 1
     SnRec me = M.sn[lo];
@@ -1228,7 +1238,7 @@ __global__ __launch_bounds__(64) void k_subtree_fwd_wave(FrontMeta M, const doub
                 if (tp >= 0) wave_wait_flag(flags + tp, err, epoch);
             }
             touch_done(pt);
-            if (dbg && lane == 0 && s == lo) dbg[3 * blockIdx.x + 1] = wall_clock64();
+            if (dbg && lane == 0 && s == lo) dbg[3 * bid + 1] = wall_clock64();
             if (r0 < f) a[r0] = xa0;
             if (r1 < f) a[r1] = xa1;
             __syncthreads();
@@ -1301,20 +1311,27 @@ __global__ __launch_bounds__(64) void k_subtree_fwd_wave(FrontMeta M, const doub
         me = nxt;
     }
     if (TOP) wave_publish_flag(flags + top_pos[hi], epoch);
-    if (dbg && lane == 0) dbg[3 * blockIdx.x + 2] = wall_clock64();
+    if (dbg && lane == 0) dbg[3 * bid + 2] = wall_clock64();
+}
+template <bool TOP>
+__global__ __launch_bounds__(64) void k_subtree_fwd_wave(FrontMeta M, const double* __restrict__ fronts, const int* __restrict__ sub_lo, const int* __restrict__ sub_hi,
+                                                         double* __restrict__ x, double* __restrict__ fvec, const int* __restrict__ top_pos, int* __restrict__ flags,
+                                                         int* __restrict__ err, const int* __restrict__ child_tp, int epoch)
+{
+    subtree_fwd_wave_body<TOP>(M, fronts, sub_lo, sub_hi, x, fvec, top_pos, flags, err, child_tp, epoch, (int)blockIdx.x);
 }
 // TOP = true: as above for the backward sweep; sub_lo = the level-sorted list, block b takes entry ntop - 1 - b (parents first) and waits
 // for its parent's flag; the ancestors' solution entries are read with agent-scope loads, its own are stored write-through
 template <bool TOP>
-__global__ __launch_bounds__(64) void k_subtree_bwd_wave(FrontMeta M, const double* __restrict__ fronts, const int* __restrict__ sub_lo, const int* __restrict__ sub_hi,
-                                                         double* __restrict__ x, int red_thr, int ntop, const int* __restrict__ top_pos, int* __restrict__ flags,
-                                                         int* __restrict__ err, const int* __restrict__ pub, int epoch, const double* __restrict__ rdiag)
+__device__ __forceinline__ void subtree_bwd_wave_body(const FrontMeta& M, const double* __restrict__ fronts, const int* __restrict__ sub_lo, const int* __restrict__ sub_hi,
+                                                      double* __restrict__ x, int red_thr, int ntop, const int* __restrict__ top_pos, int* __restrict__ flags,
+                                                      int* __restrict__ err, const int* __restrict__ pub, int epoch, const double* __restrict__ rdiag, const int bid)
 {
     __shared__ double sv[2][128];
     const int lane = threadIdx.x, r0 = lane, r1 = lane + 64;
     // TOP: walks in reverse order (ntop = number of walks); the parent of the walk's last supernode is waited for by flag, every
     // supernode of the walk publishes its own flag (children outside the walk hang off any of them)
-    const int wi = TOP ? ntop - 1 - (int)blockIdx.x : (int)blockIdx.x;
+    const int wi = TOP ? ntop - 1 - bid : bid;
     const int lo = sub_lo[wi], hi = sub_hi[wi];
     if (TOP) {
         const SnRec me = M.sn[hi];
@@ -1436,6 +1453,36 @@ __global__ __launch_bounds__(64) void k_subtree_bwd_wave(FrontMeta M, const doub
         if (TOP) { const int tp = top_pos[s]; if (pub[tp]) wave_publish_flag(flags + tp, epoch); }  // only where a child in another walk waits for it
         me = nxt;
     }
+}
+template <bool TOP>
+__global__ __launch_bounds__(64) void k_subtree_bwd_wave(FrontMeta M, const double* __restrict__ fronts, const int* __restrict__ sub_lo, const int* __restrict__ sub_hi,
+                                                         double* __restrict__ x, int red_thr, int ntop, const int* __restrict__ top_pos, int* __restrict__ flags,
+                                                         int* __restrict__ err, const int* __restrict__ pub, int epoch, const double* __restrict__ rdiag)
+{
+    subtree_bwd_wave_body<TOP>(M, fronts, sub_lo, sub_hi, x, red_thr, ntop, top_pos, flags, err, pub, epoch, rdiag, (int)blockIdx.x);
+}
+// A level that holds single-wave fronts AND wide fronts: both kinds in ONE launch (the first nn workgroups run a single-wave front on their wave 0, the
+// other waves leave at once -- a barrier does not wait for finished waves --, the rest are the wide fronts).  The two launches of such a level ran one after
+// the other, 6-13 us each whatever they did.
+__global__ __launch_bounds__(WIDE_NT) void k_level_fwd_mixed(FrontMeta M, const double* __restrict__ fronts, const int* __restrict__ list, int nn, double* __restrict__ x,
+                                                             double* __restrict__ fvec, int fcap)
+{
+    if ((int)blockIdx.x < nn) {
+        if (threadIdx.x >= 64) return;
+        subtree_fwd_wave_body<false>(M, fronts, list, list, x, fvec, nullptr, nullptr, nullptr, nullptr, 0, (int)blockIdx.x);
+        return;
+    }
+    front_fwd_wide_body(M, fronts, list + nn, x, fvec, fcap, (int)blockIdx.x - nn);
+}
+__global__ __launch_bounds__(WIDE_NT) void k_level_bwd_mixed(FrontMeta M, const double* __restrict__ fronts, const int* __restrict__ list, int nn, double* __restrict__ x,
+                                                             double* __restrict__ fvec, int fcap, int red_thr)
+{
+    if ((int)blockIdx.x < nn) {
+        if (threadIdx.x >= 64) return;
+        subtree_bwd_wave_body<false>(M, fronts, list, list, x, red_thr, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, (int)blockIdx.x);
+        return;
+    }
+    front_bwd_wide_body(M, fronts, list + nn, x, fvec, fcap, (int)blockIdx.x - nn);
 }
 
 // ---- the top of the assembly tree in ONE launch: workgroup b takes the top supernodes b, b + G, ... of the level-sorted (=
@@ -2526,6 +2573,8 @@ private:
                 if (l == r.a) hipLaunchKernelGGL(k_subtree_fwd_wave<false>, dim3(r.nwalk), dim3(64), 0, st_, M, fronts_.p, L.walk_lo.p + r.off, L.walk_hi.p + r.off, xp_.p, fvec_.p, (const int*)nullptr, (int*)nullptr, (int*)nullptr, (const int*)nullptr, 0);
                 continue;
             }
+            static const bool two_launches = debug_token("solve_level_two_launches") != nullptr;
+            if (nn > 0 && cnt > nn && !two_launches) { hipLaunchKernelGGL(k_level_fwd_mixed, dim3(cnt), dim3(WIDE_NT), L.lds[l], st_, M, fronts_.p, list, nn, xp_.p, fvec_.p, wide_fcap_); continue; }
             if (nn > 0) hipLaunchKernelGGL(k_subtree_fwd_wave<false>, dim3(nn), dim3(64), 0, st_, M, fronts_.p, list, list, xp_.p, fvec_.p, (const int*)nullptr, (int*)nullptr, (int*)nullptr, (const int*)nullptr, 0);
             if (cnt > nn) hipLaunchKernelGGL(k_front_fwd_wide, dim3(cnt - nn), dim3(WIDE_NT), L.lds[l], st_, M, fronts_.p, list + nn, xp_.p, fvec_.p, wide_fcap_);
         }
@@ -2540,6 +2589,8 @@ private:
                 if (l == r.b) hipLaunchKernelGGL(k_subtree_bwd_wave<false>, dim3(r.nwalk), dim3(64), 0, st_, M, fronts_.p, L.walk_lo.p + r.off, L.walk_hi.p + r.off, xp_.p, bwd_red_thr(), 0, (const int*)nullptr, (int*)nullptr, (int*)nullptr, (const int*)nullptr, 0, (const double*)nullptr);
                 continue;
             }
+            static const bool two_launches = debug_token("solve_level_two_launches") != nullptr;
+            if (nn > 0 && cnt > nn && !two_launches) { hipLaunchKernelGGL(k_level_bwd_mixed, dim3(cnt), dim3(WIDE_NT), L.lds[l], st_, M, fronts_.p, list, nn, xp_.p, fvec_.p, wide_fcap_, bwd_red_thr()); continue; }
             if (cnt > nn) hipLaunchKernelGGL(k_front_bwd_wide, dim3(cnt - nn), dim3(WIDE_NT), L.lds[l], st_, M, fronts_.p, list + nn, xp_.p, fvec_.p, wide_fcap_);
             if (nn > 0) hipLaunchKernelGGL(k_subtree_bwd_wave<false>, dim3(nn), dim3(64), 0, st_, M, fronts_.p, list, list, xp_.p, bwd_red_thr(), 0, (const int*)nullptr, (int*)nullptr, (int*)nullptr, (const int*)nullptr, 0, (const double*)nullptr);
         }

@@ -27,6 +27,7 @@ VARIANTS = {
     "small_subtrees": {"PIQP_AMD_DEBUG": "sub_cols=48,solve_sub_cols=8"},
     "one_launch_per_level": {"PIQP_AMD_DEBUG": "no_level_runs"},  # no merged runs of chain levels in the level-scheduled substitution
     "front_updates_whole_tiles": {"PIQP_AMD_DEBUG": "front_updates_whole_tiles"},  # the generic tile kernel also where the top of the tree takes half tiles
+    "solve_level_two_launches": {"PIQP_AMD_DEBUG": "solve_level_two_launches"},  # substitution: single-wave and wide fronts of a mixed level in two launches instead of one
     "front_factor_256": {"PIQP_AMD_DEBUG": "front_factor_256"},  # the one-workgroup launch of the levels with panel fronts on four waves instead of eight
     "front_joint_updates": {"PIQP_AMD_DEBUG": "front_joint_updates"},  # big fronts' and panel fronts' trailing updates in one launch behind the join of the two streams
     "front_no_step": {"PIQP_AMD_DEBUG": "front_no_step"},  # trailing updates of the top levels in their own launch instead of inside the panel step's
