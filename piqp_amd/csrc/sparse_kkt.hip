@@ -2162,9 +2162,17 @@ private:
     void factor_numeric(const FrontMeta& M)
     {
         PQ_ZONE("piqp_amd::SparseKKT::factor_numeric");  // sparse/ldlt.hpp:109 piqp::LDLt::factorize_numeric
+        // zero-fill, own entries and step counters of the multi-workgroup fronts need nothing from the subtrees: on the second stream, next to the subtree walks
+        const bool pre = top_big_.total > 0 && !no_fork_;
+        if (pre) {
+            PQ_HIP(hipEventRecord(ev_fork_, st_)); PQ_HIP(hipStreamWaitEvent(st2_, ev_fork_, 0));
+            big_prepare(M, top_big_, st2_);
+            PQ_HIP(hipEventRecord(ev_join_, st2_));
+        }
         factor_subtrees(M, sched_);
+        if (pre) PQ_HIP(hipStreamWaitEvent(st_, ev_join_, 0));
         // wide lower levels: one launch per level; the narrow levels near the root (<= 1024 supernodes in total): one persistent launch
-        factor_levels(M, S_.top_level_ptr, level_sn_.p, level_lds_, top_big_, top_l0_);
+        factor_levels(M, S_.top_level_ptr, level_sn_.p, level_lds_, top_big_, top_l0_, pre);
         if (top_nper_ > 0) {
             // flags carry the number of the factorisation that set them (no memset in between; a recorded graph replays fixed arguments,
             // so there they are zeroed and the epoch stays 1)
@@ -2442,16 +2450,20 @@ private:
     }
     // one launch per level of a (possibly filtered) level schedule for the fronts one workgroup factors; the level's big fronts then go through
     // the dense multi-workgroup kernels together: children merged (fixed order), then the blocked partial LDLt panel by panel
-    void factor_levels(const FrontMeta& M, const std::vector<int>& ptr, const int* sn_dev, const std::vector<int>& lds, const BigLevels& B, int lend = 1 << 30)
+    // zero-fill, own K entries and step counters of the multi-workgroup fronts of a level schedule (nothing here depends on the children)
+    void big_prepare(const FrontMeta& M, const BigLevels& B, hipStream_t s)
     {
-        if (B.total > 0) {
-            PQ_HIP(hipMemsetAsync(B.cnt.p, 0, (size_t)B.total * dense::FRONT_CNT_INTS * dense::FRONT_CNT_PANELS * sizeof(int), st_));
-            for (int q0 = 0; q0 < B.total; q0 += 65535) {  // (grid.y limit)
-                const int nq = std::min(65535, B.total - q0);
-                hipLaunchKernelGGL(k_big_zero, dim3((unsigned)std::min<long long>(256, ((long long)B.max_f * B.max_f + 255) / 256), nq), dim3(256), 0, st_, M, fronts_.p, B.list.p + q0);
-                if (B.max_own > 0) hipLaunchKernelGGL(k_big_assemble, dim3(std::min(64, (B.max_own + 255) / 256), nq), dim3(256), 0, st_, M, fronts_.p, B.list.p + q0);
-            }
+        if (B.total <= 0) return;
+        PQ_HIP(hipMemsetAsync(B.cnt.p, 0, (size_t)B.total * dense::FRONT_CNT_INTS * dense::FRONT_CNT_PANELS * sizeof(int), s));
+        for (int q0 = 0; q0 < B.total; q0 += 65535) {  // (grid.y limit)
+            const int nq = std::min(65535, B.total - q0);
+            hipLaunchKernelGGL(k_big_zero, dim3((unsigned)std::min<long long>(256, ((long long)B.max_f * B.max_f + 255) / 256), nq), dim3(256), 0, s, M, fronts_.p, B.list.p + q0);
+            if (B.max_own > 0) hipLaunchKernelGGL(k_big_assemble, dim3(std::min(64, (B.max_own + 255) / 256), nq), dim3(256), 0, s, M, fronts_.p, B.list.p + q0);
         }
+    }
+    void factor_levels(const FrontMeta& M, const std::vector<int>& ptr, const int* sn_dev, const std::vector<int>& lds, const BigLevels& B, int lend = 1 << 30, bool prepared = false)
+    {
+        if (!prepared) big_prepare(M, B, st_);
         for (int l = 0; l + 1 < (int)ptr.size() && l < lend; ++l) {
             const int cnt = ptr[l + 1] - ptr[l];
             if (cnt <= 0) continue;
