@@ -381,20 +381,21 @@ def sparse_legs(args, rank, world, local_rank, dev, pd):
                 fac_s = r["factor_ms"] * 1e-3; sol_s = r["backend_solve_ms"] * 1e-3
                 r["symbolic"] = stt
                 traffic_f = traffic_s = None
-                try:  # rocprofv3 PMC passes of the C3 and CONT-201 workloads (profiles/r02_pmc_sparse_batch.json); other workloads: not measured
+                try:  # rocprofv3 PMC passes of the C3 and CONT-201 workloads (profiles/r02_pmc_sparse_batch.json, r03_pmc_sparse_cont201.json); other workloads: not measured
                     pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_sparse_batch.json")))["sparse_c3"]
                     if key == "C3" and abs(pmc["factor_per_launch"]["algorithmic_bytes"] - bytes_factor) < 0.05 * bytes_factor:
                         traffic_f = pmc["factor_per_launch"]["traffic_bytes"]; traffic_s = pmc["solve_per_launch"]["traffic_bytes"]
-                    pmc2 = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_sparse_batch.json"))).get("sparse_cont201")
+                    f3 = os.path.join(ROOT, "profiles", "r03_pmc_sparse_cont201.json")  # the newest committed passes of the CONT-201 workload
+                    pmc2 = json.load(open(f3 if os.path.exists(f3) else os.path.join(ROOT, "profiles", "r02_pmc_sparse_batch.json"))).get("sparse_cont201")
                     if key == "MM_CONT-201" and pmc2 and abs(pmc2["factor_per_launch"]["algorithmic_bytes"] - bytes_factor) < 0.05 * bytes_factor:
                         traffic_f = pmc2["factor_per_launch"]["traffic_bytes"]; traffic_s = pmc2["solve_per_launch"]["traffic_bytes"]
                 except Exception:  # noqa: BLE001
                     pass
-                r["roofline"] = {"bound": "hbm", "kernel": "multifrontal factorisation (k_subtree_factor_lds / _pk + k_top_factor / k_front_factor levels; big fronts: k_potrf_diag_fronts / k_trsm_panel_fronts / k_syrk_lower_fronts per level), hipEvent-bracketed on the backend stream",
+                r["roofline"] = {"bound": "hbm", "kernel": "multifrontal factorisation (k_subtree_factor_lds / _pk + k_top_factor / k_front_factor levels; big fronts: k_potrf_trsm_fronts + k_syrk_lower_fronts / k_syrk_half_fronts per level, k_front_panel_step at the top of the tree), hipEvent-bracketed on the backend stream",
                                  "achieved": bytes_factor / fac_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": bytes_factor / fac_s / 1e9 / PEAK_HBM_GBS, "traffic": traffic_f,
                                  "alg_bytes_per_launch": bytes_factor, "avg_launch_ms": r["factor_ms"],
                                  "note": "dependent-latency bound (tree of small fronts), not bandwidth bound: see DESIGN.md section 6"}
-                r["roofline_solve"] = {"bound": "hbm", "kernel": "backend solve (k_subtree_fwd/bwd_wave + k_front_fwd/bwd_wide levels)", "achieved": bytes_solve / sol_s / 1e9,
+                r["roofline_solve"] = {"bound": "hbm", "kernel": "backend solve (k_subtree_fwd/bwd_wave + k_front_fwd/bwd_wide levels, k_level_fwd/bwd_mixed where a level holds both kinds)", "achieved": bytes_solve / sol_s / 1e9,
                                        "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": bytes_solve / sol_s / 1e9 / PEAK_HBM_GBS, "traffic": traffic_s,
                                        "alg_bytes_per_launch": bytes_solve, "avg_launch_ms": r["backend_solve_ms"]}
                 r["factor_gflops"] = stt["flops_factor"] / fac_s / 1e9
