@@ -378,6 +378,10 @@ int pq_batch_set_start_order(pq_batch *s, int longest_first);
  * factor / solve, fwd.hpp:44-52): the counter moves only inside *_create / *_clone / *_setup / *_update_data / *_partition calls, never in
  * update_scalings_and_factor, solve, eval_*, mul or condensed_residual, in either pointer mode */
 long long pq_debug_alloc_count(void);
+/* host-only (no device needed): the ticket-ordered task list of the persistent dense factorisation for a T x T grid of 128 x 128 tiles (csrc/dense_kernels.hip
+ * k_chol_persistent; mchunks > 0: with the assembly of dense/kkt.hpp:140-160 fused in, m = 128 mchunks), six ints per task (kind, round, a, b, gate, aux).
+ * Returns the number of tasks (-1: T outside [3, 1024]).  tests/test_chol_plan.py replays the list on the CPU: every task only waits for EARLIER tickets. */
+int pq_debug_chol_plan(int T, int mchunks, int *out6, int capacity_tasks);
 int pq_microbench_mfma_f64(int device, int iters, double *tflops_out);
 int pq_microbench_hbm_copy(int device, size_t bytes, int iters, double *gbps_out);
 /* debugging aid: average microseconds of the 128 x 128 diagonal-block factorisation kernel and 64 in-kernel shader-clock stamps

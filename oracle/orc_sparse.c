@@ -91,8 +91,20 @@ void orc_sparse_ldlt_symbolic(orc_sparse_ldlt *f, int n, const int *Ap, const in
 }
 
 /* sparse/ldlt.hpp:101-169; returns n on success, k on D[k] == 0 */
+/* EXPERIMENT HOOK (off unless ORC_EXP_CANCEL_TOL is set; tools/exp_cancel_pivot.py): additionally report pivot k as failed when |D[k]| <= tol * (largest
+ * magnitude among a_kk and the products l_ki * y_i subtracted from it) -- the cancellation-aware failure signal of the device's sparse fronts, tried on
+ * the reference's own arithmetic to see which fixtures it would move.  Not part of the restatement: ldlt.hpp:163 tests D[k] == 0.0 only. */
+static double orc_exp_cancel_tol(void)
+{
+    static int init = 0;
+    static double tol = 0.0;
+    if (!init) { const char *e = getenv("ORC_EXP_CANCEL_TOL"); tol = e ? atof(e) : 0.0; init = 1; }
+    return tol;
+}
+
 int orc_sparse_ldlt_numeric(orc_sparse_ldlt *f, int n, const int *Ap, const int *Ai, const double *Ax)
 {
+    const double ctol = orc_exp_cancel_tol();
     int *flag = f->flag, *pattern = f->pattern, *etree = f->etree, *L_cols = f->L_cols, *L_nnz = f->L_nnz, *L_ind = f->L_ind;
     double *y = f->y, *D = f->D, *L_vals = f->L_vals;
     for (int k = 0; k < n; k++) {
@@ -111,6 +123,7 @@ int orc_sparse_ldlt_numeric(orc_sparse_ldlt *f, int n, const int *Ap, const int 
             while (len > 0) pattern[--top] = pattern[--len];
         }
         D[k] = y[k];
+        double mx = fabs(y[k]);
         y[k] = 0.0;
         for (; top < n; top++) {
             int i = pattern[top];
@@ -125,11 +138,13 @@ int orc_sparse_ldlt_numeric(orc_sparse_ldlt *f, int n, const int *Ap, const int 
             double l_ki = yi / D[i];
             double tmp = l_ki * yi;
             D[k] -= tmp;
+            if (fabs(tmp) > mx) mx = fabs(tmp);
             L_ind[p] = k;
             L_vals[p] = l_ki;
             L_nnz[i]++;
         }
         if (D[k] == 0.0) return k;
+        if (ctol > 0.0 && fabs(D[k]) <= ctol * mx) return k;
     }
     for (int k = 0; k < n; k++) f->D_inv[k] = 1.0 / D[k];
     return n;

@@ -1860,11 +1860,10 @@ private:
     void launch_ipm_with()
     {
         int bytes = shared_h_.chain_lds_doubles * (int)sizeof(double);
-        static bool attr = false;
-        if (!attr) {
+        static PerDeviceOnce attr;
+        attr([&] {
             PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_batch_ipm<NTv, MODEv, WPEv>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT_BYTES));
-            attr = true;
-        }
+        });
         hipLaunchKernelGGL((k_batch_ipm<NTv, MODEv, WPEv>), dim3(batch_), dim3(NTv), bytes, st_, shared_.p, arena_.p, ruiz_c_.p, infos_.p, prof_.p, order_.p);
     }
     template <int NTv, int MODEv>

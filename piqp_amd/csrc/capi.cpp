@@ -638,6 +638,7 @@ int pq_kktsys_synchronize(pq_kktsys* k)
 
 // ------------------------------------------------------------------------------------ micro-benchmarks
 long long pq_debug_alloc_count(void) { return alloc_counter().load(); }
+int pq_debug_chol_plan(int T, int mchunks, int* out6, int capacity_tasks) { return T >= 3 && T <= 1024 ? dense::chol_debug_plan(T, mchunks, out6, capacity_tasks) : -1; }
 
 int pq_microbench_mfma_f64(int device, int iters, double* tflops_out)
 {

@@ -9,6 +9,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
+#include <mutex>
+#include <set>
 #include <string>
 #include <utility>
 #include <vector>
@@ -46,6 +48,23 @@ struct HipError {
         hipError_t e_ = (expr);                                              \
         if (e_ != hipSuccess) throw ::pq::HipError{e_, #expr, __FILE__, __LINE__}; \
     } while (0)
+
+// "Once per device": hipFuncSetAttribute (dynamic LDS limits) applies to the CURRENT device only, while handles on several devices -- and host threads -- share
+// the launch helpers' call sites.  `static PerDeviceOnce once; once([&] { ... });`
+struct PerDeviceOnce {
+    std::mutex mu;
+    std::set<int> done;
+    template <class F>
+    void operator()(F&& f)
+    {
+        int dev = 0;
+        PQ_HIP(hipGetDevice(&dev));
+        std::lock_guard<std::mutex> lk(mu);
+        if (done.count(dev)) return;
+        f();
+        done.insert(dev);
+    }
+};
 
 // Waits for a stream: polls it for up to two milliseconds, then blocks.  One interior-point iteration reads three or four scalars back (factorisation status,
 // finiteness of a solve: kkt_system.hpp:266,305), each a full drain of the stream; hipStreamSynchronize sleeps on an interrupt, and the wake-up was 30-150 us per

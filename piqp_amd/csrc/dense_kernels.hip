@@ -658,6 +658,7 @@ __global__ __launch_bounds__(256) void k_syrk_tail_reduce(SyrkArgs a)
         while (ti * (ti + 1) / 2 > b) --ti;
         tj = b - ti * (ti + 1) / 2;
     }
+    if (a.first_col_only) { ti = b; tj = 0; }
     const int row0 = ti * TS, col0 = tj * TS;
     const double* P0 = a.part + (size_t)blockIdx.x * a.k_split * TS * TS;
     {
@@ -774,22 +775,20 @@ void launch_syrk(int epi, const SyrkArgs& args_in, hipStream_t s, double* split_
     SyrkArgs a = args_in;
     if (a.n <= 0) return;
     a.unaligned = ((a.lda & 1) || (a.ldb & 1) || (reinterpret_cast<uintptr_t>(a.A) & 15) || (reinterpret_cast<uintptr_t>(a.B) & 15)) ? 1 : 0;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_set;
+    attr_set([&] {
         PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk_lower<EPI_ASSEMBLE, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, SYRK_LDS_BYTES));
         PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk_lower<EPI_SUBTRACT, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, SYRK_LDS_BYTES));
         PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk_lower<EPI_STORE, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, SYRK_LDS_BYTES));
         PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk_lower<EPI_ASSEMBLE, 4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, SYRK_LDS_BYTES));
         PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk_lower<EPI_SUBTRACT, 4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, SYRK_LDS_BYTES));
         PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk_lower<EPI_STORE, 4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, SYRK_LDS_BYTES));
-        attr_set = true;
-    }
+    });
     if (epi == EPI_SUBTRACT_POTRF) {
-        static bool fused_attr = false;
-        if (!fused_attr) {
+        static PerDeviceOnce fused_attr;
+        fused_attr([&] {
             PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk_lower<EPI_SUBTRACT_POTRF, 4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS_BYTES));
-            fused_attr = true;
-        }
+        });
         const int T = div_up(a.n, TS);
         a.tile_begin = 0; a.k_split = 1; a.part = nullptr; a.first_col_only = 0;
         if (!a.fuse_scratch || !a.fuse_flags || a.fuse_nb <= 0 || a.kdim > TS) throw std::runtime_error("fused trailing update: scratch / flags / panel width");
@@ -801,6 +800,41 @@ void launch_syrk(int epi, const SyrkArgs& args_in, hipStream_t s, double* split_
     case EPI_ASSEMBLE: launch_syrk_t<EPI_ASSEMBLE>(a, s, split_ws, split_ws_doubles); break;
     case EPI_SUBTRACT: launch_syrk_t<EPI_SUBTRACT>(a, s, split_ws, split_ws_doubles); break;
     default: launch_syrk_t<EPI_STORE>(a, s, split_ws, split_ws_doubles); break;
+    }
+    PQ_HIP(hipGetLastError());
+}
+
+// GT (n x m column-major, ld = n) -> row panels of 128 rows stored one after the other, each 128 x m column-major with ld = 128: a 128 x 16 operand stage of
+// the fused assembly is then 16 KB of consecutive memory instead of sixteen 1 KB pieces 8 n bytes apart (n = 4096: 32 KB -- outside L2 the persistent launch's
+// assembly tasks, which do not run in lockstep like the tiles of k_syrk_lower, got 2 TB/s out of that pattern: 31 us per 128-column chunk)
+__global__ __launch_bounds__(256) void k_pack_row_panels(const double* __restrict__ G, int n, int m, double* __restrict__ Gp)
+{
+    const int k = blockIdx.x, i = blockIdx.y;  // column, row panel
+    const int r = threadIdx.x;
+    if (r < 128) Gp[((size_t)i * m + k) * 128 + r] = G[(size_t)i * 128 + r + (size_t)k * n];
+}
+void launch_pack_row_panels(const double* G, int n, int m, double* Gp, hipStream_t s)
+{
+    if (n <= 0 || m <= 0) return;
+    hipLaunchKernelGGL(k_pack_row_panels, dim3(m, n / 128), dim3(128), 0, s, G, n, m, Gp);
+    PQ_HIP(hipGetLastError());
+}
+void launch_syrk_first_col(const SyrkArgs& args_in, int ks, double* ws, hipStream_t s)
+{
+    SyrkArgs a = args_in;
+    if (a.n <= 0) return;
+    a.unaligned = ((a.lda & 1) || (a.ldb & 1) || (reinterpret_cast<uintptr_t>(a.A) & 15) || (reinterpret_cast<uintptr_t>(a.B) & 15)) ? 1 : 0;
+    static PerDeviceOnce attr_set;
+    attr_set([&] { PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk_lower<EPI_ASSEMBLE, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, SYRK_LDS_BYTES)); });
+    const int T = div_up(a.n, TS);
+    a.first_col_only = 1; a.tile_order = nullptr; a.tile_begin = 0;
+    if (ks <= 1 || !ws) {
+        a.k_split = 1; a.part = nullptr;
+        hipLaunchKernelGGL((k_syrk_lower<EPI_ASSEMBLE, 2, 2>), dim3(T), dim3(256), SYRK_LDS_BYTES, s, a);
+    } else {
+        a.k_split = ks; a.part = ws;
+        hipLaunchKernelGGL((k_syrk_lower<EPI_ASSEMBLE, 2, 2>), dim3(T * ks), dim3(256), SYRK_LDS_BYTES, s, a);
+        hipLaunchKernelGGL(k_syrk_tail_reduce<EPI_ASSEMBLE>, dim3(T, TS * TS / 256), dim3(256), 0, s, a);
     }
     PQ_HIP(hipGetLastError());
 }
@@ -1343,12 +1377,11 @@ __global__ __launch_bounds__(POTRF_THREADS) void k_potrf_diag_fronts(const Front
 
 void launch_potrf_diag(bool ldlt, double* A, int lda, int nb, int kglobal, int* info, double* rdiag, double* dvec, double* pack, double* w16, hipStream_t s, long long* ts)
 {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_set;
+    attr_set([&] {
         PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_diag<false>), hipFuncAttributeMaxDynamicSharedMemorySize, POTRF_LDS_BYTES));
         PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_diag<true>), hipFuncAttributeMaxDynamicSharedMemorySize, POTRF_LDS_BYTES));
-        attr_set = true;
-    }
+    });
     if (ldlt) hipLaunchKernelGGL(k_potrf_diag<true>, dim3(1), dim3(POTRF_THREADS), POTRF_LDS_BYTES, s, A, lda, nb, kglobal, info, rdiag, dvec, pack, w16, ts);
     else hipLaunchKernelGGL(k_potrf_diag<false>, dim3(1), dim3(POTRF_THREADS), POTRF_LDS_BYTES, s, A, lda, nb, kglobal, info, rdiag, dvec, pack, w16, ts);
     PQ_HIP(hipGetLastError());
@@ -1698,8 +1731,18 @@ __device__ __forceinline__ bool panel_follow(const SyrkArgs& a, double* __restri
 // order as in the launch-per-panel path: bitwise the same factor (tools/chk_chol_persistent.py, tests/test_dense_gpu.py).
 struct CholTask {
     short kind, round, a, b;  // kind 0: helper (role a) / 1: owner / 2: panel tile (a, 0), half b (-1: the whole tile) / 3: bulk tile (a, b) of round `round`
+                              // (4 / 5: the halves of the diagonal tile of the first bulk column); fused assembly only -- 6: K-slice `round` of the assembly of the
+                              // ABSOLUTE tile (a, b); 7: the updates of panels [round, gate + 1) on the absolute tile (a, b) in one visit
     int gate;                 // panel rounds that must be complete before the ticket is drawn
+    int aux;                  // kind 6: first 128 x 128 slot of the tile's partial sums in CholArgs::part
 };
+// K-slices of an assembly tile of block column j (mchunks = m / 128 operand chunks): the early columns are wanted first and are cut finest, every slice a
+// task of its own whose partial sum goes to a slot of `part`; the last slice to finish adds them up in slice order (chol_role_reduce).  One slice: no partial.
+__host__ __device__ inline int chol_asm_slices(int j, int mchunks)
+{
+    const int band = (j - 1) >> 3, s = band >= 3 ? 1 : (8 >> band);  // block columns 1-8: 8 slices, 9-16: 4, 17-24: 2, beyond: 1
+    return s < mchunks ? s : (mchunks > 0 ? mchunks : 1);
+}
 // workgroups per panel tile: a row's task of round k needs that row's output of round k - 1, so one workgroup's update + substitution (28 + 13 us for a
 // whole tile) bound a round from below; halves (fused_tile<HALF>) keep that under the diagonal block's 30 us.  Early rounds are bound by the bulk
 // tiles anyway and keep whole tiles (half as many workgroups parked on the chain).
@@ -1730,6 +1773,19 @@ struct CholArgs {
     int* dhalf;           // per round: halves of the split diagonal tile of the first bulk column that have finished (cumulative over the factorisations)
     int gen;       // launch-unique base of the flag values
     int fcount;    // persistent factorisations this handle has run before this one (pdone counters are cumulative)
+    // fused assembly (dense/kkt.hpp:140-160 as tasks of this launch, GT != nullptr): K = Pfull + diag(x_reg) + dinv ATA + GT diag(zinv) GT^T for the tiles of the
+    // block columns >= 1 (column 0 is assembled, factored and solved before the launch); m % 128 == 0
+    const double* GT; int ldg, m; const double* zinv;
+    const double* Pfull; int ldp; const double* x_reg; const double* ATA; int ldata; double dinv;
+    double* part;  // partial sums of the K-sliced tiles, 128 x 128 column-major slots
+    int* acnt;     // per tile: slices that have stored their partial sum, cumulative over the factorisations
+    // The assembly tasks (kind 6) are NOT in the ticket list: they sit in eight queues, tile (i, j) in queue i mod 8, and the list holds one TOKEN (kind 8) per
+    // task.  A workgroup that draws a token takes the next task of the queue of ITS XCD (workgroups go to the XCDs round-robin), so the ~32 tiles an XCD works on at
+    // a time come from four block rows and a few block columns and share their operand panels in that XCD's L2 -- drawn from one list in ticket order every
+    // tile's 1 MB of operands per slice came from the fabric (25 us per 128-column chunk instead of the 15 of a tile whose operands are in L2); an empty queue
+    // steals from the next one.  A task that finds its tile not assembled yet runs assembly tasks itself until it is (help_assembled): whatever the queues'
+    // progress, nobody ever sleeps on a tile whose assembly has not been drawn.
+    const CholTask* aq; int aq_ptr[9]; int* aq_head;
     long long* trace;  // debugging aid (PIQP_AMD_DEBUG=chol_trace), nullable: per ticket 4 x wall_clock64 (100 MHz): drawn, inputs ready, done; [3] = workgroup id
 };
 
@@ -1760,6 +1816,135 @@ __device__ __forceinline__ bool chol_wait3(const int* p0, int w0, const int* p1,
     return ok;
 }
 
+// ---- fused assembly / multi-panel updates (round 4): ONE accumulate routine for both.  A visit adds `nchunk` operand chunks of 128 columns to a 128 x 128 tile:
+//   FAR = false  assembly, chunk c = columns [128 (c0 + c), +128) of GT, column operand scaled by zinv: acc += G_i diag(zinv) G_j^T, accumulators from zero;
+//                the epilogue stores the raw partial sum (part != nullptr) or C = base + acc (dense/kkt.hpp:144-158, the arithmetic of EPI_ASSEMBLE)
+//   FAR = true   trailing updates of panels [c0, c0 + nchunk): accumulators from C, column operand negated (and scaled by D for LDLt): the k-slices of the
+//                panels in ascending order, i.e. exactly the products the one-panel visits add -- bitwise the same tile, with one C fetch and one store
+// Operand stages: four (64 columns) per group through LDS, the next group's loads issued behind the LDS stores of the current one, so they fly during its products.
+struct AccumArgs {
+    const double* A0; const double* A1;  // row operand, first column of the visit: chunk 0 reads A0, chunks >= 1 read A1 (panel 0 lives in place, the others in the side copy)
+    const double* B0; const double* B1;  // column operand, likewise
+    int ld; int nchunk;
+    const double* w;                     // per-column scale of the column operand, indexed from the visit's first column (nullable)
+    double* C; int ldc; int diag;        // the tile; diag: on the block diagonal (sub-tiles above it are skipped)
+    double* part;                        // !FAR: raw partial sum instead of the epilogue
+    const double* Pt; int ldp; const double* xr; const double* At; int ldat; double dinv;  // !FAR epilogue: tile origins inside Pfull / ATA, x_reg at the tile's first row
+};
+template <int NT, bool FAR>
+__device__ __forceinline__ void accum_tile(const AccumArgs& g, double* __restrict__ smem)
+{
+    constexpr int WR = 4, WC = 2, SUBR = 32, SUBC = 64, MTR = 2, MTC = 4, PER = 1024 / NT, GRP = 4;
+    static_assert(NT == 512, "eight waves");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave / WC, wc = wave % WC;
+    const bool skip_wave = g.diag && ((wr + 1) * SUBR <= wc * SUBC);
+    d4 acc[MTC][MTR];
+#pragma unroll
+    for (int x = 0; x < MTC; ++x)
+#pragma unroll
+        for (int y = 0; y < MTR; ++y) acc[x][y] = (d4){0.0, 0.0, 0.0, 0.0};
+    if (FAR && !skip_wave) {
+#pragma unroll
+        for (int x = 0; x < MTC; ++x)
+#pragma unroll
+            for (int y = 0; y < MTR; ++y) {
+                const int li = wr * SUBR + y * 16 + (lane & 15);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int lj = wc * SUBC + x * 16 + (lane >> 4) + 4 * r;
+                    const bool ok = !g.diag || li >= lj;
+                    const double cv = ld_agent(g.C + (ok ? (size_t)li + (size_t)lj * g.ldc : 0));
+                    acc[x][y][r] = ok ? cv : 0.0;
+                }
+            }
+    }
+    // Four stages (64 operand columns) per group: the registers hold group n + 1 while LDS holds group n.  (Eight stages = a whole chunk in registers, requested
+    // behind the second group's LDS stores, did not fit next to the accumulators: 220-240 bytes of scratch per lane and 26-31 us per chunk instead of 15.)
+    d2 pa[GRP][PER], pb[GRP][PER];
+    auto request = [&](int gi) {  // group gi = stages [4 (gi & 1), +4) of chunk gi >> 1
+        const int c = gi >> 1, k0 = (gi & 1) * GRP * BK;
+        const double* A = (c == 0 ? g.A0 : g.A1) + (size_t)c * 128 * g.ld;
+        const double* B = (c == 0 ? g.B0 : g.B1) + (size_t)c * 128 * g.ld;
+#pragma unroll
+        for (int q = 0; q < GRP; ++q) { load_tile<false, NT>(A, g.ld, 0, k0 + q * BK, 0, 0, tid, pa[q]); load_tile<false, NT>(B, g.ld, 0, k0 + q * BK, 0, 0, tid, pb[q]); }
+    };
+    double* A4 = smem;                       // [GRP][BK][LDS_LD]
+    double* B4 = smem + GRP * BK * LDS_LD;   // [GRP][BK][LDS_LD]
+    const int ngroups = 2 * g.nchunk;
+    request(0);
+#pragma unroll 1
+    for (int gi = 0; gi < ngroups; ++gi) {
+        const double* wg = g.w ? g.w + (size_t)gi * GRP * BK : nullptr;
+        __syncthreads();  // every wave has read the previous group
+#pragma unroll
+        for (int q = 0; q < GRP; ++q) {
+            scale_tile<false, NT, FAR, FAR>(wg, q * BK, 0, tid, pb[q]);
+            store_tile<NT>(A4 + q * BK * LDS_LD, tid, pa[q]);
+            store_tile<NT>(B4 + q * BK * LDS_LD, tid, pb[q]);
+        }
+        if (gi + 1 < ngroups) request(gi + 1);  // (flies during this group's products)
+        __syncthreads();
+        if (!skip_wave) {
+#pragma unroll
+            for (int q = 0; q < GRP; ++q) {
+                const double* Asb = A4 + q * BK * LDS_LD + wr * SUBR + (lane & 15);
+                const double* Bsb = B4 + q * BK * LDS_LD + wc * SUBC + (lane & 15);
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int kk = ks * 4 + (lane >> 4);
+                    double af[MTR], bf[MTC];
+#pragma unroll
+                    for (int u = 0; u < MTR; ++u) af[u] = Asb[kk * LDS_LD + u * 16];
+#pragma unroll
+                    for (int u = 0; u < MTC; ++u) bf[u] = Bsb[kk * LDS_LD + u * 16];
+#pragma unroll
+                    for (int x = 0; x < MTC; ++x)
+#pragma unroll
+                        for (int y = 0; y < MTR; ++y)
+                            acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[x], af[y], acc[x][y], 0, 0, 0);
+                }
+            }
+        }
+    }
+    if (skip_wave) return;
+#pragma unroll
+    for (int x = 0; x < MTC; ++x) {
+#pragma unroll
+        for (int y = 0; y < MTR; ++y) {
+            const int li = wr * SUBR + y * 16 + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int lj = wc * SUBC + x * 16 + (lane >> 4) + 4 * r;
+                if (g.diag && li < lj) continue;
+                const double v = acc[x][y][r];
+                if constexpr (FAR) st_agent(g.C + (size_t)li + (size_t)lj * g.ldc, v);
+                else if (g.part) st_agent(g.part + li + lj * TS, v);
+                else {
+                    double base = ((const __attribute__((address_space(1))) double*)g.Pt)[(size_t)li + (size_t)lj * g.ldp];
+                    if (g.diag && li == lj) base += ((const __attribute__((address_space(1))) double*)g.xr)[li];
+                    if (g.At) base += g.dinv * ((const __attribute__((address_space(1))) double*)g.At)[(size_t)li + (size_t)lj * g.ldat];
+                    st_agent(g.C + (size_t)li + (size_t)lj * g.ldc, base + v);
+                }
+            }
+        }
+    }
+}
+// the last slice of a K-sliced assembly tile to finish adds the partial sums in slice order and applies the epilogue (k_syrk_tail_reduce's arithmetic)
+__device__ __forceinline__ void accum_reduce(const AccumArgs& g, int nslice)
+{
+    for (int idx = threadIdx.x; idx < TS * TS; idx += blockDim.x) {
+        const int li = idx & (TS - 1), lj = idx >> 7;
+        if (g.diag && li < lj) continue;
+        double v = 0.0;
+        for (int sl = 0; sl < nslice; ++sl) v += ld_agent(g.part + (size_t)sl * TS * TS + idx);
+        double base = ((const __attribute__((address_space(1))) double*)g.Pt)[(size_t)li + (size_t)lj * g.ldp];
+        if (g.diag && li == lj) base += ((const __attribute__((address_space(1))) double*)g.xr)[li];
+        if (g.At) base += g.dinv * ((const __attribute__((address_space(1))) double*)g.At)[(size_t)li + (size_t)lj * g.ldat];
+        st_agent(g.C + (size_t)li + (size_t)lj * g.ldc, base + v);
+    }
+}
+
 constexpr int CHOL_THREADS = 512;
 // The two roles as out-of-line functions: inlined into the ticket loop they drove the kernel to 256 VGPRs + 224 spilled (892 B of scratch per lane) and
 // the diagonal block took twice as long as in the launch-per-panel kernel (208 VGPRs, no spills).  The LDS view is rebuilt from the extern symbol inside
@@ -1786,10 +1971,24 @@ __device__ __noinline__ bool chol_role_half(const SyrkArgs& a, int ti, int tj, i
     const SyrkArgs b = a;
     return fused_tile<CHOL_THREADS, true, true>(b, ti, tj, smem, h);
 }
+__device__ __noinline__ void chol_role_accum_far(const AccumArgs& a)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const AccumArgs b = a;
+    accum_tile<CHOL_THREADS, true>(b, smem);
+}
+__device__ __noinline__ void chol_role_accum_asm(const AccumArgs& a)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const AccumArgs b = a;
+    accum_tile<CHOL_THREADS, false>(b, smem);
+}
 __global__ __launch_bounds__(CHOL_THREADS, 2) void k_chol_persistent(CholArgs c)
 {
     __shared__ int s_ticket;
     __shared__ CholTask s_task;
+    __shared__ CholTask s_asm;
+    __shared__ int s_help, s_last;
     const int tid = threadIdx.x;
     int* abort_w = c.ticket + 1;
     const int T = c.T, NB = FACTOR_NB, ntasks = c.ntasks;
@@ -1827,6 +2026,104 @@ __global__ __launch_bounds__(CHOL_THREADS, 2) void k_chol_persistent(CholArgs c)
         __syncthreads();
         if (t >= ntasks) return;
         if (c.trace && tid == 0) { c.trace[4 * (size_t)t] = wall_clock64(); c.trace[4 * (size_t)t + 3] = blockIdx.x; }
+        const bool asm_in = c.GT != nullptr;  // fused assembly: a tile's first update waits for tver == gen like every later one waits for gen + k
+        // thread 0: the next assembly task -- own XCD's queue first, then the others'
+        auto draw_asm = [&]() -> bool {
+            const int xcd = (int)blockIdx.x & 7;
+            for (int q = 0; q < 8; ++q) {
+                const int y = (xcd + q) & 7, len = c.aq_ptr[y + 1] - c.aq_ptr[y];
+                if (len <= 0 || ldi_agent(c.aq_head + y) >= len) continue;
+                const int hq = addi_agent(c.aq_head + y, 1);
+                if (hq < len) { s_asm = c.aq[c.aq_ptr[y] + hq]; return true; }
+            }
+            return false;
+        };
+        // one K-slice of the assembly of the absolute tile (q.a, q.b); the last slice of a tile to finish adds the partial sums up and announces the tile
+        auto run_asm = [&](const CholTask& q, long long* tr) {
+            const int i = q.a, j = q.b, sl = q.round, mch = c.m / NB, S = chol_asm_slices(j, mch);
+            const int c0 = (int)((long long)sl * mch / S), c1 = (int)((long long)(sl + 1) * mch / S);
+            AccumArgs g;
+            g.C = c.A + (size_t)i * NB + (size_t)j * NB * c.lda; g.ldc = c.lda; g.diag = i == j ? 1 : 0;
+            // (GT as row panels, launch_pack_row_panels: panel i = 128 x m, ld = 128)
+            g.A0 = g.A1 = c.GT + ((size_t)i * c.m + (size_t)c0 * NB) * NB;
+            g.B0 = g.B1 = c.GT + ((size_t)j * c.m + (size_t)c0 * NB) * NB;
+            g.ld = NB; g.nchunk = c1 - c0; g.w = c.zinv + (size_t)c0 * NB;
+            g.part = S > 1 ? c.part + ((size_t)q.aux + sl) * TS * TS : nullptr;
+            g.Pt = c.Pfull + (size_t)i * NB + (size_t)j * NB * c.ldp; g.ldp = c.ldp; g.xr = c.x_reg + (size_t)i * NB;
+            g.At = c.ATA ? c.ATA + (size_t)i * NB + (size_t)j * NB * c.ldata : nullptr; g.ldat = c.ldata; g.dinv = c.dinv;
+            if (tr && tid == 0) { tr[1] = wall_clock64(); tr[3] = (long long)blockIdx.x + 1000ll * j; }
+            chol_role_accum_asm(g);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            bool last = S == 1;
+            if (S > 1) {
+                if (tid == 0) s_last = (addi_agent(c.acnt + (size_t)i * T + j, 1) + 1 - (c.fcount + 1) * S == 0) ? 1 : 0;
+                __syncthreads();
+                last = s_last != 0;
+                __syncthreads();
+                if (last) {
+                    g.part = c.part + (size_t)q.aux * TS * TS;
+                    accum_reduce(g, S);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();
+                }
+            }
+            if (last && tid == 0) __hip_atomic_store(c.tver + (size_t)i * T + j, c.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tr && tid == 0) tr[2] = wall_clock64();
+        };
+        // before a task sleeps on its tile: if the tile is not assembled yet, assemble (anything) until it is or the queues are empty
+        auto help_assembled = [&](int i, int j) {
+            if (!asm_in) return;
+            for (;;) {
+                if (tid == 0) s_help = (ldi_agent(c.tver + (size_t)i * T + j) - c.gen >= 0) ? 2 : (draw_asm() ? 1 : 0);
+                __syncthreads();
+                const int st = s_help;
+                const CholTask q = s_asm;
+                __syncthreads();
+                if (st != 1) return;
+                run_asm(q, nullptr);
+            }
+        };
+        if (tk.kind == 8) {
+            // ---- assembly token: the next task of this XCD's queue
+            if (tid == 0) s_help = draw_asm() ? 1 : 0;
+            __syncthreads();
+            const int st = s_help;
+            const CholTask q = s_asm;
+            __syncthreads();
+            if (st == 1) run_asm(q, c.trace ? c.trace + 4 * (size_t)t : nullptr);
+            else if (c.trace && tid == 0) { c.trace[4 * (size_t)t + 1] = c.trace[4 * (size_t)t + 2] = wall_clock64(); c.trace[4 * (size_t)t + 3] = blockIdx.x; }
+            continue;
+        }
+        if (tk.kind == 7) {
+            // ---- several panels' updates of a far tile in one visit, absolute tile (i, j)
+            const int i = tk.a, j = tk.b;
+            AccumArgs g;
+            g.C = c.A + (size_t)i * NB + (size_t)j * NB * c.lda; g.ldc = c.lda; g.diag = i == j ? 1 : 0;
+            g.part = nullptr; g.Pt = nullptr; g.ldp = 0; g.xr = nullptr; g.At = nullptr; g.ldat = 0; g.dinv = 0.0;
+            const int klo = tk.round, khi = tk.gate + 1, kp = khi - 1;
+            auto ready = [&](int row) { return (c.fcount + 1) * (kp > 0 ? chol_split_row(T, kp - 1, row - kp) : 1); };
+            help_assembled(i, j);
+            // (without the fused assembly a tile that has received no update carries no mark of this launch: its first visit does not wait for one)
+            bool ok = chol_wait3((klo > 0 || asm_in) ? c.tver + (size_t)i * T + j : nullptr, c.gen + klo, kp > 0 ? c.lready + (size_t)kp * T + i : nullptr, ready(i), kp > 0 ? c.lready + (size_t)kp * T + j : nullptr, ready(j), abort_w, 1);
+            if (c.trace && tid == 0) c.trace[4 * (size_t)t + 1] = wall_clock64();
+            if (ok) {
+                const size_t col = (size_t)klo * NB * c.lda;
+                g.A0 = (klo == 0 ? c.A : c.side) + (size_t)i * NB + col; g.A1 = c.side + (size_t)i * NB + col;
+                g.B0 = (klo == 0 ? c.A : c.side) + (size_t)j * NB + col; g.B1 = c.side + (size_t)j * NB + col;
+                g.ld = c.lda; g.nchunk = khi - klo; g.w = c.ldlt ? c.dvec + (size_t)klo * NB : nullptr;
+                chol_role_accum_far(g);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (tid == 0) __hip_atomic_store(c.tver + (size_t)i * T + j, c.gen + khi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (c.trace && tid == 0) c.trace[4 * (size_t)t + 2] = wall_clock64();
+            if (!ok) {
+                if (tid == 0) { __hip_atomic_store(abort_w, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (*c.info < 0) *c.info = 0; }
+                return;
+            }
+            continue;
+        }
         const int k = tk.round, kk = k * NB, rs = c.n - kk - NB;  // rs = order of the trailing matrix of round k (a multiple of 128, >= 128)
         SyrkArgs a;
         a.n = rs; a.kdim = NB;
@@ -1857,7 +2154,8 @@ __global__ __launch_bounds__(CHOL_THREADS, 2) void k_chol_persistent(CholArgs c)
             // owner also waits until every panel task of round k - 2 is done with the pack buffer this round writes.
             const int d = k + 1;
             // (its operand, block row d of panel k, arrives slice by slice inside fused_next_diag)
-            ok = chol_wait3(k > 0 ? c.tver + (size_t)d * T + d : nullptr, c.gen + k, nullptr, 0,
+            help_assembled(d, d);
+            ok = chol_wait3((k > 0 || asm_in) ? c.tver + (size_t)d * T + d : nullptr, c.gen + k, nullptr, 0,
                             (tk.kind == 1 && k >= 2) ? c.pdone + (k - 2) : nullptr, (c.fcount + 1) * chol_panel_tasks(T, k - 2), abort_w, 0);
             if (c.trace && tid == 0) c.trace[4 * (size_t)t + 1] = wall_clock64();
             if (ok) ok = chol_role_crew(a, tk.kind == 1 ? 0 : tk.a);
@@ -1867,11 +2165,12 @@ __global__ __launch_bounds__(CHOL_THREADS, 2) void k_chol_persistent(CholArgs c)
             const int dh = tk.kind >= 4 ? tk.kind - 4 : -1;  // half of a split bulk tile (the diagonal tile of the first bulk column: it feeds the next crew)
             const int ti = tk.a, tj = panel ? 0 : tk.b;
             const int i = k + 1 + ti, j = k + 1 + tj;
+            help_assembled(i, j);
             if (panel && k > 0) {
                 ok = chol_wait3(c.tver + (size_t)i * T + j, c.gen + k, nullptr, 0, nullptr, 0, abort_w, 0);
                 a.late_p[0] = lr + i; a.late_w[0] = ready_of(i); a.late_p[1] = lr + j; a.late_w[1] = ready_of(j);
             } else {
-                ok = chol_wait3(k > 0 ? c.tver + (size_t)i * T + j : nullptr, c.gen + k, k > 0 ? lr + i : nullptr, ready_of(i), k > 0 ? lr + j : nullptr, ready_of(j), abort_w, panel ? 0 : 1);
+                ok = chol_wait3((k > 0 || asm_in) ? c.tver + (size_t)i * T + j : nullptr, c.gen + k, k > 0 ? lr + i : nullptr, ready_of(i), k > 0 ? lr + j : nullptr, ready_of(j), abort_w, panel ? 0 : 1);
             }
             if (c.trace && tid == 0) c.trace[4 * (size_t)t + 1] = wall_clock64();
             if (ok) ok = (panel && tk.b >= 0) ? chol_role_half(a, ti, 0, tk.b) : (dh >= 0 ? chol_role_half(a, ti, tj, dh) : chol_role_tile(a, ti, tj));
@@ -1910,8 +2209,14 @@ __global__ __launch_bounds__(CHOL_THREADS, 2) void k_chol_persistent(CholArgs c)
 // the chain reaches round 9 at 600 us instead of 512.  The single list meters the chain tasks out between the tiles; that is worth more than the bypass.)
 constexpr double CHOL_DEFER = 0.05;
 constexpr bool CHOL_SPLIT_DIAG = true;
+static int chol_far_g()  // PIQP_AMD_DEBUG=chol_far=<g>: panels per visit of the far tiles (1: one panel per visit as in round 3)
+{
+    static const int g = [] { const char* e = debug_token("chol_far"); const int v = e ? std::atoi(e) : 4; return v < 1 ? 1 : (v > 16 ? 16 : v); }();
+    return g;
+}
 static void chol_build_tasks(int T, std::vector<CholTask>& H)
 {
+    const int far_g = chol_far_g(), far_slack = 3;
     // One queue, sorted by a key in units of chain rounds.  The crew and panel tasks of round k have key k - 1 (drawn a round early: the crew follows the
     // slices of its operand, a panel task waits for its own rows); the first tile column of round k, which feeds them, k - 0.5; tile column tj >= 2 of
     // round k,  k + CHOL_DEFER (tj - 1):  with CHOL_DEFER = 0 that is the plain order  crew(k+1) panel(k+1) bulk(k) ...;  a small slope pushes the far
@@ -1937,9 +2242,15 @@ static void chol_build_tasks(int T, std::vector<CholTask>& H)
             // (the second tile column as well: its diagonal tile is the diagonal block two rounds on, its other tiles the panel after next -- behind the deferred far
             // columns of earlier rounds their updates arrived late, and the crew of round k + 2 waited for them)
             const double key = tj == 1 ? (double)k - 0.5 : (tj == 2 ? (double)k - 0.25 : (double)k + CHOL_DEFER * (tj - 1));
+            // round 4: the updates of a FAR tile column (absolute column j, updates k <= j - 4 - far_slack) are taken far_g panels per visit (kind 7: one C
+            // fetch, one store, one ticket for far_g x 128 operand columns; same products in the same order -- bitwise the same tile)
+            const int j = k + 1 + tj, nfar = j - 3, nb = (far_g > 1 && nfar - far_slack > 0) ? (nfar - far_slack) / far_g : 0;
+            const bool in_block = k < nb * far_g;
+            if (in_block && (k % far_g) != far_g - 1) continue;  // (the visit is listed with its last panel)
             for (int ti = tj; ti < Tk; ++ti) {
                 // tile (1, 1) is the next round's diagonal block: its update stands between this round's second panel row and the next crew -- two workgroups
-                if (ti == 1 && tj == 1 && CHOL_SPLIT_DIAG) { all.push_back({key, 3, {4, (short)k, 1, 1, k}}); all.push_back({key, 3, {5, (short)k, 1, 1, k}}); }
+                if (in_block) all.push_back({key, 3, {7, (short)(k - far_g + 1), (short)(k + 1 + ti), (short)j, k}});
+                else if (ti == 1 && tj == 1 && CHOL_SPLIT_DIAG) { all.push_back({key, 3, {4, (short)k, 1, 1, k}}); all.push_back({key, 3, {5, (short)k, 1, 1, k}}); }
                 else all.push_back({key, 3, {3, (short)k, (short)ti, (short)tj, k}});
             }
         }
@@ -1947,6 +2258,149 @@ static void chol_build_tasks(int T, std::vector<CholTask>& H)
     std::stable_sort(all.begin(), all.end(), [](const Keyed& a, const Keyed& b) { return a.key != b.key ? a.key < b.key : a.cls < b.cls; });
     H.clear();
     for (const Keyed& q : all) H.push_back(q.t);
+}
+// The task list WITH the assembly inside the launch (round 4).  What changes against chol_build_tasks:
+//  * every tile (i, j), j >= 1, is assembled by chol_asm_slices(j) tasks of kind 6 (column-major: the columns the chain needs first come first); block column 0
+//    is assembled, factored and solved by launches before this one;
+//  * the updates k <= j - 4 of a tile of column j ("far": three or more tile columns ahead of the chain) are taken FAR_G panels per visit (kind 7) as long as the
+//    visit ends FAR_SLACK columns before the chain needs the tile; the rest stay one panel per visit (kind 3), the near ones untouched;
+//  * the order comes from a time model instead of round keys (the chain cannot run ahead of the assembly of its columns any more): assembly tasks at the time the
+//    chip reaches them (FUSE_WEFF workgroups of FUSE_CHUNK_US per operand chunk), the chain's round k at tau_c(k) = max(tau_c(k - 1) + FUSE_ROUND_US, column k + 1
+//    assembled), its tasks relative to tau_c(k) like their keys relative to k before;
+//  * one relaxation pass in creation order (which is a topological order) pushes every task behind everything it waits for, so "a workgroup only ever waits for
+//    earlier tickets" -- the property that makes the single list deadlock-free under any residency -- holds by construction whatever the model says.
+constexpr int FAR_G = 4, FAR_SLACK = 3;
+constexpr double FUSE_ROUND_US = 43.0, FUSE_CHUNK_US = 17.5, FUSE_VISIT_US = 6.0, FUSE_WEFF = 200.0;
+static void chol_build_tasks_fused(int T, int mchunks, std::vector<CholTask>& H, int& part_slots, std::vector<CholTask>& Q, int (&qptr)[9])
+{
+    struct Node { double tau, dur; int cls; CholTask t; std::vector<int> deps; };
+    std::vector<Node> N;
+    auto add = [&](double tau, double dur, int cls, CholTask t, std::vector<int> deps) { N.push_back({tau, dur, cls, t, std::move(deps)}); return (int)N.size() - 1; };
+    std::vector<std::vector<int>> lastw((size_t)T * T);     // tasks whose completion the next update of tile (i, j) waits for
+    std::vector<std::vector<int>> solved((size_t)T * T);    // [k T + i]: panel tasks that solve block row i of panel k
+    std::vector<std::vector<int>> panel_of_round((size_t)T);
+    std::vector<int> owner((size_t)T, -1);
+    auto cat = [](std::vector<int> a, const std::vector<int>& b) { a.insert(a.end(), b.begin(), b.end()); return a; };
+    // ---- assembly: eight queues (tile (i, j) in queue i mod 8), each column-major and slice-major inside a column; one token per task in the ticket list
+    part_slots = 0;
+    std::vector<int> aux((size_t)T * T, 0);
+    for (int j = 1; j < T; ++j) {
+        const int S = chol_asm_slices(j, mchunks);
+        for (int i = j; i < T; ++i) { aux[(size_t)i * T + j] = part_slots; if (S > 1) part_slots += S; }
+    }
+    Q.clear();
+    std::vector<int> qpos((size_t)T * T, 0);  // position inside its queue of the LAST slice of tile (i, j)
+    std::vector<double> qdur;
+    for (int x = 0; x < 8; ++x) {
+        qptr[x] = (int)Q.size();
+        for (int j = 1; j < T; ++j) {
+            const int S = chol_asm_slices(j, mchunks);
+            for (int sl = 0; sl < S; ++sl)
+                for (int i = j; i < T; ++i) {
+                    if ((i & 7) != x) continue;
+                    qpos[(size_t)i * T + j] = (int)Q.size() - qptr[x];
+                    Q.push_back({6, (short)sl, (short)i, (short)j, x, aux[(size_t)i * T + j]});
+                    const int c0 = (int)((long long)sl * mchunks / S), c1 = (int)((long long)(sl + 1) * mchunks / S);
+                    qdur.push_back(FUSE_VISIT_US + FUSE_CHUNK_US * (c1 - c0));
+                }
+        }
+    }
+    qptr[8] = (int)Q.size();
+    // tokens: the queues advance together (one token in eight goes to each), so token number t stands for position t / 8 of every queue
+    const int ntok = (int)Q.size();
+    std::vector<int> tok((size_t)ntok);
+    {
+        double cum = 0.0;
+        int maxlen = 0;
+        for (int x = 0; x < 8; ++x) maxlen = std::max(maxlen, qptr[x + 1] - qptr[x]);
+        int made = 0;
+        for (int pos = 0; pos < maxlen; ++pos)
+            for (int x = 0; x < 8; ++x) {
+                if (pos >= qptr[x + 1] - qptr[x]) continue;
+                const double dur = qdur[(size_t)qptr[x] + pos];
+                tok[(size_t)made++] = add(cum / FUSE_WEFF, dur, 3, {8, 0, 0, 0, 0, 0}, {});
+                cum += dur;
+            }
+    }
+    std::vector<double> col_done((size_t)T, 0.0);
+    auto tile_token = [&](int i, int j) {  // the token by which tile (i, j) is expected to be drawn completely
+        const int x = i & 7;
+        int before = 0;  // tokens made before position qpos of queue x: all queues' entries at smaller positions + the queues < x at this one
+        const int pos = qpos[(size_t)i * T + j];
+        for (int y = 0; y < 8; ++y) before += std::min(qptr[y + 1] - qptr[y], pos + (y <= x ? 1 : 0));
+        return tok[(size_t)std::min(std::max(before - 1, 0), ntok - 1)];
+    };
+    for (int j = 1; j < T; ++j)
+        for (int i = j; i < T; ++i) {
+            const int id = tile_token(i, j);
+            lastw[(size_t)i * T + j].push_back(id);
+            col_done[(size_t)j] = std::max(col_done[(size_t)j], N[(size_t)id].tau + N[(size_t)id].dur + 15.0);
+        }
+    // ---- the chain's clock
+    std::vector<double> tc((size_t)T, 0.0);
+    for (int k = 0; k + 1 < T; ++k) tc[(size_t)k] = std::max(k > 0 ? tc[(size_t)k - 1] + FUSE_ROUND_US : 0.0, col_done[(size_t)k + 1] + 5.0);
+    const double R = FUSE_ROUND_US;
+    for (int k = 0; k + 1 < T; ++k) {
+        const int Tk = T - k - 1, gate = std::max(k - 1, 0), d = k + 1;
+        const double t0 = tc[(size_t)k];
+        // crew of the next diagonal block (tile (d, d)): its previous update, block row d of panel k; the owner also the panel tasks of round k - 2 (pack buffer)
+        {
+            std::vector<int> deps = lastw[(size_t)d * T + d];
+            if (k > 0) deps = cat(deps, solved[(size_t)k * T + d]);
+            for (int r = 1; r < FUSE_ROLES; ++r) add(t0 - R, 20.0, 0, {0, (short)k, (short)r, 0, gate, 0}, deps);
+            if (k >= 2) deps = cat(deps, panel_of_round[(size_t)k - 2]);
+            owner[(size_t)k] = add(t0 - R, 5.0, 1, {1, (short)k, 0, 0, gate, 0}, deps);  // (the panel rows FOLLOW the owner: a short lead)
+        }
+        for (int ti = 1; ti < Tk; ++ti) {
+            const int i = k + 1 + ti;
+            std::vector<int> deps = lastw[(size_t)i * T + d];
+            if (k > 0) deps = cat(cat(deps, solved[(size_t)k * T + i]), solved[(size_t)k * T + d]);
+            deps.push_back(owner[(size_t)k]);
+            const int spr = chol_split_row(T, k, ti);
+            std::vector<int> ids;
+            for (int h = 0; h < spr; ++h) ids.push_back(add(t0 - R, 30.0, 2, {2, (short)k, (short)ti, (short)(spr == 1 ? -1 : h), gate, 0}, deps));
+            solved[(size_t)(k + 1) * T + i] = ids;
+            lastw[(size_t)i * T + d] = ids;
+            panel_of_round[(size_t)k] = cat(panel_of_round[(size_t)k], ids);
+        }
+        for (int tj = 1; tj < Tk; ++tj) {
+            const int j = k + 1 + tj;
+            // is update k of column j part of a FAR_G visit?  (far: k <= j - 4; visits cover [0, nb FAR_G), nb = (j - 3 - FAR_SLACK) / FAR_G)
+            const int nfar = j - 3, nb = nfar - FAR_SLACK > 0 ? (nfar - FAR_SLACK) / FAR_G : 0;
+            const bool in_block = k < nb * FAR_G;
+            if (in_block && (k % FAR_G) != FAR_G - 1) continue;  // (the visit is created with its last panel)
+            const double tau = tj == 1 ? t0 - 0.5 * R : (tj == 2 ? t0 - 0.25 * R : t0 + CHOL_DEFER * R * (tj - 1));
+            for (int ti = tj; ti < Tk; ++ti) {
+                const int i = k + 1 + ti;
+                std::vector<int> deps = lastw[(size_t)i * T + j];
+                if (k > 0) deps = cat(cat(deps, solved[(size_t)k * T + i]), solved[(size_t)k * T + j]);
+                std::vector<int> ids;
+                if (in_block) ids.push_back(add(tau, FUSE_VISIT_US + FUSE_CHUNK_US * FAR_G, 3, {7, (short)(k - FAR_G + 1), (short)i, (short)j, k, 0}, deps));
+                else if (ti == 1 && tj == 1 && CHOL_SPLIT_DIAG) { ids.push_back(add(tau, 18.0, 3, {4, (short)k, 1, 1, k, 0}, deps)); ids.push_back(add(tau, 18.0, 3, {5, (short)k, 1, 1, k, 0}, deps)); }
+                else ids.push_back(add(tau, 25.0, 3, {3, (short)k, (short)ti, (short)tj, k, 0}, deps));
+                lastw[(size_t)i * T + j] = ids;
+            }
+        }
+    }
+    // a task is drawn when what it waits for is expected to be DONE (drawn earlier it would park its workgroup for the rest of the producer's run: with the
+    // producers' start times only, the tiles' first updates slept 250-600 us each behind 130-390 us assembly tasks and the launch took 7 ms)
+    // -- except along the chain itself (crew and panel tasks waiting for chain or tile tasks), which keeps its early draw: a crew follows the slices of its operand.
+    // The gate of a task (drawn only when that many rounds have ALL their panel tasks done) must refer to earlier tickets as well, or the head of the list waits
+    // for a ticket behind it: every panel task of round gate - 1 (tests/test_chol_plan.py found exactly this in the first version of this list).
+    for (Node& q : N) {
+        for (int dep : q.deps) {
+            const Node& d = N[(size_t)dep];
+            const bool early = q.cls <= 2 && d.t.kind != 8;
+            q.tau = std::max(q.tau, d.tau + (early ? 1e-3 : d.dur));
+        }
+        if (q.t.gate >= 1 && q.t.kind != 8)
+            for (int dep : panel_of_round[(size_t)q.t.gate - 1]) q.tau = std::max(q.tau, N[(size_t)dep].tau + 1e-3);
+    }
+    std::vector<int> order(N.size());
+    for (size_t q = 0; q < N.size(); ++q) order[q] = (int)q;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return N[(size_t)a].tau != N[(size_t)b].tau ? N[(size_t)a].tau < N[(size_t)b].tau : N[(size_t)a].cls < N[(size_t)b].cls; });
+    H.clear();
+    for (int q : order) H.push_back(N[(size_t)q].t);
 }
 size_t chol_task_count(int T)
 {
@@ -1960,22 +2414,28 @@ struct CholPlan {
     CholTask* tasks = nullptr;  // device
     int ntasks = 0;
     int grid = 0;
+    int part_slots = 0;         // fused assembly: 128 x 128 slots of partial sums
+    CholTask* aq = nullptr;     // fused assembly: the eight queues of assembly tasks (device), queue x = [aq_ptr[x], aq_ptr[x + 1])
+    int aq_ptr[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 };
-// device-resident task list per (device, T); built at create time (chol_prepare), never freed: a few tens of KB
-static const CholPlan* chol_plan(int T)
+// device-resident task list per (device, T, operand chunks of the fused assembly or 0); built at create time (chol_prepare), never freed: a few tens of KB
+static const CholPlan* chol_plan(int T, int mchunks = 0)
 {
     static std::mutex mu;
-    static std::map<std::pair<int, int>, CholPlan> cache;
+    static std::map<std::pair<int, std::pair<int, int>>, CholPlan> cache;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
     std::lock_guard<std::mutex> lk(mu);
-    auto it = cache.find({dev, T});
+    const auto key = std::make_pair(dev, std::make_pair(T, mchunks));
+    auto it = cache.find(key);
     if (it != cache.end()) return it->second.tasks ? &it->second : nullptr;
-    CholPlan& P = cache[{dev, T}];
+    CholPlan& P = cache[key];
     P.T = T;
-    std::vector<CholTask> h;
-    chol_build_tasks(T, h);
-    if (h.size() != chol_task_count(T)) return nullptr;
+    std::vector<CholTask> h, q;
+    if (mchunks > 0) chol_build_tasks_fused(T, mchunks, h, P.part_slots, q, P.aq_ptr);
+    else {
+        chol_build_tasks(T, h);
+    }
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_persistent), hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS_BYTES) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     int per_cu = 0, cus = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(k_chol_persistent), CHOL_THREADS, FUSED_LDS_BYTES) != hipSuccess || per_cu < 1) { (void)hipGetLastError(); return nullptr; }
@@ -1984,20 +2444,48 @@ static const CholPlan* chol_plan(int T)
     if (hipMalloc(&P.tasks, sizeof(CholTask) * h.size()) != hipSuccess) { (void)hipGetLastError(); P.tasks = nullptr; return nullptr; }
     ++alloc_counter();
     if (hipMemcpy(P.tasks, h.data(), sizeof(CholTask) * h.size(), hipMemcpyHostToDevice) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(P.tasks); P.tasks = nullptr; return nullptr; }
+    if (!q.empty()) {
+        if (hipMalloc(&P.aq, sizeof(CholTask) * q.size()) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(P.tasks); P.tasks = nullptr; return nullptr; }
+        ++alloc_counter();
+        if (hipMemcpy(P.aq, q.data(), sizeof(CholTask) * q.size(), hipMemcpyHostToDevice) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(P.tasks); (void)hipFree(P.aq); P.tasks = nullptr; return nullptr; }
+    }
     P.ntasks = (int)h.size();
     return &P;
 }
+// host-only: the ticket-ordered task list as (kind, round, a, b, gate, aux) -- tests/test_chol_plan.py checks on the CPU that every task only waits for earlier tickets
+int chol_debug_plan(int T, int mchunks, int* out6, int capacity_tasks)
+{
+    std::vector<CholTask> h, q;
+    int slots = 0, qptr[9];
+    if (mchunks > 0) chol_build_tasks_fused(T, mchunks, h, slots, q, qptr);
+    else chol_build_tasks(T, h);
+    h.insert(h.end(), q.begin(), q.end());  // (the assembly queues behind the ticket list: kind 6, gate = queue)
+    if (out6)
+        for (size_t q = 0; q < h.size() && (int)q < capacity_tasks; ++q) {
+            int* o = out6 + 6 * q;
+            o[0] = h[q].kind; o[1] = h[q].round; o[2] = h[q].a; o[3] = h[q].b; o[4] = h[q].gate; o[5] = h[q].aux;
+        }
+    return (int)h.size();
+}
 bool chol_persistent_supported(int n) { return n % FACTOR_NB == 0 && n / FACTOR_NB >= 3 && n / FACTOR_NB <= 1024; }
 bool chol_prepare(int n) { return chol_persistent_supported(n) && chol_plan(n / FACTOR_NB) != nullptr; }
-size_t chol_flag_ints(int n) { const size_t T = (size_t)(n / FACTOR_NB); return 4 + 2 * T * T + 10 * T + 1; }
+// the fused assembly needs whole operand chunks and enough of them to be worth the partial sums
+bool chol_fused_supported(int n, int m) { return chol_persistent_supported(n) && m >= 4 * FACTOR_NB && m % FACTOR_NB == 0; }
+size_t chol_prepare_fused(int n, int m)  // 0: not available; else the doubles of partial-sum workspace (>= 1)
+{
+    if (!chol_fused_supported(n, m)) return 0;
+    const CholPlan* P = chol_plan(n / FACTOR_NB, m / FACTOR_NB);
+    return P ? (size_t)std::max(P->part_slots, 1) * TS * TS : 0;
+}
+size_t chol_flag_ints(int n) { const size_t T = (size_t)(n / FACTOR_NB); return 12 + 3 * T * T + 10 * T + 1; }
 // Rounds 0 .. T - 2 of the blocked factorisation of the n x n lower triangle at A (the first diagonal block and the first panel are already
 // factored / solved: launch_potrf_diag + launch_trsm_panel).  flags: chol_flag_ints(n) ints zeroed at allocation; gen: launch-unique, advancing by
 // at least T + 2 per call; fcount: calls made before on this flag array; token_base: fused-launch tokens consumed so far (advances by T - 1).
 bool launch_chol_persistent(bool ldlt, double* A, double* side, int lda, int n, int* info, double* rdiag, double* dvec, double* pack2, double* w16, double* scratch, int* fuse_flags, int* fuse_cnt,
-                            int token_base, int* flags, int gen, int fcount, hipStream_t s)
+                            int token_base, int* flags, int gen, int fcount, hipStream_t s, const CholAssembly* fa)
 {
     const int T = n / FACTOR_NB;
-    const CholPlan* P = chol_plan(T);
+    const CholPlan* P = chol_plan(T, fa ? fa->m / FACTOR_NB : 0);
     if (!P) return false;
     static long long* trace_d = nullptr;  // PIQP_AMD_DEBUG=chol_trace: timeline of the LAST launch, summarised to stderr (synchronises: a debugging aid)
     static size_t trace_n = 0;
@@ -2012,11 +2500,15 @@ bool launch_chol_persistent(bool ldlt, double* A, double* side, int lda, int n, 
     c.info = info; c.rdiag = rdiag; c.dvec = dvec; c.pack2 = pack2; c.w16 = w16;
     c.scratch = scratch; c.fuse_flags = fuse_flags; c.fuse_cnt = fuse_cnt; c.token_base = token_base;
     c.tasks = P->tasks; c.ntasks = P->ntasks;
-    c.ticket = flags; c.lready = flags + 4; c.tver = c.lready + (size_t)T * T; c.pdone = c.tver + (size_t)T * T; c.xcnt = c.pdone + T; c.progress = c.xcnt + 8 * (size_t)T; c.dhalf = c.progress + 1;
+    c.ticket = flags; c.aq_head = flags + 4; c.lready = flags + 12; c.tver = c.lready + (size_t)T * T; c.pdone = c.tver + (size_t)T * T; c.xcnt = c.pdone + T; c.progress = c.xcnt + 8 * (size_t)T; c.dhalf = c.progress + 1;
     c.gen = gen; c.fcount = fcount;
+    c.acnt = c.dhalf + T;
+    c.GT = nullptr; c.ldg = 0; c.m = 0; c.zinv = nullptr; c.Pfull = nullptr; c.ldp = 0; c.x_reg = nullptr; c.ATA = nullptr; c.ldata = 0; c.dinv = 0.0; c.part = nullptr;
+    c.aq = P->aq; for (int x = 0; x < 9; ++x) c.aq_ptr[x] = P->aq_ptr[x];
+    if (fa) { c.GT = fa->GT; c.ldg = fa->ldg; c.m = fa->m; c.zinv = fa->zinv; c.Pfull = fa->Pfull; c.ldp = fa->ldp; c.x_reg = fa->x_reg; c.ATA = fa->ATA; c.ldata = fa->ldata; c.dinv = fa->dinv; c.part = fa->part; }
     c.trace = want_trace ? trace_d : nullptr;
     if (want_trace) PQ_HIP(hipMemsetAsync(trace_d, 0, trace_n * sizeof(long long), s));
-    PQ_HIP(hipMemsetAsync(flags, 0, 4 * sizeof(int), s));  // the ticket counter and the abort word
+    PQ_HIP(hipMemsetAsync(flags, 0, 12 * sizeof(int), s));  // the ticket counter, the abort word, the heads of the assembly queues
     hipLaunchKernelGGL(k_chol_persistent, dim3(P->grid), dim3(CHOL_THREADS), FUSED_LDS_BYTES, s, c);
     PQ_HIP(hipGetLastError());
     if (want_trace) {
@@ -2029,12 +2521,26 @@ bool launch_chol_persistent(bool ldlt, double* A, double* side, int lda, int n, 
         for (int t = 0; t < P->ntasks; ++t) t0 = std::min(t0, h[4 * (size_t)t]);
         auto us = [&](long long v) { return (double)(v - t0) * 0.01; };
         std::fprintf(stderr, "[piqp_amd] k_chol_persistent timeline (us since the first ticket), T = %d, %d tasks, grid %d\n", T, P->ntasks, P->grid);
+        if (fa) {
+            // fused assembly: per block column the end of its last assembly task; the several-panel visits of the far tiles
+            std::vector<double> aend((size_t)T, 0.0), awork((size_t)T, 0.0); std::vector<int> an((size_t)T, 0);
+            double fwork = 0, fwait = 0; int fn = 0, fpan = 0;
+            for (int t = 0; t < P->ntasks; ++t) {
+                const CholTask& q = tk[(size_t)t];
+                const double d0 = us(h[4 * (size_t)t]), d1 = us(h[4 * (size_t)t + 1]), d2 = us(h[4 * (size_t)t + 2]);
+                if (q.kind == 8 && d2 > d1) { const int jc = (int)(h[4 * (size_t)t + 3] / 1000); if (jc > 0 && jc < T) { aend[(size_t)jc] = std::max(aend[(size_t)jc], d2); awork[(size_t)jc] += d2 - d1; ++an[(size_t)jc]; } }
+                if (q.kind == 7) { fwork += d2 - d1; fwait += d1 - d0; ++fn; fpan += q.gate + 1 - q.round; }
+            }
+            std::fprintf(stderr, "[piqp_amd]  assembly tasks, block column: tasks / avg us / last end:");
+            for (int j = 1; j < T; ++j) std::fprintf(stderr, " %d: %d / %.0f / %.0f |", j, an[(size_t)j], an[(size_t)j] ? awork[(size_t)j] / an[(size_t)j] : 0.0, aend[(size_t)j]);
+            std::fprintf(stderr, "\n[piqp_amd]  far visits: %d (%d panels), avg work %.1f us, avg wait %.1f us\n", fn, fpan, fn ? fwork / fn : 0.0, fn ? fwait / fn : 0.0);
+        }
         for (int k = 0; k + 1 < T; ++k) {
             double own_ready = 0, own_done = 0, help_done = 0, pan_ready = 0, pan_done = 0, bulk_first = 1e30, bulk_last = 0, bulk_work = 0, bulk_wait = 0;
             double r1[3] = {0, 0, 0}, r2[3] = {0, 0, 0}, dg[3] = {0, 0, 0};  // first / second panel row, diagonal tile of the first bulk column: drawn, inputs, done (latest half)
             int nb = 0;
             for (int t = 0; t < P->ntasks; ++t) {
-                if (tk[(size_t)t].round != k) continue;
+                if (tk[(size_t)t].kind >= 6 || tk[(size_t)t].round != k) continue;
                 const double d0 = us(h[4 * (size_t)t]), d1 = us(h[4 * (size_t)t + 1]), d2 = us(h[4 * (size_t)t + 2]);
                 switch (tk[(size_t)t].kind) {
                 case 0: help_done = std::max(help_done, d2); break;
@@ -2358,8 +2864,8 @@ __global__ __launch_bounds__(POTRF_THREADS) void k_front_panel_step(const FrontJ
 // one panel step of the partial LDLt of many fronts: diagonal blocks and panels (two launches whatever the number of fronts), then the trailing updates
 static void front_attrs()
 {
-    static bool attr_set = false;
-    if (attr_set) return;
+    static PerDeviceOnce attr_set;
+    attr_set([&] {
     PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_diag_fronts), hipFuncAttributeMaxDynamicSharedMemorySize, POTRF_LDS_BYTES));
     PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_trsm_panel_fronts), hipFuncAttributeMaxDynamicSharedMemorySize, TRSM_LDS_BYTES));
     PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_trsm_fronts), hipFuncAttributeMaxDynamicSharedMemorySize, POTRF_LDS_BYTES));
@@ -2368,7 +2874,7 @@ static void front_attrs()
     PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk_lower_fronts<4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, SYRK_LDS_BYTES));
     PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk_half_fronts<2>), hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS_BYTES));
     PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk_half_fronts<4>), hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS_BYTES));
-    attr_set = true;
+    });
 }
 void launch_front_diag_panels(const FrontJob* jobs, int njobs, int panel, int max_rows_below, int* info, double* rdiag, hipStream_t s, bool follow)
 {
@@ -2418,12 +2924,11 @@ void launch_trsm_panel(bool ldlt, double* A, int lda, int k0, int nb, int n, con
 {
     const int rs = n - k0 - nb;
     if (rs <= 0) return;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_set;
+    attr_set([&] {
         PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_trsm_panel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, TRSM_LDS_BYTES));
         PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_trsm_panel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, TRSM_LDS_BYTES));
-        attr_set = true;
-    }
+    });
     if (ldlt) hipLaunchKernelGGL(k_trsm_panel<true>, dim3(div_up(rs, TRSM_ROWS)), dim3(256), TRSM_LDS_BYTES, s, A, lda, k0, nb, n, pack, rdiag);
     else hipLaunchKernelGGL(k_trsm_panel<false>, dim3(div_up(rs, TRSM_ROWS)), dim3(256), TRSM_LDS_BYTES, s, A, lda, k0, nb, n, pack, rdiag);
     PQ_HIP(hipGetLastError());
@@ -2922,14 +3427,13 @@ size_t trsv_flag_ints(int n) { return 2 * (size_t)div_up(n, TB) + 1; }
 void launch_trsv(const double* L, int ld, int n, double* x, const double* rdiag, bool ldlt, int* flags, int token, const double* w16, hipStream_t s, long long* ts)
 {
     if (n <= 0) return;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_set;
+    attr_set([&] {
         PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_trsv_fwd_step), hipFuncAttributeMaxDynamicSharedMemorySize, TRSV_LDS_BYTES));
         PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_trsv_bwd_step), hipFuncAttributeMaxDynamicSharedMemorySize, TRSV_LDS_BYTES));
         PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_trsv_persistent<true>), hipFuncAttributeMaxDynamicSharedMemorySize, TRSV_P_LDS_BYTES));
         PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_trsv_persistent<false>), hipFuncAttributeMaxDynamicSharedMemorySize, TRSV_P_LDS_BYTES));
-        attr_set = true;
-    }
+    });
     const int nblk = div_up(n, TB);
     const double* rd = ldlt ? nullptr : rdiag;
     const bool persistent = flags != nullptr && nblk <= 224;  // every block resident (one per CU) with room to spare

@@ -78,8 +78,21 @@ void launch_trsm_panel(bool ldlt, double* A, int lda, int k0, int nb, int n, con
 bool chol_persistent_supported(int n);
 bool chol_prepare(int n);      // builds the device task list of this size (allocates: call at create time); false = use the launch-per-panel path
 size_t chol_flag_ints(int n);  // ints of flag storage, zeroed once at allocation
+// fused assembly (round 4): the tiles of block columns >= 1 are assembled by tasks of the persistent launch (dense/kkt.hpp:140-160); block column 0 by
+// launch_syrk_first_col before it.  m % 128 == 0, m >= 512 (chol_fused_supported).
+void launch_pack_row_panels(const double* G, int n, int m, double* Gp, hipStream_t s);  // n % 128 == 0: row panel i of G (ld = n) -> Gp + i 128 m, ld = 128
+struct CholAssembly {
+    const double* GT = nullptr; int ldg = 0, m = 0; const double* zinv = nullptr;  // GT: packed as row panels (launch_pack_row_panels), ldg unused
+    const double* Pfull = nullptr; int ldp = 0; const double* x_reg = nullptr; const double* ATA = nullptr; int ldata = 0; double dinv = 0.0;
+    double* part = nullptr;  // chol_prepare_fused(n, m) doubles
+};
+int chol_debug_plan(int T, int mchunks, int* out6, int capacity_tasks);  // host-only: the task list (mchunks > 0: with the fused assembly), 6 ints per task; returns the task count
+bool chol_fused_supported(int n, int m);
+size_t chol_prepare_fused(int n, int m);  // builds the fused task list (allocates: create time); doubles of partial-sum workspace, 0 = not available
+// the assembly of block column 0 alone (tiles (i, 0)), K split over `ks` workgroups per tile with the fixed-order reduce of the tail tiles; ws: T * ks * 128 * 128 doubles
+void launch_syrk_first_col(const SyrkArgs& args, int ks, double* ws, hipStream_t s);
 bool launch_chol_persistent(bool ldlt, double* A, double* side, int lda, int n, int* info, double* rdiag, double* dvec, double* pack2, double* w16, double* scratch, int* fuse_flags, int* fuse_cnt,
-                            int token_base, int* flags, int gen, int fcount, hipStream_t s);
+                            int token_base, int* flags, int gen, int fcount, hipStream_t s, const CholAssembly* fused = nullptr);
 size_t trsv_flag_ints(int n);
 // w16: the inverted 16 x 16 diagonal pieces written by the factorisation (8 x 256 doubles per 128-column panel), nullptr: substitution only
 void launch_trsv(const double* L, int ld, int n, double* x, const double* rdiag, bool ldlt, int* flags, int token, const double* w16, hipStream_t s, long long* ts = nullptr);  // ts: debugging aid, 4 stamps per block of the forward sweep

@@ -73,7 +73,8 @@ public:
         dense::launch_reciprocal(m_, z_reg, z_reg_inv_.p, st_);
         PQ_HIP(hipMemcpyAsync(x_reg_last_.p, x_reg, sizeof(double) * n_, hipMemcpyDeviceToDevice, st_));
         int t0 = prof_.begin(0, st_);
-        update_kkt(x_reg_last_.p, fac_.p);
+        if (chol_fused_) assemble_first_block_column(x_reg_last_.p);  // (the other block columns are assembled inside the persistent launch)
+        else update_kkt(x_reg_last_.p, fac_.p);
         prof_.end(0, t0, st_);
         int t1 = prof_.begin(1, st_);
         launch_factor_panels();
@@ -172,6 +173,7 @@ private:
         alloc();
         auto cp = [&](DBuf<double>& dst, const DBuf<double>& src) { if (src.n) PQ_HIP(hipMemcpyAsync(dst.p, src.p, src.bytes(), hipMemcpyDeviceToDevice, st_)); };
         cp(Pfull_, o.Pfull_); cp(Pdiag_, o.Pdiag_); cp(AT_, o.AT_); cp(GT_, o.GT_); cp(ATA_, o.ATA_); cp(fac_, o.fac_);
+        cp(GTp_, o.GTp_);
         cp(z_reg_inv_, o.z_reg_inv_); cp(x_reg_last_, o.x_reg_last_); cp(rdiag_, o.rdiag_); cp(w16_, o.w16_);
         stream_wait(st_);
     }
@@ -197,6 +199,18 @@ private:
         // PIQP_AMD_DEBUG=chol_launches: the launch-per-panel factorisation for every size (the bitwise comparison of tests/test_dense_gpu.py)
         chol_persistent_ = !debug_token("chol_launches") && dense::chol_prepare(n_);
         if (chol_persistent_) { side_.alloc((size_t)n_ * n_); pack2_.alloc(2 * (size_t)dense::FACTOR_PACK_DOUBLES); chol_flags_.alloc(dense::chol_flag_ints(n_)); chol_flags_.zero(st_); }
+        // round 4, EXPERIMENTAL (PIQP_AMD_DEBUG=chol_fused; default: assembly launch, then the factorisation): the assembly (dense/kkt.hpp:140-160) as tasks of the
+        // persistent launch, overlapped with the factorisation.  Correct (tools/chk_chol_fused.py) and slower at n = 4096: see DESIGN.md section 4.
+        if (chol_persistent_ && m_ > 0 && debug_token("chol_fused")) {
+            const size_t d = dense::chol_prepare_fused(n_, m_);
+            if (d > 0) {
+                chol_fused_ = true;
+                asm_part_.alloc(d);
+                GTp_.alloc((size_t)n_ * m_);
+                col0_ks_ = 8;
+                col0_ws_.alloc((size_t)(n_ / dense::FACTOR_NB) * col0_ks_ * 128 * 128);
+            }
+        }
         flags_.alloc(dense::trsv_flag_ints(n_)); flags_.zero(st_);
         if (debug_token("trsv_ts")) { trsv_ts_.alloc(4 * ((n_ + 127) / 128) + 8); trsv_ts_.zero(st_); }
         if (const char* e = debug_token("fused_ts")) { dbg_panel_ = std::atoi(e); dbg_ts_.alloc(96); dbg_ts_.zero(st_); }
@@ -212,6 +226,7 @@ private:
         dense::launch_symmetrize_upper(fac_.p, n_, Pfull_.p, Pdiag_.p, st_);
         copy_in(AT_.p, d->AT, (size_t)n_ * p_ * sizeof(double), d->mem, st_);
         copy_in(GT_.p, d->GT, (size_t)n_ * m_ * sizeof(double), d->mem, st_);
+        if (chol_fused_) dense::launch_pack_row_panels(GT_.p, n_, m_, GTp_.p, st_);
         if (p_ > 0) {
             // dense/kkt.hpp:53 AT_A.lower = AT * AT^T
             dense::SyrkArgs a;
@@ -226,14 +241,20 @@ private:
     {
         const double dinv = 1.0 / delta_;
         if (m_ > 0) {
-            dense::SyrkArgs a;
-            a.n = n_; a.kdim = m_; a.A = GT_.p; a.lda = n_; a.B = GT_.p; a.ldb = n_; a.w = z_reg_inv_.p; a.C = out; a.ldc = n_;
-            a.Pfull = Pfull_.p; a.ldp = n_; a.x_reg = x_reg; a.ATA = p_ > 0 ? ATA_.p : nullptr; a.ldata = n_; a.dinv = dinv;
-            dense::launch_syrk(dense::EPI_ASSEMBLE, a, st_, split_ws_.p, split_ws_.n);
+            dense::launch_syrk(dense::EPI_ASSEMBLE, assembly_args(x_reg, out), st_, split_ws_.p, split_ws_.n);
         } else {
             dense::launch_assemble_no_g(n_, Pfull_.p, x_reg, p_ > 0 ? ATA_.p : nullptr, dinv, out, st_);
         }
     }
+
+    dense::SyrkArgs assembly_args(const double* x_reg, double* out) const
+    {
+        dense::SyrkArgs a;
+        a.n = n_; a.kdim = m_; a.A = GT_.p; a.lda = n_; a.B = GT_.p; a.ldb = n_; a.w = z_reg_inv_.p; a.C = out; a.ldc = n_;
+        a.Pfull = Pfull_.p; a.ldp = n_; a.x_reg = x_reg; a.ATA = p_ > 0 ? ATA_.p : nullptr; a.ldata = n_; a.dinv = 1.0 / delta_;
+        return a;
+    }
+    void assemble_first_block_column(const double* x_reg) { dense::launch_syrk_first_col(assembly_args(x_reg, fac_.p), col0_ks_, col0_ws_.p, st_); }
 
     // blocked right-looking factorisation of the lower triangle of fac_ (panel width 128): Eigen::LLT::compute (dense/kkt.hpp:82) or
     // LDLTNoPivot::compute (dense/ldlt_no_pivot.hpp:313-354).  One launch per panel: the fused trailing update of panel k also factors the NEXT
@@ -252,8 +273,16 @@ private:
             if (chol_gen_ > 0x3fffffff - 2 * (T + 2)) { chol_flags_.zero(st_); chol_gen_ = 0; chol_fcount_ = 0; }  // (flag values are compared as signed differences)
             chol_gen_ += T + 2;
             const int tt = prof_.begin(3, st_);
-            dense::launch_chol_persistent(ldlt_, fac_.p, side_.p, n_, n_, info_.p, rdiag_.p, dvec_.p, pack2_.p, w16_.p, fuse_scratch_.p, fuse_flags_.p, fuse_cnt_.p, fuse_token_, chol_flags_.p, chol_gen_,
-                                          chol_fcount_, st_);
+            // (false = no task list for this size on the current device; chol_prepare() built it at create time, so this is a programming error, not a state
+            // to continue from with only the first panel factored)
+            dense::CholAssembly fa;
+            if (chol_fused_) {
+                fa.GT = GTp_.p; fa.ldg = 128; fa.m = m_; fa.zinv = z_reg_inv_.p; fa.Pfull = Pfull_.p; fa.ldp = n_; fa.x_reg = x_reg_last_.p;
+                fa.ATA = p_ > 0 ? ATA_.p : nullptr; fa.ldata = n_; fa.dinv = 1.0 / delta_; fa.part = asm_part_.p;
+            }
+            if (!dense::launch_chol_persistent(ldlt_, fac_.p, side_.p, n_, n_, info_.p, rdiag_.p, dvec_.p, pack2_.p, w16_.p, fuse_scratch_.p, fuse_flags_.p, fuse_cnt_.p, fuse_token_, chol_flags_.p,
+                                               chol_gen_, chol_fcount_, st_, chol_fused_ ? &fa : nullptr))
+                throw std::runtime_error("dense factorisation: the persistent launch has no plan for this size / device");
             prof_.end(3, tt, st_);
             fuse_token_ += T - 1;
             ++chol_fcount_;
@@ -323,7 +352,10 @@ private:
     DBuf<double> Pfull_, Pdiag_, AT_, GT_, ATA_, fac_, z_reg_inv_, x_reg_last_, dvec_, part_, rdiag_, split_ws_, pack_, w16_, fuse_scratch_;
     DBuf<int> info_, flags_, fuse_flags_, fuse_cnt_, chol_flags_;
     DBuf<double> pack2_, side_;  // side_: the solved panels once more, at addresses the persistent launch has never read before (dense_kernels.hip)
-    bool chol_persistent_ = false;
+    bool chol_persistent_ = false, chol_fused_ = false;
+    DBuf<double> GTp_;  // fused assembly: GT once more, as row panels of 128 rows (consecutive operand stages)
+    DBuf<double> asm_part_, col0_ws_;  // fused assembly: partial sums of the K-sliced tiles; of block column 0's launch
+    int col0_ks_ = 1;
     int chol_gen_ = 0, chol_fcount_ = 0;
     int fuse_token_ = 0, trsv_token_ = 0;
     int next_trsv_token()

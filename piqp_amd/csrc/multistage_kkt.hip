@@ -325,14 +325,13 @@ private:
         solve_lds_bytes_ = solve_in_lds_ ? (int)sbytes : 0;
         if (2LL * hcap_ * (long long)sizeof(double) > LDS_LIMIT_BYTES) throw std::runtime_error("multistage: a stage is too wide for this backend");
         asm_chunks_ = std::max(1, (fcap_ + ASM_CHUNK - 1) / ASM_CHUNK);
-        static bool attr_set = false;
-        if (!attr_set) {
+        static PerDeviceOnce attr_set;
+        attr_set([&] {
             PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ms_factor<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT_BYTES));
             PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ms_factor<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT_BYTES));
             PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ms_solve<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT_BYTES));
             PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ms_solve<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT_BYTES));
-            attr_set = true;
-        }
+        });
     }
 
     // caller's CSC values -> front / grouped-row arenas (utri_to_kkt :599-670, transpose_to_block_mat :672-818), then AtA (:161)

@@ -174,11 +174,123 @@ __device__ __forceinline__ double pivot_rcp(double d)
     return __builtin_fma(__builtin_fma(-d, y, 1.0), y, y);
 }
 
-// Schur complement of the trailing u x u block in one pass, T[i,j] -= sum_k (L[i,k] d_k) L[j,k] (k ascending, lower triangle), 2 x 2 entries
-// per thread: five LDS reads feed four FMAs instead of twelve
-template <bool SPLIT>  // SPLIT: the panel L (LDS) and the trailing block T (HBM) are different arrays with the same f x f indexing
+// ---- the arithmetic of one elimination step (round 4).  The reference's up-looking LDLt forms every entry of row k as
+//        y[j] -= L(j,i) * y_i   (product rounded, then the difference rounded: "force compiler to not use fma instruction", ldlt.hpp:151-153)
+//        l_ki = y_i / D[i];  D[k] -= l_ki * y_i                                                       (ldlt.hpp:155-158)
+// i.e. entry (r, c), r >= c, loses  fl( fl(y_ci / d_i) * y_ri ):  the QUOTIENT of the column index's value times the unscaled value of the row index.
+// The one-workgroup fronts below do exactly that per term (before round 4: (y_ri * (1/d_i)) * y_ci with the subtraction fused), so that a pivot which
+// cancels to an EXACT zero in the reference -- two variables tied by an equality row whose pivot is -delta: 1e10 + 8e-7 - 1e10, the signal that sends
+// solver.hpp:688-708 into its recovery path on QBEACONF, fffff800, robot_arm_sqp -- does so here too whenever the entry receives its terms in the same
+// order (always for entries with one or two terms; extend-add groups the terms of a child, the up-looking loop does not).
+// y / d from the correctly rounded reciprocal: q = y dinv, one correction with the exact residual (Markstein) gives the IEEE quotient (2e8 random
+// pairs: no mismatch) in three dependent operations instead of the ~250 cycles of a division.
+__device__ __forceinline__ double ref_quot(double y, double d, double dinv)
+{
+    const double q = y * dinv;
+    return __builtin_fma(__builtin_fma(-q, d, y), dinv, q);
+}
+__device__ __forceinline__ double ref_msub(double a, double x, double y) { return __dsub_rn(a, __dmul_rn(x, y)); }  // fl(a - fl(x y)): never contracted
+// Which parts use that arithmetic (PQ_REF_MODE, bit mask; tools/exp_ref_arith.md records the variants measured in round 4):
+//   1  REF_PIVOT  every multiply-subtract of the pivot loops and the scaling of the finished columns
+//   2  REF_SCHUR  the one-pass Schur complement of the trailing block: term by term from T instead of "sum the w terms, subtract once"
+//   4  REF_DIAG   the DIAGONAL entries only (panel and trailing block), everything else as in rounds 1-3 (fused, (y_r / d) y_c, summed Schur terms)
+// A handle whose tree has no multi-workgroup front (they run on the matrix cores and cannot follow this arithmetic) uses PQ_REF_MODE, every other handle
+// PQ_REF_MODE_BIG: the kernels below are instantiated for both (template parameter RM), SparseKKT::ref_mode_ picks one per handle.
+#ifndef PQ_REF_MODE
+#define PQ_REF_MODE 3
+#endif
+#ifndef PQ_REF_MODE_BIG
+#define PQ_REF_MODE_BIG 0
+#endif
+#define PQ_LAUNCH_RM(kern, ...)                                                            \
+    do {                                                                                   \
+        if (ref_mode_ == PQ_REF_MODE) hipLaunchKernelGGL((kern<PQ_REF_MODE>), __VA_ARGS__); \
+        else hipLaunchKernelGGL((kern<PQ_REF_MODE_BIG>), __VA_ARGS__);                      \
+    } while (0)
+#define PQ_ATTR_RM(kern, bytes)                                                                                                                     \
+    do {                                                                                                                                            \
+        PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern<PQ_REF_MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (bytes)));        \
+        PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern<PQ_REF_MODE_BIG>), hipFuncAttributeMaxDynamicSharedMemorySize, (bytes)));    \
+    } while (0)
+#define PQ_REF_FLAGS constexpr bool REF_PIVOT = (RM & 1) != 0, REF_SCHUR = (RM & 2) != 0, REF_DIAG = (RM & 4) != 0; (void)REF_PIVOT; (void)REF_SCHUR; (void)REF_DIAG; static_assert(!(REF_SCHUR && REF_DIAG), "REF_SCHUR already treats the diagonal term by term")
+constexpr int TD_REGS = 4;  // trailing diagonal entries a thread carries through the pivot loop (REF_DIAG); rows beyond TD_REGS x threads go through memory
+// one panel entry of the pivot loop: W(i,j) loses the term of pivot k.  yi, yj: unscaled entries of column k in rows i and j; lj = yj / d (REF_PIVOT only)
+template <int RM>
+__device__ __forceinline__ double pivot_term(double wij, double yi, double yj, double d, double dinv, double lj, bool diag)
+{
+    PQ_REF_FLAGS;
+    if constexpr (REF_PIVOT) return ref_msub(wij, yi, lj);
+    else {
+        if (REF_DIAG && diag) return ref_msub(wij, yj, ref_quot(yj, d, dinv));
+        return wij - (yi * dinv) * yj;
+    }
+}
+template <int RM>
+__device__ __forceinline__ double scale_entry(double y, double d, double dinv) { return (RM & 1) ? ref_quot(y, d, dinv) : y * dinv; }
+// REF_DIAG: the diagonal entries of the TRAILING rows i >= w (those of the update matrix) receive the reference's term of every pivot, one rounded product and one
+// rounded difference each, in pivot order -- carried in registers through the pivot loop (thread t owns rows w + t + q nt), stored before the Schur
+// complement, which then leaves the diagonal alone.  ptr(i): address of T(i,i); ycol(i): unscaled entry of the pivot column in row i.
+template <class P>
+__device__ __forceinline__ void td_load(double (&td)[TD_REGS], int w, int f, int tid, int nt, P ptr)
+{
+#pragma unroll
+    for (int q = 0; q < TD_REGS; ++q) { const int i = w + tid + q * nt; td[q] = i < f ? *ptr(i) : 0.0; }
+}
+template <class P, class Y>
+__device__ __forceinline__ void td_step(double (&td)[TD_REGS], int w, int f, int tid, int nt, P ptr, Y ycol, double d, double dinv)
+{
+#pragma unroll
+    for (int q = 0; q < TD_REGS; ++q) {
+        const int i = w + tid + q * nt;
+        if (i < f) { const double y = ycol(i); td[q] = ref_msub(td[q], y, ref_quot(y, d, dinv)); }
+    }
+    for (int i = w + tid + TD_REGS * nt; i < f; i += nt) { double* p = ptr(i); const double y = ycol(i); *p = ref_msub(*p, y, ref_quot(y, d, dinv)); }
+}
+template <class P>
+__device__ __forceinline__ void td_store(const double (&td)[TD_REGS], int w, int f, int tid, int nt, P ptr)
+{
+#pragma unroll
+    for (int q = 0; q < TD_REGS; ++q) { const int i = w + tid + q * nt; if (i < f) *ptr(i) = td[q]; }
+}
+
+// Schur complement of the trailing u x u block in one pass (lower triangle), 2 x 2 entries per thread: T[i,j] loses fl(y_ik * l_jk) for k ascending,
+// one rounded product and one rounded difference per pivot like the reference's row loop.  y: the UNSCALED panel entries of the trailing rows (still in
+// place), l = y / d: written by scale_columns() into the strictly upper part of the front, entry (k, w + r) -- nothing else ever lives there.
+template <bool SPLIT>  // SPLIT: the panel (LDS) and the trailing block T + upper part (HBM) are different arrays with the same f x f indexing
 __device__ __forceinline__ void schur_2x2(const double* __restrict__ Lp, double* __restrict__ Tp, int f, int w, int u, int tid, int nt)
 {
+    const double* W = Lp;
+    const double* Up = SPLIT ? Tp : Lp;
+    const int tx = tid & 15, ty = tid >> 4, tys = nt >> 4;
+    const int nb = (u + 1) >> 1;
+    for (int bj = ty; bj < nb; bj += tys) {
+        for (int bi = bj + tx; bi < nb; bi += 16) {
+            const int i0 = 2 * bi, j0 = 2 * bj;
+            const bool i1ok = i0 + 1 < u, j1ok = j0 + 1 < u;
+            const double* Yi0 = W + (w + i0);
+            const double* Yi1 = W + (w + (i1ok ? i0 + 1 : i0));
+            const double* Lj0 = Up + (long long)(w + j0) * f;
+            const double* Lj1 = Up + (long long)(w + (j1ok ? j0 + 1 : j0)) * f;
+            double* T = Tp + (w + i0) + (long long)(w + j0) * f;
+            const bool ok10 = i1ok, ok01 = j1ok && i0 >= j0 + 1, ok11 = i1ok && j1ok;  // (i0, j0 + 1): below / on the diagonal only
+            double a00 = T[0], a10 = ok10 ? T[1] : 0.0, a01 = ok01 ? T[f] : 0.0, a11 = ok11 ? T[f + 1] : 0.0;
+            for (int k = 0; k < w; ++k) {
+                const long long ck = (long long)k * f;
+                const double y0 = Yi0[ck], y1 = Yi1[ck], l0 = Lj0[k], l1 = Lj1[k];
+                a00 = ref_msub(a00, y0, l0); a01 = ref_msub(a01, y0, l1); a10 = ref_msub(a10, y1, l0); a11 = ref_msub(a11, y1, l1);
+            }
+            T[0] = a00;                                    // i0 >= j0 always
+            if (ok10) T[1] = a10;                          // (i0 + 1, j0)
+            if (ok01) T[f] = a01;
+            if (ok11) T[f + 1] = a11;                      // (i0 + 1, j0 + 1)
+        }
+    }
+}
+// rounds 1-3 (and the off-diagonal entries under REF_DIAG): T[i,j] -= sum_k (L[i,k] d_k) L[j,k], the w terms summed first; the columns are SCALED here
+template <bool SPLIT, int RM>  // SPLIT: the panel L (LDS) and the trailing block T (HBM) are different arrays with the same f x f indexing
+__device__ __forceinline__ void schur_2x2_sum(const double* __restrict__ Lp, double* __restrict__ Tp, int f, int w, int u, int tid, int nt)
+{
+    PQ_REF_FLAGS;
     const double* W = Lp;
     const int tx = tid & 15, ty = tid >> 4, tys = nt >> 4;
     const int nb = (u + 1) >> 1;
@@ -198,12 +310,36 @@ __device__ __forceinline__ void schur_2x2(const double* __restrict__ Lp, double*
                 a00 += x0 * y0; a01 += x0 * y1; a10 += x1 * y0; a11 += x1 * y1;
             }
             double* T = Tp + (w + i0) + (long long)(w + j0) * f;
-            T[0] -= a00;                                   // i0 >= j0 always
+            const bool dg = REF_DIAG && i0 == j0;          // (REF_DIAG: the diagonal entries were updated pivot by pivot, front_factor_body)
+            if (!dg) T[0] -= a00;                          // i0 >= j0 always
             if (i1ok) T[1] -= a10;                         // (i0 + 1, j0)
             if (j1ok && i0 >= j0 + 1) T[f] -= a01;         // (i0, j0 + 1): below / on the diagonal only
-            if (i1ok && j1ok) T[f + 1] -= a11;             // (i0 + 1, j0 + 1)
+            if (i1ok && j1ok && !dg) T[f + 1] -= a11;      // (i0 + 1, j0 + 1)
         }
     }
+}
+// After the pivot loop the columns 0 .. w-1 hold UNSCALED entries below the diagonal.  Every one becomes l = y / d_k (the reference's L(i,k), ldlt.hpp:155):
+// the panel rows in place; the trailing rows i >= w into the strictly upper part Up[k + i f] (the Schur complement needs their unscaled values as well),
+// copied into place by place_trailing() afterwards.
+__device__ __forceinline__ void scale_columns(double* __restrict__ W, double* __restrict__ Up, int f, int w, int tid, int nt)
+{
+    const int tx = tid & 15, ty = tid >> 4, tys = nt >> 4;
+    for (int k = ty; k < w; k += tys) {
+        double d = W[k + (long long)k * f];
+        if (d == 0.0) d = 1.0;
+        const double dinv = pivot_rcp(d);
+        for (int i = k + 1 + tx; i < f; i += 16) {
+            const double l = ref_quot(W[i + (long long)k * f], d, dinv);
+            if (i < w) W[i + (long long)k * f] = l;
+            else Up[k + (long long)i * f] = l;
+        }
+    }
+}
+__device__ __forceinline__ void place_trailing(double* __restrict__ W, const double* __restrict__ Up, int f, int w, int tid, int nt)
+{
+    const int tx = tid & 15, ty = tid >> 4, tys = nt >> 4;
+    for (int k = ty; k < w; k += tys)
+        for (int i = w + tx; i < f; i += 16) W[i + (long long)k * f] = Up[k + (long long)i * f];
 }
 
 // extend-add of every child's update matrix into front s (fixed child order)
@@ -269,10 +405,11 @@ __device__ __forceinline__ void front_assemble_own(const FrontMeta& M, double* _
 // trailing block in HBM.  Same operations in the same order in all three.  Instantiations instead of one pointer chosen at run time -- such a
 // pointer compiles to FLAT loads / stores (k_front_factor had 20 + 10 of them in its pivot loops).
 enum { FRONT_HBM = 0, FRONT_LDS = 1, FRONT_PANEL = 2, FRONT_PANEL_ONLY = 3 };  // PANEL_ONLY: assembled by other kernels, Schur complement by another kernel (D left in `dvec`)
-template <int WHERE>
+template <int WHERE, int RM>
 __device__ __forceinline__ void front_factor_body(const FrontMeta& M, double* __restrict__ fronts, int s, const SnRec& me, double* __restrict__ rdiag,
                                                   int* __restrict__ info, double* __restrict__ lds, double* __restrict__ W, double* __restrict__ dvec = nullptr)
 {
+    PQ_REF_FLAGS;
     const int first = me.first, w = me.w, f = me.f;
     double* F = fronts + me.front_off;
     constexpr bool in_lds = WHERE == FRONT_LDS;
@@ -296,6 +433,11 @@ __device__ __forceinline__ void front_factor_body(const FrontMeta& M, double* __
     // ---- panel: right-looking LDLt of the first w columns, updates confined to the panel (rows k+1..f-1, columns k+1..w-1)
     const int tid = threadIdx.x, nt = blockDim.x;
     int k0 = 0;
+    constexpr bool trail_diag = REF_DIAG && WHERE != FRONT_PANEL_ONLY;  // (the trailing update of a PANEL_ONLY front runs on the matrix cores)
+    double* Tt = (WHERE == FRONT_PANEL) ? F : W;  // where the trailing block lives
+    auto tptr = [&](int i) -> double* { return Tt + i + (long long)i * f; };
+    double td[TD_REGS];
+    if constexpr (trail_diag) td_load(td, w, f, tid, nt, tptr);
     if (me.nind >= 2) {
         // independent leading pivots (merged sibling leaves): one pass instead of nind barriers, see independent_pivots_pk
         const int ni = min(me.nind, IND_SCRATCH);
@@ -316,9 +458,21 @@ __device__ __forceinline__ void front_factor_body(const FrontMeta& M, double* __
                 for (int k = 0; k < ni; ++k) {
                     const double* Ck = W + (long long)k * f;
                     const double cj = Ck[j];
-                    if (cj != 0.0) a -= (Ck[i] * scratch[k]) * cj;
+                    if (cj != 0.0) {
+                        double dk = 1.0;
+                        if constexpr (REF_PIVOT || REF_DIAG) { dk = Ck[k]; if (dk == 0.0) dk = 1.0; }
+                        a = pivot_term<RM>(a, Ck[i], cj, dk, scratch[k], REF_PIVOT ? ref_quot(cj, dk, scratch[k]) : 0.0, i == j);
+                    }
                 }
                 Wj[i] = a;
+            }
+        }
+        if constexpr (trail_diag) {
+            for (int k = 0; k < ni; ++k) {
+                const double* Ck = W + (long long)k * f;
+                double dk = Ck[k];
+                if (dk == 0.0) dk = 1.0;
+                td_step(td, w, f, tid, nt, tptr, [&](int i) { return Ck[i]; }, dk, scratch[k]);
             }
         }
         __syncthreads();
@@ -332,39 +486,56 @@ __device__ __forceinline__ void front_factor_body(const FrontMeta& M, double* __
         const int r = f - k - 1, pc = w - k - 1;
         const double* colk = W + (k + 1) + (long long)k * f;
         // W[i,j] -= (a_i / d) * a_j for k < j < w, i >= j, with the UNSCALED column k (column k is final after this step: its
-        // scaling by 1/d is deferred to one pass after the loop -> one barrier per pivot instead of two)
+        // scaling by 1/d is deferred to one pass after the loop -> one barrier per pivot instead of two); the arithmetic of a term: pivot_term<RM>()
         // (Round 3 tried two columns of a thread's stride per pass, the scaled entry a_i / d read once for both -- five LDS accesses per two multiply-adds
         // instead of six, bitwise the same: CONT-201 factorisation 2.29 instead of 2.21 ms, C3 unchanged.  Not kept.)
         {
             const int tx = tid & 15, ty = tid >> 4, tys = nt >> 4;
             for (int j = ty; j < pc; j += tys) {
                 const double cj = colk[j];
+                const double lj = REF_PIVOT ? ref_quot(cj, d, dinv) : 0.0;
                 double* Wj = W + (k + 1) + (long long)(k + 1 + j) * f;
-                for (int i = j + tx; i < r; i += 16) Wj[i] -= (colk[i] * dinv) * cj;
+                for (int i = j + tx; i < r; i += 16) Wj[i] = pivot_term<RM>(Wj[i], colk[i], cj, d, dinv, lj, i == j);
             }
         }
+        if constexpr (trail_diag) td_step(td, w, f, tid, nt, tptr, [&](int i) { return W[i + (long long)k * f]; }, d, dinv);
         __syncthreads();
     }
-    {
+    if constexpr (trail_diag) td_store(td, w, f, tid, nt, tptr);
+    if constexpr (WHERE == FRONT_PANEL_ONLY || !REF_SCHUR) {
+        // every entry below the diagonal is scaled in place (the trailing update of a PANEL_ONLY front runs on the matrix cores, k_syrk_lower_fronts)
         const int tx = tid & 15, ty = tid >> 4, tys = nt >> 4;
         for (int k = ty; k < w; k += tys) {
             double d = W[k + (long long)k * f];
             if (d == 0.0) d = 1.0;
             const double dinv = pivot_rcp(d);
-            for (int i = k + 1 + tx; i < f; i += 16) W[i + (long long)k * f] *= dinv;
+            for (int i = k + 1 + tx; i < f; i += 16) W[i + (long long)k * f] = scale_entry<RM>(W[i + (long long)k * f], d, dinv);
         }
+        __syncthreads();
     }
-    __syncthreads();
     if constexpr (WHERE == FRONT_PANEL_ONLY) {
         for (int k = tid; k < w; k += nt) { const double d = lds[k + k * f]; dvec[k] = d == 0.0 ? 1.0 : d; }
         for (int idx = tid; idx < f * w; idx += nt) F[idx] = lds[idx];
         return;
     }
-    // ---- Schur complement of the trailing block in one pass: T[i,j] -= sum_k L[i,k] d_k L[j,k]  (no barriers, long dot products)
     const int u = f - w;
-    if (u > 0) {
-        if constexpr (WHERE == FRONT_PANEL) schur_2x2<true>(lds, F, f, w, u, tid, nt);
-        else schur_2x2<false>(W, W, f, w, u, tid, nt);
+    if constexpr (REF_SCHUR) {
+        // ---- l = y / d (trailing rows: into the strictly upper part), then the Schur complement of the trailing block in one pass from the unscaled
+        //      trailing rows and those quotients (no barriers, long chains), then the trailing rows' quotients into place
+        double* Up = (WHERE == FRONT_PANEL) ? F : W;
+        scale_columns(W, Up, f, w, tid, nt);
+        __syncthreads();
+        if (u > 0) {
+            if constexpr (WHERE == FRONT_PANEL) schur_2x2<true>(lds, F, f, w, u, tid, nt);
+            else schur_2x2<false>(W, W, f, w, u, tid, nt);
+            __syncthreads();
+            place_trailing(W, Up, f, w, tid, nt);
+            __syncthreads();
+        }
+    } else if (u > 0) {
+        // ---- Schur complement of the trailing block in one pass: T[i,j] -= sum_k L[i,k] d_k L[j,k]  (no barriers, long dot products)
+        if constexpr (WHERE == FRONT_PANEL) schur_2x2_sum<true, RM>(lds, F, f, w, u, tid, nt);
+        else schur_2x2_sum<false, RM>(W, W, f, w, u, tid, nt);
         __syncthreads();
     }
     if constexpr (WHERE == FRONT_PANEL) {
@@ -379,6 +550,7 @@ __device__ __forceinline__ void front_factor_body(const FrontMeta& M, double* __
     }
 }
 
+template <int RM>
 __device__ __forceinline__ void front_factor(const FrontMeta& M, double* __restrict__ fronts, int s, double* __restrict__ rdiag,
                                              int* __restrict__ info, double* __restrict__ lds, bool own_assembled = false)
 {
@@ -386,25 +558,26 @@ __device__ __forceinline__ void front_factor(const FrontMeta& M, double* __restr
     const int w = me.w, f = me.f;
     // assembly: zero, own K entries, then the children's update matrices (fixed order)
     if (!own_assembled) front_assemble_own(M, fronts, me, lds);
-    if ((long long)f * f <= LDS_FRONT_DOUBLES) front_factor_body<FRONT_LDS>(M, fronts, s, me, rdiag, info, lds, lds);
-    else if (front_lds_doubles(f, w) > 0) front_factor_body<FRONT_PANEL>(M, fronts, s, me, rdiag, info, lds, lds);
-    else front_factor_body<FRONT_HBM>(M, fronts, s, me, rdiag, info, lds, fronts + me.front_off);
+    if ((long long)f * f <= LDS_FRONT_DOUBLES) front_factor_body<FRONT_LDS, RM>(M, fronts, s, me, rdiag, info, lds, lds);
+    else if (front_lds_doubles(f, w) > 0) front_factor_body<FRONT_PANEL, RM>(M, fronts, s, me, rdiag, info, lds, lds);
+    else front_factor_body<FRONT_HBM, RM>(M, fronts, s, me, rdiag, info, lds, fronts + me.front_off);
 }
 
 // One workgroup per front of an assembly-tree level.  Fronts on the multi-workgroup path (job_of[s] >= 0) were assembled by its kernels: a big
 // front is left to the dense kernels, a panel_front() has its panel factored here (D left in the job's dvec for the trailing update) -- in the
 // same launch as the level's one-workgroup fronts, which are independent of it.
+template <int RM>
 __global__ __launch_bounds__(1024) void k_front_factor(FrontMeta M, double* __restrict__ fronts, const int* __restrict__ list, const int* __restrict__ job_of,
                                                       const dense::FrontJob* __restrict__ jobs, double* __restrict__ rdiag, int* __restrict__ info)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int s = list[blockIdx.x];
     const int jid = job_of ? job_of[s] : -1;
-    if (jid < 0) { front_factor(M, fronts, s, rdiag, info, lds); return; }
+    if (jid < 0) { front_factor<RM>(M, fronts, s, rdiag, info, lds); return; }
     const dense::FrontJob j = jobs[jid];
     if (j.kind != 1) return;
     const SnRec me = M.sn[s];
-    front_factor_body<FRONT_PANEL_ONLY>(M, fronts, s, me, rdiag, info, lds, lds, j.dvec);
+    front_factor_body<FRONT_PANEL_ONLY, RM>(M, fronts, s, me, rdiag, info, lds, lds, j.dvec);
 }
 
 // One workgroup per small subtree, fronts never leave LDS: the front of supernode s is zeroed and assembled in LDS from the
@@ -416,8 +589,41 @@ __global__ __launch_bounds__(1024) void k_front_factor(FrontMeta M, double* __re
 // which halves the LDS of a walk -- a subtree with a 96 x 96 front drops from 147 KB to 74.5 KB and two workgroups share a CU.
 // pk_base(j, f) + i is the slot of entry (i, j), i >= j.
 __device__ __forceinline__ int pk_base(int j, int f) { return (j * (2 * f - j - 1)) >> 1; }
-__device__ __forceinline__ void schur_2x2_pk(double* __restrict__ W, int f, int w, int u, int tid, int nt)
+// (packed fronts have no upper part: the quotients l = y / d of the trailing rows go to `Lb`, entry (k, r) at Lb[k + r w] -- the walk's other LDS buffer,
+// whose update matrix the extend-add has consumed by then)
+__device__ __forceinline__ void schur_2x2_pk(double* __restrict__ W, const double* __restrict__ Lb, int f, int w, int u, int tid, int nt)
 {
+    const int tx = tid & 15, ty = tid >> 4, tys = nt >> 4;
+    const int nb = (u + 1) >> 1;
+    for (int bj = ty; bj < nb; bj += tys) {
+        for (int bi = bj + tx; bi < nb; bi += 16) {
+            const int i0 = 2 * bi, j0 = 2 * bj;
+            const bool i1ok = i0 + 1 < u, j1ok = j0 + 1 < u;
+            const int ri0 = w + i0, ri1 = w + (i1ok ? i0 + 1 : i0);
+            const double* Lj0 = Lb + j0 * w;
+            const double* Lj1 = Lb + (j1ok ? j0 + 1 : j0) * w;
+            double* T0 = W + pk_base(w + j0, f) + (w + i0);
+            double* T1 = W + pk_base(w + (j1ok ? j0 + 1 : j0), f) + (w + i0);
+            const bool ok10 = i1ok, ok01 = j1ok && i0 >= j0 + 1, ok11 = i1ok && j1ok;
+            double a00 = T0[0], a10 = ok10 ? T0[1] : 0.0, a01 = ok01 ? T1[0] : 0.0, a11 = ok11 ? T1[1] : 0.0;
+            int ck = 0;  // pk_base(k, f)
+            for (int k = 0; k < w; ++k) {
+                const double* Ck = W + ck;
+                const double y0 = Ck[ri0], y1 = Ck[ri1], l0 = Lj0[k], l1 = Lj1[k];
+                a00 = ref_msub(a00, y0, l0); a01 = ref_msub(a01, y0, l1); a10 = ref_msub(a10, y1, l0); a11 = ref_msub(a11, y1, l1);
+                ck += f - k - 1;
+            }
+            T0[0] = a00;
+            if (ok10) T0[1] = a10;
+            if (ok01) T1[0] = a01;
+            if (ok11) T1[1] = a11;
+        }
+    }
+}
+template <int RM>
+__device__ __forceinline__ void schur_2x2_pk_sum(double* __restrict__ W, int f, int w, int u, int tid, int nt)
+{
+    PQ_REF_FLAGS;
     const int tx = tid & 15, ty = tid >> 4, tys = nt >> 4;
     const int nb = (u + 1) >> 1;
     for (int bj = ty; bj < nb; bj += tys) {
@@ -435,14 +641,38 @@ __device__ __forceinline__ void schur_2x2_pk(double* __restrict__ W, int f, int 
                 ck += f - k - 1;
             }
             double* T0 = W + pk_base(w + j0, f) + (w + i0);
-            T0[0] -= a00;
+            const bool dg = REF_DIAG && i0 == j0;
+            if (!dg) T0[0] -= a00;
             if (i1ok) T0[1] -= a10;
             if (j1ok) {
                 double* T1 = W + pk_base(w + j0 + 1, f) + (w + i0);
                 if (i0 >= j0 + 1) T1[0] -= a01;
-                if (i1ok) T1[1] -= a11;
+                if (i1ok && !dg) T1[1] -= a11;
             }
         }
+    }
+}
+__device__ __forceinline__ void scale_columns_pk(double* __restrict__ W, double* __restrict__ Lb, int f, int w, int tid, int nt)
+{
+    const int tx = tid & 15, ty = tid >> 4, tys = nt >> 4;
+    for (int k = ty; k < w; k += tys) {
+        double* Ck = W + pk_base(k, f);
+        double d = Ck[k];
+        if (d == 0.0) d = 1.0;
+        const double dinv = pivot_rcp(d);
+        for (int i = k + 1 + tx; i < f; i += 16) {
+            const double l = ref_quot(Ck[i], d, dinv);
+            if (i < w) Ck[i] = l;
+            else Lb[k + (i - w) * w] = l;
+        }
+    }
+}
+__device__ __forceinline__ void place_trailing_pk(double* __restrict__ W, const double* __restrict__ Lb, int f, int w, int tid, int nt)
+{
+    const int tx = tid & 15, ty = tid >> 4, tys = nt >> 4;
+    for (int k = ty; k < w; k += tys) {
+        double* Ck = W + pk_base(k, f);
+        for (int i = w + tx; i < f; i += 16) Ck[i] = Lb[k + (i - w) * w];
     }
 }
 
@@ -450,9 +680,11 @@ __device__ __forceinline__ void schur_2x2_pk(double* __restrict__ W, int f, int 
 // need no pivot-by-pivot loop: their reciprocals go to `scratch` (LDS) and every entry of the remaining panel columns receives its nind
 // updates in one pass, in the same pivot order and with the same operands as the per-pivot loop (bitwise the same result).  Returns the
 // first pivot the per-pivot loop still has to do.
+template <int RM>
 __device__ __forceinline__ int independent_pivots_pk(double* __restrict__ W, int f, int w, int nind, int first, double* __restrict__ scratch, double* __restrict__ rdiag,
-                                                     int* __restrict__ info, int tid, int nt)
+                                                     int* __restrict__ info, int tid, int nt, double (&td)[TD_REGS])
 {
+    PQ_REF_FLAGS;
     if (nind < 2) return 0;
     const int tx = tid & 15, ty = tid >> 4, tys = nt >> 4;
     for (int k = tid; k < nind; k += nt) {
@@ -471,20 +703,36 @@ __device__ __forceinline__ int independent_pivots_pk(double* __restrict__ W, int
             for (int k = 0; k < nind; ++k) {
                 const double* Ck = W + ck;
                 const double cj = Ck[j];
-                if (cj != 0.0) a -= (Ck[i] * scratch[k]) * cj;
+                if (cj != 0.0) {
+                    double dk = 1.0;
+                    if constexpr (REF_PIVOT || REF_DIAG) { dk = Ck[k]; if (dk == 0.0) dk = 1.0; }
+                    a = pivot_term<RM>(a, Ck[i], cj, dk, scratch[k], REF_PIVOT ? ref_quot(cj, dk, scratch[k]) : 0.0, i == j);
+                }
                 ck += f - k - 1;
             }
             Wj[i] = a;
         }
     }
+    if constexpr (REF_DIAG) {
+        int ck = 0;
+        for (int k = 0; k < nind; ++k) {
+            const double* Ck = W + ck;
+            double dk = Ck[k];
+            if (dk == 0.0) dk = 1.0;
+            td_step(td, w, f, tid, nt, [&](int i) -> double* { return W + pk_base(i, f) + i; }, [&](int i) { return Ck[i]; }, dk, scratch[k]);
+            ck += f - k - 1;
+        }
+    }
     __syncthreads();
     return nind;
 }
+template <int RM>
 __global__ __launch_bounds__(1024) void k_subtree_factor_pk(FrontMeta M, double* __restrict__ fronts, const double* __restrict__ vals, const int* __restrict__ fe_offp,
                                                            const int* __restrict__ sub_lo, const int* __restrict__ sub_hi, int cap, double* __restrict__ rdiag,
                                                            int* __restrict__ info)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
+    PQ_REF_FLAGS;
     const int tid = threadIdx.x, nt = blockDim.x;
     const int tx = tid & 15, ty = tid >> 4, tys = nt >> 4;
     const int lo = sub_lo[blockIdx.x], hi = sub_hi[blockIdx.x];
@@ -522,7 +770,10 @@ __global__ __launch_bounds__(1024) void k_subtree_factor_pk(FrontMeta M, double*
             __syncthreads();
         }
         // ---- panel
-        for (int k = independent_pivots_pk(W, f, w, me.nind, first, prev, rdiag, info, tid, nt); k < w; ++k) {
+        auto tptr = [&](int i) -> double* { return W + pk_base(i, f) + i; };
+        double td[TD_REGS];
+        if constexpr (REF_DIAG) td_load(td, w, f, tid, nt, tptr);
+        for (int k = independent_pivots_pk<RM>(W, f, w, me.nind, first, prev, rdiag, info, tid, nt, td); k < w; ++k) {
             const int ck = pk_base(k, f);
             double d = W[ck + k];
             if (d == 0.0) { if (tid == 0 && *info < 0) *info = first + k; d = 1.0; }
@@ -532,23 +783,38 @@ __global__ __launch_bounds__(1024) void k_subtree_factor_pk(FrontMeta M, double*
             const double* colk = W + ck + (k + 1);
             for (int j = ty; j < pc; j += tys) {
                 const double cj = colk[j];
+                const double lj = REF_PIVOT ? ref_quot(cj, d, dinv) : 0.0;
                 double* Wj = W + pk_base(k + 1 + j, f) + (k + 1);
-                for (int i = j + tx; i < r; i += 16) Wj[i] -= (colk[i] * dinv) * cj;
+                for (int i = j + tx; i < r; i += 16) Wj[i] = pivot_term<RM>(Wj[i], colk[i], cj, d, dinv, lj, i == j);
+            }
+            if constexpr (REF_DIAG) td_step(td, w, f, tid, nt, tptr, [&](int i) { return W[ck + i]; }, d, dinv);
+            __syncthreads();
+        }
+        if constexpr (REF_DIAG) td_store(td, w, f, tid, nt, tptr);
+        const int u = f - w;
+        if constexpr (REF_SCHUR) {
+            // deferred division of the finished columns, Schur complement, trailing rows' quotients into place (see front_factor_body)
+            scale_columns_pk(W, prev, f, w, tid, nt);
+            __syncthreads();
+            if (u > 0) {
+                schur_2x2_pk(W, prev, f, w, u, tid, nt);
+                __syncthreads();
+                place_trailing_pk(W, prev, f, w, tid, nt);
+                __syncthreads();
+            }
+        } else {
+            for (int k = ty; k < w; k += tys) {   // deferred scaling of the finished columns (see front_factor)
+                double* Ck = W + pk_base(k, f);
+                double d = Ck[k];
+                if (d == 0.0) d = 1.0;
+                const double dinv = pivot_rcp(d);
+                for (int i = k + 1 + tx; i < f; i += 16) Ck[i] = scale_entry<RM>(Ck[i], d, dinv);
             }
             __syncthreads();
-        }
-        for (int k = ty; k < w; k += tys) {   // deferred scaling of the finished columns (see front_factor)
-            double* Ck = W + pk_base(k, f);
-            double d = Ck[k];
-            if (d == 0.0) d = 1.0;
-            const double dinv = pivot_rcp(d);
-            for (int i = k + 1 + tx; i < f; i += 16) Ck[i] *= dinv;
-        }
-        __syncthreads();
-        const int u = f - w;
-        if (u > 0) {
-            schur_2x2_pk(W, f, w, u, tid, nt);
-            __syncthreads();
+            if (u > 0) {
+                schur_2x2_pk_sum<RM>(W, f, w, u, tid, nt);
+                __syncthreads();
+            }
         }
         // ---- factor panel to HBM (full column-major layout there: the solves and the parents outside the subtree read it)
         double* F = fronts + me.front_off;
@@ -570,11 +836,13 @@ __global__ __launch_bounds__(1024) void k_subtree_factor_pk(FrontMeta M, double*
     }
 }
 
+template <int RM>
 __global__ __launch_bounds__(1024) void k_subtree_factor_lds(FrontMeta M, double* __restrict__ fronts, const double* __restrict__ vals, const int* __restrict__ fe_ptr,
                                                             const int* __restrict__ fe_q, const int* __restrict__ fe_off, const int* __restrict__ sub_lo,
                                                             const int* __restrict__ sub_hi, int cap, double* __restrict__ rdiag, int* __restrict__ info)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
+    PQ_REF_FLAGS;
     const int tid = threadIdx.x, nt = blockDim.x;
     const int lo = sub_lo[blockIdx.x], hi = sub_hi[blockIdx.x];
     double* cur = lds;
@@ -607,6 +875,9 @@ __global__ __launch_bounds__(1024) void k_subtree_factor_lds(FrontMeta M, double
         }
         (void)prev_f; (void)prev_w;
         // ---- panel
+        auto tptr = [&](int i) -> double* { return W + i + i * f; };
+        double td[TD_REGS];
+        if constexpr (REF_DIAG) td_load(td, w, f, tid, nt, tptr);
         for (int k = 0; k < w; ++k) {
             double d = W[k + k * f];
             if (d == 0.0) { if (tid == 0 && *info < 0) *info = first + k; d = 1.0; }
@@ -618,27 +889,42 @@ __global__ __launch_bounds__(1024) void k_subtree_factor_lds(FrontMeta M, double
                 const int tx = tid & 15, ty = tid >> 4, tys = nt >> 4;
                 for (int j = ty; j < pc; j += tys) {
                     const double cj = colk[j];
+                    const double lj = REF_PIVOT ? ref_quot(cj, d, dinv) : 0.0;
                     double* Wj = W + (k + 1) + (k + 1 + j) * f;
-                    for (int i = j + tx; i < r; i += 16) Wj[i] -= (colk[i] * dinv) * cj;
+                    for (int i = j + tx; i < r; i += 16) Wj[i] = pivot_term<RM>(Wj[i], colk[i], cj, d, dinv, lj, i == j);
+                }
+            }
+            if constexpr (REF_DIAG) td_step(td, w, f, tid, nt, tptr, [&](int i) { return W[i + k * f]; }, d, dinv);
+            __syncthreads();
+        }
+        if constexpr (REF_DIAG) td_store(td, w, f, tid, nt, tptr);
+        const int u = f - w;
+        if constexpr (REF_SCHUR) {
+            // deferred division of the finished columns, Schur complement, trailing rows' quotients into place (see front_factor_body)
+            scale_columns(W, W, f, w, tid, nt);
+            __syncthreads();
+            if (u > 0) {
+                schur_2x2<false>(W, W, f, w, u, tid, nt);
+                __syncthreads();
+                place_trailing(W, W, f, w, tid, nt);
+                __syncthreads();
+            }
+        } else {
+            {   // deferred scaling of the finished columns (see front_factor)
+                const int tx = tid & 15, ty = tid >> 4, tys = nt >> 4;
+                for (int k = ty; k < w; k += tys) {
+                    double d = W[k + k * f];
+                    if (d == 0.0) d = 1.0;
+                    const double dinv = pivot_rcp(d);
+                    for (int i = k + 1 + tx; i < f; i += 16) W[i + k * f] = scale_entry<RM>(W[i + k * f], d, dinv);
                 }
             }
             __syncthreads();
-        }
-        {   // deferred scaling of the finished columns (see front_factor)
-            const int tx = tid & 15, ty = tid >> 4, tys = nt >> 4;
-            for (int k = ty; k < w; k += tys) {
-                double d = W[k + k * f];
-                if (d == 0.0) d = 1.0;
-                const double dinv = pivot_rcp(d);
-                for (int i = k + 1 + tx; i < f; i += 16) W[i + k * f] *= dinv;
+            // ---- Schur complement
+            if (u > 0) {
+                schur_2x2_sum<false, RM>(W, W, f, w, u, tid, nt);
+                __syncthreads();
             }
-        }
-        __syncthreads();
-        // ---- Schur complement
-        const int u = f - w;
-        if (u > 0) {
-            schur_2x2<false>(W, W, f, w, u, tid, nt);
-            __syncthreads();
         }
         // ---- factor panel to HBM (the first w columns of the front are contiguous); update matrix only if nobody reads it from LDS
         double* F = fronts + me.front_off;
@@ -665,13 +951,14 @@ struct SubSchedule {
 };
 // one workgroup per small subtree: its supernodes lo..hi (a postorder range, children before parents) are factored one
 // after the other by the same workgroup -- no launch and no inter-workgroup dependency inside the subtree
+template <int RM>
 __global__ __launch_bounds__(SUB_THREADS) void k_subtree_factor(FrontMeta M, double* __restrict__ fronts, const int* __restrict__ sub_lo, const int* __restrict__ sub_hi,
                                                         double* __restrict__ rdiag, int* __restrict__ info)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int lo = sub_lo[blockIdx.x], hi = sub_hi[blockIdx.x];
     for (int s = lo; s <= hi; ++s) {
-        front_factor(M, fronts, s, rdiag, info, lds);
+        front_factor<RM>(M, fronts, s, rdiag, info, lds);
         __syncthreads();
     }
 }
@@ -1501,6 +1788,7 @@ __device__ __forceinline__ void top_done(int* flag, int epoch)
 }
 // `list` / `ntop` may be a SUFFIX of the level-sorted top list (start = its first position): children in earlier levels or in
 // subtrees were finished by earlier launches on the stream
+template <int RM>
 __global__ __launch_bounds__(512) void k_top_factor(FrontMeta M, double* __restrict__ fronts, const int* __restrict__ list, int ntop, const int* __restrict__ top_pos, int start,
                                                     int* __restrict__ flags, int* __restrict__ err, double* __restrict__ rdiag, int* __restrict__ info, int epoch)
 {
@@ -1530,7 +1818,7 @@ __global__ __launch_bounds__(512) void k_top_factor(FrontMeta M, double* __restr
             if (any) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
         __syncthreads();
-        front_factor(M, fronts, s, rdiag, info, lds, true);
+        front_factor<RM>(M, fronts, s, rdiag, info, lds, true);
         top_done(flags + b, epoch);
     }
 }
@@ -1539,11 +1827,13 @@ __global__ __launch_bounds__(512) void k_top_factor(FrontMeta M, double* __restr
 // chain with two packed lower-triangle fronts in LDS (like k_subtree_factor_pk): the update matrix of a link stays in LDS for the
 // next one, flags + HBM round trips only where the tree branches.  flags are per supernode (position in the list - start); walks are
 // sorted by the position of their last supernode, so every dependency has a smaller walk index.
+template <int RM>
 __global__ __launch_bounds__(512) void k_top_factor_walk(FrontMeta M, double* __restrict__ fronts, const double* __restrict__ vals, const int* __restrict__ fe_offp,
                                                          const int* __restrict__ walk_lo, const int* __restrict__ walk_hi, int nwalk, const int* __restrict__ top_pos, int start,
                                                          int cap, int* __restrict__ flags, int* __restrict__ err, double* __restrict__ rdiag, int* __restrict__ info, int epoch)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
+    PQ_REF_FLAGS;
     const int tid = threadIdx.x, nt = blockDim.x;
     const int tx = tid & 15, ty = tid >> 4, tys = nt >> 4;
     for (int b = blockIdx.x; b < nwalk; b += gridDim.x) {
@@ -1601,7 +1891,10 @@ __global__ __launch_bounds__(512) void k_top_factor_walk(FrontMeta M, double* __
                 }
                 __syncthreads();
             }
-            for (int k = independent_pivots_pk(W, f, w, me.nind, first, prev, rdiag, info, tid, nt); k < w; ++k) {
+            auto tptr = [&](int i) -> double* { return W + pk_base(i, f) + i; };
+            double td[TD_REGS];
+            if constexpr (REF_DIAG) td_load(td, w, f, tid, nt, tptr);
+            for (int k = independent_pivots_pk<RM>(W, f, w, me.nind, first, prev, rdiag, info, tid, nt, td); k < w; ++k) {
                 const int ck = pk_base(k, f);
                 double d = W[ck + k];
                 if (d == 0.0) { if (tid == 0 && *info < 0) *info = first + k; d = 1.0; }
@@ -1611,23 +1904,38 @@ __global__ __launch_bounds__(512) void k_top_factor_walk(FrontMeta M, double* __
                 const double* colk = W + ck + (k + 1);
                 for (int j = ty; j < pc; j += tys) {
                     const double cj = colk[j];
+                    const double lj = REF_PIVOT ? ref_quot(cj, d, dinv) : 0.0;
                     double* Wj = W + pk_base(k + 1 + j, f) + (k + 1);
-                    for (int i = j + tx; i < r; i += 16) Wj[i] -= (colk[i] * dinv) * cj;
+                    for (int i = j + tx; i < r; i += 16) Wj[i] = pivot_term<RM>(Wj[i], colk[i], cj, d, dinv, lj, i == j);
+                }
+                if constexpr (REF_DIAG) td_step(td, w, f, tid, nt, tptr, [&](int i) { return W[ck + i]; }, d, dinv);
+                __syncthreads();
+            }
+            if constexpr (REF_DIAG) td_store(td, w, f, tid, nt, tptr);
+            const int u = f - w;
+            if constexpr (REF_SCHUR) {
+                // deferred division of the finished columns, Schur complement, trailing rows' quotients into place (see front_factor_body)
+                scale_columns_pk(W, prev, f, w, tid, nt);
+                __syncthreads();
+                if (u > 0) {
+                    schur_2x2_pk(W, prev, f, w, u, tid, nt);
+                    __syncthreads();
+                    place_trailing_pk(W, prev, f, w, tid, nt);
+                    __syncthreads();
+                }
+            } else {
+                for (int k = ty; k < w; k += tys) {   // deferred scaling of the finished columns (see front_factor)
+                    double* Ck = W + pk_base(k, f);
+                    double d = Ck[k];
+                    if (d == 0.0) d = 1.0;
+                    const double dinv = pivot_rcp(d);
+                    for (int i = k + 1 + tx; i < f; i += 16) Ck[i] = scale_entry<RM>(Ck[i], d, dinv);
                 }
                 __syncthreads();
-            }
-            for (int k = ty; k < w; k += tys) {
-                double* Ck = W + pk_base(k, f);
-                double d = Ck[k];
-                if (d == 0.0) d = 1.0;
-                const double dinv = pivot_rcp(d);
-                for (int i = k + 1 + tx; i < f; i += 16) Ck[i] *= dinv;
-            }
-            __syncthreads();
-            const int u = f - w;
-            if (u > 0) {
-                schur_2x2_pk(W, f, w, u, tid, nt);
-                __syncthreads();
+                if (u > 0) {
+                    schur_2x2_pk_sum<RM>(W, f, w, u, tid, nt);
+                    __syncthreads();
+                }
             }
             double* F = fronts + me.front_off;
             for (int j = ty; j < w; j += tys) {
@@ -2046,6 +2354,7 @@ public:
 private:
     SparseKKT(const SparseKKT& o, int) : dev_(o.dev_), mode_(o.mode_), nzAA_(o.nzAA_), nzGG_(o.nzGG_), n_(o.n_), p_(o.p_), m_(o.m_), N_(o.N_), nnzK_(o.nnzK_), delta_(o.delta_), S_(o.S_), level_lds_(o.level_lds_), sub_lds_(o.sub_lds_), ntop_(o.ntop_), top_grid_(o.top_grid_), top_lds_(o.top_lds_), top_l0_(o.top_l0_), top_start_(o.top_start_), top_nper_(o.top_nper_), top_persistent_(o.top_persistent_)
     {
+        ref_mode_ = o.ref_mode_;
         PQ_HIP(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
         PQ_HIP(hipStreamCreateWithFlags(&st2_, hipStreamNonBlocking));
         PQ_HIP(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming)); PQ_HIP(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
@@ -2074,15 +2383,14 @@ private:
     // dynamic LDS of the level kernel = largest front of the level that is factored inside LDS
     void compute_level_lds()
     {
-        static bool attr_set = false;
-        if (!attr_set) {
-            PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_front_factor), hipFuncAttributeMaxDynamicSharedMemorySize, (LDS_FRONT_DOUBLES + IND_SCRATCH) * (int)sizeof(double)));
-            PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_subtree_factor), hipFuncAttributeMaxDynamicSharedMemorySize, (LDS_FRONT_DOUBLES + IND_SCRATCH) * (int)sizeof(double)));
-            PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_subtree_factor_lds), hipFuncAttributeMaxDynamicSharedMemorySize, SUBTREE_LDS_BYTES));
-            PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_subtree_factor_pk), hipFuncAttributeMaxDynamicSharedMemorySize, SUBTREE_LDS_BYTES));
-            PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_top_factor), hipFuncAttributeMaxDynamicSharedMemorySize, (LDS_FRONT_DOUBLES + IND_SCRATCH) * (int)sizeof(double)));
-            attr_set = true;
-        }
+        static PerDeviceOnce attr_set;
+        attr_set([&] {
+            PQ_ATTR_RM(k_front_factor, (LDS_FRONT_DOUBLES + IND_SCRATCH) * (int)sizeof(double));
+            PQ_ATTR_RM(k_subtree_factor, (LDS_FRONT_DOUBLES + IND_SCRATCH) * (int)sizeof(double));
+            PQ_ATTR_RM(k_subtree_factor_lds, SUBTREE_LDS_BYTES);
+            PQ_ATTR_RM(k_subtree_factor_pk, SUBTREE_LDS_BYTES);
+            PQ_ATTR_RM(k_top_factor, (LDS_FRONT_DOUBLES + IND_SCRATCH) * (int)sizeof(double));
+        });
         level_lds_.assign(S_.top_nlevels, 0);
         for (int l = 0; l < S_.top_nlevels; ++l) {
             long long mx = 0;
@@ -2109,6 +2417,12 @@ private:
         }
         top_lds_ = ((int)top_mx + IND_SCRATCH) * (int)sizeof(double);
         top_grid_ = std::min(ntop_, 224);
+        {   // arithmetic of the one-workgroup fronts: the reference's, term by term, unless some front of the tree runs on the matrix cores (see ref_quot)
+            bool multi = false;
+            for (int s = 0; s + 1 < (int)S_.sn_first.size() && !multi; ++s) multi = is_big(s);
+            ref_mode_ = multi ? PQ_REF_MODE_BIG : PQ_REF_MODE;
+            if (const char* e = debug_token("ref_mode")) ref_mode_ = std::atoi(e) == PQ_REF_MODE ? PQ_REF_MODE : PQ_REF_MODE_BIG;  // debugging aid: PIQP_AMD_DEBUG=ref_mode=<m>
+        }
         // measured: worth it for the factorisation when every top supernode gets its own workgroup; the substitution fronts are too
         // cheap to pay for agent-scope release / acquire per supernode, they stay on level launches
         top_persistent_ = ntop_ > 0 && ntop_ <= 1024 && !any_big && !debug_token("top_levels");
@@ -2150,8 +2464,8 @@ private:
                 for (const auto& wk : walks) { lo.push_back(wk.second.first); hi.push_back(wk.second.second); }
                 upload_vec(top_walk_lo_, lo, st_); upload_vec(top_walk_hi_, hi, st_);
                 ntopwalk_ = (int)walks.size(); top_walk_cap_ = (int)capP;
-                static bool attr_set = false;
-                if (!attr_set) { PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_top_factor_walk), hipFuncAttributeMaxDynamicSharedMemorySize, SUBTREE_LDS_BYTES)); attr_set = true; }
+                static PerDeviceOnce attr_set;
+                attr_set([&] { PQ_ATTR_RM(k_top_factor_walk, SUBTREE_LDS_BYTES); });
             }
         }
     }
@@ -2180,10 +2494,10 @@ private:
             if (factor_epoch_ >= 2000000000) { PQ_HIP(hipMemsetAsync(top_flags_.p, 0, sizeof(int) * (2 * (size_t)ntop_ + 1), st_)); factor_epoch_ = 0; }
             epoch = ++factor_epoch_;
             if (ntopwalk_ > 0)
-                hipLaunchKernelGGL(k_top_factor_walk, dim3(std::min(ntopwalk_, 224)), dim3(top_threads()), 2 * (size_t)top_walk_cap_ * sizeof(double), st_, M, fronts_.p, vals_.p, fe_offp_.p,
+                PQ_LAUNCH_RM(k_top_factor_walk, dim3(std::min(ntopwalk_, 224)), dim3(top_threads()), 2 * (size_t)top_walk_cap_ * sizeof(double), st_, M, fronts_.p, vals_.p, fe_offp_.p,
                                    top_walk_lo_.p, top_walk_hi_.p, ntopwalk_, top_pos_.p, top_start_, top_walk_cap_, top_flags_.p, top_flags_.p + 2 * ntop_, rdiag_.p, info_.p, epoch);
             else
-                hipLaunchKernelGGL(k_top_factor, dim3(std::min(top_nper_, 224)), dim3(top_threads()), top_lds_, st_, M, fronts_.p, level_sn_.p + top_start_, top_nper_, top_pos_.p, top_start_,
+                PQ_LAUNCH_RM(k_top_factor, dim3(std::min(top_nper_, 224)), dim3(top_threads()), top_lds_, st_, M, fronts_.p, level_sn_.p + top_start_, top_nper_, top_pos_.p, top_start_,
                                    top_flags_.p, top_flags_.p + 2 * ntop_, rdiag_.p, info_.p, epoch);
         }
     }
@@ -2355,12 +2669,12 @@ private:
     {
         for (const SubClass& c : sc.cls) {
             if (c.lds_walk && c.packed)
-                hipLaunchKernelGGL(k_subtree_factor_pk, dim3(c.nsub), dim3(c.threads), c.bytes, st_, M, fronts_.p, vals_.p, fe_offp_.p, c.lo.p, c.hi.p, c.cap, rdiag_.p, info_.p);
+                PQ_LAUNCH_RM(k_subtree_factor_pk, dim3(c.nsub), dim3(c.threads), c.bytes, st_, M, fronts_.p, vals_.p, fe_offp_.p, c.lo.p, c.hi.p, c.cap, rdiag_.p, info_.p);
             else if (c.lds_walk)
-                hipLaunchKernelGGL(k_subtree_factor_lds, dim3(c.nsub), dim3(c.threads), c.bytes, st_, M, fronts_.p, vals_.p, fe_ptr_.p, fe_q_.p, fe_off_.p, c.lo.p, c.hi.p, c.cap, rdiag_.p,
+                PQ_LAUNCH_RM(k_subtree_factor_lds, dim3(c.nsub), dim3(c.threads), c.bytes, st_, M, fronts_.p, vals_.p, fe_ptr_.p, fe_q_.p, fe_off_.p, c.lo.p, c.hi.p, c.cap, rdiag_.p,
                                    info_.p);
             else
-                hipLaunchKernelGGL(k_subtree_factor, dim3(c.nsub), dim3(SUB_THREADS), sub_lds_, st_, M, fronts_.p, c.lo.p, c.hi.p, rdiag_.p, info_.p);
+                PQ_LAUNCH_RM(k_subtree_factor, dim3(c.nsub), dim3(SUB_THREADS), sub_lds_, st_, M, fronts_.p, c.lo.p, c.hi.p, rdiag_.p, info_.p);
         }
     }
     // ---- big fronts of a level schedule, grouped by level for the batched dense path
@@ -2485,7 +2799,7 @@ private:
             // (and so does every level with at most one front per CU: BOYD1 factorisation 0.355 -> 0.343 ms, C3 unchanged)
             const int ff_threads = (!ff256 && ((nbig > 0 && B.npanel[l] > 0) || cnt <= 256)) ? 1024 : 256;
             if (small)
-                hipLaunchKernelGGL(k_front_factor, dim3(cnt), dim3(ff_threads), std::max(lds[l], nbig > 0 ? B.panel_lds[l] : 0), ss, M, fronts_.p, sn_dev + ptr[l], B.total > 0 ? B.job_of.p : (const int*)nullptr,
+                PQ_LAUNCH_RM(k_front_factor, dim3(cnt), dim3(ff_threads), std::max(lds[l], nbig > 0 ? B.panel_lds[l] : 0), ss, M, fronts_.p, sn_dev + ptr[l], B.total > 0 ? B.job_of.p : (const int*)nullptr,
                                    B.jobs.p, rdiag_.p, info_.p);
             if (fork) PQ_HIP(hipEventRecord(ev_join_, st2_));
             if (nbig <= 0) continue;
@@ -2751,6 +3065,7 @@ private:
     bool no_runs_ = debug_token("no_level_runs") != nullptr;  // debugging aid: one substitution launch per level, no merged runs of chain levels
     bool no_fork_ = debug_token("no_fork") != nullptr;  // debugging aid: everything on one stream
     mutable int tree_has_big_ = -1;  // lazily: does the top of the tree hold a front for the dense kernels (or is it too large for one persistent launch)
+    int ref_mode_ = PQ_REF_MODE;  // arithmetic of the one-workgroup fronts (PQ_REF_MODE: the reference's, term by term; PQ_REF_MODE_BIG where the tree has multi-workgroup fronts)
     bool no_big_ = debug_token("no_big") != nullptr;    // debugging aid: every front through one workgroup's pivot loop (accuracy comparisons)
     int wide_fcap_ = debug_token("no_wide_solve") ? 0 : WIDE_FCAP;  // debugging aid: wide fronts through the per-pivot routines
     BigLevels top_big_, own_big_, sh_big_;
