@@ -143,6 +143,7 @@ def main():
     ap.add_argument("--no-sparse-legs", action="store_true", help="skip the sparse C3 / C5-size KKT legs (BASELINE configs[2], configs[4])")
     ap.add_argument("--no-extra-dense-legs", action="store_true", help="skip the dense_ldlt_no_pivot and refinement-on legs of configs[1]")
     ap.add_argument("--cpu-steps", type=int, default=0, help="0 = auto (about 10-30 s of CPU work)")
+    ap.add_argument("--no-size-sweep", action="store_true", help="skip the dense size sweep n = 64 .. 4096 (device vs CPU oracle, the crossover)")
     ap.add_argument("--no-dist-c5", action="store_true", help="N > 1 only: skip the stage-partitioned single-QP leg (BASELINE configs[4])")
     args = ap.parse_args()
     self_launch(args)
@@ -190,11 +191,6 @@ def main():
     # N ranks on N distinct GPUs took part
     ranks_rows = pd.gather_stats([[float(rank), float(local_rank), float(torch.cuda.device_count())]], device=dev if world > 1 else None)
     if rank == 0:
-        L = piqp_amd._lib.load()
-        import ctypes as C
-        tf, gb = C.c_double(), C.c_double()
-        L.pq_microbench_mfma_f64(local_rank, 4000, C.byref(tf))
-        L.pq_microbench_hbm_copy(local_rank, 1 << 30, 10, C.byref(gb))
         elapsed = main_leg["elapsed"]
         ms_per_step = elapsed / args.steps * 1e3
         value = world * args.steps / elapsed
@@ -222,11 +218,8 @@ def main():
             r_upd = roof("k_syrk_lower<EPI_SUBTRACT_POTRF> = one launch per panel: trailing (panel) update of the factorisation + factorisation of the next diagonal "
                          "block + substitution of the next panel behind it (dense/ldlt_no_pivot.hpp:313-354, Eigen::LLT at dense/kkt.hpp:82); hipEvent-bracketed per "
                          "launch in a separate pass of the same steps", flops_upd, upd_s, upd_launches, "panel_update")
-        # the dominant kernel: the factorisation's persistent launch and the assembly STAGE are within 2 % of each other now (1.20 ms in ONE launch -- the longest
-        # launch of the step -- against 1.22-1.25 ms in two SYRK launches and a reduction), so a plain comparison flips the object from run to run.  The primary
-        # object stays the factorisation kernel (the one the round-2 review named, and the lower fraction of the two) unless the assembly stage exceeds its
-        # stage by more than 10 %; the other kernel is always reported beside it (roofline_secondary).
-        dominant, secondary = (r_upd, r_asm) if max(upd_s, main_leg["fac_ms"] * 1e-3) * 1.1 >= asm_s else (r_asm, r_upd)
+        # the dominant kernel = the one with the larger measured time per step, nothing else (round-3 advice); the other is reported beside it
+        dominant, secondary = (r_upd, r_asm) if upd_s >= asm_s else (r_asm, r_upd)
         out = {
             "metric": "KKT factor+solve/sec (per IPM iter)",
             "value": value,
@@ -243,10 +236,6 @@ def main():
                        "n": n, "p": p, "m": m, "parallelism": f"independent QP replicas x{world}"},
             "roofline": dominant,            # the kernel that takes the most time per step
             "roofline_secondary": secondary,
-            "measured_peaks": {"fp64_mfma_tflops": tf.value, "hbm_copy_gbs": gb.value,
-                               "note": "informational only, NOT ceilings: pq_microbench_mfma_f64 = best of nine launch shapes of a register-resident v_mfma_f64_16x16x4 stream "
-                                       "(every shape is power-limited at 47-49 TFLOP/s on this pool, below the 53-55 the LDS-fed assembly kernel sustains at 77 % pipe duty), "
-                                       "pq_microbench_hbm_copy = best of 28 shapes of a 1 GiB read + write copy; every fraction in this line is against the vendor sheet peak"},
             "stages": {"assembly_ms": main_leg["asm_ms"], "factorisation_ms": main_leg["fac_ms"],
                        "factorisation_tflops": flops_llt / (main_leg["fac_ms"] * 1e-3) / 1e12 if main_leg["fac_ms"] > 0 else 0.0,
                        "backend_solve_ms": main_leg["sol_ms"], "panel_update_ms": kk["fused_ms_per_step"], "panel_solve_ms": kk["trsm_ms_per_step"],
@@ -281,6 +270,12 @@ def main():
             bq = {"error": f"{type(e).__name__}: {e}"}
         if rank == 0:
             out["batched_qp"] = bq
+    if world == 1 and not args.no_size_sweep:
+        try:
+            sw = dense_size_sweep(piqp_amd, pd, torch, np, args, rank, world, local_rank, dev)
+        except Exception as e:  # noqa: BLE001
+            sw = {"error": f"{type(e).__name__}: {e}"}
+        out["dense_size_sweep"] = sw
     if not args.no_sparse_legs:
         try:
             sl = sparse_legs(args, rank, world, local_rank, dev, pd)
@@ -432,6 +427,7 @@ def batched_qp(args, rank, world, local_rank, dev, pd):
     def run(mb, reps=3):
         bs = piqp_amd.BatchSparseSolver(device=local_rank)
         assert bs.setup(mb["P_pattern"], mb["P_values"], mb["c"], mb["A_pattern"], mb["A_values"], mb["b"], x_l=mb["x_l"], x_u=mb["x_u"])
+        bs.set_start_order(False)  # index order: what a fresh batch gets (every figure of this leg unless it says longest_first)
         bs.solve()  # warm-up
         pd.barrier(); torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -452,25 +448,26 @@ def batched_qp(args, rank, world, local_rank, dev, pd):
         tot_solved = sum(r[0] for r in rows); tot_it = sum(r[1] for r in rows)
         res["strong"] = {"qps_total": total, "qp_per_s": total / el, "ms": el * 1e3, "solved": int(tot_solved), "iters_mean": tot_it / total,
                          "kernel_ms_rank0": bs.last_kernel_ms()[0], "threads_per_qp": bs.last_kernel_ms()[1],
-                         "start_order": "longest first by the PREVIOUS solve's iteration counts (the library's default; the timed solves follow a warm-up solve of the same "
-                                        "batch, as a receding-horizon controller re-solves its batch): see ms_index_order for the same batch started in index order"}
-    # the same batch with the start order switched off (what the first solve of a fresh batch gets)
+                         "start_order": "qp_per_s / ms = the batch started in INDEX order, what the first solve of a fresh batch gets (the headline since round 4); "
+                                        "*_longest_first = started longest first by the PREVIOUS solve's iteration counts (the library's default on a re-solve, as a "
+                                        "receding-horizon controller re-solves its batch) -- a perfect prediction here, since the timed solves repeat the warm-up's batch"}
+    # the same batch started longest first (the library's default when a batch is solved again)
     try:
-        bs.set_start_order(False)
+        bs.set_start_order(True)
         bs.solve()
         pd.barrier(); torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(3):
             bs.solve()
         torch.cuda.synchronize(); pd.barrier()
-        el_idx = pd.max_over_ranks((time.perf_counter() - t0) / 3, device=dev if world > 1 else None)
-        bs.set_start_order(True)
+        el_lf = pd.max_over_ranks((time.perf_counter() - t0) / 3, device=dev if world > 1 else None)
+        bs.set_start_order(False)
         if rank == 0:
-            res["strong"]["ms_index_order"] = el_idx * 1e3
-            res["strong"]["qp_per_s_index_order"] = total / el_idx
+            res["strong"]["ms_longest_first"] = el_lf * 1e3
+            res["strong"]["qp_per_s_longest_first"] = total / el_lf
     except Exception as e:  # noqa: BLE001
         if rank == 0:
-            res["strong"]["index_order_error"] = f"{type(e).__name__}: {e}"
+            res["strong"]["longest_first_error"] = f"{type(e).__name__}: {e}"
     if world > 1:
         bsw, solved_w, el_w = run(full)
         rows = pd.gather_stats([[float(solved_w)]], device=dev)
@@ -598,6 +595,52 @@ def dense_strongly_convex_qp_small():
     return dense_strongly_convex_qp(1024, 0, 1024, seed=7, double_sided=True, exact_shift=False)
 
 
+def dense_size_sweep(piqp_amd, pd, torch, np, args, rank, world, local_rank, dev):
+    """The reference's own factorisation-benchmark sizes (benchmarks/src/dense_cholesky_factorization_benchmark.cpp:97-102: n = 4 .. 1024, x2) carried on to the
+    BASELINE size: the same step (1 factor + 2 solves, m = n, p = 0) on the device and on the CPU oracle (one thread, and the thread count that is fastest on this
+    box), so that the crossover below which the host wins is a measured number.  n < 384 or n % 128 != 0 runs the launch-per-panel path (no persistent launch)."""
+    from oracle import pyorc
+    from qp_gen import dense_strongly_convex_qp, random_vars
+    try:
+        L = pyorc.lib(native=True)
+    except Exception:
+        L = pyorc.lib()
+    avail = os.cpu_count() or 1
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    rows = {}
+    for n in (64, 128, 256, 384, 512, 768, 1024, 1536, 2048, 3072, 4096):
+        q = dense_strongly_convex_qp(n, 0, n, seed=900 + n, double_sided=True, exact_shift=False)
+        leg = dense_leg(piqp_amd, pd, torch, np, q, n, 0, n, args.kkt_solver, False, 10, 2, rank, world, local_rank, dev, kernel_pass=0)
+        r = {"device_ms_per_step": leg["elapsed"] / 10 * 1e3, "device_assembly_ms": leg["asm_ms"], "device_factorisation_ms": leg["fac_ms"], "device_backend_solve_ms": leg["sol_ms"]}
+        if not args.no_cpu_baseline and n <= 2048:
+            od = pyorc.Data.dense(**q, L=L)
+            rng = np.random.default_rng(1000)
+            state = random_vars(n, 0, n, rng, positive=True)
+            rhs = [random_vars(n, 0, n, rng) for _ in range(2)]
+            for label, threads in (("cpu_1_thread_ms_per_step", 1), ("cpu_all_threads_ms_per_step", min(avail, 32))):
+                L.orc_set_num_threads(threads)
+                ks = pyorc.KKTSystem(od, pyorc.Settings(L, kkt_solver=args.kkt_solver))
+                ks.update_scalings_and_factor(False, 1e-6, 1e-4, state)
+                flops = float(n) * (n + 1) * n + n ** 3 / 3.0
+                reps = max(1, min(50, int(2e9 * (1 if threads == 1 else 4) / flops)))
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    ks.update_scalings_and_factor(False, 1e-6, 1e-4, state); ks.solve(rhs[0]); ks.solve(rhs[1])
+                r[label] = (time.perf_counter() - t0) / reps * 1e3
+            r["cpu_threads_all"] = min(avail, 32)
+        rows[str(n)] = r
+    cross1 = [int(n) for n, r in rows.items() if "cpu_1_thread_ms_per_step" in r and r["device_ms_per_step"] < r["cpu_1_thread_ms_per_step"]]
+    crossa = [int(n) for n, r in rows.items() if "cpu_all_threads_ms_per_step" in r and r["device_ms_per_step"] < r["cpu_all_threads_ms_per_step"]]
+    return {"workload": "dense QP, m = n, p = 0; step = 1 update_scalings_and_factor + 2 KKTSystem::solve, inputs resident (device) / in host memory (oracle)",
+            "sizes": rows, "smallest_n_where_device_beats_one_host_thread": min(cross1) if cross1 else None,
+            "smallest_n_where_device_beats_all_host_threads": min(crossa) if crossa else None,
+            "note": "device times include the per-call host synchronisations of the C-ABI (factor status read-back, solve finiteness); below the crossover a "
+                    "host-side Cholesky is the faster backend and the reference's dense_cholesky should be kept"}
+
+
 def cpu_baseline(q, n, p, m, args):
     """The oracle (CPU restatement of the reference algorithms) timed on this box's host cores on a bounded
     sample of the same workload: the same step (1 factor + 2 KKTSystem::solve).  kind = "port"."""
@@ -617,21 +660,22 @@ def cpu_baseline(q, n, p, m, args):
         pass
     # pick the thread count that is actually fastest on this box (cgroup quotas / SMT make "all logical CPUs" a bad default):
     # one factorisation of a small instance per candidate
-    cal_q = dense_strongly_convex_qp_small()
-    cal_d = pyorc.Data.dense(**cal_q, L=L)
-    cal_state = random_vars(cal_d.n, 0, cal_d.m, np.random.default_rng(1), positive=True)
+    od = pyorc.Data.dense(**q, L=L)
+    cal_state = random_vars(n, p, m, np.random.default_rng(1), positive=True)
     best, cores = None, 1
-    for t in [c for c in (1, 2, 4, 8, 16, 32, 64, 128) if c <= avail]:
+    sweep = {}
+    for t in [c for c in (1, 8, 16, 32, 64, 96, 128, 192, 256) if c <= avail]:
+        if t == 1 and float(n) * n * m > 2e10:
+            continue  # (one thread at the full size would take the whole CPU budget; its rate is printed from the size sweep's n = 2048 row)
         L.orc_set_num_threads(t)
-        kc = pyorc.KKTSystem(cal_d, pyorc.Settings(L))
-        kc.update_scalings_and_factor(False, 1e-6, 1e-4, cal_state)
+        kc = pyorc.KKTSystem(od, pyorc.Settings(L, kkt_solver=args.kkt_solver))
         t0 = time.perf_counter()
         kc.update_scalings_and_factor(False, 1e-6, 1e-4, cal_state)
         dt = time.perf_counter() - t0
+        sweep[str(t)] = (float(n) * (n + 1) * m + n ** 3 / 3.0) / dt / 1e9
         if best is None or dt < best:
             best, cores = dt, t
     L.orc_set_num_threads(cores)
-    od = pyorc.Data.dense(**q, L=L)
     ks = pyorc.KKTSystem(od, pyorc.Settings(L, kkt_solver=args.kkt_solver))
     rng = np.random.default_rng(1000)
     state = random_vars(n, p, m, rng, positive=True)
@@ -654,7 +698,10 @@ def cpu_baseline(q, n, p, m, args):
     flops = float(n) * (n + 1) * m + n ** 3 / 3.0
     return {"value": steps / el, "unit": "IPM-iter KKT (1 factor + 2 solves)/s", "cores": cores, "kind": "port",
             "sample": f"{steps} steps of the same n={n} p={p} m={m} workload (after 1 untimed step), oracle built with {build}, {cores} OpenMP threads (fastest of a 1..{avail} sweep)",
-            "seconds": el, "factor_gflops": flops * steps / el / 1e9}
+            "seconds": el, "factor_gflops": flops * steps / el / 1e9, "factor_gflops_per_thread": flops * steps / el / 1e9 / cores,
+            "thread_sweep_factor_gflops": sweep,
+            "note": "GotoBLAS-structure SYRK / rank update with a register-blocked AVX2 8 x 6 (AVX-512: 16 x 12) micro-kernel on packed panels, 2-D task decomposition "
+                    "(oracle/orc_dense.c syrk_like_lower): 22-31 GFLOP/s on one 2.1 GHz Xeon thread of the build container"}
 
 
 if __name__ == "__main__":

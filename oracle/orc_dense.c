@@ -300,7 +300,16 @@ static void syrk_like_lower(int n, int k, double alpha, const double *A, int lda
 #ifndef _OPENMP
     nthreads = 1;
 #endif
-    /* loop over K blocks outermost so every thread owns disjoint C column panels */
+    /* Tasks = lower-triangular pairs (row block of MC rows, column block of NCB columns), largest first, drawn dynamically: with row blocks only
+     * (rounds 1-3) n = 4096 gave 22 tasks of very different size to 32 threads and 9 GFLOP/s per thread; a K block is the outermost loop so that
+     * every task adds its block's contribution to a C block no other task touches. */
+    enum { NCB = 192 }; /* multiple of NR for both vector lengths */
+    const int nrow_blocks = (n + MC - 1) / MC, ncol_blocks = (n + NCB - 1) / NCB;
+    int ntask = 0;
+    int *task = (int *)xmalloc(sizeof(int) * 2 * (size_t)nrow_blocks * ncol_blocks);
+    for (int ib = nrow_blocks - 1; ib >= 0; ib--)
+        for (int jb = 0; jb < ncol_blocks; jb++)
+            if (jb * NCB < ib * MC + MC && jb * NCB < n) { task[2 * ntask] = ib; task[2 * ntask + 1] = jb; ntask++; }
     for (int pc = 0; pc < k; pc += KC) {
         int kc = k - pc < KC ? k - pc : KC;
         int ncol_panels = (n + NR - 1) / NR;
@@ -317,29 +326,35 @@ static void syrk_like_lower(int n, int k, double alpha, const double *A, int lda
                 }
             }
         }
-        int nrow_blocks = (n + MC - 1) / MC;
 #pragma omp parallel num_threads(nthreads)
         {
             double *Apack = (double *)xmalloc(sizeof(double) * (size_t)MC * kc);
             double acc[MR * NR];
+            int packed_ib = -1;
 #pragma omp for schedule(dynamic, 1)
-            for (int ib = nrow_blocks - 1; ib >= 0; ib--) {
+            for (int t = 0; t < ntask; t++) {
+                const int ib = task[2 * t], jb = task[2 * t + 1];
                 int i0 = ib * MC;
                 int mc = n - i0 < MC ? n - i0 : MC;
                 int nrp = (mc + MR - 1) / MR;
-                for (int ip = 0; ip < nrp; ip++) {
-                    double *dst = Apack + (size_t)ip * MR * kc;
-                    for (int kk = 0; kk < kc; kk++)
-                        for (int ii = 0; ii < MR; ii++) {
-                            int i = i0 + ip * MR + ii;
-                            dst[(size_t)kk * MR + ii] = i < n ? A[i + (size_t)(pc + kk) * lda] : 0.0;
-                        }
+                if (packed_ib != ib) { /* (a thread often draws neighbouring column blocks of one row block) */
+                    for (int ip = 0; ip < nrp; ip++) {
+                        double *dst = Apack + (size_t)ip * MR * kc;
+                        for (int kk = 0; kk < kc; kk++)
+                            for (int ii = 0; ii < MR; ii++) {
+                                int i = i0 + ip * MR + ii;
+                                dst[(size_t)kk * MR + ii] = i < n ? A[i + (size_t)(pc + kk) * lda] : 0.0;
+                            }
+                    }
+                    packed_ib = ib;
                 }
-                /* only column panels with j <= last row of this block */
+                /* column panels of this column block, up to the last row of the row block */
                 int jmax = i0 + mc; /* exclusive */
-                int jp_end = (jmax + NR - 1) / NR;
+                int jp_begin = jb * NCB / NR, jp_end = (jb * NCB + NCB) / NR;
+                int jp_lim = (jmax + NR - 1) / NR;
+                if (jp_end > jp_lim) jp_end = jp_lim;
                 if (jp_end > ncol_panels) jp_end = ncol_panels;
-                for (int jp = 0; jp < jp_end; jp++) {
+                for (int jp = jp_begin; jp < jp_end; jp++) {
                     int j0 = jp * NR;
                     for (int ip = 0; ip < nrp; ip++) {
                         int r0 = i0 + ip * MR;
@@ -361,6 +376,7 @@ static void syrk_like_lower(int n, int k, double alpha, const double *A, int lda
         }
         free(Bpack);
     }
+    free(task);
 }
 
 /* ------------------------------------------------------------ Eigen::LLT */

@@ -102,9 +102,8 @@ static double orc_exp_cancel_tol(void)
     return tol;
 }
 
-int orc_sparse_ldlt_numeric(orc_sparse_ldlt *f, int n, const int *Ap, const int *Ai, const double *Ax)
+static int ldlt_numeric_exp(orc_sparse_ldlt *f, int n, const int *Ap, const int *Ai, const double *Ax, const double ctol)
 {
-    const double ctol = orc_exp_cancel_tol();
     int *flag = f->flag, *pattern = f->pattern, *etree = f->etree, *L_cols = f->L_cols, *L_nnz = f->L_nnz, *L_ind = f->L_ind;
     double *y = f->y, *D = f->D, *L_vals = f->L_vals;
     for (int k = 0; k < n; k++) {
@@ -138,13 +137,59 @@ int orc_sparse_ldlt_numeric(orc_sparse_ldlt *f, int n, const int *Ap, const int 
             double l_ki = yi / D[i];
             double tmp = l_ki * yi;
             D[k] -= tmp;
-            if (fabs(tmp) > mx) mx = fabs(tmp);
+            if (ctol > 0.0) { double t2 = fabs(l_ki * yi); if (t2 > mx) mx = t2; } /* (the hook must not reuse tmp: the FMA build contracts the two statements above) */
             L_ind[p] = k;
             L_vals[p] = l_ki;
             L_nnz[i]++;
         }
         if (D[k] == 0.0) return k;
         if (ctol > 0.0 && fabs(D[k]) <= ctol * mx) return k;
+    }
+    for (int k = 0; k < n; k++) f->D_inv[k] = 1.0 / D[k];
+    return n;
+}
+
+/* sparse/ldlt.hpp:101-169; returns n on success, k on D[k] == 0 */
+int orc_sparse_ldlt_numeric(orc_sparse_ldlt *f, int n, const int *Ap, const int *Ai, const double *Ax)
+{
+    if (orc_exp_cancel_tol() > 0.0) return ldlt_numeric_exp(f, n, Ap, Ai, Ax, orc_exp_cancel_tol()); /* experiment hook, see above; the text below is round 3's, untouched */
+    int *flag = f->flag, *pattern = f->pattern, *etree = f->etree, *L_cols = f->L_cols, *L_nnz = f->L_nnz, *L_ind = f->L_ind;
+    double *y = f->y, *D = f->D, *L_vals = f->L_vals;
+    for (int k = 0; k < n; k++) {
+        y[k] = 0.0;
+        int top = n;
+        flag[k] = k;
+        L_nnz[k] = 0;
+        for (int p = Ap[k]; p < Ap[k + 1]; p++) {
+            int i = Ai[p];
+            y[i] = Ax[p];
+            int len;
+            for (len = 0; flag[i] != k; i = etree[i]) {
+                pattern[len++] = i;
+                flag[i] = k;
+            }
+            while (len > 0) pattern[--top] = pattern[--len];
+        }
+        D[k] = y[k];
+        y[k] = 0.0;
+        for (; top < n; top++) {
+            int i = pattern[top];
+            double yi = y[i];
+            y[i] = 0.0;
+            int p2 = L_cols[i] + L_nnz[i];
+            int p;
+            for (p = L_cols[i]; p < p2; p++) {
+                double tmp = L_vals[p] * yi; /* two roundings, as the reference forces */
+                y[L_ind[p]] -= tmp;
+            }
+            double l_ki = yi / D[i];
+            double tmp = l_ki * yi;
+            D[k] -= tmp;
+            L_ind[p] = k;
+            L_vals[p] = l_ki;
+            L_nnz[i]++;
+        }
+        if (D[k] == 0.0) return k;
     }
     for (int k = 0; k < n; k++) f->D_inv[k] = 1.0 / D[k];
     return n;

@@ -87,8 +87,8 @@ TRAJECTORY_SENSITIVE = {
     "mm_QBEACONF": "oracle 17 / 18 (fma); device 17",
     "mm_QCAPRI": "oracle 50 / 35 (fma); device 34", "mm_QETAMACR": "oracle 29 / 29; device 29", "mm_QGROW7": "oracle 24 / 24; device 27 (24-33 over the arithmetic variants)",
     "mm_QGROW22": "oracle 30 / 30; device 36 (30-36 over the variants)", "mm_QSHARE1B": "oracle 24 / 24; device 26 (24-26)", "mm_STADAT1": "oracle 44 / 44; device 42 (42-43)",
-    "mm_QPILOTNO": "oracle 35 / 38 (fma); device 50 (37-57)", "mm_QSHIP08L": "oracle 16 / 16; device 15", "mm_QSHIP08S": "oracle 21 / 18 (fma); device 17 (15-20)",
-    "nl_fffff800": "oracle 43 / 44 (fma); device MAX_ITER in every variant", "nl_finnis": "oracle 35 / MAX_ITER (fma); device MAX_ITER",
+    "mm_QPILOTNO": "oracle 35 / 62 (fma); device 50 (37-57)", "mm_QSHIP08L": "oracle 16 / 16; device 15", "mm_QSHIP08S": "oracle 21 / 19 (fma); device 17 (15-20)",
+    "nl_fffff800": "oracle 43 / 39 (fma); device MAX_ITER in every variant", "nl_finnis": "oracle 35 / MAX_ITER (fma); device MAX_ITER",
     "nl_perold": "oracle 49 / 177 (fma); device 42, MAX_ITER in three of five variants", "nl_forplan": "oracle 51 / 77 (fma); device 58-176",
 }
 # The one fixture of the sweeps where the device ends MAX_ITER while BOTH oracle builds solve.  The reference's rescue there is an exact zero produced by the
