@@ -3137,6 +3137,125 @@ __device__ __forceinline__ double ld_agent(const double* p)
     return __longlong_as_double((long long)__hip_atomic_load((__attribute__((address_space(1))) const u64*)reinterpret_cast<const u64*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
 
+// ---- round 4: the diagonal step of the sweeps as ONE product with the inverse of the 128 x 128 diagonal block, in double-double ----------------------------
+// x_r = L_rr^-1 b is what bounds a sweep: eight dependent 16-column groups, 3.5 of the 5.3 us a block row costs (profiles/r03: 170 us per sweep = 5 % of HBM).
+// A product with the explicit inverse takes the dependence away, but in plain double it costs accuracy exactly where it matters -- the residual of x = fl(V b) is
+// eps |L| |V| |b|, not eps |L| |x|; round 2 measured 2x in the median and 11x at worst on the rho = delta = 1e-10 states and two iteration counts moved.  Here V is
+// computed in double-double (106 bits) once per factorisation and applied with a compensated dot product, so x_r is the correctly rounded solution of the block
+// system up to one ulp: MORE accurate than the substitution it replaces, never less.  (CPU experiment on the oracle, long double substitution inside 16- /
+// 128- / whole-matrix blocks: the iteration counts of every dense parity fixture stay put, QAFIRO's 13 included.)
+// Layout of V: by diagonals -- entry (r, r - s), s = 0 .. 127, at dd_diag_off(s) + (r - s) -- so that the lane that owns row r (forward, x = V b) or column c
+// (backward, x = V^T b) walks its terms with consecutive lanes on consecutive addresses; hi and lo parts in two arrays of DD_TRI doubles per block.
+struct ddn { double h, l; };
+__device__ __forceinline__ ddn dd_two_sum(double a, double b) { const double s = a + b, bb = s - a; return {s, (a - (s - bb)) + (b - bb)}; }
+__device__ __forceinline__ ddn dd_quick(double a, double b) { const double s = a + b; return {s, b - (s - a)}; }
+__device__ __forceinline__ ddn dd_add(ddn a, ddn b) { ddn s = dd_two_sum(a.h, b.h); s.l += a.l + b.l; return dd_quick(s.h, s.l); }
+__device__ __forceinline__ ddn dd_neg(ddn a) { return {-a.h, -a.l}; }
+__device__ __forceinline__ ddn dd_mul_d(ddn a, double b) { const double p = a.h * b; const double e = __builtin_fma(a.h, b, -p); return dd_quick(p, __builtin_fma(a.l, b, e)); }
+__device__ __forceinline__ ddn dd_mul(ddn a, ddn b) { const double p = a.h * b.h; double e = __builtin_fma(a.h, b.h, -p); e += a.h * b.l + a.l * b.h; return dd_quick(p, e); }
+__device__ __forceinline__ ddn dd_div_d(ddn a, double b)
+{
+    const double q1 = a.h / b;
+    ddn r = dd_add(a, dd_neg(dd_mul_d({q1, 0.0}, b)));  // a - q1 b
+    const double q2 = r.h / b;
+    r = dd_add(r, dd_neg(dd_mul_d({q2, 0.0}, b)));
+    const double q3 = r.h / b;
+    ddn q = dd_quick(q1, q2);
+    return dd_add(q, {q3, 0.0});
+}
+constexpr int DD_TRI = 128 * 129 / 2;
+__host__ __device__ inline int dd_diag_off(int s) { return s * 128 - (s * (s - 1)) / 2; }
+// V = L_rr^-1 of every 128-row diagonal block (identity beyond the matrix; UNIT: unit diagonal, the stored one is D), 32 columns of V per workgroup:
+// block forward substitution in groups of 16 rows, X_g = W_g (E_g - sum_{h < g} L_gh X_h), W_g = L_gg^-1, everything in double-double.
+constexpr int DDI_LDS_BYTES = (128 * 32 + 8 * 256) * (int)sizeof(ddn);
+template <bool UNIT>
+__global__ __launch_bounds__(256) void k_block_inverse_dd(const double* __restrict__ L, int ld, int n, double* __restrict__ Vh, double* __restrict__ Vl)
+{
+    extern __shared__ __attribute__((aligned(16))) double ddi_sm[];
+    ddn* X = reinterpret_cast<ddn*>(ddi_sm);   // [128][32]: rows of the block, this workgroup's 32 columns
+    ddn* W = X + 128 * 32;                     // [8][16][16]: W[g][i + 16 k] = (L_gg^-1)(i, k)
+    const int tid = threadIdx.x, J = blockIdx.x, r = blockIdx.y;
+    const int row0 = r * 128, nrows = min(128, n - row0), j0 = 32 * J;
+    auto lval = [&](int i, int k) -> double {  // entry (i, k) of the block, i >= k; identity beyond the matrix, unit diagonal if UNIT
+        if (i >= nrows || k >= nrows) return i == k ? 1.0 : 0.0;
+        if (UNIT && i == k) return 1.0;
+        return L[(size_t)(row0 + i) + (size_t)(row0 + k) * ld];
+    };
+    // ---- W_g: one thread per column of every 16 x 16 diagonal piece
+    if (tid < 128) {
+        const int g = tid >> 4, k = tid & 15;
+        ddn w[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) w[i] = {0.0, 0.0};
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            if (i < k) continue;
+            ddn sacc = {i == k ? 1.0 : 0.0, 0.0};
+#pragma unroll
+            for (int m2 = 0; m2 < 16; ++m2)
+                if (m2 >= k && m2 < i) sacc = dd_add(sacc, dd_neg(dd_mul_d(w[m2], lval(16 * g + i, 16 * g + m2))));
+            w[i] = dd_div_d(sacc, lval(16 * g + i, 16 * g + i));
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) W[g * 256 + i + 16 * k] = w[i];
+    }
+    for (int idx = tid; idx < 128 * 32; idx += 256) X[idx] = {0.0, 0.0};
+    __syncthreads();
+    const int i = tid & 15, jq = tid >> 4;  // entries (i, jq) and (i, jq + 16) of the current group
+    const int g0 = j0 >> 4;                 // the rows above the first column of this column group are zero
+    for (int g = g0; g < 8; ++g) {
+        ddn t0 = {(16 * g + i == j0 + jq) ? 1.0 : 0.0, 0.0}, t1 = {(16 * g + i == j0 + jq + 16) ? 1.0 : 0.0, 0.0};
+        for (int h = g0; h < g; ++h) {
+            double lrow[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) lrow[k] = lval(16 * g + i, 16 * h + k);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                t0 = dd_add(t0, dd_neg(dd_mul_d(X[(16 * h + k) * 32 + jq], lrow[k])));
+                t1 = dd_add(t1, dd_neg(dd_mul_d(X[(16 * h + k) * 32 + jq + 16], lrow[k])));
+            }
+        }
+        // X_g = W_g T: T through LDS (the rows of X_g are free until now)
+        X[(16 * g + i) * 32 + jq] = t0; X[(16 * g + i) * 32 + jq + 16] = t1;
+        __syncthreads();
+        ddn x0 = {0.0, 0.0}, x1 = {0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            if (k > i) continue;  // W_g is lower triangular
+            const ddn wv = W[g * 256 + i + 16 * k];
+            x0 = dd_add(x0, dd_mul(wv, X[(16 * g + k) * 32 + jq]));
+            x1 = dd_add(x1, dd_mul(wv, X[(16 * g + k) * 32 + jq + 16]));
+        }
+        __syncthreads();
+        X[(16 * g + i) * 32 + jq] = x0; X[(16 * g + i) * 32 + jq + 16] = x1;
+        __syncthreads();
+    }
+    // ---- out, by diagonals
+    double* vh = Vh + (size_t)r * DD_TRI;
+    double* vl = Vl + (size_t)r * DD_TRI;
+    for (int idx = tid; idx < 128 * 32; idx += 256) {
+        const int row = idx >> 5, col = j0 + (idx & 31);
+        if (row < col) continue;
+        const ddn v = X[row * 32 + (idx & 31)];
+        const int at = dd_diag_off(row - col) + col;
+        vh[at] = v.h; vl[at] = v.l;
+    }
+}
+void launch_block_inverse_dd(bool unit, const double* L, int ld, int n, double* Vh, double* Vl, hipStream_t s)
+{
+    if (n <= 0) return;
+    static PerDeviceOnce attr_set;
+    attr_set([&] {
+        PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_block_inverse_dd<false>), hipFuncAttributeMaxDynamicSharedMemorySize, DDI_LDS_BYTES));
+        PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_block_inverse_dd<true>), hipFuncAttributeMaxDynamicSharedMemorySize, DDI_LDS_BYTES));
+    });
+    const int nblk = div_up(n, 128);
+    if (unit) hipLaunchKernelGGL(k_block_inverse_dd<true>, dim3(4, nblk), dim3(256), DDI_LDS_BYTES, s, L, ld, n, Vh, Vl);
+    else hipLaunchKernelGGL(k_block_inverse_dd<false>, dim3(4, nblk), dim3(256), DDI_LDS_BYTES, s, L, ld, n, Vh, Vl);
+    PQ_HIP(hipGetLastError());
+}
+size_t block_inverse_dd_doubles(int n) { return (size_t)div_up(n, 128) * DD_TRI; }
+
 // (Serving a block row with several workgroups on several CUs -- helpers taking the earlier producers, the owner the last one -- was
 // measured slower in round 1: 203 / 222 us per sweep with one workgroup per row, 222 / 234 with two, 257 / 267 with four; the extra
 // hand-off costs more than the shared streaming saves.  Round 2 tried replacing the serial 128-step diagonal substitution by a product with
@@ -3150,9 +3269,11 @@ __device__ __forceinline__ double ld_agent(const double* p)
 // (the conditioning level of the panel solve, which holds the accuracy gates of tests/dense_replay.py -- unlike a 128 x 128 inverse), one wave;
 // then every thread takes its 8 columns of the group off the rows still to be solved.  Two LDS barriers per group instead of a 128-step
 // dependent chain on one wave (4.2 us per block in round 1).  W16 == nullptr keeps that substitution (reciprocal pivots in rdiag).
-template <bool FWD>
-__global__ __launch_bounds__(256) void k_trsv_persistent(const double* __restrict__ L, int ld, int n, double* __restrict__ x, const double* __restrict__ rdiag,
-                                                         int nblk, int* __restrict__ flags, int* __restrict__ err, const double* __restrict__ W16, int token, long long* __restrict__ ts)
+// DD (double-double inverses, Vh / Vl): 512 threads -- the product phase uses the first 256 exactly as without DD, the diagonal step all of them (four per row)
+template <bool FWD, bool DD>
+__global__ __launch_bounds__(DD ? 512 : 256) void k_trsv_persistent(const double* __restrict__ L, int ld, int n, double* __restrict__ x, const double* __restrict__ rdiag,
+                                                         int nblk, int* __restrict__ flags, int* __restrict__ err, const double* __restrict__ W16, int token, long long* __restrict__ ts,
+                                                         const double* __restrict__ Vh, const double* __restrict__ Vl)
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double* Ls = sm;                    // own diagonal block, Ls[c * (TB+1) + r]
@@ -3165,23 +3286,39 @@ __global__ __launch_bounds__(256) void k_trsv_persistent(const double* __restric
     __shared__ int sync_w[4];           // diagonal step: [0] groups solved by the chain wave, [1], [2] groups applied by the helper waves
     if (threadIdx.x < 4) sync_w[threadIdx.x] = 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool act = !DD || tid < 256;  // takes part in the product phase
     const int ridx = (int)blockIdx.x;   // position of the block in sweep order
     const int r = FWD ? ridx : nblk - 1 - ridx;
     const int row0 = r * TB, nrows = min(TB, n - row0);
-    // stage the diagonal block (transposed for the backward sweep) and reciprocal pivots
-    stage_lower_block<TB, TB + 1, 256, !FWD>(L + row0 + (size_t)row0 * ld, ld, nrows, Ls, tid);
+    // stage the diagonal block (transposed for the backward sweep) and reciprocal pivots -- or, Vh != nullptr, its double-double inverse by diagonals (hi | lo: the
+    // same 16 512 doubles), see k_block_inverse_dd
+    if constexpr (DD) {
+        const double* vh = Vh + (size_t)r * DD_TRI;
+        const double* vl = Vl + (size_t)r * DD_TRI;
+        // (sixteen loads in flight per thread: one load per loop trip cost a memory round trip each, 65 of them in front of the first block row's turn)
+        constexpr int NTH = 512;
+        for (int base = 0; base < DD_TRI; base += 8 * NTH) {
+            double a[8], b[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { const int idx = base + q * NTH + tid; a[q] = idx < DD_TRI ? vh[idx] : 0.0; b[q] = idx < DD_TRI ? vl[idx] : 0.0; }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { const int idx = base + q * NTH + tid; if (idx < DD_TRI) { Ls[idx] = a[q]; Ls[DD_TRI + idx] = b[q]; } }
+        }
+    } else stage_lower_block<TB, TB + 1, 256, !FWD>(L + row0 + (size_t)row0 * ld, ld, nrows, Ls, tid);
     if (tid < TB) rd[tid] = (rdiag && tid < nrows) ? rdiag[row0 + tid] : 1.0;
-    if (W16) {
+    if (W16 && !DD && tid < 256) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) Wg[u * 256 + tid] = W16[(size_t)r * 8 * 256 + u * 256 + tid];
     }
-    const int row = tid & 127, half = tid >> 7;
-    double mine = (half == 0 && row < nrows) ? x[row0 + row] : 0.0;
+    const int row = tid & 127, half = (tid >> 7) & 1, quarter = tid >> 7;
+    (void)quarter;
+    double mine = (act && quarter == 0 && row < nrows) ? x[row0 + row] : 0.0;
     double acc = 0.0;
     const int nsteps = ridx;  // producers of this block row, in sweep order t = 0 .. nsteps - 1
     // operand block of step t (producer block j_t) into registers; two steps are kept in flight: the block for the next step is requested
     // before the wait for x_{j_t}, so its latency never sits between the arrival of x and the hand-off to the next block
     auto load_block = [&](int t, double (&lv)[64]) {
+        if (!act) return;
         const int j = FWD ? t : nblk - 1 - t;
         const int c0 = j * TB;
         const int nc = min(TB, n - c0);
@@ -3234,8 +3371,10 @@ __global__ __launch_bounds__(256) void k_trsv_persistent(const double* __restric
         if (t_next >= 0) load_block(t_next, nxt);
         if (tid < TB) xs[tid] = xv;
         lds_barrier();
+        if (act) {
 #pragma unroll
-        for (int c = 0; c < 64; ++c) acc += lv[c] * xs[half * 64 + c];
+            for (int c = 0; c < 64; ++c) acc += lv[c] * xs[half * 64 + c];
+        }
         lds_barrier();
         return true;
     };
@@ -3254,9 +3393,65 @@ __global__ __launch_bounds__(256) void k_trsv_persistent(const double* __restric
     }
     __syncthreads();
     if (ts && tid == 0) ts[4 * r + 1] = clock64();  // products done
-    if (half == 1) bs[row] = acc;
+    if (act && half == 1) bs[row] = acc;
     __syncthreads();
-    if (half == 0) bs[row] = mine - (acc + bs[row]);
+    if (act && half == 0) bs[row] = mine - (acc + bs[row]);
+    if constexpr (DD) {
+        // x = V b (forward) / V^T b (backward) with the double-double inverse of the block: one compensated dot product per row, four threads per row taking
+        // every fourth diagonal (entry (row, row - s) resp. (row + s, row) sits at dd_diag_off(s) + column) -- at most 32 terms per thread, eight requested from
+        // LDS per trip, two independent sums (the chain through one sum is ~50 cycles per term, and a trip that waits for its own LDS reads first twice that)
+        __syncthreads();
+        const double* Vhs = Ls;
+        const double* Vls = Ls + DD_TRI;
+        const int smax = FWD ? row : TB - 1 - row;
+        double sum = 0.0, comp = 0.0, sum2 = 0.0, comp2 = 0.0;
+        int sdg = quarter;
+        int off = dd_diag_off(quarter);
+        auto step_off = [](int sq) { return 4 * TB - 6 - 4 * sq; };  // dd_diag_off(s + 4) - dd_diag_off(s)
+        for (; sdg + 28 <= smax; sdg += 32) {
+            double vh[8], vl[8], bb[8];
+            int o2 = off;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int sq = sdg + 4 * q, at = o2 + (FWD ? row - sq : row);
+                vh[q] = Vhs[at]; vl[q] = Vls[at]; bb[q] = bs[FWD ? row - sq : row + sq];
+                o2 += step_off(sq);
+            }
+            off = o2;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const double pr = vh[q] * bb[q], er = __builtin_fma(vh[q], bb[q], -pr);
+                if (q & 1) { const ddn st = dd_two_sum(sum2, pr); sum2 = st.h; comp2 = __builtin_fma(vl[q], bb[q], comp2 + (st.l + er)); }
+                else { const ddn st = dd_two_sum(sum, pr); sum = st.h; comp = __builtin_fma(vl[q], bb[q], comp + (st.l + er)); }
+            }
+        }
+        for (; sdg <= smax; sdg += 4) {
+            const int at = off + (FWD ? row - sdg : row);
+            const double vh = Vhs[at], vl = Vls[at], bb = bs[FWD ? row - sdg : row + sdg];
+            const double pr = vh * bb, er = __builtin_fma(vh, bb, -pr);
+            const ddn st = dd_two_sum(sum, pr);
+            sum = st.h;
+            comp = __builtin_fma(vl, bb, comp + (st.l + er));
+            off += step_off(sdg);
+        }
+        { const ddn t2 = dd_add({sum, comp}, {sum2, comp2}); sum = t2.h; comp = t2.l; }
+        double* part = Wg;  // (free with DD) [3][2][TB]
+        if (quarter > 0) { part[(quarter - 1) * 2 * TB + row] = sum; part[(quarter - 1) * 2 * TB + TB + row] = comp; }
+        __syncthreads();
+        if (quarter == 0) {
+            ddn tot = {sum, comp};
+#pragma unroll
+            for (int q = 0; q < 3; ++q) tot = dd_add(tot, {part[q * 2 * TB + row], part[q * 2 * TB + TB + row]});
+            const double xv = tot.h + tot.l;
+            if (row < nrows) st_agent(x + row0 + row, xv);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        if (ts && tid == 0) ts[4 * r + 2] = clock64();
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(flags + r, token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (ts && tid == 0) ts[4 * r + 3] = clock64();
+        return;
+    }
     if (W16) {
         // The diagonal step as a dataflow inside the workgroup, no barriers (round 2; two barriers per group of 16 cost 8 500 cycles per block,
         // more than the hand-off between the blocks).  Groups of 16 columns, gi = position in sweep order; every wave has one job:
@@ -3424,15 +3619,18 @@ size_t trsv_flag_ints(int n) { return 2 * (size_t)div_up(n, TB) + 1; }
 // LLT: L y = b, L^T x = y with rdiag = 1/diag(L).  LDLt: unit L, then x *= rdiag (= 1/D), then unit L^T.
 // `flags` = trsv_flag_ints(n) ints of scratch (zeroed by the owner at allocation), `token` != 0 unique per call; nullptr, or more blocks than can be resident at once, falls back to
 // one launch per block step.
-void launch_trsv(const double* L, int ld, int n, double* x, const double* rdiag, bool ldlt, int* flags, int token, const double* w16, hipStream_t s, long long* ts)
+void launch_trsv(const double* L, int ld, int n, double* x, const double* rdiag, bool ldlt, int* flags, int token, const double* w16, hipStream_t s, long long* ts, const double* Vh,
+                 const double* Vl)
 {
     if (n <= 0) return;
     static PerDeviceOnce attr_set;
     attr_set([&] {
         PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_trsv_fwd_step), hipFuncAttributeMaxDynamicSharedMemorySize, TRSV_LDS_BYTES));
         PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_trsv_bwd_step), hipFuncAttributeMaxDynamicSharedMemorySize, TRSV_LDS_BYTES));
-        PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_trsv_persistent<true>), hipFuncAttributeMaxDynamicSharedMemorySize, TRSV_P_LDS_BYTES));
-        PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_trsv_persistent<false>), hipFuncAttributeMaxDynamicSharedMemorySize, TRSV_P_LDS_BYTES));
+        PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_trsv_persistent<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, TRSV_P_LDS_BYTES));
+        PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_trsv_persistent<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, TRSV_P_LDS_BYTES));
+        PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_trsv_persistent<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, TRSV_P_LDS_BYTES));
+        PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_trsv_persistent<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, TRSV_P_LDS_BYTES));
     });
     const int nblk = div_up(n, TB);
     const double* rd = ldlt ? nullptr : rdiag;
@@ -3441,9 +3639,11 @@ void launch_trsv(const double* L, int ld, int n, double* x, const double* rdiag,
         // layout: [fwd x flags nblk][bwd x flags nblk][err]; a block is published when its flag holds `token` (unique per call on this flag
         // array, never 0: the array is zeroed once, at allocation -- no memset per solve)
         int* err = flags + 2 * nblk;
-        hipLaunchKernelGGL(k_trsv_persistent<true>, dim3(nblk), dim3(256), TRSV_P_LDS_BYTES, s, L, ld, n, x, rd, nblk, flags, err, w16, token, ts);
+        if (Vh) hipLaunchKernelGGL((k_trsv_persistent<true, true>), dim3(nblk), dim3(512), TRSV_P_LDS_BYTES, s, L, ld, n, x, rd, nblk, flags, err, w16, token, ts, Vh, Vl);
+        else hipLaunchKernelGGL((k_trsv_persistent<true, false>), dim3(nblk), dim3(256), TRSV_P_LDS_BYTES, s, L, ld, n, x, rd, nblk, flags, err, w16, token, ts, Vh, Vl);
         if (ldlt) hipLaunchKernelGGL(k_mul_vec, dim3(div_up(n, 256)), dim3(256), 0, s, n, rdiag, x);
-        hipLaunchKernelGGL(k_trsv_persistent<false>, dim3(nblk), dim3(256), TRSV_P_LDS_BYTES, s, L, ld, n, x, rd, nblk, flags + nblk, err, w16, token, (long long*)nullptr);
+        if (Vh) hipLaunchKernelGGL((k_trsv_persistent<false, true>), dim3(nblk), dim3(512), TRSV_P_LDS_BYTES, s, L, ld, n, x, rd, nblk, flags + nblk, err, w16, token, (long long*)nullptr, Vh, Vl);
+        else hipLaunchKernelGGL((k_trsv_persistent<false, false>), dim3(nblk), dim3(256), TRSV_P_LDS_BYTES, s, L, ld, n, x, rd, nblk, flags + nblk, err, w16, token, (long long*)nullptr, Vh, Vl);
     } else {
         for (int j = 0; j < nblk; ++j)
             hipLaunchKernelGGL(k_trsv_fwd_step, dim3(nblk - j), dim3(256), TRSV_LDS_BYTES, s, L, ld, n, x, rd, j);

@@ -95,7 +95,12 @@ bool launch_chol_persistent(bool ldlt, double* A, double* side, int lda, int n, 
                             int token_base, int* flags, int gen, int fcount, hipStream_t s, const CholAssembly* fused = nullptr);
 size_t trsv_flag_ints(int n);
 // w16: the inverted 16 x 16 diagonal pieces written by the factorisation (8 x 256 doubles per 128-column panel), nullptr: substitution only
-void launch_trsv(const double* L, int ld, int n, double* x, const double* rdiag, bool ldlt, int* flags, int token, const double* w16, hipStream_t s, long long* ts = nullptr);  // ts: debugging aid, 4 stamps per block of the forward sweep
+// Vh / Vl (nullable; persistent sweeps only): the double-double inverses of the 128-row diagonal blocks written by launch_block_inverse_dd -- the diagonal step
+// of a block row becomes one compensated product with them instead of eight dependent 16-column groups
+void launch_trsv(const double* L, int ld, int n, double* x, const double* rdiag, bool ldlt, int* flags, int token, const double* w16, hipStream_t s, long long* ts = nullptr,  // ts: debugging aid, 4 stamps per block of the forward sweep
+                 const double* Vh = nullptr, const double* Vl = nullptr);
+void launch_block_inverse_dd(bool unit, const double* L, int ld, int n, double* Vh, double* Vl, hipStream_t s);  // unit: unit lower triangle (LDLt), the stored diagonal is D
+size_t block_inverse_dd_doubles(int n);  // doubles of Vh (and of Vl)
 int gemv_n_slices(int rows, int cols);
 int launch_gemv_n_partial(int rows, int cols, const double* M, int ld, const double* v, const double* scale, double alpha, double* part, hipStream_t s);
 void launch_reduce_partials(int rows, int nslices, const double* part, const double* base, double* y, hipStream_t s);
