@@ -1740,9 +1740,12 @@ struct CholTask {
 // task of its own whose partial sum goes to a slot of `part`; the last slice to finish adds them up in slice order (chol_role_reduce).  One slice: no partial.
 __host__ __device__ inline int chol_asm_slices(int j, int mchunks)
 {
-    const int band = (j - 1) >> 3, s = band >= 3 ? 1 : (8 >> band);  // block columns 1-8: 8 slices, 9-16: 4, 17-24: 2, beyond: 1
+    // block columns 1-2 (the chain starts on them): 8 slices; 3-8: 4; 9-16: 2; beyond: 1 (a task costs ~20 us besides its chunks)
+    const int s = j <= 2 ? 8 : (j <= 8 ? 4 : (j <= 16 ? 2 : 1));
     return s < mchunks ? s : (mchunks > 0 ? mchunks : 1);
 }
+// bands of block columns with one slice count, assembled slice-major (see chol_build_tasks_fused): [lo, hi)
+__host__ __device__ inline int chol_asm_band_end(int lo) { return lo <= 2 ? 3 : (lo <= 8 ? 9 : lo + 8); }
 // workgroups per panel tile: a row's task of round k needs that row's output of round k - 1, so one workgroup's update + substitution (28 + 13 us for a
 // whole tile) bound a round from below; halves (fused_tile<HALF>) keep that under the diagonal block's 30 us.  Early rounds are bound by the bulk
 // tiles anyway and keep whole tiles (half as many workgroups parked on the chain).
@@ -1859,53 +1862,74 @@ __device__ __forceinline__ void accum_tile(const AccumArgs& g, double* __restric
                 }
             }
     }
-    // Four stages (64 operand columns) per group: the registers hold group n + 1 while LDS holds group n.  (Eight stages = a whole chunk in registers, requested
-    // behind the second group's LDS stores, did not fit next to the accumulators: 220-240 bytes of scratch per lane and 26-31 us per chunk instead of 15.)
-    d2 pa[GRP][PER], pb[GRP][PER];
-    auto request = [&](int gi) {  // group gi = stages [4 (gi & 1), +4) of chunk gi >> 1
-        const int c = gi >> 1, k0 = (gi & 1) * GRP * BK;
+    // Software pipeline over groups of TWO stages (32 operand columns): LDS holds two groups (the one being multiplied and the next one), the registers two more
+    // (groups n + 2 and n + 3 in flight from memory) -- one barrier per group, and the LDS stores of group n + 1 and the loads of group n + 3 are issued in front of
+    // the products of group n instead of between two barriers.  (History: a whole chunk in registers, requested behind the second group's LDS stores, spilled --
+    // 220-240 bytes of scratch per lane, 26-31 us per 128-column chunk; four-stage groups through ONE LDS buffer with two barriers each: 21 us; the matrix cores
+    // need 13.7 us.)
+    constexpr int GS = 2;                                   // stages per group
+    constexpr int GROUP_DOUBLES = 2 * GS * BK * LDS_LD;     // A stages, then B stages
+    static_assert(2 * GROUP_DOUBLES * (int)sizeof(double) <= FUSED_LDS_BYTES, "two groups in LDS");
+    d2 ra[2][GS][PER], rb[2][GS][PER];
+    auto request = [&](int gi, d2 (&pa)[GS][PER], d2 (&pb)[GS][PER]) {  // group gi = stages [GS (gi & 3), +GS) of chunk gi >> 2
+        const int c = gi >> 2, k0 = (gi & 3) * GS * BK;
         const double* A = (c == 0 ? g.A0 : g.A1) + (size_t)c * 128 * g.ld;
         const double* B = (c == 0 ? g.B0 : g.B1) + (size_t)c * 128 * g.ld;
 #pragma unroll
-        for (int q = 0; q < GRP; ++q) { load_tile<false, NT>(A, g.ld, 0, k0 + q * BK, 0, 0, tid, pa[q]); load_tile<false, NT>(B, g.ld, 0, k0 + q * BK, 0, 0, tid, pb[q]); }
+        for (int q = 0; q < GS; ++q) { load_tile<false, NT>(A, g.ld, 0, k0 + q * BK, 0, 0, tid, pa[q]); load_tile<false, NT>(B, g.ld, 0, k0 + q * BK, 0, 0, tid, pb[q]); }
     };
-    double* A4 = smem;                       // [GRP][BK][LDS_LD]
-    double* B4 = smem + GRP * BK * LDS_LD;   // [GRP][BK][LDS_LD]
-    const int ngroups = 2 * g.nchunk;
-    request(0);
-#pragma unroll 1
-    for (int gi = 0; gi < ngroups; ++gi) {
-        const double* wg = g.w ? g.w + (size_t)gi * GRP * BK : nullptr;
-        __syncthreads();  // every wave has read the previous group
+    auto to_lds = [&](int gi, d2 (&pa)[GS][PER], d2 (&pb)[GS][PER]) {
+        double* buf = smem + (gi & 1) * GROUP_DOUBLES;
+        const double* wg = g.w ? g.w + (size_t)gi * GS * BK : nullptr;
 #pragma unroll
-        for (int q = 0; q < GRP; ++q) {
+        for (int q = 0; q < GS; ++q) {
             scale_tile<false, NT, FAR, FAR>(wg, q * BK, 0, tid, pb[q]);
-            store_tile<NT>(A4 + q * BK * LDS_LD, tid, pa[q]);
-            store_tile<NT>(B4 + q * BK * LDS_LD, tid, pb[q]);
+            store_tile<NT>(buf + q * BK * LDS_LD, tid, pa[q]);
+            store_tile<NT>(buf + (GS + q) * BK * LDS_LD, tid, pb[q]);
         }
-        if (gi + 1 < ngroups) request(gi + 1);  // (flies during this group's products)
-        __syncthreads();
-        if (!skip_wave) {
+    };
+    auto products = [&](int gi) {
+        if (skip_wave) return;
+        const double* buf = smem + (gi & 1) * GROUP_DOUBLES;
 #pragma unroll
-            for (int q = 0; q < GRP; ++q) {
-                const double* Asb = A4 + q * BK * LDS_LD + wr * SUBR + (lane & 15);
-                const double* Bsb = B4 + q * BK * LDS_LD + wc * SUBC + (lane & 15);
+        for (int q = 0; q < GS; ++q) {
+            const double* Asb = buf + q * BK * LDS_LD + wr * SUBR + (lane & 15);
+            const double* Bsb = buf + (GS + q) * BK * LDS_LD + wc * SUBC + (lane & 15);
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    const int kk = ks * 4 + (lane >> 4);
-                    double af[MTR], bf[MTC];
+            for (int ks = 0; ks < 4; ++ks) {
+                const int kk = ks * 4 + (lane >> 4);
+                double af[MTR], bf[MTC];
 #pragma unroll
-                    for (int u = 0; u < MTR; ++u) af[u] = Asb[kk * LDS_LD + u * 16];
+                for (int u = 0; u < MTR; ++u) af[u] = Asb[kk * LDS_LD + u * 16];
 #pragma unroll
-                    for (int u = 0; u < MTC; ++u) bf[u] = Bsb[kk * LDS_LD + u * 16];
+                for (int u = 0; u < MTC; ++u) bf[u] = Bsb[kk * LDS_LD + u * 16];
 #pragma unroll
-                    for (int x = 0; x < MTC; ++x)
+                for (int x = 0; x < MTC; ++x)
 #pragma unroll
-                        for (int y = 0; y < MTR; ++y)
-                            acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[x], af[y], acc[x][y], 0, 0, 0);
-                }
+                    for (int y = 0; y < MTR; ++y)
+                        acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[x], af[y], acc[x][y], 0, 0, 0);
             }
         }
+    };
+    const int ngroups = 4 * g.nchunk;  // (even)
+    request(0, ra[0], rb[0]);
+    request(1, ra[1], rb[1]);
+    __syncthreads();                   // (the LDS of the previous task is free)
+    to_lds(0, ra[0], rb[0]);
+    if (2 < ngroups) request(2, ra[0], rb[0]);
+    __syncthreads();
+#pragma unroll 1
+    for (int gi = 0; gi < ngroups; gi += 2) {
+        // even group gi: group gi + 1 waits in ra[1], group gi + 2 is in flight into ra[0]
+        to_lds(gi + 1, ra[1], rb[1]);
+        if (gi + 3 < ngroups) request(gi + 3, ra[1], rb[1]);
+        products(gi);
+        __syncthreads();
+        // odd group gi + 1
+        if (gi + 2 < ngroups) to_lds(gi + 2, ra[0], rb[0]);
+        if (gi + 4 < ngroups) request(gi + 4, ra[0], rb[0]);
+        products(gi + 1);
+        __syncthreads();
     }
     if (skip_wave) return;
 #pragma unroll
@@ -2014,6 +2038,20 @@ __global__ __launch_bounds__(CHOL_THREADS, 2) void k_chol_persistent(CholArgs c)
                     if (t != cur && t < ntasks) tk = c.tasks[t];
                     break;
                 }
+                // the head's gate is closed.  Fused assembly: an assembly task needs nothing -- take one from the queues instead of sleeping (its token becomes a
+                // no-op when the list reaches it).  Without this, 170 of 256 workgroups slept at the gate for 200 us at a time while 900 assembly tasks waited
+                // further down the list (tools/chol_trace_report.py on the first version: 31 % of the launch between tasks).
+                if (c.GT != nullptr && c.aq_ptr[8] > 0) {
+                    bool got = false;
+                    const int xcd = (int)blockIdx.x & 7;
+                    for (int q8 = 0; q8 < 8 && !got; ++q8) {
+                        const int y = (xcd + q8) & 7, len = c.aq_ptr[y + 1] - c.aq_ptr[y];
+                        if (len <= 0 || ldi_agent(c.aq_head + y) >= len) continue;
+                        const int hq = addi_agent(c.aq_head + y, 1);
+                        if (hq < len) { s_asm = c.aq[c.aq_ptr[y] + hq]; got = true; }
+                    }
+                    if (got) { t = -2; break; }
+                }
                 __builtin_amdgcn_s_sleep(127);  // (an idle workgroup polls rarely: a grid of pollers slows the write-through traffic of the chain)
                 if (((++spins & 15u) == 0 && ldi_agent(abort_w) != 0) || spins > 8000000u) { t = ntasks; break; }
             }
@@ -2025,7 +2063,8 @@ __global__ __launch_bounds__(CHOL_THREADS, 2) void k_chol_persistent(CholArgs c)
         const CholTask tk = s_task;
         __syncthreads();
         if (t >= ntasks) return;
-        if (c.trace && tid == 0) { c.trace[4 * (size_t)t] = wall_clock64(); c.trace[4 * (size_t)t + 3] = blockIdx.x; }
+        const bool gate_help = t == -2;  // an assembly task taken at a closed gate (s_asm), no ticket
+        if (!gate_help && c.trace && tid == 0) { c.trace[4 * (size_t)t] = wall_clock64(); c.trace[4 * (size_t)t + 3] = blockIdx.x; }
         const bool asm_in = c.GT != nullptr;  // fused assembly: a tile's first update waits for tver == gen like every later one waits for gen + k
         // thread 0: the next assembly task -- own XCD's queue first, then the others'
         auto draw_asm = [&]() -> bool {
@@ -2084,6 +2123,12 @@ __global__ __launch_bounds__(CHOL_THREADS, 2) void k_chol_persistent(CholArgs c)
                 run_asm(q, nullptr);
             }
         };
+        if (gate_help) {
+            const CholTask q = s_asm;
+            __syncthreads();
+            run_asm(q, nullptr);
+            continue;
+        }
         if (tk.kind == 8) {
             // ---- assembly token: the next task of this XCD's queue
             if (tid == 0) s_help = draw_asm() ? 1 : 0;
@@ -2270,7 +2315,7 @@ static void chol_build_tasks(int T, std::vector<CholTask>& H)
 //  * one relaxation pass in creation order (which is a topological order) pushes every task behind everything it waits for, so "a workgroup only ever waits for
 //    earlier tickets" -- the property that makes the single list deadlock-free under any residency -- holds by construction whatever the model says.
 constexpr int FAR_G = 4, FAR_SLACK = 3;
-constexpr double FUSE_ROUND_US = 43.0, FUSE_CHUNK_US = 17.5, FUSE_VISIT_US = 6.0, FUSE_WEFF = 200.0;
+constexpr double FUSE_ROUND_US = 43.0, FUSE_CHUNK_US = 19.5, FUSE_VISIT_US = 20.0, FUSE_WEFF = 230.0;  // (measured, PIQP_AMD_DEBUG=chol_trace: 19.5 us per 128-column chunk, 20 us per task)
 static void chol_build_tasks_fused(int T, int mchunks, std::vector<CholTask>& H, int& part_slots, std::vector<CholTask>& Q, int (&qptr)[9])
 {
     struct Node { double tau, dur; int cls; CholTask t; std::vector<int> deps; };
@@ -2293,16 +2338,20 @@ static void chol_build_tasks_fused(int T, int mchunks, std::vector<CholTask>& H,
     std::vector<double> qdur;
     for (int x = 0; x < 8; ++x) {
         qptr[x] = (int)Q.size();
-        for (int j = 1; j < T; ++j) {
-            const int S = chol_asm_slices(j, mchunks);
+        // column-major (the chain needs block column k + 1 in round k), slice-major inside a column.  (Tried: bands of eight columns slice-major, so that what an
+        // XCD runs together reads one K range of a dozen operand panels -- the chunks took the same 20 us, which is 13.7 us of matrix-core work at the clock the
+        // whole chip sustains under this load, not memory; and the band's columns all finished together, which stalled the chain for 400 us behind round 1.)
+        for (int jb = 1; jb < T; ++jb) {
+            const int S = chol_asm_slices(jb, mchunks);
             for (int sl = 0; sl < S; ++sl)
-                for (int i = j; i < T; ++i) {
-                    if ((i & 7) != x) continue;
-                    qpos[(size_t)i * T + j] = (int)Q.size() - qptr[x];
-                    Q.push_back({6, (short)sl, (short)i, (short)j, x, aux[(size_t)i * T + j]});
-                    const int c0 = (int)((long long)sl * mchunks / S), c1 = (int)((long long)(sl + 1) * mchunks / S);
-                    qdur.push_back(FUSE_VISIT_US + FUSE_CHUNK_US * (c1 - c0));
-                }
+                for (int j = jb; j < jb + 1; ++j)
+                    for (int i = j; i < T; ++i) {
+                        if ((i & 7) != x) continue;
+                        qpos[(size_t)i * T + j] = (int)Q.size() - qptr[x];
+                        Q.push_back({6, (short)sl, (short)i, (short)j, x, aux[(size_t)i * T + j]});
+                        const int c0 = (int)((long long)sl * mchunks / S), c1 = (int)((long long)(sl + 1) * mchunks / S);
+                        qdur.push_back(FUSE_VISIT_US + FUSE_CHUNK_US * (c1 - c0));
+                    }
         }
     }
     qptr[8] = (int)Q.size();
@@ -2390,6 +2439,9 @@ static void chol_build_tasks_fused(int T, int mchunks, std::vector<CholTask>& H,
     for (Node& q : N) {
         for (int dep : q.deps) {
             const Node& d = N[(size_t)dep];
+            // crew and panel tasks keep their early draw against chain and tile tasks (they FOLLOW their producers), and must: drawn at their inputs' finish
+            // times they sat BEHIND bulk tasks of their own round whose gate (the round before complete) was still closed -- every round then started only when the
+            // one before had completely finished: 150 us per round (tools/chol_trace_report.py)
             const bool early = q.cls <= 2 && d.t.kind != 8;
             q.tau = std::max(q.tau, d.tau + (early ? 1e-3 : d.dur));
         }
@@ -2520,6 +2572,15 @@ bool launch_chol_persistent(bool ldlt, double* A, double* side, int lda, int n, 
         long long t0 = h[0];
         for (int t = 0; t < P->ntasks; ++t) t0 = std::min(t0, h[4 * (size_t)t]);
         auto us = [&](long long v) { return (double)(v - t0) * 0.01; };
+        if (const char* fn = std::getenv("PIQP_AMD_CHOL_TRACE_FILE")) {
+            // raw timeline of this launch, one line per ticket: ticket kind round a b gate drawn inputs done workgroup(+1000 j for an assembly token)  [us]
+            if (FILE* fp = std::fopen(fn, "w")) {
+                for (int t = 0; t < P->ntasks; ++t)
+                    std::fprintf(fp, "%d %d %d %d %d %d %.2f %.2f %.2f %lld\n", t, tk[(size_t)t].kind, tk[(size_t)t].round, tk[(size_t)t].a, tk[(size_t)t].b, tk[(size_t)t].gate, us(h[4 * (size_t)t]),
+                                 us(h[4 * (size_t)t + 1]), us(h[4 * (size_t)t + 2]), h[4 * (size_t)t + 3]);
+                std::fclose(fp);
+            }
+        }
         std::fprintf(stderr, "[piqp_amd] k_chol_persistent timeline (us since the first ticket), T = %d, %d tasks, grid %d\n", T, P->ntasks, P->grid);
         if (fa) {
             // fused assembly: per block column the end of its last assembly task; the several-panel visits of the far tiles

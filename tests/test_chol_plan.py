@@ -22,8 +22,7 @@ def split_row(T, k, ti):
 
 
 def asm_slices(j, mch):
-    band = (j - 1) >> 3
-    s = 1 if band >= 3 else 8 >> band
+    s = 8 if j <= 2 else (4 if j <= 8 else (2 if j <= 16 else 1))
     return s if s < mch else max(mch, 1)
 
 
