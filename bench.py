@@ -19,6 +19,7 @@ import os
 import sys
 import time
 
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")  # the oracle's OpenMP threads must not spin behind a parallel region while a device leg is being timed
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -327,6 +328,10 @@ def sparse_legs(args, rank, world, local_rank, dev, pd):
               mpc_chain(12, 8, 25000, 5 + rank), piqp_amd.SPARSE_LDLT, 5)]
     # the real Maros-Meszaros cross-checks SURVEY.md 8d names next to the synthetic C3 (frozen fixtures, tests/golden/make_fixtures.py)
     from qp_io import load_qp
+    # round 4: the banded C3 recipe is the benign half of "Maros-Meszaros-style" (every row inside a 40-variable window, fronts <= 92); a wider variant beside it --
+    # rows of 10 nonzeros inside 300-variable windows, nnz(upper KKT) = 7.4e5: nnz(L) = 1.9e7, fronts up to 620, an assembly tree ~1800 levels deep
+    cases.append(("C3_wide", "sparse QP n=50000 p=20000 m=30000, rows of 10 nonzeros in 300-variable windows, nnz(upper KKT)=7.4e5, kkt_solver=sparse_ldlt (harder variant of BASELINE configs[2])",
+                  c3_problem(seed=44 + rank, spread=300, row_nnz=10), piqp_amd.SPARSE_LDLT, 1))
     for nm, what in (("CONT-201", "PDE-constrained grid, n=40397 p=40198"), ("BOYD1", "n=93261 with 18 dense equality rows")):
         q = load_qp("mm_" + nm)
         cases.append(("MM_" + nm, f"Maros-Meszaros {nm} ({what}), kkt_solver=sparse_ldlt", (q["P"], q["c"], q["A"], q["b"], q["G"], q["h_l"], q["h_u"], q["x_l"], q["x_u"]),
@@ -348,7 +353,7 @@ def sparse_legs(args, rank, world, local_rank, dev, pd):
             assert k.update_scalings_and_factor(False, 1e-6, 1e-4, state)
             k.solve(rhs[0], lhs)
         res_inf, nrm = k.condensed_residual()
-        steps = 10
+        steps = 3 if key == "C3_wide" else 10
         be = k.backend(); be.set_profiling(True)
         pd.barrier(); k.synchronize(); torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -402,7 +407,7 @@ def sparse_legs(args, rank, world, local_rank, dev, pd):
                 ko = pyorc.KKTSystem(od, pyorc.Settings(kkt_solver=oracle_ks))
                 ko.update_scalings_and_factor(False, 1e-6, 1e-4, state_h)
                 t0 = time.perf_counter()
-                cs = 3
+                cs = 1 if key == "C3_wide" else 3
                 for _ in range(cs):
                     ko.update_scalings_and_factor(False, 1e-6, 1e-4, state_h); ko.solve(rhs_h[0]); ko.solve(rhs_h[1])
                 elc = time.perf_counter() - t0

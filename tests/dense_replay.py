@@ -36,7 +36,15 @@ def replay(name, ks):
         st = fs[it]; rhs = ss[min(2 * it + 1, len(ss) - 1)]["vars"]
         okh = kh.update_scalings_and_factor(False, st["rho"], st["delta"], st["vars"])
         oko = ko.update_scalings_and_factor(False, st["rho"], st["delta"], st["vars"])
-        _, lh = kh.solve(rhs); _, lo = ko.solve(rhs)
+        # (a failed factorisation is reported, never solved with: its NaN / Inf factor would only put RuntimeWarnings into the test log)
+        lh = lo = None
+        if okh:
+            _, lh = kh.solve(rhs)
+        if oko:
+            _, lo = ko.solve(rhs)
+        if not oko:
+            out.append((it, st["rho"], st["delta"], okh, oko, float("nan"), float("nan")))
+            continue
         xr, zr, rx, rz, ry = ko.x_reg(), ko.z_reg(), ko.rhs_x_bar(), ko.rhs_z_bar(), rhs["y"]
 
         def resid(l):
@@ -46,5 +54,5 @@ def replay(name, ks):
             r3 = rz.astype(L) - G @ x + zr.astype(L) * z
             nrm = max(np.abs(rx).max(), np.abs(ry).max() if p else 0.0, np.abs(rz).max() if m else 0.0)
             return float(max(np.abs(r1).max(), np.abs(r2).max() if p else 0.0, np.abs(r3).max() if m else 0.0) / nrm)
-        out.append((it, st["rho"], st["delta"], okh, oko, resid(lh), resid(lo)))
+        out.append((it, st["rho"], st["delta"], okh, oko, resid(lh) if okh else float("nan"), resid(lo)))
     return out

@@ -152,16 +152,17 @@ def mpc_chain(nx, nu, T, seed):
     return (P, rng.standard_normal(n), A, np.zeros(p), None, None, None, -np.ones(n), np.ones(n))
 
 
-def c3_problem(n=50000, p=20000, m=30000, seed=44, spread=40):
-    """BASELINE configs[2]: sparse QP, P banded upper-tri (~3 nnz/col + diagonal), A and G rows with 5 nnz each
-    inside a window of `spread` variables; N = n + p + m = 100 000, nnz(full KKT) ~ 0.9e6"""
+def c3_problem(n=50000, p=20000, m=30000, seed=44, spread=40, row_nnz=5):
+    """BASELINE configs[2]: sparse QP, P banded upper-tri (~3 nnz/col + diagonal), A and G rows with `row_nnz` nnz each
+    inside a window of `spread` variables; N = n + p + m = 100 000.  Defaults: the banded recipe of rounds 1-3 (nnz(upper K) = 4.9e5, fronts <= 92);
+    spread = 1500, row_nnz = 10: the wider variant of round 4 (nnz(upper K) ~ 0.95e6, the BASELINE figure; constraint rows couple variables 1500 apart)"""
     import scipy.sparse as sp
     rng = np.random.default_rng(seed)
     P = sp.diags([rng.uniform(1, 2, n), rng.uniform(-0.3, 0.3, n - 1), rng.uniform(-0.2, 0.2, n - 2), rng.uniform(-0.1, 0.1, n - 3)], [0, 1, 2, 3], format="csc")
 
     def rows(k):
-        cols = (rng.integers(0, n - spread, k)[:, None] + rng.choice(spread, (k, 5), replace=True)).ravel()
-        M = sp.csc_matrix((rng.standard_normal(5 * k), (np.repeat(np.arange(k), 5), cols)), shape=(k, n))
+        cols = (rng.integers(0, n - spread, k)[:, None] + rng.choice(spread, (k, row_nnz), replace=True)).ravel()
+        M = sp.csc_matrix((rng.standard_normal(row_nnz * k), (np.repeat(np.arange(k), row_nnz), cols)), shape=(k, n))
         M.sum_duplicates()
         return M
     A, G = rows(p), rows(m)

@@ -316,8 +316,38 @@ def test_persistent_factorisation_is_bitwise_the_launch_per_panel_one(hip):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "chk_chol_persistent.py"), "384", "640", "1024", "2048"], capture_output=True, text=True, timeout=900)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "chk_chol_persistent.py"), "384", "640", "1024", "2048", "4096"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "ALL EQUAL" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("kkt_solver", [0, 16])
+@pytest.mark.parametrize("n,bad", [(512, 300), (1024, 700), (1024, 100)])
+def test_failure_inside_the_persistent_launch_then_refactor_on_the_same_handle(hip, orc, n, bad, kkt_solver):
+    """round-3 advice: the non-positive pivot (LL^T, dense/kkt.hpp:83) / exact zero pivot (LDL^T, ldlt_no_pivot.hpp:307) INSIDE k_chol_persistent -- a later
+    diagonal block, reached through the launch's own rounds -- is reported like the launch-per-panel path and the oracle report it, and the handle's cumulative
+    flag counters survive it: a good matrix factored next on the same handle gives bitwise the factor of a fresh handle"""
+    q = dense_strongly_convex_qp(n, 0, 0, seed=3 + n)
+    Pg = q["P"].copy()
+    Pb = Pg.copy()
+    if kkt_solver == 0:
+        Pb[bad, bad] = -1e6  # indefinite: LL^T must fail, LDL^T would not
+    else:
+        Pb[bad, :] = 0.0; Pb[:, bad] = 0.0  # a zero row / column: with x_reg = 0 there the pivot is exactly zero
+    x_reg = np.full(n, 1e-3); z_reg = np.zeros(0)
+    if kkt_solver == 16:
+        x_reg = x_reg.copy(); x_reg[bad] = 0.0
+    d = hip.Data(Pb, q["c"])
+    k = hip.DenseKKT(d, kkt_solver=kkt_solver)
+    assert k.update_scalings_and_factor(1.0, x_reg, z_reg) is False
+    assert orc.KKT(orc.Data.dense(Pb, q["c"]), use_ldlt=kkt_solver == 16).update_scalings_and_factor(1.0, x_reg, z_reg) is False
+    assert k.update_scalings_and_factor(1.0, x_reg, z_reg) is False  # (and again: the counters of the failed launch are consistent)
+    # the same handle, good data
+    k.update_data(hip.Data(Pg, q["c"]), 7)  # KKT_UPDATE_P | A | G
+    xg = np.full(n, 1e-3)
+    assert k.update_scalings_and_factor(1.0, xg, z_reg) is True
+    fresh = hip.DenseKKT(hip.Data(Pg, q["c"]), kkt_solver=kkt_solver)
+    assert fresh.update_scalings_and_factor(1.0, xg, z_reg) is True
+    assert np.array_equal(np.tril(k.internal_factor()), np.tril(fresh.internal_factor()))
 
 
 def test_two_persistent_factorisations_on_two_streams(hip):

@@ -20,8 +20,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 from qp_gen import c3_problem as _c3  # noqa: E402
 
 
-def c3_problem(n=50000, p=20000, m=30000, seed=44, spread=40):
-    return _c3(n, p, m, seed, spread), (n, p, m)
+def c3_problem(n=50000, p=20000, m=30000, seed=44, spread=40, row_nnz=5):
+    return _c3(n, p, m, seed, spread, row_nnz), (n, p, m)
 
 
 def main():
@@ -29,6 +29,8 @@ def main():
     ap.add_argument("--n", type=int, default=50000)
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--no-oracle", action="store_true")
+    ap.add_argument("--spread", type=int, default=40)
+    ap.add_argument("--row-nnz", type=int, default=5)
     ap.add_argument("--fixture", default=None, help="a frozen problem of tests/golden instead of the C3 generator, e.g. mm_BOYD1")
     args = ap.parse_args()
     import torch  # noqa: F401
@@ -41,7 +43,7 @@ def main():
         a = (q["P"], q["c"], q["A"], q["b"], q["G"], q["h_l"], q["h_u"], q["x_l"], q["x_u"])
         n, p, m = q["P"].shape[0], (0 if q["A"] is None else q["A"].shape[0]), (0 if q["G"] is None else q["G"].shape[0])
     else:
-        a, (n, p, m) = c3_problem(args.n, int(20000 * scale), int(30000 * scale))
+        a, (n, p, m) = c3_problem(args.n, int(20000 * scale), int(30000 * scale), spread=args.spread, row_nnz=args.row_nnz)
     nnzK = sp.triu(a[0]).nnz + (a[2].nnz if a[2] is not None else 0) + p + (a[4].nnz if a[4] is not None else 0) + m
     t0 = time.perf_counter()
     d = hip.SparseData(*a)
