@@ -211,6 +211,17 @@ int pq_kkt_set_exchange(pq_kkt *k, pq_exchange_fn exchange, void *user, double *
  * librccl is loaded with dlopen at the first of these calls; single-GPU use never needs it. */
 int pq_rccl_unique_id(unsigned char id_out[128]);
 int pq_kkt_set_comm_rccl(pq_kkt *k, const unsigned char id[128], int rank, int world);
+/* SURVEY 8(e) row 2 (reference: the stage-parallel loops of sparse/multistage_kkt.hpp:856-993, 1036-1218, 1529-1643): with a stage partition of a sparse_ldlt
+ * (KKT_FULL) backend, (a) the per-factorisation value assembly refreshes only the diagonal entries of the fronts this rank factors, and (b) the refinement
+ * residual err = rhs - K lhs (kkt_system.hpp:507-536) is evaluated only on the rows this rank's part of the next solve reads; ||err||_inf crosses the ranks in
+ * ONE collective per refinement step:
+ *   which = 3  all-reduce(MAX) of buf_norm [1 double]
+ * through the same callback (register buf_norm after pq_kkt_set_exchange) or, with the native transport, ncclAllReduce(max) on the library's own buffer.  No halo
+ * exchange is needed: the solution vectors are replicated (which = 2 gathers them), so every rank reads what its rows touch.  Without a registered buffer, for the
+ * condensed KKT modes, or with PIQP_AMD_DEBUG=replicated_residual the residual is evaluated on every row by every rank as before.  The results are bitwise those of
+ * the replicated evaluation (tests/test_partition.py).  pq_kkt_sharded_calls: out[0] = sharded residual evaluations so far, out[1] = rows in this rank's share. */
+int pq_kkt_set_exchange_norm(pq_kkt *k, double *buf_norm);
+int pq_kkt_sharded_calls(pq_kkt *k, int out[2]);
 /* test hook (sparse backends): smallest |pivot| of the last factorisation */
 int pq_kkt_min_abs_pivot(pq_kkt *k, double *out);
 /* collectives the native transport has enqueued so far: out[which] for which = 0, 1, 2 (test / bench bookkeeping) */
@@ -323,6 +334,8 @@ int pq_solver_set_exchange(pq_solver *s, pq_exchange_fn exchange, void *user, do
                            double *buf_gather);
 int pq_solver_set_comm_rccl(pq_solver *s, const unsigned char id[128], int rank, int world);
 int pq_solver_native_exchange_calls(pq_solver *s, int out[3]);
+int pq_solver_set_exchange_norm(pq_solver *s, double *buf_norm); /* as pq_kkt_set_exchange_norm */
+int pq_solver_sharded_calls(pq_solver *s, int out[2]);
 int pq_solver_comm_info(pq_solver *s, int out[4]); /* as pq_kkt_comm_info */
 
 /* ===================== Batched solver: many structurally identical sparse QPs in one launch ===================== */

@@ -366,6 +366,16 @@ int pq_kkt_comm_info(pq_kkt* k, int out[4])
     if (!k || !out) return fail(PQ_ERR_INVALID, "null argument");
     return guarded([&] { k->impl->comm_info(out); return (int)PQ_OK; });
 }
+int pq_kkt_set_exchange_norm(pq_kkt* k, double* buf_norm)
+{
+    if (!k) return fail(PQ_ERR_INVALID, "null handle");
+    return guarded([&] { k->impl->set_exchange_norm(buf_norm); return (int)PQ_OK; });
+}
+int pq_kkt_sharded_calls(pq_kkt* k, int out[2])
+{
+    if (!k || !out) return fail(PQ_ERR_INVALID, "null argument");
+    return guarded([&] { k->impl->sharded_calls(out); return (int)PQ_OK; });
+}
 int pq_kkt_native_exchange_calls(pq_kkt* k, int out[3])
 {
     if (!k || !out) return fail(PQ_ERR_INVALID, "null argument");

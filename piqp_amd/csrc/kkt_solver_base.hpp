@@ -60,6 +60,19 @@ public:
     // test hook: smallest |pivot| of the last factorisation (sparse backends), read back through the host
     virtual double min_abs_pivot() { throw std::runtime_error("min_abs_pivot: sparse backends only"); }
     virtual void native_exchange_calls(int out[3]) const { out[0] = out[1] = out[2] = 0; }
+    // SURVEY 8(e) row 2 (round 4): with a stage partition the refinement residual err = rhs - K lhs (kkt_system.hpp:507-536) is evaluated only on the rows this
+    // rank's part of the next solve reads -- its own subtrees' rows, the shared top, and nothing else -- and ||err||_inf crosses the ranks in ONE all-reduce(max)
+    // per refinement step (exchange which = 3 on the buffer registered with set_exchange_norm; the native transport owns its buffer).  false: not sharded here
+    // (single GPU, another KKT mode, a column too long for the row kernels): the caller evaluates the residual on every row as before.  On success *norm holds
+    // the global ||err||_inf (+inf stands for NaN) and err_* are valid on this rank's rows only.
+    virtual void set_exchange_norm(double* buf_norm) { (void)buf_norm; throw std::runtime_error("set_exchange_norm: not supported by this backend"); }
+    virtual bool refine_error_sharded(const double* lhs_x, const double* lhs_y, const double* lhs_z, const double* rhs_x, const double* rhs_y, const double* rhs_z, const double* x_reg,
+                                      double delta, const double* z_reg, double* err_x, double* err_y, double* err_z, double* norm)
+    {
+        (void)lhs_x; (void)lhs_y; (void)lhs_z; (void)rhs_x; (void)rhs_y; (void)rhs_z; (void)x_reg; (void)delta; (void)z_reg; (void)err_x; (void)err_y; (void)err_z; (void)norm;
+        return false;
+    }
+    virtual void sharded_calls(int out[2]) const { out[0] = out[1] = 0; }  // [0] sharded residual evaluations, [1] rows of this rank's share (of n + p + m)
     // pq_kkt_comm_info: transport (0 none, 1 callback, 2 native RCCL), and for the native one what ncclCommCount / ncclCommUserRank / ncclCommCuDevice report
     virtual void comm_info(int out[4]) const { out[0] = 0; out[1] = out[2] = out[3] = -1; }
     virtual void partition_info(int out[8]) const { (void)out; throw std::runtime_error("partition_info: not supported by this backend"); }

@@ -512,6 +512,10 @@ double KKTSystem::get_refine_error(const double* lhs_x, const double* lhs_y, con
 {
     PQ_ZONE("piqp_amd::KKTSystem::get_refine_error");
     const int n = n_, p = p_, m = m_;
+    {   // a stage-partitioned backend evaluates the residual on its own rows only and all-reduces the norm (kkt_solver_base.hpp)
+        double nrm = 0.0;
+        if (kkt_solver->refine_error_sharded(lhs_x, lhs_y, lhs_z, rhs_x, rhs_y, rhs_z, m_x_reg.p, m_delta, m_z_reg.p, err_x, err_y, err_z, &nrm)) return nrm;
+    }
     // mul_condensed_kkt: Px -> work_x ; A x -> work_y, AT y -> work_x2 ; G x -> work_z2, GT z -> work_x3
     kkt_solver->eval_P_x(1.0, lhs_x, work_x.p);
     kkt_solver->eval_A_xn_and_AT_xt(1.0, 1.0, lhs_x, lhs_y, work_y.p, work_x2.p);
@@ -593,6 +597,9 @@ bool KKTSystem::solve(const pq_vars& rhs, pq_vars& lhs)
                 lhs.z_u, lhs.s_l, lhs.s_u);
         LAUNCH1(k_box_recovery, n_x_l, st_, n_x_l, -1.0, m_delta, x_l_idx.p, x_b_scaling.p, lhs.x, m_s_bl.p, m_z_bl_inv.p, rhs.z_bl, rhs.s_bl, lhs.z_bl, lhs.s_bl);
         LAUNCH1(k_box_recovery, n_x_u, st_, n_x_u, 1.0, m_delta, x_u_idx.p, x_b_scaling.p, lhs.x, m_s_bu.p, m_z_bu_inv.p, rhs.z_bu, rhs.s_bu, lhs.z_bu, lhs.s_bu);
+        // the results must be complete when the call returns (the other branch ends with the read-back of its finiteness check): found in round 4 by ranks sharing
+        // one GPU -- a caller that read lhs.z_bu through another stream right away saw it before the last recovery kernel had run, one run in three
+        stream_wait(st_);
     } else {
         // :305 allFinite check (NaN-propagating |.|_inf is finite iff every entry is) + the recoveries, one launch; scal_d was zeroed by
         // k_rhs_bars_fused

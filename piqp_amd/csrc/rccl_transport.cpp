@@ -103,6 +103,11 @@ void all_reduce_sum(Comm* c, double* buf, size_t count, hipStream_t s)
     check(api().AllReduce(buf, buf, count, ncclFloat64, ncclSum, c->c, s), "ncclAllReduce");
 }
 
+void all_reduce_max(Comm* c, double* buf, size_t count, hipStream_t s)
+{
+    check(api().AllReduce(buf, buf, count, ncclFloat64, ncclMax, c->c, s), "ncclAllReduce(max)");
+}
+
 void all_gather(Comm* c, double* buf, size_t count_per_rank, int rank, hipStream_t s)
 {
     check(api().AllGather(buf + (size_t)rank * count_per_rank, buf, count_per_rank, ncclFloat64, c->c, s), "ncclAllGather");

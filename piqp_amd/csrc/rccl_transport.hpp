@@ -21,6 +21,7 @@ Comm* comm_create(const unsigned char id[UNIQUE_ID_BYTES], int rank, int world, 
 void comm_destroy(Comm* c);
 void comm_info(Comm* c, int out[3]);  // what the communicator itself reports: ncclCommCount, ncclCommUserRank, ncclCommCuDevice
 void all_reduce_sum(Comm* c, double* buf, size_t count, hipStream_t s);                 // in place, fp64 sum
+void all_reduce_max(Comm* c, double* buf, size_t count, hipStream_t s);                 // in place, fp64 max (the sharded refinement residual's norm)
 void all_gather(Comm* c, double* buf, size_t count_per_rank, int rank, hipStream_t s);  // in place: this rank's chunk at rank * count_per_rank
 
 }  // namespace rccl

@@ -1302,6 +1302,16 @@ int pq_solver_partition(pq_solver* s, int rank, int world, long long sizes_out[3
     if (!s || !sizes_out || !s->impl->backend()) return fail(PQ_ERR_INVALID, "solver not set up");
     return guarded([&] { s->impl->backend()->partition(rank, world, sizes_out); return (int)PQ_OK; });
 }
+int pq_solver_set_exchange_norm(pq_solver* s, double* buf_norm)
+{
+    if (!s || !s->impl) return fail(PQ_ERR_INVALID, "null handle");
+    return guarded([&] { s->impl->backend()->set_exchange_norm(buf_norm); return (int)PQ_OK; });
+}
+int pq_solver_sharded_calls(pq_solver* s, int out[2])
+{
+    if (!s || !s->impl || !out) return fail(PQ_ERR_INVALID, "null argument");
+    return guarded([&] { s->impl->backend()->sharded_calls(out); return (int)PQ_OK; });
+}
 int pq_solver_native_exchange_calls(pq_solver* s, int out[3])
 {
     if (!s || !out) return fail(PQ_ERR_INVALID, "null argument");

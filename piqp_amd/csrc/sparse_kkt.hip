@@ -101,6 +101,24 @@ __global__ void k_set_diag(int n, int p, int m, const int* __restrict__ diag_pos
 
 // condensed modes (kkt_{eq,ineq,all}_eliminated.hpp update_kkt_*): diagonal of the top-left block += x_reg, of a kept
 // constraint block = -delta / -z_reg; col indexes the columns of K in the caller's order (n, then kept p, then kept m)
+// ... on a list of columns only (stage partition: the columns of the fronts this rank factors -- SURVEY 8(e) row 2, value assembly)
+__global__ void k_set_diag_list(int ncols, const int* __restrict__ cols, int n, int p, const int* __restrict__ diag_pos, const double* __restrict__ Pdiag, const double* __restrict__ x_reg,
+                                double delta, const double* __restrict__ z_reg, double* __restrict__ vals)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ncols) return;
+    const int col = cols[t];
+    double v;
+    if (col < n) v = Pdiag[col] + x_reg[col];
+    else if (col < n + p) v = -delta;
+    else v = -z_reg[col - n - p];
+    vals[diag_pos[col]] = v;
+}
+__global__ void k_norm_to_buf(const unsigned long long* __restrict__ bits, double* __restrict__ buf)  // |err|_inf as ordered bits -> double, NaN -> +inf (it must survive a max)
+{
+    const double v = __longlong_as_double((long long)bits[0]);
+    buf[0] = v != v ? __builtin_huge_val() : v;
+}
 __global__ void k_cond_diag(int n, int np, int nm, const int* __restrict__ diag_pos, const double* __restrict__ x_reg, double delta, const double* __restrict__ z_reg,
                             double* __restrict__ vals)
 {
@@ -2090,7 +2108,11 @@ public:
         PQ_HIP(hipSetDevice(dev_));
         delta_ = delta;
         const int t0 = prof_.begin(0, st_);
-        if (mode_ == 0) {
+        static const bool full_diag = debug_token("no_diag_list") != nullptr;  // debugging aid
+        if (mode_ == 0 && part_on_ && world_ > 1 && need_all_n_ > 0 && !full_diag) {
+            // stage partition: only the diagonal entries of the fronts this rank factors (its own subtrees and the shared top)
+            hipLaunchKernelGGL(k_set_diag_list, g1(need_all_n_), dim3(256), 0, st_, need_all_n_, need_all_.p, n_, p_, diag_pos_.p, ops_.P_diag(), x_reg, delta, z_reg, vals_.p);
+        } else if (mode_ == 0) {
             hipLaunchKernelGGL(k_set_diag, g1(N_), dim3(256), 0, st_, n_, p_, m_, diag_pos_.p, ops_.P_diag(), x_reg, delta, z_reg, vals_.p);
         } else {
             // update_kkt_cost_scalings / _equality_scalings / _inequality_scaling of the mode, in the reference's accumulation order
@@ -2248,6 +2270,27 @@ public:
         for (size_t b = 0; b < bo.size(); ++b) bo[b] = PT_.owner[PT_.boundary[b]];
         upload_vec(b_sn_, PT_.boundary, st_); upload_vec(b_owner_, bo, st_); upload_vec(b_mat_off_, PT_.bmat_off, st_); upload_vec(b_vec_off_, PT_.bvec_off, st_);
         upload_vec(span_lo_d_, PT_.span_lo, st_); upload_vec(span_hi_d_, PT_.span_hi, st_);
+        {   // the rows of the KKT system whose columns this rank eliminates (owner == rank) or every rank does (shared top), in the caller's
+            // numbering, split into the x / y / z blocks -- the rows its part of a solve reads and the diagonal entries its fronts hold (KKT_FULL only)
+            std::vector<int> nx, ny, nz, nall;
+            if (mode_ == 0) {
+                for (int sn = 0; sn + 1 < (int)S_.sn_first.size(); ++sn) {
+                    if (PT_.owner[sn] != rank && PT_.owner[sn] >= 0) continue;
+                    for (int c = S_.sn_first[sn]; c < S_.sn_first[sn + 1]; ++c) {
+                        const int v = S_.P[c];
+                        nall.push_back(v);
+                        if (v < n_) nx.push_back(v);
+                        else if (v < n_ + p_) ny.push_back(v - n_);
+                        else nz.push_back(v - n_ - p_);
+                    }
+                }
+                std::sort(nx.begin(), nx.end()); std::sort(ny.begin(), ny.end()); std::sort(nz.begin(), nz.end()); std::sort(nall.begin(), nall.end());
+            }
+            upload_vec(need_x_, nx, st_); upload_vec(need_y_, ny, st_); upload_vec(need_z_, nz, st_); upload_vec(need_all_, nall, st_);
+            need_x_n_ = (int)nx.size(); need_y_n_ = (int)ny.size(); need_z_n_ = (int)nz.size(); need_all_n_ = (int)nall.size();
+            norm_bits_.alloc(4);
+            sharded_evals_ = 0;
+        }
         PQ_HIP(hipMemsetAsync(rdiag_.p, 0, sizeof(double) * (size_t)N_, st_));
         stream_wait(st_);
         part_on_ = true;
@@ -2262,8 +2305,34 @@ public:
         xfn_ = fn; xuser_ = user; xbuf_factor_ = buf_factor; xbuf_forward_ = buf_forward; xbuf_gather_ = buf_gather;
         transport_ = fn ? Transport::Callback : Transport::None;
     }
+    void set_exchange_norm(double* buf_norm) override
+    {
+        if (!part_on_) throw std::runtime_error("set_exchange_norm: call pq_kkt_partition first");
+        if (transport_ != Transport::Callback) throw std::runtime_error("set_exchange_norm: the callback transport only (the native transport owns its buffer)");
+        xbuf_norm_ = buf_norm;
+    }
+    bool refine_error_sharded(const double* lhs_x, const double* lhs_y, const double* lhs_z, const double* rhs_x, const double* rhs_y, const double* rhs_z, const double* x_reg,
+                              double delta, const double* z_reg, double* err_x, double* err_y, double* err_z, double* norm) override
+    {
+        static const bool off = debug_token("replicated_residual") != nullptr;  // debugging aid: PIQP_AMD_DEBUG=replicated_residual
+        if (off || !part_on_ || world_ < 2 || mode_ != 0 || !xbuf_norm_ || transport_ == Transport::None) return false;
+        PQ_HIP(hipSetDevice(dev_));
+        PQ_HIP(hipMemsetAsync(norm_bits_.p, 0, sizeof(unsigned long long), st_));
+        if (!ops_.residual_rows(need_x_.p, need_x_n_, need_y_.p, need_y_n_, need_z_.p, need_z_n_, lhs_x, lhs_y, lhs_z, rhs_x, rhs_y, rhs_z, x_reg, delta, z_reg, err_x, err_y, err_z,
+                                reinterpret_cast<unsigned long long*>(norm_bits_.p), st_))
+            return false;
+        hipLaunchKernelGGL(k_norm_to_buf, dim3(1), dim3(1), 0, st_, reinterpret_cast<const unsigned long long*>(norm_bits_.p), xbuf_norm_);
+        exchange(3);  // ONE all-reduce(max) per refinement step
+        PQ_HIP(hipMemcpyAsync(norm_h_.p, xbuf_norm_, sizeof(double), hipMemcpyDeviceToHost, st_));
+        stream_wait(st_);
+        *norm = norm_h_.p[0];
+        ++sharded_evals_;
+        return true;
+    }
+    void sharded_calls(int out[2]) const override { out[0] = sharded_evals_; out[1] = need_x_n_ + need_y_n_ + need_z_n_; }
     void drop_transport()
     {
+        xbuf_norm_ = nullptr; own_norm_.release();
         if (comm_) { stream_wait(st_); rccl::comm_destroy(comm_); comm_ = nullptr; }
         own_factor_.release(); own_forward_.release(); own_gather_.release();
         xfn_ = nullptr; xuser_ = nullptr; xbuf_factor_ = xbuf_forward_ = xbuf_gather_ = nullptr;
@@ -2281,6 +2350,7 @@ public:
         own_factor_.zero(st_); own_forward_.zero(st_); own_gather_.zero(st_);
         stream_wait(st_);
         xfn_ = nullptr; xbuf_factor_ = own_factor_.p; xbuf_forward_ = own_forward_.p; xbuf_gather_ = own_gather_.p;
+        own_norm_.alloc(2); own_norm_.zero(st_); stream_wait(st_); xbuf_norm_ = own_norm_.p;
         transport_ = Transport::Native;
     }
     double min_abs_pivot() override
@@ -2558,8 +2628,9 @@ private:
             // native transport: stream-ordered behind the pack kernel, the unpack kernel follows on the same stream
             if (which == 0) rccl::all_reduce_sum(comm_, xbuf_factor_, (size_t)PT_.bmat_off.back() + 1, st_);
             else if (which == 1) rccl::all_reduce_sum(comm_, xbuf_forward_, (size_t)std::max(1, PT_.bvec_off.back()), st_);
+            else if (which == 3) rccl::all_reduce_max(comm_, xbuf_norm_, 1, st_);
             else rccl::all_gather(comm_, xbuf_gather_, (size_t)std::max(1, PT_.max_span), rank_, st_);
-            ++native_calls_[which];
+            if (which < 3) ++native_calls_[which];
             return;
         }
         if (transport_ != Transport::Callback || !xfn_) throw std::runtime_error("partitioned backend used before pq_kkt_set_exchange / pq_kkt_set_comm_rccl");
@@ -3065,6 +3136,12 @@ private:
     bool no_runs_ = debug_token("no_level_runs") != nullptr;  // debugging aid: one substitution launch per level, no merged runs of chain levels
     bool no_fork_ = debug_token("no_fork") != nullptr;  // debugging aid: everything on one stream
     mutable int tree_has_big_ = -1;  // lazily: does the top of the tree hold a front for the dense kernels (or is it too large for one persistent launch)
+    // rows (caller's numbering) of the x / y / z blocks and of the whole KKT system that belong to the fronts this rank factors
+    DBuf<int> need_x_, need_y_, need_z_, need_all_;
+    int need_x_n_ = 0, need_y_n_ = 0, need_z_n_ = 0, need_all_n_ = 0, sharded_evals_ = 0;
+    DBuf<double> norm_bits_, own_norm_;
+    HBuf<double> norm_h_{2};
+    double* xbuf_norm_ = nullptr;
     int ref_mode_ = PQ_REF_MODE;  // arithmetic of the one-workgroup fronts (PQ_REF_MODE: the reference's, term by term; PQ_REF_MODE_BIG where the tree has multi-workgroup fronts)
     bool no_big_ = debug_token("no_big") != nullptr;    // debugging aid: every front through one workgroup's pivot loop (accuracy comparisons)
     int wide_fcap_ = debug_token("no_wide_solve") ? 0 : WIDE_FCAP;  // debugging aid: wide fronts through the per-pivot routines

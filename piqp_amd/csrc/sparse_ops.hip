@@ -136,6 +136,65 @@ __global__ __launch_bounds__(256) void k_recover_duals(int p, int m, const int* 
     }
 }
 
+// ---- refinement residual on listed rows (CscOperators::residual_rows) ----
+__device__ __forceinline__ double col_dot_seq(int j, const int* __restrict__ colptr, const int* __restrict__ rowind, const double* __restrict__ val, const double* __restrict__ x)
+{
+    double s = 0.0;
+    for (int q = colptr[j]; q < colptr[j + 1]; ++q) s += val[q] * x[rowind[q]];  // (the expression of wave_col_dot: same contraction, same order)
+    return s;
+}
+__global__ __launch_bounds__(256) void k_residual_rows(const int* __restrict__ rows_x, int nx, const int* __restrict__ rows_y, int ny, const int* __restrict__ rows_z, int nz,
+                                                       const int* __restrict__ Pp, const int* __restrict__ Pi, const double* __restrict__ Px, const int* __restrict__ ATp,
+                                                       const int* __restrict__ ATi, const double* __restrict__ ATx, const int* __restrict__ Ap, const int* __restrict__ Ai,
+                                                       const double* __restrict__ Ax, const int* __restrict__ GTp, const int* __restrict__ GTi, const double* __restrict__ GTx,
+                                                       const int* __restrict__ Gp, const int* __restrict__ Gi, const double* __restrict__ Gx, const double* __restrict__ lhs_x,
+                                                       const double* __restrict__ lhs_y, const double* __restrict__ lhs_z, const double* __restrict__ rhs_x,
+                                                       const double* __restrict__ rhs_y, const double* __restrict__ rhs_z, const double* __restrict__ x_reg, double delta,
+                                                       const double* __restrict__ z_reg, double* __restrict__ err_x, double* __restrict__ err_y, double* __restrict__ err_z,
+                                                       unsigned long long* __restrict__ absmax_bits)
+{
+    __shared__ double red[4];
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    double e = 0.0;
+    if (t < nx) {
+        const int i = rows_x[t];
+        const double pxv = 1.0 * col_dot_seq(i, Pp, Pi, Px, lhs_x);
+        const double aty = Ap ? 1.0 * col_dot_seq(i, Ap, Ai, Ax, lhs_y) : 0.0;
+        const double gtz = Gp ? 1.0 * col_dot_seq(i, Gp, Gi, Gx, lhs_z) : 0.0;
+        double v = pxv;             // k_err_x
+        v += x_reg[i] * lhs_x[i];
+        v += aty;
+        v += gtz;
+        e = rhs_x[i] - v;
+        err_x[i] = e;
+    } else if (t < nx + ny) {
+        const int j = rows_y[t - nx];
+        double v = 1.0 * col_dot_seq(j, ATp, ATi, ATx, lhs_x);  // k_err_yz with the scalar delta
+        v -= delta * lhs_y[j];
+        e = rhs_y[j] - v;
+        err_y[j] = e;
+    } else if (t < nx + ny + nz) {
+        const int k = rows_z[t - nx - ny];
+        double v = 1.0 * col_dot_seq(k, GTp, GTi, GTx, lhs_x);
+        v -= z_reg[k] * lhs_z[k];
+        e = rhs_z[k] - v;
+        err_z[k] = e;
+    }
+    double a = fabs(e);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double o = __shfl_xor(a, off, 64);
+        a = (a != a || o != o) ? __builtin_nan("") : (a > o ? a : o);
+    }
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double r = red[0];
+        for (int k = 1; k < 4; ++k) r = (r != r || red[k] != red[k]) ? __builtin_nan("") : (red[k] > r ? red[k] : r);
+        atomicMax(absmax_bits, (unsigned long long)__double_as_longlong(r != r ? __builtin_nan("") : r) & 0x7fffffffffffffffull);
+    }
+}
+
 // host-side CSC transpose with a value map: T = M^T, tmap[q_in_T] = q_in_M
 void transpose_with_map(int rows, int cols, const int* Mp, const int* Mi, std::vector<int>& Tp, std::vector<int>& Ti, std::vector<int>& tmap)
 {
@@ -269,6 +328,19 @@ void CscOperators::eval_G_xn_and_GT_xt(double an, double at, const double* xn, c
 {
     spmv<false>(m_, GT_p_, GT_i_, GT_x_, long_GT_, nlong_[3], xn, an, zn, st);
     spmv<false>(n_, G_p_, G_i_, G_x_, long_G_, nlong_[4], xt, at, zt, st);
+}
+bool CscOperators::residual_rows(const int* rows_x, int nx, const int* rows_y, int ny, const int* rows_z, int nz, const double* lhs_x, const double* lhs_y, const double* lhs_z,
+                                 const double* rhs_x, const double* rhs_y, const double* rhs_z, const double* x_reg, double delta, const double* z_reg, double* err_x, double* err_y,
+                                 double* err_z, unsigned long long* absmax_bits, hipStream_t st) const
+{
+    if (has_long_columns()) return false;
+    const int tot = nx + ny + nz;
+    if (tot <= 0) return true;
+    hipLaunchKernelGGL(k_residual_rows, g1(tot), dim3(256), 0, st, rows_x, nx, rows_y, ny, rows_z, nz, Pf_p_.p, Pf_i_.p, Pf_x_.p, AT_p_.p, AT_i_.p, AT_x_.p, p_ > 0 ? A_p_.p : (const int*)nullptr,
+                       A_i_.p, A_x_.p, GT_p_.p, GT_i_.p, GT_x_.p, m_ > 0 ? G_p_.p : (const int*)nullptr, G_i_.p, G_x_.p, lhs_x, lhs_y, lhs_z, rhs_x, rhs_y, rhs_z, x_reg, delta, z_reg,
+                       err_x, err_y, err_z, absmax_bits);
+    PQ_HIP(hipGetLastError());
+    return true;
 }
 void CscOperators::fold_rhs(const double* rhs_x, const double* rhs_y, const double* rhs_z, const double* zinv, double delta_inv, double* out, hipStream_t st, bool with_A,
                             bool with_G) const

@@ -45,6 +45,15 @@ public:
     void recover_duals(const double* x, const double* rhs_y, const double* rhs_z, const double* zinv, double delta_inv, double* lhs_y, double* lhs_z, hipStream_t st,
                        bool with_A = true, bool with_G = true) const;
 
+    // Refinement residual on LISTED rows only (stage partition): err_x[i] = rhs_x[i] - (((P x)_i + x_reg_i x_i) + (A^T y)_i) + (G^T z)_i),
+    // err_y[j] = rhs_y[j] - ((A x)_j - delta y_j), err_z[k] = rhs_z[k] - ((G x)_k - z_reg_k z_k) -- one thread per listed row, the column sums left to right with
+    // the multiply-add of the eval_* kernels and the statements of k_err_x / k_err_yz: bitwise the values the full evaluation leaves in those rows.
+    // |err| of the listed rows is max-combined into absmax_bits[0] (NaN-propagating, like k_absmax).  false: some column is too long for this form.
+    bool residual_rows(const int* rows_x, int nx, const int* rows_y, int ny, const int* rows_z, int nz, const double* lhs_x, const double* lhs_y, const double* lhs_z,
+                       const double* rhs_x, const double* rhs_y, const double* rhs_z, const double* x_reg, double delta, const double* z_reg, double* err_x, double* err_y,
+                       double* err_z, unsigned long long* absmax_bits, hipStream_t st) const;
+    bool has_long_columns() const { return nlong_[0] + nlong_[1] + nlong_[2] + nlong_[3] + nlong_[4] > 0; }
+
     int n() const { return n_; }
     int p() const { return p_; }
     int m() const { return m_; }

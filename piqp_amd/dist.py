@@ -130,7 +130,8 @@ class StagePartition:
         self.buf_factor = torch.zeros(self.sizes[0], dtype=torch.float64, device=dev)
         self.buf_forward = torch.zeros(self.sizes[1], dtype=torch.float64, device=dev)
         self.buf_gather = torch.zeros(self.world * self.sizes[2], dtype=torch.float64, device=dev)
-        self.calls = [0, 0, 0]
+        self.buf_norm = torch.zeros(2, dtype=torch.float64, device=dev)  # which = 3: ||err||_inf of the sharded refinement residual
+        self.calls = [0, 0, 0, 0]
         # native = True: the library's own RCCL transport (pq_kkt_set_comm_rccl: collectives enqueued on the handle's stream, no callback).
         # Default: native whenever the process group runs on RCCL ("nccl"), i.e. one GPU per rank; the callback path below remains for gloo
         # (several ranks sharing one GPU in the CPU-rendezvous tests) and as the reference implementation of the protocol.
@@ -158,6 +159,9 @@ class StagePartition:
             _lib.check(setc(h, idb, self.rank, self.world), "set_comm_rccl")
         else:
             _lib.check(setx(h, self._cb, None, self.buf_factor.data_ptr(), self.buf_forward.data_ptr(), self.buf_gather.data_ptr()), "set_exchange")
+            if self.world > 1 and os.environ.get("PIQP_AMD_REPLICATED_RESIDUAL") is None:
+                # the sharded refinement residual (KKT_FULL backends; the others ignore the buffer): one all-reduce(MAX) per refinement step
+                (L.pq_solver_set_exchange_norm if is_solver else L.pq_kkt_set_exchange_norm)(h, self.buf_norm.data_ptr())
         torch.cuda.synchronize(dev)
         self.dev = dev
 
@@ -169,7 +173,15 @@ class StagePartition:
             if self.world == 1 and not (dist.is_available() and dist.is_initialized()):
                 return 0
             staged = self.backend != "nccl"
-            if which in (0, 1):
+            if which == 3:
+                t = self.buf_norm
+                if staged:
+                    c = t.cpu()
+                    dist.all_reduce(c, op=dist.ReduceOp.MAX, group=self.group)
+                    t.copy_(c)
+                else:
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+            elif which in (0, 1):
                 t = self.buf_factor if which == 0 else self.buf_forward
                 if staged:
                     c = t.cpu()
@@ -196,7 +208,7 @@ class StagePartition:
     def exchange_calls(self):
         """collectives performed so far, [which = 0, 1, 2]: counted by the callback, or read from the library for the native transport"""
         if not self.native:
-            return list(self.calls)
+            return list(self.calls[:3])
         import ctypes as C
 
         from . import _lib
@@ -207,6 +219,19 @@ class StagePartition:
         out = (C.c_int * 3)()
         _lib.check((L.pq_solver_native_exchange_calls if is_solver else L.pq_kkt_native_exchange_calls)(h, out), "native_exchange_calls")
         return [int(v) for v in out]
+
+    def sharded_calls(self):
+        """[sharded refinement-residual evaluations so far, rows of the KKT system in this rank's share] (pq_kkt_sharded_calls)"""
+        import ctypes as C
+
+        from . import _lib
+        L = _lib.load()
+        obj = self._obj
+        is_solver = hasattr(obj, "solve") and hasattr(obj, "setup")
+        h = obj.h if is_solver else (obj.backend().h if hasattr(obj, "backend") else obj.h)
+        out = (C.c_int * 2)()
+        _lib.check((L.pq_solver_sharded_calls if is_solver else L.pq_kkt_sharded_calls)(h, C.byref(out)), "sharded_calls")
+        return [int(out[0]), int(out[1])]
 
     def comm_info(self):
         """what ran the collectives, as seen from the inside (the figures a multi-GPU bench line carries so that "RCCL saw N ranks" can be checked):

@@ -105,6 +105,27 @@ def test_partitioned_equals_single_gpu(backend, problem, nranks):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("problem,nranks", [("chain", 2), ("chain", 4), ("c3", 2)])
+def test_sharded_refinement_residual_and_assembly_equal_the_replicated_ones(problem, nranks):
+    """SURVEY 8(e) row 2 (round 4): with iterative refinement on, every rank of a stage-partitioned sparse_ldlt (KKT_FULL) backend evaluates the refinement residual
+    on its own rows only (its subtrees + the shared top) and the norm crosses the ranks in one all-reduce(max) per refinement step; the per-factorisation value
+    assembly touches only the diagonal entries of the fronts it factors.  The partitioned solve -- KKTSystem::solve with its refinement loop, and the whole
+    interior-point solve with refinement always on -- must be bitwise the single-GPU one (which evaluates everything on every row), on every rank."""
+    out = _run_ranks(nranks, ["--stages", "800", "--steps", "2", "--warmup", "1", "--backend", "ldlt", "--problem", problem, "--full-solve", "--refine"], 29690 + nranks)
+    assert out["world"] == nranks
+    assert out["bitwise_equal_all_ranks"] and out["max_abs_diff"] == 0.0
+    assert out["rel_kkt_residual"] <= 1e-10
+    sr = out["sharded_residual"]
+    assert all(e >= 2 for e in sr["evaluations_per_rank"]), sr          # the residual really was evaluated in its sharded form ...
+    assert sr["norm_all_reduces"] >= 2                                     # ... with its all-reduce(max)
+    assert max(sr["rows_per_rank"]) < 0.75 * sr["rows_total"], sr         # ... on a share of the rows (own subtrees + shared top)
+    assert sum(sr["rows_per_rank"]) >= sr["rows_total"]                   # every row is somebody's
+    assert out["refine_steps"] == out["single_gpu_refine_steps"]
+    fs = out["full_solve"]
+    assert fs["status"] == 1 and fs["identical_on_all_ranks"] and fs["x_equal_to_single_gpu"] and fs["iter"] == fs["single_gpu"]["iter"]
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("native", [True, False])
 def test_rccl_transport_with_a_one_rank_group(native):
     """all a 1-GPU box can say about the RCCL transport: a one-rank "nccl" process group with the exchanges forced on

@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--transport", default="auto", choices=["auto", "callback", "native"],
                     help="callback: torch.distributed's RCCL collectives on the registered device buffers (default); native: the library's own communicator")
     ap.add_argument("--full-solve", action="store_true")
+    ap.add_argument("--refine", action="store_true", help="iterative refinement on in every KKTSystem::solve / the whole solve (exercises the sharded refinement residual, SURVEY 8(e) row 2)")
     ap.add_argument("--no-reference", action="store_true", help="skip the unpartitioned run on every rank (bench mode)")
     ap.add_argument("--wait-stdin", action="store_true", help="block on stdin before touching the GPU (spawned by bench.py, piqp_amd.dist.spawn_waiting)")
     args = ap.parse_args()
@@ -67,34 +68,51 @@ def main():
     out = {"workload": (f"multistage chain n_x={args.nx} n_u={args.nu} stages={args.stages}" if args.problem == "chain" else ("C3 sparse QP" if args.problem == "c3" else "Maros-Meszaros CONT-101")) + f": n={n} p={p} m={m}", "backend": args.backend, "world": world,
            "transport": "gloo (host-staged, ranks share one GPU)" if shared_gpu else ("rccl" if (dist.is_available() and dist.is_initialized()) else "none")}
 
+    refine = bool(args.refine)
+
     def run_steps(k, steps):
         for i in range(steps):
-            assert k.update_scalings_and_factor(False, 1e-6, 1e-4, state)
+            assert k.update_scalings_and_factor(refine, 1e-6, 1e-4, state)
             k.solve(rhs[0]); k.solve(rhs[1])
         k.synchronize()
 
     ref = None
     if not args.no_reference:
         k0 = hip.KKTSystem(d, hip.default_settings(kkt_solver=ks), device=dev_index)
-        assert k0.update_scalings_and_factor(False, 1e-6, 1e-4, state)
+        assert k0.update_scalings_and_factor(refine, 1e-6, 1e-4, state)
         _, ref = k0.solve(rhs[0])
+        out["single_gpu_refine_steps"] = k0.last_solve_stats()
         ref = {k: v.clone() for k, v in ref.items()}
         run_steps(k0, args.warmup)
         t0 = time.perf_counter(); run_steps(k0, args.steps); t_single = (time.perf_counter() - t0) / args.steps
         out["single_gpu_ms_per_step"] = t_single * 1e3
+        # one evaluation of the refinement residual (kkt_system.hpp:507-536: five mat-vecs, three error kernels, the norm) on every row, as a single GPU does it
+        k0.condensed_residual(); k0.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            k0.condensed_residual()
+        k0.synchronize()
+        out["residual_eval_ms_single_gpu"] = (time.perf_counter() - t0) / 20 * 1e3
         del k0
 
     k1 = hip.KKTSystem(d, hip.default_settings(kkt_solver=ks), device=dev_index)
     sp = pd.StagePartition(k1, native=(args.transport == "native") if args.transport != "auto" else None)
     info = sp.info()
-    assert k1.update_scalings_and_factor(False, 1e-6, 1e-4, state)
+    assert k1.update_scalings_and_factor(refine, 1e-6, 1e-4, state)
     _, got = k1.solve(rhs[0])
+    out["refine_steps"] = k1.last_solve_stats()
     if sp.error is not None:
         raise sp.error
     if ref is not None:
         same = all(torch.equal(got[k], ref[k]) for k in ("x", "y", "z_l", "z_u", "z_bl", "z_bu", "s_l", "s_u", "s_bl", "s_bu"))
         err = max(float((got[k] - ref[k]).abs().max()) if got[k].numel() else 0.0 for k in ref)
         out["bitwise_equal_to_single_gpu"] = bool(same); out["max_abs_diff"] = err
+        if not same and os.environ.get("PIQP_AMD_DIST_DIAG"):
+            for k in ref:
+                if got[k].numel() and not torch.equal(got[k], ref[k]):
+                    dd = (got[k] - ref[k]).abs()
+                    idx = torch.nonzero(dd > 0).flatten()
+                    print(f"[rank {rank}] {k}: {idx.numel()} of {dd.numel()} entries differ, first {idx[:6].tolist()} last {idx[-3:].tolist()} max {float(dd.max()):.3e}; span {info['span']}", file=sys.stderr, flush=True)
     res, nrm = k1.condensed_residual()
     out["rel_kkt_residual"] = res / nrm
     run_steps(k1, args.warmup)
@@ -105,7 +123,20 @@ def main():
     el = pd.max_over_ranks(el)
     out["ms_per_step"] = el / args.steps * 1e3
     out["steps_per_s"] = args.steps / el
+    # ... and on this rank's rows only + the all-reduce(max) of the norm (KKT_FULL backends, otherwise the same as above)
+    k1.condensed_residual(); k1.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        k1.condensed_residual()
+    k1.synchronize()
+    out["residual_eval_ms_partitioned"] = pd.max_over_ranks((time.perf_counter() - t0) / 20) * 1e3
     out["exchange_calls"] = sp.exchange_calls()
+    sc = sp.sharded_calls()
+    shr = pd.gather_stats([[float(sc[0]), float(sc[1])]])
+    out["sharded_residual"] = {"evaluations_per_rank": [int(r[0]) for r in shr], "rows_per_rank": [int(r[1]) for r in shr], "rows_total": n + p + m,
+                               "norm_all_reduces": int(sp.calls[3]) if not sp.native else None}
     out["native_rccl"] = bool(sp.native)
     # self-proving multi-GPU record: who ran the collectives and what they saw, per rank
     ci = sp.comm_info()
@@ -130,6 +161,7 @@ def main():
     if args.full_solve:
         s0 = hip.SparseSolver(device=dev_index)
         s0.settings.kkt_solver = ks
+        s0.settings.iterative_refinement_always_enabled = bool(refine)
         assert s0.setup(*a)
         sp2 = pd.StagePartition(s0, native=(args.transport == "native") if args.transport != "auto" else None)
         t0 = time.perf_counter(); st = s0.solve(); tsol = time.perf_counter() - t0
@@ -141,7 +173,7 @@ def main():
         xs = pd.gather_stats([[float(np.sum(x)), float(np.abs(x).max()), float(s0.info.iter)]])
         out["full_solve"]["identical_on_all_ranks"] = all(r == xs[0] for r in xs)
         if not args.no_reference:
-            s1 = hip.SparseSolver(device=dev_index); s1.settings.kkt_solver = ks
+            s1 = hip.SparseSolver(device=dev_index); s1.settings.kkt_solver = ks; s1.settings.iterative_refinement_always_enabled = bool(refine)
             assert s1.setup(*a)
             t0 = time.perf_counter(); st1 = s1.solve(); t1 = time.perf_counter() - t0
             out["full_solve"]["single_gpu"] = {"status": int(st1), "iter": int(s1.info.iter), "solve_ms": t1 * 1e3}
