@@ -596,7 +596,39 @@ static void order_and_analyse(Symbolic& S)
     S.ordering = "amd";
     S.fill_perm = perm_amd;
     // ~12 us per level (one launch per level) against ~1e11 flop/s and ~1e12 B/s on small fronts
-    auto cost = [](const Symbolic& X) { return 12e-6 * (X.top_nlevels + 1) + X.flops / 1e11 + 8.0 * (double)X.front_doubles / 1e12; };
+    // round 4: fronts of >= 192 rows and >= 32 pivots run on the matrix cores (a few TFLOP/s), and a level that holds one costs a round of ~6 launches
+    // (measured on the wide C3 variant: 230 such levels with 1.1e10 padded flops 45 ms, 17 levels with 3.9e10 flops 11 ms)
+    int big_levels_max = 0;
+    auto cost_r4 = [&big_levels_max](const Symbolic& X) {
+        double t = 12e-6, small_fl = 0.0, big_fl = 0.0;
+        int nbig = 0;
+        for (int l = 0; l < X.top_nlevels; ++l) {
+            bool big = false;
+            for (int q = X.top_level_ptr[l]; q < X.top_level_ptr[l + 1] && !big; ++q) {
+                const int s2 = X.top_level_sn[q];
+                big = X.front_rows_ptr[s2 + 1] - X.front_rows_ptr[s2] >= 192 && X.sn_first[s2 + 1] - X.sn_first[s2] >= 32;
+            }
+            t += big ? 150e-6 : 12e-6;
+            nbig += big;
+        }
+        for (int s2 = 0; s2 < X.nsuper; ++s2) {
+            const double f = X.front_rows_ptr[s2 + 1] - X.front_rows_ptr[s2], w = X.sn_first[s2 + 1] - X.sn_first[s2];
+            const double fl = w * f * f - w * w * f + w * w * w / 3.0;
+            (f >= 192 && w >= 32 ? big_fl : small_fl) += fl;
+        }
+        big_levels_max = std::max(big_levels_max, nbig);
+        if (debug_token("tree_profile")) std::fprintf(stderr, "cost parts: levels %.2f ms, small-front flops %.3g, big-front flops %.3g, front doubles %.3g\n", 1e3 * t, small_fl, big_fl, (double)X.front_doubles);
+        return t + small_fl / 2.5e11 + big_fl / 5e12 + 8.0 * (double)X.front_doubles / 1e12;
+    };
+    auto cost_r3 = [](const Symbolic& X) { return 12e-6 * (X.top_nlevels + 1) + X.flops / 1e11 + 8.0 * (double)X.front_doubles / 1e12; };
+    // the round-3 model stands where it was calibrated (trees with a few levels of big fronts: every frozen fixture keeps its ordering)
+    const double c4s = cost_r4(S), c4t = cost_r4(T);
+    auto cost = [&](const Symbolic& X) { return big_levels_max > 64 ? (&X == &S ? c4s : c4t) : cost_r3(X); };
+    if (debug_token("tree_profile"))
+        std::fprintf(stderr, "ordering: amd levels %d (top %d) flops %.3g front doubles %.3g cost %.2f ms (round-3 model %.2f) | nd levels %d (top %d) flops %.3g front doubles %.3g cost %.2f ms (%.2f) | choice %s (round-3 model: %s)\n", S.nlevels, S.top_nlevels,
+                     S.flops, (double)S.front_doubles, 1e3 * cost(S), 1e3 * cost_r3(S), T.nlevels, T.top_nlevels, T.flops, (double)T.front_doubles, 1e3 * cost(T), 1e3 * cost_r3(T),
+                     cost(T) < 0.7 * cost(S) ? "nd" : "amd", cost_r3(T) < 0.7 * cost_r3(S) ? "nd" : "amd");
+    (void)cost_r3;
     if (cost(T) < 0.7 * cost(S)) S = std::move(T);
 }
 
@@ -818,6 +850,16 @@ static void analyse_with_order(Symbolic& S, const IVec& perm0, const IVec* force
     // chain walks follow the spine, then the merged leaves, then the parent -- and the analysis is redone for that order.
     if (!forced_first) {
         int WMAX = 32, FMAX = 64;
+        // Spines of WIDE fronts (band-like problems under AMD: ~1700 supernodes of ~20 pivots and ~370 rows one above the other on the wide C3 variant, every
+        // one a tree level = a round of launches of ~45 us; under nested dissection thousands of 2-5 pivot supernodes with 700-row fronts): a supernode
+        // takes in the child with the largest subtree while the merged pivot block stays within big_w columns and the padding (the child's columns grow to
+        // the merged front) within big_z percent of the merged panel.  The padded panel runs on the matrix cores; a level costs the same launches whatever
+        // its width.  Only fronts of 192 rows or more: the trees of the small fixtures, and with them their arithmetic, are untouched.
+        int big_w = 256, big_z = 40;
+        if (const char* e = debug_token("big_relax_w")) big_w = std::atoi(e);  // experiments: PIQP_AMD_DEBUG=big_relax_w=<pivots>,big_relax_z=<percent>
+        if (const char* e = debug_token("big_relax_z")) big_z = std::atoi(e);
+        std::vector<long long> zpad(ns, 0);
+        IVec feff(ns, 0);
         IVec weff(ns), live_children(ns, 0), merged_into(ns, -1), sub_cols(ns, 0);
         for (int s2 = 0; s2 < ns; ++s2) { weff[s2] = S.sn_first[s2 + 1] - S.sn_first[s2]; live_children[s2] = S.child_ptr[s2 + 1] - S.child_ptr[s2]; }
         long long nmerged = 0;
@@ -830,10 +872,9 @@ static void analyse_with_order(Symbolic& S, const IVec& perm0, const IVec* force
                 const int c = S.child[q];
                 if (live_children[c] == 0 && weff[c] <= 4) cand.push_back({weff[c], c});
             }
-            if (cand.empty()) continue;
-            std::sort(cand.begin(), cand.end());
             const int last = S.sn_first[p2 + 1] - 1;
             const int fp = (S.sn_first[p2 + 1] - S.sn_first[p2]) + cc[last];  // front of p2 before any merge
+            std::sort(cand.begin(), cand.end());
             for (const auto& cw : cand) {
                 const int wd = weff[p2] + cw.first;
                 const int fr = wd + cc[last];
@@ -844,14 +885,38 @@ static void analyse_with_order(Symbolic& S, const IVec& perm0, const IVec* force
                 live_children[p2]--;
                 ++nmerged;
             }
+            if (big_w > 0) {
+                int best = -1;
+                for (int q = S.child_ptr[p2]; q < S.child_ptr[p2 + 1]; ++q) {
+                    const int c = S.child[q];
+                    if (merged_into[c] < 0 && (best < 0 || sub_cols[c] >= sub_cols[best])) best = c;
+                }
+                if (best >= 0) {
+                    const int wd = weff[p2] + weff[best];
+                    const int fr = wd + cc[last];
+                    if (fr >= 192 && wd <= big_w) {
+                        const long long z = zpad[best] + zpad[p2] + (long long)weff[best] * (fr - feff[best]);
+                        if (z * 100 <= (long long)wd * fr * big_z) {
+                            merged_into[best] = p2;
+                            weff[p2] = wd;
+                            zpad[p2] = z;
+                            live_children[p2] += live_children[best] - 1;
+                            ++nmerged;
+                        }
+                    }
+                }
+            }
+            feff[p2] = weff[p2] + cc[last];
         }
         if (nmerged > 0) {
             // new elimination order: iterative DFS over the supernode tree
             std::vector<IVec> kids(ns), leaves(ns);
+            IVec group(ns);  // the supernode whose pivot block s2's columns end up in (parents have larger numbers: resolved top down)
+            for (int s2 = ns - 1; s2 >= 0; --s2) group[s2] = merged_into[s2] < 0 ? s2 : group[merged_into[s2]];
             for (int s2 = 0; s2 < ns; ++s2) {
                 const int ps = S.sn_parent[s2];
                 if (ps < 0) continue;
-                if (merged_into[s2] == ps) leaves[ps].push_back(s2); else kids[ps].push_back(s2);
+                if (merged_into[s2] == ps) leaves[ps].push_back(s2); else kids[group[ps]].push_back(s2);  // the live children of a merged member hang under its group
             }
             for (int s2 = 0; s2 < ns; ++s2) {
                 if (kids[s2].size() > 1) {  // largest subtree last (ties: keep the original order)
@@ -923,6 +988,19 @@ static void analyse_with_order(Symbolic& S, const IVec& perm0, const IVec* force
         maxlev = std::max(maxlev, level[s]);
     }
     S.nlevels = ns ? maxlev + 1 : 0;
+    if (debug_token("tree_profile")) {  // debugging aid: fronts per level band, their pivots and orders
+        std::vector<long long> cnt(S.nlevels, 0), wsum(S.nlevels, 0), fmaxl(S.nlevels, 0), fsum(S.nlevels, 0);
+        for (int s = 0; s < ns; ++s) {
+            const int l = level[s], w = S.sn_first[s + 1] - S.sn_first[s], f = S.front_rows_ptr[s + 1] - S.front_rows_ptr[s];
+            cnt[l]++; wsum[l] += w; fsum[l] += f; fmaxl[l] = std::max<long long>(fmaxl[l], f);
+        }
+        const int step = std::max(1, S.nlevels / 40);
+        for (int l = 0; l < S.nlevels; l += step) {
+            long long c = 0, w = 0, f = 0, fm = 0;
+            for (int q = l; q < std::min(S.nlevels, l + step); ++q) { c += cnt[q]; w += wsum[q]; f += fsum[q]; fm = std::max(fm, fmaxl[q]); }
+            std::fprintf(stderr, "levels %5d..%5d: fronts %7lld  mean pivots %6.2f  mean order %7.1f  max order %5lld\n", l, std::min(S.nlevels, l + step) - 1, c, (double)w / c, (double)f / c, fm);
+        }
+    }
     S.level_ptr.assign(S.nlevels + 1, 0);
     for (int s = 0; s < ns; ++s) S.level_ptr[level[s] + 1]++;
     for (int l = 0; l < S.nlevels; ++l) S.level_ptr[l + 1] += S.level_ptr[l];
