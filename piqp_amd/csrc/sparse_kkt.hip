@@ -33,7 +33,11 @@ namespace {
 // Fronts that go through the dense multi-workgroup MFMA kernels (all such fronts of a tree level together: ~80 us per level and panel whatever
 // their number) instead of one workgroup's pivot loop (1.5 - 2.5 us per pivot).  Fronts under 96 rows never do: C3 / C5-type trees (fronts <= 92
 // rows) keep their persistent top launch.
-__host__ __device__ inline bool big_front(int f, int w) { return f >= 192 && w >= 32; }
+// (round 4: also the wide fronts of fewer pivots whose panel does not fit one workgroup's LDS -- left to one workgroup they are factored in HBM, and their
+// Schur complement, f^2 w flops, by that one workgroup: 9.8 ms per level on the C3 variant with 1500-variable windows, fronts of 1000-4000 rows)
+// and every front of 768 rows or more: whatever its pivots, one workgroup zero-fills and extend-adds its f x f square -- 8.4 ms per level there)
+// (an accumulator supernode -- w = 0, the extend-add alone -- included)
+__host__ __device__ inline bool big_front(int f, int w) { return f >= 192 && (w >= 32 || (long long)f * w > 12288 || f >= 768); }
 constexpr int SUB_SOLVE_THREADS = 64;   // substitution inside a subtree is a chain of short vector operations: one wave per subtree
 constexpr int SUBTREE_LDS_BYTES = 150 * 1024;  // two fronts of the LDS-native subtree walker
 constexpr int SUB_THREADS = 256;    // small subtrees: fronts reach ~100 rows near the subtree root, so a full workgroup (64 threads measured 2x slower)
@@ -1133,6 +1137,13 @@ __global__ __launch_bounds__(SUB_SOLVE_THREADS) void k_subtree_bwd(FrontMeta M, 
 // sweep also keeps the per-entry operation order of front_fwd.
 constexpr int WIDE_NT = 512, WIDE_B = 16;
 constexpr int WIDE_FCAP = 7000;  // rows of a front this path keeps in LDS (56 KB); wider ones take front_fwd / front_bwd
+// HUGE fronts (round 4; the C3 variant with 1500-variable windows has a chain of ~150 fronts of 3000-4000 rows and 70-470 pivots): one workgroup streams the
+// f x w panel of such a front at ~15 GB/s, 540 us per front and sweep.  Their rows below the pivot block are therefore taken off the front's workgroup:
+// forward, the front's workgroup solves the w x w pivot block only and k_front_fwd_rows (one wave per 64 rows, any number of workgroups) applies the
+// pivots to the update rows; backward, k_front_bwd_cols forms the column sums over the update rows in chunks of HUGE_ROWS rows (partial sums, added in
+// chunk order by the front's workgroup) before the pivot block is solved.  The forward arithmetic is the one-workgroup kernel's, entry by entry.
+constexpr int HUGE_F = 1024, HUGE_ROWS = 256;
+__host__ __device__ inline bool huge_front(int f, int w) { return f >= HUGE_F && w > 0 && f - w >= HUGE_ROWS; }
 constexpr int WIDE_BCH = 12;     // backward: 64-row chunks of a column held in registers (768 rows below the block; further rows are loaded in line)
 
 __device__ __forceinline__ double wide_bcast(double v, int src)
@@ -1194,6 +1205,7 @@ __device__ __forceinline__ void front_fwd_wide_body(const FrontMeta& M, const do
     if (f > fcap) { front_fwd(M, fronts, s, x, fvec); return; }
     const double* __restrict__ F = fronts + me.front_off;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int flim = huge_front(f, w) ? w : f;  // rows this workgroup applies the pivots to (a huge front: the pivot block only, see k_front_fwd_rows)
     for (int i = tid; i < f; i += WIDE_NT) vs[i] = (i < w) ? x[first + i] : 0.0;
     __syncthreads();
     for (int ci = me.child_lo; ci < me.child_hi; ++ci) {
@@ -1224,18 +1236,18 @@ __device__ __forceinline__ void front_fwd_wide_body(const FrontMeta& M, const do
         const int nbk = FULL ? WIDE_B : min(WIDE_B, w - kb);
         const int i0 = kb + nbk + tid, i1 = i0 + WIDE_NT;
         const int wbase0 = i0 - lane, wbase1 = i1 - lane;  // first row of this wave's 64 rows: a wave entirely below the front loads nothing (uniform branch)
-        if (wbase0 < f) {
-            const bool ok0 = i0 < f;
-            const double* p0 = F + (ok0 ? i0 : f - 1) + (long long)kb * f;
+        if (wbase0 < flim) {
+            const bool ok0 = i0 < flim;
+            const double* p0 = F + (ok0 ? i0 : flim - 1) + (long long)kb * f;
 #pragma unroll
             for (int k = 0; k < WIDE_B; ++k) { o.Lr0[k] = *p0; p0 += (FULL || k + 1 < nbk) ? f : 0; }  // rows below the front are never stored, columns beyond nbk meet y = 0
         } else {
 #pragma unroll
             for (int k = 0; k < WIDE_B; ++k) o.Lr0[k] = 0.0;
         }
-        if (wbase1 < f) {
-            const bool ok1 = i1 < f;
-            const double* p1 = F + (ok1 ? i1 : f - 1) + (long long)kb * f;
+        if (wbase1 < flim) {
+            const bool ok1 = i1 < flim;
+            const double* p1 = F + (ok1 ? i1 : flim - 1) + (long long)kb * f;
 #pragma unroll
             for (int k = 0; k < WIDE_B; ++k) { o.Lr1[k] = *p1; p1 += (FULL || k + 1 < nbk) ? f : 0; }
         } else {
@@ -1264,19 +1276,19 @@ __device__ __forceinline__ void front_fwd_wide_body(const FrontMeta& M, const do
 #pragma unroll
         for (int k = 0; k < WIDE_B; ++k) { const double t = vs[kb + min(k, nbk - 1)]; y[k] = k < nbk ? t : 0.0; }
         const int i0 = kb + nbk + tid, i1 = i0 + WIDE_NT;
-        if (i0 < f) {
+        if (i0 < flim) {
             double vi = vs[i0];
 #pragma unroll
             for (int k = 0; k < WIDE_B; ++k) vi = __builtin_fma(-o.Lr0[k], y[k], vi);
             vs[i0] = vi;
         }
-        if (i1 < f) {
+        if (i1 < flim) {
             double vi = vs[i1];
 #pragma unroll
             for (int k = 0; k < WIDE_B; ++k) vi = __builtin_fma(-o.Lr1[k], y[k], vi);
             vs[i1] = vi;
         }
-        for (int i2 = i1 + WIDE_NT; i2 < f; i2 += WIDE_NT) {
+        for (int i2 = i1 + WIDE_NT; i2 < flim; i2 += WIDE_NT) {
             double vi = vs[i2];
             for (int k = 0; k < nbk; ++k) vi = __builtin_fma(-F[i2 + (long long)(kb + k) * f], y[k], vi);
             vs[i2] = vi;
@@ -1309,28 +1321,103 @@ __global__ __launch_bounds__(WIDE_NT) void k_front_fwd_wide(FrontMeta M, const d
     front_fwd_wide_body(M, fronts, list, x, fvec, fcap, (int)blockIdx.x);
 }
 
+// update rows of the huge fronts of a level: v[r] -= sum_k L[r, k] y[k], k ascending in one fma chain (the order of the one-workgroup kernel); one wave per 64 rows
+__global__ __launch_bounds__(64) void k_front_fwd_rows(FrontMeta M, const double* __restrict__ fronts, const int* __restrict__ list, double* __restrict__ fvec)
+{
+    extern __shared__ __attribute__((aligned(16))) double ys[];
+    const SnRec me = M.sn[list[blockIdx.y]];
+    const int w = me.w, f = me.f;
+    const int r0 = w + (int)blockIdx.x * 64;
+    if (r0 >= f) return;
+    double* __restrict__ v = fvec + me.rows_ptr;
+    const double* __restrict__ F = fronts + me.front_off;
+    for (int k = threadIdx.x; k < w; k += 64) ys[k] = v[k];
+    __syncthreads();
+    const int r = r0 + (int)threadIdx.x;
+    const double* __restrict__ pr = F + min(r, f - 1);
+    double vi = r < f ? v[r] : 0.0;
+    int k = 0;
+    for (; k + 8 <= w; k += 8) {
+        double l[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) l[q] = pr[(long long)(k + q) * f];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) vi = __builtin_fma(-l[q], ys[k + q], vi);
+    }
+    for (; k < w; ++k) vi = __builtin_fma(-pr[(long long)k * f], ys[k], vi);
+    if (r < f) v[r] = vi;
+}
+// column sums of the huge fronts of a level over their update rows, HUGE_ROWS rows per workgroup: part[hoff[s] + chunk * w + k] = sum_{i in chunk} L[i, k] x[rows[i]]
+__global__ __launch_bounds__(HUGE_ROWS) void k_front_bwd_cols(FrontMeta M, const double* __restrict__ fronts, const int* __restrict__ list, const double* __restrict__ x,
+                                                              const int* __restrict__ hoff, double* __restrict__ part)
+{
+    __shared__ double red[HUGE_ROWS / 64][16];
+    const int s = list[blockIdx.y];
+    const SnRec me = M.sn[s];
+    const int w = me.w, f = me.f;
+    const int r0 = w + (int)blockIdx.x * HUGE_ROWS;
+    if (r0 >= f) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = r0 + tid;
+    const double xi = i < f ? x[M.front_rows[me.rows_ptr + i]] : 0.0;  // rows below the front meet x = 0
+    const double* __restrict__ pr = fronts + me.front_off + min(i, f - 1);
+    double* __restrict__ out = part + hoff[s] + (long long)blockIdx.x * w;
+    for (int k = 0; k < w; k += 16) {
+        double a[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) a[q] = pr[(long long)min(k + q, w - 1) * f] * xi;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) a[q] = wide_wave_sum(a[q]);
+        if (lane == 0) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) red[wave][q] = a[q];
+        }
+        __syncthreads();
+        if (tid < 16 && k + tid < w) {
+            double t = red[0][tid];
+#pragma unroll
+            for (int u = 1; u < HUGE_ROWS / 64; ++u) t += red[u][tid];
+            out[k + tid] = t;
+        }
+        __syncthreads();
+    }
+}
+
 constexpr int WIDE_CPW = WIDE_B / (WIDE_NT / 64);  // backward: columns per wave
 struct WideBwdOps { double Lt[WIDE_B], col[WIDE_CPW][WIDE_BCH]; };  // triangle column (wave 0, lane = column), this wave's columns below the block
 
 __device__ __forceinline__ void front_bwd_wide_body(const FrontMeta& M, const double* __restrict__ fronts, const int* __restrict__ list, double* __restrict__ x,
-                                                    double* __restrict__ fvec, int fcap, const int bid)
+                                                    double* __restrict__ fvec, int fcap, const int bid, const int* __restrict__ hoff, const double* __restrict__ hpart)
 {
     extern __shared__ __attribute__((aligned(16))) double vs[];
     const int s = list[bid];
     const SnRec me = M.sn[s];
-    const int first = me.first, w = me.w, f = me.f;
-    if (f > fcap) { front_bwd(M, fronts, s, x, fvec); return; }
+    const int first = me.first, w = me.w;
+    if (me.f > fcap) { front_bwd(M, fronts, s, x, fvec); return; }
     const double* __restrict__ F = fronts + me.front_off;
     const int* __restrict__ rows = M.front_rows + me.rows_ptr;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool huge = huge_front(me.f, w) && hoff != nullptr;
+    const long long ldf = me.f;       // column stride of the front
+    const int f = huge ? w : me.f;    // rows this workgroup sums over (a huge front: the pivot block only, the update rows arrive as partial sums of k_front_bwd_cols)
     double* ss = vs + ((f + 1) & ~1);  // column sums of the current block
-    for (int i = tid; i < f; i += WIDE_NT) vs[i] = x[rows[i]];
+    for (int i = tid; i < f; i += WIDE_NT) {
+        double t = x[rows[i]];
+        if (huge) {
+            const double* pp = hpart + hoff[s] + i;
+            const int nch = (me.f - w + HUGE_ROWS - 1) / HUGE_ROWS;
+            double ps = pp[0];
+            for (int c = 1; c < nch; ++c) ps += pp[(long long)c * w];
+            t -= ps;
+        }
+        vs[i] = t;
+    }
     __syncthreads();
     auto prefetch_tri = [&](auto full_tag, WideBwdOps& o, int kb) {
         constexpr bool FULL = decltype(full_tag)::value;  // (see k_front_fwd_wide)
         const int nbk = FULL ? WIDE_B : min(WIDE_B, w - kb);
         if (wave == 0) {
-            const double* col = F + kb + (long long)(kb + min(lane, nbk - 1)) * f;
+            const double* col = F + kb + (long long)(kb + min(lane, nbk - 1)) * ldf;
 #pragma unroll
             for (int i = 0; i < WIDE_B; ++i) o.Lt[i] = col[min(i, nbk - 1)];  // (clamped into the block; masked where it is used)
         }
@@ -1341,7 +1428,7 @@ __device__ __forceinline__ void front_bwd_wide_body(const FrontMeta& M, const do
 #pragma unroll
         for (int c = 0; c < WIDE_CPW; ++c) {
             const int k = wave * WIDE_CPW + c;  // wave-uniform
-            const double* col = F + (long long)(kb + min(k, nbk - 1)) * f;
+            const double* col = F + (long long)(kb + min(k, nbk - 1)) * ldf;
 #pragma unroll
             for (int ch = 0; ch < WIDE_BCH; ++ch) {
                 const int i = r0 + lane + 64 * ch;
@@ -1370,7 +1457,7 @@ __device__ __forceinline__ void front_bwd_wide_body(const FrontMeta& M, const do
 #pragma unroll
             for (int c = 0; c < WIDE_CPW; ++c) {
                 const int k = wave * WIDE_CPW + c;
-                if (k < nbk) acc[c] = __builtin_fma(F[i + (long long)(kb + k) * f], xi, acc[c]);
+                if (k < nbk) acc[c] = __builtin_fma(F[i + (long long)(kb + k) * ldf], xi, acc[c]);
             }
         }
         if (kb2 >= 0) prefetch_cols(std::true_type{}, o, kb2);  // (every block after the first one processed is a full one)
@@ -1414,9 +1501,9 @@ __device__ __forceinline__ void front_bwd_wide_body(const FrontMeta& M, const do
     for (int i = tid; i < w; i += WIDE_NT) x[first + i] = vs[i];
 }
 __global__ __launch_bounds__(WIDE_NT) void k_front_bwd_wide(FrontMeta M, const double* __restrict__ fronts, const int* __restrict__ list, double* __restrict__ x,
-                                                            double* __restrict__ fvec, int fcap)
+                                                            double* __restrict__ fvec, int fcap, const int* __restrict__ hoff, const double* __restrict__ hpart)
 {
-    front_bwd_wide_body(M, fronts, list, x, fvec, fcap, (int)blockIdx.x);
+    front_bwd_wide_body(M, fronts, list, x, fvec, fcap, (int)blockIdx.x, hoff, hpart);
 }
 
 // ---- single-wave subtree substitution: the front vector lives in registers (rows lane and lane + 64, fronts of a workgroup subtree have at
@@ -1780,14 +1867,14 @@ __global__ __launch_bounds__(WIDE_NT) void k_level_fwd_mixed(FrontMeta M, const 
     front_fwd_wide_body(M, fronts, list + nn, x, fvec, fcap, (int)blockIdx.x - nn);
 }
 __global__ __launch_bounds__(WIDE_NT) void k_level_bwd_mixed(FrontMeta M, const double* __restrict__ fronts, const int* __restrict__ list, int nn, double* __restrict__ x,
-                                                             double* __restrict__ fvec, int fcap, int red_thr)
+                                                             double* __restrict__ fvec, int fcap, int red_thr, const int* __restrict__ hoff, const double* __restrict__ hpart)
 {
     if ((int)blockIdx.x < nn) {
         if (threadIdx.x >= 64) return;
         subtree_bwd_wave_body<false>(M, fronts, list, list, x, red_thr, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, (int)blockIdx.x);
         return;
     }
-    front_bwd_wide_body(M, fronts, list + nn, x, fvec, fcap, (int)blockIdx.x - nn);
+    front_bwd_wide_body(M, fronts, list + nn, x, fvec, fcap, (int)blockIdx.x - nn, hoff, hpart);
 }
 
 // ---- the top of the assembly tree in ONE launch: workgroup b takes the top supernodes b, b + G, ... of the level-sorted (=
@@ -2906,6 +2993,10 @@ private:
         std::vector<Run> runs;
         std::vector<int> run_of;  // level -> run (or -1)
         DBuf<int> walk_lo, walk_hi;
+        // huge fronts (huge_front()): per level the list [hptr[l], hptr[l + 1]) of hdev, the grids of k_front_fwd_rows / k_front_bwd_cols and the LDS of the former;
+        // hoff[s] = offset of front s's partial column sums in huge_part_ (the buffer is reused level after level)
+        std::vector<int> hptr, hfwd_grid, hbwd_grid, hlds;
+        DBuf<int> hdev, hoff;
     };
     void build_level_lists(const std::vector<int>& ptr, const std::vector<int>& sn, LevelLists& L)
     {
@@ -2923,6 +3014,30 @@ private:
             L.lds.push_back((((fmax + 1) & ~1) + WIDE_B) * (int)sizeof(double));
         }
         upload_vec(L.dev, order, st_);
+        {
+            std::vector<int> hl, ho(S_.nsuper ? S_.nsuper : 1, 0);
+            L.hptr.assign(1, 0); L.hfwd_grid.clear(); L.hbwd_grid.clear(); L.hlds.clear();
+            size_t need = 0;
+            for (int l = 0; l < nl; ++l) {
+                int gf = 0, gb = 0, wmax = 0;
+                size_t off = 0;
+                for (int q = ptr[l]; q < ptr[l + 1]; ++q) {
+                    const int s2 = sn[q], f = S_.front_rows_ptr[s2 + 1] - S_.front_rows_ptr[s2], w = S_.sn_first[s2 + 1] - S_.sn_first[s2];
+                    if (!huge_front(f, w) || f > wide_fcap_) continue;
+                    hl.push_back(s2);
+                    const int nch = (f - w + HUGE_ROWS - 1) / HUGE_ROWS;
+                    gf = std::max(gf, (f - w + 63) / 64); gb = std::max(gb, nch); wmax = std::max(wmax, w);
+                    ho[s2] = (int)off; off += (size_t)nch * w;
+                }
+                if (off > 0x7fffffffull) throw std::runtime_error("sparse backend: partial sums of a level's huge fronts exceed 2^31 doubles");
+                need = std::max(need, off);
+                L.hptr.push_back((int)hl.size()); L.hfwd_grid.push_back(gf); L.hbwd_grid.push_back(gb); L.hlds.push_back(wmax * (int)sizeof(double));
+            }
+            if (!hl.empty()) {
+                upload_vec(L.hdev, hl, st_); upload_vec(L.hoff, ho, st_);
+                if (huge_part_.n < need) { stream_wait(st_); huge_part_.alloc(need); }
+            }
+        }
         L.run_of.assign(std::max(nl, 1), -1);
         if (no_runs_) return;
         std::vector<int> lvl(S_.nsuper ? S_.nsuper : 1, -1), walk_end(S_.nsuper ? S_.nsuper : 1, -1), wlo, whi;
@@ -2971,9 +3086,14 @@ private:
                 continue;
             }
             static const bool two_launches = debug_token("solve_level_two_launches") != nullptr;
-            if (nn > 0 && cnt > nn && !two_launches) { hipLaunchKernelGGL(k_level_fwd_mixed, dim3(cnt), dim3(WIDE_NT), L.lds[l], st_, M, fronts_.p, list, nn, xp_.p, fvec_.p, wide_fcap_); continue; }
+            const int nh = L.hptr.empty() ? 0 : L.hptr[l + 1] - L.hptr[l];
+            auto huge_rows = [&] {  // the update rows of the level's huge fronts, behind their pivot blocks
+                if (nh > 0) hipLaunchKernelGGL(k_front_fwd_rows, dim3(L.hfwd_grid[l], nh), dim3(64), L.hlds[l], st_, M, fronts_.p, L.hdev.p + L.hptr[l], fvec_.p);
+            };
+            if (nn > 0 && cnt > nn && !two_launches) { hipLaunchKernelGGL(k_level_fwd_mixed, dim3(cnt), dim3(WIDE_NT), L.lds[l], st_, M, fronts_.p, list, nn, xp_.p, fvec_.p, wide_fcap_); huge_rows(); continue; }
             if (nn > 0) hipLaunchKernelGGL(k_subtree_fwd_wave<false>, dim3(nn), dim3(64), 0, st_, M, fronts_.p, list, list, xp_.p, fvec_.p, (const int*)nullptr, (int*)nullptr, (int*)nullptr, (const int*)nullptr, 0);
             if (cnt > nn) hipLaunchKernelGGL(k_front_fwd_wide, dim3(cnt - nn), dim3(WIDE_NT), L.lds[l], st_, M, fronts_.p, list + nn, xp_.p, fvec_.p, wide_fcap_);
+            huge_rows();
         }
     }
     void bwd_levels(const FrontMeta& M, const LevelLists& L)
@@ -2987,8 +3107,11 @@ private:
                 continue;
             }
             static const bool two_launches = debug_token("solve_level_two_launches") != nullptr;
-            if (nn > 0 && cnt > nn && !two_launches) { hipLaunchKernelGGL(k_level_bwd_mixed, dim3(cnt), dim3(WIDE_NT), L.lds[l], st_, M, fronts_.p, list, nn, xp_.p, fvec_.p, wide_fcap_, bwd_red_thr()); continue; }
-            if (cnt > nn) hipLaunchKernelGGL(k_front_bwd_wide, dim3(cnt - nn), dim3(WIDE_NT), L.lds[l], st_, M, fronts_.p, list + nn, xp_.p, fvec_.p, wide_fcap_);
+            const int nh = L.hptr.empty() ? 0 : L.hptr[l + 1] - L.hptr[l];
+            if (nh > 0) hipLaunchKernelGGL(k_front_bwd_cols, dim3(L.hbwd_grid[l], nh), dim3(HUGE_ROWS), 0, st_, M, fronts_.p, L.hdev.p + L.hptr[l], xp_.p, L.hoff.p, huge_part_.p);
+            const int* hoff = L.hoff.p;  // (nullptr when the schedule holds no huge front)
+            if (nn > 0 && cnt > nn && !two_launches) { hipLaunchKernelGGL(k_level_bwd_mixed, dim3(cnt), dim3(WIDE_NT), L.lds[l], st_, M, fronts_.p, list, nn, xp_.p, fvec_.p, wide_fcap_, bwd_red_thr(), hoff, huge_part_.p); continue; }
+            if (cnt > nn) hipLaunchKernelGGL(k_front_bwd_wide, dim3(cnt - nn), dim3(WIDE_NT), L.lds[l], st_, M, fronts_.p, list + nn, xp_.p, fvec_.p, wide_fcap_, hoff, huge_part_.p);
             if (nn > 0) hipLaunchKernelGGL(k_subtree_bwd_wave<false>, dim3(nn), dim3(64), 0, st_, M, fronts_.p, list, list, xp_.p, bwd_red_thr(), 0, (const int*)nullptr, (int*)nullptr, (int*)nullptr, (const int*)nullptr, 0, (const double*)nullptr);
         }
     }
@@ -3144,6 +3267,7 @@ private:
     double* xbuf_norm_ = nullptr;
     int ref_mode_ = PQ_REF_MODE;  // arithmetic of the one-workgroup fronts (PQ_REF_MODE: the reference's, term by term; PQ_REF_MODE_BIG where the tree has multi-workgroup fronts)
     bool no_big_ = debug_token("no_big") != nullptr;    // debugging aid: every front through one workgroup's pivot loop (accuracy comparisons)
+    DBuf<double> huge_part_;  // partial column sums of the huge fronts of one level (k_front_bwd_cols)
     int wide_fcap_ = debug_token("no_wide_solve") ? 0 : WIDE_FCAP;  // debugging aid: wide fronts through the per-pivot routines
     BigLevels top_big_, own_big_, sh_big_;
     int ntop_solve_ = 0, nwalk_solve_ = 0, solve_epoch_ = 0, solve_epoch_used_ = 0, factor_epoch_ = 0;

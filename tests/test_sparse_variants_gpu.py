@@ -37,14 +37,14 @@ VARIANTS = {
 }
 
 
-def _run(tmp_path, name, env_extra):
+def _run(tmp_path, name, env_extra, mode=None):
     out = str(tmp_path / (name + ".npz"))
     env = dict(os.environ)
     for k in list(env):
         if k.startswith("PIQP_AMD_"):
             env.pop(k)
     env.update(env_extra)
-    r = subprocess.run([sys.executable, WORKER, out], env=env, capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, WORKER, out] + ([mode] if mode else []), env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, name + ": " + r.stderr[-2000:]
     return dict(np.load(out))
 
@@ -60,3 +60,17 @@ def test_schedule_variants_are_bitwise_identical(tmp_path):
         assert sorted(got) == sorted(ref)
         for key in ref:
             assert np.array_equal(got[key], ref[key]), f"{name}: {key} differs from the default schedule (max |d| = {np.abs(got[key] - ref[key]).max():.3e})"
+
+
+def test_huge_fronts_substitution_agrees_with_the_per_pivot_routines(tmp_path):
+    """fronts of 1024 rows and more hand their update rows to k_front_fwd_rows / k_front_bwd_cols (several workgroups per front); the solution meets the
+    KKT residual bar of every other path and agrees with the per-pivot routines (PIQP_AMD_DEBUG=no_wide_solve: one workgroup per front, front_fwd / front_bwd)
+    -- not bitwise: the backward column sums are formed chunk by chunk"""
+    ref = _run(tmp_path, "huge_default", {}, "huge")
+    assert float(ref["rel_residual"][0]) <= 1e-10, ref["rel_residual"]
+    got = _run(tmp_path, "huge_per_pivot", {"PIQP_AMD_DEBUG": "no_wide_solve"}, "huge")
+    assert float(got["rel_residual"][0]) <= 1e-10, got["rel_residual"]
+    for key in ref:
+        if key.startswith("wide_"):
+            scale = max(1.0, float(np.abs(ref[key]).max()))
+            assert np.abs(got[key] - ref[key]).max() <= 1e-8 * scale, (key, float(np.abs(got[key] - ref[key]).max()), scale)

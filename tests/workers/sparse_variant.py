@@ -19,6 +19,27 @@ def main():
     import piqp_amd as hip
     from qp_gen import c3_problem, mpc_chain, random_vars
     out = {}
+    if len(sys.argv) > 2 and sys.argv[2] == "huge":
+        # C3 recipe with rows of 10 nonzeros in 1500-variable windows at n = 8000: a chain of fronts of 2600-3700 rows with 130-380 pivots (and accumulator
+        # supernodes between them) -- multi-workgroup fronts in the factorisation, huge fronts (k_front_fwd_rows / k_front_bwd_cols) in the substitution
+        n, p, m = 8000, 3200, 4800
+        a = c3_problem(n, p, m, 44, 1500, 10)
+        k = hip.KKTSystem(hip.SparseData(*a), hip.default_settings(kkt_solver=hip.SPARSE_LDLT))
+        st = k.backend().sparse_stats()
+        assert st["max_front"] >= 2048, st
+        rng = np.random.default_rng(0)
+        state = random_vars(n, p, m, rng, positive=True)
+        rhs = random_vars(n, p, m, rng)
+        assert k.update_scalings_and_factor(False, 1e-6, 1e-4, state)
+        ok, lhs = k.solve(rhs)
+        assert ok
+        res, nrm = k.condensed_residual()
+        out["rel_residual"] = np.array([res / nrm])
+        for key, v in lhs.items():
+            out["wide_" + key] = np.asarray(v)
+        np.savez(sys.argv[1], **out)
+        print("ok", sorted(out))
+        return
     # (a) C3 recipe at n = 6000: fronts wide enough for every schedule variant to have work
     n, p, m = 6000, 2400, 3600
     a = c3_problem(n, p, m, 44, 40)
