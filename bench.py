@@ -329,9 +329,13 @@ def sparse_legs(args, rank, world, local_rank, dev, pd):
     # the real Maros-Meszaros cross-checks SURVEY.md 8d names next to the synthetic C3 (frozen fixtures, tests/golden/make_fixtures.py)
     from qp_io import load_qp
     # round 4: the banded C3 recipe is the benign half of "Maros-Meszaros-style" (every row inside a 40-variable window, fronts <= 92); a wider variant beside it --
-    # rows of 10 nonzeros inside 300-variable windows, nnz(upper KKT) = 7.4e5: nnz(L) = 1.9e7, fronts up to 620, an assembly tree ~1800 levels deep
+    # rows of 10 nonzeros inside 300-variable windows, nnz(upper KKT) = 7.4e5: under AMD nnz(L) = 1.9e7, fronts up to 620 and an assembly tree ~1800 levels deep (the
+    # symbolic analysis picks nested dissection for it since round 4: 17 levels of merged fronts, nnz(L) = 4.6e7); and the same rows in 1500-variable windows:
+    # nnz(L) = 1.2e8, a chain of ~150 fronts of 3000-4000 rows, 3.6e11 flops per factorisation (no oracle leg: minutes per step on one core)
     cases.append(("C3_wide", "sparse QP n=50000 p=20000 m=30000, rows of 10 nonzeros in 300-variable windows, nnz(upper KKT)=7.4e5, kkt_solver=sparse_ldlt (harder variant of BASELINE configs[2])",
                   c3_problem(seed=44 + rank, spread=300, row_nnz=10), piqp_amd.SPARSE_LDLT, 1))
+    cases.append(("C3_window1500", "sparse QP n=50000 p=20000 m=30000, rows of 10 nonzeros in 1500-variable windows, nnz(upper KKT)=7.5e5, kkt_solver=sparse_ldlt (hardest variant of BASELINE configs[2])",
+                  c3_problem(seed=44 + rank, spread=1500, row_nnz=10), piqp_amd.SPARSE_LDLT, None))
     for nm, what in (("CONT-201", "PDE-constrained grid, n=40397 p=40198"), ("BOYD1", "n=93261 with 18 dense equality rows")):
         q = load_qp("mm_" + nm)
         cases.append(("MM_" + nm, f"Maros-Meszaros {nm} ({what}), kkt_solver=sparse_ldlt", (q["P"], q["c"], q["A"], q["b"], q["G"], q["h_l"], q["h_u"], q["x_l"], q["x_u"]),
@@ -353,7 +357,7 @@ def sparse_legs(args, rank, world, local_rank, dev, pd):
             assert k.update_scalings_and_factor(False, 1e-6, 1e-4, state)
             k.solve(rhs[0], lhs)
         res_inf, nrm = k.condensed_residual()
-        steps = 3 if key == "C3_wide" else 10
+        steps = 3 if key in ("C3_wide", "C3_window1500") else 10
         be = k.backend(); be.set_profiling(True)
         pd.barrier(); k.synchronize(); torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -401,7 +405,7 @@ def sparse_legs(args, rank, world, local_rank, dev, pd):
                 r["factor_gflops"] = stt["flops_factor"] / fac_s / 1e9
             except Exception as e:  # noqa: BLE001
                 r["roofline_error"] = str(e)
-            if not args.no_cpu_baseline:
+            if not args.no_cpu_baseline and oracle_ks is not None:
                 from oracle import pyorc
                 od = pyorc.Data.sparse(*a)
                 ko = pyorc.KKTSystem(od, pyorc.Settings(kkt_solver=oracle_ks))
