@@ -274,6 +274,34 @@ def test_large_banded_sparse_residual(hip):
     assert res <= 1e-10 * nrm
 
 
+@pytest.mark.parametrize("spread,row_nnz,n", [(300, 10, 6000), (1000, 8, 3000)])
+def test_wide_window_problem_whole_solve_matches_oracle(hip, orc, spread, row_nnz, n):
+    """the C3 recipe with constraint rows that couple variables hundreds of columns apart (round 4): the tree the symbolic analysis builds for it -- nested
+    dissection or AMD, merged spines, fronts of several hundred to a few thousand rows on the multi-workgroup kernels, huge-front substitution -- against the
+    reference's up-looking LDLt in its own AMD order: same status, same iteration count, same optimum, and the KKT bar on one factor + solve"""
+    from qp_gen import c3_problem
+    p, m = n * 2 // 5, n * 3 // 5
+    a = c3_problem(n, p, m, 45, spread, row_nnz)  # (the second case: fronts of ~1500 rows, the oracle needs ~12 s)
+    # inequality rows -1 <= G x <= 1 with b = 0: feasible at x = 0
+    sh = hip.SparseSolver(); sh.settings.kkt_solver = hip.SPARSE_LDLT
+    so = orc.Solver(); so.settings.kkt_solver = orc.SPARSE_LDLT
+    assert sh.setup(*a) and so.setup(*a, sparse=True)
+    st_h, st_o = sh.solve(), so.solve()
+    assert st_h == st_o == 1, (st_h, st_o)
+    assert sh.info.iter == so.info.iter, (sh.info.iter, so.info.iter)
+    assert abs(sh.info.primal_obj - so.info.primal_obj) <= 1e-6 * (1 + abs(so.info.primal_obj))
+    assert np.abs(sh.result()["x"] - so.result()["x"]).max() <= 1e-6 * max(1.0, np.abs(so.result()["x"]).max())
+    k = hip.KKTSystem(hip.SparseData(*a), hip.default_settings(kkt_solver=hip.SPARSE_LDLT))
+    st = k.backend().sparse_stats()
+    assert st["max_front"] >= 192, st  # (the multi-workgroup path is what this test is about)
+    rng = np.random.default_rng(3)
+    assert k.update_scalings_and_factor(False, 1e-6, 1e-4, random_vars(n, p, m, rng, positive=True))
+    ok, _ = k.solve(random_vars(n, p, m, rng))
+    assert ok
+    res, nrm = k.condensed_residual()
+    assert res <= 1e-10 * nrm, (res, nrm)
+
+
 COND = [("SPARSE_LDLT_EQ_COND", 2, 1), ("SPARSE_LDLT_INEQ_COND", 3, 2), ("SPARSE_LDLT_COND", 4, 3)]
 
 
