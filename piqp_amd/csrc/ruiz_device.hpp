@@ -31,8 +31,10 @@ struct RuizSparseArgs {
     double* c_scale = nullptr;  // [batch], not strided: the cost scaling c of every instance (out for RUIZ_COMPUTE, in otherwise)
     int mode = RUIZ_COMPUTE, scale_cost = 0, max_iter = 10;
     double eps = 1e-3;
+    unsigned long long* grid_ws = nullptr;  // optional, ruiz_grid_ws_words() words: with it a single instance (batch == 1) is equilibrated by a grid of workgroups
 };
 void launch_ruiz_sparse(const RuizSparseArgs& a, int batch, int threads, hipStream_t s);
+size_t ruiz_grid_ws_words();
 
 struct HostData;
 struct Ruiz;

@@ -46,9 +46,9 @@ __device__ __forceinline__ void sync_mem()
 
 // ------------------------------------------------------------------------------------------------ sparse, one workgroup per instance
 // inf-norms of the columns of the symmetric matrix stored as the upper triangle (Px): out[k] (zeroed by the caller) via atomic max
-__device__ __forceinline__ void sym_col_norms(int n, const int* __restrict__ Pp, const int* __restrict__ Pi, const double* Px, double* out)
+__device__ __forceinline__ void sym_col_norms(int n, const int* __restrict__ Pp, const int* __restrict__ Pi, const double* Px, double* out, int t0, int nt)
 {
-    for (int j = threadIdx.x; j < n; j += blockDim.x) {
+    for (int j = t0; j < n; j += nt) {
         double cm = 0.0;
         for (int q = Pp[j]; q < Pp[j + 1]; ++q) {
             const int r = Pi[q];
@@ -60,9 +60,9 @@ __device__ __forceinline__ void sym_col_norms(int n, const int* __restrict__ Pp,
     }
 }
 // inf-norms of the rows (-> rown, atomic) and the columns (-> coln, plain store) of a CSC matrix
-__device__ __forceinline__ void rows_and_cols(int cols, const int* __restrict__ Tp, const int* __restrict__ Ti, const double* Tx, double* rown, double* coln)
+__device__ __forceinline__ void rows_and_cols(int cols, const int* __restrict__ Tp, const int* __restrict__ Ti, const double* Tx, double* rown, double* coln, int t0, int nt)
 {
-    for (int j = threadIdx.x; j < cols; j += blockDim.x) {
+    for (int j = t0; j < cols; j += nt) {
         double cm = 0.0;
         for (int q = Tp[j]; q < Tp[j + 1]; ++q) {
             const double a = fabs(Tx[q]);
@@ -74,9 +74,9 @@ __device__ __forceinline__ void rows_and_cols(int cols, const int* __restrict__ 
 }
 // sparse/utils.hpp:172-199 order: rows first, then columns; `pre` multiplies first when USE_PRE (scale_P_scalar before scale_P)
 template <bool USE_PRE>
-__device__ __forceinline__ void scale_csc(int cols, const int* __restrict__ Tp, const int* __restrict__ Ti, double* Tx, const double* srow, const double* scol, double pre)
+__device__ __forceinline__ void scale_csc(int cols, const int* __restrict__ Tp, const int* __restrict__ Ti, double* Tx, const double* srow, const double* scol, double pre, int t0, int nt)
 {
-    for (int j = threadIdx.x; j < cols; j += blockDim.x) {
+    for (int j = t0; j < cols; j += nt) {
         const double sc = scol[j];
         for (int q = Tp[j]; q < Tp[j + 1]; ++q) {
             double v = Tx[q];
@@ -86,12 +86,48 @@ __device__ __forceinline__ void scale_csc(int cols, const int* __restrict__ Tp, 
     }
 }
 
+// GRID = false: one workgroup per instance (the batched solver; a single small QP).  GRID = true (round 4): the gridDim.x workgroups of the launch share ONE
+// instance -- every loop strides over the whole grid, the workgroup barriers become grid barriers (a monotonic counter in a.grid_ws; all workgroups are
+// resident: the launch has at most one per CU), the two maxima are reduced through one slot per iteration.  The statements, and the order of the one sum that
+// has an order (the mean of the column norms, thread 0 of workgroup 0), are the same: bitwise the same scaling.  One workgroup needed 13 ms for the C3 pattern.
+template <bool GRID>
+__device__ __forceinline__ void ruiz_sync(unsigned long long* ws, unsigned& epoch)
+{
+    if constexpr (!GRID) { sync_mem(); return; }
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        epoch += gridDim.x;
+        unsigned* cnt = reinterpret_cast<unsigned*>(ws);
+        __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        while (__hip_atomic_load(cnt, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < epoch) __builtin_amdgcn_s_sleep(2);
+    }
+    __syncthreads();
+    __threadfence();
+}
+// maximum over all threads that share the instance, returned to every thread; slot: a zero-initialised word of a.grid_ws used once
+template <bool GRID>
+__device__ __forceinline__ double ruiz_max(double v, double* red, unsigned long long* ws, int slot, unsigned& epoch)
+{
+    v = block_max(v, red);
+    if constexpr (!GRID) return v;
+    if (threadIdx.x == 0) amax(reinterpret_cast<double*>(ws + slot), v);
+    ruiz_sync<GRID>(ws, epoch);
+    return __longlong_as_double((long long)__hip_atomic_load(ws + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+constexpr int RUIZ_WS_DEV = 2, RUIZ_WS_CINF = 66, RUIZ_WS_GSUM = 130, RUIZ_WS_WORDS = 132;  // counter | per-iteration maxima (<= 64 iterations) | the mean's sum
+
+template <bool GRID>
 __global__ void k_ruiz_sparse(RuizSparseArgs a)
 {
     __shared__ double red[16];
     __shared__ double gsum;
-    const long long o = (long long)blockIdx.x * a.stride;
-    const int n = a.n, p = a.p, m = a.m, N = n + p + m, t = threadIdx.x, NT = blockDim.x;
+    const long long o = GRID ? 0 : (long long)blockIdx.x * a.stride;
+    const int inst = GRID ? 0 : (int)blockIdx.x;
+    const int n = a.n, p = a.p, m = a.m, N = n + p + m;
+    const int t = GRID ? (int)(blockIdx.x * blockDim.x + threadIdx.x) : (int)threadIdx.x, NT = GRID ? (int)(gridDim.x * blockDim.x) : (int)blockDim.x;
+    unsigned long long* ws = a.grid_ws;
+    unsigned epoch = 0;
     double *Px = a.Px + o, *ATx = a.ATx + o, *GTx = a.GTx + o, *c = a.c + o, *xbs = a.xbs + o;
     double *delta = a.delta + o, *delta_b = a.delta_b + o, *di = a.delta_inv + o, *dib = a.delta_b_inv + o, *tmp = a.tmp + o;
     const double *s = delta, *sb = delta_b;  // what the tail multiplies with
@@ -100,19 +136,19 @@ __global__ void k_ruiz_sparse(RuizSparseArgs a)
         double cs = 1.0;
         for (int i = t; i < N; i += NT) { delta[i] = 1.0; di[i] = 0.0; }
         for (int i = t; i < n; i += NT) { delta_b[i] = 1.0; dib[i] = 0.0; }
-        sync_mem();
+        ruiz_sync<GRID>(ws, epoch);
         for (int it = 0; it < a.max_iter; ++it) {
             double dev = 0.0;
             for (int i = t; i < N; i += NT) dev = fmax(dev, fabs(1.0 - di[i]));
             for (int i = t; i < n; i += NT) dev = fmax(dev, fabs(1.0 - dib[i]));
-            dev = block_max(dev, red);
+            dev = ruiz_max<GRID>(dev, red, ws, RUIZ_WS_DEV + it, epoch);
             if (!(dev > a.eps)) break;
             for (int i = t; i < N; i += NT) di[i] = 0.0;
-            sync_mem();
-            sym_col_norms(n, a.Pp, a.Pi, Px, di);
-            if (p > 0) rows_and_cols(p, a.ATp, a.ATi, ATx, di, di + n);
-            if (m > 0) rows_and_cols(m, a.GTp, a.GTi, GTx, di, di + n + p);
-            sync_mem();
+            ruiz_sync<GRID>(ws, epoch);
+            sym_col_norms(n, a.Pp, a.Pi, Px, di, t, NT);
+            if (p > 0) rows_and_cols(p, a.ATp, a.ATi, ATx, di, di + n, t, NT);
+            if (m > 0) rows_and_cols(m, a.GTp, a.GTi, GTx, di, di + n + p, t, NT);
+            ruiz_sync<GRID>(ws, epoch);
             for (int i = t; i < N; i += NT) {
                 if (i < n) {
                     const double xb = xbs[i];
@@ -122,27 +158,28 @@ __global__ void k_ruiz_sparse(RuizSparseArgs a)
                     di[i] = inv_sqrt_limited(di[i]);
                 }
             }
-            sync_mem();
-            scale_csc<false>(n, a.Pp, a.Pi, Px, di, di, 1.0);
+            ruiz_sync<GRID>(ws, epoch);
+            scale_csc<false>(n, a.Pp, a.Pi, Px, di, di, 1.0, t, NT);
             for (int i = t; i < n; i += NT) c[i] *= di[i];
-            if (p > 0) scale_csc<false>(p, a.ATp, a.ATi, ATx, di, di + n, 1.0);
-            if (m > 0) scale_csc<false>(m, a.GTp, a.GTi, GTx, di, di + n + p, 1.0);
+            if (p > 0) scale_csc<false>(p, a.ATp, a.ATi, ATx, di, di + n, 1.0, t, NT);
+            if (m > 0) scale_csc<false>(m, a.GTp, a.GTi, GTx, di, di + n + p, 1.0, t, NT);
             for (int i = t; i < n; i += NT) { xbs[i] *= dib[i] * di[i]; delta_b[i] *= dib[i]; }
             for (int i = t; i < N; i += NT) delta[i] *= di[i];
             if (a.scale_cost) {
                 for (int i = t; i < n; i += NT) tmp[i] = 0.0;
-                sync_mem();
-                sym_col_norms(n, a.Pp, a.Pi, Px, tmp);
-                sync_mem();
+                ruiz_sync<GRID>(ws, epoch);
+                sym_col_norms(n, a.Pp, a.Pi, Px, tmp, t, NT);
+                ruiz_sync<GRID>(ws, epoch);
                 if (t == 0) {
                     double g = 0.0;
                     for (int k = 0; k < n; ++k) g += tmp[k];
-                    gsum = g;
+                    if constexpr (GRID) __hip_atomic_store(reinterpret_cast<double*>(ws + RUIZ_WS_GSUM), g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    else gsum = g;
                 }
                 double cinf = 0.0;
                 for (int i = t; i < n; i += NT) cinf = fmax(cinf, fabs(c[i]));
-                cinf = block_max(cinf, red);  // (its barriers also publish gsum)
-                double gamma = gsum / (double)n;
+                cinf = ruiz_max<GRID>(cinf, red, ws, RUIZ_WS_CINF + it, epoch);  // (its barriers also publish gsum)
+                double gamma = (GRID ? __hip_atomic_load(reinterpret_cast<double*>(ws + RUIZ_WS_GSUM), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : gsum) / (double)n;
                 gamma = limit_scaling(gamma);
                 gamma = limit_scaling(fmax(gamma, cinf));
                 gamma = 1.0 / gamma;
@@ -150,21 +187,21 @@ __global__ void k_ruiz_sparse(RuizSparseArgs a)
                 for (int i = t; i < n; i += NT) c[i] *= gamma;
                 cs *= gamma;
             }
-            sync_mem();
+            ruiz_sync<GRID>(ws, epoch);
         }
-        __syncthreads();
+        ruiz_sync<GRID>(ws, epoch);
         for (int i = t; i < N; i += NT) di[i] = 1.0 / delta[i];
         for (int i = t; i < n; i += NT) dib[i] = 1.0 / delta_b[i];
-        if (t == 0) a.c_scale[blockIdx.x] = cs;
-        sync_mem();
+        if (t == 0) a.c_scale[inst] = cs;
+        ruiz_sync<GRID>(ws, epoch);
     } else {
         // scale_data with reuse_prev_scaling (:207-217) / unscale_data (:224-258): the same products with (c, delta) or their inverses
-        double cs = a.c_scale[blockIdx.x];
+        double cs = a.c_scale[inst];
         if (a.mode == RUIZ_UNSCALE) { cs = 1.0 / cs; s = di; sb = dib; }
-        scale_csc<true>(n, a.Pp, a.Pi, Px, s, s, cs);
+        scale_csc<true>(n, a.Pp, a.Pi, Px, s, s, cs, t, NT);
         for (int i = t; i < n; i += NT) c[i] *= cs * s[i];
-        if (p > 0) scale_csc<false>(p, a.ATp, a.ATi, ATx, s, s + n, 1.0);
-        if (m > 0) scale_csc<false>(m, a.GTp, a.GTi, GTx, s, s + n + p, 1.0);
+        if (p > 0) scale_csc<false>(p, a.ATp, a.ATi, ATx, s, s + n, 1.0, t, NT);
+        if (m > 0) scale_csc<false>(m, a.GTp, a.GTi, GTx, s, s + n + p, 1.0, t, NT);
         for (int i = t; i < n; i += NT) xbs[i] *= sb[i] * s[i];
     }
     if (a.b) for (int i = t; i < p; i += NT) a.b[o + i] *= s[n + i];
@@ -303,9 +340,25 @@ __global__ void k_rzd_vectors(int n, double* c, double* xbs, const double* s, co
 void launch_ruiz_sparse(const RuizSparseArgs& a, int batch, int threads, hipStream_t s)
 {
     if (batch <= 0) return;
-    hipLaunchKernelGGL(k_ruiz_sparse, dim3(batch), dim3(threads), 0, s, a);
+    static const bool one_wg = debug_token("ruiz_one_wg") != nullptr;  // debugging aid: PIQP_AMD_DEBUG=ruiz_one_wg
+    if (batch == 1 && a.grid_ws && a.max_iter <= 64 && !one_wg) {
+        // one instance on the whole chip: a workgroup of 256 threads per 2048 rows, at most one per CU (every workgroup must be resident: grid barriers)
+        int cus = 0, dev = 0;
+        PQ_HIP(hipGetDevice(&dev));
+        PQ_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        const int N = a.n + a.p + a.m;
+        const int g = std::max(1, std::min(cus > 0 ? cus : 64, (N + 2047) / 2048));
+        if (g > 1) {
+            PQ_HIP(hipMemsetAsync(a.grid_ws, 0, sizeof(unsigned long long) * RUIZ_WS_WORDS, s));
+            hipLaunchKernelGGL(k_ruiz_sparse<true>, dim3(g), dim3(256), 0, s, a);
+            PQ_HIP(hipGetLastError());
+            return;
+        }
+    }
+    hipLaunchKernelGGL(k_ruiz_sparse<false>, dim3(batch), dim3(threads), 0, s, a);
     PQ_HIP(hipGetLastError());
 }
+size_t ruiz_grid_ws_words() { return RUIZ_WS_WORDS; }
 
 // ------------------------------------------------------------------------------------------------ DeviceRuiz
 struct DeviceRuiz::Impl {
@@ -318,6 +371,7 @@ struct DeviceRuiz::Impl {
     DBuf<double> vec;  // c | xbs | delta | delta_inv | delta_b | delta_b_inv | tmp
     DBuf<DenseState> state;
     DBuf<double> cscale;
+    DBuf<unsigned long long> gridws;  // sparse: barrier counter and reduction slots of the grid-wide equilibration
     HBuf<double> hvec;
     double *c = nullptr, *xbs = nullptr, *delta = nullptr, *delta_inv = nullptr, *delta_b = nullptr, *delta_b_inv = nullptr, *tmp = nullptr;
     size_t vec_len = 0;
@@ -438,6 +492,8 @@ void DeviceRuiz::run(HostData& d, Ruiz& rz, int mode, bool scale_cost, int max_i
         a.delta = s.delta; a.delta_inv = s.delta_inv; a.delta_b = s.delta_b; a.delta_b_inv = s.delta_b_inv; a.tmp = s.tmp;
         a.c_scale = s.cscale.p;
         a.mode = mode; a.scale_cost = scale_cost; a.max_iter = max_iter; a.eps = eps;
+        if (!s.gridws.p) s.gridws.alloc(ruiz_grid_ws_words());
+        a.grid_ws = s.gridws.p;
         launch_ruiz_sparse(a, 1, 1024, st);
         auto dn = [&](Vec& v, const DBuf<double>& src) { if (!v.empty()) PQ_HIP(hipMemcpyAsync(v.data(), src.p, v.size() * sizeof(double), hipMemcpyDeviceToHost, st)); };
         dn(d.sP_utri.val, s.P); dn(d.sAT.val, s.AT); dn(d.sGT.val, s.GT);
