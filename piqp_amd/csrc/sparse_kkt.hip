@@ -1142,7 +1142,7 @@ constexpr int WIDE_FCAP = 7000;  // rows of a front this path keeps in LDS (56 K
 // forward, the front's workgroup solves the w x w pivot block only and k_front_fwd_rows (one wave per 64 rows, any number of workgroups) applies the
 // pivots to the update rows; backward, k_front_bwd_cols forms the column sums over the update rows in chunks of HUGE_ROWS rows (partial sums, added in
 // chunk order by the front's workgroup) before the pivot block is solved.  The forward arithmetic is the one-workgroup kernel's, entry by entry.
-constexpr int HUGE_F = 1024, HUGE_ROWS = 256;
+constexpr int HUGE_F = 1024, HUGE_ROWS = 256, HUGE_COLS = 64;
 __host__ __device__ inline bool huge_front(int f, int w) { return f >= HUGE_F && w > 0 && f - w >= HUGE_ROWS; }
 constexpr int WIDE_BCH = 12;     // backward: 64-row chunks of a column held in registers (768 rows below the block; further rows are loaded in line)
 
@@ -1337,12 +1337,12 @@ __global__ __launch_bounds__(64) void k_front_fwd_rows(FrontMeta M, const double
     const double* __restrict__ pr = F + min(r, f - 1);
     double vi = r < f ? v[r] : 0.0;
     int k = 0;
-    for (; k + 8 <= w; k += 8) {
-        double l[8];
+    for (; k + 16 <= w; k += 16) {  // sixteen loads in flight per lane (one wave per workgroup: the latency of a trip is all there is to hide)
+        double l[16];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) l[q] = pr[(long long)(k + q) * f];
+        for (int q = 0; q < 16; ++q) l[q] = pr[(long long)(k + q) * f];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) vi = __builtin_fma(-l[q], ys[k + q], vi);
+        for (int q = 0; q < 16; ++q) vi = __builtin_fma(-l[q], ys[k + q], vi);
     }
     for (; k < w; ++k) vi = __builtin_fma(-pr[(long long)k * f], ys[k], vi);
     if (r < f) v[r] = vi;
@@ -1362,7 +1362,9 @@ __global__ __launch_bounds__(HUGE_ROWS) void k_front_bwd_cols(FrontMeta M, const
     const double xi = i < f ? x[M.front_rows[me.rows_ptr + i]] : 0.0;  // rows below the front meet x = 0
     const double* __restrict__ pr = fronts + me.front_off + min(i, f - 1);
     double* __restrict__ out = part + hoff[s] + (long long)blockIdx.x * w;
-    for (int k = 0; k < w; k += 16) {
+    // blockIdx.z: groups of HUGE_COLS columns (every workgroup writes its own entries of `out`)
+    const int kend = min(w, ((int)blockIdx.z + 1) * HUGE_COLS);
+    for (int k = (int)blockIdx.z * HUGE_COLS; k < kend; k += 16) {
         double a[16];
 #pragma unroll
         for (int q = 0; q < 16; ++q) a[q] = pr[(long long)min(k + q, w - 1) * f] * xi;
@@ -2850,7 +2852,7 @@ private:
         return tree_has_big_ == 1 && panel_front(f, w);
     }
     struct BigLevels {
-        std::vector<int> ptr, rounds, ndense, npanel, panel_lds;  // level l of the schedule -> jobs [ptr[l], ptr[l + 1]); children of its widest fan-in; jobs by kind; LDS of k_front_panel
+        std::vector<int> ptr, rounds, ndense, npanel, panel_lds, lmaxf;  // level l of the schedule -> jobs [ptr[l], ptr[l + 1]); children of its widest fan-in; jobs by kind; LDS of k_front_panel
         std::vector<std::vector<int>> rows_below;  // per level, per panel: most rows below the diagonal block over the level's fronts (0 = none)
         int total = 0, max_f = 0, max_own = 0;
         DBuf<int> list, job_of;  // job_of[s] = index into jobs, -1 for the fronts one workgroup handles alone
@@ -2860,11 +2862,11 @@ private:
     };
     void build_big_levels(const std::vector<int>& ptr, const std::vector<int>& sn, BigLevels& B)
     {
-        B.ptr.assign(1, 0); B.rounds.clear(); B.rows_below.clear(); B.ndense.clear(); B.npanel.clear(); B.panel_lds.clear(); B.total = 0; B.max_f = 0; B.max_own = 0;
+        B.ptr.assign(1, 0); B.rounds.clear(); B.rows_below.clear(); B.ndense.clear(); B.npanel.clear(); B.panel_lds.clear(); B.lmaxf.clear(); B.total = 0; B.max_f = 0; B.max_own = 0;
         std::vector<int> list;
         int widest = 0;
         for (int l = 0; l + 1 < (int)ptr.size(); ++l) {
-            int rounds = 0, nd = 0, np = 0;
+            int rounds = 0, nd = 0, np = 0, lf = 0;
             long long plds = 0;
             std::vector<int> rb;
             for (int q = ptr[l]; q < ptr[l + 1]; ++q) {
@@ -2874,13 +2876,13 @@ private:
                 const int w = S_.sn_first[s + 1] - S_.sn_first[s], f = S_.front_rows_ptr[s + 1] - S_.front_rows_ptr[s];
                 if (panel_front(f, w)) { ++np; plds = std::max(plds, (long long)f * w); } else ++nd;
                 rounds = std::max(rounds, S_.child_ptr[s + 1] - S_.child_ptr[s]);
-                B.max_f = std::max(B.max_f, f); B.max_own = std::max(B.max_own, S_.fe_ptr[s + 1] - S_.fe_ptr[s]);
+                B.max_f = std::max(B.max_f, f); B.max_own = std::max(B.max_own, S_.fe_ptr[s + 1] - S_.fe_ptr[s]); lf = std::max(lf, f);
                 for (int k = 0, pn = 0; k < w; k += dense::FACTOR_NB, ++pn) {
                     if ((int)rb.size() <= pn) rb.push_back(0);
                     rb[pn] = std::max(rb[pn], f - k - std::min(dense::FACTOR_NB, w - k));
                 }
             }
-            B.ptr.push_back((int)list.size()); B.rounds.push_back(rounds); B.rows_below.push_back(rb);
+            B.ptr.push_back((int)list.size()); B.rounds.push_back(rounds); B.rows_below.push_back(rb); B.lmaxf.push_back(lf);
             B.ndense.push_back(nd); B.npanel.push_back(np); B.panel_lds.push_back((int)((plds + IND_SCRATCH) * (long long)sizeof(double)));
             widest = std::max(widest, B.ptr[l + 1] - B.ptr[l]);
             if (B.ptr[l + 1] - B.ptr[l] > 65535) throw std::runtime_error("sparse backend: more than 65535 multi-workgroup fronts on one level of the assembly tree");
@@ -2942,7 +2944,10 @@ private:
             const int nbig = B.total > 0 ? B.ptr[l + 1] - B.ptr[l] : 0;
             // (column c of a front belongs to workgroup c mod G, an entry receives its contributions in child order whatever G is: the levels with a handful
             // of fronts take a wider grid)
-            const int ea_grid = debug_token("extend_add_grid64") ? 64 : (nbig <= 4 ? 256 : (nbig <= 16 ? 128 : 64));
+            // (one or two fronts of 1500+ rows: 216 MB per level through 256 workgroups of four waves ran at 1.1 TB/s)
+            static const char* ea_wide = debug_token("extend_add_wide");
+            const int ea_big = ea_wide ? std::atoi(ea_wide) : 1024;
+            const int ea_grid = debug_token("extend_add_grid64") ? 64 : (nbig <= 2 && B.total > 0 && B.lmaxf[l] >= 1536 && ea_big > 0 ? ea_big : (nbig <= 4 ? 256 : (nbig <= 16 ? 128 : 64)));
             if (nbig > 0 && B.rounds[l] > 0) hipLaunchKernelGGL(k_big_extend_add, dim3(ea_grid, nbig), dim3(256), 0, st_, M, fronts_.p, B.list.p + B.ptr[l]);
             const bool small = cnt > nbig || (nbig > 0 && B.npanel[l] > 0);
             // the fronts one workgroup handles and the big fronts' first diagonal blocks + panels are independent: side by side on two streams,
@@ -3108,7 +3113,7 @@ private:
             }
             static const bool two_launches = debug_token("solve_level_two_launches") != nullptr;
             const int nh = L.hptr.empty() ? 0 : L.hptr[l + 1] - L.hptr[l];
-            if (nh > 0) hipLaunchKernelGGL(k_front_bwd_cols, dim3(L.hbwd_grid[l], nh), dim3(HUGE_ROWS), 0, st_, M, fronts_.p, L.hdev.p + L.hptr[l], xp_.p, L.hoff.p, huge_part_.p);
+            if (nh > 0) hipLaunchKernelGGL(k_front_bwd_cols, dim3(L.hbwd_grid[l], nh, (L.hlds[l] / (int)sizeof(double) + HUGE_COLS - 1) / HUGE_COLS), dim3(HUGE_ROWS), 0, st_, M, fronts_.p, L.hdev.p + L.hptr[l], xp_.p, L.hoff.p, huge_part_.p);
             const int* hoff = L.hoff.p;  // (nullptr when the schedule holds no huge front)
             if (nn > 0 && cnt > nn && !two_launches) { hipLaunchKernelGGL(k_level_bwd_mixed, dim3(cnt), dim3(WIDE_NT), L.lds[l], st_, M, fronts_.p, list, nn, xp_.p, fvec_.p, wide_fcap_, bwd_red_thr(), hoff, huge_part_.p); continue; }
             if (cnt > nn) hipLaunchKernelGGL(k_front_bwd_wide, dim3(cnt - nn), dim3(WIDE_NT), L.lds[l], st_, M, fronts_.p, list + nn, xp_.p, fvec_.p, wide_fcap_, hoff, huge_part_.p);

@@ -5,8 +5,10 @@
 #include <cstdio>
 #include <cmath>
 #include <cstdlib>
+#include <exception>
 #include <stdexcept>
 #include <string>
+#include <thread>
 
 namespace pq {
 namespace sparse {
@@ -579,20 +581,33 @@ static void order_and_analyse(Symbolic& S)
     const int N = S.N;
     // ---- ordering: AMD (what the reference uses, sparse/ordering.hpp:72-74) or nested dissection, whichever gives the
     // cheaper device schedule (levels = dependent kernel launches; fill = HBM traffic and flops)
-    IVec perm_amd(N);
-    amd_order(N, S.Kp.data(), S.Ki.data(), perm_amd.data());
     const char* want = std::getenv("PIQP_AMD_ORDERING");
     const std::string ord = want ? want : "auto";
-    if (ord == "amd" || (ord == "auto" && N < 200)) { analyse_with_order(S, perm_amd); S.ordering = "amd"; S.fill_perm = perm_amd; return; }
+    IVec perm_amd(N);
+    if (ord == "amd" || (ord == "auto" && N < 200)) {
+        amd_order(N, S.Kp.data(), S.Ki.data(), perm_amd.data());
+        analyse_with_order(S, perm_amd); S.ordering = "amd"; S.fill_perm = perm_amd; return;
+    }
     IVec perm_nd(N);
-    int nd_leaf = 256;  // measured with the leaf amalgamation: 96 -> 256 is +8 % on C3 and +5 % on the n = 500k chain, 384 falls off a cliff
-    nd_order(N, S.Kp.data(), S.Ki.data(), perm_nd.data(), nd_leaf);
+    const int nd_leaf = 256;  // measured with the leaf amalgamation: 96 -> 256 is +8 % on C3 and +5 % on the n = 500k chain, 384 falls off a cliff
     Symbolic T = S;
-    analyse_with_order(T, perm_nd);
-    T.ordering = "nested dissection";
-    T.fill_perm = perm_nd;
-    if (ord == "nd") { S = std::move(T); return; }
-    analyse_with_order(S, perm_amd);
+    auto do_nd = [&] {
+        nd_order(N, T.Kp.data(), T.Ki.data(), perm_nd.data(), nd_leaf);
+        analyse_with_order(T, perm_nd);
+        T.ordering = "nested dissection";
+        T.fill_perm = perm_nd;
+    };
+    if (ord == "nd") { do_nd(); S = std::move(T); return; }
+    // the two candidate analyses are independent host work (0.2 s each at N = 100 000): side by side on two threads (round 4)
+    (void)debug_token("tree_profile");  // (the token list is parsed once, here, before the second thread exists)
+    std::exception_ptr nd_err;
+    std::thread nd_thread([&] { try { do_nd(); } catch (...) { nd_err = std::current_exception(); } });
+    try {
+        amd_order(N, S.Kp.data(), S.Ki.data(), perm_amd.data());
+        analyse_with_order(S, perm_amd);
+    } catch (...) { nd_thread.join(); throw; }
+    nd_thread.join();
+    if (nd_err) std::rethrow_exception(nd_err);
     S.ordering = "amd";
     S.fill_perm = perm_amd;
     // ~12 us per level (one launch per level) against ~1e11 flop/s and ~1e12 B/s on small fronts
@@ -856,6 +871,17 @@ static void analyse_with_order(Symbolic& S, const IVec& perm0, const IVec* force
         // the merged front) within big_z percent of the merged panel.  The padded panel runs on the matrix cores; a level costs the same launches whatever
         // its width.  Only fronts of 192 rows or more: the trees of the small fixtures, and with them their arithmetic, are untouched.
         int big_w = 256, big_z = 40;
+        {   // only DEEP trees: where the levels are few the padding costs more in the substitution than the saved launches give back (CONT-201, 22 levels of
+            // big fronts: factorisation 2.02 -> 1.91 ms but 0.94 -> 1.02 ms per solve, two solves per factorisation)
+            IVec depth(ns, 0);
+            int dmax = 0;
+            for (int s2 = 0; s2 < ns; ++s2) {  // children precede parents
+                dmax = std::max(dmax, depth[s2]);
+                const int ps = S.sn_parent[s2];
+                if (ps >= 0) depth[ps] = std::max(depth[ps], depth[s2] + 1);
+            }
+            if (dmax < 96) big_w = 0;
+        }
         if (const char* e = debug_token("big_relax_w")) big_w = std::atoi(e);  // experiments: PIQP_AMD_DEBUG=big_relax_w=<pivots>,big_relax_z=<percent>
         if (const char* e = debug_token("big_relax_z")) big_z = std::atoi(e);
         std::vector<long long> zpad(ns, 0);
