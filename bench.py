@@ -61,7 +61,7 @@ def pmc_traffic(kernel_key, n, m, p):
     """HBM traffic of one launch of `kernel_key` from the committed rocprofv3 PMC passes of this workload (FETCH_SIZE / WRITE_SIZE in
     separate passes, gfx950 correction applied, see the file); None when the file does not cover this shape.  Not measured in this run:
     the source file and its commit are reported next to the number."""
-    for fname in ("r03_pmc_dense_c2.json", "r02_pmc_dense_c2.json"):
+    for fname in ("r04_pmc_dense_c2.json", "r03_pmc_dense_c2.json", "r02_pmc_dense_c2.json"):
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", fname)))
             if (pmc["n"], pmc["m"], pmc["p"]) != (n, m, p):
@@ -389,10 +389,14 @@ def sparse_legs(args, rank, world, local_rank, dev, pd):
                     pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_sparse_batch.json")))["sparse_c3"]
                     if key == "C3" and abs(pmc["factor_per_launch"]["algorithmic_bytes"] - bytes_factor) < 0.05 * bytes_factor:
                         traffic_f = pmc["factor_per_launch"]["traffic_bytes"]; traffic_s = pmc["solve_per_launch"]["traffic_bytes"]
-                    f3 = os.path.join(ROOT, "profiles", "r03_pmc_sparse_cont201.json")  # the newest committed passes of the CONT-201 workload
-                    pmc2 = json.load(open(f3 if os.path.exists(f3) else os.path.join(ROOT, "profiles", "r02_pmc_sparse_batch.json"))).get("sparse_cont201")
+                    f3 = next((f for f in (os.path.join(ROOT, "profiles", nm) for nm in ("r04_pmc_sparse_cont201.json", "r03_pmc_sparse_cont201.json", "r02_pmc_sparse_batch.json")) if os.path.exists(f)))
+                    pmc2 = json.load(open(f3)).get("sparse_cont201")  # the newest committed passes of the CONT-201 workload
                     if key == "MM_CONT-201" and pmc2 and abs(pmc2["factor_per_launch"]["algorithmic_bytes"] - bytes_factor) < 0.05 * bytes_factor:
                         traffic_f = pmc2["factor_per_launch"]["traffic_bytes"]; traffic_s = pmc2["solve_per_launch"]["traffic_bytes"]
+                    fw = os.path.join(ROOT, "profiles", "r04_pmc_sparse_c3_wide.json")
+                    if key == "C3_wide" and os.path.exists(fw):
+                        pmc3 = json.load(open(fw))["sparse_c3_wide"]
+                        traffic_f = pmc3["factor_per_launch"]["traffic_bytes"]; traffic_s = pmc3["solve_per_launch"]["traffic_bytes"]
                 except Exception:  # noqa: BLE001
                     pass
                 r["roofline"] = {"bound": "hbm", "kernel": "multifrontal factorisation (k_subtree_factor_lds / _pk + k_top_factor / k_front_factor levels; big fronts: k_potrf_trsm_fronts + k_syrk_lower_fronts / k_syrk_half_fronts per level, k_front_panel_step at the top of the tree), hipEvent-bracketed on the backend stream",
@@ -622,8 +626,12 @@ def dense_size_sweep(piqp_amd, pd, torch, np, args, rank, world, local_rank, dev
     rows = {}
     for n in (64, 128, 256, 384, 512, 768, 1024, 1536, 2048, 3072, 4096):
         q = dense_strongly_convex_qp(n, 0, n, seed=900 + n, double_sided=True, exact_shift=False)
-        leg = dense_leg(piqp_amd, pd, torch, np, q, n, 0, n, args.kkt_solver, False, 10, 2, rank, world, local_rank, dev, kernel_pass=0)
-        r = {"device_ms_per_step": leg["elapsed"] / 10 * 1e3, "device_assembly_ms": leg["asm_ms"], "device_factorisation_ms": leg["fac_ms"], "device_backend_solve_ms": leg["sol_ms"]}
+        # best of three runs of 5 steps (a run now and then carries a one-off host stall of tens of milliseconds -- the oracle's OpenMP team of the previous size
+        # winding down on the cores the device leg's host thread polls on -- which a mean over few sub-millisecond steps cannot absorb)
+        legs = [dense_leg(piqp_amd, pd, torch, np, q, n, 0, n, args.kkt_solver, False, 5, 2, rank, world, local_rank, dev, kernel_pass=0) for _ in range(3)]
+        leg = min(legs, key=lambda g: g["elapsed"])
+        r = {"device_ms_per_step": leg["elapsed"] / 5 * 1e3, "device_ms_per_step_runs": [g["elapsed"] / 5 * 1e3 for g in legs], "device_assembly_ms": leg["asm_ms"], "device_factorisation_ms": leg["fac_ms"],
+             "device_backend_solve_ms": leg["sol_ms"]}
         if not args.no_cpu_baseline and n <= 2048:
             od = pyorc.Data.dense(**q, L=L)
             rng = np.random.default_rng(1000)

@@ -993,9 +993,10 @@ __global__ __launch_bounds__(SUB_THREADS) void k_subtree_factor(FrontMeta M, dou
 // big front of the tree at the start of the factorisation.  The children are merged by one launch per level: column c of a front belongs to
 // workgroup c mod G of that front, which walks the children in order -- an entry receives its contributions in child order whatever the
 // grid (fixed summation order), and no two workgroups touch the same entry.
-__global__ __launch_bounds__(256) void k_big_zero(FrontMeta M, double* __restrict__ fronts, const int* __restrict__ list)
+__global__ __launch_bounds__(256) void k_big_zero(FrontMeta M, double* __restrict__ fronts, const int* __restrict__ list, int fuse)
 {
     const SnRec me = M.sn[list[blockIdx.y]];
+    if (fuse && me.child_hi > me.child_lo) return;  // written once by k_big_extend_add together with its first child (round 4)
     double* F = fronts + me.front_off;
     const int f = me.f;
     // the lower triangle only: nothing reads the strict upper triangle of a multi-workgroup front as a number (half the zero-fill traffic, which
@@ -1005,22 +1006,66 @@ __global__ __launch_bounds__(256) void k_big_zero(FrontMeta M, double* __restric
         for (int i = j + threadIdx.x; i < f; i += 256) Fj[i] = 0.0;
     }
 }
-__global__ __launch_bounds__(256) void k_big_assemble(FrontMeta M, double* __restrict__ fronts, const int* __restrict__ list)
+__global__ __launch_bounds__(256) void k_big_assemble(FrontMeta M, double* __restrict__ fronts, const int* __restrict__ list, int fuse)
 {
     const SnRec me = M.sn[list[blockIdx.y]];
+    if (fuse && me.child_hi > me.child_lo) return;
     double* F = fronts + me.front_off;
     for (int e = me.fe_lo + blockIdx.x * 256 + threadIdx.x; e < me.fe_hi; e += gridDim.x * 256) F[M.fe_off[e]] = M.vals[e];
 }
-__global__ __launch_bounds__(256) void k_big_extend_add(FrontMeta M, double* __restrict__ fronts, const int* __restrict__ list)
+// fuse (round 4): a front with children is not zero-filled in advance; this kernel WRITES every entry of its lower triangle once -- 0 + the first child's
+// contribution where the child has one, 0 elsewhere (inverse row map of the first child in LDS) --, adds the front's own K entries to the columns it owns and
+// goes on with the second child.  K + U1 and U1 + K are the same number, so the fronts are bitwise those of the zero-fill path; what goes away is the
+// zero-fill's write and the read half of the first child's read-modify-write (CONT-201: 50 MB + ~40 MB of 512 MB per factorisation).
+__global__ __launch_bounds__(256) void k_big_extend_add(FrontMeta M, double* __restrict__ fronts, const int* __restrict__ list, int fuse)
 {
     constexpr int OWN_CAP = 2048;
     __shared__ int own[OWN_CAP];
     __shared__ int nown;
+    extern __shared__ int inv[];  // fuse: front row -> row of the first child's update matrix (or -1)
     const SnRec me = M.sn[list[blockIdx.y]];
     const int f = me.f;
     double* F = fronts + me.front_off;
     const int G = gridDim.x, mine = blockIdx.x;
-    for (int ci = me.child_lo; ci < me.child_hi; ++ci) {
+    int cfirst = me.child_lo;
+    if (fuse && me.child_hi > me.child_lo) {
+        const SnRec ch = M.sn[M.child[me.child_lo]];
+        const int wc = ch.w, fc = ch.f, uc = fc - wc;
+        const double* U = fronts + ch.front_off + wc + (long long)wc * fc;
+        const int* rel = M.rel + ch.rel_ptr;
+        for (int i = threadIdx.x; i < f; i += 256) inv[i] = -1;
+        __syncthreads();
+        for (int j = threadIdx.x; j < uc; j += 256) inv[rel[j]] = j;
+        __syncthreads();
+        const int cnt = mine < f ? (f - mine + G - 1) / G : 0;  // columns mine, mine + G, ...
+        const int TX = cnt <= 4 ? 64 : 16, TY = 256 / TX;
+        const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+        for (int q = ty; q < cnt; q += TY) {
+            const int c = mine + q * G;
+            const int jc = inv[c];
+            double* __restrict__ Fc = F + (long long)c * f;
+            const double* __restrict__ Uj = U + (long long)(jc >= 0 ? jc : 0) * fc;
+            for (int i = c + tx; i < f; i += 4 * TX) {
+                double uv[4];
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const int iq = i + TX * q4;
+                    const int ic = (iq < f && jc >= 0) ? inv[iq] : -1;
+                    uv[q4] = ic >= 0 ? Uj[ic] : 0.0;
+                }
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) { const int iq = i + TX * q4; if (iq < f) Fc[iq] = 0.0 + uv[q4]; }
+            }
+        }
+        __syncthreads();
+        for (int e = me.fe_lo + threadIdx.x; e < me.fe_hi; e += 256) {
+            const int off = M.fe_off[e];
+            if ((off / f) % G == mine) F[off] += M.vals[e];
+        }
+        __syncthreads();
+        cfirst = me.child_lo + 1;
+    }
+    for (int ci = cfirst; ci < me.child_hi; ++ci) {
         const SnRec ch = M.sn[M.child[ci]];
         const int wc = ch.w, fc = ch.f, uc = fc - wc;
         const double* U = fronts + ch.front_off + wc + (long long)wc * fc;
@@ -2925,14 +2970,20 @@ private:
     // one launch per level of a (possibly filtered) level schedule for the fronts one workgroup factors; the level's big fronts then go through
     // the dense multi-workgroup kernels together: children merged (fixed order), then the blocked partial LDLt panel by panel
     // zero-fill, own K entries and step counters of the multi-workgroup fronts of a level schedule (nothing here depends on the children)
+    // (the inverse row map of the first child needs 4 f bytes of LDS next to the 8 KB column list)
+    static int fuse_first_child(const BigLevels& B)
+    {
+        static const bool off = debug_token("no_fused_first_child") != nullptr;  // bitwise variant test
+        return (!off && B.max_f <= 12000) ? 1 : 0;
+    }
     void big_prepare(const FrontMeta& M, const BigLevels& B, hipStream_t s)
     {
         if (B.total <= 0) return;
         PQ_HIP(hipMemsetAsync(B.cnt.p, 0, (size_t)B.total * dense::FRONT_CNT_INTS * dense::FRONT_CNT_PANELS * sizeof(int), s));
         for (int q0 = 0; q0 < B.total; q0 += 65535) {  // (grid.y limit)
             const int nq = std::min(65535, B.total - q0);
-            hipLaunchKernelGGL(k_big_zero, dim3((unsigned)std::min<long long>(256, ((long long)B.max_f * B.max_f + 255) / 256), nq), dim3(256), 0, s, M, fronts_.p, B.list.p + q0);
-            if (B.max_own > 0) hipLaunchKernelGGL(k_big_assemble, dim3(std::min(64, (B.max_own + 255) / 256), nq), dim3(256), 0, s, M, fronts_.p, B.list.p + q0);
+            hipLaunchKernelGGL(k_big_zero, dim3((unsigned)std::min<long long>(256, ((long long)B.max_f * B.max_f + 255) / 256), nq), dim3(256), 0, s, M, fronts_.p, B.list.p + q0, fuse_first_child(B));
+            if (B.max_own > 0) hipLaunchKernelGGL(k_big_assemble, dim3(std::min(64, (B.max_own + 255) / 256), nq), dim3(256), 0, s, M, fronts_.p, B.list.p + q0, fuse_first_child(B));
         }
     }
     void factor_levels(const FrontMeta& M, const std::vector<int>& ptr, const int* sn_dev, const std::vector<int>& lds, const BigLevels& B, int lend = 1 << 30, bool prepared = false)
@@ -2948,7 +2999,7 @@ private:
             static const char* ea_wide = debug_token("extend_add_wide");
             const int ea_big = ea_wide ? std::atoi(ea_wide) : 1024;
             const int ea_grid = debug_token("extend_add_grid64") ? 64 : (nbig <= 2 && B.total > 0 && B.lmaxf[l] >= 1536 && ea_big > 0 ? ea_big : (nbig <= 4 ? 256 : (nbig <= 16 ? 128 : 64)));
-            if (nbig > 0 && B.rounds[l] > 0) hipLaunchKernelGGL(k_big_extend_add, dim3(ea_grid, nbig), dim3(256), 0, st_, M, fronts_.p, B.list.p + B.ptr[l]);
+            if (nbig > 0 && B.rounds[l] > 0) hipLaunchKernelGGL(k_big_extend_add, dim3(ea_grid, nbig), dim3(256), fuse_first_child(B) ? B.lmaxf[l] * (int)sizeof(int) : 0, st_, M, fronts_.p, B.list.p + B.ptr[l], fuse_first_child(B));
             const bool small = cnt > nbig || (nbig > 0 && B.npanel[l] > 0);
             // the fronts one workgroup handles and the big fronts' first diagonal blocks + panels are independent: side by side on two streams,
             // joined before the trailing updates (which also carry the panel fronts' Schur complements)

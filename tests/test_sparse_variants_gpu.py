@@ -33,6 +33,7 @@ VARIANTS = {
     "front_no_step": {"PIQP_AMD_DEBUG": "front_no_step"},  # trailing updates of the top levels in their own launch instead of inside the panel step's
     "front_no_follow": {"PIQP_AMD_DEBUG": "front_no_follow"},  # diagonal block and panel rows of the big fronts in two launches instead of one with in-launch hand-over
     "extend_add_grid64": {"PIQP_AMD_DEBUG": "extend_add_grid64"},  # the children's update matrices merged on 64 workgroups per front at every level
+    "zero_fill_then_first_child": {"PIQP_AMD_DEBUG": "no_fused_first_child"},  # multi-workgroup fronts zero-filled in advance instead of written together with their first child
     "one_stream": {"PIQP_AMD_DEBUG": "no_fork"},  # the factorisation's second stream off (big fronts' diagonal blocks next to the one-workgroup fronts)
 }
 
@@ -68,6 +69,9 @@ def test_huge_fronts_substitution_agrees_with_the_per_pivot_routines(tmp_path):
     -- not bitwise: the backward column sums are formed chunk by chunk"""
     ref = _run(tmp_path, "huge_default", {}, "huge")
     assert float(ref["rel_residual"][0]) <= 1e-10, ref["rel_residual"]
+    zf = _run(tmp_path, "huge_zero_fill", {"PIQP_AMD_DEBUG": "no_fused_first_child"}, "huge")  # the factorisation's assembly variant: bitwise
+    for key in ref:
+        assert np.array_equal(zf[key], ref[key]), key
     got = _run(tmp_path, "huge_per_pivot", {"PIQP_AMD_DEBUG": "no_wide_solve"}, "huge")
     assert float(got["rel_residual"][0]) <= 1e-10, got["rel_residual"]
     for key in ref:
