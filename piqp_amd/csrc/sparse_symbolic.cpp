@@ -472,6 +472,13 @@ static void gram_structure(int n, int k, const int* MTp, const int* MTi, Symboli
     const int nnz = k ? MTp[k] : 0;
     for (int q = 0; q < nnz; ++q) rp[MTi[q] + 1]++;
     for (int j = 0; j < n; ++j) rp[j + 1] += rp[j];
+    {   // the term lists hold one triple per pair of entries of a constraint row: sum_c nnz_c (nnz_c + 1) / 2 of them.  Constraint rows with thousands of
+        // entries (an arrow of dense rows) make that billions -- the reference's A^T A would be a dense n x n matrix there as well; refuse instead of
+        // exhausting the host's memory (round 4: a 300 x 20 000 dense equality block asked for 6e10 triples and took the machine down)
+        double terms = 0.0;
+        for (int c = 0; c < k; ++c) { const double r = MTp[c + 1] - MTp[c]; terms += 0.5 * r * (r + 1.0); }
+        if (terms > 2.0e8) throw std::runtime_error("condensed KKT mode: the product pattern of the eliminated block needs more than 2e8 terms (constraint rows too dense); use sparse_ldlt (KKT_FULL)");
+    }
     IVec rk(nnz), rq(nnz), nx(rp.begin(), rp.end() - 1);
     for (int c = 0; c < k; ++c) for (int q = MTp[c]; q < MTp[c + 1]; ++q) { const int t = nx[MTi[q]]++; rk[t] = c; rq[t] = q; }
     Gm.colptr.assign(n + 1, 0);

@@ -155,3 +155,21 @@ def test_rccl_transport_with_a_one_rank_group(native):
     env["MASTER_PORT"] = "29672"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "nccl_world1_check.py")], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0 and "OK" in r.stdout, r.stderr[-2000:]
+
+
+def test_condensed_mode_refuses_dense_constraint_rows_instead_of_exhausting_memory():
+    """a block of dense equality rows makes A^T A dense; the term lists of the condensed modes would need billions of entries (the reference's own A^T A would be a
+    dense n x n matrix): the analysis refuses with an error instead of taking the host down (round 4), the KKT_FULL mode takes the same data"""
+    import scipy.sparse as sp
+    import piqp_amd as hip
+    from piqp_amd import _lib
+    rng = np.random.default_rng(0)
+    n, rows = 4000, 400
+    P = sp.diags([rng.uniform(1, 2, n)], [0], format="csc")
+    A = sp.csc_matrix(rng.standard_normal((rows, n)))
+    d = hip.SparseData(P, np.zeros(n), A, np.zeros(rows), None, None, None, None, None)
+    L = _lib.load()
+    desc = d.descriptor()
+    assert L.pq_sparse_partition_plan(C.byref(desc), 3, 1, None, 0, None) < 0
+    assert "2e8 terms" in L.pq_last_error_string().decode()
+    assert L.pq_sparse_partition_plan(C.byref(desc), 0, 1, None, 0, None) == n + rows
