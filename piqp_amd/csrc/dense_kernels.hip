@@ -414,7 +414,7 @@ __device__ __forceinline__ bool fused_tile(const SyrkArgs& a, const int ti, cons
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int gj = col0 + wc * SUBC + x * 16 + (lane >> 4) + 4 * r;
-                if (gi < a.n && gj < a.n && gi >= gj) {
+                if (gi < a.n && gj < a.n && gi >= gj && gj < a.ncol) {
                     double* cp = a.C + (size_t)gi + (size_t)gj * a.ldc;
                     if (PERSIST) st_agent(cp, acc[x][y][r]);
                     else if constexpr (SUMSUB) *(__attribute__((address_space(1))) double*)cp = cfetch[x][y][r] - acc[x][y][r];
@@ -479,6 +479,7 @@ __device__ __forceinline__ void syrk_lower_body(const SyrkArgs& a, const int blo
     }
     if (a.first_col_only) { ti = b; tj = 0; }
     const int row0 = ti * TS, col0 = tj * TS;
+    if (col0 >= a.ncol) return;  // (a tile column beyond the written columns)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave / WC, wc = wave % WC;
@@ -562,7 +563,7 @@ __device__ __forceinline__ void syrk_lower_body(const SyrkArgs& a, const int blo
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int gj = col0 + wc * SUBC + x * 16 + (lane >> 4) + 4 * r;
-                if (gi < a.n && gj < a.n && gi >= gj) {
+                if (gi < a.n && gj < a.n && gi >= gj && gj < a.ncol) {
                     const size_t ci = (size_t)gi + (size_t)gj * a.ldc;
                     const double v = acc[x][y][r];
                     if (EPI == EPI_ASSEMBLE) {
@@ -609,10 +610,36 @@ __global__ __launch_bounds__(64 * WR * WC, (WR * WC == 4) ? 2 : (WR * WC == 8 ? 
     if ((int)blockIdx.x >= T * (T + 1) / 2) return;
     SyrkArgs a;
     a.n = rs; a.kdim = nb;
-    a.A = j.F + (k + nb) + (size_t)k * j.f; a.lda = j.f; a.B = a.A; a.ldb = j.f; a.w = j.dvec;
+    a.A = j.F + (k + nb) + (size_t)k * j.f; a.lda = j.f; a.B = a.A; a.ldb = j.f; a.w = j.dvec + k;
     a.C = j.F + (k + nb) + (size_t)(k + nb) * j.f; a.ldc = j.f;
     a.unaligned = ((j.f & 1) || (reinterpret_cast<uintptr_t>(a.A) & 15)) ? 1 : 0;
+    if (j.multi) {  // the update-matrix region [w, f)^2 receives all panels in ONE pass after the last panel (k_syrk_multi_fronts): here only the pivot columns still to come
+        a.ncol = j.w - (k + nb);
+        if (a.ncol <= 0) return;
+    }
     syrk_lower_body<EPI_SUBTRACT, WR, WC>(a, (int)blockIdx.x);
+}
+// round 4: the update-matrix region of the fronts with several panels (FrontJob::multi), every panel's products tile by tile in panel order -- the tile is read from
+// and written to HBM once instead of once per panel (it stays in the L2 between the panels); the sums are those of the per-panel launches: each panel's
+// products summed from zero in k order and subtracted, panel after panel
+template <int WR, int WC>
+__global__ __launch_bounds__(64 * WR * WC, (WR * WC == 4) ? 2 : (WR * WC == 8 ? 2 : 4)) void k_syrk_multi_fronts(const FrontJob* __restrict__ jobs)
+{
+    const FrontJob j = jobs[blockIdx.y];
+    if (!j.multi || j.kind != 0) return;
+    const int u = j.f - j.w;
+    const int T = (u + TS - 1) / TS;
+    if (u <= 0 || (int)blockIdx.x >= T * (T + 1) / 2) return;
+    for (int k = 0; k < j.w; k += FACTOR_NB) {
+        SyrkArgs a;
+        a.n = u; a.kdim = min(FACTOR_NB, j.w - k);
+        a.A = j.F + j.w + (size_t)k * j.f; a.lda = j.f; a.B = a.A; a.ldb = j.f; a.w = j.dvec + k;
+        a.C = j.F + j.w + (size_t)j.w * j.f; a.ldc = j.f;
+        a.unaligned = ((j.f & 1) || (reinterpret_cast<uintptr_t>(a.A) & 15)) ? 1 : 0;
+        syrk_lower_body<EPI_SUBTRACT, WR, WC>(a, (int)blockIdx.x);
+        __threadfence_block();
+        __syncthreads();  // this workgroup's stores of panel k before its loads of the next panel; the LDS stages are free again
+    }
 }
 
 // The same update for the levels near the root of an assembly tree, where a handful of tiles is all there is and 250 CUs idle: two workgroups per tile (rows
@@ -636,9 +663,13 @@ __global__ __launch_bounds__(512) void k_syrk_half_fronts(const FrontJob* __rest
     if (ti * TS + (TS / SPLIT) * h >= rs) return;  // (nothing in this part)
     SyrkArgs a;
     a.n = rs; a.kdim = nb;
-    a.A = j.F + (k + nb) + (size_t)k * j.f; a.lda = j.f; a.B = a.A; a.ldb = j.f; a.w = j.dvec;
+    a.A = j.F + (k + nb) + (size_t)k * j.f; a.lda = j.f; a.B = a.A; a.ldb = j.f; a.w = j.dvec + k;
     a.C = j.F + (k + nb) + (size_t)(k + nb) * j.f; a.ldc = j.f;
     a.unaligned = ((j.f & 1) || (reinterpret_cast<uintptr_t>(a.A) & 15)) ? 1 : 0;
+    if (j.multi) {  // (see k_syrk_lower_fronts)
+        a.ncol = j.w - (k + nb);
+        if (a.ncol <= 0 || tj * TS >= a.ncol) return;
+    }
     extern __shared__ __attribute__((aligned(16))) double smem[];
     (void)fused_tile<512, false, true, true, SPLIT == 4>(a, ti, tj, smem, h);
 }
@@ -1372,7 +1403,7 @@ __global__ __launch_bounds__(POTRF_THREADS) void k_potrf_diag_fronts(const Front
     const FrontJob j = jobs[blockIdx.x];
     int k, nb, rs;
     if (j.kind != 0 || !front_panel(j, panel, k, nb, rs)) return;
-    potrf_diag_body<true>(j.F + k + (size_t)k * j.f, j.f, nb, j.first + k, info, rdiag, j.dvec, rs > 0 ? j.pack : nullptr, nullptr, nullptr, min(8, (nb + 15) >> 4));
+    potrf_diag_body<true>(j.F + k + (size_t)k * j.f, j.f, nb, j.first + k, info, rdiag, j.dvec + k, rs > 0 ? j.pack : nullptr, nullptr, nullptr, min(8, (nb + 15) >> 4));
 }
 
 void launch_potrf_diag(bool ldlt, double* A, int lda, int nb, int kglobal, int* info, double* rdiag, double* dvec, double* pack, double* w16, hipStream_t s, long long* ts)
@@ -2869,7 +2900,7 @@ __global__ __launch_bounds__(POTRF_THREADS) void k_potrf_trsm_fronts(const Front
     if (j.kind != 0 || !front_panel(j, panel, k, nb, rs)) return;
     int* cnt = j.cnt + FRONT_CNT_INTS * panel;
     if (blockIdx.x == 0) {
-        potrf_diag_body<true>(j.F + k + (size_t)k * j.f, j.f, nb, j.first + k, info, rdiag, j.dvec, rs > 0 ? j.pack : nullptr, nullptr, nullptr, min(8, (nb + 15) >> 4), rs > 0 ? cnt : nullptr, true);
+        potrf_diag_body<true>(j.F + k + (size_t)k * j.f, j.f, nb, j.first + k, info, rdiag, j.dvec + k, rs > 0 ? j.pack : nullptr, nullptr, nullptr, min(8, (nb + 15) >> 4), rs > 0 ? cnt : nullptr, true);
         return;
     }
     const int strip = (int)blockIdx.x - 1;
@@ -2892,7 +2923,7 @@ __global__ __launch_bounds__(POTRF_THREADS) void k_front_panel_step(const FrontJ
     int* done = cnt + 32;  // [strip][step]: waves of the strip whose 16 columns of that step have landed
     const int bx = (int)blockIdx.x;
     if (bx == 0) {
-        potrf_diag_body<true>(j.F + k + (size_t)k * j.f, j.f, nb, j.first + k, info, rdiag, j.dvec, rs > 0 ? j.pack : nullptr, nullptr, nullptr, min(8, (nb + 15) >> 4), rs > 0 ? cnt : nullptr, true);
+        potrf_diag_body<true>(j.F + k + (size_t)k * j.f, j.f, nb, j.first + k, info, rdiag, j.dvec + k, rs > 0 ? j.pack : nullptr, nullptr, nullptr, min(8, (nb + 15) >> 4), rs > 0 ? cnt : nullptr, true);
         return;
     }
     if (bx <= nstrips) {
@@ -2912,7 +2943,7 @@ __global__ __launch_bounds__(POTRF_THREADS) void k_front_panel_step(const FrontJ
     if (ti * TS + (TS / SPLIT) * h >= rs) return;  // (nothing in this part)
     SyrkArgs a;
     a.n = rs; a.kdim = nb;
-    a.A = j.F + (k + nb) + (size_t)k * j.f; a.lda = j.f; a.B = a.A; a.ldb = j.f; a.w = j.dvec;
+    a.A = j.F + (k + nb) + (size_t)k * j.f; a.lda = j.f; a.B = a.A; a.ldb = j.f; a.w = j.dvec + k;
     a.C = j.F + (k + nb) + (size_t)(k + nb) * j.f; a.ldc = j.f;
     a.unaligned = ((j.f & 1) || (reinterpret_cast<uintptr_t>(a.A) & 15)) ? 1 : 0;
     a.late_p[0] = done + 8 * ti; a.late_w[0] = POTRF_THREADS / 64; a.late_p[1] = done + 8 * tj; a.late_w[1] = POTRF_THREADS / 64;
@@ -2978,6 +3009,15 @@ void launch_front_updates(const FrontJob* jobs, int njobs, int panel, int max_ro
         return;
     }
     hipLaunchKernelGGL((k_syrk_lower_fronts<4, 4>), dim3(T * (T + 1) / 2, njobs), dim3(1024), SYRK_LDS_BYTES, s, jobs, panel, kind);
+    PQ_HIP(hipGetLastError());
+}
+
+void launch_front_updates_multi(const FrontJob* jobs, int njobs, int max_update_rows, hipStream_t s)
+{
+    if (njobs <= 0 || max_update_rows <= 0) return;
+    front_attrs();
+    const int T = div_up(max_update_rows, TS);
+    hipLaunchKernelGGL((k_syrk_multi_fronts<4, 4>), dim3(T * (T + 1) / 2, njobs), dim3(1024), SYRK_LDS_BYTES, s, jobs);
     PQ_HIP(hipGetLastError());
 }
 

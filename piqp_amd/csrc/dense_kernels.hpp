@@ -21,6 +21,7 @@ struct SyrkArgs {
     const double* ATA = nullptr; int ldata = 0;
     double dinv = 0.0;
     int unaligned = 0;  // set by the launcher
+    int ncol = 1 << 30; // only the columns [0, ncol) of C are written (the trailing updates of the sparse fronts with several panels)
     // tail balancing (set by the launcher): blocks [0, ...) of a split launch handle tile `tile_begin + b / k_split`,
     // K-slice `b % k_split`, and write raw 128x128 partial tiles to `part` instead of running the epilogue
     int tile_begin = 0;
@@ -119,9 +120,11 @@ struct FrontJob {
     double* F = nullptr;
     int f = 0, w = 0, first = 0;  // order, pivot columns, global index of the first pivot (rdiag / info)
     double* pack = nullptr;       // FACTOR_PACK_DOUBLES of scratch owned by this front for the duration of the level
-    double* dvec = nullptr;       // FACTOR_NB doubles, likewise: D of the current panel
+    double* dvec = nullptr;       // w doubles (rounded up to FACTOR_NB), likewise: D of the front, panel p at dvec + p * FACTOR_NB
     int kind = 0;                 // 0: diagonal block + panel by launch_front_diag_panels; 1: the caller factors the (single, w <= FACTOR_NB) panel
                                   //    itself and leaves D in dvec -- only the trailing update runs here
+    int multi = 0;                // 1: several panels and an update matrix -- the per-panel trailing updates write the remaining pivot columns only, the region
+                                  //    [w, f)^2 receives every panel in one pass after the last one (launch_front_updates_multi)
     int* cnt = nullptr;           // FRONT_CNT_INTS x FRONT_CNT_PANELS counters of this front's panels (zeroed by the caller before every factorisation): per panel
                                   //    [0, 8) steps of the diagonal block, [8] a word only a wait that gave up sets, [32, 160) per 128-row strip below it (<= 16) and
                                   //    step: waves whose 16 solved columns have landed -- the panel rows follow the diagonal block inside one launch
@@ -133,6 +136,7 @@ void launch_front_diag_panels(const FrontJob* jobs_device, int njobs, int panel,
 void launch_front_updates(const FrontJob* jobs_device, int njobs, int panel, int max_rows_below, hipStream_t s, int kind = -1);  // kind: only the fronts of that kind
 // diagonal blocks, panel rows and trailing updates of panel `panel` in ONE launch, where the level is a handful of big fronts (kind 0 only, zeroed counters); false:
 // not applicable -- the caller runs launch_front_diag_panels + launch_front_updates
+void launch_front_updates_multi(const FrontJob* jobs_device, int njobs, int max_update_rows, hipStream_t s);  // the fronts with FrontJob::multi, after their last panel
 bool launch_front_panel_step(const FrontJob* jobs_device, int njobs, int panel, int max_rows_below, int* info, double* rdiag, hipStream_t s);  // T -= L D L^T of panel `panel`, all fronts
 
 }  // namespace dense

@@ -2897,7 +2897,7 @@ private:
         return tree_has_big_ == 1 && panel_front(f, w);
     }
     struct BigLevels {
-        std::vector<int> ptr, rounds, ndense, npanel, panel_lds, lmaxf;  // level l of the schedule -> jobs [ptr[l], ptr[l + 1]); children of its widest fan-in; jobs by kind; LDS of k_front_panel
+        std::vector<int> ptr, rounds, ndense, npanel, panel_lds, lmaxf, multi_rows;  // multi_rows[l] > 0: the level's multi-panel fronts take their update matrices in one pass (most update rows)  // level l of the schedule -> jobs [ptr[l], ptr[l + 1]); children of its widest fan-in; jobs by kind; LDS of k_front_panel
         std::vector<std::vector<int>> rows_below;  // per level, per panel: most rows below the diagonal block over the level's fronts (0 = none)
         int total = 0, max_f = 0, max_own = 0;
         DBuf<int> list, job_of;  // job_of[s] = index into jobs, -1 for the fronts one workgroup handles alone
@@ -2907,7 +2907,7 @@ private:
     };
     void build_big_levels(const std::vector<int>& ptr, const std::vector<int>& sn, BigLevels& B)
     {
-        B.ptr.assign(1, 0); B.rounds.clear(); B.rows_below.clear(); B.ndense.clear(); B.npanel.clear(); B.panel_lds.clear(); B.lmaxf.clear(); B.total = 0; B.max_f = 0; B.max_own = 0;
+        B.ptr.assign(1, 0); B.rounds.clear(); B.rows_below.clear(); B.ndense.clear(); B.npanel.clear(); B.panel_lds.clear(); B.lmaxf.clear(); B.multi_rows.clear(); B.total = 0; B.max_f = 0; B.max_own = 0;
         std::vector<int> list;
         int widest = 0;
         for (int l = 0; l + 1 < (int)ptr.size(); ++l) {
@@ -2928,6 +2928,24 @@ private:
                 }
             }
             B.ptr.push_back((int)list.size()); B.rounds.push_back(rounds); B.rows_below.push_back(rb); B.lmaxf.push_back(lf);
+            {   // one pass over the update matrices of the level's multi-panel fronts (dense::launch_front_updates_multi) where the level is too wide for the
+                // one-launch panel step (that path keeps its per-panel tiles: it is bound by the chain of its few fronts, not by traffic)
+                // MEASURED SLOWER and therefore opt-in (PIQP_AMD_DEBUG=multi_update; bitwise equal, variant test): wide C3 variant 6.56 -> 6.97 ms, 1500-window
+                // variant 53.3 -> 57.3 ms per factorisation -- the trailing updates of these levels are not bound by HBM traffic (the tiles of a panel launch
+                // come from the L2 / Infinity Cache the previous launch left them in), and a tile's panels one after the other in one workgroup expose the
+                // read-modify-write of every panel
+                static const bool off = debug_token("multi_update") == nullptr;
+                const int nb0 = (int)list.size() - B.ptr[l];
+                const int T0 = rb.empty() ? 0 : (rb[0] + 127) / 128;
+                const bool step_ok = nb0 > 0 && T0 > 0 && T0 <= 16 && (long long)nb0 * T0 * (T0 + 1) <= 256;
+                int mr = 0;
+                if (!off && !step_ok && rb.size() >= 2)
+                    for (int q = B.ptr[l]; q < (int)list.size(); ++q) {
+                        const int s2 = list[q], w2 = S_.sn_first[s2 + 1] - S_.sn_first[s2], f2 = S_.front_rows_ptr[s2 + 1] - S_.front_rows_ptr[s2];
+                        if (!panel_front(f2, w2) && w2 > dense::FACTOR_NB && f2 > w2) mr = std::max(mr, f2 - w2);
+                    }
+                B.multi_rows.push_back(mr);
+            }
             B.ndense.push_back(nd); B.npanel.push_back(np); B.panel_lds.push_back((int)((plds + IND_SCRATCH) * (long long)sizeof(double)));
             widest = std::max(widest, B.ptr[l + 1] - B.ptr[l]);
             if (B.ptr[l + 1] - B.ptr[l] > 65535) throw std::runtime_error("sparse backend: more than 65535 multi-workgroup fronts on one level of the assembly tree");
@@ -2935,24 +2953,30 @@ private:
         B.total = (int)list.size();
         if (B.total == 0) return;
         // scratch of a level: D (FACTOR_NB doubles) for every front, the operand pack of the panel solve for the dense-path fronts only
+        // (D of EVERY panel of a front is kept until the level is done: w doubles rounded up to the panel width)
+        auto dpad = [&](int s2) { const int w2 = S_.sn_first[s2 + 1] - S_.sn_first[s2]; return (size_t)std::max(1, (w2 + dense::FACTOR_NB - 1) / dense::FACTOR_NB) * dense::FACTOR_NB; };
         size_t need = 0;
-        for (size_t l = 0; l < B.ndense.size(); ++l)
-            need = std::max(need, (size_t)(B.ndense[l] + B.npanel[l]) * dense::FACTOR_NB + (size_t)B.ndense[l] * dense::FACTOR_PACK_DOUBLES);
+        std::vector<size_t> dtot(B.ndense.size(), 0);
+        for (size_t l = 0; l < B.ndense.size(); ++l) {
+            for (int q = B.ptr[l]; q < B.ptr[l + 1]; ++q) dtot[l] += dpad(list[q]);
+            need = std::max(need, dtot[l] + (size_t)B.ndense[l] * dense::FACTOR_PACK_DOUBLES);
+        }
         B.scratch.alloc(need);
         (void)widest;
         std::vector<dense::FrontJob> jobs(B.total);
         B.cnt.alloc((size_t)B.total * dense::FRONT_CNT_INTS * dense::FRONT_CNT_PANELS);
         for (int l = 0; l + 1 < (int)B.ptr.size(); ++l) {
-            const int nl = B.ptr[l + 1] - B.ptr[l];
-            double* packs = B.scratch.p + (size_t)nl * dense::FACTOR_NB;
+            double* packs = B.scratch.p + dtot[l];
             int nd = 0;
+            size_t doff = 0;
             for (int q = B.ptr[l]; q < B.ptr[l + 1]; ++q) {
                 const int s = list[q];
                 dense::FrontJob& j = jobs[q];
                 j.F = fronts_.p + S_.front_off[s];
                 j.f = S_.front_rows_ptr[s + 1] - S_.front_rows_ptr[s]; j.w = S_.sn_first[s + 1] - S_.sn_first[s]; j.first = S_.sn_first[s];
                 j.kind = panel_front(j.f, j.w) ? 1 : 0;
-                j.dvec = B.scratch.p + (size_t)(q - B.ptr[l]) * dense::FACTOR_NB;
+                j.multi = (B.multi_rows[l] > 0 && j.kind == 0 && j.w > dense::FACTOR_NB && j.f > j.w) ? 1 : 0;
+                j.dvec = B.scratch.p + doff; doff += dpad(s);
                 j.pack = j.kind == 0 ? packs + (size_t)(nd++) * dense::FACTOR_PACK_DOUBLES : nullptr;
                 j.cnt = B.cnt.p + (size_t)q * dense::FRONT_CNT_INTS * dense::FRONT_CNT_PANELS;
             }
@@ -3025,7 +3049,7 @@ private:
                 // waiting for the 45-65 us pivot loops of the panel fronts at ten levels of CONT-201.)
                 const bool split = fork && pn == 0 && B.npanel[l] > 0 && B.ndense[l] > 0 && !joint_updates;
                 bool done_big = false;
-                if (B.ndense[l] > 0 && (B.npanel[l] == 0 || split || pn > 0))  // (a panel front has one panel: nothing of its kind beyond pn = 0)
+                if (B.ndense[l] > 0 && (B.npanel[l] == 0 || split || pn > 0) && B.multi_rows[l] == 0)  // (a panel front has one panel: nothing of its kind beyond pn = 0)
                     done_big = dense::launch_front_panel_step(B.jobs.p + B.ptr[l], nbig, pn, B.rows_below[l][pn], info_.p, rdiag_.p, st_);
                 if (!done_big) {
                     if (B.ndense[l] > 0) dense::launch_front_diag_panels(B.jobs.p + B.ptr[l], nbig, pn, B.rows_below[l][pn], info_.p, rdiag_.p, st_, true);
@@ -3035,6 +3059,7 @@ private:
                 if (split) dense::launch_front_updates(B.jobs.p + B.ptr[l], nbig, pn, B.rows_below[l][pn], st_, 1);
                 else if (!done_big) dense::launch_front_updates(B.jobs.p + B.ptr[l], nbig, pn, B.rows_below[l][pn], st_);
             }
+            if (B.multi_rows[l] > 0) dense::launch_front_updates_multi(B.jobs.p + B.ptr[l], nbig, B.multi_rows[l], st_);
         }
     }
     // Substitution by levels: the fronts of a level with at most 128 rows go through the single-wave kernels (one wave per front, vector in

@@ -34,6 +34,7 @@ VARIANTS = {
     "front_no_follow": {"PIQP_AMD_DEBUG": "front_no_follow"},  # diagonal block and panel rows of the big fronts in two launches instead of one with in-launch hand-over
     "extend_add_grid64": {"PIQP_AMD_DEBUG": "extend_add_grid64"},  # the children's update matrices merged on 64 workgroups per front at every level
     "zero_fill_then_first_child": {"PIQP_AMD_DEBUG": "no_fused_first_child"},  # multi-workgroup fronts zero-filled in advance instead of written together with their first child
+    "update_matrices_in_one_pass": {"PIQP_AMD_DEBUG": "multi_update"},  # the update matrix of a multi-panel front updated in one pass after the last panel instead of once per panel (opt-in: slower)
     "one_stream": {"PIQP_AMD_DEBUG": "no_fork"},  # the factorisation's second stream off (big fronts' diagonal blocks next to the one-workgroup fronts)
 }
 
@@ -72,6 +73,9 @@ def test_huge_fronts_substitution_agrees_with_the_per_pivot_routines(tmp_path):
     zf = _run(tmp_path, "huge_zero_fill", {"PIQP_AMD_DEBUG": "no_fused_first_child"}, "huge")  # the factorisation's assembly variant: bitwise
     for key in ref:
         assert np.array_equal(zf[key], ref[key]), key
+    pp = _run(tmp_path, "huge_one_pass", {"PIQP_AMD_DEBUG": "multi_update"}, "huge")  # update matrices in one pass after the last panel (opt-in): bitwise
+    for key in ref:
+        assert np.array_equal(pp[key], ref[key]), key
     got = _run(tmp_path, "huge_per_pivot", {"PIQP_AMD_DEBUG": "no_wide_solve"}, "huge")
     assert float(got["rel_residual"][0]) <= 1e-10, got["rel_residual"]
     for key in ref:
