@@ -1,7 +1,6 @@
 cd $GRAFT_REPO_ROOT
 ulimit -v 100000000
-for t in "" multi_update=2; do
-echo "== $t"
-PIQP_AMD_DEBUG=$t timeout 600 python3 tools/prof_sparse.py --spread 300 --row-nnz 10 --no-oracle --reps 5 2>&1 | grep "^device: factor" | cut -c1-200
-PIQP_AMD_DEBUG=$t timeout 600 python3 tools/prof_sparse.py --spread 1500 --row-nnz 10 --no-oracle --reps 2 2>&1 | grep "^device: factor" | cut -c1-200
+for lib in piqp_amd/lib/exp/libpiqp_amd_base.so piqp_amd/lib/libpiqp_amd.so; do
+echo "== $lib"
+PIQP_AMD_LIB=$PWD/$lib PIQP_AMD_DEBUG=trsv_ts timeout 300 python3 tools/prof_dense.py 4096 4096 0 1 0 2>&1 | grep "piqp_amd\]" | tail -2 | cut -c1-700
 done
