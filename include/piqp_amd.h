@@ -219,7 +219,10 @@ int pq_kkt_set_comm_rccl(pq_kkt *k, const unsigned char id[128], int rank, int w
  * through the same callback (register buf_norm after pq_kkt_set_exchange) or, with the native transport, ncclAllReduce(max) on the library's own buffer.  No halo
  * exchange is needed: the solution vectors are replicated (which = 2 gathers them), so every rank reads what its rows touch.  Without a registered buffer, for the
  * condensed KKT modes, or with PIQP_AMD_DEBUG=replicated_residual the residual is evaluated on every row by every rank as before.  The results are bitwise those of
- * the replicated evaluation (tests/test_partition.py).  pq_kkt_sharded_calls: out[0] = sharded residual evaluations so far, out[1] = rows in this rank's share. */
+ * the replicated evaluation (tests/test_partition.py).  pq_kkt_sharded_calls: out[0] = sharded residual evaluations so far, out[1] = rows in this rank's share.
+ * Condensed KKT modes and sparse_multistage (tree engine): a partitioned handle re-evaluates, per factorisation, only the values of the fronts it factors (P entries,
+ * delta^-1 A^T A entries, G^T W G product terms, diagonal shifts selected by destination front); there pq_kkt_sharded_calls reports out[0] = such assemblies so far,
+ * out[1] = source entries this rank evaluates (a partition of one rank selects all of them). */
 int pq_kkt_set_exchange_norm(pq_kkt *k, double *buf_norm);
 int pq_kkt_sharded_calls(pq_kkt *k, int out[2]);
 /* test hook (sparse backends): smallest |pivot| of the last factorisation */

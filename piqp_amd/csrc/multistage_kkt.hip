@@ -247,6 +247,7 @@ public:
         if (!tree_) throw std::runtime_error("partition_info: not partitioned");
         tree_->partition_info(out);
     }
+    void sharded_calls(int out[2]) const override { if (tree_) tree_->sharded_calls(out); else out[0] = out[1] = 0; }  // (the tree engine's sharded value assembly)
 
     // multistage_kkt.hpp:385-393 (same text), plus where the chain runs
     void print_info() override

@@ -123,11 +123,13 @@ __global__ void k_norm_to_buf(const unsigned long long* __restrict__ bits, doubl
     const double v = __longlong_as_double((long long)bits[0]);
     buf[0] = v != v ? __builtin_huge_val() : v;
 }
+// (sel != nullptr, here and in the two kernels below: only the listed columns / entries -- the value assembly of a stage-partitioned handle)
 __global__ void k_cond_diag(int n, int np, int nm, const int* __restrict__ diag_pos, const double* __restrict__ x_reg, double delta, const double* __restrict__ z_reg,
-                            double* __restrict__ vals)
+                            double* __restrict__ vals, const int* __restrict__ sel = nullptr, int nsel = 0)
 {
-    const int col = blockIdx.x * blockDim.x + threadIdx.x;
-    if (col >= n + np + nm) return;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (sel ? nsel : n + np + nm)) return;
+    const int col = sel ? sel[idx] : idx;
     if (col < n) vals[diag_pos[col]] += x_reg[col];
     else if (col < n + np) vals[diag_pos[col]] = -delta;
     else vals[diag_pos[col]] = -z_reg[col - n - np];
@@ -136,19 +138,28 @@ __global__ void k_cond_diag(int n, int np, int nm, const int* __restrict__ diag_
 // w == nullptr: unit weights.  out[e] (ACC: += alpha * sum, through the index map dst) 
 template <bool MAPPED>
 __global__ void k_gram_values(int nent, const int* __restrict__ ptr, const int* __restrict__ q1, const int* __restrict__ q2, const int* __restrict__ kk,
-                              const double* __restrict__ x, const double* __restrict__ w, const int* __restrict__ dst, double* __restrict__ out)
+                              const double* __restrict__ x, const double* __restrict__ w, const int* __restrict__ dst, double* __restrict__ out,
+                              const int* __restrict__ sel = nullptr)
 {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= nent) return;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nent) return;
+    const int e = sel ? sel[idx] : idx;
     double s = 0.0;
     if (w) for (int t = ptr[e]; t < ptr[e + 1]; ++t) s += x[q2[t]] * x[q1[t]] / w[kk[t]];
     else for (int t = ptr[e]; t < ptr[e + 1]; ++t) s += x[q2[t]] * x[q1[t]];
     if (MAPPED) out[dst[e]] += s; else out[e] = s;
 }
-__global__ void k_axpy_mapped(int nent, const int* __restrict__ dst, double alpha, const double* __restrict__ src, double* __restrict__ out)
+__global__ void k_axpy_mapped(int nent, const int* __restrict__ dst, double alpha, const double* __restrict__ src, double* __restrict__ out, const int* __restrict__ sel = nullptr)
 {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < nent) out[dst[e]] += alpha * src[e];
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nent) return;
+    const int e = sel ? sel[idx] : idx;
+    out[dst[e]] += alpha * src[e];
+}
+__global__ void k_remap_values_sel(int nsel, const int* __restrict__ sel, const int* __restrict__ dst_idx, const double* __restrict__ src, double* __restrict__ dst)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < nsel) { const int q = sel[idx]; dst[dst_idx[q]] = src[q]; }
 }
 __global__ void k_reciprocal(int m, const double* __restrict__ z, double* __restrict__ zinv)
 {
@@ -2248,6 +2259,20 @@ public:
             hipLaunchKernelGGL(k_set_diag_list, g1(need_all_n_), dim3(256), 0, st_, need_all_n_, need_all_.p, n_, p_, diag_pos_.p, ops_.P_diag(), x_reg, delta, z_reg, vals_.p);
         } else if (mode_ == 0) {
             hipLaunchKernelGGL(k_set_diag, g1(N_), dim3(256), 0, st_, n_, p_, m_, diag_pos_.p, ops_.P_diag(), x_reg, delta, z_reg, vals_.p);
+        } else if (part_on_ && world_ > 1 && sel_ready_ && !full_diag) {
+            // stage partition, condensed modes: the values of the fronts this rank factors (its own subtrees and the shared top) only -- the same
+            // kernels over the lists of source entries whose destination lies in such a front; the other fronts' values are never read on this rank
+            const bool eq = mode_ & 1, ineq = mode_ & 2;
+            if (m_ > 0) hipLaunchKernelGGL(k_reciprocal, g1(m_), dim3(256), 0, st_, m_, z_reg, zinv_.p);
+            for (const auto& r : own_val_ranges_) PQ_HIP(hipMemsetAsync(vals_.p + r.first, 0, sizeof(double) * (r.second - r.first), st_));
+            if (selP_n_) hipLaunchKernelGGL(k_remap_values_sel, g1(selP_n_), dim3(256), 0, st_, selP_n_, selP_.p, mapP_.p, ops_.P_x(), vals_.p);
+            if (selD_n_) hipLaunchKernelGGL(k_cond_diag, g1(selD_n_), dim3(256), 0, st_, n_, eq ? 0 : p_, ineq ? 0 : m_, diag_pos_.p, x_reg, delta, z_reg, vals_.p, selD_.p, selD_n_);
+            if (eq) { if (selAA_n_) hipLaunchKernelGGL(k_axpy_mapped, g1(selAA_n_), dim3(256), 0, st_, selAA_n_, mapAA_.p, 1.0 / delta, ata_vals_.p, vals_.p, selAA_.p); }
+            else if (selA_n_) hipLaunchKernelGGL(k_remap_values_sel, g1(selA_n_), dim3(256), 0, st_, selA_n_, selA_.p, mapA_.p, ops_.AT_x(), vals_.p);
+            if (ineq) {
+                if (selGG_n_) hipLaunchKernelGGL(k_gram_values<true>, g1(selGG_n_), dim3(256), 0, st_, selGG_n_, gg_ptr_.p, gg_q1_.p, gg_q2_.p, gg_k_.p, ops_.GT_x(), z_reg, mapGG_.p, vals_.p, selGG_.p);
+            } else if (selG_n_) hipLaunchKernelGGL(k_remap_values_sel, g1(selG_n_), dim3(256), 0, st_, selG_n_, selG_.p, mapG_.p, ops_.GT_x(), vals_.p);
+            ++sharded_asm_;
         } else {
             // update_kkt_cost_scalings / _equality_scalings / _inequality_scaling of the mode, in the reference's accumulation order
             const bool eq = mode_ & 1, ineq = mode_ & 2;
@@ -2422,6 +2447,37 @@ public:
             }
             upload_vec(need_x_, nx, st_); upload_vec(need_y_, ny, st_); upload_vec(need_z_, nz, st_); upload_vec(need_all_, nall, st_);
             need_x_n_ = (int)nx.size(); need_y_n_ = (int)ny.size(); need_z_n_ = (int)nz.size(); need_all_n_ = (int)nall.size();
+            sel_ready_ = false; sharded_asm_ = 0; own_val_ranges_.clear();
+            selP_n_ = selA_n_ = selG_n_ = selAA_n_ = selGG_n_ = selD_n_ = 0;
+            if (mode_ != 0) {
+                // condensed modes: the value array is stored front by front (position e holds PKPt entry fe_q[e]); a position is needed here when its front is
+                const bool eq = mode_ & 1, ineq = mode_ & 2;
+                std::vector<char> needed((size_t)std::max(nnzK_, 1), 0);
+                for (int sn = 0; sn + 1 < (int)S_.sn_first.size(); ++sn) {
+                    if (PT_.owner[sn] != rank && PT_.owner[sn] >= 0) continue;
+                    const int lo = S_.fe_ptr[sn], hi = S_.fe_ptr[sn + 1];
+                    for (int e = lo; e < hi; ++e) needed[e] = 1;
+                    if (hi > lo) {
+                        if (!own_val_ranges_.empty() && own_val_ranges_.back().second == (size_t)lo) own_val_ranges_.back().second = (size_t)hi;
+                        else own_val_ranges_.push_back({(size_t)lo, (size_t)hi});
+                    }
+                }
+                std::vector<int> pos((size_t)std::max(nnzK_, 1), 0);
+                for (int e = 0; e < nnzK_; ++e) pos[S_.fe_q[e]] = e;
+                auto pick = [&](size_t count, auto&& dest_of, DBuf<int>& buf, int& cnt) {
+                    std::vector<int> sel;
+                    for (size_t q = 0; q < count; ++q) if (needed[pos[dest_of(q)]]) sel.push_back((int)q);
+                    cnt = (int)sel.size();
+                    upload_vec(buf, sel, st_);
+                };
+                pick((size_t)ops_.nzP(), [&](size_t q) { return S_.PKi[S_.P_utri_to_Ki[q]]; }, selP_, selP_n_);
+                if (!eq) pick((size_t)ops_.nzA(), [&](size_t q) { return S_.PKi[S_.AT_to_Ki[q]]; }, selA_, selA_n_);
+                if (!ineq) pick((size_t)ops_.nzG(), [&](size_t q) { return S_.PKi[S_.GT_to_Ki[q]]; }, selG_, selG_n_);
+                if (eq) pick((size_t)nzAA_, [&](size_t e) { return S_.PKi[S_.gramA_to_Ki[e]]; }, selAA_, selAA_n_);
+                if (ineq) pick((size_t)nzGG_, [&](size_t e) { return S_.PKi[S_.gramG_to_Ki[e]]; }, selGG_, selGG_n_);
+                pick(S_.diag_pos.size(), [&](size_t c) { return S_.diag_pos[c]; }, selD_, selD_n_);
+                sel_ready_ = true;
+            }
             norm_bits_.alloc(4);
             sharded_evals_ = 0;
         }
@@ -2463,7 +2519,12 @@ public:
         ++sharded_evals_;
         return true;
     }
-    void sharded_calls(int out[2]) const override { out[0] = sharded_evals_; out[1] = need_x_n_ + need_y_n_ + need_z_n_; }
+    // out[1]: KKT_FULL: rows of this rank's share of the residual; condensed modes: source entries of the value assembly this rank evaluates (of all: the same sum at world 1)
+    void sharded_calls(int out[2]) const override
+    {
+        out[0] = mode_ == 0 ? sharded_evals_ : sharded_asm_;
+        out[1] = mode_ == 0 ? need_x_n_ + need_y_n_ + need_z_n_ : selP_n_ + selA_n_ + selG_n_ + selAA_n_ + selGG_n_ + selD_n_;
+    }
     void drop_transport()
     {
         xbuf_norm_ = nullptr; own_norm_.release();
@@ -3342,6 +3403,10 @@ private:
     mutable int tree_has_big_ = -1;  // lazily: does the top of the tree hold a front for the dense kernels (or is it too large for one persistent launch)
     // rows (caller's numbering) of the x / y / z blocks and of the whole KKT system that belong to the fronts this rank factors
     DBuf<int> need_x_, need_y_, need_z_, need_all_;
+    DBuf<int> selP_, selA_, selG_, selAA_, selGG_, selD_;  // condensed modes, partitioned: source entries / diagonal columns whose values land in a front this rank factors
+    int selP_n_ = 0, selA_n_ = 0, selG_n_ = 0, selAA_n_ = 0, selGG_n_ = 0, selD_n_ = 0, sharded_asm_ = 0;
+    bool sel_ready_ = false;
+    std::vector<std::pair<size_t, size_t>> own_val_ranges_;  // positions of the value array those fronts own (zeroed per factorisation)
     int need_x_n_ = 0, need_y_n_ = 0, need_z_n_ = 0, need_all_n_ = 0, sharded_evals_ = 0;
     DBuf<double> norm_bits_, own_norm_;
     HBuf<double> norm_h_{2};

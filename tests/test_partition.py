@@ -126,6 +126,24 @@ def test_sharded_refinement_residual_and_assembly_equal_the_replicated_ones(prob
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("backend,nranks", [("multistage", 2), ("ldlt_cond", 4)])
+def test_sharded_value_assembly_of_the_condensed_modes(backend, nranks):
+    """SURVEY 8(e) row 2, condensed modes (round 4): a stage-partitioned sparse_ldlt_cond / sparse_multistage (tree engine) backend re-evaluates, per factorisation, only
+    the values of the fronts it factors -- P entries, delta^-1 A^T A entries, G^T W G product terms and diagonal shifts selected by destination front.  The other
+    fronts' values are never read on that rank: factor + solve stay bitwise the single-GPU ones on every rank, and every rank evaluates a share of the entries."""
+    out = _run_ranks(nranks, ["--stages", "800", "--steps", "2", "--warmup", "1", "--backend", backend, "--full-solve"], 29720 + nranks)
+    assert out["world"] == nranks
+    assert out["bitwise_equal_all_ranks"] and out["max_abs_diff"] == 0.0
+    assert out["rel_kkt_residual"] <= 1e-10
+    sa = out["sharded_assembly"]
+    assert all(a >= 3 for a in sa["assemblies_per_rank"]), sa                      # every factorisation of the partitioned handle assembled its share only
+    total = out["sharded_assembly_entries_single_gpu"]
+    assert max(sa["entries_per_rank"]) < 0.8 * total and sum(sa["entries_per_rank"]) >= total, (sa, total)
+    fs = out["full_solve"]
+    assert fs["status"] == 1 and fs["identical_on_all_ranks"] and fs["x_equal_to_single_gpu"] and fs["iter"] == fs["single_gpu"]["iter"]
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("native", [True, False])
 def test_rccl_transport_with_a_one_rank_group(native):
     """all a 1-GPU box can say about the RCCL transport: a one-rank "nccl" process group with the exchanges forced on

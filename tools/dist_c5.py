@@ -93,6 +93,8 @@ def main():
             k0.condensed_residual()
         k0.synchronize()
         out["residual_eval_ms_single_gpu"] = (time.perf_counter() - t0) / 20 * 1e3
+        if args.backend != "ldlt":  # all source entries of the value assembly: what a partition of one rank selects
+            out["sharded_assembly_entries_single_gpu"] = int(pd.StagePartition(k0, rank=0, world=1).sharded_calls()[1])
         del k0
 
     k1 = hip.KKTSystem(d, hip.default_settings(kkt_solver=ks), device=dev_index)
@@ -137,6 +139,10 @@ def main():
     shr = pd.gather_stats([[float(sc[0]), float(sc[1])]])
     out["sharded_residual"] = {"evaluations_per_rank": [int(r[0]) for r in shr], "rows_per_rank": [int(r[1]) for r in shr], "rows_total": n + p + m,
                                "norm_all_reduces": int(sp.calls[3]) if not sp.native else None}
+    if args.backend != "ldlt":
+        # condensed modes (sparse_ldlt_cond, the multistage tree engine): sharded_calls = (value assemblies done on the rank's own fronts only, source entries it evaluates)
+        out["sharded_assembly"] = {"assemblies_per_rank": [int(r[0]) for r in shr], "entries_per_rank": [int(r[1]) for r in shr]}
+        del out["sharded_residual"]
     out["native_rccl"] = bool(sp.native)
     # self-proving multi-GPU record: who ran the collectives and what they saw, per rank
     ci = sp.comm_info()
