@@ -94,7 +94,7 @@ def main():
         k0.synchronize()
         out["residual_eval_ms_single_gpu"] = (time.perf_counter() - t0) / 20 * 1e3
         if args.backend != "ldlt":  # all source entries of the value assembly: what a partition of one rank selects
-            out["sharded_assembly_entries_single_gpu"] = int(pd.StagePartition(k0, rank=0, world=1).sharded_calls()[1])
+            out["sharded_assembly_entries_single_gpu"] = int(pd.StagePartition(k0, rank=0, world=1, native=False).sharded_calls()[1])
         del k0
 
     k1 = hip.KKTSystem(d, hip.default_settings(kkt_solver=ks), device=dev_index)
