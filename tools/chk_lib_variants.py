@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Two builds of the library on the same dense systems (PIQP_AMD_LIB selects the shared library): factor + backend solve of random condensed systems, LL^T and
 LDL^T, sizes with full and ragged last blocks -- the solutions are compared bit for bit and the solve is timed.
-   python tools/chk_lib_variants.py piqp_amd/lib/exp/libpiqp_amd_base.so [piqp_amd/lib/libpiqp_amd.so]"""
+   python tools/chk_lib_variants.py piqp_amd/lib/exp/libpiqp_amd_base.so [piqp_amd/lib/libpiqp_amd.so]
+a library may carry a debugging token: path@token (PIQP_AMD_DEBUG of that run), e.g.  piqp_amd/lib/libpiqp_amd.so piqp_amd/lib/libpiqp_amd.so@trsv_mfma"""
 import json, os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -37,7 +38,11 @@ def main():
     outs = []
     for i, lib in enumerate(libs):
         out = f"/tmp/chk_lib_{i}.npz"
+        lib, _, tok = lib.partition("@")
         env = dict(os.environ); env["PIQP_AMD_LIB"] = os.path.abspath(lib)
+        env.pop("PIQP_AMD_DEBUG", None)
+        if tok:
+            env["PIQP_AMD_DEBUG"] = tok
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", out], env=env, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(dict(np.load(out)))
@@ -47,7 +52,7 @@ def main():
         if key.startswith("t_"):
             print(f"{key[2:]:12s} solve incl. host copies: {a[key][0]:.3f} ms -> {b[key][0]:.3f} ms")
         elif not np.array_equal(a[key], b[key]):
-            bad += 1; print("DIFFERS", key, float(np.abs(a[key] - b[key]).max()))
+            bad += 1; print("DIFFERS", key, "max |d| %.3e of max |x| %.3e" % (float(np.abs(a[key] - b[key]).max()), float(np.abs(a[key]).max())))
     print("bitwise equal" if bad == 0 else f"{bad} arrays differ")
     sys.exit(1 if bad else 0)
 
