@@ -1,3 +1,6 @@
 cd $GRAFT_REPO_ROOT
 ulimit -v 100000000
-timeout 600 python3 tools/chk_lib_variants.py piqp_amd/lib/libpiqp_amd.so piqp_amd/lib/libpiqp_amd.so@trsv_mfma 2>&1 | tail -32
+mkdir -p gpurun_out
+timeout 1500 python3 tools/exp_cond_parity.py 4 > gpurun_out/r04_cond_parity.txt 2>/dev/null
+tail -3 gpurun_out/r04_cond_parity.txt | cut -c1-600
+grep -c "differs" gpurun_out/r04_cond_parity.txt
