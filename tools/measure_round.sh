@@ -1,3 +1,5 @@
+# How the records under profiles/r04_* were produced (run on the GPU box through gpurun): GPU test suite, bench line, rocprofv3 kernel stats of the bench
+# command, PMC passes of the two sparse workloads (separate FETCH_SIZE / WRITE_SIZE passes), the SQP benchmark shapes.
 mkdir -p gpurun_out
 R=$GRAFT_REPO_ROOT
 cd /tmp; export TMPDIR=/tmp
