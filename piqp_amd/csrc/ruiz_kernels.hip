@@ -342,12 +342,14 @@ void launch_ruiz_sparse(const RuizSparseArgs& a, int batch, int threads, hipStre
     if (batch <= 0) return;
     static const bool one_wg = debug_token("ruiz_one_wg") != nullptr;  // debugging aid: PIQP_AMD_DEBUG=ruiz_one_wg
     if (batch == 1 && a.grid_ws && a.max_iter <= 64 && !one_wg) {
-        // one instance on the whole chip: a workgroup of 256 threads per 2048 rows, at most one per CU (every workgroup must be resident: grid barriers)
+        // one instance on the whole chip: workgroups of 256 threads, at most one per CU (every workgroup must be resident: grid barriers)
         int cus = 0, dev = 0;
         PQ_HIP(hipGetDevice(&dev));
         PQ_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
         const int N = a.n + a.p + a.m;
-        const int g = std::max(1, std::min(cus > 0 ? cus : 64, (N + 2047) / 2048));
+        // 512 rows per workgroup, at most 48 workgroups: a barrier costs more the more workgroups poll its counter (C3 pattern, N = 100 000: 5.3 ms on 49
+        // workgroups, 12.4 ms on 196), and below 2048 rows four workgroups still halve the one-workgroup time (chain-mass N = 1822: update 1.9 -> 1.1 ms)
+        const int g = std::max(1, std::min(std::min(cus > 0 ? cus : 64, 48), (N + 511) / 512));
         if (g > 1) {
             PQ_HIP(hipMemsetAsync(a.grid_ws, 0, sizeof(unsigned long long) * RUIZ_WS_WORDS, s));
             hipLaunchKernelGGL(k_ruiz_sparse<true>, dim3(g), dim3(256), 0, s, a);
