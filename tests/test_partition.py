@@ -191,3 +191,16 @@ def test_condensed_mode_refuses_dense_constraint_rows_instead_of_exhausting_memo
     assert L.pq_sparse_partition_plan(C.byref(desc), 3, 1, None, 0, None) < 0
     assert "2e8 terms" in L.pq_last_error_string().decode()
     assert L.pq_sparse_partition_plan(C.byref(desc), 0, 1, None, 0, None) == n + rows
+
+
+@pytest.mark.parametrize("spread,row_nnz,n", [(300, 10, 6000), (1000, 8, 3000)])
+def test_symbolic_analysis_of_wide_window_problems_on_the_host(spread, row_nnz, n):
+    """the round-4 symbolic paths -- spines of wide fronts merged into their parents, nested dissection against AMD on two host threads, the cost model for trees with
+    many levels of big fronts -- on the host alone (no GPU): the analysis completes (every K entry falls inside its front, every child's update rows inside its
+    parent's front: analyse_with_order throws otherwise) and a two-rank plan covers every column"""
+    from qp_gen import c3_problem
+    a = c3_problem(n, n * 2 // 5, n * 3 // 5, 45, spread, row_nnz)
+    for mode in (0, 3):
+        owner, work = _plan(a, mode, 2)
+        assert owner.min() >= -1 and owner.max() == 1
+        assert work[:2].min() > 0
