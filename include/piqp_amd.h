@@ -48,7 +48,11 @@ typedef enum {
     PQ_SPARSE_LDLT_INEQ_COND = 3,
     PQ_SPARSE_LDLT_COND = 4,
     PQ_SPARSE_MULTISTAGE = 5,
-    PQ_DENSE_LDLT_NO_PIVOT = 16
+    PQ_DENSE_LDLT_NO_PIVOT = 16,
+    /* the two engines behind PQ_SPARSE_LDLT, selectable directly (not in the reference's enum): the reference's own up-looking elimination order on the
+     * device (sparse/ldlt.hpp:101-218 bit for bit; PQ_SPARSE_LDLT picks it up to 8192 KKT rows) and the supernodal multifrontal LDLt (above that) */
+    PQ_SPARSE_LDLT_EXACT = 17,
+    PQ_SPARSE_LDLT_MULTIFRONTAL = 18
 } pq_kkt_solver;
 
 /* kkt_fwd.hpp:23-29 KKTUpdateOptions */
@@ -225,6 +229,10 @@ int pq_kkt_set_comm_rccl(pq_kkt *k, const unsigned char id[128], int rank, int w
  * out[1] = source entries this rank evaluates (a partition of one rank selects all of them). */
 int pq_kkt_set_exchange_norm(pq_kkt *k, double *buf_norm);
 int pq_kkt_sharded_calls(pq_kkt *k, int out[2]);
+/* test hook (reference-order engine, PQ_SPARSE_LDLT_EXACT): the factor as sparse/ldlt.hpp:24-37 holds it.  what = 0 nnz(L) | 1 L_cols[N + 1] | 2 L_ind | 3 L_vals |
+ * 4 D | 5 D_inv | 6 values of P K P' (CSC order of pq_sparse_kkt_symbolic's PKp / PKi_rows) | 7 perm; copies the item into out_host (NULL: size only) and returns its
+ * length, < 0 on error (another engine) */
+long long pq_kkt_exact_factor(pq_kkt *k, int what, void *out_host);
 /* test hook (sparse backends): smallest |pivot| of the last factorisation */
 int pq_kkt_min_abs_pivot(pq_kkt *k, double *out);
 /* collectives the native transport has enqueued so far: out[which] for which = 0, 1, 2 (test / bench bookkeeping) */
@@ -259,6 +267,14 @@ int pq_sparse_permute_sym_upper(int n, const int *Ap, const int *Ai, const int *
 int pq_sparse_kkt_symbolic(const pq_sparse_data *data, int mode, int *nnz_out, int *Kp, int *Ki, int *perm, int *PKp, int *PKi_rows,
                            int *PKi);
 int pq_kkt_sparse_ordering(pq_kkt *k, int *fill_perm, int *elim_perm);
+/* host-only planning hook of the reference-order engine (PQ_SPARSE_LDLT_EXACT; no GPU needed): everything sparse/ldlt.hpp:42-169 decides from the pattern of the
+ * KKT_FULL matrix alone, as the device kernels replay it.  perm[N] (AMD, perm[new] = old), Cp[N + 1] / Ci[nnz(K)] = pattern of P K P', diag_pos[N], etree[N], L in CSC
+ * (Lp[N + 1], Li[nnz(L)], rows ascending), and row k of L in the reference's topological visiting order: entries Rp[k] .. Rp[k + 1] with column Rcol[e] and CSC
+ * position Rpos[e]; the factorisation's tasks (chains of the elimination tree: rows task_lo[t] .. task_hi[t]) and, per task, the last rows of the tasks it waits for
+ * (tchild_ptr[ntask + 1], tchild).  sizes_out = { nnz(L), tasks, tree height, dependent steps on the longest root path, nnz(K), entries of tchild }.  Every array may
+ * be NULL (sizing call).  Returns N. */
+int pq_sparse_uplooking_plan(const pq_sparse_data *data, long long sizes_out[6], int *perm, int *Cp, int *Ci, int *diag_pos, int *etree, int *Lp, int *Li, int *Rp,
+                             int *Rcol, int *Rpos, int *task_lo, int *task_hi, int *tchild_ptr, int *tchild);
 
 /* measurement hooks: when enabled, the backend brackets its stages with hipEvents on its own stream.
  * stage 0 = KKT assembly kernel (dense: k_syrk_lower<ASSEMBLE>), 1 = factorisation (all panels),

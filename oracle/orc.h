@@ -202,6 +202,12 @@ const int *orc_sparse_kkt_PKPt_rowind(const orc_kkt *k);
 const double *orc_sparse_kkt_PKPt_val(const orc_kkt *k);
 const int *orc_sparse_kkt_perm(const orc_kkt *k);
 int orc_sparse_kkt_L_nnz(const orc_kkt *k);
+const int *orc_sparse_kkt_L_cols(const orc_kkt *k);
+const int *orc_sparse_kkt_L_ind(const orc_kkt *k);
+const double *orc_sparse_kkt_L_vals(const orc_kkt *k);
+const double *orc_sparse_kkt_D(const orc_kkt *k);
+const double *orc_sparse_kkt_D_inv(const orc_kkt *k);
+const int *orc_sparse_kkt_etree(const orc_kkt *k);
 const int *orc_sparse_kkt_PKi(const orc_kkt *k);
 int orc_sparse_kkt_nnz(const orc_kkt *k);
 int orc_sparse_cond_kkt_dim(const orc_kkt *k);

@@ -91,68 +91,8 @@ void orc_sparse_ldlt_symbolic(orc_sparse_ldlt *f, int n, const int *Ap, const in
 }
 
 /* sparse/ldlt.hpp:101-169; returns n on success, k on D[k] == 0 */
-/* EXPERIMENT HOOK (off unless ORC_EXP_CANCEL_TOL is set; tools/exp_cancel_pivot.py): additionally report pivot k as failed when |D[k]| <= tol * (largest
- * magnitude among a_kk and the products l_ki * y_i subtracted from it) -- the cancellation-aware failure signal of the device's sparse fronts, tried on
- * the reference's own arithmetic to see which fixtures it would move.  Not part of the restatement: ldlt.hpp:163 tests D[k] == 0.0 only. */
-static double orc_exp_cancel_tol(void)
-{
-    static int init = 0;
-    static double tol = 0.0;
-    if (!init) { const char *e = getenv("ORC_EXP_CANCEL_TOL"); tol = e ? atof(e) : 0.0; init = 1; }
-    return tol;
-}
-
-static int ldlt_numeric_exp(orc_sparse_ldlt *f, int n, const int *Ap, const int *Ai, const double *Ax, const double ctol)
-{
-    int *flag = f->flag, *pattern = f->pattern, *etree = f->etree, *L_cols = f->L_cols, *L_nnz = f->L_nnz, *L_ind = f->L_ind;
-    double *y = f->y, *D = f->D, *L_vals = f->L_vals;
-    for (int k = 0; k < n; k++) {
-        y[k] = 0.0;
-        int top = n;
-        flag[k] = k;
-        L_nnz[k] = 0;
-        for (int p = Ap[k]; p < Ap[k + 1]; p++) {
-            int i = Ai[p];
-            y[i] = Ax[p];
-            int len;
-            for (len = 0; flag[i] != k; i = etree[i]) {
-                pattern[len++] = i;
-                flag[i] = k;
-            }
-            while (len > 0) pattern[--top] = pattern[--len];
-        }
-        D[k] = y[k];
-        double mx = fabs(y[k]);
-        y[k] = 0.0;
-        for (; top < n; top++) {
-            int i = pattern[top];
-            double yi = y[i];
-            y[i] = 0.0;
-            int p2 = L_cols[i] + L_nnz[i];
-            int p;
-            for (p = L_cols[i]; p < p2; p++) {
-                double tmp = L_vals[p] * yi; /* two roundings, as the reference forces */
-                y[L_ind[p]] -= tmp;
-            }
-            double l_ki = yi / D[i];
-            double tmp = l_ki * yi;
-            D[k] -= tmp;
-            if (ctol > 0.0) { double t2 = fabs(l_ki * yi); if (t2 > mx) mx = t2; } /* (the hook must not reuse tmp: the FMA build contracts the two statements above) */
-            L_ind[p] = k;
-            L_vals[p] = l_ki;
-            L_nnz[i]++;
-        }
-        if (D[k] == 0.0) return k;
-        if (ctol > 0.0 && fabs(D[k]) <= ctol * mx) return k;
-    }
-    for (int k = 0; k < n; k++) f->D_inv[k] = 1.0 / D[k];
-    return n;
-}
-
-/* sparse/ldlt.hpp:101-169; returns n on success, k on D[k] == 0 */
 int orc_sparse_ldlt_numeric(orc_sparse_ldlt *f, int n, const int *Ap, const int *Ai, const double *Ax)
 {
-    if (orc_exp_cancel_tol() > 0.0) return ldlt_numeric_exp(f, n, Ap, Ai, Ax, orc_exp_cancel_tol()); /* experiment hook, see above; the text below is round 3's, untouched */
     int *flag = f->flag, *pattern = f->pattern, *etree = f->etree, *L_cols = f->L_cols, *L_nnz = f->L_nnz, *L_ind = f->L_ind;
     double *y = f->y, *D = f->D, *L_vals = f->L_vals;
     for (int k = 0; k < n; k++) {
@@ -814,3 +754,10 @@ const int *orc_sparse_kkt_perm(const orc_kkt *k) { return ((const sparse_kkt *)k
 const int *orc_sparse_kkt_PKi(const orc_kkt *k) { return ((const sparse_kkt *)k)->PKi; }
 int orc_sparse_kkt_nnz(const orc_kkt *k) { return ((const sparse_kkt *)k)->nnzK; }
 int orc_sparse_kkt_L_nnz(const orc_kkt *k) { return orc_sparse_ldlt_nnz(((const sparse_kkt *)k)->ldlt); }
+/* the factor as sparse/ldlt.hpp:24-37 holds it (tests/test_exact_gpu.py compares the device's reference-order engine with it bit for bit) */
+const int *orc_sparse_kkt_L_cols(const orc_kkt *k) { return ((const sparse_kkt *)k)->ldlt->L_cols; }
+const int *orc_sparse_kkt_L_ind(const orc_kkt *k) { return ((const sparse_kkt *)k)->ldlt->L_ind; }
+const double *orc_sparse_kkt_L_vals(const orc_kkt *k) { return ((const sparse_kkt *)k)->ldlt->L_vals; }
+const double *orc_sparse_kkt_D(const orc_kkt *k) { return ((const sparse_kkt *)k)->ldlt->D; }
+const double *orc_sparse_kkt_D_inv(const orc_kkt *k) { return ((const sparse_kkt *)k)->ldlt->D_inv; }
+const int *orc_sparse_kkt_etree(const orc_kkt *k) { return ((const sparse_kkt *)k)->ldlt->etree; }

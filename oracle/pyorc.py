@@ -208,7 +208,7 @@ def _bind(L):
         L.orc_amd_order.argtypes = [C.c_int, _ip, _ip, _ip]
         L.orc_permute_sym_upper.argtypes = [C.c_int, _ip, _ip, _dp, _ip, _ip, _ip, _dp, _ip]
         for nm, rt in (("dim", C.c_int), ("PKPt_colptr", _ip), ("PKPt_rowind", _ip), ("PKPt_val", _dp), ("perm", _ip), ("L_nnz", C.c_int), ("PKi", _ip),
-                       ("nnz", C.c_int)):
+                       ("nnz", C.c_int), ("L_cols", _ip), ("L_ind", _ip), ("L_vals", _dp), ("D", _dp), ("D_inv", _dp), ("etree", _ip)):
             f = getattr(L, "orc_sparse_kkt_" + nm)
             f.restype = rt
             f.argtypes = [vp]
@@ -412,6 +412,17 @@ class KKT:
         a, ap = _f(xn); b, bp = _f(xt); zn, zt = np.zeros(d.m), np.zeros(d.n)
         self.L.orc_kkt_eval_G_xn_and_GT_xt(self.ptr, d.ptr, an, at, ap, bp, zn.ctypes.data_as(_dp), zt.ctypes.data_as(_dp))
         return zn, zt
+
+    def sparse_factor(self):
+        """sparse_ldlt (KKT_FULL) only: the factor as sparse/ldlt.hpp:24-37 holds it + P K P' (numpy copies)"""
+        L, k = self.L, self.ptr
+        N = L.orc_sparse_kkt_dim(k)
+        Lp = np.ctypeslib.as_array(L.orc_sparse_kkt_L_cols(k), (N + 1,)).copy()
+        nz = int(Lp[N]); nk = L.orc_sparse_kkt_nnz(k)
+        g = lambda f, n, : np.ctypeslib.as_array(f(k), (max(n, 1),))[:n].copy()
+        return dict(N=N, L_cols=Lp, L_ind=g(L.orc_sparse_kkt_L_ind, nz), L_vals=g(L.orc_sparse_kkt_L_vals, nz), D=g(L.orc_sparse_kkt_D, N), D_inv=g(L.orc_sparse_kkt_D_inv, N),
+                    perm=g(L.orc_sparse_kkt_perm, N), PKPt_colptr=g(L.orc_sparse_kkt_PKPt_colptr, N + 1), PKPt_rowind=g(L.orc_sparse_kkt_PKPt_rowind, nk),
+                    PKPt_val=g(L.orc_sparse_kkt_PKPt_val, nk), etree=g(L.orc_sparse_kkt_etree, N))
 
     def block_info(self):
         """multistage only: rows of (start, diag_size, off_diag_size); the last row is the arrow corner block."""

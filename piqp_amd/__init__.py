@@ -8,6 +8,7 @@ from .kkt import (DENSE_CHOLESKY, DENSE_LDLT_NO_PIVOT, KKT_UPDATE_A, KKT_UPDATE_
                   Data, DenseKKT, DenseSolver, KKTSystem, SparseData, SparseSolver, Variables, default_settings)
 SparseKKT = DenseKKT  # same handle type: pq_kkt_* dispatches on the backend (KKTSolverBase is one interface)
 SPARSE_LDLT = 1
+from .kkt import SPARSE_LDLT_EXACT, SPARSE_LDLT_MULTIFRONTAL  # noqa: E402,F401
 SPARSE_MULTISTAGE = 5
 MultistageKKT = DenseKKT
 from .batch import BatchSparseSolver  # noqa: E402,F401

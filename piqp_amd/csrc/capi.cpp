@@ -361,6 +361,13 @@ int pq_kkt_min_abs_pivot(pq_kkt* k, double* out)
     if (!k || !out) return fail(PQ_ERR_INVALID, "null argument");
     return guarded([&] { *out = k->impl->min_abs_pivot(); return (int)PQ_OK; });
 }
+long long pq_kkt_exact_factor(pq_kkt* k, int what, void* out_host)
+{
+    if (!k) return fail(PQ_ERR_INVALID, "null handle");
+    long long r = -1;
+    const int rc = guarded([&] { r = k->impl->exact_factor(what, out_host); return (int)PQ_OK; });
+    return rc < 0 ? rc : r;
+}
 int pq_kkt_comm_info(pq_kkt* k, int out[4])
 {
     if (!k || !out) return fail(PQ_ERR_INVALID, "null argument");
@@ -442,6 +449,25 @@ int pq_sparse_kkt_symbolic(const pq_sparse_data* data, int mode, int* nnz_out, i
             if (PKi) std::copy(map.begin(), map.end(), PKi);
         }
         return N;
+    });
+}
+int pq_sparse_uplooking_plan(const pq_sparse_data* data, long long sizes_out[6], int* perm, int* Cp, int* Ci, int* diag_pos, int* etree, int* Lp, int* Li, int* Rp, int* Rcol,
+                             int* Rpos, int* task_lo, int* task_hi, int* tchild_ptr, int* tchild)
+{
+    if (!data) return fail(PQ_ERR_INVALID, "bad argument");
+    return guarded([&] {
+        sparse::Symbolic S;
+        sparse::analyse_kkt_pattern(data, 0, S);
+        sparse::UpLooking U;
+        sparse::analyse_uplooking(S, data, U);
+        if (sizes_out) {
+            sizes_out[0] = U.nnzL; sizes_out[1] = (long long)U.task_lo.size(); sizes_out[2] = U.height; sizes_out[3] = U.crit_steps; sizes_out[4] = U.Cp[U.N];
+            sizes_out[5] = (long long)U.tchild.size();
+        }
+        auto cp = [](const sparse::IVec& v, int* out) { if (out) std::copy(v.begin(), v.end(), out); };
+        cp(U.perm, perm); cp(U.Cp, Cp); cp(U.Ci, Ci); cp(U.diag_pos, diag_pos); cp(U.etree, etree); cp(U.Lp, Lp); cp(U.Li, Li); cp(U.Rp, Rp); cp(U.Rcol, Rcol); cp(U.Rpos, Rpos);
+        cp(U.task_lo, task_lo); cp(U.task_hi, task_hi); cp(U.tchild_ptr, tchild_ptr); cp(U.tchild, tchild);
+        return U.N;
     });
 }
 int pq_kkt_sparse_ordering(pq_kkt* k, int* fill_perm, int* elim_perm)

@@ -57,6 +57,12 @@ public:
     }
     // native transport: the library issues the RCCL collectives itself on its stream (pq_kkt_set_comm_rccl)
     virtual void set_comm_rccl(const unsigned char* id128, int rank, int world) { (void)id128; (void)rank; (void)world; throw std::runtime_error("set_comm_rccl: not supported by this backend"); }
+    // true: this backend computes in the reference's own order of operations (sparse_exact.hip); the solver front end then runs the interior-point loop that
+    // keeps that order too (the host loop of solver.cpp, vectors summed left to right like the reference's Eigen expressions restated by the CPU oracle)
+    virtual bool reference_order() const { return false; }
+    // test hook of the reference-order engine (sparse_exact.hip, pq_kkt_exact_factor): item 0 nnz(L), 1 L_cols, 2 L_ind, 3 L_vals, 4 D, 5 D_inv, 6 values of P K P', 7 perm;
+    // copies the item to host memory when out_host != nullptr and returns its length
+    virtual long long exact_factor(int what, void* out_host) { (void)what; (void)out_host; throw std::runtime_error("exact_factor: reference-order sparse engine only"); }
     // test hook: smallest |pivot| of the last factorisation (sparse backends), read back through the host
     virtual double min_abs_pivot() { throw std::runtime_error("min_abs_pivot: sparse backends only"); }
     virtual void native_exchange_calls(int out[3]) const { out[0] = out[1] = out[2] = 0; }
@@ -84,5 +90,6 @@ public:
 KKTSolverBase* make_dense_kkt(const pq_dense_data* data, int kkt_solver, int device);
 KKTSolverBase* make_sparse_kkt(const pq_sparse_data* data, int kkt_solver, int device);
 KKTSolverBase* make_multistage_kkt(const pq_sparse_data* data, int device);
+KKTSolverBase* make_exact_sparse_kkt(const pq_sparse_data* data, int device);  // sparse_exact.hip: KKT_FULL in the reference's own elimination order
 
 }  // namespace pq

@@ -502,8 +502,12 @@ bool Solver::setup(std::unique_ptr<HostData> data)
     if (!m_kkt_system) { m_setup_done = false; return false; }
     stage_alloc();
     dipm_.reset();
+    // the interior-point loop: vectors resident in HBM (device_ipm.hip: tree reductions) -- or, behind the reference-order sparse engine, the host loop below, whose
+    // dot products and norms run left to right like the reference's: together they make a whole solve the oracle's sequence of IEEE operations
+    // (PIQP_AMD_HOST_IPM=1 / =0 force one or the other)
     const char* host_ipm = std::getenv("PIQP_AMD_HOST_IPM");
-    if (!(host_ipm && host_ipm[0] == '1')) { dipm_ = std::make_unique<DeviceIpm>(); dipm_->init(*m_data, m_preconditioner, m_kkt_system->stream()); }
+    const bool use_host = host_ipm ? host_ipm[0] == '1' : m_kkt_system->backend()->reference_order();
+    if (!use_host) { dipm_ = std::make_unique<DeviceIpm>(); dipm_->init(*m_data, m_preconditioner, m_kkt_system->stream()); }
     m_first_run = true; m_setup_done = true;
     m_info.setup_time = now_s() - t0;
     return true;

@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <stdexcept>
+#include <string>
 #include <type_traits>
 
 #include "trace.hpp"
@@ -3454,7 +3455,21 @@ KKTSolverBase* make_sparse_kkt(const pq_sparse_data* data, int kkt_solver, int d
 {
     switch (kkt_solver) {
     case PQ_SPARSE_MULTISTAGE: return make_multistage_kkt(data, device);
-    case PQ_SPARSE_LDLT: return new SparseKKT(data, 0, device);
+    case PQ_SPARSE_LDLT: {
+        // Two engines behind the reference's sparse_ldlt: the reference-order up-looking LDLt (sparse_exact.hip: L, D and the solves bitwise the
+        // reference's, so that rounding-decided trajectories are the reference's too) for KKT systems up to PIQP_AMD_EXACT_MAX_N rows (default 8192: every
+        // trajectory-sensitive netlib / Maros-Meszaros problem, and the sizes where a tree of small fronts has no throughput to offer anyway), the supernodal
+        // multifrontal one above.  PIQP_AMD_SPARSE_LDLT=exact|multifrontal forces one.
+        const char* eng = std::getenv("PIQP_AMD_SPARSE_LDLT");
+        const char* mx = std::getenv("PIQP_AMD_EXACT_MAX_N");
+        const long long max_n = mx ? std::atoll(mx) : 8192;
+        const long long N = (long long)data->n + data->p + data->m;
+        const bool exact = eng ? std::string(eng) == "exact" : N <= max_n;
+        if (exact) return make_exact_sparse_kkt(data, device);
+        return new SparseKKT(data, 0, device);
+    }
+    case PQ_SPARSE_LDLT_EXACT: return make_exact_sparse_kkt(data, device);
+    case PQ_SPARSE_LDLT_MULTIFRONTAL: return new SparseKKT(data, 0, device);
     case PQ_SPARSE_LDLT_EQ_COND: return new SparseKKT(data, 1, device);    // KKTMode::KKT_EQ_ELIMINATED
     case PQ_SPARSE_LDLT_INEQ_COND: return new SparseKKT(data, 2, device);  // KKTMode::KKT_INEQ_ELIMINATED
     case PQ_SPARSE_LDLT_COND: return new SparseKKT(data, 3, device);       // KKTMode::KKT_ALL_ELIMINATED

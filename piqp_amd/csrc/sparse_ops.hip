@@ -69,16 +69,40 @@ __device__ __forceinline__ double wave_col_dot(int j, int ncols, const int* __re
 
 // y[j] = (ACC ? y[j] : 0) + alpha * sum_q val[q] * x[row[q]] over column j  (CSC column dot)
 constexpr int SPMV_LONG_COL = 2048;  // columns with more entries than this are summed by a whole workgroup (k_spmv_long_cols)
-template <bool ACC>
+// ALPHA_FIRST: every term is val * (alpha * x[row]) and the sum is stored as it is -- the form of the reference's scatter products (sparse/kkt.hpp:188,199:
+// z.noalias() += alpha * M * x walks the columns of M and adds val * (alpha x_j) to the target row, i.e. row by row a left-to-right sum of such terms);
+// otherwise alpha * (sum of val * x[row]), the form of its transposed (column-dot) products.  max_len: columns with more entries are left to k_spmv_long_cols
+// (0: none are -- the reference-order mode sums every column left to right).
+template <bool ACC, bool ALPHA_FIRST>
 __global__ __launch_bounds__(256) void k_spmv_cols(int ncols, const int* __restrict__ colptr, const int* __restrict__ rowind, const double* __restrict__ val, const double* __restrict__ x,
-                                                   double alpha, double* __restrict__ y)
+                                                   double alpha, double* __restrict__ y, int max_len)
 {
     __shared__ double sm[DOT_LDS_DOUBLES];
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    const double s = wave_col_dot(j, ncols, colptr, rowind, val, [&](int i) { return x[i]; }, sm, SPMV_LONG_COL);
+    double s;
+    if (ALPHA_FIRST) s = wave_col_dot(j, ncols, colptr, rowind, val, [&](int i) { return alpha * x[i]; }, sm, max_len);
+    else s = wave_col_dot(j, ncols, colptr, rowind, val, [&](int i) { return x[i]; }, sm, max_len);
     if (j >= ncols) return;
-    if (colptr[j + 1] - colptr[j] > SPMV_LONG_COL) return;
-    y[j] = ACC ? y[j] + alpha * s : alpha * s;
+    if (max_len > 0 && colptr[j + 1] - colptr[j] > max_len) return;
+    const double t = ALPHA_FIRST ? s : alpha * s;
+    y[j] = ACC ? y[j] + t : t;
+}
+// eval_P_x in the reference's order (sparse/kkt.hpp:179-185: z = alpha * P_utri.selfadjointView<Upper>() * x as the CPU oracle restates it, oracle/orc_sparse.c
+// sparse_eval_P_x): row r first collects val * (alpha x_j) over the stored entries (r, j), j >= r ascending -- the scatter pass over the upper triangle --
+// and then receives alpha * (sum over the strictly upper part of column r of val * x_i).  One thread per row on the symmetrised copy, whose column r lists the
+// rows i < r (upper part of column r) before r and the mirrored entries j > r.
+__global__ __launch_bounds__(256) void k_sym_spmv_ref(int n, const int* __restrict__ colptr, const int* __restrict__ rowind, const double* __restrict__ val, const double* __restrict__ x,
+                                                      double alpha, double* __restrict__ z)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    double acc = 0.0, s = 0.0;
+    for (int q = colptr[r]; q < colptr[r + 1]; ++q) {
+        const int i = rowind[q];
+        if (i < r) s += val[q] * x[i];
+        else acc += val[q] * (alpha * x[i]);
+    }
+    z[r] = acc + alpha * s;
 }
 // A column with very many entries (a dense row of A seen from its transpose copy: MM BOYD1 has 18 of 93 261 entries each) costs a thread-per-
 // column kernel a serial loop -- 1.15 ms per mat-vec there.  One workgroup per such column: thread t sums the entries t, t + 256, ... in
@@ -304,30 +328,38 @@ void CscOperators::clone_from(const CscOperators& o, hipStream_t st)
     cpi(A_src_, o.A_src_); cpi(GT_p_, o.GT_p_); cpi(GT_i_, o.GT_i_); cpi(G_p_, o.G_p_); cpi(G_i_, o.G_i_); cpi(G_src_, o.G_src_);
     cpi(long_Pf_, o.long_Pf_); cpi(long_AT_, o.long_AT_); cpi(long_A_, o.long_A_); cpi(long_GT_, o.long_GT_); cpi(long_G_, o.long_G_);
     for (int q = 0; q < 5; ++q) nlong_[q] = o.nlong_[q];
+    ref_order_ = o.ref_order_;
 }
 
+// scatter: the product the reference forms by walking columns and adding into the target (M * x for a column-major M); ref: reference-order mode
 template <bool ACC>
 static void spmv(int ncols, const DBuf<int>& cp, const DBuf<int>& ri, const DBuf<double>& v, const DBuf<int>& long_cols, int nlong, const double* x, double alpha, double* y,
-                 hipStream_t st)
+                 hipStream_t st, bool ref = false, bool scatter = false)
 {
     if (ncols <= 0) return;
-    hipLaunchKernelGGL(k_spmv_cols<ACC>, g1(ncols), dim3(256), 0, st, ncols, cp.p, ri.p, v.p, x, alpha, y);
+    if (ref) {
+        if (scatter) hipLaunchKernelGGL((k_spmv_cols<ACC, true>), g1(ncols), dim3(256), 0, st, ncols, cp.p, ri.p, v.p, x, alpha, y, 0);
+        else hipLaunchKernelGGL((k_spmv_cols<ACC, false>), g1(ncols), dim3(256), 0, st, ncols, cp.p, ri.p, v.p, x, alpha, y, 0);
+        return;
+    }
+    hipLaunchKernelGGL((k_spmv_cols<ACC, false>), g1(ncols), dim3(256), 0, st, ncols, cp.p, ri.p, v.p, x, alpha, y, SPMV_LONG_COL);
     if (nlong > 0) hipLaunchKernelGGL(k_spmv_long_cols<ACC>, dim3(nlong), dim3(256), 0, st, long_cols.p, cp.p, ri.p, v.p, x, alpha, y);
 }
 
 void CscOperators::eval_P_x(double alpha, const double* x, double* z, hipStream_t st) const
 {
+    if (ref_order_) { if (n_ > 0) hipLaunchKernelGGL(k_sym_spmv_ref, g1(n_), dim3(256), 0, st, n_, Pf_p_.p, Pf_i_.p, Pf_x_.p, x, alpha, z); return; }
     spmv<false>(n_, Pf_p_, Pf_i_, Pf_x_, long_Pf_, nlong_[0], x, alpha, z, st);
 }
 void CscOperators::eval_A_xn_and_AT_xt(double an, double at, const double* xn, const double* xt, double* zn, double* zt, hipStream_t st) const
 {
-    spmv<false>(p_, AT_p_, AT_i_, AT_x_, long_AT_, nlong_[1], xn, an, zn, st);  // A x = (AT)^T x
-    spmv<false>(n_, A_p_, A_i_, A_x_, long_A_, nlong_[2], xt, at, zt, st);       // AT y = (A)^T y
+    spmv<false>(p_, AT_p_, AT_i_, AT_x_, long_AT_, nlong_[1], xn, an, zn, st, ref_order_, false);  // A x = (AT)^T x
+    spmv<false>(n_, A_p_, A_i_, A_x_, long_A_, nlong_[2], xt, at, zt, st, ref_order_, true);       // AT y = (A)^T y
 }
 void CscOperators::eval_G_xn_and_GT_xt(double an, double at, const double* xn, const double* xt, double* zn, double* zt, hipStream_t st) const
 {
-    spmv<false>(m_, GT_p_, GT_i_, GT_x_, long_GT_, nlong_[3], xn, an, zn, st);
-    spmv<false>(n_, G_p_, G_i_, G_x_, long_G_, nlong_[4], xt, at, zt, st);
+    spmv<false>(m_, GT_p_, GT_i_, GT_x_, long_GT_, nlong_[3], xn, an, zn, st, ref_order_, false);
+    spmv<false>(n_, G_p_, G_i_, G_x_, long_G_, nlong_[4], xt, at, zt, st, ref_order_, true);
 }
 bool CscOperators::residual_rows(const int* rows_x, int nx, const int* rows_y, int ny, const int* rows_z, int nz, const double* lhs_x, const double* lhs_y, const double* lhs_z,
                                  const double* rhs_x, const double* rhs_y, const double* rhs_z, const double* x_reg, double delta, const double* z_reg, double* err_x, double* err_y,

@@ -52,6 +52,10 @@ public:
     bool residual_rows(const int* rows_x, int nx, const int* rows_y, int ny, const int* rows_z, int nz, const double* lhs_x, const double* lhs_y, const double* lhs_z,
                        const double* rhs_x, const double* rhs_y, const double* rhs_z, const double* x_reg, double delta, const double* z_reg, double* err_x, double* err_y,
                        double* err_z, unsigned long long* absmax_bits, hipStream_t st) const;
+    // reference-order mode (the backend of sparse_exact.hip sets it): every product is formed term by term in the order of the reference's loops (sparse/kkt.hpp:179-203
+    // as restated by the CPU oracle), columns of any length left to right -- with the file built without FMA contraction the mat-vecs are then bitwise the oracle's
+    void set_reference_order(bool on) { ref_order_ = on; }
+    bool reference_order() const { return ref_order_; }
     bool has_long_columns() const { return nlong_[0] + nlong_[1] + nlong_[2] + nlong_[3] + nlong_[4] > 0; }
 
     int n() const { return n_; }
@@ -71,6 +75,7 @@ private:
     DBuf<int> Pf_p_, Pf_i_, Pf_src_, AT_p_, AT_i_, A_p_, A_i_, A_src_, GT_p_, GT_i_, G_p_, G_i_, G_src_;
     DBuf<int> long_Pf_, long_AT_, long_A_, long_GT_, long_G_;  // columns with more than SPMV_LONG_COL entries, per copy
     int nlong_[5] = {0, 0, 0, 0, 0};
+    bool ref_order_ = false;
 };
 
 // generic value movers shared by the sparse backends

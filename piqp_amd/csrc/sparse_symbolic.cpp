@@ -1267,5 +1267,96 @@ void partition_tree(const Symbolic& S, int world, Partition& P)
     }
 }
 
+// ---- the reference's elimination replayed symbolically (round 5; see UpLooking in the header)
+void analyse_uplooking(const Symbolic& S, const pq_sparse_data* d, UpLooking& U)
+{
+    const int N = S.N;
+    U.n = S.n; U.p = S.p; U.m = S.m; U.N = N; U.mode = S.mode;
+    U.perm.assign(N, 0); U.perm_inv.assign(N, 0);
+    if (N > 0) amd_order(N, S.Kp.data(), S.Ki.data(), U.perm.data());   // sparse/ordering.hpp:67-84
+    for (int k = 0; k < N; ++k) U.perm_inv[U.perm[k]] = k;
+    permute_sym_upper(N, S.Kp, S.Ki, U.perm_inv.data(), U.Cp, U.Ci, U.PKi);  // sparse/utils.hpp:32-128
+    U.diag_pos.assign(N, 0);
+    for (int col = 0; col < N; ++col) U.diag_pos[col] = U.Cp[U.perm_inv[col] + 1] - 1;  // kkt_full.hpp:181: PKPt.valuePtr()[PKPt.outerIndexPtr()[ordering.inv(col) + 1] - 1]
+    for (int col = 0; col < N; ++col)
+        if (U.Ci[U.diag_pos[col]] != U.perm_inv[col]) throw std::runtime_error("up-looking analysis: a column of P K P' does not end in its diagonal");
+    const bool eq = (S.mode & 1) != 0, ineq = (S.mode & 2) != 0;
+    const int nzP = d->P_colptr[S.n], nzA = (S.p && !eq) ? d->AT_colptr[S.p] : 0, nzG = (S.m && !ineq) ? d->GT_colptr[S.m] : 0;
+    U.mapP.resize(nzP); U.mapA.resize(nzA); U.mapG.resize(nzG);
+    for (int q = 0; q < nzP; ++q) U.mapP[q] = U.PKi[S.P_utri_to_Ki[q]];
+    for (int q = 0; q < nzA; ++q) U.mapA[q] = U.PKi[S.AT_to_Ki[q]];
+    for (int q = 0; q < nzG; ++q) U.mapG[q] = U.PKi[S.GT_to_Ki[q]];
+    // LDLt::factorize_symbolic_upper_triangular (ldlt.hpp:42-99)
+    IVec colcount;
+    elimination_tree(N, U.Cp, U.Ci, U.etree, colcount);
+    U.Lp.assign(N + 1, 0);
+    for (int k = 0; k < N; ++k) U.Lp[k + 1] = U.Lp[k] + colcount[k];
+    const int nnzL = U.Lp[N];
+    U.nnzL = nnzL;
+    U.Li.assign(nnzL, 0); U.Lcol.assign(nnzL, 0);
+    U.Rp.assign(N + 1, 0); U.Rcol.assign(nnzL, 0); U.Rpos.assign(nnzL, 0);
+    // the pattern walk of factorize_numeric_upper_triangular (ldlt.hpp:121-143) with the bookkeeping of :159-161: row k's entries in the order the
+    // reference visits them, and where each lands in L's columns (a column receives its entries in ascending row order)
+    IVec flag(N, -1), pattern(N), lnz(N, 0);
+    int w = 0;
+    for (int k = 0; k < N; ++k) {
+        int top = N;
+        flag[k] = k;
+        for (int p = U.Cp[k]; p < U.Cp[k + 1]; ++p) {
+            int i = U.Ci[p];
+            int len = 0;
+            for (; flag[i] != k; i = U.etree[i]) { pattern[len++] = i; flag[i] = k; }
+            while (len > 0) pattern[--top] = pattern[--len];
+        }
+        U.Rp[k] = w;
+        for (; top < N; ++top) {
+            const int i = pattern[top];
+            const int pos = U.Lp[i] + lnz[i]++;
+            U.Li[pos] = k; U.Lcol[pos] = i;
+            U.Rcol[w] = i; U.Rpos[w] = pos;
+            ++w;
+        }
+    }
+    U.Rp[N] = w;
+    if (w != nnzL) throw std::runtime_error("up-looking analysis: row and column counts of L disagree");
+    U.flops = 0.0;
+    for (int k = 0; k < N; ++k) U.flops += (double)colcount[k] * colcount[k] + 3.0 * colcount[k];
+    // chains of the elimination tree = tasks
+    IVec nchild(N, 0);
+    for (int k = 0; k < N; ++k) if (U.etree[k] >= 0) nchild[U.etree[k]]++;
+    U.task_lo.clear(); U.task_hi.clear();
+    IVec task_of(N, -1);
+    for (int k = 0; k < N; ++k) {
+        const bool cont = k > 0 && U.etree[k - 1] == k && nchild[k] == 1;
+        if (!cont) { U.task_lo.push_back(k); U.task_hi.push_back(k); }
+        else U.task_hi.back() = k;
+        task_of[k] = (int)U.task_lo.size() - 1;
+    }
+    const int nt = (int)U.task_lo.size();
+    U.tchild_ptr.assign(nt + 1, 0);
+    for (int k = 0; k < N; ++k) { const int pa = U.etree[k]; if (pa >= 0 && task_of[pa] != task_of[k]) U.tchild_ptr[task_of[pa] + 1]++; }
+    for (int t = 0; t < nt; ++t) U.tchild_ptr[t + 1] += U.tchild_ptr[t];
+    U.tchild.assign(U.tchild_ptr[nt], 0);
+    {
+        IVec fill(U.tchild_ptr.begin(), U.tchild_ptr.end() - 1);
+        for (int k = 0; k < N; ++k) {
+            const int pa = U.etree[k];
+            if (pa >= 0 && task_of[pa] != task_of[k]) {
+                if (pa != U.task_lo[task_of[pa]] || k != U.task_hi[task_of[k]]) throw std::runtime_error("up-looking analysis: chain decomposition");
+                U.tchild[fill[task_of[pa]]++] = k;
+            }
+        }
+    }
+    IVec h(N, 0);
+    std::vector<long long> cp(N, 0);
+    U.height = 0; U.crit_steps = 0;
+    for (int k = 0; k < N; ++k) {
+        h[k] += 1; cp[k] += U.Rp[k + 1] - U.Rp[k];
+        U.height = std::max(U.height, h[k]); U.crit_steps = std::max(U.crit_steps, cp[k]);
+        const int pa = U.etree[k];
+        if (pa >= 0) { h[pa] = std::max(h[pa], h[k]); cp[pa] = std::max(cp[pa], cp[k]); }
+    }
+}
+
 }  // namespace sparse
 }  // namespace pq

@@ -82,6 +82,31 @@ struct Symbolic {
     const char* ordering = "amd";
 };
 
+// ---- the reference's own elimination, statement for statement (round 5): sparse::KKT with AMDOrdering + LDLt (sparse/kkt.hpp:51-70, ldlt.hpp:42-169).
+// Everything the up-looking numeric phase decides at run time from the pattern alone is fixed here once: the AMD permutation WITHOUT a postorder (the
+// reference factors P K P' in AMD's own order), the elimination tree, L's column structure, and for every row k of L its pattern IN THE ORDER the
+// reference's depth-first walk produces it (ldlt.hpp:127-143) -- the order in which the terms of every entry are subtracted.  The device kernels of
+// sparse_exact.hip replay exactly that order, so that L, D and every solve are bitwise the reference's (the CPU oracle's, which restates it).
+struct UpLooking {
+    int n = 0, p = 0, m = 0, N = 0, mode = 0;
+    IVec perm, perm_inv;        // perm[new] = old (Eigen::AMDOrdering, sparse/ordering.hpp:72-76)
+    IVec Cp, Ci, PKi;           // C = upper(P K P'), sorted columns; K value index -> C value index (sparse/utils.hpp:32-128)
+    IVec diag_pos;              // C value index of the diagonal of ORIGINAL column col (kkt_full.hpp:181,194,207: the last entry of column perm_inv[col])
+    IVec mapP, mapA, mapG;      // caller's P_utri / AT / GT value index -> C value index (kkt_full.hpp:219-249)
+    IVec etree;                 // ldlt.hpp:61-83
+    IVec Lp, Li, Lcol;          // L strictly lower, CSC with ascending rows (the reference fills every column in row order); Lcol = column of every entry
+    IVec Rp, Rcol, Rpos;        // row k of L: entries Rp[k] .. Rp[k+1] in the reference's topological order: column index, position in the CSC arrays
+    // schedule of the factorisation: maximal chains k0 .. k1 of rows with etree[t-1] == t and t having no other child are ONE task (one wave walks it);
+    // a task starts when the tasks that end in a child of k0 are done
+    IVec task_lo, task_hi, tchild_ptr, tchild;
+    long long nnzL = 0;
+    double flops = 0.0;         // sum_j (c_j^2 + 3 c_j)
+    int height = 0;             // elimination tree height (rows)
+    long long crit_steps = 0;   // longest root path counted in row entries (the dependent steps of the up-looking loop)
+};
+// K of the mode must already be in S (analyse_kkt_pattern)
+void analyse_uplooking(const Symbolic& S, const pq_sparse_data* d, UpLooking& U);
+
 // Stage partition of the assembly tree over `world` processes: disjoint subtrees are owned by one rank each,
 // the supernodes above them ("shared top") are processed by every rank on exchanged data.
 struct Partition {

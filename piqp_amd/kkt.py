@@ -17,6 +17,7 @@ from ._lib import VAR_NAMES, check
 
 PIQP_INF = 1e30  # fwd.hpp:54
 DENSE_CHOLESKY, SPARSE_LDLT, SPARSE_LDLT_EQ_COND, SPARSE_LDLT_INEQ_COND, SPARSE_LDLT_COND, SPARSE_MULTISTAGE = range(6)
+SPARSE_LDLT_EXACT, SPARSE_LDLT_MULTIFRONTAL = 17, 18  # the two engines behind SPARSE_LDLT, selectable directly (include/piqp_amd.h)
 DENSE_LDLT_NO_PIVOT = 16
 KKT_UPDATE_NONE, KKT_UPDATE_P, KKT_UPDATE_A, KKT_UPDATE_G = 0, 1, 2, 4
 MEM_HOST, MEM_DEVICE = 0, 1
@@ -315,6 +316,24 @@ class DenseKKT(_Handle):
         check(self.L.pq_kkt_sparse_stats(self.h, out), "sparse_stats")
         keys = ("N", "nnz_K", "nnz_L", "supernodes", "tree_levels", "subtrees", "max_front", "flops_factor")
         return {k: (float(v) if k == "flops_factor" else int(v)) for k, v in zip(keys, out)}
+
+    def exact_factor(self):
+        """reference-order engine only (pq_kkt_exact_factor): dict with L_cols, L_ind, L_vals, D, D_inv, PKPt_val, perm as numpy arrays; raises for another engine"""
+        nnz = self.L.pq_kkt_exact_factor(self.h, 0, None)
+        check(int(min(nnz, 0)), "exact_factor")
+        N = self.n + self.p + self.m
+        out = {}
+        for key, what, dt, ln in (("L_cols", 1, np.int32, N + 1), ("L_ind", 2, np.int32, nnz), ("L_vals", 3, np.float64, nnz), ("D", 4, np.float64, N), ("D_inv", 5, np.float64, N),
+                                  ("perm", 7, np.int32, N)):
+            a = np.zeros(max(int(ln), 1), dtype=dt)
+            r = self.L.pq_kkt_exact_factor(self.h, what, a.ctypes.data)
+            check(int(min(r, 0)), "exact_factor")
+            out[key] = a[:int(ln)]
+        nk = self.L.pq_kkt_exact_factor(self.h, 6, None)
+        a = np.zeros(max(int(nk), 1))
+        self.L.pq_kkt_exact_factor(self.h, 6, a.ctypes.data)
+        out["PKPt_val"] = a[:int(nk)]
+        return out
 
     def block_info(self):
         """sparse_multistage only: rows of (start, diag_size, off_diag_size); last row = arrow corner block."""

@@ -1,6 +1,7 @@
 """Experiment (round 4): what a cancellation-aware pivot failure signal does to the reference's trajectories.  The oracle's up-looking LDLt
 (sparse/ldlt.hpp:101-169 restated) is run with the hook ORC_EXP_CANCEL_TOL = t: pivot k additionally fails when |D[k]| <= t * max(|a_kk|, |l_ki y_i|).
 For every frozen Maros-Meszaros / netlib / qp fixture: status / iterations without the hook and with t in TOLS.  CPU only.
+NEEDS an oracle built with the hook of tools/exp_cancel_pivot_hook.c.txt pasted in (round 5 removed it from oracle/orc_sparse.c).
 usage: python tools/exp_cancel_pivot.py [workers]"""
 import glob, os, subprocess, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
