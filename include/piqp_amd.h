@@ -268,13 +268,16 @@ int pq_sparse_kkt_symbolic(const pq_sparse_data *data, int mode, int *nnz_out, i
                            int *PKi);
 int pq_kkt_sparse_ordering(pq_kkt *k, int *fill_perm, int *elim_perm);
 /* host-only planning hook of the reference-order engine (PQ_SPARSE_LDLT_EXACT; no GPU needed): everything sparse/ldlt.hpp:42-169 decides from the pattern of the
- * KKT_FULL matrix alone, as the device kernels replay it.  perm[N] (AMD, perm[new] = old), Cp[N + 1] / Ci[nnz(K)] = pattern of P K P', diag_pos[N], etree[N], L in CSC
- * (Lp[N + 1], Li[nnz(L)], rows ascending), and row k of L in the reference's topological visiting order: entries Rp[k] .. Rp[k + 1] with column Rcol[e] and CSC
- * position Rpos[e]; the factorisation's tasks (chains of the elimination tree: rows task_lo[t] .. task_hi[t]) and, per task, the last rows of the tasks it waits for
- * (tchild_ptr[ntask + 1], tchild).  sizes_out = { nnz(L), tasks, tree height, dependent steps on the longest root path, nnz(K), entries of tchild }.  Every array may
- * be NULL (sizing call).  Returns N. */
-int pq_sparse_uplooking_plan(const pq_sparse_data *data, long long sizes_out[6], int *perm, int *Cp, int *Ci, int *diag_pos, int *etree, int *Lp, int *Li, int *Rp,
-                             int *Rcol, int *Rpos, int *task_lo, int *task_hi, int *tchild_ptr, int *tchild);
+ * KKT_FULL matrix alone, and the schedule the device kernels replay it with (csrc/sparse_symbolic.hpp, struct UpLooking).  Items (int32 arrays unless noted):
+ *   0 stats { nnz(L), tasks, tree height, dependent steps on the longest root path, nnz(K), tickets }   1 perm[N] (AMD, perm[new] = old)
+ *   2 Cp[N + 1]  3 Ci[nnz(K)] (pattern of P K P')   4 diag_pos[N]   5 etree[N]   6 Lp[N + 1]   7 Li[nnz(L)] (L in CSC, rows ascending)
+ *   8 Rp[N + 1]  9 Rcol  10 Rpos (row k of L in the reference's visiting order: column, CSC position)
+ *   11 task_ptr  12 task_rows (tasks = paths of the elimination tree of at most 64 rows)   13 row_task  14 row_lane  15 row_prev
+ *   16 dep_ptr  17 dep (children a row pass waits for)   18 tk_kind  19 tk_id (tickets: 0 row pass of a row, 1 path pass of a task)
+ *   20 Rcnt  21 Rtab (per entry: leading column entries the row pass scatters, -1 = own path; table row)   22 tab_ptr  23 mask_ptr  24 task_nU
+ *   25 Tmask (uint64: presence bits of every table row)
+ * len[q] receives the length of item what[q]; out[q] (may be NULL, as may `out`) receives a copy.  Returns N. */
+int pq_sparse_uplooking_plan(const pq_sparse_data *data, int nitems, const int *what, void **out, long long *len);
 
 /* measurement hooks: when enabled, the backend brackets its stages with hipEvents on its own stream.
  * stage 0 = KKT assembly kernel (dense: k_syrk_lower<ASSEMBLE>), 1 = factorisation (all panels),

@@ -197,7 +197,7 @@ def load():
     L.pq_kkt_native_exchange_calls.argtypes = [vp, _ip]
     L.pq_kkt_min_abs_pivot.argtypes = [vp, _dp]
     L.pq_kkt_exact_factor.argtypes = [vp, C.c_int, vp]
-    L.pq_sparse_uplooking_plan.argtypes = [vp] * 16
+    L.pq_sparse_uplooking_plan.argtypes = [vp, C.c_int, vp, vp, vp]
     L.pq_kkt_exact_factor.restype = C.c_longlong
     L.pq_solver_native_exchange_calls.argtypes = [vp, _ip]
     L.pq_kkt_comm_info.argtypes = [vp, _ip]

@@ -451,22 +451,52 @@ int pq_sparse_kkt_symbolic(const pq_sparse_data* data, int mode, int* nnz_out, i
         return N;
     });
 }
-int pq_sparse_uplooking_plan(const pq_sparse_data* data, long long sizes_out[6], int* perm, int* Cp, int* Ci, int* diag_pos, int* etree, int* Lp, int* Li, int* Rp, int* Rcol,
-                             int* Rpos, int* task_lo, int* task_hi, int* tchild_ptr, int* tchild)
+int pq_sparse_uplooking_plan(const pq_sparse_data* data, int nitems, const int* what, void** out, long long* len)
 {
-    if (!data) return fail(PQ_ERR_INVALID, "bad argument");
+    if (!data || nitems < 0 || (nitems && (!what || !len))) return fail(PQ_ERR_INVALID, "bad argument");
     return guarded([&] {
         sparse::Symbolic S;
         sparse::analyse_kkt_pattern(data, 0, S);
         sparse::UpLooking U;
         sparse::analyse_uplooking(S, data, U);
-        if (sizes_out) {
-            sizes_out[0] = U.nnzL; sizes_out[1] = (long long)U.task_lo.size(); sizes_out[2] = U.height; sizes_out[3] = U.crit_steps; sizes_out[4] = U.Cp[U.N];
-            sizes_out[5] = (long long)U.tchild.size();
+        const sparse::IVec stats = {(int)U.nnzL, (int)(U.task_ptr.size() - 1), U.height, (int)std::min<long long>(U.crit_steps, 2147483647LL), U.Cp[U.N], (int)U.tk_kind.size()};
+        for (int q = 0; q < nitems; ++q) {
+            const sparse::IVec* v = nullptr;
+            switch (what[q]) {
+            case 0: v = &stats; break;
+            case 1: v = &U.perm; break;
+            case 2: v = &U.Cp; break;
+            case 3: v = &U.Ci; break;
+            case 4: v = &U.diag_pos; break;
+            case 5: v = &U.etree; break;
+            case 6: v = &U.Lp; break;
+            case 7: v = &U.Li; break;
+            case 8: v = &U.Rp; break;
+            case 9: v = &U.Rcol; break;
+            case 10: v = &U.Rpos; break;
+            case 11: v = &U.task_ptr; break;
+            case 12: v = &U.task_rows; break;
+            case 13: v = &U.row_task; break;
+            case 14: v = &U.row_lane; break;
+            case 15: v = &U.row_prev; break;
+            case 16: v = &U.dep_ptr; break;
+            case 17: v = &U.dep; break;
+            case 18: v = &U.tk_kind; break;
+            case 19: v = &U.tk_id; break;
+            case 20: v = &U.Rcnt; break;
+            case 21: v = &U.Rtab; break;
+            case 22: v = &U.tab_ptr; break;
+            case 23: v = &U.mask_ptr; break;
+            case 24: v = &U.task_nU; break;
+            case 25:
+                len[q] = (long long)U.Tmask.size();
+                if (out && out[q]) std::copy(U.Tmask.begin(), U.Tmask.end(), (unsigned long long*)out[q]);
+                continue;
+            default: throw std::runtime_error("uplooking plan: unknown item");
+            }
+            len[q] = (long long)v->size();
+            if (out && out[q]) std::copy(v->begin(), v->end(), (int*)out[q]);
         }
-        auto cp = [](const sparse::IVec& v, int* out) { if (out) std::copy(v.begin(), v.end(), out); };
-        cp(U.perm, perm); cp(U.Cp, Cp); cp(U.Ci, Ci); cp(U.diag_pos, diag_pos); cp(U.etree, etree); cp(U.Lp, Lp); cp(U.Li, Li); cp(U.Rp, Rp); cp(U.Rcol, Rcol); cp(U.Rpos, Rpos);
-        cp(U.task_lo, task_lo); cp(U.task_hi, task_hi); cp(U.tchild_ptr, tchild_ptr); cp(U.tchild, tchild);
         return U.N;
     });
 }

@@ -74,6 +74,31 @@ __global__ __launch_bounds__(1024) void k_final_reduce(int nblocks, int K, Ops o
     if (lane == 0) { out[k] = x; host[k] = x; }
 }
 
+// ---- reference-order sums (behind the reference-order sparse engine, sparse_exact.hip).  The reference's dot products are left-to-right sums of rounded
+// products (Eigen's expressions as the CPU oracle restates them: oracle/orc_solver.c dot()); a tree reduction gives the same number only up to rounding, and on the
+// degenerate LPs that decide their trajectory by rounding "up to rounding" is another iteration count.  One wave per dot product: 64 products at a time across the
+// lanes, added to the running sum strictly in index order (lane 0 first).  term = a[i] b[i], or (a[i] + as da[i]) (b[i] + az db[i]) when da is set (solver.hpp:747-750).
+constexpr int MAXDOT = 12;
+struct DotJob { const double *a, *b, *da, *db; int n; };
+struct DotJobs { DotJob j[MAXDOT]; double as, az; };
+__global__ __launch_bounds__(64) void k_seq_dots(DotJobs J, double* __restrict__ out, double* __restrict__ host)
+{
+    const DotJob jb = J.j[blockIdx.x];
+    const int lane = threadIdx.x;
+    double s = 0.0;
+    for (int base = 0; base < jb.n; base += 64) {
+        const int i = base + lane;
+        double t = 0.0;
+        if (i < jb.n) t = jb.da ? (jb.a[i] + J.as * jb.da[i]) * (jb.b[i] + J.az * jb.db[i]) : jb.a[i] * jb.b[i];
+        const int cnt = min(64, jb.n - base);
+        for (int l = 0; l < cnt; ++l) {
+            const int lo = __builtin_amdgcn_readlane(__double2loint(t), l), hi = __builtin_amdgcn_readlane(__double2hiint(t), l);
+            s = s + __hiloint2double(hi, lo);
+        }
+    }
+    if (lane == 0) { out[blockIdx.x] = s; host[blockIdx.x] = s; }
+}
+
 struct Dims {
     int n, p, m, nxl, nxu;
 };
@@ -401,6 +426,17 @@ struct DeviceIpm::Impl {
     // phases that reduce in several kernels before the host needs anything use one slot each and fetch once
     double* part_slot(int slot) { return part.p + (size_t)slot * MAXB * NS; }
     void reduce_on_device(int nblocks, int K, const Ops& ops, int slot) { hipLaunchKernelGGL(k_final_reduce, dim3(1), dim3(64 * K), 0, st, nblocks, K, ops, part_slot(slot), scal.p + slot * NS, scal_h.p + slot * NS); }
+    // reference-order mode: the listed dot products, each summed left to right by one wave; results at scal_h[3 * NS + q] once the stream has drained
+    bool exact = false;
+    void seq_dots(std::initializer_list<DotJob> jobs, double as = 0.0, double az = 0.0)
+    {
+        DotJobs J{};
+        int k = 0;
+        for (const DotJob& j : jobs) J.j[k++] = j;
+        J.as = as; J.az = az;
+        hipLaunchKernelGGL(k_seq_dots, dim3(k), dim3(64), 0, st, J, scal.p + 3 * NS, scal_h.p + 3 * NS);
+    }
+    const double* seq() const { return scal_h.p + 3 * NS; }
     const double* fetch(int count)
     {
         (void)count;  // k_final_reduce wrote the scalars into the pinned buffer itself (one device-to-host copy less per synchronisation, ~9 per iteration)
@@ -425,7 +461,7 @@ void DeviceIpm::init(const HostData& d, const Ruiz& rz, hipStream_t st)
         for (int k = 0; k < 10; ++k) { DBuf<double>& b = s.bufs[q * 10 + k]; b.alloc(std::max<size_t>(len[k], 1)); b.zero(st); *f[k] = b.p; }
     }
     s.work_x.alloc(std::max(n, 1)); s.work_z.alloc(std::max(m, 1));
-    s.part.alloc((size_t)3 * MAXB * NS); s.scal.alloc(3 * NS); s.scal_h.alloc(3 * NS);
+    s.part.alloc((size_t)3 * MAXB * NS); s.scal.alloc(4 * NS); s.scal_h.alloc(4 * NS);
     s.has_l.alloc(std::max(m, 1)); s.has_u.alloc(std::max(m, 1)); s.pos_l.alloc(std::max(n, 1)); s.pos_u.alloc(std::max(n, 1)); s.x_l_idx.alloc(std::max(n, 1)); s.x_u_idx.alloc(std::max(n, 1));
     s.c.alloc(std::max(n, 1)); s.b.alloc(std::max(p, 1)); s.h_l.alloc(std::max(m, 1)); s.h_u.alloc(std::max(m, 1)); s.x_l.alloc(std::max(n, 1)); s.x_u.alloc(std::max(n, 1));
     s.xbs.alloc(std::max(n, 1)); s.dl.alloc(std::max(n + p + m, 1)); s.dli.alloc(std::max(n + p + m, 1)); s.db.alloc(std::max(n, 1)); s.dbi.alloc(std::max(n, 1));
@@ -476,6 +512,11 @@ int DeviceIpm::solve(KKTSystem& kkt, const pq_settings& set, const Ruiz& rz, pq_
     const bool has_ineq = m + s.nxl + s.nxu > 0;
     bool refine = set.iterative_refinement_always_enabled != 0;
     const Ops ops_mu = make_ops({OP_SUM});
+    s.exact = be->reference_order();
+    // calculate_mu (solver.hpp:884-891) in the reference's order: four dot products, added in this order
+    auto mu_jobs = [&]() { s.seq_dots({DotJob{s.R.s_l, s.R.z_l, nullptr, nullptr, m}, DotJob{s.R.s_u, s.R.z_u, nullptr, nullptr, m}, DotJob{s.R.s_bl, s.R.z_bl, nullptr, nullptr, s.nxl},
+                                       DotJob{s.R.s_bu, s.R.z_bu, nullptr, nullptr, s.nxu}}); };
+    auto sum4 = [](const double* q) { return ((q[0] + q[1]) + q[2]) + q[3]; };
 
     info.kkt_factor_time = 0; info.kkt_solve_time = 0;
     info.n_factor = info.n_solve = info.n_backend_solve = 0;
@@ -522,9 +563,14 @@ int DeviceIpm::solve(KKTSystem& kkt, const pq_settings& set, const Ruiz& rz, pq_
         const double* r2 = s.reduce(G, 2, o2);
         const double delta_s = std::max(0.0, -r2[0]), delta_z = std::max(0.0, -r2[1]);
         hipLaunchKernelGGL(k_shift_mu, dim3(G), dim3(NT), 0, st, d, M, s.R, delta_s, delta_z, ops_mu, s.part.p);
-        info.mu = std::max(s.reduce(G, 1, ops_mu)[0] / ntot, 1e-10);
-        hipLaunchKernelGGL(k_centre_mu, dim3(G), dim3(NT), 0, st, d, M, s.R, info.mu, delta_z, ops_mu, s.part.p);
+        if (s.exact) mu_jobs();
         info.mu = s.reduce(G, 1, ops_mu)[0] / ntot;
+        if (s.exact) info.mu = sum4(s.seq()) / ntot;
+        info.mu = std::max(info.mu, 1e-10);
+        hipLaunchKernelGGL(k_centre_mu, dim3(G), dim3(NT), 0, st, d, M, s.R, info.mu, delta_z, ops_mu, s.part.p);
+        if (s.exact) mu_jobs();
+        info.mu = s.reduce(G, 1, ops_mu)[0] / ntot;
+        if (s.exact) info.mu = sum4(s.seq()) / ntot;
     }
     hipLaunchKernelGGL(k_copy_prox, dim3(G), dim3(NT), 0, st, d, s.R, s.PX, 3);
 
@@ -536,6 +582,11 @@ int DeviceIpm::solve(KKTSystem& kkt, const pq_settings& set, const Ruiz& rz, pq_
         be->eval_G_xn_and_GT_xt(1.0, 1.0, s.R.x, s.work_z.p, s.NR.z_l, s.NR.x);
         hipLaunchKernelGGL(k_nr_after_G, dim3(G), dim3(NT), 0, st, d, s.NR, s.work_x.p, s.NR.x);
         be->eval_P_x(-1.0, s.R.x, s.NR.x);
+        if (s.exact)  // (before k_nr_x turns nr.x = -P x into the residual: solver.hpp:975 takes x . (P x) first)
+            s.seq_dots({DotJob{s.R.x, s.NR.x, nullptr, nullptr, n}, DotJob{D.c, s.R.x, nullptr, nullptr, n}, DotJob{D.b, s.R.y, nullptr, nullptr, p}, DotJob{D.h_l, s.R.z_l, nullptr, nullptr, m},
+                        DotJob{D.h_u, s.R.z_u, nullptr, nullptr, m}, DotJob{D.x_l, s.R.z_bl, nullptr, nullptr, s.nxl}, DotJob{D.x_u, s.R.z_bu, nullptr, nullptr, s.nxu},
+                        DotJob{s.R.s_l, s.R.z_l, nullptr, nullptr, m}, DotJob{s.R.s_u, s.R.z_u, nullptr, nullptr, m}, DotJob{s.R.s_bl, s.R.z_bl, nullptr, nullptr, s.nxl},
+                        DotJob{s.R.s_bu, s.R.z_bu, nullptr, nullptr, s.nxu}});
         const Ops ox = make_ops({OP_AMAXNAN, OP_SUM, OP_SUM, OP_AMAXNAN, OP_AMAXNAN});
         hipLaunchKernelGGL(k_nr_x, dim3(G), dim3(NT), 0, st, d, M, D, ci, s.R, s.NR, s.work_x.p, ox, s.part_slot(0));
         s.reduce_on_device(G, 5, ox, 0);
@@ -548,17 +599,19 @@ int DeviceIpm::solve(KKTSystem& kkt, const pq_settings& set, const Ruiz& rz, pq_
         const double* a = s.fetch(3 * NS);
         const double* bq = a + NS;
         const double* q = a + 2 * NS;
+        double dots[8] = {a[1], a[2], bq[1], bq[3], bq[4], bq[6], bq[7], q[5]};  // x.Px', c.x, b.y, h_l.z_l, h_u.z_u, x_l.z_bl, x_u.z_bu, sum s.z
+        if (s.exact) { const double* e = s.seq(); for (int t = 0; t < 7; ++t) dots[t] = e[t]; dots[7] = sum4(e + 7); }
         // objective / gap (:975-1013)
-        double tmp = -a[1];
+        double tmp = -dots[0];
         info.primal_obj = 0.5 * tmp;
         info.dual_obj = -0.5 * tmp;
         double dg_rel = ci * std::fabs(tmp);
-        tmp = a[2]; info.primal_obj += tmp; dg_rel = std::max(dg_rel, ci * std::fabs(tmp));
-        tmp = bq[1]; info.dual_obj -= tmp; dg_rel = std::max(dg_rel, ci * std::fabs(tmp));
-        tmp = -bq[3]; info.dual_obj -= tmp; dg_rel = std::max(dg_rel, ci * std::fabs(tmp));
-        tmp = bq[4]; info.dual_obj -= tmp; dg_rel = std::max(dg_rel, ci * std::fabs(tmp));
-        tmp = -bq[6]; info.dual_obj -= tmp; dg_rel = std::max(dg_rel, ci * std::fabs(tmp));
-        tmp = bq[7]; info.dual_obj -= tmp; dg_rel = std::max(dg_rel, ci * std::fabs(tmp));
+        tmp = dots[1]; info.primal_obj += tmp; dg_rel = std::max(dg_rel, ci * std::fabs(tmp));
+        tmp = dots[2]; info.dual_obj -= tmp; dg_rel = std::max(dg_rel, ci * std::fabs(tmp));
+        tmp = -dots[3]; info.dual_obj -= tmp; dg_rel = std::max(dg_rel, ci * std::fabs(tmp));
+        tmp = dots[4]; info.dual_obj -= tmp; dg_rel = std::max(dg_rel, ci * std::fabs(tmp));
+        tmp = -dots[5]; info.dual_obj -= tmp; dg_rel = std::max(dg_rel, ci * std::fabs(tmp));
+        tmp = dots[6]; info.dual_obj -= tmp; dg_rel = std::max(dg_rel, ci * std::fabs(tmp));
         info.duality_gap = std::fabs(info.primal_obj - info.dual_obj);
         info.primal_obj *= ci; info.dual_obj *= ci; info.duality_gap *= ci;
         info.duality_gap_rel = info.duality_gap / std::max(1.0, dg_rel);
@@ -574,7 +627,7 @@ int DeviceIpm::solve(KKTSystem& kkt, const pq_settings& set, const Ruiz& rz, pq_
         info.primal_res_rel = info.primal_res / std::max(1.0, primal_rel_norm);
         info.dual_res = q[4];
         info.dual_res_rel = info.dual_res / std::max(1.0, dual_rel_norm);
-        mu_sum = q[5];
+        mu_sum = dots[7];
     };
     auto residuals_r = [&]() {
         const Ops orr = make_ops({OP_AMAXNAN, OP_AMAXNAN, OP_AMAXNAN, OP_MAX, OP_AMAXNAN, OP_MAX, OP_MAX});
@@ -634,7 +687,9 @@ int DeviceIpm::solve(KKTSystem& kkt, const pq_settings& set, const Ruiz& rz, pq_
             hipLaunchKernelGGL(k_boundary_min, dim3(G), dim3(NT), 0, st, d, M, s.R, DBL_EPSILON, ob, s.part_slot(1));
             s.reduce_on_device(G, 2, ob, 1);
             hipLaunchKernelGGL(k_boundary_apply_pred, dim3(G), dim3(NT), 0, st, d, s.R, s.RS, DBL_EPSILON, s.scal.p + NS, ops_mu, s.part_slot(0));
+            if (s.exact) mu_jobs();
             info.mu = s.reduce(G, 1, ops_mu)[0] / ntot;  // equals the previous value bit for bit when nothing was shifted
+            if (s.exact) info.mu = sum4(s.seq()) / ntot;
         }
         // :668-681
         if ((info.no_primal_update > set.reg_finetune_primal_update_threshold && info.rho == info.reg_limit && info.reg_limit != set.reg_finetune_lower_limit) ||
@@ -671,7 +726,12 @@ int DeviceIpm::solve(KKTSystem& kkt, const pq_settings& set, const Ruiz& rz, pq_
             const double* a2 = s.reduce(G, 2, os);
             double alpha_s = a2[0] * set.tau, alpha_z = a2[1] * set.tau;
             hipLaunchKernelGGL(k_sigma, dim3(G), dim3(NT), 0, st, d, s.R, s.ST, alpha_s, alpha_z, ops_mu, s.part.p);
-            double sigma = s.reduce(G, 1, ops_mu)[0] / (info.mu * ntot);
+            if (s.exact)
+                s.seq_dots({DotJob{s.R.s_l, s.R.z_l, s.ST.s_l, s.ST.z_l, m}, DotJob{s.R.s_u, s.R.z_u, s.ST.s_u, s.ST.z_u, m}, DotJob{s.R.s_bl, s.R.z_bl, s.ST.s_bl, s.ST.z_bl, s.nxl},
+                            DotJob{s.R.s_bu, s.R.z_bu, s.ST.s_bu, s.ST.z_bu, s.nxu}}, alpha_s, alpha_z);
+            double sigma = s.reduce(G, 1, ops_mu)[0];
+            if (s.exact) sigma = sum4(s.seq());
+            sigma /= info.mu * ntot;
             sigma = std::max(0.0, std::min(1.0, sigma));
             info.sigma = sigma * sigma * sigma;
             hipLaunchKernelGGL(k_corrector_rhs, dim3(G), dim3(NT), 0, st, d, s.ST, s.RS, info.sigma * info.mu);

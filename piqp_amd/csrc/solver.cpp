@@ -502,11 +502,11 @@ bool Solver::setup(std::unique_ptr<HostData> data)
     if (!m_kkt_system) { m_setup_done = false; return false; }
     stage_alloc();
     dipm_.reset();
-    // the interior-point loop: vectors resident in HBM (device_ipm.hip: tree reductions) -- or, behind the reference-order sparse engine, the host loop below, whose
-    // dot products and norms run left to right like the reference's: together they make a whole solve the oracle's sequence of IEEE operations
-    // (PIQP_AMD_HOST_IPM=1 / =0 force one or the other)
+    // the interior-point loop: vectors resident in HBM (device_ipm.hip; behind the reference-order sparse engine its dot products are summed left to right like the
+    // reference's, k_seq_dots) -- or the host loop below (PIQP_AMD_HOST_IPM=1).  Behind the reference-order engine BOTH are the oracle's sequence of IEEE operations
+    // (tools/trace_diff.py: every frozen fixture up to 8192 KKT rows bitwise, with either loop).
     const char* host_ipm = std::getenv("PIQP_AMD_HOST_IPM");
-    const bool use_host = host_ipm ? host_ipm[0] == '1' : m_kkt_system->backend()->reference_order();
+    const bool use_host = host_ipm && host_ipm[0] == '1';
     if (!use_host) { dipm_ = std::make_unique<DeviceIpm>(); dipm_->init(*m_data, m_preconditioner, m_kkt_system->stream()); }
     m_first_run = true; m_setup_done = true;
     m_info.setup_time = now_s() - t0;

@@ -67,21 +67,40 @@ __global__ void k_ul_set_diag(int n, int p, int m, const int* __restrict__ diag_
 }
 
 struct UlFactorArgs {
-    int N, ntask, epoch;
+    int N, nticket, epoch;
     const int *Cp, *Ci;
     const double* Cx;
-    const int *task_lo, *task_hi, *tchild_ptr, *tchild;
-    const int *Rp, *Rcol, *Rpos, *Lp, *Li;
-    double *Lx, *D, *Dinv;
-    int *done, *ticket, *info;
+    const int *tk_kind, *tk_id, *task_ptr, *task_rows, *row_task, *row_lane, *row_prev, *dep_ptr, *dep;
+    const int *Rp, *Rcol, *Rpos, *Rcnt, *Rtab, *Lp, *Li;
+    const int *tab_ptr, *mask_ptr, *task_nU;
+    const unsigned long long* Tmask;
+    double *Lx, *D, *Dinv, *Ystash, *Pstash, *Dinit, *Lblock;
+    int *done, *p1done, *ready, *ticket, *info;
     double* yglob;  // N doubles per workgroup when y does not fit LDS
 };
 
 constexpr int UL_PF = 8;  // columns prefetched ahead of the dependent chain (their first 64 entries)
 
-// one row of L, ldlt.hpp:121-163.  y: this wave's dense work vector, all zero on entry and on exit.
+__device__ __forceinline__ bool spin_until(const int* flag, int epoch)
+{
+    long long spins = 0;
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > (1ll << 26)) return false;  // (seconds: a scheduling bug must not take the device with it)
+    }
+    return true;
+}
+
+// ROW PASS of row k (ldlt.hpp:121-163): the entries of row k in the columns outside the row's task, in the reference's order.  A row that is a task of its own is
+// finished here; for a row on a longer path the updates into the path's rows are left to the path pass (Rcnt counts only the entries of a column above them), the
+// values y_i, the products l_ki y_i and the initial values of the path columns go to Ystash / Pstash / Dinit, the quotients also into the task's table.
+// y: this wave's dense work vector, all zero on entry and on exit.
 __device__ __forceinline__ void ul_row(const UlFactorArgs& a, double* __restrict__ y, const int k, const int lane)
 {
+    const int t = a.row_task[k];
+    const int W = a.task_ptr[t + 1] - a.task_ptr[t];
+    const bool multi = W > 1;
+    const int tb = a.tab_ptr[t], lanek = a.row_lane[k];
     // scatter A(0:k, k) into y (:127-131)
     const int p0 = a.Cp[k], p1 = a.Cp[k + 1];
     for (int q = p0 + lane; q < p1; q += 64) y[a.Ci[q]] = a.Cx[q];
@@ -95,8 +114,11 @@ __device__ __forceinline__ void ul_row(const UlFactorArgs& a, double* __restrict
         const bool in = e < r1;
         const int i = in ? a.Rcol[e] : 0, pos = in ? a.Rpos[e] : 0;
         const int cs = in ? a.Lp[i] : 0;
-        const int cnt = pos - cs;  // entries of column i above row k = L_nnz[i] at this moment (:149)
-        const double Di = in ? a.D[i] : 1.0;
+        const int rc = in ? a.Rcnt[e] : 0;   // entries of column i this pass scatters: all above row k (= L_nnz[i] at this moment, :149) or those above the task's path
+        const int cnt = rc > 0 ? rc : 0;
+        const bool ext = in && rc >= 0;      // (a column of the task's own path otherwise: its value in this row comes out of the path pass)
+        const double Di = ext ? a.D[i] : 1.0;
+        const int tabu = in ? a.Rtab[e] : 0;
         const int ns = min(64, r1 - base);
         double my_yi = 0.0;
         // the first 64 entries of the columns of the next UL_PF steps travel ahead of the chain.  Every load is unconditional (lanes past the end of their
@@ -126,21 +148,109 @@ __device__ __forceinline__ void ul_row(const UlFactorArgs& a, double* __restrict
                 if (lane == s) my_yi = yi;
                 if (lane < cntu) y[t0] = msub(y[t0], v0, yi);  // :150-154, distinct targets
                 if (lane == 0 && s < ns) y[iu] = 0.0;          // :148
-                for (int q = 64 + lane; q < cntu; q += 64) { const int t = a.Li[csu + q]; y[t] = msub(y[t], a.Lx[csu + q], yi); }
+                for (int q = 64 + lane; q < cntu; q += 64) { const int tt = a.Li[csu + q]; y[tt] = msub(y[tt], a.Lx[csu + q], yi); }
                 wave_sync();
             }
         }
         // :155-161 for the 64 entries at once; D[k] loses its terms strictly in pattern order
         const double l = __ddiv_rn(my_yi, Di);
-        if (in) a.Lx[pos] = l;
         const double tp = __dmul_rn(l, my_yi);
-        for (int s = 0; s < ns; ++s) Dk = __dsub_rn(Dk, readlane_d(tp, s));
+        if (ext) a.Lx[pos] = l;
+        if (multi) {
+            if (in) a.Ystash[e] = my_yi;
+            if (ext) { a.Pstash[e] = tp; a.Lblock[tb + tabu * W + lanek] = l; }
+        } else {
+            for (int s = 0; s < ns; ++s) Dk = __dsub_rn(Dk, readlane_d(tp, s));
+        }
     }
     if (lane == 0) {
-        a.D[k] = Dk;
-        a.Dinv[k] = __ddiv_rn(1.0, Dk);  // :166
-        if (Dk == 0.0) atomicMin(a.info, k);  // :163 (the smallest such k is the row the serial loop stops at)
+        if (multi) a.Dinit[k] = Dk;
+        else {
+            a.D[k] = Dk;
+            a.Dinv[k] = __ddiv_rn(1.0, Dk);  // :166
+            if (Dk == 0.0) atomicMin(a.info, k);  // :163 (the smallest such k is the row the serial loop stops at)
+        }
     }
+}
+
+// PATH PASS of task t: its rows one after the other, the path rows as lanes.  For row k the pattern is walked once more in the reference's order; an entry in an
+// outside column i sends y_i (from the row pass) to the path rows c < k that hold an entry L(c, i) -- acc_c -= fl(L(c, i) y_i) -- and an entry in a path column c0
+// first has its value final (acc of lane c0: every term it receives comes from a column the order visits earlier) and then does the same.  The quotients and the
+// terms of D[k] follow, the latter again in pattern order.  L(c, .) is read from the task's table, where the passes that produced it left it.
+__device__ __forceinline__ bool ul_path(const UlFactorArgs& a, const int t, const int lane, double* s_acc, int* s_pos)
+{
+    const int rb = a.task_ptr[t], W = a.task_ptr[t + 1] - rb;
+    const int nU = a.task_nU[t], tb = a.tab_ptr[t], mb = a.mask_ptr[t];
+    const int lw = lane < W ? lane : W - 1;
+    double Dlane = 1.0;  // lane c: D of path row c once it is known
+    for (int j = 0; j < W; ++j) {
+        const int k = a.task_rows[rb + j];
+        if (!spin_until(a.p1done + k, a.epoch)) return false;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        const int r0 = a.Rp[k], r1 = a.Rp[k + 1];
+        s_acc[lane] = 0.0; s_pos[lane] = -1;
+        wave_sync();
+        for (int e = r0 + lane; e < r1; e += 64) {
+            const int u = a.Rtab[e];
+            if (u >= nU) { s_acc[u - nU] = a.Ystash[e]; s_pos[u - nU] = a.Rpos[e]; }
+        }
+        wave_sync();
+        double acc = s_acc[lane];
+        const int mypos = s_pos[lane];
+        wave_sync();
+        const unsigned long long below = j >= 64 ? ~0ull : ((1ull << j) - 1ull);  // path rows under row k
+        for (int base = r0; base < r1; base += 64) {
+            const int e = base + lane;
+            const bool in = e < r1;
+            const int ue = in ? a.Rtab[e] : 0;
+            const double yse = in ? a.Ystash[e] : 0.0;
+            const unsigned long long me = in ? a.Tmask[mb + ue] : 0ull;
+            const int mlo = (int)(unsigned)(me & 0xffffffffull), mhi = (int)(unsigned)(me >> 32);
+            const int ns = min(64, r1 - base);
+            double pf_v[UL_PF];
+#pragma unroll
+            for (int d = 0; d < UL_PF; ++d) pf_v[d] = a.Lblock[tb + __builtin_amdgcn_readlane(ue, d) * W + lw];
+            for (int sb = 0; sb < ns; sb += UL_PF) {
+#pragma unroll
+                for (int d = 0; d < UL_PF; ++d) {
+                    const int s = sb + d;
+                    const int u = __builtin_amdgcn_readlane(ue, s & 63);
+                    const unsigned long long m = (((unsigned long long)(unsigned)__builtin_amdgcn_readlane(mhi, s & 63) << 32) | (unsigned)__builtin_amdgcn_readlane(mlo, s & 63)) & below;
+                    const double v = pf_v[d];
+                    pf_v[d] = a.Lblock[tb + __builtin_amdgcn_readlane(ue, (s + UL_PF) & 63) * W + lw];
+                    if (s < ns) {
+                        const double src = u < nU ? readlane_d(yse, s & 63) : readlane_d(acc, (u - nU) & 63);
+                        if ((m >> lane) & 1ull) acc = msub(acc, v, src);
+                    }
+                }
+            }
+        }
+        // quotients of the path columns (:155), their places in L and in the table, their terms of D[k]
+        const bool have = lane < j && mypos >= 0;
+        const double l = __ddiv_rn(acc, Dlane);
+        const double prodp = __dmul_rn(l, acc);
+        if (have) { a.Lx[mypos] = l; a.Lblock[tb + (nU + lane) * W + j] = l; }
+        double Dk = a.Dinit[k];
+        for (int base = r0; base < r1; base += 64) {
+            const int e = base + lane;
+            const bool in = e < r1;
+            const int ue = in ? a.Rtab[e] : 0;
+            const double pse = in ? a.Pstash[e] : 0.0;
+            const int ns = min(64, r1 - base);
+            for (int s = 0; s < ns; ++s) {
+                const int u = __builtin_amdgcn_readlane(ue, s);
+                const double term = u < nU ? readlane_d(pse, s) : readlane_d(prodp, (u - nU) & 63);
+                Dk = __dsub_rn(Dk, term);
+            }
+        }
+        if (lane == 0) {
+            a.D[k] = Dk;
+            a.Dinv[k] = __ddiv_rn(1.0, Dk);
+            if (Dk == 0.0) atomicMin(a.info, k);
+        }
+        if (lane == j) Dlane = Dk;
+    }
+    return true;
 }
 
 template <bool LDSY>
@@ -148,34 +258,47 @@ __global__ __launch_bounds__(64) void k_ul_factor(UlFactorArgs a)
 {
     extern __shared__ double ul_sm[];
     __shared__ int s_task;
+    __shared__ double s_acc[64];
+    __shared__ int s_pos[64];
     double* __restrict__ y = LDSY ? ul_sm : a.yglob + (size_t)blockIdx.x * a.N;
     const int lane = threadIdx.x;
-    for (int t = lane; t < a.N; t += 64) y[t] = 0.0;
+    for (int tt = lane; tt < a.N; tt += 64) y[tt] = 0.0;
     __syncthreads();
     // (the whole workgroup is one wave: __syncthreads() costs nothing and keeps the control flow around the ticket uniform for the compiler)
-    for (int guard = 0; guard <= a.ntask; ++guard) {
+    for (int guard = 0; guard <= a.nticket; ++guard) {
         if (lane == 0) s_task = atomicAdd(a.ticket, 1);
         __syncthreads();
-        const int task = readfirst(s_task);
+        const int tk = readfirst(s_task);
         __syncthreads();
-        if (task >= a.ntask) break;
-        // the tasks that end in a child of this task's first row must be complete (their rows are descendants: every column this task reads is final)
-        const int c0 = a.tchild_ptr[task], c1 = a.tchild_ptr[task + 1];
-        bool stuck = false;
-        for (int c = c0 + lane; c < c1; c += 64) {
-            const int ch = a.tchild[c];
-            long long spins = 0;
-            while (__hip_atomic_load(a.done + ch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.epoch) {
-                __builtin_amdgcn_s_sleep(1);
-                if (++spins > (1ll << 26)) { stuck = true; break; }  // (seconds: a scheduling bug must not take the device with it)
+        if (tk >= a.nticket) break;
+        const int kind = a.tk_kind[tk], id = a.tk_id[tk];
+        bool ok = true;
+        if (kind == 0) {
+            // row pass: the row's children outside its task must be complete rows; the rows below it on its own path are not waited for -- what THEY waited for is
+            // inherited through the `ready` word of the row before
+            const int k = id;
+            const int c0 = a.dep_ptr[k], c1 = a.dep_ptr[k + 1];
+            for (int c = c0 + lane; c < c1; c += 64) ok &= spin_until(a.done + a.dep[c], a.epoch);
+            const int prev = a.row_prev[k];
+            if (prev >= 0) ok &= spin_until(a.ready + prev, a.epoch);
+            ok = __ballot(!ok) == 0;
+            if (ok) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+                __hip_atomic_store(a.ready + k, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ul_row(a, y, k, lane);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                const int t = a.row_task[k];
+                int* flag = (a.task_ptr[t + 1] - a.task_ptr[t] > 1 ? a.p1done : a.done) + k;
+                __hip_atomic_store(flag, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (every lane stores the same word: no divergence at the loop's end)
+            }
+        } else {
+            ok = ul_path(a, id, lane, s_acc, s_pos);
+            if (ok) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                __hip_atomic_store(a.done + a.task_rows[a.task_ptr[id + 1] - 1], a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
-        if (__ballot(stuck)) { if (lane == 0) atomicMin(a.info, -2); break; }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        const int lo = a.task_lo[task], hi = a.task_hi[task];
-        for (int k = lo; k <= hi; ++k) ul_row(a, y, k, lane);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        __hip_atomic_store(a.done + hi, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (every lane stores the same word: no divergence at the loop's end)
+        if (!ok) { if (lane == 0) atomicMin(a.info, -2); break; }
     }
 }
 
@@ -338,12 +461,14 @@ public:
         ctl_h_.p[0] = 0; ctl_h_.p[1] = INT_MAX;
         PQ_HIP(hipMemcpyAsync(ctl_.p, ctl_h_.p, 2 * sizeof(int), hipMemcpyHostToDevice, st_));
         UlFactorArgs a;
-        a.N = N_; a.ntask = ntask_; a.epoch = epoch_;
+        a.N = N_; a.nticket = nticket_; a.epoch = epoch_;
         a.Cp = Cp_.p; a.Ci = Ci_.p; a.Cx = vals_.p;
-        a.task_lo = task_lo_.p; a.task_hi = task_hi_.p; a.tchild_ptr = tchild_ptr_.p; a.tchild = tchild_.p;
-        a.Rp = Rp_.p; a.Rcol = Rcol_.p; a.Rpos = Rpos_.p; a.Lp = Lp_.p; a.Li = Li_.p;
-        a.Lx = Lx_.p; a.D = D_.p; a.Dinv = Dinv_.p;
-        a.done = done_.p; a.ticket = ctl_.p; a.info = ctl_.p + 1;
+        a.tk_kind = tk_kind_.p; a.tk_id = tk_id_.p; a.task_ptr = task_ptr_.p; a.task_rows = task_rows_.p; a.row_task = row_task_.p; a.row_lane = row_lane_.p;
+        a.row_prev = row_prev_.p; a.dep_ptr = dep_ptr_.p; a.dep = dep_.p;
+        a.Rp = Rp_.p; a.Rcol = Rcol_.p; a.Rpos = Rpos_.p; a.Rcnt = Rcnt_.p; a.Rtab = Rtab_.p; a.Lp = Lp_.p; a.Li = Li_.p;
+        a.tab_ptr = tab_ptr_.p; a.mask_ptr = mask_ptr_.p; a.task_nU = task_nU_.p; a.Tmask = Tmask_.p;
+        a.Lx = Lx_.p; a.D = D_.p; a.Dinv = Dinv_.p; a.Ystash = Ystash_.p; a.Pstash = Pstash_.p; a.Dinit = Dinit_.p; a.Lblock = Lblock_.p;
+        a.done = done_.p; a.p1done = p1done_.p; a.ready = ready_.p; a.ticket = ctl_.p; a.info = ctl_.p + 1;
         a.yglob = yglob_.p;
         if (N_ > 0) {
             if (lds_y_) hipLaunchKernelGGL(k_ul_factor<true>, dim3(grid_), dim3(64), (size_t)N_ * sizeof(double), st_, a);
@@ -464,8 +589,14 @@ private:
         upload_vec(mapP_, U_.mapP, st_); upload_vec(mapA_, U_.mapA, st_); upload_vec(mapG_, U_.mapG, st_);
         upload_vec(Lp_, U_.Lp, st_); upload_vec(Li_, U_.Li, st_); upload_vec(Lcol_, U_.Lcol, st_);
         upload_vec(Rp_, U_.Rp, st_); upload_vec(Rcol_, U_.Rcol, st_); upload_vec(Rpos_, U_.Rpos, st_);
-        upload_vec(task_lo_, U_.task_lo, st_); upload_vec(task_hi_, U_.task_hi, st_); upload_vec(tchild_ptr_, U_.tchild_ptr, st_); upload_vec(tchild_, U_.tchild, st_);
-        ntask_ = (int)U_.task_lo.size();
+        upload_vec(tk_kind_, U_.tk_kind, st_); upload_vec(tk_id_, U_.tk_id, st_); upload_vec(task_ptr_, U_.task_ptr, st_); upload_vec(task_rows_, U_.task_rows, st_);
+        upload_vec(row_task_, U_.row_task, st_); upload_vec(row_lane_, U_.row_lane, st_); upload_vec(row_prev_, U_.row_prev, st_); upload_vec(dep_ptr_, U_.dep_ptr, st_);
+        upload_vec(dep_, U_.dep, st_); upload_vec(Rcnt_, U_.Rcnt, st_); upload_vec(Rtab_, U_.Rtab, st_); upload_vec(tab_ptr_, U_.tab_ptr, st_); upload_vec(mask_ptr_, U_.mask_ptr, st_);
+        upload_vec(task_nU_, U_.task_nU, st_); upload_vec(Tmask_, U_.Tmask, st_);
+        ntask_ = (int)U_.task_ptr.size() - 1; nticket_ = (int)U_.tk_kind.size();
+        Ystash_.alloc(U_.nnzL ? (size_t)U_.nnzL : 1); Pstash_.alloc(U_.nnzL ? (size_t)U_.nnzL : 1); Dinit_.alloc(N_ ? N_ : 1);
+        Lblock_.alloc(U_.tab_ptr.back() ? (size_t)U_.tab_ptr.back() : 1); Lblock_.zero(st_);
+        p1done_.alloc(N_ ? N_ : 1); p1done_.zero(st_); ready_.alloc(N_ ? N_ : 1); ready_.zero(st_);
         vals_.alloc(nnzK_ ? nnzK_ : 1); vals_.zero(st_);
         Lx_.alloc(U_.nnzL ? (size_t)U_.nnzL : 1); Lx_.zero(st_);
         D_.alloc(N_ ? N_ : 1); Dinv_.alloc(N_ ? N_ : 1); D_.zero(st_); Dinv_.zero(st_);
@@ -492,6 +623,7 @@ private:
         PQ_HIP(hipDeviceGetAttribute(&dev_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, dev_));
         PQ_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev_));
         const size_t need = (size_t)N_ * sizeof(double);
+        dev_lds -= 1024;  // (the kernels' few static words come out of the same budget)
         lds_y_ = lds_x_ = need <= (size_t)dev_lds && !debug_token("exact_no_lds");
         int per_cu = 1;
         if (lds_y_) {
@@ -508,7 +640,7 @@ private:
             per_cu = std::min(per_cu, 4);
         }
         per_cu = std::max(1, per_cu);
-        grid_ = std::max(1, std::min(ntask_, per_cu * ncu));  // every workgroup of the launch is resident: tasks are taken in row order and wait only for earlier ones
+        grid_ = std::max(1, std::min(nticket_, per_cu * ncu));  // every workgroup of the launch is resident: tasks are taken in row order and wait only for earlier ones
         if (const char* t = debug_token("exact_grid")) grid_ = std::max(1, std::min(grid_, std::atoi(t)));
         yglob_.alloc(lds_y_ ? 1 : (size_t)grid_ * (size_t)N_);
         xglob_.alloc(lds_x_ ? 1 : (size_t)std::max(N_, 1));
@@ -523,13 +655,15 @@ private:
         stream_wait(st_);
     }
 
-    int dev_, n_ = 0, p_ = 0, m_ = 0, N_ = 0, nnzK_ = 0, ntask_ = 0, grid_ = 1, nbgroup_ = 0, epoch_ = 0;
+    int dev_, n_ = 0, p_ = 0, m_ = 0, N_ = 0, nnzK_ = 0, ntask_ = 0, nticket_ = 0, grid_ = 1, nbgroup_ = 0, epoch_ = 0;
     bool lds_y_ = true, lds_x_ = true;
     hipStream_t st_ = nullptr;
     sparse::UpLooking U_;
     CscOperators ops_;
-    DBuf<int> perm_, Cp_, Ci_, diag_pos_, mapP_, mapA_, mapG_, Lp_, Li_, Lcol_, Rp_, Rcol_, Rpos_, task_lo_, task_hi_, tchild_ptr_, tchild_, done_, ctl_, bgroup_;
-    DBuf<double> vals_, Lx_, D_, Dinv_, yglob_, xglob_;
+    DBuf<int> perm_, Cp_, Ci_, diag_pos_, mapP_, mapA_, mapG_, Lp_, Li_, Lcol_, Rp_, Rcol_, Rpos_, Rcnt_, Rtab_, tk_kind_, tk_id_, task_ptr_, task_rows_, row_task_, row_lane_, row_prev_, dep_ptr_, dep_, tab_ptr_, mask_ptr_, task_nU_, done_,
+        p1done_, ready_, ctl_, bgroup_;
+    DBuf<unsigned long long> Tmask_;
+    DBuf<double> vals_, Lx_, D_, Dinv_, Ystash_, Pstash_, Dinit_, Lblock_, yglob_, xglob_;
     HBuf<int> ctl_h_;
     StageProfiler prof_;
 };

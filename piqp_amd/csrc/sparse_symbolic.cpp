@@ -1321,32 +1321,6 @@ void analyse_uplooking(const Symbolic& S, const pq_sparse_data* d, UpLooking& U)
     if (w != nnzL) throw std::runtime_error("up-looking analysis: row and column counts of L disagree");
     U.flops = 0.0;
     for (int k = 0; k < N; ++k) U.flops += (double)colcount[k] * colcount[k] + 3.0 * colcount[k];
-    // chains of the elimination tree = tasks
-    IVec nchild(N, 0);
-    for (int k = 0; k < N; ++k) if (U.etree[k] >= 0) nchild[U.etree[k]]++;
-    U.task_lo.clear(); U.task_hi.clear();
-    IVec task_of(N, -1);
-    for (int k = 0; k < N; ++k) {
-        const bool cont = k > 0 && U.etree[k - 1] == k && nchild[k] == 1;
-        if (!cont) { U.task_lo.push_back(k); U.task_hi.push_back(k); }
-        else U.task_hi.back() = k;
-        task_of[k] = (int)U.task_lo.size() - 1;
-    }
-    const int nt = (int)U.task_lo.size();
-    U.tchild_ptr.assign(nt + 1, 0);
-    for (int k = 0; k < N; ++k) { const int pa = U.etree[k]; if (pa >= 0 && task_of[pa] != task_of[k]) U.tchild_ptr[task_of[pa] + 1]++; }
-    for (int t = 0; t < nt; ++t) U.tchild_ptr[t + 1] += U.tchild_ptr[t];
-    U.tchild.assign(U.tchild_ptr[nt], 0);
-    {
-        IVec fill(U.tchild_ptr.begin(), U.tchild_ptr.end() - 1);
-        for (int k = 0; k < N; ++k) {
-            const int pa = U.etree[k];
-            if (pa >= 0 && task_of[pa] != task_of[k]) {
-                if (pa != U.task_lo[task_of[pa]] || k != U.task_hi[task_of[k]]) throw std::runtime_error("up-looking analysis: chain decomposition");
-                U.tchild[fill[task_of[pa]]++] = k;
-            }
-        }
-    }
     IVec h(N, 0);
     std::vector<long long> cp(N, 0);
     U.height = 0; U.crit_steps = 0;
@@ -1355,6 +1329,95 @@ void analyse_uplooking(const Symbolic& S, const pq_sparse_data* d, UpLooking& U)
         U.height = std::max(U.height, h[k]); U.crit_steps = std::max(U.crit_steps, cp[k]);
         const int pa = U.etree[k];
         if (pa >= 0) { h[pa] = std::max(h[pa], h[k]); cp[pa] = std::max(cp[pa], cp[k]); }
+    }
+    // ---- schedule: paths of the elimination tree.  Every row continues the path of its HEAVIEST child (the one with the longest chain of dependent
+    // steps below it) until the path holds UL_PATH rows; a path is one task.  Row k of a task is computed in two passes (sparse_exact.hip):
+    //   row pass   (any wave, all rows of a task concurrently): the entries of row k whose column lies OUTSIDE the task, exactly as the reference's loop
+    //              forms them, except that the updates these columns send to rows of the task's own path are left out;
+    //   path pass  (one wave per task, its rows one after the other): those left-out updates and the entries in the task's own columns, with the path rows
+    //              as lanes -- every entry still receives its terms in the reference's order (an update into path row c comes from a descendant of c, which
+    //              the reference's pattern order visits before c; the pass walks the pattern of row k once, in that order).
+    constexpr int UL_PATH = 64;
+    IVec heavy(N, -1);
+    {
+        std::vector<long long> best(N, -1);
+        for (int k = 0; k < N; ++k) { const int pa = U.etree[k]; if (pa >= 0 && cp[k] > best[pa]) { best[pa] = cp[k]; heavy[pa] = k; } }
+    }
+    U.row_task.assign(N, -1); U.row_lane.assign(N, 0); U.row_prev.assign(N, -1);
+    std::vector<IVec> rows_of;
+    for (int k = 0; k < N; ++k) {
+        const int hc = heavy[k];
+        if (hc >= 0 && (int)rows_of[U.row_task[hc]].size() < UL_PATH && rows_of[U.row_task[hc]].back() == hc) {
+            const int t = U.row_task[hc];
+            U.row_task[k] = t; U.row_lane[k] = (int)rows_of[t].size(); U.row_prev[k] = hc;
+            rows_of[t].push_back(k);
+        } else {
+            U.row_task[k] = (int)rows_of.size(); U.row_lane[k] = 0;
+            rows_of.push_back(IVec(1, k));
+        }
+    }
+    const int nt = (int)rows_of.size();
+    U.task_ptr.assign(nt + 1, 0);
+    U.task_rows.clear();
+    for (int t = 0; t < nt; ++t) { U.task_rows.insert(U.task_rows.end(), rows_of[t].begin(), rows_of[t].end()); U.task_ptr[t + 1] = (int)U.task_rows.size(); }
+    // what the row pass of k waits for: its children outside the task (complete rows).  The rows below it on the task's own path are not waited for; their
+    // own waits are inherited through the `ready` word of the row before (set as soon as that row's waits are over).
+    U.dep_ptr.assign(N + 1, 0);
+    for (int k = 0; k < N; ++k) { const int pa = U.etree[k]; if (pa >= 0 && U.row_task[pa] != U.row_task[k]) U.dep_ptr[pa + 1]++; }
+    for (int k = 0; k < N; ++k) U.dep_ptr[k + 1] += U.dep_ptr[k];
+    U.dep.assign(U.dep_ptr[N], 0);
+    {
+        IVec fill(U.dep_ptr.begin(), U.dep_ptr.end() - 1);
+        for (int k = 0; k < N; ++k) { const int pa = U.etree[k]; if (pa >= 0 && U.row_task[pa] != U.row_task[k]) U.dep[fill[pa]++] = k; }
+    }
+    // tickets: rows ascending; the path pass of a task right behind the row pass of its last row (every wait is for an earlier ticket)
+    U.tk_kind.clear(); U.tk_id.clear();
+    for (int k = 0; k < N; ++k) {
+        U.tk_kind.push_back(0); U.tk_id.push_back(k);
+        const int t = U.row_task[k];
+        if (rows_of[t].size() > 1 && rows_of[t].back() == k) { U.tk_kind.push_back(1); U.tk_id.push_back(t); }
+    }
+    // per entry: how many leading entries of its column the row pass scatters (-1: a column of the task's own path, left to the path pass), and the
+    // row of the task's table the entry's column has; per task: the table itself -- one row per column that reaches the path (outside columns, then the path's
+    // own), one slot per path row: the values L(path row, column) the path pass reads (written by the passes that produce them) and their presence bits
+    U.Rcnt.assign(nnzL, 0); U.Rtab.assign(nnzL, 0);
+    U.tab_ptr.assign(nt + 1, 0); U.mask_ptr.assign(nt + 1, 0); U.task_nU.assign(nt, 0);
+    U.Tmask.clear();
+    {
+        IVec ucol(N, -1);  // column -> table row within the task being built
+        for (int t = 0; t < nt; ++t) {
+            const IVec& R = rows_of[t];
+            const int W = (int)R.size();
+            U.tab_ptr[t + 1] = U.tab_ptr[t]; U.mask_ptr[t + 1] = U.mask_ptr[t];
+            if (W == 1) {
+                const int k = R[0];
+                for (int e = U.Rp[k]; e < U.Rp[k + 1]; ++e) U.Rcnt[e] = U.Rpos[e] - U.Lp[U.Rcol[e]];
+                continue;
+            }
+            IVec ucols;
+            for (int k : R)
+                for (int e = U.Rp[k]; e < U.Rp[k + 1]; ++e) {
+                    const int i = U.Rcol[e];
+                    if (U.row_task[i] == t) { U.Rcnt[e] = -1; continue; }
+                    int q = U.Lp[i];
+                    while (U.row_task[U.Li[q]] != t) ++q;   // (ends: row k itself is an entry of column i)
+                    U.Rcnt[e] = q - U.Lp[i];
+                    if (ucol[i] < 0) { ucol[i] = (int)ucols.size(); ucols.push_back(i); }
+                }
+            const int nU = (int)ucols.size();
+            U.task_nU[t] = nU;
+            const size_t m0 = U.Tmask.size();
+            U.Tmask.resize(m0 + nU + W, 0ull);
+            for (int u = 0; u < nU + W; ++u) {
+                const int col = u < nU ? ucols[u] : R[u - nU];
+                for (int q = U.Lp[col]; q < U.Lp[col + 1]; ++q) if (U.row_task[U.Li[q]] == t) U.Tmask[m0 + u] |= 1ull << U.row_lane[U.Li[q]];
+            }
+            for (int k : R)
+                for (int e = U.Rp[k]; e < U.Rp[k + 1]; ++e) { const int i = U.Rcol[e]; U.Rtab[e] = U.row_task[i] == t ? nU + U.row_lane[i] : ucol[i]; }
+            for (int i : ucols) ucol[i] = -1;
+            U.tab_ptr[t + 1] = U.tab_ptr[t] + (nU + W) * W;
+            U.mask_ptr[t + 1] = (int)U.Tmask.size();
+        }
     }
 }
 

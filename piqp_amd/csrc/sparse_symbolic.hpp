@@ -96,9 +96,14 @@ struct UpLooking {
     IVec etree;                 // ldlt.hpp:61-83
     IVec Lp, Li, Lcol;          // L strictly lower, CSC with ascending rows (the reference fills every column in row order); Lcol = column of every entry
     IVec Rp, Rcol, Rpos;        // row k of L: entries Rp[k] .. Rp[k+1] in the reference's topological order: column index, position in the CSC arrays
-    // schedule of the factorisation: maximal chains k0 .. k1 of rows with etree[t-1] == t and t having no other child are ONE task (one wave walks it);
-    // a task starts when the tasks that end in a child of k0 are done
-    IVec task_lo, task_hi, tchild_ptr, tchild;
+    // schedule of the factorisation (see analyse_uplooking): tasks = paths of the elimination tree of at most 64 rows
+    IVec task_ptr, task_rows;   // rows of every task, bottom-up (each the parent of the one before)
+    IVec row_task, row_lane, row_prev;  // per row: its task, its position in it, the row before it in the task (-1: first)
+    IVec dep_ptr, dep;          // per row: the children outside its task (rows whose completion the row pass waits for)
+    IVec tk_kind, tk_id;        // tickets in issue order: 0 = row pass of row id, 1 = path pass of task id
+    IVec Rcnt, Rtab;            // per entry of a row: leading entries of its column the row pass scatters (-1: column of the task's own path); row of the task's table
+    IVec tab_ptr, mask_ptr, task_nU;  // per task: offset of its (nU + W) x W value table, of its nU + W presence words, columns outside the path that reach it
+    std::vector<unsigned long long> Tmask;
     long long nnzL = 0;
     double flops = 0.0;         // sum_j (c_j^2 + 3 c_j)
     int height = 0;             // elimination tree height (rows)

@@ -24,25 +24,26 @@ def _p(a):
     return a.ctypes.data_as(_ip)
 
 
-def plan(name_or_args):
+ITEMS = ("stats", "perm", "Cp", "Ci", "diag_pos", "etree", "Lp", "Li", "Rp", "Rcol", "Rpos", "task_ptr", "task_rows", "row_task", "row_lane", "row_prev", "dep_ptr", "dep",
+         "tk_kind", "tk_id", "Rcnt", "Rtab", "tab_ptr", "mask_ptr", "task_nU", "Tmask")
+
+
+def plan(args):
     import piqp_amd
     L = piqp_amd._lib.load()
-    args = name_or_args
     d = piqp_amd.SparseData(*args)
     desc = d.descriptor()
-    sizes = (C.c_longlong * 6)()
-    none = [None] * 14
-    N = L.pq_sparse_uplooking_plan(C.byref(desc), sizes, *none)
+    n = len(ITEMS)
+    what = (C.c_int * n)(*range(n))
+    lens = (C.c_longlong * n)()
+    N = L.pq_sparse_uplooking_plan(C.byref(desc), n, what, None, lens)
     assert N > 0, N
-    nnzL, ntask, height, crit, nnzK, nch = (int(v) for v in sizes)
-    z = lambda n: np.zeros(max(n, 1), np.int32)
-    a = dict(perm=z(N), Cp=z(N + 1), Ci=z(nnzK), diag_pos=z(N), etree=z(N), Lp=z(N + 1), Li=z(nnzL), Rp=z(N + 1), Rcol=z(nnzL), Rpos=z(nnzL), task_lo=z(ntask), task_hi=z(ntask),
-             tchild_ptr=z(ntask + 1), tchild=z(nch))
-    order = ("perm", "Cp", "Ci", "diag_pos", "etree", "Lp", "Li", "Rp", "Rcol", "Rpos", "task_lo", "task_hi", "tchild_ptr", "tchild")
-    assert L.pq_sparse_uplooking_plan(C.byref(desc), sizes, *[_p(a[k]) for k in order]) == N
+    arrs = [np.zeros(max(int(lens[q]), 1), np.uint64 if ITEMS[q] == "Tmask" else np.int32) for q in range(n)]
+    outs = (C.c_void_p * n)(*[a.ctypes.data for a in arrs])
+    assert L.pq_sparse_uplooking_plan(C.byref(desc), n, what, outs, lens) == N
+    a = {ITEMS[q]: arrs[q][:int(lens[q])] for q in range(n)}
+    nnzL, ntask, height, crit, nnzK, ntick = (int(v) for v in a["stats"])
     a.update(N=N, nnzL=nnzL, ntask=ntask, height=height, crit=crit, nnzK=nnzK)
-    for k, n in (("Ci", nnzK), ("Li", nnzL), ("Rcol", nnzL), ("Rpos", nnzL), ("tchild", nch), ("task_lo", ntask), ("task_hi", ntask)):
-        a[k] = a[k][:n]
     return a, d
 
 
@@ -51,50 +52,123 @@ def _args(q):
 
 
 def replay(pl, Cx):
-    """the kernels' order of operations on the host (numpy float64: every product and every difference rounded on its own)"""
-    N, Cp, Ci, Lp, Li, Rp, Rcol, Rpos = pl["N"], pl["Cp"], pl["Ci"], pl["Lp"], pl["Li"], pl["Rp"], pl["Rcol"], pl["Rpos"]
+    """the kernels' order of operations on the host (numpy float64: every product and every difference rounded on its own): tickets in an order a parallel run
+    could produce (the row passes of a task before its path pass, otherwise latest first), the row pass and the path pass as sparse_exact.hip runs them"""
+    N, Cp, Ci, Lp, Li, Rp, Rcol, Rpos, Rcnt, Rtab = (pl[k] for k in ("N", "Cp", "Ci", "Lp", "Li", "Rp", "Rcol", "Rpos", "Rcnt", "Rtab"))
     Lx, D, Dinv = np.zeros(pl["nnzL"]), np.zeros(N), np.zeros(N)
+    Ystash, Pstash, Dinit = np.zeros(pl["nnzL"]), np.zeros(pl["nnzL"]), np.zeros(N)
+    Lblock = np.zeros(max(int(pl["tab_ptr"][-1]), 1))
     y = np.zeros(N)
-    done = np.zeros(N, bool)
-    info = N
-    # tasks in an order a parallel run could produce: last task first among the ready ones (anything but row order)
-    ntask = pl["ntask"]
-    pending = list(range(ntask))
-    while pending:
-        ready = [t for t in pending if all(done[c] for c in pl["tchild"][pl["tchild_ptr"][t]:pl["tchild_ptr"][t + 1]])]
-        assert ready, "the task graph has a cycle"
-        t = ready[-1]
-        pending.remove(t)
-        for k in range(pl["task_lo"][t], pl["task_hi"][t] + 1):
-            if info < N:
-                break  # (a zero pivot poisons the rows above it; the oracle stops there as well)
-            y[Ci[Cp[k]:Cp[k + 1]]] = Cx[Cp[k]:Cp[k + 1]]
-            Dk = y[k]; y[k] = 0.0
-            for base in range(Rp[k], Rp[k + 1], 64):
-                hi = min(base + 64, Rp[k + 1])
-                yis = np.zeros(hi - base)
-                for e in range(base, hi):
-                    i, pos = Rcol[e], Rpos[e]
-                    yi = y[i]; y[i] = 0.0
-                    yis[e - base] = yi
+    done = np.zeros(N, bool); p1done = np.zeros(N, bool); ready = np.zeros(N, bool)
+    info = [N]
+    tptr, trows, rtask, rlane, rprev = pl["task_ptr"], pl["task_rows"], pl["row_task"], pl["row_lane"], pl["row_prev"]
+
+    def row_pass(k):
+        t = rtask[k]
+        W = tptr[t + 1] - tptr[t]
+        multi = W > 1
+        y[Ci[Cp[k]:Cp[k + 1]]] = Cx[Cp[k]:Cp[k + 1]]
+        Dk = y[k]; y[k] = 0.0
+        for base in range(Rp[k], Rp[k + 1], 64):
+            hi = min(base + 64, Rp[k + 1])
+            yis = np.zeros(hi - base)
+            for e in range(base, hi):
+                i = Rcol[e]
+                yi = y[i]; y[i] = 0.0
+                yis[e - base] = yi
+                cnt = Rcnt[e]
+                if cnt > 0:
                     cs = Lp[i]
-                    if pos > cs:
-                        tg = Li[cs:pos]
-                        y[tg] = y[tg] - Lx[cs:pos] * yi
-                with np.errstate(divide="ignore", invalid="ignore"):
-                    l = yis / D[Rcol[base:hi]]
-                    Lx[Rpos[base:hi]] = l
-                    tp = l * yis
+                    tg = Li[cs:cs + cnt]
+                    y[tg] = y[tg] - Lx[cs:cs + cnt] * yi
+            ext = Rcnt[base:hi] >= 0
+            with np.errstate(all="ignore"):
+                l = yis / D[Rcol[base:hi]]
+                tp = l * yis
+            ee = np.arange(base, hi)
+            Lx[Rpos[ee[ext]]] = l[ext]
+            if multi:
+                Ystash[base:hi] = yis
+                Pstash[ee[ext]] = tp[ext]
+                tb = pl["tab_ptr"][t]
+                Lblock[tb + Rtab[ee[ext]] * W + rlane[k]] = l[ext]
+            else:
                 for v in tp:
                     Dk = Dk - v
-            D[k] = Dk
-            with np.errstate(divide="ignore"):
-                Dinv[k] = np.float64(1.0) / Dk
-            if Dk == 0.0:
-                info = min(info, k)
-            assert info < N or not y.any()
-        done[pl["task_hi"][t]] = True
-    return Lx, D, Dinv, info
+        if multi:
+            Dinit[k] = Dk
+            p1done[k] = True
+        else:
+            finish(k, Dk)
+        assert info[0] < N or not y.any()
+
+    def finish(k, Dk):
+        D[k] = Dk
+        with np.errstate(all="ignore"):
+            Dinv[k] = np.float64(1.0) / Dk
+        if Dk == 0.0:
+            info[0] = min(info[0], k)
+        done[k] = True
+
+    def path_pass(t):
+        R = trows[tptr[t]:tptr[t + 1]]
+        W = len(R)
+        nU = pl["task_nU"][t]
+        tb, mb = pl["tab_ptr"][t], pl["mask_ptr"][t]
+        Dlane = np.zeros(W)
+        for j, k in enumerate(R):
+            assert p1done[k]
+            acc = np.zeros(W); present = np.zeros(W, bool); pos = np.zeros(W, int)
+            for e in range(Rp[k], Rp[k + 1]):
+                if Rtab[e] >= nU:
+                    c = Rtab[e] - nU
+                    acc[c] = Ystash[e]; present[c] = True; pos[c] = Rpos[e]
+            for e in range(Rp[k], Rp[k + 1]):
+                u = Rtab[e]
+                src = Ystash[e] if u < nU else acc[u - nU]
+                mask = int(pl["Tmask"][mb + u])
+                lanes = np.array([c for c in range(j) if (mask >> c) & 1], int)
+                if lanes.size:
+                    with np.errstate(all="ignore"):
+                        acc[lanes] = acc[lanes] - Lblock[tb + u * W + lanes] * src
+            with np.errstate(all="ignore"):
+                l = acc / Dlane
+                prodp = l * acc
+            for c in range(j):
+                if present[c]:
+                    Lx[pos[c]] = l[c]
+                    Lblock[tb + (nU + c) * W + j] = l[c]
+            Dk = Dinit[k]
+            for e in range(Rp[k], Rp[k + 1]):
+                u = Rtab[e]
+                with np.errstate(all="ignore"):
+                    Dk = Dk - (Pstash[e] if u < nU else prodp[u - nU])
+            finish(k, Dk)
+            Dlane[j] = Dk
+
+    # tickets: any order that respects the waits -- here: repeatedly the LAST ticket whose waits are satisfied
+    kinds, ids = pl["tk_kind"], pl["tk_id"]
+    pending = list(range(len(kinds)))
+    while pending and info[0] == N:
+        pick = None
+        for q in reversed(pending):
+            if kinds[q] == 0:
+                k = ids[q]
+                ok = all(done[c] for c in pl["dep"][pl["dep_ptr"][k]:pl["dep_ptr"][k + 1]]) and (rprev[k] < 0 or ready[rprev[k]])
+            else:
+                t = ids[q]
+                ok = all(p1done[k] for k in trows[tptr[t]:tptr[t + 1]])
+            if ok:
+                pick = q
+                break
+        assert pick is not None, "the ticket graph has a cycle"
+        pending.remove(pick)
+        if kinds[pick] == 0:
+            ready[ids[pick]] = True
+            row_pass(ids[pick])
+        else:
+            path_pass(ids[pick])
+    return Lx, D, Dinv, info[0]
 
 
 @pytest.mark.parametrize("name", FIXTURES)
@@ -122,18 +196,26 @@ def test_plan_structure_equals_the_oracle(orc, name):
         assert np.all(pl["Li"][pl["Rpos"][e0:e1]] == k)
         assert np.all(pl["Rcol"][e0:e1] < k)
     assert sorted(pl["Rpos"].tolist()) == list(range(pl["nnzL"]))
-    # tasks partition the rows into chains; a task waits for chains that end in a child of its first row
+    # tasks partition the rows into paths of the elimination tree of at most 64 rows; a row pass waits for the row's children outside its task
+    et, tptr, trows = pl["etree"], pl["task_ptr"], pl["task_rows"]
     cover = np.zeros(N, int)
-    nchild = np.bincount(pl["etree"][pl["etree"] >= 0], minlength=N)
     for t in range(pl["ntask"]):
-        lo, hi = pl["task_lo"][t], pl["task_hi"][t]
-        cover[lo:hi + 1] += 1
-        for r in range(lo + 1, hi + 1):
-            assert pl["etree"][r - 1] == r and nchild[r] == 1
-        ch = pl["tchild"][pl["tchild_ptr"][t]:pl["tchild_ptr"][t + 1]]
-        assert sorted(ch.tolist()) == sorted(np.nonzero(pl["etree"] == lo)[0].tolist())
-        assert all(c in set(pl["task_hi"].tolist()) for c in ch)
+        R = trows[tptr[t]:tptr[t + 1]]
+        assert 1 <= len(R) <= 64
+        cover[R] += 1
+        for a, b in zip(R[:-1], R[1:]):
+            assert et[a] == b and pl["row_prev"][b] == a
+        assert pl["row_prev"][R[0]] == -1
+        assert np.array_equal(pl["row_lane"][R], np.arange(len(R))) and np.all(pl["row_task"][R] == t)
     assert np.all(cover == 1)
+    for k in range(N):
+        ch = np.nonzero(et == k)[0]
+        outside = sorted(c for c in ch if pl["row_task"][c] != pl["row_task"][k])
+        assert sorted(pl["dep"][pl["dep_ptr"][k]:pl["dep_ptr"][k + 1]].tolist()) == outside
+        assert all(pl["task_rows"][pl["task_ptr"][pl["row_task"][c] + 1] - 1] == c for c in outside)  # a waited-for row ends its own task
+    # tickets: every row pass once, rows ascending; a path pass right behind the row pass of its last row
+    rows_seen = [i for kd, i in zip(pl["tk_kind"], pl["tk_id"]) if kd == 0]
+    assert rows_seen == list(range(N))
     assert pl["crit"] <= pl["nnzL"] and pl["height"] <= N
 
 

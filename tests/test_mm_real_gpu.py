@@ -70,89 +70,55 @@ def test_kkt_factor_solve_on_real_problem(hip, orc, name):
         assert _rel(lhs[key], lo[key]) < 1e-6, (name, key)
 
 
-# Degenerate netlib-derived problems whose trajectories are decided by rounding once rho = delta sit at their floor.  Evidence:
-#  * round 3 (profiles/r03_ordering_parity.txt): the ORACLE ITSELF changes its count on them when the same sources are compiled with FMA contraction
-#    (oracle/Makefile target `fma` = gcc's default at -O3 -march=native, the flags the reference documents); forcing the reference's elimination order on the device
-#    changes nothing (these problems already run in it);
-#  * round 4 (profiles/r04_ref_arith.txt, tools/exp_ref_arith.py): five builds of the device's front arithmetic -- fused / per term as the reference forms them
-#    (sparse/ldlt.hpp:151-158), on the pivot loops, the Schur complement, the diagonal only -- move exactly these fixtures and keep the other ~200 counts;
-#  * the mechanism (QBEACONF, fffff800, robot_arm_sqp): two variables tied by an equality row whose pivot is -delta; their Schur complement cancels (1e10 - 1e10,
-#    true value 8e-7) and the reference's unfused arithmetic lands on EXACTLY 0.0 on some states, which sends its loop into the recovery path (regularisation x 100,
-#    refinement on for the rest of the solve: solver.hpp:691-704) -- a rescue by accident of rounding.  Since round 4 the one-workgroup fronts form every term the
-#    reference's way (quotient, rounded product, rounded difference), so such zeros occur on the device as well: QBEACONF now takes the oracle's 17 iterations,
-#    robot_arm_sqp at default settings is solved.  A tolerance-based "cancellation" signal instead was tried on the oracle's own arithmetic and rejected
-#    (profiles/r04_cancel_pivot_experiment.txt: it moves 26+ runs and breaks three).
-# Held to: the status of one of the two oracle builds, the oracle's optimum; the count is recorded and bounded (half the smaller .. twice the larger oracle count).
-TRAJECTORY_SENSITIVE = {
-    "mm_QBEACONF": "oracle 17 / 18 (fma); device 17",
-    "mm_QCAPRI": "oracle 50 / 35 (fma); device 34", "mm_QETAMACR": "oracle 29 / 29; device 29", "mm_QGROW7": "oracle 24 / 24; device 27 (24-33 over the arithmetic variants)",
-    "mm_QGROW22": "oracle 30 / 30; device 36 (30-36 over the variants)", "mm_QSHARE1B": "oracle 24 / 24; device 26 (24-26)", "mm_STADAT1": "oracle 44 / 44; device 42 (42-43)",
-    "mm_QPILOTNO": "oracle 35 / 62 (fma); device 50 (37-57)", "mm_QSHIP08L": "oracle 16 / 16; device 15", "mm_QSHIP08S": "oracle 21 / 19 (fma); device 17 (15-20)",
-    "nl_fffff800": "oracle 43 / 39 (fma); device MAX_ITER in every variant", "nl_finnis": "oracle 35 / 35; device 35 with the fused arithmetic of rounds 1-3, MAX_ITER with every per-term variant",
-    "nl_perold": "oracle 49 / 47 (fma); device 42, MAX_ITER in two of four variants", "nl_forplan": "oracle 51 / 77 (fma); device 58-176",
-}
-# The two fixtures of the sweeps (of 217) where the device ends MAX_ITER while BOTH oracle builds solve -- recorded, not hidden:
-#  * fffff800: the reference's rescue is an exact zero produced by the ORDER of its row sum: D[k] = ((a_kk - small terms) - t1) - t2 with t1 = -t2 = 1.4e12 absorbs
-#    a_kk = 1e-13 into t1 and cancels to 0.0; a multifrontal sum groups t1 and t2 in one child's update matrix, where they cancel first, and keeps a clean pivot
-#    of 1e-13 -- the more accurate result, and no signal.  MAX_ITER in all five arithmetic variants.
-#  * finnis: the opposite case -- solved (35 = the oracle's count) by the fused arithmetic of rounds 1-3, MAX_ITER as soon as the pivot loops form their terms the
-#    reference's way: exact zeros then occur on states where the oracle's summation order has none, and the recovery path (regularisation x 100) taken at the
-#    wrong moment stalls it; the oracle shows the same when made to signal more often (profiles/r04_cancel_pivot_experiment.txt: 35 -> MAX_ITER).
-# profiles/r04_ref_arith.txt has the whole table: every variant agrees with an oracle build's status on 217 or 218 of 220 fixtures, none on all.
-STATUS_EXCEPTIONS = {"nl_fffff800", "nl_finnis"}
+# Whole solves.  Round 5: kkt_solver = sparse_ldlt runs the reference's OWN elimination order on the device for KKT systems up to 8192 rows (sparse_exact.hip), the
+# mat-vecs and the interior-point loop in the reference's order of operations, all built without FMA contraction like the oracle: a whole solve is then the same
+# sequence of IEEE operations as the oracle's, and the contract is the strongest one there is -- the per-iteration table of solver.hpp:590-602 (objectives,
+# residuals, rho, delta, mu, step lengths) BITWISE equal on every iteration, the same status, the same count, the same x.  That covers every fixture the earlier
+# rounds had to list as trajectory sensitive (the degenerate LPs that decide their path on exact zero pivots: QBEACONF, fffff800, finnis, perold, forplan, ...):
+# there is no allow-list any more.  Above 8192 rows the supernodal multifrontal engine runs (another summation order by construction): same status, the optimum
+# to 1e-6, the count within one iteration of the oracle's.
+EXACT_MAX_ROWS = 8192
+MULTIFRONTAL_ITER_SLACK = 1
 
 
-def _oracle_both_builds(orc, q, netlib=False):
-    """(status, iterations, objective) of the oracle as built (no FMA contraction in the sparse LDLt, like the reference forces) and of its FMA-contracted build"""
-    out = []
-    for L in (None, orc.lib_fma()):
-        so = orc.Solver(_L=L); so.settings.kkt_solver = orc.SPARSE_LDLT
-        if netlib:
-            so.settings.infeasibility_threshold = 0.01
-        assert so.setup(*_args(q), sparse=True)
-        out.append((so.solve(), so.info.iter, so.info.primal_obj))
-    return out
+def _rows(q):
+    return q["P"].shape[0] + (0 if q["A"] is None else q["A"].shape[0]) + (0 if q["G"] is None else q["G"].shape[0])
 
 
-def _check_sensitive(name, sh, st_h, builds):
-    (st_a, it_a, obj_a), (st_b, it_b, obj_b) = builds
-    if name in STATUS_EXCEPTIONS:
-        assert st_a == 1 and st_b == 1 and st_h in (1, -1), (name, st_a, st_b, st_h)
+def _solve_both(hip, orc, q, netlib=False):
+    sh = hip.SparseSolver(); sh.settings.kkt_solver = hip.SPARSE_LDLT
+    so = orc.Solver(); so.settings.kkt_solver = orc.SPARSE_LDLT
+    if netlib:
+        sh.settings.infeasibility_threshold = so.settings.infeasibility_threshold = 0.01
+    sh.enable_trace(1024); so.enable_trace(1024)
+    assert sh.setup(*_args(q)) and so.setup(*_args(q), sparse=True)
+    return sh, so, sh.solve(), so.solve()
+
+
+def _assert_same_solve(name, q, sh, so, st_h, st_o):
+    assert st_h == st_o, (name, st_h, st_o)
+    if _rows(q) <= EXACT_MAX_ROWS:
+        th, to = sh.trace(), so.trace()
+        assert sh.info.iter == so.info.iter, (name, sh.info.iter, so.info.iter)
+        assert th.shape == to.shape, (name, th.shape, to.shape)
+        same = (th == to) | ((th != th) & (to != to))
+        bad = np.argwhere(~same)
+        assert bad.size == 0, (name, "first differing (iteration, column)", bad[0].tolist(), th[tuple(bad[0])], to[tuple(bad[0])])
+        assert np.array_equal(np.asarray(sh.result()["x"]), np.asarray(so.result()["x"])), name
     else:
-        assert st_h in (st_a, st_b), (name, st_h, st_a, st_b)
-    if st_h == 1:
-        its = [it for st, it in ((st_a, it_a), (st_b, it_b)) if st == 1]
-        assert min(its) // 2 <= sh.info.iter <= 2 * max(its), (name, sh.info.iter, it_a, it_b)
-        obj = obj_a if st_a == 1 else obj_b
-        assert abs(sh.info.primal_obj - obj) <= 1e-6 * max(1.0, abs(obj)) + 10 * sh.settings.eps_abs
-
-
-# (The CONT-xxx family -- PDE-constrained grids, the fixtures with fronts of several hundred rows -- sat one iteration off the oracle for a while in
-# round 2: 13 / 12 instead of 12 / 11 on CONT-201 / CONT-101.  The cause was the panel solve of the big fronts multiplying by explicitly inverted 16 x 16
-# diagonal pieces, which costs an order of magnitude of KKT residual on quasi-definite fronts with pivots of rho = delta = 1e-10; with the substitution
-# form (dense_kernels.hip, trsm_panel_body<SUBST>) the device's residual is 0.2x .. 0.6x the oracle's on every recorded state of CONT-201
-# (tools/dbg_sparse_accuracy.py) and the counts are the oracle's again: no slack here.)
-ITER_SLACK = {}
+        assert abs(sh.info.iter - so.info.iter) <= MULTIFRONTAL_ITER_SLACK, (name, sh.info.iter, so.info.iter)
+        if st_h == 1:
+            assert abs(sh.info.primal_obj - so.info.primal_obj) <= 1e-6 * max(1.0, abs(so.info.primal_obj)) + 10 * so.settings.eps_abs
 
 
 @pytest.mark.parametrize("name", ALL_MM)
 def test_status_and_iterations_match_oracle(hip, orc, name):
-    """maros_meszaros_tests.cpp contract through the device solver: same status as the oracle (SOLVED wherever the reference's sweep expects it),
-    same iteration count, same objective"""
+    """maros_meszaros_tests.cpp contract through the device solver: SOLVED wherever the reference's sweep expects it, and the solve itself equal to the oracle's
+    (bitwise below 8192 KKT rows, see above)"""
     q = load_qp(name)
-    sh = hip.SparseSolver(); sh.settings.kkt_solver = hip.SPARSE_LDLT
-    so = orc.Solver(); so.settings.kkt_solver = orc.SPARSE_LDLT
-    assert sh.setup(*_args(q)) and so.setup(*_args(q), sparse=True)
-    st_h, st_o = sh.solve(), so.solve()
+    sh, so, st_h, st_o = _solve_both(hip, orc, q)
     assert st_o == 1, (name, st_o)  # the reference's sweep expects SOLVED on every file; the oracle meets it on all 110 frozen ones
-    if name in TRAJECTORY_SENSITIVE:
-        _check_sensitive(name, sh, st_h, _oracle_both_builds(orc, q))
-        return
-    else:
-        assert st_h == st_o, (name, st_h, st_o)
-        assert abs(sh.info.iter - so.info.iter) <= ITER_SLACK.get(name, 0 if so.info.iter < 30 else 1), (name, sh.info.iter, so.info.iter)
-    if st_h == 1:
-        assert abs(sh.info.primal_obj - so.info.primal_obj) <= 1e-6 * max(1.0, abs(so.info.primal_obj)) + 10 * so.settings.eps_abs
+    _assert_same_solve(name, q, sh, so, st_h, st_o)
 
 
 NETLIB_FEAS = sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(GOLDEN, "nl_*.npz")))
@@ -165,22 +131,13 @@ ORACLE_MISSES_REFERENCE = {"nl_bnl2", "nl_pilot-we", "nli_ceria3d", "nli_cplex2"
 @pytest.mark.parametrize("name", NETLIB_FEAS + NETLIB_INFEAS)
 def test_netlib_lp_status_matches_oracle(hip, orc, name):
     """tests/src/sparse/netlib_lp_tests.cpp through the device solver, with that test's setting (infeasibility_threshold = 0.01): SOLVED on the
-    feasible set, PRIMAL or DUAL INFEASIBLE on the infeasible set -- asserted against the reference's expectation wherever the oracle meets it,
-    and against the oracle's status everywhere"""
+    feasible set, PRIMAL or DUAL INFEASIBLE on the infeasible set -- asserted against the reference's expectation wherever the oracle meets it, and the whole
+    solve against the oracle's everywhere (bitwise below 8192 KKT rows)"""
     q = load_qp(name)
-    sh = hip.SparseSolver(); sh.settings.kkt_solver = hip.SPARSE_LDLT; sh.settings.infeasibility_threshold = 0.01
-    so = orc.Solver(); so.settings.kkt_solver = orc.SPARSE_LDLT; so.settings.infeasibility_threshold = 0.01
-    assert sh.setup(*_args(q)) and so.setup(*_args(q), sparse=True)
-    st_h, st_o = sh.solve(), so.solve()
+    sh, so, st_h, st_o = _solve_both(hip, orc, q, netlib=True)
     expected = (1,) if name.startswith("nl_") else (-2, -3)
     if name in ORACLE_MISSES_REFERENCE:
         assert st_o not in expected  # keeps the list honest
-        assert st_h == st_o or st_h in expected, (name, st_h, st_o)  # the device ends like the oracle -- or like the reference's own expectation
     else:
         assert st_o in expected, (name, st_o)
-        if name in TRAJECTORY_SENSITIVE:
-            _check_sensitive(name, sh, st_h, _oracle_both_builds(orc, q, netlib=True))
-            return
-        assert st_h in expected, (name, st_h, st_o)
-    if st_o == 1 and st_h == 1:
-        assert abs(sh.info.primal_obj - so.info.primal_obj) <= 1e-5 * max(1.0, abs(so.info.primal_obj)) + 10 * so.settings.eps_abs
+    _assert_same_solve(name, q, sh, so, st_h, st_o)

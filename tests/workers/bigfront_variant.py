@@ -49,7 +49,7 @@ def main():
     kind, outp = sys.argv[1], sys.argv[2]
     a, n, p, m = problem(kind)
     d = hip.SparseData(*a)
-    k = hip.KKTSystem(d, hip.default_settings(kkt_solver=hip.SPARSE_LDLT))
+    k = hip.KKTSystem(d, hip.default_settings(kkt_solver=hip.SPARSE_LDLT_MULTIFRONTAL))
     rng = np.random.default_rng(23)
     state = random_vars(d.n, d.p, d.m, rng, positive=True)
     rhs = random_vars(d.n, d.p, d.m, rng)

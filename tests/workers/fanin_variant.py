@@ -29,7 +29,7 @@ def main():
     b = rng.standard_normal(p)
     x_l = np.full(n, -2.0); x_u = np.full(n, 2.0)
     d = hip.SparseData(P, c, A, b, None, None, None, x_l, x_u)
-    k = hip.KKTSystem(d, hip.default_settings(kkt_solver=hip.SPARSE_LDLT))
+    k = hip.KKTSystem(d, hip.default_settings(kkt_solver=hip.SPARSE_LDLT_MULTIFRONTAL))
     state = random_vars(n, p, 0, rng, positive=True)
     rhs = random_vars(n, p, 0, rng)
     assert k.update_scalings_and_factor(False, 1e-6, 1e-4, state)

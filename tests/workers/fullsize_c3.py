@@ -20,7 +20,7 @@ def main():
     from qp_gen import c3_problem, random_vars
     a = c3_problem()
     n, p, m = a[0].shape[0], a[2].shape[0], a[4].shape[0]
-    k = hip.KKTSystem(hip.SparseData(*a), hip.default_settings(kkt_solver=hip.SPARSE_LDLT))
+    k = hip.KKTSystem(hip.SparseData(*a), hip.default_settings(kkt_solver=hip.SPARSE_LDLT_MULTIFRONTAL))
     rng = np.random.default_rng(0)
     state = random_vars(n, p, m, rng, positive=True)
     rhs = random_vars(n, p, m, rng)

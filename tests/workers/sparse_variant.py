@@ -24,7 +24,7 @@ def main():
         # supernodes between them) -- multi-workgroup fronts in the factorisation, huge fronts (k_front_fwd_rows / k_front_bwd_cols) in the substitution
         n, p, m = 8000, 3200, 4800
         a = c3_problem(n, p, m, 44, 1500, 10)
-        k = hip.KKTSystem(hip.SparseData(*a), hip.default_settings(kkt_solver=hip.SPARSE_LDLT))
+        k = hip.KKTSystem(hip.SparseData(*a), hip.default_settings(kkt_solver=hip.SPARSE_LDLT_MULTIFRONTAL))
         st = k.backend().sparse_stats()
         assert st["max_front"] >= 2048, st
         rng = np.random.default_rng(0)
@@ -43,7 +43,7 @@ def main():
     # (a) C3 recipe at n = 6000: fronts wide enough for every schedule variant to have work
     n, p, m = 6000, 2400, 3600
     a = c3_problem(n, p, m, 44, 40)
-    k = hip.KKTSystem(hip.SparseData(*a), hip.default_settings(kkt_solver=hip.SPARSE_LDLT))
+    k = hip.KKTSystem(hip.SparseData(*a), hip.default_settings(kkt_solver=hip.SPARSE_LDLT_MULTIFRONTAL))
     rng = np.random.default_rng(0)
     state = random_vars(n, p, m, rng, positive=True)
     rhs = random_vars(n, p, m, rng)
@@ -54,7 +54,7 @@ def main():
         out["c3_" + key] = np.asarray(v)
     # (b) a block-tridiagonal chain (the shape of BASELINE configs[4]) through the same multifrontal backend
     q = mpc_chain(6, 3, 400, 5)
-    k2 = hip.KKTSystem(hip.SparseData(*q), hip.default_settings(kkt_solver=hip.SPARSE_LDLT))
+    k2 = hip.KKTSystem(hip.SparseData(*q), hip.default_settings(kkt_solver=hip.SPARSE_LDLT_MULTIFRONTAL))
     n2, p2, m2 = q[0].shape[0], q[2].shape[0], (q[4].shape[0] if q[4] is not None else 0)
     state2 = random_vars(n2, p2, m2, rng, positive=True)
     rhs2 = random_vars(n2, p2, m2, rng)
@@ -68,7 +68,7 @@ def main():
     q3 = load_qp("mm_CONT-101")
     a3 = (q3["P"], q3["c"], q3["A"], q3["b"], q3["G"], q3["h_l"], q3["h_u"], q3["x_l"], q3["x_u"])
     d3 = hip.SparseData(*a3)
-    k3 = hip.KKTSystem(d3, hip.default_settings(kkt_solver=hip.SPARSE_LDLT))
+    k3 = hip.KKTSystem(d3, hip.default_settings(kkt_solver=hip.SPARSE_LDLT_MULTIFRONTAL))
     state3 = random_vars(d3.n, d3.p, d3.m, rng, positive=True)
     rhs3 = random_vars(d3.n, d3.p, d3.m, rng)
     assert k3.update_scalings_and_factor(False, 1e-6, 1e-4, state3)
