@@ -50,6 +50,13 @@ __device__ __forceinline__ double readlane_d(double v, int l)
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ int readfirst(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// Hand-over between waves WITHOUT fences (MI355X_MICROARCH.md, workgroup dispatch / inter-workgroup visibility: an agent-scope acquire costs 1.7 us and a release
+// 1.7 - 6.5 us per workgroup, several times that with more workgroups per CU -- more than a whole task of this engine): every word one wave writes for another is
+// written and read with agent-scope 8-byte / 4-byte atomics (write-through `sc1` stores, `sc1` loads that bypass the reader's L1), the flag follows the payload after
+// s_waitcnt vmcnt(0), and the consumer's loads follow its successful poll.  Nothing else in these kernels is written by one wave and read by another.
+__device__ __forceinline__ double ldw(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void stw(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // fl(a - fl(x y)): product rounded, then the difference rounded ("force compiler to not use fma instruction", ldlt.hpp:151-153)
 __device__ __forceinline__ double msub(double a, double x, double y) { return __dsub_rn(a, __dmul_rn(x, y)); }
 
@@ -66,20 +73,31 @@ __global__ void k_ul_set_diag(int n, int p, int m, const int* __restrict__ diag_
     vals[diag_pos[col]] = v;
 }
 
+// Device layout of the schedule (built once in build_device from sparse::UpLooking; a row costs a handful of dependent memory round trips, so everything a pass
+// needs about a row sits in ONE record and everything about its entries in arrays that are contiguous per task):
+//   rowrec[16 k ..]   es, en (the row's entries in the task-ordered entry space), cp0, cpn (its column of P K P'), task, W, lane, table offset, previous path row,
+//                     dep0, depn (children outside the task), nU
+//   taskrec[8 t ..]   first index in task_rows, W, nU, table offset
+//   E4[e]             column i, first CSC entry of column i, entries of column i the row pass scatters (-1: a column of the task's own path), CSC position of L(k, i)
+//   Etab[e], Emask[e] the entry's row in the task's table and that row's presence bits
+// Ystash / Pstash are indexed in the same entry space.
 struct UlFactorArgs {
     int N, nticket, epoch;
     const int *Cp, *Ci;
     const double* Cx;
-    const int *tk_kind, *tk_id, *task_ptr, *task_rows, *row_task, *row_lane, *row_prev, *dep_ptr, *dep;
-    const int *Rp, *Rcol, *Rpos, *Rcnt, *Rtab, *Lp, *Li;
-    const int *tab_ptr, *mask_ptr, *task_nU;
-    const unsigned long long* Tmask;
+    const int *tk_kind, *tk_id, *task_rows, *rowrec, *taskrec, *dep;
+    const int4* E4;
+    const int *Etab, *Li;
+    const unsigned long long* Emask;
     double *Lx, *D, *Dinv, *Ystash, *Pstash, *Dinit, *Lblock;
     int *done, *p1done, *ready, *ticket, *info;
     double* yglob;  // N doubles per workgroup when y does not fit LDS
+    long long* trace;  // debugging aid (PIQP_AMD_DEBUG=exact_trace), nullable: per ticket 4 x wall_clock64 (100 MHz): drawn, waits over, done; [3] = workgroup
 };
 
-constexpr int UL_PF = 8;  // columns prefetched ahead of the dependent chain (their first 64 entries)
+constexpr int UL_PF = 8;    // row pass: columns prefetched ahead of the dependent chain (their first 64 entries); a load of a word another wave wrote comes from memory,
+                            // not from L2 (write-through stores drop the line): ~2 us, i.e. the pace is latency / depth until the depth covers it
+constexpr int UL_PFP = 8;   // path pass / substitution: table values fetched ahead
 
 __device__ __forceinline__ bool spin_until(const int* flag, int epoch)
 {
@@ -92,34 +110,31 @@ __device__ __forceinline__ bool spin_until(const int* flag, int epoch)
 }
 
 // ROW PASS of row k (ldlt.hpp:121-163): the entries of row k in the columns outside the row's task, in the reference's order.  A row that is a task of its own is
-// finished here; for a row on a longer path the updates into the path's rows are left to the path pass (Rcnt counts only the entries of a column above them), the
+// finished here; for a row on a longer path the updates into the path's rows are left to the path pass (E4.z counts only the entries of a column above them), the
 // values y_i, the products l_ki y_i and the initial values of the path columns go to Ystash / Pstash / Dinit, the quotients also into the task's table.
 // y: this wave's dense work vector, all zero on entry and on exit.
-__device__ __forceinline__ void ul_row(const UlFactorArgs& a, double* __restrict__ y, const int k, const int lane)
+__device__ __forceinline__ void ul_row(const UlFactorArgs& a, double* __restrict__ y, const int k, const int lane, const int es, const int en, const int p0, const int pn,
+                                       const int W, const int lanek, const int tb)
 {
-    const int t = a.row_task[k];
-    const int W = a.task_ptr[t + 1] - a.task_ptr[t];
     const bool multi = W > 1;
-    const int tb = a.tab_ptr[t], lanek = a.row_lane[k];
     // scatter A(0:k, k) into y (:127-131)
-    const int p0 = a.Cp[k], p1 = a.Cp[k + 1];
-    for (int q = p0 + lane; q < p1; q += 64) y[a.Ci[q]] = a.Cx[q];
+    for (int q = lane; q < pn; q += 64) y[a.Ci[p0 + q]] = a.Cx[p0 + q];
     wave_sync();
     double Dk = y[k];  // :145  D[k] = y[k]
     wave_sync();
     if (lane == 0) y[k] = 0.0;
-    const int r0 = a.Rp[k], r1 = a.Rp[k + 1];
-    for (int base = r0; base < r1; base += 64) {
-        const int e = base + lane;
-        const bool in = e < r1;
-        const int i = in ? a.Rcol[e] : 0, pos = in ? a.Rpos[e] : 0;
-        const int cs = in ? a.Lp[i] : 0;
-        const int rc = in ? a.Rcnt[e] : 0;   // entries of column i this pass scatters: all above row k (= L_nnz[i] at this moment, :149) or those above the task's path
+    for (int base = 0; base < en; base += 64) {
+        const int e = es + base + lane;
+        const bool in = base + lane < en;
+        const int4 ev = a.E4[in ? e : es];
+        const int i = in ? ev.x : 0, pos = ev.w;
+        const int cs = in ? ev.y : 0;
+        const int rc = in ? ev.z : 0;        // entries of column i this pass scatters: all above row k (= L_nnz[i] at this moment, :149) or those above the task's path
         const int cnt = rc > 0 ? rc : 0;
         const bool ext = in && rc >= 0;      // (a column of the task's own path otherwise: its value in this row comes out of the path pass)
-        const double Di = ext ? a.D[i] : 1.0;
-        const int tabu = in ? a.Rtab[e] : 0;
-        const int ns = min(64, r1 - base);
+        const double Dld = ldw(a.D + i);           // (unconditional: issued together with the column prefetch below)
+        const int tabu = a.Etab[in ? e : es];
+        const int ns = min(64, en - base);
         double my_yi = 0.0;
         // the first 64 entries of the columns of the next UL_PF steps travel ahead of the chain.  Every load is unconditional (lanes past the end of their
         // column re-read its first entry, steps past the end of the row read entry 0 of the arrays): a load under a branch would be waited for at the branch
@@ -129,8 +144,9 @@ __device__ __forceinline__ void ul_row(const UlFactorArgs& a, double* __restrict
         for (int d = 0; d < UL_PF; ++d) {
             const int csu = __builtin_amdgcn_readlane(cs, d), cntu = __builtin_amdgcn_readlane(cnt, d);
             const int q = csu + (lane < cntu ? lane : 0);
-            pf_i[d] = a.Li[q]; pf_v[d] = a.Lx[q];
+            pf_i[d] = a.Li[q]; pf_v[d] = ldw(a.Lx + q);
         }
+        const double Di = ext ? Dld : 1.0;
         for (int sb = 0; sb < ns; sb += UL_PF) {
 #pragma unroll
             for (int d = 0; d < UL_PF; ++d) {
@@ -142,31 +158,32 @@ __device__ __forceinline__ void ul_row(const UlFactorArgs& a, double* __restrict
                     const int s2 = (s + UL_PF) & 63;
                     const int cs2 = __builtin_amdgcn_readlane(cs, s2), cnt2 = __builtin_amdgcn_readlane(cnt, s2);
                     const int q = cs2 + (lane < cnt2 ? lane : 0);
-                    pf_i[d] = a.Li[q]; pf_v[d] = a.Lx[q];
+                    pf_i[d] = a.Li[q]; pf_v[d] = ldw(a.Lx + q);
                 }
                 const double yi = y[iu];  // :147 (every lane reads the same word)
                 if (lane == s) my_yi = yi;
                 if (lane < cntu) y[t0] = msub(y[t0], v0, yi);  // :150-154, distinct targets
                 if (lane == 0 && s < ns) y[iu] = 0.0;          // :148
-                for (int q = 64 + lane; q < cntu; q += 64) { const int tt = a.Li[csu + q]; y[tt] = msub(y[tt], a.Lx[csu + q], yi); }
+                for (int q = 64 + lane; q < cntu; q += 64) { const int tt = a.Li[csu + q]; y[tt] = msub(y[tt], ldw(a.Lx + csu + q), yi); }
                 wave_sync();
             }
         }
         // :155-161 for the 64 entries at once; D[k] loses its terms strictly in pattern order
         const double l = __ddiv_rn(my_yi, Di);
         const double tp = __dmul_rn(l, my_yi);
-        if (ext) a.Lx[pos] = l;
+        if (ext) stw(a.Lx + pos, l);
+        if (ext) stw(a.Lblock + tb + tabu * W + lanek, l);  // (the task's table holds every entry of its rows: the substitution reads L from there)
         if (multi) {
-            if (in) a.Ystash[e] = my_yi;
-            if (ext) { a.Pstash[e] = tp; a.Lblock[tb + tabu * W + lanek] = l; }
+            if (in) stw(a.Ystash + e, my_yi);
+            if (ext) stw(a.Pstash + e, tp);
         } else {
             for (int s = 0; s < ns; ++s) Dk = __dsub_rn(Dk, readlane_d(tp, s));
         }
     }
     if (lane == 0) {
-        if (multi) a.Dinit[k] = Dk;
+        if (multi) stw(a.Dinit + k, Dk);
         else {
-            a.D[k] = Dk;
+            stw(a.D + k, Dk);
             a.Dinv[k] = __ddiv_rn(1.0, Dk);  // :166
             if (Dk == 0.0) atomicMin(a.info, k);  // :163 (the smallest such k is the row the serial loop stops at)
         }
@@ -177,49 +194,85 @@ __device__ __forceinline__ void ul_row(const UlFactorArgs& a, double* __restrict
 // outside column i sends y_i (from the row pass) to the path rows c < k that hold an entry L(c, i) -- acc_c -= fl(L(c, i) y_i) -- and an entry in a path column c0
 // first has its value final (acc of lane c0: every term it receives comes from a column the order visits earlier) and then does the same.  The quotients and the
 // terms of D[k] follow, the latter again in pattern order.  L(c, .) is read from the task's table, where the passes that produced it left it.
+// The pass starts when ALL row passes of the task are complete: from then on nothing it reads changes except what it writes itself, and the entries of row j + 2
+// and the table values of the first steps of row j + 1 are fetched while row j is computed (rows of three entries are common: memory round trips, not steps,
+// would otherwise set the pace).
+struct UlChunk { int tab, mlo, mhi, pos; double ys, ps; };
+
+__device__ __forceinline__ UlChunk ul_load_chunk(const UlFactorArgs& a, int e0, int cnt, int fallback, int lane)
+{
+    const bool in = lane < cnt;
+    const int e = in ? e0 + lane : fallback;
+    UlChunk c;
+    const int tab = a.Etab[e];
+    const unsigned long long m = a.Emask[e];
+    const double ys = ldw(a.Ystash + e), ps = ldw(a.Pstash + e);
+    const int pos = a.E4[e].w;
+    c.tab = in ? tab : 0; c.mlo = in ? (int)(unsigned)(m & 0xffffffffull) : 0; c.mhi = in ? (int)(unsigned)(m >> 32) : 0; c.pos = pos;
+    c.ys = in ? ys : 0.0; c.ps = in ? ps : 0.0;
+    return c;
+}
+
 __device__ __forceinline__ bool ul_path(const UlFactorArgs& a, const int t, const int lane, double* s_acc, int* s_pos)
 {
-    const int rb = a.task_ptr[t], W = a.task_ptr[t + 1] - rb;
-    const int nU = a.task_nU[t], tb = a.tab_ptr[t], mb = a.mask_ptr[t];
+    const int rb = a.taskrec[8 * t], W = a.taskrec[8 * t + 1], nU = a.taskrec[8 * t + 2], tb = a.taskrec[8 * t + 3];
     const int lw = lane < W ? lane : W - 1;
+    const int myk = a.task_rows[rb + lw];
+    bool ok = spin_until(a.p1done + myk, a.epoch);
+    if (__ballot(!ok)) return false;
+    // lane j <-> row j of the task
+    const int es_l = a.rowrec[16 * myk], en_l = a.rowrec[16 * myk + 1];
+    const double dinit_l = ldw(a.Dinit + myk);
+    const int E0 = __builtin_amdgcn_readlane(es_l, 0);
     double Dlane = 1.0;  // lane c: D of path row c once it is known
+    // pipeline registers: the first 64 entries of rows j (cur), j + 1 (nx1), j + 2 (nx2); the table values of the first UL_PFP steps of rows j (pfc) and j + 1 (pfn)
+    UlChunk cur = ul_load_chunk(a, E0, min(64, __builtin_amdgcn_readlane(en_l, 0)), E0, lane);
+    UlChunk nx1 = W > 1 ? ul_load_chunk(a, __builtin_amdgcn_readlane(es_l, 1), min(64, __builtin_amdgcn_readlane(en_l, 1)), E0, lane) : cur;
+    double pfc[UL_PFP], pfn[UL_PFP];
+#pragma unroll
+    for (int d = 0; d < UL_PFP; ++d) pfc[d] = ldw(a.Lblock + tb + __builtin_amdgcn_readlane(cur.tab, d) * W + lw);
     for (int j = 0; j < W; ++j) {
-        const int k = a.task_rows[rb + j];
-        if (!spin_until(a.p1done + k, a.epoch)) return false;
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        const int r0 = a.Rp[k], r1 = a.Rp[k + 1];
+        const int k = __builtin_amdgcn_readlane(myk, j), es = __builtin_amdgcn_readlane(es_l, j), en = __builtin_amdgcn_readlane(en_l, j);
+        // fetch ahead: entries of row j + 2, first table values of row j + 1
+        UlChunk nx2 = nx1;
+        if (j + 2 < W) nx2 = ul_load_chunk(a, __builtin_amdgcn_readlane(es_l, j + 2), min(64, __builtin_amdgcn_readlane(en_l, j + 2)), E0, lane);
+#pragma unroll
+        for (int d = 0; d < UL_PFP; ++d) pfn[d] = ldw(a.Lblock + tb + __builtin_amdgcn_readlane(nx1.tab, d) * W + lw);
+        // the initial values of the path columns (A(c, k), left in Ystash by the row pass) go to their lanes through LDS
         s_acc[lane] = 0.0; s_pos[lane] = -1;
         wave_sync();
-        for (int e = r0 + lane; e < r1; e += 64) {
-            const int u = a.Rtab[e];
-            if (u >= nU) { s_acc[u - nU] = a.Ystash[e]; s_pos[u - nU] = a.Rpos[e]; }
+        if (lane < en && cur.tab >= nU) { s_acc[cur.tab - nU] = cur.ys; s_pos[cur.tab - nU] = cur.pos; }
+        for (int e = es + 64 + lane; e < es + en; e += 64) {
+            const int u = a.Etab[e];
+            if (u >= nU) { s_acc[u - nU] = ldw(a.Ystash + e); s_pos[u - nU] = a.E4[e].w; }
         }
         wave_sync();
         double acc = s_acc[lane];
         const int mypos = s_pos[lane];
         wave_sync();
         const unsigned long long below = j >= 64 ? ~0ull : ((1ull << j) - 1ull);  // path rows under row k
-        for (int base = r0; base < r1; base += 64) {
-            const int e = base + lane;
-            const bool in = e < r1;
-            const int ue = in ? a.Rtab[e] : 0;
-            const double yse = in ? a.Ystash[e] : 0.0;
-            const unsigned long long me = in ? a.Tmask[mb + ue] : 0ull;
-            const int mlo = (int)(unsigned)(me & 0xffffffffull), mhi = (int)(unsigned)(me >> 32);
-            const int ns = min(64, r1 - base);
-            double pf_v[UL_PF];
+        UlChunk ch = cur;
+        for (int base = 0; base < en; base += 64) {
+            const int ns = min(64, en - base);
+            double pf_v[UL_PFP];
+            if (base == 0) {
 #pragma unroll
-            for (int d = 0; d < UL_PF; ++d) pf_v[d] = a.Lblock[tb + __builtin_amdgcn_readlane(ue, d) * W + lw];
-            for (int sb = 0; sb < ns; sb += UL_PF) {
+                for (int d = 0; d < UL_PFP; ++d) pf_v[d] = pfc[d];
+            } else {
+                ch = ul_load_chunk(a, es + base, ns, E0, lane);
 #pragma unroll
-                for (int d = 0; d < UL_PF; ++d) {
+                for (int d = 0; d < UL_PFP; ++d) pf_v[d] = ldw(a.Lblock + tb + __builtin_amdgcn_readlane(ch.tab, d) * W + lw);
+            }
+            for (int sb = 0; sb < ns; sb += UL_PFP) {
+#pragma unroll
+                for (int d = 0; d < UL_PFP; ++d) {
                     const int s = sb + d;
-                    const int u = __builtin_amdgcn_readlane(ue, s & 63);
-                    const unsigned long long m = (((unsigned long long)(unsigned)__builtin_amdgcn_readlane(mhi, s & 63) << 32) | (unsigned)__builtin_amdgcn_readlane(mlo, s & 63)) & below;
+                    const int u = __builtin_amdgcn_readlane(ch.tab, s & 63);
+                    const unsigned long long m = (((unsigned long long)(unsigned)__builtin_amdgcn_readlane(ch.mhi, s & 63) << 32) | (unsigned)__builtin_amdgcn_readlane(ch.mlo, s & 63)) & below;
                     const double v = pf_v[d];
-                    pf_v[d] = a.Lblock[tb + __builtin_amdgcn_readlane(ue, (s + UL_PF) & 63) * W + lw];
+                    pf_v[d] = ldw(a.Lblock + tb + __builtin_amdgcn_readlane(ch.tab, (s + UL_PFP) & 63) * W + lw);
                     if (s < ns) {
-                        const double src = u < nU ? readlane_d(yse, s & 63) : readlane_d(acc, (u - nU) & 63);
+                        const double src = u < nU ? readlane_d(ch.ys, s & 63) : readlane_d(acc, (u - nU) & 63);
                         if ((m >> lane) & 1ull) acc = msub(acc, v, src);
                     }
                 }
@@ -229,26 +282,37 @@ __device__ __forceinline__ bool ul_path(const UlFactorArgs& a, const int t, cons
         const bool have = lane < j && mypos >= 0;
         const double l = __ddiv_rn(acc, Dlane);
         const double prodp = __dmul_rn(l, acc);
-        if (have) { a.Lx[mypos] = l; a.Lblock[tb + (nU + lane) * W + j] = l; }
-        double Dk = a.Dinit[k];
-        for (int base = r0; base < r1; base += 64) {
-            const int e = base + lane;
-            const bool in = e < r1;
-            const int ue = in ? a.Rtab[e] : 0;
-            const double pse = in ? a.Pstash[e] : 0.0;
-            const int ns = min(64, r1 - base);
+        if (have) { stw(a.Lx + mypos, l); stw(a.Lblock + tb + (nU + lane) * W + j, l); }
+        double Dk = readlane_d(dinit_l, j);
+        ch = cur;
+        for (int base = 0; base < en; base += 64) {
+            const int ns = min(64, en - base);
+            if (base > 0) ch = ul_load_chunk(a, es + base, ns, E0, lane);
             for (int s = 0; s < ns; ++s) {
-                const int u = __builtin_amdgcn_readlane(ue, s);
-                const double term = u < nU ? readlane_d(pse, s) : readlane_d(prodp, (u - nU) & 63);
+                const int u = __builtin_amdgcn_readlane(ch.tab, s);
+                const double term = u < nU ? readlane_d(ch.ps, s) : readlane_d(prodp, (u - nU) & 63);
                 Dk = __dsub_rn(Dk, term);
             }
         }
         if (lane == 0) {
-            a.D[k] = Dk;
+            stw(a.D + k, Dk);
             a.Dinv[k] = __ddiv_rn(1.0, Dk);
             if (Dk == 0.0) atomicMin(a.info, k);
         }
         if (lane == j) Dlane = Dk;
+        // the table values of row j + 1's first steps were fetched before this row wrote its own quotients L(path row j, path column c) into the table: lane j
+        // (the newest path row under row j + 1) takes them from the registers they were computed in
+        const int en_next = j + 1 < W ? __builtin_amdgcn_readlane(en_l, j + 1) : 0;
+#pragma unroll
+        for (int d = 0; d < UL_PFP; ++d) {
+            if (d < en_next) {
+                const int un = __builtin_amdgcn_readlane(nx1.tab, d);
+                if (un >= nU) { const double lv = readlane_d(l, (un - nU) & 63); if (lane == j) pfn[d] = lv; }
+            }
+        }
+        cur = nx1; nx1 = nx2;
+#pragma unroll
+        for (int d = 0; d < UL_PFP; ++d) pfc[d] = pfn[d];
     }
     return true;
 }
@@ -263,42 +327,49 @@ __global__ __launch_bounds__(64) void k_ul_factor(UlFactorArgs a)
     double* __restrict__ y = LDSY ? ul_sm : a.yglob + (size_t)blockIdx.x * a.N;
     const int lane = threadIdx.x;
     for (int tt = lane; tt < a.N; tt += 64) y[tt] = 0.0;
+    if (lane == 0) s_task = atomicAdd(a.ticket, 1);
     __syncthreads();
     // (the whole workgroup is one wave: __syncthreads() costs nothing and keeps the control flow around the ticket uniform for the compiler)
     for (int guard = 0; guard <= a.nticket; ++guard) {
-        if (lane == 0) s_task = atomicAdd(a.ticket, 1);
-        __syncthreads();
         const int tk = readfirst(s_task);
         __syncthreads();
         if (tk >= a.nticket) break;
+        // the next ticket is drawn now and used when this one is done: its round trip to memory disappears behind the work (a wave never waits for a LATER ticket,
+        // so a ticket parked for the length of one task delays its dependants but cannot block them)
+        int next_ticket = 0;
+        if (lane == 0) next_ticket = atomicAdd(a.ticket, 1);
         const int kind = a.tk_kind[tk], id = a.tk_id[tk];
         bool ok = true;
+        if (a.trace && lane == 0) { a.trace[4 * (size_t)tk] = wall_clock64(); a.trace[4 * (size_t)tk + 3] = blockIdx.x; }
         if (kind == 0) {
             // row pass: the row's children outside its task must be complete rows; the rows below it on its own path are not waited for -- what THEY waited for is
             // inherited through the `ready` word of the row before
             const int k = id;
-            const int c0 = a.dep_ptr[k], c1 = a.dep_ptr[k + 1];
-            for (int c = c0 + lane; c < c1; c += 64) ok &= spin_until(a.done + a.dep[c], a.epoch);
-            const int prev = a.row_prev[k];
-            if (prev >= 0) ok &= spin_until(a.ready + prev, a.epoch);
+            const int4 r0 = *reinterpret_cast<const int4*>(a.rowrec + 16 * k), r1 = *reinterpret_cast<const int4*>(a.rowrec + 16 * k + 4),
+                       r2 = *reinterpret_cast<const int4*>(a.rowrec + 16 * k + 8);
+            const int es = r0.x, en = r0.y, cp0 = r0.z, cpn = r0.w, W = r1.y, lanek = r1.z, tb = r1.w, prev = r2.x, c0 = r2.y, cn = r2.z;
+            for (int c = lane; c < cn; c += 64) ok &= spin_until(a.done + a.dep[c0 + c], a.epoch);
+            (void)prev;
             ok = __ballot(!ok) == 0;
             if (ok) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
-                __hip_atomic_store(a.ready + k, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ul_row(a, y, k, lane);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                const int t = a.row_task[k];
-                int* flag = (a.task_ptr[t + 1] - a.task_ptr[t] > 1 ? a.p1done : a.done) + k;
+                if (a.trace && lane == 0) a.trace[4 * (size_t)tk + 1] = wall_clock64();
+                ul_row(a, y, k, lane, es, en, cp0, cpn, W, lanek, tb);
+                drain_stores();
+                int* flag = (W > 1 ? a.p1done : a.done) + k;
                 __hip_atomic_store(flag, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (every lane stores the same word: no divergence at the loop's end)
             }
         } else {
+            if (a.trace && lane == 0) a.trace[4 * (size_t)tk + 1] = wall_clock64();
             ok = ul_path(a, id, lane, s_acc, s_pos);
             if (ok) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                __hip_atomic_store(a.done + a.task_rows[a.task_ptr[id + 1] - 1], a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                drain_stores();
+                __hip_atomic_store(a.done + a.task_rows[a.taskrec[8 * id] + a.taskrec[8 * id + 1] - 1], a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         if (!ok) { if (lane == 0) atomicMin(a.info, -2); break; }
+        if (a.trace && lane == 0) a.trace[4 * (size_t)tk + 2] = wall_clock64();
+        if (lane == 0) s_task = next_ticket;
+        __syncthreads();
     }
 }
 
@@ -412,6 +483,148 @@ __global__ __launch_bounds__(64) void k_ul_solve(UlSolveArgs a)
     if (bad && a.err) *a.err = a.epoch;
 }
 
+
+// ---- substitution on the factorisation's tasks (lsolve, dsolve, ltsolve of ldlt.hpp:171-218 with ordering.perm / permt of sparse/kkt.hpp:139-144 folded in).
+// One persistent launch: tickets 0 .. ntask-1 are the forward passes of the tasks (in the order of their last rows), ntask .. 2 ntask-1 the backward passes in the
+// opposite order; a wave never waits for a later ticket.  The vectors live in HBM: xf (forward result), xz (xf scaled by D_inv), xb (final).
+//   forward pass of a task: its rows as lanes, acc = permuted right-hand side; the task's table rows (the columns that reach it, outside ones and its own) in
+//     ascending column order: acc_t -= fl(L(t, j) x_j) -- the order in which the reference's column loop subtracts from x_t;
+//   backward pass: its columns from the last to the first; the entries of column j in ascending row order: 64 products fl(L(t, j) x_t) across the lanes, subtracted
+//     from x_j one after the other (the reference's inner loop); x_t of a row on the same path comes from its lane, of a row above from xb.
+struct UlSolve2Args {
+    int N, n, p, m, ntask, epoch;
+    const int *perm, *taskrec, *task_rows, *tsort, *tdep, *fs_u, *fs_col, *Lp, *Li, *Lsrc;
+    const unsigned long long* Tmask;
+    const int* mask_ptr;
+    const double *Lblock, *Lx, *Dinv;
+    const double *rx, *ry, *rz;
+    double *lx, *ly, *lz;
+    double *xf, *xz, *xb;
+    int *fdone, *bdone, *ticket, *info;
+};
+
+__device__ __forceinline__ void ul_fwd_task(const UlSolve2Args& a, const int t, const int lane)
+{
+    const int rb = a.taskrec[8 * t], W = a.taskrec[8 * t + 1], nU = a.taskrec[8 * t + 2], tb = a.taskrec[8 * t + 3], fs0 = a.taskrec[8 * t + 4];
+    const int mb = a.mask_ptr[t];
+    const int nsrc = nU + W;
+    const int lw = lane < W ? lane : W - 1;
+    const int row = a.task_rows[rb + lw];
+    const int o = a.perm[row];
+    double acc = o < a.n ? a.rx[o] : (o < a.n + a.p ? a.ry[o - a.n] : a.rz[o - a.n - a.p]);
+    for (int base = 0; base < nsrc; base += 64) {
+        const bool in = base + lane < nsrc;
+        const int q = fs0 + (in ? base + lane : 0);
+        const int ue = in ? a.fs_u[q] : 0;
+        const int col = a.fs_col[q];
+        const double xs = ldw(a.xf + col);   // (an outside column is final: its task was waited for; a path column's value is taken from its lane instead)
+        const unsigned long long me = in ? a.Tmask[mb + ue] : 0ull;
+        const int mlo = (int)(unsigned)(me & 0xffffffffull), mhi = (int)(unsigned)(me >> 32);
+        const int ns = min(64, nsrc - base);
+        double pf_v[UL_PFP];
+#pragma unroll
+        for (int d = 0; d < UL_PFP; ++d) pf_v[d] = a.Lblock[tb + __builtin_amdgcn_readlane(ue, d) * W + lw];
+        for (int sb = 0; sb < ns; sb += UL_PFP) {
+#pragma unroll
+            for (int d = 0; d < UL_PFP; ++d) {
+                const int s = sb + d;
+                const int u = __builtin_amdgcn_readlane(ue, s & 63);
+                const unsigned long long m = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(mhi, s & 63) << 32) | (unsigned)__builtin_amdgcn_readlane(mlo, s & 63);
+                const double v = pf_v[d];
+                pf_v[d] = a.Lblock[tb + __builtin_amdgcn_readlane(ue, (s + UL_PFP) & 63) * W + lw];
+                if (s < ns) {
+                    const double src = u < nU ? readlane_d(xs, s & 63) : readlane_d(acc, (u - nU) & 63);
+                    if (__builtin_amdgcn_inverse_ballot_w64(m)) acc = msub(acc, v, src);
+                }
+            }
+        }
+    }
+    if (lane < W) { stw(a.xf + row, acc); stw(a.xz + row, __dmul_rn(acc, a.Dinv[row])); }
+}
+
+__device__ __forceinline__ void ul_bwd_task(const UlSolve2Args& a, const int t, const int lane)
+{
+    const int rb = a.taskrec[8 * t], W = a.taskrec[8 * t + 1];
+    const int lw = lane < W ? lane : W - 1;
+    const int row = a.task_rows[rb + lw];
+    const int lp0 = a.Lp[row], lp1 = a.Lp[row + 1];
+    double xfin = ldw(a.xz + row);
+    // the first 64 entries of the column a step ahead
+    int q0 = __builtin_amdgcn_readlane(lp0, W - 1), q1 = __builtin_amdgcn_readlane(lp1, W - 1);
+    int nt_ = a.Li[q0 + lane < q1 ? q0 + lane : (q1 > q0 ? q0 : 0)];
+    int nsl = a.Lsrc[q0 + lane < q1 ? q0 + lane : (q1 > q0 ? q0 : 0)];
+    double nv = a.Lx[q0 + lane < q1 ? q0 + lane : (q1 > q0 ? q0 : 0)];
+    double nxv = ldw(a.xb + nt_);
+    for (int c = W - 1; c >= 0; --c) {
+        const int c0 = q0, c1 = q1;
+        const int tl = nt_, sl = nsl;
+        const double v = nv, xv = nxv;
+        (void)tl;
+        if (c > 0) {
+            q0 = __builtin_amdgcn_readlane(lp0, c - 1); q1 = __builtin_amdgcn_readlane(lp1, c - 1);
+            const int qq = q0 + lane < q1 ? q0 + lane : (q1 > q0 ? q0 : 0);
+            nt_ = a.Li[qq]; nsl = a.Lsrc[qq]; nv = a.Lx[qq]; nxv = ldw(a.xb + nt_);
+        }
+        double s = readlane_d(xfin, c);
+        for (int qb = c0; qb < c1; qb += 64) {
+            const int cnt = min(64, c1 - qb);
+            int sl2 = sl; double v2 = v, xv2 = xv;
+            if (qb > c0) { const int qq = qb + lane < c1 ? qb + lane : qb; sl2 = a.Lsrc[qq]; v2 = a.Lx[qq]; xv2 = ldw(a.xb + a.Li[qq]); }
+            const double xin = __shfl(xfin, sl2 >= 0 ? sl2 : 0, 64);
+            const double pr = __dmul_rn(v2, sl2 >= 0 ? xin : xv2);
+            for (int l = 0; l < cnt; ++l) s = __dsub_rn(s, readlane_d(pr, l));
+        }
+        if (lane == c) xfin = s;
+    }
+    if (lane < W) {
+        stw(a.xb + row, xfin);
+        const int o = a.perm[row];
+        if (o < a.n) a.lx[o] = xfin;
+        else if (o < a.n + a.p) a.ly[o - a.n] = xfin;
+        else a.lz[o - a.n - a.p] = xfin;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_ul_solve2(UlSolve2Args a)
+{
+    __shared__ int s_task;
+    const int lane = threadIdx.x;
+    if (lane == 0) s_task = atomicAdd(a.ticket, 1);
+    __syncthreads();
+    for (int guard = 0; guard <= 2 * a.ntask; ++guard) {
+        const int tk = readfirst(s_task);
+        __syncthreads();
+        if (tk >= 2 * a.ntask) break;
+        int next_ticket = 0;
+        if (lane == 0) next_ticket = atomicAdd(a.ticket, 1);
+        bool ok = true;
+        if (tk < a.ntask) {
+            const int t = a.tsort[tk];
+            const int d0 = a.taskrec[8 * t + 5], dn = a.taskrec[8 * t + 6];
+            for (int c = lane; c < dn; c += 64) ok &= spin_until(a.fdone + a.tdep[d0 + c], a.epoch);
+            ok = __ballot(!ok) == 0;
+            if (ok) {
+                ul_fwd_task(a, t, lane);
+                drain_stores();
+                __hip_atomic_store(a.fdone + t, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        } else {
+            const int t = a.tsort[2 * a.ntask - 1 - tk];
+            const int parent = a.taskrec[8 * t + 7];
+            ok = spin_until(parent >= 0 ? a.bdone + parent : a.fdone + t, a.epoch);
+            ok = __ballot(!ok) == 0;
+            if (ok) {
+                ul_bwd_task(a, t, lane);
+                drain_stores();
+                __hip_atomic_store(a.bdone + t, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        if (!ok) { if (lane == 0) atomicMin(a.info, -2); break; }
+        if (lane == 0) s_task = next_ticket;
+        __syncthreads();
+    }
+}
+
 class ExactSparseKKT final : public KKTSolverBase {
 public:
     ExactSparseKKT(const pq_sparse_data* d, int device) : dev_(device)
@@ -463,13 +676,12 @@ public:
         UlFactorArgs a;
         a.N = N_; a.nticket = nticket_; a.epoch = epoch_;
         a.Cp = Cp_.p; a.Ci = Ci_.p; a.Cx = vals_.p;
-        a.tk_kind = tk_kind_.p; a.tk_id = tk_id_.p; a.task_ptr = task_ptr_.p; a.task_rows = task_rows_.p; a.row_task = row_task_.p; a.row_lane = row_lane_.p;
-        a.row_prev = row_prev_.p; a.dep_ptr = dep_ptr_.p; a.dep = dep_.p;
-        a.Rp = Rp_.p; a.Rcol = Rcol_.p; a.Rpos = Rpos_.p; a.Rcnt = Rcnt_.p; a.Rtab = Rtab_.p; a.Lp = Lp_.p; a.Li = Li_.p;
-        a.tab_ptr = tab_ptr_.p; a.mask_ptr = mask_ptr_.p; a.task_nU = task_nU_.p; a.Tmask = Tmask_.p;
+        a.tk_kind = tk_kind_.p; a.tk_id = tk_id_.p; a.task_rows = task_rows_.p; a.rowrec = rowrec_.p; a.taskrec = taskrec_.p; a.dep = dep_.p;
+        a.E4 = reinterpret_cast<const int4*>(E4_.p); a.Etab = Etab_.p; a.Li = Li_.p; a.Emask = Emask_.p;
         a.Lx = Lx_.p; a.D = D_.p; a.Dinv = Dinv_.p; a.Ystash = Ystash_.p; a.Pstash = Pstash_.p; a.Dinit = Dinit_.p; a.Lblock = Lblock_.p;
         a.done = done_.p; a.p1done = p1done_.p; a.ready = ready_.p; a.ticket = ctl_.p; a.info = ctl_.p + 1;
         a.yglob = yglob_.p;
+        a.trace = trace_.n > 1 ? trace_.p : nullptr;
         if (N_ > 0) {
             if (lds_y_) hipLaunchKernelGGL(k_ul_factor<true>, dim3(grid_), dim3(64), (size_t)N_ * sizeof(double), st_, a);
             else hipLaunchKernelGGL(k_ul_factor<false>, dim3(grid_), dim3(64), 0, st_, a);
@@ -487,15 +699,27 @@ public:
         PQ_ZONE("piqp_amd::ExactSparseKKT::solve");
         PQ_HIP(hipSetDevice(dev_));
         const int tk = prof_.begin(2, st_);
+        if (N_ > 0 && !one_wave_solve_) {
+            ++sepoch_;
+            PQ_HIP(hipMemsetAsync(ctl_.p + 2, 0, sizeof(int), st_));
+            UlSolve2Args b;
+            b.N = N_; b.n = n_; b.p = p_; b.m = m_; b.ntask = ntask_; b.epoch = sepoch_;
+            b.perm = perm_.p; b.taskrec = taskrec_.p; b.task_rows = task_rows_.p; b.tsort = tsort_.p; b.tdep = tdep_.p; b.fs_u = fs_u_.p; b.fs_col = fs_col_.p;
+            b.Lp = Lp_.p; b.Li = Li_.p; b.Lsrc = Lsrc_.p; b.Tmask = Tmask_.p; b.mask_ptr = mask_ptr_.p; b.Lblock = Lblock_.p; b.Lx = Lx_.p; b.Dinv = Dinv_.p;
+            b.rx = rhs_x; b.ry = rhs_y; b.rz = rhs_z; b.lx = lhs_x; b.ly = lhs_y; b.lz = lhs_z;
+            b.xf = xf_.p; b.xz = xz_.p; b.xb = xb_.p; b.fdone = fdone_.p; b.bdone = bdone_.p; b.ticket = ctl_.p + 2; b.info = ctl_.p + 3;
+            hipLaunchKernelGGL(k_ul_solve2, dim3(sgrid_), dim3(64), 0, st_, b);
+        } else if (N_ > 0) {
         UlSolveArgs a;
         a.N = N_; a.n = n_; a.p = p_; a.m = m_;
         a.perm = perm_.p; a.Lp = Lp_.p; a.Li = Li_.p; a.Lcol = Lcol_.p; a.Lx = Lx_.p; a.Dinv = Dinv_.p;
         a.bgroup = reinterpret_cast<const int4*>(bgroup_.p); a.nbgroup = nbgroup_;
         a.rx = rhs_x; a.ry = rhs_y; a.rz = rhs_z; a.lx = lhs_x; a.ly = lhs_y; a.lz = lhs_z;
         a.xglob = xglob_.p; a.err = nullptr; a.epoch = 0;
-        if (N_ > 0) {
+        {
             if (lds_x_) hipLaunchKernelGGL(k_ul_solve<true>, dim3(1), dim3(64), (size_t)N_ * sizeof(double), st_, a);
             else hipLaunchKernelGGL(k_ul_solve<false>, dim3(1), dim3(64), 0, st_, a);
+        }
         }
         PQ_HIP(hipGetLastError());
         prof_.end(2, tk, st_);
@@ -536,6 +760,12 @@ public:
         case 5: if (out_host && N_) PQ_HIP(hipMemcpy(out_host, Dinv_.p, sizeof(double) * (size_t)N_, hipMemcpyDeviceToHost)); return N_;
         case 6: if (out_host && nnzK_) PQ_HIP(hipMemcpy(out_host, vals_.p, sizeof(double) * (size_t)nnzK_, hipMemcpyDeviceToHost)); return nnzK_;
         case 7: if (out_host) std::copy(U_.perm.begin(), U_.perm.end(), (int*)out_host); return N_;
+        case 8: if (out_host && trace_.n > 1) PQ_HIP(hipMemcpy(out_host, trace_.p, sizeof(long long) * trace_.n, hipMemcpyDeviceToHost)); return trace_.n > 1 ? (long long)trace_.n : 0;  // PIQP_AMD_DEBUG=exact_trace
+        case 9: if (out_host) { std::copy(U_.tk_kind.begin(), U_.tk_kind.end(), (int*)out_host); } return nticket_;
+        case 10: if (out_host) { std::copy(U_.tk_id.begin(), U_.tk_id.end(), (int*)out_host); } return nticket_;
+        case 11: if (out_host) { for (int k = 0; k < N_; ++k) ((int*)out_host)[k] = U_.Rp[k + 1] - U_.Rp[k]; } return N_;
+        case 12: if (out_host) std::copy(U_.task_ptr.begin(), U_.task_ptr.end(), (int*)out_host); return ntask_ + 1;
+        case 13: if (out_host) std::copy(U_.task_rows.begin(), U_.task_rows.end(), (int*)out_host); return N_;
         default: throw std::runtime_error("exact_factor: unknown item");
         }
     }
@@ -589,11 +819,37 @@ private:
         upload_vec(mapP_, U_.mapP, st_); upload_vec(mapA_, U_.mapA, st_); upload_vec(mapG_, U_.mapG, st_);
         upload_vec(Lp_, U_.Lp, st_); upload_vec(Li_, U_.Li, st_); upload_vec(Lcol_, U_.Lcol, st_);
         upload_vec(Rp_, U_.Rp, st_); upload_vec(Rcol_, U_.Rcol, st_); upload_vec(Rpos_, U_.Rpos, st_);
-        upload_vec(tk_kind_, U_.tk_kind, st_); upload_vec(tk_id_, U_.tk_id, st_); upload_vec(task_ptr_, U_.task_ptr, st_); upload_vec(task_rows_, U_.task_rows, st_);
-        upload_vec(row_task_, U_.row_task, st_); upload_vec(row_lane_, U_.row_lane, st_); upload_vec(row_prev_, U_.row_prev, st_); upload_vec(dep_ptr_, U_.dep_ptr, st_);
-        upload_vec(dep_, U_.dep, st_); upload_vec(Rcnt_, U_.Rcnt, st_); upload_vec(Rtab_, U_.Rtab, st_); upload_vec(tab_ptr_, U_.tab_ptr, st_); upload_vec(mask_ptr_, U_.mask_ptr, st_);
-        upload_vec(task_nU_, U_.task_nU, st_); upload_vec(Tmask_, U_.Tmask, st_);
+        upload_vec(tk_kind_, U_.tk_kind, st_); upload_vec(tk_id_, U_.tk_id, st_); upload_vec(task_rows_, U_.task_rows, st_); upload_vec(dep_, U_.dep, st_);
         ntask_ = (int)U_.task_ptr.size() - 1; nticket_ = (int)U_.tk_kind.size();
+        upload_vec(tsort_, U_.tsort, st_); upload_vec(tdep_, U_.tdep, st_); upload_vec(fs_u_, U_.fs_u, st_); upload_vec(fs_col_, U_.fs_col, st_); upload_vec(Lsrc_, U_.Lsrc, st_);
+        upload_vec(Tmask_, U_.Tmask, st_); upload_vec(mask_ptr_, U_.mask_ptr, st_);
+        xf_.alloc(N_ ? N_ : 1); xz_.alloc(N_ ? N_ : 1); xb_.alloc(N_ ? N_ : 1); xb_.zero(st_); xf_.zero(st_);
+        fdone_.alloc(ntask_ ? ntask_ : 1); fdone_.zero(st_); bdone_.alloc(ntask_ ? ntask_ : 1); bdone_.zero(st_);
+        {   // the packed records and the task-ordered entry space (see UlFactorArgs)
+            const long long nnzL = U_.nnzL;
+            std::vector<int> rowrec((size_t)std::max(N_, 1) * 16, 0), taskrec((size_t)std::max(ntask_, 1) * 8, 0), e4((size_t)std::max<long long>(nnzL, 1) * 4, 0), etab(std::max<long long>(nnzL, 1), 0);
+            std::vector<unsigned long long> emask(std::max<long long>(nnzL, 1), 0ull);
+            int w = 0;
+            for (int t = 0; t < ntask_; ++t) {
+                const int rb = U_.task_ptr[t], W = U_.task_ptr[t + 1] - rb;
+                taskrec[8 * t] = rb; taskrec[8 * t + 1] = W; taskrec[8 * t + 2] = U_.task_nU[t]; taskrec[8 * t + 3] = U_.tab_ptr[t];
+                taskrec[8 * t + 4] = U_.fs_ptr[t]; taskrec[8 * t + 5] = U_.tdep_ptr[t]; taskrec[8 * t + 6] = U_.tdep_ptr[t + 1] - U_.tdep_ptr[t]; taskrec[8 * t + 7] = U_.tparent[t];
+                for (int q = 0; q < W; ++q) {
+                    const int k = U_.task_rows[rb + q];
+                    int* r = rowrec.data() + 16 * (size_t)k;
+                    r[0] = w; r[1] = U_.Rp[k + 1] - U_.Rp[k]; r[2] = U_.Cp[k]; r[3] = U_.Cp[k + 1] - U_.Cp[k]; r[4] = t; r[5] = W; r[6] = q; r[7] = U_.tab_ptr[t];
+                    r[8] = U_.row_prev[k]; r[9] = U_.dep_ptr[k]; r[10] = U_.dep_ptr[k + 1] - U_.dep_ptr[k]; r[11] = U_.task_nU[t];
+                    for (int e = U_.Rp[k]; e < U_.Rp[k + 1]; ++e, ++w) {
+                        const int i = U_.Rcol[e];
+                        e4[4 * (size_t)w] = i; e4[4 * (size_t)w + 1] = U_.Lp[i]; e4[4 * (size_t)w + 2] = U_.Rcnt[e]; e4[4 * (size_t)w + 3] = U_.Rpos[e];
+                        etab[w] = U_.Rtab[e];
+                        emask[w] = U_.Tmask[U_.mask_ptr[t] + U_.Rtab[e]];
+                    }
+                }
+            }
+            if (w != nnzL) throw std::runtime_error("reference-order engine: entry space");
+            upload_vec(rowrec_, rowrec, st_); upload_vec(taskrec_, taskrec, st_); upload_vec(E4_, e4, st_); upload_vec(Etab_, etab, st_); upload_vec(Emask_, emask, st_);
+        }
         Ystash_.alloc(U_.nnzL ? (size_t)U_.nnzL : 1); Pstash_.alloc(U_.nnzL ? (size_t)U_.nnzL : 1); Dinit_.alloc(N_ ? N_ : 1);
         Lblock_.alloc(U_.tab_ptr.back() ? (size_t)U_.tab_ptr.back() : 1); Lblock_.zero(st_);
         p1done_.alloc(N_ ? N_ : 1); p1done_.zero(st_); ready_.alloc(N_ ? N_ : 1); ready_.zero(st_);
@@ -642,6 +898,13 @@ private:
         per_cu = std::max(1, per_cu);
         grid_ = std::max(1, std::min(nticket_, per_cu * ncu));  // every workgroup of the launch is resident: tasks are taken in row order and wait only for earlier ones
         if (const char* t = debug_token("exact_grid")) grid_ = std::max(1, std::min(grid_, std::atoi(t)));
+        {
+            int per_cu_s = 1;
+            PQ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_s, k_ul_solve2, 64, 0));
+            sgrid_ = std::max(1, std::min(2 * ntask_, std::max(1, per_cu_s) * ncu));
+            if (const char* tg = debug_token("exact_grid")) sgrid_ = std::max(1, std::min(sgrid_, std::atoi(tg)));
+        }
+        trace_.alloc(debug_token("exact_trace") ? (size_t)4 * std::max(nticket_, 1) : 1);
         yglob_.alloc(lds_y_ ? 1 : (size_t)grid_ * (size_t)N_);
         xglob_.alloc(lds_x_ ? 1 : (size_t)std::max(N_, 1));
         stream_wait(st_);
@@ -660,9 +923,13 @@ private:
     hipStream_t st_ = nullptr;
     sparse::UpLooking U_;
     CscOperators ops_;
-    DBuf<int> perm_, Cp_, Ci_, diag_pos_, mapP_, mapA_, mapG_, Lp_, Li_, Lcol_, Rp_, Rcol_, Rpos_, Rcnt_, Rtab_, tk_kind_, tk_id_, task_ptr_, task_rows_, row_task_, row_lane_, row_prev_, dep_ptr_, dep_, tab_ptr_, mask_ptr_, task_nU_, done_,
-        p1done_, ready_, ctl_, bgroup_;
-    DBuf<unsigned long long> Tmask_;
+    DBuf<int> perm_, Cp_, Ci_, diag_pos_, mapP_, mapA_, mapG_, Lp_, Li_, Lcol_, Rp_, Rcol_, Rpos_, tk_kind_, tk_id_, task_rows_, dep_, rowrec_, taskrec_, E4_, Etab_, done_, p1done_, ready_, ctl_, bgroup_;
+    DBuf<int> tsort_, tdep_, fs_u_, fs_col_, Lsrc_, mask_ptr_, fdone_, bdone_;
+    DBuf<unsigned long long> Emask_, Tmask_;
+    DBuf<double> xf_, xz_, xb_;
+    DBuf<long long> trace_;
+    int sepoch_ = 0, sgrid_ = 1;
+    bool one_wave_solve_ = debug_token("exact_solve1") != nullptr;  // debugging aid: the single-wave substitution of the first version
     DBuf<double> vals_, Lx_, D_, Dinv_, Ystash_, Pstash_, Dinit_, Lblock_, yglob_, xglob_;
     HBuf<int> ctl_h_;
     StageProfiler prof_;

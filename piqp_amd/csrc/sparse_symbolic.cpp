@@ -1360,15 +1360,19 @@ void analyse_uplooking(const Symbolic& S, const pq_sparse_data* d, UpLooking& U)
     U.task_ptr.assign(nt + 1, 0);
     U.task_rows.clear();
     for (int t = 0; t < nt; ++t) { U.task_rows.insert(U.task_rows.end(), rows_of[t].begin(), rows_of[t].end()); U.task_ptr[t + 1] = (int)U.task_rows.size(); }
-    // what the row pass of k waits for: its children outside the task (complete rows).  The rows below it on the task's own path are not waited for; their
-    // own waits are inherited through the `ready` word of the row before (set as soon as that row's waits are over).
+    // what the row pass of k waits for: the children outside the task of k AND of the rows below it on the task's path (complete rows: every column the pass reads
+    // is then final).  The lists of a task's rows are prefixes of one another; they are stored per row so that a pass polls all its words at once (a chain of
+    // "the row before me has been released" words cost two microseconds per link).
     U.dep_ptr.assign(N + 1, 0);
-    for (int k = 0; k < N; ++k) { const int pa = U.etree[k]; if (pa >= 0 && U.row_task[pa] != U.row_task[k]) U.dep_ptr[pa + 1]++; }
-    for (int k = 0; k < N; ++k) U.dep_ptr[k + 1] += U.dep_ptr[k];
-    U.dep.assign(U.dep_ptr[N], 0);
+    U.dep.clear();
     {
-        IVec fill(U.dep_ptr.begin(), U.dep_ptr.end() - 1);
-        for (int k = 0; k < N; ++k) { const int pa = U.etree[k]; if (pa >= 0 && U.row_task[pa] != U.row_task[k]) U.dep[fill[pa]++] = k; }
+        std::vector<IVec> kids(N);
+        for (int k = 0; k < N; ++k) { const int pa = U.etree[k]; if (pa >= 0 && U.row_task[pa] != U.row_task[k]) kids[pa].push_back(k); }
+        for (int k = 0; k < N; ++k) {
+            const IVec& R = rows_of[U.row_task[k]];
+            for (int c = 0; c <= U.row_lane[k]; ++c) U.dep.insert(U.dep.end(), kids[R[c]].begin(), kids[R[c]].end());
+            U.dep_ptr[k + 1] = (int)U.dep.size();
+        }
     }
     // tickets: rows ascending; the path pass of a task right behind the row pass of its last row (every wait is for an earlier ticket)
     U.tk_kind.clear(); U.tk_id.clear();
@@ -1389,11 +1393,6 @@ void analyse_uplooking(const Symbolic& S, const pq_sparse_data* d, UpLooking& U)
             const IVec& R = rows_of[t];
             const int W = (int)R.size();
             U.tab_ptr[t + 1] = U.tab_ptr[t]; U.mask_ptr[t + 1] = U.mask_ptr[t];
-            if (W == 1) {
-                const int k = R[0];
-                for (int e = U.Rp[k]; e < U.Rp[k + 1]; ++e) U.Rcnt[e] = U.Rpos[e] - U.Lp[U.Rcol[e]];
-                continue;
-            }
             IVec ucols;
             for (int k : R)
                 for (int e = U.Rp[k]; e < U.Rp[k + 1]; ++e) {
@@ -1418,6 +1417,44 @@ void analyse_uplooking(const Symbolic& S, const pq_sparse_data* d, UpLooking& U)
             U.tab_ptr[t + 1] = U.tab_ptr[t] + (nU + W) * W;
             U.mask_ptr[t + 1] = (int)U.Tmask.size();
         }
+    }
+    // ---- schedule of the substitution (lsolve / ltsolve, ldlt.hpp:171-218) on the same tasks.  Forward: a task's rows as lanes, its table rows (columns that reach
+    // it) walked in ascending column order -- x_t loses fl(L(t, j) x_j) for j ascending, as the reference's column loop delivers them; a task waits for the tasks
+    // that end in a child of one of its rows.  Backward: a task's columns from the last to the first, each column's entries in ascending row order; a task waits for
+    // the task of its last row's parent.  Tasks are taken in the order of their last rows (forward ascending, backward descending).
+    {
+        U.fs_ptr.assign(nt + 1, 0); U.fs_u.clear(); U.fs_col.clear();
+        U.tdep_ptr.assign(nt + 1, 0); U.tdep.clear(); U.tparent.assign(nt, -1);
+        std::vector<std::pair<int, int>> srt;
+        IVec ucol_of;  // table row -> column, rebuilt per task the way the table was
+        IVec seen(N, -1);
+        for (int t = 0; t < nt; ++t) {
+            const IVec& R = rows_of[t];
+            const int W = (int)R.size(), nU = U.task_nU[t];
+            ucol_of.assign(nU + W, -1);
+            for (int k : R)
+                for (int e = U.Rp[k]; e < U.Rp[k + 1]; ++e) ucol_of[U.Rtab[e]] = U.Rcol[e];
+            for (int c = 0; c < W; ++c) ucol_of[nU + c] = R[c];
+            srt.clear();
+            for (int u = 0; u < nU + W; ++u) srt.emplace_back(ucol_of[u], u);
+            std::sort(srt.begin(), srt.end());
+            for (const auto& pr : srt) { U.fs_col.push_back(pr.first); U.fs_u.push_back(pr.second); }
+            U.fs_ptr[t + 1] = (int)U.fs_u.size();
+            for (int q = U.dep_ptr[R.back()]; q < U.dep_ptr[R.back() + 1]; ++q) U.tdep.push_back(U.row_task[U.dep[q]]);  // (the last row's list is the union over the task)
+            U.tdep_ptr[t + 1] = (int)U.tdep.size();
+            const int pa = U.etree[R.back()];
+            U.tparent[t] = pa >= 0 ? U.row_task[pa] : -1;
+        }
+        std::vector<std::pair<int, int>> ord;
+        for (int t = 0; t < nt; ++t) ord.emplace_back(rows_of[t].back(), t);
+        std::sort(ord.begin(), ord.end());
+        U.tsort.clear();
+        for (const auto& pr : ord) U.tsort.push_back(pr.second);
+        // per CSC entry: the lane of its row when that row lies on the path of its column's task (the backward sweep then takes x from that lane), else -1
+        U.Lsrc.assign(nnzL, -1);
+        for (int j = 0; j < N; ++j)
+            for (int q = U.Lp[j]; q < U.Lp[j + 1]; ++q) if (U.row_task[U.Li[q]] == U.row_task[j]) U.Lsrc[q] = U.row_lane[U.Li[q]];
+        (void)seen;
     }
 }
 

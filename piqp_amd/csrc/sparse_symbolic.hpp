@@ -104,6 +104,9 @@ struct UpLooking {
     IVec Rcnt, Rtab;            // per entry of a row: leading entries of its column the row pass scatters (-1: column of the task's own path); row of the task's table
     IVec tab_ptr, mask_ptr, task_nU;  // per task: offset of its (nU + W) x W value table, of its nU + W presence words, columns outside the path that reach it
     std::vector<unsigned long long> Tmask;
+    // substitution on the same tasks (see analyse_uplooking): table rows of every task sorted by column, the tasks a task's forward pass waits for, the task of
+    // its last row's parent, the tasks in the order of their last rows, and per CSC entry the lane of its row inside its column's task (-1: another task)
+    IVec fs_ptr, fs_u, fs_col, tdep_ptr, tdep, tparent, tsort, Lsrc;
     long long nnzL = 0;
     double flops = 0.0;         // sum_j (c_j^2 + 3 c_j)
     int height = 0;             // elimination tree height (rows)

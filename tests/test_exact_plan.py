@@ -154,7 +154,7 @@ def replay(pl, Cx):
         for q in reversed(pending):
             if kinds[q] == 0:
                 k = ids[q]
-                ok = all(done[c] for c in pl["dep"][pl["dep_ptr"][k]:pl["dep_ptr"][k + 1]]) and (rprev[k] < 0 or ready[rprev[k]])
+                ok = all(done[c] for c in pl["dep"][pl["dep_ptr"][k]:pl["dep_ptr"][k + 1]])
             else:
                 t = ids[q]
                 ok = all(p1done[k] for k in trows[tptr[t]:tptr[t + 1]])
@@ -208,11 +208,12 @@ def test_plan_structure_equals_the_oracle(orc, name):
         assert pl["row_prev"][R[0]] == -1
         assert np.array_equal(pl["row_lane"][R], np.arange(len(R))) and np.all(pl["row_task"][R] == t)
     assert np.all(cover == 1)
+    outside = {k: sorted(c for c in np.nonzero(et == k)[0] if pl["row_task"][c] != pl["row_task"][k]) for k in range(N)}
     for k in range(N):
-        ch = np.nonzero(et == k)[0]
-        outside = sorted(c for c in ch if pl["row_task"][c] != pl["row_task"][k])
-        assert sorted(pl["dep"][pl["dep_ptr"][k]:pl["dep_ptr"][k + 1]].tolist()) == outside
-        assert all(pl["task_rows"][pl["task_ptr"][pl["row_task"][c] + 1] - 1] == c for c in outside)  # a waited-for row ends its own task
+        R = trows[tptr[pl["row_task"][k]]:tptr[pl["row_task"][k] + 1]]
+        want = sorted(c for r in R[:pl["row_lane"][k] + 1] for c in outside[r])  # the children outside the task of k and of the path rows below it
+        assert sorted(pl["dep"][pl["dep_ptr"][k]:pl["dep_ptr"][k + 1]].tolist()) == want
+        assert all(pl["task_rows"][pl["task_ptr"][pl["row_task"][c] + 1] - 1] == c for c in want)  # a waited-for row ends its own task
     # tickets: every row pass once, rows ascending; a path pass right behind the row pass of its last row
     rows_seen = [i for kd, i in zip(pl["tk_kind"], pl["tk_id"]) if kd == 0]
     assert rows_seen == list(range(N))
