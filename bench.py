@@ -305,6 +305,12 @@ def main():
             sl = {"error": f"{type(e).__name__}: {e}"}
         if rank == 0:
             out["sparse_kkt"] = sl
+    if world == 1 and not args.no_sparse_legs:
+        try:
+            sq = small_qp_legs(args)
+        except Exception as e:  # noqa: BLE001
+            sq = {"error": f"{type(e).__name__}: {e}"}
+        out["small_qp"] = sq
     if c5_child is not None:
         pd.barrier()
         rc, c5_out, c5_err = pd.release_and_collect(c5_child, timeout=300)
@@ -548,6 +554,41 @@ def sparse_legs(args, rank, world, local_rank, dev, pd):
             res[key] = r
         del k
     return res if rank == 0 else None
+
+
+def small_qp_legs(args):
+    """Whole interior-point solves of small sparse QPs (the reference's own benchmark shapes, benchmarks/src/sqp_benchmarks.cpp, and a degenerate Maros-Meszaros LP-like
+    QP): kkt_solver = sparse_ldlt runs the reference-order engine up to 8192 KKT rows (sparse_exact.hip: the solve is the oracle's bit for bit), sparse_ldlt_multifrontal
+    forces the supernodal engine; next to the CPU oracle on one core.  Times are solve() wall clock of a warm solver (second solve), host pointers."""
+    import numpy as np
+    import piqp_amd as hip
+    from oracle import pyorc as orc
+    from qp_io import load_qp
+    res = {}
+    for name in ("qp_chain_mass_sqp", "mm_QPILOTNO"):
+        q = load_qp(name)
+        a = (q["P"], q["c"], q["A"], q["b"], q["G"], q["h_l"], q["h_u"], q["x_l"], q["x_u"])
+        so = orc.Solver(); so.settings.kkt_solver = orc.SPARSE_LDLT; so.enable_trace(1024)
+        so.setup(*a, sparse=True)
+        so.solve()
+        so.enable_trace(1024)
+        t0 = time.perf_counter(); st_o = so.solve(); t_o = time.perf_counter() - t0
+        tro = so.trace()
+        for tag, ks in (("reference_order", hip.SPARSE_LDLT), ("multifrontal", hip.SPARSE_LDLT_MULTIFRONTAL)):
+            sh = hip.SparseSolver(); sh.settings.kkt_solver = ks; sh.enable_trace(1024)
+            sh.setup(*a)
+            sh.solve()
+            sh.enable_trace(1024)
+            t0 = time.perf_counter(); st_h = sh.solve(); t_h = time.perf_counter() - t0
+            trh = sh.trace()
+            same = bool(trh.shape == tro.shape and np.array_equal(trh, tro))
+            res[f"{name}:{tag}:solve_ms"] = t_h * 1e3
+            res[f"{name}:{tag}:iterations"] = int(sh.info.iter)
+            res[f"{name}:{tag}:status_equal_oracle"] = int(st_h == st_o)
+            res[f"{name}:{tag}:trace_bitwise_equal_oracle"] = int(same)
+        res[f"{name}:oracle_1_core:solve_ms"] = t_o * 1e3
+        res[f"{name}:oracle_1_core:iterations"] = int(so.info.iter)
+    return res
 
 
 def batched_qp(args, rank, world, local_rank, dev, pd):

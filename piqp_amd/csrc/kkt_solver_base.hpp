@@ -90,6 +90,7 @@ public:
 KKTSolverBase* make_dense_kkt(const pq_dense_data* data, int kkt_solver, int device);
 KKTSolverBase* make_sparse_kkt(const pq_sparse_data* data, int kkt_solver, int device);
 KKTSolverBase* make_multistage_kkt(const pq_sparse_data* data, int device);
-KKTSolverBase* make_exact_sparse_kkt(const pq_sparse_data* data, int device);  // sparse_exact.hip: KKT_FULL in the reference's own elimination order
+KKTSolverBase* make_multifrontal_kkt(const pq_sparse_data* data, int mode, int device);  // sparse_kkt.hip: the supernodal multifrontal engine, any KKTMode
+KKTSolverBase* make_exact_sparse_kkt(const pq_sparse_data* data, int mode, int device);  // sparse_exact.hip: any KKTMode in the reference's own elimination order
 
 }  // namespace pq

@@ -400,7 +400,7 @@ KKTSolverBase* make_multistage_kkt(const pq_sparse_data* data, int device)
     ms->multistage_block_info(bi);
     const int stages = (int)bi.size() / 3 - 1;
     if (want == "chain" || (want == "auto" && stages < 16)) return ms.release();
-    std::unique_ptr<KKTSolverBase> tree(make_sparse_kkt(data, PQ_SPARSE_LDLT_COND, device));
+    std::unique_ptr<KKTSolverBase> tree(make_multifrontal_kkt(data, 3, device));  // (KKT_ALL_ELIMINATED on the multifrontal engine: the tree engine of this backend)
     if (!tree) return ms.release();
     if (want != "tree") {
         double st[8];

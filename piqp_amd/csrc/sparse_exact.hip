@@ -81,6 +81,40 @@ __global__ void k_ul_set_diag(int n, int p, int m, const int* __restrict__ diag_
 //   E4[e]             column i, first CSC entry of column i, entries of column i the row pass scatters (-1: a column of the task's own path), CSC position of L(k, i)
 //   Etab[e], Emask[e] the entry's row in the task's table and that row's presence bits
 // Ystash / Pstash are indexed in the same entry space.
+// ---- condensed KKT modes (kkt_{eq,ineq,all}_eliminated.hpp update_kkt_*): the same kernels as sparse_kkt.hip keeps for the multifrontal engine, compiled here
+// without FMA contraction; every sum in the reference's order (the CPU oracle's orc_sparse_cond.c restates them)
+__global__ void k_ul_cond_diag(int n, int np, int nm, const int* __restrict__ diag_pos, const double* __restrict__ x_reg, double delta, const double* __restrict__ z_reg,
+                               double* __restrict__ vals)
+{
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= n + np + nm) return;
+    if (col < n) vals[diag_pos[col]] += x_reg[col];
+    else if (col < n + np) vals[diag_pos[col]] = -delta;
+    else vals[diag_pos[col]] = -z_reg[col - n - np];
+}
+// value of every entry of upper(MT diag(1/w) MT^T) from its product-term list (constraints ascending, the reference's order); w == nullptr: unit weights
+template <bool MAPPED>
+__global__ void k_ul_gram_values(int nent, const int* __restrict__ ptr, const int* __restrict__ q1, const int* __restrict__ q2, const int* __restrict__ kk,
+                                 const double* __restrict__ x, const double* __restrict__ w, const int* __restrict__ dst, double* __restrict__ out)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nent) return;
+    double s = 0.0;
+    if (w) for (int t = ptr[e]; t < ptr[e + 1]; ++t) s += x[q2[t]] * x[q1[t]] / w[kk[t]];
+    else for (int t = ptr[e]; t < ptr[e + 1]; ++t) s += x[q2[t]] * x[q1[t]];
+    if (MAPPED) out[dst[e]] += s; else out[e] = s;
+}
+__global__ void k_ul_axpy_mapped(int nent, const int* __restrict__ dst, double alpha, const double* __restrict__ src, double* __restrict__ out)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < nent) out[dst[e]] += alpha * src[e];
+}
+__global__ void k_ul_reciprocal(int m, const double* __restrict__ z, double* __restrict__ zinv)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) zinv[i] = 1.0 / z[i];
+}
+
 struct UlFactorArgs {
     int N, nticket, epoch;
     const int *Cp, *Ci;
@@ -90,7 +124,8 @@ struct UlFactorArgs {
     const int *Etab, *Li;
     const unsigned long long* Emask;
     double *Lx, *D, *Dinv, *Ystash, *Pstash, *Dinit, *Lblock;
-    int *done, *p1done, *ready, *ticket, *info;
+    int *done, *p1done, *ready, *prog, *ticket, *info;
+    int rowpar;     // 1: the path pass of a row follows its row pass on the same wave (ul_path_row); 0: one path pass per task (ul_path; PIQP_AMD_DEBUG=exact_serial_path)
     double* yglob;  // N doubles per workgroup when y does not fit LDS
     long long* trace;  // debugging aid (PIQP_AMD_DEBUG=exact_trace), nullable: per ticket 4 x wall_clock64 (100 MHz): drawn, waits over, done; [3] = workgroup
 };
@@ -109,12 +144,22 @@ __device__ __forceinline__ bool spin_until(const int* flag, int epoch)
     return true;
 }
 
+__device__ __forceinline__ bool spin_until_ge(const int* flag, int want)
+{
+    long long spins = 0;
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > (1ll << 26)) return false;
+    }
+    return true;
+}
+
 // ROW PASS of row k (ldlt.hpp:121-163): the entries of row k in the columns outside the row's task, in the reference's order.  A row that is a task of its own is
 // finished here; for a row on a longer path the updates into the path's rows are left to the path pass (E4.z counts only the entries of a column above them), the
 // values y_i, the products l_ki y_i and the initial values of the path columns go to Ystash / Pstash / Dinit, the quotients also into the task's table.
 // y: this wave's dense work vector, all zero on entry and on exit.
-__device__ __forceinline__ void ul_row(const UlFactorArgs& a, double* __restrict__ y, const int k, const int lane, const int es, const int en, const int p0, const int pn,
-                                       const int W, const int lanek, const int tb)
+__device__ __forceinline__ double ul_row(const UlFactorArgs& a, double* __restrict__ y, const int k, const int lane, const int es, const int en, const int p0, const int pn,
+                                         const int W, const int lanek, const int tb)
 {
     const bool multi = W > 1;
     // scatter A(0:k, k) into y (:127-131)
@@ -188,6 +233,7 @@ __device__ __forceinline__ void ul_row(const UlFactorArgs& a, double* __restrict
             if (Dk == 0.0) atomicMin(a.info, k);  // :163 (the smallest such k is the row the serial loop stops at)
         }
     }
+    return Dk;
 }
 
 // PATH PASS of task t: its rows one after the other, the path rows as lanes.  For row k the pattern is walked once more in the reference's order; an entry in an
@@ -317,6 +363,85 @@ __device__ __forceinline__ bool ul_path(const UlFactorArgs& a, const int t, cons
     return true;
 }
 
+// PATH PASS of ONE row, run by the wave that has just finished the row's row pass (round 5, second form: the rows of a task advance side by side instead of one
+// after the other).  Same arithmetic as ul_path, entry for entry; what a row needs from the rows below it on the path arrives through memory:
+//   * before the first step: the row passes of the rows below are complete (their quotients L(c, i) in outside columns i are in the table);
+//   * at a step whose source is path column c0: D of row c0 (that row is complete), and for every path row c between c0 and this row that holds an entry
+//     L(c, c0): row c has published it (prog[c] counts the path columns a row has published; a complete row counts 127);
+//   * this row publishes its own quotient L(k, c0) and bumps its counter at once, so that the rows above can take their c0 step.
+// A row's pattern in front of its c0 entry is (about) the pattern of row c0, so rows that run side by side reach their waits about when the word arrives.
+__device__ __forceinline__ bool ul_path_row(const UlFactorArgs& a, const int k, const int lane, const int es, const int en, const int W, const int j, const int tb,
+                                            const int nU, const int rb, double Dk, double* s_acc, int* s_pos)
+{
+    const int lw = lane < W ? lane : W - 1;
+    const int rowl = a.task_rows[rb + lw];        // lane c: the path row c
+    bool ok = lane < j ? spin_until(a.p1done + rowl, a.epoch) : true;
+    if (__ballot(!ok)) return false;
+    s_acc[lane] = 0.0;
+    wave_sync();
+    for (int e = es + lane; e < es + en; e += 64) {
+        const int u = a.Etab[e];
+        if (u >= nU) s_acc[u - nU] = ldw(a.Ystash + e);   // the initial values of the path columns, A(c, k), left by the row pass
+    }
+    wave_sync();
+    double acc = s_acc[lane];
+    wave_sync();
+    (void)s_pos;
+    const unsigned long long below = j >= 64 ? ~0ull : ((1ull << j) - 1ull);  // path rows under row k
+    const int done_word = (a.epoch << 8) | 127;
+    for (int base = 0; base < en; base += 64) {
+        const int ns = min(64, en - base);
+        const UlChunk ch = ul_load_chunk(a, es + base, ns, es, lane);
+        double pf_v[UL_PFP];
+#pragma unroll
+        for (int d = 0; d < UL_PFP; ++d) pf_v[d] = ldw(a.Lblock + tb + __builtin_amdgcn_readlane(ch.tab, d) * W + lw);
+        for (int sb = 0; sb < ns; sb += UL_PFP) {
+#pragma unroll
+            for (int d = 0; d < UL_PFP; ++d) {
+                const int s = sb + d;
+                const int u = __builtin_amdgcn_readlane(ch.tab, s & 63);
+                const unsigned long long m = (((unsigned long long)(unsigned)__builtin_amdgcn_readlane(ch.mhi, s & 63) << 32) | (unsigned)__builtin_amdgcn_readlane(ch.mlo, s & 63)) & below;
+                double v = pf_v[d];
+                pf_v[d] = ldw(a.Lblock + tb + __builtin_amdgcn_readlane(ch.tab, (s + UL_PFP) & 63) * W + lw);
+                if (s < ns) {
+                    const bool bit = __builtin_amdgcn_inverse_ballot_w64(m);
+                    double src, term;
+                    if (u < nU) {
+                        src = readlane_d(ch.ys, s & 63);
+                        term = readlane_d(ch.ps, s & 63);
+                    } else {
+                        const int c0 = u - nU;
+                        src = readlane_d(acc, c0 & 63);
+                        const int row0 = __builtin_amdgcn_readlane(rowl, c0 & 63);
+                        if (!spin_until_ge(a.prog + row0, done_word)) return false;
+                        const double D0 = ldw(a.D + row0);
+                        const double l = __ddiv_rn(src, D0);
+                        term = __dmul_rn(l, src);
+                        stw(a.Lx + __builtin_amdgcn_readlane(ch.pos, s & 63), l);
+                        stw(a.Lblock + tb + u * W + j, l);
+                        drain_stores();
+                        __hip_atomic_store(a.prog + k, (a.epoch << 8) | (c0 + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        // the rows between c0 and this one that hold an entry in column c0 must have published it
+                        bool okw = bit ? spin_until_ge(a.prog + rowl, (a.epoch << 8) | (c0 + 1)) : true;
+                        if (__ballot(!okw)) return false;
+                        v = ldw(a.Lblock + tb + u * W + lw);
+                    }
+                    if (bit) acc = msub(acc, v, src);
+                    Dk = __dsub_rn(Dk, term);
+                }
+            }
+        }
+    }
+    if (lane == 0) {
+        stw(a.D + k, Dk);
+        a.Dinv[k] = __ddiv_rn(1.0, Dk);
+        if (Dk == 0.0) atomicMin(a.info, k);
+    }
+    drain_stores();
+    __hip_atomic_store(a.prog + k, done_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return true;
+}
+
 template <bool LDSY>
 __global__ __launch_bounds__(64) void k_ul_factor(UlFactorArgs a)
 {
@@ -347,17 +472,25 @@ __global__ __launch_bounds__(64) void k_ul_factor(UlFactorArgs a)
             const int k = id;
             const int4 r0 = *reinterpret_cast<const int4*>(a.rowrec + 16 * k), r1 = *reinterpret_cast<const int4*>(a.rowrec + 16 * k + 4),
                        r2 = *reinterpret_cast<const int4*>(a.rowrec + 16 * k + 8);
-            const int es = r0.x, en = r0.y, cp0 = r0.z, cpn = r0.w, W = r1.y, lanek = r1.z, tb = r1.w, prev = r2.x, c0 = r2.y, cn = r2.z;
+            const int es = r0.x, en = r0.y, cp0 = r0.z, cpn = r0.w, W = r1.y, lanek = r1.z, tb = r1.w, prev = r2.x, c0 = r2.y, cn = r2.z, nU = r2.w;
+            const int serial_task = a.rowrec[16 * k + 12];
             for (int c = lane; c < cn; c += 64) ok &= spin_until(a.done + a.dep[c0 + c], a.epoch);
             (void)prev;
             ok = __ballot(!ok) == 0;
             if (ok) {
                 if (a.trace && lane == 0) a.trace[4 * (size_t)tk + 1] = wall_clock64();
-                ul_row(a, y, k, lane, es, en, cp0, cpn, W, lanek, tb);
+                const double Dk0 = ul_row(a, y, k, lane, es, en, cp0, cpn, W, lanek, tb);
                 drain_stores();
                 int* flag = (W > 1 ? a.p1done : a.done) + k;
                 __hip_atomic_store(flag, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (every lane stores the same word: no divergence at the loop's end)
+                if (W > 1 && !serial_task) {
+                    const int rb = a.taskrec[8 * r1.x];
+                    ok = ul_path_row(a, k, lane, es, en, W, lanek, tb, nU, rb, readlane_d(Dk0, 0), s_acc, s_pos);
+                    if (ok && lanek == W - 1) __hip_atomic_store(a.done + k, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (ul_path_row has drained its stores)
+                }
             }
+        } else if (!a.rowrec[16 * a.task_rows[a.taskrec[8 * id]] + 12]) {
+            // (the rows of this task did their path pass themselves, side by side)
         } else {
             if (a.trace && lane == 0) a.trace[4 * (size_t)tk + 1] = wall_clock64();
             ok = ul_path(a, id, lane, s_acc, s_pos);
@@ -627,15 +760,27 @@ __global__ __launch_bounds__(64) void k_ul_solve2(UlSolve2Args a)
 
 class ExactSparseKKT final : public KKTSolverBase {
 public:
-    ExactSparseKKT(const pq_sparse_data* d, int device) : dev_(device)
+    ExactSparseKKT(const pq_sparse_data* d, int mode, int device) : dev_(device), mode_(mode)
     {
         if (d->mem != PQ_MEM_HOST) throw std::runtime_error("sparse data must be host-resident");
         PQ_HIP(hipSetDevice(dev_));
         PQ_HIP(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
         sparse::Symbolic S;
-        sparse::analyse_kkt_pattern(d, 0, S);
+        sparse::analyse_kkt_pattern(d, mode_, S);
         sparse::analyse_uplooking(S, d, U_);
         n_ = U_.n; p_ = U_.p; m_ = U_.m; N_ = U_.N;
+        if (mode_ != 0) {
+            // eliminated blocks: entry -> value index of P K P' and the product-term lists (kkt_all_eliminated.hpp:184-223)
+            nzAA_ = (int)S.gramA.rowind.size(); nzGG_ = (int)S.gramG.rowind.size();
+            std::vector<int> maa(nzAA_), mgg(nzGG_);
+            for (int e = 0; e < nzAA_; ++e) maa[e] = U_.PKi[S.gramA_to_Ki[e]];
+            for (int e = 0; e < nzGG_; ++e) mgg[e] = U_.PKi[S.gramG_to_Ki[e]];
+            upload_vec(mapAA_, maa, st_); upload_vec(mapGG_, mgg, st_);
+            upload_vec(aa_ptr_, S.gramA.ptr, st_); upload_vec(aa_q1_, S.gramA.q1, st_); upload_vec(aa_q2_, S.gramA.q2, st_); upload_vec(aa_k_, S.gramA.k, st_);
+            upload_vec(gg_ptr_, S.gramG.ptr, st_); upload_vec(gg_q1_, S.gramG.q1, st_); upload_vec(gg_q2_, S.gramG.q2, st_); upload_vec(gg_k_, S.gramG.k, st_);
+            ata_vals_.alloc(nzAA_ ? nzAA_ : 1);
+        }
+        zinv_.alloc(m_ ? m_ : 1); rhs_top_.alloc(n_ ? n_ : 1);
         nnzK_ = U_.Cp[N_];
         build_device();
         ops_.init(d, st_);
@@ -667,7 +812,22 @@ public:
         PQ_ZONE("piqp_amd::ExactSparseKKT::update_scalings_and_factor");
         PQ_HIP(hipSetDevice(dev_));
         const int t0 = prof_.begin(0, st_);
-        hipLaunchKernelGGL(k_ul_set_diag, g1(N_), dim3(256), 0, st_, n_, p_, m_, diag_pos_.p, ops_.P_diag(), x_reg, delta, z_reg, vals_.p);
+        delta_ = delta;
+        if (mode_ == 0) {
+            hipLaunchKernelGGL(k_ul_set_diag, g1(N_), dim3(256), 0, st_, n_, p_, m_, diag_pos_.p, ops_.P_diag(), x_reg, delta, z_reg, vals_.p);
+        } else {
+            // update_kkt_cost_scalings / _equality_scalings / _inequality_scaling of the mode, every entry's terms in the reference's order
+            const bool eq = mode_ & 1, ineq = mode_ & 2;
+            if (m_ > 0) hipLaunchKernelGGL(k_ul_reciprocal, g1(m_), dim3(256), 0, st_, m_, z_reg, zinv_.p);
+            PQ_HIP(hipMemsetAsync(vals_.p, 0, sizeof(double) * (size_t)nnzK_, st_));
+            launch_remap_values(ops_.nzP(), mapP_.p, ops_.P_x(), vals_.p, st_);
+            hipLaunchKernelGGL(k_ul_cond_diag, g1(N_), dim3(256), 0, st_, n_, eq ? 0 : p_, ineq ? 0 : m_, diag_pos_.p, x_reg, delta, z_reg, vals_.p);
+            if (eq) { if (nzAA_) hipLaunchKernelGGL(k_ul_axpy_mapped, g1(nzAA_), dim3(256), 0, st_, nzAA_, mapAA_.p, 1.0 / delta, ata_vals_.p, vals_.p); }
+            else launch_remap_values(ops_.nzA(), mapA_.p, ops_.AT_x(), vals_.p, st_);
+            if (ineq) {
+                if (nzGG_) hipLaunchKernelGGL(k_ul_gram_values<true>, g1(nzGG_), dim3(256), 0, st_, nzGG_, gg_ptr_.p, gg_q1_.p, gg_q2_.p, gg_k_.p, ops_.GT_x(), z_reg, mapGG_.p, vals_.p);
+            } else launch_remap_values(ops_.nzG(), mapG_.p, ops_.GT_x(), vals_.p, st_);
+        }
         prof_.end(0, t0, st_);
         const int t1 = prof_.begin(1, st_);
         ++epoch_;
@@ -679,7 +839,8 @@ public:
         a.tk_kind = tk_kind_.p; a.tk_id = tk_id_.p; a.task_rows = task_rows_.p; a.rowrec = rowrec_.p; a.taskrec = taskrec_.p; a.dep = dep_.p;
         a.E4 = reinterpret_cast<const int4*>(E4_.p); a.Etab = Etab_.p; a.Li = Li_.p; a.Emask = Emask_.p;
         a.Lx = Lx_.p; a.D = D_.p; a.Dinv = Dinv_.p; a.Ystash = Ystash_.p; a.Pstash = Pstash_.p; a.Dinit = Dinit_.p; a.Lblock = Lblock_.p;
-        a.done = done_.p; a.p1done = p1done_.p; a.ready = ready_.p; a.ticket = ctl_.p; a.info = ctl_.p + 1;
+        a.done = done_.p; a.p1done = p1done_.p; a.ready = ready_.p; a.prog = prog_.p; a.ticket = ctl_.p; a.info = ctl_.p + 1;
+        a.rowpar = serial_path_ ? 0 : 1;
         a.yglob = yglob_.p;
         a.trace = trace_.n > 1 ? trace_.p : nullptr;
         if (N_ > 0) {
@@ -699,28 +860,41 @@ public:
         PQ_ZONE("piqp_amd::ExactSparseKKT::solve");
         PQ_HIP(hipSetDevice(dev_));
         const int tk = prof_.begin(2, st_);
+        // sparse/kkt.hpp:113-136: the eliminated blocks are folded into the x part of the right-hand side; the KKT vector of the mode is [x; kept y; kept z]
+        const bool eq = mode_ & 1, ineq = mode_ & 2;
+        const double delta_inv = 1.0 / delta_;
+        const double *in_x = rhs_x, *in_y = rhs_y, *in_z = rhs_z;
+        double *out_y = lhs_y, *out_z = lhs_z;
+        int kp = p_, km = m_;
+        if (mode_ != 0) {
+            ops_.fold_rhs(rhs_x, rhs_y, rhs_z, zinv_.p, delta_inv, rhs_top_.p, st_, eq, ineq);
+            in_x = rhs_top_.p;
+            if (eq) { kp = 0; in_y = nullptr; out_y = nullptr; }
+            if (ineq) { km = 0; in_z = nullptr; out_z = nullptr; }
+        }
         if (N_ > 0 && !one_wave_solve_) {
             ++sepoch_;
             PQ_HIP(hipMemsetAsync(ctl_.p + 2, 0, sizeof(int), st_));
             UlSolve2Args b;
-            b.N = N_; b.n = n_; b.p = p_; b.m = m_; b.ntask = ntask_; b.epoch = sepoch_;
+            b.N = N_; b.n = n_; b.p = kp; b.m = km; b.ntask = ntask_; b.epoch = sepoch_;
             b.perm = perm_.p; b.taskrec = taskrec_.p; b.task_rows = task_rows_.p; b.tsort = tsort_.p; b.tdep = tdep_.p; b.fs_u = fs_u_.p; b.fs_col = fs_col_.p;
             b.Lp = Lp_.p; b.Li = Li_.p; b.Lsrc = Lsrc_.p; b.Tmask = Tmask_.p; b.mask_ptr = mask_ptr_.p; b.Lblock = Lblock_.p; b.Lx = Lx_.p; b.Dinv = Dinv_.p;
-            b.rx = rhs_x; b.ry = rhs_y; b.rz = rhs_z; b.lx = lhs_x; b.ly = lhs_y; b.lz = lhs_z;
+            b.rx = in_x; b.ry = in_y; b.rz = in_z; b.lx = lhs_x; b.ly = out_y; b.lz = out_z;
             b.xf = xf_.p; b.xz = xz_.p; b.xb = xb_.p; b.fdone = fdone_.p; b.bdone = bdone_.p; b.ticket = ctl_.p + 2; b.info = ctl_.p + 3;
             hipLaunchKernelGGL(k_ul_solve2, dim3(sgrid_), dim3(64), 0, st_, b);
         } else if (N_ > 0) {
         UlSolveArgs a;
-        a.N = N_; a.n = n_; a.p = p_; a.m = m_;
+        a.N = N_; a.n = n_; a.p = kp; a.m = km;
         a.perm = perm_.p; a.Lp = Lp_.p; a.Li = Li_.p; a.Lcol = Lcol_.p; a.Lx = Lx_.p; a.Dinv = Dinv_.p;
         a.bgroup = reinterpret_cast<const int4*>(bgroup_.p); a.nbgroup = nbgroup_;
-        a.rx = rhs_x; a.ry = rhs_y; a.rz = rhs_z; a.lx = lhs_x; a.ly = lhs_y; a.lz = lhs_z;
+        a.rx = in_x; a.ry = in_y; a.rz = in_z; a.lx = lhs_x; a.ly = out_y; a.lz = out_z;
         a.xglob = xglob_.p; a.err = nullptr; a.epoch = 0;
         {
             if (lds_x_) hipLaunchKernelGGL(k_ul_solve<true>, dim3(1), dim3(64), (size_t)N_ * sizeof(double), st_, a);
             else hipLaunchKernelGGL(k_ul_solve<false>, dim3(1), dim3(64), 0, st_, a);
         }
         }
+        if (mode_ != 0) ops_.recover_duals(lhs_x, rhs_y, rhs_z, zinv_.p, delta_inv, lhs_y, lhs_z, st_, eq, ineq);  // sparse/kkt.hpp:147-175
         PQ_HIP(hipGetLastError());
         prof_.end(2, tk, st_);
     }
@@ -799,10 +973,15 @@ public:
     }
 
 private:
-    ExactSparseKKT(const ExactSparseKKT& o, int) : dev_(o.dev_), n_(o.n_), p_(o.p_), m_(o.m_), N_(o.N_), nnzK_(o.nnzK_), U_(o.U_)
+    ExactSparseKKT(const ExactSparseKKT& o, int) : dev_(o.dev_), mode_(o.mode_), nzAA_(o.nzAA_), nzGG_(o.nzGG_), n_(o.n_), p_(o.p_), m_(o.m_), N_(o.N_), nnzK_(o.nnzK_), delta_(o.delta_), U_(o.U_)
     {
         PQ_HIP(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
         build_device();
+        auto cpi = [&](DBuf<int>& d, const DBuf<int>& sc) { d.alloc(sc.n ? sc.n : 1); if (sc.n) PQ_HIP(hipMemcpyAsync(d.p, sc.p, sc.bytes(), hipMemcpyDeviceToDevice, st_)); };
+        auto cpd = [&](DBuf<double>& d, const DBuf<double>& sc) { d.alloc(sc.n ? sc.n : 1); if (sc.n) PQ_HIP(hipMemcpyAsync(d.p, sc.p, sc.bytes(), hipMemcpyDeviceToDevice, st_)); };
+        cpi(mapAA_, o.mapAA_); cpi(mapGG_, o.mapGG_); cpi(aa_ptr_, o.aa_ptr_); cpi(aa_q1_, o.aa_q1_); cpi(aa_q2_, o.aa_q2_); cpi(aa_k_, o.aa_k_);
+        cpi(gg_ptr_, o.gg_ptr_); cpi(gg_q1_, o.gg_q1_); cpi(gg_q2_, o.gg_q2_); cpi(gg_k_, o.gg_k_);
+        cpd(ata_vals_, o.ata_vals_); cpd(zinv_, o.zinv_); rhs_top_.alloc(n_ ? n_ : 1);
         ops_.clone_from(o.ops_, st_);
         if (nnzK_) PQ_HIP(hipMemcpyAsync(vals_.p, o.vals_.p, sizeof(double) * (size_t)nnzK_, hipMemcpyDeviceToDevice, st_));
         if (U_.nnzL) PQ_HIP(hipMemcpyAsync(Lx_.p, o.Lx_.p, sizeof(double) * (size_t)U_.nnzL, hipMemcpyDeviceToDevice, st_));
@@ -832,13 +1011,18 @@ private:
             int w = 0;
             for (int t = 0; t < ntask_; ++t) {
                 const int rb = U_.task_ptr[t], W = U_.task_ptr[t + 1] - rb;
+                // rows side by side (ul_path_row) cost about one memory round trip per path column of a row, ~3 us each, whatever the rows hold; one wave walking the
+                // task's rows one after the other (ul_path) costs ~0.18 us per entry: short rows (chains of a few entries, STADAT-like) go to the latter
+                long long task_entries = 0;
+                for (int q = 0; q < W; ++q) { const int kk = U_.task_rows[rb + q]; task_entries += U_.Rp[kk + 1] - U_.Rp[kk]; }
+                const bool serial_task = serial_path_ || task_entries < 17ll * W;
                 taskrec[8 * t] = rb; taskrec[8 * t + 1] = W; taskrec[8 * t + 2] = U_.task_nU[t]; taskrec[8 * t + 3] = U_.tab_ptr[t];
                 taskrec[8 * t + 4] = U_.fs_ptr[t]; taskrec[8 * t + 5] = U_.tdep_ptr[t]; taskrec[8 * t + 6] = U_.tdep_ptr[t + 1] - U_.tdep_ptr[t]; taskrec[8 * t + 7] = U_.tparent[t];
                 for (int q = 0; q < W; ++q) {
                     const int k = U_.task_rows[rb + q];
                     int* r = rowrec.data() + 16 * (size_t)k;
                     r[0] = w; r[1] = U_.Rp[k + 1] - U_.Rp[k]; r[2] = U_.Cp[k]; r[3] = U_.Cp[k + 1] - U_.Cp[k]; r[4] = t; r[5] = W; r[6] = q; r[7] = U_.tab_ptr[t];
-                    r[8] = U_.row_prev[k]; r[9] = U_.dep_ptr[k]; r[10] = U_.dep_ptr[k + 1] - U_.dep_ptr[k]; r[11] = U_.task_nU[t];
+                    r[8] = U_.row_prev[k]; r[9] = U_.dep_ptr[k]; r[10] = U_.dep_ptr[k + 1] - U_.dep_ptr[k]; r[11] = U_.task_nU[t]; r[12] = serial_task ? 1 : 0;
                     for (int e = U_.Rp[k]; e < U_.Rp[k + 1]; ++e, ++w) {
                         const int i = U_.Rcol[e];
                         e4[4 * (size_t)w] = i; e4[4 * (size_t)w + 1] = U_.Lp[i]; e4[4 * (size_t)w + 2] = U_.Rcnt[e]; e4[4 * (size_t)w + 3] = U_.Rpos[e];
@@ -852,7 +1036,7 @@ private:
         }
         Ystash_.alloc(U_.nnzL ? (size_t)U_.nnzL : 1); Pstash_.alloc(U_.nnzL ? (size_t)U_.nnzL : 1); Dinit_.alloc(N_ ? N_ : 1);
         Lblock_.alloc(U_.tab_ptr.back() ? (size_t)U_.tab_ptr.back() : 1); Lblock_.zero(st_);
-        p1done_.alloc(N_ ? N_ : 1); p1done_.zero(st_); ready_.alloc(N_ ? N_ : 1); ready_.zero(st_);
+        p1done_.alloc(N_ ? N_ : 1); p1done_.zero(st_); ready_.alloc(N_ ? N_ : 1); ready_.zero(st_); prog_.alloc(N_ ? N_ : 1); prog_.zero(st_);
         vals_.alloc(nnzK_ ? nnzK_ : 1); vals_.zero(st_);
         Lx_.alloc(U_.nnzL ? (size_t)U_.nnzL : 1); Lx_.zero(st_);
         D_.alloc(N_ ? N_ : 1); Dinv_.alloc(N_ ? N_ : 1); D_.zero(st_); Dinv_.zero(st_);
@@ -911,14 +1095,23 @@ private:
     }
     void remap_values()
     {
-        launch_remap_values(ops_.nzP(), mapP_.p, ops_.P_x(), vals_.p, st_);
-        launch_remap_values(ops_.nzA(), mapA_.p, ops_.AT_x(), vals_.p, st_);
-        launch_remap_values(ops_.nzG(), mapG_.p, ops_.GT_x(), vals_.p, st_);
+        if (mode_ == 0) {
+            launch_remap_values(ops_.nzP(), mapP_.p, ops_.P_x(), vals_.p, st_);
+            launch_remap_values(ops_.nzA(), mapA_.p, ops_.AT_x(), vals_.p, st_);
+            launch_remap_values(ops_.nzG(), mapG_.p, ops_.GT_x(), vals_.p, st_);
+        } else if ((mode_ & 1) && nzAA_) {
+            // update_AT_A (kkt_all_eliminated.hpp:184-202): the values change only with the data; every factorisation rebuilds P K P'
+            hipLaunchKernelGGL(k_ul_gram_values<false>, g1(nzAA_), dim3(256), 0, st_, nzAA_, aa_ptr_.p, aa_q1_.p, aa_q2_.p, aa_k_.p, ops_.AT_x(), (const double*)nullptr,
+                               (const int*)nullptr, ata_vals_.p);
+        }
         PQ_HIP(hipGetLastError());
         stream_wait(st_);
     }
 
-    int dev_, n_ = 0, p_ = 0, m_ = 0, N_ = 0, nnzK_ = 0, ntask_ = 0, nticket_ = 0, grid_ = 1, nbgroup_ = 0, epoch_ = 0;
+    int dev_, mode_ = 0, nzAA_ = 0, nzGG_ = 0, n_ = 0, p_ = 0, m_ = 0, N_ = 0, nnzK_ = 0, ntask_ = 0, nticket_ = 0, grid_ = 1, nbgroup_ = 0, epoch_ = 0;
+    double delta_ = 1.0;
+    DBuf<int> mapAA_, mapGG_, aa_ptr_, aa_q1_, aa_q2_, aa_k_, gg_ptr_, gg_q1_, gg_q2_, gg_k_;
+    DBuf<double> ata_vals_, zinv_, rhs_top_;
     bool lds_y_ = true, lds_x_ = true;
     hipStream_t st_ = nullptr;
     sparse::UpLooking U_;
@@ -928,6 +1121,8 @@ private:
     DBuf<unsigned long long> Emask_, Tmask_;
     DBuf<double> xf_, xz_, xb_;
     DBuf<long long> trace_;
+    DBuf<int> prog_;
+    bool serial_path_ = debug_token("exact_serial_path") != nullptr;  // debugging aid: one path pass per task (the first form) instead of one per row
     int sepoch_ = 0, sgrid_ = 1;
     bool one_wave_solve_ = debug_token("exact_solve1") != nullptr;  // debugging aid: the single-wave substitution of the first version
     DBuf<double> vals_, Lx_, D_, Dinv_, Ystash_, Pstash_, Dinit_, Lblock_, yglob_, xglob_;
@@ -937,6 +1132,6 @@ private:
 
 }  // namespace
 
-KKTSolverBase* make_exact_sparse_kkt(const pq_sparse_data* data, int device) { return new ExactSparseKKT(data, device); }
+KKTSolverBase* make_exact_sparse_kkt(const pq_sparse_data* data, int mode, int device) { return new ExactSparseKKT(data, mode, device); }
 
 }  // namespace pq

@@ -38,7 +38,7 @@ namespace {
 // Schur complement, f^2 w flops, by that one workgroup: 9.8 ms per level on the C3 variant with 1500-variable windows, fronts of 1000-4000 rows)
 // and every front of 768 rows or more: whatever its pivots, one workgroup zero-fills and extend-adds its f x f square -- 8.4 ms per level there)
 // (an accumulator supernode -- w = 0, the extend-add alone -- included)
-__host__ __device__ inline bool big_front(int f, int w) { return f >= 192 && (w >= 32 || (long long)f * w > 12288 || f >= 768); }
+using sparse::big_front;  // (sparse_symbolic.hpp: the ordering cost model and the spine merging price the same classification)
 constexpr int SUB_SOLVE_THREADS = 64;   // substitution inside a subtree is a chain of short vector operations: one wave per subtree
 constexpr int SUBTREE_LDS_BYTES = 150 * 1024;  // two fronts of the LDS-native subtree walker
 constexpr int SUB_THREADS = 256;    // small subtrees: fronts reach ~100 rows near the subtree root, so a full workgroup (64 threads measured 2x slower)
@@ -2501,13 +2501,35 @@ public:
         if (!part_on_) throw std::runtime_error("set_exchange_norm: call pq_kkt_partition first");
         if (transport_ != Transport::Callback) throw std::runtime_error("set_exchange_norm: the callback transport only (the native transport owns its buffer)");
         xbuf_norm_ = buf_norm;
+        sharded_agreed_ = -1;
     }
     bool refine_error_sharded(const double* lhs_x, const double* lhs_y, const double* lhs_z, const double* rhs_x, const double* rhs_y, const double* rhs_z, const double* x_reg,
                               double delta, const double* z_reg, double* err_x, double* err_y, double* err_z, double* norm) override
     {
         static const bool off = debug_token("replicated_residual") != nullptr;  // debugging aid: PIQP_AMD_DEBUG=replicated_residual
-        if (off || !part_on_ || world_ < 2 || mode_ != 0 || !xbuf_norm_ || transport_ == Transport::None) return false;
+        if (!part_on_ || world_ < 2 || mode_ != 0 || transport_ == Transport::None) return false;  // (structure and transport: the same on every rank by construction)
         PQ_HIP(hipSetDevice(dev_));
+        if (sharded_agreed_ < 0) {
+            // Whether THIS rank can take the sharded path also depends on per-process state (a registered norm buffer, the debugging switch, a column too long for the
+            // row kernels): the ranks agree ONCE, through the factor exchange every rank has -- slot 0 carries "I can", the sum must be world -- so that no rank waits
+            // in the all-reduce(max) below for one that went the replicated way (round-4 advice).  Without a boundary there is nothing to send and nobody to wait for.
+            const bool can = !off && xbuf_norm_ != nullptr && !ops_.has_long_columns();
+            if (!xbuf_factor_) sharded_agreed_ = can ? 1 : 0;
+            else {
+                // (the factor exchange buffer: always at least one word, free between factorisations, and tests count the forward / gather exchanges of the solves)
+                PQ_HIP(hipMemsetAsync(xbuf_factor_, 0, sizeof(double) * ((size_t)PT_.bmat_off.back() + 1), st_));
+                const double mine = can ? 1.0 : 0.0;
+                PQ_HIP(hipMemcpyAsync(xbuf_factor_, &mine, sizeof(double), hipMemcpyHostToDevice, st_));
+                stream_wait(st_);
+                exchange(0);
+                double sum = 0.0;
+                PQ_HIP(hipMemcpyAsync(&sum, xbuf_factor_, sizeof(double), hipMemcpyDeviceToHost, st_));
+                stream_wait(st_);
+                sharded_agreed_ = sum == (double)world_ ? 1 : 0;
+                if (can && !sharded_agreed_) std::fprintf(stderr, "piqp_amd: sharded refinement residual switched off -- %d of %d ranks can take it (norm buffer / debug switch / long columns differ)\n", (int)sum, world_);
+            }
+        }
+        if (!sharded_agreed_) return false;
         PQ_HIP(hipMemsetAsync(norm_bits_.p, 0, sizeof(unsigned long long), st_));
         if (!ops_.residual_rows(need_x_.p, need_x_n_, need_y_.p, need_y_n_, need_z_.p, need_z_n_, lhs_x, lhs_y, lhs_z, rhs_x, rhs_y, rhs_z, x_reg, delta, z_reg, err_x, err_y, err_z,
                                 reinterpret_cast<unsigned long long*>(norm_bits_.p), st_))
@@ -2528,7 +2550,7 @@ public:
     }
     void drop_transport()
     {
-        xbuf_norm_ = nullptr; own_norm_.release();
+        xbuf_norm_ = nullptr; own_norm_.release(); sharded_agreed_ = -1;
         if (comm_) { stream_wait(st_); rccl::comm_destroy(comm_); comm_ = nullptr; }
         own_factor_.release(); own_forward_.release(); own_gather_.release();
         xfn_ = nullptr; xuser_ = nullptr; xbuf_factor_ = xbuf_forward_ = xbuf_gather_ = nullptr;
@@ -2546,7 +2568,7 @@ public:
         own_factor_.zero(st_); own_forward_.zero(st_); own_gather_.zero(st_);
         stream_wait(st_);
         xfn_ = nullptr; xbuf_factor_ = own_factor_.p; xbuf_forward_ = own_forward_.p; xbuf_gather_ = own_gather_.p;
-        own_norm_.alloc(2); own_norm_.zero(st_); stream_wait(st_); xbuf_norm_ = own_norm_.p;
+        own_norm_.alloc(2); own_norm_.zero(st_); stream_wait(st_); xbuf_norm_ = own_norm_.p; sharded_agreed_ = -1;
         transport_ = Transport::Native;
     }
     double min_abs_pivot() override
@@ -3412,6 +3434,7 @@ private:
     DBuf<double> norm_bits_, own_norm_;
     HBuf<double> norm_h_{2};
     double* xbuf_norm_ = nullptr;
+    int sharded_agreed_ = -1;  // -1: the ranks have not agreed yet on the sharded residual (reset whenever the partition or the transport changes)
     int ref_mode_ = PQ_REF_MODE;  // arithmetic of the one-workgroup fronts (PQ_REF_MODE: the reference's, term by term; PQ_REF_MODE_BIG where the tree has multi-workgroup fronts)
     bool no_big_ = debug_token("no_big") != nullptr;    // debugging aid: every front through one workgroup's pivot loop (accuracy comparisons)
     DBuf<double> huge_part_;  // partial column sums of the huge fronts of one level (k_front_bwd_cols)
@@ -3450,29 +3473,28 @@ private:
 
 }  // namespace
 
+KKTSolverBase* make_multifrontal_kkt(const pq_sparse_data* data, int mode, int device) { return new SparseKKT(data, mode, device); }
+
 // KKTSystem::init_kkt_solver<PIQP_SPARSE> (kkt_system.hpp:470-497): all six sparse backends of the reference
 KKTSolverBase* make_sparse_kkt(const pq_sparse_data* data, int kkt_solver, int device)
 {
     switch (kkt_solver) {
     case PQ_SPARSE_MULTISTAGE: return make_multistage_kkt(data, device);
-    case PQ_SPARSE_LDLT: {
-        // Two engines behind the reference's sparse_ldlt: the reference-order up-looking LDLt (sparse_exact.hip: L, D and the solves bitwise the
-        // reference's, so that rounding-decided trajectories are the reference's too) for KKT systems up to PIQP_AMD_EXACT_MAX_N rows (default 8192: every
-        // trajectory-sensitive netlib / Maros-Meszaros problem, and the sizes where a tree of small fronts has no throughput to offer anyway), the supernodal
-        // multifrontal one above.  PIQP_AMD_SPARSE_LDLT=exact|multifrontal forces one.
+    case PQ_SPARSE_LDLT: case PQ_SPARSE_LDLT_EQ_COND: case PQ_SPARSE_LDLT_INEQ_COND: case PQ_SPARSE_LDLT_COND: {
+        // Two engines behind the reference's sparse_ldlt family: the reference-order up-looking LDLt (sparse_exact.hip: L, D and the solves bitwise
+        // the reference's, so that rounding-decided trajectories are the reference's too) for KKT systems up to PIQP_AMD_EXACT_MAX_N rows (default 8192: every
+        // trajectory-sensitive netlib / Maros-Meszaros problem), the supernodal multifrontal one above.  PIQP_AMD_SPARSE_LDLT=exact|multifrontal forces one.
+        const int mode = kkt_solver - PQ_SPARSE_LDLT;  // KKTMode bits: 1 = equalities eliminated, 2 = inequalities eliminated
         const char* eng = std::getenv("PIQP_AMD_SPARSE_LDLT");
         const char* mx = std::getenv("PIQP_AMD_EXACT_MAX_N");
         const long long max_n = mx ? std::atoll(mx) : 8192;
-        const long long N = (long long)data->n + data->p + data->m;
+        const long long N = (long long)data->n + ((mode & 1) ? 0 : data->p) + ((mode & 2) ? 0 : data->m);
         const bool exact = eng ? std::string(eng) == "exact" : N <= max_n;
-        if (exact) return make_exact_sparse_kkt(data, device);
-        return new SparseKKT(data, 0, device);
+        if (exact) return make_exact_sparse_kkt(data, mode, device);
+        return new SparseKKT(data, mode, device);
     }
-    case PQ_SPARSE_LDLT_EXACT: return make_exact_sparse_kkt(data, device);
+    case PQ_SPARSE_LDLT_EXACT: return make_exact_sparse_kkt(data, 0, device);
     case PQ_SPARSE_LDLT_MULTIFRONTAL: return new SparseKKT(data, 0, device);
-    case PQ_SPARSE_LDLT_EQ_COND: return new SparseKKT(data, 1, device);    // KKTMode::KKT_EQ_ELIMINATED
-    case PQ_SPARSE_LDLT_INEQ_COND: return new SparseKKT(data, 2, device);  // KKTMode::KKT_INEQ_ELIMINATED
-    case PQ_SPARSE_LDLT_COND: return new SparseKKT(data, 3, device);       // KKTMode::KKT_ALL_ELIMINATED
     default: return nullptr;
     }
 }

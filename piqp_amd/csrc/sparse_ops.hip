@@ -138,6 +138,19 @@ __global__ __launch_bounds__(256) void k_fold_rhs(int n, const int* __restrict__
     if (j >= n) return;
     out[j] = (rhs_x[j] + sg) + delta_inv * sa;
 }
+// the same fold in the reference's order (sparse/kkt.hpp:113-136 as the CPU oracle restates it, orc_sparse_cond.c cond_solve): the terms are added INTO rhs_x[j] one
+// after the other -- first G(i, j) (zinv_i rhs_z_i) over the constraints i of column j, then A(i, j) (delta_inv rhs_y_i) -- one thread per row
+__global__ __launch_bounds__(256) void k_fold_rhs_ref(int n, const int* __restrict__ Gp, const int* __restrict__ Gi, const double* __restrict__ Gx, const int* __restrict__ Ap,
+                                                      const int* __restrict__ Ai, const double* __restrict__ Ax, const double* __restrict__ rhs_x, const double* __restrict__ rhs_y,
+                                                      const double* __restrict__ rhs_z, const double* __restrict__ zinv, double delta_inv, double* __restrict__ out, int with_A, int with_G)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    double s = rhs_x[j];
+    if (with_G) for (int q = Gp[j]; q < Gp[j + 1]; ++q) { const int i = Gi[q]; s += Gx[q] * (zinv[i] * rhs_z[i]); }
+    if (with_A) for (int q = Ap[j]; q < Ap[j + 1]; ++q) { const int i = Ai[q]; s += Ax[q] * (delta_inv * rhs_y[i]); }
+    out[j] = s;
+}
 // rows k < p: lhs_y ; rows p <= k < p + m: lhs_z.  Two grids in one launch: blocks [0, ceil(p / 256)) serve the equality rows, the rest the inequality rows
 // (a wave never straddles the two matrices).
 __global__ __launch_bounds__(256) void k_recover_duals(int p, int m, const int* __restrict__ ATp, const int* __restrict__ ATi, const double* __restrict__ ATx, const int* __restrict__ GTp,
@@ -377,6 +390,11 @@ bool CscOperators::residual_rows(const int* rows_x, int nx, const int* rows_y, i
 void CscOperators::fold_rhs(const double* rhs_x, const double* rhs_y, const double* rhs_z, const double* zinv, double delta_inv, double* out, hipStream_t st, bool with_A,
                             bool with_G) const
 {
+    if (ref_order_) {
+        hipLaunchKernelGGL(k_fold_rhs_ref, g1(n_), dim3(256), 0, st, n_, G_p_.p, G_i_.p, G_x_.p, A_p_.p, A_i_.p, A_x_.p, rhs_x, rhs_y, rhs_z, zinv, delta_inv, out, with_A ? 1 : 0,
+                           with_G ? 1 : 0);
+        return;
+    }
     hipLaunchKernelGGL(k_fold_rhs, g1(n_), dim3(256), 0, st, n_, G_p_.p, G_i_.p, G_x_.p, A_p_.p, A_i_.p, A_x_.p, rhs_x, rhs_y, rhs_z, zinv, delta_inv, out, with_A ? 1 : 0,
                        with_G ? 1 : 0);
 }

@@ -628,7 +628,7 @@ static void order_and_analyse(Symbolic& S)
             bool big = false;
             for (int q = X.top_level_ptr[l]; q < X.top_level_ptr[l + 1] && !big; ++q) {
                 const int s2 = X.top_level_sn[q];
-                big = X.front_rows_ptr[s2 + 1] - X.front_rows_ptr[s2] >= 192 && X.sn_first[s2 + 1] - X.sn_first[s2] >= 32;
+                big = big_front(X.front_rows_ptr[s2 + 1] - X.front_rows_ptr[s2], X.sn_first[s2 + 1] - X.sn_first[s2]);
             }
             t += big ? 150e-6 : 12e-6;
             nbig += big;
@@ -636,7 +636,7 @@ static void order_and_analyse(Symbolic& S)
         for (int s2 = 0; s2 < X.nsuper; ++s2) {
             const double f = X.front_rows_ptr[s2 + 1] - X.front_rows_ptr[s2], w = X.sn_first[s2 + 1] - X.sn_first[s2];
             const double fl = w * f * f - w * w * f + w * w * w / 3.0;
-            (f >= 192 && w >= 32 ? big_fl : small_fl) += fl;
+            (big_front((int)f, (int)w) ? big_fl : small_fl) += fl;
         }
         big_levels_max = std::max(big_levels_max, nbig);
         if (debug_token("tree_profile")) std::fprintf(stderr, "cost parts: levels %.2f ms, small-front flops %.3g, big-front flops %.3g, front doubles %.3g\n", 1e3 * t, small_fl, big_fl, (double)X.front_doubles);

@@ -23,6 +23,10 @@ namespace sparse {
 using IVec = std::vector<int>;
 using DVec = std::vector<double>;
 
+// Fronts that go through the dense multi-workgroup matrix-core kernels of sparse_kkt.hip instead of one workgroup's pivot loop (f rows, w pivots): shared by the
+// numeric engine, the ordering cost model and the spine merging of sparse_symbolic.cpp (round-4 advice: the model priced `f >= 192 && w >= 32` only)
+__host__ __device__ inline bool big_front(int f, int w) { return f >= 192 && (w >= 32 || (long long)f * w > 12288 || f >= 768); }
+
 struct Symbolic {
     int n = 0, p = 0, m = 0, N = 0;  // N = KKT dimension of the mode (n + p + m for KKT_FULL)
     int mode = 0;                    // KKTMode bits: 1 = equalities eliminated, 2 = inequalities eliminated

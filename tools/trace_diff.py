@@ -23,7 +23,7 @@ def run(name, verbose=True, ks=1):
         return None
     a = (q["P"], q["c"], q["A"], q["b"], q["G"], q["h_l"], q["h_u"], q["x_l"], q["x_u"])
     sh = hip.SparseSolver(); sh.settings.kkt_solver = ks; sh.enable_trace(1024)
-    so = orc.Solver(); so.settings.kkt_solver = orc.SPARSE_LDLT; so.enable_trace(1024)
+    so = orc.Solver(); so.settings.kkt_solver = ks if ks in (1, 2, 3, 4) else orc.SPARSE_LDLT; so.enable_trace(1024)
     if name.startswith("nl"):
         sh.settings.infeasibility_threshold = so.settings.infeasibility_threshold = 0.01
     assert sh.setup(*a) and so.setup(*a, sparse=True)
@@ -54,6 +54,9 @@ if __name__ == "__main__":
     if "--all" in sys.argv:
         args = sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(GOLDEN, "*.npz")))
     ks = 18 if "--multifrontal" in sys.argv else 1
+    for a_ in sys.argv:
+        if a_.startswith("--ks="):
+            ks = int(a_[5:])
     tot = [0, 0, 0, 0]
     for nm in args:
         try:
