@@ -50,6 +50,19 @@ __device__ __forceinline__ double readlane_d(double v, int l)
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ int readfirst(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// s - pr[0] - pr[1] - ... - pr[cnt - 1], one after the other (the lanes of pr in order): the ordered chains of the reference's loops (D[k] -= ..., x[j] -= ...).
+// Unrolled by eight with a scalar trip count: two lane reads and one subtraction per term.
+__device__ __forceinline__ double chain_sub(double s, const double pr, int cnt)
+{
+    cnt = __builtin_amdgcn_readfirstlane(cnt);
+    int l = 0;
+    for (; l + 8 <= cnt; l += 8) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s = __dsub_rn(s, readlane_d(pr, l + q));
+    }
+    for (; l < cnt; ++l) s = __dsub_rn(s, readlane_d(pr, l));
+    return s;
+}
 // Hand-over between waves WITHOUT fences (MI355X_MICROARCH.md, workgroup dispatch / inter-workgroup visibility: an agent-scope acquire costs 1.7 us and a release
 // 1.7 - 6.5 us per workgroup, several times that with more workgroups per CU -- more than a whole task of this engine): every word one wave writes for another is
 // written and read with agent-scope 8-byte / 4-byte atomics (write-through `sc1` stores, `sc1` loads that bypass the reader's L1), the flag follows the payload after
@@ -222,7 +235,7 @@ __device__ __forceinline__ double ul_row(const UlFactorArgs& a, double* __restri
             if (in) stw(a.Ystash + e, my_yi);
             if (ext) stw(a.Pstash + e, tp);
         } else {
-            for (int s = 0; s < ns; ++s) Dk = __dsub_rn(Dk, readlane_d(tp, s));
+            Dk = chain_sub(Dk, tp, ns);
         }
     }
     if (lane == 0) {
@@ -459,10 +472,8 @@ __global__ __launch_bounds__(64) void k_ul_factor(UlFactorArgs a)
         const int tk = readfirst(s_task);
         __syncthreads();
         if (tk >= a.nticket) break;
-        // the next ticket is drawn now and used when this one is done: its round trip to memory disappears behind the work (a wave never waits for a LATER ticket,
-        // so a ticket parked for the length of one task delays its dependants but cannot block them)
-        int next_ticket = 0;
-        if (lane == 0) next_ticket = atomicAdd(a.ticket, 1);
+        // (the next ticket is drawn when this one is done: a ticket drawn ahead sits parked for as long as the current task takes -- with rows that wait for
+        // one another side by side that was 11 ms on CONT-050, the rows above spinning for a row whose ticket nobody worked on)
         const int kind = a.tk_kind[tk], id = a.tk_id[tk];
         bool ok = true;
         if (a.trace && lane == 0) { a.trace[4 * (size_t)tk] = wall_clock64(); a.trace[4 * (size_t)tk + 3] = blockIdx.x; }
@@ -501,7 +512,7 @@ __global__ __launch_bounds__(64) void k_ul_factor(UlFactorArgs a)
         }
         if (!ok) { if (lane == 0) atomicMin(a.info, -2); break; }
         if (a.trace && lane == 0) a.trace[4 * (size_t)tk + 2] = wall_clock64();
-        if (lane == 0) s_task = next_ticket;
+        if (lane == 0) s_task = atomicAdd(a.ticket, 1);
         __syncthreads();
     }
 }
@@ -705,7 +716,7 @@ __device__ __forceinline__ void ul_bwd_task(const UlSolve2Args& a, const int t, 
             if (qb > c0) { const int qq = qb + lane < c1 ? qb + lane : qb; sl2 = a.Lsrc[qq]; v2 = a.Lx[qq]; xv2 = ldw(a.xb + a.Li[qq]); }
             const double xin = __shfl(xfin, sl2 >= 0 ? sl2 : 0, 64);
             const double pr = __dmul_rn(v2, sl2 >= 0 ? xin : xv2);
-            for (int l = 0; l < cnt; ++l) s = __dsub_rn(s, readlane_d(pr, l));
+            s = chain_sub(s, pr, cnt);
         }
         if (lane == c) xfin = s;
     }
@@ -728,8 +739,6 @@ __global__ __launch_bounds__(64) void k_ul_solve2(UlSolve2Args a)
         const int tk = readfirst(s_task);
         __syncthreads();
         if (tk >= 2 * a.ntask) break;
-        int next_ticket = 0;
-        if (lane == 0) next_ticket = atomicAdd(a.ticket, 1);
         bool ok = true;
         if (tk < a.ntask) {
             const int t = a.tsort[tk];
@@ -753,7 +762,7 @@ __global__ __launch_bounds__(64) void k_ul_solve2(UlSolve2Args a)
             }
         }
         if (!ok) { if (lane == 0) atomicMin(a.info, -2); break; }
-        if (lane == 0) s_task = next_ticket;
+        if (lane == 0) s_task = atomicAdd(a.ticket, 1);
         __syncthreads();
     }
 }
