@@ -226,9 +226,17 @@ int pq_kkt_set_comm_rccl(pq_kkt *k, const unsigned char id[128], int rank, int w
  * the replicated evaluation (tests/test_partition.py).  pq_kkt_sharded_calls: out[0] = sharded residual evaluations so far, out[1] = rows in this rank's share.
  * Condensed KKT modes and sparse_multistage (tree engine): a partitioned handle re-evaluates, per factorisation, only the values of the fronts it factors (P entries,
  * delta^-1 A^T A entries, G^T W G product terms, diagonal shifts selected by destination front); there pq_kkt_sharded_calls reports out[0] = such assemblies so far,
- * out[1] = source entries this rank evaluates (a partition of one rank selects all of them). */
+ * out[1] = source entries this rank evaluates (a partition of one rank selects all of them).
+ * Round 5, the solve side of the condensed modes and of sparse_multistage (tree engine; reference: the right-hand-side fold and the recovery of the eliminated
+ * multipliers, sparse/kkt.hpp:113-175, multistage_kkt.hpp:234-287): the refinement residual is sharded there as well -- x rows and rows of the block that stays in
+ * the system by the rank that eliminates them, rows of an eliminated block by every rank that eliminates an x column they touch.  A backend solve on that residual
+ * folds it into this rank's x rows only and recovers the eliminated multipliers on those constraint rows only; at the end of a pq_kkt_system_solve that took at
+ * least one refinement step the eliminated multipliers cross the ranks once, each row from its owner rank (which = 2 again; sizes_out[2] covers both uses).
+ * pq_kkt_sharded_solve_calls: out[0] sharded residual evaluations, [1] rows of the residual in this rank's share (of n + p + m), [2] backend solves that folded /
+ * recovered on this rank's rows only, [3] gathers of the multipliers, [4] x rows folded per such solve, [5] constraint rows recovered per such solve. */
 int pq_kkt_set_exchange_norm(pq_kkt *k, double *buf_norm);
 int pq_kkt_sharded_calls(pq_kkt *k, int out[2]);
+int pq_kkt_sharded_solve_calls(pq_kkt *k, int out[6]);
 /* test hook (reference-order engine, PQ_SPARSE_LDLT_EXACT): the factor as sparse/ldlt.hpp:24-37 holds it.  what = 0 nnz(L) | 1 L_cols[N + 1] | 2 L_ind | 3 L_vals |
  * 4 D | 5 D_inv | 6 values of P K P' (CSC order of pq_sparse_kkt_symbolic's PKp / PKi_rows) | 7 perm; copies the item into out_host (NULL: size only) and returns its
  * length, < 0 on error (another engine) */
@@ -358,6 +366,7 @@ int pq_solver_set_comm_rccl(pq_solver *s, const unsigned char id[128], int rank,
 int pq_solver_native_exchange_calls(pq_solver *s, int out[3]);
 int pq_solver_set_exchange_norm(pq_solver *s, double *buf_norm); /* as pq_kkt_set_exchange_norm */
 int pq_solver_sharded_calls(pq_solver *s, int out[2]);
+int pq_solver_sharded_solve_calls(pq_solver *s, int out[6]);
 int pq_solver_comm_info(pq_solver *s, int out[4]); /* as pq_kkt_comm_info */
 
 /* ===================== Batched solver: many structurally identical sparse QPs in one launch ===================== */

@@ -383,6 +383,11 @@ int pq_kkt_sharded_calls(pq_kkt* k, int out[2])
     if (!k || !out) return fail(PQ_ERR_INVALID, "null argument");
     return guarded([&] { k->impl->sharded_calls(out); return (int)PQ_OK; });
 }
+int pq_kkt_sharded_solve_calls(pq_kkt* k, int out[6])
+{
+    if (!k || !out) return fail(PQ_ERR_INVALID, "null argument");
+    return guarded([&] { k->impl->sharded_solve_calls(out); return (int)PQ_OK; });
+}
 int pq_kkt_native_exchange_calls(pq_kkt* k, int out[3])
 {
     if (!k || !out) return fail(PQ_ERR_INVALID, "null argument");

@@ -78,7 +78,15 @@ public:
         (void)lhs_x; (void)lhs_y; (void)lhs_z; (void)rhs_x; (void)rhs_y; (void)rhs_z; (void)x_reg; (void)delta; (void)z_reg; (void)err_x; (void)err_y; (void)err_z; (void)norm;
         return false;
     }
-    virtual void sharded_calls(int out[2]) const { out[0] = out[1] = 0; }  // [0] sharded residual evaluations, [1] rows of this rank's share (of n + p + m)
+    virtual void sharded_calls(int out[2]) const { out[0] = out[1] = 0; }
+    // Condensed backends under a stage partition (round 5): a backend solve whose right-hand side is the residual refine_error_sharded left behind folds it into
+    // this rank's x rows only and recovers the eliminated multipliers on the constraint rows next to them only; the refined multipliers of the eliminated blocks
+    // are then complete on their owner rank and cross the ranks ONCE per KKTSystem::solve -- this call, made by KKTSystem::solve after its refinement loop took at
+    // least one step (one all-gather, exchange which = 2).  No-op for every other backend.
+    virtual void finish_sharded_solve(double* lhs_y, double* lhs_z) { (void)lhs_y; (void)lhs_z; }
+    // pq_kkt_sharded_solve_calls: [0] sharded residual evaluations, [1] rows of this rank's share of the residual (of n + p + m), [2] backend solves that folded /
+    // recovered on this rank's rows only, [3] all-gathers of the eliminated multipliers, [4] x rows folded per such solve, [5] constraint rows recovered per such solve
+    virtual void sharded_solve_calls(int out[6]) const { for (int i = 0; i < 6; ++i) out[i] = 0; }  // [0] sharded residual evaluations, [1] rows of this rank's share (of n + p + m)
     // pq_kkt_comm_info: transport (0 none, 1 callback, 2 native RCCL), and for the native one what ncclCommCount / ncclCommUserRank / ncclCommCuDevice report
     virtual void comm_info(int out[4]) const { out[0] = 0; out[1] = out[2] = out[3] = -1; }
     virtual void partition_info(int out[8]) const { (void)out; throw std::runtime_error("partition_info: not supported by this backend"); }

@@ -593,6 +593,8 @@ bool KKTSystem::solve(const pq_vars& rhs, pq_vars& lhs)
             d2d(lhs.x, ref_lhs_x.p, n, st_); d2d(lhs.y, ref_lhs_y.p, p, st_); d2d(lhs_z, ref_lhs_z.p, m, st_);
             last_refine_error = refine_error;
         }
+        // (a stage-partitioned condensed backend refined the eliminated multipliers on their owner ranks only: one all-gather per solve, kkt_solver_base.hpp)
+        if (last_refine_steps > 0) kkt_solver->finish_sharded_solve(lhs.y, lhs_z);
         LAUNCH1(k_dual_recovery, m, st_, m, m_delta, has_l.p, has_u.p, m_s_l.p, m_z_l_inv.p, m_s_u.p, m_z_u_inv.p, m_z_reg.p, lhs_z, rhs.z_l, rhs.s_l, rhs.z_u, rhs.s_u, lhs.z_l,
                 lhs.z_u, lhs.s_l, lhs.s_u);
         LAUNCH1(k_box_recovery, n_x_l, st_, n_x_l, -1.0, m_delta, x_l_idx.p, x_b_scaling.p, lhs.x, m_s_bl.p, m_z_bl_inv.p, rhs.z_bl, rhs.s_bl, lhs.z_bl, lhs.s_bl);

@@ -248,6 +248,28 @@ public:
         tree_->partition_info(out);
     }
     void sharded_calls(int out[2]) const override { if (tree_) tree_->sharded_calls(out); else out[0] = out[1] = 0; }  // (the tree engine's sharded value assembly)
+    // SURVEY 8(e) row 2 (round 5): the tree engine's sharded refinement residual, partial fold / recovery and the gather of the multipliers -- this handle's stream
+    // produced the operands, the tree engine's stream the results
+    void set_exchange_norm(double* buf_norm) override
+    {
+        if (!tree_) throw std::runtime_error("set_exchange_norm: not partitioned");
+        tree_->set_exchange_norm(buf_norm);
+    }
+    bool refine_error_sharded(const double* lhs_x, const double* lhs_y, const double* lhs_z, const double* rhs_x, const double* rhs_y, const double* rhs_z, const double* x_reg,
+                              double delta, const double* z_reg, double* err_x, double* err_y, double* err_z, double* norm) override
+    {
+        if (!tree_) return false;
+        stream_wait(st_);
+        return tree_->refine_error_sharded(lhs_x, lhs_y, lhs_z, rhs_x, rhs_y, rhs_z, x_reg, delta, z_reg, err_x, err_y, err_z, norm);  // (ends with a read-back: complete)
+    }
+    void finish_sharded_solve(double* lhs_y, double* lhs_z) override
+    {
+        if (!tree_) return;
+        stream_wait(st_);
+        tree_->finish_sharded_solve(lhs_y, lhs_z);
+        stream_wait(tree_->stream());
+    }
+    void sharded_solve_calls(int out[6]) const override { if (tree_) tree_->sharded_solve_calls(out); else KKTSolverBase::sharded_solve_calls(out); }
 
     // multistage_kkt.hpp:385-393 (same text), plus where the chain runs
     void print_info() override

@@ -1316,6 +1316,11 @@ int pq_solver_sharded_calls(pq_solver* s, int out[2])
     if (!s || !s->impl || !out) return fail(PQ_ERR_INVALID, "null argument");
     return guarded([&] { s->impl->backend()->sharded_calls(out); return (int)PQ_OK; });
 }
+int pq_solver_sharded_solve_calls(pq_solver* s, int out[6])
+{
+    if (!s || !s->impl || !out || !s->impl->backend()) return fail(PQ_ERR_INVALID, "null argument / solver not set up");
+    return guarded([&] { s->impl->backend()->sharded_solve_calls(out); return (int)PQ_OK; });
+}
 int pq_solver_native_exchange_calls(pq_solver* s, int out[3])
 {
     if (!s || !out) return fail(PQ_ERR_INVALID, "null argument");

@@ -171,10 +171,15 @@ __device__ __forceinline__ bool spin_until_ge(const int* flag, int want)
 // finished here; for a row on a longer path the updates into the path's rows are left to the path pass (E4.z counts only the entries of a column above them), the
 // values y_i, the products l_ki y_i and the initial values of the path columns go to Ystash / Pstash / Dinit, the quotients also into the task's table.
 // y: this wave's dense work vector, all zero on entry and on exit.
+// wait(): the row's dependencies (rows below it outside its task) -- called after the loads that do not depend on them were issued: the row's own entries of K, the
+// first 64 records of its pattern.
+template <class Wait>
 __device__ __forceinline__ double ul_row(const UlFactorArgs& a, double* __restrict__ y, const int k, const int lane, const int es, const int en, const int p0, const int pn,
-                                         const int W, const int lanek, const int tb)
+                                         const int W, const int lanek, const int tb, Wait wait, bool& ok)
 {
     const bool multi = W > 1;
+    ok = true;
+    bool waited = false;
     // scatter A(0:k, k) into y (:127-131)
     for (int q = lane; q < pn; q += 64) y[a.Ci[p0 + q]] = a.Cx[p0 + q];
     wave_sync();
@@ -190,8 +195,9 @@ __device__ __forceinline__ double ul_row(const UlFactorArgs& a, double* __restri
         const int rc = in ? ev.z : 0;        // entries of column i this pass scatters: all above row k (= L_nnz[i] at this moment, :149) or those above the task's path
         const int cnt = rc > 0 ? rc : 0;
         const bool ext = in && rc >= 0;      // (a column of the task's own path otherwise: its value in this row comes out of the path pass)
-        const double Dld = ldw(a.D + i);           // (unconditional: issued together with the column prefetch below)
         const int tabu = a.Etab[in ? e : es];
+        if (!waited) { waited = true; if (!wait()) { ok = false; return 0.0; } }
+        const double Dld = ldw(a.D + i);           // (unconditional: issued together with the column prefetch below)
         const int ns = min(64, en - base);
         double my_yi = 0.0;
         // the first 64 entries of the columns of the next UL_PF steps travel ahead of the chain.  Every load is unconditional (lanes past the end of their
@@ -238,6 +244,7 @@ __device__ __forceinline__ double ul_row(const UlFactorArgs& a, double* __restri
             Dk = chain_sub(Dk, tp, ns);
         }
     }
+    if (!waited && !wait()) { ok = false; return 0.0; }
     if (lane == 0) {
         if (multi) stw(a.Dinit + k, Dk);
         else {
@@ -326,13 +333,13 @@ __device__ __forceinline__ bool ul_path(const UlFactorArgs& a, const int t, cons
 #pragma unroll
                 for (int d = 0; d < UL_PFP; ++d) {
                     const int s = sb + d;
-                    const int u = __builtin_amdgcn_readlane(ch.tab, s & 63);
-                    const unsigned long long m = (((unsigned long long)(unsigned)__builtin_amdgcn_readlane(ch.mhi, s & 63) << 32) | (unsigned)__builtin_amdgcn_readlane(ch.mlo, s & 63)) & below;
-                    const double v = pf_v[d];
-                    pf_v[d] = ldw(a.Lblock + tb + __builtin_amdgcn_readlane(ch.tab, (s + UL_PFP) & 63) * W + lw);
-                    if (s < ns) {
+                    if (s < ns) {  // (a row of three entries runs three steps, not eight)
+                        const int u = __builtin_amdgcn_readlane(ch.tab, s & 63);
+                        const unsigned long long m = (((unsigned long long)(unsigned)__builtin_amdgcn_readlane(ch.mhi, s & 63) << 32) | (unsigned)__builtin_amdgcn_readlane(ch.mlo, s & 63)) & below;
+                        const double v = pf_v[d];
+                        pf_v[d] = ldw(a.Lblock + tb + __builtin_amdgcn_readlane(ch.tab, (s + UL_PFP) & 63) * W + lw);
                         const double src = u < nU ? readlane_d(ch.ys, s & 63) : readlane_d(acc, (u - nU) & 63);
-                        if ((m >> lane) & 1ull) acc = msub(acc, v, src);
+                        if (__builtin_amdgcn_inverse_ballot_w64(m)) acc = msub(acc, v, src);
                     }
                 }
             }
@@ -485,12 +492,14 @@ __global__ __launch_bounds__(64) void k_ul_factor(UlFactorArgs a)
                        r2 = *reinterpret_cast<const int4*>(a.rowrec + 16 * k + 8);
             const int es = r0.x, en = r0.y, cp0 = r0.z, cpn = r0.w, W = r1.y, lanek = r1.z, tb = r1.w, prev = r2.x, c0 = r2.y, cn = r2.z, nU = r2.w;
             const int serial_task = a.rowrec[16 * k + 12];
-            for (int c = lane; c < cn; c += 64) ok &= spin_until(a.done + a.dep[c0 + c], a.epoch);
             (void)prev;
-            ok = __ballot(!ok) == 0;
-            if (ok) {
+            const double Dk0 = ul_row(a, y, k, lane, es, en, cp0, cpn, W, lanek, tb, [&]() {
+                bool w = true;
+                for (int c = lane; c < cn; c += 64) w &= spin_until(a.done + a.dep[c0 + c], a.epoch);
                 if (a.trace && lane == 0) a.trace[4 * (size_t)tk + 1] = wall_clock64();
-                const double Dk0 = ul_row(a, y, k, lane, es, en, cp0, cpn, W, lanek, tb);
+                return __ballot(!w) == 0;
+            }, ok);
+            if (ok) {
                 drain_stores();
                 int* flag = (W > 1 ? a.p1done : a.done) + k;
                 __hip_atomic_store(flag, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (every lane stores the same word: no divergence at the loop's end)
@@ -647,27 +656,34 @@ struct UlSolve2Args {
     int *fdone, *bdone, *ticket, *info;
 };
 
-__device__ __forceinline__ void ul_fwd_task(const UlSolve2Args& a, const int t, const int lane)
+// (everything that does not depend on other tasks -- the task record, its rows, the right-hand side, the first chunk of the table -- is requested BEFORE the wait
+// for the tasks below: a hop of the dependency chain then costs the flag, one load of x and the arithmetic, not five dependent loads on top)
+template <class Wait>
+__device__ __forceinline__ bool ul_fwd_task(const UlSolve2Args& a, const int t, const int lane, Wait wait)
 {
-    const int rb = a.taskrec[8 * t], W = a.taskrec[8 * t + 1], nU = a.taskrec[8 * t + 2], tb = a.taskrec[8 * t + 3], fs0 = a.taskrec[8 * t + 4];
+    const int4 r0 = *reinterpret_cast<const int4*>(a.taskrec + 8 * t);
+    const int rb = r0.x, W = r0.y, nU = r0.z, tb = r0.w, fs0 = a.taskrec[8 * t + 4];
     const int mb = a.mask_ptr[t];
     const int nsrc = nU + W;
     const int lw = lane < W ? lane : W - 1;
     const int row = a.task_rows[rb + lw];
     const int o = a.perm[row];
     double acc = o < a.n ? a.rx[o] : (o < a.n + a.p ? a.ry[o - a.n] : a.rz[o - a.n - a.p]);
+    const double dinv = a.Dinv[row];
+    bool waited = false;
     for (int base = 0; base < nsrc; base += 64) {
         const bool in = base + lane < nsrc;
         const int q = fs0 + (in ? base + lane : 0);
         const int ue = in ? a.fs_u[q] : 0;
         const int col = a.fs_col[q];
-        const double xs = ldw(a.xf + col);   // (an outside column is final: its task was waited for; a path column's value is taken from its lane instead)
         const unsigned long long me = in ? a.Tmask[mb + ue] : 0ull;
         const int mlo = (int)(unsigned)(me & 0xffffffffull), mhi = (int)(unsigned)(me >> 32);
         const int ns = min(64, nsrc - base);
         double pf_v[UL_PFP];
 #pragma unroll
         for (int d = 0; d < UL_PFP; ++d) pf_v[d] = a.Lblock[tb + __builtin_amdgcn_readlane(ue, d) * W + lw];
+        if (!waited) { if (!wait()) return false; waited = true; }
+        const double xs = ldw(a.xf + col);   // (an outside column is final: its task was waited for; a path column's value is taken from its lane instead)
         for (int sb = 0; sb < ns; sb += UL_PFP) {
 #pragma unroll
             for (int d = 0; d < UL_PFP; ++d) {
@@ -683,21 +699,26 @@ __device__ __forceinline__ void ul_fwd_task(const UlSolve2Args& a, const int t, 
             }
         }
     }
-    if (lane < W) { stw(a.xf + row, acc); stw(a.xz + row, __dmul_rn(acc, a.Dinv[row])); }
+    if (!waited && !wait()) return false;
+    if (lane < W) { stw(a.xf + row, acc); stw(a.xz + row, __dmul_rn(acc, dinv)); }
+    return true;
 }
 
-__device__ __forceinline__ void ul_bwd_task(const UlSolve2Args& a, const int t, const int lane)
+template <class Wait>
+__device__ __forceinline__ bool ul_bwd_task(const UlSolve2Args& a, const int t, const int lane, Wait wait)
 {
     const int rb = a.taskrec[8 * t], W = a.taskrec[8 * t + 1];
     const int lw = lane < W ? lane : W - 1;
     const int row = a.task_rows[rb + lw];
     const int lp0 = a.Lp[row], lp1 = a.Lp[row + 1];
-    double xfin = ldw(a.xz + row);
+    const int o = a.perm[row];
     // the first 64 entries of the column a step ahead
     int q0 = __builtin_amdgcn_readlane(lp0, W - 1), q1 = __builtin_amdgcn_readlane(lp1, W - 1);
     int nt_ = a.Li[q0 + lane < q1 ? q0 + lane : (q1 > q0 ? q0 : 0)];
     int nsl = a.Lsrc[q0 + lane < q1 ? q0 + lane : (q1 > q0 ? q0 : 0)];
     double nv = a.Lx[q0 + lane < q1 ? q0 + lane : (q1 > q0 ? q0 : 0)];
+    if (!wait()) return false;  // (the index loads above do not depend on other tasks; the values below do)
+    double xfin = ldw(a.xz + row);
     double nxv = ldw(a.xb + nt_);
     for (int c = W - 1; c >= 0; --c) {
         const int c0 = q0, c1 = q1;
@@ -722,11 +743,11 @@ __device__ __forceinline__ void ul_bwd_task(const UlSolve2Args& a, const int t, 
     }
     if (lane < W) {
         stw(a.xb + row, xfin);
-        const int o = a.perm[row];
         if (o < a.n) a.lx[o] = xfin;
         else if (o < a.n + a.p) a.ly[o - a.n] = xfin;
         else a.lz[o - a.n - a.p] = xfin;
     }
+    return true;
 }
 
 __global__ __launch_bounds__(64) void k_ul_solve2(UlSolve2Args a)
@@ -743,20 +764,20 @@ __global__ __launch_bounds__(64) void k_ul_solve2(UlSolve2Args a)
         if (tk < a.ntask) {
             const int t = a.tsort[tk];
             const int d0 = a.taskrec[8 * t + 5], dn = a.taskrec[8 * t + 6];
-            for (int c = lane; c < dn; c += 64) ok &= spin_until(a.fdone + a.tdep[d0 + c], a.epoch);
-            ok = __ballot(!ok) == 0;
+            ok = ul_fwd_task(a, t, lane, [&]() {
+                bool w = true;
+                for (int c = lane; c < dn; c += 64) w &= spin_until(a.fdone + a.tdep[d0 + c], a.epoch);
+                return __ballot(!w) == 0;
+            });
             if (ok) {
-                ul_fwd_task(a, t, lane);
                 drain_stores();
                 __hip_atomic_store(a.fdone + t, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         } else {
             const int t = a.tsort[2 * a.ntask - 1 - tk];
             const int parent = a.taskrec[8 * t + 7];
-            ok = spin_until(parent >= 0 ? a.bdone + parent : a.fdone + t, a.epoch);
-            ok = __ballot(!ok) == 0;
+            ok = ul_bwd_task(a, t, lane, [&]() { return __ballot(!spin_until(parent >= 0 ? a.bdone + parent : a.fdone + t, a.epoch)) == 0; });
             if (ok) {
-                ul_bwd_task(a, t, lane);
                 drain_stores();
                 __hip_atomic_store(a.bdone + t, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }

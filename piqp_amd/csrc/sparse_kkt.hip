@@ -2202,6 +2202,28 @@ __global__ void k_unpack_spans(int world, int rank, int max_span, const int* __r
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; lo + i < hi; i += gridDim.x * blockDim.x) x[lo + i] = buf[(long long)q * max_span + i];
 }
 
+// eliminated multipliers (condensed modes): the rows this rank owns -> its chunk of the gather buffer; afterwards every other rank's rows -> lhs_y / lhs_z.
+// rows[] holds y row j as j and z row k as p + k, rank by rank (ptr[])
+__global__ void k_pack_duals(int cnt, const int* __restrict__ rows, int p, const double* __restrict__ lhs_y, const double* __restrict__ lhs_z, double* __restrict__ chunk)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cnt) return;
+    const int r = rows[i];
+    chunk[i] = r < p ? lhs_y[r] : lhs_z[r - p];
+}
+__global__ void k_unpack_duals(int rank, int slot, const int* __restrict__ ptr, const int* __restrict__ rows, int p, const double* __restrict__ buf, double* __restrict__ lhs_y,
+                               double* __restrict__ lhs_z)
+{
+    const int q = blockIdx.y;
+    if (q == rank) return;
+    const int lo = ptr[q], cnt = ptr[q + 1] - lo;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += gridDim.x * blockDim.x) {
+        const int r = rows[lo + i];
+        const double v = buf[(long long)q * slot + i];
+        if (r < p) lhs_y[r] = v; else lhs_z[r - p] = v;
+    }
+}
+
 inline dim3 g1(int n) { return dim3(n > 0 ? (n + 255) / 256 : 1); }
 
 class SparseKKT final : public KKTSolverBase {
@@ -2321,11 +2343,16 @@ public:
         FrontMeta M = meta();
         const bool eq = mode_ & 1, ineq = mode_ & 2;
         const double delta_inv = 1.0 / delta_;
+        bool partial = false;
         if (mode_ == 0) {
             hipLaunchKernelGGL(k_perm_gather, g1(N_), dim3(256), 0, st_, N_, P_.p, rhs_x, n_, rhs_y, p_, rhs_z, xp_.p);
         } else {
             // sparse/kkt.hpp:113-136: fold the eliminated blocks into the x part of the right-hand side
-            ops_.fold_rhs(rhs_x, rhs_y, rhs_z, zinv_.p, delta_inv, rhs_top_.p, st_, eq, ineq);
+            // (a right-hand side left behind by refine_error_sharded is valid on this rank's rows only: fold those, recover those -- finish_sharded_solve completes
+            // the multipliers once per KKTSystem::solve)
+            partial = part_on_ && world_ > 1 && sharded_agreed_ == 1 && rhs_x == partial_rhs_;
+            if (partial) ops_.fold_rhs_rows(need_x_.p, fold_x_n_, rhs_x, rhs_y, rhs_z, zinv_.p, delta_inv, rhs_top_.p, st_, eq, ineq);
+            else ops_.fold_rhs(rhs_x, rhs_y, rhs_z, zinv_.p, delta_inv, rhs_top_.p, st_, eq, ineq);
             const double* tail = mode_ == 1 ? rhs_z : rhs_y;
             const int ntail = mode_ == 1 ? m_ : (mode_ == 2 ? p_ : 0);
             hipLaunchKernelGGL(k_perm_gather, g1(N_), dim3(256), 0, st_, N_, P_.p, rhs_top_.p, n_, tail, ntail, (const double*)nullptr, xp_.p);
@@ -2347,9 +2374,9 @@ public:
             subtree_bwd(M, part_sched_);
             if (world_ > 1 || (std::getenv("PIQP_AMD_EXCHANGE_WORLD1") && transport_ != Transport::None)) {
                 const int lo = PT_.span_lo[rank_], hi = PT_.span_hi[rank_];
-                if (hi > lo) hipLaunchKernelGGL(k_pack_span, g1(hi - lo), dim3(256), 0, st_, lo, hi, xp_.p, xbuf_gather_ + (size_t)rank_ * PT_.max_span);
+                if (hi > lo) hipLaunchKernelGGL(k_pack_span, g1(hi - lo), dim3(256), 0, st_, lo, hi, xp_.p, xbuf_gather_ + (size_t)rank_ * gather_slot_);
                 exchange(2);
-                hipLaunchKernelGGL(k_unpack_spans, dim3(std::max(1, std::min(256, (PT_.max_span + 255) / 256)), world_), dim3(256), 0, st_, world_, rank_, PT_.max_span, span_lo_d_.p,
+                hipLaunchKernelGGL(k_unpack_spans, dim3(std::max(1, std::min(256, (PT_.max_span + 255) / 256)), world_), dim3(256), 0, st_, world_, rank_, gather_slot_, span_lo_d_.p,
                                    span_hi_d_.p, xbuf_gather_, xp_.p);
             }
         } else {
@@ -2361,7 +2388,10 @@ public:
             double* tail = mode_ == 1 ? lhs_z : lhs_y;
             const int ntail = mode_ == 1 ? m_ : (mode_ == 2 ? p_ : 0);
             hipLaunchKernelGGL(k_perm_scatter, g1(N_), dim3(256), 0, st_, N_, P_.p, xp_.p, lhs_x, n_, tail, ntail, (double*)nullptr, solve_err_ptr_, solve_epoch_used_);
-            ops_.recover_duals(lhs_x, rhs_y, rhs_z, zinv_.p, delta_inv, lhs_y, lhs_z, st_, eq, ineq);  // sparse/kkt.hpp:147-175
+            if (partial) {
+                ops_.recover_duals_rows(need_y_.p, eq ? need_y_n_ : 0, need_z_.p, ineq ? need_z_n_ : 0, lhs_x, rhs_y, rhs_z, zinv_.p, delta_inv, lhs_y, lhs_z, st_);
+                ++sharded_solves_;
+            } else ops_.recover_duals(lhs_x, rhs_y, rhs_z, zinv_.p, delta_inv, lhs_y, lhs_z, st_, eq, ineq);  // sparse/kkt.hpp:147-175
         }
         PQ_HIP(hipGetLastError());
         prof_.end(2, tk, st_);
@@ -2433,19 +2463,65 @@ public:
         {   // the rows of the KKT system whose columns this rank eliminates (owner == rank) or every rank does (shared top), in the caller's
             // numbering, split into the x / y / z blocks -- the rows its part of a solve reads and the diagonal entries its fronts hold (KKT_FULL only)
             std::vector<int> nx, ny, nz, nall;
-            if (mode_ == 0) {
-                for (int sn = 0; sn + 1 < (int)S_.sn_first.size(); ++sn) {
-                    if (PT_.owner[sn] != rank && PT_.owner[sn] >= 0) continue;
-                    for (int c = S_.sn_first[sn]; c < S_.sn_first[sn + 1]; ++c) {
-                        const int v = S_.P[c];
-                        nall.push_back(v);
-                        if (v < n_) nx.push_back(v);
-                        else if (v < n_ + p_) ny.push_back(v - n_);
-                        else nz.push_back(v - n_ - p_);
-                    }
+            const bool elim_y = mode_ & 1, elim_z = mode_ & 2;
+            for (int sn = 0; sn + 1 < (int)S_.sn_first.size(); ++sn) {
+                if (PT_.owner[sn] != rank && PT_.owner[sn] >= 0) continue;
+                for (int c = S_.sn_first[sn]; c < S_.sn_first[sn + 1]; ++c) {
+                    const int v = S_.P[c];
+                    if (mode_ == 0) nall.push_back(v);
+                    if (v < n_) nx.push_back(v);
+                    else if (mode_ == 0) { if (v < n_ + p_) ny.push_back(v - n_); else nz.push_back(v - n_ - p_); }
+                    else if (mode_ == 1) nz.push_back(v - n_);  // (the block that stays in the system: z when the equalities are eliminated, y otherwise)
+                    else ny.push_back(v - n_);
                 }
-                std::sort(nx.begin(), nx.end()); std::sort(ny.begin(), ny.end()); std::sort(nz.begin(), nz.end()); std::sort(nall.begin(), nall.end());
             }
+            dual_own_ptr_.assign((size_t)world + 1, 0);
+            std::vector<int> dual_rows;
+            fold_x_n_ = 0;
+            if (mode_ != 0) {
+                // Condensed modes (round 5): an eliminated constraint row matters to the ranks that eliminate an x column it touches -- their folded right-hand side
+                // reads its residual and their x rows of the next residual read its multiplier.  Its OWNER (the rank whose value the others receive at the end of a
+                // KKTSystem::solve) is the rank of the first such column outside the shared top, rank 0 when there is none.
+                std::vector<int> Ap, Ai, Gp, Gi;
+                ops_.download_column_patterns(Ap, Ai, Gp, Gi, st_);
+                std::vector<int> col_owner((size_t)n_, -1);
+                for (int sn = 0; sn + 1 < (int)S_.sn_first.size(); ++sn)
+                    for (int c = S_.sn_first[sn]; c < S_.sn_first[sn + 1]; ++c) if (S_.P[c] < n_) col_owner[S_.P[c]] = PT_.owner[sn];
+                auto block = [&](bool elim, int rows, const std::vector<int>& Mp, const std::vector<int>& Mi, std::vector<int>& need, int shift) {
+                    if (!elim || rows == 0) return;
+                    std::vector<int> owner((size_t)rows, -1);
+                    std::vector<char> mine((size_t)rows, 0);
+                    for (int j = 0; j < n_; ++j) {
+                        const int o = col_owner[j];
+                        for (int q = Mp[j]; q < Mp[j + 1]; ++q) {
+                            const int i = Mi[q];
+                            if (o < 0 || o == rank) mine[i] = 1;
+                            if (o >= 0 && owner[i] < 0) owner[i] = o;
+                        }
+                    }
+                    for (int i = 0; i < rows; ++i) {
+                        if (owner[i] < 0) { owner[i] = 0; if (rank == 0) mine[i] = 1; }  // touches the shared top only, or nothing at all
+                        if (mine[i]) need.push_back(i);
+                    }
+                    for (int r = 0; r < world; ++r) for (int i = 0; i < rows; ++i) if (owner[i] == r) dual_own_ptr_[r + 1]++;
+                    dual_owner_tmp_.push_back({shift, std::move(owner)});
+                };
+                dual_owner_tmp_.clear();
+                block(elim_y, p_, Ap, Ai, ny, 0);
+                block(elim_z, m_, Gp, Gi, nz, p_);
+                for (int r = 0; r < world; ++r) dual_own_ptr_[r + 1] += dual_own_ptr_[r];
+                dual_rows.assign((size_t)dual_own_ptr_[world], 0);
+                std::vector<int> fill(dual_own_ptr_.begin(), dual_own_ptr_.end() - 1);
+                for (const auto& b : dual_owner_tmp_) for (int i = 0; i < (int)b.second.size(); ++i) dual_rows[fill[b.second[i]]++] = b.first + i;
+                dual_owner_tmp_.clear();
+                fold_x_n_ = (int)nx.size();
+            }
+            std::sort(nx.begin(), nx.end()); std::sort(ny.begin(), ny.end()); std::sort(nz.begin(), nz.end()); std::sort(nall.begin(), nall.end());
+            upload_vec(dual_rows_, dual_rows, st_); upload_vec(dual_own_ptr_d_, dual_own_ptr_, st_);
+            int most = 0;
+            for (int r = 0; r < world; ++r) most = std::max(most, dual_own_ptr_[r + 1] - dual_own_ptr_[r]);
+            gather_slot_ = std::max(std::max(1, PT_.max_span), most);
+            partial_rhs_ = nullptr; sharded_solves_ = 0; dual_gathers_ = 0;
             upload_vec(need_x_, nx, st_); upload_vec(need_y_, ny, st_); upload_vec(need_z_, nz, st_); upload_vec(need_all_, nall, st_);
             need_x_n_ = (int)nx.size(); need_y_n_ = (int)ny.size(); need_z_n_ = (int)nz.size(); need_all_n_ = (int)nall.size();
             sel_ready_ = false; sharded_asm_ = 0; own_val_ranges_.clear();
@@ -2486,7 +2562,7 @@ public:
         stream_wait(st_);
         part_on_ = true;
         drop_transport();  // a new partition invalidates both transports: their buffer sizes and the communicator's world belong to the old one
-        sizes[0] = PT_.bmat_off.back() + 1; sizes[1] = std::max(1, PT_.bvec_off.back()); sizes[2] = std::max(1, PT_.max_span);
+        sizes[0] = PT_.bmat_off.back() + 1; sizes[1] = std::max(1, PT_.bvec_off.back()); sizes[2] = gather_slot_;
     }
     void set_exchange(pq_exchange_fn fn, void* user, double* buf_factor, double* buf_forward, double* buf_gather) override
     {
@@ -2507,7 +2583,7 @@ public:
                               double delta, const double* z_reg, double* err_x, double* err_y, double* err_z, double* norm) override
     {
         static const bool off = debug_token("replicated_residual") != nullptr;  // debugging aid: PIQP_AMD_DEBUG=replicated_residual
-        if (!part_on_ || world_ < 2 || mode_ != 0 || transport_ == Transport::None) return false;  // (structure and transport: the same on every rank by construction)
+        if (!part_on_ || world_ < 2 || transport_ == Transport::None) return false;  // (structure and transport: the same on every rank by construction)
         PQ_HIP(hipSetDevice(dev_));
         if (sharded_agreed_ < 0) {
             // Whether THIS rank can take the sharded path also depends on per-process state (a registered norm buffer, the debugging switch, a column too long for the
@@ -2540,7 +2616,26 @@ public:
         stream_wait(st_);
         *norm = norm_h_.p[0];
         ++sharded_evals_;
+        partial_rhs_ = err_x;  // (condensed modes: the next backend solve on this residual folds and recovers on this rank's rows only)
         return true;
+    }
+    // kkt_solver_base.hpp: the eliminated multipliers of a refined solve, each from its owner rank, in one all-gather
+    void finish_sharded_solve(double* lhs_y, double* lhs_z) override
+    {
+        if (mode_ == 0 || !part_on_ || world_ < 2 || sharded_agreed_ != 1 || dual_own_ptr_.empty() || dual_own_ptr_.back() == 0) return;
+        PQ_HIP(hipSetDevice(dev_));
+        const int lo = dual_own_ptr_[rank_], cnt = dual_own_ptr_[rank_ + 1] - lo;
+        if (cnt > 0) hipLaunchKernelGGL(k_pack_duals, g1(cnt), dim3(256), 0, st_, cnt, dual_rows_.p + lo, p_, lhs_y, lhs_z, xbuf_gather_ + (size_t)rank_ * gather_slot_);
+        exchange(2);
+        hipLaunchKernelGGL(k_unpack_duals, dim3(std::max(1, std::min(256, (gather_slot_ + 255) / 256)), world_), dim3(256), 0, st_, rank_, gather_slot_, dual_own_ptr_d_.p, dual_rows_.p, p_,
+                           xbuf_gather_, lhs_y, lhs_z);
+        PQ_HIP(hipGetLastError());
+        ++dual_gathers_;
+    }
+    void sharded_solve_calls(int out[6]) const override
+    {
+        out[0] = sharded_evals_; out[1] = need_x_n_ + need_y_n_ + need_z_n_; out[2] = sharded_solves_; out[3] = dual_gathers_; out[4] = fold_x_n_;
+        out[5] = ((mode_ & 1) ? need_y_n_ : 0) + ((mode_ & 2) ? need_z_n_ : 0);
     }
     // out[1]: KKT_FULL: rows of this rank's share of the residual; condensed modes: source entries of the value assembly this rank evaluates (of all: the same sum at world 1)
     void sharded_calls(int out[2]) const override
@@ -2564,7 +2659,7 @@ public:
         if (rank != rank_ || world != world_) throw std::runtime_error("set_comm_rccl: rank / world differ from pq_kkt_partition");
         drop_transport();
         comm_ = rccl::comm_create(id128, rank, world, dev_);
-        own_factor_.alloc((size_t)PT_.bmat_off.back() + 1); own_forward_.alloc((size_t)std::max(1, PT_.bvec_off.back())); own_gather_.alloc((size_t)world_ * std::max(1, PT_.max_span));
+        own_factor_.alloc((size_t)PT_.bmat_off.back() + 1); own_forward_.alloc((size_t)std::max(1, PT_.bvec_off.back())); own_gather_.alloc((size_t)world_ * gather_slot_);
         own_factor_.zero(st_); own_forward_.zero(st_); own_gather_.zero(st_);
         stream_wait(st_);
         xfn_ = nullptr; xbuf_factor_ = own_factor_.p; xbuf_forward_ = own_forward_.p; xbuf_gather_ = own_gather_.p;
@@ -2847,7 +2942,7 @@ private:
             if (which == 0) rccl::all_reduce_sum(comm_, xbuf_factor_, (size_t)PT_.bmat_off.back() + 1, st_);
             else if (which == 1) rccl::all_reduce_sum(comm_, xbuf_forward_, (size_t)std::max(1, PT_.bvec_off.back()), st_);
             else if (which == 3) rccl::all_reduce_max(comm_, xbuf_norm_, 1, st_);
-            else rccl::all_gather(comm_, xbuf_gather_, (size_t)std::max(1, PT_.max_span), rank_, st_);
+            else rccl::all_gather(comm_, xbuf_gather_, (size_t)gather_slot_, rank_, st_);
             if (which < 3) ++native_calls_[which];
             return;
         }
@@ -3431,6 +3526,13 @@ private:
     bool sel_ready_ = false;
     std::vector<std::pair<size_t, size_t>> own_val_ranges_;  // positions of the value array those fronts own (zeroed per factorisation)
     int need_x_n_ = 0, need_y_n_ = 0, need_z_n_ = 0, need_all_n_ = 0, sharded_evals_ = 0;
+    // condensed modes (round 5): rows of the eliminated blocks by owner rank (dual_rows_[dual_own_ptr_[r] .. dual_own_ptr_[r + 1]) ; y row j as j, z row k as p + k), the
+    // gather slot that holds a span of solution columns or one rank's multipliers, and the residual buffer whose next backend solve is a partial one
+    std::vector<int> dual_own_ptr_;
+    std::vector<std::pair<int, std::vector<int>>> dual_owner_tmp_;
+    DBuf<int> dual_rows_, dual_own_ptr_d_;
+    int gather_slot_ = 1, fold_x_n_ = 0, sharded_solves_ = 0, dual_gathers_ = 0;
+    const double* partial_rhs_ = nullptr;
     DBuf<double> norm_bits_, own_norm_;
     HBuf<double> norm_h_{2};
     double* xbuf_norm_ = nullptr;

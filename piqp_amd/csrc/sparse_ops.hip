@@ -232,6 +232,45 @@ __global__ __launch_bounds__(256) void k_residual_rows(const int* __restrict__ r
     }
 }
 
+// ---- the condensed right-hand side and the dual recovery on listed rows (CscOperators::fold_rhs_rows / recover_duals_rows) ----
+__global__ __launch_bounds__(256) void k_fold_rhs_rows(const int* __restrict__ rows, int nrows, const int* __restrict__ Gp, const int* __restrict__ Gi, const double* __restrict__ Gx,
+                                                       const int* __restrict__ Ap, const int* __restrict__ Ai, const double* __restrict__ Ax, const double* __restrict__ rhs_x,
+                                                       const double* __restrict__ rhs_y, const double* __restrict__ rhs_z, const double* __restrict__ zinv, double delta_inv,
+                                                       double* __restrict__ out, int with_A, int with_G, int ref_order)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nrows) return;
+    const int j = rows[t];
+    if (ref_order) {  // k_fold_rhs_ref
+        double s = rhs_x[j];
+        if (with_G) for (int q = Gp[j]; q < Gp[j + 1]; ++q) { const int i = Gi[q]; s += Gx[q] * (zinv[i] * rhs_z[i]); }
+        if (with_A) for (int q = Ap[j]; q < Ap[j + 1]; ++q) { const int i = Ai[q]; s += Ax[q] * (delta_inv * rhs_y[i]); }
+        out[j] = s;
+        return;
+    }
+    double sg = 0.0, sa = 0.0;  // k_fold_rhs
+    if (with_G) for (int q = Gp[j]; q < Gp[j + 1]; ++q) { const int i = Gi[q]; sg += Gx[q] * (zinv[i] * rhs_z[i]); }
+    if (with_A) for (int q = Ap[j]; q < Ap[j + 1]; ++q) sa += Ax[q] * rhs_y[Ai[q]];
+    out[j] = (rhs_x[j] + sg) + delta_inv * sa;
+}
+__global__ __launch_bounds__(256) void k_recover_duals_rows(const int* __restrict__ rows_y, int ny, const int* __restrict__ rows_z, int nz, const int* __restrict__ ATp,
+                                                            const int* __restrict__ ATi, const double* __restrict__ ATx, const int* __restrict__ GTp, const int* __restrict__ GTi,
+                                                            const double* __restrict__ GTx, const double* __restrict__ x, const double* __restrict__ rhs_y,
+                                                            const double* __restrict__ rhs_z, const double* __restrict__ zinv, double delta_inv, double* __restrict__ lhs_y,
+                                                            double* __restrict__ lhs_z)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < ny) {
+        const int k = rows_y[t];
+        const double s = col_dot_seq(k, ATp, ATi, ATx, x);
+        lhs_y[k] = delta_inv * s - delta_inv * rhs_y[k];
+    } else if (t < ny + nz) {
+        const int i = rows_z[t - ny];
+        const double s = col_dot_seq(i, GTp, GTi, GTx, x);
+        lhs_z[i] = (s - rhs_z[i]) * zinv[i];
+    }
+}
+
 // host-side CSC transpose with a value map: T = M^T, tmap[q_in_T] = q_in_M
 void transpose_with_map(int rows, int cols, const int* Mp, const int* Mi, std::vector<int>& Tp, std::vector<int>& Ti, std::vector<int>& tmap)
 {
@@ -404,6 +443,20 @@ void CscOperators::recover_duals(const double* x, const double* rhs_y, const dou
     if (p_ + m_ > 0)
         hipLaunchKernelGGL(k_recover_duals, dim3((p_ + 255) / 256 + (m_ + 255) / 256 > 0 ? (p_ + 255) / 256 + (m_ + 255) / 256 : 1), dim3(256), 0, st, p_, m_, AT_p_.p, AT_i_.p, AT_x_.p, GT_p_.p, GT_i_.p, GT_x_.p, x, rhs_y, rhs_z, zinv, delta_inv, lhs_y, lhs_z,
                            with_A ? 1 : 0, with_G ? 1 : 0);
+}
+void CscOperators::fold_rhs_rows(const int* rows_x, int nx, const double* rhs_x, const double* rhs_y, const double* rhs_z, const double* zinv, double delta_inv, double* out,
+                                 hipStream_t st, bool with_A, bool with_G) const
+{
+    if (nx > 0)
+        hipLaunchKernelGGL(k_fold_rhs_rows, g1(nx), dim3(256), 0, st, rows_x, nx, G_p_.p, G_i_.p, G_x_.p, A_p_.p, A_i_.p, A_x_.p, rhs_x, rhs_y, rhs_z, zinv, delta_inv, out, with_A ? 1 : 0,
+                           with_G ? 1 : 0, ref_order_ ? 1 : 0);
+}
+void CscOperators::recover_duals_rows(const int* rows_y, int ny, const int* rows_z, int nz, const double* x, const double* rhs_y, const double* rhs_z, const double* zinv,
+                                      double delta_inv, double* lhs_y, double* lhs_z, hipStream_t st) const
+{
+    if (ny + nz > 0)
+        hipLaunchKernelGGL(k_recover_duals_rows, g1(ny + nz), dim3(256), 0, st, rows_y, ny, rows_z, nz, AT_p_.p, AT_i_.p, AT_x_.p, GT_p_.p, GT_i_.p, GT_x_.p, x, rhs_y, rhs_z, zinv,
+                           delta_inv, lhs_y, lhs_z);
 }
 void CscOperators::add_AT_y(double alpha, const double* y, double* z, hipStream_t st) const
 {

@@ -45,6 +45,13 @@ public:
     void recover_duals(const double* x, const double* rhs_y, const double* rhs_z, const double* zinv, double delta_inv, double* lhs_y, double* lhs_z, hipStream_t st,
                        bool with_A = true, bool with_G = true) const;
 
+    // The same two on LISTED rows only (stage partition of the condensed backends): out[j] for the listed x rows j, lhs_y / lhs_z for the
+    // listed constraint rows -- one thread per listed row, column sums left to right in the statements of the kernels above: bitwise their values in those rows.
+    void fold_rhs_rows(const int* rows_x, int nx, const double* rhs_x, const double* rhs_y, const double* rhs_z, const double* zinv, double delta_inv, double* out, hipStream_t st,
+                       bool with_A, bool with_G) const;
+    void recover_duals_rows(const int* rows_y, int ny, const int* rows_z, int nz, const double* x, const double* rhs_y, const double* rhs_z, const double* zinv, double delta_inv,
+                            double* lhs_y, double* lhs_z, hipStream_t st) const;
+
     // Refinement residual on LISTED rows only (stage partition): err_x[i] = rhs_x[i] - (((P x)_i + x_reg_i x_i) + (A^T y)_i) + (G^T z)_i),
     // err_y[j] = rhs_y[j] - ((A x)_j - delta y_j), err_z[k] = rhs_z[k] - ((G x)_k - z_reg_k z_k) -- one thread per listed row, the column sums left to right with
     // the multiply-add of the eval_* kernels and the statements of k_err_x / k_err_yz: bitwise the values the full evaluation leaves in those rows.
@@ -62,6 +69,18 @@ public:
     int p() const { return p_; }
     int m() const { return m_; }
     int nzP() const { return nzP_; }
+    // host copies of the column patterns of A (p x n) and G (m x n): the constraint rows each x variable appears in (the backend's stage partition reads them once)
+    void download_column_patterns(std::vector<int>& Ap, std::vector<int>& Ai, std::vector<int>& Gp, std::vector<int>& Gi, hipStream_t st) const
+    {
+        auto get = [&](const DBuf<int>& b, size_t cnt, std::vector<int>& out) {
+            out.assign(cnt, 0);
+            if (cnt) PQ_HIP(hipMemcpyAsync(out.data(), b.p, sizeof(int) * cnt, hipMemcpyDeviceToHost, st));
+        };
+        Ap.assign((size_t)n_ + 1, 0); Gp.assign((size_t)n_ + 1, 0); Ai.clear(); Gi.clear();
+        if (p_ > 0) { get(A_p_, (size_t)n_ + 1, Ap); get(A_i_, (size_t)nzA_, Ai); }
+        if (m_ > 0) { get(G_p_, (size_t)n_ + 1, Gp); get(G_i_, (size_t)nzG_, Gi); }
+        PQ_HIP(hipStreamSynchronize(st));
+    }
     int nzA() const { return nzA_; }
     int nzG() const { return nzG_; }
     const double* P_x() const { return P_x_.p; }    // P_utri values, caller's CSC order

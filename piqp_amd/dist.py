@@ -233,6 +233,20 @@ class StagePartition:
         _lib.check((L.pq_solver_sharded_calls if is_solver else L.pq_kkt_sharded_calls)(h, C.byref(out)), "sharded_calls")
         return [int(out[0]), int(out[1])]
 
+    def sharded_solve_calls(self):
+        """[sharded residual evaluations, residual rows in this rank's share, backend solves that folded / recovered on this rank's rows only, gathers of the
+        eliminated multipliers, x rows folded per such solve, constraint rows recovered per such solve] (pq_kkt_sharded_solve_calls)"""
+        import ctypes as C
+
+        from . import _lib
+        L = _lib.load()
+        obj = self._obj
+        is_solver = hasattr(obj, "solve") and hasattr(obj, "setup")
+        h = obj.h if is_solver else (obj.backend().h if hasattr(obj, "backend") else obj.h)
+        out = (C.c_int * 6)()
+        _lib.check((L.pq_solver_sharded_solve_calls if is_solver else L.pq_kkt_sharded_solve_calls)(h, C.byref(out)), "sharded_solve_calls")
+        return [int(v) for v in out]
+
     def comm_info(self):
         """what ran the collectives, as seen from the inside (the figures a multi-GPU bench line carries so that "RCCL saw N ranks" can be checked):
         transport, the process group's backend and size, and for the native transport the library communicator's own ncclCommCount / rank / device"""

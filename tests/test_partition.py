@@ -144,6 +144,31 @@ def test_sharded_value_assembly_of_the_condensed_modes(backend, nranks):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("backend,problem,nranks", [("multistage", "chain", 2), ("multistage", "chain", 4), ("ldlt_cond", "chain", 2), ("ldlt_cond", "c3", 4)])
+def test_sharded_solve_side_of_the_condensed_backends(backend, problem, nranks):
+    """SURVEY 8(e) row 2, the solve side of the condensed modes and of sparse_multistage (round 5): with iterative refinement on, a stage-partitioned condensed backend
+    evaluates the refinement residual on its own rows (x rows of its fronts + the constraint rows that touch them), folds that residual into ITS x rows only, recovers
+    the eliminated multipliers on THOSE constraint rows only, and the refined multipliers cross the ranks once per KKTSystem::solve -- each row from its owner rank.
+    KKTSystem::solve with its refinement loop and the whole interior-point solve must be bitwise the single-GPU ones (everything on every row) on every rank."""
+    out = _run_ranks(nranks, ["--stages", "800", "--steps", "2", "--warmup", "1", "--backend", backend, "--problem", problem, "--full-solve", "--refine"], 29760 + nranks)
+    assert out["world"] == nranks
+    assert out["bitwise_equal_all_ranks"] and out["max_abs_diff"] == 0.0
+    assert out["rel_kkt_residual"] <= 1e-10
+    ss = out["sharded_solve"]
+    assert all(e >= 2 for e in ss["residual_evaluations_per_rank"]), ss
+    assert ss["norm_all_reduces"] >= 2
+    assert all(e >= 1 for e in ss["partial_backend_solves_per_rank"]), ss     # refinement steps really solved on a partial right-hand side ...
+    assert all(e >= 1 for e in ss["multiplier_gathers_per_rank"]), ss         # ... and the multipliers crossed the ranks afterwards
+    assert max(ss["residual_rows_per_rank"]) < 0.8 * ss["rows_total"] and sum(ss["residual_rows_per_rank"]) >= ss["rows_total"], ss
+    assert max(ss["x_rows_folded_per_rank"]) < 0.8 * ss["x_rows_total"] and sum(ss["x_rows_folded_per_rank"]) >= ss["x_rows_total"], ss
+    assert max(ss["constraint_rows_recovered_per_rank"]) < 0.8 * ss["constraint_rows_total"], ss
+    assert sum(ss["constraint_rows_recovered_per_rank"]) >= ss["constraint_rows_total"], ss
+    assert out["refine_steps"] == out["single_gpu_refine_steps"]
+    fs = out["full_solve"]
+    assert fs["status"] == 1 and fs["identical_on_all_ranks"] and fs["x_equal_to_single_gpu"] and fs["iter"] == fs["single_gpu"]["iter"]
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("native", [True, False])
 def test_rccl_transport_with_a_one_rank_group(native):
     """all a 1-GPU box can say about the RCCL transport: a one-rank "nccl" process group with the exchanges forced on

@@ -60,6 +60,26 @@ def main():
         sh = hip.SparseSolver(); sh.settings.kkt_solver = hip.SPARSE_LDLT
         ro = run(so, a, {"sparse": True}, reps); rh = run(sh, a, {}, reps)
         print(f"sparse {dim:5d} | {ro[0]:2d} {ro[1]:3d} {ro[2]:9.3f} | {rh[0]:2d} {rh[1]:3d} {rh[2]:9.3f} | {rh[2] / ro[2]:6.2f}x", flush=True)
+        if dim <= 128:
+            # round 5: the same sparse QP as a batch of ONE through the batched solver (kkt_solver = sparse_multistage; the whole interior-point method of an
+            # instance in one workgroup, one launch per solve, no host round trip per iteration) -- and as a batch of 256 copies (time per QP)
+            for batch in (1, 256):
+                try:
+                    bs = hip.BatchSparseSolver()
+                    rep = lambda v: None if v is None else np.repeat(np.asarray(v, dtype=np.float64)[None, :], batch, axis=0)
+                    Pm, Am, Gm = sp.csc_matrix(qs["P"]), sp.csc_matrix(qs["A"]), sp.csc_matrix(qs["G"])
+                    for M in (Pm, Am, Gm):
+                        M.sort_indices()
+                    ok = bs.setup(Pm, rep(Pm.data), rep(qs["c"]), Am, rep(Am.data), rep(qs["b"]), Gm, rep(Gm.data), rep(qs["h_l"]), rep(qs["h_u"]), x_l=rep(qs["x_l"]), x_u=rep(qs["x_u"]))
+                    assert ok
+                    bs.solve()
+                    ts = []
+                    for _ in range(reps):
+                        t0 = time.perf_counter(); nsolved = bs.solve(); ts.append(time.perf_counter() - t0)
+                    print(f"  batched solver, batch {batch:3d}: solved {nsolved}/{batch}, iterations {bs.info(0).iter}, {min(ts) * 1e3:9.3f} ms per launch = {min(ts) * 1e3 / batch:9.4f} ms per QP "
+                          f"({min(ts) * 1e3 / batch / ro[2]:6.2f}x the oracle's time)", flush=True)
+                except Exception as e:  # noqa: BLE001
+                    print(f"  batched solver, batch {batch}: {type(e).__name__}: {str(e)[:120]}", flush=True)
 
 
 if __name__ == "__main__":

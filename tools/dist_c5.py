@@ -143,6 +143,13 @@ def main():
         # condensed modes (sparse_ldlt_cond, the multistage tree engine): sharded_calls = (value assemblies done on the rank's own fronts only, source entries it evaluates)
         out["sharded_assembly"] = {"assemblies_per_rank": [int(r[0]) for r in shr], "entries_per_rank": [int(r[1]) for r in shr]}
         del out["sharded_residual"]
+    # the solve side (round 5): sharded residual evaluations, partial backend solves (fold / recovery on this rank's rows), gathers of the eliminated multipliers
+    ss = sp.sharded_solve_calls()
+    ssr = pd.gather_stats([[float(v) for v in ss]])
+    out["sharded_solve"] = {"residual_evaluations_per_rank": [int(r[0]) for r in ssr], "residual_rows_per_rank": [int(r[1]) for r in ssr], "rows_total": n + p + m,
+                            "partial_backend_solves_per_rank": [int(r[2]) for r in ssr], "multiplier_gathers_per_rank": [int(r[3]) for r in ssr],
+                            "x_rows_folded_per_rank": [int(r[4]) for r in ssr], "constraint_rows_recovered_per_rank": [int(r[5]) for r in ssr], "x_rows_total": n,
+                            "constraint_rows_total": p + m, "norm_all_reduces": int(sp.calls[3]) if not sp.native else None}
     out["native_rccl"] = bool(sp.native)
     # self-proving multi-GPU record: who ran the collectives and what they saw, per rank
     ci = sp.comm_info()
