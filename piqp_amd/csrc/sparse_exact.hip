@@ -67,8 +67,6 @@ __device__ __forceinline__ double chain_sub(double s, const double pr, int cnt)
 // 1.7 - 6.5 us per workgroup, several times that with more workgroups per CU -- more than a whole task of this engine): every word one wave writes for another is
 // written and read with agent-scope 8-byte / 4-byte atomics (write-through `sc1` stores, `sc1` loads that bypass the reader's L1), the flag follows the payload after
 // s_waitcnt vmcnt(0), and the consumer's loads follow its successful poll.  Nothing else in these kernels is written by one wave and read by another.
-__device__ __forceinline__ double ldw(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void stw(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // fl(a - fl(x y)): product rounded, then the difference rounded ("force compiler to not use fma instruction", ldlt.hpp:151-153)
 __device__ __forceinline__ double msub(double a, double x, double y) { return __dsub_rn(a, __dmul_rn(x, y)); }
@@ -147,10 +145,142 @@ constexpr int UL_PF = 8;    // row pass: columns prefetched ahead of the depende
                             // not from L2 (write-through stores drop the line): ~2 us, i.e. the pace is latency / depth until the depth covers it
 constexpr int UL_PFP = 8;   // path pass / substitution: table values fetched ahead
 
+struct UlSolveArgs {
+    int N, n, p, m;
+    const int *perm, *Lp, *Li, *Lcol;
+    const double *Lx, *Dinv;
+    const int4* bgroup;  // backward sweep: groups of whole columns, last columns first: {qlo, qhi, -, -}
+    int nbgroup;
+    const double *rx, *ry, *rz;
+    double *lx, *ly, *lz;
+    double* xglob;
+    int* err;  // set when the result holds a non-finite value
+    int epoch;
+};
+
+// ordering.perm, lsolve, dsolve, ltsolve, ordering.permt (sparse/kkt.hpp:107-145 KKT_FULL, ldlt.hpp:171-218) by ONE wave; x in LDS
+template <bool LDSX>
+__global__ __launch_bounds__(64) void k_ul_solve(UlSolveArgs a)
+{
+    extern __shared__ double ul_sm[];
+    double* __restrict__ x = LDSX ? ul_sm : a.xglob;
+    const int lane = threadIdx.x;
+    const int N = a.N;
+    for (int j = lane; j < N; j += 64) {
+        const int o = a.perm[j];
+        x[j] = o < a.n ? a.rx[o] : (o < a.n + a.p ? a.ry[o - a.n] : a.rz[o - a.n - a.p]);
+    }
+    wave_sync();
+    // lsolve: for j ascending: x[L_ind[p]] -= fl(L_vals[p] * x[j]).  The CSC arrays are streamed 64 entries at a time; inside a chunk the columns
+    // are taken one after the other (a target receives its terms in ascending column order), the entries of one column across the lanes
+    const int nnz = a.Lp[N];
+    {
+        int col = INT_MAX, row = 0;
+        double v = 0.0;
+        if (lane < nnz) { col = a.Lcol[lane]; row = a.Li[lane]; v = a.Lx[lane]; }
+        for (int base = 0; base < nnz; base += 64) {
+            int ncol = INT_MAX, nrow = 0;
+            double nv = 0.0;
+            const int q2 = base + 64 + lane;
+            if (q2 < nnz) { ncol = a.Lcol[q2]; nrow = a.Li[q2]; nv = a.Lx[q2]; }  // the next chunk travels while this one is consumed
+            int jcur = readfirst(col);
+            unsigned long long mk = 1;
+            while (mk != 0) {
+                const double xj = x[jcur];
+                if (col == jcur) x[row] = msub(x[row], v, xj);
+                wave_sync();
+                mk = __ballot(col > jcur && col != INT_MAX);
+                if (mk != 0) jcur = __builtin_amdgcn_readlane(col, __builtin_ctzll(mk));
+            }
+            col = ncol; row = nrow; v = nv;
+        }
+    }
+    // dsolve
+    for (int j = lane; j < N; j += 64) x[j] = __dmul_rn(x[j], a.Dinv[j]);
+    wave_sync();
+    // ltsolve: for j descending: x[j] -= fl(L_vals[p] * x[L_ind[p]]) for p ascending.  Groups of whole columns (at most 64 entries, or one long column)
+    {
+        int4 g = a.nbgroup > 0 ? a.bgroup[0] : make_int4(0, 0, 0, 0);
+        int col = -1, row = 0;
+        double v = 0.0;
+        if (a.nbgroup > 0 && g.x + lane < g.y && g.y - g.x <= 64) { col = a.Lcol[g.x + lane]; row = a.Li[g.x + lane]; v = a.Lx[g.x + lane]; }
+        for (int gi = 0; gi < a.nbgroup; ++gi) {
+            int4 g2 = make_int4(0, 0, 0, 0);
+            int ncol = -1, nrow = 0;
+            double nv = 0.0;
+            if (gi + 1 < a.nbgroup) {
+                g2 = a.bgroup[gi + 1];
+                if (g2.x + lane < g2.y && g2.y - g2.x <= 64) { ncol = a.Lcol[g2.x + lane]; nrow = a.Li[g2.x + lane]; nv = a.Lx[g2.x + lane]; }
+            }
+            if (g.y - g.x <= 64) {
+                const int cnt = g.y - g.x;
+                int jcur = __builtin_amdgcn_readlane(col, cnt - 1);
+                unsigned long long nm = 1;
+                while (nm != 0) {
+                    const bool mine = col == jcur;
+                    const unsigned long long mk = __ballot(mine);
+                    const int la = __builtin_ctzll(mk), lb = 64 - __builtin_clzll(mk);
+                    double s = x[jcur];
+                    const double pr = mine ? __dmul_rn(v, x[row]) : 0.0;
+                    for (int l = la; l < lb; ++l) s = __dsub_rn(s, readlane_d(pr, l));
+                    x[jcur] = s;  // (every lane writes the same word)
+                    wave_sync();
+                    nm = __ballot(col >= 0 && col < jcur);
+                    if (nm != 0) jcur = __builtin_amdgcn_readlane(col, 63 - __builtin_clzll(nm));
+                }
+            } else {  // one long column: its entries in ascending order, 64 products at a time
+                const int j = a.Lcol[g.x];
+                double s = x[j];
+                for (int q0 = g.x; q0 < g.y; q0 += 64) {
+                    const int q = q0 + lane;
+                    const double pr = q < g.y ? __dmul_rn(a.Lx[q], x[a.Li[q]]) : 0.0;
+                    const int c = min(64, g.y - q0);
+                    for (int l = 0; l < c; ++l) s = __dsub_rn(s, readlane_d(pr, l));
+                }
+                x[j] = s;
+                wave_sync();
+            }
+            g = g2; col = ncol; row = nrow; v = nv;
+        }
+    }
+    bool bad = false;
+    for (int j = lane; j < N; j += 64) {
+        const int o = a.perm[j];
+        const double xv = x[j];
+        bad |= !(fabs(xv) <= 1.7976931348623157e308);
+        if (o < a.n) a.lx[o] = xv;
+        else if (o < a.n + a.p) a.ly[o - a.n] = xv;
+        else a.lz[o - a.n - a.p] = xv;
+    }
+    if (bad && a.err) *a.err = a.epoch;
+}
+
+
+struct UlSolve2Args {
+    int N, n, p, m, ntask, epoch;
+    const int *perm, *taskrec, *task_rows, *tsort, *tdep, *fs_u, *fs_col, *Lp, *Li, *Lsrc;
+    const int4* fs4;  // forward pass, per table row of a task in ascending column order: {table row, column, mask of the task's rows with an entry (lo, hi)}
+    const unsigned long long* Tmask;
+    const int* mask_ptr;
+    const double *Lblock, *Lx, *Dinv;
+    const double *rx, *ry, *rz;
+    double *lx, *ly, *lz;
+    double *xf, *xz, *xb;
+    int *fdone, *bdone, *ticket, *info;
+    int fwd_only;
+    const int *ta_ptr, *ta_rows, *Lsrc2;  // backward pass: per task the rows above it that its columns touch; per entry of L its operand (lane of the task, or 64 + list index)
+    int xa_cap;                           // doubles of LDS for the longest such list (a multiple of 64)
+};
+
+__device__ __forceinline__ double ldw(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void stw(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int ldf(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void stf(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 __device__ __forceinline__ bool spin_until(const int* flag, int epoch)
 {
     long long spins = 0;
-    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+    while (ldf(flag) != epoch) {
         __builtin_amdgcn_s_sleep(1);
         if (++spins > (1ll << 26)) return false;  // (seconds: a scheduling bug must not take the device with it)
     }
@@ -160,7 +290,7 @@ __device__ __forceinline__ bool spin_until(const int* flag, int epoch)
 __device__ __forceinline__ bool spin_until_ge(const int* flag, int want)
 {
     long long spins = 0;
-    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+    while (ldf(flag) < want) {
         __builtin_amdgcn_s_sleep(1);
         if (++spins > (1ll << 26)) return false;
     }
@@ -440,7 +570,7 @@ __device__ __forceinline__ bool ul_path_row(const UlFactorArgs& a, const int k, 
                         stw(a.Lx + __builtin_amdgcn_readlane(ch.pos, s & 63), l);
                         stw(a.Lblock + tb + u * W + j, l);
                         drain_stores();
-                        __hip_atomic_store(a.prog + k, (a.epoch << 8) | (c0 + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        stf(a.prog + k, (a.epoch << 8) | (c0 + 1));
                         // the rows between c0 and this one that hold an entry in column c0 must have published it
                         bool okw = bit ? spin_until_ge(a.prog + rowl, (a.epoch << 8) | (c0 + 1)) : true;
                         if (__ballot(!okw)) return false;
@@ -458,7 +588,7 @@ __device__ __forceinline__ bool ul_path_row(const UlFactorArgs& a, const int k, 
         if (Dk == 0.0) atomicMin(a.info, k);
     }
     drain_stores();
-    __hip_atomic_store(a.prog + k, done_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    stf(a.prog + k, done_word);
     return true;
 }
 
@@ -502,11 +632,11 @@ __global__ __launch_bounds__(64) void k_ul_factor(UlFactorArgs a)
             if (ok) {
                 drain_stores();
                 int* flag = (W > 1 ? a.p1done : a.done) + k;
-                __hip_atomic_store(flag, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (every lane stores the same word: no divergence at the loop's end)
+                stf(flag, a.epoch);  // (every lane stores the same word: no divergence at the loop's end)
                 if (W > 1 && !serial_task) {
                     const int rb = a.taskrec[8 * r1.x];
                     ok = ul_path_row(a, k, lane, es, en, W, lanek, tb, nU, rb, readlane_d(Dk0, 0), s_acc, s_pos);
-                    if (ok && lanek == W - 1) __hip_atomic_store(a.done + k, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (ul_path_row has drained its stores)
+                    if (ok && lanek == W - 1) stf(a.done + k, a.epoch);  // (ul_path_row has drained its stores)
                 }
             }
         } else if (!a.rowrec[16 * a.task_rows[a.taskrec[8 * id]] + 12]) {
@@ -516,7 +646,7 @@ __global__ __launch_bounds__(64) void k_ul_factor(UlFactorArgs a)
             ok = ul_path(a, id, lane, s_acc, s_pos);
             if (ok) {
                 drain_stores();
-                __hip_atomic_store(a.done + a.task_rows[a.taskrec[8 * id] + a.taskrec[8 * id + 1] - 1], a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                stf(a.done + a.task_rows[a.taskrec[8 * id] + a.taskrec[8 * id + 1] - 1], a.epoch);
             }
         }
         if (!ok) { if (lane == 0) atomicMin(a.info, -2); break; }
@@ -526,117 +656,6 @@ __global__ __launch_bounds__(64) void k_ul_factor(UlFactorArgs a)
     }
 }
 
-struct UlSolveArgs {
-    int N, n, p, m;
-    const int *perm, *Lp, *Li, *Lcol;
-    const double *Lx, *Dinv;
-    const int4* bgroup;  // backward sweep: groups of whole columns, last columns first: {qlo, qhi, -, -}
-    int nbgroup;
-    const double *rx, *ry, *rz;
-    double *lx, *ly, *lz;
-    double* xglob;
-    int* err;  // set when the result holds a non-finite value
-    int epoch;
-};
-
-// ordering.perm, lsolve, dsolve, ltsolve, ordering.permt (sparse/kkt.hpp:107-145 KKT_FULL, ldlt.hpp:171-218) by ONE wave; x in LDS
-template <bool LDSX>
-__global__ __launch_bounds__(64) void k_ul_solve(UlSolveArgs a)
-{
-    extern __shared__ double ul_sm[];
-    double* __restrict__ x = LDSX ? ul_sm : a.xglob;
-    const int lane = threadIdx.x;
-    const int N = a.N;
-    for (int j = lane; j < N; j += 64) {
-        const int o = a.perm[j];
-        x[j] = o < a.n ? a.rx[o] : (o < a.n + a.p ? a.ry[o - a.n] : a.rz[o - a.n - a.p]);
-    }
-    wave_sync();
-    // lsolve: for j ascending: x[L_ind[p]] -= fl(L_vals[p] * x[j]).  The CSC arrays are streamed 64 entries at a time; inside a chunk the columns
-    // are taken one after the other (a target receives its terms in ascending column order), the entries of one column across the lanes
-    const int nnz = a.Lp[N];
-    {
-        int col = INT_MAX, row = 0;
-        double v = 0.0;
-        if (lane < nnz) { col = a.Lcol[lane]; row = a.Li[lane]; v = a.Lx[lane]; }
-        for (int base = 0; base < nnz; base += 64) {
-            int ncol = INT_MAX, nrow = 0;
-            double nv = 0.0;
-            const int q2 = base + 64 + lane;
-            if (q2 < nnz) { ncol = a.Lcol[q2]; nrow = a.Li[q2]; nv = a.Lx[q2]; }  // the next chunk travels while this one is consumed
-            int jcur = readfirst(col);
-            unsigned long long mk = 1;
-            while (mk != 0) {
-                const double xj = x[jcur];
-                if (col == jcur) x[row] = msub(x[row], v, xj);
-                wave_sync();
-                mk = __ballot(col > jcur && col != INT_MAX);
-                if (mk != 0) jcur = __builtin_amdgcn_readlane(col, __builtin_ctzll(mk));
-            }
-            col = ncol; row = nrow; v = nv;
-        }
-    }
-    // dsolve
-    for (int j = lane; j < N; j += 64) x[j] = __dmul_rn(x[j], a.Dinv[j]);
-    wave_sync();
-    // ltsolve: for j descending: x[j] -= fl(L_vals[p] * x[L_ind[p]]) for p ascending.  Groups of whole columns (at most 64 entries, or one long column)
-    {
-        int4 g = a.nbgroup > 0 ? a.bgroup[0] : make_int4(0, 0, 0, 0);
-        int col = -1, row = 0;
-        double v = 0.0;
-        if (a.nbgroup > 0 && g.x + lane < g.y && g.y - g.x <= 64) { col = a.Lcol[g.x + lane]; row = a.Li[g.x + lane]; v = a.Lx[g.x + lane]; }
-        for (int gi = 0; gi < a.nbgroup; ++gi) {
-            int4 g2 = make_int4(0, 0, 0, 0);
-            int ncol = -1, nrow = 0;
-            double nv = 0.0;
-            if (gi + 1 < a.nbgroup) {
-                g2 = a.bgroup[gi + 1];
-                if (g2.x + lane < g2.y && g2.y - g2.x <= 64) { ncol = a.Lcol[g2.x + lane]; nrow = a.Li[g2.x + lane]; nv = a.Lx[g2.x + lane]; }
-            }
-            if (g.y - g.x <= 64) {
-                const int cnt = g.y - g.x;
-                int jcur = __builtin_amdgcn_readlane(col, cnt - 1);
-                unsigned long long nm = 1;
-                while (nm != 0) {
-                    const bool mine = col == jcur;
-                    const unsigned long long mk = __ballot(mine);
-                    const int la = __builtin_ctzll(mk), lb = 64 - __builtin_clzll(mk);
-                    double s = x[jcur];
-                    const double pr = mine ? __dmul_rn(v, x[row]) : 0.0;
-                    for (int l = la; l < lb; ++l) s = __dsub_rn(s, readlane_d(pr, l));
-                    x[jcur] = s;  // (every lane writes the same word)
-                    wave_sync();
-                    nm = __ballot(col >= 0 && col < jcur);
-                    if (nm != 0) jcur = __builtin_amdgcn_readlane(col, 63 - __builtin_clzll(nm));
-                }
-            } else {  // one long column: its entries in ascending order, 64 products at a time
-                const int j = a.Lcol[g.x];
-                double s = x[j];
-                for (int q0 = g.x; q0 < g.y; q0 += 64) {
-                    const int q = q0 + lane;
-                    const double pr = q < g.y ? __dmul_rn(a.Lx[q], x[a.Li[q]]) : 0.0;
-                    const int c = min(64, g.y - q0);
-                    for (int l = 0; l < c; ++l) s = __dsub_rn(s, readlane_d(pr, l));
-                }
-                x[j] = s;
-                wave_sync();
-            }
-            g = g2; col = ncol; row = nrow; v = nv;
-        }
-    }
-    bool bad = false;
-    for (int j = lane; j < N; j += 64) {
-        const int o = a.perm[j];
-        const double xv = x[j];
-        bad |= !(fabs(xv) <= 1.7976931348623157e308);
-        if (o < a.n) a.lx[o] = xv;
-        else if (o < a.n + a.p) a.ly[o - a.n] = xv;
-        else a.lz[o - a.n - a.p] = xv;
-    }
-    if (bad && a.err) *a.err = a.epoch;
-}
-
-
 // ---- substitution on the factorisation's tasks (lsolve, dsolve, ltsolve of ldlt.hpp:171-218 with ordering.perm / permt of sparse/kkt.hpp:139-144 folded in).
 // One persistent launch: tickets 0 .. ntask-1 are the forward passes of the tasks (in the order of their last rows), ntask .. 2 ntask-1 the backward passes in the
 // opposite order; a wave never waits for a later ticket.  The vectors live in HBM: xf (forward result), xz (xf scaled by D_inv), xb (final).
@@ -644,102 +663,164 @@ __global__ __launch_bounds__(64) void k_ul_solve(UlSolveArgs a)
 //     ascending column order: acc_t -= fl(L(t, j) x_j) -- the order in which the reference's column loop subtracts from x_t;
 //   backward pass: its columns from the last to the first; the entries of column j in ascending row order: 64 products fl(L(t, j) x_t) across the lanes, subtracted
 //     from x_j one after the other (the reference's inner loop); x_t of a row on the same path comes from its lane, of a row above from xb.
-struct UlSolve2Args {
-    int N, n, p, m, ntask, epoch;
-    const int *perm, *taskrec, *task_rows, *tsort, *tdep, *fs_u, *fs_col, *Lp, *Li, *Lsrc;
-    const unsigned long long* Tmask;
-    const int* mask_ptr;
-    const double *Lblock, *Lx, *Dinv;
-    const double *rx, *ry, *rz;
-    double *lx, *ly, *lz;
-    double *xf, *xz, *xb;
-    int *fdone, *bdone, *ticket, *info;
-};
 
 // (everything that does not depend on other tasks -- the task record, its rows, the right-hand side, the first chunk of the table -- is requested BEFORE the wait
 // for the tasks below: a hop of the dependency chain then costs the flag, one load of x and the arithmetic, not five dependent loads on top)
-template <class Wait>
+// Chunks of 64 table rows; the records of the chunk AFTER the current one ({table row, column, mask of the task rows that hold an entry}: one 16-byte load per
+// lane), its x values and -- from the middle of the current chunk on -- its table values are requested while the current chunk is computed: after the first
+// chunk no memory round trip is left on the chain of steps.
+template <int PFS, class Wait>
 __device__ __forceinline__ bool ul_fwd_task(const UlSolve2Args& a, const int t, const int lane, Wait wait)
 {
+    static_assert(PFS == 32, "the refill below assumes half a chunk");
     const int4 r0 = *reinterpret_cast<const int4*>(a.taskrec + 8 * t);
     const int rb = r0.x, W = r0.y, nU = r0.z, tb = r0.w, fs0 = a.taskrec[8 * t + 4];
-    const int mb = a.mask_ptr[t];
     const int nsrc = nU + W;
     const int lw = lane < W ? lane : W - 1;
     const int row = a.task_rows[rb + lw];
     const int o = a.perm[row];
     double acc = o < a.n ? a.rx[o] : (o < a.n + a.p ? a.ry[o - a.n] : a.rz[o - a.n - a.p]);
     const double dinv = a.Dinv[row];
-    bool waited = false;
+    int4 rec = a.fs4[fs0 + (lane < nsrc ? lane : 0)];
+    if (lane >= nsrc) { rec.x = 0; rec.z = 0; rec.w = 0; }
+    double pf_v[PFS];
+#pragma unroll
+    for (int d = 0; d < PFS; ++d) pf_v[d] = a.Lblock[tb + __builtin_amdgcn_readlane(rec.x, d) * W + lw];
+    if (!wait()) return false;
+    double xs = ldw(a.xf + rec.y);   // (an outside column is final: its task was waited for; a path column's value is taken from its lane instead)
     for (int base = 0; base < nsrc; base += 64) {
-        const bool in = base + lane < nsrc;
-        const int q = fs0 + (in ? base + lane : 0);
-        const int ue = in ? a.fs_u[q] : 0;
-        const int col = a.fs_col[q];
-        const unsigned long long me = in ? a.Tmask[mb + ue] : 0ull;
-        const int mlo = (int)(unsigned)(me & 0xffffffffull), mhi = (int)(unsigned)(me >> 32);
         const int ns = min(64, nsrc - base);
-        double pf_v[UL_PFP];
+        const int ue = rec.x, mlo = rec.z, mhi = rec.w;
+        const double xcur = xs;
+        // the chunk after this one
+        const bool more = base + 64 < nsrc;
+        const int qn = base + 64 + lane;
+        int4 nrec = a.fs4[fs0 + (more && qn < nsrc ? qn : 0)];
+        if (!more || qn >= nsrc) { nrec.x = 0; nrec.z = 0; nrec.w = 0; }
+        const double nxs = ldw(a.xf + nrec.y);
 #pragma unroll
-        for (int d = 0; d < UL_PFP; ++d) pf_v[d] = a.Lblock[tb + __builtin_amdgcn_readlane(ue, d) * W + lw];
-        if (!waited) { if (!wait()) return false; waited = true; }
-        const double xs = ldw(a.xf + col);   // (an outside column is final: its task was waited for; a path column's value is taken from its lane instead)
-        for (int sb = 0; sb < ns; sb += UL_PFP) {
+        for (int half = 0; half < 2; ++half) {
+            if (half * 32 < ns) {
 #pragma unroll
-            for (int d = 0; d < UL_PFP; ++d) {
-                const int s = sb + d;
-                const int u = __builtin_amdgcn_readlane(ue, s & 63);
-                const unsigned long long m = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(mhi, s & 63) << 32) | (unsigned)__builtin_amdgcn_readlane(mlo, s & 63);
-                const double v = pf_v[d];
-                pf_v[d] = a.Lblock[tb + __builtin_amdgcn_readlane(ue, (s + UL_PFP) & 63) * W + lw];
-                if (s < ns) {
-                    const double src = u < nU ? readlane_d(xs, s & 63) : readlane_d(acc, (u - nU) & 63);
-                    if (__builtin_amdgcn_inverse_ballot_w64(m)) acc = msub(acc, v, src);
+                for (int d = 0; d < PFS; ++d) {
+                    const int s = half * 32 + d;
+                    const int u = __builtin_amdgcn_readlane(ue, s);
+                    const unsigned long long m = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(mhi, s) << 32) | (unsigned)__builtin_amdgcn_readlane(mlo, s);
+                    const double v = pf_v[d];
+                    // refill: the table row 32 steps ahead -- of this chunk (first half) or of the next one (second half)
+                    pf_v[d] = a.Lblock[tb + __builtin_amdgcn_readlane(half == 0 ? ue : nrec.x, (s + 32) & 63) * W + lw];
+                    if (s < ns) {
+                        const double src = u < nU ? readlane_d(xcur, s) : readlane_d(acc, (u - nU) & 63);
+                        if (__builtin_amdgcn_inverse_ballot_w64(m)) acc = msub(acc, v, src);
+                    }
                 }
+            } else {
+                // (a short last chunk: nothing to compute in this half, and nothing follows)
             }
         }
+        rec = nrec; xs = nxs;
     }
-    if (!waited && !wait()) return false;
     if (lane < W) { stw(a.xf + row, acc); stw(a.xz + row, __dmul_rn(acc, dinv)); }
     return true;
 }
 
-template <class Wait>
-__device__ __forceinline__ bool ul_bwd_task(const UlSolve2Args& a, const int t, const int lane, Wait wait)
+// s - p[0] - p[1] - ... - p[cnt - 1] with the terms in LDS (every lane reads the same words: broadcasts): eight terms per round of four 16-byte reads and eight
+// subtractions -- about half the instructions of the lane-read chain, which stays for the short chains (an LDS round trip costs more than three lane reads)
+__device__ __forceinline__ double lds_chain_sub(double s, const double* __restrict__ p, int cnt)
 {
-    const int rb = a.taskrec[8 * t], W = a.taskrec[8 * t + 1];
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    int l = 0;
+    for (; l + 8 <= cnt; l += 8) {
+        const d2 t0 = *reinterpret_cast<const d2*>(p + l), t1 = *reinterpret_cast<const d2*>(p + l + 2), t2 = *reinterpret_cast<const d2*>(p + l + 4),
+                 t3 = *reinterpret_cast<const d2*>(p + l + 6);
+        s = __dsub_rn(s, t0.x); s = __dsub_rn(s, t0.y); s = __dsub_rn(s, t1.x); s = __dsub_rn(s, t1.y);
+        s = __dsub_rn(s, t2.x); s = __dsub_rn(s, t2.y); s = __dsub_rn(s, t3.x); s = __dsub_rn(s, t3.y);
+    }
+    if (l < cnt) {  // (l <= 56: the eight words are inside the buffer)
+        const int rem = cnt - l;
+        const d2 t0 = *reinterpret_cast<const d2*>(p + l), t1 = *reinterpret_cast<const d2*>(p + l + 2), t2 = *reinterpret_cast<const d2*>(p + l + 4),
+                 t3 = *reinterpret_cast<const d2*>(p + l + 6);
+        s = __dsub_rn(s, t0.x);
+        if (rem > 1) s = __dsub_rn(s, t0.y);
+        if (rem > 2) s = __dsub_rn(s, t1.x);
+        if (rem > 3) s = __dsub_rn(s, t1.y);
+        if (rem > 4) s = __dsub_rn(s, t2.x);
+        if (rem > 5) s = __dsub_rn(s, t2.y);
+        if (rem > 6) s = __dsub_rn(s, t3.x);
+    }
+    return s;
+}
+
+// Backward pass of a task (round 5, second form).  What it reads from OTHER tasks are the final x of the rows above it that its columns touch -- a short list per
+// task (the structure of its top row): fetched ONCE, into LDS (s_xa), so that a column's operands are lane shuffles and LDS reads and the only loads per column are
+// its own entries (Lsrc2: 0 .. 63 = a row of this task by lane, 64 + i = entry i of the task's list), requested UL_PB columns ahead.
+constexpr int UL_PB = 4;   // columns whose first 64 entries are in flight
+constexpr int UL_AR = 5;   // list entries per lane fetched before the wait (lists of up to 320 rows; longer ones finish in a loop)
+template <class Wait>
+__device__ __forceinline__ bool ul_bwd_task(const UlSolve2Args& a, const int t, const int lane, Wait wait, double* __restrict__ s_xa, double* __restrict__ s_pr)
+{
+    const int rb = a.taskrec[8 * t], W = readfirst(a.taskrec[8 * t + 1]);
     const int lw = lane < W ? lane : W - 1;
     const int row = a.task_rows[rb + lw];
     const int lp0 = a.Lp[row], lp1 = a.Lp[row + 1];
     const int o = a.perm[row];
-    // the first 64 entries of the column a step ahead
-    int q0 = __builtin_amdgcn_readlane(lp0, W - 1), q1 = __builtin_amdgcn_readlane(lp1, W - 1);
-    int nt_ = a.Li[q0 + lane < q1 ? q0 + lane : (q1 > q0 ? q0 : 0)];
-    int nsl = a.Lsrc[q0 + lane < q1 ? q0 + lane : (q1 > q0 ? q0 : 0)];
-    double nv = a.Lx[q0 + lane < q1 ? q0 + lane : (q1 > q0 ? q0 : 0)];
-    if (!wait()) return false;  // (the index loads above do not depend on other tasks; the values below do)
+    const int ta0 = readfirst(a.ta_ptr[t]), nA = readfirst(a.ta_ptr[t + 1]) - ta0;
+    int r_sl[UL_PB];
+    double r_v[UL_PB];
+#pragma unroll
+    for (int d = 0; d < UL_PB; ++d) {
+        const int c = W - 1 - d, cc = c >= 0 ? c : 0;
+        const int p0 = __builtin_amdgcn_readlane(lp0, cc), p1 = __builtin_amdgcn_readlane(lp1, cc);
+        const int qq = p0 + lane < p1 ? p0 + lane : (p1 > p0 ? p0 : 0);
+        r_sl[d] = a.Lsrc2[qq]; r_v[d] = a.Lx[qq];
+    }
+    int arow[UL_AR];
+#pragma unroll
+    for (int k = 0; k < UL_AR; ++k) arow[k] = a.ta_rows[ta0 + (lane + 64 * k < nA ? lane + 64 * k : 0)];  // (one word of padding behind the last list)
+    if (!wait()) return false;  // (the loads above do not depend on other tasks; the values below do)
     double xfin = ldw(a.xz + row);
-    double nxv = ldw(a.xb + nt_);
-    for (int c = W - 1; c >= 0; --c) {
-        const int c0 = q0, c1 = q1;
-        const int tl = nt_, sl = nsl;
-        const double v = nv, xv = nxv;
-        (void)tl;
-        if (c > 0) {
-            q0 = __builtin_amdgcn_readlane(lp0, c - 1); q1 = __builtin_amdgcn_readlane(lp1, c - 1);
-            const int qq = q0 + lane < q1 ? q0 + lane : (q1 > q0 ? q0 : 0);
-            nt_ = a.Li[qq]; nsl = a.Lsrc[qq]; nv = a.Lx[qq]; nxv = ldw(a.xb + nt_);
+#pragma unroll
+    for (int k = 0; k < UL_AR; ++k) {
+        const double xv = ldw(a.xb + arow[k]);
+        if (lane + 64 * k < nA) s_xa[lane + 64 * k] = xv;
+    }
+    for (int idx = lane + 64 * UL_AR; idx < nA; idx += 64) s_xa[idx] = ldw(a.xb + a.ta_rows[ta0 + idx]);
+    wave_sync();
+    for (int cb = W - 1; cb >= 0; cb -= UL_PB) {
+#pragma unroll
+        for (int d = 0; d < UL_PB; ++d) {
+            const int c = cb - d;
+            if (c >= 0) {
+                const int q0 = __builtin_amdgcn_readlane(lp0, c), q1 = __builtin_amdgcn_readlane(lp1, c);
+                int sl = r_sl[d];
+                double v = r_v[d];
+                {   // this slot: the column UL_PB below
+                    const int c2 = c - UL_PB, cc = c2 >= 0 ? c2 : 0;
+                    const int p0 = __builtin_amdgcn_readlane(lp0, cc), p1 = __builtin_amdgcn_readlane(lp1, cc);
+                    const int qq = p0 + lane < p1 ? p0 + lane : (p1 > p0 ? p0 : 0);
+                    r_sl[d] = a.Lsrc2[qq]; r_v[d] = a.Lx[qq];
+                }
+                double s = readlane_d(xfin, c);
+                for (int qb = q0; qb < q1; qb += 64) {
+                    const int cnt = min(64, q1 - qb);
+                    int nsl = 0;
+                    double nv = 0.0;
+                    if (qb + 64 < q1) { const int qq = qb + 64 + lane < q1 ? qb + 64 + lane : qb + 64; nsl = a.Lsrc2[qq]; nv = a.Lx[qq]; }  // the column's next 64 entries
+                    const double xin = __shfl(xfin, sl < 64 ? sl : 0, 64);
+                    const double xo = s_xa[sl >= 64 ? sl - 64 : 0];
+                    const double pr = __dmul_rn(v, sl < 64 ? xin : xo);
+                    if (cnt <= 4) s = chain_sub(s, pr, cnt);
+                    else {
+                        s_pr[lane] = pr;
+                        wave_sync();
+                        s = lds_chain_sub(s, s_pr, cnt);
+                        wave_sync();
+                    }
+                    sl = nsl; v = nv;
+                }
+                if (lane == c) xfin = s;
+            }
         }
-        double s = readlane_d(xfin, c);
-        for (int qb = c0; qb < c1; qb += 64) {
-            const int cnt = min(64, c1 - qb);
-            int sl2 = sl; double v2 = v, xv2 = xv;
-            if (qb > c0) { const int qq = qb + lane < c1 ? qb + lane : qb; sl2 = a.Lsrc[qq]; v2 = a.Lx[qq]; xv2 = ldw(a.xb + a.Li[qq]); }
-            const double xin = __shfl(xfin, sl2 >= 0 ? sl2 : 0, 64);
-            const double pr = __dmul_rn(v2, sl2 >= 0 ? xin : xv2);
-            s = chain_sub(s, pr, cnt);
-        }
-        if (lane == c) xfin = s;
     }
     if (lane < W) {
         stw(a.xb + row, xfin);
@@ -750,8 +831,12 @@ __device__ __forceinline__ bool ul_bwd_task(const UlSolve2Args& a, const int t, 
     return true;
 }
 
+template <int PFS>
 __global__ __launch_bounds__(64) void k_ul_solve2(UlSolve2Args a)
 {
+    extern __shared__ double ul_sx[];  // the backward pass's x of the rows above the task (xa_cap doubles), then 64 products
+    double* const s_xa = ul_sx;
+    double* const s_pr = ul_sx + a.xa_cap;
     __shared__ int s_task;
     const int lane = threadIdx.x;
     if (lane == 0) s_task = atomicAdd(a.ticket, 1);
@@ -764,22 +849,23 @@ __global__ __launch_bounds__(64) void k_ul_solve2(UlSolve2Args a)
         if (tk < a.ntask) {
             const int t = a.tsort[tk];
             const int d0 = a.taskrec[8 * t + 5], dn = a.taskrec[8 * t + 6];
-            ok = ul_fwd_task(a, t, lane, [&]() {
+            ok = ul_fwd_task<PFS>(a, t, lane, [&]() {
                 bool w = true;
                 for (int c = lane; c < dn; c += 64) w &= spin_until(a.fdone + a.tdep[d0 + c], a.epoch);
                 return __ballot(!w) == 0;
             });
             if (ok) {
                 drain_stores();
-                __hip_atomic_store(a.fdone + t, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                stf(a.fdone + t, a.epoch);
             }
         } else {
             const int t = a.tsort[2 * a.ntask - 1 - tk];
             const int parent = a.taskrec[8 * t + 7];
-            ok = ul_bwd_task(a, t, lane, [&]() { return __ballot(!spin_until(parent >= 0 ? a.bdone + parent : a.fdone + t, a.epoch)) == 0; });
+            if (a.fwd_only) ok = __ballot(!spin_until(parent >= 0 ? a.bdone + parent : a.fdone + t, a.epoch)) == 0;  // (debugging aid: the forward pass alone, for timing)
+            else ok = ul_bwd_task(a, t, lane, [&]() { return __ballot(!spin_until(parent >= 0 ? a.bdone + parent : a.fdone + t, a.epoch)) == 0; }, s_xa, s_pr);
             if (ok) {
                 drain_stores();
-                __hip_atomic_store(a.bdone + t, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                stf(a.bdone + t, a.epoch);
             }
         }
         if (!ok) { if (lane == 0) atomicMin(a.info, -2); break; }
@@ -787,6 +873,7 @@ __global__ __launch_bounds__(64) void k_ul_solve2(UlSolve2Args a)
         __syncthreads();
     }
 }
+
 
 class ExactSparseKKT final : public KKTSolverBase {
 public:
@@ -907,11 +994,13 @@ public:
             PQ_HIP(hipMemsetAsync(ctl_.p + 2, 0, sizeof(int), st_));
             UlSolve2Args b;
             b.N = N_; b.n = n_; b.p = kp; b.m = km; b.ntask = ntask_; b.epoch = sepoch_;
-            b.perm = perm_.p; b.taskrec = taskrec_.p; b.task_rows = task_rows_.p; b.tsort = tsort_.p; b.tdep = tdep_.p; b.fs_u = fs_u_.p; b.fs_col = fs_col_.p;
+            b.perm = perm_.p; b.taskrec = taskrec_.p; b.task_rows = task_rows_.p; b.tsort = tsort_.p; b.tdep = tdep_.p; b.fs_u = fs_u_.p; b.fs_col = fs_col_.p; b.fs4 = reinterpret_cast<const int4*>(fs4_.p);
             b.Lp = Lp_.p; b.Li = Li_.p; b.Lsrc = Lsrc_.p; b.Tmask = Tmask_.p; b.mask_ptr = mask_ptr_.p; b.Lblock = Lblock_.p; b.Lx = Lx_.p; b.Dinv = Dinv_.p;
             b.rx = in_x; b.ry = in_y; b.rz = in_z; b.lx = lhs_x; b.ly = out_y; b.lz = out_z;
             b.xf = xf_.p; b.xz = xz_.p; b.xb = xb_.p; b.fdone = fdone_.p; b.bdone = bdone_.p; b.ticket = ctl_.p + 2; b.info = ctl_.p + 3;
-            hipLaunchKernelGGL(k_ul_solve2, dim3(sgrid_), dim3(64), 0, st_, b);
+            b.fwd_only = fwd_only_ ? 1 : 0;
+            b.ta_ptr = ta_ptr_.p; b.ta_rows = ta_rows_.p; b.Lsrc2 = Lsrc2_.p; b.xa_cap = xa_cap_;
+            hipLaunchKernelGGL(k_ul_solve2<32>, dim3(sgrid_), dim3(64), (size_t)(xa_cap_ + 64) * sizeof(double), st_, b);
         } else if (N_ > 0) {
         UlSolveArgs a;
         a.N = N_; a.n = n_; a.p = kp; a.m = km;
@@ -1031,6 +1120,36 @@ private:
         upload_vec(tk_kind_, U_.tk_kind, st_); upload_vec(tk_id_, U_.tk_id, st_); upload_vec(task_rows_, U_.task_rows, st_); upload_vec(dep_, U_.dep, st_);
         ntask_ = (int)U_.task_ptr.size() - 1; nticket_ = (int)U_.tk_kind.size();
         upload_vec(tsort_, U_.tsort, st_); upload_vec(tdep_, U_.tdep, st_); upload_vec(fs_u_, U_.fs_u, st_); upload_vec(fs_col_, U_.fs_col, st_); upload_vec(Lsrc_, U_.Lsrc, st_);
+        {   // the forward pass's records in step order: no second, dependent load for the mask
+            std::vector<int> f4((size_t)std::max<size_t>(U_.fs_u.size(), 1) * 4, 0);
+            for (int t = 0; t < ntask_; ++t)
+                for (int q = U_.fs_ptr[t]; q < U_.fs_ptr[t + 1]; ++q) {
+                    const unsigned long long mk = U_.Tmask[(size_t)U_.mask_ptr[t] + U_.fs_u[q]];
+                    f4[4 * (size_t)q] = U_.fs_u[q]; f4[4 * (size_t)q + 1] = U_.fs_col[q]; f4[4 * (size_t)q + 2] = (int)(unsigned)(mk & 0xffffffffull); f4[4 * (size_t)q + 3] = (int)(unsigned)(mk >> 32);
+                }
+            upload_vec(fs4_, f4, st_);
+        }
+        {   // the backward pass's lists: per task the rows above it that its columns touch (first seen first), per entry of L where its operand comes from
+            std::vector<int> tap((size_t)ntask_ + 1, 0), tar, src2(std::max<size_t>(U_.Lsrc.size(), 1), 0), seen((size_t)std::max(N_, 1), -1), slot((size_t)std::max(N_, 1), 0);
+            int longest = 0;
+            for (int t = 0; t < ntask_; ++t) {
+                const int base = (int)tar.size();
+                for (int g = U_.task_ptr[t]; g < U_.task_ptr[t + 1]; ++g) {
+                    const int j = U_.task_rows[g];
+                    for (int q = U_.Lp[j]; q < U_.Lp[j + 1]; ++q) {
+                        if (U_.Lsrc[q] >= 0) { src2[q] = U_.Lsrc[q]; continue; }
+                        const int r = U_.Li[q];
+                        if (seen[r] != t) { seen[r] = t; slot[r] = (int)tar.size() - base; tar.push_back(r); }
+                        src2[q] = 64 + slot[r];
+                    }
+                }
+                tap[t + 1] = (int)tar.size();
+                longest = std::max(longest, (int)tar.size() - base);
+            }
+            tar.push_back(0);  // (padding: a task without such rows still forms the address of its first one)
+            xa_cap_ = std::max(64, (longest + 63) / 64 * 64);
+            upload_vec(ta_ptr_, tap, st_); upload_vec(ta_rows_, tar, st_); upload_vec(Lsrc2_, src2, st_);
+        }
         upload_vec(Tmask_, U_.Tmask, st_); upload_vec(mask_ptr_, U_.mask_ptr, st_);
         xf_.alloc(N_ ? N_ : 1); xz_.alloc(N_ ? N_ : 1); xb_.alloc(N_ ? N_ : 1); xb_.zero(st_); xf_.zero(st_);
         fdone_.alloc(ntask_ ? ntask_ : 1); fdone_.zero(st_); bdone_.alloc(ntask_ ? ntask_ : 1); bdone_.zero(st_);
@@ -1114,7 +1233,13 @@ private:
         if (const char* t = debug_token("exact_grid")) grid_ = std::max(1, std::min(grid_, std::atoi(t)));
         {
             int per_cu_s = 1;
-            PQ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_s, k_ul_solve2, 64, 0));
+            const size_t sneed = (size_t)(xa_cap_ + 64) * sizeof(double);
+            if (sneed > (size_t)dev_lds) one_wave_solve_ = true;  // (a task whose columns reach more rows above it than LDS holds: the single-wave substitution)
+            else if (sneed > 48 * 1024) {
+                static PerDeviceOnce once_s;
+                once_s([&] { PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ul_solve2<32>), hipFuncAttributeMaxDynamicSharedMemorySize, dev_lds)); });
+            }
+            PQ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_s, k_ul_solve2<32>, 64, one_wave_solve_ ? 0 : sneed));
             sgrid_ = std::max(1, std::min(2 * ntask_, std::max(1, per_cu_s) * ncu));
             if (const char* tg = debug_token("exact_grid")) sgrid_ = std::max(1, std::min(sgrid_, std::atoi(tg)));
         }
@@ -1147,13 +1272,15 @@ private:
     sparse::UpLooking U_;
     CscOperators ops_;
     DBuf<int> perm_, Cp_, Ci_, diag_pos_, mapP_, mapA_, mapG_, Lp_, Li_, Lcol_, Rp_, Rcol_, Rpos_, tk_kind_, tk_id_, task_rows_, dep_, rowrec_, taskrec_, E4_, Etab_, done_, p1done_, ready_, ctl_, bgroup_;
-    DBuf<int> tsort_, tdep_, fs_u_, fs_col_, Lsrc_, mask_ptr_, fdone_, bdone_;
+    DBuf<int> tsort_, tdep_, fs_u_, fs_col_, fs4_, Lsrc_, mask_ptr_, fdone_, bdone_, ta_ptr_, ta_rows_, Lsrc2_;
+    int xa_cap_ = 64;
     DBuf<unsigned long long> Emask_, Tmask_;
     DBuf<double> xf_, xz_, xb_;
     DBuf<long long> trace_;
     DBuf<int> prog_;
     bool serial_path_ = debug_token("exact_serial_path") != nullptr;  // debugging aid: one path pass per task (the first form) instead of one per row
     int sepoch_ = 0, sgrid_ = 1;
+    bool fwd_only_ = debug_token("exact_fwd_only") != nullptr;  // debugging aid (timing): the backward pass of the substitution skipped
     bool one_wave_solve_ = debug_token("exact_solve1") != nullptr;  // debugging aid: the single-wave substitution of the first version
     DBuf<double> vals_, Lx_, D_, Dinv_, Ystash_, Pstash_, Dinit_, Lblock_, yglob_, xglob_;
     HBuf<int> ctl_h_;
