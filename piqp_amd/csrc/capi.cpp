@@ -465,8 +465,20 @@ int pq_sparse_uplooking_plan(const pq_sparse_data* data, int nitems, const int* 
         sparse::UpLooking U;
         sparse::analyse_uplooking(S, data, U);
         const sparse::IVec stats = {(int)U.nnzL, (int)(U.task_ptr.size() - 1), U.height, (int)std::min<long long>(U.crit_steps, 2147483647LL), U.Cp[U.N], (int)U.tk_kind.size()};
+        sparse::IVec mode_stats;
         for (int q = 0; q < nitems; ++q) {
             const sparse::IVec* v = nullptr;
+            if (what[q] >= 100 && what[q] <= 103) {
+                // the plan of another KKT mode (what - 100: bit 0 equalities eliminated, bit 1 inequalities eliminated): {N, nnz(L), kiloflops of the factorisation}
+                sparse::Symbolic Sm;
+                sparse::analyse_kkt_pattern(data, what[q] - 100, Sm);
+                sparse::UpLooking Um;
+                sparse::analyse_uplooking(Sm, data, Um);
+                mode_stats = {Um.N, (int)std::min<long long>(Um.nnzL, 2147483647LL), (int)std::min(Um.flops / 1e3, 2147483647.0)};
+                len[q] = 3;
+                if (out && out[q]) std::copy(mode_stats.begin(), mode_stats.end(), (int*)out[q]);
+                continue;
+            }
             switch (what[q]) {
             case 0: v = &stats; break;
             case 1: v = &U.perm; break;

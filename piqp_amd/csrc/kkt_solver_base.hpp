@@ -99,6 +99,6 @@ KKTSolverBase* make_dense_kkt(const pq_dense_data* data, int kkt_solver, int dev
 KKTSolverBase* make_sparse_kkt(const pq_sparse_data* data, int kkt_solver, int device);
 KKTSolverBase* make_multistage_kkt(const pq_sparse_data* data, int device);
 KKTSolverBase* make_multifrontal_kkt(const pq_sparse_data* data, int mode, int device);  // sparse_kkt.hip: the supernodal multifrontal engine, any KKTMode
-KKTSolverBase* make_exact_sparse_kkt(const pq_sparse_data* data, int mode, int device);  // sparse_exact.hip: any KKTMode in the reference's own elimination order
+KKTSolverBase* make_exact_sparse_kkt(const pq_sparse_data* data, int mode, int device, double max_flops = 0.0);  // sparse_exact.hip: any KKTMode in the reference's own elimination order
 
 }  // namespace pq

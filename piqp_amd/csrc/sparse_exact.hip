@@ -682,10 +682,33 @@ __device__ __forceinline__ bool ul_fwd_task(const UlSolve2Args& a, const int t, 
     double acc = o < a.n ? a.rx[o] : (o < a.n + a.p ? a.ry[o - a.n] : a.rz[o - a.n - a.p]);
     const double dinv = a.Dinv[row];
     int4 rec = a.fs4[fs0 + (lane < nsrc ? lane : 0)];
-    if (lane >= nsrc) { rec.x = 0; rec.z = 0; rec.w = 0; }
+    if (lane >= nsrc) { rec.x = 0; rec.z = 0; rec.w = 0; }  // (steps past the end: empty masks -- they run, and change nothing)
+    const double* __restrict__ tbase = a.Lblock + tb;        // row u of the task's table: tbase + u W, this lane's value at + lw
+    // one step: acc_t -= fl(L(t, j) x_j) for the task rows t of the mask.  No branch: both candidate operands are read (the x of an outside column from its
+    // lane of xc, the value of a path column from its lane of acc) and one is selected.
+    auto step = [&](const int ue, const int mlo, const int mhi, const double xc, const int sl, const double v) {
+        const int u = __builtin_amdgcn_readlane(ue, sl);
+        const unsigned long long m = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(mhi, sl) << 32) | (unsigned)__builtin_amdgcn_readlane(mlo, sl);
+        const double xo = readlane_d(xc, sl), xa = readlane_d(acc, (u - nU) & 63);
+        const double src = u < nU ? xo : xa;
+        const double r = msub(acc, v, src);
+        acc = __builtin_amdgcn_inverse_ballot_w64(m) ? r : acc;
+    };
+    if (nsrc <= 8) {
+        // most tasks are a row or two with a handful of columns: eight steps, nothing in flight behind them
+        double tv[8];
+#pragma unroll
+        for (int d = 0; d < 8; ++d) tv[d] = (tbase + (size_t)__builtin_amdgcn_readlane(rec.x, d) * W)[lw];
+        if (!wait()) return false;
+        const double xs8 = ldw(a.xf + rec.y);
+#pragma unroll
+        for (int d = 0; d < 8; ++d) step(rec.x, rec.z, rec.w, xs8, d, tv[d]);
+        if (lane < W) { stw(a.xf + row, acc); stw(a.xz + row, __dmul_rn(acc, dinv)); }
+        return true;
+    }
     double pf_v[PFS];
 #pragma unroll
-    for (int d = 0; d < PFS; ++d) pf_v[d] = a.Lblock[tb + __builtin_amdgcn_readlane(rec.x, d) * W + lw];
+    for (int d = 0; d < PFS; ++d) pf_v[d] = (tbase + (size_t)__builtin_amdgcn_readlane(rec.x, d) * W)[lw];
     if (!wait()) return false;
     double xs = ldw(a.xf + rec.y);   // (an outside column is final: its task was waited for; a path column's value is taken from its lane instead)
     for (int base = 0; base < nsrc; base += 64) {
@@ -703,19 +726,12 @@ __device__ __forceinline__ bool ul_fwd_task(const UlSolve2Args& a, const int t, 
             if (half * 32 < ns) {
 #pragma unroll
                 for (int d = 0; d < PFS; ++d) {
-                    const int s = half * 32 + d;
-                    const int u = __builtin_amdgcn_readlane(ue, s);
-                    const unsigned long long m = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(mhi, s) << 32) | (unsigned)__builtin_amdgcn_readlane(mlo, s);
+                    const int sl = half * 32 + d;
                     const double v = pf_v[d];
                     // refill: the table row 32 steps ahead -- of this chunk (first half) or of the next one (second half)
-                    pf_v[d] = a.Lblock[tb + __builtin_amdgcn_readlane(half == 0 ? ue : nrec.x, (s + 32) & 63) * W + lw];
-                    if (s < ns) {
-                        const double src = u < nU ? readlane_d(xcur, s) : readlane_d(acc, (u - nU) & 63);
-                        if (__builtin_amdgcn_inverse_ballot_w64(m)) acc = msub(acc, v, src);
-                    }
+                    pf_v[d] = (tbase + (size_t)__builtin_amdgcn_readlane(half == 0 ? ue : nrec.x, (sl + 32) & 63) * W)[lw];
+                    step(ue, mlo, mhi, xcur, sl, v);
                 }
-            } else {
-                // (a short last chunk: nothing to compute in this half, and nothing follows)
             }
         }
         rec = nrec; xs = nxs;
@@ -877,14 +893,16 @@ __global__ __launch_bounds__(64) void k_ul_solve2(UlSolve2Args a)
 
 class ExactSparseKKT final : public KKTSolverBase {
 public:
-    ExactSparseKKT(const pq_sparse_data* d, int mode, int device) : dev_(device), mode_(mode)
+    struct TooCostly {};  // thrown by the constructor before anything is allocated: the factorisation has more flops than the caller's limit
+    ExactSparseKKT(const pq_sparse_data* d, int mode, int device, double max_flops) : dev_(device), mode_(mode)
     {
         if (d->mem != PQ_MEM_HOST) throw std::runtime_error("sparse data must be host-resident");
-        PQ_HIP(hipSetDevice(dev_));
-        PQ_HIP(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
         sparse::Symbolic S;
         sparse::analyse_kkt_pattern(d, mode_, S);
         sparse::analyse_uplooking(S, d, U_);
+        if (max_flops > 0.0 && U_.flops > max_flops) throw TooCostly{};
+        PQ_HIP(hipSetDevice(dev_));
+        PQ_HIP(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
         n_ = U_.n; p_ = U_.p; m_ = U_.m; N_ = U_.N;
         if (mode_ != 0) {
             // eliminated blocks: entry -> value index of P K P' and the product-term lists (kkt_all_eliminated.hpp:184-223)
@@ -1289,6 +1307,14 @@ private:
 
 }  // namespace
 
-KKTSolverBase* make_exact_sparse_kkt(const pq_sparse_data* data, int mode, int device) { return new ExactSparseKKT(data, mode, device); }
+// max_flops > 0: nullptr when the factorisation would take more flops than that (the caller then builds the multifrontal engine)
+KKTSolverBase* make_exact_sparse_kkt(const pq_sparse_data* data, int mode, int device, double max_flops)
+{
+    try {
+        return new ExactSparseKKT(data, mode, device, max_flops);
+    } catch (const ExactSparseKKT::TooCostly&) {
+        return nullptr;
+    }
+}
 
 }  // namespace pq

@@ -3584,15 +3584,22 @@ KKTSolverBase* make_sparse_kkt(const pq_sparse_data* data, int kkt_solver, int d
     case PQ_SPARSE_MULTISTAGE: return make_multistage_kkt(data, device);
     case PQ_SPARSE_LDLT: case PQ_SPARSE_LDLT_EQ_COND: case PQ_SPARSE_LDLT_INEQ_COND: case PQ_SPARSE_LDLT_COND: {
         // Two engines behind the reference's sparse_ldlt family: the reference-order up-looking LDLt (sparse_exact.hip: L, D and the solves bitwise
-        // the reference's, so that rounding-decided trajectories are the reference's too) for KKT systems up to PIQP_AMD_EXACT_MAX_N rows (default 8192: every
-        // trajectory-sensitive netlib / Maros-Meszaros problem), the supernodal multifrontal one above.  PIQP_AMD_SPARSE_LDLT=exact|multifrontal forces one.
+        // the reference's, so that rounding-decided trajectories are the reference's too) for KKT systems up to PIQP_AMD_EXACT_MAX_N rows (default 8192) whose
+        // factorisation takes up to PIQP_AMD_EXACT_MAX_FLOPS flops (default 4e7) -- every netlib / Maros-Meszaros problem of that size (the largest, STCQP2, takes
+        // 3.3e7); that engine is a chain of ordered operations, and on denser systems (the reference's dense-vs-sparse benchmark at dim >= 256: 4.5e7 flops and up) the
+        // supernodal multifrontal engine is several times to 20 x faster.  PIQP_AMD_SPARSE_LDLT=exact|multifrontal forces one.
         const int mode = kkt_solver - PQ_SPARSE_LDLT;  // KKTMode bits: 1 = equalities eliminated, 2 = inequalities eliminated
         const char* eng = std::getenv("PIQP_AMD_SPARSE_LDLT");
         const char* mx = std::getenv("PIQP_AMD_EXACT_MAX_N");
         const long long max_n = mx ? std::atoll(mx) : 8192;
         const long long N = (long long)data->n + ((mode & 1) ? 0 : data->p) + ((mode & 2) ? 0 : data->m);
         const bool exact = eng ? std::string(eng) == "exact" : N <= max_n;
-        if (exact) return make_exact_sparse_kkt(data, mode, device);
+        if (exact) {
+            const char* mf = std::getenv("PIQP_AMD_EXACT_MAX_FLOPS");
+            // (the condensed modes' systems are denser -- nl_czprob 2.1e9 flops, eleven fixtures above 2e8 -- and keep their bitwise contract too: limit 3e9 there)
+            const double max_flops = eng ? 0.0 : (mf ? std::atof(mf) : (mode == 0 ? 4e7 : 3e9));
+            if (KKTSolverBase* k = make_exact_sparse_kkt(data, mode, device, max_flops)) return k;
+        }
         return new SparseKKT(data, mode, device);
     }
     case PQ_SPARSE_LDLT_EXACT: return make_exact_sparse_kkt(data, 0, device);
