@@ -956,18 +956,20 @@ __device__ __forceinline__ void wave_lds_sync()
 }
 
 // 1/sqrt(d) to ~1 ulp without the IEEE sqrt + divide chains (two Newton steps on v_rsq_f64)
+// PIVOT_NEWTON Newton steps on the hardware's reciprocal (square root): tools/ub/rsq_accuracy.hip measures what one and two steps leave
+constexpr int PIVOT_NEWTON = 2;  // (one step: 37 / 20 ulp and NO change in the cycles of the 128-block -- 55 793 against 56 100 -- the loop is bound by instruction issue: round 5)
 __device__ __forceinline__ double rsqrt_newton(double d)
 {
     double y = __builtin_amdgcn_rsq(d);
     y = y * (1.5 - 0.5 * d * y * y);
-    y = y * (1.5 - 0.5 * d * y * y);
+    if (PIVOT_NEWTON > 1) y = y * (1.5 - 0.5 * d * y * y);
     return y;
 }
 __device__ __forceinline__ double rcp_newton(double d)
 {
     double y = __builtin_amdgcn_rcp(d);
     y = y * (2.0 - d * y);
-    y = y * (2.0 - d * y);
+    if (PIVOT_NEWTON > 1) y = y * (2.0 - d * y);
     return y;
 }
 
