@@ -297,6 +297,25 @@ __device__ __forceinline__ bool spin_until_ge(const int* flag, int want)
     return true;
 }
 
+// a word that has not been written in this factorisation: a quiet NaN no computation produces (hardware NaNs are canonical, propagated ones carry their
+// operand's payload); k_ul_fill_sent puts it into D and into the tasks' tables before every factorisation
+constexpr long long UL_SENT = 0x7ff8dead5eed0001ll;
+__global__ void k_ul_fill_sent(size_t n, double* __restrict__ p)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = __longlong_as_double(UL_SENT);
+}
+__device__ __forceinline__ bool poll_value(const double* p, double& out)
+{
+    long long spins = 0;
+    for (;;) {
+        const double v = ldw(p);
+        if (__double_as_longlong(v) != UL_SENT) { out = v; return true; }
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > (1ll << 26)) return false;
+    }
+}
+
 // ROW PASS of row k (ldlt.hpp:121-163): the entries of row k in the columns outside the row's task, in the reference's order.  A row that is a task of its own is
 // finished here; for a row on a longer path the updates into the path's rows are left to the path pass (E4.z counts only the entries of a column above them), the
 // values y_i, the products l_ki y_i and the initial values of the path columns go to Ystash / Pstash / Dinit, the quotients also into the task's table.
@@ -538,7 +557,6 @@ __device__ __forceinline__ bool ul_path_row(const UlFactorArgs& a, const int k, 
     wave_sync();
     (void)s_pos;
     const unsigned long long below = j >= 64 ? ~0ull : ((1ull << j) - 1ull);  // path rows under row k
-    const int done_word = (a.epoch << 8) | 127;
     for (int base = 0; base < en; base += 64) {
         const int ns = min(64, en - base);
         const UlChunk ch = ul_load_chunk(a, es + base, ns, es, lane);
@@ -560,21 +578,23 @@ __device__ __forceinline__ bool ul_path_row(const UlFactorArgs& a, const int k, 
                         src = readlane_d(ch.ys, s & 63);
                         term = readlane_d(ch.ps, s & 63);
                     } else {
+                        // A path column c0.  What this row needs from the rows below arrives AS VALUES (round 5): D of row c0 and, for the rows c between c0 and
+                        // this one that hold an entry in column c0, their quotient L(c, c0) -- words that hold UL_SENT until their row stores them (k_ul_fill_sent
+                        // before every factorisation), polled with the same loads that fetch them: one round trip per hand-over instead of flag, value, drained
+                        // store, flag, value.  This row's own quotient goes out the same way, at once.
                         const int c0 = u - nU;
                         src = readlane_d(acc, c0 & 63);
                         const int row0 = __builtin_amdgcn_readlane(rowl, c0 & 63);
-                        if (!spin_until_ge(a.prog + row0, done_word)) return false;
-                        const double D0 = ldw(a.D + row0);
+                        double D0;
+                        if (!poll_value(a.D + row0, D0)) return false;
                         const double l = __ddiv_rn(src, D0);
                         term = __dmul_rn(l, src);
-                        stw(a.Lx + __builtin_amdgcn_readlane(ch.pos, s & 63), l);
                         stw(a.Lblock + tb + u * W + j, l);
-                        drain_stores();
-                        stf(a.prog + k, (a.epoch << 8) | (c0 + 1));
-                        // the rows between c0 and this one that hold an entry in column c0 must have published it
-                        bool okw = bit ? spin_until_ge(a.prog + rowl, (a.epoch << 8) | (c0 + 1)) : true;
+                        stw(a.Lx + __builtin_amdgcn_readlane(ch.pos, s & 63), l);
+                        double vv = 0.0;
+                        const bool okw = bit ? poll_value(a.Lblock + tb + u * W + lw, vv) : true;
                         if (__ballot(!okw)) return false;
-                        v = ldw(a.Lblock + tb + u * W + lw);
+                        v = vv;
                     }
                     if (bit) acc = msub(acc, v, src);
                     Dk = __dsub_rn(Dk, term);
@@ -583,12 +603,11 @@ __device__ __forceinline__ bool ul_path_row(const UlFactorArgs& a, const int k, 
         }
     }
     if (lane == 0) {
-        stw(a.D + k, Dk);
+        stw(a.D + k, Dk);   // (the rows above poll this word)
         a.Dinv[k] = __ddiv_rn(1.0, Dk);
         if (Dk == 0.0) atomicMin(a.info, k);
     }
-    drain_stores();
-    stf(a.prog + k, done_word);
+    drain_stores();  // (the task's last row is followed by its `done` word, which other tasks take as "everything of this row is there")
     return true;
 }
 
@@ -979,6 +998,8 @@ public:
         a.yglob = yglob_.p;
         a.trace = trace_.n > 1 ? trace_.p : nullptr;
         if (N_ > 0) {
+            hipLaunchKernelGGL(k_ul_fill_sent, dim3((unsigned)((D_.n + 255) / 256)), dim3(256), 0, st_, D_.n, D_.p);
+            hipLaunchKernelGGL(k_ul_fill_sent, dim3((unsigned)((Lblock_.n + 255) / 256)), dim3(256), 0, st_, Lblock_.n, Lblock_.p);
             if (lds_y_) hipLaunchKernelGGL(k_ul_factor<true>, dim3(grid_), dim3(64), (size_t)N_ * sizeof(double), st_, a);
             else hipLaunchKernelGGL(k_ul_factor<false>, dim3(grid_), dim3(64), 0, st_, a);
         }
@@ -1182,7 +1203,7 @@ private:
                 // task's rows one after the other (ul_path) costs ~0.18 us per entry: short rows (chains of a few entries, STADAT-like) go to the latter
                 long long task_entries = 0;
                 for (int q = 0; q < W; ++q) { const int kk = U_.task_rows[rb + q]; task_entries += U_.Rp[kk + 1] - U_.Rp[kk]; }
-                const bool serial_task = serial_path_ || task_entries < 17ll * W;
+                const bool serial_task = serial_path_ || task_entries < (long long)serial_below_ * W;
                 taskrec[8 * t] = rb; taskrec[8 * t + 1] = W; taskrec[8 * t + 2] = U_.task_nU[t]; taskrec[8 * t + 3] = U_.tab_ptr[t];
                 taskrec[8 * t + 4] = U_.fs_ptr[t]; taskrec[8 * t + 5] = U_.tdep_ptr[t]; taskrec[8 * t + 6] = U_.tdep_ptr[t + 1] - U_.tdep_ptr[t]; taskrec[8 * t + 7] = U_.tparent[t];
                 for (int q = 0; q < W; ++q) {
@@ -1296,6 +1317,9 @@ private:
     DBuf<double> xf_, xz_, xb_;
     DBuf<long long> trace_;
     DBuf<int> prog_;
+    // tasks with fewer entries per row than this run their path pass on ONE wave (ul_path).  0 since the rows of a task hand over by values (one round trip per
+    // row): side by side wins at every row length measured (QAFIRO 0.09 -> 0.05 ms, finnis 0.39 -> 0.28, STADAT1 7.9 -> 6.7; 17 before, when a hand-over cost five)
+    int serial_below_ = debug_token("exact_serial_below") ? std::atoi(debug_token("exact_serial_below")) : 0;
     bool serial_path_ = debug_token("exact_serial_path") != nullptr;  // debugging aid: one path pass per task (the first form) instead of one per row
     int sepoch_ = 0, sgrid_ = 1;
     bool fwd_only_ = debug_token("exact_fwd_only") != nullptr;  // debugging aid (timing): the backward pass of the substitution skipped
