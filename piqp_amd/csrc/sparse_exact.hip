@@ -270,6 +270,7 @@ struct UlSolve2Args {
     int fwd_only;
     const int *ta_ptr, *ta_rows, *Lsrc2;  // backward pass: per task the rows above it that its columns touch; per entry of L its operand (lane of the task, or 64 + list index)
     int xa_cap;                           // doubles of LDS for the longest such list (a multiple of 64)
+    long long* trace;                     // debugging aid (PIQP_AMD_DEBUG=exact_trace), nullable: per ticket 4 x wall_clock64: drawn, waits over, done; [3] = workgroup
 };
 
 __device__ __forceinline__ double ldw(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -764,6 +765,26 @@ __device__ __forceinline__ bool ul_fwd_task(const UlSolve2Args& a, const int t, 
 __device__ __forceinline__ double lds_chain_sub(double s, const double* __restrict__ p, int cnt)
 {
     typedef double d2 __attribute__((ext_vector_type(2)));
+    if (cnt == 64) {
+        // a full batch (the columns of hundreds of entries are made of these): ONE straight run of instructions, the reads of the next eight terms requested
+        // before the current eight are subtracted -- in a loop every round waits for its own reads (~100 cycles of LDS latency per eight terms, more than the
+        // eight subtractions take)
+        d2 t[4], n[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) t[q] = *reinterpret_cast<const d2*>(p + 2 * q);
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            if (g < 7) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) n[q] = *reinterpret_cast<const d2*>(p + 8 * (g + 1) + 2 * q);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { s = __dsub_rn(s, t[q].x); s = __dsub_rn(s, t[q].y); }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) t[q] = n[q];
+        }
+        return s;
+    }
     int l = 0;
     for (; l + 8 <= cnt; l += 8) {
         const d2 t0 = *reinterpret_cast<const d2*>(p + l), t1 = *reinterpret_cast<const d2*>(p + l + 2), t2 = *reinterpret_cast<const d2*>(p + l + 4),
@@ -881,12 +902,14 @@ __global__ __launch_bounds__(64) void k_ul_solve2(UlSolve2Args a)
         __syncthreads();
         if (tk >= 2 * a.ntask) break;
         bool ok = true;
+        if (a.trace && lane == 0) { a.trace[4 * (size_t)tk] = wall_clock64(); a.trace[4 * (size_t)tk + 3] = blockIdx.x; }
         if (tk < a.ntask) {
             const int t = a.tsort[tk];
             const int d0 = a.taskrec[8 * t + 5], dn = a.taskrec[8 * t + 6];
             ok = ul_fwd_task<PFS>(a, t, lane, [&]() {
                 bool w = true;
                 for (int c = lane; c < dn; c += 64) w &= spin_until(a.fdone + a.tdep[d0 + c], a.epoch);
+                if (a.trace && lane == 0) a.trace[4 * (size_t)tk + 1] = wall_clock64();
                 return __ballot(!w) == 0;
             });
             if (ok) {
@@ -897,13 +920,18 @@ __global__ __launch_bounds__(64) void k_ul_solve2(UlSolve2Args a)
             const int t = a.tsort[2 * a.ntask - 1 - tk];
             const int parent = a.taskrec[8 * t + 7];
             if (a.fwd_only) ok = __ballot(!spin_until(parent >= 0 ? a.bdone + parent : a.fdone + t, a.epoch)) == 0;  // (debugging aid: the forward pass alone, for timing)
-            else ok = ul_bwd_task(a, t, lane, [&]() { return __ballot(!spin_until(parent >= 0 ? a.bdone + parent : a.fdone + t, a.epoch)) == 0; }, s_xa, s_pr);
+            else ok = ul_bwd_task(a, t, lane, [&]() {
+                const bool w = spin_until(parent >= 0 ? a.bdone + parent : a.fdone + t, a.epoch);
+                if (a.trace && lane == 0) a.trace[4 * (size_t)tk + 1] = wall_clock64();
+                return __ballot(!w) == 0;
+            }, s_xa, s_pr);
             if (ok) {
                 drain_stores();
                 stf(a.bdone + t, a.epoch);
             }
         }
         if (!ok) { if (lane == 0) atomicMin(a.info, -2); break; }
+        if (a.trace && lane == 0) a.trace[4 * (size_t)tk + 2] = wall_clock64();
         if (lane == 0) s_task = atomicAdd(a.ticket, 1);
         __syncthreads();
     }
@@ -1039,6 +1067,7 @@ public:
             b.xf = xf_.p; b.xz = xz_.p; b.xb = xb_.p; b.fdone = fdone_.p; b.bdone = bdone_.p; b.ticket = ctl_.p + 2; b.info = ctl_.p + 3;
             b.fwd_only = fwd_only_ ? 1 : 0;
             b.ta_ptr = ta_ptr_.p; b.ta_rows = ta_rows_.p; b.Lsrc2 = Lsrc2_.p; b.xa_cap = xa_cap_;
+            b.trace = strace_.n > 1 ? strace_.p : nullptr;
             hipLaunchKernelGGL(k_ul_solve2<32>, dim3(sgrid_), dim3(64), (size_t)(xa_cap_ + 64) * sizeof(double), st_, b);
         } else if (N_ > 0) {
         UlSolveArgs a;
@@ -1098,6 +1127,10 @@ public:
         case 11: if (out_host) { for (int k = 0; k < N_; ++k) ((int*)out_host)[k] = U_.Rp[k + 1] - U_.Rp[k]; } return N_;
         case 12: if (out_host) std::copy(U_.task_ptr.begin(), U_.task_ptr.end(), (int*)out_host); return ntask_ + 1;
         case 13: if (out_host) std::copy(U_.task_rows.begin(), U_.task_rows.end(), (int*)out_host); return N_;
+        case 14: if (out_host && strace_.n > 1) PQ_HIP(hipMemcpy(out_host, strace_.p, sizeof(long long) * strace_.n, hipMemcpyDeviceToHost)); return strace_.n > 1 ? (long long)strace_.n : 0;  // the last solve's timeline
+        case 15: if (out_host) std::copy(U_.tsort.begin(), U_.tsort.end(), (int*)out_host); return ntask_;
+        case 16: if (out_host) std::copy(U_.task_nU.begin(), U_.task_nU.end(), (int*)out_host); return ntask_;
+        case 17: if (out_host) std::copy(U_.tparent.begin(), U_.tparent.end(), (int*)out_host); return ntask_;
         default: throw std::runtime_error("exact_factor: unknown item");
         }
     }
@@ -1283,6 +1316,7 @@ private:
             if (const char* tg = debug_token("exact_grid")) sgrid_ = std::max(1, std::min(sgrid_, std::atoi(tg)));
         }
         trace_.alloc(debug_token("exact_trace") ? (size_t)4 * std::max(nticket_, 1) : 1);
+        strace_.alloc(debug_token("exact_trace") ? (size_t)8 * std::max(ntask_, 1) : 1);
         yglob_.alloc(lds_y_ ? 1 : (size_t)grid_ * (size_t)N_);
         xglob_.alloc(lds_x_ ? 1 : (size_t)std::max(N_, 1));
         stream_wait(st_);
@@ -1315,7 +1349,7 @@ private:
     int xa_cap_ = 64;
     DBuf<unsigned long long> Emask_, Tmask_;
     DBuf<double> xf_, xz_, xb_;
-    DBuf<long long> trace_;
+    DBuf<long long> trace_, strace_;
     DBuf<int> prog_;
     // tasks with fewer entries per row than this run their path pass on ONE wave (ul_path).  0 since the rows of a task hand over by values (one round trip per
     // row): side by side wins at every row length measured (QAFIRO 0.09 -> 0.05 ms, finnis 0.39 -> 0.28, STADAT1 7.9 -> 6.7; 17 before, when a hand-over cost five)

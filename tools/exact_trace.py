@@ -44,3 +44,34 @@ for kd, name in ((0, "row pass"), (1, "path pass")):
 order = np.argsort(tr[:, 2])[-12:]
 for tk in order:
     print(f"   ticket {tk:5d} kind {kind[tk]} id {ids[tk]:5d} drawn {us(tr[tk, 0]):8.1f} ready {us(tr[tk, 1]):8.1f} done {us(tr[tk, 2]):8.1f}  steps {rlen[ids[tk]] if kind[tk] == 0 else rlen[trows[tptr[ids[tk]]:tptr[ids[tk] + 1]]].sum()}")
+
+# ---- the substitution (k_ul_solve2): tickets 0 .. ntask-1 forward passes in tsort order, ntask .. 2 ntask-1 backward passes in the opposite order
+rx, ry, rz = rng.standard_normal(d.n), rng.standard_normal(d.p), rng.standard_normal(d.m)
+for _ in range(3):
+    k.solve(rx, ry, rz)
+st = item(14, np.int64).reshape(-1, 4)
+tsort, nU, tpar, Lp = item(15, np.int32), item(16, np.int32), item(17, np.int32), item(1, np.int32)
+nt = len(tsort)
+W = np.diff(tptr)
+colent = np.diff(Lp)
+bent = np.array([colent[trows[tptr[t]:tptr[t + 1]]].sum() for t in range(nt)])
+s0 = st[:, 0].min()
+su = lambda c: (c - s0) / 100.0
+print(f"substitution: {2 * nt} tickets, total {su(st[:, 2].max()):.1f} us; forward done at {su(st[:nt, 2].max()):.1f} us, first backward ready at {su(st[nt:, 1].min()):.1f} us")
+for name, sl, task_of, size in (("forward", slice(0, nt), lambda tk: tsort[tk], lambda t: nU[t] + W[t]), ("backward", slice(nt, 2 * nt), lambda tk: tsort[2 * nt - 1 - tk], lambda t: bent[t])):
+    tks = np.arange(2 * nt)[sl]
+    tasks = np.array([task_of(tk) for tk in tks])
+    wait = (st[sl, 1] - st[sl, 0]) / 100.0; work = (st[sl, 2] - st[sl, 1]) / 100.0
+    sz = np.array([size(t) for t in tasks])
+    A = np.vstack([np.ones(len(tks)), W[tasks], sz]).T
+    coef = np.linalg.lstsq(A, work, rcond=None)[0]
+    print(f"  {name}: work sum {work.sum():.0f} us, mean {work.mean():.2f}, max {work.max():.1f}; fit work = {coef[0]:.2f} us + {1e3 * coef[1]:.0f} ns x rows + {1e3 * coef[2]:.1f} ns x {'table rows' if name == 'forward' else 'entries'}")
+    big = np.argsort(work)[-6:]
+    for i in big:
+        t = tasks[i]
+        print(f"     task {t:5d} W {W[t]:2d} size {sz[i]:6d}: drawn {su(st[tks[i], 0]):8.1f} ready {su(st[tks[i], 1]):8.1f} done {su(st[tks[i], 2]):8.1f}  work {work[i]:7.1f} us = {1e3 * work[i] / max(sz[i], 1):.0f} ns per unit")
+    # critical chain: follow the latest-finishing ticket back through what it waited for
+order = np.argsort(st[:, 2])[-8:]
+for tk in order:
+    t = tsort[tk] if tk < nt else tsort[2 * nt - 1 - tk]
+    print(f"   last: ticket {tk:5d} ({'fwd' if tk < nt else 'bwd'}) task {t:5d} W {W[t]:2d} drawn {su(st[tk, 0]):8.1f} ready {su(st[tk, 1]):8.1f} done {su(st[tk, 2]):8.1f}")
