@@ -23,3 +23,14 @@ timeout 300 python3 tools/time_exact.py 2>/dev/null > $O/r05_exact_engine_timing
 timeout 300 python3 tools/sqp_benchmarks.py > $O/r05_sqp_benchmarks.txt 2>/dev/null
 tail -2 $O/r05_sqp_benchmarks.txt | cut -c1-200
 timeout 600 python3 tools/mm_timing.py mm_ nl_ > $O/r05_mm_timing.txt 2>/dev/null; tail -17 $O/r05_mm_timing.txt | cut -c1-160
+timeout 900 python3 tools/dense_sparse_solver_benchmark.py > $O/r05_dense_sparse_solver_benchmark.txt 2>/dev/null; tail -4 $O/r05_dense_sparse_solver_benchmark.txt | cut -c1-160
+# stage partition, ranks sharing this one GPU through gloo (no scaling can be read off these: they show what each rank evaluates and that the results are bitwise)
+for b in multistage ldlt_cond; do
+  timeout 600 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node=2 --master-addr 127.0.0.1 --master-port 29811 tools/dist_c5.py --stages 800 --steps 3 --warmup 1 --backend $b --full-solve --refine 2>/dev/null | grep '^{' | tail -1 > $O/r05_sharded_solve_${b}_world2.json
+  python3 -c "
+import json,sys
+d=json.load(open('$O/r05_sharded_solve_${b}_world2.json'))
+print('$b world 2: bitwise', d['bitwise_equal_all_ranks'], 'residual eval ms single / partitioned', round(d['residual_eval_ms_single_gpu'],3), round(d['residual_eval_ms_partitioned'],3), 'step ms single / partitioned', round(d['single_gpu_ms_per_step'],3), round(d['ms_per_step'],3), d['sharded_solve'])
+" | cut -c1-400
+done
+timeout 300 python3 tools/exact_trace.py mm_QPILOTNO 2>/dev/null | cut -c1-220 > $O/r05_exact_engine_timeline.txt; tail -30 $O/r05_exact_engine_timeline.txt
