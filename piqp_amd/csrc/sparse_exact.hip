@@ -561,12 +561,9 @@ __device__ __forceinline__ bool ul_path_row(const UlFactorArgs& a, const int k, 
     for (int base = 0; base < en; base += 64) {
         const int ns = min(64, en - base);
         const UlChunk ch = ul_load_chunk(a, es + base, ns, es, lane);
-        double pf_v[UL_PFP], pf_D[UL_PFP];
-        // (D of the path column a step belongs to travels with the step's table row: lane c of rowl is path row c; a step in an outside column reads D of path row 0,
-        // which nobody uses)
-        auto drow = [&](const int sl) { const int uu = __builtin_amdgcn_readlane(ch.tab, sl); return __builtin_amdgcn_readlane(rowl, uu >= nU ? (uu - nU) & 63 : 0); };
+        double pf_v[UL_PFP];
 #pragma unroll
-        for (int d = 0; d < UL_PFP; ++d) { pf_v[d] = ldw(a.Lblock + tb + __builtin_amdgcn_readlane(ch.tab, d) * W + lw); pf_D[d] = ldw(a.D + drow(d)); }
+        for (int d = 0; d < UL_PFP; ++d) pf_v[d] = ldw(a.Lblock + tb + __builtin_amdgcn_readlane(ch.tab, d) * W + lw);
         for (int sb = 0; sb < ns; sb += UL_PFP) {
 #pragma unroll
             for (int d = 0; d < UL_PFP; ++d) {
@@ -574,9 +571,7 @@ __device__ __forceinline__ bool ul_path_row(const UlFactorArgs& a, const int k, 
                 const int u = __builtin_amdgcn_readlane(ch.tab, s & 63);
                 const unsigned long long m = (((unsigned long long)(unsigned)__builtin_amdgcn_readlane(ch.mhi, s & 63) << 32) | (unsigned)__builtin_amdgcn_readlane(ch.mlo, s & 63)) & below;
                 double v = pf_v[d];
-                const double Dpf = pf_D[d];
                 pf_v[d] = ldw(a.Lblock + tb + __builtin_amdgcn_readlane(ch.tab, (s + UL_PFP) & 63) * W + lw);
-                pf_D[d] = ldw(a.D + drow((s + UL_PFP) & 63));
                 if (s < ns) {
                     const bool bit = __builtin_amdgcn_inverse_ballot_w64(m);
                     double src, term;
@@ -591,16 +586,16 @@ __device__ __forceinline__ bool ul_path_row(const UlFactorArgs& a, const int k, 
                         const int c0 = u - nU;
                         src = readlane_d(acc, c0 & 63);
                         const int row0 = __builtin_amdgcn_readlane(rowl, c0 & 63);
-                        // (what was requested eight steps ago is usually there already: the rows below finished their steps in these columns long ago -- only a word
-                        // that still holds the sentinel is polled)
-                        double D0 = Dpf;
-                        if (__double_as_longlong(D0) == UL_SENT && !poll_value(a.D + row0, D0)) return false;
+                        double D0;
+                        if (!poll_value(a.D + row0, D0)) return false;
                         const double l = __ddiv_rn(src, D0);
                         term = __dmul_rn(l, src);
                         stw(a.Lblock + tb + u * W + j, l);
                         stw(a.Lx + __builtin_amdgcn_readlane(ch.pos, s & 63), l);
-                        double vv = v;
-                        const bool okw = (bit && __double_as_longlong(vv) == UL_SENT) ? poll_value(a.Lblock + tb + u * W + lw, vv) : true;
+                        // (measured and not kept: D and the quotients requested eight steps ahead with the table row and polled only while they still hold the
+                        // sentinel -- the extra loads cost more than the saved round trips: chain-mass 2.32 -> 2.48 ms, STADAT1 6.7 -> 7.3)
+                        double vv = 0.0;
+                        const bool okw = bit ? poll_value(a.Lblock + tb + u * W + lw, vv) : true;
                         if (__ballot(!okw)) return false;
                         v = vv;
                     }
