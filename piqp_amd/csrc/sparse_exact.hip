@@ -68,6 +68,16 @@ __device__ __forceinline__ double chain_sub(double s, const double pr, int cnt)
 // written and read with agent-scope 8-byte / 4-byte atomics (write-through `sc1` stores, `sc1` loads that bypass the reader's L1), the flag follows the payload after
 // s_waitcnt vmcnt(0), and the consumer's loads follow its successful poll.  Nothing else in these kernels is written by one wave and read by another.
 __device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// A word whose readers all run on the writer's XCD (round 5, per-XCD row queues): a plain store leaves the line in that XCD's L2, where the readers' L1-bypassing
+// loads (ldw) find it after an L2 round trip; a write-through (sc1) store drops the line and the same readers go out to the fabric (MI355X_MICROARCH.md,
+// "stores of each flavour").  Nothing on another XCD may read such a word before the launch ends.
+__device__ __forceinline__ void stl(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ int xcc_id()
+{
+    int x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(x));
+    return x & 7;
+}
 // fl(a - fl(x y)): product rounded, then the difference rounded ("force compiler to not use fma instruction", ldlt.hpp:151-153)
 __device__ __forceinline__ double msub(double a, double x, double y) { return __dsub_rn(a, __dmul_rn(x, y)); }
 
@@ -136,6 +146,8 @@ struct UlFactorArgs {
     const unsigned long long* Emask;
     double *Lx, *D, *Dinv, *Ystash, *Pstash, *Dinit, *Lblock;
     int *done, *p1done, *ready, *prog, *ticket, *info;
+    const int *xq_ptr, *xq_rows;  // per-XCD row queues (nullable: one queue of tickets): XCD q works rows xq_rows[xq_ptr[q] .. xq_ptr[q + 1]), ascending; a.ticket + 16 q counts
+    double* Dloc;                 // with the queues: D once more, stored plainly for the rows of the same task (same XCD) to poll
     int rowpar;     // 1: the path pass of a row follows its row pass on the same wave (ul_path_row); 0: one path pass per task (ul_path; PIQP_AMD_DEBUG=exact_serial_path)
     double* yglob;  // N doubles per workgroup when y does not fit LDS
     long long* trace;  // debugging aid (PIQP_AMD_DEBUG=exact_trace), nullable: per ticket 4 x wall_clock64 (100 MHz): drawn, waits over, done; [3] = workgroup
@@ -306,6 +318,11 @@ __global__ void k_ul_fill_sent(size_t n, double* __restrict__ p)
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = __longlong_as_double(UL_SENT);
 }
+// which XCD does a workgroup of a launch of this shape land on?  (the per-XCD queues are only used when every one of the eight gets workgroups)
+__global__ void k_ul_xcd_probe(int* __restrict__ count)
+{
+    if (threadIdx.x == 0) atomicAdd(count + xcc_id(), 1);
+}
 __device__ __forceinline__ bool poll_value(const double* p, double& out)
 {
     long long spins = 0;
@@ -386,7 +403,7 @@ __device__ __forceinline__ double ul_row(const UlFactorArgs& a, double* __restri
         const double l = __ddiv_rn(my_yi, Di);
         const double tp = __dmul_rn(l, my_yi);
         if (ext) stw(a.Lx + pos, l);
-        if (ext) stw(a.Lblock + tb + tabu * W + lanek, l);  // (the task's table holds every entry of its rows: the substitution reads L from there)
+        if (ext) { if (a.xq_ptr) stl(a.Lblock + tb + tabu * W + lanek, l); else stw(a.Lblock + tb + tabu * W + lanek, l); }  // (the task's table holds every entry of its rows: the substitution reads L from there; its readers inside this launch are rows of the same task)
         if (multi) {
             if (in) stw(a.Ystash + e, my_yi);
             if (ext) stw(a.Pstash + e, tp);
@@ -587,10 +604,10 @@ __device__ __forceinline__ bool ul_path_row(const UlFactorArgs& a, const int k, 
                         src = readlane_d(acc, c0 & 63);
                         const int row0 = __builtin_amdgcn_readlane(rowl, c0 & 63);
                         double D0;
-                        if (!poll_value(a.D + row0, D0)) return false;
+                        if (!poll_value((a.xq_ptr ? a.Dloc : a.D) + row0, D0)) return false;
                         const double l = __ddiv_rn(src, D0);
                         term = __dmul_rn(l, src);
-                        stw(a.Lblock + tb + u * W + j, l);
+                        if (a.xq_ptr) stl(a.Lblock + tb + u * W + j, l); else stw(a.Lblock + tb + u * W + j, l);
                         stw(a.Lx + __builtin_amdgcn_readlane(ch.pos, s & 63), l);
                         // (measured and not kept: D and the quotients requested eight steps ahead with the table row and polled only while they still hold the
                         // sentinel -- the extra loads cost more than the saved round trips: chain-mass 2.32 -> 2.48 ms, STADAT1 6.7 -> 7.3)
@@ -606,7 +623,8 @@ __device__ __forceinline__ bool ul_path_row(const UlFactorArgs& a, const int k, 
         }
     }
     if (lane == 0) {
-        stw(a.D + k, Dk);   // (the rows above poll this word)
+        if (a.xq_ptr) stl(a.Dloc + k, Dk);   // (the rows above poll this word)
+        stw(a.D + k, Dk);
         a.Dinv[k] = __ddiv_rn(1.0, Dk);
         if (Dk == 0.0) atomicMin(a.info, k);
     }
@@ -624,16 +642,23 @@ __global__ __launch_bounds__(64) void k_ul_factor(UlFactorArgs a)
     double* __restrict__ y = LDSY ? ul_sm : a.yglob + (size_t)blockIdx.x * a.N;
     const int lane = threadIdx.x;
     for (int tt = lane; tt < a.N; tt += 64) y[tt] = 0.0;
-    if (lane == 0) s_task = atomicAdd(a.ticket, 1);
+    // Per-XCD queues (round 5): the rows of a task are all in the queue of ONE XCD and a workgroup only draws from the queue of the XCD it runs on, so the words the
+    // rows of a task hand to one another stay in that XCD's L2.  Every queue is in ascending row order: the smallest unfinished row of the whole matrix has been
+    // drawn in its queue (everything before it there is finished) and waits for nothing -- progress never depends on another queue's workgroups.
+    const int xq = a.xq_ptr ? xcc_id() : 0;
+    const int qbeg = a.xq_ptr ? a.xq_ptr[xq] : 0, qcnt = a.xq_ptr ? a.xq_ptr[xq + 1] - qbeg : a.nticket;
+    int* const tcount = a.ticket + (a.xq_ptr ? 16 * xq : 0);
+    if (lane == 0) s_task = atomicAdd(tcount, 1);
     __syncthreads();
     // (the whole workgroup is one wave: __syncthreads() costs nothing and keeps the control flow around the ticket uniform for the compiler)
     for (int guard = 0; guard <= a.nticket; ++guard) {
-        const int tk = readfirst(s_task);
+        const int tq = readfirst(s_task);
         __syncthreads();
-        if (tk >= a.nticket) break;
+        if (tq >= qcnt) break;
+        const int tk = qbeg + tq;
         // (the next ticket is drawn when this one is done: a ticket drawn ahead sits parked for as long as the current task takes -- with rows that wait for
         // one another side by side that was 11 ms on CONT-050, the rows above spinning for a row whose ticket nobody worked on)
-        const int kind = a.tk_kind[tk], id = a.tk_id[tk];
+        const int kind = a.xq_ptr ? 0 : a.tk_kind[tk], id = a.xq_ptr ? a.xq_rows[tk] : a.tk_id[tk];
         bool ok = true;
         if (a.trace && lane == 0) { a.trace[4 * (size_t)tk] = wall_clock64(); a.trace[4 * (size_t)tk + 3] = blockIdx.x; }
         if (kind == 0) {
@@ -673,7 +698,7 @@ __global__ __launch_bounds__(64) void k_ul_factor(UlFactorArgs a)
         }
         if (!ok) { if (lane == 0) atomicMin(a.info, -2); break; }
         if (a.trace && lane == 0) a.trace[4 * (size_t)tk + 2] = wall_clock64();
-        if (lane == 0) s_task = atomicAdd(a.ticket, 1);
+        if (lane == 0) s_task = atomicAdd(tcount, 1);
         __syncthreads();
     }
 }
@@ -1017,18 +1042,21 @@ public:
         ++epoch_;
         ctl_h_.p[0] = 0; ctl_h_.p[1] = INT_MAX;
         PQ_HIP(hipMemcpyAsync(ctl_.p, ctl_h_.p, 2 * sizeof(int), hipMemcpyHostToDevice, st_));
+        if (xq_on_) PQ_HIP(hipMemsetAsync(xtick_.p, 0, sizeof(int) * 8 * 16, st_));
         UlFactorArgs a;
         a.N = N_; a.nticket = nticket_; a.epoch = epoch_;
         a.Cp = Cp_.p; a.Ci = Ci_.p; a.Cx = vals_.p;
         a.tk_kind = tk_kind_.p; a.tk_id = tk_id_.p; a.task_rows = task_rows_.p; a.rowrec = rowrec_.p; a.taskrec = taskrec_.p; a.dep = dep_.p;
         a.E4 = reinterpret_cast<const int4*>(E4_.p); a.Etab = Etab_.p; a.Li = Li_.p; a.Emask = Emask_.p;
         a.Lx = Lx_.p; a.D = D_.p; a.Dinv = Dinv_.p; a.Ystash = Ystash_.p; a.Pstash = Pstash_.p; a.Dinit = Dinit_.p; a.Lblock = Lblock_.p;
-        a.done = done_.p; a.p1done = p1done_.p; a.ready = ready_.p; a.prog = prog_.p; a.ticket = ctl_.p; a.info = ctl_.p + 1;
+        a.done = done_.p; a.p1done = p1done_.p; a.ready = ready_.p; a.prog = prog_.p; a.ticket = xq_on_ ? xtick_.p : ctl_.p; a.info = ctl_.p + 1;
+        a.xq_ptr = xq_on_ ? xq_ptr_.p : nullptr; a.xq_rows = xq_rows_.p; a.Dloc = Dloc_.p;
         a.rowpar = serial_path_ ? 0 : 1;
         a.yglob = yglob_.p;
         a.trace = trace_.n > 1 ? trace_.p : nullptr;
         if (N_ > 0) {
             hipLaunchKernelGGL(k_ul_fill_sent, dim3((unsigned)((D_.n + 255) / 256)), dim3(256), 0, st_, D_.n, D_.p);
+            if (xq_on_) hipLaunchKernelGGL(k_ul_fill_sent, dim3((unsigned)((Dloc_.n + 255) / 256)), dim3(256), 0, st_, Dloc_.n, Dloc_.p);
             hipLaunchKernelGGL(k_ul_fill_sent, dim3((unsigned)((Lblock_.n + 255) / 256)), dim3(256), 0, st_, Lblock_.n, Lblock_.p);
             if (lds_y_) hipLaunchKernelGGL(k_ul_factor<true>, dim3(grid_), dim3(64), (size_t)N_ * sizeof(double), st_, a);
             else hipLaunchKernelGGL(k_ul_factor<false>, dim3(grid_), dim3(64), 0, st_, a);
@@ -1124,8 +1152,8 @@ public:
         case 6: if (out_host && nnzK_) PQ_HIP(hipMemcpy(out_host, vals_.p, sizeof(double) * (size_t)nnzK_, hipMemcpyDeviceToHost)); return nnzK_;
         case 7: if (out_host) std::copy(U_.perm.begin(), U_.perm.end(), (int*)out_host); return N_;
         case 8: if (out_host && trace_.n > 1) PQ_HIP(hipMemcpy(out_host, trace_.p, sizeof(long long) * trace_.n, hipMemcpyDeviceToHost)); return trace_.n > 1 ? (long long)trace_.n : 0;  // PIQP_AMD_DEBUG=exact_trace
-        case 9: if (out_host) { std::copy(U_.tk_kind.begin(), U_.tk_kind.end(), (int*)out_host); } return nticket_;
-        case 10: if (out_host) { std::copy(U_.tk_id.begin(), U_.tk_id.end(), (int*)out_host); } return nticket_;
+        case 9: if (out_host) { if (xq_on_) std::fill((int*)out_host, (int*)out_host + N_, 0); else std::copy(U_.tk_kind.begin(), U_.tk_kind.end(), (int*)out_host); } return xq_on_ ? N_ : nticket_;  // (per-XCD queues: trace slot = position in xq_rows)
+        case 10: if (out_host) { if (xq_on_) std::copy(xq_rows_h_.begin(), xq_rows_h_.begin() + N_, (int*)out_host); else std::copy(U_.tk_id.begin(), U_.tk_id.end(), (int*)out_host); } return xq_on_ ? N_ : nticket_;
         case 11: if (out_host) { for (int k = 0; k < N_; ++k) ((int*)out_host)[k] = U_.Rp[k + 1] - U_.Rp[k]; } return N_;
         case 12: if (out_host) std::copy(U_.task_ptr.begin(), U_.task_ptr.end(), (int*)out_host); return ntask_ + 1;
         case 13: if (out_host) std::copy(U_.task_rows.begin(), U_.task_rows.end(), (int*)out_host); return N_;
@@ -1265,6 +1293,28 @@ private:
         D_.alloc(N_ ? N_ : 1); Dinv_.alloc(N_ ? N_ : 1); D_.zero(st_); Dinv_.zero(st_);
         done_.alloc(N_ ? N_ : 1); done_.zero(st_);
         ctl_.alloc(4); ctl_h_.alloc(4);
+        {   // per-XCD row queues: tasks in the order of their last rows, each to the queue with the least work so far (entries of its rows); rows ascending per queue
+            xq_on_ = !serial_path_ && debug_token("exact_one_queue") == nullptr;
+            std::vector<int> order((size_t)ntask_), qof((size_t)std::max(ntask_, 1), 0);
+            for (int t = 0; t < ntask_; ++t) order[t] = t;
+            std::sort(order.begin(), order.end(), [&](int x, int y) { return U_.task_rows[U_.task_ptr[x + 1] - 1] < U_.task_rows[U_.task_ptr[y + 1] - 1]; });
+            long long load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int t : order) {
+                long long w = 0;
+                for (int g = U_.task_ptr[t]; g < U_.task_ptr[t + 1]; ++g) { const int k = U_.task_rows[g]; w += 4 + (U_.Rp[k + 1] - U_.Rp[k]); }
+                int best = 0;
+                for (int q = 1; q < 8; ++q) if (load[q] < load[best]) best = q;
+                qof[t] = best; load[best] += w;
+            }
+            std::vector<int> qp(9, 0), qr((size_t)std::max(N_, 1), 0);
+            for (int k = 0; k < N_; ++k) qp[qof[U_.row_task[k]] + 1]++;
+            for (int q = 0; q < 8; ++q) qp[q + 1] += qp[q];
+            std::vector<int> fill(qp.begin(), qp.end() - 1);
+            for (int k = 0; k < N_; ++k) qr[fill[qof[U_.row_task[k]]]++] = k;  // (k ascending: every queue ascending)
+            upload_vec(xq_ptr_, qp, st_); upload_vec(xq_rows_, qr, st_); xq_rows_h_ = qr;
+            xtick_.alloc(8 * 16); xtick_.zero(st_);
+            Dloc_.alloc(N_ ? N_ : 1); Dloc_.zero(st_);
+        }
         {   // backward sweep groups: whole columns, last first, at most 64 entries each (a longer column alone)
             std::vector<int> g;
             int j = N_ - 1;
@@ -1305,6 +1355,16 @@ private:
         per_cu = std::max(1, per_cu);
         grid_ = std::max(1, std::min(nticket_, per_cu * ncu));  // every workgroup of the launch is resident: tasks are taken in row order and wait only for earlier ones
         if (const char* t = debug_token("exact_grid")) grid_ = std::max(1, std::min(grid_, std::atoi(t)));
+        if (xq_on_) {
+            // every XCD's queue needs workgroups of its own: at least 64 workgroups, and a probe launch of the same shape must find all eight XCDs served
+            grid_ = std::max(grid_, std::min(64, per_cu * ncu));
+            DBuf<int> cnt; cnt.alloc(8); cnt.zero(st_);
+            hipLaunchKernelGGL(k_ul_xcd_probe, dim3(grid_), dim3(64), 0, st_, cnt.p);
+            int h[8];
+            PQ_HIP(hipMemcpyAsync(h, cnt.p, sizeof(h), hipMemcpyDeviceToHost, st_));
+            stream_wait(st_);
+            for (int q = 0; q < 8; ++q) if (h[q] < 1) xq_on_ = false;  // (another partition mode, fewer XCDs: one queue of tickets as before)
+        }
         {
             int per_cu_s = 1;
             const size_t sneed = (size_t)(xa_cap_ + 64) * sizeof(double);
@@ -1352,6 +1412,10 @@ private:
     DBuf<unsigned long long> Emask_, Tmask_;
     DBuf<double> xf_, xz_, xb_;
     DBuf<long long> trace_, strace_;
+    DBuf<int> xq_ptr_, xq_rows_, xtick_;
+    DBuf<double> Dloc_;
+    bool xq_on_ = false;
+    std::vector<int> xq_rows_h_;
     DBuf<int> prog_;
     // tasks with fewer entries per row than this run their path pass on ONE wave (ul_path).  0 since the rows of a task hand over by values (one round trip per
     // row): side by side wins at every row length measured (QAFIRO 0.09 -> 0.05 ms, finnis 0.39 -> 0.28, STADAT1 7.9 -> 6.7; 17 before, when a hand-over cost five)
