@@ -585,11 +585,11 @@ __device__ __forceinline__ bool ul_path_row(const UlFactorArgs& a, const int k, 
 #pragma unroll
             for (int d = 0; d < UL_PFP; ++d) {
                 const int s = sb + d;
-                const int u = __builtin_amdgcn_readlane(ch.tab, s & 63);
-                const unsigned long long m = (((unsigned long long)(unsigned)__builtin_amdgcn_readlane(ch.mhi, s & 63) << 32) | (unsigned)__builtin_amdgcn_readlane(ch.mlo, s & 63)) & below;
-                double v = pf_v[d];
-                pf_v[d] = ldw(a.Lblock + tb + __builtin_amdgcn_readlane(ch.tab, (s + UL_PFP) & 63) * W + lw);
-                if (s < ns) {
+                if (s < ns) {  // (a row of three entries runs three steps, not eight: what follows its last step is on the chain of hand-overs)
+                    const int u = __builtin_amdgcn_readlane(ch.tab, s & 63);
+                    const unsigned long long m = (((unsigned long long)(unsigned)__builtin_amdgcn_readlane(ch.mhi, s & 63) << 32) | (unsigned)__builtin_amdgcn_readlane(ch.mlo, s & 63)) & below;
+                    double v = pf_v[d];
+                    pf_v[d] = ldw(a.Lblock + tb + __builtin_amdgcn_readlane(ch.tab, (s + UL_PFP) & 63) * W + lw);
                     const bool bit = __builtin_amdgcn_inverse_ballot_w64(m);
                     double src, term;
                     if (u < nU) {
@@ -1206,6 +1206,7 @@ private:
         ops_.clone_from(o.ops_, st_);
         if (nnzK_) PQ_HIP(hipMemcpyAsync(vals_.p, o.vals_.p, sizeof(double) * (size_t)nnzK_, hipMemcpyDeviceToDevice, st_));
         if (U_.nnzL) PQ_HIP(hipMemcpyAsync(Lx_.p, o.Lx_.p, sizeof(double) * (size_t)U_.nnzL, hipMemcpyDeviceToDevice, st_));
+        if (o.Lblock_.n) PQ_HIP(hipMemcpyAsync(Lblock_.p, o.Lblock_.p, o.Lblock_.bytes(), hipMemcpyDeviceToDevice, st_));  // (the substitution reads L from the tasks' tables)
         if (N_) {
             PQ_HIP(hipMemcpyAsync(D_.p, o.D_.p, sizeof(double) * (size_t)N_, hipMemcpyDeviceToDevice, st_));
             PQ_HIP(hipMemcpyAsync(Dinv_.p, o.Dinv_.p, sizeof(double) * (size_t)N_, hipMemcpyDeviceToDevice, st_));
