@@ -23,6 +23,7 @@ def item(what, dt, n=None):
     return out[:int(n)]
 tr = item(8, np.int64).reshape(-1, 4)
 kind, ids, rlen, tptr, trows = item(9, np.int32), item(10, np.int32), item(11, np.int32), item(12, np.int32), item(13, np.int32)
+tr = tr[:len(kind)]  # (per-XCD queues: one slot per row, in the order of the queues)
 t0 = tr[:, 0].min()
 us = lambda c: (c - t0) / 100.0
 tot = us(tr[:, 2].max())

@@ -144,6 +144,49 @@ __global__ void k_pivot_shared(double* out, long long* t, int sleep_arg)
     out[threadIdx.x] = col + dk;
     if (threadIdx.x == 0) { t[0] = t1 - t0; prog = 1; }
 }
+// ---- round 5: an ordered chain of 64 subtractions s -= p[l] (the substitution's backward pass) with the terms in LDS (every lane reads the same words: 16-byte or
+// 8-byte reads) or in the lanes of a register (two lane reads per term)
+typedef double d2 __attribute__((ext_vector_type(2)));
+template <int MODE>
+__global__ void k_chain64(double* out, long long* t)
+{
+    __shared__ double p[64 * 4];
+    const int lane = threadIdx.x;
+    for (int r = 0; r < 4; ++r) p[lane + 64 * r] = 1e-9 * (lane + 1 + r);
+    __syncthreads();
+    double s = out[lane];
+    const double pr = 1e-9 * (lane + 1);
+    long long t0 = tick(s);
+#pragma unroll
+    for (int rep = 0; rep < 4; ++rep) {
+        const double* q = p + 64 * rep;
+        if (MODE == 0) {
+            d2 tt[4], nn[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) tt[k] = *reinterpret_cast<const d2*>(q + 2 * k);
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                if (g < 7) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) nn[k] = *reinterpret_cast<const d2*>(q + 8 * (g + 1) + 2 * k);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { s = s - tt[k].x; s = s - tt[k].y; }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) tt[k] = nn[k];
+            }
+        } else if (MODE == 1) {
+#pragma unroll
+            for (int l = 0; l < 64; ++l) s = s - q[l];
+        } else {
+#pragma unroll
+            for (int l = 0; l < 64; ++l) s = s - readlane_d(pr, l);
+        }
+    }
+    long long t1 = tick(s);
+    out[lane] = s;
+    if (lane == 0) t[0] = t1 - t0;
+}
 int main()
 {
     double* out; long long* t;
@@ -164,6 +207,9 @@ int main()
         hipLaunchKernelGGL(k_pivot_shared, dim3(1), dim3(128), 0, 0, out, t, 1); rep("pivot + sleeping poller", 12);
         hipLaunchKernelGGL(k_pivot_shared, dim3(1), dim3(128), 0, 0, out, t, 0); rep("pivot + busy poller", 12);
         hipLaunchKernelGGL(k_pivot_shared, dim3(1), dim3(320), 0, 0, out, t, 1); rep("pivot + 4 sleeping pollers", 12);
+        hipLaunchKernelGGL(k_chain64<0>, dim3(1), dim3(64), 0, 0, out, t); rep("chain: 16-byte LDS reads ahead", 1);
+        hipLaunchKernelGGL(k_chain64<1>, dim3(1), dim3(64), 0, 0, out, t); rep("chain: 8-byte LDS reads", 1);
+        hipLaunchKernelGGL(k_chain64<2>, dim3(1), dim3(64), 0, 0, out, t); rep("chain: two lane reads per term", 1);
     }
     return 0;
 }
