@@ -1253,7 +1253,7 @@ __device__ __forceinline__ double wide_wave_sum(double v)
 struct WideFwdOps { double Lt[WIDE_B], Lr0[WIDE_B], Lr1[WIDE_B]; };  // triangle row (wave 0, lane = row), two rows below the block per thread
 
 __device__ __forceinline__ void front_fwd_wide_body(const FrontMeta& M, const double* __restrict__ fronts, const int* __restrict__ list, double* __restrict__ x,
-                                                    double* __restrict__ fvec, int fcap, const int bid)
+                                                    double* __restrict__ fvec, int fcap, const int bid, const int* __restrict__ hoff)
 {
     extern __shared__ __attribute__((aligned(16))) double vs[];
     const int s = list[bid];
@@ -1262,7 +1262,9 @@ __device__ __forceinline__ void front_fwd_wide_body(const FrontMeta& M, const do
     if (f > fcap) { front_fwd(M, fronts, s, x, fvec); return; }
     const double* __restrict__ F = fronts + me.front_off;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int flim = huge_front(f, w) ? w : f;  // rows this workgroup applies the pivots to (a huge front: the pivot block only, see k_front_fwd_rows)
+    // rows this workgroup applies the pivots to: a huge front's pivot block only WHEN the caller runs k_front_fwd_rows behind this launch -- which it says by passing
+    // the schedule's offsets of the huge fronts, as for the backward kernels (round-4 advice: without them the whole front is eliminated here, slower and correct)
+    const int flim = (hoff != nullptr && huge_front(f, w)) ? w : f;
     for (int i = tid; i < f; i += WIDE_NT) vs[i] = (i < w) ? x[first + i] : 0.0;
     __syncthreads();
     for (int ci = me.child_lo; ci < me.child_hi; ++ci) {
@@ -1373,9 +1375,9 @@ __device__ __forceinline__ void front_fwd_wide_body(const FrontMeta& M, const do
     }
 }
 __global__ __launch_bounds__(WIDE_NT) void k_front_fwd_wide(FrontMeta M, const double* __restrict__ fronts, const int* __restrict__ list, double* __restrict__ x,
-                                                            double* __restrict__ fvec, int fcap)
+                                                            double* __restrict__ fvec, int fcap, const int* __restrict__ hoff)
 {
-    front_fwd_wide_body(M, fronts, list, x, fvec, fcap, (int)blockIdx.x);
+    front_fwd_wide_body(M, fronts, list, x, fvec, fcap, (int)blockIdx.x, hoff);
 }
 
 // update rows of the huge fronts of a level: v[r] -= sum_k L[r, k] y[k], k ascending in one fma chain (the order of the one-workgroup kernel); one wave per 64 rows
@@ -1916,14 +1918,14 @@ __global__ __launch_bounds__(64) void k_subtree_bwd_wave(FrontMeta M, const doub
 // other waves leave at once -- a barrier does not wait for finished waves --, the rest are the wide fronts).  The two launches of such a level ran one after
 // the other, 6-13 us each whatever they did.
 __global__ __launch_bounds__(WIDE_NT) void k_level_fwd_mixed(FrontMeta M, const double* __restrict__ fronts, const int* __restrict__ list, int nn, double* __restrict__ x,
-                                                             double* __restrict__ fvec, int fcap)
+                                                             double* __restrict__ fvec, int fcap, const int* __restrict__ hoff)
 {
     if ((int)blockIdx.x < nn) {
         if (threadIdx.x >= 64) return;
         subtree_fwd_wave_body<false>(M, fronts, list, list, x, fvec, nullptr, nullptr, nullptr, nullptr, 0, (int)blockIdx.x);
         return;
     }
-    front_fwd_wide_body(M, fronts, list + nn, x, fvec, fcap, (int)blockIdx.x - nn);
+    front_fwd_wide_body(M, fronts, list + nn, x, fvec, fcap, (int)blockIdx.x - nn, hoff);
 }
 __global__ __launch_bounds__(WIDE_NT) void k_level_bwd_mixed(FrontMeta M, const double* __restrict__ fronts, const int* __restrict__ list, int nn, double* __restrict__ x,
                                                              double* __restrict__ fvec, int fcap, int red_thr, const int* __restrict__ hoff, const double* __restrict__ hpart)
@@ -3350,9 +3352,9 @@ private:
             auto huge_rows = [&] {  // the update rows of the level's huge fronts, behind their pivot blocks
                 if (nh > 0) hipLaunchKernelGGL(k_front_fwd_rows, dim3(L.hfwd_grid[l], nh), dim3(64), L.hlds[l], st_, M, fronts_.p, L.hdev.p + L.hptr[l], fvec_.p);
             };
-            if (nn > 0 && cnt > nn && !two_launches) { hipLaunchKernelGGL(k_level_fwd_mixed, dim3(cnt), dim3(WIDE_NT), L.lds[l], st_, M, fronts_.p, list, nn, xp_.p, fvec_.p, wide_fcap_); huge_rows(); continue; }
+            if (nn > 0 && cnt > nn && !two_launches) { hipLaunchKernelGGL(k_level_fwd_mixed, dim3(cnt), dim3(WIDE_NT), L.lds[l], st_, M, fronts_.p, list, nn, xp_.p, fvec_.p, wide_fcap_, (const int*)L.hoff.p); huge_rows(); continue; }
             if (nn > 0) hipLaunchKernelGGL(k_subtree_fwd_wave<false>, dim3(nn), dim3(64), 0, st_, M, fronts_.p, list, list, xp_.p, fvec_.p, (const int*)nullptr, (int*)nullptr, (int*)nullptr, (const int*)nullptr, 0);
-            if (cnt > nn) hipLaunchKernelGGL(k_front_fwd_wide, dim3(cnt - nn), dim3(WIDE_NT), L.lds[l], st_, M, fronts_.p, list + nn, xp_.p, fvec_.p, wide_fcap_);
+            if (cnt > nn) hipLaunchKernelGGL(k_front_fwd_wide, dim3(cnt - nn), dim3(WIDE_NT), L.lds[l], st_, M, fronts_.p, list + nn, xp_.p, fvec_.p, wide_fcap_, (const int*)L.hoff.p);
             huge_rows();
         }
     }

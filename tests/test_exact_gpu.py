@@ -93,3 +93,16 @@ def test_zero_pivot_is_reported_like_the_reference(hip, orc):
     ok_h = k.update_scalings_and_factor(1e-8, np.full(n, 1e-8), np.zeros(0)); ok_o = ko.update_scalings_and_factor(1e-8, np.full(n, 1e-8), np.zeros(0))
     assert ok_o and ok_h
     assert np.array_equal(k.exact_factor()["D"], ko.sparse_factor()["D"])
+
+
+@pytest.mark.parametrize("tokens", ["exact_one_queue", "exact_serial_path", "exact_no_lds", "exact_solve1", "exact_one_queue,exact_grid=7"])
+def test_schedule_variants_are_bitwise_the_oracle_too(tokens):
+    """the engine's other schedules (PIQP_AMD_DEBUG, read once per process: a worker each): one queue of tickets instead of the per-XCD queues, the path pass of a
+    task on one wave, work vectors in HBM, the single-wave substitution, a handful of workgroups -- who computes an entry and when changes, the operations do not"""
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    env["PIQP_AMD_DEBUG"] = tokens
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "workers", "exact_variant.py")
+    r = subprocess.run([sys.executable, worker, "mm_QAFIRO", "mm_QBEACONF", "qp_chain_mass_sqp", "mm_STADAT1", "nl_finnis"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
