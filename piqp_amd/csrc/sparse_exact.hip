@@ -22,6 +22,8 @@
 // Algorithmic work: the same sum_j (c_j^2 + 3 c_j) flops as any LDLt of this pattern; the dependent chain is one LDS round trip per entry of L
 // on the longest root path of the elimination tree (UpLooking::crit_steps), not a memory round trip: the columns a step reads are prefetched.
 #include <algorithm>
+#include <map>
+#include <mutex>
 #include <climits>
 #include <cstdio>
 #include <cstdlib>
@@ -965,6 +967,36 @@ __global__ __launch_bounds__(64) void k_ul_solve2(UlSolve2Args a)
 }
 
 
+// With the per-XCD queues a factorisation needs workgroups on every XCD: two persistent launches from different handles / streams that each hold a part of the chip could
+// wait for one another's unscheduled workgroups (seen once in a while with two host threads before this ordering: a wait without end).  The engine's persistent launches of
+// one device -- factorisations and substitutions -- are therefore ordered on the device: a launch waits (hipStreamWaitEvent, nothing on the host) for the previous one.
+struct XqLaunchOrder {
+    std::mutex mu;
+    struct Last { hipStream_t st = nullptr; hipEvent_t ev = nullptr; };
+    std::map<int, Last> last;
+    // wait for the previous launch of this device IF it went to another stream, launch, record on the handle's own event -- under ONE lock: two threads must not
+    // both find "nothing to wait for".  A single handle pays an event record per launch and no wait.
+    template <class Launch>
+    void run(int dev, hipStream_t st, hipEvent_t own, Launch&& launch)
+    {
+        static const bool off = debug_token("exact_no_order") != nullptr;  // (measurement aid)
+        if (off) { launch(); return; }
+        std::lock_guard<std::mutex> lk(mu);
+        Last& l = last[dev];
+        if (l.ev != nullptr && l.st != st) PQ_HIP(hipStreamWaitEvent(st, l.ev, 0));
+        launch();
+        PQ_HIP(hipEventRecord(own, st));
+        l.st = st; l.ev = own;
+    }
+    void forget(int dev, hipEvent_t own)  // (a handle is going away)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = last.find(dev);
+        if (it != last.end() && it->second.ev == own) last.erase(it);
+    }
+};
+inline XqLaunchOrder& xq_launch_order() { static XqLaunchOrder o; return o; }
+
 class ExactSparseKKT final : public KKTSolverBase {
 public:
     struct TooCostly {};  // thrown by the constructor before anything is allocated: the factorisation has more flops than the caller's limit
@@ -999,7 +1031,9 @@ public:
     ~ExactSparseKKT() override
     {
         (void)hipSetDevice(dev_);
-        if (st_) { (void)hipStreamSynchronize(st_); (void)hipStreamDestroy(st_); }
+        if (st_) { (void)hipStreamSynchronize(st_); }
+        if (xq_event_) { xq_launch_order().forget(dev_, xq_event_); (void)hipEventDestroy(xq_event_); }
+        if (st_) (void)hipStreamDestroy(st_);
     }
     KKTSolverBase* clone() const override
     {
@@ -1058,14 +1092,22 @@ public:
             hipLaunchKernelGGL(k_ul_fill_sent, dim3((unsigned)((D_.n + 255) / 256)), dim3(256), 0, st_, D_.n, D_.p);
             if (xq_on_) hipLaunchKernelGGL(k_ul_fill_sent, dim3((unsigned)((Dloc_.n + 255) / 256)), dim3(256), 0, st_, Dloc_.n, Dloc_.p);
             hipLaunchKernelGGL(k_ul_fill_sent, dim3((unsigned)((Lblock_.n + 255) / 256)), dim3(256), 0, st_, Lblock_.n, Lblock_.p);
-            if (lds_y_) hipLaunchKernelGGL(k_ul_factor<true>, dim3(grid_), dim3(64), (size_t)N_ * sizeof(double), st_, a);
-            else hipLaunchKernelGGL(k_ul_factor<false>, dim3(grid_), dim3(64), 0, st_, a);
+            auto launch = [&] {
+                if (lds_y_) hipLaunchKernelGGL(k_ul_factor<true>, dim3(grid_), dim3(64), (size_t)N_ * sizeof(double), st_, a);
+                else hipLaunchKernelGGL(k_ul_factor<false>, dim3(grid_), dim3(64), 0, st_, a);
+            };
+            if (xq_on_) xq_launch_order().run(dev_, st_, xq_event_, launch);
+            else launch();
         }
         PQ_HIP(hipGetLastError());
         prof_.end(1, t1, st_);
         PQ_HIP(hipMemcpyAsync(ctl_h_.p + 2, ctl_.p + 1, sizeof(int), hipMemcpyDeviceToHost, st_));
         stream_wait(st_);
-        if (ctl_h_.p[2] == -2) throw std::runtime_error("reference-order factorisation: a task waited for its children without end (scheduling error)");
+        if (ctl_h_.p[2] <= -2) {
+            std::string qs;
+            if (xq_on_) for (int q = 0; q < 8; ++q) { int tq = 0; (void)hipMemcpy(&tq, xtick_.p + 16 * q, sizeof(int), hipMemcpyDeviceToHost); qs += " " + std::to_string(tq); }
+            throw std::runtime_error("reference-order factorisation: a task waited for its children without end (scheduling error)" + (xq_on_ ? "; tickets drawn per XCD queue:" + qs : std::string()));
+        }
         return ctl_h_.p[2] == INT_MAX;  // n == cols (sparse/kkt.hpp:104)
     }
     // sparse/kkt.hpp:107-145, KKT_FULL
@@ -1098,7 +1140,11 @@ public:
             b.fwd_only = fwd_only_ ? 1 : 0;
             b.ta_ptr = ta_ptr_.p; b.ta_rows = ta_rows_.p; b.Lsrc2 = Lsrc2_.p; b.xa_cap = xa_cap_;
             b.trace = strace_.n > 1 ? strace_.p : nullptr;
-            hipLaunchKernelGGL(k_ul_solve2<32>, dim3(sgrid_), dim3(64), (size_t)(xa_cap_ + 64) * sizeof(double), st_, b);
+            // (with the per-XCD queues the engine's persistent launches of one device run one after the other, the substitutions included: a factorisation then only
+            // ever shares the chip with short launches that leave on their own -- see XqLaunchOrder)
+            auto launch = [&] { hipLaunchKernelGGL(k_ul_solve2<32>, dim3(sgrid_), dim3(64), (size_t)(xa_cap_ + 64) * sizeof(double), st_, b); };
+            if (xq_on_) xq_launch_order().run(dev_, st_, xq_event_, launch);
+            else launch();
         } else if (N_ > 0) {
         UlSolveArgs a;
         a.N = N_; a.n = n_; a.p = kp; a.m = km;
@@ -1296,6 +1342,7 @@ private:
         ctl_.alloc(4); ctl_h_.alloc(4);
         {   // per-XCD row queues: tasks in the order of their last rows, each to the queue with the least work so far (entries of its rows); rows ascending per queue
             xq_on_ = !serial_path_ && debug_token("exact_one_queue") == nullptr;
+            if (!xq_event_) PQ_HIP(hipEventCreateWithFlags(&xq_event_, hipEventDisableTiming));
             std::vector<int> order((size_t)ntask_), qof((size_t)std::max(ntask_, 1), 0);
             for (int t = 0; t < ntask_; ++t) order[t] = t;
             std::sort(order.begin(), order.end(), [&](int x, int y) { return U_.task_rows[U_.task_ptr[x + 1] - 1] < U_.task_rows[U_.task_ptr[y + 1] - 1]; });
@@ -1313,7 +1360,7 @@ private:
             std::vector<int> fill(qp.begin(), qp.end() - 1);
             for (int k = 0; k < N_; ++k) qr[fill[qof[U_.row_task[k]]]++] = k;  // (k ascending: every queue ascending)
             upload_vec(xq_ptr_, qp, st_); upload_vec(xq_rows_, qr, st_); xq_rows_h_ = qr;
-            xtick_.alloc(8 * 16); xtick_.zero(st_);
+            xtick_.alloc(8 * 16 + 16); xtick_.zero(st_);
             Dloc_.alloc(N_ ? N_ : 1); Dloc_.zero(st_);
         }
         {   // backward sweep groups: whole columns, last first, at most 64 entries each (a longer column alone)
@@ -1416,6 +1463,7 @@ private:
     DBuf<int> xq_ptr_, xq_rows_, xtick_;
     DBuf<double> Dloc_;
     bool xq_on_ = false;
+    hipEvent_t xq_event_ = nullptr;
     std::vector<int> xq_rows_h_;
     DBuf<int> prog_;
     // tasks with fewer entries per row than this run their path pass on ONE wave (ul_path).  0 since the rows of a task hand over by values (one round trip per

@@ -106,3 +106,39 @@ def test_schedule_variants_are_bitwise_the_oracle_too(tokens):
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "workers", "exact_variant.py")
     r = subprocess.run([sys.executable, worker, "mm_QAFIRO", "mm_QBEACONF", "qp_chain_mass_sqp", "mm_STADAT1", "nl_finnis"], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
+
+
+def test_two_factorisations_of_two_handles_at_the_same_time(hip, orc):
+    """two handles of the reference-order engine factor and solve from two host threads at the same time (two streams): with the per-XCD queues a factorisation needs
+    workgroups on every XCD, so such launches are ordered on the device (sparse_exact.hip XqLaunchOrder) -- every result equals the single-threaded one bit for bit"""
+    import threading
+    q = load_qp("mm_QPILOTNO")
+    d = hip.SparseData(*_args(q))
+    n, p, m = d.n, d.p, d.m
+    rng = np.random.default_rng(3)
+    x_reg, z_reg = np.full(n, 1e-6), np.abs(rng.standard_normal(m)) + 0.1
+    rx, ry, rz = rng.standard_normal(n), rng.standard_normal(p), rng.standard_normal(m)
+    ks = [hip.SparseKKT(d, kkt_solver=hip.SPARSE_LDLT_EXACT) for _ in range(2)]
+    out, err = {}, []
+
+    def work(tag, k, reps):
+        try:
+            ref = None
+            for it in range(reps):
+                assert k.update_scalings_and_factor(1e-4, x_reg, z_reg)
+                x = np.asarray(k.solve(rx, ry, rz)[0]).copy()
+                if ref is None:
+                    ref = x
+                assert np.array_equal(x, ref), (tag, it)
+            out[tag] = ref
+        except Exception as e:  # noqa: BLE001
+            err.append((tag, repr(e)))
+
+    work("single", ks[0], 2)
+    ts = [threading.Thread(target=work, args=(t, k, 30)) for t, k in zip("ab", ks)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(300)
+    assert not err, err
+    assert np.array_equal(out["a"], out["single"]) and np.array_equal(out["b"], out["single"])
