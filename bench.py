@@ -60,7 +60,7 @@ def pmc_traffic(kernel_key, n, m, p):
     """HBM traffic of one launch of `kernel_key` from the committed rocprofv3 PMC passes of this workload (FETCH_SIZE / WRITE_SIZE in
     separate passes, gfx950 correction applied, see the file); None when the file does not cover this shape.  Not measured in this run:
     the source file and its commit are reported next to the number."""
-    for fname in ("r04_pmc_dense_c2.json", "r03_pmc_dense_c2.json", "r02_pmc_dense_c2.json"):
+    for fname in ("r05_pmc_dense_c2.json", "r04_pmc_dense_c2.json", "r03_pmc_dense_c2.json", "r02_pmc_dense_c2.json"):
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", fname)))
             if (pmc["n"], pmc["m"], pmc["p"]) != (n, m, p):

@@ -33,4 +33,8 @@ d=json.load(open('$O/r05_sharded_solve_${b}_world2.json'))
 print('$b world 2: bitwise', d['bitwise_equal_all_ranks'], 'residual eval ms single / partitioned', round(d['residual_eval_ms_single_gpu'],3), round(d['residual_eval_ms_partitioned'],3), 'step ms single / partitioned', round(d['single_gpu_ms_per_step'],3), round(d['ms_per_step'],3), d['sharded_solve'])
 " | cut -c1-400
 done
+rm -rf $O/pmc_f $O/pmc_w
+timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmc_f -- python3 tools/prof_dense.py 4096 4096 0 3 0 > /dev/null 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pmc_w -- python3 tools/prof_dense.py 4096 4096 0 3 0 > /dev/null 2>&1
+python3 tools/make_pmc_json.py $O/pmc_f $O/pmc_w 4096 4096 0 "round 5, final code" > $O/r05_pmc_dense_c2.json; rm -rf $O/pmc_f $O/pmc_w
 timeout 300 python3 tools/exact_trace.py mm_QPILOTNO 2>/dev/null | cut -c1-220 > $O/r05_exact_engine_timeline.txt; tail -30 $O/r05_exact_engine_timeline.txt
