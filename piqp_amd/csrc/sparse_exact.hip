@@ -789,51 +789,28 @@ __device__ __forceinline__ bool ul_fwd_task(const UlSolve2Args& a, const int t, 
     return true;
 }
 
-// s - p[0] - p[1] - ... - p[cnt - 1] with the terms in LDS (every lane reads the same words: broadcasts): eight terms per round of four 16-byte reads and eight
-// subtractions -- about half the instructions of the lane-read chain, which stays for the short chains (an LDS round trip costs more than three lane reads)
-__device__ __forceinline__ double lds_chain_sub(double s, const double* __restrict__ p, int cnt)
+// s - p[0] - ... - p[NT - 1] with the terms in LDS (every lane reads the same words: broadcasts): ALL the 16-byte reads are requested first, then the NT subtractions
+// run one after the other.  Inside this kernel an LDS read comes back after ~300 cycles, not the ~100 of an idle compute unit: a loop that reads eight terms per round
+// and waits for them spent five times the subtractions' own time waiting (43 cycles per term measured against 12 in isolation, tools/ub/chain.hip).
+template <int NT>
+__device__ __forceinline__ double lds_chain_straight(double s, const double* __restrict__ p)
 {
     typedef double d2 __attribute__((ext_vector_type(2)));
-    if (cnt == 64) {
-        // a full batch (the columns of hundreds of entries are made of these): ONE straight run of instructions, the reads of the next eight terms requested
-        // before the current eight are subtracted -- in a loop every round waits for its own reads (~100 cycles of LDS latency per eight terms, more than the
-        // eight subtractions take)
-        d2 t[4], n[4];
+    d2 t[NT / 2];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) t[q] = *reinterpret_cast<const d2*>(p + 2 * q);
+    for (int q = 0; q < NT / 2; ++q) t[q] = *reinterpret_cast<const d2*>(p + 2 * q);
 #pragma unroll
-        for (int g = 0; g < 8; ++g) {
-            if (g < 7) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) n[q] = *reinterpret_cast<const d2*>(p + 8 * (g + 1) + 2 * q);
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { s = __dsub_rn(s, t[q].x); s = __dsub_rn(s, t[q].y); }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) t[q] = n[q];
-        }
-        return s;
-    }
-    int l = 0;
-    for (; l + 8 <= cnt; l += 8) {
-        const d2 t0 = *reinterpret_cast<const d2*>(p + l), t1 = *reinterpret_cast<const d2*>(p + l + 2), t2 = *reinterpret_cast<const d2*>(p + l + 4),
-                 t3 = *reinterpret_cast<const d2*>(p + l + 6);
-        s = __dsub_rn(s, t0.x); s = __dsub_rn(s, t0.y); s = __dsub_rn(s, t1.x); s = __dsub_rn(s, t1.y);
-        s = __dsub_rn(s, t2.x); s = __dsub_rn(s, t2.y); s = __dsub_rn(s, t3.x); s = __dsub_rn(s, t3.y);
-    }
-    if (l < cnt) {  // (l <= 56: the eight words are inside the buffer)
-        const int rem = cnt - l;
-        const d2 t0 = *reinterpret_cast<const d2*>(p + l), t1 = *reinterpret_cast<const d2*>(p + l + 2), t2 = *reinterpret_cast<const d2*>(p + l + 4),
-                 t3 = *reinterpret_cast<const d2*>(p + l + 6);
-        s = __dsub_rn(s, t0.x);
-        if (rem > 1) s = __dsub_rn(s, t0.y);
-        if (rem > 2) s = __dsub_rn(s, t1.x);
-        if (rem > 3) s = __dsub_rn(s, t1.y);
-        if (rem > 4) s = __dsub_rn(s, t2.x);
-        if (rem > 5) s = __dsub_rn(s, t2.y);
-        if (rem > 6) s = __dsub_rn(s, t3.x);
-    }
+    for (int q = 0; q < NT / 2; ++q) { s = __dsub_rn(s, t[q].x); s = __dsub_rn(s, t[q].y); }
     return s;
+}
+// s - p[0] - ... - p[cnt - 1]; the caller has stored +0.0 in p[cnt .. 63] (x - 0.0 == x for every x, signed zeros and NaNs included), so the chain may run over the
+// next multiple of 16 terms
+__device__ __forceinline__ double lds_chain_sub(double s, const double* __restrict__ p, int cnt)
+{
+    if (cnt <= 16) return lds_chain_straight<16>(s, p);
+    if (cnt <= 32) return lds_chain_straight<32>(s, p);
+    if (cnt <= 48) return lds_chain_straight<48>(s, p);
+    return lds_chain_straight<64>(s, p);
 }
 
 // Backward pass of a task (round 5, second form).  What it reads from OTHER tasks are the final x of the rows above it that its columns touch -- a short list per
@@ -896,7 +873,7 @@ __device__ __forceinline__ bool ul_bwd_task(const UlSolve2Args& a, const int t, 
                     const double pr = __dmul_rn(v, sl < 64 ? xin : xo);
                     if (cnt <= 4) s = chain_sub(s, pr, cnt);
                     else {
-                        s_pr[lane] = pr;
+                        s_pr[lane] = lane < cnt ? pr : 0.0;
                         wave_sync();
                         s = lds_chain_sub(s, s_pr, cnt);
                         wave_sync();
