@@ -50,7 +50,8 @@ typedef enum {
     PQ_SPARSE_MULTISTAGE = 5,
     PQ_DENSE_LDLT_NO_PIVOT = 16,
     /* the two engines behind PQ_SPARSE_LDLT, selectable directly (not in the reference's enum): the reference's own up-looking elimination order on the
-     * device (sparse/ldlt.hpp:101-218 bit for bit; PQ_SPARSE_LDLT picks it up to 8192 KKT rows) and the supernodal multifrontal LDLt (above that) */
+     * device (sparse/ldlt.hpp:101-218 bit for bit; PQ_SPARSE_LDLT picks it up to 8192 KKT rows and 4e7 flops per factorisation -- 3e9 in the condensed modes) and the
+     * supernodal multifrontal LDLt (everything else) */
     PQ_SPARSE_LDLT_EXACT = 17,
     PQ_SPARSE_LDLT_MULTIFRONTAL = 18
 } pq_kkt_solver;
@@ -238,8 +239,8 @@ int pq_kkt_set_exchange_norm(pq_kkt *k, double *buf_norm);
 int pq_kkt_sharded_calls(pq_kkt *k, int out[2]);
 int pq_kkt_sharded_solve_calls(pq_kkt *k, int out[6]);
 /* test hook (reference-order engine, PQ_SPARSE_LDLT_EXACT): the factor as sparse/ldlt.hpp:24-37 holds it.  what = 0 nnz(L) | 1 L_cols[N + 1] | 2 L_ind | 3 L_vals |
- * 4 D | 5 D_inv | 6 values of P K P' (CSC order of pq_sparse_kkt_symbolic's PKp / PKi_rows) | 7 perm; copies the item into out_host (NULL: size only) and returns its
- * length, < 0 on error (another engine) */
+ * 4 D | 5 D_inv | 6 values of P K P' (CSC order of pq_sparse_kkt_symbolic's PKp / PKi_rows) | 7 perm | 8 .. 17 timelines and schedule of the last factorisation / solve
+ * (PIQP_AMD_DEBUG=exact_trace, tools/exact_trace.py); copies the item into out_host (NULL: size only) and returns its length, < 0 on error (another engine) */
 long long pq_kkt_exact_factor(pq_kkt *k, int what, void *out_host);
 /* test hook (sparse backends): smallest |pivot| of the last factorisation */
 int pq_kkt_min_abs_pivot(pq_kkt *k, double *out);
@@ -284,6 +285,8 @@ int pq_kkt_sparse_ordering(pq_kkt *k, int *fill_perm, int *elim_perm);
  *   16 dep_ptr  17 dep (children a row pass waits for)   18 tk_kind  19 tk_id (tickets: 0 row pass of a row, 1 path pass of a task)
  *   20 Rcnt  21 Rtab (per entry: leading column entries the row pass scatters, -1 = own path; table row)   22 tab_ptr  23 mask_ptr  24 task_nU
  *   25 Tmask (uint64: presence bits of every table row)
+ *   100 + mode (mode = KKTMode bits: 1 equalities eliminated, 2 inequalities eliminated): { N, nnz(L), kiloflops of the factorisation } of that mode's system -- what the
+ *       engine choice of pq_kkt_create_sparse looks at (PIQP_AMD_EXACT_MAX_N, PIQP_AMD_EXACT_MAX_FLOPS)
  * len[q] receives the length of item what[q]; out[q] (may be NULL, as may `out`) receives a copy.  Returns N. */
 int pq_sparse_uplooking_plan(const pq_sparse_data *data, int nitems, const int *what, void **out, long long *len);
 
