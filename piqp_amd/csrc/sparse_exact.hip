@@ -147,7 +147,7 @@ struct UlFactorArgs {
     const int *Etab, *Li;
     const unsigned long long* Emask;
     double *Lx, *D, *Dinv, *Ystash, *Pstash, *Dinit, *Lblock;
-    int *done, *p1done, *ready, *prog, *ticket, *info;
+    int *done, *p1done, *ticket, *info;
     const int *xq_ptr, *xq_rows;  // per-XCD row queues (nullable: one queue of tickets): XCD q works rows xq_rows[xq_ptr[q] .. xq_ptr[q + 1]), ascending; a.ticket + 16 q counts
     double* Dloc;                 // with the queues: D once more, stored plainly for the rows of the same task (same XCD) to poll
     int rowpar;     // 1: the path pass of a row follows its row pass on the same wave (ul_path_row); 0: one path pass per task (ul_path; PIQP_AMD_DEBUG=exact_serial_path)
@@ -298,16 +298,6 @@ __device__ __forceinline__ bool spin_until(const int* flag, int epoch)
     while (ldf(flag) != epoch) {
         __builtin_amdgcn_s_sleep(1);
         if (++spins > (1ll << 26)) return false;  // (seconds: a scheduling bug must not take the device with it)
-    }
-    return true;
-}
-
-__device__ __forceinline__ bool spin_until_ge(const int* flag, int want)
-{
-    long long spins = 0;
-    while (ldf(flag) < want) {
-        __builtin_amdgcn_s_sleep(1);
-        if (++spins > (1ll << 26)) return false;
     }
     return true;
 }
@@ -1060,7 +1050,7 @@ public:
         a.tk_kind = tk_kind_.p; a.tk_id = tk_id_.p; a.task_rows = task_rows_.p; a.rowrec = rowrec_.p; a.taskrec = taskrec_.p; a.dep = dep_.p;
         a.E4 = reinterpret_cast<const int4*>(E4_.p); a.Etab = Etab_.p; a.Li = Li_.p; a.Emask = Emask_.p;
         a.Lx = Lx_.p; a.D = D_.p; a.Dinv = Dinv_.p; a.Ystash = Ystash_.p; a.Pstash = Pstash_.p; a.Dinit = Dinit_.p; a.Lblock = Lblock_.p;
-        a.done = done_.p; a.p1done = p1done_.p; a.ready = ready_.p; a.prog = prog_.p; a.ticket = xq_on_ ? xtick_.p : ctl_.p; a.info = ctl_.p + 1;
+        a.done = done_.p; a.p1done = p1done_.p; a.ticket = xq_on_ ? xtick_.p : ctl_.p; a.info = ctl_.p + 1;
         a.xq_ptr = xq_on_ ? xq_ptr_.p : nullptr; a.xq_rows = xq_rows_.p; a.Dloc = Dloc_.p;
         a.rowpar = serial_path_ ? 0 : 1;
         a.yglob = yglob_.p;
@@ -1311,7 +1301,7 @@ private:
         }
         Ystash_.alloc(U_.nnzL ? (size_t)U_.nnzL : 1); Pstash_.alloc(U_.nnzL ? (size_t)U_.nnzL : 1); Dinit_.alloc(N_ ? N_ : 1);
         Lblock_.alloc(U_.tab_ptr.back() ? (size_t)U_.tab_ptr.back() : 1); Lblock_.zero(st_);
-        p1done_.alloc(N_ ? N_ : 1); p1done_.zero(st_); ready_.alloc(N_ ? N_ : 1); ready_.zero(st_); prog_.alloc(N_ ? N_ : 1); prog_.zero(st_);
+        p1done_.alloc(N_ ? N_ : 1); p1done_.zero(st_);
         vals_.alloc(nnzK_ ? nnzK_ : 1); vals_.zero(st_);
         Lx_.alloc(U_.nnzL ? (size_t)U_.nnzL : 1); Lx_.zero(st_);
         D_.alloc(N_ ? N_ : 1); Dinv_.alloc(N_ ? N_ : 1); D_.zero(st_); Dinv_.zero(st_);
@@ -1431,7 +1421,7 @@ private:
     hipStream_t st_ = nullptr;
     sparse::UpLooking U_;
     CscOperators ops_;
-    DBuf<int> perm_, Cp_, Ci_, diag_pos_, mapP_, mapA_, mapG_, Lp_, Li_, Lcol_, Rp_, Rcol_, Rpos_, tk_kind_, tk_id_, task_rows_, dep_, rowrec_, taskrec_, E4_, Etab_, done_, p1done_, ready_, ctl_, bgroup_;
+    DBuf<int> perm_, Cp_, Ci_, diag_pos_, mapP_, mapA_, mapG_, Lp_, Li_, Lcol_, Rp_, Rcol_, Rpos_, tk_kind_, tk_id_, task_rows_, dep_, rowrec_, taskrec_, E4_, Etab_, done_, p1done_, ctl_, bgroup_;
     DBuf<int> tsort_, tdep_, fs_u_, fs_col_, fs4_, Lsrc_, mask_ptr_, fdone_, bdone_, ta_ptr_, ta_rows_, Lsrc2_;
     int xa_cap_ = 64;
     DBuf<unsigned long long> Emask_, Tmask_;
@@ -1442,7 +1432,6 @@ private:
     bool xq_on_ = false;
     hipEvent_t xq_event_ = nullptr;
     std::vector<int> xq_rows_h_;
-    DBuf<int> prog_;
     // tasks with fewer entries per row than this run their path pass on ONE wave (ul_path).  0 since the rows of a task hand over by values (one round trip per
     // row): side by side wins at every row length measured (QAFIRO 0.09 -> 0.05 ms, finnis 0.39 -> 0.28, STADAT1 7.9 -> 6.7; 17 before, when a hand-over cost five)
     int serial_below_ = debug_token("exact_serial_below") ? std::atoi(debug_token("exact_serial_below")) : 0;
