@@ -274,6 +274,7 @@ struct UlSolve2Args {
     int N, n, p, m, ntask, epoch;
     const int *perm, *taskrec, *task_rows, *tsort, *tdep, *fs_u, *fs_col, *Lp, *Li, *Lsrc;
     const int4* fs4;  // forward pass, per table row of a task in ascending column order: {table row, column, mask of the task's rows with an entry (lo, hi)}
+    const int* fs_task;  // ... and the task that column belongs to (its forward pass must be complete before the column's x is read)
     const unsigned long long* Tmask;
     const int* mask_ptr;
     const double *Lblock, *Lx, *Dinv;
@@ -721,7 +722,8 @@ __device__ __forceinline__ bool ul_fwd_task(const UlSolve2Args& a, const int t, 
     double acc = o < a.n ? a.rx[o] : (o < a.n + a.p ? a.ry[o - a.n] : a.rz[o - a.n - a.p]);
     const double dinv = a.Dinv[row];
     int4 rec = a.fs4[fs0 + (lane < nsrc ? lane : 0)];
-    if (lane >= nsrc) { rec.x = 0; rec.z = 0; rec.w = 0; }  // (steps past the end: empty masks -- they run, and change nothing)
+    int rt = a.fs_task[fs0 + (lane < nsrc ? lane : 0)];
+    if (lane >= nsrc) { rec.x = 0; rec.z = 0; rec.w = 0; rt = t; }  // (steps past the end: empty masks -- they run, and change nothing)
     const double* __restrict__ tbase = a.Lblock + tb;        // row u of the task's table: tbase + u W, this lane's value at + lw
     // one step: acc_t -= fl(L(t, j) x_j) for the task rows t of the mask.  No branch: both candidate operands are read (the x of an outside column from its
     // lane of xc, the value of a path column from its lane of acc) and one is selected.
@@ -733,33 +735,45 @@ __device__ __forceinline__ bool ul_fwd_task(const UlSolve2Args& a, const int t, 
         const double r = msub(acc, v, src);
         acc = __builtin_amdgcn_inverse_ballot_w64(m) ? r : acc;
     };
+    // A column's x is read when the forward pass of ITS task is complete -- waited for column by column, chunk by chunk, not for all the tasks below at the start:
+    // most of a big task's columns belong to tasks that finished long ago, and the task right below it on the tree (the one it would wait for longest) holds the
+    // LAST outside columns of the list.  The top of the tree then overlaps: a task works through its early chunks while the task below is still running.
+    auto wait_sources = [&](const int src_task) { const bool w = src_task == t ? true : spin_until(a.fdone + src_task, a.epoch); return __ballot(!w) == 0; };
     if (nsrc <= 8) {
         // most tasks are a row or two with a handful of columns: eight steps, nothing in flight behind them
         double tv[8];
 #pragma unroll
         for (int d = 0; d < 8; ++d) tv[d] = (tbase + (size_t)__builtin_amdgcn_readlane(rec.x, d) * W)[lw];
-        if (!wait()) return false;
+        if (!wait() || !wait_sources(rt)) return false;
         const double xs8 = ldw(a.xf + rec.y);
 #pragma unroll
         for (int d = 0; d < 8; ++d) step(rec.x, rec.z, rec.w, xs8, d, tv[d]);
         if (lane < W) { stw(a.xf + row, acc); stw(a.xz + row, __dmul_rn(acc, dinv)); }
         return true;
     }
+    auto fetch = [&](const int base, int4& r, int& rtask) {
+        const int q = base + lane;
+        const bool live = q < nsrc;
+        r = a.fs4[fs0 + (live ? q : 0)];
+        rtask = a.fs_task[fs0 + (live ? q : 0)];
+        if (!live) { r.x = 0; r.z = 0; r.w = 0; rtask = t; }
+    };
+    int4 nrec; int nrt;
+    fetch(64, nrec, nrt);
     double pf_v[PFS];
 #pragma unroll
     for (int d = 0; d < PFS; ++d) pf_v[d] = (tbase + (size_t)__builtin_amdgcn_readlane(rec.x, d) * W)[lw];
-    if (!wait()) return false;
-    double xs = ldw(a.xf + rec.y);   // (an outside column is final: its task was waited for; a path column's value is taken from its lane instead)
+    if (!wait() || !wait_sources(rt)) return false;
+    double xs = ldw(a.xf + rec.y);   // (a path column's value is taken from its lane instead)
     for (int base = 0; base < nsrc; base += 64) {
         const int ns = min(64, nsrc - base);
         const int ue = rec.x, mlo = rec.z, mhi = rec.w;
         const double xcur = xs;
-        // the chunk after this one
-        const bool more = base + 64 < nsrc;
-        const int qn = base + 64 + lane;
-        int4 nrec = a.fs4[fs0 + (more && qn < nsrc ? qn : 0)];
-        if (!more || qn >= nsrc) { nrec.x = 0; nrec.z = 0; nrec.w = 0; }
-        const double nxs = ldw(a.xf + nrec.y);
+        // two chunks ahead: the records; one chunk ahead: a look at its columns' tasks and, on the assumption that they are complete, its x values
+        int4 nnrec; int nnrt;
+        fetch(base + 128, nnrec, nnrt);
+        const int nflag = ldf(a.fdone + nrt);
+        double nxs = ldw(a.xf + nrec.y);
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             if (half * 32 < ns) {
@@ -773,7 +787,12 @@ __device__ __forceinline__ bool ul_fwd_task(const UlSolve2Args& a, const int t, 
                 }
             }
         }
-        rec = nrec; xs = nxs;
+        if (base + 64 < nsrc && __ballot(nrt != t && nflag != a.epoch) != 0) {
+            // some column of the next chunk belongs to a task that was still running a chunk ago: wait for it now, and read the x values again
+            if (!wait_sources(nrt)) return false;
+            nxs = ldw(a.xf + nrec.y);
+        }
+        rec = nrec; rt = nrt; xs = nxs; nrec = nnrec; nrt = nnrt;
     }
     if (lane < W) { stw(a.xf + row, acc); stw(a.xz + row, __dmul_rn(acc, dinv)); }
     return true;
@@ -901,12 +920,9 @@ __global__ __launch_bounds__(64) void k_ul_solve2(UlSolve2Args a)
         if (a.trace && lane == 0) { a.trace[4 * (size_t)tk] = wall_clock64(); a.trace[4 * (size_t)tk + 3] = blockIdx.x; }
         if (tk < a.ntask) {
             const int t = a.tsort[tk];
-            const int d0 = a.taskrec[8 * t + 5], dn = a.taskrec[8 * t + 6];
-            ok = ul_fwd_task<PFS>(a, t, lane, [&]() {
-                bool w = true;
-                for (int c = lane; c < dn; c += 64) w &= spin_until(a.fdone + a.tdep[d0 + c], a.epoch);
+            ok = ul_fwd_task<PFS>(a, t, lane, [&]() {  // (the task waits for the tasks of its columns as it reaches them: ul_fwd_task)
                 if (a.trace && lane == 0) a.trace[4 * (size_t)tk + 1] = wall_clock64();
-                return __ballot(!w) == 0;
+                return true;
             });
             if (ok) {
                 drain_stores();
@@ -1100,7 +1116,7 @@ public:
             PQ_HIP(hipMemsetAsync(ctl_.p + 2, 0, sizeof(int), st_));
             UlSolve2Args b;
             b.N = N_; b.n = n_; b.p = kp; b.m = km; b.ntask = ntask_; b.epoch = sepoch_;
-            b.perm = perm_.p; b.taskrec = taskrec_.p; b.task_rows = task_rows_.p; b.tsort = tsort_.p; b.tdep = tdep_.p; b.fs_u = fs_u_.p; b.fs_col = fs_col_.p; b.fs4 = reinterpret_cast<const int4*>(fs4_.p);
+            b.perm = perm_.p; b.taskrec = taskrec_.p; b.task_rows = task_rows_.p; b.tsort = tsort_.p; b.tdep = tdep_.p; b.fs_u = fs_u_.p; b.fs_col = fs_col_.p; b.fs4 = reinterpret_cast<const int4*>(fs4_.p); b.fs_task = fs_task_.p;
             b.Lp = Lp_.p; b.Li = Li_.p; b.Lsrc = Lsrc_.p; b.Tmask = Tmask_.p; b.mask_ptr = mask_ptr_.p; b.Lblock = Lblock_.p; b.Lx = Lx_.p; b.Dinv = Dinv_.p;
             b.rx = in_x; b.ry = in_y; b.rz = in_z; b.lx = lhs_x; b.ly = out_y; b.lz = out_z;
             b.xf = xf_.p; b.xz = xz_.p; b.xb = xb_.p; b.fdone = fdone_.p; b.bdone = bdone_.p; b.ticket = ctl_.p + 2; b.info = ctl_.p + 3;
@@ -1244,6 +1260,9 @@ private:
                     f4[4 * (size_t)q] = U_.fs_u[q]; f4[4 * (size_t)q + 1] = U_.fs_col[q]; f4[4 * (size_t)q + 2] = (int)(unsigned)(mk & 0xffffffffull); f4[4 * (size_t)q + 3] = (int)(unsigned)(mk >> 32);
                 }
             upload_vec(fs4_, f4, st_);
+            std::vector<int> ft(std::max<size_t>(U_.fs_col.size(), 1), 0);
+            for (size_t q = 0; q < U_.fs_col.size(); ++q) ft[q] = U_.row_task[U_.fs_col[q]];
+            upload_vec(fs_task_, ft, st_);
         }
         {   // the backward pass's lists: per task the rows above it that its columns touch (first seen first), per entry of L where its operand comes from
             std::vector<int> tap((size_t)ntask_ + 1, 0), tar, src2(std::max<size_t>(U_.Lsrc.size(), 1), 0), seen((size_t)std::max(N_, 1), -1), slot((size_t)std::max(N_, 1), 0);
@@ -1422,7 +1441,7 @@ private:
     sparse::UpLooking U_;
     CscOperators ops_;
     DBuf<int> perm_, Cp_, Ci_, diag_pos_, mapP_, mapA_, mapG_, Lp_, Li_, Lcol_, Rp_, Rcol_, Rpos_, tk_kind_, tk_id_, task_rows_, dep_, rowrec_, taskrec_, E4_, Etab_, done_, p1done_, ctl_, bgroup_;
-    DBuf<int> tsort_, tdep_, fs_u_, fs_col_, fs4_, Lsrc_, mask_ptr_, fdone_, bdone_, ta_ptr_, ta_rows_, Lsrc2_;
+    DBuf<int> tsort_, tdep_, fs_u_, fs_col_, fs4_, fs_task_, Lsrc_, mask_ptr_, fdone_, bdone_, ta_ptr_, ta_rows_, Lsrc2_;
     int xa_cap_ = 64;
     DBuf<unsigned long long> Emask_, Tmask_;
     DBuf<double> xf_, xz_, xb_;
