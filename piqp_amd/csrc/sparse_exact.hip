@@ -825,6 +825,7 @@ __device__ __forceinline__ double lds_chain_sub(double s, const double* __restri
 // Backward pass of a task (round 5, second form).  What it reads from OTHER tasks are the final x of the rows above it that its columns touch -- a short list per
 // task (the structure of its top row): fetched ONCE, into LDS (s_xa), so that a column's operands are lane shuffles and LDS reads and the only loads per column are
 // its own entries (Lsrc2: 0 .. 63 = a row of this task by lane, 64 + i = entry i of the task's list), requested UL_PB columns ahead.
+constexpr int UL_LANE_CHAIN = 12;  // ordered chains up to this length run on lane reads (15-21 cycles a term), longer ones through LDS (~300 cycles + 7 a term)
 constexpr int UL_PB = 4;   // columns whose first 64 entries are in flight
 constexpr int UL_AR = 5;   // list entries per lane fetched before the wait (lists of up to 320 rows; longer ones finish in a loop)
 template <class Wait>
@@ -880,7 +881,7 @@ __device__ __forceinline__ bool ul_bwd_task(const UlSolve2Args& a, const int t, 
                     const double xin = __shfl(xfin, sl < 64 ? sl : 0, 64);
                     const double xo = s_xa[sl >= 64 ? sl - 64 : 0];
                     const double pr = __dmul_rn(v, sl < 64 ? xin : xo);
-                    if (cnt <= 4) s = chain_sub(s, pr, cnt);
+                    if (cnt <= UL_LANE_CHAIN) s = chain_sub(s, pr, cnt);  // (short chains by lane reads: an LDS round trip costs more than a dozen of them)
                     else {
                         s_pr[lane] = lane < cnt ? pr : 0.0;
                         wave_sync();
