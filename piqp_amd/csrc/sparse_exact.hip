@@ -758,22 +758,29 @@ __device__ __forceinline__ bool ul_fwd_task(const UlSolve2Args& a, const int t, 
         rtask = a.fs_task[fs0 + (live ? q : 0)];
         if (!live) { r.x = 0; r.z = 0; r.w = 0; rtask = t; }
     };
-    int4 nrec; int nrt;
+    // Pipeline over the chunks of 64 columns: records three chunks ahead, the "done" words of a chunk's tasks two chunks ahead, its x values one chunk ahead -- and
+    // the x values ONLY after every one of those words has been SEEN set (a load of x issued behind a load of the word that has not returned yet may be served
+    // before it: the word would say "complete" about an x read too early; found by two netlib fixtures whose solves differed in the last bits).  A chunk with a
+    // task still running is waited for after the current chunk's steps.
+    int4 nrec, nnrec; int nrt, nnrt;
     fetch(64, nrec, nrt);
+    fetch(128, nnrec, nnrt);
     double pf_v[PFS];
 #pragma unroll
     for (int d = 0; d < PFS; ++d) pf_v[d] = (tbase + (size_t)__builtin_amdgcn_readlane(rec.x, d) * W)[lw];
+    int nflag = ldf(a.fdone + nrt);
     if (!wait() || !wait_sources(rt)) return false;
     double xs = ldw(a.xf + rec.y);   // (a path column's value is taken from its lane instead)
     for (int base = 0; base < nsrc; base += 64) {
         const int ns = min(64, nsrc - base);
         const int ue = rec.x, mlo = rec.z, mhi = rec.w;
         const double xcur = xs;
-        // two chunks ahead: the records; one chunk ahead: a look at its columns' tasks and, on the assumption that they are complete, its x values
-        int4 nnrec; int nnrt;
-        fetch(base + 128, nnrec, nnrt);
-        const int nflag = ldf(a.fdone + nrt);
-        double nxs = ldw(a.xf + nrec.y);
+        const bool spec = __ballot(nrt != t && nflag != a.epoch) == 0;  // (nflag was requested a whole chunk ago: it is here)
+        double nxs = 0.0;
+        if (spec) nxs = ldw(a.xf + nrec.y);
+        const int nnflag = ldf(a.fdone + nnrt);
+        int4 n3rec; int n3rt;
+        fetch(base + 192, n3rec, n3rt);
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             if (half * 32 < ns) {
@@ -787,12 +794,11 @@ __device__ __forceinline__ bool ul_fwd_task(const UlSolve2Args& a, const int t, 
                 }
             }
         }
-        if (base + 64 < nsrc && __ballot(nrt != t && nflag != a.epoch) != 0) {
-            // some column of the next chunk belongs to a task that was still running a chunk ago: wait for it now, and read the x values again
+        if (!spec && base + 64 < nsrc) {
             if (!wait_sources(nrt)) return false;
             nxs = ldw(a.xf + nrec.y);
         }
-        rec = nrec; rt = nrt; xs = nxs; nrec = nnrec; nrt = nnrt;
+        rec = nrec; rt = nrt; xs = nxs; nrec = nnrec; nrt = nnrt; nflag = nnflag; nnrec = n3rec; nnrt = n3rt;
     }
     if (lane < W) { stw(a.xf + row, acc); stw(a.xz + row, __dmul_rn(acc, dinv)); }
     return true;
