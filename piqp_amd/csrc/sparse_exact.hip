@@ -304,12 +304,20 @@ __device__ __forceinline__ bool spin_until(const int* flag, int epoch)
 }
 
 // a word that has not been written in this factorisation: a quiet NaN no computation produces (hardware NaNs are canonical, propagated ones carry their
-// operand's payload); k_ul_fill_sent puts it into D and into the tasks' tables before every factorisation
+// operand's payload); k_ul_prepare puts it into D and into the tasks' tables before every factorisation
 constexpr long long UL_SENT = 0x7ff8dead5eed0001ll;
-__global__ void k_ul_fill_sent(size_t n, double* __restrict__ p)
+// ... in ONE launch with the reset of the ticket counters and of the result word (five small operations on the stream before: ~20 us of a 60 us factorisation
+// of a 59-row system)
+__global__ void k_ul_prepare(size_t nd, double* __restrict__ D, size_t nl, double* __restrict__ Dloc, size_t nt, double* __restrict__ table, int* __restrict__ ctl,
+                             int* __restrict__ xtick)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = __longlong_as_double(UL_SENT);
+    const double sent = __longlong_as_double(UL_SENT);
+    if (i < nd) D[i] = sent;
+    if (i < nl) Dloc[i] = sent;
+    for (size_t j = i; j < nt; j += (size_t)gridDim.x * blockDim.x) table[j] = sent;
+    if (i < 128 && xtick) xtick[i] = 0;
+    if (i == 0) { ctl[0] = 0; ctl[1] = INT_MAX; }
 }
 // which XCD does a workgroup of a launch of this shape land on?  (the per-XCD queues are only used when every one of the eight gets workgroups)
 __global__ void k_ul_xcd_probe(int* __restrict__ count)
@@ -590,7 +598,7 @@ __device__ __forceinline__ bool ul_path_row(const UlFactorArgs& a, const int k, 
                         term = readlane_d(ch.ps, s & 63);
                     } else {
                         // A path column c0.  What this row needs from the rows below arrives AS VALUES (round 5): D of row c0 and, for the rows c between c0 and
-                        // this one that hold an entry in column c0, their quotient L(c, c0) -- words that hold UL_SENT until their row stores them (k_ul_fill_sent
+                        // this one that hold an entry in column c0, their quotient L(c, c0) -- words that hold UL_SENT until their row stores them (k_ul_prepare
                         // before every factorisation), polled with the same loads that fetch them: one round trip per hand-over instead of flag, value, drained
                         // store, flag, value.  This row's own quotient goes out the same way, at once.
                         const int c0 = u - nU;
@@ -1064,9 +1072,6 @@ public:
         prof_.end(0, t0, st_);
         const int t1 = prof_.begin(1, st_);
         ++epoch_;
-        ctl_h_.p[0] = 0; ctl_h_.p[1] = INT_MAX;
-        PQ_HIP(hipMemcpyAsync(ctl_.p, ctl_h_.p, 2 * sizeof(int), hipMemcpyHostToDevice, st_));
-        if (xq_on_) PQ_HIP(hipMemsetAsync(xtick_.p, 0, sizeof(int) * 8 * 16, st_));
         UlFactorArgs a;
         a.N = N_; a.nticket = nticket_; a.epoch = epoch_;
         a.Cp = Cp_.p; a.Ci = Ci_.p; a.Cx = vals_.p;
@@ -1079,9 +1084,11 @@ public:
         a.yglob = yglob_.p;
         a.trace = trace_.n > 1 ? trace_.p : nullptr;
         if (N_ > 0) {
-            hipLaunchKernelGGL(k_ul_fill_sent, dim3((unsigned)((D_.n + 255) / 256)), dim3(256), 0, st_, D_.n, D_.p);
-            if (xq_on_) hipLaunchKernelGGL(k_ul_fill_sent, dim3((unsigned)((Dloc_.n + 255) / 256)), dim3(256), 0, st_, Dloc_.n, Dloc_.p);
-            hipLaunchKernelGGL(k_ul_fill_sent, dim3((unsigned)((Lblock_.n + 255) / 256)), dim3(256), 0, st_, Lblock_.n, Lblock_.p);
+            {
+                const size_t most = std::max(std::max(D_.n, Lblock_.n / 8 + 1), (size_t)128);  // (the table: up to eight words per thread)
+                hipLaunchKernelGGL(k_ul_prepare, dim3((unsigned)((most + 255) / 256)), dim3(256), 0, st_, D_.n, D_.p, xq_on_ ? Dloc_.n : (size_t)0, Dloc_.p, Lblock_.n, Lblock_.p, ctl_.p,
+                                   xq_on_ ? xtick_.p : (int*)nullptr);
+            }
             auto launch = [&] {
                 if (lds_y_) hipLaunchKernelGGL(k_ul_factor<true>, dim3(grid_), dim3(64), (size_t)N_ * sizeof(double), st_, a);
                 else hipLaunchKernelGGL(k_ul_factor<false>, dim3(grid_), dim3(64), 0, st_, a);
@@ -1091,6 +1098,7 @@ public:
         }
         PQ_HIP(hipGetLastError());
         prof_.end(1, t1, st_);
+        if (N_ == 0) { stream_wait(st_); return true; }  // (nothing to factor)
         PQ_HIP(hipMemcpyAsync(ctl_h_.p + 2, ctl_.p + 1, sizeof(int), hipMemcpyDeviceToHost, st_));
         stream_wait(st_);
         if (ctl_h_.p[2] <= -2) {
