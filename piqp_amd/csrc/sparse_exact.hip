@@ -993,7 +993,7 @@ struct XqLaunchOrder {
         if (it != last.end() && it->second.ev == own) last.erase(it);
     }
 };
-inline XqLaunchOrder& xq_launch_order() { static XqLaunchOrder o; return o; }
+inline XqLaunchOrder& xq_launch_order() { static XqLaunchOrder* o = new XqLaunchOrder; return *o; }  // (never destroyed: handles may outlive the statics at process exit)
 
 class ExactSparseKKT final : public KKTSolverBase {
 public:
