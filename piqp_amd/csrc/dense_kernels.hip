@@ -3221,7 +3221,7 @@ __global__ __launch_bounds__(256) void k_trsv_bwd_step(const double* __restrict_
 
 // ------------------------------------------------------------------------------------------------
 // Persistent triangular sweep: ONE launch per sweep, one workgroup per 128-row block, blocks chained through
-// per-block flags instead of kernel boundaries.  Block r waits only for the x_j it consumes next; the 128x128
+// the solution values themselves instead of kernel boundaries (round 5; per-block flags until round 4 -- see below).  Block r waits only for the x_j it consumes next; the 128x128
 // block of L it will multiply by x_j is already in registers when x_j arrives (its loads are issued before the
 // wait), and its own diagonal block is staged in LDS at kernel start.  Hand-off follows the write-through recipe
 // (cdna_hip_programming.md, Guideline 16 R1): x_r is stored with agent-scope relaxed atomics (sc1, L2
@@ -3234,6 +3234,46 @@ __device__ __forceinline__ void st_agent(double* p, double v)
     // (explicit global address space: these helpers only ever touch device memory, and inside the out-of-line roles of k_chol_persistent a pointer read from
     // the argument struct is a generic one to the compiler -- FLAT instructions, which tie the LDS waits to the global traffic)
     __hip_atomic_store((__attribute__((address_space(1))) u64*)reinterpret_cast<u64*>(p), (u64)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// round 5: the hand-over is the VALUE.  The solution of a sweep is written into a buffer of its own (ypoll: one per direction) that holds TRSV_SENT -- a NaN with a
+// payload no arithmetic produces -- in every word not yet solved; a consumer polls the 128 words it needs (one per lane of its first two waves) until they are no
+// sentinels.  One trip to the memory side instead of two (flag, then values), and the producer neither drains its stores nor publishes.  A block puts the
+// sentinels back into the OTHER direction's buffer when it is done (stream order separates the sweeps), so the buffers are ready for the next solve.
+constexpr u64 TRSV_SENT = 0x7ff8dead5eed0002ull;
+__device__ __forceinline__ void st_agent_bits(double* p, u64 v)
+{
+    __hip_atomic_store((__attribute__((address_space(1))) u64*)reinterpret_cast<u64*>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// ONE XCD (round 5): a sweep of at most 32 block rows runs on the 32 compute units of XCD 0 alone -- the launch has eight times the workgroups, those that land
+// elsewhere leave at once, the others take their block rows by ticket.  Producer and consumer then share an L2: the values are stored plainly (they stay in that
+// L2) and polled there, instead of travelling to the memory side and back between two XCDs (1.8 us of the 3.5 us a block row took).
+__device__ __forceinline__ void st_wg(double* p, double v)
+{
+    __hip_atomic_store((__attribute__((address_space(1))) u64*)reinterpret_cast<u64*>(p), (u64)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ int xcc_id_of_wave()
+{
+    int v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(v));
+    return v & 7;
+}
+__global__ void k_xcd_probe(int* __restrict__ count)
+{
+    if (threadIdx.x == 0) atomicAdd(count + xcc_id_of_wave(), 1);
+}
+// true when a launch of 8 x 32 workgroups puts exactly 32 on every XCD (eight XCDs served round robin: the mode this device is normally in)
+bool probe_one_xcd_sweeps(hipStream_t s)
+{
+    int* cnt = nullptr;
+    PQ_HIP(hipMalloc(&cnt, 8 * sizeof(int)));
+    PQ_HIP(hipMemsetAsync(cnt, 0, 8 * sizeof(int), s));
+    hipLaunchKernelGGL(k_xcd_probe, dim3(256), dim3(256), 0, s, cnt);
+    int h[8];
+    PQ_HIP(hipMemcpyAsync(h, cnt, sizeof(h), hipMemcpyDeviceToHost, s));
+    PQ_HIP(hipStreamSynchronize(s));
+    PQ_HIP(hipFree(cnt));
+    for (int q = 0; q < 8; ++q) if (h[q] != 32) return false;
+    return true;
 }
 __device__ __forceinline__ double ld_agent(const double* p)
 {
@@ -3266,85 +3306,102 @@ __device__ __forceinline__ ddn dd_div_d(ddn a, double b)
     ddn q = dd_quick(q1, q2);
     return dd_add(q, {q3, 0.0});
 }
-constexpr int DD_TRI = 128 * 129 / 2;
 __host__ __device__ inline int dd_diag_off(int s) { return s * 128 - (s * (s - 1)) / 2; }
-// V = L_rr^-1 of every 128-row diagonal block (identity beyond the matrix; UNIT: unit diagonal, the stored one is D), 32 columns of V per workgroup:
-// block forward substitution in groups of 16 rows, X_g = W_g (E_g - sum_{h < g} L_gh X_h), W_g = L_gg^-1, everything in double-double.
-constexpr int DDI_LDS_BYTES = (128 * 32 + 8 * 256) * (int)sizeof(ddn);
+// V = L_rr^-1 of every 128-row diagonal block (identity beyond the matrix; UNIT: unit diagonal, the stored one is D), rounded to double, 8 columns of V per
+// workgroup: block forward substitution in groups of 16 rows, X_g = W_g (E_g - sum_{h < g} L_gh X_h).  The sums over the earlier groups -- where the conditioning
+// of the whole block enters -- run in double-double; W_g = L_gg^-1, the inverse of one 16 x 16 piece, in double (its error is eps times the condition of that piece).
+// Thread = (row i of the group, column jq, half ks of the 16 terms of a product); the two halves sit 32 lanes apart in one wave.
+constexpr int DDI_LDS_BYTES = 128 * 8 * (int)sizeof(ddn) + (8 * 256 + 36 * 256) * (int)sizeof(double);
+__device__ __forceinline__ ddn dd_lane_sum32(ddn a)  // a + the value of the lane 32 further (both lanes get the sum)
+{
+    const ddn o = {__shfl_xor(a.h, 32), __shfl_xor(a.l, 32)};
+    return dd_add(a, o);
+}
 template <bool UNIT>
-__global__ __launch_bounds__(256) void k_block_inverse_dd(const double* __restrict__ L, int ld, int n, double* __restrict__ Vh, double* __restrict__ Vl)
+__global__ __launch_bounds__(256) void k_block_inverse_dd(const double* __restrict__ L, int ld, int n, double* __restrict__ Vsq)
 {
     extern __shared__ __attribute__((aligned(16))) double ddi_sm[];
-    ddn* X = reinterpret_cast<ddn*>(ddi_sm);   // [128][32]: rows of the block, this workgroup's 32 columns
-    ddn* W = X + 128 * 32;                     // [8][16][16]: W[g][i + 16 k] = (L_gg^-1)(i, k)
-    const int tid = threadIdx.x, J = blockIdx.x, r = blockIdx.y;
-    const int row0 = r * 128, nrows = min(128, n - row0), j0 = 32 * J;
-    auto lval = [&](int i, int k) -> double {  // entry (i, k) of the block, i >= k; identity beyond the matrix, unit diagonal if UNIT
-        if (i >= nrows || k >= nrows) return i == k ? 1.0 : 0.0;
-        if (UNIT && i == k) return 1.0;
-        return L[(size_t)(row0 + i) + (size_t)(row0 + k) * ld];
-    };
-    // ---- W_g: one thread per column of every 16 x 16 diagonal piece
-    if (tid < 128) {
-        const int g = tid >> 4, k = tid & 15;
-        ddn w[16];
+    ddn* X = reinterpret_cast<ddn*>(ddi_sm);                  // [128][8]: rows of the block, this workgroup's 8 columns
+    double* W = reinterpret_cast<double*>(X + 128 * 8);       // [8][16][16]: W[g][i + 16 k] = (L_gg^-1)(i, k)
+    double* Lt = W + 8 * 256;                                 // the block's 16 x 16 tiles (g, h), h <= g: tile at 256 (g (g + 1) / 2 + h), entry (i, k) at [16 k + i]
+    const int tid = threadIdx.x, J = blockIdx.y, r = blockIdx.x;  // (dispatch order: the column groups with the most rows below them first, for every block)
+    const int row0 = r * 128, nrows = min(128, n - row0), j0 = 8 * J;
+    const int g0 = J >> 1;  // the rows above the first column of this column group are zero
+    // tiles with g0 <= h <= g; identity beyond the matrix, unit diagonal if UNIT.  (Read from global memory where they are used, every one of the up to 28 (g, h)
+    // steps of a thread waited for a memory round trip.)
+    {
+        const int i = tid & 15, k = tid >> 4;
+        double v[36];  // (every load requested before the first store)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) w[i] = {0.0, 0.0};
+        for (int g = 0; g < 8; ++g)
+#pragma unroll
+            for (int h = 0; h <= g; ++h) {
+                const int gi = 16 * g + i, gk = 16 * h + k;
+                double e = gi == gk ? 1.0 : 0.0;
+                if (h >= g0 && gi < nrows && gk < nrows && !(UNIT && gi == gk)) e = gi >= gk ? L[(size_t)(row0 + gi) + (size_t)(row0 + gk) * ld] : 0.0;
+                v[g * (g + 1) / 2 + h] = e;
+            }
+#pragma unroll
+        for (int t = 0; t < 36; ++t) Lt[256 * t + 16 * k + i] = v[t];
+    }
+    for (int idx = tid; idx < 128 * 8; idx += 256) X[idx] = {0.0, 0.0};
+    __syncthreads();
+    auto lval = [&](int gi, int gk) -> double { return Lt[256 * ((gi >> 4) * ((gi >> 4) + 1) / 2 + (gk >> 4)) + 16 * (gk & 15) + (gi & 15)]; };  // gi >= gk >= 16 g0
+    // ---- W_g: one thread per column of every 16 x 16 diagonal piece this workgroup needs
+    if (tid < 128 && (tid >> 4) >= g0) {
+        const int g = tid >> 4, k = tid & 15;
+        double w[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            if (i < k) continue;
-            ddn sacc = {i == k ? 1.0 : 0.0, 0.0};
+            double sacc = i == k ? 1.0 : 0.0;
 #pragma unroll
             for (int m2 = 0; m2 < 16; ++m2)
-                if (m2 >= k && m2 < i) sacc = dd_add(sacc, dd_neg(dd_mul_d(w[m2], lval(16 * g + i, 16 * g + m2))));
-            w[i] = dd_div_d(sacc, lval(16 * g + i, 16 * g + i));
+                if (m2 < i) sacc -= (m2 >= k ? w[m2] : 0.0) * lval(16 * g + i, 16 * g + m2);
+            w[i] = i < k ? 0.0 : sacc / lval(16 * g + i, 16 * g + i);
         }
 #pragma unroll
         for (int i = 0; i < 16; ++i) W[g * 256 + i + 16 * k] = w[i];
     }
-    for (int idx = tid; idx < 128 * 32; idx += 256) X[idx] = {0.0, 0.0};
     __syncthreads();
-    const int i = tid & 15, jq = tid >> 4;  // entries (i, jq) and (i, jq + 16) of the current group
-    const int g0 = j0 >> 4;                 // the rows above the first column of this column group are zero
+    const int lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, jq = 2 * wave + ((lane >> 4) & 1), ks = lane >> 5;
     for (int g = g0; g < 8; ++g) {
-        ddn t0 = {(16 * g + i == j0 + jq) ? 1.0 : 0.0, 0.0}, t1 = {(16 * g + i == j0 + jq + 16) ? 1.0 : 0.0, 0.0};
+        ddn ta = {0.0, 0.0}, tb = {0.0, 0.0};
         for (int h = g0; h < g; ++h) {
-            double lrow[16];
+            double lrow[8];
 #pragma unroll
-            for (int k = 0; k < 16; ++k) lrow[k] = lval(16 * g + i, 16 * h + k);
+            for (int k = 0; k < 8; ++k) lrow[k] = lval(16 * g + i, 16 * h + 8 * ks + k);
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                t0 = dd_add(t0, dd_neg(dd_mul_d(X[(16 * h + k) * 32 + jq], lrow[k])));
-                t1 = dd_add(t1, dd_neg(dd_mul_d(X[(16 * h + k) * 32 + jq + 16], lrow[k])));
+            for (int k = 0; k < 8; k += 2) {  // (two sums: the chain through one double-double sum is what the thread waits for)
+                ta = dd_add(ta, dd_mul_d(X[(16 * h + 8 * ks + k) * 8 + jq], lrow[k]));
+                tb = dd_add(tb, dd_mul_d(X[(16 * h + 8 * ks + k + 1) * 8 + jq], lrow[k + 1]));
             }
         }
+        const ddn tsum = dd_lane_sum32(dd_add(ta, tb));
+        const ddn t0 = dd_add({(16 * g + i == j0 + jq) ? 1.0 : 0.0, 0.0}, dd_neg(tsum));
         // X_g = W_g T: T through LDS (the rows of X_g are free until now)
-        X[(16 * g + i) * 32 + jq] = t0; X[(16 * g + i) * 32 + jq + 16] = t1;
+        if (ks == 0) X[(16 * g + i) * 8 + jq] = t0;
         __syncthreads();
-        ddn x0 = {0.0, 0.0}, x1 = {0.0, 0.0};
+        ddn xa = {0.0, 0.0};
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            if (k > i) continue;  // W_g is lower triangular
-            const ddn wv = W[g * 256 + i + 16 * k];
-            x0 = dd_add(x0, dd_mul(wv, X[(16 * g + k) * 32 + jq]));
-            x1 = dd_add(x1, dd_mul(wv, X[(16 * g + k) * 32 + jq + 16]));
+        for (int k = 0; k < 8; ++k) {
+            const int kk = 8 * ks + k;
+            if (kk <= i) xa = dd_add(xa, dd_mul_d(X[(16 * g + kk) * 8 + jq], W[g * 256 + i + 16 * kk]));  // W_g is lower triangular
         }
+        xa = dd_lane_sum32(xa);
         __syncthreads();
-        X[(16 * g + i) * 32 + jq] = x0; X[(16 * g + i) * 32 + jq + 16] = x1;
+        if (ks == 0) X[(16 * g + i) * 8 + jq] = xa;
         __syncthreads();
     }
-    // ---- out, by diagonals
-    double* vh = Vh + (size_t)r * DD_TRI;
-    double* vl = Vl + (size_t)r * DD_TRI;
-    for (int idx = tid; idx < 128 * 32; idx += 256) {
-        const int row = idx >> 5, col = j0 + (idx & 31);
-        if (row < col) continue;
-        const ddn v = X[row * 32 + (idx & 31)];
-        const int at = dd_diag_off(row - col) + col;
-        vh[at] = v.h; vl[at] = v.l;
+    // ---- out: the inverse rounded to double, a plain 128 x 128 column-major block (zeros above the diagonal)
+    double* vs = Vsq + (size_t)r * 128 * 128;
+    for (int idx = tid; idx < 128 * 8; idx += 256) {
+        const int row = idx & 127, cl = idx >> 7, col = j0 + cl;
+        const ddn v = X[row * 8 + cl];
+        vs[(size_t)col * 128 + row] = row < col ? 0.0 : v.h + v.l;
     }
 }
-void launch_block_inverse_dd(bool unit, const double* L, int ld, int n, double* Vh, double* Vl, hipStream_t s)
+void launch_block_inverse_dd(bool unit, const double* L, int ld, int n, double* Vsq, hipStream_t s)
 {
     if (n <= 0) return;
     static PerDeviceOnce attr_set;
@@ -3353,11 +3410,11 @@ void launch_block_inverse_dd(bool unit, const double* L, int ld, int n, double* 
         PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_block_inverse_dd<true>), hipFuncAttributeMaxDynamicSharedMemorySize, DDI_LDS_BYTES));
     });
     const int nblk = div_up(n, 128);
-    if (unit) hipLaunchKernelGGL(k_block_inverse_dd<true>, dim3(4, nblk), dim3(256), DDI_LDS_BYTES, s, L, ld, n, Vh, Vl);
-    else hipLaunchKernelGGL(k_block_inverse_dd<false>, dim3(4, nblk), dim3(256), DDI_LDS_BYTES, s, L, ld, n, Vh, Vl);
+    if (unit) hipLaunchKernelGGL(k_block_inverse_dd<true>, dim3(nblk, 16), dim3(256), DDI_LDS_BYTES, s, L, ld, n, Vsq);
+    else hipLaunchKernelGGL(k_block_inverse_dd<false>, dim3(nblk, 16), dim3(256), DDI_LDS_BYTES, s, L, ld, n, Vsq);
     PQ_HIP(hipGetLastError());
 }
-size_t block_inverse_dd_doubles(int n) { return (size_t)div_up(n, 128) * DD_TRI; }
+size_t block_inverse_dd_doubles(int n) { return (size_t)div_up(n, 128) * 128 * 128; }
 
 // (Serving a block row with several workgroups on several CUs -- helpers taking the earlier producers, the owner the last one -- was
 // measured slower in round 1: 203 / 222 us per sweep with one workgroup per row, 222 / 234 with two, 257 / 267 with four; the extra
@@ -3372,11 +3429,13 @@ size_t block_inverse_dd_doubles(int n) { return (size_t)div_up(n, 128) * DD_TRI;
 // (the conditioning level of the panel solve, which holds the accuracy gates of tests/dense_replay.py -- unlike a 128 x 128 inverse), one wave;
 // then every thread takes its 8 columns of the group off the rows still to be solved.  Two LDS barriers per group instead of a 128-step
 // dependent chain on one wave (4.2 us per block in round 1).  W16 == nullptr keeps that substitution (reciprocal pivots in rdiag).
-// DD (double-double inverses, Vh / Vl): 512 threads -- the product phase uses the first 256 exactly as without DD, the diagonal step all of them (four per row)
-template <bool FWD, bool DD>
-__global__ __launch_bounds__(DD ? 512 : 256) void k_trsv_persistent(const double* __restrict__ L, int ld, int n, double* __restrict__ x, const double* __restrict__ rdiag,
-                                                         int nblk, int* __restrict__ flags, int* __restrict__ err, const double* __restrict__ W16, int token, long long* __restrict__ ts,
-                                                         const double* __restrict__ Vh, const double* __restrict__ Vl)
+// INV (round 5; Vinv = the rounded inverses of the 128 x 128 diagonal blocks, launch_block_inverse_dd): the diagonal step is ONE product x_r = V_r b_r, the entries
+// of V_r held in registers for the whole launch (64 per thread -- the workgroup keeps its 256 threads: 512 of them have 256 registers each, and two operand
+// blocks in flight next to V spill; round 4's 512-thread compensated product with the double-double inverse spilled 300 - 1200 registers and was removed)
+template <bool FWD, bool INV>
+__global__ __launch_bounds__(256) void k_trsv_persistent(const double* __restrict__ L, int ld, int n, double* __restrict__ x, const double* __restrict__ rdiag,
+                                                         int nblk, double* __restrict__ ysrc, double* __restrict__ yother, const double* __restrict__ dscale, int* __restrict__ err,
+                                                         const double* __restrict__ W16, long long* __restrict__ ts, const double* __restrict__ Vinv, int* __restrict__ tkt, int tbase, int H, double* __restrict__ psrc, double* __restrict__ pother)
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double* Ls = sm;                    // own diagonal block, Ls[c * (TB+1) + r]
@@ -3387,59 +3446,91 @@ __global__ __launch_bounds__(DD ? 512 : 256) void k_trsv_persistent(const double
     double* up = Wg + 8 * 256;          // scratch of the diagonal step
     __shared__ int ok_s;
     __shared__ int sync_w[4];           // diagonal step: [0] groups solved by the chain wave, [1], [2] groups applied by the helper waves
+    __shared__ int ridx_s;
+    const bool xq = tkt != nullptr;     // one-XCD mode: block rows by ticket among the workgroups on XCD 0
+    if (xq && xcc_id_of_wave() != 0) return;
     if (threadIdx.x < 4) sync_w[threadIdx.x] = 0;
+    if (threadIdx.x == 0) { ok_s = 1; ridx_s = xq ? atomicAdd(tkt, 1) - tbase : (int)blockIdx.x; }
+    __syncthreads();
+    // INV, H > 0: every block row has H helper workgroups in front of its owner (workgroup = ridx (1 + H) + role, the owner's role is H).  Helper h multiplies the
+    // operand blocks of the producers t = h, h + H, ... < nsteps - 2 and hands its partial sums over (psrc, polled like the solution values); the owner keeps the last
+    // two producers, the diagonal step and the hand-over.  One workgroup per block row streams its whole row of L through one compute unit -- 131 KB per step, ~2.5 us
+    // -- which no chain shorter than that can hide; with the helpers a row's operand blocks arrive through up to eight compute units.
+    const int role = (INV && H > 0) ? ridx_s % (1 + H) : 0;
+    const bool helper = INV && H > 0 && role < H;
+    if (ridx_s / ((INV && H > 0) ? 1 + H : 1) >= nblk) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const bool act = !DD || tid < 256;  // takes part in the product phase
-    const int ridx = (int)blockIdx.x;   // position of the block in sweep order
+    constexpr int NQ = 2;               // threads per row in the product phase: CW columns of the operand block each
+    constexpr int CW = TB / NQ;
+    const bool act = true;
+    const int ridx = (INV && H > 0) ? ridx_s / (1 + H) : ridx_s;  // position of the block in sweep order
     const int r = FWD ? ridx : nblk - 1 - ridx;
     const int row0 = r * TB, nrows = min(TB, n - row0);
     // stage the diagonal block (transposed for the backward sweep) and reciprocal pivots -- or, Vh != nullptr, its double-double inverse by diagonals (hi | lo: the
     // same 16 512 doubles), see k_block_inverse_dd
-    if constexpr (DD) {
-        const double* vh = Vh + (size_t)r * DD_TRI;
-        const double* vl = Vl + (size_t)r * DD_TRI;
-        // (sixteen loads in flight per thread: one load per loop trip cost a memory round trip each, 65 of them in front of the first block row's turn)
-        constexpr int NTH = 512;
-        for (int base = 0; base < DD_TRI; base += 8 * NTH) {
-            double a[8], b[8];
+    if constexpr (INV) {
+        // the rounded inverse of the block (128 x 128 column-major, zeros included): Ls[c * (TB + 1) + row] = V(row, c) for the forward sweep, V(c, row) for the
+        // backward one (x = V^T b)
+        const double* vs = Vinv + (size_t)r * TB * TB;
+        for (int base = 0; base < (helper ? 0 : TB * TB); base += 8 * 256) {
+            double a[8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) { const int idx = base + q * NTH + tid; a[q] = idx < DD_TRI ? vh[idx] : 0.0; b[q] = idx < DD_TRI ? vl[idx] : 0.0; }
+            for (int q = 0; q < 8; ++q) a[q] = vs[base + q * 256 + tid];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) { const int idx = base + q * NTH + tid; if (idx < DD_TRI) { Ls[idx] = a[q]; Ls[DD_TRI + idx] = b[q]; } }
+            for (int q = 0; q < 8; ++q) {
+                const int idx = base + q * 256 + tid, lo = idx & (TB - 1), hi = idx >> 7;  // entry (lo, hi) of V
+                if (FWD) Ls[hi * (TB + 1) + lo] = a[q]; else Ls[lo * (TB + 1) + hi] = a[q];
+            }
         }
     } else stage_lower_block<TB, TB + 1, 256, !FWD>(L + row0 + (size_t)row0 * ld, ld, nrows, Ls, tid);
     if (tid < TB) rd[tid] = (rdiag && tid < nrows) ? rdiag[row0 + tid] : 1.0;
-    if (W16 && !DD && tid < 256) {
+    if (W16 && !INV) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) Wg[u * 256 + tid] = W16[(size_t)r * 8 * 256 + u * 256 + tid];
     }
-    const int row = tid & 127, half = (tid >> 7) & 1, quarter = tid >> 7;
-    (void)quarter;
-    double mine = (act && quarter == 0 && row < nrows) ? x[row0 + row] : 0.0;
+    const int row = tid & 127, half = (tid >> 7) & 1, quarter = tid >> 7;  // (256 threads: quarter == half)
+    (void)half;
+    // the right-hand side: x for the forward sweep; the forward sweep's solution (times 1 / D for LDLt) for the backward one
+    double mine = 0.0;
+    if (!helper && quarter == 0 && row < nrows) {
+        if (FWD) mine = x[row0 + row];
+        else { mine = yother[row0 + row]; if (dscale) mine *= dscale[row0 + row]; }
+    }
+    // INV: this thread's 64 entries of the inverse, V(row, 64 half + c) resp. V(64 half + c, row), move from LDS into registers when the block turns to its LAST
+    // producer -- into the operand buffer that has no next block to receive (earlier they would sit next to two operand blocks in flight and spill)
+    constexpr int LOADV = -2;
+    auto load_v = [&](double (&vr)[CW]) {
+#pragma unroll
+        for (int c = 0; c < CW; ++c) vr[c] = Ls[(half * CW + c) * (TB + 1) + row];
+        // (pinned here: left to itself the compiler sinks these reads to their use, behind the arrival of the last producer's values -- 1 000 cycles of LDS
+        // traffic on the chain of every block row)
+#pragma unroll
+        for (int c = 0; c < CW; ++c) asm volatile("" : "+v"(vr[c]));
+    };
     double acc = 0.0;
     const int nsteps = ridx;  // producers of this block row, in sweep order t = 0 .. nsteps - 1
     // operand block of step t (producer block j_t) into registers; two steps are kept in flight: the block for the next step is requested
     // before the wait for x_{j_t}, so its latency never sits between the arrival of x and the hand-off to the next block
-    auto load_block = [&](int t, double (&lv)[64]) {
+    auto load_block = [&](int t, double (&lv)[CW]) {
         if (!act) return;
         const int j = FWD ? t : nblk - 1 - t;
         const int c0 = j * TB;
         const int nc = min(TB, n - c0);
         if (FWD) {  // rows of block r, columns of block j: L[row0+row, c0 + half*64 + c]
-            const double* Lp = L + (row0 + row) + (size_t)(c0 + half * 64) * ld;
+            const double* Lp = L + (row0 + row) + (size_t)(c0 + quarter * CW) * ld;
 #pragma unroll
-            for (int c = 0; c < 64; ++c) lv[c] = (row < nrows) ? Lp[(size_t)c * ld] : 0.0;
+            for (int c = 0; c < CW; ++c) lv[c] = (row < nrows) ? Lp[(size_t)c * ld] : 0.0;
         } else {    // transposed: L[c0 + half*64 + c, row0+row] (column row0+row of L, contiguous in c)
-            const double* Lp = L + (c0 + half * 64) + (size_t)(row0 + row) * ld;
+            const double* Lp = L + (c0 + quarter * CW) + (size_t)(row0 + row) * ld;
             if (((ld & 1) == 0) && ((reinterpret_cast<uintptr_t>(L) & 15) == 0) && nc == TB && row < nrows) {
 #pragma unroll
-                for (int c = 0; c < 64; c += 2) {
+                for (int c = 0; c < CW; c += 2) {
                     const d2 t2 = *reinterpret_cast<const d2*>(Lp + c);
                     lv[c] = t2.x; lv[c + 1] = t2.y;
                 }
             } else {
 #pragma unroll
-                for (int c = 0; c < 64; ++c) lv[c] = (row < nrows && half * 64 + c < nc) ? Lp[c] : 0.0;
+                for (int c = 0; c < CW; ++c) lv[c] = (row < nrows && quarter * CW + c < nc) ? Lp[c] : 0.0;
             }
         }
     };
@@ -3449,112 +3540,142 @@ __global__ __launch_bounds__(DD ? 512 : 256) void k_trsv_persistent(const double
         __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
         __builtin_amdgcn_s_barrier();
     };
-    auto wait_flag = [&](const int* f) -> bool {
-        if (tid == 0) {
-            int ok = 1;
-            unsigned spins = 0;
-            while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != token) {
-                __builtin_amdgcn_s_sleep(1);
-                if (++spins > 20000000u) { ok = 0; __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-            }
-            ok_s = ok;
-        }
-        lds_barrier();
-        return ok_s != 0;
-    };
-    // consumes step t with the operand block lv; the request for the next step (into nxt) is issued right AFTER the load of x_j, so that the
+    // consumes step t with the operand block lv; the request for the next step (into nxt) is issued right AFTER x_j has arrived, so that the
     // in-order return of x_j does not wait behind it
-    auto consume = [&](int t, const double (&lv)[64], double (&nxt)[64], int t_next) -> bool {
+    auto consume = [&](int t, const double (&lv)[CW], double (&nxt)[CW], int t_next) -> bool {
         const int j = FWD ? t : nblk - 1 - t;
         const int c0 = j * TB;
         const int nc = min(TB, n - c0);
-        if (!wait_flag(flags + j)) return false;
-        if (ts && tid == 0 && t + 1 == nsteps) ts[4 * r + 0] = clock64();  // debugging aid: the last producer's flag seen
-        const double xv = (tid < TB && tid < nc) ? ld_agent(x + c0 + tid) : 0.0;
+        if (INV && t_next == LOADV) load_v(nxt);
+        double xv = 0.0;
+        if (tid < TB && tid < nc) {
+            unsigned spins = 0;
+            while (true) {
+                xv = ld_agent(ysrc + c0 + tid);
+                if ((u64)__double_as_longlong(xv) != TRSV_SENT) break;
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > 20000000u) { ok_s = 0; __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            }
+        }
+        if (ts && tid == 0 && t + 1 == nsteps) ts[4 * r + 0] = wall_clock64();  // debugging aid: the last producer's values seen (by the first lane)
         if (t_next >= 0) load_block(t_next, nxt);
         if (tid < TB) xs[tid] = xv;
         lds_barrier();
+        if (!ok_s) return false;
         if (act) {
 #pragma unroll
-            for (int c = 0; c < 64; ++c) acc += lv[c] * xs[half * 64 + c];
+            for (int c = 0; c < CW; ++c) acc += lv[c] * xs[quarter * CW + c];
         }
         lds_barrier();
         return true;
     };
     // a producer never arrived (bounded wait; cannot happen with a healthy device): this block's part of the solution becomes NaN, which the caller's
     // allFinite check (kkt_system.hpp:266,305) turns into a failed solve -- a wrong x is never returned as a success
-    auto poison = [&] { if (tid < nrows) st_agent(x + row0 + tid, __longlong_as_double(0x7ff8000000000000LL)); };
+    auto poison = [&] { if (tid < nrows) { st_agent(ysrc + row0 + tid, __longlong_as_double(0x7ff8000000000000LL)); if (!FWD) x[row0 + tid] = __longlong_as_double(0x7ff8000000000000LL); st_agent_bits(yother + row0 + tid, TRSV_SENT); } };
+    // the solution of this block row: to the consumers (and, backward sweep, to the caller), and the sentinels back into the other direction's buffer
+    auto publish = [&](int i, double v) {
+        if (xq) st_wg(ysrc + row0 + i, v); else st_agent(ysrc + row0 + i, v);
+        if (!FWD) x[row0 + i] = v;
+        st_agent_bits(yother + row0 + i, TRSV_SENT);
+    };
     {
-        double lvA[64], lvB[64];
-        if (nsteps > 0) load_block(0, lvA);
+        double lvA[CW], lvB[CW];
+        if (!INV && nsteps > 0) load_block(0, lvA);
         int q = 0;
-        for (; q + 1 < nsteps; q += 2) {
-            if (!consume(q, lvA, lvB, q + 1)) { poison(); return; }
-            if (!consume(q + 1, lvB, lvA, q + 2 < nsteps ? q + 2 : -1)) { poison(); return; }
+        if constexpr (INV) {
+            // x = V b (forward) / V^T b (backward): two threads per row, 64 terms each from registers, the right-hand side read from LDS at one address per read for
+            // the whole wave, every read requested before the first multiplication
+            auto inv_tail = [&](const double (&vr)[CW]) {
+                __syncthreads();
+                if (ts && tid == 0) ts[4 * r + 1] = wall_clock64();  // products done
+                if (half == 1) bs[row] = acc;
+                __syncthreads();
+                if (half == 0) bs[row] = mine - (acc + bs[row]);
+                __syncthreads();
+                double vv[CW];
+#pragma unroll
+                for (int c = 0; c < CW; ++c) vv[c] = bs[half * CW + c];
+                double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+                for (int c = 0; c < CW; c += 4) {
+                    s0 = __builtin_fma(vr[c], vv[c], s0); s1 = __builtin_fma(vr[c + 1], vv[c + 1], s1);
+                    s2 = __builtin_fma(vr[c + 2], vv[c + 2], s2); s3 = __builtin_fma(vr[c + 3], vv[c + 3], s3);
+                }
+                const double pq = (s0 + s1) + (s2 + s3);
+                if (half == 1) up[row] = pq;  // (TB doubles of the diagonal step's scratch; xs is still being read)
+                __syncthreads();
+                if (half == 0 && row < nrows) publish(row, pq + up[row]);
+                if (ts && tid == 0) { ts[4 * r + 2] = wall_clock64(); ts[4 * r + 3] = wall_clock64(); }
+            };
+            // ONE loop for both roles (every further inlined copy of a step costs registers at the joins): producers t0, t0 + stride, ... < tend
+            const int first = H > 0 ? max(0, nsteps - 2) : 0;  // the owner's producers: first .. nsteps - 1
+            if (helper && role >= first) return;              // (no producer of its own: the owner does not look at its partial sums either)
+            const int t0 = helper ? role : first, stride = helper ? H : 1, tend = helper ? first : nsteps;
+            const bool pre = !helper && H > 0 && t0 + 1 < tend;  // the owner of a row with helpers requests both its operand blocks at once
+            if (t0 < tend) load_block(t0, lvA);
+            if (pre) load_block(t0 + 1, lvB);
+            if (!helper && H > 0 && half == 0) {
+                // the helpers' partial sums (ready two producers ahead of the chain)
+                constexpr int HMAX = 7;
+                const int hl = min(H, first);  // helpers with producers of their own
+                double pv[HMAX];
+#pragma unroll
+                for (int h = 0; h < HMAX; ++h) pv[h] = h < hl ? ld_agent(psrc + ((size_t)r * H + h) * TB + row) : 0.0;
+                double ps = 0.0;
+#pragma unroll
+                for (int h = 0; h < HMAX; ++h) {
+                    if (h < hl) {
+                        unsigned spins = 0;
+                        while ((u64)__double_as_longlong(pv[h]) == TRSV_SENT) {
+                            __builtin_amdgcn_s_sleep(1);
+                            if (++spins > 20000000u) { ok_s = 0; __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                            pv[h] = ld_agent(psrc + ((size_t)r * H + h) * TB + row);
+                        }
+                        ps += pv[h];
+                    }
+                }
+                // (the other direction's partial sums of this block row -- whose helpers are not the ones of this direction: all of them -- ready for the next sweep)
+                for (int h = 0; h < H; ++h) st_agent_bits(pother + ((size_t)r * H + h) * TB + row, TRSV_SENT);
+                acc = ps;
+            }
+            auto next_of = [&](int tt) { const int tn = tt + stride; return tn >= tend ? (helper ? -1 : LOADV) : ((pre && tt == t0) ? -1 : tn); };
+            bool fine = true, v_in_b = false;
+            int t = t0;
+            if (t >= tend && !helper) { __syncthreads(); load_v(lvA); }
+            while (t < tend) {
+                fine = consume(t, lvA, lvB, next_of(t));
+                v_in_b = true;
+                t += stride;
+                if (!fine || t >= tend) break;
+                fine = consume(t, lvB, lvA, next_of(t));
+                v_in_b = false;
+                t += stride;
+                if (!fine) break;
+            }
+            if (helper) {
+                // (a failed wait leaves NaN partial sums: the owner's solution, and with it everything after, is NaN)
+                __syncthreads();
+                if (half == 1) bs[row] = acc;
+                __syncthreads();
+                if (half == 0) st_agent(psrc + ((size_t)r * H + role) * TB + row, fine ? acc + bs[row] : __longlong_as_double(0x7ff8000000000000LL));
+                return;
+            }
+            if (!fine) { poison(); return; }
+            if (v_in_b) inv_tail(lvB); else inv_tail(lvA);
+            return;
+        } else {
+            for (; q + 1 < nsteps; q += 2) {
+                if (!consume(q, lvA, lvB, q + 1)) { poison(); return; }
+                if (!consume(q + 1, lvB, lvA, q + 2 < nsteps ? q + 2 : -1)) { poison(); return; }
+            }
+            if (q < nsteps) { if (!consume(q, lvA, lvB, -1)) { poison(); return; } }
         }
-        if (q < nsteps) { if (!consume(q, lvA, lvB, -1)) { poison(); return; } }
     }
     __syncthreads();
-    if (ts && tid == 0) ts[4 * r + 1] = clock64();  // products done
-    if (act && half == 1) bs[row] = acc;
+    if (ts && tid == 0) ts[4 * r + 1] = wall_clock64();  // products done
+    if (half == 1) bs[row] = acc;
     __syncthreads();
-    if (act && half == 0) bs[row] = mine - (acc + bs[row]);
-    if constexpr (DD) {
-        // x = V b (forward) / V^T b (backward) with the double-double inverse of the block: one compensated dot product per row, four threads per row taking
-        // every fourth diagonal (entry (row, row - s) resp. (row + s, row) sits at dd_diag_off(s) + column) -- at most 32 terms per thread, eight requested from
-        // LDS per trip, two independent sums (the chain through one sum is ~50 cycles per term, and a trip that waits for its own LDS reads first twice that)
-        __syncthreads();
-        const double* Vhs = Ls;
-        const double* Vls = Ls + DD_TRI;
-        const int smax = FWD ? row : TB - 1 - row;
-        double sum = 0.0, comp = 0.0, sum2 = 0.0, comp2 = 0.0;
-        int sdg = quarter;
-        int off = dd_diag_off(quarter);
-        auto step_off = [](int sq) { return 4 * TB - 6 - 4 * sq; };  // dd_diag_off(s + 4) - dd_diag_off(s)
-        for (; sdg + 28 <= smax; sdg += 32) {
-            double vh[8], vl[8], bb[8];
-            int o2 = off;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int sq = sdg + 4 * q, at = o2 + (FWD ? row - sq : row);
-                vh[q] = Vhs[at]; vl[q] = Vls[at]; bb[q] = bs[FWD ? row - sq : row + sq];
-                o2 += step_off(sq);
-            }
-            off = o2;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const double pr = vh[q] * bb[q], er = __builtin_fma(vh[q], bb[q], -pr);
-                if (q & 1) { const ddn st = dd_two_sum(sum2, pr); sum2 = st.h; comp2 = __builtin_fma(vl[q], bb[q], comp2 + (st.l + er)); }
-                else { const ddn st = dd_two_sum(sum, pr); sum = st.h; comp = __builtin_fma(vl[q], bb[q], comp + (st.l + er)); }
-            }
-        }
-        for (; sdg <= smax; sdg += 4) {
-            const int at = off + (FWD ? row - sdg : row);
-            const double vh = Vhs[at], vl = Vls[at], bb = bs[FWD ? row - sdg : row + sdg];
-            const double pr = vh * bb, er = __builtin_fma(vh, bb, -pr);
-            const ddn st = dd_two_sum(sum, pr);
-            sum = st.h;
-            comp = __builtin_fma(vl, bb, comp + (st.l + er));
-            off += step_off(sdg);
-        }
-        { const ddn t2 = dd_add({sum, comp}, {sum2, comp2}); sum = t2.h; comp = t2.l; }
-        double* part = Wg;  // (free with DD) [3][2][TB]
-        if (quarter > 0) { part[(quarter - 1) * 2 * TB + row] = sum; part[(quarter - 1) * 2 * TB + TB + row] = comp; }
-        __syncthreads();
-        if (quarter == 0) {
-            ddn tot = {sum, comp};
-#pragma unroll
-            for (int q = 0; q < 3; ++q) tot = dd_add(tot, {part[q * 2 * TB + row], part[q * 2 * TB + TB + row]});
-            const double xv = tot.h + tot.l;
-            if (row < nrows) st_agent(x + row0 + row, xv);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        if (ts && tid == 0) ts[4 * r + 2] = clock64();
-        __syncthreads();
-        if (tid == 0) __hip_atomic_store(flags + r, token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (ts && tid == 0) ts[4 * r + 3] = clock64();
-        return;
-    }
+    if (half == 0) bs[row] = mine - (acc + bs[row]);
     if (W16) {
         // The diagonal step as a dataflow inside the workgroup, no barriers (round 2; two barriers per group of 16 cost 8 500 cycles per block,
         // more than the hand-off between the blocks).  Groups of 16 columns, gi = position in sweep order; every wave has one job:
@@ -3689,14 +3810,9 @@ __global__ __launch_bounds__(DD ? 512 : 256) void k_trsv_persistent(const double
             }
         }
         __syncthreads();
-        if (ts && tid == 0) ts[4 * r + 2] = clock64();  // diagonal block solved
-        if (tid < TB) {
-            if (tid < nrows) st_agent(x + row0 + tid, bs[tid]);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __syncthreads();
-        if (tid == 0) __hip_atomic_store(flags + r, token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (ts && tid == 0) ts[4 * r + 3] = clock64();  // published
+        if (ts && tid == 0) ts[4 * r + 2] = wall_clock64();  // diagonal block solved
+        if (tid < nrows) publish(tid, bs[tid]);
+        if (ts && tid == 0) ts[4 * r + 3] = wall_clock64();  // published
         return;
     }
     __syncthreads();
@@ -3704,10 +3820,8 @@ __global__ __launch_bounds__(DD ? 512 : 256) void k_trsv_persistent(const double
         double b0 = bs[lane], b1 = bs[lane + 64];
         if (FWD) diag_solve_fwd(Ls, rd, lane, b0, b1);
         else diag_solve_bwd(Ls, rd, lane, b0, b1);
-        if (lane < nrows) st_agent(x + row0 + lane, b0);
-        if (lane + 64 < nrows) st_agent(x + row0 + lane + 64, b1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_store(flags + r, token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane < nrows) publish(lane, b0);
+        if (lane + 64 < nrows) publish(lane + 64, b1);
     }
 }
 
@@ -3717,13 +3831,25 @@ __global__ void k_mul_vec(int n, const double* __restrict__ d, double* __restric
     if (i < n) x[i] *= d[i];
 }
 
-size_t trsv_flag_ints(int n) { return 2 * (size_t)div_up(n, TB) + 1; }
+size_t trsv_poll_doubles(int n) { return 16 * (size_t)div_up(n, TB) * TB; }  // solution values of the two sweeps, partial sums of up to seven helpers per block row and sweep
+__global__ void k_fill_bits(size_t n, u64 v, double* __restrict__ p)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) reinterpret_cast<u64*>(p)[i] = v;
+}
+void launch_trsv_poll_init(double* ypoll, int n, hipStream_t s)
+{
+    const size_t cnt = trsv_poll_doubles(n);
+    if (cnt == 0) return;
+    hipLaunchKernelGGL(k_fill_bits, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s, cnt, TRSV_SENT, ypoll);
+    PQ_HIP(hipGetLastError());
+}
 
 // LLT: L y = b, L^T x = y with rdiag = 1/diag(L).  LDLt: unit L, then x *= rdiag (= 1/D), then unit L^T.
-// `flags` = trsv_flag_ints(n) ints of scratch (zeroed by the owner at allocation), `token` != 0 unique per call; nullptr, or more blocks than can be resident at once, falls back to
-// one launch per block step.
-void launch_trsv(const double* L, int ld, int n, double* x, const double* rdiag, bool ldlt, int* flags, int token, const double* w16, hipStream_t s, long long* ts, const double* Vh,
-                 const double* Vl)
+// `ypoll` = trsv_poll_doubles(n) doubles of scratch, prepared ONCE by launch_trsv_poll_init (every sweep leaves the other direction's half prepared again), `err` one int;
+// ypoll == nullptr, or more blocks than can be resident at once, falls back to one launch per block step.
+void launch_trsv(const double* L, int ld, int n, double* x, const double* rdiag, bool ldlt, double* ypoll, int* ctl, const double* w16, hipStream_t s, long long* ts, const double* Vinv,
+                 int xcd_seq)
 {
     if (n <= 0) return;
     static PerDeviceOnce attr_set;
@@ -3737,16 +3863,26 @@ void launch_trsv(const double* L, int ld, int n, double* x, const double* rdiag,
     });
     const int nblk = div_up(n, TB);
     const double* rd = ldlt ? nullptr : rdiag;
-    const bool persistent = flags != nullptr && nblk <= 224;  // every block resident (one per CU) with room to spare
+    const bool persistent = ypoll != nullptr && nblk <= 224;  // every block resident (one per CU) with room to spare
     if (persistent) {
-        // layout: [fwd x flags nblk][bwd x flags nblk][err]; a block is published when its flag holds `token` (unique per call on this flag
-        // array, never 0: the array is zeroed once, at allocation -- no memset per solve)
-        int* err = flags + 2 * nblk;
-        if (Vh) hipLaunchKernelGGL((k_trsv_persistent<true, true>), dim3(nblk), dim3(512), TRSV_P_LDS_BYTES, s, L, ld, n, x, rd, nblk, flags, err, w16, token, ts, Vh, Vl);
-        else hipLaunchKernelGGL((k_trsv_persistent<true, false>), dim3(nblk), dim3(256), TRSV_P_LDS_BYTES, s, L, ld, n, x, rd, nblk, flags, err, w16, token, ts, Vh, Vl);
-        if (ldlt) hipLaunchKernelGGL(k_mul_vec, dim3(div_up(n, 256)), dim3(256), 0, s, n, rdiag, x);
-        if (Vh) hipLaunchKernelGGL((k_trsv_persistent<false, true>), dim3(nblk), dim3(512), TRSV_P_LDS_BYTES, s, L, ld, n, x, rd, nblk, flags + nblk, err, w16, token, (long long*)nullptr, Vh, Vl);
-        else hipLaunchKernelGGL((k_trsv_persistent<false, false>), dim3(nblk), dim3(256), TRSV_P_LDS_BYTES, s, L, ld, n, x, rd, nblk, flags + nblk, err, w16, token, (long long*)nullptr, Vh, Vl);
+        double* yf = ypoll;
+        double* yb = ypoll + (size_t)nblk * TB;
+        const double* dsc = ldlt ? rdiag : nullptr;  // the 1 / D between the sweeps of L D L^T: applied where the backward sweep reads its right-hand side
+        // ctl: [0] error word, [1] / [2] tickets of the forward / backward sweeps in one-XCD mode (xcd_seq >= 0: the number of such solves on this ctl before)
+        int* err = ctl;
+        // helper workgroups (with the inverses only): as many per block row as leave the whole launch resident at once
+        const int H = (Vinv && nblk >= 8) ? std::min(7, 224 / nblk - 1) : 0;
+        double* pf = ypoll + 2 * (size_t)nblk * TB;
+        double* pb = pf + 7 * (size_t)nblk * TB;
+        const bool one_xcd = xcd_seq >= 0 && nblk <= 32 && H == 0;
+        int* tf = one_xcd ? ctl + 1 : nullptr;
+        int* tb = one_xcd ? ctl + 2 : nullptr;
+        const int tbase = one_xcd ? xcd_seq * nblk : 0;
+        const dim3 grid(one_xcd ? 8 * nblk : nblk * (1 + H));
+        if (Vinv) hipLaunchKernelGGL((k_trsv_persistent<true, true>), grid, dim3(256), TRSV_P_LDS_BYTES, s, L, ld, n, x, rd, nblk, yf, yb, (const double*)nullptr, err, w16, ts, Vinv, tf, tbase, H, pf, pb);
+        else hipLaunchKernelGGL((k_trsv_persistent<true, false>), grid, dim3(256), TRSV_P_LDS_BYTES, s, L, ld, n, x, rd, nblk, yf, yb, (const double*)nullptr, err, w16, ts, Vinv, tf, tbase, H, pf, pb);
+        if (Vinv) hipLaunchKernelGGL((k_trsv_persistent<false, true>), grid, dim3(256), TRSV_P_LDS_BYTES, s, L, ld, n, x, rd, nblk, yb, yf, dsc, err, w16, (long long*)nullptr, Vinv, tb, tbase, H, pb, pf);
+        else hipLaunchKernelGGL((k_trsv_persistent<false, false>), grid, dim3(256), TRSV_P_LDS_BYTES, s, L, ld, n, x, rd, nblk, yb, yf, dsc, err, w16, (long long*)nullptr, Vinv, tb, tbase, H, pb, pf);
     } else {
         for (int j = 0; j < nblk; ++j)
             hipLaunchKernelGGL(k_trsv_fwd_step, dim3(nblk - j), dim3(256), TRSV_LDS_BYTES, s, L, ld, n, x, rd, j);

@@ -94,13 +94,17 @@ size_t chol_prepare_fused(int n, int m);  // builds the fused task list (allocat
 void launch_syrk_first_col(const SyrkArgs& args, int ks, double* ws, hipStream_t s);
 bool launch_chol_persistent(bool ldlt, double* A, double* side, int lda, int n, int* info, double* rdiag, double* dvec, double* pack2, double* w16, double* scratch, int* fuse_flags, int* fuse_cnt,
                             int token_base, int* flags, int gen, int fcount, hipStream_t s, const CholAssembly* fused = nullptr);
-size_t trsv_flag_ints(int n);
+size_t trsv_poll_doubles(int n);  // scratch of the persistent sweeps (launch_trsv), to be prepared once with launch_trsv_poll_init
+void launch_trsv_poll_init(double* ypoll, int n, hipStream_t s);
 // w16: the inverted 16 x 16 diagonal pieces written by the factorisation (8 x 256 doubles per 128-column panel), nullptr: substitution only
-// Vh / Vl (nullable; persistent sweeps only): the double-double inverses of the 128-row diagonal blocks written by launch_block_inverse_dd -- the diagonal step
-// of a block row becomes one compensated product with them instead of eight dependent 16-column groups
-void launch_trsv(const double* L, int ld, int n, double* x, const double* rdiag, bool ldlt, int* flags, int token, const double* w16, hipStream_t s, long long* ts = nullptr,  // ts: debugging aid, 4 stamps per block of the forward sweep
-                 const double* Vh = nullptr, const double* Vl = nullptr);
-void launch_block_inverse_dd(bool unit, const double* L, int ld, int n, double* Vh, double* Vl, hipStream_t s);  // unit: unit lower triangle (LDLt), the stored diagonal is D
+// Vinv (nullable; persistent sweeps only): the inverses of the 128-row diagonal blocks written by launch_block_inverse_dd -- the diagonal step of a block row
+// becomes one product with them instead of eight dependent 16-column groups
+// ctl: 3 ints, zeroed by the owner: error word, tickets of the two sweeps.  xcd_seq >= 0 (only when probe_one_xcd_sweeps() said yes; sweeps of at most 32 block rows):
+// the sweep runs on XCD 0 alone, xcd_seq = the number of such solves on this ctl before this one (the owner zeroes the tickets again before xcd_seq * 32 overflows)
+void launch_trsv(const double* L, int ld, int n, double* x, const double* rdiag, bool ldlt, double* ypoll, int* ctl, const double* w16, hipStream_t s, long long* ts = nullptr,  // ts: debugging aid, 4 stamps per block of the forward sweep
+                 const double* Vinv = nullptr, int xcd_seq = -1);
+bool probe_one_xcd_sweeps(hipStream_t s);
+void launch_block_inverse_dd(bool unit, const double* L, int ld, int n, double* Vsq, hipStream_t s);  // unit: unit lower triangle (LDLt), the stored diagonal is D.  Vsq: 128 x 128 doubles per block
 size_t block_inverse_dd_doubles(int n);  // doubles of Vh (and of Vl)
 int gemv_n_slices(int rows, int cols);
 int launch_gemv_n_partial(int rows, int cols, const double* M, int ld, const double* v, const double* scale, double alpha, double* part, hipStream_t s);

@@ -79,7 +79,7 @@ public:
         int t1 = prof_.begin(1, st_);
         launch_factor_panels();
         // the double-double inverses of the 128-row diagonal blocks for the sweeps (dense_kernels.hip, k_block_inverse_dd): 4 x blocks workgroups, ~25 us
-        if (dd_sweeps_) dense::launch_block_inverse_dd(ldlt_, fac_.p, n_, n_, vinv_hi_.p, vinv_lo_.p, st_);
+        if (inv_sweeps_) dense::launch_block_inverse_dd(ldlt_, fac_.p, n_, n_, vinv_.p, st_);
         prof_.end(1, t1, st_);
         return factor_status();
     }
@@ -97,8 +97,7 @@ public:
         if (p_ > 0) nsl += dense::launch_gemv_n_partial(n_, p_, AT_.p, n_, rhs_y, nullptr, delta_inv, part_.p + (size_t)nsl * n_, st_);
         dense::launch_reduce_partials(n_, nsl, part_.p, rhs_x, lhs_x, st_);
         // solve_ldlt_in_place: llt.solveInPlace(lhs_x)
-        { const int tt = prof_.begin(5, st_); dense::launch_trsv(fac_.p, n_, n_, lhs_x, rdiag_.p, ldlt_, flags_.p, next_trsv_token(), w16_.p, st_, trsv_ts_.p, dd_sweeps_ ? vinv_hi_.p : nullptr,
-                                                               dd_sweeps_ ? vinv_lo_.p : nullptr);
+        { const int tt = prof_.begin(5, st_); dense::launch_trsv(fac_.p, n_, n_, lhs_x, rdiag_.p, ldlt_, ypoll_.p, flags_.p, w16_.p, st_, trsv_ts_.p, inv_sweeps_ ? vinv_.p : nullptr, next_xcd_seq());
           if (trsv_ts_.p) dump_trsv_ts(); prof_.end(5, tt, st_); }
         // lhs_y = delta_inv * AT^T lhs_x - delta_inv * rhs_y
         if (p_ > 0) dense::launch_gemv_t(n_, p_, AT_.p, n_, lhs_x, delta_inv, -delta_inv, rhs_y, nullptr, lhs_y, st_);
@@ -176,7 +175,7 @@ private:
         alloc();
         auto cp = [&](DBuf<double>& dst, const DBuf<double>& src) { if (src.n) PQ_HIP(hipMemcpyAsync(dst.p, src.p, src.bytes(), hipMemcpyDeviceToDevice, st_)); };
         cp(Pfull_, o.Pfull_); cp(Pdiag_, o.Pdiag_); cp(AT_, o.AT_); cp(GT_, o.GT_); cp(ATA_, o.ATA_); cp(fac_, o.fac_);
-        cp(GTp_, o.GTp_); cp(vinv_hi_, o.vinv_hi_); cp(vinv_lo_, o.vinv_lo_);
+        cp(GTp_, o.GTp_); cp(vinv_, o.vinv_);
         cp(z_reg_inv_, o.z_reg_inv_); cp(x_reg_last_, o.x_reg_last_); cp(rdiag_, o.rdiag_); cp(w16_, o.w16_);
         stream_wait(st_);
     }
@@ -214,13 +213,15 @@ private:
                 col0_ws_.alloc((size_t)(n_ / dense::FACTOR_NB) * col0_ks_ * 128 * 128);
             }
         }
-        flags_.alloc(dense::trsv_flag_ints(n_)); flags_.zero(st_);
-        // EXPERIMENTAL (PIQP_AMD_DEBUG=dd_sweeps=1; default off): the diagonal step of the sweeps as one compensated product with the double-double inverse of the
-        // 128-row block.  More accurate than the substitution (tools/chk_dd_sweeps.py: residual 0.6-1.0x) and SLOWER as built: the product is bound by the issue
-        // of ~22 instructions per term, 11 000 cycles per block row against the substitution's 8 000
-        dd_sweeps_ = false;
-        if (const char* e = debug_token("dd_sweeps")) dd_sweeps_ = std::atoi(e) != 0 && (n_ + 127) / 128 <= 224;
-        if (dd_sweeps_) { vinv_hi_.alloc(dense::block_inverse_dd_doubles(n_)); vinv_lo_.alloc(dense::block_inverse_dd_doubles(n_)); }
+        flags_.alloc(3); flags_.zero(st_);  // (error word and tickets of the sweeps)
+        one_xcd_ = (n_ + 127) / 128 <= 32 && !debug_token("no_one_xcd") && dense::probe_one_xcd_sweeps(st_);
+        ypoll_.alloc(dense::trsv_poll_doubles(n_)); dense::launch_trsv_poll_init(ypoll_.p, n_, st_);
+        // the diagonal step of the sweeps as one product with the inverse of the 128-row block (computed in double-double after every factorisation, rounded to
+        // double), helper workgroups streaming the block rows: from eight block rows on (below that the sweeps are not what a solve waits for, and the small
+        // problems of the parity suite keep the substitution's arithmetic).  PIQP_AMD_DEBUG=inv_sweeps=0 / =1: never / whenever the sweeps are persistent
+        inv_sweeps_ = (n_ + 127) / 128 >= 8 && (n_ + 127) / 128 <= 224;
+        if (const char* e = debug_token("inv_sweeps")) inv_sweeps_ = std::atoi(e) != 0 && (n_ + 127) / 128 <= 224;
+        if (inv_sweeps_) vinv_.alloc(dense::block_inverse_dd_doubles(n_));
         if (debug_token("trsv_ts")) { trsv_ts_.alloc(4 * ((n_ + 127) / 128) + 8); trsv_ts_.zero(st_); }
         if (const char* e = debug_token("fused_ts")) { dbg_panel_ = std::atoi(e); dbg_ts_.alloc(96); dbg_ts_.zero(st_); }
         x_reg_last_.zero(st_);
@@ -361,18 +362,22 @@ private:
     DBuf<double> Pfull_, Pdiag_, AT_, GT_, ATA_, fac_, z_reg_inv_, x_reg_last_, dvec_, part_, rdiag_, split_ws_, pack_, w16_, fuse_scratch_;
     DBuf<int> info_, flags_, fuse_flags_, fuse_cnt_, chol_flags_;
     DBuf<double> pack2_, side_;  // side_: the solved panels once more, at addresses the persistent launch has never read before (dense_kernels.hip)
-    bool dd_sweeps_ = false;
-    DBuf<double> vinv_hi_, vinv_lo_;  // double-double inverses of the 128-row diagonal blocks of the factor, by diagonals (dense_kernels.hip)
+    bool inv_sweeps_ = false;
+    DBuf<double> vinv_;  // inverses of the 128-row diagonal blocks of the factor (dense_kernels.hip, launch_block_inverse_dd)
     bool chol_persistent_ = false, chol_fused_ = false;
     DBuf<double> GTp_;  // fused assembly: GT once more, as row panels of 128 rows (consecutive operand stages)
     DBuf<double> asm_part_, col0_ws_;  // fused assembly: partial sums of the K-sliced tiles; of block column 0's launch
     int col0_ks_ = 1;
     int chol_gen_ = 0, chol_fcount_ = 0;
-    int fuse_token_ = 0, trsv_token_ = 0;
-    int next_trsv_token()
+    int fuse_token_ = 0;
+    DBuf<double> ypoll_;  // the sweeps' hand-over buffers (dense_kernels.hip, launch_trsv)
+    bool one_xcd_ = false;
+    int xcd_seq_ = 0;
+    int next_xcd_seq()
     {
-        if (trsv_token_ == 0x7fffffff) { flags_.zero(st_); trsv_token_ = 0; }
-        return ++trsv_token_;
+        if (!one_xcd_) return -1;
+        if (xcd_seq_ >= 50000000) { flags_.zero(st_); xcd_seq_ = 0; }
+        return xcd_seq_++;
     }
     HBuf<int> info_h_;
     StageProfiler prof_;
@@ -388,6 +393,10 @@ private:
         std::fprintf(stderr, "[piqp_amd] forward sweep, per block (flag seen -> products / -> solved / -> published):");
         const size_t nb = (h.size() - 8) / 4;
         for (size_t r = 1; r < nb; ++r) std::fprintf(stderr, " %lld/%lld/%lld", h[4 * r + 1] - h[4 * r], h[4 * r + 2] - h[4 * r], h[4 * r + 3] - h[4 * r]);
+        std::fprintf(stderr, "\n[piqp_amd]   from one block's published to the next one's seen:");
+        for (size_t r = 2; r < nb; ++r) std::fprintf(stderr, " %lld", h[4 * r] - h[4 * (r - 1) + 3]);
+        std::fprintf(stderr, "\n[piqp_amd]   published at (since block 1's):");
+        for (size_t r = 1; r < nb; ++r) std::fprintf(stderr, " %lld", h[4 * r + 3] - h[4 * 1 + 3]);
         std::fprintf(stderr, "\n[piqp_amd]   block 1, groups of the diagonal step done at (since products):");
         for (int g = 0; g < 8; ++g) std::fprintf(stderr, " %lld", h[4 * nb + g] - h[4 * 1 + 1]);
         std::fprintf(stderr, "\n");

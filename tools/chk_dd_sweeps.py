@@ -52,7 +52,10 @@ def main():
     import numpy as np
     sizes = sys.argv[1:] or ["200", "1000", "2048", "4096"]
     res = {}
-    for name, tok in (("dd", "dd_sweeps=1"), ("subst", "dd_sweeps=0")):
+    variants = [("dd", "dd_sweeps=1"), ("subst", "dd_sweeps=0")]
+    if os.environ.get("CHK_VARIANTS"):  # e.g. CHK_VARIANTS="inv1:inv_sweeps=1,inv2:inv_sweeps=2" -- each compared with the substitution
+        variants = [tuple(v.split(":")) for v in os.environ["CHK_VARIANTS"].split(",")] + [("subst", "dd_sweeps=0")]
+    for name, tok in variants:
         e = dict(os.environ); e["PIQP_AMD_DEBUG"] = tok; e["CHK_TAG"] = name
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child"] + sizes, env=e, capture_output=True, text=True, timeout=900)
         line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
@@ -60,12 +63,13 @@ def main():
             print(name, "FAILED", r.stdout[-1500:], r.stderr[-3000:]); return 1
         res[name] = json.loads(line[0][7:])
     bad = 0
-    for key in res["dd"]:
+    for vname, _ in variants[:-1]:
+      for key in res[vname]:
         n, ks = key.split("/")
-        xa = np.load(f"/tmp/chk_dd_dd_{n}_{ks}.npy"); xb = np.load(f"/tmp/chk_dd_subst_{n}_{ks}.npy")
+        xa = np.load(f"/tmp/chk_dd_{vname}_{n}_{ks}.npy"); xb = np.load(f"/tmp/chk_dd_subst_{n}_{ks}.npy")
         dx = float(np.abs(xa - xb).max() / np.abs(xb).max())
-        a, b = res["dd"][key], res["subst"][key]
-        print(f"n/kkt_solver {key:8s} residual vs own factor: dd {a['res']:.2e}  substitution {b['res']:.2e}   |x_dd - x_subst| / |x| = {dx:.2e}   solve wall ms (host pointers): dd {a['ms']:.3f}  substitution {b['ms']:.3f}")
+        a, b = res[vname][key], res["subst"][key]
+        print(f"n/kkt_solver {key:8s} residual vs own factor: {vname} {a['res']:.2e}  substitution {b['res']:.2e}   |x_{vname} - x_subst| / |x| = {dx:.2e}   solve wall ms (host pointers): {vname} {a['ms']:.3f}  substitution {b['ms']:.3f}")
         bad += (a["res"] > 2.0 * b["res"] + 1e-15) or dx > 1e-6
     print("OK" if not bad else f"{bad} PROBLEMS")
     return 1 if bad else 0
