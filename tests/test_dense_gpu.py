@@ -5,6 +5,8 @@ comparisons against the oracle use bounds scaled by the conditioning of the test
 Mirrors the reference's tests/src/dense/kkt_test.cpp (UpdateData, FactorizeSolve) and ldlt_test.cpp,
 run against both implementations.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -245,6 +247,31 @@ def test_device_pointer_mode_matches_host_mode(hip):
     for key in lhs:
         cnt = {"z_bl": d.n_x_l, "s_bl": d.n_x_l, "z_bu": d.n_x_u, "s_bu": d.n_x_u}.get(key, len(lhs[key]))
         assert np.array_equal(lhs[key][:cnt], dl[key].cpu().numpy()[:cnt]), key
+
+
+@pytest.mark.parametrize("kkt_solver", [0, 16])
+@pytest.mark.parametrize("n", [1024, 1100, 1930])
+def test_sweeps_with_block_inverses_against_the_substitution_sweeps(hip, kkt_solver, n):
+    """round 5: from eight block rows on the triangular sweeps multiply by the inverses of the 128-row diagonal blocks (computed in double-double after every
+    factorisation) and helper workgroups stream the block rows; PIQP_AMD_DEBUG=inv_sweeps=0 keeps the substitution form (tests/workers/dense_sweeps.py runs one
+    of the two).  Same factor, five solves in a row on one handle (the hand-over buffers are re-armed by the sweeps themselves), a ragged last block at
+    n = 1100 / 1930: each solution solves L L^T x = b (L D L^T x = b) to the substitution's residual, and the two agree to rounding."""
+    import json
+    import subprocess
+    import sys
+    out = {}
+    for tag, tok in (("inv", "inv_sweeps=1"), ("subst", "inv_sweeps=0")):
+        env = dict(os.environ); env["PIQP_AMD_DEBUG"] = tok
+        r = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "workers", "dense_sweeps.py"), str(n), str(kkt_solver), tag], env=env,
+                           capture_output=True, text=True, timeout=600)
+        line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
+        assert line, (r.stdout[-2000:], r.stderr[-2000:])
+        out[tag] = json.loads(line[0][7:])
+    for i, (ri, rs) in enumerate(zip(out["inv"]["res"], out["subst"]["res"])):
+        assert ri <= 2.0 * rs + 1e-15, (i, ri, rs)
+    xa = np.load(out["inv"]["x"]); xb = np.load(out["subst"]["x"])
+    assert np.abs(xa - xb).max() <= 1e-9 * np.abs(xb).max()
+    assert out["inv"]["repeat_bitwise"] and out["subst"]["repeat_bitwise"]
 
 
 @pytest.mark.parametrize("n,m", [(1024, 1024), (2048, 1536)])

@@ -130,6 +130,21 @@ def test_iteration_parity_random_qp(hip, orc, kkt_solver, dims):
     assert abs(sh.info.primal_obj - so.info.primal_obj) <= 1e-8 * (1 + abs(so.info.primal_obj))
 
 
+@pytest.mark.parametrize("kkt_solver", [0, 16])
+def test_iteration_parity_where_the_sweeps_use_block_inverses(hip, orc, kkt_solver):
+    """nine block rows (n = 1100, ragged last block): the dense backend's sweeps multiply by the inverted diagonal blocks there (round 5) -- same status, iteration
+    count and trajectory as the CPU path"""
+    n, p, m = 1100, 40, 300
+    q = dense_strongly_convex_qp(n, p, m, seed=11, exact_shift=False)
+    args = (q["P"], q["c"], q["A"], q["b"], q["G"], q["h_l"], q["h_u"], q["x_l"], q["x_u"])
+    sh, so, st_h, st_o = _both(hip, orc, args, kkt_solver)
+    assert st_h == st_o == 1
+    assert sh.info.iter == so.info.iter
+    th, to = sh.trace(), so.trace()
+    assert np.allclose(th[:, 6:9], to[:, 6:9], rtol=1e-6)  # rho, delta, mu
+    assert np.allclose(sh.result()["x"], so.result()["x"], rtol=1e-6, atol=1e-8)
+
+
 def test_c0_notebook_trace(hip, orc):
     """the recorded reference trace through the GPU-backed solver: 12 iterations, objective 4451.73"""
     q = load_qp("qp_c0_scenario_mpc")
