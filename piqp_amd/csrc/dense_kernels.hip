@@ -3435,7 +3435,7 @@ size_t block_inverse_dd_doubles(int n) { return (size_t)div_up(n, 128) * 128 * 1
 template <bool FWD, bool INV>
 __global__ __launch_bounds__(256) void k_trsv_persistent(const double* __restrict__ L, int ld, int n, double* __restrict__ x, const double* __restrict__ rdiag,
                                                          int nblk, double* __restrict__ ysrc, double* __restrict__ yother, const double* __restrict__ dscale, int* __restrict__ err,
-                                                         const double* __restrict__ W16, long long* __restrict__ ts, const double* __restrict__ Vinv, int* __restrict__ tkt, int tbase, int H, double* __restrict__ psrc, double* __restrict__ pother)
+                                                         const double* __restrict__ W16, long long* __restrict__ ts, const double* __restrict__ Vinv, int* __restrict__ tkt, int tbase, int H, double* __restrict__ psrc, double* __restrict__ pother, double* __restrict__ ylsrc, double* __restrict__ ylother)
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double* Ls = sm;                    // own diagonal block, Ls[c * (TB+1) + r]
@@ -3550,8 +3550,11 @@ __global__ __launch_bounds__(256) void k_trsv_persistent(const double* __restric
         double xv = 0.0;
         if (tid < TB && tid < nc) {
             unsigned spins = 0;
+            // (the owners of a launch with seven helpers per block row all sit on one XCD: they hand over among themselves through that XCD's L2 -- ylsrc, stored
+            // plainly -- while the helpers on the other XCDs read the copy that went to the memory side)
+            const double* yp = (INV && ylsrc && !helper) ? ylsrc : ysrc;
             while (true) {
-                xv = ld_agent(ysrc + c0 + tid);
+                xv = ld_agent(yp + c0 + tid);
                 if ((u64)__double_as_longlong(xv) != TRSV_SENT) break;
                 __builtin_amdgcn_s_sleep(1);
                 if (++spins > 20000000u) { ok_s = 0; __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
@@ -3574,6 +3577,7 @@ __global__ __launch_bounds__(256) void k_trsv_persistent(const double* __restric
     auto poison = [&] { if (tid < nrows) { st_agent(ysrc + row0 + tid, __longlong_as_double(0x7ff8000000000000LL)); if (!FWD) x[row0 + tid] = __longlong_as_double(0x7ff8000000000000LL); st_agent_bits(yother + row0 + tid, TRSV_SENT); } };
     // the solution of this block row: to the consumers (and, backward sweep, to the caller), and the sentinels back into the other direction's buffer
     auto publish = [&](int i, double v) {
+        if (INV && ylsrc) { st_wg(ylsrc + row0 + i, v); st_wg(ylother + row0 + i, __longlong_as_double((long long)TRSV_SENT)); }
         if (xq) st_wg(ysrc + row0 + i, v); else st_agent(ysrc + row0 + i, v);
         if (!FWD) x[row0 + i] = v;
         st_agent_bits(yother + row0 + i, TRSV_SENT);
@@ -3831,7 +3835,7 @@ __global__ void k_mul_vec(int n, const double* __restrict__ d, double* __restric
     if (i < n) x[i] *= d[i];
 }
 
-size_t trsv_poll_doubles(int n) { return 16 * (size_t)div_up(n, TB) * TB; }  // solution values of the two sweeps, partial sums of up to seven helpers per block row and sweep
+size_t trsv_poll_doubles(int n) { return 18 * (size_t)div_up(n, TB) * TB; }  // solution values of the two sweeps, partial sums of up to seven helpers per block row and sweep
 __global__ void k_fill_bits(size_t n, u64 v, double* __restrict__ p)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -3871,18 +3875,24 @@ void launch_trsv(const double* L, int ld, int n, double* x, const double* rdiag,
         // ctl: [0] error word, [1] / [2] tickets of the forward / backward sweeps in one-XCD mode (xcd_seq >= 0: the number of such solves on this ctl before)
         int* err = ctl;
         // helper workgroups (with the inverses only): as many per block row as leave the whole launch resident at once
-        const int H = (Vinv && nblk >= 8) ? std::min(7, 224 / nblk - 1) : 0;
+        // (all waits target workgroups with lower indices, so the launch need not be resident as a whole: 8 x 32 workgroups at n = 4096)
+        const int H = (Vinv && nblk >= 8) ? std::min(7, 256 / nblk - 1) : 0;
         double* pf = ypoll + 2 * (size_t)nblk * TB;
         double* pb = pf + 7 * (size_t)nblk * TB;
+        // seven helpers: the owners are the workgroups 7, 15, 23, ... -- one XCD when the launch is dealt out round robin (xcd_seq >= 0: the probe said so)
+        static const bool local_off = debug_token("sweep_local") && std::atoi(debug_token("sweep_local")) == 0;
+        const bool local = H == 7 && xcd_seq >= 0 && !local_off;
+        double* ylf = local ? pb + 7 * (size_t)nblk * TB : nullptr;
+        double* ylb = local ? ylf + (size_t)nblk * TB : nullptr;
         const bool one_xcd = xcd_seq >= 0 && nblk <= 32 && H == 0;
         int* tf = one_xcd ? ctl + 1 : nullptr;
         int* tb = one_xcd ? ctl + 2 : nullptr;
         const int tbase = one_xcd ? xcd_seq * nblk : 0;
         const dim3 grid(one_xcd ? 8 * nblk : nblk * (1 + H));
-        if (Vinv) hipLaunchKernelGGL((k_trsv_persistent<true, true>), grid, dim3(256), TRSV_P_LDS_BYTES, s, L, ld, n, x, rd, nblk, yf, yb, (const double*)nullptr, err, w16, ts, Vinv, tf, tbase, H, pf, pb);
-        else hipLaunchKernelGGL((k_trsv_persistent<true, false>), grid, dim3(256), TRSV_P_LDS_BYTES, s, L, ld, n, x, rd, nblk, yf, yb, (const double*)nullptr, err, w16, ts, Vinv, tf, tbase, H, pf, pb);
-        if (Vinv) hipLaunchKernelGGL((k_trsv_persistent<false, true>), grid, dim3(256), TRSV_P_LDS_BYTES, s, L, ld, n, x, rd, nblk, yb, yf, dsc, err, w16, (long long*)nullptr, Vinv, tb, tbase, H, pb, pf);
-        else hipLaunchKernelGGL((k_trsv_persistent<false, false>), grid, dim3(256), TRSV_P_LDS_BYTES, s, L, ld, n, x, rd, nblk, yb, yf, dsc, err, w16, (long long*)nullptr, Vinv, tb, tbase, H, pb, pf);
+        if (Vinv) hipLaunchKernelGGL((k_trsv_persistent<true, true>), grid, dim3(256), TRSV_P_LDS_BYTES, s, L, ld, n, x, rd, nblk, yf, yb, (const double*)nullptr, err, w16, ts, Vinv, tf, tbase, H, pf, pb, ylf, ylb);
+        else hipLaunchKernelGGL((k_trsv_persistent<true, false>), grid, dim3(256), TRSV_P_LDS_BYTES, s, L, ld, n, x, rd, nblk, yf, yb, (const double*)nullptr, err, w16, ts, Vinv, tf, tbase, H, pf, pb, ylf, ylb);
+        if (Vinv) hipLaunchKernelGGL((k_trsv_persistent<false, true>), grid, dim3(256), TRSV_P_LDS_BYTES, s, L, ld, n, x, rd, nblk, yb, yf, dsc, err, w16, (long long*)nullptr, Vinv, tb, tbase, H, pb, pf, ylb, ylf);
+        else hipLaunchKernelGGL((k_trsv_persistent<false, false>), grid, dim3(256), TRSV_P_LDS_BYTES, s, L, ld, n, x, rd, nblk, yb, yf, dsc, err, w16, (long long*)nullptr, Vinv, tb, tbase, H, pb, pf, ylb, ylf);
     } else {
         for (int j = 0; j < nblk; ++j)
             hipLaunchKernelGGL(k_trsv_fwd_step, dim3(nblk - j), dim3(256), TRSV_LDS_BYTES, s, L, ld, n, x, rd, j);
