@@ -3433,7 +3433,7 @@ size_t block_inverse_dd_doubles(int n) { return (size_t)div_up(n, 128) * 128 * 1
 // of V_r held in registers for the whole launch (64 per thread -- the workgroup keeps its 256 threads: 512 of them have 256 registers each, and two operand
 // blocks in flight next to V spill; round 4's 512-thread compensated product with the double-double inverse spilled 300 - 1200 registers and was removed)
 template <bool FWD, bool INV>
-__global__ __launch_bounds__(256) void k_trsv_persistent(const double* __restrict__ L, int ld, int n, double* __restrict__ x, const double* __restrict__ rdiag,
+__global__ __launch_bounds__(INV ? 512 : 256) void k_trsv_persistent(const double* __restrict__ L, int ld, int n, double* __restrict__ x, const double* __restrict__ rdiag,
                                                          int nblk, double* __restrict__ ysrc, double* __restrict__ yother, const double* __restrict__ dscale, int* __restrict__ err,
                                                          const double* __restrict__ W16, long long* __restrict__ ts, const double* __restrict__ Vinv, int* __restrict__ tkt, int tbase, int H, double* __restrict__ psrc, double* __restrict__ pother, double* __restrict__ ylsrc, double* __restrict__ ylother)
 {
@@ -3460,7 +3460,11 @@ __global__ __launch_bounds__(256) void k_trsv_persistent(const double* __restric
     const bool helper = INV && H > 0 && role < H;
     if (ridx_s / ((INV && H > 0) ? 1 + H : 1) >= nblk) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    constexpr int NQ = 2;               // threads per row in the product phase: CW columns of the operand block each
+    // threads per row in the product phase, CW columns of the operand block each.  INV: four (512 threads, two waves per SIMD: one wave issues an instruction every
+    // ~5 cycles, and a step of 64 multiply-adds, their LDS reads and the moves out of the AGPRs was 1.2 us of every block row); 256 registers each are enough for two
+    // operand blocks of 32 columns in flight and the 32 entries of the inverse
+    constexpr int NQ = INV ? 4 : 2;
+    constexpr int NTH = 128 * NQ;
     constexpr int CW = TB / NQ;
     const bool act = true;
     const int ridx = (INV && H > 0) ? ridx_s / (1 + H) : ridx_s;  // position of the block in sweep order
@@ -3472,16 +3476,17 @@ __global__ __launch_bounds__(256) void k_trsv_persistent(const double* __restric
         // the rounded inverse of the block (128 x 128 column-major, zeros included): Ls[c * (TB + 1) + row] = V(row, c) for the forward sweep, V(c, row) for the
         // backward one (x = V^T b)
         const double* vs = Vinv + (size_t)r * TB * TB;
-        for (int base = 0; base < (helper ? 0 : TB * TB); base += 8 * 256) {
+        for (int base = 0; base < (helper ? 0 : TB * TB); base += 8 * NTH) {
             double a[8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) a[q] = vs[base + q * 256 + tid];
+            for (int q = 0; q < 8; ++q) a[q] = vs[base + q * NTH + tid];
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                const int idx = base + q * 256 + tid, lo = idx & (TB - 1), hi = idx >> 7;  // entry (lo, hi) of V
+                const int idx = base + q * NTH + tid, lo = idx & (TB - 1), hi = idx >> 7;  // entry (lo, hi) of V
                 if (FWD) Ls[hi * (TB + 1) + lo] = a[q]; else Ls[lo * (TB + 1) + hi] = a[q];
             }
         }
+        if (!helper) __syncthreads();  // (the owner of a row with one producer moves V into registers before any other barrier)
     } else stage_lower_block<TB, TB + 1, 256, !FWD>(L + row0 + (size_t)row0 * ld, ld, nrows, Ls, tid);
     if (tid < TB) rd[tid] = (rdiag && tid < nrows) ? rdiag[row0 + tid] : 1.0;
     if (W16 && !INV) {
@@ -3501,7 +3506,7 @@ __global__ __launch_bounds__(256) void k_trsv_persistent(const double* __restric
     constexpr int LOADV = -2;
     auto load_v = [&](double (&vr)[CW]) {
 #pragma unroll
-        for (int c = 0; c < CW; ++c) vr[c] = Ls[(half * CW + c) * (TB + 1) + row];
+        for (int c = 0; c < CW; ++c) vr[c] = Ls[(quarter * CW + c) * (TB + 1) + row];
         // (pinned here: left to itself the compiler sinks these reads to their use, behind the arrival of the last producer's values -- 1 000 cycles of LDS
         // traffic on the chain of every block row)
 #pragma unroll
@@ -3592,13 +3597,13 @@ __global__ __launch_bounds__(256) void k_trsv_persistent(const double* __restric
             auto inv_tail = [&](const double (&vr)[CW]) {
                 __syncthreads();
                 if (ts && tid == 0) ts[4 * r + 1] = wall_clock64();  // products done
-                if (half == 1) bs[row] = acc;
+                if (quarter > 0) Wg[(quarter - 1) * TB + row] = acc;
                 __syncthreads();
-                if (half == 0) bs[row] = mine - (acc + bs[row]);
+                if (quarter == 0) bs[row] = mine - (((acc + Wg[row]) + Wg[TB + row]) + Wg[2 * TB + row]);
                 __syncthreads();
                 double vv[CW];
 #pragma unroll
-                for (int c = 0; c < CW; ++c) vv[c] = bs[half * CW + c];
+                for (int c = 0; c < CW; ++c) vv[c] = bs[quarter * CW + c];
                 double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
 #pragma unroll
                 for (int c = 0; c < CW; c += 4) {
@@ -3606,9 +3611,9 @@ __global__ __launch_bounds__(256) void k_trsv_persistent(const double* __restric
                     s2 = __builtin_fma(vr[c + 2], vv[c + 2], s2); s3 = __builtin_fma(vr[c + 3], vv[c + 3], s3);
                 }
                 const double pq = (s0 + s1) + (s2 + s3);
-                if (half == 1) up[row] = pq;  // (TB doubles of the diagonal step's scratch; xs is still being read)
+                if (quarter > 0) Wg[(quarter - 1) * TB + row] = pq;  // (the partial sums of the right-hand side were read before the last barrier)
                 __syncthreads();
-                if (half == 0 && row < nrows) publish(row, pq + up[row]);
+                if (quarter == 0 && row < nrows) publish(row, ((pq + Wg[row]) + Wg[TB + row]) + Wg[2 * TB + row]);
                 if (ts && tid == 0) { ts[4 * r + 2] = wall_clock64(); ts[4 * r + 3] = wall_clock64(); }
             };
             // ONE loop for both roles (every further inlined copy of a step costs registers at the joins): producers t0, t0 + stride, ... < tend
@@ -3618,7 +3623,7 @@ __global__ __launch_bounds__(256) void k_trsv_persistent(const double* __restric
             const bool pre = !helper && H > 0 && t0 + 1 < tend;  // the owner of a row with helpers requests both its operand blocks at once
             if (t0 < tend) load_block(t0, lvA);
             if (pre) load_block(t0 + 1, lvB);
-            if (!helper && H > 0 && half == 0) {
+            if (!helper && H > 0 && quarter == 0) {
                 // the helpers' partial sums (ready two producers ahead of the chain)
                 constexpr int HMAX = 7;
                 const int hl = min(H, first);  // helpers with producers of their own
@@ -3659,9 +3664,9 @@ __global__ __launch_bounds__(256) void k_trsv_persistent(const double* __restric
             if (helper) {
                 // (a failed wait leaves NaN partial sums: the owner's solution, and with it everything after, is NaN)
                 __syncthreads();
-                if (half == 1) bs[row] = acc;
+                if (quarter > 0) Wg[(quarter - 1) * TB + row] = acc;
                 __syncthreads();
-                if (half == 0) st_agent(psrc + ((size_t)r * H + role) * TB + row, fine ? acc + bs[row] : __longlong_as_double(0x7ff8000000000000LL));
+                if (quarter == 0) st_agent(psrc + ((size_t)r * H + role) * TB + row, fine ? ((acc + Wg[row]) + Wg[TB + row]) + Wg[2 * TB + row] : __longlong_as_double(0x7ff8000000000000LL));
                 return;
             }
             if (!fine) { poison(); return; }
@@ -3889,9 +3894,9 @@ void launch_trsv(const double* L, int ld, int n, double* x, const double* rdiag,
         int* tb = one_xcd ? ctl + 2 : nullptr;
         const int tbase = one_xcd ? xcd_seq * nblk : 0;
         const dim3 grid(one_xcd ? 8 * nblk : nblk * (1 + H));
-        if (Vinv) hipLaunchKernelGGL((k_trsv_persistent<true, true>), grid, dim3(256), TRSV_P_LDS_BYTES, s, L, ld, n, x, rd, nblk, yf, yb, (const double*)nullptr, err, w16, ts, Vinv, tf, tbase, H, pf, pb, ylf, ylb);
+        if (Vinv) hipLaunchKernelGGL((k_trsv_persistent<true, true>), grid, dim3(512), TRSV_P_LDS_BYTES, s, L, ld, n, x, rd, nblk, yf, yb, (const double*)nullptr, err, w16, ts, Vinv, tf, tbase, H, pf, pb, ylf, ylb);
         else hipLaunchKernelGGL((k_trsv_persistent<true, false>), grid, dim3(256), TRSV_P_LDS_BYTES, s, L, ld, n, x, rd, nblk, yf, yb, (const double*)nullptr, err, w16, ts, Vinv, tf, tbase, H, pf, pb, ylf, ylb);
-        if (Vinv) hipLaunchKernelGGL((k_trsv_persistent<false, true>), grid, dim3(256), TRSV_P_LDS_BYTES, s, L, ld, n, x, rd, nblk, yb, yf, dsc, err, w16, (long long*)nullptr, Vinv, tb, tbase, H, pb, pf, ylb, ylf);
+        if (Vinv) hipLaunchKernelGGL((k_trsv_persistent<false, true>), grid, dim3(512), TRSV_P_LDS_BYTES, s, L, ld, n, x, rd, nblk, yb, yf, dsc, err, w16, (long long*)nullptr, Vinv, tb, tbase, H, pb, pf, ylb, ylf);
         else hipLaunchKernelGGL((k_trsv_persistent<false, false>), grid, dim3(256), TRSV_P_LDS_BYTES, s, L, ld, n, x, rd, nblk, yb, yf, dsc, err, w16, (long long*)nullptr, Vinv, tb, tbase, H, pb, pf, ylb, ylf);
     } else {
         for (int j = 0; j < nblk; ++j)
