@@ -41,6 +41,9 @@ public:
     ~DenseKKT() override
     {
         (void)hipSetDevice(dev_);
+        if (st_inv_) { (void)hipStreamSynchronize(st_inv_); (void)hipStreamDestroy(st_inv_); }
+        if (ev_fac_) (void)hipEventDestroy(ev_fac_);
+        if (ev_inv_) (void)hipEventDestroy(ev_inv_);
         if (st_) { (void)hipStreamSynchronize(st_); (void)hipStreamDestroy(st_); }
     }
 
@@ -48,6 +51,7 @@ public:
     KKTSolverBase* clone() const override
     {
         PQ_HIP(hipSetDevice(dev_));
+        const_cast<DenseKKT*>(this)->join_inverses();
         stream_wait(st_);
         DenseKKT* k = new DenseKKT(*this, 0);
         return k;
@@ -70,6 +74,7 @@ public:
         PQ_ZONE("piqp_amd::DenseKKT::update_scalings_and_factor");
         PQ_HIP(hipSetDevice(dev_));
         delta_ = delta;
+        join_inverses();  // (a factorisation nobody solved with: its inverses still read the factor this one overwrites)
         dense::launch_reciprocal(m_, z_reg, z_reg_inv_.p, st_);
         PQ_HIP(hipMemcpyAsync(x_reg_last_.p, x_reg, sizeof(double) * n_, hipMemcpyDeviceToDevice, st_));
         int t0 = prof_.begin(0, st_);
@@ -79,8 +84,16 @@ public:
         int t1 = prof_.begin(1, st_);
         launch_factor_panels();
         // the double-double inverses of the 128-row diagonal blocks for the sweeps (dense_kernels.hip, k_block_inverse_dd): 4 x blocks workgroups, ~25 us
-        if (inv_sweeps_) dense::launch_block_inverse_dd(ldlt_, fac_.p, n_, n_, vinv_.p, st_);
         prof_.end(1, t1, st_);
+        // the inverses of the 128-row diagonal blocks for the sweeps: on a stream of their own, next to whatever follows the factorisation (the right-hand sides of
+        // the first solve), joined where the first sweep starts
+        if (inv_sweeps_) {
+            PQ_HIP(hipEventRecord(ev_fac_, st_));
+            PQ_HIP(hipStreamWaitEvent(st_inv_, ev_fac_, 0));
+            dense::launch_block_inverse_dd(ldlt_, fac_.p, n_, n_, vinv_.p, st_inv_);
+            PQ_HIP(hipEventRecord(ev_inv_, st_inv_));
+            inv_pending_ = true;
+        }
         return factor_status();
     }
 
@@ -97,6 +110,7 @@ public:
         if (p_ > 0) nsl += dense::launch_gemv_n_partial(n_, p_, AT_.p, n_, rhs_y, nullptr, delta_inv, part_.p + (size_t)nsl * n_, st_);
         dense::launch_reduce_partials(n_, nsl, part_.p, rhs_x, lhs_x, st_);
         // solve_ldlt_in_place: llt.solveInPlace(lhs_x)
+        join_inverses();
         { const int tt = prof_.begin(5, st_); dense::launch_trsv(fac_.p, n_, n_, lhs_x, rdiag_.p, ldlt_, ypoll_.p, flags_.p, w16_.p, st_, trsv_ts_.p, inv_sweeps_ ? vinv_.p : nullptr, next_xcd_seq());
           if (trsv_ts_.p) dump_trsv_ts(); prof_.end(5, tt, st_); }
         // lhs_y = delta_inv * AT^T lhs_x - delta_inv * rhs_y
@@ -221,7 +235,12 @@ private:
         // problems of the parity suite keep the substitution's arithmetic).  PIQP_AMD_DEBUG=inv_sweeps=0 / =1: never / whenever the sweeps are persistent
         inv_sweeps_ = (n_ + 127) / 128 >= 8 && (n_ + 127) / 128 <= 224;
         if (const char* e = debug_token("inv_sweeps")) inv_sweeps_ = std::atoi(e) != 0 && (n_ + 127) / 128 <= 224;
-        if (inv_sweeps_) vinv_.alloc(dense::block_inverse_dd_doubles(n_));
+        if (inv_sweeps_) {
+            vinv_.alloc(dense::block_inverse_dd_doubles(n_));
+            PQ_HIP(hipStreamCreateWithFlags(&st_inv_, hipStreamNonBlocking));
+            PQ_HIP(hipEventCreateWithFlags(&ev_fac_, hipEventDisableTiming));
+            PQ_HIP(hipEventCreateWithFlags(&ev_inv_, hipEventDisableTiming));
+        }
         if (debug_token("trsv_ts")) { trsv_ts_.alloc(4 * ((n_ + 127) / 128) + 8); trsv_ts_.zero(st_); }
         if (const char* e = debug_token("fused_ts")) { dbg_panel_ = std::atoi(e); dbg_ts_.alloc(96); dbg_ts_.zero(st_); }
         x_reg_last_.zero(st_);
@@ -362,7 +381,15 @@ private:
     DBuf<double> Pfull_, Pdiag_, AT_, GT_, ATA_, fac_, z_reg_inv_, x_reg_last_, dvec_, part_, rdiag_, split_ws_, pack_, w16_, fuse_scratch_;
     DBuf<int> info_, flags_, fuse_flags_, fuse_cnt_, chol_flags_;
     DBuf<double> pack2_, side_;  // side_: the solved panels once more, at addresses the persistent launch has never read before (dense_kernels.hip)
-    bool inv_sweeps_ = false;
+    bool inv_sweeps_ = false, inv_pending_ = false;
+    hipStream_t st_inv_ = nullptr;
+    hipEvent_t ev_fac_ = nullptr, ev_inv_ = nullptr;
+    void join_inverses()
+    {
+        if (!inv_pending_) return;
+        PQ_HIP(hipStreamWaitEvent(st_, ev_inv_, 0));
+        inv_pending_ = false;
+    }
     DBuf<double> vinv_;  // inverses of the 128-row diagonal blocks of the factor (dense_kernels.hip, launch_block_inverse_dd)
     bool chol_persistent_ = false, chol_fused_ = false;
     DBuf<double> GTp_;  // fused assembly: GT once more, as row panels of 128 rows (consecutive operand stages)
