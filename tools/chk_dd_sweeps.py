@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Sweeps with the double-double block inverses (PIQP_AMD_DEBUG=dd_sweeps=1, round 4) against the substitution form (=0): backend solve of the condensed system on
-random right-hand sides -- residual of both in extended precision against the device's own factor L L^T (or L D L^T), agreement of the two solutions, time.
+"""Sweeps with the inverted 128-row diagonal blocks (PIQP_AMD_DEBUG=inv_sweeps=1; the default from eight block rows on, round 5) against the substitution form
+(inv_sweeps=0): backend solve of the condensed system on random right-hand sides -- residual of both in extended precision against the device's own factor L L^T
+(or L D L^T), agreement of the two solutions, time.  With PIQP_AMD_DEBUG=...,trsv_ts the --child form prints the forward sweep's timeline (100 MHz clock).
    python tools/chk_dd_sweeps.py [n ...]"""
 import json
 import os
@@ -52,9 +53,9 @@ def main():
     import numpy as np
     sizes = sys.argv[1:] or ["200", "1000", "2048", "4096"]
     res = {}
-    variants = [("dd", "dd_sweeps=1"), ("subst", "dd_sweeps=0")]
+    variants = [("inv", "inv_sweeps=1"), ("subst", "inv_sweeps=0")]
     if os.environ.get("CHK_VARIANTS"):  # e.g. CHK_VARIANTS="inv1:inv_sweeps=1,inv2:inv_sweeps=2" -- each compared with the substitution
-        variants = [tuple(v.split(":")) for v in os.environ["CHK_VARIANTS"].split(",")] + [("subst", "dd_sweeps=0")]
+        variants = [tuple(v.split(":")) for v in os.environ["CHK_VARIANTS"].split(",")] + [("subst", "inv_sweeps=0")]
     for name, tok in variants:
         e = dict(os.environ); e["PIQP_AMD_DEBUG"] = tok; e["CHK_TAG"] = name
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child"] + sizes, env=e, capture_output=True, text=True, timeout=900)

@@ -33,6 +33,13 @@ d=json.load(open('$O/r05_sharded_solve_${b}_world2.json'))
 print('$b world 2: bitwise', d['bitwise_equal_all_ranks'], 'residual eval ms single / partitioned', round(d['residual_eval_ms_single_gpu'],3), round(d['residual_eval_ms_partitioned'],3), 'step ms single / partitioned', round(d['single_gpu_ms_per_step'],3), round(d['ms_per_step'],3), d['sharded_solve'])
 " | cut -c1-400
 done
+# the dense sweeps: block inverses against the substitution form (residuals, agreement), the forward sweep's timeline on the 100 MHz clock, time per solve
+timeout 600 python3 tools/chk_dd_sweeps.py 1024 1100 2048 4096 2>&1 | tail -9 | cut -c1-230 > $O/r05_dense_sweeps.txt
+for v in inv_sweeps=1 inv_sweeps=0; do
+  PIQP_AMD_DEBUG=$v timeout 300 python3 tools/time_sweeps.py 2>&1 | tail -1 >> $O/r05_dense_sweeps.txt
+  PIQP_AMD_DEBUG=$v,trsv_ts CHK_TAG=t timeout 300 python3 tools/chk_dd_sweeps.py --child 4096 2>&1 | grep -m1 -A3 "forward sweep" | cut -c1-700 >> $O/r05_dense_sweeps.txt
+done
+tail -12 $O/r05_dense_sweeps.txt | cut -c1-200
 rm -rf $O/pmc_f $O/pmc_w
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmc_f -- python3 tools/prof_dense.py 4096 4096 0 3 0 > /dev/null 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pmc_w -- python3 tools/prof_dense.py 4096 4096 0 3 0 > /dev/null 2>&1
