@@ -3280,15 +3280,13 @@ __device__ __forceinline__ double ld_agent(const double* p)
     return __longlong_as_double((long long)__hip_atomic_load((__attribute__((address_space(1))) const u64*)reinterpret_cast<const u64*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
 
-// ---- round 4: the diagonal step of the sweeps as ONE product with the inverse of the 128 x 128 diagonal block, in double-double ----------------------------
-// x_r = L_rr^-1 b is what bounds a sweep: eight dependent 16-column groups, 3.5 of the 5.3 us a block row costs (profiles/r03: 170 us per sweep = 5 % of HBM).
-// A product with the explicit inverse takes the dependence away, but in plain double it costs accuracy exactly where it matters -- the residual of x = fl(V b) is
-// eps |L| |V| |b|, not eps |L| |x|; round 2 measured 2x in the median and 11x at worst on the rho = delta = 1e-10 states and two iteration counts moved.  Here V is
-// computed in double-double (106 bits) once per factorisation and applied with a compensated dot product, so x_r is the correctly rounded solution of the block
-// system up to one ulp: MORE accurate than the substitution it replaces, never less.  (CPU experiment on the oracle, long double substitution inside 16- /
-// 128- / whole-matrix blocks: the iteration counts of every dense parity fixture stay put, QAFIRO's 13 included.)
-// Layout of V: by diagonals -- entry (r, r - s), s = 0 .. 127, at dd_diag_off(s) + (r - s) -- so that the lane that owns row r (forward, x = V b) or column c
-// (backward, x = V^T b) walks its terms with consecutive lanes on consecutive addresses; hi and lo parts in two arrays of DD_TRI doubles per block.
+// ---- the diagonal step of the sweeps as ONE product with the inverse of the 128 x 128 diagonal block (rounds 4 / 5) -----------------------------------------
+// x_r = L_rr^-1 b is what bounded a sweep: eight dependent 16-column groups, 3.5 of the 5.3 us a block row cost (profiles/r03: 170 us per sweep = 5 % of HBM).
+// A product with the explicit inverse takes the dependence away, but with an inverse FORMED in double it costs accuracy exactly where it matters -- round 2
+// measured 2x the residual in the median and 11x at worst on the rho = delta = 1e-10 states, and two iteration counts moved.  Here V is computed in double-double
+// (106 bits) where the conditioning of the whole block enters and rounded to double once per factorisation: fl(V b) then carries the rounding of one product of
+// 128 terms, and the residuals against the factor are 0.5 - 1.0 x the substitution's (profiles/r05_dense_sweeps.txt).  (Round 4 applied the double-double V with
+// a compensated product in a 512-thread kernel that, it turned out, spilled 300 - 1200 registers; removed.)
 struct ddn { double h, l; };
 __device__ __forceinline__ ddn dd_two_sum(double a, double b) { const double s = a + b, bb = s - a; return {s, (a - (s - bb)) + (b - bb)}; }
 __device__ __forceinline__ ddn dd_quick(double a, double b) { const double s = a + b; return {s, b - (s - a)}; }
@@ -3296,17 +3294,6 @@ __device__ __forceinline__ ddn dd_add(ddn a, ddn b) { ddn s = dd_two_sum(a.h, b.
 __device__ __forceinline__ ddn dd_neg(ddn a) { return {-a.h, -a.l}; }
 __device__ __forceinline__ ddn dd_mul_d(ddn a, double b) { const double p = a.h * b; const double e = __builtin_fma(a.h, b, -p); return dd_quick(p, __builtin_fma(a.l, b, e)); }
 __device__ __forceinline__ ddn dd_mul(ddn a, ddn b) { const double p = a.h * b.h; double e = __builtin_fma(a.h, b.h, -p); e += a.h * b.l + a.l * b.h; return dd_quick(p, e); }
-__device__ __forceinline__ ddn dd_div_d(ddn a, double b)
-{
-    const double q1 = a.h / b;
-    ddn r = dd_add(a, dd_neg(dd_mul_d({q1, 0.0}, b)));  // a - q1 b
-    const double q2 = r.h / b;
-    r = dd_add(r, dd_neg(dd_mul_d({q2, 0.0}, b)));
-    const double q3 = r.h / b;
-    ddn q = dd_quick(q1, q2);
-    return dd_add(q, {q3, 0.0});
-}
-__host__ __device__ inline int dd_diag_off(int s) { return s * 128 - (s * (s - 1)) / 2; }
 // V = L_rr^-1 of every 128-row diagonal block (identity beyond the matrix; UNIT: unit diagonal, the stored one is D), rounded to double, 8 columns of V per
 // workgroup: block forward substitution in groups of 16 rows, X_g = W_g (E_g - sum_{h < g} L_gh X_h).  The sums over the earlier groups -- where the conditioning
 // of the whole block enters -- run in double-double; W_g = L_gg^-1, the inverse of one 16 x 16 piece, in double (its error is eps times the condition of that piece).
@@ -3416,11 +3403,10 @@ void launch_block_inverse_dd(bool unit, const double* L, int ld, int n, double* 
 }
 size_t block_inverse_dd_doubles(int n) { return (size_t)div_up(n, 128) * 128 * 128; }
 
-// (Serving a block row with several workgroups on several CUs -- helpers taking the earlier producers, the owner the last one -- was
-// measured slower in round 1: 203 / 222 us per sweep with one workgroup per row, 222 / 234 with two, 257 / 267 with four; the extra
-// hand-off costs more than the shared streaming saves.  Round 2 tried replacing the serial 128-step diagonal substitution by a product with
-// the inverted diagonal block: 108 / 151 us per sweep, but the residuals on the rho = delta = 1e-10 states doubled and two iteration-parity
-// tests moved; with one refinement step against the block the accuracy returned and the time was worse than the substitution.  Both removed.)
+// (Round 1 had served a block row with several workgroups and measured it slower -- 203 / 222 us per sweep with one workgroup per row, 222 / 234 with two,
+// 257 / 267 with four: with a 5 us diagonal step the extra hand-off cost more than the shared streaming saved.  With the diagonal step down to one product the
+// streaming IS what a block row waits for, and round 5's helpers pay: see INV below.  Round 2 had tried the inverted diagonal block formed in double: 108 / 151 us
+// per sweep, but the residuals on the rho = delta = 1e-10 states doubled and two iteration-parity tests moved.)
 // (Round 3 tried folding W_g into the blocks of the diagonal step once per factorisation -- S_gj = W_g L_gj, so that x_g = (W_g b_g) - sum_j S_gj x_j needs one
 // dependent 16 x 16 product per group instead of two: 700 instead of 850 cycles per group, 0.315 instead of 0.330 ms per solve, every accuracy gate held, but
 // the dense mm_QAFIRO solve left the oracle's iteration count -- an LP at rho = delta = 1e-10 whose count the oracle keeps even when compiled with FMA
@@ -3429,9 +3415,8 @@ size_t block_inverse_dd_doubles(int n) { return (size_t)div_up(n, 128) * 128 * 1
 // (the conditioning level of the panel solve, which holds the accuracy gates of tests/dense_replay.py -- unlike a 128 x 128 inverse), one wave;
 // then every thread takes its 8 columns of the group off the rows still to be solved.  Two LDS barriers per group instead of a 128-step
 // dependent chain on one wave (4.2 us per block in round 1).  W16 == nullptr keeps that substitution (reciprocal pivots in rdiag).
-// INV (round 5; Vinv = the rounded inverses of the 128 x 128 diagonal blocks, launch_block_inverse_dd): the diagonal step is ONE product x_r = V_r b_r, the entries
-// of V_r held in registers for the whole launch (64 per thread -- the workgroup keeps its 256 threads: 512 of them have 256 registers each, and two operand
-// blocks in flight next to V spill; round 4's 512-thread compensated product with the double-double inverse spilled 300 - 1200 registers and was removed)
+// INV (round 5; Vinv = the rounded inverses of the 128 x 128 diagonal blocks, launch_block_inverse_dd): the diagonal step is ONE product x_r = V_r b_r; 512 threads,
+// four per row; H helper workgroups per block row multiply the operand blocks of all producers but the owner's last two
 template <bool FWD, bool INV>
 __global__ __launch_bounds__(INV ? 512 : 256) void k_trsv_persistent(const double* __restrict__ L, int ld, int n, double* __restrict__ x, const double* __restrict__ rdiag,
                                                          int nblk, double* __restrict__ ysrc, double* __restrict__ yother, const double* __restrict__ dscale, int* __restrict__ err,
