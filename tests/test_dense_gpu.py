@@ -383,13 +383,15 @@ def test_failure_inside_the_persistent_launch_then_refactor_on_the_same_handle(h
     assert np.array_equal(np.tril(k.internal_factor()), np.tril(fresh.internal_factor()))
 
 
-def test_two_persistent_factorisations_on_two_streams(hip):
+@pytest.mark.parametrize("n", [2048, 640])
+def test_two_persistent_factorisations_on_two_streams(hip, n):
     """two handles (one a clone of the other) factor and solve from two host threads at the same time: the persistent launches of both compete for the
     CUs, neither is ever fully resident -- the ticket order guarantees progress with any number of resident workgroups -- and every result equals the
-    single-threaded one bit for bit"""
+    single-threaded one bit for bit.  n = 2048: sweeps with block inverses and helper workgroups, the inverses on a side stream; n = 640: substitution sweeps
+    on one XCD (both handles draw their block rows by ticket among the workgroups that land there)"""
     import threading
     import torch
-    n = m = 2048
+    m = n
     q = dense_strongly_convex_qp(n, 0, m, seed=5, double_sided=True, exact_shift=False)
     k1 = hip.KKTSystem(hip.Data(**q), hip.default_settings(kkt_solver=0))
     k2 = k1.clone()
