@@ -178,7 +178,7 @@ int pq_kkt_eval_A_xn_and_AT_xt(pq_kkt *k, double alpha_n, double alpha_t, const 
 int pq_kkt_eval_G_xn_and_GT_xt(pq_kkt *k, double alpha_n, double alpha_t, const double *xn, const double *xt,
                                double *zn, double *zt);
 int pq_kkt_print_info(pq_kkt *k);                                   /* kkt_solver_base.hpp:43 */
-int pq_kkt_synchronize(pq_kkt *k);                                  /* wait for the handle's stream */
+int pq_kkt_synchronize(pq_kkt *k);                                  /* wait for the handle's stream (everything a later call of the handle depends on is ordered behind it on the device) */
 void *pq_kkt_stream(pq_kkt *k);                                     /* hipStream_t of the handle */
 /* test hooks: dense/kkt.hpp:134 internal_kkt_mat() and the factor; copy n*n doubles to HOST memory */
 int pq_kkt_internal_kkt_mat(pq_kkt *k, double *out_host);
