@@ -3608,8 +3608,14 @@ __global__ __launch_bounds__(INV ? 512 : 256) void k_trsv_persistent(const doubl
             const bool pre = !helper && H > 0 && t0 + 1 < tend;  // the owner of a row with helpers requests both its operand blocks at once
             if (t0 < tend) load_block(t0, lvA);
             if (pre) load_block(t0 + 1, lvB);
-            if (!helper && H > 0 && quarter == 0) {
-                // the helpers' partial sums (ready two producers ahead of the chain)
+            // (the other direction's partial sums of this block row -- whose helpers are not the ones of this direction: all of them -- ready for the next sweep)
+            if (!helper && H > 0 && quarter == 0)
+                for (int h = 0; h < H; ++h) st_agent_bits(pother + ((size_t)r * H + h) * TB + row, TRSV_SENT);
+            // the helpers' partial sums: asked for AFTER the owner's first step.  The last of them comes from the producer three block rows back, through a helper on
+            // another XCD -- a good 2.5 us from that producer's hand-over to here, more than two block rows of the chain take: waited for up front, every third block
+            // row stalled on them (the timeline's gaps went 1.5, 0.15, 0.15, 1.5, ... us)
+            auto poll_partials = [&] {
+                if (quarter != 0) return;
                 constexpr int HMAX = 7;
                 const int hl = min(H, first);  // helpers with producers of their own
                 double pv[HMAX];
@@ -3628,10 +3634,8 @@ __global__ __launch_bounds__(INV ? 512 : 256) void k_trsv_persistent(const doubl
                         ps += pv[h];
                     }
                 }
-                // (the other direction's partial sums of this block row -- whose helpers are not the ones of this direction: all of them -- ready for the next sweep)
-                for (int h = 0; h < H; ++h) st_agent_bits(pother + ((size_t)r * H + h) * TB + row, TRSV_SENT);
-                acc = ps;
-            }
+                acc += ps;
+            };
             auto next_of = [&](int tt) { const int tn = tt + stride; return tn >= tend ? (helper ? -1 : LOADV) : ((pre && tt == t0) ? -1 : tn); };
             bool fine = true, v_in_b = false;
             int t = t0;
@@ -3639,6 +3643,7 @@ __global__ __launch_bounds__(INV ? 512 : 256) void k_trsv_persistent(const doubl
             while (t < tend) {
                 fine = consume(t, lvA, lvB, next_of(t));
                 v_in_b = true;
+                if (pre && t == t0) poll_partials();  // (pre: the only owners whose helpers have producers)
                 t += stride;
                 if (!fine || t >= tend) break;
                 fine = consume(t, lvB, lvA, next_of(t));
