@@ -3757,7 +3757,7 @@ __global__ __launch_bounds__(INV ? 512 : 256) void k_trsv_persistent(const doubl
                 wave_lds_sync();
                 if (lane == 0) *cprog = gi + 1;
                 asm volatile("" ::: "memory");
-                if (ts && lane == 0 && r == 1) ts[4 * nblk + gi] = clock64();  // debugging aid: the groups of block 1
+                if (ts && lane == 0 && r == 1) ts[4 * nblk + gi] = wall_clock64();  // debugging aid: the groups of block 1
                 tv = tn;
 #pragma unroll
                 for (int t = 0; t < 4; ++t) { wv[t] = wn[t]; l1[t] = ln[t]; }

@@ -410,22 +410,25 @@ private:
     StageProfiler prof_;
     int dbg_panel_ = -1;
     DBuf<long long> dbg_ts_, trsv_ts_;
-    // PIQP_AMD_DEBUG=trsv_ts: per block of the forward sweep, cycles from seeing the last producer's flag to products done / diagonal block
-    // solved / published (one workgroup's own clock: differences only)
+    // PIQP_AMD_DEBUG=trsv_ts: per block of the forward sweep, ticks of the device-wide 100 MHz clock (the compute units' own cycle counters are not
+    // comparable with each other) from seeing the last producer's values to products done / diagonal block solved / handed over, the gaps between one block's
+    // hand-over and the next block seeing it, and the hand-over times since block 1's
     void dump_trsv_ts()
     {
         std::vector<long long> h(trsv_ts_.n);
         PQ_HIP(hipMemcpyAsync(h.data(), trsv_ts_.p, trsv_ts_.bytes(), hipMemcpyDeviceToHost, st_));
         stream_wait(st_);
-        std::fprintf(stderr, "[piqp_amd] forward sweep, per block (flag seen -> products / -> solved / -> published):");
+        std::fprintf(stderr, "[piqp_amd] forward sweep, ticks of the device-wide 100 MHz clock; per block (last producer's values seen -> products / -> solved / -> handed over):");
         const size_t nb = (h.size() - 8) / 4;
         for (size_t r = 1; r < nb; ++r) std::fprintf(stderr, " %lld/%lld/%lld", h[4 * r + 1] - h[4 * r], h[4 * r + 2] - h[4 * r], h[4 * r + 3] - h[4 * r]);
         std::fprintf(stderr, "\n[piqp_amd]   from one block's published to the next one's seen:");
         for (size_t r = 2; r < nb; ++r) std::fprintf(stderr, " %lld", h[4 * r] - h[4 * (r - 1) + 3]);
         std::fprintf(stderr, "\n[piqp_amd]   published at (since block 1's):");
         for (size_t r = 1; r < nb; ++r) std::fprintf(stderr, " %lld", h[4 * r + 3] - h[4 * 1 + 3]);
-        std::fprintf(stderr, "\n[piqp_amd]   block 1, groups of the diagonal step done at (since products):");
-        for (int g = 0; g < 8; ++g) std::fprintf(stderr, " %lld", h[4 * nb + g] - h[4 * 1 + 1]);
+        if (h[4 * nb] != 0) {  // (the substitution form only)
+            std::fprintf(stderr, "\n[piqp_amd]   block 1, groups of the diagonal step done at (since products):");
+            for (int g = 0; g < 8; ++g) std::fprintf(stderr, " %lld", h[4 * nb + g] - h[4 * 1 + 1]);
+        }
         std::fprintf(stderr, "\n");
     }
 };
