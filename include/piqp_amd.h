@@ -434,6 +434,12 @@ int pq_microbench_hbm_copy(int device, size_t bytes, int iters, double *gbps_out
 /* debugging aid: average microseconds of the 128 x 128 diagonal-block factorisation kernel and 64 in-kernel shader-clock stamps
  * (step k at stamps64[8 k + q], see potrf_block in csrc/dense_kernels.hip); stamps64 may be NULL */
 int pq_microbench_potrf_block(int device, int ldlt, int reps, double *us_out, long long *stamps64);
+/* testing aid: the diagonal-block factorisation kernel (potrf_block: the unblocked part of Eigen::LLT, dense/kkt.hpp:82, resp. dense/ldlt_no_pivot.hpp:278-311) on the
+ * caller's symmetric block A of order nb <= 128 (host memory, column-major, leading dimension 128, lower triangle read), `reps` times.  Outputs of the last repetition
+ * (host memory): the factor L (128 x 128, lower triangle; LDLT: unit L with D on the diagonal), the reciprocal pivots rdiag[128] (LLT: 1 / l_cc, LDLT: 1 / d_c), D dvec[128]
+ * (LDLT), the operand pack of the panel solve pack[36 * 256] (blocks j (j - 1) / 2 + k: -L(j, k), blocks 28 + k: the inverse of L_kk; column-major 16 x 16 each), info
+ * (-1 or the first failing column), and the number of repetitions whose outputs differ from the first one's in any bit (0: the kernel is deterministic) */
+int pq_debug_potrf_block(int device, int ldlt, int nb, int reps, const double *A, double *L, double *rdiag, double *dvec, double *pack, int *info, int *differing_reps);
 
 #ifdef __cplusplus
 }

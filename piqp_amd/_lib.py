@@ -83,7 +83,7 @@ SYMBOLS = [
     "pq_solver_get_result", "pq_solver_dims", "pq_solver_set_trace", "pq_solver_trace_rows", "pq_solver_partition", "pq_solver_set_exchange",
     "pq_batch_create", "pq_batch_destroy", "pq_batch_settings", "pq_batch_setup_sparse", "pq_batch_update", "pq_batch_update_data", "pq_batch_solve", "pq_batch_info", "pq_batch_get_result",
     "pq_batch_dims", "pq_batch_block_info", "pq_batch_get_profile", "pq_batch_last_kernel_ms", "pq_batch_set_start_order",
-    "pq_debug_alloc_count", "pq_debug_chol_plan", "pq_kkt_set_exchange_norm", "pq_kkt_sharded_calls", "pq_kkt_sharded_solve_calls", "pq_solver_sharded_solve_calls", "pq_solver_set_exchange_norm", "pq_solver_sharded_calls", "pq_microbench_mfma_f64", "pq_microbench_hbm_copy", "pq_microbench_potrf_block", "pq_rccl_unique_id", "pq_kkt_set_comm_rccl", "pq_solver_set_comm_rccl", "pq_kkt_native_exchange_calls", "pq_kkt_min_abs_pivot", "pq_solver_native_exchange_calls",
+    "pq_debug_alloc_count", "pq_debug_chol_plan", "pq_kkt_set_exchange_norm", "pq_kkt_sharded_calls", "pq_kkt_sharded_solve_calls", "pq_solver_sharded_solve_calls", "pq_solver_set_exchange_norm", "pq_solver_sharded_calls", "pq_microbench_mfma_f64", "pq_microbench_hbm_copy", "pq_microbench_potrf_block", "pq_debug_potrf_block", "pq_rccl_unique_id", "pq_kkt_set_comm_rccl", "pq_solver_set_comm_rccl", "pq_kkt_native_exchange_calls", "pq_kkt_min_abs_pivot", "pq_solver_native_exchange_calls",
     "pq_sparse_amd_order", "pq_sparse_permute_sym_upper", "pq_sparse_kkt_symbolic", "pq_kkt_sparse_ordering", "pq_kkt_comm_info", "pq_solver_comm_info", "pq_kkt_exact_factor", "pq_sparse_uplooking_plan",
 ]
 
@@ -217,6 +217,7 @@ def load():
     L.pq_microbench_mfma_f64.argtypes = [C.c_int, C.c_int, _dp]
     L.pq_microbench_hbm_copy.argtypes = [C.c_int, C.c_size_t, C.c_int, _dp]
     L.pq_microbench_potrf_block.argtypes = [C.c_int, C.c_int, C.c_int, _dp, C.c_void_p]
+    L.pq_debug_potrf_block.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     _lib = L
     return L
 

@@ -736,6 +736,13 @@ int pq_microbench_potrf_block(int device, int ldlt, int reps, double* us_out, lo
     if (rc < 0) return rc;
     return guarded([&] { PQ_HIP(hipSetDevice(device)); *us_out = dense::microbench_potrf_block(ldlt != 0, reps, stamps64, nullptr); return (int)PQ_OK; });
 }
+int pq_debug_potrf_block(int device, int ldlt, int nb, int reps, const double* A, double* L, double* rdiag, double* dvec, double* pack, int* info, int* differing_reps)
+{
+    if (!A || !L || !rdiag || !dvec || !pack || !info || !differing_reps || nb < 1 || nb > 128 || reps < 1) return fail(PQ_ERR_INVALID, "bad argument");
+    int rc = check_device(device);
+    if (rc < 0) return rc;
+    return guarded([&] { PQ_HIP(hipSetDevice(device)); *differing_reps = dense::debug_potrf_block(ldlt != 0, nb, reps, A, L, rdiag, dvec, pack, info, nullptr); return (int)PQ_OK; });
+}
 int pq_microbench_hbm_copy(int device, size_t bytes, int iters, double* gbps_out)
 {
     int rc = check_device(device);

@@ -23,6 +23,7 @@
 #include <vector>
 #include <cstdlib>
 #include <cstdio>
+#include <cstring>
 
 namespace pq {
 namespace dense {
@@ -4174,6 +4175,39 @@ double microbench_potrf_block(bool ldlt, int reps, long long* stamps64, hipStrea
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     return reps > 1 ? total / (reps - 1) * 1e3 : 0.0;
+}
+
+// testing aid: `reps` factorisations of the caller's block of order nb <= 128 (host, column-major, leading dimension 128) by the diagonal-block kernel;
+// the results of the last one to the host, and the number of repetitions whose factor / pivots / pack differ from the first one's in any bit
+int debug_potrf_block(bool ldlt, int nb, int reps, const double* A_host, double* L_host, double* rdiag_host, double* dvec_host, double* pack_host, int* info_host, hipStream_t s)
+{
+    const int n = 128;
+    DBuf<double> A0((size_t)n * n), A((size_t)n * n), rdiag(n), dvec(n), pack(FACTOR_PACK_DOUBLES);
+    DBuf<int> info(1);
+    PQ_HIP(hipMemcpy(A0.p, A_host, A0.bytes(), hipMemcpyHostToDevice));
+    std::vector<double> first, cur((size_t)n * n + 2 * n + FACTOR_PACK_DOUBLES);
+    int differ = 0;
+    for (int r = 0; r < reps; ++r) {
+        PQ_HIP(hipMemcpyAsync(A.p, A0.p, A.bytes(), hipMemcpyDeviceToDevice, s));
+        PQ_HIP(hipMemsetAsync(info.p, 0xFF, sizeof(int), s));
+        PQ_HIP(hipMemsetAsync(rdiag.p, 0, rdiag.bytes(), s));
+        PQ_HIP(hipMemsetAsync(dvec.p, 0, dvec.bytes(), s));
+        PQ_HIP(hipMemsetAsync(pack.p, 0, pack.bytes(), s));
+        launch_potrf_diag(ldlt, A.p, n, nb, 0, info.p, rdiag.p, dvec.p, pack.p, nullptr, s, nullptr);
+        stream_wait(s);
+        PQ_HIP(hipMemcpy(cur.data(), A.p, A.bytes(), hipMemcpyDeviceToHost));
+        PQ_HIP(hipMemcpy(cur.data() + (size_t)n * n, rdiag.p, rdiag.bytes(), hipMemcpyDeviceToHost));
+        PQ_HIP(hipMemcpy(cur.data() + (size_t)n * n + n, dvec.p, dvec.bytes(), hipMemcpyDeviceToHost));
+        PQ_HIP(hipMemcpy(cur.data() + (size_t)n * n + 2 * n, pack.p, pack.bytes(), hipMemcpyDeviceToHost));
+        if (r == 0) first = cur;
+        else if (memcmp(first.data(), cur.data(), cur.size() * sizeof(double)) != 0) ++differ;
+    }
+    memcpy(L_host, cur.data(), (size_t)n * n * sizeof(double));
+    memcpy(rdiag_host, cur.data() + (size_t)n * n, n * sizeof(double));
+    memcpy(dvec_host, cur.data() + (size_t)n * n + n, n * sizeof(double));
+    memcpy(pack_host, cur.data() + (size_t)n * n + 2 * n, FACTOR_PACK_DOUBLES * sizeof(double));
+    PQ_HIP(hipMemcpy(info_host, info.p, sizeof(int), hipMemcpyDeviceToHost));
+    return differ;
 }
 
 template <int U, bool NT>

@@ -73,6 +73,9 @@ void launch_potrf_diag(bool ldlt, double* A, int lda, int nb, int kglobal, int* 
                        long long* ts = nullptr);  // w16 (nullable): the eight inverted 16 x 16 diagonal pieces of this block, 8 x 256 doubles (for launch_trsv)
 // debugging aid: `reps` factorisations of a synthetic 128 x 128 block; average microseconds and the 64 shader-clock stamps of potrf_block
 double microbench_potrf_block(bool ldlt, int reps, long long* stamps64, hipStream_t s);
+// testing aid: the caller's block of order nb <= 128 (host, leading dimension 128) through the same kernel, `reps` times; outputs of the last repetition to the
+// host (factor 128 x 128, reciprocal pivots 128, D 128, pack FACTOR_PACK_DOUBLES, info); returns the number of repetitions that differ from the first in any bit
+int debug_potrf_block(bool ldlt, int nb, int reps, const double* A_host, double* L_host, double* rdiag_host, double* dvec_host, double* pack_host, int* info_host, hipStream_t s);
 // rows k0 + nb .. n of the panel at column k0:  A21 <- A21 L11^-T (D^-1), with the pack written by the factorisation of L11
 void launch_trsm_panel(bool ldlt, double* A, int lda, int k0, int nb, int n, const double* pack, const double* rdiag, hipStream_t s);
 // the persistent factorisation (k_chol_persistent, dense_kernels.hip): every round after the first diagonal block and panel in one launch
