@@ -31,7 +31,10 @@ def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(f) > t for f in sources() + headers())
+    if any(os.path.getmtime(f) > t for f in sources() + headers()):
+        return True
+    # (objects without the record of their command line -- built by an older build.py -- are rebuilt once)
+    return any(not os.path.exists(os.path.join(OUT, os.path.basename(s) + ".o.cmd")) for s in sources())
 
 
 def build(force=False, verbose=False):
@@ -43,19 +46,27 @@ def build(force=False, verbose=False):
     procs = []
     for s in sources():
         o = os.path.join(OUT, os.path.basename(s) + ".o")
-        if not force and os.path.exists(o) and os.path.getmtime(o) > max(os.path.getmtime(f) for f in [s] + headers()):
-            objs.append(o)
-            continue
         contract = "off" if os.path.basename(s) in NO_CONTRACT else "on"
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-ffp-contract=" + contract,
                "-Wall", "-Wno-unused-function", "-c", s, "-o", o]
+        # an object is reused only if it is newer than its sources AND was built with this very command line (the flags are part of the contract: an object
+        # of one of the NO_CONTRACT files built with contraction on would silently break the bitwise parity of the reference-order path)
+        stamp = o + ".cmd"
+        same_cmd = os.path.exists(stamp) and open(stamp).read() == " ".join(cmd)
+        if not force and same_cmd and os.path.exists(o) and os.path.getmtime(o) > max(os.path.getmtime(f) for f in [s] + headers()):
+            objs.append(o)
+            continue
         if verbose:
             print(" ".join(cmd), flush=True)
-        procs.append((s, subprocess.Popen(cmd)))
+        if os.path.exists(stamp):
+            os.remove(stamp)
+        procs.append((s, subprocess.Popen(cmd), stamp, " ".join(cmd)))
         objs.append(o)
-    for s, p in procs:
+    for s, p, stamp, line in procs:
         if p.wait() != 0:
             raise RuntimeError("hipcc failed on " + s)
+        with open(stamp, "w") as f:
+            f.write(line)
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     subprocess.check_call(cmd)
     return LIB

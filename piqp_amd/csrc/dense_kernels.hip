@@ -3444,7 +3444,7 @@ __global__ __launch_bounds__(INV ? 512 : 256) void k_trsv_persistent(const doubl
     // -- which no chain shorter than that can hide; with the helpers a row's operand blocks arrive through up to eight compute units.
     const int role = (INV && H > 0) ? ridx_s % (1 + H) : 0;
     const bool helper = INV && H > 0 && role < H;
-    if (ridx_s / ((INV && H > 0) ? 1 + H : 1) >= nblk) return;
+    if (ridx_s < 0 || ridx_s / ((INV && H > 0) ? 1 + H : 1) >= nblk) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // threads per row in the product phase, CW columns of the operand block each.  INV: four (512 threads, two waves per SIMD: one wave issues an instruction every
     // ~5 cycles, and a step of 64 multiply-adds, their LDS reads and the moves out of the AGPRs was 1.2 us of every block row); 256 registers each are enough for two
@@ -3883,7 +3883,11 @@ void launch_trsv(const double* L, int ld, int n, double* x, const double* rdiag,
         const bool one_xcd = xcd_seq >= 0 && nblk <= 32 && H == 0;
         int* tf = one_xcd ? ctl + 1 : nullptr;
         int* tb = one_xcd ? ctl + 2 : nullptr;
-        const int tbase = one_xcd ? xcd_seq * nblk : 0;
+        // (the two ticket words start every pair of sweeps from zero: a launch that is dealt more or fewer workgroups on XCD 0 than the probe at handle creation saw
+        // -- another process on the device, another partition mode -- then only affects itself: surplus workgroups leave, missing ones end in the bounded waits'
+        // error word; with counters running on across launches every later solve on the handle would have been out of step)
+        if (one_xcd) PQ_HIP(hipMemsetAsync(ctl + 1, 0, 2 * sizeof(int), s));
+        const int tbase = 0;
         const dim3 grid(one_xcd ? 8 * nblk : nblk * (1 + H));
         if (Vinv) hipLaunchKernelGGL((k_trsv_persistent<true, true>), grid, dim3(512), TRSV_P_LDS_BYTES, s, L, ld, n, x, rd, nblk, yf, yb, (const double*)nullptr, err, w16, ts, Vinv, tf, tbase, H, pf, pb, ylf, ylb);
         else hipLaunchKernelGGL((k_trsv_persistent<true, false>), grid, dim3(256), TRSV_P_LDS_BYTES, s, L, ld, n, x, rd, nblk, yf, yb, (const double*)nullptr, err, w16, ts, Vinv, tf, tbase, H, pf, pb, ylf, ylb);

@@ -103,7 +103,7 @@ void launch_trsv_poll_init(double* ypoll, int n, hipStream_t s);
 // Vinv (nullable; persistent sweeps only): the inverses of the 128-row diagonal blocks written by launch_block_inverse_dd -- the diagonal step of a block row
 // becomes one product with them instead of eight dependent 16-column groups
 // ctl: 3 ints, zeroed by the owner: error word, tickets of the two sweeps.  xcd_seq >= 0 (only when probe_one_xcd_sweeps() said yes; sweeps of at most 32 block rows):
-// the sweep runs on XCD 0 alone, xcd_seq = the number of such solves on this ctl before this one (the owner zeroes the tickets again before xcd_seq * 32 overflows)
+// the sweep runs on XCD 0 alone (launch_trsv zeroes the two ticket words on the stream before every pair of sweeps; the value of xcd_seq beyond its sign is no longer used)
 void launch_trsv(const double* L, int ld, int n, double* x, const double* rdiag, bool ldlt, double* ypoll, int* ctl, const double* w16, hipStream_t s, long long* ts = nullptr,  // ts: debugging aid, 4 stamps per block of the forward sweep
                  const double* Vinv = nullptr, int xcd_seq = -1);
 bool probe_one_xcd_sweeps(hipStream_t s);

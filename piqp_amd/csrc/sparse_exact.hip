@@ -293,12 +293,15 @@ __device__ __forceinline__ void stw(double* p, double v) { __hip_atomic_store(p,
 __device__ __forceinline__ int ldf(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void stf(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// bound of every wait of the engine: ~0.7 us a poll, so a few seconds -- the longest legitimate wait is a fraction of one factorisation (hundreds of milliseconds on the
+// largest fixtures); what ends here is reported (info = -2), retried once on the single ticket queue by the factorisation, and thrown if it happens again
+constexpr long long UL_SPIN_LIMIT = 1ll << 22;
 __device__ __forceinline__ bool spin_until(const int* flag, int epoch)
 {
     long long spins = 0;
     while (ldf(flag) != epoch) {
         __builtin_amdgcn_s_sleep(1);
-        if (++spins > (1ll << 26)) return false;  // (seconds: a scheduling bug must not take the device with it)
+        if (++spins > UL_SPIN_LIMIT) return false;  // (a few seconds: a scheduling bug must not take the device with it)
     }
     return true;
 }
@@ -319,6 +322,10 @@ __global__ void k_ul_prepare(size_t nd, double* __restrict__ D, size_t nl, doubl
     if (i < 128 && xtick) xtick[i] = 0;
     if (i == 0) { ctl[0] = 0; ctl[1] = INT_MAX; }
 }
+__global__ void k_ul_poison_if_failed(const int* __restrict__ info, double* __restrict__ x, int n)
+{
+    if (*info <= -2 && (int)threadIdx.x < n) x[threadIdx.x] = __longlong_as_double(0x7ff8000000000000ll);
+}
 // which XCD does a workgroup of a launch of this shape land on?  (the per-XCD queues are only used when every one of the eight gets workgroups)
 __global__ void k_ul_xcd_probe(int* __restrict__ count)
 {
@@ -331,7 +338,7 @@ __device__ __forceinline__ bool poll_value(const double* p, double& out)
         const double v = ldw(p);
         if (__double_as_longlong(v) != UL_SENT) { out = v; return true; }
         __builtin_amdgcn_s_sleep(1);
-        if (++spins > (1ll << 26)) return false;
+        if (++spins > UL_SPIN_LIMIT) return false;
     }
 }
 
@@ -1071,6 +1078,7 @@ public:
         }
         prof_.end(0, t0, st_);
         const int t1 = prof_.begin(1, st_);
+        for (int attempt = 0;; ++attempt) {
         ++epoch_;
         UlFactorArgs a;
         a.N = N_; a.nticket = nticket_; a.epoch = epoch_;
@@ -1097,16 +1105,21 @@ public:
             else launch();
         }
         PQ_HIP(hipGetLastError());
-        prof_.end(1, t1, st_);
-        if (N_ == 0) { stream_wait(st_); return true; }  // (nothing to factor)
+        if (N_ == 0) { prof_.end(1, t1, st_); stream_wait(st_); return true; }  // (nothing to factor)
         PQ_HIP(hipMemcpyAsync(ctl_h_.p + 2, ctl_.p + 1, sizeof(int), hipMemcpyDeviceToHost, st_));
         stream_wait(st_);
         if (ctl_h_.p[2] <= -2) {
-            std::string qs;
-            if (xq_on_) for (int q = 0; q < 8; ++q) { int tq = 0; (void)hipMemcpy(&tq, xtick_.p + 16 * q, sizeof(int), hipMemcpyDeviceToHost); qs += " " + std::to_string(tq); }
-            throw std::runtime_error("reference-order factorisation: a task waited for its children without end (scheduling error)" + (xq_on_ ? "; tickets drawn per XCD queue:" + qs : std::string()));
+            // A wait ran into its bound.  With the per-XCD queues that is what happens when an XCD has no resident workgroup of this launch -- the residency was
+            // probed once, at build time, and another process on the device (test workers, ranks sharing one GPU) or another long persistent kernel can take
+            // it away: the queue of that XCD then never moves.  The single ticket queue has no such requirement (tickets are drawn by whoever runs, waits only
+            // target earlier tickets), so the factorisation is run again on it, once, and this handle keeps it; only a second failure is an error.
+            if (xq_on_ && attempt == 0) { xq_on_ = false; ++xq_fallbacks_; continue; }
+            prof_.end(1, t1, st_);
+            throw std::runtime_error("reference-order factorisation: a task waited for its children without end (scheduling error)");
         }
+        prof_.end(1, t1, st_);
         return ctl_h_.p[2] == INT_MAX;  // n == cols (sparse/kkt.hpp:104)
+        }
     }
     // sparse/kkt.hpp:107-145, KKT_FULL
     void solve(const double* rhs_x, const double* rhs_y, const double* rhs_z, double* lhs_x, double* lhs_y, double* lhs_z) override
@@ -1128,7 +1141,7 @@ public:
         }
         if (N_ > 0 && !one_wave_solve_) {
             ++sepoch_;
-            PQ_HIP(hipMemsetAsync(ctl_.p + 2, 0, sizeof(int), st_));
+            PQ_HIP(hipMemsetAsync(ctl_.p + 2, 0, 2 * sizeof(int), st_));  // the substitution's ticket and its result word
             UlSolve2Args b;
             b.N = N_; b.n = n_; b.p = kp; b.m = km; b.ntask = ntask_; b.epoch = sepoch_;
             b.perm = perm_.p; b.taskrec = taskrec_.p; b.task_rows = task_rows_.p; b.tsort = tsort_.p; b.tdep = tdep_.p; b.fs_u = fs_u_.p; b.fs_col = fs_col_.p; b.fs4 = reinterpret_cast<const int4*>(fs4_.p); b.fs_task = fs_task_.p;
@@ -1143,6 +1156,9 @@ public:
             auto launch = [&] { hipLaunchKernelGGL(k_ul_solve2<32>, dim3(sgrid_), dim3(64), (size_t)(xa_cap_ + 64) * sizeof(double), st_, b); };
             if (xq_on_) xq_launch_order().run(dev_, st_, xq_event_, launch);
             else launch();
+            // a wait of the substitution that ran into its bound leaves tasks undone and stale finite values in the solution: poison it (the dense sweeps do the same),
+            // so that KKTSystem's refinement / the solver's finiteness checks fail the step instead of taking it
+            hipLaunchKernelGGL(k_ul_poison_if_failed, dim3(1), dim3(64), 0, st_, ctl_.p + 3, lhs_x, n_);
         } else if (N_ > 0) {
         UlSolveArgs a;
         a.N = N_; a.n = n_; a.p = kp; a.m = km;
@@ -1464,6 +1480,7 @@ private:
     DBuf<int> xq_ptr_, xq_rows_, xtick_;
     DBuf<double> Dloc_;
     bool xq_on_ = false;
+    int xq_fallbacks_ = 0;  // factorisations that were run again on the single ticket queue
     hipEvent_t xq_event_ = nullptr;
     std::vector<int> xq_rows_h_;
     // tasks with fewer entries per row than this run their path pass on ONE wave (ul_path).  0 since the rows of a task hand over by values (one round trip per

@@ -75,10 +75,13 @@ def test_kkt_factor_solve_on_real_problem(hip, orc, name):
 # sequence of IEEE operations as the oracle's, and the contract is the strongest one there is -- the per-iteration table of solver.hpp:590-602 (objectives,
 # residuals, rho, delta, mu, step lengths) BITWISE equal on every iteration, the same status, the same count, the same x.  That covers every fixture the earlier
 # rounds had to list as trajectory sensitive (the degenerate LPs that decide their path on exact zero pivots: QBEACONF, fffff800, finnis, perold, forplan, ...):
-# there is no allow-list any more.  Above 8192 rows the supernodal multifrontal engine runs (another summation order by construction): same status, the optimum
-# to 1e-6, the count within one iteration of the oracle's.
+# there is no allow-list any more.  Above 8192 rows the default engine is the supernodal multifrontal one (another summation order by construction, 10-60 x faster
+# there: profiles/r06_big_engines.txt): same status, the optimum to 1e-6 and the oracle's iteration count -- no slack (round 6) -- except on the two of the eight
+# such fixtures where the two summation orders end one iteration apart, pinned by name to the count the device takes (a change of either is a change of arithmetic).
+# The reference-order engine does not stop at 8192 rows, though: kkt_solver = SPARSE_LDLT_EXACT runs it on any size, and all eight fixtures -- CONT-201, SURVEY 8(d)'s
+# named cross-check, among them: 12 iterations like the oracle -- are held to the bitwise contract through it as well (test below; 0.1-4 s per whole solve).
 EXACT_MAX_ROWS = 8192
-MULTIFRONTAL_ITER_SLACK = 1
+MULTIFRONTAL_COUNTS = {"mm_CONT-201": (13, 12), "mm_STADAT3": (14, 15)}  # fixture -> (multifrontal engine, oracle)
 
 
 def _rows(q):
@@ -106,9 +109,39 @@ def _assert_same_solve(name, q, sh, so, st_h, st_o):
         assert bad.size == 0, (name, "first differing (iteration, column)", bad[0].tolist(), th[tuple(bad[0])], to[tuple(bad[0])])
         assert np.array_equal(np.asarray(sh.result()["x"]), np.asarray(so.result()["x"])), name
     else:
-        assert abs(sh.info.iter - so.info.iter) <= MULTIFRONTAL_ITER_SLACK, (name, sh.info.iter, so.info.iter)
+        if name in MULTIFRONTAL_COUNTS:
+            assert (sh.info.iter, so.info.iter) == MULTIFRONTAL_COUNTS[name], (name, sh.info.iter, so.info.iter)
+        else:
+            assert sh.info.iter == so.info.iter, (name, sh.info.iter, so.info.iter)
         if st_h == 1:
             assert abs(sh.info.primal_obj - so.info.primal_obj) <= 1e-6 * max(1.0, abs(so.info.primal_obj)) + 10 * so.settings.eps_abs
+
+
+ABOVE_EXACT_MAX_ROWS = ["mm_BOYD1", "mm_CONT-101", "mm_CONT-201", "mm_LISWET1", "mm_POWELL20", "mm_STADAT3", "mm_UBH1", "nl_truss"]
+
+
+@pytest.mark.parametrize("name", ABOVE_EXACT_MAX_ROWS)
+def test_fixtures_above_8192_rows_bitwise_through_the_reference_order_engine(hip, orc, name):
+    """the eight frozen fixtures whose KKT system has more than 8192 rows (9 806 .. 93 279) through kkt_solver = SPARSE_LDLT_EXACT: the per-iteration table, the status,
+    the count and x BITWISE the oracle's, like the other 214 (sparse/ldlt.hpp:101-169 in the reference's own order of operations at any size; above 20 000 rows the
+    work vector of the row pass lives in HBM).  Record: profiles/r06_exact_big.txt"""
+    q = load_qp(name)
+    netlib = name.startswith("nl")
+    sh = hip.SparseSolver(); sh.settings.kkt_solver = hip.SPARSE_LDLT_EXACT
+    so = orc.Solver(); so.settings.kkt_solver = orc.SPARSE_LDLT
+    if netlib:
+        sh.settings.infeasibility_threshold = so.settings.infeasibility_threshold = 0.01
+    sh.enable_trace(1024); so.enable_trace(1024)
+    assert sh.setup(*_args(q)) and so.setup(*_args(q), sparse=True)
+    st_h, st_o = sh.solve(), so.solve()
+    assert st_h == st_o == 1, (name, st_h, st_o)
+    assert sh.info.iter == so.info.iter, (name, sh.info.iter, so.info.iter)
+    th, to = sh.trace(), so.trace()
+    assert th.shape == to.shape, (name, th.shape, to.shape)
+    same = (th == to) | ((th != th) & (to != to))
+    bad = np.argwhere(~same)
+    assert bad.size == 0, (name, "first differing (iteration, column)", bad[0].tolist(), th[tuple(bad[0])], to[tuple(bad[0])])
+    assert np.array_equal(np.asarray(sh.result()["x"]), np.asarray(so.result()["x"])), name
 
 
 @pytest.mark.parametrize("name", ALL_MM)

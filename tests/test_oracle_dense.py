@@ -270,3 +270,27 @@ def test_fixture_problems_solved(orc, name):
     s = orc.Solver()
     assert s.setup(*dense_args(q))
     assert s.solve() == orc.SOLVED
+
+
+def _dense_sweep_names():
+    import glob
+    import os
+    from qp_io import GOLDEN
+    out = []
+    for f in sorted(glob.glob(os.path.join(GOLDEN, "mm_*.npz"))):
+        name = os.path.basename(f)[:-4]
+        q = load_qp(name)
+        n = q["P"].shape[0]; p = 0 if q["A"] is None else q["A"].shape[0]; m = 0 if q["G"] is None else q["G"].shape[0]
+        if n <= 1000 and p + m <= 1000:
+            out.append(name)
+    return out
+
+
+@pytest.mark.parametrize("name", _dense_sweep_names())
+def test_oracle_meets_the_dense_maros_meszaros_contract(orc, name):
+    """the reference's dense sweep as a pin of the ORACLE (/root/reference/tests/src/dense/maros_meszaros_tests.cpp:21-51): every Maros-Meszaros problem with n <= 1000
+    and p + m <= 1000 through DenseSolver at default settings ends PIQP_SOLVED -- all 72 frozen problems that pass the reference's filter (the device's side of the
+    same sweep: tests/test_mm_dense_gpu.py)"""
+    s = orc.Solver()
+    assert s.setup(*dense_args(load_qp(name)))
+    assert s.solve() == orc.SOLVED

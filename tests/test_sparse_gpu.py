@@ -371,6 +371,33 @@ def test_condensed_modes_whole_solves_bitwise_the_oracle(hip, orc, ks, ksid, mod
     assert np.array_equal(np.asarray(sh.result()["x"]), np.asarray(so.result()["x"])), name
 
 
+@pytest.mark.parametrize("ks,ksid,mode", COND)
+def test_condensed_modes_on_cont_201(hip, orc, ks, ksid, mode, monkeypatch):
+    """SURVEY 8(d)'s named cross-check (mm_CONT-201: 80 595 KKT rows, 12 iterations in the reference's notebook and in the oracle) in the three condensed modes.  The
+    default engine above 8192 rows is the multifrontal one (another summation order): SOLVED with the optimum to 1e-6, its iteration count pinned per mode next to the
+    oracle's 12.  The reference-order engine (PIQP_AMD_SPARSE_LDLT=exact; the condensed modes have no kkt_solver value of their own for it) takes the oracle's 12 in every
+    mode, with the per-iteration table bitwise equal.  Record: profiles/r06_exact_big.txt"""
+    q = load_qp("mm_CONT-201")
+    multifrontal_count = {1: 14, 2: 13, 3: 14}[mode]
+    for engine in ("multifrontal", "exact"):
+        monkeypatch.setenv("PIQP_AMD_SPARSE_LDLT", engine)
+        sh = hip.SparseSolver(); sh.settings.kkt_solver = ksid
+        so = orc.Solver(); so.settings.kkt_solver = getattr(orc, ks)
+        sh.enable_trace(1024); so.enable_trace(1024)
+        assert sh.setup(*_args(q)) and so.setup(*_args(q), sparse=True)
+        st_h, st_o = sh.solve(), so.solve()
+        assert st_h == st_o == 1
+        assert so.info.iter == 12
+        if engine == "exact":
+            th, to = sh.trace(), so.trace()
+            assert sh.info.iter == 12 and th.shape == to.shape
+            assert ((th == to) | ((th != th) & (to != to))).all()
+            assert np.array_equal(np.asarray(sh.result()["x"]), np.asarray(so.result()["x"]))
+        else:
+            assert sh.info.iter == multifrontal_count, (ks, sh.info.iter)
+            assert abs(sh.info.primal_obj - so.info.primal_obj) <= 1e-6 * max(1.0, abs(so.info.primal_obj)) + 10 * so.settings.eps_abs
+
+
 def test_condensed_mode_on_long_chain(hip):
     """sparse_ldlt_cond on a C5-style chain: the condensed matrix is the block-tridiagonal system the multistage backend factors
     serially; the multifrontal backend factors it with a nested-dissection tree.  Property: relative KKT residual <= 1e-10."""
