@@ -3579,6 +3579,105 @@ private:
 
 KKTSolverBase* make_multifrontal_kkt(const pq_sparse_data* data, int mode, int device) { return new SparseKKT(data, mode, device); }
 
+namespace {
+// A host copy of the matrices a sparse backend is built from (the C-ABI lends them for the duration of a call only).
+struct SparseDataCopy {
+    std::vector<int> pc, pr, ac, ar, gc, gr, hl, hu, xl, xu;
+    std::vector<double> pv, av, gv, xb;
+    pq_sparse_data d{};
+    bool has_xb = false;
+    void take(const pq_sparse_data* s)
+    {
+        auto csc = [](int cols, const int* cp, const int* ri, const double* v, std::vector<int>& c, std::vector<int>& r, std::vector<double>& x) {
+            c.assign(cp, cp + cols + 1);
+            r.assign(ri, ri + c[cols]);
+            x.assign(v, v + c[cols]);
+        };
+        csc(s->n, s->P_colptr, s->P_rowind, s->P_val, pc, pr, pv);
+        csc(s->p, s->AT_colptr, s->AT_rowind, s->AT_val, ac, ar, av);
+        csc(s->m, s->GT_colptr, s->GT_rowind, s->GT_val, gc, gr, gv);
+        auto idx = [](const int* p, int k, std::vector<int>& o) { if (p && k > 0) o.assign(p, p + k); else o.clear(); };
+        idx(s->h_l_idx, s->n_h_l, hl); idx(s->h_u_idx, s->n_h_u, hu); idx(s->x_l_idx, s->n_x_l, xl); idx(s->x_u_idx, s->n_x_u, xu);
+        has_xb = s->x_b_scaling != nullptr;
+        if (has_xb) xb.assign(s->x_b_scaling, s->x_b_scaling + s->n);
+        d = *s;
+        d.P_colptr = pc.data(); d.P_rowind = pr.data(); d.P_val = pv.data();
+        d.AT_colptr = ac.data(); d.AT_rowind = ar.data(); d.AT_val = av.data();
+        d.GT_colptr = gc.data(); d.GT_rowind = gr.data(); d.GT_val = gv.data();
+        d.h_l_idx = hl.data(); d.h_u_idx = hu.data(); d.x_l_idx = xl.data(); d.x_u_idx = xu.data();
+        d.x_b_scaling = has_xb ? xb.data() : nullptr;
+        d.mem = PQ_MEM_HOST;
+    }
+};
+
+// kkt_solver = sparse_ldlt (or a condensed mode) on a system small enough for the reference-order engine -- which has no stage partition: a caller that asks for one
+// (pq_kkt_partition) gets the multifrontal engine from there on, built from this wrapper's copy of the data, instead of "not supported" (round-5 advice).  Everything
+// else is forwarded to the engine in use.
+class EngineSwitchKKT final : public KKTSolverBase {
+public:
+    EngineSwitchKKT(KKTSolverBase* exact, const pq_sparse_data* data, int mode, int device) : cur_(exact), mode_(mode), dev_(device) { copy_.take(data); }
+    ~EngineSwitchKKT() override { delete cur_; }
+    KKTSolverBase* clone() const override
+    {
+        auto* c = new EngineSwitchKKT(cur_->clone(), &copy_.d, mode_, dev_);
+        c->switched_ = switched_;
+        return c;
+    }
+    void update_data_sparse(const pq_sparse_data* data, int options) override { copy_.take(data); cur_->update_data_sparse(data, options); }
+    bool update_scalings_and_factor(double delta, const double* x_reg, const double* z_reg) override { return cur_->update_scalings_and_factor(delta, x_reg, z_reg); }
+    void solve(const double* rx, const double* ry, const double* rz, double* lx, double* ly, double* lz) override { cur_->solve(rx, ry, rz, lx, ly, lz); }
+    void eval_P_x(double alpha, const double* x, double* z) override { cur_->eval_P_x(alpha, x, z); }
+    void eval_A_xn_and_AT_xt(double an, double at, const double* xn, const double* xt, double* zn, double* zt) override { cur_->eval_A_xn_and_AT_xt(an, at, xn, xt, zn, zt); }
+    void eval_G_xn_and_GT_xt(double an, double at, const double* xn, const double* xt, double* zn, double* zt) override { cur_->eval_G_xn_and_GT_xt(an, at, xn, xt, zn, zt); }
+    void print_info() override { cur_->print_info(); }
+    const double* P_diag_device() const override { return cur_->P_diag_device(); }
+    int n() const override { return cur_->n(); }
+    int p() const override { return cur_->p(); }
+    int m() const override { return cur_->m(); }
+    hipStream_t stream() const override { return cur_->stream(); }
+    int device() const override { return cur_->device(); }
+    void sparse_stats(double out[8]) const override { cur_->sparse_stats(out); }
+    int sparse_ordering(int* fill_perm, int* elim_perm) const override { return cur_->sparse_ordering(fill_perm, elim_perm); }
+    void partition(int rank, int world, long long sizes[3]) override
+    {
+        if (!switched_) {
+            // (the streams of the two engines are their own: whatever the caller queued on the old one is finished before it goes)
+            stream_wait(cur_->stream());
+            KKTSolverBase* mf = make_multifrontal_kkt(&copy_.d, mode_, dev_);
+            delete cur_;
+            cur_ = mf;
+            switched_ = true;
+        }
+        cur_->partition(rank, world, sizes);
+    }
+    void set_exchange(pq_exchange_fn fn, void* user, double* bf, double* bw, double* bg) override { cur_->set_exchange(fn, user, bf, bw, bg); }
+    void set_comm_rccl(const unsigned char* id128, int rank, int world) override { cur_->set_comm_rccl(id128, rank, world); }
+    bool reference_order() const override { return cur_->reference_order(); }
+    long long exact_factor(int what, void* out_host) override { return cur_->exact_factor(what, out_host); }
+    double min_abs_pivot() override { return cur_->min_abs_pivot(); }
+    void native_exchange_calls(int out[3]) const override { cur_->native_exchange_calls(out); }
+    void set_exchange_norm(double* buf_norm) override { cur_->set_exchange_norm(buf_norm); }
+    bool refine_error_sharded(const double* lx, const double* ly, const double* lz, const double* rx, const double* ry, const double* rz, const double* x_reg, double delta,
+                              const double* z_reg, double* ex, double* ey, double* ez, double* norm) override
+    {
+        return cur_->refine_error_sharded(lx, ly, lz, rx, ry, rz, x_reg, delta, z_reg, ex, ey, ez, norm);
+    }
+    void sharded_calls(int out[2]) const override { cur_->sharded_calls(out); }
+    void finish_sharded_solve(double* ly, double* lz) override { cur_->finish_sharded_solve(ly, lz); }
+    void sharded_solve_calls(int out[6]) const override { cur_->sharded_solve_calls(out); }
+    void comm_info(int out[4]) const override { cur_->comm_info(out); }
+    void partition_info(int out[8]) const override { cur_->partition_info(out); }
+    void set_profiling(int level) override { cur_->set_profiling(level); }
+    void get_profile(int stage, double* total_ms, int* count) override { cur_->get_profile(stage, total_ms, count); }
+
+private:
+    KKTSolverBase* cur_;
+    SparseDataCopy copy_;
+    int mode_, dev_;
+    bool switched_ = false;
+};
+}  // namespace
+
 // KKTSystem::init_kkt_solver<PIQP_SPARSE> (kkt_system.hpp:470-497): all six sparse backends of the reference
 KKTSolverBase* make_sparse_kkt(const pq_sparse_data* data, int kkt_solver, int device)
 {
@@ -3600,7 +3699,7 @@ KKTSolverBase* make_sparse_kkt(const pq_sparse_data* data, int kkt_solver, int d
             const char* mf = std::getenv("PIQP_AMD_EXACT_MAX_FLOPS");
             // (the condensed modes' systems are denser -- nl_czprob 2.1e9 flops, eleven fixtures above 2e8 -- and keep their bitwise contract too: limit 3e9 there)
             const double max_flops = eng ? 0.0 : (mf ? std::atof(mf) : (mode == 0 ? 4e7 : 3e9));
-            if (KKTSolverBase* k = make_exact_sparse_kkt(data, mode, device, max_flops)) return k;
+            if (KKTSolverBase* k = make_exact_sparse_kkt(data, mode, device, max_flops)) return new EngineSwitchKKT(k, data, mode, device);
         }
         return new SparseKKT(data, mode, device);
     }

@@ -169,6 +169,43 @@ def test_sharded_solve_side_of_the_condensed_backends(backend, problem, nranks):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("ks", [1, 4])
+def test_partition_of_a_system_small_enough_for_the_reference_order_engine(ks):
+    """round-5 advice: kkt_solver = sparse_ldlt (and the condensed modes) on a KKT system of at most 8192 rows builds the reference-order engine, which has no stage
+    partition.  pq_kkt_partition on such a handle used to fail ("not supported by this backend"); now the handle switches to the multifrontal engine, built from its
+    own copy of the data, and partitions that: the partitioned (world = 1) factor + solve equals the multifrontal engine's, bit for bit."""
+    import numpy as np
+    import piqp_amd as hip
+    from piqp_amd.dist import StagePartition
+    from qp_gen import c3_problem
+    args = c3_problem(n=900, p=300, m=500, seed=11, spread=40)
+    d = hip.SparseData(*args)
+    n, p, m = d.n, d.p, d.m
+    rng = np.random.default_rng(3)
+    x_reg = rng.uniform(0.5, 2.0, n); z_reg = rng.uniform(0.1, 3.0, m)
+    r = [rng.standard_normal(k) for k in (n, p, m)]
+    k = hip.SparseKKT(d, kkt_solver=ks)
+    assert k.update_scalings_and_factor(0.7, x_reg, z_reg)
+    ref_order = k.solve(*r)                                  # (the reference-order engine's answer, before the switch)
+    part = StagePartition(k, rank=0, world=1)
+    assert part.sizes[2] >= 0
+    assert k.update_scalings_and_factor(0.7, x_reg, z_reg)
+    got = k.solve(*r)
+    env_ks = {1: hip.SPARSE_LDLT_MULTIFRONTAL, 4: 4}[ks]
+    import os
+    os.environ["PIQP_AMD_SPARSE_LDLT"] = "multifrontal"
+    try:
+        k2 = hip.SparseKKT(d, kkt_solver=env_ks)
+    finally:
+        del os.environ["PIQP_AMD_SPARSE_LDLT"]
+    assert k2.update_scalings_and_factor(0.7, x_reg, z_reg)
+    want = k2.solve(*r)
+    for a, b, c in zip(got, want, ref_order):
+        assert np.array_equal(a, b)
+        assert np.allclose(a, c, rtol=1e-8, atol=1e-10)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("native", [True, False])
 def test_rccl_transport_with_a_one_rank_group(native):
     """all a 1-GPU box can say about the RCCL transport: a one-rank "nccl" process group with the exchanges forced on
