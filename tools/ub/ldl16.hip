@@ -198,6 +198,101 @@ __device__ __forceinline__ void follow16(d4& acc, d4& dn, int lane, const lds_vd
     }
 }
 
+// the form the in-kernel attempt used (tools/ub/potrf_block_ldl_attempt.hip.txt): reciprocals kept in registers and written by lane 0 every fourth column, pivots
+// read off the accumulator's diagonal at the end, no per-pivot bookkeeping.  VARIANT bit 0: s_setprio 3 around it; bit 1: column masks precomputed (ballots before the loop)
+template <int VARIANT>
+__device__ __forceinline__ void factor16_k(d4& sn, double& ddiag, int lane, lds_vdouble* Upub, lds_vdouble* rpub, lds_vint* prog, int base)
+{
+    const int g = lane >> 4, il = pi16(lane & 15);
+    d4 s = sn;
+    d4 Un = {0.0, 0.0, 0.0, 0.0};
+    double col = s[0];
+    double rq[4];
+    if (VARIANT & 1) __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        const int gc = c >> 2, rc = c & 3;
+        const int c1 = (c + 1) & 15, rn = c1 & 3;
+        const double dneg = readlane_d(col, 16 * gc + pi16(c));
+        const double y0 = __builtin_amdgcn_rcp(-dneg);
+        const double e = __builtin_fma(dneg, y0, 1.0);
+        const double p = __builtin_fma(e, e, e);
+        const double rinv = __builtin_fma(y0, p, y0);
+        rq[rc] = rinv;
+        const double un = (g == gc && il > c) ? col * rinv : 0.0;
+        Un[rc] += un;
+        if (c < 15) {
+            const double u1n = readlane_d(col, 16 * gc + pi16(c1)) * rinv;
+            const double cold = col;
+            if (rn != 0) {
+                col = __builtin_fma(cold, u1n, s[rn]);
+                s = __builtin_amdgcn_mfma_f64_16x16x4f64(un, cold, s, 0, 0, 0);
+            } else {
+                s = __builtin_amdgcn_mfma_f64_16x16x4f64(un, cold, s, 0, 0, 0);
+                col = s[0];
+                asm volatile("" : "+v"(col));
+            }
+        }
+        if (rc == 3) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Upub[q * 64 + lane] = Un[q];
+            if (lane == 0) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) rpub[4 * gc + q] = rq[q];
+            }
+            asm volatile("" ::: "memory");
+            if (lane == 0) *prog = base + c + 1;
+            asm volatile("" ::: "memory");
+        }
+    }
+    if (VARIANT & 1) __builtin_amdgcn_s_setprio(0);
+    {
+        const int r = il & 3;
+        ddiag = r == 0 ? s[0] : (r == 1 ? s[1] : (r == 2 ? s[2] : s[3]));
+    }
+    sn = Un;
+}
+// the in-kernel conditions one by one: wave 0 factors; waves 1 .. are OTHERS bit 0: the hot follower (wave 1), bit 1: plain followers (waves 2, 3), bit 2: waves that
+// only poll the progress word with s_sleep (waves 4 ..), like the waves of a block that wait for a later step
+template <int VARIANT, int OTHERS>
+__global__ void k_panel_k(const double* __restrict__ A, int lda, double* out, long long* ts)
+{
+    __shared__ double Upub[256], rpub[128], Zt[256], Zr[4];
+    __shared__ int prog;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, il = pi16(lane & 15);
+    for (int e = tid; e < 256; e += blockDim.x) Zt[e] = 0.0;
+    if (tid < 4) Zr[tid] = 0.0;
+    if (tid == 0) prog = 0;
+    __syncthreads();
+    if (wave == 0) {
+        d4 t;
+        for (int r = 0; r < 4; ++r) t[r] = -A[il + (size_t)(4 * g + r) * lda];
+        double dd;
+        asm volatile("" : "+v"(t));
+        const long long t0 = tick();
+        factor16_k<VARIANT>(t, dd, lane, (lds_vdouble*)Upub, (lds_vdouble*)rpub, (lds_vint*)&prog, 0);
+        asm volatile("" : "+v"(t), "+v"(dd));
+        const long long t1 = tick();
+        if (lane == 0) { ts[0] = t0; ts[1] = t1; }
+        for (int r = 0; r < 4; ++r) out[r * 64 + lane] = t[r] + dd;
+    } else if ((wave == 1 && (OTHERS & 1)) || ((wave == 2 || wave == 3) && (OTHERS & 2))) {
+        d4 acc, dn;
+        for (int r = 0; r < 4; ++r) { acc[r] = A[16 + il + (size_t)(4 * g + r) * lda]; dn[r] = -A[16 + il + (size_t)(16 + 4 * g + r) * lda]; }
+        asm volatile("" : "+v"(acc), "+v"(dn));
+        if (wave == 1) follow16<true>(acc, dn, lane, (lds_vdouble*)Upub, (lds_vdouble*)rpub, (lds_vint*)&prog, 0, (lds_vdouble*)Zt, (lds_vdouble*)Zr);
+        else follow16<false>(acc, dn, lane, (lds_vdouble*)Upub, (lds_vdouble*)rpub, (lds_vint*)&prog, 0, (lds_vdouble*)Zt, (lds_vdouble*)Zr);
+        asm volatile("" : "+v"(acc), "+v"(dn));
+        const long long t2 = tick();
+        if (wave == 1 && lane == 0) ts[2] = t2;
+        out[1024 + wave * 64 + lane] = acc[0] + acc[1] + acc[2] + acc[3] + dn[0];
+    } else if (wave >= 4 && (OTHERS & 4)) {
+        lds_vint* pr = (lds_vint*)&prog;
+        while (*pr < 16) __builtin_amdgcn_s_sleep(8);
+        out[2048 + tid] = 1.0;
+    }
+}
+
 // one workgroup: wave 0 factors A00, wave 1 follows with A10 and its diagonal tile A11 (HOT), waves 2.. follow with copies of A10 (not hot: the load of the other SIMDs)
 template <int TRICK>
 __global__ void k_panel(const double* __restrict__ A, int lda, double* out, long long* ts, int nrep)
@@ -303,6 +398,25 @@ int main()
     (void)hipMalloc(&dA, n * n * 8);
     (void)hipMemcpy(dA, A.data(), n * n * 8, hipMemcpyHostToDevice);
     std::vector<double> o(8192);
+    {
+        auto run = [&](const char* name, auto kern, int nw) {
+            long long best = 1LL << 60, tail = 0;
+            for (int it = 0; it < 5; ++it) {
+                hipLaunchKernelGGL(kern, dim3(1), dim3(64 * nw), 0, 0, dA, n, out, t);
+                (void)hipDeviceSynchronize();
+                (void)hipMemcpy(h, t, 24, hipMemcpyDeviceToHost);
+                if (h[1] - h[0] < best) { best = h[1] - h[0]; tail = h[2] - h[1]; }
+            }
+            printf("%-96s factor16 %5lld ticks (%5.1f per pivot), hot follower's tail %5lld\n", name, best, best / 16.0, tail);
+        };
+        run("in-kernel form, alone (1 wave)", k_panel_k<0, 0>, 1);
+        run("in-kernel form + s_setprio 3, alone", k_panel_k<1, 0>, 1);
+        run("in-kernel form, + hot follower on the next SIMD", k_panel_k<0, 1>, 2);
+        run("in-kernel form, + hot follower + two followers (4 waves, one per SIMD)", k_panel_k<0, 3>, 4);
+        run("in-kernel form, + hot + two followers + four pollers (8 waves; wave 4 shares the factoring SIMD)", k_panel_k<0, 7>, 8);
+        run("in-kernel form + s_setprio 3, the same 8 waves", k_panel_k<1, 7>, 8);
+        run("in-kernel form, 8 waves, only pollers beside it", k_panel_k<0, 4>, 8);
+    }
     for (int trick = 0; trick < 2; ++trick)
         for (int nw : {2, 4, 8}) {
             long long best[3] = {1LL << 60, 1LL << 60, 1LL << 60};
