@@ -383,6 +383,8 @@ def emit(out, limit=6144):
     line["config"] = {k: short(v, 240) for k, v in out.get("config", {}).items()}
     line["roofline"] = roof_short(out.get("roofline"))
     line["roofline_secondary"] = roof_short(out.get("roofline_secondary"))
+    if "longest_stage" in out:
+        line["longest_stage"] = out["longest_stage"]
     if "cpu_baseline" in out:
         cb = out["cpu_baseline"]
         line["cpu_baseline"] = {k: short(cb[k], 240) for k in ("value", "unit", "cores", "kind", "sample", "seconds", "factor_gflops") if k in cb}
@@ -787,7 +789,9 @@ def dense_strongly_convex_qp_small():
     return dense_strongly_convex_qp(1024, 0, 1024, seed=7, double_sided=True, exact_shift=False)
 
 
-SWEEP_SIZES = (64, 128, 256, 384, 512, 768, 1024, 1536, 2048, 3072, 4096)
+# (4 .. 1024 x 2 are the reference's own factorisation-benchmark sizes, dense_cholesky_factorization_benchmark.cpp:97-102; `device_factorisation_ms` of a row is the
+# factorisation alone, hipEvent-bracketed on the backend's stream)
+SWEEP_SIZES = (4, 8, 16, 32, 64, 128, 256, 384, 512, 768, 1024, 1536, 2048, 3072, 4096)
 
 
 def dense_size_sweep(piqp_amd, pd, torch, np, args, rank, world, local_rank, dev, cpu_rows):

@@ -4041,6 +4041,20 @@ void launch_symmetrize_upper(const double* Pu, int n, double* Pf, double* pdiag,
 }
 
 // z_reg_inv = 1 / z_reg   (dense/kkt.hpp:78)
+// dense_ldlt_no_pivot on the condensed KKT matrix (this library's extension: dense/kkt.hpp itself only calls Eigen::LLT).  The matrix is positive definite by construction,
+// so a pivot that is not positive is a numerical breakdown of the factorisation -- LDLTNoPivot's own test (== 0, ldlt_no_pivot.hpp:307) is met by the reference's unblocked loop
+// on degenerate problems and practically never by a blocked summation order, which then carries a NEGATIVE pivot on and hands the interior-point loop a wrong
+// step (round 6: QBEACONF, QGROW15, QGROW22 ended MAX_ITER that way).  The first such column is reported like a failed LLT pivot: the solver regularises and factors again.
+__global__ __launch_bounds__(256) void k_flag_nonpositive(int n, const double* __restrict__ rdiag, int* __restrict__ info)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && !(rdiag[i] > 0.0)) atomicMin(reinterpret_cast<unsigned*>(info), (unsigned)i);  // (info = -1 = UINT_MAX while nothing has failed)
+}
+void launch_flag_nonpositive(int n, const double* rdiag, int* info, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_flag_nonpositive, dim3(div_up(n, 256)), dim3(256), 0, s, n, rdiag, info);
+}
+
 __global__ void k_reciprocal(int n, const double* __restrict__ a, double* __restrict__ out)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -115,6 +115,8 @@ void launch_reduce_partials(int rows, int nslices, const double* part, const dou
 void launch_gemv_t(int rows, int cols, const double* M, int ld, const double* v, double alpha, double beta, const double* c, const double* sc, double* out, hipStream_t s);
 void launch_symmetrize_upper(const double* Pu, int n, double* Pf, double* pdiag, hipStream_t s);
 void launch_reciprocal(int n, const double* a, double* out, hipStream_t s);
+// dense_ldlt_no_pivot: *info <- the first column whose reciprocal pivot is not positive (unchanged if there is none or an earlier column has failed already)
+void launch_flag_nonpositive(int n, const double* rdiag, int* info, hipStream_t s);
 double microbench_mfma_f64(int iters, hipStream_t s);
 double microbench_hbm_copy(size_t bytes, int iters, hipStream_t s);
 

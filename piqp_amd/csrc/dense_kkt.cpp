@@ -360,6 +360,7 @@ private:
     // llt.info() == Success (dense/kkt.hpp:83): one 4-byte read-back per factor call
     bool factor_status()
     {
+        if (ldlt_) dense::launch_flag_nonpositive(n_, rdiag_.p, info_.p, st_);  // (a negative pivot of this positive definite matrix is a breakdown: see k_flag_nonpositive)
         PQ_HIP(hipMemcpyAsync(info_h_.p, info_.p, sizeof(int), hipMemcpyDeviceToHost, st_));
         if (chol_persistent_) PQ_HIP(hipMemcpyAsync(info_h_.p + 1, chol_flags_.p + 1, sizeof(int), hipMemcpyDeviceToHost, st_));  // the launch's abort word
         stream_wait(st_);

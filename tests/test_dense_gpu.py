@@ -121,7 +121,11 @@ def test_update_data_equals_fresh_bitwise(hip, orc):
 
 
 def test_factor_failure_semantics(hip, orc):
-    """LLT fails iff a pivot <= 0 (dense/kkt.hpp:83); LDLTNoPivot only on an exact zero pivot (ldlt_no_pivot.hpp:307)"""
+    """LLT fails iff a pivot <= 0 (dense/kkt.hpp:83); LDLTNoPivot, the class, only on an exact zero pivot (ldlt_no_pivot.hpp:307: tests/test_potrf_block_gpu.py holds the
+    kernel to that, indefinite blocks included).  The dense BACKEND with kkt_solver = dense_ldlt_no_pivot -- this library's extension: dense/kkt.hpp itself only ever calls
+    Eigen::LLT -- reports a pivot that is not positive like the LLT backend does (round 6): its matrix is positive definite by construction, a negative pivot is a
+    breakdown, and carrying it on cost three Maros-Meszaros problems their convergence (profiles/r06_dense_mm_parity.txt).  The oracle's restated class keeps the
+    reference's test."""
     n = 40
     P = -np.eye(n)  # negative definite, no constraints
     d = hip.Data(P, np.zeros(n))
@@ -129,7 +133,7 @@ def test_factor_failure_semantics(hip, orc):
     x_reg = np.full(n, 0.5); z_reg = np.zeros(0)
     assert hip.DenseKKT(d).update_scalings_and_factor(1.0, x_reg, z_reg) is False
     assert orc.KKT(od).update_scalings_and_factor(1.0, x_reg, z_reg) is False
-    assert hip.DenseKKT(d, kkt_solver=16).update_scalings_and_factor(1.0, x_reg, z_reg) is True
+    assert hip.DenseKKT(d, kkt_solver=16).update_scalings_and_factor(1.0, x_reg, z_reg) is False
     assert orc.KKT(od, use_ldlt=True).update_scalings_and_factor(1.0, x_reg, z_reg) is True
     x_reg0 = np.full(n, 1.0)  # P + I = 0 -> exact zero pivot
     assert hip.DenseKKT(d, kkt_solver=16).update_scalings_and_factor(1.0, x_reg0, z_reg) is False
@@ -308,7 +312,7 @@ def test_assembly_split_k_tail_matches_numpy(hip):
 
 
 
-KNOWN_DEVICE_ONLY_FAILURES = {0: [], 16: []}  # replay of qp_robot_arm_sqp: kkt_solver -> states the oracle factorises and the device reports as failed (round 5: none -- the scalings x_reg / z_reg are formed without FMA contraction now, bitwise the oracle's, and state 12 of the LL^T replay no longer differs in the sign of its last pivot; rounds 3-4 had [12])
+KNOWN_DEVICE_ONLY_FAILURES = {0: [], 16: [12, 13, 16, 18, 19, 20]}  # replay of qp_robot_arm_sqp: kkt_solver -> states the oracle factorises and the device reports as failed (round 5: none -- the scalings x_reg / z_reg are formed without FMA contraction now, bitwise the oracle's, and state 12 of the LL^T replay no longer differs in the sign of its last pivot; rounds 3-4 had [12])
 
 
 @pytest.mark.parametrize("kkt_solver", [0, 16])
@@ -330,7 +334,9 @@ def test_accuracy_on_recorded_ipm_states_of_the_hardest_fixture(hip, orc, kkt_so
     # assembly's rounding error and its sign -- the failure criterion of Eigen::LLT, dense/kkt.hpp:83 -- is decided by the summation order of G' W G
     # (measured in round 3: state 12 of 20 for LL^T, none for LDL^T)
     floor = {it for it, rho, delta, okh, oko, rh, ro in rows if rho <= 1e-9 and delta <= 1e-9}
-    assert len(dev_only_fail) <= 1 and set(dev_only_fail) <= floor, dev_only_fail
+    # (kkt_solver = 16, round 6: the device's dense L D L^T backend reports a pivot that is not positive -- like LLT -- where the oracle's restated class only tests for an
+    # exact zero and factors on with a negative pivot: six states of this replay, all at the floor)
+    assert (kkt_solver == 16 or len(dev_only_fail) <= 1) and set(dev_only_fail) <= floor, dev_only_fail
     # pinned (round-3 advice): exactly the known state for LL^T, none for LDL^T -- a second one, or another one, is a change of the assembly's arithmetic
     assert dev_only_fail == KNOWN_DEVICE_ONLY_FAILURES[kkt_solver], (kkt_solver, dev_only_fail)
     assert len(both) >= 10

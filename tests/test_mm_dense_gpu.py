@@ -57,3 +57,16 @@ def test_dense_solver_meets_the_reference_sweep_and_the_oracle(hip, orc, name):
         assert (sh.info.iter, so.info.iter) == ROUNDING_DECIDED[name], (name, sh.info.iter, so.info.iter)
     else:
         assert sh.info.iter == so.info.iter, (name, sh.info.iter, so.info.iter)
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_dense_ldlt_backend_on_the_same_sweep(hip, orc, name):
+    """kkt_solver = dense_ldlt_no_pivot (this library's extension of the dense backend; dense/kkt.hpp only calls Eigen::LLT) on the same 72 problems: SOLVED, at the optimum the
+    reference's backend finds.  Round 6: the backend reports a pivot that is not positive like LLT does; before, QBEACONF, QGROW15 and QGROW22 ended MAX_ITER on
+    factorisations that had carried a negative pivot on (profiles/r06_dense_mm_parity.txt)."""
+    args = dense_args(load_qp(name))
+    sh, so = hip.DenseSolver(), orc.Solver()
+    sh.settings.kkt_solver = 16
+    assert sh.setup(*args) and so.setup(*args)
+    assert sh.solve() == 1 and so.solve() == orc.SOLVED
+    assert abs(sh.info.primal_obj - so.info.primal_obj) <= 1e-6 * max(1.0, abs(so.info.primal_obj)) + 10 * so.settings.eps_abs, (name, sh.info.primal_obj, so.info.primal_obj)
