@@ -1778,6 +1778,14 @@ __host__ __device__ inline int chol_asm_slices(int j, int mchunks)
     const int s = j <= 2 ? 8 : (j <= 8 ? 4 : (j <= 16 ? 2 : 1));
     return s < mchunks ? s : (mchunks > 0 ? mchunks : 1);
 }
+// (the threshold of chol_bulk_bound: rounds with at least that many trailing tile rows keep whole panel tiles.  22 was the best of a sweep in round 3; PIQP_AMD_DEBUG=chol_whole=<rows>
+// overrides it -- one value per process: the cumulative counters of a handle assume the same split in every factorisation)
+constexpr int CHOL_WHOLE_ROWS = 22;
+static int chol_split_thr()
+{
+    static const int v = [] { const char* e = debug_token("chol_whole"); return e ? std::atoi(e) : CHOL_WHOLE_ROWS; }();
+    return v;
+}
 // bands of block columns with one slice count, assembled slice-major (see chol_build_tasks_fused): [lo, hi)
 __host__ __device__ inline int chol_asm_band_end(int lo) { return lo <= 2 ? 3 : (lo <= 8 ? 9 : lo + 8); }
 // workgroups per panel tile: a row's task of round k needs that row's output of round k - 1, so one workgroup's update + substitution (28 + 13 us for a
@@ -1786,17 +1794,17 @@ __host__ __device__ inline int chol_asm_band_end(int lo) { return lo <= 2 ? 3 : 
 // A round with >= 22 trailing tile rows (> 230 bulk tiles) is bound by the bulk tiles, not by the chain: there whole tiles park half as many workgroups on
 // the chain and leave them to the bulk.
 // (threshold swept at T = 32, factorisation ms: never 1.28-1.32, 30: 1.28, 26: 1.26, 22: 1.245, 18: 1.27, 14: 1.29, 10: 1.32)
-__host__ __device__ inline bool chol_bulk_bound(int T, int k) { return T - k - 1 >= 22; }
-__host__ __device__ inline int chol_split(int T, int k) { return chol_bulk_bound(T, k) ? 1 : 2; }
+__host__ __device__ inline bool chol_bulk_bound(int T, int k, int thr) { return T - k - 1 >= thr; }
+__host__ __device__ inline int chol_split(int T, int k, int thr) { return chol_bulk_bound(T, k, thr) ? 1 : 2; }
 // ... except the first CHOL_FAST_ROWS block rows below the diagonal block, which are always halves: the first row's slices feed the next crew and the second
 // row's completion starts the next round's first row, and a whole tile's update (31 us) arrives at the diagonal block when that is finished (the rounds with
 // whole first rows ran at 48 us, the others at 36)
 constexpr int CHOL_FAST_ROWS = 2;
-__host__ __device__ inline int chol_split_row(int T, int k, int ti) { return ti <= CHOL_FAST_ROWS ? 2 : chol_split(T, k); }
-__host__ __device__ inline int chol_panel_tasks(int T, int k)  // panel tasks of round k (rows ti = 1 .. T - k - 2)
+__host__ __device__ inline int chol_split_row(int T, int k, int ti, int thr) { return ti <= CHOL_FAST_ROWS ? 2 : chol_split(T, k, thr); }
+__host__ __device__ inline int chol_panel_tasks(int T, int k, int thr)  // panel tasks of round k (rows ti = 1 .. T - k - 2)
 {
     const int rows = T - k - 2, fast = rows < CHOL_FAST_ROWS ? rows : CHOL_FAST_ROWS;
-    return rows <= 0 ? 0 : 2 * fast + chol_split(T, k) * (rows - fast);
+    return rows <= 0 ? 0 : 2 * fast + chol_split(T, k, thr) * (rows - fast);
 }
 struct CholArgs {
     double* A; double* side; int lda, n, T, ldlt;
@@ -1810,6 +1818,7 @@ struct CholArgs {
     int* dhalf;           // per round: halves of the split diagonal tile of the first bulk column that have finished (cumulative over the factorisations)
     int gen;       // launch-unique base of the flag values
     int fcount;    // persistent factorisations this handle has run before this one (pdone counters are cumulative)
+    int split_thr; // chol_split_thr(): rounds with at least this many trailing tile rows keep whole panel tiles
     // fused assembly (dense/kkt.hpp:140-160 as tasks of this launch, GT != nullptr): K = Pfull + diag(x_reg) + dinv ATA + GT diag(zinv) GT^T for the tiles of the
     // block columns >= 1 (column 0 is assembled, factored and solved before the launch); m % 128 == 0
     const double* GT; int ldg, m; const double* zinv;
@@ -2181,7 +2190,7 @@ __global__ __launch_bounds__(CHOL_THREADS, 2) void k_chol_persistent(CholArgs c)
             g.C = c.A + (size_t)i * NB + (size_t)j * NB * c.lda; g.ldc = c.lda; g.diag = i == j ? 1 : 0;
             g.part = nullptr; g.Pt = nullptr; g.ldp = 0; g.xr = nullptr; g.At = nullptr; g.ldat = 0; g.dinv = 0.0;
             const int klo = tk.round, khi = tk.gate + 1, kp = khi - 1;
-            auto ready = [&](int row) { return (c.fcount + 1) * (kp > 0 ? chol_split_row(T, kp - 1, row - kp) : 1); };
+            auto ready = [&](int row) { return (c.fcount + 1) * (kp > 0 ? chol_split_row(T, kp - 1, row - kp, c.split_thr) : 1); };
             help_assembled(i, j);
             // (without the fused assembly a tile that has received no update carries no mark of this launch: its first visit does not wait for one)
             bool ok = chol_wait3((klo > 0 || asm_in) ? c.tver + (size_t)i * T + j : nullptr, c.gen + klo, kp > 0 ? c.lready + (size_t)kp * T + i : nullptr, ready(i), kp > 0 ? c.lready + (size_t)kp * T + j : nullptr, ready(j), abort_w, 1);
@@ -2226,7 +2235,7 @@ __global__ __launch_bounds__(CHOL_THREADS, 2) void k_chol_persistent(CholArgs c)
         // absolute block coordinates of what this task touches: relative tile (ti, tj) of round k = absolute (k + 1 + ti, k + 1 + tj)
         const int* lr = c.lready + (size_t)k * T;   // panel k
         // (cumulative counters: block row i of panel k was solved by the split_row(k - 1, i - k) tasks of round k - 1; the first row of panel k, i = k + 1, by two)
-        auto ready_of = [&](int i) { return (c.fcount + 1) * (k > 0 ? chol_split_row(T, k - 1, i - k) : 1); };
+        auto ready_of = [&](int i) { return (c.fcount + 1) * (k > 0 ? chol_split_row(T, k - 1, i - k, c.split_thr) : 1); };
         bool ok = true;
         if (tk.kind <= 1) {
             // crew of the next diagonal block: its tile (k + 1, k + 1) must have received U_0 .. U_{k-1}; operand = block row k + 1 of panel k.  The
@@ -2235,7 +2244,7 @@ __global__ __launch_bounds__(CHOL_THREADS, 2) void k_chol_persistent(CholArgs c)
             // (its operand, block row d of panel k, arrives slice by slice inside fused_next_diag)
             help_assembled(d, d);
             ok = chol_wait3((k > 0 || asm_in) ? c.tver + (size_t)d * T + d : nullptr, c.gen + k, nullptr, 0,
-                            (tk.kind == 1 && k >= 2) ? c.pdone + (k - 2) : nullptr, (c.fcount + 1) * chol_panel_tasks(T, k - 2), abort_w, 0);
+                            (tk.kind == 1 && k >= 2) ? c.pdone + (k - 2) : nullptr, (c.fcount + 1) * chol_panel_tasks(T, k - 2, c.split_thr), abort_w, 0);
             if (c.trace && tid == 0) c.trace[4 * (size_t)t + 1] = wall_clock64();
             if (ok) ok = chol_role_crew(a, tk.kind == 1 ? 0 : tk.a);
         } else {
@@ -2260,7 +2269,7 @@ __global__ __launch_bounds__(CHOL_THREADS, 2) void k_chol_persistent(CholArgs c)
                     addi_agent(c.lready + (size_t)(k + 1) * T + i, 1);
                     const int before = addi_agent(c.pdone + k, 1);
                     // the last panel task of the round: rounds complete in order (row i of panel k + 1 needs row i of panel k)
-                    if (before + 1 - (c.fcount + 1) * chol_panel_tasks(T, k) == 0) sti_agent(c.progress, c.gen + k + 1);
+                    if (before + 1 - (c.fcount + 1) * chol_panel_tasks(T, k, c.split_thr) == 0) sti_agent(c.progress, c.gen + k + 1);
                 } else if (dh < 0 || addi_agent(c.dhalf + k, 1) + 1 == 2 * (c.fcount + 1)) {  // (a split tile: the second half to finish announces it)
                     __hip_atomic_store(c.tver + (size_t)i * T + j, c.gen + k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
@@ -2288,14 +2297,19 @@ __global__ __launch_bounds__(CHOL_THREADS, 2) void k_chol_persistent(CholArgs c)
 // the chain reaches round 9 at 600 us instead of 512.  The single list meters the chain tasks out between the tiles; that is worth more than the bypass.)
 constexpr double CHOL_DEFER = 0.05;
 constexpr bool CHOL_SPLIT_DIAG = true;
-static int chol_far_g()  // PIQP_AMD_DEBUG=chol_far=<g>: panels per visit of the far tiles (1: one panel per visit as in round 3)
+static int chol_far_g()  // PIQP_AMD_DEBUG=chol_far=<g>: panels per visit of the far tiles (1: one panel per visit as in round 3; 4: rounds 4-5)
 {
-    static const int g = [] { const char* e = debug_token("chol_far"); const int v = e ? std::atoi(e) : 4; return v < 1 ? 1 : (v > 16 ? 16 : v); }();
+    // round 6, persistent launch at n = 4096 (tools/time_chol.py): g = 1 1.238 ms, 2 1.158, 3 1.17, 4 1.203, 6 1.32, 8 1.37 with the visits in phase; out of phase by
+    // the tile's column (below) 2: 1.131, 3: 1.147, 4: 1.181
+    static const int g = [] { const char* e = debug_token("chol_far"); const int v = e ? std::atoi(e) : 2; return v < 1 ? 1 : (v > 16 ? 16 : v); }();
     return g;
 }
 static void chol_build_tasks(int T, std::vector<CholTask>& H)
 {
-    const int far_g = chol_far_g(), far_slack = 3;
+    static const int far_slack = [] { const char* e = debug_token("chol_slack"); return e ? std::atoi(e) : 3; }();
+    static const double defer = [] { const char* e = debug_token("chol_defer"); return e ? std::atof(e) : CHOL_DEFER; }();
+    const int far_g = chol_far_g();
+    static const int far_phase = [] { const char* e = debug_token("chol_phase"); return e ? std::atoi(e) : 1; }();  // 0: every tile's visits end with the same panels (g - 1, 2 g - 1, ...: rounds 4-5); 1: shifted by the tile's column (default); 2: by row + column
     // One queue, sorted by a key in units of chain rounds.  The crew and panel tasks of round k have key k - 1 (drawn a round early: the crew follows the
     // slices of its operand, a panel task waits for its own rows); the first tile column of round k, which feeds them, k - 0.5; tile column tj >= 2 of
     // round k,  k + CHOL_DEFER (tj - 1):  with CHOL_DEFER = 0 that is the plain order  crew(k+1) panel(k+1) bulk(k) ...;  a small slope pushes the far
@@ -2313,20 +2327,25 @@ static void chol_build_tasks(int T, std::vector<CholTask>& H)
         // (Tried: drawing the panel tasks of the rows >= 3 of the bulk-bound rounds only when their inputs exist -- gate k, key k - 0.3 ... k - 0.7 -- so that they do
         // not park a workgroup for a round: 1.24-1.27 ms against 1.26, inside the run-to-run spread.  Not kept.)
         for (int ti = 1; ti < Tk; ++ti) {
-            const int spr = chol_split_row(T, k, ti);
+            const int spr = chol_split_row(T, k, ti, chol_split_thr());
             if (spr == 1) all.push_back({kc, 2, {2, (short)k, (short)ti, -1, gate}});
             else for (int h = 0; h < spr; ++h) all.push_back({kc, 2, {2, (short)k, (short)ti, (short)h, gate}});
         }
         for (int tj = 1; tj < Tk; ++tj) {
             // (the second tile column as well: its diagonal tile is the diagonal block two rounds on, its other tiles the panel after next -- behind the deferred far
             // columns of earlier rounds their updates arrived late, and the crew of round k + 2 waited for them)
-            const double key = tj == 1 ? (double)k - 0.5 : (tj == 2 ? (double)k - 0.25 : (double)k + CHOL_DEFER * (tj - 1));
+            const double key = tj == 1 ? (double)k - 0.5 : (tj == 2 ? (double)k - 0.25 : (double)k + defer * (tj - 1));
             // round 4: the updates of a FAR tile column (absolute column j, updates k <= j - 4 - far_slack) are taken far_g panels per visit (kind 7: one C
             // fetch, one store, one ticket for far_g x 128 operand columns; same products in the same order -- bitwise the same tile)
-            const int j = k + 1 + tj, nfar = j - 3, nb = (far_g > 1 && nfar - far_slack > 0) ? (nfar - far_slack) / far_g : 0;
-            const bool in_block = k < nb * far_g;
-            if (in_block && (k % far_g) != far_g - 1) continue;  // (the visit is listed with its last panel)
+            const int j = k + 1 + tj, nfar = j - 3;
             for (int ti = tj; ti < Tk; ++ti) {
+                // (round 6: the visits of different tiles are out of phase -- with every far tile visited in the rounds 3, 7, 11, ... those rounds carried a burst of
+                // ~150 four-panel tasks and the chain's own tasks queued behind it: rounds of 55-65 us among rounds of 37-42, profiles/r04_chol_timeline.txt)
+                const int i = k + 1 + ti;
+                const int o = far_g > 1 ? (far_phase == 1 ? j % far_g : (far_phase == 2 ? (i + j) % far_g : 0)) : 0;  // the first o panels of the tile one by one
+                const int nb = (far_g > 1 && nfar - far_slack - o > 0) ? (nfar - far_slack - o) / far_g : 0;
+                const bool in_block = k >= o && k < o + nb * far_g;
+                if (in_block && ((k - o) % far_g) != far_g - 1) continue;  // (the visit is listed with its last panel)
                 // tile (1, 1) is the next round's diagonal block: its update stands between this round's second panel row and the next crew -- two workgroups
                 if (in_block) all.push_back({key, 3, {7, (short)(k - far_g + 1), (short)(k + 1 + ti), (short)j, k}});
                 else if (ti == 1 && tj == 1 && CHOL_SPLIT_DIAG) { all.push_back({key, 3, {4, (short)k, 1, 1, k}}); all.push_back({key, 3, {5, (short)k, 1, 1, k}}); }
@@ -2439,7 +2458,7 @@ static void chol_build_tasks_fused(int T, int mchunks, std::vector<CholTask>& H,
             std::vector<int> deps = lastw[(size_t)i * T + d];
             if (k > 0) deps = cat(cat(deps, solved[(size_t)k * T + i]), solved[(size_t)k * T + d]);
             deps.push_back(owner[(size_t)k]);
-            const int spr = chol_split_row(T, k, ti);
+            const int spr = chol_split_row(T, k, ti, chol_split_thr());
             std::vector<int> ids;
             for (int h = 0; h < spr; ++h) ids.push_back(add(t0 - R, 30.0, 2, {2, (short)k, (short)ti, (short)(spr == 1 ? -1 : h), gate, 0}, deps));
             solved[(size_t)(k + 1) * T + i] = ids;
@@ -2491,7 +2510,7 @@ static void chol_build_tasks_fused(int T, int mchunks, std::vector<CholTask>& H,
 size_t chol_task_count(int T)
 {
     size_t n = 0;
-    for (int k = 0; k + 1 < T; ++k) { const int Tk = T - k - 1; n += FUSE_ROLES + (size_t)chol_panel_tasks(T, k) + (size_t)Tk * (Tk - 1) / 2 + ((CHOL_SPLIT_DIAG && Tk >= 2) ? 1 : 0); }
+    for (int k = 0; k + 1 < T; ++k) { const int Tk = T - k - 1; n += FUSE_ROLES + (size_t)chol_panel_tasks(T, k, chol_split_thr()) + (size_t)Tk * (Tk - 1) / 2 + ((CHOL_SPLIT_DIAG && Tk >= 2) ? 1 : 0); }
     return n;
 }
 
@@ -2587,7 +2606,7 @@ bool launch_chol_persistent(bool ldlt, double* A, double* side, int lda, int n, 
     c.scratch = scratch; c.fuse_flags = fuse_flags; c.fuse_cnt = fuse_cnt; c.token_base = token_base;
     c.tasks = P->tasks; c.ntasks = P->ntasks;
     c.ticket = flags; c.aq_head = flags + 4; c.lready = flags + 12; c.tver = c.lready + (size_t)T * T; c.pdone = c.tver + (size_t)T * T; c.xcnt = c.pdone + T; c.progress = c.xcnt + 8 * (size_t)T; c.dhalf = c.progress + 1;
-    c.gen = gen; c.fcount = fcount;
+    c.gen = gen; c.fcount = fcount; c.split_thr = chol_split_thr();
     c.acnt = c.dhalf + T;
     c.GT = nullptr; c.ldg = 0; c.m = 0; c.zinv = nullptr; c.Pfull = nullptr; c.ldp = 0; c.x_reg = nullptr; c.ATA = nullptr; c.ldata = 0; c.dinv = 0.0; c.part = nullptr;
     c.aq = P->aq; for (int x = 0; x < 9; ++x) c.aq_ptr[x] = P->aq_ptr[x];
