@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""hipEvent time of the persistent factorisation launch at C2 (n = 4096) for the schedule variant in PIQP_AMD_DEBUG:  python tools/time_chol.py [steps]"""
+"""hipEvent time of the persistent factorisation launch (default: C2, n = 4096) for the schedule variant in PIQP_AMD_DEBUG:  python tools/time_chol.py [steps] [n]"""
 import os
 import sys
 
@@ -12,7 +12,7 @@ import piqp_amd
 from qp_gen import dense_strongly_convex_qp, random_vars
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
-n = 4096
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 q = dense_strongly_convex_qp(n, 0, n, seed=3, double_sided=True, exact_shift=False)
 k = piqp_amd.KKTSystem(piqp_amd.Data(**q), piqp_amd.default_settings(kkt_solver=0))
 rng = np.random.default_rng(0)
@@ -29,4 +29,4 @@ k.solve(rhs, lhs)
 k.synchronize()
 b.set_profiling(0)
 p = [b.get_profile(s) for s in range(6)]
-print(f"PIQP_AMD_DEBUG={os.environ.get('PIQP_AMD_DEBUG', '')!r}: persistent launch {p[3][0] / max(p[3][1], 1):.4f} ms ({p[3][1]} launches), factorisation stage {p[1][0] / max(p[1][1], 1):.4f} ms, x[0] = {float(lhs['x'][0].cpu()):.17g}")
+print(f"PIQP_AMD_DEBUG={os.environ.get('PIQP_AMD_DEBUG', '')!r}: n = {n}: persistent launch {p[3][0] / max(p[3][1], 1):.4f} ms ({p[3][1]} launches), factorisation stage {p[1][0] / max(p[1][1], 1):.4f} ms, x[0] = {float(lhs['x'][0].cpu()):.17g}")
