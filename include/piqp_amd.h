@@ -419,6 +419,27 @@ int pq_batch_last_kernel_ms(const pq_batch *s, double *ms, int *threads_per_qp);
  * depend on it. */
 int pq_batch_set_start_order(pq_batch *s, int longest_first);
 
+/* ===================== the dense factorisation classes as objects of their own ===================== */
+/* piqp::dense::LDLTNoPivot<Mat, UpLo> (dense/ldlt_no_pivot.hpp:87-262; kind = PQ_DENSE_LDLT_NO_PIVOT) and the Eigen::LLT<Mat, UpLo> that dense/kkt.hpp:82 uses
+ * (kind = PQ_DENSE_CHOLESKY), for either triangle: what tests/src/dense/ldlt_test.cpp and benchmarks/src/dense_cholesky_factorization_benchmark.cpp:16-109 exercise.
+ * The kernels are the dense KKT backend's; the Upper variants work on the transposed view as ldlt_no_pivot.hpp:357-371 does, so U = L^T bit for bit. */
+enum { PQ_LOWER = 1, PQ_UPPER = 2 }; /* Eigen::Lower, Eigen::Upper */
+typedef struct pq_dense_factor pq_dense_factor;
+int pq_dense_factor_create(pq_dense_factor **out, int device, int n, int kind, int uplo); /* ldlt_no_pivot.hpp:126-131 (preallocating constructor) */
+void pq_dense_factor_destroy(pq_dense_factor *f);
+/* compute(), ldlt_no_pivot.hpp:393-423: reads the `uplo` triangle of A (column-major, leading dimension lda >= n, in host or device memory per `mem`).
+ * Returns info(): 0 = Eigen::Success, 1 = Eigen::NumericalIssue (LDLTNoPivot: an exact zero pivot, :307; LLT: a pivot <= 0), negative = PQ_ERR_*. */
+int pq_dense_factor_compute(pq_dense_factor *f, const double *A, int lda, int mem);
+int pq_dense_factor_info(const pq_dense_factor *f); /* ldlt_no_pivot.hpp:231 */
+/* solveInPlace(), ldlt_no_pivot.hpp:432-450 / 464-470: x[n] <- A^-1 x */
+int pq_dense_factor_solve_in_place(pq_dense_factor *f, double *x, int mem);
+/* matrixLDLT(), ldlt_no_pivot.hpp:217 (LLT: matrixLLT()): writes the `uplo` triangle of out_host (column-major, leading dimension ldo): the strictly triangular
+ * part of unit L (PQ_UPPER: of U = L^T) with D on the diagonal; LLT: L resp. U.  The other triangle of out_host is not touched. */
+int pq_dense_factor_matrix(pq_dense_factor *f, double *out_host, int ldo);
+/* out2[0]: device time of the factorisation launches of the last compute() (hipEvents), out2[1]: wall time of the whole call (copy + symmetric completion +
+ * factorisation + status read-back), both in ms */
+int pq_dense_factor_last_ms(const pq_dense_factor *f, double out2[2]);
+
 /* ===================== small utilities used by the measurement harness ===================== */
 /* fp64 MFMA / HBM micro-benchmarks on `device` (used once by bench.py to report measured peaks) */
 /* number of device / pinned-host allocations the library has made in this process.  Contract (the reference's tests assert allocation-free

@@ -12,3 +12,4 @@ from .kkt import SPARSE_LDLT_EXACT, SPARSE_LDLT_MULTIFRONTAL  # noqa: E402,F401
 SPARSE_MULTISTAGE = 5
 MultistageKKT = DenseKKT
 from .batch import BatchSparseSolver  # noqa: E402,F401
+from .factor import LLT, LDLTNoPivot, LOWER, UPPER  # noqa: E402,F401

@@ -83,6 +83,7 @@ SYMBOLS = [
     "pq_solver_get_result", "pq_solver_dims", "pq_solver_set_trace", "pq_solver_trace_rows", "pq_solver_partition", "pq_solver_set_exchange",
     "pq_batch_create", "pq_batch_destroy", "pq_batch_settings", "pq_batch_setup_sparse", "pq_batch_update", "pq_batch_update_data", "pq_batch_solve", "pq_batch_info", "pq_batch_get_result",
     "pq_batch_dims", "pq_batch_block_info", "pq_batch_get_profile", "pq_batch_last_kernel_ms", "pq_batch_set_start_order",
+    "pq_dense_factor_create", "pq_dense_factor_destroy", "pq_dense_factor_compute", "pq_dense_factor_info", "pq_dense_factor_solve_in_place", "pq_dense_factor_matrix", "pq_dense_factor_last_ms",
     "pq_debug_alloc_count", "pq_debug_chol_plan", "pq_kkt_set_exchange_norm", "pq_kkt_sharded_calls", "pq_kkt_sharded_solve_calls", "pq_solver_sharded_solve_calls", "pq_solver_set_exchange_norm", "pq_solver_sharded_calls", "pq_microbench_mfma_f64", "pq_microbench_hbm_copy", "pq_microbench_potrf_block", "pq_debug_potrf_block", "pq_rccl_unique_id", "pq_kkt_set_comm_rccl", "pq_solver_set_comm_rccl", "pq_kkt_native_exchange_calls", "pq_kkt_min_abs_pivot", "pq_solver_native_exchange_calls",
     "pq_sparse_amd_order", "pq_sparse_permute_sym_upper", "pq_sparse_kkt_symbolic", "pq_kkt_sparse_ordering", "pq_kkt_comm_info", "pq_solver_comm_info", "pq_kkt_exact_factor", "pq_sparse_uplooking_plan",
 ]
@@ -152,6 +153,14 @@ def load():
     L.pq_batch_get_profile.argtypes = [vp, C.c_int, vp]
     L.pq_batch_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_double), _ip]
     L.pq_batch_set_start_order.argtypes = [vp, C.c_int]
+    L.pq_dense_factor_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int]
+    L.pq_dense_factor_destroy.argtypes = [vp]
+    L.pq_dense_factor_destroy.restype = None
+    L.pq_dense_factor_compute.argtypes = [vp, vp, C.c_int, C.c_int]
+    L.pq_dense_factor_info.argtypes = [vp]
+    L.pq_dense_factor_solve_in_place.argtypes = [vp, vp, C.c_int]
+    L.pq_dense_factor_matrix.argtypes = [vp, vp, C.c_int]
+    L.pq_dense_factor_last_ms.argtypes = [vp, vp]
     L.pq_kkt_set_profiling.argtypes = [vp, C.c_int]
     L.pq_kkt_get_profile.argtypes = [vp, C.c_int, _dp, _ip]
     L.pq_kktsys_create_dense.argtypes = [C.POINTER(vp), C.POINTER(DenseData), C.POINTER(Settings), C.c_int]

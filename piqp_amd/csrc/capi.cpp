@@ -1,6 +1,8 @@
 // piqp_amd/csrc/capi.cpp -- the extern "C" boundary declared in include/piqp_amd.h.
 // Thin: argument checks, host<->device staging for PQ_MEM_HOST callers, exception fencing.
 #include <algorithm>
+#include <chrono>
+#include <vector>
 #include <memory>
 #include <stdexcept>
 
@@ -310,6 +312,122 @@ int pq_kkt_internal_factor(pq_kkt* k, double* out_host)
     if (!k || !out_host) return fail(PQ_ERR_INVALID, "null argument");
     return guarded([&] { k->impl->internal_factor(out_host); return (int)PQ_OK; });
 }
+// ---------------------------------------------------------------------------------------------------------------------------------------------------
+// The reference's dense factorisation CLASSES as objects of their own: piqp::dense::LDLTNoPivot<Mat, UpLo> (dense/ldlt_no_pivot.hpp:87-262) and the Eigen::LLT
+// dense/kkt.hpp:82 uses, for either triangle -- what benchmarks/src/dense_cholesky_factorization_benchmark.cpp and tests/src/dense/ldlt_test.cpp exercise.  The
+// arithmetic is the dense backend's (a backend with p = m = 0, zero regularisation: its assembly is P + 0); the Upper variants work on the transposed view exactly as
+// ldlt_no_pivot.hpp:357-371 does (Transpose<MatrixType>), so U = L^T bit for bit.
+struct pq_dense_factor {
+    std::unique_ptr<KKTSolverBase> impl;
+    int device = 0, n = 0, kind = PQ_DENSE_LDLT_NO_PIVOT, uplo = PQ_LOWER, info = 1;
+    DBuf<double> stage, full, zero, xb;
+    std::vector<double> host;
+    double last_ms[2] = {0.0, 0.0};
+};
+
+int pq_dense_factor_create(pq_dense_factor** out, int device, int n, int kind, int uplo)
+{
+    if (!out) return fail(PQ_ERR_INVALID, "null argument");
+    if (n <= 0 || (kind != PQ_DENSE_LDLT_NO_PIVOT && kind != PQ_DENSE_CHOLESKY) || (uplo != PQ_LOWER && uplo != PQ_UPPER)) return fail(PQ_ERR_INVALID, "dense factor: bad n / kind / uplo");
+    return guarded([&] {
+        PQ_HIP(hipSetDevice(device));
+        std::unique_ptr<pq_dense_factor> f(new pq_dense_factor);
+        f->device = device; f->n = n; f->kind = kind; f->uplo = uplo;
+        const size_t nn = (size_t)n * n;
+        f->stage.alloc(nn); f->full.alloc(nn); f->zero.alloc(n); f->xb.alloc(n);
+        f->zero.zero(nullptr);
+        PQ_HIP(hipDeviceSynchronize());
+        *out = f.release();
+        return (int)PQ_OK;
+    });
+}
+void pq_dense_factor_destroy(pq_dense_factor* f) { delete f; }
+
+// LDLTNoPivot::compute (ldlt_no_pivot.hpp:393-423) / Eigen::LLT::compute: reads the `uplo` triangle of A (column-major, leading dimension lda >= n; mem says where A
+// lives).  Returns info(): 0 = Eigen::Success, 1 = Eigen::NumericalIssue (:231, :418-420).
+int pq_dense_factor_compute(pq_dense_factor* f, const double* A, int lda, int mem)
+{
+    if (!f || !A) return fail(PQ_ERR_INVALID, "null argument");
+    if (lda < f->n) return fail(PQ_ERR_INVALID, "dense factor: lda < n");
+    int info = 1;
+    const int rc = guarded([&] {
+        PQ_HIP(hipSetDevice(f->device));
+        const int n = f->n;
+        const auto w0 = std::chrono::steady_clock::now();
+        hipStream_t st = f->impl ? f->impl->stream() : nullptr;
+        PQ_HIP(hipMemcpy2DAsync(f->stage.p, sizeof(double) * n, A, sizeof(double) * lda, sizeof(double) * n, n, mem == PQ_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+        dense::launch_symmetrize(f->stage.p, n, f->uplo == PQ_LOWER, n, f->full.p, nullptr, st);
+        if (!st) PQ_HIP(hipStreamSynchronize(nullptr)); else stream_wait(st);
+        pq_dense_data d{};
+        d.n = n; d.p = 0; d.m = 0; d.P_utri = f->full.p; d.mem = PQ_MEM_DEVICE;
+        if (!f->impl) {
+            f->impl.reset(make_dense_kkt(&d, f->kind, f->device));
+            f->impl->set_class_failure_semantics(true);
+            f->impl->set_profiling(1);
+        } else {
+            f->impl->update_data_dense(&d, PQ_KKT_UPDATE_P);
+        }
+        double before = 0.0; int cnt = 0;
+        f->impl->get_profile(1, &before, &cnt);
+        const bool ok = f->impl->update_scalings_and_factor(1.0, f->zero.p, nullptr);
+        double after = 0.0;
+        f->impl->get_profile(1, &after, &cnt);
+        f->last_ms[0] = after - before;
+        f->last_ms[1] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
+        info = ok ? 0 : 1;
+        f->info = info;
+        return (int)PQ_OK;
+    });
+    return rc == PQ_OK ? info : rc;
+}
+int pq_dense_factor_info(const pq_dense_factor* f) { return f ? f->info : fail(PQ_ERR_INVALID, "null argument"); }
+
+// solveInPlace (ldlt_no_pivot.hpp:432-450: L, D, U sweeps / Eigen::LLT::solveInPlace), one right-hand side of n entries
+int pq_dense_factor_solve_in_place(pq_dense_factor* f, double* x, int mem)
+{
+    if (!f || !x) return fail(PQ_ERR_INVALID, "null argument");
+    if (!f->impl) return fail(PQ_ERR_INVALID, "dense factor: solve before compute");
+    return guarded([&] {
+        PQ_HIP(hipSetDevice(f->device));
+        hipStream_t st = f->impl->stream();
+        double* xd = x;
+        if (mem != PQ_MEM_DEVICE) { copy_in(f->xb.p, x, sizeof(double) * f->n, PQ_MEM_HOST, st); xd = f->xb.p; }
+        f->impl->solve(xd, nullptr, nullptr, xd, nullptr, nullptr);
+        if (mem != PQ_MEM_DEVICE) PQ_HIP(hipMemcpyAsync(x, xd, sizeof(double) * f->n, hipMemcpyDeviceToHost, st));
+        stream_wait(st);
+        return (int)PQ_OK;
+    });
+}
+
+// matrixLDLT() (ldlt_no_pivot.hpp:217) / Eigen::LLT::matrixLLT(): the `uplo` triangle of out (host, column-major, leading dimension ldo) receives the factor -- the
+// strictly lower part of unit L with D on the diagonal, resp. L; for PQ_UPPER the transposes (U, D) -- the other triangle is left alone.
+int pq_dense_factor_matrix(pq_dense_factor* f, double* out_host, int ldo)
+{
+    if (!f || !out_host) return fail(PQ_ERR_INVALID, "null argument");
+    if (!f->impl) return fail(PQ_ERR_INVALID, "dense factor: no factorisation yet");
+    if (ldo < f->n) return fail(PQ_ERR_INVALID, "dense factor: ldo < n");
+    return guarded([&] {
+        const int n = f->n;
+        f->host.resize((size_t)n * n);
+        f->impl->internal_factor(f->host.data());
+        for (int j = 0; j < n; ++j)
+            for (int i = j; i < n; ++i) {
+                const double v = f->host[i + (size_t)j * n];
+                if (f->uplo == PQ_LOWER) out_host[i + (size_t)j * ldo] = v;
+                else out_host[j + (size_t)i * ldo] = v;
+            }
+        return (int)PQ_OK;
+    });
+}
+
+// device time of the factorisation launches of the last compute() (hipEvents) and the wall time of the whole call, ms
+int pq_dense_factor_last_ms(const pq_dense_factor* f, double out2[2])
+{
+    if (!f || !out2) return fail(PQ_ERR_INVALID, "null argument");
+    out2[0] = f->last_ms[0]; out2[1] = f->last_ms[1];
+    return PQ_OK;
+}
+
 int pq_kkt_set_profiling(pq_kkt* k, int enable)
 {
     if (!k) return fail(PQ_ERR_INVALID, "null argument");

@@ -43,7 +43,10 @@ __device__ __forceinline__ double readlane_d(double v, int srclane)
 // ------------------------------------------------------------------------------------------------
 // P_full = symmetric completion of P_utri (used by the assembly epilogue, coalesced along rows, and
 // by eval_P_x as a plain column-dot GEMV).  dense/kkt.hpp:112-113 reads both triangles of P_utri.
-__global__ __launch_bounds__(256) void k_symmetrize_upper(const double* __restrict__ Pu, int n, double* __restrict__ Pf, double* __restrict__ pdiag)
+// FROM_LOWER: the source holds the LOWER triangle (LDLTNoPivot<.., Eigen::Lower>::compute of a caller's matrix, ldlt_no_pivot.hpp:408-411): the element (r, c) of the
+// upper triangle this kernel works from is then the source's (c, r) -- read along the source's columns all the same.
+template <bool FROM_LOWER>
+__global__ __launch_bounds__(256) void k_symmetrize_upper(const double* __restrict__ Pu, int ldu, int n, double* __restrict__ Pf, double* __restrict__ pdiag)
 {
     __shared__ double tile[32][33];
     const int r0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
@@ -51,8 +54,13 @@ __global__ __launch_bounds__(256) void k_symmetrize_upper(const double* __restri
     const int sr0 = lower_tile ? c0 : r0, sc0 = lower_tile ? r0 : c0;  // source tile in the upper triangle
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;            // 32 x 8
     for (int cc = ty; cc < 32; cc += 8) {
-        int r = sr0 + tx, c = sc0 + cc;
-        tile[cc][tx] = (r < n && c < n) ? Pu[r + (size_t)c * n] : 0.0;  // tile[col][row] of the source
+        if constexpr (FROM_LOWER) {
+            int c = sc0 + tx, r = sr0 + cc;
+            tile[tx][cc] = (r < n && c < n) ? Pu[c + (size_t)r * ldu] : 0.0;
+        } else {
+            int r = sr0 + tx, c = sc0 + cc;
+            tile[cc][tx] = (r < n && c < n) ? Pu[r + (size_t)c * ldu] : 0.0;  // tile[col][row] of the source
+        }
     }
     __syncthreads();
     for (int cc = ty; cc < 32; cc += 8) {
@@ -4052,10 +4060,13 @@ void launch_gemv_t(int rows, int cols, const double* M, int ld, const double* v,
     PQ_HIP(hipGetLastError());
 }
 
-void launch_symmetrize_upper(const double* Pu, int n, double* Pf, double* pdiag, hipStream_t s)
+void launch_symmetrize_upper(const double* Pu, int n, double* Pf, double* pdiag, hipStream_t s) { launch_symmetrize(Pu, n, false, n, Pf, pdiag, s); }
+void launch_symmetrize(const double* A, int lda, bool from_lower, int n, double* Pf, double* pdiag, hipStream_t s)
 {
     if (n <= 0) return;
-    hipLaunchKernelGGL(k_symmetrize_upper, dim3(div_up(n, 32), div_up(n, 32)), dim3(256), 0, s, Pu, n, Pf, pdiag);
+    dim3 grid((n + 31) / 32, (n + 31) / 32);
+    if (from_lower) hipLaunchKernelGGL(k_symmetrize_upper<true>, grid, dim3(256), 0, s, A, lda, n, Pf, pdiag);
+    else hipLaunchKernelGGL(k_symmetrize_upper<false>, grid, dim3(256), 0, s, A, lda, n, Pf, pdiag);
     PQ_HIP(hipGetLastError());
 }
 

@@ -114,6 +114,8 @@ int launch_gemv_n_partial(int rows, int cols, const double* M, int ld, const dou
 void launch_reduce_partials(int rows, int nslices, const double* part, const double* base, double* y, hipStream_t s);
 void launch_gemv_t(int rows, int cols, const double* M, int ld, const double* v, double alpha, double beta, const double* c, const double* sc, double* out, hipStream_t s);
 void launch_symmetrize_upper(const double* Pu, int n, double* Pf, double* pdiag, hipStream_t s);
+// ... of a matrix with leading dimension lda of which only ONE triangle is valid: the upper one, or (from_lower) the lower one
+void launch_symmetrize(const double* A, int lda, bool from_lower, int n, double* Pf, double* pdiag, hipStream_t s);
 void launch_reciprocal(int n, const double* a, double* out, hipStream_t s);
 // dense_ldlt_no_pivot: *info <- the first column whose reciprocal pivot is not positive (unchanged if there is none or an earlier column has failed already)
 void launch_flag_nonpositive(int n, const double* rdiag, int* info, hipStream_t s);

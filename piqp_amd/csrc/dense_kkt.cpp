@@ -174,6 +174,7 @@ public:
         PQ_HIP(hipSetDevice(dev_));
         prof_.collect(stage, st_, total_ms, count);
     }
+    void set_class_failure_semantics(bool on) override { class_semantics_ = on; }
     void internal_factor(double* out_host) override
     {
         PQ_HIP(hipSetDevice(dev_));
@@ -183,7 +184,7 @@ public:
 
 private:
     // copy-construction for clone(): same device, fresh stream, deep copies of all state
-    DenseKKT(const DenseKKT& o, int) : dev_(o.dev_), n_(o.n_), p_(o.p_), m_(o.m_), ldlt_(o.ldlt_), delta_(o.delta_)
+    DenseKKT(const DenseKKT& o, int) : dev_(o.dev_), n_(o.n_), p_(o.p_), m_(o.m_), ldlt_(o.ldlt_), class_semantics_(o.class_semantics_), delta_(o.delta_)
     {
         PQ_HIP(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
         alloc();
@@ -360,7 +361,7 @@ private:
     // llt.info() == Success (dense/kkt.hpp:83): one 4-byte read-back per factor call
     bool factor_status()
     {
-        if (ldlt_) dense::launch_flag_nonpositive(n_, rdiag_.p, info_.p, st_);  // (a negative pivot of this positive definite matrix is a breakdown: see k_flag_nonpositive)
+        if (ldlt_ && !class_semantics_) dense::launch_flag_nonpositive(n_, rdiag_.p, info_.p, st_);  // (a negative pivot of this positive definite matrix is a breakdown: see k_flag_nonpositive)
         PQ_HIP(hipMemcpyAsync(info_h_.p, info_.p, sizeof(int), hipMemcpyDeviceToHost, st_));
         if (chol_persistent_) PQ_HIP(hipMemcpyAsync(info_h_.p + 1, chol_flags_.p + 1, sizeof(int), hipMemcpyDeviceToHost, st_));  // the launch's abort word
         stream_wait(st_);
@@ -377,6 +378,7 @@ private:
 
     int dev_, n_, p_, m_;
     bool ldlt_;
+    bool class_semantics_ = false;  // see KKTSolverBase::set_class_failure_semantics
     double delta_ = 1.0;
     hipStream_t st_ = nullptr;
     DBuf<double> Pfull_, Pdiag_, AT_, GT_, ATA_, fac_, z_reg_inv_, x_reg_last_, dvec_, part_, rdiag_, split_ws_, pack_, w16_, fuse_scratch_;

@@ -40,6 +40,9 @@ public:
     virtual int device() const = 0;
     // test hooks (dense/kkt.hpp:134): copy n*n doubles to host
     virtual void internal_kkt_mat(double* out_host) { (void)out_host; throw std::runtime_error("internal_kkt_mat: dense only"); }
+    // dense backends: true = a factorisation fails exactly where the reference's CLASS fails (LDLTNoPivot: an exact zero pivot, ldlt_no_pivot.hpp:307), not where this
+    // library's dense_ldlt_no_pivot BACKEND also gives up (a pivot that is not positive); used by the raw factorisation object (pq_dense_factor)
+    virtual void set_class_failure_semantics(bool on) { (void)on; throw std::runtime_error("set_class_failure_semantics: dense only"); }
     virtual void internal_factor(double* out_host) { (void)out_host; throw std::runtime_error("internal_factor: dense only"); }
     // test hook: rows of (start, diag_size, off_diag_size) of the multistage backend (print_info, multistage_kkt.hpp:385-393)
     virtual void multistage_block_info(std::vector<int>& out) const { (void)out; throw std::runtime_error("block_info: sparse_multistage only"); }
