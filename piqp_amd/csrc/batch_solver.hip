@@ -62,6 +62,7 @@ struct BatchShared {
     int ent_flat;
     int n_ent;
     int fcap, lofs, hcap, chain_lds_doubles;
+    int chain_rows;  // the uniform run of the chain is FACTORED with one lane per row of a front (msdev::factor_chain_rows) instead of one lane per entry
     int chain_reg_w, chain_reg_k, chain_reg_nst;  // chain_reg_w > 0: stages 0 .. chain_reg_k - 1 of the chain_reg_nst stages form a uniform gap-free chain without arrow -- register-carried substitution (msdev::solve_chain_wave_reg)
     int meta_ofs;  // LDS offset (doubles) of the per-stage structure tables copied in at kernel start
     int res_f, res_pan, res_x, res_chain;  // MODE_RESIDENT: LDS offsets (doubles) of the fronts, the factor panels, the solve vector, chain scratch
@@ -93,12 +94,37 @@ __device__ __forceinline__ double dpp_move(double v)
     const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
     return __hiloint2double(hi, lo);
 }
+// A sum depends on its order: the xor butterfly the parity tests were pinned with, `for (o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o)`.  The same tree -- at every
+// level every lane adds the value of the same partner lane, and an addition commutes, so the sum is the butterfly's bit for bit -- without the six round trips
+// through the LDS crossbar: the two halves / the odd and even rows of 16 lanes through the gfx950 lane swaps, the rest inside a row through DPP.
+__device__ __forceinline__ double wave_sum_butterfly(double v)
+{
+    {   // lane ^ 32: v_permlane32_swap leaves one half of the wave's values in every lane of its first operand and the other half in its second
+        const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(v), __double2loint(v), false, false);
+        const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(v), __double2hiint(v), false, false);
+        v = __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+    }
+    {   // lane ^ 16: odd rows of the first operand against even rows of the second
+        const auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(v), __double2loint(v), false, false);
+        const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(v), __double2hiint(v), false, false);
+        v = __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+    }
+    v += dpp_move<0x128>(v);  // lane ^ 8: row_ror:8
+    {   // lane ^ 4: the lanes 0-3 and 8-11 of a row read four lanes up (row_shl:4, banks 0 and 2), the others four lanes down (row_shr:4, banks 1 and 3)
+        const int l = __double2loint(v), h = __double2hiint(v);
+        int pl = __builtin_amdgcn_update_dpp(l, l, 0x104, 0xf, 0x5, false), ph = __builtin_amdgcn_update_dpp(h, h, 0x104, 0xf, 0x5, false);
+        pl = __builtin_amdgcn_update_dpp(pl, l, 0x114, 0xf, 0xa, false); ph = __builtin_amdgcn_update_dpp(ph, h, 0x114, 0xf, 0xa, false);
+        v += __hiloint2double(ph, pl);
+    }
+    v += dpp_move<0x4e>(v);  // lane ^ 2: quad_perm [2, 3, 0, 1]
+    v += dpp_move<0xb1>(v);  // lane ^ 1: quad_perm [1, 0, 3, 2]
+    return v;
+}
 template <int NT, class Op>
 __device__ __forceinline__ double wg_reduce(double v, Op op, double* red)
 {
     if constexpr (std::is_same<Op, OpSum>::value) {
-        // a sum depends on its order: the xor butterfly the parity tests were pinned with (six cross-lane permutes through the LDS crossbar)
-        for (int o = 32; o > 0; o >>= 1) v = op(v, __shfl_xor(v, o));
+        v = wave_sum_butterfly(v);
     } else {
         // maxima and minima do not: four DPP steps inside each row of 16 lanes, then the four rows through v_readlane -- ~150 cycles instead of ~800
         v = op(v, dpp_move<0xb1>(v));   // quad_perm [1, 0, 3, 2]
@@ -326,7 +352,7 @@ struct Ipm {
             msdev::assemble_flat<NT>(PM, S.GG, at(B_XG), at(B_PF), at(B_ATAF), zinv, x_reg, delta_inv, F, g(S.ent_b), g(S.ent_rc), S.n_ent);
             __syncthreads();
             t1 = wall_clock64();
-            msdev::factor_chain_wave(PM, (msdev::global_cdouble*)F, dyn + S.res_pan, S.chain_reg_w > 0 ? S.chain_reg_k : 0);
+            msdev::factor_chain_wave<(WPE <= 2)>(PM, (msdev::global_cdouble*)F, dyn + S.res_pan, S.chain_reg_w > 0 ? S.chain_reg_k : 0, S.chain_rows != 0 ? dyn + S.res_x : nullptr);  // (the solve vector's LDS is free during a factorisation)
         } else {
             double* F = RES ? dyn + S.res_f : gen(at(B_F));
             double* PAN = RES ? dyn + S.res_pan : gen(at(B_PAN));
@@ -1801,6 +1827,7 @@ private:
                 const bool ok = chain && K >= 4;
                 if (debug_token("batch_chain_info"))
                     std::fprintf(stderr, "[piqp_amd] batch chain: %d stages, arrow %d, register-carried substitution for the first %d (w = %d)\n", nst, sym_.arrow, ok ? K : 0, W0);
+                S.chain_rows = (ok && 4 * W0 * W0 <= n && !debug_token("batch_no_chain_rows")) ? 1 : 0;  // ((2 W)^2 doubles of staging in the solve vector's LDS)
                 S.chain_reg_w = ok ? W0 : 0;
                 S.chain_reg_k = ok ? K : 0;
                 S.chain_reg_nst = ok ? nst : 0;

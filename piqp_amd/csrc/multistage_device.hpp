@@ -395,9 +395,132 @@ __device__ __forceinline__ void factor_stage_wave(double& f, const int h, const 
     }
 }
 
+// value of the lane SH further up in the same row of 16 lanes (0.0 past the row's end)
+template <int SH>
+__device__ __forceinline__ double dpp_row_shl(double v)
+{
+    static_assert(SH >= 1 && SH <= 15, "row shift");
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x100 + SH, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x100 + SH, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+// The leading run of a uniform chain -- K stages of ONE shape (W columns eliminated, u <= W rows below them, gap-free, no arrow: the run the register-carried
+// substitution uses, checked at setup) -- with ONE LANE PER ROW of the front: lane r holds row r, its h = W + u <= 2 W entries in registers.  factor_stage_wave keeps
+// one ENTRY per lane, and everything a pivot needs from another entry is a trip through the LDS crossbar (two per pivot and two per column of the Schur complement,
+// each ~130 cycles of latency: ~1 900 cycles a stage, 0.39 of the 1.25 ms a lone instance takes).  With a row per lane the pivot, and the entry L(c, j) that row r's
+// update of column c needs, are wave-uniform lane reads, and the update itself stays in the lane's registers.  Every entry receives the same updates in the same
+// order with the same operands as in factor_stage_wave (panel columns right-looking, the Schur complement by ascending pivot; products commute): the panels are
+// bitwise the same.  Returns, in the one-entry-per-lane layout of stage K - 1, what factor_chain_wave carries into stage K.
+template <int W, class Meta>
+__device__ __forceinline__ double factor_chain_rows(const Meta& M, global_cdouble* fronts_g, double* __restrict__ pan, const int K, double* __restrict__ stage)
+{
+    // stage: (2 W)^2 doubles of LDS nobody else uses during the factorisation.  A front arrives from memory as before -- ONE load per lane, entry l of the front in lane
+    // l, requested two stages ahead -- and is turned into rows through `stage` (one write, then this lane's row read back) behind the arithmetic of the stage before:
+    // a lane loading its row itself is h loads per stage instead of one, and with every compute unit full (8192 instances) the extra memory instructions cost
+    // more than the lane reads save.
+    constexpr int HM = 2 * W;
+    const int lane = threadIdx.x;
+    const int u = __builtin_amdgcn_readfirstlane(M.Off(0));
+    const int h = W + u, PS = W * W + u * W, hh = h * h;
+    const long long f0 = uni(M.FrontOff(0)), p0 = uni(M.PanOff(0));
+    const int r = lane;  // this lane's row (lanes >= h idle along)
+    const bool ent = lane < hh;
+    double* const wr = stage + (ent ? (lane % h) * HM + lane / h : 0);  // where this lane's ENTRY goes
+    const double* const rd = stage + (r < h ? r : 0) * HM;            // this lane's ROW
+    auto load_entry = [&](int b) -> double { return (ent && b < K) ? fronts_g[f0 + (long long)b * hh + lane] : 0.0; };
+    double rows[HM], fr[HM];
+    auto to_rows = [&](double e) {
+        if (ent) *wr = e;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int c = 0; c < HM; ++c) rows[c] = c < h ? rd[c] : 0.0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    to_rows(load_entry(0));
+    double gA = load_entry(1), gB = load_entry(2);
+#pragma unroll
+    for (int c = 0; c < HM; ++c) fr[c] = 0.0;
+    auto stage_b = [&](const int b, double& g) __attribute__((always_inline)) {
+        // ---- this stage's front + what the stage before left for its first u rows and columns ----
+        double carried[W];
+#pragma unroll
+        for (int c = 0; c < W; ++c) carried[c] = (b > 0 && c < u) ? dpp_row_shl<W>(fr[W + c]) : 0.0;
+#pragma unroll
+        for (int c = 0; c < HM; ++c) {
+            double add = 0.0;
+            if (c < W) add = (b > 0 && r < u && c < u && r >= c) ? carried[c] : 0.0;
+            fr[c] = rows[c] + add;
+        }
+        // ---- panel columns and Schur complement, right-looking ----
+        double invs[W];
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+            const double d = lane_bcast(fr[j], j);
+            const double inv = d > 0.0 ? rsqrt_newton(d) : 0.0;
+            invs[j] = inv;
+            fr[j] = r == j ? d * inv : (r > j ? fr[j] * inv : fr[j]);
+            const double lr = fr[j];
+#pragma unroll
+            for (int c = j + 1; c < HM; ++c) {
+                if (c < h) {
+                    const double lc = lane_bcast(fr[j], c);
+                    if (r >= c) fr[c] -= lr * lc;
+                }
+            }
+        }
+        // ---- the next front: entries (requested two stages ago) -> rows; its register then takes the request for the front three stages on ----
+        if (b + 1 < K) {
+            to_rows(g);
+            g = load_entry(b + 3);
+        }
+        // ---- Linv: lane j < W builds column j of L^{-1} (1 / L_kk = invs[k]) ----
+        double X[W];
+#pragma unroll
+        for (int rr = 0; rr < W; ++rr) {
+            double sacc = 0.0;
+#pragma unroll
+            for (int k = 0; k < rr; ++k) sacc += lane_bcast(fr[k], rr) * X[k];  // X[k] is 0 for k < lane
+            X[rr] = lane == rr ? invs[rr] : (lane < rr ? -invs[rr] * sacc : 0.0);
+        }
+        double* P = pan + p0 + (long long)b * PS;
+#pragma unroll
+        for (int k = 0; k < W; ++k)
+            if (lane < W) P[k + lane * W] = X[k];
+        // ---- Q = [C; F] Linv ----
+#pragma unroll
+        for (int t = 0; t < W; ++t) {
+            if (t < u) {
+                double q = 0.0;
+#pragma unroll
+                for (int k = 0; k < W; ++k) q += lane_bcast(fr[k], W + t) * X[k];
+                if (lane < W) P[W * W + t + lane * u] = q;
+            }
+        }
+    };
+    for (int b = 0; b < K; b += 2) {
+        stage_b(b, gA);
+        if (b + 1 < K) stage_b(b + 1, gB);
+    }
+    // hand-over: entry (rr, cc) of stage K - 1's front to lane rr + cc h
+    double out = 0.0;
+    const int rr = lane % h, cc = lane / h;
+#pragma unroll
+    for (int c = 0; c < HM; ++c) {
+        const double t = bperm_d(rr << 2, fr[c]);
+        if (cc == c) out = t;
+    }
+    return ent ? out : 0.0;
+}
+
 // fronts_g: assembled fronts in HBM; pan: LDS, per stage Linv (w x w) then Q (u x w) at PanOff(b)
-template <class Meta>
-__device__ __forceinline__ void factor_chain_wave(const Meta& M, global_cdouble* fronts_g, double* __restrict__ pan, const int reg_k = 0)
+// ROWS: the kernel variant may factor the uniform run with one lane per row (factor_chain_rows; rows_stage != nullptr says that this chain has such a run and where
+// the LDS staging is).  A compile-time switch because the mere presence of that code in the variants built for full compute units (four waves per SIMD, 128
+// registers) cost them 3-8 % (measured at 8192 instances: 5.74 ms without it, 5.9-6.0 with it, 6.2 on the one-entry-per-lane path next to it).
+template <bool ROWS = false, class Meta>
+__device__ __forceinline__ void factor_chain_wave(const Meta& M, global_cdouble* fronts_g, double* __restrict__ pan, const int reg_k = 0, double* __restrict__ rows_stage = nullptr)
 {
     // reg_k > 0: the stages 0 .. reg_k - 1 have ONE shape and follow each other without gaps (the run the register-carried substitution uses, checked at
     // setup): their widths and offsets are affine in the stage number and are not looked up in the table (five LDS reads + waits per stage)
@@ -406,16 +529,30 @@ __device__ __forceinline__ void factor_chain_wave(const Meta& M, global_cdouble*
     const int rw = reg_k > 0 ? __builtin_amdgcn_readfirstlane(M.W(0)) : 0, ro = reg_k > 0 ? __builtin_amdgcn_readfirstlane(M.Off(0)) : 0;
     const int rh = rw + ro;
     const long long rf0 = reg_k > 0 ? uni(M.FrontOff(0)) : 0, rp0 = reg_k > 0 ? uni(M.PanOff(0)) : 0;
-    int h = __builtin_amdgcn_readfirstlane(M.H(0));
-    double nxt = lane < h * h ? fronts_g[uni(M.FrontOff(0)) + lane] : 0.0;
-    int r = lane % h, c = lane / h;  // lane -> (row, col) of the current front; recomputed only when h changes
     int h_prev = 0, w_prev = 0, off_prev = 0;
     double f = 0.0;                  // after a stage: lanes (r >= w, c >= w, r >= c) hold the carried update matrix
+    int b_first = 0;
+    if constexpr (ROWS)
+    if (rows_stage != nullptr && reg_k > 0 && reg_k < N && rw <= 6 && ro >= 1 && ro <= rw) {
+        // the uniform run with one lane per row (factor_chain_rows); the stages behind it -- usually one terminal stage -- below
+        switch (rw) {
+        case 1: f = factor_chain_rows<1>(M, fronts_g, pan, reg_k, rows_stage); break;
+        case 2: f = factor_chain_rows<2>(M, fronts_g, pan, reg_k, rows_stage); break;
+        case 3: f = factor_chain_rows<3>(M, fronts_g, pan, reg_k, rows_stage); break;
+        case 4: f = factor_chain_rows<4>(M, fronts_g, pan, reg_k, rows_stage); break;
+        case 5: f = factor_chain_rows<5>(M, fronts_g, pan, reg_k, rows_stage); break;
+        default: f = factor_chain_rows<6>(M, fronts_g, pan, reg_k, rows_stage); break;
+        }
+        b_first = reg_k; h_prev = rh; w_prev = rw; off_prev = ro;
+    }
+    int h = __builtin_amdgcn_readfirstlane(M.H(b_first));
+    double nxt = (h > 0 && lane < h * h) ? fronts_g[uni(M.FrontOff(b_first)) + lane] : 0.0;
+    int r = h > 0 ? lane % h : 0, c = h > 0 ? lane / h : 0;  // lane -> (row, col) of the current front; recomputed only when h changes
     // the carried update is a fixed cross-lane permutation per stage SHAPE: source lane and mask are recomputed only when the shape changes
     int c_sig[7] = {-1, -1, -1, -1, -1, -1, -1};
     int c_addr = 0;
     bool c_has = false;
-    for (int b = 0; b < N; ++b) {
+    for (int b = b_first; b < N; ++b) {
         if (h == 0) break;  // no arrow corner
         const bool affine = b < reg_k;
         const int w = affine ? rw : __builtin_amdgcn_readfirstlane(M.W(b));
@@ -521,14 +658,6 @@ __device__ __forceinline__ void solve_stage_bwd_wave(const double* __restrict__ 
 // the right-hand side, requested a stage ahead together with the coefficients.  The stage table is read once (lane b holds stage b; a v_readlane per use).
 // What a stage waits for is its own arithmetic -- W lane reads and W multiply-adds -- instead of two to three LDS round trips and two wave syncs
 // (the chain substitution was 0.66 ms of an instance's 2.8 ms).  Same products in the same order: bitwise the same solution.
-template <int SH>
-__device__ __forceinline__ double dpp_row_shl(double v)
-{
-    static_assert(SH >= 1 && SH <= 15, "row shift");
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x100 + SH, 0xf, 0xf, true);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x100 + SH, 0xf, 0xf, true);
-    return __hiloint2double(hi, lo);
-}
 // FWD = true: the forward sweep over stages 0 .. K - 1 (the state stage K expects is left in x); false: the backward sweep over stages K - 1 .. 0 (stage K's
 // solution is read from x).  K < nst: the stages K .. nst - 1 -- a terminal stage of another width, say -- go through solve_stage_*_wave in between.
 template <int W, bool FWD, class Meta>
@@ -545,19 +674,22 @@ __device__ __forceinline__ void solve_chain_wave_reg(const Meta& M, const double
         const double* cfp = pan + p0 + (top ? lane : W * W + (lane < h ? lane - W : 0));
         const int cs = top ? W : u;
         double* xp = x + s0 + lane;
-        double cf[W];
+        // (two copies of the stage per loop trip, the operands of one requested by the other: handing the registers of the next stage's operands on at the end of
+        // a trip -- cf = cfn -- made every stage wait for the loads it had just issued, an LDS latency per stage that nothing hid)
+        double cfA[W], cfB[W];
 #pragma unroll
-        for (int k = 0; k < W; ++k) cf[k] = cfp[k * cs];
+        for (int k = 0; k < W; ++k) cfA[k] = cfp[k * cs];
         double cur = lane < h ? xp[0] : 0.0;
-        for (int b = 0; b < K; ++b) {
+        // (the entries of x a stage is the first to touch -- still the right-hand side -- are requested two stages ahead for the same reason)
+        double freshA = (K > 1 && lane >= u && lane < h) ? xp[W] : 0.0, freshB = 0.0;
+        auto stage_fwd = [&](const int b, double (&cf)[W], double (&cfn)[W], double& fresh_in, double& fresh_out) __attribute__((always_inline)) {
             cfp += PS;
-            double cfn[W];
-            double fresh = 0.0;
+            fresh_out = 0.0;
             if (b + 1 < K) {
 #pragma unroll
                 for (int k = 0; k < W; ++k) cfn[k] = cfp[k * cs];
-                if (lane >= u && lane < h) fresh = xp[W];  // (entries no earlier stage has written: still the right-hand side)
             }
+            if (b + 2 < K && lane >= u && lane < h) fresh_out = xp[2 * W];
             double xk[W];
 #pragma unroll
             for (int k = 0; k < W; ++k) xk[k] = lane_bcast(cur, k);
@@ -566,10 +698,12 @@ __device__ __forceinline__ void solve_chain_wave_reg(const Meta& M, const double
             for (int k = 0; k < W; ++k) acc += (top ? cf[k] : -cf[k]) * xk[k];
             if (top) xp[0] = acc;  // y_b (read again by the backward sweep only)
             const double down = dpp_row_shl<W>(acc);
-            cur = lane < u ? down : fresh;
-#pragma unroll
-            for (int k = 0; k < W; ++k) cf[k] = cfn[k];
+            cur = lane < u ? down : fresh_in;
             xp += W;
+        };
+        for (int b = 0; b < K; b += 2) {
+            stage_fwd(b, cfA, cfB, freshA, freshB);
+            if (b + 1 < K) stage_fwd(b + 1, cfB, cfA, freshB, freshA);
         }
         if (K < nst && lane < u) xp[0] = cur;  // hand-over: what stage K finds in x
     } else {
@@ -577,32 +711,35 @@ __device__ __forceinline__ void solve_chain_wave_reg(const Meta& M, const double
         const double* lp = pan + p0 + (K - 1) * PS + (top ? lane : 0) * W;  // Linv_b[k + lane W]
         const double* qp = pan + p0 + (K - 1) * PS + W * W + (top ? lane : 0) * u;  // Q_b[t + lane u]
         double* xb = x + s0 + (K - 1) * W;
-        double lv[W], yv[W];
+        double lvA[W], yvA[W], lvB[W], yvB[W];
 #pragma unroll
-        for (int k = 0; k < W; ++k) { lv[k] = lp[k]; yv[k] = xb[k]; }
+        for (int k = 0; k < W; ++k) { lvA[k] = lp[k]; yvA[k] = xb[k]; }
         double sol = 0.0;  // lanes < u: the solution of the stage above, as far as this stage needs it
         if (K < nst && lane < u) sol = xb[W + lane];
-        for (int b = K - 1; b >= 0; --b) {
-            double qv[WAVE_WMAX];
+        double qvA[W], qvB[W];  // (u <= W in such a run)
 #pragma unroll
-            for (int t = 0; t < WAVE_WMAX; ++t) qv[t] = t < u ? qp[t] : 0.0;
-            double lvn[W], yvn[W];
+        for (int t = 0; t < W; ++t) qvA[t] = t < u ? qp[t] : 0.0;
+        auto stage_bwd = [&](const int b, double (&lv)[W], double (&yv)[W], double (&qv)[W], double (&lvn)[W], double (&yvn)[W], double (&qvn)[W]) __attribute__((always_inline)) {
             if (b > 0) {
 #pragma unroll
                 for (int k = 0; k < W; ++k) { lvn[k] = lp[k - PS]; yvn[k] = xb[k - W]; }
+#pragma unroll
+                for (int t = 0; t < W; ++t) qvn[t] = t < u ? qp[t - PS] : 0.0;
             }
             double acc = 0.0;
 #pragma unroll
             for (int k = 0; k < W; ++k)
                 if (k >= lane) acc += lv[k] * yv[k];
 #pragma unroll
-            for (int t = 0; t < WAVE_WMAX; ++t)
+            for (int t = 0; t < W; ++t)
                 if (t < u) acc -= qv[t] * lane_bcast(sol, t);
             if (top) xb[lane] = acc;
             sol = acc;
-#pragma unroll
-            for (int k = 0; k < W; ++k) { lv[k] = lvn[k]; yv[k] = yvn[k]; }
             lp -= PS; qp -= PS; xb -= W;
+        };
+        for (int b = K - 1; b >= 0; b -= 2) {
+            stage_bwd(b, lvA, yvA, qvA, lvB, yvB, qvB);
+            if (b - 1 >= 0) stage_bwd(b - 1, lvB, yvB, qvB, lvA, yvA, qvA);
         }
     }
 }
