@@ -463,13 +463,14 @@ __device__ __forceinline__ double factor_chain_rows(const Meta& M, global_cdoubl
             invs[j] = inv;
             fr[j] = r == j ? d * inv : (r > j ? fr[j] * inv : fr[j]);
             const double lr = fr[j];
+            // (all 2 W columns, no branch on the run's h: a column beyond the front belongs to idle lanes that hold zeros -- the lane reads of a pivot then go out
+            // together instead of one per branch)
+            double lc[HM];
 #pragma unroll
-            for (int c = j + 1; c < HM; ++c) {
-                if (c < h) {
-                    const double lc = lane_bcast(fr[j], c);
-                    if (r >= c) fr[c] -= lr * lc;
-                }
-            }
+            for (int c = j + 1; c < HM; ++c) lc[c] = lane_bcast(fr[j], c);
+#pragma unroll
+            for (int c = j + 1; c < HM; ++c)
+                if (r >= c) fr[c] -= lr * lc[c];
         }
         // ---- the next front: entries (requested two stages ago) -> rows; its register then takes the request for the front three stages on ----
         if (b + 1 < K) {
@@ -492,12 +493,13 @@ __device__ __forceinline__ double factor_chain_rows(const Meta& M, global_cdoubl
         // ---- Q = [C; F] Linv ----
 #pragma unroll
         for (int t = 0; t < W; ++t) {
-            if (t < u) {
-                double q = 0.0;
+            double lq[W];
 #pragma unroll
-                for (int k = 0; k < W; ++k) q += lane_bcast(fr[k], W + t) * X[k];
-                if (lane < W) P[W * W + t + lane * u] = q;
-            }
+            for (int k = 0; k < W; ++k) lq[k] = lane_bcast(fr[k], W + t);  // (t >= u: an idle lane's zeros, nothing stored)
+            double q = 0.0;
+#pragma unroll
+            for (int k = 0; k < W; ++k) q += lq[k] * X[k];
+            if (lane < W && t < u) P[W * W + t + lane * u] = q;
         }
     };
     for (int b = 0; b < K; b += 2) {
