@@ -809,6 +809,26 @@ def dense_size_sweep(piqp_amd, pd, torch, np, args, rank, world, local_rank, dev
         r = {"device_ms_per_step": leg["elapsed"] / 5 * 1e3, "device_ms_per_step_max": legs[2]["elapsed"] / 5 * 1e3, "device_ms_per_step_runs": [g["elapsed"] / 5 * 1e3 for g in legs],
              "device_assembly_ms": leg["asm_ms"], "device_factorisation_ms": leg["fac_ms"], "device_backend_solve_ms": leg["sol_ms"]}
         r.update((cpu_rows or {}).get(str(n), {}))
+        # factor-only, as the reference's benchmark measures it (compute() of a positive definite matrix resident in device memory) through the class objects
+        # (pq_dense_factor_*): [device time of the factorisation launches, wall time of the whole compute() call], microseconds, median of 15
+        try:
+            S = q["P"] + q["P"].T - np.diag(np.diag(q["P"])) + float(n) * np.eye(n)
+            fo = {}
+            for name, cls, uplo in (("LLT_Lower", piqp_amd.LLT, piqp_amd.LOWER), ("LDLTNoPivot_Lower", piqp_amd.LDLTNoPivot, piqp_amd.LOWER), ("LDLTNoPivot_Upper", piqp_amd.LDLTNoPivot, piqp_amd.UPPER)):
+                t = torch.from_numpy(np.ascontiguousarray(S)).to(dev)  # (symmetric: either triangle of either storage order is the same matrix)
+                f = cls(n, uplo, device=local_rank)
+                for _ in range(2):
+                    f.compute_colmajor(t)
+                assert f.info() == 0
+                ms = []
+                for _ in range(15):
+                    f.compute_colmajor(t)
+                    ms.append(f.last_ms())
+                fo[name] = [float(np.median([a for a, _ in ms])) * 1e3, float(np.median([b for _, b in ms])) * 1e3]
+                del f
+            r["factor_only_us"] = fo
+        except Exception as e:  # noqa: BLE001
+            r["factor_only_error"] = f"{type(e).__name__}: {e}"
         rows[str(n)] = r
     cross1 = [int(n) for n, r in rows.items() if "cpu_1_thread_ms_per_step" in r and r["device_ms_per_step"] < r["cpu_1_thread_ms_per_step"]]
     crossa = [int(n) for n, r in rows.items() if "cpu_all_threads_ms_per_step" in r and r["device_ms_per_step"] < r["cpu_all_threads_ms_per_step"]]
