@@ -46,3 +46,13 @@ timeout 900 python3 tools/dense_mm_parity.py > $O/r06_dense_mm_parity.txt 2>/dev
 timeout 900 python3 tools/time_big_engines.py > $O/r06_big_engines.txt 2>/dev/null; tail -3 $O/r06_big_engines.txt
 timeout 900 python3 tools/soak_stalls.py 2000 > $O/r06_soak_dense.txt 2>/dev/null; grep -c "above 3 x median: 0" $O/r06_soak_dense.txt
 timeout 300 python3 tools/exact_trace.py mm_QPILOTNO 2>/dev/null | cut -c1-220 > $O/r06_exact_engine_timeline.txt; tail -30 $O/r06_exact_engine_timeline.txt
+# round 6, late: the factor-only benchmark through the class objects, the batched kernel's in-kernel split per batch size, PMC passes of the dense step and the C4 batch
+timeout 900 python3 tools/dense_cholesky_factorization_benchmark.py > $O/r06_dense_cholesky_factorization_benchmark.txt 2>/dev/null; tail -4 $O/r06_dense_cholesky_factorization_benchmark.txt | cut -c1-200
+timeout 300 python3 tools/prof_batch_split.py 1 256 1024 2048 4096 8192 16384 > $O/r06_batch_split.txt 2>&1
+timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmc_f -- python3 tools/prof_dense.py 4096 4096 0 3 0 > /dev/null 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pmc_w -- python3 tools/prof_dense.py 4096 4096 0 3 0 > /dev/null 2>&1
+python3 tools/make_pmc_json.py $O/pmc_f $O/pmc_w 4096 4096 0 "round 6, final code" > $O/r06_pmc_dense_c2.json
+timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmc_bf -- python3 tools/dbg_batch.py 8192 0 > /dev/null 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pmc_bw -- python3 tools/dbg_batch.py 8192 0 > /dev/null 2>&1
+python3 tools/rocprof_pmc.py $O/pmc_bf k_batch_ipm; python3 tools/rocprof_pmc.py $O/pmc_bw k_batch_ipm   # -> profiles/r06_pmc_batch_c4.json
+rm -rf $O/pmc_f $O/pmc_w $O/pmc_bf $O/pmc_bw
