@@ -225,3 +225,35 @@ def test_start_order_does_not_change_results(hip):
     bs.set_start_order(False)
     assert bs.solve() == B  # index order again
     assert np.array_equal(bs.result("x"), x1) and np.array_equal(np.asarray(bs.iterations()), it1)
+
+
+# (nx, nu, T): chains whose uniform run eliminates w = nx + nu columns with u = nx coupling rows -- w = 2 .. 6, u = 1 .. 4: every width of the register-carried
+# substitution (msdev::solve_chain_wave_reg) and of the one-lane-per-row factorisation of the small-batch kernel variants (msdev::factor_chain_rows, round 6; needs
+# (2 w)^2 <= n doubles of staging: T is chosen so that it holds)
+CHAIN_SHAPES = [(1, 1, 24), (1, 2, 20), (2, 1, 40), (2, 2, 20), (3, 1, 20), (2, 3, 24), (3, 2, 24), (3, 3, 26), (4, 2, 26)]
+
+
+@pytest.mark.parametrize("shape", CHAIN_SHAPES)
+@pytest.mark.parametrize("B", [5, 3000])
+def test_chain_shapes_match_the_oracle_in_both_kernel_variants(hip, orc, shape, B):
+    """B = 5: the variant for a few instances per compute unit (one lane per row of a front in the uniform run, two substitution stages per loop trip); B = 3000: a
+    variant for full compute units (one lane per entry).  Every 97th instance against the oracle alone; all instances solved and the two batches' common instances
+    bitwise equal (an instance does not depend on the batch it is in, nor on the kernel variant: the arithmetic is the same)."""
+    nx, nu, T = shape
+    mb = mpc_batch(B, T=T, nx=nx, nu=nu, seed=300 + 10 * nx + nu)
+    bs, solved = _run_batch(hip, mb)
+    assert solved == B
+    x, y = bs.result("x"), bs.result("y")
+    for i in range(0, B, 97):
+        st, it, obj, ref = _oracle_solve(orc, mpc_instance(mb, i))
+        info = bs.info(i)
+        assert info.status == st == 1 and info.iter == it, (shape, i, info.status, st, info.iter, it)
+        assert np.abs(x[i] - ref["x"]).max() <= 1e-7 * (1 + np.abs(ref["x"]).max())
+        assert np.abs(y[i] - ref["y"]).max() <= 1e-6 * (1 + np.abs(ref["y"]).max())
+    if B > 5:
+        sub = {k: (v[:5] if isinstance(v, np.ndarray) and v.ndim == 2 else v) for k, v in mb.items()}
+        bs5, solved5 = _run_batch(hip, sub)
+        assert solved5 == 5
+        for f in ("x", "y", "z_bl", "z_bu", "s_bl", "s_bu"):
+            assert np.array_equal(bs5.result(f), bs.result(f)[:5]), (shape, f)
+        assert [bs5.info(i).iter for i in range(5)] == [bs.info(i).iter for i in range(5)]
