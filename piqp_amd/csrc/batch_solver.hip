@@ -1825,9 +1825,10 @@ private:
                        sym_.qpan_off[K + 1] - sym_.qpan_off[K] == (long long)W0 * W0 + (long long)sym_.off[0] * W0 &&
                        sym_.front_off[K + 1] - sym_.front_off[K] == (long long)sym_.h[0] * sym_.h[0] && sym_.h[K] == sym_.h[0]) ++K;
                 const bool ok = chain && K >= 4;
-                if (debug_token("batch_chain_info"))
-                    std::fprintf(stderr, "[piqp_amd] batch chain: %d stages, arrow %d, register-carried substitution for the first %d (w = %d)\n", nst, sym_.arrow, ok ? K : 0, W0);
                 S.chain_rows = (ok && 4 * W0 * W0 <= n && !debug_token("batch_no_chain_rows")) ? 1 : 0;  // ((2 W)^2 doubles of staging in the solve vector's LDS)
+                if (debug_token("batch_chain_info"))
+                    std::fprintf(stderr, "[piqp_amd] batch chain: %d stages, arrow %d, register-carried substitution for the first %d (w = %d, u = %d); one lane per row in their factorisation: %s "
+                                 "(kernel variant for %d waves per SIMD)\n", nst, sym_.arrow, ok ? K : 0, W0, nst > 0 ? sym_.off[0] : 0, S.chain_rows ? (wpe_ <= 2 ? "yes" : "no (variant for full compute units)") : "no", wpe_);
                 S.chain_reg_w = ok ? W0 : 0;
                 S.chain_reg_k = ok ? K : 0;
                 S.chain_reg_nst = ok ? nst : 0;

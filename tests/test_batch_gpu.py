@@ -230,7 +230,9 @@ def test_start_order_does_not_change_results(hip):
 # (nx, nu, T): chains whose uniform run eliminates w = nx + nu columns with u = nx coupling rows -- w = 2 .. 6, u = 1 .. 4: every width of the register-carried
 # substitution (msdev::solve_chain_wave_reg) and of the one-lane-per-row factorisation of the small-batch kernel variants (msdev::factor_chain_rows, round 6; needs
 # (2 w)^2 <= n doubles of staging: T is chosen so that it holds)
-CHAIN_SHAPES = [(1, 1, 24), (1, 2, 20), (2, 1, 40), (2, 2, 20), (3, 1, 20), (2, 3, 24), (3, 2, 24), (3, 3, 26), (4, 2, 26)]
+CHAIN_SHAPES = [(1, 1, 24), (1, 2, 20), (2, 1, 40), (2, 2, 20), (3, 1, 20), (2, 3, 24), (3, 2, 24), (2, 4, 26),
+                # (fronts of more than 64 entries: the resident / staged modes of the kernel, no register-carried chain)
+                (3, 3, 26), (4, 2, 26)]
 
 
 @pytest.mark.parametrize("shape", CHAIN_SHAPES)
