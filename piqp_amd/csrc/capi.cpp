@@ -354,22 +354,26 @@ int pq_dense_factor_compute(pq_dense_factor* f, const double* A, int lda, int me
         PQ_HIP(hipSetDevice(f->device));
         const int n = f->n;
         const auto w0 = std::chrono::steady_clock::now();
-        hipStream_t st = f->impl ? f->impl->stream() : nullptr;
-        PQ_HIP(hipMemcpy2DAsync(f->stage.p, sizeof(double) * n, A, sizeof(double) * lda, sizeof(double) * n, n, mem == PQ_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
-        dense::launch_symmetrize(f->stage.p, n, f->uplo == PQ_LOWER, n, f->full.p, nullptr, st);
-        if (!st) PQ_HIP(hipStreamSynchronize(nullptr)); else stream_wait(st);
-        pq_dense_data d{};
-        d.n = n; d.p = 0; d.m = 0; d.P_utri = f->full.p; d.mem = PQ_MEM_DEVICE;
         if (!f->impl) {
+            // the backend object behind this one: a dense KKT backend with p = m = 0 (its P is never used: factor_symmetric writes the factor buffer directly)
+            f->full.zero(nullptr);
+            PQ_HIP(hipStreamSynchronize(nullptr));
+            pq_dense_data d{};
+            d.n = n; d.p = 0; d.m = 0; d.P_utri = f->full.p; d.mem = PQ_MEM_DEVICE;
             f->impl.reset(make_dense_kkt(&d, f->kind, f->device));
             f->impl->set_class_failure_semantics(true);
             f->impl->set_profiling(1);
-        } else {
-            f->impl->update_data_dense(&d, PQ_KKT_UPDATE_P);
+        }
+        hipStream_t st = f->impl->stream();
+        const double* src = A;
+        int ld = lda;
+        if (mem != PQ_MEM_DEVICE) {  // a host matrix: one copy to the device (the leading dimension kept out of it)
+            PQ_HIP(hipMemcpy2DAsync(f->stage.p, sizeof(double) * n, A, sizeof(double) * lda, sizeof(double) * n, n, hipMemcpyHostToDevice, st));
+            src = f->stage.p; ld = n;
         }
         double before = 0.0; int cnt = 0;
         f->impl->get_profile(1, &before, &cnt);
-        const bool ok = f->impl->update_scalings_and_factor(1.0, f->zero.p, nullptr);
+        const bool ok = f->impl->factor_symmetric(src, ld, f->uplo == PQ_LOWER);
         double after = 0.0;
         f->impl->get_profile(1, &after, &cnt);
         f->last_ms[0] = after - before;

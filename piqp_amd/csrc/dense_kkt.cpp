@@ -175,6 +175,25 @@ public:
         prof_.collect(stage, st_, total_ms, count);
     }
     void set_class_failure_semantics(bool on) override { class_semantics_ = on; }
+    bool factor_symmetric(const double* A_dev, int lda, bool from_lower) override
+    {
+        if (p_ != 0 || m_ != 0) throw std::runtime_error("factor_symmetric: a handle with p = m = 0 only");
+        PQ_HIP(hipSetDevice(dev_));
+        join_inverses();
+        delta_ = 1.0;
+        dense::launch_symmetrize(A_dev, lda, from_lower, n_, fac_.p, nullptr, st_);  // (the factorisation reads the lower triangle of fac_)
+        const int t1 = prof_.begin(1, st_);
+        launch_factor_panels();
+        prof_.end(1, t1, st_);
+        if (inv_sweeps_) {
+            PQ_HIP(hipEventRecord(ev_fac_, st_));
+            PQ_HIP(hipStreamWaitEvent(st_inv_, ev_fac_, 0));
+            dense::launch_block_inverse_dd(ldlt_, fac_.p, n_, n_, vinv_.p, st_inv_);
+            PQ_HIP(hipEventRecord(ev_inv_, st_inv_));
+            inv_pending_ = true;
+        }
+        return factor_status();
+    }
     void internal_factor(double* out_host) override
     {
         PQ_HIP(hipSetDevice(dev_));

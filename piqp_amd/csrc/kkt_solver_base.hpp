@@ -42,6 +42,9 @@ public:
     virtual void internal_kkt_mat(double* out_host) { (void)out_host; throw std::runtime_error("internal_kkt_mat: dense only"); }
     // dense backends: true = a factorisation fails exactly where the reference's CLASS fails (LDLTNoPivot: an exact zero pivot, ldlt_no_pivot.hpp:307), not where this
     // library's dense_ldlt_no_pivot BACKEND also gives up (a pivot that is not positive); used by the raw factorisation object (pq_dense_factor)
+    // dense backends with p = m = 0: factor the symmetric matrix of which A (device memory, column-major, leading dimension lda) holds the upper or (from_lower) the
+    // lower triangle -- straight into the factor buffer, no data copy, no assembly; solve() then works as after update_scalings_and_factor.  (pq_dense_factor)
+    virtual bool factor_symmetric(const double* A_dev, int lda, bool from_lower) { (void)A_dev; (void)lda; (void)from_lower; throw std::runtime_error("factor_symmetric: dense only"); }
     virtual void set_class_failure_semantics(bool on) { (void)on; throw std::runtime_error("set_class_failure_semantics: dense only"); }
     virtual void internal_factor(double* out_host) { (void)out_host; throw std::runtime_error("internal_factor: dense only"); }
     // test hook: rows of (start, diag_size, off_diag_size) of the multistage backend (print_info, multistage_kkt.hpp:385-393)

@@ -3,8 +3,8 @@
 matrix, n = 4, 8, ..., 1024, for Eigen::LLT and LDLTNoPivot, Lower and Upper) through the device objects (piqp_amd.LLT / piqp_amd.LDLTNoPivot, pq_dense_factor_*),
 the matrix resident in device memory, next to the oracle's restatement of the same classes on one host core.
     python tools/dense_cholesky_factorization_benchmark.py [max_n] > profiles/r06_dense_cholesky_factorization_benchmark.txt
-device columns: median over the repetitions of (hipEvent time of the factorisation launches) / (wall time of the whole compute(): device-to-device copy of the
-matrix, symmetric completion, assembly P + 0, factorisation, one 4-byte status read-back).  Eigen's LDLT with pivoting (BM_EIGEN_LDLT_*) has no counterpart here:
+device columns: median over the repetitions of (hipEvent time of the factorisation launches) / (wall time of the whole compute(): symmetric completion of the
+named triangle straight into the factor buffer, factorisation, one 4-byte status read-back).  Eigen's LDLT with pivoting (BM_EIGEN_LDLT_*) has no counterpart here:
 it is not on PIQP's path."""
 import os
 import sys
