@@ -427,7 +427,8 @@ __device__ __forceinline__ double factor_chain_rows(const Meta& M, global_cdoubl
     const bool ent = lane < hh;
     double* const wr = stage + (ent ? (lane % h) * HM + lane / h : 0);  // where this lane's ENTRY goes
     const double* const rd = stage + (r < h ? r : 0) * HM;            // this lane's ROW
-    auto load_entry = [&](int b) -> double { return (ent && b < K) ? fronts_g[f0 + (long long)b * hh + lane] : 0.0; };
+    // (requests without uniform branches, from clamped addresses: see solve_chain_wave_reg)
+    auto load_entry = [&](int b) -> double { return ent ? fronts_g[f0 + (long long)min(b, K - 1) * hh + lane] : 0.0; };
     double rows[HM], fr[HM];
     auto to_rows = [&](double e) {
         if (ent) *wr = e;
@@ -435,7 +436,7 @@ __device__ __forceinline__ double factor_chain_rows(const Meta& M, global_cdoubl
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-        for (int c = 0; c < HM; ++c) rows[c] = c < h ? rd[c] : 0.0;
+        for (int c = 0; c < HM; ++c) { const double rv = rd[c < h ? c : 0]; rows[c] = c < h ? rv : 0.0; }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     };
@@ -473,10 +474,8 @@ __device__ __forceinline__ double factor_chain_rows(const Meta& M, global_cdoubl
                 if (r >= c) fr[c] -= lr * lc[c];
         }
         // ---- the next front: entries (requested two stages ago) -> rows; its register then takes the request for the front three stages on ----
-        if (b + 1 < K) {
-            to_rows(g);
-            g = load_entry(b + 3);
-        }
+        to_rows(g);  // (at the last stage of the run: a front nobody uses)
+        g = load_entry(b + 3);
         // ---- Linv: lane j < W builds column j of L^{-1} (1 / L_kk = invs[k]) ----
         double X[W];
 #pragma unroll
@@ -685,13 +684,12 @@ __device__ __forceinline__ void solve_chain_wave_reg(const Meta& M, const double
         // (the entries of x a stage is the first to touch -- still the right-hand side -- are requested two stages ahead for the same reason)
         double freshA = (K > 1 && lane >= u && lane < h) ? xp[W] : 0.0, freshB = 0.0;
         auto stage_fwd = [&](const int b, double (&cf)[W], double (&cfn)[W], double& fresh_in, double& fresh_out) __attribute__((always_inline)) {
-            cfp += PS;
-            fresh_out = 0.0;
-            if (b + 1 < K) {
+            // (unconditional requests from clamped addresses: a load under a uniform branch makes the compiler's wait counts at the join conservative -- it
+            // waited for ALL LDS reads, the ones just issued included, in front of every stage's lane reads)
+            cfp += (b + 1 < K) ? PS : 0;
 #pragma unroll
-                for (int k = 0; k < W; ++k) cfn[k] = cfp[k * cs];
-            }
-            if (b + 2 < K && lane >= u && lane < h) fresh_out = xp[2 * W];
+            for (int k = 0; k < W; ++k) cfn[k] = cfp[k * cs];
+            fresh_out = (lane >= u && lane < h) ? xp[(b + 2 < K) ? 2 * W : 0] : 0.0;
             double xk[W];
 #pragma unroll
             for (int k = 0; k < W; ++k) xk[k] = lane_bcast(cur, k);
@@ -720,13 +718,14 @@ __device__ __forceinline__ void solve_chain_wave_reg(const Meta& M, const double
         if (K < nst && lane < u) sol = xb[W + lane];
         double qvA[W], qvB[W];  // (u <= W in such a run)
 #pragma unroll
-        for (int t = 0; t < W; ++t) qvA[t] = t < u ? qp[t] : 0.0;
+        for (int t = 0; t < W; ++t) { const double qv_t = qp[t < u ? t : 0]; qvA[t] = t < u ? qv_t : 0.0; }
         auto stage_bwd = [&](const int b, double (&lv)[W], double (&yv)[W], double (&qv)[W], double (&lvn)[W], double (&yvn)[W], double (&qvn)[W]) __attribute__((always_inline)) {
-            if (b > 0) {
+            {   // (unconditional, clamped: see the forward sweep)
+                const int bp = b > 0 ? PS : 0, bw = b > 0 ? W : 0;
 #pragma unroll
-                for (int k = 0; k < W; ++k) { lvn[k] = lp[k - PS]; yvn[k] = xb[k - W]; }
+                for (int k = 0; k < W; ++k) { lvn[k] = lp[k - bp]; yvn[k] = xb[k - bw]; }
 #pragma unroll
-                for (int t = 0; t < W; ++t) qvn[t] = t < u ? qp[t - PS] : 0.0;
+                for (int t = 0; t < W; ++t) { const double qv_t = qp[(t < u ? t : 0) - bp]; qvn[t] = t < u ? qv_t : 0.0; }
             }
             double acc = 0.0;
 #pragma unroll
