@@ -1888,6 +1888,12 @@ private:
     void launch_ipm_with()
     {
         int bytes = shared_h_.chain_lds_doubles * (int)sizeof(double);
+        if (const char* e = debug_token("batch_per_cu")) {
+            // measurement aid: at most <n> workgroups per compute unit (the launch asks for as much LDS as 1 / n of a unit's 160 KB: fewer resident instances, a smaller
+            // footprint in the caches)
+            const int n = std::max(1, std::atoi(e));
+            bytes = std::max(bytes, std::min(LDS_LIMIT_BYTES, (160 * 1024) / n - 2560 - 512));
+        }
         static PerDeviceOnce attr;
         attr([&] {
             PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_batch_ipm<NTv, MODEv, WPEv>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT_BYTES));
