@@ -352,7 +352,7 @@ struct Ipm {
             msdev::assemble_flat<NT>(PM, S.GG, at(B_XG), at(B_PF), at(B_ATAF), zinv, x_reg, delta_inv, F, g(S.ent_b), g(S.ent_rc), S.n_ent);
             __syncthreads();
             t1 = wall_clock64();
-            msdev::factor_chain_wave<(WPE <= 2)>(PM, (msdev::global_cdouble*)F, dyn + S.res_pan, S.chain_reg_w > 0 ? S.chain_reg_k : 0, S.chain_rows != 0 ? dyn + S.res_x : nullptr);  // (the solve vector's LDS is free during a factorisation)
+            msdev::factor_chain_wave<(WPE <= 3)>(PM, (msdev::global_cdouble*)F, dyn + S.res_pan, S.chain_reg_w > 0 ? S.chain_reg_k : 0, S.chain_rows != 0 ? dyn + S.res_x : nullptr);  // (the solve vector's LDS is free during a factorisation)
         } else {
             double* F = RES ? dyn + S.res_f : gen(at(B_F));
             double* PAN = RES ? dyn + S.res_pan : gen(at(B_PAN));
@@ -1828,7 +1828,7 @@ private:
                 S.chain_rows = (ok && 4 * W0 * W0 <= n && !debug_token("batch_no_chain_rows")) ? 1 : 0;  // ((2 W)^2 doubles of staging in the solve vector's LDS)
                 if (debug_token("batch_chain_info"))
                     std::fprintf(stderr, "[piqp_amd] batch chain: %d stages, arrow %d, register-carried substitution for the first %d (w = %d, u = %d); one lane per row in their factorisation: %s "
-                                 "(kernel variant for %d waves per SIMD)\n", nst, sym_.arrow, ok ? K : 0, W0, nst > 0 ? sym_.off[0] : 0, S.chain_rows ? (wpe_ <= 2 ? "yes" : "no (variant for full compute units)") : "no", wpe_);
+                                 "(kernel variant for %d waves per SIMD)\n", nst, sym_.arrow, ok ? K : 0, W0, nst > 0 ? sym_.off[0] : 0, S.chain_rows ? (wpe_ <= 3 ? "yes" : "no (variant for full compute units)") : "no", wpe_);
                 S.chain_reg_w = ok ? W0 : 0;
                 S.chain_reg_k = ok ? K : 0;
                 S.chain_reg_nst = ok ? nst : 0;

@@ -519,7 +519,8 @@ __device__ __forceinline__ double factor_chain_rows(const Meta& M, global_cdoubl
 // fronts_g: assembled fronts in HBM; pan: LDS, per stage Linv (w x w) then Q (u x w) at PanOff(b)
 // ROWS: the kernel variant may factor the uniform run with one lane per row (factor_chain_rows; rows_stage != nullptr says that this chain has such a run and where
 // the LDS staging is).  A compile-time switch because the mere presence of that code in the variants built for full compute units (four waves per SIMD, 128
-// registers) cost them 3-8 % (measured at 8192 instances: 5.74 ms without it, 5.9-6.0 with it, 6.2 on the one-entry-per-lane path next to it).
+// registers) cost them 3-8 % (measured at 8192 instances: 5.74 ms without it, 5.9-6.0 with it, 6.2 on the one-entry-per-lane path next to it); the variants for
+// two and three waves per SIMD (up to 12 instances per compute unit) have it: 2304 / 3072 instances 2.08 / 2.33 -> 1.88 / 2.10 ms.
 template <bool ROWS = false, class Meta>
 __device__ __forceinline__ void factor_chain_wave(const Meta& M, global_cdouble* fronts_g, double* __restrict__ pan, const int reg_k = 0, double* __restrict__ rows_stage = nullptr)
 {
